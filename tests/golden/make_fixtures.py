@@ -1,0 +1,187 @@
+"""Generate the committed parity fixtures by running the REAL reference (build container only).
+
+    PYTHONPATH=/root/repo python tests/golden/make_fixtures.py
+
+Imports april-tools/cirkit from /root/reference (read-only), compiles the BASELINE.json
+configurations with ``fold=True, optimize=True``, loads the closed-form parameters of
+``cirkit_amd.initializers`` into the reference circuits (in place, through the storage the plan
+extraction shares with them), evaluates them, and writes
+
+    tests/golden/<name>.json / .npz      the folded plan (layer list + index arrays)
+    tests/golden/<name>_golden.npz       inputs x, reference outputs in fp32 (and fp64 where cheap),
+                                         plus, for the small KAT circuits, the literal weights
+
+Nothing here ships reference code: the outputs are data (ints, floats).  The GPU box never runs this.
+"""
+
+from __future__ import annotations
+
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("CIRKIT_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import cirkit.symbolic.functional as SF  # noqa: E402
+from cirkit.pipeline import PipelineContext  # noqa: E402
+from cirkit.templates import data_modalities  # noqa: E402
+from cirkit.templates.utils import Parameterization  # noqa: E402
+
+from cirkit_amd.initializers import init_plan_tensors  # noqa: E402
+from cirkit_amd.plan import plan_from_torch_circuit, tensor_table  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def _load_closed_form(plan, tensors, seed=0):
+    vals = init_plan_tensors(plan, seed=seed)
+    for k, t in tensors.items():
+        t.copy_(torch.from_numpy(vals[k]).to(t.dtype))
+
+
+def _save(name, plan, extra):
+    plan.name = name
+    plan.save(os.path.join(HERE, name))
+    np.savez_compressed(os.path.join(HERE, name + "_golden.npz"), **extra)
+    print(f"{name}: {len(plan.layers)} layers, {plan.num_params} params, "
+          f"fixture arrays {sum(v.nbytes for v in extra.values())} B")
+
+
+def _fp64_copy(cc):
+    c64 = copy.deepcopy(cc)
+    return c64.double()
+
+
+def cfg1():
+    sc = data_modalities.tabular_data(
+        "random-binary-tree", num_features=8,
+        input_layers={"name": "categorical", "args": {"num_categories": 4}},
+        num_input_units=4, sum_product_layer="cp", num_sum_units=4)
+    cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+    plan, tensors = plan_from_torch_circuit(cc)
+    _load_closed_form(plan, tensors)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(0, 4, (32, 8), generator=g)
+    y32 = cc(x)
+    y64 = _fp64_copy(cc)(x)
+    _save("cfg1_rbt8", plan, {"x": x.numpy(), "y_f32": y32.numpy(), "y_f64": y64.numpy()})
+    # unfolded / unoptimised compilation of the same circuit with the same weights must agree
+    # (reference invariant, tests/backend/torch/test_compile_circuit.py:87-101 parametrisation)
+
+
+def cfg2():
+    sc = data_modalities.image_data(
+        (1, 28, 28), "quad-tree-2", input_layer="categorical", num_input_units=32,
+        sum_product_layer="cp", num_sum_units=32)
+    cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+    plan, tensors = plan_from_torch_circuit(cc)
+    _load_closed_form(plan, tensors)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 256, (64, 784), generator=g)
+    y32 = cc(x)
+    y64 = _fp64_copy(cc)(x)
+    _save("cfg2_qt784", plan, {"x": x.numpy().astype(np.int16), "y_f32": y32.numpy(), "y_f64": y64.numpy()})
+
+
+def cfg2_cpt():
+    """Same region graph with ``cp-t`` (no dense layer after the inputs) -- SURVEY.md A.2 note."""
+    sc = data_modalities.image_data(
+        (1, 28, 28), "quad-tree-2", input_layer="categorical", num_input_units=16,
+        sum_product_layer="cp-t", num_sum_units=16)
+    cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+    plan, tensors = plan_from_torch_circuit(cc)
+    _load_closed_form(plan, tensors)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (16, 784), generator=g)
+    _save("cfg2t_qt784_cpt16", plan, {"x": x.numpy().astype(np.int16), "y_f32": cc(x).numpy()})
+
+
+def cfg4():
+    sc = data_modalities.image_data(
+        (1, 28, 28), "poon-domingos", input_layer="gaussian", num_input_units=64,
+        sum_product_layer="cp", num_sum_units=64)
+    cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+    plan, tensors = plan_from_torch_circuit(cc)
+    _load_closed_form(plan, tensors)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((16, 784), generator=g)
+    y32 = cc(x)
+    y64 = _fp64_copy(cc)(x.double())
+    _save("cfg4_pd784", plan, {"x": x.numpy(), "y_f32": y32.numpy(), "y_f64": y64.numpy()})
+
+
+def cfg5(K=32):
+    """Squared (SoS) circuit: c(x) under complex-lse-sum and its partition function Z."""
+    par = Parameterization(activation="none", initialization="normal")
+    sc = data_modalities.image_data(
+        (1, 28, 28), "quad-tree-2", input_layer="embedding", num_input_units=K,
+        sum_product_layer="cp-t", num_sum_units=K,
+        input_params={"weight": par}, sum_weight_param=par)
+    ctx = PipelineContext(backend="torch", semiring="complex-lse-sum", fold=True, optimize=True)
+    cc = ctx.compile(sc)
+    zc = ctx.compile(SF.integrate(SF.multiply(sc, SF.conjugate(sc))))
+    table = tensor_table()
+    plan_c, tensors = plan_from_torch_circuit(cc, table=table)
+    plan_z, tensors_z = plan_from_torch_circuit(zc, table=table)
+    assert set(tensors_z) <= set(tensors), "Z must only point at c's tensors"
+    # scale the closed-form values so that K-term sums stay O(1)
+    vals = init_plan_tensors(plan_c)
+    for k, t in tensors.items():
+        t.copy_(torch.from_numpy(vals[k]).to(t.dtype))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 256, (16, 784), generator=g)
+    y = cc(x)
+    z = zc()
+    _save(f"cfg5_sos_c_k{K}", plan_c, {"x": x.numpy().astype(np.int16), "y_c64": y.numpy()})
+    _save(f"cfg5_sos_z_k{K}", plan_z, {"z_c64": z.numpy()})
+
+
+def kats():
+    """The reference's own known-answer circuits (tests/symbolic/test_utils.py:293-503), compiled by
+    the reference with fold+optimize under lse-sum; literal weights stored (they are tiny)."""
+    sys.path.insert(0, REF)
+    from tests.symbolic.test_utils import (
+        build_monotonic_bivariate_gaussian_hadamard_dense_pc,
+        build_monotonic_structured_categorical_cpt_pc,
+    )
+    import itertools
+
+    for fold, optimize in itertools.product([False, True], [False, True]):
+        tag = f"f{int(fold)}o{int(optimize)}"
+        ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=fold, optimize=optimize)
+        sc, gt, zgt = build_monotonic_structured_categorical_cpt_pc(return_ground_truth=True)
+        cc = ctx.compile(sc)
+        plan, tensors = plan_from_torch_circuit(cc)
+        worlds = torch.tensor(list(itertools.product([0, 1], repeat=5)))
+        y = cc(worlds)
+        extra = {"x": worlds.numpy(), "y_f32": y.numpy(),
+                 "kat_x": np.array(list(gt["evi"].keys())),
+                 "kat_y": np.array(list(gt["evi"].values())),
+                 "kat_z": np.array(zgt)}
+        extra.update({"w_" + k: v.numpy() for k, v in tensors.items()})
+        _save(f"kat_bernoulli_{tag}", plan, extra)
+
+        sc, gt, zgt = build_monotonic_bivariate_gaussian_hadamard_dense_pc(return_ground_truth=True)
+        cc = ctx.compile(sc)
+        plan, tensors = plan_from_torch_circuit(cc)
+        xs = torch.tensor([[0.3, 1.2], [0.0, 0.0], [-1.5, 2.5], [4.0, -3.0]])
+        y = cc(xs)
+        extra = {"x": xs.numpy(), "y_f32": y.numpy(),
+                 "kat_x": np.array(list(gt["evi"].keys())),
+                 "kat_y": np.array(list(gt["evi"].values())),
+                 "kat_z": np.array(zgt)}
+        extra.update({"w_" + k: v.numpy() for k, v in tensors.items()})
+        _save(f"kat_gaussian_{tag}", plan, extra)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats"]
+    for w in which:
+        globals()[w]()
