@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: log-likelihood evaluations / second of the folded log-space forward.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]; configs[2] at N=8): 784-variable QuadTree-2 circuit,
+Categorical-256 inputs, CP sum layers, K=32, fp32, batch 4096 PER GPU (weak scaling), synthetic
+int64 batches resident in HBM, closed-form random-init parameters (cirkit_amd.initializers).
+One "step" = one forward of the rank's 4096-row batch (parameter softmax/log recomputed every step,
+as the reference does) + the device-side sum of the log-likelihoods (+ for N > 1 the single RCCL
+all-reduce of the [sum, count] pair).
+
+Prints ONE JSON line on rank 0 (contract in the task description), with
+  roofline     -- dominant kernel: algorithmic bytes (SURVEY.md section 8 d) / HIP-event duration,
+                  against the 8 TB/s HBM3E peak; plus the whole-forward figure;
+  cpu_baseline -- the CPU oracle (op-for-op port of the reference's torch-CPU path) timed on the
+                  host cores of this box on a bounded sample (rank 0, N = 1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="rows per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-graph", action="store_true", help="replay the launch list eagerly instead of as a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.plan import Plan
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(
+                f"--gpus {args.gpus} needs one process per GPU: launch with "
+                f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ..."
+            )
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    plan = Plan.load(os.path.join(ROOT, "tests", "golden", "cfg2_qt784"))
+    tensors = init_plan_tensors(plan)
+    B = args.batch
+    circuit = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph)
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randint(0, 256, (B, plan.num_variables), generator=g).to(device)  # int64, like the reference
+
+    stream = torch.cuda.Stream(device)
+    nll = torch.zeros(2, dtype=torch.float64, device=device)
+
+    def step() -> None:
+        ll = circuit.log_likelihood_sum(x)  # forward + device-side sum, enqueued on `stream`
+        if world > 1:
+            nll.copy_(ll)
+            dist.all_reduce(nll, op=dist.ReduceOp.SUM)  # the ONE exchange: 16 bytes over xGMI
+        else:
+            nll.copy_(ll)
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record(stream)
+            step()
+            b.record(stream)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+    step_ms_events = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    total_nll = float(nll[0].item())
+    total_rows = float(nll[1].item())
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+    alg = plan.algorithmic_bytes(B)  # 615.7 KB per evaluation at this config
+
+    result = {
+        "metric": "log-likelihood evals/sec (batch 4096 per GPU) on 784-var QuadTree PC",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "QuadTree-2 28x28 (784 vars), Categorical-256 leaves, CP sum layers, K=32, "
+                        f"batch {B}/GPU, lse-sum, fold+optimize plan (12 folded layers)",
+            "global_batch": world * B,
+            "parallelism": f"dp{world} (batch-sharded, replicated parameters, one all-reduce of the summed LL)",
+            "hip_graph": not args.no_graph,
+            "params_recomputed_every_step": True,
+        },
+        "check": {"mean_ll": total_nll / max(total_rows, 1.0), "rows": total_rows},
+    }
+
+    if rank == 0:
+        fwd_ms = step_ms_events
+        roof = {
+            "bound": "hbm",
+            "unit": "GB/s",
+            "peak": HBM_PEAK_GBS,
+            "traffic": None,
+            "forward": {
+                "algorithmic_bytes": alg["total"],
+                "avg_ms": fwd_ms,
+                "achieved": alg["total"] / (fwd_ms * 1e-3) / 1e9,
+                "frac": alg["total"] / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            },
+        }
+        if not args.no_kernel_breakdown:
+            with torch.cuda.stream(stream):
+                rows = circuit.profile_kernels(x, iters=10)
+            # aggregate per kernel
+            agg: dict[str, dict] = {}
+            for r in rows:
+                a = agg.setdefault(r["kernel"], {"ms": 0.0, "bytes": 0.0, "launches": 0})
+                a["ms"] += r["ms"]
+                a["bytes"] += r["algorithmic_bytes"]
+                a["launches"] += 1
+            dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            name, a = dom
+            roof.update(
+                {
+                    "kernel": name,
+                    "launches_per_step": a["launches"],
+                    "avg_us_per_launch": 1e3 * a["ms"] / a["launches"],
+                    "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+                    "achieved": a["bytes"] / (a["ms"] * 1e-3) / 1e9,
+                    "frac": a["bytes"] / (a["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernels": {
+                        k: {
+                            "launches": v["launches"],
+                            "ms_per_step": v["ms"],
+                            "algorithmic_GB_per_s": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None,
+                        }
+                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+                    },
+                }
+            )
+        else:
+            roof.update({"kernel": "forward program", "achieved": roof["forward"]["achieved"], "frac": roof["forward"]["frac"]})
+        result["roofline"] = roof
+
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.torch_oracle import as_torch, evaluate_plan
+
+            tt = as_torch(tensors)
+            xs = x[:B].cpu()
+            # pick the host thread count that serves this op mix best (ATen's small-op overheads
+            # make "all cores" far from optimal), on a 512-row probe
+            best_thr, best_rate = 1, 0.0
+            ncpu = os.cpu_count() or 1
+            for thr in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+                torch.set_num_threads(thr)
+                evaluate_plan(plan, tt, xs[:512])
+                t1 = time.perf_counter()
+                evaluate_plan(plan, tt, xs[:512])
+                rate = 512 / (time.perf_counter() - t1)
+                if rate > best_rate:
+                    best_thr, best_rate = thr, rate
+            torch.set_num_threads(best_thr)
+            evaluate_plan(plan, tt, xs[:256])  # warm-up
+            reps, t_cpu = 0, 0.0
+            while reps < 5 and t_cpu < 15.0:
+                t1 = time.perf_counter()
+                evaluate_plan(plan, tt, xs)
+                t_cpu += time.perf_counter() - t1
+                reps += 1
+            result["cpu_baseline"] = {
+                "value": reps * B / t_cpu,
+                "unit": "evals/s",
+                "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"{reps} x one {B}-row batch of the same workload through oracle/torch_oracle.py "
+                          "(op-for-op restatement of the reference's torch-CPU forward, fp32, no_grad)",
+            }
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

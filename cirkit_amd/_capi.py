@@ -1,0 +1,115 @@
+"""ctypes binding of include/cirkit_hip.h.  Fails loudly: there is no CPU or eager fallback --
+if the HIP extension is missing or a call returns an error status, an exception is raised."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
+
+ABI_VERSION = 1
+
+CK_SUM_CAT = 0
+CK_SUM_PROD = 1
+CK_UNARY_SIGMOID = 0
+CK_UNARY_SCALED_SIGMOID = 1
+CK_UNARY_EXP = 2
+CK_UNARY_LOG = 3
+CK_UNARY_SQUARE = 4
+
+_p = C.c_void_p
+_i = C.c_int
+_l = C.c_int64
+_f = C.c_float
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+SIGNATURES: dict[str, list[Any]] = {
+    "ck_abi_version": [],
+    "ck_device_info": [_i, C.POINTER(_l)],
+    "ck_transpose_i64_to_i32": [_p, _p, _i, _i, _p],
+    "ck_transpose_f32": [_p, _p, _i, _i, _p],
+    "ck_categorical_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_gaussian_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_embedding_clog_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_embedding_log_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_constant_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_sum_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_debug_force_generic": [_i],
+    "ck_sum_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_mixing_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_hadamard_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_kronecker_fwd": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_tensordot_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_tensordot_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_param_softmax": [_p, _p, _l, _i, _l, _i, _p],
+    "ck_param_unary": [_i, _p, _p, _l, _f, _f, _p],
+    "ck_param_gather_folds": [_p, _p, _p, _l, _l, _p],
+    "ck_param_conj": [_p, _p, _l, _p],
+    "ck_param_mixing_weight": [_p, _p, _i, _i, _i, _p],
+    "ck_param_bmm": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_param_transpose_last2": [_p, _p, _l, _i, _i, _i, _p],
+    "ck_ll_sum": [_p, _l, _l, _p, _p],
+    "ck_program_begin": [C.POINTER(_p)],
+    "ck_program_end": [_p],
+    "ck_program_num_ops": [_p],
+    "ck_program_launch": [_p, _i, _p],
+    "ck_program_destroy": [_p],
+}
+_RESTYPES = {"ck_last_error": C.c_char_p}
+
+
+class HipExtensionError(RuntimeError):
+    """The HIP extension is missing, stale, or returned an error status."""
+
+
+_lib: C.CDLL | None = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libcirkit_hip.so (built by `python -m cirkit_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch provides the device storage and must bring up ITS HIP runtime first: the library then
+    # binds to the libamdhip64 already in the process instead of loading a second copy.
+    import torch  # noqa: F401
+
+    if not os.path.exists(_LIB_PATH):
+        raise HipExtensionError(
+            f"{_LIB_PATH} not found: build it with `python -m cirkit_amd.build` "
+            "(there is no CPU fallback for the evaluation path)"
+        )
+    lib = C.CDLL(_LIB_PATH)
+    lib.ck_last_error.restype = C.c_char_p
+    lib.ck_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    got = lib.ck_abi_version()
+    if got != ABI_VERSION:
+        raise HipExtensionError(f"libcirkit_hip.so ABI {got} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().ck_last_error().decode("utf-8", "replace")
+        if status == -1:
+            raise ValueError(f"{what}: {msg}")
+        if status == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise HipExtensionError(f"{what}: status {status}: {msg}")
+
+
+def call(name: str, *args: Any) -> None:
+    """Call an entry point and raise on a non-zero status.  ValueError on CK_ERR_INVALID mirrors the
+    reference's shape errors (e.g. TorchSumLayer.__init__, layers/inner.py:237-242)."""
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,362 @@
+"""`HipCircuit`: the MI355X-native counterpart of ``TorchCircuit`` for the forward pass.
+
+Replaces, for one compiled circuit (reference lines in parentheses):
+
+* ``TorchCircuit.forward`` / ``_evaluate_layers``                 circuits.py:242-278
+* the interpreter loop ``TorchDiAcyclicGraph.evaluate``           graph/modules.py:303-335
+* the gather of ``LayerAddressBook.lookup`` (cat + index copy)    circuits.py:30-71
+
+Design (MI355X-first): all layer outputs live in ONE activation arena in HBM, laid
+out ``(F, B, K)`` per layer; a fold index becomes a table of arena offsets that the kernels read
+directly, so the reference's ``(F, H, B, K)`` gather copies (30 % of its CPU time, 2x the traffic
+on a GPU) never exist.  For each batch size the launch sequence is recorded once into a native
+``ck_program`` and replayed with one host call (optionally as a hipGraph), instead of a Python loop
+with ~10 ATen launches per layer.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from .layers import HipConstantValueLayer, HipInputLayer, HipLayer, layer_from_spec
+from .parameters import TensorStore
+from .plan import Plan, resolve_fold_index
+
+_ALIGN = 64  # arena alignment of every layer block, in activation elements (>= 256 B)
+
+
+class _Binding:
+    """Everything that depends on the batch size: arena, offset tables, recorded program."""
+
+    def __init__(self) -> None:
+        self.B = 0
+        self.arena: torch.Tensor | None = None
+        self.views: list[torch.Tensor] = []
+        self.row_off: list[torch.Tensor | None] = []
+        self.xt: torch.Tensor | None = None
+        self.program = None  # ck_program*
+        self.store_version = -1
+        self.ll: torch.Tensor | None = None
+
+    def destroy(self) -> None:
+        if self.program is not None:
+            capi.load().ck_program_destroy(self.program)
+            self.program = None
+
+
+class HipCircuit:
+    """Evaluate a folded plan on one MI355X.
+
+    Args:
+        plan: the folded layer list (`cirkit_amd.plan.Plan`).
+        tensors: parameter values by plan tensor name (numpy arrays or torch tensors).
+        device: a ROCm device, e.g. ``"cuda:0"``.
+        use_graph: replay each batch size's launch list as a hipGraph.
+        input_dtype: dtype of the batches (``torch.int64`` like the reference, or any integer /
+            float dtype; converted once on device).
+    """
+
+    def __init__(
+        self,
+        plan: Plan,
+        tensors: Mapping[str, object] | TensorStore,
+        *,
+        device: str | torch.device = "cuda:0",
+        use_graph: bool = True,
+    ) -> None:
+        if plan.semiring not in ("lse-sum", "complex-lse-sum"):
+            raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise capi.HipExtensionError("HipCircuit needs a ROCm device; there is no CPU fallback")
+        capi.load()
+        self.plan = plan
+        self.use_graph = use_graph
+        if isinstance(tensors, TensorStore):
+            self.store = tensors
+        else:
+            self.store = TensorStore(self.device)
+            self.store.update(tensors)
+        missing = [k for k in plan.tensors if k not in self.store]
+        if missing:
+            raise ValueError(f"missing parameter tensors: {missing}")
+        self.layers: list[HipLayer] = [layer_from_spec(s, self.store, plan.semiring) for s in plan.layers]
+        self._folds = [l.num_folds for l in self.layers]
+        self._complex = plan.semiring == "complex-lse-sum"
+        self._act_dtype = torch.complex64 if self._complex else torch.float32
+        # (producer, fold) pairs of every inner layer's children and of the circuit output
+        self._children = [
+            None if s.inputs is None else resolve_fold_index(s.inputs, self._folds) for s in plan.layers
+        ]
+        for s, ch, l in zip(plan.layers, self._children, self.layers):
+            if ch is not None and ch.shape[:2] != (l.num_folds, l.arity):
+                raise ValueError(
+                    f"fold index of a {s.type} layer has shape {ch.shape[:2]}, expected {(l.num_folds, l.arity)}"
+                )
+        self._out_pairs = resolve_fold_index(plan.output, self._folds).reshape(-1, 2)
+        self._float_input = any(getattr(l, "wants_float_input", False) for l in self.layers)
+        self._bindings: dict[int, _Binding] = {}
+        self._side: torch.cuda.Stream | None = None  # graphs cannot be captured on the null stream
+
+    # -- reference surface -----------------------------------------------------------------------
+    @property
+    def num_variables(self) -> int:
+        return self.plan.num_variables
+
+    def __call__(self, x: torch.Tensor | None = None) -> torch.Tensor:
+        return self.forward(x)
+
+    def __del__(self) -> None:  # pragma: no cover - interpreter teardown order
+        try:
+            for b in self._bindings.values():
+                b.destroy()
+        except Exception:
+            pass
+
+    # -- binding ---------------------------------------------------------------------------------
+    def _layer_batch(self, l: HipLayer, B: int) -> int:
+        return B
+
+    def _bind(self, B: int) -> _Binding:
+        bd = self._bindings.get(B)
+        if bd is not None and bd.store_version == self.store.version:
+            return bd
+        if bd is not None:
+            bd.destroy()
+        if len(self._bindings) >= 4:  # keep a handful of batch sizes resident
+            old = next(iter(self._bindings))
+            self._bindings.pop(old).destroy()
+        bd = _Binding()
+        bd.B = B
+        bd.store_version = self.store.version
+        # arena layout
+        bases, total = [], 0
+        for l in self.layers:
+            bases.append(total)
+            n = l.num_folds * B * l.num_output_units
+            total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        bd.arena = torch.empty(total, dtype=self._act_dtype, device=self.device)
+        bd.views = [
+            bd.arena[b : b + l.num_folds * B * l.num_output_units].view(l.num_folds, B, l.num_output_units)
+            for b, l in zip(bases, self.layers)
+        ]
+        # children offset tables: element offsets into the arena (replaces circuits.py:42-47)
+        bd.row_off = []
+        for ch, l in zip(self._children, self.layers):
+            if ch is None:
+                bd.row_off.append(None)
+                continue
+            prod, fold = ch[..., 0], ch[..., 1]
+            ko = np.asarray([self.layers[p].num_output_units for p in prod.reshape(-1)]).reshape(prod.shape)
+            if not np.all(ko == l.num_input_units):
+                raise ValueError("a layer's children do not all have its number of input units")
+            off = np.asarray(bases, dtype=np.int64)[prod] + fold * (B * l.num_input_units)
+            bd.row_off.append(torch.from_numpy(np.ascontiguousarray(off)).to(self.device))
+        if self.plan.num_variables:
+            bd.xt = torch.empty(
+                (self.plan.num_variables, B),
+                dtype=torch.float32 if self._float_input else torch.int32,
+                device=self.device,
+            )
+        bd.ll = torch.empty(2, dtype=torch.float64, device=self.device)
+        # record the launch list once
+        prog = C.c_void_p()
+        capi.call("ck_program_begin", C.byref(prog))
+        try:
+            self._enqueue_all(bd, 0)
+        finally:
+            capi.call("ck_program_end", prog)
+        bd.program = prog
+        self._bindings[B] = bd
+        return bd
+
+    def _enqueue_all(self, bd: _Binding, stream: int) -> None:
+        """One forward: per layer, parameter graph then the layer kernel (the order of
+        graph/modules.py:326-334)."""
+        B = bd.B
+        for l, view, ro in zip(self.layers, bd.views, bd.row_off):
+            l.prepare(stream)
+            if isinstance(l, HipConstantValueLayer):
+                l.launch_const(view, B, stream)
+            elif isinstance(l, HipInputLayer):
+                l.launch_input(bd.xt, self.plan.num_variables, view, B, stream)
+            else:
+                l.launch(bd.arena, ro, view, B, stream)
+
+    # -- evaluation ------------------------------------------------------------------------------
+    def _stage_input(self, bd: _Binding, x: torch.Tensor, stream: int) -> None:
+        """(B, D) batch -> (D, B) staging copy (replaces circuits.py:66)."""
+        B, D = x.shape
+        if x.device != self.device:
+            x = x.to(self.device)
+        x = x.contiguous()
+        if self._float_input:
+            if x.dtype != torch.float32:
+                x = x.to(torch.float32)
+            capi.call("ck_transpose_f32", x.data_ptr(), bd.xt.data_ptr(), B, D, stream)
+        else:
+            if x.dtype != torch.int64:
+                x = x.to(torch.int64)  # float batches are truncated like `x.long()` (input.py:400-401)
+            capi.call("ck_transpose_i64_to_i32", x.data_ptr(), bd.xt.data_ptr(), B, D, stream)
+
+    def _run(self, x: torch.Tensor | None) -> _Binding:
+        if self.plan.num_variables:
+            if x is None:
+                raise ValueError(f"Expected some input 'x', as the circuit has {self.plan.num_variables} variables")
+            if x.dim() != 2:
+                raise ValueError(
+                    "The input to the circuit should have shape (B, D), where B is the batch size and D "
+                    "is the number of variables the circuit is defined on"
+                )
+            if x.shape[1] < self.plan.num_variables:
+                raise ValueError(f"expected at least {self.plan.num_variables} variables, found {x.shape[1]}")
+            B = int(x.shape[0])
+        else:
+            B = 1 if x is None else int(x.shape[0])
+        if B <= 0:
+            raise ValueError("empty batch")
+        bd = self._bind(B)
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            run = cur
+            if self.use_graph and cur.cuda_stream == 0:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(self.device)
+                run = self._side
+                run.wait_stream(cur)
+            stream = run.cuda_stream
+            if self.plan.num_variables:
+                if x.shape[1] != self.plan.num_variables:
+                    x = x[:, : self.plan.num_variables]
+                self._stage_input(bd, x, stream)
+            capi.call("ck_program_launch", bd.program, 1 if self.use_graph else 0, stream)
+            if run is not cur:
+                cur.wait_stream(run)
+        return bd
+
+    def forward(self, x: torch.Tensor | None = None) -> torch.Tensor:
+        """Returns ``(B, O, K)`` like ``TorchCircuit.forward`` (``(O, K)`` for an empty-scope circuit).
+        The result aliases the circuit's arena: it is overwritten by the next call with the same
+        batch size (clone it to keep it)."""
+        bd = self._run(x)
+        pairs = self._out_pairs
+        if len(pairs) == 1:
+            p, f = int(pairs[0, 0]), int(pairs[0, 1])
+            y = bd.views[p][f : f + 1]  # (1, B, K)
+        else:
+            y = torch.stack([bd.views[int(p)][int(f)] for p, f in pairs], dim=0)  # (O, B, K)
+        y = y.transpose(0, 1)
+        if self.plan.num_variables == 0:
+            y = y.squeeze(0)
+        return y
+
+    def layer_outputs(self, x: torch.Tensor | None = None) -> list[torch.Tensor]:
+        """All ``(F, B, Ko)`` layer outputs of one forward (views of the arena) -- for parity tests."""
+        return list(self._run(x).views)
+
+    def log_likelihood_sum(self, x: torch.Tensor) -> torch.Tensor:
+        """Device tensor ``[sum_b log p(x_b), B]`` in fp64 -- the two numbers the data-parallel
+        all-reduce exchanges (SURVEY.md section 8 e).  Requires a single scalar output."""
+        bd = self._run(x)
+        pairs = self._out_pairs
+        if len(pairs) != 1 or self._complex:
+            raise ValueError("log_likelihood_sum needs a real circuit with one output")
+        p, f = int(pairs[0, 0]), int(pairs[0, 1])
+        view = bd.views[p]
+        if view.shape[2] != 1:
+            raise ValueError("log_likelihood_sum needs a scalar output unit")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        capi.call("ck_ll_sum", view[f].data_ptr(), bd.B, 1, bd.ll.data_ptr(), stream)
+        return bd.ll
+
+    # -- instrumentation -------------------------------------------------------------------------
+    def kernel_label(self, i: int) -> str:
+        """Name of the HIP kernel that evaluates layer i (as it appears in a rocprofv3 trace)."""
+        l, s = self.layers[i], self.plan.layers[i]
+        if s.type in ("categorical", "embedding"):
+            return "gather_rows_vec" if l.num_output_units % 4 == 0 else "gather_rows_scalar"
+        if s.type == "gaussian":
+            return "gaussian_kernel"
+        if s.type == "constant":
+            return "constant_kernel"
+        if s.type == "hadamard":
+            return "hadamard_vec" if (l.num_input_units * l.esize) % 4 == 0 else "hadamard_scalar"
+        if s.type == "kronecker":
+            return "kronecker_kernel"
+        if s.type == "tensordot":
+            return "tensordot_lse_kernel"
+        if getattr(l, "_mixing", False):
+            return "mixing_lse_kernel"
+        prod_like = s.type == "cpt" or l.arity == 1
+        if (not self._complex and prod_like and l.num_input_units == l.num_output_units
+                and l.num_input_units in (32, 64)):
+            return f"sum_lse_mfma<{l.num_input_units // 32}>"
+        return "sum_lse_generic"
+
+    def profile_kernels(self, x: torch.Tensor | None, iters: int = 10) -> list[dict]:
+        """Eager (non-graph) forwards with HIP events around every layer's parameter kernels and
+        layer kernel, recorded on the current stream (the stream the kernels are launched on).
+        Returns one row per launch group: kernel label, mean ms, algorithmic bytes."""
+        bd = self._run(x)  # make sure the binding (arena, staging copy) exists and is warm
+        B = bd.B
+        cur = torch.cuda.current_stream(self.device)
+        stream = cur.cuda_stream
+        esz = 8 if self._complex else 4
+        rows: list[dict] = []
+        acc: list[list[float]] = []
+        for it in range(iters + 1):
+            evs = []
+            for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e2 = torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                l.prepare(stream)
+                e1.record(cur)
+                if isinstance(l, HipConstantValueLayer):
+                    l.launch_const(view, B, stream)
+                elif isinstance(l, HipInputLayer):
+                    l.launch_input(bd.xt, self.plan.num_variables, view, B, stream)
+                else:
+                    l.launch(bd.arena, ro, view, B, stream)
+                e2.record(cur)
+                evs.append((e0, e1, e2))
+            torch.cuda.synchronize(self.device)
+            if it == 0:
+                continue  # warm-up
+            acc.append([t for e0, e1, e2 in evs for t in (e0.elapsed_time(e1), e1.elapsed_time(e2))])
+        mean = np.mean(np.asarray(acc), axis=0)
+        for i, (l, s) in enumerate(zip(self.layers, self.plan.layers)):
+            pbytes = 0
+            for pg in s.params.values():
+                for n in pg.nodes:
+                    if n.op in ("tensor", "pointer"):
+                        shp, dt = self.plan.tensors[n.config["tensor"]]
+                        per_fold = int(np.prod(shp[1:])) * (8 if "complex" in dt else 4)
+                        pbytes += per_fold * n.num_folds
+            if s.params:
+                rows.append({"layer": i, "kernel": "param kernels (softmax/log/transpose)", "ms": float(mean[2 * i]),
+                             "algorithmic_bytes": float(pbytes)})
+            if s.inputs is not None:
+                rd = l.num_folds * l.arity * B * l.num_input_units * esz
+            elif s.scope_idx is not None and s.scope_idx.size:
+                rd = int(s.scope_idx.size) * B * 8
+            else:
+                rd = 0
+            wr = l.num_folds * B * l.num_output_units * esz
+            rows.append({"layer": i, "kernel": self.kernel_label(i), "ms": float(mean[2 * i + 1]),
+                         "algorithmic_bytes": float(rd + wr)})
+        return rows
+
+    # -- accounting ------------------------------------------------------------------------------
+    def arena_bytes(self, B: int) -> int:
+        esz = 8 if self._complex else 4
+        return sum(l.num_folds * B * l.num_output_units for l in self.layers) * esz
+
+    def num_launches(self, B: int) -> int:
+        return int(capi.load().ck_program_num_ops(self._bind(B).program))

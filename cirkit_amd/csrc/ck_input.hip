@@ -1,0 +1,266 @@
+// Input layers: batch staging (transpose), Categorical, Gaussian, Embedding, ConstantValue.
+//
+// All of these are pure HBM-write-bound streams: one (f, b) row of K outputs is produced from one
+// scalar of the batch plus a K-row of per-fold parameters that stays in L2/Infinity Cache.  The
+// kernels therefore (a) read the batch through a (D, B) transposed copy so the scalar loads are
+// contiguous along B, (b) keep the parameter row contiguous in K (tables are (F, C, K)), and
+// (c) write float4 per lane, a whole 256-row x K tile per workgroup, contiguous in HBM.
+#include <algorithm>
+
+#include "ck_internal.h"
+
+namespace {
+
+constexpr int kTile = 32;
+
+template <typename TI, typename TO>
+__global__ void transpose_kernel(const TI* __restrict__ x, TO* __restrict__ xt, int B, int D) {
+  __shared__ TO tile[kTile][kTile + 1];
+  const int d0 = blockIdx.x * kTile, b0 = blockIdx.y * kTile;
+  const int tx = threadIdx.x, ty = threadIdx.y;  // (32, 8)
+#pragma unroll
+  for (int j = 0; j < kTile; j += 8) {
+    const int b = b0 + ty + j, d = d0 + tx;
+    if (b < B && d < D) tile[ty + j][tx] = static_cast<TO>(x[static_cast<int64_t>(b) * D + d]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kTile; j += 8) {
+    const int d = d0 + ty + j, b = b0 + tx;
+    if (b < B && d < D) xt[static_cast<int64_t>(d) * B + b] = tile[tx][ty + j];
+  }
+}
+
+template <typename TI, typename TO>
+int transpose_impl(const TI* x, TO* xt, int B, int D, void* stream, const char* who) {
+  CK_REQUIRE(x != nullptr && xt != nullptr, "%s: null pointer", who);
+  CK_REQUIRE(B > 0 && D > 0, "%s: B=%d D=%d must be positive", who, B, D);
+  dim3 grid((D + kTile - 1) / kTile, (B + kTile - 1) / kTile), block(kTile, 8);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, block, 0, s, x, xt, B, D);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+// ---- gather-type input layers ------------------------------------------------------------------
+// MODE 0: copy table row (categorical, lse-sum)
+// MODE 1: log of table row (embedding, lse-sum)
+// MODE 2: complex log of the real table row (embedding, complex-lse-sum): (log|w|, w<0 ? pi : 0)
+__device__ __forceinline__ float4 log4(float4 v) {
+  return make_float4(__logf(v.x), __logf(v.y), __logf(v.z), __logf(v.w));
+}
+
+// vector path: K % 4 == 0.  One lane = 4 consecutive units of one (f, b) row.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+    gather_rows_vec(const float* __restrict__ table, const int32_t* __restrict__ xt,
+                    const int64_t* __restrict__ scope, float* __restrict__ out, int B, int K, int C,
+                    int rows_per_block) {
+  const int f = blockIdx.y;
+  const int kv = K >> 2;                      // float4 per row
+  const int lanes_rows = blockDim.x / kv;     // rows handled per pass
+  const int r_in = threadIdx.x / kv, q = threadIdx.x - r_in * kv;
+  if (r_in >= lanes_rows) return;
+  const int64_t var = scope[f];
+  const int32_t* xrow = xt + var * B;
+  const float4* tab = reinterpret_cast<const float4*>(table + static_cast<int64_t>(f) * C * K);
+  const int b_begin = blockIdx.x * rows_per_block;
+  const int b_end = min(B, b_begin + rows_per_block);
+  for (int b = b_begin + r_in; b < b_end; b += lanes_rows) {
+    int c = xrow[b];
+    c = min(max(c, 0), C - 1);  // memory safety; the reference raises on out-of-range categories
+    float4 v = tab[static_cast<int64_t>(c) * kv + q];
+    const int64_t o = (static_cast<int64_t>(f) * B + b) * K + 4 * q;
+    if (MODE == 0) {
+      *reinterpret_cast<float4*>(out + o) = v;
+    } else if (MODE == 1) {
+      *reinterpret_cast<float4*>(out + o) = log4(v);
+    } else {
+      const float pi = 3.14159265358979323846f;
+      float4 l = make_float4(logf(fabsf(v.x)), logf(fabsf(v.y)), logf(fabsf(v.z)), logf(fabsf(v.w)));
+      float4* oc = reinterpret_cast<float4*>(out + 2 * o);
+      oc[0] = make_float4(l.x, v.x < 0.f ? pi : 0.f, l.y, v.y < 0.f ? pi : 0.f);
+      oc[1] = make_float4(l.z, v.z < 0.f ? pi : 0.f, l.w, v.w < 0.f ? pi : 0.f);
+    }
+  }
+}
+
+// scalar path: any K.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+    gather_rows_scalar(const float* __restrict__ table, const int32_t* __restrict__ xt,
+                       const int64_t* __restrict__ scope, float* __restrict__ out, int B, int K,
+                       int C) {
+  const int f = blockIdx.y;
+  const int64_t var = scope[f];
+  const int64_t n = static_cast<int64_t>(B) * K;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(i / K), k = static_cast<int>(i - static_cast<int64_t>(b) * K);
+    int c = xt[var * B + b];
+    c = min(max(c, 0), C - 1);
+    const float v = table[(static_cast<int64_t>(f) * C + c) * K + k];
+    const int64_t o = static_cast<int64_t>(f) * n + i;
+    if (MODE == 0) {
+      out[o] = v;
+    } else if (MODE == 1) {
+      out[o] = __logf(v);
+    } else {
+      out[2 * o] = logf(fabsf(v));
+      out[2 * o + 1] = v < 0.f ? 3.14159265358979323846f : 0.f;
+    }
+  }
+}
+
+template <int MODE>
+int gather_impl(const float* table, const int32_t* xt, const int64_t* scope, float* out, int F,
+                int B, int K, int C, int D, void* stream, const char* who) {
+  CK_REQUIRE(table && xt && scope && out, "%s: null pointer", who);
+  CK_REQUIRE(F > 0 && B > 0 && K > 0 && C > 0 && D > 0, "%s: non-positive size F=%d B=%d K=%d C=%d D=%d",
+             who, F, B, K, C, D);
+  CK_REQUIRE(F <= 65535, "%s: F=%d exceeds grid.y", who, F);
+  const bool vec = (K % 4 == 0) && (K / 4 <= 256) && ck::aligned16(table) && ck::aligned16(out);
+  if (vec) {
+    const int rows_per_block = 256;
+    dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          hipLaunchKernelGGL((gather_rows_vec<MODE>), grid, block, 0, s, table, xt, scope, out, B, K,
+                             C, rows_per_block);
+          return hipGetLastError();
+        },
+        stream);
+  }
+  const int64_t n = static_cast<int64_t>(B) * K;
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 4096)), F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL((gather_rows_scalar<MODE>), grid, block, 0, s, table, xt, scope, out, B, K, C);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+// ---- Gaussian ----------------------------------------------------------------------------------
+// Normal(mean, stddev).log_prob(x) exactly as torch.distributions.Normal computes it:
+//   -((x - mean)**2) / (2 * stddev**2) - log(stddev) - log(sqrt(2*pi))
+__global__ void __launch_bounds__(256)
+    gaussian_kernel(const float* __restrict__ mean, const float* __restrict__ stddev,
+                    const float* __restrict__ logz, const float* __restrict__ xt,
+                    const int64_t* __restrict__ scope, float* __restrict__ out, int B, int K,
+                    int rows_per_block) {
+  const int f = blockIdx.y;
+  const int kk = K <= 256 ? K : 256;  // lanes along the unit axis
+  const int lanes_rows = 256 / kk;    // rows per pass
+  const int r_in = threadIdx.x / kk, k0 = threadIdx.x - r_in * kk;
+  if (r_in >= lanes_rows) return;
+  const float* xrow = xt + scope[f] * B;
+  const int b_begin = blockIdx.x * rows_per_block;
+  const int b_end = min(B, b_begin + rows_per_block);
+  const float kHalfLog2Pi = 0.91893853320467274178f;
+  for (int k = k0; k < K; k += kk) {
+    const float mu = mean[static_cast<int64_t>(f) * K + k];
+    const float sd = stddev[static_cast<int64_t>(f) * K + k];
+    const float two_var = 2.f * (sd * sd);
+    const float tail = __logf(sd);
+    const float lz = logz != nullptr ? logz[static_cast<int64_t>(f) * K + k] : 0.f;
+    for (int b = b_begin + r_in; b < b_end; b += lanes_rows) {
+      const float d = xrow[b] - mu;
+      float lp = -(d * d) / two_var - tail - kHalfLog2Pi;
+      if (logz != nullptr) lp += lz;
+      out[(static_cast<int64_t>(f) * B + b) * K + k] = lp;
+    }
+  }
+}
+
+// ---- ConstantValue -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    constant_kernel(const float* __restrict__ value, float* __restrict__ out, int B, int K,
+                    int log_space, int value_is_complex, int complex_out) {
+  const int f = blockIdx.y;
+  const int64_t n = static_cast<int64_t>(B) * K;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int k = static_cast<int>(i % K);
+    const int64_t vi = static_cast<int64_t>(f) * K + k;
+    ck::c32 v;
+    if (value_is_complex) {
+      v = {value[2 * vi], value[2 * vi + 1]};
+    } else {
+      v = {value[vi], 0.f};
+    }
+    const int64_t o = static_cast<int64_t>(f) * n + i;
+    if (complex_out) {
+      ck::c32 r = log_space ? v : ck::c_log_shift(v, 0.f);
+      out[2 * o] = r.re;
+      out[2 * o + 1] = r.im;
+    } else {
+      out[o] = log_space ? v.re : __logf(v.re);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ck_transpose_i64_to_i32(const int64_t* x, int32_t* xt, int B, int D, void* stream) {
+  return transpose_impl<int64_t, int32_t>(x, xt, B, D, stream, "ck_transpose_i64_to_i32");
+}
+
+int ck_transpose_f32(const float* x, float* xt, int B, int D, void* stream) {
+  return transpose_impl<float, float>(x, xt, B, D, stream, "ck_transpose_f32");
+}
+
+int ck_categorical_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out,
+                       int F, int B, int K, int C, int D, void* stream) {
+  return gather_impl<0>(table, xt, scope, out, F, B, K, C, D, stream, "ck_categorical_fwd");
+}
+
+int ck_embedding_log_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out,
+                         int F, int B, int K, int C, int D, void* stream) {
+  return gather_impl<1>(table, xt, scope, out, F, B, K, C, D, stream, "ck_embedding_log_fwd");
+}
+
+int ck_embedding_clog_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out_c,
+                          int F, int B, int K, int C, int D, void* stream) {
+  return gather_impl<2>(table, xt, scope, out_c, F, B, K, C, D, stream, "ck_embedding_clog_fwd");
+}
+
+int ck_gaussian_fwd(const float* mean, const float* stddev, const float* log_partition,
+                    const float* xt, const int64_t* scope, float* out, int F, int B, int K, int D,
+                    void* stream) {
+  CK_REQUIRE(mean && stddev && xt && scope && out, "ck_gaussian_fwd: null pointer");
+  CK_REQUIRE(F > 0 && B > 0 && K > 0 && D > 0, "ck_gaussian_fwd: non-positive size");
+  CK_REQUIRE(F <= 65535, "ck_gaussian_fwd: F=%d exceeds grid.y", F);
+  const int rows_per_block = 256;
+  dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(gaussian_kernel, grid, block, 0, s, mean, stddev, log_partition, xt, scope,
+                           out, B, K, rows_per_block);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_constant_fwd(const float* value, float* out, int F, int B, int K, int log_space,
+                    int value_is_complex, int complex_out, void* stream) {
+  CK_REQUIRE(value && out, "ck_constant_fwd: null pointer");
+  CK_REQUIRE(F > 0 && B > 0 && K > 0, "ck_constant_fwd: non-positive size");
+  CK_REQUIRE(F <= 65535, "ck_constant_fwd: F=%d exceeds grid.y", F);
+  CK_REQUIRE(complex_out || !value_is_complex, "ck_constant_fwd: complex value needs complex output");
+  const int64_t n = static_cast<int64_t>(B) * K;
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 1024)), F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(constant_kernel, grid, block, 0, s, value, out, B, K, log_space,
+                           value_is_complex, complex_out);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+// Parameter-graph kernels (softmax / sigmoid / mixing weights / matmul / ...) on fold-stacked
+// blocks, and the log-likelihood reduction that feeds the data-parallel all-reduce.
+//
+// The reference re-evaluates these on every forward with one ATen launch per node
+// (cirkit/backend/torch/parameters/parameter.py:180-188); total volume is the parameter size
+// (32 MB at the north-star config), i.e. ~1 % of the activation traffic.
+#include <algorithm>
+
+#include "ck_internal.h"
+
+namespace {
+
+// softmax over `len` with stride `inner`; one wave per (outer, inner) line when inner == 1,
+// otherwise one thread per line (lines are then adjacent in memory -> coalesced across threads).
+__global__ void __launch_bounds__(256)
+    softmax_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t rows, int len,
+                        int log_space) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = blockIdx.x * static_cast<int64_t>(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* src = in + row * len;
+  float* dst = out + row * len;
+  float mx = -INFINITY;
+  for (int i = lane; i < len; i += 64) mx = fmaxf(mx, src[i]);
+  mx = ck::wave_max(mx);
+  float sum = 0.f;
+  for (int i = lane; i < len; i += 64) sum += expf(src[i] - mx);
+  sum = ck::wave_sum(sum);
+  if (log_space) {
+    const float ls = logf(sum);
+    for (int i = lane; i < len; i += 64) dst[i] = (src[i] - mx) - ls;
+  } else {
+    for (int i = lane; i < len; i += 64) dst[i] = expf(src[i] - mx) / sum;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    softmax_strided_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t outer,
+                           int len, int64_t inner, int log_space) {
+  const int64_t line = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (line >= outer * inner) return;
+  const int64_t o = line / inner, i = line - o * inner;
+  const float* src = in + o * len * inner + i;
+  float* dst = out + o * len * inner + i;
+  float mx = -INFINITY;
+  for (int j = 0; j < len; ++j) mx = fmaxf(mx, src[j * inner]);
+  float sum = 0.f;
+  for (int j = 0; j < len; ++j) sum += expf(src[j * inner] - mx);
+  const float ls = logf(sum);
+  for (int j = 0; j < len; ++j)
+    dst[j * inner] = log_space ? (src[j * inner] - mx) - ls : expf(src[j * inner] - mx) / sum;
+}
+
+__global__ void __launch_bounds__(256)
+    unary_kernel(int op, const float* __restrict__ in, float* __restrict__ out, int64_t n, float a,
+                 float b) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const float x = in[i];
+    float y;
+    switch (op) {
+      case CK_UNARY_SIGMOID:
+        y = 1.f / (1.f + expf(-x));
+        break;
+      case CK_UNARY_SCALED_SIGMOID:
+        y = (1.f / (1.f + expf(-x))) * (b - a) + a;
+        break;
+      case CK_UNARY_EXP:
+        y = expf(x);
+        break;
+      case CK_UNARY_LOG:
+        y = logf(x);
+        break;
+      default:
+        y = x * x;
+        break;
+    }
+    out[i] = y;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    gather_folds_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx,
+                        float* __restrict__ out, int64_t per_fold) {
+  const int64_t f = blockIdx.y;
+  const float* src = in + idx[f] * per_fold;
+  float* dst = out + f * per_fold;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < per_fold;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(256)
+    conj_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    out[2 * i] = in[2 * i];
+    out[2 * i + 1] = -in[2 * i + 1];
+  }
+}
+
+// (F,K,H) -> (F,K,H*K): out[f,k,h*K+k'] = in[f,k,h] * (k == k')
+__global__ void __launch_bounds__(256)
+    mixing_weight_kernel(const float* __restrict__ in, float* __restrict__ out, int K, int H) {
+  const int64_t f = blockIdx.y;
+  const int64_t n = static_cast<int64_t>(K) * H * K;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int k = static_cast<int>(i / (static_cast<int64_t>(H) * K));
+    const int r = static_cast<int>(i - static_cast<int64_t>(k) * H * K);
+    const int h = r / K, k2 = r - h * K;
+    out[f * n + i] = (k == k2) ? in[(f * K + k) * H + h] : 0.f;
+  }
+}
+
+// out[f,m,n] = sum_k A(m,k) B(k,n); 16x16 LDS tiles.
+constexpr int kMM = 16;
+__global__ void __launch_bounds__(256)
+    bmm_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+               int M, int N, int Kd, int trans_a, int trans_b) {
+  __shared__ float as[kMM][kMM + 1], bs[kMM][kMM + 1];
+  const int64_t f = blockIdx.z;
+  const float* af = a + f * static_cast<int64_t>(M) * Kd;
+  const float* bf = b + f * static_cast<int64_t>(Kd) * N;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m = blockIdx.y * kMM + ty, n = blockIdx.x * kMM + tx;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < Kd; k0 += kMM) {
+    const int ka = k0 + tx, kb = k0 + ty;
+    as[ty][tx] = (m < M && ka < Kd) ? (trans_a ? af[static_cast<int64_t>(ka) * M + m] : af[static_cast<int64_t>(m) * Kd + ka]) : 0.f;
+    bs[ty][tx] = (kb < Kd && n < N) ? (trans_b ? bf[static_cast<int64_t>(n) * Kd + kb] : bf[static_cast<int64_t>(kb) * N + n]) : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kMM; ++k) acc = fmaf(as[ty][k], bs[k][tx], acc);
+    __syncthreads();
+  }
+  if (m < M && n < N) out[f * static_cast<int64_t>(M) * N + static_cast<int64_t>(m) * N + n] = acc;
+}
+
+// (R, A, Bd) -> (R, Bd, A) through a 32x32 LDS tile, optional log.
+__global__ void __launch_bounds__(256)
+    transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int Bd,
+                           int take_log) {
+  __shared__ float tile[32][33];
+  const int64_t r = blockIdx.z;
+  const float* src = in + r * static_cast<int64_t>(A) * Bd;
+  float* dst = out + r * static_cast<int64_t>(A) * Bd;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // (32, 8)
+  const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int ai = a0 + ty + j, bi = b0 + tx;
+    if (ai < A && bi < Bd) {
+      const float v = src[static_cast<int64_t>(ai) * Bd + bi];
+      tile[ty + j][tx] = take_log ? logf(v) : v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int bi = b0 + ty + j, ai = a0 + tx;
+    if (ai < A && bi < Bd) dst[static_cast<int64_t>(bi) * A + ai] = tile[tx][ty + j];
+  }
+}
+
+// ---- log-likelihood sum ------------------------------------------------------------------------
+// Single workgroup: B is a batch (<= a few 10^5 rows), and a one-block tree gives a
+// run-to-run deterministic fp64 sum (no atomics).
+__global__ void __launch_bounds__(1024)
+    ll_sum_kernel(const float* __restrict__ ll, int64_t B, int64_t stride, double* __restrict__ out) {
+  __shared__ double part[16];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) acc += static_cast<double>(ll[i * stride]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < static_cast<int>(blockDim.x >> 6); ++i) t += part[i];
+    out[0] = t;
+    out[1] = static_cast<double>(B);
+  }
+}
+
+unsigned grid1d(int64_t n, int cap = 2048) {
+  return static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, cap));
+}
+
+}  // namespace
+
+extern "C" {
+
+int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_t inner,
+                     int log_space, void* stream) {
+  CK_REQUIRE(in && out, "ck_param_softmax: null pointer");
+  CK_REQUIRE(outer > 0 && len > 0 && inner > 0, "ck_param_softmax: non-positive size");
+  if (inner == 1) {
+    const int64_t rows = outer;
+    dim3 grid(static_cast<unsigned>((rows + 3) / 4)), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          hipLaunchKernelGGL(softmax_rows_kernel, grid, block, 0, s, in, out, rows, len, log_space);
+          return hipGetLastError();
+        },
+        stream);
+  }
+  dim3 grid(static_cast<unsigned>((outer * inner + 255) / 256)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(softmax_strided_kernel, grid, block, 0, s, in, out, outer, len, inner, log_space);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_unary(int op, const float* in, float* out, int64_t n, float a, float b, void* stream) {
+  CK_REQUIRE(in && out, "ck_param_unary: null pointer");
+  CK_REQUIRE(n > 0, "ck_param_unary: n must be positive");
+  CK_REQUIRE(op >= CK_UNARY_SIGMOID && op <= CK_UNARY_SQUARE, "ck_param_unary: unknown op %d", op);
+  dim3 grid(grid1d(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(unary_kernel, grid, block, 0, s, op, in, out, n, a, b);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_gather_folds(const float* in, const int64_t* idx, float* out, int64_t F_out,
+                          int64_t per_fold, void* stream) {
+  CK_REQUIRE(in && idx && out, "ck_param_gather_folds: null pointer");
+  CK_REQUIRE(F_out > 0 && per_fold > 0, "ck_param_gather_folds: non-positive size");
+  CK_REQUIRE(F_out <= 65535, "ck_param_gather_folds: F_out exceeds grid.y");
+  dim3 grid(grid1d(per_fold, 64), static_cast<unsigned>(F_out)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(gather_folds_kernel, grid, block, 0, s, in, idx, out, per_fold);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_conj(const float* in_c, float* out_c, int64_t n, void* stream) {
+  CK_REQUIRE(in_c && out_c, "ck_param_conj: null pointer");
+  CK_REQUIRE(n > 0, "ck_param_conj: n must be positive");
+  dim3 grid(grid1d(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(conj_kernel, grid, block, 0, s, in_c, out_c, n);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_mixing_weight(const float* in, float* out, int F, int K, int H, void* stream) {
+  CK_REQUIRE(in && out, "ck_param_mixing_weight: null pointer");
+  CK_REQUIRE(F > 0 && K > 0 && H > 0, "ck_param_mixing_weight: non-positive size");
+  CK_REQUIRE(F <= 65535, "ck_param_mixing_weight: F exceeds grid.y");
+  dim3 grid(grid1d(static_cast<int64_t>(K) * H * K, 256), F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(mixing_weight_kernel, grid, block, 0, s, in, out, K, H);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd,
+                 int trans_a, int trans_b, void* stream) {
+  CK_REQUIRE(a && b && out, "ck_param_bmm: null pointer");
+  CK_REQUIRE(F > 0 && M > 0 && N > 0 && Kd > 0, "ck_param_bmm: non-positive size");
+  CK_REQUIRE(F <= 65535, "ck_param_bmm: F exceeds grid.z");
+  dim3 grid((N + kMM - 1) / kMM, (M + kMM - 1) / kMM, F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(bmm_kernel, grid, block, 0, s, a, b, out, M, N, Kd, trans_a, trans_b);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int Bd, int take_log,
+                             void* stream) {
+  CK_REQUIRE(in && out, "ck_param_transpose_last2: null pointer");
+  CK_REQUIRE(R > 0 && A > 0 && Bd > 0, "ck_param_transpose_last2: non-positive size");
+  CK_REQUIRE(R <= 65535, "ck_param_transpose_last2: R exceeds grid.z");
+  dim3 grid((Bd + 31) / 32, (A + 31) / 32, static_cast<unsigned>(R)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(transpose_last2_kernel, grid, block, 0, s, in, out, A, Bd, take_log);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_ll_sum(const float* ll, int64_t B, int64_t stride, double* out_dev, void* stream) {
+  CK_REQUIRE(ll && out_dev, "ck_ll_sum: null pointer");
+  CK_REQUIRE(B > 0 && stride > 0, "ck_ll_sum: non-positive size");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(ll_sum_kernel, dim3(1), dim3(1024), 0, s, ll, B, stride, out_dev);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+}  // extern "C"

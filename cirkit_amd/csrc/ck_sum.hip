@@ -1,0 +1,469 @@
+// Sum-type inner layers fused with the log-sum-exp semiring reduction:
+//   TorchSumLayer (dense / general arity), TorchCPTLayer (Hadamard -> dense), mixing layers,
+//   TorchTensorDotLayer; real (lse-sum) and complex (complex-lse-sum).
+//
+// Numerics follow LSESumSemiring.apply_reduce (cirkit/backend/torch/semiring.py:383-408):
+//   m = clamp(max_i v_i) over the INPUTS only, y_o = sum_i W[o,i] * exp(v_i - m) in linear space,
+//   out_o = log(y_o) + m.
+//
+// Two real-valued implementations:
+//   * `sum_lse_mfma`  -- Ki, Ko in {32, 64}: one wavefront owns 32 batch rows of one fold and
+//     evaluates the 32xKi . KixKo contraction with v_mfma_f32_32x32x2_f32 (exact fp32, an fmaf
+//     chain).  The lane layout is chosen so that (a) the row maximum needs a single cross-lane
+//     exchange, (b) inputs are read and outputs written as float4, and (c) the OUTPUT register
+//     layout equals the INPUT register layout of the next layer (what cross-layer fusion needs).
+//   * `sum_lse_generic` -- any shape; LDS-staged exp(v - m) rows and W chunks.
+#include <algorithm>
+
+#include "ck_internal.h"
+
+namespace {
+
+using ck::c32;
+
+// ------------------------------------------------------------------------------------------------
+// MFMA path
+// ------------------------------------------------------------------------------------------------
+// Lane l of a wave: b = l & 31 (batch row inside the 32-row tile), kh = l >> 5.
+// Unit ownership: lane (b, kh) holds, for every 32-unit block q, units 32q + 8g + 4kh + t
+// (g, t in 0..3) in register j = 4g + t  -> four float4 per block at float offset 32q + 8g + 4kh.
+//
+// v_mfma_f32_32x32x2_f32 computes D[i][j] += A[i][k] B[k][j], k in {0,1}, with
+//   A: lane l supplies A[i = l&31][k = l>>5],  B: lane l supplies B[k = l>>5][j = l&31],
+//   D: lane l holds D[i = (r&3) + 8(r>>2) + 4(l>>5)][j = l&31] in accumulator register r.
+// We put the WEIGHTS in A (i = output unit) and the ACTIVATIONS in B (j = batch row): step
+// s = 4g+t of block q contracts units {32q+8g+t (kh=0), 32q+8g+4+t (kh=1)} -- exactly what lane
+// (., kh) holds in register (q, s) for both operands.  The result D[o][b] lands in lane
+// (b, hi) register r with o = 8(r>>2) + 4hi + (r&3): the same ownership as the inputs.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NKI, int NKO, int MODE>
+__global__ void __launch_bounds__(256)
+    sum_lse_mfma(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
+                 const float* __restrict__ w, float* __restrict__ out, int H, int B,
+                 int tiles_per_wave) {
+  constexpr int KI = 32 * NKI, KO = 32 * NKO;
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int waves_per_block = blockDim.x >> 6;
+
+  // Weights of this fold in A-operand layout: wa[p][q][j] = W[32p + b_in][32q + 8g + 4kh + t]
+  float wa[NKO][NKI][16];
+  const float* wf = w + static_cast<int64_t>(f) * KO * KI;
+#pragma unroll
+  for (int p = 0; p < NKO; ++p)
+#pragma unroll
+    for (int q = 0; q < NKI; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 t4 = *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(32 * p + b_in) * KI +
+                                                           32 * q + 8 * g + 4 * kh);
+        wa[p][q][4 * g + 0] = t4.x;
+        wa[p][q][4 * g + 1] = t4.y;
+        wa[p][q][4 * g + 2] = t4.z;
+        wa[p][q][4 * g + 3] = t4.w;
+      }
+
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int tile0 = (blockIdx.x * waves_per_block + wave) * tiles_per_wave;
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+    const int b0 = (tile0 + tt) * 32;
+    if (b0 >= B) break;
+    const int b = b0 + b_in;
+    const bool live = b < B;
+    const int bl = live ? b : B - 1;  // clamp loads; stores are masked
+
+    float v[NKI][16];
+#pragma unroll
+    for (int q = 0; q < NKI; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[q][j] = 0.f;
+    // MODE PROD: sum the H children elementwise (semiring.prod, semiring.py:375-376)
+    // MODE CAT with H == 1 is the same code path (dense layer).
+    for (int h = 0; h < H; ++h) {
+      const float* src = arena + ro[h] + static_cast<int64_t>(bl) * KI + 4 * kh;
+#pragma unroll
+      for (int q = 0; q < NKI; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 t4 = *reinterpret_cast<const float4*>(src + 32 * q + 8 * g);
+          v[q][4 * g + 0] += t4.x;
+          v[q][4 * g + 1] += t4.y;
+          v[q][4 * g + 2] += t4.z;
+          v[q][4 * g + 3] += t4.w;
+        }
+    }
+    float m = v[0][0];
+#pragma unroll
+    for (int q = 0; q < NKI; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) m = fmaxf(m, v[q][j]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = ck::clamp_finite(m);
+#pragma unroll
+    for (int q = 0; q < NKI; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[q][j] = __expf(v[q][j] - m);
+
+    float* dst = out + (static_cast<int64_t>(f) * B + bl) * KO + 4 * kh;
+#pragma unroll
+    for (int p = 0; p < NKO; ++p) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NKI; ++q)
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[p][q][s], v[q][s], acc, 0, 0, 0);
+      if (live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 o4;
+          o4.x = __logf(acc[4 * g + 0]) + m;
+          o4.y = __logf(acc[4 * g + 1]) + m;
+          o4.z = __logf(acc[4 * g + 2]) + m;
+          o4.w = __logf(acc[4 * g + 3]) + m;
+          *reinterpret_cast<float4*>(dst + 32 * p + 8 * g) = o4;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic path (any H, Ki, Ko; real or complex activations; real or complex weights)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Num;
+template <>
+struct Num<float> {
+  static __device__ __forceinline__ float zero() { return 0.f; }
+  static __device__ __forceinline__ float re(float a) { return a; }
+  static __device__ __forceinline__ float add(float a, float b) { return a + b; }
+  static __device__ __forceinline__ float exp_shift(float a, float m) { return __expf(a - m); }
+  static __device__ __forceinline__ float log_shift(float a, float m) { return __logf(a) + m; }
+};
+template <>
+struct Num<c32> {
+  static __device__ __forceinline__ c32 zero() { return {0.f, 0.f}; }
+  static __device__ __forceinline__ float re(c32 a) { return a.re; }
+  static __device__ __forceinline__ c32 add(c32 a, c32 b) { return ck::c_add(a, b); }
+  static __device__ __forceinline__ c32 exp_shift(c32 a, float m) { return ck::c_exp_shift(a, m); }
+  static __device__ __forceinline__ c32 log_shift(c32 a, float m) { return ck::c_log_shift(a, m); }
+};
+__device__ __forceinline__ float fma_w(float w, float e, float acc) { return fmaf(w, e, acc); }
+__device__ __forceinline__ c32 fma_w(float w, c32 e, c32 acc) {
+  return {fmaf(w, e.re, acc.re), fmaf(w, e.im, acc.im)};
+}
+__device__ __forceinline__ c32 fma_w(c32 w, c32 e, c32 acc) {
+  return {fmaf(w.re, e.re, fmaf(-w.im, e.im, acc.re)), fmaf(w.re, e.im, fmaf(w.im, e.re, acc.im))};
+}
+
+constexpr int kGenNC = 32;  // W chunk width staged in LDS
+constexpr int kGenOT = 64;  // output units per pass
+
+// AT: activation type (float | c32), WT: weight type (float | c32).  RPT: rows per thread.
+// Block = 256 threads = 64 output lanes x 4 row groups; tile = 4*RPT batch rows of one fold.
+template <typename AT, typename WT, int RPT>
+__global__ void __launch_bounds__(256)
+    sum_lse_generic(const AT* __restrict__ arena, const int64_t* __restrict__ row_off,
+                    const WT* __restrict__ w, AT* __restrict__ out, int H, int B, int Ki, int Ko,
+                    int mode) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TB = 4 * RPT;
+  const int N = mode == CK_SUM_PROD ? Ki : H * Ki;
+  AT* e_s = reinterpret_cast<AT*>(smem);                          // [TB][N]
+  WT* w_s = reinterpret_cast<WT*>(e_s + static_cast<size_t>(TB) * N);  // [kGenOT][kGenNC+1]
+  float* m_s = reinterpret_cast<float*>(w_s + kGenOT * (kGenNC + 1));  // [TB]
+
+  const int f = blockIdx.y;
+  const int b0 = blockIdx.x * TB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+
+  // phase A: gather v (cat or product of children), row maximum, e = exp(v - m) into LDS
+  for (int r = wave; r < TB; r += 4) {
+    const int b = min(b0 + r, B - 1);
+    float mx = -INFINITY;
+    for (int n = lane; n < N; n += 64) {
+      AT v;
+      if (mode == CK_SUM_PROD) {
+        v = arena[ro[0] + static_cast<int64_t>(b) * Ki + n];
+        for (int h = 1; h < H; ++h) v = Num<AT>::add(v, arena[ro[h] + static_cast<int64_t>(b) * Ki + n]);
+      } else {
+        const int h = n / Ki, k = n - h * Ki;
+        v = arena[ro[h] + static_cast<int64_t>(b) * Ki + k];
+      }
+      e_s[static_cast<size_t>(r) * N + n] = v;
+      mx = fmaxf(mx, Num<AT>::re(v));
+    }
+    mx = ck::clamp_finite(ck::wave_max(mx));
+    for (int n = lane; n < N; n += 64)
+      e_s[static_cast<size_t>(r) * N + n] = Num<AT>::exp_shift(e_s[static_cast<size_t>(r) * N + n], mx);
+    if (lane == 0) m_s[r] = mx;
+  }
+  __syncthreads();
+
+  // phase B: y[r][o] = sum_n W[o][n] e[r][n]
+  const int o_l = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const WT* wf = w + static_cast<int64_t>(f) * Ko * N;
+  for (int o_base = 0; o_base < Ko; o_base += kGenOT) {
+    AT acc[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) acc[j] = Num<AT>::zero();
+    for (int n0 = 0; n0 < N; n0 += kGenNC) {
+      // stage W[o_base .. +64][n0 .. +32] (coalesced along n)
+      for (int i = threadIdx.x; i < kGenOT * kGenNC; i += 256) {
+        const int oo = i / kGenNC, nn = i - oo * kGenNC;
+        WT val{};
+        if (o_base + oo < Ko && n0 + nn < N) val = wf[static_cast<int64_t>(o_base + oo) * N + n0 + nn];
+        w_s[oo * (kGenNC + 1) + nn] = val;
+      }
+      __syncthreads();
+      const int nmax = min(kGenNC, N - n0);
+      for (int nn = 0; nn < nmax; ++nn) {
+        const WT wv = w_s[o_l * (kGenNC + 1) + nn];
+#pragma unroll
+        for (int j = 0; j < RPT; ++j)
+          acc[j] = fma_w(wv, e_s[static_cast<size_t>(rg * RPT + j) * N + n0 + nn], acc[j]);
+      }
+      __syncthreads();
+    }
+    if (o_base + o_l < Ko) {
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        const int r = rg * RPT + j, b = b0 + r;
+        if (b < B)
+          out[(static_cast<int64_t>(f) * B + b) * Ko + o_base + o_l] = Num<AT>::log_shift(acc[j], m_s[r]);
+      }
+    }
+  }
+}
+
+template <typename AT, typename WT>
+int launch_generic(const AT* arena, const int64_t* row_off, const WT* w, AT* out, int F, int H,
+                   int B, int Ki, int Ko, int mode, void* stream) {
+  const int N = mode == CK_SUM_PROD ? Ki : H * Ki;
+  auto lds_bytes = [&](int tb) {
+    return static_cast<size_t>(tb) * N * sizeof(AT) + kGenOT * (kGenNC + 1) * sizeof(WT) + tb * sizeof(float);
+  };
+  int rpt = 4;
+  while (rpt > 1 && lds_bytes(4 * rpt) > 64 * 1024) rpt >>= 1;
+  const size_t lds = lds_bytes(4 * rpt);
+  if (lds > 160 * 1024)
+    return ck::fail(CK_ERR_UNSUPPORTED, "ck_sum_lse_fwd: N=%d inputs per row do not fit in LDS", N);
+  const int tb = 4 * rpt;
+  dim3 grid((B + tb - 1) / tb, F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        auto go = [&](auto kern) {
+          if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+          }
+          hipLaunchKernelGGL(kern, grid, block, lds, s, arena, row_off, w, out, H, B, Ki, Ko, mode);
+          return hipGetLastError();
+        };
+        if (rpt == 4) return go(sum_lse_generic<AT, WT, 4>);
+        if (rpt == 2) return go(sum_lse_generic<AT, WT, 2>);
+        return go(sum_lse_generic<AT, WT, 1>);
+      },
+      stream);
+}
+
+int check_sum_args(const void* arena, const void* row_off, const void* w, const void* out, int F,
+                   int H, int B, int Ki, int Ko, int mode, const char* who) {
+  CK_REQUIRE(arena && row_off && w && out, "%s: null pointer", who);
+  CK_REQUIRE(F > 0 && H > 0 && B > 0 && Ki > 0 && Ko > 0, "%s: non-positive size F=%d H=%d B=%d Ki=%d Ko=%d",
+             who, F, H, B, Ki, Ko);
+  CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD, "%s: unknown mode %d", who, mode);
+  CK_REQUIRE(F <= 65535, "%s: F=%d exceeds grid.y", who, F);
+  return CK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mixing layer: out[k] = log(sum_h mw[k,h] exp(x[h,k] - m)) + m, m over all (h,k)
+// ------------------------------------------------------------------------------------------------
+// One wave per batch row; lanes stride over k.  Two passes over the H*K inputs (the second one
+// hits L1/L2).
+__global__ void __launch_bounds__(256)
+    mixing_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
+                      const float* __restrict__ mw, float* __restrict__ out, int H, int B, int K,
+                      int rows_per_block) {
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const float* mwf = mw + static_cast<int64_t>(f) * K * H;
+  const int b_begin = blockIdx.x * rows_per_block;
+  const int b_end = min(B, b_begin + rows_per_block);
+  for (int b = b_begin + wave; b < b_end; b += 4) {
+    float mx = -INFINITY;
+    for (int h = 0; h < H; ++h) {
+      const float* src = arena + ro[h] + static_cast<int64_t>(b) * K;
+      for (int k = lane; k < K; k += 64) mx = fmaxf(mx, src[k]);
+    }
+    mx = ck::clamp_finite(ck::wave_max(mx));
+    for (int k = lane; k < K; k += 64) {
+      float acc = 0.f;
+      for (int h = 0; h < H; ++h)
+        acc = fmaf(mwf[static_cast<int64_t>(k) * H + h], __expf(arena[ro[h] + static_cast<int64_t>(b) * K + k] - mx), acc);
+      out[(static_cast<int64_t>(f) * B + b) * K + k] = __logf(acc) + mx;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TensorDot: x (B, Kj*Kq) viewed (Kj, Kq); for each q: m_q = max_j x[j,q];
+//   out[q*Kk + k] = log(sum_j W[k,j] exp(x[j,q] - m_q)) + m_q
+// ------------------------------------------------------------------------------------------------
+// One workgroup per (fold, batch row): e[q][j] staged in LDS (transposed), W[k][j] in LDS;
+// thread t -> outputs (q, k) strided.  Kj, Kk are small (the rank K of the squared circuit).
+template <typename AT, typename WT>
+__global__ void __launch_bounds__(256)
+    tensordot_lse_kernel(const AT* __restrict__ arena, const int64_t* __restrict__ row_off,
+                         const WT* __restrict__ w, AT* __restrict__ out, int B, int Kj, int Kq,
+                         int Kk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  AT* e_s = reinterpret_cast<AT*>(smem);                                 // [Kq][Kj+1]
+  WT* w_s = reinterpret_cast<WT*>(e_s + static_cast<size_t>(Kq) * (Kj + 1));  // [Kk][Kj+1]
+  float* m_s = reinterpret_cast<float*>(w_s + static_cast<size_t>(Kk) * (Kj + 1));  // [Kq]
+  const int f = blockIdx.y, b = blockIdx.x;
+  const AT* src = arena + row_off[f] + static_cast<int64_t>(b) * Kj * Kq;
+  const WT* wf = w + static_cast<int64_t>(f) * Kk * Kj;
+  for (int i = threadIdx.x; i < Kk * Kj; i += blockDim.x) {
+    const int k = i / Kj, j = i - k * Kj;
+    w_s[k * (Kj + 1) + j] = wf[i];
+  }
+  for (int i = threadIdx.x; i < Kj * Kq; i += blockDim.x) {  // coalesced read of x[j][q]
+    const int j = i / Kq, q = i - j * Kq;
+    e_s[q * (Kj + 1) + j] = src[i];
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < Kq; q += blockDim.x) {
+    float mx = -INFINITY;
+    for (int j = 0; j < Kj; ++j) mx = fmaxf(mx, Num<AT>::re(e_s[q * (Kj + 1) + j]));
+    m_s[q] = ck::clamp_finite(mx);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Kj * Kq; i += blockDim.x) {
+    const int q = i / Kj, j = i - q * Kj;
+    e_s[q * (Kj + 1) + j] = Num<AT>::exp_shift(e_s[q * (Kj + 1) + j], m_s[q]);
+  }
+  __syncthreads();
+  AT* dst = out + (static_cast<int64_t>(f) * B + b) * Kq * Kk;
+  for (int i = threadIdx.x; i < Kq * Kk; i += blockDim.x) {
+    const int q = i / Kk, k = i - q * Kk;
+    AT acc = Num<AT>::zero();
+    for (int j = 0; j < Kj; ++j) acc = fma_w(w_s[k * (Kj + 1) + j], e_s[q * (Kj + 1) + j], acc);
+    dst[i] = Num<AT>::log_shift(acc, m_s[q]);
+  }
+}
+
+template <typename AT, typename WT>
+int launch_tensordot(const AT* arena, const int64_t* row_off, const WT* w, AT* out, int F, int B,
+                     int Kj, int Kq, int Kk, void* stream, const char* who) {
+  CK_REQUIRE(arena && row_off && w && out, "%s: null pointer", who);
+  CK_REQUIRE(F > 0 && B > 0 && Kj > 0 && Kq > 0 && Kk > 0, "%s: non-positive size", who);
+  CK_REQUIRE(F <= 65535, "%s: F=%d exceeds grid.y", who, F);
+  const size_t lds = static_cast<size_t>(Kq) * (Kj + 1) * sizeof(AT) + static_cast<size_t>(Kk) * (Kj + 1) * sizeof(WT) +
+                     static_cast<size_t>(Kq) * sizeof(float);
+  if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "%s: Kj*Kq=%d does not fit in LDS", who, Kj * Kq);
+  dim3 grid(B, F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        auto kern = tensordot_lse_kernel<AT, WT>;
+        if (lds > 48 * 1024) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+          if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, block, lds, s, arena, row_off, w, out, B, Kj, Kq, Kk);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+bool g_force_generic = false;
+
+}  // namespace
+
+extern "C" {
+
+// Test hook: route every ck_sum_lse_fwd call through the generic kernel (A/B the MFMA path).
+int ck_debug_force_generic(int on) {
+  g_force_generic = on != 0;
+  return CK_OK;
+}
+
+int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
+                   int H, int B, int Ki, int Ko, int mode, void* stream) {
+  if (int st = check_sum_args(arena, row_off, w, out, F, H, B, Ki, Ko, mode, "ck_sum_lse_fwd")) return st;
+  const bool prod_like = mode == CK_SUM_PROD || H == 1;
+  const bool mfma_ok = !g_force_generic && prod_like && Ki == Ko && (Ki == 32 || Ki == 64) &&
+                       ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out);
+  if (mfma_ok) {
+    // 4 waves per workgroup, each wave `tpw` 32-row tiles of the same fold (weights stay in
+    // registers across tiles).  Keep >= ~8 workgroups per CU in flight when the layer allows it.
+    const int tiles = (B + 31) / 32;
+    int tpw = 1;
+    while (tpw < 4 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
+    dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
+    const bool k32 = Ki == 32;
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          if (k32)
+            hipLaunchKernelGGL((sum_lse_mfma<1, 1, CK_SUM_PROD>), grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
+          else
+            hipLaunchKernelGGL((sum_lse_mfma<2, 2, CK_SUM_PROD>), grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
+          return hipGetLastError();
+        },
+        stream);
+  }
+  return launch_generic<float, float>(arena, row_off, w, out, F, H, B, Ki, Ko, mode, stream);
+}
+
+int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w, float* out_c,
+                     int F, int H, int B, int Ki, int Ko, int mode, int w_is_complex, void* stream) {
+  if (int st = check_sum_args(arena_c, row_off, w, out_c, F, H, B, Ki, Ko, mode, "ck_sum_lse_fwd_c")) return st;
+  const c32* a = reinterpret_cast<const c32*>(arena_c);
+  c32* o = reinterpret_cast<c32*>(out_c);
+  if (w_is_complex)
+    return launch_generic<c32, c32>(a, row_off, reinterpret_cast<const c32*>(w), o, F, H, B, Ki, Ko, mode, stream);
+  return launch_generic<c32, float>(a, row_off, w, o, F, H, B, Ki, Ko, mode, stream);
+}
+
+int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* mw, float* out,
+                      int F, int H, int B, int K, void* stream) {
+  CK_REQUIRE(arena && row_off && mw && out, "ck_mixing_lse_fwd: null pointer");
+  CK_REQUIRE(F > 0 && H > 0 && B > 0 && K > 0, "ck_mixing_lse_fwd: non-positive size");
+  CK_REQUIRE(F <= 65535, "ck_mixing_lse_fwd: F=%d exceeds grid.y", F);
+  const int rows_per_block = 32;
+  dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(mixing_lse_kernel, grid, block, 0, s, arena, row_off, mw, out, H, B, K, rows_per_block);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_tensordot_lse_fwd(const float* arena, const int64_t* row_off, const float* w, float* out,
+                         int F, int B, int Kj, int Kq, int Kk, void* stream) {
+  return launch_tensordot<float, float>(arena, row_off, w, out, F, B, Kj, Kq, Kk, stream, "ck_tensordot_lse_fwd");
+}
+
+int ck_tensordot_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w,
+                           float* out_c, int F, int B, int Kj, int Kq, int Kk, int w_is_complex,
+                           void* stream) {
+  const c32* a = reinterpret_cast<const c32*>(arena_c);
+  c32* o = reinterpret_cast<c32*>(out_c);
+  if (w_is_complex)
+    return launch_tensordot<c32, c32>(a, row_off, reinterpret_cast<const c32*>(w), o, F, B, Kj, Kq, Kk, stream,
+                                      "ck_tensordot_lse_fwd_c");
+  return launch_tensordot<c32, float>(a, row_off, w, o, F, B, Kj, Kq, Kk, stream, "ck_tensordot_lse_fwd_c");
+}
+
+}  // extern "C"

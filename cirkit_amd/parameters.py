@@ -1,0 +1,273 @@
+"""Device-side evaluation of layer parameter graphs.
+
+Host mirror of ``cirkit.backend.torch.parameters`` for the nodes on the hot path (SURVEY.md
+section 8 a13): the same node vocabulary (tensor, pointer, softmax, scaled_sigmoid, mixing_weight,
+conj, matmul, einsum, flatten ...) evaluated with the ``ck_param_*`` HIP kernels on fold-stacked
+blocks.  torch tensors are used as device storage only.
+
+Reference: ``TorchParameter.forward`` cirkit/backend/torch/parameters/parameter.py:180-188, node
+forwards in parameters/nodes.py (line numbers cited per op below).
+"""
+
+from __future__ import annotations
+
+from typing import Mapping
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from .plan import IDX_ARRAY, IDX_NONE, FoldIndex, ParamGraph, resolve_fold_index
+
+
+def _ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()
+
+
+class TensorStore:
+    """Named parameter tensors on one device -- the counterpart of the ``nn.Parameter`` owned by
+    ``TorchTensorParameter`` (nodes.py:188-201).  In-place updates are seen by the next forward;
+    replacing a tensor object requires re-binding the circuits that use it (`version` bumps)."""
+
+    def __init__(self, device: torch.device | str):
+        self.device = torch.device(device)
+        self._t: dict[str, torch.Tensor] = {}
+        self.version = 0
+
+    def set(self, name: str, value) -> None:
+        if isinstance(value, np.ndarray):
+            value = torch.from_numpy(np.ascontiguousarray(value))
+        value = value.detach()
+        if value.dtype not in (torch.float32, torch.complex64):
+            value = value.to(torch.complex64 if value.is_complex() else torch.float32)
+        cur = self._t.get(name)
+        if cur is not None and cur.shape == value.shape and cur.dtype == value.dtype:
+            cur.copy_(value)  # keep the pointer recorded programs hold
+            return
+        self._t[name] = value.to(self.device).contiguous()
+        self.version += 1
+
+    def update(self, values: Mapping[str, object]) -> None:
+        for k, v in values.items():
+            self.set(k, v)
+
+    def __getitem__(self, name: str) -> torch.Tensor:
+        return self._t[name]
+
+    def __contains__(self, name: str) -> bool:
+        return name in self._t
+
+    def names(self) -> list[str]:
+        return list(self._t)
+
+
+def _einsum_as_bmm(einsum, shapes):
+    """Map a two-operand einsum over per-fold matrices onto ck_param_bmm; returns
+    (swap, M, N, Kd, trans_a, trans_b) or None."""
+    if len(einsum) != 3 or any(len(e) != 2 for e in einsum):
+        return None
+    a, b, o = (tuple(e) for e in einsum)
+    for swap in (False, True):
+        x, y = (b, a) if swap else (a, b)
+        sx, sy = (shapes[1], shapes[0]) if swap else (shapes[0], shapes[1])
+        m, n = o
+        if m in x and n in y:
+            kx = [i for i in x if i != m]
+            ky = [i for i in y if i != n]
+            if len(kx) == 1 and kx == ky and kx[0] not in o:
+                trans_a = 0 if x.index(m) == 0 else 1
+                trans_b = 0 if y.index(n) == 1 else 1
+                M = sx[x.index(m)]
+                N = sy[y.index(n)]
+                Kd = sx[x.index(kx[0])]
+                return swap, M, N, Kd, trans_a, trans_b
+    return None
+
+
+class HipParameter:
+    """A parameter graph bound to a TensorStore.  ``evaluate()`` enqueues the kernels that
+    recompute it (as the reference does on every forward) and returns the device tensor
+    ``(F, *shape)``; buffers are allocated once so recorded programs can replay the launches."""
+
+    def __init__(self, graph: ParamGraph, store: TensorStore):
+        self.graph = graph
+        self.store = store
+        self._bufs: dict[object, torch.Tensor] = {}
+        self._idx: dict[object, torch.Tensor] = {}
+
+    # -- surface mirrored from TorchParameter -------------------------------------------------
+    @property
+    def num_folds(self) -> int:
+        return self.graph.num_folds
+
+    @property
+    def shape(self) -> tuple[int, ...]:
+        return self.graph.shape
+
+    @property
+    def ops(self) -> list[str]:
+        return self.graph.ops
+
+    def __call__(self) -> torch.Tensor:
+        return self.evaluate()
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _buf(self, key, shape, dtype=torch.float32) -> torch.Tensor:
+        t = self._bufs.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(tuple(shape), dtype=dtype, device=self.store.device)
+            self._bufs[key] = t
+        return t
+
+    def _index_tensor(self, key, arr: np.ndarray) -> torch.Tensor:
+        t = self._idx.get(key)
+        if t is None:
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(self.store.device)
+            self._idx[key] = t
+        return t
+
+    def _gather(self, key, src: torch.Tensor, idx: np.ndarray, stream: int) -> torch.Tensor:
+        per_fold = int(np.prod(src.shape[1:])) * (2 if src.is_complex() else 1)
+        out = self._buf(("g", key), (len(idx), *src.shape[1:]), src.dtype)
+        capi.call(
+            "ck_param_gather_folds",
+            _ptr(src),
+            _ptr(self._index_tensor(("gi", key), idx)),
+            _ptr(out),
+            len(idx),
+            per_fold,
+            stream,
+        )
+        return out
+
+    def _select(self, key, outs: list[torch.Tensor], fi: FoldIndex, stream: int) -> torch.Tensor:
+        """parameter.py:41-47: cat the producers along folds, then index."""
+        if len(fi.ids) == 1:
+            src = outs[fi.ids[0]]
+            if fi.kind == IDX_NONE:
+                return src
+            assert fi.kind == IDX_ARRAY
+            idx = np.asarray(fi.array, dtype=np.int64).reshape(-1)
+            if np.array_equal(idx, np.arange(src.shape[0])):
+                return src
+            return self._gather(key, src, idx, stream)
+        # several producers: gather each producer's rows into the concatenation, then index it
+        folds = {i: outs[i].shape[0] for i in fi.ids}
+        pairs = resolve_fold_index(fi, [folds.get(i, 0) for i in range(max(fi.ids) + 1)])
+        pairs = pairs.reshape(-1, 2)
+        first = outs[fi.ids[0]]
+        cat = self._buf(("cat", key), (sum(folds.values()), *first.shape[1:]), first.dtype)
+        off = 0
+        for i in fi.ids:
+            n = folds[i]
+            per_fold = int(np.prod(first.shape[1:])) * (2 if first.is_complex() else 1)
+            capi.call(
+                "ck_param_gather_folds",
+                _ptr(outs[i]),
+                _ptr(self._index_tensor(("ci", key, i), np.arange(n))),
+                _ptr(cat[off : off + n]),
+                n,
+                per_fold,
+                stream,
+            )
+            off += n
+        if fi.kind == IDX_NONE:
+            return cat
+        return self._gather(key, cat, np.asarray(fi.array, dtype=np.int64).reshape(-1), stream)
+
+    # -- evaluation ----------------------------------------------------------------------------
+    def evaluate(self, stream: int = 0, *, upto: int | None = None) -> torch.Tensor:
+        """Enqueue the graph on `stream`.  With ``upto=j`` return the output of node j instead of
+        the graph output (used by layers that fuse the tail of the graph into their own kernel)."""
+        g = self.graph
+        outs: list[torch.Tensor] = []
+        last = len(g.nodes) - 1 if upto is None else upto
+        for j, n in enumerate(g.nodes[: last + 1]):
+            xs = [self._select((j, k), outs, fi, stream) for k, fi in enumerate(n.inputs)]
+            c = n.config
+            shape = (n.num_folds, *n.shape)
+            if n.op == "tensor":  # nodes.py:203-220
+                y = self.store[c["tensor"]]
+            elif n.op == "pointer":  # nodes.py:277-279
+                y = self.store[c["tensor"]]
+                if c.get("fold_idx") is not None:
+                    y = self._gather(("p", j), y, np.asarray(c["fold_idx"], dtype=np.int64), stream)
+            elif n.op in ("softmax", "log_softmax"):  # nodes.py:764-783
+                x = xs[0]
+                if x.is_complex():
+                    raise NotImplementedError("softmax of a complex parameter")
+                dim = int(c["dim"]) + 1
+                outer = int(np.prod(x.shape[:dim]))
+                inner = int(np.prod(x.shape[dim + 1 :]))
+                y = self._buf(j, shape)
+                capi.call(
+                    "ck_param_softmax", _ptr(x), _ptr(y), outer, int(x.shape[dim]), inner,
+                    1 if n.op == "log_softmax" else 0, stream,
+                )
+            elif n.op in ("sigmoid", "scaled_sigmoid", "exp", "log", "square"):  # nodes.py:656-699
+                x = xs[0]
+                if x.is_complex():
+                    raise NotImplementedError(f"{n.op} of a complex parameter")
+                code = {
+                    "sigmoid": capi.CK_UNARY_SIGMOID,
+                    "scaled_sigmoid": capi.CK_UNARY_SCALED_SIGMOID,
+                    "exp": capi.CK_UNARY_EXP,
+                    "log": capi.CK_UNARY_LOG,
+                    "square": capi.CK_UNARY_SQUARE,
+                }[n.op]
+                y = self._buf(j, shape)
+                capi.call(
+                    "ck_param_unary", code, _ptr(x), _ptr(y), x.numel(),
+                    float(c.get("vmin", 0.0)), float(c.get("vmax", 1.0)), stream,
+                )
+            elif n.op == "conj":  # nodes.py:745-746
+                x = xs[0]
+                if x.is_complex():
+                    y = self._buf(j, shape, torch.complex64)
+                    capi.call("ck_param_conj", _ptr(x), _ptr(y), x.numel(), stream)
+                else:
+                    y = x  # conj of a real tensor is the tensor
+            elif n.op == "mixing_weight":  # nodes.py:857-862
+                x = xs[0]
+                F, K, H = x.shape
+                y = self._buf(j, (F, K, H * K))
+                capi.call("ck_param_mixing_weight", _ptr(x), _ptr(y), F, K, H, stream)
+            elif n.op == "matmul":  # nodes.py:802-805
+                a, b = xs
+                if a.is_complex() or b.is_complex():
+                    raise NotImplementedError("matmul of complex parameters")
+                F, M, Kd = a.shape
+                N = b.shape[2]
+                y = self._buf(j, (F, M, N))
+                capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), F, M, N, Kd, 0, 0, stream)
+            elif n.op == "einsum":  # optimized.py:282-284
+                if len(xs) != 2 or any(x.is_complex() for x in xs):
+                    raise NotImplementedError("einsum parameter beyond two real matrix operands")
+                m = _einsum_as_bmm(c["einsum"], [tuple(x.shape[1:]) for x in xs])
+                if m is None:
+                    raise NotImplementedError(f"einsum pattern {c['einsum']}")
+                swap, M, N, Kd, ta, tb = m
+                a, b = (xs[1], xs[0]) if swap else (xs[0], xs[1])
+                y = self._buf(j, (a.shape[0], M, N))
+                capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), a.shape[0], M, N, Kd, ta, tb, stream)
+            elif n.op == "flatten":  # nodes.py:843-844
+                y = xs[0].reshape(shape)
+            else:
+                raise NotImplementedError(f"parameter op {n.op}")
+            outs.append(y)
+        if upto is not None:
+            return outs[upto]
+        return self._select("out", outs, g.output, stream)
+
+    def tail_is(self, *ops: str) -> bool:
+        """True when the graph ends with `ops` feeding the output untouched (identity output index
+        over a single producer) -- lets a layer fuse the tail into its kernel."""
+        g = self.graph
+        if len(g.nodes) < len(ops) or [n.op for n in g.nodes[-len(ops) :]] != list(ops):
+            return False
+        if g.output.ids != [len(g.nodes) - 1]:
+            return False
+        if g.output.kind == IDX_NONE:
+            return True
+        idx = np.asarray(g.output.array).reshape(-1)
+        return np.array_equal(idx, np.arange(g.nodes[-1].num_folds))

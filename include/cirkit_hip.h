@@ -1,0 +1,185 @@
+/* cirkit_hip.h -- C ABI of the MI355X (gfx950) layer-evaluation backend for cirkit's folded
+ * log-space sum-product forward.
+ *
+ * cirkit has no FFI of its own: its "plugin/operator API" is Python (TorchLayer.forward and the
+ * parameter nodes).  Each entry point below therefore names the reference Python function it
+ * replaces (paths relative to the reference checkout); the Python shims in cirkit_amd/ bind them
+ * with ctypes (see INTEGRATION.md for the stub a cirkit maintainer would add).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into caller-owned storage (e.g. torch.Tensor.data_ptr());
+ *    the library never frees or retains it past the call (ck_program_* excepted: a program keeps
+ *    the pointers it was recorded with until ck_program_destroy);
+ *  - every call only ENQUEUES work on the given hipStream_t (passed as void*); no implicit sync;
+ *  - returns CK_OK (0) or a negative ck_status; ck_last_error() returns a thread-local message;
+ *  - no C++ exception crosses the ABI; no global mutable state besides a device-property cache;
+ *  - activations are fp32 (or interleaved complex64 for the *_c entry points), laid out
+ *    (F, B, K) row-major with K fastest -- the reference's layout;
+ *  - inner layers read their children from one activation ARENA through element offsets:
+ *    child h of fold f is the (B, Ki) block at arena + row_off[f*H + h]  (offsets in elements of
+ *    the activation type).  This replaces the materialising gather of LayerAddressBook.lookup,
+ *    cirkit/backend/torch/circuits.py:42-47.
+ */
+#ifndef CIRKIT_HIP_H
+#define CIRKIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ck_status {
+  CK_OK = 0,
+  CK_ERR_INVALID = -1,     /* bad shape / null pointer / misaligned buffer */
+  CK_ERR_UNSUPPORTED = -2, /* valid request outside what the kernels cover */
+  CK_ERR_HIP = -3,         /* a HIP runtime call failed (message has hipGetErrorString) */
+  CK_ERR_STATE = -4        /* program API misuse */
+} ck_status;
+
+/* modes of ck_sum_lse_fwd */
+#define CK_SUM_CAT 0  /* TorchSumLayer: children concatenated -> N = H*Ki inputs        */
+#define CK_SUM_PROD 1 /* TorchCPTLayer: children multiplied (log-space add) -> N = Ki   */
+
+/* unary parameter ops of ck_param_unary */
+#define CK_UNARY_SIGMOID 0
+#define CK_UNARY_SCALED_SIGMOID 1 /* sigmoid(x)*(b-a)+a ; nodes.py:698-699 */
+#define CK_UNARY_EXP 2
+#define CK_UNARY_LOG 3
+#define CK_UNARY_SQUARE 4
+
+const char* ck_last_error(void);
+/* ABI version; bumped on any signature change. */
+int ck_abi_version(void);
+/* Device facts used by the host for launch heuristics: out[0]=CU count, out[1]=LDS bytes/CU,
+ * out[2]=wavefront size, out[3]=gcnArch is gfx950 (1/0). */
+int ck_device_info(int device, int64_t out[4]);
+
+/* ---------------------------------------------------------------- input layers ------------- */
+
+/* (B, D) int64 -> (D, B) int32.  Stages the batch for the categorical/embedding gathers so that
+ * they read x contiguously along B.  Replaces the `in_graph[..., scope_idx].permute(1,0,2)` copy of
+ * circuits.py:66. */
+int ck_transpose_i64_to_i32(const int64_t* x, int32_t* xt, int B, int D, void* stream);
+/* (B, D) fp32 -> (D, B) fp32, same purpose for continuous inputs. */
+int ck_transpose_f32(const float* x, float* xt, int B, int D, void* stream);
+
+/* TorchCategoricalLayer.log_unnormalized_likelihood, layers/input.py:399-412.
+ * table: (F, C, K) log-probabilities / logits ALREADY transposed so a (f, c) row is contiguous
+ *        (built by ck_param_log_transpose or ck_param_transpose_last2);
+ * xt   : (D, B) int32 (see above); scope[f] = variable of fold f;  out: (F, B, K). */
+int ck_categorical_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out,
+                       int F, int B, int K, int C, int D, void* stream);
+
+/* TorchGaussianLayer.log_unnormalized_likelihood, layers/input.py:661-670:
+ * out = -(x-mean)^2 / (2 stddev^2) - log(stddev) - log(sqrt(2 pi)) (+ log_partition).
+ * xt: (D, B) fp32 (ck_transpose_f32); mean/stddev/log_partition: (F, K); log_partition may be
+ * NULL. */
+int ck_gaussian_fwd(const float* mean, const float* stddev, const float* log_partition,
+                    const float* xt, const int64_t* scope, float* out, int F, int B, int K, int D,
+                    void* stream);
+
+/* TorchEmbeddingLayer.forward under complex-lse-sum, layers/input.py:258-266 + semiring.py:507-509:
+ * out[f,b,k] = clog(weight[f,k,x[b,scope[f]]] + 0j).  table: (F, C, K) fp32 (transposed weight). */
+int ck_embedding_clog_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out_c,
+                          int F, int B, int K, int C, int D, void* stream);
+/* same under lse-sum (semiring.py:495-497): out = log(weight[...]) */
+int ck_embedding_log_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out,
+                         int F, int B, int K, int C, int D, void* stream);
+
+/* TorchConstantValueLayer.forward, layers/input.py:739-743: broadcast value (F, K) over B.
+ * complex_out: activations are complex64; value_is_complex: `value` is complex64;
+ * log_space 0: apply the map from sum-product (log / clog), 1: value already in log space. */
+int ck_constant_fwd(const float* value, float* out, int F, int B, int K, int log_space,
+                    int value_is_complex, int complex_out, void* stream);
+
+/* ---------------------------------------------------------------- inner layers ------------- */
+
+/* TorchSumLayer.forward (inner.py:266-273, mode CK_SUM_CAT) and TorchCPTLayer.forward
+ * (optimized.py:171-178, mode CK_SUM_PROD) fused with LSESumSemiring.apply_reduce
+ * (semiring.py:383-408): v = cat_h/sum_h children; m = clamp(max v); out = log(W . exp(v - m)) + m.
+ * w: (F, Ko, N) linear-space weights, N = H*Ki (cat) or Ki (prod).  out: (F, B, Ko). */
+int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
+                   int H, int B, int Ki, int Ko, int mode, void* stream);
+/* Test hook: route ck_sum_lse_fwd through the shape-generic kernel even where the MFMA kernel
+ * applies (A/B parity of the two implementations). */
+int ck_debug_force_generic(int on);
+/* complex-lse-sum variant (semiring.py:441-476); w real (w_is_complex=0) or complex64. */
+int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w, float* out_c,
+                     int F, int H, int B, int Ki, int Ko, int mode, int w_is_complex, void* stream);
+
+/* Mixing layer = TorchSumLayer whose weight is TorchMixingWeightParameter (nodes.py:847-862):
+ * out[f,b,k] = log(sum_h mw[f,k,h] * exp(x[f,h,b,k] - m)) + m,  m = max over all (h,k) of the row.
+ * The (K, H*K) block-diagonal weight is never materialised.  mw: (F, K, H). */
+int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* mw, float* out,
+                      int F, int H, int B, int K, void* stream);
+
+/* TorchHadamardLayer.forward, inner.py:126-127 (lse: sum over the arity axis). esize = 1 (fp32)
+ * or 2 (complex64: K counts complex elements). */
+int ck_hadamard_fwd(const float* arena, const int64_t* row_off, float* out, int F, int H, int B,
+                    int K, int esize, void* stream);
+
+/* TorchKroneckerLayer.forward, inner.py:178-187, arity 2: out[f,b,i*K+j] = x0[f,b,i] + x1[f,b,j]. */
+int ck_kronecker_fwd(const float* arena, const int64_t* row_off, float* out, int F, int B, int K,
+                     int esize, void* stream);
+
+/* TorchTensorDotLayer.forward, optimized.py:287-300: x (F,B,Kj*Kq) viewed (Kj,Kq);
+ * out[f,b,q*Kk+k] = log(sum_j w[f,k,j] * exp(x[f,b,j,q] - m[f,b,q])) + m[f,b,q]. w: (F, Kk, Kj). */
+int ck_tensordot_lse_fwd(const float* arena, const int64_t* row_off, const float* w, float* out,
+                         int F, int B, int Kj, int Kq, int Kk, void* stream);
+int ck_tensordot_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w,
+                           float* out_c, int F, int B, int Kj, int Kq, int Kk, int w_is_complex,
+                           void* stream);
+
+/* ---------------------------------------------------------------- parameter graphs --------- */
+/* The reference re-evaluates each layer's parameter DAG on every forward
+ * (parameters/parameter.py:180-188); these kernels do the same on the fold-stacked blocks. */
+
+/* TorchSoftmaxParameter / TorchLogSoftmaxParameter (nodes.py:764-783) over the middle axis of an
+ * (outer, len, inner) view. */
+int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_t inner,
+                     int log_space, void* stream);
+/* entrywise ops (nodes.py:656-699); a, b only used by CK_UNARY_SCALED_SIGMOID (vmin, vmax). */
+int ck_param_unary(int op, const float* in, float* out, int64_t n, float a, float b, void* stream);
+/* out[f] = in[idx[f]] over blocks of `per_fold` 4-byte words (pointer fold_idx nodes.py:277-279,
+ * parameter address-book gathers parameter.py:41-47). */
+int ck_param_gather_folds(const float* in, const int64_t* idx, float* out, int64_t F_out,
+                          int64_t per_fold, void* stream);
+/* TorchConjugateParameter (nodes.py:745-746) on complex64 data (n complex elements). */
+int ck_param_conj(const float* in_c, float* out_c, int64_t n, void* stream);
+/* TorchMixingWeightParameter (nodes.py:857-862): (F,K,H) -> dense (F,K,H*K). Only needed when the
+ * mixing weight feeds another parameter op (e.g. MatMul after SumCollapse). */
+int ck_param_mixing_weight(const float* in, float* out, int F, int K, int H, void* stream);
+/* Batched matmul out[f] = op(a[f]) . op(b[f]): TorchMatMulParameter (nodes.py:802-805) and the
+ * two-operand TorchEinsumParameter patterns (optimized.py:282-284).  a: (F,M,Kd) or (F,Kd,M) if
+ * trans_a; b: (F,Kd,N) or (F,N,Kd) if trans_b; out: (F,M,N). */
+int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd,
+                 int trans_a, int trans_b, void* stream);
+/* (R, A, Bd) -> (R, Bd, A) transpose of the last two axes, optionally taking log first
+ * (categorical: log(probs) -> table (F, C, K), input.py:405-408). */
+int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int Bd, int take_log,
+                             void* stream);
+
+/* ---------------------------------------------------------------- reductions --------------- */
+/* Sum of B log-likelihoods (stride in floats between consecutive rows) into out_dev[0] (fp64) and
+ * the row count into out_dev[1]; the pair feeds the one RCCL all-reduce of the data-parallel NLL
+ * (notebooks/learning-a-circuit.ipynb cell 20: `circuit(batch).sum()`).  out_dev is overwritten. */
+int ck_ll_sum(const float* ll, int64_t B, int64_t stride, double* out_dev, void* stream);
+
+/* ---------------------------------------------------------------- program (launch list) ---- */
+/* A program records the exact sequence of the calls above for one (plan, batch size) and replays
+ * it with ONE host call -- the native replacement for the per-batch Python interpreter loop
+ * TorchDiAcyclicGraph.evaluate (graph/modules.py:303-335).  While recording, every ck_* call made
+ * on the recording thread is appended instead of launched.  With use_graph != 0 the first launch
+ * captures the sequence into a hipGraph and later launches replay the instantiated graph. */
+typedef struct ck_program ck_program;
+int ck_program_begin(ck_program** out);
+int ck_program_end(ck_program* prog);
+int ck_program_num_ops(const ck_program* prog);
+int ck_program_launch(ck_program* prog, int use_graph, void* stream);
+int ck_program_destroy(ck_program* prog);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIRKIT_HIP_H */
