@@ -24,6 +24,18 @@ _i = C.c_int
 _l = C.c_int64
 _f = C.c_float
 
+class SoftmaxJob(C.Structure):
+    _fields_ = [
+        ("inp", C.c_void_p),
+        ("out", C.c_void_p),
+        ("rows", C.c_int64),
+        ("len", C.c_int32),
+        ("k", C.c_int32),
+        ("kind", C.c_int32),
+        ("block_begin", C.c_int32),
+    ]
+
+
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
 SIGNATURES: dict[str, list[Any]] = {
     "ck_abi_version": [],
@@ -37,13 +49,16 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_constant_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_sum_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_debug_force_generic": [_i],
+    "ck_debug_ablate": [_i],
     "ck_sum_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_mixing_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_hadamard_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_kronecker_fwd": [_p, _p, _p, _i, _i, _i, _i, _p],
     "ck_tensordot_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_tensordot_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_subtree_cat_cpt_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _i, _i, _i, _i, _i, _p],
     "ck_param_softmax": [_p, _p, _l, _i, _l, _i, _p],
+    "ck_param_softmax_batch": [C.POINTER(SoftmaxJob), _i, _p],
     "ck_param_unary": [_i, _p, _p, _l, _f, _f, _p],
     "ck_param_gather_folds": [_p, _p, _p, _l, _l, _p],
     "ck_param_conj": [_p, _p, _l, _p],

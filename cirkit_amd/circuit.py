@@ -23,8 +23,9 @@ import numpy as np
 import torch
 
 from . import _capi as capi
+from .fusion import SubtreeGroup, find_subtree_groups
 from .layers import HipConstantValueLayer, HipInputLayer, HipLayer, layer_from_spec
-from .parameters import TensorStore
+from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
 
 _ALIGN = 64  # arena alignment of every layer block, in activation elements (>= 256 B)
@@ -57,8 +58,10 @@ class HipCircuit:
         tensors: parameter values by plan tensor name (numpy arrays or torch tensors).
         device: a ROCm device, e.g. ``"cuda:0"``.
         use_graph: replay each batch size's launch list as a hipGraph.
-        input_dtype: dtype of the batches (``torch.int64`` like the reference, or any integer /
-            float dtype; converted once on device).
+        fuse: cross-layer fusion of the leaf region (cirkit_amd/fusion.py); an int caps the number
+            of fused CP-T levels, False evaluates layer by layer (every layer output materialised).
+        batch_params: recompute all softmax parameters with one launch per forward
+            (`ck_param_softmax_batch`) instead of one launch per parameter node.
     """
 
     def __init__(
@@ -68,6 +71,8 @@ class HipCircuit:
         *,
         device: str | torch.device = "cuda:0",
         use_graph: bool = True,
+        fuse: bool | int = True,
+        batch_params: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -102,6 +107,16 @@ class HipCircuit:
         self._float_input = any(getattr(l, "wants_float_input", False) for l in self.layers)
         self._bindings: dict[int, _Binding] = {}
         self._side: torch.cuda.Stream | None = None  # graphs cannot be captured on the null stream
+        depth = 0 if fuse is False else (4 if fuse is True else int(fuse))
+        self._groups: list[SubtreeGroup] = (
+            find_subtree_groups(plan, self.layers, self._children, self._out_pairs, depth) if fuse is not False else []
+        )
+        self._group_of_root = {g.root: g for g in self._groups}
+        self._virtual = {i for g in self._groups for i in g.virtual}
+        self._group_dev: dict[int, tuple] = {}
+        self.batch_params = batch_params
+        self._batch: ParamBatch | None = None
+        self._batch_version = -1
 
     # -- reference surface -----------------------------------------------------------------------
     @property
@@ -136,19 +151,23 @@ class HipCircuit:
         bd.store_version = self.store.version
         # arena layout
         bases, total = [], 0
-        for l in self.layers:
+        for i, l in enumerate(self.layers):
             bases.append(total)
+            if i in self._virtual:  # fused away: never materialised
+                continue
             n = l.num_folds * B * l.num_output_units
             total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
         bd.arena = torch.empty(total, dtype=self._act_dtype, device=self.device)
         bd.views = [
-            bd.arena[b : b + l.num_folds * B * l.num_output_units].view(l.num_folds, B, l.num_output_units)
-            for b, l in zip(bases, self.layers)
+            None
+            if i in self._virtual
+            else bd.arena[b : b + l.num_folds * B * l.num_output_units].view(l.num_folds, B, l.num_output_units)
+            for i, (b, l) in enumerate(zip(bases, self.layers))
         ]
         # children offset tables: element offsets into the arena (replaces circuits.py:42-47)
         bd.row_off = []
-        for ch, l in zip(self._children, self.layers):
-            if ch is None:
+        for i, (ch, l) in enumerate(zip(self._children, self.layers)):
+            if ch is None or i in self._virtual or i in self._group_of_root:
                 bd.row_off.append(None)
                 continue
             prod, fold = ch[..., 0], ch[..., 1]
@@ -179,14 +198,47 @@ class HipCircuit:
         """One forward: per layer, parameter graph then the layer kernel (the order of
         graph/modules.py:326-334)."""
         B = bd.B
-        for l, view, ro in zip(self.layers, bd.views, bd.row_off):
-            l.prepare(stream)
-            if isinstance(l, HipConstantValueLayer):
+        self._launch_param_batch(stream)
+        for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
+            l.prepare(stream, batched=self.batch_params)
+            if i in self._virtual:
+                continue
+            if i in self._group_of_root:
+                self._launch_group(self._group_of_root[i], bd, view, stream)
+            elif isinstance(l, HipConstantValueLayer):
                 l.launch_const(view, B, stream)
             elif isinstance(l, HipInputLayer):
                 l.launch_input(bd.xt, self.plan.num_variables, view, B, stream)
             else:
                 l.launch(bd.arena, ro, view, B, stream)
+
+    def _launch_param_batch(self, stream: int) -> None:
+        if not self.batch_params:
+            return
+        if self._batch is None or self._batch_version != self.store.version:
+            self._batch = ParamBatch()
+            for l in self.layers:
+                l._batched = False
+                l.register_batched(self._batch)
+            self._batch_version = self.store.version
+        self._batch.launch(stream)
+
+    def _launch_group(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int) -> None:
+        """One fused launch for Categorical -> [dense] -> CP-T levels (cirkit_amd/csrc/ck_fused.hip)."""
+        dev = self._group_dev.get(g.root)
+        if dev is None:
+            dev = (torch.from_numpy(g.nodes).to(self.device),)
+            self._group_dev[g.root] = dev
+        cat = self.layers[g.input_layer]
+        w_dense = None if g.dense_layer is None else self.layers[g.dense_layer]._w
+        levels = (C.c_void_p * max(1, g.depth))(*[self.layers[j]._w.data_ptr() for j in g.levels])
+        node_off = (C.c_int32 * (g.depth + 1))(*g.node_off)
+        capi.call(
+            "ck_subtree_cat_cpt_fwd", cat._table.data_ptr(), bd.xt.data_ptr(), cat._scope(self.device).data_ptr(),
+            None if w_dense is None else w_dense.data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off,
+            out.data_ptr(), g.depth, self.layers[g.root].num_folds, bd.B, cat.num_output_units,
+            cat.num_categories, stream,
+        )
 
     # -- evaluation ------------------------------------------------------------------------------
     def _stage_input(self, bd: _Binding, x: torch.Tensor, stream: int) -> None:
@@ -256,7 +308,8 @@ class HipCircuit:
         return y
 
     def layer_outputs(self, x: torch.Tensor | None = None) -> list[torch.Tensor]:
-        """All ``(F, B, Ko)`` layer outputs of one forward (views of the arena) -- for parity tests."""
+        """All ``(F, B, Ko)`` layer outputs of one forward (views of the arena; None for layers that
+        cross-layer fusion never materialises) -- for parity tests."""
         return list(self._run(x).views)
 
     def log_likelihood_sum(self, x: torch.Tensor) -> torch.Tensor:
@@ -278,6 +331,9 @@ class HipCircuit:
     def kernel_label(self, i: int) -> str:
         """Name of the HIP kernel that evaluates layer i (as it appears in a rocprofv3 trace)."""
         l, s = self.layers[i], self.plan.layers[i]
+        if i in self._group_of_root:
+            g = self._group_of_root[i]
+            return f"subtree_cat_cpt_kernel<{g.depth}, {'true' if g.dense_layer is not None else 'false'}>"
         if s.type in ("categorical", "embedding"):
             return "gather_rows_vec" if l.num_output_units % 4 == 0 else "gather_rows_scalar"
         if s.type == "gaussian":
@@ -316,9 +372,15 @@ class HipCircuit:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e2 = torch.cuda.Event(enable_timing=True)
                 e0.record(cur)
-                l.prepare(stream)
+                if i == 0:
+                    self._launch_param_batch(stream)
+                l.prepare(stream, batched=self.batch_params)
                 e1.record(cur)
-                if isinstance(l, HipConstantValueLayer):
+                if i in self._virtual:
+                    pass
+                elif i in self._group_of_root:
+                    self._launch_group(self._group_of_root[i], bd, view, stream)
+                elif isinstance(l, HipConstantValueLayer):
                     l.launch_const(view, B, stream)
                 elif isinstance(l, HipInputLayer):
                     l.launch_input(bd.xt, self.plan.num_variables, view, B, stream)
@@ -331,6 +393,7 @@ class HipCircuit:
                 continue  # warm-up
             acc.append([t for e0, e1, e2 in evs for t in (e0.elapsed_time(e1), e1.elapsed_time(e2))])
         mean = np.mean(np.asarray(acc), axis=0)
+        layer_bytes: dict[int, float] = {}
         for i, (l, s) in enumerate(zip(self.layers, self.plan.layers)):
             pbytes = 0
             for pg in s.params.values():
@@ -349,8 +412,14 @@ class HipCircuit:
             else:
                 rd = 0
             wr = l.num_folds * B * l.num_output_units * esz
+            layer_bytes[i] = float(rd + wr)
+            if i in self._virtual:
+                continue
+            nbytes = layer_bytes[i]
+            if i in self._group_of_root:  # the fused launch does the work of every layer it replaces
+                nbytes += sum(layer_bytes[j] for j in self._group_of_root[i].virtual)
             rows.append({"layer": i, "kernel": self.kernel_label(i), "ms": float(mean[2 * i + 1]),
-                         "algorithmic_bytes": float(rd + wr)})
+                         "algorithmic_bytes": nbytes})
         return rows
 
     # -- accounting ------------------------------------------------------------------------------

@@ -163,6 +163,93 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- batched softmax prologue -------------------------------------------------------------------
+// All `tensor -> softmax(last axis)` parameters of a circuit in ONE launch (the reference spends one
+// ATen launch per node per layer, parameters/parameter.py:180-188).  kind 0: linear-space rows
+// (sum-layer weights).  kind 1: Categorical probs (F, K, C) -> log-probability table (F, C, K),
+// i.e. softmax + log (input.py:405-408) + the transpose the gather kernels want, through LDS.
+constexpr int kMaxJobs = 48;
+struct JobTable {
+  ck_softmax_job job[kMaxJobs];
+  int n;
+};
+
+__device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int blk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int len = j.len;
+  if (len <= 32) {
+    // two rows per wave pass (one per 32-lane half); 16 rows per workgroup pass, 64 rows per block
+    const int half = lane >> 5, l = lane & 31;
+    for (int it = 0; it < 8; ++it) {
+      const int64_t row = static_cast<int64_t>(blk) * 64 + it * 8 + wave * 2 + half;
+      const bool ok = row < j.rows && l < len;
+      const float x = ok ? j.in[row * len + l] : -INFINITY;
+      float mx = x;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float e = ok ? __expf(x - mx) : 0.f;
+      float sum = e;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (ok) j.out[row * len + l] = e / sum;
+    }
+  } else {
+    for (int it = 0; it < 16; ++it) {
+      const int64_t row = static_cast<int64_t>(blk) * 64 + it * 4 + wave;
+      if (row >= j.rows) break;
+      const float* src = j.in + row * len;
+      float mx = -INFINITY;
+      for (int i = lane; i < len; i += 64) mx = fmaxf(mx, src[i]);
+      mx = ck::wave_max(mx);
+      float sum = 0.f;
+      for (int i = lane; i < len; i += 64) sum += __expf(src[i] - mx);
+      sum = ck::wave_sum(sum);
+      for (int i = lane; i < len; i += 64) j.out[row * len + i] = __expf(src[i] - mx) / sum;
+    }
+  }
+}
+
+__device__ __forceinline__ void softmax_job_table(const ck_softmax_job& j, int f, float* tile) {
+  // tile[c][k], row stride K+1
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = j.len, K = j.k;
+  const float* src = j.in + static_cast<int64_t>(f) * K * C;
+  for (int k = wave; k < K; k += 4) {
+    const float* row = src + static_cast<int64_t>(k) * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+    mx = ck::wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += __expf(row[c] - mx);
+    sum = ck::wave_sum(sum);
+    const float ls = __logf(sum);
+    for (int c = lane; c < C; c += 64) {
+      const float d = row[c] - mx;
+      // log(exp(d)/sum); exp(d) underflows to 0 below ~-103.97 -> the reference yields log(0) = -inf
+      tile[c * (K + 1) + k] = d < -103.9f ? -INFINITY : d - ls;
+    }
+  }
+  __syncthreads();
+  float* dst = j.out + static_cast<int64_t>(f) * C * K;
+  for (int i = threadIdx.x; i < C * K; i += blockDim.x) {
+    const int c = i / K, k = i - c * K;
+    dst[i] = tile[c * (K + 1) + k];
+  }
+}
+
+__global__ void __launch_bounds__(256) softmax_batch_kernel(const JobTable t) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int bid = blockIdx.x;
+  int ji = 0;
+  while (ji + 1 < t.n && bid >= t.job[ji + 1].block_begin) ++ji;
+  const ck_softmax_job& j = t.job[ji];
+  const int blk = bid - j.block_begin;
+  if (j.kind == 0)
+    softmax_job_rows(j, blk);
+  else
+    softmax_job_table(j, blk, tile);
+}
+
 // ---- log-likelihood sum ------------------------------------------------------------------------
 // Single workgroup: B is a batch (<= a few 10^5 rows), and a one-block tree gives a
 // run-to-run deterministic fp64 sum (no atomics).
@@ -292,6 +379,47 @@ int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int 
         return hipGetLastError();
       },
       stream);
+}
+
+int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) {
+  CK_REQUIRE(jobs != nullptr && njobs > 0, "ck_param_softmax_batch: no jobs");
+  for (int start = 0; start < njobs; start += kMaxJobs) {
+    JobTable t{};
+    t.n = std::min(kMaxJobs, njobs - start);
+    int blocks = 0;
+    size_t lds = 0;
+    for (int i = 0; i < t.n; ++i) {
+      ck_softmax_job j = jobs[start + i];
+      CK_REQUIRE(j.in && j.out && j.rows > 0 && j.len > 0, "ck_param_softmax_batch: bad job %d", start + i);
+      CK_REQUIRE(j.kind == 0 || j.kind == 1, "ck_param_softmax_batch: job %d has unknown kind %d", start + i, j.kind);
+      j.block_begin = blocks;
+      if (j.kind == 0) {
+        blocks += static_cast<int>((j.rows + 63) / 64);
+      } else {
+        CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", start + i);
+        const size_t need = static_cast<size_t>(j.len) * (j.k + 1) * sizeof(float);
+        if (need > 64 * 1024)
+          return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
+        lds = std::max(lds, need);
+        blocks += static_cast<int>(j.rows);
+      }
+      t.job[i] = j;
+    }
+    const dim3 grid(blocks), block(256);
+    int st = ck::dispatch(
+        [=](hipStream_t s) {
+          if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_batch_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+          }
+          hipLaunchKernelGGL(softmax_batch_kernel, grid, block, lds, s, t);
+          return hipGetLastError();
+        },
+        stream);
+    if (st != CK_OK) return st;
+  }
+  return CK_OK;
 }
 
 int ck_ll_sum(const float* ll, int64_t B, int64_t stride, double* out_dev, void* stream) {

@@ -97,8 +97,16 @@ class HipLayer:
         return self.forward(*a, **k)
 
     # -- HIP side ----------------------------------------------------------------------------------
-    def prepare(self, stream: int) -> None:
-        """Enqueue the parameter-graph evaluation (and any layer-specific re-layout)."""
+    def prepare(self, stream: int, batched: bool = False) -> None:
+        """Enqueue the parameter-graph evaluation (and any layer-specific re-layout).  With
+        ``batched`` the caller has already launched the `ParamBatch` this layer registered in."""
+
+    def register_batched(self, batch) -> bool:
+        """Hand the layer's softmax parameters to a circuit-wide `ParamBatch`; returns True if the
+        layer needs no parameter work of its own afterwards."""
+        return False
+
+    _batched = False
 
     def _check_param(self, name: str, p: HipParameter, shape: tuple[int, ...]) -> None:
         if p.num_folds != self.num_folds or tuple(p.shape) != tuple(shape):
@@ -200,7 +208,19 @@ class HipCategoricalLayer(HipInputLayer):
     def params(self) -> Mapping[str, HipParameter]:
         return {"probs": self.probs} if self.logits is None else {"logits": self.logits}
 
-    def prepare(self, stream: int) -> None:
+    def register_batched(self, batch) -> bool:
+        src = None if self.probs is None else self.probs.softmax_source()
+        if src is None:
+            return False
+        F, K, C = src.shape
+        self._table = torch.empty((F, C, K), dtype=torch.float32, device=src.device)
+        batch.add_log_table(src, self._table)
+        self._batched = True
+        return True
+
+    def prepare(self, stream: int, batched: bool = False) -> None:
+        if batched and self._batched:
+            return
         # table (F, C, K) = transpose(log(probs())) | transpose(logits())  -- input.py:405-408
         p = self.probs if self.probs is not None else self.logits
         v = p.evaluate(stream)
@@ -254,7 +274,7 @@ class HipEmbeddingLayer(HipInputLayer):
     def params(self) -> Mapping[str, HipParameter]:
         return {"weight": self.weight}
 
-    def prepare(self, stream: int) -> None:
+    def prepare(self, stream: int, batched: bool = False) -> None:
         v = self.weight.evaluate(stream)
         if v.is_complex():
             raise NotImplementedError("complex embedding weights")
@@ -307,7 +327,7 @@ class HipGaussianLayer(HipInputLayer):
             p["log_partition"] = self.log_partition
         return p
 
-    def prepare(self, stream: int) -> None:
+    def prepare(self, stream: int, batched: bool = False) -> None:
         self._vals = (
             self.mean.evaluate(stream),
             self.stddev.evaluate(stream),
@@ -353,7 +373,7 @@ class HipConstantValueLayer(HipLayer):
     def params(self) -> Mapping[str, HipParameter]:
         return {"value": self.value}
 
-    def prepare(self, stream: int) -> None:
+    def prepare(self, stream: int, batched: bool = False) -> None:
         self._val = self.value.evaluate(stream)
 
     def launch_const(self, out: torch.Tensor, B: int, stream: int) -> None:
@@ -488,7 +508,18 @@ class HipSumLayer(HipInnerLayer):
         fi = g.nodes[-1].inputs[0]
         return fi.ids == [len(g.nodes) - 2] and fi.kind == "none" and self.num_input_units == self.num_output_units
 
-    def prepare(self, stream: int) -> None:
+    def register_batched(self, batch) -> bool:
+        src = None if (self._mixing or self.is_complex) else self.weight.softmax_source()
+        if src is None:
+            return False
+        self._w = torch.empty_like(src)
+        batch.add_softmax(src, self._w)
+        self._batched = True
+        return True
+
+    def prepare(self, stream: int, batched: bool = False) -> None:
+        if batched and self._batched:
+            return
         if self._mixing:
             self._w = self.weight.evaluate(stream, upto=len(self.weight.graph.nodes) - 2)  # (F, K, H)
         else:
@@ -564,7 +595,7 @@ class HipTensorDotLayer(HipInnerLayer):
     def params(self) -> Mapping[str, HipParameter]:
         return {"weight": self.weight}
 
-    def prepare(self, stream: int) -> None:
+    def prepare(self, stream: int, batched: bool = False) -> None:
         self._w = self.weight.evaluate(stream)
 
     def launch(self, arena, row_off, out, B, stream) -> None:

@@ -61,6 +61,42 @@ class TensorStore:
         return list(self._t)
 
 
+class ParamBatch:
+    """All ``tensor -> softmax(last axis)`` parameters of a circuit, recomputed by ONE launch
+    (`ck_param_softmax_batch`) at the start of every forward."""
+
+    def __init__(self) -> None:
+        self._jobs: list[tuple] = []
+        self._keep: list[torch.Tensor] = []
+        self._arr = None
+
+    def add_softmax(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        """dst = softmax(src, dim=-1); both (..., len) contiguous fp32."""
+        rows = src.numel() // src.shape[-1]
+        self._jobs.append((src.data_ptr(), dst.data_ptr(), rows, int(src.shape[-1]), 0, 0))
+        self._keep += [src, dst]
+        self._arr = None
+
+    def add_log_table(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        """src (F, K, C) logits -> dst (F, C, K) = log softmax over C, transposed."""
+        F, K, Cc = src.shape
+        self._jobs.append((src.data_ptr(), dst.data_ptr(), int(F), int(Cc), int(K), 1))
+        self._keep += [src, dst]
+        self._arr = None
+
+    def __len__(self) -> int:
+        return len(self._jobs)
+
+    def launch(self, stream: int) -> None:
+        if not self._jobs:
+            return
+        if self._arr is None:
+            self._arr = (capi.SoftmaxJob * len(self._jobs))()
+            for a, (i, o, rows, ln, k, kind) in zip(self._arr, self._jobs):
+                a.inp, a.out, a.rows, a.len, a.k, a.kind, a.block_begin = i, o, rows, ln, k, kind, 0
+        capi.call("ck_param_softmax_batch", self._arr, len(self._jobs), stream)
+
+
 def _einsum_as_bmm(einsum, shapes):
     """Map a two-operand einsum over per-fold matrices onto ck_param_bmm; returns
     (swap, M, N, Kd, trans_a, trans_b) or None."""
@@ -258,6 +294,21 @@ class HipParameter:
         if upto is not None:
             return outs[upto]
         return self._select("out", outs, g.output, stream)
+
+    def softmax_source(self) -> torch.Tensor | None:
+        """The raw tensor when the graph is exactly ``tensor -> softmax(last axis)`` with identity
+        fold indices (the default parameterisation of sum weights and Categorical probs), else None."""
+        g = self.graph
+        if g.ops != ["tensor", "softmax"] or not self.tail_is("softmax"):
+            return None
+        n = g.nodes[1]
+        if int(n.config["dim"]) != len(n.shape) - 1:
+            return None
+        fi = n.inputs[0]
+        if fi.ids != [0] or fi.kind != IDX_NONE:
+            return None
+        t = self.store[g.nodes[0].config["tensor"]]
+        return None if t.is_complex() else t
 
     def tail_is(self, *ops: str) -> bool:
         """True when the graph ends with `ops` feeding the output untouched (identity output index

@@ -131,6 +131,28 @@ int ck_tensordot_lse_fwd_c(const float* arena_c, const int64_t* row_off, const f
                            float* out_c, int F, int B, int Kj, int Kq, int Kk, int w_is_complex,
                            void* stream);
 
+/* ---------------------------------------------------------------- cross-layer fusion ------- */
+/* Categorical input layer -> [dense TorchSumLayer] -> `depth` levels of arity-2 TorchCPTLayer,
+ * evaluated depth-first per (root fold, 32-row batch tile) in registers; only the root level's
+ * (F_root, B, K) output is written.  Same arithmetic per step as ck_categorical_fwd +
+ * ck_sum_lse_fwd (reference: input.py:399-412, inner.py:266-273, optimized.py:171-178,
+ * semiring.py:383-408); K must be 32.
+ *   table (F0,C,K), xt (D,B) int32, scope (F0): as ck_categorical_fwd;
+ *   w_dense: (F_dense,K,K) linear weights or NULL when the leaves feed the CP-T layers directly;
+ *   w_levels: HOST array of `depth` device pointers, w_levels[l-1] = (F_l,K,K) weights of level l;
+ *   nodes: DEVICE int32 tables; node_off: HOST array of depth+1 offsets into `nodes`:
+ *          nodes+node_off[l] is (F_root, 2^(depth-l)) = fold (in level l's layer) of every node of
+ *          the subtree of each root fold, left to right (level 0 = dense layer, or input layer);
+ *   leaf_off: offset of the (F_root, 2^depth) table of input-layer folds of the leaves. */
+int ck_subtree_cat_cpt_fwd(const float* table, const int32_t* xt, const int64_t* scope,
+                           const float* w_dense, const float* const* w_levels,
+                           const int32_t* nodes, const int32_t* node_off, int leaf_off, float* out,
+                           int depth, int F_root, int B, int K, int C, void* stream);
+
+/* Debug: ablation mask applied to fused launches issued afterwards (bit0 no weight loads, bit1 no
+ * table gather, bit2 no MFMA, bit3 no exp/log); results are then meaningless.  0 = normal. */
+int ck_debug_ablate(int mask);
+
 /* ---------------------------------------------------------------- parameter graphs --------- */
 /* The reference re-evaluates each layer's parameter DAG on every forward
  * (parameters/parameter.py:180-188); these kernels do the same on the fold-stacked blocks. */
@@ -139,6 +161,21 @@ int ck_tensordot_lse_fwd_c(const float* arena_c, const int64_t* row_off, const f
  * (outer, len, inner) view. */
 int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_t inner,
                      int log_space, void* stream);
+/* All `tensor -> softmax(last axis)` parameters of a circuit in one launch.  `jobs` is a HOST array
+ * (copied into the launch).  kind 0: out[r, :] = softmax(in[r, :]) for `rows` rows of `len`.
+ * kind 1 (Categorical probs, input.py:405-408): in (rows=F, k=K, len=C) logits ->
+ * out (F, C, K) = log(softmax over C), transposed for the gather kernels. block_begin is ignored
+ * on input. */
+typedef struct ck_softmax_job {
+  const float* in;
+  float* out;
+  int64_t rows;
+  int32_t len;
+  int32_t k;
+  int32_t kind;
+  int32_t block_begin;
+} ck_softmax_job;
+int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream);
 /* entrywise ops (nodes.py:656-699); a, b only used by CK_UNARY_SCALED_SIGMOID (vmin, vmax). */
 int ck_param_unary(int op, const float* in, float* out, int64_t n, float a, float b, void* stream);
 /* out[f] = in[idx[f]] over blocks of `per_fold` 4-byte words (pointer fold_idx nodes.py:277-279,
