@@ -40,6 +40,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="rows per GPU (default: the BASELINE config)")
     ap.add_argument("--no-graph", action="store_true", help="replay the launch list eagerly instead of as a hipGraph")
     ap.add_argument("--fuse", type=int, default=-1, help="-1: full leaf fusion (default), 0: layer-wise, n: n CP-T levels")
+    ap.add_argument("--contraction", default="f32", choices=["f32", "f16x3"],
+                    help="K=32 sum layers: exact fp32 MFMA (default) or 3-term split-fp16 MFMA with fp32 accumulation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     args = ap.parse_args()
@@ -74,7 +76,8 @@ def main() -> None:
     tensors = init_plan_tensors(plan)
     B = args.batch
     fuse = True if args.fuse < 0 else (False if args.fuse == 0 else args.fuse)
-    circuit = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse)
+    circuit = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse,
+                         contraction=args.contraction)
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randint(0, 256, (B, plan.num_variables), generator=g).to(device)  # int64, like the reference
 
@@ -140,6 +143,8 @@ def main() -> None:
             "parallelism": f"dp{world} (batch-sharded, replicated parameters, one all-reduce of the summed LL)",
             "hip_graph": not args.no_graph,
             "fused_leaf_levels": [g.depth for g in circuit._groups],
+            "fused_tail_layers": len(circuit._tail),
+            "contraction": args.contraction,
             "params_recomputed_every_step": True,
         },
         "check": {"mean_ll": total_nll / max(total_rows, 1.0), "rows": total_rows},

@@ -9,10 +9,13 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
+CK_W_ROWMAJOR = 0
+CK_W_TILED_F32 = 1
+CK_W_TILED_F16X3 = 2
 CK_UNARY_SIGMOID = 0
 CK_UNARY_SCALED_SIGMOID = 1
 CK_UNARY_EXP = 2
@@ -47,16 +50,17 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_embedding_clog_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_embedding_log_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_constant_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "ck_sum_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_sum_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_debug_force_generic": [_i],
-    "ck_debug_ablate": [_i],
     "ck_sum_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_mixing_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_hadamard_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_kronecker_fwd": [_p, _p, _p, _i, _i, _i, _i, _p],
     "ck_tensordot_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_tensordot_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "ck_subtree_cat_cpt_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _i, _i, _i, _i, _i, _p],
+    "ck_subtree_cat_cpt_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_tail_lse_fwd": [_p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32),
+                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _i, _p],
     "ck_param_softmax": [_p, _p, _l, _i, _l, _i, _p],
     "ck_param_softmax_batch": [C.POINTER(SoftmaxJob), _i, _p],
     "ck_param_unary": [_i, _p, _p, _l, _f, _f, _p],

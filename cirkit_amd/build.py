@@ -18,7 +18,11 @@ SRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libcirkit_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -amdgpu-mfma-vgpr-form: gfx950 has a unified VGPR/AGPR file; keeping MFMA results in VGPRs removes
+# the v_accvgpr_read/write pair around every accumulator (32 VALU instructions per 32x32x32 step,
+# which matter because fp32-input MFMA shares the fp32 ALUs with the VALU -- DESIGN.md section 4.2).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _newer(target: str, deps: list[str]) -> bool:

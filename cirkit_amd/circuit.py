@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _capi as capi
-from .fusion import SubtreeGroup, find_subtree_groups
+from .fusion import SubtreeGroup, find_subtree_groups, find_tail
 from .layers import HipConstantValueLayer, HipInputLayer, HipLayer, layer_from_spec
 from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
@@ -62,6 +62,10 @@ class HipCircuit:
             of fused CP-T levels, False evaluates layer by layer (every layer output materialised).
         batch_params: recompute all softmax parameters with one launch per forward
             (`ck_param_softmax_batch`) instead of one launch per parameter node.
+        contraction: how the K = 32 sum layers contract in linear space.  ``"f32"``: exact fp32
+            (v_mfma_f32_32x32x2_f32).  ``"f16x3"``: 3-term split-fp16 products with fp32 accumulation
+            on the matrix pipe (~22-bit effective significand, see cirkit_amd/csrc/ck_tile.h);
+            layers that are not eligible stay on the exact path.
     """
 
     def __init__(
@@ -73,6 +77,7 @@ class HipCircuit:
         use_graph: bool = True,
         fuse: bool | int = True,
         batch_params: bool = True,
+        contraction: str = "f32",
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -114,9 +119,43 @@ class HipCircuit:
         self._group_of_root = {g.root: g for g in self._groups}
         self._virtual = {i for g in self._groups for i in g.virtual}
         self._group_dev: dict[int, tuple] = {}
+        self._tail: list[int] = (
+            find_tail(plan, self.layers, self._virtual | set(self._group_of_root)) if fuse is not False else []
+        )
         self.batch_params = batch_params
         self._batch: ParamBatch | None = None
         self._batch_version = -1
+        if contraction not in ("f32", "f16x3"):
+            raise ValueError(f"unknown contraction {contraction!r} (expected 'f32' or 'f16x3')")
+        if contraction == "f16x3" and not batch_params:
+            raise ValueError("contraction='f16x3' needs batch_params=True (the prologue writes the split weights)")
+        self.contraction = contraction
+        self._assign_weight_layouts()
+
+    def _assign_weight_layouts(self) -> None:
+        """Pick the weight layout of every K = 32 sum layer (ck_tile.h): tiled layouts only where
+        the batched prologue can write them, and uniformly inside a fused launch."""
+        tiled = capi.CK_W_TILED_F16X3 if self.contraction == "f16x3" else capi.CK_W_TILED_F32
+        elig = {
+            i: self.batch_params and getattr(l, "tile32_eligible", False) for i, l in enumerate(self.layers)
+        }
+        layout = {i: (tiled if ok else capi.CK_W_ROWMAJOR) for i, ok in elig.items()}
+        for g in self._groups:
+            members = ([g.dense_layer] if g.dense_layer is not None else []) + g.levels
+            if not all(elig[j] for j in members):
+                for j in members:
+                    layout[j] = capi.CK_W_ROWMAJOR
+        k32 = [j for j in self._tail if self.layers[j].num_output_units == 32]
+        if not all(elig[j] for j in k32):
+            for j in k32:
+                layout[j] = capi.CK_W_ROWMAJOR
+        for i, l in enumerate(self.layers):
+            if hasattr(l, "_w_layout"):
+                l._w_layout = layout[i]
+
+    def _group_layout(self, g: SubtreeGroup) -> int:
+        members = ([g.dense_layer] if g.dense_layer is not None else []) + g.levels
+        return self.layers[members[0]]._w_layout
 
     # -- reference surface -----------------------------------------------------------------------
     @property
@@ -200,6 +239,12 @@ class HipCircuit:
         B = bd.B
         self._launch_param_batch(stream)
         for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
+            if self._tail and i in self._tail:
+                if i == self._tail[0]:
+                    for j in self._tail:
+                        self.layers[j].prepare(stream, batched=self.batch_params)
+                    self._launch_tail(bd, stream)
+                continue
             l.prepare(stream, batched=self.batch_params)
             if i in self._virtual:
                 continue
@@ -217,11 +262,29 @@ class HipCircuit:
             return
         if self._batch is None or self._batch_version != self.store.version:
             self._batch = ParamBatch()
+            self._assign_weight_layouts()
             for l in self.layers:
                 l._batched = False
                 l.register_batched(self._batch)
             self._batch_version = self.store.version
         self._batch.launch(stream)
+
+    def _launch_tail(self, bd: _Binding, stream: int) -> None:
+        """One launch for the trailing few-fold layers (cirkit_amd/csrc/ck_tail.hip)."""
+        n = len(self._tail)
+        ls = [self.layers[j] for j in self._tail]
+        for l in ls:
+            if l._w.is_complex():
+                raise ValueError("complex weights under the real lse-sum semiring")
+        vp = C.c_void_p * n
+        ip = C.c_int32 * n
+        capi.call(
+            "ck_tail_lse_fwd", bd.arena.data_ptr(), n,
+            vp(*[bd.row_off[j].data_ptr() for j in self._tail]), vp(*[l._w.data_ptr() for l in ls]),
+            vp(*[bd.views[j].data_ptr() for j in self._tail]), ip(*[l.num_folds for l in ls]),
+            ip(*[l.arity for l in ls]), ip(*[l.num_output_units for l in ls]), bd.B, ls[0].num_input_units,
+            next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR), stream,
+        )
 
     def _launch_group(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int) -> None:
         """One fused launch for Categorical -> [dense] -> CP-T levels (cirkit_amd/csrc/ck_fused.hip)."""
@@ -237,7 +300,7 @@ class HipCircuit:
             "ck_subtree_cat_cpt_fwd", cat._table.data_ptr(), bd.xt.data_ptr(), cat._scope(self.device).data_ptr(),
             None if w_dense is None else w_dense.data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off,
             out.data_ptr(), g.depth, self.layers[g.root].num_folds, bd.B, cat.num_output_units,
-            cat.num_categories, stream,
+            cat.num_categories, self._group_layout(g), stream,
         )
 
     # -- evaluation ------------------------------------------------------------------------------
@@ -351,7 +414,7 @@ class HipCircuit:
         prod_like = s.type == "cpt" or l.arity == 1
         if (not self._complex and prod_like and l.num_input_units == l.num_output_units
                 and l.num_input_units in (32, 64)):
-            return f"sum_lse_mfma<{l.num_input_units // 32}>"
+            return "sum_lse_tile32" if l.num_input_units == 32 else "sum_lse_mfma<2, 2>"
         return "sum_lse_generic"
 
     def profile_kernels(self, x: torch.Tensor | None, iters: int = 10) -> list[dict]:
@@ -374,9 +437,17 @@ class HipCircuit:
                 e0.record(cur)
                 if i == 0:
                     self._launch_param_batch(stream)
-                l.prepare(stream, batched=self.batch_params)
+                in_tail = bool(self._tail) and i in self._tail
+                if in_tail and i == self._tail[0]:
+                    for j in self._tail:
+                        self.layers[j].prepare(stream, batched=self.batch_params)
+                elif not in_tail:
+                    l.prepare(stream, batched=self.batch_params)
                 e1.record(cur)
-                if i in self._virtual:
+                if in_tail:
+                    if i == self._tail[0]:
+                        self._launch_tail(bd, stream)
+                elif i in self._virtual:
                     pass
                 elif i in self._group_of_root:
                     self._launch_group(self._group_of_root[i], bd, view, stream)
@@ -414,6 +485,12 @@ class HipCircuit:
             wr = l.num_folds * B * l.num_output_units * esz
             layer_bytes[i] = float(rd + wr)
             if i in self._virtual:
+                continue
+            if self._tail and i in self._tail:
+                if i == self._tail[-1]:
+                    rows.append({"layer": self._tail[0], "kernel": "tail_kernel",
+                                 "ms": float(mean[2 * self._tail[0] + 1]),
+                                 "algorithmic_bytes": sum(layer_bytes[j] for j in self._tail)})
                 continue
             nbytes = layer_bytes[i]
             if i in self._group_of_root:  # the fused launch does the work of every layer it replaces

@@ -178,20 +178,51 @@ __device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int bl
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int len = j.len;
   if (len <= 32) {
-    // two rows per wave pass (one per 32-lane half); 16 rows per workgroup pass, 64 rows per block
+    // two rows per wave pass (one per 32-lane half); 64 rows per block; all loads issued up front
     const int half = lane >> 5, l = lane & 31;
+    float x[8];
+    bool ok[8];
+#pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int64_t row = static_cast<int64_t>(blk) * 64 + it * 8 + wave * 2 + half;
-      const bool ok = row < j.rows && l < len;
-      const float x = ok ? j.in[row * len + l] : -INFINITY;
-      float mx = x;
+      ok[it] = row < j.rows && l < len;
+      x[it] = ok[it] ? j.in[row * len + l] : -INFINITY;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int64_t row = static_cast<int64_t>(blk) * 64 + it * 8 + wave * 2 + half;
+      float mx = x[it];
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-      float e = ok ? __expf(x - mx) : 0.f;
+      const float e = ok[it] ? __expf(x[it] - mx) : 0.f;
       float sum = e;
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-      if (ok) j.out[row * len + l] = e / sum;
+      if (ok[it]) {
+        const float p = e / sum;
+        if (j.kind == 0) {
+          j.out[row * len + l] = p;
+        } else {
+          // MFMA-tiled layouts of ck_tile.h: row = fold*32 + o, l = input unit
+          const int64_t fold = row >> 5;
+          const int o = static_cast<int>(row & 31);
+          const int g = l >> 3, kh2 = (l >> 2) & 1, t = l & 3;
+          const int ln = o + 32 * kh2;
+          float* base = j.out + fold * 1024;
+          if (j.kind == 2) {
+            base[g * 256 + ln * 4 + t] = p;
+          } else {
+            // 2-term fp16 split of Wt = 2048 p:  Wt = hi + lo / 2048
+            const float wt = p * 2048.f;
+            const _Float16 hi = static_cast<_Float16>(wt);
+            const _Float16 lo = static_cast<_Float16>((wt - static_cast<float>(hi)) * 2048.f);
+            _Float16* h16 = reinterpret_cast<_Float16*>(base);
+            const int q = g >> 1, jj = 4 * (g & 1) + t;
+            h16[(q * 256 + ln * 4) * 2 + jj] = hi;
+            h16[((q + 2) * 256 + ln * 4) * 2 + jj] = lo;
+          }
+        }
+      }
     }
   } else {
     for (int it = 0; it < 16; ++it) {
@@ -210,30 +241,39 @@ __device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int bl
 }
 
 __device__ __forceinline__ void softmax_job_table(const ck_softmax_job& j, int f, float* tile) {
-  // tile[c][k], row stride K+1
+  // tile[k][c], row stride C+1 (conflict-free both for the row reductions and the transposed read)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int C = j.len, K = j.k;
+  const int C = j.len, K = j.k, ld = C + 1;
   const float* src = j.in + static_cast<int64_t>(f) * K * C;
+  float* stat = tile + K * ld;  // [K] max, [K] log-sum
+  // phase 1: the whole (K, C) block of logits, coalesced, every load in flight at once
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+    const int k = i / C, c = i - k * C;
+    tile[k * ld + c] = src[i];
+  }
+  __syncthreads();
+  // phase 2: per-row max and log-sum-exp from LDS
   for (int k = wave; k < K; k += 4) {
-    const float* row = src + static_cast<int64_t>(k) * C;
+    const float* row = tile + k * ld;
     float mx = -INFINITY;
     for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
     mx = ck::wave_max(mx);
     float sum = 0.f;
     for (int c = lane; c < C; c += 64) sum += __expf(row[c] - mx);
     sum = ck::wave_sum(sum);
-    const float ls = __logf(sum);
-    for (int c = lane; c < C; c += 64) {
-      const float d = row[c] - mx;
-      // log(exp(d)/sum); exp(d) underflows to 0 below ~-103.97 -> the reference yields log(0) = -inf
-      tile[c * (K + 1) + k] = d < -103.9f ? -INFINITY : d - ls;
+    if (lane == 0) {
+      stat[k] = mx;
+      stat[K + k] = __logf(sum);
     }
   }
   __syncthreads();
+  // phase 3: out[c][k] = log(exp(d)/sum), d = theta - max; written coalesced (k fastest)
   float* dst = j.out + static_cast<int64_t>(f) * C * K;
   for (int i = threadIdx.x; i < C * K; i += blockDim.x) {
     const int c = i / K, k = i - c * K;
-    dst[i] = tile[c * (K + 1) + k];
+    const float d = tile[k * ld + c] - stat[k];
+    // exp(d) underflows to 0 below ~-103.97 -> the reference yields log(0) = -inf
+    dst[i] = d < -103.9f ? -INFINITY : d - stat[K + k];
   }
 }
 
@@ -244,10 +284,10 @@ __global__ void __launch_bounds__(256) softmax_batch_kernel(const JobTable t) {
   while (ji + 1 < t.n && bid >= t.job[ji + 1].block_begin) ++ji;
   const ck_softmax_job& j = t.job[ji];
   const int blk = bid - j.block_begin;
-  if (j.kind == 0)
-    softmax_job_rows(j, blk);
-  else
+  if (j.kind == 1)
     softmax_job_table(j, blk, tile);
+  else
+    softmax_job_rows(j, blk);
 }
 
 // ---- log-likelihood sum ------------------------------------------------------------------------
@@ -391,13 +431,15 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
     for (int i = 0; i < t.n; ++i) {
       ck_softmax_job j = jobs[start + i];
       CK_REQUIRE(j.in && j.out && j.rows > 0 && j.len > 0, "ck_param_softmax_batch: bad job %d", start + i);
-      CK_REQUIRE(j.kind == 0 || j.kind == 1, "ck_param_softmax_batch: job %d has unknown kind %d", start + i, j.kind);
+      CK_REQUIRE(j.kind >= 0 && j.kind <= 3, "ck_param_softmax_batch: job %d has unknown kind %d", start + i, j.kind);
+      CK_REQUIRE(j.kind < 2 || (j.len == 32 && j.rows % 32 == 0),
+                 "ck_param_softmax_batch: tiled job %d needs len = 32 and rows %% 32 = 0", start + i);
       j.block_begin = blocks;
-      if (j.kind == 0) {
+      if (j.kind != 1) {
         blocks += static_cast<int>((j.rows + 63) / 64);
       } else {
         CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", start + i);
-        const size_t need = static_cast<size_t>(j.len) * (j.k + 1) * sizeof(float);
+        const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k) * sizeof(float);
         if (need > 64 * 1024)
           return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
         lds = std::max(lds, need);

@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "ck_internal.h"
+#include "ck_tile.h"
 
 namespace {
 
@@ -35,7 +36,6 @@ using ck::c32;
 // s = 4g+t of block q contracts units {32q+8g+t (kh=0), 32q+8g+4+t (kh=1)} -- exactly what lane
 // (., kh) holds in register (q, s) for both operands.  The result D[o][b] lands in lane
 // (b, hi) register r with o = 8(r>>2) + 4hi + (r&3): the same ownership as the inputs.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int NKI, int NKO, int MODE>
 __global__ void __launch_bounds__(256)
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < NKI; ++q)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[q][j] = __expf(v[q][j] - m);
+      for (int j = 0; j < 16; ++j) v[q][j] = __builtin_amdgcn_exp2f(fmaf(v[q][j], kL2E, -m * kL2E));
 
     float* dst = out + (static_cast<int64_t>(f) * B + bl) * KO + 4 * kh;
 #pragma unroll
@@ -121,14 +121,43 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float4 o4;
-          o4.x = __logf(acc[4 * g + 0]) + m;
-          o4.y = __logf(acc[4 * g + 1]) + m;
-          o4.z = __logf(acc[4 * g + 2]) + m;
-          o4.w = __logf(acc[4 * g + 3]) + m;
+          o4.x = fmaf(__builtin_amdgcn_logf(acc[4 * g + 0]), kLN2, m);
+          o4.y = fmaf(__builtin_amdgcn_logf(acc[4 * g + 1]), kLN2, m);
+          o4.z = fmaf(__builtin_amdgcn_logf(acc[4 * g + 2]), kLN2, m);
+          o4.w = fmaf(__builtin_amdgcn_logf(acc[4 * g + 3]), kLN2, m);
           *reinterpret_cast<float4*>(dst + 32 * p + 8 * g) = o4;
         }
       }
     }
+  }
+}
+
+// K = 32 on the shared register tile (ck_tile.h): supports the tiled weight layouts and the
+// split-precision contraction; each wave keeps the fold's weights in registers across its tiles.
+template <int LAYOUT>
+__global__ void __launch_bounds__(256)
+    sum_lse_tile32(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
+                   const float* __restrict__ w, float* __restrict__ out, int H, int B,
+                   int tiles_per_wave) {
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  WRegs wr;
+  load_w<LAYOUT>(w + static_cast<int64_t>(f) * kK * kK, lane, wr);
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+    const int b0 = (tile0 + tt) * 32;
+    if (b0 >= B) break;
+    const int b = b0 + b_in;
+    const bool live = b < B;
+    const int bl = live ? b : B - 1;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = 0.f;
+    for (int h = 0; h < H; ++h) tile_load_add(arena + ro[h] + static_cast<int64_t>(bl) * kK + 4 * kh, v);
+    sum_step<LAYOUT>(wr, v);
+    if (live) tile_store(out + (static_cast<int64_t>(f) * B + b) * kK + 4 * kh, v);
   }
 }
 
@@ -399,10 +428,33 @@ int ck_debug_force_generic(int on) {
 }
 
 int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
-                   int H, int B, int Ki, int Ko, int mode, void* stream) {
+                   int H, int B, int Ki, int Ko, int mode, int w_layout, void* stream) {
   if (int st = check_sum_args(arena, row_off, w, out, F, H, B, Ki, Ko, mode, "ck_sum_lse_fwd")) return st;
+  CK_REQUIRE(w_layout >= CK_W_ROWMAJOR && w_layout <= CK_W_TILED_F16X3, "ck_sum_lse_fwd: unknown w_layout %d", w_layout);
   const bool prod_like = mode == CK_SUM_PROD || H == 1;
-  const bool mfma_ok = !g_force_generic && prod_like && Ki == Ko && (Ki == 32 || Ki == 64) &&
+  if (w_layout != CK_W_ROWMAJOR) {
+    CK_REQUIRE(prod_like && Ki == kK && Ko == kK, "ck_sum_lse_fwd: tiled weight layouts need Ki = Ko = 32 and a product-type input");
+    CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out), "ck_sum_lse_fwd: buffers must be 16-byte aligned");
+  }
+  if (w_layout != CK_W_ROWMAJOR || (!g_force_generic && prod_like && Ki == kK && Ko == kK && ck::aligned16(arena) &&
+                                    ck::aligned16(w) && ck::aligned16(out))) {
+    const int tiles = (B + 31) / 32;
+    int tpw = 1;
+    while (tpw < 4 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
+    dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          if (w_layout == CK_W_ROWMAJOR)
+            hipLaunchKernelGGL(sum_lse_tile32<CK_W_ROWMAJOR>, grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
+          else if (w_layout == CK_W_TILED_F32)
+            hipLaunchKernelGGL(sum_lse_tile32<CK_W_TILED_F32>, grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
+          else
+            hipLaunchKernelGGL(sum_lse_tile32<CK_W_TILED_F16X3>, grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
+          return hipGetLastError();
+        },
+        stream);
+  }
+  const bool mfma_ok = !g_force_generic && prod_like && Ki == Ko && Ki == 64 &&
                        ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out);
   if (mfma_ok) {
     // 4 waves per workgroup, each wave `tpw` 32-row tiles of the same fold (weights stay in
@@ -411,13 +463,9 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
     int tpw = 1;
     while (tpw < 4 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
-    const bool k32 = Ki == 32;
     return ck::dispatch(
         [=](hipStream_t s) {
-          if (k32)
-            hipLaunchKernelGGL((sum_lse_mfma<1, 1, CK_SUM_PROD>), grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
-          else
-            hipLaunchKernelGGL((sum_lse_mfma<2, 2, CK_SUM_PROD>), grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
+          hipLaunchKernelGGL((sum_lse_mfma<2, 2, CK_SUM_PROD>), grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
           return hipGetLastError();
         },
         stream);

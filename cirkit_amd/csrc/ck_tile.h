@@ -1,0 +1,155 @@
+// The 32-row x 32-unit register tile shared by sum_lse_mfma (ck_sum.hip), the fused leaf kernel
+// (ck_fused.hip) and the fused tail (ck_tail.hip).
+//
+// Lane l of a wave: b = l & 31 (batch row of the 32-row tile), kh = l >> 5.  Lane (b, kh) holds
+// units 8g + 4kh + t (g, t in 0..3) of row b in register j = 4g + t.  Both MFMA shapes used here
+// (v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_f16) return D[o][b] in lane (b, hi) register r
+// with o = 8(r>>2) + 4hi + (r&3): the OUTPUT layout of a step is the INPUT layout of the next.
+//
+// Weight layouts of one fold (32 outputs x 32 inputs = 1024 dwords):
+//   CK_W_ROWMAJOR    W[o][i] fp32 -- the reference's layout; lane (o, kh) reads 4 x 16 B at stride 32 B
+//   CK_W_TILED_F32   dword (q, lane, t) = W[o = lane&31][8q + 4(lane>>5) + t]: every wave load
+//                    instruction reads one contiguous KiB (8 lines instead of 32)
+//   CK_W_TILED_F16X3 same tiling, contents = 2-term fp16 split of 2048*W for the split-precision
+//                    contraction below: q = 0,1 hold hi (8 halves each), q = 2,3 hold lo
+// The tiled layouts are produced by the softmax prologue (ck_param.hip, kinds 2 and 3).
+#pragma once
+
+#include "ck_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kK = 32;
+
+struct WRegs {
+  float4 q[4];
+};
+
+template <int LAYOUT>
+__device__ __forceinline__ void load_w(const float* __restrict__ wf, int lane, WRegs& w) {
+  if constexpr (LAYOUT == CK_W_ROWMAJOR) {
+    const float* wrow = wf + (lane & 31) * kK + 4 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w.q[g] = *reinterpret_cast<const float4*>(wrow + 8 * g);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w.q[q] = *reinterpret_cast<const float4*>(wf + q * 256 + lane * 4);
+  }
+}
+
+__device__ __forceinline__ float row_max16(const float (&v)[16]) {
+  float m = v[0];
+#pragma unroll
+  for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  return ck::clamp_finite(m);  // torch.clamp(amax, finfo.min, finfo.max), semiring.py:392-399
+}
+
+constexpr float kL2E = 1.44269504088896340736f;
+constexpr float kLN2 = 0.69314718055994530942f;
+
+// One log-einsum-exp step  v <- log(W . exp(v - max v)) + max v  on a register tile.
+//
+// LAYOUT ROWMAJOR / TILED_F32: exact fp32 contraction on v_mfma_f32_32x32x2_f32 (an fmaf chain).
+//   Measured on MI355X: this MFMA shares the fp32 ALUs with the VALU, the two never
+//   co-execute, so its 16 x 64 cycles add to the exp/log work.
+// LAYOUT TILED_F16X3: split-precision contraction on the real matrix pipe.  E = 2048 exp(v - m) is
+//   split EXACTLY into hiE (top 11 significand bits, representable in fp16) + loE; the weights
+//   were split by the prologue into hiW + loW/2048 (of 2048 W).  Three fp16 MFMA products with fp32
+//   accumulation,  2^22 y = (hiW.hiE + hiW.loE) + (loW.hiE)/2048,  drop only the lo.lo term:
+//   relative error <= ~3 x 2^-22 of the dominant terms (fp32 is 2^-24) -- below the error of the
+//   v_exp_f32/v_log_f32 pair used on either path.  6 MFMAs x 32 cycles that overlap with VALU.
+template <int LAYOUT>
+__device__ __forceinline__ void sum_step(const WRegs& w, float (&v)[16]) {
+  const float m = row_max16(v);
+  if constexpr (LAYOUT != CK_W_TILED_F16X3) {
+    const float nml = -m * kL2E;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = __builtin_amdgcn_exp2f(fmaf(v[j], kL2E, nml));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.q[g].x, v[4 * g + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.q[g].y, v[4 * g + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.q[g].z, v[4 * g + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.q[g].w, v[4 * g + 3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m);
+  } else {
+    const float nml = fmaf(-m, kL2E, 11.f);  // E = 2^11 exp(v - m) in (0, 2048]
+    union {
+      f16x8 v8[2];
+      uint32_t v2[8];
+    } hi, lo;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const float e0 = __builtin_amdgcn_exp2f(fmaf(v[2 * p], kL2E, nml));
+      const float e1 = __builtin_amdgcn_exp2f(fmaf(v[2 * p + 1], kL2E, nml));
+      const float h0 = __uint_as_float(__float_as_uint(e0) & 0xFFFFE000u);
+      const float h1 = __uint_as_float(__float_as_uint(e1) & 0xFFFFE000u);
+      hi.v2[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0, h1));  // exact: 11 significant bits
+      lo.v2[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(e0 - h0, e1 - h1));  // residual < 2^-11 E
+    }
+    union {
+      float4 f4;
+      f16x8 h8;
+    } a0, a1, a2, a3;
+    a0.f4 = w.q[0];
+    a1.f4 = w.q[1];
+    a2.f4 = w.q[2];
+    a3.f4 = w.q[3];
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = 0.f;
+      acc1[r] = 0.f;
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h8, hi.v8[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2.h8, hi.v8[0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h8, hi.v8[1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3.h8, hi.v8[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h8, lo.v8[0], acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h8, lo.v8[1], acc0, 0, 0, 0);
+    const float mm = fmaf(-22.f, kLN2, m);  // undo the two 2^11 scalings
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      v[r] = fmaf(__builtin_amdgcn_logf(fmaf(acc1[r], 4.8828125e-4f, acc0[r])), kLN2, mm);
+  }
+}
+
+// Read one (32 rows x 32 units) tile of a (B, 32) block in register layout, adding it to v.
+__device__ __forceinline__ void tile_load_add(const float* __restrict__ src_row, float (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 t4 = *reinterpret_cast<const float4*>(src_row + 8 * g);
+    v[4 * g + 0] += t4.x;
+    v[4 * g + 1] += t4.y;
+    v[4 * g + 2] += t4.z;
+    v[4 * g + 3] += t4.w;
+  }
+}
+
+__device__ __forceinline__ void tile_load(const float* __restrict__ src_row, float (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 t4 = *reinterpret_cast<const float4*>(src_row + 8 * g);
+    v[4 * g + 0] = t4.x;
+    v[4 * g + 1] = t4.y;
+    v[4 * g + 2] = t4.z;
+    v[4 * g + 3] = t4.w;
+  }
+}
+
+__device__ __forceinline__ void tile_store(float* __restrict__ dst_row, const float (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(dst_row + 8 * g) =
+        make_float4(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+
+}  // namespace

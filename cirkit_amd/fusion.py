@@ -117,3 +117,33 @@ def find_subtree_groups(plan, layers, children, out_pairs, max_depth: int = MAX_
             SubtreeGroup(i0, dense, levels, np.concatenate(packed).astype(np.int32), node_off, leaf_off)
         )
     return groups
+
+
+MAX_TAIL_LAYERS = 12
+
+
+def find_tail(plan, layers, skip: set[int], max_folds: int = 64) -> list[int]:
+    """Trailing layers with few folds that `ck_tail_lse_fwd` evaluates in one launch: real CP-T /
+    dense sum steps with 32 input units, 32 output units (fewer only for terminal layers, e.g. the
+    scalar root), at most `max_folds` folds each."""
+    if plan.semiring != "lse-sum":
+        return []
+    tail: list[int] = []
+    for i in range(len(layers) - 1, -1, -1):
+        s, l = plan.layers[i], layers[i]
+        ok = (
+            i not in skip
+            and s.inputs is not None
+            and (s.type == "cpt" or (s.type == "sum" and l.arity == 1))
+            and not getattr(l, "_mixing", False)
+            and l.num_input_units == FUSED_K
+            and (l.num_output_units == FUSED_K or (l.num_output_units < FUSED_K and not tail))
+            and l.num_folds <= max_folds
+            and len(tail) < MAX_TAIL_LAYERS
+        )
+        if not ok:
+            break
+        tail.append(i)
+    tail.reverse()
+    # a terminal layer with Ko < 32 may only be consumed by the circuit output
+    return tail if len(tail) >= 2 else []

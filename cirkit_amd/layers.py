@@ -482,6 +482,7 @@ class HipSumLayer(HipInnerLayer):
         self._check_param("weight", weight, self._weight_shape)
         self.weight = weight
         self._w: torch.Tensor | None = None
+        self._w_layout = capi.CK_W_ROWMAJOR  # set by HipCircuit before register_batched
         self._mixing = self._is_mixing()
 
     @property
@@ -508,18 +509,34 @@ class HipSumLayer(HipInnerLayer):
         fi = g.nodes[-1].inputs[0]
         return fi.ids == [len(g.nodes) - 2] and fi.kind == "none" and self.num_input_units == self.num_output_units
 
+    @property
+    def tile32_eligible(self) -> bool:
+        """Ki = Ko = 32 product-type real layer whose weight is a plain softmax: may take the
+        MFMA-tiled weight layouts written by the batched prologue."""
+        return (
+            not self._mixing
+            and not self.is_complex
+            and (self._mode == capi.CK_SUM_PROD or self.arity == 1)
+            and self.num_input_units == 32
+            and self.num_output_units == 32
+            and self.weight.softmax_source() is not None
+        )
+
     def register_batched(self, batch) -> bool:
         src = None if (self._mixing or self.is_complex) else self.weight.softmax_source()
         if src is None:
+            self._w_layout = capi.CK_W_ROWMAJOR
             return False
         self._w = torch.empty_like(src)
-        batch.add_softmax(src, self._w)
+        batch.add_softmax(src, self._w, self._w_layout)
         self._batched = True
         return True
 
     def prepare(self, stream: int, batched: bool = False) -> None:
         if batched and self._batched:
             return
+        if self._w_layout != capi.CK_W_ROWMAJOR:
+            raise capi.HipExtensionError("tiled weight layouts are only produced by the batched prologue")
         if self._mixing:
             self._w = self.weight.evaluate(stream, upto=len(self.weight.graph.nodes) - 2)  # (F, K, H)
         else:
@@ -542,7 +559,7 @@ class HipSumLayer(HipInnerLayer):
                 raise ValueError("complex weights under the real lse-sum semiring")
             capi.call(
                 "ck_sum_lse_fwd", _ptr(arena), _ptr(row_off), _ptr(w), _ptr(out), self.num_folds, self.arity,
-                B, self.num_input_units, self.num_output_units, self._mode, stream,
+                B, self.num_input_units, self.num_output_units, self._mode, self._w_layout, stream,
             )
 
 

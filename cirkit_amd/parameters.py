@@ -70,10 +70,12 @@ class ParamBatch:
         self._keep: list[torch.Tensor] = []
         self._arr = None
 
-    def add_softmax(self, src: torch.Tensor, dst: torch.Tensor) -> None:
-        """dst = softmax(src, dim=-1); both (..., len) contiguous fp32."""
+    def add_softmax(self, src: torch.Tensor, dst: torch.Tensor, layout: int = 0) -> None:
+        """dst = softmax(src, dim=-1); both (..., len) contiguous fp32.  `layout` 1 / 2 writes the
+        (F, 32, 32) result in the MFMA-tiled fp32 / split-fp16 layout of ck_tile.h instead."""
         rows = src.numel() // src.shape[-1]
-        self._jobs.append((src.data_ptr(), dst.data_ptr(), rows, int(src.shape[-1]), 0, 0))
+        kind = {0: 0, 1: 2, 2: 3}[layout]
+        self._jobs.append((src.data_ptr(), dst.data_ptr(), rows, int(src.shape[-1]), 0, kind))
         self._keep += [src, dst]
         self._arr = None
 

@@ -41,6 +41,12 @@ typedef enum ck_status {
 #define CK_SUM_CAT 0  /* TorchSumLayer: children concatenated -> N = H*Ki inputs        */
 #define CK_SUM_PROD 1 /* TorchCPTLayer: children multiplied (log-space add) -> N = Ki   */
 
+/* weight layouts of the Ki = Ko = 32 sum kernels (cirkit_amd/csrc/ck_tile.h).  The tiled layouts
+ * are written by ck_param_softmax_batch (job kinds 2 / 3). */
+#define CK_W_ROWMAJOR 0    /* (F, Ko, N) fp32, the reference's layout                                 */
+#define CK_W_TILED_F32 1   /* per fold: dword (q, lane, t) = W[lane&31][8q + 4(lane>>5) + t], fp32     */
+#define CK_W_TILED_F16X3 2 /* same tiling, 2-term fp16 split of 2048*W: split-precision MFMA contraction */
+
 /* unary parameter ops of ck_param_unary */
 #define CK_UNARY_SIGMOID 0
 #define CK_UNARY_SCALED_SIGMOID 1 /* sigmoid(x)*(b-a)+a ; nodes.py:698-699 */
@@ -98,9 +104,11 @@ int ck_constant_fwd(const float* value, float* out, int F, int B, int K, int log
 /* TorchSumLayer.forward (inner.py:266-273, mode CK_SUM_CAT) and TorchCPTLayer.forward
  * (optimized.py:171-178, mode CK_SUM_PROD) fused with LSESumSemiring.apply_reduce
  * (semiring.py:383-408): v = cat_h/sum_h children; m = clamp(max v); out = log(W . exp(v - m)) + m.
- * w: (F, Ko, N) linear-space weights, N = H*Ki (cat) or Ki (prod).  out: (F, B, Ko). */
+ * w: (F, Ko, N) linear-space weights, N = H*Ki (cat) or Ki (prod), in layout `w_layout`
+ * (CK_W_ROWMAJOR for any shape; the tiled layouts need Ki = Ko = 32, H = 1 or mode PROD).
+ * out: (F, B, Ko). */
 int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
-                   int H, int B, int Ki, int Ko, int mode, void* stream);
+                   int H, int B, int Ki, int Ko, int mode, int w_layout, void* stream);
 /* Test hook: route ck_sum_lse_fwd through the shape-generic kernel even where the MFMA kernel
  * applies (A/B parity of the two implementations). */
 int ck_debug_force_generic(int on);
@@ -147,11 +155,18 @@ int ck_tensordot_lse_fwd_c(const float* arena_c, const int64_t* row_off, const f
 int ck_subtree_cat_cpt_fwd(const float* table, const int32_t* xt, const int64_t* scope,
                            const float* w_dense, const float* const* w_levels,
                            const int32_t* nodes, const int32_t* node_off, int leaf_off, float* out,
-                           int depth, int F_root, int B, int K, int C, void* stream);
+                           int depth, int F_root, int B, int K, int C, int w_layout, void* stream);
 
-/* Debug: ablation mask applied to fused launches issued afterwards (bit0 no weight loads, bit1 no
- * table gather, bit2 no MFMA, bit3 no exp/log); results are then meaningless.  0 = normal. */
-int ck_debug_ablate(int mask);
+/* The last `n_layers` levels of a circuit (few folds each) in one launch: one workgroup per 32-row
+ * batch tile walks the layers in order, a workgroup barrier between levels.  Layer i is a
+ * TorchCPTLayer / dense TorchSumLayer step over the product of its H[i] children (CK_SUM_PROD
+ * semantics), Ki = 32, Ko[i] = 32 or < 32 (e.g. the scalar root).  All arrays are HOST arrays of
+ * length n_layers; row_off[i] (F[i], H[i]) device offset tables, w[i] (F[i], Ko[i], 32), out[i]
+ * (F[i], B, Ko[i]) inside or outside the arena.  w_layout applies to the Ko = 32 layers; layers
+ * with Ko < 32 always take row-major fp32 weights. */
+int ck_tail_lse_fwd(const float* arena, int n_layers, const int64_t* const* row_off,
+                    const float* const* w, float* const* out, const int32_t* F, const int32_t* H,
+                    const int32_t* Ko, int B, int K, int w_layout, void* stream);
 
 /* ---------------------------------------------------------------- parameter graphs --------- */
 /* The reference re-evaluates each layer's parameter DAG on every forward
@@ -164,8 +179,9 @@ int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_
 /* All `tensor -> softmax(last axis)` parameters of a circuit in one launch.  `jobs` is a HOST array
  * (copied into the launch).  kind 0: out[r, :] = softmax(in[r, :]) for `rows` rows of `len`.
  * kind 1 (Categorical probs, input.py:405-408): in (rows=F, k=K, len=C) logits ->
- * out (F, C, K) = log(softmax over C), transposed for the gather kernels. block_begin is ignored
- * on input. */
+ * out (F, C, K) = log(softmax over C), transposed for the gather kernels.
+ * kind 2 / 3: as kind 0 for (F*32, 32) weights, written in CK_W_TILED_F32 / CK_W_TILED_F16X3
+ * layout (rows must be a multiple of 32, len = 32).  block_begin is ignored on input. */
 typedef struct ck_softmax_job {
   const float* in;
   float* out;

@@ -32,13 +32,13 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_invalid_arguments_return_status_and_message():
     lib = capi.load()
-    st = lib.ck_sum_lse_fwd(None, None, None, None, 1, 1, 1, 32, 32, 0, None)
+    st = lib.ck_sum_lse_fwd(None, None, None, None, 1, 1, 1, 32, 32, 0, 0, None)
     assert st == -1 and b"null pointer" in lib.ck_last_error()
     buf = (C.c_float * 64)()
     p = C.cast(buf, C.c_void_p)
-    st = lib.ck_sum_lse_fwd(p, p, p, p, 1, 1, 0, 32, 32, 0, None)
+    st = lib.ck_sum_lse_fwd(p, p, p, p, 1, 1, 0, 32, 32, 0, 0, None)
     assert st == -1 and b"non-positive" in lib.ck_last_error()
-    st = lib.ck_sum_lse_fwd(p, p, p, p, 1, 1, 4, 32, 32, 7, None)
+    st = lib.ck_sum_lse_fwd(p, p, p, p, 1, 1, 4, 32, 32, 7, 0, None)
     assert st == -1 and b"unknown mode" in lib.ck_last_error()
     st = lib.ck_hadamard_fwd(p, p, p, 1, 2, 4, 8, 3, None)
     assert st == -1 and b"esize" in lib.ck_last_error()
@@ -47,7 +47,9 @@ def test_invalid_arguments_return_status_and_message():
     with pytest.raises(NotImplementedError):  # CK_ERR_UNSUPPORTED
         wl = (C.c_void_p * 1)(p)
         no = (C.c_int32 * 2)(0, 0)
-        capi.call("ck_subtree_cat_cpt_fwd", p, p, p, p, wl, p, no, 0, p, 1, 1, 32, 64, 4, None)
+        capi.call("ck_subtree_cat_cpt_fwd", p, p, p, p, wl, p, no, 0, p, 1, 1, 32, 64, 4, 0, None)
+    st = lib.ck_sum_lse_fwd(p, p, p, p, 1, 2, 4, 16, 16, 0, 1, None)  # tiled layout needs K = 32
+    assert st == -1 and b"tiled" in lib.ck_last_error()
 
 
 def test_program_recording_needs_no_device():

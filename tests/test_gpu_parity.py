@@ -225,6 +225,31 @@ def test_batched_and_per_node_parameter_paths_agree(hip_device, name):
     assert float(((yb - ref).abs() / ref.abs()).max()) <= REL
 
 
+@pytest.mark.parametrize("fuse", [False, 2, True])
+def test_split_fp16_contraction_is_fp32_class(hip_device, fuse):
+    """contraction='f16x3' (3-term split-fp16 MFMA, fp32 accumulate): the circuit output must stay
+    within the same 1e-4 bar with orders of margin, and every materialised layer within the
+    fp32 per-layer bound used for the exact path."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    x = _x_of(plan, g)
+    hc = HipCircuit(plan, tensors, device=hip_device, use_graph=False, fuse=fuse, contraction="f16x3")
+    from cirkit_amd import _capi as capi
+    assert any(getattr(l, "_w_layout", 0) == capi.CK_W_TILED_F16X3 for l in hc.layers)
+    y = hc(x.to(hip_device)).cpu().double()
+    ref64 = torch.from_numpy(g["y_f64"])
+    rel = float(((y - ref64).abs() / ref64.abs()).max())
+    assert rel <= 2e-6, rel  # fp32 exact path measures ~1e-7; the bar is 1e-4
+    _check_layers(plan, tensors, x, hc, atol_scale=4e-6)
+    # ragged batch + exact-vs-split agreement
+    gen = torch.Generator().manual_seed(5)
+    xr = torch.randint(0, 256, (77, 784), generator=gen).to(hip_device)
+    he = HipCircuit(plan, tensors, device=hip_device, use_graph=False, fuse=fuse, contraction="f32")
+    ya, yb = hc(xr).cpu(), he(xr).cpu()
+    assert float(((ya - yb).abs() / yb.abs()).max()) <= 2e-6
+
+
 def test_ll_sum(hip_device):
     from cirkit_amd.circuit import HipCircuit
 
