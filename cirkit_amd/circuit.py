@@ -430,6 +430,10 @@ class HipCircuit:
         acc: list[list[float]] = []
         for it in range(iters + 1):
             evs = []
+            try:  # keep the GPU busy while the host enqueues, so the events bracket GPU time only
+                torch.cuda._sleep(4_000_000)
+            except Exception:  # pragma: no cover
+                pass
             for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
@@ -463,6 +467,8 @@ class HipCircuit:
             if it == 0:
                 continue  # warm-up
             acc.append([t for e0, e1, e2 in evs for t in (e0.elapsed_time(e1), e1.elapsed_time(e2))])
+        # an event pair with nothing between still measures ~5 us of marker overhead: intervals
+        # without a launch are zeroed below (`has_prep` / virtual layers)
         mean = np.mean(np.asarray(acc), axis=0)
         layer_bytes: dict[int, float] = {}
         for i, (l, s) in enumerate(zip(self.layers, self.plan.layers)):
@@ -473,8 +479,13 @@ class HipCircuit:
                         shp, dt = self.plan.tensors[n.config["tensor"]]
                         per_fold = int(np.prod(shp[1:])) * (8 if "complex" in dt else 4)
                         pbytes += per_fold * n.num_folds
-            if s.params:
-                rows.append({"layer": i, "kernel": "param kernels (softmax/log/transpose)", "ms": float(mean[2 * i]),
+            has_prep = bool(s.params) and not (self.batch_params and l._batched)
+            if i == 0 and self.batch_params and self._batch is not None and len(self._batch):
+                rows.append({"layer": 0, "kernel": "softmax_batch_kernel", "ms": float(mean[0]),
+                             "algorithmic_bytes": float(2 * sum(
+                                 int(np.prod(shp)) * 4 for shp, _ in self.plan.tensors.values()))})
+            elif has_prep:
+                rows.append({"layer": i, "kernel": "param kernels (per node)", "ms": float(mean[2 * i]),
                              "algorithmic_bytes": float(pbytes)})
             if s.inputs is not None:
                 rd = l.num_folds * l.arity * B * l.num_input_units * esz
