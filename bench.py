@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 BATCH_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+FP32_MFMA_PEAK_TF = 157.3  # dense fp32-input MFMA peak (= fp32 vector peak), same guide
 
 
 def main() -> None:
@@ -195,9 +196,10 @@ def main() -> None:
             # aggregate per kernel
             agg: dict[str, dict] = {}
             for r in rows:
-                a = agg.setdefault(r["kernel"], {"ms": 0.0, "bytes": 0.0, "launches": 0})
+                a = agg.setdefault(r["kernel"], {"ms": 0.0, "bytes": 0.0, "flops": 0.0, "launches": 0})
                 a["ms"] += r["ms"]
                 a["bytes"] += r["algorithmic_bytes"]
+                a["flops"] += r.get("algorithmic_flops", 0.0)
                 a["launches"] += 1
             dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
             name, a = dom
@@ -209,6 +211,17 @@ def main() -> None:
                     "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
                     "achieved": a["bytes"] / (a["ms"] * 1e-3) / 1e9,
                     "frac": a["bytes"] / (a["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    # the same kernel against the matrix roofline of its dtype (fp32-input MFMA,
+                    # 157.3 TFLOP/s dense, MI355X_MICROARCH.md): a cross-layer-fused kernel moves a
+                    # fraction of the algorithmic bytes and is bound by fp32 issue, not by HBM
+                    "mfma_view": {
+                        "bound": "mfma",
+                        "unit": "TFLOP/s",
+                        "peak": FP32_MFMA_PEAK_TF,
+                        "algorithmic_flops_per_launch": a["flops"] / a["launches"],
+                        "achieved": a["flops"] / (a["ms"] * 1e-3) / 1e12,
+                        "frac": a["flops"] / (a["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+                    },
                     "kernels": {
                         k: {
                             "launches": v["launches"],

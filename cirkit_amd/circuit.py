@@ -396,7 +396,8 @@ class HipCircuit:
         l, s = self.layers[i], self.plan.layers[i]
         if i in self._group_of_root:
             g = self._group_of_root[i]
-            return f"subtree_cat_cpt_kernel<{g.depth}, {'true' if g.dense_layer is not None else 'false'}>"
+            return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if g.dense_layer is not None else 'false'}, "
+                    f"{self._group_layout(g)}>")
         if s.type in ("categorical", "embedding"):
             return "gather_rows_vec" if l.num_output_units % 4 == 0 else "gather_rows_scalar"
         if s.type == "gaussian":
@@ -410,11 +411,13 @@ class HipCircuit:
         if s.type == "tensordot":
             return "tensordot_lse_kernel"
         if getattr(l, "_mixing", False):
-            return "mixing_lse_kernel"
+            k4 = l.num_output_units // 4
+            vec = l.num_output_units % 4 == 0 and 1 <= k4 <= 64 and (k4 & (k4 - 1)) == 0
+            return "mixing_lse_vec" if vec else "mixing_lse_kernel"
         prod_like = s.type == "cpt" or l.arity == 1
         if (not self._complex and prod_like and l.num_input_units == l.num_output_units
                 and l.num_input_units in (32, 64)):
-            return "sum_lse_tile32" if l.num_input_units == 32 else "sum_lse_mfma<2, 2>"
+            return f"sum_lse_tile32<{l._w_layout}>" if l.num_input_units == 32 else "sum_lse_mfma<2, 2, 1>"
         return "sum_lse_generic"
 
     def profile_kernels(self, x: torch.Tensor | None, iters: int = 10) -> list[dict]:
@@ -471,6 +474,7 @@ class HipCircuit:
         # without a launch are zeroed below (`has_prep` / virtual layers)
         mean = np.mean(np.asarray(acc), axis=0)
         layer_bytes: dict[int, float] = {}
+        layer_flops: dict[int, float] = {}
         for i, (l, s) in enumerate(zip(self.layers, self.plan.layers)):
             pbytes = 0
             for pg in s.params.values():
@@ -495,19 +499,30 @@ class HipCircuit:
                 rd = 0
             wr = l.num_folds * B * l.num_output_units * esz
             layer_bytes[i] = float(rd + wr)
+            if s.type in ("sum", "cpt", "tensordot") and not getattr(l, "_mixing", False):
+                n_in = l.num_input_units * (l.arity if s.type == "sum" else 1)
+                if s.type == "tensordot":
+                    n_in = l._num_contract_units
+                layer_flops[i] = 2.0 * l.num_folds * B * l.num_output_units * n_in * (4 if self._complex else 1)
+            else:
+                layer_flops[i] = 0.0
             if i in self._virtual:
                 continue
             if self._tail and i in self._tail:
                 if i == self._tail[-1]:
-                    rows.append({"layer": self._tail[0], "kernel": "tail_kernel",
+                    tl = next((self.layers[j]._w_layout for j in self._tail
+                               if self.layers[j].num_output_units == 32), 0)
+                    rows.append({"layer": self._tail[0], "kernel": f"tail_kernel<{tl}>",
                                  "ms": float(mean[2 * self._tail[0] + 1]),
-                                 "algorithmic_bytes": sum(layer_bytes[j] for j in self._tail)})
+                                 "algorithmic_bytes": sum(layer_bytes[j] for j in self._tail),
+                                 "algorithmic_flops": sum(layer_flops[j] for j in self._tail)})
                 continue
-            nbytes = layer_bytes[i]
+            nbytes, nflops = layer_bytes[i], layer_flops[i]
             if i in self._group_of_root:  # the fused launch does the work of every layer it replaces
                 nbytes += sum(layer_bytes[j] for j in self._group_of_root[i].virtual)
+                nflops += sum(layer_flops[j] for j in self._group_of_root[i].virtual)
             rows.append({"layer": i, "kernel": self.kernel_label(i), "ms": float(mean[2 * i + 1]),
-                         "algorithmic_bytes": nbytes})
+                         "algorithmic_bytes": nbytes, "algorithmic_flops": nflops})
         return rows
 
     # -- accounting ------------------------------------------------------------------------------

@@ -101,10 +101,11 @@ __global__ void __launch_bounds__(256)
       for (int j = 0; j < 16; ++j) m = fmaxf(m, v[q][j]);
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     m = ck::clamp_finite(m);
+    const float nml = exp_offset(m, 0.f);
 #pragma unroll
     for (int q = 0; q < NKI; ++q)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[q][j] = __builtin_amdgcn_exp2f(fmaf(v[q][j], kL2E, -m * kL2E));
+      for (int j = 0; j < 16; ++j) v[q][j] = __builtin_amdgcn_exp2f(fmaf(v[q][j], kL2E, nml));
 
     float* dst = out + (static_cast<int64_t>(f) * B + bl) * KO + 4 * kh;
 #pragma unroll
@@ -344,6 +345,50 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// float4 variant: K/4 lanes per row (K/4 a power of two <= 64), 64/(K/4) rows per wave pass.
+__global__ void __launch_bounds__(256)
+    mixing_lse_vec(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
+                   const float* __restrict__ mw, float* __restrict__ out, int H, int B, int K,
+                   int rows_per_block) {
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lpr = K >> 2, rpw = 64 / lpr;
+  const int r_in = lane / lpr, q = lane - r_in * lpr;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const float* mwf = mw + static_cast<int64_t>(f) * K * H;
+  const int b_begin = blockIdx.x * rows_per_block;
+  const int b_end = min(B, b_begin + rows_per_block);
+  for (int b0 = b_begin + wave * rpw; b0 < b_end; b0 += 4 * rpw) {
+    const int b = min(b0 + r_in, B - 1);
+    const bool live = b0 + r_in < b_end;
+    float mx = -INFINITY;
+    for (int h = 0; h < H; ++h) {
+      const float4 v = reinterpret_cast<const float4*>(arena + ro[h] + static_cast<int64_t>(b) * K)[q];
+      mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = ck::clamp_finite(mx);
+    const float nml = exp_offset(mx, 0.f);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = 0; h < H; ++h) {
+      const float4 v = reinterpret_cast<const float4*>(arena + ro[h] + static_cast<int64_t>(b) * K)[q];
+      const float* w4 = mwf + static_cast<int64_t>(4 * q) * H + h;
+      acc.x = fmaf(w4[0], __builtin_amdgcn_exp2f(fmaf(v.x, kL2E, nml)), acc.x);
+      acc.y = fmaf(w4[H], __builtin_amdgcn_exp2f(fmaf(v.y, kL2E, nml)), acc.y);
+      acc.z = fmaf(w4[2 * H], __builtin_amdgcn_exp2f(fmaf(v.z, kL2E, nml)), acc.z);
+      acc.w = fmaf(w4[3 * H], __builtin_amdgcn_exp2f(fmaf(v.w, kL2E, nml)), acc.w);
+    }
+    if (live) {
+      float4 o4;
+      o4.x = fmaf(__builtin_amdgcn_logf(acc.x), kLN2, mx);
+      o4.y = fmaf(__builtin_amdgcn_logf(acc.y), kLN2, mx);
+      o4.z = fmaf(__builtin_amdgcn_logf(acc.z), kLN2, mx);
+      o4.w = fmaf(__builtin_amdgcn_logf(acc.w), kLN2, mx);
+      reinterpret_cast<float4*>(out + (static_cast<int64_t>(f) * B + b) * K)[q] = o4;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // TensorDot: x (B, Kj*Kq) viewed (Kj, Kq); for each q: m_q = max_j x[j,q];
 //   out[q*Kk + k] = log(sum_j W[k,j] exp(x[j,q] - m_q)) + m_q
@@ -488,11 +533,17 @@ int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* m
   CK_REQUIRE(arena && row_off && mw && out, "ck_mixing_lse_fwd: null pointer");
   CK_REQUIRE(F > 0 && H > 0 && B > 0 && K > 0, "ck_mixing_lse_fwd: non-positive size");
   CK_REQUIRE(F <= 65535, "ck_mixing_lse_fwd: F=%d exceeds grid.y", F);
-  const int rows_per_block = 32;
+  const int lpr = K / 4;
+  const bool vec = (K % 4 == 0) && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && ck::aligned16(arena) &&
+                   ck::aligned16(out);
+  const int rows_per_block = vec ? 128 : 32;
   dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(mixing_lse_kernel, grid, block, 0, s, arena, row_off, mw, out, H, B, K, rows_per_block);
+        if (vec)
+          hipLaunchKernelGGL(mixing_lse_vec, grid, block, 0, s, arena, row_off, mw, out, H, B, K, rows_per_block);
+        else
+          hipLaunchKernelGGL(mixing_lse_kernel, grid, block, 0, s, arena, row_off, mw, out, H, B, K, rows_per_block);
         return hipGetLastError();
       },
       stream);

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(kTailWaves * 64) tail_kernel(const TailArgs a)
         // Ko < 32 (the root: Ko = 1): plain dot products, lanes (b, 0) and (b, 1) each hold half a row
         // (these few-output layers always take ROW-MAJOR fp32 weights)
         const float m = row_max16(v);
-        const float nml = -m * kL2E;
+        const float nml = exp_offset(m, 0.f);
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = __builtin_amdgcn_exp2f(fmaf(v[j], kL2E, nml));
         for (int o = 0; o < L.Ko; ++o) {

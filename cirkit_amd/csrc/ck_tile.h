@@ -50,6 +50,14 @@ __device__ __forceinline__ float row_max16(const float (&v)[16]) {
 constexpr float kL2E = 1.44269504088896340736f;
 constexpr float kLN2 = 0.69314718055994530942f;
 
+// exp(v - m) is evaluated as exp2(fma(v, log2 e, c)) with c = -m log2 e (+ a scaling exponent).
+// When the row maximum was clamped from -inf / +inf to -+FLT_MAX, -m log2 e overflows and the FMA
+// would produce NaN where the reference gets exp(-inf - m) = 0 (an all -inf row must come out as
+// -inf, semiring.py:392-408); c = `shift` alone keeps those limits.
+__device__ __forceinline__ float exp_offset(float m, float shift) {
+  return fabsf(m) > 1e38f ? shift : fmaf(-m, kL2E, shift);
+}
+
 // One log-einsum-exp step  v <- log(W . exp(v - max v)) + max v  on a register tile.
 //
 // LAYOUT ROWMAJOR / TILED_F32: exact fp32 contraction on v_mfma_f32_32x32x2_f32 (an fmaf chain).
@@ -65,7 +73,7 @@ template <int LAYOUT>
 __device__ __forceinline__ void sum_step(const WRegs& w, float (&v)[16]) {
   const float m = row_max16(v);
   if constexpr (LAYOUT != CK_W_TILED_F16X3) {
-    const float nml = -m * kL2E;
+    const float nml = exp_offset(m, 0.f);
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = __builtin_amdgcn_exp2f(fmaf(v[j], kL2E, nml));
     f32x16 acc;
@@ -81,7 +89,7 @@ __device__ __forceinline__ void sum_step(const WRegs& w, float (&v)[16]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m);
   } else {
-    const float nml = fmaf(-m, kL2E, 11.f);  // E = 2^11 exp(v - m) in (0, 2048]
+    const float nml = exp_offset(m, 11.f);  // E = 2^11 exp(v - m) in (0, 2048]
     union {
       f16x8 v8[2];
       uint32_t v2[8];

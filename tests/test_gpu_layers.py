@@ -1,0 +1,241 @@
+"""Per-layer drop-in contract on the GPU: every HIP layer, called the way the reference calls its
+TorchLayer (``forward(x: (F,H,B,Ki)) -> (F,B,Ko)`` etc.), against the
+oracle's restatement of the same reference forward, over awkward shapes and edge values."""
+import numpy as np
+import pytest
+import torch
+
+from cirkit_amd.plan import IDX_NONE, FoldIndex, LayerSpec, ParamGraph, ParamNode
+
+pytestmark = pytest.mark.gpu
+
+
+def _pg(store, name, value, extra=()):
+    """tensor [-> ops]: returns (HipParameter, ParamGraph, cpu tensors dict)."""
+    from cirkit_amd.parameters import HipParameter
+
+    store.set(name, value)
+    F, shape = value.shape[0], tuple(value.shape[1:])
+    nodes = [ParamNode("tensor", F, shape, {"tensor": name}, [])]
+    for op, cfg, oshape in extra:
+        nodes.append(ParamNode(op, F, oshape, cfg, [FoldIndex([len(nodes) - 1], IDX_NONE)]))
+    g = ParamGraph(nodes, FoldIndex([len(nodes) - 1], IDX_NONE), F, nodes[-1].shape)
+    return HipParameter(g, store), g
+
+
+def _oracle(spec, params_cpu, x, semiring="lse-sum"):
+    from oracle.torch_oracle import _CLSE, _LSE, _layer_forward, eval_param
+
+    sr = _CLSE if semiring == "complex-lse-sum" else _LSE
+    with torch.no_grad():
+        p = {pn: eval_param(pg, params_cpu) for pn, pg in spec.params.items()}
+        return _layer_forward(sr, spec, p, x)
+
+
+def _close(a, b, tol=2e-5):
+    a, b = a.cpu(), b
+    assert a.shape == b.shape
+    fin = torch.isfinite(b)
+    assert torch.equal(torch.isfinite(a), fin)
+    assert torch.equal(a[~fin], b[~fin])  # -inf stays -inf, never NaN
+    if fin.any():
+        scale = max(1.0, float(b[fin].abs().max()))
+        assert float((a[fin] - b[fin]).abs().max()) <= tol * scale, float((a[fin] - b[fin]).abs().max())
+
+
+@pytest.mark.parametrize("F,H,B,Ki,Ko", [(3, 1, 37, 32, 32), (2, 1, 5, 64, 64), (4, 1, 9, 7, 5), (2, 3, 33, 6, 4),
+                                         (1, 11, 17, 64, 64), (5, 1, 1, 1, 1), (2, 2, 70, 40, 96), (1, 1, 3, 300, 2)])
+def test_sum_layer_contract(hip_device, F, H, B, Ki, Ko):
+    from cirkit_amd.layers import HipSumLayer
+    from cirkit_amd.parameters import TensorStore
+
+    g = torch.Generator().manual_seed(F * 1000 + H * 100 + Ki)
+    w = torch.softmax(torch.randn(F, Ko, H * Ki, generator=g), dim=-1)
+    x = torch.randn(F, H, B, Ki, generator=g) * 4 - 6
+    store = TensorStore(hip_device)
+    p, pg = _pg(store, "w", w)
+    layer = HipSumLayer(Ki, Ko, H, weight=p, num_folds=F)
+    spec = LayerSpec("sum", F, H, Ki, Ko, dict(layer.config), {"weight": pg})
+    _close(layer.forward(x.to(hip_device)), _oracle(spec, {"w": w}, x))
+
+
+@pytest.mark.parametrize("F,H,B,Ki,Ko", [(3, 2, 37, 32, 32), (2, 2, 64, 64, 64), (2, 3, 10, 32, 32), (4, 2, 9, 12, 1),
+                                         (1, 2, 130, 32, 1), (2, 4, 3, 5, 7)])
+def test_cpt_layer_contract(hip_device, F, H, B, Ki, Ko):
+    from cirkit_amd.layers import HipCPTLayer
+    from cirkit_amd.parameters import TensorStore
+
+    g = torch.Generator().manual_seed(F * 1000 + H * 100 + Ki + 1)
+    w = torch.softmax(torch.randn(F, Ko, Ki, generator=g), dim=-1)
+    x = torch.randn(F, H, B, Ki, generator=g) * 4 - 6
+    store = TensorStore(hip_device)
+    p, pg = _pg(store, "w", w)
+    layer = HipCPTLayer(Ki, Ko, H, weight=p, num_folds=F)
+    spec = LayerSpec("cpt", F, H, Ki, Ko, dict(layer.config), {"weight": pg})
+    _close(layer.forward(x.to(hip_device)), _oracle(spec, {"w": w}, x))
+
+
+def test_lse_edge_values(hip_device):
+    """Rows that are entirely -inf give -inf (amax clamped to finfo.min, semiring.py:392-399), single
+    finite entries survive, and a 200-nat spread does not underflow the result."""
+    from cirkit_amd.layers import HipCPTLayer, HipSumLayer
+    from cirkit_amd.parameters import TensorStore
+
+    F, B, K = 2, 40, 32
+    g = torch.Generator().manual_seed(3)
+    w = torch.softmax(torch.randn(F, K, K, generator=g), dim=-1)
+    x = torch.randn(F, 1, B, K, generator=g)
+    x[0, 0, 0, :] = float("-inf")
+    x[0, 0, 1, 1:] = float("-inf")
+    x[1, 0, 2, :] = -200.0
+    x[1, 0, 2, 5] = -5.0
+    x[1, 0, 3, :] = 3.0e4
+    store = TensorStore(hip_device)
+    p, pg = _pg(store, "w", w)
+    for cls, typ in ((HipSumLayer, "sum"), (HipCPTLayer, "cpt")):
+        layer = cls(K, K, 1, weight=p, num_folds=F) if typ == "sum" else cls(K, K, 2, weight=p, num_folds=F)
+        xx = x if typ == "sum" else torch.cat([x, torch.zeros_like(x)], dim=1)
+        spec = LayerSpec(typ, F, xx.shape[1], K, K, dict(layer.config), {"weight": pg})
+        _close(layer.forward(xx.to(hip_device)), _oracle(spec, {"w": w}, xx))
+
+
+@pytest.mark.parametrize("F,H,B,K", [(3, 2, 33, 64), (2, 5, 7, 64), (4, 12, 3, 1), (2, 3, 50, 24), (1, 2, 9, 6)])
+def test_mixing_layer_contract(hip_device, F, H, B, K):
+    from cirkit_amd.layers import HipSumLayer
+    from cirkit_amd.parameters import TensorStore
+
+    g = torch.Generator().manual_seed(F + H + K)
+    theta = torch.randn(F, K, H, generator=g)
+    x = torch.randn(F, H, B, K, generator=g) * 3 - 4
+    store = TensorStore(hip_device)
+    p, pg = _pg(store, "m", theta, [("softmax", {"dim": 1}, (K, H)), ("mixing_weight", {}, (K, H * K))])
+    layer = HipSumLayer(K, K, H, weight=p, num_folds=F)
+    assert layer._mixing
+    spec = LayerSpec("sum", F, H, K, K, dict(layer.config), {"weight": pg})
+    _close(layer.forward(x.to(hip_device)), _oracle(spec, {"m": theta}, x))
+
+
+@pytest.mark.parametrize("F,H,B,K,cplx", [(3, 2, 33, 64, False), (2, 16, 5, 64, False), (2, 3, 7, 5, False), (2, 2, 9, 6, True)])
+def test_hadamard_layer_contract(hip_device, F, H, B, K, cplx):
+    from cirkit_amd.layers import HipHadamardLayer
+
+    g = torch.Generator().manual_seed(F + H + K)
+    x = torch.randn(F, H, B, K, generator=g)
+    sem = "lse-sum"
+    if cplx:
+        x = torch.complex(x, torch.randn(F, H, B, K, generator=g))
+        sem = "complex-lse-sum"
+    layer = HipHadamardLayer(K, H, semiring=sem, num_folds=F)
+    spec = LayerSpec("hadamard", F, H, K, K, dict(layer.config), {})
+    got = layer.forward(x.to(hip_device)).cpu()
+    want = _oracle(spec, {}, x, sem)
+    assert float((got - want).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("F,B,K,cplx", [(3, 33, 8, False), (2, 5, 5, False), (2, 4, 6, True)])
+def test_kronecker_layer_contract(hip_device, F, B, K, cplx):
+    from cirkit_amd.layers import HipKroneckerLayer
+
+    g = torch.Generator().manual_seed(F + K)
+    x = torch.randn(F, 2, B, K, generator=g)
+    sem = "lse-sum"
+    if cplx:
+        x = torch.complex(x, torch.randn(F, 2, B, K, generator=g))
+        sem = "complex-lse-sum"
+    layer = HipKroneckerLayer(K, 2, semiring=sem, num_folds=F)
+    spec = LayerSpec("kronecker", F, 2, K, K * K, dict(layer.config), {})
+    got = layer.forward(x.to(hip_device)).cpu()
+    want = _oracle(spec, {}, x, sem)
+    assert got.shape == (F, B, K * K) and float((got - want).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("F,B,Kj,Kq,Kk", [(3, 4, 8, 8, 8), (2, 3, 5, 7, 3), (1, 2, 32, 32, 32)])
+def test_tensordot_layer_contract(hip_device, F, B, Kj, Kq, Kk):
+    from cirkit_amd.layers import HipTensorDotLayer
+    from cirkit_amd.parameters import TensorStore
+
+    g = torch.Generator().manual_seed(Kj + Kq + Kk)
+    w = torch.rand(F, Kk, Kj, generator=g) + 0.05
+    x = torch.randn(F, 1, B, Kj * Kq, generator=g) * 2
+    store = TensorStore(hip_device)
+    p, pg = _pg(store, "w", w)
+    layer = HipTensorDotLayer(Kj * Kq, Kq * Kk, weight=p, num_folds=F)
+    spec = LayerSpec("tensordot", F, 1, Kj * Kq, Kq * Kk, dict(layer.config), {"weight": pg})
+    _close(layer.forward(x.to(hip_device)), _oracle(spec, {"w": w}, x))
+
+
+@pytest.mark.parametrize("F,B,K,C", [(5, 33, 32, 256), (3, 7, 6, 4), (2, 300, 1, 3)])
+@pytest.mark.parametrize("kind", ["probs", "logits"])
+def test_categorical_layer_contract(hip_device, F, B, K, C, kind):
+    from cirkit_amd.layers import HipCategoricalLayer
+    from cirkit_amd.parameters import TensorStore
+
+    g = torch.Generator().manual_seed(F + K + C)
+    theta = torch.randn(F, K, C, generator=g)
+    x = torch.randint(0, C, (F, B, 1), generator=g)
+    store = TensorStore(hip_device)
+    extra = [("softmax", {"dim": 1}, (K, C))] if kind == "probs" else []
+    p, pg = _pg(store, "t", theta, extra)
+    layer = HipCategoricalLayer(np.arange(F)[:, None], K, num_categories=C, **{kind: p})
+    spec = LayerSpec("categorical", F, 1, 1, K, dict(layer.config), {kind: pg}, None, np.arange(F)[:, None])
+    _close(layer.forward(x.to(hip_device)), _oracle(spec, {"t": theta}, x))
+    # float-typed batches are truncated like `x.long()` (input.py:400-401)
+    _close(layer.forward(x.to(hip_device).float() + 0.25), _oracle(spec, {"t": theta}, x))
+
+
+@pytest.mark.parametrize("with_logz", [False, True])
+@pytest.mark.parametrize("F,B,K", [(5, 33, 64), (3, 7, 5), (2, 300, 1)])
+def test_gaussian_layer_contract(hip_device, F, B, K, with_logz):
+    from cirkit_amd.layers import HipGaussianLayer
+    from cirkit_amd.parameters import TensorStore
+
+    g = torch.Generator().manual_seed(F + K)
+    mean, raw = torch.randn(F, K, generator=g), torch.randn(F, K, generator=g)
+    lz = torch.randn(F, K, generator=g)
+    x = torch.randn(F, B, 1, generator=g) * 2
+    store = TensorStore(hip_device)
+    pm, gm = _pg(store, "mean", mean)
+    ps, gs = _pg(store, "raw", raw, [("scaled_sigmoid", {"vmin": 1e-5, "vmax": 1.0}, (K,))])
+    params, graphs, vals = {"mean": pm, "stddev": ps}, {"mean": gm, "stddev": gs}, {"mean": mean, "raw": raw}
+    if with_logz:
+        pz, gz = _pg(store, "lz", lz)
+        params["log_partition"], graphs["log_partition"], vals["lz"] = pz, gz, lz
+    layer = HipGaussianLayer(np.arange(F)[:, None], K, **params)
+    spec = LayerSpec("gaussian", F, 1, 1, K, dict(layer.config), graphs, None, np.arange(F)[:, None])
+    _close(layer.forward(x.to(hip_device)), _oracle(spec, vals, x), tol=5e-5)
+
+
+@pytest.mark.parametrize("sem", ["lse-sum", "complex-lse-sum"])
+def test_embedding_and_constant_layer_contract(hip_device, sem):
+    from cirkit_amd.layers import HipConstantValueLayer, HipEmbeddingLayer
+    from cirkit_amd.parameters import TensorStore
+
+    F, B, K, C = 4, 19, 8, 11
+    g = torch.Generator().manual_seed(11)
+    w = torch.rand(F, K, C, generator=g) + 0.1
+    if sem == "complex-lse-sum":
+        w = w - 0.6  # signed weights -> imaginary part pi
+    x = torch.randint(0, C, (F, B, 1), generator=g)
+    store = TensorStore(hip_device)
+    p, pg = _pg(store, "w", w)
+    layer = HipEmbeddingLayer(np.arange(F)[:, None], K, num_states=C, weight=p, semiring=sem)
+    spec = LayerSpec("embedding", F, 1, 1, K, dict(layer.config), {"weight": pg}, None, np.arange(F)[:, None])
+    got, want = layer.forward(x.to(hip_device)).cpu(), _oracle(spec, {"w": w}, x, sem)
+    assert got.dtype == want.dtype and float((got - want).abs().max()) <= 1e-5
+    v = torch.rand(F, K, generator=g) + 0.2
+    pv, gv = _pg(store, "v", v)
+    for log_space in (False, True):
+        cl = HipConstantValueLayer(K, log_space=log_space, value=pv, semiring=sem)
+        cs = LayerSpec("constant", F, 1, 0, K, dict(cl.config), {"value": gv}, None, np.zeros((F, 0), dtype=np.int64))
+        got, want = cl.forward(6).cpu(), _oracle(cs, {"v": v}, 6, sem)
+        assert got.shape == (F, 6, K) and float((got - want).abs().max()) <= 1e-5
+
+
+def test_layer_forward_rejects_bad_inputs(hip_device):
+    from cirkit_amd.layers import HipHadamardLayer
+
+    layer = HipHadamardLayer(8, 2, num_folds=3)
+    with pytest.raises(ValueError):
+        layer.forward(torch.zeros(3, 3, 4, 8, device=hip_device))
+    with pytest.raises(ValueError):
+        layer.forward(torch.zeros(3, 2, 4, 8, device=hip_device, dtype=torch.complex64))
