@@ -152,6 +152,7 @@ def main() -> None:
             "fused_leaf_levels": [g.depth for g in circuit._groups],
             "fused_tail_layers": len(circuit._tail),
             "contraction": args.contraction,
+            "dense_on_table": circuit.dense_on_table,
             "params_recomputed_every_step": True,
         },
         "check": {"mean_ll": total_nll / max(total_rows, 1.0), "rows": total_rows},

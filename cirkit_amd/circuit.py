@@ -66,6 +66,10 @@ class HipCircuit:
             (v_mfma_f32_32x32x2_f32).  ``"f16x3"``: 3-term split-fp16 products with fp32 accumulation
             on the matrix pipe (~22-bit effective significand, see cirkit_amd/csrc/ck_tile.h);
             layers that are not eligible stay on the exact path.
+        dense_on_table: a Categorical input layer followed fold-by-fold by a dense sum layer only
+            takes C distinct values per fold, so the dense layer is applied once per forward to the
+            (F, C, K) log-probability table (same kernel, batch = C) instead of to every batch row;
+            bit-identical results, B/C times less work for that layer.
     """
 
     def __init__(
@@ -78,6 +82,7 @@ class HipCircuit:
         fuse: bool | int = True,
         batch_params: bool = True,
         contraction: str = "f32",
+        dense_on_table: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -130,6 +135,7 @@ class HipCircuit:
         if contraction == "f16x3" and not batch_params:
             raise ValueError("contraction='f16x3' needs batch_params=True (the prologue writes the split weights)")
         self.contraction = contraction
+        self.dense_on_table = bool(dense_on_table)
         self._assign_weight_layouts()
 
     def _assign_weight_layouts(self) -> None:
@@ -294,10 +300,27 @@ class HipCircuit:
             self._group_dev[g.root] = dev
         cat = self.layers[g.input_layer]
         w_dense = None if g.dense_layer is None else self.layers[g.dense_layer]._w
+        table = cat._table
+        if w_dense is not None and self.dense_on_table and g.depth > 0:
+            # push the dense layer through the table: T'[d] = dense_d(table[leaf(d)]) over the C categories
+            dl = self.layers[g.dense_layer]
+            Cn, K = cat.num_categories, cat.num_output_units
+            if len(dev) == 1:
+                leaf_of_dense = self._children[g.dense_layer][:, 0, 1].astype(np.int64)
+                dev = dev + (
+                    torch.empty((dl.num_folds, Cn, K), dtype=torch.float32, device=self.device),
+                    torch.from_numpy(np.ascontiguousarray(leaf_of_dense * (Cn * K))).to(self.device),
+                )
+                self._group_dev[g.root] = dev
+            capi.call(
+                "ck_sum_lse_fwd", table.data_ptr(), dev[2].data_ptr(), w_dense.data_ptr(), dev[1].data_ptr(),
+                dl.num_folds, 1, Cn, K, K, capi.CK_SUM_CAT, dl._w_layout, stream,
+            )
+            table, w_dense = dev[1], None
         levels = (C.c_void_p * max(1, g.depth))(*[self.layers[j]._w.data_ptr() for j in g.levels])
         node_off = (C.c_int32 * (g.depth + 1))(*g.node_off)
         capi.call(
-            "ck_subtree_cat_cpt_fwd", cat._table.data_ptr(), bd.xt.data_ptr(), cat._scope(self.device).data_ptr(),
+            "ck_subtree_cat_cpt_fwd", table.data_ptr(), bd.xt.data_ptr(), cat._scope(self.device).data_ptr(),
             None if w_dense is None else w_dense.data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off,
             out.data_ptr(), g.depth, self.layers[g.root].num_folds, bd.B, cat.num_output_units,
             cat.num_categories, self._group_layout(g), stream,
@@ -396,7 +419,8 @@ class HipCircuit:
         l, s = self.layers[i], self.plan.layers[i]
         if i in self._group_of_root:
             g = self._group_of_root[i]
-            return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if g.dense_layer is not None else 'false'}, "
+            in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)
+            return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")
         if s.type in ("categorical", "embedding"):
             return "gather_rows_vec" if l.num_output_units % 4 == 0 else "gather_rows_scalar"

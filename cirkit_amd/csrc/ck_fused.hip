@@ -107,8 +107,12 @@ __global__ void __launch_bounds__(256) subtree_cat_cpt_kernel(const SubtreeArgs 
     const int v = a.xt[a.scope[leaf_ids[i]] * static_cast<int64_t>(a.B) + bl];
     xv[i] = min(max(v, 0), a.C - 1);  // memory safety; the reference raises on out-of-range categories
   }
+  // table fold: the input-layer fold when the dense layer runs in this kernel, else the level-0
+  // fold (= the input fold for cp-t plans, or the dense fold when the host has already pushed the
+  // dense layer through the table, see cirkit_amd/circuit.py `dense_on_table`)
   auto row_ptr = [&](int i) {
-    return a.table + (static_cast<int64_t>(leaf_ids[i]) * a.C + xv[i]) * kK + 4 * kh;
+    const int tf = HAS_DENSE ? leaf_ids[i] : dense_ids[i];
+    return a.table + (static_cast<int64_t>(tf) * a.C + xv[i]) * kK + 4 * kh;
   };
 
   WRegs wcur, wnxt;

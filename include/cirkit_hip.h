@@ -146,7 +146,10 @@ int ck_tensordot_lse_fwd_c(const float* arena_c, const int64_t* row_off, const f
  * ck_sum_lse_fwd (reference: input.py:399-412, inner.py:266-273, optimized.py:171-178,
  * semiring.py:383-408); K must be 32.
  *   table (F0,C,K), xt (D,B) int32, scope (F0): as ck_categorical_fwd;
- *   w_dense: (F_dense,K,K) linear weights or NULL when the leaves feed the CP-T layers directly;
+ *   w_dense: (F_dense,K,K) linear weights, or NULL when the leaves feed the CP-T layers directly --
+ *            the table is then indexed by the LEVEL-0 fold (node_off[0] table), which lets a caller
+ *            apply a dense layer to the (F,C,K) table itself first (one ck_sum_lse_fwd with B = C:
+ *            a categorical input has only C distinct values per fold) and fuse only the CP-T levels;
  *   w_levels: HOST array of `depth` device pointers, w_levels[l-1] = (F_l,K,K) weights of level l;
  *   nodes: DEVICE int32 tables; node_off: HOST array of depth+1 offsets into `nodes`:
  *          nodes+node_off[l] is (F_root, 2^(depth-l)) = fold (in level l's layer) of every node of

@@ -250,6 +250,24 @@ def test_split_fp16_contraction_is_fp32_class(hip_device, fuse):
     assert float(((ya - yb).abs() / yb.abs()).max()) <= 2e-6
 
 
+def test_dense_on_table_is_bit_identical(hip_device):
+    """Applying the dense layer to the (F, C, K) table instead of to every batch row is the same
+    arithmetic on the same values: outputs must be bit-for-bit equal."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    x = _x_of(plan, g).to(hip_device)
+    for contraction in ("f32", "f16x3"):
+        a = HipCircuit(plan, tensors, device=hip_device, use_graph=False, contraction=contraction, dense_on_table=True)
+        b = HipCircuit(plan, tensors, device=hip_device, use_graph=False, contraction=contraction, dense_on_table=False)
+        ya, yb = a(x).clone(), b(x).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), float((ya - yb).abs().max())
+        oa, ob = a.layer_outputs(x), b.layer_outputs(x)
+        torch.cuda.synchronize()
+        assert torch.equal(oa[5], ob[5])
+
+
 def test_ll_sum(hip_device):
     from cirkit_amd.circuit import HipCircuit
 
