@@ -54,7 +54,7 @@ def main() -> None:
 
     from cirkit_amd.circuit import HipCircuit
     from cirkit_amd.initializers import init_plan_tensors
-    from cirkit_amd.plan import Plan
+    from cirkit_amd.templates import image_data
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -74,7 +74,10 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    plan = Plan.load(os.path.join(ROOT, "tests", "golden", "cfg2_qt784"))
+    # BASELINE configs[1], built natively (cirkit_amd/templates.py; identical to the plan the reference
+    # compiles -- tests/test_templates.py pins it against the committed reference fixture)
+    plan = image_data((1, 28, 28), region_graph="quad-tree-2", input_layer="categorical", num_input_units=32,
+                      sum_product_layer="cp", num_sum_units=32)
     tensors = init_plan_tensors(plan)
     B = args.batch
     fuse = True if args.fuse < 0 else (False if args.fuse == 0 else args.fuse)

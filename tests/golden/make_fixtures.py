@@ -181,7 +181,36 @@ def kats():
         _save(f"kat_gaussian_{tag}", plan, extra)
 
 
+def plans_only():
+    """Plan-only fixtures (no outputs) that pin the native plan builders of cirkit_amd/templates.py on
+    awkward shapes: odd borders, single rows, quad-tree-4, deeper random trees."""
+    ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)
+    cases = []
+    for (h, w), rgname, sp in [((5, 7), "quad-tree-2", "cp"), ((3, 3), "quad-tree-2", "cp-t"), ((1, 6), "quad-tree-2", "cp"),
+                               ((6, 1), "quad-tree-2", "cp-t"), ((9, 4), "quad-tree-4", "cp"), ((2, 2), "quad-tree-2", "cp"),
+                               ((7, 7), "quad-tree-4", "cp-t")]:
+        sc = data_modalities.image_data((1, h, w), rgname, input_layer="categorical", num_input_units=3,
+                                        sum_product_layer=sp, num_sum_units=3)
+        cases.append((f"plan_{rgname.replace('-', '')}_{h}x{w}_{sp.replace('-', '')}", sc))
+    for n, depth, sp in [(13, None, "cp"), (6, 2, "cp-t"), (21, 3, "cp")]:
+        kw = {} if depth is None else {"region_graph_args": {"depth": depth}}
+        try:
+            sc = data_modalities.tabular_data("random-binary-tree", num_features=n,
+                                              input_layers={"name": "categorical", "args": {"num_categories": 3}},
+                                              num_input_units=2, sum_product_layer=sp, num_sum_units=2, **kw)
+        except TypeError:
+            if depth is not None:
+                continue
+            raise
+        cases.append((f"plan_rbt{n}_d{depth}_{sp.replace('-', '')}", sc))
+    for name, sc in cases:
+        plan, _ = plan_from_torch_circuit(ctx.compile(sc))
+        plan.name = name
+        plan.save(os.path.join(HERE, name))
+        print(name, len(plan.layers), "layers")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "plans_only"]
     for w in which:
         globals()[w]()
