@@ -246,34 +246,90 @@ __device__ __forceinline__ void softmax_job_table(const ck_softmax_job& j, int f
   const int C = j.len, K = j.k, ld = C + 1;
   const float* src = j.in + static_cast<int64_t>(f) * K * C;
   float* stat = tile + K * ld;  // [K] max, [K] log-sum
-  // phase 1: the whole (K, C) block of logits, coalesced, every load in flight at once
-  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
-    const int k = i / C, c = i - k * C;
-    tile[k * ld + c] = src[i];
-  }
-  __syncthreads();
-  // phase 2: per-row max and log-sum-exp from LDS
-  for (int k = wave; k < K; k += 4) {
-    const float* row = tile + k * ld;
-    float mx = -INFINITY;
-    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
-    mx = ck::wave_max(mx);
-    float sum = 0.f;
-    for (int c = lane; c < C; c += 64) sum += __expf(row[c] - mx);
-    sum = ck::wave_sum(sum);
-    if (lane == 0) {
-      stat[k] = mx;
-      stat[K + k] = __logf(sum);
+  // phase 1: the whole (K, C) block of logits, coalesced 16-byte loads, all in flight at once
+  if ((C & 3) == 0) {
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    for (int i = threadIdx.x; i < (K * C) >> 2; i += blockDim.x) {
+      const float4 v = src4[i];
+      const int e = i << 2, k = e / C, c = e - k * C;
+      float* d = tile + k * ld + c;
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+      const int k = i / C, c = i - k * C;
+      tile[k * ld + c] = src[i];
     }
   }
   __syncthreads();
-  // phase 3: out[c][k] = log(exp(d)/sum), d = theta - max; written coalesced (k fastest)
+  // phase 2: per-row max and log-sum-exp from LDS; 8 rows per wave pass so that the 2 x 6 shuffle
+  // steps of the reductions of different rows overlap
+  for (int k0 = wave; k0 < K; k0 += 32) {
+    float mx[8], sum[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = min(k0 + 4 * r, K - 1);
+      const float* row = tile + k * ld;
+      float m = -INFINITY;
+      for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+      mx[r] = m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = min(k0 + 4 * r, K - 1);
+      const float* row = tile + k * ld;
+      float sacc = 0.f;
+      for (int c = lane; c < C; c += 64) sacc += __expf(row[c] - mx[r]);
+      sum[r] = sacc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum[r] += __shfl_xor(sum[r], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int k = k0 + 4 * r;
+        if (k < K) {
+          stat[k] = mx[r];
+          stat[K + k] = __logf(sum[r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // phase 3: out[c][k] = log(exp(d)/sum), d = theta - max; written coalesced (k fastest), 16 B per lane
+  // exp(d) underflows to 0 below ~-103.97 -> the reference yields log(0) = -inf
   float* dst = j.out + static_cast<int64_t>(f) * C * K;
-  for (int i = threadIdx.x; i < C * K; i += blockDim.x) {
-    const int c = i / K, k = i - c * K;
-    const float d = tile[k * ld + c] - stat[k];
-    // exp(d) underflows to 0 below ~-103.97 -> the reference yields log(0) = -inf
-    dst[i] = d < -103.9f ? -INFINITY : d - stat[K + k];
+  if ((K & 3) == 0) {
+    const int k4n = K >> 2;
+    for (int i = threadIdx.x; i < C * k4n; i += blockDim.x) {
+      const int c = i / k4n, k = (i - c * k4n) << 2;
+      float4 o;
+      float d;
+      d = tile[(k + 0) * ld + c] - stat[k + 0];
+      o.x = d < -103.9f ? -INFINITY : d - stat[K + k + 0];
+      d = tile[(k + 1) * ld + c] - stat[k + 1];
+      o.y = d < -103.9f ? -INFINITY : d - stat[K + k + 1];
+      d = tile[(k + 2) * ld + c] - stat[k + 2];
+      o.z = d < -103.9f ? -INFINITY : d - stat[K + k + 2];
+      d = tile[(k + 3) * ld + c] - stat[k + 3];
+      o.w = d < -103.9f ? -INFINITY : d - stat[K + k + 3];
+      reinterpret_cast<float4*>(dst)[i] = o;
+    }
+  } else {
+    for (int i = threadIdx.x; i < C * K; i += blockDim.x) {
+      const int c = i / K, k = i - c * K;
+      const float d = tile[k * ld + c] - stat[k];
+      dst[i] = d < -103.9f ? -INFINITY : d - stat[K + k];
+    }
   }
 }
 
