@@ -68,11 +68,17 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
-    device = torch.device(f"cuda:{local_rank}")
+    # one process per GPU; BENCH_DIST_BACKEND=gloo lets the N > 1 path be exercised on a 1-GPU box
+    # (ranks then share the device; RCCL itself refuses two ranks on one GPU)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    device = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # BASELINE configs[1], built natively (cirkit_amd/templates.py; identical to the plan the reference
     # compiles -- tests/test_templates.py pins it against the committed reference fixture)

@@ -13,6 +13,7 @@ ABI_VERSION = 2
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
+CK_SUM_KRON = 2
 CK_W_ROWMAJOR = 0
 CK_W_TILED_F32 = 1
 CK_W_TILED_F16X3 = 2

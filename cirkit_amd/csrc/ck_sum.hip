@@ -172,6 +172,7 @@ struct Num<float> {
   static __device__ __forceinline__ float zero() { return 0.f; }
   static __device__ __forceinline__ float re(float a) { return a; }
   static __device__ __forceinline__ float add(float a, float b) { return a + b; }
+  static __device__ __forceinline__ float mul(float a, float b) { return a * b; }
   static __device__ __forceinline__ float exp_shift(float a, float m) { return __expf(a - m); }
   static __device__ __forceinline__ float log_shift(float a, float m) { return __logf(a) + m; }
 };
@@ -180,6 +181,9 @@ struct Num<c32> {
   static __device__ __forceinline__ c32 zero() { return {0.f, 0.f}; }
   static __device__ __forceinline__ float re(c32 a) { return a.re; }
   static __device__ __forceinline__ c32 add(c32 a, c32 b) { return ck::c_add(a, b); }
+  static __device__ __forceinline__ c32 mul(c32 a, c32 b) {
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+  }
   static __device__ __forceinline__ c32 exp_shift(c32 a, float m) { return ck::c_exp_shift(a, m); }
   static __device__ __forceinline__ c32 log_shift(c32 a, float m) { return ck::c_log_shift(a, m); }
 };
@@ -203,7 +207,7 @@ __global__ void __launch_bounds__(256)
                     int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TB = 4 * RPT;
-  const int N = mode == CK_SUM_PROD ? Ki : H * Ki;
+  const int N = mode == CK_SUM_PROD ? Ki : (mode == CK_SUM_KRON ? Ki * Ki : H * Ki);
   AT* e_s = reinterpret_cast<AT*>(smem);                          // [TB][N]
   WT* w_s = reinterpret_cast<WT*>(e_s + static_cast<size_t>(TB) * N);  // [kGenOT][kGenNC+1]
   float* m_s = reinterpret_cast<float*>(w_s + kGenOT * (kGenNC + 1));  // [TB]
@@ -214,6 +218,30 @@ __global__ void __launch_bounds__(256)
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
 
   // phase A: gather v (cat or product of children), row maximum, e = exp(v - m) into LDS
+  if (mode == CK_SUM_KRON) {
+    // Tucker (optimized.py:89-103): one maximum PER INPUT, e[i*Ki + j] = exp(x0[i]-m0) exp(x1[j]-m1),
+    // the outer product is formed in LDS and never reaches memory.  The tail of e_s is scratch.
+    for (int r = wave; r < TB; r += 4) {
+      const int b = min(b0 + r, B - 1);
+      AT* er = e_s + static_cast<size_t>(r) * N;
+      float m01[2];
+      for (int h = 0; h < 2; ++h) {
+        float mx = -INFINITY;
+        for (int k = lane; k < Ki; k += 64) mx = fmaxf(mx, Num<AT>::re(arena[ro[h] + static_cast<int64_t>(b) * Ki + k]));
+        m01[h] = ck::clamp_finite(ck::wave_max(mx));
+      }
+      AT* xr = reinterpret_cast<AT*>(m_s + TB) + static_cast<size_t>(r) * 2 * Ki;  // [2][Ki] shifted inputs
+      for (int h = 0; h < 2; ++h)
+        for (int k = lane; k < Ki; k += 64)
+          xr[h * Ki + k] = Num<AT>::exp_shift(arena[ro[h] + static_cast<int64_t>(b) * Ki + k], m01[h]);
+      __builtin_amdgcn_wave_barrier();
+      for (int n = lane; n < N; n += 64) {
+        const int i = n / Ki, jj = n - i * Ki;
+        er[n] = Num<AT>::mul(xr[i], xr[Ki + jj]);
+      }
+      if (lane == 0) m_s[r] = m01[0] + m01[1];
+    }
+  } else
   for (int r = wave; r < TB; r += 4) {
     const int b = min(b0 + r, B - 1);
     float mx = -INFINITY;
@@ -275,9 +303,10 @@ __global__ void __launch_bounds__(256)
 template <typename AT, typename WT>
 int launch_generic(const AT* arena, const int64_t* row_off, const WT* w, AT* out, int F, int H,
                    int B, int Ki, int Ko, int mode, void* stream) {
-  const int N = mode == CK_SUM_PROD ? Ki : H * Ki;
+  const int N = mode == CK_SUM_PROD ? Ki : (mode == CK_SUM_KRON ? Ki * Ki : H * Ki);
   auto lds_bytes = [&](int tb) {
-    return static_cast<size_t>(tb) * N * sizeof(AT) + kGenOT * (kGenNC + 1) * sizeof(WT) + tb * sizeof(float);
+    return static_cast<size_t>(tb) * N * sizeof(AT) + kGenOT * (kGenNC + 1) * sizeof(WT) + tb * sizeof(float) +
+           (mode == CK_SUM_KRON ? static_cast<size_t>(tb) * 2 * Ki * sizeof(AT) : 0);
   };
   int rpt = 4;
   while (rpt > 1 && lds_bytes(4 * rpt) > 64 * 1024) rpt >>= 1;
@@ -309,7 +338,8 @@ int check_sum_args(const void* arena, const void* row_off, const void* w, const 
   CK_REQUIRE(arena && row_off && w && out, "%s: null pointer", who);
   CK_REQUIRE(F > 0 && H > 0 && B > 0 && Ki > 0 && Ko > 0, "%s: non-positive size F=%d H=%d B=%d Ki=%d Ko=%d",
              who, F, H, B, Ki, Ko);
-  CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD, "%s: unknown mode %d", who, mode);
+  CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD || mode == CK_SUM_KRON, "%s: unknown mode %d", who, mode);
+  CK_REQUIRE(mode != CK_SUM_KRON || H == 2, "%s: CK_SUM_KRON (Tucker) needs arity 2, found %d", who, H);
   CK_REQUIRE(F <= 65535, "%s: F=%d exceeds grid.y", who, F);
   return CK_OK;
 }

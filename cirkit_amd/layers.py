@@ -573,6 +573,30 @@ class HipCPTLayer(HipSumLayer):
         return self.num_output_units, self.num_input_units
 
 
+class HipTuckerLayer(HipSumLayer):
+    """``TorchTuckerLayer`` (layers/optimized.py:17-103), arity 2: weight (Ko, Ki**2); one maximum
+    per input, the Kronecker product of the two shifted inputs is formed on chip."""
+
+    _mode = capi.CK_SUM_KRON
+
+    def __init__(self, num_input_units: int, num_output_units: int, arity: int = 2, *, weight: HipParameter,
+                 semiring: str | None = None, num_folds: int = 1) -> None:
+        if arity != 2:
+            raise NotImplementedError("Tucker layers of arity != 2")
+        super().__init__(num_input_units, num_output_units, arity, weight=weight, semiring=semiring, num_folds=num_folds)
+
+    @property
+    def _weight_shape(self) -> tuple[int, ...]:
+        return self.num_output_units, self.num_input_units**self.arity
+
+    def _is_mixing(self) -> bool:
+        return False
+
+    @property
+    def tile32_eligible(self) -> bool:
+        return False
+
+
 class HipTensorDotLayer(HipInnerLayer):
     """``TorchTensorDotLayer`` (layers/optimized.py:181-300)."""
 
@@ -642,6 +666,7 @@ LAYER_CLASSES: dict[str, type] = {
     "hadamard": HipHadamardLayer,
     "kronecker": HipKroneckerLayer,
     "tensordot": HipTensorDotLayer,
+    "tucker": HipTuckerLayer,
 }
 
 

@@ -40,6 +40,8 @@ typedef enum ck_status {
 /* modes of ck_sum_lse_fwd */
 #define CK_SUM_CAT 0  /* TorchSumLayer: children concatenated -> N = H*Ki inputs        */
 #define CK_SUM_PROD 1 /* TorchCPTLayer: children multiplied (log-space add) -> N = Ki   */
+#define CK_SUM_KRON 2 /* TorchTuckerLayer (arity 2): Kronecker of the children -> N = Ki*Ki,
+                         one maximum per child (optimized.py:89-103)                     */
 
 /* weight layouts of the Ki = Ko = 32 sum kernels (cirkit_amd/csrc/ck_tile.h).  The tiled layouts
  * are written by ck_param_softmax_batch (job kinds 2 / 3). */

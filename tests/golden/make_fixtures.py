@@ -181,6 +181,19 @@ def kats():
         _save(f"kat_gaussian_{tag}", plan, extra)
 
 
+def tucker():
+    """Tucker sum-product layers (Kronecker -> dense fused into TorchTuckerLayer): small QuadTree."""
+    sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", input_layer="categorical", num_input_units=6,
+                                    sum_product_layer="tucker", num_sum_units=6)
+    cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+    plan, tensors = plan_from_torch_circuit(cc)
+    _load_closed_form(plan, tensors)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randint(0, 256, (24, 16), generator=g)
+    _save("tucker_qt16_k6", plan, {"x": x.numpy().astype(np.int16), "y_f32": cc(x).numpy(),
+                                   "y_f64": _fp64_copy(cc)(x).numpy()})
+
+
 def plans_only():
     """Plan-only fixtures (no outputs) that pin the native plan builders of cirkit_amd/templates.py on
     awkward shapes: odd borders, single rows, quad-tree-4, deeper random trees."""
@@ -211,6 +224,6 @@ def plans_only():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "plans_only"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only"]
     for w in which:
         globals()[w]()

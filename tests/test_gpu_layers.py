@@ -75,6 +75,30 @@ def test_cpt_layer_contract(hip_device, F, H, B, Ki, Ko):
     _close(layer.forward(x.to(hip_device)), _oracle(spec, {"w": w}, x))
 
 
+@pytest.mark.parametrize("F,B,Ki,Ko,cplx", [(3, 37, 6, 5, False), (2, 9, 32, 32, False), (1, 5, 64, 8, False), (2, 7, 4, 3, True)])
+def test_tucker_layer_contract(hip_device, F, B, Ki, Ko, cplx):
+    from cirkit_amd.layers import HipTuckerLayer
+    from cirkit_amd.parameters import TensorStore
+
+    g = torch.Generator().manual_seed(F * 10 + Ki)
+    w = torch.softmax(torch.randn(F, Ko, Ki * Ki, generator=g), dim=-1)
+    x = torch.randn(F, 2, B, Ki, generator=g) * 3 - 4
+    sem = "lse-sum"
+    if cplx:
+        x = torch.complex(x, torch.randn(F, 2, B, Ki, generator=g))
+        w = w - 0.5 / (Ki * Ki)
+        sem = "complex-lse-sum"
+    store = TensorStore(hip_device)
+    p, pg = _pg(store, "w", w)
+    layer = HipTuckerLayer(Ki, Ko, 2, weight=p, semiring=sem, num_folds=F)
+    spec = LayerSpec("tucker", F, 2, Ki, Ko, dict(layer.config), {"weight": pg})
+    got, want = layer.forward(x.to(hip_device)).cpu(), _oracle(spec, {"w": w}, x, sem)
+    if cplx:
+        assert float((got.real - want.real).abs().max()) <= 2e-4 * max(1.0, float(want.real.abs().max()))
+    else:
+        _close(got, want)
+
+
 def test_lse_edge_values(hip_device):
     """Rows that are entirely -inf give -inf (amax clamped to finfo.min, semiring.py:392-399), single
     finite entries survive, and a 200-nat spread does not underflow the result."""

@@ -99,7 +99,7 @@ def _check_complex_layers_locally(plan, tensors, x, hc, outs_ref, atol_scale):
         assert float(ph.max()) <= 1e-3 + 4.0 * float(ph_ref.max()), (i, spec.type, float(ph.max()), float(ph_ref.max()))
 
 
-@pytest.mark.parametrize("name", ["cfg1_rbt8", "cfg2_qt784", "cfg2t_qt784_cpt16", "cfg4_pd784"])
+@pytest.mark.parametrize("name", ["cfg1_rbt8", "cfg2_qt784", "cfg2t_qt784_cpt16", "cfg4_pd784", "tucker_qt16_k6"])
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("fuse", [False, 1, 2, 3, True])
 def test_real_configs_match_reference(hip_device, name, use_graph, fuse):
