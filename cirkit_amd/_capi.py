@@ -70,6 +70,14 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_mixing_weight": [_p, _p, _i, _i, _i, _p],
     "ck_param_bmm": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_param_transpose_last2": [_p, _p, _l, _i, _i, _i, _p],
+    "ck_fill_f32": [_p, _l, _f, _p],
+    "ck_sum_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_hadamard_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_categorical_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_param_softmax_bwd": [_p, _p, _p, _l, _i, _i, _p],
+    "ck_param_log_table_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p],
+    "ck_sgd_step": [_p, _p, _l, _f, _f, _p],
     "ck_ll_sum": [_p, _l, _l, _p, _p],
     "ck_program_begin": [C.POINTER(_p)],
     "ck_program_end": [_p],

@@ -83,6 +83,7 @@ class HipCircuit:
         batch_params: bool = True,
         contraction: str = "f32",
         dense_on_table: bool = True,
+        tiled_weights: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -136,6 +137,9 @@ class HipCircuit:
             raise ValueError("contraction='f16x3' needs batch_params=True (the prologue writes the split weights)")
         self.contraction = contraction
         self.dense_on_table = bool(dense_on_table)
+        self.tiled_weights = bool(tiled_weights)
+        if contraction == "f16x3" and not tiled_weights:
+            raise ValueError("contraction='f16x3' needs tiled_weights=True")
         self._assign_weight_layouts()
 
     def _assign_weight_layouts(self) -> None:
@@ -143,7 +147,8 @@ class HipCircuit:
         the batched prologue can write them, and uniformly inside a fused launch."""
         tiled = capi.CK_W_TILED_F16X3 if self.contraction == "f16x3" else capi.CK_W_TILED_F32
         elig = {
-            i: self.batch_params and getattr(l, "tile32_eligible", False) for i, l in enumerate(self.layers)
+            i: self.batch_params and self.tiled_weights and getattr(l, "tile32_eligible", False)
+            for i, l in enumerate(self.layers)
         }
         layout = {i: (tiled if ok else capi.CK_W_ROWMAJOR) for i, ok in elig.items()}
         for g in self._groups:

@@ -1,0 +1,222 @@
+"""Training step on the HIP backend: forward, backward, optimiser -- SURVEY.md section 8 (f3).
+
+The reference trains with autograd through its torch forward (notebooks/learning-a-circuit.ipynb,
+cell 18: ``loss = -torch.mean(circuit(batch)); loss.backward(); optimizer.step()``).  Here the
+forward is the layer-wise HIP path with every layer output kept in the arena, and the backward is a
+second launch list of hand-written kernels (cirkit_amd/csrc/ck_backward.hip) walking the plan in
+reverse.  Data-parallel training = one process per GPU, the batch sharded, and ONE all-reduce of a
+single flat gradient buffer (all parameter gradients are views of it) over RCCL/xGMI per step.
+
+Covered: real lse-sum circuits made of Categorical (probs = softmax), Sum / CP-T (softmax or raw
+weights) and Hadamard layers -- BASELINE configs 1-3.  Other layers raise NotImplementedError.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping
+
+import numpy as np
+import torch
+
+from . import _capi as capi
+from .circuit import HipCircuit
+from .layers import HipCategoricalLayer, HipCPTLayer, HipHadamardLayer, HipSumLayer
+from .plan import Plan
+
+
+class HipTrainer:
+    """Maximum-likelihood training of a plan's parameters: ``loss = -mean_b log p(x_b)``."""
+
+    def __init__(
+        self,
+        plan: Plan,
+        tensors: Mapping[str, object],
+        *,
+        device: str | torch.device = "cuda:0",
+        lr: float = 0.01,
+        optimizer: str = "adam",
+        betas: tuple[float, float] = (0.9, 0.999),
+        eps: float = 1e-8,
+    ) -> None:
+        if plan.semiring != "lse-sum":
+            raise NotImplementedError("training is implemented for the real lse-sum semiring")
+        if optimizer not in ("adam", "sgd"):
+            raise ValueError(f"unknown optimizer {optimizer!r}")
+        # layer-wise forward, every activation materialised, row-major linear weights
+        self.circuit = HipCircuit(plan, tensors, device=device, use_graph=False, fuse=False,
+                                  batch_params=True, tiled_weights=False, dense_on_table=False)
+        self.plan, self.device = plan, self.circuit.device
+        self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
+        self.step_count = 0
+        c = self.circuit
+        if len(c._out_pairs) != 1:
+            raise NotImplementedError("training needs a single circuit output")
+        self._check_supported()
+        # one flat gradient buffer; per-tensor gradients are views of it (single all-reduce)
+        names = list(plan.tensors)
+        sizes = [int(np.prod(plan.tensors[n][0])) for n in names]
+        self._flat_grad = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
+        self.grads: dict[str, torch.Tensor] = {}
+        off = 0
+        for n, sz in zip(names, sizes):
+            self.grads[n] = self._flat_grad[off : off + sz].view(plan.tensors[n][0])
+            off += sz
+        self._m1 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
+        self._m2 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
+        self._moments: dict[str, tuple] = {}
+        if optimizer == "adam":
+            off = 0
+            for n, sz in zip(names, sizes):
+                self._moments[n] = (self._m1[off : off + sz], self._m2[off : off + sz])
+                off += sz
+        self._bwd: dict[int, dict] = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _check_supported(self) -> None:
+        for spec, l in zip(self.plan.layers, self.circuit.layers):
+            if isinstance(l, HipCategoricalLayer):
+                if l.probs is None or l.probs.softmax_source() is None:
+                    raise NotImplementedError("training: Categorical layers need probs = softmax(tensor)")
+            elif isinstance(l, (HipSumLayer, HipCPTLayer)) and type(l) in (HipSumLayer, HipCPTLayer):
+                if l._mixing:
+                    raise NotImplementedError("training: mixing layers")
+                ops = l.weight.ops
+                if ops not in (["tensor", "softmax"], ["tensor"]) or (ops == ["tensor", "softmax"] and l.weight.softmax_source() is None):
+                    raise NotImplementedError(f"training: weight parameterisation {ops}")
+            elif isinstance(l, HipHadamardLayer):
+                pass
+            else:
+                raise NotImplementedError(f"training: layer type {spec.type!r}")
+
+    def _accumulate_flags(self) -> tuple[dict[int, int], set[int]]:
+        """Per consumer layer: 0 store / 1 add / 2 atomic; and the producer layers whose gradient
+        block must be zeroed first."""
+        c = self.circuit
+        consumers: dict[int, list[int]] = {}
+        dup_in_layer: dict[int, bool] = {}
+        for j, ch in enumerate(c._children):
+            if ch is None:
+                continue
+            pairs = ch.reshape(-1, 2)
+            dup_in_layer[j] = len(np.unique(pairs, axis=0)) != len(pairs)
+            for p in np.unique(pairs[:, 0]):
+                consumers.setdefault(int(p), []).append(j)
+        need_zero = {p for p, js in consumers.items() if len(js) > 1 or any(dup_in_layer[j] for j in js)}
+        flags: dict[int, int] = {}
+        for j, ch in enumerate(c._children):
+            if ch is None:
+                continue
+            prods = {int(p) for p in np.unique(ch[..., 0])}
+            if dup_in_layer[j]:
+                flags[j] = 2
+            elif prods & need_zero:
+                flags[j] = 1
+            else:
+                flags[j] = 0
+        # a launch with flag 1/2 adds into ALL its producers: they all must start from zero
+        for j, fl in flags.items():
+            if fl:
+                need_zero |= {int(p) for p in np.unique(c._children[j][..., 0])}
+        return flags, need_zero
+
+    def _bind_backward(self, B: int) -> dict:
+        st = self._bwd.get(B)
+        bd = self.circuit._bind(B)
+        if st is not None and st["arena_ptr"] == bd.arena.data_ptr():
+            return st
+        c = self.circuit
+        garena = torch.zeros_like(bd.arena)
+        gviews = []
+        base = 0
+        for i, l in enumerate(c.layers):
+            n = l.num_folds * B * l.num_output_units
+            off = bd.views[i].data_ptr() - bd.arena.data_ptr()
+            gviews.append(garena.view(torch.uint8)[off : off + 4 * n].view(torch.float32).view(l.num_folds, B, l.num_output_units))
+        flags, need_zero = self._accumulate_flags()
+        dws = {}
+        for i, l in enumerate(c.layers):
+            if isinstance(l, (HipSumLayer, HipCPTLayer)):
+                dws[i] = torch.zeros_like(l._w) if l._w is not None else None
+            elif isinstance(l, HipCategoricalLayer):
+                dws[i] = torch.zeros_like(l._table)
+        st = {"arena_ptr": bd.arena.data_ptr(), "garena": garena, "gviews": gviews, "flags": flags,
+              "need_zero": need_zero, "dws": dws}
+        self._bwd[B] = st
+        return st
+
+    # ------------------------------------------------------------------------------------------
+    def loss_and_grads(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
+        """Forward + backward for ``loss = -(1/global_batch) sum_b log p(x_b)``; gradients land in
+        ``self.grads`` (views of one flat buffer).  Returns the device tensor [sum log p, count]."""
+        c = self.circuit
+        ll = c.log_likelihood_sum(x)  # forward (all activations stay in the arena)
+        B = int(x.shape[0])
+        bd = c._bind(B)
+        st = self._bind_backward(B)
+        for i, l in enumerate(c.layers):  # buffers allocated lazily by the first forward
+            if st["dws"].get(i, 0) is None:
+                st["dws"][i] = torch.zeros_like(l._w)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        gB = float(global_batch or B)
+        gviews, flags = st["gviews"], st["flags"]
+        for p in st["need_zero"]:
+            capi.call("ck_fill_f32", gviews[p].data_ptr(), gviews[p].numel(), 0.0, stream)
+        po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
+        if c.layers[po].num_output_units != 1:
+            raise NotImplementedError("training needs a scalar output unit")
+        capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel(), 0.0, stream)
+        capi.call("ck_fill_f32", gviews[po][fo].data_ptr(), B, -1.0 / gB, stream)
+        for i in range(len(c.layers) - 1, -1, -1):
+            l = c.layers[i]
+            if isinstance(l, HipCategoricalLayer):
+                dT = st["dws"][i]
+                capi.call("ck_fill_f32", dT.data_ptr(), dT.numel(), 0.0, stream)
+                capi.call("ck_categorical_bwd", gviews[i].data_ptr(), bd.xt.data_ptr(), l._scope(self.device).data_ptr(),
+                          dT.data_ptr(), l.num_folds, B, l.num_output_units, l.num_categories, stream)
+                name = l.probs.graph.nodes[0].config["tensor"]
+                capi.call("ck_param_log_table_bwd", l._table.data_ptr(), dT.data_ptr(), self.grads[name].data_ptr(),
+                          l.num_folds, l.num_output_units, l.num_categories, 0, stream)
+            elif isinstance(l, HipHadamardLayer):
+                capi.call("ck_hadamard_bwd", st["garena"].data_ptr(), bd.row_off[i].data_ptr(), gviews[i].data_ptr(),
+                          l.num_folds, l.arity, B, l.num_input_units, flags[i], stream)
+            else:  # sum / cpt
+                name = l.weight.graph.nodes[0].config["tensor"]
+                soft = l.weight.ops == ["tensor", "softmax"]
+                dW = st["dws"][i] if soft else self.grads[name]
+                capi.call("ck_fill_f32", dW.data_ptr(), dW.numel(), 0.0, stream)
+                capi.call("ck_sum_lse_bwd", bd.arena.data_ptr(), st["garena"].data_ptr(), bd.row_off[i].data_ptr(),
+                          l._w.data_ptr(), bd.views[i].data_ptr(), gviews[i].data_ptr(), dW.data_ptr(), l.num_folds,
+                          l.arity, B, l.num_input_units, l.num_output_units, l._mode, flags[i], stream)
+                if soft:
+                    rows = l.num_folds * l.num_output_units
+                    capi.call("ck_param_softmax_bwd", l._w.data_ptr(), dW.data_ptr(), self.grads[name].data_ptr(),
+                              rows, dW.shape[-1], 0, stream)
+        return ll
+
+    def all_reduce_grads(self) -> None:
+        """The one gradient exchange of data-parallel training: SUM over ranks of the flat buffer."""
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+
+    def apply_gradients(self) -> None:
+        self.step_count += 1
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        for n, g in self.grads.items():
+            p = self.circuit.store[n]
+            if self.optimizer == "adam":
+                m1, m2 = self._moments[n]
+                capi.call("ck_adam_step", p.data_ptr(), g.data_ptr(), m1.data_ptr(), m2.data_ptr(), p.numel(),
+                          self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, stream)
+            else:
+                capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, stream)
+
+    def step(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
+        """One optimisation step on this rank's shard; returns the device tensor [sum log p, count]
+        of the shard (before the update)."""
+        ll = self.loss_and_grads(x, global_batch=global_batch)
+        self.all_reduce_grads()
+        self.apply_gradients()
+        return ll

@@ -218,6 +218,38 @@ int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N
 int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int Bd, int take_log,
                              void* stream);
 
+/* ---------------------------------------------------------------- backward (training) ------ */
+/* Gradients of a scalar loss through the lse-sum forward -- what the reference gets from autograd
+ * through LSESumSemiring.apply_reduce (semiring.py:383-408) and the layer forwards.  `garena` mirrors
+ * the activation arena (same offsets).  accumulate: 0 store, 1 add (ordered launches), 2 atomic add
+ * (a producer fold read several times by this layer). */
+int ck_fill_f32(float* p, int64_t n, float value, void* stream);
+/* TorchSumLayer / TorchCPTLayer backward (modes CK_SUM_CAT / CK_SUM_PROD), row-major linear
+ * weights w (F,Ko,N): children gradients into garena, dW (F,Ko,N) accumulated with atomics
+ * (zero it first). out/gout: (F,B,Ko) forward output and its gradient. */
+int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* w,
+                   const float* out, const float* gout, float* dw, int F, int H, int B, int Ki, int Ko,
+                   int mode, int accumulate, void* stream);
+/* TorchHadamardLayer backward: every child receives gout (F,B,K). */
+int ck_hadamard_bwd(float* garena, const int64_t* row_off, const float* gout, int F, int H, int B, int K,
+                    int accumulate, void* stream);
+/* TorchCategoricalLayer backward: dtable[f,c,:] += sum_{b: x[b,scope f]=c} gout[f,b,:]  (dtable
+ * (F,C,K), same transposed layout as the forward table). */
+int ck_categorical_bwd(const float* gout, const int32_t* xt, const int64_t* scope, float* dtable, int F,
+                       int B, int K, int C, void* stream);
+/* softmax parameter backward over the last axis: dtheta = W * (dW - sum(W*dW)). */
+int ck_param_softmax_bwd(const float* w, const float* dw, float* dtheta, int64_t rows, int len,
+                         int accumulate, void* stream);
+/* Categorical probs backward: table (F,C,K) = transposed log softmax_C(theta (F,K,C));
+ * dtheta[f,k,c] = dT[f,c,k] - exp(T[f,c,k]) sum_c' dT[f,c',k]. */
+int ck_param_log_table_bwd(const float* table, const float* dtable, float* dtheta, int F, int K, int C,
+                           int accumulate, void* stream);
+/* Optimiser steps on one flat tensor; grad_scale multiplies the gradient first (e.g. 1/world). Adam
+ * follows torch.optim.Adam's defaults semantics (bias-corrected, no weight decay, no amsgrad). */
+int ck_adam_step(float* p, const float* g, float* m1, float* m2, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int step, float grad_scale, void* stream);
+int ck_sgd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, void* stream);
+
 /* ---------------------------------------------------------------- reductions --------------- */
 /* Sum of B log-likelihoods (stride in floats between consecutive rows) into out_dev[0] (fp64) and
  * the row count into out_dev[1]; the pair feeds the one RCCL all-reduce of the data-parallel NLL

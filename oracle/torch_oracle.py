@@ -267,6 +267,7 @@ def evaluate_plan(
     x: Tensor | None,
     *,
     return_all: bool = False,
+    grad: bool = False,
 ):
     """TorchCircuit.forward, circuits.py:242-278 + the interpreter loop graph/modules.py:303-335.
 
@@ -274,7 +275,9 @@ def evaluate_plan(
     ``return_all`` also the list of every layer's ``(F, B, Ko)`` output."""
     sr = _CLSE if plan.semiring == "complex-lse-sum" else _LSE
     outs: list[Tensor] = []
-    with torch.no_grad():
+    # grad=True keeps the autograd graph: the reference trains by back-propagating through exactly
+    # these ops (notebooks/learning-a-circuit.ipynb, `loss = -torch.mean(circuit(batch))`)
+    with torch.enable_grad() if grad else torch.no_grad():
         for l in plan.layers:
             params = {pn: eval_param(pg, tensors) for pn, pg in l.params.items()}
             if l.inputs is not None:  # circuits.py:39-48

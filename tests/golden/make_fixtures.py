@@ -194,6 +194,46 @@ def tucker():
                                    "y_f64": _fp64_copy(cc)(x).numpy()})
 
 
+def grads():
+    """Parameter gradients of loss = -mean(log p) from the reference's own autograd (training path,
+    notebooks/learning-a-circuit.ipynb cell 18).  cfg1: every gradient; cfg2 (B = 16): per-tensor
+    norm, sum and the first 16 entries."""
+    torch.set_grad_enabled(True)
+    try:
+        for name, build, xgen in [
+            ("cfg1_rbt8", lambda: data_modalities.tabular_data(
+                "random-binary-tree", num_features=8, input_layers={"name": "categorical", "args": {"num_categories": 4}},
+                num_input_units=4, sum_product_layer="cp", num_sum_units=4),
+             lambda g: torch.randint(0, 4, (32, 8), generator=g)),
+            ("cfg2_qt784", lambda: data_modalities.image_data(
+                (1, 28, 28), "quad-tree-2", input_layer="categorical", num_input_units=32,
+                sum_product_layer="cp", num_sum_units=32),
+             lambda g: torch.randint(0, 256, (16, 784), generator=g)),
+        ]:
+            cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(build())
+            plan, tensors = plan_from_torch_circuit(cc)
+            with torch.no_grad():
+                _load_closed_form(plan, tensors)
+            g = torch.Generator().manual_seed(11)
+            x = xgen(g)
+            loss = -cc(x).mean()
+            loss.backward()
+            by_ptr = {p.data_ptr(): p for p in cc.parameters()}
+            extra = {"x": x.numpy().astype(np.int16), "loss": np.array(loss.item())}
+            for k, t in tensors.items():
+                gr = by_ptr[t.data_ptr()].grad
+                if name.startswith("cfg1"):
+                    extra["g_" + k] = gr.numpy()
+                else:
+                    extra["gnorm_" + k] = np.array(gr.norm().item())
+                    extra["gsum_" + k] = np.array(gr.double().sum().item())
+                    extra["ghead_" + k] = gr.reshape(-1)[:16].numpy()
+            np.savez_compressed(os.path.join(HERE, name + "_grads.npz"), **extra)
+            print(name, "grads:", {k: float(np.linalg.norm(v)) for k, v in extra.items() if k.startswith("g_")} or "summaries")
+    finally:
+        torch.set_grad_enabled(False)
+
+
 def plans_only():
     """Plan-only fixtures (no outputs) that pin the native plan builders of cirkit_amd/templates.py on
     awkward shapes: odd borders, single rows, quad-tree-4, deeper random trees."""
@@ -224,6 +264,6 @@ def plans_only():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads"]
     for w in which:
         globals()[w]()
