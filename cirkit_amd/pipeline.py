@@ -63,6 +63,16 @@ class HipPipelineContext:
         return HipCircuit(plan, tvals, device=self.device, use_graph=self.use_graph)
 
 
+def compile_unfolded(plan: Plan, tensors: Mapping[str, Any], **ctx_kwargs: Any) -> HipCircuit:
+    """An UNFOLDED plan (one fold per layer, e.g. extracted with ``fold=False, optimize=False`` or
+    written by hand) -> optimise + fold natively (cirkit_amd/compiler.py) -> `HipCircuit`."""
+    from .compiler import compile_plan
+
+    ctx = HipPipelineContext(**ctx_kwargs)
+    plan, vals = compile_plan(plan, tensors, fold=ctx.fold, optimize=ctx.optimize)
+    return ctx.compile(plan, vals)
+
+
 def compile(circuit: Any, tensors: Mapping[str, Any] | None = None, **ctx_kwargs: Any) -> HipCircuit:
     """``cirkit_amd.pipeline.compile(sc)`` -- see the module docstring."""
     return HipPipelineContext(**ctx_kwargs).compile(circuit, tensors)
