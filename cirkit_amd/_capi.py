@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -69,7 +69,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_conj": [_p, _p, _l, _p],
     "ck_param_mixing_weight": [_p, _p, _i, _i, _i, _p],
     "ck_param_bmm": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "ck_param_transpose_last2": [_p, _p, _l, _i, _i, _i, _p],
+    "ck_param_transpose_last2": [_p, _p, _l, _i, _i, _i, _i, _p],
+    "ck_param_table_integral_row": [_p, _i, _i, _i, _i, _p],
     "ck_fill_f32": [_p, _l, _f, _p],
     "ck_sum_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_hadamard_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],

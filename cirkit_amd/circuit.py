@@ -173,8 +173,8 @@ class HipCircuit:
     def num_variables(self) -> int:
         return self.plan.num_variables
 
-    def __call__(self, x: torch.Tensor | None = None) -> torch.Tensor:
-        return self.forward(x)
+    def __call__(self, x: torch.Tensor | None = None, *, integrate_vars=None) -> torch.Tensor:
+        return self.forward(x, integrate_vars=integrate_vars)
 
     def __del__(self) -> None:  # pragma: no cover - interpreter teardown order
         try:
@@ -312,14 +312,14 @@ class HipCircuit:
             Cn, K = cat.num_categories, cat.num_output_units
             if len(dev) == 1:
                 leaf_of_dense = self._children[g.dense_layer][:, 0, 1].astype(np.int64)
-                dev = dev + (
-                    torch.empty((dl.num_folds, Cn, K), dtype=torch.float32, device=self.device),
-                    torch.from_numpy(np.ascontiguousarray(leaf_of_dense * (Cn * K))).to(self.device),
+                dev = dev + (  # Cn + 1 rows: the integral row goes through the dense layer as well
+                    torch.empty((dl.num_folds, Cn + 1, K), dtype=torch.float32, device=self.device),
+                    torch.from_numpy(np.ascontiguousarray(leaf_of_dense * ((Cn + 1) * K))).to(self.device),
                 )
                 self._group_dev[g.root] = dev
             capi.call(
                 "ck_sum_lse_fwd", table.data_ptr(), dev[2].data_ptr(), w_dense.data_ptr(), dev[1].data_ptr(),
-                dl.num_folds, 1, Cn, K, K, capi.CK_SUM_CAT, dl._w_layout, stream,
+                dl.num_folds, 1, Cn + 1, K, K, capi.CK_SUM_CAT, dl._w_layout, stream,
             )
             table, w_dense = dev[1], None
         levels = (C.c_void_p * max(1, g.depth))(*[self.layers[j]._w.data_ptr() for j in g.levels])
@@ -346,6 +346,37 @@ class HipCircuit:
             if x.dtype != torch.int64:
                 x = x.to(torch.int64)  # float batches are truncated like `x.long()` (input.py:400-401)
             capi.call("ck_transpose_i64_to_i32", x.data_ptr(), bd.xt.data_ptr(), B, D, stream)
+
+    def _apply_integration_mask(self, x: torch.Tensor, integrate_vars) -> torch.Tensor:
+        """Marginalisation (IntegrateQuery, cirkit/backend/torch/queries.py:19-184): a boolean mask
+        ``(B, D)`` / ``(1, D)`` / ``(D,)`` or an iterable of variable ids.  Masked entries are replaced by
+        the sentinel the input kernels understand (negative category / NaN), which makes them emit
+        the layer's integral instead of a likelihood."""
+        D = self.plan.num_variables
+        if not isinstance(integrate_vars, torch.Tensor):
+            ids = sorted(int(v) for v in integrate_vars)
+            if ids and (ids[0] < 0 or ids[-1] >= D):
+                raise ValueError("The variables to marginalize must be a subset of the circuit scope")
+            mask = torch.zeros((1, D), dtype=torch.bool)
+            mask[0, ids] = True
+        else:
+            mask = integrate_vars
+            if mask.dtype != torch.bool:
+                raise ValueError(f"Expected dtype of tensor to be torch.bool, got {mask.dtype}")
+            if mask.dim() == 1:
+                mask = mask.unsqueeze(0)
+            if mask.shape[1] != D:
+                raise ValueError(f"Circuit scope has {D} variables but integrate_vars was defined over "
+                                 f"{mask.shape[1]} != {D} variables")
+        if mask.shape[0] not in (1, x.shape[0]):
+            raise ValueError("The number of scopes to integrate over must either match the batch size of x, or be 1")
+        for l in self.layers:
+            if isinstance(l, HipInputLayer) and not l.can_integrate:
+                raise NotImplementedError(f"marginalisation through {type(l).__name__}")
+        mask = mask.to(x.device)
+        if self._float_input:
+            return torch.where(mask, torch.full((), float("nan"), device=x.device, dtype=torch.float32), x.to(torch.float32))
+        return torch.where(mask, torch.full((), -1, device=x.device, dtype=torch.int64), x.to(torch.int64))
 
     def _run(self, x: torch.Tensor | None) -> _Binding:
         if self.plan.num_variables:
@@ -382,10 +413,15 @@ class HipCircuit:
                 cur.wait_stream(run)
         return bd
 
-    def forward(self, x: torch.Tensor | None = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor | None = None, *, integrate_vars=None) -> torch.Tensor:
         """Returns ``(B, O, K)`` like ``TorchCircuit.forward`` (``(O, K)`` for an empty-scope circuit).
-        The result aliases the circuit's arena: it is overwritten by the next call with the same
-        batch size (clone it to keep it)."""
+        With ``integrate_vars`` the listed / masked variables are marginalised out
+        (``IntegrateQuery.__call__``).  The result aliases the circuit's arena: it is overwritten by
+        the next call with the same batch size (clone it to keep it)."""
+        if integrate_vars is not None:
+            if x is None:
+                raise ValueError("integrate_vars needs an input batch")
+            x = self._apply_integration_mask(x.to(self.device), integrate_vars)
         bd = self._run(x)
         pairs = self._out_pairs
         if len(pairs) == 1:

@@ -177,22 +177,22 @@ __global__ void __launch_bounds__(256)
     categorical_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ xt,
                            const int64_t* __restrict__ scope, float* __restrict__ dtable, int B, int K,
                            int C) {
-  extern __shared__ __attribute__((aligned(16))) float hist[];  // [C][K]
+  extern __shared__ __attribute__((aligned(16))) float hist[];  // [C+1][K] (row C: marginalised rows)
   const int f = blockIdx.x;
-  for (int i = threadIdx.x; i < C * K; i += blockDim.x) hist[i] = 0.f;
+  for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) hist[i] = 0.f;
   __syncthreads();
   const int32_t* xrow = xt + scope[f] * static_cast<int64_t>(B);
   const float* g = gout + static_cast<int64_t>(f) * B * K;
   for (int64_t i = threadIdx.x; i < static_cast<int64_t>(B) * K; i += blockDim.x) {
     const int b = static_cast<int>(i / K), k = static_cast<int>(i - static_cast<int64_t>(b) * K);
     int c = xrow[b];
-    c = min(max(c, 0), C - 1);
+    c = c < 0 ? C : min(c, C - 1);
     const float v = g[i];
     if (v != 0.f) atomicAdd(&hist[c * K + k], v);
   }
   __syncthreads();
-  float* dst = dtable + static_cast<int64_t>(f) * C * K;
-  for (int i = threadIdx.x; i < C * K; i += blockDim.x) dst[i] += hist[i];
+  float* dst = dtable + static_cast<int64_t>(f) * (C + 1) * K;
+  for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) dst[i] += hist[i];
 }
 
 // softmax backward over rows: dtheta = W * (dW - sum(W * dW));  W given row-major (rows, len).
@@ -223,8 +223,8 @@ __global__ void __launch_bounds__(256)
                          float* __restrict__ dtheta, int K, int C, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float colsum[];  // [K]
   const int f = blockIdx.x;
-  const float* T = table + static_cast<int64_t>(f) * C * K;
-  const float* dT = dtable + static_cast<int64_t>(f) * C * K;
+  const float* T = table + static_cast<int64_t>(f) * (C + 1) * K;  // rows 0..C-1; row C (integral, = 0) has no gradient
+  const float* dT = dtable + static_cast<int64_t>(f) * (C + 1) * K;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += dT[c * K + k];
@@ -344,7 +344,7 @@ int ck_categorical_bwd(const float* gout, const int32_t* xt, const int64_t* scop
                        int B, int K, int C, void* stream) {
   CK_REQUIRE(gout && xt && scope && dtable, "ck_categorical_bwd: null pointer");
   CK_REQUIRE(F > 0 && B > 0 && K > 0 && C > 0, "ck_categorical_bwd: non-positive size");
-  const size_t lds = static_cast<size_t>(C) * K * sizeof(float);
+  const size_t lds = static_cast<size_t>(C + 1) * K * sizeof(float);
   if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_categorical_bwd: C*K=%d does not fit in LDS", C * K);
   dim3 grid(F), block(256);
   return ck::dispatch(

@@ -28,7 +28,7 @@ namespace {
 constexpr int kMaxDepth = 4;
 
 struct SubtreeArgs {
-  const float* table;    // (F0, C, K) leaf log-prob table (transposed)
+  const float* table;    // (F0, C+1, K) leaf log-prob table (transposed; row C = integral row)
   const int32_t* xt;     // (Dvars, B) staged batch
   const int64_t* scope;  // (F0) variable of each leaf fold
   const float* w_dense;  // (F_dense, 1024 dwords) weights of the dense layer, or nullptr
@@ -105,14 +105,14 @@ __global__ void __launch_bounds__(256) subtree_cat_cpt_kernel(const SubtreeArgs 
 #pragma unroll
   for (int i = 0; i < kLeaves; ++i) {
     const int v = a.xt[a.scope[leaf_ids[i]] * static_cast<int64_t>(a.B) + bl];
-    xv[i] = min(max(v, 0), a.C - 1);  // memory safety; the reference raises on out-of-range categories
+    xv[i] = v < 0 ? a.C : min(v, a.C - 1);  // negative = marginalised -> integral row C; clamp for memory safety
   }
   // table fold: the input-layer fold when the dense layer runs in this kernel, else the level-0
   // fold (= the input fold for cp-t plans, or the dense fold when the host has already pushed the
   // dense layer through the table, see cirkit_amd/circuit.py `dense_on_table`)
   auto row_ptr = [&](int i) {
     const int tf = HAS_DENSE ? leaf_ids[i] : dense_ids[i];
-    return a.table + (static_cast<int64_t>(tf) * a.C + xv[i]) * kK + 4 * kh;
+    return a.table + (static_cast<int64_t>(tf) * (a.C + 1) + xv[i]) * kK + 4 * kh;
   };
 
   WRegs wcur, wnxt;

@@ -65,12 +65,14 @@ __global__ void __launch_bounds__(256)
   if (r_in >= lanes_rows) return;
   const int64_t var = scope[f];
   const int32_t* xrow = xt + var * B;
-  const float4* tab = reinterpret_cast<const float4*>(table + static_cast<int64_t>(f) * C * K);
+  // tables carry C + 1 rows per fold: row C is the fold's integral (log-partition) row, selected by
+  // a negative category = "this variable is marginalised" (IntegrateQuery, queries.py:103-150)
+  const float4* tab = reinterpret_cast<const float4*>(table + static_cast<int64_t>(f) * (C + 1) * K);
   const int b_begin = blockIdx.x * rows_per_block;
   const int b_end = min(B, b_begin + rows_per_block);
   for (int b = b_begin + r_in; b < b_end; b += lanes_rows) {
     int c = xrow[b];
-    c = min(max(c, 0), C - 1);  // memory safety; the reference raises on out-of-range categories
+    c = c < 0 ? C : min(c, C - 1);  // memory safety; the reference raises on out-of-range categories
     float4 v = tab[static_cast<int64_t>(c) * kv + q];
     const int64_t o = (static_cast<int64_t>(f) * B + b) * K + 4 * q;
     if (MODE == 0) {
@@ -100,8 +102,8 @@ __global__ void __launch_bounds__(256)
        i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const int b = static_cast<int>(i / K), k = static_cast<int>(i - static_cast<int64_t>(b) * K);
     int c = xt[var * B + b];
-    c = min(max(c, 0), C - 1);
-    const float v = table[(static_cast<int64_t>(f) * C + c) * K + k];
+    c = c < 0 ? C : min(c, C - 1);
+    const float v = table[(static_cast<int64_t>(f) * (C + 1) + c) * K + k];
     const int64_t o = static_cast<int64_t>(f) * n + i;
     if (MODE == 0) {
       out[o] = v;
@@ -167,9 +169,12 @@ __global__ void __launch_bounds__(256)
     const float tail = __logf(sd);
     const float lz = logz != nullptr ? logz[static_cast<int64_t>(f) * K + k] : 0.f;
     for (int b = b_begin + r_in; b < b_end; b += lanes_rows) {
-      const float d = xrow[b] - mu;
+      const float xv = xrow[b];
+      const float d = xv - mu;
       float lp = -(d * d) / two_var - tail - kHalfLog2Pi;
       if (logz != nullptr) lp += lz;
+      // NaN = "marginalised": the layer's integral, log_partition or 0 (input.py:672-679)
+      if (xv != xv) lp = logz != nullptr ? lz : 0.f;
       out[(static_cast<int64_t>(f) * B + b) * K + k] = lp;
     }
   }

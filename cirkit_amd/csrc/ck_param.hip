@@ -140,11 +140,11 @@ __global__ void __launch_bounds__(256)
 // (R, A, Bd) -> (R, Bd, A) through a 32x32 LDS tile, optional log.
 __global__ void __launch_bounds__(256)
     transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int Bd,
-                           int take_log) {
+                           int take_log, int out_rows) {
   __shared__ float tile[32][33];
   const int64_t r = blockIdx.z;
   const float* src = in + r * static_cast<int64_t>(A) * Bd;
-  float* dst = out + r * static_cast<int64_t>(A) * Bd;
+  float* dst = out + r * static_cast<int64_t>(A) * out_rows;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // (32, 8)
   const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
 #pragma unroll
@@ -160,6 +160,25 @@ __global__ void __launch_bounds__(256)
   for (int j = 0; j < 32; j += 8) {
     const int bi = b0 + ty + j, ai = a0 + tx;
     if (ai < A && bi < Bd) dst[static_cast<int64_t>(bi) * A + ai] = tile[tx][ty + j];
+  }
+}
+
+// integral row of a gather table (F, C+1, K): mode 0 zeros (normalised probs), 1 logsumexp over the
+// C rows (unnormalised logits, TorchCategoricalLayer.log_partition_function input.py:414-421),
+// 2 ones (embedding tables: never selected, kept finite)
+__global__ void __launch_bounds__(256)
+    table_integral_row_kernel(float* __restrict__ table, int C, int K, int mode) {
+  float* t = table + static_cast<int64_t>(blockIdx.x) * (C + 1) * K;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float v = mode == 2 ? 1.f : 0.f;
+    if (mode == 1) {
+      float mx = -INFINITY;
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, t[c * K + k]);
+      float sacc = 0.f;
+      for (int c = 0; c < C; ++c) sacc += expf(t[c * K + k] - mx);
+      v = mx + logf(sacc);
+    }
+    t[static_cast<int64_t>(C) * K + k] = v;
   }
 }
 
@@ -307,7 +326,8 @@ __device__ __forceinline__ void softmax_job_table(const ck_softmax_job& j, int f
   __syncthreads();
   // phase 3: out[c][k] = log(exp(d)/sum), d = theta - max; written coalesced (k fastest), 16 B per lane
   // exp(d) underflows to 0 below ~-103.97 -> the reference yields log(0) = -inf
-  float* dst = j.out + static_cast<int64_t>(f) * C * K;
+  float* dst = j.out + static_cast<int64_t>(f) * (C + 1) * K;  // (C + 1, K): row C = integral row
+  for (int k = threadIdx.x; k < K; k += blockDim.x) dst[static_cast<int64_t>(C) * K + k] = 0.f;  // log sum_c p = 0
   if ((K & 3) == 0) {
     const int k4n = K >> 2;
     for (int i = threadIdx.x; i < C * k4n; i += blockDim.x) {
@@ -464,14 +484,27 @@ int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N
 }
 
 int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int Bd, int take_log,
-                             void* stream) {
+                             int out_rows, void* stream) {
   CK_REQUIRE(in && out, "ck_param_transpose_last2: null pointer");
   CK_REQUIRE(R > 0 && A > 0 && Bd > 0, "ck_param_transpose_last2: non-positive size");
+  CK_REQUIRE(out_rows >= Bd, "ck_param_transpose_last2: out_rows=%d < Bd=%d", out_rows, Bd);
   CK_REQUIRE(R <= 65535, "ck_param_transpose_last2: R exceeds grid.z");
   dim3 grid((Bd + 31) / 32, (A + 31) / 32, static_cast<unsigned>(R)), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(transpose_last2_kernel, grid, block, 0, s, in, out, A, Bd, take_log);
+        hipLaunchKernelGGL(transpose_last2_kernel, grid, block, 0, s, in, out, A, Bd, take_log, out_rows);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_table_integral_row(float* table, int F, int C, int K, int mode, void* stream) {
+  CK_REQUIRE(table != nullptr, "ck_param_table_integral_row: null pointer");
+  CK_REQUIRE(F > 0 && C > 0 && K > 0 && mode >= 0 && mode <= 2, "ck_param_table_integral_row: bad arguments");
+  dim3 grid(F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(table_integral_row_kernel, grid, block, 0, s, table, C, K, mode);
         return hipGetLastError();
       },
       stream);

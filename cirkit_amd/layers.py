@@ -171,6 +171,7 @@ class HipInputLayer(HipLayer):
         return out
 
     wants_float_input = False
+    can_integrate = False  # whether a marginalised variable (negative category / NaN) is understood
 
 
 class HipCategoricalLayer(HipInputLayer):
@@ -200,6 +201,8 @@ class HipCategoricalLayer(HipInputLayer):
         self.probs, self.logits = probs, logits
         self._table: torch.Tensor | None = None
 
+    can_integrate = True
+
     @property
     def config(self) -> Mapping[str, Any]:
         return {"num_output_units": self.num_output_units, "num_categories": self.num_categories}
@@ -213,7 +216,7 @@ class HipCategoricalLayer(HipInputLayer):
         if src is None:
             return False
         F, K, C = src.shape
-        self._table = torch.empty((F, C, K), dtype=torch.float32, device=src.device)
+        self._table = torch.empty((F, C + 1, K), dtype=torch.float32, device=src.device)  # row C: integral row
         batch.add_log_table(src, self._table)
         self._batched = True
         return True
@@ -221,18 +224,20 @@ class HipCategoricalLayer(HipInputLayer):
     def prepare(self, stream: int, batched: bool = False) -> None:
         if batched and self._batched:
             return
-        # table (F, C, K) = transpose(log(probs())) | transpose(logits())  -- input.py:405-408
+        # table (F, C+1, K) = transpose(log(probs())) | transpose(logits())  -- input.py:405-408;
+        # row C = the layer's integral (log_partition_function, input.py:414-421)
         p = self.probs if self.probs is not None else self.logits
         v = p.evaluate(stream)
         if v.is_complex():
             raise NotImplementedError("complex categorical parameters")
         F, K, C = v.shape
         if self._table is None or self._table.device != v.device:
-            self._table = torch.empty((F, C, K), dtype=torch.float32, device=v.device)
+            self._table = torch.empty((F, C + 1, K), dtype=torch.float32, device=v.device)
         capi.call(
             "ck_param_transpose_last2", _ptr(v), _ptr(self._table), F, K, C,
-            1 if self.probs is not None else 0, stream,
+            1 if self.probs is not None else 0, C + 1, stream,
         )
+        capi.call("ck_param_table_integral_row", _ptr(self._table), F, C, K, 0 if self.probs is not None else 1, stream)
 
     def launch_input(self, xt, D, out, B, stream) -> None:
         if self.is_complex:
@@ -280,8 +285,9 @@ class HipEmbeddingLayer(HipInputLayer):
             raise NotImplementedError("complex embedding weights")
         F, K, C = v.shape
         if self._table is None or self._table.device != v.device:
-            self._table = torch.empty((F, C, K), dtype=torch.float32, device=v.device)
-        capi.call("ck_param_transpose_last2", _ptr(v), _ptr(self._table), F, K, C, 0, stream)
+            self._table = torch.empty((F, C + 1, K), dtype=torch.float32, device=v.device)
+        capi.call("ck_param_transpose_last2", _ptr(v), _ptr(self._table), F, K, C, 0, C + 1, stream)
+        capi.call("ck_param_table_integral_row", _ptr(self._table), F, C, K, 2, stream)
 
     def launch_input(self, xt, D, out, B, stream) -> None:
         capi.call(
@@ -295,6 +301,7 @@ class HipGaussianLayer(HipInputLayer):
     """``TorchGaussianLayer`` (layers/input.py:564-690), log_unnormalized_likelihood :661-670."""
 
     wants_float_input = True
+    can_integrate = True
 
     def __init__(
         self,

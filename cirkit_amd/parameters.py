@@ -80,7 +80,7 @@ class ParamBatch:
         self._arr = None
 
     def add_log_table(self, src: torch.Tensor, dst: torch.Tensor) -> None:
-        """src (F, K, C) logits -> dst (F, C, K) = log softmax over C, transposed."""
+        """src (F, K, C) logits -> dst (F, C+1, K) = log softmax over C, transposed; row C = 0."""
         F, K, Cc = src.shape
         self._jobs.append((src.data_ptr(), dst.data_ptr(), int(F), int(Cc), int(K), 1))
         self._keep += [src, dst]

@@ -73,8 +73,12 @@ int ck_transpose_i64_to_i32(const int64_t* x, int32_t* xt, int B, int D, void* s
 int ck_transpose_f32(const float* x, float* xt, int B, int D, void* stream);
 
 /* TorchCategoricalLayer.log_unnormalized_likelihood, layers/input.py:399-412.
- * table: (F, C, K) log-probabilities / logits ALREADY transposed so a (f, c) row is contiguous
- *        (built by ck_param_log_transpose or ck_param_transpose_last2);
+ * table: (F, C+1, K) log-probabilities / logits ALREADY transposed so a (f, c) row is contiguous
+ *        (built by ck_param_softmax_batch kind 1 or ck_param_transpose_last2 with out_rows = C+1);
+ *        row C is the fold's INTEGRAL row (log-partition of each unit; ck_param_table_integral_row):
+ *        a NEGATIVE category selects it = "this variable is marginalised" -- the per-row,
+ *        per-variable mask of IntegrateQuery (cirkit/backend/torch/queries.py:103-150,
+ *        TorchInputLayer.integrate input.py:280-282, 414-421);
  * xt   : (D, B) int32 (see above); scope[f] = variable of fold f;  out: (F, B, K). */
 int ck_categorical_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out,
                        int F, int B, int K, int C, int D, void* stream);
@@ -82,7 +86,7 @@ int ck_categorical_fwd(const float* table, const int32_t* xt, const int64_t* sco
 /* TorchGaussianLayer.log_unnormalized_likelihood, layers/input.py:661-670:
  * out = -(x-mean)^2 / (2 stddev^2) - log(stddev) - log(sqrt(2 pi)) (+ log_partition).
  * xt: (D, B) fp32 (ck_transpose_f32); mean/stddev/log_partition: (F, K); log_partition may be
- * NULL. */
+ * NULL.  A NaN input = marginalised variable: the output is log_partition (or 0), input.py:672-679. */
 int ck_gaussian_fwd(const float* mean, const float* stddev, const float* log_partition,
                     const float* xt, const int64_t* scope, float* out, int F, int B, int K, int D,
                     void* stream);
@@ -147,7 +151,7 @@ int ck_tensordot_lse_fwd_c(const float* arena_c, const int64_t* row_off, const f
  * (F_root, B, K) output is written.  Same arithmetic per step as ck_categorical_fwd +
  * ck_sum_lse_fwd (reference: input.py:399-412, inner.py:266-273, optimized.py:171-178,
  * semiring.py:383-408); K must be 32.
- *   table (F0,C,K), xt (D,B) int32, scope (F0): as ck_categorical_fwd;
+ *   table (F0,C+1,K), xt (D,B) int32, scope (F0): as ck_categorical_fwd;
  *   w_dense: (F_dense,K,K) linear weights, or NULL when the leaves feed the CP-T layers directly --
  *            the table is then indexed by the LEVEL-0 fold (node_off[0] table), which lets a caller
  *            apply a dense layer to the (F,C,K) table itself first (one ck_sum_lse_fwd with B = C:
@@ -184,7 +188,7 @@ int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_
 /* All `tensor -> softmax(last axis)` parameters of a circuit in one launch.  `jobs` is a HOST array
  * (copied into the launch).  kind 0: out[r, :] = softmax(in[r, :]) for `rows` rows of `len`.
  * kind 1 (Categorical probs, input.py:405-408): in (rows=F, k=K, len=C) logits ->
- * out (F, C, K) = log(softmax over C), transposed for the gather kernels.
+ * out (F, C+1, K) = log(softmax over C), transposed for the gather kernels, row C = 0 (integral).
  * kind 2 / 3: as kind 0 for (F*32, 32) weights, written in CK_W_TILED_F32 / CK_W_TILED_F16X3
  * layout (rows must be a multiple of 32, len = 32).  block_begin is ignored on input. */
 typedef struct ck_softmax_job {
@@ -213,10 +217,13 @@ int ck_param_mixing_weight(const float* in, float* out, int F, int K, int H, voi
  * trans_a; b: (F,Kd,N) or (F,N,Kd) if trans_b; out: (F,M,N). */
 int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd,
                  int trans_a, int trans_b, void* stream);
-/* (R, A, Bd) -> (R, Bd, A) transpose of the last two axes, optionally taking log first
- * (categorical: log(probs) -> table (F, C, K), input.py:405-408). */
+/* (R, A, Bd) -> (R, out_rows >= Bd, A) transpose of the last two axes (rows beyond Bd untouched),
+ * optionally taking log first (categorical: log(probs) -> table (F, C+1, K), input.py:405-408). */
 int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int Bd, int take_log,
-                             void* stream);
+                             int out_rows, void* stream);
+/* Integral row (row C) of a gather table (F, C+1, K): mode 0 zeros (normalised probabilities),
+ * 1 logsumexp over the C category rows (unnormalised logits, input.py:414-421), 2 ones (embedding). */
+int ck_param_table_integral_row(float* table, int F, int C, int K, int mode, void* stream);
 
 /* ---------------------------------------------------------------- backward (training) ------ */
 /* Gradients of a scalar loss through the lse-sum forward -- what the reference gets from autograd
@@ -234,13 +241,13 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
 int ck_hadamard_bwd(float* garena, const int64_t* row_off, const float* gout, int F, int H, int B, int K,
                     int accumulate, void* stream);
 /* TorchCategoricalLayer backward: dtable[f,c,:] += sum_{b: x[b,scope f]=c} gout[f,b,:]  (dtable
- * (F,C,K), same transposed layout as the forward table). */
+ * (F,C+1,K), same transposed layout as the forward table). */
 int ck_categorical_bwd(const float* gout, const int32_t* xt, const int64_t* scope, float* dtable, int F,
                        int B, int K, int C, void* stream);
 /* softmax parameter backward over the last axis: dtheta = W * (dW - sum(W*dW)). */
 int ck_param_softmax_bwd(const float* w, const float* dw, float* dtheta, int64_t rows, int len,
                          int accumulate, void* stream);
-/* Categorical probs backward: table (F,C,K) = transposed log softmax_C(theta (F,K,C));
+/* Categorical probs backward: table (F,C+1,K) = transposed log softmax_C(theta (F,K,C));
  * dtheta[f,k,c] = dT[f,c,k] - exp(T[f,c,k]) sum_c' dT[f,c',k]. */
 int ck_param_log_table_bwd(const float* table, const float* dtable, float* dtheta, int F, int K, int C,
                            int accumulate, void* stream);

@@ -261,6 +261,29 @@ def _layer_forward(sr, l: LayerSpec, params: Mapping[str, Tensor], x) -> Tensor:
     raise NotImplementedError(t)
 
 
+def _integrate_input(sr, l: LayerSpec, params, output: Tensor, mask: Tensor) -> Tensor:
+    """IntegrateQuery._layer_fn, queries.py:103-150: where the (B, D) mask marks the layer's variable,
+    replace the output by ``layer.integrate()`` (TorchExpFamilyLayer.integrate input.py:280-282;
+    log_partition_function :414-421 for Categorical, :672-679 for Gaussian)."""
+    if mask.dim() == 1:
+        mask = mask.unsqueeze(0)
+    m = mask[:, torch.from_numpy(l.scope_idx)]  # (B|1, F, 1)
+    m = m.permute(1, 0, 2)
+    if l.type == "categorical":
+        if "probs" in params:
+            integ = torch.zeros((l.num_folds, 1, l.num_output_units), dtype=output.dtype)
+        else:
+            integ = torch.logsumexp(params["logits"], dim=2).unsqueeze(1)
+    elif l.type == "gaussian":
+        if "log_partition" in params:
+            integ = params["log_partition"].unsqueeze(1)
+        else:
+            integ = torch.zeros((l.num_folds, 1, l.num_output_units), dtype=output.dtype)
+    else:
+        raise NotImplementedError(f"integrate() of a {l.type} layer")
+    return torch.where(m, sr.from_lse(integ.to(output.real.dtype)), output)
+
+
 def evaluate_plan(
     plan: Plan,
     tensors: Mapping[str, Tensor],
@@ -268,6 +291,7 @@ def evaluate_plan(
     *,
     return_all: bool = False,
     grad: bool = False,
+    integrate_mask: Tensor | None = None,
 ):
     """TorchCircuit.forward, circuits.py:242-278 + the interpreter loop graph/modules.py:303-335.
 
@@ -287,7 +311,10 @@ def evaluate_plan(
             else:  # circuits.py:66
                 assert x is not None and x.dim() == 2
                 xin = x[..., torch.from_numpy(l.scope_idx)].permute(1, 0, 2)
-            outs.append(_layer_forward(sr, l, params, xin))
+            y_l = _layer_forward(sr, l, params, xin)
+            if integrate_mask is not None and l.inputs is None and l.type != "constant":
+                y_l = _integrate_input(sr, l, params, y_l, integrate_mask)
+            outs.append(y_l)
         y = _select(outs, plan.output)  # (O, B, K)
         y = y.transpose(0, 1)
         if plan.num_variables == 0:

@@ -234,6 +234,60 @@ def grads():
         torch.set_grad_enabled(False)
 
 
+def marginals():
+    """Marginal queries through the reference's IntegrateQuery (cirkit/backend/torch/queries.py):
+    the KAT circuits (reference ground truth: mar (1,0,1,1,.) = 16.845, Z = 318; mar (0.3,.) =
+    23.528960785605985, Z = 44) and random per-row masks on configs 1 and 2."""
+    from cirkit.backend.torch.queries import IntegrateQuery
+    from tests.symbolic.test_utils import (
+        build_monotonic_bivariate_gaussian_hadamard_dense_pc,
+        build_monotonic_structured_categorical_cpt_pc,
+    )
+
+    ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)
+    sc, gt, zgt = build_monotonic_structured_categorical_cpt_pc(return_ground_truth=True)
+    cc = ctx.compile(sc)
+    q = IntegrateQuery(cc)
+    x = torch.tensor([[1, 0, 1, 1, 0], [1, 0, 1, 1, 1], [0, 1, 0, 0, 1], [1, 1, 1, 0, 0]])
+    mask = torch.tensor([[0, 0, 0, 0, 1], [1, 1, 1, 1, 1], [1, 0, 1, 0, 0], [0, 0, 0, 0, 0]], dtype=torch.bool)
+    y = q(x, integrate_vars=mask)
+    np.savez_compressed(os.path.join(HERE, "kat_bernoulli_f1o1_marg.npz"), x=x.numpy(), mask=mask.numpy(), y=y.numpy(),
+                        kat_mar=np.array(list(gt["mar"].values())), kat_z=np.array(zgt))
+    print("bernoulli marginals", torch.exp(y).flatten().tolist(), gt["mar"], zgt)
+
+    sc, gt, zgt = build_monotonic_bivariate_gaussian_hadamard_dense_pc(return_ground_truth=True)
+    cc = ctx.compile(sc)
+    q = IntegrateQuery(cc)
+    x = torch.tensor([[0.3, 1.2], [0.3, 1.2], [0.3, 1.2], [-1.0, 2.0]])
+    mask = torch.tensor([[0, 1], [1, 1], [0, 0], [1, 0]], dtype=torch.bool)
+    y = q(x, integrate_vars=mask)
+    np.savez_compressed(os.path.join(HERE, "kat_gaussian_f1o1_marg.npz"), x=x.numpy(), mask=mask.numpy(), y=y.numpy(),
+                        kat_mar=np.array(list(gt["mar"].values())), kat_z=np.array(zgt))
+    print("gaussian marginals", torch.exp(y).flatten().tolist(), gt["mar"], zgt)
+
+    for name, build, xgen, B in [
+        ("cfg1_rbt8", lambda: data_modalities.tabular_data(
+            "random-binary-tree", num_features=8, input_layers={"name": "categorical", "args": {"num_categories": 4}},
+            num_input_units=4, sum_product_layer="cp", num_sum_units=4),
+         lambda g, B: torch.randint(0, 4, (B, 8), generator=g), 32),
+        ("cfg2_qt784", lambda: data_modalities.image_data(
+            (1, 28, 28), "quad-tree-2", input_layer="categorical", num_input_units=32,
+            sum_product_layer="cp", num_sum_units=32),
+         lambda g, B: torch.randint(0, 256, (B, 784), generator=g), 8),
+    ]:
+        cc = ctx.compile(build())
+        plan, tensors = plan_from_torch_circuit(cc)
+        _load_closed_form(plan, tensors)
+        g = torch.Generator().manual_seed(21)
+        x = xgen(g, B)
+        mask = torch.rand(x.shape, generator=g) < 0.3
+        mask[0] = False
+        mask[1] = True
+        y = IntegrateQuery(cc)(x, integrate_vars=mask)
+        np.savez_compressed(os.path.join(HERE, name + "_marg.npz"), x=x.numpy().astype(np.int16), mask=mask.numpy(), y=y.numpy())
+        print(name, "marginals", y.flatten()[:4].tolist())
+
+
 def plans_only():
     """Plan-only fixtures (no outputs) that pin the native plan builders of cirkit_amd/templates.py on
     awkward shapes: odd borders, single rows, quad-tree-4, deeper random trees."""
@@ -264,6 +318,6 @@ def plans_only():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "marginals"]
     for w in which:
         globals()[w]()
