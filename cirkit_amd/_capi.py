@@ -73,6 +73,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_table_integral_row": [_p, _i, _i, _i, _i, _p],
     "ck_fill_f32": [_p, _l, _f, _p],
     "ck_sum_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_debug_force_generic_bwd": [_i],
     "ck_hadamard_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_categorical_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_param_softmax_bwd": [_p, _p, _p, _l, _i, _i, _p],

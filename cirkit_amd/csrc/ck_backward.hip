@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "ck_internal.h"
+#include "ck_tile.h"
 
 namespace {
 
@@ -157,6 +158,113 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// K = 32 product-type sum layers (dense / CP-T) on the register tile of ck_tile.h: three exact fp32
+// MFMA contractions per 32-row tile --  y = W e,  gv = e * (W^T gy),  dW += gy^T e.  The last one
+// contracts over the batch rows, so gy and e are transposed through LDS (8 KB per wave) into the
+// MFMA A / B operand layouts; dW accumulates in registers across the wave's tiles, is reduced over
+// the workgroup's waves in LDS and leaves with one atomic per element and workgroup.
+__global__ void __launch_bounds__(256)
+    sum_lse_bwd_tile32(const float* __restrict__ arena, float* __restrict__ garena,
+                       const int64_t* __restrict__ row_off, const float* __restrict__ w,
+                       const float* __restrict__ gout, float* __restrict__ dw, int H, int B,
+                       int tiles_per_wave, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float lds[4][2][32 * 32];  // per wave: gy[b][o], e[b][n]
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const float* wf = w + static_cast<int64_t>(f) * kK * kK;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  WRegs wr;  // A operand of y = W e: lane (o, kh) holds W[o][u(s, kh)]
+  load_w<CK_W_ROWMAJOR>(wf, lane, wr);
+  float wt[16];  // A operand of gv = W^T gy: lane (n, kh) holds W[u(s, kh)][n]
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wt[4 * g + t] = wf[(8 * g + 4 * kh + t) * kK + b_in];
+  f32x16 dwacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dwacc[r] = 0.f;
+  float* gy_s = lds[wave][0];
+  float* e_s = lds[wave][1];
+  const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+    const int b0 = (tile0 + tt) * 32;
+    if (b0 >= B) break;
+    const int b = b0 + b_in;
+    const bool live = b < B;
+    const int bl = live ? b : B - 1;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = 0.f;
+    for (int h = 0; h < H; ++h) tile_load_add(arena + ro[h] + static_cast<int64_t>(bl) * kK + 4 * kh, v);
+    const float m = row_max16(v);
+    float e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[j] = live ? expf(v[j] - m) : 0.f;  // accurate exp: softmax gradients cancel
+    // y = W e
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr.q[g].x, e[4 * g + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr.q[g].y, e[4 * g + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr.q[g].z, e[4 * g + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr.q[g].w, e[4 * g + 3], acc, 0, 0, 0);
+    }
+    // gy = gout / y
+    float gy[16];
+    {
+      float go[16];
+      tile_load(gout + (static_cast<int64_t>(f) * B + bl) * kK + 4 * kh, go);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gy[r] = (live && acc[r] > 0.f && go[r] != 0.f) ? go[r] / acc[r] : 0.f;
+    }
+    // gv = e * (W^T gy)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[s2], gy[s2], acc, 0, 0, 0);
+    if (live) {
+      for (int h = 0; h < H; ++h) {
+        float* dst = garena + ro[h] + static_cast<int64_t>(b) * kK + 4 * kh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) grad_store(dst + 8 * g + t, acc[4 * g + t] * e[4 * g + t], accumulate);
+      }
+    }
+    // dW += gy^T e : transpose both tiles through LDS (row b, unit u at [b * 32 + u])
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<float4*>(gy_s + b_in * 32 + 8 * g + 4 * kh) = make_float4(gy[4 * g], gy[4 * g + 1], gy[4 * g + 2], gy[4 * g + 3]);
+      *reinterpret_cast<float4*>(e_s + b_in * 32 + 8 * g + 4 * kh) = make_float4(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int bb = 16 * kh + s2;  // batch row contracted by lanes (., kh) at step s2
+      dwacc = __builtin_amdgcn_mfma_f32_32x32x2f32(gy_s[bb * 32 + b_in], e_s[bb * 32 + b_in], dwacc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // reduce dW over the 4 waves, then one atomic per element: D[o][n] in lane (n, hi) reg r, o = u(r, hi)
+  __syncthreads();
+  float* red = &lds[0][0][0];  // 4 x 1024 floats
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = 8 * (r >> 2) + 4 * kh + (r & 3);
+    red[wave * 1024 + o * 32 + b_in] = dwacc[r];
+  }
+  __syncthreads();
+  float* dwf = dw + static_cast<int64_t>(f) * kK * kK;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const float sacc = red[i] + red[1024 + i] + red[2048 + i] + red[3072 + i];
+    if (sacc != 0.f) atomicAdd(&dwf[i], sacc);
+  }
+}
+
 // Hadamard backward: every child receives the output gradient.
 __global__ void __launch_bounds__(256)
     hadamard_bwd_kernel(float* __restrict__ garena, const int64_t* __restrict__ row_off,
@@ -183,12 +291,44 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   const int32_t* xrow = xt + scope[f] * static_cast<int64_t>(B);
   const float* g = gout + static_cast<int64_t>(f) * B * K;
-  for (int64_t i = threadIdx.x; i < static_cast<int64_t>(B) * K; i += blockDim.x) {
-    const int b = static_cast<int>(i / K), k = static_cast<int>(i - static_cast<int64_t>(b) * K);
-    int c = xrow[b];
-    c = c < 0 ? C : min(c, C - 1);
-    const float v = g[i];
-    if (v != 0.f) atomicAdd(&hist[c * K + k], v);
+  if ((K & 3) == 0 && K <= 1024) {
+    // float4 per lane, 4 independent rows per thread in flight (the loop is load-latency bound)
+    const int kq = K >> 2;                    // float4 per row
+    const int rows_pass = blockDim.x / kq;    // rows covered by the block per pass
+    const int r_in = threadIdx.x / kq, q = threadIdx.x - r_in * kq;
+    if (r_in < rows_pass) {
+      for (int b0 = r_in; b0 < B; b0 += 4 * rows_pass) {
+        float4 v[4];
+        int c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int b = b0 + u * rows_pass;
+          c[u] = -2;
+          if (b < B) {
+            const int cc = xrow[b];
+            c[u] = cc < 0 ? C : min(cc, C - 1);
+            v[u] = reinterpret_cast<const float4*>(g + static_cast<int64_t>(b) * K)[q];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (c[u] == -2) continue;
+          float* h = hist + c[u] * K + 4 * q;
+          if (v[u].x != 0.f) atomicAdd(h + 0, v[u].x);
+          if (v[u].y != 0.f) atomicAdd(h + 1, v[u].y);
+          if (v[u].z != 0.f) atomicAdd(h + 2, v[u].z);
+          if (v[u].w != 0.f) atomicAdd(h + 3, v[u].w);
+        }
+      }
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < static_cast<int64_t>(B) * K; i += blockDim.x) {
+      const int b = static_cast<int>(i / K), k = static_cast<int>(i - static_cast<int64_t>(b) * K);
+      int c = xrow[b];
+      c = c < 0 ? C : min(c, C - 1);
+      const float v = g[i];
+      if (v != 0.f) atomicAdd(&hist[c * K + k], v);
+    }
   }
   __syncthreads();
   float* dst = dtable + static_cast<int64_t>(f) * (C + 1) * K;
@@ -216,25 +356,49 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// Categorical parameter backward: table (F, C, K) = log softmax_C(theta (F, K, C)) transposed.
-// dtheta[f,k,c] = dT[f,c,k] - exp(T[f,c,k]) * sum_c' dT[f,c',k].   One block per fold.
+// Categorical parameter backward: table (F, C+1, K) = log softmax_C(theta (F, K, C)) transposed.
+// dtheta[f,k,c] = dT[f,c,k] - exp(T[f,c,k]) * sum_c' dT[f,c',k].   One block per fold; both (C, K)
+// tiles go through LDS (row stride K+1) so that global reads (k fastest) and writes (c fastest) are
+// both coalesced.
 __global__ void __launch_bounds__(256)
     log_table_bwd_kernel(const float* __restrict__ table, const float* __restrict__ dtable,
                          float* __restrict__ dtheta, int K, int C, int accumulate) {
-  extern __shared__ __attribute__((aligned(16))) float colsum[];  // [K]
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int ld = K + 1;
+  float* d_s = sm;                 // [C][K+1] dT
+  float* p_s = d_s + C * ld;       // [C][K+1] exp(T)
+  float* colsum = p_s + C * ld;    // [K]
   const int f = blockIdx.x;
   const float* T = table + static_cast<int64_t>(f) * (C + 1) * K;  // rows 0..C-1; row C (integral, = 0) has no gradient
   const float* dT = dtable + static_cast<int64_t>(f) * (C + 1) * K;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s += dT[c * K + k];
-    colsum[k] = s;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) colsum[k] = 0.f;
+  for (int i = threadIdx.x; i < C * K; i += blockDim.x) {
+    const int c = i / K, k = i - c * K;
+    d_s[c * ld + k] = dT[i];
+    p_s[c * ld + k] = expf(T[i]);
+  }
+  __syncthreads();
+  {
+    const int kk = threadIdx.x % K, c0 = threadIdx.x / K, cstep = blockDim.x / K;
+    if (cstep > 0) {
+      if (c0 < cstep) {
+        float sacc = 0.f;
+        for (int c = c0; c < C; c += cstep) sacc += d_s[c * ld + kk];
+        atomicAdd(&colsum[kk], sacc);
+      }
+    } else {
+      for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float sacc = 0.f;
+        for (int c = 0; c < C; ++c) sacc += d_s[c * ld + k];
+        colsum[k] = sacc;
+      }
+    }
   }
   __syncthreads();
   float* dst = dtheta + static_cast<int64_t>(f) * K * C;
   for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
     const int k = i / C, c = i - k * C;
-    const float g = dT[c * K + k] - expf(T[c * K + k]) * colsum[k];
+    const float g = d_s[c * ld + k] - p_s[c * ld + k] * colsum[k];
     if (accumulate)
       dst[i] += g;
     else
@@ -271,11 +435,19 @@ __global__ void __launch_bounds__(256)
     p[i] -= lr * gscale * g[i];
 }
 
+bool g_bwd_force_generic = false;
+
 unsigned grid1(int64_t n, int cap = 2048) { return static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, cap)); }
 
 }  // namespace
 
 extern "C" {
+
+// Test hook: route ck_sum_lse_bwd through the shape-generic kernel even for K = 32.
+int ck_debug_force_generic_bwd(int on) {
+  g_bwd_force_generic = on != 0;
+  return CK_OK;
+}
 
 int ck_fill_f32(float* p, int64_t n, float value, void* stream) {
   CK_REQUIRE(p != nullptr && n > 0, "ck_fill_f32: bad arguments");
@@ -296,6 +468,19 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
   CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD, "ck_sum_lse_bwd: unsupported mode %d", mode);
   CK_REQUIRE(accumulate >= 0 && accumulate <= 2, "ck_sum_lse_bwd: accumulate must be 0, 1 or 2");
   CK_REQUIRE(F <= 65535, "ck_sum_lse_bwd: F=%d exceeds grid.y", F);
+  if ((mode == CK_SUM_PROD || H == 1) && Ki == kK && Ko == kK && !g_bwd_force_generic && ck::aligned16(arena) &&
+      ck::aligned16(garena) && ck::aligned16(w) && ck::aligned16(gout)) {
+    const int tiles = (B + 31) / 32;
+    int tpw = 1;
+    while (tpw < 8 && (tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2) >= 4) tpw *= 2;  // ~4+ workgroups per fold
+    dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          hipLaunchKernelGGL(sum_lse_bwd_tile32, grid, block, 0, s, arena, garena, row_off, w, gout, dw, H, B, tpw, accumulate);
+          return hipGetLastError();
+        },
+        stream);
+  }
   const int N = mode == CK_SUM_PROD ? Ki : H * Ki;
   auto lds_bytes = [&](int tb) {
     return (static_cast<size_t>(2) * tb * N + static_cast<size_t>(tb) * Ko + 64 * (kBwdNC + 1) + tb) * sizeof(float);
@@ -378,9 +563,15 @@ int ck_param_log_table_bwd(const float* table, const float* dtable, float* dthet
   CK_REQUIRE(table && dtable && dtheta, "ck_param_log_table_bwd: null pointer");
   CK_REQUIRE(F > 0 && K > 0 && C > 0, "ck_param_log_table_bwd: non-positive size");
   dim3 grid(F), block(256);
-  const size_t lds = static_cast<size_t>(K) * sizeof(float);
+  const size_t lds = (static_cast<size_t>(2) * C * (K + 1) + K) * sizeof(float);
+  if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_log_table_bwd: C*K=%d does not fit in LDS", C * K);
   return ck::dispatch(
       [=](hipStream_t s) {
+        if (lds > 48 * 1024) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(log_table_bwd_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+          if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(log_table_bwd_kernel, grid, block, lds, s, table, dtable, dtheta, K, C, accumulate);
         return hipGetLastError();
       },

@@ -134,14 +134,21 @@ class HipTrainer:
             off = bd.views[i].data_ptr() - bd.arena.data_ptr()
             gviews.append(garena.view(torch.uint8)[off : off + 4 * n].view(torch.float32).view(l.num_folds, B, l.num_output_units))
         flags, need_zero = self._accumulate_flags()
-        dws = {}
+        # linear-space weight gradients (dW, dTable) live in ONE flat buffer: a single fill per step
+        sizes = {}
         for i, l in enumerate(c.layers):
-            if isinstance(l, (HipSumLayer, HipCPTLayer)):
-                dws[i] = torch.zeros_like(l._w) if l._w is not None else None
+            if isinstance(l, (HipSumLayer, HipCPTLayer)) and l.weight.ops == ["tensor", "softmax"]:
+                sizes[i] = tuple(l._w.shape)
             elif isinstance(l, HipCategoricalLayer):
-                dws[i] = torch.zeros_like(l._table)
+                sizes[i] = tuple(l._table.shape)
+        flat = torch.zeros(sum(int(np.prod(sh)) for sh in sizes.values()) or 1, dtype=torch.float32, device=self.device)
+        dws, off = {}, 0
+        for i, sh in sizes.items():
+            n = int(np.prod(sh))
+            dws[i] = flat[off : off + n].view(sh)
+            off += n
         st = {"arena_ptr": bd.arena.data_ptr(), "garena": garena, "gviews": gviews, "flags": flags,
-              "need_zero": need_zero, "dws": dws}
+              "need_zero": need_zero, "dws": dws, "dw_flat": flat}
         self._bwd[B] = st
         return st
 
@@ -154,10 +161,8 @@ class HipTrainer:
         B = int(x.shape[0])
         bd = c._bind(B)
         st = self._bind_backward(B)
-        for i, l in enumerate(c.layers):  # buffers allocated lazily by the first forward
-            if st["dws"].get(i, 0) is None:
-                st["dws"][i] = torch.zeros_like(l._w)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        capi.call("ck_fill_f32", st["dw_flat"].data_ptr(), st["dw_flat"].numel(), 0.0, stream)
         gB = float(global_batch or B)
         gviews, flags = st["gviews"], st["flags"]
         for p in st["need_zero"]:
@@ -171,7 +176,6 @@ class HipTrainer:
             l = c.layers[i]
             if isinstance(l, HipCategoricalLayer):
                 dT = st["dws"][i]
-                capi.call("ck_fill_f32", dT.data_ptr(), dT.numel(), 0.0, stream)
                 capi.call("ck_categorical_bwd", gviews[i].data_ptr(), bd.xt.data_ptr(), l._scope(self.device).data_ptr(),
                           dT.data_ptr(), l.num_folds, B, l.num_output_units, l.num_categories, stream)
                 name = l.probs.graph.nodes[0].config["tensor"]
@@ -184,7 +188,8 @@ class HipTrainer:
                 name = l.weight.graph.nodes[0].config["tensor"]
                 soft = l.weight.ops == ["tensor", "softmax"]
                 dW = st["dws"][i] if soft else self.grads[name]
-                capi.call("ck_fill_f32", dW.data_ptr(), dW.numel(), 0.0, stream)
+                if not soft:
+                    capi.call("ck_fill_f32", dW.data_ptr(), dW.numel(), 0.0, stream)
                 capi.call("ck_sum_lse_bwd", bd.arena.data_ptr(), st["garena"].data_ptr(), bd.row_off[i].data_ptr(),
                           l._w.data_ptr(), bd.views[i].data_ptr(), gviews[i].data_ptr(), dW.data_ptr(), l.num_folds,
                           l.arity, B, l.num_input_units, l.num_output_units, l._mode, flags[i], stream)

@@ -237,6 +237,7 @@ int ck_fill_f32(float* p, int64_t n, float value, void* stream);
 int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* w,
                    const float* out, const float* gout, float* dw, int F, int H, int B, int Ki, int Ko,
                    int mode, int accumulate, void* stream);
+int ck_debug_force_generic_bwd(int on); /* test hook, like ck_debug_force_generic */
 /* TorchHadamardLayer backward: every child receives gout (F,B,K). */
 int ck_hadamard_bwd(float* garena, const int64_t* row_off, const float* gout, int F, int H, int B, int K,
                     int accumulate, void* stream);

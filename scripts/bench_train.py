@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Training-step timing on the GPU box (config 2: 784-var QuadTree, K = 32):
+    python scripts/bench_train.py [B] [steps]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from cirkit_amd.initializers import init_plan_tensors  # noqa: E402
+from cirkit_amd.templates import image_data  # noqa: E402
+from cirkit_amd.training import HipTrainer  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+plan = image_data((1, 28, 28), num_input_units=32, num_sum_units=32)
+tr = HipTrainer(plan, init_plan_tensors(plan), device="cuda:0", lr=0.01)
+x = torch.randint(0, 256, (B, 784)).cuda()
+lls = []
+for _ in range(3):
+    ll = tr.step(x)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(steps):
+    ll = tr.step(x)
+    lls.append(ll.clone())
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / steps
+print(f"train step {dt * 1e3:.3f} ms  {B / dt:.3e} samples/s  mean LL first {float(lls[0][0] / lls[0][1]):.3f} last {float(lls[-1][0] / lls[-1][1]):.3f}")
