@@ -39,7 +39,8 @@ class _Binding:
         self.arena: torch.Tensor | None = None
         self.views: list[torch.Tensor] = []
         self.row_off: list[torch.Tensor | None] = []
-        self.xt: torch.Tensor | None = None
+        self.xt: torch.Tensor | None = None  # (D, B) fp32 staging copy of the batch
+        self.xt_i: torch.Tensor | None = None  # (D, B) int32 staging copy
         self.program = None  # ck_program*
         self.store_version = -1
         self.ll: torch.Tensor | None = None
@@ -115,7 +116,9 @@ class HipCircuit:
                     f"fold index of a {s.type} layer has shape {ch.shape[:2]}, expected {(l.num_folds, l.arity)}"
                 )
         self._out_pairs = resolve_fold_index(plan.output, self._folds).reshape(-1, 2)
-        self._float_input = any(getattr(l, "wants_float_input", False) for l in self.layers)
+        data_inputs = [l for l in self.layers if isinstance(l, HipInputLayer) and not isinstance(l, HipConstantValueLayer)]
+        self._float_input = any(l.wants_float_input for l in data_inputs)
+        self._int_input = any(not l.wants_float_input for l in data_inputs)
         self._bindings: dict[int, _Binding] = {}
         self._side: torch.cuda.Stream | None = None  # graphs cannot be captured on the null stream
         depth = 0 if fuse is False else (4 if fuse is True else int(fuse))
@@ -226,12 +229,10 @@ class HipCircuit:
                 raise ValueError("a layer's children do not all have its number of input units")
             off = np.asarray(bases, dtype=np.int64)[prod] + fold * (B * l.num_input_units)
             bd.row_off.append(torch.from_numpy(np.ascontiguousarray(off)).to(self.device))
-        if self.plan.num_variables:
-            bd.xt = torch.empty(
-                (self.plan.num_variables, B),
-                dtype=torch.float32 if self._float_input else torch.int32,
-                device=self.device,
-            )
+        if self.plan.num_variables:  # (D, B) staging copies of the batch: fp32 and / or int32
+            shape = (self.plan.num_variables, B)
+            bd.xt = torch.empty(shape, dtype=torch.float32, device=self.device) if self._float_input else None
+            bd.xt_i = torch.empty(shape, dtype=torch.int32, device=self.device) if self._int_input else None
         bd.ll = torch.empty(2, dtype=torch.float64, device=self.device)
         # record the launch list once
         prog = C.c_void_p()
@@ -264,7 +265,7 @@ class HipCircuit:
             elif isinstance(l, HipConstantValueLayer):
                 l.launch_const(view, B, stream)
             elif isinstance(l, HipInputLayer):
-                l.launch_input(bd.xt, self.plan.num_variables, view, B, stream)
+                l.launch_input(bd.xt if l.wants_float_input else bd.xt_i, self.plan.num_variables, view, B, stream)
             else:
                 l.launch(bd.arena, ro, view, B, stream)
 
@@ -325,27 +326,38 @@ class HipCircuit:
         levels = (C.c_void_p * max(1, g.depth))(*[self.layers[j]._w.data_ptr() for j in g.levels])
         node_off = (C.c_int32 * (g.depth + 1))(*g.node_off)
         capi.call(
-            "ck_subtree_cat_cpt_fwd", table.data_ptr(), bd.xt.data_ptr(), cat._scope(self.device).data_ptr(),
+            "ck_subtree_cat_cpt_fwd", table.data_ptr(), bd.xt_i.data_ptr(), cat._scope(self.device).data_ptr(),
             None if w_dense is None else w_dense.data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off,
             out.data_ptr(), g.depth, self.layers[g.root].num_folds, bd.B, cat.num_output_units,
             cat.num_categories, self._group_layout(g), stream,
         )
 
     # -- evaluation ------------------------------------------------------------------------------
-    def _stage_input(self, bd: _Binding, x: torch.Tensor, stream: int) -> None:
-        """(B, D) batch -> (D, B) staging copy (replaces circuits.py:66)."""
-        B, D = x.shape
+    def _prepare_input(self, x: torch.Tensor) -> tuple[torch.Tensor | None, torch.Tensor | None]:
+        """Device / dtype conversions of the (B, D) batch (torch ops on the CURRENT stream, so they
+        must be issued before the evaluation stream waits on it).  Returns the float32 and the int64
+        view of the batch, whichever the input layers need (both for mixed continuous / discrete
+        inputs; a float batch is truncated like ``x.long()``, input.py:400-401, and a NaN -- the
+        marginalisation sentinel of the continuous layers -- becomes the discrete sentinel -1)."""
         if x.device != self.device:
             x = x.to(self.device)
-        x = x.contiguous()
+        if x.shape[1] != self.plan.num_variables:
+            x = x[:, : self.plan.num_variables]
+        xf = xi = None
         if self._float_input:
-            if x.dtype != torch.float32:
-                x = x.to(torch.float32)
-            capi.call("ck_transpose_f32", x.data_ptr(), bd.xt.data_ptr(), B, D, stream)
-        else:
-            if x.dtype != torch.int64:
-                x = x.to(torch.int64)  # float batches are truncated like `x.long()` (input.py:400-401)
-            capi.call("ck_transpose_i64_to_i32", x.data_ptr(), bd.xt.data_ptr(), B, D, stream)
+            xf = x.to(torch.float32).contiguous()
+        if self._int_input:
+            if x.is_floating_point():
+                x = torch.where(torch.isnan(x), torch.full((), -1.0, device=x.device, dtype=x.dtype), x)
+            xi = x.to(torch.int64).contiguous()
+        return xf, xi
+
+    def _stage_input(self, bd: _Binding, xf, xi, stream: int) -> None:
+        """(B, D) batch -> (D, B) staging copies (replaces circuits.py:66)."""
+        if xf is not None:
+            capi.call("ck_transpose_f32", xf.data_ptr(), bd.xt.data_ptr(), bd.B, self.plan.num_variables, stream)
+        if xi is not None:
+            capi.call("ck_transpose_i64_to_i32", xi.data_ptr(), bd.xt_i.data_ptr(), bd.B, self.plan.num_variables, stream)
 
     def _apply_integration_mask(self, x: torch.Tensor, integrate_vars) -> torch.Tensor:
         """Marginalisation (IntegrateQuery, cirkit/backend/torch/queries.py:19-184): a boolean mask
@@ -374,7 +386,7 @@ class HipCircuit:
             if isinstance(l, HipInputLayer) and not l.can_integrate:
                 raise NotImplementedError(f"marginalisation through {type(l).__name__}")
         mask = mask.to(x.device)
-        if self._float_input:
+        if self._float_input:  # (the discrete layers of a mixed circuit see NaN as -1, _prepare_input)
             return torch.where(mask, torch.full((), float("nan"), device=x.device, dtype=torch.float32), x.to(torch.float32))
         return torch.where(mask, torch.full((), -1, device=x.device, dtype=torch.int64), x.to(torch.int64))
 
@@ -396,6 +408,7 @@ class HipCircuit:
             raise ValueError("empty batch")
         bd = self._bind(B)
         with torch.cuda.device(self.device):
+            xf, xi = self._prepare_input(x) if self.plan.num_variables else (None, None)
             cur = torch.cuda.current_stream(self.device)
             run = cur
             if self.use_graph and cur.cuda_stream == 0:
@@ -405,9 +418,7 @@ class HipCircuit:
                 run.wait_stream(cur)
             stream = run.cuda_stream
             if self.plan.num_variables:
-                if x.shape[1] != self.plan.num_variables:
-                    x = x[:, : self.plan.num_variables]
-                self._stage_input(bd, x, stream)
+                self._stage_input(bd, xf, xi, stream)
             capi.call("ck_program_launch", bd.program, 1 if self.use_graph else 0, stream)
             if run is not cur:
                 cur.wait_stream(run)
@@ -526,7 +537,7 @@ class HipCircuit:
                 elif isinstance(l, HipConstantValueLayer):
                     l.launch_const(view, B, stream)
                 elif isinstance(l, HipInputLayer):
-                    l.launch_input(bd.xt, self.plan.num_variables, view, B, stream)
+                    l.launch_input(bd.xt if l.wants_float_input else bd.xt_i, self.plan.num_variables, view, B, stream)
                 else:
                     l.launch(bd.arena, ro, view, B, stream)
                 e2.record(cur)

@@ -204,10 +204,9 @@ template <typename AT, typename WT, int RPT>
 __global__ void __launch_bounds__(256)
     sum_lse_generic(const AT* __restrict__ arena, const int64_t* __restrict__ row_off,
                     const WT* __restrict__ w, AT* __restrict__ out, int H, int B, int Ki, int Ko,
-                    int mode) {
+                    int mode, int N) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TB = 4 * RPT;
-  const int N = mode == CK_SUM_PROD ? Ki : (mode == CK_SUM_KRON ? Ki * Ki : H * Ki);
+  constexpr int TB = 4 * RPT;  // N: Ki (product), H*Ki (concatenation) or Ki**H (Kronecker)
   AT* e_s = reinterpret_cast<AT*>(smem);                          // [TB][N]
   WT* w_s = reinterpret_cast<WT*>(e_s + static_cast<size_t>(TB) * N);  // [kGenOT][kGenNC+1]
   float* m_s = reinterpret_cast<float*>(w_s + kGenOT * (kGenNC + 1));  // [TB]
@@ -219,27 +218,33 @@ __global__ void __launch_bounds__(256)
 
   // phase A: gather v (cat or product of children), row maximum, e = exp(v - m) into LDS
   if (mode == CK_SUM_KRON) {
-    // Tucker (optimized.py:89-103): one maximum PER INPUT, e[i*Ki + j] = exp(x0[i]-m0) exp(x1[j]-m1),
-    // the outer product is formed in LDS and never reaches memory.  The tail of e_s is scratch.
+    // Tucker (optimized.py:89-103): one maximum PER INPUT; e[(i_0, .., i_{H-1})] = prod_h exp(x_h[i_h]-m_h)
+    // with i_0 the slowest index.  The outer product is formed in LDS and never reaches memory.
     for (int r = wave; r < TB; r += 4) {
       const int b = min(b0 + r, B - 1);
       AT* er = e_s + static_cast<size_t>(r) * N;
-      float m01[2];
-      for (int h = 0; h < 2; ++h) {
+      AT* xr = reinterpret_cast<AT*>(m_s + TB) + static_cast<size_t>(r) * H * Ki;  // [H][Ki] shifted inputs
+      float msum = 0.f;
+      for (int h = 0; h < H; ++h) {
         float mx = -INFINITY;
         for (int k = lane; k < Ki; k += 64) mx = fmaxf(mx, Num<AT>::re(arena[ro[h] + static_cast<int64_t>(b) * Ki + k]));
-        m01[h] = ck::clamp_finite(ck::wave_max(mx));
-      }
-      AT* xr = reinterpret_cast<AT*>(m_s + TB) + static_cast<size_t>(r) * 2 * Ki;  // [2][Ki] shifted inputs
-      for (int h = 0; h < 2; ++h)
+        mx = ck::clamp_finite(ck::wave_max(mx));
         for (int k = lane; k < Ki; k += 64)
-          xr[h * Ki + k] = Num<AT>::exp_shift(arena[ro[h] + static_cast<int64_t>(b) * Ki + k], m01[h]);
+          xr[h * Ki + k] = Num<AT>::exp_shift(arena[ro[h] + static_cast<int64_t>(b) * Ki + k], mx);
+        msum += mx;
+      }
       __builtin_amdgcn_wave_barrier();
       for (int n = lane; n < N; n += 64) {
-        const int i = n / Ki, jj = n - i * Ki;
-        er[n] = Num<AT>::mul(xr[i], xr[Ki + jj]);
+        int rem = n;
+        AT v = xr[(H - 1) * Ki + rem % Ki];
+        rem /= Ki;
+        for (int h = H - 2; h >= 0; --h) {
+          v = Num<AT>::mul(xr[h * Ki + rem % Ki], v);
+          rem /= Ki;
+        }
+        er[n] = v;
       }
-      if (lane == 0) m_s[r] = m01[0] + m01[1];
+      if (lane == 0) m_s[r] = msum;
     }
   } else
   for (int r = wave; r < TB; r += 4) {
@@ -303,10 +308,17 @@ __global__ void __launch_bounds__(256)
 template <typename AT, typename WT>
 int launch_generic(const AT* arena, const int64_t* row_off, const WT* w, AT* out, int F, int H,
                    int B, int Ki, int Ko, int mode, void* stream) {
-  const int N = mode == CK_SUM_PROD ? Ki : (mode == CK_SUM_KRON ? Ki * Ki : H * Ki);
+  int64_t n64 = mode == CK_SUM_PROD ? Ki : static_cast<int64_t>(H) * Ki;
+  if (mode == CK_SUM_KRON) {
+    n64 = 1;
+    for (int h = 0; h < H && n64 <= (1 << 20); ++h) n64 *= Ki;
+    if (n64 > (1 << 20))
+      return ck::fail(CK_ERR_UNSUPPORTED, "ck_sum_lse_fwd: Kronecker product of %d inputs with %d units is too large", H, Ki);
+  }
+  const int N = static_cast<int>(n64);
   auto lds_bytes = [&](int tb) {
     return static_cast<size_t>(tb) * N * sizeof(AT) + kGenOT * (kGenNC + 1) * sizeof(WT) + tb * sizeof(float) +
-           (mode == CK_SUM_KRON ? static_cast<size_t>(tb) * 2 * Ki * sizeof(AT) : 0);
+           (mode == CK_SUM_KRON ? static_cast<size_t>(tb) * H * Ki * sizeof(AT) : 0);
   };
   int rpt = 4;
   while (rpt > 1 && lds_bytes(4 * rpt) > 64 * 1024) rpt >>= 1;
@@ -323,7 +335,7 @@ int launch_generic(const AT* arena, const int64_t* row_off, const WT* w, AT* out
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
             if (e != hipSuccess) return e;
           }
-          hipLaunchKernelGGL(kern, grid, block, lds, s, arena, row_off, w, out, H, B, Ki, Ko, mode);
+          hipLaunchKernelGGL(kern, grid, block, lds, s, arena, row_off, w, out, H, B, Ki, Ko, mode, N);
           return hipGetLastError();
         };
         if (rpt == 4) return go(sum_lse_generic<AT, WT, 4>);
@@ -339,7 +351,7 @@ int check_sum_args(const void* arena, const void* row_off, const void* w, const 
   CK_REQUIRE(F > 0 && H > 0 && B > 0 && Ki > 0 && Ko > 0, "%s: non-positive size F=%d H=%d B=%d Ki=%d Ko=%d",
              who, F, H, B, Ki, Ko);
   CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD || mode == CK_SUM_KRON, "%s: unknown mode %d", who, mode);
-  CK_REQUIRE(mode != CK_SUM_KRON || H == 2, "%s: CK_SUM_KRON (Tucker) needs arity 2, found %d", who, H);
+  CK_REQUIRE(mode != CK_SUM_KRON || H >= 2, "%s: CK_SUM_KRON (Tucker) needs arity >= 2, found %d", who, H);
   CK_REQUIRE(F <= 65535, "%s: F=%d exceeds grid.y", who, F);
   return CK_OK;
 }

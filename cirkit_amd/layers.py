@@ -581,15 +581,15 @@ class HipCPTLayer(HipSumLayer):
 
 
 class HipTuckerLayer(HipSumLayer):
-    """``TorchTuckerLayer`` (layers/optimized.py:17-103), arity 2: weight (Ko, Ki**2); one maximum
-    per input, the Kronecker product of the two shifted inputs is formed on chip."""
+    """``TorchTuckerLayer`` (layers/optimized.py:17-103): weight (Ko, Ki**arity); one maximum per
+    input, the Kronecker product of the shifted inputs is formed on chip."""
 
     _mode = capi.CK_SUM_KRON
 
     def __init__(self, num_input_units: int, num_output_units: int, arity: int = 2, *, weight: HipParameter,
                  semiring: str | None = None, num_folds: int = 1) -> None:
-        if arity != 2:
-            raise NotImplementedError("Tucker layers of arity != 2")
+        if arity < 2:
+            raise ValueError("The arity should be at least 2")
         super().__init__(num_input_units, num_output_units, arity, weight=weight, semiring=semiring, num_folds=num_folds)
 
     @property

@@ -176,7 +176,7 @@ class HipTrainer:
             l = c.layers[i]
             if isinstance(l, HipCategoricalLayer):
                 dT = st["dws"][i]
-                capi.call("ck_categorical_bwd", gviews[i].data_ptr(), bd.xt.data_ptr(), l._scope(self.device).data_ptr(),
+                capi.call("ck_categorical_bwd", gviews[i].data_ptr(), bd.xt_i.data_ptr(), l._scope(self.device).data_ptr(),
                           dT.data_ptr(), l.num_folds, B, l.num_output_units, l.num_categories, stream)
                 name = l.probs.graph.nodes[0].config["tensor"]
                 capi.call("ck_param_log_table_bwd", l._table.data_ptr(), dT.data_ptr(), self.grads[name].data_ptr(),

@@ -248,14 +248,15 @@ def _layer_forward(sr, l: LayerSpec, params: Mapping[str, Tensor], x) -> Tensor:
         xs = xs.view(xs.shape[0], xs.shape[1], kj, kq).permute(0, 1, 3, 2)
         y = _einsum(sr, "fbqj,fkj->fbqk", inputs=(xs,), operands=(w,), dim=-1, keepdim=True)
         return y.reshape(y.shape[0], y.shape[1], l.num_output_units)
-    if t == "tucker":  # optimized.py:89-103 (arity 2 as emitted by the templates)
-        w = params["weight"].view(-1, l.num_output_units, *(l.num_input_units for _ in range(l.arity)))
-        if l.arity != 2:
-            raise NotImplementedError("tucker arity != 2")
+    if t == "tucker":  # optimized.py:57-103: einsum (f,b,i_0), .., (f,b,i_{H-1}), (f,o,i_0..i_{H-1}) -> (f,b,o)
+        H = l.arity
+        w = params["weight"].view(-1, l.num_output_units, *(l.num_input_units for _ in range(H)))
         ops = tuple(sr.cast(o) for o in (w,))
+        sub = tuple((0, 1, i + 2) for i in range(H)) + ((0, H + 2, *tuple(i + 2 for i in range(H))),)
 
-        def func(a: Tensor, b: Tensor) -> Tensor:
-            return torch.einsum("fbi,fbj,foij->fbo", a, b, *ops)
+        def func(*xs: Tensor) -> Tensor:
+            args = [a for pair in zip((*xs, *ops), sub) for a in pair]
+            return torch.einsum(*args, (0, 1, H + 2))
 
         return _apply_reduce(sr, func, *x.unbind(dim=1), dim=-1, keepdim=True)
     raise NotImplementedError(t)

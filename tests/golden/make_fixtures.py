@@ -17,6 +17,7 @@ Nothing here ships reference code: the outputs are data (ints, floats).  The GPU
 from __future__ import annotations
 
 import copy
+import functools
 import os
 import sys
 
@@ -194,6 +195,34 @@ def tucker():
                                    "y_f64": _fp64_copy(cc)(x).numpy()})
 
 
+def templates_extra():
+    """Golden outputs for template features beyond the BASELINE configs: a Tucker block of arity 4
+    (quad-tree-4), a quad-graph (two partitionings per region: mixing layers + collapsed sums) and a
+    tabular circuit with per-feature input families (categorical and Gaussian columns in one batch)."""
+    ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)
+    g = torch.Generator().manual_seed(9)
+    cases = [
+        ("tucker4_qt16_k3", data_modalities.image_data((1, 4, 4), "quad-tree-4", input_layer="categorical", num_input_units=3,
+                                                       sum_product_layer="tucker", num_sum_units=3),
+         torch.randint(0, 256, (24, 16), generator=g)),
+        ("quadgraph_6x6_k4", data_modalities.image_data((1, 6, 6), "quad-graph", input_layer="categorical", num_input_units=4,
+                                                        sum_product_layer="cp", num_sum_units=4),
+         torch.randint(0, 256, (24, 36), generator=g)),
+    ]
+    xm = torch.randn(24, 6, generator=g)
+    xm[:, 0::2] = torch.randint(0, 3, (24, 3), generator=g).float()
+    cases.append(("rbt6_perfeature_k2", data_modalities.tabular_data(
+        "random-binary-tree", num_features=6,
+        input_layers=[{"name": "categorical", "args": {"num_categories": 3}}, {"name": "gaussian", "args": {}}] * 3,
+        num_input_units=2, sum_product_layer="cp", num_sum_units=2), xm))
+    for name, sc, x in cases:
+        cc = ctx.compile(sc)
+        plan, tensors = plan_from_torch_circuit(cc)
+        _load_closed_form(plan, tensors)
+        xs = x.numpy().astype(np.float32 if x.is_floating_point() else np.int16)
+        _save(name, plan, {"x": xs, "y_f32": cc(x).numpy(), "y_f64": _fp64_copy(cc)(x).numpy()})
+
+
 def grads():
     """Parameter gradients of loss = -mean(log p) from the reference's own autograd (training path,
     notebooks/learning-a-circuit.ipynb cell 18).  cfg1: every gradient; cfg2 (B = 16): per-tensor
@@ -310,6 +339,40 @@ def plans_only():
                 continue
             raise
         cases.append((f"plan_rbt{n}_d{depth}_{sp.replace('-', '')}", sc))
+    # region graphs with several partitionings per region (mixing layers, collapsed sums), Tucker
+    # blocks, multi-channel pixels (factorised inputs), shallow random trees, per-feature inputs
+    img = dict(input_layer="categorical", num_input_units=3, num_sum_units=3)
+    for shape, rgname, sp, extra in [
+        ((1, 4, 4), "quad-graph", "cp", {}), ((1, 5, 7), "quad-graph", "cp-t", {}), ((1, 6, 6), "quad-graph", "tucker", {}),
+        ((3, 4, 4), "quad-graph", "cp", {}), ((1, 8, 8), "quad-graph", "cp", {"use_mixing_weights": False}),
+        ((1, 4, 4), "quad-graph", "cp", {"num_classes": 3}), ((1, 4, 4), "quad-tree-4", "tucker", {}),
+        ((2, 3, 5), "quad-tree-2", "cp-t", {}), ((1, 8, 8), "poon-domingos", "cp", {}),
+        ((1, 12, 10), "poon-domingos", "cp-t", {}), ((1, 20, 20), "poon-domingos", "tucker", {}),
+        ((2, 17, 9), "poon-domingos", "cp", {}), ((1, 12, 13), "random-binary-tree", "cp", {}),
+    ]:
+        sc = data_modalities.image_data(shape, rgname, sum_product_layer=sp, **img, **extra)
+        tag = "".join(f"_{k}{v}" for k, v in extra.items()).replace("use_mixing_weights", "mix").replace("num_classes", "nc")
+        cases.append((f"plan_{rgname.replace('-', '')}_{'x'.join(map(str, shape))}_{sp.replace('-', '')}{tag}", sc))
+
+    from cirkit.symbolic.parameters import mixing_weight_factory
+    from cirkit.templates.region_graph import PoonDomingos, RandomBinaryTree
+    from cirkit.templates.utils import Parameterization, name_to_input_layer_factory, parameterization_to_factory
+
+    def from_rg(rg, sp, input_name="categorical", **input_kwargs):
+        swf = parameterization_to_factory(Parameterization(activation="softmax", initialization="normal"))
+        return rg.build_circuit(
+            input_factory=name_to_input_layer_factory(input_name, **input_kwargs), sum_product=sp, sum_weight_factory=swf,
+            nary_sum_weight_factory=functools.partial(mixing_weight_factory, param_factory=swf),
+            num_input_units=2, num_sum_units=2, num_classes=1, factorize_multivariate=True)
+
+    cases.append(("plan_pd_1x12x12_delta6-3_cp", from_rg(PoonDomingos((1, 12, 12), delta=[6, 3]), "cp", num_categories=5)))
+    cases.append(("plan_pd_1x9x6_delta2_depth2_cp", from_rg(PoonDomingos((1, 9, 6), delta=2, max_depth=2), "cp", num_categories=5)))
+    cases.append(("plan_rbt11_d2_cp", from_rg(RandomBinaryTree(11, depth=2), "cp", num_categories=3)))
+    cases.append(("plan_rbt19_d3_cpt", from_rg(RandomBinaryTree(19, depth=3, seed=7), "cp-t", num_categories=3)))
+    cases.append(("plan_rbt6_perfeature_cp", data_modalities.tabular_data(
+        "random-binary-tree", num_features=6,
+        input_layers=[{"name": "categorical", "args": {"num_categories": 3}}, {"name": "gaussian", "args": {}}] * 3,
+        num_input_units=2, sum_product_layer="cp", num_sum_units=2)))
     for name, sc in cases:
         plan, _ = plan_from_torch_circuit(ctx.compile(sc))
         plan.name = name
@@ -318,6 +381,6 @@ def plans_only():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "marginals"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "marginals", "templates_extra"]
     for w in which:
         globals()[w]()

@@ -99,7 +99,8 @@ def _check_complex_layers_locally(plan, tensors, x, hc, outs_ref, atol_scale):
         assert float(ph.max()) <= 1e-3 + 4.0 * float(ph_ref.max()), (i, spec.type, float(ph.max()), float(ph_ref.max()))
 
 
-@pytest.mark.parametrize("name", ["cfg1_rbt8", "cfg2_qt784", "cfg2t_qt784_cpt16", "cfg4_pd784", "tucker_qt16_k6"])
+@pytest.mark.parametrize("name", ["cfg1_rbt8", "cfg2_qt784", "cfg2t_qt784_cpt16", "cfg4_pd784", "tucker_qt16_k6",
+                                  "tucker4_qt16_k3", "quadgraph_6x6_k4", "rbt6_perfeature_k2"])
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("fuse", [False, 1, 2, 3, True])
 def test_real_configs_match_reference(hip_device, name, use_graph, fuse):
@@ -277,3 +278,64 @@ def test_ll_sum(hip_device):
     s = hc.log_likelihood_sum(x).cpu()
     assert s[1].item() == x.shape[0]
     assert abs(s[0].item() - float(g["y_f64"].sum())) <= 1e-4 * abs(float(g["y_f64"].sum()))
+
+
+# ---------------------------------------------------------------------------------------------
+# natively built plans (tests/test_templates.py pins their structure against the reference; here
+# they are EVALUATED: mixing layers, collapsed sums with MatMul weights, Tucker blocks, factorised
+# multi-channel inputs, per-feature input families)
+# ---------------------------------------------------------------------------------------------
+def _native_plan_names():
+    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "plan_*.json")))
+
+
+def _random_batch(plan, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    cols = []
+    for l in plan.layers:
+        if l.inputs is not None or l.scope_idx is None:
+            continue
+        for v in l.scope_idx[:, 0]:
+            if l.type == "gaussian":
+                cols.append((int(v), torch.randn(B, generator=g)))
+            else:
+                n = int(l.config.get("num_categories", l.config.get("num_states", 2)))
+                cols.append((int(v), torch.randint(0, n, (B,), generator=g).float()))
+    x = torch.zeros(B, plan.num_variables)
+    for v, c in cols:
+        x[:, v] = c
+    kinds = {l.type for l in plan.layers if l.inputs is None}
+    return x if "gaussian" in kinds else x.long()
+
+
+@pytest.mark.parametrize("name", _native_plan_names())
+@pytest.mark.parametrize("fuse", [True, False])
+def test_native_template_plans_match_oracle(name, fuse, hip_device):
+    from cirkit_amd import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from test_templates import _rebuild
+
+    plan = _rebuild(name)
+    tensors = init_plan_tensors(plan, seed=3)
+    x = _random_batch(plan, 48, seed=11)
+    hc = HipCircuit(plan, tensors, device=hip_device, fuse=fuse, use_graph=fuse)
+    y_ref = _check_layers(plan, tensors, x, hc)
+    y = hc(x.to(hip_device)).cpu()
+    assert y.shape == y_ref.shape
+    assert torch.allclose(y, y_ref, rtol=REL, atol=1e-5), float((y - y_ref).abs().max())
+
+
+def test_native_poon_domingos_784_matches_golden(hip_device):
+    """BASELINE config 4 built natively (no plan fixture involved) reproduces the reference's
+    committed log-likelihoods."""
+    from cirkit_amd import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+
+    _, _, g = load_case("cfg4_pd784")
+    plan = image_data((1, 28, 28), "poon-domingos", input_layer="gaussian", num_input_units=64,
+                      sum_product_layer="cp", num_sum_units=64)
+    hc = HipCircuit(plan, init_plan_tensors(plan), device=hip_device)
+    y = hc(torch.from_numpy(g["x"].astype(np.float32)).to(hip_device)).cpu().numpy().reshape(-1)
+    ref = g["y_f64"].reshape(-1)
+    assert np.allclose(y, ref, rtol=REL), float(np.abs(y - ref).max())

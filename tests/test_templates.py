@@ -61,20 +61,56 @@ def test_random_binary_tree_8_matches_reference_plan():
 PLAN_ONLY = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "plan_*.json")))
 
 
-@pytest.mark.parametrize("name", PLAN_ONLY)
-def test_awkward_shapes_match_reference_plans(name):
-    ref = Plan.load(os.path.join(GOLDEN, name))
+def _rebuild(name: str) -> Plan:
+    """The native call that corresponds to the reference call which produced fixture `name`
+    (tests/golden/make_fixtures.py:plans_only)."""
+    from cirkit_amd.templates import build_plan, image_data, poon_domingos, tabular_data
+
+    sps = {"cp": "cp", "cpt": "cp-t", "tucker": "tucker"}
     m = re.fullmatch(r"plan_quadtree(\d)_(\d+)x(\d+)_(cp|cpt)", name)
     if m:
-        splits, h, w, sp = int(m[1]), int(m[2]), int(m[3]), {"cp": "cp", "cpt": "cp-t"}[m[4]]
-        built = quad_tree_plan((1, h, w), num_patch_splits=splits, input_layer=InputSpec("categorical", 256),
-                               sum_product=sp, num_input_units=3, num_sum_units=3)
-    else:
-        m = re.fullmatch(r"plan_rbt(\d+)_dNone_(cp|cpt)", name)
-        assert m, name
-        built = random_binary_tree_plan(int(m[1]), input_layer=InputSpec("categorical", 3),
-                                        sum_product={"cp": "cp", "cpt": "cp-t"}[m[2]], num_input_units=2, num_sum_units=2)
-    _assert_same_plan(built, ref)
+        return quad_tree_plan((1, int(m[2]), int(m[3])), num_patch_splits=int(m[1]), input_layer=InputSpec("categorical", 256),
+                              sum_product=sps[m[4]], num_input_units=3, num_sum_units=3)
+    m = re.fullmatch(r"plan_rbt(\d+)_dNone_(cp|cpt)", name)
+    if m:
+        return random_binary_tree_plan(int(m[1]), input_layer=InputSpec("categorical", 3), sum_product=sps[m[2]],
+                                       num_input_units=2, num_sum_units=2)
+    m = re.fullmatch(r"plan_(quadgraph|quadtree2|quadtree4|poondomingos|randombinarytree)_(\d+)x(\d+)x(\d+)_(cp|cpt|tucker)(_mixFalse)?(_nc3)?", name)
+    if m:
+        rg = {"quadgraph": "quad-graph", "quadtree2": "quad-tree-2", "quadtree4": "quad-tree-4", "poondomingos": "poon-domingos",
+              "randombinarytree": "random-binary-tree"}[m[1]]
+        return image_data((int(m[2]), int(m[3]), int(m[4])), rg, input_layer="categorical", num_input_units=3,
+                          sum_product_layer=sps[m[5]], num_sum_units=3, use_mixing_weights=not m[6], num_classes=3 if m[7] else 1)
+    small = dict(num_input_units=2, num_sum_units=2, sum_product="cp")
+    if name == "plan_pd_1x12x12_delta6-3_cp":
+        return build_plan(poon_domingos((1, 12, 12), delta=[6, 3]), input_layer=InputSpec("categorical", 5), **small)
+    if name == "plan_pd_1x9x6_delta2_depth2_cp":
+        return build_plan(poon_domingos((1, 9, 6), delta=2, max_depth=2), input_layer=InputSpec("categorical", 5), **small)
+    if name == "plan_rbt11_d2_cp":
+        return random_binary_tree_plan(11, depth=2, input_layer=InputSpec("categorical", 3), **small)
+    if name == "plan_rbt19_d3_cpt":
+        return random_binary_tree_plan(19, depth=3, seed=7, input_layer=InputSpec("categorical", 3), **{**small, "sum_product": "cp-t"})
+    if name == "plan_rbt6_perfeature_cp":
+        return tabular_data("random-binary-tree", num_features=6,
+                            input_layers=[{"name": "categorical", "args": {"num_categories": 3}}, {"name": "gaussian", "args": {}}] * 3,
+                            num_input_units=2, sum_product_layer="cp", num_sum_units=2)
+    raise AssertionError(f"no native recipe for fixture {name}")
+
+
+@pytest.mark.parametrize("name", PLAN_ONLY)
+def test_awkward_shapes_match_reference_plans(name):
+    _assert_same_plan(_rebuild(name), Plan.load(os.path.join(GOLDEN, name)))
+
+
+def test_poon_domingos_784_gaussian_matches_reference_plan():
+    """BASELINE config 4: 10 904 symbolic layers -> 38 folded, mixing layers of arity 2..12, one
+    collapsed Sum -> Sum pair whose weight is a MatMul parameter node."""
+    from cirkit_amd.templates import image_data
+
+    built = image_data((1, 28, 28), "poon-domingos", input_layer="gaussian", num_input_units=64,
+                       sum_product_layer="cp", num_sum_units=64)
+    _assert_same_plan(built, Plan.load(os.path.join(GOLDEN, "cfg4_pd784")))
+    assert [n.op for n in built.layers[35].params["weight"].nodes] == ["tensor", "tensor", "softmax", "softmax", "mixing_weight", "matmul"]
 
 
 def test_template_entry_points_mirror_the_reference_signatures():
@@ -87,10 +123,13 @@ def test_template_entry_points_mirror_the_reference_signatures():
                      input_layers={"name": "categorical", "args": {"num_categories": 4}},
                      num_input_units=4, sum_product_layer="cp", num_sum_units=4)
     _assert_same_plan(b, Plan.load(os.path.join(GOLDEN, "cfg1_rbt8")))
+    with pytest.raises(ValueError):
+        image_data((1, 28, 28), region_graph="hexagons", num_input_units=4, num_sum_units=4)
     with pytest.raises(NotImplementedError):
-        image_data((1, 28, 28), region_graph="poon-domingos", num_input_units=4, num_sum_units=4)
+        image_data((1, 4, 4), input_layer="binomial", num_input_units=4, num_sum_units=4)
     with pytest.raises(NotImplementedError):
-        image_data((3, 8, 8), num_input_units=4, num_sum_units=4)
+        tabular_data("chow-liu-tree", num_features=4, input_layers={"name": "gaussian", "args": {}},
+                     num_input_units=2, num_sum_units=2)
 
 
 def test_region_graph_structure():
