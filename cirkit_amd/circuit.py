@@ -71,6 +71,10 @@ class HipCircuit:
             takes C distinct values per fold, so the dense layer is applied once per forward to the
             (F, C, K) log-probability table (same kernel, batch = C) instead of to every batch row;
             bit-identical results, B/C times less work for that layer.
+        cache_params: the reference re-evaluates every parameter graph (softmax, log, ...) on every
+            forward and so does the default here.  True keeps the derived parameters of the last
+            forward and recomputes them only after a parameter value changed (`TensorStore.set`,
+            `invalidate_parameters`) -- the serving configuration.
     """
 
     def __init__(
@@ -85,6 +89,7 @@ class HipCircuit:
         contraction: str = "f32",
         dense_on_table: bool = True,
         tiled_weights: bool = True,
+        cache_params: bool = False,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -94,6 +99,9 @@ class HipCircuit:
         capi.load()
         self.plan = plan
         self.use_graph = use_graph
+        self.cache_params = bool(cache_params)
+        self._pprog = None
+        self._pprog_version = self._pprog_data_version = -1
         if isinstance(tensors, TensorStore):
             self.store = tensors
         else:
@@ -183,6 +191,8 @@ class HipCircuit:
         try:
             for b in self._bindings.values():
                 b.destroy()
+            if self._pprog is not None:
+                capi.load().ck_program_destroy(self._pprog)
         except Exception:
             pass
 
@@ -199,6 +209,8 @@ class HipCircuit:
         if len(self._bindings) >= 4:  # keep a handful of batch sizes resident
             old = next(iter(self._bindings))
             self._bindings.pop(old).destroy()
+        if self.cache_params:
+            self._param_program()  # allocates the derived-parameter buffers the layer launches point at
         bd = _Binding()
         bd.B = B
         bd.store_version = self.store.version
@@ -238,26 +250,55 @@ class HipCircuit:
         prog = C.c_void_p()
         capi.call("ck_program_begin", C.byref(prog))
         try:
-            self._enqueue_all(bd, 0)
+            if not self.cache_params:
+                self._enqueue_params(0)
+            self._enqueue_layers(bd, 0)
         finally:
             capi.call("ck_program_end", prog)
         bd.program = prog
         self._bindings[B] = bd
         return bd
 
-    def _enqueue_all(self, bd: _Binding, stream: int) -> None:
-        """One forward: per layer, parameter graph then the layer kernel (the order of
-        graph/modules.py:326-334)."""
-        B = bd.B
+    def _param_program(self):
+        """`cache_params`: the parameter-only launch list, recorded once per set of tensor objects
+        and replayed only after a parameter VALUE changed (`TensorStore.data_version`)."""
+        if self._pprog is not None and self._pprog_version == self.store.version:
+            return self._pprog
+        if self._pprog is not None:
+            capi.load().ck_program_destroy(self._pprog)
+            self._pprog = None
+        prog = C.c_void_p()
+        capi.call("ck_program_begin", C.byref(prog))
+        try:
+            self._enqueue_params(0)
+        finally:
+            capi.call("ck_program_end", prog)
+        self._pprog, self._pprog_version, self._pprog_data_version = prog, self.store.version, -1
+        return prog
+
+    def invalidate_parameters(self) -> None:
+        """Tell a `cache_params` circuit that parameter values were modified in place behind the
+        store's back (e.g. by an optimiser kernel writing through a raw pointer)."""
+        self.store.touch()
+
+    def _enqueue_params(self, stream: int) -> None:
+        """Everything that depends on the parameters only (the reference re-evaluates the parameter
+        graphs on every forward, parameters/parameter.py:180-188): the batched softmax prologue, the
+        remaining parameter graphs, table re-layouts, and the dense layer pushed through the table."""
         self._launch_param_batch(stream)
+        for l in self.layers:
+            l.prepare(stream, batched=self.batch_params)
+        for g in self._groups:
+            self._group_table(g, stream)
+
+    def _enqueue_layers(self, bd: _Binding, stream: int) -> None:
+        """The layer kernels of one forward, in plan order (graph/modules.py:326-334)."""
+        B = bd.B
         for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
             if self._tail and i in self._tail:
                 if i == self._tail[0]:
-                    for j in self._tail:
-                        self.layers[j].prepare(stream, batched=self.batch_params)
                     self._launch_tail(bd, stream)
                 continue
-            l.prepare(stream, batched=self.batch_params)
             if i in self._virtual:
                 continue
             if i in self._group_of_root:
@@ -298,31 +339,39 @@ class HipCircuit:
             next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR), stream,
         )
 
-    def _launch_group(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int) -> None:
-        """One fused launch for Categorical -> [dense] -> CP-T levels (cirkit_amd/csrc/ck_fused.hip)."""
+    def _group_table(self, g: SubtreeGroup, stream: int | None):
+        """The (table, in-kernel dense weight) pair a fused leaf launch reads.  With `dense_on_table`
+        the dense layer is pushed through the table first: T'[d] = dense_d(table[leaf(d)]) over the
+        C categories (+ the integral row); `stream` None only looks the buffers up."""
         dev = self._group_dev.get(g.root)
         if dev is None:
             dev = (torch.from_numpy(g.nodes).to(self.device),)
             self._group_dev[g.root] = dev
         cat = self.layers[g.input_layer]
         w_dense = None if g.dense_layer is None else self.layers[g.dense_layer]._w
-        table = cat._table
-        if w_dense is not None and self.dense_on_table and g.depth > 0:
-            # push the dense layer through the table: T'[d] = dense_d(table[leaf(d)]) over the C categories
-            dl = self.layers[g.dense_layer]
-            Cn, K = cat.num_categories, cat.num_output_units
-            if len(dev) == 1:
-                leaf_of_dense = self._children[g.dense_layer][:, 0, 1].astype(np.int64)
-                dev = dev + (  # Cn + 1 rows: the integral row goes through the dense layer as well
-                    torch.empty((dl.num_folds, Cn + 1, K), dtype=torch.float32, device=self.device),
-                    torch.from_numpy(np.ascontiguousarray(leaf_of_dense * ((Cn + 1) * K))).to(self.device),
-                )
-                self._group_dev[g.root] = dev
+        if w_dense is None or not self.dense_on_table or g.depth == 0:
+            return cat._table, w_dense
+        dl = self.layers[g.dense_layer]
+        Cn, K = cat.num_categories, cat.num_output_units
+        if len(dev) == 1:
+            leaf_of_dense = self._children[g.dense_layer][:, 0, 1].astype(np.int64)
+            dev = dev + (
+                torch.empty((dl.num_folds, Cn + 1, K), dtype=torch.float32, device=self.device),
+                torch.from_numpy(np.ascontiguousarray(leaf_of_dense * ((Cn + 1) * K))).to(self.device),
+            )
+            self._group_dev[g.root] = dev
+        if stream is not None:
             capi.call(
-                "ck_sum_lse_fwd", table.data_ptr(), dev[2].data_ptr(), w_dense.data_ptr(), dev[1].data_ptr(),
+                "ck_sum_lse_fwd", cat._table.data_ptr(), dev[2].data_ptr(), w_dense.data_ptr(), dev[1].data_ptr(),
                 dl.num_folds, 1, Cn + 1, K, K, capi.CK_SUM_CAT, dl._w_layout, stream,
             )
-            table, w_dense = dev[1], None
+        return dev[1], None
+
+    def _launch_group(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int, *, with_table: bool = False) -> None:
+        """One fused launch for Categorical -> [dense] -> CP-T levels (cirkit_amd/csrc/ck_fused.hip)."""
+        table, w_dense = self._group_table(g, stream if with_table else None)
+        dev = self._group_dev[g.root]
+        cat = self.layers[g.input_layer]
         levels = (C.c_void_p * max(1, g.depth))(*[self.layers[j]._w.data_ptr() for j in g.levels])
         node_off = (C.c_int32 * (g.depth + 1))(*g.node_off)
         capi.call(
@@ -419,6 +468,9 @@ class HipCircuit:
             stream = run.cuda_stream
             if self.plan.num_variables:
                 self._stage_input(bd, xf, xi, stream)
+            if self.cache_params and self._pprog_data_version != self.store.data_version:
+                self._pprog_data_version = self.store.data_version
+                capi.call("ck_program_launch", self._param_program(), 1 if self.use_graph else 0, stream)
             capi.call("ck_program_launch", bd.program, 1 if self.use_graph else 0, stream)
             if run is not cur:
                 cur.wait_stream(run)
@@ -533,7 +585,7 @@ class HipCircuit:
                 elif i in self._virtual:
                     pass
                 elif i in self._group_of_root:
-                    self._launch_group(self._group_of_root[i], bd, view, stream)
+                    self._launch_group(self._group_of_root[i], bd, view, stream, with_table=True)
                 elif isinstance(l, HipConstantValueLayer):
                     l.launch_const(view, B, stream)
                 elif isinstance(l, HipInputLayer):

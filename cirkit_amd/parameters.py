@@ -32,12 +32,18 @@ class TensorStore:
     def __init__(self, device: torch.device | str):
         self.device = torch.device(device)
         self._t: dict[str, torch.Tensor] = {}
-        self.version = 0
+        self.version = 0  # bumps when a tensor OBJECT is replaced (recorded pointers go stale)
+        self.data_version = 0  # bumps on every value change (derived-parameter caches go stale)
+
+    def touch(self) -> None:
+        """Record that tensor values were modified in place outside `set`."""
+        self.data_version += 1
 
     def set(self, name: str, value) -> None:
         if isinstance(value, np.ndarray):
             value = torch.from_numpy(np.ascontiguousarray(value))
         value = value.detach()
+        self.data_version += 1
         if value.dtype not in (torch.float32, torch.complex64):
             value = value.to(torch.complex64 if value.is_complex() else torch.float32)
         cur = self._t.get(name)

@@ -217,6 +217,7 @@ class HipTrainer:
                           self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, stream)
             else:
                 capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, stream)
+        self.circuit.store.touch()  # values changed in place: circuits that cache derived parameters must refresh
 
     def step(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
         """One optimisation step on this rank's shard; returns the device tensor [sum log p, count]

@@ -339,3 +339,28 @@ def test_native_poon_domingos_784_matches_golden(hip_device):
     y = hc(torch.from_numpy(g["x"].astype(np.float32)).to(hip_device)).cpu().numpy().reshape(-1)
     ref = g["y_f64"].reshape(-1)
     assert np.allclose(y, ref, rtol=REL), float(np.abs(y - ref).max())
+
+
+def test_cached_parameters_are_refreshed_when_values_change(hip_device):
+    """`cache_params=True` (serving): derived parameters are computed on the first forward and after
+    every parameter update, never in between -- results equal the recompute-every-forward default."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    x = _x_of(plan, g).to(hip_device)
+    ref = HipCircuit(plan, tensors, device=hip_device)
+    hc = HipCircuit(plan, tensors, device=hip_device, cache_params=True)
+    y0 = hc(x).clone()
+    assert torch.equal(y0, ref(x))
+    assert torch.equal(hc(x), y0) and torch.equal(hc(x[:7]), y0[:7])  # replays (and a new batch size) reuse the cache
+    bumped = {k: (v + 0.25 * np.sin(np.arange(v.size, dtype=np.float32)).reshape(v.shape)) for k, v in tensors.items()}
+    hc.store.update(bumped)
+    ref.store.update(bumped)
+    y1 = hc(x).clone()
+    assert torch.equal(y1, ref(x)) and not torch.equal(y1, y0)
+    # in-place edits behind the store's back need an explicit invalidation
+    hc.store["t1"].mul_(0.5)
+    ref.store["t1"].mul_(0.5)
+    assert torch.equal(hc(x), y1)
+    hc.invalidate_parameters()
+    assert torch.equal(hc(x), ref(x))
