@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _capi as capi
-from .fusion import SubtreeGroup, find_subtree_groups, find_tail
+from .fusion import CPBlock, SubtreeGroup, find_cp_blocks, find_subtree_groups, find_tail
 from .layers import HipConstantValueLayer, HipInputLayer, HipLayer, layer_from_spec
 from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
@@ -41,6 +41,8 @@ class _Binding:
         self.row_off: list[torch.Tensor | None] = []
         self.xt: torch.Tensor | None = None  # (D, B) fp32 staging copy of the batch
         self.xt_i: torch.Tensor | None = None  # (D, B) int32 staging copy
+        self.leftover: dict[int, tuple[torch.Tensor, torch.Tensor]] = {}
+        self.cp_tabs: dict[int, torch.Tensor] = {}  # device-address tables of the weight matrices (keep alive)
         self.program = None  # ck_program*
         self.store_version = -1
         self.ll: torch.Tensor | None = None
@@ -139,6 +141,15 @@ class HipCircuit:
         self._tail: list[int] = (
             find_tail(plan, self.layers, self._virtual | set(self._group_of_root)) if fuse is not False else []
         )
+        # dense sum layers evaluated inside the Hadamard layer that multiplies them (ck_cp.hip)
+        self._cp_blocks: dict[int, CPBlock] = {}
+        self._cp_leftover: dict[int, np.ndarray] = {}
+        if fuse is not False:
+            blocks, leftover, virt = find_cp_blocks(
+                plan, self.layers, self._children, self._out_pairs, self._virtual | set(self._group_of_root) | set(self._tail))
+            self._cp_blocks = {b.layer: b for b in blocks}
+            self._cp_leftover = leftover
+            self._virtual |= virt
         self.batch_params = batch_params
         self._batch: ParamBatch | None = None
         self._batch_version = -1
@@ -171,6 +182,10 @@ class HipCircuit:
         if not all(elig[j] for j in k32):
             for j in k32:
                 layout[j] = capi.CK_W_ROWMAJOR
+        for b in self._cp_blocks.values():  # ck_cp_lse_fwd stages row-major matrices itself
+            for d in np.unique(b.slot_dense[..., 0]):
+                if d >= 0:
+                    layout[int(d)] = capi.CK_W_ROWMAJOR
         for i, l in enumerate(self.layers):
             if hasattr(l, "_w_layout"):
                 l._w_layout = layout[i]
@@ -235,6 +250,8 @@ class HipCircuit:
             if ch is None or i in self._virtual or i in self._group_of_root:
                 bd.row_off.append(None)
                 continue
+            if i in self._cp_blocks:  # slots read the dense folds' own inputs
+                ch = self._cp_blocks[i].slot_child
             prod, fold = ch[..., 0], ch[..., 1]
             ko = np.asarray([self.layers[p].num_output_units for p in prod.reshape(-1)]).reshape(prod.shape)
             if not np.all(ko == l.num_input_units):
@@ -245,6 +262,10 @@ class HipCircuit:
             shape = (self.plan.num_variables, B)
             bd.xt = torch.empty(shape, dtype=torch.float32, device=self.device) if self._float_input else None
             bd.xt_i = torch.empty(shape, dtype=torch.int32, device=self.device) if self._int_input else None
+        for d, folds in self._cp_leftover.items():  # (row offsets, output offsets) of the folds still materialised
+            K = self.layers[d].num_output_units
+            bd.leftover[d] = (bd.row_off[d][torch.from_numpy(folds).to(self.device)].contiguous(),
+                              torch.from_numpy(bases[d] + folds * (B * K)).to(self.device))
         bd.ll = torch.empty(2, dtype=torch.float64, device=self.device)
         # record the launch list once
         prog = C.c_void_p()
@@ -303,12 +324,44 @@ class HipCircuit:
                 continue
             if i in self._group_of_root:
                 self._launch_group(self._group_of_root[i], bd, view, stream)
+            elif i in self._cp_blocks or i in self._cp_leftover:
+                self._launch_cp(i, bd, stream)
             elif isinstance(l, HipConstantValueLayer):
                 l.launch_const(view, B, stream)
             elif isinstance(l, HipInputLayer):
                 l.launch_input(bd.xt if l.wants_float_input else bd.xt_i, self.plan.num_variables, view, B, stream)
             else:
                 l.launch(bd.arena, ro, view, B, stream)
+
+    def _launch_cp(self, i: int, bd: _Binding, stream: int) -> None:
+        """`ck_cp_lse_fwd`: a Hadamard layer with its dense layers folded in, or the folds of a dense
+        layer that consumers outside such blocks still read."""
+        l = self.layers[i]
+        K = l.num_output_units
+        tab = bd.cp_tabs.get(i)
+        if i in self._cp_blocks:
+            blk = self._cp_blocks[i]
+            if tab is None:
+                addr = np.zeros(blk.slot_dense.shape[:2], dtype=np.int64)
+                for d in np.unique(blk.slot_dense[..., 0]):
+                    if d < 0:
+                        continue
+                    w = self.layers[int(d)]._w
+                    if w.is_complex() or w.dtype != torch.float32 or not w.is_contiguous():
+                        raise ValueError("CP blocks need real, contiguous fp32 weights")
+                    sel = blk.slot_dense[..., 0] == d
+                    addr[sel] = w.data_ptr() + blk.slot_dense[..., 1][sel] * (K * K * 4)
+                tab = bd.cp_tabs[i] = torch.from_numpy(addr).to(self.device)
+            F, S = blk.slot_dense.shape[:2]
+            capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), None,
+                      bd.views[i].data_ptr(), F, S, 1, bd.B, K, stream)
+            return
+        folds = self._cp_leftover[i]
+        ro, oo = bd.leftover[i]
+        if tab is None:
+            tab = bd.cp_tabs[i] = torch.from_numpy(l._w.data_ptr() + folds.astype(np.int64) * (K * K * 4)).to(self.device)
+        capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), oo.data_ptr(),
+                  bd.arena.data_ptr(), len(folds), 1, 1, bd.B, K, stream)
 
     def _launch_param_batch(self, stream: int) -> None:
         if not self.batch_params:
@@ -499,8 +552,11 @@ class HipCircuit:
 
     def layer_outputs(self, x: torch.Tensor | None = None) -> list[torch.Tensor]:
         """All ``(F, B, Ko)`` layer outputs of one forward (views of the arena; None for layers that
-        cross-layer fusion never materialises) -- for parity tests."""
-        return list(self._run(x).views)
+        cross-layer fusion never materialises, or materialises only in part) -- for parity tests."""
+        views = list(self._run(x).views)
+        for d in self._cp_leftover:
+            views[d] = None
+        return views
 
     def log_likelihood_sum(self, x: torch.Tensor) -> torch.Tensor:
         """Device tensor ``[sum_b log p(x_b), B]`` in fp64 -- the two numbers the data-parallel
@@ -521,6 +577,8 @@ class HipCircuit:
     def kernel_label(self, i: int) -> str:
         """Name of the HIP kernel that evaluates layer i (as it appears in a rocprofv3 trace)."""
         l, s = self.layers[i], self.plan.layers[i]
+        if i in self._cp_blocks or i in self._cp_leftover:
+            return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root:
             g = self._group_of_root[i]
             in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)
@@ -545,7 +603,7 @@ class HipCircuit:
         prod_like = s.type == "cpt" or l.arity == 1
         if (not self._complex and prod_like and l.num_input_units == l.num_output_units
                 and l.num_input_units in (32, 64)):
-            return f"sum_lse_tile32<{l._w_layout}>" if l.num_input_units == 32 else "sum_lse_mfma<2, 2, 1>"
+            return f"sum_lse_tile32<{l._w_layout}>" if l.num_input_units == 32 else "cp_lse_kernel<2, 8, false>"
         return "sum_lse_generic"
 
     def profile_kernels(self, x: torch.Tensor | None, iters: int = 10) -> list[dict]:
@@ -586,6 +644,8 @@ class HipCircuit:
                     pass
                 elif i in self._group_of_root:
                     self._launch_group(self._group_of_root[i], bd, view, stream, with_table=True)
+                elif i in self._cp_blocks or i in self._cp_leftover:
+                    self._launch_cp(i, bd, stream)
                 elif isinstance(l, HipConstantValueLayer):
                     l.launch_const(view, B, stream)
                 elif isinstance(l, HipInputLayer):
@@ -646,6 +706,16 @@ class HipCircuit:
                                  "algorithmic_flops": sum(layer_flops[j] for j in self._tail)})
                 continue
             nbytes, nflops = layer_bytes[i], layer_flops[i]
+            if i in self._cp_leftover:  # only the folds other consumers need are evaluated here
+                share = len(self._cp_leftover[i]) / l.num_folds
+                nbytes, nflops = nbytes * share, nflops * share
+            if i in self._cp_blocks:  # plus the dense folds evaluated inside the launch
+                dl = self._cp_blocks[i].slot_dense[..., 0]
+                for d in np.unique(dl):
+                    if d >= 0:
+                        share = float((dl == d).sum()) / self.layers[int(d)].num_folds
+                        nbytes += share * layer_bytes[int(d)]
+                        nflops += share * layer_flops[int(d)]
             if i in self._group_of_root:  # the fused launch does the work of every layer it replaces
                 nbytes += sum(layer_bytes[j] for j in self._group_of_root[i].virtual)
                 nflops += sum(layer_flops[j] for j in self._group_of_root[i].virtual)

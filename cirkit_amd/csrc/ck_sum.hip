@@ -6,12 +6,13 @@
 //   m = clamp(max_i v_i) over the INPUTS only, y_o = sum_i W[o,i] * exp(v_i - m) in linear space,
 //   out_o = log(y_o) + m.
 //
-// Two real-valued implementations:
-//   * `sum_lse_mfma`  -- Ki, Ko in {32, 64}: one wavefront owns 32 batch rows of one fold and
-//     evaluates the 32xKi . KixKo contraction with v_mfma_f32_32x32x2_f32 (exact fp32, an fmaf
-//     chain).  The lane layout is chosen so that (a) the row maximum needs a single cross-lane
-//     exchange, (b) inputs are read and outputs written as float4, and (c) the OUTPUT register
-//     layout equals the INPUT register layout of the next layer (what cross-layer fusion needs).
+// Real-valued implementations:
+//   * MFMA paths -- Ki = Ko in {32, 64}: one wavefront owns 32 batch rows of one fold and
+//     evaluates the contraction with v_mfma_f32_32x32x2_f32 (exact fp32, an fmaf chain).  The lane
+//     layout is chosen so that (a) the row maximum needs a single cross-lane exchange, (b) inputs
+//     are read and outputs written as float4, and (c) the OUTPUT register layout equals the INPUT
+//     register layout of the next layer (what cross-layer fusion needs).  K = 32: `sum_lse_tile32`
+//     below (weights in registers, tiled layouts); K = 64: `cp_lse_kernel` (ck_cp.hip, weights in LDS).
 //   * `sum_lse_generic` -- any shape; LDS-staged exp(v - m) rows and W chunks.
 #include <algorithm>
 
@@ -36,102 +37,6 @@ using ck::c32;
 // s = 4g+t of block q contracts units {32q+8g+t (kh=0), 32q+8g+4+t (kh=1)} -- exactly what lane
 // (., kh) holds in register (q, s) for both operands.  The result D[o][b] lands in lane
 // (b, hi) register r with o = 8(r>>2) + 4hi + (r&3): the same ownership as the inputs.
-
-template <int NKI, int NKO, int MODE>
-__global__ void __launch_bounds__(256)
-    sum_lse_mfma(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
-                 const float* __restrict__ w, float* __restrict__ out, int H, int B,
-                 int tiles_per_wave) {
-  constexpr int KI = 32 * NKI, KO = 32 * NKO;
-  const int f = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b_in = lane & 31, kh = lane >> 5;
-  const int waves_per_block = blockDim.x >> 6;
-
-  // Weights of this fold in A-operand layout: wa[p][q][j] = W[32p + b_in][32q + 8g + 4kh + t]
-  float wa[NKO][NKI][16];
-  const float* wf = w + static_cast<int64_t>(f) * KO * KI;
-#pragma unroll
-  for (int p = 0; p < NKO; ++p)
-#pragma unroll
-    for (int q = 0; q < NKI; ++q)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 t4 = *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(32 * p + b_in) * KI +
-                                                           32 * q + 8 * g + 4 * kh);
-        wa[p][q][4 * g + 0] = t4.x;
-        wa[p][q][4 * g + 1] = t4.y;
-        wa[p][q][4 * g + 2] = t4.z;
-        wa[p][q][4 * g + 3] = t4.w;
-      }
-
-  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
-  const int tile0 = (blockIdx.x * waves_per_block + wave) * tiles_per_wave;
-  for (int tt = 0; tt < tiles_per_wave; ++tt) {
-    const int b0 = (tile0 + tt) * 32;
-    if (b0 >= B) break;
-    const int b = b0 + b_in;
-    const bool live = b < B;
-    const int bl = live ? b : B - 1;  // clamp loads; stores are masked
-
-    float v[NKI][16];
-#pragma unroll
-    for (int q = 0; q < NKI; ++q)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[q][j] = 0.f;
-    // MODE PROD: sum the H children elementwise (semiring.prod, semiring.py:375-376)
-    // MODE CAT with H == 1 is the same code path (dense layer).
-    for (int h = 0; h < H; ++h) {
-      const float* src = arena + ro[h] + static_cast<int64_t>(bl) * KI + 4 * kh;
-#pragma unroll
-      for (int q = 0; q < NKI; ++q)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 t4 = *reinterpret_cast<const float4*>(src + 32 * q + 8 * g);
-          v[q][4 * g + 0] += t4.x;
-          v[q][4 * g + 1] += t4.y;
-          v[q][4 * g + 2] += t4.z;
-          v[q][4 * g + 3] += t4.w;
-        }
-    }
-    float m = v[0][0];
-#pragma unroll
-    for (int q = 0; q < NKI; ++q)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) m = fmaxf(m, v[q][j]);
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    m = ck::clamp_finite(m);
-    const float nml = exp_offset(m, 0.f);
-#pragma unroll
-    for (int q = 0; q < NKI; ++q)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[q][j] = __builtin_amdgcn_exp2f(fmaf(v[q][j], kL2E, nml));
-
-    float* dst = out + (static_cast<int64_t>(f) * B + bl) * KO + 4 * kh;
-#pragma unroll
-    for (int p = 0; p < NKO; ++p) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int q = 0; q < NKI; ++q)
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[p][q][s], v[q][s], acc, 0, 0, 0);
-      if (live) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float4 o4;
-          o4.x = fmaf(__builtin_amdgcn_logf(acc[4 * g + 0]), kLN2, m);
-          o4.y = fmaf(__builtin_amdgcn_logf(acc[4 * g + 1]), kLN2, m);
-          o4.z = fmaf(__builtin_amdgcn_logf(acc[4 * g + 2]), kLN2, m);
-          o4.w = fmaf(__builtin_amdgcn_logf(acc[4 * g + 3]), kLN2, m);
-          *reinterpret_cast<float4*>(dst + 32 * p + 8 * g) = o4;
-        }
-      }
-    }
-  }
-}
 
 // K = 32 on the shared register tile (ck_tile.h): supports the tiled weight layouts and the
 // split-precision contraction; each wave keeps the fold's weights in registers across its tiles.
@@ -544,18 +449,7 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
   const bool mfma_ok = !g_force_generic && prod_like && Ki == Ko && Ki == 64 &&
                        ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out);
   if (mfma_ok) {
-    // 4 waves per workgroup, each wave `tpw` 32-row tiles of the same fold (weights stay in
-    // registers across tiles).  Keep >= ~8 workgroups per CU in flight when the layer allows it.
-    const int tiles = (B + 31) / 32;
-    int tpw = 1;
-    while (tpw < 4 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
-    dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
-    return ck::dispatch(
-        [=](hipStream_t s) {
-          hipLaunchKernelGGL((sum_lse_mfma<2, 2, CK_SUM_PROD>), grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
-          return hipGetLastError();
-        },
-        stream);
+    return ck::cp_single_slot(arena, row_off, w, out, F, H, B, Ki, stream);  // ck_cp.hip
   }
   return launch_generic<float, float>(arena, row_off, w, out, F, H, B, Ki, Ko, mode, stream);
 }

@@ -147,3 +147,83 @@ def find_tail(plan, layers, skip: set[int], max_folds: int = 64) -> list[int]:
     tail.reverse()
     # a terminal layer with Ko < 32 may only be consumed by the circuit output
     return tail if len(tail) >= 2 else []
+
+
+# ---------------------------------------------------------------------------------------------
+# CP blocks: dense sum layers folded into the Hadamard layer that multiplies their outputs
+# ---------------------------------------------------------------------------------------------
+CP_K = (32, 64)
+
+
+@dataclass
+class CPBlock:
+    """One Hadamard layer evaluated by `ck_cp_lse_fwd`: slot (f, s) reads `slot_child[f, s]`
+    (producer layer, fold) and, where `slot_dense[f, s, 0] >= 0`, pushes it through fold
+    `slot_dense[f, s, 1]` of dense layer `slot_dense[f, s, 0]` first."""
+
+    layer: int
+    slot_child: np.ndarray  # (F, S, 2)
+    slot_dense: np.ndarray  # (F, S, 2), -1 = plain slot
+
+
+def find_cp_blocks(plan, layers, children, out_pairs, skip: set[int]):
+    """Returns (blocks, leftover, virtual).
+
+    A fold of a dense layer (arity-1 real sum, K -> K with K in CP_K, not a mixing layer) that is
+    consumed exactly once, by a Hadamard layer with the same K, is evaluated inside that Hadamard's
+    launch and never written to memory.  `leftover[d]` lists the folds of dense layer d that other
+    consumers still need (they are evaluated in place by a launch over that subset); a dense layer
+    without leftovers is `virtual` (no activation storage at all)."""
+    if plan.semiring != "lse-sum":
+        return [], {}, set()
+    n = len(layers)
+
+    def is_dense(j: int) -> bool:
+        s, l = plan.layers[j], layers[j]
+        return (j not in skip and s.type == "sum" and l.arity == 1 and not getattr(l, "_mixing", False)
+                and l.num_input_units == l.num_output_units and l.num_output_units in CP_K
+                and not l.is_complex)
+
+    def is_prod(j: int) -> bool:
+        s, l = plan.layers[j], layers[j]
+        return j not in skip and s.type == "hadamard" and l.num_input_units in CP_K and l.arity >= 2
+
+    # how often each (layer, fold) is read, and by whom
+    uses = [np.zeros(l.num_folds, dtype=np.int64) for l in layers]
+    by_prod = [np.zeros(l.num_folds, dtype=np.int64) for l in layers]
+    for j, ch in enumerate(children):
+        if ch is None:
+            continue
+        flat = ch.reshape(-1, 2)
+        for p in np.unique(flat[:, 0]):
+            cnt = np.bincount(flat[flat[:, 0] == p, 1], minlength=layers[int(p)].num_folds)
+            uses[int(p)] += cnt
+            if is_prod(j) and layers[j].num_input_units == layers[int(p)].num_output_units:
+                by_prod[int(p)] += cnt
+    for p, f in out_pairs:
+        uses[int(p)][int(f)] += 1
+    fusable = {d: (uses[d] == 1) & (by_prod[d] == 1) for d in range(n) if is_dense(d)}
+    fusable = {d: m for d, m in fusable.items() if m.any()}
+    if not fusable:
+        return [], {}, set()
+    blocks: list[CPBlock] = []
+    for j in range(n):
+        if not is_prod(j):
+            continue
+        ch = children[j]  # (F, S, 2)
+        slot_child = ch.copy()
+        slot_dense = np.full_like(ch, -1)
+        hit = False
+        for d, mask in fusable.items():
+            sel = (ch[..., 0] == d) & mask[np.where(ch[..., 0] == d, ch[..., 1], 0)]
+            if not sel.any():
+                continue
+            hit = True
+            folds = ch[..., 1][sel]
+            slot_dense[sel] = np.stack([np.full_like(folds, d), folds], axis=-1)
+            slot_child[sel] = children[d][folds, 0]  # the dense fold's own input
+        if hit:
+            blocks.append(CPBlock(j, slot_child, slot_dense))
+    leftover = {d: np.nonzero(~m)[0] for d, m in fusable.items() if not m.all()}
+    virtual = {d for d, m in fusable.items() if m.all()}
+    return blocks, leftover, virtual

@@ -128,6 +128,18 @@ int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* 
 int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* mw, float* out,
                       int F, int H, int B, int K, void* stream);
 
+/* CP sum-product block (what RegionGraph.build_circuit emits for sum_product='cp',
+ * templates/region_graph/graph.py:424-456: one dense TorchSumLayer per child region, inner.py:266-273,
+ * feeding a TorchHadamardLayer, inner.py:126-127) evaluated without materialising the dense outputs:
+ *   out[f,b,:] = sum_s G_s,  G_s = log(W_{f,s} . exp(v_s - m_s)) + m_s  or  G_s = v_s (plain slot),
+ *   v_s = sum_h arena[row_off[f,s,h] + b*K + :],  m_s = clamp(max v_s).
+ * row_off: (F, S, H) element offsets.  w_addr: (F, S) DEVICE ADDRESSES (as int64) of row-major (K, K)
+ * fp32 linear-space weight matrices, 0 for a plain slot; the matrices stay caller-owned.  K in {32, 64}.
+ * out_off: (F) element offsets of each fold's (B, K) output block inside `out`, or NULL for f*B*K
+ * (lets one launch evaluate a subset of the folds of a layer in place). */
+int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* out_off,
+                  float* out, int F, int S, int H, int B, int K, void* stream);
+
 /* TorchHadamardLayer.forward, inner.py:126-127 (lse: sum over the arity axis). esize = 1 (fp32)
  * or 2 (complex64: K counts complex elements). */
 int ck_hadamard_fwd(const float* arena, const int64_t* row_off, float* out, int F, int H, int B,
