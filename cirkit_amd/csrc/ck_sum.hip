@@ -293,37 +293,70 @@ __global__ void __launch_bounds__(256)
 }
 
 // float4 variant: K/4 lanes per row (K/4 a power of two <= 64), 64/(K/4) rows per wave pass.
+// All H inputs of a row are loaded ONCE into registers (H <= HMAX; every load of a lane is in flight
+// before the first use) and serve both the maximum and the weighted sum; the (K, H) coefficients are
+// transposed into LDS so that a lane reads its four per input as one 16-byte word.  HMAX = 0: any H,
+// two passes over the inputs (the second one hits L1/L2).
+template <int HMAX>
 __global__ void __launch_bounds__(256)
     mixing_lse_vec(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                    const float* __restrict__ mw, float* __restrict__ out, int H, int B, int K,
                    int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float mw_s[];  // [H][K]
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lpr = K >> 2, rpw = 64 / lpr;
   const int r_in = lane / lpr, q = lane - r_in * lpr;
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
   const float* mwf = mw + static_cast<int64_t>(f) * K * H;
+  for (int i = threadIdx.x; i < K * H; i += blockDim.x) {
+    const int k = i / H, h = i - k * H;
+    mw_s[h * K + k] = mwf[i];
+  }
+  __syncthreads();
   const int b_begin = blockIdx.x * rows_per_block;
   const int b_end = min(B, b_begin + rows_per_block);
   for (int b0 = b_begin + wave * rpw; b0 < b_end; b0 += 4 * rpw) {
     const int b = min(b0 + r_in, B - 1);
     const bool live = b0 + r_in < b_end;
     float mx = -INFINITY;
-    for (int h = 0; h < H; ++h) {
-      const float4 v = reinterpret_cast<const float4*>(arena + ro[h] + static_cast<int64_t>(b) * K)[q];
-      mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-    }
-    for (int o = lpr >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    mx = ck::clamp_finite(mx);
-    const float nml = exp_offset(mx, 0.f);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int h = 0; h < H; ++h) {
-      const float4 v = reinterpret_cast<const float4*>(arena + ro[h] + static_cast<int64_t>(b) * K)[q];
-      const float* w4 = mwf + static_cast<int64_t>(4 * q) * H + h;
-      acc.x = fmaf(w4[0], __builtin_amdgcn_exp2f(fmaf(v.x, kL2E, nml)), acc.x);
-      acc.y = fmaf(w4[H], __builtin_amdgcn_exp2f(fmaf(v.y, kL2E, nml)), acc.y);
-      acc.z = fmaf(w4[2 * H], __builtin_amdgcn_exp2f(fmaf(v.z, kL2E, nml)), acc.z);
-      acc.w = fmaf(w4[3 * H], __builtin_amdgcn_exp2f(fmaf(v.w, kL2E, nml)), acc.w);
+    if constexpr (HMAX > 0) {
+      float4 v[HMAX];
+#pragma unroll
+      for (int h = 0; h < HMAX; ++h)
+        if (h < H) v[h] = reinterpret_cast<const float4*>(arena + ro[h] + static_cast<int64_t>(b) * K)[q];
+#pragma unroll
+      for (int h = 0; h < HMAX; ++h)
+        if (h < H) mx = fmaxf(mx, fmaxf(fmaxf(v[h].x, v[h].y), fmaxf(v[h].z, v[h].w)));
+      for (int o = lpr >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = ck::clamp_finite(mx);
+      const float nml = exp_offset(mx, 0.f);
+#pragma unroll
+      for (int h = 0; h < HMAX; ++h)
+        if (h < H) {
+          const float4 w4 = *reinterpret_cast<const float4*>(mw_s + h * K + 4 * q);
+          acc.x = fmaf(w4.x, __builtin_amdgcn_exp2f(fmaf(v[h].x, kL2E, nml)), acc.x);
+          acc.y = fmaf(w4.y, __builtin_amdgcn_exp2f(fmaf(v[h].y, kL2E, nml)), acc.y);
+          acc.z = fmaf(w4.z, __builtin_amdgcn_exp2f(fmaf(v[h].z, kL2E, nml)), acc.z);
+          acc.w = fmaf(w4.w, __builtin_amdgcn_exp2f(fmaf(v[h].w, kL2E, nml)), acc.w);
+        }
+    } else {
+      for (int h = 0; h < H; ++h) {
+        const float4 v = reinterpret_cast<const float4*>(arena + ro[h] + static_cast<int64_t>(b) * K)[q];
+        mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+      }
+      for (int o = lpr >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      mx = ck::clamp_finite(mx);
+      const float nml = exp_offset(mx, 0.f);
+      for (int h = 0; h < H; ++h) {
+        const float4 v = reinterpret_cast<const float4*>(arena + ro[h] + static_cast<int64_t>(b) * K)[q];
+        const float4 w4 = *reinterpret_cast<const float4*>(mw_s + h * K + 4 * q);
+        acc.x = fmaf(w4.x, __builtin_amdgcn_exp2f(fmaf(v.x, kL2E, nml)), acc.x);
+        acc.y = fmaf(w4.y, __builtin_amdgcn_exp2f(fmaf(v.y, kL2E, nml)), acc.y);
+        acc.z = fmaf(w4.z, __builtin_amdgcn_exp2f(fmaf(v.z, kL2E, nml)), acc.z);
+        acc.w = fmaf(w4.w, __builtin_amdgcn_exp2f(fmaf(v.w, kL2E, nml)), acc.w);
+      }
     }
     if (live) {
       float4 o4;
@@ -474,10 +507,18 @@ int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* m
                    ck::aligned16(out);
   const int rows_per_block = vec ? 128 : 32;
   dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
+  const size_t lds = static_cast<size_t>(K) * H * sizeof(float);
+  CK_REQUIRE(!vec || lds <= 64 * 1024, "ck_mixing_lse_fwd: K*H=%d coefficients do not fit in LDS", K * H);
   return ck::dispatch(
       [=](hipStream_t s) {
-        if (vec)
-          hipLaunchKernelGGL(mixing_lse_vec, grid, block, 0, s, arena, row_off, mw, out, H, B, K, rows_per_block);
+        if (vec && H <= 4)
+          hipLaunchKernelGGL(mixing_lse_vec<4>, grid, block, lds, s, arena, row_off, mw, out, H, B, K, rows_per_block);
+        else if (vec && H <= 8)
+          hipLaunchKernelGGL(mixing_lse_vec<8>, grid, block, lds, s, arena, row_off, mw, out, H, B, K, rows_per_block);
+        else if (vec && H <= 16)
+          hipLaunchKernelGGL(mixing_lse_vec<16>, grid, block, lds, s, arena, row_off, mw, out, H, B, K, rows_per_block);
+        else if (vec)
+          hipLaunchKernelGGL(mixing_lse_vec<0>, grid, block, lds, s, arena, row_off, mw, out, H, B, K, rows_per_block);
         else
           hipLaunchKernelGGL(mixing_lse_kernel, grid, block, 0, s, arena, row_off, mw, out, H, B, K, rows_per_block);
         return hipGetLastError();
