@@ -48,6 +48,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_transpose_f32": [_p, _p, _i, _i, _p],
     "ck_categorical_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_gaussian_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_gaussian_prod_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_embedding_clog_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_embedding_log_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_constant_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p],

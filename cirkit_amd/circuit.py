@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _capi as capi
-from .fusion import CPBlock, SubtreeGroup, find_cp_blocks, find_subtree_groups, find_tail
+from .fusion import CPBlock, SubtreeGroup, find_cp_blocks, find_input_products, find_subtree_groups, find_tail
 from .layers import HipConstantValueLayer, HipInputLayer, HipLayer, layer_from_spec
 from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
@@ -144,9 +144,15 @@ class HipCircuit:
         # dense sum layers evaluated inside the Hadamard layer that multiplies them (ck_cp.hip)
         self._cp_blocks: dict[int, CPBlock] = {}
         self._cp_leftover: dict[int, np.ndarray] = {}
+        self._input_prod: dict[int, int] = {}  # Hadamard layer -> the Gaussian layer it multiplies (ck_input.hip)
+        self._input_prod_dev: dict[int, torch.Tensor] = {}
         if fuse is not False:
-            blocks, leftover, virt = find_cp_blocks(
+            self._input_prod = find_input_products(
                 plan, self.layers, self._children, self._out_pairs, self._virtual | set(self._group_of_root) | set(self._tail))
+            self._virtual |= set(self._input_prod.values())
+            blocks, leftover, virt = find_cp_blocks(
+                plan, self.layers, self._children, self._out_pairs,
+                self._virtual | set(self._group_of_root) | set(self._tail) | set(self._input_prod))
             self._cp_blocks = {b.layer: b for b in blocks}
             self._cp_leftover = leftover
             self._virtual |= virt
@@ -326,12 +332,27 @@ class HipCircuit:
                 self._launch_group(self._group_of_root[i], bd, view, stream)
             elif i in self._cp_blocks or i in self._cp_leftover:
                 self._launch_cp(i, bd, stream)
+            elif i in self._input_prod:
+                self._launch_input_prod(i, bd, stream)
             elif isinstance(l, HipConstantValueLayer):
                 l.launch_const(view, B, stream)
             elif isinstance(l, HipInputLayer):
                 l.launch_input(bd.xt if l.wants_float_input else bd.xt_i, self.plan.num_variables, view, B, stream)
             else:
                 l.launch(bd.arena, ro, view, B, stream)
+
+    def _launch_input_prod(self, i: int, bd: _Binding, stream: int) -> None:
+        """`ck_gaussian_prod_fwd`: a Hadamard layer over Gaussian folds, straight from the batch."""
+        g = self.layers[self._input_prod[i]]
+        tab = self._input_prod_dev.get(i)
+        if tab is None:
+            tab = self._input_prod_dev[i] = torch.from_numpy(
+                np.ascontiguousarray(self._children[i][..., 1].astype(np.int32))).to(self.device)
+        mean, stddev, lz = g._vals
+        l = self.layers[i]
+        capi.call("ck_gaussian_prod_fwd", mean.data_ptr(), stddev.data_ptr(), None if lz is None else lz.data_ptr(),
+                  bd.xt.data_ptr(), g._scope(self.device).data_ptr(), tab.data_ptr(), bd.views[i].data_ptr(),
+                  l.num_folds, l.arity, bd.B, l.num_output_units, stream)
 
     def _launch_cp(self, i: int, bd: _Binding, stream: int) -> None:
         """`ck_cp_lse_fwd`: a Hadamard layer with its dense layers folded in, or the folds of a dense
@@ -577,6 +598,8 @@ class HipCircuit:
     def kernel_label(self, i: int) -> str:
         """Name of the HIP kernel that evaluates layer i (as it appears in a rocprofv3 trace)."""
         l, s = self.layers[i], self.plan.layers[i]
+        if i in self._input_prod:
+            return "gaussian_prod_kernel<8>"
         if i in self._cp_blocks or i in self._cp_leftover:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root:
@@ -646,6 +669,8 @@ class HipCircuit:
                     self._launch_group(self._group_of_root[i], bd, view, stream, with_table=True)
                 elif i in self._cp_blocks or i in self._cp_leftover:
                     self._launch_cp(i, bd, stream)
+                elif i in self._input_prod:
+                    self._launch_input_prod(i, bd, stream)
                 elif isinstance(l, HipConstantValueLayer):
                     l.launch_const(view, B, stream)
                 elif isinstance(l, HipInputLayer):
@@ -706,6 +731,8 @@ class HipCircuit:
                                  "algorithmic_flops": sum(layer_flops[j] for j in self._tail)})
                 continue
             nbytes, nflops = layer_bytes[i], layer_flops[i]
+            if i in self._input_prod:
+                nbytes += layer_bytes[self._input_prod[i]]
             if i in self._cp_leftover:  # only the folds other consumers need are evaluated here
                 share = len(self._cp_leftover[i]) / l.num_folds
                 nbytes, nflops = nbytes * share, nflops * share

@@ -180,6 +180,57 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Fully factorised multivariate input: the Hadamard product of H Gaussian folds (what
+// RegionGraph.build_circuit emits for an input region over several variables with
+// factorize_multivariate=True, templates/region_graph/graph.py:531-540) without writing the
+// H (B, K) blocks of the Gaussian layer:  out[f,b,k] = sum_j logN(x[b, var(g_j)]; mean[g_j,k], stddev[g_j,k]),
+// g_j = gfold[f, j].  Thread = one unit k and RPT batch rows; the parameters of (g_j, k) are loaded
+// once per thread and x[b, var] is a broadcast read.
+template <int RPT>
+__global__ void __launch_bounds__(256)
+    gaussian_prod_kernel(const float* __restrict__ mean, const float* __restrict__ stddev,
+                         const float* __restrict__ logz, const float* __restrict__ xt,
+                         const int64_t* __restrict__ scope, const int32_t* __restrict__ gfold,
+                         float* __restrict__ out, int H, int B, int K) {
+  const int f = blockIdx.y;
+  const int kk = K <= 256 ? K : 256;
+  const int lanes_rows = 256 / kk;
+  const int r_in = threadIdx.x / kk, k0 = threadIdx.x - r_in * kk;
+  if (r_in >= lanes_rows) return;
+  const int b0 = blockIdx.x * (lanes_rows * RPT) + r_in;
+  const float kHalfLog2Pi = 0.91893853320467274178f;
+  const int32_t* gf = gfold + static_cast<int64_t>(f) * H;
+  for (int k = k0; k < K; k += kk) {
+    float acc[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) acc[i] = 0.f;
+    for (int j = 0; j < H; ++j) {
+      const int64_t g = gf[j];
+      const float mu = mean[g * K + k];
+      const float sd = stddev[g * K + k];
+      const float two_var = 2.f * (sd * sd);
+      const float tail = __logf(sd);
+      const float lz = logz != nullptr ? logz[g * K + k] : 0.f;
+      const float* xrow = xt + scope[g] * B;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int b = min(b0 + i * lanes_rows, B - 1);
+        const float xv = xrow[b];
+        const float d = xv - mu;
+        float lp = -(d * d) / two_var - tail - kHalfLog2Pi;
+        if (logz != nullptr) lp += lz;
+        if (xv != xv) lp = logz != nullptr ? lz : 0.f;  // NaN = marginalised (input.py:672-679)
+        acc[i] += lp;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int b = b0 + i * lanes_rows;
+      if (b < B) out[(static_cast<int64_t>(f) * B + b) * K + k] = acc[i];
+    }
+  }
+}
+
 // ---- ConstantValue -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
     constant_kernel(const float* __restrict__ value, float* __restrict__ out, int B, int K,
@@ -246,6 +297,26 @@ int ck_gaussian_fwd(const float* mean, const float* stddev, const float* log_par
       [=](hipStream_t s) {
         hipLaunchKernelGGL(gaussian_kernel, grid, block, 0, s, mean, stddev, log_partition, xt, scope,
                            out, B, K, rows_per_block);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_gaussian_prod_fwd(const float* mean, const float* stddev, const float* log_partition, const float* xt,
+                         const int64_t* scope, const int32_t* gfold, float* out, int F, int H, int B, int K,
+                         void* stream) {
+  CK_REQUIRE(mean && stddev && xt && scope && gfold && out, "ck_gaussian_prod_fwd: null pointer");
+  CK_REQUIRE(F > 0 && H > 0 && B > 0 && K > 0, "ck_gaussian_prod_fwd: non-positive size");
+  CK_REQUIRE(F <= 65535, "ck_gaussian_prod_fwd: F=%d exceeds grid.y", F);
+  constexpr int RPT = 8;
+  const int lanes_rows = 256 / (K <= 256 ? K : 256);
+  CK_REQUIRE(lanes_rows >= 1, "ck_gaussian_prod_fwd: unsupported K=%d", K);
+  const int rows_per_block = lanes_rows * RPT;
+  dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(gaussian_prod_kernel<RPT>, grid, block, 0, s, mean, stddev, log_partition, xt, scope,
+                           gfold, out, H, B, K);
         return hipGetLastError();
       },
       stream);

@@ -227,3 +227,32 @@ def find_cp_blocks(plan, layers, children, out_pairs, skip: set[int]):
     leftover = {d: np.nonzero(~m)[0] for d, m in fusable.items() if not m.all()}
     virtual = {d for d, m in fusable.items() if m.all()}
     return blocks, leftover, virtual
+
+
+# ---------------------------------------------------------------------------------------------
+# factorised multivariate inputs: Gaussian folds multiplied straight away by a Hadamard layer
+# ---------------------------------------------------------------------------------------------
+def find_input_products(plan, layers, children, out_pairs, skip: set[int]) -> dict[int, int]:
+    """{hadamard layer: gaussian layer} where EVERY fold of the Gaussian layer is read exactly once,
+    by that Hadamard layer only: `ck_gaussian_prod_fwd` then evaluates the product directly from
+    the batch and the Gaussian layer output is never written."""
+    if plan.semiring != "lse-sum":
+        return {}
+    found: dict[int, int] = {}
+    outs = {int(p) for p in out_pairs[:, 0]}
+    for j, (s, ch) in enumerate(zip(plan.layers, children)):
+        if j in skip or s.type != "hadamard" or ch is None:
+            continue
+        prods = np.unique(ch[..., 0])
+        if len(prods) != 1:
+            continue
+        g = int(prods[0])
+        sg = plan.layers[g]
+        if g in skip or g in outs or sg.type != "gaussian" or sg.scope_idx.shape[1] != 1:
+            continue
+        if any(c is not None and k != j and (c[..., 0] == g).any() for k, c in enumerate(children)):
+            continue
+        if not _uses_each_fold_once(ch, g, layers[g].num_folds):
+            continue
+        found[j] = g
+    return found

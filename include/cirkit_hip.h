@@ -90,6 +90,13 @@ int ck_categorical_fwd(const float* table, const int32_t* xt, const int64_t* sco
 int ck_gaussian_fwd(const float* mean, const float* stddev, const float* log_partition,
                     const float* xt, const int64_t* scope, float* out, int F, int B, int K, int D,
                     void* stream);
+/* A fully factorised multivariate input region (templates/region_graph/graph.py:531-540: one
+ * Gaussian layer per variable multiplied by a TorchHadamardLayer, inner.py:126-127) in one pass:
+ * out[f,b,:] = sum_j ck_gaussian_fwd(fold gfold[f,j])[b,:].  mean/stddev/log_partition/scope are
+ * those of the Gaussian layer (G folds), gfold: (F, H) int32 fold ids into it, out: (F, B, K). */
+int ck_gaussian_prod_fwd(const float* mean, const float* stddev, const float* log_partition, const float* xt,
+                         const int64_t* scope, const int32_t* gfold, float* out, int F, int H, int B, int K,
+                         void* stream);
 
 /* TorchEmbeddingLayer.forward under complex-lse-sum, layers/input.py:258-266 + semiring.py:507-509:
  * out[f,b,k] = clog(weight[f,k,x[b,scope[f]]] + 0j).  table: (F, C, K) fp32 (transposed weight). */
