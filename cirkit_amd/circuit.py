@@ -627,6 +627,9 @@ class HipCircuit:
         if (not self._complex and prod_like and l.num_input_units == l.num_output_units
                 and l.num_input_units in (32, 64)):
             return f"sum_lse_tile32<{l._w_layout}>" if l.num_input_units == 32 else "cp_lse_kernel<2, 8, false>"
+        if (not self._complex and s.type == "sum" and l.arity > 1 and l.num_input_units == l.num_output_units
+                and l.num_input_units in (32, 64)):
+            return f"cat_lse_kernel<{l.num_input_units // 32}, 8>"
         return "sum_lse_generic"
 
     def profile_kernels(self, x: torch.Tensor | None, iters: int = 10) -> list[dict]:

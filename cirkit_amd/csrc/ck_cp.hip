@@ -145,6 +145,104 @@ __global__ void __launch_bounds__(WAVES * 64)
   }
 }
 
+// Dense sum layer over the CONCATENATION of H children (TorchSumLayer with arity > 1 and a full
+// (K, H*K) weight, inner.py:266-273 -- e.g. the Sum -> Sum pair the reference collapses into one
+// layer with a MatMul weight, optimization/layers.py:162-198):
+//   m = max over all children, out = log(sum_h W[:, hK:(h+1)K] . exp(x_h - m)) + m.
+// One maximum for the whole row (first pass over the children), then the H column blocks of the
+// weight are contracted one after the other into the same accumulators.
+template <int NK, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+    cat_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
+                   const float* __restrict__ w, float* __restrict__ out, int H, int B) {
+  constexpr int K = 32 * NK;
+  constexpr int WF4 = K * K / 4;
+  __shared__ __attribute__((aligned(16))) float w_s[2][K * K];
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int b = (blockIdx.x * WAVES + wave) * 32 + b_in;
+  const bool live = b < B;
+  const int bl = live ? b : B - 1;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int ldw = H * K;
+  const float* wf = w + static_cast<int64_t>(f) * K * ldw;
+  auto stage = [&](int h, int buf) {  // column block h of the row-major (K, H*K) matrix
+    for (int i = threadIdx.x; i < WF4; i += WAVES * 64) {
+      const int o = i / (K / 4), k = 4 * (i - o * (K / 4));
+      const int p = o >> 5, q = k >> 5, g = (k >> 3) & 3, ln = (o & 31) + 32 * ((k >> 2) & 1);
+      *reinterpret_cast<float4*>(&w_s[buf][((((p * NK + q) * 4 + g) * 64) + ln) * 4]) =
+          *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o) * ldw + h * K + k);
+    }
+  };
+  stage(0, 0);
+  float m = -INFINITY;
+  for (int h = 0; h < H; ++h) {
+    const float* src = arena + ro[h] + static_cast<int64_t>(bl) * K + 4 * kh;
+#pragma unroll
+    for (int q = 0; q < NK; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 t4 = *reinterpret_cast<const float4*>(src + 32 * q + 8 * g);
+        m = fmaxf(m, fmaxf(fmaxf(t4.x, t4.y), fmaxf(t4.z, t4.w)));
+      }
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  m = ck::clamp_finite(m);
+  const float nml = exp_offset(m, 0.f);
+  f32x16 acc[NK];
+#pragma unroll
+  for (int p = 0; p < NK; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  for (int h = 0; h < H; ++h) {
+    float v[NK][16];
+    const float* src = arena + ro[h] + static_cast<int64_t>(bl) * K + 4 * kh;
+#pragma unroll
+    for (int q = 0; q < NK; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 t4 = *reinterpret_cast<const float4*>(src + 32 * q + 8 * g);
+        v[q][4 * g + 0] = __builtin_amdgcn_exp2f(fmaf(t4.x, kL2E, nml));
+        v[q][4 * g + 1] = __builtin_amdgcn_exp2f(fmaf(t4.y, kL2E, nml));
+        v[q][4 * g + 2] = __builtin_amdgcn_exp2f(fmaf(t4.z, kL2E, nml));
+        v[q][4 * g + 3] = __builtin_amdgcn_exp2f(fmaf(t4.w, kL2E, nml));
+      }
+    if (h + 1 < H) {
+      if (h >= 1) __syncthreads();  // every wave is done with block h - 1, whose buffer is reused now
+      stage(h + 1, (h + 1) & 1);
+    }
+    __syncthreads();  // block h is staged
+    const float* wb = &w_s[h & 1][0];
+#pragma unroll
+    for (int p = 0; p < NK; ++p)
+#pragma unroll
+      for (int q = 0; q < NK; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wb + ((((p * NK + q) * 4 + g) * 64) + lane) * 4);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, v[q][4 * g + 0], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, v[q][4 * g + 1], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, v[q][4 * g + 2], acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, v[q][4 * g + 3], acc[p], 0, 0, 0);
+        }
+  }
+  if (live) {
+    float* dst = out + (static_cast<int64_t>(f) * B + b) * K + 4 * kh;
+#pragma unroll
+    for (int p = 0; p < NK; ++p)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 o4;
+        o4.x = fmaf(__builtin_amdgcn_logf(acc[p][4 * g + 0]), kLN2, m);
+        o4.y = fmaf(__builtin_amdgcn_logf(acc[p][4 * g + 1]), kLN2, m);
+        o4.z = fmaf(__builtin_amdgcn_logf(acc[p][4 * g + 2]), kLN2, m);
+        o4.w = fmaf(__builtin_amdgcn_logf(acc[p][4 * g + 3]), kLN2, m);
+        *reinterpret_cast<float4*>(dst + 32 * p + 8 * g) = o4;
+      }
+  }
+}
+
 template <int NK>
 int launch_cp(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* w_base,
               const int64_t* out_off, float* out, int F, int S, int H, int B, void* stream) {
@@ -165,6 +263,23 @@ int launch_cp(const float* arena, const int64_t* row_off, const int64_t* w_addr,
 }  // namespace
 
 namespace ck {
+// Dense layer over the concatenation of H children, contiguous (F, K, H*K) weights, K in {32, 64}.
+int cat_dense(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,
+              void* stream) {
+  constexpr int WAVES = 8;
+  const int tiles = (B + 31) / 32;
+  dim3 grid((tiles + WAVES - 1) / WAVES, F), block(WAVES * 64);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (K == 64)
+          hipLaunchKernelGGL((cat_lse_kernel<2, WAVES>), grid, block, 0, s, arena, row_off, w, out, H, B);
+        else
+          hipLaunchKernelGGL((cat_lse_kernel<1, WAVES>), grid, block, 0, s, arena, row_off, w, out, H, B);
+        return hipGetLastError();
+      },
+      stream);
+}
+
 // K = 64 dense / CP-T layers of ck_sum_lse_fwd (one slot, contiguous (F, K, K) weights).
 int cp_single_slot(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,
                    void* stream) {

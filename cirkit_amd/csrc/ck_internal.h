@@ -21,6 +21,8 @@ int dispatch(Launch fn, void* stream);
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ck_cp.hip: one dense / CP-T slot with contiguous (F, K, K) weights, K in {32, 64}.
+int cat_dense(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,
+              void* stream);
 int cp_single_slot(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,
                    void* stream);
 

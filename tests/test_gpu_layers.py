@@ -44,7 +44,8 @@ def _close(a, b, tol=2e-5):
 
 
 @pytest.mark.parametrize("F,H,B,Ki,Ko", [(3, 1, 37, 32, 32), (2, 1, 5, 64, 64), (4, 1, 9, 7, 5), (2, 3, 33, 6, 4),
-                                         (1, 11, 17, 64, 64), (5, 1, 1, 1, 1), (2, 2, 70, 40, 96), (1, 1, 3, 300, 2)])
+                                         (1, 11, 17, 64, 64), (5, 1, 1, 1, 1), (2, 2, 70, 40, 96), (1, 1, 3, 300, 2),
+                                         (3, 2, 300, 32, 32), (2, 3, 65, 64, 64), (2, 1, 257, 64, 64)])
 def test_sum_layer_contract(hip_device, F, H, B, Ki, Ko):
     from cirkit_amd.layers import HipSumLayer
     from cirkit_amd.parameters import TensorStore
