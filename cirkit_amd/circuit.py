@@ -23,7 +23,8 @@ import numpy as np
 import torch
 
 from . import _capi as capi
-from .fusion import CPBlock, SubtreeGroup, find_cp_blocks, find_input_products, find_subtree_groups, find_tail
+from .fusion import (CPBlock, RegionBlock, SubtreeGroup, find_cp_blocks, find_input_products, find_region_blocks,
+                     find_subtree_groups, find_tail)
 from .layers import HipConstantValueLayer, HipInputLayer, HipLayer, layer_from_spec
 from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
@@ -92,6 +93,7 @@ class HipCircuit:
         dense_on_table: bool = True,
         tiled_weights: bool = True,
         cache_params: bool = False,
+        fuse_regions: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -144,6 +146,8 @@ class HipCircuit:
         # dense sum layers evaluated inside the Hadamard layer that multiplies them (ck_cp.hip)
         self._cp_blocks: dict[int, CPBlock] = {}
         self._cp_leftover: dict[int, np.ndarray] = {}
+        self._cp_subset: dict[int, np.ndarray] = {}  # CP-block layers of which only these folds are evaluated
+        self._regions: dict[int, RegionBlock] = {}
         self._input_prod: dict[int, int] = {}  # Hadamard layer -> the Gaussian layer it multiplies (ck_input.hip)
         self._input_prod_dev: dict[int, torch.Tensor] = {}
         if fuse is not False:
@@ -156,6 +160,16 @@ class HipCircuit:
             self._cp_blocks = {b.layer: b for b in blocks}
             self._cp_leftover = leftover
             self._virtual |= virt
+            # mixing layers that take over the CP blocks they combine (ck_cp.hip: region_lse_kernel)
+            regions, absorbed = find_region_blocks(
+                plan, self.layers, self._children, self._out_pairs, self._cp_blocks,
+                self._virtual | set(self._group_of_root) | set(self._tail)) if fuse_regions else ([], {})
+            self._regions = {r.layer: r for r in regions}
+            for h, mask in absorbed.items():
+                if mask.all():
+                    self._virtual.add(h)
+                else:  # the folds single-partition regions still read are evaluated on their own
+                    self._cp_subset[h] = np.nonzero(~mask)[0]
         self.batch_params = batch_params
         self._batch: ParamBatch | None = None
         self._batch_version = -1
@@ -258,6 +272,8 @@ class HipCircuit:
                 continue
             if i in self._cp_blocks:  # slots read the dense folds' own inputs
                 ch = self._cp_blocks[i].slot_child
+            if i in self._regions:
+                ch = self._regions[i].slot_child  # (F, H, S, 2)
             prod, fold = ch[..., 0], ch[..., 1]
             ko = np.asarray([self.layers[p].num_output_units for p in prod.reshape(-1)]).reshape(prod.shape)
             if not np.all(ko == l.num_input_units):
@@ -268,6 +284,10 @@ class HipCircuit:
             shape = (self.plan.num_variables, B)
             bd.xt = torch.empty(shape, dtype=torch.float32, device=self.device) if self._float_input else None
             bd.xt_i = torch.empty(shape, dtype=torch.int32, device=self.device) if self._int_input else None
+        for h, folds in self._cp_subset.items():
+            K = self.layers[h].num_output_units
+            bd.leftover[h] = (bd.row_off[h][torch.from_numpy(folds).to(self.device)].contiguous(),
+                              torch.from_numpy(bases[h] + folds * (B * K)).to(self.device))
         for d, folds in self._cp_leftover.items():  # (row offsets, output offsets) of the folds still materialised
             K = self.layers[d].num_output_units
             bd.leftover[d] = (bd.row_off[d][torch.from_numpy(folds).to(self.device)].contiguous(),
@@ -332,6 +352,8 @@ class HipCircuit:
                 self._launch_group(self._group_of_root[i], bd, view, stream)
             elif i in self._cp_blocks or i in self._cp_leftover:
                 self._launch_cp(i, bd, stream)
+            elif i in self._regions:
+                self._launch_region(i, bd, stream)
             elif i in self._input_prod:
                 self._launch_input_prod(i, bd, stream)
             elif isinstance(l, HipConstantValueLayer):
@@ -340,6 +362,31 @@ class HipCircuit:
                 l.launch_input(bd.xt if l.wants_float_input else bd.xt_i, self.plan.num_variables, view, B, stream)
             else:
                 l.launch(bd.arena, ro, view, B, stream)
+
+    def _weight_addresses(self, slot_dense: np.ndarray, K: int) -> np.ndarray:
+        """Device addresses of the (K, K) weight matrices of the dense folds in `slot_dense` (0 = none)."""
+        addr = np.zeros(slot_dense.shape[:-1], dtype=np.int64)
+        for d in np.unique(slot_dense[..., 0]):
+            if d < 0:
+                continue
+            w = self.layers[int(d)]._w
+            if w.is_complex() or w.dtype != torch.float32 or not w.is_contiguous():
+                raise ValueError("CP blocks need real, contiguous fp32 weights")
+            sel = slot_dense[..., 0] == d
+            addr[sel] = w.data_ptr() + slot_dense[..., 1][sel] * (K * K * 4)
+        return addr
+
+    def _launch_region(self, i: int, bd: _Binding, stream: int) -> None:
+        """`ck_region_lse_fwd`: a mixing layer together with the CP blocks it combines."""
+        l = self.layers[i]
+        reg = self._regions[i]
+        K = l.num_output_units
+        tab = bd.cp_tabs.get(i)
+        if tab is None:
+            tab = bd.cp_tabs[i] = torch.from_numpy(self._weight_addresses(reg.slot_dense, K)).to(self.device)
+        F, H, S = reg.slot_dense.shape[:3]
+        capi.call("ck_region_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), l._w.data_ptr(),
+                  bd.views[i].data_ptr(), F, H, S, bd.B, K, stream)
 
     def _launch_input_prod(self, i: int, bd: _Binding, stream: int) -> None:
         """`ck_gaussian_prod_fwd`: a Hadamard layer over Gaussian folds, straight from the batch."""
@@ -362,20 +409,18 @@ class HipCircuit:
         tab = bd.cp_tabs.get(i)
         if i in self._cp_blocks:
             blk = self._cp_blocks[i]
+            sub = self._cp_subset.get(i)
             if tab is None:
-                addr = np.zeros(blk.slot_dense.shape[:2], dtype=np.int64)
-                for d in np.unique(blk.slot_dense[..., 0]):
-                    if d < 0:
-                        continue
-                    w = self.layers[int(d)]._w
-                    if w.is_complex() or w.dtype != torch.float32 or not w.is_contiguous():
-                        raise ValueError("CP blocks need real, contiguous fp32 weights")
-                    sel = blk.slot_dense[..., 0] == d
-                    addr[sel] = w.data_ptr() + blk.slot_dense[..., 1][sel] * (K * K * 4)
-                tab = bd.cp_tabs[i] = torch.from_numpy(addr).to(self.device)
+                addr = self._weight_addresses(blk.slot_dense, K)
+                tab = bd.cp_tabs[i] = torch.from_numpy(np.ascontiguousarray(addr if sub is None else addr[sub])).to(self.device)
             F, S = blk.slot_dense.shape[:2]
-            capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), None,
-                      bd.views[i].data_ptr(), F, S, 1, bd.B, K, stream)
+            if sub is None:
+                capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), None,
+                          bd.views[i].data_ptr(), F, S, 1, bd.B, K, stream)
+            else:
+                ro, oo = bd.leftover[i]
+                capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), oo.data_ptr(),
+                          bd.arena.data_ptr(), len(sub), S, 1, bd.B, K, stream)
             return
         folds = self._cp_leftover[i]
         ro, oo = bd.leftover[i]
@@ -575,7 +620,7 @@ class HipCircuit:
         """All ``(F, B, Ko)`` layer outputs of one forward (views of the arena; None for layers that
         cross-layer fusion never materialises, or materialises only in part) -- for parity tests."""
         views = list(self._run(x).views)
-        for d in self._cp_leftover:
+        for d in list(self._cp_leftover) + list(self._cp_subset):
             views[d] = None
         return views
 
@@ -600,6 +645,8 @@ class HipCircuit:
         l, s = self.layers[i], self.plan.layers[i]
         if i in self._input_prod:
             return "gaussian_prod_kernel<8>"
+        if i in self._regions:
+            return f"region_lse_kernel<{l.num_output_units // 32}, 8>"
         if i in self._cp_blocks or i in self._cp_leftover:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root:
@@ -672,6 +719,8 @@ class HipCircuit:
                     self._launch_group(self._group_of_root[i], bd, view, stream, with_table=True)
                 elif i in self._cp_blocks or i in self._cp_leftover:
                     self._launch_cp(i, bd, stream)
+                elif i in self._regions:
+                    self._launch_region(i, bd, stream)
                 elif i in self._input_prod:
                     self._launch_input_prod(i, bd, stream)
                 elif isinstance(l, HipConstantValueLayer):
@@ -740,18 +789,34 @@ class HipCircuit:
                 share = len(self._cp_leftover[i]) / l.num_folds
                 nbytes, nflops = nbytes * share, nflops * share
             if i in self._cp_blocks:  # plus the dense folds evaluated inside the launch
-                dl = self._cp_blocks[i].slot_dense[..., 0]
-                for d in np.unique(dl):
-                    if d >= 0:
-                        share = float((dl == d).sum()) / self.layers[int(d)].num_folds
-                        nbytes += share * layer_bytes[int(d)]
-                        nflops += share * layer_flops[int(d)]
+                sub = self._cp_subset.get(i)
+                nb, nf = self._cp_fold_cost(i, np.arange(l.num_folds) if sub is None else sub, layer_bytes, layer_flops)
+                nbytes, nflops = nb, nf
+            if i in self._regions:  # plus the CP blocks (and their dense folds) it takes over
+                ch = self._children[i]
+                for h in np.unique(ch[..., 0]):
+                    nb, nf = self._cp_fold_cost(int(h), ch[..., 1][ch[..., 0] == h], layer_bytes, layer_flops)
+                    nbytes += nb
+                    nflops += nf
             if i in self._group_of_root:  # the fused launch does the work of every layer it replaces
                 nbytes += sum(layer_bytes[j] for j in self._group_of_root[i].virtual)
                 nflops += sum(layer_flops[j] for j in self._group_of_root[i].virtual)
             rows.append({"layer": i, "kernel": self.kernel_label(i), "ms": float(mean[2 * i + 1]),
                          "algorithmic_bytes": nbytes, "algorithmic_flops": nflops})
         return rows
+
+    def _cp_fold_cost(self, i: int, folds: np.ndarray, layer_bytes, layer_flops) -> tuple[float, float]:
+        """Algorithmic bytes / flops (reference layer boundaries) of `folds` of CP-block layer i,
+        including the dense folds evaluated inside them."""
+        nb = layer_bytes[i] * len(folds) / self.layers[i].num_folds
+        nf = layer_flops[i] * len(folds) / self.layers[i].num_folds
+        dl = self._cp_blocks[i].slot_dense[folds][..., 0]
+        for d in np.unique(dl):
+            if d >= 0:
+                share = float((dl == d).sum()) / self.layers[int(d)].num_folds
+                nb += share * layer_bytes[int(d)]
+                nf += share * layer_flops[int(d)]
+        return nb, nf
 
     # -- accounting ------------------------------------------------------------------------------
     def arena_bytes(self, B: int) -> int:

@@ -47,13 +47,14 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (w_addr == nullptr) return w_base + static_cast<int64_t>(f) * K * K;
     return reinterpret_cast<const float*>(static_cast<uintptr_t>(w_addr[static_cast<int64_t>(f) * S + s]));
   };
-  // coalesced read of the row-major (K, K) matrix, scattered into the operand layout
+  // row-major (K, K) matrix -> operand layout
   auto stage = [&](const float* wf, int buf) {
+    // consecutive threads fill consecutive LDS words (conflict-free); the global side reads 32 B
+    // pieces of 32 rows per wave instruction, out of L2
     for (int i = threadIdx.x; i < WF4; i += WAVES * 64) {
-      const int o = i / (K / 4), k = 4 * (i - o * (K / 4));
-      const int p = o >> 5, q = k >> 5, g = (k >> 3) & 3, ln = (o & 31) + 32 * ((k >> 2) & 1);
-      *reinterpret_cast<float4*>(&w_s[buf][((((p * NK + q) * 4 + g) * 64) + ln) * 4]) =
-          *reinterpret_cast<const float4*>(wf + 4 * static_cast<int64_t>(i));
+      const int ln = i & 63, g = (i >> 6) & 3, pq = i >> 8, q = pq % NK, p = pq / NK;
+      *reinterpret_cast<float4*>(&w_s[buf][4 * i]) = *reinterpret_cast<const float4*>(
+          wf + static_cast<int64_t>(32 * p + (ln & 31)) * K + 32 * q + 8 * g + 4 * (ln >> 5));
     }
   };
 
@@ -145,6 +146,164 @@ __global__ void __launch_bounds__(WAVES * 64)
   }
 }
 
+// A whole region with several partitionings in one launch:
+//     P_h = sum_s G_{h,s}                      (the CP block of partitioning h, as in cp_lse_kernel)
+//     out = log(sum_h mw[:, h] * exp(P_h - M)) + M,   M = max over all (h, k)     (the mixing layer)
+// i.e. RegionGraph.build_circuit's `mix_ins = [sum_prod_builder_(...) for ptn in region_inputs]`
+// followed by the arity-H SumLayer with mixing weights (templates/region_graph/graph.py:556-583,
+// symbolic/parameters.py:1007-1044, nodes.py:847-862).  The H Hadamard outputs the reference writes
+// and reads back stay in registers.  The mixing sum is accumulated ONLINE over h: a running row
+// maximum M and accumulators rescaled by exp(M_old - M_new) -- the same sum the reference forms
+// with the final M, up to fp32 rounding of the rescaling.
+//
+// Weight matrices go through a ring of three LDS buffers (step t = h*S + s): W_{t+2} is staged
+// after the barrier of step t, when every wave has left the MFMA chain of step t - 1 that read the
+// buffer being overwritten -- one barrier per step.
+template <int NK, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 4)  // 4 waves per SIMD (two workgroups per CU): at most 128 VGPRs
+    region_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
+                      const int64_t* __restrict__ w_addr, const float* __restrict__ mw,
+                      float* __restrict__ out, int H, int S, int B) {
+  constexpr int K = 32 * NK;
+  constexpr int WF4 = K * K / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w_s = smem;               // [3][K*K]
+  float* mw_s = smem + 3 * K * K;  // [H][K]
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int b = (blockIdx.x * WAVES + wave) * 32 + b_in;
+  const bool live = b < B;
+  const int bl = live ? b : B - 1;
+  const int T = H * S;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * T;
+  const int64_t* wa = w_addr + static_cast<int64_t>(f) * T;
+  auto stage = [&](int t) {
+    const float* wf = reinterpret_cast<const float*>(static_cast<uintptr_t>(wa[t]));
+    if (wf == nullptr) return;
+    float* dstb = w_s + (t % 3) * K * K;
+    for (int i = threadIdx.x; i < WF4; i += WAVES * 64) {  // conflict-free LDS side, see cp_lse_kernel
+      const int ln = i & 63, g = (i >> 6) & 3, pq = i >> 8, q = pq % NK, p = pq / NK;
+      *reinterpret_cast<float4*>(&dstb[4 * i]) = *reinterpret_cast<const float4*>(
+          wf + static_cast<int64_t>(32 * p + (ln & 31)) * K + 32 * q + 8 * g + 4 * (ln >> 5));
+    }
+  };
+  const float* mwf = mw + static_cast<int64_t>(f) * K * H;
+  for (int i = threadIdx.x; i < K * H; i += WAVES * 64) {
+    const int k = i / H, h = i - k * H;
+    mw_s[h * K + k] = mwf[i];
+  }
+  stage(0);
+  if (T > 1) stage(1);
+
+  float A[NK][16];
+#pragma unroll
+  for (int p = 0; p < NK; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) A[p][r] = 0.f;
+  float M = -INFINITY;
+  int t = 0;
+  for (int h = 0; h < H; ++h) {
+    float P[NK][16];
+    for (int s = 0; s < S; ++s, ++t) {
+      float v[NK][16];
+      const float* src = arena + ro[t] + static_cast<int64_t>(bl) * K + 4 * kh;
+#pragma unroll
+      for (int q = 0; q < NK; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 t4 = *reinterpret_cast<const float4*>(src + 32 * q + 8 * g);
+          v[q][4 * g + 0] = t4.x;
+          v[q][4 * g + 1] = t4.y;
+          v[q][4 * g + 2] = t4.z;
+          v[q][4 * g + 3] = t4.w;
+        }
+      const bool dense = wa[t] != 0;  // uniform over the workgroup
+      float m = 0.f;
+      if (dense) {
+        m = v[0][0];
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) m = fmaxf(m, v[q][j]);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = ck::clamp_finite(m);
+        const float nml = exp_offset(m, 0.f);
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[q][j] = __builtin_amdgcn_exp2f(fmaf(v[q][j], kL2E, nml));
+      }
+      __syncthreads();  // W_t is staged; every wave has left the MFMA chain of step t - 1
+      if (t + 2 < T) stage(t + 2);
+      if (dense) {
+        const float* wb = w_s + (t % 3) * K * K;
+#pragma unroll
+        for (int p = 0; p < NK; ++p) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int q = 0; q < NK; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 w4 = *reinterpret_cast<const float4*>(wb + ((((p * NK + q) * 4 + g) * 64) + lane) * 4);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, v[q][4 * g + 0], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, v[q][4 * g + 1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, v[q][4 * g + 2], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, v[q][4 * g + 3], acc, 0, 0, 0);
+            }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float gs = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m);
+            P[p][r] = s == 0 ? gs : P[p][r] + gs;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) P[q][j] = s == 0 ? v[q][j] : P[q][j] + v[q][j];
+      }
+    }
+    // mixing: fold P_h into the running sum
+    float pm = P[0][0];
+#pragma unroll
+    for (int p = 0; p < NK; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pm = fmaxf(pm, P[p][r]);
+    pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+    const float Mn = ck::clamp_finite(fmaxf(M, pm));
+    const float scale = __builtin_amdgcn_exp2f((M - Mn) * kL2E);  // 0 on the first partitioning (M = -inf)
+    const float nml = exp_offset(Mn, 0.f);
+#pragma unroll
+    for (int p = 0; p < NK; ++p)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 c4 = *reinterpret_cast<const float4*>(mw_s + h * K + 32 * p + 8 * g + 4 * kh);
+        A[p][4 * g + 0] = fmaf(c4.x, __builtin_amdgcn_exp2f(fmaf(P[p][4 * g + 0], kL2E, nml)), A[p][4 * g + 0] * scale);
+        A[p][4 * g + 1] = fmaf(c4.y, __builtin_amdgcn_exp2f(fmaf(P[p][4 * g + 1], kL2E, nml)), A[p][4 * g + 1] * scale);
+        A[p][4 * g + 2] = fmaf(c4.z, __builtin_amdgcn_exp2f(fmaf(P[p][4 * g + 2], kL2E, nml)), A[p][4 * g + 2] * scale);
+        A[p][4 * g + 3] = fmaf(c4.w, __builtin_amdgcn_exp2f(fmaf(P[p][4 * g + 3], kL2E, nml)), A[p][4 * g + 3] * scale);
+      }
+    M = Mn;
+  }
+  if (live) {
+    float* dst = out + (static_cast<int64_t>(f) * B + b) * K + 4 * kh;
+#pragma unroll
+    for (int p = 0; p < NK; ++p)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 o4;
+        o4.x = fmaf(__builtin_amdgcn_logf(A[p][4 * g + 0]), kLN2, M);
+        o4.y = fmaf(__builtin_amdgcn_logf(A[p][4 * g + 1]), kLN2, M);
+        o4.z = fmaf(__builtin_amdgcn_logf(A[p][4 * g + 2]), kLN2, M);
+        o4.w = fmaf(__builtin_amdgcn_logf(A[p][4 * g + 3]), kLN2, M);
+        *reinterpret_cast<float4*>(dst + 32 * p + 8 * g) = o4;
+      }
+  }
+}
+
 // Dense sum layer over the CONCATENATION of H children (TorchSumLayer with arity > 1 and a full
 // (K, H*K) weight, inner.py:266-273 -- e.g. the Sum -> Sum pair the reference collapses into one
 // layer with a MatMul weight, optimization/layers.py:162-198):
@@ -168,11 +327,10 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int ldw = H * K;
   const float* wf = w + static_cast<int64_t>(f) * K * ldw;
   auto stage = [&](int h, int buf) {  // column block h of the row-major (K, H*K) matrix
-    for (int i = threadIdx.x; i < WF4; i += WAVES * 64) {
-      const int o = i / (K / 4), k = 4 * (i - o * (K / 4));
-      const int p = o >> 5, q = k >> 5, g = (k >> 3) & 3, ln = (o & 31) + 32 * ((k >> 2) & 1);
-      *reinterpret_cast<float4*>(&w_s[buf][((((p * NK + q) * 4 + g) * 64) + ln) * 4]) =
-          *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o) * ldw + h * K + k);
+    for (int i = threadIdx.x; i < WF4; i += WAVES * 64) {  // conflict-free LDS side, see cp_lse_kernel
+      const int ln = i & 63, g = (i >> 6) & 3, pq = i >> 8, q = pq % NK, p = pq / NK;
+      *reinterpret_cast<float4*>(&w_s[buf][4 * i]) = *reinterpret_cast<const float4*>(
+          wf + static_cast<int64_t>(32 * p + (ln & 31)) * ldw + h * K + 32 * q + 8 * g + 4 * (ln >> 5));
     }
   };
   stage(0, 0);
@@ -297,4 +455,27 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
   CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(out), "ck_cp_lse_fwd: buffers must be 16-byte aligned");
   if (K == 64) return launch_cp<2>(arena, row_off, w_addr, nullptr, out_off, out, F, S, H, B, stream);
   return launch_cp<1>(arena, row_off, w_addr, nullptr, out_off, out, F, S, H, B, stream);
+}
+
+extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
+                                 float* out, int F, int H, int S, int B, int K, void* stream) {
+  CK_REQUIRE(arena && row_off && w_addr && mw && out, "ck_region_lse_fwd: null pointer");
+  CK_REQUIRE(F > 0 && S > 0 && H > 0 && B > 0, "ck_region_lse_fwd: non-positive size F=%d H=%d S=%d B=%d", F, H, S, B);
+  CK_REQUIRE(K == 32 || K == 64, "ck_region_lse_fwd: K must be 32 or 64, found %d", K);
+  CK_REQUIRE(F <= 65535, "ck_region_lse_fwd: F=%d exceeds grid.y", F);
+  CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(out), "ck_region_lse_fwd: buffers must be 16-byte aligned");
+  constexpr int WAVES = 8;
+  const size_t lds = (static_cast<size_t>(3) * K * K + static_cast<size_t>(H) * K) * sizeof(float);
+  CK_REQUIRE(lds <= 64 * 1024, "ck_region_lse_fwd: H=%d mixing coefficients do not fit in LDS", H);
+  const int tiles = (B + 31) / 32;
+  dim3 grid((tiles + WAVES - 1) / WAVES, F), block(WAVES * 64);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (K == 64)
+          hipLaunchKernelGGL((region_lse_kernel<2, WAVES>), grid, block, lds, s, arena, row_off, w_addr, mw, out, H, S, B);
+        else
+          hipLaunchKernelGGL((region_lse_kernel<1, WAVES>), grid, block, lds, s, arena, row_off, w_addr, mw, out, H, S, B);
+        return hipGetLastError();
+      },
+      stream);
 }

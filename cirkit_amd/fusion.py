@@ -256,3 +256,58 @@ def find_input_products(plan, layers, children, out_pairs, skip: set[int]) -> di
             continue
         found[j] = g
     return found
+
+
+# ---------------------------------------------------------------------------------------------
+# regions: a mixing layer together with the CP blocks it combines
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class RegionBlock:
+    """One mixing layer evaluated by `ck_region_lse_fwd`: partitioning (f, h) is the CP block
+    `slot_child[f, h]` / `slot_dense[f, h]` (S slots, as in `CPBlock`)."""
+
+    layer: int
+    slot_child: np.ndarray  # (F, H, S, 2)
+    slot_dense: np.ndarray  # (F, H, S, 2)
+
+
+def find_region_blocks(plan, layers, children, out_pairs, cp_blocks: dict[int, CPBlock], skip: set[int]):
+    """Returns (regions, absorbed).  A mixing layer whose every input is a fold of a CP-block
+    Hadamard layer, read by nobody else, takes those folds over: `absorbed[hadamard layer]` is the
+    boolean mask of its folds that are no longer evaluated (nor stored) on their own."""
+    if plan.semiring != "lse-sum" or not cp_blocks:
+        return [], {}
+    uses = [np.zeros(l.num_folds, dtype=np.int64) for l in layers]
+    for ch in children:
+        if ch is not None:
+            flat = ch.reshape(-1, 2)
+            for p in np.unique(flat[:, 0]):
+                uses[int(p)] += np.bincount(flat[flat[:, 0] == p, 1], minlength=layers[int(p)].num_folds)
+    for p, f in out_pairs:
+        uses[int(p)][int(f)] += 1
+    regions: list[RegionBlock] = []
+    absorbed: dict[int, np.ndarray] = {}
+    for j, (s, l) in enumerate(zip(plan.layers, layers)):
+        if j in skip or s.type != "sum" or not getattr(l, "_mixing", False) or l.num_output_units not in CP_K:
+            continue
+        ch = children[j]  # (F, H, 2)
+        prods = [int(p) for p in np.unique(ch[..., 0])]
+        if any(p not in cp_blocks for p in prods):
+            continue
+        arities = {cp_blocks[p].slot_child.shape[1] for p in prods}
+        if len(arities) != 1:
+            continue
+        if any((uses[p][ch[..., 1][ch[..., 0] == p]] != 1).any() for p in prods):
+            continue
+        S = arities.pop()
+        F, H = ch.shape[:2]
+        slot_child = np.zeros((F, H, S, 2), dtype=np.int64)
+        slot_dense = np.zeros((F, H, S, 2), dtype=np.int64)
+        for p in prods:
+            sel = ch[..., 0] == p
+            folds = ch[..., 1][sel]
+            slot_child[sel] = cp_blocks[p].slot_child[folds]
+            slot_dense[sel] = cp_blocks[p].slot_dense[folds]
+            absorbed.setdefault(p, np.zeros(layers[p].num_folds, dtype=bool))[folds] = True
+        regions.append(RegionBlock(j, slot_child, slot_dense))
+    return regions, absorbed

@@ -147,6 +147,15 @@ int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* m
 int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* out_off,
                   float* out, int F, int S, int H, int B, int K, void* stream);
 
+/* A region with H partitionings in one launch: the H CP blocks (as in ck_cp_lse_fwd, S slots each)
+ * and the mixing layer that combines them (templates/region_graph/graph.py:556-583: `mix_ins` and the
+ * arity-H SumLayer with TorchMixingWeightParameter weights, nodes.py:847-862):
+ *   P_h = sum_s G_{h,s};  out[f,b,k] = log(sum_h mw[f,k,h] * exp(P_h[k] - M)) + M,  M = max_{h,k} P_h[k].
+ * row_off, w_addr: (F, H, S) as in ck_cp_lse_fwd; mw: (F, K, H) mixing coefficients; out: (F, B, K).
+ * The sum over h is accumulated online (running maximum), see ck_cp.hip. */
+int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
+                      float* out, int F, int H, int S, int B, int K, void* stream);
+
 /* TorchHadamardLayer.forward, inner.py:126-127 (lse: sum over the arity axis). esize = 1 (fp32)
  * or 2 (complex64: K counts complex elements). */
 int ck_hadamard_fwd(const float* arena, const int64_t* row_off, float* out, int F, int H, int B,
