@@ -671,6 +671,9 @@ class HipCircuit:
             vec = l.num_output_units % 4 == 0 and 1 <= k4 <= 64 and (k4 & (k4 - 1)) == 0
             return "mixing_lse_vec" if vec else "mixing_lse_kernel"
         prod_like = s.type == "cpt" or l.arity == 1
+        if (self._complex and prod_like and s.type in ("sum", "cpt") and l.num_input_units == l.num_output_units == 32
+                and l._w is not None and not l._w.is_complex()):
+            return "sum_clse_tile32"
         if (not self._complex and prod_like and l.num_input_units == l.num_output_units
                 and l.num_input_units in (32, 64)):
             return f"sum_lse_tile32<{l._w_layout}>" if l.num_input_units == 32 else "cp_lse_kernel<2, 8, false>"

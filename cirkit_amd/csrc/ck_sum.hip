@@ -67,6 +67,76 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// complex-lse-sum, K = 32, real weights (ComplexLSESumSemiring.apply_reduce, semiring.py:441-476, with
+// `cast(weight)` real -> complex, :416-422): exp(z - m) = E_re + i E_im is split into two real 32 x 32
+// register tiles, each goes through the SAME fp32 MFMA chain as the real layer (W . E_re, W . E_im),
+// and the complex logarithm recombines them.  All 64 lanes work in every phase (the shape-generic
+// kernel keeps half of them idle at K = 32), transcendental functions as in ck_internal.h.
+__global__ void __launch_bounds__(256)
+    sum_clse_tile32(const c32* __restrict__ arena, const int64_t* __restrict__ row_off,
+                    const float* __restrict__ w, c32* __restrict__ out, int H, int B, int tiles_per_wave) {
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  WRegs wr;
+  load_w<CK_W_ROWMAJOR>(w + static_cast<int64_t>(f) * kK * kK, lane, wr);
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+    const int b0 = (tile0 + tt) * 32;
+    if (b0 >= B) break;
+    const int b = b0 + b_in;
+    const bool live = b < B;
+    const int bl = live ? b : B - 1;
+    float zr[16], zi[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) zr[j] = zi[j] = 0.f;
+    for (int h = 0; h < H; ++h) {  // product of the children: complex addition in log space
+      const float* src = reinterpret_cast<const float*>(arena + ro[h] + static_cast<int64_t>(bl) * kK + 4 * kh);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // units 8g + 4kh + t: four (re, im) pairs = two float4
+        const float4 a4 = *reinterpret_cast<const float4*>(src + 16 * g);
+        const float4 b4 = *reinterpret_cast<const float4*>(src + 16 * g + 4);
+        zr[4 * g + 0] += a4.x; zi[4 * g + 0] += a4.y;
+        zr[4 * g + 1] += a4.z; zi[4 * g + 1] += a4.w;
+        zr[4 * g + 2] += b4.x; zi[4 * g + 2] += b4.y;
+        zr[4 * g + 3] += b4.z; zi[4 * g + 3] += b4.w;
+      }
+    }
+    const float m = row_max16(zr);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const c32 e = ck::c_exp_shift(c32{zr[j], zi[j]}, m);
+      zr[j] = e.re;
+      zi[j] = e.im;
+    }
+    f32x16 yr, yi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yr[r] = yi[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float wq[4] = {wr.q[g].x, wr.q[g].y, wr.q[g].z, wr.q[g].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        yr = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[t], zr[4 * g + t], yr, 0, 0, 0);
+        yi = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[t], zi[4 * g + t], yi, 0, 0, 0);
+      }
+    }
+    if (live) {
+      float* dst = reinterpret_cast<float*>(out + (static_cast<int64_t>(f) * B + b) * kK + 4 * kh);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const c32 o0 = ck::c_log_shift(c32{yr[4 * g + 0], yi[4 * g + 0]}, m);
+        const c32 o1 = ck::c_log_shift(c32{yr[4 * g + 1], yi[4 * g + 1]}, m);
+        const c32 o2 = ck::c_log_shift(c32{yr[4 * g + 2], yi[4 * g + 2]}, m);
+        const c32 o3 = ck::c_log_shift(c32{yr[4 * g + 3], yi[4 * g + 3]}, m);
+        *reinterpret_cast<float4*>(dst + 16 * g) = make_float4(o0.re, o0.im, o1.re, o1.im);
+        *reinterpret_cast<float4*>(dst + 16 * g + 4) = make_float4(o2.re, o2.im, o3.re, o3.im);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Generic path (any H, Ki, Ko; real or complex activations; real or complex weights)
 // ------------------------------------------------------------------------------------------------
@@ -497,6 +567,19 @@ int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* 
   c32* o = reinterpret_cast<c32*>(out_c);
   if (w_is_complex)
     return launch_generic<c32, c32>(a, row_off, reinterpret_cast<const c32*>(w), o, F, H, B, Ki, Ko, mode, stream);
+  if (!g_force_generic && (mode == CK_SUM_PROD || H == 1) && Ki == kK && Ko == kK && ck::aligned16(arena_c) &&
+      ck::aligned16(w) && ck::aligned16(out_c)) {
+    const int tiles = (B + 31) / 32;
+    int tpw = 1;
+    while (tpw < 4 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
+    dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          hipLaunchKernelGGL(sum_clse_tile32, grid, block, 0, s, a, row_off, w, o, H, B, tpw);
+          return hipGetLastError();
+        },
+        stream);
+  }
   return launch_generic<c32, float>(a, row_off, w, o, F, H, B, Ki, Ko, mode, stream);
 }
 

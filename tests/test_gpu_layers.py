@@ -264,3 +264,33 @@ def test_layer_forward_rejects_bad_inputs(hip_device):
         layer.forward(torch.zeros(3, 3, 4, 8, device=hip_device))
     with pytest.raises(ValueError):
         layer.forward(torch.zeros(3, 2, 4, 8, device=hip_device, dtype=torch.complex64))
+
+
+@pytest.mark.parametrize("F,H,B", [(3, 2, 70), (2, 1, 33), (1, 3, 257)])
+def test_complex_cpt_layer_matches_generic_kernel_and_oracle(hip_device, F, H, B):
+    """complex-lse-sum CP-T layer, K = 32, real signed weights (BASELINE config 5): the MFMA kernel
+    (exp(z - m) split into real and imaginary tiles) against the shape-generic kernel and the oracle.
+    Positive weights keep the sums well conditioned, so both must agree to fp32 round-off."""
+    from cirkit_amd import _capi as capi
+    from cirkit_amd.layers import HipCPTLayer
+    from cirkit_amd.parameters import TensorStore
+
+    K = 32
+    g = torch.Generator().manual_seed(F * 100 + H * 10 + 7)
+    w = torch.rand(F, K, K, generator=g) + 0.05
+    x = torch.complex(torch.randn(F, H, B, K, generator=g) * 3 - 4, torch.randn(F, H, B, K, generator=g) * 0.3)
+    store = TensorStore(hip_device)
+    p, pg = _pg(store, "w", w)
+    layer = HipCPTLayer(K, K, H, weight=p, num_folds=F, semiring="complex-lse-sum")
+    spec = LayerSpec("cpt", F, H, K, K, dict(layer.config), {"weight": pg})
+    ref = _oracle(spec, {"w": w}, x, semiring="complex-lse-sum")
+    got = layer.forward(x.to(hip_device)).cpu()
+    capi.call("ck_debug_force_generic", 1)
+    try:
+        gen = layer.forward(x.to(hip_device)).cpu()
+    finally:
+        capi.call("ck_debug_force_generic", 0)
+    for a in (got, gen):
+        assert float((a.real - ref.real).abs().max()) <= 2e-5 * max(1.0, float(ref.real.abs().max()))
+        d = torch.remainder(a.imag - ref.imag + np.pi, 2 * np.pi) - np.pi
+        assert float(d.abs().max()) <= 2e-5
