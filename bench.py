@@ -33,6 +33,63 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s mea
 FP32_MFMA_PEAK_TF = 157.3  # dense fp32-input MFMA peak (= fp32 vector peak), same guide
 
 
+def other_configs(device, stream, B: int) -> dict:
+    """BASELINE configs 4 and 5 (parity-test cases, tests/test_gpu_parity.py) timed for reference:
+    plans built natively, closed-form parameters, synthetic batch, hipGraph replay, HIP events on
+    the launch stream.  Informational only -- `value` and `roofline` are config 2."""
+    import numpy as np
+    import torch
+
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.functional import squared_partition_plan
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+
+    def time_forward(hc, x, steps=20):
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                hc(x)
+            torch.cuda.synchronize(device)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            for a, b in ev:
+                a.record(stream)
+                hc(x)
+                b.record(stream)
+            torch.cuda.synchronize(device)
+        return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+    out = {}
+    g = torch.Generator().manual_seed(4)
+    plan4 = image_data((1, 28, 28), "poon-domingos", input_layer="gaussian", num_input_units=64,
+                       sum_product_layer="cp", num_sum_units=64)
+    hc = HipCircuit(plan4, init_plan_tensors(plan4), device=device)
+    ms = time_forward(hc, torch.randn((B, 784), generator=g).to(device))
+    alg = plan4.algorithmic_bytes(B)["total"]
+    out["config4"] = {
+        "workload": f"Poon-Domingos 28x28 (delta 4), Gaussian leaves, CP sum layers, mixing layers, K=64, batch {B}, "
+                    "38 folded layers; CP blocks + mixing layers fused per region (cirkit_amd/csrc/ck_cp.hip)",
+        "ms_per_forward": ms, "evals_per_s": B / ms * 1e3, "algorithmic_bytes": alg,
+        "hbm_roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }
+    del hc
+    plan5 = image_data((1, 28, 28), "quad-tree-2", input_layer="embedding", num_input_units=32, sum_product_layer="cp-t",
+                       num_sum_units=32, sum_weight_activation="none", semiring="complex-lse-sum")
+    t5 = init_plan_tensors(plan5)
+    hc = HipCircuit(plan5, t5, device=device)
+    ms = time_forward(hc, torch.randint(0, 256, (B, 784), generator=g).to(device))
+    alg = plan5.algorithmic_bytes(B)["total"]
+    hz = HipCircuit(squared_partition_plan(plan5), hc.store, device=device)
+    ms_z = time_forward(hz, None)
+    out["config5"] = {
+        "workload": f"squared (SoS) circuit: QuadTree-2 28x28, Embedding-256, CP-T, K=32, complex-lse-sum, batch {B}; "
+                    "Z = integral |c|^2 built from the plan of c (cirkit_amd/functional.py)",
+        "ms_per_forward": ms, "evals_per_s": B / ms * 1e3, "algorithmic_bytes": alg,
+        "hbm_roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "ms_partition_function": ms_z,
+    }
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,6 +101,8 @@ def main() -> None:
     ap.add_argument("--contraction", default="f32", choices=["f32", "f16x3"],
                     help="K=32 sum layers: exact fp32 MFMA (default) or 3-term split-fp16 MFMA with fp32 accumulation")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary f16x3 measurement")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short measurements of BASELINE configs 4 and 5 (never part of `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     args = ap.parse_args()
@@ -304,6 +363,8 @@ def main() -> None:
                           "(op-for-op restatement of the reference's torch-CPU forward, fp32, no_grad)",
             }
         result["variants"] = variants
+        if world == 1 and not args.no_other_configs:
+            result["other_configs"] = other_configs(device, stream, B)
         print(json.dumps(result), flush=True)
 
     if world > 1:

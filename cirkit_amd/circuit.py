@@ -712,6 +712,8 @@ class HipCircuit:
                         self.layers[j].prepare(stream, batched=self.batch_params)
                 elif not in_tail:
                     l.prepare(stream, batched=self.batch_params)
+                if i in self._group_of_root:  # the dense layer pushed through the table is parameter-side work
+                    self._group_table(self._group_of_root[i], stream)
                 e1.record(cur)
                 if in_tail:
                     if i == self._tail[0]:
@@ -719,7 +721,7 @@ class HipCircuit:
                 elif i in self._virtual:
                     pass
                 elif i in self._group_of_root:
-                    self._launch_group(self._group_of_root[i], bd, view, stream, with_table=True)
+                    self._launch_group(self._group_of_root[i], bd, view, stream)
                 elif i in self._cp_blocks or i in self._cp_leftover:
                     self._launch_cp(i, bd, stream)
                 elif i in self._regions:
@@ -759,6 +761,13 @@ class HipCircuit:
             elif has_prep:
                 rows.append({"layer": i, "kernel": "param kernels (per node)", "ms": float(mean[2 * i]),
                              "algorithmic_bytes": float(pbytes)})
+            if i in self._group_of_root:
+                g = self._group_of_root[i]
+                if g.dense_layer is not None and self.dense_on_table and g.depth > 0:
+                    cat, dl = self.layers[g.input_layer], self.layers[g.dense_layer]
+                    tb = 2.0 * dl.num_folds * (cat.num_categories + 1) * cat.num_output_units * 4
+                    rows.append({"layer": i, "kernel": f"sum_lse_tile32<{dl._w_layout}> (dense layer on the table)",
+                                 "ms": float(mean[2 * i]), "algorithmic_bytes": tb})
             if s.inputs is not None:
                 rd = l.num_folds * l.arity * B * l.num_input_units * esz
             elif s.scope_idx is not None and s.scope_idx.size:

@@ -1,4 +1,4 @@
-// The 32-row x 32-unit register tile shared by sum_lse_mfma (ck_sum.hip), the fused leaf kernel
+// The 32-row x 32-unit register tile shared by sum_lse_tile32 (ck_sum.hip), cp_lse_kernel (ck_cp.hip), the fused leaf kernel
 // (ck_fused.hip) and the fused tail (ck_tail.hip).
 //
 // Lane l of a wave: b = l & 31 (batch row of the 32-row tile), kh = l >> 5.  Lane (b, kh) holds
