@@ -45,13 +45,15 @@ class _Binding:
         self.leftover: dict[int, tuple[torch.Tensor, torch.Tensor]] = {}
         self.cp_tabs: dict[int, torch.Tensor] = {}  # device-address tables of the weight matrices (keep alive)
         self.program = None  # ck_program*
+        self.program_ll = None  # the same followed by ck_ll_sum
         self.store_version = -1
         self.ll: torch.Tensor | None = None
 
     def destroy(self) -> None:
-        if self.program is not None:
-            capi.load().ck_program_destroy(self.program)
-            self.program = None
+        for name in ("program", "program_ll"):
+            if getattr(self, name) is not None:
+                capi.load().ck_program_destroy(getattr(self, name))
+                setattr(self, name, None)
 
 
 class HipCircuit:
@@ -293,18 +295,25 @@ class HipCircuit:
             bd.leftover[d] = (bd.row_off[d][torch.from_numpy(folds).to(self.device)].contiguous(),
                               torch.from_numpy(bases[d] + folds * (B * K)).to(self.device))
         bd.ll = torch.empty(2, dtype=torch.float64, device=self.device)
-        # record the launch list once
+        bd.program = self._record(bd, with_ll=False)  # the launch list, recorded once
+        self._bindings[B] = bd
+        return bd
+
+    def _record(self, bd: _Binding, *, with_ll: bool):
+        """Record one forward for this binding; `with_ll` appends the device-side log-likelihood sum
+        so that `log_likelihood_sum` replays ONE graph."""
         prog = C.c_void_p()
         capi.call("ck_program_begin", C.byref(prog))
         try:
             if not self.cache_params:
                 self._enqueue_params(0)
             self._enqueue_layers(bd, 0)
+            if with_ll:
+                p, f = int(self._out_pairs[0, 0]), int(self._out_pairs[0, 1])
+                capi.call("ck_ll_sum", bd.views[p][f].data_ptr(), bd.B, 1, bd.ll.data_ptr(), 0)
         finally:
             capi.call("ck_program_end", prog)
-        bd.program = prog
-        self._bindings[B] = bd
-        return bd
+        return prog
 
     def _param_program(self):
         """`cache_params`: the parameter-only launch list, recorded once per set of tensor objects
@@ -558,7 +567,7 @@ class HipCircuit:
             return torch.where(mask, torch.full((), float("nan"), device=x.device, dtype=torch.float32), x.to(torch.float32))
         return torch.where(mask, torch.full((), -1, device=x.device, dtype=torch.int64), x.to(torch.int64))
 
-    def _run(self, x: torch.Tensor | None) -> _Binding:
+    def _run(self, x: torch.Tensor | None, *, with_ll: bool = False) -> _Binding:
         if self.plan.num_variables:
             if x is None:
                 raise ValueError(f"Expected some input 'x', as the circuit has {self.plan.num_variables} variables")
@@ -590,7 +599,9 @@ class HipCircuit:
             if self.cache_params and self._pprog_data_version != self.store.data_version:
                 self._pprog_data_version = self.store.data_version
                 capi.call("ck_program_launch", self._param_program(), 1 if self.use_graph else 0, stream)
-            capi.call("ck_program_launch", bd.program, 1 if self.use_graph else 0, stream)
+            if with_ll and bd.program_ll is None:
+                bd.program_ll = self._record(bd, with_ll=True)
+            capi.call("ck_program_launch", bd.program_ll if with_ll else bd.program, 1 if self.use_graph else 0, stream)
             if run is not cur:
                 cur.wait_stream(run)
         return bd
@@ -627,17 +638,12 @@ class HipCircuit:
     def log_likelihood_sum(self, x: torch.Tensor) -> torch.Tensor:
         """Device tensor ``[sum_b log p(x_b), B]`` in fp64 -- the two numbers the data-parallel
         all-reduce exchanges (SURVEY.md section 8 e).  Requires a single scalar output."""
-        bd = self._run(x)
         pairs = self._out_pairs
         if len(pairs) != 1 or self._complex:
             raise ValueError("log_likelihood_sum needs a real circuit with one output")
-        p, f = int(pairs[0, 0]), int(pairs[0, 1])
-        view = bd.views[p]
-        if view.shape[2] != 1:
+        if self.layers[int(pairs[0, 0])].num_output_units != 1:
             raise ValueError("log_likelihood_sum needs a scalar output unit")
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        capi.call("ck_ll_sum", view[f].data_ptr(), bd.B, 1, bd.ll.data_ptr(), stream)
-        return bd.ll
+        return self._run(x, with_ll=True).ll
 
     # -- instrumentation -------------------------------------------------------------------------
     def kernel_label(self, i: int) -> str:
@@ -646,7 +652,7 @@ class HipCircuit:
         if i in self._input_prod:
             return "gaussian_prod_kernel<8>"
         if i in self._regions:
-            return f"region_lse_kernel<{l.num_output_units // 32}, 8>"
+            return "region_lse_kernel<2, 4, 3>" if l.num_output_units == 64 else "region_lse_kernel<1, 8, 4>"
         if i in self._cp_blocks or i in self._cp_leftover:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root:
@@ -740,9 +746,20 @@ class HipCircuit:
             if it == 0:
                 continue  # warm-up
             acc.append([t for e0, e1, e2 in evs for t in (e0.elapsed_time(e1), e1.elapsed_time(e2))])
-        # an event pair with nothing between still measures ~5 us of marker overhead: intervals
-        # without a launch are zeroed below (`has_prep` / virtual layers)
-        mean = np.mean(np.asarray(acc), axis=0)
+        # an event pair with nothing between still measures a few us of marker overhead: it is
+        # calibrated on empty pairs and subtracted; intervals without a launch are dropped below
+        # (`has_prep` / virtual layers)
+        try:
+            torch.cuda._sleep(4_000_000)
+        except Exception:  # pragma: no cover
+            pass
+        empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)]
+        for a, b in empty:
+            a.record(cur)
+            b.record(cur)
+        torch.cuda.synchronize(self.device)
+        overhead = float(np.median([a.elapsed_time(b) for a, b in empty]))
+        mean = np.maximum(np.mean(np.asarray(acc), axis=0) - overhead, 0.0)
         layer_bytes: dict[int, float] = {}
         layer_flops: dict[int, float] = {}
         for i, (l, s) in enumerate(zip(self.layers, self.plan.layers)):

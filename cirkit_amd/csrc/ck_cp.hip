@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(WAVES * 64)
 // Weight matrices go through a ring of three LDS buffers (step t = h*S + s): W_{t+2} is staged
 // after the barrier of step t, when every wave has left the MFMA chain of step t - 1 that read the
 // buffer being overwritten -- one barrier per step.
-template <int NK, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, 4)  // 4 waves per SIMD (two workgroups per CU): at most 128 VGPRs
+template <int NK, int WAVES, int MINW>
+__global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: caps the VGPR budget
     region_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                       const int64_t* __restrict__ w_addr, const float* __restrict__ mw,
                       float* __restrict__ out, int H, int S, int B) {
@@ -404,15 +404,17 @@ __global__ void __launch_bounds__(WAVES * 64)
 template <int NK>
 int launch_cp(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* w_base,
               const int64_t* out_off, float* out, int F, int S, int H, int B, void* stream) {
-  constexpr int WAVES = 8;
   const int tiles = (B + 31) / 32;
-  dim3 grid((tiles + WAVES - 1) / WAVES, F), block(WAVES * 64);
   return ck::dispatch(
       [=](hipStream_t s) {
+        auto go = [&](auto kern, int waves) {
+          dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
+          hipLaunchKernelGGL(kern, grid, block, 0, s, arena, row_off, w_addr, w_base, out_off, out, S, H, B);
+        };
         if (S == 1)
-          hipLaunchKernelGGL((cp_lse_kernel<NK, WAVES, false>), grid, block, 0, s, arena, row_off, w_addr, w_base, out_off, out, S, H, B);
+          go(cp_lse_kernel<NK, 8, false>, 8);
         else
-          hipLaunchKernelGGL((cp_lse_kernel<NK, WAVES, true>), grid, block, 0, s, arena, row_off, w_addr, w_base, out_off, out, S, H, B);
+          go(cp_lse_kernel<NK, 8, true>, 8);  // 4 waves per workgroup measured the same on config 4
         return hipGetLastError();
       },
       stream);
@@ -464,17 +466,21 @@ extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, con
   CK_REQUIRE(K == 32 || K == 64, "ck_region_lse_fwd: K must be 32 or 64, found %d", K);
   CK_REQUIRE(F <= 65535, "ck_region_lse_fwd: F=%d exceeds grid.y", F);
   CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(out), "ck_region_lse_fwd: buffers must be 16-byte aligned");
-  constexpr int WAVES = 8;
   const size_t lds = (static_cast<size_t>(3) * K * K + static_cast<size_t>(H) * K) * sizeof(float);
   CK_REQUIRE(lds <= 64 * 1024, "ck_region_lse_fwd: H=%d mixing coefficients do not fit in LDS", H);
   const int tiles = (B + 31) / 32;
-  dim3 grid((tiles + WAVES - 1) / WAVES, F), block(WAVES * 64);
   return ck::dispatch(
       [=](hipStream_t s) {
+        auto go = [&](auto kern, int waves) {
+          dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
+          hipLaunchKernelGGL(kern, grid, block, lds, s, arena, row_off, w_addr, mw, out, H, S, B);
+        };
+        // measured on config 4 (MI355X): 4 waves per workgroup at <= 168 VGPRs (no spills, three
+        // workgroups per CU) 2.85 ms; 8 waves capped at 128 VGPRs (spills) 3.28 ms; 2 waves 4.3 ms
         if (K == 64)
-          hipLaunchKernelGGL((region_lse_kernel<2, WAVES>), grid, block, lds, s, arena, row_off, w_addr, mw, out, H, S, B);
+          go(region_lse_kernel<2, 4, 3>, 4);
         else
-          hipLaunchKernelGGL((region_lse_kernel<1, WAVES>), grid, block, lds, s, arena, row_off, w_addr, mw, out, H, S, B);
+          go(region_lse_kernel<1, 8, 4>, 8);
         return hipGetLastError();
       },
       stream);
