@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -37,6 +37,8 @@ class SoftmaxJob(C.Structure):
         ("k", C.c_int32),
         ("kind", C.c_int32),
         ("block_begin", C.c_int32),
+        ("in2", C.c_void_p),
+        ("idx", C.c_void_p),
     ]
 
 

@@ -146,6 +146,7 @@ class HipCircuit:
             find_tail(plan, self.layers, self._virtual | set(self._group_of_root)) if fuse is not False else []
         )
         # dense sum layers evaluated inside the Hadamard layer that multiplies them (ck_cp.hip)
+        self._table_fused: set[int] = set()  # group roots whose table + dense layer are one prologue job
         self._cp_blocks: dict[int, CPBlock] = {}
         self._cp_leftover: dict[int, np.ndarray] = {}
         self._cp_subset: dict[int, np.ndarray] = {}  # CP-block layers of which only these folds are evaluated
@@ -444,11 +445,41 @@ class HipCircuit:
         if self._batch is None or self._batch_version != self.store.version:
             self._batch = ParamBatch()
             self._assign_weight_layouts()
-            for l in self.layers:
-                l._batched = False
-                l.register_batched(self._batch)
+            covered = self._register_table_jobs(self._batch)
+            for i, l in enumerate(self.layers):
+                l._batched = i in covered
+                if i not in covered:
+                    l.register_batched(self._batch)
             self._batch_version = self.store.version
         self._batch.launch(stream)
+
+    def _register_table_jobs(self, batch: ParamBatch) -> set[int]:
+        """`dense_on_table` inside the prologue: for a leaf group whose Categorical probabilities and
+        dense weights are plain softmaxes, ONE job per dense fold builds the log-table and pushes it
+        through the dense layer (ck_param.hip kind 4) -- neither the table nor the dense weights
+        reach memory.  Returns the layers whose parameters are fully covered by such jobs."""
+        covered: set[int] = set()
+        self._table_fused = set()
+        if not (self.dense_on_table and self.contraction == "f32"):
+            return covered
+        for g in self._groups:
+            if g.dense_layer is None or g.depth == 0:
+                continue
+            cat, dl = self.layers[g.input_layer], self.layers[g.dense_layer]
+            src = None if getattr(cat, "probs", None) is None else cat.probs.softmax_source()
+            wsrc = dl.weight.softmax_source()
+            if src is None or wsrc is None or cat.num_output_units != 32 or tuple(wsrc.shape[1:]) != (32, 32):
+                continue
+            Cn = cat.num_categories
+            leaf = self._children[g.dense_layer][:, 0, 1].astype(np.int64)
+            idx = None if np.array_equal(leaf, np.arange(len(leaf))) else torch.from_numpy(leaf).to(self.device)
+            dst = torch.empty((dl.num_folds, Cn + 1, 32), dtype=torch.float32, device=self.device)
+            batch.add_log_table_dense(src, wsrc, idx, dst)
+            dev = self._group_dev.get(g.root) or (torch.from_numpy(g.nodes).to(self.device),)
+            self._group_dev[g.root] = (dev[0], dst, torch.from_numpy(np.ascontiguousarray(leaf * ((Cn + 1) * 32))).to(self.device))
+            self._table_fused.add(g.root)
+            covered |= {g.input_layer, g.dense_layer}
+        return covered
 
     def _launch_tail(self, bd: _Binding, stream: int) -> None:
         """One launch for the trailing few-fold layers (cirkit_amd/csrc/ck_tail.hip)."""
@@ -477,6 +508,8 @@ class HipCircuit:
             self._group_dev[g.root] = dev
         cat = self.layers[g.input_layer]
         w_dense = None if g.dense_layer is None else self.layers[g.dense_layer]._w
+        if g.root in self._table_fused:  # built by the prologue (kind-4 job)
+            return dev[1], None
         if w_dense is None or not self.dense_on_table or g.depth == 0:
             return cat._table, w_dense
         dl = self.layers[g.dense_layer]
@@ -780,7 +813,7 @@ class HipCircuit:
                              "algorithmic_bytes": float(pbytes)})
             if i in self._group_of_root:
                 g = self._group_of_root[i]
-                if g.dense_layer is not None and self.dense_on_table and g.depth > 0:
+                if g.dense_layer is not None and self.dense_on_table and g.depth > 0 and i not in self._table_fused:
                     cat, dl = self.layers[g.input_layer], self.layers[g.dense_layer]
                     tb = 2.0 * dl.num_folds * (cat.num_categories + 1) * cat.num_output_units * 4
                     rows.append({"layer": i, "kernel": f"sum_lse_tile32<{dl._w_layout}> (dense layer on the table)",

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "ck_internal.h"
+#include "ck_tile.h"
 
 namespace {
 
@@ -193,23 +194,28 @@ struct JobTable {
   int n;
 };
 
+// wavefronts per workgroup of the batched prologue: a table job is one workgroup per fold whose phases are
+// separated by barriers, so its latency -- which IS the kernel time when all folds run at once -- scales
+// is not simply shorter with more waves (measured on config 2: 2 waves 39 us, 4 waves 29 us, 8 waves 38 us, 16 waves 60 us)
+constexpr int kPW = 4;
+
 __device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int blk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int len = j.len;
   if (len <= 32) {
-    // two rows per wave pass (one per 32-lane half); 64 rows per block; all loads issued up front
+    // two rows per wave pass (one per 32-lane half); 16 rows per wave and block; all loads issued up front
     const int half = lane >> 5, l = lane & 31;
     float x[8];
     bool ok[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int64_t row = static_cast<int64_t>(blk) * 64 + it * 8 + wave * 2 + half;
+      const int64_t row = static_cast<int64_t>(blk) * (16 * kPW) + it * (2 * kPW) + wave * 2 + half;
       ok[it] = row < j.rows && l < len;
       x[it] = ok[it] ? j.in[row * len + l] : -INFINITY;
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int64_t row = static_cast<int64_t>(blk) * 64 + it * 8 + wave * 2 + half;
+      const int64_t row = static_cast<int64_t>(blk) * (16 * kPW) + it * (2 * kPW) + wave * 2 + half;
       float mx = x[it];
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -245,7 +251,7 @@ __device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int bl
     }
   } else {
     for (int it = 0; it < 16; ++it) {
-      const int64_t row = static_cast<int64_t>(blk) * 64 + it * 4 + wave;
+      const int64_t row = static_cast<int64_t>(blk) * (16 * kPW) + it * kPW + wave;
       if (row >= j.rows) break;
       const float* src = j.in + row * len;
       float mx = -INFINITY;
@@ -286,11 +292,11 @@ __device__ __forceinline__ void softmax_job_table(const ck_softmax_job& j, int f
   __syncthreads();
   // phase 2: per-row max and log-sum-exp from LDS; 8 rows per wave pass so that the 2 x 6 shuffle
   // steps of the reductions of different rows overlap
-  for (int k0 = wave; k0 < K; k0 += 32) {
+  for (int k0 = wave; k0 < K; k0 += 8 * kPW) {
     float mx[8], sum[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int k = min(k0 + 4 * r, K - 1);
+      const int k = min(k0 + kPW * r, K - 1);
       const float* row = tile + k * ld;
       float m = -INFINITY;
       for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
@@ -302,7 +308,7 @@ __device__ __forceinline__ void softmax_job_table(const ck_softmax_job& j, int f
       for (int r = 0; r < 8; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int k = min(k0 + 4 * r, K - 1);
+      const int k = min(k0 + kPW * r, K - 1);
       const float* row = tile + k * ld;
       float sacc = 0.f;
       for (int c = lane; c < C; c += 64) sacc += __expf(row[c] - mx[r]);
@@ -315,7 +321,7 @@ __device__ __forceinline__ void softmax_job_table(const ck_softmax_job& j, int f
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const int k = k0 + 4 * r;
+        const int k = k0 + kPW * r;
         if (k < K) {
           stat[k] = mx[r];
           stat[K + k] = __logf(sum[r]);
@@ -353,7 +359,115 @@ __device__ __forceinline__ void softmax_job_table(const ck_softmax_job& j, int f
   }
 }
 
-__global__ void __launch_bounds__(256) softmax_batch_kernel(const JobTable t) {
+// kind 4: the Categorical log-table of fold idx[d] pushed through dense layer fold d in the same block:
+//   T'[d, c, :] = log(W_d . exp(T[c, :] - m_c)) + m_c,  T = log softmax_C(theta_cat[idx[d]]) transposed,
+//   W_d = softmax(theta_dense[d]) (rows of 32), c = 0..C (row C: the integral row, T = 0).
+// Exactly the arithmetic of the kind-1 job followed by ck_sum_lse_fwd on the table (the register-tile
+// step of ck_tile.h on 32-row tiles of categories) and of the 32-wide rows job for W -- bit-identical
+// to running them one after the other -- without the (F, C+1, K) table ever reaching memory.
+__device__ __forceinline__ void softmax_job_table_dense(const ck_softmax_job& j, int d, float* tile) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = j.len, K = j.k, ld = C + 1;  // K == 32
+  const int64_t f = j.idx != nullptr ? j.idx[d] : d;
+  const float* src = j.in + f * K * C;
+  float* stat = tile + K * ld;   // [K] max, [K] log-sum
+  float* w_s = stat + 2 * K;     // [32][32] row-major linear weights of dense fold d
+  if ((C & 3) == 0) {
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    for (int i = threadIdx.x; i < (K * C) >> 2; i += blockDim.x) {
+      const float4 v = src4[i];
+      const int e = i << 2, k = e / C, c = e - k * C;
+      float* dd = tile + k * ld + c;
+      dd[0] = v.x;
+      dd[1] = v.y;
+      dd[2] = v.z;
+      dd[3] = v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+      const int k = i / C, c = i - k * C;
+      tile[k * ld + c] = src[i];
+    }
+  }
+  {  // W_d: 32 rows of 32, two rows per wave pass (same reduction tree as softmax_job_rows)
+    const int half = lane >> 5, l = lane & 31;
+    const float* th = j.in2 + static_cast<int64_t>(d) * 1024;
+#pragma unroll
+    for (int it = 0; it < 16 / kPW; ++it) {
+      const int row = it * (2 * kPW) + wave * 2 + half;
+      const float x = th[row * 32 + l];
+      float mx = x;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float e = __expf(x - mx);
+      float sum = e;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      w_s[row * 32 + l] = e / sum;
+    }
+  }
+  __syncthreads();
+  for (int k0 = wave; k0 < K; k0 += 8 * kPW) {  // per-unit max and log-sum-exp over the categories (as kind 1)
+    float mx[8], sum[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = min(k0 + kPW * r, K - 1);
+      const float* row = tile + k * ld;
+      float m = -INFINITY;
+      for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+      mx[r] = m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = min(k0 + kPW * r, K - 1);
+      const float* row = tile + k * ld;
+      float sacc = 0.f;
+      for (int c = lane; c < C; c += 64) sacc += __expf(row[c] - mx[r]);
+      sum[r] = sacc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum[r] += __shfl_xor(sum[r], o, 64);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int k = k0 + kPW * r;
+        if (k < K) {
+          stat[k] = mx[r];
+          stat[K + k] = __logf(sum[r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  WRegs wr;
+  load_w<CK_W_ROWMAJOR>(w_s, lane, wr);
+  const int b_in = lane & 31, kh = lane >> 5;
+  float* dst = j.out + static_cast<int64_t>(d) * (C + 1) * K;
+  for (int t = wave; t * 32 <= C; t += kPW) {  // 32 categories per register tile, rows 0..C
+    const int c = t * 32 + b_in;
+    const int cl = min(c, C - 1);
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int k = 8 * g + 4 * kh + tt;
+        const float dlt = tile[k * ld + cl] - stat[k];
+        const float val = dlt < -103.9f ? -INFINITY : dlt - stat[K + k];
+        v[4 * g + tt] = c >= C ? 0.f : val;  // row C: log sum_c p = 0
+      }
+    sum_step<CK_W_ROWMAJOR>(wr, v);
+    if (c <= C) tile_store(dst + static_cast<int64_t>(c) * K + 4 * kh, v);
+  }
+}
+
+__global__ void __launch_bounds__(kPW * 64) softmax_batch_kernel(const JobTable t) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   const int bid = blockIdx.x;
   int ji = 0;
@@ -362,6 +476,8 @@ __global__ void __launch_bounds__(256) softmax_batch_kernel(const JobTable t) {
   const int blk = bid - j.block_begin;
   if (j.kind == 1)
     softmax_job_table(j, blk, tile);
+  else if (j.kind == 4)
+    softmax_job_table_dense(j, blk, tile);
   else
     softmax_job_rows(j, blk);
 }
@@ -520,15 +636,16 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
     for (int i = 0; i < t.n; ++i) {
       ck_softmax_job j = jobs[start + i];
       CK_REQUIRE(j.in && j.out && j.rows > 0 && j.len > 0, "ck_param_softmax_batch: bad job %d", start + i);
-      CK_REQUIRE(j.kind >= 0 && j.kind <= 3, "ck_param_softmax_batch: job %d has unknown kind %d", start + i, j.kind);
-      CK_REQUIRE(j.kind < 2 || (j.len == 32 && j.rows % 32 == 0),
+      CK_REQUIRE(j.kind >= 0 && j.kind <= 4, "ck_param_softmax_batch: job %d has unknown kind %d", start + i, j.kind);
+      CK_REQUIRE(j.kind < 2 || j.kind == 4 || (j.len == 32 && j.rows % 32 == 0),
                  "ck_param_softmax_batch: tiled job %d needs len = 32 and rows %% 32 = 0", start + i);
+      CK_REQUIRE(j.kind != 4 || (j.k == 32 && j.in2 != nullptr), "ck_param_softmax_batch: job %d (kind 4) needs k = 32 and in2", start + i);
       j.block_begin = blocks;
-      if (j.kind != 1) {
-        blocks += static_cast<int>((j.rows + 63) / 64);
+      if (j.kind != 1 && j.kind != 4) {
+        blocks += static_cast<int>((j.rows + 16 * kPW - 1) / (16 * kPW));
       } else {
         CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", start + i);
-        const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k) * sizeof(float);
+        const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k + (j.kind == 4 ? 1024 : 0)) * sizeof(float);
         if (need > 64 * 1024)
           return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
         lds = std::max(lds, need);
@@ -536,7 +653,7 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
       }
       t.job[i] = j;
     }
-    const dim3 grid(blocks), block(256);
+    const dim3 grid(blocks), block(kPW * 64);
     int st = ck::dispatch(
         [=](hipStream_t s) {
           if (lds > 48 * 1024) {

@@ -218,7 +218,12 @@ int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_
  * kind 1 (Categorical probs, input.py:405-408): in (rows=F, k=K, len=C) logits ->
  * out (F, C+1, K) = log(softmax over C), transposed for the gather kernels, row C = 0 (integral).
  * kind 2 / 3: as kind 0 for (F*32, 32) weights, written in CK_W_TILED_F32 / CK_W_TILED_F16X3
- * layout (rows must be a multiple of 32, len = 32).  block_begin is ignored on input. */
+ * layout (rows must be a multiple of 32, len = 32).
+ * kind 4: kind 1 followed by a dense sum layer applied to the table (k = 32): for each of the `rows`
+ * dense folds d, out[d] (C+1, 32) = log(softmax(in2[d]) . exp(T - m)) + m row by row, with T the kind-1
+ * table of categorical fold idx[d] (a Categorical layer followed fold by fold by a dense layer only
+ * takes C distinct values per fold, so the dense layer is evaluated on the table instead of on the batch).
+ * block_begin is ignored on input. */
 typedef struct ck_softmax_job {
   const float* in;
   float* out;
@@ -227,6 +232,8 @@ typedef struct ck_softmax_job {
   int32_t k;
   int32_t kind;
   int32_t block_begin;
+  const float* in2;   /* kind 4: (rows, 32, 32) logits of the dense layer */
+  const int64_t* idx; /* kind 4: categorical fold of each dense fold, or NULL for the identity */
 } ck_softmax_job;
 int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream);
 /* entrywise ops (nodes.py:656-699); a, b only used by CK_UNARY_SCALED_SIGMOID (vmin, vmax). */
