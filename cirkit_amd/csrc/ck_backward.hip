@@ -406,6 +406,145 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- Gaussian input layer ------------------------------------------------------------------------
+// lp = -(x - mu)^2 / (2 sd^2) - log sd - log sqrt(2 pi)   (input.py:661-670)
+//   d lp / d mu = (x - mu) / sd^2,   d lp / d sd = (x - mu)^2 / sd^3 - 1 / sd
+// One workgroup per fold: thread = unit k x row group; partial sums over the batch in registers,
+// then an LDS reduction over the row groups.  A NaN input (marginalised variable) contributes nothing.
+__global__ void __launch_bounds__(256)
+    gaussian_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ xt, const int64_t* __restrict__ scope,
+                        const float* __restrict__ mean, const float* __restrict__ stddev, float* __restrict__ dmean,
+                        float* __restrict__ dstd, int B, int K) {
+  extern __shared__ float red[];  // [2][groups][kk]
+  const int f = blockIdx.x;
+  const int kk = K <= 256 ? K : 256;
+  const int groups = 256 / kk;
+  const int r_in = threadIdx.x / kk, k0 = threadIdx.x - r_in * kk;
+  const float* xrow = xt + scope[f] * B;
+  const float* g = gout + static_cast<int64_t>(f) * B * K;
+  for (int k = k0; k < K; k += kk) {
+    float am = 0.f, as = 0.f;
+    if (r_in < groups) {
+      const float mu = mean[static_cast<int64_t>(f) * K + k];
+      const float sd = stddev[static_cast<int64_t>(f) * K + k];
+      const float inv_var = 1.f / (sd * sd), inv_sd = 1.f / sd;
+      for (int b = r_in; b < B; b += groups) {
+        const float xv = xrow[b];
+        if (xv != xv) continue;
+        const float d = xv - mu, gg = g[static_cast<int64_t>(b) * K + k];
+        am = fmaf(gg, d * inv_var, am);
+        as = fmaf(gg, d * d * inv_var * inv_sd - inv_sd, as);
+      }
+      red[r_in * kk + k0] = am;
+      red[(groups + r_in) * kk + k0] = as;
+    }
+    __syncthreads();
+    if (r_in == 0) {
+      float tm = 0.f, ts = 0.f;
+      for (int r = 0; r < groups; ++r) {
+        tm += red[r * kk + k0];
+        ts += red[(groups + r) * kk + k0];
+      }
+      dmean[static_cast<int64_t>(f) * K + k] = tm;
+      dstd[static_cast<int64_t>(f) * K + k] = ts;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- Mixing layer ----------------------------------------------------------------------------------
+// out[k] = log(sum_h w[k,h] e_h[k]) + m, e_h[k] = exp(x_h[k] - m), m = max over (h, k) of the row
+// (ck_mixing_lse_fwd).  With y[k] = exp(out[k] - m) recomputed as sum_h w e:
+//   g x_h[k] = gout[k] w[k,h] e_h[k] / y[k],     d w[k,h] += sum_b gout[k] e_h[k] / y[k].
+// One wave per batch row (lanes over k), dW partials in LDS per workgroup, one atomic per (k, h).
+__global__ void __launch_bounds__(256)
+    mixing_bwd_kernel(const float* __restrict__ arena, float* __restrict__ garena, const int64_t* __restrict__ row_off,
+                      const float* __restrict__ mw, const float* __restrict__ gout, float* __restrict__ dmw, int H,
+                      int B, int K, int rows_per_block, int accumulate) {
+  extern __shared__ float dw_s[];  // [K][H]
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const float* mwf = mw + static_cast<int64_t>(f) * K * H;
+  for (int i = threadIdx.x; i < K * H; i += blockDim.x) dw_s[i] = 0.f;
+  __syncthreads();
+  const int b_begin = blockIdx.x * rows_per_block;
+  const int b_end = min(B, b_begin + rows_per_block);
+  for (int b = b_begin + wave; b < b_end; b += 4) {
+    float mx = -INFINITY;
+    for (int h = 0; h < H; ++h) {
+      const float* src = arena + ro[h] + static_cast<int64_t>(b) * K;
+      for (int k = lane; k < K; k += 64) mx = fmaxf(mx, src[k]);
+    }
+    mx = ck::clamp_finite(ck::wave_max(mx));
+    for (int k = lane; k < K; k += 64) {
+      float y = 0.f;
+      for (int h = 0; h < H; ++h)
+        y = fmaf(mwf[static_cast<int64_t>(k) * H + h], expf(arena[ro[h] + static_cast<int64_t>(b) * K + k] - mx), y);
+      const float gy = gout[(static_cast<int64_t>(f) * B + b) * K + k] / y;
+      for (int h = 0; h < H; ++h) {
+        const float e = expf(arena[ro[h] + static_cast<int64_t>(b) * K + k] - mx);
+        const float ge = gy * e;
+        float* dst = garena + ro[h] + static_cast<int64_t>(b) * K + k;
+        const float gv = ge * mwf[static_cast<int64_t>(k) * H + h];
+        if (accumulate == 0)
+          *dst = gv;
+        else if (accumulate == 1)
+          *dst += gv;
+        else
+          atomicAdd(dst, gv);
+        atomicAdd(&dw_s[k * H + h], ge);
+      }
+    }
+  }
+  __syncthreads();
+  float* dwf = dmw + static_cast<int64_t>(f) * K * H;
+  for (int i = threadIdx.x; i < K * H; i += blockDim.x) atomicAdd(&dwf[i], dw_s[i]);
+}
+
+// ---- parameter-graph backward pieces -------------------------------------------------------------
+// scaled sigmoid y = s (vmax - vmin) + vmin:  dx = dy (y - vmin)(vmax - y) / (vmax - vmin)
+__global__ void __launch_bounds__(256)
+    scaled_sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                              int64_t n, float vmin, float vmax, int accumulate) {
+  const float inv = 1.f / (vmax - vmin);
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const float g = dy[i] * (y[i] - vmin) * (vmax - y[i]) * inv;
+    dx[i] = accumulate ? dx[i] + g : g;
+  }
+}
+// mixing weight (F, K, H) -> (F, K, H*K) block diagonal: dx[f,k,h] = dy[f,k,h*K + k]
+__global__ void __launch_bounds__(256)
+    mixing_weight_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t n, int K, int H,
+                             int accumulate) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int h = static_cast<int>(i % H);
+    const int64_t fk = i / H;
+    const int k = static_cast<int>(fk % K);
+    const float g = dy[fk * (static_cast<int64_t>(H) * K) + static_cast<int64_t>(h) * K + k];
+    dx[i] = accumulate ? dx[i] + g : g;
+  }
+}
+// backward of a fold gather (parameter address book, parameter.py:41-47): ddst[idx[i]] += dsrc[i]
+__global__ void __launch_bounds__(256)
+    scatter_add_folds_kernel(const float* __restrict__ dsrc, const int64_t* __restrict__ idx, float* __restrict__ ddst,
+                             int64_t per_fold) {
+  const int64_t i = blockIdx.y;
+  const float* src = dsrc + i * per_fold;
+  float* dst = ddst + idx[i] * per_fold;
+  for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < per_fold;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    atomicAdd(dst + e, src[e]);
+}
+__global__ void __launch_bounds__(256)
+    axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, int64_t n) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    y[i] = fmaf(a, x[i], y[i]);
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, int64_t n, float v) {
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x)
@@ -455,6 +594,89 @@ int ck_fill_f32(float* p, int64_t n, float value, void* stream) {
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(fill_kernel, grid, block, 0, s, p, n, value);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_gaussian_bwd(const float* gout, const float* xt, const int64_t* scope, const float* mean, const float* stddev,
+                    float* dmean, float* dstddev, int F, int B, int K, void* stream) {
+  CK_REQUIRE(gout && xt && scope && mean && stddev && dmean && dstddev, "ck_gaussian_bwd: null pointer");
+  CK_REQUIRE(F > 0 && B > 0 && K > 0, "ck_gaussian_bwd: non-positive size");
+  const int kk = K <= 256 ? K : 256;
+  const size_t lds = static_cast<size_t>(2) * (256 / kk) * kk * sizeof(float);
+  dim3 grid(F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(gaussian_bwd_kernel, grid, block, lds, s, gout, xt, scope, mean, stddev, dmean, dstddev, B, K);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_mixing_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* mw, const float* gout,
+                      float* dmw, int F, int H, int B, int K, int accumulate, void* stream) {
+  CK_REQUIRE(arena && garena && row_off && mw && gout && dmw, "ck_mixing_lse_bwd: null pointer");
+  CK_REQUIRE(F > 0 && H > 0 && B > 0 && K > 0, "ck_mixing_lse_bwd: non-positive size");
+  CK_REQUIRE(accumulate >= 0 && accumulate <= 2, "ck_mixing_lse_bwd: accumulate must be 0, 1 or 2");
+  CK_REQUIRE(F <= 65535, "ck_mixing_lse_bwd: F=%d exceeds grid.y", F);
+  const size_t lds = static_cast<size_t>(K) * H * sizeof(float);
+  CK_REQUIRE(lds <= 64 * 1024, "ck_mixing_lse_bwd: K*H=%d coefficients do not fit in LDS", K * H);
+  const int rows_per_block = 64;
+  dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(mixing_bwd_kernel, grid, block, lds, s, arena, garena, row_off, mw, gout, dmw, H, B, K,
+                           rows_per_block, accumulate);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_scaled_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, float vmin, float vmax,
+                                int accumulate, void* stream) {
+  CK_REQUIRE(y && dy && dx && n > 0, "ck_param_scaled_sigmoid_bwd: bad arguments");
+  CK_REQUIRE(vmax > vmin, "ck_param_scaled_sigmoid_bwd: vmax must exceed vmin");
+  dim3 grid(grid1(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(scaled_sigmoid_bwd_kernel, grid, block, 0, s, y, dy, dx, n, vmin, vmax, accumulate);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_mixing_weight_bwd(const float* dy, float* dx, int F, int K, int H, int accumulate, void* stream) {
+  CK_REQUIRE(dy && dx && F > 0 && K > 0 && H > 0, "ck_param_mixing_weight_bwd: bad arguments");
+  const int64_t n = static_cast<int64_t>(F) * K * H;
+  dim3 grid(grid1(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(mixing_weight_bwd_kernel, grid, block, 0, s, dy, dx, n, K, H, accumulate);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_scatter_add_folds(const float* dsrc, const int64_t* idx, float* ddst, int64_t n, int64_t per_fold,
+                               void* stream) {
+  CK_REQUIRE(dsrc && idx && ddst && n > 0 && per_fold > 0, "ck_param_scatter_add_folds: bad arguments");
+  CK_REQUIRE(n <= 65535, "ck_param_scatter_add_folds: n exceeds grid.y");
+  dim3 grid(grid1(per_fold, 64), static_cast<unsigned>(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(scatter_add_folds_kernel, grid, block, 0, s, dsrc, idx, ddst, per_fold);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream) {
+  CK_REQUIRE(y && x && n > 0, "ck_axpy_f32: bad arguments");
+  dim3 grid(grid1(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(axpy_kernel, grid, block, 0, s, y, x, a, n);
         return hipGetLastError();
       },
       stream);

@@ -316,6 +316,112 @@ class HipParameter:
             return outs[upto]
         return self._select("out", outs, g.output, stream)
 
+    # -- backward -----------------------------------------------------------------------------
+    def backward(self, dout: torch.Tensor, grads: Mapping[str, torch.Tensor], stream: int = 0, *,
+                 upto: int | None = None) -> None:
+        """Reverse-mode pass over the graph: `dout` is the gradient w.r.t. the value `evaluate`
+        returned last (with the same `upto`); the gradients of the parameter tensors are ADDED into
+        `grads[name]`.  Covers what the region-graph templates build -- tensor, softmax (last axis),
+        scaled sigmoid, mixing weight, matmul -- including the fold re-indexing between nodes that
+        folding introduces when the layers of a group carry different parameter graphs."""
+        g = self.graph
+        last = len(g.nodes) - 1 if upto is None else upto
+        folds = [n.num_folds for n in g.nodes]
+
+        def value(j: int) -> torch.Tensor:
+            n = g.nodes[j]
+            return self.store[n.config["tensor"]] if n.op == "tensor" else self._bufs[j]
+
+        gb: dict[int, torch.Tensor] = {}
+
+        def target(i: int) -> torch.Tensor:
+            """The (accumulating) gradient buffer of node i: the caller's for tensors, a zeroed scratch otherwise."""
+            n = g.nodes[i]
+            if n.op == "tensor":
+                return grads[n.config["tensor"]]
+            if i not in gb:
+                gb[i] = self._buf(("grad", i), value(i).shape)
+                capi.call("ck_fill_f32", _ptr(gb[i]), gb[i].numel(), 0.0, stream)
+            return gb[i]
+
+        def is_identity(fi: FoldIndex) -> bool:
+            return len(fi.ids) == 1 and (fi.kind == IDX_NONE or (
+                fi.kind == IDX_ARRAY and np.array_equal(np.asarray(fi.array).reshape(-1), np.arange(folds[fi.ids[0]]))))
+
+        def scatter(key, fi: FoldIndex, dgathered: torch.Tensor) -> None:
+            """Backward of `_select`: add the rows of `dgathered` into the producers they were gathered from."""
+            if is_identity(fi):
+                t = target(fi.ids[0])
+                if t.data_ptr() != dgathered.data_ptr():
+                    capi.call("ck_axpy_f32", _ptr(t), _ptr(dgathered), 1.0, dgathered.numel(), stream)
+                return
+            pairs = resolve_fold_index(fi, [folds[i] if i in fi.ids else 0 for i in range(max(fi.ids) + 1)]).reshape(-1, 2)
+            per_fold = dgathered.numel() // dgathered.shape[0]
+            for p in fi.ids:
+                rows = np.nonzero(pairs[:, 0] == p)[0]
+                if len(rows) == 0:
+                    continue
+                if np.array_equal(rows, np.arange(rows[0], rows[0] + len(rows))):
+                    src = dgathered[rows[0] : rows[0] + len(rows)]
+                else:
+                    src = self._gather(("gs", key, p), dgathered, rows, stream)
+                capi.call("ck_param_scatter_add_folds", _ptr(src), _ptr(self._index_tensor(("si", key, p), pairs[rows, 1])),
+                          _ptr(target(p)), len(rows), per_fold, stream)
+
+        def operand(j: int, k: int) -> torch.Tensor:
+            fi = g.nodes[j].inputs[k]
+            return value(fi.ids[0]) if is_identity(fi) else self._bufs[("g", (j, k))]
+
+        def direct(j: int, k: int):
+            """(buffer, accumulate flag, needs scatter) for the gradient of operand k of node j."""
+            fi = g.nodes[j].inputs[k]
+            if is_identity(fi):
+                return target(fi.ids[0]), 1, False
+            return self._buf(("gop", j, k), operand(j, k).shape), 0, True
+
+        if upto is None:
+            scatter("out", g.output, dout)
+        else:
+            gb[upto] = dout
+        for j in range(last, -1, -1):
+            n = g.nodes[j]
+            if n.op == "tensor" or j not in gb:
+                continue
+            dj = gb[j]
+            if n.op == "softmax":
+                if int(n.config["dim"]) != len(n.shape) - 1:
+                    raise NotImplementedError("softmax backward along an inner axis")
+                y = value(j)
+                dx, acc, sc = direct(j, 0)
+                capi.call("ck_param_softmax_bwd", _ptr(y), _ptr(dj), _ptr(dx), y.numel() // y.shape[-1], int(y.shape[-1]), acc, stream)
+                if sc:
+                    scatter((j, 0), n.inputs[0], dx)
+            elif n.op == "scaled_sigmoid":
+                y = value(j)
+                dx, acc, sc = direct(j, 0)
+                capi.call("ck_param_scaled_sigmoid_bwd", _ptr(y), _ptr(dj), _ptr(dx), y.numel(),
+                          float(n.config.get("vmin", 0.0)), float(n.config.get("vmax", 1.0)), acc, stream)
+                if sc:
+                    scatter((j, 0), n.inputs[0], dx)
+            elif n.op == "mixing_weight":
+                F, K, H = operand(j, 0).shape
+                dx, acc, sc = direct(j, 0)
+                capi.call("ck_param_mixing_weight_bwd", _ptr(dj), _ptr(dx), F, K, H, acc, stream)
+                if sc:
+                    scatter((j, 0), n.inputs[0], dx)
+            elif n.op == "matmul":  # y = a b: da = dy b^T, db = a^T dy
+                a, b = operand(j, 0), operand(j, 1)
+                F, M, Kd = a.shape
+                N = b.shape[2]
+                da = self._buf(("gtmp", j, 0), (F, M, Kd))
+                db = self._buf(("gtmp", j, 1), (F, Kd, N))
+                capi.call("ck_param_bmm", _ptr(dj), _ptr(b), _ptr(da), F, M, Kd, N, 0, 1, stream)
+                capi.call("ck_param_bmm", _ptr(a), _ptr(dj), _ptr(db), F, Kd, N, M, 1, 0, stream)
+                scatter((j, 0), n.inputs[0], da)
+                scatter((j, 1), n.inputs[1], db)
+            else:
+                raise NotImplementedError(f"parameter backward through {n.op!r}")
+
     def softmax_source(self) -> torch.Tensor | None:
         """The raw tensor when the graph is exactly ``tensor -> softmax(last axis)`` with identity
         fold indices (the default parameterisation of sum weights and Categorical probs), else None."""

@@ -7,8 +7,10 @@ second launch list of hand-written kernels (cirkit_amd/csrc/ck_backward.hip) wal
 reverse.  Data-parallel training = one process per GPU, the batch sharded, and ONE all-reduce of a
 single flat gradient buffer (all parameter gradients are views of it) over RCCL/xGMI per step.
 
-Covered: real lse-sum circuits made of Categorical (probs = softmax), Sum / CP-T (softmax or raw
-weights) and Hadamard layers -- BASELINE configs 1-3.  Other layers raise NotImplementedError.
+Covered: real lse-sum circuits made of Categorical (probs = softmax) or Gaussian inputs, Sum / CP-T
+layers (softmax, raw, or any parameter graph `HipParameter.backward` handles, e.g. the MatMul weight
+of a collapsed Sum -> Sum pair), mixing layers and Hadamard layers -- what the image / tabular
+templates build with 'cp' and 'cp-t' (BASELINE configs 1-4).  Other layers raise NotImplementedError.
 """
 
 from __future__ import annotations
@@ -21,7 +23,7 @@ import torch
 
 from . import _capi as capi
 from .circuit import HipCircuit
-from .layers import HipCategoricalLayer, HipCPTLayer, HipHadamardLayer, HipSumLayer
+from .layers import HipCategoricalLayer, HipCPTLayer, HipGaussianLayer, HipHadamardLayer, HipSumLayer
 from .plan import Plan
 
 
@@ -73,21 +75,27 @@ class HipTrainer:
         self._bwd: dict[int, dict] = {}
 
     # ------------------------------------------------------------------------------------------
+    _PARAM_OPS = {"tensor", "softmax", "scaled_sigmoid", "mixing_weight", "matmul"}
+
     def _check_supported(self) -> None:
         for spec, l in zip(self.plan.layers, self.circuit.layers):
             if isinstance(l, HipCategoricalLayer):
                 if l.probs is None or l.probs.softmax_source() is None:
                     raise NotImplementedError("training: Categorical layers need probs = softmax(tensor)")
+            elif isinstance(l, HipGaussianLayer):
+                if l.log_partition is not None or (set(l.mean.ops) | set(l.stddev.ops)) - self._PARAM_OPS:
+                    raise NotImplementedError("training: Gaussian layers with a log-partition or exotic parameters")
             elif isinstance(l, (HipSumLayer, HipCPTLayer)) and type(l) in (HipSumLayer, HipCPTLayer):
-                if l._mixing:
-                    raise NotImplementedError("training: mixing layers")
-                ops = l.weight.ops
-                if ops not in (["tensor", "softmax"], ["tensor"]) or (ops == ["tensor", "softmax"] and l.weight.softmax_source() is None):
-                    raise NotImplementedError(f"training: weight parameterisation {ops}")
+                if set(l.weight.ops) - self._PARAM_OPS:
+                    raise NotImplementedError(f"training: weight parameterisation {l.weight.ops}")
             elif isinstance(l, HipHadamardLayer):
                 pass
             else:
                 raise NotImplementedError(f"training: layer type {spec.type!r}")
+
+    def _fast_softmax(self, l) -> bool:
+        """tensor -> softmax weights evaluated by the batched prologue: their backward is one kernel."""
+        return l.weight.ops == ["tensor", "softmax"] and l.weight.softmax_source() is not None and not l._mixing
 
     def _accumulate_flags(self) -> tuple[dict[int, int], set[int]]:
         """Per consumer layer: 0 store / 1 add / 2 atomic; and the producer layers whose gradient
@@ -137,10 +145,12 @@ class HipTrainer:
         # linear-space weight gradients (dW, dTable) live in ONE flat buffer: a single fill per step
         sizes = {}
         for i, l in enumerate(c.layers):
-            if isinstance(l, (HipSumLayer, HipCPTLayer)) and l.weight.ops == ["tensor", "softmax"]:
-                sizes[i] = tuple(l._w.shape)
+            if isinstance(l, (HipSumLayer, HipCPTLayer)) and not (l.weight.ops == ["tensor"]):
+                sizes[i] = tuple(l._w.shape)  # mixing layers: the (F, K, H) coefficients
             elif isinstance(l, HipCategoricalLayer):
                 sizes[i] = tuple(l._table.shape)
+            elif isinstance(l, HipGaussianLayer):
+                sizes[(i, "mean")] = sizes[(i, "stddev")] = (l.num_folds, l.num_output_units)
         flat = torch.zeros(sum(int(np.prod(sh)) for sh in sizes.values()) or 1, dtype=torch.float32, device=self.device)
         dws, off = {}, 0
         for i, sh in sizes.items():
@@ -163,6 +173,7 @@ class HipTrainer:
         st = self._bind_backward(B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         capi.call("ck_fill_f32", st["dw_flat"].data_ptr(), st["dw_flat"].numel(), 0.0, stream)
+        capi.call("ck_fill_f32", self._flat_grad.data_ptr(), self._flat_grad.numel(), 0.0, stream)
         gB = float(global_batch or B)
         gviews, flags = st["gviews"], st["flags"]
         for p in st["need_zero"]:
@@ -181,22 +192,36 @@ class HipTrainer:
                 name = l.probs.graph.nodes[0].config["tensor"]
                 capi.call("ck_param_log_table_bwd", l._table.data_ptr(), dT.data_ptr(), self.grads[name].data_ptr(),
                           l.num_folds, l.num_output_units, l.num_categories, 0, stream)
+            elif isinstance(l, HipGaussianLayer):
+                mean, stddev, _ = l._vals
+                dm, ds = st["dws"][(i, "mean")], st["dws"][(i, "stddev")]
+                capi.call("ck_gaussian_bwd", gviews[i].data_ptr(), bd.xt.data_ptr(), l._scope(self.device).data_ptr(),
+                          mean.data_ptr(), stddev.data_ptr(), dm.data_ptr(), ds.data_ptr(), l.num_folds, B,
+                          l.num_output_units, stream)
+                l.mean.backward(dm, self.grads, stream)
+                l.stddev.backward(ds, self.grads, stream)
             elif isinstance(l, HipHadamardLayer):
                 capi.call("ck_hadamard_bwd", st["garena"].data_ptr(), bd.row_off[i].data_ptr(), gviews[i].data_ptr(),
                           l.num_folds, l.arity, B, l.num_input_units, flags[i], stream)
+            elif l._mixing:
+                dmw = st["dws"][i]
+                capi.call("ck_mixing_lse_bwd", bd.arena.data_ptr(), st["garena"].data_ptr(), bd.row_off[i].data_ptr(),
+                          l._w.data_ptr(), gviews[i].data_ptr(), dmw.data_ptr(), l.num_folds, l.arity, B,
+                          l.num_output_units, flags[i], stream)
+                l.weight.backward(dmw, self.grads, stream, upto=len(l.weight.graph.nodes) - 2)
             else:  # sum / cpt
-                name = l.weight.graph.nodes[0].config["tensor"]
-                soft = l.weight.ops == ["tensor", "softmax"]
-                dW = st["dws"][i] if soft else self.grads[name]
-                if not soft:
-                    capi.call("ck_fill_f32", dW.data_ptr(), dW.numel(), 0.0, stream)
+                raw = l.weight.ops == ["tensor"]
+                dW = self.grads[l.weight.graph.nodes[0].config["tensor"]] if raw else st["dws"][i]
                 capi.call("ck_sum_lse_bwd", bd.arena.data_ptr(), st["garena"].data_ptr(), bd.row_off[i].data_ptr(),
                           l._w.data_ptr(), bd.views[i].data_ptr(), gviews[i].data_ptr(), dW.data_ptr(), l.num_folds,
                           l.arity, B, l.num_input_units, l.num_output_units, l._mode, flags[i], stream)
-                if soft:
+                if self._fast_softmax(l):
+                    name = l.weight.graph.nodes[0].config["tensor"]
                     rows = l.num_folds * l.num_output_units
                     capi.call("ck_param_softmax_bwd", l._w.data_ptr(), dW.data_ptr(), self.grads[name].data_ptr(),
                               rows, dW.shape[-1], 0, stream)
+                elif not raw:
+                    l.weight.backward(dW, self.grads, stream)
         return ll
 
     def all_reduce_grads(self) -> None:

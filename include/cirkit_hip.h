@@ -276,6 +276,23 @@ int ck_debug_force_generic_bwd(int on); /* test hook, like ck_debug_force_generi
 /* TorchHadamardLayer backward: every child receives gout (F,B,K). */
 int ck_hadamard_bwd(float* garena, const int64_t* row_off, const float* gout, int F, int H, int B, int K,
                     int accumulate, void* stream);
+/* Gaussian input layer backward (input.py:661-670): dmean[f,k] = sum_b gout (x-mu)/sd^2,
+ * dstddev[f,k] = sum_b gout ((x-mu)^2/sd^3 - 1/sd); NaN inputs (marginalised) contribute nothing. */
+int ck_gaussian_bwd(const float* gout, const float* xt, const int64_t* scope, const float* mean, const float* stddev,
+                    float* dmean, float* dstddev, int F, int B, int K, void* stream);
+/* Mixing layer backward (forward: ck_mixing_lse_fwd): input gradients into garena at the children's
+ * offsets (accumulate 0 store / 1 add / 2 atomic), dmw (F, K, H) += batch sums (zero it first). */
+int ck_mixing_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* mw, const float* gout,
+                      float* dmw, int F, int H, int B, int K, int accumulate, void* stream);
+/* Parameter-graph backward pieces: scaled sigmoid (nodes.py:698-699) from its OUTPUT y, the mixing-weight
+ * expansion (nodes.py:857-862), y += a x. */
+int ck_param_scaled_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, float vmin, float vmax,
+                                int accumulate, void* stream);
+int ck_param_mixing_weight_bwd(const float* dy, float* dx, int F, int K, int H, int accumulate, void* stream);
+int ck_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
+/* Backward of ck_param_gather_folds: ddst[idx[i]] += dsrc[i] over blocks of `per_fold` fp32 words. */
+int ck_param_scatter_add_folds(const float* dsrc, const int64_t* idx, float* ddst, int64_t n, int64_t per_fold,
+                               void* stream);
 /* TorchCategoricalLayer backward: dtable[f,c,:] += sum_{b: x[b,scope f]=c} gout[f,b,:]  (dtable
  * (F,C+1,K), same transposed layout as the forward table). */
 int ck_categorical_bwd(const float* gout, const int32_t* xt, const int64_t* scope, float* dtable, int F,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Training-step timing on the GPU box (config 2: 784-var QuadTree, K = 32):
-    python scripts/bench_train.py [B] [steps]"""
+"""Training-step timing on the GPU box:
+    python scripts/bench_train.py [B] [steps] [config]
+config 2 (default): 784-var QuadTree, Categorical, K = 32; config 4: Poon-Domingos, Gaussian, K = 64."""
 import os
 import sys
 import time
@@ -15,9 +16,15 @@ from cirkit_amd.training import HipTrainer  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-plan = image_data((1, 28, 28), num_input_units=32, num_sum_units=32)
+cfg = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+if cfg == 4:
+    plan = image_data((1, 28, 28), "poon-domingos", input_layer="gaussian", num_input_units=64,
+                      sum_product_layer="cp", num_sum_units=64)
+    x = torch.randn(B, 784).cuda()
+else:
+    plan = image_data((1, 28, 28), "quad-tree-2", num_input_units=32, num_sum_units=32)
+    x = torch.randint(0, 256, (B, 784)).cuda()
 tr = HipTrainer(plan, init_plan_tensors(plan), device="cuda:0", lr=0.01)
-x = torch.randint(0, 256, (B, 784)).cuda()
 lls = []
 for _ in range(3):
     ll = tr.step(x)

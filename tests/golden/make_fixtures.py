@@ -209,6 +209,9 @@ def templates_extra():
                                                         sum_product_layer="cp", num_sum_units=4),
          torch.randint(0, 256, (24, 36), generator=g)),
     ]
+    cases.append(("pd_gauss_6x6_k4", data_modalities.image_data((1, 6, 6), "poon-domingos", input_layer="gaussian", num_input_units=4,
+                                                       sum_product_layer="cp", num_sum_units=4),
+                  torch.randn(24, 36, generator=g)))
     xm = torch.randn(24, 6, generator=g)
     xm[:, 0::2] = torch.randint(0, 3, (24, 3), generator=g).float()
     cases.append(("rbt6_perfeature_k2", data_modalities.tabular_data(
@@ -238,6 +241,15 @@ def grads():
                 (1, 28, 28), "quad-tree-2", input_layer="categorical", num_input_units=32,
                 sum_product_layer="cp", num_sum_units=32),
              lambda g: torch.randint(0, 256, (16, 784), generator=g)),
+            # mixing layers, a collapsed Sum -> Sum pair (MatMul weight), Gaussian inputs (scaled-sigmoid stddev)
+            ("quadgraph_6x6_k4", lambda: data_modalities.image_data(
+                (1, 6, 6), "quad-graph", input_layer="categorical", num_input_units=4,
+                sum_product_layer="cp", num_sum_units=4),
+             lambda g: torch.randint(0, 256, (24, 36), generator=g)),
+            ("pd_gauss_6x6_k4", lambda: data_modalities.image_data(
+                (1, 6, 6), "poon-domingos", input_layer="gaussian", num_input_units=4,
+                sum_product_layer="cp", num_sum_units=4),
+             lambda g: torch.randn(24, 36, generator=g)),
         ]:
             cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(build())
             plan, tensors = plan_from_torch_circuit(cc)
@@ -248,10 +260,10 @@ def grads():
             loss = -cc(x).mean()
             loss.backward()
             by_ptr = {p.data_ptr(): p for p in cc.parameters()}
-            extra = {"x": x.numpy().astype(np.int16), "loss": np.array(loss.item())}
+            extra = {"x": x.numpy().astype(np.float32 if x.is_floating_point() else np.int16), "loss": np.array(loss.item())}
             for k, t in tensors.items():
                 gr = by_ptr[t.data_ptr()].grad
-                if name.startswith("cfg1"):
+                if not name.startswith("cfg2"):
                     extra["g_" + k] = gr.numpy()
                 else:
                     extra["gnorm_" + k] = np.array(gr.norm().item())

@@ -100,7 +100,7 @@ def _check_complex_layers_locally(plan, tensors, x, hc, outs_ref, atol_scale):
 
 
 @pytest.mark.parametrize("name", ["cfg1_rbt8", "cfg2_qt784", "cfg2t_qt784_cpt16", "cfg4_pd784", "tucker_qt16_k6",
-                                  "tucker4_qt16_k3", "quadgraph_6x6_k4", "rbt6_perfeature_k2"])
+                                  "tucker4_qt16_k3", "quadgraph_6x6_k4", "rbt6_perfeature_k2", "pd_gauss_6x6_k4"])
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("fuse", [False, 1, 2, 3, True])
 def test_real_configs_match_reference(hip_device, name, use_graph, fuse):

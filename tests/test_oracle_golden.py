@@ -26,7 +26,7 @@ def _x_of(g):
 
 
 @pytest.mark.parametrize("name", ["cfg1_rbt8", "cfg2_qt784", "cfg2t_qt784_cpt16", "cfg4_pd784", "tucker_qt16_k6",
-                                  "tucker4_qt16_k3", "quadgraph_6x6_k4", "rbt6_perfeature_k2"])
+                                  "tucker4_qt16_k3", "quadgraph_6x6_k4", "rbt6_perfeature_k2", "pd_gauss_6x6_k4"])
 def test_oracle_is_bit_exact_vs_reference_fp32(name):
     plan, tensors, g = load_case(name)
     y = evaluate_plan(plan, as_torch(tensors), _x_of(g))
