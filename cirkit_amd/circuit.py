@@ -76,6 +76,10 @@ class HipCircuit:
             takes C distinct values per fold, so the dense layer is applied once per forward to the
             (F, C, K) log-probability table (same kernel, batch = C) instead of to every batch row;
             bit-identical results, B/C times less work for that layer.
+        linear_levels: inside the fused leaf launch a value is handed from one CP-T level to the next as
+            (linear tile, per-row log scale) instead of taking its log and exponentiating it again; the
+            same sums with one log per row instead of 64 transcendentals (cirkit_amd/csrc/ck_fused.hip).
+            False keeps the log / exp of the reference between the levels.
         cache_params: the reference re-evaluates every parameter graph (softmax, log, ...) on every
             forward and so does the default here.  True keeps the derived parameters of the last
             forward and recomputes them only after a parameter value changed (`TensorStore.set`,
@@ -96,6 +100,7 @@ class HipCircuit:
         tiled_weights: bool = True,
         cache_params: bool = False,
         fuse_regions: bool = True,
+        linear_levels: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -106,6 +111,7 @@ class HipCircuit:
         self.plan = plan
         self.use_graph = use_graph
         self.cache_params = bool(cache_params)
+        self.linear_levels = bool(linear_levels)
         self._pprog = None
         self._pprog_version = self._pprog_data_version = -1
         if isinstance(tensors, TensorStore):
@@ -460,8 +466,8 @@ class HipCircuit:
         reach memory.  Returns the layers whose parameters are fully covered by such jobs."""
         covered: set[int] = set()
         self._table_fused = set()
-        if not (self.dense_on_table and self.contraction == "f32"):
-            return covered
+        if not self.dense_on_table or (self.contraction != "f32" and not self.linear_levels):
+            return covered  # (the log-space table job contracts in exact fp32 only)
         for g in self._groups:
             if g.dense_layer is None or g.depth == 0:
                 continue
@@ -474,9 +480,10 @@ class HipCircuit:
             leaf = self._children[g.dense_layer][:, 0, 1].astype(np.int64)
             idx = None if np.array_equal(leaf, np.arange(len(leaf))) else torch.from_numpy(leaf).to(self.device)
             dst = torch.empty((dl.num_folds, Cn + 1, 32), dtype=torch.float32, device=self.device)
-            batch.add_log_table_dense(src, wsrc, idx, dst)
+            scale = torch.empty((dl.num_folds, Cn + 1), dtype=torch.float32, device=self.device) if self.linear_levels else None
+            batch.add_log_table_dense(src, wsrc, idx, dst, scale)
             dev = self._group_dev.get(g.root) or (torch.from_numpy(g.nodes).to(self.device),)
-            self._group_dev[g.root] = (dev[0], dst, torch.from_numpy(np.ascontiguousarray(leaf * ((Cn + 1) * 32))).to(self.device))
+            self._group_dev[g.root] = (dev[0], dst, torch.from_numpy(np.ascontiguousarray(leaf * ((Cn + 1) * 32))).to(self.device), scale)
             self._table_fused.add(g.root)
             covered |= {g.input_layer, g.dense_layer}
         return covered
@@ -535,8 +542,10 @@ class HipCircuit:
         cat = self.layers[g.input_layer]
         levels = (C.c_void_p * max(1, g.depth))(*[self.layers[j]._w.data_ptr() for j in g.levels])
         node_off = (C.c_int32 * (g.depth + 1))(*g.node_off)
+        scale = dev[3] if g.root in self._table_fused and len(dev) > 3 else None
         capi.call(
-            "ck_subtree_cat_cpt_fwd", table.data_ptr(), bd.xt_i.data_ptr(), cat._scope(self.device).data_ptr(),
+            "ck_subtree_cat_cpt_fwd", table.data_ptr(), None if scale is None else scale.data_ptr(), bd.xt_i.data_ptr(),
+            cat._scope(self.device).data_ptr(),
             None if w_dense is None else w_dense.data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off,
             out.data_ptr(), g.depth, self.layers[g.root].num_folds, bd.B, cat.num_output_units,
             cat.num_categories, self._group_layout(g), stream,
@@ -691,6 +700,8 @@ class HipCircuit:
         if i in self._group_of_root:
             g = self._group_of_root[i]
             in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)
+            if i in self._table_fused and self.linear_levels:
+                return f"subtree_linear_kernel<{g.depth}, {self._group_layout(g)}>"
             return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")
         if s.type in ("categorical", "embedding"):

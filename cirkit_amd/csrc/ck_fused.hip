@@ -38,6 +38,7 @@ struct SubtreeArgs {
                                 // (level 0 = folds of the dense layer, or of the input layer)
   int leaf_off;                 // nodes + leaf_off -> (F_root, 2^D) input-layer fold of each leaf
   float* out;                   // (F_root, B, K)
+  const float* scale;           // LINEAR kernels: (F0, C+1) log scale of each table row
   int B, C, F_root, groups_per_root;
 };
 
@@ -188,14 +189,137 @@ hipError_t launch_depth(const SubtreeArgs& a, int depth, bool has_dense, dim3 gr
   }
 }
 
+// ---- linear-domain variant -----------------------------------------------------------------------
+// Between two fused CP-T levels the reference takes a log and the next level immediately exponentiates
+// again: v = log y_l + m_l + log y_r + m_r, e = exp(v - max v).  Here a node is carried as
+// (y: linear tile in [0, 1], s: per-row log scale) and the next level forms
+//     p = y_l * y_r,   e = p / max_k p,   s = s_l + s_r + log(max_k p),   y = W . e
+// -- the same quantities, with ONE log per row instead of 32 exp + 32 log per row and no rounding of
+// a log/exp round trip.  The leaf table comes in the same representation (rows in linear space +
+// `scale`, written by the prologue job that pushes the table through the dense layer); the root
+// level is converted back, out = log y + s.  If every product of a row underflows fp32 (children
+// whose large units do not overlap by more than ~1e-38) the step is redone in log space.
+template <int D, int LAYOUT>
+__global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, i_in = bid >> 3;
+  const int chunk = i_in / a.groups_per_root, tg = i_in - chunk * a.groups_per_root;
+  const int t = chunk * 8 + xcd;
+  if (t >= a.F_root) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int b0 = (tg * 4 + wave) * 32;
+  if (b0 >= a.B) return;
+  const int b = b0 + b_in;
+  const bool live = b < a.B;
+  const int bl = live ? b : a.B - 1;
+
+  constexpr int kLeaves = 1 << D;
+  const int32_t* leaf_ids = a.nodes + a.leaf_off + t * kLeaves;
+  const int32_t* fold0 = a.nodes + a.node_off[0] + t * kLeaves;  // table fold of each leaf
+  auto w_ptr = [&](int i, int lvl) -> const float* {
+    const int fold = a.nodes[a.node_off[lvl + 1] + t * (kLeaves >> (lvl + 1)) + (i >> (lvl + 1))];
+    return a.w[lvl] + static_cast<int64_t>(fold) * (kK * kK);
+  };
+  int64_t row[kLeaves];  // table row (fold, category) of each leaf
+#pragma unroll
+  for (int i = 0; i < kLeaves; ++i) {
+    const int v = a.xt[a.scope[leaf_ids[i]] * static_cast<int64_t>(a.B) + bl];
+    const int c = v < 0 ? a.C : min(v, a.C - 1);  // negative = marginalised -> integral row C
+    row[i] = static_cast<int64_t>(fold0[i]) * (a.C + 1) + c;
+  }
+  WRegs wcur, wnxt;
+  load_w<LAYOUT>(w_ptr(1, 0), lane, wcur);  // first step: level 1 after leaf 1
+  float stack[D][16], sstack[D];
+  float cur[16], nxt[16], cs, ns;
+  tile_load(a.table + row[0] * kK + 4 * kh, nxt);
+  ns = a.scale[row[0]];
+
+#pragma unroll
+  for (int i = 0; i < kLeaves; ++i) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] = nxt[j];
+    cs = ns;
+    if (i + 1 < kLeaves) {  // the next leaf's gather is in flight while this one is consumed
+      tile_load(a.table + row[i + 1] * kK + 4 * kh, nxt);
+      ns = a.scale[row[i + 1]];
+    }
+#pragma unroll
+    for (int l = 0; l < D; ++l) {
+      if (((i >> l) & 1) == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) stack[l][j] = cur[j];
+        sstack[l] = cs;
+        break;
+      }
+      int ni = 0, nl = 0;
+      const bool more = next_step<D, false>(i, l, ni, nl);
+      if (more) load_w<LAYOUT>(w_ptr(ni, nl), lane, wnxt);
+      float p[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) p[j] = cur[j] * stack[l][j];
+      float mx = p[0];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) mx = fmaxf(mx, p[j]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      cs += sstack[l];
+      if (__builtin_expect(__any(!(mx > 1e-30f)), 0)) {
+        // rare: products at the edge of the fp32 range -> this step in log space (semiring.py:383-408)
+        float m2 = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          p[j] = __logf(cur[j]) + __logf(stack[l][j]);
+          m2 = fmaxf(m2, p[j]);
+        }
+        m2 = ck::clamp_finite(fmaxf(m2, __shfl_xor(m2, 32, 64)));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cur[j] = __expf(p[j] - m2);
+        cs += m2;
+      } else {
+        const float inv = 1.f / mx;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cur[j] = p[j] * inv;
+        cs += __logf(mx);
+      }
+      contract_linear<LAYOUT>(wcur, cur);
+      if (more) wcur = wnxt;
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] = fmaf(__builtin_amdgcn_logf(cur[j]), kLN2, cs);
+    tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
+  }
+}
+
+template <int LAYOUT>
+hipError_t launch_linear(const SubtreeArgs& a, int depth, dim3 grid, hipStream_t s) {
+  switch (depth) {
+    case 1:
+      hipLaunchKernelGGL((subtree_linear_kernel<1, LAYOUT>), grid, dim3(256), 0, s, a);
+      break;
+    case 2:
+      hipLaunchKernelGGL((subtree_linear_kernel<2, LAYOUT>), grid, dim3(256), 0, s, a);
+      break;
+    case 3:
+      hipLaunchKernelGGL((subtree_linear_kernel<3, LAYOUT>), grid, dim3(256), 0, s, a);
+      break;
+    default:
+      hipLaunchKernelGGL((subtree_linear_kernel<4, LAYOUT>), grid, dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
 
-int ck_subtree_cat_cpt_fwd(const float* table, const int32_t* xt, const int64_t* scope,
+int ck_subtree_cat_cpt_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
                            const float* w_dense, const float* const* w_levels,
                            const int32_t* nodes, const int32_t* node_off, int leaf_off, float* out,
                            int depth, int F_root, int B, int K, int C, int w_layout, void* stream) {
+  CK_REQUIRE(table_scale == nullptr || (w_dense == nullptr && depth >= 1),
+             "ck_subtree_cat_cpt_fwd: a linear table needs depth >= 1 and no in-kernel dense layer");
   CK_REQUIRE(table && xt && scope && nodes && node_off && out, "ck_subtree_cat_cpt_fwd: null pointer");
   CK_REQUIRE(depth >= 0 && depth <= kMaxDepth, "ck_subtree_cat_cpt_fwd: depth %d outside [0, %d]", depth, kMaxDepth);
   CK_REQUIRE(depth == 0 || w_levels != nullptr, "ck_subtree_cat_cpt_fwd: w_levels is null");
@@ -218,6 +342,7 @@ int ck_subtree_cat_cpt_fwd(const float* table, const int32_t* xt, const int64_t*
   for (int l = 0; l <= depth; ++l) a.node_off[l] = node_off[l];
   a.leaf_off = leaf_off;
   a.out = out;
+  a.scale = table_scale;
   a.B = B;
   a.C = C;
   a.F_root = F_root;
@@ -228,6 +353,11 @@ int ck_subtree_cat_cpt_fwd(const float* table, const int32_t* xt, const int64_t*
   const bool has_dense = w_dense != nullptr;
   return ck::dispatch(
       [=](hipStream_t s) {
+        if (table_scale != nullptr) {
+          if (w_layout == CK_W_ROWMAJOR) return launch_linear<CK_W_ROWMAJOR>(a, depth, grid, s);
+          if (w_layout == CK_W_TILED_F32) return launch_linear<CK_W_TILED_F32>(a, depth, grid, s);
+          return launch_linear<CK_W_TILED_F16X3>(a, depth, grid, s);
+        }
         if (w_layout == CK_W_ROWMAJOR) return launch_depth<CK_W_ROWMAJOR>(a, depth, has_dense, grid, s);
         if (w_layout == CK_W_TILED_F32) return launch_depth<CK_W_TILED_F32>(a, depth, has_dense, grid, s);
         return launch_depth<CK_W_TILED_F16X3>(a, depth, has_dense, grid, s);

@@ -462,7 +462,16 @@ __device__ __forceinline__ void softmax_job_table_dense(const ck_softmax_job& j,
         const float val = dlt < -103.9f ? -INFINITY : dlt - stat[K + k];
         v[4 * g + tt] = c >= C ? 0.f : val;  // row C: log sum_c p = 0
       }
-    sum_step<CK_W_ROWMAJOR>(wr, v);
+    if (j.kind == 4) {
+      sum_step<CK_W_ROWMAJOR>(wr, v);
+    } else {  // kind 5: the row stays in linear space, y = W . exp(v - m), with its log scale m stored aside
+      const float m = row_max16(v);
+      const float nml = exp_offset(m, 0.f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_exp2f(fmaf(v[r], kL2E, nml));
+      contract_linear<CK_W_ROWMAJOR>(wr, v);
+      if (c <= C && kh == 0) j.out2[static_cast<int64_t>(d) * (C + 1) + c] = m;
+    }
     if (c <= C) tile_store(dst + static_cast<int64_t>(c) * K + 4 * kh, v);
   }
 }
@@ -476,7 +485,7 @@ __global__ void __launch_bounds__(kPW * 64) softmax_batch_kernel(const JobTable 
   const int blk = bid - j.block_begin;
   if (j.kind == 1)
     softmax_job_table(j, blk, tile);
-  else if (j.kind == 4)
+  else if (j.kind == 4 || j.kind == 5)
     softmax_job_table_dense(j, blk, tile);
   else
     softmax_job_rows(j, blk);
@@ -636,16 +645,17 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
     for (int i = 0; i < t.n; ++i) {
       ck_softmax_job j = jobs[start + i];
       CK_REQUIRE(j.in && j.out && j.rows > 0 && j.len > 0, "ck_param_softmax_batch: bad job %d", start + i);
-      CK_REQUIRE(j.kind >= 0 && j.kind <= 4, "ck_param_softmax_batch: job %d has unknown kind %d", start + i, j.kind);
-      CK_REQUIRE(j.kind < 2 || j.kind == 4 || (j.len == 32 && j.rows % 32 == 0),
+      CK_REQUIRE(j.kind >= 0 && j.kind <= 5, "ck_param_softmax_batch: job %d has unknown kind %d", start + i, j.kind);
+      CK_REQUIRE(j.kind < 2 || j.kind >= 4 || (j.len == 32 && j.rows % 32 == 0),
                  "ck_param_softmax_batch: tiled job %d needs len = 32 and rows %% 32 = 0", start + i);
-      CK_REQUIRE(j.kind != 4 || (j.k == 32 && j.in2 != nullptr), "ck_param_softmax_batch: job %d (kind 4) needs k = 32 and in2", start + i);
+      CK_REQUIRE(j.kind < 4 || (j.k == 32 && j.in2 != nullptr), "ck_param_softmax_batch: job %d (kind 4/5) needs k = 32 and in2", start + i);
+      CK_REQUIRE(j.kind != 5 || j.out2 != nullptr, "ck_param_softmax_batch: job %d (kind 5) needs out2", start + i);
       j.block_begin = blocks;
-      if (j.kind != 1 && j.kind != 4) {
+      if (j.kind != 1 && j.kind < 4) {
         blocks += static_cast<int>((j.rows + 16 * kPW - 1) / (16 * kPW));
       } else {
         CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", start + i);
-        const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k + (j.kind == 4 ? 1024 : 0)) * sizeof(float);
+        const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k + (j.kind >= 4 ? 1024 : 0)) * sizeof(float);
         if (need > 64 * 1024)
           return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
         lds = std::max(lds, need);

@@ -130,6 +130,62 @@ __device__ __forceinline__ void sum_step(const WRegs& w, float (&v)[16]) {
   }
 }
 
+// e <- W . e in LINEAR space (e in [0, 1]): the contraction of `sum_step` without the exp before and the
+// log after it.  Used by kernels that carry a value between fused levels as (linear tile, per-row log
+// scale) instead of going through log and exp again (ck_fused.hip).
+template <int LAYOUT>
+__device__ __forceinline__ void contract_linear(const WRegs& w, float (&e)[16]) {
+  if constexpr (LAYOUT != CK_W_TILED_F16X3) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.q[g].x, e[4 * g + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.q[g].y, e[4 * g + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.q[g].z, e[4 * g + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.q[g].w, e[4 * g + 3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = acc[r];
+  } else {
+    union {
+      f16x8 v8[2];
+      uint32_t v2[8];
+    } hi, lo;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const float e0 = e[2 * p] * 2048.f, e1 = e[2 * p + 1] * 2048.f;  // E = 2^11 e, exact
+      const float h0 = __uint_as_float(__float_as_uint(e0) & 0xFFFFE000u);
+      const float h1 = __uint_as_float(__float_as_uint(e1) & 0xFFFFE000u);
+      hi.v2[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+      lo.v2[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(e0 - h0, e1 - h1));
+    }
+    union {
+      float4 f4;
+      f16x8 h8;
+    } a0, a1, a2, a3;
+    a0.f4 = w.q[0];
+    a1.f4 = w.q[1];
+    a2.f4 = w.q[2];
+    a3.f4 = w.q[3];
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = 0.f;
+      acc1[r] = 0.f;
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h8, hi.v8[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2.h8, hi.v8[0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h8, hi.v8[1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3.h8, hi.v8[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h8, lo.v8[0], acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h8, lo.v8[1], acc0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = fmaf(acc1[r], 4.8828125e-4f, acc0[r]) * 2.384185791015625e-07f;  // 2^-22
+  }
+}
+
 // Read one (32 rows x 32 units) tile of a (B, 32) block in register layout, adding it to v.
 __device__ __forceinline__ void tile_load_add(const float* __restrict__ src_row, float (&v)[16]) {
 #pragma unroll

@@ -81,27 +81,29 @@ class ParamBatch:
         (F, 32, 32) result in the MFMA-tiled fp32 / split-fp16 layout of ck_tile.h instead."""
         rows = src.numel() // src.shape[-1]
         kind = {0: 0, 1: 2, 2: 3}[layout]
-        self._jobs.append((src.data_ptr(), dst.data_ptr(), rows, int(src.shape[-1]), 0, kind, None, None))
+        self._jobs.append((src.data_ptr(), dst.data_ptr(), rows, int(src.shape[-1]), 0, kind, None, None, None))
         self._keep += [src, dst]
         self._arr = None
 
     def add_log_table(self, src: torch.Tensor, dst: torch.Tensor) -> None:
         """src (F, K, C) logits -> dst (F, C+1, K) = log softmax over C, transposed; row C = 0."""
         F, K, Cc = src.shape
-        self._jobs.append((src.data_ptr(), dst.data_ptr(), int(F), int(Cc), int(K), 1, None, None))
+        self._jobs.append((src.data_ptr(), dst.data_ptr(), int(F), int(Cc), int(K), 1, None, None, None))
         self._keep += [src, dst]
         self._arr = None
 
     def add_log_table_dense(self, src: torch.Tensor, dense_src: torch.Tensor, idx: torch.Tensor | None,
-                            dst: torch.Tensor) -> None:
+                            dst: torch.Tensor, scale: torch.Tensor | None = None) -> None:
         """dst (Fd, C+1, 32) = the log-table of categorical fold idx[d] (src (F, 32, C) logits) pushed
-        through dense fold d (dense_src (Fd, 32, 32) logits, softmax over the last axis)."""
+        through dense fold d (dense_src (Fd, 32, 32) logits, softmax over the last axis).  With
+        `scale` (Fd, C+1) the rows are left in linear space and their log scales go to `scale`."""
         F, K, Cc = src.shape
         if K != 32 or tuple(dense_src.shape[1:]) != (32, 32) or tuple(dst.shape) != (dense_src.shape[0], Cc + 1, 32):
             raise ValueError("add_log_table_dense needs K = 32 and matching shapes")
-        self._jobs.append((src.data_ptr(), dst.data_ptr(), int(dense_src.shape[0]), int(Cc), 32, 4,
-                           dense_src.data_ptr(), None if idx is None else idx.data_ptr()))
-        self._keep += [src, dense_src, dst] + ([] if idx is None else [idx])
+        self._jobs.append((src.data_ptr(), dst.data_ptr(), int(dense_src.shape[0]), int(Cc), 32, 4 if scale is None else 5,
+                           dense_src.data_ptr(), None if idx is None else idx.data_ptr(),
+                           None if scale is None else scale.data_ptr()))
+        self._keep += [src, dense_src, dst] + ([] if idx is None else [idx]) + ([] if scale is None else [scale])
         self._arr = None
 
     def __len__(self) -> int:
@@ -112,9 +114,9 @@ class ParamBatch:
             return
         if self._arr is None:
             self._arr = (capi.SoftmaxJob * len(self._jobs))()
-            for a, (i, o, rows, ln, k, kind, in2, idx) in zip(self._arr, self._jobs):
+            for a, (i, o, rows, ln, k, kind, in2, idx, out2) in zip(self._arr, self._jobs):
                 a.inp, a.out, a.rows, a.len, a.k, a.kind, a.block_begin = i, o, rows, ln, k, kind, 0
-                a.in2, a.idx = in2, idx
+                a.in2, a.idx, a.out2 = in2, idx, out2
         capi.call("ck_param_softmax_batch", self._arr, len(self._jobs), stream)
 
 

@@ -188,8 +188,13 @@ int ck_tensordot_lse_fwd_c(const float* arena_c, const int64_t* row_off, const f
  *   nodes: DEVICE int32 tables; node_off: HOST array of depth+1 offsets into `nodes`:
  *          nodes+node_off[l] is (F_root, 2^(depth-l)) = fold (in level l's layer) of every node of
  *          the subtree of each root fold, left to right (level 0 = dense layer, or input layer);
- *   leaf_off: offset of the (F_root, 2^depth) table of input-layer folds of the leaves. */
-int ck_subtree_cat_cpt_fwd(const float* table, const int32_t* xt, const int64_t* scope,
+ *   leaf_off: offset of the (F_root, 2^depth) table of input-layer folds of the leaves;
+ *   table_scale: NULL, or (F0, C+1) log scales when `table` holds its rows in LINEAR space (value =
+ *          log(row) + scale; written by the kind-5 job of ck_param_softmax_batch).  The levels are then
+ *          chained in linear space -- p = y_l y_r, e = p / max p, y = W e, one log per row for the
+ *          scale -- instead of log followed by exp; mathematically the same sums (needs depth >= 1 and
+ *          w_dense = NULL). */
+int ck_subtree_cat_cpt_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
                            const float* w_dense, const float* const* w_levels,
                            const int32_t* nodes, const int32_t* node_off, int leaf_off, float* out,
                            int depth, int F_root, int B, int K, int C, int w_layout, void* stream);
@@ -223,6 +228,8 @@ int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_
  * dense folds d, out[d] (C+1, 32) = log(softmax(in2[d]) . exp(T - m)) + m row by row, with T the kind-1
  * table of categorical fold idx[d] (a Categorical layer followed fold by fold by a dense layer only
  * takes C distinct values per fold, so the dense layer is evaluated on the table instead of on the batch).
+ * kind 5: as kind 4 but every row is left in LINEAR space, out[d, c, :] = softmax(in2[d]) . exp(T[c] - m_c),
+ * with its log scale m_c in out2[d, c] (the representation ck_subtree_cat_cpt_fwd takes with table_scale).
  * block_begin is ignored on input. */
 typedef struct ck_softmax_job {
   const float* in;
@@ -233,7 +240,8 @@ typedef struct ck_softmax_job {
   int32_t kind;
   int32_t block_begin;
   const float* in2;   /* kind 4: (rows, 32, 32) logits of the dense layer */
-  const int64_t* idx; /* kind 4: categorical fold of each dense fold, or NULL for the identity */
+  const int64_t* idx; /* kind 4/5: categorical fold of each dense fold, or NULL for the identity */
+  float* out2;        /* kind 5: (rows, C+1) log scale of each table row */
 } ck_softmax_job;
 int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream);
 /* entrywise ops (nodes.py:656-699); a, b only used by CK_UNARY_SCALED_SIGMOID (vmin, vmax). */

@@ -259,14 +259,70 @@ def test_dense_on_table_is_bit_identical(hip_device):
     plan, tensors, g = load_case("cfg2_qt784")
     x = _x_of(plan, g).to(hip_device)
     for contraction in ("f32", "f16x3"):
-        a = HipCircuit(plan, tensors, device=hip_device, use_graph=False, contraction=contraction, dense_on_table=True)
-        b = HipCircuit(plan, tensors, device=hip_device, use_graph=False, contraction=contraction, dense_on_table=False)
+        a = HipCircuit(plan, tensors, device=hip_device, use_graph=False, contraction=contraction, dense_on_table=True,
+                       linear_levels=False)
+        b = HipCircuit(plan, tensors, device=hip_device, use_graph=False, contraction=contraction, dense_on_table=False,
+                       linear_levels=False)
         ya, yb = a(x).clone(), b(x).clone()
         torch.cuda.synchronize()
         assert torch.equal(ya, yb), float((ya - yb).abs().max())
         oa, ob = a.layer_outputs(x), b.layer_outputs(x)
         torch.cuda.synchronize()
         assert torch.equal(oa[5], ob[5])
+
+
+@pytest.mark.parametrize("contraction", ["f32", "f16x3"])
+def test_linear_levels_agree_with_log_space_levels(hip_device, contraction):
+    """Chaining the fused levels in linear space (value = linear tile x per-row scale) computes the same
+    sums as log -> exp between the levels: both within the 1e-4 bar of the reference's fp64 output, and
+    the linear chain -- which skips a log / exp round trip per level -- at least as close to it."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    x = _x_of(plan, g).to(hip_device)
+    ref = torch.from_numpy(g["y_f64"])
+    lin = HipCircuit(plan, tensors, device=hip_device, contraction=contraction, linear_levels=True)
+    log = HipCircuit(plan, tensors, device=hip_device, contraction=contraction, linear_levels=False)
+    ya, yb = lin(x).cpu().double(), log(x).cpu().double()
+    assert lin.kernel_label(lin._groups[0].root).startswith("subtree_linear_kernel")
+    assert log.kernel_label(log._groups[0].root).startswith("subtree_cat_cpt_kernel")
+    ea, eb = float(((ya - ref) / ref).abs().max()), float(((yb - ref) / ref).abs().max())
+    assert ea <= REL and eb <= REL
+    assert ea <= 2.0 * eb + 1e-7, (ea, eb)
+    # marginalised variables take the integral row of the linear table as well
+    mask = torch.zeros(x.shape, dtype=torch.bool)
+    mask[:, ::3] = True
+    ma, mb = lin(x, integrate_vars=mask).cpu(), log(x, integrate_vars=mask).cpu()
+    assert torch.allclose(ma, mb, rtol=1e-5, atol=1e-4)
+
+
+def test_linear_levels_survive_products_at_the_edge_of_fp32(hip_device):
+    """Children whose large units do not overlap: every product of a row underflows fp32 in linear space,
+    the step is redone in log space (ck_fused.hip)."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import InputSpec, quad_tree_plan
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan = quad_tree_plan((1, 4, 4), input_layer=InputSpec("categorical", 8), sum_product="cp", num_input_units=32, num_sum_units=32)
+    tensors = init_plan_tensors(plan, seed=2)
+    # mixture components 0..15 put their mass on category 0, components 16..31 on category 1 (logit gap 80),
+    # and the dense layer keeps the two halves apart (gap 80): for sibling pixels (0, 1) every unit of one
+    # child is ~1 where the other is ~e^-80, so all 32 products are ~2e-35 -- below what the linear chain
+    # accepts -- while the log-space value is perfectly finite
+    half = (np.arange(32) < 16)
+    t0 = np.full(tensors["t0"].shape, -80.0, dtype=np.float32)
+    t0[:, half, 0] = 0.0
+    t0[:, ~half, 1] = 0.0
+    t1 = np.where(half[:, None] == half[None, :], 0.0, -80.0).astype(np.float32)
+    tensors = {**tensors, "t0": t0, "t1": np.broadcast_to(t1, tensors["t1"].shape).copy()}
+    x = torch.randint(0, 3, (64, 16), generator=torch.Generator().manual_seed(1))
+    hc = HipCircuit(plan, tensors, device=hip_device)
+    y = hc(x.to(hip_device)).cpu()
+    assert hc._groups and hc._table_fused and hc.kernel_label(hc._groups[0].root).startswith("subtree_linear_kernel")
+    ref = evaluate_plan(plan, as_torch(tensors), x)
+    assert torch.isfinite(ref).all() and float(ref.min()) < -150.0
+    assert torch.allclose(y, ref, rtol=1e-4, atol=1e-3), float((y - ref).abs().max())
 
 
 def test_ll_sum(hip_device):
