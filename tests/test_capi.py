@@ -47,7 +47,7 @@ def test_invalid_arguments_return_status_and_message():
     with pytest.raises(NotImplementedError):  # CK_ERR_UNSUPPORTED
         wl = (C.c_void_p * 1)(p)
         no = (C.c_int32 * 2)(0, 0)
-        capi.call("ck_subtree_cat_cpt_fwd", p, p, p, p, wl, p, no, 0, p, 1, 1, 32, 64, 4, 0, None)
+        capi.call("ck_subtree_cat_cpt_fwd", p, None, p, p, p, wl, p, no, 0, p, 1, 1, 32, 64, 4, 0, None)
     st = lib.ck_sum_lse_fwd(p, p, p, p, 1, 2, 4, 16, 16, 0, 1, None)  # tiled layout needs K = 32
     assert st == -1 and b"tiled" in lib.ck_last_error()
 
