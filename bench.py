@@ -254,24 +254,26 @@ def main() -> None:
             t3 = torch.tensor([w3], dtype=torch.float64, device=device)
             dist.all_reduce(t3, op=dist.ReduceOp.MAX)
             w3 = float(t3.item())
-        # Two forwards in flight: the small latency-bound kernels of one step (parameter prologue, fused
-        # tail) fill the bubbles of the other step's leaf kernel.  Two circuits (own arenas and derived
-        # parameters, shared raw parameters), steps alternate between two HIP streams.
-        pair_c = [circuit, HipCircuit(plan, circuit.store, device=device, use_graph=not args.no_graph, fuse=fuse)]
-        streams2 = [stream, torch.cuda.Stream(device)]
-        for c, st in zip(pair_c, streams2):
-            with torch.cuda.stream(st):
-                for _ in range(max(args.warmup, 2)):
-                    c.log_likelihood_sum(x)
+        # Two forwards in flight (cirkit_amd.circuit.HipCircuitStreams): the small latency-bound kernels of
+        # one step (parameter prologue, fused tail) fill the bubbles of the other step's leaf kernel.
+        from cirkit_amd.circuit import HipCircuitStreams
+
+        pool = HipCircuitStreams(plan, circuit.store, n=2, device=device, wait_for_input=False,
+                                 use_graph=not args.no_graph, fuse=fuse)  # x is resident
+        with torch.cuda.stream(stream):
+            for _ in range(max(args.warmup, 4)):
+                pool.log_likelihood_sum(x)
+        pool.synchronize()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            with torch.cuda.stream(streams2[i % 2]):
-                ll = pair_c[i % 2].log_likelihood_sum(x)
+        with torch.cuda.stream(stream):
+            for _ in range(args.steps):
+                ll, st = pool.log_likelihood_sum(x)
                 if world > 1:
-                    dist.all_reduce(ll, op=dist.ReduceOp.SUM)
+                    with torch.cuda.stream(st):
+                        dist.all_reduce(ll, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -280,13 +282,13 @@ def main() -> None:
             t4 = torch.tensor([w4], dtype=torch.float64, device=device)
             dist.all_reduce(t4, op=dist.ReduceOp.MAX)
             w4 = float(t4.item())
+        del pool
         variants["streams=2"] = {
-            "what": "steps issued alternately on two HIP streams (two circuits sharing the raw parameters): "
-                    "consecutive forwards overlap on the device; per-step latency is unchanged",
+            "what": "steps issued alternately on two HIP streams (HipCircuitStreams: two circuits sharing the raw "
+                    "parameters): consecutive forwards overlap on the device; per-step latency is unchanged",
             "value": world * B * args.steps / w4,
             "ms_per_step": 1e3 * w4 / args.steps,
         }
-        del pair_c
         variants["cache_params=True"] = {
             "what": "parameter graphs evaluated once and reused while the parameters do not change "
                     "(the reference, and `value`, recompute them inside every step)",

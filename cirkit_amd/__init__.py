@@ -2,7 +2,7 @@
 
 from .plan import Plan, plan_from_torch_circuit  # noqa: F401
 
-__all__ = ["Plan", "plan_from_torch_circuit", "HipCircuit", "compile"]
+__all__ = ["Plan", "plan_from_torch_circuit", "HipCircuit", "HipCircuitStreams", "compile"]
 
 
 def __getattr__(name):  # lazy: importing the package must not require torch/ROCm
@@ -10,6 +10,10 @@ def __getattr__(name):  # lazy: importing the package must not require torch/ROC
         from .circuit import HipCircuit
 
         return HipCircuit
+    if name == "HipCircuitStreams":
+        from .circuit import HipCircuitStreams
+
+        return HipCircuitStreams
     if name == "compile":
         from .pipeline import compile
 

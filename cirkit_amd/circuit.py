@@ -898,3 +898,57 @@ class HipCircuit:
 
     def num_launches(self, B: int) -> int:
         return int(capi.load().ck_program_num_ops(self._bind(B).program))
+
+
+class HipCircuitStreams:
+    """Several forwards in flight: `n` circuits over the SAME parameter store (own activation arenas
+    and derived parameters), calls dealt round-robin to `n` HIP streams.
+
+    A forward of a small circuit is a short chain of kernels of which only one fills the GPU (at
+    BASELINE config 2: 98 of 171 us); the parameter prologue and the few-fold tail are latency-bound.
+    With two forwards in flight those fill each other's bubbles: 31 M instead of 24 M evaluations/s at
+    config 2 (`bench.py`, `variants["streams=2"]`).  Per-call latency is unchanged, and every result is
+    the complete forward of its own batch.
+
+    `forward` / `log_likelihood_sum` return the result together with the stream it is being computed on;
+    consume it on that stream or after `synchronize()`."""
+
+    def __init__(self, plan: Plan, tensors, *, n: int = 2, device: str | torch.device = "cuda:0",
+                 wait_for_input: bool = True, **kwargs) -> None:
+        """`wait_for_input`: make the chosen stream wait for the work already queued on the caller's current
+        stream (where `x` is presumably produced).  An event record + wait per call costs a few microseconds;
+        pass False when the inputs are known to be ready (e.g. resident batches)."""
+        if n < 1:
+            raise ValueError("n must be at least 1")
+        self.wait_for_input = bool(wait_for_input)
+        first = HipCircuit(plan, tensors, device=device, **kwargs)
+        self.circuits = [first] + [HipCircuit(plan, first.store, device=device, **kwargs) for _ in range(n - 1)]
+        self.streams = [torch.cuda.Stream(first.device) for _ in range(n)]
+        self.device = first.device
+        self.store = first.store
+        self._next = 0
+
+    def _take(self):
+        i = self._next
+        self._next = (i + 1) % len(self.circuits)
+        return self.circuits[i], self.streams[i]
+
+    def forward(self, x: torch.Tensor | None = None, *, integrate_vars=None):
+        c, st = self._take()
+        if self.wait_for_input:
+            st.wait_stream(torch.cuda.current_stream(self.device))  # x may still be in production
+        with torch.cuda.stream(st):
+            return c.forward(x, integrate_vars=integrate_vars), st
+
+    __call__ = forward
+
+    def log_likelihood_sum(self, x: torch.Tensor):
+        c, st = self._take()
+        if self.wait_for_input:
+            st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st):
+            return c.log_likelihood_sum(x), st
+
+    def synchronize(self) -> None:
+        for st in self.streams:
+            st.synchronize()

@@ -420,3 +420,24 @@ def test_cached_parameters_are_refreshed_when_values_change(hip_device):
     assert torch.equal(hc(x), y1)
     hc.invalidate_parameters()
     assert torch.equal(hc(x), ref(x))
+
+
+def test_forwards_in_flight_on_two_streams(hip_device):
+    """HipCircuitStreams: results of interleaved forwards on two streams equal the single-stream ones."""
+    from cirkit_amd import HipCircuit, HipCircuitStreams
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    x = _x_of(plan, g).to(hip_device)
+    ref = HipCircuit(plan, tensors, device=hip_device)(x).clone()
+    pool = HipCircuitStreams(plan, tensors, n=2, device=hip_device)
+    outs = []
+    for i in range(6):
+        y, st = pool(x[: 64 - i])
+        with torch.cuda.stream(st):
+            outs.append(y.clone())
+    pool.synchronize()
+    for i, y in enumerate(outs):
+        assert torch.equal(y, ref[: 64 - i])
+    s, st = pool.log_likelihood_sum(x)
+    pool.synchronize()
+    assert abs(float(s[0]) - float(ref.double().sum())) <= 1e-6 * abs(float(ref.double().sum()))
