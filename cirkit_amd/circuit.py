@@ -730,6 +730,11 @@ class HipCircuit:
         if (not self._complex and s.type == "sum" and l.arity > 1 and l.num_input_units == l.num_output_units
                 and l.num_input_units in (32, 64)):
             return f"cat_lse_kernel<{l.num_input_units // 32}, 8>"
+        if not self._complex and s.type in ("sum", "cpt") and not getattr(l, "_mixing", False):
+            cat = s.type == "sum" and l.arity > 1
+            n = l.num_input_units * (l.arity if cat else 1)
+            if l.num_input_units % 32 == 0 and l.num_output_units % 32 == 0 and 32 <= n <= 256:
+                return f"sum_lse_gemm_kernel<{n // 32}, {'true' if cat else 'false'}>"
         return "sum_lse_generic"
 
     def profile_kernels(self, x: torch.Tensor | None, iters: int = 10) -> list[dict]:

@@ -656,7 +656,7 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
       } else {
         CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", start + i);
         const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k + (j.kind >= 4 ? 1024 : 0)) * sizeof(float);
-        if (need > 64 * 1024)
+        if (need > 160 * 1024)
           return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
         lds = std::max(lds, need);
         blocks += static_cast<int>(j.rows);

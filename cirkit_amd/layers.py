@@ -216,6 +216,8 @@ class HipCategoricalLayer(HipInputLayer):
         if src is None:
             return False
         F, K, C = src.shape
+        if (K * (C + 1) + 2 * K) * 4 > 160 * 1024:  # the table job keeps one fold's (K, C) block in LDS
+            return False  # -> per-node kernels in `prepare`
         self._table = torch.empty((F, C + 1, K), dtype=torch.float32, device=src.device)  # row C: integral row
         batch.add_log_table(src, self._table)
         self._batched = True

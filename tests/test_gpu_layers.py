@@ -45,7 +45,9 @@ def _close(a, b, tol=2e-5):
 
 @pytest.mark.parametrize("F,H,B,Ki,Ko", [(3, 1, 37, 32, 32), (2, 1, 5, 64, 64), (4, 1, 9, 7, 5), (2, 3, 33, 6, 4),
                                          (1, 11, 17, 64, 64), (5, 1, 1, 1, 1), (2, 2, 70, 40, 96), (1, 1, 3, 300, 2),
-                                         (3, 2, 300, 32, 32), (2, 3, 65, 64, 64), (2, 1, 257, 64, 64)])
+                                         (3, 2, 300, 32, 32), (2, 3, 65, 64, 64), (2, 1, 257, 64, 64),
+                                         (2, 1, 130, 128, 128), (1, 1, 40, 256, 96), (2, 2, 33, 64, 32), (1, 1, 9, 32, 160),
+                                         (2, 4, 70, 64, 128)])
 def test_sum_layer_contract(hip_device, F, H, B, Ki, Ko):
     from cirkit_amd.layers import HipSumLayer
     from cirkit_amd.parameters import TensorStore
@@ -61,7 +63,8 @@ def test_sum_layer_contract(hip_device, F, H, B, Ki, Ko):
 
 
 @pytest.mark.parametrize("F,H,B,Ki,Ko", [(3, 2, 37, 32, 32), (2, 2, 64, 64, 64), (2, 3, 10, 32, 32), (4, 2, 9, 12, 1),
-                                         (1, 2, 130, 32, 1), (2, 4, 3, 5, 7)])
+                                         (1, 2, 130, 32, 1), (2, 4, 3, 5, 7), (2, 2, 100, 128, 128), (1, 3, 37, 256, 256),
+                                         (2, 2, 64, 96, 224), (1, 2, 5, 32, 64)])
 def test_cpt_layer_contract(hip_device, F, H, B, Ki, Ko):
     from cirkit_amd.layers import HipCPTLayer
     from cirkit_amd.parameters import TensorStore
