@@ -441,3 +441,40 @@ def test_forwards_in_flight_on_two_streams(hip_device):
     s, st = pool.log_likelihood_sum(x)
     pool.synchronize()
     assert abs(float(s[0]) - float(ref.double().sum())) <= 1e-6 * abs(float(ref.double().sum()))
+
+
+@pytest.mark.parametrize("rg,shape,sp,K,inp,B", [
+    ("poon-domingos", (1, 8, 8), "cp", 32, "gaussian", 37),      # region_lse_kernel<1>, cp blocks, gaussian products
+    ("poon-domingos", (1, 8, 8), "cp", 64, "categorical", 130),  # region_lse_kernel<2>, leftovers, subsets
+    ("poon-domingos", (2, 8, 8), "cp", 64, "gaussian", 33),      # two channels: factorised inputs
+    ("quad-graph", (1, 8, 8), "cp", 32, "categorical", 70),
+    ("quad-graph", (1, 7, 9), "cp", 64, "gaussian", 65),
+    ("quad-graph", (1, 8, 8), "cp-t", 64, "categorical", 40),    # mixing layers without CP blocks
+    ("quad-tree-2", (1, 8, 8), "cp", 64, "categorical", 96),     # K = 64 dense / CP-T on the tile kernels
+    ("quad-tree-2", (1, 8, 8), "cp", 128, "categorical", 50),    # sum_lse_gemm_kernel
+    ("quad-tree-4", (1, 8, 8), "cp-t", 96, "gaussian", 35),      # arity-4 CP-T, 96 units
+    ("random-binary-tree", (1, 5, 5), "cp", 32, "categorical", 64),
+])
+@pytest.mark.parametrize("use_mixing", [True, False])
+def test_template_circuits_on_the_mfma_kernels(hip_device, rg, shape, sp, K, inp, B, use_mixing):
+    """Region-graph templates at unit counts that take the MFMA kernels (32, 64, 96, 128) -- the committed
+    reference plans of these shapes use 2-4 units and only reach the shape-generic kernels -- against the
+    oracle, layer by layer where the layer is materialised."""
+    from cirkit_amd import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+
+    if not use_mixing and rg in ("quad-tree-2", "quad-tree-4", "random-binary-tree"):
+        pytest.skip("no regions with several partitionings")
+    plan = image_data(shape, rg, input_layer=inp, num_input_units=K, sum_product_layer=sp, num_sum_units=K,
+                      use_mixing_weights=use_mixing)
+    tensors = init_plan_tensors(plan, seed=5)
+    x = _random_batch(plan, B, seed=17)
+    if inp == "categorical":
+        x = torch.randint(0, 256, x.shape, generator=torch.Generator().manual_seed(3))
+    hc = HipCircuit(plan, tensors, device=hip_device)
+    y_ref = _check_layers(plan, tensors, x, hc)
+    y = hc(x.to(hip_device)).cpu()
+    assert torch.allclose(y, y_ref, rtol=REL, atol=1e-4), float((y - y_ref).abs().max())
+    y2 = HipCircuit(plan, tensors, device=hip_device, fuse=False)(x.to(hip_device)).cpu()
+    assert torch.allclose(y2, y_ref, rtol=REL, atol=1e-4)
