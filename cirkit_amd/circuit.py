@@ -215,6 +215,8 @@ class HipCircuit:
             for d in np.unique(b.slot_dense[..., 0]):
                 if d >= 0:
                     layout[int(d)] = capi.CK_W_ROWMAJOR
+            if b.post:
+                layout[b.layer] = capi.CK_W_ROWMAJOR
         for i, l in enumerate(self.layers):
             if hasattr(l, "_w_layout"):
                 l._w_layout = layout[i]
@@ -430,19 +432,28 @@ class HipCircuit:
                 addr = self._weight_addresses(blk.slot_dense, K)
                 tab = bd.cp_tabs[i] = torch.from_numpy(np.ascontiguousarray(addr if sub is None else addr[sub])).to(self.device)
             F, S = blk.slot_dense.shape[:2]
+            post = None
+            if blk.post:  # the CP-T layer's own weights, one matrix per evaluated fold
+                post = bd.cp_tabs.get((i, "post"))
+                if post is None:
+                    folds = np.arange(F, dtype=np.int64) if sub is None else sub.astype(np.int64)
+                    if l._w.is_complex() or not l._w.is_contiguous():
+                        raise ValueError("CP blocks need real, contiguous fp32 weights")
+                    post = bd.cp_tabs[(i, "post")] = torch.from_numpy(l._w.data_ptr() + folds * (K * K * 4)).to(self.device)
+            pp = None if post is None else post.data_ptr()
             if sub is None:
-                capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), None,
+                capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), pp, None,
                           bd.views[i].data_ptr(), F, S, 1, bd.B, K, stream)
             else:
                 ro, oo = bd.leftover[i]
-                capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), oo.data_ptr(),
+                capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), pp, oo.data_ptr(),
                           bd.arena.data_ptr(), len(sub), S, 1, bd.B, K, stream)
             return
         folds = self._cp_leftover[i]
         ro, oo = bd.leftover[i]
         if tab is None:
             tab = bd.cp_tabs[i] = torch.from_numpy(l._w.data_ptr() + folds.astype(np.int64) * (K * K * 4)).to(self.device)
-        capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), oo.data_ptr(),
+        capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), None, oo.data_ptr(),
                   bd.arena.data_ptr(), len(folds), 1, 1, bd.B, K, stream)
 
     def _launch_param_batch(self, stream: int) -> None:

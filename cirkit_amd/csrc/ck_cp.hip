@@ -30,7 +30,8 @@ template <int NK, int WAVES, bool MULTI>
 __global__ void __launch_bounds__(WAVES * 64)
     cp_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                   const int64_t* __restrict__ w_addr, const float* __restrict__ w_base,
-                  const int64_t* __restrict__ out_off, float* __restrict__ out, int S, int H, int B) {
+                  const int64_t* __restrict__ w_post, const int64_t* __restrict__ out_off,
+                  float* __restrict__ out, int S, int H, int B) {
   constexpr int K = 32 * NK;
   constexpr int WF4 = K * K / 4;  // float4 elements of one weight matrix
   // [buffer][p][q][g][lane] float4: the A operand of MFMA step (p, q, 4g .. 4g+3) for every lane
@@ -58,6 +59,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
   };
 
+  // a CP-T consumer: its own dense sum is applied to the product of the slots (step `nslots` of the pipeline)
+  const float* w_last = w_post != nullptr ? reinterpret_cast<const float*>(static_cast<uintptr_t>(w_post[f])) : nullptr;
   float o[NK][16];
   const float* w_cur = weights_of(0);
   if (w_cur != nullptr) stage(w_cur, 0);
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
     // The next slot's weights land in the other buffer while this slot computes.  That buffer was
     // last read by slot s - 1, which slower waves may still be in: fence first (never taken for S <= 2).
-    const float* w_next = MULTI && s + 1 < nslots ? weights_of(s + 1) : nullptr;
+    const float* w_next = MULTI && s + 1 < nslots ? weights_of(s + 1) : (s + 1 == nslots ? w_last : nullptr);
     if (w_next != nullptr) {
       if (s >= 1) __syncthreads();
       stage(w_next, (s + 1) & 1);
@@ -135,6 +138,41 @@ __global__ void __launch_bounds__(WAVES * 64)
         for (int j = 0; j < 16; ++j) o[q][j] = (!MULTI || s == 0) ? v[q][j] : o[q][j] + v[q][j];
     }
     w_cur = w_next;
+  }
+  if (w_last != nullptr) {  // out = log(W_post . exp(P - max P)) + max P on the register tile P = o
+    float m = o[0][0];
+#pragma unroll
+    for (int q = 0; q < NK; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) m = fmaxf(m, o[q][j]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = ck::clamp_finite(m);
+    const float nml = exp_offset(m, 0.f);
+    float e[NK][16];
+#pragma unroll
+    for (int q = 0; q < NK; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) e[q][j] = __builtin_amdgcn_exp2f(fmaf(o[q][j], kL2E, nml));
+    __syncthreads();  // W_post is staged (during the last slot)
+    const float* wb = &w_s[nslots & 1][0];
+#pragma unroll
+    for (int p = 0; p < NK; ++p) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NK; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wb + ((((p * NK + q) * 4 + g) * 64) + lane) * 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, e[q][4 * g + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, e[q][4 * g + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, e[q][4 * g + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, e[q][4 * g + 3], acc, 0, 0, 0);
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[p][r] = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m);
+    }
   }
   if (live) {
     float* dst = out + (out_off != nullptr ? out_off[f] : static_cast<int64_t>(f) * B * K) + static_cast<int64_t>(b) * K + 4 * kh;
@@ -403,15 +441,15 @@ __global__ void __launch_bounds__(WAVES * 64)
 
 template <int NK>
 int launch_cp(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* w_base,
-              const int64_t* out_off, float* out, int F, int S, int H, int B, void* stream) {
+              const int64_t* w_post, const int64_t* out_off, float* out, int F, int S, int H, int B, void* stream) {
   const int tiles = (B + 31) / 32;
   return ck::dispatch(
       [=](hipStream_t s) {
         auto go = [&](auto kern, int waves) {
           dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
-          hipLaunchKernelGGL(kern, grid, block, 0, s, arena, row_off, w_addr, w_base, out_off, out, S, H, B);
+          hipLaunchKernelGGL(kern, grid, block, 0, s, arena, row_off, w_addr, w_base, w_post, out_off, out, S, H, B);
         };
-        if (S == 1)
+        if (S == 1 && w_post == nullptr)
           go(cp_lse_kernel<NK, 8, false>, 8);
         else
           go(cp_lse_kernel<NK, 8, true>, 8);  // 4 waves per workgroup measured the same on config 4
@@ -443,20 +481,20 @@ int cat_dense(const float* arena, const int64_t* row_off, const float* w, float*
 // K = 64 dense / CP-T layers of ck_sum_lse_fwd (one slot, contiguous (F, K, K) weights).
 int cp_single_slot(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,
                    void* stream) {
-  if (K == 64) return launch_cp<2>(arena, row_off, nullptr, w, nullptr, out, F, 1, H, B, stream);
-  return launch_cp<1>(arena, row_off, nullptr, w, nullptr, out, F, 1, H, B, stream);
+  if (K == 64) return launch_cp<2>(arena, row_off, nullptr, w, nullptr, nullptr, out, F, 1, H, B, stream);
+  return launch_cp<1>(arena, row_off, nullptr, w, nullptr, nullptr, out, F, 1, H, B, stream);
 }
 }  // namespace ck
 
-extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* out_off,
-                             float* out, int F, int S, int H, int B, int K, void* stream) {
+extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* w_post,
+                             const int64_t* out_off, float* out, int F, int S, int H, int B, int K, void* stream) {
   CK_REQUIRE(arena && row_off && w_addr && out, "ck_cp_lse_fwd: null pointer");
   CK_REQUIRE(F > 0 && S > 0 && H > 0 && B > 0, "ck_cp_lse_fwd: non-positive size F=%d S=%d H=%d B=%d", F, S, H, B);
   CK_REQUIRE(K == 32 || K == 64, "ck_cp_lse_fwd: K must be 32 or 64, found %d", K);
   CK_REQUIRE(F <= 65535, "ck_cp_lse_fwd: F=%d exceeds grid.y", F);
   CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(out), "ck_cp_lse_fwd: buffers must be 16-byte aligned");
-  if (K == 64) return launch_cp<2>(arena, row_off, w_addr, nullptr, out_off, out, F, S, H, B, stream);
-  return launch_cp<1>(arena, row_off, w_addr, nullptr, out_off, out, F, S, H, B, stream);
+  if (K == 64) return launch_cp<2>(arena, row_off, w_addr, nullptr, w_post, out_off, out, F, S, H, B, stream);
+  return launch_cp<1>(arena, row_off, w_addr, nullptr, w_post, out_off, out, F, S, H, B, stream);
 }
 
 extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,

@@ -164,14 +164,15 @@ class CPBlock:
     layer: int
     slot_child: np.ndarray  # (F, S, 2)
     slot_dense: np.ndarray  # (F, S, 2), -1 = plain slot
+    post: bool = False  # the consumer is a CP-T layer: its own dense sum follows the product
 
 
 def find_cp_blocks(plan, layers, children, out_pairs, skip: set[int]):
     """Returns (blocks, leftover, virtual).
 
     A fold of a dense layer (arity-1 real sum, K -> K with K in CP_K, not a mixing layer) that is
-    consumed exactly once, by a Hadamard layer with the same K, is evaluated inside that Hadamard's
-    launch and never written to memory.  `leftover[d]` lists the folds of dense layer d that other
+    consumed exactly once, by a Hadamard or CP-T layer with the same K, is evaluated inside that
+    consumer's launch and never written to memory.  `leftover[d]` lists the folds of dense layer d that other
     consumers still need (they are evaluated in place by a launch over that subset); a dense layer
     without leftovers is `virtual` (no activation storage at all)."""
     if plan.semiring != "lse-sum":
@@ -185,8 +186,13 @@ def find_cp_blocks(plan, layers, children, out_pairs, skip: set[int]):
                 and not l.is_complex)
 
     def is_prod(j: int) -> bool:
+        """A Hadamard layer, or a CP-T layer (Hadamard -> dense sum, K -> K) -- both multiply their children."""
         s, l = plan.layers[j], layers[j]
-        return j not in skip and s.type == "hadamard" and l.num_input_units in CP_K and l.arity >= 2
+        if j in skip or l.num_input_units not in CP_K or l.is_complex:
+            return False
+        if s.type == "hadamard":
+            return l.arity >= 2
+        return s.type == "cpt" and l.num_output_units == l.num_input_units
 
     # how often each (layer, fold) is read, and by whom
     uses = [np.zeros(l.num_folds, dtype=np.int64) for l in layers]
@@ -223,7 +229,7 @@ def find_cp_blocks(plan, layers, children, out_pairs, skip: set[int]):
             slot_dense[sel] = np.stack([np.full_like(folds, d), folds], axis=-1)
             slot_child[sel] = children[d][folds, 0]  # the dense fold's own input
         if hit:
-            blocks.append(CPBlock(j, slot_child, slot_dense))
+            blocks.append(CPBlock(j, slot_child, slot_dense, post=plan.layers[j].type == "cpt"))
     leftover = {d: np.nonzero(~m)[0] for d, m in fusable.items() if not m.all()}
     virtual = {d for d, m in fusable.items() if m.all()}
     return blocks, leftover, virtual
@@ -292,7 +298,7 @@ def find_region_blocks(plan, layers, children, out_pairs, cp_blocks: dict[int, C
             continue
         ch = children[j]  # (F, H, 2)
         prods = [int(p) for p in np.unique(ch[..., 0])]
-        if any(p not in cp_blocks for p in prods):
+        if any(p not in cp_blocks or cp_blocks[p].post for p in prods):
             continue
         arities = {cp_blocks[p].slot_child.shape[1] for p in prods}
         if len(arities) != 1:

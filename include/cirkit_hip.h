@@ -142,10 +142,13 @@ int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* m
  *   v_s = sum_h arena[row_off[f,s,h] + b*K + :],  m_s = clamp(max v_s).
  * row_off: (F, S, H) element offsets.  w_addr: (F, S) DEVICE ADDRESSES (as int64) of row-major (K, K)
  * fp32 linear-space weight matrices, 0 for a plain slot; the matrices stay caller-owned.  K in {32, 64}.
+ * w_post: NULL, or (F) device addresses of one more (K, K) matrix per fold applied to the product,
+ *   out = log(W_post . exp(P - max P)) + max P with P = sum_s G_s -- the consumer is then a TorchCPTLayer
+ *   (optimized.py:171-178; Hadamard -> Sum fused by the reference) instead of a bare Hadamard layer.
  * out_off: (F) element offsets of each fold's (B, K) output block inside `out`, or NULL for f*B*K
  * (lets one launch evaluate a subset of the folds of a layer in place). */
-int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* out_off,
-                  float* out, int F, int S, int H, int B, int K, void* stream);
+int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* w_post,
+                  const int64_t* out_off, float* out, int F, int S, int H, int B, int K, void* stream);
 
 /* A region with H partitionings in one launch: the H CP blocks (as in ck_cp_lse_fwd, S slots each)
  * and the mixing layer that combines them (templates/region_graph/graph.py:556-583: `mix_ins` and the
