@@ -24,7 +24,7 @@ import torch
 
 from . import _capi as capi
 from .fusion import (CPBlock, RegionBlock, SubtreeGroup, find_cp_blocks, find_input_products, find_region_blocks,
-                     find_subtree_groups, find_tail)
+                     find_subtree_groups, find_table_dense, find_tail)
 from .layers import HipConstantValueLayer, HipInputLayer, HipLayer, layer_from_spec
 from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
@@ -159,6 +159,23 @@ class HipCircuit:
         self._regions: dict[int, RegionBlock] = {}
         self._input_prod: dict[int, int] = {}  # Hadamard layer -> the Gaussian layer it multiplies (ck_input.hip)
         self._input_prod_dev: dict[int, torch.Tensor] = {}
+        self._tdense: dict[int, int] = {}  # dense layer -> the Categorical layer it is tabulated over
+        self._tdense_dev: dict[int, tuple] = {}  # dense layer -> (T' (F, C+1, 32), scope (F) int64, variables (F) numpy)
+        if fuse is not False and dense_on_table and batch_params:
+            busy = self._virtual | set(self._group_of_root) | set(self._tail)
+            cand = find_table_dense(plan, self.layers, self._children, busy)
+            self._tdense = {d: c for d, c in cand.items()
+                            if self.layers[c].probs is not None and self.layers[c].probs.softmax_source() is not None
+                            and self.layers[d].weight.softmax_source() is not None}
+            readers: dict[int, set[int]] = {}
+            for j, ch in enumerate(self._children):
+                if ch is not None:
+                    for p in np.unique(ch[..., 0]):
+                        readers.setdefault(int(p), set()).add(j)
+            outs = {int(p) for p in self._out_pairs[:, 0]}
+            for c in set(self._tdense.values()):  # a Categorical layer only read through tables is never evaluated
+                if c not in outs and readers.get(c, set()) <= set(self._tdense):
+                    self._virtual.add(c)
         if fuse is not False:
             self._input_prod = find_input_products(
                 plan, self.layers, self._children, self._out_pairs, self._virtual | set(self._group_of_root) | set(self._tail))
@@ -368,6 +385,8 @@ class HipCircuit:
                 continue
             if i in self._group_of_root:
                 self._launch_group(self._group_of_root[i], bd, view, stream)
+            elif i in self._tdense:
+                self._launch_table_dense(i, bd, stream)
             elif i in self._cp_blocks or i in self._cp_leftover:
                 self._launch_cp(i, bd, stream)
             elif i in self._regions:
@@ -381,11 +400,47 @@ class HipCircuit:
             else:
                 l.launch(bd.arena, ro, view, B, stream)
 
+    def _launch_table_dense(self, i: int, bd: _Binding, stream: int) -> None:
+        """A dense layer over a Categorical layer, evaluated as a gather from its per-category table T'
+        (all folds, or only those a consumer outside the CP blocks still reads)."""
+        l = self.layers[i]
+        table, scope, _ = self._tdense_dev[i]
+        Cn = self.layers[self._tdense[i]].num_categories
+        sub = self._cp_leftover.get(i)
+        if sub is None:
+            capi.call("ck_categorical_fwd", table.data_ptr(), bd.xt_i.data_ptr(), scope.data_ptr(), bd.views[i].data_ptr(),
+                      l.num_folds, bd.B, l.num_output_units, Cn, self.plan.num_variables, stream)
+            return
+        for f in sub:  # a handful of folds
+            capi.call("ck_categorical_fwd", table[int(f)].data_ptr(), bd.xt_i.data_ptr(), scope[int(f) : int(f) + 1].data_ptr(),
+                      bd.views[i][int(f)].data_ptr(), 1, bd.B, l.num_output_units, Cn, self.plan.num_variables, stream)
+
+    def _gather_tables(self, slot_dense: np.ndarray, key, bd: _Binding):
+        """(g_addr, g_var, C) device tables for the slots of `slot_dense` whose dense layer is tabulated, or Nones."""
+        if not any(int(d) in self._tdense for d in np.unique(slot_dense[..., 0]) if d >= 0):
+            return None, None, 0
+        tabs = bd.cp_tabs.get((key, "gather"))
+        Cn = 0
+        if tabs is None:
+            addr = np.zeros(slot_dense.shape[:-1], dtype=np.int64)
+            var = np.full(slot_dense.shape[:-1], -1, dtype=np.int32)
+            for d in np.unique(slot_dense[..., 0]):
+                if d < 0 or int(d) not in self._tdense:
+                    continue
+                table, _, variables = self._tdense_dev[int(d)]
+                sel = slot_dense[..., 0] == d
+                folds = slot_dense[..., 1][sel]
+                addr[sel] = table.data_ptr() + folds * (table.shape[1] * table.shape[2] * 4)
+                var[sel] = variables[folds]
+            tabs = bd.cp_tabs[(key, "gather")] = (torch.from_numpy(addr).to(self.device), torch.from_numpy(var).to(self.device))
+        Cn = self.layers[next(self._tdense[int(d)] for d in np.unique(slot_dense[..., 0]) if int(d) in self._tdense)].num_categories
+        return tabs[0], tabs[1], Cn
+
     def _weight_addresses(self, slot_dense: np.ndarray, K: int) -> np.ndarray:
         """Device addresses of the (K, K) weight matrices of the dense folds in `slot_dense` (0 = none)."""
         addr = np.zeros(slot_dense.shape[:-1], dtype=np.int64)
         for d in np.unique(slot_dense[..., 0]):
-            if d < 0:
+            if d < 0 or int(d) in self._tdense:  # tabulated dense layers are gather slots without weights
                 continue
             w = self.layers[int(d)]._w
             if w.is_complex() or w.dtype != torch.float32 or not w.is_contiguous():
@@ -403,8 +458,10 @@ class HipCircuit:
         if tab is None:
             tab = bd.cp_tabs[i] = torch.from_numpy(self._weight_addresses(reg.slot_dense, K)).to(self.device)
         F, H, S = reg.slot_dense.shape[:3]
+        ga, gv, Cn = self._gather_tables(reg.slot_dense, i, bd)
         capi.call("ck_region_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), l._w.data_ptr(),
-                  bd.views[i].data_ptr(), F, H, S, bd.B, K, stream)
+                  bd.views[i].data_ptr(), None if ga is None else ga.data_ptr(), None if gv is None else gv.data_ptr(),
+                  None if ga is None else bd.xt_i.data_ptr(), Cn, F, H, S, bd.B, K, stream)
 
     def _launch_input_prod(self, i: int, bd: _Binding, stream: int) -> None:
         """`ck_gaussian_prod_fwd`: a Hadamard layer over Gaussian folds, straight from the batch."""
@@ -441,20 +498,23 @@ class HipCircuit:
                         raise ValueError("CP blocks need real, contiguous fp32 weights")
                     post = bd.cp_tabs[(i, "post")] = torch.from_numpy(l._w.data_ptr() + folds * (K * K * 4)).to(self.device)
             pp = None if post is None else post.data_ptr()
+            ga, gv, Cn = self._gather_tables(blk.slot_dense if sub is None else blk.slot_dense[sub], i, bd)
+            gargs = (None if ga is None else ga.data_ptr(), None if gv is None else gv.data_ptr(),
+                     None if ga is None else bd.xt_i.data_ptr(), Cn)
             if sub is None:
                 capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), pp, None,
-                          bd.views[i].data_ptr(), F, S, 1, bd.B, K, stream)
+                          bd.views[i].data_ptr(), *gargs, F, S, 1, bd.B, K, stream)
             else:
                 ro, oo = bd.leftover[i]
                 capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), pp, oo.data_ptr(),
-                          bd.arena.data_ptr(), len(sub), S, 1, bd.B, K, stream)
+                          bd.arena.data_ptr(), *gargs, len(sub), S, 1, bd.B, K, stream)
             return
         folds = self._cp_leftover[i]
         ro, oo = bd.leftover[i]
         if tab is None:
             tab = bd.cp_tabs[i] = torch.from_numpy(l._w.data_ptr() + folds.astype(np.int64) * (K * K * 4)).to(self.device)
         capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), None, oo.data_ptr(),
-                  bd.arena.data_ptr(), len(folds), 1, 1, bd.B, K, stream)
+                  bd.arena.data_ptr(), None, None, None, 0, len(folds), 1, 1, bd.B, K, stream)
 
     def _launch_param_batch(self, stream: int) -> None:
         if not self.batch_params:
@@ -477,6 +537,18 @@ class HipCircuit:
         reach memory.  Returns the layers whose parameters are fully covered by such jobs."""
         covered: set[int] = set()
         self._table_fused = set()
+        for d, c in self._tdense.items():  # dense layers tabulated over their Categorical layer (any plan shape)
+            cat, dl = self.layers[c], self.layers[d]
+            Cn = cat.num_categories
+            leaf = self._children[d][:, 0, 1].astype(np.int64)
+            idx = None if np.array_equal(leaf, np.arange(len(leaf))) and cat.num_folds == len(leaf) else torch.from_numpy(leaf).to(self.device)
+            dst = torch.empty((dl.num_folds, Cn + 1, 32), dtype=torch.float32, device=self.device)
+            batch.add_log_table_dense(cat.probs.softmax_source(), dl.weight.softmax_source(), idx, dst)
+            variables = cat.scope_idx[leaf, 0].astype(np.int64)
+            self._tdense_dev[d] = (dst, torch.from_numpy(np.ascontiguousarray(variables)).to(self.device), variables)
+            covered.add(d)
+            if c in self._virtual:
+                covered.add(c)
         if not self.dense_on_table or (self.contraction != "f32" and not self.linear_levels):
             return covered  # (the log-space table job contracts in exact fp32 only)
         for g in self._groups:
@@ -704,6 +776,8 @@ class HipCircuit:
         l, s = self.layers[i], self.plan.layers[i]
         if i in self._input_prod:
             return "gaussian_prod_kernel<8>"
+        if i in self._tdense:
+            return "gather_rows_vec (dense layer tabulated over its categories)"
         if i in self._regions:
             return "region_lse_kernel<2, 4, 3>" if l.num_output_units == 64 else "region_lse_kernel<1, 8, 4>"
         if i in self._cp_blocks or i in self._cp_leftover:
@@ -788,6 +862,8 @@ class HipCircuit:
                     pass
                 elif i in self._group_of_root:
                     self._launch_group(self._group_of_root[i], bd, view, stream)
+                elif i in self._tdense:
+                    self._launch_table_dense(i, bd, stream)
                 elif i in self._cp_blocks or i in self._cp_leftover:
                     self._launch_cp(i, bd, stream)
                 elif i in self._regions:

@@ -24,6 +24,30 @@
 
 namespace {
 
+// Slots that read a TABLE instead of the arena: a dense layer applied to a Categorical layer only takes
+// C distinct values per fold, so its output rows are precomputed per category (ck_param.hip kind-4 job:
+// T'[d] = dense_d(log-table of the leaf fold)) and slot (f, s) gathers row x[b, var] of its table --
+// a plain slot (no weights) whose input never existed as an (F, B, K) tensor.
+struct GatherSlots {
+  const int64_t* addr;  // (F, S...) device address of row 0 of the slot's (C+1, K) table, used where var >= 0
+  const int32_t* var;   // (F, S...) variable of the slot, -1 = read the arena through row_off
+  const int32_t* xt;    // (D, B) staged batch
+  int C;                // categories (row C = the integral row, taken by negative values)
+};
+
+__device__ __forceinline__ const float* slot_source(const GatherSlots& gs, const float* arena, int64_t off, int64_t e,
+                                                    int bl, int B, int K, int kh) {
+  if (gs.var != nullptr) {
+    const int v = gs.var[e];
+    if (v >= 0) {
+      const int x = gs.xt[static_cast<int64_t>(v) * B + bl];
+      const int c = x < 0 ? gs.C : min(x, gs.C - 1);
+      return reinterpret_cast<const float*>(static_cast<uintptr_t>(gs.addr[e])) + static_cast<int64_t>(c) * K + 4 * kh;
+    }
+  }
+  return arena + off + static_cast<int64_t>(bl) * K + 4 * kh;
+}
+
 // NK: K / 32.  WAVES: wavefronts (= 32-row tiles) per workgroup.  MULTI: more than one slot (the
 // single-slot instance keeps no running sum and fits 7 waves per SIMD instead of 4).
 template <int NK, int WAVES, bool MULTI>
@@ -31,7 +55,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     cp_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                   const int64_t* __restrict__ w_addr, const float* __restrict__ w_base,
                   const int64_t* __restrict__ w_post, const int64_t* __restrict__ out_off,
-                  float* __restrict__ out, int S, int H, int B) {
+                  float* __restrict__ out, const GatherSlots gs, int S, int H, int B) {
   constexpr int K = 32 * NK;
   constexpr int WF4 = K * K / 4;  // float4 elements of one weight matrix
   // [buffer][p][q][g][lane] float4: the A operand of MFMA step (p, q, 4g .. 4g+3) for every lane
@@ -73,7 +97,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[q][j] = 0.f;
     for (int h = 0; h < H; ++h) {
-      const float* src = arena + ro[s * H + h] + static_cast<int64_t>(bl) * K + 4 * kh;
+      const float* src = slot_source(gs, arena, ro[s * H + h], (static_cast<int64_t>(f) * S + s) * H + h, bl, B, K, kh);
 #pragma unroll
       for (int q = 0; q < NK; ++q)
 #pragma unroll
@@ -201,7 +225,7 @@ template <int NK, int WAVES, int MINW>
 __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: caps the VGPR budget
     region_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                       const int64_t* __restrict__ w_addr, const float* __restrict__ mw,
-                      float* __restrict__ out, int H, int S, int B) {
+                      float* __restrict__ out, const GatherSlots gs, int H, int S, int B) {
   constexpr int K = 32 * NK;
   constexpr int WF4 = K * K / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -245,7 +269,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
     float P[NK][16];
     for (int s = 0; s < S; ++s, ++t) {
       float v[NK][16];
-      const float* src = arena + ro[t] + static_cast<int64_t>(bl) * K + 4 * kh;
+      const float* src = slot_source(gs, arena, ro[t], static_cast<int64_t>(f) * T + t, bl, B, K, kh);
 #pragma unroll
       for (int q = 0; q < NK; ++q)
 #pragma unroll
@@ -441,13 +465,14 @@ __global__ void __launch_bounds__(WAVES * 64)
 
 template <int NK>
 int launch_cp(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* w_base,
-              const int64_t* w_post, const int64_t* out_off, float* out, int F, int S, int H, int B, void* stream) {
+              const int64_t* w_post, const int64_t* out_off, float* out, GatherSlots gs, int F, int S, int H, int B,
+              void* stream) {
   const int tiles = (B + 31) / 32;
   return ck::dispatch(
       [=](hipStream_t s) {
         auto go = [&](auto kern, int waves) {
           dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
-          hipLaunchKernelGGL(kern, grid, block, 0, s, arena, row_off, w_addr, w_base, w_post, out_off, out, S, H, B);
+          hipLaunchKernelGGL(kern, grid, block, 0, s, arena, row_off, w_addr, w_base, w_post, out_off, out, gs, S, H, B);
         };
         if (S == 1 && w_post == nullptr)
           go(cp_lse_kernel<NK, 8, false>, 8);
@@ -481,24 +506,30 @@ int cat_dense(const float* arena, const int64_t* row_off, const float* w, float*
 // K = 64 dense / CP-T layers of ck_sum_lse_fwd (one slot, contiguous (F, K, K) weights).
 int cp_single_slot(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,
                    void* stream) {
-  if (K == 64) return launch_cp<2>(arena, row_off, nullptr, w, nullptr, nullptr, out, F, 1, H, B, stream);
-  return launch_cp<1>(arena, row_off, nullptr, w, nullptr, nullptr, out, F, 1, H, B, stream);
+  if (K == 64) return launch_cp<2>(arena, row_off, nullptr, w, nullptr, nullptr, out, GatherSlots{}, F, 1, H, B, stream);
+  return launch_cp<1>(arena, row_off, nullptr, w, nullptr, nullptr, out, GatherSlots{}, F, 1, H, B, stream);
 }
 }  // namespace ck
 
 extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* w_post,
-                             const int64_t* out_off, float* out, int F, int S, int H, int B, int K, void* stream) {
+                             const int64_t* out_off, float* out, const int64_t* g_addr, const int32_t* g_var,
+                             const int32_t* xt, int C, int F, int S, int H, int B, int K, void* stream) {
+  CK_REQUIRE(g_var == nullptr || (g_addr && xt && C > 0), "ck_cp_lse_fwd: gather slots need g_addr, xt and C");
+  const GatherSlots gs{g_addr, g_var, xt, C};
   CK_REQUIRE(arena && row_off && w_addr && out, "ck_cp_lse_fwd: null pointer");
   CK_REQUIRE(F > 0 && S > 0 && H > 0 && B > 0, "ck_cp_lse_fwd: non-positive size F=%d S=%d H=%d B=%d", F, S, H, B);
   CK_REQUIRE(K == 32 || K == 64, "ck_cp_lse_fwd: K must be 32 or 64, found %d", K);
   CK_REQUIRE(F <= 65535, "ck_cp_lse_fwd: F=%d exceeds grid.y", F);
   CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(out), "ck_cp_lse_fwd: buffers must be 16-byte aligned");
-  if (K == 64) return launch_cp<2>(arena, row_off, w_addr, nullptr, w_post, out_off, out, F, S, H, B, stream);
-  return launch_cp<1>(arena, row_off, w_addr, nullptr, w_post, out_off, out, F, S, H, B, stream);
+  if (K == 64) return launch_cp<2>(arena, row_off, w_addr, nullptr, w_post, out_off, out, gs, F, S, H, B, stream);
+  return launch_cp<1>(arena, row_off, w_addr, nullptr, w_post, out_off, out, gs, F, S, H, B, stream);
 }
 
 extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
-                                 float* out, int F, int H, int S, int B, int K, void* stream) {
+                                 float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
+                                 int F, int H, int S, int B, int K, void* stream) {
+  CK_REQUIRE(g_var == nullptr || (g_addr && xt && C > 0), "ck_region_lse_fwd: gather slots need g_addr, xt and C");
+  const GatherSlots gs{g_addr, g_var, xt, C};
   CK_REQUIRE(arena && row_off && w_addr && mw && out, "ck_region_lse_fwd: null pointer");
   CK_REQUIRE(F > 0 && S > 0 && H > 0 && B > 0, "ck_region_lse_fwd: non-positive size F=%d H=%d S=%d B=%d", F, H, S, B);
   CK_REQUIRE(K == 32 || K == 64, "ck_region_lse_fwd: K must be 32 or 64, found %d", K);
@@ -511,7 +542,7 @@ extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, con
       [=](hipStream_t s) {
         auto go = [&](auto kern, int waves) {
           dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
-          hipLaunchKernelGGL(kern, grid, block, lds, s, arena, row_off, w_addr, mw, out, H, S, B);
+          hipLaunchKernelGGL(kern, grid, block, lds, s, arena, row_off, w_addr, mw, out, gs, H, S, B);
         };
         // measured on config 4 (MI355X): 4 waves per workgroup at <= 168 VGPRs (no spills, three
         // workgroups per CU) 2.85 ms; 8 waves capped at 128 VGPRs (spills) 3.28 ms; 2 waves 4.3 ms

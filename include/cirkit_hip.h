@@ -146,18 +146,25 @@ int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* m
  *   out = log(W_post . exp(P - max P)) + max P with P = sum_s G_s -- the consumer is then a TorchCPTLayer
  *   (optimized.py:171-178; Hadamard -> Sum fused by the reference) instead of a bare Hadamard layer.
  * out_off: (F) element offsets of each fold's (B, K) output block inside `out`, or NULL for f*B*K
- * (lets one launch evaluate a subset of the folds of a layer in place). */
+ * (lets one launch evaluate a subset of the folds of a layer in place).
+ * g_var / g_addr (both NULL, or (F, S, H) like row_off): slots with g_var >= 0 do not read the arena but row
+ *   x[b, g_var] (row C for a negative value) of the (C+1, K) table at device address g_addr -- the output of
+ *   a dense layer over a Categorical layer, precomputed per category (ck_param_softmax_batch kind 4); such
+ *   slots carry no weights.  xt: (D, B) staged batch. */
 int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* w_post,
-                  const int64_t* out_off, float* out, int F, int S, int H, int B, int K, void* stream);
+                  const int64_t* out_off, float* out, const int64_t* g_addr, const int32_t* g_var,
+                  const int32_t* xt, int C, int F, int S, int H, int B, int K, void* stream);
 
 /* A region with H partitionings in one launch: the H CP blocks (as in ck_cp_lse_fwd, S slots each)
  * and the mixing layer that combines them (templates/region_graph/graph.py:556-583: `mix_ins` and the
  * arity-H SumLayer with TorchMixingWeightParameter weights, nodes.py:847-862):
  *   P_h = sum_s G_{h,s};  out[f,b,k] = log(sum_h mw[f,k,h] * exp(P_h[k] - M)) + M,  M = max_{h,k} P_h[k].
  * row_off, w_addr: (F, H, S) as in ck_cp_lse_fwd; mw: (F, K, H) mixing coefficients; out: (F, B, K).
- * The sum over h is accumulated online (running maximum), see ck_cp.hip. */
+ * The sum over h is accumulated online (running maximum), see ck_cp.hip.  g_addr / g_var / xt / C: table
+ * slots as in ck_cp_lse_fwd, shaped (F, H, S). */
 int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
-                      float* out, int F, int H, int S, int B, int K, void* stream);
+                      float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
+                      int F, int H, int S, int B, int K, void* stream);
 
 /* TorchHadamardLayer.forward, inner.py:126-127 (lse: sum over the arity axis). esize = 1 (fp32)
  * or 2 (complex64: K counts complex elements). */
