@@ -189,7 +189,7 @@ class HipCircuit:
             # mixing layers that take over the CP blocks they combine (ck_cp.hip: region_lse_kernel)
             regions, absorbed = find_region_blocks(
                 plan, self.layers, self._children, self._out_pairs, self._cp_blocks,
-                self._virtual | set(self._group_of_root) | set(self._tail)) if fuse_regions else ([], {})
+                self._virtual | set(self._group_of_root) | set(self._tail) | set(self._input_prod)) if fuse_regions else ([], {})
             self._regions = {r.layer: r for r in regions}
             for h, mask in absorbed.items():
                 if mask.all():

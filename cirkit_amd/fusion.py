@@ -280,8 +280,9 @@ class RegionBlock:
 def find_region_blocks(plan, layers, children, out_pairs, cp_blocks: dict[int, CPBlock], skip: set[int]):
     """Returns (regions, absorbed).  A mixing layer whose every input is a fold of a CP-block
     Hadamard layer, read by nobody else, takes those folds over: `absorbed[hadamard layer]` is the
-    boolean mask of its folds that are no longer evaluated (nor stored) on their own."""
-    if plan.semiring != "lse-sum" or not cp_blocks:
+    boolean mask of its folds that are no longer evaluated (nor stored) on their own.  May add
+    plain-slot blocks for bare Hadamard layers to `cp_blocks`."""
+    if plan.semiring != "lse-sum":
         return [], {}
     uses = [np.zeros(l.num_folds, dtype=np.int64) for l in layers]
     for ch in children:
@@ -298,13 +299,20 @@ def find_region_blocks(plan, layers, children, out_pairs, cp_blocks: dict[int, C
             continue
         ch = children[j]  # (F, H, 2)
         prods = [int(p) for p in np.unique(ch[..., 0])]
-        if any(p not in cp_blocks or cp_blocks[p].post for p in prods):
+        # a bare Hadamard layer (no dense fold to absorb) counts as a block of plain slots: the region
+        # launch then computes mixing-of-products straight from the Hadamard's own inputs
+        bare = {p: CPBlock(p, children[p].copy(), np.full_like(children[p], -1)) for p in prods
+                if (p not in cp_blocks and p not in skip and plan.layers[p].type == "hadamard" and not layers[p].is_complex
+                    and layers[p].num_input_units == l.num_output_units)}
+        blk = {**cp_blocks, **bare}
+        if any(p not in blk or blk[p].post for p in prods):
             continue
-        arities = {cp_blocks[p].slot_child.shape[1] for p in prods}
+        arities = {blk[p].slot_child.shape[1] for p in prods}
         if len(arities) != 1:
             continue
         if any((uses[p][ch[..., 1][ch[..., 0] == p]] != 1).any() for p in prods):
             continue
+        cp_blocks.update(bare)
         S = arities.pop()
         F, H = ch.shape[:2]
         slot_child = np.zeros((F, H, S, 2), dtype=np.int64)
