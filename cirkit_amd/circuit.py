@@ -164,9 +164,13 @@ class HipCircuit:
         if fuse is not False and dense_on_table and batch_params:
             busy = self._virtual | set(self._group_of_root) | set(self._tail)
             cand = find_table_dense(plan, self.layers, self._children, busy)
+            def fits(d: int, c: int) -> bool:  # one fold's (K, C) block + statistics + weights in LDS
+                K, Cn = self.layers[d].num_output_units, self.layers[c].num_categories
+                return (K * (Cn + 1) + 2 * K + K * K) * 4 <= 160 * 1024
+
             self._tdense = {d: c for d, c in cand.items()
                             if self.layers[c].probs is not None and self.layers[c].probs.softmax_source() is not None
-                            and self.layers[d].weight.softmax_source() is not None}
+                            and self.layers[d].weight.softmax_source() is not None and fits(d, c)}
             readers: dict[int, set[int]] = {}
             for j, ch in enumerate(self._children):
                 if ch is not None:
@@ -542,7 +546,7 @@ class HipCircuit:
             Cn = cat.num_categories
             leaf = self._children[d][:, 0, 1].astype(np.int64)
             idx = None if np.array_equal(leaf, np.arange(len(leaf))) and cat.num_folds == len(leaf) else torch.from_numpy(leaf).to(self.device)
-            dst = torch.empty((dl.num_folds, Cn + 1, 32), dtype=torch.float32, device=self.device)
+            dst = torch.empty((dl.num_folds, Cn + 1, dl.num_output_units), dtype=torch.float32, device=self.device)
             batch.add_log_table_dense(cat.probs.softmax_source(), dl.weight.softmax_source(), idx, dst)
             variables = cat.scope_idx[leaf, 0].astype(np.int64)
             self._tdense_dev[d] = (dst, torch.from_numpy(np.ascontiguousarray(variables)).to(self.device), variables)

@@ -476,6 +476,101 @@ __device__ __forceinline__ void softmax_job_table_dense(const ck_softmax_job& j,
   }
 }
 
+// kind 4 with 64 units: the same job on the two-block register tile (weights in LDS in MFMA operand layout,
+// as in ck_cp.hip); W rows of 64 follow the arithmetic of the long-row branch of softmax_job_rows.
+__device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& j, int d, float* tile) {
+  constexpr int K = 64, NK = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = j.len, ld = C + 1;
+  const int64_t f = j.idx != nullptr ? j.idx[d] : d;
+  const float* src = j.in + f * K * C;
+  float* stat = tile + K * ld;  // [K] max, [K] log-sum
+  float* w_s = stat + 2 * K;    // [p][q][g][lane][4] linear weights of dense fold d
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+    const int k = i / C, c = i - k * C;
+    tile[k * ld + c] = src[i];
+  }
+  {
+    const float* th = j.in2 + static_cast<int64_t>(d) * (K * K);
+    for (int o = wave; o < K; o += kPW) {
+      const float x = th[o * K + lane];
+      const float mx = ck::wave_max(x);
+      const float e = __expf(x - mx);
+      const float sum = ck::wave_sum(e);
+      const int k = lane, p = o >> 5, q = k >> 5, g = (k >> 3) & 3, ln = (o & 31) + 32 * ((k >> 2) & 1);
+      w_s[((((p * NK + q) * 4 + g) * 64) + ln) * 4 + (k & 3)] = e / sum;
+    }
+  }
+  __syncthreads();
+  for (int k = wave; k < K; k += kPW) {  // per-unit max and log-sum-exp over the categories
+    const float* row = tile + k * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+    m = ck::wave_max(m);
+    float sacc = 0.f;
+    for (int c = lane; c < C; c += 64) sacc += __expf(row[c] - m);
+    sacc = ck::wave_sum(sacc);
+    if (lane == 0) {
+      stat[k] = m;
+      stat[K + k] = __logf(sacc);
+    }
+  }
+  __syncthreads();
+  const int b_in = lane & 31, kh = lane >> 5;
+  float* dst = j.out + static_cast<int64_t>(d) * (C + 1) * K;
+  for (int t = wave; t * 32 <= C; t += kPW) {
+    const int c = t * 32 + b_in;
+    const int cl = min(c, C - 1);
+    float v[NK][16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NK; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int k = 32 * q + 8 * g + 4 * kh + tt;
+          const float dlt = tile[k * ld + cl] - stat[k];
+          const float val = dlt < -103.9f ? -INFINITY : dlt - stat[K + k];
+          v[q][4 * g + tt] = c >= C ? 0.f : val;
+          m = fmaxf(m, v[q][4 * g + tt]);
+        }
+    m = ck::clamp_finite(fmaxf(m, __shfl_xor(m, 32, 64)));
+    const float nml = exp_offset(m, 0.f);
+#pragma unroll
+    for (int q = 0; q < NK; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[q][r] = __builtin_amdgcn_exp2f(fmaf(v[q][r], kL2E, nml));
+#pragma unroll
+    for (int p = 0; p < NK; ++p) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NK; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 w4 = *reinterpret_cast<const float4*>(w_s + ((((p * NK + q) * 4 + g) * 64) + lane) * 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, v[q][4 * g + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, v[q][4 * g + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, v[q][4 * g + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, v[q][4 * g + 3], acc, 0, 0, 0);
+        }
+      if (c <= C) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 o4;
+          o4.x = fmaf(__builtin_amdgcn_logf(acc[4 * g + 0]), kLN2, m);
+          o4.y = fmaf(__builtin_amdgcn_logf(acc[4 * g + 1]), kLN2, m);
+          o4.z = fmaf(__builtin_amdgcn_logf(acc[4 * g + 2]), kLN2, m);
+          o4.w = fmaf(__builtin_amdgcn_logf(acc[4 * g + 3]), kLN2, m);
+          *reinterpret_cast<float4*>(dst + static_cast<int64_t>(c) * K + 32 * p + 8 * g + 4 * kh) = o4;
+        }
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kPW * 64) softmax_batch_kernel(const JobTable t) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   const int bid = blockIdx.x;
@@ -485,6 +580,8 @@ __global__ void __launch_bounds__(kPW * 64) softmax_batch_kernel(const JobTable 
   const int blk = bid - j.block_begin;
   if (j.kind == 1)
     softmax_job_table(j, blk, tile);
+  else if (j.kind == 4 && j.k == 64)
+    softmax_job_table_dense64(j, blk, tile);
   else if (j.kind == 4 || j.kind == 5)
     softmax_job_table_dense(j, blk, tile);
   else
@@ -648,14 +745,15 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
       CK_REQUIRE(j.kind >= 0 && j.kind <= 5, "ck_param_softmax_batch: job %d has unknown kind %d", start + i, j.kind);
       CK_REQUIRE(j.kind < 2 || j.kind >= 4 || (j.len == 32 && j.rows % 32 == 0),
                  "ck_param_softmax_batch: tiled job %d needs len = 32 and rows %% 32 = 0", start + i);
-      CK_REQUIRE(j.kind < 4 || (j.k == 32 && j.in2 != nullptr), "ck_param_softmax_batch: job %d (kind 4/5) needs k = 32 and in2", start + i);
+      CK_REQUIRE(j.kind < 4 || ((j.k == 32 || (j.k == 64 && j.kind == 4)) && j.in2 != nullptr),
+                 "ck_param_softmax_batch: job %d (kind 4/5) needs k = 32 (kind 4: or 64) and in2", start + i);
       CK_REQUIRE(j.kind != 5 || j.out2 != nullptr, "ck_param_softmax_batch: job %d (kind 5) needs out2", start + i);
       j.block_begin = blocks;
       if (j.kind != 1 && j.kind < 4) {
         blocks += static_cast<int>((j.rows + 16 * kPW - 1) / (16 * kPW));
       } else {
         CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", start + i);
-        const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k + (j.kind >= 4 ? 1024 : 0)) * sizeof(float);
+        const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k + (j.kind >= 4 ? j.k * j.k : 0)) * sizeof(float);
         if (need > 160 * 1024)
           return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
         lds = std::max(lds, need);

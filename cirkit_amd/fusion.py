@@ -331,7 +331,7 @@ def find_region_blocks(plan, layers, children, out_pairs, cp_blocks: dict[int, C
 # dense layers over a Categorical layer: one table row per category instead of one MFMA per batch row
 # ---------------------------------------------------------------------------------------------
 def find_table_dense(plan, layers, children, skip: set[int]) -> dict[int, int]:
-    """{dense layer: categorical layer} for dense layers (arity-1 sums, 32 -> 32 units, weights = plain
+    """{dense layer: categorical layer} for dense layers (arity-1 sums, 32 -> 32 or 64 -> 64 units, weights = plain
     softmax) ALL of whose inputs are folds of one Categorical layer with probs = plain softmax.  Such a
     layer takes C distinct values per fold: T'[d] = dense_d(log-table of its leaf fold) is built once per
     forward by the prologue (ck_param.hip, kind 4) and the layer -- or the CP-block slot that absorbed it
@@ -341,7 +341,7 @@ def find_table_dense(plan, layers, children, skip: set[int]) -> dict[int, int]:
     found: dict[int, int] = {}
     for j, (s, l) in enumerate(zip(plan.layers, layers)):
         if (j in skip or s.type != "sum" or l.arity != 1 or getattr(l, "_mixing", False) or l.is_complex
-                or l.num_input_units != FUSED_K or l.num_output_units != FUSED_K):
+                or l.num_input_units not in CP_K or l.num_output_units != l.num_input_units):
             continue
         ch = children[j]
         prods = np.unique(ch[..., 0])

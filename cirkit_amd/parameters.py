@@ -98,9 +98,10 @@ class ParamBatch:
         through dense fold d (dense_src (Fd, 32, 32) logits, softmax over the last axis).  With
         `scale` (Fd, C+1) the rows are left in linear space and their log scales go to `scale`."""
         F, K, Cc = src.shape
-        if K != 32 or tuple(dense_src.shape[1:]) != (32, 32) or tuple(dst.shape) != (dense_src.shape[0], Cc + 1, 32):
-            raise ValueError("add_log_table_dense needs K = 32 and matching shapes")
-        self._jobs.append((src.data_ptr(), dst.data_ptr(), int(dense_src.shape[0]), int(Cc), 32, 4 if scale is None else 5,
+        if (K not in (32, 64) or tuple(dense_src.shape[1:]) != (K, K) or tuple(dst.shape) != (dense_src.shape[0], Cc + 1, K)
+                or (K == 64 and scale is not None)):
+            raise ValueError("add_log_table_dense needs K = 32 (or 64 without scales) and matching shapes")
+        self._jobs.append((src.data_ptr(), dst.data_ptr(), int(dense_src.shape[0]), int(Cc), int(K), 4 if scale is None else 5,
                            dense_src.data_ptr(), None if idx is None else idx.data_ptr(),
                            None if scale is None else scale.data_ptr()))
         self._keep += [src, dense_src, dst] + ([] if idx is None else [idx]) + ([] if scale is None else [scale])

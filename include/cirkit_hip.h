@@ -234,7 +234,7 @@ int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_
  * out (F, C+1, K) = log(softmax over C), transposed for the gather kernels, row C = 0 (integral).
  * kind 2 / 3: as kind 0 for (F*32, 32) weights, written in CK_W_TILED_F32 / CK_W_TILED_F16X3
  * layout (rows must be a multiple of 32, len = 32).
- * kind 4: kind 1 followed by a dense sum layer applied to the table (k = 32): for each of the `rows`
+ * kind 4: kind 1 followed by a dense sum layer applied to the table (k = 32 or 64): for each of the `rows`
  * dense folds d, out[d] (C+1, 32) = log(softmax(in2[d]) . exp(T - m)) + m row by row, with T the kind-1
  * table of categorical fold idx[d] (a Categorical layer followed fold by fold by a dense layer only
  * takes C distinct values per fold, so the dense layer is evaluated on the table instead of on the batch).
