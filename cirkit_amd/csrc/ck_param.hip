@@ -571,6 +571,9 @@ __device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& 
   }
 }
 
+// WIDE: the launch that carries the 64-unit table jobs -- kept apart so that their two-block tile does not set
+// the register budget (and with it the occupancy) of every other job
+template <bool WIDE>
 __global__ void __launch_bounds__(kPW * 64) softmax_batch_kernel(const JobTable t) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   const int bid = blockIdx.x;
@@ -578,10 +581,12 @@ __global__ void __launch_bounds__(kPW * 64) softmax_batch_kernel(const JobTable 
   while (ji + 1 < t.n && bid >= t.job[ji + 1].block_begin) ++ji;
   const ck_softmax_job& j = t.job[ji];
   const int blk = bid - j.block_begin;
+  if constexpr (WIDE) {
+    softmax_job_table_dense64(j, blk, tile);
+    return;
+  }
   if (j.kind == 1)
     softmax_job_table(j, blk, tile);
-  else if (j.kind == 4 && j.k == 64)
-    softmax_job_table_dense64(j, blk, tile);
   else if (j.kind == 4 || j.kind == 5)
     softmax_job_table_dense(j, blk, tile);
   else
@@ -734,46 +739,54 @@ int ck_param_table_integral_row(float* table, int F, int C, int K, int mode, voi
 
 int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) {
   CK_REQUIRE(jobs != nullptr && njobs > 0, "ck_param_softmax_batch: no jobs");
-  for (int start = 0; start < njobs; start += kMaxJobs) {
-    JobTable t{};
-    t.n = std::min(kMaxJobs, njobs - start);
-    int blocks = 0;
-    size_t lds = 0;
-    for (int i = 0; i < t.n; ++i) {
-      ck_softmax_job j = jobs[start + i];
-      CK_REQUIRE(j.in && j.out && j.rows > 0 && j.len > 0, "ck_param_softmax_batch: bad job %d", start + i);
-      CK_REQUIRE(j.kind >= 0 && j.kind <= 5, "ck_param_softmax_batch: job %d has unknown kind %d", start + i, j.kind);
-      CK_REQUIRE(j.kind < 2 || j.kind >= 4 || (j.len == 32 && j.rows % 32 == 0),
-                 "ck_param_softmax_batch: tiled job %d needs len = 32 and rows %% 32 = 0", start + i);
-      CK_REQUIRE(j.kind < 4 || ((j.k == 32 || (j.k == 64 && j.kind == 4)) && j.in2 != nullptr),
-                 "ck_param_softmax_batch: job %d (kind 4/5) needs k = 32 (kind 4: or 64) and in2", start + i);
-      CK_REQUIRE(j.kind != 5 || j.out2 != nullptr, "ck_param_softmax_batch: job %d (kind 5) needs out2", start + i);
-      j.block_begin = blocks;
-      if (j.kind != 1 && j.kind < 4) {
-        blocks += static_cast<int>((j.rows + 16 * kPW - 1) / (16 * kPW));
-      } else {
-        CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", start + i);
-        const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k + (j.kind >= 4 ? j.k * j.k : 0)) * sizeof(float);
-        if (need > 160 * 1024)
-          return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
-        lds = std::max(lds, need);
-        blocks += static_cast<int>(j.rows);
+  for (int wide = 0; wide < 2; ++wide) {
+    int start = 0;
+    while (start < njobs) {
+      JobTable t{};
+      int blocks = 0;
+      size_t lds = 0;
+      while (start < njobs && t.n < kMaxJobs) {
+        ck_softmax_job j = jobs[start];
+        const int idx = start++;
+        CK_REQUIRE(j.in && j.out && j.rows > 0 && j.len > 0, "ck_param_softmax_batch: bad job %d", idx);
+        CK_REQUIRE(j.kind >= 0 && j.kind <= 5, "ck_param_softmax_batch: job %d has unknown kind %d", idx, j.kind);
+        CK_REQUIRE(j.kind < 2 || j.kind >= 4 || (j.len == 32 && j.rows % 32 == 0),
+                   "ck_param_softmax_batch: tiled job %d needs len = 32 and rows %% 32 = 0", idx);
+        CK_REQUIRE(j.kind < 4 || ((j.k == 32 || (j.k == 64 && j.kind == 4)) && j.in2 != nullptr),
+                   "ck_param_softmax_batch: job %d (kind 4/5) needs k = 32 (kind 4: or 64) and in2", idx);
+        CK_REQUIRE(j.kind != 5 || j.out2 != nullptr, "ck_param_softmax_batch: job %d (kind 5) needs out2", idx);
+        if ((j.kind == 4 && j.k == 64) != (wide == 1)) continue;  // the other pass takes it
+        j.block_begin = blocks;
+        if (j.kind != 1 && j.kind < 4) {
+          blocks += static_cast<int>((j.rows + 16 * kPW - 1) / (16 * kPW));
+        } else {
+          CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", idx);
+          const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k + (j.kind >= 4 ? j.k * j.k : 0)) * sizeof(float);
+          if (need > 160 * 1024)
+            return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
+          lds = std::max(lds, need);
+          blocks += static_cast<int>(j.rows);
+        }
+        t.job[t.n++] = j;
       }
-      t.job[i] = j;
+      if (t.n == 0) continue;
+      const dim3 grid(blocks), block(kPW * 64);
+      int st = ck::dispatch(
+          [=](hipStream_t s) {
+            auto go = [&](auto kern) {
+              if (lds > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+                if (e != hipSuccess) return e;
+              }
+              hipLaunchKernelGGL(kern, grid, block, lds, s, t);
+              return hipGetLastError();
+            };
+            return wide ? go(softmax_batch_kernel<true>) : go(softmax_batch_kernel<false>);
+          },
+          stream);
+      if (st != CK_OK) return st;
     }
-    const dim3 grid(blocks), block(kPW * 64);
-    int st = ck::dispatch(
-        [=](hipStream_t s) {
-          if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_batch_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-            if (e != hipSuccess) return e;
-          }
-          hipLaunchKernelGGL(softmax_batch_kernel, grid, block, lds, s, t);
-          return hipGetLastError();
-        },
-        stream);
-    if (st != CK_OK) return st;
   }
   return CK_OK;
 }
