@@ -912,7 +912,7 @@ class HipCircuit:
                         pbytes += per_fold * n.num_folds
             has_prep = bool(s.params) and not (self.batch_params and l._batched)
             if i == 0 and self.batch_params and self._batch is not None and len(self._batch):
-                rows.append({"layer": 0, "kernel": "softmax_batch_kernel", "ms": float(mean[0]),
+                rows.append({"layer": 0, "kernel": "softmax_batch_kernel<false>", "ms": float(mean[0]),
                              "algorithmic_bytes": float(2 * sum(
                                  int(np.prod(shp)) * 4 for shp, _ in self.plan.tensors.values()))})
             elif has_prep:
