@@ -157,16 +157,34 @@ def main() -> None:
         """W untimed + exactly K timed steps, barrier + synchronize on both sides; returns
         (wall seconds, mean HIP-event ms per step on the launch stream, final [sum, count])."""
         last = [None]
+        # N > 1: the 16-byte all-reduce of step k runs on RCCL's stream WHILE step k + 1 computes (its
+        # input is copied out of the circuit's [sum, count] buffer, which the next step overwrites);
+        # a ring of buffers, each reused only after its previous collective has completed
+        ring = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(8)] if world > 1 else []
+        works: list = [None] * len(ring)
+        count = [0]
 
         def step() -> None:
             ll = circ.log_likelihood_sum(x)  # forward + device-side sum, enqueued on `stream`
             if world > 1:
-                dist.all_reduce(ll, op=dist.ReduceOp.SUM)  # the ONE exchange: 16 bytes over xGMI
+                i = count[0] % len(ring)
+                count[0] += 1
+                if works[i] is not None:
+                    works[i].wait()  # stream-level wait on a collective issued 8 steps ago
+                ring[i].copy_(ll)
+                works[i] = dist.all_reduce(ring[i], op=dist.ReduceOp.SUM, async_op=True)  # the ONE exchange: 16 bytes over xGMI
+                ll = ring[i]
             last[0] = ll
+
+        def drain() -> None:
+            for w in works:
+                if w is not None:
+                    w.wait()
 
         with torch.cuda.stream(stream):
             for _ in range(warmup):
                 step()
+            drain()
             torch.cuda.synchronize(device)
             if world > 1:
                 dist.barrier()
@@ -178,6 +196,7 @@ def main() -> None:
             e0.record(stream)
             for _ in range(steps):
                 step()
+            drain()  # every collective of the timed steps has completed before the clock stops
             e1.record(stream)
             torch.cuda.synchronize(device)
             if world > 1:
@@ -230,7 +249,7 @@ def main() -> None:
 
     # Secondary figure (never `value`): the same step with the split-fp16 contraction.
     variants = {}
-    if args.contraction == "f32" and not args.no_variants:
+    if args.contraction == "f32" and not args.no_variants and world == 1:  # single-GPU extras only
         alt = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse, contraction="f16x3")
         w2, ms2, pair2 = timed_region(alt, args.steps, args.warmup)
         if world > 1:
