@@ -81,4 +81,60 @@ __device__ __forceinline__ c32 c_log_shift(c32 z, float m) {
   return {lr + m, atan2f(z.im, z.re)};
 }
 
+// ---- cheaper complex exp / log for the K = 32 tile kernel -----------------------------------------------
+// The OCML sincosf / atan2f / log1pf spend most of their ~300 instructions per element on argument ranges
+// that cannot occur here: a phase is a sum of H values of atan2 (|im| <= H pi), and the magnitudes are
+// sums of at most a few hundred terms <= |W|.  Polynomials fitted for this kernel (max error in fp32:
+// sin 1.06 ulp, cos 0.86 ulp on [-pi/4, pi/4]; atan 1.63 ulp on [0, 1]), Cody-Waite reduction by pi/2.
+__device__ __forceinline__ void sincos_small(float x, float& s, float& c) {
+  if (__builtin_expect(fabsf(x) > 8192.f, 0)) {  // never for phases built as above
+    sincosf(x, &s, &c);
+    return;
+  }
+  const float n = rintf(x * 0.63661977236758134f);
+  float r = fmaf(-n, 1.57079637050628662109375f, x);
+  r = fmaf(-n, -4.371138828673793e-08f, r);
+  const float z = r * r;
+  float sp = fmaf(z, 2.717982852118439e-06f, -1.983928814297542e-04f);
+  sp = fmaf(sp, z, 8.333329111337662e-03f);
+  sp = fmaf(sp, z, -1.666666716337204e-01f);
+  const float sn = fmaf(sp * z, r, r);
+  float cp = fmaf(z, 2.438902811263688e-05f, -1.3886739034205675e-03f);
+  cp = fmaf(cp, z, 4.166662320494652e-02f);
+  cp = fmaf(cp, z, -0.5f);
+  const float cs = fmaf(cp, z, 1.f);
+  const int q = static_cast<int>(n);
+  const float s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ c32 c_exp_shift_tile(c32 z, float m) {
+  const float r = expf(z.re - m);
+  float s, c;
+  sincos_small(z.im, s, c);
+  return {r * c, r * s};
+}
+__device__ __forceinline__ c32 c_log_shift_tile(c32 z, float m) {
+  const float ax = fabsf(z.re), ay = fabsf(z.im);
+  const float big = fmaxf(ax, ay), small = fminf(ax, ay);
+  if (__builtin_expect(!(big > 0.f) || !(big < 3.0e38f), 0)) return c_log_shift(z, m);  // zeros, infinities, NaN
+  const float rc = __builtin_amdgcn_rcpf(big);
+  float q = small * rc;
+  q = fmaf(fmaf(-q, big, small), rc, q);  // one Newton step: q = small / big to ~1 ulp
+  const float t = q * q;
+  // log|z| = log big + log(1 + t) / 2   (1 + t in [1, 2]: v_log_f32 is accurate to an absolute 1e-7 there)
+  const float lr = 0.69314718055994530942f * fmaf(0.5f, __builtin_amdgcn_logf(1.f + t), __builtin_amdgcn_logf(big)) + m;
+  float a = fmaf(t, 2.8786147013306618e-03f, -1.6197500750422478e-02f);
+  a = fmaf(a, t, 4.292982071638107e-02f);
+  a = fmaf(a, t, -7.527676224708557e-02f);
+  a = fmaf(a, t, 1.0653974115848541e-01f);
+  a = fmaf(a, t, -1.4207743108272552e-01f);
+  a = fmaf(a, t, 1.9993291795253754e-01f);
+  a = fmaf(a, t, -3.333311975002289e-01f);
+  a = fmaf(a * t, q, q);                               // atan(q), q in [0, 1]
+  if (ay > ax) a = 1.57079632679489661923f - a;        // |im| > |re|
+  if (z.re < 0.f) a = 3.14159265358979323846f - a;     // left half plane
+  return {lr, copysignf(a, z.im)};
+}
+
 }  // namespace ck

@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256)
     const float m = row_max16(zr);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const c32 e = ck::c_exp_shift(c32{zr[j], zi[j]}, m);
+      const c32 e = ck::c_exp_shift_tile(c32{zr[j], zi[j]}, m);
       zr[j] = e.re;
       zi[j] = e.im;
     }
@@ -126,10 +126,10 @@ __global__ void __launch_bounds__(256)
       float* dst = reinterpret_cast<float*>(out + (static_cast<int64_t>(f) * B + b) * kK + 4 * kh);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const c32 o0 = ck::c_log_shift(c32{yr[4 * g + 0], yi[4 * g + 0]}, m);
-        const c32 o1 = ck::c_log_shift(c32{yr[4 * g + 1], yi[4 * g + 1]}, m);
-        const c32 o2 = ck::c_log_shift(c32{yr[4 * g + 2], yi[4 * g + 2]}, m);
-        const c32 o3 = ck::c_log_shift(c32{yr[4 * g + 3], yi[4 * g + 3]}, m);
+        const c32 o0 = ck::c_log_shift_tile(c32{yr[4 * g + 0], yi[4 * g + 0]}, m);
+        const c32 o1 = ck::c_log_shift_tile(c32{yr[4 * g + 1], yi[4 * g + 1]}, m);
+        const c32 o2 = ck::c_log_shift_tile(c32{yr[4 * g + 2], yi[4 * g + 2]}, m);
+        const c32 o3 = ck::c_log_shift_tile(c32{yr[4 * g + 3], yi[4 * g + 3]}, m);
         *reinterpret_cast<float4*>(dst + 16 * g) = make_float4(o0.re, o0.im, o1.re, o1.im);
         *reinterpret_cast<float4*>(dst + 16 * g + 4) = make_float4(o2.re, o2.im, o3.re, o3.im);
       }
