@@ -25,7 +25,7 @@ import torch
 from . import _capi as capi
 from .fusion import (CPBlock, RegionBlock, SubtreeGroup, find_cp_blocks, find_input_products, find_region_blocks,
                      find_subtree_groups, find_table_dense, find_tail)
-from .layers import HipConstantValueLayer, HipInputLayer, HipLayer, layer_from_spec
+from .layers import HipConstantValueLayer, HipEmbeddingLayer, HipInputLayer, HipLayer, layer_from_spec
 from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
 
@@ -159,6 +159,29 @@ class HipCircuit:
         self._regions: dict[int, RegionBlock] = {}
         self._input_prod: dict[int, int] = {}  # Hadamard layer -> the Gaussian layer it multiplies (ck_input.hip)
         self._input_prod_dev: dict[int, torch.Tensor] = {}
+        # complex CP-T / dense layers (K = 32, real weights) whose children are all folds of ONE Embedding layer
+        # that nobody else reads: they gather from its weight table, the Embedding output is never written
+        self._emb_gather: dict[int, int] = {}
+        self._emb_gather_dev: dict[int, tuple] = {}
+        if fuse is not False and self._complex:
+            readers: dict[int, set[int]] = {}
+            for j, ch in enumerate(self._children):
+                if ch is not None:
+                    for p in np.unique(ch[..., 0]):
+                        readers.setdefault(int(p), set()).add(j)
+            outs = {int(p) for p in self._out_pairs[:, 0]}
+            for j, (sp, l) in enumerate(zip(plan.layers, self.layers)):
+                ch = self._children[j]
+                if ch is None or sp.type not in ("cpt", "sum") or (sp.type == "sum" and l.arity != 1):
+                    continue
+                if l.num_input_units != 32 or l.num_output_units != 32 or l.weight.ops != ["tensor"]:
+                    continue
+                prods = np.unique(ch[..., 0])
+                e = int(prods[0])
+                if (len(prods) == 1 and isinstance(self.layers[e], HipEmbeddingLayer) and readers.get(e) == {j}
+                        and e not in outs and self.layers[e].scope_idx.shape[1] == 1):
+                    self._emb_gather[j] = e
+                    self._virtual.add(e)
         self._tdense: dict[int, int] = {}  # dense layer -> the Categorical layer it is tabulated over
         self._tdense_dev: dict[int, tuple] = {}  # dense layer -> (T' (F, C+1, 32), scope (F) int64, variables (F) numpy)
         if fuse is not False and dense_on_table and batch_params:
@@ -391,6 +414,8 @@ class HipCircuit:
                 self._launch_group(self._group_of_root[i], bd, view, stream)
             elif i in self._tdense:
                 self._launch_table_dense(i, bd, stream)
+            elif i in self._emb_gather:
+                self._launch_emb_gather(i, bd, stream)
             elif i in self._cp_blocks or i in self._cp_leftover:
                 self._launch_cp(i, bd, stream)
             elif i in self._regions:
@@ -403,6 +428,20 @@ class HipCircuit:
                 l.launch_input(bd.xt if l.wants_float_input else bd.xt_i, self.plan.num_variables, view, B, stream)
             else:
                 l.launch(bd.arena, ro, view, B, stream)
+
+    def _launch_emb_gather(self, i: int, bd: _Binding, stream: int) -> None:
+        """`ck_sum_clse_gather_fwd`: a complex CP-T / dense layer reading its Embedding children from the table."""
+        l, emb = self.layers[i], self.layers[self._emb_gather[i]]
+        tabs = self._emb_gather_dev.get(i)
+        if tabs is None:
+            folds = self._children[i][..., 1].astype(np.int32)
+            variables = emb.scope_idx[folds, 0].astype(np.int32)
+            tabs = self._emb_gather_dev[i] = (torch.from_numpy(np.ascontiguousarray(folds)).to(self.device),
+                                              torch.from_numpy(np.ascontiguousarray(variables)).to(self.device))
+        if l._w.is_complex():
+            raise ValueError("gathering CP-T layers take real weights")
+        capi.call("ck_sum_clse_gather_fwd", emb._table.data_ptr(), bd.xt_i.data_ptr(), tabs[0].data_ptr(), tabs[1].data_ptr(),
+                  l._w.data_ptr(), bd.views[i].data_ptr(), l.num_folds, l.arity, bd.B, emb.num_states, stream)
 
     def _launch_table_dense(self, i: int, bd: _Binding, stream: int) -> None:
         """A dense layer over a Categorical layer, evaluated as a gather from its per-category table T'
@@ -782,6 +821,8 @@ class HipCircuit:
             return "gaussian_prod_kernel<8>"
         if i in self._tdense:
             return "gather_rows_vec (dense layer tabulated over its categories)"
+        if i in self._emb_gather:
+            return "sum_clse_tile32 (Embedding rows gathered from the table)"
         if i in self._regions:
             return "region_lse_kernel<2, 4, 3>" if l.num_output_units == 64 else "region_lse_kernel<1, 8, 4>"
         if i in self._cp_blocks or i in self._cp_leftover:
@@ -868,6 +909,8 @@ class HipCircuit:
                     self._launch_group(self._group_of_root[i], bd, view, stream)
                 elif i in self._tdense:
                     self._launch_table_dense(i, bd, stream)
+                elif i in self._emb_gather:
+                    self._launch_emb_gather(i, bd, stream)
                 elif i in self._cp_blocks or i in self._cp_leftover:
                     self._launch_cp(i, bd, stream)
                 elif i in self._regions:
@@ -954,6 +997,8 @@ class HipCircuit:
             nbytes, nflops = layer_bytes[i], layer_flops[i]
             if i in self._input_prod:
                 nbytes += layer_bytes[self._input_prod[i]]
+            if i in self._emb_gather:
+                nbytes += layer_bytes[self._emb_gather[i]]
             if i in self._cp_leftover:  # only the folds other consumers need are evaluated here
                 share = len(self._cp_leftover[i]) / l.num_folds
                 nbytes, nflops = nbytes * share, nflops * share

@@ -74,7 +74,9 @@ __global__ void __launch_bounds__(256)
 // kernel keeps half of them idle at K = 32), transcendental functions as in ck_internal.h.
 __global__ void __launch_bounds__(256)
     sum_clse_tile32(const c32* __restrict__ arena, const int64_t* __restrict__ row_off,
-                    const float* __restrict__ w, c32* __restrict__ out, int H, int B, int tiles_per_wave) {
+                    const float* __restrict__ w, c32* __restrict__ out, int H, int B, int tiles_per_wave,
+                    const float* __restrict__ table, const int32_t* __restrict__ child_fold,
+                    const int32_t* __restrict__ child_var, const int32_t* __restrict__ xt, int C) {
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 31, kh = lane >> 5;
@@ -92,6 +94,26 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < 16; ++j) zr[j] = zi[j] = 0.f;
     for (int h = 0; h < H; ++h) {  // product of the children: complex addition in log space
+      if (table != nullptr) {
+        // the children are Embedding folds: rows of the REAL weight table (F0, C+1, 32) gathered by the batch
+        // values and mapped to the complex-log semiring on the fly, z = (log|w|, pi if w < 0)
+        // (TorchEmbeddingLayer.forward input.py:258-266, csafelog utils.py:32-50) -- as ck_embedding_clog_fwd
+        const int64_t e = static_cast<int64_t>(f) * H + h;
+        const int xv = xt[static_cast<int64_t>(child_var[e]) * B + bl];
+        const int c = xv < 0 ? C : min(xv, C - 1);
+        const float* src = table + (static_cast<int64_t>(child_fold[e]) * (C + 1) + c) * kK + 4 * kh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 w4 = *reinterpret_cast<const float4*>(src + 8 * g);
+          const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            zr[4 * g + t] += logf(fabsf(wv[t]));
+            zi[4 * g + t] += wv[t] < 0.f ? 3.14159265358979323846f : 0.f;
+          }
+        }
+        continue;
+      }
       const float* src = reinterpret_cast<const float*>(arena + ro[h] + static_cast<int64_t>(bl) * kK + 4 * kh);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // units 8g + 4kh + t: four (re, im) pairs = two float4
@@ -577,12 +599,34 @@ int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* 
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
     return ck::dispatch(
         [=](hipStream_t s) {
-          hipLaunchKernelGGL(sum_clse_tile32, grid, block, 0, s, a, row_off, w, o, H, B, tpw);
+          hipLaunchKernelGGL(sum_clse_tile32, grid, block, 0, s, a, row_off, w, o, H, B, tpw, static_cast<const float*>(nullptr),
+                             static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr),
+                             static_cast<const int32_t*>(nullptr), 0);
           return hipGetLastError();
         },
         stream);
   }
   return launch_generic<c32, float>(a, row_off, w, o, F, H, B, Ki, Ko, mode, stream);
+}
+
+int ck_sum_clse_gather_fwd(const float* table, const int32_t* xt, const int32_t* child_fold, const int32_t* child_var,
+                           const float* w, float* out_c, int F, int H, int B, int C, void* stream) {
+  CK_REQUIRE(table && xt && child_fold && child_var && w && out_c, "ck_sum_clse_gather_fwd: null pointer");
+  CK_REQUIRE(F > 0 && H > 0 && B > 0 && C > 0, "ck_sum_clse_gather_fwd: non-positive size");
+  CK_REQUIRE(F <= 65535, "ck_sum_clse_gather_fwd: F=%d exceeds grid.y", F);
+  CK_REQUIRE(ck::aligned16(table) && ck::aligned16(w) && ck::aligned16(out_c), "ck_sum_clse_gather_fwd: buffers must be 16-byte aligned");
+  const int tiles = (B + 31) / 32;
+  int tpw = 1;
+  while (tpw < 4 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
+  dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
+  c32* o = reinterpret_cast<c32*>(out_c);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(sum_clse_tile32, grid, block, 0, s, static_cast<const c32*>(nullptr),
+                           static_cast<const int64_t*>(nullptr), w, o, H, B, tpw, table, child_fold, child_var, xt, C);
+        return hipGetLastError();
+      },
+      stream);
 }
 
 int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* mw, float* out,

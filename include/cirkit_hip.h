@@ -129,6 +129,14 @@ int ck_debug_force_generic(int on);
 int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w, float* out_c,
                      int F, int H, int B, int Ki, int Ko, int mode, int w_is_complex, void* stream);
 
+/* complex-lse-sum CP-T / dense layer (32 -> 32 units, real weights) whose children are folds of an Embedding
+ * layer: their rows are gathered from the layer's REAL weight table (F0, C+1, 32) (the table of
+ * ck_embedding_clog_fwd) by the batch values and mapped to (log|w|, pi if w < 0) on the fly, instead of
+ * reading a materialised (F0, B, 32) complex output.
+ * child_fold / child_var: (F, H) int32 -- table fold and variable of every child; xt: (D, B) staged batch. */
+int ck_sum_clse_gather_fwd(const float* table, const int32_t* xt, const int32_t* child_fold, const int32_t* child_var,
+                           const float* w, float* out_c, int F, int H, int B, int C, void* stream);
+
 /* Mixing layer = TorchSumLayer whose weight is TorchMixingWeightParameter (nodes.py:847-862):
  * out[f,b,k] = log(sum_h mw[f,k,h] * exp(x[f,h,b,k] - m)) + m,  m = max over all (h,k) of the row.
  * The (K, H*K) block-diagonal weight is never materialised.  mw: (F, K, H). */
