@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256)
           const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            zr[4 * g + t] += logf(fabsf(wv[t]));
+            zr[4 * g + t] += __builtin_amdgcn_logf(fabsf(wv[t])) * kLN2;
             zi[4 * g + t] += wv[t] < 0.f ? 3.14159265358979323846f : 0.f;
           }
         }
