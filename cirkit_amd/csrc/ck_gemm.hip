@@ -101,6 +101,213 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Tucker layer of arity 2 (TorchTuckerLayer, inner.py:359-420: einsum "fbi,fbj,foij->fbo" between the exp and
+// the log): per fold a (B x Ki^2) . (Ki^2 x Ko) product whose left operand is the outer product
+// e_l (x) e_r of the two exponentiated children.  The outer product is never materialised: a wave keeps
+// e_r of its 32 rows as a register tile, reads e_l[b, i] from LDS, and forms e_l[b, i] * e_r[b, j] with one
+// multiply per MFMA operand.  The (Ko, Ki^2) weight matrix (1 MiB per fold at K = 64 -- the dominant
+// traffic at small batches) is streamed once per workgroup through two LDS buffers, CI left indices i
+// and NB blocks of 32 outputs at a time, and shared by the four waves.
+// NK = Ki / 32, NB = blocks of 32 outputs accumulated together (independent MFMA chains).
+// SPLIT = false: the four waves are four tiles of 32 rows and every wave contracts the whole chunk.
+// SPLIT = true (few folds x rows: the launch would not fill the chip and its time is the serial length of ONE
+//   workgroup): the four waves share ONE tile of 32 rows, wave w contracts left index i0 + w of every chunk, and the
+//   four partial sums are added through LDS in a fixed order -- a quarter of the serial length, 4x the workgroups.
+// Ko need not be a multiple of 32 (the root layer has Ko = 1): rows >= Ko of the last block are staged as zeros.
+template <int NK, int NB, bool SPLIT>
+__global__ void __launch_bounds__(256)
+    tucker_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off, const float* __restrict__ w,
+                      float* __restrict__ out, int F, int B, int Ko, int gx, int gsplit) {
+  constexpr int Ki = 32 * NK;
+  constexpr int N = Ki * Ki;
+  constexpr int CI = SPLIT ? 4 : (NK == 1 ? 2 : 1);   // left indices per staged chunk
+  constexpr int CHUNK = CI * NB * NK * 1024;          // floats per buffer
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w_s = smem;                                  // [2][CI][NB][NK][4][64] float4
+  float* el_s = smem + 2 * CHUNK;                     // [4 waves][Ki][32]
+  float* red_s = el_s + 4 * Ki * 32;                  // SPLIT: [4 waves][NB][16][64] partial sums
+  // XCD-aware mapping (consecutive workgroup ids go to consecutive XCDs): every workgroup of one fold -- its
+  // row tiles and output splits -- gets the same id % 8, so the fold's weights are fetched into ONE XCD's L2.
+  const int xcd = blockIdx.x & 7, i_in = blockIdx.x >> 3;
+  const int per_fold = gx * gsplit;
+  const int f = (i_in / per_fold) * 8 + xcd;
+  if (f >= F) return;
+  const int tg = i_in % per_fold, tx = tg % gx, z = tg / gx;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int b = (SPLIT ? tx : tx * 4 + wave) * 32 + b_in;
+  const bool live = b < B;
+  const int bl = live ? b : B - 1;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * 2;
+  const int nblocks = (Ko + 31) / 32;
+  const int ngroups = nblocks / NB / gsplit;          // groups of NB output blocks handled by this workgroup
+  const int nchunks = ngroups * (Ki / CI);
+  const int o_base = z * ngroups * 32 * NB;           // first output of this workgroup
+  const float* wf = w + static_cast<int64_t>(f) * Ko * N;
+
+  // chunk c = (output group, left indices i0 .. i0 + CI - 1).  Its weights travel global -> registers one
+  // iteration ahead of the registers -> LDS copy, so the HBM latency is covered by a whole chunk of MFMAs.
+  // 4 consecutive threads read 64 contiguous bytes of one weight row; 16 rows per 64 threads.
+  constexpr int PF = CHUNK / 4 / 256;
+  float4 pre[PF];
+  auto fetch = [&](int c) {
+    const int grp = c / (Ki / CI), i0 = (c % (Ki / CI)) * CI;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int idx = threadIdx.x + 256 * k;
+      const int c4 = ((idx >> 6) % (2 * NK)) * 4 + (idx & 3);
+      const int rest = (idx >> 6) / (2 * NK);
+      const int o = o_base + 32 * NB * grp + (rest % (2 * NB)) * 16 + ((idx >> 2) & 15);
+      const int ci = rest / (2 * NB);
+      pre[k] = o < Ko ? *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o) * N + (i0 + ci) * Ki + 4 * c4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&](int buf) {
+    float* dst = w_s + buf * CHUNK;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int idx = threadIdx.x + 256 * k;
+      const int c4 = ((idx >> 6) % (2 * NK)) * 4 + (idx & 3);
+      const int rest = (idx >> 6) / (2 * NK);
+      const int o = (rest % (2 * NB)) * 16 + ((idx >> 2) & 15);
+      const int ci = rest / (2 * NB);
+      const int col = 4 * c4, q = col >> 5, g = (col >> 3) & 3, k2 = (col >> 2) & 1;
+      *reinterpret_cast<float4*>(dst + ((((ci * NB + (o >> 5)) * NK + q) * 4 + g) * 64 + (o & 31) + 32 * k2) * 4) = pre[k];
+    }
+  };
+  fetch(0);
+
+  // exponentiated children: e_r as a register tile, e_l through LDS (read back by left index)
+  float er[NK][16];
+  float m;
+  {
+    float el[NK][16];
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+      tile_load(arena + ro[0] + static_cast<int64_t>(bl) * Ki + 32 * q + 4 * kh, el[q]);
+      tile_load(arena + ro[1] + static_cast<int64_t>(bl) * Ki + 32 * q + 4 * kh, er[q]);
+    }
+    float ml = el[0][0], mr = er[0][0];
+#pragma unroll
+    for (int q = 0; q < NK; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        ml = fmaxf(ml, el[q][j]);
+        mr = fmaxf(mr, er[q][j]);
+      }
+    ml = ck::clamp_finite(fmaxf(ml, __shfl_xor(ml, 32, 64)));
+    mr = ck::clamp_finite(fmaxf(mr, __shfl_xor(mr, 32, 64)));
+    const float nl = exp_offset(ml, 0.f), nr = exp_offset(mr, 0.f);
+    float* eb = el_s + wave * (Ki * 32) + b_in;
+#pragma unroll
+    for (int q = 0; q < NK; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        er[q][j] = __builtin_amdgcn_exp2f(fmaf(er[q][j], kL2E, nr));
+        eb[(32 * q + 8 * (j >> 2) + 4 * kh + (j & 3)) * 32] = __builtin_amdgcn_exp2f(fmaf(el[q][j], kL2E, nl));
+      }
+    m = ml + mr;
+  }
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+  const float* el_w = el_s + wave * (Ki * 32) + b_in;
+  float* dst = out + (static_cast<int64_t>(f) * B + bl) * Ko;
+  commit(0);
+  if (nchunks > 1) fetch(1);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();  // chunk c (and, the first time, e_l) is in LDS; every wave has left chunk c - 1
+    if (c + 1 < nchunks) commit((c + 1) & 1);
+    if (c + 2 < nchunks) fetch(c + 2);
+    const float* wb = w_s + (c & 1) * CHUNK;
+    const int i0 = (c % (Ki / CI)) * CI;
+#pragma unroll
+    for (int cc = 0; cc < (SPLIT ? 1 : CI); ++cc) {
+      const int ci = SPLIT ? wave : cc;
+      const float eli = el_w[(i0 + ci) * 32];
+#pragma unroll
+      for (int q = 0; q < NK; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 w4[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            w4[nb] = *reinterpret_cast<const float4*>(wb + ((((ci * NB + nb) * NK + q) * 4 + g) * 64 + lane) * 4);
+          const float p0 = eli * er[q][4 * g + 0], p1 = eli * er[q][4 * g + 1];
+          const float p2 = eli * er[q][4 * g + 2], p3 = eli * er[q][4 * g + 3];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[nb].x, p0, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[nb].y, p1, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[nb].z, p2, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[nb].w, p3, acc[nb], 0, 0, 0);
+        }
+    }
+    if (i0 + CI == Ki) {  // the output group is complete
+      const int grp = c / (Ki / CI);
+      if constexpr (SPLIT) {  // add the four partial sums (fixed order), wave 0 writes the result
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red_s[((wave * NB + nb) * 16 + r) * 64 + lane] = acc[nb][r];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[nb][r] = (red_s[((0 * NB + nb) * 16 + r) * 64 + lane] + red_s[((1 * NB + nb) * 16 + r) * 64 + lane]) +
+                           (red_s[((2 * NB + nb) * 16 + r) * 64 + lane] + red_s[((3 * NB + nb) * 16 + r) * 64 + lane]);
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int o0 = o_base + 32 * (NB * grp + nb) + 4 * kh;
+        if (live && (!SPLIT || wave == 0)) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float o4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o4[t] = fmaf(__builtin_amdgcn_logf(acc[nb][4 * g + t]), kLN2, m);
+            if ((Ko & 31) == 0) {
+              *reinterpret_cast<float4*>(dst + o0 + 8 * g) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            } else {
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                if (o0 + 8 * g + t < Ko) dst[o0 + 8 * g + t] = o4[t];
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+      }
+    }
+  }
+}
+
+template <int NK, int NB, bool SPLIT>
+hipError_t launch_tucker(hipStream_t s, const float* arena, const int64_t* row_off, const float* w, float* out, int F,
+                         int B, int Ko, int gx, int gsplit) {
+  constexpr int CI = SPLIT ? 4 : (NK == 1 ? 2 : 1);
+  const size_t lds = (2 * CI * NB * NK * 1024 + 4 * 32 * NK * 32 + (SPLIT ? 4 * NB * 1024 : 0)) * sizeof(float);
+  auto kern = tucker_lse_kernel<NK, NB, SPLIT>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
+  const dim3 grid(static_cast<unsigned>((F + 7) / 8 * 8 * gx * gsplit));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, arena, row_off, w, out, F, B, Ko, gx, gsplit);
+  return hipGetLastError();
+}
+
 template <int NQ>
 hipError_t launch_nq(bool cat, dim3 grid, size_t lds, hipStream_t s, const float* arena, const int64_t* row_off,
                      const float* w, float* out, int H, int B, int Ki, int Ko) {
@@ -124,6 +331,31 @@ bool gemm_applies(int H, int Ki, int Ko, int mode) {
   const bool cat = mode == CK_SUM_CAT && H > 1;
   const int n = cat ? H * Ki : Ki;
   return (mode == CK_SUM_CAT || mode == CK_SUM_PROD) && Ki % 32 == 0 && Ko % 32 == 0 && n / 32 >= 1 && n / 32 <= 8;
+}
+
+bool tucker_applies(int H, int Ki, int Ko, int mode) { return mode == CK_SUM_KRON && H == 2 && (Ki == 32 || Ki == 64); }
+
+// Tucker layer of arity 2 with 32 or 64 units per child.
+int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int B, int Ki, int Ko,
+               void* stream) {
+  const int tiles = (B + 31) / 32, nblocks = (Ko + 31) / 32;
+  // Many workgroups: two blocks of outputs share every e_l * e_r product.  Fewer: one block per workgroup, so that a
+  // fold's work is spread over Ko / 32 workgroups.  Fewer than the chip has CUs: the waves of a workgroup split the
+  // contraction instead of the rows (SPLIT).
+  const int64_t wg1 = static_cast<int64_t>(F) * ((tiles + 3) / 4) * nblocks;  // workgroups at one block each
+  const bool two = nblocks % 2 == 0 && wg1 > 4096;
+  const bool split = wg1 <= 128;
+  const int gx = split ? tiles : (tiles + 3) / 4;
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (two) return Ki == 32 ? launch_tucker<1, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1)
+                                 : launch_tucker<2, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1);
+        if (split) return Ki == 32 ? launch_tucker<1, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks)
+                                   : launch_tucker<2, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks);
+        return Ki == 32 ? launch_tucker<1, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks)
+                        : launch_tucker<2, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks);
+      },
+      stream);
 }
 
 // Real dense / CP-T layer with Ki, Ko multiples of 32 and at most 256 contracted inputs.

@@ -23,6 +23,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ck_cp.hip: one dense / CP-T slot with contiguous (F, K, K) weights, K in {32, 64}.
 // ck_gemm.hip: dense / CP-T layers with Ki, Ko multiples of 32 and up to 256 contracted inputs.
 bool gemm_applies(int H, int Ki, int Ko, int mode);
+bool tucker_applies(int H, int Ki, int Ko, int mode);
+int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int B, int Ki, int Ko,
+               void* stream);
 int sum_lse_gemm(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int Ki,
                  int Ko, int mode, void* stream);
 int cat_dense(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,

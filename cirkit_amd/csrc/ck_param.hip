@@ -617,6 +617,73 @@ unsigned grid1d(int64_t n, int cap = 2048) {
   return static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, cap));
 }
 
+// Softmax over LONG rows (Tucker weights: Ki^2 = 1024 / 4096 entries per row): one wavefront per row, the row
+// held in registers between the single read and the single write (N4 float4 per lane, all loads in flight
+// at once), so the kernel moves 2 x 4 bytes per entry -- the row-at-a-time loop of softmax_job_rows
+// reads every row three times with one dependent load per pass.
+template <int N4>
+__global__ void __launch_bounds__(256) softmax_long_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int64_t rows, int len) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = len >> 2;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave; row < rows; row += static_cast<int64_t>(gridDim.x) * 4) {
+    const float4* src = reinterpret_cast<const float4*>(in + row * len);
+    float4 x[N4];
+#pragma unroll
+    for (int k = 0; k < N4; ++k) {
+      const int i = lane + 64 * k;
+      x[k] = i < n4 ? src[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < N4; ++k) mx = fmaxf(fmaxf(mx, fmaxf(x[k].x, x[k].y)), fmaxf(x[k].z, x[k].w));
+    mx = ck::wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < N4; ++k) {
+      x[k].x = __expf(x[k].x - mx);
+      x[k].y = __expf(x[k].y - mx);
+      x[k].z = __expf(x[k].z - mx);
+      x[k].w = __expf(x[k].w - mx);
+      sum += (x[k].x + x[k].y) + (x[k].z + x[k].w);
+    }
+    sum = ck::wave_sum(sum);
+    float4* dst = reinterpret_cast<float4*>(out + row * len);
+#pragma unroll
+    for (int k = 0; k < N4; ++k) {
+      const int i = lane + 64 * k;
+      if (i < n4) dst[i] = make_float4(x[k].x / sum, x[k].y / sum, x[k].z / sum, x[k].w / sum);
+    }
+  }
+}
+
+bool long_row_job(const ck_softmax_job& j) {
+  return j.kind == 0 && j.len >= 512 && j.len <= 4096 && j.len % 4 == 0 && ck::aligned16(j.in) && ck::aligned16(j.out);
+}
+
+int launch_long_rows(const ck_softmax_job& j, void* stream) {
+  const int n4 = (static_cast<int>(j.len) / 4 + 63) / 64;
+  const int64_t want = (j.rows + 3) / 4;
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>(want, 256 * 16))), block(256);
+  const float* in = j.in;
+  float* out = j.out;
+  const int64_t rows = j.rows;
+  const int len = static_cast<int>(j.len);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (n4 <= 2)
+          hipLaunchKernelGGL(softmax_long_rows_kernel<2>, grid, block, 0, s, in, out, rows, len);
+        else if (n4 <= 4)
+          hipLaunchKernelGGL(softmax_long_rows_kernel<4>, grid, block, 0, s, in, out, rows, len);
+        else if (n4 <= 8)
+          hipLaunchKernelGGL(softmax_long_rows_kernel<8>, grid, block, 0, s, in, out, rows, len);
+        else
+          hipLaunchKernelGGL(softmax_long_rows_kernel<16>, grid, block, 0, s, in, out, rows, len);
+        return hipGetLastError();
+      },
+      stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -739,6 +806,9 @@ int ck_param_table_integral_row(float* table, int F, int C, int K, int mode, voi
 
 int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) {
   CK_REQUIRE(jobs != nullptr && njobs > 0, "ck_param_softmax_batch: no jobs");
+  for (int i = 0; i < njobs; ++i)
+    if (jobs[i].in && jobs[i].out && jobs[i].rows > 0 && long_row_job(jobs[i]))
+      if (int st = launch_long_rows(jobs[i], stream)) return st;
   for (int wide = 0; wide < 2; ++wide) {
     int start = 0;
     while (start < njobs) {
@@ -756,6 +826,7 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
                    "ck_param_softmax_batch: job %d (kind 4/5) needs k = 32 (kind 4: or 64) and in2", idx);
         CK_REQUIRE(j.kind != 5 || j.out2 != nullptr, "ck_param_softmax_batch: job %d (kind 5) needs out2", idx);
         if ((j.kind == 4 && j.k == 64) != (wide == 1)) continue;  // the other pass takes it
+        if (long_row_job(j)) continue;                             // done by softmax_long_rows_kernel
         j.block_begin = blocks;
         if (j.kind != 1 && j.kind < 4) {
           blocks += static_cast<int>((j.rows + 16 * kPW - 1) / (16 * kPW));

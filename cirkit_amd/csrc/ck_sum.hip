@@ -581,6 +581,8 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
     return ck::cat_dense(arena, row_off, w, out, F, H, B, Ki, stream);  // ck_cp.hip
   if (!g_force_generic && ck::gemm_applies(H, Ki, Ko, mode) && ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out))
     return ck::sum_lse_gemm(arena, row_off, w, out, F, H, B, Ki, Ko, mode, stream);  // ck_gemm.hip
+  if (!g_force_generic && ck::tucker_applies(H, Ki, Ko, mode) && ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out))
+    return ck::tucker_lse(arena, row_off, w, out, F, B, Ki, Ko, stream);  // ck_gemm.hip
   return launch_generic<float, float>(arena, row_off, w, out, F, H, B, Ki, Ko, mode, stream);
 }
 

@@ -32,11 +32,15 @@ with torch.cuda.stream(s):
     torch.cuda.synchronize()
     ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
     rows = hc.profile_kernels(x, iters=3)
+if os.environ.get("ROWS"):
+    for r, l in ((r, plan.layers[r["layer"]]) for r in rows):
+        print(f"  layer {r['layer']:3d} {l.type:10s} F={l.num_folds:5d} H={l.arity} {l.num_input_units}->{l.num_output_units}  {r['kernel']:40s} {r['ms']:.4f} ms")
 agg = {}
 for r in rows:
     agg[r["kernel"]] = agg.get(r["kernel"], 0.0) + r["ms"]
 alg = plan.algorithmic_bytes(B)["total"]
-flops = sum(2.0 * l.num_folds * B * l.num_output_units * l.num_input_units * (l.arity if l.type == "sum" else 1)
-            for l in plan.layers if l.type in ("sum", "cpt"))
+flops = sum(2.0 * l.num_folds * B * l.num_output_units *
+            (l.num_input_units ** l.arity if l.type == "tucker" else l.num_input_units * (l.arity if l.type == "sum" else 1))
+            for l in plan.layers if l.type in ("sum", "cpt", "tucker"))
 print(f"K={K} B={B} {rg} {sp}: {ms:.3f} ms  {B / ms * 1e3:.3e} evals/s  {alg / ms / 1e6:.0f} GB/s algorithmic  "
       f"{flops / ms / 1e9:.1f} TFLOP/s  kernels {dict(sorted(((k, round(v, 3)) for k, v in agg.items()), key=lambda kv: -kv[1])[:4])}")

@@ -79,7 +79,10 @@ def test_cpt_layer_contract(hip_device, F, H, B, Ki, Ko):
     _close(layer.forward(x.to(hip_device)), _oracle(spec, {"w": w}, x))
 
 
-@pytest.mark.parametrize("F,B,Ki,Ko,cplx", [(3, 37, 6, 5, False), (2, 9, 32, 32, False), (1, 5, 64, 8, False), (2, 7, 4, 3, True)])
+@pytest.mark.parametrize("F,B,Ki,Ko,cplx", [(3, 37, 6, 5, False), (2, 9, 32, 32, False), (1, 5, 64, 8, False), (2, 7, 4, 3, True),
+                                            (3, 130, 32, 64, False), (2, 70, 64, 64, False), (2, 33, 64, 32, False),
+                                            (1, 40, 32, 96, False), (1, 129, 64, 128, False), (2, 128, 64, 1, False),
+                                            (40, 300, 32, 64, False), (70, 700, 64, 64, False), (5, 50, 32, 10, False), (520, 512, 32, 64, False)])
 def test_tucker_layer_contract(hip_device, F, B, Ki, Ko, cplx):
     from cirkit_amd.layers import HipTuckerLayer
     from cirkit_amd.parameters import TensorStore
