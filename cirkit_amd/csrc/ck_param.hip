@@ -198,10 +198,59 @@ struct JobTable {
 // separated by barriers, so its latency -- which IS the kernel time when all folds run at once -- scales
 // is not simply shorter with more waves (measured on config 2: 2 waves 39 us, 4 waves 29 us, 8 waves 38 us, 16 waves 60 us)
 constexpr int kPW = 4;
+// the 64-unit table jobs (WIDE launch): 83 KB of LDS allow one workgroup per CU, so the workgroup itself has to
+// supply the parallelism -- 9 category tiles, 64 weight rows and 64 statistics rows over 8 waves
+constexpr int kPW64 = 8;
+
+// Rows of 33..256 entries (kind 0): NE entries per lane (lane, lane + 64, ...), 16 / NE rows of a wave in flight
+// at once.  Same arithmetic, in the same order, as the row-at-a-time loop at the end of softmax_job_rows
+// (per-lane partial results in entry order, then the wave reduction) -- only the loads are issued up front.
+template <int NE>
+__device__ __forceinline__ void softmax_rows_medium(const ck_softmax_job& j, int blk) {
+  constexpr int RB = 16 / NE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int len = j.len;
+  for (int it0 = 0; it0 < 16; it0 += RB) {
+    float x[RB][NE];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int64_t row = static_cast<int64_t>(blk) * (16 * kPW) + (it0 + r) * kPW + wave;
+#pragma unroll
+      for (int k = 0; k < NE; ++k)
+        x[r][k] = (row < j.rows && lane + 64 * k < len) ? j.in[row * len + lane + 64 * k] : -INFINITY;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int64_t row = static_cast<int64_t>(blk) * (16 * kPW) + (it0 + r) * kPW + wave;
+      if (row >= j.rows) continue;
+      float mx = x[r][0];
+#pragma unroll
+      for (int k = 1; k < NE; ++k) mx = fmaxf(mx, x[r][k]);
+      mx = ck::wave_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NE; ++k)
+        if (lane + 64 * k < len) sum += __expf(x[r][k] - mx);
+      sum = ck::wave_sum(sum);
+#pragma unroll
+      for (int k = 0; k < NE; ++k)
+        if (lane + 64 * k < len) j.out[row * len + lane + 64 * k] = __expf(x[r][k] - mx) / sum;
+    }
+  }
+}
 
 __device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int blk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int len = j.len;
+  if (j.kind == 0 && len > 32 && len <= 256) {
+    if (len <= 64)
+      softmax_rows_medium<1>(j, blk);
+    else if (len <= 128)
+      softmax_rows_medium<2>(j, blk);
+    else
+      softmax_rows_medium<4>(j, blk);
+    return;
+  }
   if (len <= 32) {
     // two rows per wave pass (one per 32-lane half); 16 rows per wave and block; all loads issued up front
     const int half = lane >> 5, l = lane & 31;
@@ -486,39 +535,101 @@ __device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& 
   const float* src = j.in + f * K * C;
   float* stat = tile + K * ld;  // [K] max, [K] log-sum
   float* w_s = stat + 2 * K;    // [p][q][g][lane][4] linear weights of dense fold d
-  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
-    const int k = i / C, c = i - k * C;
-    tile[k * ld + c] = src[i];
+  // every global load of the job is issued before the first use: the (K, C) logits as 16-byte loads and the
+  // K / kPW64 weight rows of this wave (the job's latency is the kernel time, see kPW)
+  const float* th = j.in2 + static_cast<int64_t>(d) * (K * K);
+  float wx[K / kPW64];
+#pragma unroll
+  for (int r = 0; r < K / kPW64; ++r) wx[r] = th[(wave + kPW64 * r) * K + lane];
+  if ((C & 3) == 0) {
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    const int n4 = (K * C) >> 2;
+    for (int base = threadIdx.x; base < n4; base += 8 * kPW64 * 64) {  // 8 loads in flight per thread
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * (kPW64 * 64);
+        if (i < n4) v[u] = src4[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * (kPW64 * 64);
+        if (i < n4) {
+          const int e = i << 2, k = e / C, c = e - k * C;
+          float* dd = tile + k * ld + c;
+          dd[0] = v[u].x;
+          dd[1] = v[u].y;
+          dd[2] = v[u].z;
+          dd[3] = v[u].w;
+        }
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+      const int k = i / C, c = i - k * C;
+      tile[k * ld + c] = src[i];
+    }
   }
-  {
-    const float* th = j.in2 + static_cast<int64_t>(d) * (K * K);
-    for (int o = wave; o < K; o += kPW) {
-      const float x = th[o * K + lane];
-      const float mx = ck::wave_max(x);
-      const float e = __expf(x - mx);
-      const float sum = ck::wave_sum(e);
+  {  // the rows of this wave are reduced together, so that the shuffle steps of different rows overlap
+    constexpr int R = K / kPW64;
+    float mx[R], e[R], sum[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mx[r] = wx[r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < R; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum[r] = e[r] = __expf(wx[r] - mx[r]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < R; ++r) sum[r] += __shfl_xor(sum[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int o = wave + kPW64 * r;
       const int k = lane, p = o >> 5, q = k >> 5, g = (k >> 3) & 3, ln = (o & 31) + 32 * ((k >> 2) & 1);
-      w_s[((((p * NK + q) * 4 + g) * 64) + ln) * 4 + (k & 3)] = e / sum;
+      w_s[((((p * NK + q) * 4 + g) * 64) + ln) * 4 + (k & 3)] = e[r] / sum[r];
     }
   }
   __syncthreads();
-  for (int k = wave; k < K; k += kPW) {  // per-unit max and log-sum-exp over the categories
-    const float* row = tile + k * ld;
-    float m = -INFINITY;
-    for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
-    m = ck::wave_max(m);
-    float sacc = 0.f;
-    for (int c = lane; c < C; c += 64) sacc += __expf(row[c] - m);
-    sacc = ck::wave_sum(sacc);
+  {  // per-unit max and log-sum-exp over the categories, K / kPW64 units per wave, reduced together
+    constexpr int R = K / kPW64;
+    float mx[R], sum[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float* row = tile + (wave + kPW64 * r) * ld;
+      float m = -INFINITY;
+      for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+      mx[r] = m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < R; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float* row = tile + (wave + kPW64 * r) * ld;
+      float sacc = 0.f;
+      for (int c = lane; c < C; c += 64) sacc += __expf(row[c] - mx[r]);
+      sum[r] = sacc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < R; ++r) sum[r] += __shfl_xor(sum[r], o, 64);
     if (lane == 0) {
-      stat[k] = m;
-      stat[K + k] = __logf(sacc);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        stat[wave + kPW64 * r] = mx[r];
+        stat[K + wave + kPW64 * r] = __logf(sum[r]);
+      }
     }
   }
   __syncthreads();
   const int b_in = lane & 31, kh = lane >> 5;
   float* dst = j.out + static_cast<int64_t>(d) * (C + 1) * K;
-  for (int t = wave; t * 32 <= C; t += kPW) {
+  for (int t = wave; t * 32 <= C; t += kPW64) {
     const int c = t * 32 + b_in;
     const int cl = min(c, C - 1);
     float v[NK][16];
@@ -574,7 +685,7 @@ __device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& 
 // WIDE: the launch that carries the 64-unit table jobs -- kept apart so that their two-block tile does not set
 // the register budget (and with it the occupancy) of every other job
 template <bool WIDE>
-__global__ void __launch_bounds__(kPW * 64) softmax_batch_kernel(const JobTable t) {
+__global__ void __launch_bounds__((WIDE ? kPW64 : kPW) * 64) softmax_batch_kernel(const JobTable t) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   const int bid = blockIdx.x;
   int ji = 0;
@@ -841,7 +952,7 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
         t.job[t.n++] = j;
       }
       if (t.n == 0) continue;
-      const dim3 grid(blocks), block(kPW * 64);
+      const dim3 grid(blocks), block((wide ? kPW64 : kPW) * 64);
       int st = ck::dispatch(
           [=](hipStream_t s) {
             auto go = [&](auto kern) {
