@@ -865,6 +865,10 @@ class HipCircuit:
             n = l.num_input_units * (l.arity if cat else 1)
             if l.num_input_units % 32 == 0 and l.num_output_units % 32 == 0 and 32 <= n <= 256:
                 return f"sum_lse_gemm_kernel<{n // 32}, {'true' if cat else 'false'}>"
+            if l.num_input_units % 32 == 0 and l.num_output_units % 32 == 0 and (
+                    (256 < n <= 512 and n % 64 == 0) or n in (768, 1024)):
+                sp = 2 if n <= 512 else 4
+                return f"sum_lse_gemm_split_kernel<{n // 32 // sp}, {sp}, {'true' if cat else 'false'}>"
         if not self._complex and s.type == "tucker" and l.arity == 2 and l.num_input_units in (32, 64):
             return f"tucker_lse_kernel<{l.num_input_units // 32}>"
         return "sum_lse_generic"

@@ -34,15 +34,29 @@ __global__ void __launch_bounds__(256)
   const float* wf = w + static_cast<int64_t>(f) * Ko * N;
   const int npb = Ko >> 5;  // output blocks
 
-  auto stage = [&](int p, int buf) {  // rows 32p .. 32p+31 of the (Ko, N) matrix -> operand layout
-    float* dst = w_s + buf * (NQ * 1024);
-    for (int i = threadIdx.x; i < NQ * 256; i += 256) {
+  // rows 32p .. 32p+31 of the (Ko, N) matrix -> operand layout; global -> registers one block ahead of the
+  // registers -> LDS copy, so that the load latency is covered by a whole block of MFMAs
+  float pre[NQ][4];
+  auto fetch = [&](int p) {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int i = threadIdx.x + 256 * k;
       const int ln = i & 63, g = (i >> 6) & 3, q = i >> 8;
-      *reinterpret_cast<float4*>(dst + 4 * i) = *reinterpret_cast<const float4*>(
-          wf + static_cast<int64_t>(32 * p + (ln & 31)) * N + 32 * q + 8 * g + 4 * (ln >> 5));
+      const float4 v = *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(32 * p + (ln & 31)) * N + 32 * q +
+                                                        8 * g + 4 * (ln >> 5));
+      pre[k][0] = v.x;
+      pre[k][1] = v.y;
+      pre[k][2] = v.z;
+      pre[k][3] = v.w;
     }
   };
-  stage(0, 0);
+  auto commit = [&](int buf) {
+    float* dst = w_s + buf * (NQ * 1024);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+      *reinterpret_cast<float4*>(dst + 4 * (threadIdx.x + 256 * k)) = make_float4(pre[k][0], pre[k][1], pre[k][2], pre[k][3]);
+  };
+  fetch(0);
 
   float e[NQ][16];
   if (CAT) {
@@ -70,9 +84,12 @@ __global__ void __launch_bounds__(256)
     for (int j = 0; j < 16; ++j) e[q][j] = __builtin_amdgcn_exp2f(fmaf(e[q][j], kL2E, nml));
 
   float* dst = out + (static_cast<int64_t>(f) * B + bl) * Ko + 4 * kh;
+  commit(0);
+  fetch(npb > 1 ? 1 : 0);
   for (int p = 0; p < npb; ++p) {
     __syncthreads();  // block p is staged; every wave has left the contraction of block p - 1
-    if (p + 1 < npb) stage(p + 1, (p + 1) & 1);
+    if (p + 1 < npb) commit((p + 1) & 1);
+    fetch(p + 2 < npb ? p + 2 : npb - 1);  // (the last two fetches are redundant re-reads, never committed)
     const float* wb = w_s + (p & 1) * (NQ * 1024);
     f32x16 acc;
 #pragma unroll
@@ -99,6 +116,167 @@ __global__ void __launch_bounds__(256)
       }
     }
   }
+}
+
+// The same layer with 257..1024 contracted inputs: the exponentiated row block no longer fits the registers of one
+// wave, so S waves share a tile of 32 rows and each keeps 1 / S of the inputs (NQ blocks of 32).  Per block of 32
+// outputs every wave contracts its inputs against its slice of the weight rows and the S partial sums are added
+// through LDS in a fixed order.  Weights travel global -> registers -> LDS one step ahead of their use (steps of
+// QS input blocks per wave, two LDS buffers), as in the Tucker kernel below.
+template <int NQ, int S, bool CAT>
+__global__ void __launch_bounds__(256)
+    sum_lse_gemm_split_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
+                              const float* __restrict__ w, float* __restrict__ out, int H, int B, int Ki, int Ko) {
+  constexpr int N = 32 * NQ * S;
+  constexpr int R = 4 / S;                                    // row tiles per workgroup
+  constexpr int QS = S == 4 ? 2 : (NQ % 2 == 0 ? NQ / 2 : NQ);  // input blocks per wave and step
+  constexpr int STEPS = NQ / QS;
+  constexpr int CHUNK = S * QS * 1024;                        // floats per buffer
+  constexpr int PF = CHUNK / 4 / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w_s = smem;                    // [2][S][QS][4][64] float4
+  float* red_s = smem + 2 * CHUNK;      // [4 waves][16][64] partial sums; first used for the row maxima
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rt = wave / S, sp = wave % S;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int b = (blockIdx.x * R + rt) * 32 + b_in;
+  const bool live = b < B;
+  const int bl = live ? b : B - 1;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const float* wf = w + static_cast<int64_t>(f) * Ko * N;
+  const int nsteps = (Ko >> 5) * STEPS;
+
+  float pre[PF][4];  // (a float4 array copied whole stays in scratch memory: SROA does not split it)
+  auto fetch = [&](int c) {  // step c = (output block p, input blocks h * QS .. of every wave)
+    const int p = c / STEPS, h = c % STEPS;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int ln = i & 63, g = (i >> 6) & 3, qq = (i >> 8) % QS, s2 = (i >> 8) / QS;
+      const float4 v = *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(32 * p + (ln & 31)) * N +
+                                                        32 * (s2 * NQ + h * QS + qq) + 8 * g + 4 * (ln >> 5));
+      pre[k][0] = v.x;
+      pre[k][1] = v.y;
+      pre[k][2] = v.z;
+      pre[k][3] = v.w;
+    }
+  };
+  auto commit = [&](int buf) {
+    float* dst = w_s + buf * CHUNK;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) *reinterpret_cast<float4*>(dst + 4 * (threadIdx.x + 256 * k)) = make_float4(pre[k][0], pre[k][1], pre[k][2], pre[k][3]);
+  };
+  fetch(0);
+
+  float e[NQ][16];
+  if (CAT) {
+    const int qpc = Ki >> 5;  // 32-unit blocks per child
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int Q = sp * NQ + q;
+      tile_load(arena + ro[Q / qpc] + static_cast<int64_t>(bl) * Ki + 32 * (Q % qpc) + 4 * kh, e[q]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) tile_load(arena + ro[0] + static_cast<int64_t>(bl) * Ki + 32 * (sp * NQ + q) + 4 * kh, e[q]);
+    for (int h = 1; h < H; ++h)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        tile_load_add(arena + ro[h] + static_cast<int64_t>(bl) * Ki + 32 * (sp * NQ + q) + 4 * kh, e[q]);
+  }
+  float m = e[0][0];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, e[q][j]);
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  red_s[wave * 64 + lane] = m;
+  __syncthreads();
+#pragma unroll
+  for (int s2 = 0; s2 < S; ++s2) m = fmaxf(m, red_s[(rt * S + s2) * 64 + lane]);
+  m = ck::clamp_finite(m);
+  const float nml = exp_offset(m, 0.f);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[q][j] = __builtin_amdgcn_exp2f(fmaf(e[q][j], kL2E, nml));
+  __syncthreads();  // the maxima have been read: red_s is free for the partial sums
+
+  float* dst = out + (static_cast<int64_t>(f) * B + bl) * Ko + 4 * kh;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  commit(0);
+  fetch(nsteps > 1 ? 1 : 0);
+  for (int c = 0; c < nsteps; ++c) {
+    __syncthreads();  // step c is in LDS; every wave has left step c - 1
+    if (c + 1 < nsteps) commit((c + 1) & 1);
+    fetch(c + 2 < nsteps ? c + 2 : nsteps - 1);  // (the last two fetches are redundant re-reads, never committed)
+    const float* wb = w_s + (c & 1) * CHUNK + sp * (QS * 1024);
+    const int h = c % STEPS;
+#pragma unroll
+    for (int hh = 0; hh < STEPS; ++hh)  // static register indices: the body of the taken h only
+      if (hh == h) {
+#pragma unroll
+        for (int qq = 0; qq < QS; ++qq)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wb + ((qq * 4 + g) * 64 + lane) * 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, e[hh * QS + qq][4 * g + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, e[hh * QS + qq][4 * g + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, e[hh * QS + qq][4 * g + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, e[hh * QS + qq][4 * g + 3], acc, 0, 0, 0);
+          }
+      }
+    if (h == STEPS - 1) {  // output block p is complete: add the S partial sums, wave 0 of the tile writes
+      const int p = c / STEPS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red_s[(wave * 16 + r) * 64 + lane] = acc[r];
+      __syncthreads();
+      if (sp == 0 && live) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float t = red_s[((rt * S) * 16 + r) * 64 + lane];
+#pragma unroll
+          for (int s2 = 1; s2 < S; ++s2) t += red_s[((rt * S + s2) * 16 + r) * 64 + lane];
+          acc[r] = t;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 o4;
+          o4.x = fmaf(__builtin_amdgcn_logf(acc[4 * g + 0]), kLN2, m);
+          o4.y = fmaf(__builtin_amdgcn_logf(acc[4 * g + 1]), kLN2, m);
+          o4.z = fmaf(__builtin_amdgcn_logf(acc[4 * g + 2]), kLN2, m);
+          o4.w = fmaf(__builtin_amdgcn_logf(acc[4 * g + 3]), kLN2, m);
+          *reinterpret_cast<float4*>(dst + 32 * p + 8 * g) = o4;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      // the barrier at the top of the next step separates these reads from the next writes of red_s: a wave
+      // reaches its next write only after a whole step, i.e. after that barrier
+    }
+  }
+}
+
+template <int NQ, int S>
+hipError_t launch_split(bool cat, hipStream_t s, const float* arena, const int64_t* row_off, const float* w, float* out,
+                        int F, int H, int B, int Ki, int Ko) {
+  constexpr int QS = S == 4 ? 2 : (NQ % 2 == 0 ? NQ / 2 : NQ);
+  const size_t lds = (2 * S * QS * 1024 + 4 * 16 * 64) * sizeof(float);
+  const int tiles = (B + 31) / 32, R = 4 / S;
+  const dim3 grid((tiles + R - 1) / R, F);
+  auto go = [&](auto kern) {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(lds));
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, arena, row_off, w, out, H, B, Ki, Ko);
+    return hipGetLastError();
+  };
+  return cat ? go(sum_lse_gemm_split_kernel<NQ, S, true>) : go(sum_lse_gemm_split_kernel<NQ, S, false>);
 }
 
 // Tucker layer of arity 2 (TorchTuckerLayer, inner.py:359-420: einsum "fbi,fbj,foij->fbo" between the exp and
@@ -330,7 +508,8 @@ namespace ck {
 bool gemm_applies(int H, int Ki, int Ko, int mode) {
   const bool cat = mode == CK_SUM_CAT && H > 1;
   const int n = cat ? H * Ki : Ki;
-  return (mode == CK_SUM_CAT || mode == CK_SUM_PROD) && Ki % 32 == 0 && Ko % 32 == 0 && n / 32 >= 1 && n / 32 <= 8;
+  if (!((mode == CK_SUM_CAT || mode == CK_SUM_PROD) && Ki % 32 == 0 && Ko % 32 == 0)) return false;
+  return (n >= 32 && n <= 256) || (n > 256 && n <= 512 && n % 64 == 0) || n == 768 || n == 1024;
 }
 
 bool tucker_applies(int H, int Ki, int Ko, int mode) { return mode == CK_SUM_KRON && H == 2 && (Ki == 32 || Ki == 64); }
@@ -358,11 +537,25 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
       stream);
 }
 
-// Real dense / CP-T layer with Ki, Ko multiples of 32 and at most 256 contracted inputs.
+// Real dense / CP-T layer with Ki, Ko multiples of 32 and at most 1024 contracted inputs.
 int sum_lse_gemm(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int Ki,
                  int Ko, int mode, void* stream) {
   const bool cat = mode == CK_SUM_CAT && H > 1;
   const int nq = (cat ? H * Ki : Ki) / 32;
+  if (nq > 8) {  // the inputs of a row tile are split over 2 or 4 waves
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          switch (nq) {
+            case 10: return launch_split<5, 2>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            case 12: return launch_split<6, 2>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            case 14: return launch_split<7, 2>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            case 16: return launch_split<8, 2>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            case 24: return launch_split<6, 4>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            default: return launch_split<8, 4>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+          }
+        },
+        stream);
+  }
   const size_t lds = static_cast<size_t>(2) * nq * 1024 * sizeof(float);
   const int tiles = (B + 31) / 32;
   dim3 grid((tiles + 3) / 4, F);

@@ -79,6 +79,26 @@ def test_cpt_layer_contract(hip_device, F, H, B, Ki, Ko):
     _close(layer.forward(x.to(hip_device)), _oracle(spec, {"w": w}, x))
 
 
+@pytest.mark.parametrize("F,H,B,Ki,Ko,typ", [(2, 2, 70, 512, 512, "cpt"), (1, 1, 33, 320, 64, "sum"), (2, 3, 40, 128, 96, "sum"),
+                                             (1, 2, 130, 448, 32, "cpt"), (1, 1, 64, 1024, 64, "sum"), (2, 2, 36, 384, 128, "sum"),
+                                             (1, 2, 50, 768, 32, "cpt"), (3, 1, 200, 512, 512, "sum")])
+def test_many_unit_layers(hip_device, F, H, B, Ki, Ko, typ):
+    """Dense / CP-T layers with 257..1024 contracted inputs (the row block is split over 2 or 4 waves)."""
+    from cirkit_amd.layers import HipCPTLayer, HipSumLayer
+    from cirkit_amd.parameters import TensorStore
+
+    g = torch.Generator().manual_seed(F * 1000 + H * 100 + Ki + Ko)
+    n = Ki if typ == "cpt" else H * Ki
+    w = torch.softmax(torch.randn(F, Ko, n, generator=g), dim=-1)
+    x = torch.randn(F, H, B, Ki, generator=g) * 4 - 6
+    store = TensorStore(hip_device)
+    p, pg = _pg(store, "w", w)
+    cls = HipCPTLayer if typ == "cpt" else HipSumLayer
+    layer = cls(Ki, Ko, H, weight=p, num_folds=F)
+    spec = LayerSpec(typ, F, H, Ki, Ko, dict(layer.config), {"weight": pg})
+    _close(layer.forward(x.to(hip_device)), _oracle(spec, {"w": w}, x))
+
+
 @pytest.mark.parametrize("F,B,Ki,Ko,cplx", [(3, 37, 6, 5, False), (2, 9, 32, 32, False), (1, 5, 64, 8, False), (2, 7, 4, 3, True),
                                             (3, 130, 32, 64, False), (2, 70, 64, 64, False), (2, 33, 64, 32, False),
                                             (1, 40, 32, 96, False), (1, 129, 64, 128, False), (2, 128, 64, 1, False),
