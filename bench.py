@@ -87,6 +87,20 @@ def other_configs(device, stream, B: int) -> dict:
         "hbm_roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "ms_partition_function": ms_z,
     }
+    del hc, hz
+    # The only forward timing the reference publishes (notebooks/compilation-options.ipynb:594):
+    # QuadGraph 28x28, Categorical-256, Tucker layers, K = 64, batch 128, fold + optimize: 38.6 ms on an unnamed
+    # CUDA GPU.  Different hardware and not the north-star metric, so it stays out of `vs_baseline`.
+    plan_nb = image_data((1, 28, 28), "quad-graph", input_layer="categorical", num_input_units=64,
+                         sum_product_layer="tucker", num_sum_units=64)
+    hc = HipCircuit(plan_nb, init_plan_tensors(plan_nb), device=device)
+    ms = time_forward(hc, torch.randint(0, 256, (128, 784), generator=g).to(device))
+    out["notebook_quadgraph_tucker_k64_b128"] = {
+        "workload": "QuadGraph 28x28, Categorical-256, Tucker, K=64, batch 128 (the reference's compilation-options "
+                    "notebook); Tucker layers on MFMA (cirkit_amd/csrc/ck_gemm.hip)",
+        "ms_per_forward": ms, "evals_per_s": 128 / ms * 1e3,
+        "reference_published_ms": 38.6, "reference_hardware": "unnamed CUDA GPU (notebook output)",
+    }
     return out
 
 

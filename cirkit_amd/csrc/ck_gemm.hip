@@ -279,7 +279,7 @@ hipError_t launch_split(bool cat, hipStream_t s, const float* arena, const int64
   return cat ? go(sum_lse_gemm_split_kernel<NQ, S, true>) : go(sum_lse_gemm_split_kernel<NQ, S, false>);
 }
 
-// Tucker layer of arity 2 (TorchTuckerLayer, inner.py:359-420: einsum "fbi,fbj,foij->fbo" between the exp and
+// Tucker layer of arity 2 (TorchTuckerLayer.forward, optimized.py:89-103: einsum "fbi,fbj,foij->fbo" between the exp and
 // the log): per fold a (B x Ki^2) . (Ki^2 x Ko) product whose left operand is the outer product
 // e_l (x) e_r of the two exponentiated children.  The outer product is never materialised: a wave keeps
 // e_r of its 32 rows as a register tile, reads e_l[b, i] from LDS, and forms e_l[b, i] * e_r[b, j] with one
