@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import _capi as capi
+from . import padding
 from .fusion import (CPBlock, RegionBlock, SubtreeGroup, find_cp_blocks, find_input_products, find_region_blocks,
                      find_subtree_groups, find_table_dense, find_tail)
 from .layers import HipConstantValueLayer, HipEmbeddingLayer, HipInputLayer, HipLayer, layer_from_spec
@@ -101,6 +102,7 @@ class HipCircuit:
         cache_params: bool = False,
         fuse_regions: bool = True,
         linear_levels: bool = True,
+        pad_units: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -108,6 +110,19 @@ class HipCircuit:
         if self.device.type != "cuda":
             raise capi.HipExtensionError("HipCircuit needs a ROCm device; there is no CPU fallback")
         capi.load()
+        # unit counts that are not multiples of 32 are padded (cirkit_amd/padding.py): same function, MFMA tiles
+        self.user_plan = plan
+        self._pad_info = None
+        if pad_units:
+            if isinstance(tensors, TensorStore):
+                hit = tensors._padded.get(id(plan))
+                if hit is not None:
+                    _, plan, self._pad_info = hit
+            else:
+                res = padding.pad_units(plan)
+                if res is not None:
+                    plan, self._pad_info = res
+                    tensors = padding.pad_tensors(self._pad_info, tensors)
         self.plan = plan
         self.use_graph = use_graph
         self.cache_params = bool(cache_params)
@@ -119,6 +134,9 @@ class HipCircuit:
         else:
             self.store = TensorStore(self.device)
             self.store.update(tensors)
+            if self._pad_info is not None:
+                self.store._pad = self._pad_info
+                self.store._padded[id(self.user_plan)] = (self.user_plan, plan, self._pad_info)
         missing = [k for k in plan.tensors if k not in self.store]
         if missing:
             raise ValueError(f"missing parameter tensors: {missing}")
@@ -791,6 +809,8 @@ class HipCircuit:
         else:
             y = torch.stack([bd.views[int(p)][int(f)] for p, f in pairs], dim=0)  # (O, B, K)
         y = y.transpose(0, 1)
+        if self._pad_info is not None and y.shape[-1] != self._pad_info.out_units:
+            y = y[..., : self._pad_info.out_units]
         if self.plan.num_variables == 0:
             y = y.squeeze(0)
         return y
@@ -801,6 +821,8 @@ class HipCircuit:
         views = list(self._run(x).views)
         for d in list(self._cp_leftover) + list(self._cp_subset):
             views[d] = None
+        if self._pad_info is not None:
+            views = [v if v is None else v[..., : s.num_output_units] for v, s in zip(views, self.user_plan.layers)]
         return views
 
     def log_likelihood_sum(self, x: torch.Tensor) -> torch.Tensor:

@@ -34,6 +34,10 @@ class TensorStore:
         self._t: dict[str, torch.Tensor] = {}
         self.version = 0  # bumps when a tensor OBJECT is replaced (recorded pointers go stale)
         self.data_version = 0  # bumps on every value change (derived-parameter caches go stale)
+        # set by a HipCircuit that padded its unit counts (cirkit_amd/padding.py): values arrive and leave in
+        # the shapes of the user's plan
+        self._pad = None
+        self._padded: dict[int, tuple] = {}  # id(user plan) -> (user plan, padded plan, PadInfo)
 
     def touch(self) -> None:
         """Record that tensor values were modified in place outside `set`."""
@@ -43,6 +47,10 @@ class TensorStore:
         if isinstance(value, np.ndarray):
             value = torch.from_numpy(np.ascontiguousarray(value))
         value = value.detach()
+        if self._pad is not None and name in self._pad.shapes:
+            old, new = self._pad.shapes[name]
+            if old != new and tuple(value.shape) == tuple(old):
+                value = torch.from_numpy(self._pad.pad(name, value.cpu().numpy()))
         self.data_version += 1
         if value.dtype not in (torch.float32, torch.complex64):
             value = value.to(torch.complex64 if value.is_complex() else torch.float32)
@@ -56,6 +64,13 @@ class TensorStore:
     def update(self, values: Mapping[str, object]) -> None:
         for k, v in values.items():
             self.set(k, v)
+
+    def export(self, name: str) -> np.ndarray:
+        """The value of a tensor in the shape of the user's plan (host copy)."""
+        v = self._t[name].detach().cpu().numpy()
+        if self._pad is not None and name in self._pad.shapes and self._pad.shapes[name][0] != self._pad.shapes[name][1]:
+            v = self._pad.unpad(name, v)
+        return v
 
     def __getitem__(self, name: str) -> torch.Tensor:
         return self._t[name]

@@ -47,7 +47,7 @@ class HipTrainer:
             raise ValueError(f"unknown optimizer {optimizer!r}")
         # layer-wise forward, every activation materialised, row-major linear weights
         self.circuit = HipCircuit(plan, tensors, device=device, use_graph=False, fuse=False,
-                                  batch_params=True, tiled_weights=False, dense_on_table=False)
+                                  batch_params=True, tiled_weights=False, dense_on_table=False, pad_units=False)
         self.plan, self.device = plan, self.circuit.device
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self.step_count = 0

@@ -478,3 +478,43 @@ def test_template_circuits_on_the_mfma_kernels(hip_device, rg, shape, sp, K, inp
     assert torch.allclose(y, y_ref, rtol=REL, atol=1e-4), float((y - y_ref).abs().max())
     y2 = HipCircuit(plan, tensors, device=hip_device, fuse=False)(x.to(hip_device)).cpu()
     assert torch.allclose(y2, y_ref, rtol=REL, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,K", [(dict(region_graph="quad-tree-2", sum_product_layer="cp"), 8),
+                                  (dict(region_graph="quad-graph", sum_product_layer="cp"), 20),
+                                  (dict(region_graph="quad-graph", sum_product_layer="tucker"), 12),
+                                  (dict(region_graph="poon-domingos", sum_product_layer="cp", input_layer="gaussian"), 48),
+                                  (dict(region_graph="quad-tree-2", sum_product_layer="cp", num_classes=10), 100)])
+def test_padded_units_match_oracle(hip_device, kw, K):
+    """Unit counts that are not multiples of 32 are padded to MFMA tiles (cirkit_amd/padding.py): same
+    log-likelihoods as the oracle on the user's plan and as the unpadded HIP path; parameter updates and
+    exports keep the user's shapes."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan = image_data((1, 8, 8), num_input_units=K, num_sum_units=K, **kw)
+    tensors = init_plan_tensors(plan)
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn((70, 64), generator=g) if kw.get("input_layer") == "gaussian" else torch.randint(0, 256, (70, 64), generator=g)
+    want = evaluate_plan(plan, as_torch(tensors), x)
+    hc = HipCircuit(plan, tensors, device=hip_device)
+    assert hc._pad_info is not None and all(l.num_output_units in (1, 32, 64, 128) for l in hc.plan.layers)
+    got = hc(x.to(hip_device)).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= REL * float(want.abs().max())
+    plain = HipCircuit(plan, tensors, device=hip_device, pad_units=False)
+    assert plain._pad_info is None
+    assert float((plain(x.to(hip_device)).cpu() - want).abs().max()) <= REL * float(want.abs().max())
+    # a parameter update in the user's shape reaches the padded storage; export gives the user's shape back
+    name = sorted(plan.tensors)[1]
+    new = tensors[name] * 0.5 + 0.1
+    hc.store.set(name, new)
+    assert np.array_equal(hc.store.export(name), new.astype(np.float32))
+    t2 = dict(tensors)
+    t2[name] = new
+    want2 = evaluate_plan(plan, as_torch(t2), x)
+    got2 = hc(x.to(hip_device)).cpu()
+    assert float((got2 - want2).abs().max()) <= REL * float(want2.abs().max())

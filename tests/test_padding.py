@@ -1,0 +1,85 @@
+"""`cirkit_amd.padding.pad_units`: the padded plan computes the same function (checked with the CPU oracle),
+parameter values convert both ways, and unsupported plans are left alone."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cirkit_amd.initializers import init_plan_tensors  # noqa: E402
+from cirkit_amd.padding import pad_tensors, pad_units  # noqa: E402
+from cirkit_amd.templates import image_data, tabular_data  # noqa: E402
+from oracle.torch_oracle import as_torch, evaluate_plan  # noqa: E402
+
+CASES = [
+    dict(region_graph="quad-tree-2", sum_product_layer="cp"),
+    dict(region_graph="quad-tree-4", sum_product_layer="cp-t"),
+    dict(region_graph="quad-graph", sum_product_layer="cp"),
+    dict(region_graph="quad-graph", sum_product_layer="tucker"),
+    dict(region_graph="poon-domingos", sum_product_layer="cp", input_layer="gaussian"),
+    dict(region_graph="random-binary-tree", sum_product_layer="cp", use_mixing_weights=False),
+]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[f"{c['region_graph']}-{c['sum_product_layer']}" for c in CASES])
+@pytest.mark.parametrize("K", [6, 40])
+def test_padded_plan_is_the_same_function(kw, K):
+    if K == 40 and kw["sum_product_layer"] == "tucker":
+        pytest.skip("oracle too slow")
+    plan = image_data((1, 4, 4), num_input_units=K, num_sum_units=K, **kw)
+    res = pad_units(plan)
+    assert res is not None
+    padded, info = res
+    assert all(l.num_output_units in (1, 32, 64) and l.num_input_units in (1, 32, 64) for l in padded.layers)
+    tensors = init_plan_tensors(plan)
+    ptens = pad_tensors(info, tensors)
+    for name, (shape, _) in padded.tensors.items():
+        assert tuple(ptens[name].shape) == tuple(shape)
+        assert np.array_equal(info.unpad(name, ptens[name]), tensors[name])
+    g = torch.Generator().manual_seed(1)
+    if kw.get("input_layer") == "gaussian":
+        x = torch.randn((9, 16), generator=g)
+    else:
+        x = torch.randint(0, 256, (9, 16), generator=g)
+    want = evaluate_plan(plan, as_torch(tensors), x)
+    got = evaluate_plan(padded, as_torch(ptens), x)[..., : info.out_units]
+    assert got.shape == want.shape
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_multiclass_output_is_sliced():
+    plan = tabular_data(6, "random-binary-tree", input_layers=[{"name": "categorical", "args": {"num_categories": 3}}],
+                        num_input_units=5, num_sum_units=5, num_classes=3) if False else None
+    plan = image_data((1, 4, 4), "quad-tree-2", num_input_units=5, num_sum_units=5, num_classes=3)
+    padded, info = pad_units(plan)
+    assert info.out_units == 3
+    tensors = init_plan_tensors(plan)
+    x = torch.randint(0, 256, (4, 16))
+    want = evaluate_plan(plan, as_torch(tensors), x)
+    got = evaluate_plan(padded, as_torch(pad_tensors(info, tensors)), x)[..., :3]
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_nothing_to_do_or_unsupported():
+    assert pad_units(image_data((1, 4, 4), "quad-tree-2", num_input_units=32, num_sum_units=32)) is None
+    sq = image_data((1, 4, 4), "quad-tree-2", input_layer="embedding", num_input_units=6, sum_product_layer="cp-t",
+                    num_sum_units=6, sum_weight_activation="none", semiring="complex-lse-sum")
+    assert pad_units(sq) is None
+
+
+def test_unconstrained_parameters():
+    """Raw (activation-free) parameters: padded weights are 0, a padded Gaussian keeps a positive stddev."""
+    from conftest import load_case
+
+    for name in ("kat_gaussian_f1o1", "kat_bernoulli_f1o1"):
+        plan, tensors, g = load_case(name)
+        padded, info = pad_units(plan)
+        x = torch.from_numpy(np.asarray(g["x"]))
+        want = evaluate_plan(plan, as_torch(tensors), x)
+        got = evaluate_plan(padded, as_torch(pad_tensors(info, tensors)), x)[..., : info.out_units]
+        assert torch.isfinite(got).all()
+        assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
