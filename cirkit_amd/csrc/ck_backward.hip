@@ -36,7 +36,8 @@ __device__ __forceinline__ void grad_store(float* p, float g, int accumulate) {
 template <int TB>
 __global__ void __launch_bounds__(256)
     sum_lse_bwd_generic(const float* __restrict__ arena, float* __restrict__ garena,
-                        const int64_t* __restrict__ row_off, const float* __restrict__ w,
+                        const int64_t* __restrict__ row_off, const int64_t* __restrict__ grow_off,
+                        const float* __restrict__ w,
                         const float* __restrict__ /*out: not needed, y is recomputed*/,
                         const float* __restrict__ gout, float* __restrict__ dw, int H, int B, int Ki,
                         int Ko, int mode, int accumulate) {
@@ -51,6 +52,7 @@ __global__ void __launch_bounds__(256)
   const int b0 = blockIdx.x * TB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t* gro = grow_off + static_cast<int64_t>(f) * H;  // where the children's gradients go
   const float* wf = w + static_cast<int64_t>(f) * Ko * N;
   float* dwf = dw + static_cast<int64_t>(f) * Ko * N;
 
@@ -150,10 +152,10 @@ __global__ void __launch_bounds__(256)
     if (b >= B) continue;
     const float g = gv_s[i] * e_s[i];
     if (mode == CK_SUM_PROD) {
-      for (int h = 0; h < H; ++h) grad_store(garena + ro[h] + static_cast<int64_t>(b) * Ki + n, g, accumulate);
+      for (int h = 0; h < H; ++h) grad_store(garena + gro[h] + static_cast<int64_t>(b) * Ki + n, g, accumulate);
     } else {
       const int h = n / Ki, k = n - h * Ki;
-      grad_store(garena + ro[h] + static_cast<int64_t>(b) * Ki + k, g, accumulate);
+      grad_store(garena + gro[h] + static_cast<int64_t>(b) * Ki + k, g, accumulate);
     }
   }
 }
@@ -165,8 +167,8 @@ __global__ void __launch_bounds__(256)
 // the workgroup's waves in LDS and leaves with one atomic per element and workgroup.
 __global__ void __launch_bounds__(256)
     sum_lse_bwd_tile32(const float* __restrict__ arena, float* __restrict__ garena,
-                       const int64_t* __restrict__ row_off, const float* __restrict__ w,
-                       const float* __restrict__ gout, float* __restrict__ dw, int H, int B,
+                       const int64_t* __restrict__ row_off, const int64_t* __restrict__ grow_off,
+                       const float* __restrict__ w, const float* __restrict__ gout, float* __restrict__ dw, int H, int B,
                        int tiles_per_wave, int accumulate) {
   __shared__ __attribute__((aligned(16))) float lds[4][2][32 * 32];  // per wave: gy[b][o], e[b][n]
   const int f = blockIdx.y;
@@ -174,6 +176,7 @@ __global__ void __launch_bounds__(256)
   const int b_in = lane & 31, kh = lane >> 5;
   const float* wf = w + static_cast<int64_t>(f) * kK * kK;
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t* gro = grow_off + static_cast<int64_t>(f) * H;  // where the children's gradients go
   WRegs wr;  // A operand of y = W e: lane (o, kh) holds W[o][u(s, kh)]
   load_w<CK_W_ROWMAJOR>(wf, lane, wr);
   float wt[16];  // A operand of gv = W^T gy: lane (n, kh) holds W[u(s, kh)][n]
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(256)
     for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[s2], gy[s2], acc, 0, 0, 0);
     if (live) {
       for (int h = 0; h < H; ++h) {
-        float* dst = garena + ro[h] + static_cast<int64_t>(b) * kK + 4 * kh;
+        float* dst = garena + gro[h] + static_cast<int64_t>(b) * kK + 4 * kh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 gv = make_float4(acc[4 * g] * e[4 * g], acc[4 * g + 1] * e[4 * g + 1], acc[4 * g + 2] * e[4 * g + 2],
@@ -275,6 +278,218 @@ __global__ void __launch_bounds__(256)
   for (int i = threadIdx.x; i < 1024; i += 256) {
     const float sacc = red[i] + red[1024 + i] + red[2048 + i] + red[3072 + i];
     if (sacc != 0.f) atomicAdd(&dwf[i], sacc);
+  }
+}
+
+// The same three contractions for K = 64 (two 32-unit blocks per row): both operand layouts of W -- for y = W e and
+// for gv = W^T gy -- are staged in LDS once per workgroup and shared by its four waves (they do not fit in
+// registers next to the 64 x 64 dW accumulator); gy and e go through per-wave LDS tiles (row stride 68: the
+// transposed 16-byte writes of 32 rows spread over all banks) for the batch-contracted dW += gy^T e.
+constexpr int kT64 = 68;  // row stride of the per-wave transpose tiles
+__global__ void __launch_bounds__(256)
+    sum_lse_bwd_tile64(const float* __restrict__ arena, float* __restrict__ garena, const int64_t* __restrict__ row_off,
+                       const int64_t* __restrict__ grow_off, const float* __restrict__ w, const float* __restrict__ gout, float* __restrict__ dw, int H, int B,
+                       int tiles_per_wave, int accumulate) {
+  constexpr int K = 64;
+  extern __shared__ __attribute__((aligned(16))) float sm64[];
+  float* w_a = sm64;          // [p][q][g][lane][4]: W[32p + (lane & 31)][32q + 8g + 4(lane >> 5) + t]
+  float* w_t = sm64 + 4096;   // [q][p][g][lane][4]: W[32p + 8g + 4(lane >> 5) + t][32q + (lane & 31)]
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  float* gy_s = sm64 + 8192 + wave * (2 * 32 * kT64);
+  float* e_s = gy_s + 32 * kT64;
+  const float* wf = w + static_cast<int64_t>(f) * K * K;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t* gro = grow_off + static_cast<int64_t>(f) * H;  // where the children's gradients go
+  {  // all loads of the staging first (a load -> store loop would pay the memory latency once per iteration)
+    float4 a4[4];
+    float tv[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      const int ln = i & 63, g = (i >> 6) & 3, q = (i >> 8) & 1, p = i >> 9;
+      a4[u] = *reinterpret_cast<const float4*>(wf + (32 * p + (ln & 31)) * K + 32 * q + 8 * g + 4 * (ln >> 5));
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      const int t = i & 3, ln = (i >> 2) & 63, g = (i >> 8) & 3, p = (i >> 10) & 1, q = i >> 11;
+      tv[u] = wf[(32 * p + 8 * g + 4 * (ln >> 5) + t) * K + 32 * q + (ln & 31)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(w_a + 4 * (threadIdx.x + 256 * u)) = a4[u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w_t[threadIdx.x + 256 * u] = tv[u];
+  }
+  __syncthreads();
+  f32x16 dwacc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dwacc[p][q][r] = 0.f;
+  const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+    const int b0 = (tile0 + tt) * 32;
+    if (b0 >= B) break;
+    const int b = b0 + b_in;
+    const bool live = b < B;
+    const int bl = live ? b : B - 1;
+    float e[2][16];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) e[q][j] = 0.f;
+      for (int h = 0; h < H; ++h) tile_load_add(arena + ro[h] + static_cast<int64_t>(bl) * K + 32 * q + 4 * kh, e[q]);
+    }
+    float m = e[0][0];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) m = fmaxf(m, e[q][j]);
+    m = ck::clamp_finite(fmaxf(m, __shfl_xor(m, 32, 64)));
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) e[q][j] = live ? expf(e[q][j] - m) : 0.f;  // accurate exp: softmax gradients cancel
+    // y = W e, gy = gout / y
+    float gy[2][16];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 w4 = *reinterpret_cast<const float4*>(w_a + ((((p * 2 + q) * 4 + g) * 64) + lane) * 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, e[q][4 * g + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, e[q][4 * g + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, e[q][4 * g + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, e[q][4 * g + 3], acc, 0, 0, 0);
+        }
+      float go[16];
+      tile_load(gout + (static_cast<int64_t>(f) * B + bl) * K + 32 * p + 4 * kh, go);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gy[p][r] = (live && acc[r] > 0.f && go[r] != 0.f) ? go[r] / acc[r] : 0.f;
+    }
+    // gv = e * (W^T gy)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 w4 = *reinterpret_cast<const float4*>(w_t + ((((q * 2 + p) * 4 + g) * 64) + lane) * 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, gy[p][4 * g + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, gy[p][4 * g + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, gy[p][4 * g + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, gy[p][4 * g + 3], acc, 0, 0, 0);
+        }
+      if (live) {
+        for (int h = 0; h < H; ++h) {
+          float* dst = garena + gro[h] + static_cast<int64_t>(b) * K + 32 * q + 4 * kh;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 gv = make_float4(acc[4 * g] * e[q][4 * g], acc[4 * g + 1] * e[q][4 * g + 1],
+                                          acc[4 * g + 2] * e[q][4 * g + 2], acc[4 * g + 3] * e[q][4 * g + 3]);
+            float4* d4 = reinterpret_cast<float4*>(dst + 8 * g);
+            if (accumulate == 0) {
+              *d4 = gv;
+            } else if (accumulate == 1) {
+              const float4 o = *d4;
+              *d4 = make_float4(o.x + gv.x, o.y + gv.y, o.z + gv.z, o.w + gv.w);
+            } else {
+              atomicAdd(dst + 8 * g + 0, gv.x);
+              atomicAdd(dst + 8 * g + 1, gv.y);
+              atomicAdd(dst + 8 * g + 2, gv.z);
+              atomicAdd(dst + 8 * g + 3, gv.w);
+            }
+          }
+        }
+      }
+    }
+    // dW += gy^T e: both tiles row-major through LDS (row b, unit u at [b * kT64 + u])
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(gy_s + b_in * kT64 + 32 * q + 8 * g + 4 * kh) =
+            make_float4(gy[q][4 * g], gy[q][4 * g + 1], gy[q][4 * g + 2], gy[q][4 * g + 3]);
+        *reinterpret_cast<float4*>(e_s + b_in * kT64 + 32 * q + 8 * g + 4 * kh) =
+            make_float4(e[q][4 * g], e[q][4 * g + 1], e[q][4 * g + 2], e[q][4 * g + 3]);
+      }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int bb = 16 * kh + s2;  // batch row contracted by lanes (., kh) at step s2
+      const float a0 = gy_s[bb * kT64 + b_in], a1 = gy_s[bb * kT64 + 32 + b_in];
+      const float c0 = e_s[bb * kT64 + b_in], c1 = e_s[bb * kT64 + 32 + b_in];
+      dwacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c0, dwacc[0][0], 0, 0, 0);
+      dwacc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c1, dwacc[0][1], 0, 0, 0);
+      dwacc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c0, dwacc[1][0], 0, 0, 0);
+      dwacc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c1, dwacc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // reduce dW over the 4 waves, then one atomic per element: D[o][n] in lane (n, hi) reg r, o = u(r, hi)
+  __syncthreads();
+  float* red = sm64 + 8192;  // 4 x 4096 floats (the transpose tiles are no longer needed)
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = 32 * p + 8 * (r >> 2) + 4 * kh + (r & 3);
+        red[wave * 4096 + o * K + 32 * q + b_in] = dwacc[p][q][r];
+      }
+  __syncthreads();
+  float* dwf = dw + static_cast<int64_t>(f) * K * K;
+  for (int i = threadIdx.x; i < 4096; i += 256) {
+    const float sacc = (red[i] + red[4096 + i]) + (red[8192 + i] + red[12288 + i]);
+    if (sacc != 0.f) atomicAdd(&dwf[i], sacc);
+  }
+}
+
+// Gradient of children that several folds of ONE layer share (a region used by several partitionings): the layer's
+// backward writes every (fold, child slot) contribution to its own block of a temporary -- plain stores -- and this
+// kernel adds the blocks of each distinct child in list order: no float atomics (69 M of them per launch at
+// BASELINE config 4, the bulk of that backward) and a summation order that does not depend on scheduling.
+__global__ void __launch_bounds__(256)
+    segment_add_kernel(const float* __restrict__ tmp, const int32_t* __restrict__ cptr, const int32_t* __restrict__ clist,
+                       const int64_t* __restrict__ coff, float* __restrict__ garena, int64_t block_elems) {
+  const int c = blockIdx.y;
+  const int s0 = cptr[c], s1 = cptr[c + 1];
+  float* dst = garena + coff[c];
+  if ((block_elems & 3) == 0) {
+    const int64_t n4 = block_elems >> 2;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+      float4 a = reinterpret_cast<float4*>(dst)[i];
+      for (int j = s0; j < s1; ++j) {
+        const float4 v = reinterpret_cast<const float4*>(tmp + static_cast<int64_t>(clist[j]) * block_elems)[i];
+        a.x += v.x;
+        a.y += v.y;
+        a.z += v.z;
+        a.w += v.w;
+      }
+      reinterpret_cast<float4*>(dst)[i] = a;
+    }
+  } else {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < block_elems;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+      float a = dst[i];
+      for (int j = s0; j < s1; ++j) a += tmp[static_cast<int64_t>(clist[j]) * block_elems + i];
+      dst[i] = a;
+    }
   }
 }
 
@@ -559,12 +774,14 @@ __global__ void __launch_bounds__(256)
 // One wave per batch row (lanes over k), dW partials in LDS per workgroup, one atomic per (k, h).
 __global__ void __launch_bounds__(256)
     mixing_bwd_kernel(const float* __restrict__ arena, float* __restrict__ garena, const int64_t* __restrict__ row_off,
+                      const int64_t* __restrict__ grow_off,
                       const float* __restrict__ mw, const float* __restrict__ gout, float* __restrict__ dmw, int H,
                       int B, int K, int rows_per_block, int accumulate) {
   extern __shared__ float dw_s[];  // [K][H]
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t* gro = grow_off + static_cast<int64_t>(f) * H;  // where the children's gradients go
   const float* mwf = mw + static_cast<int64_t>(f) * K * H;
   for (int i = threadIdx.x; i < K * H; i += blockDim.x) dw_s[i] = 0.f;
   __syncthreads();
@@ -585,7 +802,7 @@ __global__ void __launch_bounds__(256)
       for (int h = 0; h < H; ++h) {
         const float e = expf(arena[ro[h] + static_cast<int64_t>(b) * K + k] - mx);
         const float ge = gy * e;
-        float* dst = garena + ro[h] + static_cast<int64_t>(b) * K + k;
+        float* dst = garena + gro[h] + static_cast<int64_t>(b) * K + k;
         const float gv = ge * mwf[static_cast<int64_t>(k) * H + h];
         if (accumulate == 0)
           *dst = gv;
@@ -600,6 +817,73 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   float* dwf = dmw + static_cast<int64_t>(f) * K * H;
   for (int i = threadIdx.x; i < K * H; i += blockDim.x) atomicAdd(&dwf[i], dw_s[i]);
+}
+
+// The same for K = 32 / 64 and H <= HMAX with the coefficient gradients in REGISTERS: a lane owns one unit k (64 / K
+// rows per wave pass), keeps e_h[k] of its row and accumulates d w[k, h] over all rows the wave visits; the four waves
+// are added through LDS with plain stores and leave with one atomic per (k, h) and workgroup.  (The LDS float
+// atomics of the general kernel retire ~4 cycles per lane and were 3/4 of its time.)
+template <int HMAX>
+__global__ void __launch_bounds__(256)
+    mixing_bwd_reg_kernel(const float* __restrict__ arena, float* __restrict__ garena, const int64_t* __restrict__ row_off,
+                          const int64_t* __restrict__ grow_off, const float* __restrict__ mw,
+                          const float* __restrict__ gout, float* __restrict__ dmw, int H, int B, int K, int rows_per_block,
+                          int accumulate) {
+  __shared__ float red[4][64][HMAX + 1];
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rpw = 64 / K;               // rows per wave pass
+  const int k = lane % K, sub = lane / K;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t* gro = grow_off + static_cast<int64_t>(f) * H;
+  float wk[HMAX], dacc[HMAX];
+#pragma unroll
+  for (int h = 0; h < HMAX; ++h) {
+    wk[h] = h < H ? mw[(static_cast<int64_t>(f) * K + k) * H + h] : 0.f;
+    dacc[h] = 0.f;
+  }
+  const int b_begin = blockIdx.x * rows_per_block;
+  const int b_end = min(B, b_begin + rows_per_block);
+  for (int b0 = b_begin + wave * rpw; b0 < b_end; b0 += 4 * rpw) {
+    const int b = b0 + sub;
+    const bool live = b < b_end;
+    const int bl = live ? b : b_end - 1;
+    float x[HMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (h < H) {
+        x[h] = arena[ro[h] + static_cast<int64_t>(bl) * K + k];
+        mx = fmaxf(mx, x[h]);
+      }
+    for (int o = K >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));  // over the K lanes of the row
+    mx = ck::clamp_finite(mx);
+    float y = 0.f;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (h < H) {
+        x[h] = expf(x[h] - mx);
+        y = fmaf(wk[h], x[h], y);
+      }
+    const float gy = live ? gout[(static_cast<int64_t>(f) * B + bl) * K + k] / y : 0.f;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (h < H) {
+        const float ge = gy * x[h];
+        dacc[h] += ge;
+        if (live) grad_store(garena + gro[h] + static_cast<int64_t>(b) * K + k, ge * wk[h], accumulate);
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < HMAX; ++h) red[wave][lane][h] = dacc[h];
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * H; i += 256) {
+    const int kk = i / H, h = i - kk * H;
+    float t = 0.f;
+    for (int wv = 0; wv < 4; ++wv)
+      for (int sb = 0; sb < rpw; ++sb) t += red[wv][sb * K + kk][h];
+    if (t != 0.f) atomicAdd(&dmw[(static_cast<int64_t>(f) * K + kk) * H + h], t);
+  }
 }
 
 // ---- parameter-graph backward pieces -------------------------------------------------------------
@@ -714,19 +998,37 @@ int ck_gaussian_bwd(const float* gout, const float* xt, const int64_t* scope, co
       stream);
 }
 
-int ck_mixing_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* mw, const float* gout,
+int ck_mixing_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const int64_t* grad_row_off,
+                      const float* mw, const float* gout,
                       float* dmw, int F, int H, int B, int K, int accumulate, void* stream) {
   CK_REQUIRE(arena && garena && row_off && mw && gout && dmw, "ck_mixing_lse_bwd: null pointer");
+  const int64_t* grow = grad_row_off ? grad_row_off : row_off;
   CK_REQUIRE(F > 0 && H > 0 && B > 0 && K > 0, "ck_mixing_lse_bwd: non-positive size");
   CK_REQUIRE(accumulate >= 0 && accumulate <= 2, "ck_mixing_lse_bwd: accumulate must be 0, 1 or 2");
   CK_REQUIRE(F <= 65535, "ck_mixing_lse_bwd: F=%d exceeds grid.y", F);
   const size_t lds = static_cast<size_t>(K) * H * sizeof(float);
   CK_REQUIRE(lds <= 64 * 1024, "ck_mixing_lse_bwd: K*H=%d coefficients do not fit in LDS", K * H);
+  if ((K == 32 || K == 64) && H <= 16) {
+    int rpb = 16;  // rows per workgroup: more amortise the final atomics, fewer fill the chip when there are few folds
+    while (rpb < 512 && static_cast<int64_t>(F) * ((B + 2 * rpb - 1) / (2 * rpb)) >= 2048) rpb *= 2;
+    dim3 grid((B + rpb - 1) / rpb, F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          if (H <= 4)
+            hipLaunchKernelGGL(mixing_bwd_reg_kernel<4>, grid, block, 0, s, arena, garena, row_off, grow, mw, gout, dmw, H, B, K, rpb, accumulate);
+          else if (H <= 8)
+            hipLaunchKernelGGL(mixing_bwd_reg_kernel<8>, grid, block, 0, s, arena, garena, row_off, grow, mw, gout, dmw, H, B, K, rpb, accumulate);
+          else
+            hipLaunchKernelGGL(mixing_bwd_reg_kernel<16>, grid, block, 0, s, arena, garena, row_off, grow, mw, gout, dmw, H, B, K, rpb, accumulate);
+          return hipGetLastError();
+        },
+        stream);
+  }
   const int rows_per_block = 64;
   dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(mixing_bwd_kernel, grid, block, lds, s, arena, garena, row_off, mw, gout, dmw, H, B, K,
+        hipLaunchKernelGGL(mixing_bwd_kernel, grid, block, lds, s, arena, garena, row_off, grow, mw, gout, dmw, H, B, K,
                            rows_per_block, accumulate);
         return hipGetLastError();
       },
@@ -782,10 +1084,27 @@ int ck_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream) {
       stream);
 }
 
-int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* w,
+int ck_segment_add_rows(const float* tmp, const int32_t* cptr, const int32_t* clist, const int64_t* coff, float* garena,
+                        int n_child, int64_t block_elems, void* stream) {
+  CK_REQUIRE(tmp && cptr && clist && coff && garena, "ck_segment_add_rows: null pointer");
+  CK_REQUIRE(n_child > 0 && block_elems > 0, "ck_segment_add_rows: non-positive size");
+  CK_REQUIRE(n_child <= 65535, "ck_segment_add_rows: %d children exceed grid.y", n_child);
+  CK_REQUIRE((block_elems & 3) != 0 || (ck::aligned16(tmp) && ck::aligned16(garena)), "ck_segment_add_rows: unaligned buffers");
+  const int64_t work = (block_elems & 3) == 0 ? block_elems >> 2 : block_elems;
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>((work + 255) / 256, 4096)), n_child), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(segment_add_kernel, grid, block, 0, s, tmp, cptr, clist, coff, garena, block_elems);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const int64_t* grad_row_off, const float* w,
                    const float* out, const float* gout, float* dw, int F, int H, int B, int Ki, int Ko,
                    int mode, int accumulate, void* stream) {
   CK_REQUIRE(arena && garena && row_off && w && out && gout && dw, "ck_sum_lse_bwd: null pointer");
+  const int64_t* grow = grad_row_off ? grad_row_off : row_off;
   CK_REQUIRE(F > 0 && H > 0 && B > 0 && Ki > 0 && Ko > 0, "ck_sum_lse_bwd: non-positive size");
   CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD, "ck_sum_lse_bwd: unsupported mode %d", mode);
   CK_REQUIRE(accumulate >= 0 && accumulate <= 2, "ck_sum_lse_bwd: accumulate must be 0, 1 or 2");
@@ -800,7 +1119,24 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
     return ck::dispatch(
         [=](hipStream_t s) {
-          hipLaunchKernelGGL(sum_lse_bwd_tile32, grid, block, 0, s, arena, garena, row_off, w, gout, dw, H, B, tpw, accumulate);
+          hipLaunchKernelGGL(sum_lse_bwd_tile32, grid, block, 0, s, arena, garena, row_off, grow, w, gout, dw, H, B, tpw, accumulate);
+          return hipGetLastError();
+        },
+        stream);
+  }
+  if ((mode == CK_SUM_PROD || H == 1) && Ki == 64 && Ko == 64 && !g_bwd_force_generic && ck::aligned16(arena) &&
+      ck::aligned16(garena) && ck::aligned16(w) && ck::aligned16(gout)) {
+    const int tiles = (B + 31) / 32;
+    int tpw = 1;
+    while (tpw < 8 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 1024) tpw *= 2;
+    dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
+    const size_t lds = (8192 + 4 * 2 * 32 * kT64) * sizeof(float);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sum_lse_bwd_tile64),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+          if (e != hipSuccess) return e;
+          hipLaunchKernelGGL(sum_lse_bwd_tile64, grid, block, lds, s, arena, garena, row_off, grow, w, gout, dw, H, B, tpw, accumulate);
           return hipGetLastError();
         },
         stream);
@@ -822,7 +1158,7 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
             if (e != hipSuccess) return e;
           }
-          hipLaunchKernelGGL(kern, grid, block, lds, s, arena, garena, row_off, w, out, gout, dw, H, B, Ki, Ko, mode,
+          hipLaunchKernelGGL(kern, grid, block, lds, s, arena, garena, row_off, grow, w, out, gout, dw, H, B, Ki, Ko, mode,
                              accumulate);
           return hipGetLastError();
         };

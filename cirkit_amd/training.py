@@ -157,8 +157,30 @@ class HipTrainer:
             n = int(np.prod(sh))
             dws[i] = flat[off : off + n].view(sh)
             off += n
+        # layers whose folds share children: contributions go to a temporary (one block per (fold, slot)) and are
+        # added per distinct child by ck_segment_add_rows instead of through float atomics
+        shared, tmp_elems = {}, 0
+        for j, fl in flags.items():
+            l = c.layers[j]
+            if fl != 2:
+                continue
+            ro = bd.row_off[j].cpu().numpy().reshape(-1)  # element offsets of the (fold, slot) children in the arena
+            block = B * l.num_input_units
+            uniq, inv = np.unique(ro, return_inverse=True)
+            order = np.argsort(inv, kind="stable")
+            cptr = np.concatenate([[0], np.cumsum(np.bincount(inv, minlength=len(uniq)))])
+            dev = self.device
+            shared[j] = {
+                "row_off": (torch.arange(len(ro), dtype=torch.int64) * block).to(dev),
+                "cptr": torch.from_numpy(cptr.astype(np.int32)).to(dev),
+                "clist": torch.from_numpy(order.astype(np.int32)).to(dev),
+                "coff": torch.from_numpy(uniq.astype(np.int64)).to(dev),
+                "n_child": int(len(uniq)), "block": int(block),
+            }
+            tmp_elems = max(tmp_elems, len(ro) * block)
+        tmp = torch.empty(max(tmp_elems, 1), dtype=torch.float32, device=self.device)
         st = {"arena_ptr": bd.arena.data_ptr(), "garena": garena, "gviews": gviews, "flags": flags,
-              "need_zero": need_zero, "dws": dws, "dw_flat": flat}
+              "need_zero": need_zero, "dws": dws, "dw_flat": flat, "shared": shared, "tmp": tmp}
         self._bwd[B] = st
         return st
 
@@ -183,6 +205,21 @@ class HipTrainer:
             raise NotImplementedError("training needs a scalar output unit")
         capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel(), 0.0, stream)
         capi.call("ck_fill_f32", gviews[po][fo].data_ptr(), B, -1.0 / gB, stream)
+        shared, tmp = st["shared"], st["tmp"]
+
+        def target(i):
+            """(gradient arena, child offsets, accumulate flag) of layer i's backward launch."""
+            sh = shared.get(i)
+            if sh is None:
+                return st["garena"].data_ptr(), bd.row_off[i].data_ptr(), flags[i]
+            return tmp.data_ptr(), sh["row_off"].data_ptr(), 0
+
+        def gather_shared(i):
+            sh = shared.get(i)
+            if sh is not None:
+                capi.call("ck_segment_add_rows", tmp.data_ptr(), sh["cptr"].data_ptr(), sh["clist"].data_ptr(),
+                          sh["coff"].data_ptr(), st["garena"].data_ptr(), sh["n_child"], sh["block"], stream)
+
         for i in range(len(c.layers) - 1, -1, -1):
             l = c.layers[i]
             if isinstance(l, HipCategoricalLayer):
@@ -201,20 +238,25 @@ class HipTrainer:
                 l.mean.backward(dm, self.grads, stream)
                 l.stddev.backward(ds, self.grads, stream)
             elif isinstance(l, HipHadamardLayer):
-                capi.call("ck_hadamard_bwd", st["garena"].data_ptr(), bd.row_off[i].data_ptr(), gviews[i].data_ptr(),
-                          l.num_folds, l.arity, B, l.num_input_units, flags[i], stream)
+                ga, ro, fl = target(i)
+                capi.call("ck_hadamard_bwd", ga, ro, gviews[i].data_ptr(), l.num_folds, l.arity, B, l.num_input_units, fl, stream)
+                gather_shared(i)
             elif l._mixing:
                 dmw = st["dws"][i]
-                capi.call("ck_mixing_lse_bwd", bd.arena.data_ptr(), st["garena"].data_ptr(), bd.row_off[i].data_ptr(),
+                ga, ro, fl = target(i)
+                capi.call("ck_mixing_lse_bwd", bd.arena.data_ptr(), ga, bd.row_off[i].data_ptr(), ro,
                           l._w.data_ptr(), gviews[i].data_ptr(), dmw.data_ptr(), l.num_folds, l.arity, B,
-                          l.num_output_units, flags[i], stream)
+                          l.num_output_units, fl, stream)
+                gather_shared(i)
                 l.weight.backward(dmw, self.grads, stream, upto=len(l.weight.graph.nodes) - 2)
             else:  # sum / cpt
                 raw = l.weight.ops == ["tensor"]
                 dW = self.grads[l.weight.graph.nodes[0].config["tensor"]] if raw else st["dws"][i]
-                capi.call("ck_sum_lse_bwd", bd.arena.data_ptr(), st["garena"].data_ptr(), bd.row_off[i].data_ptr(),
+                ga, ro, fl = target(i)
+                capi.call("ck_sum_lse_bwd", bd.arena.data_ptr(), ga, bd.row_off[i].data_ptr(), ro,
                           l._w.data_ptr(), bd.views[i].data_ptr(), gviews[i].data_ptr(), dW.data_ptr(), l.num_folds,
-                          l.arity, B, l.num_input_units, l.num_output_units, l._mode, flags[i], stream)
+                          l.arity, B, l.num_input_units, l.num_output_units, l._mode, fl, stream)
+                gather_shared(i)
                 if self._fast_softmax(l):
                     name = l.weight.graph.nodes[0].config["tensor"]
                     rows = l.num_folds * l.num_output_units

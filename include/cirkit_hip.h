@@ -292,11 +292,17 @@ int ck_param_table_integral_row(float* table, int F, int C, int K, int mode, voi
  * the activation arena (same offsets).  accumulate: 0 store, 1 add (ordered launches), 2 atomic add
  * (a producer fold read several times by this layer). */
 int ck_fill_f32(float* p, int64_t n, float value, void* stream);
+/* garena[coff[c] + i] += sum_{j in [cptr[c], cptr[c+1])} tmp[clist[j] * block_elems + i]: the gradients that the folds
+ * of one layer contribute to a child they share (autograd's accumulation into a tensor indexed twice by
+ * LayerAddressBook.lookup, circuits.py:39-48), without float atomics and in list order. */
+int ck_segment_add_rows(const float* tmp, const int32_t* cptr, const int32_t* clist, const int64_t* coff, float* garena,
+                        int n_child, int64_t block_elems, void* stream);
 /* TorchSumLayer / TorchCPTLayer backward (modes CK_SUM_CAT / CK_SUM_PROD), row-major linear
- * weights w (F,Ko,N): children gradients into garena, dW (F,Ko,N) accumulated with atomics
+ * weights w (F,Ko,N): children gradients into garena at grad_row_off (NULL: at row_off, the mirror of the arena),
+ * dW (F,Ko,N) accumulated with atomics
  * (zero it first). out/gout: (F,B,Ko) forward output and its gradient. */
-int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* w,
-                   const float* out, const float* gout, float* dw, int F, int H, int B, int Ki, int Ko,
+int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const int64_t* grad_row_off,
+                   const float* w, const float* out, const float* gout, float* dw, int F, int H, int B, int Ki, int Ko,
                    int mode, int accumulate, void* stream);
 int ck_debug_force_generic_bwd(int on); /* test hook, like ck_debug_force_generic */
 /* TorchHadamardLayer backward: every child receives gout (F,B,K). */
@@ -308,8 +314,9 @@ int ck_gaussian_bwd(const float* gout, const float* xt, const int64_t* scope, co
                     float* dmean, float* dstddev, int F, int B, int K, void* stream);
 /* Mixing layer backward (forward: ck_mixing_lse_fwd): input gradients into garena at the children's
  * offsets (accumulate 0 store / 1 add / 2 atomic), dmw (F, K, H) += batch sums (zero it first). */
-int ck_mixing_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* mw, const float* gout,
-                      float* dmw, int F, int H, int B, int K, int accumulate, void* stream);
+int ck_mixing_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const int64_t* grad_row_off,
+                      const float* mw, const float* gout, float* dmw, int F, int H, int B, int K, int accumulate,
+                      void* stream);
 /* Parameter-graph backward pieces: scaled sigmoid (nodes.py:698-699) from its OUTPUT y, the mixing-weight
  * expansion (nodes.py:857-862), y += a x. */
 int ck_param_scaled_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, float vmin, float vmax,
