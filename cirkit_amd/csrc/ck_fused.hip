@@ -221,28 +221,39 @@ __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a
     const int fold = a.nodes[a.node_off[lvl + 1] + t * (kLeaves >> (lvl + 1)) + (i >> (lvl + 1))];
     return a.w[lvl] + static_cast<int64_t>(fold) * (kK * kK);
   };
-  int64_t row[kLeaves];  // table row (fold, category) of each leaf
+  int32_t row[kLeaves];  // table row (fold, category) of each leaf
 #pragma unroll
   for (int i = 0; i < kLeaves; ++i) {
     const int v = a.xt[a.scope[leaf_ids[i]] * static_cast<int64_t>(a.B) + bl];
     const int c = v < 0 ? a.C : min(v, a.C - 1);  // negative = marginalised -> integral row C
-    row[i] = static_cast<int64_t>(fold0[i]) * (a.C + 1) + c;
+    row[i] = fold0[i] * (a.C + 1) + c;
   }
+  auto row_of = [&](int i) -> int64_t { return static_cast<int64_t>(row[i]); };
   WRegs wcur, wnxt;
   load_w<LAYOUT>(w_ptr(1, 0), lane, wcur);  // first step: level 1 after leaf 1
   float stack[D][16], sstack[D];
-  float cur[16], nxt[16], cs, ns;
-  tile_load(a.table + row[0] * kK + 4 * kh, nxt);
-  ns = a.scale[row[0]];
+  // two leaf rows in flight: leaves come in pairs with no contraction between them (L L C L L C C ...), so a
+  // gather issued one leaf ahead would be waited for right away at every second leaf
+  float cur[16], nxt[16], nx2[16], cs, ns, ns2;
+  tile_load(a.table + row_of(0) * kK + 4 * kh, nxt);
+  ns = a.scale[row_of(0)];
+  if (kLeaves > 1) {
+    tile_load(a.table + row_of(1) * kK + 4 * kh, nx2);
+    ns2 = a.scale[row_of(1)];
+  }
 
 #pragma unroll
   for (int i = 0; i < kLeaves; ++i) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) cur[j] = nxt[j];
+    for (int j = 0; j < 16; ++j) {
+      cur[j] = nxt[j];
+      nxt[j] = nx2[j];
+    }
     cs = ns;
-    if (i + 1 < kLeaves) {  // the next leaf's gather is in flight while this one is consumed
-      tile_load(a.table + row[i + 1] * kK + 4 * kh, nxt);
-      ns = a.scale[row[i + 1]];
+    ns = ns2;
+    if (i + 2 < kLeaves) {
+      tile_load(a.table + row_of(i + 2) * kK + 4 * kh, nx2);
+      ns2 = a.scale[row_of(i + 2)];
     }
 #pragma unroll
     for (int l = 0; l < D; ++l) {
