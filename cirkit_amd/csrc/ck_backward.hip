@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256)
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int j = 0; j < 16; ++j) m = fmaxf(m, e[q][j]);
-    m = ck::clamp_finite(fmaxf(m, __shfl_xor(m, 32, 64)));
+    m = ck::clamp_finite(ck::xhalf_max(m));
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll

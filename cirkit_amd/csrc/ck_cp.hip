@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       for (int q = 0; q < NK; ++q)
 #pragma unroll
         for (int j = 0; j < 16; ++j) m = fmaxf(m, v[q][j]);
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = ck::xhalf_max(m);
       m = ck::clamp_finite(m);
       const float nml = exp_offset(m, 0.f);
 #pragma unroll
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     for (int q = 0; q < NK; ++q)
 #pragma unroll
       for (int j = 0; j < 16; ++j) m = fmaxf(m, o[q][j]);
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = ck::xhalf_max(m);
     m = ck::clamp_finite(m);
     const float nml = exp_offset(m, 0.f);
     float e[NK][16];
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
         for (int q = 0; q < NK; ++q)
 #pragma unroll
           for (int j = 0; j < 16; ++j) m = fmaxf(m, v[q][j]);
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = ck::xhalf_max(m);
         m = ck::clamp_finite(m);
         const float nml = exp_offset(m, 0.f);
 #pragma unroll
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
     for (int p = 0; p < NK; ++p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) pm = fmaxf(pm, P[p][r]);
-    pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+    pm = ck::xhalf_max(pm);
     const float Mn = ck::clamp_finite(fmaxf(M, pm));
     const float scale = __builtin_amdgcn_exp2f((M - Mn) * kL2E);  // 0 on the first partitioning (M = -inf)
     const float nml = exp_offset(Mn, 0.f);
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         m = fmaxf(m, fmaxf(fmaxf(t4.x, t4.y), fmaxf(t4.z, t4.w)));
       }
   }
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  m = ck::xhalf_max(m);
   m = ck::clamp_finite(m);
   const float nml = exp_offset(m, 0.f);
   f32x16 acc[NK];

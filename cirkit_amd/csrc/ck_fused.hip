@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a
       float mx = p[0];
 #pragma unroll
       for (int j = 1; j < 16; ++j) mx = fmaxf(mx, p[j]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = ck::xhalf_max(mx);
       cs += sstack[l];
       if (__builtin_expect(__any(!(mx > 1e-30f)), 0)) {
         // rare: products at the edge of the fp32 range -> this step in log space (semiring.py:383-408)
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a
           p[j] = __logf(cur[j]) + __logf(stack[l][j]);
           m2 = fmaxf(m2, p[j]);
         }
-        m2 = ck::clamp_finite(fmaxf(m2, __shfl_xor(m2, 32, 64)));
+        m2 = ck::clamp_finite(ck::xhalf_max(m2));
 #pragma unroll
         for (int j = 0; j < 16; ++j) cur[j] = __expf(p[j] - m2);
         cs += m2;

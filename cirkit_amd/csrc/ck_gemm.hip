@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256)
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int j = 0; j < 16; ++j) m = fmaxf(m, e[q][j]);
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  m = ck::xhalf_max(m);
   m = ck::clamp_finite(m);
   const float nml = exp_offset(m, 0.f);
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256)
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int j = 0; j < 16; ++j) m = fmaxf(m, e[q][j]);
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  m = ck::xhalf_max(m);
   red_s[wave * 64 + lane] = m;
   __syncthreads();
 #pragma unroll
@@ -374,8 +374,8 @@ __global__ void __launch_bounds__(256)
         ml = fmaxf(ml, el[q][j]);
         mr = fmaxf(mr, er[q][j]);
       }
-    ml = ck::clamp_finite(fmaxf(ml, __shfl_xor(ml, 32, 64)));
-    mr = ck::clamp_finite(fmaxf(mr, __shfl_xor(mr, 32, 64)));
+    ml = ck::clamp_finite(ck::xhalf_max(ml));
+    mr = ck::clamp_finite(ck::xhalf_max(mr));
     const float nl = exp_offset(ml, 0.f), nr = exp_offset(mr, 0.f);
     float* eb = el_s + wave * (Ki * 32) + b_in;
 #pragma unroll

@@ -51,6 +51,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// max of a value with its partner in the other 32-lane half of the wave (the two halves of a 32-row tile hold the
+// two unit groups of a row).  v_permlane32_swap_b32 (gfx950) exchanges the halves inside the VALU; the __shfl_xor it
+// replaces compiled to ds_bpermute_b32, an LDS round trip in the middle of every log-sum-exp step.
+__device__ __forceinline__ float xhalf_max(float m) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 // torch.clamp(amax, finfo.min, finfo.max) of semiring.py:392-399
 __device__ __forceinline__ float clamp_finite(float m) {
   return fminf(fmaxf(m, -3.402823466e+38f), 3.402823466e+38f);

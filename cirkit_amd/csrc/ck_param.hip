@@ -646,7 +646,7 @@ __device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& 
           v[q][4 * g + tt] = c >= C ? 0.f : val;
           m = fmaxf(m, v[q][4 * g + tt]);
         }
-    m = ck::clamp_finite(fmaxf(m, __shfl_xor(m, 32, 64)));
+    m = ck::clamp_finite(ck::xhalf_max(m));
     const float nml = exp_offset(m, 0.f);
 #pragma unroll
     for (int q = 0; q < NK; ++q)

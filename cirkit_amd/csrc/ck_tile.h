@@ -43,7 +43,7 @@ __device__ __forceinline__ float row_max16(const float (&v)[16]) {
   float m = v[0];
 #pragma unroll
   for (int j = 1; j < 16; ++j) m = fmaxf(m, v[j]);
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  m = ck::xhalf_max(m);
   return ck::clamp_finite(m);  // torch.clamp(amax, finfo.min, finfo.max), semiring.py:392-399
 }
 
