@@ -209,6 +209,33 @@ __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 31, kh = lane >> 5;
   const int b0 = (tg * 4 + wave) * 32;
+  // Tiled weight layouts: the weights of all 2^D - 1 nodes of this root's subtree (4 KB each, the same for the four
+  // waves) are staged in LDS once per workgroup, in step order -- a quarter of the L2 traffic of every wave fetching
+  // them itself, no weight registers held across steps, and an LDS read right before use instead of an L2 round trip.
+  constexpr bool kLdsW = LAYOUT != CK_W_ROWMAJOR;
+  constexpr int kNodes = (1 << D) - 1;
+  __shared__ __attribute__((aligned(16))) float w_lds[kLdsW ? kNodes * 1024 : 4];
+  if constexpr (kLdsW) {
+    float4 stg[kNodes];
+    {
+      int si = 1, sl = 0, n = 0;  // first step: level 1 after leaf 1
+      bool more = true;
+#pragma unroll
+      for (int k = 0; k < kNodes; ++k) {
+        if (more) {
+          const int fold = a.nodes[a.node_off[sl + 1] + t * ((1 << D) >> (sl + 1)) + (si >> (sl + 1))];
+          stg[n++] = *reinterpret_cast<const float4*>(a.w[sl] + static_cast<int64_t>(fold) * (kK * kK) + 4 * threadIdx.x);
+          int ni = 0, nl = 0;
+          more = next_step<D, false>(si, sl, ni, nl);
+          si = ni;
+          sl = nl;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kNodes; ++k) *reinterpret_cast<float4*>(w_lds + k * 1024 + 4 * threadIdx.x) = stg[k];
+    __syncthreads();
+  }
   if (b0 >= a.B) return;
   const int b = b0 + b_in;
   const bool live = b < a.B;
@@ -230,7 +257,8 @@ __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a
   }
   auto row_of = [&](int i) -> int64_t { return static_cast<int64_t>(row[i]); };
   WRegs wcur, wnxt;
-  load_w<LAYOUT>(w_ptr(1, 0), lane, wcur);  // first step: level 1 after leaf 1
+  if constexpr (!kLdsW) load_w<LAYOUT>(w_ptr(1, 0), lane, wcur);  // first step: level 1 after leaf 1
+  int step = 0;  // index of the next contraction in the static step order
   float stack[D][16], sstack[D];
   // two leaf rows in flight: leaves come in pairs with no contraction between them (L L C L L C C ...), so a
   // gather issued one leaf ahead would be waited for right away at every second leaf
@@ -265,7 +293,13 @@ __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a
       }
       int ni = 0, nl = 0;
       const bool more = next_step<D, false>(i, l, ni, nl);
-      if (more) load_w<LAYOUT>(w_ptr(ni, nl), lane, wnxt);
+      if constexpr (kLdsW) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
+        ++step;
+      } else if (more) {
+        load_w<LAYOUT>(w_ptr(ni, nl), lane, wnxt);
+      }
       float p[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) p[j] = cur[j] * stack[l][j];
@@ -293,7 +327,9 @@ __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a
         cs += __logf(mx);
       }
       contract_linear<LAYOUT>(wcur, cur);
-      if (more) wcur = wnxt;
+      if constexpr (!kLdsW) {
+        if (more) wcur = wnxt;
+      }
     }
   }
   if (live) {
