@@ -118,6 +118,19 @@ class HipCircuit:
                 hit = tensors._padded.get(id(plan))
                 if hit is not None:
                     _, plan, self._pad_info = hit
+                elif tensors._pad is not None:
+                    # a store that another circuit padded: this plan must be padded the same way to read it
+                    res = padding.pad_units(plan, tensors._pad.multiple)
+                    ok = res is not None and all(
+                        tuple(tensors[k].shape) == tuple(sh) for k, (sh, _) in res[0].tensors.items() if k in tensors)
+                    if not ok and any(k in tensors and tuple(tensors[k].shape) != tuple(sh) for k, (sh, _) in plan.tensors.items()):
+                        raise ValueError(
+                            "this TensorStore holds parameters padded to multiples of 32 units by another HipCircuit, "
+                            "and this plan cannot be padded the same way; build the first circuit with pad_units=False "
+                            "to share its parameters")
+                    if ok:
+                        plan, self._pad_info = res
+                        tensors._padded[id(self.user_plan)] = (self.user_plan, plan, self._pad_info)
             else:
                 res = padding.pad_units(plan)
                 if res is not None:

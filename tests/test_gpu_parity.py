@@ -518,3 +518,27 @@ def test_padded_units_match_oracle(hip_device, kw, K):
     want2 = evaluate_plan(plan, as_torch(t2), x)
     got2 = hc(x.to(hip_device)).cpu()
     assert float((got2 - want2).abs().max()) <= REL * float(want2.abs().max())
+
+
+def test_shared_store_of_a_padded_circuit(hip_device):
+    """A second circuit over the parameter store of a padded one: the same plan is padded the same way; a plan that
+    cannot be (here: its squared-partition plan, built from einsum / conj nodes) is refused with a clear message."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.functional import squared_partition_plan
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+
+    plan = image_data((1, 4, 4), "quad-tree-2", num_input_units=6, num_sum_units=6)
+    hc = HipCircuit(plan, init_plan_tensors(plan), device=hip_device)
+    assert hc._pad_info is not None
+    x = torch.randint(0, 256, (40, 16)).to(hip_device)
+    y = hc(x).clone()
+    plan_again = image_data((1, 4, 4), "quad-tree-2", num_input_units=6, num_sum_units=6)
+    other = HipCircuit(plan_again, hc.store, device=hip_device)
+    assert other._pad_info is not None and torch.equal(other(x), y)
+    try:
+        zplan = squared_partition_plan(plan)
+    except (ValueError, NotImplementedError):
+        return  # (squares of this layer mix are not built natively: nothing more to check)
+    with pytest.raises(ValueError, match="pad_units=False"):
+        HipCircuit(zplan, hc.store, device=hip_device)
