@@ -1115,7 +1115,8 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
     // tiles per wave: more amortise the weight loads and the dW atomics (one per element and workgroup), fewer give
     // a launch with few folds enough workgroups to fill the chip -- keep >= ~2048 workgroups where the batch allows
     int tpw = 1;
-    while (tpw < 8 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
+    while (tpw < 8 && 4 * tpw * 2 <= tiles && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048)
+      tpw *= 2;
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
     return ck::dispatch(
         [=](hipStream_t s) {
@@ -1127,8 +1128,9 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
   if ((mode == CK_SUM_PROD || H == 1) && Ki == 64 && Ko == 64 && !g_bwd_force_generic && ck::aligned16(arena) &&
       ck::aligned16(garena) && ck::aligned16(w) && ck::aligned16(gout)) {
     const int tiles = (B + 31) / 32;
-    int tpw = 1;
-    while (tpw < 8 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 1024) tpw *= 2;
+    int tpw = 1;  // (never more than the four waves of a workgroup can share: a small batch keeps all of them busy)
+    while (tpw < 8 && 4 * tpw * 2 <= tiles && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 1024)
+      tpw *= 2;
     dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
     const size_t lds = (8192 + 4 * 2 * 32 * kT64) * sizeof(float);
     return ck::dispatch(
@@ -1192,7 +1194,7 @@ int ck_categorical_bwd(const float* gout, const int32_t* xt, const int64_t* scop
   const size_t lds = static_cast<size_t>(C + 1) * K * sizeof(float);
   if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_categorical_bwd: C*K=%d does not fit in LDS", C * K);
   const size_t lds_sorted = lds + (static_cast<size_t>(2) * C + 3 + kCatChunk) * sizeof(int);
-  if (K % 32 == 0 && lds_sorted <= 64 * 1024 && B >= 256) {
+  if (K % 32 == 0 && lds_sorted <= 160 * 1024 && B >= 256) {
     dim3 grid(F), block(1024);
     return ck::dispatch(
         [=](hipStream_t s) {

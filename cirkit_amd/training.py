@@ -24,6 +24,7 @@ import torch
 from . import _capi as capi
 from .circuit import HipCircuit
 from .layers import HipCategoricalLayer, HipCPTLayer, HipGaussianLayer, HipHadamardLayer, HipSumLayer
+from .parameters import TensorStore
 from .plan import Plan
 
 
@@ -45,8 +46,27 @@ class HipTrainer:
             raise NotImplementedError("training is implemented for the real lse-sum semiring")
         if optimizer not in ("adam", "sgd"):
             raise ValueError(f"unknown optimizer {optimizer!r}")
+        # all parameters live in ONE flat buffer (the store's tensors are views of it, in plan order -- the order of
+        # the flat gradient and moment buffers): the optimizer step is a single launch
+        dev = torch.device(device)
+        names = list(plan.tensors)
+        sizes = [int(np.prod(plan.tensors[n][0])) for n in names]
+        self._flat_param = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        if isinstance(tensors, TensorStore):
+            src = {n: tensors[n] for n in names}
+        else:
+            src = tensors
+        store = TensorStore(dev)
+        off = 0
+        for n, sz in zip(names, sizes):
+            view = self._flat_param[off : off + sz].view(plan.tensors[n][0])
+            v = src[n]
+            view.copy_(torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach().to(torch.float32))
+            store._t[n] = view
+            off += sz
+        store.version += 1
         # layer-wise forward, every activation materialised, row-major linear weights
-        self.circuit = HipCircuit(plan, tensors, device=device, use_graph=False, fuse=False,
+        self.circuit = HipCircuit(plan, store, device=device, use_graph=False, fuse=False,
                                   batch_params=True, tiled_weights=False, dense_on_table=False, pad_units=False)
         self.plan, self.device = plan, self.circuit.device
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
@@ -56,8 +76,6 @@ class HipTrainer:
             raise NotImplementedError("training needs a single circuit output")
         self._check_supported()
         # one flat gradient buffer; per-tensor gradients are views of it (single all-reduce)
-        names = list(plan.tensors)
-        sizes = [int(np.prod(plan.tensors[n][0])) for n in names]
         self._flat_grad = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
         self.grads: dict[str, torch.Tensor] = {}
         off = 0
@@ -276,14 +294,12 @@ class HipTrainer:
     def apply_gradients(self) -> None:
         self.step_count += 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        for n, g in self.grads.items():
-            p = self.circuit.store[n]
-            if self.optimizer == "adam":
-                m1, m2 = self._moments[n]
-                capi.call("ck_adam_step", p.data_ptr(), g.data_ptr(), m1.data_ptr(), m2.data_ptr(), p.numel(),
-                          self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, stream)
-            else:
-                capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, stream)
+        p, g = self._flat_param, self._flat_grad
+        if self.optimizer == "adam":
+            capi.call("ck_adam_step", p.data_ptr(), g.data_ptr(), self._m1.data_ptr(), self._m2.data_ptr(), p.numel(),
+                      self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, stream)
+        else:
+            capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, stream)
         self.circuit.store.touch()  # values changed in place: circuits that cache derived parameters must refresh
 
     def step(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Training-step timing on the GPU box:
     python scripts/bench_train.py [B] [steps] [config]
-config 2 (default): 784-var QuadTree, Categorical, K = 32; config 4: Poon-Domingos, Gaussian, K = 64."""
+config 2 (default): 784-var QuadTree, Categorical, K = 32; config 4: Poon-Domingos, Gaussian, K = 64;
+config 6: QuadGraph, Categorical, CP, K = 64 (the circuit of the reference's learning-a-circuit notebook, batch 256)."""
 import os
 import sys
 import time
@@ -21,6 +22,10 @@ if cfg == 4:
     plan = image_data((1, 28, 28), "poon-domingos", input_layer="gaussian", num_input_units=64,
                       sum_product_layer="cp", num_sum_units=64)
     x = torch.randn(B, 784).cuda()
+elif cfg == 6:
+    plan = image_data((1, 28, 28), "quad-graph", input_layer="categorical", num_input_units=64,
+                      sum_product_layer="cp", num_sum_units=64)
+    x = torch.randint(0, 256, (B, 784)).cuda()
 else:
     plan = image_data((1, 28, 28), "quad-tree-2", num_input_units=32, num_sum_units=32)
     x = torch.randint(0, 256, (B, 784)).cuda()
