@@ -392,6 +392,62 @@ def plans_only():
         print(name, len(plan.layers), "layers")
 
 
+def _clt_datasets():
+    """Seeded tabular datasets with a dependence structure worth learning (a shuffled noisy chain /
+    a few latent factors), small enough to commit."""
+    rng = np.random.default_rng(11)
+    # categorical: a noisy Markov chain over a shuffled variable order, 4 categories
+    n, d, c = 400, 9, 4
+    order = rng.permutation(d)
+    cat = np.zeros((n, d), dtype=np.int64)
+    cat[:, order[0]] = rng.integers(0, c, n)
+    for a, b in zip(order[:-1], order[1:]):
+        flip = rng.random(n) < 0.35
+        cat[:, b] = np.where(flip, rng.integers(0, c, n), cat[:, a])
+    # gaussian: 7 features driven by 2 latent factors with different loadings
+    z = rng.standard_normal((300, 2))
+    load = rng.standard_normal((2, 7))
+    gau = (z @ load + 0.6 * rng.standard_normal((300, 7))).astype(np.float32)
+    # mixed: categorical columns 0, 2, 4 (3 categories) and Gaussian columns 1, 3, 5 that follow them
+    m = 350
+    mix = np.zeros((m, 6), dtype=np.float32)
+    base = rng.integers(0, 3, m)
+    for j in range(6):
+        if j % 2 == 0:
+            base = np.where(rng.random(m) < 0.3, rng.integers(0, 3, m), base)
+            mix[:, j] = base
+        else:
+            mix[:, j] = base + 0.5 * rng.standard_normal(m)
+    return cat, gau, mix
+
+
+def chow_liu():
+    """Plans of HCLT circuits: the structure is LEARNED from data by the reference
+    (templates/region_graph/algorithms/chow_liu.py) -- the data, the learned tree (list of predecessors)
+    and the compiled plan are committed; cirkit_amd.templates must learn the same tree and emit the same plan."""
+    from cirkit.templates.region_graph.algorithms.chow_liu import ChowLiuTree
+
+    ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)
+    cat, gau, mix = _clt_datasets()
+    cases = [
+        ("plan_clt_cat9_cp", torch.from_numpy(cat), {"name": "categorical", "args": {"num_categories": 4}}, "cp"),
+        ("plan_clt_gauss7_cpt", torch.from_numpy(gau), {"name": "gaussian", "args": {}}, "cp-t"),
+        ("plan_clt_mixed6_cp", torch.from_numpy(mix),
+         [{"name": "categorical", "args": {"num_categories": 3}}, {"name": "gaussian", "args": {}}] * 3, "cp"),
+    ]
+    for name, data, inputs, sp in cases:
+        sc = data_modalities.tabular_data("chow-liu-tree", data=data, input_layers=inputs, num_input_units=3,
+                                          sum_product_layer=sp, num_sum_units=3)
+        itype = inputs["name"] if isinstance(inputs, dict) else [i["name"] for i in inputs]
+        ncat = inputs["args"]["num_categories"] if isinstance(inputs, dict) and inputs["name"] == "categorical" else None
+        tree = ChowLiuTree(data, itype, num_categories=ncat, as_region_graph=False)
+        plan, _ = plan_from_torch_circuit(ctx.compile(sc))
+        plan.name = name
+        plan.save(os.path.join(HERE, name))
+        np.savez_compressed(os.path.join(HERE, name + "_data.npz"), data=data.numpy(), tree=np.asarray(tree, dtype=np.int64))
+        print(name, len(plan.layers), "layers; tree", list(map(int, tree)))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "marginals", "templates_extra"]
     for w in which:

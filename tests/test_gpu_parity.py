@@ -542,3 +542,22 @@ def test_shared_store_of_a_padded_circuit(hip_device):
         return  # (squares of this layer mix are not built natively: nothing more to check)
     with pytest.raises(ValueError, match="pad_units=False"):
         HipCircuit(zplan, hc.store, device=hip_device)
+
+
+@pytest.mark.parametrize("name", ["plan_clt_cat9_cp", "plan_clt_gauss7_cpt", "plan_clt_mixed6_cp"])
+def test_chow_liu_circuits_match_oracle(hip_device, name):
+    """HCLT circuits (structure learned from the committed data, partitions of any arity, mixed input families)
+    on the HIP path against the oracle, evaluated on the rows the structure was learned from."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.plan import Plan
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan = Plan.load(os.path.join(GOLDEN, name))
+    with np.load(os.path.join(GOLDEN, name + "_data.npz")) as z:
+        x = torch.from_numpy(z["data"])
+    tensors = init_plan_tensors(plan, seed=9)
+    want = evaluate_plan(plan, as_torch(tensors), x)
+    got = HipCircuit(plan, tensors, device=hip_device)(x.to(hip_device)).cpu()
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= REL * max(1.0, float(want.abs().max()))
