@@ -316,6 +316,57 @@ def random_binary_tree(num_variables: int, *, depth: int | None = None, seed: in
     return b.graph(root)
 
 
+def fully_factorized(num_variables: int, *, num_repetitions: int = 1) -> RegionGraph:
+    """The root region split `num_repetitions` times into all its single variables
+    (templates/region_graph/algorithms/factorized.py:9-43); every repetition has its own leaf regions."""
+    if num_variables <= 0:
+        raise ValueError("The number of variables must be positive")
+    if num_repetitions <= 0:
+        raise ValueError("The number of repetitions must be positive")
+    b = _RGBuilder()
+    root = b.new(True, range(num_variables))
+    b.ins[root] = []
+    if num_variables == 1:
+        return b.graph(root)
+    for _ in range(num_repetitions):
+        leaves = [b.new(True, [v]) for v in range(num_variables)]
+        ptn = b.new(False, range(num_variables))
+        b.ins[ptn] = leaves
+        b.ins[root].append(ptn)
+    return b.graph(root)
+
+
+def linear_tree(num_variables: int, *, num_repetitions: int = 1, ordering: list[int] | None = None,
+                randomize: bool = False, seed: int = 42) -> RegionGraph:
+    """A chain of partitions that split off one variable at a time in the given (or, per repetition, shuffled)
+    order (templates/region_graph/algorithms/linear.py:15-77)."""
+    if num_variables <= 0:
+        raise ValueError("The number of variables must be positive")
+    if num_repetitions <= 0:
+        raise ValueError("The number of repetitions must be positive")
+    if ordering is not None and sorted(ordering) != list(range(num_variables)):
+        raise ValueError(f"The variables ordering must be a permutation of values from 0 to {num_variables-1}")
+    b = _RGBuilder()
+    root = b.new(True, range(num_variables))
+    if num_variables == 1:
+        return b.graph(root)
+    order = list(range(num_variables)) if ordering is None else list(ordering)
+    rs = np.random.RandomState(seed) if randomize else None
+    for _ in range(num_repetitions):
+        if rs is not None:
+            rs.shuffle(order)
+        node, rest = root, set(range(num_variables))
+        for v in order[:-1]:
+            ptn = b.new(False, rest)
+            rest = rest - {v}
+            leaf = b.new(True, [v])
+            nxt = b.new(True, rest)
+            b.ins.setdefault(node, []).append(ptn)
+            b.ins[ptn] = [leaf, nxt]
+            node = nxt
+    return b.graph(root)
+
+
 # ---------------------------------------------------------------------------------------------
 # structure learned from data: Chow-Liu tree -> hidden Chow-Liu tree region graph
 # (templates/region_graph/algorithms/chow_liu.py, utils.py:66-131 of the reference)

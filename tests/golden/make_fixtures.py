@@ -381,6 +381,13 @@ def plans_only():
     cases.append(("plan_pd_1x9x6_delta2_depth2_cp", from_rg(PoonDomingos((1, 9, 6), delta=2, max_depth=2), "cp", num_categories=5)))
     cases.append(("plan_rbt11_d2_cp", from_rg(RandomBinaryTree(11, depth=2), "cp", num_categories=3)))
     cases.append(("plan_rbt19_d3_cpt", from_rg(RandomBinaryTree(19, depth=3, seed=7), "cp-t", num_categories=3)))
+    from cirkit.templates.region_graph import FullyFactorized, LinearTree
+
+    cases.append(("plan_ff5_r1_cp", from_rg(FullyFactorized(5), "cp", num_categories=3)))
+    cases.append(("plan_ff4_r3_cp", from_rg(FullyFactorized(4, num_repetitions=3), "cp", num_categories=3)))
+    cases.append(("plan_lt6_r1_cp", from_rg(LinearTree(6), "cp", num_categories=3)))
+    cases.append(("plan_lt5_r2_rand3_cpt", from_rg(LinearTree(5, num_repetitions=2, randomize=True, seed=3), "cp-t", num_categories=3)))
+    cases.append(("plan_lt4_order2031_cp", from_rg(LinearTree(4, ordering=[2, 0, 3, 1]), "cp", num_categories=3)))
     cases.append(("plan_rbt6_perfeature_cp", data_modalities.tabular_data(
         "random-binary-tree", num_features=6,
         input_layers=[{"name": "categorical", "args": {"num_categories": 3}}, {"name": "gaussian", "args": {}}] * 3,

@@ -65,7 +65,7 @@ PLAN_ONLY = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLD
 def _rebuild(name: str) -> Plan:
     """The native call that corresponds to the reference call which produced fixture `name`
     (tests/golden/make_fixtures.py:plans_only)."""
-    from cirkit_amd.templates import build_plan, image_data, poon_domingos, tabular_data
+    from cirkit_amd.templates import build_plan, fully_factorized, image_data, linear_tree, poon_domingos, tabular_data
 
     sps = {"cp": "cp", "cpt": "cp-t", "tucker": "tucker"}
     m = re.fullmatch(r"plan_quadtree(\d)_(\d+)x(\d+)_(cp|cpt)", name)
@@ -91,10 +91,26 @@ def _rebuild(name: str) -> Plan:
         return random_binary_tree_plan(11, depth=2, input_layer=InputSpec("categorical", 3), **small)
     if name == "plan_rbt19_d3_cpt":
         return random_binary_tree_plan(19, depth=3, seed=7, input_layer=InputSpec("categorical", 3), **{**small, "sum_product": "cp-t"})
+    cat3 = dict(input_layer=InputSpec("categorical", 3), **small)
+    if name == "plan_ff5_r1_cp":
+        return build_plan(fully_factorized(5), **cat3)
+    if name == "plan_ff4_r3_cp":
+        return build_plan(fully_factorized(4, num_repetitions=3), **cat3)
+    if name == "plan_lt6_r1_cp":
+        return build_plan(linear_tree(6), **cat3)
+    if name == "plan_lt5_r2_rand3_cpt":
+        return build_plan(linear_tree(5, num_repetitions=2, randomize=True, seed=3), **{**cat3, "sum_product": "cp-t"})
+    if name == "plan_lt4_order2031_cp":
+        return build_plan(linear_tree(4, ordering=[2, 0, 3, 1]), **cat3)
     if name == "plan_rbt6_perfeature_cp":
         return tabular_data("random-binary-tree", num_features=6,
                             input_layers=[{"name": "categorical", "args": {"num_categories": 3}}, {"name": "gaussian", "args": {}}] * 3,
                             num_input_units=2, sum_product_layer="cp", num_sum_units=2)
+    if name in CLT_CASES:
+        inputs, sp = CLT_CASES[name]
+        with np.load(os.path.join(GOLDEN, name + "_data.npz")) as z:
+            return tabular_data("chow-liu-tree", data=z["data"], input_layers=inputs, num_input_units=3,
+                                sum_product_layer=sp, num_sum_units=3)
     raise AssertionError(f"no native recipe for fixture {name}")
 
 
