@@ -80,10 +80,33 @@ def _embedding_square_integral(l: LayerSpec, conjugate: bool) -> LayerSpec:
     return LayerSpec("constant", F, 1, 0, K * K, {"num_output_units": K * K, "log_space": False}, {"value": value})
 
 
+def _categorical_square_integral(l: LayerSpec) -> LayerSpec:
+    """log sum_x p_k(x) p_l(x) for every unit pair (k, l): the product of two Categorical layers (logits added
+    unit pair by unit pair, operators.py:106-139) integrated over their variable (the log-sum-exp of those logits
+    over the categories, operators.py:51-63) is a constant layer in log space with K*K units.  Written on the
+    probabilities: log of the (K, K) Gram matrix of the rows of `probs` (of exp(logits) for a logits layer)."""
+    K, F = l.num_output_units, l.num_folds
+    src = "probs" if "probs" in l.params else "logits"
+    g = _pointer_graph(l.params[src], conjugate=False)
+    nodes = list(g.nodes)
+    if g.output.kind != IDX_ARRAY or len(g.output.ids) != 1 or not np.array_equal(g.output.array, np.arange(F)):
+        raise NotImplementedError("categorical parameter graphs whose output re-orders folds")
+    a = g.output.ids[0]
+    if src == "logits":
+        nodes.append(ParamNode("exp", F, tuple(g.shape), {}, [FoldIndex([a], IDX_NONE)]))
+        a = len(nodes) - 1
+    nodes.append(ParamNode("einsum", F, (K, K), {"einsum": [[0, 1], [2, 1], [0, 2]]}, [FoldIndex([a], IDX_NONE), FoldIndex([a], IDX_NONE)]))
+    nodes.append(ParamNode("log", F, (K, K), {}, [FoldIndex([len(nodes) - 1], IDX_NONE)]))
+    nodes.append(ParamNode("flatten", F, (K * K,), {"start_dim": 0, "end_dim": 1}, [FoldIndex([len(nodes) - 1], IDX_NONE)]))
+    value = ParamGraph(nodes, FoldIndex([len(nodes) - 1], IDX_ARRAY, np.arange(F, dtype=np.int64)), F, (K * K,))
+    return LayerSpec("constant", F, 1, 0, K * K, {"num_output_units": K * K, "log_space": True}, {"value": value})
+
+
 def squared_partition_plan(plan: Plan, *, conjugate: bool | None = None) -> Plan:
     """The plan of ``Z = integral of c(x) * conj(c(x)) dx`` for a circuit ``c`` made of Embedding
     inputs, Hadamard products and dense sums (as such or fused into CP-T layers).  Z has no
-    variables: evaluate it with ``HipCircuit(z_plan, tensors_of_c)()`` -> ``(1, 1)``.
+    variables: evaluate it with ``HipCircuit(z_plan, tensors_of_c)()`` -> ``(1, 1)``.  Categorical inputs are
+    covered too (a real circuit squared: Z = sum_x c(x)^2).
 
     `conjugate` defaults to True under the complex semiring (|c|^2) and False otherwise (c^2)."""
     if conjugate is None:
@@ -108,6 +131,11 @@ def squared_partition_plan(plan: Plan, *, conjugate: bool | None = None) -> Plan
             if l.scope_idx is None or l.scope_idx.shape[1] != 1:
                 raise NotImplementedError("integrating input layers over several variables")
             last_of[i] = push(_embedding_square_integral(l, conjugate))
+            continue
+        if l.type == "categorical":
+            if l.scope_idx is None or l.scope_idx.shape[1] != 1:
+                raise NotImplementedError("integrating input layers over several variables")
+            last_of[i] = push(_categorical_square_integral(l))
             continue
         if l.type in ("hadamard", "cpt"):
             cur = push(LayerSpec("hadamard", F, l.arity, Ki * Ki, Ki * Ki, {"num_input_units": Ki * Ki, "arity": l.arity},

@@ -144,6 +144,24 @@ def cfg5(K=32):
     _save(f"cfg5_sos_z_k{K}", plan_z, {"z_c64": z.numpy()})
 
 
+def sq_categorical():
+    """A REAL circuit squared: Categorical inputs, CP-T layers, lse-sum.  Z = integrate(multiply(c, c)) from the
+    reference (operators.py:51-63 integrate Categorical, :106-139 Categorical x Categorical), with the closed-form
+    parameters; the native functional.squared_partition_plan must reproduce the value."""
+    sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", input_layer="categorical", num_input_units=5,
+                                    sum_product_layer="cp-t", num_sum_units=5)
+    ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)
+    cc = ctx.compile(sc)
+    zc = ctx.compile(SF.integrate(SF.multiply(sc, sc)))
+    table = tensor_table()
+    plan_c, tensors = plan_from_torch_circuit(cc, table=table)
+    _load_closed_form(plan_c, tensors, seed=6)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randint(0, 256, (8, 16), generator=g)
+    _save("sq_cat_qt4x4_k5", plan_c, {"x": x.numpy().astype(np.int16), "y_f32": cc(x).numpy(), "z_f32": zc().numpy(),
+                                      "z_f64": _fp64_copy(zc)().numpy()})
+
+
 def kats():
     """The reference's own known-answer circuits (tests/symbolic/test_utils.py:293-503), compiled by
     the reference with fold+optimize under lse-sum; literal weights stored (they are tiny)."""

@@ -63,7 +63,7 @@ def test_conjugate_plan_conjugates_the_output():
 
 
 def test_unsupported_layers_are_refused():
-    plan = build_plan(random_binary_tree(4), input_layer=InputSpec("categorical", 3), num_input_units=2, num_sum_units=2)
+    plan = build_plan(random_binary_tree(4), input_layer=InputSpec("gaussian"), num_input_units=2, num_sum_units=2)
     with pytest.raises(NotImplementedError):
         squared_partition_plan(plan)
 
@@ -96,3 +96,38 @@ def test_partition_function_is_the_sum_over_all_worlds_gpu(hip_device, sum_produ
     z = HipCircuit(squared_partition_plan(plan), tensors, device=hip_device)().cpu().reshape(-1)[0]
     total = float(torch.logsumexp(2 * c.real, dim=0))
     assert abs(float(z.real) - total) < 1e-4 * max(1.0, abs(total))
+
+
+def _sq_cat():
+    plan, _, g = load_case("sq_cat_qt4x4_k5")
+    return plan, init_plan_tensors(plan, seed=6), g
+
+
+def test_squared_categorical_circuit_reproduces_reference_partition_function():
+    """A real circuit with Categorical inputs, squared: Z = integrate(multiply(c, c)) of the reference
+    (tests/golden/make_fixtures.py:sq_categorical) from the natively built plan, and sum_x c(x)^2 = Z by
+    enumeration on a circuit small enough to enumerate."""
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan, tensors, g = _sq_cat()
+    assert np.allclose(evaluate_plan(plan, as_torch(tensors), torch.from_numpy(g["x"].astype(np.int64))).numpy(), g["y_f32"], rtol=1e-6)
+    z = evaluate_plan(squared_partition_plan(plan), as_torch(tensors), None)
+    assert abs(float(z.reshape(-1)[0]) - float(g["z_f64"].reshape(-1)[0])) <= 1e-5 * abs(float(g["z_f64"].reshape(-1)[0]))
+    small = build_plan(quad_tree(2, 2), input_layer=InputSpec("categorical", 4), sum_product="cp", num_input_units=3, num_sum_units=3)
+    t = init_plan_tensors(small, seed=3)
+    worlds = torch.tensor(list(itertools.product(range(4), repeat=4)), dtype=torch.int64)
+    ll = evaluate_plan(small, as_torch(t), worlds).double().reshape(-1)
+    zs = evaluate_plan(squared_partition_plan(small), as_torch(t), None)
+    assert abs(float(zs.reshape(-1)[0]) - float(torch.logsumexp(2 * ll, 0))) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_squared_categorical_partition_function_on_the_gpu(hip_device):
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = _sq_cat()
+    hc = HipCircuit(plan, tensors, device=hip_device, pad_units=False)  # Z shares c's (unpadded) parameters
+    hz = HipCircuit(squared_partition_plan(plan), hc.store, device=hip_device)
+    z = float(hz().cpu().reshape(-1)[0])
+    ref = float(g["z_f64"].reshape(-1)[0])
+    assert abs(z - ref) <= 1e-4 * abs(ref)
