@@ -704,6 +704,23 @@ __global__ void __launch_bounds__((WIDE ? kPW64 : kPW) * 64) softmax_batch_kerne
     softmax_job_rows(j, blk);
 }
 
+// log of the integral of the product of two Gaussian densities, for every pair of units (nodes.py:975-988):
+//   out[f, i * K2 + j] = -0.5 (log 2 pi + log(s1_i^2 + s2_j^2) + (m1_i - m2_j)^2 / (s1_i^2 + s2_j^2))
+__global__ void __launch_bounds__(256) gaussian_product_logz_kernel(const float* __restrict__ m1, const float* __restrict__ s1,
+                                                                    const float* __restrict__ m2, const float* __restrict__ s2,
+                                                                    float* __restrict__ out, int64_t F, int K1, int K2) {
+  const int64_t n = F * K1 * K2;
+  for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < n;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t f = e / (static_cast<int64_t>(K1) * K2);
+    const int r = static_cast<int>(e - f * K1 * K2), i = r / K2, j = r - i * K2;
+    const float a = s1[f * K1 + i], b = s2[f * K2 + j];
+    const float var = a * a + b * b;
+    const float d = m1[f * K1 + i] - m2[f * K2 + j];
+    out[e] = -0.5f * (1.8378770664093453f + logf(var) + d * d * (1.f / var));
+  }
+}
+
 // ---- log-likelihood sum ------------------------------------------------------------------------
 // Single workgroup: B is a batch (<= a few 10^5 rows), and a one-block tree gives a
 // run-to-run deterministic fp64 sum (no atomics).
@@ -971,6 +988,19 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
     }
   }
   return CK_OK;
+}
+
+int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
+                                   float* out, int64_t F, int K1, int K2, void* stream) {
+  CK_REQUIRE(mean1 && stddev1 && mean2 && stddev2 && out, "ck_param_gaussian_product_logz: null pointer");
+  CK_REQUIRE(F > 0 && K1 > 0 && K2 > 0, "ck_param_gaussian_product_logz: non-positive size");
+  dim3 grid(grid1d(F * K1 * K2)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(gaussian_product_logz_kernel, grid, block, 0, s, mean1, stddev1, mean2, stddev2, out, F, K1, K2);
+        return hipGetLastError();
+      },
+      stream);
 }
 
 int ck_ll_sum(const float* ll, int64_t B, int64_t stride, double* out_dev, void* stream) {

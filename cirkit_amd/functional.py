@@ -102,11 +102,37 @@ def _categorical_square_integral(l: LayerSpec) -> LayerSpec:
     return LayerSpec("constant", F, 1, 0, K * K, {"num_output_units": K * K, "log_space": True}, {"value": value})
 
 
+def _gaussian_square_integral(l: LayerSpec) -> LayerSpec:
+    """log of the integral of N(x; m_k, s_k) N(x; m_l, s_l) dx for every unit pair (k, l): the log-partition of the
+    product of two Gaussian layers (operators.py:142-200, nodes.py:975-988), which integrating that layer turns
+    into a constant layer in log space (operators.py:66-77)."""
+    if "log_partition" in l.params:
+        raise NotImplementedError("squaring Gaussian layers that carry a log-partition")
+    K, F = l.num_output_units, l.num_folds
+    nodes: list[ParamNode] = []
+    heads = []
+    for name in ("mean", "stddev"):
+        g = _pointer_graph(l.params[name], conjugate=False)
+        if g.output.kind != IDX_ARRAY or len(g.output.ids) != 1 or not np.array_equal(g.output.array, np.arange(F)):
+            raise NotImplementedError("Gaussian parameter graphs whose output re-orders folds")
+        off = len(nodes)
+        for n in g.nodes:  # the two graphs share one node list: shift the operand ids of the second
+            nodes.append(ParamNode(n.op, n.num_folds, tuple(n.shape), dict(n.config),
+                                   [FoldIndex([i + off for i in fi.ids], fi.kind, None if fi.array is None else fi.array.copy())
+                                    for fi in n.inputs]))
+        heads.append(g.output.ids[0] + off)
+    m, sd = heads
+    nodes.append(ParamNode("gaussian_product_log_partition", F, (K * K,), {},
+                           [FoldIndex([m], IDX_NONE), FoldIndex([sd], IDX_NONE), FoldIndex([m], IDX_NONE), FoldIndex([sd], IDX_NONE)]))
+    value = ParamGraph(nodes, FoldIndex([len(nodes) - 1], IDX_ARRAY, np.arange(F, dtype=np.int64)), F, (K * K,))
+    return LayerSpec("constant", F, 1, 0, K * K, {"num_output_units": K * K, "log_space": True}, {"value": value})
+
+
 def squared_partition_plan(plan: Plan, *, conjugate: bool | None = None) -> Plan:
     """The plan of ``Z = integral of c(x) * conj(c(x)) dx`` for a circuit ``c`` made of Embedding
     inputs, Hadamard products and dense sums (as such or fused into CP-T layers).  Z has no
-    variables: evaluate it with ``HipCircuit(z_plan, tensors_of_c)()`` -> ``(1, 1)``.  Categorical inputs are
-    covered too (a real circuit squared: Z = sum_x c(x)^2).
+    variables: evaluate it with ``HipCircuit(z_plan, tensors_of_c)()`` -> ``(1, 1)``.  Categorical and Gaussian
+    inputs are covered too (a real circuit squared: Z = sum / integral of c(x)^2).
 
     `conjugate` defaults to True under the complex semiring (|c|^2) and False otherwise (c^2)."""
     if conjugate is None:
@@ -132,10 +158,10 @@ def squared_partition_plan(plan: Plan, *, conjugate: bool | None = None) -> Plan
                 raise NotImplementedError("integrating input layers over several variables")
             last_of[i] = push(_embedding_square_integral(l, conjugate))
             continue
-        if l.type == "categorical":
+        if l.type in ("categorical", "gaussian"):
             if l.scope_idx is None or l.scope_idx.shape[1] != 1:
                 raise NotImplementedError("integrating input layers over several variables")
-            last_of[i] = push(_categorical_square_integral(l))
+            last_of[i] = push(_categorical_square_integral(l) if l.type == "categorical" else _gaussian_square_integral(l))
             continue
         if l.type in ("hadamard", "cpt"):
             cur = push(LayerSpec("hadamard", F, l.arity, Ki * Ki, Ki * Ki, {"num_input_units": Ki * Ki, "arity": l.arity},

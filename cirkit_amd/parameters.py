@@ -327,6 +327,11 @@ class HipParameter:
                 capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), a.shape[0], M, N, Kd, ta, tb, stream)
             elif n.op == "flatten":  # nodes.py:843-844
                 y = xs[0].reshape(shape)
+            elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
+                m1, s1, m2, s2 = (x.contiguous() for x in xs)
+                F, K1, K2 = m1.shape[0], m1.shape[1], m2.shape[1]
+                y = self._buf(j, (F, K1 * K2))
+                capi.call("ck_param_gaussian_product_logz", _ptr(m1), _ptr(s1), _ptr(m2), _ptr(s2), _ptr(y), F, K1, K2, stream)
             else:
                 raise NotImplementedError(f"parameter op {n.op}")
             outs.append(y)

@@ -61,6 +61,7 @@ PARAM_OPS = {
     "TorchMatMulParameter": "matmul",
     "TorchEinsumParameter": "einsum",
     "TorchFlattenParameter": "flatten",
+    "TorchGaussianProductLogPartition": "gaussian_product_log_partition",
 }
 
 

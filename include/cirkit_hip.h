@@ -262,6 +262,10 @@ typedef struct ck_softmax_job {
   float* out2;        /* kind 5: (rows, C+1) log scale of each table row */
 } ck_softmax_job;
 int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream);
+/* TorchGaussianProductLogPartition.forward (nodes.py:975-988): out[f, i*K2 + j] = log of the integral of the product
+ * of Gaussian unit i of (mean1, stddev1) and unit j of (mean2, stddev2); all inputs (F, K). */
+int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
+                                   float* out, int64_t F, int K1, int K2, void* stream);
 /* entrywise ops (nodes.py:656-699); a, b only used by CK_UNARY_SCALED_SIGMOID (vmin, vmax). */
 int ck_param_unary(int op, const float* in, float* out, int64_t n, float a, float b, void* stream);
 /* out[f] = in[idx[f]] over blocks of `per_fold` 4-byte words (pointer fold_idx nodes.py:277-279,

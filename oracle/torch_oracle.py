@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import functools
 import itertools
+import math
 from typing import Mapping
 
 import numpy as np
@@ -193,6 +194,11 @@ def eval_param(pg: ParamGraph, tensors: Mapping[str, Tensor]) -> Tensor:
             y = torch.einsum(*args, folded[-1])
         elif n.op == "flatten":  # nodes.py:843-844
             y = torch.flatten(xs[0], start_dim=c["start_dim"] + 1, end_dim=c["end_dim"] + 1)
+        elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
+            mean1, stddev1, mean2, stddev2 = xs
+            var12 = torch.square(stddev1).unsqueeze(dim=2) + torch.square(stddev2).unsqueeze(dim=1)
+            sq = torch.square(mean1.unsqueeze(dim=2) - mean2.unsqueeze(dim=1)) * torch.reciprocal(var12)
+            y = (-0.5 * (math.log(2.0 * math.pi) + torch.log(var12) + sq)).view(mean1.shape[0], -1)
         else:
             raise NotImplementedError(n.op)
         outs.append(y)

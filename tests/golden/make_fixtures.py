@@ -162,6 +162,23 @@ def sq_categorical():
                                       "z_f64": _fp64_copy(zc)().numpy()})
 
 
+def sq_gaussian():
+    """A real circuit with Gaussian inputs, squared: Z = integrate(multiply(c, c)) from the reference
+    (operators.py:66-77, 142-200; nodes.py:975-988)."""
+    sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", input_layer="gaussian", num_input_units=4,
+                                    sum_product_layer="cp", num_sum_units=4)
+    ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)
+    cc = ctx.compile(sc)
+    zc = ctx.compile(SF.integrate(SF.multiply(sc, sc)))
+    table = tensor_table()
+    plan_c, tensors = plan_from_torch_circuit(cc, table=table)
+    _load_closed_form(plan_c, tensors, seed=8)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((8, 16), generator=g)
+    _save("sq_gauss_qt4x4_k4", plan_c, {"x": x.numpy(), "y_f32": cc(x).numpy(), "z_f32": zc().numpy(),
+                                        "z_f64": _fp64_copy(zc)().numpy()})
+
+
 def kats():
     """The reference's own known-answer circuits (tests/symbolic/test_utils.py:293-503), compiled by
     the reference with fold+optimize under lse-sum; literal weights stored (they are tiny)."""

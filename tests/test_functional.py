@@ -63,7 +63,9 @@ def test_conjugate_plan_conjugates_the_output():
 
 
 def test_unsupported_layers_are_refused():
-    plan = build_plan(random_binary_tree(4), input_layer=InputSpec("gaussian"), num_input_units=2, num_sum_units=2)
+    from cirkit_amd.templates import image_data
+
+    plan = image_data((1, 4, 4), "quad-tree-2", num_input_units=2, sum_product_layer="tucker", num_sum_units=2)
     with pytest.raises(NotImplementedError):
         squared_partition_plan(plan)
 
@@ -131,3 +133,27 @@ def test_squared_categorical_partition_function_on_the_gpu(hip_device):
     z = float(hz().cpu().reshape(-1)[0])
     ref = float(g["z_f64"].reshape(-1)[0])
     assert abs(z - ref) <= 1e-4 * abs(ref)
+
+
+def test_squared_gaussian_circuit_reproduces_reference_partition_function():
+    """Gaussian inputs: the integral of the product of two Gaussian units in closed form (nodes.py:975-988)."""
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan, _, g = load_case("sq_gauss_qt4x4_k4")
+    tensors = init_plan_tensors(plan, seed=8)
+    assert np.allclose(evaluate_plan(plan, as_torch(tensors), torch.from_numpy(g["x"])).numpy(), g["y_f32"], rtol=1e-6)
+    z = evaluate_plan(squared_partition_plan(plan), as_torch(tensors), None)
+    ref = float(g["z_f64"].reshape(-1)[0])
+    assert abs(float(z.reshape(-1)[0]) - ref) <= 1e-5 * abs(ref)
+
+
+@pytest.mark.gpu
+def test_squared_gaussian_partition_function_on_the_gpu(hip_device):
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, _, g = load_case("sq_gauss_qt4x4_k4")
+    tensors = init_plan_tensors(plan, seed=8)
+    hc = HipCircuit(plan, tensors, device=hip_device, pad_units=False)
+    hz = HipCircuit(squared_partition_plan(plan), hc.store, device=hip_device)
+    ref = float(g["z_f64"].reshape(-1)[0])
+    assert abs(float(hz().cpu().reshape(-1)[0]) - ref) <= 1e-4 * abs(ref)
