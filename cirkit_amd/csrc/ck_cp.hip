@@ -240,37 +240,23 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
   const int T = H * S;
   const int64_t* ro = row_off + static_cast<int64_t>(f) * T;
   const int64_t* wa = w_addr + static_cast<int64_t>(f) * T;
-  // W_t: global -> registers (`fetch`, right after the barrier of step t - 2, so the L2 latency is covered by that
-  // step's MFMA chain) -> LDS buffer t % 3 (`commit`, at the top of step t - 1).  The buffer was last read in step
-  // t - 3, which every wave left before the barrier of step t - 2.
+  // W_t travels global -> LDS buffer t % 3 directly (global_load_lds_dwordx4: no registers, no store instruction),
+  // issued right after the barrier of step t - 2 -- every wave has then left step t - 3, the last reader of that
+  // buffer -- and covered by that step's MFMA chain; a wave waits for its own loads (vmcnt) before the barrier of
+  // step t - 1.  Lane l of wave w writes 16 bytes at LDS word 4 (k * WAVES * 64 + w * 64 + l): the operand layout.
   constexpr int PF = (WF4 + WAVES * 64 - 1) / (WAVES * 64);
-  float pre[PF][4];
-  bool pre_valid = false;
-  auto fetch = [&](int t) {
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto stage_async = [&](int t) {
     const float* wf = reinterpret_cast<const float*>(static_cast<uintptr_t>(wa[t]));
-    pre_valid = wf != nullptr;
-    if (!pre_valid) return;
-#pragma unroll
-    for (int k = 0; k < PF; ++k) {
-      const int i = threadIdx.x + k * (WAVES * 64);
-      if (WF4 % (WAVES * 64) != 0 && i >= WF4) continue;
-      const int ln = i & 63, g = (i >> 6) & 3, pq = i >> 8, q = pq % NK, p = pq / NK;
-      const float4 v4 = *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(32 * p + (ln & 31)) * K + 32 * q + 8 * g +
-                                                         4 * (ln >> 5));
-      pre[k][0] = v4.x;
-      pre[k][1] = v4.y;
-      pre[k][2] = v4.z;
-      pre[k][3] = v4.w;
-    }
-  };
-  auto commit = [&](int t) {
-    if (!pre_valid) return;
+    if (wf == nullptr) return;
     float* dstb = w_s + (t % 3) * K * K;
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
       const int i = threadIdx.x + k * (WAVES * 64);
       if (WF4 % (WAVES * 64) != 0 && i >= WF4) continue;
-      *reinterpret_cast<float4*>(&dstb[4 * i]) = make_float4(pre[k][0], pre[k][1], pre[k][2], pre[k][3]);
+      const int ln = i & 63, g = (i >> 6) & 3, pq = i >> 8, q = pq % NK, p = pq / NK;
+      const float* src = wf + static_cast<int64_t>(32 * p + (ln & 31)) * K + 32 * q + 8 * g + 4 * (ln >> 5);
+      __builtin_amdgcn_global_load_lds((ck::gptr_t)src, (ck::lptr_t)(dstb + 4 * (k * WAVES * 64 + wave_u * 64)), 16, 0, 0);
     }
   };
   const float* mwf = mw + static_cast<int64_t>(f) * K * H;
@@ -278,9 +264,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
     const int k = i / H, h = i - k * H;
     mw_s[h * K + k] = mwf[i];
   }
-  fetch(0);
-  commit(0);
-  if (T > 1) fetch(1);
+  stage_async(0);
+  if (T > 1) stage_async(1);
 
   float A[NK][16];
 #pragma unroll
@@ -292,7 +277,6 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
   for (int h = 0; h < H; ++h) {
     float P[NK][16];
     for (int s = 0; s < S; ++s, ++t) {
-      if (t + 1 < T) commit(t + 1);  // fetched during step t - 1
       float v[NK][16];
       const float* src = slot_source(gs, arena, ro[t], static_cast<int64_t>(f) * T + t, bl, B, K, kh);
 #pragma unroll
@@ -321,8 +305,9 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[q][j] = __builtin_amdgcn_exp2f(fmaf(v[q][j], kL2E, nml));
       }
-      __syncthreads();  // W_t is in LDS; every wave has left the MFMA chain of step t - 1
-      if (t + 2 < T) fetch(t + 2);
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of W_t (and W_{t+1}) has landed in LDS
+      __syncthreads();                      // W_t is in LDS; every wave has left the MFMA chain of step t - 1
+      if (t + 2 < T) stage_async(t + 2);
       if (dense) {
         const float* wb = w_s + (t % 3) * K * K;
 #pragma unroll

@@ -58,6 +58,9 @@ __device__ __forceinline__ float xhalf_max(float m) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+// address-space-qualified pointers for __builtin_amdgcn_global_load_lds (global memory -> LDS without registers)
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
 // torch.clamp(amax, finfo.min, finfo.max) of semiring.py:392-399
 __device__ __forceinline__ float clamp_finite(float m) {
   return fminf(fmaxf(m, -3.402823466e+38f), 3.402823466e+38f);
