@@ -34,29 +34,21 @@ __global__ void __launch_bounds__(256)
   const float* wf = w + static_cast<int64_t>(f) * Ko * N;
   const int npb = Ko >> 5;  // output blocks
 
-  // rows 32p .. 32p+31 of the (Ko, N) matrix -> operand layout; global -> registers one block ahead of the
-  // registers -> LDS copy, so that the load latency is covered by a whole block of MFMAs
-  float pre[NQ][4];
-  auto fetch = [&](int p) {
+  // rows 32p .. 32p+31 of the (Ko, N) matrix -> operand layout, global -> LDS directly (global_load_lds_dwordx4: lane l
+  // of wave w writes 16 bytes at LDS word 4 (256 k + 64 w + l)), one block ahead of its use: the loads are in flight
+  // during a whole block of MFMAs and a wave waits for its own share (vmcnt) before the barrier that publishes it
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto stage_async = [&](int p, int buf) {
+    float* dst = w_s + buf * (NQ * 1024);
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
       const int i = threadIdx.x + 256 * k;
       const int ln = i & 63, g = (i >> 6) & 3, q = i >> 8;
-      const float4 v = *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(32 * p + (ln & 31)) * N + 32 * q +
-                                                        8 * g + 4 * (ln >> 5));
-      pre[k][0] = v.x;
-      pre[k][1] = v.y;
-      pre[k][2] = v.z;
-      pre[k][3] = v.w;
+      const float* src = wf + static_cast<int64_t>(32 * p + (ln & 31)) * N + 32 * q + 8 * g + 4 * (ln >> 5);
+      __builtin_amdgcn_global_load_lds((ck::gptr_t)src, (ck::lptr_t)(dst + 4 * (256 * k + 64 * wave_u)), 16, 0, 0);
     }
   };
-  auto commit = [&](int buf) {
-    float* dst = w_s + buf * (NQ * 1024);
-#pragma unroll
-    for (int k = 0; k < NQ; ++k)
-      *reinterpret_cast<float4*>(dst + 4 * (threadIdx.x + 256 * k)) = make_float4(pre[k][0], pre[k][1], pre[k][2], pre[k][3]);
-  };
-  fetch(0);
+  stage_async(0, 0);
 
   float e[NQ][16];
   if (CAT) {
@@ -84,12 +76,10 @@ __global__ void __launch_bounds__(256)
     for (int j = 0; j < 16; ++j) e[q][j] = __builtin_amdgcn_exp2f(fmaf(e[q][j], kL2E, nml));
 
   float* dst = out + (static_cast<int64_t>(f) * B + bl) * Ko + 4 * kh;
-  commit(0);
-  fetch(npb > 1 ? 1 : 0);
   for (int p = 0; p < npb; ++p) {
-    __syncthreads();  // block p is staged; every wave has left the contraction of block p - 1
-    if (p + 1 < npb) commit((p + 1) & 1);
-    fetch(p + 2 < npb ? p + 2 : npb - 1);  // (the last two fetches are redundant re-reads, never committed)
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of block p has landed in LDS
+    __syncthreads();                      // block p is staged; every wave has left the contraction of block p - 1
+    if (p + 1 < npb) stage_async(p + 1, (p + 1) & 1);
     const float* wb = w_s + (p & 1) * (NQ * 1024);
     f32x16 acc;
 #pragma unroll
