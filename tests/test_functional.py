@@ -157,3 +157,17 @@ def test_squared_gaussian_partition_function_on_the_gpu(hip_device):
     hz = HipCircuit(squared_partition_plan(plan), hc.store, device=hip_device)
     ref = float(g["z_f64"].reshape(-1)[0])
     assert abs(float(hz().cpu().reshape(-1)[0]) - ref) <= 1e-4 * abs(ref)
+
+
+@pytest.mark.gpu
+def test_partition_function_of_a_padded_circuit(hip_device):
+    """Unit counts padded to 32: squaring the PADDED plan (`hc.plan`) over the padded parameter store gives the same Z
+    (padded units carry weight 0 everywhere)."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = _sq_cat()
+    hc = HipCircuit(plan, tensors, device=hip_device)  # K = 5 -> 32
+    assert hc._pad_info is not None
+    hz = HipCircuit(squared_partition_plan(hc.plan), hc.store, device=hip_device)
+    ref = float(g["z_f64"].reshape(-1)[0])
+    assert abs(float(hz().cpu().reshape(-1)[0]) - ref) <= 1e-4 * abs(ref)
