@@ -133,8 +133,12 @@ def _pad_graph(g: ParamGraph, roles: list[_Role | None], multiple: int, info: Pa
 
     def assign(ids, r, op):
         for i in ids:
-            if i in node_roles and (node_roles[i] != r or above[i] != op):
-                raise _Unsupported("a parameter node is consumed with two unit structures")
+            if i in node_roles:
+                if node_roles[i] != r:
+                    raise _Unsupported("a parameter node is consumed with two unit structures")
+                if above[i] != op:  # e.g. mixing weights used as they are by some folds and inside a product by others
+                    above[i] = "*"  # (only matters for a raw tensor, which is then refused)
+                continue
             node_roles[i] = r
             above[i] = op
 

@@ -41,11 +41,26 @@ class HipTrainer:
         optimizer: str = "adam",
         betas: tuple[float, float] = (0.9, 0.999),
         eps: float = 1e-8,
+        pad_units: bool = False,
     ) -> None:
+        """`pad_units`: train the plan with its unit counts padded to multiples of 32 (cirkit_amd/padding.py), so that
+        the MFMA forward / backward tiles apply to any width.  The padded entries never receive a gradient (softmax
+        at a -inf logit, zero weight on every padded unit), so the padded circuit stays the same function; `self.grads`
+        and the parameter store then hold the PADDED tensors -- `gradients()` / `parameters()` return user shapes."""
         if plan.semiring != "lse-sum":
             raise NotImplementedError("training is implemented for the real lse-sum semiring")
         if optimizer not in ("adam", "sgd"):
             raise ValueError(f"unknown optimizer {optimizer!r}")
+        self.user_plan, self._pad_info = plan, None
+        if pad_units:
+            from . import padding
+
+            res = padding.pad_units(plan)
+            if res is not None:
+                plan, self._pad_info = res
+                host = {n: (tensors[n].detach().cpu().numpy() if hasattr(tensors[n], "detach") else np.asarray(tensors[n]))
+                        for n in self.user_plan.tensors}
+                tensors = padding.pad_tensors(self._pad_info, host)
         # all parameters live in ONE flat buffer (the store's tensors are views of it, in plan order -- the order of
         # the flat gradient and moment buffers): the optimizer step is a single launch
         dev = torch.device(device)
@@ -283,6 +298,19 @@ class HipTrainer:
                 elif not raw:
                     l.weight.backward(dW, self.grads, stream)
         return ll
+
+    def gradients(self) -> dict[str, np.ndarray]:
+        """The gradients of the last `loss_and_grads`, host copies in the shapes of the user's plan."""
+        out = {}
+        for n in self.user_plan.tensors:
+            g = self.grads[n].detach().cpu().numpy()
+            out[n] = self._pad_info.unpad(n, g) if self._pad_info is not None else g
+        return out
+
+    def parameters(self) -> dict[str, np.ndarray]:
+        """The current parameter values, host copies in the shapes of the user's plan."""
+        return {n: self.circuit.store.export(n) if self._pad_info is None else
+                self._pad_info.unpad(n, self.circuit.store[n].detach().cpu().numpy()) for n in self.user_plan.tensors}
 
     def all_reduce_grads(self) -> None:
         """The one gradient exchange of data-parallel training: SUM over ranks of the flat buffer."""

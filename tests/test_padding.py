@@ -64,6 +64,30 @@ def test_multiclass_output_is_sliced():
     assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("name", ["quadgraph_6x6_k4", "pd_gauss_6x6_k4", "cfg1_rbt8", "plan_quadgraph_1x8x8_cp_mixFalse"])
+def test_reference_plans_with_mixed_parameter_graphs(name):
+    """Plans extracted from the reference (folds of one layer built from DIFFERENT parameter graphs: plain mixing
+    weights next to collapsed Sum -> Sum products) pad to the same function."""
+    from conftest import GOLDEN, load_case
+    from cirkit_amd.plan import Plan
+
+    if name.startswith("plan_"):  # plan-only fixture
+        plan = Plan.load(os.path.join(GOLDEN, name))
+        tensors = init_plan_tensors(plan, seed=1)
+    else:
+        plan, tensors, _ = load_case(name)
+    res = pad_units(plan)
+    assert res is not None
+    padded, info = res
+    gen = torch.Generator().manual_seed(2)
+    gauss = any(l.type == "gaussian" for l in plan.layers)
+    x = torch.randn((7, plan.num_variables), generator=gen) if gauss else torch.randint(0, 3, (7, plan.num_variables), generator=gen)
+    want = evaluate_plan(plan, as_torch(tensors), x)
+    got = evaluate_plan(padded, as_torch(pad_tensors(info, tensors)), x)[..., : info.out_units]
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_nothing_to_do_or_unsupported():
     assert pad_units(image_data((1, 4, 4), "quad-tree-2", num_input_units=32, num_sum_units=32)) is None
     sq = image_data((1, 4, 4), "quad-tree-2", input_layer="embedding", num_input_units=6, sum_product_layer="cp-t",
