@@ -78,3 +78,25 @@ def test_full_batch_normalisation_and_sum_rule(hip_device, cfg):
     joint = hc(grid.to(hip_device)).reshape(16, 256).double()
     marg = hc(base.to(hip_device), integrate_vars=[v]).reshape(16).double()
     assert float((torch.logsumexp(joint, dim=1) - marg).abs().max()) <= 1e-4 * float(marg.abs().max())
+
+
+def test_many_batch_sizes_and_long_replay(hip_device):
+    """Serving pattern: batch sizes change from call to call (the circuit keeps a few bindings and re-binds the
+    rest), results must not depend on it; and a long run of replays neither drifts nor grows memory."""
+    plan, tensors, x, hc = _circuit(2, hip_device)
+    xd = x.to(hip_device)
+    full = hc(xd).clone()
+    g = torch.Generator().manual_seed(0)
+    for _ in range(40):
+        b = int(torch.randint(1, 4097, (1,), generator=g))
+        y = hc(xd[:b])
+        assert y.shape[0] == b
+        assert float((y - full[:b]).abs().max()) <= 2e-4 * float(full[:b].abs().max())
+    ref = hc.log_likelihood_sum(xd).clone()
+    torch.cuda.synchronize()
+    m0 = torch.cuda.memory_allocated()
+    for _ in range(2000):
+        r = hc.log_likelihood_sum(xd)
+    torch.cuda.synchronize()
+    assert torch.equal(r, ref)
+    assert torch.cuda.memory_allocated() == m0
