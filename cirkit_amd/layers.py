@@ -532,6 +532,16 @@ class HipSumLayer(HipInnerLayer):
         )
 
     def register_batched(self, batch) -> bool:
+        if self._mixing and not self.is_complex:
+            # the (F, K, H) mixing coefficients: rows of H <= 32 entries in the same batched launch
+            src = self.weight.mixing_softmax_source()
+            self._w_layout = capi.CK_W_ROWMAJOR
+            if src is None or src.shape[-1] > 32:
+                return False
+            self._w = torch.empty_like(src)
+            batch.add_softmax(src, self._w, capi.CK_W_ROWMAJOR)
+            self._batched = True
+            return True
         src = None if (self._mixing or self.is_complex) else self.weight.softmax_source()
         if src is None:
             self._w_layout = capi.CK_W_ROWMAJOR

@@ -460,6 +460,22 @@ class HipParameter:
         t = self.store[g.nodes[0].config["tensor"]]
         return None if t.is_complex() else t
 
+    def mixing_softmax_source(self) -> torch.Tensor | None:
+        """The raw (F, K, H) tensor when the graph is exactly ``tensor -> softmax(last axis) -> mixing_weight`` with
+        identity fold indices (the default parameterisation of a mixing layer), else None."""
+        g = self.graph
+        if g.ops != ["tensor", "softmax", "mixing_weight"] or not self.tail_is("mixing_weight"):
+            return None
+        n = g.nodes[1]
+        if int(n.config["dim"]) != len(n.shape) - 1:
+            return None
+        for node, src in ((g.nodes[1], 0), (g.nodes[2], 1)):
+            fi = node.inputs[0]
+            if fi.ids != [src] or fi.kind != IDX_NONE:
+                return None
+        t = self.store[g.nodes[0].config["tensor"]]
+        return None if t.is_complex() else t
+
     def tail_is(self, *ops: str) -> bool:
         """True when the graph ends with `ops` feeding the output untouched (identity output index
         over a single producer) -- lets a layer fuse the tail into its kernel."""

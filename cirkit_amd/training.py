@@ -281,7 +281,12 @@ class HipTrainer:
                           l._w.data_ptr(), gviews[i].data_ptr(), dmw.data_ptr(), l.num_folds, l.arity, B,
                           l.num_output_units, fl, stream)
                 gather_shared(i)
-                l.weight.backward(dmw, self.grads, stream, upto=len(l.weight.graph.nodes) - 2)
+                if l._batched:  # tensor -> softmax evaluated by the batched prologue: its backward is one kernel
+                    name = l.weight.graph.nodes[0].config["tensor"]
+                    capi.call("ck_param_softmax_bwd", l._w.data_ptr(), dmw.data_ptr(), self.grads[name].data_ptr(),
+                              l.num_folds * l.num_output_units, dmw.shape[-1], 0, stream)
+                else:
+                    l.weight.backward(dmw, self.grads, stream, upto=len(l.weight.graph.nodes) - 2)
             else:  # sum / cpt
                 raw = l.weight.ops == ["tensor"]
                 dW = self.grads[l.weight.graph.nodes[0].config["tensor"]] if raw else st["dws"][i]
