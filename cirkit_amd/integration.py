@@ -29,8 +29,11 @@ from .plan import plan_from_torch_circuit, tensor_table
 def to_hip(circuit: Any, *, device: str | torch.device = "cuda:0", **kw: Any) -> HipCircuit:
     """A compiled reference ``TorchCircuit`` -> `HipCircuit` with the same parameters.  When the
     reference circuit already lives on `device` the parameter storage is shared (in-place optimiser
-    steps on the reference's ``nn.Parameter``s are seen by the next HIP forward)."""
+    steps on the reference's ``nn.Parameter``s are seen by the next HIP forward).  That is why unit counts are NOT
+    padded to multiples of 32 here by default (padding copies the parameters into larger tensors): pass
+    ``pad_units=True`` to trade the sharing for the MFMA tiles when the widths are not multiples of 32."""
     plan, tensors = plan_from_torch_circuit(circuit)
+    kw.setdefault("pad_units", False)
     return HipCircuit(plan, tensors, device=device, **kw)
 
 
