@@ -869,7 +869,7 @@ class HipCircuit:
                 return f"subtree_linear_kernel<{g.depth}, {self._group_layout(g)}>"
             return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")
-        if s.type in ("categorical", "embedding"):
+        if s.type in ("categorical", "embedding", "binomial"):
             return "gather_rows_vec" if l.num_output_units % 4 == 0 else "gather_rows_scalar"
         if s.type == "gaussian":
             return "gaussian_kernel"

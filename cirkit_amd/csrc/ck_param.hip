@@ -704,6 +704,35 @@ __global__ void __launch_bounds__((WIDE ? kPW64 : kPW) * 64) softmax_batch_kerne
     softmax_job_rows(j, blk);
 }
 
+// Binomial log-pmf table (TorchBinomialLayer.log_unnormalized_likelihood, input.py:530-541, through
+// torch.distributions.Binomial.log_prob): table[f, c, k] = c l - lgamma(c + 1) - lgamma(n - c + 1)
+//   - (n max(l, 0) + n log1p(exp(-|l|)) - lgamma(n + 1)),  l = logits[f, k] or log(p) - log1p(-p) of the clamped
+// probability (probs_to_logits); row n + 1 is the integral row (a normalised distribution: 0).
+__global__ void __launch_bounds__(256) binomial_table_kernel(const float* __restrict__ p, int is_logits, float* __restrict__ table,
+                                                             int64_t F, int K, int n) {
+  const int64_t rows = n + 2;
+  const int64_t total = F * rows * K;
+  for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int k = static_cast<int>(e % K);
+    const int c = static_cast<int>((e / K) % rows);
+    const int64_t f = e / (K * rows);
+    if (c == n + 1) {
+      table[e] = 0.f;
+      continue;
+    }
+    float l = p[f * K + k];
+    if (!is_logits) {
+      const float eps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps: clamp_probs
+      const float q = fminf(fmaxf(l, eps), 1.f - eps);
+      l = logf(q) - log1pf(-q);
+    }
+    const float nf = static_cast<float>(n), cf = static_cast<float>(c);
+    const float norm = nf * fmaxf(l, 0.f) + nf * log1pf(expf(-fabsf(l))) - lgammaf(nf + 1.f);
+    table[e] = cf * l - lgammaf(cf + 1.f) - lgammaf(nf - cf + 1.f) - norm;
+  }
+}
+
 // log of the integral of the product of two Gaussian densities, for every pair of units (nodes.py:975-988):
 //   out[f, i * K2 + j] = -0.5 (log 2 pi + log(s1_i^2 + s2_j^2) + (m1_i - m2_j)^2 / (s1_i^2 + s2_j^2))
 __global__ void __launch_bounds__(256) gaussian_product_logz_kernel(const float* __restrict__ m1, const float* __restrict__ s1,
@@ -988,6 +1017,18 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
     }
   }
   return CK_OK;
+}
+
+int ck_param_binomial_table(const float* p, int is_logits, float* table, int64_t F, int K, int total_count, void* stream) {
+  CK_REQUIRE(p && table, "ck_param_binomial_table: null pointer");
+  CK_REQUIRE(F > 0 && K > 0 && total_count >= 0, "ck_param_binomial_table: bad sizes");
+  dim3 grid(grid1d(F * (total_count + 2) * K)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(binomial_table_kernel, grid, block, 0, s, p, is_logits, table, F, K, total_count);
+        return hipGetLastError();
+      },
+      stream);
 }
 
 int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,

@@ -250,6 +250,46 @@ class HipCategoricalLayer(HipInputLayer):
         )
 
 
+class HipBinomialLayer(HipCategoricalLayer):
+    """``TorchBinomialLayer`` (layers/input.py:437-549): every unit a Binomial(total_count, p_k) over the values
+    0 .. total_count.  Evaluated like a Categorical layer with total_count + 1 categories whose log-table is the
+    Binomial log-pmf (`ck_param_binomial_table`, the arithmetic of torch.distributions.Binomial.log_prob)."""
+
+    def __init__(self, scope_idx, num_output_units: int, *, total_count: int = 1, probs: HipParameter | None = None,
+                 logits: HipParameter | None = None, semiring: str | None = None) -> None:
+        if total_count < 0:
+            raise ValueError("The number of trials should be non-negative")
+        HipInputLayer.__init__(self, scope_idx, num_output_units, semiring=semiring)
+        if self.num_variables != 1:
+            raise ValueError("The Binomial layer encodes a univariate distribution")
+        if not ((logits is None) ^ (probs is None)):
+            raise ValueError("Exactly one between 'logits' and 'probs' must be specified")
+        self.total_count = total_count
+        self.num_categories = total_count + 1
+        p = probs if probs is not None else logits
+        self._check_param("probs" if probs is not None else "logits", p, (num_output_units,))
+        self.probs, self.logits = probs, logits
+        self._table = None
+
+    @property
+    def config(self) -> Mapping[str, Any]:
+        return {"num_output_units": self.num_output_units, "total_count": self.total_count}
+
+    def register_batched(self, batch) -> bool:
+        return False
+
+    def prepare(self, stream: int, batched: bool = False) -> None:
+        p = self.probs if self.probs is not None else self.logits
+        v = p.evaluate(stream)
+        if v.is_complex():
+            raise NotImplementedError("complex binomial parameters")
+        F, K = v.shape
+        if self._table is None or self._table.device != v.device:
+            self._table = torch.empty((F, self.total_count + 2, K), dtype=torch.float32, device=v.device)
+        capi.call("ck_param_binomial_table", _ptr(v.contiguous()), 0 if self.probs is not None else 1, _ptr(self._table),
+                  F, K, self.total_count, stream)
+
+
 class HipEmbeddingLayer(HipInputLayer):
     """``TorchEmbeddingLayer`` (layers/input.py:186-266): ``weight[f, :, x]`` mapped from the
     sum-product semiring, i.e. log (lse-sum) or complex log (complex-lse-sum)."""
@@ -677,6 +717,7 @@ class HipTensorDotLayer(HipInnerLayer):
 
 LAYER_CLASSES: dict[str, type] = {
     "categorical": HipCategoricalLayer,
+    "binomial": HipBinomialLayer,
     "gaussian": HipGaussianLayer,
     "embedding": HipEmbeddingLayer,
     "constant": HipConstantValueLayer,

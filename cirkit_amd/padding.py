@@ -8,10 +8,12 @@ of 32 WITHOUT changing what the circuit computes:
 * the raw parameter tensors are enlarged; entries of a sum weight that multiply a padded INPUT unit are
   filled so that the parameter graph maps them to exactly 0 (``-inf`` under softmax / exp / sigmoid, ``0``
   for an unconstrained weight), so a padded unit never contributes to a real one;
-* rows that produce a padded OUTPUT unit (and the parameters of padded input-layer units) are filled with
-  ``0``: such a unit carries a finite value of the same scale as its real neighbours (a uniform mixture of
-  the real inputs, a uniform Categorical, a standard Gaussian), which keeps the row maxima of the
-  log-sum-exp reductions (semiring.py:383-408) where they were -- and nobody reads it;
+* rows that produce a padded OUTPUT unit of a sum layer are filled with ``0``: such a unit is a uniform mixture of
+  the real inputs, never larger than the largest of them, so the row maxima of the log-sum-exp reductions
+  (semiring.py:383-408) stay where they were -- and nobody reads it;
+* the padded units of an INPUT layer are copies of its real units (same parameters), for the same reason: a dummy
+  distribution could be far more likely than every real unit at some input (a Gaussian in its tail, a Binomial at the
+  end of its support) and the shifted exponentials of all real units would underflow;
 * the parameter graphs themselves are unchanged (same nodes, new shapes), so training updates keep the
   invariant: the gradient of a softmax w.r.t. a ``-inf`` logit is 0.
 
@@ -34,7 +36,7 @@ from .plan import LayerSpec, ParamGraph, ParamNode, Plan
 
 _UNARY = {"softmax", "sigmoid", "scaled_sigmoid", "exp", "square"}
 _ZERO_AT_NEG_INF = {"softmax", "sigmoid", "exp"}  # ops that map -inf to exactly 0
-_LAYERS = {"categorical", "gaussian", "sum", "cpt", "tucker", "hadamard"}
+_LAYERS = {"categorical", "binomial", "gaussian", "sum", "cpt", "tucker", "hadamard"}
 
 
 @dataclass(frozen=True)
@@ -88,7 +90,20 @@ class PadInfo:
                 sl[ax] = mask
                 out[tuple(sl)] = fill_in
         out[np.ix_(np.arange(old[0]), *pos)] = value
+        for ax, r in enumerate(roles, start=1):
+            if r is not None and r.kind == "dup" and new[ax] > old[ax]:  # padded units repeat the real ones cyclically
+                dst = [slice(None)] * len(new)
+                dst[ax] = slice(old[ax], new[ax])
+                out[tuple(dst)] = np.take(out, np.arange(old[ax], new[ax]) % old[ax], axis=ax)
         return out
+
+    def duplicated_axes(self, name: str) -> list[tuple[int, int, int]]:
+        """(axis, real size, padded size) of the axes of tensor `name` whose padded entries are copies of real ones
+        (input-layer units) -- whoever updates the real entries in place must refresh the copies."""
+        roles, _, _ = self.tensors[name]
+        old, new = self.shapes[name]
+        return [(ax, old[ax], new[ax]) for ax, r in enumerate(roles, start=1)
+                if r is not None and r.kind == "dup" and new[ax] > old[ax]]
 
     def unpad(self, name: str, value: np.ndarray) -> np.ndarray:
         roles, _, _ = self.tensors[name]
@@ -105,10 +120,15 @@ def _pad(k: int, multiple: int) -> int:
 def _param_roles(layer: LayerSpec, name: str) -> list[_Role | None] | None:
     """Unit structure of the axes of a layer parameter (per-fold shape)."""
     ki, ko, h = layer.num_input_units, layer.num_output_units, layer.arity
+    # input layers: a padded unit is a COPY of a real unit (kind "dup"), so its value never exceeds the largest real
+    # value of its row -- a dummy distribution could, and the row maximum of the first log-sum-exp would then underflow
+    # every real unit (e.g. a Gaussian evaluated far in its tail, a Binomial at the end of its support)
     if layer.type in ("categorical",) and name in ("probs", "logits"):
-        return [_Role(ko, 1, "cat", "out"), None]
+        return [_Role(ko, 1, "cat", "dup"), None]
     if layer.type == "gaussian" and name in ("mean", "stddev", "log_partition"):
-        return [_Role(ko, 1, "cat", "out")]
+        return [_Role(ko, 1, "cat", "dup")]
+    if layer.type == "binomial" and name in ("probs", "logits"):
+        return [_Role(ko, 1, "cat", "dup")]
     if layer.type == "sum" and name == "weight":
         return [_Role(ko, 1, "cat", "out"), _Role(ki, h, "cat", "in")]
     if layer.type == "cpt" and name == "weight":

@@ -36,6 +36,7 @@ IDX_NONE = "none"  # ``x[()]``        : identity (parameter graphs only)
 LAYER_TYPES = {
     "TorchCategoricalLayer": "categorical",
     "TorchGaussianLayer": "gaussian",
+    "TorchBinomialLayer": "binomial",
     "TorchEmbeddingLayer": "embedding",
     "TorchConstantValueLayer": "constant",
     "TorchSumLayer": "sum",

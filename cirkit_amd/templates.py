@@ -533,6 +533,8 @@ def _activation_node(shape: tuple[int, ...], activation: str) -> _PN | None:
         return _PN("softmax", shape, {"dim": len(shape) - 1})
     if activation == "scaled-sigmoid":
         return _PN("scaled_sigmoid", shape, {"vmin": 1e-05, "vmax": 1.0})
+    if activation == "sigmoid":
+        return _PN("sigmoid", shape, {})
     if activation == "none":
         return None
     raise NotImplementedError(f"activation {activation!r}")
@@ -562,7 +564,8 @@ def _pg_matmul(a: _PG, c: _PG) -> _PG:
 @dataclass
 class InputSpec:
     """Input-layer family: ``categorical`` (probs = softmax over categories), ``embedding``
-    (weight, no activation) or ``gaussian`` (mean, stddev = scaled sigmoid)."""
+    (weight, no activation), ``gaussian`` (mean, stddev = scaled sigmoid) or ``binomial`` (probs = sigmoid;
+    `num_states` values 0 .. total_count)."""
 
     name: str = "categorical"
     num_states: int = 256
@@ -591,6 +594,8 @@ class _L:
                 cfg["num_categories"] = self.spec.num_states
             elif self.spec.name == "embedding":
                 cfg["num_states"] = self.spec.num_states
+            elif self.spec.name == "binomial":
+                cfg["total_count"] = self.spec.num_states - 1
             return cfg
         if self.kind in ("hadamard", "kronecker"):
             return {"num_input_units": self.ki, "arity": self.arity}
@@ -610,8 +615,10 @@ def _input_layer(var: int, spec: InputSpec, k: int, activation: str | None) -> _
         params = {"weight": _pg_tensor((k, spec.num_states), activation or "none")}
     elif spec.name == "gaussian":
         params = {"mean": _pg_tensor((k,), "none"), "stddev": _pg_tensor((k,), "scaled-sigmoid")}
+    elif spec.name == "binomial":  # probs = sigmoid(tensor), symbolic/layers.py:406-410
+        params = {"probs": _pg_tensor((k,), "sigmoid")}
     else:
-        raise NotImplementedError(f"input layer {spec.name!r} (supported: categorical, embedding, gaussian)")
+        raise NotImplementedError(f"input layer {spec.name!r} (supported: categorical, binomial, embedding, gaussian)")
     return _L("input", 1, k, var=var, spec=spec, params=params)
 
 
@@ -976,6 +983,8 @@ def image_data(
 
 def _tabular_input_spec(d: dict) -> InputSpec:
     args = dict(d.get("args", {}))
+    if d["name"] == "binomial":
+        return InputSpec("binomial", int(args.get("total_count", 1)) + 1)
     return InputSpec(d["name"], int(args.get("num_categories", args.get("num_states", 2))))
 
 

@@ -333,6 +333,12 @@ class HipTrainer:
                       self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, stream)
         else:
             capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, stream)
+        if self._pad_info is not None:  # padded input-layer units are copies of real ones: follow their update
+            for n in self.user_plan.tensors:
+                for ax, old, new in self._pad_info.duplicated_axes(n):
+                    t = self.circuit.store[n]
+                    idx = (torch.arange(old, new, device=t.device) % old)
+                    t.narrow(ax, old, new - old).copy_(t.index_select(ax, idx))
         self.circuit.store.touch()  # values changed in place: circuits that cache derived parameters must refresh
 
     def step(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:

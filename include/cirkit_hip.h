@@ -262,6 +262,10 @@ typedef struct ck_softmax_job {
   float* out2;        /* kind 5: (rows, C+1) log scale of each table row */
 } ck_softmax_job;
 int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream);
+/* TorchBinomialLayer.log_unnormalized_likelihood (input.py:530-541) as a table: table (F, total_count + 2, K) --
+ * row c = log-pmf of the value c for every unit, the last row the layer's integral (0); p (F, K) probabilities or logits.
+ * ck_categorical_fwd then gathers row x[b] exactly as for a Categorical layer with total_count + 1 categories. */
+int ck_param_binomial_table(const float* p, int is_logits, float* table, int64_t F, int K, int total_count, void* stream);
 /* TorchGaussianProductLogPartition.forward (nodes.py:975-988): out[f, i*K2 + j] = log of the integral of the product
  * of Gaussian unit i of (mean1, stddev1) and unit j of (mean2, stddev2); all inputs (F, K). */
 int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,

@@ -223,6 +223,14 @@ def _layer_forward(sr, l: LayerSpec, params: Mapping[str, Tensor], x) -> Tensor:
         if "log_partition" in params:
             lp = lp + params["log_partition"].unsqueeze(dim=1)
         return sr.from_lse(lp)
+    if t == "binomial":  # input.py:530-541
+        xi = x.long() if x.is_floating_point() else x
+        n = int(l.config["total_count"])
+        if "probs" in params:
+            dist = torch.distributions.Binomial(n, probs=params["probs"].unsqueeze(dim=1))
+        else:
+            dist = torch.distributions.Binomial(n, logits=params["logits"].unsqueeze(dim=1))
+        return sr.from_lse(dist.log_prob(xi))
     if t == "embedding":  # input.py:258-266
         xi = x.long() if x.is_floating_point() else x
         xi = xi.squeeze(dim=2)
@@ -286,6 +294,8 @@ def _integrate_input(sr, l: LayerSpec, params, output: Tensor, mask: Tensor) -> 
             integ = params["log_partition"].unsqueeze(1)
         else:
             integ = torch.zeros((l.num_folds, 1, l.num_output_units), dtype=output.dtype)
+    elif l.type == "binomial":  # input.py:543-549
+        integ = torch.zeros((l.num_folds, 1, l.num_output_units), dtype=output.dtype)
     else:
         raise NotImplementedError(f"integrate() of a {l.type} layer")
     return torch.where(m, sr.from_lse(integ.to(output.real.dtype)), output)

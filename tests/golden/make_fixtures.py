@@ -179,6 +179,22 @@ def sq_gaussian():
                                         "z_f64": _fp64_copy(zc)().numpy()})
 
 
+def binomial():
+    """Binomial input layers (image_data(..., input_layer="binomial"): total_count 255, probs = sigmoid(tensor)):
+    plan + outputs of the reference on 12 rows, closed-form parameters."""
+    sc = data_modalities.image_data((1, 6, 6), "quad-graph", input_layer="binomial", num_input_units=4,
+                                    sum_product_layer="cp", num_sum_units=4)
+    ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)
+    cc = ctx.compile(sc)
+    plan, tensors = plan_from_torch_circuit(cc)
+    _load_closed_form(plan, tensors, seed=12)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randint(0, 256, (12, 36), generator=g)
+    x[0, :] = 0
+    x[1, :] = 255  # the ends of the support
+    _save("binomial_qg6x6_k4", plan, {"x": x.numpy().astype(np.int16), "y_f32": cc(x).numpy(), "y_f64": _fp64_copy(cc)(x).numpy()})
+
+
 def kats():
     """The reference's own known-answer circuits (tests/symbolic/test_utils.py:293-503), compiled by
     the reference with fold+optimize under lse-sum; literal weights stored (they are tiny)."""

@@ -561,3 +561,46 @@ def test_chow_liu_circuits_match_oracle(hip_device, name):
     got = HipCircuit(plan, tensors, device=hip_device)(x.to(hip_device)).cpu()
     assert got.shape == want.shape and torch.isfinite(got).all()
     assert float((got - want).abs().max()) <= REL * max(1.0, float(want.abs().max()))
+
+
+def test_binomial_inputs_match_reference_on_the_gpu(hip_device):
+    """Binomial input layers: reference outputs (incl. the ends of the support, x = 0 and x = 255), a marginal query,
+    and a padded run."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan, _, g = load_case("binomial_qg6x6_k4")
+    tensors = init_plan_tensors(plan, seed=12)
+    x = torch.from_numpy(g["x"].astype(np.int64))
+    ref64 = torch.from_numpy(g["y_f64"])
+    for pad in (False, True):
+        hc = HipCircuit(plan, tensors, device=hip_device, pad_units=pad)
+        y = hc(x.to(hip_device)).cpu()
+        assert float(((y.double() - ref64).abs() / ref64.abs()).max()) <= REL
+    mask = torch.zeros(36, dtype=torch.bool)
+    mask[[3, 17, 30]] = True
+    want = evaluate_plan(plan, as_torch(tensors), x, integrate_mask=mask.unsqueeze(0).expand(12, 36))
+    got = hc(x.to(hip_device), integrate_vars=mask).cpu()
+    assert float((got - want).abs().max()) <= REL * float(want.abs().max())
+
+
+def test_padded_circuits_far_in_the_tails(hip_device):
+    """Rows where every real input unit is astronomically unlikely (a Gaussian 40 sigma out, a Binomial at the ends of
+    its support): the padded HIP circuit (input units padded with COPIES of real units) returns the oracle's finite
+    value -- a dummy padded unit would win the row maximum and underflow everything real."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    for kw, x in ((dict(input_layer="gaussian"), torch.full((33, 64), 40.0)),
+                  (dict(input_layer="binomial"), torch.tensor([[0] * 64, [255] * 64, [128] * 64]))):
+        plan = image_data((1, 8, 8), "quad-graph", num_input_units=5, num_sum_units=5, **kw)
+        tensors = init_plan_tensors(plan, seed=2)
+        want = evaluate_plan(plan, as_torch(tensors), x)
+        hc = HipCircuit(plan, tensors, device=hip_device)
+        assert hc._pad_info is not None
+        got = hc(x.to(hip_device)).cpu()
+        assert torch.isfinite(got).all(), kw
+        assert float((got - want).abs().max()) <= REL * float(want.abs().max()), kw

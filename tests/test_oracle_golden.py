@@ -106,3 +106,22 @@ def test_semiring_underflow_case():
     z = torch.full((4,), float("-inf"))
     out = _einsum(_LSE, "i,i->", inputs=(z,), operands=(torch.ones(4),), dim=0, keepdim=False)
     assert float(out) == float("-inf")
+
+
+def test_binomial_inputs_match_reference():
+    """Binomial input layers (input.py:437-549): the oracle reproduces the reference outputs bit for bit, and the
+    native `image_data(..., input_layer="binomial")` plan is the reference's."""
+    import numpy as np
+    import torch
+    from conftest import load_case
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+    from oracle.torch_oracle import as_torch, evaluate_plan
+    from test_templates import _assert_same_plan
+
+    plan, _, g = load_case("binomial_qg6x6_k4")
+    tensors = init_plan_tensors(plan, seed=12)
+    y = evaluate_plan(plan, as_torch(tensors), torch.from_numpy(g["x"].astype(np.int64)))
+    assert np.array_equal(y.numpy(), g["y_f32"])
+    _assert_same_plan(image_data((1, 6, 6), "quad-graph", input_layer="binomial", num_input_units=4, sum_product_layer="cp",
+                                 num_sum_units=4), plan)

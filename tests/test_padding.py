@@ -64,7 +64,8 @@ def test_multiclass_output_is_sliced():
     assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("name", ["quadgraph_6x6_k4", "pd_gauss_6x6_k4", "cfg1_rbt8", "plan_quadgraph_1x8x8_cp_mixFalse"])
+@pytest.mark.parametrize("name", ["quadgraph_6x6_k4", "pd_gauss_6x6_k4", "cfg1_rbt8", "plan_quadgraph_1x8x8_cp_mixFalse",
+                                  "binomial_qg6x6_k4"])
 def test_reference_plans_with_mixed_parameter_graphs(name):
     """Plans extracted from the reference (folds of one layer built from DIFFERENT parameter graphs: plain mixing
     weights next to collapsed Sum -> Sum products) pad to the same function."""
@@ -81,7 +82,7 @@ def test_reference_plans_with_mixed_parameter_graphs(name):
     padded, info = res
     gen = torch.Generator().manual_seed(2)
     gauss = any(l.type == "gaussian" for l in plan.layers)
-    x = torch.randn((7, plan.num_variables), generator=gen) if gauss else torch.randint(0, 3, (7, plan.num_variables), generator=gen)
+    x = torch.randn((7, plan.num_variables), generator=gen) if gauss else torch.randint(0, 2, (7, plan.num_variables), generator=gen)
     want = evaluate_plan(plan, as_torch(tensors), x)
     got = evaluate_plan(padded, as_torch(pad_tensors(info, tensors)), x)[..., : info.out_units]
     assert torch.isfinite(got).all()
@@ -107,3 +108,23 @@ def test_unconstrained_parameters():
         got = evaluate_plan(padded, as_torch(pad_tensors(info, tensors)), x)[..., : info.out_units]
         assert torch.isfinite(got).all()
         assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_padded_input_units_never_dominate():
+    """Inputs far in the tails: every real unit of a Gaussian / Binomial layer is astronomically unlikely.  Padded
+    input units are copies of real ones, so the padded circuit still returns the finite value of the original
+    (a dummy unit, e.g. a standard Gaussian, would win every row maximum and underflow the real units to log 0)."""
+    for kw, x in ((dict(input_layer="gaussian"), torch.full((3, 16), 40.0)),
+                  (dict(input_layer="binomial"), torch.tensor([[0] * 16, [255] * 16, [128] * 16])),
+                  (dict(input_layer="categorical"), torch.zeros((2, 16), dtype=torch.int64))):
+        plan = image_data((1, 4, 4), "quad-tree-2", num_input_units=5, num_sum_units=5, **kw)
+        tensors = init_plan_tensors(plan, seed=2)
+        if kw["input_layer"] == "categorical":  # peaked distributions that give category 0 a probability ~ e^-95 (a denormal)
+            name = plan.layers[0].params["probs"].nodes[0].config["tensor"]
+            tensors[name] = tensors[name].copy()
+            tensors[name][..., 0] -= 95.0
+        padded, info = pad_units(plan)
+        want = evaluate_plan(plan, as_torch(tensors), x)
+        got = evaluate_plan(padded, as_torch(pad_tensors(info, tensors)), x)[..., : info.out_units]
+        assert torch.isfinite(want).all() and torch.isfinite(got).all(), kw
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), kw

@@ -142,8 +142,7 @@ def test_template_entry_points_mirror_the_reference_signatures():
     _assert_same_plan(b, Plan.load(os.path.join(GOLDEN, "cfg1_rbt8")))
     with pytest.raises(ValueError):
         image_data((1, 28, 28), region_graph="hexagons", num_input_units=4, num_sum_units=4)
-    with pytest.raises(NotImplementedError):
-        image_data((1, 4, 4), input_layer="binomial", num_input_units=4, num_sum_units=4)
+    assert image_data((1, 4, 4), input_layer="binomial", num_input_units=4, num_sum_units=4).layers[0].config["total_count"] == 255
     with pytest.raises(ValueError, match="data="):  # same error as the reference: the structure is learned from data
         tabular_data("chow-liu-tree", num_features=4, input_layers={"name": "gaussian", "args": {}},
                      num_input_units=2, num_sum_units=2)
