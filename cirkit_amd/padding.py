@@ -8,12 +8,12 @@ of 32 WITHOUT changing what the circuit computes:
 * the raw parameter tensors are enlarged; entries of a sum weight that multiply a padded INPUT unit are
   filled so that the parameter graph maps them to exactly 0 (``-inf`` under softmax / exp / sigmoid, ``0``
   for an unconstrained weight), so a padded unit never contributes to a real one;
-* rows that produce a padded OUTPUT unit of a sum layer are filled with ``0``: such a unit is a uniform mixture of
-  the real inputs, never larger than the largest of them, so the row maxima of the log-sum-exp reductions
-  (semiring.py:383-408) stay where they were -- and nobody reads it;
-* the padded units of an INPUT layer are copies of its real units (same parameters), for the same reason: a dummy
-  distribution could be far more likely than every real unit at some input (a Gaussian in its tail, a Binomial at the
-  end of its support) and the shifted exponentials of all real units would underflow;
+* every padded unit -- of an input layer or of a sum layer -- is a COPY of a real unit of the same layer (same
+  parameters: copied input distributions, copied weight rows), so at every layer the padded values repeat real
+  values and the row maxima of the log-sum-exp reductions (semiring.py:383-408) stay where they were.  A dummy unit
+  could be astronomically more likely than every real unit at some input (a Gaussian in its tail, a Binomial at the
+  end of its support, a uniform mixture next to outputs that all avoid the one large input) and the shifted
+  exponentials of all real units would underflow; nobody reads the copies (weight 0 on every padded input);
 * the parameter graphs themselves are unchanged (same nodes, new shapes), so training updates keep the
   invariant: the gradient of a softmax w.r.t. a ``-inf`` logit is 0.
 
@@ -42,7 +42,8 @@ _LAYERS = {"categorical", "binomial", "gaussian", "sum", "cpt", "tucker", "hadam
 @dataclass(frozen=True)
 class _Role:
     """One axis of a parameter: `reps` groups of `k` units, concatenated ("cat") or as the flattened
-    index of a `reps`-fold product ("kron"); kind "in" = multiplies input units, "out" = produces units."""
+    index of a `reps`-fold product ("kron"); kind "in" = multiplies input units (padded entries evaluate to 0),
+    "dup" = produces units (padded entries are copies of real ones)."""
 
     k: int
     reps: int
@@ -130,11 +131,11 @@ def _param_roles(layer: LayerSpec, name: str) -> list[_Role | None] | None:
     if layer.type == "binomial" and name in ("probs", "logits"):
         return [_Role(ko, 1, "cat", "dup")]
     if layer.type == "sum" and name == "weight":
-        return [_Role(ko, 1, "cat", "out"), _Role(ki, h, "cat", "in")]
+        return [_Role(ko, 1, "cat", "dup"), _Role(ki, h, "cat", "in")]
     if layer.type == "cpt" and name == "weight":
-        return [_Role(ko, 1, "cat", "out"), _Role(ki, 1, "cat", "in")]
+        return [_Role(ko, 1, "cat", "dup"), _Role(ki, 1, "cat", "in")]
     if layer.type == "tucker" and name == "weight" and h == 2:  # (K^H inputs: padding a higher arity explodes)
-        return [_Role(ko, 1, "cat", "out"), _Role(ki, h, "kron", "in")]
+        return [_Role(ko, 1, "cat", "dup"), _Role(ki, h, "kron", "in")]
     return None
 
 
@@ -202,7 +203,7 @@ def _pad_graph(g: ParamGraph, roles: list[_Role | None], multiple: int, info: Pa
             info.tensors[name] = entry
             info.shapes[name] = (old, new)
         elif n.op in _UNARY:
-            if n.op == "softmax" and any(role is not None and role.kind == "out" and ax == n.config.get("dim")
+            if n.op == "softmax" and any(role is not None and role.kind == "dup" and ax == n.config.get("dim")
                                          for ax, role in enumerate(r)):
                 raise _Unsupported("softmax over output units")
             assign(ins[0], r, n.op)
@@ -211,16 +212,16 @@ def _pad_graph(g: ParamGraph, roles: list[_Role | None], multiple: int, info: Pa
             k = n.shape[0]
             if r[1] is not None and (r[1].mode != "cat" or r[1].k != k):
                 raise _Unsupported("mixing weight with another unit structure")
-            row = r[0] if r[0] is not None else (_Role(k, 1, "cat", "out") if r[1] is not None else None)
+            row = r[0] if r[0] is not None else (_Role(k, 1, "cat", "dup") if r[1] is not None else None)
             if row is not None and r[1] is None and k > 1:
                 raise _Unsupported("mixing weight rows padded without its columns")
             new_nodes[i].shape = (row.size(_pad(k, multiple)) if row is not None else k, new_nodes[i].shape[1])
-            assign(ins[0], [None if row is None else _Role(k, 1, "cat", "out"), None], n.op)
+            assign(ins[0], [None if row is None else _Role(k, 1, "cat", "dup"), None], n.op)
         elif n.op == "matmul":
             a, b = ins
             km = g.nodes[a[0]].shape[1]
             inner_in = _Role(km, 1, "cat", "in") if _pad(km, multiple) != km else None
-            inner_out = _Role(km, 1, "cat", "out") if inner_in is not None else None
+            inner_out = _Role(km, 1, "cat", "dup") if inner_in is not None else None
             assign(a, [r[0], inner_in], n.op)
             assign(b, [inner_out, r[1]], n.op)
         else:

@@ -128,3 +128,25 @@ def test_padded_input_units_never_dominate():
         got = evaluate_plan(padded, as_torch(pad_tensors(info, tensors)), x)[..., : info.out_units]
         assert torch.isfinite(want).all() and torch.isfinite(got).all(), kw
         assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), kw
+
+
+def test_padded_sum_units_never_dominate():
+    """Every real output of the first dense layer puts (almost) all its weight on an input unit that is e^-80
+    unlikely at the observed values, while another input unit is likely.  A padded output unit that mixed the inputs
+    uniformly would be ~80 nats above every real output and underflow them in the next layer; padded rows are
+    copies of real rows, so the padded circuit returns the original's finite value."""
+    plan = image_data((1, 4, 4), "quad-tree-2", num_input_units=2, num_sum_units=2)
+    tensors = {k: v.copy() for k, v in init_plan_tensors(plan, seed=4).items()}
+    cat = plan.layers[0].params["probs"].nodes[0].config["tensor"]
+    dense = plan.layers[1].params["weight"].nodes[0].config["tensor"]
+    tensors[cat][:, 0, :] = 0.0
+    tensors[cat][:, 0, 7] = -80.0   # unit 0: category 7 has probability ~ e^-80 / 255
+    tensors[cat][:, 1, :] = 0.0     # unit 1: uniform
+    tensors[dense][:, :, 0] = 200.0  # every dense output: weight ~ 1 on unit 0, ~ e^-200 on unit 1
+    tensors[dense][:, :, 1] = 0.0
+    x = torch.full((2, 16), 7, dtype=torch.int64)
+    padded, info = pad_units(plan)
+    want = evaluate_plan(plan, as_torch(tensors), x)
+    got = evaluate_plan(padded, as_torch(pad_tensors(info, tensors)), x)[..., : info.out_units]
+    assert torch.isfinite(want).all() and torch.isfinite(got).all()
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
