@@ -1,0 +1,84 @@
+"""Live comparison with the real reference -- only where it is importable (the build container: /root/reference).
+Compiles circuits with april-tools/cirkit itself and checks, on the spot, that (1) the native plan builder emits the
+reference's folded plan, (2) the oracle reproduces the reference's forward bit for bit with the same parameters, and
+(3) the natively built partition function of a squared circuit equals the reference's `integrate(multiply(c, c))`.
+The committed fixtures pin a fixed set of circuits; this sweeps further combinations every time the CPU suite runs
+here.  Skipped wherever the reference is absent (e.g. on the GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REF = os.environ.get("CIRKIT_REFERENCE", "/root/reference")
+if not os.path.isdir(os.path.join(REF, "cirkit")):
+    pytest.skip("the reference checkout is not available here", allow_module_level=True)
+sys.path.insert(0, REF)
+try:
+    import cirkit.symbolic.functional as SF  # noqa: E402
+    from cirkit.pipeline import PipelineContext  # noqa: E402
+    from cirkit.templates import data_modalities  # noqa: E402
+except Exception as e:  # pragma: no cover - depends on the environment
+    pytest.skip(f"the reference does not import here: {e}", allow_module_level=True)
+
+from cirkit_amd.functional import squared_partition_plan  # noqa: E402
+from cirkit_amd.plan import plan_from_torch_circuit, tensor_table  # noqa: E402
+from cirkit_amd.templates import image_data, tabular_data  # noqa: E402
+from oracle.torch_oracle import evaluate_plan  # noqa: E402
+from test_templates import _assert_same_plan  # noqa: E402
+
+CASES = [
+    ((1, 5, 4), "quad-graph", "categorical", "cp", 3, 1, True),
+    ((1, 6, 6), "quad-tree-4", "categorical", "tucker", 2, 1, True),
+    ((2, 4, 4), "quad-tree-2", "gaussian", "cp-t", 3, 1, True),
+    ((1, 8, 8), "poon-domingos", "gaussian", "cp", 2, 1, True),
+    ((1, 4, 6), "random-binary-tree", "binomial", "cp", 3, 1, True),
+    ((1, 6, 6), "quad-graph", "categorical", "cp", 3, 4, False),
+    ((1, 7, 5), "poon-domingos", "binomial", "cp-t", 2, 1, True),
+]
+
+
+@pytest.mark.parametrize("shape,rg,inp,sp,k,ncls,mix", CASES, ids=[f"{c[1]}-{c[2]}-{c[3]}" for c in CASES])
+def test_plan_and_forward_match_the_live_reference(shape, rg, inp, sp, k, ncls, mix):
+    torch.manual_seed(0)
+    kw = dict(input_layer=inp, num_input_units=k, sum_product_layer=sp, num_sum_units=k, num_classes=ncls, use_mixing_weights=mix)
+    sc = data_modalities.image_data(shape, rg, **kw)
+    cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+    plan, tensors = plan_from_torch_circuit(cc)
+    _assert_same_plan(image_data(shape, rg, **kw), plan)
+    d = int(np.prod(shape))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((6, d), generator=g) if inp == "gaussian" else torch.randint(0, 256, (6, d), generator=g)
+    with torch.no_grad():
+        want = cc(x)
+        got = evaluate_plan(plan, {n: t.detach() for n, t in tensors.items()}, x)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("inp", ["categorical", "gaussian"])
+def test_squared_partition_function_matches_the_live_reference(inp):
+    torch.manual_seed(0)
+    sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", input_layer=inp, num_input_units=3, sum_product_layer="cp-t",
+                                    num_sum_units=3)
+    ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)
+    cc = ctx.compile(sc)
+    zc = ctx.compile(SF.integrate(SF.multiply(sc, sc)))
+    plan, tensors = plan_from_torch_circuit(cc, table=tensor_table())
+    with torch.no_grad():
+        want = float(zc().reshape(-1)[0])
+        got = float(evaluate_plan(squared_partition_plan(plan), {n: t.detach() for n, t in tensors.items()}, None).reshape(-1)[0])
+    assert abs(got - want) <= 1e-5 * abs(want)
+
+
+def test_chow_liu_matches_the_live_reference():
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal((200, 2))
+    data = torch.from_numpy((z @ rng.standard_normal((2, 6)) + 0.5 * rng.standard_normal((200, 6))).astype(np.float32))
+    inputs = {"name": "gaussian", "args": {}}
+    sc = data_modalities.tabular_data("chow-liu-tree", data=data, input_layers=inputs, num_input_units=2,
+                                      sum_product_layer="cp", num_sum_units=2)
+    cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+    plan, _ = plan_from_torch_circuit(cc)
+    _assert_same_plan(tabular_data("chow-liu-tree", data=data.numpy(), input_layers=inputs, num_input_units=2,
+                                   sum_product_layer="cp", num_sum_units=2), plan)
