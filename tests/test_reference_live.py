@@ -82,3 +82,26 @@ def test_chow_liu_matches_the_live_reference():
     plan, _ = plan_from_torch_circuit(cc)
     _assert_same_plan(tabular_data("chow-liu-tree", data=data.numpy(), input_layers=inputs, num_input_units=2,
                                    sum_product_layer="cp", num_sum_units=2), plan)
+
+
+def test_complex_squared_circuit_matches_the_live_reference():
+    """Embedding inputs, unconstrained weights, complex-lse-sum: c(x) through the oracle and Z built natively."""
+    from cirkit.templates.utils import Parameterization
+
+    torch.manual_seed(0)
+    par = Parameterization(activation="none", initialization="normal")
+    sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", input_layer="embedding", num_input_units=3, sum_product_layer="cp-t",
+                                    num_sum_units=3, input_params={"weight": par}, sum_weight_param=par)
+    ctx = PipelineContext(backend="torch", semiring="complex-lse-sum", fold=True, optimize=True)
+    cc = ctx.compile(sc)
+    zc = ctx.compile(SF.integrate(SF.multiply(sc, SF.conjugate(sc))))
+    plan, tensors = plan_from_torch_circuit(cc, table=tensor_table())
+    _assert_same_plan(image_data((1, 4, 4), "quad-tree-2", input_layer="embedding", num_input_units=3, sum_product_layer="cp-t",
+                                 num_sum_units=3, sum_weight_activation="none", semiring="complex-lse-sum"), plan)
+    tens = {n: t.detach() for n, t in tensors.items()}
+    x = torch.randint(0, 256, (5, 16), generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        assert torch.equal(evaluate_plan(plan, tens, x), cc(x))
+        want = zc().reshape(-1)[0]
+        got = evaluate_plan(squared_partition_plan(plan), tens, None).reshape(-1)[0]
+    assert abs(float(got.real) - float(want.real)) <= 1e-5 * abs(float(want.real))
