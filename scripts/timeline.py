@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 c = sqlite3.connect(sys.argv[1])
-anchor = sys.argv[2] if len(sys.argv) > 2 else "subtree_cat_cpt_kernel"
+anchor = sys.argv[2] if len(sys.argv) > 2 else "subtree_linear_kernel"
 nth = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 rows = list(c.execute("select name, start, end from kernels order by start"))
 names = [r[0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0] for r in rows]
