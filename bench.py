@@ -253,7 +253,8 @@ def main() -> None:
                         f"batch {B}/GPU, lse-sum, fold+optimize plan (12 folded layers)",
             "global_batch": world * B,
             "parallelism": f"dp{world} (batch-sharded, replicated parameters, one all-reduce of the summed LL)",
-            "hip_graph": not args.no_graph,
+            # short launch lists (config 2: 4 kernels) are replayed eagerly by the native executor, long ones as a hipGraph
+            "hip_graph": circuit.replays_as_graph(B, with_ll=True),
             "fused_leaf_levels": [g.depth for g in circuit._groups],
             "fused_tail_layers": len(circuit._tail),
             "contraction": args.contraction,

@@ -64,7 +64,10 @@ class HipCircuit:
         plan: the folded layer list (`cirkit_amd.plan.Plan`).
         tensors: parameter values by plan tensor name (numpy arrays or torch tensors).
         device: a ROCm device, e.g. ``"cuda:0"``.
-        use_graph: replay each batch size's launch list as a hipGraph.
+        use_graph: replay each batch size's launch list as a hipGraph.  A graph launch leaves the GPU idle for ~8 us
+            before its first kernel (measured, profiles/), a launch list of a handful of kernels replayed eagerly by
+            the native executor only ~1-2 us per kernel; so graphs are used for programs of more than
+            `graph_min_launches` launches (default 8) and short programs are replayed eagerly.  False: never a graph.
         fuse: cross-layer fusion of the leaf region (cirkit_amd/fusion.py); an int caps the number
             of fused CP-T levels, False evaluates layer by layer (every layer output materialised).
         batch_params: recompute all softmax parameters with one launch per forward
@@ -94,6 +97,7 @@ class HipCircuit:
         *,
         device: str | torch.device = "cuda:0",
         use_graph: bool = True,
+        graph_min_launches: int = 8,
         fuse: bool | int = True,
         batch_params: bool = True,
         contraction: str = "f32",
@@ -138,6 +142,7 @@ class HipCircuit:
                     tensors = padding.pad_tensors(self._pad_info, tensors)
         self.plan = plan
         self.use_graph = use_graph
+        self.graph_min_launches = int(graph_min_launches)
         self.cache_params = bool(cache_params)
         self.linear_levels = bool(linear_levels)
         self._pprog = None
@@ -800,10 +805,21 @@ class HipCircuit:
                 capi.call("ck_program_launch", self._param_program(), 1 if self.use_graph else 0, stream)
             if with_ll and bd.program_ll is None:
                 bd.program_ll = self._record(bd, with_ll=True)
-            capi.call("ck_program_launch", bd.program_ll if with_ll else bd.program, 1 if self.use_graph else 0, stream)
+            prog = bd.program_ll if with_ll else bd.program
+            as_graph = self.use_graph and capi.load().ck_program_num_ops(prog) > self.graph_min_launches
+            capi.call("ck_program_launch", prog, 1 if as_graph else 0, stream)
             if run is not cur:
                 cur.wait_stream(run)
         return bd
+
+    def replays_as_graph(self, B: int, *, with_ll: bool = False) -> bool:
+        """Whether a forward of batch size B is replayed as a hipGraph (long launch lists) or eagerly by the native
+        executor (short ones, see `use_graph`)."""
+        bd = self._bind(B)
+        if with_ll and bd.program_ll is None:
+            bd.program_ll = self._record(bd, with_ll=True)
+        prog = bd.program_ll if with_ll else bd.program
+        return bool(self.use_graph) and capi.load().ck_program_num_ops(prog) > self.graph_min_launches
 
     def forward(self, x: torch.Tensor | None = None, *, integrate_vars=None) -> torch.Tensor:
         """Returns ``(B, O, K)`` like ``TorchCircuit.forward`` (``(O, K)`` for an empty-scope circuit).
