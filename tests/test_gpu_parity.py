@@ -604,3 +604,19 @@ def test_padded_circuits_far_in_the_tails(hip_device):
         got = hc(x.to(hip_device)).cpu()
         assert torch.isfinite(got).all(), kw
         assert float((got - want).abs().max()) <= REL * float(want.abs().max()), kw
+
+
+@pytest.mark.parametrize("name", ["cfg2_qt784", "quadgraph_6x6_k4", "cfg4_pd784"])
+def test_graph_replay_equals_eager_replay(hip_device, name):
+    """The recorded launch list replayed as a hipGraph (`graph_min_launches=0`) and eagerly by the native executor
+    (the default for lists this short) give bit-identical outputs, forward and log-likelihood sum."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case(name)
+    x = _x_of(plan, g).to(hip_device)
+    eager = HipCircuit(plan, tensors, device=hip_device)
+    graph = HipCircuit(plan, tensors, device=hip_device, graph_min_launches=0)
+    assert not eager.replays_as_graph(x.shape[0]) and graph.replays_as_graph(x.shape[0])
+    for _ in range(2):  # second call: the instantiated graph is replayed
+        assert torch.equal(eager(x), graph(x))
+    assert torch.equal(eager.log_likelihood_sum(x), graph.log_likelihood_sum(x))
