@@ -37,7 +37,7 @@ FP32_MFMA_PEAK_TF = 157.3  # dense fp32-input MFMA peak (= fp32 vector peak), sa
 
 def other_configs(device, stream, B: int) -> dict:
     """BASELINE configs 4 and 5 (parity-test cases, tests/test_gpu_parity.py) timed for reference:
-    plans built natively, closed-form parameters, synthetic batch, hipGraph replay, HIP events on
+    plans built natively, closed-form parameters, synthetic batch, recorded launch list replayed per call, HIP events on
     the launch stream.  Informational only -- `value` and `roofline` are config 2."""
     import numpy as np
     import torch
@@ -112,7 +112,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="rows per GPU (default: the BASELINE config)")
-    ap.add_argument("--no-graph", action="store_true", help="replay the launch list eagerly instead of as a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="never replay as a hipGraph (only lists of more than 64 launches are by default)")
     ap.add_argument("--fuse", type=int, default=-1, help="-1: full leaf fusion (default), 0: layer-wise, n: n CP-T levels")
     ap.add_argument("--contraction", default="f32", choices=["f32", "f16x3"],
                     help="K=32 sum layers: exact fp32 MFMA (default) or 3-term split-fp16 MFMA with fp32 accumulation")
@@ -253,7 +253,7 @@ def main() -> None:
                         f"batch {B}/GPU, lse-sum, fold+optimize plan (12 folded layers)",
             "global_batch": world * B,
             "parallelism": f"dp{world} (batch-sharded, replicated parameters, one all-reduce of the summed LL)",
-            # short launch lists (config 2: 4 kernels) are replayed eagerly by the native executor, long ones as a hipGraph
+            # launch lists are replayed eagerly by the native executor; a hipGraph only beyond 64 launches (cirkit_amd/circuit.py)
             "hip_graph": circuit.replays_as_graph(B, with_ll=True),
             "fused_leaf_levels": [g.depth for g in circuit._groups],
             "fused_tail_layers": len(circuit._tail),
