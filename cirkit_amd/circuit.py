@@ -794,7 +794,15 @@ class HipCircuit:
             xf, xi = self._prepare_input(x) if self.plan.num_variables else (None, None)
             cur = torch.cuda.current_stream(self.device)
             run = cur
-            if self.use_graph and cur.cuda_stream == 0:
+            if with_ll and bd.program_ll is None:
+                bd.program_ll = self._record(bd, with_ll=True)
+            prog = bd.program_ll if with_ll else bd.program
+            lib = capi.load()
+            as_graph = bool(self.use_graph) and lib.ck_program_num_ops(prog) > self.graph_min_launches
+            refresh = self.cache_params and self._pprog_data_version != self.store.data_version
+            pprog = self._param_program() if refresh else None
+            p_graph = refresh and bool(self.use_graph) and lib.ck_program_num_ops(pprog) > self.graph_min_launches
+            if (as_graph or p_graph) and cur.cuda_stream == 0:  # a capture cannot run on the legacy default stream
                 if self._side is None:
                     self._side = torch.cuda.Stream(self.device)
                 run = self._side
@@ -802,13 +810,9 @@ class HipCircuit:
             stream = run.cuda_stream
             if self.plan.num_variables:
                 self._stage_input(bd, xf, xi, stream)
-            if self.cache_params and self._pprog_data_version != self.store.data_version:
+            if refresh:
                 self._pprog_data_version = self.store.data_version
-                capi.call("ck_program_launch", self._param_program(), 1 if self.use_graph else 0, stream)
-            if with_ll and bd.program_ll is None:
-                bd.program_ll = self._record(bd, with_ll=True)
-            prog = bd.program_ll if with_ll else bd.program
-            as_graph = self.use_graph and capi.load().ck_program_num_ops(prog) > self.graph_min_launches
+                capi.call("ck_program_launch", pprog, 1 if p_graph else 0, stream)
             capi.call("ck_program_launch", prog, 1 if as_graph else 0, stream)
             if run is not cur:
                 cur.wait_stream(run)
