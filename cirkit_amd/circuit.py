@@ -25,7 +25,7 @@ import torch
 from . import _capi as capi
 from . import padding
 from .fusion import (CPBlock, RegionBlock, SubtreeGroup, find_cp_blocks, find_input_products, find_region_blocks,
-                     find_subtree_groups, find_table_dense, find_tail)
+                     find_subtree_groups, find_table_dense, find_tail, leaf_segments)
 from .layers import HipConstantValueLayer, HipEmbeddingLayer, HipInputLayer, HipLayer, layer_from_spec
 from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
@@ -90,6 +90,10 @@ class HipCircuit:
             forward and so does the default here.  True keeps the derived parameters of the last
             forward and recomputes them only after a parameter value changed (`TensorStore.set`,
             `invalidate_parameters`) -- the serving configuration.
+        persistent_leaf: the fused leaf launch as ONE resident workgroup per CU walking (root, tile range) segments
+            (cirkit_amd/csrc/ck_leaf.hip) instead of one workgroup per 128 rows.  None: whenever the launch is eligible
+            (linear table, tiled fp32 weights) and has at least one 32-row tile per CU; bit-identical either way.
+        leaf_waves: wavefronts per workgroup of the persistent leaf launch (8 or 12).
     """
 
     def __init__(
@@ -109,6 +113,8 @@ class HipCircuit:
         fuse_regions: bool = True,
         linear_levels: bool = True,
         pad_units: bool = True,
+        persistent_leaf: bool | None = None,
+        leaf_waves: int = 8,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -147,6 +153,11 @@ class HipCircuit:
         self.graph_min_launches = int(graph_min_launches)
         self.cache_params = bool(cache_params)
         self.linear_levels = bool(linear_levels)
+        self.persistent_leaf = persistent_leaf
+        if leaf_waves not in (8, 12):
+            raise ValueError("leaf_waves must be 8 or 12")
+        self.leaf_waves = int(leaf_waves)
+        self._n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self._pprog = None
         self._pprog_version = self._pprog_data_version = -1
         if isinstance(tensors, TensorStore):
@@ -699,6 +710,15 @@ class HipCircuit:
             )
         return dev[1], None
 
+    def _leaf_is_persistent(self, g: SubtreeGroup, B: int) -> bool:
+        """Whether the fused leaf launch of group g at batch size B is the persistent one (ck_leaf.hip)."""
+        cat = self.layers[g.input_layer]
+        if (self.persistent_leaf is False or g.root not in self._table_fused or not self.linear_levels or g.depth < 1
+                or cat.num_output_units != 32 or cat.num_categories >= 65535
+                or self._group_layout(g) != capi.CK_W_TILED_F32):
+            return False
+        return self.persistent_leaf is True or self.layers[g.root].num_folds * ((B + 31) // 32) >= self._n_cu
+
     def _launch_group(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int, *, with_table: bool = False) -> None:
         """One fused launch for Categorical -> [dense] -> CP-T levels (cirkit_amd/csrc/ck_fused.hip)."""
         table, w_dense = self._group_table(g, stream if with_table else None)
@@ -707,6 +727,20 @@ class HipCircuit:
         levels = (C.c_void_p * max(1, g.depth))(*[self.layers[j]._w.data_ptr() for j in g.levels])
         node_off = (C.c_int32 * (g.depth + 1))(*g.node_off)
         scale = dev[3] if g.root in self._table_fused and len(dev) > 3 else None
+        F_root, n_tiles = self.layers[g.root].num_folds, (bd.B + 31) // 32
+        persistent = scale is not None and w_dense is None and self._leaf_is_persistent(g, bd.B)
+        if persistent:
+            work = bd.cp_tabs.get((g.root, "leaf_work"))
+            if work is None:
+                work = bd.cp_tabs[(g.root, "leaf_work")] = torch.from_numpy(
+                    leaf_segments(F_root, n_tiles, self._n_cu)).to(self.device)
+            capi.call(
+                "ck_leaf_persistent_fwd", table.data_ptr(), scale.data_ptr(), bd.xt_i.data_ptr(),
+                cat._scope(self.device).data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off, out.data_ptr(),
+                work.data_ptr(), int(work.shape[0]), self._n_cu, self.leaf_waves, g.depth, bd.B, cat.num_output_units,
+                cat.num_categories, stream,
+            )
+            return
         capi.call(
             "ck_subtree_cat_cpt_fwd", table.data_ptr(), None if scale is None else scale.data_ptr(), bd.xt_i.data_ptr(),
             cat._scope(self.device).data_ptr(),
@@ -871,7 +905,7 @@ class HipCircuit:
         return self._run(x, with_ll=True).ll
 
     # -- instrumentation -------------------------------------------------------------------------
-    def kernel_label(self, i: int) -> str:
+    def kernel_label(self, i: int, B: int = 4096) -> str:
         """Name of the HIP kernel that evaluates layer i (as it appears in a rocprofv3 trace)."""
         l, s = self.layers[i], self.plan.layers[i]
         if i in self._input_prod:
@@ -888,6 +922,8 @@ class HipCircuit:
             g = self._group_of_root[i]
             in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)
             if i in self._table_fused and self.linear_levels:
+                if self._leaf_is_persistent(g, B):
+                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}>"
                 return f"subtree_linear_kernel<{g.depth}, {self._group_layout(g)}>"
             return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")
@@ -1078,7 +1114,7 @@ class HipCircuit:
             if i in self._group_of_root:  # the fused launch does the work of every layer it replaces
                 nbytes += sum(layer_bytes[j] for j in self._group_of_root[i].virtual)
                 nflops += sum(layer_flops[j] for j in self._group_of_root[i].virtual)
-            rows.append({"layer": i, "kernel": self.kernel_label(i), "ms": float(mean[2 * i + 1]),
+            rows.append({"layer": i, "kernel": self.kernel_label(i, B), "ms": float(mean[2 * i + 1]),
                          "algorithmic_bytes": nbytes, "algorithmic_flops": nflops})
         return rows
 

@@ -199,6 +199,25 @@ hipError_t launch_depth(const SubtreeArgs& a, int depth, bool has_dense, dim3 gr
 // `scale`, written by the prologue job that pushes the table through the dense layer); the root
 // level is converted back, out = log y + s.  If every product of a row underflows fp32 (children
 // whose large units do not overlap by more than ~1e-38) the step is redone in log space.
+
+// (leaf, level) of the k-th CP-T step of the depth-first walk without an in-kernel dense layer
+template <int D>
+__host__ __device__ constexpr int next_step_leaf(int k) {
+  for (int i = 0; i < (1 << D); ++i) {
+    if (k < steps_after(i)) return i;
+    k -= steps_after(i);
+  }
+  return 0;
+}
+template <int D>
+__host__ __device__ constexpr int next_step_level(int k) {
+  for (int i = 0; i < (1 << D); ++i) {
+    if (k < steps_after(i)) return k;
+    k -= steps_after(i);
+  }
+  return 0;
+}
+
 template <int D, int LAYOUT>
 __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a) {
   const int bid = blockIdx.x;
@@ -258,20 +277,19 @@ __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a
   auto row_of = [&](int i) -> int64_t { return static_cast<int64_t>(row[i]); };
   WRegs wcur, wnxt;
   if constexpr (!kLdsW) load_w<LAYOUT>(w_ptr(1, 0), lane, wcur);  // first step: level 1 after leaf 1
-  int step = 0;  // index of the next contraction in the static step order
   float stack[D][16], sstack[D];
   // two leaf rows in flight: leaves come in pairs with no contraction between them (L L C L L C C ...), so a
   // gather issued one leaf ahead would be waited for right away at every second leaf
   float cur[16], nxt[16], nx2[16], cs, ns, ns2;
+  bool bad = false;
   tile_load(a.table + row_of(0) * kK + 4 * kh, nxt);
   ns = a.scale[row_of(0)];
   if (kLeaves > 1) {
     tile_load(a.table + row_of(1) * kK + 4 * kh, nx2);
     ns2 = a.scale[row_of(1)];
   }
-
-#pragma unroll
-  for (int i = 0; i < kLeaves; ++i) {
+  static_for<0, kLeaves>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       cur[j] = nxt[j];
@@ -279,58 +297,61 @@ __global__ void __launch_bounds__(256) subtree_linear_kernel(const SubtreeArgs a
     }
     cs = ns;
     ns = ns2;
-    if (i + 2 < kLeaves) {
+    if constexpr (i + 2 < kLeaves) {
       tile_load(a.table + row_of(i + 2) * kK + 4 * kh, nx2);
       ns2 = a.scale[row_of(i + 2)];
     }
-#pragma unroll
-    for (int l = 0; l < D; ++l) {
-      if (((i >> l) & 1) == 0) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) stack[l][j] = cur[j];
-        sstack[l] = cs;
-        break;
-      }
-      int ni = 0, nl = 0;
-      const bool more = next_step<D, false>(i, l, ni, nl);
+    static_for<0, steps_after(i)>([&](auto lc) {
+      constexpr int l = decltype(lc)::value, step = steps_before(i) + l;
       if constexpr (kLdsW) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
-        ++step;
-      } else if (more) {
+      } else if constexpr (step + 1 < kNodes) {
+        constexpr int ni = next_step_leaf<D>(step + 1), nl = next_step_level<D>(step + 1);
         load_w<LAYOUT>(w_ptr(ni, nl), lane, wnxt);
       }
-      float p[16];
+      // the first level is the bare product; deeper levels renormalise by a power of two (ck_tile.h: linear_product)
+      if constexpr (l == 0) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) p[j] = cur[j] * stack[l][j];
-      float mx = p[0];
-#pragma unroll
-      for (int j = 1; j < 16; ++j) mx = fmaxf(mx, p[j]);
-      mx = ck::xhalf_max(mx);
-      cs += sstack[l];
-      if (__builtin_expect(__any(!(mx > 1e-30f)), 0)) {
-        // rare: products at the edge of the fp32 range -> this step in log space (semiring.py:383-408)
-        float m2 = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          p[j] = __logf(cur[j]) + __logf(stack[l][j]);
-          m2 = fmaxf(m2, p[j]);
-        }
-        m2 = ck::clamp_finite(ck::xhalf_max(m2));
-#pragma unroll
-        for (int j = 0; j < 16; ++j) cur[j] = __expf(p[j] - m2);
-        cs += m2;
+        for (int j = 0; j < 16; ++j) cur[j] *= stack[0][j];
+        cs += sstack[0];
       } else {
-        const float inv = 1.f / mx;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) cur[j] = p[j] * inv;
-        cs += __logf(mx);
+        linear_product<true>(cur, stack[l], cs, sstack[l], bad);
       }
       contract_linear<LAYOUT>(wcur, cur);
-      if constexpr (!kLdsW) {
-        if (more) wcur = wnxt;
-      }
+      if constexpr (!kLdsW && step + 1 < kNodes) wcur = wnxt;
+    });
+    if constexpr (steps_after(i) < D) {
+      constexpr int l = steps_after(i);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) stack[l][j] = cur[j];
+      sstack[l] = cs;
     }
+  });
+  if constexpr (D == 1) bad |= !(tile_row_max(cur) > kLinearFloor);  // (deeper roots are renormalised steps)
+  if (__builtin_expect(__any(bad), 0)) {
+    // rare: a row of products fell out of the fp32 range -> the whole tile again in log space (semiring.py:383-408)
+    SubtreeSource src{};
+    src.table = a.table;
+    src.scale = a.scale;
+    src.xt = a.xt;
+    src.scope = a.scope;
+    src.leaf_ids = leaf_ids;
+    src.fold0 = fold0;
+    src.w_steps = kLdsW ? w_lds : nullptr;
+#pragma unroll
+    for (int l = 0; l < D; ++l) src.w[l] = a.w[l];
+    src.nodes = a.nodes;
+#pragma unroll
+    for (int l = 0; l <= D; ++l) src.node_off[l] = a.node_off[l];
+    src.t = t;
+    src.B = a.B;
+    src.C = a.C;
+    src.bl = bl;
+    float fb[16];  // (its address escapes into the out-of-line call: never `cur`, which must stay in registers)
+    subtree_tile_logspace<D, LAYOUT>(src, lane, fb);
+    if (live) tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+    return;
   }
   if (live) {
 #pragma unroll

@@ -1,0 +1,292 @@
+// Persistent form of the fused leaf region (ck_fused.hip, linear-domain variant): ONE workgroup per CU that stays
+// resident and walks a list of (root fold, range of 32-row batch tiles) segments.
+//
+//     linear Categorical table (dense layer already pushed through it)  ->  D levels of CP-T layers
+//
+// Same arithmetic, in the same order, as subtree_linear_kernel -- the outputs are bit-identical
+// (tests/test_gpu_parity.py) -- but organised for the machine instead of for the launch grid:
+//
+//  * the 2^D - 1 weight matrices of a root's subtree (60 KB at D = 4) travel global -> LDS ONCE per segment
+//    (global_load_lds_dwordx4, no staging registers) and are shared by all waves of the CU; the grid-per-tile
+//    kernel staged them once per 128 rows (1568 times instead of 256 at the north-star config);
+//  * the waves of the workgroup draw tiles from an LDS counter, so a CU's SIMDs finish within one tile of each
+//    other whatever the number of tiles per CU (24.5 at batch 4096 on 256 CUs);
+//  * the leaf rows are gathered global -> LDS by the DMA path with EIGHT lanes per 128-byte table row (one
+//    wave instruction = 8 full rows = 8 cache lines; the register gather touched 32 lines per instruction,
+//    32 bytes of each) into a two-slot ring per wave, XOR-swizzled so that the ds_read_b128 that brings a row
+//    into the MFMA operand layout is bank-conflict free; no prefetch registers, 3 waves per SIMD fit.
+//
+// Reference semantics per step (unchanged): TorchCategoricalLayer input.py:399-412, TorchSumLayer
+// inner.py:266-273, TorchCPTLayer optimized.py:171-178, LSESumSemiring.apply_reduce semiring.py:383-408.
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+#include "ck_internal.h"
+#include "ck_tile.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMaxDepthP = 4;
+
+struct LeafArgs {
+  const float* table;    // (F0, C+1, 32) rows in LINEAR space (kind-5 prologue job)
+  const float* scale;    // (F0, C+1) log scale of each table row
+  const int32_t* xt;     // (Dvars, B) staged batch
+  const int64_t* scope;  // (F_in) variable of each input-layer fold
+  const float* w[kMaxDepthP];  // w[l-1]: (F_l, 1024 dwords) CK_W_TILED_F32 weights of CP-T level l
+  const int32_t* nodes;        // packed node tables (as ck_subtree_cat_cpt_fwd)
+  int node_off[kMaxDepthP + 1];
+  int leaf_off;
+  float* out;           // (F_root, B, 32)
+  const int32_t* work;  // (n_seg, 4): root fold, first tile, end tile, 0
+  int n_seg, B, C;
+};
+
+template <int D, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafArgs a) {
+  constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2) ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) float w_lds[kNodes * 1024];  // subtree weights, in step order
+  // gathered leaf tiles, a ring of kSlots 4 KB slots per wave (a gather that misses the XCD's L2 -- six roots' tables,
+  // 3.6 MB, are live per XCD -- takes ~1 us: with three slots a leaf is requested three leaves, ~1.5 contractions,
+  // before it is read).  The slots are READ with inline-asm ds_read_b128: the compiler's
+  // wait-count insertion cannot tell a read of one slot from the DMA in flight into the other and would put
+  // s_waitcnt vmcnt(0) before every slot read -- i.e. wait for the gather that has just been issued.  The vmcnt /
+  // lgkmcnt waits around the slot reads are therefore explicit.
+  __shared__ __attribute__((aligned(16))) float g_lds[WAVES * kSlots * 1024];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b_in = lane & 31, kh = lane >> 5;
+  float* const my_slots = g_lds + wave * (kSlots * 1024);
+  uint32_t rd_addr[4];  // LDS byte address of chunk 2g + kh of row b_in in slot 0 (slot s: + 4096 s)
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    rd_addr[g] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(my_slots)) + (b_in * 8 + ((2 * g + kh) ^ ((b_in >> 1) & 7))) * 16;
+
+  for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
+    const int t = a.work[4 * seg], tile_begin = a.work[4 * seg + 1], tile_end = a.work[4 * seg + 2];
+    if (seg != static_cast<int>(blockIdx.x)) __syncthreads();  // every wave has left the previous segment
+    // weights of the 2^D - 1 nodes, in the static order of the steps: 4 x 1 KiB wave-DMAs per node
+    static_for<0, kLeaves>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      static_for<0, steps_after(i)>([&](auto lc) {
+        constexpr int l = decltype(lc)::value, k = steps_before(i) + l;
+        const int fold = a.nodes[a.node_off[l + 1] + t * (kLeaves >> (l + 1)) + (i >> (l + 1))];
+        const float* src = a.w[l] + static_cast<int64_t>(fold) * 1024 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((k * 4 + q) % WAVES == wave)
+            __builtin_amdgcn_global_load_lds((ck::gptr_t)(src + q * 256), (ck::lptr_t)(w_lds + k * 1024 + q * 256), 16, 0, 0);
+      });
+    });
+    // per-root constants (scalar registers): variable row of xt and first table row of every leaf
+    const int32_t* leaf_ids = a.nodes + a.leaf_off + t * kLeaves;
+    const int32_t* fold0 = a.nodes + a.node_off[0] + t * kLeaves;
+    int64_t var_off[kLeaves];
+    int32_t row_base[kLeaves];
+#pragma unroll
+    for (int i = 0; i < kLeaves; ++i) {
+      var_off[i] = a.scope[leaf_ids[i]] * static_cast<int64_t>(a.B);
+      row_base[i] = fold0[i] * (a.C + 1);
+    }
+    // The tiles of a segment are dealt round-robin to the waves (wave w: tile_begin + w, + WAVES, ...), so a wave knows
+    // its next tiles and fetches their inputs while it computes: the batch values of tile k + 2 and, from those of tile
+    // k + 1, its table rows' scales and first two leaf rows are requested when the gathers of tile k are over (the
+    // last 2^(D-1)... contractions of a tile have no memory waits).  A tile therefore starts without the chain
+    // batch values -> scales -> leaf rows (three dependent memory round trips) in front of it.
+    auto batch_row = [&](int tile) { return min(tile * 32 + b_in, a.B - 1); };
+    auto load_x = [&](int tile, int32_t (&xv)[kLeaves]) {
+      const int blx = batch_row(tile);
+#pragma unroll
+      for (int i = 0; i < kLeaves; ++i) xv[i] = a.xt[var_off[i] + blx];
+    };
+    // categories of a tile, two per register (C < 65536 is checked on the host): negative = marginalised -> the
+    // integral row C of the table
+    auto pack_categories = [&](const int32_t (&xv)[kLeaves], uint32_t (&cp)[kLeaves / 2]) {
+#pragma unroll
+      for (int j = 0; j < kLeaves / 2; ++j) {
+        const int c0 = xv[2 * j] < 0 ? a.C : min(xv[2 * j], a.C - 1), c1 = xv[2 * j + 1] < 0 ? a.C : min(xv[2 * j + 1], a.C - 1);
+        cp[j] = static_cast<uint32_t>(c0) | (static_cast<uint32_t>(c1) << 16);
+      }
+    };
+    auto row_of = [&](const uint32_t (&cp)[kLeaves / 2], auto ic) -> int32_t {  // table row of leaf ic.value for batch row b_in
+      constexpr int i = decltype(ic)::value;
+      return row_base[i] + static_cast<int32_t>((i & 1) ? cp[i >> 1] >> 16 : cp[i >> 1] & 0xffffu);
+    };
+    // leaf -> slot: lane (r8 = lane >> 3, c8 = lane & 7) of DMA q fetches 16-byte chunk c8 ^ swz(r) of row r = 8q + r8
+    auto dma = [&](int32_t rowv, int slot) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 8 * q + (lane >> 3);
+        const int ridx = __builtin_amdgcn_ds_bpermute(4 * r, rowv);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const float* src = a.table + static_cast<int64_t>(ridx) * kK + c * 4;
+        __builtin_amdgcn_global_load_lds((ck::gptr_t)src, (ck::lptr_t)(my_slots + slot * 1024 + q * 256), 16, 0, 0);
+      }
+    };
+    // one request = the leaf rows (4 wave DMAs) and the log scale (1 load) of a leaf: 5 vector-memory operations
+    float sld[4];  // scales of the leaves in flight (ring; leaf i -> sld[i & 3])
+    auto request = [&](const uint32_t (&cp)[kLeaves / 2], auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int32_t r = row_of(cp, ic);
+      dma(r, i % kSlots);
+      sld[i & 3] = a.scale[r];
+    };
+    int tile = tile_begin + wave;
+    int32_t xnext[kLeaves];        // batch values of the NEXT tile of this wave (requested one tile ahead)
+    uint32_t cat[kLeaves / 2];     // packed categories of the current tile
+    if (tile < tile_end) {  // the first tile of the wave: the chain is paid once per segment
+      load_x(tile, xnext);
+      pack_categories(xnext, cat);
+      static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
+      load_x(min(tile + WAVES, tile_end - 1), xnext);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the weights (and its first leaf rows) have landed
+    __syncthreads();
+
+    for (; tile < tile_end; tile += WAVES) {
+      const int b = tile * 32 + b_in;
+      const bool live = b < a.B;
+      const int bl = live ? b : a.B - 1;
+      float stack[D][16], sstack[D];
+      float cur[16], cs = 0.f, sprev = 0.f;
+      bool bad = false;
+      static_for<0, kLeaves>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        // the request of leaf i has landed (at most those of the next kSlots - 1 leaves, 5 operations each, are younger;
+        // at leaf 0 everything requested during the previous tile is waited for); read the slot into the operand
+        // layout; the reads have returned before the slot is refilled
+        f32x4 r0, r1, r2, r3;
+        constexpr int kYounger = i == 0 ? 0 : 5 * (kLeaves - 1 - i < kSlots - 1 ? kLeaves - 1 - i : kSlots - 1);
+        asm volatile(
+            "s_waitcnt vmcnt(%9)\n\tds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\t"
+            "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+            : "v"(rd_addr[0]), "v"(rd_addr[1]), "v"(rd_addr[2]), "v"(rd_addr[3]), "n"((i % kSlots) * 4096), "n"(kYounger)
+            : "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cur[e] = r0[e];
+          cur[4 + e] = r1[e];
+          cur[8 + e] = r2[e];
+          cur[12 + e] = r3[e];
+        }
+        const float s_i = sld[i & 3];
+        if constexpr (i + kSlots < kLeaves) request(cat, std::integral_constant<int, i + kSlots>{});
+        if constexpr (i + 1 == kLeaves) {
+          // the gathers of this tile are over: request what the next tile starts with (see above)
+          if (tile + WAVES < tile_end) {
+            pack_categories(xnext, cat);
+            static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
+            load_x(min(tile + 2 * WAVES, tile_end - 1), xnext);
+          }
+        }
+        if constexpr ((i & 1) != 0) cs = s_i + sprev;  // log scale of the pair (i - 1, i)
+        else sprev = s_i;
+        static_for<0, steps_after(i)>([&](auto lc) {
+          constexpr int l = decltype(lc)::value, step = steps_before(i) + l;
+          WRegs wcur;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
+          if constexpr (l == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cur[j] *= stack[0][j];  // first level: the bare product (ck_tile.h)
+          } else {
+            linear_product<true>(cur, stack[l], cs, sstack[l], bad);
+          }
+          contract_linear<CK_W_TILED_F32>(wcur, cur);
+        });
+        if constexpr (steps_after(i) < D) {  // left sibling at this level: wait for the right one
+          constexpr int l = steps_after(i);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) stack[l][j] = cur[j];
+          sstack[l] = cs;
+        }
+      });
+      if constexpr (D == 1) bad |= !(tile_row_max(cur) > kLinearFloor);  // (deeper roots are renormalised steps)
+      if (__builtin_expect(__any(bad), 0)) {
+        // rare: a row of products fell out of the fp32 range -> the whole tile again in log space (semiring.py:383-408)
+        SubtreeSource src{};
+        src.table = a.table;
+        src.scale = a.scale;
+        src.xt = a.xt;
+        src.scope = a.scope;
+        src.leaf_ids = leaf_ids;
+        src.fold0 = fold0;
+        src.w_steps = w_lds;
+        src.t = t;
+        src.B = a.B;
+        src.C = a.C;
+        src.bl = bl;
+        float fb[16];  // (its address escapes into the out-of-line call: never `cur`, which must stay in registers)
+        subtree_tile_logspace<D, CK_W_TILED_F32>(src, lane, fb);
+        if (live) tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+      } else if (live) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cur[j] = fmaf(__builtin_amdgcn_logf(cur[j]), kLN2, cs);
+        tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
+      }
+    }
+  }
+}
+
+template <int D>
+hipError_t launch_waves(const LeafArgs& a, int waves, dim3 grid, hipStream_t s) {
+  if (waves == 12)
+    hipLaunchKernelGGL((leaf_persistent_kernel<D, 12>), grid, dim3(768), 0, s, a);
+  else
+    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8>), grid, dim3(512), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
+                           const float* const* w_levels, const int32_t* nodes, const int32_t* node_off, int leaf_off,
+                           float* out, const int32_t* work, int n_seg, int n_wg, int waves, int depth, int B, int K,
+                           int C, void* stream) {
+  CK_REQUIRE(table && table_scale && xt && scope && w_levels && nodes && node_off && out && work,
+             "ck_leaf_persistent_fwd: null pointer");
+  CK_REQUIRE(depth >= 1 && depth <= kMaxDepthP, "ck_leaf_persistent_fwd: depth %d outside [1, %d]", depth, kMaxDepthP);
+  CK_REQUIRE(n_seg > 0 && n_wg > 0 && B > 0 && C > 0, "ck_leaf_persistent_fwd: non-positive size");
+  CK_REQUIRE(waves == 8 || waves == 12, "ck_leaf_persistent_fwd: waves must be 8 or 12 (got %d)", waves);
+  if (K != kK) return ck::fail(CK_ERR_UNSUPPORTED, "ck_leaf_persistent_fwd: K=%d (only K=32 is fused)", K);
+  CK_REQUIRE(ck::aligned16(table) && ck::aligned16(out), "ck_leaf_persistent_fwd: buffers must be 16-byte aligned");
+  LeafArgs a{};
+  a.table = table;
+  a.scale = table_scale;
+  a.xt = xt;
+  a.scope = scope;
+  for (int l = 0; l < depth; ++l) {
+    CK_REQUIRE(w_levels[l] != nullptr && ck::aligned16(w_levels[l]), "ck_leaf_persistent_fwd: bad weights of level %d", l + 1);
+    a.w[l] = w_levels[l];
+  }
+  a.nodes = nodes;
+  for (int l = 0; l <= depth; ++l) a.node_off[l] = node_off[l];
+  a.leaf_off = leaf_off;
+  a.out = out;
+  a.work = work;
+  a.n_seg = n_seg;
+  a.B = B;
+  a.C = C;
+  dim3 grid(static_cast<unsigned>(std::min(n_wg, n_seg)));
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        switch (depth) {
+          case 1:
+            return launch_waves<1>(a, waves, grid, s);
+          case 2:
+            return launch_waves<2>(a, waves, grid, s);
+          case 3:
+            return launch_waves<3>(a, waves, grid, s);
+          default:
+            return launch_waves<4>(a, waves, grid, s);
+        }
+      },
+      stream);
+}
+
+}  // extern "C"

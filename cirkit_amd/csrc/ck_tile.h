@@ -15,6 +15,9 @@
 // The tiled layouts are produced by the softmax prologue (ck_param.hip, kinds 2 and 3).
 #pragma once
 
+#include <type_traits>
+#include <utility>
+
 #include "ck_internal.h"
 
 namespace {
@@ -184,6 +187,139 @@ __device__ __forceinline__ void contract_linear(const WRegs& w, float (&e)[16]) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) e[r] = fmaf(acc1[r], 4.8828125e-4f, acc0[r]) * 2.384185791015625e-07f;  // 2^-22
   }
+}
+
+// ---- linear-domain chaining of fused CP-T levels (ck_fused.hip, ck_leaf.hip) -------------------------------------
+// A node is carried as (y: linear tile, s: per-row log scale), value = log y + s.  A level forms e = y_l * y_r
+// (linear_product) and contracts y = W e (contract_linear).  What this costs matters: fp32-input MFMA and the VALU
+// share the fp32 lanes of a SIMD, so every VALU instruction of a step ADDS ~4 cycles to its 1024 cycles of MFMA
+// (measured, scripts/ubench/leaf_step.hip: the former max + division + log step ran at 1.45x the MFMA time whatever
+// the number of waves).  Hence:
+//   * RESCALE = false (the first fused level, 8 of the 15 nodes of a depth-4 subtree): the bare product, 16 multiplies;
+//   * RESCALE = true: the product is renormalised by a POWER OF TWO, 2^-k with k the exponent of the row maximum --
+//     exact (no rounding at all, unlike a division by the maximum), s += k ln 2; v_frexp_exp + v_ldexp instead of an
+//     IEEE division and a log;
+//   * no branch per step: `bad` collects rows whose maximum fell below 2^-80 ~ 8e-25 (children with disjoint large
+//     units; also NaN); the caller then redoes the whole tile in log space (tile_walk_logspace), exactly the
+//     reference's arithmetic (semiring.py:383-408).  An unscaled level cannot hide an underflow from the next
+//     rescaled level or from the final check of the root tile: a row maximum above 2^-80 there means the terms lost
+//     below it (< 2^-126) were smaller than 2^-46 of it.
+constexpr float kLinearFloor = 8.2718061e-25f;  // 2^-80
+
+__device__ __forceinline__ float tile_row_max(const float (&p)[16]) {
+  const float m0 = __builtin_fmaxf(__builtin_fmaxf(p[0], p[1]), p[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(p[3], p[4]), p[5]);
+  const float m2 = __builtin_fmaxf(__builtin_fmaxf(p[6], p[7]), p[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(p[9], p[10]), p[11]);
+  const float m4 = __builtin_fmaxf(__builtin_fmaxf(p[12], p[13]), p[14]);
+  const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), m2), __builtin_fmaxf(__builtin_fmaxf(m3, m4), p[15]));
+  return ck::xhalf_max(m);
+}
+
+// cur <- cur * sib (renormalised), s <- s_cur + s_sib (+ k ln 2)
+template <bool RESCALE>
+__device__ __forceinline__ void linear_product(float (&cur)[16], const float (&sib)[16], float& s, float s_sib, bool& bad) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) cur[j] *= sib[j];
+  s += s_sib;
+  if constexpr (RESCALE) {
+    const float mx = tile_row_max(cur);
+    const int k = __builtin_amdgcn_frexp_expf(mx);  // mx = f 2^k, f in [0.5, 1)
+    const float sc = __builtin_amdgcn_ldexpf(1.f, -k);
+    bad |= !(mx > kLinearFloor);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] *= sc;
+    s = fmaf(static_cast<float>(k), kLN2, s);
+  }
+}
+
+// compile-time loop: the walks below are fully unrolled (the sibling stack and the step order are static)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// CP-T steps that follow leaf i in the depth-first walk (= trailing one bits of i) and the steps before leaf i
+__host__ __device__ constexpr int steps_after(int i) {
+  int n = 0;
+  while (i & 1) {
+    ++n;
+    i >>= 1;
+  }
+  return n;
+}
+__host__ __device__ constexpr int steps_before(int i) {
+  int n = 0;
+  for (int j = 0; j < i; ++j) n += steps_after(j);
+  return n;
+}
+
+// The depth-first walk of one subtree tile entirely in LOG space (the fallback of the linear chain): leaves are
+// log(table row) + scale, a level adds the siblings and applies sum_step -- the reference's arithmetic.
+//   leaf(ic, v):               fills v with the LINEAR table row of leaf ic.value, returns its log scale
+//   weights(sc, ic, lc, w):    loads the weights of contraction number sc.value = level lc.value + 1 after leaf ic.value
+template <int D, int LAYOUT, class LeafFn, class WFn>
+__device__ __forceinline__ void tile_walk_logspace(LeafFn&& leaf, WFn&& weights, float (&cur)[16]) {
+  float stack[D][16];
+  static_for<0, (1 << D)>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const float s = leaf(ic, cur);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cur[j] = logf(cur[j]) + s;
+    static_for<0, steps_after(i)>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cur[j] += stack[l][j];
+      WRegs w;
+      weights(std::integral_constant<int, steps_before(i) + l>{}, ic, lc, w);
+      sum_step<LAYOUT>(w, cur);
+    });
+    if constexpr (steps_after(i) < D) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) stack[steps_after(i)][j] = cur[j];
+    }
+  });
+}
+
+__device__ __forceinline__ void tile_load(const float* __restrict__ src_row, float (&v)[16]);
+
+// Where the log-space fallback of a fused leaf launch finds its operands (plain pointers and ints: the fallback is an
+// out-of-line function, so that its registers -- sibling stack, weights -- are not part of the hot path's allocation).
+struct SubtreeSource {
+  const float* table;     // (F0, C+1, 32) LINEAR table rows
+  const float* scale;     // (F0, C+1) their log scales
+  const int32_t* xt;      // (Dvars, B)
+  const int64_t* scope;   // variable of each input-layer fold
+  const int32_t* leaf_ids;  // (2^D) input-layer fold of each leaf of this root
+  const int32_t* fold0;     // (2^D) table fold of each leaf
+  const float* w_steps;     // the root's weights in step order (a flat pointer to their LDS copy), or nullptr:
+  const float* w[4];        // ... then level l + 1 weights are w[l] + fold * 1024,
+  const int32_t* nodes;     //     fold = nodes[node_off[l + 1] + t * (2^D >> (l + 1)) + (i >> (l + 1))]
+  int node_off[5];
+  int t, B, C, bl;
+};
+
+template <int D, int LAYOUT>
+__device__ __noinline__ void subtree_tile_logspace(const SubtreeSource src, int lane, float (&out)[16]) {
+  const int kh = lane >> 5;
+  tile_walk_logspace<D, LAYOUT>(
+      [&](auto ic, float (&v)[16]) {
+        constexpr int i = decltype(ic)::value;
+        const int x = src.xt[src.scope[src.leaf_ids[i]] * static_cast<int64_t>(src.B) + src.bl];
+        const int64_t r = static_cast<int64_t>(src.fold0[i]) * (src.C + 1) + (x < 0 ? src.C : min(x, src.C - 1));
+        tile_load(src.table + r * kK + 4 * kh, v);
+        return src.scale[r];
+      },
+      [&](auto sc, auto ic, auto lc, WRegs& w) {
+        constexpr int i = decltype(ic)::value, l = decltype(lc)::value;
+        if (src.w_steps != nullptr) {
+          load_w<CK_W_TILED_F32>(src.w_steps + decltype(sc)::value * 1024, lane, w);  // (tiled layouts: one KiB per q)
+        } else {
+          const int fold = src.nodes[src.node_off[l + 1] + src.t * ((1 << D) >> (l + 1)) + (i >> (l + 1))];
+          load_w<LAYOUT>(src.w[l] + static_cast<int64_t>(fold) * (kK * kK), lane, w);
+        }
+      },
+      out);
 }
 
 // Read one (32 rows x 32 units) tile of a (B, 32) block in register layout, adding it to v.

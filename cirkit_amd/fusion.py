@@ -353,3 +353,31 @@ def find_table_dense(plan, layers, children, skip: set[int]) -> dict[int, int]:
             continue
         found[j] = c
     return found
+
+
+def leaf_segments(num_roots: int, num_tiles: int, num_wg: int) -> np.ndarray:
+    """Segment list ``(n_seg, 4)`` int32 -- rows ``{root fold, first tile, end tile, 0}`` -- of the persistent leaf
+    launch (`ck_leaf_persistent_fwd`): workgroup g of `num_wg` takes segments g, g + num_wg, ...
+
+    Segments never straddle two roots (a root's 2^D - 1 weight matrices are staged in LDS once per segment).  With
+    at least as many workgroups as roots every workgroup gets ONE segment: root r owns the slots
+    ``{p : p * num_roots // num_wg == r}`` (floor or ceil of num_wg / num_roots of them) and its tiles are split
+    evenly among them; slot p is given to workgroup ``b`` with ``p = (b % 8) * (num_wg / 8) + b // 8`` -- workgroup b
+    runs on XCD b % 8 (MI355X_MICROARCH.md), so the workgroups sharing a root's table rows and weights share one L2.
+    With more roots than workgroups the segments are whole roots dealt round-robin.
+    """
+    if num_roots >= num_wg:
+        seg = [[r, 0, num_tiles, 0] for r in range(num_roots)]
+        return np.asarray(seg, dtype=np.int32).reshape(-1, 4)
+    slots = [[] for _ in range(num_roots)]
+    for p in range(num_wg):
+        slots[p * num_roots // num_wg].append(p)
+    by_slot = np.zeros((num_wg, 4), dtype=np.int32)
+    for r, ps in enumerate(slots):
+        c = len(ps)
+        for j, p in enumerate(ps):
+            by_slot[p] = (r, j * num_tiles // c, (j + 1) * num_tiles // c, 0)
+    if num_wg % 8 == 0:
+        b = np.arange(num_wg)
+        return np.ascontiguousarray(by_slot[(b % 8) * (num_wg // 8) + b // 8])
+    return by_slot

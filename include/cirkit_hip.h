@@ -217,6 +217,19 @@ int ck_subtree_cat_cpt_fwd(const float* table, const float* table_scale, const i
                            const int32_t* nodes, const int32_t* node_off, int leaf_off, float* out,
                            int depth, int F_root, int B, int K, int C, int w_layout, void* stream);
 
+/* The same fused leaf region (linear table, CK_W_TILED_F32 weights, no in-kernel dense layer, depth >= 1) as a
+ * PERSISTENT launch: `n_wg` workgroups of `waves` (8 or 12) wavefronts, one per CU, walk the segment list
+ * `work` = DEVICE (n_seg, 4) int32 rows {root fold, first 32-row tile, end tile, 0}: workgroup g takes segments
+ * g, g + n_wg, ...; inside a segment its wavefronts draw tiles from an LDS counter.  A segment's 2^depth - 1
+ * weight matrices are staged in LDS once; leaf rows are gathered global -> LDS (global_load_lds_dwordx4, 8 lanes
+ * per 128-byte row).  Bit-identical outputs to ck_subtree_cat_cpt_fwd with table_scale; the caller chooses the
+ * segment list (cirkit_amd/circuit.py: whole roots split evenly over the CUs of one XCD).  Reference semantics as
+ * ck_subtree_cat_cpt_fwd. */
+int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
+                           const float* const* w_levels, const int32_t* nodes, const int32_t* node_off, int leaf_off,
+                           float* out, const int32_t* work, int n_seg, int n_wg, int waves, int depth, int B, int K,
+                           int C, void* stream);
+
 /* The last `n_layers` levels of a circuit (few folds each) in one launch: one workgroup per 32-row
  * batch tile walks the layers in order, a workgroup barrier between levels.  Layer i is a
  * TorchCPTLayer / dense TorchSumLayer step over the product of its H[i] children (CK_SUM_PROD

@@ -284,7 +284,7 @@ def test_linear_levels_agree_with_log_space_levels(hip_device, contraction):
     lin = HipCircuit(plan, tensors, device=hip_device, contraction=contraction, linear_levels=True)
     log = HipCircuit(plan, tensors, device=hip_device, contraction=contraction, linear_levels=False)
     ya, yb = lin(x).cpu().double(), log(x).cpu().double()
-    assert lin.kernel_label(lin._groups[0].root).startswith("subtree_linear_kernel")
+    assert lin.kernel_label(lin._groups[0].root).startswith(("subtree_linear_kernel", "leaf_persistent_kernel"))
     assert log.kernel_label(log._groups[0].root).startswith("subtree_cat_cpt_kernel")
     ea, eb = float(((ya - ref) / ref).abs().max()), float(((yb - ref) / ref).abs().max())
     assert ea <= REL and eb <= REL
@@ -319,10 +319,63 @@ def test_linear_levels_survive_products_at_the_edge_of_fp32(hip_device):
     x = torch.randint(0, 3, (64, 16), generator=torch.Generator().manual_seed(1))
     hc = HipCircuit(plan, tensors, device=hip_device)
     y = hc(x.to(hip_device)).cpu()
-    assert hc._groups and hc._table_fused and hc.kernel_label(hc._groups[0].root).startswith("subtree_linear_kernel")
+    assert hc._groups and hc._table_fused and hc.kernel_label(hc._groups[0].root, 64).startswith("subtree_linear_kernel")
     ref = evaluate_plan(plan, as_torch(tensors), x)
     assert torch.isfinite(ref).all() and float(ref.min()) < -150.0
     assert torch.allclose(y, ref, rtol=1e-4, atol=1e-3), float((y - ref).abs().max())
+
+
+@pytest.mark.parametrize("B", [1, 33, 1000, 4096])
+def test_persistent_leaf_launch_is_bit_identical(hip_device, B):
+    """The fused leaf region as ONE resident workgroup per CU (ck_leaf.hip: weights staged once per segment, leaf rows
+    gathered global -> LDS, next tile's inputs requested while the current one computes) computes exactly what the
+    workgroup-per-128-rows launch computes: same arithmetic in the same order, bit for bit -- also with marginalised
+    variables and a batch that is not a multiple of the 32-row tile."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    gen = torch.Generator().manual_seed(B)
+    x = torch.randint(0, 256, (B, 784), generator=gen)
+    x[::3, ::5] = -1
+    x = x.to(hip_device)
+    a = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=False)
+    b = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True)
+    c = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True, fuse=2)
+    d = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=False, fuse=2)
+    assert a.kernel_label(a._groups[0].root).startswith("subtree_linear_kernel")
+    assert b.kernel_label(b._groups[0].root).startswith("leaf_persistent_kernel")
+    ya, yb = a(x).clone(), b(x).clone()
+    assert torch.equal(ya, yb)
+    assert torch.equal(c(x), d(x))
+    ref = HipCircuit(plan, tensors, device=hip_device, fuse=False)(x)
+    assert torch.allclose(yb, ref, rtol=1e-5, atol=2e-3)
+
+
+def test_persistent_leaf_falls_back_to_log_space(hip_device):
+    """Products at the edge of fp32 (see test_linear_levels_survive_products_at_the_edge_of_fp32) under the persistent
+    launch: the tile is redone in log space by the same out-of-line walk, bit-identical to the other launch."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import InputSpec, quad_tree_plan
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan = quad_tree_plan((1, 8, 8), input_layer=InputSpec("categorical", 8), sum_product="cp", num_input_units=32, num_sum_units=32)
+    tensors = init_plan_tensors(plan, seed=2)
+    half = (np.arange(32) < 16)
+    t0 = np.full(tensors["t0"].shape, -80.0, dtype=np.float32)
+    t0[:, half, 0] = 0.0
+    t0[:, ~half, 1] = 0.0
+    t1 = np.where(half[:, None] == half[None, :], 0.0, -80.0).astype(np.float32)
+    tensors = {**tensors, "t0": t0, "t1": np.broadcast_to(t1, tensors["t1"].shape).copy()}
+    x = torch.randint(0, 3, (256, 64), generator=torch.Generator().manual_seed(1))
+    a = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=False)
+    b = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True)
+    assert b.kernel_label(b._groups[0].root).startswith("leaf_persistent_kernel")
+    ya, yb = a(x.to(hip_device)).cpu(), b(x.to(hip_device)).cpu()
+    assert torch.equal(ya, yb)
+    ref = evaluate_plan(plan, as_torch(tensors), x)
+    assert torch.isfinite(ref).all()
+    assert torch.allclose(yb, ref, rtol=1e-4, atol=1e-3), float((yb - ref).abs().max())
 
 
 def test_ll_sum(hip_device):
