@@ -30,6 +30,11 @@ from .layers import HipConstantValueLayer, HipEmbeddingLayer, HipInputLayer, Hip
 from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
 
+# ck_tail16_fold of include/cirkit_hip.h
+_TAIL16_FOLD = np.dtype([("w", "<u8"), ("out", "<u8"), ("child", "<u8", (4,)), ("child_src", "<i4", (4,)), ("H", "<i4"),
+                         ("Ko", "<i4"), ("pad", "<i4", (2,))])
+assert _TAIL16_FOLD.itemsize == 80
+
 _ALIGN = 64  # arena alignment of every layer block, in activation elements (>= 256 B)
 
 
@@ -94,6 +99,8 @@ class HipCircuit:
             (cirkit_amd/csrc/ck_leaf.hip) instead of one workgroup per 128 rows.  None: whenever the launch is eligible
             (linear table, tiled fp32 weights) and has at least one 32-row tile per CU; bit-identical either way.
         leaf_waves: wavefronts per workgroup of the persistent leaf launch (8 or 12).
+        tail16: the fused tail on 16-row tiles with its fold outputs kept in LDS and `log_likelihood_sum`'s reduction
+            folded in (cirkit_amd/csrc/ck_tail16.hip); False keeps the 32-row walk of ck_tail.hip.
     """
 
     def __init__(
@@ -115,6 +122,7 @@ class HipCircuit:
         pad_units: bool = True,
         persistent_leaf: bool | None = None,
         leaf_waves: int = 8,
+        tail16: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -157,6 +165,7 @@ class HipCircuit:
         if leaf_waves not in (8, 12):
             raise ValueError("leaf_waves must be 8 or 12")
         self.leaf_waves = int(leaf_waves)
+        self.tail16 = bool(tail16)
         self._n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self._pprog = None
         self._pprog_version = self._pprog_data_version = -1
@@ -409,8 +418,8 @@ class HipCircuit:
         try:
             if not self.cache_params:
                 self._enqueue_params(0)
-            self._enqueue_layers(bd, 0)
-            if with_ll:
+            self._enqueue_layers(bd, 0, with_ll=with_ll)
+            if with_ll and not self._tail_fuses_ll():
                 p, f = int(self._out_pairs[0, 0]), int(self._out_pairs[0, 1])
                 capi.call("ck_ll_sum", bd.views[p][f].data_ptr(), bd.B, 1, bd.ll.data_ptr(), 0)
         finally:
@@ -449,13 +458,13 @@ class HipCircuit:
         for g in self._groups:
             self._group_table(g, stream)
 
-    def _enqueue_layers(self, bd: _Binding, stream: int) -> None:
+    def _enqueue_layers(self, bd: _Binding, stream: int, *, with_ll: bool = False) -> None:
         """The layer kernels of one forward, in plan order (graph/modules.py:326-334)."""
         B = bd.B
         for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
             if self._tail and i in self._tail:
                 if i == self._tail[0]:
-                    self._launch_tail(bd, stream)
+                    self._launch_tail(bd, stream, with_ll=with_ll)
                 continue
             if i in self._virtual:
                 continue
@@ -663,8 +672,24 @@ class HipCircuit:
             covered |= {g.input_layer, g.dense_layer}
         return covered
 
-    def _launch_tail(self, bd: _Binding, stream: int) -> None:
-        """One launch for the trailing few-fold layers (cirkit_amd/csrc/ck_tail.hip)."""
+    def _tail16_ok(self) -> bool:
+        """The tail as ONE launch on 16-row tiles with its fold outputs kept in LDS (ck_tail16.hip): real weights in
+        row-major or tiled fp32 layout, at most 72 folds of 32 units."""
+        ls = [self.layers[j] for j in self._tail]
+        lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
+        return (self.tail16 and lay in (capi.CK_W_ROWMAJOR, capi.CK_W_TILED_F32) and len(ls) <= 15
+                and sum(l.num_folds for l in ls) <= 64 and all(l.arity <= 4 and l.num_input_units == 32 for l in ls))
+
+    def _tail_fuses_ll(self) -> bool:
+        """Whether `log_likelihood_sum`'s reduction is part of the tail launch (the circuit output is the scalar root)."""
+        if not self._tail or not self._tail16_ok() or len(self._out_pairs) != 1:
+            return False
+        last = self._tail[-1]
+        return (int(self._out_pairs[0, 0]) == last and self.layers[last].num_folds == 1
+                and self.layers[last].num_output_units == 1)
+
+    def _launch_tail(self, bd: _Binding, stream: int, *, with_ll: bool = False) -> None:
+        """One launch for the trailing few-fold layers (cirkit_amd/csrc/ck_tail16.hip; ck_tail.hip otherwise)."""
         n = len(self._tail)
         ls = [self.layers[j] for j in self._tail]
         for l in ls:
@@ -672,12 +697,49 @@ class HipCircuit:
                 raise ValueError("complex weights under the real lse-sum semiring")
         vp = C.c_void_p * n
         ip = C.c_int32 * n
+        lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
+        if self._tail16_ok():
+            tabs = bd.cp_tabs.get("tail16")
+            if tabs is None:
+                first, acc = {}, 0
+                for j, l in zip(self._tail, ls):
+                    first[j] = acc
+                    acc += l.num_folds
+                desc = np.zeros(acc, dtype=_TAIL16_FOLD)
+                arena = bd.arena.data_ptr()
+                for j, l in zip(self._tail, ls):
+                    ch = self._children[j]  # (F, H, 2): producer layer, fold
+                    off = bd.row_off[j].cpu().numpy()
+                    Ko = l.num_output_units
+                    for f in range(l.num_folds):
+                        d = desc[first[j] + f]
+                        d["w"] = l._w.data_ptr() + f * Ko * 32 * 4
+                        d["out"] = bd.views[j].data_ptr() + f * bd.B * Ko * 4
+                        d["H"], d["Ko"] = l.arity, Ko
+                        d["child_src"][:] = -1
+                        for h in range(l.arity):
+                            pj, pf = int(ch[f, h, 0]), int(ch[f, h, 1])
+                            if pj in first and self.layers[pj].num_output_units == 32:
+                                d["child_src"][h] = first[pj] + pf
+                            d["child"][h] = arena + int(off[f, h]) * 4
+                levels = np.asarray([first[j] for j in self._tail] + [acc], dtype=np.int32)
+                tabs = bd.cp_tabs["tail16"] = (
+                    torch.from_numpy(desc.view(np.uint8)).to(self.device), torch.from_numpy(levels).to(self.device), acc,
+                    torch.zeros((bd.B + 15) // 16 + 1, dtype=torch.float64, device=self.device),
+                    torch.zeros(1, dtype=torch.int32, device=self.device))
+            desc_dev, levels_dev, n_folds, scratch, ticket = tabs
+            fuse_ll = with_ll and self._tail_fuses_ll()
+            capi.call(
+                "ck_tail16_lse_fwd", desc_dev.data_ptr(), n_folds, levels_dev.data_ptr(), n, bd.B, 32, lay,
+                bd.ll.data_ptr() if fuse_ll else None, scratch.data_ptr() if fuse_ll else None,
+                ticket.data_ptr() if fuse_ll else None, stream,
+            )
+            return
         capi.call(
             "ck_tail_lse_fwd", bd.arena.data_ptr(), n,
             vp(*[bd.row_off[j].data_ptr() for j in self._tail]), vp(*[l._w.data_ptr() for l in ls]),
             vp(*[bd.views[j].data_ptr() for j in self._tail]), ip(*[l.num_folds for l in ls]),
-            ip(*[l.arity for l in ls]), ip(*[l.num_output_units for l in ls]), bd.B, ls[0].num_input_units,
-            next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR), stream,
+            ip(*[l.arity for l in ls]), ip(*[l.num_output_units for l in ls]), bd.B, ls[0].num_input_units, lay, stream,
         )
 
     def _group_table(self, g: SubtreeGroup, stream: int | None):
@@ -1088,7 +1150,7 @@ class HipCircuit:
                 if i == self._tail[-1]:
                     tl = next((self.layers[j]._w_layout for j in self._tail
                                if self.layers[j].num_output_units == 32), 0)
-                    rows.append({"layer": self._tail[0], "kernel": f"tail_kernel<{tl}>",
+                    rows.append({"layer": self._tail[0], "kernel": (f"tail16_kernel<{tl}>" if self._tail16_ok() else f"tail_kernel<{tl}>"),
                                  "ms": float(mean[2 * self._tail[0] + 1]),
                                  "algorithmic_bytes": sum(layer_bytes[j] for j in self._tail),
                                  "algorithmic_flops": sum(layer_flops[j] for j in self._tail)})

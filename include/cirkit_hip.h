@@ -241,6 +241,27 @@ int ck_tail_lse_fwd(const float* arena, int n_layers, const int64_t* const* row_
                     const float* const* w, float* const* out, const int32_t* F, const int32_t* H,
                     const int32_t* Ko, int B, int K, int w_layout, void* stream);
 
+/* The same walk on 16-row tiles (v_mfma_f32_16x16x4_f32): one workgroup of 16 wavefronts per 16 batch rows; the fold
+ * descriptors are staged in LDS once, every fold output is kept in LDS for the levels above it (and written to its
+ * `out` block as before), the weights of a wave's next fold are requested before the level barrier.
+ * folds: DEVICE array of n_folds descriptors in level order (16-byte aligned); level_begin: DEVICE (n_levels + 1)
+ * first fold of each level (folds of one level never read each other).  A fold is a TorchCPTLayer / dense TorchSumLayer
+ * step over the product of its H <= 4 children (CK_SUM_PROD semantics), Ki = 32, Ko = 32 or < 32 (e.g. the scalar root;
+ * row-major weights; never a child inside the tail).  w_layout (Ko = 32 folds): CK_W_ROWMAJOR or CK_W_TILED_F32.
+ * ll != NULL folds ck_ll_sum in (the last fold must be the scalar root): ll[0] = sum_b out[b] in fp64 -- per-workgroup
+ * sums in row order, then workgroup order: deterministic -- ll[1] = B; ll_partial: ceil(B / 16) doubles of scratch,
+ * ll_ticket: one zero-initialised uint32 (left zero). */
+typedef struct ck_tail16_fold {
+  const float* w;          /* (Ko, 32) linear weights of this fold                                             */
+  float* out;              /* (B, Ko) output block of this fold                                                */
+  const float* child[4];   /* (B, 32) block of child h when child_src[h] < 0                                   */
+  int32_t child_src[4];    /* index (in `folds`) of child h when it is a 32-unit fold of the tail itself, else -1 */
+  int32_t H, Ko;
+  int32_t pad[2];
+} ck_tail16_fold;
+int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* level_begin, int n_levels, int B, int K,
+                      int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, void* stream);
+
 /* ---------------------------------------------------------------- parameter graphs --------- */
 /* The reference re-evaluates each layer's parameter DAG on every forward
  * (parameters/parameter.py:180-188); these kernels do the same on the fold-stacked blocks. */

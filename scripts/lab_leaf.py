@@ -25,7 +25,9 @@ from cirkit_amd.initializers import init_plan_tensors
 from cirkit_amd.templates import image_data
 
 CONFIGS = {
-    "classic": dict(persistent_leaf=False),
+    "classic": dict(persistent_leaf=False, tail16=False),
+    "tail32": dict(tail16=False),
+    "default": dict(),
     "persistent8": dict(persistent_leaf=True, leaf_waves=8),
     "persistent12": dict(persistent_leaf=True, leaf_waves=12),
 }
@@ -53,6 +55,8 @@ def main() -> None:
                 ref = y
             same = bool(torch.equal(y, ref))
             maxdiff = float((y - ref).abs().max())
+            ll = hc.log_likelihood_sum(x).cpu()
+            ll_err = abs(float(ll[0]) - float(y.double().sum())) / abs(float(y.double().sum()))
             for _ in range(10):
                 hc.log_likelihood_sum(x)
             rounds = []
@@ -66,7 +70,7 @@ def main() -> None:
                 torch.cuda.synchronize(dev)
                 rounds.append(e0.elapsed_time(e1) / steps)
         print(json.dumps({"config": name, "B": B, "bit_identical_to_first": same, "max_abs_diff": maxdiff,
-                          "mean_ll": float(y.mean()), "ms_per_step_median": float(np.median(rounds)),
+                          "mean_ll": float(y.mean()), "ll_sum_rel_err": ll_err, "ll_count": float(ll[1]), "ms_per_step_median": float(np.median(rounds)),
                           "ms_per_step_min": float(min(rounds))}), flush=True)
         del hc
 

@@ -342,9 +342,9 @@ def test_persistent_leaf_launch_is_bit_identical(hip_device, B):
     b = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True)
     c = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True, fuse=2)
     d = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=False, fuse=2)
-    assert a.kernel_label(a._groups[0].root).startswith("subtree_linear_kernel")
-    assert b.kernel_label(b._groups[0].root).startswith("leaf_persistent_kernel")
     ya, yb = a(x).clone(), b(x).clone()
+    assert a.kernel_label(a._groups[0].root, B).startswith("subtree_linear_kernel")
+    assert b.kernel_label(b._groups[0].root, B).startswith("leaf_persistent_kernel")
     assert torch.equal(ya, yb)
     assert torch.equal(c(x), d(x))
     ref = HipCircuit(plan, tensors, device=hip_device, fuse=False)(x)
@@ -370,12 +370,38 @@ def test_persistent_leaf_falls_back_to_log_space(hip_device):
     x = torch.randint(0, 3, (256, 64), generator=torch.Generator().manual_seed(1))
     a = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=False)
     b = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True)
-    assert b.kernel_label(b._groups[0].root).startswith("leaf_persistent_kernel")
     ya, yb = a(x.to(hip_device)).cpu(), b(x.to(hip_device)).cpu()
+    assert b.kernel_label(b._groups[0].root, 256).startswith("leaf_persistent_kernel")
     assert torch.equal(ya, yb)
     ref = evaluate_plan(plan, as_torch(tensors), x)
     assert torch.isfinite(ref).all()
     assert torch.allclose(yb, ref, rtol=1e-4, atol=1e-3), float((yb - ref).abs().max())
+
+
+@pytest.mark.parametrize("B", [1, 17, 300, 4096])
+def test_tail_on_16_row_tiles(hip_device, B):
+    """The fused tail on 16-row tiles (ck_tail16.hip: descriptors and fold outputs in LDS, v_mfma_f32_16x16x4_f32)
+    against the 32-row walk of ck_tail.hip and the layer-wise evaluation: every tail layer's output agrees to fp32
+    rounding (the two MFMA shapes add the 32 products in different orders), and the log-likelihood sum folded into the
+    launch equals the sum of its own outputs (fp64, deterministic)."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(B)).to(hip_device)
+    a = HipCircuit(plan, tensors, device=hip_device, tail16=False)
+    b = HipCircuit(plan, tensors, device=hip_device, tail16=True)
+    assert b._tail16_ok() and b._tail_fuses_ll() and not a._tail16_ok()
+    la, lb = a.layer_outputs(x), b.layer_outputs(x)
+    for j in b._tail:
+        assert torch.allclose(la[j], lb[j], rtol=1e-6, atol=1e-6 * float(la[j].abs().max())), j
+    y = b(x).clone()
+    s1 = b.log_likelihood_sum(x).clone().cpu()
+    s2 = b.log_likelihood_sum(x).clone().cpu()
+    assert torch.equal(s1, s2)  # deterministic reduction
+    assert s1[1].item() == B
+    assert abs(s1[0].item() - float(y.double().sum())) <= 1e-9 * abs(float(y.double().sum()))
+    sa = a.log_likelihood_sum(x).cpu()
+    assert abs(sa[0].item() - s1[0].item()) <= 1e-6 * abs(s1[0].item())
 
 
 def test_ll_sum(hip_device):
