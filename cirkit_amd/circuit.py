@@ -1031,7 +1031,10 @@ class HipCircuit:
     def profile_kernels(self, x: torch.Tensor | None, iters: int = 10) -> list[dict]:
         """Eager (non-graph) forwards with HIP events around every layer's parameter kernels and
         layer kernel, recorded on the current stream (the stream the kernels are launched on).
-        Returns one row per launch group: kernel label, mean ms, algorithmic bytes."""
+        Returns one row per launch group: kernel label, mean ms, algorithmic bytes / flops (those of the
+        reference layers the launch stands for) and `executed_flops` (the contraction flops the launch itself issues: a
+        dense layer pushed through its category table is executed by the prologue on C + 1 rows, not by the leaf launch
+        on B rows)."""
         bd = self._run(x)  # make sure the binding (arena, staging copy) exists and is warm
         B = bd.B
         cur = torch.cuda.current_stream(self.device)
@@ -1106,6 +1109,7 @@ class HipCircuit:
         mean = np.maximum(np.mean(np.asarray(acc), axis=0) - overhead, 0.0)
         layer_bytes: dict[int, float] = {}
         layer_flops: dict[int, float] = {}
+        moved = [0.0]  # flops of dense layers evaluated on their category tables by the prologue
         for i, (l, s) in enumerate(zip(self.layers, self.plan.layers)):
             pbytes = 0
             for pg in s.params.values():
@@ -1173,11 +1177,24 @@ class HipCircuit:
                     nb, nf = self._cp_fold_cost(int(h), ch[..., 1][ch[..., 0] == h], layer_bytes, layer_flops)
                     nbytes += nb
                     nflops += nf
+            executed = nflops
             if i in self._group_of_root:  # the fused launch does the work of every layer it replaces
-                nbytes += sum(layer_bytes[j] for j in self._group_of_root[i].virtual)
-                nflops += sum(layer_flops[j] for j in self._group_of_root[i].virtual)
+                g = self._group_of_root[i]
+                nbytes += sum(layer_bytes[j] for j in g.virtual)
+                nflops += sum(layer_flops[j] for j in g.virtual)
+                executed = nflops
+                if g.dense_layer is not None and (i in self._table_fused or (self.dense_on_table and g.depth > 0)):
+                    # the dense layer is evaluated on the (C + 1)-row table by the parameter prologue, not by this launch:
+                    # its flops are part of what the launch stands for (algorithmic) but not of what it executes
+                    executed -= layer_flops[g.dense_layer]
+                    Cn = self.layers[g.input_layer].num_categories
+                    moved[0] += layer_flops[g.dense_layer] * (Cn + 1) / B
             rows.append({"layer": i, "kernel": self.kernel_label(i, B), "ms": float(mean[2 * i + 1]),
-                         "algorithmic_bytes": nbytes, "algorithmic_flops": nflops})
+                         "algorithmic_bytes": nbytes, "algorithmic_flops": nflops, "executed_flops": executed})
+        for r in rows:  # the prologue executes the dense layers that were pushed through their tables
+            if r["kernel"].startswith("softmax_batch_kernel"):
+                r["executed_flops"] = r.get("executed_flops", 0.0) + moved[0]
+            r.setdefault("executed_flops", r.get("algorithmic_flops", 0.0))
         return rows
 
     def _cp_fold_cost(self, i: int, folds: np.ndarray, layer_bytes, layer_flops) -> tuple[float, float]:
@@ -1200,6 +1217,13 @@ class HipCircuit:
 
     def num_launches(self, B: int) -> int:
         return int(capi.load().ck_program_num_ops(self._bind(B).program))
+
+    def num_launches_ll(self, B: int) -> int:
+        """Launches of one `log_likelihood_sum` step (without the staging of the batch)."""
+        bd = self._bind(B)
+        if bd.program_ll is None:
+            bd.program_ll = self._record(bd, with_ll=True)
+        return int(capi.load().ck_program_num_ops(bd.program_ll))
 
 
 class HipCircuitStreams:

@@ -100,3 +100,37 @@ def test_many_batch_sizes_and_long_replay(hip_device):
     torch.cuda.synchronize()
     assert torch.equal(r, ref)
     assert torch.cuda.memory_allocated() == m0
+
+
+def test_config3_per_node_batch_on_one_gpu(hip_device):
+    """BASELINE config 3's global batch (32768 rows = 8 shards of 4096) evaluated on ONE GPU: the eight 4096-row shards a
+    data-parallel run would hold give the same rows as the single 32768-row batch, the [sum, count] pairs of the shards
+    add up to the pair of the whole (what the one all-reduce of the N-GPU run computes), and a slice matches the oracle."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan = image_data((1, 28, 28), "quad-tree-2", input_layer="categorical", num_input_units=32,
+                      sum_product_layer="cp", num_sum_units=32)
+    tensors = init_plan_tensors(plan)
+    G = 32768
+    x = torch.randint(0, 256, (G, 784), generator=torch.Generator().manual_seed(3))
+    xd = x.to(hip_device)
+    hc = HipCircuit(plan, tensors, device=hip_device)
+    y = hc(xd).clone()
+    assert y.shape == (G, 1, 1) and bool(torch.isfinite(y).all())
+    whole = hc.log_likelihood_sum(xd).clone().cpu()
+    assert whole[1].item() == G
+    assert abs(whole[0].item() - float(y.double().sum())) <= 1e-9 * abs(float(y.double().sum()))
+    tot = torch.zeros(2, dtype=torch.float64)
+    for r in range(8):  # rank r of 8 holds rows [4096 r, 4096 (r + 1))
+        shard = xd[4096 * r : 4096 * (r + 1)]
+        ys = hc(shard)
+        assert float((ys - y[4096 * r : 4096 * (r + 1)]).abs().max()) <= 2e-4 * float(y.abs().max())
+        tot += hc.log_likelihood_sum(shard).cpu()
+    assert tot[1].item() == G
+    assert abs(tot[0].item() - whole[0].item()) <= 1e-6 * abs(whole[0].item())
+    rows = slice(20000, 20064)
+    want = evaluate_plan(plan, as_torch(tensors), x[rows])
+    assert float((y[rows].cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max())
