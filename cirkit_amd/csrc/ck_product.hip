@@ -43,22 +43,28 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// out[f,b,i*K+j] = x0[f,b,i] + x1[f,b,j]; esize words per element.
+// out[f, b, r] = sum_h x_h[f, b, digit_h(r)], r = sum_h digit_h K^(H-1-h) (child 0 is the most significant digit:
+// flatten(y0[..., None] + x_i[..., None, :]) repeated, inner.py:178-187); esize words per element.
 __global__ void __launch_bounds__(256)
     kronecker_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
-                     float* __restrict__ out, int B, int K, int esize) {
+                     float* __restrict__ out, int H, int B, int K, int64_t kk, int esize) {
   const int f = blockIdx.y;
-  const int64_t o0 = row_off[2 * f] * esize, o1 = row_off[2 * f + 1] * esize;
-  const int64_t kk = static_cast<int64_t>(K) * K;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
   const int64_t n = static_cast<int64_t>(B) * kk;
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const int64_t b = i / kk;
-    const int r = static_cast<int>(i - b * kk);
-    const int ii = r / K, jj = r - ii * K;
-    for (int c = 0; c < esize; ++c)
-      out[(static_cast<int64_t>(f) * n + i) * esize + c] =
-          arena[o0 + (b * K + ii) * esize + c] + arena[o1 + (b * K + jj) * esize + c];
+    int64_t r = i - b * kk;
+    float acc[2] = {0.f, 0.f};
+    for (int h = H - 1; h >= 0; --h) {
+      const int64_t q = r / K;
+      const int d = static_cast<int>(r - q * K);
+      r = q;
+      const float* src = arena + (ro[h] + b * K + d) * esize;
+      acc[0] += src[0];
+      if (esize == 2) acc[1] += src[1];
+    }
+    for (int c = 0; c < esize; ++c) out[(static_cast<int64_t>(f) * n + i) * esize + c] = acc[c];
   }
 }
 
@@ -93,17 +99,22 @@ int ck_hadamard_fwd(const float* arena, const int64_t* row_off, float* out, int 
       stream);
 }
 
-int ck_kronecker_fwd(const float* arena, const int64_t* row_off, float* out, int F, int B, int K,
+int ck_kronecker_fwd(const float* arena, const int64_t* row_off, float* out, int F, int H, int B, int K,
                      int esize, void* stream) {
   CK_REQUIRE(arena && row_off && out, "ck_kronecker_fwd: null pointer");
-  CK_REQUIRE(F > 0 && B > 0 && K > 0, "ck_kronecker_fwd: non-positive size");
+  CK_REQUIRE(F > 0 && H >= 2 && B > 0 && K > 0, "ck_kronecker_fwd: non-positive size or arity < 2");
   CK_REQUIRE(esize == 1 || esize == 2, "ck_kronecker_fwd: esize must be 1 or 2");
   CK_REQUIRE(F <= 65535, "ck_kronecker_fwd: F=%d exceeds grid.y", F);
-  const int64_t n = static_cast<int64_t>(B) * K * K;
+  int64_t kk = 1;
+  for (int h = 0; h < H; ++h) {
+    kk *= K;
+    CK_REQUIRE(kk <= (int64_t{1} << 31), "ck_kronecker_fwd: K^H = %d^%d output units", K, H);
+  }
+  const int64_t n = static_cast<int64_t>(B) * kk;
   dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 2048)), F), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(kronecker_kernel, grid, block, 0, s, arena, row_off, out, B, K, esize);
+        hipLaunchKernelGGL(kronecker_kernel, grid, block, 0, s, arena, row_off, out, H, B, K, kk, esize);
         return hipGetLastError();
       },
       stream);

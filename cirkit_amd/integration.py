@@ -9,9 +9,8 @@ b3  `HipModuleFn(circuit)` -- a ``ModuleEvalFunctional`` (cirkit/backend/torch/g
     layer with the HIP kernels through the per-layer ``forward`` contract.  Zero patches to cirkit.
 b4  `to_hip(circuit)` -- replace the whole forward: extract the folded plan from the compiled
     ``TorchCircuit`` and return a `HipCircuit` (fused gathers, recorded launch list, leaf fusion).
-b2  `layer_rule_for(...)` -- the shape of a layer compilation rule
-    (``PipelineContext.add_layer_compilation_rule``, pipeline.py:110-116); see INTEGRATION.md for the
-    stub a cirkit maintainer would add.
+b2  layer compilation rules returning ``TorchLayer`` subclasses that call the C ABI live in
+    `cirkit_amd/cirkit_plugin.py` (it imports cirkit; ``plugin.register(ctx)``, pipeline.py:110-116).
 """
 
 from __future__ import annotations
@@ -41,17 +40,29 @@ class HipModuleFn:
     """``module_fn`` for ``TorchDiAcyclicGraph.evaluate``: ``fn(module, *inputs) -> Tensor``."""
 
     def __init__(self, circuit: Any, *, device: str | torch.device = "cuda:0") -> None:
-        self.device = torch.device(device)
         table = tensor_table()
-        self.plan, tensors = plan_from_torch_circuit(circuit, table=table)
+        plan, tensors = plan_from_torch_circuit(circuit, table=table)
+        entries = [e for e in circuit.address_book if e.module is not None]
+        self._bind(plan, tensors, [e.module for e in entries], device)
+
+    @classmethod
+    def from_plan(cls, plan: Any, tensors: Any, modules: list, *, device: str | torch.device = "cuda:0") -> "HipModuleFn":
+        """The hook for an interpreter loop whose modules are `modules` (in address-book order) and whose folded plan
+        and parameter values are already known -- e.g. extracted earlier, or loaded from a plan file."""
+        self = cls.__new__(cls)
+        self._bind(plan, tensors, list(modules), device)
+        return self
+
+    def _bind(self, plan: Any, tensors: Any, modules: list, device: str | torch.device) -> None:
+        self.device = torch.device(device)
+        self.plan = plan
         self.store = TensorStore(self.device)
         self.store.update(tensors)
         self._by_module: dict[int, HipLayer] = {}
-        entries = [e for e in circuit.address_book if e.module is not None]
-        if len(entries) != len(self.plan.layers):
-            raise ValueError("address book and extracted plan disagree")
-        for e, spec in zip(entries, self.plan.layers):
-            self._by_module[id(e.module)] = layer_from_spec(spec, self.store, self.plan.semiring)
+        if len(modules) != len(plan.layers):
+            raise ValueError("address book and plan disagree")
+        for m, spec in zip(modules, plan.layers):
+            self._by_module[id(m)] = layer_from_spec(spec, self.store, plan.semiring)
 
     def layer_of(self, module: Any) -> HipLayer:
         try:
@@ -68,18 +79,3 @@ class HipModuleFn:
         if isinstance(layer, HipInputLayer):
             return layer.forward(x.to(self.device))
         return layer.forward(x.to(self.device))
-
-
-def layer_rule_for(hip_layer_cls: type, symbolic_layer_cls: type):
-    """Build a layer compilation rule ``rule(compiler, sl: symbolic_layer_cls)`` whose registry key is
-    the annotation of its last parameter (cirkit/backend/compiler.py:101-113).  The rule body a
-    maintainer writes is in INTEGRATION.md; this helper only fixes the signature convention."""
-
-    def rule(compiler: Any, sl: Any):  # pragma: no cover - needs cirkit
-        raise NotImplementedError(
-            "bind this rule inside cirkit (see INTEGRATION.md): it must return a TorchLayer subclass "
-            f"that forwards to {hip_layer_cls.__name__}"
-        )
-
-    rule.__annotations__ = {"compiler": Any, "sl": symbolic_layer_cls, "return": Any}
-    return rule

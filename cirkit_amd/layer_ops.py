@@ -1,0 +1,198 @@
+"""Layer forwards as plain functions over torch tensors -- the C ABI (`include/cirkit_hip.h`) with the shapes of the
+reference's ``TorchLayer.forward`` contracts and already-evaluated parameters.
+
+These are what a layer subclass living INSIDE cirkit calls (`cirkit_amd/cirkit_plugin.py`, SURVEY.md section 8 b2: a
+layer compilation rule returning a ``TorchLayer`` subclass): the subclass keeps the reference's parameter graph
+(``self.weight()`` ...) and hands the evaluated tensors to the HIP kernel.  Nothing here imports cirkit, so the functions
+are exercised on the GPU box (tests/test_gpu_layer_ops.py) where the reference is absent.
+
+Every function enqueues on the current stream of the input's device and raises if the input is not on a ROCm device:
+there is no CPU or eager fallback.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import _capi as capi
+
+__all__ = ["sum_lse", "hadamard", "kronecker", "tensordot_lse", "categorical_log_likelihood", "gaussian_log_likelihood",
+           "embedding", "constant_value"]
+
+
+def _on_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise capi.HipExtensionError(f"{what} is on {t.device}: the HIP layers evaluate on a ROCm device only (no CPU fallback)")
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _children(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, int, int, int, int]:
+    """(F, H, B, Ki) gathered children -> contiguous storage + the (F, H) element offsets the kernels read through."""
+    if x.dim() != 4:
+        raise ValueError(f"expected an input of shape (F, H, B, Ki), found {tuple(x.shape)}")
+    _on_device(x, "the layer input")
+    x = x.contiguous()
+    F, H, B, Ki = x.shape
+    row_off = (torch.arange(F * H, dtype=torch.int64, device=x.device) * (B * Ki)).reshape(F, H)
+    return x, row_off, F, H, B, Ki
+
+
+def sum_lse(x: torch.Tensor, weight: torch.Tensor, mode: int = capi.CK_SUM_CAT) -> torch.Tensor:
+    """``TorchSumLayer.forward`` (inner.py:266-273, mode CK_SUM_CAT), ``TorchCPTLayer.forward`` (optimized.py:171-178,
+    CK_SUM_PROD) and ``TorchTuckerLayer.forward`` (optimized.py:89-103, CK_SUM_KRON) under lse-sum / complex-lse-sum:
+    x (F, H, B, Ki) log-space children, weight (F, Ko, N) linear-space -> (F, B, Ko)."""
+    x, row_off, F, H, B, Ki = _children(x)
+    if weight.dim() != 3 or weight.shape[0] != F:
+        raise ValueError(f"expected a weight of shape (F={F}, Ko, N), found {tuple(weight.shape)}")
+    _on_device(weight, "the weight")
+    Ko = int(weight.shape[1])
+    n_in = {capi.CK_SUM_CAT: H * Ki, capi.CK_SUM_PROD: Ki, capi.CK_SUM_KRON: Ki**H}[mode]
+    if weight.shape[2] != n_in:
+        raise ValueError(f"the weight has {weight.shape[2]} inputs per output, the layer contracts {n_in}")
+    with torch.cuda.device(x.device):
+        st = _stream(x.device)
+        if x.is_complex():
+            w = weight.contiguous()
+            w = w.to(torch.complex64) if w.is_complex() else w.to(torch.float32)
+            out = torch.empty((F, B, Ko), dtype=torch.complex64, device=x.device)
+            capi.call("ck_sum_lse_fwd_c", x.data_ptr(), row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, H, B, Ki, Ko,
+                      mode, 1 if w.is_complex() else 0, st)
+            return out
+        if weight.is_complex():
+            raise ValueError("complex weights under the real lse-sum semiring")
+        w = weight.to(torch.float32).contiguous()
+        out = torch.empty((F, B, Ko), dtype=torch.float32, device=x.device)
+        capi.call("ck_sum_lse_fwd", x.to(torch.float32).data_ptr() if x.dtype != torch.float32 else x.data_ptr(),
+                  row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, H, B, Ki, Ko, mode, capi.CK_W_ROWMAJOR, st)
+        return out
+
+
+def hadamard(x: torch.Tensor) -> torch.Tensor:
+    """``TorchHadamardLayer.forward`` (inner.py:126-127) in log space: the sum over the arity axis."""
+    x, row_off, F, H, B, K = _children(x)
+    out = torch.empty((F, B, K), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.call("ck_hadamard_fwd", x.data_ptr(), row_off.data_ptr(), out.data_ptr(), F, H, B, K, 2 if x.is_complex() else 1,
+                  _stream(x.device))
+    return out
+
+
+def kronecker(x: torch.Tensor) -> torch.Tensor:
+    """``TorchKroneckerLayer.forward`` (inner.py:178-187), any arity: (F, H, B, K) -> (F, B, K ** H)."""
+    x, row_off, F, H, B, K = _children(x)
+    if H < 2:
+        raise ValueError("The arity should be at least 2")
+    out = torch.empty((F, B, K**H), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.call("ck_kronecker_fwd", x.data_ptr(), row_off.data_ptr(), out.data_ptr(), F, H, B, K, 2 if x.is_complex() else 1,
+                  _stream(x.device))
+    return out
+
+
+def tensordot_lse(x: torch.Tensor, weight: torch.Tensor, num_contract_units: int, num_batch_units: int) -> torch.Tensor:
+    """``TorchTensorDotLayer.forward`` (optimized.py:287-300): x (F, 1, B, Kj * Kq), weight (F, Kk, Kj) -> (F, B, Kq * Kk)."""
+    x, row_off, F, H, B, Ki = _children(x)
+    Kj, Kq = int(num_contract_units), int(num_batch_units)
+    if H != 1 or Ki != Kj * Kq or weight.shape[0] != F or weight.shape[2] != Kj:
+        raise ValueError(f"tensordot: input {tuple(x.shape)}, weight {tuple(weight.shape)}, Kj={Kj}, Kq={Kq}")
+    _on_device(weight, "the weight")
+    Kk = int(weight.shape[1])
+    with torch.cuda.device(x.device):
+        st = _stream(x.device)
+        if x.is_complex():
+            w = weight.contiguous()
+            w = w.to(torch.complex64) if w.is_complex() else w.to(torch.float32)
+            out = torch.empty((F, B, Kq * Kk), dtype=torch.complex64, device=x.device)
+            capi.call("ck_tensordot_lse_fwd_c", x.data_ptr(), row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, B, Kj, Kq, Kk,
+                      1 if w.is_complex() else 0, st)
+            return out
+        w = weight.to(torch.float32).contiguous()
+        out = torch.empty((F, B, Kq * Kk), dtype=torch.float32, device=x.device)
+        capi.call("ck_tensordot_lse_fwd", x.data_ptr(), row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, B, Kj, Kq, Kk, st)
+        return out
+
+
+def _discrete_input(x: torch.Tensor, num_states: int) -> torch.Tensor:
+    """(F, B, 1) -> (F, B) int32; like the reference's advanced indexing an out-of-range value is an IndexError."""
+    _on_device(x, "the layer input")
+    if x.dim() != 3 or x.shape[2] != 1:
+        raise ValueError(f"expected an input of shape (F, B, 1), found {tuple(x.shape)}")
+    if x.is_floating_point():
+        x = x.long()  # input.py:400-401
+    x = x.squeeze(dim=2)
+    if x.numel() and (int(x.min()) < -num_states or int(x.max()) >= num_states):
+        raise IndexError(f"index out of range for {num_states} states")
+    x = torch.where(x < 0, x + num_states, x)  # torch indexing wraps negative indices
+    return x.to(torch.int32).contiguous()
+
+
+def categorical_log_likelihood(x: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
+    """``TorchCategoricalLayer.log_unnormalized_likelihood`` (input.py:399-412): x (F, B, 1) categories, logits (F, K, C)
+    (``log(probs())`` or ``logits()``) -> (F, B, K)."""
+    F, K, C = logits.shape
+    xi = _discrete_input(x, C)
+    B = xi.shape[1]
+    # the gather kernel reads a (F, C + 1, K) table (row C = the integral row, unused here) through per-fold variables
+    table = torch.empty((F, C + 1, K), dtype=torch.float32, device=x.device)
+    table[:, :C] = logits.to(torch.float32).transpose(1, 2)
+    table[:, C] = 0.0
+    scope = torch.arange(F, dtype=torch.int64, device=x.device)
+    out = torch.empty((F, B, K), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.call("ck_categorical_fwd", table.data_ptr(), xi.data_ptr(), scope.data_ptr(), out.data_ptr(), F, B, K, C, F,
+                  _stream(x.device))
+    return out
+
+
+def gaussian_log_likelihood(x: torch.Tensor, mean: torch.Tensor, stddev: torch.Tensor,
+                            log_partition: torch.Tensor | None = None) -> torch.Tensor:
+    """``TorchGaussianLayer.log_unnormalized_likelihood`` (input.py:661-670): x (F, B, 1), mean / stddev (F, K)."""
+    _on_device(x, "the layer input")
+    if x.dim() != 3 or x.shape[2] != 1:
+        raise ValueError(f"expected an input of shape (F, B, 1), found {tuple(x.shape)}")
+    F, K = mean.shape
+    xt = x.squeeze(dim=2).to(torch.float32).contiguous()  # (F, B): "variable" f of a (D = F, B) staging copy
+    B = xt.shape[1]
+    scope = torch.arange(F, dtype=torch.int64, device=x.device)
+    out = torch.empty((F, B, K), dtype=torch.float32, device=x.device)
+    lz = None if log_partition is None else log_partition.to(torch.float32).contiguous()
+    with torch.cuda.device(x.device):
+        capi.call("ck_gaussian_fwd", mean.to(torch.float32).contiguous().data_ptr(), stddev.to(torch.float32).contiguous().data_ptr(),
+                  None if lz is None else lz.data_ptr(), xt.data_ptr(), scope.data_ptr(), out.data_ptr(), F, B, K, F,
+                  _stream(x.device))
+    return out
+
+
+def embedding(x: torch.Tensor, weight: torch.Tensor, *, complex_out: bool) -> torch.Tensor:
+    """``TorchEmbeddingLayer.forward`` (input.py:258-266) mapped into lse-sum (log) / complex-lse-sum (complex log):
+    x (F, B, 1) states, weight (F, K, C) real -> (F, B, K)."""
+    F, K, C = weight.shape
+    xi = _discrete_input(x, C)
+    B = xi.shape[1]
+    # (F, C + 1, K) like every gather table (row C: the integral row of the marginal queries, not reachable from here)
+    table = torch.zeros((F, C + 1, K), dtype=torch.float32, device=x.device)
+    table[:, :C] = weight.to(torch.float32).transpose(1, 2)
+    scope = torch.arange(F, dtype=torch.int64, device=x.device)
+    out = torch.empty((F, B, K), dtype=torch.complex64 if complex_out else torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        capi.call("ck_embedding_clog_fwd" if complex_out else "ck_embedding_log_fwd", table.data_ptr(), xi.data_ptr(),
+                  scope.data_ptr(), out.data_ptr(), F, B, K, C, F, _stream(x.device))
+    return out
+
+
+def constant_value(value: torch.Tensor, batch_size: int, *, log_space: bool, complex_out: bool) -> torch.Tensor:
+    """``TorchConstantValueLayer.forward`` (input.py:739-743): value (F, K) broadcast over the batch."""
+    _on_device(value, "the value")
+    F, K = value.shape
+    v = value.contiguous()
+    v = v.to(torch.complex64) if v.is_complex() else v.to(torch.float32)
+    if v.is_complex() and not complex_out:
+        raise ValueError("complex constant value under the real lse-sum semiring")
+    out = torch.empty((F, batch_size, K), dtype=torch.complex64 if complex_out else torch.float32, device=value.device)
+    with torch.cuda.device(value.device):
+        capi.call("ck_constant_fwd", v.data_ptr(), out.data_ptr(), F, batch_size, K, 1 if log_space else 0,
+                  1 if v.is_complex() else 0, 1 if complex_out else 0, _stream(value.device))
+    return out

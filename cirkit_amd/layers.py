@@ -491,11 +491,11 @@ class HipHadamardLayer(HipInnerLayer):
 
 
 class HipKroneckerLayer(HipInnerLayer):
-    """``TorchKroneckerLayer`` (layers/inner.py:138-199), forward :178-187 (arity 2)."""
+    """``TorchKroneckerLayer`` (layers/inner.py:138-199), forward :178-187 (any arity >= 2)."""
 
     def __init__(self, num_input_units: int, arity: int = 2, *, semiring: str | None = None, num_folds: int = 1):
-        if arity != 2:
-            raise NotImplementedError("Kronecker layers of arity != 2")
+        if arity < 2:
+            raise ValueError("The arity should be at least 2")
         super().__init__(num_input_units, num_input_units**arity, arity=arity, semiring=semiring, num_folds=num_folds)
 
     @property
@@ -504,7 +504,7 @@ class HipKroneckerLayer(HipInnerLayer):
 
     def launch(self, arena, row_off, out, B, stream) -> None:
         capi.call(
-            "ck_kronecker_fwd", _ptr(arena), _ptr(row_off), _ptr(out), self.num_folds, B,
+            "ck_kronecker_fwd", _ptr(arena), _ptr(row_off), _ptr(out), self.num_folds, self.arity, B,
             self.num_input_units, self.esize, stream,
         )
 

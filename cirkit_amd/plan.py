@@ -393,7 +393,8 @@ def plan_from_torch_circuit(
         if layer is None:
             output = _fold_index_of(entry.in_module_ids[0], entry.in_fold_idx[0])
             break
-        cls = type(layer).__name__
+        # by class name along the MRO: a subclass of a reference layer (cirkit_amd/cirkit_plugin.py) is its base
+        cls = next((k.__name__ for k in type(layer).__mro__ if k.__name__ in LAYER_TYPES), type(layer).__name__)
         if cls not in LAYER_TYPES:
             raise NotImplementedError(
                 f"layer {cls} is outside the supported hot path (SURVEY.md section 8 a)"

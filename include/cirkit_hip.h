@@ -99,7 +99,8 @@ int ck_gaussian_prod_fwd(const float* mean, const float* stddev, const float* lo
                          void* stream);
 
 /* TorchEmbeddingLayer.forward under complex-lse-sum, layers/input.py:258-266 + semiring.py:507-509:
- * out[f,b,k] = clog(weight[f,k,x[b,scope[f]]] + 0j).  table: (F, C, K) fp32 (transposed weight). */
+ * out[f,b,k] = clog(weight[f,k,x[b,scope[f]]] + 0j).  table: (F, C+1, K) fp32 (transposed weight; row C = the
+ * integral row sum_c weight[f,k,c], selected by a negative state as in ck_categorical_fwd). */
 int ck_embedding_clog_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out_c,
                           int F, int B, int K, int C, int D, void* stream);
 /* same under lse-sum (semiring.py:495-497): out = log(weight[...]) */
@@ -179,8 +180,9 @@ int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t*
 int ck_hadamard_fwd(const float* arena, const int64_t* row_off, float* out, int F, int H, int B,
                     int K, int esize, void* stream);
 
-/* TorchKroneckerLayer.forward, inner.py:178-187, arity 2: out[f,b,i*K+j] = x0[f,b,i] + x1[f,b,j]. */
-int ck_kronecker_fwd(const float* arena, const int64_t* row_off, float* out, int F, int B, int K,
+/* TorchKroneckerLayer.forward, inner.py:178-187, any arity H >= 2: out[f, b, r] = sum_h x_h[f, b, digit_h(r)] with
+ * r = sum_h digit_h K^(H-1-h) (arity 2: out[f,b,i*K+j] = x0[f,b,i] + x1[f,b,j]); row_off (F, H). */
+int ck_kronecker_fwd(const float* arena, const int64_t* row_off, float* out, int F, int H, int B, int K,
                      int esize, void* stream);
 
 /* TorchTensorDotLayer.forward, optimized.py:287-300: x (F,B,Kj*Kq) viewed (Kj,Kq);

@@ -1,0 +1,126 @@
+"""cirkit_amd/layer_ops.py -- the forward bodies of the TorchLayer subclasses of cirkit_amd/cirkit_plugin.py (row b2) --
+on the GPU against the reference's formulas restated in torch (the same restatements oracle/torch_oracle.py uses:
+layers/inner.py:126-127,178-187,266-273; layers/optimized.py:89-103,171-178,287-300; layers/input.py:258-266,399-412,
+661-670,739-743; semiring.py:383-408)."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _lse_einsum(eq, x, w):
+    m = x.real.amax(dim=-1, keepdim=True) if x.is_complex() else x.amax(dim=-1, keepdim=True)
+    m = torch.clamp(m, torch.finfo(torch.float32).min, torch.finfo(torch.float32).max)
+    e = torch.exp(x - m)
+    y = torch.einsum(eq, e, w.to(e.dtype))
+    return torch.log(y) + m
+
+
+def _close(got, want, tol=2e-5):
+    got, want = got.cpu(), want.cpu()
+    assert got.shape == want.shape and got.dtype == want.dtype
+    scale = float(want.abs().max()) + 1.0
+    if want.is_complex():
+        assert float((got.real - want.real).abs().max()) <= tol * scale
+        d = (got.imag - want.imag).abs() % (2 * math.pi)
+        assert float(torch.minimum(d, 2 * math.pi - d).max()) <= 1e-3
+    else:
+        assert float((got - want).abs().max()) <= tol * scale
+
+
+@pytest.mark.parametrize("F,H,B,Ki,Ko,cplx", [(3, 1, 33, 32, 32, False), (2, 3, 5, 8, 6, False), (2, 2, 7, 16, 4, True)])
+def test_sum_cpt_tucker(hip_device, F, H, B, Ki, Ko, cplx):
+    from cirkit_amd import _capi as capi
+    from cirkit_amd import layer_ops as ops
+
+    g = torch.Generator().manual_seed(F * 100 + Ki)
+    x = torch.randn(F, H, B, Ki, generator=g) * 2
+    if cplx:
+        x = torch.complex(x, torch.randn(F, H, B, Ki, generator=g))
+    xd = x.to(hip_device)
+    w = torch.rand(F, Ko, H * Ki, generator=g) + 0.05
+    _close(ops.sum_lse(xd, w.to(hip_device), capi.CK_SUM_CAT),
+           _lse_einsum("fbi,foi->fbo", x.permute(0, 2, 1, 3).flatten(start_dim=2), w))
+    w = torch.rand(F, Ko, Ki, generator=g) + 0.05
+    _close(ops.sum_lse(xd, w.to(hip_device), capi.CK_SUM_PROD), _lse_einsum("fbi,foi->fbo", x.sum(dim=1), w))
+    if H == 2 and not cplx:
+        w = torch.rand(F, Ko, Ki * Ki, generator=g) + 0.05
+        m0 = x[:, 0].amax(dim=-1, keepdim=True)
+        m1 = x[:, 1].amax(dim=-1, keepdim=True)
+        y = torch.einsum("fbi,fbj,foij->fbo", torch.exp(x[:, 0] - m0), torch.exp(x[:, 1] - m1), w.view(F, Ko, Ki, Ki))
+        _close(ops.sum_lse(xd, w.to(hip_device), capi.CK_SUM_KRON), torch.log(y) + m0 + m1)
+    with pytest.raises(ValueError):
+        ops.sum_lse(xd, torch.rand(F, Ko, Ki + 1).to(hip_device), capi.CK_SUM_PROD)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_products_and_tensordot(hip_device, cplx):
+    from cirkit_amd import layer_ops as ops
+
+    g = torch.Generator().manual_seed(7)
+    F, H, B, K = 3, 3, 9, 4
+    x = torch.randn(F, H, B, K, generator=g)
+    if cplx:
+        x = torch.complex(x, torch.randn(F, H, B, K, generator=g))
+    xd = x.to(hip_device)
+    _close(ops.hadamard(xd), x.sum(dim=1))
+    y0 = x[:, 0]
+    for i in range(1, H):
+        y0 = torch.flatten(y0.unsqueeze(-1) + x[:, i].unsqueeze(-2), start_dim=-2)
+    _close(ops.kronecker(xd), y0)
+    Kj, Kq, Kk = 5, 3, 4
+    xt = torch.randn(F, 1, B, Kj * Kq, generator=g)
+    if cplx:
+        xt = torch.complex(xt, torch.randn(F, 1, B, Kj * Kq, generator=g))
+    w = torch.rand(F, Kk, Kj, generator=g) + 0.05
+    xv = xt.squeeze(1).view(F, B, Kj, Kq).permute(0, 1, 3, 2)
+    want = _lse_einsum("fbqj,fkj->fbqk", xv, w).reshape(F, B, Kq * Kk)
+    _close(ops.tensordot_lse(xt.to(hip_device), w.to(hip_device), Kj, Kq), want)
+
+
+def test_input_layers(hip_device):
+    from cirkit_amd import layer_ops as ops
+
+    g = torch.Generator().manual_seed(11)
+    F, B, K, C = 5, 37, 8, 11
+    logits = torch.randn(F, K, C, generator=g)
+    x = torch.randint(0, C, (F, B, 1), generator=g)
+    idx = torch.arange(F)
+    _close(ops.categorical_log_likelihood(x.to(hip_device), logits.to(hip_device)), logits[idx[:, None], :, x.squeeze(2)])
+    # a float batch is truncated like x.long() (input.py:400-401); a negative index wraps like torch indexing
+    xf = x.to(torch.float32) + 0.25
+    _close(ops.categorical_log_likelihood(xf.to(hip_device), logits.to(hip_device)), logits[idx[:, None], :, x.squeeze(2)])
+    xn = x.clone()
+    xn[0, 0, 0] = -1
+    _close(ops.categorical_log_likelihood(xn.to(hip_device), logits.to(hip_device)), logits[idx[:, None], :, xn.squeeze(2)])
+    bad = x.clone()
+    bad[1, 2, 0] = C
+    with pytest.raises(IndexError):  # the reference's advanced indexing raises
+        ops.categorical_log_likelihood(bad.to(hip_device), logits.to(hip_device))
+    mean, std = torch.randn(F, K, generator=g), torch.rand(F, K, generator=g) + 0.3
+    lz = torch.randn(F, K, generator=g)
+    xr = torch.randn(F, B, 1, generator=g)
+    want = torch.distributions.Normal(mean.unsqueeze(1), std.unsqueeze(1)).log_prob(xr) + lz.unsqueeze(1)
+    _close(ops.gaussian_log_likelihood(xr.to(hip_device), mean.to(hip_device), std.to(hip_device), lz.to(hip_device)), want)
+    wemb = torch.randn(F, K, C, generator=g)
+    sel = wemb[idx[:, None], :, x.squeeze(2)]
+    _close(ops.embedding(x.to(hip_device), wemb.to(hip_device), complex_out=True), torch.log(sel.to(torch.complex64)))
+    _close(ops.embedding(x.to(hip_device), wemb.abs().to(hip_device), complex_out=False), torch.log(wemb.abs()[idx[:, None], :, x.squeeze(2)]))
+    v = torch.rand(F, K, generator=g) + 0.1
+    _close(ops.constant_value(v.to(hip_device), 6, log_space=False, complex_out=False), torch.log(v).unsqueeze(1).expand(F, 6, K).contiguous())
+    _close(ops.constant_value(v.to(hip_device), 6, log_space=True, complex_out=True), v.unsqueeze(1).expand(F, 6, K).to(torch.complex64).contiguous())
+
+
+def test_no_cpu_fallback():
+    from cirkit_amd import layer_ops as ops
+    from cirkit_amd._capi import HipExtensionError
+
+    with pytest.raises(HipExtensionError):
+        ops.hadamard(torch.zeros(1, 2, 3, 4))

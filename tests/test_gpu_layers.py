@@ -183,21 +183,23 @@ def test_hadamard_layer_contract(hip_device, F, H, B, K, cplx):
     assert float((got - want).abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize("F,B,K,cplx", [(3, 33, 8, False), (2, 5, 5, False), (2, 4, 6, True)])
-def test_kronecker_layer_contract(hip_device, F, B, K, cplx):
+@pytest.mark.parametrize("F,B,K,H,cplx", [(3, 33, 8, 2, False), (2, 5, 5, 2, False), (2, 4, 6, 2, True),
+                                          (2, 7, 4, 3, False), (1, 3, 3, 4, False), (2, 5, 4, 3, True)])
+def test_kronecker_layer_contract(hip_device, F, B, K, H, cplx):
+    """TorchKroneckerLayer.forward iterates over any arity (inner.py:178-187): child 0 is the most significant digit."""
     from cirkit_amd.layers import HipKroneckerLayer
 
-    g = torch.Generator().manual_seed(F + K)
-    x = torch.randn(F, 2, B, K, generator=g)
+    g = torch.Generator().manual_seed(F + K + H)
+    x = torch.randn(F, H, B, K, generator=g)
     sem = "lse-sum"
     if cplx:
-        x = torch.complex(x, torch.randn(F, 2, B, K, generator=g))
+        x = torch.complex(x, torch.randn(F, H, B, K, generator=g))
         sem = "complex-lse-sum"
-    layer = HipKroneckerLayer(K, 2, semiring=sem, num_folds=F)
-    spec = LayerSpec("kronecker", F, 2, K, K * K, dict(layer.config), {})
+    layer = HipKroneckerLayer(K, H, semiring=sem, num_folds=F)
+    spec = LayerSpec("kronecker", F, H, K, K**H, dict(layer.config), {})
     got = layer.forward(x.to(hip_device)).cpu()
     want = _oracle(spec, {}, x, sem)
-    assert got.shape == (F, B, K * K) and float((got - want).abs().max()) <= 1e-5
+    assert got.shape == (F, B, K**H) and float((got - want).abs().max()) <= 1e-5
 
 
 @pytest.mark.parametrize("F,B,Kj,Kq,Kk", [(3, 4, 8, 8, 8), (2, 3, 5, 7, 3), (1, 2, 32, 32, 32)])
