@@ -15,7 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests.conftest import load_case  # noqa: E402
+from conftest import load_case  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
