@@ -99,6 +99,9 @@ class HipCircuit:
             (cirkit_amd/csrc/ck_leaf.hip) instead of one workgroup per 128 rows.  None: whenever the launch is eligible
             (linear table, tiled fp32 weights) and has at least one 32-row tile per CU; bit-identical either way.
         leaf_waves: wavefronts per workgroup of the persistent leaf launch (8 or 12).
+        validate_inputs: discrete inputs are range-checked on the device while they are staged (no extra launch, no host
+            synchronisation): a category >= the layer's number of categories -- an ``IndexError`` in the reference -- makes
+            the outputs NaN and `check_inputs()` raise.  Negative values are this library's "marginalised" sentinel.
         tail16: the fused tail on 16-row tiles with its fold outputs kept in LDS and `log_likelihood_sum`'s reduction
             folded in (cirkit_amd/csrc/ck_tail16.hip); False keeps the 32-row walk of ck_tail.hip.
     """
@@ -123,6 +126,7 @@ class HipCircuit:
         persistent_leaf: bool | None = None,
         leaf_waves: int = 8,
         tail16: bool = True,
+        validate_inputs: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -166,6 +170,9 @@ class HipCircuit:
             raise ValueError("leaf_waves must be 8 or 12")
         self.leaf_waves = int(leaf_waves)
         self.tail16 = bool(tail16)
+        self.validate_inputs = bool(validate_inputs)
+        self._num_states: torch.Tensor | None = None
+        self._bad_input = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self._pprog = None
         self._pprog_version = self._pprog_data_version = -1
@@ -252,6 +259,15 @@ class HipCircuit:
             self._tdense = {d: c for d, c in cand.items()
                             if self.layers[c].probs is not None and self.layers[c].probs.softmax_source() is not None
                             and self.layers[d].weight.softmax_source() is not None and fits(d, c)}
+            # the block kernels (ck_cp.hip) take ONE category count for all the gather slots of a launch: dense layers
+            # tabulated over Categorical layers with another number of categories than the most common one are simply
+            # not tabulated (they are evaluated as ordinary dense folds)
+            counts: dict[int, int] = {}
+            for d, c in self._tdense.items():
+                counts[self.layers[c].num_categories] = counts.get(self.layers[c].num_categories, 0) + self.layers[d].num_folds
+            if len(counts) > 1:
+                keep = max(counts, key=lambda k: (counts[k], k))
+                self._tdense = {d: c for d, c in self._tdense.items() if self.layers[c].num_categories == keep}
             readers: dict[int, set[int]] = {}
             for j, ch in enumerate(self._children):
                 if ch is not None:
@@ -419,6 +435,10 @@ class HipCircuit:
             if not self.cache_params:
                 self._enqueue_params(0)
             self._enqueue_layers(bd, 0, with_ll=with_ll)
+            if self.validate_inputs and self._int_input and not self._poison_in_tail() and not self._complex:
+                for p, f in self._out_pairs:
+                    v = bd.views[int(p)][int(f)]
+                    capi.call("ck_poison_outputs", v.data_ptr(), v.numel(), self._bad_input.data_ptr(), 0)
             if with_ll and not self._tail_fuses_ll():
                 p, f = int(self._out_pairs[0, 0]), int(self._out_pairs[0, 1])
                 capi.call("ck_ll_sum", bd.views[p][f].data_ptr(), bd.B, 1, bd.ll.data_ptr(), 0)
@@ -534,8 +554,10 @@ class HipCircuit:
                 addr[sel] = table.data_ptr() + folds * (table.shape[1] * table.shape[2] * 4)
                 var[sel] = variables[folds]
             tabs = bd.cp_tabs[(key, "gather")] = (torch.from_numpy(addr).to(self.device), torch.from_numpy(var).to(self.device))
-        Cn = self.layers[next(self._tdense[int(d)] for d in np.unique(slot_dense[..., 0]) if int(d) in self._tdense)].num_categories
-        return tabs[0], tabs[1], Cn
+        cats = {self.layers[self._tdense[int(d)]].num_categories for d in np.unique(slot_dense[..., 0]) if int(d) in self._tdense}
+        if len(cats) != 1:  # (cannot happen: __init__ tabulates one category count only)
+            raise ValueError(f"gather slots over tables with different numbers of categories {sorted(cats)}")
+        return tabs[0], tabs[1], cats.pop()
 
     def _weight_addresses(self, slot_dense: np.ndarray, K: int) -> np.ndarray:
         """Device addresses of the (K, K) weight matrices of the dense folds in `slot_dense` (0 = none)."""
@@ -680,6 +702,13 @@ class HipCircuit:
         return (self.tail16 and lay in (capi.CK_W_ROWMAJOR, capi.CK_W_TILED_F32) and len(ls) <= 15
                 and sum(l.num_folds for l in ls) <= 64 and all(l.arity <= 4 and l.num_input_units == 32 for l in ls))
 
+    def _poison_in_tail(self) -> bool:
+        """Whether the tail launch turns the input-validation flag into NaN outputs itself (it writes every circuit
+        output: all outputs are few-unit folds of tail layers); otherwise one `ck_poison_outputs` per output follows."""
+        if not (self.validate_inputs and self._int_input and self._tail and self._tail16_ok()):
+            return False
+        return all(int(p) in self._tail and self.layers[int(p)].num_output_units < 32 for p in self._out_pairs[:, 0])
+
     def _tail_fuses_ll(self) -> bool:
         """Whether `log_likelihood_sum`'s reduction is part of the tail launch (the circuit output is the scalar root)."""
         if not self._tail or not self._tail16_ok() or len(self._out_pairs) != 1:
@@ -732,7 +761,7 @@ class HipCircuit:
             capi.call(
                 "ck_tail16_lse_fwd", desc_dev.data_ptr(), n_folds, levels_dev.data_ptr(), n, bd.B, 32, lay,
                 bd.ll.data_ptr() if fuse_ll else None, scratch.data_ptr() if fuse_ll else None,
-                ticket.data_ptr() if fuse_ll else None, stream,
+                ticket.data_ptr() if fuse_ll else None, self._bad_input.data_ptr() if self._poison_in_tail() else None, stream,
             )
             return
         capi.call(
@@ -836,7 +865,41 @@ class HipCircuit:
         if xf is not None:
             capi.call("ck_transpose_f32", xf.data_ptr(), bd.xt.data_ptr(), bd.B, self.plan.num_variables, stream)
         if xi is not None:
-            capi.call("ck_transpose_i64_to_i32", xi.data_ptr(), bd.xt_i.data_ptr(), bd.B, self.plan.num_variables, stream)
+            if self.validate_inputs:
+                capi.call("ck_stage_categories", xi.data_ptr(), bd.xt_i.data_ptr(), bd.B, self.plan.num_variables,
+                          self._num_states_dev().data_ptr(), self._bad_input.data_ptr(), stream)
+            else:
+                capi.call("ck_transpose_i64_to_i32", xi.data_ptr(), bd.xt_i.data_ptr(), bd.B, self.plan.num_variables, stream)
+
+    def _num_states_dev(self) -> torch.Tensor:
+        """(D,) int32: number of states the discrete input layers index variable d with (the smallest, if several layers
+        read it; 0 = no discrete layer reads it)."""
+        if self._num_states is None:
+            ns = np.zeros(max(1, self.plan.num_variables), dtype=np.int64)
+            for l in self.layers:
+                if not isinstance(l, HipInputLayer) or isinstance(l, HipConstantValueLayer) or l.wants_float_input:
+                    continue
+                n = getattr(l, "num_categories", None) or getattr(l, "num_states", None)
+                if n is None and hasattr(l, "total_count"):
+                    n = int(l.total_count) + 1
+                if n is None:
+                    continue
+                for v in np.unique(l.scope_idx):
+                    ns[v] = n if ns[v] == 0 else min(ns[v], n)
+            self._num_states = torch.from_numpy(ns.astype(np.int32)).to(self.device)
+        return self._num_states
+
+    def check_inputs(self) -> None:
+        """Raise ``IndexError`` if a batch evaluated since the last check held a category outside its layer's range
+        (what ``TorchCategoricalLayer`` / ``TorchEmbeddingLayer`` raise from their advanced indexing, input.py:258-266,
+        399-412).  The forward itself never waits for the device: an invalid batch makes the circuit's outputs NaN (the
+        flag is sticky, like a device-side assert) and this call -- which synchronises -- says why and clears it."""
+        if not self.validate_inputs:
+            return
+        if int(self._bad_input.item()) != 0:
+            self._bad_input.zero_()
+            raise IndexError("a batch held a category index out of range for its input layer "
+                             "(outputs are NaN from that batch on until this check)")
 
     def _apply_integration_mask(self, x: torch.Tensor, integrate_vars) -> torch.Tensor:
         """Marginalisation (IntegrateQuery, cirkit/backend/torch/queries.py:19-184): a boolean mask
@@ -1035,6 +1098,10 @@ class HipCircuit:
         reference layers the launch stands for) and `executed_flops` (the contraction flops the launch itself issues: a
         dense layer pushed through its category table is executed by the prologue on C + 1 rows, not by the leaf launch
         on B rows)."""
+        with torch.cuda.device(self.device):
+            return self._profile_kernels(x, iters)
+
+    def _profile_kernels(self, x: torch.Tensor | None, iters: int) -> list[dict]:
         bd = self._run(x)  # make sure the binding (arena, staging copy) exists and is warm
         B = bd.B
         cur = torch.cuda.current_stream(self.device)

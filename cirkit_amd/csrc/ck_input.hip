@@ -31,6 +31,40 @@ __global__ void transpose_kernel(const TI* __restrict__ x, TO* __restrict__ xt, 
   }
 }
 
+// (B, D) int64 -> (D, B) int32 like transpose_kernel, and input validation on the way: a category >= num_states[d]
+// (num_states[d] > 0) raises the sticky flag -- the reference's advanced indexing raises IndexError there
+// (layers/input.py:399-412); the consumers clamp for memory safety, the circuit's last launch turns the flag into NaN outputs.
+__global__ void stage_categories_kernel(const int64_t* __restrict__ x, int32_t* __restrict__ xt, int B, int D,
+                                        const int32_t* __restrict__ num_states, int32_t* __restrict__ flag) {
+  __shared__ int32_t tile[kTile][kTile + 1];
+  const int d0 = blockIdx.x * kTile, b0 = blockIdx.y * kTile;
+  const int tx = threadIdx.x, ty = threadIdx.y;  // (32, 8)
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < kTile; j += 8) {
+    const int b = b0 + ty + j, d = d0 + tx;
+    if (b < B && d < D) {
+      const int64_t v = x[static_cast<int64_t>(b) * D + d];
+      const int ns = num_states[d];
+      bad |= ns > 0 && v >= ns;
+      tile[ty + j][tx] = static_cast<int32_t>(v);
+    }
+  }
+  if (__any(bad) && ((threadIdx.y * 32 + threadIdx.x) & 63) == 0) atomicOr(flag, 1);
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kTile; j += 8) {
+    const int d = d0 + ty + j, b = b0 + tx;
+    if (b < B && d < D) xt[static_cast<int64_t>(d) * B + b] = tile[tx][ty + j];
+  }
+}
+
+__global__ void poison_kernel(float* __restrict__ out, int64_t n, const int32_t* __restrict__ flag) {
+  if (*flag == 0) return;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    out[i] = __builtin_nanf("");
+}
+
 template <typename TI, typename TO>
 int transpose_impl(const TI* x, TO* xt, int B, int D, void* stream, const char* who) {
   CK_REQUIRE(x != nullptr && xt != nullptr, "%s: null pointer", who);
@@ -266,6 +300,29 @@ extern "C" {
 
 int ck_transpose_i64_to_i32(const int64_t* x, int32_t* xt, int B, int D, void* stream) {
   return transpose_impl<int64_t, int32_t>(x, xt, B, D, stream, "ck_transpose_i64_to_i32");
+}
+
+int ck_stage_categories(const int64_t* x, int32_t* xt, int B, int D, const int32_t* num_states, int32_t* flag, void* stream) {
+  CK_REQUIRE(x && xt && num_states && flag, "ck_stage_categories: null pointer");
+  CK_REQUIRE(B > 0 && D > 0, "ck_stage_categories: B=%d D=%d must be positive", B, D);
+  dim3 grid((D + kTile - 1) / kTile, (B + kTile - 1) / kTile), block(kTile, 8);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(stage_categories_kernel, grid, block, 0, s, x, xt, B, D, num_states, flag);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_poison_outputs(float* out, int64_t n, const int32_t* flag, void* stream) {
+  CK_REQUIRE(out && flag && n > 0, "ck_poison_outputs: null pointer or empty output");
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 256))), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(poison_kernel, grid, block, 0, s, out, n, flag);
+        return hipGetLastError();
+      },
+      stream);
 }
 
 int ck_transpose_f32(const float* x, float* xt, int B, int D, void* stream) {

@@ -43,6 +43,7 @@ struct Tail16Args {
   double* ll;          // nullptr, or [sum_b log p, B]: the last fold must then be the scalar root
   double* ll_partial;  // (gridDim.x) partial sums
   unsigned int* ll_ticket;
+  const int32_t* bad_input;  // nullptr, or the sticky input-validation flag (ck_stage_categories): nonzero -> NaN outputs
   int n_folds, n_levels, B;
 };
 
@@ -67,6 +68,7 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
     for (int i = threadIdx.x; i <= a.n_levels; i += blockDim.x) s_level[i] = a.level_begin[i];
   }
   __syncthreads();
+  const bool poison = a.bad_input != nullptr && *a.bad_input != 0;
   WRegs16 w;
   int w_for = -1;  // fold whose 32-output weights are in `w`
   auto prefetch = [&](int t) {
@@ -146,7 +148,8 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
             acc = fmaf(w4.w, v[4 * beta + 3], acc);
           }
           acc = xquad_sum(acc);
-          const float y = fmaf(__builtin_amdgcn_logf(acc), kLN2, m);
+          float y = fmaf(__builtin_amdgcn_logf(acc), kLN2, m);
+          if (poison) y = __builtin_nanf("");  // an out-of-range category somewhere in the batch (the reference raises)
           if (live && kq == 0) out[static_cast<int64_t>(b) * Ko + o] = y;
           if (a.ll != nullptr && t == a.n_folds - 1) {
             // sum of this workgroup's (up to) 16 root values, rows in order, in double precision
@@ -193,7 +196,8 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
 extern "C" {
 
 int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* level_begin, int n_levels, int B, int K,
-                      int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, void* stream) {
+                      int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, const int32_t* bad_input,
+                      void* stream) {
   CK_REQUIRE(folds && level_begin, "ck_tail16_lse_fwd: null pointer");
   CK_REQUIRE(n_folds > 0 && n_folds <= kTail16MaxFolds, "ck_tail16_lse_fwd: n_folds=%d outside [1, %d]", n_folds, kTail16MaxFolds);
   CK_REQUIRE(n_levels > 0 && n_levels <= kTail16MaxLevels, "ck_tail16_lse_fwd: n_levels=%d outside [1, %d]", n_levels, kTail16MaxLevels);
@@ -212,6 +216,7 @@ int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* l
   a.ll = ll;
   a.ll_partial = ll_partial;
   a.ll_ticket = ll_ticket;
+  a.bad_input = bad_input;
   const size_t lds = static_cast<size_t>(n_folds) * (512 * sizeof(float) + sizeof(FoldDesc)) + (n_levels + 1) * sizeof(int32_t) + 16;
   dim3 grid((B + 15) / 16), block(kTail16Waves * 64);
   return ck::dispatch(

@@ -155,19 +155,20 @@ class HipInputLayer(HipLayer):
             raise ValueError(f"expected input of shape (F={self.num_folds}, B, 1), found {tuple(x.shape)}")
         F, B, _ = x.shape
         dev = x.device
-        stream = _stream(dev)
-        # the (F, B) slice already is the (D=F, B) staging layout with scope = identity
-        if self.wants_float_input:
-            xt = x.reshape(F, B).to(torch.float32).contiguous()
-        else:
-            xt = x.reshape(F, B).to(torch.int32).contiguous()
-        saved, self._scope_dev = self._scope_dev, torch.arange(F, dtype=torch.int64, device=dev)
-        try:
-            self.prepare(stream)
-            out = torch.empty((F, B, self.num_output_units), dtype=self.act_dtype, device=dev)
-            self.launch_input(xt, F, out, B, stream)
-        finally:
-            self._scope_dev = saved
+        with torch.cuda.device(dev):  # the launches below go to a stream of the input's device
+            stream = _stream(dev)
+            # the (F, B) slice already is the (D=F, B) staging layout with scope = identity
+            if self.wants_float_input:
+                xt = x.reshape(F, B).to(torch.float32).contiguous()
+            else:
+                xt = x.reshape(F, B).to(torch.int32).contiguous()
+            saved, self._scope_dev = self._scope_dev, torch.arange(F, dtype=torch.int64, device=dev)
+            try:
+                self.prepare(stream)
+                out = torch.empty((F, B, self.num_output_units), dtype=self.act_dtype, device=dev)
+                self.launch_input(xt, F, out, B, stream)
+            finally:
+                self._scope_dev = saved
         return out
 
     wants_float_input = False
@@ -436,10 +437,11 @@ class HipConstantValueLayer(HipLayer):
 
     def forward(self, batch_size: int) -> torch.Tensor:
         dev = self.value.store.device
-        stream = _stream(dev)
-        self.prepare(stream)
-        out = torch.empty((self.num_folds, batch_size, self.num_output_units), dtype=self.act_dtype, device=dev)
-        self.launch_const(out, batch_size, stream)
+        with torch.cuda.device(dev):
+            stream = _stream(dev)
+            self.prepare(stream)
+            out = torch.empty((self.num_folds, batch_size, self.num_output_units), dtype=self.act_dtype, device=dev)
+            self.launch_const(out, batch_size, stream)
         return out
 
 
@@ -463,11 +465,12 @@ class HipInnerLayer(HipLayer):
         x = x.contiguous()
         F, H, B, Ki = x.shape
         dev = x.device
-        stream = _stream(dev)
-        row_off = (torch.arange(F * H, dtype=torch.int64, device=dev) * (B * Ki)).reshape(F, H)
-        self.prepare(stream)
-        out = torch.empty((F, B, self.num_output_units), dtype=self.act_dtype, device=dev)
-        self.launch(x, row_off, out, B, stream)
+        with torch.cuda.device(dev):  # the launches below go to a stream of the input's device
+            stream = _stream(dev)
+            row_off = (torch.arange(F * H, dtype=torch.int64, device=dev) * (B * Ki)).reshape(F, H)
+            self.prepare(stream)
+            out = torch.empty((F, B, self.num_output_units), dtype=self.act_dtype, device=dev)
+            self.launch(x, row_off, out, B, stream)
         return out
 
 

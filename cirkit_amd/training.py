@@ -214,13 +214,28 @@ class HipTrainer:
         tmp = torch.empty(max(tmp_elems, 1), dtype=torch.float32, device=self.device)
         st = {"arena_ptr": bd.arena.data_ptr(), "garena": garena, "gviews": gviews, "flags": flags,
               "need_zero": need_zero, "dws": dws, "dw_flat": flat, "shared": shared, "tmp": tmp}
+        while len(self._bwd) >= 4:  # like the forward bindings: a handful of batch sizes stay resident
+            self._bwd.pop(next(iter(self._bwd)))
         self._bwd[B] = st
         return st
 
     # ------------------------------------------------------------------------------------------
     def loss_and_grads(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
         """Forward + backward for ``loss = -(1/global_batch) sum_b log p(x_b)``; gradients land in
-        ``self.grads`` (views of one flat buffer).  Returns the device tensor [sum log p, count]."""
+        ``self.grads`` (views of one flat buffer).  Returns the device tensor [sum log p, count] of this shard -- a view
+        of the circuit's own buffer, overwritten by the next step (clone it to keep it).
+
+        ``global_batch`` defaults to the number of rows of ALL ranks when torch.distributed is initialised (every rank is
+        assumed to hold as many rows as this one; pass it explicitly otherwise), so that the SUM all-reduce of
+        `all_reduce_grads` yields the gradient of the mean NLL of the global batch."""
+        with torch.cuda.device(self.device):  # every launch below goes to a stream of self.device
+            return self._loss_and_grads(x, global_batch)
+
+    def _loss_and_grads(self, x: torch.Tensor, global_batch: int | None) -> torch.Tensor:
+        import torch.distributed as dist
+
+        if global_batch is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            global_batch = int(x.shape[0]) * dist.get_world_size()
         c = self.circuit
         ll = c.log_likelihood_sum(x)  # forward (all activations stay in the arena)
         B = int(x.shape[0])
@@ -325,6 +340,10 @@ class HipTrainer:
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
 
     def apply_gradients(self) -> None:
+        with torch.cuda.device(self.device):
+            self._apply_gradients()
+
+    def _apply_gradients(self) -> None:
         self.step_count += 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         p, g = self._flat_param, self._flat_grad

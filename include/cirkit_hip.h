@@ -69,6 +69,15 @@ int ck_device_info(int device, int64_t out[4]);
  * they read x contiguously along B.  Replaces the `in_graph[..., scope_idx].permute(1,0,2)` copy of
  * circuits.py:66. */
 int ck_transpose_i64_to_i32(const int64_t* x, int32_t* xt, int B, int D, void* stream);
+/* The same staging copy WITH input validation: a value x[b, d] >= num_states[d] (num_states[d] > 0; 0 = variable not
+ * checked) sets *flag (a sticky DEVICE int32 owned by the caller) -- TorchCategoricalLayer / TorchEmbeddingLayer raise
+ * IndexError on such an index (layers/input.py:258-266, 399-412).  The kernels clamp the category for memory safety; the
+ * caller turns the flag into NaN outputs (ck_tail16_lse_fwd's bad_input, or ck_poison_outputs) and into an IndexError on
+ * the host when it next looks (HipCircuit.check_inputs).  Negative values stay what they are for this library: the
+ * "marginalised variable" sentinel of the integral row. */
+int ck_stage_categories(const int64_t* x, int32_t* xt, int B, int D, const int32_t* num_states, int32_t* flag, void* stream);
+/* out[0..n) = NaN if *flag != 0 (one small launch; circuits whose last launch is ck_tail16_lse_fwd do not need it). */
+int ck_poison_outputs(float* out, int64_t n, const int32_t* flag, void* stream);
 /* (B, D) fp32 -> (D, B) fp32, same purpose for continuous inputs. */
 int ck_transpose_f32(const float* x, float* xt, int B, int D, void* stream);
 
@@ -252,7 +261,8 @@ int ck_tail_lse_fwd(const float* arena, int n_layers, const int64_t* const* row_
  * row-major weights; never a child inside the tail).  w_layout (Ko = 32 folds): CK_W_ROWMAJOR or CK_W_TILED_F32.
  * ll != NULL folds ck_ll_sum in (the last fold must be the scalar root): ll[0] = sum_b out[b] in fp64 -- per-workgroup
  * sums in row order, then workgroup order: deterministic -- ll[1] = B; ll_partial: ceil(B / 16) doubles of scratch,
- * ll_ticket: one zero-initialised uint32 (left zero). */
+ * ll_ticket: one zero-initialised uint32 (left zero).  bad_input: NULL, or the flag of ck_stage_categories -- when it is
+ * nonzero the few-output folds (the circuit's root) write NaN: an invalid batch never yields a plausible likelihood. */
 typedef struct ck_tail16_fold {
   const float* w;          /* (Ko, 32) linear weights of this fold                                             */
   float* out;              /* (B, Ko) output block of this fold                                                */
@@ -262,7 +272,8 @@ typedef struct ck_tail16_fold {
   int32_t pad[2];
 } ck_tail16_fold;
 int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* level_begin, int n_levels, int B, int K,
-                      int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, void* stream);
+                      int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, const int32_t* bad_input,
+                      void* stream);
 
 /* ---------------------------------------------------------------- parameter graphs --------- */
 /* The reference re-evaluates each layer's parameter DAG on every forward

@@ -404,6 +404,39 @@ def test_tail_on_16_row_tiles(hip_device, B):
     assert abs(sa[0].item() - s1[0].item()) <= 1e-6 * abs(s1[0].item())
 
 
+@pytest.mark.parametrize("case", ["cfg1_rbt8", "cfg2_qt784"])
+def test_out_of_range_category_is_an_error_not_a_number(hip_device, case):
+    """``TorchCategoricalLayer`` raises IndexError on a category >= num_categories (advanced indexing, input.py:399-412).
+    Here the staging kernel flags it on the device: the outputs of that batch -- and of every batch until the flag is
+    looked at -- are NaN, `check_inputs()` raises IndexError and clears the flag; valid batches are untouched, and the
+    marginalisation sentinel (negative) is not an error."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case(case)
+    x = _x_of(plan, g).to(hip_device)
+    hc = HipCircuit(plan, tensors, device=hip_device)
+    good = hc(x).clone()
+    hc.check_inputs()
+    assert bool(torch.isfinite(good).all())
+    C = max(l.num_categories for l in hc.layers if hasattr(l, "num_categories"))
+    bad = x.clone()
+    bad[3, 5] = C
+    y = hc(bad).clone()
+    assert bool(torch.isnan(y).all())
+    assert bool(torch.isnan(hc.log_likelihood_sum(bad)[0]))
+    assert bool(torch.isnan(hc(x)).all())  # sticky until checked
+    with pytest.raises(IndexError):
+        hc.check_inputs()
+    hc.check_inputs()  # cleared
+    assert torch.equal(hc(x), good)
+    m = x.clone()
+    m[:, 2] = -1  # marginalised: not an error
+    assert bool(torch.isfinite(hc(m)).all())
+    hc.check_inputs()
+    loose = HipCircuit(plan, tensors, device=hip_device, validate_inputs=False)
+    assert bool(torch.isfinite(loose(bad)).all())  # (clamped to the last category, as before)
+
+
 def test_ll_sum(hip_device):
     from cirkit_amd.circuit import HipCircuit
 
