@@ -806,7 +806,7 @@ class HipCircuit:
         cat = self.layers[g.input_layer]
         if (self.persistent_leaf is False or g.root not in self._table_fused or not self.linear_levels or g.depth < 1
                 or cat.num_output_units != 32 or cat.num_categories >= 65535
-                or self._group_layout(g) != capi.CK_W_TILED_F32):
+                or self._group_layout(g) != capi.CK_W_TILED_F32 or self.plan.num_variables * B >= 2**31):
             return False
         return self.persistent_leaf is True or self.layers[g.root].num_folds * ((B + 31) // 32) >= self._n_cu
 

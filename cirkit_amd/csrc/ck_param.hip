@@ -525,6 +525,99 @@ __device__ __forceinline__ void softmax_job_table_dense(const ck_softmax_job& j,
   }
 }
 
+// maximum / sum over the 64 lanes of a wave without LDS: DPP inside the 16-lane rows, v_permlane16_swap and
+// v_permlane32_swap across them (a __shfl_xor is a ds_bpermute: an LDS round trip per step)
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce_dpp(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x140, 0xF, 0xF, true)));  // row_mirror
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return op(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+
+// kind 5 for C <= 256, C % 4 == 0 (the usual Categorical sizes): a wave holds a whole (unit, all categories) row of
+// logits in registers -- one float4 per lane -- so the per-unit maximum and log-sum-exp are wave reductions in registers
+// (the job above makes two passes over the logits in LDS for them: 8 of its 22 us at config 2), and the tile in LDS
+// already holds the normalised log-probabilities the dense layer is applied to.
+//   T[c, k] = (theta[k, c] - max_c theta[k, .]) - log sum_c exp(theta[k, c] - max)      (-inf below -103.9, as above)
+//   out[d, c, :] = W_d . exp(T[c, :] - m_c),  out2[d, c] = m_c = max_k T[c, k];  row C: T = 0 (the integral row)
+// Same arithmetic as the job above up to the order of the two reductions over the categories.
+__device__ __forceinline__ void softmax_job_table_dense_rows(const ck_softmax_job& j, int d, float* tile) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = j.len, n4 = C >> 2;
+  constexpr int K = 32;
+  const int ld = C + 4;  // row stride of tile[k][c]: 16-byte aligned rows (C % 4 == 0), conflict-free both ways
+  const int64_t f = j.idx != nullptr ? j.idx[d] : d;
+  const float4* src = reinterpret_cast<const float4*>(j.in + f * K * C);
+  float* w_s = tile + K * ld;  // [32][32] row-major linear weights of dense fold d
+  float4 x[8];
+  const bool on = lane < n4;
+#pragma unroll
+  for (int r = 0; r < 8; ++r)  // unit k = wave + 4 r: one row of C logits per wave and r, all loads in flight
+    x[r] = on ? src[(wave + kPW * r) * n4 + lane] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  {  // W_d: 32 rows of 32, two rows per wave pass (same reduction tree as softmax_job_rows)
+    const int half = lane >> 5, l = lane & 31;
+    const float* th = j.in2 + static_cast<int64_t>(d) * 1024;
+    float t[16 / kPW];
+#pragma unroll
+    for (int it = 0; it < 16 / kPW; ++it) t[it] = th[(it * (2 * kPW) + wave * 2 + half) * 32 + l];
+#pragma unroll
+    for (int it = 0; it < 16 / kPW; ++it) {
+      const int row = it * (2 * kPW) + wave * 2 + half;
+      float mx = t[it];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float e = __expf(t[it] - mx);
+      float sum = e;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      w_s[row * 32 + l] = e / sum;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int k = wave + kPW * r;
+    const float mx = wave_reduce_dpp<true>(fmaxf(fmaxf(x[r].x, x[r].y), fmaxf(x[r].z, x[r].w)));
+    const float4 dl = make_float4(x[r].x - mx, x[r].y - mx, x[r].z - mx, x[r].w - mx);
+    const float part = on ? (__expf(dl.x) + __expf(dl.y)) + (__expf(dl.z) + __expf(dl.w)) : 0.f;
+    const float ls = __logf(wave_reduce_dpp<false>(part));
+    if (on) {
+      float4 o;
+      o.x = dl.x < -103.9f ? -INFINITY : dl.x - ls;
+      o.y = dl.y < -103.9f ? -INFINITY : dl.y - ls;
+      o.z = dl.z < -103.9f ? -INFINITY : dl.z - ls;
+      o.w = dl.w < -103.9f ? -INFINITY : dl.w - ls;
+      *reinterpret_cast<float4*>(tile + k * ld + 4 * lane) = o;
+    }
+  }
+  __syncthreads();
+  WRegs wr;
+  load_w<CK_W_ROWMAJOR>(w_s, lane, wr);
+  const int b_in = lane & 31, kh = lane >> 5;
+  float* dst = j.out + static_cast<int64_t>(d) * (C + 1) * K;
+  for (int t = wave; t * 32 <= C; t += kPW) {  // 32 categories per register tile, rows 0..C
+    const int c = t * 32 + b_in;
+    const int cl = min(c, C - 1);
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) v[4 * g + tt] = c >= C ? 0.f : tile[(8 * g + 4 * kh + tt) * ld + cl];  // row C: log sum_c p = 0
+    const float m = row_max16(v);
+    const float nml = exp_offset(m, 0.f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_exp2f(fmaf(v[r], kL2E, nml));
+    contract_linear<CK_W_ROWMAJOR>(wr, v);
+    if (c <= C && kh == 0) j.out2[static_cast<int64_t>(d) * (C + 1) + c] = m;
+    if (c <= C) tile_store(dst + static_cast<int64_t>(c) * K + 4 * kh, v);
+  }
+}
+
 // kind 4 with 64 units: the same job on the two-block register tile (weights in LDS in MFMA operand layout,
 // as in ck_cp.hip); W rows of 64 follow the arithmetic of the long-row branch of softmax_job_rows.
 __device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& j, int d, float* tile) {
@@ -698,6 +791,8 @@ __global__ void __launch_bounds__((WIDE ? kPW64 : kPW) * 64) softmax_batch_kerne
   }
   if (j.kind == 1)
     softmax_job_table(j, blk, tile);
+  else if (j.kind == 5 && j.k == 32 && j.len <= 256 && (j.len & 3) == 0)
+    softmax_job_table_dense_rows(j, blk, tile);
   else if (j.kind == 4 || j.kind == 5)
     softmax_job_table_dense(j, blk, tile);
   else
@@ -989,7 +1084,7 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
           blocks += static_cast<int>((j.rows + 16 * kPW - 1) / (16 * kPW));
         } else {
           CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", idx);
-          const size_t need = (static_cast<size_t>(j.k) * (j.len + 1) + 2 * j.k + (j.kind >= 4 ? j.k * j.k : 0)) * sizeof(float);
+          const size_t need = (static_cast<size_t>(j.k) * (j.len + 4) + 2 * j.k + (j.kind >= 4 ? j.k * j.k : 0)) * sizeof(float);  // (row stride up to len + 4)
           if (need > 160 * 1024)
             return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
           lds = std::max(lds, need);

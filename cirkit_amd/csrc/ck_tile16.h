@@ -47,6 +47,8 @@ __device__ __forceinline__ float w16_elem(const WRegs16& w, int beta, int s) {
   return (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
 }
 
+__device__ __forceinline__ void tile16_load(const float* __restrict__ row_kq, float (&v)[8]);
+
 // maximum of a value over the four lanes (b, 0..3) that hold one row (v_permlane16_swap / v_permlane32_swap: no LDS)
 __device__ __forceinline__ float xquad_max(float m) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
