@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -49,7 +49,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_device_info": [_i, C.POINTER(_l)],
     "ck_transpose_i64_to_i32": [_p, _p, _i, _i, _p],
     "ck_transpose_f32": [_p, _p, _i, _i, _p],
-    "ck_stage_categories": [_p, _p, _i, _i, _p, _p, _p],
+    "ck_stage_categories": [_p, _p, _i, _i, _p, _p, _i, _p],
     "ck_poison_outputs": [_p, _l, _p, _p],
     "ck_categorical_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_gaussian_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -69,7 +69,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_tensordot_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_tensordot_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_subtree_cat_cpt_fwd": [_p, _p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _i, _i, _i, _i, _i, _i, _p],
-    "ck_leaf_persistent_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_leaf_persistent_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_tail_lse_fwd": [_p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32),
                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _i, _p],
     "ck_tail16_lse_fwd": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],

@@ -172,6 +172,7 @@ class HipCircuit:
         self.tail16 = bool(tail16)
         self.validate_inputs = bool(validate_inputs)
         self._num_states: torch.Tensor | None = None
+        self._states_consistent = True
         self._bad_input = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self._pprog = None
@@ -829,7 +830,7 @@ class HipCircuit:
                 "ck_leaf_persistent_fwd", table.data_ptr(), scale.data_ptr(), bd.xt_i.data_ptr(),
                 cat._scope(self.device).data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off, out.data_ptr(),
                 work.data_ptr(), int(work.shape[0]), self._n_cu, self.leaf_waves, g.depth, bd.B, cat.num_output_units,
-                cat.num_categories, stream,
+                cat.num_categories, 1 if self._preclamp() else 0, stream,
             )
             return
         capi.call(
@@ -867,15 +868,22 @@ class HipCircuit:
         if xi is not None:
             if self.validate_inputs:
                 capi.call("ck_stage_categories", xi.data_ptr(), bd.xt_i.data_ptr(), bd.B, self.plan.num_variables,
-                          self._num_states_dev().data_ptr(), self._bad_input.data_ptr(), stream)
+                          self._num_states_dev().data_ptr(), self._bad_input.data_ptr(), 1 if self._preclamp() else 0, stream)
             else:
                 capi.call("ck_transpose_i64_to_i32", xi.data_ptr(), bd.xt_i.data_ptr(), bd.B, self.plan.num_variables, stream)
+
+    def _preclamp(self) -> bool:
+        """Whether the staging kernel writes table row numbers (the range mapping every consumer would apply) instead of
+        raw values: possible when every discrete layer reading a variable indexes it with the same number of states."""
+        self._num_states_dev()
+        return self.validate_inputs and self._states_consistent
 
     def _num_states_dev(self) -> torch.Tensor:
         """(D,) int32: number of states the discrete input layers index variable d with (the smallest, if several layers
         read it; 0 = no discrete layer reads it)."""
         if self._num_states is None:
             ns = np.zeros(max(1, self.plan.num_variables), dtype=np.int64)
+            self._states_consistent = True
             for l in self.layers:
                 if not isinstance(l, HipInputLayer) or isinstance(l, HipConstantValueLayer) or l.wants_float_input:
                     continue
@@ -885,6 +893,8 @@ class HipCircuit:
                 if n is None:
                     continue
                 for v in np.unique(l.scope_idx):
+                    if ns[v] not in (0, n):
+                        self._states_consistent = False
                     ns[v] = n if ns[v] == 0 else min(ns[v], n)
             self._num_states = torch.from_numpy(ns.astype(np.int32)).to(self.device)
         return self._num_states

@@ -42,6 +42,7 @@ struct LeafArgs {
   float* out;           // (F_root, B, 32)
   const int32_t* work;  // (n_seg, 4): root fold, first tile, end tile, 0
   int n_seg, B, C;
+  int preclamped;  // xt holds -1 .. C - 1 only
 };
 
 template <int D, int WAVES>
@@ -63,6 +64,12 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     rd_addr[g] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(my_slots)) + (b_in * 8 + ((2 * g + kh) ^ ((b_in >> 1) & 7))) * 16;
+
+  // table + byte offset of the chunk this lane fetches: the swizzle (r >> 1) & 7 of row r = 8 q + (lane >> 3) is
+  // (4 q + (lane >> 4)) & 7, i.e. one value for even q and one for odd q
+  uint32_t g_coff[2];  // (the table is smaller than 4 GB: checked on the host)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) g_coff[q] = ((lane & 7) ^ ((4 * q + (lane >> 4)) & 7)) * 16;
 
   for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
     const int t = a.work[4 * seg], tile_begin = a.work[4 * seg + 1], tile_end = a.work[4 * seg + 2];
@@ -106,22 +113,27 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     auto pack_categories = [&](const int32_t (&xv)[kLeaves], uint32_t (&cp)[kLeaves / 2]) {
 #pragma unroll
       for (int j = 0; j < kLeaves / 2; ++j) {
-        const int c0 = xv[2 * j] < 0 ? a.C : min(xv[2 * j], a.C - 1), c1 = xv[2 * j + 1] < 0 ? a.C : min(xv[2 * j + 1], a.C - 1);
-        cp[j] = static_cast<uint32_t>(c0) | (static_cast<uint32_t>(c1) << 16);
+        if (a.preclamped) {  // values are -1 .. C - 1 (ck_stage_categories): -1 = 0xffffffff -> the integral row C (uniform branch)
+          const uint32_t uc = static_cast<uint32_t>(a.C);
+          cp[j] = min(static_cast<uint32_t>(xv[2 * j]), uc) | (min(static_cast<uint32_t>(xv[2 * j + 1]), uc) << 16);
+        } else {
+          const int c0 = xv[2 * j] < 0 ? a.C : min(xv[2 * j], a.C - 1), c1 = xv[2 * j + 1] < 0 ? a.C : min(xv[2 * j + 1], a.C - 1);
+          cp[j] = static_cast<uint32_t>(c0) | (static_cast<uint32_t>(c1) << 16);
+        }
       }
     };
     auto row_of = [&](const uint32_t (&cp)[kLeaves / 2], auto ic) -> int32_t {  // table row of leaf ic.value for batch row b_in
       constexpr int i = decltype(ic)::value;
       return row_base[i] + static_cast<int32_t>((i & 1) ? cp[i >> 1] >> 16 : cp[i >> 1] & 0xffffu);
     };
-    // leaf -> slot: lane (r8 = lane >> 3, c8 = lane & 7) of DMA q fetches 16-byte chunk c8 ^ swz(r) of row r = 8q + r8
+    // leaf -> slot: lane (r8 = lane >> 3, c8 = lane & 7) of DMA q fetches 16-byte chunk c8 ^ swz(r) of row r = 8q + r8.
+    // The address is the (uniform) table pointer plus a 32-bit lane offset (row index << 7) + chunk offset: one VALU
+    // instruction per DMA (global_load_lds with an SGPR base).
     auto dma = [&](int32_t rowv, int slot) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int r = 8 * q + (lane >> 3);
-        const int ridx = __builtin_amdgcn_ds_bpermute(4 * r, rowv);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const float* src = a.table + static_cast<int64_t>(ridx) * kK + c * 4;
+        const uint32_t ridx = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(4 * (8 * q + (lane >> 3)), rowv));
+        const char* src = reinterpret_cast<const char*>(a.table) + static_cast<uint32_t>((ridx << 7) + g_coff[q & 1]);
         __builtin_amdgcn_global_load_lds((ck::gptr_t)src, (ck::lptr_t)(my_slots + slot * 1024 + q * 256), 16, 0, 0);
       }
     };
@@ -247,7 +259,7 @@ extern "C" {
 int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
                            const float* const* w_levels, const int32_t* nodes, const int32_t* node_off, int leaf_off,
                            float* out, const int32_t* work, int n_seg, int n_wg, int waves, int depth, int B, int K,
-                           int C, void* stream) {
+                           int C, int preclamped, void* stream) {
   CK_REQUIRE(table && table_scale && xt && scope && w_levels && nodes && node_off && out && work,
              "ck_leaf_persistent_fwd: null pointer");
   CK_REQUIRE(depth >= 1 && depth <= kMaxDepthP, "ck_leaf_persistent_fwd: depth %d outside [1, %d]", depth, kMaxDepthP);
@@ -272,6 +284,7 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
   a.n_seg = n_seg;
   a.B = B;
   a.C = C;
+  a.preclamped = preclamped;
   dim3 grid(static_cast<unsigned>(std::min(n_wg, n_seg)));
   return ck::dispatch(
       [=](hipStream_t s) {

@@ -74,8 +74,11 @@ int ck_transpose_i64_to_i32(const int64_t* x, int32_t* xt, int B, int D, void* s
  * IndexError on such an index (layers/input.py:258-266, 399-412).  The kernels clamp the category for memory safety; the
  * caller turns the flag into NaN outputs (ck_tail16_lse_fwd's bad_input, or ck_poison_outputs) and into an IndexError on
  * the host when it next looks (HipCircuit.check_inputs).  Negative values stay what they are for this library: the
- * "marginalised variable" sentinel of the integral row. */
-int ck_stage_categories(const int64_t* x, int32_t* xt, int B, int D, const int32_t* num_states, int32_t* flag, void* stream);
+ * "marginalised variable" sentinel of the integral row.  clamp != 0: checked variables are stored range-mapped --
+ * min(x, n - 1), or -1 for any negative x, n = num_states[d] -- which every consumer's own mapping leaves unchanged and
+ * lets the persistent leaf launch (preclamped) turn a value into its table row with one unsigned minimum. */
+int ck_stage_categories(const int64_t* x, int32_t* xt, int B, int D, const int32_t* num_states, int32_t* flag, int clamp,
+                        void* stream);
 /* out[0..n) = NaN if *flag != 0 (one small launch; circuits whose last launch is ck_tail16_lse_fwd do not need it). */
 int ck_poison_outputs(float* out, int64_t n, const int32_t* flag, void* stream);
 /* (B, D) fp32 -> (D, B) fp32, same purpose for continuous inputs. */
@@ -234,12 +237,14 @@ int ck_subtree_cat_cpt_fwd(const float* table, const float* table_scale, const i
  * g, g + n_wg, ...; inside a segment its wavefronts draw tiles from an LDS counter.  A segment's 2^depth - 1
  * weight matrices are staged in LDS once; leaf rows are gathered global -> LDS (global_load_lds_dwordx4, 8 lanes
  * per 128-byte row).  Bit-identical outputs to ck_subtree_cat_cpt_fwd with table_scale; the caller chooses the
- * segment list (cirkit_amd/circuit.py: whole roots split evenly over the CUs of one XCD).  Reference semantics as
+ * segment list (cirkit_amd/circuit.py: whole roots split evenly over the CUs of one XCD).  preclamped != 0: xt holds
+ * -1 .. C - 1 only (ck_stage_categories with clamp != 0): the table row is then min_u32(x, C) -- the integral row C for
+ * the marginalisation sentinel -- instead of a compare, a select and a minimum.  Reference semantics as
  * ck_subtree_cat_cpt_fwd. */
 int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
                            const float* const* w_levels, const int32_t* nodes, const int32_t* node_off, int leaf_off,
                            float* out, const int32_t* work, int n_seg, int n_wg, int waves, int depth, int B, int K,
-                           int C, void* stream);
+                           int C, int preclamped, void* stream);
 
 /* The last `n_layers` levels of a circuit (few folds each) in one launch: one workgroup per 32-row
  * batch tile walks the layers in order, a workgroup barrier between levels.  Layer i is a

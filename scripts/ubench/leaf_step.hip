@@ -100,8 +100,19 @@ __global__ void __launch_bounds__(256 * WPS) step_loop(float* out, long long* t,
         }
         cs = fmaf(static_cast<float>(k), kLN2, cs);
       }
-      if (PRIO & 2) __builtin_amdgcn_s_setprio(3);
+      if (PRIO == 4) {  // asymmetric: the first wave of a SIMD wins every arbitration while both are in their chains
+        if ((threadIdx.x >> 6) >= 4)
+          __builtin_amdgcn_s_setprio(2);
+        else
+          __builtin_amdgcn_s_setprio(3);
+      } else if (PRIO & 2) {
+        __builtin_amdgcn_s_setprio(3);
+      }
       contract_linear<CK_W_TILED_F32>(wcur, cur);
+      if (PRIO == 4) {
+        asm volatile("" ::"v"(cur[0]));
+        __builtin_amdgcn_s_setprio(0);
+      }
       if (PRIO & 2) {
         if ((PRIO & 1) && (threadIdx.x >> 6) >= 4)
           __builtin_amdgcn_s_setprio(2);
@@ -405,7 +416,7 @@ int main() {
   run<0, 2>(iters, w); run<1, 2>(iters, w); run<2, 2>(iters, w); run<4, 2>(iters, w); run<5, 2>(iters, w);
   run<0, 3>(iters, w); run<1, 3>(iters, w); run<2, 3>(iters, w); run<4, 3>(iters, w); run<5, 3>(iters, w);
   run<2, 2, 1>(iters, w); run<2, 2, 2>(iters, w); run<2, 2, 3>(iters, w);
-  run<4, 2, 1>(iters, w); run<4, 2, 2>(iters, w); run<4, 2, 3>(iters, w);
+  run<4, 2, 1>(iters, w); run<4, 2, 2>(iters, w); run<4, 2, 3>(iters, w); run<4, 2, 4>(iters, w); run<2, 2, 4>(iters, w);
   run_pipe<1>(iters, w);
   run_pipe<2>(iters, w);
   return 0;
