@@ -43,7 +43,7 @@ def main():
             "write_bytes_per_launch": wk * 1024,
             "hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024,
         }
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    path = os.environ.get("TRAFFIC_OUT") or os.path.join(ROOT, "profiles", "traffic.json")
     allj = json.load(open(path)) if os.path.exists(path) else {}
     allj[key] = out
     json.dump(allj, open(path, "w"), indent=1, sort_keys=True)
