@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -56,6 +56,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_gaussian_prod_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_embedding_clog_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_embedding_log_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_categorical_clog_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_lse_to_clse": [_p, _p, _l, _p],
     "ck_constant_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_sum_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_debug_force_generic": [_i],

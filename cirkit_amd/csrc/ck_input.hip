@@ -84,6 +84,8 @@ int transpose_impl(const TI* x, TO* xt, int B, int D, void* stream, const char* 
 // MODE 0: copy table row (categorical, lse-sum)
 // MODE 1: log of table row (embedding, lse-sum)
 // MODE 2: complex log of the real table row (embedding, complex-lse-sum): (log|w|, w<0 ? pi : 0)
+// MODE 3: table row as a complex number with phase 0 (categorical, complex-lse-sum: the real log-likelihood mapped into
+//         the complex semiring, layers/input.py:276-278 + semiring.py:512-514)
 __device__ __forceinline__ float4 log4(float4 v) {
   return make_float4(__logf(v.x), __logf(v.y), __logf(v.z), __logf(v.w));
 }
@@ -115,6 +117,10 @@ __global__ void __launch_bounds__(256)
       *reinterpret_cast<float4*>(out + o) = v;
     } else if (MODE == 1) {
       *reinterpret_cast<float4*>(out + o) = log4(v);
+    } else if (MODE == 3) {
+      float4* oc = reinterpret_cast<float4*>(out + 2 * o);
+      oc[0] = make_float4(v.x, 0.f, v.y, 0.f);
+      oc[1] = make_float4(v.z, 0.f, v.w, 0.f);
     } else {
       const float pi = 3.14159265358979323846f;
       float4 l = make_float4(logf(fabsf(v.x)), logf(fabsf(v.y)), logf(fabsf(v.z)), logf(fabsf(v.w)));
@@ -145,6 +151,9 @@ __global__ void __launch_bounds__(256)
       out[o] = v;
     } else if (MODE == 1) {
       out[o] = __logf(v);
+    } else if (MODE == 3) {
+      out[2 * o] = v;
+      out[2 * o + 1] = 0.f;
     } else {
       out[2 * o] = logf(fabsf(v));
       out[2 * o + 1] = v < 0.f ? 3.14159265358979323846f : 0.f;
@@ -269,6 +278,13 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- lse-sum -> complex-lse-sum ---------------------------------------------------------------------
+// ComplexLSESumSemiring.map_from(x, LSESumSemiring) = x.to(complex) (semiring.py:512-514): (x, 0)
+__global__ void __launch_bounds__(256) lse_to_clse_kernel(const float* __restrict__ in, float2* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    out[i] = make_float2(in[i], 0.f);
+}
+
 // ---- ConstantValue -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
     constant_kernel(const float* __restrict__ value, float* __restrict__ out, int B, int K,
@@ -335,6 +351,22 @@ int ck_transpose_f32(const float* x, float* xt, int B, int D, void* stream) {
 int ck_categorical_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out,
                        int F, int B, int K, int C, int D, void* stream) {
   return gather_impl<0>(table, xt, scope, out, F, B, K, C, D, stream, "ck_categorical_fwd");
+}
+
+int ck_categorical_clog_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out_c,
+                            int F, int B, int K, int C, int D, void* stream) {
+  return gather_impl<3>(table, xt, scope, out_c, F, B, K, C, D, stream, "ck_categorical_clog_fwd");
+}
+
+int ck_lse_to_clse(const float* in, float* out_c, int64_t n, void* stream) {
+  CK_REQUIRE(in && out_c && n > 0, "ck_lse_to_clse: null pointer or empty input");
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 8192))), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(lse_to_clse_kernel, grid, block, 0, s, in, reinterpret_cast<float2*>(out_c), n);
+        return hipGetLastError();
+      },
+      stream);
 }
 
 int ck_embedding_log_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out,

@@ -142,6 +142,8 @@ class HipInputLayer(HipLayer):
     def _scope(self, device) -> torch.Tensor:
         if self._scope_dev is None or self._scope_dev.device != device:
             if self.scope_idx.shape[1] != 1:
+                # (F, D') is the base-class shape (input.py:13-123); every concrete input layer on this path refuses
+                # D' != 1 in its constructor, in the reference (input.py:220-221, 345-346, 478-479, 603-604) and here
                 raise NotImplementedError("input layers over more than one variable per fold")
             self._scope_dev = torch.from_numpy(np.ascontiguousarray(self.scope_idx[:, 0])).to(device)
         return self._scope_dev
@@ -243,10 +245,9 @@ class HipCategoricalLayer(HipInputLayer):
         capi.call("ck_param_table_integral_row", _ptr(self._table), F, C, K, 0 if self.probs is not None else 1, stream)
 
     def launch_input(self, xt, D, out, B, stream) -> None:
-        if self.is_complex:
-            raise NotImplementedError("categorical layer under complex-lse-sum")
+        # under complex-lse-sum the real log-likelihood is mapped into the complex semiring (input.py:276-278)
         capi.call(
-            "ck_categorical_fwd", _ptr(self._table), _ptr(xt), _ptr(self._scope(xt.device)), _ptr(out),
+            "ck_categorical_clog_fwd" if self.is_complex else "ck_categorical_fwd", _ptr(self._table), _ptr(xt), _ptr(self._scope(xt.device)), _ptr(out),
             self.num_folds, B, self.num_output_units, self.num_categories, D, stream,
         )
 
@@ -385,13 +386,16 @@ class HipGaussianLayer(HipInputLayer):
         )
 
     def launch_input(self, xt, D, out, B, stream) -> None:
-        if self.is_complex:
-            raise NotImplementedError("gaussian layer under complex-lse-sum")
         mean, stddev, lz = self._vals
+        real = out
+        if self.is_complex:  # the real log-density, then its image in the complex semiring (input.py:276-278)
+            real = torch.empty(out.shape, dtype=torch.float32, device=out.device)
         capi.call(
             "ck_gaussian_fwd", _ptr(mean), _ptr(stddev), _ptr(lz), _ptr(xt), _ptr(self._scope(xt.device)),
-            _ptr(out), self.num_folds, B, self.num_output_units, D, stream,
+            _ptr(real), self.num_folds, B, self.num_output_units, D, stream,
         )
+        if self.is_complex:
+            capi.call("ck_lse_to_clse", _ptr(real), _ptr(out), real.numel(), stream)
 
 
 class HipConstantValueLayer(HipLayer):

@@ -119,6 +119,14 @@ int ck_embedding_clog_fwd(const float* table, const int32_t* xt, const int64_t* 
 int ck_embedding_log_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out,
                          int F, int B, int K, int C, int D, void* stream);
 
+/* TorchCategoricalLayer.forward under complex-lse-sum: the real log-likelihood gather of ck_categorical_fwd mapped into the
+ * complex semiring (layers/input.py:276-278 -> semiring.py:512-514): out_c[f,b,k] = (table[f, x, k], 0). */
+int ck_categorical_clog_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out_c,
+                            int F, int B, int K, int C, int D, void* stream);
+/* ComplexLSESumSemiring.map_from(x, LSESumSemiring) (semiring.py:512-514) on n fp32 values: out_c[i] = (in[i], 0).
+ * Used for input layers whose log-density kernel is real (Gaussian) under complex-lse-sum. */
+int ck_lse_to_clse(const float* in, float* out_c, int64_t n, void* stream);
+
 /* TorchConstantValueLayer.forward, layers/input.py:739-743: broadcast value (F, K) over B.
  * complex_out: activations are complex64; value_is_complex: `value` is complex64;
  * log_space 0: apply the map from sum-product (log / clog), 1: value already in log space. */

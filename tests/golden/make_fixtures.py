@@ -179,6 +179,34 @@ def sq_gaussian():
                                         "z_f64": _fp64_copy(zc)().numpy()})
 
 
+def complex_inputs():
+    """Categorical (logits) and Gaussian input layers under complex-lse-sum: the reference maps their real
+    log-likelihoods into the complex semiring (layers/input.py:276-278, semiring.py:512-514) and the signed sum
+    weights make the activations genuinely complex from the first sum layer on.  c(x) on 12 rows in complex64 and
+    complex128."""
+    par = Parameterization(activation="none", initialization="normal")
+    for name, kw, seed in (
+        ("sos_cat_c_qt4x4_k6", dict(input_layer="categorical", num_input_units=6, num_sum_units=6,
+                                    input_params={"logits": par}), 21),
+        ("sos_gauss_c_qt4x4_k4", dict(input_layer="gaussian", num_input_units=4, num_sum_units=4), 22),
+    ):
+        sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", sum_product_layer="cp-t", sum_weight_param=par, **kw)
+        ctx = PipelineContext(backend="torch", semiring="complex-lse-sum", fold=True, optimize=True)
+        cc = ctx.compile(sc)
+        plan, tensors = plan_from_torch_circuit(cc)
+        _load_closed_form(plan, tensors)
+        g = torch.Generator().manual_seed(seed)
+        if kw["input_layer"] == "categorical":
+            x = torch.randint(0, 256, (12, 16), generator=g)
+            xs, x64 = x.numpy().astype(np.int16), x
+        else:
+            x = torch.randn((12, 16), generator=g)
+            xs, x64 = x.numpy(), x.double()
+        y = cc(x)
+        y128 = _fp64_copy(cc)(x64)
+        _save(name, plan, {"x": xs, "y_c64": y.numpy(), "y_c128": y128.numpy()})
+
+
 def binomial():
     """Binomial input layers (image_data(..., input_layer="binomial"): total_count 255, probs = sigmoid(tensor)):
     plan + outputs of the reference on 12 rows, closed-form parameters."""

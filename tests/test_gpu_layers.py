@@ -284,6 +284,35 @@ def test_embedding_and_constant_layer_contract(hip_device, sem):
         assert got.shape == (F, 6, K) and float((got - want).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("K", [32, 6, 1])
+def test_real_input_layers_under_the_complex_semiring(hip_device, K):
+    """Categorical and Gaussian layers under complex-lse-sum: the real log-likelihood with phase 0
+    (layers/input.py:276-278 -> semiring.py:512-514)."""
+    from cirkit_amd.layers import HipCategoricalLayer, HipGaussianLayer
+    from cirkit_amd.parameters import TensorStore
+
+    sem, F, B, C = "complex-lse-sum", 3, 37, 9
+    g = torch.Generator().manual_seed(K)
+    store = TensorStore(hip_device)
+    theta = torch.randn(F, K, C, generator=g)
+    xi = torch.randint(0, C, (F, B, 1), generator=g)
+    p, pg = _pg(store, "t", theta)
+    layer = HipCategoricalLayer(np.arange(F)[:, None], K, num_categories=C, logits=p, semiring=sem)
+    spec = LayerSpec("categorical", F, 1, 1, K, dict(layer.config), {"logits": pg}, None, np.arange(F)[:, None])
+    got, want = layer.forward(xi.to(hip_device)).cpu(), _oracle(spec, {"t": theta}, xi, sem)
+    assert got.dtype == want.dtype == torch.complex64 and torch.equal(got, want)  # a gather: bit-exact
+    mean, raw = torch.randn(F, K, generator=g), torch.randn(F, K, generator=g)
+    xf = torch.randn(F, B, 1, generator=g) * 2
+    pm, gm = _pg(store, "mean", mean)
+    ps, gs = _pg(store, "raw", raw, [("scaled_sigmoid", {"vmin": 1e-5, "vmax": 1.0}, (K,))])
+    gl = HipGaussianLayer(np.arange(F)[:, None], K, mean=pm, stddev=ps, semiring=sem)
+    gspec = LayerSpec("gaussian", F, 1, 1, K, dict(gl.config), {"mean": gm, "stddev": gs}, None, np.arange(F)[:, None])
+    got, want = gl.forward(xf.to(hip_device)).cpu(), _oracle(gspec, {"mean": mean, "raw": raw}, xf, sem)
+    assert got.dtype == want.dtype == torch.complex64
+    assert torch.equal(got.imag, torch.zeros_like(got.imag))
+    _close(got.real, want.real, tol=5e-5)
+
+
 def test_layer_forward_rejects_bad_inputs(hip_device):
     from cirkit_amd.layers import HipHadamardLayer
 

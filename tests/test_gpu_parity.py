@@ -173,6 +173,26 @@ def test_sos_complex_circuit_and_partition(hip_device):
     _check_layers(plan_z, tensors, None, hz)
 
 
+@pytest.mark.parametrize("name", ["sos_cat_c_qt4x4_k6", "sos_gauss_c_qt4x4_k4"])
+def test_real_input_layers_in_a_complex_circuit(hip_device, name):
+    """SURVEY.md 8d config 5 in its other form: Categorical (logits) -- and Gaussian -- input layers under
+    complex-lse-sum (layers/input.py:276-278), signed sum weights.  Real part against the reference to 1e-4 of the
+    value, the phase as a unit vector."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case(name)
+    x = _x_of(plan, g)
+    hc = HipCircuit(plan, tensors, device=hip_device, use_graph=False)
+    y = hc(x.to(hip_device)).cpu()
+    yr, y128 = torch.from_numpy(g["y_c64"]), torch.from_numpy(g["y_c128"])
+    assert y.shape == yr.shape and y.dtype == torch.complex64
+    # the reference's own fp32 run is this far from its fp64 run: the bar is REL or four times that
+    own = float(((yr.real.double() - y128.real).abs() / y128.real.abs().clamp_min(1.0)).max())
+    assert float(((y.real.double() - y128.real).abs() / y128.real.abs().clamp_min(1.0)).max()) <= max(REL, 4 * own)
+    assert float((torch.exp(1j * y.imag.double()) - torch.exp(1j * y128.imag)).abs().max()) <= 5e-3
+    _check_layers(plan, tensors, x, hc)
+
+
 def test_mfma_and_generic_sum_kernels_agree(hip_device):
     from cirkit_amd import _capi as capi
     from cirkit_amd.circuit import HipCircuit

@@ -62,6 +62,15 @@ def test_oracle_complex_sos_circuit_and_partition_function():
     assert torch.isfinite(lp).all()
 
 
+@pytest.mark.parametrize("name", ["sos_cat_c_qt4x4_k6", "sos_gauss_c_qt4x4_k4"])
+def test_oracle_real_input_layers_under_the_complex_semiring(name):
+    """Categorical / Gaussian log-likelihoods mapped into complex-lse-sum (layers/input.py:276-278)."""
+    plan, tensors, g = load_case(name)
+    y = evaluate_plan(plan, as_torch(tensors), _x_of(g))
+    assert y.dtype == torch.complex64
+    assert np.array_equal(y.numpy(), g["y_c64"])
+
+
 KATS = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "kat_*.json")))
 
 
