@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -65,7 +65,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_sum_clse_gather_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_mixing_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_cp_lse_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "ck_region_lse_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_region_lse_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     "ck_hadamard_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_kronecker_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_tensordot_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

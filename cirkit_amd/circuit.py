@@ -583,9 +583,15 @@ class HipCircuit:
             tab = bd.cp_tabs[i] = torch.from_numpy(self._weight_addresses(reg.slot_dense, K)).to(self.device)
         F, H, S = reg.slot_dense.shape[:3]
         ga, gv, Cn = self._gather_tables(reg.slot_dense, i, bd)
+        redo = None
+        if self.linear_levels and ga is None:  # linear-space products + marked workgroups again in log space
+            redo = bd.cp_tabs.get((i, "redo"))
+            if redo is None:
+                redo = bd.cp_tabs[(i, "redo")] = torch.zeros(F * ((bd.B + 127) // 128), dtype=torch.int32, device=self.device)
         capi.call("ck_region_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), l._w.data_ptr(),
                   bd.views[i].data_ptr(), None if ga is None else ga.data_ptr(), None if gv is None else gv.data_ptr(),
-                  None if ga is None else bd.xt_i.data_ptr(), Cn, F, H, S, bd.B, K, stream)
+                  None if ga is None else bd.xt_i.data_ptr(), Cn, None if redo is None else redo.data_ptr(),
+                  F, H, S, bd.B, K, stream)
 
     def _launch_input_prod(self, i: int, bd: _Binding, stream: int) -> None:
         """`ck_gaussian_prod_fwd`: a Hadamard layer over Gaussian folds, straight from the batch."""

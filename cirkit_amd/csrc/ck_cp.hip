@@ -225,10 +225,16 @@ template <int NK, int WAVES, int MINW>
 __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: caps the VGPR budget
     region_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                       const int64_t* __restrict__ w_addr, const float* __restrict__ mw,
-                      float* __restrict__ out, const GatherSlots gs, int H, int S, int B) {
+                      float* __restrict__ out, const GatherSlots gs, int32_t* __restrict__ redo, int H, int S, int B) {
   constexpr int K = 32 * NK;
   constexpr int WF4 = K * K / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (redo != nullptr) {  // second launch of a region: only the workgroups the linear-space launch marked
+    int32_t* flag = redo + (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x);
+    if (*flag == 0) return;  // (uniform over the workgroup)
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = 0;  // ready for the next replay of the program
+  }
   float* w_s = smem;               // [3][K*K]
   float* mw_s = smem + 3 * K * K;  // [H][K]
   const int f = blockIdx.y;
@@ -359,6 +365,283 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
         A[p][4 * g + 3] = fmaf(c4.w, __builtin_amdgcn_exp2f(fmaf(P[p][4 * g + 3], kL2E, nml)), A[p][4 * g + 3] * scale);
       }
     M = Mn;
+  }
+  if (live) {
+    float* dst = out + (static_cast<int64_t>(f) * B + b) * K + 4 * kh;
+#pragma unroll
+    for (int p = 0; p < NK; ++p)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 o4;
+        o4.x = fmaf(__builtin_amdgcn_logf(A[p][4 * g + 0]), kLN2, M);
+        o4.y = fmaf(__builtin_amdgcn_logf(A[p][4 * g + 1]), kLN2, M);
+        o4.z = fmaf(__builtin_amdgcn_logf(A[p][4 * g + 2]), kLN2, M);
+        o4.w = fmaf(__builtin_amdgcn_logf(A[p][4 * g + 3]), kLN2, M);
+        *reinterpret_cast<float4*>(dst + 32 * p + 8 * g) = o4;
+      }
+  }
+}
+
+// The region launch with every operand staged through LDS by the DMA path (global_load_lds_dwordx4), for regions
+// whose slots all read the arena (no table gathers):
+//   * the 32-row input tile of step t + 1 travels global -> LDS while step t computes -- whole 128-byte lines per
+//     request (a wave instruction of the register path touches 32 bytes of 32 rows), no registers held for data in
+//     flight (the register path could not prefetch: > 168 VGPRs), one private 32 x K slot per wave;
+//   * LDS reads -- the tile and the weights -- are inline ds_read_b128: for plain C++ loads from a buffer the DMA also
+//     writes, the compiler waits for EVERY outstanding DMA (s_waitcnt vmcnt(0)) before the first read, which turned
+//     the asynchronous weight staging of region_lse_kernel into a round trip per step.
+// Tile slot layout: 16-byte chunk c of row r at chunk position c ^ swz(r) of row r (swz(r) = r & 15 for K = 64,
+// (r >> 1) & 7 for K = 32): lane (b, kh) reading chunk 2g + kh (+ 8q) of row b then hits 16 distinct positions per 16
+// lanes -- no bank conflicts -- and the DMA, whose LDS side is linear in the lane, applies the swizzle on its global side.
+// Weights: ring of TWO buffers (W_{t+1} is staged after the barrier of step t, a whole MFMA chain ahead of its use).
+// Same arithmetic, in the same order, as region_lse_kernel: the two agree bit for bit.
+__device__ __forceinline__ void lds_read4(f32x4v& a, f32x4v& b, f32x4v& c, f32x4v& d, uint32_t a0, uint32_t a1,
+                                          uint32_t a2, uint32_t a3) {
+  asm volatile(
+      "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+      : "memory");
+}
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void lds_read4_off(f32x4v& a, f32x4v& b, f32x4v& c, f32x4v& d, uint32_t base) {
+  asm volatile(
+      "ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"
+      "ds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(base), "n"(O0), "n"(O1), "n"(O2), "n"(O3)
+      : "memory");
+}
+
+template <int NK, int WAVES, int MINW, bool LINEAR>
+__global__ void __launch_bounds__(WAVES * 64, MINW)
+    region_dma_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
+                      const int64_t* __restrict__ w_addr, const float* __restrict__ mw, float* __restrict__ out,
+                      int32_t* __restrict__ redo, int H, int S, int B) {
+  constexpr int K = 32 * NK;
+  constexpr int UF4 = 32 * K / 4;    // float4 elements of one weight UNIT: the 32 output rows 32 p .. 32 p + 31 of a matrix
+  constexpr int CH = K / 4;          // 16-byte chunks per row
+  constexpr int TD = 32 * CH / 64;   // wave DMAs per tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w_s = smem;                           // [2][32*K]: ring of two weight units
+  float* tile_s = smem + 2 * 32 * K;           // [WAVES][32*K]
+  float* mw_s = tile_s + WAVES * 32 * K;       // [H][K]
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int b0 = (blockIdx.x * WAVES + wave_u) * 32;
+  const int b = b0 + b_in;
+  const bool live = b < B;
+  const int T = H * S;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * T;
+  const int64_t* wa = w_addr + static_cast<int64_t>(f) * T;
+  // weight unit u = t * NK + p goes to ring buffer u & 1, in the operand layout [(q * 4 + g) * 64 + lane] float4
+  constexpr int PF = (UF4 + WAVES * 64 - 1) / (WAVES * 64);
+  static_assert(NK == 1 || UF4 % (WAVES * 64) == 0, "the vmcnt bookkeeping of later units assumes every wave stages a share");
+  // (addresses = a uniform base + a 32-bit lane offset: global_load_lds with an SGPR base, no 64-bit lane arithmetic)
+  uint32_t w_off[PF];  // byte offset of this lane's 16 bytes inside a unit's 32 rows
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+    const int i = threadIdx.x + k * (WAVES * 64);
+    const int ln = i & 63, g = (i >> 6) & 3, q = i >> 8;
+    w_off[k] = static_cast<uint32_t>(((ln & 31) * K + 32 * q + 8 * g + 4 * (ln >> 5)) * 4);
+  }
+  auto stage_w = [&](int u) {
+    const int t = u / NK, p = u % NK;
+    const uint64_t wv = static_cast<uint64_t>(wa[t]);
+    if (wv == 0) return;
+    // (made uniform explicitly: the compiler otherwise carries the loaded address in vector registers)
+    const uint64_t wu = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv >> 32)))) << 32) |
+                        static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv)));
+    const char* wf = reinterpret_cast<const char*>(static_cast<uintptr_t>(wu)) + p * (32 * K * 4);
+    float* dstb = w_s + (u & 1) * (32 * K);
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      if (UF4 % (WAVES * 64) != 0 && static_cast<int>(threadIdx.x) + k * (WAVES * 64) >= UF4) continue;  // (whole waves)
+      uint32_t o = w_off[k];
+      asm volatile("" : "+v"(o));
+      __builtin_amdgcn_global_load_lds((ck::gptr_t)(wf + o), (ck::lptr_t)(dstb + 4 * (k * WAVES * 64 + wave_u * 64)), 16, 0, 0);
+    }
+  };
+  // the wave's tile slot; DMA k, lane l fills chunk position l % CH of row k * (64 / CH) + l / CH
+  float* const my_tile = tile_s + wave_u * (32 * K);
+  uint32_t src_off[TD];  // byte offset of this lane's chunk inside a slot's (B, K) block (< 2^32: checked on the host)
+#pragma unroll
+  for (int k = 0; k < TD; ++k) {
+    const int r = k * (64 / CH) + lane / CH, pos = lane % CH;
+    const int swz = CH == 16 ? (r & 15) : ((r >> 1) & 7);
+    src_off[k] = static_cast<uint32_t>(min(b0 + r, B - 1) * K + 4 * (pos ^ swz)) * 4u;
+  }
+  auto stage_tile = [&](int t) {
+    const char* base = reinterpret_cast<const char*>(arena + ro[t]);
+#pragma unroll
+    for (int k = 0; k < TD; ++k) {
+      uint32_t o = src_off[k];
+      asm volatile("" : "+v"(o));  // (keeps the offset a 32-bit register: hoisted, it is widened to a 64-bit pair per request)
+      __builtin_amdgcn_global_load_lds((ck::gptr_t)(base + o), (ck::lptr_t)(my_tile + k * 256), 16, 0, 0);
+    }
+  };
+  // LDS byte address of chunk position (c ^ swz(b_in)) of row b_in is rd_row ^ (16 c)
+  const uint32_t swz_b = CH == 16 ? (b_in & 15) : ((b_in >> 1) & 7);
+  const uint32_t rd_row = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(my_tile)) + (b_in * CH + swz_b) * 16;
+  const uint32_t w_rd = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + lane * 16;
+
+  const float* mwf = mw + static_cast<int64_t>(f) * K * H;
+  for (int i = threadIdx.x; i < K * H; i += WAVES * 64) {
+    const int k = i / H, h = i - k * H;
+    mw_s[h * K + k] = mwf[i];
+  }
+  stage_w(0);
+  stage_tile(0);
+
+  float A[NK][16];
+#pragma unroll
+  for (int p = 0; p < NK; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) A[p][r] = 0.f;
+  float M = -INFINITY;
+  int t = 0;
+  bool bad = false;
+  for (int h = 0; h < H; ++h) {
+    float P[NK][16];
+    float sc = 0.f;  // LINEAR: log scale of the rows of P
+    for (int s = 0; s < S; ++s, ++t) {
+      float v[NK][16];
+      // tile t (requested a step ago) and this wave's share of W_t (requested before it) have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < NK; ++q) {
+        f32x4v r0, r1, r2, r3;
+        lds_read4(r0, r1, r2, r3, rd_row ^ (16u * (8 * q + kh)), rd_row ^ (16u * (8 * q + 2 + kh)),
+                  rd_row ^ (16u * (8 * q + 4 + kh)), rd_row ^ (16u * (8 * q + 6 + kh)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[q][e] = r0[e];
+          v[q][4 + e] = r1[e];
+          v[q][8 + e] = r2[e];
+          v[q][12 + e] = r3[e];
+        }
+      }
+      const bool dense = wa[t] != 0;  // uniform over the workgroup
+      float m = 0.f;
+      if (dense || LINEAR) {  // (LINEAR: a plain slot enters the product as exp(v - m) with log scale m)
+        m = v[0][0];
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) m = fmaxf(m, v[q][j]);
+        m = ck::xhalf_max(m);
+        m = ck::clamp_finite(m);
+        const float nml = exp_offset(m, 0.f);
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[q][j] = __builtin_amdgcn_exp2f(fmaf(v[q][j], kL2E, nml));
+      }
+      static_for<0, NK>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        const int u = t * NK + p;
+        // unit u is in LDS: this wave's share has landed (at p = 0 by the wait at the top of the step; later units were
+        // requested BEFORE the next tile, whose TD requests may still be in flight) -- and so have the other waves'
+        if constexpr (p > 0) {
+          if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TD) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... and every wave has left unit u - 1
+        if (u + 1 < T * NK) stage_w(u + 1);
+        if constexpr (p == 0) {
+          if (t + 1 < T) stage_tile(t + 1);  // (the slot is free since its reads returned)
+        }
+        if (dense) {
+          const uint32_t wb = w_rd + (u & 1) * (32 * K * 4);
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          static_for<0, NK>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int o = q * 4096;
+            f32x4v w0, w1, w2, w3;
+            lds_read4_off<o, o + 1024, o + 2048, o + 3072>(w0, w1, w2, w3, wb);
+            const f32x4v* wg[4] = {&w0, &w1, &w2, &w3};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[0], v[q][4 * g + 0], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[1], v[q][4 * g + 1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[2], v[q][4 * g + 2], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[3], v[q][4 * g + 3], acc, 0, 0, 0);
+            }
+          });
+          if constexpr (LINEAR) {  // P = prod_s G_s stays in linear space; the row's log scale is the sum of the m_s
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[p][r] = s == 0 ? acc[r] : P[p][r] * acc[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float gs = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m);
+              P[p][r] = s == 0 ? gs : P[p][r] + gs;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            if constexpr (LINEAR) P[p][j] = s == 0 ? v[p][j] : P[p][j] * v[p][j];  // (exp(v - m): see below)
+            else P[p][j] = s == 0 ? v[p][j] : P[p][j] + v[p][j];
+          }
+        }
+      });
+      if constexpr (LINEAR) sc = s == 0 ? m : sc + m;
+    }
+    // mixing: fold P_h into the running sum
+    float pm = P[0][0];
+#pragma unroll
+    for (int p = 0; p < NK; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pm = fmaxf(pm, P[p][r]);
+    pm = ck::xhalf_max(pm);
+    const uint32_t mw_rd = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(mw_s)) + (h * K + 4 * kh) * 4;
+    if constexpr (LINEAR) {
+      // the partition's rows are P * exp(sc): two exponentials per ROW (instead of one per element) rescale the
+      // running sum and the new term to the running maximum.  A row whose largest product fell below 2^-80 (the
+      // factors are <= 1 with different supports, or an input row was all -inf / non-finite) has lost elements the
+      // log-space evaluation keeps: the tile is marked and evaluated again by region_lse_kernel.
+      bad |= !(pm > kLinearFloor);
+      const float Mh = fmaf(__builtin_amdgcn_logf(pm), kLN2, sc);
+      const float Mn = ck::clamp_finite(fmaxf(M, Mh));
+      const float c_old = __builtin_amdgcn_exp2f((M - Mn) * kL2E);  // 0 on the first partitioning (M = -inf)
+      const float c_new = __builtin_amdgcn_exp2f((sc - Mn) * kL2E);
+      static_for<0, NK>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        f32x4v c0, c1, c2, c3;
+        lds_read4_off<128 * p, 128 * p + 32, 128 * p + 64, 128 * p + 96>(c0, c1, c2, c3, mw_rd);
+        const f32x4v* cg[4] = {&c0, &c1, &c2, &c3};
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            A[p][4 * g + e] = fmaf((*cg[g])[e] * c_new, P[p][4 * g + e], A[p][4 * g + e] * c_old);
+      });
+      M = Mn;
+    } else {
+      const float Mn = ck::clamp_finite(fmaxf(M, pm));
+      const float scale = __builtin_amdgcn_exp2f((M - Mn) * kL2E);  // 0 on the first partitioning (M = -inf)
+      const float nml = exp_offset(Mn, 0.f);
+      static_for<0, NK>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        f32x4v c0, c1, c2, c3;
+        lds_read4_off<128 * p, 128 * p + 32, 128 * p + 64, 128 * p + 96>(c0, c1, c2, c3, mw_rd);
+        const f32x4v* cg[4] = {&c0, &c1, &c2, &c3};
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            A[p][4 * g + e] = fmaf((*cg[g])[e], __builtin_amdgcn_exp2f(fmaf(P[p][4 * g + e], kL2E, nml)), A[p][4 * g + e] * scale);
+      });
+      M = Mn;
+    }
+  }
+  if constexpr (LINEAR) {
+    if (__any(bad) && lane == 0) atomicOr(redo + (static_cast<int64_t>(f) * gridDim.x + blockIdx.x), 1);
   }
   if (live) {
     float* dst = out + (static_cast<int64_t>(f) * B + b) * K + 4 * kh;
@@ -537,7 +820,7 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
 
 extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
                                  float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
-                                 int F, int H, int S, int B, int K, void* stream) {
+                                 int32_t* redo, int F, int H, int S, int B, int K, void* stream) {
   CK_REQUIRE(g_var == nullptr || (g_addr && xt && C > 0), "ck_region_lse_fwd: gather slots need g_addr, xt and C");
   const GatherSlots gs{g_addr, g_var, xt, C};
   CK_REQUIRE(arena && row_off && w_addr && mw && out, "ck_region_lse_fwd: null pointer");
@@ -548,19 +831,36 @@ extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, con
   const size_t lds = (static_cast<size_t>(3) * K * K + static_cast<size_t>(H) * K) * sizeof(float);
   CK_REQUIRE(lds <= 64 * 1024, "ck_region_lse_fwd: H=%d mixing coefficients do not fit in LDS", H);
   const int tiles = (B + 31) / 32;
+  const int waves = K == 64 ? 4 : 8;  // (both kernels: one 32-row tile per wave, the same workgroup <-> tiles mapping)
+  const dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
+  // every operand through the LDS DMA path (region_dma_kernel) unless a slot gathers table rows
+  const size_t lds_dma = (static_cast<size_t>(2) * 32 * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(H) * K) * sizeof(float);
+  const bool dma = g_var == nullptr && !ck::debug_force_generic() && lds_dma <= 80 * 1024 &&
+                   static_cast<int64_t>(B) * K < (int64_t{1} << 30);
+  auto exact = [=](hipStream_t s, int32_t* redo_ws) {  // region_lse_kernel: everything, or (redo_ws) the marked workgroups
+    // measured on config 4 (MI355X): 4 waves per workgroup at <= 168 VGPRs (no spills, three
+    // workgroups per CU) 2.85 ms; 8 waves capped at 128 VGPRs (spills) 3.28 ms; 2 waves 4.3 ms
+    if (K == 64)
+      hipLaunchKernelGGL((region_lse_kernel<2, 4, 3>), grid, block, lds, s, arena, row_off, w_addr, mw, out, gs, redo_ws, H, S, B);
+    else
+      hipLaunchKernelGGL((region_lse_kernel<1, 8, 4>), grid, block, lds, s, arena, row_off, w_addr, mw, out, gs, redo_ws, H, S, B);
+    return hipGetLastError();
+  };
+  if (!dma) return ck::dispatch([=](hipStream_t s) { return exact(s, nullptr); }, stream);
   return ck::dispatch(
       [=](hipStream_t s) {
-        auto go = [&](auto kern, int waves) {
-          dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
-          hipLaunchKernelGGL(kern, grid, block, lds, s, arena, row_off, w_addr, mw, out, gs, H, S, B);
+        auto go = [&](auto kern) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds_dma));
+          if (e != hipSuccess) return e;
+          hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, w_addr, mw, out, redo, H, S, B);
+          return hipGetLastError();
         };
-        // measured on config 4 (MI355X): 4 waves per workgroup at <= 168 VGPRs (no spills, three
-        // workgroups per CU) 2.85 ms; 8 waves capped at 128 VGPRs (spills) 3.28 ms; 2 waves 4.3 ms
-        if (K == 64)
-          go(region_lse_kernel<2, 4, 3>, 4);
-        else
-          go(region_lse_kernel<1, 8, 4>, 8);
-        return hipGetLastError();
+        // K = 64: 48 KiB + H x 256 B of LDS and <= 168 VGPRs: three workgroups (12 waves) per CU while H <= 20
+        if (redo == nullptr) return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
+        const hipError_t e = K == 64 ? go(region_dma_kernel<2, 4, 3, true>) : go(region_dma_kernel<1, 8, 2, true>);
+        if (e != hipSuccess) return e;
+        return exact(s, redo);  // the workgroups the linear-space launch marked, in log space (none, normally: they exit at once)
       },
       stream);
 }

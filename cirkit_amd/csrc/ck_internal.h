@@ -20,6 +20,9 @@ int dispatch(Launch fn, void* stream);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ck_sum.hip: the test hook ck_debug_force_generic is on (A/B runs of the specialised kernels against the plain ones)
+bool debug_force_generic();
+
 // ck_cp.hip: one dense / CP-T slot with contiguous (F, K, K) weights, K in {32, 64}.
 // ck_gemm.hip: dense / CP-T layers with Ki, Ko multiples of 32 and up to 256 contracted inputs.
 bool gemm_applies(int H, int Ki, int Ko, int mode);

@@ -536,6 +536,10 @@ bool g_force_generic = false;
 
 }  // namespace
 
+namespace ck {
+bool debug_force_generic() { return g_force_generic; }
+}  // namespace ck
+
 extern "C" {
 
 // Test hook: route every ck_sum_lse_fwd call through the generic kernel (A/B the MFMA path).

@@ -21,8 +21,6 @@
 
 namespace {
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
 struct WRegs16 {
   float4 q[4];  // q[beta' * 2 + g]
 };

@@ -190,10 +190,16 @@ int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_a
  *   P_h = sum_s G_{h,s};  out[f,b,k] = log(sum_h mw[f,k,h] * exp(P_h[k] - M)) + M,  M = max_{h,k} P_h[k].
  * row_off, w_addr: (F, H, S) as in ck_cp_lse_fwd; mw: (F, K, H) mixing coefficients; out: (F, B, K).
  * The sum over h is accumulated online (running maximum), see ck_cp.hip.  g_addr / g_var / xt / C: table
- * slots as in ck_cp_lse_fwd, shaped (F, H, S). */
+ * slots as in ck_cp_lse_fwd, shaped (F, H, S).
+ * redo: NULL, or a workspace of at least F * ceil(B / 128) int32 that is ZERO on entry (and zero again when the call's
+ * launches have run).  With it, regions without table slots are evaluated with the products P_h and the mixing sum in
+ * LINEAR space (row scales; one exponential per input element and two per row and partitioning instead of an exp, a
+ * log and another exp per element), and every workgroup whose rows left the safe fp32 range (largest product of a row
+ * <= 2^-80) marks itself and is evaluated again, in log space, by a second launch in which all other workgroups exit
+ * at once.  Without it everything is evaluated in log space. */
 int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
                       float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
-                      int F, int H, int S, int B, int K, void* stream);
+                      int32_t* redo, int F, int H, int S, int B, int K, void* stream);
 
 /* TorchHadamardLayer.forward, inner.py:126-127 (lse: sum over the arity axis). esize = 1 (fp32)
  * or 2 (complex64: K counts complex elements). */

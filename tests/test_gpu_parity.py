@@ -575,6 +575,115 @@ def test_forwards_in_flight_on_two_streams(hip_device):
     assert abs(float(s[0]) - float(ref.double().sum())) <= 1e-6 * abs(float(ref.double().sum()))
 
 
+@pytest.mark.parametrize("K,F,H,S,B", [(64, 3, 3, 2, 300), (64, 2, 1, 3, 33), (32, 5, 4, 2, 257), (32, 1, 2, 1, 4096)])
+def test_region_kernels_agree_bit_for_bit(hip_device, K, F, H, S, B):
+    """`ck_region_lse_fwd` through the C ABI on a synthetic arena: the launch that stages input tiles and weights by LDS
+    DMA (region_dma_kernel) and the register-path launch (region_lse_kernel, taken under ck_debug_force_generic) do the
+    same arithmetic in the same order.  Some slots carry no dense layer (plain slots)."""
+    from cirkit_amd import _capi as capi
+
+    g = torch.Generator().manual_seed(K + F + H + S)
+    T = H * S
+    arena = (torch.randn(F * T, B, K, generator=g) * 3 - 5).to(hip_device)
+    row_off = (torch.arange(F * T, dtype=torch.int64) * (B * K)).reshape(F, T)
+    row_off = row_off[:, torch.randperm(T, generator=g)].contiguous().to(hip_device)
+    w = torch.softmax(torch.randn(F * T, K, K, generator=g), dim=-1).to(hip_device)
+    addr = torch.tensor([w.data_ptr() + i * K * K * 4 for i in range(F * T)], dtype=torch.int64).reshape(F, T)
+    if T > 1:
+        addr[:, -1] = 0  # a plain slot
+    addr = addr.to(hip_device)
+    mw = torch.softmax(torch.randn(F, K, H, generator=g), dim=-1).to(hip_device)
+    outs = []
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    for force in (0, 1):
+        out = torch.full((F, B, K), float("nan"), device=hip_device)
+        capi.call("ck_debug_force_generic", force)
+        try:
+            capi.call("ck_region_lse_fwd", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), mw.data_ptr(),
+                      out.data_ptr(), None, None, None, 0, None, F, H, S, B, K, stream)
+        finally:
+            capi.call("ck_debug_force_generic", 0)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    # and the value: log sum_h mw[:, h] prod_s G_{h,s}
+    a, ro, wc, ad = arena.cpu().double(), row_off.cpu(), w.cpu().double(), addr.cpu()
+    ref = torch.zeros(F, B, K, dtype=torch.float64)
+    for f in range(F):
+        acc = torch.zeros(B, K, dtype=torch.float64)
+        for h in range(H):
+            p = torch.zeros(B, K, dtype=torch.float64)
+            for s_ in range(S):
+                t = h * S + s_
+                v = a[int(ro[f, t]) // (B * K)]
+                if int(ad[f, t]) != 0:
+                    wi = (int(ad[f, t]) - w.data_ptr()) // (K * K * 4)
+                    v = torch.log(torch.exp(v) @ wc[wi].T)
+                p = p + v
+            acc = acc + mw[f, :, h].cpu().double() * torch.exp(p)
+        ref[f] = torch.log(acc)
+    assert float(((outs[0].double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-5
+    # linear-space products (redo workspace given): same values to fp32 rounding, no workgroup marked
+    redo = torch.zeros(F * ((B + 127) // 128), dtype=torch.int32, device=hip_device)
+    out = torch.full((F, B, K), float("nan"), device=hip_device)
+    capi.call("ck_region_lse_fwd", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), mw.data_ptr(),
+              out.data_ptr(), None, None, None, 0, redo.data_ptr(), F, H, S, B, K, stream)
+    torch.cuda.synchronize()
+    assert int(redo.abs().sum()) == 0
+    assert float(((out.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-5
+
+
+@pytest.mark.parametrize("K", [64, 32])
+def test_region_linear_space_falls_back_to_log_space(hip_device, K):
+    """Rows whose products leave the fp32 range in linear space (factors with disjoint supports, all -inf inputs, +inf):
+    the linear-space launch marks their workgroups and the log-space launch evaluates them again -- same bits as the
+    log-space evaluation alone; the workspace is clean afterwards (the program can be replayed)."""
+    from cirkit_amd import _capi as capi
+
+    F, H, S, B = 2, 2, 2, 700
+    T = H * S
+    g = torch.Generator().manual_seed(K)
+    arena = torch.randn(F * T, B, K, generator=g) * 2 - 3
+    # fold 0, rows 40..49: the two children of every partitioning are (almost) one-hot at different units and the
+    # weights of fold 0 are identity matrices, so every product is exp(-60) or exp(-120): representable in log space,
+    # below the linear-space floor
+    for blk, unit in ((0, 3), (1, 7), (2, 11), (3, 13)):
+        arena[blk, 40:50] = -60.0
+        arena[blk, 40:50, unit] = 0.0
+    arena[2, 300] = float("-inf")       # an impossible row
+    arena[3, 301, 5] = float("inf")
+    arena = arena.to(hip_device)
+    row_off = (torch.arange(F * T, dtype=torch.int64) * (B * K)).reshape(F, T).to(hip_device)
+    w = torch.softmax(torch.randn(F * T, K, K, generator=g) * 2, dim=-1)
+    w[:T] = torch.eye(K)
+    w = w.to(hip_device)
+    addr = torch.tensor([w.data_ptr() + i * K * K * 4 for i in range(F * T)], dtype=torch.int64).reshape(F, T).to(hip_device)
+    mw = torch.softmax(torch.randn(F, K, H, generator=g), dim=-1).to(hip_device)
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    exact = torch.full((F, B, K), float("nan"), device=hip_device)
+    capi.call("ck_region_lse_fwd", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), mw.data_ptr(),
+              exact.data_ptr(), None, None, None, 0, None, F, H, S, B, K, stream)
+    redo = torch.zeros(F * ((B + 127) // 128), dtype=torch.int32, device=hip_device)
+    for _ in range(2):  # twice: the workspace must be clean again
+        out = torch.full((F, B, K), float("nan"), device=hip_device)
+        capi.call("ck_region_lse_fwd", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), mw.data_ptr(),
+                  out.data_ptr(), None, None, None, 0, redo.data_ptr(), F, H, S, B, K, stream)
+        torch.cuda.synchronize()
+        assert int(redo.abs().sum()) == 0
+        e, o = exact.cpu(), out.cpu()
+        rows_per_wg = 128 if K == 64 else 256
+        marked = {(0, 40 // rows_per_wg), (0, 300 // rows_per_wg), (0, 301 // rows_per_wg)}
+        for f in range(F):
+            for wg in range((B + rows_per_wg - 1) // rows_per_wg):
+                a, b = e[f, wg * rows_per_wg:(wg + 1) * rows_per_wg], o[f, wg * rows_per_wg:(wg + 1) * rows_per_wg]
+                if (f, wg) in marked:
+                    assert torch.equal(a.isnan(), b.isnan()) and torch.equal(a[~a.isnan()], b[~b.isnan()]), (f, wg)
+                else:
+                    assert torch.allclose(a, b, rtol=1e-5, atol=1e-4), (f, wg)
+    assert torch.isfinite(e[0, 40:50]).all() and float(e[0, 40:50].max()) < -50  # a legitimate, very small, value
+
+
 @pytest.mark.parametrize("rg,shape,sp,K,inp,B", [
     ("poon-domingos", (1, 8, 8), "cp", 32, "gaussian", 37),      # region_lse_kernel<1>, cp blocks, gaussian products
     ("poon-domingos", (1, 8, 8), "cp", 64, "categorical", 130),  # region_lse_kernel<2>, leftovers, subsets
