@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -71,10 +71,10 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_tensordot_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_tensordot_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_subtree_cat_cpt_fwd": [_p, _p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _i, _i, _i, _i, _i, _i, _p],
-    "ck_leaf_persistent_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_leaf_persistent_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "ck_tail_lse_fwd": [_p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32),
                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _i, _p],
-    "ck_tail16_lse_fwd": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p],
+    "ck_tail16_lse_fwd": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p],
     "ck_param_softmax": [_p, _p, _l, _i, _l, _i, _p],
     "ck_param_softmax_batch": [C.POINTER(SoftmaxJob), _i, _p],
     "ck_param_unary": [_i, _p, _p, _l, _f, _f, _p],

@@ -114,6 +114,7 @@ class HipCircuit:
         device: str | torch.device = "cuda:0",
         use_graph: bool = True,
         graph_min_launches: int = 64,
+        signed_real: bool = True,
         fuse: bool | int = True,
         batch_params: bool = True,
         contraction: str = "f32",
@@ -208,14 +209,23 @@ class HipCircuit:
         self._bindings: dict[int, _Binding] = {}
         self._side: torch.cuda.Stream | None = None  # graphs cannot be captured on the null stream
         depth = 0 if fuse is False else (4 if fuse is True else int(fuse))
+        # A complex-lse-sum circuit whose parameters are all real -- Embedding inputs and plain real sum weights, the
+        # squared circuits of BASELINE config 5 -- is REAL-valued: the reference carries (log|v|, 0 or pi).  Its fused
+        # launches then work on signed linear tiles (ck_leaf.hip, ck_tail16.hip with signed_values) instead of pairs of
+        # complex exponentials; memory blocks stay complex64 as the reference's layer outputs are.
+        self._signed = bool(signed_real) and self._complex and fuse is not False and persistent_leaf is not False and tail16 \
+            and linear_levels and self._is_real_valued()
         self._groups: list[SubtreeGroup] = (
-            find_subtree_groups(plan, self.layers, self._children, self._out_pairs, depth) if fuse is not False else []
+            find_subtree_groups(plan, self.layers, self._children, self._out_pairs, depth, signed=self._signed)
+            if fuse is not False else []
         )
+        if self._signed and (not self._groups or any(g.depth < 1 or self.layers[g.input_layer].num_states >= 65535 for g in self._groups)):
+            self._signed, self._groups = False, []
         self._group_of_root = {g.root: g for g in self._groups}
         self._virtual = {i for g in self._groups for i in g.virtual}
         self._group_dev: dict[int, tuple] = {}
         self._tail: list[int] = (
-            find_tail(plan, self.layers, self._virtual | set(self._group_of_root)) if fuse is not False else []
+            find_tail(plan, self.layers, self._virtual | set(self._group_of_root), signed=self._signed) if fuse is not False else []
         )
         # dense sum layers evaluated inside the Hadamard layer that multiplies them (ck_cp.hip)
         self._table_fused: set[int] = set()  # group roots whose table + dense layer are one prologue job
@@ -239,6 +249,8 @@ class HipCircuit:
             for j, (sp, l) in enumerate(zip(plan.layers, self.layers)):
                 ch = self._children[j]
                 if ch is None or sp.type not in ("cpt", "sum") or (sp.type == "sum" and l.arity != 1):
+                    continue
+                if j in self._virtual or j in self._group_of_root or j in self._tail:
                     continue
                 if l.num_input_units != 32 or l.num_output_units != 32 or l.weight.ops != ["tensor"]:
                     continue
@@ -311,6 +323,26 @@ class HipCircuit:
         if contraction == "f16x3" and not tiled_weights:
             raise ValueError("contraction='f16x3' needs tiled_weights=True")
         self._assign_weight_layouts()
+        if self._signed and self._tail and not self._tail16_ok():
+            self._tail = []  # (only the 16-row tail walks signed values; the layers then take the complex kernels)
+
+    def _is_real_valued(self) -> bool:
+        """Every data input an Embedding layer and every parameter a plain real tensor (no parameter graph beyond the
+        tensor itself): the circuit's values are real numbers, signed."""
+        for l in self.layers:
+            if isinstance(l, HipConstantValueLayer):
+                return False
+            if isinstance(l, HipInputLayer):
+                if not isinstance(l, HipEmbeddingLayer):
+                    return False
+                ps = [l.weight]
+            else:
+                w = getattr(l, "weight", None)
+                ps = [] if w is None else [w]
+            for p in ps:
+                if p.ops != ["tensor"]:
+                    return False
+        return not any(self.store[n].is_complex() for n in self.store.names())
 
     def _assign_weight_layouts(self) -> None:
         """Pick the weight layout of every K = 32 sum layer (ck_tile.h): tiled layouts only where
@@ -718,7 +750,7 @@ class HipCircuit:
 
     def _tail_fuses_ll(self) -> bool:
         """Whether `log_likelihood_sum`'s reduction is part of the tail launch (the circuit output is the scalar root)."""
-        if not self._tail or not self._tail16_ok() or len(self._out_pairs) != 1:
+        if not self._tail or not self._tail16_ok() or len(self._out_pairs) != 1 or self._signed:
             return False
         last = self._tail[-1]
         return (int(self._out_pairs[0, 0]) == last and self.layers[last].num_folds == 1
@@ -730,7 +762,7 @@ class HipCircuit:
         ls = [self.layers[j] for j in self._tail]
         for l in ls:
             if l._w.is_complex():
-                raise ValueError("complex weights under the real lse-sum semiring")
+                raise ValueError("complex weights in the fused tail")
         vp = C.c_void_p * n
         ip = C.c_int32 * n
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
@@ -743,6 +775,7 @@ class HipCircuit:
                     acc += l.num_folds
                 desc = np.zeros(acc, dtype=_TAIL16_FOLD)
                 arena = bd.arena.data_ptr()
+                esz = 8 if self._signed else 4  # (signed: complex64 blocks)
                 for j, l in zip(self._tail, ls):
                     ch = self._children[j]  # (F, H, 2): producer layer, fold
                     off = bd.row_off[j].cpu().numpy()
@@ -750,14 +783,14 @@ class HipCircuit:
                     for f in range(l.num_folds):
                         d = desc[first[j] + f]
                         d["w"] = l._w.data_ptr() + f * Ko * 32 * 4
-                        d["out"] = bd.views[j].data_ptr() + f * bd.B * Ko * 4
+                        d["out"] = bd.views[j].data_ptr() + f * bd.B * Ko * esz
                         d["H"], d["Ko"] = l.arity, Ko
                         d["child_src"][:] = -1
                         for h in range(l.arity):
                             pj, pf = int(ch[f, h, 0]), int(ch[f, h, 1])
                             if pj in first and self.layers[pj].num_output_units == 32:
                                 d["child_src"][h] = first[pj] + pf
-                            d["child"][h] = arena + int(off[f, h]) * 4
+                            d["child"][h] = arena + int(off[f, h]) * esz
                 levels = np.asarray([first[j] for j in self._tail] + [acc], dtype=np.int32)
                 tabs = bd.cp_tabs["tail16"] = (
                     torch.from_numpy(desc.view(np.uint8)).to(self.device), torch.from_numpy(levels).to(self.device), acc,
@@ -768,7 +801,8 @@ class HipCircuit:
             capi.call(
                 "ck_tail16_lse_fwd", desc_dev.data_ptr(), n_folds, levels_dev.data_ptr(), n, bd.B, 32, lay,
                 bd.ll.data_ptr() if fuse_ll else None, scratch.data_ptr() if fuse_ll else None,
-                ticket.data_ptr() if fuse_ll else None, self._bad_input.data_ptr() if self._poison_in_tail() else None, stream,
+                ticket.data_ptr() if fuse_ll else None, self._bad_input.data_ptr() if self._poison_in_tail() else None,
+                1 if self._signed else 0, stream,
             )
             return
         capi.call(
@@ -819,6 +853,8 @@ class HipCircuit:
 
     def _launch_group(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int, *, with_table: bool = False) -> None:
         """One fused launch for Categorical -> [dense] -> CP-T levels (cirkit_amd/csrc/ck_fused.hip)."""
+        if self._signed:
+            return self._launch_group_signed(g, bd, out, stream)
         table, w_dense = self._group_table(g, stream if with_table else None)
         dev = self._group_dev[g.root]
         cat = self.layers[g.input_layer]
@@ -836,7 +872,7 @@ class HipCircuit:
                 "ck_leaf_persistent_fwd", table.data_ptr(), scale.data_ptr(), bd.xt_i.data_ptr(),
                 cat._scope(self.device).data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off, out.data_ptr(),
                 work.data_ptr(), int(work.shape[0]), self._n_cu, self.leaf_waves, g.depth, bd.B, cat.num_output_units,
-                cat.num_categories, 1 if self._preclamp() else 0, stream,
+                cat.num_categories, 1 if self._preclamp() else 0, capi.CK_W_TILED_F32, None, F_root, stream,
             )
             return
         capi.call(
@@ -845,6 +881,31 @@ class HipCircuit:
             None if w_dense is None else w_dense.data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off,
             out.data_ptr(), g.depth, self.layers[g.root].num_folds, bd.B, cat.num_output_units,
             cat.num_categories, self._group_layout(g), stream,
+        )
+
+    def _launch_group_signed(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int) -> None:
+        """Embedding -> CP-T levels of a real-valued complex circuit: the persistent leaf launch on signed linear tiles
+        (the Embedding weight table IS the linear table, scale 0) followed by its marked-tile launch."""
+        emb = self.layers[g.input_layer]
+        dev = self._group_dev.get(g.root)
+        if dev is None or len(dev) < 2:
+            nodes = dev[0] if dev else torch.from_numpy(g.nodes).to(self.device)
+            dev = self._group_dev[g.root] = (
+                nodes, torch.zeros((emb.num_folds, emb.num_states + 1), dtype=torch.float32, device=self.device))
+        levels = (C.c_void_p * g.depth)(*[self.layers[j]._w.data_ptr() for j in g.levels])
+        node_off = (C.c_int32 * (g.depth + 1))(*g.node_off)
+        F_root, n_tiles = self.layers[g.root].num_folds, (bd.B + 31) // 32
+        work = bd.cp_tabs.get((g.root, "leaf_work"))
+        if work is None:
+            work = bd.cp_tabs[(g.root, "leaf_work")] = (
+                torch.from_numpy(leaf_segments(F_root, n_tiles, self._n_cu)).to(self.device),
+                torch.zeros(F_root * n_tiles, dtype=torch.int32, device=self.device))
+        segs, redo = work
+        capi.call(
+            "ck_leaf_persistent_fwd", emb._table.data_ptr(), dev[1].data_ptr(), bd.xt_i.data_ptr(),
+            emb._scope(self.device).data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off, out.data_ptr(),
+            segs.data_ptr(), int(segs.shape[0]), self._n_cu, 8, g.depth, bd.B, emb.num_output_units,
+            emb.num_states, 1 if self._preclamp() else 0, self._group_layout(g), redo.data_ptr(), F_root, stream,
         )
 
     # -- evaluation ------------------------------------------------------------------------------
@@ -1059,6 +1120,8 @@ class HipCircuit:
             return "region_lse_kernel<2, 4, 3>" if l.num_output_units == 64 else "region_lse_kernel<1, 8, 4>"
         if i in self._cp_blocks or i in self._cp_leftover:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
+        if i in self._group_of_root and self._signed:
+            return f"leaf_persistent_kernel<{self._group_of_root[i].depth}, 8, true> (signed: real-valued complex circuit)"
         if i in self._group_of_root:
             g = self._group_of_root[i]
             in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)

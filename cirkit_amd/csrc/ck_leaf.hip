@@ -43,9 +43,11 @@ struct LeafArgs {
   const int32_t* work;  // (n_seg, 4): root fold, first tile, end tile, 0
   int n_seg, B, C;
   int preclamped;  // xt holds -1 .. C - 1 only
+  int32_t* redo;   // SIGNED: (F_root, tiles) flags of the tiles to evaluate again in log space (leaf_signed_redo_kernel)
+  int w_rowmajor;  // the level weights are row-major (F_l, 32, 32) matrices instead of CK_W_TILED_F32
 };
 
-template <int D, int WAVES>
+template <int D, int WAVES, bool SIGNED>
 __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafArgs a) {
   constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2) ? 3 : 2;
   __shared__ __attribute__((aligned(16))) float w_lds[kNodes * 1024];  // subtree weights, in step order
@@ -80,11 +82,13 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       static_for<0, steps_after(i)>([&](auto lc) {
         constexpr int l = decltype(lc)::value, k = steps_before(i) + l;
         const int fold = a.nodes[a.node_off[l + 1] + t * (kLeaves >> (l + 1)) + (i >> (l + 1))];
-        const float* src = a.w[l] + static_cast<int64_t>(fold) * 1024 + lane * 4;
+        // lane's 16 bytes of chunk q: tiled, dword 256 q + 4 lane; row-major, W[lane & 31][8 q + 4 (lane >> 5) ..] (ck_tile.h)
+        const float* src = a.w[l] + static_cast<int64_t>(fold) * 1024 + (a.w_rowmajor ? (lane & 31) * 32 + 4 * (lane >> 5) : lane * 4);
+        const int qstride = a.w_rowmajor ? 8 : 256;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if ((k * 4 + q) % WAVES == wave)
-            __builtin_amdgcn_global_load_lds((ck::gptr_t)(src + q * 256), (ck::lptr_t)(w_lds + k * 1024 + q * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((ck::gptr_t)(src + q * qstride), (ck::lptr_t)(w_lds + k * 1024 + q * 256), 16, 0, 0);
       });
     });
     // per-root constants (scalar registers): variable row of xt and first table row of every leaf
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
 #pragma unroll
             for (int j = 0; j < 16; ++j) cur[j] *= stack[0][j];  // first level: the bare product (ck_tile.h)
           } else {
-            linear_product<true>(cur, stack[l], cs, sstack[l], bad);
+            linear_product<true, SIGNED>(cur, stack[l], cs, sstack[l], bad);
           }
           contract_linear<CK_W_TILED_F32>(wcur, cur);
         });
@@ -216,7 +220,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           sstack[l] = cs;
         }
       });
-      if constexpr (D == 1) bad |= !(tile_row_max(cur) > kLinearFloor);  // (deeper roots are renormalised steps)
+      if constexpr (D == 1) bad |= !((SIGNED ? tile_row_max_abs(cur) : tile_row_max(cur)) > kLinearFloor);  // (deeper roots are renormalised steps)
       if (__builtin_expect(__any(bad), 0)) {
         // rare: a row of products fell out of the fp32 range -> the whole tile again in log space (semiring.py:383-408)
         SubtreeSource src{};
@@ -232,23 +236,76 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         src.C = a.C;
         src.bl = bl;
         float fb[16];  // (its address escapes into the out-of-line call: never `cur`, which must stay in registers)
-        subtree_tile_logspace<D, CK_W_TILED_F32>(src, lane, fb);
-        if (live) tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+        if constexpr (SIGNED) {
+          // (an out-of-line call here costs the hot loop ~100 spilled registers: the tile is marked and evaluated by
+          // leaf_signed_redo_kernel, launched right after this kernel)
+          (void)src;
+          (void)fb;
+          if (lane == 0) a.redo[static_cast<int64_t>(t) * ((a.B + 31) >> 5) + tile] = 1;
+        } else {
+          subtree_tile_logspace<D, CK_W_TILED_F32>(src, lane, fb);
+          if (live) tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+        }
       } else if (live) {
+        if constexpr (SIGNED) {  // the complex logarithm of a real number: (log|v|, 0 or pi)
+          uint32_t sg = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) cur[j] = fmaf(__builtin_amdgcn_logf(cur[j]), kLN2, cs);
-        tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
+          for (int j = 0; j < 16; ++j) {
+            sg |= (cur[j] < 0.f ? 1u : 0u) << j;
+            cur[j] = fmaf(__builtin_amdgcn_logf(__builtin_fabsf(cur[j])), kLN2, cs);
+          }
+          tile_store_clog(a.out + ((static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh) * 2, cur, sg);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) cur[j] = fmaf(__builtin_amdgcn_logf(cur[j]), kLN2, cs);
+          tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
+        }
       }
     }
   }
 }
 
+// The tiles a SIGNED launch marked (a row of products below the linear-space floor), in log space with signs
+// (tile_walk_logspace_signed): one wave per (root, tile); unmarked tiles exit at once.
 template <int D>
-hipError_t launch_waves(const LeafArgs& a, int waves, dim3 grid, hipStream_t s) {
-  if (waves == 12)
-    hipLaunchKernelGGL((leaf_persistent_kernel<D, 12>), grid, dim3(768), 0, s, a);
+__global__ void __launch_bounds__(64) leaf_signed_redo_kernel(const LeafArgs a) {
+  const int tile = blockIdx.x, t = blockIdx.y;
+  int32_t* flag = a.redo + static_cast<int64_t>(t) * gridDim.x + tile;
+  if (*flag == 0) return;
+  const int lane = threadIdx.x, b = tile * 32 + (lane & 31), kh = lane >> 5;
+  SubtreeSource src{};
+  src.table = a.table;
+  src.scale = a.scale;
+  src.xt = a.xt;
+  src.scope = a.scope;
+  src.leaf_ids = a.nodes + a.leaf_off + t * (1 << D);
+  src.fold0 = a.nodes + a.node_off[0] + t * (1 << D);
+  src.w_steps = nullptr;
+  for (int l = 0; l < D; ++l) src.w[l] = a.w[l];
+  src.nodes = a.nodes;
+  for (int l = 0; l <= D; ++l) src.node_off[l] = a.node_off[l];
+  src.t = t;
+  src.B = a.B;
+  src.C = a.C;
+  src.bl = min(b, a.B - 1);
+  float v[16];
+  uint32_t sg = 0;
+  if (a.w_rowmajor) subtree_tile_logspace<D, CK_W_ROWMAJOR, true>(src, lane, v, &sg);
+  else subtree_tile_logspace<D, CK_W_TILED_F32, true>(src, lane, v, &sg);
+  if (b < a.B) tile_store_clog(a.out + ((static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh) * 2, v, sg);
+  if (lane == 0) *flag = 0;  // ready for the next replay
+}
+
+template <int D>
+hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_roots, dim3 grid, hipStream_t s) {
+  if (is_signed) {
+    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true>), grid, dim3(512), 0, s, a);
+    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+    hipLaunchKernelGGL((leaf_signed_redo_kernel<D>), dim3((a.B + 31) / 32, n_roots), dim3(64), 0, s, a);
+  } else if (waves == 12)
+    hipLaunchKernelGGL((leaf_persistent_kernel<D, 12, false>), grid, dim3(768), 0, s, a);
   else
-    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8>), grid, dim3(512), 0, s, a);
+    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false>), grid, dim3(512), 0, s, a);
   return hipGetLastError();
 }
 
@@ -259,7 +316,7 @@ extern "C" {
 int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
                            const float* const* w_levels, const int32_t* nodes, const int32_t* node_off, int leaf_off,
                            float* out, const int32_t* work, int n_seg, int n_wg, int waves, int depth, int B, int K,
-                           int C, int preclamped, void* stream) {
+                           int C, int preclamped, int w_layout, int32_t* signed_redo, int n_roots, void* stream) {
   CK_REQUIRE(table && table_scale && xt && scope && w_levels && nodes && node_off && out && work,
              "ck_leaf_persistent_fwd: null pointer");
   CK_REQUIRE(depth >= 1 && depth <= kMaxDepthP, "ck_leaf_persistent_fwd: depth %d outside [1, %d]", depth, kMaxDepthP);
@@ -285,18 +342,23 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
   a.B = B;
   a.C = C;
   a.preclamped = preclamped;
+  a.redo = signed_redo;
+  CK_REQUIRE(w_layout == CK_W_TILED_F32 || (w_layout == CK_W_ROWMAJOR && signed_redo != nullptr),
+             "ck_leaf_persistent_fwd: weights must be CK_W_TILED_F32 (signed launches: or row-major)");
+  a.w_rowmajor = w_layout == CK_W_ROWMAJOR ? 1 : 0;
+  CK_REQUIRE(signed_redo == nullptr || (n_roots > 0 && n_roots <= 65535), "ck_leaf_persistent_fwd: signed launch needs 0 < n_roots <= 65535");
   dim3 grid(static_cast<unsigned>(std::min(n_wg, n_seg)));
   return ck::dispatch(
       [=](hipStream_t s) {
         switch (depth) {
           case 1:
-            return launch_waves<1>(a, waves, grid, s);
+            return launch_waves<1>(a, waves, signed_redo != nullptr, n_roots, grid, s);
           case 2:
-            return launch_waves<2>(a, waves, grid, s);
+            return launch_waves<2>(a, waves, signed_redo != nullptr, n_roots, grid, s);
           case 3:
-            return launch_waves<3>(a, waves, grid, s);
+            return launch_waves<3>(a, waves, signed_redo != nullptr, n_roots, grid, s);
           default:
-            return launch_waves<4>(a, waves, grid, s);
+            return launch_waves<4>(a, waves, signed_redo != nullptr, n_roots, grid, s);
         }
       },
       stream);

@@ -47,9 +47,13 @@ struct Tail16Args {
   int n_folds, n_levels, B;
 };
 
-template <int LAYOUT>
+// SIGNED: a real-valued circuit under complex-lse-sum (semiring.py:441-476): memory blocks are (B, Ko) complex64 holding
+// (log|v|, 0 or pi); inside the walk a value is (log|v|, sign bit) -- one word of sign bits per lane and fold in LDS next
+// to the fold's tile.  A product adds the logarithms and xors the signs, a sum step exponentiates with the sign.
+template <int LAYOUT, bool SIGNED>
 __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16Args a) {
-  // [tail fold][beta][lane] float4 tiles (2 KB each), then the fold descriptors and the level table
+  // [tail fold][beta][lane] float4 tiles (2 KB each), (SIGNED: [tail fold][lane] sign words,) then the fold descriptors and
+  // the level table
   extern __shared__ __attribute__((aligned(16))) float tiles[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 15, kq = lane >> 4;
@@ -58,7 +62,8 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
   const int bl = live ? b : a.B - 1;
   // The descriptors of all folds and the level table go to LDS first -- one 16-byte load per thread, all in flight at
   // once: afterwards nothing in the walk waits for an index or a pointer from memory.
-  FoldDesc* s_fold = reinterpret_cast<FoldDesc*>(tiles + a.n_folds * 512);
+  uint32_t* s_sign = reinterpret_cast<uint32_t*>(tiles + a.n_folds * 512);
+  FoldDesc* s_fold = reinterpret_cast<FoldDesc*>(tiles + a.n_folds * (SIGNED ? 576 : 512));
   int32_t* s_level = reinterpret_cast<int32_t*>(s_fold + a.n_folds);
   {
     const int n16 = a.n_folds * static_cast<int>(sizeof(FoldDesc) / 16);
@@ -79,9 +84,10 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
     }
   };
   auto first_fold_of = [&](int li) { return li < a.n_levels && s_level[li] + wave < s_level[li + 1] ? s_level[li] + wave : -1; };
-  auto gather = [&](int t, float (&v)[8]) {
+  auto gather = [&](int t, float (&v)[8], uint32_t& sg) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    sg = 0;
     const int H = s_fold[t].H;
     for (int h = 0; h < H; ++h) {
       const int src = s_fold[t].child_src[h];
@@ -95,6 +101,19 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
           v[4 * beta + 2] += t4.z;
           v[4 * beta + 3] += t4.w;
         }
+        if constexpr (SIGNED) sg ^= s_sign[src * 64 + lane];
+      } else if constexpr (SIGNED) {
+        // (B, 32) complex64: units 16 beta + 4 kq + r of row b are the 8 floats at 2 (32 b + 16 beta + 4 kq)
+        const float* row = s_fold[t].child[h] + (static_cast<int64_t>(bl) * kK + 4 * kq) * 2;
+#pragma unroll
+        for (int beta = 0; beta < 2; ++beta) {
+          const float4 c0 = *reinterpret_cast<const float4*>(row + 32 * beta), c1 = *reinterpret_cast<const float4*>(row + 32 * beta + 4);
+          v[4 * beta + 0] += c0.x;
+          v[4 * beta + 1] += c0.z;
+          v[4 * beta + 2] += c1.x;
+          v[4 * beta + 3] += c1.z;
+          sg ^= ((c0.y > 1.5f ? 1u : 0u) | (c0.w > 1.5f ? 2u : 0u) | (c1.y > 1.5f ? 4u : 0u) | (c1.w > 1.5f ? 8u : 0u)) << (4 * beta);
+        }
       } else {
         tile16_load_add(s_fold[t].child[h] + static_cast<int64_t>(bl) * kK + 4 * kq, v);
       }
@@ -107,23 +126,33 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
     // with those of the first one
     const int t2 = s_level[li] + wave + kTail16Waves;
     float v2[8];
-    if (t2 < t1) gather(t2, v2);
+    uint32_t sg2 = 0;
+    if (t2 < t1) gather(t2, v2, sg2);
     for (int t = s_level[li] + wave; t < t1; t += kTail16Waves) {
       float v[8];
+      uint32_t sg = 0;
       if (t == t2) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v2[j];
+        sg = sg2;
       } else {
-        gather(t, v);
+        gather(t, v, sg);
       }
       const int Ko = s_fold[t].Ko;
       float* out = s_fold[t].out;
       const int t_next = t + kTail16Waves < t1 ? t + kTail16Waves : first_fold_of(li + 1);
       if (Ko == kK) {
         if (w_for != t) load_w16<LAYOUT>(s_fold[t].w, lane, w);
-        sum_step16(w, v);
-        prefetch(t_next);
-        if (live) tile16_store(out + static_cast<int64_t>(b) * kK + 4 * kq, v);
+        if constexpr (SIGNED) {
+          sum_step16_signed(w, v, sg);
+          prefetch(t_next);
+          if (live) tile16_store_clog(out + (static_cast<int64_t>(b) * kK + 4 * kq) * 2, v, sg);
+          s_sign[t * 64 + lane] = sg;
+        } else {
+          sum_step16(w, v);
+          prefetch(t_next);
+          if (live) tile16_store(out + static_cast<int64_t>(b) * kK + 4 * kq, v);
+        }
         float* tl = tiles + t * 512 + lane * 4;
 #pragma unroll
         for (int beta = 0; beta < 2; ++beta)
@@ -135,7 +164,10 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
         const float m = ck::clamp_finite(row_max8(v));
         const float nml = exp_offset(m, 0.f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_exp2f(fmaf(v[j], kL2E, nml));
+        for (int j = 0; j < 8; ++j) {
+          v[j] = __builtin_amdgcn_exp2f(fmaf(v[j], kL2E, nml));
+          if constexpr (SIGNED) v[j] = (sg >> j) & 1u ? -v[j] : v[j];
+        }
         for (int o = 0; o < Ko; ++o) {
           const float* wrow = wf + o * kK + 4 * kq;
           float acc = 0.f;
@@ -148,9 +180,14 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
             acc = fmaf(w4.w, v[4 * beta + 3], acc);
           }
           acc = xquad_sum(acc);
-          float y = fmaf(__builtin_amdgcn_logf(acc), kLN2, m);
+          float y = fmaf(__builtin_amdgcn_logf(SIGNED ? __builtin_fabsf(acc) : acc), kLN2, m);
           if (poison) y = __builtin_nanf("");  // an out-of-range category somewhere in the batch (the reference raises)
-          if (live && kq == 0) out[static_cast<int64_t>(b) * Ko + o] = y;
+          if constexpr (SIGNED) {
+            if (live && kq == 0)
+              *reinterpret_cast<float2*>(out + (static_cast<int64_t>(b) * Ko + o) * 2) = make_float2(y, acc < 0.f ? 3.14159265358979323846f : 0.f);
+          } else {
+            if (live && kq == 0) out[static_cast<int64_t>(b) * Ko + o] = y;
+          }
           if (a.ll != nullptr && t == a.n_folds - 1) {
             // sum of this workgroup's (up to) 16 root values, rows in order, in double precision
             double s = 0.0;
@@ -197,7 +234,7 @@ extern "C" {
 
 int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* level_begin, int n_levels, int B, int K,
                       int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, const int32_t* bad_input,
-                      void* stream) {
+                      int signed_values, void* stream) {
   CK_REQUIRE(folds && level_begin, "ck_tail16_lse_fwd: null pointer");
   CK_REQUIRE(n_folds > 0 && n_folds <= kTail16MaxFolds, "ck_tail16_lse_fwd: n_folds=%d outside [1, %d]", n_folds, kTail16MaxFolds);
   CK_REQUIRE(n_levels > 0 && n_levels <= kTail16MaxLevels, "ck_tail16_lse_fwd: n_levels=%d outside [1, %d]", n_levels, kTail16MaxLevels);
@@ -207,6 +244,7 @@ int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* l
     return ck::fail(CK_ERR_UNSUPPORTED, "ck_tail16_lse_fwd: w_layout %d (row-major or tiled fp32 only)", w_layout);
   CK_REQUIRE(ll == nullptr || (ll_partial != nullptr && ll_ticket != nullptr), "ck_tail16_lse_fwd: ll needs ll_partial and ll_ticket");
   CK_REQUIRE(ck::aligned16(folds), "ck_tail16_lse_fwd: folds not 16-byte aligned");
+  CK_REQUIRE(!signed_values || ll == nullptr, "ck_tail16_lse_fwd: no log-likelihood sum of signed (complex) outputs");
   Tail16Args a{};
   a.folds = reinterpret_cast<const FoldDesc*>(folds);
   a.level_begin = level_begin;
@@ -217,21 +255,20 @@ int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* l
   a.ll_partial = ll_partial;
   a.ll_ticket = ll_ticket;
   a.bad_input = bad_input;
-  const size_t lds = static_cast<size_t>(n_folds) * (512 * sizeof(float) + sizeof(FoldDesc)) + (n_levels + 1) * sizeof(int32_t) + 16;
+  const size_t lds = static_cast<size_t>(n_folds) * ((signed_values ? 576 : 512) * sizeof(float) + sizeof(FoldDesc)) + (n_levels + 1) * sizeof(int32_t) + 16;
   dim3 grid((B + 15) / 16), block(kTail16Waves * 64);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipError_t e = hipSuccess;
-        if (w_layout == CK_W_ROWMAJOR) {
-          if (lds > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail16_kernel<CK_W_ROWMAJOR>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-          if (e != hipSuccess) return e;
-          hipLaunchKernelGGL(tail16_kernel<CK_W_ROWMAJOR>, grid, block, lds, s, a);
-        } else {
-          if (lds > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail16_kernel<CK_W_TILED_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-          if (e != hipSuccess) return e;
-          hipLaunchKernelGGL(tail16_kernel<CK_W_TILED_F32>, grid, block, lds, s, a);
-        }
-        return hipGetLastError();
+        auto go = [&](auto kern) {
+          if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+          }
+          hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+          return hipGetLastError();
+        };
+        if (signed_values) return w_layout == CK_W_ROWMAJOR ? go(tail16_kernel<CK_W_ROWMAJOR, true>) : go(tail16_kernel<CK_W_TILED_F32, true>);
+        return w_layout == CK_W_ROWMAJOR ? go(tail16_kernel<CK_W_ROWMAJOR, false>) : go(tail16_kernel<CK_W_TILED_F32, false>);
       },
       stream);
 }

@@ -215,14 +215,23 @@ __device__ __forceinline__ float tile_row_max(const float (&p)[16]) {
   return ck::xhalf_max(m);
 }
 
+// the same of |p| (SIGNED tiles: a real-valued circuit under complex-lse-sum carries signed linear values; the sign is
+// the phase 0 / pi of the reference's complex logarithm, semiring.py:441-476)
+__device__ __forceinline__ float tile_row_max_abs(const float (&p)[16]) {
+  float m = __builtin_fabsf(p[0]);
+#pragma unroll
+  for (int j = 1; j < 16; j += 3) m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(p[j])), __builtin_fmaxf(__builtin_fabsf(p[j + 1]), __builtin_fabsf(p[j + 2])));
+  return ck::xhalf_max(m);
+}
+
 // cur <- cur * sib (renormalised), s <- s_cur + s_sib (+ k ln 2)
-template <bool RESCALE>
+template <bool RESCALE, bool SIGNED = false>
 __device__ __forceinline__ void linear_product(float (&cur)[16], const float (&sib)[16], float& s, float s_sib, bool& bad) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) cur[j] *= sib[j];
   s += s_sib;
   if constexpr (RESCALE) {
-    const float mx = tile_row_max(cur);
+    const float mx = SIGNED ? tile_row_max_abs(cur) : tile_row_max(cur);
     const int k = __builtin_amdgcn_frexp_expf(mx);  // mx = f 2^k, f in [0.5, 1)
     const float sc = __builtin_amdgcn_ldexpf(1.f, -k);
     bad |= !(mx > kLinearFloor);
@@ -282,6 +291,57 @@ __device__ __forceinline__ void tile_walk_logspace(LeafFn&& leaf, WFn&& weights,
   });
 }
 
+// The same walk for SIGNED values: a node is (log|v|, sign) -- the reference's complex logarithm of a real number,
+// (log|v|, 0 or pi) -- `sg` holds the 16 sign bits of a lane's registers.  A product adds the logarithms and xors the
+// signs; a sum step exponentiates with the sign, contracts, and takes log|y| and the sign of y.
+template <int LAYOUT>
+__device__ __forceinline__ void sum_step_signed(const WRegs& w, float (&v)[16], uint32_t& sg) {
+  static_assert(LAYOUT != CK_W_TILED_F16X3, "exact fp32 contraction only");
+  const float m = row_max16(v);
+  const float nml = exp_offset(m, 0.f);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float e = __builtin_amdgcn_exp2f(fmaf(v[j], kL2E, nml));
+    v[j] = (sg >> j) & 1u ? -e : e;
+  }
+  contract_linear<LAYOUT>(w, v);
+  sg = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    sg |= (v[j] < 0.f ? 1u : 0u) << j;
+    v[j] = fmaf(__builtin_amdgcn_logf(__builtin_fabsf(v[j])), kLN2, m);
+  }
+}
+template <int D, int LAYOUT, class LeafFn, class WFn>
+__device__ __forceinline__ void tile_walk_logspace_signed(LeafFn&& leaf, WFn&& weights, float (&cur)[16], uint32_t& sg) {
+  float stack[D][16];
+  uint32_t sstack[D];
+  static_for<0, (1 << D)>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const float s = leaf(ic, cur);
+    sg = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      sg |= (cur[j] < 0.f ? 1u : 0u) << j;
+      cur[j] = logf(__builtin_fabsf(cur[j])) + s;
+    }
+    static_for<0, steps_after(i)>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cur[j] += stack[l][j];
+      sg ^= sstack[l];
+      WRegs w;
+      weights(std::integral_constant<int, steps_before(i) + l>{}, ic, lc, w);
+      sum_step_signed<LAYOUT>(w, cur, sg);
+    });
+    if constexpr (steps_after(i) < D) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) stack[steps_after(i)][j] = cur[j];
+      sstack[steps_after(i)] = sg;
+    }
+  });
+}
+
 __device__ __forceinline__ void tile_load(const float* __restrict__ src_row, float (&v)[16]);
 
 // Where the log-space fallback of a fused leaf launch finds its operands (plain pointers and ints: the fallback is an
@@ -300,27 +360,32 @@ struct SubtreeSource {
   int t, B, C, bl;
 };
 
-template <int D, int LAYOUT>
-__device__ __noinline__ void subtree_tile_logspace(const SubtreeSource src, int lane, float (&out)[16]) {
+template <int D, int LAYOUT, bool SIGNED = false>
+__device__ __noinline__ void subtree_tile_logspace(const SubtreeSource src, int lane, float (&out)[16], uint32_t* sign_out = nullptr) {
   const int kh = lane >> 5;
-  tile_walk_logspace<D, LAYOUT>(
-      [&](auto ic, float (&v)[16]) {
-        constexpr int i = decltype(ic)::value;
-        const int x = src.xt[src.scope[src.leaf_ids[i]] * static_cast<int64_t>(src.B) + src.bl];
-        const int64_t r = static_cast<int64_t>(src.fold0[i]) * (src.C + 1) + (x < 0 ? src.C : min(x, src.C - 1));
-        tile_load(src.table + r * kK + 4 * kh, v);
-        return src.scale[r];
-      },
-      [&](auto sc, auto ic, auto lc, WRegs& w) {
-        constexpr int i = decltype(ic)::value, l = decltype(lc)::value;
-        if (src.w_steps != nullptr) {
-          load_w<CK_W_TILED_F32>(src.w_steps + decltype(sc)::value * 1024, lane, w);  // (tiled layouts: one KiB per q)
-        } else {
-          const int fold = src.nodes[src.node_off[l + 1] + src.t * ((1 << D) >> (l + 1)) + (i >> (l + 1))];
-          load_w<LAYOUT>(src.w[l] + static_cast<int64_t>(fold) * (kK * kK), lane, w);
-        }
-      },
-      out);
+  auto leaf = [&](auto ic, float (&v)[16]) {
+    constexpr int i = decltype(ic)::value;
+    const int x = src.xt[src.scope[src.leaf_ids[i]] * static_cast<int64_t>(src.B) + src.bl];
+    const int64_t r = static_cast<int64_t>(src.fold0[i]) * (src.C + 1) + (x < 0 ? src.C : min(x, src.C - 1));
+    tile_load(src.table + r * kK + 4 * kh, v);
+    return src.scale[r];
+  };
+  auto weights = [&](auto sc, auto ic, auto lc, WRegs& w) {
+    constexpr int i = decltype(ic)::value, l = decltype(lc)::value;
+    if (src.w_steps != nullptr) {
+      load_w<CK_W_TILED_F32>(src.w_steps + decltype(sc)::value * 1024, lane, w);  // (tiled layouts: one KiB per q)
+    } else {
+      const int fold = src.nodes[src.node_off[l + 1] + src.t * ((1 << D) >> (l + 1)) + (i >> (l + 1))];
+      load_w<LAYOUT>(src.w[l] + static_cast<int64_t>(fold) * (kK * kK), lane, w);
+    }
+  };
+  if constexpr (SIGNED) {
+    uint32_t sg = 0;
+    tile_walk_logspace_signed<D, LAYOUT>(leaf, weights, out, sg);
+    *sign_out = sg;
+  } else {
+    tile_walk_logspace<D, LAYOUT>(leaf, weights, out);
+  }
 }
 
 // Read one (32 rows x 32 units) tile of a (B, 32) block in register layout, adding it to v.
@@ -343,6 +408,19 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ src_row, flo
     v[4 * g + 1] = t4.y;
     v[4 * g + 2] = t4.z;
     v[4 * g + 3] = t4.w;
+  }
+}
+
+// The tile as complex logarithms of real numbers, (v[j], pi if bit j of sg else 0), into a (B, 32) complex64 block:
+// dst_row points at the lane's first complex element (float offset 2 (32 b + 4 kh) of the block).
+__device__ __forceinline__ void tile_store_clog(float* __restrict__ dst_row, const float (&v)[16], uint32_t sg) {
+  constexpr float kPi = 3.14159265358979323846f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float p0 = (sg >> (4 * g)) & 1u ? kPi : 0.f, p1 = (sg >> (4 * g + 1)) & 1u ? kPi : 0.f;
+    const float p2 = (sg >> (4 * g + 2)) & 1u ? kPi : 0.f, p3 = (sg >> (4 * g + 3)) & 1u ? kPi : 0.f;
+    *reinterpret_cast<float4*>(dst_row + 16 * g) = make_float4(v[4 * g + 0], p0, v[4 * g + 1], p1);
+    *reinterpret_cast<float4*>(dst_row + 16 * g + 4) = make_float4(v[4 * g + 2], p2, v[4 * g + 3], p3);
   }
 }
 

@@ -90,6 +90,37 @@ __device__ __forceinline__ void sum_step16(const WRegs16& w, float (&v)[8]) {
   for (int j = 0; j < 8; ++j) v[j] = fmaf(__builtin_amdgcn_logf(v[j]), kLN2, m);
 }
 
+// The same for SIGNED values (log|v|, sign bit j of sg): exp with the sign, contraction, log|y| and the sign of y
+__device__ __forceinline__ void sum_step16_signed(const WRegs16& w, float (&v)[8], uint32_t& sg) {
+  const float m = ck::clamp_finite(row_max8(v));
+  const float nml = exp_offset(m, 0.f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float e = __builtin_amdgcn_exp2f(fmaf(v[j], kL2E, nml));
+    v[j] = (sg >> j) & 1u ? -e : e;
+  }
+  contract16(w, v);
+  sg = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sg |= (v[j] < 0.f ? 1u : 0u) << j;
+    v[j] = fmaf(__builtin_amdgcn_logf(__builtin_fabsf(v[j])), kLN2, m);
+  }
+}
+
+// the tile as complex logarithms (v[j], pi if bit j of sg else 0) into a (B, 32) complex64 block; row_kq points at the
+// lane's first complex element (float offset 2 (32 b + 4 kq))
+__device__ __forceinline__ void tile16_store_clog(float* __restrict__ row_kq, const float (&v)[8], uint32_t sg) {
+  constexpr float kPi = 3.14159265358979323846f;
+#pragma unroll
+  for (int beta = 0; beta < 2; ++beta) {
+    const float p0 = (sg >> (4 * beta)) & 1u ? kPi : 0.f, p1 = (sg >> (4 * beta + 1)) & 1u ? kPi : 0.f;
+    const float p2 = (sg >> (4 * beta + 2)) & 1u ? kPi : 0.f, p3 = (sg >> (4 * beta + 3)) & 1u ? kPi : 0.f;
+    *reinterpret_cast<float4*>(row_kq + 32 * beta) = make_float4(v[4 * beta + 0], p0, v[4 * beta + 1], p1);
+    *reinterpret_cast<float4*>(row_kq + 32 * beta + 4) = make_float4(v[4 * beta + 2], p2, v[4 * beta + 3], p3);
+  }
+}
+
 // (B, 32) blocks <-> register tile: lane (b, kq) moves 2 x 16 bytes of row b (units 16 beta + 4 kq ..)
 __device__ __forceinline__ void tile16_load(const float* __restrict__ row_kq, float (&v)[8]) {
 #pragma unroll

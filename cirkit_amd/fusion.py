@@ -62,15 +62,18 @@ def _uses_each_fold_once(ch: np.ndarray, producer: int, n_folds: int) -> bool:
     return len(folds) == n_folds and np.array_equal(folds, np.arange(n_folds))
 
 
-def find_subtree_groups(plan, layers, children, out_pairs, max_depth: int = MAX_DEPTH) -> list[SubtreeGroup]:
-    """`layers`: the HipLayer objects; `children[j]`: (F_j, H_j, 2) producer/fold pairs or None."""
-    if plan.semiring != "lse-sum":
+def find_subtree_groups(plan, layers, children, out_pairs, max_depth: int = MAX_DEPTH, *,
+                        signed: bool = False) -> list[SubtreeGroup]:
+    """`layers`: the HipLayer objects; `children[j]`: (F_j, H_j, 2) producer/fold pairs or None.
+    `signed`: a real-valued circuit under complex-lse-sum -- the leaves are Embedding layers (signed table rows), the
+    levels CP-T layers with plain real weights, no dense layer in between (ck_leaf_persistent_fwd with signed_redo)."""
+    if plan.semiring != ("complex-lse-sum" if signed else "lse-sum"):
         return []
     max_depth = max(0, min(int(max_depth), MAX_DEPTH))
     cons = _consumers(children, out_pairs, len(layers))
     groups: list[SubtreeGroup] = []
     for i0, (spec, l) in enumerate(zip(plan.layers, layers)):
-        if spec.type != "categorical" or l.num_output_units != FUSED_K or spec.scope_idx.shape[1] != 1:
+        if spec.type != ("embedding" if signed else "categorical") or l.num_output_units != FUSED_K or spec.scope_idx.shape[1] != 1:
             continue
         cur, dense, levels = i0, None, []
         while len(cons[cur]) == 1:
@@ -84,7 +87,7 @@ def find_subtree_groups(plan, layers, children, out_pairs, max_depth: int = MAX_
                 break
             if getattr(lj, "_mixing", False):
                 break
-            if sj.type == "sum" and lj.arity == 1 and cur == i0 and dense is None:
+            if sj.type == "sum" and lj.arity == 1 and cur == i0 and dense is None and not signed:
                 dense = j
             elif sj.type == "cpt" and lj.arity == 2 and len(levels) < max_depth:
                 levels.append(j)
@@ -122,11 +125,11 @@ def find_subtree_groups(plan, layers, children, out_pairs, max_depth: int = MAX_
 MAX_TAIL_LAYERS = 12
 
 
-def find_tail(plan, layers, skip: set[int], max_folds: int = 64) -> list[int]:
+def find_tail(plan, layers, skip: set[int], max_folds: int = 64, *, signed: bool = False) -> list[int]:
     """Trailing layers with few folds that `ck_tail_lse_fwd` evaluates in one launch: real CP-T /
     dense sum steps with 32 input units, 32 output units (fewer only for terminal layers, e.g. the
     scalar root), at most `max_folds` folds each."""
-    if plan.semiring != "lse-sum":
+    if plan.semiring != ("complex-lse-sum" if signed else "lse-sum"):
         return []
     tail: list[int] = []
     for i in range(len(layers) - 1, -1, -1):

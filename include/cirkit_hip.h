@@ -254,11 +254,19 @@ int ck_subtree_cat_cpt_fwd(const float* table, const float* table_scale, const i
  * segment list (cirkit_amd/circuit.py: whole roots split evenly over the CUs of one XCD).  preclamped != 0: xt holds
  * -1 .. C - 1 only (ck_stage_categories with clamp != 0): the table row is then min_u32(x, C) -- the integral row C for
  * the marginalisation sentinel -- instead of a compare, a select and a minimum.  Reference semantics as
- * ck_subtree_cat_cpt_fwd. */
+ * ck_subtree_cat_cpt_fwd.
+ * signed_redo != NULL: the table rows are SIGNED linear values (an Embedding layer's weights, layers/input.py:258-266)
+ * and the weights may be signed: a real-valued circuit under complex-lse-sum (semiring.py:441-476), whose activations
+ * the reference carries as complex logarithms (log|v|, 0 or pi).  The same walk on signed tiles (renormalised by the
+ * largest magnitude of a row); `out` is then (F_root, B, 32) complex64: out = (log|v|, pi if v < 0 else 0).  8 waves.
+ * signed_redo is a workspace of n_roots * ceil(B / 32) int32, ZERO on entry and zero again afterwards: tiles whose
+ * products left the linear-space range are marked there and evaluated again, in log space with signs, by a second
+ * launch in which every other wave exits at once.  n_roots = folds of the root layer (only read for signed launches).
+ * w_layout: CK_W_TILED_F32; a signed launch also takes CK_W_ROWMAJOR (plain (F_l, 32, 32) parameter tensors). */
 int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
                            const float* const* w_levels, const int32_t* nodes, const int32_t* node_off, int leaf_off,
                            float* out, const int32_t* work, int n_seg, int n_wg, int waves, int depth, int B, int K,
-                           int C, int preclamped, void* stream);
+                           int C, int preclamped, int w_layout, int32_t* signed_redo, int n_roots, void* stream);
 
 /* The last `n_layers` levels of a circuit (few folds each) in one launch: one workgroup per 32-row
  * batch tile walks the layers in order, a workgroup barrier between levels.  Layer i is a
@@ -290,9 +298,11 @@ typedef struct ck_tail16_fold {
   int32_t H, Ko;
   int32_t pad[2];
 } ck_tail16_fold;
+/* signed_values != 0: a real-valued circuit under complex-lse-sum (semiring.py:441-476): every block in memory (children,
+ * outputs) is (B, Ko) complex64 holding (log|v|, 0 or pi), the weights may be signed; `ll` must then be NULL. */
 int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* level_begin, int n_levels, int B, int K,
                       int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, const int32_t* bad_input,
-                      void* stream);
+                      int signed_values, void* stream);
 
 /* ---------------------------------------------------------------- parameter graphs --------- */
 /* The reference re-evaluates each layer's parameter DAG on every forward

@@ -193,6 +193,110 @@ def test_real_input_layers_in_a_complex_circuit(hip_device, name):
     _check_layers(plan, tensors, x, hc)
 
 
+def _fp64_outputs(plan, tensors, x):
+    """Every layer of the plan evaluated by the oracle in fp64 / complex128 (the whole circuit, un-isolated)."""
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    t64 = {k: (v.to(torch.complex128) if v.is_complex() else v.double()) for k, v in as_torch(tensors).items()}
+    torch.set_default_dtype(torch.float64)
+    try:
+        return evaluate_plan(plan, t64, x, return_all=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_real_valued_complex_circuit_whole_chain_against_fp64(hip_device):
+    """Config 5 with the WHOLE chain under one check: the circuit's parameters are real, so c(x) is a real number and
+    the fused launches work on signed linear tiles (ck_leaf.hip / ck_tail16.hip, signed).  Every materialised layer
+    output -- not each layer in isolation -- against the oracle in fp64: Re within 1e-4 of the layer's scale, the phase
+    as a unit vector, and never worse than twice the reference's own fp32 run."""
+    from cirkit_amd.circuit import HipCircuit
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan, tensors, g = load_case("cfg5_sos_c_k32")
+    x = _x_of(plan, g)
+    hc = HipCircuit(plan, tensors, device=hip_device)
+    assert hc._signed and hc._groups and hc._tail
+    y = hc(x.to(hip_device)).cpu()
+    outs = hc.layer_outputs(x.to(hip_device))
+    torch.cuda.synchronize()
+    y64, outs64 = _fp64_outputs(plan, tensors, x)
+    _, outs32 = evaluate_plan(plan, as_torch(tensors), x, return_all=True)
+    def lin(z, m):  # the value relative to the largest magnitude of its row: what the next sum layer consumes
+        return torch.exp(z.real - m) * torch.cos(z.imag)
+
+    checked = 0
+    for i, (a, r64, r32) in enumerate(zip(outs, outs64, outs32)):
+        if a is None:
+            continue
+        a = a.cpu().to(torch.complex128)
+        assert bool(((a.imag == 0) | ((a.imag - np.pi).abs() < 1e-6)).all())  # phases 0 / pi exactly on this path
+        m = r64.real.amax(dim=-1, keepdim=True)
+        z64, zh, z32 = lin(r64, m), lin(a, m), lin(r32.to(torch.complex128), m)
+        err, own = float((zh - z64).abs().max()), float((z32 - z64).abs().max())
+        # signed sums cancel: an entry is only as accurate as fp32 allows RELATIVE TO ITS ROW -- the measure is the
+        # linear value over the row's largest magnitude, and the reference's own fp32 run is the yardstick
+        assert err <= max(2e-5, 2 * own), (i, plan.layers[i].type, err, own)
+        big = z64.abs() >= 0.1  # well-conditioned entries: also in log space, 1e-4 of the layer's scale
+        scale = max(1.0, float(r64.real.abs().max()))
+        assert float((a.real - r64.real)[big].abs().max()) <= 1e-4 * scale, (i, plan.layers[i].type)
+        assert bool((torch.cos(a.imag)[big] * torch.cos(r64.imag)[big] > 0).all()), (i, "sign")
+        checked += 1
+    assert checked >= 2  # the roots of the fused leaf launch and the circuit output
+    assert float(((y.real.double() - y64.real).abs() / y64.real.abs()).max()) <= REL
+
+
+def test_signed_tiles_fall_back_to_log_space(hip_device):
+    """Embedding rows that are one-hot at DIFFERENT units for sibling variables: every product of the first levels is
+    tiny (1e-30 squared), far below the linear-space floor, yet a legitimate value in log space.  The signed leaf launch
+    marks those tiles and its second launch evaluates them in log space with signs: same result as the layer-by-layer
+    complex kernels and the oracle."""
+    from cirkit_amd.circuit import HipCircuit
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan, tensors, g = load_case("cfg5_sos_c_k32")
+    tensors = {k: np.array(v, copy=True) for k, v in tensors.items()}
+    emb = next(l for l in plan.layers if l.type == "embedding")
+    wname = emb.params["weight"].nodes[0].config["tensor"]
+    w = tensors[wname]  # (784, 32, 256)
+    F = w.shape[0]
+    hot = np.full_like(w, 1e-30)
+    sign = np.where(np.arange(F) % 3 == 0, -1.0, 1.0).astype(w.dtype)
+    hot[np.arange(F), np.arange(F) % 32, :] = 1.0
+    tensors[wname] = hot * sign[:, None, None]
+    x = _x_of(plan, g)
+    want = evaluate_plan(plan, as_torch(tensors), x)
+    assert bool(torch.isfinite(want.real).all())
+    hs = HipCircuit(plan, tensors, device=hip_device)
+    hl = HipCircuit(plan, tensors, device=hip_device, signed_real=False)
+    assert hs._signed and not hl._signed
+    for _ in range(2):  # (twice: the marked-tile workspace must be clean again)
+        ys, yl = hs(x.to(hip_device)).cpu(), hl(x.to(hip_device)).cpu()
+        for got in (ys, yl):
+            assert float(((got.real - want.real).abs() / want.real.abs().clamp_min(1.0)).max()) <= 1e-4
+            assert float((torch.exp(1j * got.imag) - torch.exp(1j * want.imag)).abs().max()) <= 5e-3
+    assert all(int(v[1].abs().sum()) == 0 for k, v in hs._bindings[x.shape[0]].cp_tabs.items() if isinstance(k, tuple) and k[1] == "leaf_work")
+
+
+@pytest.mark.parametrize("B", [1, 33, 100])
+def test_signed_path_ragged_batches(hip_device, B):
+    """The signed launches at batch sizes that are not multiples of their tiles, against the oracle and the
+    layer-by-layer complex kernels."""
+    from cirkit_amd.circuit import HipCircuit
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan, tensors, _ = load_case("cfg5_sos_c_k32")
+    gen = torch.Generator().manual_seed(B)
+    x = torch.randint(0, 256, (B, 784), generator=gen)
+    hs = HipCircuit(plan, tensors, device=hip_device)
+    hl = HipCircuit(plan, tensors, device=hip_device, signed_real=False)
+    want = evaluate_plan(plan, as_torch(tensors), x)
+    ys, yl = hs(x.to(hip_device)).cpu(), hl(x.to(hip_device)).cpu()
+    for got in (ys, yl):
+        assert float(((got.real - want.real).abs() / want.real.abs()).max()) <= REL
+        assert float((torch.exp(1j * got.imag) - torch.exp(1j * want.imag)).abs().max()) <= 5e-3
+
+
 def test_mfma_and_generic_sum_kernels_agree(hip_device):
     from cirkit_amd import _capi as capi
     from cirkit_amd.circuit import HipCircuit
