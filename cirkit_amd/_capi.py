@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1

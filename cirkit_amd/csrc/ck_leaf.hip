@@ -149,22 +149,31 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       dma(r, i % kSlots);
       sld[i & 3] = a.scale[r];
     };
-    int tile = tile_begin + wave;
+    // The tiles of a segment in chunks of 64 x WAVES (one chunk, normally): a wave notes the tiles whose products left the
+    // linear range in a 64-bit mask (scalar registers) and evaluates them in log space AFTER its walk over the chunk.
+    // Doing that inside the walk -- an out-of-line call with the whole walk state live -- cost the hot loop its
+    // registers (256 + spills against 237; 79 -> 74.5 us at the north-star configuration).
     int32_t xnext[kLeaves];        // batch values of the NEXT tile of this wave (requested one tile ahead)
     uint32_t cat[kLeaves / 2];     // packed categories of the current tile
-    if (tile < tile_end) {  // the first tile of the wave: the chain is paid once per segment
+    for (int chunk_begin = tile_begin; chunk_begin < tile_end; chunk_begin += 64 * WAVES) {
+    const int chunk_end = min(tile_end, chunk_begin + 64 * WAVES);
+    int tile = chunk_begin + wave;
+    if (tile < chunk_end) {  // the first tile of the wave: the chain is paid once per chunk
       load_x(tile, xnext);
       pack_categories(xnext, cat);
       static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
-      load_x(min(tile + WAVES, tile_end - 1), xnext);
+      load_x(min(tile + WAVES, chunk_end - 1), xnext);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the weights (and its first leaf rows) have landed
-    __syncthreads();
+    if (chunk_begin == tile_begin) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the weights (and its first leaf rows) have landed
+      __syncthreads();
+    }
+    uint64_t bad_tiles = 0;
+    int nth = 0;  // tile number `nth` of this wave in the chunk
 
-    for (; tile < tile_end; tile += WAVES) {
+    for (; tile < chunk_end; tile += WAVES, ++nth) {
       const int b = tile * 32 + b_in;
       const bool live = b < a.B;
-      const int bl = live ? b : a.B - 1;
       float stack[D][16], sstack[D];
       float cur[16], cs = 0.f, sprev = 0.f;
       bool bad = false;
@@ -192,10 +201,10 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         if constexpr (i + kSlots < kLeaves) request(cat, std::integral_constant<int, i + kSlots>{});
         if constexpr (i + 1 == kLeaves) {
           // the gathers of this tile are over: request what the next tile starts with (see above)
-          if (tile + WAVES < tile_end) {
+          if (tile + WAVES < chunk_end) {
             pack_categories(xnext, cat);
             static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
-            load_x(min(tile + 2 * WAVES, tile_end - 1), xnext);
+            load_x(min(tile + 2 * WAVES, chunk_end - 1), xnext);
           }
         }
         if constexpr ((i & 1) != 0) cs = s_i + sprev;  // log scale of the pair (i - 1, i)
@@ -222,29 +231,12 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       });
       if constexpr (D == 1) bad |= !((SIGNED ? tile_row_max_abs(cur) : tile_row_max(cur)) > kLinearFloor);  // (deeper roots are renormalised steps)
       if (__builtin_expect(__any(bad), 0)) {
-        // rare: a row of products fell out of the fp32 range -> the whole tile again in log space (semiring.py:383-408)
-        SubtreeSource src{};
-        src.table = a.table;
-        src.scale = a.scale;
-        src.xt = a.xt;
-        src.scope = a.scope;
-        src.leaf_ids = leaf_ids;
-        src.fold0 = fold0;
-        src.w_steps = w_lds;
-        src.t = t;
-        src.B = a.B;
-        src.C = a.C;
-        src.bl = bl;
-        float fb[16];  // (its address escapes into the out-of-line call: never `cur`, which must stay in registers)
+        // rare: evaluated again in log space -- below, after the walk; SIGNED: by leaf_signed_redo_kernel (the signed
+        // log-space walk as a callee costs this kernel 67 spilled registers: 84 -> 88 us at config 5)
         if constexpr (SIGNED) {
-          // (an out-of-line call here costs the hot loop ~100 spilled registers: the tile is marked and evaluated by
-          // leaf_signed_redo_kernel, launched right after this kernel)
-          (void)src;
-          (void)fb;
           if (lane == 0) a.redo[static_cast<int64_t>(t) * ((a.B + 31) >> 5) + tile] = 1;
         } else {
-          subtree_tile_logspace<D, CK_W_TILED_F32>(src, lane, fb);
-          if (live) tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+          bad_tiles |= uint64_t{1} << nth;
         }
       } else if (live) {
         if constexpr (SIGNED) {  // the complex logarithm of a real number: (log|v|, 0 or pi)
@@ -262,6 +254,31 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         }
       }
     }
+    // the noted tiles: a row of products fell out of the fp32 range -> the whole tile in log space (semiring.py:383-408)
+    while (bad_tiles != 0) {
+      const int k = __builtin_ctzll(bad_tiles);
+      bad_tiles &= bad_tiles - 1;
+      const int btile = chunk_begin + wave + k * WAVES;
+      const int b = btile * 32 + b_in;
+      SubtreeSource src{};
+      src.table = a.table;
+      src.scale = a.scale;
+      src.xt = a.xt;
+      src.scope = a.scope;
+      src.leaf_ids = leaf_ids;
+      src.fold0 = fold0;
+      src.w_steps = w_lds;
+      src.t = t;
+      src.B = a.B;
+      src.C = a.C;
+      src.bl = min(b, a.B - 1);
+      float fb[16];
+      if constexpr (!SIGNED) {
+        subtree_tile_logspace<D, CK_W_TILED_F32>(src, lane, fb);
+        if (b < a.B) tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+      }
+    }
+    }  // chunk
   }
 }
 
@@ -342,11 +359,10 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
   a.B = B;
   a.C = C;
   a.preclamped = preclamped;
-  a.redo = signed_redo;
-  CK_REQUIRE(w_layout == CK_W_TILED_F32 || (w_layout == CK_W_ROWMAJOR && signed_redo != nullptr),
-             "ck_leaf_persistent_fwd: weights must be CK_W_TILED_F32 (signed launches: or row-major)");
-  a.w_rowmajor = w_layout == CK_W_ROWMAJOR ? 1 : 0;
+  CK_REQUIRE(w_layout == CK_W_TILED_F32 || w_layout == CK_W_ROWMAJOR, "ck_leaf_persistent_fwd: weights must be CK_W_TILED_F32 or row-major");
   CK_REQUIRE(signed_redo == nullptr || (n_roots > 0 && n_roots <= 65535), "ck_leaf_persistent_fwd: signed launch needs 0 < n_roots <= 65535");
+  a.redo = signed_redo;
+  a.w_rowmajor = w_layout == CK_W_ROWMAJOR ? 1 : 0;
   dim3 grid(static_cast<unsigned>(std::min(n_wg, n_seg)));
   return ck::dispatch(
       [=](hipStream_t s) {

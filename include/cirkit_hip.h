@@ -255,14 +255,17 @@ int ck_subtree_cat_cpt_fwd(const float* table, const float* table_scale, const i
  * -1 .. C - 1 only (ck_stage_categories with clamp != 0): the table row is then min_u32(x, C) -- the integral row C for
  * the marginalisation sentinel -- instead of a compare, a select and a minimum.  Reference semantics as
  * ck_subtree_cat_cpt_fwd.
+ * Tiles whose products leave the linear-space range (largest product of a row <= 2^-80) are noted by the wave and
+ * evaluated again, in log space, after its walk (reference arithmetic, semiring.py:383-408).
+ * w_layout: CK_W_TILED_F32, or CK_W_ROWMAJOR (plain (F_l, 32, 32) parameter tensors).
  * signed_redo != NULL: the table rows are SIGNED linear values (an Embedding layer's weights, layers/input.py:258-266)
  * and the weights may be signed: a real-valued circuit under complex-lse-sum (semiring.py:441-476), whose activations
  * the reference carries as complex logarithms (log|v|, 0 or pi).  The same walk on signed tiles (renormalised by the
  * largest magnitude of a row); `out` is then (F_root, B, 32) complex64: out = (log|v|, pi if v < 0 else 0).  8 waves.
- * signed_redo is a workspace of n_roots * ceil(B / 32) int32, ZERO on entry and zero again afterwards: tiles whose
- * products left the linear-space range are marked there and evaluated again, in log space with signs, by a second
- * launch in which every other wave exits at once.  n_roots = folds of the root layer (only read for signed launches).
- * w_layout: CK_W_TILED_F32; a signed launch also takes CK_W_ROWMAJOR (plain (F_l, 32, 32) parameter tensors). */
+ * signed_redo is a workspace of n_roots * ceil(B / 32) int32, ZERO on entry and zero again afterwards: here the tiles that
+ * leave the linear range are marked in it and evaluated, in log space with signs, by a second launch in which every other
+ * wave exits at once (as a callee of the main kernel that walk costs it 67 spilled registers).  n_roots = folds of the root
+ * layer (only read for signed launches). */
 int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
                            const float* const* w_levels, const int32_t* nodes, const int32_t* node_off, int leaf_off,
                            float* out, const int32_t* work, int n_seg, int n_wg, int waves, int depth, int B, int K,

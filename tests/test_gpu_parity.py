@@ -249,8 +249,8 @@ def test_real_valued_complex_circuit_whole_chain_against_fp64(hip_device):
 def test_signed_tiles_fall_back_to_log_space(hip_device):
     """Embedding rows that are one-hot at DIFFERENT units for sibling variables: every product of the first levels is
     tiny (1e-30 squared), far below the linear-space floor, yet a legitimate value in log space.  The signed leaf launch
-    marks those tiles and its second launch evaluates them in log space with signs: same result as the layer-by-layer
-    complex kernels and the oracle."""
+    notes those tiles and evaluates them again in log space with signs: same result as the layer-by-layer complex kernels
+    and the oracle."""
     from cirkit_amd.circuit import HipCircuit
     from oracle.torch_oracle import as_torch, evaluate_plan
 
@@ -275,7 +275,6 @@ def test_signed_tiles_fall_back_to_log_space(hip_device):
         for got in (ys, yl):
             assert float(((got.real - want.real).abs() / want.real.abs().clamp_min(1.0)).max()) <= 1e-4
             assert float((torch.exp(1j * got.imag) - torch.exp(1j * want.imag)).abs().max()) <= 5e-3
-    assert all(int(v[1].abs().sum()) == 0 for k, v in hs._bindings[x.shape[0]].cp_tabs.items() if isinstance(k, tuple) and k[1] == "leaf_work")
 
 
 @pytest.mark.parametrize("B", [1, 33, 100])
