@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -107,6 +107,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_program_end": [_p],
     "ck_program_num_ops": [_p],
     "ck_program_launch": [_p, _i, _p],
+    "ck_set_workspace": [_p, _l],
     "ck_program_destroy": [_p],
 }
 _RESTYPES = {"ck_last_error": C.c_char_p}

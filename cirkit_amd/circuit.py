@@ -207,6 +207,7 @@ class HipCircuit:
         self._float_input = any(l.wants_float_input for l in data_inputs)
         self._int_input = any(not l.wants_float_input for l in data_inputs)
         self._bindings: dict[int, _Binding] = {}
+        self._scratch_buf: torch.Tensor | bool | None = None
         self._side: torch.cuda.Stream | None = None  # graphs cannot be captured on the null stream
         depth = 0 if fuse is False else (4 if fuse is True else int(fuse))
         # A complex-lse-sum circuit whose parameters are all real -- Embedding inputs and plain real sum weights, the
@@ -511,8 +512,32 @@ class HipCircuit:
         for g in self._groups:
             self._group_table(g, stream)
 
+    def _scratch(self) -> torch.Tensor | None:
+        """The workspace lent to the stream-K Tucker launches (`ck_set_workspace`): ticket counters (zero between
+        launches) + two 16 KiB partial-tile slots per persistent workgroup.  None when no layer can use it."""
+        if self._scratch_buf is None:
+            tuck = [l for s, l in zip(self.plan.layers, self.layers)
+                    if s.type == "tucker" and l.arity == 2 and l.num_input_units in (32, 64) and not self._complex]
+            if not tuck:
+                self._scratch_buf = False
+            else:
+                tiles = max(l.num_folds * ((l.num_output_units + 31) // 32) for l in tuck) * 8  # (row groups at B <= 1024)
+                nbytes = self._n_cu * 3 * 2 * 4 * 1024 * 4 + tiles * 4
+                self._scratch_buf = torch.zeros(nbytes // 4, dtype=torch.int32, device=self.device)
+        return None if self._scratch_buf is False else self._scratch_buf
+
     def _enqueue_layers(self, bd: _Binding, stream: int, *, with_ll: bool = False) -> None:
         """The layer kernels of one forward, in plan order (graph/modules.py:326-334)."""
+        ws = self._scratch()
+        if ws is None:
+            return self._enqueue_layers_(bd, stream, with_ll=with_ll)
+        capi.call("ck_set_workspace", ws.data_ptr(), ws.numel() * 4)
+        try:
+            self._enqueue_layers_(bd, stream, with_ll=with_ll)
+        finally:
+            capi.call("ck_set_workspace", None, 0)
+
+    def _enqueue_layers_(self, bd: _Binding, stream: int, *, with_ll: bool = False) -> None:
         B = bd.B
         for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
             if self._tail and i in self._tail:
@@ -1167,6 +1192,9 @@ class HipCircuit:
                 sp = 2 if n <= 512 else 4
                 return f"sum_lse_gemm_split_kernel<{n // 32 // sp}, {sp}, {'true' if cat else 'false'}>"
         if not self._complex and s.type == "tucker" and l.arity == 2 and l.num_input_units in (32, 64):
+            wg1 = l.num_folds * ((l.num_output_units + 31) // 32) * ((B + 127) // 128)
+            if wg1 <= 8 * 3 * self._n_cu and self._scratch() is not None:  # (ck_gemm.hip tucker_lse: few tiles per slot)
+                return f"tucker_streamk_kernel<{l.num_input_units // 32}>"
             return f"tucker_lse_kernel<{l.num_input_units // 32}>"
         return "sum_lse_generic"
 
@@ -1188,6 +1216,9 @@ class HipCircuit:
         esz = 8 if self._complex else 4
         rows: list[dict] = []
         acc: list[list[float]] = []
+        ws = self._scratch()
+        if ws is not None:  # (as `_enqueue_layers` does: the launches below are the ones a forward records)
+            capi.call("ck_set_workspace", ws.data_ptr(), ws.numel() * 4)
         for it in range(iters + 1):
             evs = []
             try:  # keep the GPU busy while the host enqueues, so the events bracket GPU time only
@@ -1239,6 +1270,8 @@ class HipCircuit:
             if it == 0:
                 continue  # warm-up
             acc.append([t for e0, e1, e2 in evs for t in (e0.elapsed_time(e1), e1.elapsed_time(e2))])
+        if ws is not None:
+            capi.call("ck_set_workspace", None, 0)
         # an event pair with nothing between still measures a few us of marker overhead: it is
         # calibrated on empty pairs and subtracted; intervals without a launch are dropped below
         # (`has_prep` / virtual layers)

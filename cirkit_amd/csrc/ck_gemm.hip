@@ -476,6 +476,198 @@ hipError_t launch_tucker(hipStream_t s, const float* arena, const int64_t* row_o
   return hipGetLastError();
 }
 
+// ---- stream-K Tucker launch --------------------------------------------------------------------------------------
+// tucker_lse_kernel gives a workgroup one (fold, 32 outputs, 128 rows) tile: at batch 128 a layer of F folds is 2 F
+// workgroups of 55 us each over 768 resident slots -- 2.04 rounds for F = 784 (a third of the machine idle in the
+// last one), 1.02 for F = 392, and whole layers of 2..42 folds that take one workgroup's serial time (36 us).  Here the
+// work is the flat list of CHUNKS (tile, left index i) and each of G persistent workgroups takes a contiguous
+// 1/G of it: every workgroup does the same number of MFMAs whatever F is.  A tile whose chunks straddle workgroups
+// is a sum of partial accumulators (they share the row maxima, which only depend on the inputs): each contributor
+// stores its 128 x 32 partial sum in its own workspace slot and takes a ticket; the last one adds the slots in
+// contributor order -- its own included, so the order never depends on who arrives last -- and writes log(sum) + m.
+// Nobody waits for anybody.  Exact fp32 MFMA as tucker_lse_kernel; the split points change the order of the adds, so
+// the two agree to fp32 rounding.
+struct StreamKArgs {
+  const float* arena;
+  const int64_t* row_off;
+  const float* w;
+  float* out;
+  float* ws;            // (G, 2, 128 x 32) partial accumulators: slot 0 = a workgroup's first tile, slot 1 = its last
+  uint32_t* tickets;    // (tiles) zero on entry, zero again afterwards
+  int F, B, Ko, nblk, rgroups;
+  int64_t total;        // chunks = F * nblk * rgroups * Ki
+};
+
+template <int NK>
+__global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a) {
+  constexpr int Ki = 32 * NK;
+  constexpr int N = Ki * Ki;
+  constexpr int CHUNK = NK * 1024;  // floats of one chunk: 32 outputs x Ki right indices, operand layout
+  constexpr int PF = CHUNK / 4 / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w_s = smem;               // [2][CHUNK]
+  float* el_s = smem + 2 * CHUNK;  // [4 waves][Ki][32]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int64_t G = gridDim.x, g = blockIdx.x;
+  auto start_of = [&](int64_t gg) { return gg * a.total / G; };
+  auto owner_of = [&](int64_t c) {  // the workgroup whose range holds chunk c
+    int64_t gg = (c * G + G - 1) / a.total;  // >= the answer - 1 ... narrow down
+    if (gg > G - 1) gg = G - 1;
+    while (gg > 0 && start_of(gg) > c) --gg;
+    while (gg + 1 < G && start_of(gg + 1) <= c) ++gg;
+    return gg;
+  };
+  const int64_t c0 = start_of(g), c1 = start_of(g + 1);
+  const int64_t first_tile = c0 / Ki;
+  float4 pre[PF];
+
+  for (int64_t c = c0; c < c1;) {
+    const int64_t tile = c / Ki;
+    const int i_begin = static_cast<int>(c - tile * Ki);
+    const int i_end = static_cast<int>(min<int64_t>(Ki, i_begin + (c1 - c)));
+    const int rg = static_cast<int>(tile % a.rgroups);
+    const int nb = static_cast<int>((tile / a.rgroups) % a.nblk);
+    const int f = static_cast<int>(tile / (static_cast<int64_t>(a.rgroups) * a.nblk));
+    const int b = (rg * 4 + wave) * 32 + b_in;
+    const bool live = b < a.B;
+    const int bl = live ? b : a.B - 1;
+    const int64_t* ro = a.row_off + static_cast<int64_t>(f) * 2;
+    const float* wf = a.w + static_cast<int64_t>(f) * a.Ko * N;
+    const int o_base = 32 * nb;
+    auto fetch = [&](int i) {  // 4 consecutive threads read 64 contiguous bytes of one weight row; 16 rows per 64 threads
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int idx = threadIdx.x + 256 * k;
+        const int c4 = ((idx >> 6) % (2 * NK)) * 4 + (idx & 3);
+        const int rest = (idx >> 6) / (2 * NK);
+        const int o = o_base + (rest % 2) * 16 + ((idx >> 2) & 15);
+        pre[k] = o < a.Ko ? *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o) * N + i * Ki + 4 * c4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto commit = [&](int buf) {
+      float* dst = w_s + buf * CHUNK;
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int idx = threadIdx.x + 256 * k;
+        const int c4 = ((idx >> 6) % (2 * NK)) * 4 + (idx & 3);
+        const int rest = (idx >> 6) / (2 * NK);
+        const int o = (rest % 2) * 16 + ((idx >> 2) & 15);
+        const int col = 4 * c4, q = col >> 5, gq = (col >> 3) & 3, k2 = (col >> 2) & 1;
+        *reinterpret_cast<float4*>(dst + (((q * 4 + gq) * 64) + (o & 31) + 32 * k2) * 4) = pre[k];
+      }
+    };
+    fetch(i_begin);
+    // exponentiated children of (fold f, this wave's 32 rows): e_r as a register tile, e_l through LDS
+    float er[NK][16];
+    float m;
+    __syncthreads();  // every wave has left the previous tile (its e_l rows and weight buffers)
+    {
+      float el[NK][16];
+#pragma unroll
+      for (int q = 0; q < NK; ++q) {
+        tile_load(a.arena + ro[0] + static_cast<int64_t>(bl) * Ki + 32 * q + 4 * kh, el[q]);
+        tile_load(a.arena + ro[1] + static_cast<int64_t>(bl) * Ki + 32 * q + 4 * kh, er[q]);
+      }
+      float ml = el[0][0], mr = er[0][0];
+#pragma unroll
+      for (int q = 0; q < NK; ++q)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          ml = fmaxf(ml, el[q][j]);
+          mr = fmaxf(mr, er[q][j]);
+        }
+      ml = ck::clamp_finite(ck::xhalf_max(ml));
+      mr = ck::clamp_finite(ck::xhalf_max(mr));
+      const float nl = exp_offset(ml, 0.f), nr = exp_offset(mr, 0.f);
+      float* eb = el_s + wave * (Ki * 32) + b_in;
+#pragma unroll
+      for (int q = 0; q < NK; ++q)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          er[q][j] = __builtin_amdgcn_exp2f(fmaf(er[q][j], kL2E, nr));
+          eb[(32 * q + 8 * (j >> 2) + 4 * kh + (j & 3)) * 32] = __builtin_amdgcn_exp2f(fmaf(el[q][j], kL2E, nl));
+        }
+      m = ml + mr;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* el_w = el_s + wave * (Ki * 32) + b_in;
+    commit(0);
+    if (i_begin + 1 < i_end) fetch(i_begin + 1);
+    for (int i = i_begin; i < i_end; ++i) {
+      __syncthreads();  // chunk i (and, the first time, e_l) is in LDS; every wave has left chunk i - 1
+      if (i + 1 < i_end) commit((i + 1 - i_begin) & 1);
+      if (i + 2 < i_end) fetch(i + 2);
+      const float* wb = w_s + ((i - i_begin) & 1) * CHUNK;
+      const float eli = el_w[i * 32];
+#pragma unroll
+      for (int q = 0; q < NK; ++q)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wb + (((q * 4 + gq) * 64) + lane) * 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, eli * er[q][4 * gq + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, eli * er[q][4 * gq + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, eli * er[q][4 * gq + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, eli * er[q][4 * gq + 3], acc, 0, 0, 0);
+        }
+    }
+    float* dst = a.out + (static_cast<int64_t>(f) * a.B + bl) * a.Ko;
+    const int o0 = o_base + 4 * kh;
+    auto write_out = [&](const f32x16& y) {
+      if (!live) return;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        float o4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o4[t] = fmaf(__builtin_amdgcn_logf(y[4 * gq + t]), kLN2, m);
+        if ((a.Ko & 31) == 0) {
+          *reinterpret_cast<float4*>(dst + o0 + 8 * gq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (o0 + 8 * gq + t < a.Ko) dst[o0 + 8 * gq + t] = o4[t];
+        }
+      }
+    };
+    if (i_begin == 0 && i_end == Ki) {
+      write_out(acc);  // the whole tile is this workgroup's
+    } else {
+      // partial: slot (g, tile == first tile ? 0 : 1); lane-major so that a wave writes 16 contiguous KiB-quarters
+      float* slot = a.ws + ((g * 2 + (tile == first_tile ? 0 : 1)) * 4 + wave) * 1024;
+      // agent-scope atomic stores and loads (write-through / past the non-coherent caches) instead of release / acquire
+      // fences: a fence writes back and invalidates a whole L2 -- with 768 workgroups doing it, a sixth of the launch
+#pragma unroll
+      for (int r = 0; r < 16; ++r) __hip_atomic_store(slot + r * 64 + lane, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have completed
+      __syncthreads();  // ... those of all four waves
+      const int64_t t0 = tile * Ki;
+      const int64_t g_first = owner_of(t0), g_last = owner_of(t0 + Ki - 1);
+      unsigned int ticket = 0;
+      if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __shared__ unsigned int s_ticket;
+      if (threadIdx.x == 0) s_ticket = ticket;
+      __syncthreads();
+      if (s_ticket == static_cast<unsigned int>(g_last - g_first)) {  // the last contributor: everybody's slot is visible
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = 0.f;
+        for (int64_t gg = g_first; gg <= g_last; ++gg) {
+          const int which = (start_of(gg) / Ki == tile) ? 0 : 1;
+          const float* src = a.ws + ((gg * 2 + which) * 4 + wave) * 1024;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) y[r] += __hip_atomic_load(src + r * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        write_out(y);
+        if (threadIdx.x == 0) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    c += i_end - i_begin;
+  }
+}
+
 template <int NQ>
 hipError_t launch_nq(bool cat, dim3 grid, size_t lds, hipStream_t s, const float* arena, const int64_t* row_off,
                      const float* w, float* out, int H, int B, int Ki, int Ko) {
@@ -512,6 +704,48 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
   // fold's work is spread over Ko / 32 workgroups.  Fewer than the chip has CUs: the waves of a workgroup split the
   // contraction instead of the rows (SPLIT).
   const int64_t wg1 = static_cast<int64_t>(F) * ((tiles + 3) / 4) * nblocks;  // workgroups at one block each
+  // Few workgroups per resident slot: the flat chunk list dealt evenly to persistent workgroups (tucker_streamk_kernel),
+  // if the caller lent a workspace for the partial tiles
+  {
+    const int slots = ck::num_cus() * 3;  // 48 KiB of LDS per workgroup
+    const ck::Workspace ws = ck::workspace();
+    const int rgroups = (tiles + 3) / 4;
+    const int64_t total = wg1 * Ki;
+    // (at least 8 chunks per workgroup: each pays the exponentials of its tile's children once; measured 4 / 8 / 16 / 32:
+    // 22 / 22 / 30 / 48 us for the layers of 2..12 folds, no difference for the large ones)
+    const int64_t G = std::max<int64_t>(1, std::min<int64_t>(total / 8, slots));
+    // workspace layout (the same for every launch that shares it): [slots x 2 partial tiles of 16 KiB][ticket per tile]
+    const int64_t slot_bytes = static_cast<int64_t>(slots) * 2 * 4 * 1024 * static_cast<int64_t>(sizeof(float));
+    const int64_t need = slot_bytes + wg1 * 4;
+    if (wg1 <= 8 * static_cast<int64_t>(slots) && ws.ptr != nullptr && ws.bytes >= need && !ck::debug_force_generic()) {
+      StreamKArgs a{};
+      a.arena = arena;
+      a.row_off = row_off;
+      a.w = w;
+      a.out = out;
+      a.ws = static_cast<float*>(ws.ptr);
+      a.tickets = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.ptr) + slot_bytes);
+      a.F = F;
+      a.B = B;
+      a.Ko = Ko;
+      a.nblk = nblocks;
+      a.rgroups = rgroups;
+      a.total = total;
+      return ck::dispatch(
+          [=](hipStream_t s) {
+            auto go = [&](auto kern, size_t lds) {
+              hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+              if (e != hipSuccess) return e;
+              hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(G)), dim3(256), lds, s, a);
+              return hipGetLastError();
+            };
+            return Ki == 32 ? go(tucker_streamk_kernel<1>, (2 * 1024 + 4 * 32 * 32) * sizeof(float))
+                            : go(tucker_streamk_kernel<2>, (2 * 2048 + 4 * 64 * 32) * sizeof(float));
+          },
+          stream);
+    }
+  }
   const bool two = nblocks % 2 == 0 && wg1 > 4096;
   const bool split = wg1 <= 128;
   const int gx = split ? tiles : (tiles + 3) / 4;

@@ -20,6 +20,14 @@ int dispatch(Launch fn, void* stream);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ck_runtime.hip: the scratch buffer the caller lent to this thread's launches (ck_set_workspace), or {nullptr, 0}
+struct Workspace {
+  void* ptr;
+  int64_t bytes;
+};
+Workspace workspace();
+int num_cus();  // compute units of the current device (cached)
+
 // ck_sum.hip: the test hook ck_debug_force_generic is on (A/B runs of the specialised kernels against the plain ones)
 bool debug_force_generic();
 

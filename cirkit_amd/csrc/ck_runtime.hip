@@ -41,11 +41,28 @@ int dispatch(Launch fn, void* stream) {
 
 }  // namespace ck
 
+namespace {
+thread_local ck::Workspace g_workspace{nullptr, 0};
+}
+namespace ck {
+Workspace workspace() { return g_workspace; }
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+}  // namespace ck
+
 extern "C" {
 
 const char* ck_last_error(void) { return g_err; }
 
-int ck_abi_version(void) { return 22; }
+int ck_abi_version(void) { return 23; }
 
 int ck_device_info(int device, int64_t out[4]) {
   if (out == nullptr) return ck::fail(CK_ERR_INVALID, "ck_device_info: out is null");
@@ -56,6 +73,13 @@ int ck_device_info(int device, int64_t out[4]) {
   out[1] = static_cast<int64_t>(p.maxSharedMemoryPerMultiProcessor);
   out[2] = p.warpSize;
   out[3] = strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+  return CK_OK;
+}
+
+int ck_set_workspace(void* ptr, int64_t bytes) {
+  if ((ptr == nullptr) != (bytes <= 0)) return ck::fail(CK_ERR_INVALID, "ck_set_workspace: pointer and size disagree");
+  if (ptr != nullptr && !ck::aligned16(ptr)) return ck::fail(CK_ERR_INVALID, "ck_set_workspace: not 16-byte aligned");
+  g_workspace = {ptr, bytes > 0 ? bytes : 0};
   return CK_OK;
 }
 

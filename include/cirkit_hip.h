@@ -447,6 +447,14 @@ int ck_program_begin(ck_program** out);
 int ck_program_end(ck_program* prog);
 int ck_program_num_ops(const ck_program* prog);
 int ck_program_launch(ck_program* prog, int use_graph, void* stream);
+
+/* Lend a device scratch buffer to the launches this THREAD issues or records from now on (NULL, 0: take it back).  It
+ * must be ZERO when lent; the part that has to stay zero (ticket counters behind the first CUs x 3 x 32 KiB) is zero again
+ * after every launch that used it; launches that share it must be ordered (one stream, or one recorded program).  Used
+ * by the stream-K Tucker launch of ck_sum_lse_fwd (CK_SUM_KRON, arity 2, 32 / 64 units): partial accumulators of tiles that
+ * straddle workgroups; without a workspace of CUs x 3 x 32 KiB + 4 bytes per (fold, 32 outputs, 128 rows) tile those
+ * layers take one workgroup per tile. */
+int ck_set_workspace(void* ptr, int64_t bytes);
 int ck_program_destroy(ck_program* prog);
 
 #ifdef __cplusplus

@@ -126,6 +126,51 @@ def test_tucker_layer_contract(hip_device, F, B, Ki, Ko, cplx):
         _close(got, want)
 
 
+@pytest.mark.parametrize("F,B,Ki,Ko", [(3, 128, 64, 64), (7, 37, 32, 64), (1, 128, 64, 1), (20, 128, 64, 64), (5, 300, 32, 32),
+                                       (2, 100, 64, 40), (9, 128, 64, 128)])
+def test_tucker_streamk_launch(hip_device, F, B, Ki, Ko):
+    """The Tucker launch that deals the flat (tile, left index) chunk list evenly to persistent workgroups and combines the
+    tiles that straddle two of them through the workspace lent with `ck_set_workspace`: against the one-workgroup-per-tile
+    launch (same sums, another order: fp32 rounding) and the oracle; twice, because the ticket counters must be zero again."""
+    from cirkit_amd import _capi as capi
+    from oracle.torch_oracle import _LSE, _layer_forward
+
+    g = torch.Generator().manual_seed(F + B + Ki + Ko)
+    w = torch.softmax(torch.randn(F, Ko, Ki * Ki, generator=g), dim=-1)
+    x = torch.randn(F, 2, B, Ki, generator=g) * 3 - 4
+    x[0, 0, 1] = float("-inf")  # an impossible row
+    spec = LayerSpec("tucker", F, 2, Ki, Ko, {"num_input_units": Ki, "num_output_units": Ko, "arity": 2}, {})
+    with torch.no_grad():
+        want = _layer_forward(_LSE, spec, {"weight": w.reshape(F, Ko, Ki, Ki)}, x)
+    xd, wd = x.to(hip_device).contiguous(), w.to(hip_device).contiguous()
+    row_off = (torch.arange(F * 2, dtype=torch.int64) * (B * Ki)).reshape(F, 2).to(hip_device)
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    n_cu = torch.cuda.get_device_properties(hip_device).multi_processor_count
+    tiles = F * ((Ko + 31) // 32) * ((B + 127) // 128)
+    slot_words = n_cu * 3 * 2 * 4 * 1024
+    ws = torch.zeros(slot_words + tiles, dtype=torch.int32, device=hip_device)
+
+    def run(with_ws):
+        out = torch.full((F, B, Ko), float("nan"), device=hip_device)
+        capi.call("ck_set_workspace", ws.data_ptr() if with_ws else None, ws.numel() * 4 if with_ws else 0)
+        try:
+            capi.call("ck_sum_lse_fwd", xd.data_ptr(), row_off.data_ptr(), wd.data_ptr(), out.data_ptr(), F, 2, B, Ki, Ko,
+                      capi.CK_SUM_KRON, capi.CK_W_ROWMAJOR, stream)
+        finally:
+            capi.call("ck_set_workspace", None, 0)
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    plain = run(False)
+    for _ in range(2):
+        sk = run(True)
+        assert int(ws[slot_words:].abs().sum()) == 0  # tickets back to zero
+        _close(sk, want)
+        fin = torch.isfinite(plain)
+        assert torch.equal(torch.isfinite(sk), fin) and float((sk[fin] - plain[fin]).abs().max()) <= 1e-4
+    _close(plain, want)
+
+
 def test_lse_edge_values(hip_device):
     """Rows that are entirely -inf give -inf (amax clamped to finfo.min, semiring.py:392-399), single
     finite entries survive, and a 200-nat spread does not underflow the result."""
