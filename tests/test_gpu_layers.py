@@ -171,6 +171,38 @@ def test_tucker_streamk_launch(hip_device, F, B, Ki, Ko):
     _close(plain, want)
 
 
+@pytest.mark.parametrize("B,D", [(4096, 784), (100, 784), (33, 784), (64, 7), (8, 130), (260, 66)])
+@pytest.mark.parametrize("clamp", [0, 1])
+def test_stage_categories(hip_device, B, D, clamp):
+    """`ck_stage_categories` (both the 16-byte-access kernel and the plain one): the (D, B) int32 staging copy, the
+    range mapping of `clamp`, and the sticky flag for categories >= the number of states (layers/input.py:399-412 raises)."""
+    from cirkit_amd import _capi as capi
+
+    g = torch.Generator().manual_seed(B + D)
+    ns = torch.randint(2, 300, (D,), generator=g, dtype=torch.int32)
+    ns[::5] = 0  # variables no discrete layer reads
+    x = (torch.rand(B, D, generator=g) * torch.where(ns > 0, ns, torch.full_like(ns, 4)).float() * 0.999).long()
+    x[::3, ::7] = -1  # marginalised
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    for poison in (False, True):
+        xx = x.clone()
+        if poison:
+            d = int((ns > 0).nonzero()[-1])
+            xx[B // 2, d] = int(ns[d]) + 5
+        xt = torch.full((D, B), -7, dtype=torch.int32, device=hip_device)
+        flag = torch.zeros(1, dtype=torch.int32, device=hip_device)
+        xd, nsd = xx.to(hip_device), ns.to(hip_device)
+        capi.call("ck_stage_categories", xd.data_ptr(), xt.data_ptr(), B, D, nsd.data_ptr(), flag.data_ptr(), clamp, stream)
+        torch.cuda.synchronize()
+        want = xx.t().clone()
+        if clamp:
+            lim = ns.long()[:, None]
+            mapped = torch.where(want < 0, torch.full_like(want, -1), torch.minimum(want, lim - 1))
+            want = torch.where(lim > 0, mapped, want)
+        assert torch.equal(xt.cpu().long(), want)
+        assert int(flag) == (1 if poison else 0)
+
+
 def test_lse_edge_values(hip_device):
     """Rows that are entirely -inf give -inf (amax clamped to finfo.min, semiring.py:392-399), single
     finite entries survive, and a 200-nat spread does not underflow the result."""
