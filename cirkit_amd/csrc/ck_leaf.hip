@@ -108,9 +108,12 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     // batch values -> scales -> leaf rows (three dependent memory round trips) in front of it.
     auto batch_row = [&](int tile) { return min(tile * 32 + b_in, a.B - 1); };
     auto load_x = [&](int tile, int32_t (&xv)[kLeaves]) {
-      const int blx = batch_row(tile);
+      // (a uniform row pointer + a 32-bit lane offset: no 64-bit lane arithmetic per load)
+      uint32_t boff = static_cast<uint32_t>(batch_row(tile)) * 4u;
+      asm volatile("" : "+v"(boff));
 #pragma unroll
-      for (int i = 0; i < kLeaves; ++i) xv[i] = a.xt[var_off[i] + blx];
+      for (int i = 0; i < kLeaves; ++i)
+        xv[i] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.xt + var_off[i]) + boff);
     };
     // categories of a tile, two per register (C < 65536 is checked on the host): negative = marginalised -> the
     // integral row C of the table
@@ -147,7 +150,9 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       constexpr int i = decltype(ic)::value;
       const int32_t r = row_of(cp, ic);
       dma(r, i % kSlots);
-      sld[i & 3] = a.scale[r];
+      uint32_t soff = static_cast<uint32_t>(r) << 2;  // (uniform pointer + 32-bit lane offset, as the gathers)
+      asm volatile("" : "+v"(soff));
+      sld[i & 3] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.scale) + soff);
     };
     // The tiles of a segment in chunks of 64 x WAVES (one chunk, normally): a wave notes the tiles whose products left the
     // linear range in a 64-bit mask (scalar registers) and evaluates them in log space AFTER its walk over the chunk.
@@ -215,8 +220,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
 #pragma unroll
           for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
           if constexpr (l == 0) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) cur[j] *= stack[0][j];  // first level: the bare product (ck_tile.h)
+            tile_mul(cur, stack[0]);  // first level: the bare product (ck_tile.h)
           } else {
             linear_product<true, SIGNED>(cur, stack[l], cs, sstack[l], bad);
           }

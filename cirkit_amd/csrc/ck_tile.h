@@ -224,19 +224,46 @@ __device__ __forceinline__ float tile_row_max_abs(const float (&p)[16]) {
   return ck::xhalf_max(m);
 }
 
+// cur <- cur * sib as eight packed multiplies (v_pk_mul_f32: two products per VALU instruction -- every VALU
+// instruction of a step adds to its MFMA time, see above)
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tile_mul(float (&cur)[16], const float (&sib)[16]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f32x2v a = {cur[2 * j], cur[2 * j + 1]};
+    const f32x2v b = {sib[2 * j], sib[2 * j + 1]};
+    a = a * b;
+    cur[2 * j] = a.x;
+    cur[2 * j + 1] = a.y;
+  }
+}
+__device__ __forceinline__ void tile_scale(float (&cur)[16], float sc) {
+  // (a multiply by a splat is scalarised by the compiler, so the second half is laundered: it cannot tell; spelling
+  // the instruction out in inline asm is WRONG here -- the hazard recogniser does not see inside an asm block and omits
+  // the wait states between a VALU write and the MFMA that reads it)
+  float sc2 = sc;
+  asm volatile("" : "+v"(sc2));
+  const f32x2v b = {sc, sc2};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f32x2v a = {cur[2 * j], cur[2 * j + 1]};
+    a = a * b;
+    cur[2 * j] = a.x;
+    cur[2 * j + 1] = a.y;
+  }
+}
+
 // cur <- cur * sib (renormalised), s <- s_cur + s_sib (+ k ln 2)
 template <bool RESCALE, bool SIGNED = false>
 __device__ __forceinline__ void linear_product(float (&cur)[16], const float (&sib)[16], float& s, float s_sib, bool& bad) {
-#pragma unroll
-  for (int j = 0; j < 16; ++j) cur[j] *= sib[j];
+  tile_mul(cur, sib);
   s += s_sib;
   if constexpr (RESCALE) {
     const float mx = SIGNED ? tile_row_max_abs(cur) : tile_row_max(cur);
     const int k = __builtin_amdgcn_frexp_expf(mx);  // mx = f 2^k, f in [0.5, 1)
     const float sc = __builtin_amdgcn_ldexpf(1.f, -k);
     bad |= !(mx > kLinearFloor);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) cur[j] *= sc;
+    tile_scale(cur, sc);
     s = fmaf(static_cast<float>(k), kLN2, s);
   }
 }
