@@ -1152,7 +1152,7 @@ class HipCircuit:
             in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)
             if i in self._table_fused and self.linear_levels:
                 if self._leaf_is_persistent(g, B):
-                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}>"
+                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}, false>"
                 return f"subtree_linear_kernel<{g.depth}, {self._group_layout(g)}>"
             return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")
@@ -1333,7 +1333,7 @@ class HipCircuit:
                 if i == self._tail[-1]:
                     tl = next((self.layers[j]._w_layout for j in self._tail
                                if self.layers[j].num_output_units == 32), 0)
-                    rows.append({"layer": self._tail[0], "kernel": (f"tail16_kernel<{tl}>" if self._tail16_ok() else f"tail_kernel<{tl}>"),
+                    rows.append({"layer": self._tail[0], "kernel": (f"tail16_kernel<{tl}, {'true' if self._signed else 'false'}>" if self._tail16_ok() else f"tail_kernel<{tl}>"),
                                  "ms": float(mean[2 * self._tail[0] + 1]),
                                  "algorithmic_bytes": sum(layer_bytes[j] for j in self._tail),
                                  "algorithmic_flops": sum(layer_flops[j] for j in self._tail)})
