@@ -167,7 +167,11 @@ int gather_impl(const float* table, const int32_t* xt, const int64_t* scope, flo
   CK_REQUIRE(table && xt && scope && out, "%s: null pointer", who);
   CK_REQUIRE(F > 0 && B > 0 && K > 0 && C > 0 && D > 0, "%s: non-positive size F=%d B=%d K=%d C=%d D=%d",
              who, F, B, K, C, D);
-  CK_REQUIRE(F <= 65535, "%s: F=%d exceeds grid.y", who, F);
+  if (F > ck::kMaxFoldsPerLaunch)
+    return ck::chunk_folds(F, [&](int f0, int n) {
+      return gather_impl<MODE>(table + static_cast<int64_t>(f0) * (C + 1) * K, xt, scope + f0,
+                               out + static_cast<int64_t>(f0) * B * K * (MODE >= 2 ? 2 : 1), n, B, K, C, D, stream, who);
+    });
   const bool vec = (K % 4 == 0) && (K / 4 <= 256) && ck::aligned16(table) && ck::aligned16(out);
   if (vec) {
     const int rows_per_block = 256;
@@ -384,7 +388,12 @@ int ck_gaussian_fwd(const float* mean, const float* stddev, const float* log_par
                     void* stream) {
   CK_REQUIRE(mean && stddev && xt && scope && out, "ck_gaussian_fwd: null pointer");
   CK_REQUIRE(F > 0 && B > 0 && K > 0 && D > 0, "ck_gaussian_fwd: non-positive size");
-  CK_REQUIRE(F <= 65535, "ck_gaussian_fwd: F=%d exceeds grid.y", F);
+  if (F > ck::kMaxFoldsPerLaunch)
+    return ck::chunk_folds(F, [&](int f0, int n) {
+      const int64_t o = static_cast<int64_t>(f0) * K;
+      return ck_gaussian_fwd(mean + o, stddev + o, log_partition == nullptr ? nullptr : log_partition + o, xt, scope + f0,
+                             out + static_cast<int64_t>(f0) * B * K, n, B, K, D, stream);
+    });
   const int rows_per_block = 256;
   dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
   return ck::dispatch(
@@ -420,8 +429,13 @@ int ck_constant_fwd(const float* value, float* out, int F, int B, int K, int log
                     int value_is_complex, int complex_out, void* stream) {
   CK_REQUIRE(value && out, "ck_constant_fwd: null pointer");
   CK_REQUIRE(F > 0 && B > 0 && K > 0, "ck_constant_fwd: non-positive size");
-  CK_REQUIRE(F <= 65535, "ck_constant_fwd: F=%d exceeds grid.y", F);
   CK_REQUIRE(complex_out || !value_is_complex, "ck_constant_fwd: complex value needs complex output");
+  if (F > ck::kMaxFoldsPerLaunch)
+    return ck::chunk_folds(F, [&](int f0, int n) {
+      return ck_constant_fwd(value + static_cast<int64_t>(f0) * K * (value_is_complex ? 2 : 1),
+                             out + static_cast<int64_t>(f0) * B * K * (complex_out ? 2 : 1), n, B, K, log_space, value_is_complex,
+                             complex_out, stream);
+    });
   const int64_t n = static_cast<int64_t>(B) * K;
   dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 1024)), F), block(256);
   return ck::dispatch(

@@ -28,6 +28,18 @@ struct Workspace {
 Workspace workspace();
 int num_cus();  // compute units of the current device (cached)
 
+// Folds ride on grid.y (<= 65535): a layer with more folds -- a 256 x 256 image has 65536 leaves -- is launched in chunks
+// of folds; `fn(first fold, folds)` issues one chunk with the per-fold pointers advanced by the caller.
+constexpr int kMaxFoldsPerLaunch = 65535;
+template <class Fn>
+inline int chunk_folds(int F, Fn&& fn) {
+  for (int f0 = 0; f0 < F; f0 += kMaxFoldsPerLaunch) {
+    const int n = F - f0 < kMaxFoldsPerLaunch ? F - f0 : kMaxFoldsPerLaunch;
+    if (int st = fn(f0, n)) return st;
+  }
+  return 0;
+}
+
 // ck_sum.hip: the test hook ck_debug_force_generic is on (A/B runs of the specialised kernels against the plain ones)
 bool debug_force_generic();
 

@@ -77,8 +77,11 @@ int ck_hadamard_fwd(const float* arena, const int64_t* row_off, float* out, int 
   CK_REQUIRE(arena && row_off && out, "ck_hadamard_fwd: null pointer");
   CK_REQUIRE(F > 0 && H > 0 && B > 0 && K > 0, "ck_hadamard_fwd: non-positive size");
   CK_REQUIRE(esize == 1 || esize == 2, "ck_hadamard_fwd: esize must be 1 or 2");
-  CK_REQUIRE(F <= 65535, "ck_hadamard_fwd: F=%d exceeds grid.y", F);
   const int64_t words = static_cast<int64_t>(B) * K * esize;
+  if (F > ck::kMaxFoldsPerLaunch)
+    return ck::chunk_folds(F, [&](int f0, int n) {
+      return ck_hadamard_fwd(arena, row_off + static_cast<int64_t>(f0) * H, out + f0 * words, n, H, B, K, esize, stream);
+    });
   // row_off counts activation ELEMENTS (esize words each); the kernels index 4-byte words.
   const bool vec = (words % 4 == 0) && ck::aligned16(arena) && ck::aligned16(out);
   if (vec) {
@@ -104,12 +107,16 @@ int ck_kronecker_fwd(const float* arena, const int64_t* row_off, float* out, int
   CK_REQUIRE(arena && row_off && out, "ck_kronecker_fwd: null pointer");
   CK_REQUIRE(F > 0 && H >= 2 && B > 0 && K > 0, "ck_kronecker_fwd: non-positive size or arity < 2");
   CK_REQUIRE(esize == 1 || esize == 2, "ck_kronecker_fwd: esize must be 1 or 2");
-  CK_REQUIRE(F <= 65535, "ck_kronecker_fwd: F=%d exceeds grid.y", F);
   int64_t kk = 1;
   for (int h = 0; h < H; ++h) {
     kk *= K;
     CK_REQUIRE(kk <= (int64_t{1} << 31), "ck_kronecker_fwd: K^H = %d^%d output units", K, H);
   }
+  if (F > ck::kMaxFoldsPerLaunch)
+    return ck::chunk_folds(F, [&](int f0, int n) {
+      return ck_kronecker_fwd(arena, row_off + static_cast<int64_t>(f0) * H, out + static_cast<int64_t>(f0) * B * kk * esize, n, H, B, K,
+                              esize, stream);
+    });
   const int64_t n = static_cast<int64_t>(B) * kk;
   dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 2048)), F), block(256);
   return ck::dispatch(

@@ -349,7 +349,6 @@ int check_sum_args(const void* arena, const void* row_off, const void* w, const 
              who, F, H, B, Ki, Ko);
   CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD || mode == CK_SUM_KRON, "%s: unknown mode %d", who, mode);
   CK_REQUIRE(mode != CK_SUM_KRON || H >= 2, "%s: CK_SUM_KRON (Tucker) needs arity >= 2, found %d", who, H);
-  CK_REQUIRE(F <= 65535, "%s: F=%d exceeds grid.y", who, F);
   return CK_OK;
 }
 
@@ -552,6 +551,15 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
                    int H, int B, int Ki, int Ko, int mode, int w_layout, void* stream) {
   if (int st = check_sum_args(arena, row_off, w, out, F, H, B, Ki, Ko, mode, "ck_sum_lse_fwd")) return st;
   CK_REQUIRE(w_layout >= CK_W_ROWMAJOR && w_layout <= CK_W_TILED_F16X3, "ck_sum_lse_fwd: unknown w_layout %d", w_layout);
+  if (F > ck::kMaxFoldsPerLaunch) {  // (words of weights per fold: Ko x the contracted inputs, whatever the layout)
+    int64_t nin = Ki;
+    if (mode == CK_SUM_CAT) nin = static_cast<int64_t>(H) * Ki;
+    if (mode == CK_SUM_KRON) for (int h = 1; h < H; ++h) nin *= Ki;
+    return ck::chunk_folds(F, [&](int f0, int n) {
+      return ck_sum_lse_fwd(arena, row_off + static_cast<int64_t>(f0) * H, w + f0 * Ko * nin, out + static_cast<int64_t>(f0) * B * Ko, n,
+                            H, B, Ki, Ko, mode, w_layout, stream);
+    });
+  }
   const bool prod_like = mode == CK_SUM_PROD || H == 1;
   if (w_layout != CK_W_ROWMAJOR) {
     CK_REQUIRE(prod_like && Ki == kK && Ko == kK, "ck_sum_lse_fwd: tiled weight layouts need Ki = Ko = 32 and a product-type input");
@@ -593,6 +601,15 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
 int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w, float* out_c,
                      int F, int H, int B, int Ki, int Ko, int mode, int w_is_complex, void* stream) {
   if (int st = check_sum_args(arena_c, row_off, w, out_c, F, H, B, Ki, Ko, mode, "ck_sum_lse_fwd_c")) return st;
+  if (F > ck::kMaxFoldsPerLaunch) {
+    int64_t nin = Ki;
+    if (mode == CK_SUM_CAT) nin = static_cast<int64_t>(H) * Ki;
+    if (mode == CK_SUM_KRON) for (int h = 1; h < H; ++h) nin *= Ki;
+    return ck::chunk_folds(F, [&](int f0, int n) {
+      return ck_sum_lse_fwd_c(arena_c, row_off + static_cast<int64_t>(f0) * H, w + f0 * Ko * nin * (w_is_complex ? 2 : 1),
+                              out_c + static_cast<int64_t>(f0) * B * Ko * 2, n, H, B, Ki, Ko, mode, w_is_complex, stream);
+    });
+  }
   const c32* a = reinterpret_cast<const c32*>(arena_c);
   c32* o = reinterpret_cast<c32*>(out_c);
   if (w_is_complex)
@@ -639,7 +656,11 @@ int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* m
                       int F, int H, int B, int K, void* stream) {
   CK_REQUIRE(arena && row_off && mw && out, "ck_mixing_lse_fwd: null pointer");
   CK_REQUIRE(F > 0 && H > 0 && B > 0 && K > 0, "ck_mixing_lse_fwd: non-positive size");
-  CK_REQUIRE(F <= 65535, "ck_mixing_lse_fwd: F=%d exceeds grid.y", F);
+  if (F > ck::kMaxFoldsPerLaunch)
+    return ck::chunk_folds(F, [&](int f0, int n) {
+      return ck_mixing_lse_fwd(arena, row_off + static_cast<int64_t>(f0) * H, mw + static_cast<int64_t>(f0) * K * H,
+                               out + static_cast<int64_t>(f0) * B * K, n, H, B, K, stream);
+    });
   const int lpr = K / 4;
   const bool vec = (K % 4 == 0) && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && ck::aligned16(arena) &&
                    ck::aligned16(out);

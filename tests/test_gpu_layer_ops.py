@@ -118,6 +118,52 @@ def test_input_layers(hip_device):
     _close(ops.constant_value(v.to(hip_device), 6, log_space=True, complex_out=True), v.unsqueeze(1).expand(F, 6, K).to(torch.complex64).contiguous())
 
 
+def test_layers_with_more_than_65535_folds(hip_device):
+    """Folds ride on grid.y (<= 65535): a layer with more folds -- the leaves of a 256 x 256 image -- is launched in
+    chunks.  Categorical, Gaussian, Embedding (complex), dense sum, CP-T (K = 32 tile kernel), Hadamard, Kronecker and
+    constant layers with 70 000 folds against plain torch."""
+    from cirkit_amd import _capi as capi
+    from cirkit_amd import layer_ops as ops
+
+    F, B = 70_000, 3
+    g = torch.Generator().manual_seed(7)
+    dev = hip_device
+    # Categorical
+    K, C = 4, 5
+    logits = torch.randn(F, K, C, generator=g)
+    x = torch.randint(0, C, (F, B, 1), generator=g)
+    got = ops.categorical_log_likelihood(x.to(dev), logits.to(dev)).cpu()
+    want = logits[torch.arange(F)[:, None], :, x[..., 0]]
+    assert torch.equal(got, want)
+    # Gaussian
+    mean, std = torch.randn(F, K, generator=g), torch.rand(F, K, generator=g) + 0.5
+    xf = torch.randn(F, B, 1, generator=g)
+    got = ops.gaussian_log_likelihood(xf.to(dev), mean.to(dev), std.to(dev)).cpu()
+    want = torch.distributions.Normal(mean[:, None], std[:, None]).log_prob(xf)
+    assert float((got - want).abs().max()) <= 1e-4
+    # Embedding, complex logarithm
+    w = torch.randn(F, K, C, generator=g)
+    got = ops.embedding(x.to(dev), w.to(dev), complex_out=True).cpu()
+    val = w[torch.arange(F)[:, None], :, x[..., 0]]
+    assert float((got.real - val.abs().log()).abs().max()) <= 1e-5 and torch.equal(got.imag > 1.0, val < 0)
+    # dense sum (generic kernel) and CP-T on the 32-unit tile kernel
+    for Ki, Ko, H, mode in ((4, 3, 1, capi.CK_SUM_CAT), (32, 32, 2, capi.CK_SUM_PROD)):
+        xs = torch.randn(F, H, B, Ki, generator=g) - 2
+        ws = torch.softmax(torch.randn(F, Ko, Ki, generator=g), dim=-1)
+        got = ops.sum_lse(xs.to(dev), ws.to(dev), mode).cpu()
+        xin = xs.sum(dim=1) if mode == capi.CK_SUM_PROD else xs[:, 0]
+        want = torch.log(torch.einsum("fbi,foi->fbo", torch.exp(xin.double()), ws.double())).float()
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    # products and constants
+    xs = torch.randn(F, 2, B, K, generator=g)
+    assert float((ops.hadamard(xs.to(dev)).cpu() - xs.sum(dim=1)).abs().max()) <= 1e-6
+    kr = ops.kronecker(xs.to(dev)).cpu()
+    assert float((kr - (xs[:, 0, :, :, None] + xs[:, 1, :, None, :]).flatten(2)).abs().max()) <= 1e-6
+    v = torch.rand(F, K, generator=g) + 0.1
+    cv = ops.constant_value(v.to(dev), B, log_space=False, complex_out=False).cpu()
+    assert float((cv - v.log()[:, None].expand(F, B, K)).abs().max()) <= 1e-6
+
+
 def test_no_cpu_fallback():
     from cirkit_amd import layer_ops as ops
     from cirkit_amd._capi import HipExtensionError
