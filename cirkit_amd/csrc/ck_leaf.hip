@@ -224,6 +224,9 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           } else {
             linear_product<true, SIGNED>(cur, stack[l], cs, sstack[l], bad);
           }
+          // (the products stay in front of the MFMA chain: interleaved into it, the compiler's pre-emit pass splits every
+          // v_pk_mul_f32 that follows an MFMA back into two multiplies)
+          __builtin_amdgcn_sched_barrier(0);
           contract_linear<CK_W_TILED_F32>(wcur, cur);
         });
         if constexpr (steps_after(i) < D) {  // left sibling at this level: wait for the right one
