@@ -23,7 +23,8 @@ fixtures extracted from the real reference:
                            the same procedure one level down for the parameter graphs of a group
                            (utils/algorithms.py:71-97, graph/folding.py:62-298, torch/compiler.py:335-506)
 
-Chow-Liu trees (structure learnt from data) and Binomial inputs are not built here.
+Chow-Liu trees learnt from data (`chow_liu_tree`, region_graph='chow-liu-tree') and Binomial input layers are built here
+as well (round 1; outside SURVEY.md section 8's f1 list -- kept, not extended).
 """
 
 from __future__ import annotations

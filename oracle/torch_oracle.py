@@ -12,7 +12,7 @@ in the same order reproduce the reference bit-for-bit on CPU; that is pinned by
 * tests/golden/*.npz -- outputs of the real reference, generated in the build container by
   tests/golden/make_fixtures.py (which imports /root/reference), and
 * the reference's own known-answer tests (tests/symbolic/test_utils.py:293-503 of the reference),
-  restated in tests/test_oracle_kat.py.
+  restated in tests/test_oracle_golden.py::test_reference_known_answers (fixtures tests/golden/kat_*).
 
 Every function cites the reference lines it follows (paths relative to the reference checkout).
 """
