@@ -285,7 +285,7 @@ hipError_t launch_split(bool cat, hipStream_t s, const float* arena, const int64
 template <int NK, int NB, bool SPLIT>
 __global__ void __launch_bounds__(256)
     tucker_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off, const float* __restrict__ w,
-                      float* __restrict__ out, int F, int B, int Ko, int gx, int gsplit) {
+                      float* __restrict__ out, int F, int B, int Ko, int gx, int gsplit, const float* __restrict__ lognorm) {
   constexpr int Ki = 32 * NK;
   constexpr int N = Ki * Ki;
   constexpr int CI = SPLIT ? 4 : (NK == 1 ? 2 : 1);   // left indices per staged chunk
@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(256)
   // 4 consecutive threads read 64 contiguous bytes of one weight row; 16 rows per 64 threads.
   constexpr int PF = CHUNK / 4 / 256;
   float4 pre[PF];
+  float nl2[PF];  // logits mode: -lognorm[f, o] log2 e of the row each staged float4 belongs to (o < Ko), +inf marker unused
   auto fetch = [&](int c) {
     const int grp = c / (Ki / CI), i0 = (c % (Ki / CI)) * CI;
 #pragma unroll
@@ -329,6 +330,14 @@ __global__ void __launch_bounds__(256)
       const int ci = rest / (2 * NB);
       pre[k] = o < Ko ? *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o) * N + (i0 + ci) * Ki + 4 * c4)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lognorm != nullptr) {
+        if (o < Ko) {  // softmax(theta) = exp(theta - L), applied here: the weights never exist in memory
+          const float n = -lognorm[static_cast<int64_t>(f) * Ko + o] * kL2E;
+          nl2[k] = n;
+        } else {
+          nl2[k] = __builtin_nanf("");  // (rows past Ko stay zero)
+        }
+      }
     }
   };
   auto commit = [&](int buf) {
@@ -341,7 +350,14 @@ __global__ void __launch_bounds__(256)
       const int o = (rest % (2 * NB)) * 16 + ((idx >> 2) & 15);
       const int ci = rest / (2 * NB);
       const int col = 4 * c4, q = col >> 5, g = (col >> 3) & 3, k2 = (col >> 2) & 1;
-      *reinterpret_cast<float4*>(dst + ((((ci * NB + (o >> 5)) * NK + q) * 4 + g) * 64 + (o & 31) + 32 * k2) * 4) = pre[k];
+      float4 v = pre[k];
+      if (lognorm != nullptr && nl2[k] == nl2[k]) {
+        v.x = __builtin_amdgcn_exp2f(fmaf(v.x, kL2E, nl2[k]));
+        v.y = __builtin_amdgcn_exp2f(fmaf(v.y, kL2E, nl2[k]));
+        v.z = __builtin_amdgcn_exp2f(fmaf(v.z, kL2E, nl2[k]));
+        v.w = __builtin_amdgcn_exp2f(fmaf(v.w, kL2E, nl2[k]));
+      }
+      *reinterpret_cast<float4*>(dst + ((((ci * NB + (o >> 5)) * NK + q) * 4 + g) * 64 + (o & 31) + 32 * k2) * 4) = v;
     }
   };
   fetch(0);
@@ -462,7 +478,7 @@ __global__ void __launch_bounds__(256)
 
 template <int NK, int NB, bool SPLIT>
 hipError_t launch_tucker(hipStream_t s, const float* arena, const int64_t* row_off, const float* w, float* out, int F,
-                         int B, int Ko, int gx, int gsplit) {
+                         int B, int Ko, int gx, int gsplit, const float* lognorm) {
   constexpr int CI = SPLIT ? 4 : (NK == 1 ? 2 : 1);
   const size_t lds = (2 * CI * NB * NK * 1024 + 4 * 32 * NK * 32 + (SPLIT ? 4 * NB * 1024 : 0)) * sizeof(float);
   auto kern = tucker_lse_kernel<NK, NB, SPLIT>;
@@ -472,7 +488,7 @@ hipError_t launch_tucker(hipStream_t s, const float* arena, const int64_t* row_o
     if (e != hipSuccess) return e;
   }
   const dim3 grid(static_cast<unsigned>((F + 7) / 8 * 8 * gx * gsplit));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, arena, row_off, w, out, F, B, Ko, gx, gsplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, arena, row_off, w, out, F, B, Ko, gx, gsplit, lognorm);
   return hipGetLastError();
 }
 
@@ -492,6 +508,7 @@ struct StreamKArgs {
   const int64_t* row_off;
   const float* w;
   float* out;
+  const float* lognorm; // nullptr, or (F, Ko): `w` holds logits and the weights are exp(w - lognorm[f, o])
   float* ws;            // (G, 2, 128 x 32) partial accumulators: slot 0 = a workgroup's first tile, slot 1 = its last
   uint32_t* tickets;    // (tiles) zero on entry, zero again afterwards
   int F, B, Ko, nblk, rgroups;
@@ -546,6 +563,14 @@ __global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a
                           : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
+    // logits mode: the negated log-normalisers (x log2 e) of the PF weight rows this thread stages -- fixed per tile
+    float nl2[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int idx = threadIdx.x + 256 * k;
+      const int o = o_base + (((idx >> 6) / (2 * NK)) % 2) * 16 + ((idx >> 2) & 15);
+      nl2[k] = a.lognorm != nullptr && o < a.Ko ? -a.lognorm[static_cast<int64_t>(f) * a.Ko + o] * kL2E : 0.f;
+    }
     auto commit = [&](int buf) {
       float* dst = w_s + buf * CHUNK;
 #pragma unroll
@@ -555,7 +580,14 @@ __global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a
         const int rest = (idx >> 6) / (2 * NK);
         const int o = (rest % 2) * 16 + ((idx >> 2) & 15);
         const int col = 4 * c4, q = col >> 5, gq = (col >> 3) & 3, k2 = (col >> 2) & 1;
-        *reinterpret_cast<float4*>(dst + (((q * 4 + gq) * 64) + (o & 31) + 32 * k2) * 4) = pre[k];
+        float4 v = pre[k];
+        if (a.lognorm != nullptr && o_base + o < a.Ko) {  // softmax(theta) = exp(theta - L): the weights never exist in memory
+          v.x = __builtin_amdgcn_exp2f(fmaf(v.x, kL2E, nl2[k]));
+          v.y = __builtin_amdgcn_exp2f(fmaf(v.y, kL2E, nl2[k]));
+          v.z = __builtin_amdgcn_exp2f(fmaf(v.z, kL2E, nl2[k]));
+          v.w = __builtin_amdgcn_exp2f(fmaf(v.w, kL2E, nl2[k]));
+        }
+        *reinterpret_cast<float4*>(dst + (((q * 4 + gq) * 64) + (o & 31) + 32 * k2) * 4) = v;
       }
     };
     fetch(i_begin);
@@ -698,7 +730,7 @@ bool tucker_applies(int H, int Ki, int Ko, int mode) { return mode == CK_SUM_KRO
 
 // Tucker layer of arity 2 with 32 or 64 units per child.
 int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int B, int Ki, int Ko,
-               void* stream) {
+               void* stream, const float* lognorm) {
   const int tiles = (B + 31) / 32, nblocks = (Ko + 31) / 32;
   // Many workgroups: two blocks of outputs share every e_l * e_r product.  Fewer: one block per workgroup, so that a
   // fold's work is spread over Ko / 32 workgroups.  Fewer than the chip has CUs: the waves of a workgroup split the
@@ -723,6 +755,7 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
       a.row_off = row_off;
       a.w = w;
       a.out = out;
+      a.lognorm = lognorm;
       a.ws = static_cast<float*>(ws.ptr);
       a.tickets = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.ptr) + slot_bytes);
       a.F = F;
@@ -751,12 +784,12 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
   const int gx = split ? tiles : (tiles + 3) / 4;
   return ck::dispatch(
       [=](hipStream_t s) {
-        if (two) return Ki == 32 ? launch_tucker<1, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1)
-                                 : launch_tucker<2, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1);
-        if (split) return Ki == 32 ? launch_tucker<1, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks)
-                                   : launch_tucker<2, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks);
-        return Ki == 32 ? launch_tucker<1, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks)
-                        : launch_tucker<2, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks);
+        if (two) return Ki == 32 ? launch_tucker<1, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1, lognorm)
+                                 : launch_tucker<2, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1, lognorm);
+        if (split) return Ki == 32 ? launch_tucker<1, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks, lognorm)
+                                   : launch_tucker<2, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks, lognorm);
+        return Ki == 32 ? launch_tucker<1, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks, lognorm)
+                        : launch_tucker<2, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks, lognorm);
       },
       stream);
 }

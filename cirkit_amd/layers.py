@@ -662,6 +662,42 @@ class HipTuckerLayer(HipSumLayer):
     def tile32_eligible(self) -> bool:
         return False
 
+    # set by HipCircuit(fused_weight_softmax=True): the batched prologue only writes the row log-normalisers of a
+    # softmax(theta) weight and the Tucker launch applies exp(theta - lognorm) while it stages the weights
+    # (`ck_tucker_logits_fwd`) -- the (F, Ko, Ki^2) normalised weights are never written.  Not for training: the backward
+    # kernels read `_w`.
+    _logits_ok = False
+    _lognorm: torch.Tensor | None = None
+    _theta: torch.Tensor | None = None
+    _use_logits = False
+
+    def register_batched(self, batch) -> bool:
+        self._lognorm = self._theta = None
+        src = None if self.is_complex else self.weight.softmax_source()
+        n = self.num_input_units ** self.arity
+        if (self._logits_ok and src is not None and self.arity == 2 and self.num_input_units in (32, 64)
+                and 512 <= n <= 4096 and src.is_contiguous() and src.data_ptr() % 16 == 0):
+            self._theta = src
+            self._lognorm = torch.empty(src.shape[:-1], dtype=torch.float32, device=src.device)
+            self._w_layout = capi.CK_W_ROWMAJOR
+            batch.add_row_lognorm(src, self._lognorm)
+            self._batched = True
+            return True
+        return super().register_batched(batch)
+
+    def prepare(self, stream: int, batched: bool = False) -> None:
+        self._use_logits = bool(batched and self._batched and self._lognorm is not None)
+        if not self._use_logits:
+            if batched and self._batched:
+                return
+            self._w = self.weight.evaluate(stream)  # (the per-node path evaluates the normalised weights)
+
+    def launch(self, arena, row_off, out, B, stream) -> None:
+        if not self._use_logits:
+            return super().launch(arena, row_off, out, B, stream)
+        capi.call("ck_tucker_logits_fwd", _ptr(arena), _ptr(row_off), _ptr(self._theta), _ptr(self._lognorm), _ptr(out),
+                  self.num_folds, B, self.num_input_units, self.num_output_units, stream)
+
 
 class HipTensorDotLayer(HipInnerLayer):
     """``TorchTensorDotLayer`` (layers/optimized.py:181-300)."""

@@ -82,7 +82,8 @@ class HipTrainer:
         store.version += 1
         # layer-wise forward, every activation materialised, row-major linear weights
         self.circuit = HipCircuit(plan, store, device=device, use_graph=False, fuse=False,
-                                  batch_params=True, tiled_weights=False, dense_on_table=False, pad_units=False)
+                                  batch_params=True, tiled_weights=False, dense_on_table=False, pad_units=False,
+                                  fused_weight_softmax=False)
         self.plan, self.device = plan, self.circuit.device
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self.step_count = 0

@@ -146,6 +146,12 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
 /* Test hook: route ck_sum_lse_fwd through the shape-generic kernel even where the MFMA kernel
  * applies (A/B parity of the two implementations). */
 int ck_debug_force_generic(int on);
+/* TorchTuckerLayer.forward (optimized.py:89-103) of arity 2 with 32 / 64 input units whose weight is softmax(theta) over its
+ * last axis (parameters/nodes.py:764-772), WITHOUT the normalised weights in memory: theta (F, Ko, Ki^2) raw logits,
+ * lognorm (F, Ko) their row log-normalisers (ck_param_softmax_batch kind 6); the launch applies exp(theta - lognorm)
+ * while it stages the weights.  Same launches as ck_sum_lse_fwd in CK_SUM_KRON mode (ck_set_workspace applies). */
+int ck_tucker_logits_fwd(const float* arena, const int64_t* row_off, const float* theta, const float* lognorm, float* out,
+                         int F, int B, int Ki, int Ko, void* stream);
 /* complex-lse-sum variant (semiring.py:441-476); w real (w_is_complex=0) or complex64. */
 int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w, float* out_c,
                      int F, int H, int B, int Ki, int Ko, int mode, int w_is_complex, void* stream);
@@ -325,6 +331,8 @@ int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_
  * dense folds d, out[d] (C+1, 32) = log(softmax(in2[d]) . exp(T - m)) + m row by row, with T the kind-1
  * table of categorical fold idx[d] (a Categorical layer followed fold by fold by a dense layer only
  * takes C distinct values per fold, so the dense layer is evaluated on the table instead of on the batch).
+ * kind 6: out[r] = max + log sum exp(in[r, :] - max), the log-normaliser of each of `rows` rows of 512..4096 entries
+ * (out: `rows` floats): consumed by ck_tucker_logits_fwd, which applies exp(in - out) = softmax(in) while it stages weights.
  * kind 5: as kind 4 but every row is left in LINEAR space, out[d, c, :] = softmax(in2[d]) . exp(T[c] - m_c),
  * with its log scale m_c in out2[d, c] (the representation ck_subtree_cat_cpt_fwd takes with table_scale).
  * block_begin is ignored on input. */

@@ -203,6 +203,48 @@ def test_stage_categories(hip_device, B, D, clamp):
         assert int(flag) == (1 if poison else 0)
 
 
+@pytest.mark.parametrize("F,B,Ki,Ko", [(3, 128, 64, 64), (7, 37, 32, 64), (1, 128, 64, 1), (2, 100, 64, 40), (5, 300, 32, 32),
+                                       (2, 2500, 64, 64)])
+@pytest.mark.parametrize("streamk", [False, True])
+def test_tucker_logits_launch(hip_device, F, B, Ki, Ko, streamk):
+    """`ck_tucker_logits_fwd`: the Tucker layer on raw logits + row log-normalisers (kind-6 prologue job), weights =
+    exp(theta - L) applied while they are staged -- against the launch on normalised weights and the oracle, with and
+    without the stream-K workspace."""
+    from cirkit_amd import _capi as capi
+    from cirkit_amd.parameters import ParamBatch
+    from oracle.torch_oracle import _LSE, _layer_forward
+
+    g = torch.Generator().manual_seed(F + B + Ki + Ko)
+    theta = torch.randn(F, Ko, Ki * Ki, generator=g) * 2
+    theta[0, 0, 5] = -200.0  # (a weight that underflows to exactly 0)
+    w = torch.softmax(theta, dim=-1)
+    x = torch.randn(F, 2, B, Ki, generator=g) * 3 - 4
+    spec = LayerSpec("tucker", F, 2, Ki, Ko, {"num_input_units": Ki, "num_output_units": Ko, "arity": 2}, {})
+    with torch.no_grad():
+        want = _layer_forward(_LSE, spec, {"weight": w.reshape(F, Ko, Ki, Ki)}, x)
+    xd, td = x.to(hip_device).contiguous(), theta.to(hip_device).contiguous()
+    row_off = (torch.arange(F * 2, dtype=torch.int64) * (B * Ki)).reshape(F, 2).to(hip_device)
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    lognorm = torch.empty(F, Ko, device=hip_device)
+    batch = ParamBatch()
+    batch.add_row_lognorm(td, lognorm)
+    batch.launch(stream)
+    torch.cuda.synchronize()
+    assert float((lognorm.cpu() - torch.logsumexp(theta, dim=-1)).abs().max()) <= 1e-5
+    n_cu = torch.cuda.get_device_properties(hip_device).multi_processor_count
+    tiles = F * ((Ko + 31) // 32) * ((B + 127) // 128)
+    ws = torch.zeros(n_cu * 3 * 2 * 4 * 1024 + tiles, dtype=torch.int32, device=hip_device)
+    out = torch.full((F, B, Ko), float("nan"), device=hip_device)
+    capi.call("ck_set_workspace", ws.data_ptr() if streamk else None, ws.numel() * 4 if streamk else 0)
+    try:
+        capi.call("ck_tucker_logits_fwd", xd.data_ptr(), row_off.data_ptr(), td.data_ptr(), lognorm.data_ptr(), out.data_ptr(),
+                  F, B, Ki, Ko, stream)
+    finally:
+        capi.call("ck_set_workspace", None, 0)
+    torch.cuda.synchronize()
+    _close(out.cpu(), want)
+
+
 def test_lse_edge_values(hip_device):
     """Rows that are entirely -inf give -inf (amax clamped to finfo.min, semiring.py:392-399), single
     finite entries survive, and a 200-nat spread does not underflow the result."""
