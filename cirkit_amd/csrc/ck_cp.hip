@@ -395,24 +395,6 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
 // lanes -- no bank conflicts -- and the DMA, whose LDS side is linear in the lane, applies the swizzle on its global side.
 // Weights: ring of TWO buffers (W_{t+1} is staged after the barrier of step t, a whole MFMA chain ahead of its use).
 // Same arithmetic, in the same order, as region_lse_kernel: the two agree bit for bit.
-__device__ __forceinline__ void lds_read4(f32x4v& a, f32x4v& b, f32x4v& c, f32x4v& d, uint32_t a0, uint32_t a1,
-                                          uint32_t a2, uint32_t a3) {
-  asm volatile(
-      "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
-      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
-      : "memory");
-}
-template <int O0, int O1, int O2, int O3>
-__device__ __forceinline__ void lds_read4_off(f32x4v& a, f32x4v& b, f32x4v& c, f32x4v& d, uint32_t base) {
-  asm volatile(
-      "ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"
-      "ds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
-      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
-      : "v"(base), "n"(O0), "n"(O1), "n"(O2), "n"(O3)
-      : "memory");
-}
-
 template <int NK, int WAVES, int MINW, bool LINEAR>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
     region_dma_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,

@@ -77,23 +77,28 @@ __global__ void __launch_bounds__(256)
 
   float* dst = out + (static_cast<int64_t>(f) * B + bl) * Ko + 4 * kh;
   for (int p = 0; p < npb; ++p) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of block p has landed in LDS
-    __syncthreads();                      // block p is staged; every wave has left the contraction of block p - 1
+    // this wave's share of block p has landed in LDS; block p is staged when every wave has; every wave has left block p - 1
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (p + 1 < npb) stage_async(p + 1, (p + 1) & 1);
-    const float* wb = w_s + (p & 1) * (NQ * 1024);
+    // (inline LDS reads: with plain loads the compiler waits for the block requested two lines above, ck_tile.h)
+    const uint32_t wb = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + (p & 1) * (NQ * 4096) + lane * 16;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    static_for<0, NQ>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int o = q * 4096;
+      f32x4v w0, w1, w2, w3;
+      lds_read4_off<o, o + 1024, o + 2048, o + 3072>(w0, w1, w2, w3, wb);
+      const f32x4v* wg[4] = {&w0, &w1, &w2, &w3};
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 w4 = *reinterpret_cast<const float4*>(wb + ((q * 4 + g) * 64 + lane) * 4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, e[q][4 * g + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, e[q][4 * g + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, e[q][4 * g + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, e[q][4 * g + 3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[0], e[q][4 * g + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[1], e[q][4 * g + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[2], e[q][4 * g + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[3], e[q][4 * g + 3], acc, 0, 0, 0);
       }
+    });
     if (live) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {

@@ -268,6 +268,27 @@ __device__ __forceinline__ void linear_product(float (&cur)[16], const float (&s
   }
 }
 
+// LDS reads of buffers that global_load_lds_dwordx4 also writes, spelled out: for a plain C++ load the compiler puts
+// s_waitcnt vmcnt(0) in front -- it cannot tell the read from the DMA in flight -- i.e. it waits for every request the wave
+// has just issued (ck_cp.hip, ck_gemm.hip, ck_leaf.hip).
+__device__ __forceinline__ void lds_read4(f32x4v& a, f32x4v& b, f32x4v& c, f32x4v& d, uint32_t a0, uint32_t a1,
+                                          uint32_t a2, uint32_t a3) {
+  asm volatile(
+      "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+      : "memory");
+}
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void lds_read4_off(f32x4v& a, f32x4v& b, f32x4v& c, f32x4v& d, uint32_t base) {
+  asm volatile(
+      "ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"
+      "ds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(base), "n"(O0), "n"(O1), "n"(O2), "n"(O3)
+      : "memory");
+}
+
 // compile-time loop: the walks below are fully unrolled (the sibling stack and the step order are static)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
