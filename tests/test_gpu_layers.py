@@ -269,7 +269,8 @@ def test_lse_edge_values(hip_device):
         _close(layer.forward(xx.to(hip_device)), _oracle(spec, {"w": w}, xx))
 
 
-@pytest.mark.parametrize("F,H,B,K", [(3, 2, 33, 64), (2, 5, 7, 64), (4, 12, 3, 1), (2, 3, 50, 24), (1, 2, 9, 6)])
+@pytest.mark.parametrize("F,H,B,K", [(3, 2, 33, 64), (2, 5, 7, 64), (4, 12, 3, 1), (2, 3, 50, 24), (1, 2, 9, 6), (1, 12, 4096, 1), (3, 16, 300, 3),
+                                     (2, 17, 40, 2)])
 def test_mixing_layer_contract(hip_device, F, H, B, K):
     from cirkit_amd.layers import HipSumLayer
     from cirkit_amd.parameters import TensorStore
