@@ -1189,7 +1189,11 @@ class HipCircuit:
             return f"sum_lse_tile32<{l._w_layout}>" if l.num_input_units == 32 else "cp_lse_kernel<2, 8, false>"
         if (not self._complex and s.type == "sum" and l.arity > 1 and l.num_input_units == l.num_output_units
                 and l.num_input_units in (32, 64)):
-            return f"cat_lse_kernel<{l.num_input_units // 32}, 8>"
+            nk = l.num_input_units // 32
+            waves = 4 if nk == 2 else 8
+            if (2 * 32 + waves * 32 + l.arity) * l.num_input_units * 4 <= 80 * 1024:  # (ck_cp.hip cat_dense)
+                return f"region_dma_kernel<{nk}, {waves}, {3 if nk == 2 else 2}, false>"
+            return f"cat_lse_kernel<{nk}, 8>"
         if not self._complex and s.type in ("sum", "cpt") and not getattr(l, "_mixing", False):
             cat = s.type == "sum" and l.arity > 1
             n = l.num_input_units * (l.arity if cat else 1)

@@ -399,7 +399,11 @@ template <int NK, int WAVES, int MINW, bool LINEAR>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
     region_dma_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                       const int64_t* __restrict__ w_addr, const float* __restrict__ mw, float* __restrict__ out,
-                      int32_t* __restrict__ redo, int H, int S, int B) {
+                      int32_t* __restrict__ redo, int H, int S, int B, const float* __restrict__ w_cat) {
+  // w_cat != nullptr: a dense Sum layer over the CONCATENATION of H children (inner.py:266-273 with a full (K, H K) weight)
+  // as a region with one slot per "partitioning" and unit mixing coefficients: W_h = columns h K .. h K + K - 1 of fold f's
+  // row-major matrix (row stride H K), no w_addr / mw tables.  log sum_h exp(log(W_h e_h) + m_h) is the layer's value
+  // whatever maxima are subtracted on the way.
   constexpr int K = 32 * NK;
   constexpr int UF4 = 32 * K / 4;    // float4 elements of one weight UNIT: the 32 output rows 32 p .. 32 p + 31 of a matrix
   constexpr int CH = K / 4;          // 16-byte chunks per row
@@ -422,21 +426,24 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   constexpr int PF = (UF4 + WAVES * 64 - 1) / (WAVES * 64);
   static_assert(NK == 1 || UF4 % (WAVES * 64) == 0, "the vmcnt bookkeeping of later units assumes every wave stages a share");
   // (addresses = a uniform base + a 32-bit lane offset: global_load_lds with an SGPR base, no 64-bit lane arithmetic)
+  const int w_ld = w_cat != nullptr ? K * T : K;  // row stride of a weight matrix
   uint32_t w_off[PF];  // byte offset of this lane's 16 bytes inside a unit's 32 rows
 #pragma unroll
   for (int k = 0; k < PF; ++k) {
     const int i = threadIdx.x + k * (WAVES * 64);
     const int ln = i & 63, g = (i >> 6) & 3, q = i >> 8;
-    w_off[k] = static_cast<uint32_t>(((ln & 31) * K + 32 * q + 8 * g + 4 * (ln >> 5)) * 4);
+    w_off[k] = static_cast<uint32_t>(((ln & 31) * w_ld + 32 * q + 8 * g + 4 * (ln >> 5)) * 4);
   }
   auto stage_w = [&](int u) {
     const int t = u / NK, p = u % NK;
-    const uint64_t wv = static_cast<uint64_t>(wa[t]);
+    const uint64_t wv = w_cat != nullptr
+                            ? static_cast<uint64_t>(reinterpret_cast<uintptr_t>(w_cat + (static_cast<int64_t>(f) * K * T + t) * K))
+                            : static_cast<uint64_t>(wa[t]);
     if (wv == 0) return;
     // (made uniform explicitly: the compiler otherwise carries the loaded address in vector registers)
     const uint64_t wu = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv >> 32)))) << 32) |
                         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv)));
-    const char* wf = reinterpret_cast<const char*>(static_cast<uintptr_t>(wu)) + p * (32 * K * 4);
+    const char* wf = reinterpret_cast<const char*>(static_cast<uintptr_t>(wu)) + static_cast<int64_t>(p) * (32 * 4) * w_ld;
     float* dstb = w_s + (u & 1) * (32 * K);
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
@@ -469,10 +476,9 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   const uint32_t rd_row = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(my_tile)) + (b_in * CH + swz_b) * 16;
   const uint32_t w_rd = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + lane * 16;
 
-  const float* mwf = mw + static_cast<int64_t>(f) * K * H;
   for (int i = threadIdx.x; i < K * H; i += WAVES * 64) {
     const int k = i / H, h = i - k * H;
-    mw_s[h * K + k] = mwf[i];
+    mw_s[h * K + k] = mw != nullptr ? mw[static_cast<int64_t>(f) * K * H + i] : 1.f;
   }
   stage_w(0);
   stage_tile(0);
@@ -505,7 +511,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
           v[q][12 + e] = r3[e];
         }
       }
-      const bool dense = wa[t] != 0;  // uniform over the workgroup
+      const bool dense = w_cat != nullptr || wa[t] != 0;  // uniform over the workgroup
       float m = 0.f;
       if (dense || LINEAR) {  // (LINEAR: a plain slot enters the product as exp(v - m) with log scale m)
         m = v[0][0];
@@ -766,6 +772,27 @@ int cat_dense(const float* arena, const int64_t* row_off, const float* w, float*
               void* stream) {
   constexpr int WAVES = 8;
   const int tiles = (B + 31) / 32;
+  {  // as a region of H one-slot "partitionings" on the DMA-staged kernel (inputs and weights prefetched a step ahead)
+    const int waves = K == 64 ? 4 : 8;
+    const size_t lds_dma = (static_cast<size_t>(2) * 32 * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(H) * K) * sizeof(float);
+    if (lds_dma <= 80 * 1024 && static_cast<int64_t>(B) * K < (int64_t{1} << 30) && static_cast<int64_t>(H) * K * 32 * 4 < (int64_t{1} << 31) &&
+        !ck::debug_force_generic()) {
+      const dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
+      return ck::dispatch(
+          [=](hipStream_t s) {
+            auto go = [&](auto kern) {
+              hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds_dma));
+              if (e != hipSuccess) return e;
+              hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, static_cast<const int64_t*>(nullptr),
+                                 static_cast<const float*>(nullptr), out, static_cast<int32_t*>(nullptr), H, 1, B, w);
+              return hipGetLastError();
+            };
+            return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
+          },
+          stream);
+    }
+  }
   dim3 grid((tiles + WAVES - 1) / WAVES, F), block(WAVES * 64);
   return ck::dispatch(
       [=](hipStream_t s) {
@@ -835,7 +862,7 @@ extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, con
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds_dma));
           if (e != hipSuccess) return e;
-          hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, w_addr, mw, out, redo, H, S, B);
+          hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, w_addr, mw, out, redo, H, S, B, static_cast<const float*>(nullptr));
           return hipGetLastError();
         };
         // K = 64: 48 KiB + H x 256 B of LDS and <= 168 VGPRs: three workgroups (12 waves) per CU while H <= 20
