@@ -540,6 +540,18 @@ __device__ __forceinline__ float wave_reduce_dpp(float v) {
   return op(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
 
+// the same over each 32-lane half of a wave (rows of 32 weights, two rows per wave)
+template <bool MAX>
+__device__ __forceinline__ float half_reduce_dpp(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x140, 0xF, 0xF, true)));  // row_mirror
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);  // rows 0<->1, 2<->3
+  return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // kind 5 for C <= 256, C % 4 == 0 (the usual Categorical sizes): a wave holds a whole (unit, all categories) row of
 // logits in registers -- one float4 per lane -- so the per-unit maximum and log-sum-exp are wave reductions in registers
 // (the job above makes two passes over the logits in LDS for them: 8 of its 22 us at config 2), and the tile in LDS
@@ -569,13 +581,11 @@ __device__ __forceinline__ void softmax_job_table_dense_rows(const ck_softmax_jo
 #pragma unroll
     for (int it = 0; it < 16 / kPW; ++it) {
       const int row = it * (2 * kPW) + wave * 2 + half;
-      float mx = t[it];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      // (reductions over the 32 lanes of a half by DPP / v_permlane16_swap: a __shfl_xor is an LDS round trip per step,
+      // ten of them per row in a chain)
+      const float mx = half_reduce_dpp<true>(t[it]);
       const float e = __expf(t[it] - mx);
-      float sum = e;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const float sum = half_reduce_dpp<false>(e);
       w_s[row * 32 + l] = e / sum;
     }
   }
