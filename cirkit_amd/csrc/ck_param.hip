@@ -239,6 +239,9 @@ __device__ __forceinline__ void softmax_rows_medium(const ck_softmax_job& j, int
   }
 }
 
+template <bool MAX>
+__device__ __forceinline__ float half_reduce_dpp(float v);  // (below: over each 32-lane half of a wave, no LDS)
+
 __device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int blk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int len = j.len;
@@ -265,13 +268,9 @@ __device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int bl
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int64_t row = static_cast<int64_t>(blk) * (16 * kPW) + it * (2 * kPW) + wave * 2 + half;
-      float mx = x[it];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float mx = half_reduce_dpp<true>(x[it]);
       const float e = ok[it] ? __expf(x[it] - mx) : 0.f;
-      float sum = e;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const float sum = half_reduce_dpp<false>(e);
       if (ok[it]) {
         const float p = e / sum;
         if (j.kind == 0) {
@@ -445,13 +444,9 @@ __device__ __forceinline__ void softmax_job_table_dense(const ck_softmax_job& j,
     for (int it = 0; it < 16 / kPW; ++it) {
       const int row = it * (2 * kPW) + wave * 2 + half;
       const float x = th[row * 32 + l];
-      float mx = x;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float mx = half_reduce_dpp<true>(x);
       const float e = __expf(x - mx);
-      float sum = e;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const float sum = half_reduce_dpp<false>(e);
       w_s[row * 32 + l] = e / sum;
     }
   }
