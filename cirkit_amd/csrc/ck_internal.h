@@ -64,16 +64,23 @@ constexpr int kWave = 64;  // gfx950 wavefront
   } while (0)
 
 // ---- device-side helpers ---------------------------------------------------------------------
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+// maximum / sum over the 64 lanes of a wave, every lane gets the result, without LDS: DPP inside the 16-lane rows,
+// v_permlane16_swap and v_permlane32_swap (gfx950) across them.  (A __shfl_xor compiles to ds_bpermute_b32: an LDS round
+// trip per step, six of them in a chain per reduction.)
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
+  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x140, 0xF, 0xF, true)));  // row_mirror
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return op(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce<true>(v); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce<false>(v); }
 // max of a value with its partner in the other 32-lane half of the wave (the two halves of a 32-row tile hold the
 // two unit groups of a row).  v_permlane32_swap_b32 (gfx950) exchanges the halves inside the VALU; the __shfl_xor it
 // replaces compiled to ds_bpermute_b32, an LDS round trip in the middle of every log-sum-exp step.

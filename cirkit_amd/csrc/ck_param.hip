@@ -520,19 +520,9 @@ __device__ __forceinline__ void softmax_job_table_dense(const ck_softmax_job& j,
   }
 }
 
-// maximum / sum over the 64 lanes of a wave without LDS: DPP inside the 16-lane rows, v_permlane16_swap and
-// v_permlane32_swap across them (a __shfl_xor is a ds_bpermute: an LDS round trip per step)
 template <bool MAX>
 __device__ __forceinline__ float wave_reduce_dpp(float v) {
-  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x140, 0xF, 0xF, true)));  // row_mirror
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
-  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return op(__uint_as_float(q[0]), __uint_as_float(q[1]));
+  return ck::wave_reduce<MAX>(v);  // (ck_internal.h)
 }
 
 // the same over each 32-lane half of a wave (rows of 32 weights, two rows per wave)
