@@ -290,7 +290,7 @@ hipError_t launch_split(bool cat, hipStream_t s, const float* arena, const int64
 template <int NK, int NB, bool SPLIT>
 __global__ void __launch_bounds__(256)
     tucker_lse_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off, const float* __restrict__ w,
-                      float* __restrict__ out, int F, int B, int Ko, int gx, int gsplit, const float* __restrict__ lognorm) {
+                      float* __restrict__ out, int F, int B, int Ko, int gx, int gsplit) {
   constexpr int Ki = 32 * NK;
   constexpr int N = Ki * Ki;
   constexpr int CI = SPLIT ? 4 : (NK == 1 ? 2 : 1);   // left indices per staged chunk
@@ -323,7 +323,6 @@ __global__ void __launch_bounds__(256)
   // 4 consecutive threads read 64 contiguous bytes of one weight row; 16 rows per 64 threads.
   constexpr int PF = CHUNK / 4 / 256;
   float4 pre[PF];
-  float nl2[PF];  // logits mode: -lognorm[f, o] log2 e of the row each staged float4 belongs to (o < Ko), +inf marker unused
   auto fetch = [&](int c) {
     const int grp = c / (Ki / CI), i0 = (c % (Ki / CI)) * CI;
 #pragma unroll
@@ -335,14 +334,6 @@ __global__ void __launch_bounds__(256)
       const int ci = rest / (2 * NB);
       pre[k] = o < Ko ? *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o) * N + (i0 + ci) * Ki + 4 * c4)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lognorm != nullptr) {
-        if (o < Ko) {  // softmax(theta) = exp(theta - L), applied here: the weights never exist in memory
-          const float n = -lognorm[static_cast<int64_t>(f) * Ko + o] * kL2E;
-          nl2[k] = n;
-        } else {
-          nl2[k] = __builtin_nanf("");  // (rows past Ko stay zero)
-        }
-      }
     }
   };
   auto commit = [&](int buf) {
@@ -355,14 +346,7 @@ __global__ void __launch_bounds__(256)
       const int o = (rest % (2 * NB)) * 16 + ((idx >> 2) & 15);
       const int ci = rest / (2 * NB);
       const int col = 4 * c4, q = col >> 5, g = (col >> 3) & 3, k2 = (col >> 2) & 1;
-      float4 v = pre[k];
-      if (lognorm != nullptr && nl2[k] == nl2[k]) {
-        v.x = __builtin_amdgcn_exp2f(fmaf(v.x, kL2E, nl2[k]));
-        v.y = __builtin_amdgcn_exp2f(fmaf(v.y, kL2E, nl2[k]));
-        v.z = __builtin_amdgcn_exp2f(fmaf(v.z, kL2E, nl2[k]));
-        v.w = __builtin_amdgcn_exp2f(fmaf(v.w, kL2E, nl2[k]));
-      }
-      *reinterpret_cast<float4*>(dst + ((((ci * NB + (o >> 5)) * NK + q) * 4 + g) * 64 + (o & 31) + 32 * k2) * 4) = v;
+      *reinterpret_cast<float4*>(dst + ((((ci * NB + (o >> 5)) * NK + q) * 4 + g) * 64 + (o & 31) + 32 * k2) * 4) = pre[k];
     }
   };
   fetch(0);
@@ -483,7 +467,7 @@ __global__ void __launch_bounds__(256)
 
 template <int NK, int NB, bool SPLIT>
 hipError_t launch_tucker(hipStream_t s, const float* arena, const int64_t* row_off, const float* w, float* out, int F,
-                         int B, int Ko, int gx, int gsplit, const float* lognorm) {
+                         int B, int Ko, int gx, int gsplit) {
   constexpr int CI = SPLIT ? 4 : (NK == 1 ? 2 : 1);
   const size_t lds = (2 * CI * NB * NK * 1024 + 4 * 32 * NK * 32 + (SPLIT ? 4 * NB * 1024 : 0)) * sizeof(float);
   auto kern = tucker_lse_kernel<NK, NB, SPLIT>;
@@ -493,7 +477,7 @@ hipError_t launch_tucker(hipStream_t s, const float* arena, const int64_t* row_o
     if (e != hipSuccess) return e;
   }
   const dim3 grid(static_cast<unsigned>((F + 7) / 8 * 8 * gx * gsplit));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, arena, row_off, w, out, F, B, Ko, gx, gsplit, lognorm);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, arena, row_off, w, out, F, B, Ko, gx, gsplit);
   return hipGetLastError();
 }
 
@@ -640,15 +624,25 @@ __global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a
       if (i + 2 < i_end) fetch(i + 2);
       const float* wb = w_s + ((i - i_begin) & 1) * CHUNK;
       const float eli = el_w[i * 32];
+      // the outer-product row e_l[i] * e_r[.] as packed multiplies IN FRONT of the MFMA chain (interleaved into it, one
+      // multiply per MFMA, the compiler emits 32 single ones: every VALU instruction adds to the chain's time)
+      float pr[NK][16];
+#pragma unroll
+      for (int q = 0; q < NK; ++q) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) pr[q][j] = er[q][j];
+        tile_scale(pr[q], eli);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < NK; ++q)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const float4 w4 = *reinterpret_cast<const float4*>(wb + (((q * 4 + gq) * 64) + lane) * 4);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, eli * er[q][4 * gq + 0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, eli * er[q][4 * gq + 1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, eli * er[q][4 * gq + 2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, eli * er[q][4 * gq + 3], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, pr[q][4 * gq + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, pr[q][4 * gq + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, pr[q][4 * gq + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, pr[q][4 * gq + 3], acc, 0, 0, 0);
         }
     }
     float* dst = a.out + (static_cast<int64_t>(f) * a.B + bl) * a.Ko;
@@ -784,17 +778,20 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
           stream);
     }
   }
+  if (lognorm != nullptr)  // (one workgroup per tile would apply the exponential once per 128 rows: the caller normalises first)
+    return ck::fail(CK_ERR_UNSUPPORTED, "Tucker launch on logits: %lld tiles need the stream-K launch (a workspace and at most %d tiles)",
+                    static_cast<long long>(wg1), 8 * ck::num_cus() * 3);
   const bool two = nblocks % 2 == 0 && wg1 > 4096;
   const bool split = wg1 <= 128;
   const int gx = split ? tiles : (tiles + 3) / 4;
   return ck::dispatch(
       [=](hipStream_t s) {
-        if (two) return Ki == 32 ? launch_tucker<1, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1, lognorm)
-                                 : launch_tucker<2, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1, lognorm);
-        if (split) return Ki == 32 ? launch_tucker<1, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks, lognorm)
-                                   : launch_tucker<2, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks, lognorm);
-        return Ki == 32 ? launch_tucker<1, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks, lognorm)
-                        : launch_tucker<2, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks, lognorm);
+        if (two) return Ki == 32 ? launch_tucker<1, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1)
+                                 : launch_tucker<2, 2, false>(s, arena, row_off, w, out, F, B, Ko, gx, 1);
+        if (split) return Ki == 32 ? launch_tucker<1, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks)
+                                   : launch_tucker<2, 1, true>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks);
+        return Ki == 32 ? launch_tucker<1, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks)
+                        : launch_tucker<2, 1, false>(s, arena, row_off, w, out, F, B, Ko, gx, nblocks);
       },
       stream);
 }

@@ -911,6 +911,19 @@ __global__ void __launch_bounds__(256) softmax_long_rows_kernel(const float* __r
   }
 }
 
+// out[r, :] = exp(in[r, :] - lognorm[r]): the normalised weights from logits and row log-normalisers (kind-6 job), for the
+// launches that need them in memory
+__global__ void __launch_bounds__(256) exp_rows_kernel(const float* __restrict__ in, const float* __restrict__ lognorm,
+                                                       float* __restrict__ out, int64_t rows, int len4) {
+  const int64_t n = rows * len4;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const float nl = -lognorm[i / len4] * 1.4426950408889634f;
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(__builtin_amdgcn_exp2f(fmaf(v.x, 1.4426950408889634f, nl)), __builtin_amdgcn_exp2f(fmaf(v.y, 1.4426950408889634f, nl)),
+                                                   __builtin_amdgcn_exp2f(fmaf(v.z, 1.4426950408889634f, nl)), __builtin_amdgcn_exp2f(fmaf(v.w, 1.4426950408889634f, nl)));
+  }
+}
+
 bool long_row_job(const ck_softmax_job& j) {  // kind 6: the log-normaliser of every row instead of the softmax
   return (j.kind == 0 || j.kind == 6) && j.len >= 512 && j.len <= 4096 && j.len % 4 == 0 && ck::aligned16(j.in) &&
          (j.kind == 6 || ck::aligned16(j.out));
@@ -956,6 +969,20 @@ int launch_long_rows(const ck_softmax_job& j, void* stream) {
 }  // namespace
 
 extern "C" {
+
+int ck_param_exp_rows(const float* in, const float* lognorm, float* out, int64_t rows, int len, void* stream) {
+  CK_REQUIRE(in && lognorm && out, "ck_param_exp_rows: null pointer");
+  CK_REQUIRE(rows > 0 && len > 0 && len % 4 == 0, "ck_param_exp_rows: rows=%lld len=%d (len must be a multiple of 4)", static_cast<long long>(rows), len);
+  CK_REQUIRE(ck::aligned16(in) && ck::aligned16(out), "ck_param_exp_rows: buffers must be 16-byte aligned");
+  const int len4 = len / 4;
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>((rows * len4 + 255) / 256, 256 * 32))), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(exp_rows_kernel, grid, block, 0, s, in, lognorm, out, rows, len4);
+        return hipGetLastError();
+      },
+      stream);
+}
 
 int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_t inner,
                      int log_space, void* stream) {

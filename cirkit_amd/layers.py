@@ -695,8 +695,17 @@ class HipTuckerLayer(HipSumLayer):
     def launch(self, arena, row_off, out, B, stream) -> None:
         if not self._use_logits:
             return super().launch(arena, row_off, out, B, stream)
-        capi.call("ck_tucker_logits_fwd", _ptr(arena), _ptr(row_off), _ptr(self._theta), _ptr(self._lognorm), _ptr(out),
-                  self.num_folds, B, self.num_input_units, self.num_output_units, stream)
+        try:
+            capi.call("ck_tucker_logits_fwd", _ptr(arena), _ptr(row_off), _ptr(self._theta), _ptr(self._lognorm), _ptr(out),
+                      self.num_folds, B, self.num_input_units, self.num_output_units, stream)
+        except NotImplementedError:
+            # many tiles per resident workgroup (a large batch): one workgroup per tile would apply the exponential once per
+            # 128 rows, so the normalised weights are written after all -- exp(theta - lognorm) -- and the launch reads them
+            if self._w is None or self._w.shape != self._theta.shape or self._w.data_ptr() == self._theta.data_ptr():
+                self._w = torch.empty_like(self._theta)
+            rows = self._theta.numel() // self._theta.shape[-1]
+            capi.call("ck_param_exp_rows", _ptr(self._theta), _ptr(self._lognorm), _ptr(self._w), rows, int(self._theta.shape[-1]), stream)
+            super().launch(arena, row_off, out, B, stream)
 
 
 class HipTensorDotLayer(HipInnerLayer):

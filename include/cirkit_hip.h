@@ -149,7 +149,12 @@ int ck_debug_force_generic(int on);
 /* TorchTuckerLayer.forward (optimized.py:89-103) of arity 2 with 32 / 64 input units whose weight is softmax(theta) over its
  * last axis (parameters/nodes.py:764-772), WITHOUT the normalised weights in memory: theta (F, Ko, Ki^2) raw logits,
  * lognorm (F, Ko) their row log-normalisers (ck_param_softmax_batch kind 6); the launch applies exp(theta - lognorm)
- * while it stages the weights.  Same launches as ck_sum_lse_fwd in CK_SUM_KRON mode (ck_set_workspace applies). */
+ * while it stages the weights (the stream-K launch of ck_sum_lse_fwd in CK_SUM_KRON mode: needs the workspace of
+ * ck_set_workspace and few tiles per resident workgroup, otherwise CK_ERR_UNSUPPORTED -- with one workgroup per tile the
+ * exponential would be applied once per 128 rows: normalise with ck_param_exp_rows and call ck_sum_lse_fwd instead). */
+/* out[r, :] = exp(in[r, :] - lognorm[r]) for `rows` rows of `len` (a multiple of 4): softmax(in) from the kind-6 row
+ * log-normalisers, for consumers that need the normalised weights in memory. */
+int ck_param_exp_rows(const float* in, const float* lognorm, float* out, int64_t rows, int len, void* stream);
 int ck_tucker_logits_fwd(const float* arena, const int64_t* row_off, const float* theta, const float* lognorm, float* out,
                          int F, int B, int Ki, int Ko, void* stream);
 /* complex-lse-sum variant (semiring.py:441-476); w real (w_is_complex=0) or complex64. */

@@ -237,8 +237,17 @@ def test_tucker_logits_launch(hip_device, F, B, Ki, Ko, streamk):
     out = torch.full((F, B, Ko), float("nan"), device=hip_device)
     capi.call("ck_set_workspace", ws.data_ptr() if streamk else None, ws.numel() * 4 if streamk else 0)
     try:
-        capi.call("ck_tucker_logits_fwd", xd.data_ptr(), row_off.data_ptr(), td.data_ptr(), lognorm.data_ptr(), out.data_ptr(),
-                  F, B, Ki, Ko, stream)
+        if streamk:
+            capi.call("ck_tucker_logits_fwd", xd.data_ptr(), row_off.data_ptr(), td.data_ptr(), lognorm.data_ptr(), out.data_ptr(),
+                      F, B, Ki, Ko, stream)
+        else:  # without the stream-K launch the exponential would be applied once per 128 rows: refused, normalise first
+            with pytest.raises(NotImplementedError):
+                capi.call("ck_tucker_logits_fwd", xd.data_ptr(), row_off.data_ptr(), td.data_ptr(), lognorm.data_ptr(),
+                          out.data_ptr(), F, B, Ki, Ko, stream)
+            wn = torch.empty_like(td)
+            capi.call("ck_param_exp_rows", td.data_ptr(), lognorm.data_ptr(), wn.data_ptr(), F * Ko, Ki * Ki, stream)
+            capi.call("ck_sum_lse_fwd", xd.data_ptr(), row_off.data_ptr(), wn.data_ptr(), out.data_ptr(), F, 2, B, Ki, Ko,
+                      capi.CK_SUM_KRON, capi.CK_W_ROWMAJOR, stream)
     finally:
         capi.call("ck_set_workspace", None, 0)
     torch.cuda.synchronize()
