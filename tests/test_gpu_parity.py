@@ -474,6 +474,28 @@ def test_persistent_leaf_launch_is_bit_identical(hip_device, B):
     assert torch.allclose(yb, ref, rtol=1e-5, atol=2e-3)
 
 
+def test_persistent_leaf_segments_longer_than_a_chunk(hip_device, monkeypatch):
+    """A segment of more than 64 x 8 tiles is walked in chunks (the 64-bit mask of tiles to redo covers one chunk): with
+    whole roots as segments and 17 000 rows (532 tiles per segment) the launch is still bit-identical to the
+    workgroup-per-128-rows launch."""
+    import cirkit_amd.circuit as circuit_mod
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    B = 17_000
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 256, (B, 784), generator=gen)
+    x[::11, ::3] = -1
+    x = x.to(hip_device)
+    monkeypatch.setattr(circuit_mod, "leaf_segments",
+                        lambda num_roots, num_tiles, num_wg: np.asarray([[r, 0, num_tiles, 0] for r in range(num_roots)], dtype=np.int32))
+    a = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=False)
+    b = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True)
+    ya, yb = a(x).clone(), b(x).clone()
+    assert b.kernel_label(b._groups[0].root, B).startswith("leaf_persistent_kernel")
+    assert torch.equal(ya, yb)
+
+
 def test_persistent_leaf_falls_back_to_log_space(hip_device):
     """Products at the edge of fp32 (see test_linear_levels_survive_products_at_the_edge_of_fp32) under the persistent
     launch: the tile is redone in log space by the same out-of-line walk, bit-identical to the other launch."""
