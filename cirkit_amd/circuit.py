@@ -530,7 +530,7 @@ class HipCircuit:
                 self._scratch_buf = False
             else:
                 tiles = max(l.num_folds * ((l.num_output_units + 31) // 32) for l in tuck) * 8  # (row groups at B <= 1024)
-                nbytes = self._n_cu * 3 * 2 * 4 * 1024 * 4 + tiles * 4
+                nbytes = self._n_cu * 3 * 2 * (4 * 1024 + 64) * 4 + tiles * 4  # partial tiles, their (max, sum) rows, tickets
                 self._scratch_buf = torch.zeros(nbytes // 4, dtype=torch.int32, device=self.device)
         return None if self._scratch_buf is False else self._scratch_buf
 

@@ -492,27 +492,51 @@ hipError_t launch_tucker(hipStream_t s, const float* arena, const int64_t* row_o
 // contributor order -- its own included, so the order never depends on who arrives last -- and writes log(sum) + m.
 // Nobody waits for anybody.  Exact fp32 MFMA as tucker_lse_kernel; the split points change the order of the adds, so
 // the two agree to fp32 rounding.
+// reductions over the 8 lanes that share a weight row (DPP: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror)
+__device__ __forceinline__ float oct_max(float v) {
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));
+  return fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));
+}
+__device__ __forceinline__ float oct_sum(float v) {
+  v += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true));
+  v += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true));
+  return v + __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true));
+}
+
 struct StreamKArgs {
   const float* arena;
   const int64_t* row_off;
   const float* w;
   float* out;
-  const float* lognorm; // nullptr, or (F, Ko): `w` holds logits and the weights are exp(w - lognorm[f, o])
   float* ws;            // (G, 2, 128 x 32) partial accumulators: slot 0 = a workgroup's first tile, slot 1 = its last
+  float* stats;         // LOGITS: (G, 2, 64) running maximum (log2 units) and sum of the 32 weight rows of a partial tile
   uint32_t* tickets;    // (tiles) zero on entry, zero again afterwards
   int F, B, Ko, nblk, rgroups;
   int64_t total;        // chunks = F * nblk * rgroups * Ki
 };
 
-template <int NK>
-__global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a) {
+// LOGITS: `w` holds logits theta and the weights are softmax(theta) over the (i, j) axis (parameters/nodes.py:764-772),
+// normalised ONLINE: a workgroup stages exp(theta - m) with a running row maximum m (raised, with the accumulators and the
+// running sum rescaled, only when a chunk's maximum exceeds it by more than 2^24 -- in practice on no chunk but the
+// first), keeps sum exp(theta - m) beside the accumulators and subtracts log(sum) once per output; partial tiles carry
+// (m, sum) per weight row into the combine.  The logits are read ONCE per forward and no normalised copy or normaliser
+// ever exists in memory.
+template <int NK, bool LOGITS>
+__global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArgs a) {  // three workgroups per CU
   constexpr int Ki = 32 * NK;
   constexpr int N = Ki * Ki;
-  constexpr int CHUNK = NK * 1024;  // floats of one chunk: 32 outputs x Ki right indices, operand layout
+  // floats of one chunk: 32 outputs x Ki right indices as [c4][o_local ^ 8 (c4 & 1)] float4s -- the operand layout with
+  // the rows of odd float4 columns swizzled, so that the 64 float4s a wave stages per instruction (8 rows x 8 columns)
+  // fall on 16 bank groups x 4, the minimum
+  constexpr int CHUNK = NK * 1024;
   constexpr int PF = CHUNK / 4 / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* w_s = smem;               // [2][CHUNK]
   float* el_s = smem + 2 * CHUNK;  // [4 waves][Ki][32]
+  float* alpha_s = el_s + 4 * Ki * 32;                             // LOGITS: [2][32] accumulator rescaling of chunk buffer b
+  uint32_t* flag_s = reinterpret_cast<uint32_t*>(alpha_s + 2 * 32); // [2][4] "some row of wave w was rescaled"
+  float* stat_s = alpha_s + 2 * 32 + 2 * 4;                        // [2][32] final (m, sum) of the tile part
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 31, kh = lane >> 5;
   const int64_t G = gridDim.x, g = blockIdx.x;
@@ -541,43 +565,54 @@ __global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a
     const int64_t* ro = a.row_off + static_cast<int64_t>(f) * 2;
     const float* wf = a.w + static_cast<int64_t>(f) * a.Ko * N;
     const int o_base = 32 * nb;
-    auto fetch = [&](int i) {  // 4 consecutive threads read 64 contiguous bytes of one weight row; 16 rows per 64 threads
+    // weight row o_local = 8 wave + lane / 8 (one row per 8 lanes: its maximum is three DPP steps away), float4 column
+    // c4 = lane % 8 + 8 k: 8 lanes read 128 contiguous bytes; the operand layout in LDS is [c4][o_local] float4s
+    const int o_local = wave * 8 + (lane >> 3);
+    const bool o_live = o_base + o_local < a.Ko;
+    auto fetch = [&](int i) {
+      const float fill = LOGITS ? -INFINITY : 0.f;  // (an absent row: weight 0 whatever the running maximum is)
 #pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        const int idx = threadIdx.x + 256 * k;
-        const int c4 = ((idx >> 6) % (2 * NK)) * 4 + (idx & 3);
-        const int rest = (idx >> 6) / (2 * NK);
-        const int o = o_base + (rest % 2) * 16 + ((idx >> 2) & 15);
-        pre[k] = o < a.Ko ? *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o) * N + i * Ki + 4 * c4)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int k = 0; k < PF; ++k)
+        pre[k] = o_live ? *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o_base + o_local) * N + i * Ki + 4 * ((lane & 7) + 8 * k))
+                        : make_float4(fill, fill, fill, fill);
     };
-    // logits mode: the negated log-normalisers (x log2 e) of the PF weight rows this thread stages -- fixed per tile
-    float nl2[PF];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) {
-      const int idx = threadIdx.x + 256 * k;
-      const int o = o_base + (((idx >> 6) / (2 * NK)) % 2) * 16 + ((idx >> 2) & 15);
-      nl2[k] = a.lognorm != nullptr && o < a.Ko ? -a.lognorm[static_cast<int64_t>(f) * a.Ko + o] * kL2E : 0.f;
-    }
-    auto commit = [&](int buf) {
+    float mrun = 0.f, srun = 0.f;  // LOGITS: running maximum (log2 units) of the row, this lane's share of sum exp2(t - mrun)
+    auto commit = [&](int i, int buf) {
       float* dst = w_s + buf * CHUNK;
+      float4 v[PF];
 #pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        const int idx = threadIdx.x + 256 * k;
-        const int c4 = ((idx >> 6) % (2 * NK)) * 4 + (idx & 3);
-        const int rest = (idx >> 6) / (2 * NK);
-        const int o = (rest % 2) * 16 + ((idx >> 2) & 15);
-        const int col = 4 * c4, q = col >> 5, gq = (col >> 3) & 3, k2 = (col >> 2) & 1;
-        float4 v = pre[k];
-        if (a.lognorm != nullptr && o_base + o < a.Ko) {  // softmax(theta) = exp(theta - L): the weights never exist in memory
-          v.x = __builtin_amdgcn_exp2f(fmaf(v.x, kL2E, nl2[k]));
-          v.y = __builtin_amdgcn_exp2f(fmaf(v.y, kL2E, nl2[k]));
-          v.z = __builtin_amdgcn_exp2f(fmaf(v.z, kL2E, nl2[k]));
-          v.w = __builtin_amdgcn_exp2f(fmaf(v.w, kL2E, nl2[k]));
+      for (int k = 0; k < PF; ++k) v[k] = pre[k];
+      if constexpr (LOGITS) {
+        float cm = v[0].x;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) cm = fmaxf(fmaxf(fmaxf(cm, v[k].x), fmaxf(v[k].y, v[k].z)), v[k].w);
+        cm = ck::clamp_finite(oct_max(cm) * kL2E);
+        float alpha = 1.f;
+        bool raised = false;
+        if (i == i_begin) {
+          mrun = cm;
+          srun = 0.f;
+        } else if (cm > mrun + 24.f) {
+          raised = true;
+          alpha = __builtin_amdgcn_exp2f(mrun - cm);
+          srun *= alpha;
+          mrun = cm;
         }
-        *reinterpret_cast<float4*>(dst + (((q * 4 + gq) * 64) + (o & 31) + 32 * k2) * 4) = v;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+          v[k].x = __builtin_amdgcn_exp2f(fmaf(v[k].x, kL2E, -mrun));
+          v[k].y = __builtin_amdgcn_exp2f(fmaf(v[k].y, kL2E, -mrun));
+          v[k].z = __builtin_amdgcn_exp2f(fmaf(v[k].z, kL2E, -mrun));
+          v[k].w = __builtin_amdgcn_exp2f(fmaf(v[k].w, kL2E, -mrun));
+          srun += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+        if ((lane & 7) == 0) alpha_s[buf * 32 + o_local] = alpha;
+        const bool any_raised = __any(raised);
+        if (lane == 0) flag_s[buf * 4 + wave] = any_raised ? 1u : 0u;
       }
+#pragma unroll
+      for (int k = 0; k < PF; ++k)
+        *reinterpret_cast<float4*>(dst + (((lane & 7) + 8 * k) * 32 + (o_local ^ ((lane & 1) * 8))) * 4) = v[k];
     };
     fetch(i_begin);
     // exponentiated children of (fold f, this wave's 32 rows): e_r as a register tile, e_l through LDS
@@ -616,13 +651,27 @@ __global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* el_w = el_s + wave * (Ki * 32) + b_in;
-    commit(0);
+    commit(i_begin, 0);
     if (i_begin + 1 < i_end) fetch(i_begin + 1);
     for (int i = i_begin; i < i_end; ++i) {
       __syncthreads();  // chunk i (and, the first time, e_l) is in LDS; every wave has left chunk i - 1
-      if (i + 1 < i_end) commit((i + 1 - i_begin) & 1);
+      if (i + 1 < i_end) commit(i + 1, (i + 1 - i_begin) & 1);
       if (i + 2 < i_end) fetch(i + 2);
       const float* wb = w_s + ((i - i_begin) & 1) * CHUNK;
+      if constexpr (LOGITS) {  // chunk i was staged against a higher maximum than the accumulators hold (rare)
+        const int buf = (i - i_begin) & 1;
+        const uint4 fl = *reinterpret_cast<const uint4*>(flag_s + 4 * buf);
+        if (__builtin_amdgcn_readfirstlane(fl.x | fl.y | fl.z | fl.w) != 0) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const float4 al = *reinterpret_cast<const float4*>(alpha_s + 32 * buf + 8 * gq + 4 * kh);
+            acc[4 * gq + 0] *= al.x;
+            acc[4 * gq + 1] *= al.y;
+            acc[4 * gq + 2] *= al.z;
+            acc[4 * gq + 3] *= al.w;
+          }
+        }
+      }
       const float eli = el_w[i * 32];
       // the outer-product row e_l[i] * e_r[.] as packed multiplies IN FRONT of the MFMA chain (interleaved into it, one
       // multiply per MFMA, the compiler emits 32 single ones: every VALU instruction adds to the chain's time)
@@ -638,7 +687,7 @@ __global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a
       for (int q = 0; q < NK; ++q)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const float4 w4 = *reinterpret_cast<const float4*>(wb + (((q * 4 + gq) * 64) + lane) * 4);
+          const float4 w4 = *reinterpret_cast<const float4*>(wb + ((q * 4 + gq) * 64 + kh * 32 + (b_in ^ (8 * kh))) * 4);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, pr[q][4 * gq + 0], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, pr[q][4 * gq + 1], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, pr[q][4 * gq + 2], acc, 0, 0, 0);
@@ -647,13 +696,26 @@ __global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a
     }
     float* dst = a.out + (static_cast<int64_t>(f) * a.B + bl) * a.Ko;
     const int o0 = o_base + 4 * kh;
-    auto write_out = [&](const f32x16& y) {
+    if constexpr (LOGITS) {  // (m, sum) of the 32 weight rows of this tile part
+      const float st = oct_sum(srun);
+      if ((lane & 7) == 0) {
+        stat_s[o_local] = mrun;
+        stat_s[32 + o_local] = st;
+      }
+      __syncthreads();
+    }
+    // y: sums of weights * products; sw (LOGITS): the sums of the weights of the rows, log(y / sw) + m is the output
+    auto write_out = [&](const f32x16& y, const f32x16& sw) {
       if (!live) return;
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         float o4[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) o4[t] = fmaf(__builtin_amdgcn_logf(y[4 * gq + t]), kLN2, m);
+        for (int t = 0; t < 4; ++t) {
+          float l2 = __builtin_amdgcn_logf(y[4 * gq + t]);
+          if constexpr (LOGITS) l2 -= __builtin_amdgcn_logf(sw[4 * gq + t]);
+          o4[t] = fmaf(l2, kLN2, m);
+        }
         if ((a.Ko & 31) == 0) {
           *reinterpret_cast<float4*>(dst + o0 + 8 * gq) = make_float4(o4[0], o4[1], o4[2], o4[3]);
         } else {
@@ -663,15 +725,22 @@ __global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a
         }
       }
     };
-    if (i_begin == 0 && i_end == Ki) {
-      write_out(acc);  // the whole tile is this workgroup's
+    if (i_begin == 0 && i_end == Ki) {  // the whole tile is this workgroup's
+      f32x16 sw;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sw[r] = LOGITS ? stat_s[32 + 8 * (r >> 2) + 4 * kh + (r & 3)] : 1.f;
+      write_out(acc, sw);
     } else {
       // partial: slot (g, tile == first tile ? 0 : 1); lane-major so that a wave writes 16 contiguous KiB-quarters
-      float* slot = a.ws + ((g * 2 + (tile == first_tile ? 0 : 1)) * 4 + wave) * 1024;
+      const int64_t my_slot = g * 2 + (tile == first_tile ? 0 : 1);
+      float* slot = a.ws + (my_slot * 4 + wave) * 1024;
       // agent-scope atomic stores and loads (write-through / past the non-coherent caches) instead of release / acquire
       // fences: a fence writes back and invalidates a whole L2 -- with 768 workgroups doing it, a sixth of the launch
 #pragma unroll
       for (int r = 0; r < 16; ++r) __hip_atomic_store(slot + r * 64 + lane, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (LOGITS) {
+        if (threadIdx.x < 64) __hip_atomic_store(a.stats + my_slot * 64 + threadIdx.x, stat_s[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have completed
       __syncthreads();  // ... those of all four waves
       const int64_t t0 = tile * Ki;
@@ -682,16 +751,60 @@ __global__ void __launch_bounds__(256) tucker_streamk_kernel(const StreamKArgs a
       if (threadIdx.x == 0) s_ticket = ticket;
       __syncthreads();
       if (s_ticket == static_cast<unsigned int>(g_last - g_first)) {  // the last contributor: everybody's slot is visible
-        f32x16 y;
+        f32x16 y, sw;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = 0.f;
-        for (int64_t gg = g_first; gg <= g_last; ++gg) {
-          const int which = (start_of(gg) / Ki == tile) ? 0 : 1;
-          const float* src = a.ws + ((gg * 2 + which) * 4 + wave) * 1024;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) y[r] += __hip_atomic_load(src + r * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = 0; r < 16; ++r) {
+          y[r] = 0.f;
+          sw[r] = 1.f;
         }
-        write_out(y);
+        auto slot_of = [&](int64_t gg) { return gg * 2 + ((start_of(gg) / Ki == tile) ? 0 : 1); };
+        auto load_part = [&](int64_t gg, f32x16& p) {
+          const float* src = a.ws + (slot_of(gg) * 4 + wave) * 1024;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p[r] = __hip_atomic_load(src + r * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // one pass over the parts in contributor order, the next part's loads in flight while this one is added (each
+        // is a round trip to L2)
+        f32x16 cur, nxt;
+        load_part(g_first, cur);
+        // LOGITS: the parts were staged against different row maxima m_p.  With M = max_p m_p the factors
+        // e_p = exp2(m_p - M) bring them to one scale: y = sum_p e_p acc_p, sum of weights = sum_p e_p s_p.  All (m_p, s_p)
+        // are fetched at once (a thread per part and row), the factors go through LDS (the chunk buffers are free now).
+        float* ef_s = w_s;                                                 // [parts][32] m_p, then e_p
+        float* sp_s = w_s + 32 * static_cast<int>(g_last - g_first + 1);   // [parts][32] s_p; row 0 becomes the total
+        if constexpr (LOGITS) {
+          const int np = static_cast<int>(g_last - g_first + 1);  // <= Ki / 8 + 1: a workgroup has at least 8 chunks
+          for (int idx = threadIdx.x; idx < np * 32; idx += 256) {
+            const float* st = a.stats + slot_of(g_first + (idx >> 5)) * 64 + (idx & 31);
+            ef_s[idx] = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sp_s[idx] = __hip_atomic_load(st + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          __syncthreads();
+          if (threadIdx.x < 32) {
+            float mm = ef_s[threadIdx.x];
+            for (int q = 1; q < np; ++q) mm = fmaxf(mm, ef_s[q * 32 + threadIdx.x]);
+            float tot = 0.f;
+            for (int q = 0; q < np; ++q) {
+              const float e = __builtin_amdgcn_exp2f(ef_s[q * 32 + threadIdx.x] - mm);
+              ef_s[q * 32 + threadIdx.x] = e;
+              tot = fmaf(sp_s[q * 32 + threadIdx.x], e, tot);
+            }
+            sp_s[threadIdx.x] = tot;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sw[r] = sp_s[8 * (r >> 2) + 4 * kh + (r & 3)];
+        }
+        for (int64_t gg = g_first; gg <= g_last; ++gg) {
+          if (gg < g_last) load_part(gg + 1, nxt);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (LOGITS) y[r] = fmaf(cur[r], ef_s[static_cast<int>(gg - g_first) * 32 + 8 * (r >> 2) + 4 * kh + (r & 3)], y[r]);
+            else y[r] += cur[r];
+          }
+          cur = nxt;
+        }
+        write_out(y, sw);
         if (threadIdx.x == 0) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -729,7 +842,7 @@ bool tucker_applies(int H, int Ki, int Ko, int mode) { return mode == CK_SUM_KRO
 
 // Tucker layer of arity 2 with 32 or 64 units per child.
 int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int B, int Ki, int Ko,
-               void* stream, const float* lognorm) {
+               void* stream, bool logits) {
   const int tiles = (B + 31) / 32, nblocks = (Ko + 31) / 32;
   // Many workgroups: two blocks of outputs share every e_l * e_r product.  Fewer: one block per workgroup, so that a
   // fold's work is spread over Ko / 32 workgroups.  Fewer than the chip has CUs: the waves of a workgroup split the
@@ -745,18 +858,20 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
     // (at least 8 chunks per workgroup: each pays the exponentials of its tile's children once; measured 4 / 8 / 16 / 32:
     // 22 / 22 / 30 / 48 us for the layers of 2..12 folds, no difference for the large ones)
     const int64_t G = std::max<int64_t>(1, std::min<int64_t>(total / 8, slots));
-    // workspace layout (the same for every launch that shares it): [slots x 2 partial tiles of 16 KiB][ticket per tile]
+    // workspace layout (the same for every launch that shares it):
+    // [slots x 2 partial tiles of 16 KiB][slots x 2 x (32 maxima, 32 sums)][ticket per tile]
     const int64_t slot_bytes = static_cast<int64_t>(slots) * 2 * 4 * 1024 * static_cast<int64_t>(sizeof(float));
-    const int64_t need = slot_bytes + wg1 * 4;
+    const int64_t stat_bytes = static_cast<int64_t>(slots) * 2 * 64 * static_cast<int64_t>(sizeof(float));
+    const int64_t need = slot_bytes + stat_bytes + wg1 * 4;
     if (wg1 <= 8 * static_cast<int64_t>(slots) && ws.ptr != nullptr && ws.bytes >= need && !ck::debug_force_generic()) {
       StreamKArgs a{};
       a.arena = arena;
       a.row_off = row_off;
       a.w = w;
       a.out = out;
-      a.lognorm = lognorm;
       a.ws = static_cast<float*>(ws.ptr);
-      a.tickets = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.ptr) + slot_bytes);
+      a.stats = reinterpret_cast<float*>(static_cast<char*>(ws.ptr) + slot_bytes);
+      a.tickets = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.ptr) + slot_bytes + stat_bytes);
       a.F = F;
       a.B = B;
       a.Ko = Ko;
@@ -772,13 +887,15 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
               hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(G)), dim3(256), lds, s, a);
               return hipGetLastError();
             };
-            return Ki == 32 ? go(tucker_streamk_kernel<1>, (2 * 1024 + 4 * 32 * 32) * sizeof(float))
-                            : go(tucker_streamk_kernel<2>, (2 * 2048 + 4 * 64 * 32) * sizeof(float));
+            constexpr size_t extra = 2 * 32 + 2 * 4 + 2 * 32;  // (alpha_s, flag_s, stat_s)
+            const size_t lds = ((Ki == 32 ? 2 * 1024 + 4 * 32 * 32 : 2 * 2048 + 4 * 64 * 32) + extra) * sizeof(float);
+            if (logits) return Ki == 32 ? go(tucker_streamk_kernel<1, true>, lds) : go(tucker_streamk_kernel<2, true>, lds);
+            return Ki == 32 ? go(tucker_streamk_kernel<1, false>, lds) : go(tucker_streamk_kernel<2, false>, lds);
           },
           stream);
     }
   }
-  if (lognorm != nullptr)  // (one workgroup per tile would apply the exponential once per 128 rows: the caller normalises first)
+  if (logits)  // (one workgroup per tile would apply the exponential once per 128 rows: the caller normalises first)
     return ck::fail(CK_ERR_UNSUPPORTED, "Tucker launch on logits: %lld tiles need the stream-K launch (a workspace and at most %d tiles)",
                     static_cast<long long>(wg1), 8 * ck::num_cus() * 3);
   const bool two = nblocks % 2 == 0 && wg1 > 4096;

@@ -48,7 +48,8 @@ bool debug_force_generic();
 bool gemm_applies(int H, int Ki, int Ko, int mode);
 bool tucker_applies(int H, int Ki, int Ko, int mode);
 int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int B, int Ki, int Ko,
-               void* stream, const float* lognorm = nullptr);  // lognorm: w holds logits, weights = exp(w - lognorm[f, o])
+               void* stream, bool logits = false);
+// logits: w holds logits theta and the weights are softmax(theta) over the last axis, normalised online by the launch
 int sum_lse_gemm(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int Ki,
                  int Ko, int mode, void* stream);
 int cat_dense(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,

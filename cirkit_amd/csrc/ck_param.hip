@@ -868,10 +868,7 @@ unsigned grid1d(int64_t n, int cap = 2048) {
 // held in registers between the single read and the single write (N4 float4 per lane, all loads in flight
 // at once), so the kernel moves 2 x 4 bytes per entry -- the row-at-a-time loop of softmax_job_rows
 // reads every row three times with one dependent load per pass.
-// STATS: only the row's log-normaliser L = max + log sum exp(x - max) is written (one float per row): the consumer applies
-// exp(x - L) = softmax(x) itself while it stages the weights (the Tucker launches of ck_gemm.hip) -- the (rows, len) matrix of
-// normalised weights, 1.6 GB at the reference's notebook configuration, is then neither written nor read back.
-template <int N4, bool STATS = false>
+template <int N4>
 __global__ void __launch_bounds__(256) softmax_long_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 int64_t rows, int len) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -898,35 +895,17 @@ __global__ void __launch_bounds__(256) softmax_long_rows_kernel(const float* __r
       sum += (x[k].x + x[k].y) + (x[k].z + x[k].w);
     }
     sum = ck::wave_sum(sum);
-    if constexpr (STATS) {
-      if (lane == 0) out[row] = mx + __logf(sum);
-    } else {
-      float4* dst = reinterpret_cast<float4*>(out + row * len);
+    float4* dst = reinterpret_cast<float4*>(out + row * len);
 #pragma unroll
-      for (int k = 0; k < N4; ++k) {
-        const int i = lane + 64 * k;
-        if (i < n4) dst[i] = make_float4(x[k].x / sum, x[k].y / sum, x[k].z / sum, x[k].w / sum);
-      }
+    for (int k = 0; k < N4; ++k) {
+      const int i = lane + 64 * k;
+      if (i < n4) dst[i] = make_float4(x[k].x / sum, x[k].y / sum, x[k].z / sum, x[k].w / sum);
     }
   }
 }
 
-// out[r, :] = exp(in[r, :] - lognorm[r]): the normalised weights from logits and row log-normalisers (kind-6 job), for the
-// launches that need them in memory
-__global__ void __launch_bounds__(256) exp_rows_kernel(const float* __restrict__ in, const float* __restrict__ lognorm,
-                                                       float* __restrict__ out, int64_t rows, int len4) {
-  const int64_t n = rows * len4;
-  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const float nl = -lognorm[i / len4] * 1.4426950408889634f;
-    const float4 v = reinterpret_cast<const float4*>(in)[i];
-    reinterpret_cast<float4*>(out)[i] = make_float4(__builtin_amdgcn_exp2f(fmaf(v.x, 1.4426950408889634f, nl)), __builtin_amdgcn_exp2f(fmaf(v.y, 1.4426950408889634f, nl)),
-                                                   __builtin_amdgcn_exp2f(fmaf(v.z, 1.4426950408889634f, nl)), __builtin_amdgcn_exp2f(fmaf(v.w, 1.4426950408889634f, nl)));
-  }
-}
-
-bool long_row_job(const ck_softmax_job& j) {  // kind 6: the log-normaliser of every row instead of the softmax
-  return (j.kind == 0 || j.kind == 6) && j.len >= 512 && j.len <= 4096 && j.len % 4 == 0 && ck::aligned16(j.in) &&
-         (j.kind == 6 || ck::aligned16(j.out));
+bool long_row_job(const ck_softmax_job& j) {
+  return j.kind == 0 && j.len >= 512 && j.len <= 4096 && j.len % 4 == 0 && ck::aligned16(j.in) && ck::aligned16(j.out);
 }
 
 int launch_long_rows(const ck_softmax_job& j, void* stream) {
@@ -937,20 +916,6 @@ int launch_long_rows(const ck_softmax_job& j, void* stream) {
   float* out = j.out;
   const int64_t rows = j.rows;
   const int len = static_cast<int>(j.len);
-  if (j.kind == 6)
-    return ck::dispatch(
-        [=](hipStream_t s) {
-          if (n4 <= 2)
-            hipLaunchKernelGGL((softmax_long_rows_kernel<2, true>), grid, block, 0, s, in, out, rows, len);
-          else if (n4 <= 4)
-            hipLaunchKernelGGL((softmax_long_rows_kernel<4, true>), grid, block, 0, s, in, out, rows, len);
-          else if (n4 <= 8)
-            hipLaunchKernelGGL((softmax_long_rows_kernel<8, true>), grid, block, 0, s, in, out, rows, len);
-          else
-            hipLaunchKernelGGL((softmax_long_rows_kernel<16, true>), grid, block, 0, s, in, out, rows, len);
-          return hipGetLastError();
-        },
-        stream);
   return ck::dispatch(
       [=](hipStream_t s) {
         if (n4 <= 2)
@@ -969,20 +934,6 @@ int launch_long_rows(const ck_softmax_job& j, void* stream) {
 }  // namespace
 
 extern "C" {
-
-int ck_param_exp_rows(const float* in, const float* lognorm, float* out, int64_t rows, int len, void* stream) {
-  CK_REQUIRE(in && lognorm && out, "ck_param_exp_rows: null pointer");
-  CK_REQUIRE(rows > 0 && len > 0 && len % 4 == 0, "ck_param_exp_rows: rows=%lld len=%d (len must be a multiple of 4)", static_cast<long long>(rows), len);
-  CK_REQUIRE(ck::aligned16(in) && ck::aligned16(out), "ck_param_exp_rows: buffers must be 16-byte aligned");
-  const int len4 = len / 4;
-  dim3 grid(static_cast<unsigned>(std::min<int64_t>((rows * len4 + 255) / 256, 256 * 32))), block(256);
-  return ck::dispatch(
-      [=](hipStream_t s) {
-        hipLaunchKernelGGL(exp_rows_kernel, grid, block, 0, s, in, lognorm, out, rows, len4);
-        return hipGetLastError();
-      },
-      stream);
-}
 
 int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_t inner,
                      int log_space, void* stream) {
@@ -1115,11 +1066,10 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
         ck_softmax_job j = jobs[start];
         const int idx = start++;
         CK_REQUIRE(j.in && j.out && j.rows > 0 && j.len > 0, "ck_param_softmax_batch: bad job %d", idx);
-        CK_REQUIRE(j.kind >= 0 && j.kind <= 6, "ck_param_softmax_batch: job %d has unknown kind %d", idx, j.kind);
-        CK_REQUIRE(j.kind != 6 || long_row_job(j), "ck_param_softmax_batch: job %d (kind 6) needs rows of 512..4096 entries", idx);
+        CK_REQUIRE(j.kind >= 0 && j.kind <= 5, "ck_param_softmax_batch: job %d has unknown kind %d", idx, j.kind);
         CK_REQUIRE(j.kind < 2 || j.kind >= 4 || (j.len == 32 && j.rows % 32 == 0),
                    "ck_param_softmax_batch: tiled job %d needs len = 32 and rows %% 32 = 0", idx);
-        CK_REQUIRE(j.kind < 4 || j.kind == 6 || ((j.k == 32 || (j.k == 64 && j.kind == 4)) && j.in2 != nullptr),
+        CK_REQUIRE(j.kind < 4 || ((j.k == 32 || (j.k == 64 && j.kind == 4)) && j.in2 != nullptr),
                    "ck_param_softmax_batch: job %d (kind 4/5) needs k = 32 (kind 4: or 64) and in2", idx);
         CK_REQUIRE(j.kind != 5 || j.out2 != nullptr, "ck_param_softmax_batch: job %d (kind 5) needs out2", idx);
         if ((j.kind == 4 && j.k == 64) != (wide == 1)) continue;  // the other pass takes it

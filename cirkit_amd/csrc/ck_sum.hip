@@ -630,18 +630,18 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
   return launch_generic<float, float>(arena, row_off, w, out, F, H, B, Ki, Ko, mode, stream);
 }
 
-int ck_tucker_logits_fwd(const float* arena, const int64_t* row_off, const float* theta, const float* lognorm, float* out,
-                         int F, int B, int Ki, int Ko, void* stream) {
-  CK_REQUIRE(arena && row_off && theta && lognorm && out, "ck_tucker_logits_fwd: null pointer");
+int ck_tucker_logits_fwd(const float* arena, const int64_t* row_off, const float* theta, float* out, int F, int B, int Ki,
+                         int Ko, void* stream) {
+  CK_REQUIRE(arena && row_off && theta && out, "ck_tucker_logits_fwd: null pointer");
   CK_REQUIRE(F > 0 && B > 0 && Ko > 0, "ck_tucker_logits_fwd: non-positive size F=%d B=%d Ko=%d", F, B, Ko);
   CK_REQUIRE(Ki == 32 || Ki == 64, "ck_tucker_logits_fwd: Ki must be 32 or 64, found %d", Ki);
   CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(theta) && ck::aligned16(out), "ck_tucker_logits_fwd: buffers must be 16-byte aligned");
   if (F > ck::kMaxFoldsPerLaunch)
     return ck::chunk_folds(F, [&](int f0, int n) {
       return ck_tucker_logits_fwd(arena, row_off + static_cast<int64_t>(f0) * 2, theta + static_cast<int64_t>(f0) * Ko * Ki * Ki,
-                                  lognorm + static_cast<int64_t>(f0) * Ko, out + static_cast<int64_t>(f0) * B * Ko, n, B, Ki, Ko, stream);
+                                  out + static_cast<int64_t>(f0) * B * Ko, n, B, Ki, Ko, stream);
     });
-  return ck::tucker_lse(arena, row_off, theta, out, F, B, Ki, Ko, stream, lognorm);
+  return ck::tucker_lse(arena, row_off, theta, out, F, B, Ki, Ko, stream, true);
 }
 
 int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w, float* out_c,

@@ -662,31 +662,28 @@ class HipTuckerLayer(HipSumLayer):
     def tile32_eligible(self) -> bool:
         return False
 
-    # set by HipCircuit(fused_weight_softmax=True): the batched prologue only writes the row log-normalisers of a
-    # softmax(theta) weight and the Tucker launch applies exp(theta - lognorm) while it stages the weights
-    # (`ck_tucker_logits_fwd`) -- the (F, Ko, Ki^2) normalised weights are never written.  Not for training: the backward
-    # kernels read `_w`.
+    # set by HipCircuit(fused_weight_softmax=True): a softmax(theta) weight is not evaluated by the prologue at all -- the
+    # stream-K Tucker launch reads the logits and normalises them online (`ck_tucker_logits_fwd`: running row maximum
+    # and sum beside the accumulators), so the (F, Ko, Ki^2) weights are read once per forward and never written.  Not
+    # for training: the backward kernels read `_w`.
     _logits_ok = False
-    _lognorm: torch.Tensor | None = None
     _theta: torch.Tensor | None = None
     _use_logits = False
 
     def register_batched(self, batch) -> bool:
-        self._lognorm = self._theta = None
+        self._theta = None
         src = None if self.is_complex else self.weight.softmax_source()
         n = self.num_input_units ** self.arity
         if (self._logits_ok and src is not None and self.arity == 2 and self.num_input_units in (32, 64)
-                and 512 <= n <= 4096 and src.is_contiguous() and src.data_ptr() % 16 == 0):
+                and src.shape[-1] == n and src.is_contiguous() and src.data_ptr() % 16 == 0):
             self._theta = src
-            self._lognorm = torch.empty(src.shape[:-1], dtype=torch.float32, device=src.device)
             self._w_layout = capi.CK_W_ROWMAJOR
-            batch.add_row_lognorm(src, self._lognorm)
-            self._batched = True
+            self._batched = True  # (nothing for the prologue to do)
             return True
         return super().register_batched(batch)
 
     def prepare(self, stream: int, batched: bool = False) -> None:
-        self._use_logits = bool(batched and self._batched and self._lognorm is not None)
+        self._use_logits = bool(batched and self._batched and self._theta is not None)
         if not self._use_logits:
             if batched and self._batched:
                 return
@@ -696,15 +693,12 @@ class HipTuckerLayer(HipSumLayer):
         if not self._use_logits:
             return super().launch(arena, row_off, out, B, stream)
         try:
-            capi.call("ck_tucker_logits_fwd", _ptr(arena), _ptr(row_off), _ptr(self._theta), _ptr(self._lognorm), _ptr(out),
+            capi.call("ck_tucker_logits_fwd", _ptr(arena), _ptr(row_off), _ptr(self._theta), _ptr(out),
                       self.num_folds, B, self.num_input_units, self.num_output_units, stream)
         except NotImplementedError:
-            # many tiles per resident workgroup (a large batch): one workgroup per tile would apply the exponential once per
-            # 128 rows, so the normalised weights are written after all -- exp(theta - lognorm) -- and the launch reads them
-            if self._w is None or self._w.shape != self._theta.shape or self._w.data_ptr() == self._theta.data_ptr():
-                self._w = torch.empty_like(self._theta)
-            rows = self._theta.numel() // self._theta.shape[-1]
-            capi.call("ck_param_exp_rows", _ptr(self._theta), _ptr(self._lognorm), _ptr(self._w), rows, int(self._theta.shape[-1]), stream)
+            # many tiles per resident workgroup (a large batch): one workgroup per tile would exponentiate the weights once
+            # per 128 rows, so the normalised weights are written after all and the ordinary launch reads them
+            self._w = self.weight.evaluate(stream)
             super().launch(arena, row_off, out, B, stream)
 
 

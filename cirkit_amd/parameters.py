@@ -100,13 +100,6 @@ class ParamBatch:
         self._keep += [src, dst]
         self._arr = None
 
-    def add_row_lognorm(self, src: torch.Tensor, dst: torch.Tensor) -> None:
-        """dst[r] = logsumexp(src[r, :]) for rows of 512..4096 entries (kind 6): the consumer applies exp(src - dst) itself."""
-        rows = src.numel() // src.shape[-1]
-        self._jobs.append((src.data_ptr(), dst.data_ptr(), rows, int(src.shape[-1]), 0, 6, None, None, None))
-        self._keep += [src, dst]
-        self._arr = None
-
     def add_log_table(self, src: torch.Tensor, dst: torch.Tensor) -> None:
         """src (F, K, C) logits -> dst (F, C+1, K) = log softmax over C, transposed; row C = 0."""
         F, K, Cc = src.shape

@@ -147,16 +147,13 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
  * applies (A/B parity of the two implementations). */
 int ck_debug_force_generic(int on);
 /* TorchTuckerLayer.forward (optimized.py:89-103) of arity 2 with 32 / 64 input units whose weight is softmax(theta) over its
- * last axis (parameters/nodes.py:764-772), WITHOUT the normalised weights in memory: theta (F, Ko, Ki^2) raw logits,
- * lognorm (F, Ko) their row log-normalisers (ck_param_softmax_batch kind 6); the launch applies exp(theta - lognorm)
- * while it stages the weights (the stream-K launch of ck_sum_lse_fwd in CK_SUM_KRON mode: needs the workspace of
- * ck_set_workspace and few tiles per resident workgroup, otherwise CK_ERR_UNSUPPORTED -- with one workgroup per tile the
- * exponential would be applied once per 128 rows: normalise with ck_param_exp_rows and call ck_sum_lse_fwd instead). */
-/* out[r, :] = exp(in[r, :] - lognorm[r]) for `rows` rows of `len` (a multiple of 4): softmax(in) from the kind-6 row
- * log-normalisers, for consumers that need the normalised weights in memory. */
-int ck_param_exp_rows(const float* in, const float* lognorm, float* out, int64_t rows, int len, void* stream);
-int ck_tucker_logits_fwd(const float* arena, const int64_t* row_off, const float* theta, const float* lognorm, float* out,
-                         int F, int B, int Ki, int Ko, void* stream);
+ * last axis (parameters/nodes.py:764-772), WITHOUT the normalised weights in memory: theta (F, Ko, Ki^2) raw logits, which
+ * the launch reads once and normalises online (running row maximum and sum beside the accumulators).  This is the stream-K
+ * launch of ck_sum_lse_fwd in CK_SUM_KRON mode: it needs the workspace of ck_set_workspace and few tiles per resident
+ * workgroup, otherwise CK_ERR_UNSUPPORTED (with one workgroup per tile the exponentials would be applied once per 128
+ * rows: evaluate softmax(theta) with ck_param_softmax and call ck_sum_lse_fwd instead). */
+int ck_tucker_logits_fwd(const float* arena, const int64_t* row_off, const float* theta, float* out, int F, int B, int Ki,
+                         int Ko, void* stream);
 /* complex-lse-sum variant (semiring.py:441-476); w real (w_is_complex=0) or complex64. */
 int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w, float* out_c,
                      int F, int H, int B, int Ki, int Ko, int mode, int w_is_complex, void* stream);
@@ -336,8 +333,6 @@ int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_
  * dense folds d, out[d] (C+1, 32) = log(softmax(in2[d]) . exp(T - m)) + m row by row, with T the kind-1
  * table of categorical fold idx[d] (a Categorical layer followed fold by fold by a dense layer only
  * takes C distinct values per fold, so the dense layer is evaluated on the table instead of on the batch).
- * kind 6: out[r] = max + log sum exp(in[r, :] - max), the log-normaliser of each of `rows` rows of 512..4096 entries
- * (out: `rows` floats): consumed by ck_tucker_logits_fwd, which applies exp(in - out) = softmax(in) while it stages weights.
  * kind 5: as kind 4 but every row is left in LINEAR space, out[d, c, :] = softmax(in2[d]) . exp(T[c] - m_c),
  * with its log scale m_c in out2[d, c] (the representation ck_subtree_cat_cpt_fwd takes with table_scale).
  * block_begin is ignored on input. */
@@ -462,11 +457,11 @@ int ck_program_num_ops(const ck_program* prog);
 int ck_program_launch(ck_program* prog, int use_graph, void* stream);
 
 /* Lend a device scratch buffer to the launches this THREAD issues or records from now on (NULL, 0: take it back).  It
- * must be ZERO when lent; the part that has to stay zero (ticket counters behind the first CUs x 3 x 32 KiB) is zero again
- * after every launch that used it; launches that share it must be ordered (one stream, or one recorded program).  Used
+ * must be ZERO when lent; the part that has to stay zero (ticket counters behind the first CUs x 3 x (32 KiB + 512 B)) is zero
+ * again after every launch that used it; launches that share it must be ordered (one stream, or one recorded program).  Used
  * by the stream-K Tucker launch of ck_sum_lse_fwd (CK_SUM_KRON, arity 2, 32 / 64 units): partial accumulators of tiles that
- * straddle workgroups; without a workspace of CUs x 3 x 32 KiB + 4 bytes per (fold, 32 outputs, 128 rows) tile those
- * layers take one workgroup per tile. */
+ * straddle workgroups (and, on logits, their row maxima and sums); without a workspace of CUs x 3 x (32 KiB + 512 B) +
+ * 4 bytes per (fold, 32 outputs, 128 rows) tile those layers take one workgroup per tile. */
 int ck_set_workspace(void* ptr, int64_t bytes);
 int ck_program_destroy(ck_program* prog);
 

@@ -147,7 +147,7 @@ def test_tucker_streamk_launch(hip_device, F, B, Ki, Ko):
     stream = torch.cuda.current_stream(hip_device).cuda_stream
     n_cu = torch.cuda.get_device_properties(hip_device).multi_processor_count
     tiles = F * ((Ko + 31) // 32) * ((B + 127) // 128)
-    slot_words = n_cu * 3 * 2 * 4 * 1024
+    slot_words = n_cu * 3 * 2 * (4 * 1024 + 64)  # partial tiles + their (max, sum) rows
     ws = torch.zeros(slot_words + tiles, dtype=torch.int32, device=hip_device)
 
     def run(with_ws):
@@ -207,16 +207,20 @@ def test_stage_categories(hip_device, B, D, clamp):
                                        (2, 2500, 64, 64)])
 @pytest.mark.parametrize("streamk", [False, True])
 def test_tucker_logits_launch(hip_device, F, B, Ki, Ko, streamk):
-    """`ck_tucker_logits_fwd`: the Tucker layer on raw logits + row log-normalisers (kind-6 prologue job), weights =
-    exp(theta - L) applied while they are staged -- against the launch on normalised weights and the oracle, with and
-    without the stream-K workspace."""
+    """`ck_tucker_logits_fwd`: the Tucker layer on raw logits, softmax(theta) normalised online (running row maximum and sum
+    kept beside the accumulators, carried through the partial tiles of the stream-K launch) -- against the oracle on
+    softmax(theta), with and without the stream-K workspace.  Rows whose maximum sits in a late chunk exercise the
+    rescaling of the accumulators, small layers the combine of parts staged against different maxima."""
     from cirkit_amd import _capi as capi
-    from cirkit_amd.parameters import ParamBatch
     from oracle.torch_oracle import _LSE, _layer_forward
 
     g = torch.Generator().manual_seed(F + B + Ki + Ko)
     theta = torch.randn(F, Ko, Ki * Ki, generator=g) * 2
     theta[0, 0, 5] = -200.0  # (a weight that underflows to exactly 0)
+    theta[0, Ko - 1, Ki * Ki - 3] = 60.0  # (the running maximum rises in the last chunk, and twice in the next row)
+    if Ko > 1:
+        theta[F - 1, 0, Ki * 7 + 1] = 25.0
+        theta[F - 1, 0, Ki * 20 + 2] = 70.0
     w = torch.softmax(theta, dim=-1)
     x = torch.randn(F, 2, B, Ki, generator=g) * 3 - 4
     spec = LayerSpec("tucker", F, 2, Ki, Ko, {"num_input_units": Ki, "num_output_units": Ko, "arity": 2}, {})
@@ -225,27 +229,23 @@ def test_tucker_logits_launch(hip_device, F, B, Ki, Ko, streamk):
     xd, td = x.to(hip_device).contiguous(), theta.to(hip_device).contiguous()
     row_off = (torch.arange(F * 2, dtype=torch.int64) * (B * Ki)).reshape(F, 2).to(hip_device)
     stream = torch.cuda.current_stream(hip_device).cuda_stream
-    lognorm = torch.empty(F, Ko, device=hip_device)
-    batch = ParamBatch()
-    batch.add_row_lognorm(td, lognorm)
-    batch.launch(stream)
-    torch.cuda.synchronize()
-    assert float((lognorm.cpu() - torch.logsumexp(theta, dim=-1)).abs().max()) <= 1e-5
     n_cu = torch.cuda.get_device_properties(hip_device).multi_processor_count
     tiles = F * ((Ko + 31) // 32) * ((B + 127) // 128)
-    ws = torch.zeros(n_cu * 3 * 2 * 4 * 1024 + tiles, dtype=torch.int32, device=hip_device)
+    slot_words = n_cu * 3 * 2 * (4 * 1024 + 64)
+    ws = torch.zeros(slot_words + tiles, dtype=torch.int32, device=hip_device)
     out = torch.full((F, B, Ko), float("nan"), device=hip_device)
     capi.call("ck_set_workspace", ws.data_ptr() if streamk else None, ws.numel() * 4 if streamk else 0)
     try:
         if streamk:
-            capi.call("ck_tucker_logits_fwd", xd.data_ptr(), row_off.data_ptr(), td.data_ptr(), lognorm.data_ptr(), out.data_ptr(),
-                      F, B, Ki, Ko, stream)
-        else:  # without the stream-K launch the exponential would be applied once per 128 rows: refused, normalise first
+            for _ in range(2):
+                capi.call("ck_tucker_logits_fwd", xd.data_ptr(), row_off.data_ptr(), td.data_ptr(), out.data_ptr(), F, B, Ki, Ko, stream)
+                torch.cuda.synchronize()
+                assert int(ws[slot_words:].abs().max()) == 0  # tickets back at zero
+        else:  # without the stream-K launch the exponentials would be applied once per 128 rows: refused, normalise first
             with pytest.raises(NotImplementedError):
-                capi.call("ck_tucker_logits_fwd", xd.data_ptr(), row_off.data_ptr(), td.data_ptr(), lognorm.data_ptr(),
-                          out.data_ptr(), F, B, Ki, Ko, stream)
+                capi.call("ck_tucker_logits_fwd", xd.data_ptr(), row_off.data_ptr(), td.data_ptr(), out.data_ptr(), F, B, Ki, Ko, stream)
             wn = torch.empty_like(td)
-            capi.call("ck_param_exp_rows", td.data_ptr(), lognorm.data_ptr(), wn.data_ptr(), F * Ko, Ki * Ki, stream)
+            capi.call("ck_param_softmax", td.data_ptr(), wn.data_ptr(), F * Ko, Ki * Ki, 1, 0, stream)
             capi.call("ck_sum_lse_fwd", xd.data_ptr(), row_off.data_ptr(), wn.data_ptr(), out.data_ptr(), F, 2, B, Ki, Ko,
                       capi.CK_SUM_KRON, capi.CK_W_ROWMAJOR, stream)
     finally:
