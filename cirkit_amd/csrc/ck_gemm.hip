@@ -617,7 +617,7 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
     fetch(i_begin);
     // exponentiated children of (fold f, this wave's 32 rows): e_r as a register tile, e_l through LDS
     float er[NK][16];
-    float m;
+    float m = 0.f;
     __syncthreads();  // every wave has left the previous tile (its e_l rows and weight buffers)
     {
       float el[NK][16];
@@ -651,12 +651,11 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* el_w = el_s + wave * (Ki * 32) + b_in;
-    commit(i_begin, 0);
-    if (i_begin + 1 < i_end) fetch(i_begin + 1);
-    for (int i = i_begin; i < i_end; ++i) {
-      __syncthreads();  // chunk i (and, the first time, e_l) is in LDS; every wave has left chunk i - 1
+    auto stage_ahead = [&](int i) {  // after the barrier of chunk i: chunk i + 1 into the other buffer, chunk i + 2 requested
       if (i + 1 < i_end) commit(i + 1, (i + 1 - i_begin) & 1);
       if (i + 2 < i_end) fetch(i + 2);
+    };
+    auto contract = [&](int i) {  // chunk i against the outer-product row e_l[i] * e_r[.]
       const float* wb = w_s + ((i - i_begin) & 1) * CHUNK;
       if constexpr (LOGITS) {  // chunk i was staged against a higher maximum than the accumulators hold (rare)
         const int buf = (i - i_begin) & 1;
@@ -672,27 +671,36 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
           }
         }
       }
+      // acc[b, o] += e_l[b, i] * sum_j W[o, i, j] e_r[b, j]: the chain runs on e_r as it is and its result enters the
+      // accumulators with ONE multiply-add per output (16 per chunk instead of the 32 products e_l[i] * e_r[j])
       const float eli = el_w[i * 32];
-      // the outer-product row e_l[i] * e_r[.] as packed multiplies IN FRONT of the MFMA chain (interleaved into it, one
-      // multiply per MFMA, the compiler emits 32 single ones: every VALU instruction adds to the chain's time)
-      float pr[NK][16];
-#pragma unroll
-      for (int q = 0; q < NK; ++q) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) pr[q][j] = er[q][j];
-        tile_scale(pr[q], eli);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      f32x16 part;
 #pragma unroll
       for (int q = 0; q < NK; ++q)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const float4 w4 = *reinterpret_cast<const float4*>(wb + ((q * 4 + gq) * 64 + kh * 32 + (b_in ^ (8 * kh))) * 4);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, pr[q][4 * gq + 0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, pr[q][4 * gq + 1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, pr[q][4 * gq + 2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, pr[q][4 * gq + 3], acc, 0, 0, 0);
+          if (q == 0 && gq == 0) {
+            f32x16 zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            part = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, er[q][0], zero, 0, 0, 0);
+          } else {
+            part = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, er[q][4 * gq + 0], part, 0, 0, 0);
+          }
+          part = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, er[q][4 * gq + 1], part, 0, 0, 0);
+          part = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, er[q][4 * gq + 2], part, 0, 0, 0);
+          part = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, er[q][4 * gq + 3], part, 0, 0, 0);
         }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = fmaf(part[r], eli, acc[r]);
+    };
+    commit(i_begin, 0);
+    if (i_begin + 1 < i_end) fetch(i_begin + 1);
+    for (int i = i_begin; i < i_end; ++i) {
+      __syncthreads();  // chunk i (and, the first time, e_l) is in LDS; every wave has left chunk i - 1
+      stage_ahead(i);
+      contract(i);
     }
     float* dst = a.out + (static_cast<int64_t>(f) * a.B + bl) * a.Ko;
     const int o0 = o_base + 4 * kh;
@@ -739,7 +747,7 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) __hip_atomic_store(slot + r * 64 + lane, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if constexpr (LOGITS) {
-        if (threadIdx.x < 64) __hip_atomic_store(a.stats + my_slot * 64 + threadIdx.x, stat_s[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0) __hip_atomic_store(a.stats + my_slot * 64 + lane, stat_s[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have completed
       __syncthreads();  // ... those of all four waves
