@@ -580,6 +580,19 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
       });
       if constexpr (LINEAR) sc = s == 0 ? m : sc + m;
     }
+    if constexpr (!LINEAR) {
+      if (mw == nullptr && w_cat == nullptr) {  // a CP block on its own (H = 1, no mixing layer behind it): P is the output
+        if (live) {
+          float* dst = out + (static_cast<int64_t>(f) * B + b) * K + 4 * kh;
+#pragma unroll
+          for (int p = 0; p < NK; ++p)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(dst + 32 * p + 8 * g) = make_float4(P[p][4 * g], P[p][4 * g + 1], P[p][4 * g + 2], P[p][4 * g + 3]);
+        }
+        return;
+      }
+    }
     // mixing: fold P_h into the running sum
     float pm = P[0][0];
 #pragma unroll
@@ -823,6 +836,30 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
   CK_REQUIRE(K == 32 || K == 64, "ck_cp_lse_fwd: K must be 32 or 64, found %d", K);
   CK_REQUIRE(F <= 65535, "ck_cp_lse_fwd: F=%d exceeds grid.y", F);
   CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(out), "ck_cp_lse_fwd: buffers must be 16-byte aligned");
+  // a plain block (products of one child per slot, no CP-T sum behind it, contiguous output) on the DMA-staged kernel of
+  // the regions: every operand prefetched a step ahead through LDS
+  {
+    const int waves = K == 64 ? 4 : 8;
+    const size_t lds_dma = (static_cast<size_t>(2) * 32 * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(K)) * sizeof(float);
+    if (H == 1 && g_var == nullptr && w_post == nullptr && out_off == nullptr && !ck::debug_force_generic() &&
+        static_cast<int64_t>(B) * K < (int64_t{1} << 30)) {
+      const int tiles = (B + 31) / 32;
+      const dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
+      return ck::dispatch(
+          [=](hipStream_t s) {
+            auto go = [&](auto kern) {
+              hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds_dma));
+              if (e != hipSuccess) return e;
+              hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, w_addr, static_cast<const float*>(nullptr), out,
+                                 static_cast<int32_t*>(nullptr), 1, S, B, static_cast<const float*>(nullptr));
+              return hipGetLastError();
+            };
+            return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
+          },
+          stream);
+    }
+  }
   if (K == 64) return launch_cp<2>(arena, row_off, w_addr, nullptr, w_post, out_off, out, gs, F, S, H, B, stream);
   return launch_cp<1>(arena, row_off, w_addr, nullptr, w_post, out_off, out, gs, F, S, H, B, stream);
 }

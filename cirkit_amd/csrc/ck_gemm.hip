@@ -583,29 +583,48 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
 #pragma unroll
       for (int k = 0; k < PF; ++k) v[k] = pre[k];
       if constexpr (LOGITS) {
-        float cm = v[0].x;
-#pragma unroll
-        for (int k = 0; k < PF; ++k) cm = fmaxf(fmaxf(fmaxf(cm, v[k].x), fmaxf(v[k].y, v[k].z)), v[k].w);
-        cm = ck::clamp_finite(oct_max(cm) * kL2E);
+        // The row maximum of a chunk is only computed when it is needed: on the first chunk of a tile part, and when the
+        // exponentials against the running maximum come out larger than 2^24 for some lane (then the maximum is raised and
+        // they are computed again) -- otherwise eight maxima, three DPP steps and a comparison per chunk would buy nothing.
         float alpha = 1.f;
         bool raised = false;
-        if (i == i_begin) {
-          mrun = cm;
-          srun = 0.f;
-        } else if (cm > mrun + 24.f) {
-          raised = true;
-          alpha = __builtin_amdgcn_exp2f(mrun - cm);
-          srun *= alpha;
-          mrun = cm;
-        }
+        auto row_max = [&] {
+          float cm = v[0].x;
 #pragma unroll
-        for (int k = 0; k < PF; ++k) {
-          v[k].x = __builtin_amdgcn_exp2f(fmaf(v[k].x, kL2E, -mrun));
-          v[k].y = __builtin_amdgcn_exp2f(fmaf(v[k].y, kL2E, -mrun));
-          v[k].z = __builtin_amdgcn_exp2f(fmaf(v[k].z, kL2E, -mrun));
-          v[k].w = __builtin_amdgcn_exp2f(fmaf(v[k].w, kL2E, -mrun));
-          srun += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+          for (int k = 0; k < PF; ++k) cm = fmaxf(fmaxf(fmaxf(cm, v[k].x), fmaxf(v[k].y, v[k].z)), v[k].w);
+          return ck::clamp_finite(oct_max(cm) * kL2E);
+        };
+        if (i == i_begin) {
+          mrun = row_max();
+          srun = 0.f;
         }
+        float4 e[PF];
+        float part = 0.f;
+        auto exps = [&] {
+          part = 0.f;
+#pragma unroll
+          for (int k = 0; k < PF; ++k) {
+            e[k].x = __builtin_amdgcn_exp2f(fmaf(v[k].x, kL2E, -mrun));
+            e[k].y = __builtin_amdgcn_exp2f(fmaf(v[k].y, kL2E, -mrun));
+            e[k].z = __builtin_amdgcn_exp2f(fmaf(v[k].z, kL2E, -mrun));
+            e[k].w = __builtin_amdgcn_exp2f(fmaf(v[k].w, kL2E, -mrun));
+            part += (e[k].x + e[k].y) + (e[k].z + e[k].w);
+          }
+        };
+        exps();
+        if (__any(!(part <= 134217728.f))) {  // 2^27 = 8 values of 2^24 (or a NaN): rare, uniform over the wave
+          const float cm = row_max();
+          if (cm > mrun) {
+            raised = true;
+            alpha = __builtin_amdgcn_exp2f(mrun - cm);
+            srun *= alpha;
+            mrun = cm;
+          }
+          exps();
+        }
+        srun += part;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) v[k] = e[k];
         if ((lane & 7) == 0) alpha_s[buf * 32 + o_local] = alpha;
         const bool any_raised = __any(raised);
         if (lane == 0) flag_s[buf * 4 + wave] = any_raised ? 1u : 0u;
