@@ -759,6 +759,48 @@ def test_region_kernels_agree_bit_for_bit(hip_device, K, F, H, S, B):
     assert float(((out.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-5
 
 
+@pytest.mark.parametrize("K,F,S,B", [(64, 3, 2, 300), (64, 2, 3, 33), (32, 5, 2, 257), (32, 1, 1, 4096)])
+def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B):
+    """`ck_cp_lse_fwd` for a plain CP block (one child per slot, no CP-T sum behind the product, contiguous output): the
+    launch on the DMA-staged region kernel (the product is the output) and the register-path launch (cp_lse_kernel, taken
+    under ck_debug_force_generic) do the same arithmetic in the same order; value = sum_s log(W_s exp(x_s))."""
+    from cirkit_amd import _capi as capi
+
+    g = torch.Generator().manual_seed(K + F + S + B)
+    arena = (torch.randn(F * S, B, K, generator=g) * 3 - 5).to(hip_device)
+    row_off = (torch.arange(F * S, dtype=torch.int64) * (B * K)).reshape(F, S)
+    row_off = row_off[:, torch.randperm(S, generator=g)].contiguous().to(hip_device)
+    w = torch.softmax(torch.randn(F * S, K, K, generator=g), dim=-1).to(hip_device)
+    addr = torch.tensor([w.data_ptr() + i * K * K * 4 for i in range(F * S)], dtype=torch.int64).reshape(F, S)
+    if S > 2:
+        addr[:, 1] = 0  # a plain slot
+    addr = addr.to(hip_device)
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    outs = []
+    for force in (0, 1):
+        out = torch.full((F, B, K), float("nan"), device=hip_device)
+        capi.call("ck_debug_force_generic", force)
+        try:
+            capi.call("ck_cp_lse_fwd", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), None, None, out.data_ptr(),
+                      None, None, None, 0, F, S, 1, B, K, stream)
+        finally:
+            capi.call("ck_debug_force_generic", 0)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    a, ro, wc, ad = arena.cpu().double(), row_off.cpu(), w.cpu().double(), addr.cpu()
+    ref = torch.zeros(F, B, K, dtype=torch.float64)
+    for f in range(F):
+        for s_ in range(S):
+            v = a[int(ro[f, s_]) // (B * K)]
+            if int(ad[f, s_]) != 0:
+                wi = (int(ad[f, s_]) - w.data_ptr()) // (K * K * 4)
+                v = torch.log(torch.exp(v) @ wc[wi].T)
+            ref[f] += v
+    assert float(((outs[0].double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-5
+
+
 @pytest.mark.parametrize("K", [64, 32])
 def test_region_linear_space_falls_back_to_log_space(hip_device, K):
     """Rows whose products leave the fp32 range in linear space (factors with disjoint supports, all -inf inputs, +inf):
