@@ -87,10 +87,10 @@ class HipCircuit:
             takes C distinct values per fold, so the dense layer is applied once per forward to the
             (F, C, K) log-probability table (same kernel, batch = C) instead of to every batch row;
             bit-identical results, B/C times less work for that layer.
-        fused_weight_softmax: Tucker layers (arity 2, 32 / 64 units) whose weight is softmax(theta): the prologue writes the
-            row log-normalisers only and the layer's launch applies exp(theta - lognorm) to the logits as it stages them;
-            the normalised (F, Ko, Ki^2) weights -- 1.6 GB at the reference's notebook configuration -- are never written
-            nor read back.  Off for training (the backward kernels read the normalised weights).
+        fused_weight_softmax: Tucker layers (arity 2, 32 / 64 units) whose weight is softmax(theta): the prologue skips them
+            and the layer's stream-K launch reads the logits, normalising them online (`ck_tucker_logits_fwd`); the
+            normalised (F, Ko, Ki^2) weights -- 1.6 GB at the reference's notebook configuration -- are never written nor
+            read back.  Off for training (the backward kernels read the normalised weights).
         linear_levels: inside the fused leaf launch a value is handed from one CP-T level to the next as
             (linear tile, per-row log scale) instead of taking its log and exponentiating it again; the
             same sums with one log per row instead of 64 transcendentals (cirkit_amd/csrc/ck_fused.hip).
@@ -195,7 +195,7 @@ class HipCircuit:
         if missing:
             raise ValueError(f"missing parameter tensors: {missing}")
         self.layers: list[HipLayer] = [layer_from_spec(s, self.store, plan.semiring) for s in plan.layers]
-        for l in self.layers:  # Tucker weights softmax(theta): only their row log-normalisers are computed (ck_tucker_logits_fwd)
+        for l in self.layers:  # Tucker weights softmax(theta): the launch reads the logits (ck_tucker_logits_fwd)
             if hasattr(l, "_logits_ok"):
                 l._logits_ok = bool(fused_weight_softmax)
         self._folds = [l.num_folds for l in self.layers]

@@ -399,7 +399,11 @@ template <int NK, int WAVES, int MINW, bool LINEAR>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
     region_dma_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                       const int64_t* __restrict__ w_addr, const float* __restrict__ mw, float* __restrict__ out,
-                      int32_t* __restrict__ redo, int H, int S, int B, const float* __restrict__ w_cat) {
+                      int32_t* __restrict__ redo, int H, int S, int B, const float* __restrict__ w_cat,
+                      const int64_t* __restrict__ w_post) {
+  // mw == nullptr && w_cat == nullptr (LINEAR = false, H = 1): a CP block on its own -- the product P of the slots is the
+  // output, or (w_post[f] != 0, a CP-T layer: optimized.py:171-178) log(W_post . exp(P - max P)) + max P, one more step
+  // of the weight pipeline on the register tile P.
   // w_cat != nullptr: a dense Sum layer over the CONCATENATION of H children (inner.py:266-273 with a full (K, H K) weight)
   // as a region with one slot per "partitioning" and unit mixing coefficients: W_h = columns h K .. h K + K - 1 of fold f's
   // row-major matrix (row stride H K), no w_addr / mw tables.  log sum_h exp(log(W_h e_h) + m_h) is the layer's value
@@ -422,6 +426,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   const int T = H * S;
   const int64_t* ro = row_off + static_cast<int64_t>(f) * T;
   const int64_t* wa = w_addr + static_cast<int64_t>(f) * T;
+  const int TU = (T + (w_post != nullptr ? 1 : 0)) * NK;  // weight units of the launch
   // weight unit u = t * NK + p goes to ring buffer u & 1, in the operand layout [(q * 4 + g) * 64 + lane] float4
   constexpr int PF = (UF4 + WAVES * 64 - 1) / (WAVES * 64);
   static_assert(NK == 1 || UF4 % (WAVES * 64) == 0, "the vmcnt bookkeeping of later units assumes every wave stages a share");
@@ -438,7 +443,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
     const int t = u / NK, p = u % NK;
     const uint64_t wv = w_cat != nullptr
                             ? static_cast<uint64_t>(reinterpret_cast<uintptr_t>(w_cat + (static_cast<int64_t>(f) * K * T + t) * K))
-                            : static_cast<uint64_t>(wa[t]);
+                            : static_cast<uint64_t>(t == T ? w_post[f] : wa[t]);
     if (wv == 0) return;
     // (made uniform explicitly: the compiler otherwise carries the loaded address in vector registers)
     const uint64_t wu = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv >> 32)))) << 32) |
@@ -537,7 +542,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... and every wave has left unit u - 1
-        if (u + 1 < T * NK) stage_w(u + 1);
+        if (u + 1 < TU) stage_w(u + 1);
         if constexpr (p == 0) {
           if (t + 1 < T) stage_tile(t + 1);  // (the slot is free since its reads returned)
         }
@@ -581,7 +586,48 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
       if constexpr (LINEAR) sc = s == 0 ? m : sc + m;
     }
     if constexpr (!LINEAR) {
-      if (mw == nullptr && w_cat == nullptr) {  // a CP block on its own (H = 1, no mixing layer behind it): P is the output
+      if (mw == nullptr && w_cat == nullptr) {  // a CP block on its own (H = 1, no mixing layer behind it)
+        if (w_post != nullptr) {  // the CP-T sum on the register tile P: weight units T NK .. T NK + NK - 1
+          float m = P[0][0];
+#pragma unroll
+          for (int q = 0; q < NK; ++q)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) m = fmaxf(m, P[q][j]);
+          m = ck::clamp_finite(ck::xhalf_max(m));
+          const float nml = exp_offset(m, 0.f);
+          float e[NK][16];
+#pragma unroll
+          for (int q = 0; q < NK; ++q)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) e[q][j] = __builtin_amdgcn_exp2f(fmaf(P[q][j], kL2E, nml));
+          static_for<0, NK>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            const int u = T * NK + p;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's share of unit u has landed
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everybody's; every wave has left unit u - 1
+            if (u + 1 < TU) stage_w(u + 1);
+            const uint32_t wb = w_rd + (u & 1) * (32 * K * 4);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            static_for<0, NK>([&](auto qc) {
+              constexpr int q = decltype(qc)::value;
+              constexpr int o = q * 4096;
+              f32x4v w0, w1, w2, w3;
+              lds_read4_off<o, o + 1024, o + 2048, o + 3072>(w0, w1, w2, w3, wb);
+              const f32x4v* wg[4] = {&w0, &w1, &w2, &w3};
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[0], e[q][4 * g + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[1], e[q][4 * g + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[2], e[q][4 * g + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[3], e[q][4 * g + 3], acc, 0, 0, 0);
+              }
+            });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) P[p][r] = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m);
+          });
+        }
         if (live) {
           float* dst = out + (static_cast<int64_t>(f) * B + b) * K + 4 * kh;
 #pragma unroll
@@ -798,7 +844,8 @@ int cat_dense(const float* arena, const int64_t* row_off, const float* w, float*
                                                  static_cast<int>(lds_dma));
               if (e != hipSuccess) return e;
               hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, static_cast<const int64_t*>(nullptr),
-                                 static_cast<const float*>(nullptr), out, static_cast<int32_t*>(nullptr), H, 1, B, w);
+                                 static_cast<const float*>(nullptr), out, static_cast<int32_t*>(nullptr), H, 1, B, w,
+                                 static_cast<const int64_t*>(nullptr));
               return hipGetLastError();
             };
             return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
@@ -836,12 +883,12 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
   CK_REQUIRE(K == 32 || K == 64, "ck_cp_lse_fwd: K must be 32 or 64, found %d", K);
   CK_REQUIRE(F <= 65535, "ck_cp_lse_fwd: F=%d exceeds grid.y", F);
   CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(out), "ck_cp_lse_fwd: buffers must be 16-byte aligned");
-  // a plain block (products of one child per slot, no CP-T sum behind it, contiguous output) on the DMA-staged kernel of
-  // the regions: every operand prefetched a step ahead through LDS
+  // a block of one child per slot with contiguous output on the DMA-staged kernel of the regions: every operand (the CP-T
+  // matrix included) prefetched a step ahead through LDS
   {
     const int waves = K == 64 ? 4 : 8;
     const size_t lds_dma = (static_cast<size_t>(2) * 32 * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(K)) * sizeof(float);
-    if (H == 1 && g_var == nullptr && w_post == nullptr && out_off == nullptr && !ck::debug_force_generic() &&
+    if (H == 1 && g_var == nullptr && out_off == nullptr && !ck::debug_force_generic() &&
         static_cast<int64_t>(B) * K < (int64_t{1} << 30)) {
       const int tiles = (B + 31) / 32;
       const dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
@@ -852,7 +899,7 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
                                                  static_cast<int>(lds_dma));
               if (e != hipSuccess) return e;
               hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, w_addr, static_cast<const float*>(nullptr), out,
-                                 static_cast<int32_t*>(nullptr), 1, S, B, static_cast<const float*>(nullptr));
+                                 static_cast<int32_t*>(nullptr), 1, S, B, static_cast<const float*>(nullptr), w_post);
               return hipGetLastError();
             };
             return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
@@ -899,7 +946,8 @@ extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, con
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds_dma));
           if (e != hipSuccess) return e;
-          hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, w_addr, mw, out, redo, H, S, B, static_cast<const float*>(nullptr));
+          hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, w_addr, mw, out, redo, H, S, B, static_cast<const float*>(nullptr),
+                             static_cast<const int64_t*>(nullptr));
           return hipGetLastError();
         };
         // K = 64: 48 KiB + H x 256 B of LDS and <= 168 VGPRs: three workgroups (12 waves) per CU while H <= 20

@@ -759,11 +759,12 @@ def test_region_kernels_agree_bit_for_bit(hip_device, K, F, H, S, B):
     assert float(((out.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-5
 
 
+@pytest.mark.parametrize("post", [False, True])
 @pytest.mark.parametrize("K,F,S,B", [(64, 3, 2, 300), (64, 2, 3, 33), (32, 5, 2, 257), (32, 1, 1, 4096)])
-def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B):
-    """`ck_cp_lse_fwd` for a plain CP block (one child per slot, no CP-T sum behind the product, contiguous output): the
-    launch on the DMA-staged region kernel (the product is the output) and the register-path launch (cp_lse_kernel, taken
-    under ck_debug_force_generic) do the same arithmetic in the same order; value = sum_s log(W_s exp(x_s))."""
+def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B, post):
+    """`ck_cp_lse_fwd` for a CP block of one child per slot with contiguous output, with and without a CP-T sum behind the
+    product: the launch on the DMA-staged region kernel and the register-path launch (cp_lse_kernel, taken under
+    ck_debug_force_generic) do the same arithmetic in the same order; value = [W_post .] prod_s (W_s . x_s) in log space."""
     from cirkit_amd import _capi as capi
 
     g = torch.Generator().manual_seed(K + F + S + B)
@@ -775,13 +776,15 @@ def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B):
     if S > 2:
         addr[:, 1] = 0  # a plain slot
     addr = addr.to(hip_device)
+    wp = torch.softmax(torch.randn(F, K, K, generator=g), dim=-1).to(hip_device)
+    paddr = torch.tensor([wp.data_ptr() + i * K * K * 4 for i in range(F)], dtype=torch.int64).to(hip_device)
     stream = torch.cuda.current_stream(hip_device).cuda_stream
     outs = []
     for force in (0, 1):
         out = torch.full((F, B, K), float("nan"), device=hip_device)
         capi.call("ck_debug_force_generic", force)
         try:
-            capi.call("ck_cp_lse_fwd", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), None, None, out.data_ptr(),
+            capi.call("ck_cp_lse_fwd", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), paddr.data_ptr() if post else None, None, out.data_ptr(),
                       None, None, None, 0, F, S, 1, B, K, stream)
         finally:
             capi.call("ck_debug_force_generic", 0)
@@ -798,6 +801,9 @@ def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B):
                 wi = (int(ad[f, s_]) - w.data_ptr()) // (K * K * 4)
                 v = torch.log(torch.exp(v) @ wc[wi].T)
             ref[f] += v
+        if post:
+            mx = ref[f].amax(dim=-1, keepdim=True)
+            ref[f] = torch.log(torch.exp(ref[f] - mx) @ wp[f].cpu().double().T) + mx
     assert float(((outs[0].double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-5
 
 
