@@ -719,7 +719,15 @@ int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* m
   const int lpr = K / 4;
   const bool vec = (K % 4 == 0) && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && ck::aligned16(arena) &&
                    ck::aligned16(out);
-  const int rows_per_block = vec ? 128 : 32;
+  // 128 rows per workgroup when that fills the chip; small launches (a few folds at batch 128) are one dependent load
+  // chain per 4 x (256 / K) rows long: fewer rows per workgroup, down to one pass of its four waves
+  int rows_per_block = vec ? 128 : 32;
+  if (vec) {
+    const int one_pass = 4 * (64 / lpr);
+    while (rows_per_block > one_pass && static_cast<int64_t>(F) * ((B + rows_per_block - 1) / rows_per_block) < 4 * ck::num_cus())
+      rows_per_block /= 2;
+    rows_per_block = std::max(rows_per_block, one_pass);
+  }
   dim3 grid((B + rows_per_block - 1) / rows_per_block, F), block(256);
   const size_t lds = static_cast<size_t>(K) * H * sizeof(float);
   CK_REQUIRE(!vec || lds <= 64 * 1024, "ck_mixing_lse_fwd: K*H=%d coefficients do not fit in LDS", K * H);
