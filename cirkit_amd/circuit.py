@@ -1149,8 +1149,17 @@ class HipCircuit:
             return "gather_rows_vec (dense layer tabulated over its categories)"
         if i in self._emb_gather:
             return "sum_clse_tile32 (Embedding rows gathered from the table)"
+        def gathers(slot_dense) -> bool:  # some slot reads a tabulated dense layer
+            return any(int(d) in self._tdense for d in np.unique(slot_dense[..., 0]) if d >= 0)
+
+        dma = "2, 4, 3" if l.num_output_units == 64 else "1, 8, 2"  # (ck_cp.hip: region_dma_kernel<NK, WAVES, MINW, ..>)
         if i in self._regions:
-            return "region_lse_kernel<2, 4, 3>" if l.num_output_units == 64 else "region_lse_kernel<1, 8, 4>"
+            if gathers(self._regions[i].slot_dense):
+                return "region_lse_kernel<2, 4, 3>" if l.num_output_units == 64 else "region_lse_kernel<1, 8, 4>"
+            return f"region_dma_kernel<{dma}, {'true' if self.linear_levels else 'false'}, false>"
+        if i in self._cp_blocks and self._cp_subset.get(i) is None and (
+                self._cp_blocks[i].slot_dense.shape[1] <= 8 or not gathers(self._cp_blocks[i].slot_dense)):
+            return f"region_dma_kernel<{dma}, false, true>"
         if i in self._cp_blocks or i in self._cp_leftover:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root and self._signed:

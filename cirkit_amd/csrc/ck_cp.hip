@@ -395,13 +395,19 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
 // lanes -- no bank conflicts -- and the DMA, whose LDS side is linear in the lane, applies the swizzle on its global side.
 // Weights: ring of TWO buffers (W_{t+1} is staged after the barrier of step t, a whole MFMA chain ahead of its use).
 // Same arithmetic, in the same order, as region_lse_kernel: the two agree bit for bit.
-template <int NK, int WAVES, int MINW, bool LINEAR>
+// BLOCK: the launch is a CP block on its own (H = 1, LINEAR = false; see below) -- the variants without it carry neither
+// the CP-T step nor the table gathers, the variant with it no mixing sum.
+template <int NK, int WAVES, int MINW, bool LINEAR, bool BLOCK = false>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
     region_dma_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                       const int64_t* __restrict__ w_addr, const float* __restrict__ mw, float* __restrict__ out,
                       int32_t* __restrict__ redo, int H, int S, int B, const float* __restrict__ w_cat,
-                      const int64_t* __restrict__ w_post) {
-  // mw == nullptr && w_cat == nullptr (LINEAR = false, H = 1): a CP block on its own -- the product P of the slots is the
+                      const int64_t* __restrict__ w_post, const GatherSlots gs) {
+  // gs.var != nullptr: slots with gs.var[f, t] >= 0 read rows of a (C+1, K) TABLE picked by the batch values instead of
+  // an arena block (tabulated dense layers over Categorical inputs): the same whole-row DMAs with the row index taken
+  // from the batch -- the wave's 32 values of every such slot are parked in LDS once, at the start.
+  static_assert(!(BLOCK && LINEAR), "CP blocks on their own are evaluated in log space");
+  // BLOCK (mw == nullptr, w_cat == nullptr, H = 1): a CP block on its own -- the product P of the slots is the
   // output, or (w_post[f] != 0, a CP-T layer: optimized.py:171-178) log(W_post . exp(P - max P)) + max P, one more step
   // of the weight pipeline on the register tile P.
   // w_cat != nullptr: a dense Sum layer over the CONCATENATION of H children (inner.py:266-273 with a full (K, H K) weight)
@@ -416,6 +422,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   float* w_s = smem;                           // [2][32*K]: ring of two weight units
   float* tile_s = smem + 2 * 32 * K;           // [WAVES][32*K]
   float* mw_s = tile_s + WAVES * 32 * K;       // [H][K]
+  int32_t* xg_s = reinterpret_cast<int32_t*>(mw_s + H * K);  // gather slots: [WAVES][T][32] batch values, DMA order
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -426,7 +433,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   const int T = H * S;
   const int64_t* ro = row_off + static_cast<int64_t>(f) * T;
   const int64_t* wa = w_addr + static_cast<int64_t>(f) * T;
-  const int TU = (T + (w_post != nullptr ? 1 : 0)) * NK;  // weight units of the launch
+  const int TU = (T + (BLOCK && w_post != nullptr ? 1 : 0)) * NK;  // weight units of the launch
   // weight unit u = t * NK + p goes to ring buffer u & 1, in the operand layout [(q * 4 + g) * 64 + lane] float4
   constexpr int PF = (UF4 + WAVES * 64 - 1) / (WAVES * 64);
   static_assert(NK == 1 || UF4 % (WAVES * 64) == 0, "the vmcnt bookkeeping of later units assumes every wave stages a share");
@@ -443,7 +450,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
     const int t = u / NK, p = u % NK;
     const uint64_t wv = w_cat != nullptr
                             ? static_cast<uint64_t>(reinterpret_cast<uintptr_t>(w_cat + (static_cast<int64_t>(f) * K * T + t) * K))
-                            : static_cast<uint64_t>(t == T ? w_post[f] : wa[t]);
+                            : static_cast<uint64_t>(BLOCK && t == T ? w_post[f] : wa[t]);
     if (wv == 0) return;
     // (made uniform explicitly: the compiler otherwise carries the loaded address in vector registers)
     const uint64_t wu = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv >> 32)))) << 32) |
@@ -467,7 +474,30 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
     const int swz = CH == 16 ? (r & 15) : ((r >> 1) & 7);
     src_off[k] = static_cast<uint32_t>(min(b0 + r, B - 1) * K + 4 * (pos ^ swz)) * 4u;
   }
+  const int32_t* gvar = BLOCK && gs.var != nullptr ? gs.var + static_cast<int64_t>(f) * T : nullptr;
+  // a lane's TD values of slot t are contiguous: index (lane / CH) * TD + k holds the value of row k * (64 / CH) + lane / CH
+  const uint32_t xg_rd = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(xg_s)) + ((wave_u * T) * 32 + (lane / CH) * TD) * 4;
   auto stage_tile = [&](int t) {
+    if (BLOCK && gvar != nullptr && gvar[t] >= 0) {  // (uniform) rows x[b] of the slot's table
+      const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(gs.addr[static_cast<int64_t>(f) * T + t]));
+      int32_t xv[TD];
+      static_for<0, TD / 4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        f32x4v r;
+        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(xg_rd + t * 128), "n"(16 * j) : "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[4 * j + e] = __float_as_int(r[e]);
+      });
+#pragma unroll
+      for (int k = 0; k < TD; ++k) {
+        const int r = k * (64 / CH) + lane / CH, pos = lane % CH;
+        const int swz = CH == 16 ? (r & 15) : ((r >> 1) & 7);
+        const int c = xv[k] < 0 ? gs.C : min(xv[k], gs.C - 1);
+        const uint32_t o = static_cast<uint32_t>(c * K + 4 * (pos ^ swz)) * 4u;
+        __builtin_amdgcn_global_load_lds((ck::gptr_t)(base + o), (ck::lptr_t)(my_tile + k * 256), 16, 0, 0);
+      }
+      return;
+    }
     const char* base = reinterpret_cast<const char*>(arena + ro[t]);
 #pragma unroll
     for (int k = 0; k < TD; ++k) {
@@ -484,6 +514,13 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   for (int i = threadIdx.x; i < K * H; i += WAVES * 64) {
     const int k = i / H, h = i - k * H;
     mw_s[h * K + k] = mw != nullptr ? mw[static_cast<int64_t>(f) * K * H + i] : 1.f;
+  }
+  if (BLOCK && gvar != nullptr && lane < 32) {  // row `lane` of this wave's tile: slot t's value at DMA-order index (see xg_rd)
+    const int row = min(b0 + lane, B - 1);
+    for (int t = 0; t < T; ++t) {
+      const int v = gvar[t];
+      if (v >= 0) xg_s[(wave_u * T + t) * 32 + (lane % (64 / CH)) * TD + lane / (64 / CH)] = gs.xt[static_cast<int64_t>(v) * B + row];
+    }
   }
   stage_w(0);
   stage_tile(0);
@@ -585,8 +622,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
       });
       if constexpr (LINEAR) sc = s == 0 ? m : sc + m;
     }
-    if constexpr (!LINEAR) {
-      if (mw == nullptr && w_cat == nullptr) {  // a CP block on its own (H = 1, no mixing layer behind it)
+    if constexpr (BLOCK) {
+      {  // (H = 1, no mixing layer behind the product)
         if (w_post != nullptr) {  // the CP-T sum on the register tile P: weight units T NK .. T NK + NK - 1
           float m = P[0][0];
 #pragma unroll
@@ -845,7 +882,7 @@ int cat_dense(const float* arena, const int64_t* row_off, const float* w, float*
               if (e != hipSuccess) return e;
               hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, static_cast<const int64_t*>(nullptr),
                                  static_cast<const float*>(nullptr), out, static_cast<int32_t*>(nullptr), H, 1, B, w,
-                                 static_cast<const int64_t*>(nullptr));
+                                 static_cast<const int64_t*>(nullptr), GatherSlots{});
               return hipGetLastError();
             };
             return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
@@ -887,8 +924,9 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
   // matrix included) prefetched a step ahead through LDS
   {
     const int waves = K == 64 ? 4 : 8;
-    const size_t lds_dma = (static_cast<size_t>(2) * 32 * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(K)) * sizeof(float);
-    if (H == 1 && g_var == nullptr && out_off == nullptr && !ck::debug_force_generic() &&
+    const size_t lds_dma = (static_cast<size_t>(2) * 32 * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(K) +
+                            (g_var != nullptr ? static_cast<size_t>(waves) * S * 32 : 0)) * sizeof(float);
+    if (H == 1 && (g_var == nullptr || S <= 8) && out_off == nullptr && !ck::debug_force_generic() &&
         static_cast<int64_t>(B) * K < (int64_t{1} << 30)) {
       const int tiles = (B + 31) / 32;
       const dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
@@ -899,10 +937,10 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
                                                  static_cast<int>(lds_dma));
               if (e != hipSuccess) return e;
               hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, w_addr, static_cast<const float*>(nullptr), out,
-                                 static_cast<int32_t*>(nullptr), 1, S, B, static_cast<const float*>(nullptr), w_post);
+                                 static_cast<int32_t*>(nullptr), 1, S, B, static_cast<const float*>(nullptr), w_post, gs);
               return hipGetLastError();
             };
-            return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
+            return K == 64 ? go(region_dma_kernel<2, 4, 3, false, true>) : go(region_dma_kernel<1, 8, 2, false, true>);
           },
           stream);
     }
@@ -947,7 +985,7 @@ extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, con
                                              static_cast<int>(lds_dma));
           if (e != hipSuccess) return e;
           hipLaunchKernelGGL(kern, grid, block, lds_dma, s, arena, row_off, w_addr, mw, out, redo, H, S, B, static_cast<const float*>(nullptr),
-                             static_cast<const int64_t*>(nullptr));
+                             static_cast<const int64_t*>(nullptr), GatherSlots{});
           return hipGetLastError();
         };
         // K = 64: 48 KiB + H x 256 B of LDS and <= 168 VGPRs: three workgroups (12 waves) per CU while H <= 20

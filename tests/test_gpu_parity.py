@@ -759,15 +759,17 @@ def test_region_kernels_agree_bit_for_bit(hip_device, K, F, H, S, B):
     assert float(((out.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-5
 
 
-@pytest.mark.parametrize("post", [False, True])
+@pytest.mark.parametrize("post,gather", [(False, False), (True, False), (True, True), (False, True)])
 @pytest.mark.parametrize("K,F,S,B", [(64, 3, 2, 300), (64, 2, 3, 33), (32, 5, 2, 257), (32, 1, 1, 4096)])
-def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B, post):
+def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B, post, gather):
     """`ck_cp_lse_fwd` for a CP block of one child per slot with contiguous output, with and without a CP-T sum behind the
-    product: the launch on the DMA-staged region kernel and the register-path launch (cp_lse_kernel, taken under
+    product, with and without slots that gather the rows of a table by the batch values (tabulated dense layers): the
+    launch on the DMA-staged region kernel and the register-path launch (cp_lse_kernel, taken under
     ck_debug_force_generic) do the same arithmetic in the same order; value = [W_post .] prod_s (W_s . x_s) in log space."""
     from cirkit_amd import _capi as capi
 
     g = torch.Generator().manual_seed(K + F + S + B)
+    C, D = 7, 5
     arena = (torch.randn(F * S, B, K, generator=g) * 3 - 5).to(hip_device)
     row_off = (torch.arange(F * S, dtype=torch.int64) * (B * K)).reshape(F, S)
     row_off = row_off[:, torch.randperm(S, generator=g)].contiguous().to(hip_device)
@@ -775,7 +777,17 @@ def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B, post):
     addr = torch.tensor([w.data_ptr() + i * K * K * 4 for i in range(F * S)], dtype=torch.int64).reshape(F, S)
     if S > 2:
         addr[:, 1] = 0  # a plain slot
-    addr = addr.to(hip_device)
+    # gather slots: slot 0 of every fold reads row x[b, var] of its own (C + 1, K) table (negative = the integral row C)
+    tab = (torch.randn(F, C + 1, K, generator=g) * 2 - 3).to(hip_device)
+    xt = torch.randint(-1, C, (D, B), generator=g, dtype=torch.int32).to(hip_device)
+    g_var = torch.full((F, S), -1, dtype=torch.int32)
+    g_addr = torch.zeros(F, S, dtype=torch.int64)
+    if gather:
+        g_var[:, 0] = torch.arange(F, dtype=torch.int32) % D
+        g_addr[:, 0] = torch.tensor([tab.data_ptr() + f * (C + 1) * K * 4 for f in range(F)], dtype=torch.int64)
+        addr[:, 0] = 0  # (tabulated: no weights of their own)
+    addr, g_var, g_addr = addr.to(hip_device), g_var.to(hip_device), g_addr.to(hip_device)
+    gargs = (g_addr.data_ptr(), g_var.data_ptr(), xt.data_ptr(), C) if gather else (None, None, None, 0)
     wp = torch.softmax(torch.randn(F, K, K, generator=g), dim=-1).to(hip_device)
     paddr = torch.tensor([wp.data_ptr() + i * K * K * 4 for i in range(F)], dtype=torch.int64).to(hip_device)
     stream = torch.cuda.current_stream(hip_device).cuda_stream
@@ -785,7 +797,7 @@ def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B, post):
         capi.call("ck_debug_force_generic", force)
         try:
             capi.call("ck_cp_lse_fwd", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), paddr.data_ptr() if post else None, None, out.data_ptr(),
-                      None, None, None, 0, F, S, 1, B, K, stream)
+                      *gargs, F, S, 1, B, K, stream)
         finally:
             capi.call("ck_debug_force_generic", 0)
         torch.cuda.synchronize()
@@ -793,10 +805,15 @@ def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B, post):
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
     a, ro, wc, ad = arena.cpu().double(), row_off.cpu(), w.cpu().double(), addr.cpu()
+    tc, xc, gv = tab.cpu().double(), xt.cpu().long(), g_var.cpu()
     ref = torch.zeros(F, B, K, dtype=torch.float64)
     for f in range(F):
         for s_ in range(S):
-            v = a[int(ro[f, s_]) // (B * K)]
+            if int(gv[f, s_]) >= 0:
+                xb = xc[int(gv[f, s_])]
+                v = tc[f][torch.where(xb < 0, torch.full_like(xb, C), xb)]
+            else:
+                v = a[int(ro[f, s_]) // (B * K)]
             if int(ad[f, s_]) != 0:
                 wi = (int(ad[f, s_]) - w.data_ptr()) // (K * K * 4)
                 v = torch.log(torch.exp(v) @ wc[wi].T)
