@@ -33,6 +33,7 @@ struct GatherSlots {
   const int32_t* var;   // (F, S...) variable of the slot, -1 = read the arena through row_off
   const int32_t* xt;    // (D, B) staged batch
   int C;                // categories (row C = the integral row, taken by negative values)
+  int F;                // region_dma_kernel<.., BLOCK>: folds of the launch (its grid is one-dimensional)
 };
 
 __device__ __forceinline__ const float* slot_source(const GatherSlots& gs, const float* arena, int64_t off, int64_t e,
@@ -423,11 +424,21 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   float* tile_s = smem + 2 * 32 * K;           // [WAVES][32*K]
   float* mw_s = tile_s + WAVES * 32 * K;       // [H][K]
   int32_t* xg_s = reinterpret_cast<int32_t*>(mw_s + H * K);  // gather slots: [WAVES][T][32] batch values, DMA order
-  const int f = blockIdx.y;
+  // BLOCK: a one-dimensional grid, XCD-aware (consecutive workgroup ids go to consecutive XCDs): every workgroup of a
+  // fold gets the same id % 8, so the fold's tables and weights are fetched into ONE XCD's L2 and found there by the
+  // fold's other row tiles (gridDim.y = 1; the F x row-tile grid otherwise)
+  int f = blockIdx.y, bx = blockIdx.x;
+  if constexpr (BLOCK) {
+    const int gx = (B + WAVES * 32 - 1) / (WAVES * 32);
+    const int n = blockIdx.x >> 3;
+    f = (n / gx) * 8 + (blockIdx.x & 7);
+    bx = n % gx;
+    if (f >= gs.F) return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int b_in = lane & 31, kh = lane >> 5;
-  const int b0 = (blockIdx.x * WAVES + wave_u) * 32;
+  const int b0 = (bx * WAVES + wave_u) * 32;
   const int b = b0 + b_in;
   const bool live = b < B;
   const int T = H * S;
@@ -725,7 +736,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
     }
   }
   if constexpr (LINEAR) {
-    if (__any(bad) && lane == 0) atomicOr(redo + (static_cast<int64_t>(f) * gridDim.x + blockIdx.x), 1);
+    if (__any(bad) && lane == 0) atomicOr(redo + (static_cast<int64_t>(f) * gridDim.x + bx), 1);
   }
   if (live) {
     float* dst = out + (static_cast<int64_t>(f) * B + b) * K + 4 * kh;
@@ -914,7 +925,7 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
                              const int64_t* out_off, float* out, const int64_t* g_addr, const int32_t* g_var,
                              const int32_t* xt, int C, int F, int S, int H, int B, int K, void* stream) {
   CK_REQUIRE(g_var == nullptr || (g_addr && xt && C > 0), "ck_cp_lse_fwd: gather slots need g_addr, xt and C");
-  const GatherSlots gs{g_addr, g_var, xt, C};
+  const GatherSlots gs{g_addr, g_var, xt, C, F};
   CK_REQUIRE(arena && row_off && w_addr && out, "ck_cp_lse_fwd: null pointer");
   CK_REQUIRE(F > 0 && S > 0 && H > 0 && B > 0, "ck_cp_lse_fwd: non-positive size F=%d S=%d H=%d B=%d", F, S, H, B);
   CK_REQUIRE(K == 32 || K == 64, "ck_cp_lse_fwd: K must be 32 or 64, found %d", K);
@@ -928,8 +939,8 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
                             (g_var != nullptr ? static_cast<size_t>(waves) * S * 32 : 0)) * sizeof(float);
     if (H == 1 && (g_var == nullptr || S <= 8) && out_off == nullptr && !ck::debug_force_generic() &&
         static_cast<int64_t>(B) * K < (int64_t{1} << 30)) {
-      const int tiles = (B + 31) / 32;
-      const dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
+      const int tiles = (B + 31) / 32, gx = (tiles + waves - 1) / waves;
+      const dim3 grid(static_cast<unsigned>((F + 7) / 8 * 8 * gx)), block(waves * 64);  // (XCD-aware: see the kernel)
       return ck::dispatch(
           [=](hipStream_t s) {
             auto go = [&](auto kern) {
@@ -953,7 +964,7 @@ extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, con
                                  float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
                                  int32_t* redo, int F, int H, int S, int B, int K, void* stream) {
   CK_REQUIRE(g_var == nullptr || (g_addr && xt && C > 0), "ck_region_lse_fwd: gather slots need g_addr, xt and C");
-  const GatherSlots gs{g_addr, g_var, xt, C};
+  const GatherSlots gs{g_addr, g_var, xt, C, F};
   CK_REQUIRE(arena && row_off && w_addr && mw && out, "ck_region_lse_fwd: null pointer");
   CK_REQUIRE(F > 0 && S > 0 && H > 0 && B > 0, "ck_region_lse_fwd: non-positive size F=%d H=%d S=%d B=%d", F, H, S, B);
   CK_REQUIRE(K == 32 || K == 64, "ck_region_lse_fwd: K must be 32 or 64, found %d", K);
