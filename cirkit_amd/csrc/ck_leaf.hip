@@ -137,10 +137,18 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     // The address is the (uniform) table pointer plus a 32-bit lane offset (row index << 7) + chunk offset: one VALU
     // instruction per DMA (global_load_lds with an SGPR base).
     auto dma = [&](int32_t rowv, int slot) {
+      // the four row indices of this lane with ONE wait (the compiler pairs them: two LDS round trips per leaf)
+      uint32_t ridx[4];
+      const uint32_t bp = 4 * (lane >> 3);
+      asm volatile(
+          "ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %5 offset:32\n\tds_bpermute_b32 %2, %4, %5 offset:64\n\t"
+          "ds_bpermute_b32 %3, %4, %5 offset:96\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(ridx[0]), "=&v"(ridx[1]), "=&v"(ridx[2]), "=&v"(ridx[3])
+          : "v"(bp), "v"(rowv)
+          : "memory");
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint32_t ridx = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(4 * (8 * q + (lane >> 3)), rowv));
-        const char* src = reinterpret_cast<const char*>(a.table) + static_cast<uint32_t>((ridx << 7) + g_coff[q & 1]);
+        const char* src = reinterpret_cast<const char*>(a.table) + static_cast<uint32_t>((ridx[q] << 7) + g_coff[q & 1]);
         __builtin_amdgcn_global_load_lds((ck::gptr_t)src, (ck::lptr_t)(my_slots + slot * 1024 + q * 256), 16, 0, 0);
       }
     };
