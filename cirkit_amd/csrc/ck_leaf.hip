@@ -197,6 +197,12 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         // layout; the reads have returned before the slot is refilled
         f32x4 r0, r1, r2, r3;
         constexpr int kYounger = i == 0 ? 0 : 5 * (kLeaves - 1 - i < kSlots - 1 ? kLeaves - 1 - i : kSlots - 1);
+        // (the weights of the leaf's first contraction are requested in front of the slot reads: one LDS round trip for both)
+        WRegs wfirst;
+        if constexpr (steps_after(i) > 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wfirst.q[q] = *reinterpret_cast<const float4*>(w_lds + steps_before(i) * 1024 + q * 256 + lane * 4);
+        }
         asm volatile(
             "s_waitcnt vmcnt(%9)\n\tds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\t"
             "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
@@ -225,8 +231,12 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         static_for<0, steps_after(i)>([&](auto lc) {
           constexpr int l = decltype(lc)::value, step = steps_before(i) + l;
           WRegs wcur;
+          if constexpr (l == 0) {
+            wcur = wfirst;
+          } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
+            for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
+          }
           if constexpr (l == 0) {
             tile_mul(cur, stack[0]);  // first level: the bare product (ck_tile.h)
           } else {
