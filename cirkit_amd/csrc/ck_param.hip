@@ -603,13 +603,67 @@ __device__ __forceinline__ void softmax_job_table_dense_rows(const ck_softmax_jo
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) v[4 * g + tt] = c >= C ? 0.f : tile[(8 * g + 4 * kh + tt) * ld + cl];  // row C: log sum_c p = 0
-    const float m = row_max16(v);
-    const float nml = exp_offset(m, 0.f);
+    if (j.kind == 4) {  // out = log(W . exp(T - m)) + m: the dense layer's own output row
+      sum_step<CK_W_ROWMAJOR>(wr, v);
+    } else {  // kind 5: the row stays in linear space with its log scale m stored aside
+      const float m = row_max16(v);
+      const float nml = exp_offset(m, 0.f);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_exp2f(fmaf(v[r], kL2E, nml));
-    contract_linear<CK_W_ROWMAJOR>(wr, v);
-    if (c <= C && kh == 0) j.out2[static_cast<int64_t>(d) * (C + 1) + c] = m;
+      for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_exp2f(fmaf(v[r], kL2E, nml));
+      contract_linear<CK_W_ROWMAJOR>(wr, v);
+      if (c <= C && kh == 0) j.out2[static_cast<int64_t>(d) * (C + 1) + c] = m;
+    }
     if (c <= C) tile_store(dst + static_cast<int64_t>(c) * K + 4 * kh, v);
+  }
+}
+
+// kind 1 for C <= 256, C % 4 == 0: the rows-in-registers form of the table job (as softmax_job_table_dense_rows: the same
+// reductions, so the tables of the three jobs agree bit for bit) -- one pass through LDS, transposed on the way in:
+// tile_T[c][k], row stride K + 1 (the float4 columns of the output are then read without bank conflicts).
+__device__ __forceinline__ void softmax_job_table_rows(const ck_softmax_job& j, int f, float* tile) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = j.len, K = j.k, n4 = C >> 2, ldT = K + 1;
+  const float4* src = reinterpret_cast<const float4*>(j.in + static_cast<int64_t>(f) * K * C);
+  const bool on = lane < n4;
+  for (int k0 = wave; k0 < K; k0 += 8 * kPW) {  // 8 rows (units) per wave and pass, all loads in flight
+    float4 x[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = k0 + kPW * r;
+      x[r] = on && k < K ? src[k * n4 + lane] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = k0 + kPW * r;
+      if (k >= K) break;  // (uniform over the wave)
+      const float mx = wave_reduce_dpp<true>(fmaxf(fmaxf(x[r].x, x[r].y), fmaxf(x[r].z, x[r].w)));
+      const float4 dl = make_float4(x[r].x - mx, x[r].y - mx, x[r].z - mx, x[r].w - mx);
+      const float part = on ? (__expf(dl.x) + __expf(dl.y)) + (__expf(dl.z) + __expf(dl.w)) : 0.f;
+      const float ls = __logf(wave_reduce_dpp<false>(part));
+      if (on) {
+        float* col = tile + (4 * lane) * ldT + k;
+        col[0] = dl.x < -103.9f ? -INFINITY : dl.x - ls;
+        col[ldT] = dl.y < -103.9f ? -INFINITY : dl.y - ls;
+        col[2 * ldT] = dl.z < -103.9f ? -INFINITY : dl.z - ls;
+        col[3 * ldT] = dl.w < -103.9f ? -INFINITY : dl.w - ls;
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = j.out + static_cast<int64_t>(f) * (C + 1) * K;  // (C + 1, K): row C = integral row
+  for (int k = threadIdx.x; k < K; k += blockDim.x) dst[static_cast<int64_t>(C) * K + k] = 0.f;  // log sum_c p = 0
+  if ((K & 3) == 0) {
+    const int k4n = K >> 2;
+    for (int i = threadIdx.x; i < C * k4n; i += blockDim.x) {
+      const int c = i / k4n, k = (i - c * k4n) << 2;
+      const float* row = tile + c * ldT + k;
+      reinterpret_cast<float4*>(dst)[i] = make_float4(row[0], row[1], row[2], row[3]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < C * K; i += blockDim.x) {
+      const int c = i / K, k = i - c * K;
+      dst[i] = tile[c * ldT + k];
+    }
   }
 }
 
@@ -784,9 +838,12 @@ __global__ void __launch_bounds__((WIDE ? kPW64 : kPW) * 64) softmax_batch_kerne
     softmax_job_table_dense64(j, blk, tile);
     return;
   }
-  if (j.kind == 1)
+  const bool rows_form = j.len <= 256 && (j.len & 3) == 0;  // a (unit, all categories) row is one float4 per lane
+  if (j.kind == 1 && rows_form)
+    softmax_job_table_rows(j, blk, tile);
+  else if (j.kind == 1)
     softmax_job_table(j, blk, tile);
-  else if (j.kind == 5 && j.k == 32 && j.len <= 256 && (j.len & 3) == 0)
+  else if ((j.kind == 4 || j.kind == 5) && j.k == 32 && rows_form)
     softmax_job_table_dense_rows(j, blk, tile);
   else if (j.kind == 4 || j.kind == 5)
     softmax_job_table_dense(j, blk, tile);
@@ -1079,7 +1136,8 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
           blocks += static_cast<int>((j.rows + 16 * kPW - 1) / (16 * kPW));
         } else {
           CK_REQUIRE(j.k > 0, "ck_param_softmax_batch: job %d needs k > 0", idx);
-          const size_t need = (static_cast<size_t>(j.k) * (j.len + 4) + 2 * j.k + (j.kind >= 4 ? j.k * j.k : 0)) * sizeof(float);  // (row stride up to len + 4)
+          size_t need = (static_cast<size_t>(j.k) * (j.len + 4) + 2 * j.k + (j.kind >= 4 ? j.k * j.k : 0)) * sizeof(float);  // (row stride up to len + 4)
+          if (j.kind == 1) need = std::max(need, static_cast<size_t>(j.len) * (j.k + 1) * sizeof(float));  // (transposed: [len][k + 1])
           if (need > 160 * 1024)
             return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
           lds = std::max(lds, need);
