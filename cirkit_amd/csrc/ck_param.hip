@@ -672,18 +672,29 @@ __device__ __forceinline__ void softmax_job_table_rows(const ck_softmax_job& j, 
 __device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& j, int d, float* tile) {
   constexpr int K = 64, NK = 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int C = j.len, ld = C + 1;
+  const int C = j.len;
+  // rows form (C <= 256, C % 4 == 0): a (unit, all categories) row is one float4 per lane -- maximum and log-sum-exp are
+  // wave reductions in registers and the tile in LDS holds the NORMALISED log-probabilities (one pass through LDS, the
+  // same reductions as softmax_job_table_rows / softmax_job_table_dense_rows); otherwise two passes over the logits in LDS
+  const bool rows_form = C <= 256 && (C & 3) == 0;
+  const int ld = rows_form ? C + 4 : C + 1;
   const int64_t f = j.idx != nullptr ? j.idx[d] : d;
   const float* src = j.in + f * K * C;
-  float* stat = tile + K * ld;  // [K] max, [K] log-sum
-  float* w_s = stat + 2 * K;    // [p][q][g][lane][4] linear weights of dense fold d
+  float* stat = tile + K * (C + 4);  // [K] max, [K] log-sum
+  float* w_s = stat + 2 * K;         // [p][q][g][lane][4] linear weights of dense fold d
   // every global load of the job is issued before the first use: the (K, C) logits as 16-byte loads and the
   // K / kPW64 weight rows of this wave (the job's latency is the kernel time, see kPW)
   const float* th = j.in2 + static_cast<int64_t>(d) * (K * K);
   float wx[K / kPW64];
 #pragma unroll
   for (int r = 0; r < K / kPW64; ++r) wx[r] = th[(wave + kPW64 * r) * K + lane];
-  if ((C & 3) == 0) {
+  float4 x[K / kPW64];
+  if (rows_form) {
+    const int n4r = C >> 2;
+#pragma unroll
+    for (int r = 0; r < K / kPW64; ++r)
+      x[r] = lane < n4r ? reinterpret_cast<const float4*>(src)[(wave + kPW64 * r) * n4r + lane] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  } else if ((C & 3) == 0) {
     const float4* src4 = reinterpret_cast<const float4*>(src);
     const int n4 = (K * C) >> 2;
     for (int base = threadIdx.x; base < n4; base += 8 * kPW64 * 64) {  // 8 loads in flight per thread
@@ -734,8 +745,27 @@ __device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& 
       w_s[((((p * NK + q) * 4 + g) * 64) + ln) * 4 + (k & 3)] = e[r] / sum[r];
     }
   }
+  if (rows_form) {
+    const bool on = lane < (C >> 2);
+#pragma unroll
+    for (int r = 0; r < K / kPW64; ++r) {
+      const int k = wave + kPW64 * r;
+      const float mx = wave_reduce_dpp<true>(fmaxf(fmaxf(x[r].x, x[r].y), fmaxf(x[r].z, x[r].w)));
+      const float4 dl = make_float4(x[r].x - mx, x[r].y - mx, x[r].z - mx, x[r].w - mx);
+      const float part = on ? (__expf(dl.x) + __expf(dl.y)) + (__expf(dl.z) + __expf(dl.w)) : 0.f;
+      const float ls = __logf(wave_reduce_dpp<false>(part));
+      if (on) {
+        float4 o;
+        o.x = dl.x < -103.9f ? -INFINITY : dl.x - ls;
+        o.y = dl.y < -103.9f ? -INFINITY : dl.y - ls;
+        o.z = dl.z < -103.9f ? -INFINITY : dl.z - ls;
+        o.w = dl.w < -103.9f ? -INFINITY : dl.w - ls;
+        *reinterpret_cast<float4*>(tile + k * ld + 4 * lane) = o;
+      }
+    }
+  }
   __syncthreads();
-  {  // per-unit max and log-sum-exp over the categories, K / kPW64 units per wave, reduced together
+  if (!rows_form) {  // per-unit max and log-sum-exp over the categories, K / kPW64 units per wave, reduced together
     constexpr int R = K / kPW64;
     float mx[R], sum[R];
 #pragma unroll
@@ -783,8 +813,11 @@ __device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& 
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           const int k = 32 * q + 8 * g + 4 * kh + tt;
-          const float dlt = tile[k * ld + cl] - stat[k];
-          const float val = dlt < -103.9f ? -INFINITY : dlt - stat[K + k];
+          float val = tile[k * ld + cl];
+          if (!rows_form) {
+            const float dlt = val - stat[k];
+            val = dlt < -103.9f ? -INFINITY : dlt - stat[K + k];
+          }
           v[q][4 * g + tt] = c >= C ? 0.f : val;
           m = fmaxf(m, v[q][4 * g + tt]);
         }
