@@ -114,6 +114,14 @@ def other_configs(device, stream, B: int) -> dict:
     return out
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
 def _cpu_model() -> str:
     try:
         with open("/proc/cpuinfo", encoding="utf-8") as f:
@@ -200,8 +208,20 @@ def main() -> None:
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not run the three short rocprofv3 counter passes (roofline.traffic then comes from profiles/)")
+    ap.add_argument("--dist", action="store_true",
+                    help="take the distributed code path (process group + the async all-reduce of every step) even at world size 1")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as invoked by hand / by the driver: become the launcher -- one rank per GPU under
+        # torch.distributed.run on this node (rendezvous on 127.0.0.1), same arguments; rank 0 prints the JSON line
+        import subprocess
+
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import numpy as np
     import torch
@@ -215,22 +235,21 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(
-                f"--gpus {args.gpus} needs one process per GPU: launch with "
-                f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ..."
-            )
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
     # one process per GPU; BENCH_DIST_BACKEND=gloo lets the N > 1 path be exercised on a 1-GPU box
-    # (ranks then share the device; RCCL itself refuses two ranks on one GPU)
+    # (ranks then share the device; RCCL itself refuses two ranks on one GPU).  `--dist` (or BENCH_FORCE_DIST=1) takes
+    # the distributed code path -- process group, ring of async all-reduces, barriers, MAX over ranks -- at world size 1
+    # too: that is how RCCL itself is exercised on a 1-GPU box (tests/test_gpu_bench_distributed.py).
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    use_dist = world > 1 or args.dist or os.environ.get("BENCH_FORCE_DIST") == "1"
     device = torch.device(f"cuda:{local_rank % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
     ranks_seen = 1
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -271,7 +290,7 @@ def main() -> None:
         # N > 1: the 16-byte all-reduce of step k runs on RCCL's stream WHILE step k + 1 computes (its
         # input is copied out of the circuit's [sum, count] buffer, which the next step overwrites);
         # a ring of buffers, each reused only after its previous collective has completed
-        ring = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(8)] if world > 1 else []
+        ring = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(8)] if use_dist else []
         works: list = [None] * len(ring)
         count = [0]
         fed = [0]
@@ -279,7 +298,7 @@ def main() -> None:
         def step() -> None:
             ll = circ.log_likelihood_sum(xs[fed[0] % nb])  # forward + device-side sum, enqueued on `stream`
             fed[0] += 1
-            if world > 1:
+            if use_dist:
                 i = count[0] % len(ring)
                 count[0] += 1
                 if works[i] is not None:
@@ -301,7 +320,7 @@ def main() -> None:
             drain()
             for _ in range(rounds):
                 torch.cuda.synchronize(device)
-                if world > 1:
+                if use_dist:
                     dist.barrier()
                 torch.cuda.synchronize(device)
                 # ONE event pair around the K steps (an event record between steps costs a command-processor
@@ -314,11 +333,11 @@ def main() -> None:
                 drain()  # every collective of the timed steps has completed before the clock stops
                 e1.record(stream)
                 torch.cuda.synchronize(device)
-                if world > 1:
+                if use_dist:
                     dist.barrier()
                 torch.cuda.synchronize(device)
                 wall = time.perf_counter() - t0
-                if world > 1:
+                if use_dist:
                     t = torch.tensor([wall], dtype=torch.float64, device=device)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     wall = float(t.item())
@@ -347,6 +366,8 @@ def main() -> None:
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "steps_timed_total": len(walls) * args.steps,
+        "first_round_ms_per_step": 1e3 * walls[0] / args.steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -372,8 +393,9 @@ def main() -> None:
             "hip_event_ms_per_step_by_round": evms,
             "input_batches_rotated": nb, "input_bytes_resident": nb * B * plan.num_variables * 8,
         },
-        "distributed": {"backend": backend if world > 1 else None, "world_size": world,
-                        "ranks_seen_by_backend": ranks_seen},
+        "distributed": {"backend": backend if use_dist else None, "world_size": world,
+                        "ranks_seen_by_backend": ranks_seen,
+                        "all_reduce_per_step": bool(use_dist)},
         "check": {"mean_ll": total_nll / max(total_rows, 1.0), "rows": total_rows},
     }
 
@@ -564,7 +586,7 @@ def main() -> None:
             result["other_configs"] = other_configs(device, stream, B)
         print(json.dumps(result), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

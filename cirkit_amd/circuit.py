@@ -768,7 +768,7 @@ class HipCircuit:
 
     def _tail16_ok(self) -> bool:
         """The tail as ONE launch on 16-row tiles with its fold outputs kept in LDS (ck_tail16.hip): real weights in
-        row-major or tiled fp32 layout, at most 72 folds of 32 units."""
+        row-major or tiled fp32 layout, at most 64 folds (kTail16MaxFolds) of 32 units."""
         ls = [self.layers[j] for j in self._tail]
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
         return (self.tail16 and lay in (capi.CK_W_ROWMAJOR, capi.CK_W_TILED_F32) and len(ls) <= 15

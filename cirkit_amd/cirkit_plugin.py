@@ -2,7 +2,7 @@
 SUBCLASSES whose ``forward`` calls the C ABI, registered on a ``PipelineContext``::
 
     import cirkit_amd.cirkit_plugin as plugin
-    ctx = plugin.register(PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True))
+    ctx = plugin.HipLayersContext(semiring="lse-sum", fold=True, optimize=True)   # or plugin.register(existing_ctx)
     cc = ctx.compile(symbolic_circuit).to("cuda")      # every layer is a Hip* subclass of the reference's class
     cc(x)                                              # the reference's interpreter loop and gather, HIP layer kernels
 
@@ -23,10 +23,16 @@ calls -- `cirkit_amd.layer_ops` -- does not.  What it relies on in the reference
 Parameters stay the reference's ``TorchParameter`` graphs (evaluated by torch on the same device); the layer forward --
 the gather from the category table, the log-einsum-exp, the products -- is the HIP kernel.  Semirings: lse-sum and
 complex-lse-sum; anything else raises (no fallback to the stock forward).
+
+**Inference only.**  The layer forwards write into fresh buffers, so their results carry no ``grad_fn``:
+``loss = -cc(x).mean(); loss.backward()`` cannot train through them.  They therefore RAISE when gradients are enabled and
+an input or parameter requires them (`cirkit_amd.layer_ops._forward_only`) -- wrap evaluation in ``torch.no_grad()``.
+Training on the HIP path is `cirkit_amd.training.HipTrainer` (hand-written backward kernels over the plan, b4 level).
 """
 
 from __future__ import annotations
 
+import weakref
 from typing import Any
 
 import torch
@@ -41,13 +47,14 @@ from cirkit.backend.torch.layers.input import (
 )
 from cirkit.backend.torch.layers.optimized import TorchCPTLayer, TorchTensorDotLayer
 from cirkit.backend.torch.optimization.registry import LayerOptMatch
+from cirkit.pipeline import PipelineContext
 from cirkit.backend.torch.rules.layers import DEFAULT_LAYER_COMPILATION_RULES
 from cirkit.backend.torch.semiring import ComplexLSESumSemiring, LSESumSemiring
 
 from . import _capi as capi
 from . import layer_ops as ops
 
-__all__ = ["register", "to_hip_layer", "HIP_LAYER_CLASSES"]
+__all__ = ["register", "HipLayersContext", "to_hip_layer", "HIP_LAYER_CLASSES"]
 
 
 def _complex(layer: TorchLayer) -> bool:
@@ -183,12 +190,20 @@ def to_hip_layer(layer: TorchLayer) -> TorchLayer:
     return cls(semiring=layer.semiring, **kwargs)
 
 
+# Compilers whose layers are converted.  The reference hands its module-level DEFAULT_LAYER_COMPILATION_RULES dict to
+# every compiler's registry WITHOUT copying it (backend/registry.py:26-27, torch/compiler.py:118), so a rule added through
+# the public ``add_layer_compilation_rule`` is seen by every other context of the process: the rules below therefore act
+# as the reference's own rule unless the compiler that calls them was enabled here (no private registry state is touched).
+_ENABLED: "weakref.WeakSet" = weakref.WeakSet()
+
+
 def _layer_rule(default_rule):
-    """The reference's own compilation rule, followed by the conversion of its result."""
+    """The reference's own compilation rule, followed (for enabled compilers) by the conversion of its result."""
     ann = dict(default_rule.__annotations__)
 
     def rule(compiler, sl):
-        return to_hip_layer(default_rule(compiler, sl))
+        out = default_rule(compiler, sl)
+        return to_hip_layer(out) if compiler in _ENABLED else out
 
     rule.__annotations__ = ann
     rule._cirkit_amd = True
@@ -207,19 +222,13 @@ def _opt_rule(default_apply):
     return apply
 
 
-def register(ctx):
-    """Register the HIP layer rules on a ``PipelineContext`` (torch backend) and return it: every layer compilation
-    rule of the reference is replaced by one that returns the HIP subclass, and the apply functions of the "fuse" and
-    "shatter" optimisation registries are wrapped the same way."""
-    compiler = ctx._compiler
-    # the reference hands its module-level DEFAULT_LAYER_COMPILATION_RULES dict to the registry WITHOUT copying it
-    # (backend/registry.py:26-27, torch/compiler.py:118), so adding a rule would change every other context of the
-    # process: this context gets its own table first
-    registry = compiler._layers_registry
-    if registry._rules is DEFAULT_LAYER_COMPILATION_RULES:
-        registry._rules = dict(DEFAULT_LAYER_COMPILATION_RULES)
-    for signature in list(registry.signatures):
-        rule = registry.retrieve_rule(signature)
+def _enable(ctx, compiler) -> None:
+    """Public calls only: ``PipelineContext.add_layer_compilation_rule`` (pipeline.py:110-116) for every rule of the
+    public DEFAULT_LAYER_COMPILATION_RULES table, ``retrieve_layer_optimization_registry`` (torch/compiler.py:226-227)
+    + ``signatures`` / ``retrieve_rule`` / ``add_rule`` (backend/registry.py) for the "fuse" and "shatter" apply functions
+    (those registries are per-compiler copies in the reference)."""
+    _ENABLED.add(compiler)
+    for signature, rule in list(DEFAULT_LAYER_COMPILATION_RULES.items()):
         if not getattr(rule, "_cirkit_amd", False):
             ctx.add_layer_compilation_rule(_layer_rule(rule))
     for kind in ("fuse", "shatter"):
@@ -228,4 +237,27 @@ def register(ctx):
             apply = registry.retrieve_rule(pattern)
             if not getattr(apply, "_cirkit_amd", False):
                 registry.add_rule(_opt_rule(apply), signature=pattern)
+
+
+class HipLayersContext(PipelineContext):
+    """A ``PipelineContext`` (torch backend) whose compiled layers are the HIP subclasses -- the recommended entry point::
+
+        ctx = HipLayersContext(semiring="lse-sum", fold=True, optimize=True)
+        cc = ctx.compile(symbolic_circuit).to("cuda")
+
+    A subclass reaches its base's compiler the way the base itself does; nothing else of the reference's state is used."""
+
+    def __init__(self, backend: str = "torch", **backend_kwargs: Any) -> None:
+        if backend != "torch":
+            raise NotImplementedError("the HIP layers subclass the torch backend's layers")
+        super().__init__(backend=backend, **backend_kwargs)
+        _enable(self, self._compiler)
+
+
+def register(ctx):
+    """Enable the HIP layers on an EXISTING ``PipelineContext`` (torch backend) and return it: every layer compilation
+    rule of the reference is replaced by one that returns the HIP subclass, and the apply functions of the "fuse" and
+    "shatter" optimisation registries are wrapped the same way.  The context's compiler is the one attribute read that
+    ``PipelineContext`` does not expose through a method (`HipLayersContext` needs no such access)."""
+    _enable(ctx, getattr(ctx, "_compiler"))
     return ctx

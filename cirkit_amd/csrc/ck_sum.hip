@@ -588,7 +588,7 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
     if (mode == CK_SUM_CAT) nin = static_cast<int64_t>(H) * Ki;
     if (mode == CK_SUM_KRON) for (int h = 1; h < H; ++h) nin *= Ki;
     return ck::chunk_folds(F, [&](int f0, int n) {
-      return ck_sum_lse_fwd(arena, row_off + static_cast<int64_t>(f0) * H, w + f0 * Ko * nin, out + static_cast<int64_t>(f0) * B * Ko, n,
+      return ck_sum_lse_fwd(arena, row_off + static_cast<int64_t>(f0) * H, w + static_cast<int64_t>(f0) * Ko * nin, out + static_cast<int64_t>(f0) * B * Ko, n,
                             H, B, Ki, Ko, mode, w_layout, stream);
     });
   }
@@ -652,7 +652,7 @@ int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* 
     if (mode == CK_SUM_CAT) nin = static_cast<int64_t>(H) * Ki;
     if (mode == CK_SUM_KRON) for (int h = 1; h < H; ++h) nin *= Ki;
     return ck::chunk_folds(F, [&](int f0, int n) {
-      return ck_sum_lse_fwd_c(arena_c, row_off + static_cast<int64_t>(f0) * H, w + f0 * Ko * nin * (w_is_complex ? 2 : 1),
+      return ck_sum_lse_fwd_c(arena_c, row_off + static_cast<int64_t>(f0) * H, w + static_cast<int64_t>(f0) * Ko * nin * (w_is_complex ? 2 : 1),
                               out_c + static_cast<int64_t>(f0) * B * Ko * 2, n, H, B, Ki, Ko, mode, w_is_complex, stream);
     });
   }

@@ -25,6 +25,18 @@ def _on_device(t: torch.Tensor, what: str) -> None:
         raise capi.HipExtensionError(f"{what} is on {t.device}: the HIP layers evaluate on a ROCm device only (no CPU fallback)")
 
 
+def _forward_only(*tensors: torch.Tensor | None) -> None:
+    """The kernels behind these functions write into fresh buffers: their results carry no ``grad_fn``.  Under autograd
+    that would silently train nothing (or fail far from the cause), so asking for gradients here raises.  Training on
+    the HIP path is `cirkit_amd.training.HipTrainer` (hand-written backward kernels over the whole plan)."""
+    if any(t is not None and not t.is_cuda for t in tensors):
+        return  # (the device check of the caller raises first: no ROCm device, no forward at all)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise RuntimeError(
+            "the HIP layer forwards are inference-only (no autograd graph is recorded): call them under torch.no_grad(), "
+            "or train through cirkit_amd.training.HipTrainer")
+
+
 def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -44,6 +56,7 @@ def sum_lse(x: torch.Tensor, weight: torch.Tensor, mode: int = capi.CK_SUM_CAT) 
     """``TorchSumLayer.forward`` (inner.py:266-273, mode CK_SUM_CAT), ``TorchCPTLayer.forward`` (optimized.py:171-178,
     CK_SUM_PROD) and ``TorchTuckerLayer.forward`` (optimized.py:89-103, CK_SUM_KRON) under lse-sum / complex-lse-sum:
     x (F, H, B, Ki) log-space children, weight (F, Ko, N) linear-space -> (F, B, Ko)."""
+    _forward_only(x, weight)
     x, row_off, F, H, B, Ki = _children(x)
     if weight.dim() != 3 or weight.shape[0] != F:
         raise ValueError(f"expected a weight of shape (F={F}, Ko, N), found {tuple(weight.shape)}")
@@ -65,13 +78,16 @@ def sum_lse(x: torch.Tensor, weight: torch.Tensor, mode: int = capi.CK_SUM_CAT) 
             raise ValueError("complex weights under the real lse-sum semiring")
         w = weight.to(torch.float32).contiguous()
         out = torch.empty((F, B, Ko), dtype=torch.float32, device=x.device)
-        capi.call("ck_sum_lse_fwd", x.to(torch.float32).data_ptr() if x.dtype != torch.float32 else x.data_ptr(),
-                  row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, H, B, Ki, Ko, mode, capi.CK_W_ROWMAJOR, st)
+        xf = x if x.dtype == torch.float32 else x.to(torch.float32)  # (kept alive until the launch has been enqueued)
+        capi.call("ck_sum_lse_fwd", xf.data_ptr(), row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, H, B, Ki, Ko, mode,
+                  capi.CK_W_ROWMAJOR, st)
+        del xf
         return out
 
 
 def hadamard(x: torch.Tensor) -> torch.Tensor:
     """``TorchHadamardLayer.forward`` (inner.py:126-127) in log space: the sum over the arity axis."""
+    _forward_only(x)
     x, row_off, F, H, B, K = _children(x)
     out = torch.empty((F, B, K), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
@@ -82,6 +98,7 @@ def hadamard(x: torch.Tensor) -> torch.Tensor:
 
 def kronecker(x: torch.Tensor) -> torch.Tensor:
     """``TorchKroneckerLayer.forward`` (inner.py:178-187), any arity: (F, H, B, K) -> (F, B, K ** H)."""
+    _forward_only(x)
     x, row_off, F, H, B, K = _children(x)
     if H < 2:
         raise ValueError("The arity should be at least 2")
@@ -94,6 +111,7 @@ def kronecker(x: torch.Tensor) -> torch.Tensor:
 
 def tensordot_lse(x: torch.Tensor, weight: torch.Tensor, num_contract_units: int, num_batch_units: int) -> torch.Tensor:
     """``TorchTensorDotLayer.forward`` (optimized.py:287-300): x (F, 1, B, Kj * Kq), weight (F, Kk, Kj) -> (F, B, Kq * Kk)."""
+    _forward_only(x, weight)
     x, row_off, F, H, B, Ki = _children(x)
     Kj, Kq = int(num_contract_units), int(num_batch_units)
     if H != 1 or Ki != Kj * Kq or weight.shape[0] != F or weight.shape[2] != Kj:
@@ -123,8 +141,10 @@ def _discrete_input(x: torch.Tensor, num_states: int) -> torch.Tensor:
     if x.is_floating_point():
         x = x.long()  # input.py:400-401
     x = x.squeeze(dim=2)
-    if x.numel() and (int(x.min()) < -num_states or int(x.max()) >= num_states):
-        raise IndexError(f"index out of range for {num_states} states")
+    if x.numel():
+        lo, hi = torch.stack(torch.aminmax(x)).tolist()  # ONE host synchronisation for both bounds
+        if lo < -num_states or hi >= num_states:
+            raise IndexError(f"index out of range for {num_states} states")
     x = torch.where(x < 0, x + num_states, x)  # torch indexing wraps negative indices
     return x.to(torch.int32).contiguous()
 
@@ -132,6 +152,7 @@ def _discrete_input(x: torch.Tensor, num_states: int) -> torch.Tensor:
 def categorical_log_likelihood(x: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
     """``TorchCategoricalLayer.log_unnormalized_likelihood`` (input.py:399-412): x (F, B, 1) categories, logits (F, K, C)
     (``log(probs())`` or ``logits()``) -> (F, B, K)."""
+    _forward_only(logits)
     F, K, C = logits.shape
     xi = _discrete_input(x, C)
     B = xi.shape[1]
@@ -150,6 +171,7 @@ def categorical_log_likelihood(x: torch.Tensor, logits: torch.Tensor) -> torch.T
 def gaussian_log_likelihood(x: torch.Tensor, mean: torch.Tensor, stddev: torch.Tensor,
                             log_partition: torch.Tensor | None = None) -> torch.Tensor:
     """``TorchGaussianLayer.log_unnormalized_likelihood`` (input.py:661-670): x (F, B, 1), mean / stddev (F, K)."""
+    _forward_only(x, mean, stddev, log_partition)
     _on_device(x, "the layer input")
     if x.dim() != 3 or x.shape[2] != 1:
         raise ValueError(f"expected an input of shape (F, B, 1), found {tuple(x.shape)}")
@@ -169,6 +191,7 @@ def gaussian_log_likelihood(x: torch.Tensor, mean: torch.Tensor, stddev: torch.T
 def embedding(x: torch.Tensor, weight: torch.Tensor, *, complex_out: bool) -> torch.Tensor:
     """``TorchEmbeddingLayer.forward`` (input.py:258-266) mapped into lse-sum (log) / complex-lse-sum (complex log):
     x (F, B, 1) states, weight (F, K, C) real -> (F, B, K)."""
+    _forward_only(weight)
     F, K, C = weight.shape
     xi = _discrete_input(x, C)
     B = xi.shape[1]
@@ -185,6 +208,7 @@ def embedding(x: torch.Tensor, weight: torch.Tensor, *, complex_out: bool) -> to
 
 def constant_value(value: torch.Tensor, batch_size: int, *, log_space: bool, complex_out: bool) -> torch.Tensor:
     """``TorchConstantValueLayer.forward`` (input.py:739-743): value (F, K) broadcast over the batch."""
+    _forward_only(value)
     _on_device(value, "the value")
     F, K = value.shape
     v = value.contiguous()

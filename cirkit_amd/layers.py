@@ -366,6 +366,7 @@ class HipGaussianLayer(HipInputLayer):
             self._check_param("log_partition", log_partition, (num_output_units,))
         self.mean, self.stddev, self.log_partition = mean, stddev, log_partition
         self._vals: tuple | None = None
+        self._real_scratch: dict[tuple, torch.Tensor] = {}  # fp32 log-densities under complex-lse-sum (launch_input)
 
     @property
     def config(self) -> Mapping[str, Any]:
@@ -389,7 +390,14 @@ class HipGaussianLayer(HipInputLayer):
         mean, stddev, lz = self._vals
         real = out
         if self.is_complex:  # the real log-density, then its image in the complex semiring (input.py:276-278)
-            real = torch.empty(out.shape, dtype=torch.float32, device=out.device)
+            # The launches below may be RECORDED (ck_program) and replayed later: the scratch block has to outlive this
+            # call, so it belongs to the layer (one per output shape / device), never to the caching allocator.
+            key = (tuple(out.shape), str(out.device))
+            real = self._real_scratch.get(key)
+            if real is None:
+                if len(self._real_scratch) >= 8:  # (a circuit keeps at most 4 batch sizes bound, oldest evicted first)
+                    self._real_scratch.pop(next(iter(self._real_scratch)))
+                real = self._real_scratch[key] = torch.empty(out.shape, dtype=torch.float32, device=out.device)
         capi.call(
             "ck_gaussian_fwd", _ptr(mean), _ptr(stddev), _ptr(lz), _ptr(xt), _ptr(self._scope(xt.device)),
             _ptr(real), self.num_folds, B, self.num_output_units, D, stream,

@@ -337,7 +337,8 @@ class HipTrainer:
         """The one gradient exchange of data-parallel training: SUM over ranks of the flat buffer."""
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # (also at world size 1: the collective is then RCCL's identity, and the same call path is what a 1-GPU box can test)
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
 
     def apply_gradients(self) -> None:

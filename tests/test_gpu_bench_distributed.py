@@ -1,7 +1,14 @@
-"""`bench.py --gpus 2` launched exactly as the driver launches it (python -m torch.distributed.run, one process per rank),
-on ONE device with the gloo backend (RCCL refuses two ranks on one GPU; BENCH_DIST_BACKEND=gloo exists for this): the
-N > 1 path of the benchmark -- per-rank seeds, the ring of asynchronous all-reduces of the [sum, count] pair, max-over-ranks
-timing, rank 0 printing ONE JSON line -- must report the global batch and the sum over ranks."""
+"""The N > 1 path of `bench.py` on a 1-GPU box.
+
+* `bench.py --gpus 2` launched exactly as the driver launches it (python -m torch.distributed.run, one process per rank)
+  AND as a plain `python bench.py --gpus 2` (bench.py then becomes the launcher itself), on ONE device with the gloo backend
+  (RCCL refuses two ranks on one GPU; BENCH_DIST_BACKEND=gloo exists for this): per-rank seeds, the ring of asynchronous
+  all-reduces of the [sum, count] pair, max-over-ranks timing, rank 0 printing ONE JSON line -- must report the global
+  batch and the sum over ranks.
+* RCCL itself at world size 1 (`bench.py --gpus 1 --dist`, backend "nccl" = librccl): the same code path -- process group
+  bound to the device, ring buffers, `copy_`, `all_reduce(async_op=True)`, `work.wait()` on the launch stream, barriers,
+  MAX-reduce of the wall time -- and `HipTrainer.all_reduce_grads` through the library; results equal the
+  single-process ones bit for bit."""
 import json
 import os
 import subprocess
@@ -15,36 +22,123 @@ sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
 
+STEPS, WARMUP, ROUNDS, NB, B = 3, 1, 2, 2, 4096
+BENCH_ARGS = ["--steps", str(STEPS), "--warmup", str(WARMUP), "--rounds", str(ROUNDS), "--batches", str(NB), "--no-variants",
+              "--no-other-configs", "--no-cpu-baseline", "--no-kernel-breakdown", "--no-live-pmc"]
 
-def test_bench_two_ranks_gloo_on_one_device(hip_device):
+
+def _one_json_line(out) -> dict:
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
+    return json.loads(lines[0])
+
+
+def _expected_last_step(hip_device, world: int) -> torch.Tensor:
+    """[sum, count] over ranks of the LAST timed step, evaluated in this process from the per-rank seeds of bench.py."""
     from cirkit_amd.circuit import HipCircuit
     from cirkit_amd.initializers import init_plan_tensors
     from cirkit_amd.templates import image_data
 
-    steps, warmup, rounds, nb, B = 3, 1, 2, 2, 4096
-    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", str(warmup),
-           "--rounds", str(rounds), "--batches", str(nb), "--no-variants", "--no-other-configs", "--no-cpu-baseline",
-           "--no-kernel-breakdown", "--no-live-pmc"]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * B and d["scaling"] == "weak"
-    assert d["distributed"] == {"backend": "gloo", "world_size": 2, "ranks_seen_by_backend": 2}
-    assert d["check"]["rows"] == 2 * B
-    assert d["value"] > 0 and abs(d["value"] - 2 * B / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
-    # the reported mean LL is the all-reduced [sum, count] of the LAST step: the same batches evaluated in this process
     plan = image_data((1, 28, 28), region_graph="quad-tree-2", input_layer="categorical", num_input_units=32,
                       sum_product_layer="cp", num_sum_units=32)
     hc = HipCircuit(plan, init_plan_tensors(plan), device=hip_device)
-    last = (warmup + rounds * steps - 1) % nb
+    last = (WARMUP + ROUNDS * STEPS - 1) % NB
     tot = torch.zeros(2, dtype=torch.float64)
-    for rank in range(2):
+    for rank in range(world):
         g = torch.Generator().manual_seed(1234 + rank)
-        xs = [torch.randint(0, 256, (B, 784), generator=g) for _ in range(nb)]
+        xs = [torch.randint(0, 256, (B, 784), generator=g) for _ in range(NB)]
         tot += hc.log_likelihood_sum(xs[last].to(hip_device)).cpu()
+    return tot
+
+
+def _check_two_ranks(d: dict, hip_device) -> None:
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * B and d["scaling"] == "weak"
+    assert d["distributed"] == {"backend": "gloo", "world_size": 2, "ranks_seen_by_backend": 2, "all_reduce_per_step": True}
+    assert d["check"]["rows"] == 2 * B
+    assert d["steps_timed_total"] == ROUNDS * STEPS
+    assert d["value"] > 0 and abs(d["value"] - 2 * B / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    # the reported mean LL is the all-reduced [sum, count] of the LAST step: the same batches evaluated in this process
+    tot = _expected_last_step(hip_device, 2)
     assert tot[1].item() == 2 * B
     assert abs(d["check"]["mean_ll"] - tot[0].item() / tot[1].item()) <= 1e-9 * abs(tot[0].item() / tot[1].item())
+
+
+def test_bench_two_ranks_gloo_on_one_device(hip_device):
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", *BENCH_ARGS]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    _check_two_ranks(_one_json_line(out), hip_device)
+
+
+def test_bench_launches_its_own_ranks(hip_device):
+    """`python bench.py --gpus 2` with no launcher around it and no WORLD_SIZE in the environment (how a user, and the
+    driver's 1-GPU invocation, call it): bench.py re-executes itself under torch.distributed.run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", *BENCH_ARGS]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    _check_two_ranks(_one_json_line(out), hip_device)
+
+
+def test_bench_runs_rccl_at_world_size_one(hip_device):
+    """The distributed path of bench.py through librccl (backend "nccl") with ONE rank: every collective of the N > 1 path
+    is executed by RCCL; the numbers are those of a single process."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "BENCH_DIST_BACKEND")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist", *BENCH_ARGS]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    d = _one_json_line(out)
+    assert d["distributed"] == {"backend": "nccl", "world_size": 1, "ranks_seen_by_backend": 1, "all_reduce_per_step": True}
+    assert d["n_gpus"] == 1 and d["check"]["rows"] == B
+    tot = _expected_last_step(hip_device, 1)
+    assert d["check"]["mean_ll"] == tot[0].item() / tot[1].item()  # bit for bit: SUM over one rank is the identity
+
+
+_TRAINER_SCRIPT = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cirkit_amd.initializers import init_plan_tensors
+from cirkit_amd.templates import image_data
+from cirkit_amd.training import HipTrainer
+
+use_dist = sys.argv[2] == "1"
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+if use_dist:
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    probe = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(probe)
+    assert probe.item() == 1.0 and dist.get_backend() == "nccl"
+plan = image_data((1, 8, 8), region_graph="quad-tree-2", input_layer="categorical", num_input_units=32,
+                  sum_product_layer="cp", num_sum_units=32)
+tr = HipTrainer(plan, init_plan_tensors(plan), device=dev, lr=0.01)
+g = torch.Generator().manual_seed(7)
+lls = []
+for _ in range(3):
+    x = torch.randint(0, 256, (256, 64), generator=g).to(dev)
+    lls.append(tr.step(x).cpu().tolist())
+torch.cuda.synchronize()
+h = float(sum(float(np.abs(v).sum()) for v in tr.parameters().values()))
+print("RESULT " + json.dumps({"lls": lls, "param_abs_sum": h, "dist": use_dist}))
+if use_dist:
+    dist.destroy_process_group()
+"""
+
+
+def test_trainer_gradient_all_reduce_through_rccl(hip_device, tmp_path):
+    """`HipTrainer.step` (forward, backward, `all_reduce_grads`, optimizer) with a one-rank RCCL process group against the
+    same three steps without any process group: identical log-likelihoods and parameters."""
+    script = tmp_path / "rccl_trainer.py"
+    script.write_text(_TRAINER_SCRIPT)
+    res = []
+    for flag in ("1", "0"):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+        out = subprocess.run([sys.executable, str(script), ROOT, flag], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res.append(json.loads(next(l for l in out.stdout.splitlines() if l.startswith("RESULT "))[7:]))
+    assert res[0]["dist"] and not res[1]["dist"]
+    assert res[0]["lls"] == res[1]["lls"] and res[0]["param_abs_sum"] == res[1]["param_abs_sum"]
