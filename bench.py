@@ -385,7 +385,8 @@ def main() -> None:
             "contraction": args.contraction,
             "dense_on_table": circuit.dense_on_table,
             "params_recomputed_every_step": True,
-            "launches_per_step": int(circuit.num_launches_ll(B)),
+            "launches_per_step": int(circuit.num_launches_ll(B)),  # incl. the staging launch of the batch, if any
+            "leaf_reads_raw_batch": bool(circuit.reads_batch_directly(B)),
         },
         "timing": {
             "rounds": len(walls), "steps_per_round": args.steps, "reported": "median round",

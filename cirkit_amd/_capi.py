@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -43,6 +43,52 @@ class SoftmaxJob(C.Structure):
     ]
 
 
+class LeafLaunch(C.Structure):
+    """ck_leaf_launch of include/cirkit_hip.h."""
+
+    _fields_ = [
+        ("table", C.c_void_p),
+        ("table_scale", C.c_void_p),
+        ("xt", C.c_void_p),
+        ("scope", C.c_void_p),
+        ("w_levels", C.POINTER(C.c_void_p)),
+        ("nodes", C.c_void_p),
+        ("node_off", C.POINTER(C.c_int32)),
+        ("leaf_off", C.c_int32),
+        ("n_seg", C.c_int32),
+        ("out", C.c_void_p),
+        ("work", C.c_void_p),
+        ("n_wg", C.c_int32), ("waves", C.c_int32), ("depth", C.c_int32), ("B", C.c_int32), ("K", C.c_int32),
+        ("C", C.c_int32), ("preclamped", C.c_int32), ("w_layout", C.c_int32),
+        ("signed_redo", C.c_void_p),
+        ("n_roots", C.c_int32),
+        ("x_input", C.c_int32),
+        ("x_rows", C.c_void_p),
+        ("D", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Tail16Launch(C.Structure):
+    """ck_tail16_launch of include/cirkit_hip.h."""
+
+    _fields_ = [
+        ("folds", C.c_void_p),
+        ("level_begin", C.c_void_p),
+        ("n_folds", C.c_int32), ("n_levels", C.c_int32), ("B", C.c_int32), ("K", C.c_int32), ("w_layout", C.c_int32),
+        ("signed_values", C.c_int32),
+        ("ll", C.c_void_p),
+        ("ll_partial", C.c_void_p),
+        ("ll_ticket", C.c_void_p),
+        ("bad_input", C.c_void_p),
+        ("x_rows", C.c_void_p),
+        ("num_states", C.c_void_p),
+        ("bad_flag", C.c_void_p),
+        ("D", C.c_int32),
+        ("x_input", C.c_int32),
+    ]
+
+
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
 SIGNATURES: dict[str, list[Any]] = {
     "ck_abi_version": [],
@@ -73,9 +119,11 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_tensordot_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_subtree_cat_cpt_fwd": [_p, _p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_leaf_persistent_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
+    "ck_leaf_walk_fwd": [C.POINTER(LeafLaunch), _p],
     "ck_tail_lse_fwd": [_p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32),
                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _i, _p],
     "ck_tail16_lse_fwd": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p],
+    "ck_tail16_walk_fwd": [C.POINTER(Tail16Launch), _p],
     "ck_param_softmax": [_p, _p, _l, _i, _l, _i, _p],
     "ck_param_softmax_batch": [C.POINTER(SoftmaxJob), _i, _p],
     "ck_param_unary": [_i, _p, _p, _l, _f, _f, _p],
@@ -108,6 +156,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_program_end": [_p],
     "ck_program_num_ops": [_p],
     "ck_program_launch": [_p, _i, _p],
+    "ck_program_set_input": [_p, _i, _p],
     "ck_set_workspace": [_p, _l],
     "ck_program_destroy": [_p],
 }

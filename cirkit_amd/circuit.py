@@ -54,6 +54,8 @@ class _Binding:
         self.program_ll = None  # the same followed by ck_ll_sum
         self.store_version = -1
         self.ll: torch.Tensor | None = None
+        self.direct = False  # the leaf launches read the caller's int64 batch themselves (no staged copy of it)
+        self.x_last: torch.Tensor | None = None  # ... the batch of the last call (kept alive; read by eager launches)
 
     def destroy(self) -> None:
         for name in ("program", "program_ll"):
@@ -108,6 +110,10 @@ class HipCircuit:
             the outputs NaN and `check_inputs()` raise.  Negative values are this library's "marginalised" sentinel.
         tail16: the fused tail on 16-row tiles with its fold outputs kept in LDS and `log_likelihood_sum`'s reduction
             folded in (cirkit_amd/csrc/ck_tail16.hip); False keeps the 32-row walk of ck_tail.hip.
+        direct_input: when the persistent leaf launches are the only readers of a discrete batch, they read the caller's
+            ``(B, D)`` int64 tensor themselves (`ck_leaf_walk_fwd` with a program input) and the tail launch validates it
+            (`ck_tail16_walk_fwd`): no staging launch, no staged copy.  An out-of-range category then makes the outputs of
+            ITS ROW NaN (and `check_inputs()` raise) instead of the whole batch's.  False always stages the batch.
     """
 
     def __init__(
@@ -133,6 +139,7 @@ class HipCircuit:
         leaf_waves: int = 8,
         tail16: bool = True,
         validate_inputs: bool = True,
+        direct_input: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -177,6 +184,8 @@ class HipCircuit:
         self.leaf_waves = int(leaf_waves)
         self.tail16 = bool(tail16)
         self.validate_inputs = bool(validate_inputs)
+        self.direct_input = bool(direct_input)
+        self._recording = False
         self._num_states: torch.Tensor | None = None
         self._states_consistent = True
         self._bad_input = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -464,20 +473,57 @@ class HipCircuit:
             bd.leftover[d] = (bd.row_off[d][torch.from_numpy(folds).to(self.device)].contiguous(),
                               torch.from_numpy(bases[d] + folds * (B * K)).to(self.device))
         bd.ll = torch.empty(2, dtype=torch.float64, device=self.device)
+        bd.direct = self._direct_input(B)
         bd.program = self._record(bd, with_ll=False)  # the launch list, recorded once
+        if bd.direct and self.use_graph and capi.load().ck_program_num_ops(bd.program) > self.graph_min_launches:
+            # a hipGraph keeps the pointers of its capture: long launch lists read the staged copy of the batch
+            capi.load().ck_program_destroy(bd.program)
+            bd.direct = False
+            bd.program = self._record(bd, with_ll=False)
         self._bindings[B] = bd
         return bd
+
+    def _block_gathers(self, slot_dense: np.ndarray) -> bool:
+        """Some slot of a CP block / region reads a dense layer tabulated over its categories (a staged-batch consumer)."""
+        return any(int(d) in self._tdense for d in np.unique(slot_dense[..., 0]) if d >= 0)
+
+    def _direct_input(self, B: int) -> bool:
+        """Whether a forward at batch size B needs no staged copy of the discrete batch: its only readers are persistent
+        leaf launches, which then read the caller's int64 tensor (low dwords), and the 16-row tail launch validates the
+        full values of its rows (`ck_tail16_walk_fwd`).  Byte offsets into the batch are 32-bit."""
+        if not (self.direct_input and self._int_input and self._groups and self._tail and self._tail16_ok()):
+            return False
+        if self.leaf_waves != 8 or self.plan.num_variables * B * 8 >= 2**32:
+            return False
+        if self.validate_inputs and not self._poison_in_tail():
+            return False
+        for i, l in enumerate(self.layers):
+            if i in self._virtual or i in self._tail:
+                continue
+            if i in self._group_of_root:
+                if not (self._signed or self._leaf_is_persistent(self._group_of_root[i], B)):
+                    return False
+            elif i in self._tdense or i in self._emb_gather:
+                return False
+            elif i in self._cp_blocks and self._block_gathers(self._cp_blocks[i].slot_dense):
+                return False
+            elif i in self._regions and self._block_gathers(self._regions[i].slot_dense):
+                return False
+            elif isinstance(l, HipInputLayer) and not isinstance(l, HipConstantValueLayer) and not l.wants_float_input:
+                return False
+        return True
 
     def _record(self, bd: _Binding, *, with_ll: bool):
         """Record one forward for this binding; `with_ll` appends the device-side log-likelihood sum
         so that `log_likelihood_sum` replays ONE graph."""
         prog = C.c_void_p()
         capi.call("ck_program_begin", C.byref(prog))
+        self._recording = True
         try:
             if not self.cache_params:
                 self._enqueue_params(0)
             self._enqueue_layers(bd, 0, with_ll=with_ll)
-            if self.validate_inputs and self._int_input and not self._poison_in_tail() and not self._complex:
+            if self.validate_inputs and self._int_input and not bd.direct and not self._poison_in_tail() and not self._complex:
                 for p, f in self._out_pairs:
                     v = bd.views[int(p)][int(f)]
                     capi.call("ck_poison_outputs", v.data_ptr(), v.numel(), self._bad_input.data_ptr(), 0)
@@ -485,8 +531,18 @@ class HipCircuit:
                 p, f = int(self._out_pairs[0, 0]), int(self._out_pairs[0, 1])
                 capi.call("ck_ll_sum", bd.views[p][f].data_ptr(), bd.B, 1, bd.ll.data_ptr(), 0)
         finally:
+            self._recording = False
             capi.call("ck_program_end", prog)
         return prog
+
+    def _raw_batch_args(self, bd: _Binding) -> tuple[int | None, int]:
+        """(x_rows, x_input) of a launch that reads the caller's batch: program input cell 0 while recording, the batch of
+        the last call for an eager launch (profiling)."""
+        if self._recording:
+            return None, 0
+        if bd.x_last is None:
+            raise RuntimeError("an eager launch over the raw batch needs a forward first")
+        return bd.x_last.data_ptr(), -1
 
     def _param_program(self):
         """`cache_params`: the parameter-only launch list, recorded once per set of tensor objects
@@ -831,12 +887,19 @@ class HipCircuit:
                     torch.zeros(1, dtype=torch.int32, device=self.device))
             desc_dev, levels_dev, n_folds, scratch, ticket = tabs
             fuse_ll = with_ll and self._tail_fuses_ll()
-            capi.call(
-                "ck_tail16_lse_fwd", desc_dev.data_ptr(), n_folds, levels_dev.data_ptr(), n, bd.B, 32, lay,
-                bd.ll.data_ptr() if fuse_ll else None, scratch.data_ptr() if fuse_ll else None,
-                ticket.data_ptr() if fuse_ll else None, self._bad_input.data_ptr() if self._poison_in_tail() else None,
-                1 if self._signed else 0, stream,
-            )
+            d = capi.Tail16Launch()
+            d.folds, d.n_folds, d.level_begin, d.n_levels = desc_dev.data_ptr(), n_folds, levels_dev.data_ptr(), n
+            d.B, d.K, d.w_layout, d.signed_values = bd.B, 32, lay, (1 if self._signed else 0)
+            d.ll = bd.ll.data_ptr() if fuse_ll else None
+            d.ll_partial = scratch.data_ptr() if fuse_ll else None
+            d.ll_ticket = ticket.data_ptr() if fuse_ll else None
+            d.bad_input, d.x_rows, d.x_input = None, None, -1
+            if bd.direct and self.validate_inputs:  # the leaf launches read low dwords only: this launch validates its rows
+                d.x_rows, d.x_input = self._raw_batch_args(bd)
+                d.num_states, d.bad_flag, d.D = self._num_states_dev().data_ptr(), self._bad_input.data_ptr(), self.plan.num_variables
+            elif not bd.direct and self._poison_in_tail():
+                d.bad_input = self._bad_input.data_ptr()
+            capi.call("ck_tail16_walk_fwd", C.byref(d), stream)
             return
         capi.call(
             "ck_tail_lse_fwd", bd.arena.data_ptr(), n,
@@ -901,12 +964,10 @@ class HipCircuit:
             if work is None:
                 work = bd.cp_tabs[(g.root, "leaf_work")] = torch.from_numpy(
                     leaf_segments(F_root, n_tiles, self._n_cu)).to(self.device)
-            capi.call(
-                "ck_leaf_persistent_fwd", table.data_ptr(), scale.data_ptr(), bd.xt_i.data_ptr(),
-                cat._scope(self.device).data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off, out.data_ptr(),
-                work.data_ptr(), int(work.shape[0]), self._n_cu, self.leaf_waves, g.depth, bd.B, cat.num_output_units,
-                cat.num_categories, 1 if self._preclamp() else 0, capi.CK_W_TILED_F32, None, F_root, stream,
-            )
+            self._leaf_walk(bd, table=table, scale=scale, scope=cat._scope(self.device), levels=levels, nodes=dev[0],
+                            node_off=node_off, leaf_off=g.leaf_off, out=out, work=work, depth=g.depth,
+                            K=cat.num_output_units, Cn=cat.num_categories, w_layout=capi.CK_W_TILED_F32, redo=None,
+                            n_roots=F_root, waves=self.leaf_waves, stream=stream)
             return
         capi.call(
             "ck_subtree_cat_cpt_fwd", table.data_ptr(), None if scale is None else scale.data_ptr(), bd.xt_i.data_ptr(),
@@ -934,12 +995,25 @@ class HipCircuit:
                 torch.from_numpy(leaf_segments(F_root, n_tiles, self._n_cu)).to(self.device),
                 torch.zeros(F_root * n_tiles, dtype=torch.int32, device=self.device))
         segs, redo = work
-        capi.call(
-            "ck_leaf_persistent_fwd", emb._table.data_ptr(), dev[1].data_ptr(), bd.xt_i.data_ptr(),
-            emb._scope(self.device).data_ptr(), levels, dev[0].data_ptr(), node_off, g.leaf_off, out.data_ptr(),
-            segs.data_ptr(), int(segs.shape[0]), self._n_cu, 8, g.depth, bd.B, emb.num_output_units,
-            emb.num_states, 1 if self._preclamp() else 0, self._group_layout(g), redo.data_ptr(), F_root, stream,
-        )
+        self._leaf_walk(bd, table=emb._table, scale=dev[1], scope=emb._scope(self.device), levels=levels, nodes=dev[0],
+                        node_off=node_off, leaf_off=g.leaf_off, out=out, work=segs, depth=g.depth, K=emb.num_output_units,
+                        Cn=emb.num_states, w_layout=self._group_layout(g), redo=redo, n_roots=F_root, waves=8, stream=stream)
+
+    def _leaf_walk(self, bd: _Binding, *, table, scale, scope, levels, nodes, node_off, leaf_off, out, work, depth, K, Cn,
+                   w_layout, redo, n_roots, waves, stream) -> None:
+        """`ck_leaf_walk_fwd`: the persistent leaf launch over the staged batch or -- `bd.direct` -- over the caller's."""
+        d = capi.LeafLaunch()
+        d.table, d.table_scale, d.scope = table.data_ptr(), scale.data_ptr(), scope.data_ptr()
+        d.w_levels, d.nodes, d.node_off, d.leaf_off = levels, nodes.data_ptr(), node_off, leaf_off
+        d.out, d.work, d.n_seg, d.n_wg, d.waves, d.depth = out.data_ptr(), work.data_ptr(), int(work.shape[0]), self._n_cu, waves, depth
+        d.B, d.K, d.C, d.w_layout = bd.B, K, Cn, w_layout
+        d.signed_redo, d.n_roots = (None if redo is None else redo.data_ptr()), n_roots
+        if bd.direct:
+            d.xt, d.preclamped, d.D = None, 0, self.plan.num_variables
+            d.x_rows, d.x_input = self._raw_batch_args(bd)
+        else:
+            d.xt, d.preclamped, d.x_rows, d.x_input = bd.xt_i.data_ptr(), (1 if self._preclamp() else 0), None, -1
+        capi.call("ck_leaf_walk_fwd", C.byref(d), stream)
 
     # -- evaluation ------------------------------------------------------------------------------
     def _prepare_input(self, x: torch.Tensor) -> tuple[torch.Tensor | None, torch.Tensor | None]:
@@ -1078,7 +1152,12 @@ class HipCircuit:
                 run.wait_stream(cur)
             stream = run.cuda_stream
             if self.plan.num_variables:
-                self._stage_input(bd, xf, xi, stream)
+                self._stage_input(bd, xf, None if bd.direct else xi, stream)
+            if bd.direct:  # the recorded leaf / tail launches read the pointer from input cell 0 at replay
+                if as_graph:
+                    raise RuntimeError("a binding that reads the raw batch cannot be replayed as a hipGraph")
+                bd.x_last = xi
+                capi.call("ck_program_set_input", prog, 0, xi.data_ptr())
             if refresh:
                 self._pprog_data_version = self.store.data_version
                 capi.call("ck_program_launch", pprog, 1 if p_graph else 0, stream)
@@ -1240,12 +1319,20 @@ class HipCircuit:
         ws = self._scratch()
         if ws is not None:  # (as `_enqueue_layers` does: the launches below are the ones a forward records)
             capi.call("ck_set_workspace", ws.data_ptr(), ws.numel() * 4)
+        stage_ms: list[float] = []
+        xf_xi = self._prepare_input(x) if self.plan.num_variables else (None, None)
         for it in range(iters + 1):
             evs = []
             try:  # keep the GPU busy while the host enqueues, so the events bracket GPU time only
                 torch.cuda._sleep(4_000_000)
             except Exception:  # pragma: no cover
                 pass
+            if self.plan.num_variables and not (bd.direct and xf_xi[0] is None):  # the staging launch(es) of a forward
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record(cur)
+                self._stage_input(bd, xf_xi[0], None if bd.direct else xf_xi[1], stream)
+                s1.record(cur)
+                stage_ms.append((s0, s1))
             for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
@@ -1307,6 +1394,10 @@ class HipCircuit:
         torch.cuda.synchronize(self.device)
         overhead = float(np.median([a.elapsed_time(b) for a, b in empty]))
         mean = np.maximum(np.mean(np.asarray(acc), axis=0) - overhead, 0.0)
+        if stage_ms:
+            ms = max(float(np.mean([a.elapsed_time(b) for a, b in stage_ms[1:]])) - overhead, 0.0)
+            rows.append({"layer": -1, "kernel": "stage_categories_kernel" if self._int_input else "transpose_kernel<float, float>",
+                         "ms": ms, "algorithmic_bytes": float(self.plan.num_variables * B * 8)})
         layer_bytes: dict[int, float] = {}
         layer_flops: dict[int, float] = {}
         moved = [0.0]  # flops of dense layers evaluated on their category tables by the prologue
@@ -1419,11 +1510,16 @@ class HipCircuit:
         return int(capi.load().ck_program_num_ops(self._bind(B).program))
 
     def num_launches_ll(self, B: int) -> int:
-        """Launches of one `log_likelihood_sum` step (without the staging of the batch)."""
+        """Launches of one `log_likelihood_sum` step: the recorded program plus the staging of the batch in front of it
+        (none when the leaf launches read the caller's batch, `direct_input`)."""
         bd = self._bind(B)
         if bd.program_ll is None:
             bd.program_ll = self._record(bd, with_ll=True)
-        return int(capi.load().ck_program_num_ops(bd.program_ll))
+        staging = 0 if bd.direct else int(self._float_input) + int(self._int_input)
+        return int(capi.load().ck_program_num_ops(bd.program_ll)) + (staging if self.plan.num_variables else 0)
+
+    def reads_batch_directly(self, B: int) -> bool:
+        return self._bind(B).direct
 
 
 class HipCircuitStreams:

@@ -26,6 +26,11 @@ struct Workspace {
   int64_t bytes;
 };
 Workspace workspace();
+// ck_runtime.hip: per-launch inputs of a recorded program (ck_program_set_input).  While a program is being recorded on
+// this thread, the address of its input cell `index` -- a recorded launch reads the pointer from it at every replay --
+// otherwise nullptr.
+constexpr int kProgramInputs = 4;
+const void* const* program_input_slot(int index);
 int num_cus();  // compute units of the current device (cached)
 
 // Folds ride on grid.y (<= 65535): a layer with more folds -- a 256 x 256 image has 65536 leaves -- is launched in chunks

@@ -45,9 +45,15 @@ struct LeafArgs {
   int preclamped;  // xt holds -1 .. C - 1 only
   int32_t* redo;   // SIGNED: (F_root, tiles) flags of the tiles to evaluate again in log space (leaf_signed_redo_kernel)
   int w_rowmajor;  // the level weights are row-major (F_l, 32, 32) matrices instead of CK_W_TILED_F32
+  // XRAW: the batch as the caller holds it, (B, D) int64 row-major -- no staging launch in front of this one
+  const int64_t* x64;
+  int D;
 };
 
-template <int D, int WAVES, bool SIGNED>
+// XRAW: the categories are read from the caller's (B, D) int64 batch directly (a.x64), one tile ahead; the staging launch
+// (25.7 MB read + 12.9 MB written + a launch boundary per forward at the north-star configuration) disappears.  A tile
+// reads 4 x 32 bytes of each of its 32 batch rows when the root covers a 4 x 4 pixel block (QuadTree): whole sectors.
+template <int D, int WAVES, bool SIGNED, bool XRAW>
 __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafArgs a) {
   constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2) ? 3 : 2;
   __shared__ __attribute__((aligned(16))) float w_lds[kNodes * 1024];  // subtree weights, in step order
@@ -94,11 +100,11 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     // per-root constants (scalar registers): variable row of xt and first table row of every leaf
     const int32_t* leaf_ids = a.nodes + a.leaf_off + t * kLeaves;
     const int32_t* fold0 = a.nodes + a.node_off[0] + t * kLeaves;
-    int64_t var_off[kLeaves];
+    int64_t var_off[kLeaves];  // element offset of the leaf's variable: row of xt, or column of the raw batch
     int32_t row_base[kLeaves];
 #pragma unroll
     for (int i = 0; i < kLeaves; ++i) {
-      var_off[i] = a.scope[leaf_ids[i]] * static_cast<int64_t>(a.B);
+      var_off[i] = XRAW ? a.scope[leaf_ids[i]] : a.scope[leaf_ids[i]] * static_cast<int64_t>(a.B);
       row_base[i] = fold0[i] * (a.C + 1);
     }
     // The tiles of a segment are dealt round-robin to the waves (wave w: tile_begin + w, + WAVES, ...), so a wave knows
@@ -107,27 +113,32 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     // last 2^(D-1)... contractions of a tile have no memory waits).  A tile therefore starts without the chain
     // batch values -> scales -> leaf rows (three dependent memory round trips) in front of it.
     auto batch_row = [&](int tile) { return min(tile * 32 + b_in, a.B - 1); };
-    auto load_x = [&](int tile, int32_t (&xv)[kLeaves]) {
+    // XRAW: the LOW dword of the int64 value at (row, variable) of the caller's batch.  Whether the full 64-bit value
+    // is a legal category is not decided here (that needs the high dword: twice the registers in flight): the tail
+    // launch validates the batch (ck_tail16_lse_fwd with x_rows) -- this walk only has to stay memory-safe.
+    using RawT = int32_t;
+    auto load_x = [&](int tile, RawT (&xv)[kLeaves]) {
       // (a uniform row pointer + a 32-bit lane offset: no 64-bit lane arithmetic per load)
-      uint32_t boff = static_cast<uint32_t>(batch_row(tile)) * 4u;
+      uint32_t boff = static_cast<uint32_t>(batch_row(tile)) * (XRAW ? static_cast<uint32_t>(a.D) * 8u : 4u);
       asm volatile("" : "+v"(boff));
 #pragma unroll
-      for (int i = 0; i < kLeaves; ++i)
-        xv[i] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.xt + var_off[i]) + boff);
-    };
-    // categories of a tile, two per register (C < 65536 is checked on the host): negative = marginalised -> the
-    // integral row C of the table
-    auto pack_categories = [&](const int32_t (&xv)[kLeaves], uint32_t (&cp)[kLeaves / 2]) {
-#pragma unroll
-      for (int j = 0; j < kLeaves / 2; ++j) {
-        if (a.preclamped) {  // values are -1 .. C - 1 (ck_stage_categories): -1 = 0xffffffff -> the integral row C (uniform branch)
-          const uint32_t uc = static_cast<uint32_t>(a.C);
-          cp[j] = min(static_cast<uint32_t>(xv[2 * j]), uc) | (min(static_cast<uint32_t>(xv[2 * j + 1]), uc) << 16);
-        } else {
-          const int c0 = xv[2 * j] < 0 ? a.C : min(xv[2 * j], a.C - 1), c1 = xv[2 * j + 1] < 0 ? a.C : min(xv[2 * j + 1], a.C - 1);
-          cp[j] = static_cast<uint32_t>(c0) | (static_cast<uint32_t>(c1) << 16);
-        }
+      for (int i = 0; i < kLeaves; ++i) {
+        if constexpr (XRAW) xv[i] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.x64 + var_off[i]) + boff);
+        else xv[i] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.xt + var_off[i]) + boff);
       }
+    };
+    // categories of a tile, two per register (C < 65535 is checked on the host): negative = marginalised -> the
+    // integral row C of the table
+    auto table_row = [&](RawT v) -> uint32_t {
+      const uint32_t uc = static_cast<uint32_t>(a.C);
+      // staged values are -1 .. C - 1 (ck_stage_categories with clamp); raw low dwords: anything.  -1 = 0xffffffff -> row C;
+      // an out-of-range category lands on row C too (memory-safe; the validating launch turns that row's result into NaN)
+      if (XRAW || a.preclamped) return min(static_cast<uint32_t>(v), uc);
+      return v < 0 ? uc : static_cast<uint32_t>(min(v, a.C - 1));
+    };
+    auto pack_categories = [&](const RawT (&xv)[kLeaves], uint32_t (&cp)[kLeaves / 2]) {
+#pragma unroll
+      for (int j = 0; j < kLeaves / 2; ++j) cp[j] = table_row(xv[2 * j]) | (table_row(xv[2 * j + 1]) << 16);
     };
     auto row_of = [&](const uint32_t (&cp)[kLeaves / 2], auto ic) -> int32_t {  // table row of leaf ic.value for batch row b_in
       constexpr int i = decltype(ic)::value;
@@ -166,16 +177,20 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     // linear range in a 64-bit mask (scalar registers) and evaluates them in log space AFTER its walk over the chunk.
     // Doing that inside the walk -- an out-of-line call with the whole walk state live -- cost the hot loop its
     // registers (256 + spills against 237; 79 -> 74.5 us at the north-star configuration).
-    int32_t xnext[kLeaves];        // batch values of the NEXT tile of this wave (requested one tile ahead)
-    uint32_t cat[kLeaves / 2];     // packed categories of the current tile
+    // Batch values are requested two tiles ahead and turned into packed table rows as soon as they have landed (the
+    // first wait of the next tile): `xraw` is live only from the last contractions of a tile -- when the sibling stack
+    // is empty -- to the first leaf of the next one.
+    RawT xraw[kLeaves];            // batch values of the tile AFTER the current one
+    uint32_t cat[kLeaves / 2];     // packed table rows of the current tile
+    uint32_t catnext[kLeaves / 2];  // ... of the next tile of this wave
     for (int chunk_begin = tile_begin; chunk_begin < tile_end; chunk_begin += 64 * WAVES) {
     const int chunk_end = min(tile_end, chunk_begin + 64 * WAVES);
     int tile = chunk_begin + wave;
     if (tile < chunk_end) {  // the first tile of the wave: the chain is paid once per chunk
-      load_x(tile, xnext);
-      pack_categories(xnext, cat);
+      load_x(tile, xraw);
+      pack_categories(xraw, cat);
       static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
-      load_x(min(tile + WAVES, chunk_end - 1), xnext);
+      load_x(min(tile + WAVES, chunk_end - 1), xraw);
     }
     if (chunk_begin == tile_begin) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the weights (and its first leaf rows) have landed
@@ -217,13 +232,14 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           cur[12 + e] = r3[e];
         }
         const float s_i = sld[i & 3];
+        if constexpr (i == 0) pack_categories(xraw, catnext);  // (everything requested before this tile has landed)
         if constexpr (i + kSlots < kLeaves) request(cat, std::integral_constant<int, i + kSlots>{});
         if constexpr (i + 1 == kLeaves) {
           // the gathers of this tile are over: request what the next tile starts with (see above)
           if (tile + WAVES < chunk_end) {
-            pack_categories(xnext, cat);
+#pragma unroll
+            for (int j = 0; j < kLeaves / 2; ++j) cat[j] = catnext[j];
             static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
-            load_x(min(tile + 2 * WAVES, chunk_end - 1), xnext);
           }
         }
         if constexpr ((i & 1) != 0) cs = s_i + sprev;  // log scale of the pair (i - 1, i)
@@ -246,6 +262,12 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           // v_pk_mul_f32 that follows an MFMA back into two multiplies)
           __builtin_amdgcn_sched_barrier(0);
           contract_linear<CK_W_TILED_F32>(wcur, cur);
+          // batch values of the tile after the next one: requested once half of the sibling stack has been consumed
+          if constexpr (i + 1 == kLeaves && l == (D >= 3 ? 1 : 0)) {
+            __builtin_amdgcn_sched_barrier(0);  // (not hoisted above the contraction: the stack registers are free only now)
+            if (tile + WAVES < chunk_end) load_x(min(tile + 2 * WAVES, chunk_end - 1), xraw);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         });
         if constexpr (steps_after(i) < D) {  // left sibling at this level: wait for the right one
           constexpr int l = steps_after(i);
@@ -338,71 +360,129 @@ __global__ void __launch_bounds__(64) leaf_signed_redo_kernel(const LeafArgs a) 
   if (lane == 0) *flag = 0;  // ready for the next replay
 }
 
-template <int D>
+template <int D, bool XRAW>
 hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_roots, dim3 grid, hipStream_t s) {
   if (is_signed) {
-    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true>), grid, dim3(512), 0, s, a);
+    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true, XRAW>), grid, dim3(512), 0, s, a);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     hipLaunchKernelGGL((leaf_signed_redo_kernel<D>), dim3((a.B + 31) / 32, n_roots), dim3(64), 0, s, a);
-  } else if (waves == 12)
-    hipLaunchKernelGGL((leaf_persistent_kernel<D, 12, false>), grid, dim3(768), 0, s, a);
-  else
-    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false>), grid, dim3(512), 0, s, a);
+  } else if (waves == 12) {
+    if constexpr (XRAW) return hipErrorInvalidValue;  // (checked by the caller: 12 waves read the staged batch only)
+    else hipLaunchKernelGGL((leaf_persistent_kernel<D, 12, false, false>), grid, dim3(768), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, XRAW>), grid, dim3(512), 0, s, a);
+  }
   return hipGetLastError();
+}
+
+template <bool XRAW>
+hipError_t launch_depth(const LeafArgs& a, int depth, int waves, bool is_signed, int n_roots, dim3 grid, hipStream_t s) {
+  switch (depth) {
+    case 1:
+      return launch_waves<1, XRAW>(a, waves, is_signed, n_roots, grid, s);
+    case 2:
+      return launch_waves<2, XRAW>(a, waves, is_signed, n_roots, grid, s);
+    case 3:
+      return launch_waves<3, XRAW>(a, waves, is_signed, n_roots, grid, s);
+    default:
+      return launch_waves<4, XRAW>(a, waves, is_signed, n_roots, grid, s);
+  }
 }
 
 }  // namespace
 
 extern "C" {
 
+int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
+  CK_REQUIRE(d != nullptr, "ck_leaf_walk_fwd: null descriptor");
+  const bool raw = d->x_rows != nullptr || d->x_input >= 0;
+  CK_REQUIRE(d->table && d->table_scale && d->scope && d->w_levels && d->nodes && d->node_off && d->out && d->work,
+             "ck_leaf_walk_fwd: null pointer");
+  CK_REQUIRE(raw != (d->xt != nullptr), "ck_leaf_walk_fwd: give either the staged batch xt or the raw batch (x_rows / x_input)");
+  CK_REQUIRE(d->depth >= 1 && d->depth <= kMaxDepthP, "ck_leaf_walk_fwd: depth %d outside [1, %d]", d->depth, kMaxDepthP);
+  CK_REQUIRE(d->n_seg > 0 && d->n_wg > 0 && d->B > 0 && d->C > 0, "ck_leaf_walk_fwd: non-positive size");
+  CK_REQUIRE(d->waves == 8 || d->waves == 12, "ck_leaf_walk_fwd: waves must be 8 or 12 (got %d)", d->waves);
+  if (d->K != kK) return ck::fail(CK_ERR_UNSUPPORTED, "ck_leaf_walk_fwd: K=%d (only K=32 is fused)", d->K);
+  CK_REQUIRE(ck::aligned16(d->table) && ck::aligned16(d->out), "ck_leaf_walk_fwd: buffers must be 16-byte aligned");
+  LeafArgs a{};
+  a.table = d->table;
+  a.scale = d->table_scale;
+  a.xt = d->xt;
+  a.scope = d->scope;
+  for (int l = 0; l < d->depth; ++l) {
+    CK_REQUIRE(d->w_levels[l] != nullptr && ck::aligned16(d->w_levels[l]), "ck_leaf_walk_fwd: bad weights of level %d", l + 1);
+    a.w[l] = d->w_levels[l];
+  }
+  a.nodes = d->nodes;
+  for (int l = 0; l <= d->depth; ++l) a.node_off[l] = d->node_off[l];
+  a.leaf_off = d->leaf_off;
+  a.out = d->out;
+  a.work = d->work;
+  a.n_seg = d->n_seg;
+  a.B = d->B;
+  a.C = d->C;
+  a.preclamped = d->preclamped;
+  CK_REQUIRE(d->w_layout == CK_W_TILED_F32 || d->w_layout == CK_W_ROWMAJOR, "ck_leaf_walk_fwd: weights must be CK_W_TILED_F32 or row-major");
+  CK_REQUIRE(d->signed_redo == nullptr || (d->n_roots > 0 && d->n_roots <= 65535), "ck_leaf_walk_fwd: signed launch needs 0 < n_roots <= 65535");
+  a.redo = d->signed_redo;
+  a.w_rowmajor = d->w_layout == CK_W_ROWMAJOR ? 1 : 0;
+  const void* const* slot = nullptr;
+  if (raw) {
+    CK_REQUIRE(d->waves == 8, "ck_leaf_walk_fwd: the raw batch is read by 8-wave workgroups only");
+    CK_REQUIRE(d->D > 0 && static_cast<int64_t>(d->B) * d->D * 8 < (int64_t{1} << 32),
+               "ck_leaf_walk_fwd: raw batch of B=%d x D=%d int64 values exceeds 32-bit byte offsets (stage it instead)", d->B, d->D);
+    CK_REQUIRE(d->C < 65535, "ck_leaf_walk_fwd: C=%d categories do not fit the packed rows", d->C);
+    a.D = d->D;
+    a.x64 = d->x_rows;
+    if (d->x_input >= 0) {
+      slot = ck::program_input_slot(d->x_input);
+      CK_REQUIRE(slot != nullptr, "ck_leaf_walk_fwd: x_input=%d names a program input, but no program is being recorded on this "
+                                  "thread (or the index is out of range)", d->x_input);
+    }
+  }
+  const int depth = d->depth, waves = d->waves, n_roots = d->n_roots;
+  const bool is_signed = d->signed_redo != nullptr;
+  dim3 grid(static_cast<unsigned>(std::min(d->n_wg, d->n_seg)));
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (!raw) return launch_depth<false>(a, depth, waves, is_signed, n_roots, grid, s);
+        LeafArgs b = a;
+        if (slot != nullptr) b.x64 = static_cast<const int64_t*>(*slot);  // the batch of THIS replay (ck_program_set_input)
+        if (b.x64 == nullptr) return hipErrorInvalidValue;
+        return launch_depth<true>(b, depth, waves, is_signed, n_roots, grid, s);
+      },
+      stream);
+}
+
 int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const int32_t* xt, const int64_t* scope,
                            const float* const* w_levels, const int32_t* nodes, const int32_t* node_off, int leaf_off,
                            float* out, const int32_t* work, int n_seg, int n_wg, int waves, int depth, int B, int K,
                            int C, int preclamped, int w_layout, int32_t* signed_redo, int n_roots, void* stream) {
-  CK_REQUIRE(table && table_scale && xt && scope && w_levels && nodes && node_off && out && work,
-             "ck_leaf_persistent_fwd: null pointer");
-  CK_REQUIRE(depth >= 1 && depth <= kMaxDepthP, "ck_leaf_persistent_fwd: depth %d outside [1, %d]", depth, kMaxDepthP);
-  CK_REQUIRE(n_seg > 0 && n_wg > 0 && B > 0 && C > 0, "ck_leaf_persistent_fwd: non-positive size");
-  CK_REQUIRE(waves == 8 || waves == 12, "ck_leaf_persistent_fwd: waves must be 8 or 12 (got %d)", waves);
-  if (K != kK) return ck::fail(CK_ERR_UNSUPPORTED, "ck_leaf_persistent_fwd: K=%d (only K=32 is fused)", K);
-  CK_REQUIRE(ck::aligned16(table) && ck::aligned16(out), "ck_leaf_persistent_fwd: buffers must be 16-byte aligned");
-  LeafArgs a{};
-  a.table = table;
-  a.scale = table_scale;
-  a.xt = xt;
-  a.scope = scope;
-  for (int l = 0; l < depth; ++l) {
-    CK_REQUIRE(w_levels[l] != nullptr && ck::aligned16(w_levels[l]), "ck_leaf_persistent_fwd: bad weights of level %d", l + 1);
-    a.w[l] = w_levels[l];
-  }
-  a.nodes = nodes;
-  for (int l = 0; l <= depth; ++l) a.node_off[l] = node_off[l];
-  a.leaf_off = leaf_off;
-  a.out = out;
-  a.work = work;
-  a.n_seg = n_seg;
-  a.B = B;
-  a.C = C;
-  a.preclamped = preclamped;
-  CK_REQUIRE(w_layout == CK_W_TILED_F32 || w_layout == CK_W_ROWMAJOR, "ck_leaf_persistent_fwd: weights must be CK_W_TILED_F32 or row-major");
-  CK_REQUIRE(signed_redo == nullptr || (n_roots > 0 && n_roots <= 65535), "ck_leaf_persistent_fwd: signed launch needs 0 < n_roots <= 65535");
-  a.redo = signed_redo;
-  a.w_rowmajor = w_layout == CK_W_ROWMAJOR ? 1 : 0;
-  dim3 grid(static_cast<unsigned>(std::min(n_wg, n_seg)));
-  return ck::dispatch(
-      [=](hipStream_t s) {
-        switch (depth) {
-          case 1:
-            return launch_waves<1>(a, waves, signed_redo != nullptr, n_roots, grid, s);
-          case 2:
-            return launch_waves<2>(a, waves, signed_redo != nullptr, n_roots, grid, s);
-          case 3:
-            return launch_waves<3>(a, waves, signed_redo != nullptr, n_roots, grid, s);
-          default:
-            return launch_waves<4>(a, waves, signed_redo != nullptr, n_roots, grid, s);
-        }
-      },
-      stream);
+  ck_leaf_launch d{};
+  d.table = table;
+  d.table_scale = table_scale;
+  d.xt = xt;
+  d.scope = scope;
+  d.w_levels = w_levels;
+  d.nodes = nodes;
+  d.node_off = node_off;
+  d.leaf_off = leaf_off;
+  d.out = out;
+  d.work = work;
+  d.n_seg = n_seg;
+  d.n_wg = n_wg;
+  d.waves = waves;
+  d.depth = depth;
+  d.B = B;
+  d.K = K;
+  d.C = C;
+  d.preclamped = preclamped;
+  d.w_layout = w_layout;
+  d.signed_redo = signed_redo;
+  d.n_roots = n_roots;
+  d.x_rows = nullptr;
+  d.x_input = -1;
+  return ck_leaf_walk_fwd(&d, stream);
 }
 
 }  // extern "C"

@@ -14,6 +14,7 @@ thread_local ck_program* g_recording = nullptr;
 
 struct ck_program {
   std::vector<ck::Launch> ops;
+  const void* inputs[ck::kProgramInputs] = {nullptr, nullptr, nullptr, nullptr};  // ck_program_set_input
   bool finished = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -41,6 +42,13 @@ int dispatch(Launch fn, void* stream) {
 
 }  // namespace ck
 
+namespace ck {
+const void* const* program_input_slot(int index) {
+  if (g_recording == nullptr || index < 0 || index >= kProgramInputs) return nullptr;
+  return &g_recording->inputs[index];  // (a program lives on the heap until ck_program_destroy: the address is stable)
+}
+}  // namespace ck
+
 namespace {
 thread_local ck::Workspace g_workspace{nullptr, 0};
 }
@@ -62,7 +70,7 @@ extern "C" {
 
 const char* ck_last_error(void) { return g_err; }
 
-int ck_abi_version(void) { return 26; }
+int ck_abi_version(void) { return 27; }
 
 int ck_device_info(int device, int64_t out[4]) {
   if (out == nullptr) return ck::fail(CK_ERR_INVALID, "ck_device_info: out is null");
@@ -95,6 +103,13 @@ int ck_program_end(ck_program* prog) {
   if (prog == nullptr || g_recording != prog) return ck::fail(CK_ERR_STATE, "ck_program_end: not the recording program");
   g_recording = nullptr;
   prog->finished = true;
+  return CK_OK;
+}
+
+int ck_program_set_input(ck_program* prog, int index, const void* ptr) {
+  if (prog == nullptr || index < 0 || index >= ck::kProgramInputs)
+    return ck::fail(CK_ERR_INVALID, "ck_program_set_input: null program or index %d outside [0, %d)", index, ck::kProgramInputs);
+  prog->inputs[index] = ptr;
   return CK_OK;
 }
 

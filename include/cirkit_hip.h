@@ -279,6 +279,43 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
                            float* out, const int32_t* work, int n_seg, int n_wg, int waves, int depth, int B, int K,
                            int C, int preclamped, int w_layout, int32_t* signed_redo, int n_roots, void* stream);
 
+/* ck_leaf_persistent_fwd with its arguments in a descriptor (every field as the parameter of the same name there; plain
+ * pointers and sizes, the two marked arrays are HOST arrays read during the call), plus what the positional form cannot
+ * express:
+ *
+ *  Raw input (x_rows != NULL or x_input >= 0; xt must then be NULL; 8 waves): the launch reads the categories from the
+ *  caller's (B, D) int64 batch itself -- what TorchCategoricalLayer.log_unnormalized_likelihood indexes with
+ *  (layers/input.py:399-412: `x.long()`) -- no staged copy, no ck_stage_categories launch in front.  Only the low dword
+ *  of a value is looked at here: u = (uint32_t) x selects table row min(u, C), i.e. a negative value selects the integral
+ *  row C (this library's marginalisation sentinel, cirkit/backend/torch/queries.py:19-184) and so does anything else that
+ *  is not a category (memory-safe, not meaningful).  VALIDATION is the job of the launch that consumes the roots:
+ *  ck_tail16_lse_fwd with x_rows checks the full 64-bit values of its rows and turns the results of rows holding a value
+ *  >= C -- an IndexError in the reference -- into NaN.  B * D * 8 must be below 2^32.
+ *  x_input >= 0: the call is being RECORDED into a ck_program and the batch pointer is read, at every replay, from that
+ *  program's input cell x_input (ck_program_set_input) -- a recorded forward then follows the caller's batch without a
+ *  copy.  Not usable with use_graph != 0 launches (a hipGraph keeps the pointer of its capture). */
+typedef struct ck_leaf_launch {
+  const float* table;
+  const float* table_scale;
+  const int32_t* xt;             /* staged (Dvars, B) int32 batch, or NULL (raw input) */
+  const int64_t* scope;
+  const float* const* w_levels;  /* HOST array of `depth` device pointers */
+  const int32_t* nodes;
+  const int32_t* node_off;       /* HOST array of depth + 1 offsets */
+  int32_t leaf_off;
+  int32_t n_seg;
+  float* out;
+  const int32_t* work;
+  int32_t n_wg, waves, depth, B, K, C, preclamped, w_layout;
+  int32_t* signed_redo;
+  int32_t n_roots;
+  int32_t x_input;               /* -1, or the program input cell holding the raw batch pointer */
+  const int64_t* x_rows;         /* raw (B, D) int64 batch, or NULL */
+  int32_t D;                     /* variables per row of the raw batch */
+  int32_t reserved;
+} ck_leaf_launch;
+int ck_leaf_walk_fwd(const ck_leaf_launch* desc, void* stream);
+
 /* The last `n_layers` levels of a circuit (few folds each) in one launch: one workgroup per 32-row
  * batch tile walks the layers in order, a workgroup barrier between levels.  Layer i is a
  * TorchCPTLayer / dense TorchSumLayer step over the product of its H[i] children (CK_SUM_PROD
@@ -314,6 +351,30 @@ typedef struct ck_tail16_fold {
 int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* level_begin, int n_levels, int B, int K,
                       int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, const int32_t* bad_input,
                       int signed_values, void* stream);
+/* ck_tail16_lse_fwd with its arguments in a descriptor (fields as the parameters of the same name), plus VALIDATION OF THE
+ * RAW BATCH for circuits whose leaf launch read it directly (ck_leaf_walk_fwd with x_rows / x_input, which looks at low
+ * dwords only): with x_rows != NULL (or x_input >= 0: read at every replay from that input cell of the program being
+ * recorded, ck_program_set_input) every workgroup checks the full 64-bit values x[b, d] of its 16 rows against
+ * num_states[d] (DEVICE (D) int32; 0 = variable not checked) while its fold descriptors travel to LDS.  A row holding a
+ * value >= num_states[d] -- TorchCategoricalLayer / TorchEmbeddingLayer raise IndexError there (layers/input.py:258-266,
+ * 399-412) -- or below -2^31 gets NaN for every few-unit output of the tail (the circuit's outputs) and *bad_flag (if not
+ * NULL) is raised; other rows, and later launches, are unaffected.  Negative values down to -2^31 are this library's
+ * marginalisation sentinel. */
+typedef struct ck_tail16_launch {
+  const ck_tail16_fold* folds;
+  const int32_t* level_begin;
+  int32_t n_folds, n_levels, B, K, w_layout, signed_values;
+  double* ll;
+  double* ll_partial;
+  uint32_t* ll_ticket;
+  const int32_t* bad_input;
+  const int64_t* x_rows;      /* raw (B, D) int64 batch to validate, or NULL */
+  const int32_t* num_states;  /* (D) */
+  int32_t* bad_flag;
+  int32_t D;
+  int32_t x_input;            /* -1, or the program input cell holding the raw batch pointer */
+} ck_tail16_launch;
+int ck_tail16_walk_fwd(const ck_tail16_launch* desc, void* stream);
 
 /* ---------------------------------------------------------------- parameter graphs --------- */
 /* The reference re-evaluates each layer's parameter DAG on every forward
@@ -455,6 +516,11 @@ int ck_program_begin(ck_program** out);
 int ck_program_end(ck_program* prog);
 int ck_program_num_ops(const ck_program* prog);
 int ck_program_launch(ck_program* prog, int use_graph, void* stream);
+/* Per-launch inputs: a program has 4 input cells; a call recorded with a program-input index (ck_leaf_walk_fwd's x_input)
+ * reads the pointer stored in that cell at every eager replay.  Set them before ck_program_launch; the memory must stay
+ * valid until the replayed launches have run (stream order).  This is what lets the recorded forward -- the replacement
+ * of TorchCircuit.forward(x), circuits.py:242-278 -- take a different batch per call without staging it. */
+int ck_program_set_input(ck_program* prog, int index, const void* ptr);
 
 /* Lend a device scratch buffer to the launches this THREAD issues or records from now on (NULL, 0: take it back).  It
  * must be ZERO when lent; the part that has to stay zero (ticket counters behind the first CUs x 3 x (32 KiB + 512 B)) is zero

@@ -130,7 +130,7 @@ if use_dist:
 
 def test_trainer_gradient_all_reduce_through_rccl(hip_device, tmp_path):
     """`HipTrainer.step` (forward, backward, `all_reduce_grads`, optimizer) with a one-rank RCCL process group against the
-    same three steps without any process group: identical log-likelihoods and parameters."""
+    same three steps without any process group: the same log-likelihoods and parameters."""
     script = tmp_path / "rccl_trainer.py"
     script.write_text(_TRAINER_SCRIPT)
     res = []
@@ -141,4 +141,9 @@ def test_trainer_gradient_all_reduce_through_rccl(hip_device, tmp_path):
         assert out.returncode == 0, out.stderr[-3000:]
         res.append(json.loads(next(l for l in out.stdout.splitlines() if l.startswith("RESULT "))[7:]))
     assert res[0]["dist"] and not res[1]["dist"]
-    assert res[0]["lls"] == res[1]["lls"] and res[0]["param_abs_sum"] == res[1]["param_abs_sum"]
+    # (the backward accumulates weight gradients with float atomics across batch tiles: two runs of the same three steps
+    # agree to rounding, not bit for bit -- with or without a process group; the first step's LL precedes any update)
+    assert res[0]["lls"][0] == res[1]["lls"][0]
+    for a, b in zip(res[0]["lls"], res[1]["lls"]):
+        assert a[1] == b[1] and abs(a[0] - b[0]) <= 1e-6 * abs(b[0])
+    assert abs(res[0]["param_abs_sum"] - res[1]["param_abs_sum"]) <= 1e-6 * res[1]["param_abs_sum"]

@@ -549,17 +549,81 @@ def test_tail_on_16_row_tiles(hip_device, B):
     assert abs(sa[0].item() - s1[0].item()) <= 1e-6 * abs(s1[0].item())
 
 
+@pytest.mark.parametrize("B", [1, 33, 1000, 4096])
+def test_leaf_launch_reads_the_raw_batch(hip_device, B):
+    """`direct_input` (default): when persistent leaf launches are the only readers of the discrete batch they read the
+    caller's (B, D) int64 tensor themselves and no staged copy is made (`ck_leaf_walk_fwd` with a program input; the
+    batch pointer of each call reaches the recorded launches through `ck_program_set_input`).  Same table rows, same
+    arithmetic: bit-identical to the staged path -- ragged batches, marginalised entries, a different tensor per call,
+    `forward` and `log_likelihood_sum`."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    a = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True, direct_input=False)
+    b = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True)
+    assert b.reads_batch_directly(B) and not a.reads_batch_directly(B)
+    assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1  # no staging launch
+    for seed in range(3):  # three different tensors through the same recorded program
+        x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(100 * B + seed))
+        x[::3, ::5] = -1
+        x[::7, 1::9] = -(2**31)  # the most negative sentinel the low dword still carries
+        x = x.to(hip_device)
+        ya, yb = a(x).clone(), b(x).clone()
+        assert torch.equal(ya, yb)
+        assert torch.equal(a.log_likelihood_sum(x), b.log_likelihood_sum(x))
+        del x  # (the circuit keeps the batch of its last call alive)
+    b.check_inputs()
+    assert not b.reads_batch_directly(B) or b._bindings[B].x_last is not None
+
+
+def test_raw_batch_is_validated_row_by_row(hip_device):
+    """The leaf launches look at low dwords only; the tail launch checks the full 64-bit values of its 16 rows
+    (`ck_tail16_walk_fwd`): a row holding a category >= num_categories (an IndexError in the reference, input.py:399-412),
+    a value whose LOW DWORD alone would pass for a category (2^32 + 5), or a value below -2^31 comes out NaN and
+    `check_inputs()` raises once; every other row of the batch equals the clean evaluation, later batches are unaffected."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    B = 200
+    hc = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True)
+    assert hc.reads_batch_directly(B)
+    x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(3))
+    x[5, 7] = -1
+    good = hc(x.to(hip_device)).clone().reshape(-1)
+    hc.check_inputs()
+    assert bool(torch.isfinite(good).all())
+    bad = x.clone()
+    bad[3, 5] = 256            # first value past the table
+    bad[40, 783] = 2**32 + 5   # low dword 5
+    bad[41, 0] = -(2**31) - 1  # low dword 0x7fffffff
+    bad[199, 300] = 2**40
+    y = hc(bad.to(hip_device)).clone().reshape(-1)
+    rows = torch.zeros(B, dtype=torch.bool)
+    rows[[3, 40, 41, 199]] = True
+    assert torch.equal(torch.isnan(y).cpu(), rows)
+    assert torch.equal(y[~rows.to(hip_device)], good[~rows.to(hip_device)])
+    assert bool(torch.isnan(hc.log_likelihood_sum(bad.to(hip_device))[0]))
+    assert torch.equal(hc(x.to(hip_device)).reshape(-1), good)  # not sticky: the next batch is evaluated normally
+    with pytest.raises(IndexError):
+        hc.check_inputs()
+    hc.check_inputs()  # cleared
+    loose = HipCircuit(plan, tensors, device=hip_device, persistent_leaf=True, validate_inputs=False)
+    assert loose.reads_batch_directly(B)
+    assert bool(torch.isfinite(loose(bad.to(hip_device))).all())  # (memory-safe: such values select the integral row)
+    loose.check_inputs()
+
+
 @pytest.mark.parametrize("case", ["cfg1_rbt8", "cfg2_qt784"])
 def test_out_of_range_category_is_an_error_not_a_number(hip_device, case):
     """``TorchCategoricalLayer`` raises IndexError on a category >= num_categories (advanced indexing, input.py:399-412).
-    Here the staging kernel flags it on the device: the outputs of that batch -- and of every batch until the flag is
-    looked at -- are NaN, `check_inputs()` raises IndexError and clears the flag; valid batches are untouched, and the
-    marginalisation sentinel (negative) is not an error."""
+    With a staged batch the staging kernel flags it on the device: the outputs of that batch -- and of every batch until
+    the flag is looked at -- are NaN, `check_inputs()` raises IndexError and clears the flag; valid batches are untouched,
+    and the marginalisation sentinel (negative) is not an error."""
     from cirkit_amd.circuit import HipCircuit
 
     plan, tensors, g = load_case(case)
     x = _x_of(plan, g).to(hip_device)
-    hc = HipCircuit(plan, tensors, device=hip_device)
+    hc = HipCircuit(plan, tensors, device=hip_device, direct_input=False)
     good = hc(x).clone()
     hc.check_inputs()
     assert bool(torch.isfinite(good).all())
