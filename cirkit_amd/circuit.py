@@ -473,6 +473,7 @@ class HipCircuit:
             bd.leftover[d] = (bd.row_off[d][torch.from_numpy(folds).to(self.device)].contiguous(),
                               torch.from_numpy(bases[d] + folds * (B * K)).to(self.device))
         bd.ll = torch.empty(2, dtype=torch.float64, device=self.device)
+        self._ensure_param_batch()  # (which leaf launches are persistent depends on the prologue's table jobs)
         bd.direct = self._direct_input(B)
         bd.program = self._record(bd, with_ll=False)  # the launch list, recorded once
         if bd.direct and self.use_graph and capi.load().ck_program_num_ops(bd.program) > self.graph_min_launches:
@@ -770,6 +771,14 @@ class HipCircuit:
     def _launch_param_batch(self, stream: int) -> None:
         if not self.batch_params:
             return
+        self._ensure_param_batch()
+        self._batch.launch(stream)
+
+    def _ensure_param_batch(self) -> None:
+        """Build the job list of the batched prologue (and with it `_table_fused`: which leaf groups read a table made by
+        one of its jobs) for the current set of parameter tensors."""
+        if not self.batch_params:
+            return
         if self._batch is None or self._batch_version != self.store.version:
             self._batch = ParamBatch()
             self._assign_weight_layouts()
@@ -779,7 +788,6 @@ class HipCircuit:
                 if i not in covered:
                     l.register_batched(self._batch)
             self._batch_version = self.store.version
-        self._batch.launch(stream)
 
     def _register_table_jobs(self, batch: ParamBatch) -> set[int]:
         """`dense_on_table` inside the prologue: for a leaf group whose Categorical probabilities and
