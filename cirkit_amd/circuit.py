@@ -496,8 +496,9 @@ class HipCircuit:
             return False
         if self.leaf_waves != 8 or self.plan.num_variables * B * 8 >= 2**32:
             return False
-        if self.validate_inputs and not self._poison_in_tail():
-            return False
+        if self.validate_inputs and not (self._poison_in_tail() and len(self._tail) >= 2
+                                         and all(int(p) != self._tail[0] for p in self._out_pairs[:, 0])):
+            return False  # (the tail launch validates its rows while its FIRST level computes)
         for i, l in enumerate(self.layers):
             if i in self._virtual or i in self._tail:
                 continue

@@ -177,9 +177,9 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     // linear range in a 64-bit mask (scalar registers) and evaluates them in log space AFTER its walk over the chunk.
     // Doing that inside the walk -- an out-of-line call with the whole walk state live -- cost the hot loop its
     // registers (256 + spills against 237; 79 -> 74.5 us at the north-star configuration).
-    // Batch values are requested two tiles ahead and turned into packed table rows as soon as they have landed (the
-    // first wait of the next tile): `xraw` is live only from the last contractions of a tile -- when the sibling stack
-    // is empty -- to the first leaf of the next one.
+    // Batch values are requested two tiles ahead (after the last gather request of a tile) and turned into packed table
+    // rows as soon as they have landed (the first wait of the next tile): `xraw` is live only from the last contractions
+    // of a tile to the first leaf of the next one.
     RawT xraw[kLeaves];            // batch values of the tile AFTER the current one
     uint32_t cat[kLeaves / 2];     // packed table rows of the current tile
     uint32_t catnext[kLeaves / 2];  // ... of the next tile of this wave
@@ -240,6 +240,9 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
 #pragma unroll
             for (int j = 0; j < kLeaves / 2; ++j) cat[j] = catnext[j];
             static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
+            // ... and the batch values of the tile after it (the youngest requests in flight: the contractions that
+            // follow wait for nothing, and the first leaf of the next tile drains them all)
+            load_x(min(tile + 2 * WAVES, chunk_end - 1), xraw);
           }
         }
         if constexpr ((i & 1) != 0) cs = s_i + sprev;  // log scale of the pair (i - 1, i)
@@ -262,12 +265,6 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           // v_pk_mul_f32 that follows an MFMA back into two multiplies)
           __builtin_amdgcn_sched_barrier(0);
           contract_linear<CK_W_TILED_F32>(wcur, cur);
-          // batch values of the tile after the next one: requested once half of the sibling stack has been consumed
-          if constexpr (i + 1 == kLeaves && l == (D >= 3 ? 1 : 0)) {
-            __builtin_amdgcn_sched_barrier(0);  // (not hoisted above the contraction: the stack registers are free only now)
-            if (tile + WAVES < chunk_end) load_x(min(tile + 2 * WAVES, chunk_end - 1), xraw);
-            __builtin_amdgcn_sched_barrier(0);
-          }
         });
         if constexpr (steps_after(i) < D) {  // left sibling at this level: wait for the right one
           constexpr int l = steps_after(i);

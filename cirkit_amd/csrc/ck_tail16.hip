@@ -126,13 +126,6 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
     for (int i = threadIdx.x; i <= a.n_levels; i += blockDim.x) s_level[i] = a.level_begin[i];
   }
   __syncthreads();
-  if (a.x64 != nullptr) {  // (the verdict is read after the walk's level barriers)
-    x_check(0);
-    for (int first = kXInFlight * static_cast<int>(blockDim.x); first < x_total; first += kXInFlight * static_cast<int>(blockDim.x)) {
-      x_load(first);
-      x_check(first);
-    }
-  }
   bool poison = a.bad_input != nullptr && *a.bad_input != 0;
   WRegs16 w;
   int w_for = -1;  // fold whose 32-output weights are in `w`
@@ -283,6 +276,16 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
         prefetch(t_next);
       }
     }
+    if (li == 0 && a.x64 != nullptr) {
+      // the batch values requested at the top have landed while the first level computed: check them now; the verdict
+      // (s_badrows) is published by this level's barrier and read when the circuit outputs are written.  (A circuit whose
+      // tail is ONE level writes its outputs before this check: the host never asks such a launch to validate.)
+      x_check(0);
+      for (int first = kXInFlight * static_cast<int>(blockDim.x); first < x_total; first += kXInFlight * static_cast<int>(blockDim.x)) {
+        x_load(first);
+        x_check(first);
+      }
+    }
     if (w_for < 0 && s_level[li] + wave >= t1) prefetch(first_fold_of(li + 1));  // (no fold in this level: get ready for the next one)
     // level boundary: the level's tiles are in LDS.  Not __syncthreads(): that also waits for the level's stores to memory
     // and for the weights requested for the next level (s_waitcnt vmcnt(0)), a memory round trip per level
@@ -348,6 +351,8 @@ int ck_tail16_walk_fwd(const ck_tail16_launch* d, void* stream) {
   const void* const* slot = nullptr;
   if (raw) {
     CK_REQUIRE(d->D > 0 && d->num_states != nullptr, "ck_tail16_walk_fwd: validating the raw batch needs D and num_states");
+    CK_REQUIRE(n_levels >= 2, "ck_tail16_walk_fwd: the batch is validated while the first level computes: the outputs must "
+                              "belong to a later level (n_levels=%d)", n_levels);
     a.x64 = d->x_rows;
     a.D = d->D;
     a.num_states = d->num_states;
