@@ -64,28 +64,9 @@ class LeafLaunch(C.Structure):
         ("n_roots", C.c_int32),
         ("x_input", C.c_int32),
         ("x_rows", C.c_void_p),
+        ("bad_input", C.c_void_p),
         ("D", C.c_int32),
         ("reserved", C.c_int32),
-    ]
-
-
-class Tail16Launch(C.Structure):
-    """ck_tail16_launch of include/cirkit_hip.h."""
-
-    _fields_ = [
-        ("folds", C.c_void_p),
-        ("level_begin", C.c_void_p),
-        ("n_folds", C.c_int32), ("n_levels", C.c_int32), ("B", C.c_int32), ("K", C.c_int32), ("w_layout", C.c_int32),
-        ("signed_values", C.c_int32),
-        ("ll", C.c_void_p),
-        ("ll_partial", C.c_void_p),
-        ("ll_ticket", C.c_void_p),
-        ("bad_input", C.c_void_p),
-        ("x_rows", C.c_void_p),
-        ("num_states", C.c_void_p),
-        ("bad_flag", C.c_void_p),
-        ("D", C.c_int32),
-        ("x_input", C.c_int32),
     ]
 
 
@@ -123,7 +104,6 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_tail_lse_fwd": [_p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32),
                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _i, _p],
     "ck_tail16_lse_fwd": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p],
-    "ck_tail16_walk_fwd": [C.POINTER(Tail16Launch), _p],
     "ck_param_softmax": [_p, _p, _l, _i, _l, _i, _p],
     "ck_param_softmax_batch": [C.POINTER(SoftmaxJob), _i, _p],
     "ck_param_unary": [_i, _p, _p, _l, _f, _f, _p],

@@ -110,10 +110,10 @@ class HipCircuit:
             the outputs NaN and `check_inputs()` raise.  Negative values are this library's "marginalised" sentinel.
         tail16: the fused tail on 16-row tiles with its fold outputs kept in LDS and `log_likelihood_sum`'s reduction
             folded in (cirkit_amd/csrc/ck_tail16.hip); False keeps the 32-row walk of ck_tail.hip.
-        direct_input: when the persistent leaf launches are the only readers of a discrete batch, they read the caller's
-            ``(B, D)`` int64 tensor themselves (`ck_leaf_walk_fwd` with a program input) and the tail launch validates it
-            (`ck_tail16_walk_fwd`): no staging launch, no staged copy.  An out-of-range category then makes the outputs of
-            ITS ROW NaN (and `check_inputs()` raise) instead of the whole batch's.  False always stages the batch.
+        direct_input: when the persistent leaf launches are the only readers of a discrete batch, they read -- and validate --
+            the caller's ``(B, D)`` int64 tensor themselves (`ck_leaf_walk_fwd` with a program input): no staging launch,
+            no staged copy.  An out-of-range category then makes the outputs of ITS ROW NaN (and `check_inputs()` raise)
+            instead of the whole batch's, and later batches are unaffected.  False always stages the batch.
     """
 
     def __init__(
@@ -490,17 +490,14 @@ class HipCircuit:
 
     def _direct_input(self, B: int) -> bool:
         """Whether a forward at batch size B needs no staged copy of the discrete batch: its only readers are persistent
-        leaf launches, which then read the caller's int64 tensor (low dwords), and the 16-row tail launch validates the
-        full values of its rows (`ck_tail16_walk_fwd`).  Byte offsets into the batch are 32-bit."""
-        if not (self.direct_input and self._int_input and self._groups and self._tail and self._tail16_ok()):
+        leaf launches, which then read -- and validate -- the caller's int64 tensor (`ck_leaf_walk_fwd` with x_input).
+        Byte offsets into the batch are 32-bit."""
+        if not (self.direct_input and self._int_input and self._groups):
             return False
         if self.leaf_waves != 8 or self.plan.num_variables * B * 8 >= 2**32:
             return False
-        if self.validate_inputs and not (self._poison_in_tail() and len(self._tail) >= 2
-                                         and all(int(p) != self._tail[0] for p in self._out_pairs[:, 0])):
-            return False  # (the tail launch validates its rows while its FIRST level computes)
         for i, l in enumerate(self.layers):
-            if i in self._virtual or i in self._tail:
+            if i in self._virtual or (self._tail and i in self._tail):
                 continue
             if i in self._group_of_root:
                 if not (self._signed or self._leaf_is_persistent(self._group_of_root[i], B)):
@@ -896,19 +893,13 @@ class HipCircuit:
                     torch.zeros(1, dtype=torch.int32, device=self.device))
             desc_dev, levels_dev, n_folds, scratch, ticket = tabs
             fuse_ll = with_ll and self._tail_fuses_ll()
-            d = capi.Tail16Launch()
-            d.folds, d.n_folds, d.level_begin, d.n_levels = desc_dev.data_ptr(), n_folds, levels_dev.data_ptr(), n
-            d.B, d.K, d.w_layout, d.signed_values = bd.B, 32, lay, (1 if self._signed else 0)
-            d.ll = bd.ll.data_ptr() if fuse_ll else None
-            d.ll_partial = scratch.data_ptr() if fuse_ll else None
-            d.ll_ticket = ticket.data_ptr() if fuse_ll else None
-            d.bad_input, d.x_rows, d.x_input = None, None, -1
-            if bd.direct and self.validate_inputs:  # the leaf launches read low dwords only: this launch validates its rows
-                d.x_rows, d.x_input = self._raw_batch_args(bd)
-                d.num_states, d.bad_flag, d.D = self._num_states_dev().data_ptr(), self._bad_input.data_ptr(), self.plan.num_variables
-            elif not bd.direct and self._poison_in_tail():
-                d.bad_input = self._bad_input.data_ptr()
-            capi.call("ck_tail16_walk_fwd", C.byref(d), stream)
+            capi.call(
+                "ck_tail16_lse_fwd", desc_dev.data_ptr(), n_folds, levels_dev.data_ptr(), n, bd.B, 32, lay,
+                bd.ll.data_ptr() if fuse_ll else None, scratch.data_ptr() if fuse_ll else None,
+                ticket.data_ptr() if fuse_ll else None,
+                self._bad_input.data_ptr() if (self._poison_in_tail() and not bd.direct) else None,
+                1 if self._signed else 0, stream,
+            )
             return
         capi.call(
             "ck_tail_lse_fwd", bd.arena.data_ptr(), n,
@@ -1020,6 +1011,7 @@ class HipCircuit:
         if bd.direct:
             d.xt, d.preclamped, d.D = None, 0, self.plan.num_variables
             d.x_rows, d.x_input = self._raw_batch_args(bd)
+            d.bad_input = self._bad_input.data_ptr() if self.validate_inputs else None
         else:
             d.xt, d.preclamped, d.x_rows, d.x_input = bd.xt_i.data_ptr(), (1 if self._preclamp() else 0), None, -1
         capi.call("ck_leaf_walk_fwd", C.byref(d), stream)

@@ -48,6 +48,7 @@ struct LeafArgs {
   // XRAW: the batch as the caller holds it, (B, D) int64 row-major -- no staging launch in front of this one
   const int64_t* x64;
   int D;
+  int32_t* bad_flag;  // XRAW: raised (atomicOr 1) when a row holds an illegal value; nullptr = rows are not checked
 };
 
 // XRAW: the categories are read from the caller's (B, D) int64 batch directly (a.x64), one tile ahead; the staging launch
@@ -113,32 +114,63 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     // last 2^(D-1)... contractions of a tile have no memory waits).  A tile therefore starts without the chain
     // batch values -> scales -> leaf rows (three dependent memory round trips) in front of it.
     auto batch_row = [&](int tile) { return min(tile * 32 + b_in, a.B - 1); };
-    // XRAW: the LOW dword of the int64 value at (row, variable) of the caller's batch.  Whether the full 64-bit value
-    // is a legal category is not decided here (that needs the high dword: twice the registers in flight): the tail
-    // launch validates the batch (ck_tail16_lse_fwd with x_rows) -- this walk only has to stay memory-safe.
+    // Batch values of one tile in registers.  Staged: v[i] = value of leaf i (both halves of the wave hold the same).
+    // XRAW: lane (b, kh) holds the two dwords (v[2j], v[2j + 1]) = (low, high) of the int64 value of leaf 2j + kh -- one
+    // 8-byte load per PAIR of leaves: half the cache lines of a dword load per leaf (the 32 rows of a tile are 32
+    // different lines whatever is loaded from them, and for these launches line requests are what the gathers already
+    // spend the L1's time on), and the high dwords needed to validate the value come with them.
     using RawT = int32_t;
     auto load_x = [&](int tile, RawT (&xv)[kLeaves]) {
-      // (a uniform row pointer + a 32-bit lane offset: no 64-bit lane arithmetic per load)
-      uint32_t boff = static_cast<uint32_t>(batch_row(tile)) * (XRAW ? static_cast<uint32_t>(a.D) * 8u : 4u);
-      asm volatile("" : "+v"(boff));
+      // (a uniform pointer + a 32-bit lane offset: no 64-bit lane arithmetic per load)
+      if constexpr (XRAW) {
+        const uint32_t rowb = static_cast<uint32_t>(batch_row(tile)) * (static_cast<uint32_t>(a.D) * 8u);
 #pragma unroll
-      for (int i = 0; i < kLeaves; ++i) {
-        if constexpr (XRAW) xv[i] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.x64 + var_off[i]) + boff);
-        else xv[i] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.xt + var_off[i]) + boff);
+        for (int j = 0; j < kLeaves / 2; ++j) {
+          uint32_t off = rowb + (kh ? static_cast<uint32_t>(var_off[2 * j + 1]) : static_cast<uint32_t>(var_off[2 * j])) * 8u;
+          asm volatile("" : "+v"(off));
+          const int2 t = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(a.x64) + off);
+          xv[2 * j] = t.x;
+          xv[2 * j + 1] = t.y;
+        }
+      } else {
+        uint32_t boff = static_cast<uint32_t>(batch_row(tile)) * 4u;
+        asm volatile("" : "+v"(boff));
+#pragma unroll
+        for (int i = 0; i < kLeaves; ++i)
+          xv[i] = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(a.xt + var_off[i]) + boff);
       }
     };
-    // categories of a tile, two per register (C < 65535 is checked on the host): negative = marginalised -> the
-    // integral row C of the table
-    auto table_row = [&](RawT v) -> uint32_t {
+    // categories of a tile as table rows, two per register (C < 65535 is checked on the host): negative = marginalised
+    // -> the integral row C of the table.  XRAW: returns whether the lane's batch row holds a value that is not a legal
+    // input -- a category >= C (TorchCategoricalLayer's advanced indexing raises IndexError there, layers/input.py:399-412)
+    // or anything that does not fit 32 bits; such a value selects the integral row (memory-safe) and the row's root tile is
+    // written as NaN below (the launches that consume it carry the NaN to the circuit output of that row).
+    auto pack_categories = [&](const RawT (&xv)[kLeaves], uint32_t (&cp)[kLeaves / 2]) -> uint32_t {
       const uint32_t uc = static_cast<uint32_t>(a.C);
-      // staged values are -1 .. C - 1 (ck_stage_categories with clamp); raw low dwords: anything.  -1 = 0xffffffff -> row C;
-      // an out-of-range category lands on row C too (memory-safe; the validating launch turns that row's result into NaN)
-      if (XRAW || a.preclamped) return min(static_cast<uint32_t>(v), uc);
-      return v < 0 ? uc : static_cast<uint32_t>(min(v, a.C - 1));
-    };
-    auto pack_categories = [&](const RawT (&xv)[kLeaves], uint32_t (&cp)[kLeaves / 2]) {
+      uint32_t bad = 0;
 #pragma unroll
-      for (int j = 0; j < kLeaves / 2; ++j) cp[j] = table_row(xv[2 * j]) | (table_row(xv[2 * j + 1]) << 16);
+      for (int j = 0; j < kLeaves / 2; ++j) {
+        if constexpr (XRAW) {
+          const int32_t lo = xv[2 * j], hi = xv[2 * j + 1];
+          bad |= static_cast<uint32_t>((hi != (lo >> 31)) | (lo >= a.C));
+          // (v_permlane32_swap of a value with itself: r[0] = what the lanes (b, 0) hold, r[1] = what the lanes (b, 1) hold)
+          const uint32_t mine = min(static_cast<uint32_t>(lo), uc);
+          const auto r = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+          cp[j] = r[0] | (r[1] << 16);
+        } else {
+          auto row = [&](int32_t v) -> uint32_t {
+            // preclamped: -1 .. C - 1 (ck_stage_categories): -1 = 0xffffffff -> the integral row C (uniform branch)
+            if (a.preclamped) return min(static_cast<uint32_t>(v), uc);
+            return v < 0 ? uc : static_cast<uint32_t>(min(v, a.C - 1));
+          };
+          cp[j] = row(xv[2 * j]) | (row(xv[2 * j + 1]) << 16);
+        }
+      }
+      if constexpr (XRAW) {
+        const auto r = __builtin_amdgcn_permlane32_swap(bad, bad, false, false);
+        bad = a.bad_flag != nullptr ? (r[0] | r[1]) : 0u;  // (no flag: the caller asked for no validation)
+      }
+      return bad;
     };
     auto row_of = [&](const uint32_t (&cp)[kLeaves / 2], auto ic) -> int32_t {  // table row of leaf ic.value for batch row b_in
       constexpr int i = decltype(ic)::value;
@@ -183,12 +215,13 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     RawT xraw[kLeaves];            // batch values of the tile AFTER the current one
     uint32_t cat[kLeaves / 2];     // packed table rows of the current tile
     uint32_t catnext[kLeaves / 2];  // ... of the next tile of this wave
+    uint32_t bad_cur = 0, bad_next = 0;  // XRAW: the lane's row of the current / next tile holds an illegal value
     for (int chunk_begin = tile_begin; chunk_begin < tile_end; chunk_begin += 64 * WAVES) {
     const int chunk_end = min(tile_end, chunk_begin + 64 * WAVES);
     int tile = chunk_begin + wave;
     if (tile < chunk_end) {  // the first tile of the wave: the chain is paid once per chunk
       load_x(tile, xraw);
-      pack_categories(xraw, cat);
+      bad_cur = pack_categories(xraw, cat);
       static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
       load_x(min(tile + WAVES, chunk_end - 1), xraw);
     }
@@ -199,7 +232,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     uint64_t bad_tiles = 0;
     int nth = 0;  // tile number `nth` of this wave in the chunk
 
-    for (; tile < chunk_end; tile += WAVES, ++nth) {
+    for (; tile < chunk_end; tile += WAVES, ++nth, bad_cur = bad_next) {
       const int b = tile * 32 + b_in;
       const bool live = b < a.B;
       float stack[D][16], sstack[D];
@@ -232,7 +265,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           cur[12 + e] = r3[e];
         }
         const float s_i = sld[i & 3];
-        if constexpr (i == 0) pack_categories(xraw, catnext);  // (everything requested before this tile has landed)
+        if constexpr (i == 0) bad_next = pack_categories(xraw, catnext);  // (everything requested before this tile has landed)
         if constexpr (i + kSlots < kLeaves) request(cat, std::integral_constant<int, i + kSlots>{});
         if constexpr (i + 1 == kLeaves) {
           // the gathers of this tile are over: request what the next tile starts with (see above)
@@ -283,6 +316,13 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           bad_tiles |= uint64_t{1} << nth;
         }
       } else if (live) {
+        if constexpr (XRAW) {
+          if (__builtin_expect(__any(bad_cur != 0), 0)) {  // an illegal input in some row of this tile: that row is NaN
+            if (a.bad_flag != nullptr && lane == 0) atomicOr(a.bad_flag, 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cur[j] = bad_cur != 0 ? __builtin_nanf("") : cur[j];
+          }
+        }
         if constexpr (SIGNED) {  // the complex logarithm of a real number: (log|v|, 0 or pi)
           uint32_t sg = 0;
 #pragma unroll
@@ -308,6 +348,8 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       src.table = a.table;
       src.scale = a.scale;
       src.xt = a.xt;
+      src.x64 = a.x64;
+      src.D = a.D;
       src.scope = a.scope;
       src.leaf_ids = leaf_ids;
       src.fold0 = fold0;
@@ -319,6 +361,16 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       float fb[16];
       if constexpr (!SIGNED) {
         subtree_tile_logspace<D, CK_W_TILED_F32>(src, lane, fb);
+        if constexpr (XRAW) {  // (rows with an illegal value are NaN here too)
+          RawT xb[kLeaves];
+          uint32_t cb[kLeaves / 2];
+          load_x(btile, xb);
+          if (pack_categories(xb, cb) != 0) {
+            if (a.bad_flag != nullptr) atomicOr(a.bad_flag, 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) fb[j] = __builtin_nanf("");
+          }
+        }
         if (b < a.B) tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
       }
     }
@@ -338,6 +390,8 @@ __global__ void __launch_bounds__(64) leaf_signed_redo_kernel(const LeafArgs a) 
   src.table = a.table;
   src.scale = a.scale;
   src.xt = a.xt;
+  src.x64 = a.x64;
+  src.D = a.D;
   src.scope = a.scope;
   src.leaf_ids = a.nodes + a.leaf_off + t * (1 << D);
   src.fold0 = a.nodes + a.node_off[0] + t * (1 << D);
@@ -430,6 +484,7 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
                "ck_leaf_walk_fwd: raw batch of B=%d x D=%d int64 values exceeds 32-bit byte offsets (stage it instead)", d->B, d->D);
     CK_REQUIRE(d->C < 65535, "ck_leaf_walk_fwd: C=%d categories do not fit the packed rows", d->C);
     a.D = d->D;
+    a.bad_flag = d->bad_input;
     a.x64 = d->x_rows;
     if (d->x_input >= 0) {
       slot = ck::program_input_slot(d->x_input);

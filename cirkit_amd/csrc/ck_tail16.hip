@@ -45,18 +45,7 @@ struct Tail16Args {
   unsigned int* ll_ticket;
   const int32_t* bad_input;  // nullptr, or the sticky input-validation flag (ck_stage_categories): nonzero -> NaN outputs
   int n_folds, n_levels, B;
-  // validation of the raw batch (the leaf launch read only low dwords, ck_leaf_walk_fwd with x_rows): every workgroup
-  // checks the full 64-bit values of ITS 16 rows while the fold descriptors are on their way to LDS; a row holding a
-  // value >= num_states[d] (or below -2^31, whose low dword could pass for a category) gets NaN outputs and raises *bad_flag
-  const int64_t* x64;          // (B, D) int64 or nullptr
-  const int32_t* num_states;   // (D): states of variable d, 0 = not checked
-  int32_t* bad_flag;
-  int D;
 };
-
-__device__ __forceinline__ bool bad_category(int64_t v, int ns) {
-  return ns > 0 && (v >= static_cast<int64_t>(ns) || v < -2147483648LL);
-}
 
 // SIGNED: a real-valued circuit under complex-lse-sum (semiring.py:441-476): memory blocks are (B, Ko) complex64 holding
 // (log|v|, 0 or pi); inside the walk a value is (log|v|, sign bit) -- one word of sign bits per lane and fold in LDS next
@@ -76,48 +65,6 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
   uint32_t* s_sign = reinterpret_cast<uint32_t*>(tiles + a.n_folds * 512);
   FoldDesc* s_fold = reinterpret_cast<FoldDesc*>(tiles + a.n_folds * (SIGNED ? 576 : 512));
   int32_t* s_level = reinterpret_cast<int32_t*>(s_fold + a.n_folds);
-  uint32_t* s_badrows = reinterpret_cast<uint32_t*>(s_level + a.n_levels + 1);  // bit r: row r of this workgroup holds a bad value
-  constexpr int kXInFlight = 8;  // 16-byte pieces of the batch per thread in flight (8 x 1024 x 16 B = 16 rows x 1024 variables)
-  const bool x_pairs = a.x64 != nullptr && (a.D & 1) == 0;  // rows are 16-byte aligned: two values per load
-  const int x_per_row = x_pairs ? a.D >> 1 : a.D, x_total = a.x64 != nullptr ? 16 * x_per_row : 0;
-  int4 xv[kXInFlight];
-  auto x_load = [&](int first) {
-#pragma unroll
-    for (int k = 0; k < kXInFlight; ++k) {
-      const int c = first + k * static_cast<int>(blockDim.x) + threadIdx.x;
-      xv[k] = make_int4(0, 0, 0, 0);
-      if (c < x_total) {
-        const int r = c / x_per_row, p = c - r * x_per_row;
-        const int64_t row = min(blockIdx.x * 16 + r, a.B - 1);
-        if (x_pairs) {
-          xv[k] = *reinterpret_cast<const int4*>(a.x64 + row * a.D + 2 * p);
-        } else {
-          const int2 t = *reinterpret_cast<const int2*>(a.x64 + row * a.D + p);
-          xv[k] = make_int4(t.x, t.y, 0, 0);
-        }
-      }
-    }
-  };
-  auto x_check = [&](int first) {
-#pragma unroll
-    for (int k = 0; k < kXInFlight; ++k) {
-      const int c = first + k * static_cast<int>(blockDim.x) + threadIdx.x;
-      if (c < x_total) {
-        const int r = c / x_per_row, p = c - r * x_per_row;
-        const int64_t v0 = (static_cast<int64_t>(xv[k].y) << 32) | static_cast<uint32_t>(xv[k].x);
-        bool bad;
-        if (x_pairs) {
-          const int64_t v1 = (static_cast<int64_t>(xv[k].w) << 32) | static_cast<uint32_t>(xv[k].z);
-          bad = bad_category(v0, a.num_states[2 * p]) || bad_category(v1, a.num_states[2 * p + 1]);
-        } else {
-          bad = bad_category(v0, a.num_states[p]);
-        }
-        if (bad) atomicOr(s_badrows, 1u << r);
-      }
-    }
-  };
-  if (threadIdx.x == 0) *s_badrows = 0;
-  if (a.x64 != nullptr) x_load(0);
   {
     const int n16 = a.n_folds * static_cast<int>(sizeof(FoldDesc) / 16);
     const int4* src = reinterpret_cast<const int4*>(a.folds);
@@ -126,7 +73,7 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
     for (int i = threadIdx.x; i <= a.n_levels; i += blockDim.x) s_level[i] = a.level_begin[i];
   }
   __syncthreads();
-  bool poison = a.bad_input != nullptr && *a.bad_input != 0;
+  const bool poison = a.bad_input != nullptr && *a.bad_input != 0;
   WRegs16 w;
   int w_for = -1;  // fold whose 32-output weights are in `w`
   auto prefetch = [&](int t) {
@@ -234,9 +181,7 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
           }
           acc = xquad_sum(acc);
           float y = fmaf(__builtin_amdgcn_logf(SIGNED ? __builtin_fabsf(acc) : acc), kLN2, m);
-          // an out-of-range category (the reference raises): somewhere in the batch (staged input, sticky flag), or in
-          // THIS row (raw input, checked above; the level barriers in between have published s_badrows)
-          if (poison || (a.x64 != nullptr && ((*s_badrows >> b_in) & 1u) != 0)) y = __builtin_nanf("");
+          if (poison) y = __builtin_nanf("");  // an out-of-range category somewhere in the batch (the reference raises)
           if constexpr (SIGNED) {
             if (live && kq == 0)
               *reinterpret_cast<float2*>(out + (static_cast<int64_t>(b) * Ko + o) * 2) = make_float2(y, acc < 0.f ? 3.14159265358979323846f : 0.f);
@@ -276,22 +221,11 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
         prefetch(t_next);
       }
     }
-    if (li == 0 && a.x64 != nullptr) {
-      // the batch values requested at the top have landed while the first level computed: check them now; the verdict
-      // (s_badrows) is published by this level's barrier and read when the circuit outputs are written.  (A circuit whose
-      // tail is ONE level writes its outputs before this check: the host never asks such a launch to validate.)
-      x_check(0);
-      for (int first = kXInFlight * static_cast<int>(blockDim.x); first < x_total; first += kXInFlight * static_cast<int>(blockDim.x)) {
-        x_load(first);
-        x_check(first);
-      }
-    }
     if (w_for < 0 && s_level[li] + wave >= t1) prefetch(first_fold_of(li + 1));  // (no fold in this level: get ready for the next one)
     // level boundary: the level's tiles are in LDS.  Not __syncthreads(): that also waits for the level's stores to memory
     // and for the weights requested for the next level (s_waitcnt vmcnt(0)), a memory round trip per level
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  if (a.x64 != nullptr && a.bad_flag != nullptr && threadIdx.x == 0 && *s_badrows != 0) atomicOr(a.bad_flag, 1);
 }
 
 }  // namespace
@@ -301,32 +235,6 @@ extern "C" {
 int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* level_begin, int n_levels, int B, int K,
                       int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, const int32_t* bad_input,
                       int signed_values, void* stream) {
-  ck_tail16_launch d{};
-  d.folds = folds;
-  d.n_folds = n_folds;
-  d.level_begin = level_begin;
-  d.n_levels = n_levels;
-  d.B = B;
-  d.K = K;
-  d.w_layout = w_layout;
-  d.ll = ll;
-  d.ll_partial = ll_partial;
-  d.ll_ticket = ll_ticket;
-  d.bad_input = bad_input;
-  d.signed_values = signed_values;
-  d.x_input = -1;
-  return ck_tail16_walk_fwd(&d, stream);
-}
-
-int ck_tail16_walk_fwd(const ck_tail16_launch* d, void* stream) {
-  CK_REQUIRE(d != nullptr, "ck_tail16_walk_fwd: null descriptor");
-  const ck_tail16_fold* folds = d->folds;
-  const int32_t* level_begin = d->level_begin;
-  const int n_folds = d->n_folds, n_levels = d->n_levels, B = d->B, K = d->K, w_layout = d->w_layout, signed_values = d->signed_values;
-  double* ll = d->ll;
-  double* ll_partial = d->ll_partial;
-  uint32_t* ll_ticket = d->ll_ticket;
-  const int32_t* bad_input = d->bad_input;
   CK_REQUIRE(folds && level_begin, "ck_tail16_lse_fwd: null pointer");
   CK_REQUIRE(n_folds > 0 && n_folds <= kTail16MaxFolds, "ck_tail16_lse_fwd: n_folds=%d outside [1, %d]", n_folds, kTail16MaxFolds);
   CK_REQUIRE(n_levels > 0 && n_levels <= kTail16MaxLevels, "ck_tail16_lse_fwd: n_levels=%d outside [1, %d]", n_levels, kTail16MaxLevels);
@@ -347,29 +255,10 @@ int ck_tail16_walk_fwd(const ck_tail16_launch* d, void* stream) {
   a.ll_partial = ll_partial;
   a.ll_ticket = ll_ticket;
   a.bad_input = bad_input;
-  const bool raw = d->x_rows != nullptr || d->x_input >= 0;
-  const void* const* slot = nullptr;
-  if (raw) {
-    CK_REQUIRE(d->D > 0 && d->num_states != nullptr, "ck_tail16_walk_fwd: validating the raw batch needs D and num_states");
-    CK_REQUIRE(n_levels >= 2, "ck_tail16_walk_fwd: the batch is validated while the first level computes: the outputs must "
-                              "belong to a later level (n_levels=%d)", n_levels);
-    a.x64 = d->x_rows;
-    a.D = d->D;
-    a.num_states = d->num_states;
-    a.bad_flag = d->bad_flag;
-    if (d->x_input >= 0) {
-      slot = ck::program_input_slot(d->x_input);
-      CK_REQUIRE(slot != nullptr, "ck_tail16_walk_fwd: x_input=%d names a program input, but no program is being recorded on "
-                                  "this thread (or the index is out of range)", d->x_input);
-    }
-  }
   const size_t lds = static_cast<size_t>(n_folds) * ((signed_values ? 576 : 512) * sizeof(float) + sizeof(FoldDesc)) + (n_levels + 1) * sizeof(int32_t) + 16;
   dim3 grid((B + 15) / 16), block(kTail16Waves * 64);
   return ck::dispatch(
-      [=, a0 = a](hipStream_t s) {
-        Tail16Args a = a0;
-        if (slot != nullptr) a.x64 = static_cast<const int64_t*>(*slot);  // the batch of THIS replay (ck_program_set_input)
-        if (raw && a.x64 == nullptr) return hipErrorInvalidValue;
+      [=](hipStream_t s) {
         auto go = [&](auto kern) {
           if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

@@ -397,7 +397,9 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ src_row, flo
 struct SubtreeSource {
   const float* table;     // (F0, C+1, 32) LINEAR table rows
   const float* scale;     // (F0, C+1) their log scales
-  const int32_t* xt;      // (Dvars, B)
+  const int32_t* xt;      // (Dvars, B) staged batch, or nullptr:
+  const int64_t* x64;     // ... the raw (B, D) int64 batch (ck_leaf_walk_fwd with x_rows: low dwords, row min_u32(x, C))
+  int D;
   const int64_t* scope;   // variable of each input-layer fold
   const int32_t* leaf_ids;  // (2^D) input-layer fold of each leaf of this root
   const int32_t* fold0;     // (2^D) table fold of each leaf
@@ -413,8 +415,14 @@ __device__ __noinline__ void subtree_tile_logspace(const SubtreeSource src, int 
   const int kh = lane >> 5;
   auto leaf = [&](auto ic, float (&v)[16]) {
     constexpr int i = decltype(ic)::value;
-    const int x = src.xt[src.scope[src.leaf_ids[i]] * static_cast<int64_t>(src.B) + src.bl];
-    const int64_t r = static_cast<int64_t>(src.fold0[i]) * (src.C + 1) + (x < 0 ? src.C : min(x, src.C - 1));
+    const int64_t var = src.scope[src.leaf_ids[i]];
+    int64_t r = static_cast<int64_t>(src.fold0[i]) * (src.C + 1);
+    if (src.xt != nullptr) {
+      const int x = src.xt[var * static_cast<int64_t>(src.B) + src.bl];
+      r += x < 0 ? src.C : min(x, src.C - 1);
+    } else {  // the same mapping as the walk that noted this tile
+      r += min(static_cast<uint32_t>(src.x64[static_cast<int64_t>(src.bl) * src.D + var]), static_cast<uint32_t>(src.C));
+    }
     tile_load(src.table + r * kK + 4 * kh, v);
     return src.scale[r];
   };

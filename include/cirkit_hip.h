@@ -285,12 +285,13 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
  *
  *  Raw input (x_rows != NULL or x_input >= 0; xt must then be NULL; 8 waves): the launch reads the categories from the
  *  caller's (B, D) int64 batch itself -- what TorchCategoricalLayer.log_unnormalized_likelihood indexes with
- *  (layers/input.py:399-412: `x.long()`) -- no staged copy, no ck_stage_categories launch in front.  Only the low dword
- *  of a value is looked at here: u = (uint32_t) x selects table row min(u, C), i.e. a negative value selects the integral
- *  row C (this library's marginalisation sentinel, cirkit/backend/torch/queries.py:19-184) and so does anything else that
- *  is not a category (memory-safe, not meaningful).  VALIDATION is the job of the launch that consumes the roots:
- *  ck_tail16_lse_fwd with x_rows checks the full 64-bit values of its rows and turns the results of rows holding a value
- *  >= C -- an IndexError in the reference -- into NaN.  B * D * 8 must be below 2^32.
+ *  (layers/input.py:399-412: `x.long()`) -- no staged copy, no ck_stage_categories launch in front.  A value v selects
+ *  table row v for 0 <= v < C; a negative value down to -2^31 selects the integral row C (this library's marginalisation
+ *  sentinel, cirkit/backend/torch/queries.py:19-184).  Anything else -- v >= C, an IndexError in the reference, or a value
+ *  that does not fit 32 bits -- is an illegal input: with bad_input != NULL the root outputs of THAT BATCH ROW are written
+ *  as NaN (every launch downstream carries the NaN to the circuit outputs of the row; other rows are unaffected) and
+ *  *bad_input (a DEVICE int32 owned by the caller, as ck_stage_categories' flag) is raised; with bad_input == NULL such a
+ *  value is evaluated as the integral row (memory-safe, not meaningful).  B * D * 8 must be below 2^32.
  *  x_input >= 0: the call is being RECORDED into a ck_program and the batch pointer is read, at every replay, from that
  *  program's input cell x_input (ck_program_set_input) -- a recorded forward then follows the caller's batch without a
  *  copy.  Not usable with use_graph != 0 launches (a hipGraph keeps the pointer of its capture). */
@@ -311,6 +312,7 @@ typedef struct ck_leaf_launch {
   int32_t n_roots;
   int32_t x_input;               /* -1, or the program input cell holding the raw batch pointer */
   const int64_t* x_rows;         /* raw (B, D) int64 batch, or NULL */
+  int32_t* bad_input;            /* raw input: validation flag (rows with illegal values become NaN), or NULL */
   int32_t D;                     /* variables per row of the raw batch */
   int32_t reserved;
 } ck_leaf_launch;
@@ -351,30 +353,7 @@ typedef struct ck_tail16_fold {
 int ck_tail16_lse_fwd(const ck_tail16_fold* folds, int n_folds, const int32_t* level_begin, int n_levels, int B, int K,
                       int w_layout, double* ll, double* ll_partial, uint32_t* ll_ticket, const int32_t* bad_input,
                       int signed_values, void* stream);
-/* ck_tail16_lse_fwd with its arguments in a descriptor (fields as the parameters of the same name), plus VALIDATION OF THE
- * RAW BATCH for circuits whose leaf launch read it directly (ck_leaf_walk_fwd with x_rows / x_input, which looks at low
- * dwords only): with x_rows != NULL (or x_input >= 0: read at every replay from that input cell of the program being
- * recorded, ck_program_set_input) every workgroup checks the full 64-bit values x[b, d] of its 16 rows against
- * num_states[d] (DEVICE (D) int32; 0 = variable not checked) while its fold descriptors travel to LDS.  A row holding a
- * value >= num_states[d] -- TorchCategoricalLayer / TorchEmbeddingLayer raise IndexError there (layers/input.py:258-266,
- * 399-412) -- or below -2^31 gets NaN for every few-unit output of the tail (the circuit's outputs) and *bad_flag (if not
- * NULL) is raised; other rows, and later launches, are unaffected.  Negative values down to -2^31 are this library's
- * marginalisation sentinel. */
-typedef struct ck_tail16_launch {
-  const ck_tail16_fold* folds;
-  const int32_t* level_begin;
-  int32_t n_folds, n_levels, B, K, w_layout, signed_values;
-  double* ll;
-  double* ll_partial;
-  uint32_t* ll_ticket;
-  const int32_t* bad_input;
-  const int64_t* x_rows;      /* raw (B, D) int64 batch to validate, or NULL */
-  const int32_t* num_states;  /* (D) */
-  int32_t* bad_flag;
-  int32_t D;
-  int32_t x_input;            /* -1, or the program input cell holding the raw batch pointer */
-} ck_tail16_launch;
-int ck_tail16_walk_fwd(const ck_tail16_launch* desc, void* stream);
+
 
 /* ---------------------------------------------------------------- parameter graphs --------- */
 /* The reference re-evaluates each layer's parameter DAG on every forward
