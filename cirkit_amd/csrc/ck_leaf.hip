@@ -24,11 +24,40 @@
 
 #include "ck_internal.h"
 #include "ck_tile.h"
+#include "ck_tile16.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxDepthP = 4;
+
+// one fold of the tail, as the host lays it out (ck_tail16_fold in cirkit_hip.h; ck_tail16.hip's FoldDesc)
+struct TailFold {
+  const float* w;
+  float* out;
+  const float* child[4];
+  int32_t child_src[4];
+  int32_t H, Ko;
+  int32_t pad[2];
+};
+static_assert(sizeof(TailFold) == sizeof(ck_tail16_fold), "TailFold mirrors ck_tail16_fold");
+
+// 16-byte accesses that other CUs (other XCDs) must see / that must see other CUs' stores: write-through stores and loads
+// past the non-coherent caches, sc0 sc1 on both sides (MI355X_MICROARCH.md, inter-workgroup visibility) -- no cache-wide
+// release / acquire.  The compiler does not see these memory operations: the waits are explicit.
+__device__ __forceinline__ void store4_wt(float* p, float x, float y, float z, float w) {
+  const f32x4v v = {x, y, z, w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4v load4_wt(const float* p) {
+  f32x4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void tile_store_wt(float* __restrict__ dst_row, const float (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) store4_wt(dst_row + 8 * g, v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
 
 struct LeafArgs {
   const float* table;    // (F0, C+1, 32) rows in LINEAR space (kind-5 prologue job)
@@ -49,7 +78,217 @@ struct LeafArgs {
   const int64_t* x64;
   int D;
   int32_t* bad_flag;  // XRAW: raised (atomicOr 1) when a row holds an illegal value; nullptr = rows are not checked
+  // TAIL: the trailing few-fold levels (ck_tail16.hip's walk) inside this launch -- see leaf_tail_phase
+  const TailFold* tail_folds;    // (tail_n_folds) in level order
+  const int32_t* tail_level_begin;  // (tail_n_levels + 1)
+  int tail_n_folds, tail_n_levels;
+  int tail_write;                // the 32-unit fold outputs of the tail are layer outputs somebody reads: store them too
+  int tail_w_rowmajor;           // layout of the 32-output tail weights (else CK_W_TILED_F32)
+  const int32_t* tail_bad_input; // staged batch: ck_stage_categories' sticky flag -> NaN circuit outputs (nullptr: none)
+  double* ll;                    // nullptr, or [sum_b log p, B]
+  double* ll_partial;            // (ceil(B / 16))
+  unsigned int* ll_ticket;
+  unsigned long long* arrive;    // monotonic arrival counter of the launches of this binding
+  unsigned int* tail_state;      // (ceil(B / 16)) epoch in which each 16-row tile was last claimed
 };
+
+// ---- the tail of the circuit inside the leaf launch -------------------------------------------------------------------
+// The trailing few-fold levels (24, 11, 6, 4, 2, 1 folds at the north-star configuration) are a chain of tiny dependent
+// steps; as a launch of their own (ck_tail16.hip) they cost a launch boundary, the start-up of 256 new workgroups, and
+// a round trip through HBM for the roots -- 22 us behind a 70 us leaf launch.  Here the resident workgroups of the leaf
+// launch walk them after their segments:
+//   * root tiles are stored write-through (tile_store_wt), so a workgroup's roots are at the memory side when its
+//     stores have completed; it then arrives on a monotonic counter (one 8-byte agent-scope atomic per workgroup);
+//   * a workgroup waits until every workgroup of the launch has arrived (the roots of a row come from every workgroup),
+//     then claims 16-row tiles of the batch -- its own first (tile = workgroup index), by an epoch compare-and-swap -- and
+//     walks each exactly as tail16_kernel does: fold outputs of the tail stay in LDS (the leaf walk's 156 KB are free),
+//     children produced by the leaf walk are read past the caches (load4_wt), the log-likelihood sum is folded in;
+//   * NOTHING depends on all workgroups being resident at once: a workgroup that has waited 200 us -- another launch holds
+//     compute units this one needs -- leaves without claiming; whoever passes the wait later finds its tiles unclaimed in
+//     the sweep that follows its own tiles and walks them.
+// Same arithmetic per fold as tail16_kernel (the fold -> wave assignment differs, the values do not).
+constexpr unsigned long long kTailTimeoutTicks = 20000;  // wall_clock64 runs at 100 MHz: 200 us
+
+template <int WAVES>
+__device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, float* tiles, const TailFold* s_fold,
+                                               const int32_t* s_level, bool poison) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 15, kq = lane >> 4;
+  const int b = tile * 16 + b_in;
+  const bool live = b < a.B;
+  const int bl = live ? b : a.B - 1;
+  auto load_w = [&](int t, WRegs16& w) {
+    if (a.tail_w_rowmajor) load_w16<CK_W_ROWMAJOR>(s_fold[t].w, lane, w);
+    else load_w16<CK_W_TILED_F32>(s_fold[t].w, lane, w);
+  };
+  for (int li = 0; li < a.tail_n_levels; ++li) {
+    const int t1 = s_level[li + 1];
+    for (int t = s_level[li] + wave; t < t1; t += WAVES) {
+      const int H = s_fold[t].H, Ko = s_fold[t].Ko;
+      WRegs16 w;
+      if (Ko == kK) load_w(t, w);  // (parameters: written by an earlier launch, plain loads)
+      // children: folds of the tail from LDS, roots of the leaf walk from memory -- all requests first, one wait
+      f32x4v mem[4][2];
+      for (int h = 0; h < H; ++h)
+        if (s_fold[t].child_src[h] < 0) {
+          const float* row = s_fold[t].child[h] + static_cast<int64_t>(bl) * kK + 4 * kq;
+          mem[h][0] = load4_wt(row);
+          mem[h][1] = load4_wt(row + 16);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      for (int h = 0; h < H; ++h) {
+        const int src = s_fold[t].child_src[h];
+        if (src >= 0) {
+          const float* tl = tiles + src * 512 + lane * 4;
+#pragma unroll
+          for (int beta = 0; beta < 2; ++beta) {
+            const float4 t4 = *reinterpret_cast<const float4*>(tl + beta * 256);
+            v[4 * beta + 0] += t4.x;
+            v[4 * beta + 1] += t4.y;
+            v[4 * beta + 2] += t4.z;
+            v[4 * beta + 3] += t4.w;
+          }
+        } else {
+#pragma unroll
+          for (int beta = 0; beta < 2; ++beta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * beta + r] += mem[h][beta][r];
+        }
+      }
+      float* out = s_fold[t].out;
+      if (Ko == kK) {
+        sum_step16(w, v);
+        if (a.tail_write && live) tile16_store(out + static_cast<int64_t>(b) * kK + 4 * kq, v);
+        float* tl = tiles + t * 512 + lane * 4;
+#pragma unroll
+        for (int beta = 0; beta < 2; ++beta)
+          *reinterpret_cast<float4*>(tl + beta * 256) = make_float4(v[4 * beta + 0], v[4 * beta + 1], v[4 * beta + 2], v[4 * beta + 3]);
+      } else {
+        // Ko < 32 (the root: Ko = 1): plain dot products, row-major fp32 weights (as tail16_kernel)
+        const float* wf = s_fold[t].w;
+        const float m = ck::clamp_finite(row_max8(v));
+        const float nml = exp_offset(m, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_exp2f(fmaf(v[j], kL2E, nml));
+        for (int o = 0; o < Ko; ++o) {
+          const float* wrow = wf + o * kK + 4 * kq;
+          float acc = 0.f;
+#pragma unroll
+          for (int beta = 0; beta < 2; ++beta) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wrow + 16 * beta);
+            acc = fmaf(w4.x, v[4 * beta + 0], acc);
+            acc = fmaf(w4.y, v[4 * beta + 1], acc);
+            acc = fmaf(w4.z, v[4 * beta + 2], acc);
+            acc = fmaf(w4.w, v[4 * beta + 3], acc);
+          }
+          acc = xquad_sum(acc);
+          float y = fmaf(__builtin_amdgcn_logf(acc), kLN2, m);
+          if (poison) y = __builtin_nanf("");
+          if (live && kq == 0) out[static_cast<int64_t>(b) * Ko + o] = y;
+          if (a.ll != nullptr && t == a.tail_n_folds - 1) {
+            // this tile's (up to) 16 root values, rows in order, in double precision; the last tile of the launch to get
+            // here adds up the per-tile sums in index order (deterministic; ck_tail16.hip)
+            double sacc = 0.0;
+            for (int r = 0; r < 16; ++r) {
+              const float yr = __shfl(y, r, 64);
+              if (tile * 16 + r < a.B) sacc += static_cast<double>(yr);
+            }
+            const unsigned int n_tiles = static_cast<unsigned int>((a.B + 15) >> 4);
+            unsigned int ticket = 0;
+            if (lane == 0) {
+              __hip_atomic_store(a.ll_partial + tile, sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              ticket = __hip_atomic_fetch_add(a.ll_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ticket = __shfl(ticket, 0, 64);
+            if (ticket == n_tiles - 1) {
+              double tot = 0.0;
+              for (unsigned int g = lane; g < n_tiles; g += 64)
+                tot += __hip_atomic_load(a.ll_partial + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+              for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+              if (lane == 0) {
+                a.ll[0] = tot;
+                a.ll[1] = static_cast<double>(a.B);
+                __hip_atomic_store(a.ll_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the level's tiles are in LDS
+  }
+}
+
+template <int WAVES>
+__device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* lds) {
+  const int n_tiles = (a.B + 15) >> 4;
+  float* tiles = lds;  // [tail fold][beta][lane] float4 tiles, 2 KB each
+  TailFold* s_fold = reinterpret_cast<TailFold*>(tiles + a.tail_n_folds * 512);
+  int32_t* s_level = reinterpret_cast<int32_t*>(s_fold + a.tail_n_folds);
+  unsigned int* s_ctl = reinterpret_cast<unsigned int*>(s_level + a.tail_n_levels + 1);
+  // this workgroup's roots: the write-through stores have completed -> they are at the memory side
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // (every wave has left the walk: its LDS is free)
+  if (threadIdx.x == 0) {
+    const unsigned long long n = gridDim.x;
+    const unsigned long long old = __hip_atomic_fetch_add(a.arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ctl[0] = static_cast<unsigned int>(old / n + 1);  // the epoch of this launch
+    s_ctl[2] = static_cast<unsigned int>(n - 1 - old % n);  // arrivals still missing (as of this one)
+  }
+  {  // fold descriptors and level table -> LDS while the others arrive
+    const int n16 = a.tail_n_folds * static_cast<int>(sizeof(TailFold) / 16);
+    const int4* src = reinterpret_cast<const int4*>(a.tail_folds);
+    int4* dst = reinterpret_cast<int4*>(s_fold);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i <= a.tail_n_levels; i += blockDim.x) s_level[i] = a.tail_level_begin[i];
+  }
+  __syncthreads();
+  const unsigned int epoch = s_ctl[0];
+  if (threadIdx.x == 0) {
+    const unsigned long long target = static_cast<unsigned long long>(epoch) * gridDim.x;
+    const unsigned long long t0 = wall_clock64();
+    unsigned int ok = 1;
+    if (s_ctl[2] != 0)
+      while (__hip_atomic_load(a.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > kTailTimeoutTicks) {
+          ok = 0;
+          break;
+        }
+      }
+    s_ctl[1] = ok;
+  }
+  __syncthreads();
+  if (s_ctl[1] == 0) return;  // gave up waiting: the tiles of this workgroup are left to the sweep of those that pass
+  const bool poison = a.tail_bad_input != nullptr && *a.tail_bad_input != 0;
+  auto claim = [&](int tile) -> bool {  // exactly one workgroup of the launch walks a tile
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned int expected = epoch - 1;
+      s_ctl[3] = __hip_atomic_compare_exchange_strong(a.tail_state + tile, &expected, epoch, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+    }
+    __syncthreads();
+    return s_ctl[3] != 0;
+  };
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
+    if (claim(tile)) leaf_tail_walk<WAVES>(a, tile, tiles, s_fold, s_level, poison);
+  // sweep: tiles whose workgroup left without claiming them (never, unless launches compete for compute units)
+  for (int base = 0; base < n_tiles; base += static_cast<int>(blockDim.x)) {
+    const int tl = base + static_cast<int>(threadIdx.x);
+    const int open = tl < n_tiles && __hip_atomic_load(a.tail_state + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch - 1;
+    if (__syncthreads_or(open)) {
+      const int end = min(n_tiles, base + static_cast<int>(blockDim.x));
+      for (int t2 = base; t2 < end; ++t2)
+        if (claim(t2)) leaf_tail_walk<WAVES>(a, t2, tiles, s_fold, s_level, poison);
+    }
+  }
+}
 
 // XRAW: the categories are read from the caller's (B, D) int64 batch directly (a.x64), one tile ahead; the staging launch
 // (25.7 MB read + 12.9 MB written + a launch boundary per forward at the north-star configuration) disappears.  A tile
