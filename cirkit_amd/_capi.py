@@ -66,7 +66,18 @@ class LeafLaunch(C.Structure):
         ("x_rows", C.c_void_p),
         ("bad_input", C.c_void_p),
         ("D", C.c_int32),
+        ("tail_write", C.c_int32),
+        ("tail_folds", C.c_void_p),
+        ("tail_level_begin", C.c_void_p),
+        ("tail_n_folds", C.c_int32), ("tail_n_levels", C.c_int32),
+        ("tail_w_layout", C.c_int32),
         ("reserved", C.c_int32),
+        ("tail_bad_input", C.c_void_p),
+        ("ll", C.c_void_p),
+        ("ll_partial", C.c_void_p),
+        ("ll_ticket", C.c_void_p),
+        ("tail_arrive", C.c_void_p),
+        ("tail_state", C.c_void_p),
     ]
 
 

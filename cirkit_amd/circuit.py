@@ -54,6 +54,8 @@ class _Binding:
         self.program_ll = None  # the same followed by ck_ll_sum
         self.store_version = -1
         self.ll: torch.Tensor | None = None
+        self.tail_in_leaf = False  # the last leaf launch walks the tail too (no tail launch)
+        self.tail_sync: tuple | None = None  # (arrival counter, per-tile epochs) of that launch
         self.direct = False  # the leaf launches read the caller's int64 batch themselves (no staged copy of it)
         self.x_last: torch.Tensor | None = None  # ... the batch of the last call (kept alive; read by eager launches)
 
@@ -114,6 +116,11 @@ class HipCircuit:
             the caller's ``(B, D)`` int64 tensor themselves (`ck_leaf_walk_fwd` with a program input): no staging launch,
             no staged copy.  An out-of-range category then makes the outputs of ITS ROW NaN (and `check_inputs()` raise)
             instead of the whole batch's, and later batches are unaffected.  False always stages the batch.
+        merge_tail: the trailing few-fold levels are walked by the persistent leaf launch itself after its segments
+            (`ck_leaf_walk_fwd` with tail_folds: roots stored write-through, arrival counter, 16-row tiles claimed by the
+            resident workgroups) instead of by a launch of their own; same arithmetic per fold as `ck_tail16_lse_fwd`.
+        keep_layer_outputs: False: `forward` does not store the 32-unit fold outputs of a tail walked inside the leaf
+            launch (nobody but `layer_outputs()` reads them; `log_likelihood_sum` never stores them).
     """
 
     def __init__(
@@ -140,6 +147,8 @@ class HipCircuit:
         tail16: bool = True,
         validate_inputs: bool = True,
         direct_input: bool = True,
+        merge_tail: bool = True,
+        keep_layer_outputs: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -185,6 +194,8 @@ class HipCircuit:
         self.tail16 = bool(tail16)
         self.validate_inputs = bool(validate_inputs)
         self.direct_input = bool(direct_input)
+        self.merge_tail = bool(merge_tail)
+        self.keep_layer_outputs = bool(keep_layer_outputs)
         self._recording = False
         self._num_states: torch.Tensor | None = None
         self._states_consistent = True
@@ -475,6 +486,10 @@ class HipCircuit:
         bd.ll = torch.empty(2, dtype=torch.float64, device=self.device)
         self._ensure_param_batch()  # (which leaf launches are persistent depends on the prologue's table jobs)
         bd.direct = self._direct_input(B)
+        bd.tail_in_leaf = self._tail_in_leaf(B)
+        if bd.tail_in_leaf:
+            bd.tail_sync = (torch.zeros(1, dtype=torch.int64, device=self.device),
+                            torch.zeros((B + 15) // 16, dtype=torch.int32, device=self.device))
         bd.program = self._record(bd, with_ll=False)  # the launch list, recorded once
         if bd.direct and self.use_graph and capi.load().ck_program_num_ops(bd.program) > self.graph_min_launches:
             # a hipGraph keeps the pointers of its capture: long launch lists read the staged copy of the batch
@@ -487,6 +502,29 @@ class HipCircuit:
     def _block_gathers(self, slot_dense: np.ndarray) -> bool:
         """Some slot of a CP block / region reads a dense layer tabulated over its categories (a staged-batch consumer)."""
         return any(int(d) in self._tdense for d in np.unique(slot_dense[..., 0]) if d >= 0)
+
+    def _tail_host_group(self) -> int | None:
+        """Root layer of the leaf group whose launch is the last one in front of the tail (None: something else is)."""
+        if not self._tail or not self._groups:
+            return None
+        last = None
+        for i in range(self._tail[0]):
+            if i not in self._virtual:
+                last = i
+        return last if last in self._group_of_root else None
+
+    def _tail_in_leaf(self, B: int) -> bool:
+        """Whether the tail is walked by the last leaf launch (ck_leaf.hip, leaf_tail_phase) at batch size B: that launch
+        is persistent with a fused depth >= 2 and directly precedes the tail; unsigned values; the tail's folds fit its LDS."""
+        root = self._tail_host_group()
+        if not self.merge_tail or root is None or self._signed or not self._tail16_ok() or self.leaf_waves != 8:
+            return False
+        g = self._group_of_root[root]
+        if g.depth < 2 or not self._leaf_is_persistent(g, B):
+            return False
+        folds = sum(self.layers[j].num_folds for j in self._tail)
+        cap = 48 + (((1 << g.depth) - 1) * 4096 - 8192) // 2048
+        return folds <= cap and folds * 80 + (len(self._tail) + 1) * 4 + 16 <= 8192
 
     def _direct_input(self, B: int) -> bool:
         """Whether a forward at batch size B needs no staged copy of the discrete batch: its only readers are persistent
@@ -604,13 +642,13 @@ class HipCircuit:
         B = bd.B
         for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
             if self._tail and i in self._tail:
-                if i == self._tail[0]:
+                if i == self._tail[0] and not bd.tail_in_leaf:
                     self._launch_tail(bd, stream, with_ll=with_ll)
                 continue
             if i in self._virtual:
                 continue
             if i in self._group_of_root:
-                self._launch_group(self._group_of_root[i], bd, view, stream)
+                self._launch_group(self._group_of_root[i], bd, view, stream, with_ll=with_ll)
             elif i in self._tdense:
                 self._launch_table_dense(i, bd, stream)
             elif i in self._emb_gather:
@@ -862,36 +900,7 @@ class HipCircuit:
         ip = C.c_int32 * n
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
         if self._tail16_ok():
-            tabs = bd.cp_tabs.get("tail16")
-            if tabs is None:
-                first, acc = {}, 0
-                for j, l in zip(self._tail, ls):
-                    first[j] = acc
-                    acc += l.num_folds
-                desc = np.zeros(acc, dtype=_TAIL16_FOLD)
-                arena = bd.arena.data_ptr()
-                esz = 8 if self._signed else 4  # (signed: complex64 blocks)
-                for j, l in zip(self._tail, ls):
-                    ch = self._children[j]  # (F, H, 2): producer layer, fold
-                    off = bd.row_off[j].cpu().numpy()
-                    Ko = l.num_output_units
-                    for f in range(l.num_folds):
-                        d = desc[first[j] + f]
-                        d["w"] = l._w.data_ptr() + f * Ko * 32 * 4
-                        d["out"] = bd.views[j].data_ptr() + f * bd.B * Ko * esz
-                        d["H"], d["Ko"] = l.arity, Ko
-                        d["child_src"][:] = -1
-                        for h in range(l.arity):
-                            pj, pf = int(ch[f, h, 0]), int(ch[f, h, 1])
-                            if pj in first and self.layers[pj].num_output_units == 32:
-                                d["child_src"][h] = first[pj] + pf
-                            d["child"][h] = arena + int(off[f, h]) * esz
-                levels = np.asarray([first[j] for j in self._tail] + [acc], dtype=np.int32)
-                tabs = bd.cp_tabs["tail16"] = (
-                    torch.from_numpy(desc.view(np.uint8)).to(self.device), torch.from_numpy(levels).to(self.device), acc,
-                    torch.zeros((bd.B + 15) // 16 + 1, dtype=torch.float64, device=self.device),
-                    torch.zeros(1, dtype=torch.int32, device=self.device))
-            desc_dev, levels_dev, n_folds, scratch, ticket = tabs
+            desc_dev, levels_dev, n_folds, scratch, ticket, lay = self._tail16_tables(bd)
             fuse_ll = with_ll and self._tail_fuses_ll()
             capi.call(
                 "ck_tail16_lse_fwd", desc_dev.data_ptr(), n_folds, levels_dev.data_ptr(), n, bd.B, 32, lay,
@@ -907,6 +916,42 @@ class HipCircuit:
             vp(*[bd.views[j].data_ptr() for j in self._tail]), ip(*[l.num_folds for l in ls]),
             ip(*[l.arity for l in ls]), ip(*[l.num_output_units for l in ls]), bd.B, ls[0].num_input_units, lay, stream,
         )
+
+    def _tail16_tables(self, bd: _Binding) -> tuple:
+        """(fold descriptors, level table, number of folds, per-tile LL sums, LL ticket, weight layout) of the 16-row tail
+        walk -- `ck_tail16_lse_fwd`, or the tail phase of the leaf launch -- for this binding."""
+        ls = [self.layers[j] for j in self._tail]
+        lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
+        tabs = bd.cp_tabs.get("tail16")
+        if tabs is None:
+            first, acc = {}, 0
+            for j, l in zip(self._tail, ls):
+                first[j] = acc
+                acc += l.num_folds
+            desc = np.zeros(acc, dtype=_TAIL16_FOLD)
+            arena = bd.arena.data_ptr()
+            esz = 8 if self._signed else 4  # (signed: complex64 blocks)
+            for j, l in zip(self._tail, ls):
+                ch = self._children[j]  # (F, H, 2): producer layer, fold
+                off = bd.row_off[j].cpu().numpy()
+                Ko = l.num_output_units
+                for f in range(l.num_folds):
+                    d = desc[first[j] + f]
+                    d["w"] = l._w.data_ptr() + f * Ko * 32 * 4
+                    d["out"] = bd.views[j].data_ptr() + f * bd.B * Ko * esz
+                    d["H"], d["Ko"] = l.arity, Ko
+                    d["child_src"][:] = -1
+                    for h in range(l.arity):
+                        pj, pf = int(ch[f, h, 0]), int(ch[f, h, 1])
+                        if pj in first and self.layers[pj].num_output_units == 32:
+                            d["child_src"][h] = first[pj] + pf
+                        d["child"][h] = arena + int(off[f, h]) * esz
+            levels = np.asarray([first[j] for j in self._tail] + [acc], dtype=np.int32)
+            tabs = bd.cp_tabs["tail16"] = (
+                torch.from_numpy(desc.view(np.uint8)).to(self.device), torch.from_numpy(levels).to(self.device), acc,
+                torch.zeros((bd.B + 15) // 16 + 1, dtype=torch.float64, device=self.device),
+                torch.zeros(1, dtype=torch.int32, device=self.device))
+        return (*tabs, lay)
 
     def _group_table(self, g: SubtreeGroup, stream: int | None):
         """The (table, in-kernel dense weight) pair a fused leaf launch reads.  With `dense_on_table`
@@ -947,7 +992,8 @@ class HipCircuit:
             return False
         return self.persistent_leaf is True or self.layers[g.root].num_folds * ((B + 31) // 32) >= self._n_cu
 
-    def _launch_group(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int, *, with_table: bool = False) -> None:
+    def _launch_group(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int, *, with_table: bool = False,
+                      with_ll: bool = False) -> None:
         """One fused launch for Categorical -> [dense] -> CP-T levels (cirkit_amd/csrc/ck_fused.hip)."""
         if self._signed:
             return self._launch_group_signed(g, bd, out, stream)
@@ -967,7 +1013,8 @@ class HipCircuit:
             self._leaf_walk(bd, table=table, scale=scale, scope=cat._scope(self.device), levels=levels, nodes=dev[0],
                             node_off=node_off, leaf_off=g.leaf_off, out=out, work=work, depth=g.depth,
                             K=cat.num_output_units, Cn=cat.num_categories, w_layout=capi.CK_W_TILED_F32, redo=None,
-                            n_roots=F_root, waves=self.leaf_waves, stream=stream)
+                            n_roots=F_root, waves=self.leaf_waves, stream=stream,
+                            tail=(bd.tail_in_leaf and g.root == self._tail_host_group()), with_ll=with_ll)
             return
         capi.call(
             "ck_subtree_cat_cpt_fwd", table.data_ptr(), None if scale is None else scale.data_ptr(), bd.xt_i.data_ptr(),
@@ -1000,7 +1047,7 @@ class HipCircuit:
                         Cn=emb.num_states, w_layout=self._group_layout(g), redo=redo, n_roots=F_root, waves=8, stream=stream)
 
     def _leaf_walk(self, bd: _Binding, *, table, scale, scope, levels, nodes, node_off, leaf_off, out, work, depth, K, Cn,
-                   w_layout, redo, n_roots, waves, stream) -> None:
+                   w_layout, redo, n_roots, waves, stream, tail: bool = False, with_ll: bool = False) -> None:
         """`ck_leaf_walk_fwd`: the persistent leaf launch over the staged batch or -- `bd.direct` -- over the caller's."""
         d = capi.LeafLaunch()
         d.table, d.table_scale, d.scope = table.data_ptr(), scale.data_ptr(), scope.data_ptr()
@@ -1014,6 +1061,18 @@ class HipCircuit:
             d.bad_input = self._bad_input.data_ptr() if self.validate_inputs else None
         else:
             d.xt, d.preclamped, d.x_rows, d.x_input = bd.xt_i.data_ptr(), (1 if self._preclamp() else 0), None, -1
+        if tail:  # the trailing levels inside this launch (leaf_tail_phase)
+            desc_dev, levels_dev, n_folds, scratch, ticket, lay = self._tail16_tables(bd)
+            fuse_ll = with_ll and self._tail_fuses_ll()
+            d.tail_folds, d.tail_level_begin, d.tail_n_folds, d.tail_n_levels = desc_dev.data_ptr(), levels_dev.data_ptr(), n_folds, len(self._tail)
+            d.tail_w_layout = lay
+            # the 32-unit fold outputs of the tail are layer outputs: stored for `forward` unless the caller opted out
+            d.tail_write = 1 if (self.keep_layer_outputs and not with_ll) else 0
+            d.tail_bad_input = self._bad_input.data_ptr() if (self._poison_in_tail() and not bd.direct) else None
+            d.ll = bd.ll.data_ptr() if fuse_ll else None
+            d.ll_partial = scratch.data_ptr() if fuse_ll else None
+            d.ll_ticket = ticket.data_ptr() if fuse_ll else None
+            d.tail_arrive, d.tail_state = bd.tail_sync[0].data_ptr(), bd.tail_sync[1].data_ptr()
         capi.call("ck_leaf_walk_fwd", C.byref(d), stream)
 
     # -- evaluation ------------------------------------------------------------------------------
@@ -1243,13 +1302,16 @@ class HipCircuit:
         if i in self._cp_blocks or i in self._cp_leftover:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root and self._signed:
-            return f"leaf_persistent_kernel<{self._group_of_root[i].depth}, 8, true> (signed: real-valued complex circuit)"
+            raw = "true" if self._direct_input(B) else "false"
+            return f"leaf_persistent_kernel<{self._group_of_root[i].depth}, 8, true, {raw}, false> (signed: real-valued complex circuit)"
         if i in self._group_of_root:
             g = self._group_of_root[i]
             in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)
             if i in self._table_fused and self.linear_levels:
                 if self._leaf_is_persistent(g, B):
-                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}, false>"
+                    raw = "true" if self._direct_input(B) else "false"
+                    tail = "true" if (self._tail_in_leaf(B) and i == self._tail_host_group()) else "false"
+                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}, false, {raw}, {tail}>"
                 return f"subtree_linear_kernel<{g.depth}, {self._group_layout(g)}>"
             return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")
@@ -1351,7 +1413,7 @@ class HipCircuit:
                     self._group_table(self._group_of_root[i], stream)
                 e1.record(cur)
                 if in_tail:
-                    if i == self._tail[0]:
+                    if i == self._tail[0] and not bd.tail_in_leaf:
                         self._launch_tail(bd, stream)
                 elif i in self._virtual:
                     pass
@@ -1443,7 +1505,12 @@ class HipCircuit:
             if i in self._virtual:
                 continue
             if self._tail and i in self._tail:
-                if i == self._tail[-1]:
+                if i == self._tail[-1] and bd.tail_in_leaf:  # walked by the leaf launch: its row stands for these layers too
+                    host = next(r for r in rows if r["layer"] == self._tail_host_group() and "executed_flops" in r)
+                    host["algorithmic_bytes"] += sum(layer_bytes[j] for j in self._tail)
+                    host["algorithmic_flops"] += sum(layer_flops[j] for j in self._tail)
+                    host["executed_flops"] += sum(layer_flops[j] for j in self._tail)
+                elif i == self._tail[-1]:
                     tl = next((self.layers[j]._w_layout for j in self._tail
                                if self.layers[j].num_output_units == 32), 0)
                     rows.append({"layer": self._tail[0], "kernel": (f"tail16_kernel<{tl}, {'true' if self._signed else 'false'}>" if self._tail16_ok() else f"tail_kernel<{tl}>"),

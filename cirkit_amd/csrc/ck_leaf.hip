@@ -109,8 +109,19 @@ struct LeafArgs {
 // Same arithmetic per fold as tail16_kernel (the fold -> wave assignment differs, the values do not).
 constexpr unsigned long long kTailTimeoutTicks = 20000;  // wall_clock64 runs at 100 MHz: 200 us
 
+// LDS of the tail phase (the leaf walk's two arrays, free by then): the [beta][lane] float4 tiles of the tail's folds, 2 KB
+// each, fill the gather slots (`n_main` folds) and go on behind the first kTailCtlFloats floats of the weight array, which
+// hold the fold descriptors, the level table and four control words.
+constexpr int kTailCtlFloats = 2048;
+struct TailTiles {
+  float* main;
+  float* more;
+  int n_main;
+  __device__ __forceinline__ float* of(int t) const { return t < n_main ? main + t * 512 : more + (t - n_main) * 512; }
+};
+
 template <int WAVES>
-__device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, float* tiles, const TailFold* s_fold,
+__device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, const TailTiles& tiles, const TailFold* s_fold,
                                                const int32_t* s_level, bool poison) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 15, kq = lane >> 4;
@@ -142,7 +153,7 @@ __device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, floa
       for (int h = 0; h < H; ++h) {
         const int src = s_fold[t].child_src[h];
         if (src >= 0) {
-          const float* tl = tiles + src * 512 + lane * 4;
+          const float* tl = tiles.of(src) + lane * 4;
 #pragma unroll
           for (int beta = 0; beta < 2; ++beta) {
             const float4 t4 = *reinterpret_cast<const float4*>(tl + beta * 256);
@@ -162,7 +173,7 @@ __device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, floa
       if (Ko == kK) {
         sum_step16(w, v);
         if (a.tail_write && live) tile16_store(out + static_cast<int64_t>(b) * kK + 4 * kq, v);
-        float* tl = tiles + t * 512 + lane * 4;
+        float* tl = tiles.of(t) + lane * 4;
 #pragma unroll
         for (int beta = 0; beta < 2; ++beta)
           *reinterpret_cast<float4*>(tl + beta * 256) = make_float4(v[4 * beta + 0], v[4 * beta + 1], v[4 * beta + 2], v[4 * beta + 3]);
@@ -225,10 +236,10 @@ __device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, floa
 }
 
 template <int WAVES>
-__device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* lds) {
+__device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots, int n_main, float* wbuf) {
   const int n_tiles = (a.B + 15) >> 4;
-  float* tiles = lds;  // [tail fold][beta][lane] float4 tiles, 2 KB each
-  TailFold* s_fold = reinterpret_cast<TailFold*>(tiles + a.tail_n_folds * 512);
+  const TailTiles tiles{slots, wbuf + kTailCtlFloats, n_main};
+  TailFold* s_fold = reinterpret_cast<TailFold*>(wbuf);
   int32_t* s_level = reinterpret_cast<int32_t*>(s_fold + a.tail_n_folds);
   unsigned int* s_ctl = reinterpret_cast<unsigned int*>(s_level + a.tail_n_levels + 1);
   // this workgroup's roots: the write-through stores have completed -> they are at the memory side
@@ -293,9 +304,13 @@ __device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* lds) {
 // XRAW: the categories are read from the caller's (B, D) int64 batch directly (a.x64), one tile ahead; the staging launch
 // (25.7 MB read + 12.9 MB written + a launch boundary per forward at the north-star configuration) disappears.  A tile
 // reads 4 x 32 bytes of each of its 32 batch rows when the root covers a 4 x 4 pixel block (QuadTree): whole sectors.
-template <int D, int WAVES, bool SIGNED, bool XRAW>
+// TAIL: the trailing levels of the circuit are walked by this launch too (leaf_tail_phase above): root tiles are then
+// stored write-through.
+template <int D, int WAVES, bool SIGNED, bool XRAW, bool TAIL = false>
 __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafArgs a) {
   constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2) ? 3 : 2;
+  // (two arrays, not one: with the gather slots at a constant offset inside a single array their addresses became
+  // values in scalar registers -- 110 spilled instead of 36)
   __shared__ __attribute__((aligned(16))) float w_lds[kNodes * 1024];  // subtree weights, in step order
   // gathered leaf tiles, a ring of kSlots 4 KB slots per wave (a gather that misses the XCD's L2 -- six roots' tables,
   // 3.6 MB, are live per XCD -- takes ~1 us: with three slots a leaf is requested three leaves, ~1.5 contractions,
@@ -573,7 +588,8 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j) cur[j] = fmaf(__builtin_amdgcn_logf(cur[j]), kLN2, cs);
-          tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
+          if constexpr (TAIL) tile_store_wt(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
+          else tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
         }
       }
     }
@@ -610,10 +626,17 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             for (int j = 0; j < 16; ++j) fb[j] = __builtin_nanf("");
           }
         }
-        if (b < a.B) tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+        if (b < a.B) {
+          if constexpr (TAIL) tile_store_wt(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+          else tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+        }
       }
     }
     }  // chunk
+  }
+  if constexpr (TAIL) {
+    static_assert(!SIGNED, "the in-launch tail walks unsigned values");
+    leaf_tail_phase<WAVES>(a, g_lds, WAVES * kSlots * 2, w_lds);
   }
 }
 
@@ -652,6 +675,10 @@ __global__ void __launch_bounds__(64) leaf_signed_redo_kernel(const LeafArgs a) 
 
 template <int D, bool XRAW>
 hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_roots, dim3 grid, hipStream_t s) {
+  if (a.tail_folds != nullptr) {  // (checked by the caller: unsigned, 8 waves)
+    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, XRAW, true>), grid, dim3(512), 0, s, a);
+    return hipGetLastError();
+  }
   if (is_signed) {
     hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true, XRAW>), grid, dim3(512), 0, s, a);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
@@ -730,6 +757,32 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
       CK_REQUIRE(slot != nullptr, "ck_leaf_walk_fwd: x_input=%d names a program input, but no program is being recorded on this "
                                   "thread (or the index is out of range)", d->x_input);
     }
+  }
+  if (d->tail_folds != nullptr) {
+    CK_REQUIRE(d->waves == 8 && d->signed_redo == nullptr, "ck_leaf_walk_fwd: the in-launch tail needs 8 waves and unsigned values");
+    CK_REQUIRE(d->tail_level_begin && d->tail_arrive && d->tail_state, "ck_leaf_walk_fwd: tail needs level_begin, arrive and state");
+    CK_REQUIRE(d->tail_n_folds > 0 && d->tail_n_levels > 0 && d->tail_n_levels <= 15, "ck_leaf_walk_fwd: bad tail sizes");
+    CK_REQUIRE(ck::aligned16(d->tail_folds), "ck_leaf_walk_fwd: tail_folds not 16-byte aligned");
+    CK_REQUIRE(d->ll == nullptr || (d->ll_partial != nullptr && d->ll_ticket != nullptr), "ck_leaf_walk_fwd: ll needs ll_partial and ll_ticket");
+    CK_REQUIRE(d->tail_w_layout == CK_W_TILED_F32 || d->tail_w_layout == CK_W_ROWMAJOR, "ck_leaf_walk_fwd: tail weights must be CK_W_TILED_F32 or row-major");
+    // LDS of the tail phase (leaf_tail_phase): fold tiles in the gather slots and behind the control block of the weight array
+    CK_REQUIRE(d->depth >= 2, "ck_leaf_walk_fwd: the in-launch tail needs a fused depth of at least 2 (its control block lives in the weight array)");
+    const size_t ctl = static_cast<size_t>(d->tail_n_folds) * sizeof(TailFold) + (d->tail_n_levels + 1) * sizeof(int32_t) + 16;
+    const int cap = 8 * 3 * 2 + (((1 << d->depth) - 1) * 4096 - kTailCtlFloats * 4) / 2048;
+    if (ctl > kTailCtlFloats * sizeof(float) || d->tail_n_folds > cap)
+      return ck::fail(CK_ERR_UNSUPPORTED, "ck_leaf_walk_fwd: %d tail folds do not fit the launch's LDS (at most %d)", d->tail_n_folds, cap);
+    a.tail_folds = reinterpret_cast<const TailFold*>(d->tail_folds);
+    a.tail_level_begin = d->tail_level_begin;
+    a.tail_n_folds = d->tail_n_folds;
+    a.tail_n_levels = d->tail_n_levels;
+    a.tail_write = d->tail_write;
+    a.tail_w_rowmajor = d->tail_w_layout == CK_W_ROWMAJOR ? 1 : 0;
+    a.tail_bad_input = d->tail_bad_input;
+    a.ll = d->ll;
+    a.ll_partial = d->ll_partial;
+    a.ll_ticket = d->ll_ticket;
+    a.arrive = reinterpret_cast<unsigned long long*>(d->tail_arrive);
+    a.tail_state = d->tail_state;
   }
   const int depth = d->depth, waves = d->waves, n_roots = d->n_roots;
   const bool is_signed = d->signed_redo != nullptr;

@@ -544,91 +544,76 @@ __device__ __forceinline__ float half_reduce_dpp(float v) {
 //   T[c, k] = (theta[k, c] - max_c theta[k, .]) - log sum_c exp(theta[k, c] - max)      (-inf below -103.9, as above)
 //   out[d, c, :] = W_d . exp(T[c, :] - m_c),  out2[d, c] = m_c = max_k T[c, k];  row C: T = 0 (the integral row)
 // Same arithmetic as the job above up to the order of the two reductions over the categories.
-// (`d2` >= 0: the workgroup takes a SECOND fold after the first, whose logits and dense weights are requested together
-// with the first one's -- see softmax_batch_kernel: with one fold per workgroup every workgroup of the launch loads, then
-// computes, then stores at the same time, and the launch takes the SUM of the three phases; with two folds the second
-// fold's 36 KB are on their way while the first one computes and the first one's stores drain while the second computes.)
-__device__ __forceinline__ void softmax_job_table_dense_rows(const ck_softmax_job& j, int d, float* tile, int d2 = -1) {
+__device__ __forceinline__ void softmax_job_table_dense_rows(const ck_softmax_job& j, int d, float* tile) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = j.len, n4 = C >> 2;
   constexpr int K = 32;
   const int ld = C + 4;  // row stride of tile[k][c]: 16-byte aligned rows (C % 4 == 0), conflict-free both ways
-  float* w_s = tile + K * ld;  // [32][32] row-major linear weights of the dense fold
+  const int64_t f = j.idx != nullptr ? j.idx[d] : d;
+  const float4* src = reinterpret_cast<const float4*>(j.in + f * K * C);
+  float* w_s = tile + K * ld;  // [32][32] row-major linear weights of dense fold d
+  float4 x[8];
   const bool on = lane < n4;
-  const int half = lane >> 5, l = lane & 31;
-  constexpr int NW = 16 / kPW;
-  float4 x[2][8];
-  float t[2][NW];
-  const int dd[2] = {d, d2};
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (dd[u] < 0) continue;
-    const int64_t f = j.idx != nullptr ? j.idx[dd[u]] : dd[u];
-    const float4* src = reinterpret_cast<const float4*>(j.in + f * K * C);
+  for (int r = 0; r < 8; ++r)  // unit k = wave + 4 r: one row of C logits per wave and r, all loads in flight
+    x[r] = on ? src[(wave + kPW * r) * n4 + lane] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  {  // W_d: 32 rows of 32, two rows per wave pass (same reduction tree as softmax_job_rows)
+    const int half = lane >> 5, l = lane & 31;
+    const float* th = j.in2 + static_cast<int64_t>(d) * 1024;
+    float t[16 / kPW];
 #pragma unroll
-    for (int r = 0; r < 8; ++r)  // unit k = wave + 4 r: one row of C logits per wave and r, all loads in flight
-      x[u][r] = on ? src[(wave + kPW * r) * n4 + lane] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    const float* th = j.in2 + static_cast<int64_t>(dd[u]) * 1024;
+    for (int it = 0; it < 16 / kPW; ++it) t[it] = th[(it * (2 * kPW) + wave * 2 + half) * 32 + l];
 #pragma unroll
-    for (int it = 0; it < NW; ++it) t[u][it] = th[(it * (2 * kPW) + wave * 2 + half) * 32 + l];
-  }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (dd[u] < 0) continue;
-    if (u == 1) __syncthreads();  // every wave has read the first fold's tile and weights
-    // W_d: 32 rows of 32, two rows per wave pass (same reduction tree as softmax_job_rows)
-#pragma unroll
-    for (int it = 0; it < NW; ++it) {
+    for (int it = 0; it < 16 / kPW; ++it) {
       const int row = it * (2 * kPW) + wave * 2 + half;
       // (reductions over the 32 lanes of a half by DPP / v_permlane16_swap: a __shfl_xor is an LDS round trip per step,
       // ten of them per row in a chain)
-      const float mx = half_reduce_dpp<true>(t[u][it]);
-      const float e = __expf(t[u][it] - mx);
+      const float mx = half_reduce_dpp<true>(t[it]);
+      const float e = __expf(t[it] - mx);
       const float sum = half_reduce_dpp<false>(e);
       w_s[row * 32 + l] = e / sum;
     }
+  }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int k = wave + kPW * r;
-      const float4 xr = x[u][r];
-      const float mx = wave_reduce_dpp<true>(fmaxf(fmaxf(xr.x, xr.y), fmaxf(xr.z, xr.w)));
-      const float4 dl = make_float4(xr.x - mx, xr.y - mx, xr.z - mx, xr.w - mx);
-      const float part = on ? (__expf(dl.x) + __expf(dl.y)) + (__expf(dl.z) + __expf(dl.w)) : 0.f;
-      const float ls = __logf(wave_reduce_dpp<false>(part));
-      if (on) {
-        float4 o;
-        o.x = dl.x < -103.9f ? -INFINITY : dl.x - ls;
-        o.y = dl.y < -103.9f ? -INFINITY : dl.y - ls;
-        o.z = dl.z < -103.9f ? -INFINITY : dl.z - ls;
-        o.w = dl.w < -103.9f ? -INFINITY : dl.w - ls;
-        *reinterpret_cast<float4*>(tile + k * ld + 4 * lane) = o;
-      }
+  for (int r = 0; r < 8; ++r) {
+    const int k = wave + kPW * r;
+    const float mx = wave_reduce_dpp<true>(fmaxf(fmaxf(x[r].x, x[r].y), fmaxf(x[r].z, x[r].w)));
+    const float4 dl = make_float4(x[r].x - mx, x[r].y - mx, x[r].z - mx, x[r].w - mx);
+    const float part = on ? (__expf(dl.x) + __expf(dl.y)) + (__expf(dl.z) + __expf(dl.w)) : 0.f;
+    const float ls = __logf(wave_reduce_dpp<false>(part));
+    if (on) {
+      float4 o;
+      o.x = dl.x < -103.9f ? -INFINITY : dl.x - ls;
+      o.y = dl.y < -103.9f ? -INFINITY : dl.y - ls;
+      o.z = dl.z < -103.9f ? -INFINITY : dl.z - ls;
+      o.w = dl.w < -103.9f ? -INFINITY : dl.w - ls;
+      *reinterpret_cast<float4*>(tile + k * ld + 4 * lane) = o;
     }
-    __syncthreads();
-    WRegs wr;
-    load_w<CK_W_ROWMAJOR>(w_s, lane, wr);
-    const int b_in = lane & 31, kh = lane >> 5;
-    float* dst = j.out + static_cast<int64_t>(dd[u]) * (C + 1) * K;
-    for (int tt0 = wave; tt0 * 32 <= C; tt0 += kPW) {  // 32 categories per register tile, rows 0..C
-      const int c = tt0 * 32 + b_in;
-      const int cl = min(c, C - 1);
-      float v[16];
+  }
+  __syncthreads();
+  WRegs wr;
+  load_w<CK_W_ROWMAJOR>(w_s, lane, wr);
+  const int b_in = lane & 31, kh = lane >> 5;
+  float* dst = j.out + static_cast<int64_t>(d) * (C + 1) * K;
+  for (int t = wave; t * 32 <= C; t += kPW) {  // 32 categories per register tile, rows 0..C
+    const int c = t * 32 + b_in;
+    const int cl = min(c, C - 1);
+    float v[16];
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) v[4 * g + tt] = c >= C ? 0.f : tile[(8 * g + 4 * kh + tt) * ld + cl];  // row C: log sum_c p = 0
-      if (j.kind == 4) {  // out = log(W . exp(T - m)) + m: the dense layer's own output row
-        sum_step<CK_W_ROWMAJOR>(wr, v);
-      } else {  // kind 5: the row stays in linear space with its log scale m stored aside
-        const float m = row_max16(v);
-        const float nml = exp_offset(m, 0.f);
+      for (int tt = 0; tt < 4; ++tt) v[4 * g + tt] = c >= C ? 0.f : tile[(8 * g + 4 * kh + tt) * ld + cl];  // row C: log sum_c p = 0
+    if (j.kind == 4) {  // out = log(W . exp(T - m)) + m: the dense layer's own output row
+      sum_step<CK_W_ROWMAJOR>(wr, v);
+    } else {  // kind 5: the row stays in linear space with its log scale m stored aside
+      const float m = row_max16(v);
+      const float nml = exp_offset(m, 0.f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_exp2f(fmaf(v[r], kL2E, nml));
-        contract_linear<CK_W_ROWMAJOR>(wr, v);
-        if (c <= C && kh == 0) j.out2[static_cast<int64_t>(dd[u]) * (C + 1) + c] = m;
-      }
-      if (c <= C) tile_store(dst + static_cast<int64_t>(c) * K + 4 * kh, v);
+      for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_exp2f(fmaf(v[r], kL2E, nml));
+      contract_linear<CK_W_ROWMAJOR>(wr, v);
+      if (c <= C && kh == 0) j.out2[static_cast<int64_t>(d) * (C + 1) + c] = m;
     }
+    if (c <= C) tile_store(dst + static_cast<int64_t>(c) * K + 4 * kh, v);
   }
 }
 
@@ -891,13 +876,8 @@ __global__ void __launch_bounds__((WIDE ? kPW64 : kPW) * 64) softmax_batch_kerne
     softmax_job_table_rows(j, blk, tile);
   else if (j.kind == 1)
     softmax_job_table(j, blk, tile);
-  else if ((j.kind == 4 || j.kind == 5) && j.k == 32 && rows_form) {
-    // (a job the host gave ceil(rows / 2) workgroups: fold blk and fold blk + ceil(rows / 2) -- the pairing is read off
-    // the block range of the job)
-    const int nblk = (ji + 1 < t.n ? t.job[ji + 1].block_begin : static_cast<int>(gridDim.x)) - j.block_begin;
-    const int d2 = nblk < j.rows ? blk + nblk : -1;
-    softmax_job_table_dense_rows(j, blk, tile, d2 >= 0 && d2 < j.rows ? d2 : -1);
-  }
+  else if ((j.kind == 4 || j.kind == 5) && j.k == 32 && rows_form)
+    softmax_job_table_dense_rows(j, blk, tile);
   else if (j.kind == 4 || j.kind == 5)
     softmax_job_table_dense(j, blk, tile);
   else
@@ -1194,10 +1174,7 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
           if (need > 160 * 1024)
             return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_softmax_batch: C*K=%d too large for the table job", j.len * j.k);
           lds = std::max(lds, need);
-          // two folds per workgroup for the big rows-in-registers table jobs (softmax_job_table_dense_rows): enough
-          // workgroups remain to fill the chip twice over, and a workgroup's second fold is in flight while its first computes
-          const bool pair = (j.kind == 4 || j.kind == 5) && j.k == 32 && j.len <= 256 && (j.len & 3) == 0 && j.rows >= 2 * ck::num_cus();
-          blocks += pair ? static_cast<int>((j.rows + 1) / 2) : static_cast<int>(j.rows);
+          blocks += static_cast<int>(j.rows);
         }
         t.job[t.n++] = j;
       }

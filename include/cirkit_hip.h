@@ -292,9 +292,19 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
  *  as NaN (every launch downstream carries the NaN to the circuit outputs of the row; other rows are unaffected) and
  *  *bad_input (a DEVICE int32 owned by the caller, as ck_stage_categories' flag) is raised; with bad_input == NULL such a
  *  value is evaluated as the integral row (memory-safe, not meaningful).  B * D * 8 must be below 2^32.
+ *  In-launch tail (tail_folds != NULL): the trailing few-fold levels of the circuit -- what ck_tail16_lse_fwd walks as a
+ *  launch of its own, same descriptors, same arithmetic per fold (TorchCPTLayer optimized.py:171-178 / dense TorchSumLayer
+ *  inner.py:266-273 + LSESumSemiring.apply_reduce semiring.py:383-408), same log-likelihood sum -- are evaluated by the
+ *  resident workgroups of this launch after their segments: roots are stored write-through, a workgroup arrives on
+ *  *tail_arrive, waits (at most 200 us) for the other workgroups of the launch, then claims 16-row tiles of the batch in
+ *  tail_state and walks them with the tail's fold outputs in LDS; tiles of workgroups that gave up waiting are walked by
+ *  those that did not (no assumption that all workgroups are resident at once).  The children the descriptors name by
+ *  pointer must be outputs of THIS launch (`out`) or of earlier launches.  tail_arrive / tail_state carry state from one
+ *  launch to the next: every launch that uses them must have the same grid (n_wg, n_seg) and batch size.
  *  x_input >= 0: the call is being RECORDED into a ck_program and the batch pointer is read, at every replay, from that
  *  program's input cell x_input (ck_program_set_input) -- a recorded forward then follows the caller's batch without a
  *  copy.  Not usable with use_graph != 0 launches (a hipGraph keeps the pointer of its capture). */
+struct ck_tail16_fold; /* (defined with ck_tail16_lse_fwd below) */
 typedef struct ck_leaf_launch {
   const float* table;
   const float* table_scale;
@@ -314,7 +324,19 @@ typedef struct ck_leaf_launch {
   const int64_t* x_rows;         /* raw (B, D) int64 batch, or NULL */
   int32_t* bad_input;            /* raw input: validation flag (rows with illegal values become NaN), or NULL */
   int32_t D;                     /* variables per row of the raw batch */
+  int32_t tail_write;            /* tail: also store the 32-unit fold outputs of the tail (they are layer outputs) */
+  /* In-launch tail (tail_folds != NULL; 8 waves, unsigned values): see below. */
+  const struct ck_tail16_fold* tail_folds;  /* DEVICE (tail_n_folds) descriptors in level order, as ck_tail16_lse_fwd */
+  const int32_t* tail_level_begin;          /* DEVICE (tail_n_levels + 1) */
+  int32_t tail_n_folds, tail_n_levels;
+  int32_t tail_w_layout;                    /* CK_W_ROWMAJOR or CK_W_TILED_F32 of the 32-output tail weights */
   int32_t reserved;
+  const int32_t* tail_bad_input;            /* staged batch: ck_stage_categories' flag (NaN outputs), or NULL */
+  double* ll;                               /* NULL, or DEVICE [sum_b log p, B] as ck_tail16_lse_fwd */
+  double* ll_partial;                       /* DEVICE (ceil(B / 16)) */
+  uint32_t* ll_ticket;                      /* DEVICE, zero */
+  uint64_t* tail_arrive;                    /* DEVICE counter, ZERO when first used, owned by this (circuit, batch size) */
+  uint32_t* tail_state;                     /* DEVICE (ceil(B / 16)), ZERO when first used, same owner */
 } ck_leaf_launch;
 int ck_leaf_walk_fwd(const ck_leaf_launch* desc, void* stream);
 

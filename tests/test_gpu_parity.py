@@ -576,6 +576,38 @@ def test_leaf_launch_reads_the_raw_batch(hip_device, B):
     assert not b.reads_batch_directly(B) or b._bindings[B].x_last is not None
 
 
+@pytest.mark.parametrize("B", [1, 33, 1000, 4096, 5000])
+@pytest.mark.parametrize("direct", [True, False])
+def test_tail_walked_by_the_leaf_launch(hip_device, B, direct):
+    """`merge_tail` (default): the trailing few-fold levels are walked by the resident workgroups of the persistent leaf
+    launch after their segments (ck_leaf.hip, leaf_tail_phase: write-through roots, arrival counter, claimed 16-row tiles)
+    -- the same arithmetic per fold as the 16-row tail launch: every tail layer output, the circuit output and the fused
+    log-likelihood sum are bit-identical to the two-launch form; repeated calls reuse the arrival / claim state; with
+    `keep_layer_outputs=False` only the circuit output is stored.  B = 5000: more 16-row tiles than workgroups."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    kw = dict(device=hip_device, persistent_leaf=True, direct_input=direct)
+    a = HipCircuit(plan, tensors, merge_tail=False, **kw)
+    b = HipCircuit(plan, tensors, **kw)
+    c = HipCircuit(plan, tensors, keep_layer_outputs=False, **kw)
+    assert b._bind(B).tail_in_leaf and not a._bind(B).tail_in_leaf
+    assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1
+    assert b.kernel_label(b._groups[0].root, B).endswith("true>")
+    for seed in range(3):
+        x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(7 * B + seed))
+        x[::5, ::7] = -1
+        x = x.to(hip_device)
+        la, lb = a.layer_outputs(x), b.layer_outputs(x)
+        for j in b._tail:
+            assert torch.equal(la[j], lb[j]), j
+        ya = a(x).clone()
+        assert torch.equal(ya, b(x)) and torch.equal(ya, c(x))
+        sa = a.log_likelihood_sum(x).clone()
+        assert torch.equal(sa, b.log_likelihood_sum(x)) and torch.equal(sa, c.log_likelihood_sum(x))
+        assert torch.equal(sa, b.log_likelihood_sum(x))  # (the ticket and the claim epochs are ready for the next launch)
+
+
 def test_raw_batch_is_validated_row_by_row(hip_device):
     """The leaf launches look at low dwords only; the tail launch checks the full 64-bit values of its 16 rows
     (`ck_tail16_walk_fwd`): a row holding a category >= num_categories (an IndexError in the reference, input.py:399-412),
