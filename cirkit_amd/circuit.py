@@ -520,7 +520,7 @@ class HipCircuit:
         if not self.merge_tail or root is None or self._signed or not self._tail16_ok() or self.leaf_waves != 8:
             return False
         g = self._group_of_root[root]
-        if g.depth < 2 or not self._leaf_is_persistent(g, B):
+        if g.depth < 2 or not self._leaf_is_persistent(g, B) or B * 128 >= 2**31:
             return False
         folds = sum(self.layers[j].num_folds for j in self._tail)
         cap = 48 + (((1 << g.depth) - 1) * 4096 - 8192) // 2048

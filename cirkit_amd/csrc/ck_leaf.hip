@@ -44,19 +44,27 @@ static_assert(sizeof(TailFold) == sizeof(ck_tail16_fold), "TailFold mirrors ck_t
 
 // 16-byte accesses that other CUs (other XCDs) must see / that must see other CUs' stores: write-through stores and loads
 // past the non-coherent caches, sc0 sc1 on both sides (MI355X_MICROARCH.md, inter-workgroup visibility) -- no cache-wide
-// release / acquire.  The compiler does not see these memory operations: the waits are explicit.
-__device__ __forceinline__ void store4_wt(float* p, float x, float y, float z, float w) {
-  const f32x4v v = {x, y, z, w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+// release / acquire.  Buffer instructions through the compiler's intrinsics (cache-policy bits in `aux`), NOT inline asm:
+// an asm load's destination registers are fair game for the register allocator before the data has arrived, and the
+// hazard recogniser does not see an asm store's data registers (both observed: memory faults, not wrong digits).
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+constexpr int kAuxWriteThrough = 17;  // gfx940+: bit 0 = sc0, bit 4 = sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_buffer(const void* uniform_base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_base), 0, 0x7fffffff, 0x27000);  // raw dwords, byte offsets
 }
-__device__ __forceinline__ f32x4v load4_wt(const float* p) {
-  f32x4v v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
+__device__ __forceinline__ void store4_wt(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, float x, float y, float z, float w) {
+  const u32x4v v = {__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, kAuxWriteThrough);
 }
-__device__ __forceinline__ void tile_store_wt(float* __restrict__ dst_row, const float (&v)[16]) {
+__device__ __forceinline__ f32x4v load4_wt(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kAuxWriteThrough);
+  return f32x4v{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+}
+// a register tile into the (rows, 32) block at `uniform_block` (32-bit byte offsets inside the block: checked on the host)
+__device__ __forceinline__ void tile_store_wt(const float* uniform_block, uint32_t row_byte_off, const float (&v)[16]) {
+  const __amdgpu_buffer_rsrc_t r = wt_buffer(uniform_block);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) store4_wt(dst_row + 8 * g, v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+  for (int g = 0; g < 4; ++g) store4_wt(r, row_byte_off + 32 * g, v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 
 struct LeafArgs {
@@ -123,34 +131,49 @@ struct TailTiles {
 template <int WAVES>
 __device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, const TailTiles& tiles, const TailFold* s_fold,
                                                const int32_t* s_level, bool poison) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b_in = lane & 15, kq = lane >> 4;
   const int b = tile * 16 + b_in;
   const bool live = b < a.B;
   const int bl = live ? b : a.B - 1;
-  auto load_w = [&](int t, WRegs16& w) {
-    if (a.tail_w_rowmajor) load_w16<CK_W_ROWMAJOR>(s_fold[t].w, lane, w);
-    else load_w16<CK_W_TILED_F32>(s_fold[t].w, lane, w);
+  const uint32_t row_off = static_cast<uint32_t>(bl * kK + 4 * kq) * 4u;  // byte offset of the lane's 16 bytes in a (B, 32) block
+  struct Children {
+    f32x4v m[4][2];
+  };
+  // the children a fold reads from memory (roots of the leaf walk, written by any workgroup of this launch: past the caches)
+  auto fetch = [&](int t, Children& c) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      if (h < s_fold[t].H && s_fold[t].child_src[h] < 0) {  // (uniform: t is)
+        const uint64_t p = reinterpret_cast<uint64_t>(s_fold[t].child[h]);
+        const uint64_t pu = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(p >> 32))) << 32) |
+                            __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(p));
+        const __amdgpu_buffer_rsrc_t r = wt_buffer(reinterpret_cast<const void*>(pu));
+        c.m[h][0] = load4_wt(r, row_off);
+        c.m[h][1] = load4_wt(r, row_off + 64);
+      }
+    }
   };
   for (int li = 0; li < a.tail_n_levels; ++li) {
     const int t1 = s_level[li + 1];
-    for (int t = s_level[li] + wave; t < t1; t += WAVES) {
+    int t = s_level[li] + wave;
+    Children cur, nxt;
+    if (t < t1) fetch(t, cur);
+    for (; t < t1; t += WAVES) {
+      if (t + WAVES < t1) fetch(t + WAVES, nxt);  // the next fold's children are on their way while this one computes
       const int H = s_fold[t].H, Ko = s_fold[t].Ko;
       WRegs16 w;
-      if (Ko == kK) load_w(t, w);  // (parameters: written by an earlier launch, plain loads)
-      // children: folds of the tail from LDS, roots of the leaf walk from memory -- all requests first, one wait
-      f32x4v mem[4][2];
-      for (int h = 0; h < H; ++h)
-        if (s_fold[t].child_src[h] < 0) {
-          const float* row = s_fold[t].child[h] + static_cast<int64_t>(bl) * kK + 4 * kq;
-          mem[h][0] = load4_wt(row);
-          mem[h][1] = load4_wt(row + 16);
-        }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (Ko == kK) {  // (parameters: written by an earlier launch, plain loads)
+        if (a.tail_w_rowmajor) load_w16<CK_W_ROWMAJOR>(s_fold[t].w, lane, w);
+        else load_w16<CK_W_TILED_F32>(s_fold[t].w, lane, w);
+      }
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      for (int h = 0; h < H; ++h) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        if (h >= H) break;
         const int src = s_fold[t].child_src[h];
         if (src >= 0) {
           const float* tl = tiles.of(src) + lane * 4;
@@ -166,7 +189,7 @@ __device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, cons
 #pragma unroll
           for (int beta = 0; beta < 2; ++beta)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * beta + r] += mem[h][beta][r];
+            for (int r = 0; r < 4; ++r) v[4 * beta + r] += cur.m[h][beta][r];
         }
       }
       float* out = s_fold[t].out;
@@ -230,8 +253,9 @@ __device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, cons
           }
         }
       }
+      cur = nxt;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the level's tiles are in LDS
+    __syncthreads();  // the level's tiles are in LDS
   }
 }
 
@@ -242,7 +266,7 @@ __device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots,
   TailFold* s_fold = reinterpret_cast<TailFold*>(wbuf);
   int32_t* s_level = reinterpret_cast<int32_t*>(s_fold + a.tail_n_folds);
   unsigned int* s_ctl = reinterpret_cast<unsigned int*>(s_level + a.tail_n_levels + 1);
-  // this workgroup's roots: the write-through stores have completed -> they are at the memory side
+  // this workgroup's roots: once the write-through stores have completed they are at the memory side
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // (every wave has left the walk: its LDS is free)
   if (threadIdx.x == 0) {
@@ -588,7 +612,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j) cur[j] = fmaf(__builtin_amdgcn_logf(cur[j]), kLN2, cs);
-          if constexpr (TAIL) tile_store_wt(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
+          if constexpr (TAIL) tile_store_wt(a.out + static_cast<int64_t>(t) * a.B * kK, static_cast<uint32_t>(b * kK + 4 * kh) * 4u, cur);
           else tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
         }
       }
@@ -627,7 +651,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           }
         }
         if (b < a.B) {
-          if constexpr (TAIL) tile_store_wt(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+          if constexpr (TAIL) tile_store_wt(a.out + static_cast<int64_t>(t) * a.B * kK, static_cast<uint32_t>(b * kK + 4 * kh) * 4u, fb);
           else tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
         }
       }
@@ -762,6 +786,7 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
     CK_REQUIRE(d->waves == 8 && d->signed_redo == nullptr, "ck_leaf_walk_fwd: the in-launch tail needs 8 waves and unsigned values");
     CK_REQUIRE(d->tail_level_begin && d->tail_arrive && d->tail_state, "ck_leaf_walk_fwd: tail needs level_begin, arrive and state");
     CK_REQUIRE(d->tail_n_folds > 0 && d->tail_n_levels > 0 && d->tail_n_levels <= 15, "ck_leaf_walk_fwd: bad tail sizes");
+    CK_REQUIRE(static_cast<int64_t>(d->B) * kK * 4 < (int64_t{1} << 31), "ck_leaf_walk_fwd: B=%d rows exceed the 32-bit offsets of the in-launch tail", d->B);
     CK_REQUIRE(ck::aligned16(d->tail_folds), "ck_leaf_walk_fwd: tail_folds not 16-byte aligned");
     CK_REQUIRE(d->ll == nullptr || (d->ll_partial != nullptr && d->ll_ticket != nullptr), "ck_leaf_walk_fwd: ll needs ll_partial and ll_ticket");
     CK_REQUIRE(d->tail_w_layout == CK_W_TILED_F32 || d->tail_w_layout == CK_W_ROWMAJOR, "ck_leaf_walk_fwd: tail weights must be CK_W_TILED_F32 or row-major");
