@@ -147,8 +147,10 @@ __device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, cons
     for (int h = 0; h < 4; ++h) {
       if (h < s_fold[t].H && s_fold[t].child_src[h] < 0) {  // (uniform: t is)
         const uint64_t p = reinterpret_cast<uint64_t>(s_fold[t].child[h]);
-        const uint64_t pu = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(p >> 32))) << 32) |
-                            __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(p));
+        // (readfirstlane returns a signed int: through uint32_t, or a set bit 31 of the low half smears into the high half)
+        const uint32_t p_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(p))));
+        const uint32_t p_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(p >> 32))));
+        const uint64_t pu = (static_cast<uint64_t>(p_hi) << 32) | p_lo;
         const __amdgpu_buffer_rsrc_t r = wt_buffer(reinterpret_cast<const void*>(pu));
         c.m[h][0] = load4_wt(r, row_off);
         c.m[h][1] = load4_wt(r, row_off + 64);
