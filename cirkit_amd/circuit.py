@@ -147,7 +147,7 @@ class HipCircuit:
         tail16: bool = True,
         validate_inputs: bool = True,
         direct_input: bool = True,
-        merge_tail: bool = True,
+        merge_tail: bool = False,
         keep_layer_outputs: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
@@ -1073,6 +1073,8 @@ class HipCircuit:
             d.ll_partial = scratch.data_ptr() if fuse_ll else None
             d.ll_ticket = ticket.data_ptr() if fuse_ll else None
             d.tail_arrive, d.tail_state = bd.tail_sync[0].data_ptr(), bd.tail_sync[1].data_ptr()
+            import os as _os
+            d.reserved = int(_os.environ.get("CK_TAIL_DBG", "0"))
         capi.call("ck_leaf_walk_fwd", C.byref(d), stream)
 
     # -- evaluation ------------------------------------------------------------------------------

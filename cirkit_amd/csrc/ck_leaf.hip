@@ -98,6 +98,7 @@ struct LeafArgs {
   unsigned int* ll_ticket;
   unsigned long long* arrive;    // monotonic arrival counter of the launches of this binding
   unsigned int* tail_state;      // (ceil(B / 16)) epoch in which each 16-row tile was last claimed
+  int dbg;
 };
 
 // ---- the tail of the circuit inside the leaf launch -------------------------------------------------------------------
@@ -286,6 +287,7 @@ __device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots,
   }
   __syncthreads();
   const unsigned int epoch = s_ctl[0];
+  if (a.dbg & 8) return;
   if (threadIdx.x == 0) {
     const unsigned long long target = static_cast<unsigned long long>(epoch) * gridDim.x;
     const unsigned long long t0 = wall_clock64();
@@ -313,8 +315,10 @@ __device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots,
     __syncthreads();
     return s_ctl[3] != 0;
   };
+  if (a.dbg & 4) return;
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
-    if (claim(tile)) leaf_tail_walk<WAVES>(a, tile, tiles, s_fold, s_level, poison);
+    if (claim(tile) && !(a.dbg & 1)) leaf_tail_walk<WAVES>(a, tile, tiles, s_fold, s_level, poison);
+  if (a.dbg & 2) return;
   // sweep: tiles whose workgroup left without claiming them (never, unless launches compete for compute units)
   for (int base = 0; base < n_tiles; base += static_cast<int>(blockDim.x)) {
     const int tl = base + static_cast<int>(threadIdx.x);
@@ -810,6 +814,7 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
     a.ll_ticket = d->ll_ticket;
     a.arrive = reinterpret_cast<unsigned long long*>(d->tail_arrive);
     a.tail_state = d->tail_state;
+    a.dbg = d->reserved;
   }
   const int depth = d->depth, waves = d->waves, n_roots = d->n_roots;
   const bool is_signed = d->signed_redo != nullptr;

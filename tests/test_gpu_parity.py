@@ -579,7 +579,7 @@ def test_leaf_launch_reads_the_raw_batch(hip_device, B):
 @pytest.mark.parametrize("B", [1, 33, 1000, 4096, 5000])
 @pytest.mark.parametrize("direct", [True, False])
 def test_tail_walked_by_the_leaf_launch(hip_device, B, direct):
-    """`merge_tail` (default): the trailing few-fold levels are walked by the resident workgroups of the persistent leaf
+    """`merge_tail=True`: the trailing few-fold levels are walked by the resident workgroups of the persistent leaf
     launch after their segments (ck_leaf.hip, leaf_tail_phase: write-through roots, arrival counter, claimed 16-row tiles)
     -- the same arithmetic per fold as the 16-row tail launch: every tail layer output, the circuit output and the fused
     log-likelihood sum are bit-identical to the two-launch form; repeated calls reuse the arrival / claim state; with
@@ -589,8 +589,8 @@ def test_tail_walked_by_the_leaf_launch(hip_device, B, direct):
     plan, tensors, g = load_case("cfg2_qt784")
     kw = dict(device=hip_device, persistent_leaf=True, direct_input=direct)
     a = HipCircuit(plan, tensors, merge_tail=False, **kw)
-    b = HipCircuit(plan, tensors, **kw)
-    c = HipCircuit(plan, tensors, keep_layer_outputs=False, **kw)
+    b = HipCircuit(plan, tensors, merge_tail=True, **kw)
+    c = HipCircuit(plan, tensors, merge_tail=True, keep_layer_outputs=False, **kw)
     assert b._bind(B).tail_in_leaf and not a._bind(B).tail_in_leaf
     assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1
     assert b.kernel_label(b._groups[0].root, B).endswith("true>")
