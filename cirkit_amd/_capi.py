@@ -78,6 +78,16 @@ class LeafLaunch(C.Structure):
         ("ll_ticket", C.c_void_p),
         ("tail_arrive", C.c_void_p),
         ("tail_state", C.c_void_p),
+        ("cat_logits", C.c_void_p),
+        ("cat_idx", C.c_void_p),
+        ("dense_logits", C.c_void_p),
+        ("w_logits", C.POINTER(C.c_void_p)),
+        ("groot_off", C.c_void_p),
+        ("groot", C.c_void_p),
+        ("params_arrive", C.c_void_p),
+        ("xjobs", C.c_void_p),
+        ("n_xjobs", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 

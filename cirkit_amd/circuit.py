@@ -54,6 +54,8 @@ class _Binding:
         self.program_ll = None  # the same followed by ck_ll_sum
         self.store_version = -1
         self.ll: torch.Tensor | None = None
+        self.params_in_leaf = False  # the leaf launch evaluates its parameters (no prologue launch for them)
+        self.params_sync: torch.Tensor | None = None
         self.tail_in_leaf = False  # the last leaf launch walks the tail too (no tail launch)
         self.tail_sync: tuple | None = None  # (arrival counter, per-tile epochs) of that launch
         self.direct = False  # the leaf launches read the caller's int64 batch themselves (no staged copy of it)
@@ -119,6 +121,10 @@ class HipCircuit:
         merge_tail: the trailing few-fold levels are walked by the persistent leaf launch itself after its segments
             (`ck_leaf_walk_fwd` with tail_folds: roots stored write-through, arrival counter, 16-row tiles claimed by the
             resident workgroups) instead of by a launch of their own; same arithmetic per fold as `ck_tail16_lse_fwd`.
+        inlaunch_params: the persistent leaf launch evaluates the parameter graphs it depends on itself (`ck_leaf_walk_fwd` with
+            cat_logits: the Categorical log-tables pushed through their dense folds, the weights of its levels, and the
+            32-wide softmaxes of the layers behind it) with the device functions of the prologue launch -- same bits -- so
+            that a forward has no parameter launch in front of it.  Needs one leaf group, C <= 256, exact fp32.
         keep_layer_outputs: False: `forward` does not store the 32-unit fold outputs of a tail walked inside the leaf
             launch (nobody but `layer_outputs()` reads them; `log_likelihood_sum` never stores them).
     """
@@ -149,6 +155,7 @@ class HipCircuit:
         direct_input: bool = True,
         merge_tail: bool = False,
         keep_layer_outputs: bool = True,
+        inlaunch_params: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -196,6 +203,8 @@ class HipCircuit:
         self.direct_input = bool(direct_input)
         self.merge_tail = bool(merge_tail)
         self.keep_layer_outputs = bool(keep_layer_outputs)
+        self.inlaunch_params = bool(inlaunch_params)
+        self._inlaunch: dict | None = None
         self._recording = False
         self._num_states: torch.Tensor | None = None
         self._states_consistent = True
@@ -487,6 +496,9 @@ class HipCircuit:
         self._ensure_param_batch()  # (which leaf launches are persistent depends on the prologue's table jobs)
         bd.direct = self._direct_input(B)
         bd.tail_in_leaf = self._tail_in_leaf(B)
+        bd.params_in_leaf = self._params_in_leaf(B)
+        if bd.params_in_leaf:
+            bd.params_sync = torch.zeros(8 * 16, dtype=torch.int64, device=self.device)
         if bd.tail_in_leaf:
             bd.tail_sync = (torch.zeros(1, dtype=torch.int64, device=self.device),
                             torch.zeros((B + 15) // 16, dtype=torch.int32, device=self.device))
@@ -558,7 +570,7 @@ class HipCircuit:
         self._recording = True
         try:
             if not self.cache_params:
-                self._enqueue_params(0)
+                self._enqueue_params(0, in_leaf=bd.params_in_leaf)
             self._enqueue_layers(bd, 0, with_ll=with_ll)
             if self.validate_inputs and self._int_input and not bd.direct and not self._poison_in_tail() and not self._complex:
                 for p, f in self._out_pairs:
@@ -603,11 +615,18 @@ class HipCircuit:
         store's back (e.g. by an optimiser kernel writing through a raw pointer)."""
         self.store.touch()
 
-    def _enqueue_params(self, stream: int) -> None:
+    def _enqueue_params(self, stream: int, *, in_leaf: bool = False) -> None:
         """Everything that depends on the parameters only (the reference re-evaluates the parameter
         graphs on every forward, parameters/parameter.py:180-188): the batched softmax prologue, the
-        remaining parameter graphs, table re-layouts, and the dense layer pushed through the table."""
-        self._launch_param_batch(stream)
+        remaining parameter graphs, table re-layouts, and the dense layer pushed through the table.
+        `in_leaf`: the persistent leaf launch evaluates what `_plan_inlaunch_params` assigned to it; only the rest is
+        launched here."""
+        if in_leaf:
+            self._ensure_param_batch()
+            if self._inlaunch["rest"] is not None:
+                self._inlaunch["rest"].launch(stream)
+        else:
+            self._launch_param_batch(stream)
         for l in self.layers:
             l.prepare(stream, batched=self.batch_params)
         for g in self._groups:
@@ -804,6 +823,15 @@ class HipCircuit:
         capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), None, oo.data_ptr(),
                   bd.arena.data_ptr(), None, None, None, 0, len(folds), 1, 1, bd.B, K, stream)
 
+    def _enqueue_params_batch_only(self, stream: int, bd: _Binding) -> None:
+        """The prologue launch of a forward of this binding (profiling): all jobs, or what the leaf launch leaves."""
+        if bd.params_in_leaf:
+            self._ensure_param_batch()
+            if self._inlaunch["rest"] is not None:
+                self._inlaunch["rest"].launch(stream)
+        else:
+            self._launch_param_batch(stream)
+
     def _launch_param_batch(self, stream: int) -> None:
         if not self.batch_params:
             return
@@ -819,11 +847,63 @@ class HipCircuit:
             self._batch = ParamBatch()
             self._assign_weight_layouts()
             covered = self._register_table_jobs(self._batch)
+            self._jobs_of_layer: dict[int, list[int]] = {}
             for i, l in enumerate(self.layers):
                 l._batched = i in covered
                 if i not in covered:
+                    n0 = len(self._batch._jobs)
                     l.register_batched(self._batch)
+                    self._jobs_of_layer[i] = list(range(n0, len(self._batch._jobs)))
+            self._inlaunch = self._plan_inlaunch_params()
             self._batch_version = self.store.version
+
+    def _plan_inlaunch_params(self) -> dict | None:
+        """Which jobs of the prologue the persistent leaf launch can take over (`inlaunch_params`): the table job of the
+        (single) leaf group, the softmaxes of its level weights, and every other 32-wide softmax; what is left stays a
+        (smaller, often empty) prologue launch.  None: nothing is taken over."""
+        if not (self.inlaunch_params and self.batch_params and not self.cache_params and self.contraction == "f32"
+                and len(self._groups) == 1 and not self._signed and self.leaf_waves == 8):
+            return None
+        g = self._groups[0]
+        cat = self.layers[g.input_layer]
+        if (g.root not in self._table_fused or g.depth < 2 or not self.linear_levels or cat.num_categories > 256
+                or cat.num_categories % 4 or self._group_layout(g) != capi.CK_W_TILED_F32):
+            return None
+        meta = self._batch._meta
+        table = [k for k, m in enumerate(meta) if m["kind"] == 5 and m["dst"] is self._group_dev[g.root][1]]
+        if len(table) != 1:
+            return None
+        taken = set(table)
+        levels = []
+        for j in g.levels:
+            jobs = self._jobs_of_layer.get(j, [])
+            if len(jobs) != 1 or meta[jobs[0]]["kind"] != 2 or tuple(meta[jobs[0]]["src"].shape[1:]) != (32, 32):
+                return None
+            levels.append(meta[jobs[0]]["src"])
+            taken.add(jobs[0])
+        xjobs = []
+        for k, m in enumerate(meta):
+            if k in taken or m["kind"] not in (0, 2) or m["src"].shape[-1] != 32 or not m["src"].is_contiguous():
+                continue
+            src, dst = m["src"], m["dst"]
+            rows = src.numel() // 32
+            per = 32 if (src.dim() >= 2 and src.shape[-2] == 32) else (rows if rows <= 32 and m["kind"] == 0 else 0)
+            if per == 0 or (m["kind"] == 2 and per != 32):
+                continue
+            for f in range(rows // per):
+                xjobs.append((src.data_ptr() + f * per * 128, dst.data_ptr() + f * per * 128, per, 1 if m["kind"] == 2 else 0))
+            taken.add(k)
+        xj = np.zeros(max(1, len(xjobs)), dtype=np.dtype([("in", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("tiled", "<i4")]))
+        for r, t in zip(xj, xjobs):
+            r["in"], r["out"], r["rows"], r["tiled"] = t
+        rest = [k for k in range(len(meta)) if k not in taken]
+        return {"root": g.root, "table": meta[table[0]], "levels": levels, "n_xjobs": len(xjobs),
+                "xjobs": torch.from_numpy(xj.view(np.uint8)).to(self.device), "rest": self._batch.subset(rest) if rest else None}
+
+    def _params_in_leaf(self, B: int) -> bool:
+        """Whether the leaf launch of a forward at batch size B evaluates the parameters (it is the persistent launch)."""
+        return (self._inlaunch is not None and self._leaf_is_persistent(self._groups[0], B)
+                and not self._tail_in_leaf(B))
 
     def _register_table_jobs(self, batch: ParamBatch) -> set[int]:
         """`dense_on_table` inside the prologue: for a leaf group whose Categorical probabilities and
@@ -1010,6 +1090,7 @@ class HipCircuit:
             if work is None:
                 work = bd.cp_tabs[(g.root, "leaf_work")] = torch.from_numpy(
                     leaf_segments(F_root, n_tiles, self._n_cu)).to(self.device)
+            self._leaf_walk_root = g.root
             self._leaf_walk(bd, table=table, scale=scale, scope=cat._scope(self.device), levels=levels, nodes=dev[0],
                             node_off=node_off, leaf_off=g.leaf_off, out=out, work=work, depth=g.depth,
                             K=cat.num_output_units, Cn=cat.num_categories, w_layout=capi.CK_W_TILED_F32, redo=None,
@@ -1061,6 +1142,26 @@ class HipCircuit:
             d.bad_input = self._bad_input.data_ptr() if self.validate_inputs else None
         else:
             d.xt, d.preclamped, d.x_rows, d.x_input = bd.xt_i.data_ptr(), (1 if self._preclamp() else 0), None, -1
+        if bd.params_in_leaf and self._inlaunch is not None and self._inlaunch["root"] == getattr(self, "_leaf_walk_root", None):
+            il = self._inlaunch
+            d.cat_logits, d.dense_logits = il["table"]["src"].data_ptr(), il["table"]["dense"].data_ptr()
+            d.cat_idx = None if il["table"]["idx"] is None else il["table"]["idx"].data_ptr()
+            d.w_logits = (C.c_void_p * depth)(*[t.data_ptr() for t in il["levels"]])
+            groups = bd.cp_tabs.get("groot")
+            if groups is None:
+                segs = work.cpu().numpy()
+                n_wg = min(self._n_cu, segs.shape[0])
+                roots: list[list[int]] = [[] for _ in range(8)]
+                for sidx in range(segs.shape[0]):
+                    r, g8 = int(segs[sidx, 0]), (sidx % n_wg) % 8
+                    if r not in roots[g8]:
+                        roots[g8].append(r)
+                off = np.cumsum([0] + [len(r) for r in roots]).astype(np.int32)
+                flat = np.asarray([r for rs in roots for r in rs] or [0], dtype=np.int32)
+                groups = bd.cp_tabs["groot"] = (torch.from_numpy(off).to(self.device), torch.from_numpy(flat).to(self.device))
+            d.groot_off, d.groot = groups[0].data_ptr(), groups[1].data_ptr()
+            d.params_arrive = bd.params_sync.data_ptr()
+            d.xjobs, d.n_xjobs = il["xjobs"].data_ptr(), il["n_xjobs"]
         if tail:  # the trailing levels inside this launch (leaf_tail_phase)
             desc_dev, levels_dev, n_folds, scratch, ticket, lay = self._tail16_tables(bd)
             fuse_ll = with_ll and self._tail_fuses_ll()
@@ -1073,8 +1174,6 @@ class HipCircuit:
             d.ll_partial = scratch.data_ptr() if fuse_ll else None
             d.ll_ticket = ticket.data_ptr() if fuse_ll else None
             d.tail_arrive, d.tail_state = bd.tail_sync[0].data_ptr(), bd.tail_sync[1].data_ptr()
-            import os as _os
-            d.reserved = int(_os.environ.get("CK_TAIL_DBG", "0"))
         capi.call("ck_leaf_walk_fwd", C.byref(d), stream)
 
     # -- evaluation ------------------------------------------------------------------------------
@@ -1305,7 +1404,7 @@ class HipCircuit:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root and self._signed:
             raw = "true" if self._direct_input(B) else "false"
-            return f"leaf_persistent_kernel<{self._group_of_root[i].depth}, 8, true, {raw}, false> (signed: real-valued complex circuit)"
+            return f"leaf_persistent_kernel<{self._group_of_root[i].depth}, 8, true, {raw}, false, false> (signed: real-valued complex circuit)"
         if i in self._group_of_root:
             g = self._group_of_root[i]
             in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)
@@ -1313,7 +1412,8 @@ class HipCircuit:
                 if self._leaf_is_persistent(g, B):
                     raw = "true" if self._direct_input(B) else "false"
                     tail = "true" if (self._tail_in_leaf(B) and i == self._tail_host_group()) else "false"
-                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}, false, {raw}, {tail}>"
+                    par = "true" if self._params_in_leaf(B) else "false"
+                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}, false, {raw}, {tail}, {par}>"
                 return f"subtree_linear_kernel<{g.depth}, {self._group_layout(g)}>"
             return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")
@@ -1404,7 +1504,7 @@ class HipCircuit:
                 e2 = torch.cuda.Event(enable_timing=True)
                 e0.record(cur)
                 if i == 0:
-                    self._launch_param_batch(stream)
+                    self._enqueue_params_batch_only(stream, bd)
                 in_tail = bool(self._tail) and i in self._tail
                 if in_tail and i == self._tail[0]:
                     for j in self._tail:
@@ -1475,7 +1575,8 @@ class HipCircuit:
                         per_fold = int(np.prod(shp[1:])) * (8 if "complex" in dt else 4)
                         pbytes += per_fold * n.num_folds
             has_prep = bool(s.params) and not (self.batch_params and l._batched)
-            if i == 0 and self.batch_params and self._batch is not None and len(self._batch):
+            if i == 0 and self.batch_params and self._batch is not None and len(self._batch) and not (
+                    bd.params_in_leaf and self._inlaunch["rest"] is None):
                 rows.append({"layer": 0, "kernel": "softmax_batch_kernel<false>", "ms": float(mean[0]),
                              "algorithmic_bytes": float(2 * sum(
                                  int(np.prod(shp)) * 4 for shp, _ in self.plan.tensors.values()))})

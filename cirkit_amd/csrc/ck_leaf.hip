@@ -23,6 +23,7 @@
 #include <utility>
 
 #include "ck_internal.h"
+#include "ck_softmax.h"
 #include "ck_tile.h"
 #include "ck_tile16.h"
 
@@ -98,7 +99,16 @@ struct LeafArgs {
   unsigned int* ll_ticket;
   unsigned long long* arrive;    // monotonic arrival counter of the launches of this binding
   unsigned int* tail_state;      // (ceil(B / 16)) epoch in which each 16-row tile was last claimed
-  int dbg;
+  // PARAMS: the launch evaluates the parameters it reads -- see leaf_params_phase
+  const float* cat_logits;       // (F_cat, 32, C) logits of the Categorical layer
+  const int64_t* cat_idx;        // (F0) Categorical fold of each table (dense) fold, or nullptr: the identity
+  const float* dense_logits;     // (F0, 32, 32) logits of the dense layer pushed through the table
+  const float* wraw[kMaxDepthP]; // wraw[l-1]: (F_l, 32, 32) logits of the weights of CP-T level l
+  const int32_t* groot_off;      // (9): roots whose tables the workgroups b with b % 8 == g build are groot[groot_off[g] .. groot_off[g + 1])
+  const int32_t* groot;
+  unsigned long long* parrive;   // 8 arrival counters, 16 words apart
+  const ck_rows32_job* xjobs;    // other 32-wide softmaxes (weights of the layers behind this launch)
+  int n_xjobs;
 };
 
 // ---- the tail of the circuit inside the leaf launch -------------------------------------------------------------------
@@ -287,7 +297,6 @@ __device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots,
   }
   __syncthreads();
   const unsigned int epoch = s_ctl[0];
-  if (a.dbg & 8) return;
   if (threadIdx.x == 0) {
     const unsigned long long target = static_cast<unsigned long long>(epoch) * gridDim.x;
     const unsigned long long t0 = wall_clock64();
@@ -315,10 +324,8 @@ __device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots,
     __syncthreads();
     return s_ctl[3] != 0;
   };
-  if (a.dbg & 4) return;
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
-    if (claim(tile) && !(a.dbg & 1)) leaf_tail_walk<WAVES>(a, tile, tiles, s_fold, s_level, poison);
-  if (a.dbg & 2) return;
+    if (claim(tile)) leaf_tail_walk<WAVES>(a, tile, tiles, s_fold, s_level, poison);
   // sweep: tiles whose workgroup left without claiming them (never, unless launches compete for compute units)
   for (int base = 0; base < n_tiles; base += static_cast<int>(blockDim.x)) {
     const int tl = base + static_cast<int>(threadIdx.x);
@@ -331,12 +338,105 @@ __device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots,
   }
 }
 
+// ---- the parameters of the launch, evaluated by the launch ------------------------------------------------------------
+// The reference re-evaluates every parameter graph on every forward (parameters/parameter.py:180-188); as a launch of its
+// own (ck_param_softmax_batch) that is 21 us in front of a 70 us leaf launch at the north-star configuration -- 784
+// table jobs that all load, then all compute, then all store -- although it is ~6 us of work per compute unit.  PARAMS:
+//   * the 8 waves of a workgroup run TWO table jobs at a time (ck_softmax.h: the Categorical log-table of a leaf pushed
+//     through its dense fold, 4 waves each, tiles in the gather slots that the walk does not need yet); the workgroups
+//     b with b % 8 == g (one XCD, as workgroups are placed today -- nothing depends on it) share out the tables of the
+//     roots that any of them walks (groot), 3-4 jobs each; the table rows are stored write-through;
+//   * they then meet on an arrival counter of their own (32 pollers on one line, not 256).  A workgroup that has waited
+//     200 us builds every table of its class itself: the jobs are idempotent -- whoever runs them writes the same bits --
+//     so no workgroup ever depends on another one being resident;
+//   * the 2^D - 1 weight matrices of a segment's root are softmaxed from their logits straight into the LDS layout the
+//     walk reads (no tiled copy in memory, no DMA), and the 32-wide softmaxes of the layers BEHIND this launch (xjobs:
+//     the weights the tail launch reads) are dealt to the workgroups, one matrix each.
+// Same functions, same arithmetic as the prologue launch: bit-identical tables, weights and outputs.
+constexpr unsigned long long kParamsTimeoutTicks = 20000;  // wall_clock64 at 100 MHz: 200 us
+
+template <int D, int WAVES>
+__device__ __forceinline__ void leaf_params_phase(const LeafArgs& a, float* slots) {
+  static_assert(WAVES == 8, "two table jobs of four waves each");
+  constexpr int kLeaves = 1 << D;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = wave >> 2, w4 = wave & 3, kh = lane >> 5;
+  const int C = a.C;
+  float* tile = slots + half * (32 * (C + 4) + 1024);
+  float* const table_w = const_cast<float*>(a.table);
+  float* const scale_w = const_cast<float*>(a.scale);
+  const int grp = blockIdx.x & 7, rank = blockIdx.x >> 3;
+  const int gsize = (static_cast<int>(gridDim.x) - grp + 7) >> 3;  // workgroups of this class
+  const int r0 = a.groot_off[grp], n_jobs = (a.groot_off[grp + 1] - r0) * kLeaves;
+  auto sync = [] { __syncthreads(); };
+  auto run_jobs = [&](int first, int stride) {
+    for (int j0 = first; j0 < n_jobs; j0 += stride) {
+      const int j = j0 + half;
+      const float *theta = nullptr, *theta_w = nullptr;
+      int d = 0;
+      if (j < n_jobs) {
+        const int root = a.groot[r0 + j / kLeaves];
+        d = a.nodes[a.node_off[0] + root * kLeaves + j % kLeaves];
+        const int64_t f = a.cat_idx != nullptr ? a.cat_idx[d] : d;
+        theta = a.cat_logits + f * 32 * C;
+        theta_w = a.dense_logits + static_cast<int64_t>(d) * 1024;
+      }
+      const __amdgpu_buffer_rsrc_t rt = wt_buffer(table_w + static_cast<int64_t>(d) * (C + 1) * 32);
+      const __amdgpu_buffer_rsrc_t rs = wt_buffer(scale_w + static_cast<int64_t>(d) * (C + 1));
+      table_dense_rows<4, true>(theta, theta_w, C, tile, w4, lane, sync, [&](int c, const float (&v)[16], float m) {
+        if (c <= C) {
+          if (kh == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rs, static_cast<uint32_t>(c) * 4u, 0, kAuxWriteThrough);
+          const uint32_t off = static_cast<uint32_t>(c * 32 + 4 * kh) * 4u;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) store4_wt(rt, off + 32 * g, v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        }
+      });
+      __syncthreads();  // (the tiles are free for the next pair of jobs)
+    }
+  };
+  run_jobs(rank * 2, gsize * 2);
+  // 32-wide softmaxes of other layers: one (rows <= 32, 32) block per workgroup turn, two rows per wave pass
+  for (int x = blockIdx.x; x < a.n_xjobs; x += gridDim.x) {
+    const ck_rows32_job xj = a.xjobs[x];
+    softmax_rows32<2>(xj.in, xj.rows, wave, 8, lane, [&](int row, int l, float p) { xj.out[w32_index(row, l, xj.tiled != 0)] = p; });
+  }
+  // this workgroup's tables are at the memory side once its write-through stores have completed: arrive, wait for the class
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ unsigned int s_alone;
+  if (threadIdx.x == 0) {
+    unsigned long long* ctr = a.parrive + grp * 16;
+    const unsigned long long n = static_cast<unsigned long long>(gsize);
+    const unsigned long long old = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (old / n + 1) * n;
+    const unsigned long long t0 = wall_clock64();
+    unsigned int alone = 0;
+    if (old + 1 < target)
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > kParamsTimeoutTicks) {
+          alone = 1;
+          break;
+        }
+      }
+    s_alone = alone;
+  }
+  __syncthreads();
+  if (s_alone != 0) {  // (never, unless launches compete for compute units) every table of the class, here
+    run_jobs(0, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 // XRAW: the categories are read from the caller's (B, D) int64 batch directly (a.x64), one tile ahead; the staging launch
 // (25.7 MB read + 12.9 MB written + a launch boundary per forward at the north-star configuration) disappears.  A tile
 // reads 4 x 32 bytes of each of its 32 batch rows when the root covers a 4 x 4 pixel block (QuadTree): whole sectors.
 // TAIL: the trailing levels of the circuit are walked by this launch too (leaf_tail_phase above): root tiles are then
 // stored write-through.
-template <int D, int WAVES, bool SIGNED, bool XRAW, bool TAIL = false>
+// PARAMS: tables and weights are evaluated by this launch from the raw parameters (leaf_params_phase above).
+template <int D, int WAVES, bool SIGNED, bool XRAW, bool TAIL = false, bool PARAMS = false>
 __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafArgs a) {
   constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2) ? 3 : 2;
   // (two arrays, not one: with the gather slots at a constant offset inside a single array their addresses became
@@ -364,6 +464,8 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
 #pragma unroll
   for (int q = 0; q < 2; ++q) g_coff[q] = ((lane & 7) ^ ((4 * q + (lane >> 4)) & 7)) * 16;
 
+  if constexpr (PARAMS) leaf_params_phase<D, WAVES>(a, g_lds);
+
   for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
     const int t = a.work[4 * seg], tile_begin = a.work[4 * seg + 1], tile_end = a.work[4 * seg + 2];
     if (seg != static_cast<int>(blockIdx.x)) __syncthreads();  // every wave has left the previous segment
@@ -373,6 +475,12 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       static_for<0, steps_after(i)>([&](auto lc) {
         constexpr int l = decltype(lc)::value, k = steps_before(i) + l;
         const int fold = a.nodes[a.node_off[l + 1] + t * (kLeaves >> (l + 1)) + (i >> (l + 1))];
+        if constexpr (PARAMS) {
+          // softmax of the fold's (32, 32) logits straight into the walk's LDS layout: rows 2 * wave + half and + 16 of it
+          softmax_rows32<2>(a.wraw[l] + static_cast<int64_t>(fold) * 1024, 32, wave, WAVES, lane,
+                            [&](int row, int ll, float p) { w_lds[k * 1024 + w32_index(row, ll, true)] = p; });
+          return;
+        }
         // lane's 16 bytes of chunk q: tiled, dword 256 q + 4 lane; row-major, W[lane & 31][8 q + 4 (lane >> 5) ..] (ck_tile.h)
         const float* src = a.w[l] + static_cast<int64_t>(fold) * 1024 + (a.w_rowmajor ? (lane & 31) * 32 + 4 * (lane >> 5) : lane * 4);
         const int qstride = a.w_rowmajor ? 8 : 256;
@@ -705,6 +813,10 @@ __global__ void __launch_bounds__(64) leaf_signed_redo_kernel(const LeafArgs a) 
 
 template <int D, bool XRAW>
 hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_roots, dim3 grid, hipStream_t s) {
+  if (a.cat_logits != nullptr) {  // (checked by the caller: unsigned, 8 waves, no in-launch tail)
+    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, XRAW, false, true>), grid, dim3(512), 0, s, a);
+    return hipGetLastError();
+  }
   if (a.tail_folds != nullptr) {  // (checked by the caller: unsigned, 8 waves)
     hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, XRAW, true>), grid, dim3(512), 0, s, a);
     return hipGetLastError();
@@ -757,7 +869,7 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
   a.xt = d->xt;
   a.scope = d->scope;
   for (int l = 0; l < d->depth; ++l) {
-    CK_REQUIRE(d->w_levels[l] != nullptr && ck::aligned16(d->w_levels[l]), "ck_leaf_walk_fwd: bad weights of level %d", l + 1);
+    CK_REQUIRE(d->cat_logits != nullptr || (d->w_levels[l] != nullptr && ck::aligned16(d->w_levels[l])), "ck_leaf_walk_fwd: bad weights of level %d", l + 1);
     a.w[l] = d->w_levels[l];
   }
   a.nodes = d->nodes;
@@ -814,7 +926,28 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
     a.ll_ticket = d->ll_ticket;
     a.arrive = reinterpret_cast<unsigned long long*>(d->tail_arrive);
     a.tail_state = d->tail_state;
-    a.dbg = d->reserved;
+  }
+  if (d->cat_logits != nullptr) {
+    CK_REQUIRE(d->waves == 8 && d->signed_redo == nullptr && d->tail_folds == nullptr,
+               "ck_leaf_walk_fwd: parameters are evaluated in-launch by 8-wave, unsigned launches without a tail");
+    CK_REQUIRE(d->dense_logits && d->w_logits && d->groot_off && d->groot && d->params_arrive, "ck_leaf_walk_fwd: in-launch parameters need "
+               "dense_logits, w_logits, groot_off, groot and params_arrive");
+    CK_REQUIRE(d->w_layout == CK_W_TILED_F32, "ck_leaf_walk_fwd: in-launch weights are written in the tiled layout");
+    CK_REQUIRE(d->C <= 256 && (d->C & 3) == 0 && d->depth >= 2, "ck_leaf_walk_fwd: in-launch tables need C <= 256, C %% 4 == 0 and depth >= 2 "
+               "(two 32 x (C + 4) tiles in the gather slots)");
+    CK_REQUIRE(d->n_xjobs == 0 || d->xjobs != nullptr, "ck_leaf_walk_fwd: xjobs is null");
+    a.cat_logits = d->cat_logits;
+    a.cat_idx = d->cat_idx;
+    a.dense_logits = d->dense_logits;
+    for (int l = 0; l < d->depth; ++l) {
+      CK_REQUIRE(d->w_logits[l] != nullptr, "ck_leaf_walk_fwd: no logits for the weights of level %d", l + 1);
+      a.wraw[l] = d->w_logits[l];
+    }
+    a.groot_off = d->groot_off;
+    a.groot = d->groot;
+    a.parrive = reinterpret_cast<unsigned long long*>(d->params_arrive);
+    a.xjobs = d->xjobs;
+    a.n_xjobs = d->n_xjobs;
   }
   const int depth = d->depth, waves = d->waves, n_roots = d->n_roots;
   const bool is_signed = d->signed_redo != nullptr;

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "ck_internal.h"
+#include "ck_softmax.h"
 #include "ck_tile.h"
 
 namespace {
@@ -238,9 +239,6 @@ __device__ __forceinline__ void softmax_rows_medium(const ck_softmax_job& j, int
     }
   }
 }
-
-template <bool MAX>
-__device__ __forceinline__ float half_reduce_dpp(float v);  // (below: over each 32-lane half of a wave, no LDS)
 
 __device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int blk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -520,23 +518,6 @@ __device__ __forceinline__ void softmax_job_table_dense(const ck_softmax_job& j,
   }
 }
 
-template <bool MAX>
-__device__ __forceinline__ float wave_reduce_dpp(float v) {
-  return ck::wave_reduce<MAX>(v);  // (ck_internal.h)
-}
-
-// the same over each 32-lane half of a wave (rows of 32 weights, two rows per wave)
-template <bool MAX>
-__device__ __forceinline__ float half_reduce_dpp(float v) {
-  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x140, 0xF, 0xF, true)));  // row_mirror
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);  // rows 0<->1, 2<->3
-  return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-
 // kind 5 for C <= 256, C % 4 == 0 (the usual Categorical sizes): a wave holds a whole (unit, all categories) row of
 // logits in registers -- one float4 per lane -- so the per-unit maximum and log-sum-exp are wave reductions in registers
 // (the job above makes two passes over the logits in LDS for them: 8 of its 22 us at config 2), and the tile in LDS
@@ -545,75 +526,25 @@ __device__ __forceinline__ float half_reduce_dpp(float v) {
 //   out[d, c, :] = W_d . exp(T[c, :] - m_c),  out2[d, c] = m_c = max_k T[c, k];  row C: T = 0 (the integral row)
 // Same arithmetic as the job above up to the order of the two reductions over the categories.
 __device__ __forceinline__ void softmax_job_table_dense_rows(const ck_softmax_job& j, int d, float* tile) {
+  // (the job itself lives in ck_softmax.h: the persistent leaf launch runs it too)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int C = j.len, n4 = C >> 2;
+  const int C = j.len;
   constexpr int K = 32;
-  const int ld = C + 4;  // row stride of tile[k][c]: 16-byte aligned rows (C % 4 == 0), conflict-free both ways
   const int64_t f = j.idx != nullptr ? j.idx[d] : d;
-  const float4* src = reinterpret_cast<const float4*>(j.in + f * K * C);
-  float* w_s = tile + K * ld;  // [32][32] row-major linear weights of dense fold d
-  float4 x[8];
-  const bool on = lane < n4;
-#pragma unroll
-  for (int r = 0; r < 8; ++r)  // unit k = wave + 4 r: one row of C logits per wave and r, all loads in flight
-    x[r] = on ? src[(wave + kPW * r) * n4 + lane] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-  {  // W_d: 32 rows of 32, two rows per wave pass (same reduction tree as softmax_job_rows)
-    const int half = lane >> 5, l = lane & 31;
-    const float* th = j.in2 + static_cast<int64_t>(d) * 1024;
-    float t[16 / kPW];
-#pragma unroll
-    for (int it = 0; it < 16 / kPW; ++it) t[it] = th[(it * (2 * kPW) + wave * 2 + half) * 32 + l];
-#pragma unroll
-    for (int it = 0; it < 16 / kPW; ++it) {
-      const int row = it * (2 * kPW) + wave * 2 + half;
-      // (reductions over the 32 lanes of a half by DPP / v_permlane16_swap: a __shfl_xor is an LDS round trip per step,
-      // ten of them per row in a chain)
-      const float mx = half_reduce_dpp<true>(t[it]);
-      const float e = __expf(t[it] - mx);
-      const float sum = half_reduce_dpp<false>(e);
-      w_s[row * 32 + l] = e / sum;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int k = wave + kPW * r;
-    const float mx = wave_reduce_dpp<true>(fmaxf(fmaxf(x[r].x, x[r].y), fmaxf(x[r].z, x[r].w)));
-    const float4 dl = make_float4(x[r].x - mx, x[r].y - mx, x[r].z - mx, x[r].w - mx);
-    const float part = on ? (__expf(dl.x) + __expf(dl.y)) + (__expf(dl.z) + __expf(dl.w)) : 0.f;
-    const float ls = __logf(wave_reduce_dpp<false>(part));
-    if (on) {
-      float4 o;
-      o.x = dl.x < -103.9f ? -INFINITY : dl.x - ls;
-      o.y = dl.y < -103.9f ? -INFINITY : dl.y - ls;
-      o.z = dl.z < -103.9f ? -INFINITY : dl.z - ls;
-      o.w = dl.w < -103.9f ? -INFINITY : dl.w - ls;
-      *reinterpret_cast<float4*>(tile + k * ld + 4 * lane) = o;
-    }
-  }
-  __syncthreads();
-  WRegs wr;
-  load_w<CK_W_ROWMAJOR>(w_s, lane, wr);
-  const int b_in = lane & 31, kh = lane >> 5;
+  const float* theta = j.in + f * K * C;
+  const float* theta_w = j.in2 + static_cast<int64_t>(d) * 1024;
   float* dst = j.out + static_cast<int64_t>(d) * (C + 1) * K;
-  for (int t = wave; t * 32 <= C; t += kPW) {  // 32 categories per register tile, rows 0..C
-    const int c = t * 32 + b_in;
-    const int cl = min(c, C - 1);
-    float v[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) v[4 * g + tt] = c >= C ? 0.f : tile[(8 * g + 4 * kh + tt) * ld + cl];  // row C: log sum_c p = 0
-    if (j.kind == 4) {  // out = log(W . exp(T - m)) + m: the dense layer's own output row
-      sum_step<CK_W_ROWMAJOR>(wr, v);
-    } else {  // kind 5: the row stays in linear space with its log scale m stored aside
-      const float m = row_max16(v);
-      const float nml = exp_offset(m, 0.f);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = __builtin_amdgcn_exp2f(fmaf(v[r], kL2E, nml));
-      contract_linear<CK_W_ROWMAJOR>(wr, v);
+  const int kh = lane >> 5;
+  auto sync = [] { __syncthreads(); };
+  if (j.kind == 4) {
+    table_dense_rows<kPW, false>(theta, theta_w, C, tile, wave, lane, sync, [&](int c, const float (&v)[16], float) {
+      if (c <= C) tile_store(dst + static_cast<int64_t>(c) * K + 4 * kh, v);
+    });
+  } else {
+    table_dense_rows<kPW, true>(theta, theta_w, C, tile, wave, lane, sync, [&](int c, const float (&v)[16], float m) {
       if (c <= C && kh == 0) j.out2[static_cast<int64_t>(d) * (C + 1) + c] = m;
-    }
-    if (c <= C) tile_store(dst + static_cast<int64_t>(c) * K + 4 * kh, v);
+      if (c <= C) tile_store(dst + static_cast<int64_t>(c) * K + 4 * kh, v);
+    });
   }
 }
 

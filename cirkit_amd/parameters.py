@@ -89,7 +89,17 @@ class ParamBatch:
     def __init__(self) -> None:
         self._jobs: list[tuple] = []
         self._keep: list[torch.Tensor] = []
+        self._meta: list[dict] = []  # per job: its kind and tensors (for whoever takes a job over, HipCircuit._plan_inlaunch_params)
         self._arr = None
+
+    def subset(self, indices) -> "ParamBatch":
+        """A batch of the listed jobs only (same tensors)."""
+        pb = ParamBatch()
+        for i in indices:
+            pb._jobs.append(self._jobs[i])
+            pb._meta.append(self._meta[i])
+        pb._keep = list(self._keep)
+        return pb
 
     def add_softmax(self, src: torch.Tensor, dst: torch.Tensor, layout: int = 0) -> None:
         """dst = softmax(src, dim=-1); both (..., len) contiguous fp32.  `layout` 1 / 2 writes the
@@ -97,6 +107,7 @@ class ParamBatch:
         rows = src.numel() // src.shape[-1]
         kind = {0: 0, 1: 2, 2: 3}[layout]
         self._jobs.append((src.data_ptr(), dst.data_ptr(), rows, int(src.shape[-1]), 0, kind, None, None, None))
+        self._meta.append({"kind": kind, "src": src, "dst": dst})
         self._keep += [src, dst]
         self._arr = None
 
@@ -104,6 +115,7 @@ class ParamBatch:
         """src (F, K, C) logits -> dst (F, C+1, K) = log softmax over C, transposed; row C = 0."""
         F, K, Cc = src.shape
         self._jobs.append((src.data_ptr(), dst.data_ptr(), int(F), int(Cc), int(K), 1, None, None, None))
+        self._meta.append({"kind": 1, "src": src, "dst": dst})
         self._keep += [src, dst]
         self._arr = None
 
@@ -119,6 +131,7 @@ class ParamBatch:
         self._jobs.append((src.data_ptr(), dst.data_ptr(), int(dense_src.shape[0]), int(Cc), int(K), 4 if scale is None else 5,
                            dense_src.data_ptr(), None if idx is None else idx.data_ptr(),
                            None if scale is None else scale.data_ptr()))
+        self._meta.append({"kind": 4 if scale is None else 5, "src": src, "dense": dense_src, "idx": idx, "dst": dst, "scale": scale})
         self._keep += [src, dense_src, dst] + ([] if idx is None else [idx]) + ([] if scale is None else [scale])
         self._arr = None
 

@@ -301,10 +301,27 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
  *  those that did not (no assumption that all workgroups are resident at once).  The children the descriptors name by
  *  pointer must be outputs of THIS launch (`out`) or of earlier launches.  tail_arrive / tail_state carry state from one
  *  launch to the next: every launch that uses them must have the same grid (n_wg, n_seg) and batch size.
+ *  In-launch parameters (cat_logits != NULL): the launch evaluates the parameter graphs it depends on itself -- what
+ *  ck_param_softmax_batch does as a launch of its own (parameters/parameter.py:180-188: re-evaluated on every forward),
+ *  with the same device functions, bit for bit: `table` / `table_scale` are then OUTPUTS of the launch (kind-5 job: the
+ *  log-table of Categorical fold cat_idx[d] pushed through dense fold d, rows linear + log scales; layers/input.py:399-412,
+ *  layers/inner.py:266-273) built by the workgroups b, b % 8 == g, for the roots groot[groot_off[g] ..) -- every root a
+ *  workgroup of the class walks must be listed -- and stored write-through; the class then meets on params_arrive[16 g]
+ *  (a workgroup that has waited 200 us builds all tables of its class itself: the jobs are idempotent).  w_levels is
+ *  not read: a segment's weights are softmaxed from w_logits straight into LDS.  xjobs: further 32-wide softmaxes (weights
+ *  of the layers behind this launch), one job per workgroup turn, plain stores (visible to later launches).
  *  x_input >= 0: the call is being RECORDED into a ck_program and the batch pointer is read, at every replay, from that
  *  program's input cell x_input (ck_program_set_input) -- a recorded forward then follows the caller's batch without a
  *  copy.  Not usable with use_graph != 0 launches (a hipGraph keeps the pointer of its capture). */
 struct ck_tail16_fold; /* (defined with ck_tail16_lse_fwd below) */
+/* out = softmax over the last axis of a (rows <= 32, 32) block of logits; tiled != 0: written in CK_W_TILED_F32 order
+ * (rows must then be 32) instead of row-major -- one 32-wide parameter graph tensor -> softmax (nodes.py) */
+typedef struct ck_rows32_job {
+  const float* in;
+  float* out;
+  int32_t rows;
+  int32_t tiled;
+} ck_rows32_job;
 typedef struct ck_leaf_launch {
   const float* table;
   const float* table_scale;
@@ -337,6 +354,17 @@ typedef struct ck_leaf_launch {
   uint32_t* ll_ticket;                      /* DEVICE, zero */
   uint64_t* tail_arrive;                    /* DEVICE counter, ZERO when first used, owned by this (circuit, batch size) */
   uint32_t* tail_state;                     /* DEVICE (ceil(B / 16)), ZERO when first used, same owner */
+  /* In-launch parameters (cat_logits != NULL; 8 waves, unsigned, CK_W_TILED_F32, no in-launch tail): see below. */
+  const float* cat_logits;                  /* DEVICE (F_cat, 32, C) logits of the Categorical layer */
+  const int64_t* cat_idx;                   /* DEVICE (F0) Categorical fold of each table fold, or NULL: the identity */
+  const float* dense_logits;                /* DEVICE (F0, 32, 32) logits of the dense layer pushed through the table */
+  const float* const* w_logits;             /* HOST array of `depth` DEVICE pointers: (F_l, 32, 32) logits of the level weights */
+  const int32_t* groot_off;                 /* DEVICE (9) */
+  const int32_t* groot;                     /* DEVICE: roots whose tables the workgroups b, b % 8 == g, build: groot[groot_off[g] .. groot_off[g+1]) */
+  uint64_t* params_arrive;                  /* DEVICE 8 x 16 words, ZERO when first used, owned by this (circuit, batch size) */
+  const struct ck_rows32_job* xjobs;        /* DEVICE (n_xjobs), or NULL */
+  int32_t n_xjobs;
+  int32_t reserved2;
 } ck_leaf_launch;
 int ck_leaf_walk_fwd(const ck_leaf_launch* desc, void* stream);
 
