@@ -118,13 +118,16 @@ class HipCircuit:
             the caller's ``(B, D)`` int64 tensor themselves (`ck_leaf_walk_fwd` with a program input): no staging launch,
             no staged copy.  An out-of-range category then makes the outputs of ITS ROW NaN (and `check_inputs()` raise)
             instead of the whole batch's, and later batches are unaffected.  False always stages the batch.
-        merge_tail: the trailing few-fold levels are walked by the persistent leaf launch itself after its segments
+        merge_tail: (off by default: 11 us slower than the tail launch as it stands) the trailing
+            few-fold levels are walked by the persistent leaf launch itself after its segments
             (`ck_leaf_walk_fwd` with tail_folds: roots stored write-through, arrival counter, 16-row tiles claimed by the
             resident workgroups) instead of by a launch of their own; same arithmetic per fold as `ck_tail16_lse_fwd`.
         inlaunch_params: the persistent leaf launch evaluates the parameter graphs it depends on itself (`ck_leaf_walk_fwd` with
             cat_logits: the Categorical log-tables pushed through their dense folds, the weights of its levels, and the
             32-wide softmaxes of the layers behind it) with the device functions of the prologue launch -- same bits -- so
-            that a forward has no parameter launch in front of it.  Needs one leaf group, C <= 256, exact fp32.
+            that a forward has no parameter launch in front of it.  Needs one leaf group, C <= 256, exact fp32.  Off by
+            default: measured at the north-star configuration the phase costs the leaf launch 30 us + 4 us of waiting,
+            the prologue launch it replaces 21 us.
         keep_layer_outputs: False: `forward` does not store the 32-unit fold outputs of a tail walked inside the leaf
             launch (nobody but `layer_outputs()` reads them; `log_likelihood_sum` never stores them).
     """
@@ -155,7 +158,7 @@ class HipCircuit:
         direct_input: bool = True,
         merge_tail: bool = False,
         keep_layer_outputs: bool = True,
-        inlaunch_params: bool = True,
+        inlaunch_params: bool = False,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")

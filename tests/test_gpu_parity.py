@@ -587,7 +587,7 @@ def test_tail_walked_by_the_leaf_launch(hip_device, B, direct):
     from cirkit_amd.circuit import HipCircuit
 
     plan, tensors, g = load_case("cfg2_qt784")
-    kw = dict(device=hip_device, persistent_leaf=True, direct_input=direct)
+    kw = dict(device=hip_device, persistent_leaf=True, direct_input=direct, inlaunch_params=False)
     a = HipCircuit(plan, tensors, merge_tail=False, **kw)
     b = HipCircuit(plan, tensors, merge_tail=True, **kw)
     c = HipCircuit(plan, tensors, merge_tail=True, keep_layer_outputs=False, **kw)
@@ -610,7 +610,7 @@ def test_tail_walked_by_the_leaf_launch(hip_device, B, direct):
 
 @pytest.mark.parametrize("B", [33, 1000, 4096])
 def test_leaf_launch_evaluates_its_parameters(hip_device, B):
-    """`inlaunch_params` (default): the persistent leaf launch builds the Categorical log-tables (pushed through their dense
+    """`inlaunch_params=True`: the persistent leaf launch builds the Categorical log-tables (pushed through their dense
     folds), softmaxes the weights of its levels straight into LDS and deals out the 32-wide softmaxes of the layers behind
     it -- the jobs of the prologue launch (ck_param_softmax_batch), run by the same device functions: tables, log scales,
     tail weights and circuit outputs are bit-identical to the two-launch form, also after the parameters have changed
@@ -621,7 +621,7 @@ def test_leaf_launch_evaluates_its_parameters(hip_device, B):
     tensors = {k: np.array(v, copy=True) for k, v in tensors.items()}
     kw = dict(device=hip_device, persistent_leaf=True)
     a = HipCircuit(plan, tensors, inlaunch_params=False, **kw)
-    b = HipCircuit(plan, tensors, **kw)
+    b = HipCircuit(plan, tensors, inlaunch_params=True, **kw)
     assert b._bind(B).params_in_leaf and not a._bind(B).params_in_leaf
     assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1 and b._inlaunch["rest"] is None
     assert b.kernel_label(b._groups[0].root, B).endswith("true>")
