@@ -252,9 +252,20 @@ __device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, cons
             }
             ticket = __shfl(ticket, 0, 64);
             if (ticket == n_tiles - 1) {
-              double tot = 0.0;
-              for (unsigned int g = lane; g < n_tiles; g += 64)
-                tot += __hip_atomic_load(a.ll_partial + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              double tot = 0.0;  // (four past-the-cache loads in flight per lane, as ck_tail16.hip)
+              const __amdgpu_buffer_rsrc_t rp = wt_buffer(a.ll_partial);
+              for (unsigned int g0 = 0; g0 < n_tiles; g0 += 256) {
+                typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+                u32x2v pv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const unsigned int g = g0 + lane + 64 * k;
+                  pv[k] = g < n_tiles ? __builtin_amdgcn_raw_buffer_load_b64(rp, g * 8u, 0, kAuxWriteThrough) : u32x2v{0u, 0u};
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  if (g0 + lane + 64 * k < n_tiles) tot += __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(pv[k].y) << 32) | pv[k].x));
+              }
 #pragma unroll
               for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
               if (lane == 0) {
