@@ -87,7 +87,7 @@ class LeafLaunch(C.Structure):
         ("params_arrive", C.c_void_p),
         ("xjobs", C.c_void_p),
         ("n_xjobs", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("x_pairs", C.c_int32),
     ]
 
 

@@ -1094,6 +1094,7 @@ class HipCircuit:
                 work = bd.cp_tabs[(g.root, "leaf_work")] = torch.from_numpy(
                     leaf_segments(F_root, n_tiles, self._n_cu)).to(self.device)
             self._leaf_walk_root = g.root
+            self._leaf_walk_pairs = self._leaves_in_adjacent_pairs(g)
             self._leaf_walk(bd, table=table, scale=scale, scope=cat._scope(self.device), levels=levels, nodes=dev[0],
                             node_off=node_off, leaf_off=g.leaf_off, out=out, work=work, depth=g.depth,
                             K=cat.num_output_units, Cn=cat.num_categories, w_layout=capi.CK_W_TILED_F32, redo=None,
@@ -1126,9 +1127,24 @@ class HipCircuit:
                 torch.from_numpy(leaf_segments(F_root, n_tiles, self._n_cu)).to(self.device),
                 torch.zeros(F_root * n_tiles, dtype=torch.int32, device=self.device))
         segs, redo = work
+        self._leaf_walk_root = g.root
+        self._leaf_walk_pairs = self._leaves_in_adjacent_pairs(g)
         self._leaf_walk(bd, table=emb._table, scale=dev[1], scope=emb._scope(self.device), levels=levels, nodes=dev[0],
                         node_off=node_off, leaf_off=g.leaf_off, out=out, work=segs, depth=g.depth, K=emb.num_output_units,
                         Cn=emb.num_states, w_layout=self._group_layout(g), redo=redo, n_roots=F_root, waves=8, stream=stream)
+
+    def _leaves_in_adjacent_pairs(self, g: SubtreeGroup) -> bool:
+        """Leaves 2j and 2j + 1 of every root of the group read variables v and v + 1, v even (what region graphs over
+        images give): the raw batch is then fetched with one 16-byte load per pair of leaves."""
+        hit = self._group_dev.get(("pairs", g.root))
+        if hit is None:
+            kl = 1 << g.depth
+            leaf_ids = np.asarray(g.nodes[g.leaf_off:g.leaf_off + self.layers[g.root].num_folds * kl]).reshape(-1, kl)
+            var = self.layers[g.input_layer].scope_idx[:, 0][leaf_ids]
+            hit = bool(kl >= 4 and self.plan.num_variables % 2 == 0 and np.all(var[:, 0::2] % 2 == 0)
+                       and np.all(var[:, 1::2] == var[:, 0::2] + 1))
+            self._group_dev[("pairs", g.root)] = hit
+        return hit
 
     def _leaf_walk(self, bd: _Binding, *, table, scale, scope, levels, nodes, node_off, leaf_off, out, work, depth, K, Cn,
                    w_layout, redo, n_roots, waves, stream, tail: bool = False, with_ll: bool = False) -> None:
@@ -1143,6 +1159,7 @@ class HipCircuit:
             d.xt, d.preclamped, d.D = None, 0, self.plan.num_variables
             d.x_rows, d.x_input = self._raw_batch_args(bd)
             d.bad_input = self._bad_input.data_ptr() if self.validate_inputs else None
+            d.x_pairs = 1 if getattr(self, "_leaf_walk_pairs", False) else 0
         else:
             d.xt, d.preclamped, d.x_rows, d.x_input = bd.xt_i.data_ptr(), (1 if self._preclamp() else 0), None, -1
         if bd.params_in_leaf and self._inlaunch is not None and self._inlaunch["root"] == getattr(self, "_leaf_walk_root", None):

@@ -87,6 +87,7 @@ struct LeafArgs {
   const int64_t* x64;
   int D;
   int32_t* bad_flag;  // XRAW: raised (atomicOr 1) when a row holds an illegal value; nullptr = rows are not checked
+  int x_pairs;        // XRAW: leaves 2j, 2j + 1 of every root read adjacent, 16-byte aligned variables (one load per pair)
   // TAIL: the trailing few-fold levels (ck_tail16.hip's walk) inside this launch -- see leaf_tail_phase
   const TailFold* tail_folds;    // (tail_n_folds) in level order
   const int32_t* tail_level_begin;  // (tail_n_levels + 1)
@@ -527,6 +528,24 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       // (a uniform pointer + a 32-bit lane offset: no 64-bit lane arithmetic per load)
       if constexpr (XRAW) {
         const uint32_t rowb = static_cast<uint32_t>(batch_row(tile)) * (static_cast<uint32_t>(a.D) * 8u);
+        if constexpr (kLeaves >= 4) {
+          if (a.x_pairs) {
+            // leaves 2j and 2j + 1 read ADJACENT variables of the batch (16-byte aligned: checked on the host) -- what a
+            // region graph over an image gives -- so lane (b, kh) takes the two values of leaves 4m + 2kh, 4m + 2kh + 1
+            // with ONE 16-byte load: xv[4m .. 4m + 3] = (low, high, low, high); half the line requests again
+#pragma unroll
+            for (int m = 0; m < kLeaves / 4; ++m) {
+              uint32_t off = rowb + (kh ? static_cast<uint32_t>(var_off[4 * m + 2]) : static_cast<uint32_t>(var_off[4 * m])) * 8u;
+              asm volatile("" : "+v"(off));
+              const int4 t = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.x64) + off);
+              xv[4 * m] = t.x;
+              xv[4 * m + 1] = t.y;
+              xv[4 * m + 2] = t.z;
+              xv[4 * m + 3] = t.w;
+            }
+            return;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < kLeaves / 2; ++j) {
           uint32_t off = rowb + (kh ? static_cast<uint32_t>(var_off[2 * j + 1]) : static_cast<uint32_t>(var_off[2 * j])) * 8u;
@@ -551,6 +570,21 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     auto pack_categories = [&](const RawT (&xv)[kLeaves], uint32_t (&cp)[kLeaves / 2]) -> uint32_t {
       const uint32_t uc = static_cast<uint32_t>(a.C);
       uint32_t bad = 0;
+      if constexpr (XRAW && kLeaves >= 4) {
+        if (a.x_pairs) {  // (see load_x) lane (b, kh) holds leaves 4m + 2kh and 4m + 2kh + 1: the packed pair 2m + kh
+#pragma unroll
+          for (int m = 0; m < kLeaves / 4; ++m) {
+            const int32_t lo0 = xv[4 * m], hi0 = xv[4 * m + 1], lo1 = xv[4 * m + 2], hi1 = xv[4 * m + 3];
+            bad |= static_cast<uint32_t>((hi0 != (lo0 >> 31)) | (lo0 >= a.C) | (hi1 != (lo1 >> 31)) | (lo1 >= a.C));
+            const uint32_t mine = min(static_cast<uint32_t>(lo0), uc) | (min(static_cast<uint32_t>(lo1), uc) << 16);
+            const auto r = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+            cp[2 * m] = r[0];
+            cp[2 * m + 1] = r[1];
+          }
+          const auto rb = __builtin_amdgcn_permlane32_swap(bad, bad, false, false);
+          return a.bad_flag != nullptr ? (rb[0] | rb[1]) : 0u;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < kLeaves / 2; ++j) {
         if constexpr (XRAW) {
@@ -904,6 +938,7 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
     CK_REQUIRE(d->C < 65535, "ck_leaf_walk_fwd: C=%d categories do not fit the packed rows", d->C);
     a.D = d->D;
     a.bad_flag = d->bad_input;
+    a.x_pairs = d->x_pairs != 0 && (d->D & 1) == 0;
     a.x64 = d->x_rows;
     if (d->x_input >= 0) {
       slot = ck::program_input_slot(d->x_input);

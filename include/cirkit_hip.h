@@ -364,7 +364,8 @@ typedef struct ck_leaf_launch {
   uint64_t* params_arrive;                  /* DEVICE 8 x 16 words, ZERO when first used, owned by this (circuit, batch size) */
   const struct ck_rows32_job* xjobs;        /* DEVICE (n_xjobs), or NULL */
   int32_t n_xjobs;
-  int32_t reserved2;
+  int32_t x_pairs;                          /* raw input: for every root, leaves 2j and 2j + 1 read variables v and v + 1 with v even
+                                               (and D even): the launch then fetches both values with one 16-byte load */
 } ck_leaf_launch;
 int ck_leaf_walk_fwd(const ck_leaf_launch* desc, void* stream);
 
