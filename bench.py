@@ -133,7 +133,7 @@ def _cpu_model() -> str:
     return "unknown"
 
 
-def live_pmc(argv_child: list[str], timeout_s: float = 150.0) -> dict | None:
+def live_pmc(argv_child: list[str], timeout_s: float = 200.0) -> dict | None:
     """HBM bytes and MFMA-busy cycles per launch of every kernel of a step, measured NOW: three short rocprofv3 passes
     (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_VALU_MFMA_BUSY_CYCLES`; one counter per pass, kernel trace only --
     MI355X_MICROARCH.md, HBM / rocprofv3 sections) over `bench.py --pmc-child` (the same circuit and inputs, 12 steps).
@@ -150,8 +150,34 @@ def live_pmc(argv_child: list[str], timeout_s: float = 150.0) -> dict | None:
         return None
     out: dict[str, dict] = {}
     t_end = time.time() + timeout_s
+
+    def short_name(name: str) -> str:
+        return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         env = dict(os.environ, TMPDIR="/tmp", CIRKIT_BENCH_NO_PMC="1")
+        # pass 0: kernel trace alone (no counters): the launch durations the profiler sees, warm -- 100 steps, the last
+        # 50 dispatches of every kernel averaged.  HIP events around every launch (the instrumented pass of
+        # profile_kernels) stretch a launch by a few microseconds; this is the figure a rocprofv3 --stats summary gives.
+        d = os.path.join(tmp, "trace")
+        cmd = [exe, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+               "--pmc-child", "--pmc-steps", "100", *argv_child]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=max(10.0, t_end - time.time()), check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("results.db")]
+            con = sqlite3.connect(dbs[0])
+            per: dict[str, list[float]] = {}
+            for name, start, end in con.execute("select name, start, end from kernels order by start"):
+                per.setdefault(short_name(name), []).append(float(end - start))
+            con.close()
+            for short, durs in per.items():
+                if short.startswith(("__amd", "at::")) or len(durs) < 60:
+                    continue
+                tail_d = durs[-50:]
+                out.setdefault(short, {})["trace_us"] = sum(tail_d) / len(tail_d) / 1e3
+        except Exception:  # noqa: BLE001 -- the trace figure is optional
+            pass
         for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
             d = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable,
@@ -167,10 +193,11 @@ def live_pmc(argv_child: list[str], timeout_s: float = 150.0) -> dict | None:
             except Exception:  # noqa: BLE001 -- any failure: no live numbers
                 return None
             for name, n, avg in rows:
-                short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                short = short_name(name)
                 if short.startswith(("__amd", "at::")):
                     continue
-                e = out.setdefault(short, {"launches_sampled": int(n)})
+                e = out.setdefault(short, {})
+                e["launches_sampled"] = int(n)
                 if ctr == "FETCH_SIZE":
                     e["read_bytes"] = 2.0 * avg * 1024.0
                 elif ctr == "WRITE_SIZE":
@@ -211,6 +238,7 @@ def main() -> None:
     ap.add_argument("--dist", action="store_true",
                     help="take the distributed code path (process group + the async all-reduce of every step) even at world size 1")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-steps", type=int, default=12, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -277,7 +305,7 @@ def main() -> None:
 
     if args.pmc_child:  # profiled by live_pmc(): the same steps, nothing else
         with torch.cuda.stream(stream):
-            for k in range(12):
+            for k in range(max(1, args.pmc_steps)):
                 circuit.log_likelihood_sum(xs[k % nb])
         torch.cuda.synchronize(device)
         return
@@ -514,12 +542,22 @@ def main() -> None:
                 "peak": FP32_MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
                 "achieved": exec_tf if mfma_bound else (kp["hbm_bytes"] / t_launch / 1e9 if kp and "hbm_bytes" in kp else None),
                 "frac": exec_tf / FP32_MFMA_PEAK_TF if mfma_bound else hbm_frac,
+                # the same with the launch duration of a plain rocprofv3 kernel trace (no events between the launches)
+                "trace_us_per_launch": kp.get("trace_us") if kp else None,
+                "frac_trace_timed": (a["exec"] / a["launches"] / (kp["trace_us"] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF)
+                if (kp and kp.get("trace_us") and mfma_bound) else None,
                 "executed_flops_per_launch": a["exec"] / a["launches"],
                 "traffic": kp.get("hbm_bytes") if kp else None,
                 "traffic_source": pmc_source,
                 "hbm_measured_frac": hbm_frac,
                 "mfma_busy_frac": (kp["mfma_busy_cycles"] / (4 * n_cu * t_launch * 2.4e9)) if kp and "mfma_busy_cycles" in kp else None,
                 "mfma_busy_frac_note": "SQ_VALU_MFMA_BUSY_CYCLES per launch / (4 SIMDs x CUs x launch time x 2.4 GHz)",
+                # HBM bytes of the whole step (sum over its kernels, PMC) against what a step must move:
+                # the raw parameters read once + the int64 batch read once + the per-row results
+                "step_traffic": (sum(v.get("hbm_bytes", 0.0) for k2, v in (pmc or {}).items()
+                                     if any(k2.split("<")[0] == kk.split("<")[0] for kk in agg)) or None) if pmc else None,
+                "compulsory_bytes": float(sum(int(np.prod(shp)) * 4 for shp, _ in plan.tensors.values())
+                                          + B * plan.num_variables * 8 + B * 4),
                 "algorithmic": {
                     "what": "SURVEY.md 8d figures of the reference layers this launch stands for (not what it moves or executes)",
                     "bytes_per_launch": a["bytes"] / a["launches"], "flops_per_launch": a["flops"] / a["launches"],
@@ -532,6 +570,8 @@ def main() -> None:
                         "executed_TFLOPps": (v["exec"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else None,
                         "hbm_bytes_per_launch": next((pv.get("hbm_bytes") for pk, pv in (pmc or {}).items()
                                                       if pk.split("<")[0] == k.split("<")[0]), None),
+                        "trace_us_per_launch": next((pv.get("trace_us") for pk, pv in (pmc or {}).items()
+                                                     if pk.split("<")[0] == k.split("<")[0]), None),
                     }
                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
                 },

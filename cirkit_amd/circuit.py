@@ -32,7 +32,7 @@ from .plan import Plan, resolve_fold_index
 
 # ck_tail16_fold of include/cirkit_hip.h
 _TAIL16_FOLD = np.dtype([("w", "<u8"), ("out", "<u8"), ("child", "<u8", (4,)), ("child_src", "<i4", (4,)), ("H", "<i4"),
-                         ("Ko", "<i4"), ("pad", "<i4", (2,))])
+                         ("Ko", "<i4"), ("skip_store", "<i4"), ("pad", "<i4")])
 assert _TAIL16_FOLD.itemsize == 80
 
 _ALIGN = 64  # arena alignment of every layer block, in activation elements (>= 256 B)
@@ -983,7 +983,10 @@ class HipCircuit:
         ip = C.c_int32 * n
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
         if self._tail16_ok():
-            desc_dev, levels_dev, n_folds, scratch, ticket, lay = self._tail16_tables(bd)
+            # `log_likelihood_sum` returns [sum, count] only: the tail's inner folds stay in LDS; `forward` keeps the layer
+            # outputs (`layer_outputs()` reads them) unless the caller opted out
+            keep = self.keep_layer_outputs and not with_ll
+            desc_dev, levels_dev, n_folds, scratch, ticket, lay = self._tail16_tables(bd, keep=keep)
             fuse_ll = with_ll and self._tail_fuses_ll()
             capi.call(
                 "ck_tail16_lse_fwd", desc_dev.data_ptr(), n_folds, levels_dev.data_ptr(), n, bd.B, 32, lay,
@@ -1000,18 +1003,23 @@ class HipCircuit:
             ip(*[l.arity for l in ls]), ip(*[l.num_output_units for l in ls]), bd.B, ls[0].num_input_units, lay, stream,
         )
 
-    def _tail16_tables(self, bd: _Binding) -> tuple:
+    def _tail16_tables(self, bd: _Binding, *, keep: bool = True) -> tuple:
         """(fold descriptors, level table, number of folds, per-tile LL sums, LL ticket, weight layout) of the 16-row tail
-        walk -- `ck_tail16_lse_fwd`, or the tail phase of the leaf launch -- for this binding."""
+        walk -- `ck_tail16_lse_fwd`, or the tail phase of the leaf launch -- for this binding.  keep=False: 32-unit folds
+        that only the tail itself reads are not stored (they are not circuit outputs and no later launch reads them)."""
         ls = [self.layers[j] for j in self._tail]
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
-        tabs = bd.cp_tabs.get("tail16")
+        key = "tail16" if keep else "tail16-nokeep"
+        tabs = bd.cp_tabs.get(key)
         if tabs is None:
             first, acc = {}, 0
             for j, l in zip(self._tail, ls):
                 first[j] = acc
                 acc += l.num_folds
             desc = np.zeros(acc, dtype=_TAIL16_FOLD)
+            outs = {int(p) for p in self._out_pairs[:, 0]}
+            read_later = {int(p) for jj, ch in enumerate(self._children) if ch is not None and jj not in self._tail
+                          for p in np.unique(ch[..., 0])}
             arena = bd.arena.data_ptr()
             esz = 8 if self._signed else 4  # (signed: complex64 blocks)
             for j, l in zip(self._tail, ls):
@@ -1023,6 +1031,7 @@ class HipCircuit:
                     d["w"] = l._w.data_ptr() + f * Ko * 32 * 4
                     d["out"] = bd.views[j].data_ptr() + f * bd.B * Ko * esz
                     d["H"], d["Ko"] = l.arity, Ko
+                    d["skip_store"] = 0 if (keep or Ko != 32 or j in outs or j in read_later) else 1
                     d["child_src"][:] = -1
                     for h in range(l.arity):
                         pj, pf = int(ch[f, h, 0]), int(ch[f, h, 1])
@@ -1030,10 +1039,11 @@ class HipCircuit:
                             d["child_src"][h] = first[pj] + pf
                         d["child"][h] = arena + int(off[f, h]) * esz
             levels = np.asarray([first[j] for j in self._tail] + [acc], dtype=np.int32)
-            tabs = bd.cp_tabs["tail16"] = (
+            shared = bd.cp_tabs.get("tail16") or bd.cp_tabs.get("tail16-nokeep")  # (one LL scratch / ticket per binding)
+            tabs = bd.cp_tabs[key] = (
                 torch.from_numpy(desc.view(np.uint8)).to(self.device), torch.from_numpy(levels).to(self.device), acc,
-                torch.zeros((bd.B + 15) // 16 + 1, dtype=torch.float64, device=self.device),
-                torch.zeros(1, dtype=torch.int32, device=self.device))
+                shared[3] if shared else torch.zeros((bd.B + 15) // 16 + 1, dtype=torch.float64, device=self.device),
+                shared[4] if shared else torch.zeros(1, dtype=torch.int32, device=self.device))
         return (*tabs, lay)
 
     def _group_table(self, g: SubtreeGroup, stream: int | None):

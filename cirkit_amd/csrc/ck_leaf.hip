@@ -39,7 +39,8 @@ struct TailFold {
   const float* child[4];
   int32_t child_src[4];
   int32_t H, Ko;
-  int32_t pad[2];
+  int32_t skip_store;
+  int32_t pad;
 };
 static_assert(sizeof(TailFold) == sizeof(ck_tail16_fold), "TailFold mirrors ck_tail16_fold");
 
@@ -209,7 +210,7 @@ __device__ __forceinline__ void leaf_tail_walk(const LeafArgs& a, int tile, cons
       float* out = s_fold[t].out;
       if (Ko == kK) {
         sum_step16(w, v);
-        if (a.tail_write && live) tile16_store(out + static_cast<int64_t>(b) * kK + 4 * kq, v);
+        if (a.tail_write && live && s_fold[t].skip_store == 0) tile16_store(out + static_cast<int64_t>(b) * kK + 4 * kq, v);
         float* tl = tiles.of(t) + lane * 4;
 #pragma unroll
         for (int beta = 0; beta < 2; ++beta)

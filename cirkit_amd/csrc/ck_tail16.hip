@@ -32,7 +32,8 @@ struct FoldDesc {
   const float* child[kTail16MaxArity];    // (B, 32) blocks of the children read from memory (when child_src < 0)
   int32_t child_src[kTail16MaxArity];     // index of the child among the tail's folds (its tile is in LDS), or -1
   int32_t H, Ko;
-  int32_t pad[2];
+  int32_t skip_store;  // != 0: a 32-unit fold nobody outside the tail reads -- its tile stays in LDS, `out` is not written
+  int32_t pad;
 };
 static_assert(sizeof(FoldDesc) == 80, "FoldDesc layout");
 static_assert(sizeof(FoldDesc) == sizeof(ck_tail16_fold), "FoldDesc mirrors ck_tail16_fold");
@@ -146,12 +147,12 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
         if constexpr (SIGNED) {
           sum_step16_signed(w, v, sg);
           prefetch(t_next);
-          if (live) tile16_store_clog(out + (static_cast<int64_t>(b) * kK + 4 * kq) * 2, v, sg);
+          if (live && s_fold[t].skip_store == 0) tile16_store_clog(out + (static_cast<int64_t>(b) * kK + 4 * kq) * 2, v, sg);
           s_sign[t * 64 + lane] = sg;
         } else {
           sum_step16(w, v);
           prefetch(t_next);
-          if (live) tile16_store(out + static_cast<int64_t>(b) * kK + 4 * kq, v);
+          if (live && s_fold[t].skip_store == 0) tile16_store(out + static_cast<int64_t>(b) * kK + 4 * kq, v);
         }
         float* tl = tiles + t * 512 + lane * 4;
 #pragma unroll

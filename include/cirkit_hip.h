@@ -397,7 +397,10 @@ typedef struct ck_tail16_fold {
   const float* child[4];   /* (B, 32) block of child h when child_src[h] < 0                                   */
   int32_t child_src[4];    /* index (in `folds`) of child h when it is a 32-unit fold of the tail itself, else -1 */
   int32_t H, Ko;
-  int32_t pad[2];
+  int32_t skip_store;      /* != 0 (32-unit folds only): the output is a child inside the tail and nobody else reads it --
+                              it stays in LDS and `out` is not written (the reference keeps every layer output alive,
+                              graph/modules.py:303-335; a forward that returns only the circuit outputs need not)           */
+  int32_t pad;
 } ck_tail16_fold;
 /* signed_values != 0: a real-valued circuit under complex-lse-sum (semiring.py:441-476): every block in memory (children,
  * outputs) is (B, Ko) complex64 holding (log|v|, 0 or pi), the weights may be signed; `ll` must then be NULL. */

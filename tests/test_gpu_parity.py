@@ -644,6 +644,27 @@ def test_leaf_launch_evaluates_its_parameters(hip_device, B):
             b.store.set(name, new)
 
 
+def test_forward_only_mode_keeps_results(hip_device):
+    """`keep_layer_outputs=False` / `log_likelihood_sum`: the 32-unit folds of the tail that nobody outside it reads are
+    not stored (ck_tail16_fold.skip_store: 24.7 MB per 4096-row batch at the north-star configuration) -- circuit outputs
+    and the log-likelihood sum are unchanged, and `layer_outputs()` of the default circuit still sees every tail layer."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    B = 1000
+    x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(9)).to(hip_device)
+    a = HipCircuit(plan, tensors, device=hip_device)
+    b = HipCircuit(plan, tensors, device=hip_device, keep_layer_outputs=False)
+    ya = a(x).clone()
+    assert torch.equal(ya, b(x))
+    sa = a.log_likelihood_sum(x).clone()
+    assert torch.equal(sa, b.log_likelihood_sum(x))
+    la = a.layer_outputs(x)
+    ref = HipCircuit(plan, tensors, device=hip_device, fuse=False).layer_outputs(x)
+    for j in a._tail:  # (written by the forward program although log_likelihood_sum ran in between)
+        assert torch.allclose(la[j], ref[j], rtol=1e-5, atol=2e-3), j
+
+
 def test_raw_batch_is_validated_row_by_row(hip_device):
     """The leaf launches look at low dwords only; the tail launch checks the full 64-bit values of its 16 rows
     (`ck_tail16_walk_fwd`): a row holding a category >= num_categories (an IndexError in the reference, input.py:399-412),
