@@ -138,6 +138,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_sum_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_debug_force_generic_bwd": [_i],
     "ck_hadamard_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_kronecker_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_gaussian_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "ck_mixing_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_param_scaled_sigmoid_bwd": [_p, _p, _p, _l, _f, _f, _i, _p],

@@ -42,12 +42,17 @@ __global__ void __launch_bounds__(256)
                         const float* __restrict__ gout, float* __restrict__ dw, int H, int B, int Ki,
                         int Ko, int mode, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int N = mode == CK_SUM_PROD ? Ki : H * Ki;
+  int N = mode == CK_SUM_PROD ? Ki : H * Ki;
+  if (mode == CK_SUM_KRON) {  // TorchTuckerLayer (optimized.py:89-103): the weight contracts the Kronecker product of the children
+    N = 1;
+    for (int h = 0; h < H; ++h) N *= Ki;
+  }
   float* e_s = reinterpret_cast<float*>(smem);   // [TB][N]
   float* gv_s = e_s + static_cast<size_t>(TB) * N;  // [TB][N]
   float* gy_s = gv_s + static_cast<size_t>(TB) * N;  // [TB][Ko]
   float* w_s = gy_s + static_cast<size_t>(TB) * Ko;  // [64][kBwdNC+1]
   float* m_s = w_s + 64 * (kBwdNC + 1);              // [TB]
+  float* eh_s = m_s + TB;                            // CK_SUM_KRON: [TB][H * Ki] per-child exp(v_h - max_h)
   const int f = blockIdx.y;
   const int b0 = blockIdx.x * TB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -56,8 +61,35 @@ __global__ void __launch_bounds__(256)
   const float* wf = w + static_cast<int64_t>(f) * Ko * N;
   float* dwf = dw + static_cast<int64_t>(f) * Ko * N;
 
+  if (mode == CK_SUM_KRON) {
+    // phase A (Tucker): one maximum PER CHILD (semiring.py:383-408 applied to the einsum's operands), e = e_0 (x) e_1 (x) ...
+    // with child 0 most significant (n = i_0 Ki^(H-1) + ... + i_(H-1), optimized.py:89-103)
+    for (int rh = wave; rh < TB * H; rh += 4) {
+      const int r = rh / H, h = rh - r * H, b = b0 + r;
+      float mx = -INFINITY;
+      for (int i = lane; i < Ki; i += 64) {
+        const float v = b < B ? arena[ro[h] + static_cast<int64_t>(b) * Ki + i] : -INFINITY;
+        eh_s[(r * H + h) * Ki + i] = v;
+        mx = fmaxf(mx, v);
+      }
+      mx = ck::clamp_finite(ck::wave_max(mx));
+      for (int i = lane; i < Ki; i += 64) eh_s[(r * H + h) * Ki + i] = expf(eh_s[(r * H + h) * Ki + i] - mx);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TB * N; i += 256) {
+      const int r = i / N;
+      int n = i - r * N;
+      float p = 1.f;
+      for (int h = H - 1; h >= 0; --h) {
+        p *= eh_s[(r * H + h) * Ki + n % Ki];
+        n /= Ki;
+      }
+      e_s[i] = p;
+    }
+    __syncthreads();
+  }
   // phase A: v, m, e (rows beyond B are zeroed so they contribute nothing)
-  for (int r = wave; r < TB; r += 4) {
+  for (int r = wave; r < TB && mode != CK_SUM_KRON; r += 4) {
     const int b = b0 + r;
     float mx = -INFINITY;
     for (int n = lane; n < N; n += 64) {
@@ -145,6 +177,23 @@ __global__ void __launch_bounds__(256)
       }
       __syncthreads();
     }
+  }
+  if (mode == CK_SUM_KRON) {
+    // phase C (Tucker): d loss / d v_h[i] = sum over the n whose digit h is i of e[n] (W^T gy)[n]  (the factor e_h[i] is
+    // part of e[n]); one thread per (row, child, unit), the other digits in a fixed order: deterministic
+    for (int i = threadIdx.x; i < TB * N; i += 256) gv_s[i] *= e_s[i];
+    __syncthreads();
+    const int rest = N / Ki;
+    for (int t = threadIdx.x; t < TB * H * Ki; t += 256) {
+      const int r = t / (H * Ki), h = (t / Ki) % H, i = t % Ki, b = b0 + r;
+      if (b >= B) continue;
+      int sh = 1;  // stride of digit h
+      for (int k = h + 1; k < H; ++k) sh *= Ki;
+      float acc = 0.f;
+      for (int m = 0; m < rest; ++m) acc += gv_s[static_cast<size_t>(r) * N + (m / sh) * (sh * Ki) + i * sh + (m % sh)];
+      grad_store(garena + gro[h] + static_cast<int64_t>(b) * Ki + i, acc, accumulate);
+    }
+    return;
   }
   // phase C: gv *= e, scatter to the children
   for (int i = threadIdx.x; i < TB * N; i += 256) {
@@ -490,6 +539,27 @@ __global__ void __launch_bounds__(256)
       for (int j = s0; j < s1; ++j) a += tmp[static_cast<int64_t>(clist[j]) * block_elems + i];
       dst[i] = a;
     }
+  }
+}
+
+// TorchKroneckerLayer backward (inner.py:178-187): out[b, n] = sum_h v_h[b, digit_h(n)] in log space, child 0 most
+// significant, so d loss / d v_h[b, i] = sum of gout[b, n] over the n whose digit h is i.  One thread per (row, child, unit),
+// the other digits in a fixed order.
+__global__ void __launch_bounds__(256)
+    kronecker_bwd_kernel(float* __restrict__ garena, const int64_t* __restrict__ row_off, const float* __restrict__ gout, int H,
+                         int B, int K, int N, int accumulate) {
+  const int f = blockIdx.y;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const float* g = gout + static_cast<int64_t>(f) * B * N;
+  const int rest = N / K;
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < static_cast<int64_t>(B) * H * K;
+       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(t / (H * K)), h = static_cast<int>((t / K) % H), i = static_cast<int>(t % K);
+    int sh = 1;
+    for (int k = h + 1; k < H; ++k) sh *= K;
+    float acc = 0.f;
+    for (int m = 0; m < rest; ++m) acc += g[static_cast<int64_t>(b) * N + (m / sh) * (sh * K) + i * sh + (m % sh)];
+    grad_store(garena + ro[h] + static_cast<int64_t>(b) * K + i, acc, accumulate);
   }
 }
 
@@ -1106,7 +1176,7 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
   CK_REQUIRE(arena && garena && row_off && w && out && gout && dw, "ck_sum_lse_bwd: null pointer");
   const int64_t* grow = grad_row_off ? grad_row_off : row_off;
   CK_REQUIRE(F > 0 && H > 0 && B > 0 && Ki > 0 && Ko > 0, "ck_sum_lse_bwd: non-positive size");
-  CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD, "ck_sum_lse_bwd: unsupported mode %d", mode);
+  CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD || mode == CK_SUM_KRON, "ck_sum_lse_bwd: unsupported mode %d", mode);
   CK_REQUIRE(accumulate >= 0 && accumulate <= 2, "ck_sum_lse_bwd: accumulate must be 0, 1 or 2");
   CK_REQUIRE(F <= 65535, "ck_sum_lse_bwd: F=%d exceeds grid.y", F);
   if ((mode == CK_SUM_PROD || H == 1) && Ki == kK && Ko == kK && !g_bwd_force_generic && ck::aligned16(arena) &&
@@ -1143,12 +1213,20 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
         },
         stream);
   }
-  const int N = mode == CK_SUM_PROD ? Ki : H * Ki;
+  int64_t N64 = mode == CK_SUM_PROD ? Ki : static_cast<int64_t>(H) * Ki;
+  if (mode == CK_SUM_KRON) {
+    N64 = 1;
+    for (int h = 0; h < H && N64 <= (1 << 20); ++h) N64 *= Ki;
+  }
+  if (N64 > (1 << 16)) return ck::fail(CK_ERR_UNSUPPORTED, "ck_sum_lse_bwd: %lld contracted inputs do not fit in LDS", static_cast<long long>(N64));
+  const int N = static_cast<int>(N64);
   auto lds_bytes = [&](int tb) {
-    return (static_cast<size_t>(2) * tb * N + static_cast<size_t>(tb) * Ko + 64 * (kBwdNC + 1) + tb) * sizeof(float);
+    return (static_cast<size_t>(2) * tb * N + static_cast<size_t>(tb) * Ko + 64 * (kBwdNC + 1) + tb +
+            (mode == CK_SUM_KRON ? static_cast<size_t>(tb) * H * Ki : 0)) * sizeof(float);
   };
   int tb = 16;
   while (tb > 4 && lds_bytes(tb) > 64 * 1024) tb >>= 1;
+  if (mode == CK_SUM_KRON && lds_bytes(tb) > 160 * 1024) tb = 1;  // (one row per workgroup: K = 64 Tucker layers, 4096 products a row)
   const size_t lds = lds_bytes(tb);
   if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_sum_lse_bwd: N=%d does not fit in LDS", N);
   dim3 grid((B + tb - 1) / tb, F), block(256);
@@ -1166,7 +1244,30 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
         };
         if (tb == 16) return go(sum_lse_bwd_generic<16>);
         if (tb == 8) return go(sum_lse_bwd_generic<8>);
+        if (tb == 1) return go(sum_lse_bwd_generic<1>);
         return go(sum_lse_bwd_generic<4>);
+      },
+      stream);
+}
+
+int ck_kronecker_bwd(float* garena, const int64_t* row_off, const float* gout, int F, int H, int B, int K,
+                     int accumulate, void* stream) {
+  CK_REQUIRE(garena && row_off && gout, "ck_kronecker_bwd: null pointer");
+  CK_REQUIRE(F > 0 && H >= 2 && B > 0 && K > 0, "ck_kronecker_bwd: non-positive size or arity below 2");
+  CK_REQUIRE(accumulate >= 0 && accumulate <= 2, "ck_kronecker_bwd: accumulate must be 0, 1 or 2");
+  CK_REQUIRE(F <= 65535, "ck_kronecker_bwd: F=%d exceeds grid.y", F);
+  int64_t N = 1;
+  for (int h = 0; h < H; ++h) {
+    N *= K;
+    CK_REQUIRE(N <= (int64_t{1} << 24), "ck_kronecker_bwd: K^H too large");
+  }
+  const int64_t words = static_cast<int64_t>(B) * H * K;
+  dim3 grid(grid1(words), F), block(256);
+  const int n = static_cast<int>(N);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(kronecker_bwd_kernel, grid, block, 0, s, garena, row_off, gout, H, B, K, n, accumulate);
+        return hipGetLastError();
       },
       stream);
 }

@@ -648,8 +648,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     // Doing that inside the walk -- an out-of-line call with the whole walk state live -- cost the hot loop its
     // registers (256 + spills against 237; 79 -> 74.5 us at the north-star configuration).
     // Batch values are requested two tiles ahead (after the last gather request of a tile) and turned into packed table
-    // rows as soon as they have landed (the first wait of the next tile): `xraw` is live only from the last contractions
-    // of a tile to the first leaf of the next one.
+    // rows half a tile later: `xraw` is live from the last contractions of a tile to the middle of the next one.
     RawT xraw[kLeaves];            // batch values of the tile AFTER the current one
     uint32_t cat[kLeaves / 2];     // packed table rows of the current tile
     uint32_t catnext[kLeaves / 2];  // ... of the next tile of this wave
@@ -678,11 +677,16 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       bool bad = false;
       static_for<0, kLeaves>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        // the request of leaf i has landed (at most those of the next kSlots - 1 leaves, 5 operations each, are younger;
-        // at leaf 0 everything requested during the previous tile is waited for); read the slot into the operand
-        // layout; the reads have returned before the slot is refilled
+        // the request of leaf i has landed: at most those of the next kSlots - 1 leaves, 5 operations each, are younger --
+        // and, for the leaves requested during the PREVIOUS tile (i < kSlots), the batch values of the tile after this
+        // one, which were requested right behind them and are not needed before leaf kLeaves / 2: waiting for them here
+        // (vmcnt(0) at leaf 0) stalled every tile on an HBM round trip that had only the last contractions of the
+        // previous tile to complete in.  kXLoads is the FEWEST load instructions a tile's batch values take (a smaller
+        // count only waits longer; the tile's output stores, younger too, are not counted for the same reason).  Read the
+        // slot into the operand layout; the reads have returned before the slot is refilled
         f32x4 r0, r1, r2, r3;
-        constexpr int kYounger = i == 0 ? 0 : 5 * (kLeaves - 1 - i < kSlots - 1 ? kLeaves - 1 - i : kSlots - 1);
+        constexpr int kXLoads = XRAW ? (kLeaves >= 4 ? kLeaves / 4 : kLeaves / 2) : kLeaves;
+        constexpr int kYounger = 5 * (kLeaves - 1 - i < kSlots - 1 ? kLeaves - 1 - i : kSlots - 1) + (i < kSlots ? kXLoads : 0);
         // (the weights of the leaf's first contraction are requested in front of the slot reads: one LDS round trip for both)
         WRegs wfirst;
         if constexpr (steps_after(i) > 0) {
@@ -703,7 +707,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           cur[12 + e] = r3[e];
         }
         const float s_i = sld[i & 3];
-        if constexpr (i == 0) bad_next = pack_categories(xraw, catnext);  // (everything requested before this tile has landed)
+        if constexpr (i == kLeaves / 2) bad_next = pack_categories(xraw, catnext);  // (requested half a tile + four contractions ago)
         if constexpr (i + kSlots < kLeaves) request(cat, std::integral_constant<int, i + kSlots>{});
         if constexpr (i + 1 == kLeaves) {
           // the gathers of this tile are over: request what the next tile starts with (see above)

@@ -7,10 +7,11 @@ second launch list of hand-written kernels (cirkit_amd/csrc/ck_backward.hip) wal
 reverse.  Data-parallel training = one process per GPU, the batch sharded, and ONE all-reduce of a
 single flat gradient buffer (all parameter gradients are views of it) over RCCL/xGMI per step.
 
-Covered: real lse-sum circuits made of Categorical (probs = softmax) or Gaussian inputs, Sum / CP-T
-layers (softmax, raw, or any parameter graph `HipParameter.backward` handles, e.g. the MatMul weight
-of a collapsed Sum -> Sum pair), mixing layers and Hadamard layers -- what the image / tabular
-templates build with 'cp' and 'cp-t' (BASELINE configs 1-4).  Other layers raise NotImplementedError.
+Covered: real lse-sum circuits made of Categorical (probs = softmax) or Gaussian inputs, Sum / CP-T /
+Tucker layers (softmax, raw, or any parameter graph `HipParameter.backward` handles, e.g. the MatMul weight
+of a collapsed Sum -> Sum pair), mixing layers, Hadamard and Kronecker layers -- what the image / tabular
+templates build with 'cp', 'cp-t' and 'tucker' (BASELINE configs 1-4, the reference's Tucker notebook).  Other layers
+(TensorDot, the complex semiring) raise NotImplementedError.
 """
 
 from __future__ import annotations
@@ -23,7 +24,8 @@ import torch
 
 from . import _capi as capi
 from .circuit import HipCircuit
-from .layers import HipCategoricalLayer, HipCPTLayer, HipGaussianLayer, HipHadamardLayer, HipSumLayer
+from .layers import (HipCategoricalLayer, HipCPTLayer, HipGaussianLayer, HipHadamardLayer, HipKroneckerLayer, HipSumLayer,
+                     HipTuckerLayer)
 from .parameters import TensorStore
 from .plan import Plan
 
@@ -119,10 +121,10 @@ class HipTrainer:
             elif isinstance(l, HipGaussianLayer):
                 if l.log_partition is not None or (set(l.mean.ops) | set(l.stddev.ops)) - self._PARAM_OPS:
                     raise NotImplementedError("training: Gaussian layers with a log-partition or exotic parameters")
-            elif isinstance(l, (HipSumLayer, HipCPTLayer)) and type(l) in (HipSumLayer, HipCPTLayer):
+            elif isinstance(l, (HipSumLayer, HipCPTLayer)) and type(l) in (HipSumLayer, HipCPTLayer, HipTuckerLayer):
                 if set(l.weight.ops) - self._PARAM_OPS:
                     raise NotImplementedError(f"training: weight parameterisation {l.weight.ops}")
-            elif isinstance(l, HipHadamardLayer):
+            elif isinstance(l, (HipHadamardLayer, HipKroneckerLayer)):
                 pass
             else:
                 raise NotImplementedError(f"training: layer type {spec.type!r}")
@@ -289,6 +291,10 @@ class HipTrainer:
             elif isinstance(l, HipHadamardLayer):
                 ga, ro, fl = target(i)
                 capi.call("ck_hadamard_bwd", ga, ro, gviews[i].data_ptr(), l.num_folds, l.arity, B, l.num_input_units, fl, stream)
+                gather_shared(i)
+            elif isinstance(l, HipKroneckerLayer):  # inner.py:178-187
+                ga, ro, fl = target(i)
+                capi.call("ck_kronecker_bwd", ga, ro, gviews[i].data_ptr(), l.num_folds, l.arity, B, l.num_input_units, fl, stream)
                 gather_shared(i)
             elif l._mixing:
                 dmw = st["dws"][i]

@@ -486,7 +486,8 @@ int ck_fill_f32(float* p, int64_t n, float value, void* stream);
  * LayerAddressBook.lookup, circuits.py:39-48), without float atomics and in list order. */
 int ck_segment_add_rows(const float* tmp, const int32_t* cptr, const int32_t* clist, const int64_t* coff, float* garena,
                         int n_child, int64_t block_elems, void* stream);
-/* TorchSumLayer / TorchCPTLayer backward (modes CK_SUM_CAT / CK_SUM_PROD), row-major linear
+/* TorchSumLayer / TorchCPTLayer / TorchTuckerLayer backward (modes CK_SUM_CAT / CK_SUM_PROD / CK_SUM_KRON:
+ * optimized.py:89-103, one maximum per child, N = Ki^H contracted inputs), row-major linear
  * weights w (F,Ko,N): children gradients into garena at grad_row_off (NULL: at row_off, the mirror of the arena),
  * dW (F,Ko,N) accumulated with atomics
  * (zero it first). out/gout: (F,B,Ko) forward output and its gradient. */
@@ -494,6 +495,10 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
                    const float* w, const float* out, const float* gout, float* dw, int F, int H, int B, int Ki, int Ko,
                    int mode, int accumulate, void* stream);
 int ck_debug_force_generic_bwd(int on); /* test hook, like ck_debug_force_generic */
+/* TorchKroneckerLayer backward (inner.py:178-187): gout (F, B, K^H); the gradient of child h's unit i is the sum of gout
+ * over the outputs whose digit h (child 0 most significant) is i. */
+int ck_kronecker_bwd(float* garena, const int64_t* row_off, const float* gout, int F, int H, int B, int K,
+                     int accumulate, void* stream);
 /* TorchHadamardLayer backward: every child receives gout (F,B,K). */
 int ck_hadamard_bwd(float* garena, const int64_t* row_off, const float* gout, int F, int H, int B, int K,
                     int accumulate, void* stream);

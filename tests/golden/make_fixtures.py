@@ -354,6 +354,42 @@ def grads():
         torch.set_grad_enabled(False)
 
 
+def grads_tucker():
+    """Round 3: parameter gradients of the reference's autograd through Tucker layers (optimized.py:89-103) and through
+    stand-alone Kronecker + dense sum layers (inner.py:178-187; `optimize=False` keeps them unfused) -- the plans, a forward
+    fixture and every gradient."""
+    torch.set_grad_enabled(True)
+    try:
+        for name, sc, optimize, xgen in [
+            ("quadgraph_6x6_tucker_k4", data_modalities.image_data(
+                (1, 6, 6), "quad-graph", input_layer="categorical", num_input_units=4,
+                sum_product_layer="tucker", num_sum_units=4), True,
+             lambda g: torch.randint(0, 256, (24, 36), generator=g)),
+            ("quadtree_4x4_kron_k3", data_modalities.image_data(
+                (1, 4, 4), "quad-tree-2", input_layer="categorical", num_input_units=3,
+                sum_product_layer="tucker", num_sum_units=3), False,
+             lambda g: torch.randint(0, 256, (20, 16), generator=g)),
+        ]:
+            cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=optimize).compile(sc)
+            plan, tensors = plan_from_torch_circuit(cc)
+            with torch.no_grad():
+                _load_closed_form(plan, tensors)
+            g = torch.Generator().manual_seed(13)
+            x = xgen(g)
+            with torch.no_grad():
+                _save(name, plan, {"x": x.numpy().astype(np.int16), "y_f32": cc(x).numpy(), "y_f64": _fp64_copy(cc)(x).numpy()})
+            loss = -cc(x).mean()
+            loss.backward()
+            by_ptr = {p.data_ptr(): p for p in cc.parameters()}
+            extra = {"x": x.numpy().astype(np.int16), "loss": np.array(loss.item())}
+            for k, t in tensors.items():
+                extra["g_" + k] = by_ptr[t.data_ptr()].grad.numpy()
+            np.savez_compressed(os.path.join(HERE, name + "_grads.npz"), **extra)
+            print(name, [l.type for l in plan.layers], "grads:", {k: float(np.linalg.norm(v)) for k, v in extra.items() if k.startswith("g_")})
+    finally:
+        torch.set_grad_enabled(False)
+
+
 def marginals():
     """Marginal queries through the reference's IntegrateQuery (cirkit/backend/torch/queries.py):
     the KAT circuits (reference ground truth: mar (1,0,1,1,.) = 16.845, Z = 318; mar (0.3,.) =
@@ -535,6 +571,6 @@ def chow_liu():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "marginals", "templates_extra"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "grads_tucker", "marginals", "templates_extra"]
     for w in which:
         globals()[w]()
