@@ -538,6 +538,8 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             for (int m = 0; m < kLeaves / 4; ++m) {
               uint32_t off = rowb + (kh ? static_cast<uint32_t>(var_off[4 * m + 2]) : static_cast<uint32_t>(var_off[4 * m])) * 8u;
               asm volatile("" : "+v"(off));
+              // (plain loads: a line of the batch is used by up to four roots of the XCD; fetched non-temporal -- so as
+              // not to push the roots' tables out of the L2 -- the launch took 83.7 instead of 77.6 us)
               const int4 t = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(a.x64) + off);
               xv[4 * m] = t.x;
               xv[4 * m + 1] = t.y;
