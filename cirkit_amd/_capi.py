@@ -99,6 +99,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_transpose_f32": [_p, _p, _i, _i, _p],
     "ck_stage_categories": [_p, _p, _i, _i, _p, _p, _i, _p],
     "ck_poison_outputs": [_p, _l, _p, _p],
+    "ck_zero_if_flag": [_p, _l, _p, _p],
     "ck_categorical_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_gaussian_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_gaussian_prod_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -575,10 +575,10 @@ class HipCircuit:
             if not self.cache_params:
                 self._enqueue_params(0, in_leaf=bd.params_in_leaf)
             self._enqueue_layers(bd, 0, with_ll=with_ll)
-            if self.validate_inputs and self._int_input and not bd.direct and not self._poison_in_tail() and not self._complex:
-                for p, f in self._out_pairs:
+            if self.validate_inputs and self._int_input and not bd.direct and not self._poison_in_tail():
+                for p, f in self._out_pairs:  # (complex outputs: both halves of every element)
                     v = bd.views[int(p)][int(f)]
-                    capi.call("ck_poison_outputs", v.data_ptr(), v.numel(), self._bad_input.data_ptr(), 0)
+                    capi.call("ck_poison_outputs", v.data_ptr(), v.numel() * (2 if self._complex else 1), self._bad_input.data_ptr(), 0)
             if with_ll and not self._tail_fuses_ll():
                 p, f = int(self._out_pairs[0, 0]), int(self._out_pairs[0, 1])
                 capi.call("ck_ll_sum", bd.views[p][f].data_ptr(), bd.B, 1, bd.ll.data_ptr(), 0)
@@ -644,14 +644,35 @@ class HipCircuit:
             if not tuck:
                 self._scratch_buf = False
             else:
-                tiles = max(l.num_folds * ((l.num_output_units + 31) // 32) for l in tuck) * 8  # (row groups at B <= 1024)
-                nbytes = self._n_cu * 3 * 2 * (4 * 1024 + 64) * 4 + tiles * 4  # partial tiles, their (max, sum) rows, tickets
-                self._scratch_buf = torch.zeros(nbytes // 4, dtype=torch.int32, device=self.device)
+                self._scratch_rows = 8  # row groups of 128 the ticket area covers (B <= 1024); grown by `_scratch_for`
+                self._scratch_buf = self._new_scratch(tuck, self._scratch_rows)
+                self._scratch_old: list[torch.Tensor] = []
         return None if self._scratch_buf is False else self._scratch_buf
+
+    def _new_scratch(self, tuck, row_groups: int) -> torch.Tensor:
+        tiles = max(l.num_folds * ((l.num_output_units + 31) // 32) for l in tuck) * row_groups
+        nbytes = self._n_cu * 3 * 2 * (4 * 1024 + 64) * 4 + tiles * 4  # partial tiles, their (max, sum) rows, tickets
+        return torch.zeros(nbytes // 4, dtype=torch.int32, device=self.device)
+
+    def _scratch_for(self, B: int) -> torch.Tensor | None:
+        """The workspace for a binding of batch size B: the ticket area grows with ceil(B / 128) (a workspace
+        provisioned for B <= 1024 silently sent larger batches to the one-workgroup-per-tile launch).  Buffers that
+        recorded programs of other bindings point at stay alive."""
+        ws = self._scratch()
+        if ws is None:
+            return None
+        need = (B + 127) // 128
+        if need > self._scratch_rows:
+            tuck = [l for s, l in zip(self.plan.layers, self.layers)
+                    if s.type == "tucker" and l.arity == 2 and l.num_input_units in (32, 64) and not self._complex]
+            self._scratch_old.append(self._scratch_buf)
+            self._scratch_rows = need
+            self._scratch_buf = self._new_scratch(tuck, need)
+        return self._scratch_buf
 
     def _enqueue_layers(self, bd: _Binding, stream: int, *, with_ll: bool = False) -> None:
         """The layer kernels of one forward, in plan order (graph/modules.py:326-334)."""
-        ws = self._scratch()
+        ws = self._scratch_for(bd.B)
         if ws is None:
             return self._enqueue_layers_(bd, stream, with_ll=with_ll)
         capi.call("ck_set_workspace", ws.data_ptr(), ws.numel() * 4)
@@ -1511,7 +1532,7 @@ class HipCircuit:
         esz = 8 if self._complex else 4
         rows: list[dict] = []
         acc: list[list[float]] = []
-        ws = self._scratch()
+        ws = self._scratch_for(B)
         if ws is not None:  # (as `_enqueue_layers` does: the launches below are the ones a forward records)
             capi.call("ck_set_workspace", ws.data_ptr(), ws.numel() * 4)
         stage_ms: list[float] = []

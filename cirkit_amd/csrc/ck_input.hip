@@ -67,6 +67,12 @@ __global__ void poison_kernel(float* __restrict__ out, int64_t n, const int32_t*
     out[i] = __builtin_nanf("");
 }
 
+__global__ void zero_if_flag_kernel(float* __restrict__ p, int64_t n, const int32_t* __restrict__ flag) {
+  if (*flag == 0) return;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    p[i] = 0.f;
+}
+
 template <typename TI, typename TO>
 int transpose_impl(const TI* x, TO* xt, int B, int D, void* stream, const char* who) {
   CK_REQUIRE(x != nullptr && xt != nullptr, "%s: null pointer", who);
@@ -343,6 +349,17 @@ int ck_poison_outputs(float* out, int64_t n, const int32_t* flag, void* stream) 
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(poison_kernel, grid, block, 0, s, out, n, flag);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_zero_if_flag(float* p, int64_t n, const int32_t* flag, void* stream) {
+  CK_REQUIRE(p && flag && n > 0, "ck_zero_if_flag: null pointer or empty buffer");
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 1024))), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(zero_if_flag_kernel, grid, block, 0, s, p, n, flag);
         return hipGetLastError();
       },
       stream);

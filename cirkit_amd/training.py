@@ -372,6 +372,18 @@ class HipTrainer:
         """One optimisation step on this rank's shard; returns the device tensor [sum log p, count]
         of the shard (before the update)."""
         ll = self.loss_and_grads(x, global_batch=global_batch)
+        c = self.circuit
+        if c.validate_inputs and c._int_input:
+            # a batch with an out-of-range category (NaN log-likelihood, the flag `check_inputs()` reports) must not reach the
+            # parameters: its gradients are dropped on the device -- no host synchronisation -- before the exchange and the update
+            with torch.cuda.device(self.device):
+                capi.call("ck_zero_if_flag", self._flat_grad.data_ptr(), self._flat_grad.numel(), c._bad_input.data_ptr(),
+                          torch.cuda.current_stream(self.device).cuda_stream)
         self.all_reduce_grads()
         self.apply_gradients()
         return ll
+
+    def check_inputs(self) -> None:
+        """Raise ``IndexError`` if a batch since the last check held a category out of range (`HipCircuit.check_inputs`);
+        the steps on such batches changed nothing but the optimizer's step count and moment decay."""
+        self.circuit.check_inputs()

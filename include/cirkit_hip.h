@@ -81,6 +81,10 @@ int ck_stage_categories(const int64_t* x, int32_t* xt, int B, int D, const int32
                         void* stream);
 /* out[0..n) = NaN if *flag != 0 (one small launch; circuits whose last launch is ck_tail16_lse_fwd do not need it). */
 int ck_poison_outputs(float* out, int64_t n, const int32_t* flag, void* stream);
+/* p[0..n) = 0 if *flag != 0: the gradients of a batch that held an illegal category are dropped before the optimizer
+ * sees them (the reference raises IndexError before any update, layers/input.py:399-412; a device-side flag cannot raise,
+ * but it must not let NaN gradients into the parameters either). */
+int ck_zero_if_flag(float* p, int64_t n, const int32_t* flag, void* stream);
 /* (B, D) fp32 -> (D, B) fp32, same purpose for continuous inputs. */
 int ck_transpose_f32(const float* x, float* xt, int B, int D, void* stream);
 

@@ -4,5 +4,5 @@ python bench.py --no-variants --no-other-configs --no-cpu-baseline --no-live-pmc
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/bk.json"))
-print("ms_per_step", round(d["ms_per_step"], 5), {k.split("<")[0] + "<" + k.split("<")[1][:24]: round(1e3 * v["ms_per_step"], 2) for k, v in d["roofline"].get("kernels", {}).items()})
+print("ms_per_step", round(d["ms_per_step"], 5), {k[:40]: round(1e3 * v["ms_per_step"], 2) for k, v in d["roofline"].get("kernels", {}).items()})
 PY
