@@ -237,6 +237,9 @@ def main() -> None:
                     help="do not run the three short rocprofv3 counter passes (roofline.traffic then comes from profiles/)")
     ap.add_argument("--dist", action="store_true",
                     help="take the distributed code path (process group + the async all-reduce of every step) even at world size 1")
+    ap.add_argument("--params-at-end", action="store_true",
+                    help="evaluate the parameter graphs at the END of every forward, for the next one, inside the launch that walks "
+                         "the tail (HipCircuit(params_at_end=True)); every step still evaluates them once")
     ap.add_argument("--staged-input", action="store_true",
                     help="stage the batch (int64 (B, D) -> int32 (D, B)) with a launch of its own, as in round 2, instead of "
                          "letting the leaf launch read the caller's tensor")
@@ -298,7 +301,8 @@ def main() -> None:
     B = args.batch
     fuse = True if args.fuse < 0 else (False if args.fuse == 0 else args.fuse)
     circuit = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse,
-                         contraction=args.contraction, direct_input=not args.staged_input)
+                         contraction=args.contraction, direct_input=not args.staged_input,
+                         params_at_end=args.params_at_end)
     g = torch.Generator().manual_seed(1234 + rank)
     nb = max(1, args.batches)
     xs = [torch.randint(0, 256, (B, plan.num_variables), generator=g).to(device) for _ in range(nb)]  # int64, like the reference
@@ -504,6 +508,8 @@ def main() -> None:
                 child.append("--no-graph")
             if args.staged_input:
                 child.append("--staged-input")
+            if args.params_at_end:
+                child.append("--params-at-end")
             pmc = live_pmc(child)
             pmc_source = "three rocprofv3 counter passes run by this bench.py invocation (FETCH_SIZE x2, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES)"
         if pmc is None:

@@ -91,6 +91,28 @@ class LeafLaunch(C.Structure):
     ]
 
 
+class TailParamsLaunch(C.Structure):
+    """ck_tail_params_launch of include/cirkit_hip.h."""
+
+    _fields_ = [
+        ("folds", C.c_void_p),
+        ("level_begin", C.c_void_p),
+        ("n_folds", C.c_int32), ("n_levels", C.c_int32), ("n_slots", C.c_int32), ("B", C.c_int32), ("w_layout", C.c_int32),
+        ("C", C.c_int32),
+        ("ll", C.c_void_p),
+        ("ll_partial", C.c_void_p),
+        ("ll_ticket", C.c_void_p),
+        ("bad_input", C.c_void_p),
+        ("cat_logits", C.c_void_p),
+        ("cat_idx", C.c_void_p),
+        ("dense_logits", C.c_void_p),
+        ("table", C.c_void_p),
+        ("table_scale", C.c_void_p),
+        ("rows", C.c_void_p),
+        ("n_tables", C.c_int32), ("n_rows", C.c_int32),
+    ]
+
+
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
 SIGNATURES: dict[str, list[Any]] = {
     "ck_abi_version": [],
@@ -123,6 +145,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_subtree_cat_cpt_fwd": [_p, _p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_leaf_persistent_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "ck_leaf_walk_fwd": [C.POINTER(LeafLaunch), _p],
+    "ck_tail_params_fwd": [C.POINTER(TailParamsLaunch), _p],
     "ck_tail_lse_fwd": [_p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32),
                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _i, _p],
     "ck_tail16_lse_fwd": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p],

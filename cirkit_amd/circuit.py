@@ -32,7 +32,7 @@ from .plan import Plan, resolve_fold_index
 
 # ck_tail16_fold of include/cirkit_hip.h
 _TAIL16_FOLD = np.dtype([("w", "<u8"), ("out", "<u8"), ("child", "<u8", (4,)), ("child_src", "<i4", (4,)), ("H", "<i4"),
-                         ("Ko", "<i4"), ("skip_store", "<i4"), ("pad", "<i4")])
+                         ("Ko", "<i4"), ("skip_store", "<i4"), ("slot", "<i4")])
 assert _TAIL16_FOLD.itemsize == 80
 
 _ALIGN = 64  # arena alignment of every layer block, in activation elements (>= 256 B)
@@ -54,6 +54,7 @@ class _Binding:
         self.program_ll = None  # the same followed by ck_ll_sum
         self.store_version = -1
         self.ll: torch.Tensor | None = None
+        self.params_at_end = False  # the tail launch evaluates the parameters of the next forward (ck_tail_params_fwd)
         self.params_in_leaf = False  # the leaf launch evaluates its parameters (no prologue launch for them)
         self.params_sync: torch.Tensor | None = None
         self.tail_in_leaf = False  # the last leaf launch walks the tail too (no tail launch)
@@ -128,6 +129,12 @@ class HipCircuit:
             that a forward has no parameter launch in front of it.  Needs one leaf group, C <= 256, exact fp32.  Off by
             default: measured at the north-star configuration the phase costs the leaf launch 30 us + 4 us of waiting,
             the prologue launch it replaces 21 us.
+        params_at_end: the parameter graphs are re-evaluated once per forward as in the reference, but at the END of a
+            forward and for the next one: the launch that walks the tail carries the prologue's workgroups beside its own
+            (`ck_tail_params_fwd`: both are latency-bound and independent, a tail block and a parameter block share a compute
+            unit).  A forward whose `TensorStore` has changed since (`store.set`, `invalidate_parameters`) evaluates them at
+            its start first.  Parameter values modified in place behind the store's back are picked up one forward late --
+            the same contract as `cache_params`, which is why this is opt-in.  Needs the conditions of `inlaunch_params`.
         keep_layer_outputs: False: `forward` does not store the 32-unit fold outputs of a tail walked inside the leaf
             launch (nobody but `layer_outputs()` reads them; `log_likelihood_sum` never stores them).
     """
@@ -159,6 +166,7 @@ class HipCircuit:
         merge_tail: bool = False,
         keep_layer_outputs: bool = True,
         inlaunch_params: bool = False,
+        params_at_end: bool = False,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -207,6 +215,8 @@ class HipCircuit:
         self.merge_tail = bool(merge_tail)
         self.keep_layer_outputs = bool(keep_layer_outputs)
         self.inlaunch_params = bool(inlaunch_params)
+        self.params_at_end = bool(params_at_end)
+        self._params_valid_version = -1  # store.data_version the derived parameters in memory were evaluated from
         self._inlaunch: dict | None = None
         self._recording = False
         self._num_states: torch.Tensor | None = None
@@ -500,6 +510,7 @@ class HipCircuit:
         bd.direct = self._direct_input(B)
         bd.tail_in_leaf = self._tail_in_leaf(B)
         bd.params_in_leaf = self._params_in_leaf(B)
+        bd.params_at_end = self._params_at_end(B)
         if bd.params_in_leaf:
             bd.params_sync = torch.zeros(8 * 16, dtype=torch.int64, device=self.device)
         if bd.tail_in_leaf:
@@ -573,7 +584,7 @@ class HipCircuit:
         self._recording = True
         try:
             if not self.cache_params:
-                self._enqueue_params(0, in_leaf=bd.params_in_leaf)
+                self._enqueue_params(0, in_leaf=bd.params_in_leaf or bd.params_at_end)
             self._enqueue_layers(bd, 0, with_ll=with_ll)
             if self.validate_inputs and self._int_input and not bd.direct and not self._poison_in_tail():
                 for p, f in self._out_pairs:  # (complex outputs: both halves of every element)
@@ -849,7 +860,7 @@ class HipCircuit:
 
     def _enqueue_params_batch_only(self, stream: int, bd: _Binding) -> None:
         """The prologue launch of a forward of this binding (profiling): all jobs, or what the leaf launch leaves."""
-        if bd.params_in_leaf:
+        if bd.params_in_leaf or bd.params_at_end:
             self._ensure_param_batch()
             if self._inlaunch["rest"] is not None:
                 self._inlaunch["rest"].launch(stream)
@@ -885,7 +896,7 @@ class HipCircuit:
         """Which jobs of the prologue the persistent leaf launch can take over (`inlaunch_params`): the table job of the
         (single) leaf group, the softmaxes of its level weights, and every other 32-wide softmax; what is left stays a
         (smaller, often empty) prologue launch.  None: nothing is taken over."""
-        if not (self.inlaunch_params and self.batch_params and not self.cache_params and self.contraction == "f32"
+        if not ((self.inlaunch_params or self.params_at_end) and self.batch_params and not self.cache_params and self.contraction == "f32"
                 and len(self._groups) == 1 and not self._signed and self.leaf_waves == 8):
             return None
         g = self._groups[0]
@@ -921,13 +932,72 @@ class HipCircuit:
         for r, t in zip(xj, xjobs):
             r["in"], r["out"], r["rows"], r["tiled"] = t
         rest = [k for k in range(len(meta)) if k not in taken]
+        lv = []  # the level weights as 32-wide jobs too (for the launch that evaluates everything beside the tail)
+        for j in g.levels:
+            m = meta[self._jobs_of_layer[j][0]]
+            for f in range(m["src"].shape[0]):
+                lv.append((m["src"].data_ptr() + f * 4096, m["dst"].data_ptr() + f * 4096, 32, 1))
+        xa = np.zeros(max(1, len(xjobs) + len(lv)), dtype=xj.dtype)
+        for r, t in zip(xa, xjobs + lv):
+            r["in"], r["out"], r["rows"], r["tiled"] = t
         return {"root": g.root, "table": meta[table[0]], "levels": levels, "n_xjobs": len(xjobs),
+                "rows_all": torch.from_numpy(xa.view(np.uint8)).to(self.device), "n_rows_all": len(xjobs) + len(lv),
                 "xjobs": torch.from_numpy(xj.view(np.uint8)).to(self.device), "rest": self._batch.subset(rest) if rest else None}
 
     def _params_in_leaf(self, B: int) -> bool:
         """Whether the leaf launch of a forward at batch size B evaluates the parameters (it is the persistent launch)."""
-        return (self._inlaunch is not None and self._leaf_is_persistent(self._groups[0], B)
+        return (self.inlaunch_params and self._inlaunch is not None and self._leaf_is_persistent(self._groups[0], B)
                 and not self._tail_in_leaf(B))
+
+    def _params_at_end(self, B: int) -> bool:
+        """Whether the tail launch of a forward at batch size B also evaluates the parameters of the next forward."""
+        if not (self.params_at_end and self._inlaunch is not None and not self._params_in_leaf(B) and not self._tail_in_leaf(B)
+                and self._tail and self._tail16_ok() and not self._signed):
+            return False
+        n_slots = self._tail_slots()[2]
+        return 8192 + n_slots * 2048 <= 80 * 1024 and sum(self.layers[j].num_folds for j in self._tail) * 80 + 64 <= 8192
+
+    def _tail_slots(self) -> tuple[dict, dict, int]:
+        """LDS slots for the fold tiles of the tail when LDS is tight (`ck_tail_params_fwd`): (slot of each (layer, fold),
+        last level that reads it, number of slots).  A slot is reused at level L + 1 at the earliest if its fold was read
+        for the last time at level L (within a level folds are read and written concurrently)."""
+        hit = getattr(self, "_tail_slots_cache", None)
+        if hit is not None:
+            return hit
+        level_of = {j: li for li, j in enumerate(self._tail)}
+        last_use: dict[tuple[int, int], int] = {}
+        for j in self._tail:
+            for f in range(self.layers[j].num_folds):
+                if self.layers[j].num_output_units == 32:
+                    last_use[(j, f)] = level_of[j]
+        for j in self._tail:
+            ch = self._children[j]
+            for f in range(ch.shape[0]):
+                for h in range(ch.shape[1]):
+                    key = (int(ch[f, h, 0]), int(ch[f, h, 1]))
+                    if key in last_use:
+                        last_use[key] = max(last_use[key], level_of[j])
+        slot: dict[tuple[int, int], int] = {}
+        free: list[int] = []
+        busy_until: dict[int, int] = {}
+        n_slots = 0
+        for li, j in enumerate(self._tail):
+            free += sorted(s_ for s_, u in busy_until.items() if u < li)
+            for s_ in list(busy_until):
+                if busy_until[s_] < li:
+                    del busy_until[s_]
+            for f in range(self.layers[j].num_folds):
+                if (j, f) not in last_use:
+                    continue
+                if free:
+                    sl = free.pop(0)
+                else:
+                    sl = n_slots
+                    n_slots += 1
+                slot[(j, f)] = sl
+                busy_until[sl] = last_use[(j, f)]
+        self._tail_slots_cache = (slot, last_use, max(1, n_slots))
+        return self._tail_slots_cache
 
     def _register_table_jobs(self, batch: ParamBatch) -> set[int]:
         """`dense_on_table` inside the prologue: for a leaf group whose Categorical probabilities and
@@ -1003,6 +1073,26 @@ class HipCircuit:
         vp = C.c_void_p * n
         ip = C.c_int32 * n
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
+        if self._tail16_ok() and bd.params_at_end:
+            keep = self.keep_layer_outputs and not with_ll
+            desc_dev, levels_dev, n_folds, scratch, ticket, lay = self._tail16_tables(bd, keep=keep, slots=True)
+            fuse_ll = with_ll and self._tail_fuses_ll()
+            il = self._inlaunch
+            d = capi.TailParamsLaunch()
+            d.folds, d.level_begin, d.n_folds, d.n_levels = desc_dev.data_ptr(), levels_dev.data_ptr(), n_folds, n
+            d.n_slots, d.B, d.w_layout = self._tail_slots()[2], bd.B, lay
+            d.ll = bd.ll.data_ptr() if fuse_ll else None
+            d.ll_partial = scratch.data_ptr() if fuse_ll else None
+            d.ll_ticket = ticket.data_ptr() if fuse_ll else None
+            d.bad_input = self._bad_input.data_ptr() if (self._poison_in_tail() and not bd.direct) else None
+            t = il["table"]
+            d.cat_logits, d.dense_logits = t["src"].data_ptr(), t["dense"].data_ptr()
+            d.cat_idx = None if t["idx"] is None else t["idx"].data_ptr()
+            d.table, d.table_scale = t["dst"].data_ptr(), t["scale"].data_ptr()
+            d.n_tables, d.C = int(t["dense"].shape[0]), int(t["src"].shape[2])
+            d.rows, d.n_rows = il["rows_all"].data_ptr(), il["n_rows_all"]
+            capi.call("ck_tail_params_fwd", C.byref(d), stream)
+            return
         if self._tail16_ok():
             # `log_likelihood_sum` returns [sum, count] only: the tail's inner folds stay in LDS; `forward` keeps the layer
             # outputs (`layer_outputs()` reads them) unless the caller opted out
@@ -1024,13 +1114,14 @@ class HipCircuit:
             ip(*[l.arity for l in ls]), ip(*[l.num_output_units for l in ls]), bd.B, ls[0].num_input_units, lay, stream,
         )
 
-    def _tail16_tables(self, bd: _Binding, *, keep: bool = True) -> tuple:
+    def _tail16_tables(self, bd: _Binding, *, keep: bool = True, slots: bool = False) -> tuple:
         """(fold descriptors, level table, number of folds, per-tile LL sums, LL ticket, weight layout) of the 16-row tail
         walk -- `ck_tail16_lse_fwd`, or the tail phase of the leaf launch -- for this binding.  keep=False: 32-unit folds
         that only the tail itself reads are not stored (they are not circuit outputs and no later launch reads them)."""
         ls = [self.layers[j] for j in self._tail]
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
-        key = "tail16" if keep else "tail16-nokeep"
+        key = ("tail16" if keep else "tail16-nokeep") + ("-slots" if slots else "")
+        slot_of = self._tail_slots()[0] if slots else None
         tabs = bd.cp_tabs.get(key)
         if tabs is None:
             first, acc = {}, 0
@@ -1053,14 +1144,16 @@ class HipCircuit:
                     d["out"] = bd.views[j].data_ptr() + f * bd.B * Ko * esz
                     d["H"], d["Ko"] = l.arity, Ko
                     d["skip_store"] = 0 if (keep or Ko != 32 or j in outs or j in read_later) else 1
+                    d["slot"] = (slot_of.get((j, f), 0) if slots else first[j] + f)
                     d["child_src"][:] = -1
                     for h in range(l.arity):
                         pj, pf = int(ch[f, h, 0]), int(ch[f, h, 1])
                         if pj in first and self.layers[pj].num_output_units == 32:
-                            d["child_src"][h] = first[pj] + pf
+                            d["child_src"][h] = slot_of[(pj, pf)] if slots else first[pj] + pf
                         d["child"][h] = arena + int(off[f, h]) * esz
             levels = np.asarray([first[j] for j in self._tail] + [acc], dtype=np.int32)
-            shared = bd.cp_tabs.get("tail16") or bd.cp_tabs.get("tail16-nokeep")  # (one LL scratch / ticket per binding)
+            shared = next((bd.cp_tabs[k] for k in ("tail16", "tail16-nokeep", "tail16-slots", "tail16-nokeep-slots")
+                           if k in bd.cp_tabs), None)  # (one LL scratch / ticket per binding)
             tabs = bd.cp_tabs[key] = (
                 torch.from_numpy(desc.view(np.uint8)).to(self.device), torch.from_numpy(levels).to(self.device), acc,
                 shared[3] if shared else torch.zeros((bd.B + 15) // 16 + 1, dtype=torch.float64, device=self.device),
@@ -1373,6 +1466,12 @@ class HipCircuit:
             if refresh:
                 self._pprog_data_version = self.store.data_version
                 capi.call("ck_program_launch", pprog, 1 if p_graph else 0, stream)
+            if bd.params_at_end:
+                # the launch that ends this forward re-evaluates the parameters for the next one; a store that has changed
+                # since the derived parameters in memory were evaluated gets them evaluated now, on their own
+                if self._params_valid_version != self.store.data_version:
+                    self._launch_param_batch(stream)
+                self._params_valid_version = self.store.data_version
             capi.call("ck_program_launch", prog, 1 if as_graph else 0, stream)
             if run is not cur:
                 cur.wait_stream(run)
@@ -1627,7 +1726,7 @@ class HipCircuit:
                         pbytes += per_fold * n.num_folds
             has_prep = bool(s.params) and not (self.batch_params and l._batched)
             if i == 0 and self.batch_params and self._batch is not None and len(self._batch) and not (
-                    bd.params_in_leaf and self._inlaunch["rest"] is None):
+                    (bd.params_in_leaf or bd.params_at_end) and self._inlaunch["rest"] is None):
                 rows.append({"layer": 0, "kernel": "softmax_batch_kernel<false>", "ms": float(mean[0]),
                              "algorithmic_bytes": float(2 * sum(
                                  int(np.prod(shp)) * 4 for shp, _ in self.plan.tensors.values()))})
@@ -1667,7 +1766,7 @@ class HipCircuit:
                 elif i == self._tail[-1]:
                     tl = next((self.layers[j]._w_layout for j in self._tail
                                if self.layers[j].num_output_units == 32), 0)
-                    rows.append({"layer": self._tail[0], "kernel": (f"tail16_kernel<{tl}, {'true' if self._signed else 'false'}>" if self._tail16_ok() else f"tail_kernel<{tl}>"),
+                    rows.append({"layer": self._tail[0], "kernel": ("tail_params_kernel" if bd.params_at_end else f"tail16_kernel<{tl}, {'true' if self._signed else 'false'}>" if self._tail16_ok() else f"tail_kernel<{tl}>"),
                                  "ms": float(mean[2 * self._tail[0] + 1]),
                                  "algorithmic_bytes": sum(layer_bytes[j] for j in self._tail),
                                  "algorithmic_flops": sum(layer_flops[j] for j in self._tail)})

@@ -373,6 +373,34 @@ typedef struct ck_leaf_launch {
 } ck_leaf_launch;
 int ck_leaf_walk_fwd(const ck_leaf_launch* desc, void* stream);
 
+/* The trailing few-fold levels of forward k (ck_tail16_lse_fwd's walk, 8 waves per 16-row tile, optional fused
+ * `circuit(batch).sum()`) and the parameter graphs of forward k + 1 (ck_param_softmax_batch's kind-5 table jobs and 32-wide
+ * softmaxes) in ONE launch: both are latency-bound on their own and independent of each other.  The reference
+ * re-evaluates its parameter graphs once per forward (parameters/parameter.py:180-188); this launch does that at the END of
+ * a forward, for the next one -- the caller evaluates them on their own (ck_param_softmax_batch) before a forward whose
+ * parameters have changed since.  folds: as ck_tail16_lse_fwd, with `slot` = the LDS slot of each fold's tile (a slot may
+ * be reused by a later fold once every reader of the earlier one has run) and child_src[h] = the child's SLOT; n_slots
+ * slots of 2 KB + 8 KB of descriptors must stay below 80 KB.  Table job d (0 <= d < n_tables): log-table of Categorical
+ * fold cat_idx[d] pushed through dense fold d -> table[d] (C + 1, 32) linear rows, table_scale[d] (C + 1) log scales
+ * (layers/input.py:399-412, layers/inner.py:266-273).  rows: 32-wide softmaxes (nodes.py softmax over the last axis). */
+typedef struct ck_tail_params_launch {
+  const struct ck_tail16_fold* folds;
+  const int32_t* level_begin;
+  int32_t n_folds, n_levels, n_slots, B, w_layout, C;
+  double* ll;
+  double* ll_partial;
+  uint32_t* ll_ticket;
+  const int32_t* bad_input;
+  const float* cat_logits;
+  const int64_t* cat_idx;
+  const float* dense_logits;
+  float* table;
+  float* table_scale;
+  const struct ck_rows32_job* rows;
+  int32_t n_tables, n_rows;
+} ck_tail_params_launch;
+int ck_tail_params_fwd(const ck_tail_params_launch* desc, void* stream);
+
 /* The last `n_layers` levels of a circuit (few folds each) in one launch: one workgroup per 32-row
  * batch tile walks the layers in order, a workgroup barrier between levels.  Layer i is a
  * TorchCPTLayer / dense TorchSumLayer step over the product of its H[i] children (CK_SUM_PROD
@@ -404,7 +432,9 @@ typedef struct ck_tail16_fold {
   int32_t skip_store;      /* != 0 (32-unit folds only): the output is a child inside the tail and nobody else reads it --
                               it stays in LDS and `out` is not written (the reference keeps every layer output alive,
                               graph/modules.py:303-335; a forward that returns only the circuit outputs need not)           */
-  int32_t pad;
+  int32_t slot;            /* LDS slot of the fold's tile for the launches that assign slots (ck_leaf_walk_fwd's tail:
+                              the fold index; ck_tail_params_fwd: any reuse-respecting assignment); ck_tail16_lse_fwd
+                              ignores it */
 } ck_tail16_fold;
 /* signed_values != 0: a real-valued circuit under complex-lse-sum (semiring.py:441-476): every block in memory (children,
  * outputs) is (B, Ko) complex64 holding (log|v|, 0 or pi), the weights may be signed; `ll` must then be NULL. */

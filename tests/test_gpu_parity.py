@@ -665,6 +665,45 @@ def test_forward_only_mode_keeps_results(hip_device):
         assert torch.allclose(la[j], ref[j], rtol=1e-5, atol=2e-3), j
 
 
+@pytest.mark.parametrize("B", [33, 1000, 4096, 5000])
+def test_parameters_evaluated_at_the_end_of_a_forward(hip_device, B):
+    """`params_at_end=True`: the launch that walks the tail of a forward also re-evaluates the parameter graphs, for the next
+    forward (`ck_tail_params_fwd`: tail blocks on 8 waves with their fold tiles in reused LDS slots, table-job blocks, 32-wide
+    softmax blocks).  Same device functions as the two launches it replaces: tables, log scales, every weight, every tail
+    layer output, the circuit output and the fused log-likelihood sum are bit-identical; a forward after `store.set` sees
+    the new values (they are evaluated at its start); two launches per forward."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    tensors = {k: np.array(v, copy=True) for k, v in tensors.items()}
+    kw = dict(device=hip_device, persistent_leaf=True)
+    a = HipCircuit(plan, tensors, **kw)
+    b = HipCircuit(plan, tensors, params_at_end=True, **kw)
+    assert b._bind(B).params_at_end and not a._bind(B).params_at_end
+    assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1
+    assert b._tail_slots()[2] < sum(b.layers[j].num_folds for j in b._tail)  # (slots are reused)
+    rng = np.random.default_rng(B)
+    for step in range(5):
+        x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(13 * B + step))
+        x[::5, ::7] = -1
+        x = x.to(hip_device)
+        la, lb = a.layer_outputs(x), b.layer_outputs(x)
+        for j in b._tail:
+            assert torch.equal(la[j], lb[j]), (step, j)
+        ya = a(x).clone()
+        assert torch.equal(ya, b(x)), step
+        assert torch.equal(a.log_likelihood_sum(x), b.log_likelihood_sum(x)), step
+        ra, rb = a._groups[0].root, b._groups[0].root
+        assert torch.equal(a._group_dev[ra][1], b._group_dev[rb][1]) and torch.equal(a._group_dev[ra][3], b._group_dev[rb][3])
+        for j in list(b._tail) + list(b._groups[0].levels):
+            assert torch.equal(a.layers[j]._w, b.layers[j]._w), (step, j)
+        if step in (1, 2):  # new parameter values: the next forward must use them
+            for name in list(tensors)[:4]:
+                new = a.store[name].cpu().numpy() + 0.1 * rng.standard_normal(tuple(a.store[name].shape)).astype(np.float32)
+                a.store.set(name, new)
+                b.store.set(name, new)
+
+
 def test_raw_batch_is_validated_row_by_row(hip_device):
     """The leaf launches look at low dwords only; the tail launch checks the full 64-bit values of its 16 rows
     (`ck_tail16_walk_fwd`): a row holding a category >= num_categories (an IndexError in the reference, input.py:399-412),
