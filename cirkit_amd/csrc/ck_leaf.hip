@@ -156,7 +156,7 @@ __device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots,
     return s_ctl[3] != 0;
   };
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
-    if (claim(tile)) tail_walk<WAVES, true>(wa, tile, tiles, s_fold, s_level, poison);
+    if (claim(tile)) tail_walk<WAVES, true>(wa, tile, tiles, s_fold, s_level, poison, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), WorkgroupBarrier{});
   // sweep: tiles whose workgroup left without claiming them (never, unless launches compete for compute units)
   for (int base = 0; base < n_tiles; base += static_cast<int>(blockDim.x)) {
     const int tl = base + static_cast<int>(threadIdx.x);
@@ -164,7 +164,7 @@ __device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots,
     if (__syncthreads_or(open)) {
       const int end = min(n_tiles, base + static_cast<int>(blockDim.x));
       for (int t2 = base; t2 < end; ++t2)
-        if (claim(t2)) tail_walk<WAVES, true>(wa, t2, tiles, s_fold, s_level, poison);
+        if (claim(t2)) tail_walk<WAVES, true>(wa, t2, tiles, s_fold, s_level, poison, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), WorkgroupBarrier{});
     }
   }
 }

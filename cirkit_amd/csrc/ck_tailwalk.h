@@ -72,11 +72,32 @@ struct TailWalkArgs {
 // together: a workgroup barrier per level).  Fold t's tile lives in LDS slot s_fold[t].slot (`tiles.of`); child_src[h] >= 0
 // names the SLOT of a child that is a fold of the tail.  WT: children in memory were written by other workgroups of the
 // SAME launch (write-through): read them past the caches; otherwise they come from earlier launches (plain loads).
-template <int WAVES, bool WT>
+// the barrier of a whole workgroup whose LDS data is to be published (not __syncthreads(): no wait for memory operations)
+struct WorkgroupBarrier {
+  __device__ __forceinline__ void operator()() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+};
+// A barrier among `n` of a workgroup's waves only -- the hardware barrier takes all of them -- through a counter in LDS:
+// a wave's LDS writes have completed (lgkmcnt) before it arrives; lane 0 arrives and polls, the wave follows it.  ~0.1 us.
+struct WaveGroupBarrier {
+  unsigned int* ctr;  // in LDS, zero at the start; one per group
+  unsigned int n;
+  unsigned int round;
+  __device__ __forceinline__ void operator()() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ++round;
+    if ((threadIdx.x & 63) == 0) {
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < round * n) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  }
+};
+
+// `wave`: this wave's number among the WAVES that walk the tile; `barrier`: their barrier.
+template <int WAVES, bool WT, class Barrier>
 __device__ __forceinline__ void tail_walk(const TailWalkArgs& a, int tile, const TailTiles& tiles, const TailFold* s_fold,
-                                          const int32_t* s_level, bool poison) {
+                                          const int32_t* s_level, bool poison, int wave, Barrier&& barrier) {
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b_in = lane & 15, kq = lane >> 4;
   const int b = tile * 16 + b_in;
   const bool live = b < a.B;
@@ -108,6 +129,24 @@ __device__ __forceinline__ void tail_walk(const TailWalkArgs& a, int tile, const
       }
     }
   };
+  // the weights of a wave's NEXT fold are requested while the current one computes -- across the level barrier too: they do
+  // not depend on the level below (a weight fetch from L2 per level, exposed, was a third of this walk's time)
+  auto load_w = [&](int t, WRegs16& w) {
+    if (s_fold[t].Ko == kK) {  // (parameters: written by an earlier launch, plain loads)
+      if (a.w_rowmajor) load_w16<CK_W_ROWMAJOR>(s_fold[t].w, lane, w);
+      else load_w16<CK_W_TILED_F32>(s_fold[t].w, lane, w);
+    }
+  };
+  auto first_fold_from = [&](int li) {  // this wave's first fold at or behind level li, or -1
+    for (; li < a.n_levels; ++li)
+      if (s_level[li] + wave < s_level[li + 1]) return s_level[li] + wave;
+    return -1;
+  };
+  WRegs16 w, wn;
+  {
+    const int t0 = first_fold_from(0);
+    if (t0 >= 0) load_w(t0, w);
+  }
   for (int li = 0; li < a.n_levels; ++li) {
     const int t1 = s_level[li + 1];
     int t = s_level[li] + wave;
@@ -115,12 +154,9 @@ __device__ __forceinline__ void tail_walk(const TailWalkArgs& a, int tile, const
     if (t < t1) fetch(t, cur);
     for (; t < t1; t += WAVES) {
       if (t + WAVES < t1) fetch(t + WAVES, nxt);  // the next fold's children are on their way while this one computes
+      const int t_next = t + WAVES < t1 ? t + WAVES : first_fold_from(li + 1);
+      if (t_next >= 0) load_w(t_next, wn);
       const int H = s_fold[t].H, Ko = s_fold[t].Ko;
-      WRegs16 w;
-      if (Ko == kK) {  // (parameters: written by an earlier launch, plain loads)
-        if (a.w_rowmajor) load_w16<CK_W_ROWMAJOR>(s_fold[t].w, lane, w);
-        else load_w16<CK_W_TILED_F32>(s_fold[t].w, lane, w);
-      }
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -218,8 +254,9 @@ __device__ __forceinline__ void tail_walk(const TailWalkArgs& a, int tile, const
         }
       }
       cur = nxt;
+      w = wn;
     }
-    __syncthreads();  // the level's tiles are in LDS
+    barrier();  // the level's tiles are in LDS (no wait for the weights just requested for the next level)
   }
 }
 
