@@ -462,6 +462,20 @@ def main() -> None:
             "mean_ll": float(pair3[0]) / max(float(pair3[1]), 1.0),
         }
         del alt
+        if not args.params_at_end:
+            alt = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse, params_at_end=True)
+            w5s, _, pair5 = timed_region(alt, args.steps, args.warmup, 3)
+            w5 = float(np.median(w5s))
+            variants["params_at_end=True"] = {
+                "what": "every step still evaluates every parameter graph once, exact fp32 -- but in the launch that ENDS the forward "
+                        "(tail of forward k + parameters for forward k+1 in one launch, ck_tail_params_fwd): 2 launches per step; a "
+                        "store that changed since is re-evaluated at the start of the forward (cirkit_amd/csrc/ck_tailp.hip)",
+                "value": world * B * args.steps / w5,
+                "ms_per_step": 1e3 * w5 / args.steps,
+                "mean_ll": float(pair5[0]) / max(float(pair5[1]), 1.0),
+                "launches_per_step": alt.num_launches_ll(B) if hasattr(alt, "num_launches_ll") else None,
+            }
+            del alt
         # Two forwards in flight (cirkit_amd.circuit.HipCircuitStreams): the small latency-bound kernels of
         # one step (parameter prologue, fused tail) fill the bubbles of the other step's leaf kernel.
         from cirkit_amd.circuit import HipCircuitStreams

@@ -216,7 +216,7 @@ class HipCircuit:
         self.keep_layer_outputs = bool(keep_layer_outputs)
         self.inlaunch_params = bool(inlaunch_params)
         self.params_at_end = bool(params_at_end)
-        self._params_valid_version = -1  # store.data_version the derived parameters in memory were evaluated from
+        self._params_valid_version = None  # store.state() the derived parameters in memory were evaluated from
         self._inlaunch: dict | None = None
         self._recording = False
         self._num_states: torch.Tensor | None = None
@@ -224,7 +224,7 @@ class HipCircuit:
         self._bad_input = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self._pprog = None
-        self._pprog_version = self._pprog_data_version = -1
+        self._pprog_version, self._pprog_data_version = -1, None
         if isinstance(tensors, TensorStore):
             self.store = tensors
         else:
@@ -621,7 +621,7 @@ class HipCircuit:
             self._enqueue_params(0)
         finally:
             capi.call("ck_program_end", prog)
-        self._pprog, self._pprog_version, self._pprog_data_version = prog, self.store.version, -1
+        self._pprog, self._pprog_version, self._pprog_data_version = prog, self.store.version, None
         return prog
 
     def invalidate_parameters(self) -> None:
@@ -1447,7 +1447,8 @@ class HipCircuit:
             prog = bd.program_ll if with_ll else bd.program
             lib = capi.load()
             as_graph = bool(self.use_graph) and lib.ck_program_num_ops(prog) > self.graph_min_launches
-            refresh = self.cache_params and self._pprog_data_version != self.store.data_version
+            state = self.store.state() if (self.cache_params or bd.params_at_end) else None
+            refresh = self.cache_params and self._pprog_data_version != state
             pprog = self._param_program() if refresh else None
             p_graph = refresh and bool(self.use_graph) and lib.ck_program_num_ops(pprog) > self.graph_min_launches
             if (as_graph or p_graph) and cur.cuda_stream == 0:  # a capture cannot run on the legacy default stream
@@ -1464,14 +1465,14 @@ class HipCircuit:
                 bd.x_last = xi
                 capi.call("ck_program_set_input", prog, 0, xi.data_ptr())
             if refresh:
-                self._pprog_data_version = self.store.data_version
+                self._pprog_data_version = state
                 capi.call("ck_program_launch", pprog, 1 if p_graph else 0, stream)
             if bd.params_at_end:
                 # the launch that ends this forward re-evaluates the parameters for the next one; a store that has changed
                 # since the derived parameters in memory were evaluated gets them evaluated now, on their own
-                if self._params_valid_version != self.store.data_version:
+                if self._params_valid_version != state:
                     self._launch_param_batch(stream)
-                self._params_valid_version = self.store.data_version
+                self._params_valid_version = state
             capi.call("ck_program_launch", prog, 1 if as_graph else 0, stream)
             if run is not cur:
                 cur.wait_stream(run)

@@ -563,20 +563,17 @@ __device__ __forceinline__ void softmax_job_table_rows(const ck_softmax_job& j, 
       const int k = k0 + kPW * r;
       x[r] = on && k < K ? src[k * n4 + lane] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
+    log_softmax_rows<8>(x);  // (ck_softmax.h; rows k >= K hold -inf throughout and are not stored)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int k = k0 + kPW * r;
       if (k >= K) break;  // (uniform over the wave)
-      const float mx = wave_reduce_dpp<true>(fmaxf(fmaxf(x[r].x, x[r].y), fmaxf(x[r].z, x[r].w)));
-      const float4 dl = make_float4(x[r].x - mx, x[r].y - mx, x[r].z - mx, x[r].w - mx);
-      const float part = on ? (__expf(dl.x) + __expf(dl.y)) + (__expf(dl.z) + __expf(dl.w)) : 0.f;
-      const float ls = __logf(wave_reduce_dpp<false>(part));
       if (on) {
         float* col = tile + (4 * lane) * ldT + k;
-        col[0] = dl.x < -103.9f ? -INFINITY : dl.x - ls;
-        col[ldT] = dl.y < -103.9f ? -INFINITY : dl.y - ls;
-        col[2 * ldT] = dl.z < -103.9f ? -INFINITY : dl.z - ls;
-        col[3 * ldT] = dl.w < -103.9f ? -INFINITY : dl.w - ls;
+        col[0] = x[r].x;
+        col[ldT] = x[r].y;
+        col[2 * ldT] = x[r].z;
+        col[3 * ldT] = x[r].w;
       }
     }
   }
@@ -678,21 +675,10 @@ __device__ __forceinline__ void softmax_job_table_dense64(const ck_softmax_job& 
   }
   if (rows_form) {
     const bool on = lane < (C >> 2);
+    log_softmax_rows<K / kPW64>(x);  // (ck_softmax.h)
+    if (on) {
 #pragma unroll
-    for (int r = 0; r < K / kPW64; ++r) {
-      const int k = wave + kPW64 * r;
-      const float mx = wave_reduce_dpp<true>(fmaxf(fmaxf(x[r].x, x[r].y), fmaxf(x[r].z, x[r].w)));
-      const float4 dl = make_float4(x[r].x - mx, x[r].y - mx, x[r].z - mx, x[r].w - mx);
-      const float part = on ? (__expf(dl.x) + __expf(dl.y)) + (__expf(dl.z) + __expf(dl.w)) : 0.f;
-      const float ls = __logf(wave_reduce_dpp<false>(part));
-      if (on) {
-        float4 o;
-        o.x = dl.x < -103.9f ? -INFINITY : dl.x - ls;
-        o.y = dl.y < -103.9f ? -INFINITY : dl.y - ls;
-        o.z = dl.z < -103.9f ? -INFINITY : dl.z - ls;
-        o.w = dl.w < -103.9f ? -INFINITY : dl.w - ls;
-        *reinterpret_cast<float4*>(tile + k * ld + 4 * lane) = o;
-      }
+      for (int r = 0; r < K / kPW64; ++r) *reinterpret_cast<float4*>(tile + (wave + kPW64 * r) * ld + 4 * lane) = x[r];
     }
   }
   __syncthreads();

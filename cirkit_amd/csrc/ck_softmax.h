@@ -15,19 +15,95 @@ namespace {
 
 // maximum / sum over each 32-lane half of a wave (rows of 32 weights, two rows per wave), without LDS: DPP inside the
 // 16-lane rows, v_permlane16_swap across them (a __shfl_xor is an LDS round trip per step, ten of them per row in a chain)
+// Maximum reductions by hand.  fmaxf() costs three instructions per DPP step (v_mov_dpp, a canonicalising v_max x x that
+// quietens a signalling NaN the move could carry, v_max) plus the wait states of a dependent chain, and there is no way to tell
+// this compiler that the values are not NaNs (#pragma float_control is not supported on the target).  A row of logits does
+// not need fmaxf's NaN rule: a NaN anywhere in it makes the whole softmax row NaN either way (exp(NaN - m) enters the sum).
+// FOUR independent values go through the tree together, their steps interleaved: one v_max_f32_dpp per value and step, and
+// every DPP / permlane operand was written four instructions earlier (two wait states needed; the s_nop covers the first).
+// The maximum is exact: same value as fmaxf for every non-NaN input.
+__device__ __forceinline__ float max_plain(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#define CK_DPP4(ctrl)                                                                     \
+  "v_max_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+  "v_max_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+  "v_max_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+  "v_max_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define CK_SWAP4(op)                                                                      \
+  "v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"       \
+  op " %0, %4\n\t" op " %1, %5\n\t" op " %2, %6\n\t" op " %3, %7\n\t"                     \
+  "v_max_f32 %0, %0, %4\n\tv_max_f32 %1, %1, %5\n\tv_max_f32 %2, %2, %6\n\tv_max_f32 %3, %3, %7\n\t"
+// maximum over each 32-lane half (WAVE = false) or over the wave of four values at once
+template <bool WAVE>
+__device__ __forceinline__ void max4_dpp(float& a, float& b, float& c, float& d) {
+  float t0, t1, t2, t3;
+  if constexpr (WAVE)
+    asm("s_nop 1\n\t" CK_DPP4("quad_perm:[1,0,3,2]") CK_DPP4("quad_perm:[2,3,0,1]") CK_DPP4("row_half_mirror") CK_DPP4("row_mirror")
+            CK_SWAP4("v_permlane16_swap_b32") CK_SWAP4("v_permlane32_swap_b32")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+  else
+    asm("s_nop 1\n\t" CK_DPP4("quad_perm:[1,0,3,2]") CK_DPP4("quad_perm:[2,3,0,1]") CK_DPP4("row_half_mirror") CK_DPP4("row_mirror")
+            CK_SWAP4("v_permlane16_swap_b32")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+}
+#undef CK_DPP4
+#undef CK_SWAP4
+// (one value: the same steps with their wait states)
+#define CK_DPP_MAX(name, ctrl)                                                                                     \
+  __device__ __forceinline__ float name(float v) {                                                                 \
+    float r;                                                                                                       \
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v)); \
+    return r;                                                                                                      \
+  }
+CK_DPP_MAX(dpp_max_q1, "quad_perm:[1,0,3,2]")
+CK_DPP_MAX(dpp_max_q2, "quad_perm:[2,3,0,1]")
+CK_DPP_MAX(dpp_max_hm, "row_half_mirror")
+CK_DPP_MAX(dpp_max_rm, "row_mirror")
+#undef CK_DPP_MAX
+__device__ __forceinline__ float row16_max(float v) { return dpp_max_rm(dpp_max_hm(dpp_max_q2(dpp_max_q1(v)))); }
+template <bool MAX>
+__device__ __forceinline__ float half_reduce_dpp(float v);
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce_dpp(float v);
+// the maxima of N independent values, four at a time
+template <bool WAVE, int N>
+__device__ __forceinline__ void max_n_dpp(float (&v)[N]) {
+  int i = 0;
+#pragma unroll
+  for (; i + 4 <= N; i += 4) max4_dpp<WAVE>(v[i], v[i + 1], v[i + 2], v[i + 3]);
+#pragma unroll
+  for (; i < N; ++i) v[i] = WAVE ? wave_reduce_dpp<true>(v[i]) : half_reduce_dpp<true>(v[i]);
+}
 template <bool MAX>
 __device__ __forceinline__ float half_reduce_dpp(float v) {
-  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
-  v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x140, 0xF, 0xF, true)));  // row_mirror
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);  // rows 0<->1, 2<->3
-  return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  if constexpr (MAX) {
+    v = row16_max(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);  // rows 0<->1, 2<->3
+    return max_plain(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  } else {
+    auto op = [](float a, float b) { return a + b; };
+    v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+    v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+    v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
+    v = op(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x140, 0xF, 0xF, true)));  // row_mirror
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);  // rows 0<->1, 2<->3
+    return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
 }
 template <bool MAX>
 __device__ __forceinline__ float wave_reduce_dpp(float v) {
-  return ck::wave_reduce<MAX>(v);  // (ck_internal.h)
+  if constexpr (MAX) {
+    v = row16_max(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = max_plain(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return max_plain(__uint_as_float(q[0]), __uint_as_float(q[1]));
+  } else {
+    return ck::wave_reduce<false>(v);  // (ck_internal.h: v_add_f32_dpp steps already)
+  }
 }
 
 // Where a softmaxed 32 x 32 weight matrix goes: dword index of W[o][l] inside the fold's 1024-dword block
@@ -52,13 +128,50 @@ __device__ __forceinline__ void softmax_rows32(const float* __restrict__ in, int
     ok[p] = row < rows;
     x[p] = ok[p] ? in[row * 32 + l] : -INFINITY;
   }
+  float mx[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) mx[p] = x[p];
+  max_n_dpp<false, PASSES>(mx);
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
     const int row = 2 * (first_pair + p * pair_stride) + half;
-    const float mx = half_reduce_dpp<true>(x[p]);
-    const float e = ok[p] ? __expf(x[p] - mx) : 0.f;
+    const float e = ok[p] ? __expf(x[p] - mx[p]) : 0.f;
     const float sum = half_reduce_dpp<false>(e);
     if (ok[p]) put(row, l, e / sum);
+  }
+}
+
+// Log-softmax of R rows of logits held by a wave, four per lane (lanes past a row hold -inf), in place:
+//   x <- (x - max) - log sum exp(x - max),   -inf where x - max < -103.9 (where the reference's softmax underflows to 0 and
+//   its logarithm gives -inf: layers/input.py:399-412).
+// Stage by stage over the rows, so that their independent chains interleave (one row after the other is a chain of ~60
+// dependent instructions with wait states in between), and branch-free: lanes past the row hold -inf, exp2 makes them 0.
+// The straightforward form -- fmaxf reductions, __logf, a select per step, row by row -- was 105 instructions per row, and a
+// table job is bound by instruction issue.  Every table job of the prologue uses this function: their tables
+// agree bit for bit.
+template <int R>
+__device__ __forceinline__ void log_softmax_rows(float4 (&x)[R]) {
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  float mx[R], ls[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) mx[r] = max_plain(max_plain(x[r].x, x[r].y), max_plain(x[r].z, x[r].w));
+  max_n_dpp<true, R>(mx);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    x[r] = make_float4(x[r].x - mx[r], x[r].y - mx[r], x[r].z - mx[r], x[r].w - mx[r]);
+    const f32x2v a01 = f32x2v{x[r].x, x[r].y} * 1.44269504088896340736f, a23 = f32x2v{x[r].z, x[r].w} * 1.44269504088896340736f;  // (= __expf's multiply)
+    ls[r] = (__builtin_amdgcn_exp2f(a01.x) + __builtin_amdgcn_exp2f(a01.y)) + (__builtin_amdgcn_exp2f(a23.x) + __builtin_amdgcn_exp2f(a23.y));
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) ls[r] = __builtin_amdgcn_logf(wave_reduce_dpp<false>(ls[r]));  // log2 of the sum, in [0, log2 C]: no denormal to rescale
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    // x - ln 2 * log2(sum) as ONE explicit FMA: a multiply and a subtraction would be contracted by the compiler in one caller
+    // and not in another, and the tables of the different jobs have to agree bit for bit
+    x[r].x = x[r].x < -103.9f ? -INFINITY : __builtin_fmaf(-kLN2, ls[r], x[r].x);
+    x[r].y = x[r].y < -103.9f ? -INFINITY : __builtin_fmaf(-kLN2, ls[r], x[r].y);
+    x[r].z = x[r].z < -103.9f ? -INFINITY : __builtin_fmaf(-kLN2, ls[r], x[r].z);
+    x[r].w = x[r].w < -103.9f ? -INFINITY : __builtin_fmaf(-kLN2, ls[r], x[r].w);
   }
 }
 
@@ -80,30 +193,23 @@ __device__ __forceinline__ void table_dense_rows(const float* __restrict__ theta
   constexpr int K = 32;
   static_assert(K % NW == 0 && 16 % NW == 0, "waves per job");
   constexpr int RPW = K / NW;  // units (rows of logits) per wave
+  __builtin_assume(w >= 0 && w < NW);  // (every row of W this wave takes exists: no bounds branch per pass)
   const int n4 = C >> 2, ld = C + 4;  // row stride of tile[k][c]: 16-byte aligned rows, conflict-free both ways
   float* w_s = tile + K * ld;          // [32][32] row-major linear weights of the dense fold
   const bool on = lane < n4 && theta != nullptr;
   float4 x[RPW];
 #pragma unroll
-  for (int r = 0; r < RPW; ++r)  // unit k = w + NW r: one row of C logits per wave and r, all loads in flight
-    x[r] = on ? reinterpret_cast<const float4*>(theta)[(w + NW * r) * n4 + lane] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int r = 0; r < RPW; ++r) x[r] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  if (on) {  // unit k = w + NW r: one row of C logits per wave and r, all loads in flight
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) x[r] = reinterpret_cast<const float4*>(theta)[(w + NW * r) * n4 + lane];
+  }
   if (theta_w != nullptr)  // W: 32 rows of 32, two rows per wave pass
     softmax_rows32<16 / NW>(theta_w, 32, w, NW, lane, [&](int row, int l, float p) { w_s[row * 32 + l] = p; });
+  log_softmax_rows<RPW>(x);
+  if (on) {
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int k = w + NW * r;
-    const float mx = wave_reduce_dpp<true>(fmaxf(fmaxf(x[r].x, x[r].y), fmaxf(x[r].z, x[r].w)));
-    const float4 dl = make_float4(x[r].x - mx, x[r].y - mx, x[r].z - mx, x[r].w - mx);
-    const float part = on ? (__expf(dl.x) + __expf(dl.y)) + (__expf(dl.z) + __expf(dl.w)) : 0.f;
-    const float ls = __logf(wave_reduce_dpp<false>(part));
-    if (on) {
-      float4 o;
-      o.x = dl.x < -103.9f ? -INFINITY : dl.x - ls;
-      o.y = dl.y < -103.9f ? -INFINITY : dl.y - ls;
-      o.z = dl.z < -103.9f ? -INFINITY : dl.z - ls;
-      o.w = dl.w < -103.9f ? -INFINITY : dl.w - ls;
-      *reinterpret_cast<float4*>(tile + k * ld + 4 * lane) = o;
-    }
+    for (int r = 0; r < RPW; ++r) *reinterpret_cast<float4*>(tile + (w + NW * r) * ld + 4 * lane) = x[r];
   }
   sync();
   if (theta == nullptr) return;
@@ -114,10 +220,15 @@ __device__ __forceinline__ void table_dense_rows(const float* __restrict__ theta
     const int c = t * 32 + b_in;
     const int cl = min(c, C - 1);
     float v[16];
+    const float* col = tile + 4 * kh * ld + cl;  // (read unconditionally -- cl is a valid column --, then selected: a load under a
+    const bool past = c >= C;                    //  condition is a branch per element)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) v[4 * g + tt] = c >= C ? 0.f : tile[(8 * g + 4 * kh + tt) * ld + cl];  // row C: log sum_c p = 0
+      for (int tt = 0; tt < 4; ++tt) {
+        const float t = col[(8 * g + tt) * ld];
+        v[4 * g + tt] = past ? 0.f : t;  // row C: log sum_c p = 0
+      }
     float m = 0.f;
     if constexpr (!KIND5) {
       sum_step<CK_W_ROWMAJOR>(wr, v);

@@ -39,6 +39,12 @@ class TensorStore:
         self._pad = None
         self._padded: dict[int, tuple] = {}  # id(user plan) -> (user plan, padded plan, PadInfo)
 
+    def state(self) -> tuple:
+        """What a cache of derived parameters compares: `data_version` (set / touch) and the sum of the tensors' torch
+        version counters -- any in-place torch operation on a stored tensor (an optimizer step, `store[name].mul_(..)`)
+        bumps one.  Writes through raw pointers by foreign kernels are invisible to both: call `touch()` after them."""
+        return (self.data_version, sum(t._version for t in self._t.values()))
+
     def touch(self) -> None:
         """Record that tensor values were modified in place outside `set`."""
         self.data_version += 1
