@@ -237,9 +237,11 @@ def main() -> None:
                     help="do not run the three short rocprofv3 counter passes (roofline.traffic then comes from profiles/)")
     ap.add_argument("--dist", action="store_true",
                     help="take the distributed code path (process group + the async all-reduce of every step) even at world size 1")
-    ap.add_argument("--params-at-end", action="store_true",
-                    help="evaluate the parameter graphs at the END of every forward, for the next one, inside the launch that walks "
-                         "the tail (HipCircuit(params_at_end=True)); every step still evaluates them once")
+    ap.add_argument("--params-at-start", action="store_true",
+                    help="evaluate the parameter graphs with a launch of their own at the START of every forward "
+                         "(HipCircuit(params_at_end=False)) instead of inside the launch that walks the tail of the forward "
+                         "before (the default; every step evaluates them once either way)")
+    ap.add_argument("--params-at-end", action="store_true", help=argparse.SUPPRESS)  # (the default now; kept for old command lines)
     ap.add_argument("--staged-input", action="store_true",
                     help="stage the batch (int64 (B, D) -> int32 (D, B)) with a launch of its own, as in round 2, instead of "
                          "letting the leaf launch read the caller's tensor")
@@ -302,7 +304,7 @@ def main() -> None:
     fuse = True if args.fuse < 0 else (False if args.fuse == 0 else args.fuse)
     circuit = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse,
                          contraction=args.contraction, direct_input=not args.staged_input,
-                         params_at_end=args.params_at_end)
+                         params_at_end=not args.params_at_start)
     g = torch.Generator().manual_seed(1234 + rank)
     nb = max(1, args.batches)
     xs = [torch.randint(0, 256, (B, plan.num_variables), generator=g).to(device) for _ in range(nb)]  # int64, like the reference
@@ -420,6 +422,9 @@ def main() -> None:
             "contraction": args.contraction,
             "dense_on_table": circuit.dense_on_table,
             "params_recomputed_every_step": True,
+            "params_evaluated": ("at the start of each forward, by a launch of their own" if not getattr(circuit._bind(B), "params_at_end", False)
+                                 else "once per forward, by the launch that ends it (for the next forward; a store that changed in "
+                                      "between -- TensorStore.state() -- is re-evaluated at the start)"),
             "launches_per_step": int(circuit.num_launches_ll(B)),  # incl. the staging launch of the batch, if any
             "leaf_reads_raw_batch": bool(circuit.reads_batch_directly(B)),
         },
@@ -462,14 +467,14 @@ def main() -> None:
             "mean_ll": float(pair3[0]) / max(float(pair3[1]), 1.0),
         }
         del alt
-        if not args.params_at_end:
-            alt = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse, params_at_end=True)
+        if not args.params_at_start:
+            alt = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse, params_at_end=False)
             w5s, _, pair5 = timed_region(alt, args.steps, args.warmup, 3)
             w5 = float(np.median(w5s))
-            variants["params_at_end=True"] = {
-                "what": "every step still evaluates every parameter graph once, exact fp32 -- but in the launch that ENDS the forward "
-                        "(tail of forward k + parameters for forward k+1 in one launch, ck_tail_params_fwd): 2 launches per step; a "
-                        "store that changed since is re-evaluated at the start of the forward (cirkit_amd/csrc/ck_tailp.hip)",
+            variants["params_at_end=False"] = {
+                "what": "the parameter graphs evaluated by a launch of their own at the START of every forward (3 launches per step) "
+                        "instead of by the launch that ends the forward before (`value`: tail of forward k + parameters for forward "
+                        "k+1 in one launch, ck_tail_params_fwd).  Every parameter graph is evaluated once per step, exact fp32, either way",
                 "value": world * B * args.steps / w5,
                 "ms_per_step": 1e3 * w5 / args.steps,
                 "mean_ll": float(pair5[0]) / max(float(pair5[1]), 1.0),
@@ -522,8 +527,8 @@ def main() -> None:
                 child.append("--no-graph")
             if args.staged_input:
                 child.append("--staged-input")
-            if args.params_at_end:
-                child.append("--params-at-end")
+            if args.params_at_start:
+                child.append("--params-at-start")
             pmc = live_pmc(child)
             pmc_source = "three rocprofv3 counter passes run by this bench.py invocation (FETCH_SIZE x2, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES)"
         if pmc is None:

@@ -588,7 +588,7 @@ def test_tail_walked_by_the_leaf_launch(hip_device, B, direct):
 
     plan, tensors, g = load_case("cfg2_qt784")
     kw = dict(device=hip_device, persistent_leaf=True, direct_input=direct, inlaunch_params=False)
-    a = HipCircuit(plan, tensors, merge_tail=False, **kw)
+    a = HipCircuit(plan, tensors, merge_tail=False, params_at_end=False, **kw)
     b = HipCircuit(plan, tensors, merge_tail=True, **kw)
     c = HipCircuit(plan, tensors, merge_tail=True, keep_layer_outputs=False, **kw)
     assert b._bind(B).tail_in_leaf and not a._bind(B).tail_in_leaf
@@ -620,7 +620,7 @@ def test_leaf_launch_evaluates_its_parameters(hip_device, B):
     plan, tensors, g = load_case("cfg2_qt784")
     tensors = {k: np.array(v, copy=True) for k, v in tensors.items()}
     kw = dict(device=hip_device, persistent_leaf=True)
-    a = HipCircuit(plan, tensors, inlaunch_params=False, **kw)
+    a = HipCircuit(plan, tensors, inlaunch_params=False, params_at_end=False, **kw)
     b = HipCircuit(plan, tensors, inlaunch_params=True, **kw)
     assert b._bind(B).params_in_leaf and not a._bind(B).params_in_leaf
     assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1 and b._inlaunch["rest"] is None
@@ -677,8 +677,8 @@ def test_parameters_evaluated_at_the_end_of_a_forward(hip_device, B):
     plan, tensors, g = load_case("cfg2_qt784")
     tensors = {k: np.array(v, copy=True) for k, v in tensors.items()}
     kw = dict(device=hip_device, persistent_leaf=True)
-    a = HipCircuit(plan, tensors, **kw)
-    b = HipCircuit(plan, tensors, params_at_end=True, **kw)
+    a = HipCircuit(plan, tensors, params_at_end=False, **kw)
+    b = HipCircuit(plan, tensors, **kw)  # (the default)
     assert b._bind(B).params_at_end and not a._bind(B).params_at_end
     assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1
     assert b._tail_slots()[2] < sum(b.layers[j].num_folds for j in b._tail)  # (slots are reused)
@@ -876,9 +876,17 @@ def test_cached_parameters_are_refreshed_when_values_change(hip_device):
     # the storage but not the version counter
     hc.store["t1"].data.mul_(2.0)
     ref.store["t1"].data.mul_(2.0)
-    if torch.equal(hc(x), y2):  # (not seen -- the documented contract)
-        hc.invalidate_parameters()
-    assert torch.equal(hc(x), ref(x))
+    assert torch.equal(hc(x), y2)  # (not seen -- the documented contract, also of the default `params_at_end`)
+    hc.invalidate_parameters()
+    ref.store.touch()
+    y3 = hc(x).clone()
+    assert torch.equal(y3, ref(x)) and not torch.equal(y3, y2)
+    # a circuit that evaluates its parameters at the start of every forward sees such writes without being told
+    eager = HipCircuit(plan, tensors, device=hip_device, params_at_end=False)
+    eager.store.update({k: hc.store.export(k) for k in tensors})
+    assert torch.equal(eager(x), y3)
+    eager.store["t1"].data.mul_(0.5)
+    assert torch.equal(eager(x), y2)
 
 
 def test_forwards_in_flight_on_two_streams(hip_device):
