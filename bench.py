@@ -226,9 +226,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="rows per GPU (default: the BASELINE config)")
     ap.add_argument("--no-graph", action="store_true", help="never replay as a hipGraph (only lists of more than 64 launches are by default)")
     ap.add_argument("--fuse", type=int, default=-1, help="-1: full leaf fusion (default), 0: layer-wise, n: n CP-T levels")
-    ap.add_argument("--contraction", default="f32", choices=["f32", "f16x3"],
-                    help="K=32 sum layers: exact fp32 MFMA (default) or 3-term split-fp16 MFMA with fp32 accumulation")
-    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (f16x3, cached parameters, two streams)")
+    ap.add_argument("--contraction", default="f32", choices=["f32"], help="K=32 sum layers: exact fp32 MFMA (the only form)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (cached parameters, parameters at the start, two streams)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short measurements of BASELINE configs 4 and 5 (never part of `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -443,17 +442,6 @@ def main() -> None:
     # Secondary figures (never `value`).
     variants = {}
     if args.contraction == "f32" and not args.no_variants and world == 1:  # single-GPU extras only
-        alt = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse, contraction="f16x3")
-        w2s, _, pair2 = timed_region(alt, args.steps, args.warmup, 3)
-        w2 = float(np.median(w2s))
-        variants["contraction=f16x3"] = {
-            "what": "K=32 sum layers contract with 3-term split-fp16 MFMA products, fp32 accumulation "
-                    "(~22-bit significand; cirkit_amd/csrc/ck_tile.h); everything else identical",
-            "value": world * B * args.steps / w2,
-            "ms_per_step": 1e3 * w2 / args.steps,
-            "mean_ll": float(pair2[0]) / max(float(pair2[1]), 1.0),
-        }
-        del alt
         # "... and additionally reported cached": derived parameters (softmax, log
         # tables, tiled weights) kept from the previous step -- the serving configuration.
         alt = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse, cache_params=True)

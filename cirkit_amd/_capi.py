@@ -9,14 +9,13 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
 CK_SUM_KRON = 2
 CK_W_ROWMAJOR = 0
 CK_W_TILED_F32 = 1
-CK_W_TILED_F16X3 = 2
 CK_UNARY_SIGMOID = 0
 CK_UNARY_SCALED_SIGMOID = 1
 CK_UNARY_EXP = 2

@@ -86,10 +86,8 @@ class HipCircuit:
             of fused CP-T levels, False evaluates layer by layer (every layer output materialised).
         batch_params: recompute all softmax parameters with one launch per forward
             (`ck_param_softmax_batch`) instead of one launch per parameter node.
-        contraction: how the K = 32 sum layers contract in linear space.  ``"f32"``: exact fp32
-            (v_mfma_f32_32x32x2_f32).  ``"f16x3"``: 3-term split-fp16 products with fp32 accumulation
-            on the matrix pipe (~22-bit effective significand, see cirkit_amd/csrc/ck_tile.h);
-            layers that are not eligible stay on the exact path.
+        contraction: how the K = 32 sum layers contract in linear space: ``"f32"``, exact fp32
+            (v_mfma_f32_32x32x2_f32), is the only value (a split-fp16 variant, "f16x3", was slower and is gone).
         dense_on_table: a Categorical input layer followed fold-by-fold by a dense sum layer only
             takes C distinct values per fold, so the dense layer is applied once per forward to the
             (F, C, K) log-probability table (same kernel, batch = C) instead of to every batch row;
@@ -366,15 +364,11 @@ class HipCircuit:
         self.batch_params = batch_params
         self._batch: ParamBatch | None = None
         self._batch_version = -1
-        if contraction not in ("f32", "f16x3"):
-            raise ValueError(f"unknown contraction {contraction!r} (expected 'f32' or 'f16x3')")
-        if contraction == "f16x3" and not batch_params:
-            raise ValueError("contraction='f16x3' needs batch_params=True (the prologue writes the split weights)")
+        if contraction != "f32":
+            raise ValueError(f"unknown contraction {contraction!r} (only 'f32', exact fp32, exists)")
         self.contraction = contraction
         self.dense_on_table = bool(dense_on_table)
         self.tiled_weights = bool(tiled_weights)
-        if contraction == "f16x3" and not tiled_weights:
-            raise ValueError("contraction='f16x3' needs tiled_weights=True")
         self._assign_weight_layouts()
         if self._signed and self._tail and not self._tail16_ok():
             self._tail = []  # (only the 16-row tail walks signed values; the layers then take the complex kernels)
@@ -400,7 +394,7 @@ class HipCircuit:
     def _assign_weight_layouts(self) -> None:
         """Pick the weight layout of every K = 32 sum layer (ck_tile.h): tiled layouts only where
         the batched prologue can write them, and uniformly inside a fused launch."""
-        tiled = capi.CK_W_TILED_F16X3 if self.contraction == "f16x3" else capi.CK_W_TILED_F32
+        tiled = capi.CK_W_TILED_F32
         elig = {
             i: self.batch_params and self.tiled_weights and getattr(l, "tile32_eligible", False)
             for i, l in enumerate(self.layers)

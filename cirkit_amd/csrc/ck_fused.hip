@@ -393,7 +393,7 @@ int ck_subtree_cat_cpt_fwd(const float* table, const float* table_scale, const i
   CK_REQUIRE(depth == 0 || w_levels != nullptr, "ck_subtree_cat_cpt_fwd: w_levels is null");
   CK_REQUIRE(depth > 0 || w_dense != nullptr, "ck_subtree_cat_cpt_fwd: nothing to fuse (depth 0, no dense layer)");
   CK_REQUIRE(F_root > 0 && B > 0 && C > 0, "ck_subtree_cat_cpt_fwd: non-positive size");
-  CK_REQUIRE(w_layout >= CK_W_ROWMAJOR && w_layout <= CK_W_TILED_F16X3, "ck_subtree_cat_cpt_fwd: unknown w_layout %d", w_layout);
+  CK_REQUIRE(w_layout == CK_W_ROWMAJOR || w_layout == CK_W_TILED_F32, "ck_subtree_cat_cpt_fwd: unknown w_layout %d", w_layout);
   if (K != kK) return ck::fail(CK_ERR_UNSUPPORTED, "ck_subtree_cat_cpt_fwd: K=%d (only K=32 is fused)", K);
   CK_REQUIRE(ck::aligned16(table) && ck::aligned16(out) && (!w_dense || ck::aligned16(w_dense)),
              "ck_subtree_cat_cpt_fwd: buffers must be 16-byte aligned");
@@ -423,12 +423,10 @@ int ck_subtree_cat_cpt_fwd(const float* table, const float* table_scale, const i
       [=](hipStream_t s) {
         if (table_scale != nullptr) {
           if (w_layout == CK_W_ROWMAJOR) return launch_linear<CK_W_ROWMAJOR>(a, depth, grid, s);
-          if (w_layout == CK_W_TILED_F32) return launch_linear<CK_W_TILED_F32>(a, depth, grid, s);
-          return launch_linear<CK_W_TILED_F16X3>(a, depth, grid, s);
+          return launch_linear<CK_W_TILED_F32>(a, depth, grid, s);
         }
         if (w_layout == CK_W_ROWMAJOR) return launch_depth<CK_W_ROWMAJOR>(a, depth, has_dense, grid, s);
-        if (w_layout == CK_W_TILED_F32) return launch_depth<CK_W_TILED_F32>(a, depth, has_dense, grid, s);
-        return launch_depth<CK_W_TILED_F16X3>(a, depth, has_dense, grid, s);
+        return launch_depth<CK_W_TILED_F32>(a, depth, has_dense, grid, s);
       },
       stream);
 }

@@ -280,18 +280,7 @@ __device__ __forceinline__ void softmax_job_rows(const ck_softmax_job& j, int bl
           const int g = l >> 3, kh2 = (l >> 2) & 1, t = l & 3;
           const int ln = o + 32 * kh2;
           float* base = j.out + fold * 1024;
-          if (j.kind == 2) {
-            base[g * 256 + ln * 4 + t] = p;
-          } else {
-            // 2-term fp16 split of Wt = 2048 p:  Wt = hi + lo / 2048
-            const float wt = p * 2048.f;
-            const _Float16 hi = static_cast<_Float16>(wt);
-            const _Float16 lo = static_cast<_Float16>((wt - static_cast<float>(hi)) * 2048.f);
-            _Float16* h16 = reinterpret_cast<_Float16*>(base);
-            const int q = g >> 1, jj = 4 * (g & 1) + t;
-            h16[(q * 256 + ln * 4) * 2 + jj] = hi;
-            h16[((q + 2) * 256 + ln * 4) * 2 + jj] = lo;
-          }
+          base[g * 256 + ln * 4 + t] = p;  // (kind 2)
         }
       }
     }
@@ -1073,7 +1062,7 @@ int ck_param_softmax_batch(const ck_softmax_job* jobs, int njobs, void* stream) 
         ck_softmax_job j = jobs[start];
         const int idx = start++;
         CK_REQUIRE(j.in && j.out && j.rows > 0 && j.len > 0, "ck_param_softmax_batch: bad job %d", idx);
-        CK_REQUIRE(j.kind >= 0 && j.kind <= 5, "ck_param_softmax_batch: job %d has unknown kind %d", idx, j.kind);
+        CK_REQUIRE(j.kind >= 0 && j.kind <= 5 && j.kind != 3, "ck_param_softmax_batch: job %d has unknown kind %d", idx, j.kind);
         CK_REQUIRE(j.kind < 2 || j.kind >= 4 || (j.len == 32 && j.rows % 32 == 0),
                    "ck_param_softmax_batch: tiled job %d needs len = 32 and rows %% 32 = 0", idx);
         CK_REQUIRE(j.kind < 4 || ((j.k == 32 || (j.k == 64 && j.kind == 4)) && j.in2 != nullptr),

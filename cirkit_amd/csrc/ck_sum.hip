@@ -582,7 +582,7 @@ int ck_debug_force_generic(int on) {
 int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
                    int H, int B, int Ki, int Ko, int mode, int w_layout, void* stream) {
   if (int st = check_sum_args(arena, row_off, w, out, F, H, B, Ki, Ko, mode, "ck_sum_lse_fwd")) return st;
-  CK_REQUIRE(w_layout >= CK_W_ROWMAJOR && w_layout <= CK_W_TILED_F16X3, "ck_sum_lse_fwd: unknown w_layout %d", w_layout);
+  CK_REQUIRE(w_layout == CK_W_ROWMAJOR || w_layout == CK_W_TILED_F32, "ck_sum_lse_fwd: unknown w_layout %d", w_layout);
   if (F > ck::kMaxFoldsPerLaunch) {  // (words of weights per fold: Ko x the contracted inputs, whatever the layout)
     int64_t nin = Ki;
     if (mode == CK_SUM_CAT) nin = static_cast<int64_t>(H) * Ki;
@@ -607,10 +607,8 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
         [=](hipStream_t s) {
           if (w_layout == CK_W_ROWMAJOR)
             hipLaunchKernelGGL(sum_lse_tile32<CK_W_ROWMAJOR>, grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
-          else if (w_layout == CK_W_TILED_F32)
-            hipLaunchKernelGGL(sum_lse_tile32<CK_W_TILED_F32>, grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
           else
-            hipLaunchKernelGGL(sum_lse_tile32<CK_W_TILED_F16X3>, grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
+            hipLaunchKernelGGL(sum_lse_tile32<CK_W_TILED_F32>, grid, block, 0, s, arena, row_off, w, out, H, B, tpw);
           return hipGetLastError();
         },
         stream);

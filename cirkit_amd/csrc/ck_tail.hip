@@ -89,7 +89,7 @@ int ck_tail_lse_fwd(const float* arena, int n_layers, const int64_t* const* row_
   CK_REQUIRE(n_layers > 0 && n_layers <= kMaxTail, "ck_tail_lse_fwd: n_layers=%d outside [1, %d]", n_layers, kMaxTail);
   CK_REQUIRE(B > 0, "ck_tail_lse_fwd: B must be positive");
   if (K != kK) return ck::fail(CK_ERR_UNSUPPORTED, "ck_tail_lse_fwd: K=%d (only K=32)", K);
-  CK_REQUIRE(w_layout >= CK_W_ROWMAJOR && w_layout <= CK_W_TILED_F16X3, "ck_tail_lse_fwd: unknown w_layout %d", w_layout);
+  CK_REQUIRE(w_layout == CK_W_ROWMAJOR || w_layout == CK_W_TILED_F32, "ck_tail_lse_fwd: unknown w_layout %d", w_layout);
   TailArgs a{};
   a.arena = arena;
   a.n = n_layers;
@@ -106,10 +106,8 @@ int ck_tail_lse_fwd(const float* arena, int n_layers, const int64_t* const* row_
       [=](hipStream_t s) {
         if (w_layout == CK_W_ROWMAJOR)
           hipLaunchKernelGGL(tail_kernel<CK_W_ROWMAJOR>, grid, block, 0, s, a);
-        else if (w_layout == CK_W_TILED_F32)
-          hipLaunchKernelGGL(tail_kernel<CK_W_TILED_F32>, grid, block, 0, s, a);
         else
-          hipLaunchKernelGGL(tail_kernel<CK_W_TILED_F16X3>, grid, block, 0, s, a);
+          hipLaunchKernelGGL(tail_kernel<CK_W_TILED_F32>, grid, block, 0, s, a);
         return hipGetLastError();
       },
       stream);

@@ -2,17 +2,14 @@
 // (ck_fused.hip) and the fused tail (ck_tail.hip).
 //
 // Lane l of a wave: b = l & 31 (batch row of the 32-row tile), kh = l >> 5.  Lane (b, kh) holds
-// units 8g + 4kh + t (g, t in 0..3) of row b in register j = 4g + t.  Both MFMA shapes used here
-// (v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_f16) return D[o][b] in lane (b, hi) register r
-// with o = 8(r>>2) + 4hi + (r&3): the OUTPUT layout of a step is the INPUT layout of the next.
+// units 8g + 4kh + t (g, t in 0..3) of row b in register j = 4g + t.  v_mfma_f32_32x32x2_f32 returns D[o][b] in lane
+// (b, hi) register r with o = 8(r>>2) + 4hi + (r&3): the OUTPUT layout of a step is the INPUT layout of the next.
 //
 // Weight layouts of one fold (32 outputs x 32 inputs = 1024 dwords):
 //   CK_W_ROWMAJOR    W[o][i] fp32 -- the reference's layout; lane (o, kh) reads 4 x 16 B at stride 32 B
 //   CK_W_TILED_F32   dword (q, lane, t) = W[o = lane&31][8q + 4(lane>>5) + t]: every wave load
 //                    instruction reads one contiguous KiB (8 lines instead of 32)
-//   CK_W_TILED_F16X3 same tiling, contents = 2-term fp16 split of 2048*W for the split-precision
-//                    contraction below: q = 0,1 hold hi (8 halves each), q = 2,3 hold lo
-// The tiled layouts are produced by the softmax prologue (ck_param.hip, kinds 2 and 3).
+// The tiled layout is produced by the softmax prologue (ck_param.hip, kind 2).
 #pragma once
 
 #include <type_traits>
@@ -24,7 +21,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int kK = 32;
 
 struct WRegs {
@@ -67,16 +63,12 @@ __device__ __forceinline__ float exp_offset(float m, float shift) {
 // LAYOUT ROWMAJOR / TILED_F32: exact fp32 contraction on v_mfma_f32_32x32x2_f32 (an fmaf chain).
 //   Measured on MI355X: this MFMA shares the fp32 ALUs with the VALU, the two never
 //   co-execute, so its 16 x 64 cycles add to the exp/log work.
-// LAYOUT TILED_F16X3: split-precision contraction on the real matrix pipe.  E = 2048 exp(v - m) is
-//   split EXACTLY into hiE (top 11 significand bits, representable in fp16) + loE; the weights
-//   were split by the prologue into hiW + loW/2048 (of 2048 W).  Three fp16 MFMA products with fp32
-//   accumulation,  2^22 y = (hiW.hiE + hiW.loE) + (loW.hiE)/2048,  drop only the lo.lo term:
-//   relative error <= ~3 x 2^-22 of the dominant terms (fp32 is 2^-24) -- below the error of the
-//   v_exp_f32/v_log_f32 pair used on either path.  6 MFMAs x 32 cycles that overlap with VALU.
+// (A split-fp16 variant -- three v_mfma_f32_32x32x16_f16 products per step, ~22-bit significand -- lived here until round 3:
+//  0.154 ms per step against 0.105 for this exact path, and its low parts underflowed on small weights.  Removed.)
 template <int LAYOUT>
 __device__ __forceinline__ void sum_step(const WRegs& w, float (&v)[16]) {
   const float m = row_max16(v);
-  if constexpr (LAYOUT != CK_W_TILED_F16X3) {
+  {
     const float nml = exp_offset(m, 0.f);
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = __builtin_amdgcn_exp2f(fmaf(v[j], kL2E, nml));
@@ -92,45 +84,6 @@ __device__ __forceinline__ void sum_step(const WRegs& w, float (&v)[16]) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m);
-  } else {
-    const float nml = exp_offset(m, 11.f);  // E = 2^11 exp(v - m) in (0, 2048]
-    union {
-      f16x8 v8[2];
-      uint32_t v2[8];
-    } hi, lo;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const float e0 = __builtin_amdgcn_exp2f(fmaf(v[2 * p], kL2E, nml));
-      const float e1 = __builtin_amdgcn_exp2f(fmaf(v[2 * p + 1], kL2E, nml));
-      const float h0 = __uint_as_float(__float_as_uint(e0) & 0xFFFFE000u);
-      const float h1 = __uint_as_float(__float_as_uint(e1) & 0xFFFFE000u);
-      hi.v2[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0, h1));  // exact: 11 significant bits
-      lo.v2[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(e0 - h0, e1 - h1));  // residual < 2^-11 E
-    }
-    union {
-      float4 f4;
-      f16x8 h8;
-    } a0, a1, a2, a3;
-    a0.f4 = w.q[0];
-    a1.f4 = w.q[1];
-    a2.f4 = w.q[2];
-    a3.f4 = w.q[3];
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc0[r] = 0.f;
-      acc1[r] = 0.f;
-    }
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h8, hi.v8[0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2.h8, hi.v8[0], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h8, hi.v8[1], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3.h8, hi.v8[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h8, lo.v8[0], acc0, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h8, lo.v8[1], acc0, 0, 0, 0);
-    const float mm = fmaf(-22.f, kLN2, m);  // undo the two 2^11 scalings
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      v[r] = fmaf(__builtin_amdgcn_logf(fmaf(acc1[r], 4.8828125e-4f, acc0[r])), kLN2, mm);
   }
 }
 
@@ -139,7 +92,7 @@ __device__ __forceinline__ void sum_step(const WRegs& w, float (&v)[16]) {
 // scale) instead of going through log and exp again (ck_fused.hip).
 template <int LAYOUT>
 __device__ __forceinline__ void contract_linear(const WRegs& w, float (&e)[16]) {
-  if constexpr (LAYOUT != CK_W_TILED_F16X3) {
+  {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -152,41 +105,6 @@ __device__ __forceinline__ void contract_linear(const WRegs& w, float (&e)[16]) 
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) e[r] = acc[r];
-  } else {
-    union {
-      f16x8 v8[2];
-      uint32_t v2[8];
-    } hi, lo;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const float e0 = e[2 * p] * 2048.f, e1 = e[2 * p + 1] * 2048.f;  // E = 2^11 e, exact
-      const float h0 = __uint_as_float(__float_as_uint(e0) & 0xFFFFE000u);
-      const float h1 = __uint_as_float(__float_as_uint(e1) & 0xFFFFE000u);
-      hi.v2[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-      lo.v2[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(e0 - h0, e1 - h1));
-    }
-    union {
-      float4 f4;
-      f16x8 h8;
-    } a0, a1, a2, a3;
-    a0.f4 = w.q[0];
-    a1.f4 = w.q[1];
-    a2.f4 = w.q[2];
-    a3.f4 = w.q[3];
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc0[r] = 0.f;
-      acc1[r] = 0.f;
-    }
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h8, hi.v8[0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2.h8, hi.v8[0], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h8, hi.v8[1], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3.h8, hi.v8[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h8, lo.v8[0], acc0, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h8, lo.v8[1], acc0, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) e[r] = fmaf(acc1[r], 4.8828125e-4f, acc0[r]) * 2.384185791015625e-07f;  // 2^-22
   }
 }
 
@@ -344,7 +262,6 @@ __device__ __forceinline__ void tile_walk_logspace(LeafFn&& leaf, WFn&& weights,
 // signs; a sum step exponentiates with the sign, contracts, and takes log|y| and the sign of y.
 template <int LAYOUT>
 __device__ __forceinline__ void sum_step_signed(const WRegs& w, float (&v)[16], uint32_t& sg) {
-  static_assert(LAYOUT != CK_W_TILED_F16X3, "exact fp32 contraction only");
   const float m = row_max16(v);
   const float nml = exp_offset(m, 0.f);
 #pragma unroll

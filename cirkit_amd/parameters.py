@@ -108,10 +108,10 @@ class ParamBatch:
         return pb
 
     def add_softmax(self, src: torch.Tensor, dst: torch.Tensor, layout: int = 0) -> None:
-        """dst = softmax(src, dim=-1); both (..., len) contiguous fp32.  `layout` 1 / 2 writes the
-        (F, 32, 32) result in the MFMA-tiled fp32 / split-fp16 layout of ck_tile.h instead."""
+        """dst = softmax(src, dim=-1); both (..., len) contiguous fp32.  `layout` 1 writes the
+        (F, 32, 32) result in the MFMA-tiled fp32 layout of ck_tile.h instead."""
         rows = src.numel() // src.shape[-1]
-        kind = {0: 0, 1: 2, 2: 3}[layout]
+        kind = {0: 0, 1: 2}[layout]
         self._jobs.append((src.data_ptr(), dst.data_ptr(), rows, int(src.shape[-1]), 0, kind, None, None, None))
         self._meta.append({"kind": kind, "src": src, "dst": dst})
         self._keep += [src, dst]

@@ -43,11 +43,10 @@ typedef enum ck_status {
 #define CK_SUM_KRON 2 /* TorchTuckerLayer (arity 2): Kronecker of the children -> N = Ki*Ki,
                          one maximum per child (optimized.py:89-103)                     */
 
-/* weight layouts of the Ki = Ko = 32 sum kernels (cirkit_amd/csrc/ck_tile.h).  The tiled layouts
- * are written by ck_param_softmax_batch (job kinds 2 / 3). */
+/* weight layouts of the Ki = Ko = 32 sum kernels (cirkit_amd/csrc/ck_tile.h).  The tiled layout
+ * is written by ck_param_softmax_batch (job kind 2).  (Layout 2 was a split-fp16 form: removed.) */
 #define CK_W_ROWMAJOR 0    /* (F, Ko, N) fp32, the reference's layout                                 */
 #define CK_W_TILED_F32 1   /* per fold: dword (q, lane, t) = W[lane&31][8q + 4(lane>>5) + t], fp32     */
-#define CK_W_TILED_F16X3 2 /* same tiling, 2-term fp16 split of 2048*W: split-precision MFMA contraction */
 
 /* unary parameter ops of ck_param_unary */
 #define CK_UNARY_SIGMOID 0
@@ -455,8 +454,8 @@ int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_
  * (copied into the launch).  kind 0: out[r, :] = softmax(in[r, :]) for `rows` rows of `len`.
  * kind 1 (Categorical probs, input.py:405-408): in (rows=F, k=K, len=C) logits ->
  * out (F, C+1, K) = log(softmax over C), transposed for the gather kernels, row C = 0 (integral).
- * kind 2 / 3: as kind 0 for (F*32, 32) weights, written in CK_W_TILED_F32 / CK_W_TILED_F16X3
- * layout (rows must be a multiple of 32, len = 32).
+ * kind 2: as kind 0 for (F*32, 32) weights, written in CK_W_TILED_F32 layout (rows must be a multiple of 32,
+ * len = 32).  (kind 3 wrote the split-fp16 layout of a contraction that no longer exists: rejected.)
  * kind 4: kind 1 followed by a dense sum layer applied to the table (k = 32 or 64): for each of the `rows`
  * dense folds d, out[d] (C+1, 32) = log(softmax(in2[d]) . exp(T - m)) + m row by row, with T the kind-1
  * table of categorical fold idx[d] (a Categorical layer followed fold by fold by a dense layer only
