@@ -24,10 +24,13 @@ Parameters stay the reference's ``TorchParameter`` graphs (evaluated by torch on
 the gather from the category table, the log-einsum-exp, the products -- is the HIP kernel.  Semirings: lse-sum and
 complex-lse-sum; anything else raises (no fallback to the stock forward).
 
-**Inference only.**  The layer forwards write into fresh buffers, so their results carry no ``grad_fn``:
-``loss = -cc(x).mean(); loss.backward()`` cannot train through them.  They therefore RAISE when gradients are enabled and
-an input or parameter requires them (`cirkit_amd.layer_ops._forward_only`) -- wrap evaluation in ``torch.no_grad()``.
-Training on the HIP path is `cirkit_amd.training.HipTrainer` (hand-written backward kernels over the plan, b4 level).
+**Training.**  Under the real lse-sum semiring the Sum / CP-T / Tucker / Hadamard / Kronecker / Categorical / Gaussian
+forwards are ``torch.autograd.Function``s (`cirkit_amd.layer_ops`): ``loss = -cc(x).mean(); loss.backward(); opt.step()``
+-- the reference's training loop, notebooks/learning-a-circuit.ipynb -- runs unchanged; autograd differentiates the
+reference's parameter graphs and the gather between layers, the hand-written kernels of ck_backward.hip supply each
+layer's d/dx and d/dW.  The complex semiring, Embedding, TensorDot and ConstantValue layers record no graph: they RAISE
+when gradients are enabled and an input or parameter requires them (`layer_ops._forward_only`) -- evaluate those under
+``torch.no_grad()``.  The fast path for training a whole plan is `cirkit_amd.training.HipTrainer` (b4 level).
 """
 
 from __future__ import annotations

@@ -8,6 +8,14 @@ are exercised on the GPU box (tests/test_gpu_layer_ops.py) where the reference i
 
 Every function enqueues on the current stream of the input's device and raises if the input is not on a ROCm device:
 there is no CPU or eager fallback.
+
+Autograd.  Under the real lse-sum semiring `sum_lse`, `hadamard`, `kronecker`, `categorical_log_likelihood` and
+`gaussian_log_likelihood` are `torch.autograd.Function`s whose backward is the hand-written kernels of
+cirkit_amd/csrc/ck_backward.hip (the ones `HipTrainer` walks a whole plan with): the reference's training loop
+(``loss = -circuit(x).mean(); loss.backward(); opt.step()``, notebooks/learning-a-circuit.ipynb) works unchanged on a
+circuit compiled with the plugin -- autograd differentiates the reference's own parameter graphs (softmax, ...) and the
+gather between layers, these functions supply d/dx and d/dW of each layer.  The complex semiring, Embedding, TensorDot and
+ConstantValue forwards record no graph: asking them for gradients raises (`_forward_only`).
 """
 
 from __future__ import annotations
@@ -52,11 +60,142 @@ def _children(x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, int, int, in
     return x, row_off, F, H, B, Ki
 
 
+class _SumLSE(torch.autograd.Function):
+    """Real `sum_lse`: forward `ck_sum_lse_fwd`, backward `ck_sum_lse_bwd` (children gradients + dW with float atomics over
+    the batch tiles: rounding-level run-to-run differences, as in `HipTrainer`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, row_off, mode):
+        F, H, B, Ki = x.shape
+        Ko = int(weight.shape[1])
+        xf = x.detach().to(torch.float32).contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        out = torch.empty((F, B, Ko), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            capi.call("ck_sum_lse_fwd", xf.data_ptr(), row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, H, B, Ki, Ko, mode,
+                      capi.CK_W_ROWMAJOR, _stream(x.device))
+        ctx.save_for_backward(xf, w, out, row_off)
+        ctx.mode, ctx.dtypes = mode, (x.dtype, weight.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xf, w, out, row_off = ctx.saved_tensors
+        F, H, B, Ki = xf.shape
+        Ko = int(w.shape[1])
+        g = gout.to(torch.float32).contiguous()
+        gx = torch.empty_like(xf)
+        dw = torch.zeros_like(w)
+        with torch.cuda.device(xf.device):
+            capi.call("ck_sum_lse_bwd", xf.data_ptr(), gx.data_ptr(), row_off.data_ptr(), None, w.data_ptr(), out.data_ptr(),
+                      g.data_ptr(), dw.data_ptr(), F, H, B, Ki, Ko, ctx.mode, 0, _stream(xf.device))
+        return gx.to(ctx.dtypes[0]), dw.to(ctx.dtypes[1]), None, None
+
+
+class _Product(torch.autograd.Function):
+    """Real `hadamard` / `kronecker` (log space: sums of the children's values)."""
+
+    @staticmethod
+    def forward(ctx, x, row_off, kron):
+        F, H, B, K = x.shape
+        xf = x.detach().to(torch.float32).contiguous()
+        out = torch.empty((F, B, K**H if kron else K), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            capi.call("ck_kronecker_fwd" if kron else "ck_hadamard_fwd", xf.data_ptr(), row_off.data_ptr(), out.data_ptr(), F, H,
+                      B, K, 1, _stream(x.device))
+        ctx.save_for_backward(row_off)
+        ctx.kron, ctx.shape, ctx.dtype = kron, tuple(x.shape), x.dtype
+        return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (row_off,) = ctx.saved_tensors
+        F, H, B, K = ctx.shape
+        g = gout.to(torch.float32).contiguous()
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            capi.call("ck_kronecker_bwd" if ctx.kron else "ck_hadamard_bwd", gx.data_ptr(), row_off.data_ptr(), g.data_ptr(), F, H,
+                      B, K, 0, _stream(g.device))
+        return gx.to(ctx.dtype), None, None
+
+
+class _Categorical(torch.autograd.Function):
+    """`categorical_log_likelihood`: the gather of table rows; backward = `ck_categorical_bwd`, a scatter-add into the
+    (F, C + 1, K) table, handed back in the (F, K, C) shape of the logits."""
+
+    @staticmethod
+    def forward(ctx, logits, xi):
+        F, K, C = logits.shape
+        B = xi.shape[1]
+        dev = xi.device
+        # the gather kernel reads a (F, C + 1, K) table (row C = the integral row, unused here) through per-fold variables
+        table = torch.empty((F, C + 1, K), dtype=torch.float32, device=dev)
+        table[:, :C] = logits.detach().to(torch.float32).transpose(1, 2)
+        table[:, C] = 0.0
+        scope = torch.arange(F, dtype=torch.int64, device=dev)
+        out = torch.empty((F, B, K), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            capi.call("ck_categorical_fwd", table.data_ptr(), xi.data_ptr(), scope.data_ptr(), out.data_ptr(), F, B, K, C, F,
+                      _stream(dev))
+        ctx.save_for_backward(xi, scope)
+        ctx.dims, ctx.dtype = (F, K, C, B), logits.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xi, scope = ctx.saved_tensors
+        F, K, C, B = ctx.dims
+        g = gout.to(torch.float32).contiguous()
+        dtable = torch.zeros((F, C + 1, K), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            capi.call("ck_categorical_bwd", g.data_ptr(), xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C,
+                      _stream(g.device))
+        return dtable[:, :C].transpose(1, 2).contiguous().to(ctx.dtype), None
+
+
+class _Gaussian(torch.autograd.Function):
+    """`gaussian_log_likelihood`; backward = `ck_gaussian_bwd` (d mean, d stddev as batch sums) and the batch sum of the
+    incoming gradient for the log-partition."""
+
+    @staticmethod
+    def forward(ctx, mean, stddev, log_partition, xt):
+        F, K = mean.shape
+        B = xt.shape[1]
+        dev = xt.device
+        m = mean.detach().to(torch.float32).contiguous()
+        sd = stddev.detach().to(torch.float32).contiguous()
+        lz = None if log_partition is None else log_partition.detach().to(torch.float32).contiguous()
+        scope = torch.arange(F, dtype=torch.int64, device=dev)
+        out = torch.empty((F, B, K), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            capi.call("ck_gaussian_fwd", m.data_ptr(), sd.data_ptr(), None if lz is None else lz.data_ptr(), xt.data_ptr(),
+                      scope.data_ptr(), out.data_ptr(), F, B, K, F, _stream(dev))
+        ctx.save_for_backward(m, sd, xt, scope)
+        ctx.has_lz = log_partition is not None
+        ctx.dtypes = (mean.dtype, stddev.dtype, None if log_partition is None else log_partition.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        m, sd, xt, scope = ctx.saved_tensors
+        F, K = m.shape
+        B = xt.shape[1]
+        g = gout.to(torch.float32).contiguous()
+        dm, ds = torch.zeros_like(m), torch.zeros_like(sd)
+        with torch.cuda.device(g.device):
+            capi.call("ck_gaussian_bwd", g.data_ptr(), xt.data_ptr(), scope.data_ptr(), m.data_ptr(), sd.data_ptr(), dm.data_ptr(),
+                      ds.data_ptr(), F, B, K, _stream(g.device))
+        dlz = g.sum(dim=1).to(ctx.dtypes[2]) if ctx.has_lz else None
+        return dm.to(ctx.dtypes[0]), ds.to(ctx.dtypes[1]), dlz, None
+
+
+
 def sum_lse(x: torch.Tensor, weight: torch.Tensor, mode: int = capi.CK_SUM_CAT) -> torch.Tensor:
     """``TorchSumLayer.forward`` (inner.py:266-273, mode CK_SUM_CAT), ``TorchCPTLayer.forward`` (optimized.py:171-178,
     CK_SUM_PROD) and ``TorchTuckerLayer.forward`` (optimized.py:89-103, CK_SUM_KRON) under lse-sum / complex-lse-sum:
     x (F, H, B, Ki) log-space children, weight (F, Ko, N) linear-space -> (F, B, Ko)."""
-    _forward_only(x, weight)
+    if x.is_complex() or weight.is_complex():
+        _forward_only(x, weight)
     x, row_off, F, H, B, Ki = _children(x)
     if weight.dim() != 3 or weight.shape[0] != F:
         raise ValueError(f"expected a weight of shape (F={F}, Ko, N), found {tuple(weight.shape)}")
@@ -76,36 +215,34 @@ def sum_lse(x: torch.Tensor, weight: torch.Tensor, mode: int = capi.CK_SUM_CAT) 
             return out
         if weight.is_complex():
             raise ValueError("complex weights under the real lse-sum semiring")
-        w = weight.to(torch.float32).contiguous()
-        out = torch.empty((F, B, Ko), dtype=torch.float32, device=x.device)
-        xf = x if x.dtype == torch.float32 else x.to(torch.float32)  # (kept alive until the launch has been enqueued)
-        capi.call("ck_sum_lse_fwd", xf.data_ptr(), row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, H, B, Ki, Ko, mode,
-                  capi.CK_W_ROWMAJOR, st)
-        del xf
-        return out
+        return _SumLSE.apply(x, weight, row_off, mode)
 
 
 def hadamard(x: torch.Tensor) -> torch.Tensor:
     """``TorchHadamardLayer.forward`` (inner.py:126-127) in log space: the sum over the arity axis."""
-    _forward_only(x)
+    if x.is_complex():
+        _forward_only(x)
     x, row_off, F, H, B, K = _children(x)
+    if not x.is_complex():
+        return _Product.apply(x, row_off, False)
     out = torch.empty((F, B, K), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        capi.call("ck_hadamard_fwd", x.data_ptr(), row_off.data_ptr(), out.data_ptr(), F, H, B, K, 2 if x.is_complex() else 1,
-                  _stream(x.device))
+        capi.call("ck_hadamard_fwd", x.data_ptr(), row_off.data_ptr(), out.data_ptr(), F, H, B, K, 2, _stream(x.device))
     return out
 
 
 def kronecker(x: torch.Tensor) -> torch.Tensor:
     """``TorchKroneckerLayer.forward`` (inner.py:178-187), any arity: (F, H, B, K) -> (F, B, K ** H)."""
-    _forward_only(x)
+    if x.is_complex():
+        _forward_only(x)
     x, row_off, F, H, B, K = _children(x)
     if H < 2:
         raise ValueError("The arity should be at least 2")
+    if not x.is_complex():
+        return _Product.apply(x, row_off, True)
     out = torch.empty((F, B, K**H), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
-        capi.call("ck_kronecker_fwd", x.data_ptr(), row_off.data_ptr(), out.data_ptr(), F, H, B, K, 2 if x.is_complex() else 1,
-                  _stream(x.device))
+        capi.call("ck_kronecker_fwd", x.data_ptr(), row_off.data_ptr(), out.data_ptr(), F, H, B, K, 2, _stream(x.device))
     return out
 
 
@@ -152,40 +289,20 @@ def _discrete_input(x: torch.Tensor, num_states: int) -> torch.Tensor:
 def categorical_log_likelihood(x: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
     """``TorchCategoricalLayer.log_unnormalized_likelihood`` (input.py:399-412): x (F, B, 1) categories, logits (F, K, C)
     (``log(probs())`` or ``logits()``) -> (F, B, K)."""
-    _forward_only(logits)
     F, K, C = logits.shape
     xi = _discrete_input(x, C)
-    B = xi.shape[1]
-    # the gather kernel reads a (F, C + 1, K) table (row C = the integral row, unused here) through per-fold variables
-    table = torch.empty((F, C + 1, K), dtype=torch.float32, device=x.device)
-    table[:, :C] = logits.to(torch.float32).transpose(1, 2)
-    table[:, C] = 0.0
-    scope = torch.arange(F, dtype=torch.int64, device=x.device)
-    out = torch.empty((F, B, K), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        capi.call("ck_categorical_fwd", table.data_ptr(), xi.data_ptr(), scope.data_ptr(), out.data_ptr(), F, B, K, C, F,
-                  _stream(x.device))
-    return out
+    return _Categorical.apply(logits, xi)
 
 
 def gaussian_log_likelihood(x: torch.Tensor, mean: torch.Tensor, stddev: torch.Tensor,
                             log_partition: torch.Tensor | None = None) -> torch.Tensor:
     """``TorchGaussianLayer.log_unnormalized_likelihood`` (input.py:661-670): x (F, B, 1), mean / stddev (F, K)."""
-    _forward_only(x, mean, stddev, log_partition)
+    _forward_only(x)  # (no gradient with respect to the data)
     _on_device(x, "the layer input")
     if x.dim() != 3 or x.shape[2] != 1:
         raise ValueError(f"expected an input of shape (F, B, 1), found {tuple(x.shape)}")
-    F, K = mean.shape
-    xt = x.squeeze(dim=2).to(torch.float32).contiguous()  # (F, B): "variable" f of a (D = F, B) staging copy
-    B = xt.shape[1]
-    scope = torch.arange(F, dtype=torch.int64, device=x.device)
-    out = torch.empty((F, B, K), dtype=torch.float32, device=x.device)
-    lz = None if log_partition is None else log_partition.to(torch.float32).contiguous()
-    with torch.cuda.device(x.device):
-        capi.call("ck_gaussian_fwd", mean.to(torch.float32).contiguous().data_ptr(), stddev.to(torch.float32).contiguous().data_ptr(),
-                  None if lz is None else lz.data_ptr(), xt.data_ptr(), scope.data_ptr(), out.data_ptr(), F, B, K, F,
-                  _stream(x.device))
-    return out
+    xt = x.detach().squeeze(dim=2).to(torch.float32).contiguous()  # (F, B): "variable" f of a (D = F, B) staging copy
+    return _Gaussian.apply(mean, stddev, log_partition, xt)
 
 
 def embedding(x: torch.Tensor, weight: torch.Tensor, *, complex_out: bool) -> torch.Tensor:

@@ -170,3 +170,92 @@ def test_no_cpu_fallback():
 
     with pytest.raises(HipExtensionError):
         ops.hadamard(torch.zeros(1, 2, 3, 4))
+
+
+def _grads_close(got, want, tol=2e-4):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape
+    scale = float(want.abs().max()) + 1e-6
+    assert float((got - want).abs().max()) <= tol * scale, (float((got - want).abs().max()), scale)
+
+
+@pytest.mark.parametrize("F,H,B,Ki,Ko", [(3, 1, 33, 32, 32), (2, 3, 5, 8, 6), (2, 2, 70, 16, 4), (2, 2, 40, 64, 64)])
+def test_sum_layers_backward_is_the_references_autograd(hip_device, F, H, B, Ki, Ko):
+    """`loss.backward()` through `layer_ops.sum_lse` (the TorchLayer subclasses of the plugin): d/dx and d/dW from
+    ck_sum_lse_bwd equal autograd through the reference's formula (semiring.py:383-408 restated in float64)."""
+    from cirkit_amd import _capi as capi
+    from cirkit_amd import layer_ops as ops
+
+    g = torch.Generator().manual_seed(F * 131 + Ki)
+    x0 = torch.randn(F, H, B, Ki, generator=g) * 2
+    gy = torch.randn(F, B, Ko, generator=g)
+    cases = [(capi.CK_SUM_CAT, H * Ki, lambda x: x.permute(0, 2, 1, 3).flatten(start_dim=2)),
+             (capi.CK_SUM_PROD, Ki, lambda x: x.sum(dim=1))]
+    if H == 2 and Ki <= 16:
+        cases.append((capi.CK_SUM_KRON, Ki * Ki, lambda x: (x[:, 0].unsqueeze(-1) + x[:, 1].unsqueeze(-2)).flatten(start_dim=-2)))
+    for mode, n, prep in cases:
+        theta0 = torch.randn(F, Ko, n, generator=g)
+        # reference: softmax weights (a parameter graph autograd differentiates on both sides), float64
+        xr, tr = x0.double().requires_grad_(True), theta0.double().requires_grad_(True)
+        yr = torch.logsumexp(prep(xr).unsqueeze(2) + torch.log_softmax(tr, dim=-1).unsqueeze(1), dim=-1)
+        (yr * gy.double()).sum().backward()
+        xd, td = x0.to(hip_device).requires_grad_(True), theta0.to(hip_device).requires_grad_(True)
+        y = ops.sum_lse(xd, torch.softmax(td, dim=-1), mode)
+        assert y.requires_grad
+        _close(y.detach(), yr.detach().float())
+        (y * gy.to(hip_device)).sum().backward()
+        _grads_close(xd.grad, xr.grad)
+        _grads_close(td.grad, tr.grad)
+    # no graph under no_grad; the complex semiring stays forward-only
+    with torch.no_grad():
+        assert not ops.sum_lse(x0.to(hip_device).requires_grad_(True), torch.rand(F, Ko, Ki).to(hip_device), capi.CK_SUM_PROD).requires_grad
+    with pytest.raises(RuntimeError):
+        ops.sum_lse(torch.complex(x0, x0).to(hip_device).requires_grad_(True), torch.rand(F, Ko, Ki).to(hip_device), capi.CK_SUM_PROD)
+
+
+def test_products_and_inputs_backward(hip_device):
+    """Hadamard / Kronecker (inner.py:126-127, 178-187), Categorical (input.py:399-412) and Gaussian (input.py:661-670)
+    forwards of `layer_ops` under autograd against the same formulas in torch."""
+    from cirkit_amd import layer_ops as ops
+
+    g = torch.Generator().manual_seed(23)
+    F, H, B, K = 3, 3, 19, 4
+    x0 = torch.randn(F, H, B, K, generator=g)
+    for kron in (False, True):
+        xr = x0.double().requires_grad_(True)
+        if kron:
+            yr = xr[:, 0]
+            for i in range(1, H):
+                yr = torch.flatten(yr.unsqueeze(-1) + xr[:, i].unsqueeze(-2), start_dim=-2)
+        else:
+            yr = xr.sum(dim=1)
+        gy = torch.randn(yr.shape, generator=g)
+        (yr * gy.double()).sum().backward()
+        xd = x0.to(hip_device).requires_grad_(True)
+        y = ops.kronecker(xd) if kron else ops.hadamard(xd)
+        (y * gy.to(hip_device)).sum().backward()
+        _grads_close(xd.grad, xr.grad)
+    C = 11
+    logits0 = torch.randn(F, K, C, generator=g)
+    xc = torch.randint(0, C, (F, B, 1), generator=g)
+    idx = torch.arange(F)
+    gy = torch.randn(F, B, K, generator=g)
+    lr = logits0.double().requires_grad_(True)
+    (torch.log_softmax(lr, dim=-1)[idx[:, None], :, xc.squeeze(2)] * gy.double()).sum().backward()
+    ld = logits0.to(hip_device).requires_grad_(True)
+    y = ops.categorical_log_likelihood(xc.to(hip_device), torch.log_softmax(ld, dim=-1))
+    (y * gy.to(hip_device)).sum().backward()
+    _grads_close(ld.grad, lr.grad)
+    mean0, std0, lz0 = torch.randn(F, K, generator=g), torch.rand(F, K, generator=g) + 0.3, torch.randn(F, K, generator=g)
+    xr_ = torch.randn(F, B, 1, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (mean0, std0, lz0)]
+    yr = torch.distributions.Normal(ref[0].unsqueeze(1), ref[1].unsqueeze(1)).log_prob(xr_.double()) + ref[2].unsqueeze(1)
+    (yr * gy.double()).sum().backward()
+    dev = [t.to(hip_device).requires_grad_(True) for t in (mean0, std0, lz0)]
+    y = ops.gaussian_log_likelihood(xr_.to(hip_device), dev[0], dev[1], dev[2])
+    (y * gy.to(hip_device)).sum().backward()
+    for a, b in zip(dev, ref):
+        _grads_close(a.grad, b.grad)
+    # still forward-only: Embedding
+    with pytest.raises(RuntimeError):
+        ops.embedding(xc.to(hip_device), logits0.to(hip_device).requires_grad_(True), complex_out=False)
