@@ -256,6 +256,21 @@ def test_products_and_inputs_backward(hip_device):
     (y * gy.to(hip_device)).sum().backward()
     for a, b in zip(dev, ref):
         _grads_close(a.grad, b.grad)
+    # TensorDot (optimized.py:287-300): a dense layer over the rows (b, q) of the permuted input
+    Kj, Kq, Kk = 5, 3, 4
+    xt0 = torch.randn(F, 1, B, Kj * Kq, generator=g)
+    th0 = torch.randn(F, Kk, Kj, generator=g)
+    gy = torch.randn(F, B, Kq * Kk, generator=g)
+    xr, tr = xt0.double().requires_grad_(True), th0.double().requires_grad_(True)
+    xv = xr.squeeze(1).view(F, B, Kj, Kq).permute(0, 1, 3, 2)
+    yr = torch.logsumexp(xv.unsqueeze(3) + torch.log_softmax(tr, dim=-1)[:, None, None], dim=-1).reshape(F, B, Kq * Kk)
+    (yr * gy.double()).sum().backward()
+    xd, td = xt0.to(hip_device).requires_grad_(True), th0.to(hip_device).requires_grad_(True)
+    y = ops.tensordot_lse(xd, torch.softmax(td, dim=-1), Kj, Kq)
+    _close(y.detach(), yr.detach().float())
+    (y * gy.to(hip_device)).sum().backward()
+    _grads_close(xd.grad, xr.grad)
+    _grads_close(td.grad, tr.grad)
     # still forward-only: Embedding
     with pytest.raises(RuntimeError):
         ops.embedding(xc.to(hip_device), logits0.to(hip_device).requires_grad_(True), complex_out=False)
