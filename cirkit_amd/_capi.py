@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -159,6 +159,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_table_integral_row": [_p, _i, _i, _i, _i, _p],
     "ck_fill_f32": [_p, _l, _f, _p],
     "ck_sum_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_sum_lse_bwd_c": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_debug_force_generic_bwd": [_i],
     "ck_hadamard_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_kronecker_bwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -28,7 +28,8 @@ complex-lse-sum; anything else raises (no fallback to the stock forward).
 forwards are ``torch.autograd.Function``s (`cirkit_amd.layer_ops`): ``loss = -cc(x).mean(); loss.backward(); opt.step()``
 -- the reference's training loop, notebooks/learning-a-circuit.ipynb -- runs unchanged; autograd differentiates the
 reference's parameter graphs and the gather between layers, the hand-written kernels of ck_backward.hip supply each
-layer's d/dx and d/dW.  The complex semiring, Embedding and ConstantValue layers record no graph (TensorDot differentiates as the dense layer it is): they RAISE
+layer's d/dx and d/dW.  Under complex-lse-sum the sum layers (`ck_sum_lse_bwd_c`), Hadamard, Embedding and ConstantValue layers do the
+same (squared circuits train through the reference's loop); only complex Kronecker / TensorDot layers record no graph: they RAISE
 when gradients are enabled and an input or parameter requires them (`layer_ops._forward_only`) -- evaluate those under
 ``torch.no_grad()``.  The fast path for training a whole plan is `cirkit_amd.training.HipTrainer` (b4 level).
 """

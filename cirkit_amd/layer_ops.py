@@ -14,8 +14,9 @@ Autograd.  Under the real lse-sum semiring `sum_lse`, `hadamard`, `kronecker`, `
 cirkit_amd/csrc/ck_backward.hip (the ones `HipTrainer` walks a whole plan with): the reference's training loop
 (``loss = -circuit(x).mean(); loss.backward(); opt.step()``, notebooks/learning-a-circuit.ipynb) works unchanged on a
 circuit compiled with the plugin -- autograd differentiates the reference's own parameter graphs (softmax, ...) and the
-gather between layers, these functions supply d/dx and d/dW of each layer.  The complex semiring, Embedding and ConstantValue forwards
-record no graph (TensorDot differentiates as the dense sum layer it is, over a permuted view): asking them for gradients raises (`_forward_only`).
+gather between layers, these functions supply d/dx and d/dW of each layer.  So do, under complex-lse-sum, `sum_lse` (`ck_sum_lse_bwd_c`), `hadamard`
+and `embedding`; TensorDot differentiates as the dense sum layer it is, over a permuted view.  `constant_value` too (its gradient is a batch sum).  Complex Kronecker /
+TensorDot forwards record no graph: asking them for gradients raises (`_forward_only`).
 """
 
 from __future__ import annotations
@@ -98,25 +99,99 @@ class _Product(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, row_off, kron):
         F, H, B, K = x.shape
-        xf = x.detach().to(torch.float32).contiguous()
-        out = torch.empty((F, B, K**H if kron else K), dtype=torch.float32, device=x.device)
+        cplx = x.is_complex()
+        xf = x.detach().to(torch.complex64 if cplx else torch.float32).contiguous()
+        out = torch.empty((F, B, K**H if kron else K), dtype=xf.dtype, device=x.device)
         with torch.cuda.device(x.device):
             capi.call("ck_kronecker_fwd" if kron else "ck_hadamard_fwd", xf.data_ptr(), row_off.data_ptr(), out.data_ptr(), F, H,
-                      B, K, 1, _stream(x.device))
+                      B, K, 2 if cplx else 1, _stream(x.device))
         ctx.save_for_backward(row_off)
         ctx.kron, ctx.shape, ctx.dtype = kron, tuple(x.shape), x.dtype
-        return out if x.dtype == torch.float32 else out.to(x.dtype)
+        return out if x.dtype == out.dtype else out.to(x.dtype)
 
     @staticmethod
     def backward(ctx, gout):
         (row_off,) = ctx.saved_tensors
         F, H, B, K = ctx.shape
-        g = gout.to(torch.float32).contiguous()
-        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        cplx = gout.is_complex()
+        g = gout.to(torch.complex64 if cplx else torch.float32).contiguous()
+        gx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
         with torch.cuda.device(g.device):
-            capi.call("ck_kronecker_bwd" if ctx.kron else "ck_hadamard_bwd", gx.data_ptr(), row_off.data_ptr(), g.data_ptr(), F, H,
-                      B, K, 0, _stream(g.device))
+            if cplx:  # a complex (F, H, B, K) block is a float block of 2 K units per row: every child receives gout
+                capi.call("ck_hadamard_bwd", gx.data_ptr(), (row_off * 2).data_ptr(), g.data_ptr(), F, H, B, 2 * K, 0, _stream(g.device))
+            else:
+                capi.call("ck_kronecker_bwd" if ctx.kron else "ck_hadamard_bwd", gx.data_ptr(), row_off.data_ptr(), g.data_ptr(), F,
+                          H, B, K, 0, _stream(g.device))
         return gx.to(ctx.dtype), None, None
+
+
+class _SumCLSE(torch.autograd.Function):
+    """Complex `sum_lse` (ComplexLSESumSemiring.apply_reduce, semiring.py:441-476): forward `ck_sum_lse_fwd_c`, backward
+    `ck_sum_lse_bwd_c` -- y is holomorphic in inputs and weights, gradients are conj(dy/d.) * gout as torch defines them;
+    real weights receive the real part."""
+
+    @staticmethod
+    def forward(ctx, x, weight, row_off, mode):
+        F, H, B, Ki = x.shape
+        Ko = int(weight.shape[1])
+        xc = x.detach().to(torch.complex64).contiguous()
+        w = weight.detach().contiguous()
+        w = w.to(torch.complex64) if w.is_complex() else w.to(torch.float32)
+        out = torch.empty((F, B, Ko), dtype=torch.complex64, device=x.device)
+        with torch.cuda.device(x.device):
+            capi.call("ck_sum_lse_fwd_c", xc.data_ptr(), row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, H, B, Ki, Ko,
+                      mode, 1 if w.is_complex() else 0, _stream(x.device))
+        ctx.save_for_backward(xc, w, out, row_off)
+        ctx.mode, ctx.dtypes = mode, (x.dtype, weight.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xc, w, out, row_off = ctx.saved_tensors
+        F, H, B, Ki = xc.shape
+        Ko = int(w.shape[1])
+        g = gout.to(torch.complex64).contiguous()
+        gx = torch.empty_like(xc)
+        dw = torch.zeros_like(w)
+        with torch.cuda.device(xc.device):
+            capi.call("ck_sum_lse_bwd_c", xc.data_ptr(), gx.data_ptr(), row_off.data_ptr(), w.data_ptr(), out.data_ptr(),
+                      g.data_ptr(), dw.data_ptr(), F, H, B, Ki, Ko, ctx.mode, 1 if w.is_complex() else 0, _stream(xc.device))
+        return gx.to(ctx.dtypes[0]), dw.to(ctx.dtypes[1]), None, None
+
+
+class _Embedding(torch.autograd.Function):
+    """`embedding`: out[f, b, :] = log(weight[f, :, x[f, b]]) (ComplexSafeLog of a real number under complex-lse-sum,
+    utils.py:22-50); d out / d weight = 1 / weight, so the gradient is the scatter-add of Re(gout) over the batch
+    (`ck_categorical_bwd`) divided by the weight."""
+
+    @staticmethod
+    def forward(ctx, weight, xi, complex_out):
+        F, K, C = weight.shape
+        B = xi.shape[1]
+        dev = xi.device
+        # (F, C + 1, K) like every gather table (row C: the integral row of the marginal queries, not reachable from here)
+        table = torch.zeros((F, C + 1, K), dtype=torch.float32, device=dev)
+        table[:, :C] = weight.detach().to(torch.float32).transpose(1, 2)
+        scope = torch.arange(F, dtype=torch.int64, device=dev)
+        out = torch.empty((F, B, K), dtype=torch.complex64 if complex_out else torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            capi.call("ck_embedding_clog_fwd" if complex_out else "ck_embedding_log_fwd", table.data_ptr(), xi.data_ptr(),
+                      scope.data_ptr(), out.data_ptr(), F, B, K, C, F, _stream(dev))
+        ctx.save_for_backward(xi, scope, table)
+        ctx.dims, ctx.dtype = (F, K, C, B), weight.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xi, scope, table = ctx.saved_tensors
+        F, K, C, B = ctx.dims
+        g = (gout.real if gout.is_complex() else gout).to(torch.float32).contiguous()
+        dtable = torch.zeros((F, C + 1, K), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            capi.call("ck_categorical_bwd", g.data_ptr(), xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C,
+                      _stream(g.device))
+        dw = dtable[:, :C] / table[:, :C]  # (entries no batch row selected: 0 / w = 0)
+        return dw.transpose(1, 2).contiguous().to(ctx.dtype), None, None
 
 
 class _Categorical(torch.autograd.Function):
@@ -194,8 +269,6 @@ def sum_lse(x: torch.Tensor, weight: torch.Tensor, mode: int = capi.CK_SUM_CAT) 
     """``TorchSumLayer.forward`` (inner.py:266-273, mode CK_SUM_CAT), ``TorchCPTLayer.forward`` (optimized.py:171-178,
     CK_SUM_PROD) and ``TorchTuckerLayer.forward`` (optimized.py:89-103, CK_SUM_KRON) under lse-sum / complex-lse-sum:
     x (F, H, B, Ki) log-space children, weight (F, Ko, N) linear-space -> (F, B, Ko)."""
-    if x.is_complex() or weight.is_complex():
-        _forward_only(x, weight)
     x, row_off, F, H, B, Ki = _children(x)
     if weight.dim() != 3 or weight.shape[0] != F:
         raise ValueError(f"expected a weight of shape (F={F}, Ko, N), found {tuple(weight.shape)}")
@@ -207,12 +280,7 @@ def sum_lse(x: torch.Tensor, weight: torch.Tensor, mode: int = capi.CK_SUM_CAT) 
     with torch.cuda.device(x.device):
         st = _stream(x.device)
         if x.is_complex():
-            w = weight.contiguous()
-            w = w.to(torch.complex64) if w.is_complex() else w.to(torch.float32)
-            out = torch.empty((F, B, Ko), dtype=torch.complex64, device=x.device)
-            capi.call("ck_sum_lse_fwd_c", x.data_ptr(), row_off.data_ptr(), w.data_ptr(), out.data_ptr(), F, H, B, Ki, Ko,
-                      mode, 1 if w.is_complex() else 0, st)
-            return out
+            return _SumCLSE.apply(x, weight, row_off, mode)
         if weight.is_complex():
             raise ValueError("complex weights under the real lse-sum semiring")
         return _SumLSE.apply(x, weight, row_off, mode)
@@ -220,15 +288,8 @@ def sum_lse(x: torch.Tensor, weight: torch.Tensor, mode: int = capi.CK_SUM_CAT) 
 
 def hadamard(x: torch.Tensor) -> torch.Tensor:
     """``TorchHadamardLayer.forward`` (inner.py:126-127) in log space: the sum over the arity axis."""
-    if x.is_complex():
-        _forward_only(x)
     x, row_off, F, H, B, K = _children(x)
-    if not x.is_complex():
-        return _Product.apply(x, row_off, False)
-    out = torch.empty((F, B, K), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
-        capi.call("ck_hadamard_fwd", x.data_ptr(), row_off.data_ptr(), out.data_ptr(), F, H, B, K, 2, _stream(x.device))
-    return out
+    return _Product.apply(x, row_off, False)
 
 
 def kronecker(x: torch.Tensor) -> torch.Tensor:
@@ -315,32 +376,45 @@ def gaussian_log_likelihood(x: torch.Tensor, mean: torch.Tensor, stddev: torch.T
 def embedding(x: torch.Tensor, weight: torch.Tensor, *, complex_out: bool) -> torch.Tensor:
     """``TorchEmbeddingLayer.forward`` (input.py:258-266) mapped into lse-sum (log) / complex-lse-sum (complex log):
     x (F, B, 1) states, weight (F, K, C) real -> (F, B, K)."""
-    _forward_only(weight)
+    if weight.is_complex():
+        raise ValueError("embedding: a real weight is expected")
     F, K, C = weight.shape
     xi = _discrete_input(x, C)
-    B = xi.shape[1]
-    # (F, C + 1, K) like every gather table (row C: the integral row of the marginal queries, not reachable from here)
-    table = torch.zeros((F, C + 1, K), dtype=torch.float32, device=x.device)
-    table[:, :C] = weight.to(torch.float32).transpose(1, 2)
-    scope = torch.arange(F, dtype=torch.int64, device=x.device)
-    out = torch.empty((F, B, K), dtype=torch.complex64 if complex_out else torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        capi.call("ck_embedding_clog_fwd" if complex_out else "ck_embedding_log_fwd", table.data_ptr(), xi.data_ptr(),
-                  scope.data_ptr(), out.data_ptr(), F, B, K, C, F, _stream(x.device))
-    return out
+    return _Embedding.apply(weight, xi, bool(complex_out))
 
 
 def constant_value(value: torch.Tensor, batch_size: int, *, log_space: bool, complex_out: bool) -> torch.Tensor:
     """``TorchConstantValueLayer.forward`` (input.py:739-743): value (F, K) broadcast over the batch."""
-    _forward_only(value)
     _on_device(value, "the value")
-    F, K = value.shape
-    v = value.contiguous()
-    v = v.to(torch.complex64) if v.is_complex() else v.to(torch.float32)
-    if v.is_complex() and not complex_out:
+    if value.is_complex() and not complex_out:
         raise ValueError("complex constant value under the real lse-sum semiring")
-    out = torch.empty((F, batch_size, K), dtype=torch.complex64 if complex_out else torch.float32, device=value.device)
-    with torch.cuda.device(value.device):
-        capi.call("ck_constant_fwd", v.data_ptr(), out.data_ptr(), F, batch_size, K, 1 if log_space else 0,
-                  1 if v.is_complex() else 0, 1 if complex_out else 0, _stream(value.device))
-    return out
+    return _Constant.apply(value, int(batch_size), bool(log_space), bool(complex_out))
+
+
+class _Constant(torch.autograd.Function):
+    """`constant_value`: out[f, b, :] = value[f] (log_space) or log(value[f]); the gradient is the batch sum of the incoming
+    one (a handful of rows: these layers carry the partition function of a squared circuit, batch 1), times conj(1 / value)
+    for the logarithm; a real value receives the real part."""
+
+    @staticmethod
+    def forward(ctx, value, batch_size, log_space, complex_out):
+        F, K = value.shape
+        v = value.detach().contiguous()
+        v = v.to(torch.complex64) if v.is_complex() else v.to(torch.float32)
+        out = torch.empty((F, batch_size, K), dtype=torch.complex64 if complex_out else torch.float32, device=value.device)
+        with torch.cuda.device(value.device):
+            capi.call("ck_constant_fwd", v.data_ptr(), out.data_ptr(), F, batch_size, K, 1 if log_space else 0,
+                      1 if v.is_complex() else 0, 1 if complex_out else 0, _stream(value.device))
+        ctx.save_for_backward(v)
+        ctx.log_space, ctx.dtype = log_space, value.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (v,) = ctx.saved_tensors
+        g = gout.sum(dim=1)
+        if not ctx.log_space:
+            g = g / (v.conj() if v.is_complex() else v)
+        if not v.is_complex() and g.is_complex():
+            g = g.real
+        return g.to(ctx.dtype), None, None, None

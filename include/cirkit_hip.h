@@ -528,6 +528,13 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
                    const float* w, const float* out, const float* gout, float* dw, int F, int H, int B, int Ki, int Ko,
                    int mode, int accumulate, void* stream);
 int ck_debug_force_generic_bwd(int on); /* test hook, like ck_debug_force_generic */
+/* The same layers under complex-lse-sum (ComplexLSESumSemiring.apply_reduce, semiring.py:441-476; ComplexSafeLog,
+ * utils.py:22-50): arena / garena / out / gout hold complex64 (re, im) pairs, row_off counts complex elements, the
+ * children's gradients are STORED at row_off of garena (torch's convention: conj(dy/dx) * gout), dw -- (F, Ko, N) floats, or
+ * complex pairs when w_is_complex -- is accumulated with atomics (zero it first; real weights receive the real part). */
+int ck_sum_lse_bwd_c(const float* arena_c, float* garena_c, const int64_t* row_off, const float* w, const float* out_c,
+                     const float* gout_c, float* dw, int F, int H, int B, int Ki, int Ko, int mode, int w_is_complex,
+                     void* stream);
 /* TorchKroneckerLayer backward (inner.py:178-187): gout (F, B, K^H); the gradient of child h's unit i is the sum of gout
  * over the outputs whose digit h (child 0 most significant) is i. */
 int ck_kronecker_bwd(float* garena, const int64_t* row_off, const float* gout, int F, int H, int B, int K,

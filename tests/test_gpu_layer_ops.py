@@ -209,8 +209,9 @@ def test_sum_layers_backward_is_the_references_autograd(hip_device, F, H, B, Ki,
     # no graph under no_grad; the complex semiring stays forward-only
     with torch.no_grad():
         assert not ops.sum_lse(x0.to(hip_device).requires_grad_(True), torch.rand(F, Ko, Ki).to(hip_device), capi.CK_SUM_PROD).requires_grad
-    with pytest.raises(RuntimeError):
-        ops.sum_lse(torch.complex(x0, x0).to(hip_device).requires_grad_(True), torch.rand(F, Ko, Ki).to(hip_device), capi.CK_SUM_PROD)
+    if H >= 2:
+        with pytest.raises(RuntimeError):  # (complex Kronecker layers stay forward-only)
+            ops.kronecker(torch.complex(x0, x0).to(hip_device).requires_grad_(True))
 
 
 def test_products_and_inputs_backward(hip_device):
@@ -271,6 +272,74 @@ def test_products_and_inputs_backward(hip_device):
     (y * gy.to(hip_device)).sum().backward()
     _grads_close(xd.grad, xr.grad)
     _grads_close(td.grad, tr.grad)
-    # still forward-only: Embedding
+    # ConstantValue (input.py:739-743): log of the value, broadcast over the batch
+    v0 = torch.rand(F, K, generator=g) + 0.2
+    gy = torch.randn(F, 4, K, generator=g)
+    vr = v0.double().requires_grad_(True)
+    (torch.log(vr).unsqueeze(1).expand(F, 4, K) * gy.double()).sum().backward()
+    vd = v0.to(hip_device).requires_grad_(True)
+    (ops.constant_value(vd, 4, log_space=False, complex_out=False) * gy.to(hip_device)).sum().backward()
+    _grads_close(vd.grad, vr.grad)
+    cg = torch.complex(gy, gy.flip(0))
+    vc0 = torch.complex(torch.randn(F, K, generator=g), torch.randn(F, K, generator=g))
+    vr = vc0.to(torch.complex128).requires_grad_(True)
+    (torch.log(vr).unsqueeze(1).expand(F, 4, K) * cg.to(torch.complex128)).real.sum().backward()
+    vd = vc0.to(hip_device).requires_grad_(True)
+    (ops.constant_value(vd, 4, log_space=False, complex_out=True) * cg.to(hip_device)).real.sum().backward()
+    assert float((vd.grad.cpu().to(torch.complex128) - vr.grad).abs().max()) <= 1e-4 * float(vr.grad.abs().max())
+    # still forward-only: complex TensorDot
     with pytest.raises(RuntimeError):
-        ops.embedding(xc.to(hip_device), logits0.to(hip_device).requires_grad_(True), complex_out=False)
+        ops.tensordot_lse(torch.complex(xt0, xt0).to(hip_device).requires_grad_(True), torch.rand(F, Kk, Kj).to(hip_device), Kj, Kq)
+
+
+@pytest.mark.parametrize("F,H,B,Ki,Ko,wc", [(2, 2, 7, 16, 4, False), (3, 1, 33, 32, 32, False), (2, 2, 9, 8, 6, True), (2, 3, 5, 4, 3, True)])
+def test_complex_semiring_backward(hip_device, F, H, B, Ki, Ko, wc):
+    """Backward through complex-lse-sum (ComplexLSESumSemiring.apply_reduce, semiring.py:441-476; ComplexSafeLog,
+    utils.py:22-50): `sum_lse` (three modes, real or complex weights), `hadamard` and `embedding` under autograd against
+    autograd through the same formulas in torch complex128, for a real loss Re(sum(y * c))."""
+    from cirkit_amd import _capi as capi
+    from cirkit_amd import layer_ops as ops
+
+    g = torch.Generator().manual_seed(F * 17 + Ki + (5 if wc else 0))
+    x0 = torch.complex(torch.randn(F, H, B, Ki, generator=g), torch.randn(F, H, B, Ki, generator=g) * 3)
+    cases = [(capi.CK_SUM_CAT, H * Ki, lambda x: x.permute(0, 2, 1, 3).flatten(start_dim=2)),
+             (capi.CK_SUM_PROD, Ki, lambda x: x.sum(dim=1))]
+    if H == 2:
+        cases.append((capi.CK_SUM_KRON, Ki * Ki, lambda x: (x[:, 0].unsqueeze(-1) + x[:, 1].unsqueeze(-2)).flatten(start_dim=-2)))
+    for mode, n, prep in cases:
+        w0 = torch.randn(F, Ko, n, generator=g)  # signed weights (sum_weight_activation none, as the squared circuits use)
+        if wc:
+            w0 = torch.complex(w0, torch.randn(F, Ko, n, generator=g))
+        c = torch.complex(torch.randn(F, B, Ko, generator=g), torch.randn(F, B, Ko, generator=g))
+        xr = x0.to(torch.complex128).requires_grad_(True)
+        wr = w0.to(torch.complex128 if wc else torch.float64).requires_grad_(True)
+        v = prep(xr)
+        m = v.real.amax(dim=-1, keepdim=True)
+        yr = torch.log(torch.einsum("fbn,fon->fbo", torch.exp(v - m), wr.to(torch.complex128))) + m
+        (yr * c.to(torch.complex128)).real.sum().backward()
+        xd, wd = x0.to(hip_device).requires_grad_(True), w0.to(hip_device).requires_grad_(True)
+        y = ops.sum_lse(xd, wd, mode)
+        assert y.requires_grad and y.dtype == torch.complex64
+        (y * c.to(hip_device)).real.sum().backward()
+        scale = float(xr.grad.abs().max())
+        assert float((xd.grad.cpu().to(torch.complex128) - xr.grad).abs().max()) <= 5e-4 * scale
+        scale = float(wr.grad.abs().max())
+        assert wd.grad.dtype == w0.dtype
+        assert float((wd.grad.cpu().to(wr.grad.dtype) - wr.grad).abs().max()) <= 5e-4 * scale
+    # Hadamard: every child receives the gradient
+    c = torch.complex(torch.randn(F, B, Ki, generator=g), torch.randn(F, B, Ki, generator=g))
+    xd = x0.to(hip_device).requires_grad_(True)
+    (ops.hadamard(xd) * c.to(hip_device)).real.sum().backward()
+    xr = x0.clone().requires_grad_(True)
+    (xr.sum(dim=1) * c).real.sum().backward()
+    assert torch.allclose(xd.grad.cpu(), xr.grad)
+    # Embedding: log of a signed real weight
+    C = 7
+    w0 = torch.randn(F, Ki, C, generator=g)
+    xc = torch.randint(0, C, (F, B, 1), generator=g)
+    idx = torch.arange(F)
+    wr = w0.double().requires_grad_(True)
+    (torch.log(wr.to(torch.complex128))[idx[:, None], :, xc.squeeze(2)] * c.to(torch.complex128)).real.sum().backward()
+    wd = w0.to(hip_device).requires_grad_(True)
+    (ops.embedding(xc.to(hip_device), wd, complex_out=True) * c.to(hip_device)).real.sum().backward()
+    _grads_close(wd.grad, wr.grad)
