@@ -29,7 +29,7 @@ forwards are ``torch.autograd.Function``s (`cirkit_amd.layer_ops`): ``loss = -cc
 -- the reference's training loop, notebooks/learning-a-circuit.ipynb -- runs unchanged; autograd differentiates the
 reference's parameter graphs and the gather between layers, the hand-written kernels of ck_backward.hip supply each
 layer's d/dx and d/dW.  Under complex-lse-sum the sum layers (`ck_sum_lse_bwd_c`), Hadamard, Embedding and ConstantValue layers do the
-same (squared circuits train through the reference's loop); only complex Kronecker / TensorDot layers record no graph: they RAISE
+same (squared circuits train through the reference's loop); only complex Kronecker layers record no graph: they RAISE
 when gradients are enabled and an input or parameter requires them (`layer_ops._forward_only`) -- evaluate those under
 ``torch.no_grad()``.  The fast path for training a whole plan is `cirkit_amd.training.HipTrainer` (b4 level).
 """

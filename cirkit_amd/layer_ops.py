@@ -15,8 +15,8 @@ cirkit_amd/csrc/ck_backward.hip (the ones `HipTrainer` walks a whole plan with):
 (``loss = -circuit(x).mean(); loss.backward(); opt.step()``, notebooks/learning-a-circuit.ipynb) works unchanged on a
 circuit compiled with the plugin -- autograd differentiates the reference's own parameter graphs (softmax, ...) and the
 gather between layers, these functions supply d/dx and d/dW of each layer.  So do, under complex-lse-sum, `sum_lse` (`ck_sum_lse_bwd_c`), `hadamard`
-and `embedding`; TensorDot differentiates as the dense sum layer it is, over a permuted view.  `constant_value` too (its gradient is a batch sum).  Complex Kronecker /
-TensorDot forwards record no graph: asking them for gradients raises (`_forward_only`).
+and `embedding`; TensorDot differentiates as the dense sum layer it is, over a permuted view.  `constant_value` too (its gradient is a batch sum).  Complex Kronecker
+forwards record no graph: asking them for gradients raises (`_forward_only`).
 """
 
 from __future__ import annotations
@@ -309,20 +309,21 @@ def kronecker(x: torch.Tensor) -> torch.Tensor:
 
 def tensordot_lse(x: torch.Tensor, weight: torch.Tensor, num_contract_units: int, num_batch_units: int) -> torch.Tensor:
     """``TorchTensorDotLayer.forward`` (optimized.py:287-300): x (F, 1, B, Kj * Kq), weight (F, Kk, Kj) -> (F, B, Kq * Kk)."""
-    if x.is_complex() or weight.is_complex():
-        _forward_only(x, weight)
     x, row_off, F, H, B, Ki = _children(x)
     Kj, Kq = int(num_contract_units), int(num_batch_units)
     if H != 1 or Ki != Kj * Kq or weight.shape[0] != F or weight.shape[2] != Kj:
         raise ValueError(f"tensordot: input {tuple(x.shape)}, weight {tuple(weight.shape)}, Kj={Kj}, Kq={Kq}")
     _on_device(weight, "the weight")
     Kk = int(weight.shape[1])
-    if not x.is_complex() and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
         # under autograd: the layer IS a dense sum layer over the rows (b, q) of the permuted input (optimized.py:289-296);
-        # the permutation is torch's (it knows its own backward), the contraction and its backward are `_SumLSE`
+        # the permutation is torch's (it knows its own backward), the contraction and its backward are `_SumLSE` / `_SumCLSE`
         xp = x.view(F, B, Kj, Kq).permute(0, 1, 3, 2).reshape(F, 1, B * Kq, Kj)
         ro = (torch.arange(F, dtype=torch.int64, device=x.device) * (B * Kq * Kj)).reshape(F, 1)
-        return _SumLSE.apply(xp, weight, ro, capi.CK_SUM_PROD).view(F, B, Kq * Kk)
+        fn = _SumCLSE if x.is_complex() else _SumLSE
+        if weight.is_complex() and not x.is_complex():
+            raise ValueError("complex weights under the real lse-sum semiring")
+        return fn.apply(xp, weight, ro, capi.CK_SUM_PROD).view(F, B, Kq * Kk)
     with torch.cuda.device(x.device):
         st = _stream(x.device)
         if x.is_complex():

@@ -390,6 +390,46 @@ def grads_tucker():
         torch.set_grad_enabled(False)
 
 
+def grads_sos():
+    """Round 3: the reference's autograd through the COMPLEX semiring (ComplexLSESumSemiring.apply_reduce, semiring.py:441-476;
+    ComplexSafeLog, utils.py:22-50): a small squared circuit c (Embedding, CP-T, signed weights) and its partition function
+    Z = integral |c|^2, loss = -mean(2 Re c(x) - Re Z) -- the negative log-likelihood of the squared model -- and the gradient
+    of every tensor."""
+    torch.set_grad_enabled(True)
+    try:
+        par = Parameterization(activation="none", initialization="normal")
+        sc = data_modalities.image_data(
+            (1, 4, 4), "quad-tree-2", input_layer="embedding", num_input_units=4,
+            sum_product_layer="cp-t", num_sum_units=4, input_params={"weight": par}, sum_weight_param=par)
+        ctx = PipelineContext(backend="torch", semiring="complex-lse-sum", fold=True, optimize=True)
+        cc = ctx.compile(sc)
+        zc = ctx.compile(SF.integrate(SF.multiply(sc, SF.conjugate(sc))))
+        table = tensor_table()
+        plan_c, tensors = plan_from_torch_circuit(cc, table=table)
+        plan_z, tensors_z = plan_from_torch_circuit(zc, table=table)
+        assert set(tensors_z) <= set(tensors)
+        with torch.no_grad():
+            vals = init_plan_tensors(plan_c)
+            for k, t in tensors.items():
+                t.copy_(torch.from_numpy(vals[k]).to(t.dtype))
+        g = torch.Generator().manual_seed(17)
+        x = torch.randint(0, 256, (12, 16), generator=g)
+        with torch.no_grad():
+            _save("sos_4x4_c_k4", plan_c, {"x": x.numpy().astype(np.int16), "y_c64": cc(x).numpy()})
+            _save("sos_4x4_z_k4", plan_z, {"z_c64": zc().numpy()})
+        loss = -(2.0 * cc(x).real - zc().real).mean()
+        loss.backward()
+        by_ptr = {p.data_ptr(): p for p in cc.parameters()}
+        extra = {"x": x.numpy().astype(np.int16), "loss": np.array(loss.item())}
+        for k, t in tensors.items():
+            extra["g_" + k] = by_ptr[t.data_ptr()].grad.numpy()
+        np.savez_compressed(os.path.join(HERE, "sos_4x4_k4_grads.npz"), **extra)
+        print("sos_4x4", [l.type for l in plan_c.layers], [l.type for l in plan_z.layers],
+              "loss", loss.item(), {k: float(np.linalg.norm(v)) for k, v in extra.items() if k.startswith("g_")})
+    finally:
+        torch.set_grad_enabled(False)
+
+
 def marginals():
     """Marginal queries through the reference's IntegrateQuery (cirkit/backend/torch/queries.py):
     the KAT circuits (reference ground truth: mar (1,0,1,1,.) = 16.845, Z = 318; mar (0.3,.) =
@@ -571,6 +611,6 @@ def chow_liu():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "grads_tucker", "marginals", "templates_extra"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "grads_tucker", "grads_sos", "marginals", "templates_extra"]
     for w in which:
         globals()[w]()

@@ -287,9 +287,6 @@ def test_products_and_inputs_backward(hip_device):
     vd = vc0.to(hip_device).requires_grad_(True)
     (ops.constant_value(vd, 4, log_space=False, complex_out=True) * cg.to(hip_device)).real.sum().backward()
     assert float((vd.grad.cpu().to(torch.complex128) - vr.grad).abs().max()) <= 1e-4 * float(vr.grad.abs().max())
-    # still forward-only: complex TensorDot
-    with pytest.raises(RuntimeError):
-        ops.tensordot_lse(torch.complex(xt0, xt0).to(hip_device).requires_grad_(True), torch.rand(F, Kk, Kj).to(hip_device), Kj, Kq)
 
 
 @pytest.mark.parametrize("F,H,B,Ki,Ko,wc", [(2, 2, 7, 16, 4, False), (3, 1, 33, 32, 32, False), (2, 2, 9, 8, 6, True), (2, 3, 5, 4, 3, True)])
