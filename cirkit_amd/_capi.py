@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -39,6 +39,20 @@ class SoftmaxJob(C.Structure):
         ("in2", C.c_void_p),
         ("idx", C.c_void_p),
         ("out2", C.c_void_p),
+    ]
+
+
+class EinsumDesc(C.Structure):
+    """ck_einsum_desc of include/cirkit_hip.h."""
+
+    _fields_ = [
+        ("x", C.c_void_p * 4),
+        ("out", C.c_void_p),
+        ("n_ops", C.c_int32), ("n_idx", C.c_int32), ("n_out", C.c_int32), ("F", C.c_int32), ("out_complex", C.c_int32),
+        ("is_complex", C.c_int32 * 4),
+        ("extent", C.c_int32 * 8),
+        ("stride", (C.c_int64 * 8) * 4),
+        ("fold_stride", C.c_int64 * 4),
     ]
 
 
@@ -155,6 +169,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_conj": [_p, _p, _l, _p],
     "ck_param_mixing_weight": [_p, _p, _i, _i, _i, _p],
     "ck_param_bmm": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_param_einsum": [_p, _p],
     "ck_param_transpose_last2": [_p, _p, _l, _i, _i, _i, _i, _p],
     "ck_param_table_integral_row": [_p, _i, _i, _i, _i, _p],
     "ck_fill_f32": [_p, _l, _f, _p],

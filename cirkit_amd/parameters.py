@@ -328,22 +328,24 @@ class HipParameter:
                 capi.call("ck_param_mixing_weight", _ptr(x), _ptr(y), F, K, H, stream)
             elif n.op == "matmul":  # nodes.py:802-805
                 a, b = xs
-                if a.is_complex() or b.is_complex():
-                    raise NotImplementedError("matmul of complex parameters")
-                F, M, Kd = a.shape
-                N = b.shape[2]
-                y = self._buf(j, (F, M, N))
-                capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), F, M, N, Kd, 0, 0, stream)
+                if a.is_complex() or b.is_complex():  # (the generic einsum: "ik,kj->ij" over complex pairs)
+                    y = self._einsum(j, ((0, 1), (1, 2), (0, 2)), [a, b], stream)
+                else:
+                    F, M, Kd = a.shape
+                    N = b.shape[2]
+                    y = self._buf(j, (F, M, N))
+                    capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), F, M, N, Kd, 0, 0, stream)
             elif n.op == "einsum":  # optimized.py:282-284
-                if len(xs) != 2 or any(x.is_complex() for x in xs):
-                    raise NotImplementedError("einsum parameter beyond two real matrix operands")
-                m = _einsum_as_bmm(c["einsum"], [tuple(x.shape[1:]) for x in xs])
-                if m is None:
-                    raise NotImplementedError(f"einsum pattern {c['einsum']}")
-                swap, M, N, Kd, ta, tb = m
-                a, b = (xs[1], xs[0]) if swap else (xs[0], xs[1])
-                y = self._buf(j, (a.shape[0], M, N))
-                capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), a.shape[0], M, N, Kd, ta, tb, stream)
+                m = None
+                if len(xs) == 2 and not any(x.is_complex() for x in xs):
+                    m = _einsum_as_bmm(c["einsum"], [tuple(x.shape[1:]) for x in xs])
+                if m is None:  # any other pattern, complex operands: the generic kernel
+                    y = self._einsum(j, c["einsum"], xs, stream)
+                else:
+                    swap, M, N, Kd, ta, tb = m
+                    a, b = (xs[1], xs[0]) if swap else (xs[0], xs[1])
+                    y = self._buf(j, (a.shape[0], M, N))
+                    capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), a.shape[0], M, N, Kd, ta, tb, stream)
             elif n.op == "flatten":  # nodes.py:843-844
                 y = xs[0].reshape(shape)
             elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
@@ -357,6 +359,46 @@ class HipParameter:
         if upto is not None:
             return outs[upto]
         return self._select("out", outs, g.output, stream)
+
+    def _einsum(self, j: int, einsum, xs: list[torch.Tensor], stream: int) -> torch.Tensor:
+        """`ck_param_einsum`: TorchEinsumParameter.forward (parameters/optimized.py:282-284) for any index pattern over up to
+        four real or complex operands (F, *shape); `einsum` = the operands' index tuples, then the output's."""
+        import ctypes as C
+
+        *ins, out_idx = [tuple(int(i) for i in e) for e in einsum]
+        if len(ins) != len(xs) or not 1 <= len(xs) <= 4:
+            raise NotImplementedError(f"einsum parameter over {len(xs)} operands")
+        extent: dict[int, int] = {}
+        for e, x in zip(ins, xs):
+            if len(e) != x.dim() - 1:
+                raise ValueError(f"einsum indices {e} against an operand of shape {tuple(x.shape)}")
+            for lab, n in zip(e, x.shape[1:]):
+                if extent.setdefault(lab, int(n)) != int(n):
+                    raise ValueError(f"einsum index {lab}: extents {extent[lab]} and {int(n)}")
+        if len(set(out_idx)) != len(out_idx) or any(lab not in extent for lab in out_idx):
+            raise ValueError(f"einsum output indices {out_idx}")
+        order = list(out_idx) + sorted(lab for lab in extent if lab not in out_idx)
+        if len(order) > 8:
+            raise NotImplementedError(f"einsum parameter over {len(order)} indices")
+        F = int(xs[0].shape[0])
+        cplx = any(x.is_complex() for x in xs)
+        if not all(x.is_contiguous() for x in xs):  # (a torch copy here would not be part of the recorded launches)
+            raise NotImplementedError("einsum parameter over a non-contiguous operand")
+        y = self._buf(j, (F, *(extent[lab] for lab in out_idx)), torch.complex64 if cplx else torch.float32)
+        d = capi.EinsumDesc()
+        d.out, d.n_ops, d.n_idx, d.n_out, d.F, d.out_complex = _ptr(y), len(xs), len(order), len(out_idx), F, 1 if cplx else 0
+        for i, lab in enumerate(order):
+            d.extent[i] = extent[lab]
+        for k, (e, x) in enumerate(zip(ins, xs)):
+            if int(x.shape[0]) != F:
+                raise ValueError("einsum operands with different numbers of folds")
+            d.x[k], d.is_complex[k] = _ptr(x), 1 if x.is_complex() else 0
+            d.fold_stride[k] = int(np.prod(x.shape[1:]))
+            strides = [int(np.prod(x.shape[2 + a:])) for a in range(len(e))]
+            for a, lab in enumerate(e):
+                d.stride[k][order.index(lab)] += strides[a]  # (a repeated index walks the diagonal)
+        capi.call("ck_param_einsum", C.byref(d), stream)
+        return y
 
     # -- backward -----------------------------------------------------------------------------
     def backward(self, dout: torch.Tensor, grads: Mapping[str, torch.Tensor], stream: int = 0, *,

@@ -502,6 +502,23 @@ int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N
                  int trans_a, int trans_b, void* stream);
 /* (R, A, Bd) -> (R, out_rows >= Bd, A) transpose of the last two axes (rows beyond Bd untouched),
  * optionally taking log first (categorical: log(probs) -> table (F, C+1, K), input.py:405-408). */
+/* TorchEinsumParameter (parameters/optimized.py:282-284) for any pattern: out[f, o...] = sum over the contracted indices of
+ * prod_k x[k][f, ...].  Indices are numbered so that 0 .. n_out - 1 are the output's (in its order) and n_out .. n_idx - 1 the
+ * contracted ones; stride[k][i] is the ELEMENT stride of operand k along index i inside a fold (0: the operand does not carry
+ * it; a repeated index: the sum of its strides), fold_stride[k] its elements per fold.  Complex operands hold (re, im) pairs
+ * (strides count complex elements); the output (F, extents of the output indices) is complex iff out_complex. */
+#define CK_EINSUM_MAX_OPERANDS 4
+#define CK_EINSUM_MAX_INDICES 8
+typedef struct ck_einsum_desc {
+  const float* x[CK_EINSUM_MAX_OPERANDS];
+  float* out;
+  int32_t n_ops, n_idx, n_out, F, out_complex;
+  int32_t is_complex[CK_EINSUM_MAX_OPERANDS];
+  int32_t extent[CK_EINSUM_MAX_INDICES];
+  int64_t stride[CK_EINSUM_MAX_OPERANDS][CK_EINSUM_MAX_INDICES];
+  int64_t fold_stride[CK_EINSUM_MAX_OPERANDS];
+} ck_einsum_desc;
+int ck_param_einsum(const ck_einsum_desc* d, void* stream);
 int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int Bd, int take_log,
                              int out_rows, void* stream);
 /* Integral row (row C) of a gather table (F, C+1, K): mode 0 zeros (normalised probabilities),

@@ -1,0 +1,70 @@
+"""`TorchEinsumParameter` (parameters/optimized.py:282-284) and complex `TorchMatMulParameter` (nodes.py:802-805) on the GPU:
+`HipParameter.evaluate` over parameter graphs with einsum / matmul nodes against torch.einsum on the host -- three- and
+four-operand patterns, batch and repeated indices, complex operands (what products of more than two circuits and complex
+parameters compile to), next to the two-real-matrix patterns that go to `ck_param_bmm`."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+from cirkit_amd.parameters import HipParameter, TensorStore  # noqa: E402
+from cirkit_amd.plan import IDX_NONE, FoldIndex, ParamGraph, ParamNode  # noqa: E402
+
+LETTERS = "abcdefgh"
+
+
+def _graph(store, shapes, dtypes, op, config, out_shape, F, g):
+    nodes, vals = [], []
+    for i, (sh, dt) in enumerate(zip(shapes, dtypes)):
+        v = torch.randn((F, *sh), generator=g)
+        if dt == "c":
+            v = torch.complex(v, torch.randn((F, *sh), generator=g))
+        store.set(f"t{i}", v)
+        vals.append(v)
+        nodes.append(ParamNode("tensor", F, tuple(sh), {"tensor": f"t{i}"}, []))
+    nodes.append(ParamNode(op, F, tuple(out_shape), dict(config), [FoldIndex([i], IDX_NONE) for i in range(len(shapes))]))
+    return HipParameter(ParamGraph(nodes, FoldIndex([len(nodes) - 1], IDX_NONE), F, tuple(out_shape)), store), vals
+
+
+@pytest.mark.parametrize("einsum,shapes,dtypes", [
+    (((0, 1), (1, 2), (0, 2)), [(3, 4), (4, 5)], "rr"),                      # a matrix product (ck_param_bmm)
+    (((0, 1), (2, 3), (0, 2, 1, 3)), [(3, 4), (2, 5)], "rr"),                # an outer product (Kronecker weights)
+    (((0, 1), (0, 1), (0,)), [(3, 4), (3, 4)], "rc"),                        # a batch index and a contraction, real x complex
+    (((0, 1), (1, 2), (2, 3), (0, 3)), [(3, 4), (4, 2), (2, 5)], "rrr"),     # a chain of three
+    (((0, 1), (1, 2), (2, 3), (3, 4), (0, 4)), [(2, 3), (3, 4), (4, 2), (2, 3)], "crcr"),  # four operands, complex
+    (((0, 0), (0,)), [(4, 4)], "c"),                                         # a repeated index: the diagonal
+    (((0, 1, 2), (2, 1), (0,)), [(3, 4, 5), (5, 4)], "cc"),                  # two contracted indices
+])
+def test_einsum_parameters(hip_device, einsum, shapes, dtypes):
+    g = torch.Generator().manual_seed(len(einsum) * 7 + len(shapes[0]))
+    F = 3
+    store = TensorStore(hip_device)
+    ext = {}
+    for e, sh in zip(einsum, shapes):
+        ext.update(zip(e, sh))
+    out_shape = tuple(ext[i] for i in einsum[-1])
+    p, vals = _graph(store, shapes, dtypes, "einsum", {"einsum": einsum}, out_shape, F, g)
+    y = p.evaluate(torch.cuda.current_stream(hip_device).cuda_stream)
+    torch.cuda.synchronize()
+    eq = ",".join("z" + "".join(LETTERS[i] for i in e) for e in einsum[:-1]) + "->z" + "".join(LETTERS[i] for i in einsum[-1])
+    cplx = "c" in dtypes
+    want = torch.einsum(eq, *[v.to(torch.complex128 if cplx else torch.float64) for v in vals])
+    assert tuple(y.shape) == tuple(want.shape) and y.is_complex() == cplx
+    assert float((y.cpu().to(want.dtype) - want).abs().max()) <= 2e-5 * (float(want.abs().max()) + 1.0)
+
+
+def test_complex_matmul_parameter(hip_device):
+    g = torch.Generator().manual_seed(3)
+    store = TensorStore(hip_device)
+    p, (a, b) = _graph(store, [(4, 6), (6, 5)], "cr", "matmul", {}, (4, 5), 2, g)
+    y = p.evaluate(torch.cuda.current_stream(hip_device).cuda_stream)
+    torch.cuda.synchronize()
+    want = torch.matmul(a.to(torch.complex128), b.to(torch.complex128))
+    assert float((y.cpu().to(torch.complex128) - want).abs().max()) <= 2e-5 * float(want.abs().max())
