@@ -156,12 +156,13 @@ def live_pmc(argv_child: list[str], timeout_s: float = 200.0) -> dict | None:
 
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         env = dict(os.environ, TMPDIR="/tmp", CIRKIT_BENCH_NO_PMC="1")
-        # pass 0: kernel trace alone (no counters): the launch durations the profiler sees, warm -- 100 steps, the last
+        # pass 0: kernel trace alone (no counters): the launch durations the profiler sees, warm -- 1500 steps, the last
         # 50 dispatches of every kernel averaged.  HIP events around every launch (the instrumented pass of
         # profile_kernels) stretch a launch by a few microseconds; this is the figure a rocprofv3 --stats summary gives.
         d = os.path.join(tmp, "trace")
         cmd = [exe, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-               "--pmc-child", "--pmc-steps", "100", *argv_child]
+               "--pmc-child", "--pmc-steps", "1500", *argv_child]  # (the clocks take ~0.1 s to settle: the first rounds of the
+        # timed region are ~10 % slower too -- `first_round_ms_per_step`)
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=max(10.0, t_end - time.time()), check=True)
