@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -101,6 +101,7 @@ class LeafLaunch(C.Structure):
         ("xjobs", C.c_void_p),
         ("n_xjobs", C.c_int32),
         ("x_pairs", C.c_int32),
+        ("root_tab", C.c_void_p),
     ]
 
 

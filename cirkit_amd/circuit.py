@@ -1266,6 +1266,31 @@ class HipCircuit:
             self._group_dev[("pairs", g.root)] = hit
         return hit
 
+    def _leaf_root_table(self, nodes: torch.Tensor, node_off, leaf_off: int, scope: torch.Tensor, depth: int, n_roots: int) -> torch.Tensor:
+        """(roots, 3 * 2^depth) int32 on the device (`ck_leaf_launch.root_tab`): per root of a fused leaf region the variable
+        and the table fold of each of its leaves, then the folds of its nodes in the order of the walk's steps (leaf i is
+        followed by as many steps as i has trailing one bits: level l + 1 takes fold nodes[node_off[l + 1] + ...])."""
+        key = ("root_tab", nodes.data_ptr(), int(leaf_off), depth)
+        hit = self._group_dev.get(key)
+        if hit is None:
+            nd = nodes.cpu().numpy().astype(np.int64)
+            sc = scope.cpu().numpy().astype(np.int64)
+            off = [int(v) for v in node_off[: depth + 1]]
+            kl = 1 << depth
+            tab = np.zeros((n_roots, 3 * kl), dtype=np.int32)
+            for t in range(n_roots):
+                tab[t, :kl] = sc[nd[leaf_off + t * kl: leaf_off + (t + 1) * kl]]
+                tab[t, kl:2 * kl] = nd[off[0] + t * kl: off[0] + (t + 1) * kl]
+                k = 0
+                for i in range(kl):
+                    l = 0
+                    while (i >> l) & 1:  # the steps behind leaf i: levels 1, 2, ... while the bits of i are set
+                        tab[t, 2 * kl + k] = nd[off[l + 1] + t * (kl >> (l + 1)) + (i >> (l + 1))]
+                        k += 1
+                        l += 1
+            hit = self._group_dev[key] = torch.from_numpy(tab).to(self.device)
+        return hit
+
     def _leaf_walk(self, bd: _Binding, *, table, scale, scope, levels, nodes, node_off, leaf_off, out, work, depth, K, Cn,
                    w_layout, redo, n_roots, waves, stream, tail: bool = False, with_ll: bool = False) -> None:
         """`ck_leaf_walk_fwd`: the persistent leaf launch over the staged batch or -- `bd.direct` -- over the caller's."""
@@ -1275,6 +1300,7 @@ class HipCircuit:
         d.out, d.work, d.n_seg, d.n_wg, d.waves, d.depth = out.data_ptr(), work.data_ptr(), int(work.shape[0]), self._n_cu, waves, depth
         d.B, d.K, d.C, d.w_layout = bd.B, K, Cn, w_layout
         d.signed_redo, d.n_roots = (None if redo is None else redo.data_ptr()), n_roots
+        d.root_tab = self._leaf_root_table(nodes, node_off, leaf_off, scope, depth, n_roots).data_ptr()
         if bd.direct:
             d.xt, d.preclamped, d.D = None, 0, self.plan.num_variables
             d.x_rows, d.x_input = self._raw_batch_args(bd)

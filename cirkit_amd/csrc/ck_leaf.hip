@@ -53,6 +53,9 @@ struct LeafArgs {
   int D;
   int32_t* bad_flag;  // XRAW: raised (atomicOr 1) when a row holds an illegal value; nullptr = rows are not checked
   int x_pairs;        // XRAW: leaves 2j, 2j + 1 of every root read adjacent, 16-byte aligned variables (one load per pair)
+  const int32_t* root_tab;  // nullptr, or (F_root, 3 * 2^D): per root the variable and the table fold of every leaf and the folds
+                            // of its 2^D - 1 nodes in step order -- what the start of a segment otherwise collects from `nodes`,
+                            // `scope` and the level tables in three dependent rounds of loads
   // TAIL: the trailing few-fold levels (ck_tail16.hip's walk) inside this launch -- see leaf_tail_phase
   const TailFold* tail_folds;    // (tail_n_folds) in level order
   const int32_t* tail_level_begin;  // (tail_n_levels + 1)
@@ -300,12 +303,49 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
   for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
     const int t = a.work[4 * seg], tile_begin = a.work[4 * seg + 1], tile_end = a.work[4 * seg + 2];
     if (seg != static_cast<int>(blockIdx.x)) __syncthreads();  // every wave has left the previous segment
-    // weights of the 2^D - 1 nodes, in the static order of the steps: 4 x 1 KiB wave-DMAs per node
+    // weights of the 2^D - 1 nodes, in the static order of the steps: 4 x 1 KiB wave-DMAs per node.  The nodes' fold indices
+    // are ALL fetched before the first DMA is issued: read one by one in front of each node's DMAs they cost a memory round
+    // trip per node -- vmcnt counts in order, so every wait for an index also waited for the DMAs issued before it: fifteen
+    // round trips in a row at the start of every workgroup.
+    // Per-root constants (scalar registers): variable row of xt / column of the raw batch and first table row of every leaf.
+    // With `root_tab` they and the node folds are ONE round of loads from one 192-byte row; without it the variables take
+    // two more (leaf id -> scope).  Everything is fetched before the first DMA: what starts a workgroup is the chain
+    // constants -> batch values -> table rows, and the weights travel beside it.
+    int node_fold[kNodes];
+    const int32_t* leaf_ids = a.nodes + a.leaf_off + t * kLeaves;
+    const int32_t* fold0 = a.nodes + a.node_off[0] + t * kLeaves;
+    int64_t var_off[kLeaves];  // element offset of the leaf's variable: row of xt, or column of the raw batch
+    int32_t row_base[kLeaves];
+    if (a.root_tab != nullptr) {
+      const int32_t* rt = a.root_tab + static_cast<int64_t>(t) * (3 * kLeaves);
+#pragma unroll
+      for (int i = 0; i < kLeaves; ++i) {
+        var_off[i] = XRAW ? static_cast<int64_t>(rt[i]) : rt[i] * static_cast<int64_t>(a.B);
+        row_base[i] = rt[kLeaves + i] * (a.C + 1);
+      }
+#pragma unroll
+      for (int k = 0; k < kNodes; ++k) node_fold[k] = rt[2 * kLeaves + k];
+    } else {
+      static_for<0, kLeaves>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, steps_after(i)>([&](auto lc) {
+          constexpr int l = decltype(lc)::value, k = steps_before(i) + l;
+          node_fold[k] = a.nodes[a.node_off[l + 1] + t * (kLeaves >> (l + 1)) + (i >> (l + 1))];
+        });
+      });
+#pragma unroll
+      for (int i = 0; i < kLeaves; ++i) {
+        var_off[i] = XRAW ? a.scope[leaf_ids[i]] : a.scope[leaf_ids[i]] * static_cast<int64_t>(a.B);
+        row_base[i] = fold0[i] * (a.C + 1);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kNodes; ++k) asm volatile("" : "+v"(node_fold[k]));  // (loaded here, not sunk to the uses)
     static_for<0, kLeaves>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       static_for<0, steps_after(i)>([&](auto lc) {
         constexpr int l = decltype(lc)::value, k = steps_before(i) + l;
-        const int fold = a.nodes[a.node_off[l + 1] + t * (kLeaves >> (l + 1)) + (i >> (l + 1))];
+        const int fold = __builtin_amdgcn_readfirstlane(node_fold[k]);
         if constexpr (PARAMS) {
           // softmax of the fold's (32, 32) logits straight into the walk's LDS layout: rows 2 * wave + half and + 16 of it
           softmax_rows32<2>(a.wraw[l] + static_cast<int64_t>(fold) * 1024, 32, wave, WAVES, lane,
@@ -321,16 +361,6 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             __builtin_amdgcn_global_load_lds((ck::gptr_t)(src + q * qstride), (ck::lptr_t)(w_lds + k * 1024 + q * 256), 16, 0, 0);
       });
     });
-    // per-root constants (scalar registers): variable row of xt and first table row of every leaf
-    const int32_t* leaf_ids = a.nodes + a.leaf_off + t * kLeaves;
-    const int32_t* fold0 = a.nodes + a.node_off[0] + t * kLeaves;
-    int64_t var_off[kLeaves];  // element offset of the leaf's variable: row of xt, or column of the raw batch
-    int32_t row_base[kLeaves];
-#pragma unroll
-    for (int i = 0; i < kLeaves; ++i) {
-      var_off[i] = XRAW ? a.scope[leaf_ids[i]] : a.scope[leaf_ids[i]] * static_cast<int64_t>(a.B);
-      row_base[i] = fold0[i] * (a.C + 1);
-    }
     // The tiles of a segment are dealt round-robin to the waves (wave w: tile_begin + w, + WAVES, ...), so a wave knows
     // its next tiles and fetches their inputs while it computes: the batch values of tile k + 2 and, from those of tile
     // k + 1, its table rows' scales and first two leaf rows are requested when the gathers of tile k are over (the
@@ -745,6 +775,7 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
     a.w[l] = d->w_levels[l];
   }
   a.nodes = d->nodes;
+  a.root_tab = d->root_tab;
   for (int l = 0; l <= d->depth; ++l) a.node_off[l] = d->node_off[l];
   a.leaf_off = d->leaf_off;
   a.out = d->out;

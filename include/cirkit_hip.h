@@ -369,6 +369,11 @@ typedef struct ck_leaf_launch {
   int32_t n_xjobs;
   int32_t x_pairs;                          /* raw input: for every root, leaves 2j and 2j + 1 read variables v and v + 1 with v even
                                                (and D even): the launch then fetches both values with one 16-byte load */
+  const int32_t* root_tab;                  /* DEVICE (n_roots of the region, 3 * 2^depth), or NULL: row t = for each leaf i of root t its
+                                               variable scope[nodes[leaf_off + t 2^depth + i]] and its table fold
+                                               nodes[node_off[0] + t 2^depth + i], then the folds of the root's 2^depth - 1 nodes in the
+                                               order of the walk's steps (rest of the row unused): one load round at the start of a
+                                               segment instead of three dependent ones */
 } ck_leaf_launch;
 int ck_leaf_walk_fwd(const ck_leaf_launch* desc, void* stream);
 
