@@ -1586,7 +1586,9 @@ class HipCircuit:
                     raw = "true" if self._direct_input(B) else "false"
                     tail = "true" if (self._tail_in_leaf(B) and i == self._tail_host_group()) else "false"
                     par = "true" if self._params_in_leaf(B) else "false"
-                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}, false, {raw}, {tail}, {par}>"
+                    xp = "true" if (raw == "true" and tail == par == "false" and g.depth >= 2 and self.leaf_waves == 8
+                                    and self._leaves_in_adjacent_pairs(g)) else "false"
+                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}, false, {raw}, {tail}, {par}, {xp}>"
                 return f"subtree_linear_kernel<{g.depth}, {self._group_layout(g)}>"
             return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")

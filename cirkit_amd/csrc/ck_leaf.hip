@@ -270,7 +270,10 @@ __device__ __forceinline__ void leaf_params_phase(const LeafArgs& a, float* slot
 // TAIL: the trailing levels of the circuit are walked by this launch too (leaf_tail_phase above): root tiles are then
 // stored write-through.
 // PARAMS: tables and weights are evaluated by this launch from the raw parameters (leaf_params_phase above).
-template <int D, int WAVES, bool SIGNED, bool XRAW, bool TAIL = false, bool PARAMS = false>
+// XP: (XRAW) leaves 2j, 2j + 1 of every root read adjacent, 16-byte aligned variables (LeafArgs::x_pairs) -- a template
+// parameter, not a branch: with two load sequences of different lengths behind a run-time test the compiler's wait-count
+// pass gives up counting and waits for EVERYTHING in flight (vmcnt(0)) where the batch values are packed, in every tile.
+template <int D, int WAVES, bool SIGNED, bool XRAW, bool TAIL = false, bool PARAMS = false, bool XP = false>
 __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafArgs a) {
   constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2) ? 3 : 2;
   // (two arrays, not one: with the gather slots at a constant offset inside a single array their addresses became
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         // one cached line instead, the launch takes 71.3 instead of 76.5 us -- the batch is 5 us of this launch)
         const uint32_t rowb = static_cast<uint32_t>(batch_row(tile)) * (static_cast<uint32_t>(a.D) * 8u);
         if constexpr (kLeaves >= 4) {
-          if (a.x_pairs) {
+          if constexpr (XP) {
             // leaves 2j and 2j + 1 read ADJACENT variables of the batch (16-byte aligned: checked on the host) -- what a
             // region graph over an image gives -- so lane (b, kh) takes the two values of leaves 4m + 2kh, 4m + 2kh + 1
             // with ONE 16-byte load: xv[4m .. 4m + 3] = (low, high, low, high); half the line requests again
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       const uint32_t uc = static_cast<uint32_t>(a.C);
       uint32_t bad = 0;
       if constexpr (XRAW && kLeaves >= 4) {
-        if (a.x_pairs) {  // (see load_x) lane (b, kh) holds leaves 4m + 2kh and 4m + 2kh + 1: the packed pair 2m + kh
+        if constexpr (XP) {  // (see load_x) lane (b, kh) holds leaves 4m + 2kh and 4m + 2kh + 1: the packed pair 2m + kh
 #pragma unroll
           for (int m = 0; m < kLeaves / 4; ++m) {
             const int32_t lo0 = xv[4 * m], hi0 = xv[4 * m + 1], lo1 = xv[4 * m + 2], hi1 = xv[4 * m + 3];
@@ -512,7 +515,6 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       load_x(tile, xraw);
       bad_cur = pack_categories(xraw, cat);
       static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
-      load_x(min(tile + WAVES, chunk_end - 1), xraw);
     }
     if (chunk_begin == tile_begin) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the weights (and its first leaf rows) have landed
@@ -530,15 +532,13 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       static_for<0, kLeaves>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         // the request of leaf i has landed: at most those of the next kSlots - 1 leaves, 5 operations each, are younger --
-        // and, for the leaves requested during the PREVIOUS tile (i < kSlots), the batch values of the tile after this
-        // one, which were requested right behind them and are not needed before leaf kLeaves / 2: waiting for them here
-        // (vmcnt(0) at leaf 0) stalled every tile on an HBM round trip that had only the last contractions of the
-        // previous tile to complete in.  kXLoads is the FEWEST load instructions a tile's batch values take (a smaller
-        // count only waits longer; the tile's output stores, younger too, are not counted for the same reason).  Read the
-        // slot into the operand layout; the reads have returned before the slot is refilled
+        // and, for leaves 1 .. kSlots - 1, the batch values of the wave's next tile, requested at leaf 0 and not needed before
+        // leaf kLeaves / 2.  kXLoads is the FEWEST load instructions a tile's batch values take (a smaller count only waits
+        // longer; the previous tile's output stores, younger than its successor's first requests, are not counted for the
+        // same reason).  Read the slot into the operand layout; the reads have returned before the slot is refilled
         f32x4 r0, r1, r2, r3;
-        constexpr int kXLoads = XRAW ? (kLeaves >= 4 ? kLeaves / 4 : kLeaves / 2) : kLeaves;
-        constexpr int kYounger = 5 * (kLeaves - 1 - i < kSlots - 1 ? kLeaves - 1 - i : kSlots - 1) + (i < kSlots ? kXLoads : 0);
+        constexpr int kXLoads = XRAW ? (XP ? kLeaves / 4 : kLeaves / 2) : kLeaves;  // (exactly: XP is a template parameter)
+        constexpr int kYounger = 5 * (kLeaves - 1 - i < kSlots - 1 ? kLeaves - 1 - i : kSlots - 1) + (i >= 1 && i < kSlots ? kXLoads : 0);
         // (the weights of the leaf's first contraction are requested in front of the slot reads: one LDS round trip for both)
         WRegs wfirst;
         if constexpr (steps_after(i) > 0) {
@@ -559,7 +559,13 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           cur[12 + e] = r3[e];
         }
         const float s_i = sld[i & 3];
-        if constexpr (i == kLeaves / 2) bad_next = pack_categories(xraw, catnext);  // (requested half a tile + four contractions ago)
+        // The batch values of this wave's NEXT tile: requested here, behind the first slot read, and packed half a tile
+        // later IN THE SAME ITERATION -- requested at the end of the previous tile (one more tile of lead) the compiler's
+        // wait-count pass loses count across the loop's back edge and puts s_waitcnt vmcnt(0) in front of the packing: every
+        // tile then waited for the leaf rows requested a moment before.  (They sit between the requests of leaves
+        // kSlots - 1 and kSlots: leaves 1 .. kSlots - 1 count them among the younger operations.)
+        if constexpr (i == 0) load_x(min(tile + WAVES, chunk_end - 1), xraw);
+        if constexpr (i == kLeaves / 2) bad_next = pack_categories(xraw, catnext);
         if constexpr (i + kSlots < kLeaves) request(cat, std::integral_constant<int, i + kSlots>{});
         if constexpr (i + 1 == kLeaves) {
           // the gathers of this tile are over: request what the next tile starts with (see above)
@@ -567,9 +573,6 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
 #pragma unroll
             for (int j = 0; j < kLeaves / 2; ++j) cat[j] = catnext[j];
             static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
-            // ... and the batch values of the tile after it (the youngest requests in flight: the contractions that
-            // follow wait for nothing, and the first leaf of the next tile drains them all)
-            load_x(min(tile + 2 * WAVES, chunk_end - 1), xraw);
           }
         }
         if constexpr ((i & 1) != 0) cs = s_i + sprev;  // log scale of the pair (i - 1, i)
@@ -731,6 +734,12 @@ hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_root
     if constexpr (XRAW) return hipErrorInvalidValue;  // (checked by the caller: 12 waves read the staged batch only)
     else hipLaunchKernelGGL((leaf_persistent_kernel<D, 12, false, false>), grid, dim3(768), 0, s, a);
   } else {
+    if constexpr (XRAW && D >= 2) {
+      if (a.x_pairs) {
+        hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, false, false, true>), grid, dim3(512), 0, s, a);
+        return hipGetLastError();
+      }
+    }
     hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, XRAW>), grid, dim3(512), 0, s, a);
   }
   return hipGetLastError();

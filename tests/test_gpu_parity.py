@@ -568,7 +568,7 @@ def test_tail_walked_by_the_leaf_launch(hip_device, B, direct):
     c = HipCircuit(plan, tensors, merge_tail=True, keep_layer_outputs=False, **kw)
     assert b._bind(B).tail_in_leaf and not a._bind(B).tail_in_leaf
     assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1
-    assert b.kernel_label(b._groups[0].root, B).endswith("true, false>")
+    assert b.kernel_label(b._groups[0].root, B).endswith("true, false, false>")  # (.., TAIL, PARAMS, XP)
     for seed in range(3):
         x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(7 * B + seed))
         x[::5, ::7] = -1
@@ -599,7 +599,7 @@ def test_leaf_launch_evaluates_its_parameters(hip_device, B):
     b = HipCircuit(plan, tensors, inlaunch_params=True, **kw)
     assert b._bind(B).params_in_leaf and not a._bind(B).params_in_leaf
     assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1 and b._inlaunch["rest"] is None
-    assert b.kernel_label(b._groups[0].root, B).endswith("true>")
+    assert b.kernel_label(b._groups[0].root, B).endswith("true, false>")  # (.., PARAMS, XP)
     rng = np.random.default_rng(B)
     for step in range(4):
         x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(11 * B + step))
