@@ -242,6 +242,8 @@ def main() -> None:
                          "(HipCircuit(params_at_end=False)) instead of inside the launch that walks the tail of the forward "
                          "before (the default; every step evaluates them once either way)")
     ap.add_argument("--params-at-end", action="store_true", help=argparse.SUPPRESS)  # (the default now; kept for old command lines)
+    ap.add_argument("--settle", type=int, default=2000,
+                    help="untimed steps in front of every timed region beside --warmup (the clocks settle over ~50 ms of work)")
     ap.add_argument("--staged-input", action="store_true",
                     help="stage the batch (int64 (B, D) -> int32 (D, B)) with a launch of its own, as in round 2, instead of "
                          "letting the leaf launch read the caller's tensor")
@@ -319,6 +321,11 @@ def main() -> None:
         torch.cuda.synchronize(device)
         return
 
+    # The device's clocks keep rising over its first ~50 ms of work (0.113 -> 0.101 ms per step from the first round of 50
+    # steps to the seventh, `profiles/r03_d_bench.json`): beside the W warm-up steps every timed region is preceded by
+    # `--settle` untimed steps (0.2 s by default), reported as `timing.settle_steps`, so that the rounds measure one state.
+    settle_steps = max(0, int(args.settle))
+
     def timed_region(circ, steps, warmup, rounds=1):
         """W untimed steps, then `rounds` rounds of exactly K timed steps, each round with a barrier + synchronize on both
         sides.  Returns (wall seconds per round -- max over ranks --, HIP-event ms per step per round on the launch
@@ -352,7 +359,7 @@ def main() -> None:
 
         walls, evms = [], []
         with torch.cuda.stream(stream):
-            for _ in range(warmup):
+            for _ in range(warmup + settle_steps):
                 step()
             drain()
             for _ in range(rounds):
@@ -429,7 +436,7 @@ def main() -> None:
             "leaf_reads_raw_batch": bool(circuit.reads_batch_directly(B)),
         },
         "timing": {
-            "rounds": len(walls), "steps_per_round": args.steps, "reported": "median round",
+            "rounds": len(walls), "steps_per_round": args.steps, "reported": "median round", "settle_steps": settle_steps,
             "ms_per_step_by_round": [1e3 * w / args.steps for w in walls],
             "hip_event_ms_per_step_by_round": evms,
             "input_batches_rotated": nb, "input_bytes_resident": nb * B * plan.num_variables * 8,

@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 STEPS, WARMUP, ROUNDS, NB, B = 3, 1, 2, 2, 4096
-BENCH_ARGS = ["--steps", str(STEPS), "--warmup", str(WARMUP), "--rounds", str(ROUNDS), "--batches", str(NB), "--no-variants",
+BENCH_ARGS = ["--steps", str(STEPS), "--warmup", str(WARMUP), "--settle", "0", "--rounds", str(ROUNDS), "--batches", str(NB), "--no-variants",
               "--no-other-configs", "--no-cpu-baseline", "--no-kernel-breakdown", "--no-live-pmc"]
 
 
