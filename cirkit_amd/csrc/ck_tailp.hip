@@ -20,8 +20,9 @@
 // and the parameter blocks' loads, MFMAs and stores fill the tail's waits.  Same device functions as the launches this one
 // replaces: bit-identical tables, weights, layer outputs and log-likelihood sum.
 //
-// Measured (MI355X, north-star shape, instrumented pass): 31 us, against 16.8 + 21.8 us for the two launches it replaces;
-// the tail part alone 20 us, the parameter part alone 21 us.  What limits the overlap is instruction issue, not memory: a
+// Measured (MI355X, north-star shape, instrumented pass): 31 us, against 16.8 + 21.8 us for the two launches it replaced
+// -- 29 us against 16.7 + 17.9 us once the table jobs had lost half their instructions (ck_softmax.h); the tail part alone
+// 20 us (six levels: 10.2 / 4.3 / 1.8 / 2.1 / 1.8 / 2.1 us by the cycle counter), the parameter part alone 21 -> 18 us.  What limits the overlap is instruction issue, not memory: a
 // table job is ~3 us of dependent VALU/MFMA/DPP issue on its busiest wave, three jobs per compute unit, and with the tail
 // block holding half of a CU's LDS and registers only two jobs per CU are resident.  Tried and dropped: ONE 16-wave block per
 // CU (waves 0-7 the tail, waves 8-15 two table-job groups looping over their jobs, LDS-counter barriers among the waves
