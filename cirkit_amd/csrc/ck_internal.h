@@ -94,6 +94,25 @@ __device__ __forceinline__ float xhalf_max(float m) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+// A pointer that came out of a descriptor table (LDS, kernel arguments by index) is a GENERIC pointer to the compiler: loads
+// through it are FLAT instructions, which count on vmcnt AND lgkmcnt -- every wait behind one becomes "everything in flight,
+// memory and LDS" and a prefetch stops overlapping anything.  as_global() says what the host guarantees: device memory.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(const T* p) {
+  return (const __attribute__((address_space(1))) T*)p;
+}
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T* as_global(T* p) {
+  return (__attribute__((address_space(1))) T*)p;
+}
+// (float4 is a class in HIP: its copy operators do not take references into an address space -- 16-byte accesses to device
+// memory through the compiler's own vector type)
+typedef float gvec4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const float* p) {
+  const gvec4 t = *as_global(reinterpret_cast<const gvec4*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void gstore4(float* p, float4 v) { *as_global(reinterpret_cast<gvec4*>(p)) = gvec4{v.x, v.y, v.z, v.w}; }
 // address-space-qualified pointers for __builtin_amdgcn_global_load_lds (global memory -> LDS without registers)
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;

@@ -126,7 +126,7 @@ __device__ __forceinline__ void softmax_rows32(const float* __restrict__ in, int
   for (int p = 0; p < PASSES; ++p) {
     const int row = 2 * (first_pair + p * pair_stride) + half;
     ok[p] = row < rows;
-    x[p] = ok[p] ? in[row * 32 + l] : -INFINITY;
+    x[p] = ok[p] ? ck::as_global(in)[row * 32 + l] : -INFINITY;  // (`in` is device memory in every caller)
   }
   float mx[PASSES];
 #pragma unroll

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
         const float* row = s_fold[t].child[h] + (static_cast<int64_t>(bl) * kK + 4 * kq) * 2;
 #pragma unroll
         for (int beta = 0; beta < 2; ++beta) {
-          const float4 c0 = *reinterpret_cast<const float4*>(row + 32 * beta), c1 = *reinterpret_cast<const float4*>(row + 32 * beta + 4);
+          const float4 c0 = ck::gload4(row + 32 * beta), c1 = ck::gload4(row + 32 * beta + 4);
           v[4 * beta + 0] += c0.x;
           v[4 * beta + 1] += c0.z;
           v[4 * beta + 2] += c1.x;
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
           float acc = 0.f;
 #pragma unroll
           for (int beta = 0; beta < 2; ++beta) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wrow + 16 * beta);
+            const float4 w4 = ck::gload4(wrow + 16 * beta);
             acc = fmaf(w4.x, v[4 * beta + 0], acc);
             acc = fmaf(w4.y, v[4 * beta + 1], acc);
             acc = fmaf(w4.z, v[4 * beta + 2], acc);
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(kTail16Waves * 64) tail16_kernel(const Tail16A
             if (live && kq == 0)
               *reinterpret_cast<float2*>(out + (static_cast<int64_t>(b) * Ko + o) * 2) = make_float2(y, acc < 0.f ? 3.14159265358979323846f : 0.f);
           } else {
-            if (live && kq == 0) out[static_cast<int64_t>(b) * Ko + o] = y;
+            if (live && kq == 0) ck::as_global(out)[static_cast<int64_t>(b) * Ko + o] = y;
           }
           if (a.ll != nullptr && t == a.n_folds - 1) {
             // sum of this workgroup's (up to) 16 root values, rows in order, in double precision

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(512, 4) tail_params_kernel(const TailParamsArg
   const int x0 = (v - a.n_pair) * kRowsPerBlock;
   for (int x = x0; x < min(x0 + kRowsPerBlock, a.n_rows); ++x) {
     const ck_rows32_job xj = a.rows[x];
-    softmax_rows32<2>(xj.in, xj.rows, wave, 8, lane, [&](int row, int l, float p) { xj.out[w32_index(row, l, xj.tiled != 0)] = p; });
+    softmax_rows32<2>(xj.in, xj.rows, wave, 8, lane, [&](int row, int l, float p) { ck::as_global(xj.out)[w32_index(row, l, xj.tiled != 0)] = p; });
   }
 }
 

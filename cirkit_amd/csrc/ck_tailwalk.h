@@ -122,7 +122,7 @@ __device__ __forceinline__ void tail_walk(const TailWalkArgs& a, int tile, const
           c.m[h][1] = load4_wt(r, row_off + 64);
         } else {
           const float* row = reinterpret_cast<const float*>(pu) + (row_off >> 2);
-          const float4 x0 = *reinterpret_cast<const float4*>(row), x1 = *reinterpret_cast<const float4*>(row + 16);
+          const float4 x0 = ck::gload4(row), x1 = ck::gload4(row + 16);
           c.m[h][0] = f32x4v{x0.x, x0.y, x0.z, x0.w};
           c.m[h][1] = f32x4v{x1.x, x1.y, x1.z, x1.w};
         }
@@ -201,7 +201,7 @@ __device__ __forceinline__ void tail_walk(const TailWalkArgs& a, int tile, const
           float acc = 0.f;
 #pragma unroll
           for (int beta = 0; beta < 2; ++beta) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wrow + 16 * beta);
+            const float4 w4 = ck::gload4(wrow + 16 * beta);
             acc = fmaf(w4.x, v[4 * beta + 0], acc);
             acc = fmaf(w4.y, v[4 * beta + 1], acc);
             acc = fmaf(w4.z, v[4 * beta + 2], acc);
@@ -210,7 +210,7 @@ __device__ __forceinline__ void tail_walk(const TailWalkArgs& a, int tile, const
           acc = xquad_sum(acc);
           float y = fmaf(__builtin_amdgcn_logf(acc), kLN2, m);
           if (poison) y = __builtin_nanf("");
-          if (live && kq == 0) out[static_cast<int64_t>(b) * Ko + o] = y;
+          if (live && kq == 0) ck::as_global(out)[static_cast<int64_t>(b) * Ko + o] = y;
           if (a.ll != nullptr && t == a.n_folds - 1) {
             // this tile's (up to) 16 root values, rows in order, in double precision; the last tile of the launch to get
             // here adds up the per-tile sums in index order (deterministic; ck_tail16.hip)

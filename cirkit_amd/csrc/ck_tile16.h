@@ -38,7 +38,7 @@ __device__ __forceinline__ int w16_offset(int lane, int bg) {
 template <int LAYOUT>
 __device__ __forceinline__ void load_w16(const float* __restrict__ wf, int lane, WRegs16& w) {
 #pragma unroll
-  for (int bg = 0; bg < 4; ++bg) w.q[bg] = *reinterpret_cast<const float4*>(wf + w16_offset<LAYOUT>(lane, bg));
+  for (int bg = 0; bg < 4; ++bg) w.q[bg] = ck::gload4(wf + w16_offset<LAYOUT>(lane, bg));  // (device memory)
 }
 __device__ __forceinline__ float w16_elem(const WRegs16& w, int beta, int s) {
   const float4& q = w.q[beta * 2 + (s >> 2)];
@@ -116,8 +116,8 @@ __device__ __forceinline__ void tile16_store_clog(float* __restrict__ row_kq, co
   for (int beta = 0; beta < 2; ++beta) {
     const float p0 = (sg >> (4 * beta)) & 1u ? kPi : 0.f, p1 = (sg >> (4 * beta + 1)) & 1u ? kPi : 0.f;
     const float p2 = (sg >> (4 * beta + 2)) & 1u ? kPi : 0.f, p3 = (sg >> (4 * beta + 3)) & 1u ? kPi : 0.f;
-    *reinterpret_cast<float4*>(row_kq + 32 * beta) = make_float4(v[4 * beta + 0], p0, v[4 * beta + 1], p1);
-    *reinterpret_cast<float4*>(row_kq + 32 * beta + 4) = make_float4(v[4 * beta + 2], p2, v[4 * beta + 3], p3);
+    ck::gstore4(row_kq + 32 * beta, make_float4(v[4 * beta + 0], p0, v[4 * beta + 1], p1));
+    ck::gstore4(row_kq + 32 * beta + 4, make_float4(v[4 * beta + 2], p2, v[4 * beta + 3], p3));
   }
 }
 
@@ -125,7 +125,7 @@ __device__ __forceinline__ void tile16_store_clog(float* __restrict__ row_kq, co
 __device__ __forceinline__ void tile16_load(const float* __restrict__ row_kq, float (&v)[8]) {
 #pragma unroll
   for (int beta = 0; beta < 2; ++beta) {
-    const float4 t4 = *reinterpret_cast<const float4*>(row_kq + 16 * beta);
+    const float4 t4 = ck::gload4(row_kq + 16 * beta);
     v[4 * beta + 0] = t4.x;
     v[4 * beta + 1] = t4.y;
     v[4 * beta + 2] = t4.z;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void tile16_load(const float* __restrict__ row_kq, fl
 __device__ __forceinline__ void tile16_load_add(const float* __restrict__ row_kq, float (&v)[8]) {
 #pragma unroll
   for (int beta = 0; beta < 2; ++beta) {
-    const float4 t4 = *reinterpret_cast<const float4*>(row_kq + 16 * beta);
+    const float4 t4 = ck::gload4(row_kq + 16 * beta);
     v[4 * beta + 0] += t4.x;
     v[4 * beta + 1] += t4.y;
     v[4 * beta + 2] += t4.z;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void tile16_load_add(const float* __restrict__ row_kq
 __device__ __forceinline__ void tile16_store(float* __restrict__ row_kq, const float (&v)[8]) {
 #pragma unroll
   for (int beta = 0; beta < 2; ++beta)
-    *reinterpret_cast<float4*>(row_kq + 16 * beta) = make_float4(v[4 * beta + 0], v[4 * beta + 1], v[4 * beta + 2], v[4 * beta + 3]);
+    ck::gstore4(row_kq + 16 * beta, make_float4(v[4 * beta + 0], v[4 * beta + 1], v[4 * beta + 2], v[4 * beta + 3]));
 }
 
 }  // namespace
