@@ -1236,3 +1236,28 @@ def test_graph_replay_equals_eager_replay(hip_device, name):
     for _ in range(2):  # second call: the instantiated graph is replayed
         assert torch.equal(eager(x), graph(x))
     assert torch.equal(eager.log_likelihood_sum(x), graph.log_likelihood_sum(x))
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 31, 32, 33, 100, 255, 257, 511, 2047, 4097])
+def test_default_path_over_batch_sizes(hip_device, B):
+    """The default evaluation of the north-star circuit (leaf launch on the raw batch, tail + next parameters in one launch)
+    at ragged batch sizes: bit-identical to the three-launch form with a staged batch, within fp32 rounding of the
+    layer-by-layer evaluation, LL sum = sum of the outputs; a second batch right behind the first (the parameters it uses
+    were evaluated by the first one's last launch)."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    a = HipCircuit(plan, tensors, device=hip_device)
+    b = HipCircuit(plan, tensors, device=hip_device, params_at_end=False, direct_input=False)
+    c = HipCircuit(plan, tensors, device=hip_device, fuse=False, use_graph=False)
+    gen = torch.Generator().manual_seed(1000 + B)
+    for rep in range(2):
+        x = torch.randint(0, 256, (B, 784), generator=gen)
+        if rep == 1 and B > 2:
+            x[B // 2, ::3] = -1  # (marginalised variables)
+        x = x.to(hip_device)
+        ya, yb, yc = a(x).clone(), b(x).clone(), c(x).clone()
+        assert torch.equal(ya, yb), (B, rep, float((ya - yb).abs().max()))
+        assert float(((ya - yc).abs() / yc.abs()).max()) <= 2e-6, (B, rep)
+        ll = a.log_likelihood_sum(x).cpu()
+        assert ll[1].item() == B and abs(ll[0].item() - float(ya.double().sum())) <= 1e-6 * abs(ll[0].item())
