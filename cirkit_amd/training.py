@@ -242,12 +242,18 @@ class HipTrainer:
         c = self.circuit
         ll = c.log_likelihood_sum(x)  # forward (all activations stay in the arena)
         B = int(x.shape[0])
+        self._backward(B, float(global_batch or B), None)
+        return ll
+
+    def _backward(self, B: int, gB: float, seed: torch.Tensor | None) -> None:
+        """The backward launch list over the activations of the LAST forward at batch size B: gradients of
+        ``sum_b seed[b] * log p(x_b)`` (seed None: of ``-(1 / gB) sum_b log p(x_b)``) into `self.grads`."""
+        c = self.circuit
         bd = c._bind(B)
         st = self._bind_backward(B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         capi.call("ck_fill_f32", st["dw_flat"].data_ptr(), st["dw_flat"].numel(), 0.0, stream)
         capi.call("ck_fill_f32", self._flat_grad.data_ptr(), self._flat_grad.numel(), 0.0, stream)
-        gB = float(global_batch or B)
         gviews, flags = st["gviews"], st["flags"]
         for p in st["need_zero"]:
             capi.call("ck_fill_f32", gviews[p].data_ptr(), gviews[p].numel(), 0.0, stream)
@@ -255,7 +261,10 @@ class HipTrainer:
         if c.layers[po].num_output_units != 1:
             raise NotImplementedError("training needs a scalar output unit")
         capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel(), 0.0, stream)
-        capi.call("ck_fill_f32", gviews[po][fo].data_ptr(), B, -1.0 / gB, stream)
+        if seed is None:
+            capi.call("ck_fill_f32", gviews[po][fo].data_ptr(), B, -1.0 / gB, stream)
+        else:  # (an arbitrary gradient of the outputs: `HipCircuitModule` under autograd)
+            gviews[po][fo].reshape(-1)[:B].copy_(seed.reshape(-1))
         shared, tmp = st["shared"], st["tmp"]
 
         def target(i):
@@ -324,7 +333,6 @@ class HipTrainer:
                               rows, dW.shape[-1], 0, stream)
                 elif not raw:
                     l.weight.backward(dW, self.grads, stream)
-        return ll
 
     def gradients(self) -> dict[str, np.ndarray]:
         """The gradients of the last `loss_and_grads`, host copies in the shapes of the user's plan."""
@@ -387,3 +395,57 @@ class HipTrainer:
         """Raise ``IndexError`` if a batch since the last check held a category out of range (`HipCircuit.check_inputs`);
         the steps on such batches changed nothing but the optimizer's step count and moment decay."""
         self.circuit.check_inputs()
+
+
+class _CircuitFunction(torch.autograd.Function):
+    """``y = circuit(x)`` with the hand-written backward of `HipTrainer` behind it."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        tr = module._trainer
+        with torch.cuda.device(tr.device):
+            tr.circuit.log_likelihood_sum(x)  # layer-wise forward, every activation kept in the arena
+            B = int(x.shape[0])
+            bd = tr.circuit._bind(B)
+            po, fo = int(tr.circuit._out_pairs[0, 0]), int(tr.circuit._out_pairs[0, 1])
+            y = bd.views[po][fo].reshape(B, 1, 1).clone()
+        module._generation += 1
+        ctx.module, ctx.B, ctx.generation = module, B, module._generation
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        m = ctx.module
+        if ctx.generation != m._generation:
+            raise RuntimeError("HipCircuitModule: backward of a forward that is not the last one (the activations live in ONE "
+                               "arena: call backward before the next forward)")
+        tr = m._trainer
+        with torch.cuda.device(tr.device):
+            tr._backward(ctx.B, float(ctx.B), gout.to(torch.float32).contiguous())
+        return (None, None, *[tr.grads[n].clone() for n in m._names])
+
+
+class HipCircuitModule(torch.nn.Module):
+    """A ``torch.nn.Module`` over a plan: the reference's training loop, unchanged, on the plan-level HIP path --
+
+        m = HipCircuitModule(plan, tensors);  opt = torch.optim.Adam(m.parameters(), lr=0.01)
+        loss = -m(batch).mean();  loss.backward();  opt.step()          # notebooks/learning-a-circuit.ipynb, cell 18
+
+    `forward` is the layer-wise HIP forward (``(B, 1, 1)`` log-likelihoods like ``TorchCircuit.forward``), `backward` the
+    launch list of cirkit_amd/csrc/ck_backward.hip (`HipTrainer`), for ANY gradient of the outputs.  The parameters are
+    ``nn.Parameter``s over the trainer's own storage (one flat buffer), so any torch optimizer updates the circuit in place.
+    One forward at a time: its activations live in one arena, `backward` must run before the next `forward`.  Same
+    coverage as `HipTrainer` (real lse-sum circuits with one scalar output)."""
+
+    def __init__(self, plan: Plan, tensors: Mapping[str, object], *, device: str | torch.device = "cuda:0") -> None:
+        super().__init__()
+        self._trainer = HipTrainer(plan, tensors, device=device, optimizer="sgd", lr=0.0)
+        self._names = list(self._trainer.plan.tensors)
+        self._generation = 0
+        self.params = torch.nn.ParameterList([torch.nn.Parameter(self._trainer.circuit.store[n]) for n in self._names])
+
+    def named_tensors(self) -> dict[str, torch.nn.Parameter]:
+        return dict(zip(self._names, self.params))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _CircuitFunction.apply(self, x, *self.params)
