@@ -2,7 +2,7 @@
 
 from .plan import Plan, plan_from_torch_circuit  # noqa: F401
 
-__all__ = ["Plan", "plan_from_torch_circuit", "HipCircuit", "HipCircuitStreams", "compile"]
+__all__ = ["Plan", "plan_from_torch_circuit", "HipCircuit", "HipCircuitStreams", "HipTrainer", "HipCircuitModule", "compile"]
 
 
 def __getattr__(name):  # lazy: importing the package must not require torch/ROCm
@@ -14,6 +14,10 @@ def __getattr__(name):  # lazy: importing the package must not require torch/ROC
         from .circuit import HipCircuitStreams
 
         return HipCircuitStreams
+    if name in ("HipTrainer", "HipCircuitModule"):
+        from . import training
+
+        return getattr(training, name)
     if name == "compile":
         from .pipeline import compile
 
