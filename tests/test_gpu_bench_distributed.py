@@ -147,3 +147,31 @@ def test_trainer_gradient_all_reduce_through_rccl(hip_device, tmp_path):
     for a, b in zip(res[0]["lls"], res[1]["lls"]):
         assert a[1] == b[1] and abs(a[0] - b[0]) <= 1e-6 * abs(b[0])
     assert abs(res[0]["param_abs_sum"] - res[1]["param_abs_sum"]) <= 1e-6 * res[1]["param_abs_sum"]
+
+
+def test_bench_line_carries_the_contract(hip_device):
+    """`python bench.py` (N = 1, short): ONE JSON line with the fields the driver reads -- metric / value / unit / n_gpus / steps /
+    warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload -- plus `roofline` (dominant
+    kernel: bound, achieved, peak, unit, frac, traffic) and `cpu_baseline` (value, unit, cores, kind, sample); value = rows / time."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "BENCH_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--settle", "20", "--rounds", "2",
+           "--no-variants", "--no-other-configs", "--no-live-pmc"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _one_json_line(out)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "steps_timed_total", "first_round_ms_per_step"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "evals/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    assert r["kernel"].startswith("leaf_persistent_kernel")
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+    assert d["check"]["max_rel_err_vs_oracle"] <= 1e-5
