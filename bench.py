@@ -7,13 +7,13 @@ Workload (BASELINE.json configs[1]; configs[2] at N=8): 784-variable QuadTree-2 
 Categorical-256 inputs, CP sum layers, K=32, fp32, batch 4096 PER GPU (weak scaling), synthetic
 int64 batches resident in HBM, closed-form random-init parameters (cirkit_amd.initializers).
 One "step" = one forward of the rank's 4096-row batch (parameter softmax/log recomputed every step,
-as the reference does) + the device-side sum of the log-likelihoods (+ for N > 1 the single RCCL
-all-reduce of the [sum, count] pair).
+as the reference does) + the device-side sum of the log-likelihoods (+ for N > 1 the exchange of its [sum, count]
+pair: RCCL all-reduces carrying the pairs of up to 64 consecutive steps each, all completed inside the timed region).
 
 K timed steps rotate through 12 distinct resident batches (308 MB of int64, more than the 256 MB Infinity Cache); the
 timed region is repeated `--rounds` times (each round: exactly K steps between barrier + synchronize) and the MEDIAN
 round is reported; by default there are at least 5 rounds and enough of them for ~400 steps in all, because the device
-keeps speeding up over its first ~150 steps (0.135 -> 0.123 ms per step, round by round) -- `timing` lists every round.
+keeps speeding up over its first ~50 ms of work; `--settle` untimed steps precede every timed region -- `timing` lists every round.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with
   roofline     -- the dominant kernel (by HIP-event time per launch, measured here): the contraction flops it EXECUTES
@@ -236,7 +236,7 @@ def main() -> None:
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not run the three short rocprofv3 counter passes (roofline.traffic then comes from profiles/)")
     ap.add_argument("--dist", action="store_true",
-                    help="take the distributed code path (process group + the async all-reduce of every step) even at world size 1")
+                    help="take the distributed code path (process group + the bucketed all-reduce of every step's [sum, count]) even at world size 1")
     ap.add_argument("--params-at-start", action="store_true",
                     help="evaluate the parameter graphs with a launch of their own at the START of every forward "
                          "(HipCircuit(params_at_end=False)) instead of inside the launch that walks the tail of the forward "
@@ -329,33 +329,48 @@ def main() -> None:
     def timed_region(circ, steps, warmup, rounds=1):
         """W untimed steps, then `rounds` rounds of exactly K timed steps, each round with a barrier + synchronize on both
         sides.  Returns (wall seconds per round -- max over ranks --, HIP-event ms per step per round on the launch
-        stream, final [sum, count], the [sum, count] of every step of the last round)."""
+        stream, the [sum, count] over ranks of the last step)."""
         last = [None]
-        # N > 1: the 16-byte all-reduce of step k runs on RCCL's stream WHILE step k + 1 computes (its
-        # input is copied out of the circuit's [sum, count] buffer, which the next step overwrites);
-        # a ring of buffers, each reused only after its previous collective has completed
-        ring = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(8)] if use_dist else []
-        works: list = [None] * len(ring)
-        count = [0]
+        # N > 1: every step's [sum, count] pair is exchanged, in BUCKETS: step k copies its pair into row k % BUCKET of a
+        # (BUCKET, 2) buffer and one all-reduce per full bucket (and one at the end of a round) carries them all -- fewer,
+        # larger collectives (a collective per step cost 15 us of every 102 us step at world size 1: its own launch, an event
+        # pair between the streams, and the host side of the call).  Two buffers alternate: the collective of one runs on
+        # RCCL's stream while the steps fill the other; a buffer is reused only after its previous collective has completed.
+        BUCKET = 64
+        bufs = [torch.zeros((BUCKET, 2), dtype=torch.float64, device=device) for _ in range(2)] if use_dist else []
+        works: list = [None, None]
+        cur = [0, 0]  # (buffer in use, rows filled)
         fed = [0]
 
+        def flush() -> None:
+            i, n = cur
+            if n:
+                works[i] = dist.all_reduce(bufs[i][:n], op=dist.ReduceOp.SUM, async_op=True)  # the exchange: n x 16 bytes over xGMI
+                cur[0], cur[1] = 1 - i, 0
+                if works[1 - i] is not None:
+                    works[1 - i].wait()  # (stream-level: the buffer about to be refilled has been reduced)
+                    works[1 - i] = None
+
         def step() -> None:
-            ll = circ.log_likelihood_sum(xs[fed[0] % nb])  # forward + device-side sum, enqueued on `stream`
+            x = xs[fed[0] % nb]
             fed[0] += 1
             if use_dist:
-                i = count[0] % len(ring)
-                count[0] += 1
-                if works[i] is not None:
-                    works[i].wait()  # stream-level wait on a collective issued 8 steps ago
-                ring[i].copy_(ll)
-                works[i] = dist.all_reduce(ring[i], op=dist.ReduceOp.SUM, async_op=True)  # the ONE exchange: 16 bytes over xGMI
-                ll = ring[i]
-            last[0] = ll
+                i, n = cur
+                # forward + device-side sum, enqueued on `stream`; the launch that ends the forward writes the pair into its row
+                last[0] = circ.log_likelihood_sum(x, out=bufs[i][n])
+                cur[1] = n + 1
+                if cur[1] == BUCKET:
+                    flush()
+            else:
+                last[0] = circ.log_likelihood_sum(x)
 
         def drain() -> None:
-            for w in works:
-                if w is not None:
-                    w.wait()
+            if use_dist:
+                flush()
+                for i in range(2):
+                    if works[i] is not None:
+                        works[i].wait()
+                        works[i] = None
 
         walls, evms = [], []
         with torch.cuda.stream(stream):
@@ -443,7 +458,8 @@ def main() -> None:
         },
         "distributed": {"backend": backend if use_dist else None, "world_size": world,
                         "ranks_seen_by_backend": ranks_seen,
-                        "all_reduce_per_step": bool(use_dist)},
+                        # every step's [sum, count] goes through the backend; one collective carries up to 64 steps' pairs
+                        "every_step_exchanged": bool(use_dist), "steps_per_collective": (64 if use_dist else None)},
         "check": {"mean_ll": total_nll / max(total_rows, 1.0), "rows": total_rows},
     }
 

@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -124,6 +124,7 @@ class TailParamsLaunch(C.Structure):
         ("table_scale", C.c_void_p),
         ("rows", C.c_void_p),
         ("n_tables", C.c_int32), ("n_rows", C.c_int32),
+        ("ll_cell", C.c_int32),
     ]
 
 

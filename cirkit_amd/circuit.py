@@ -54,6 +54,7 @@ class _Binding:
         self.program_ll = None  # the same followed by ck_ll_sum
         self.store_version = -1
         self.ll: torch.Tensor | None = None
+        self.ll_cell = 0  # program input cell of program_ll that redirects the [sum, count] pair (0: none)
         self.params_at_end = False  # the tail launch evaluates the parameters of the next forward (ck_tail_params_fwd)
         self.params_in_leaf = False  # the leaf launch evaluates its parameters (no prologue launch for them)
         self.params_sync: torch.Tensor | None = None
@@ -1080,6 +1081,9 @@ class HipCircuit:
             d.ll = bd.ll.data_ptr() if fuse_ll else None
             d.ll_partial = scratch.data_ptr() if fuse_ll else None
             d.ll_ticket = ticket.data_ptr() if fuse_ll else None
+            if fuse_ll and self._recording:  # `log_likelihood_sum(x, out=row)`: the pair goes where input cell 1 points
+                d.ll_cell = 1
+                bd.ll_cell = 1
             d.bad_input = self._bad_input.data_ptr() if (self._poison_in_tail() and not bd.direct) else None
             t = il["table"]
             d.cat_logits, d.dense_logits = t["src"].data_ptr(), t["dense"].data_ptr()
@@ -1443,7 +1447,7 @@ class HipCircuit:
             return torch.where(mask, torch.full((), float("nan"), device=x.device, dtype=torch.float32), x.to(torch.float32))
         return torch.where(mask, torch.full((), -1, device=x.device, dtype=torch.int64), x.to(torch.int64))
 
-    def _run(self, x: torch.Tensor | None, *, with_ll: bool = False) -> _Binding:
+    def _run(self, x: torch.Tensor | None, *, with_ll: bool = False, ll_out: torch.Tensor | None = None) -> _Binding:
         if self.plan.num_variables:
             if x is None:
                 raise ValueError(f"Expected some input 'x', as the circuit has {self.plan.num_variables} variables")
@@ -1486,6 +1490,11 @@ class HipCircuit:
                     raise RuntimeError("a binding that reads the raw batch cannot be replayed as a hipGraph")
                 bd.x_last = xi
                 capi.call("ck_program_set_input", prog, 0, xi.data_ptr())
+            if with_ll and bd.ll_cell:  # (an eager replay reads the cell; NULL = the binding's own pair)
+                direct_ll = ll_out is not None and not as_graph
+                capi.call("ck_program_set_input", prog, bd.ll_cell, ll_out.data_ptr() if direct_ll else None)
+                if direct_ll:
+                    ll_out = None
             if refresh:
                 self._pprog_data_version = state
                 capi.call("ck_program_launch", pprog, 1 if p_graph else 0, stream)
@@ -1498,6 +1507,8 @@ class HipCircuit:
             capi.call("ck_program_launch", prog, 1 if as_graph else 0, stream)
             if run is not cur:
                 cur.wait_stream(run)
+            if ll_out is not None:  # no launch of this binding takes the destination: one 16-byte copy
+                ll_out.copy_(bd.ll)
         return bd
 
     def replays_as_graph(self, B: int, *, with_ll: bool = False) -> bool:
@@ -1542,14 +1553,25 @@ class HipCircuit:
             views = [v if v is None else v[..., : s.num_output_units] for v, s in zip(views, self.user_plan.layers)]
         return views
 
-    def log_likelihood_sum(self, x: torch.Tensor) -> torch.Tensor:
+    def log_likelihood_sum(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         """Device tensor ``[sum_b log p(x_b), B]`` in fp64 -- the two numbers the data-parallel
-        all-reduce exchanges (SURVEY.md section 8 e).  Requires a single scalar output."""
+        all-reduce exchanges (SURVEY.md section 8 e).  Requires a single scalar output.
+
+        `out`: a contiguous fp64 tensor of two elements on this device (e.g. one row of a (steps, 2) buffer that a single
+        collective will carry) that receives the pair and is returned; the launch that ends the forward writes it there
+        itself where it can (ck_tail_params_fwd's ll_cell), a 16-byte copy does otherwise.  Without `out` the result is the
+        binding's own buffer, overwritten by the next call at this batch size."""
         pairs = self._out_pairs
         if len(pairs) != 1 or self._complex:
             raise ValueError("log_likelihood_sum needs a real circuit with one output")
         if self.layers[int(pairs[0, 0])].num_output_units != 1:
             raise ValueError("log_likelihood_sum needs a scalar output unit")
+        if out is not None:
+            index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            if out.dtype != torch.float64 or out.numel() != 2 or not out.is_contiguous() or not out.is_cuda or out.device.index != index:
+                raise ValueError(f"out must be a contiguous float64 tensor of 2 elements on {self.device}")
+            self._run(x, with_ll=True, ll_out=out)
+            return out
         return self._run(x, with_ll=True).ll
 
     # -- instrumentation -------------------------------------------------------------------------

@@ -135,7 +135,7 @@ extern "C" int ck_tail_params_fwd(const ck_tail_params_launch* d, void* stream) 
   const size_t lds = std::max(lds_tail, lds_pair);
   if (ctl > kTailCtlFloats * sizeof(float) || d->n_slots <= 0 || lds > 80 * 1024)
     return ck::fail(CK_ERR_UNSUPPORTED, "ck_tail_params_fwd: %d folds in %d slots do not fit two blocks per compute unit", d->n_folds, d->n_slots);
-  TailParamsArgs a{};
+  TailParamsArgs a{};  // (`a0` below: the copy the recorded launch keeps)
   a.folds = reinterpret_cast<const TailFold*>(d->folds);
   a.level_begin = d->level_begin;
   a.walk.B = d->B;
@@ -160,8 +160,18 @@ extern "C" int ck_tail_params_fwd(const ck_tail_params_launch* d, void* stream) 
   a.rows = d->rows;
   a.n_rows = d->n_rows;
   const int blocks = a.n_tail + a.n_pair + (d->n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  const TailParamsArgs a0 = a;
+  const void* const* ll_slot = nullptr;
+  if (d->ll_cell != 0) {
+    CK_REQUIRE(d->ll != nullptr, "ck_tail_params_fwd: ll_cell=%d without ll (the pair's home while the cell is NULL)", d->ll_cell);
+    ll_slot = ck::program_input_slot(d->ll_cell);
+    CK_REQUIRE(d->ll_cell > 0 && ll_slot != nullptr, "ck_tail_params_fwd: ll_cell=%d names a program input, but no program is being "
+               "recorded on this thread (or the index is outside 1..%d)", d->ll_cell, ck::kProgramInputs - 1);
+  }
   return ck::dispatch(
       [=](hipStream_t s) {
+        TailParamsArgs a = a0;
+        if (ll_slot != nullptr && *ll_slot != nullptr) a.walk.ll = static_cast<double*>(const_cast<void*>(*ll_slot));
         if (lds > 48 * 1024) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_params_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));

@@ -402,6 +402,10 @@ typedef struct ck_tail_params_launch {
   float* table_scale;
   const struct ck_rows32_job* rows;
   int32_t n_tables, n_rows;
+  int32_t ll_cell;                          /* 0: the pair is written to `ll`.  k in 1..3 while RECORDING: at every eager replay the pair
+                                               goes to the pointer in program input cell k (ck_program_set_input), to `ll` while that
+                                               cell is NULL -- a caller collecting the pairs of many steps in one buffer (one
+                                               collective for all of them) hands each step its row instead of copying it there */
 } ck_tail_params_launch;
 int ck_tail_params_fwd(const ck_tail_params_launch* desc, void* stream);
 
@@ -616,8 +620,8 @@ int ck_program_begin(ck_program** out);
 int ck_program_end(ck_program* prog);
 int ck_program_num_ops(const ck_program* prog);
 int ck_program_launch(ck_program* prog, int use_graph, void* stream);
-/* Per-launch inputs: a program has 4 input cells; a call recorded with a program-input index (ck_leaf_walk_fwd's x_input)
- * reads the pointer stored in that cell at every eager replay.  Set them before ck_program_launch; the memory must stay
+/* Per-launch inputs: a program has 4 input cells; a call recorded with a program-input index (ck_leaf_walk_fwd's x_input,
+ * ck_tail_params_fwd's ll_cell) reads the pointer stored in that cell at every eager replay.  Set them before ck_program_launch; the memory must stay
  * valid until the replayed launches have run (stream order).  This is what lets the recorded forward -- the replacement
  * of TorchCircuit.forward(x), circuits.py:242-278 -- take a different batch per call without staging it. */
 int ck_program_set_input(ck_program* prog, int index, const void* ptr);

@@ -54,7 +54,8 @@ def _expected_last_step(hip_device, world: int) -> torch.Tensor:
 
 def _check_two_ranks(d: dict, hip_device) -> None:
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * B and d["scaling"] == "weak"
-    assert d["distributed"] == {"backend": "gloo", "world_size": 2, "ranks_seen_by_backend": 2, "all_reduce_per_step": True}
+    assert d["distributed"] == {"backend": "gloo", "world_size": 2, "ranks_seen_by_backend": 2, "every_step_exchanged": True,
+                                "steps_per_collective": 64}
     assert d["check"]["rows"] == 2 * B
     assert d["steps_timed_total"] == ROUNDS * STEPS
     assert d["value"] > 0 and abs(d["value"] - 2 * B / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
@@ -90,7 +91,8 @@ def test_bench_runs_rccl_at_world_size_one(hip_device):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist", *BENCH_ARGS]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     d = _one_json_line(out)
-    assert d["distributed"] == {"backend": "nccl", "world_size": 1, "ranks_seen_by_backend": 1, "all_reduce_per_step": True}
+    assert d["distributed"] == {"backend": "nccl", "world_size": 1, "ranks_seen_by_backend": 1, "every_step_exchanged": True,
+                                "steps_per_collective": 64}
     assert d["n_gpus"] == 1 and d["check"]["rows"] == B
     tot = _expected_last_step(hip_device, 1)
     assert d["check"]["mean_ll"] == tot[0].item() / tot[1].item()  # bit for bit: SUM over one rank is the identity

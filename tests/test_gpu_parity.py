@@ -1261,3 +1261,32 @@ def test_default_path_over_batch_sizes(hip_device, B):
         assert float(((ya - yc).abs() / yc.abs()).max()) <= 2e-6, (B, rep)
         ll = a.log_likelihood_sum(x).cpu()
         assert ll[1].item() == B and abs(ll[0].item() - float(ya.double().sum())) <= 1e-6 * abs(ll[0].item())
+
+
+def test_log_likelihood_sum_into_a_row_of_the_callers_buffer(hip_device):
+    """`log_likelihood_sum(x, out=row)`: the pair of each step lands in the caller's (steps, 2) buffer -- written by the
+    forward's last launch on the default path (ck_tail_params_fwd's ll_cell), by a 16-byte copy on the others -- and equals
+    what the call without `out` returns; the binding's own pair is written again as soon as `out` is left out."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    gen = torch.Generator().manual_seed(77)
+    xs = [torch.randint(0, 256, (64, 784), generator=gen).to(hip_device) for _ in range(5)]
+    for kw in ({}, {"params_at_end": False}, {"fuse": False, "use_graph": False}):
+        hc = HipCircuit(plan, tensors, device=hip_device, **kw)
+        want = torch.stack([hc.log_likelihood_sum(x).clone() for x in xs])
+        assert (hc._bind(64).ll_cell == 1) == (kw == {})
+        buf = torch.full((5, 2), float("nan"), dtype=torch.float64, device=hip_device)
+        own = hc._bind(64).ll
+        own.fill_(-1.0)
+        for k, x in enumerate(xs):
+            r = hc.log_likelihood_sum(x, out=buf[k])
+            assert r.data_ptr() == buf[k].data_ptr()
+        assert torch.equal(buf, want), kw
+        if kw == {}:
+            assert torch.equal(own.cpu(), torch.tensor([-1.0, -1.0], dtype=torch.float64))  # (nothing was written there)
+        assert torch.equal(hc.log_likelihood_sum(xs[2]), want[2]) and hc.log_likelihood_sum(xs[2]).data_ptr() == own.data_ptr()
+        with pytest.raises(ValueError, match="float64"):
+            hc.log_likelihood_sum(xs[0], out=torch.zeros(2, device=hip_device))
+        with pytest.raises(ValueError, match="float64"):
+            hc.log_likelihood_sum(xs[0], out=torch.zeros((2, 2), dtype=torch.float64, device=hip_device)[:, 0])
