@@ -288,6 +288,32 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
   __shared__ __attribute__((aligned(16))) float g_lds[WAVES * kSlots * 1024];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // CK_LEAF_STAMPS (scripts/leaf_stamps.py builds a copy of the library with it; never defined in the product): shader-clock
+  // stamps of one tile of every wave of one workgroup -- where the instruction stream of a wave is when.  Stamp 3i: leaf i
+  // begins; 3i + 1: its rows are in registers; 3i + 2: the request of leaf i + 3 is out; 48: the root's chain is issued;
+  // 49: the tile is stored.  The workgroup is a.n_xjobs, the tile of each wave its a.tail_write-th; buffer: a.redo.
+#ifdef CK_LEAF_STAMPS
+  constexpr bool kStamps = XP && !TAIL && !PARAMS && WAVES == 8;  // (the others have no LDS to spare)
+  __shared__ long long s_stamps[kStamps ? WAVES : 1][kStamps ? 64 : 1];
+  bool stamp_on = false;
+#define CK_STAMP(id)                               \
+  do {                                             \
+    if (kStamps && stamp_on) {                     \
+      const long long c_ = clock64();              \
+      if (lane == 0) s_stamps[wave][(id)] = c_;    \
+    }                                              \
+  } while (0)
+  // per-workgroup wall-clock stamps (100 MHz): 0 entry, 1 weights landed, 2 first segment walked, 3 exit -> buffer[512 + 4 wg + k]
+#define CK_WG_STAMP(k)                                                                                                   \
+  do {                                                                                                                   \
+    if (kStamps && a.redo != nullptr && threadIdx.x == 0)                                                                \
+      reinterpret_cast<long long*>(a.redo)[512 + 4 * blockIdx.x + (k)] = static_cast<long long>(wall_clock64());          \
+  } while (0)
+#else
+#define CK_STAMP(id)
+#define CK_WG_STAMP(k)
+#endif
+  CK_WG_STAMP(0);
   const int b_in = lane & 31, kh = lane >> 5;
   float* const my_slots = g_lds + wave * (kSlots * 1024);
   uint32_t rd_addr[4];  // LDS byte address of chunk 2g + kh of row b_in in slot 0 (slot s: + 4096 s)
@@ -364,6 +390,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             __builtin_amdgcn_global_load_lds((ck::gptr_t)(src + q * qstride), (ck::lptr_t)(w_lds + k * 1024 + q * 256), 16, 0, 0);
       });
     });
+    if (seg == static_cast<int>(blockIdx.x)) CK_WG_STAMP(1024 + 0);  // (the weights' DMAs are out: the root's row has arrived)
     // The tiles of a segment are dealt round-robin to the waves (wave w: tile_begin + w, + WAVES, ...), so a wave knows
     // its next tiles and fetches their inputs while it computes: the batch values of tile k + 2 and, from those of tile
     // k + 1, its table rows' scales and first two leaf rows are requested when the gathers of tile k are over (the
@@ -498,6 +525,52 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       asm volatile("" : "+v"(soff));
       sld[i & 3] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.scale) + soff);
     };
+    // PIPE (three slots, depth >= 3).  The stamps of scripts/leaf_stamps.py show what two waves on a SIMD do to each other: a
+    // VALU instruction of one is not issued while the other is inside a chain of contractions (16, 32, ... dependent MFMAs:
+    // 1024 cycles each) -- and a wave issues in order, so everything behind that instruction waits with it.  A request as
+    // written above is row index (VALU) -> ds_bpermute -> address (VALU) -> DMA: the wave that has just finished its chains
+    // stood at the first of these for the whole chain of its neighbour, 14.5 k of the 44 k cycles of a tile, with its
+    // gathers and slot reads behind it.  Here the leaves are walked in PAIRS and the instructions of a pair are ordered
+    //   [slot reads of both leaves, the DMAs of the two leaves three ahead, the ds_bpermutes of the two leaves five ahead]
+    //   [VALU: their addresses, the row indices of the two leaves seven ahead, the products]   [the chains]
+    // so that between a wave's chains and its next VALU block there is only LDS and vector-memory work, which proceeds
+    // while the neighbour computes.  State between pairs: addresses (4 + 4 registers), scale offsets, two row indices.
+    constexpr bool kPipe = kSlots == 3 && D >= 3;
+    uint32_t p_addr[2][4], p_soff[2], p_ridx[2][4];
+    int32_t p_row[2];
+    const uint32_t bperm = 4 * (lane >> 3);
+    auto pipe_perm = [&](int h) {  // row indices of the lanes whose rows this lane fetches (results: p_ridx[h], in flight)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p_ridx[h][q] = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(bperm + 32 * q), p_row[h]));
+    };
+    auto pipe_addr = [&](int h) {  // VALU: addresses of the four DMAs and of the scale load from the exchanged row indices
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p_addr[h][q] = (p_ridx[h][q] << 7) + g_coff[q & 1];
+      p_soff[h] = static_cast<uint32_t>(p_row[h]) << 2;
+    };
+    auto pipe_issue = [&](int h, auto ic) {  // the request of leaf i: 4 DMAs + the scale load, no other instruction
+      constexpr int i = decltype(ic)::value;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const char* src = reinterpret_cast<const char*>(a.table) + p_addr[h][q];
+        __builtin_amdgcn_global_load_lds((ck::gptr_t)src, (ck::lptr_t)(my_slots + (i % kSlots) * 1024 + q * 256), 16, 0, 0);
+      }
+      sld[i & 3] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.scale) + p_soff[h]);
+    };
+    // what a tile starts with: the requests of its first three leaves as above, and the pipeline state of pair 0
+    auto start_tile = [&](const uint32_t (&cp)[kLeaves / 2]) {
+      static_for<0, kSlots>([&](auto jc) { request(cp, jc); });
+      if constexpr (kPipe) {
+        p_row[0] = row_of(cp, std::integral_constant<int, 3>{});
+        p_row[1] = row_of(cp, std::integral_constant<int, 4>{});
+        pipe_perm(0);
+        pipe_perm(1);
+        pipe_addr(0);
+        pipe_addr(1);
+        p_row[0] = row_of(cp, std::integral_constant<int, 5>{});
+        p_row[1] = row_of(cp, std::integral_constant<int, 6>{});
+      }
+    };
     // The tiles of a segment in chunks of 64 x WAVES (one chunk, normally): a wave notes the tiles whose products left the
     // linear range in a 64-bit mask (scalar registers) and evaluates them in log space AFTER its walk over the chunk.
     // Doing that inside the walk -- an out-of-line call with the whole walk state live -- cost the hot loop its
@@ -513,12 +586,16 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     int tile = chunk_begin + wave;
     if (tile < chunk_end) {  // the first tile of the wave: the chain is paid once per chunk
       load_x(tile, xraw);
+      if (chunk_begin == tile_begin && seg == static_cast<int>(blockIdx.x)) CK_WG_STAMP(1024 + 1);  // (batch values requested)
       bad_cur = pack_categories(xraw, cat);
-      static_for<0, kSlots>([&](auto jc) { request(cat, jc); });
+      if (chunk_begin == tile_begin && seg == static_cast<int>(blockIdx.x)) CK_WG_STAMP(1024 + 2);  // (... arrived and packed)
+      start_tile(cat);
+      if (chunk_begin == tile_begin && seg == static_cast<int>(blockIdx.x)) CK_WG_STAMP(1024 + 3);  // (first rows requested)
     }
     if (chunk_begin == tile_begin) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the weights (and its first leaf rows) have landed
       __syncthreads();
+      CK_WG_STAMP(1);
     }
     uint64_t bad_tiles = 0;
     int nth = 0;  // tile number `nth` of this wave in the chunk
@@ -529,15 +606,96 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       float stack[D][16], sstack[D];
       float cur[16], cs = 0.f, sprev = 0.f;
       bool bad = false;
+#ifdef CK_LEAF_STAMPS
+      stamp_on = static_cast<int>(blockIdx.x) == a.n_xjobs && nth == a.tail_write;
+#endif
+      constexpr int kXLoads = XRAW ? (XP ? kLeaves / 4 : kLeaves / 2) : kLeaves;  // (exactly: XP is a template parameter)
+      if constexpr (kPipe) {
+        static_for<0, kLeaves / 2>([&](auto pc) {
+          constexpr int e = 2 * decltype(pc)::value, o = e + 1;
+          float s_e = 0.f, s_o = 0.f;
+          WRegs wfirst;
+          // ---- LDS and vector memory only
+          static_for<0, 2>([&](auto hc) {
+            constexpr int h = decltype(hc)::value, i = e + h;
+            CK_STAMP(3 * i);
+            // younger than the request of leaf i: those of the next two leaves and, between the requests of leaves 4 and 5
+            // (the VALU block of leaf 1), the batch values of the wave's next tile
+            constexpr int kYounger = 5 * (kLeaves - 1 - i < 2 ? kLeaves - 1 - i : 2) + (i >= 2 && i <= 4 ? kXLoads : 0);
+            f32x4 r0, r1, r2, r3;
+            if constexpr (h == 1) {  // (the weights of the pair's first contraction with the slot reads: one LDS round trip)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) wfirst.q[q] = *reinterpret_cast<const float4*>(w_lds + steps_before(o) * 1024 + q * 256 + lane * 4);
+            }
+            asm volatile(
+                "s_waitcnt vmcnt(%9)\n\tds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\t"
+                "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                : "v"(rd_addr[0]), "v"(rd_addr[1]), "v"(rd_addr[2]), "v"(rd_addr[3]), "n"((i % kSlots) * 4096), "n"(kYounger)
+                : "memory");
+            float(&dst)[16] = h == 0 ? stack[0] : cur;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              dst[k] = r0[k];
+              dst[4 + k] = r1[k];
+              dst[8 + k] = r2[k];
+              dst[12 + k] = r3[k];
+            }
+            (h == 0 ? s_e : s_o) = sld[i & 3];
+            CK_STAMP(3 * i + 1);
+            if constexpr (i + kSlots < kLeaves) pipe_issue(h, std::integral_constant<int, i + kSlots>{});
+            if constexpr (i + 5 < kLeaves) pipe_perm(h);
+            CK_STAMP(3 * i + 2);
+          });
+          // ---- VALU
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (e == 0) load_x(min(tile + WAVES, chunk_end - 1), xraw);
+          if constexpr (e == kLeaves / 2) bad_next = pack_categories(xraw, catnext);
+          cs = s_o + s_e;  // log scale of the pair
+          tile_mul(cur, stack[0]);  // first level: the bare product (ck_tile.h)
+          static_for<0, 2>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            if constexpr (e + h + 5 < kLeaves) pipe_addr(h);
+            if constexpr (e + h + 7 < kLeaves) p_row[h] = row_of(cat, std::integral_constant<int, e + h + 7>{});
+          });
+          if constexpr (o + 1 == kLeaves) {
+            // the gathers of this tile are over: request what the next tile starts with
+            if (tile + WAVES < chunk_end) {
+#pragma unroll
+              for (int j = 0; j < kLeaves / 2; ++j) cat[j] = catnext[j];
+              start_tile(cat);
+            }
+          }
+          static_for<0, steps_after(o)>([&](auto lc) {
+            constexpr int l = decltype(lc)::value, step = steps_before(o) + l;
+            WRegs wcur;
+            if constexpr (l == 0) {
+              wcur = wfirst;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
+              linear_product<true, SIGNED>(cur, stack[l], cs, sstack[l], bad);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            contract_linear<CK_W_TILED_F32>(wcur, cur);
+          });
+          if constexpr (steps_after(o) < D) {  // left sibling at this level: wait for the right one
+            constexpr int l = steps_after(o);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) stack[l][j] = cur[j];
+            sstack[l] = cs;
+          }
+        });
+      } else
       static_for<0, kLeaves>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
+        CK_STAMP(3 * i);
         // the request of leaf i has landed: at most those of the next kSlots - 1 leaves, 5 operations each, are younger --
         // and, for leaves 1 .. kSlots - 1, the batch values of the wave's next tile, requested at leaf 0 and not needed before
         // leaf kLeaves / 2.  kXLoads is the FEWEST load instructions a tile's batch values take (a smaller count only waits
         // longer; the previous tile's output stores, younger than its successor's first requests, are not counted for the
         // same reason).  Read the slot into the operand layout; the reads have returned before the slot is refilled
         f32x4 r0, r1, r2, r3;
-        constexpr int kXLoads = XRAW ? (XP ? kLeaves / 4 : kLeaves / 2) : kLeaves;  // (exactly: XP is a template parameter)
         constexpr int kYounger = 5 * (kLeaves - 1 - i < kSlots - 1 ? kLeaves - 1 - i : kSlots - 1) + (i >= 1 && i < kSlots ? kXLoads : 0);
         // (the weights of the leaf's first contraction are requested in front of the slot reads: one LDS round trip for both)
         WRegs wfirst;
@@ -559,6 +717,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           cur[12 + e] = r3[e];
         }
         const float s_i = sld[i & 3];
+        CK_STAMP(3 * i + 1);
         // The batch values of this wave's NEXT tile: requested here, behind the first slot read, and packed half a tile
         // later IN THE SAME ITERATION -- requested at the end of the previous tile (one more tile of lead) the compiler's
         // wait-count pass loses count across the loop's back edge and puts s_waitcnt vmcnt(0) in front of the packing: every
@@ -577,6 +736,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         }
         if constexpr ((i & 1) != 0) cs = s_i + sprev;  // log scale of the pair (i - 1, i)
         else sprev = s_i;
+        CK_STAMP(3 * i + 2);
         static_for<0, steps_after(i)>([&](auto lc) {
           constexpr int l = decltype(lc)::value, step = steps_before(i) + l;
           WRegs wcur;
@@ -604,6 +764,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         }
       });
       if constexpr (D == 1) bad |= !((SIGNED ? tile_row_max_abs(cur) : tile_row_max(cur)) > kLinearFloor);  // (deeper roots are renormalised steps)
+      CK_STAMP(48);
       if (__builtin_expect(__any(bad), 0)) {
         // rare: evaluated again in log space -- below, after the walk; SIGNED: by leaf_signed_redo_kernel (the signed
         // log-space walk as a callee costs this kernel 67 spilled registers: 84 -> 88 us at config 5)
@@ -635,6 +796,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           else tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
         }
       }
+      CK_STAMP(49);
     }
     // the noted tiles: a row of products fell out of the fp32 range -> the whole tile in log space (semiring.py:383-408)
     while (bad_tiles != 0) {
@@ -676,11 +838,20 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       }
     }
     }  // chunk
+    CK_WG_STAMP(2);
   }
   if constexpr (TAIL) {
     static_assert(!SIGNED, "the in-launch tail walks unsigned values");
     leaf_tail_phase<WAVES>(a, g_lds, WAVES * kSlots * 2, w_lds);
   }
+#ifdef CK_LEAF_STAMPS
+  __syncthreads();
+  CK_WG_STAMP(3);
+  if (kStamps && static_cast<int>(blockIdx.x) == a.n_xjobs && a.redo != nullptr)
+    for (int i = threadIdx.x; i < WAVES * 64; i += blockDim.x) reinterpret_cast<long long*>(a.redo)[i] = s_stamps[i >> 6][i & 63];
+#endif
+#undef CK_STAMP
+#undef CK_WG_STAMP
 }
 
 // The tiles a SIGNED launch marked (a row of products below the linear-space floor), in log space with signs
@@ -862,6 +1033,13 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
     a.xjobs = d->xjobs;
     a.n_xjobs = d->n_xjobs;
   }
+#ifdef CK_LEAF_STAMPS
+  if (d->cat_logits == nullptr && d->signed_redo == nullptr && getenv("CK_STAMP_PTR") != nullptr) {
+    a.redo = reinterpret_cast<int32_t*>(strtoull(getenv("CK_STAMP_PTR"), nullptr, 0));
+    a.n_xjobs = getenv("CK_STAMP_WG") ? atoi(getenv("CK_STAMP_WG")) : 0;
+    a.tail_write = getenv("CK_STAMP_TILE") ? atoi(getenv("CK_STAMP_TILE")) : 1;
+  }
+#endif
   const int depth = d->depth, waves = d->waves, n_roots = d->n_roots;
   const bool is_signed = d->signed_redo != nullptr;
   dim3 grid(static_cast<unsigned>(std::min(d->n_wg, d->n_seg)));
