@@ -545,12 +545,14 @@ def main() -> None:
             pmc_source = "three rocprofv3 counter passes run by this bench.py invocation (FETCH_SIZE x2, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES)"
         if pmc is None:
             tj = os.path.join(ROOT, "profiles", "traffic.json")
-            key = f"r02,fuse={[g.depth for g in circuit._groups]},tail={len(circuit._tail)},contraction={args.contraction},B={B}"
-            if os.path.exists(tj):
+            # the committed passes of the default configuration (scripts/profile_round.sh r03 e); kernels are matched by label
+            default_cfg = ([g.depth for g in circuit._groups] == [4] and len(circuit._tail) == 6 and args.contraction == "f32" and B == 4096
+                           and not (args.staged_input or args.params_at_start))
+            if os.path.exists(tj) and default_cfg:
                 with open(tj, encoding="utf-8") as f:
                     tr = json.load(f)
-                if key in tr:
-                    pmc, pmc_source = tr[key], "profiles/traffic.json (committed rocprofv3 passes of the same configuration; not measured in this run)"
+                if "r03,e" in tr:
+                    pmc, pmc_source = tr["r03,e"], "profiles/traffic.json (committed rocprofv3 passes of the same configuration; not measured in this run)"
         if not args.no_kernel_breakdown:
             with torch.cuda.stream(stream):
                 rows = circuit.profile_kernels(x, iters=10)
