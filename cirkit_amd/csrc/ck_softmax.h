@@ -116,18 +116,20 @@ __device__ __forceinline__ int w32_index(int o, int l, bool tiled) {
 // this wave in flight at once: pass p handles rows 2 * (first_pair + p * pair_stride) + half.  The reduction tree and
 // the order of operations are those of every 32-wide softmax of the prologue (softmax_job_rows, len <= 32).
 //   put(row, l, p): stores the probability of entry l of `row`.
-template <int PASSES, class Put>
-__device__ __forceinline__ void softmax_rows32(const float* __restrict__ in, int rows, int first_pair, int pair_stride, int lane,
-                                               Put&& put) {
+// (in two halves, so that a caller with several blocks to do can request all of them before it evaluates the first)
+template <int PASSES>
+__device__ __forceinline__ void softmax_rows32_load(const float* __restrict__ in, int rows, int first_pair, int pair_stride, int lane,
+                                                    float (&x)[PASSES]) {
   const int half = lane >> 5, l = lane & 31;
-  float x[PASSES];
-  bool ok[PASSES];
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
     const int row = 2 * (first_pair + p * pair_stride) + half;
-    ok[p] = row < rows;
-    x[p] = ok[p] ? ck::as_global(in)[row * 32 + l] : -INFINITY;  // (`in` is device memory in every caller)
+    x[p] = row < rows ? ck::as_global(in)[row * 32 + l] : -INFINITY;  // (`in` is device memory in every caller)
   }
+}
+template <int PASSES, class Put>
+__device__ __forceinline__ void softmax_rows32_apply(const float (&x)[PASSES], int rows, int first_pair, int pair_stride, int lane, Put&& put) {
+  const int half = lane >> 5, l = lane & 31;
   float mx[PASSES];
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) mx[p] = x[p];
@@ -135,10 +137,18 @@ __device__ __forceinline__ void softmax_rows32(const float* __restrict__ in, int
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
     const int row = 2 * (first_pair + p * pair_stride) + half;
-    const float e = ok[p] ? __expf(x[p] - mx[p]) : 0.f;
+    const bool ok = row < rows;
+    const float e = ok ? __expf(x[p] - mx[p]) : 0.f;
     const float sum = half_reduce_dpp<false>(e);
-    if (ok[p]) put(row, l, e / sum);
+    if (ok) put(row, l, e / sum);
   }
+}
+template <int PASSES, class Put>
+__device__ __forceinline__ void softmax_rows32(const float* __restrict__ in, int rows, int first_pair, int pair_stride, int lane,
+                                               Put&& put) {
+  float x[PASSES];
+  softmax_rows32_load<PASSES>(in, rows, first_pair, pair_stride, lane, x);
+  softmax_rows32_apply<PASSES>(x, rows, first_pair, pair_stride, lane, put);
 }
 
 // Log-softmax of R rows of logits held by a wave, four per lane (lanes past a row hold -inf), in place:

@@ -41,7 +41,7 @@
 
 namespace {
 
-constexpr int kRowsPerBlock = 16;  // 32 x 32 softmaxes per block of the last kind
+constexpr int kRowsPerBlock = 4;  // 32 x 32 softmaxes per block of the last kind
 
 struct TailParamsArgs {
   // tail
@@ -62,13 +62,28 @@ struct TailParamsArgs {
   // 32-wide softmaxes
   const ck_rows32_job* rows;
   int n_rows;
+#ifdef CK_TAILP_STAMPS
+  long long* stamps;  // scripts/tailp_stamps.py: 16 wall-clock stamps (100 MHz) per block
+#endif
 };
+
+// CK_TAILP_STAMPS (a copy of the library built by scripts/tailp_stamps.py; never defined in the product): when each block of
+// the launch enters and leaves, and when a tail block has finished each of its levels (ck_tailwalk.h, CK_TAIL_LEVEL_STAMP).
+#ifdef CK_TAILP_STAMPS
+#define CK_TP_STAMP(k)                                                                                          \
+  do {                                                                                                          \
+    if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[16 * blockIdx.x + (k)] = static_cast<long long>(wall_clock64()); \
+  } while (0)
+#else
+#define CK_TP_STAMP(k)
+#endif
 
 __global__ void __launch_bounds__(512, 4) tail_params_kernel(const TailParamsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = blockIdx.x;
+  CK_TP_STAMP(0);
   if (bid < a.n_tail) {
     // ---- one 16-row tile of the tail
     TailFold* s_fold = reinterpret_cast<TailFold*>(smem);
@@ -84,7 +99,12 @@ __global__ void __launch_bounds__(512, 4) tail_params_kernel(const TailParamsArg
     __syncthreads();
     const bool poison = a.bad_input != nullptr && *a.bad_input != 0;
     const TailTiles tiles{tiles_base, tiles_base, a.n_slots};
+#ifdef CK_TAILP_STAMPS
+    g_tail_level_stamps = a.stamps != nullptr ? a.stamps + 16 * blockIdx.x + 2 : nullptr;
+#endif
+    CK_TP_STAMP(1);
     tail_walk<8, false>(a.walk, bid, tiles, s_fold, s_level, poison, wave, WorkgroupBarrier{});
+    CK_TP_STAMP(15);
     return;
   }
   const int v = bid - a.n_tail;
@@ -106,14 +126,30 @@ __global__ void __launch_bounds__(512, 4) tail_params_kernel(const TailParamsArg
       if (c <= C && kh == 0) dsc[c] = m;
       if (c <= C) tile_store(dst + static_cast<int64_t>(c) * 32 + 4 * kh, val);
     });
+    CK_TP_STAMP(15);
     return;
   }
-  // ---- 32-wide softmaxes: one (rows <= 32, 32) block per turn, two rows per wave pass
+  // ---- 32-wide softmaxes: kRowsPerBlock (rows <= 32, 32) blocks, two rows of each per wave pass.  ALL their logits are
+  // requested before the first is evaluated: one after the other they are sixteen memory round trips in a row, 16 us for a
+  // block that enters at 12 us -- these blocks, not the tail, were what the launch ended on (scripts/tailp_stamps.py).
+  // (descriptors first, then every block's logits, then the arithmetic: three memory round trips per workgroup)
   const int x0 = (v - a.n_pair) * kRowsPerBlock;
-  for (int x = x0; x < min(x0 + kRowsPerBlock, a.n_rows); ++x) {
-    const ck_rows32_job xj = a.rows[x];
-    softmax_rows32<2>(xj.in, xj.rows, wave, 8, lane, [&](int row, int l, float p) { ck::as_global(xj.out)[w32_index(row, l, xj.tiled != 0)] = p; });
+  const int n = min(kRowsPerBlock, a.n_rows - x0);
+  ck_rows32_job xj[kRowsPerBlock];
+#pragma unroll
+  for (int i = 0; i < kRowsPerBlock; ++i) xj[i] = a.rows[x0 + min(i, n - 1)];
+  float xr[kRowsPerBlock][2];
+#pragma unroll
+  for (int i = 0; i < kRowsPerBlock; ++i) softmax_rows32_load<2>(xj[i].in, xj[i].rows, wave, 8, lane, xr[i]);
+#pragma unroll
+  for (int i = 0; i < kRowsPerBlock; ++i) {
+    if (i < n) {
+      float* const out = xj[i].out;
+      const bool tiled = xj[i].tiled != 0;
+      softmax_rows32_apply<2>(xr[i], xj[i].rows, wave, 8, lane, [&](int row, int l, float p) { ck::as_global(out)[w32_index(row, l, tiled)] = p; });
+    }
   }
+  CK_TP_STAMP(15);
 }
 
 }  // namespace
@@ -159,6 +195,9 @@ extern "C" int ck_tail_params_fwd(const ck_tail_params_launch* d, void* stream) 
   a.n_pair = (d->n_tables + 1) / 2;
   a.rows = d->rows;
   a.n_rows = d->n_rows;
+#ifdef CK_TAILP_STAMPS
+  a.stamps = getenv("CK_STAMP_PTR") != nullptr ? reinterpret_cast<long long*>(strtoull(getenv("CK_STAMP_PTR"), nullptr, 0)) : nullptr;
+#endif
   const int blocks = a.n_tail + a.n_pair + (d->n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
   const TailParamsArgs a0 = a;
   const void* const* ll_slot = nullptr;

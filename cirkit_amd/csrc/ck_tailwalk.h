@@ -93,6 +93,9 @@ struct WaveGroupBarrier {
   }
 };
 
+#ifdef CK_TAILP_STAMPS
+__shared__ long long* g_tail_level_stamps;  // (ck_tailp.hip, CK_TAILP_STAMPS: where thread 0 notes the end of each level)
+#endif
 // `wave`: this wave's number among the WAVES that walk the tile; `barrier`: their barrier.
 template <int WAVES, bool WT, class Barrier>
 __device__ __forceinline__ void tail_walk(const TailWalkArgs& a, int tile, const TailTiles& tiles, const TailFold* s_fold,
@@ -257,6 +260,9 @@ __device__ __forceinline__ void tail_walk(const TailWalkArgs& a, int tile, const
       w = wn;
     }
     barrier();  // the level's tiles are in LDS (no wait for the weights just requested for the next level)
+#ifdef CK_TAILP_STAMPS
+    if (threadIdx.x == 0 && g_tail_level_stamps != nullptr && li < 12) g_tail_level_stamps[li] = static_cast<long long>(wall_clock64());
+#endif
   }
 }
 
