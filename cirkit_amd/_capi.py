@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -79,29 +79,32 @@ class LeafLaunch(C.Structure):
         ("x_rows", C.c_void_p),
         ("bad_input", C.c_void_p),
         ("D", C.c_int32),
-        ("tail_write", C.c_int32),
-        ("tail_folds", C.c_void_p),
-        ("tail_level_begin", C.c_void_p),
-        ("tail_n_folds", C.c_int32), ("tail_n_levels", C.c_int32),
-        ("tail_w_layout", C.c_int32),
-        ("reserved", C.c_int32),
-        ("tail_bad_input", C.c_void_p),
-        ("ll", C.c_void_p),
-        ("ll_partial", C.c_void_p),
-        ("ll_ticket", C.c_void_p),
-        ("tail_arrive", C.c_void_p),
-        ("tail_state", C.c_void_p),
-        ("cat_logits", C.c_void_p),
-        ("cat_idx", C.c_void_p),
-        ("dense_logits", C.c_void_p),
-        ("w_logits", C.POINTER(C.c_void_p)),
-        ("groot_off", C.c_void_p),
-        ("groot", C.c_void_p),
-        ("params_arrive", C.c_void_p),
-        ("xjobs", C.c_void_p),
-        ("n_xjobs", C.c_int32),
+        ("keep_levels", C.POINTER(C.c_void_p)),
+        ("keep_redo", C.c_void_p),
         ("x_pairs", C.c_int32),
         ("root_tab", C.c_void_p),
+    ]
+
+
+class LeafBwdLaunch(C.Structure):
+    """ck_leaf_bwd_launch of include/cirkit_hip.h."""
+
+    _fields_ = [
+        ("unit_tab", C.c_void_p),
+        ("work", C.c_void_p),
+        ("n_seg", C.c_int32), ("n_wg", C.c_int32), ("B", C.c_int32), ("C", C.c_int32), ("D", C.c_int32), ("leaf", C.c_int32),
+        ("gin", C.c_void_p),
+        ("y_p", C.c_void_p),
+        ("y_q", C.c_void_p),
+        ("y_c", C.c_void_p),
+        ("table", C.c_void_p),
+        ("x_rows", C.c_void_p),
+        ("w_p", C.c_void_p),
+        ("w_q", C.c_void_p),
+        ("dw_p", C.c_void_p),
+        ("dw_q", C.c_void_p),
+        ("gout", C.c_void_p),
+        ("redo", C.c_void_p),
     ]
 
 
@@ -189,11 +192,13 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_gaussian_product_logz": [_p, _p, _p, _p, _p, _l, _i, _i, _p],
     "ck_segment_add_rows": [_p, _p, _p, _p, _p, _i, _l, _p],
     "ck_param_scatter_add_folds": [_p, _p, _p, _l, _l, _p],
-    "ck_categorical_bwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_categorical_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_leaf_walk_bwd": [C.POINTER(LeafBwdLaunch), _p],
     "ck_param_softmax_bwd": [_p, _p, _p, _l, _i, _i, _p],
     "ck_param_log_table_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],
-    "ck_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p],
-    "ck_sgd_step": [_p, _p, _l, _f, _f, _p],
+    "ck_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p, _p],
+    "ck_sgd_step": [_p, _p, _l, _f, _f, _p, _p],
+    "ck_latch_flag": [_p, _p, _p],
     "ck_ll_sum": [_p, _l, _l, _p, _p],
     "ck_program_begin": [C.POINTER(_p)],
     "ck_program_end": [_p],

@@ -56,10 +56,7 @@ class _Binding:
         self.ll: torch.Tensor | None = None
         self.ll_cell = 0  # program input cell of program_ll that redirects the [sum, count] pair (0: none)
         self.params_at_end = False  # the tail launch evaluates the parameters of the next forward (ck_tail_params_fwd)
-        self.params_in_leaf = False  # the leaf launch evaluates its parameters (no prologue launch for them)
-        self.params_sync: torch.Tensor | None = None
-        self.tail_in_leaf = False  # the last leaf launch walks the tail too (no tail launch)
-        self.tail_sync: tuple | None = None  # (arrival counter, per-tile epochs) of that launch
+        self.keep: dict[int, tuple] = {}  # `keep_levels`: leaf group root -> ([(F_l, B, 32) linear tiles per level], tile flags)
         self.direct = False  # the leaf launches read the caller's int64 batch themselves (no staged copy of it)
         self.x_last: torch.Tensor | None = None  # ... the batch of the last call (kept alive; read by eager launches)
 
@@ -108,7 +105,6 @@ class HipCircuit:
         persistent_leaf: the fused leaf launch as ONE resident workgroup per CU walking (root, tile range) segments
             (cirkit_amd/csrc/ck_leaf.hip) instead of one workgroup per 128 rows.  None: whenever the launch is eligible
             (linear table, tiled fp32 weights) and has at least one 32-row tile per CU; bit-identical either way.
-        leaf_waves: wavefronts per workgroup of the persistent leaf launch (8 or 12).
         validate_inputs: discrete inputs are range-checked on the device while they are staged (no extra launch, no host
             synchronisation): a category >= the layer's number of categories -- an ``IndexError`` in the reference -- makes
             the outputs NaN and `check_inputs()` raise.  Negative values are this library's "marginalised" sentinel.
@@ -118,26 +114,21 @@ class HipCircuit:
             the caller's ``(B, D)`` int64 tensor themselves (`ck_leaf_walk_fwd` with a program input): no staging launch,
             no staged copy.  An out-of-range category then makes the outputs of ITS ROW NaN (and `check_inputs()` raise)
             instead of the whole batch's, and later batches are unaffected.  False always stages the batch.
-        merge_tail: (off by default: 11 us slower than the tail launch as it stands) the trailing
-            few-fold levels are walked by the persistent leaf launch itself after its segments
-            (`ck_leaf_walk_fwd` with tail_folds: roots stored write-through, arrival counter, 16-row tiles claimed by the
-            resident workgroups) instead of by a launch of their own; same arithmetic per fold as `ck_tail16_lse_fwd`.
-        inlaunch_params: the persistent leaf launch evaluates the parameter graphs it depends on itself (`ck_leaf_walk_fwd` with
-            cat_logits: the Categorical log-tables pushed through their dense folds, the weights of its levels, and the
-            32-wide softmaxes of the layers behind it) with the device functions of the prologue launch -- same bits -- so
-            that a forward has no parameter launch in front of it.  Needs one leaf group, C <= 256, exact fp32.  Off by
-            default: measured at the north-star configuration the phase costs the leaf launch 30 us + 4 us of waiting,
-            the prologue launch it replaces 21 us.
         params_at_end: the parameter graphs are re-evaluated once per forward as in the reference, but at the END of a
             forward and for the next one: the launch that walks the tail carries the prologue's workgroups beside its own
             (`ck_tail_params_fwd`: both are latency-bound and independent, a tail block and a parameter block share a compute
             unit).  A forward whose `TensorStore` has changed since (`store.set`, `invalidate_parameters`) evaluates them at
             its start first (`TensorStore.state()`: `store.set` / `touch` and the torch version counters of the stored tensors,
             so an optimizer's in-place step is seen; only a write through a raw pointer by a foreign kernel needs `touch()`).
-            On by default where it applies (the conditions of `inlaunch_params` + a 16-row tail): 28.8 us for the launch
-            against 16.7 + 17.9 us for the two it replaces at the north-star configuration.
-        keep_layer_outputs: False: `forward` does not store the 32-unit fold outputs of a tail walked inside the leaf
-            launch (nobody but `layer_outputs()` reads them; `log_likelihood_sum` never stores them).
+            Applies to circuits with ONE persistent leaf launch (table and dense layer built by one prologue job, C <= 256,
+            tiled fp32 weights) and a 16-row tail: 27 us for the launch against 16.7 + 17.9 us for the two it replaces at
+            the north-star configuration.  (Two further fusions -- the tail and the parameters INSIDE the leaf launch -- were
+            built, were bit-identical and slower; LAB_NOTES.md has the measurements, the code is gone.)
+        keep_levels: the training forward (cirkit_amd/training.py): every persistent leaf launch also stores the linear tile of
+            each node it evaluates (`ck_leaf_walk_fwd` with keep_levels) -- what the fused backward (`ck_leaf_walk_bwd`) reads
+            instead of the materialised layer outputs the reference's autograd keeps.  Needs `direct_input`.
+        keep_layer_outputs: False: `forward` does not store the 32-unit fold outputs of the tail that only the tail itself
+            reads (nobody but `layer_outputs()` wants them; `log_likelihood_sum` never stores them).
     """
 
     def __init__(
@@ -160,14 +151,12 @@ class HipCircuit:
         linear_levels: bool = True,
         pad_units: bool = True,
         persistent_leaf: bool | None = None,
-        leaf_waves: int = 8,
         tail16: bool = True,
         validate_inputs: bool = True,
         direct_input: bool = True,
-        merge_tail: bool = False,
         keep_layer_outputs: bool = True,
-        inlaunch_params: bool = False,
         params_at_end: bool = True,
+        keep_levels: bool = False,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -207,18 +196,14 @@ class HipCircuit:
         self.cache_params = bool(cache_params)
         self.linear_levels = bool(linear_levels)
         self.persistent_leaf = persistent_leaf
-        if leaf_waves not in (8, 12):
-            raise ValueError("leaf_waves must be 8 or 12")
-        self.leaf_waves = int(leaf_waves)
         self.tail16 = bool(tail16)
         self.validate_inputs = bool(validate_inputs)
         self.direct_input = bool(direct_input)
-        self.merge_tail = bool(merge_tail)
         self.keep_layer_outputs = bool(keep_layer_outputs)
-        self.inlaunch_params = bool(inlaunch_params)
         self.params_at_end = bool(params_at_end)
+        self.keep_levels = bool(keep_levels)
         self._params_valid_version = None  # store.state() the derived parameters in memory were evaluated from
-        self._inlaunch: dict | None = None
+        self._tailp: dict | None = None  # what the tail + parameters launch evaluates (`_plan_tail_params`)
         self._recording = False
         self._num_states: torch.Tensor | None = None
         self._states_consistent = True
@@ -505,14 +490,7 @@ class HipCircuit:
         bd.ll = torch.empty(2, dtype=torch.float64, device=self.device)
         self._ensure_param_batch()  # (which leaf launches are persistent depends on the prologue's table jobs)
         bd.direct = self._direct_input(B)
-        bd.tail_in_leaf = self._tail_in_leaf(B)
-        bd.params_in_leaf = self._params_in_leaf(B)
         bd.params_at_end = self._params_at_end(B)
-        if bd.params_in_leaf:
-            bd.params_sync = torch.zeros(8 * 16, dtype=torch.int64, device=self.device)
-        if bd.tail_in_leaf:
-            bd.tail_sync = (torch.zeros(1, dtype=torch.int64, device=self.device),
-                            torch.zeros((B + 15) // 16, dtype=torch.int32, device=self.device))
         bd.program = self._record(bd, with_ll=False)  # the launch list, recorded once
         if bd.direct and self.use_graph and capi.load().ck_program_num_ops(bd.program) > self.graph_min_launches:
             # a hipGraph keeps the pointers of its capture: long launch lists read the staged copy of the batch
@@ -526,36 +504,13 @@ class HipCircuit:
         """Some slot of a CP block / region reads a dense layer tabulated over its categories (a staged-batch consumer)."""
         return any(int(d) in self._tdense for d in np.unique(slot_dense[..., 0]) if d >= 0)
 
-    def _tail_host_group(self) -> int | None:
-        """Root layer of the leaf group whose launch is the last one in front of the tail (None: something else is)."""
-        if not self._tail or not self._groups:
-            return None
-        last = None
-        for i in range(self._tail[0]):
-            if i not in self._virtual:
-                last = i
-        return last if last in self._group_of_root else None
-
-    def _tail_in_leaf(self, B: int) -> bool:
-        """Whether the tail is walked by the last leaf launch (ck_leaf.hip, leaf_tail_phase) at batch size B: that launch
-        is persistent with a fused depth >= 2 and directly precedes the tail; unsigned values; the tail's folds fit its LDS."""
-        root = self._tail_host_group()
-        if not self.merge_tail or root is None or self._signed or not self._tail16_ok() or self.leaf_waves != 8:
-            return False
-        g = self._group_of_root[root]
-        if g.depth < 2 or not self._leaf_is_persistent(g, B) or B * 128 >= 2**31:
-            return False
-        folds = sum(self.layers[j].num_folds for j in self._tail)
-        cap = 48 + (((1 << g.depth) - 1) * 4096 - 8192) // 2048
-        return folds <= cap and folds * 80 + (len(self._tail) + 1) * 4 + 16 <= 8192
-
     def _direct_input(self, B: int) -> bool:
         """Whether a forward at batch size B needs no staged copy of the discrete batch: its only readers are persistent
         leaf launches, which then read -- and validate -- the caller's int64 tensor (`ck_leaf_walk_fwd` with x_input).
         Byte offsets into the batch are 32-bit."""
         if not (self.direct_input and self._int_input and self._groups):
             return False
-        if self.leaf_waves != 8 or self.plan.num_variables * B * 8 >= 2**32:
+        if self.plan.num_variables * B * 8 >= 2**32:
             return False
         for i, l in enumerate(self.layers):
             if i in self._virtual or (self._tail and i in self._tail):
@@ -581,7 +536,7 @@ class HipCircuit:
         self._recording = True
         try:
             if not self.cache_params:
-                self._enqueue_params(0, in_leaf=bd.params_in_leaf or bd.params_at_end)
+                self._enqueue_params(0, at_end=bd.params_at_end)
             self._enqueue_layers(bd, 0, with_ll=with_ll)
             if self.validate_inputs and self._int_input and not bd.direct and not self._poison_in_tail():
                 for p, f in self._out_pairs:  # (complex outputs: both halves of every element)
@@ -626,16 +581,16 @@ class HipCircuit:
         store's back (e.g. by an optimiser kernel writing through a raw pointer)."""
         self.store.touch()
 
-    def _enqueue_params(self, stream: int, *, in_leaf: bool = False) -> None:
+    def _enqueue_params(self, stream: int, *, at_end: bool = False) -> None:
         """Everything that depends on the parameters only (the reference re-evaluates the parameter
         graphs on every forward, parameters/parameter.py:180-188): the batched softmax prologue, the
         remaining parameter graphs, table re-layouts, and the dense layer pushed through the table.
-        `in_leaf`: the persistent leaf launch evaluates what `_plan_inlaunch_params` assigned to it; only the rest is
+        `at_end`: the tail launch of the PREVIOUS forward evaluated what `_plan_tail_params` assigned to it; only the rest is
         launched here."""
-        if in_leaf:
+        if at_end:
             self._ensure_param_batch()
-            if self._inlaunch["rest"] is not None:
-                self._inlaunch["rest"].launch(stream)
+            if self._tailp["rest"] is not None:
+                self._tailp["rest"].launch(stream)
         else:
             self._launch_param_batch(stream)
         for l in self.layers:
@@ -693,13 +648,13 @@ class HipCircuit:
         B = bd.B
         for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
             if self._tail and i in self._tail:
-                if i == self._tail[0] and not bd.tail_in_leaf:
+                if i == self._tail[0]:
                     self._launch_tail(bd, stream, with_ll=with_ll)
                 continue
             if i in self._virtual:
                 continue
             if i in self._group_of_root:
-                self._launch_group(self._group_of_root[i], bd, view, stream, with_ll=with_ll)
+                self._launch_group(self._group_of_root[i], bd, view, stream)
             elif i in self._tdense:
                 self._launch_table_dense(i, bd, stream)
             elif i in self._emb_gather:
@@ -857,10 +812,10 @@ class HipCircuit:
 
     def _enqueue_params_batch_only(self, stream: int, bd: _Binding) -> None:
         """The prologue launch of a forward of this binding (profiling): all jobs, or what the leaf launch leaves."""
-        if bd.params_in_leaf or bd.params_at_end:
+        if bd.params_at_end:
             self._ensure_param_batch()
-            if self._inlaunch["rest"] is not None:
-                self._inlaunch["rest"].launch(stream)
+            if self._tailp["rest"] is not None:
+                self._tailp["rest"].launch(stream)
         else:
             self._launch_param_batch(stream)
 
@@ -886,15 +841,15 @@ class HipCircuit:
                     n0 = len(self._batch._jobs)
                     l.register_batched(self._batch)
                     self._jobs_of_layer[i] = list(range(n0, len(self._batch._jobs)))
-            self._inlaunch = self._plan_inlaunch_params()
+            self._tailp = self._plan_tail_params()
             self._batch_version = self.store.version
 
-    def _plan_inlaunch_params(self) -> dict | None:
-        """Which jobs of the prologue the persistent leaf launch can take over (`inlaunch_params`): the table job of the
+    def _plan_tail_params(self) -> dict | None:
+        """Which jobs of the prologue the launch that walks the tail takes over (`params_at_end`): the table job of the
         (single) leaf group, the softmaxes of its level weights, and every other 32-wide softmax; what is left stays a
         (smaller, often empty) prologue launch.  None: nothing is taken over."""
-        if not ((self.inlaunch_params or self.params_at_end) and self.batch_params and not self.cache_params and self.contraction == "f32"
-                and len(self._groups) == 1 and not self._signed and self.leaf_waves == 8):
+        if not (self.params_at_end and self.batch_params and not self.cache_params and self.contraction == "f32"
+                and len(self._groups) == 1 and not self._signed):
             return None
         g = self._groups[0]
         cat = self.layers[g.input_layer]
@@ -925,31 +880,23 @@ class HipCircuit:
             for f in range(rows // per):
                 xjobs.append((src.data_ptr() + f * per * 128, dst.data_ptr() + f * per * 128, per, 1 if m["kind"] == 2 else 0))
             taken.add(k)
-        xj = np.zeros(max(1, len(xjobs)), dtype=np.dtype([("in", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("tiled", "<i4")]))
-        for r, t in zip(xj, xjobs):
-            r["in"], r["out"], r["rows"], r["tiled"] = t
+        job_t = np.dtype([("in", "<u8"), ("out", "<u8"), ("rows", "<i4"), ("tiled", "<i4")])
         rest = [k for k in range(len(meta)) if k not in taken]
         lv = []  # the level weights as 32-wide jobs too (for the launch that evaluates everything beside the tail)
         for j in g.levels:
             m = meta[self._jobs_of_layer[j][0]]
             for f in range(m["src"].shape[0]):
                 lv.append((m["src"].data_ptr() + f * 4096, m["dst"].data_ptr() + f * 4096, 32, 1))
-        xa = np.zeros(max(1, len(xjobs) + len(lv)), dtype=xj.dtype)
+        xa = np.zeros(max(1, len(xjobs) + len(lv)), dtype=job_t)
         for r, t in zip(xa, xjobs + lv):
             r["in"], r["out"], r["rows"], r["tiled"] = t
-        return {"root": g.root, "table": meta[table[0]], "levels": levels, "n_xjobs": len(xjobs),
+        return {"root": g.root, "table": meta[table[0]],
                 "rows_all": torch.from_numpy(xa.view(np.uint8)).to(self.device), "n_rows_all": len(xjobs) + len(lv),
-                "xjobs": torch.from_numpy(xj.view(np.uint8)).to(self.device), "rest": self._batch.subset(rest) if rest else None}
-
-    def _params_in_leaf(self, B: int) -> bool:
-        """Whether the leaf launch of a forward at batch size B evaluates the parameters (it is the persistent launch)."""
-        return (self.inlaunch_params and self._inlaunch is not None and self._leaf_is_persistent(self._groups[0], B)
-                and not self._tail_in_leaf(B))
+                "rest": self._batch.subset(rest) if rest else None}
 
     def _params_at_end(self, B: int) -> bool:
         """Whether the tail launch of a forward at batch size B also evaluates the parameters of the next forward."""
-        if not (self.params_at_end and self._inlaunch is not None and not self._params_in_leaf(B) and not self._tail_in_leaf(B)
-                and self._tail and self._tail16_ok() and not self._signed):
+        if not (self.params_at_end and self._tailp is not None and self._tail and self._tail16_ok() and not self._signed):
             return False
         n_slots = self._tail_slots()[2]
         return 8192 + n_slots * 2048 <= 80 * 1024 and sum(self.layers[j].num_folds for j in self._tail) * 80 + 64 <= 8192
@@ -1071,10 +1018,10 @@ class HipCircuit:
         ip = C.c_int32 * n
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
         if self._tail16_ok() and bd.params_at_end:
-            keep = self.keep_layer_outputs and not with_ll
+            keep = self.keep_layer_outputs and (not with_ll or self.keep_levels)  # (a training forward keeps them for the backward)
             desc_dev, levels_dev, n_folds, scratch, ticket, lay = self._tail16_tables(bd, keep=keep, slots=True)
             fuse_ll = with_ll and self._tail_fuses_ll()
-            il = self._inlaunch
+            il = self._tailp
             d = capi.TailParamsLaunch()
             d.folds, d.level_begin, d.n_folds, d.n_levels = desc_dev.data_ptr(), levels_dev.data_ptr(), n_folds, n
             d.n_slots, d.B, d.w_layout = self._tail_slots()[2], bd.B, lay
@@ -1096,7 +1043,7 @@ class HipCircuit:
         if self._tail16_ok():
             # `log_likelihood_sum` returns [sum, count] only: the tail's inner folds stay in LDS; `forward` keeps the layer
             # outputs (`layer_outputs()` reads them) unless the caller opted out
-            keep = self.keep_layer_outputs and not with_ll
+            keep = self.keep_layer_outputs and (not with_ll or self.keep_levels)  # (a training forward keeps them for the backward)
             desc_dev, levels_dev, n_folds, scratch, ticket, lay = self._tail16_tables(bd, keep=keep)
             fuse_ll = with_ll and self._tail_fuses_ll()
             capi.call(
@@ -1195,7 +1142,7 @@ class HipCircuit:
         cat = self.layers[g.input_layer]
         if (self.persistent_leaf is False or g.root not in self._table_fused or not self.linear_levels or g.depth < 1
                 or cat.num_output_units != 32 or cat.num_categories >= 65535
-                or self._group_layout(g) != capi.CK_W_TILED_F32 or self.plan.num_variables * B >= 2**31):
+                or self._group_layout(g) not in (capi.CK_W_TILED_F32, capi.CK_W_ROWMAJOR) or self.plan.num_variables * B >= 2**31):
             return False
         return self.persistent_leaf is True or self.layers[g.root].num_folds * ((B + 31) // 32) >= self._n_cu
 
@@ -1221,9 +1168,8 @@ class HipCircuit:
             self._leaf_walk_pairs = self._leaves_in_adjacent_pairs(g)
             self._leaf_walk(bd, table=table, scale=scale, scope=cat._scope(self.device), levels=levels, nodes=dev[0],
                             node_off=node_off, leaf_off=g.leaf_off, out=out, work=work, depth=g.depth,
-                            K=cat.num_output_units, Cn=cat.num_categories, w_layout=capi.CK_W_TILED_F32, redo=None,
-                            n_roots=F_root, waves=self.leaf_waves, stream=stream,
-                            tail=(bd.tail_in_leaf and g.root == self._tail_host_group()), with_ll=with_ll)
+                            K=cat.num_output_units, Cn=cat.num_categories, w_layout=self._group_layout(g), redo=None,
+                            n_roots=F_root, waves=8, stream=stream, keep=self._keep_buffers(g, bd))
             return
         capi.call(
             "ck_subtree_cat_cpt_fwd", table.data_ptr(), None if scale is None else scale.data_ptr(), bd.xt_i.data_ptr(),
@@ -1232,6 +1178,18 @@ class HipCircuit:
             out.data_ptr(), g.depth, self.layers[g.root].num_folds, bd.B, cat.num_output_units,
             cat.num_categories, self._group_layout(g), stream,
         )
+
+    def _keep_buffers(self, g: SubtreeGroup, bd: _Binding):
+        """`keep_levels`: ([(F_l, B, 32) per fused level], (F_root, tiles) int32 flags) of group g in this binding, else None."""
+        if not self.keep_levels:
+            return None
+        hit = bd.keep.get(g.root)
+        if hit is None:
+            tiles = (bd.B + 31) // 32
+            hit = bd.keep[g.root] = (
+                [torch.empty((self.layers[j].num_folds, bd.B, 32), dtype=torch.float32, device=self.device) for j in g.levels],
+                torch.zeros(self.layers[g.root].num_folds * tiles, dtype=torch.int32, device=self.device))
+        return hit
 
     def _launch_group_signed(self, g: SubtreeGroup, bd: _Binding, out: torch.Tensor, stream: int) -> None:
         """Embedding -> CP-T levels of a real-valued complex circuit: the persistent leaf launch on signed linear tiles
@@ -1296,7 +1254,7 @@ class HipCircuit:
         return hit
 
     def _leaf_walk(self, bd: _Binding, *, table, scale, scope, levels, nodes, node_off, leaf_off, out, work, depth, K, Cn,
-                   w_layout, redo, n_roots, waves, stream, tail: bool = False, with_ll: bool = False) -> None:
+                   w_layout, redo, n_roots, waves, stream, keep=None) -> None:
         """`ck_leaf_walk_fwd`: the persistent leaf launch over the staged batch or -- `bd.direct` -- over the caller's."""
         d = capi.LeafLaunch()
         d.table, d.table_scale, d.scope = table.data_ptr(), scale.data_ptr(), scope.data_ptr()
@@ -1312,38 +1270,11 @@ class HipCircuit:
             d.x_pairs = 1 if getattr(self, "_leaf_walk_pairs", False) else 0
         else:
             d.xt, d.preclamped, d.x_rows, d.x_input = bd.xt_i.data_ptr(), (1 if self._preclamp() else 0), None, -1
-        if bd.params_in_leaf and self._inlaunch is not None and self._inlaunch["root"] == getattr(self, "_leaf_walk_root", None):
-            il = self._inlaunch
-            d.cat_logits, d.dense_logits = il["table"]["src"].data_ptr(), il["table"]["dense"].data_ptr()
-            d.cat_idx = None if il["table"]["idx"] is None else il["table"]["idx"].data_ptr()
-            d.w_logits = (C.c_void_p * depth)(*[t.data_ptr() for t in il["levels"]])
-            groups = bd.cp_tabs.get("groot")
-            if groups is None:
-                segs = work.cpu().numpy()
-                n_wg = min(self._n_cu, segs.shape[0])
-                roots: list[list[int]] = [[] for _ in range(8)]
-                for sidx in range(segs.shape[0]):
-                    r, g8 = int(segs[sidx, 0]), (sidx % n_wg) % 8
-                    if r not in roots[g8]:
-                        roots[g8].append(r)
-                off = np.cumsum([0] + [len(r) for r in roots]).astype(np.int32)
-                flat = np.asarray([r for rs in roots for r in rs] or [0], dtype=np.int32)
-                groups = bd.cp_tabs["groot"] = (torch.from_numpy(off).to(self.device), torch.from_numpy(flat).to(self.device))
-            d.groot_off, d.groot = groups[0].data_ptr(), groups[1].data_ptr()
-            d.params_arrive = bd.params_sync.data_ptr()
-            d.xjobs, d.n_xjobs = il["xjobs"].data_ptr(), il["n_xjobs"]
-        if tail:  # the trailing levels inside this launch (leaf_tail_phase)
-            desc_dev, levels_dev, n_folds, scratch, ticket, lay = self._tail16_tables(bd)
-            fuse_ll = with_ll and self._tail_fuses_ll()
-            d.tail_folds, d.tail_level_begin, d.tail_n_folds, d.tail_n_levels = desc_dev.data_ptr(), levels_dev.data_ptr(), n_folds, len(self._tail)
-            d.tail_w_layout = lay
-            # the 32-unit fold outputs of the tail are layer outputs: stored for `forward` unless the caller opted out
-            d.tail_write = 1 if (self.keep_layer_outputs and not with_ll) else 0
-            d.tail_bad_input = self._bad_input.data_ptr() if (self._poison_in_tail() and not bd.direct) else None
-            d.ll = bd.ll.data_ptr() if fuse_ll else None
-            d.ll_partial = scratch.data_ptr() if fuse_ll else None
-            d.ll_ticket = ticket.data_ptr() if fuse_ll else None
-            d.tail_arrive, d.tail_state = bd.tail_sync[0].data_ptr(), bd.tail_sync[1].data_ptr()
+        if keep is not None:
+            if not bd.direct:
+                raise ValueError("keep_levels needs the leaf launch to read the caller's batch (direct_input)")
+            d.keep_levels = (C.c_void_p * depth)(*[t.data_ptr() for t in keep[0]])
+            d.keep_redo = keep[1].data_ptr()
         capi.call("ck_leaf_walk_fwd", C.byref(d), stream)
 
     # -- evaluation ------------------------------------------------------------------------------
@@ -1606,11 +1537,8 @@ class HipCircuit:
             if i in self._table_fused and self.linear_levels:
                 if self._leaf_is_persistent(g, B):
                     raw = "true" if self._direct_input(B) else "false"
-                    tail = "true" if (self._tail_in_leaf(B) and i == self._tail_host_group()) else "false"
-                    par = "true" if self._params_in_leaf(B) else "false"
-                    xp = "true" if (raw == "true" and tail == par == "false" and g.depth >= 2 and self.leaf_waves == 8
-                                    and self._leaves_in_adjacent_pairs(g)) else "false"
-                    return f"leaf_persistent_kernel<{g.depth}, {self.leaf_waves}, false, {raw}, {tail}, {par}, {xp}>"
+                    xp = "true" if (raw == "true" and g.depth >= 2 and self._leaves_in_adjacent_pairs(g)) else "false"
+                    return f"leaf_persistent_kernel<{g.depth}, 8, false, {raw}, {xp}, false>"
                 return f"subtree_linear_kernel<{g.depth}, {self._group_layout(g)}>"
             return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")
@@ -1712,7 +1640,7 @@ class HipCircuit:
                     self._group_table(self._group_of_root[i], stream)
                 e1.record(cur)
                 if in_tail:
-                    if i == self._tail[0] and not bd.tail_in_leaf:
+                    if i == self._tail[0]:
                         self._launch_tail(bd, stream)
                 elif i in self._virtual:
                     pass
@@ -1773,7 +1701,7 @@ class HipCircuit:
                         pbytes += per_fold * n.num_folds
             has_prep = bool(s.params) and not (self.batch_params and l._batched)
             if i == 0 and self.batch_params and self._batch is not None and len(self._batch) and not (
-                    (bd.params_in_leaf or bd.params_at_end) and self._inlaunch["rest"] is None):
+                    bd.params_at_end and self._tailp["rest"] is None):
                 rows.append({"layer": 0, "kernel": "softmax_batch_kernel<false>", "ms": float(mean[0]),
                              "algorithmic_bytes": float(2 * sum(
                                  int(np.prod(shp)) * 4 for shp, _ in self.plan.tensors.values()))})
@@ -1805,12 +1733,7 @@ class HipCircuit:
             if i in self._virtual:
                 continue
             if self._tail and i in self._tail:
-                if i == self._tail[-1] and bd.tail_in_leaf:  # walked by the leaf launch: its row stands for these layers too
-                    host = next(r for r in rows if r["layer"] == self._tail_host_group() and "executed_flops" in r)
-                    host["algorithmic_bytes"] += sum(layer_bytes[j] for j in self._tail)
-                    host["algorithmic_flops"] += sum(layer_flops[j] for j in self._tail)
-                    host["executed_flops"] += sum(layer_flops[j] for j in self._tail)
-                elif i == self._tail[-1]:
+                if i == self._tail[-1]:
                     tl = next((self.layers[j]._w_layout for j in self._tail
                                if self.layers[j].num_output_units == 32), 0)
                     rows.append({"layer": self._tail[0], "kernel": ("tail_params_kernel" if bd.params_at_end else f"tail16_kernel<{tl}, {'true' if self._signed else 'false'}>" if self._tail16_ok() else f"tail_kernel<{tl}>"),

@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(256)
 // Categorical backward: dtable[f, c, :] += sum over rows b with x[b] = c of gout[f, b, :].
 // One workgroup per fold accumulates a (C, K) histogram in LDS (ds_add_f32), then writes it once.
 __global__ void __launch_bounds__(256)
-    categorical_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ xt,
+    categorical_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ gfold, const int32_t* __restrict__ xt,
                            const int64_t* __restrict__ scope, float* __restrict__ dtable, int B, int K,
                            int C) {
   extern __shared__ __attribute__((aligned(16))) float hist[];  // [C+1][K] (row C: marginalised rows)
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256)
   for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) hist[i] = 0.f;
   __syncthreads();
   const int32_t* xrow = xt + scope[f] * static_cast<int64_t>(B);
-  const float* g = gout + static_cast<int64_t>(f) * B * K;
+  const float* g = gout + static_cast<int64_t>(gfold != nullptr ? gfold[f] : f) * B * K;
   if ((K & 3) == 0 && K <= 1024) {
     // float4 per lane, 4 independent rows per thread in flight (the loop is load-latency bound)
     const int kq = K >> 2;                    // float4 per row
@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(256)
 // flight to stream gout at HBM rate.  K must be a multiple of 32.
 constexpr int kCatChunk = 4096;  // rows sorted at a time
 __global__ void __launch_bounds__(1024)
-    categorical_bwd_sorted_kernel(const float* __restrict__ gout, const int32_t* __restrict__ xt,
+    categorical_bwd_sorted_kernel(const float* __restrict__ gout, const int32_t* __restrict__ gfold, const int32_t* __restrict__ xt,
                                   const int64_t* __restrict__ scope, float* __restrict__ dtable, int B, int K, int C) {
   extern __shared__ __attribute__((aligned(16))) float hist[];  // [C+1][K], then the int arrays below
   int* start = reinterpret_cast<int*>(hist + (C + 1) * K);      // [C+2] exclusive prefix of the counts
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(1024)
   const int k_in = lane & 31, slot = lane >> 5;
   for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) hist[i] = 0.f;
   const int32_t* xrow = xt + scope[f] * static_cast<int64_t>(B);
-  const float* g = gout + static_cast<int64_t>(f) * B * K;
+  const float* g = gout + static_cast<int64_t>(gfold != nullptr ? gfold[f] : f) * B * K;
   for (int b0 = 0; b0 < B; b0 += kCatChunk) {
     const int nb = min(kCatChunk, B - b0);
     for (int i = threadIdx.x; i < C + 2; i += blockDim.x) start[i] = 0;
@@ -1006,10 +1006,18 @@ __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, int64_
 }
 
 // Adam step (torch.optim.Adam defaults semantics, no weight decay / amsgrad), fused over one tensor.
+// skip_flag (nullable): nonzero = this step saw an invalid batch: parameters, moments and the step count stay as they are
+// (`skipped` counts such launches; the bias corrections use step - skipped).
 __global__ void __launch_bounds__(256)
     adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1,
-                float* __restrict__ m2, int64_t n, float lr, float b1, float b2, float eps, float bc1,
-                float bc2, float gscale) {
+                float* __restrict__ m2, int64_t n, float lr, float b1, float b2, float eps, int step,
+                float gscale, const int32_t* __restrict__ skip_flag, int32_t* __restrict__ skipped) {
+  if (skip_flag != nullptr && *skip_flag != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && skipped != nullptr) *skipped += 1;  // (no launch reads it while this one runs)
+    return;
+  }
+  const float t = static_cast<float>(step - (skipped != nullptr ? *skipped : 0));
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     const float gi = g[i] * gscale;
@@ -1022,10 +1030,19 @@ __global__ void __launch_bounds__(256)
 }
 
 __global__ void __launch_bounds__(256)
-    sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr, float gscale) {
+    sgd_kernel(float* __restrict__ p, const float* __restrict__ g, int64_t n, float lr, float gscale,
+               const int32_t* __restrict__ skip_flag) {
+  if (skip_flag != nullptr && *skip_flag != 0) return;
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x)
     p[i] -= lr * gscale * g[i];
+}
+
+__global__ void latch_flag_kernel(int32_t* __restrict__ src, int32_t* __restrict__ dst) {
+  if (*src != 0) {
+    *dst |= *src;
+    *src = 0;
+  }
 }
 
 bool g_bwd_force_generic = false;
@@ -1288,7 +1305,7 @@ int ck_hadamard_bwd(float* garena, const int64_t* row_off, const float* gout, in
       stream);
 }
 
-int ck_categorical_bwd(const float* gout, const int32_t* xt, const int64_t* scope, float* dtable, int F,
+int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* xt, const int64_t* scope, float* dtable, int F,
                        int B, int K, int C, void* stream) {
   CK_REQUIRE(gout && xt && scope && dtable, "ck_categorical_bwd: null pointer");
   CK_REQUIRE(F > 0 && B > 0 && K > 0 && C > 0, "ck_categorical_bwd: non-positive size");
@@ -1304,7 +1321,7 @@ int ck_categorical_bwd(const float* gout, const int32_t* xt, const int64_t* scop
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_sorted));
             if (e != hipSuccess) return e;
           }
-          hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds_sorted, s, gout, xt, scope, dtable, B, K, C);
+          hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds_sorted, s, gout, gfold, xt, scope, dtable, B, K, C);
           return hipGetLastError();
         },
         stream);
@@ -1317,7 +1334,7 @@ int ck_categorical_bwd(const float* gout, const int32_t* xt, const int64_t* scop
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
           if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(categorical_bwd_kernel, grid, block, lds, s, gout, xt, scope, dtable, B, K, C);
+        hipLaunchKernelGGL(categorical_bwd_kernel, grid, block, lds, s, gout, gfold, xt, scope, dtable, B, K, C);
         return hipGetLastError();
       },
       stream);
@@ -1357,27 +1374,36 @@ int ck_param_log_table_bwd(const float* table, const float* dtable, float* dthet
 }
 
 int ck_adam_step(float* p, const float* g, float* m1, float* m2, int64_t n, float lr, float beta1,
-                 float beta2, float eps, int step, float grad_scale, void* stream) {
+                 float beta2, float eps, int step, float grad_scale, const int32_t* skip_flag, int32_t* skipped,
+                 void* stream) {
   CK_REQUIRE(p && g && m1 && m2, "ck_adam_step: null pointer");
   CK_REQUIRE(n > 0 && step > 0, "ck_adam_step: n and step must be positive");
-  const float bc1 = 1.f - powf(beta1, static_cast<float>(step));
-  const float bc2 = 1.f - powf(beta2, static_cast<float>(step));
   dim3 grid(grid1(n)), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(adam_kernel, grid, block, 0, s, p, g, m1, m2, n, lr, beta1, beta2, eps, bc1, bc2, grad_scale);
+        hipLaunchKernelGGL(adam_kernel, grid, block, 0, s, p, g, m1, m2, n, lr, beta1, beta2, eps, step, grad_scale, skip_flag, skipped);
         return hipGetLastError();
       },
       stream);
 }
 
-int ck_sgd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, void* stream) {
+int ck_sgd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, const int32_t* skip_flag, void* stream) {
   CK_REQUIRE(p && g, "ck_sgd_step: null pointer");
   CK_REQUIRE(n > 0, "ck_sgd_step: n must be positive");
   dim3 grid(grid1(n)), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(sgd_kernel, grid, block, 0, s, p, g, n, lr, grad_scale);
+        hipLaunchKernelGGL(sgd_kernel, grid, block, 0, s, p, g, n, lr, grad_scale, skip_flag);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_latch_flag(int32_t* src, int32_t* dst, void* stream) {
+  CK_REQUIRE(src && dst, "ck_latch_flag: null pointer");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(latch_flag_kernel, dim3(1), dim3(1), 0, s, src, dst);
         return hipGetLastError();
       },
       stream);

@@ -23,10 +23,7 @@
 #include <utility>
 
 #include "ck_internal.h"
-#include "ck_softmax.h"
 #include "ck_tile.h"
-#include "ck_tile16.h"
-#include "ck_tailwalk.h"
 
 namespace {
 
@@ -46,235 +43,47 @@ struct LeafArgs {
   const int32_t* work;  // (n_seg, 4): root fold, first tile, end tile, 0
   int n_seg, B, C;
   int preclamped;  // xt holds -1 .. C - 1 only
-  int32_t* redo;   // SIGNED: (F_root, tiles) flags of the tiles to evaluate again in log space (leaf_signed_redo_kernel)
+  int32_t* redo;   // SIGNED: (F_root, tiles) flags of the tiles to evaluate again in log space (leaf_signed_redo_kernel); KEEP: see below
   int w_rowmajor;  // the level weights are row-major (F_l, 32, 32) matrices instead of CK_W_TILED_F32
   // XRAW: the batch as the caller holds it, (B, D) int64 row-major -- no staging launch in front of this one
   const int64_t* x64;
   int D;
   int32_t* bad_flag;  // XRAW: raised (atomicOr 1) when a row holds an illegal value; nullptr = rows are not checked
   int x_pairs;        // XRAW: leaves 2j, 2j + 1 of every root read adjacent, 16-byte aligned variables (one load per pair)
+  // KEEP (training forward): the linear tile of every node is stored as well -- keep[l - 1]: (F_l, B, 32), the value the NEXT
+  // level multiplies (the backward, ck_leaf_bwd.hip, needs a level's tiles to be consistent with each other, not their log
+  // scales); tiles whose walk left the linear range are marked in `redo` (their kept tiles mean nothing)
+  float* keep[kMaxDepthP];
+#ifdef CK_LEAF_STAMPS
+  int stamp_wg, stamp_tile;
+#endif
   const int32_t* root_tab;  // nullptr, or (F_root, 3 * 2^D): per root the variable and the table fold of every leaf and the folds
                             // of its 2^D - 1 nodes in step order -- what the start of a segment otherwise collects from `nodes`,
                             // `scope` and the level tables in three dependent rounds of loads
-  // TAIL: the trailing few-fold levels (ck_tail16.hip's walk) inside this launch -- see leaf_tail_phase
-  const TailFold* tail_folds;    // (tail_n_folds) in level order
-  const int32_t* tail_level_begin;  // (tail_n_levels + 1)
-  int tail_n_folds, tail_n_levels;
-  int tail_write;                // the 32-unit fold outputs of the tail are layer outputs somebody reads: store them too
-  int tail_w_rowmajor;           // layout of the 32-output tail weights (else CK_W_TILED_F32)
-  const int32_t* tail_bad_input; // staged batch: ck_stage_categories' sticky flag -> NaN circuit outputs (nullptr: none)
-  double* ll;                    // nullptr, or [sum_b log p, B]
-  double* ll_partial;            // (ceil(B / 16))
-  unsigned int* ll_ticket;
-  unsigned long long* arrive;    // monotonic arrival counter of the launches of this binding
-  unsigned int* tail_state;      // (ceil(B / 16)) epoch in which each 16-row tile was last claimed
-  // PARAMS: the launch evaluates the parameters it reads -- see leaf_params_phase
-  const float* cat_logits;       // (F_cat, 32, C) logits of the Categorical layer
-  const int64_t* cat_idx;        // (F0) Categorical fold of each table (dense) fold, or nullptr: the identity
-  const float* dense_logits;     // (F0, 32, 32) logits of the dense layer pushed through the table
-  const float* wraw[kMaxDepthP]; // wraw[l-1]: (F_l, 32, 32) logits of the weights of CP-T level l
-  const int32_t* groot_off;      // (9): roots whose tables the workgroups b with b % 8 == g build are groot[groot_off[g] .. groot_off[g + 1])
-  const int32_t* groot;
-  unsigned long long* parrive;   // 8 arrival counters, 16 words apart
-  const ck_rows32_job* xjobs;    // other 32-wide softmaxes (weights of the layers behind this launch)
-  int n_xjobs;
 };
-
-// ---- the tail of the circuit inside the leaf launch -------------------------------------------------------------------
-// The trailing few-fold levels (24, 11, 6, 4, 2, 1 folds at the north-star configuration) are a chain of tiny dependent
-// steps; as a launch of their own (ck_tail16.hip) they cost a launch boundary, the start-up of 256 new workgroups, and
-// a round trip through HBM for the roots -- 22 us behind a 70 us leaf launch.  Here the resident workgroups of the leaf
-// launch walk them after their segments:
-//   * root tiles are stored write-through (tile_store_wt), so a workgroup's roots are at the memory side when its
-//     stores have completed; it then arrives on a monotonic counter (one 8-byte agent-scope atomic per workgroup);
-//   * a workgroup waits until every workgroup of the launch has arrived (the roots of a row come from every workgroup),
-//     then claims 16-row tiles of the batch -- its own first (tile = workgroup index), by an epoch compare-and-swap -- and
-//     walks each exactly as tail16_kernel does: fold outputs of the tail stay in LDS (the leaf walk's 156 KB are free),
-//     children produced by the leaf walk are read past the caches (load4_wt), the log-likelihood sum is folded in;
-//   * NOTHING depends on all workgroups being resident at once: a workgroup that has waited 200 us -- another launch holds
-//     compute units this one needs -- leaves without claiming; whoever passes the wait later finds its tiles unclaimed in
-//     the sweep that follows its own tiles and walks them.
-// Same arithmetic per fold as tail16_kernel (the fold -> wave assignment differs, the values do not).
-constexpr unsigned long long kTailTimeoutTicks = 20000;  // wall_clock64 runs at 100 MHz: 200 us
-
-template <int WAVES>
-__device__ __forceinline__ void leaf_tail_phase(const LeafArgs& a, float* slots, int n_main, float* wbuf) {
-  const int n_tiles = (a.B + 15) >> 4;
-  const TailTiles tiles{slots, wbuf + kTailCtlFloats, n_main};
-  TailFold* s_fold = reinterpret_cast<TailFold*>(wbuf);
-  int32_t* s_level = reinterpret_cast<int32_t*>(s_fold + a.tail_n_folds);
-  unsigned int* s_ctl = reinterpret_cast<unsigned int*>(s_level + a.tail_n_levels + 1);
-  // this workgroup's roots: once the write-through stores have completed they are at the memory side
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // (every wave has left the walk: its LDS is free)
-  if (threadIdx.x == 0) {
-    const unsigned long long n = gridDim.x;
-    const unsigned long long old = __hip_atomic_fetch_add(a.arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_ctl[0] = static_cast<unsigned int>(old / n + 1);  // the epoch of this launch
-    s_ctl[2] = static_cast<unsigned int>(n - 1 - old % n);  // arrivals still missing (as of this one)
-  }
-  {  // fold descriptors and level table -> LDS while the others arrive
-    const int n16 = a.tail_n_folds * static_cast<int>(sizeof(TailFold) / 16);
-    const int4* src = reinterpret_cast<const int4*>(a.tail_folds);
-    int4* dst = reinterpret_cast<int4*>(s_fold);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
-    for (int i = threadIdx.x; i <= a.tail_n_levels; i += blockDim.x) s_level[i] = a.tail_level_begin[i];
-  }
-  __syncthreads();
-  const unsigned int epoch = s_ctl[0];
-  if (threadIdx.x == 0) {
-    const unsigned long long target = static_cast<unsigned long long>(epoch) * gridDim.x;
-    const unsigned long long t0 = wall_clock64();
-    unsigned int ok = 1;
-    if (s_ctl[2] != 0)
-      while (__hip_atomic_load(a.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > kTailTimeoutTicks) {
-          ok = 0;
-          break;
-        }
-      }
-    s_ctl[1] = ok;
-  }
-  __syncthreads();
-  if (s_ctl[1] == 0) return;  // gave up waiting: the tiles of this workgroup are left to the sweep of those that pass
-  const bool poison = a.tail_bad_input != nullptr && *a.tail_bad_input != 0;
-  TailWalkArgs wa{};
-  wa.B = a.B;
-  wa.n_levels = a.tail_n_levels;
-  wa.n_folds = a.tail_n_folds;
-  wa.w_rowmajor = a.tail_w_rowmajor;
-  wa.write = a.tail_write;
-  wa.ll = a.ll;
-  wa.ll_partial = a.ll_partial;
-  wa.ll_ticket = a.ll_ticket;
-  auto claim = [&](int tile) -> bool {  // exactly one workgroup of the launch walks a tile
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned int expected = epoch - 1;
-      s_ctl[3] = __hip_atomic_compare_exchange_strong(a.tail_state + tile, &expected, epoch, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
-    }
-    __syncthreads();
-    return s_ctl[3] != 0;
-  };
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
-    if (claim(tile)) tail_walk<WAVES, true>(wa, tile, tiles, s_fold, s_level, poison, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), WorkgroupBarrier{});
-  // sweep: tiles whose workgroup left without claiming them (never, unless launches compete for compute units)
-  for (int base = 0; base < n_tiles; base += static_cast<int>(blockDim.x)) {
-    const int tl = base + static_cast<int>(threadIdx.x);
-    const int open = tl < n_tiles && __hip_atomic_load(a.tail_state + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch - 1;
-    if (__syncthreads_or(open)) {
-      const int end = min(n_tiles, base + static_cast<int>(blockDim.x));
-      for (int t2 = base; t2 < end; ++t2)
-        if (claim(t2)) tail_walk<WAVES, true>(wa, t2, tiles, s_fold, s_level, poison, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), WorkgroupBarrier{});
-    }
-  }
-}
-
-// ---- the parameters of the launch, evaluated by the launch ------------------------------------------------------------
-// The reference re-evaluates every parameter graph on every forward (parameters/parameter.py:180-188); as a launch of its
-// own (ck_param_softmax_batch) that is 21 us in front of a 70 us leaf launch at the north-star configuration -- 784
-// table jobs that all load, then all compute, then all store -- although it is ~6 us of work per compute unit.  PARAMS:
-//   * the 8 waves of a workgroup run TWO table jobs at a time (ck_softmax.h: the Categorical log-table of a leaf pushed
-//     through its dense fold, 4 waves each, tiles in the gather slots that the walk does not need yet); the workgroups
-//     b with b % 8 == g (one XCD, as workgroups are placed today -- nothing depends on it) share out the tables of the
-//     roots that any of them walks (groot), 3-4 jobs each; the table rows are stored write-through;
-//   * they then meet on an arrival counter of their own (32 pollers on one line, not 256).  A workgroup that has waited
-//     200 us builds every table of its class itself: the jobs are idempotent -- whoever runs them writes the same bits --
-//     so no workgroup ever depends on another one being resident;
-//   * the 2^D - 1 weight matrices of a segment's root are softmaxed from their logits straight into the LDS layout the
-//     walk reads (no tiled copy in memory, no DMA), and the 32-wide softmaxes of the layers BEHIND this launch (xjobs:
-//     the weights the tail launch reads) are dealt to the workgroups, one matrix each.
-// Same functions, same arithmetic as the prologue launch: bit-identical tables, weights and outputs.
-constexpr unsigned long long kParamsTimeoutTicks = 20000;  // wall_clock64 at 100 MHz: 200 us
-
-template <int D, int WAVES>
-__device__ __forceinline__ void leaf_params_phase(const LeafArgs& a, float* slots) {
-  static_assert(WAVES == 8, "two table jobs of four waves each");
-  constexpr int kLeaves = 1 << D;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int half = wave >> 2, w4 = wave & 3, kh = lane >> 5;
-  const int C = a.C;
-  float* tile = slots + half * (32 * (C + 4) + 1024);
-  float* const table_w = const_cast<float*>(a.table);
-  float* const scale_w = const_cast<float*>(a.scale);
-  const int grp = blockIdx.x & 7, rank = blockIdx.x >> 3;
-  const int gsize = (static_cast<int>(gridDim.x) - grp + 7) >> 3;  // workgroups of this class
-  const int r0 = a.groot_off[grp], n_jobs = (a.groot_off[grp + 1] - r0) * kLeaves;
-  auto sync = [] { __syncthreads(); };
-  auto run_jobs = [&](int first, int stride) {
-    for (int j0 = first; j0 < n_jobs; j0 += stride) {
-      const int j = j0 + half;
-      const float *theta = nullptr, *theta_w = nullptr;
-      int d = 0;
-      if (j < n_jobs) {
-        const int root = a.groot[r0 + j / kLeaves];
-        d = a.nodes[a.node_off[0] + root * kLeaves + j % kLeaves];
-        const int64_t f = a.cat_idx != nullptr ? a.cat_idx[d] : d;
-        theta = a.cat_logits + f * 32 * C;
-        theta_w = a.dense_logits + static_cast<int64_t>(d) * 1024;
-      }
-      const __amdgpu_buffer_rsrc_t rt = wt_buffer(table_w + static_cast<int64_t>(d) * (C + 1) * 32);
-      const __amdgpu_buffer_rsrc_t rs = wt_buffer(scale_w + static_cast<int64_t>(d) * (C + 1));
-      table_dense_rows<4, true>(theta, theta_w, C, tile, w4, lane, sync, [&](int c, const float (&v)[16], float m) {
-        if (c <= C) {
-          if (kh == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rs, static_cast<uint32_t>(c) * 4u, 0, kAuxWriteThrough);
-          const uint32_t off = static_cast<uint32_t>(c * 32 + 4 * kh) * 4u;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) store4_wt(rt, off + 32 * g, v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-        }
-      });
-      __syncthreads();  // (the tiles are free for the next pair of jobs)
-    }
-  };
-  run_jobs(rank * 2, gsize * 2);
-  // 32-wide softmaxes of other layers: one (rows <= 32, 32) block per workgroup turn, two rows per wave pass
-  for (int x = blockIdx.x; x < a.n_xjobs; x += gridDim.x) {
-    const ck_rows32_job xj = a.xjobs[x];
-    softmax_rows32<2>(xj.in, xj.rows, wave, 8, lane, [&](int row, int l, float p) { xj.out[w32_index(row, l, xj.tiled != 0)] = p; });
-  }
-  // this workgroup's tables are at the memory side once its write-through stores have completed: arrive, wait for the class
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  __shared__ unsigned int s_alone;
-  if (threadIdx.x == 0) {
-    unsigned long long* ctr = a.parrive + grp * 16;
-    const unsigned long long n = static_cast<unsigned long long>(gsize);
-    const unsigned long long old = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long target = (old / n + 1) * n;
-    const unsigned long long t0 = wall_clock64();
-    unsigned int alone = 0;
-    if (old + 1 < target)
-      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > kParamsTimeoutTicks) {
-          alone = 1;
-          break;
-        }
-      }
-    s_alone = alone;
-  }
-  __syncthreads();
-  if (s_alone != 0) {  // (never, unless launches compete for compute units) every table of the class, here
-    run_jobs(0, 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-}
 
 // XRAW: the categories are read from the caller's (B, D) int64 batch directly (a.x64), one tile ahead; the staging launch
 // (25.7 MB read + 12.9 MB written + a launch boundary per forward at the north-star configuration) disappears.  A tile
 // reads 4 x 32 bytes of each of its 32 batch rows when the root covers a 4 x 4 pixel block (QuadTree): whole sectors.
-// TAIL: the trailing levels of the circuit are walked by this launch too (leaf_tail_phase above): root tiles are then
-// stored write-through.
-// PARAMS: tables and weights are evaluated by this launch from the raw parameters (leaf_params_phase above).
 // XP: (XRAW) leaves 2j, 2j + 1 of every root read adjacent, 16-byte aligned variables (LeafArgs::x_pairs) -- a template
 // parameter, not a branch: with two load sequences of different lengths behind a run-time test the compiler's wait-count
 // pass gives up counting and waits for EVERYTHING in flight (vmcnt(0)) where the batch values are packed, in every tile.
-template <int D, int WAVES, bool SIGNED, bool XRAW, bool TAIL = false, bool PARAMS = false, bool XP = false>
+// KEEP: the training forward (LeafArgs::keep).  Its stores sit between the gathers of the walk: vector-memory operations of
+// a wave complete in the order they were issued (loads and stores share vmcnt on gfx9: the compiler's own wait counts rely
+// on it), so the explicit vmcnt(N) in front of a slot read counts the stores issued since that slot's request as well.
+__host__ __device__ constexpr int keep_stores_pipe(int i) {  // pair walk: between the request of leaf i >= 3 and its slot read
+  int n = 0;
+  for (int q = (i - 3) >> 1; q < (i >> 1); ++q) n += steps_after(2 * q + 1);
+  return 4 * n;
+}
+__host__ __device__ constexpr int keep_stores_plain(int i, int slots) {  // leaf-by-leaf walk: leaf i >= slots
+  int n = 0;
+  for (int m = i - slots; m < i; ++m) n += steps_after(m);
+  return 4 * n;
+}
+template <int D, int WAVES, bool SIGNED, bool XRAW, bool XP = false, bool KEEP = false>
 __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafArgs a) {
+  static_assert(!KEEP || (!SIGNED && WAVES == 8), "the training forward walks unsigned values with 8 waves");
   constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2) ? 3 : 2;
   // (two arrays, not one: with the gather slots at a constant offset inside a single array their addresses became
   // values in scalar registers -- 110 spilled instead of 36)
@@ -291,9 +100,9 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
   // CK_LEAF_STAMPS (scripts/leaf_stamps.py builds a copy of the library with it; never defined in the product): shader-clock
   // stamps of one tile of every wave of one workgroup -- where the instruction stream of a wave is when.  Stamp 3i: leaf i
   // begins; 3i + 1: its rows are in registers; 3i + 2: the request of leaf i + 3 is out; 48: the root's chain is issued;
-  // 49: the tile is stored.  The workgroup is a.n_xjobs, the tile of each wave its a.tail_write-th; buffer: a.redo.
+  // 49: the tile is stored.  The workgroup is a.stamp_wg, the tile of each wave its a.stamp_tile-th; buffer: a.redo.
 #ifdef CK_LEAF_STAMPS
-  constexpr bool kStamps = XP && !TAIL && !PARAMS && WAVES == 8;  // (the others have no LDS to spare)
+  constexpr bool kStamps = XP && WAVES == 8;  // (the others have no LDS to spare)
   __shared__ long long s_stamps[kStamps ? WAVES : 1][kStamps ? 64 : 1];
   bool stamp_on = false;
 #define CK_STAMP(id)                               \
@@ -326,8 +135,6 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
   uint32_t g_coff[2];  // (the table is smaller than 4 GB: checked on the host)
 #pragma unroll
   for (int q = 0; q < 2; ++q) g_coff[q] = ((lane & 7) ^ ((4 * q + (lane >> 4)) & 7)) * 16;
-
-  if constexpr (PARAMS) leaf_params_phase<D, WAVES>(a, g_lds);
 
   for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
     const int t = a.work[4 * seg], tile_begin = a.work[4 * seg + 1], tile_end = a.work[4 * seg + 2];
@@ -370,17 +177,13 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     }
 #pragma unroll
     for (int k = 0; k < kNodes; ++k) asm volatile("" : "+v"(node_fold[k]));  // (loaded here, not sunk to the uses)
+    float* keep_base[KEEP ? kNodes : 1];  // KEEP: block of each node of this root in its level's (F_l, B, 32) array
     static_for<0, kLeaves>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       static_for<0, steps_after(i)>([&](auto lc) {
         constexpr int l = decltype(lc)::value, k = steps_before(i) + l;
         const int fold = __builtin_amdgcn_readfirstlane(node_fold[k]);
-        if constexpr (PARAMS) {
-          // softmax of the fold's (32, 32) logits straight into the walk's LDS layout: rows 2 * wave + half and + 16 of it
-          softmax_rows32<2>(a.wraw[l] + static_cast<int64_t>(fold) * 1024, 32, wave, WAVES, lane,
-                            [&](int row, int ll, float p) { w_lds[k * 1024 + w32_index(row, ll, true)] = p; });
-          return;
-        }
+        if constexpr (KEEP) keep_base[k] = a.keep[l] + static_cast<int64_t>(fold) * a.B * kK;
         // lane's 16 bytes of chunk q: tiled, dword 256 q + 4 lane; row-major, W[lane & 31][8 q + 4 (lane >> 5) ..] (ck_tile.h)
         const float* src = a.w[l] + static_cast<int64_t>(fold) * 1024 + (a.w_rowmajor ? (lane & 31) * 32 + 4 * (lane >> 5) : lane * 4);
         const int qstride = a.w_rowmajor ? 8 : 256;
@@ -603,11 +406,12 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     for (; tile < chunk_end; tile += WAVES, ++nth, bad_cur = bad_next) {
       const int b = tile * 32 + b_in;
       const bool live = b < a.B;
+      const int koff = b * kK + 4 * kh;  // (KEEP) this lane's part of a node's (B, 32) block
       float stack[D][16], sstack[D];
       float cur[16], cs = 0.f, sprev = 0.f;
       bool bad = false;
 #ifdef CK_LEAF_STAMPS
-      stamp_on = static_cast<int>(blockIdx.x) == a.n_xjobs && nth == a.tail_write;
+      stamp_on = static_cast<int>(blockIdx.x) == a.stamp_wg && nth == a.stamp_tile;
 #endif
       constexpr int kXLoads = XRAW ? (XP ? kLeaves / 4 : kLeaves / 2) : kLeaves;  // (exactly: XP is a template parameter)
       if constexpr (kPipe) {
@@ -621,7 +425,8 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             CK_STAMP(3 * i);
             // younger than the request of leaf i: those of the next two leaves and, between the requests of leaves 4 and 5
             // (the VALU block of leaf 1), the batch values of the wave's next tile
-            constexpr int kYounger = 5 * (kLeaves - 1 - i < 2 ? kLeaves - 1 - i : 2) + (i >= 2 && i <= 4 ? kXLoads : 0);
+            constexpr int kYounger = 5 * (kLeaves - 1 - i < 2 ? kLeaves - 1 - i : 2) + (i >= 2 && i <= 4 ? kXLoads : 0) +
+                                     (KEEP && i >= 3 ? keep_stores_pipe(i) : 0);
             f32x4 r0, r1, r2, r3;
             if constexpr (h == 1) {  // (the weights of the pair's first contraction with the slot reads: one LDS round trip)
 #pragma unroll
@@ -678,6 +483,9 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             }
             __builtin_amdgcn_sched_barrier(0);
             contract_linear<CK_W_TILED_F32>(wcur, cur);
+            if constexpr (KEEP) {
+              if (live) tile_store(keep_base[step] + koff, cur);
+            }
           });
           if constexpr (steps_after(o) < D) {  // left sibling at this level: wait for the right one
             constexpr int l = steps_after(o);
@@ -696,7 +504,8 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         // longer; the previous tile's output stores, younger than its successor's first requests, are not counted for the
         // same reason).  Read the slot into the operand layout; the reads have returned before the slot is refilled
         f32x4 r0, r1, r2, r3;
-        constexpr int kYounger = 5 * (kLeaves - 1 - i < kSlots - 1 ? kLeaves - 1 - i : kSlots - 1) + (i >= 1 && i < kSlots ? kXLoads : 0);
+        constexpr int kYounger = 5 * (kLeaves - 1 - i < kSlots - 1 ? kLeaves - 1 - i : kSlots - 1) + (i >= 1 && i < kSlots ? kXLoads : 0) +
+                                 (KEEP && i >= kSlots ? keep_stores_plain(i, kSlots) : 0);
         // (the weights of the leaf's first contraction are requested in front of the slot reads: one LDS round trip for both)
         WRegs wfirst;
         if constexpr (steps_after(i) > 0) {
@@ -755,6 +564,9 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           // v_pk_mul_f32 that follows an MFMA back into two multiplies)
           __builtin_amdgcn_sched_barrier(0);
           contract_linear<CK_W_TILED_F32>(wcur, cur);
+          if constexpr (KEEP) {
+            if (live) tile_store(keep_base[step] + koff, cur);
+          }
         });
         if constexpr (steps_after(i) < D) {  // left sibling at this level: wait for the right one
           constexpr int l = steps_after(i);
@@ -772,6 +584,9 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           if (lane == 0) a.redo[static_cast<int64_t>(t) * ((a.B + 31) >> 5) + tile] = 1;
         } else {
           bad_tiles |= uint64_t{1} << nth;
+          if constexpr (KEEP) {
+            if (lane == 0) a.redo[static_cast<int64_t>(t) * ((a.B + 31) >> 5) + tile] = 1;
+          }
         }
       } else if (live) {
         if constexpr (XRAW) {
@@ -792,8 +607,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j) cur[j] = fmaf(__builtin_amdgcn_logf(cur[j]), kLN2, cs);
-          if constexpr (TAIL) tile_store_wt(a.out + static_cast<int64_t>(t) * a.B * kK, static_cast<uint32_t>(b * kK + 4 * kh) * 4u, cur);
-          else tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
+          tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, cur);
         }
       }
       CK_STAMP(49);
@@ -832,22 +646,17 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           }
         }
         if (b < a.B) {
-          if constexpr (TAIL) tile_store_wt(a.out + static_cast<int64_t>(t) * a.B * kK, static_cast<uint32_t>(b * kK + 4 * kh) * 4u, fb);
-          else tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
+          tile_store(a.out + (static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh, fb);
         }
       }
     }
     }  // chunk
     CK_WG_STAMP(2);
   }
-  if constexpr (TAIL) {
-    static_assert(!SIGNED, "the in-launch tail walks unsigned values");
-    leaf_tail_phase<WAVES>(a, g_lds, WAVES * kSlots * 2, w_lds);
-  }
 #ifdef CK_LEAF_STAMPS
   __syncthreads();
   CK_WG_STAMP(3);
-  if (kStamps && static_cast<int>(blockIdx.x) == a.n_xjobs && a.redo != nullptr)
+  if (kStamps && static_cast<int>(blockIdx.x) == a.stamp_wg && a.redo != nullptr)
     for (int i = threadIdx.x; i < WAVES * 64; i += blockDim.x) reinterpret_cast<long long*>(a.redo)[i] = s_stamps[i >> 6][i & 63];
 #endif
 #undef CK_STAMP
@@ -889,25 +698,28 @@ __global__ void __launch_bounds__(64) leaf_signed_redo_kernel(const LeafArgs a) 
 
 template <int D, bool XRAW>
 hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_roots, dim3 grid, hipStream_t s) {
-  if (a.cat_logits != nullptr) {  // (checked by the caller: unsigned, 8 waves, no in-launch tail)
-    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, XRAW, false, true>), grid, dim3(512), 0, s, a);
-    return hipGetLastError();
-  }
-  if (a.tail_folds != nullptr) {  // (checked by the caller: unsigned, 8 waves)
-    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, XRAW, true>), grid, dim3(512), 0, s, a);
-    return hipGetLastError();
+  if (a.keep[0] != nullptr) {  // (checked by the caller: raw input, unsigned, 8 waves)
+    if constexpr (XRAW) {
+      if constexpr (D >= 2) {
+        if (a.x_pairs) {
+          hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, true, true>), grid, dim3(512), 0, s, a);
+          return hipGetLastError();
+        }
+      }
+      hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, false, true>), grid, dim3(512), 0, s, a);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
   }
   if (is_signed) {
     hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true, XRAW>), grid, dim3(512), 0, s, a);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     hipLaunchKernelGGL((leaf_signed_redo_kernel<D>), dim3((a.B + 31) / 32, n_roots), dim3(64), 0, s, a);
-  } else if (waves == 12) {
-    if constexpr (XRAW) return hipErrorInvalidValue;  // (checked by the caller: 12 waves read the staged batch only)
-    else hipLaunchKernelGGL((leaf_persistent_kernel<D, 12, false, false>), grid, dim3(768), 0, s, a);
   } else {
     if constexpr (XRAW && D >= 2) {
       if (a.x_pairs) {
-        hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, false, false, true>), grid, dim3(512), 0, s, a);
+        hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, true>), grid, dim3(512), 0, s, a);
         return hipGetLastError();
       }
     }
@@ -942,7 +754,7 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
   CK_REQUIRE(raw != (d->xt != nullptr), "ck_leaf_walk_fwd: give either the staged batch xt or the raw batch (x_rows / x_input)");
   CK_REQUIRE(d->depth >= 1 && d->depth <= kMaxDepthP, "ck_leaf_walk_fwd: depth %d outside [1, %d]", d->depth, kMaxDepthP);
   CK_REQUIRE(d->n_seg > 0 && d->n_wg > 0 && d->B > 0 && d->C > 0, "ck_leaf_walk_fwd: non-positive size");
-  CK_REQUIRE(d->waves == 8 || d->waves == 12, "ck_leaf_walk_fwd: waves must be 8 or 12 (got %d)", d->waves);
+  CK_REQUIRE(d->waves == 8, "ck_leaf_walk_fwd: waves must be 8 (got %d)", d->waves);
   if (d->K != kK) return ck::fail(CK_ERR_UNSUPPORTED, "ck_leaf_walk_fwd: K=%d (only K=32 is fused)", d->K);
   CK_REQUIRE(ck::aligned16(d->table) && ck::aligned16(d->out), "ck_leaf_walk_fwd: buffers must be 16-byte aligned");
   LeafArgs a{};
@@ -951,7 +763,7 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
   a.xt = d->xt;
   a.scope = d->scope;
   for (int l = 0; l < d->depth; ++l) {
-    CK_REQUIRE(d->cat_logits != nullptr || (d->w_levels[l] != nullptr && ck::aligned16(d->w_levels[l])), "ck_leaf_walk_fwd: bad weights of level %d", l + 1);
+    CK_REQUIRE(d->w_levels[l] != nullptr && ck::aligned16(d->w_levels[l]), "ck_leaf_walk_fwd: bad weights of level %d", l + 1);
     a.w[l] = d->w_levels[l];
   }
   a.nodes = d->nodes;
@@ -984,60 +796,22 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
                                   "thread (or the index is out of range)", d->x_input);
     }
   }
-  if (d->tail_folds != nullptr) {
-    CK_REQUIRE(d->waves == 8 && d->signed_redo == nullptr, "ck_leaf_walk_fwd: the in-launch tail needs 8 waves and unsigned values");
-    CK_REQUIRE(d->tail_level_begin && d->tail_arrive && d->tail_state, "ck_leaf_walk_fwd: tail needs level_begin, arrive and state");
-    CK_REQUIRE(d->tail_n_folds > 0 && d->tail_n_levels > 0 && d->tail_n_levels <= 15, "ck_leaf_walk_fwd: bad tail sizes");
-    CK_REQUIRE(static_cast<int64_t>(d->B) * kK * 4 < (int64_t{1} << 31), "ck_leaf_walk_fwd: B=%d rows exceed the 32-bit offsets of the in-launch tail", d->B);
-    CK_REQUIRE(ck::aligned16(d->tail_folds), "ck_leaf_walk_fwd: tail_folds not 16-byte aligned");
-    CK_REQUIRE(d->ll == nullptr || (d->ll_partial != nullptr && d->ll_ticket != nullptr), "ck_leaf_walk_fwd: ll needs ll_partial and ll_ticket");
-    CK_REQUIRE(d->tail_w_layout == CK_W_TILED_F32 || d->tail_w_layout == CK_W_ROWMAJOR, "ck_leaf_walk_fwd: tail weights must be CK_W_TILED_F32 or row-major");
-    // LDS of the tail phase (leaf_tail_phase): fold tiles in the gather slots and behind the control block of the weight array
-    CK_REQUIRE(d->depth >= 2, "ck_leaf_walk_fwd: the in-launch tail needs a fused depth of at least 2 (its control block lives in the weight array)");
-    const size_t ctl = static_cast<size_t>(d->tail_n_folds) * sizeof(TailFold) + (d->tail_n_levels + 1) * sizeof(int32_t) + 16;
-    const int cap = 8 * 3 * 2 + (((1 << d->depth) - 1) * 4096 - kTailCtlFloats * 4) / 2048;
-    if (ctl > kTailCtlFloats * sizeof(float) || d->tail_n_folds > cap)
-      return ck::fail(CK_ERR_UNSUPPORTED, "ck_leaf_walk_fwd: %d tail folds do not fit the launch's LDS (at most %d)", d->tail_n_folds, cap);
-    a.tail_folds = reinterpret_cast<const TailFold*>(d->tail_folds);
-    a.tail_level_begin = d->tail_level_begin;
-    a.tail_n_folds = d->tail_n_folds;
-    a.tail_n_levels = d->tail_n_levels;
-    a.tail_write = d->tail_write;
-    a.tail_w_rowmajor = d->tail_w_layout == CK_W_ROWMAJOR ? 1 : 0;
-    a.tail_bad_input = d->tail_bad_input;
-    a.ll = d->ll;
-    a.ll_partial = d->ll_partial;
-    a.ll_ticket = d->ll_ticket;
-    a.arrive = reinterpret_cast<unsigned long long*>(d->tail_arrive);
-    a.tail_state = d->tail_state;
-  }
-  if (d->cat_logits != nullptr) {
-    CK_REQUIRE(d->waves == 8 && d->signed_redo == nullptr && d->tail_folds == nullptr,
-               "ck_leaf_walk_fwd: parameters are evaluated in-launch by 8-wave, unsigned launches without a tail");
-    CK_REQUIRE(d->dense_logits && d->w_logits && d->groot_off && d->groot && d->params_arrive, "ck_leaf_walk_fwd: in-launch parameters need "
-               "dense_logits, w_logits, groot_off, groot and params_arrive");
-    CK_REQUIRE(d->w_layout == CK_W_TILED_F32, "ck_leaf_walk_fwd: in-launch weights are written in the tiled layout");
-    CK_REQUIRE(d->C <= 256 && (d->C & 3) == 0 && d->depth >= 2, "ck_leaf_walk_fwd: in-launch tables need C <= 256, C %% 4 == 0 and depth >= 2 "
-               "(two 32 x (C + 4) tiles in the gather slots)");
-    CK_REQUIRE(d->n_xjobs == 0 || d->xjobs != nullptr, "ck_leaf_walk_fwd: xjobs is null");
-    a.cat_logits = d->cat_logits;
-    a.cat_idx = d->cat_idx;
-    a.dense_logits = d->dense_logits;
+  if (d->keep_levels != nullptr) {
+    CK_REQUIRE(raw && d->waves == 8 && d->signed_redo == nullptr, "ck_leaf_walk_fwd: the training forward (keep_levels) reads the raw batch "
+               "with 8-wave workgroups and walks unsigned values");
+    CK_REQUIRE(d->keep_redo != nullptr, "ck_leaf_walk_fwd: keep_levels needs keep_redo");
+    CK_REQUIRE(static_cast<int64_t>(d->B) * kK < (int64_t{1} << 31), "ck_leaf_walk_fwd: B=%d rows exceed the 32-bit offsets of the kept tiles", d->B);
     for (int l = 0; l < d->depth; ++l) {
-      CK_REQUIRE(d->w_logits[l] != nullptr, "ck_leaf_walk_fwd: no logits for the weights of level %d", l + 1);
-      a.wraw[l] = d->w_logits[l];
+      CK_REQUIRE(d->keep_levels[l] != nullptr && ck::aligned16(d->keep_levels[l]), "ck_leaf_walk_fwd: bad keep_levels[%d]", l);
+      a.keep[l] = d->keep_levels[l];
     }
-    a.groot_off = d->groot_off;
-    a.groot = d->groot;
-    a.parrive = reinterpret_cast<unsigned long long*>(d->params_arrive);
-    a.xjobs = d->xjobs;
-    a.n_xjobs = d->n_xjobs;
+    a.redo = d->keep_redo;
   }
 #ifdef CK_LEAF_STAMPS
-  if (d->cat_logits == nullptr && d->signed_redo == nullptr && getenv("CK_STAMP_PTR") != nullptr) {
+  if (d->signed_redo == nullptr && getenv("CK_STAMP_PTR") != nullptr) {
     a.redo = reinterpret_cast<int32_t*>(strtoull(getenv("CK_STAMP_PTR"), nullptr, 0));
-    a.n_xjobs = getenv("CK_STAMP_WG") ? atoi(getenv("CK_STAMP_WG")) : 0;
-    a.tail_write = getenv("CK_STAMP_TILE") ? atoi(getenv("CK_STAMP_TILE")) : 1;
+    a.stamp_wg = getenv("CK_STAMP_WG") ? atoi(getenv("CK_STAMP_WG")) : 0;
+    a.stamp_tile = getenv("CK_STAMP_TILE") ? atoi(getenv("CK_STAMP_TILE")) : 1;
   }
 #endif
   const int depth = d->depth, waves = d->waves, n_roots = d->n_roots;

@@ -188,7 +188,7 @@ class _Embedding(torch.autograd.Function):
         g = (gout.real if gout.is_complex() else gout).to(torch.float32).contiguous()
         dtable = torch.zeros((F, C + 1, K), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            capi.call("ck_categorical_bwd", g.data_ptr(), xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C,
+            capi.call("ck_categorical_bwd", g.data_ptr(), None, xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C,
                       _stream(g.device))
         dw = dtable[:, :C] / table[:, :C]  # (entries no batch row selected: 0 / w = 0)
         return dw.transpose(1, 2).contiguous().to(ctx.dtype), None, None
@@ -223,7 +223,7 @@ class _Categorical(torch.autograd.Function):
         g = gout.to(torch.float32).contiguous()
         dtable = torch.zeros((F, C + 1, K), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            capi.call("ck_categorical_bwd", g.data_ptr(), xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C,
+            capi.call("ck_categorical_bwd", g.data_ptr(), None, xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C,
                       _stream(g.device))
         return dtable[:, :C].transpose(1, 2).contiguous().to(ctx.dtype), None
 

@@ -95,7 +95,7 @@ class ParamBatch:
     def __init__(self) -> None:
         self._jobs: list[tuple] = []
         self._keep: list[torch.Tensor] = []
-        self._meta: list[dict] = []  # per job: its kind and tensors (for whoever takes a job over, HipCircuit._plan_inlaunch_params)
+        self._meta: list[dict] = []  # per job: its kind and tensors (for whoever takes a job over, HipCircuit._plan_tail_params)
         self._arr = None
 
     def subset(self, indices) -> "ParamBatch":

@@ -1,10 +1,19 @@
 """Training step on the HIP backend: forward, backward, optimiser -- SURVEY.md section 8 (f3).
 
 The reference trains with autograd through its torch forward (notebooks/learning-a-circuit.ipynb,
-cell 18: ``loss = -torch.mean(circuit(batch)); loss.backward(); optimizer.step()``).  Here the
-forward is the layer-wise HIP path with every layer output kept in the arena, and the backward is a
-second launch list of hand-written kernels (cirkit_amd/csrc/ck_backward.hip) walking the plan in
-reverse.  Data-parallel training = one process per GPU, the batch sharded, and ONE all-reduce of a
+cell 18: ``loss = -torch.mean(circuit(batch)); loss.backward(); optimizer.step()``).  Two forms here:
+
+* FUSED (circuits whose leaf region is one persistent launch -- Categorical -> dense -> 2 or 4 CP-T levels, BASELINE
+  configs 2 / 3 -- `HipTrainer(fused=None)` picks it when it applies): the forward is the fused inference forward that also
+  keeps the linear tile of every node of the leaf region (`ck_leaf_walk_fwd` keep_levels) and the outputs of the tail; the
+  backward walks the tail layer by layer, then the leaf region two levels per launch on those tiles (`ck_leaf_walk_bwd`:
+  no layer gradient is materialised above the leaves), scatters the leaf gradients into the (F, C + 1, 32) table by
+  category, and pushes the table gradient through the dense layer and the Categorical log-softmax ON THE TABLE (C + 1
+  rows per fold, like `dense_on_table` in the forward);
+* LAYER-WISE (everything else, and the checker of the fused form): the forward with every layer output kept in the arena,
+  then a reverse launch list of hand-written kernels (cirkit_amd/csrc/ck_backward.hip) over the plan.
+
+Data-parallel training = one process per GPU, the batch sharded, and ONE all-reduce of a
 single flat gradient buffer (all parameter gradients are views of it) over RCCL/xGMI per step.
 
 Covered: real lse-sum circuits made of Categorical (probs = softmax) or Gaussian inputs, Sum / CP-T /
@@ -44,11 +53,14 @@ class HipTrainer:
         betas: tuple[float, float] = (0.9, 0.999),
         eps: float = 1e-8,
         pad_units: bool = False,
+        fused: bool | None = None,
     ) -> None:
         """`pad_units`: train the plan with its unit counts padded to multiples of 32 (cirkit_amd/padding.py), so that
         the MFMA forward / backward tiles apply to any width.  The padded entries never receive a gradient (softmax
         at a -inf logit, zero weight on every padded unit), so the padded circuit stays the same function; `self.grads`
-        and the parameter store then hold the PADDED tensors -- `gradients()` / `parameters()` return user shapes."""
+        and the parameter store then hold the PADDED tensors -- `gradients()` / `parameters()` return user shapes.
+        `fused`: None takes the fused forward / backward when the plan qualifies (module docstring), True insists
+        (NotImplementedError says why not), False forces the layer-wise form."""
         if plan.semiring != "lse-sum":
             raise NotImplementedError("training is implemented for the real lse-sum semiring")
         if optimizer not in ("adam", "sgd"):
@@ -82,17 +94,24 @@ class HipTrainer:
             store._t[n] = view
             off += sz
         store.version += 1
-        # layer-wise forward, every activation materialised, row-major linear weights
-        self.circuit = HipCircuit(plan, store, device=device, use_graph=False, fuse=False,
-                                  batch_params=True, tiled_weights=False, dense_on_table=False, pad_units=False,
-                                  fused_weight_softmax=False)
-        self.plan, self.device = plan, self.circuit.device
+        self.plan = plan
+        self.fused, self._fz = False, None
+        why = "fused=False" if fused is False else self._setup_fused(plan, store, device)
+        if why is not None:
+            if fused is True:
+                raise NotImplementedError(f"fused training does not apply to this plan: {why}")
+            # layer-wise forward, every activation materialised, row-major linear weights
+            self.circuit = HipCircuit(plan, store, device=device, use_graph=False, fuse=False,
+                                      batch_params=True, tiled_weights=False, dense_on_table=False, pad_units=False,
+                                      fused_weight_softmax=False)
+        self.device = self.circuit.device
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self.step_count = 0
         c = self.circuit
         if len(c._out_pairs) != 1:
             raise NotImplementedError("training needs a single circuit output")
-        self._check_supported()
+        if not self.fused:
+            self._check_supported()
         # one flat gradient buffer; per-tensor gradients are views of it (single all-reduce)
         self._flat_grad = torch.zeros(sum(sizes), dtype=torch.float32, device=self.device)
         self.grads: dict[str, torch.Tensor] = {}
@@ -109,6 +128,10 @@ class HipTrainer:
                 self._moments[n] = (self._m1[off : off + sz], self._m2[off : off + sz])
                 off += sz
         self._bwd: dict[int, dict] = {}
+        # input validation: the circuit's flag is raised by a batch with an out-of-range category; a step on such a batch
+        # changes nothing (`step`), the flag is latched into `_bad_seen` -- what `check_inputs()` reports -- and cleared
+        self._bad_seen = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)  # Adam steps that did not count
 
     # ------------------------------------------------------------------------------------------
     _PARAM_OPS = {"tensor", "softmax", "scaled_sigmoid", "mixing_weight", "matmul"}
@@ -132,6 +155,177 @@ class HipTrainer:
     def _fast_softmax(self, l) -> bool:
         """tensor -> softmax weights evaluated by the batched prologue: their backward is one kernel."""
         return l.weight.ops == ["tensor", "softmax"] and l.weight.softmax_source() is not None and not l._mixing
+
+    # ---- the fused form ----------------------------------------------------------------------------------------------
+    def _setup_fused(self, plan: Plan, store: TensorStore, device) -> str | None:
+        """Build the fused training circuit; returns None on success, else why the plan does not qualify."""
+        if self._pad_info is not None:
+            return "padded unit counts"
+        c = HipCircuit(plan, store, device=device, use_graph=False, fuse=True, batch_params=True, tiled_weights=False,
+                       dense_on_table=True, pad_units=False, fused_weight_softmax=False, persistent_leaf=True,
+                       params_at_end=False, keep_levels=True, direct_input=True)
+        if len(c._out_pairs) != 1 or c._signed or len(c._groups) != 1:
+            return "needs one output and exactly one fused leaf region"
+        g = c._groups[0]
+        c._ensure_param_batch()
+        cat = c.layers[g.input_layer]
+        if g.depth not in (2, 4) or g.dense_layer is None or g.root not in c._table_fused or not c.linear_levels:
+            return "the leaf region must be Categorical -> dense -> 2 or 4 CP-T levels with the table built by one prologue job"
+        if not isinstance(cat, HipCategoricalLayer) or cat.num_output_units != 32:
+            return "the leaf region needs a 32-unit Categorical input layer"
+        covered = set(g.virtual) | {g.root} | set(c._tail)
+        if covered != set(range(len(c.layers))) or c._tdense or c._cp_blocks or c._regions or c._input_prod:
+            return "layers outside the leaf region and the tail"
+        if c._tail and not c._tail16_ok():
+            return "the tail does not fit the 16-row walk"
+        for j in list(g.levels) + [g.dense_layer] + list(c._tail):
+            l = c.layers[j]
+            if not (isinstance(l, (HipSumLayer, HipCPTLayer)) and type(l) in (HipSumLayer, HipCPTLayer) and self._fast_softmax(l)
+                    and l.num_input_units == 32):
+                return f"layer {j}: weights must be softmax(tensor) over 32 inputs"
+        for j in g.levels:
+            if c.layers[j].num_output_units != 32 or c.layers[j].arity != 2:
+                return "fused levels must be binary CP-T layers of 32 units"
+        if cat.probs is None or cat.probs.softmax_source() is None:
+            return "Categorical layers need probs = softmax(tensor)"
+        leaf_of_dense = c._children[g.dense_layer][:, 0, 1].astype(np.int64)
+        if not np.array_equal(leaf_of_dense, np.arange(cat.num_folds)):
+            return "the dense layer must read the Categorical folds in order"
+        self.circuit, self.fused = c, True
+        dev = c.device
+        dl = c.layers[g.dense_layer]
+        Cn = cat.num_categories
+        from .parameters import ParamBatch
+
+        extra = ParamBatch()  # what only the backward reads: the log-table itself and the dense layer's linear weights
+        T = torch.empty((cat.num_folds, Cn + 1, 32), dtype=torch.float32, device=dev)
+        Wd = torch.empty((dl.num_folds, 32, 32), dtype=torch.float32, device=dev)
+        extra.add_log_table(cat.probs.softmax_source(), T)
+        extra.add_softmax(dl.weight.softmax_source(), Wd)
+        kl = 1 << g.depth
+        nodes = np.asarray(g.nodes).astype(np.int64)
+        n_roots = c.layers[g.root].num_folds
+        off = [int(v) for v in g.node_off]
+        var_of_leaf = cat.scope_idx[:, 0].astype(np.int64)
+
+        def lvl(l: int, t: int, j: int) -> int:  # fold of the j-th node of level l under root t (level 0: table folds)
+            return int(nodes[off[l] + t * (kl >> l) + j])
+
+        launches = []  # top first: (unit table, level of P)
+        for top in range(g.depth, 0, -2):
+            per_root = kl >> top  # nodes of level `top` per root
+            tab = np.zeros((n_roots * per_root, 16), dtype=np.int32)
+            for t in range(n_roots):
+                for j in range(per_root):
+                    r = tab[t * per_root + j]
+                    r[0] = lvl(top, t, j) if top == g.depth else lvl(top + 1, t, j >> 1)
+                    r[1] = lvl(top, t, j)
+                    r[2], r[3] = lvl(top - 1, t, 2 * j), lvl(top - 1, t, 2 * j + 1)
+                    for i in range(4):
+                        r[4 + i] = lvl(top - 2, t, 4 * j + i)
+                        if top == 2:
+                            r[8 + i] = var_of_leaf[int(nodes[g.leaf_off + t * kl + 4 * j + i])]
+                    r[12] = t
+            launches.append((torch.from_numpy(tab).to(dev), top))
+        # Categorical scatter: table fold d takes the gradient tile of the level-1 node above it
+        gfold = np.zeros(dl.num_folds, dtype=np.int32)
+        var_of_table = np.zeros(dl.num_folds, dtype=np.int64)
+        for t in range(n_roots):
+            for i in range(kl):
+                d = lvl(0, t, i)
+                gfold[d] = lvl(1, t, i >> 1)
+                var_of_table[d] = var_of_leaf[int(nodes[g.leaf_off + t * kl + i])]
+        self._fz = {
+            "group": g, "extra": extra, "T": T, "Wd": Wd, "launches": launches,
+            "gfold": torch.from_numpy(gfold).to(dev), "var": torch.from_numpy(var_of_table).to(dev),
+            "trow": (torch.arange(dl.num_folds, dtype=torch.int64) * ((Cn + 1) * 32)).to(dev),
+            "gT": torch.empty_like(T), "dTp": None, "per_B": {},
+        }
+        return None
+
+    def _fused_binding(self, B: int, bd) -> dict:
+        fz = self._fz
+        hit = fz["per_B"].get(B)
+        if hit is not None and hit["arena_ptr"] == bd.arena.data_ptr():
+            return hit
+        from .fusion import leaf_segments
+
+        c, g = self.circuit, fz["group"]
+        dev = self.device
+        n_tiles = (B + 31) // 32
+        hit = {"arena_ptr": bd.arena.data_ptr(), "work": [], "G": []}
+        for tab, top in fz["launches"]:
+            hit["work"].append(torch.from_numpy(leaf_segments(int(tab.shape[0]), n_tiles, c._n_cu)).to(dev))
+            # the tiles this launch leaves for the level below its Q nodes (one per Q node)
+            hit["G"].append(torch.empty((c.layers[g.levels[top - 2]].num_folds, B, 32), dtype=torch.float32, device=dev))
+        while len(fz["per_B"]) >= 4:
+            fz["per_B"].pop(next(iter(fz["per_B"])))
+        fz["per_B"][B] = hit
+        return hit
+
+    def _backward_fused(self, B: int, gB: float, seed, bd, st: dict, stream: int) -> None:
+        c, fz = self.circuit, self._fz
+        g = fz["group"]
+        fb = self._fused_binding(B, bd)
+        keep, redo = bd.keep[g.root]
+        gviews = st["gviews"]
+        capi.call("ck_fill_f32", st["dw_flat"].data_ptr(), st["dw_flat"].numel(), 0.0, stream)
+        capi.call("ck_fill_f32", self._flat_grad.data_ptr(), self._flat_grad.numel(), 0.0, stream)
+        for p in st["need_zero"]:
+            if gviews[p] is not None:
+                capi.call("ck_fill_f32", gviews[p].data_ptr(), gviews[p].numel(), 0.0, stream)
+        po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
+        if c.layers[po].num_output_units != 1:
+            raise NotImplementedError("training needs a scalar output unit")
+        capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel(), 0.0, stream)
+        if seed is None:
+            capi.call("ck_fill_f32", gviews[po][fo].data_ptr(), B, -1.0 / gB, stream)
+        else:
+            gviews[po][fo].reshape(-1)[:B].copy_(seed.reshape(-1))
+        fz["extra"].launch(stream)  # (the log-table and the dense weights the table backward reads)
+        for i in reversed(c._tail):  # the few-fold layers above the leaf region, layer by layer
+            self._bwd_sum_layer(i, bd, st, B, stream)
+        # the leaf region, two levels per launch, top first
+        cat, dl = c.layers[g.input_layer], c.layers[g.dense_layer]
+        gin = gviews[g.root]
+        for k, (tab, top) in enumerate(fz["launches"]):
+            lp, lq = g.levels[top - 1], g.levels[top - 2]
+            d = capi.LeafBwdLaunch()
+            d.unit_tab, d.work = tab.data_ptr(), fb["work"][k].data_ptr()
+            d.n_seg, d.n_wg, d.B = int(fb["work"][k].shape[0]), c._n_cu, B
+            d.C, d.D, d.leaf = cat.num_categories, self.plan.num_variables, 1 if top == 2 else 0
+            d.gin = gin.data_ptr()
+            d.y_p, d.y_q = keep[top - 1].data_ptr(), keep[top - 2].data_ptr()
+            if top == 2:
+                d.table, d.x_rows = c._group_dev[g.root][1].data_ptr(), bd.x_last.data_ptr()
+            else:
+                d.y_c = keep[top - 3].data_ptr()
+            d.w_p, d.w_q = c.layers[lp]._w.data_ptr(), c.layers[lq]._w.data_ptr()
+            d.dw_p, d.dw_q = st["dws"][lp].data_ptr(), st["dws"][lq].data_ptr()
+            d.gout = fb["G"][k].data_ptr()
+            d.redo = redo.data_ptr()
+            capi.call("ck_leaf_walk_bwd", C.byref(d), stream)
+            gin = fb["G"][k]
+        for j in g.levels:  # softmax parameterisation of the level weights
+            l = c.layers[j]
+            name = l.weight.graph.nodes[0].config["tensor"]
+            capi.call("ck_param_softmax_bwd", l._w.data_ptr(), st["dws"][j].data_ptr(), self.grads[name].data_ptr(),
+                      l.num_folds * 32, 32, 0, stream)
+        # leaves: scatter by category into the gradient of the (F0, C + 1, 32) table T' = dense(log-table) ...
+        Cn = cat.num_categories
+        dTp = st["dws"][g.input_layer]
+        capi.call("ck_transpose_i64_to_i32", bd.x_last.data_ptr(), bd.xt_i.data_ptr(), B, self.plan.num_variables, stream)
+        capi.call("ck_categorical_bwd", gin.data_ptr(), fz["gfold"].data_ptr(), bd.xt_i.data_ptr(), fz["var"].data_ptr(),
+                  dTp.data_ptr(), dl.num_folds, B, 32, Cn, stream)
+        # ... then the dense layer and the log-softmax of the Categorical layer backward ON THE TABLE (C + 1 rows per fold)
+        dWd = st["dws"][g.dense_layer]
+        capi.call("ck_sum_lse_bwd", fz["T"].data_ptr(), fz["gT"].data_ptr(), fz["trow"].data_ptr(), fz["trow"].data_ptr(),
+                  fz["Wd"].data_ptr(), fz["T"].data_ptr(), dTp.data_ptr(), dWd.data_ptr(), dl.num_folds, 1, Cn + 1, 32, 32,
+                  dl._mode, 0, stream)
+        capi.call("ck_param_softmax_bwd", fz["Wd"].data_ptr(), dWd.data_ptr(),
+                  self.grads[dl.weight.graph.nodes[0].config["tensor"]].data_ptr(), dl.num_folds * 32, 32, 0, stream)
+        capi.call("ck_param_log_table_bwd", fz["T"].data_ptr(), fz["gT"].data_ptr(),
+                  self.grads[cat.probs.graph.nodes[0].config["tensor"]].data_ptr(), cat.num_folds, 32, Cn, 0, stream)
 
     def _accumulate_flags(self) -> tuple[dict[int, int], set[int]]:
         """Per consumer layer: 0 store / 1 add / 2 atomic; and the producer layers whose gradient
@@ -174,6 +368,9 @@ class HipTrainer:
         gviews = []
         base = 0
         for i, l in enumerate(c.layers):
+            if bd.views[i] is None:  # (fused: never materialised)
+                gviews.append(None)
+                continue
             n = l.num_folds * B * l.num_output_units
             off = bd.views[i].data_ptr() - bd.arena.data_ptr()
             gviews.append(garena.view(torch.uint8)[off : off + 4 * n].view(torch.float32).view(l.num_folds, B, l.num_output_units))
@@ -182,9 +379,9 @@ class HipTrainer:
         sizes = {}
         for i, l in enumerate(c.layers):
             if isinstance(l, (HipSumLayer, HipCPTLayer)) and not (l.weight.ops == ["tensor"]):
-                sizes[i] = tuple(l._w.shape)  # mixing layers: the (F, K, H) coefficients
+                sizes[i] = tuple(l._w.shape) if l._w is not None else (l.num_folds, l.num_output_units, l.num_input_units)  # mixing layers: the (F, K, H) coefficients
             elif isinstance(l, HipCategoricalLayer):
-                sizes[i] = tuple(l._table.shape)
+                sizes[i] = (l.num_folds, l.num_categories + 1, l.num_output_units)
             elif isinstance(l, HipGaussianLayer):
                 sizes[(i, "mean")] = sizes[(i, "stddev")] = (l.num_folds, l.num_output_units)
         flat = torch.zeros(sum(int(np.prod(sh)) for sh in sizes.values()) or 1, dtype=torch.float32, device=self.device)
@@ -198,7 +395,7 @@ class HipTrainer:
         shared, tmp_elems = {}, 0
         for j, fl in flags.items():
             l = c.layers[j]
-            if fl != 2:
+            if fl != 2 or bd.row_off[j] is None:
                 continue
             ro = bd.row_off[j].cpu().numpy().reshape(-1)  # element offsets of the (fold, slot) children in the arena
             block = B * l.num_input_units
@@ -239,11 +436,20 @@ class HipTrainer:
 
         if global_batch is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             global_batch = int(x.shape[0]) * dist.get_world_size()
-        c = self.circuit
-        ll = c.log_likelihood_sum(x)  # forward (all activations stay in the arena)
         B = int(x.shape[0])
+        ll = self._forward(x)
         self._backward(B, float(global_batch or B), None)
         return ll
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
+        """The training forward: [sum log p, count] of the batch; fused: kept tiles of the leaf region + tail outputs,
+        layer-wise: every activation stays in the arena."""
+        c = self.circuit
+        if self.fused:  # the tiles a previous forward marked as evaluated in log space
+            kept = c._bind(int(x.shape[0])).keep.get(self._fz["group"].root)
+            if kept is not None:
+                capi.call("ck_fill_f32", kept[1].data_ptr(), kept[1].numel(), 0.0, torch.cuda.current_stream(self.device).cuda_stream)
+        return c.log_likelihood_sum(x)
 
     def _backward(self, B: int, gB: float, seed: torch.Tensor | None) -> None:
         """The backward launch list over the activations of the LAST forward at batch size B: gradients of
@@ -252,6 +458,8 @@ class HipTrainer:
         bd = c._bind(B)
         st = self._bind_backward(B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        if self.fused:
+            return self._backward_fused(B, gB, seed, bd, st, stream)
         capi.call("ck_fill_f32", st["dw_flat"].data_ptr(), st["dw_flat"].numel(), 0.0, stream)
         capi.call("ck_fill_f32", self._flat_grad.data_ptr(), self._flat_grad.numel(), 0.0, stream)
         gviews, flags = st["gviews"], st["flags"]
@@ -284,7 +492,7 @@ class HipTrainer:
             l = c.layers[i]
             if isinstance(l, HipCategoricalLayer):
                 dT = st["dws"][i]
-                capi.call("ck_categorical_bwd", gviews[i].data_ptr(), bd.xt_i.data_ptr(), l._scope(self.device).data_ptr(),
+                capi.call("ck_categorical_bwd", gviews[i].data_ptr(), None, bd.xt_i.data_ptr(), l._scope(self.device).data_ptr(),
                           dT.data_ptr(), l.num_folds, B, l.num_output_units, l.num_categories, stream)
                 name = l.probs.graph.nodes[0].config["tensor"]
                 capi.call("ck_param_log_table_bwd", l._table.data_ptr(), dT.data_ptr(), self.grads[name].data_ptr(),
@@ -319,20 +527,33 @@ class HipTrainer:
                 else:
                     l.weight.backward(dmw, self.grads, stream, upto=len(l.weight.graph.nodes) - 2)
             else:  # sum / cpt
-                raw = l.weight.ops == ["tensor"]
-                dW = self.grads[l.weight.graph.nodes[0].config["tensor"]] if raw else st["dws"][i]
-                ga, ro, fl = target(i)
-                capi.call("ck_sum_lse_bwd", bd.arena.data_ptr(), ga, bd.row_off[i].data_ptr(), ro,
-                          l._w.data_ptr(), bd.views[i].data_ptr(), gviews[i].data_ptr(), dW.data_ptr(), l.num_folds,
-                          l.arity, B, l.num_input_units, l.num_output_units, l._mode, fl, stream)
-                gather_shared(i)
-                if self._fast_softmax(l):
-                    name = l.weight.graph.nodes[0].config["tensor"]
-                    rows = l.num_folds * l.num_output_units
-                    capi.call("ck_param_softmax_bwd", l._w.data_ptr(), dW.data_ptr(), self.grads[name].data_ptr(),
-                              rows, dW.shape[-1], 0, stream)
-                elif not raw:
-                    l.weight.backward(dW, self.grads, stream)
+                self._bwd_sum_layer(i, bd, st, B, stream)
+
+    def _bwd_sum_layer(self, i: int, bd, st: dict, B: int, stream: int) -> None:
+        """Backward launch of sum / CP-T layer i over its materialised inputs and output gradient, then its weight's
+        parameter graph (semiring.py:383-408 under autograd)."""
+        c = self.circuit
+        l, gviews, flags = c.layers[i], st["gviews"], st["flags"]
+        raw = l.weight.ops == ["tensor"]
+        dW = self.grads[l.weight.graph.nodes[0].config["tensor"]] if raw else st["dws"][i]
+        sh = st["shared"].get(i)
+        if sh is None:
+            ga, ro, fl = st["garena"].data_ptr(), bd.row_off[i].data_ptr(), flags[i]
+        else:
+            ga, ro, fl = st["tmp"].data_ptr(), sh["row_off"].data_ptr(), 0
+        capi.call("ck_sum_lse_bwd", bd.arena.data_ptr(), ga, bd.row_off[i].data_ptr(), ro,
+                  l._w.data_ptr(), bd.views[i].data_ptr(), gviews[i].data_ptr(), dW.data_ptr(), l.num_folds,
+                  l.arity, B, l.num_input_units, l.num_output_units, l._mode, fl, stream)
+        if sh is not None:
+            capi.call("ck_segment_add_rows", st["tmp"].data_ptr(), sh["cptr"].data_ptr(), sh["clist"].data_ptr(),
+                      sh["coff"].data_ptr(), st["garena"].data_ptr(), sh["n_child"], sh["block"], stream)
+        if self._fast_softmax(l):
+            name = l.weight.graph.nodes[0].config["tensor"]
+            rows = l.num_folds * l.num_output_units
+            capi.call("ck_param_softmax_bwd", l._w.data_ptr(), dW.data_ptr(), self.grads[name].data_ptr(),
+                      rows, dW.shape[-1], 0, stream)
+        elif not raw:
+            l.weight.backward(dW, self.grads, stream)
 
     def gradients(self) -> dict[str, np.ndarray]:
         """The gradients of the last `loss_and_grads`, host copies in the shapes of the user's plan."""
@@ -355,19 +576,22 @@ class HipTrainer:
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
 
-    def apply_gradients(self) -> None:
+    def apply_gradients(self, skip_flag: torch.Tensor | None = None) -> None:
+        """The optimizer step on `self.grads`.  `skip_flag`: a device int32; when it is nonzero at launch time the step
+        changes nothing (parameters, moments, Adam's step count)."""
         with torch.cuda.device(self.device):
-            self._apply_gradients()
+            self._apply_gradients(skip_flag)
 
-    def _apply_gradients(self) -> None:
+    def _apply_gradients(self, skip_flag: torch.Tensor | None = None) -> None:
         self.step_count += 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         p, g = self._flat_param, self._flat_grad
+        skip = None if skip_flag is None else skip_flag.data_ptr()
         if self.optimizer == "adam":
             capi.call("ck_adam_step", p.data_ptr(), g.data_ptr(), self._m1.data_ptr(), self._m2.data_ptr(), p.numel(),
-                      self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, stream)
+                      self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, skip, self._skipped.data_ptr(), stream)
         else:
-            capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, stream)
+            capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, skip, stream)
         if self._pad_info is not None:  # padded input-layer units are copies of real ones: follow their update
             for n in self.user_plan.tensors:
                 for ax, old, new in self._pad_info.duplicated_axes(n):
@@ -379,21 +603,36 @@ class HipTrainer:
     def step(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
         """One optimisation step on this rank's shard; returns the device tensor [sum log p, count]
         of the shard (before the update)."""
+        import torch.distributed as dist
+
         ll = self.loss_and_grads(x, global_batch=global_batch)
         c = self.circuit
-        if c.validate_inputs and c._int_input:
-            # a batch with an out-of-range category (NaN log-likelihood, the flag `check_inputs()` reports) must not reach the
-            # parameters: its gradients are dropped on the device -- no host synchronisation -- before the exchange and the update
+        validate = c.validate_inputs and c._int_input
+        alone = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if validate:
+            # a batch with an out-of-range category (NaN log-likelihood) must not reach the parameters.  The flag it raised is
+            # THIS step's (it is latched and cleared below), everything stays on the device -- no host synchronisation:
+            # its gradients are dropped before the exchange, and on a single rank the optimizer launch changes nothing at all
+            # (with several ranks the other ranks' gradients are valid and every rank must take the same step)
             with torch.cuda.device(self.device):
                 capi.call("ck_zero_if_flag", self._flat_grad.data_ptr(), self._flat_grad.numel(), c._bad_input.data_ptr(),
                           torch.cuda.current_stream(self.device).cuda_stream)
         self.all_reduce_grads()
-        self.apply_gradients()
+        self.apply_gradients(c._bad_input if (validate and alone) else None)
+        if validate:
+            with torch.cuda.device(self.device):
+                capi.call("ck_latch_flag", c._bad_input.data_ptr(), self._bad_seen.data_ptr(),
+                          torch.cuda.current_stream(self.device).cuda_stream)
         return ll
 
     def check_inputs(self) -> None:
-        """Raise ``IndexError`` if a batch since the last check held a category out of range (`HipCircuit.check_inputs`);
-        the steps on such batches changed nothing but the optimizer's step count and moment decay."""
+        """Raise ``IndexError`` if a batch since the last check held a category out of range (as
+        `TorchCategoricalLayer`'s indexing would have, layers/input.py:399-412).  On a single rank the steps on such
+        batches changed nothing (parameters, moments, Adam's step count); later valid batches train normally."""
+        if int(self._bad_seen.item()) != 0:
+            self._bad_seen.zero_()
+            self.circuit._bad_input.zero_()
+            raise IndexError("a batch held a category outside [0, num_categories) of its variable")
         self.circuit.check_inputs()
 
 
@@ -404,7 +643,7 @@ class _CircuitFunction(torch.autograd.Function):
     def forward(ctx, module, x, *params):
         tr = module._trainer
         with torch.cuda.device(tr.device):
-            tr.circuit.log_likelihood_sum(x)  # layer-wise forward, every activation kept in the arena
+            tr._forward(x)  # the training forward (what the backward needs stays on the device)
             B = int(x.shape[0])
             bd = tr.circuit._bind(B)
             po, fo = int(tr.circuit._out_pairs[0, 0]), int(tr.circuit._out_pairs[0, 1])

@@ -295,24 +295,13 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
  *  as NaN (every launch downstream carries the NaN to the circuit outputs of the row; other rows are unaffected) and
  *  *bad_input (a DEVICE int32 owned by the caller, as ck_stage_categories' flag) is raised; with bad_input == NULL such a
  *  value is evaluated as the integral row (memory-safe, not meaningful).  B * D * 8 must be below 2^32.
- *  In-launch tail (tail_folds != NULL): the trailing few-fold levels of the circuit -- what ck_tail16_lse_fwd walks as a
- *  launch of its own, same descriptors, same arithmetic per fold (TorchCPTLayer optimized.py:171-178 / dense TorchSumLayer
- *  inner.py:266-273 + LSESumSemiring.apply_reduce semiring.py:383-408), same log-likelihood sum -- are evaluated by the
- *  resident workgroups of this launch after their segments: roots are stored write-through, a workgroup arrives on
- *  *tail_arrive, waits (at most 200 us) for the other workgroups of the launch, then claims 16-row tiles of the batch in
- *  tail_state and walks them with the tail's fold outputs in LDS; tiles of workgroups that gave up waiting are walked by
- *  those that did not (no assumption that all workgroups are resident at once).  The children the descriptors name by
- *  pointer must be outputs of THIS launch (`out`) or of earlier launches.  tail_arrive / tail_state carry state from one
- *  launch to the next: every launch that uses them must have the same grid (n_wg, n_seg) and batch size.
- *  In-launch parameters (cat_logits != NULL): the launch evaluates the parameter graphs it depends on itself -- what
- *  ck_param_softmax_batch does as a launch of its own (parameters/parameter.py:180-188: re-evaluated on every forward),
- *  with the same device functions, bit for bit: `table` / `table_scale` are then OUTPUTS of the launch (kind-5 job: the
- *  log-table of Categorical fold cat_idx[d] pushed through dense fold d, rows linear + log scales; layers/input.py:399-412,
- *  layers/inner.py:266-273) built by the workgroups b, b % 8 == g, for the roots groot[groot_off[g] ..) -- every root a
- *  workgroup of the class walks must be listed -- and stored write-through; the class then meets on params_arrive[16 g]
- *  (a workgroup that has waited 200 us builds all tables of its class itself: the jobs are idempotent).  w_levels is
- *  not read: a segment's weights are softmaxed from w_logits straight into LDS.  xjobs: further 32-wide softmaxes (weights
- *  of the layers behind this launch), one job per workgroup turn, plain stores (visible to later launches).
+ *  Training forward (keep_levels != NULL; raw input, unsigned values, 8 waves): beside the root outputs the launch stores the
+ *  LINEAR tile of every node it evaluates -- keep_levels[l - 1] is (F_l, B, 32) for CP-T level l = 1 .. depth, the value the
+ *  next level multiplies (per row it differs from exp(layer output) by the power-of-two scale the walk carries; the backward,
+ *  ck_leaf_walk_bwd, only needs a level's tiles to be consistent with each other) -- i.e. what the reference's autograd keeps
+ *  alive as the outputs of those layers (graph/modules.py:303-335).  keep_redo: (n_roots, ceil(B / 32)) int32, zero on
+ *  entry: tiles whose products left the linear range (evaluated again in log space for `out`) are marked 1 there; their
+ *  kept tiles are not meaningful and ck_leaf_walk_bwd recomputes them in log space.
  *  x_input >= 0: the call is being RECORDED into a ck_program and the batch pointer is read, at every replay, from that
  *  program's input cell x_input (ck_program_set_input) -- a recorded forward then follows the caller's batch without a
  *  copy.  Not usable with use_graph != 0 launches (a hipGraph keeps the pointer of its capture). */
@@ -344,29 +333,8 @@ typedef struct ck_leaf_launch {
   const int64_t* x_rows;         /* raw (B, D) int64 batch, or NULL */
   int32_t* bad_input;            /* raw input: validation flag (rows with illegal values become NaN), or NULL */
   int32_t D;                     /* variables per row of the raw batch */
-  int32_t tail_write;            /* tail: also store the 32-unit fold outputs of the tail (they are layer outputs) */
-  /* In-launch tail (tail_folds != NULL; 8 waves, unsigned values): see below. */
-  const struct ck_tail16_fold* tail_folds;  /* DEVICE (tail_n_folds) descriptors in level order, as ck_tail16_lse_fwd */
-  const int32_t* tail_level_begin;          /* DEVICE (tail_n_levels + 1) */
-  int32_t tail_n_folds, tail_n_levels;
-  int32_t tail_w_layout;                    /* CK_W_ROWMAJOR or CK_W_TILED_F32 of the 32-output tail weights */
-  int32_t reserved;
-  const int32_t* tail_bad_input;            /* staged batch: ck_stage_categories' flag (NaN outputs), or NULL */
-  double* ll;                               /* NULL, or DEVICE [sum_b log p, B] as ck_tail16_lse_fwd */
-  double* ll_partial;                       /* DEVICE (ceil(B / 16)) */
-  uint32_t* ll_ticket;                      /* DEVICE, zero */
-  uint64_t* tail_arrive;                    /* DEVICE counter, ZERO when first used, owned by this (circuit, batch size) */
-  uint32_t* tail_state;                     /* DEVICE (ceil(B / 16)), ZERO when first used, same owner */
-  /* In-launch parameters (cat_logits != NULL; 8 waves, unsigned, CK_W_TILED_F32, no in-launch tail): see below. */
-  const float* cat_logits;                  /* DEVICE (F_cat, 32, C) logits of the Categorical layer */
-  const int64_t* cat_idx;                   /* DEVICE (F0) Categorical fold of each table fold, or NULL: the identity */
-  const float* dense_logits;                /* DEVICE (F0, 32, 32) logits of the dense layer pushed through the table */
-  const float* const* w_logits;             /* HOST array of `depth` DEVICE pointers: (F_l, 32, 32) logits of the level weights */
-  const int32_t* groot_off;                 /* DEVICE (9) */
-  const int32_t* groot;                     /* DEVICE: roots whose tables the workgroups b, b % 8 == g, build: groot[groot_off[g] .. groot_off[g+1]) */
-  uint64_t* params_arrive;                  /* DEVICE 8 x 16 words, ZERO when first used, owned by this (circuit, batch size) */
-  const struct ck_rows32_job* xjobs;        /* DEVICE (n_xjobs), or NULL */
-  int32_t n_xjobs;
+  float* const* keep_levels;     /* NULL, or HOST array of `depth` DEVICE pointers: (F_l, B, 32) linear tiles of level l's nodes */
+  int32_t* keep_redo;            /* with keep_levels: DEVICE (n_roots, ceil(B / 32)) flags of the tiles evaluated in log space */
   int32_t x_pairs;                          /* raw input: for every root, leaves 2j and 2j + 1 read variables v and v + 1 with v even
                                                (and D even): the launch then fetches both values with one 16-byte load */
   const int32_t* root_tab;                  /* DEVICE (n_roots of the region, 3 * 2^depth), or NULL: row t = for each leaf i of root t its
@@ -586,10 +554,45 @@ int ck_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
 /* Backward of ck_param_gather_folds: ddst[idx[i]] += dsrc[i] over blocks of `per_fold` fp32 words. */
 int ck_param_scatter_add_folds(const float* dsrc, const int64_t* idx, float* ddst, int64_t n, int64_t per_fold,
                                void* stream);
-/* TorchCategoricalLayer backward: dtable[f,c,:] += sum_{b: x[b,scope f]=c} gout[f,b,:]  (dtable
- * (F,C+1,K), same transposed layout as the forward table). */
-int ck_categorical_bwd(const float* gout, const int32_t* xt, const int64_t* scope, float* dtable, int F,
+/* TorchCategoricalLayer backward (the scatter-add that autograd performs for the advanced indexing of
+ * layers/input.py:399-412): dtable[f,c,:] += sum_{b: x[b,scope f]=c} gout[g(f),b,:]  (dtable (F,C+1,K), same transposed
+ * layout as the forward table).  gfold: NULL (g(f) = f), or DEVICE (F) int32: the (B, K) block of `gout` that holds fold f's
+ * gradient -- in a fused backward the two leaves of a product share ONE gradient tile (ck_leaf_walk_bwd). */
+int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* xt, const int64_t* scope, float* dtable, int F,
                        int B, int K, int C, void* stream);
+
+/* Backward of the fused leaf region, two CP-T levels per launch (cirkit_amd/csrc/ck_leaf_bwd.hip) -- what autograd does for
+ * TorchCPTLayer.forward (layers/optimized.py:171-178) under LSESumSemiring.apply_reduce (semiring.py:383-408), on the tiles
+ * ck_leaf_walk_fwd kept (keep_levels) instead of materialised layer outputs and layer gradients.
+ * A unit is a node P of level L, its children Q0, Q1 (level L - 1) and their four children c0..c3 (level L - 2, or -- leaf
+ * != 0, L = 2 -- the Categorical table rows of four leaves), for one 32-row batch tile.  unit_tab: DEVICE (n_units, 16)
+ * int32 rows [fold of P's gradient tile in `gin`, fold of P, of Q0, of Q1, of c0..c3 (leaf: table folds), variables of the four
+ * leaves (leaf only), root fold of the region (for `redo`), 0, 0, 0]; work: DEVICE (n_seg, 4) [row of unit_tab, first tile,
+ * end tile, 0] dealt to n_wg resident workgroups.  gin: (F, B, 32) gradient w.r.t. the LOG-space output of P (for the top
+ * launch the gradient of the root layer's output; below, the tile the previous launch left in ITS `gout` for P's parent).
+ * y_p / y_q / y_c: the kept linear tiles of the three levels ((F_l, B, 32)); w_p / w_q: (F_l, 32, 32) row-major linear
+ * weights; dw_p / dw_q: their gradients, accumulated (+=, atomically per segment); gout: (F_q, B, 32), written: the
+ * log-space gradient node Q leaves for BOTH its children (the two children of a product receive the same one).
+ * redo: NULL or ck_leaf_walk_fwd's keep_redo flags: flagged (root, tile) units are skipped (their kept tiles are not
+ * meaningful; the caller evaluates them with the layer-wise kernels). */
+typedef struct ck_leaf_bwd_launch {
+  const int32_t* unit_tab;
+  const int32_t* work;
+  int32_t n_seg, n_wg, B, C, D, leaf;
+  const float* gin;
+  const float* y_p;
+  const float* y_q;
+  const float* y_c;
+  const float* table;
+  const int64_t* x_rows;
+  const float* w_p;
+  const float* w_q;
+  float* dw_p;
+  float* dw_q;
+  float* gout;
+  const int32_t* redo;
+} ck_leaf_bwd_launch;
+int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* desc, void* stream);
 /* softmax parameter backward over the last axis: dtheta = W * (dW - sum(W*dW)). */
 int ck_param_softmax_bwd(const float* w, const float* dw, float* dtheta, int64_t rows, int len,
                          int accumulate, void* stream);
@@ -598,10 +601,17 @@ int ck_param_softmax_bwd(const float* w, const float* dw, float* dtheta, int64_t
 int ck_param_log_table_bwd(const float* table, const float* dtable, float* dtheta, int F, int K, int C,
                            int accumulate, void* stream);
 /* Optimiser steps on one flat tensor; grad_scale multiplies the gradient first (e.g. 1/world). Adam
- * follows torch.optim.Adam's defaults semantics (bias-corrected, no weight decay, no amsgrad). */
+ * follows torch.optim.Adam's defaults semantics (bias-corrected, no weight decay, no amsgrad; the reference's training
+ * loop, notebooks/learning-a-circuit.ipynb cell 18).  skip_flag: NULL, or a DEVICE int32: when it is nonzero at launch time
+ * -- the step's batch held an illegal value, ck_leaf_walk_fwd / ck_stage_categories -- the launch changes NOTHING
+ * (parameters, moments), and Adam adds 1 to *skipped (DEVICE int32, zero-initialised by the caller, or NULL): the bias
+ * corrections use step - *skipped, so a skipped step does not count. */
 int ck_adam_step(float* p, const float* g, float* m1, float* m2, int64_t n, float lr, float beta1,
-                 float beta2, float eps, int step, float grad_scale, void* stream);
-int ck_sgd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, void* stream);
+                 float beta2, float eps, int step, float grad_scale, const int32_t* skip_flag, int32_t* skipped,
+                 void* stream);
+int ck_sgd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, const int32_t* skip_flag, void* stream);
+/* *dst |= *src; *src = 0 (DEVICE int32 flags): turns a per-step validation flag into a sticky one. */
+int ck_latch_flag(int32_t* src, int32_t* dst, void* stream);
 
 /* ---------------------------------------------------------------- reductions --------------- */
 /* Sum of B log-likelihoods (stride in floats between consecutive rows) into out_dev[0] (fp64) and

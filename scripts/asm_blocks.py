@@ -3,7 +3,7 @@
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -Iinclude -Icirkit_amd/csrc \
           -S --cuda-device-only -o leaf.s cirkit_amd/csrc/ck_leaf.hip
-    python scripts/asm_blocks.py leaf.s _ZN12_GLOBAL__N_122leaf_persistent_kernelILi4ELi8ELb0ELb1ELb0ELb0ELb1EEEvNS_8LeafArgsE [--all]
+    python scripts/asm_blocks.py leaf.s _ZN12_GLOBAL__N_122leaf_persistent_kernelILi4ELi8ELb0ELb1ELb1ELb0EEEvNS_8LeafArgsE [--all]
 
 Per block (by default those with MFMAs or at least 40 instructions): label, first line, instruction count, counts by class
 (mfma, valu, salu, lds, vmem = vector memory, smem, lane = v_readlane / v_writelane i.e. spilled scalar registers, scr =

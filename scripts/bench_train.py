@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training-step timing on the GPU box:
-    python scripts/bench_train.py [B] [steps] [config]
+    python scripts/bench_train.py [B] [steps] [config] [fused|layerwise]
 config 2 (default): 784-var QuadTree, Categorical, K = 32; config 4: Poon-Domingos, Gaussian, K = 64;
 config 6: QuadGraph, Categorical, CP, K = 64 (the circuit of the reference's learning-a-circuit notebook, batch 256)."""
 import os
@@ -29,7 +29,9 @@ elif cfg == 6:
 else:
     plan = image_data((1, 28, 28), "quad-tree-2", num_input_units=32, num_sum_units=32)
     x = torch.randint(0, 256, (B, 784)).cuda()
-tr = HipTrainer(plan, init_plan_tensors(plan), device="cuda:0", lr=0.01)
+mode = sys.argv[4] if len(sys.argv) > 4 else "auto"
+tr = HipTrainer(plan, init_plan_tensors(plan), device="cuda:0", lr=0.01, fused={"auto": None, "fused": True, "layerwise": False}[mode])
+print("fused" if tr.fused else "layer-wise", "training step")
 lls = []
 for _ in range(3):
     ll = tr.step(x)

@@ -28,8 +28,7 @@ CONFIGS = {
     "classic": dict(persistent_leaf=False, tail16=False),
     "tail32": dict(tail16=False),
     "default": dict(),
-    "persistent8": dict(persistent_leaf=True, leaf_waves=8),
-    "persistent12": dict(persistent_leaf=True, leaf_waves=12),
+    "persistent": dict(persistent_leaf=True),
 }
 
 

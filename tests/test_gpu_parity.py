@@ -551,74 +551,6 @@ def test_leaf_launch_reads_the_raw_batch(hip_device, B):
     assert not b.reads_batch_directly(B) or b._bindings[B].x_last is not None
 
 
-@pytest.mark.parametrize("B", [1, 33, 1000, 4096, 5000])
-@pytest.mark.parametrize("direct", [True, False])
-def test_tail_walked_by_the_leaf_launch(hip_device, B, direct):
-    """`merge_tail=True`: the trailing few-fold levels are walked by the resident workgroups of the persistent leaf
-    launch after their segments (ck_leaf.hip, leaf_tail_phase: write-through roots, arrival counter, claimed 16-row tiles)
-    -- the same arithmetic per fold as the 16-row tail launch: every tail layer output, the circuit output and the fused
-    log-likelihood sum are bit-identical to the two-launch form; repeated calls reuse the arrival / claim state; with
-    `keep_layer_outputs=False` only the circuit output is stored.  B = 5000: more 16-row tiles than workgroups."""
-    from cirkit_amd.circuit import HipCircuit
-
-    plan, tensors, g = load_case("cfg2_qt784")
-    kw = dict(device=hip_device, persistent_leaf=True, direct_input=direct, inlaunch_params=False)
-    a = HipCircuit(plan, tensors, merge_tail=False, params_at_end=False, **kw)
-    b = HipCircuit(plan, tensors, merge_tail=True, **kw)
-    c = HipCircuit(plan, tensors, merge_tail=True, keep_layer_outputs=False, **kw)
-    assert b._bind(B).tail_in_leaf and not a._bind(B).tail_in_leaf
-    assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1
-    assert b.kernel_label(b._groups[0].root, B).endswith("true, false, false>")  # (.., TAIL, PARAMS, XP)
-    for seed in range(3):
-        x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(7 * B + seed))
-        x[::5, ::7] = -1
-        x = x.to(hip_device)
-        la, lb = a.layer_outputs(x), b.layer_outputs(x)
-        for j in b._tail:
-            assert torch.equal(la[j], lb[j]), j
-        ya = a(x).clone()
-        assert torch.equal(ya, b(x)) and torch.equal(ya, c(x))
-        sa = a.log_likelihood_sum(x).clone()
-        assert torch.equal(sa, b.log_likelihood_sum(x)) and torch.equal(sa, c.log_likelihood_sum(x))
-        assert torch.equal(sa, b.log_likelihood_sum(x))  # (the ticket and the claim epochs are ready for the next launch)
-
-
-@pytest.mark.parametrize("B", [33, 1000, 4096])
-def test_leaf_launch_evaluates_its_parameters(hip_device, B):
-    """`inlaunch_params=True`: the persistent leaf launch builds the Categorical log-tables (pushed through their dense
-    folds), softmaxes the weights of its levels straight into LDS and deals out the 32-wide softmaxes of the layers behind
-    it -- the jobs of the prologue launch (ck_param_softmax_batch), run by the same device functions: tables, log scales,
-    tail weights and circuit outputs are bit-identical to the two-launch form, also after the parameters have changed
-    (nothing may be served from a cache that still holds the previous step's tables), and no parameter launch is left."""
-    from cirkit_amd.circuit import HipCircuit
-
-    plan, tensors, g = load_case("cfg2_qt784")
-    tensors = {k: np.array(v, copy=True) for k, v in tensors.items()}
-    kw = dict(device=hip_device, persistent_leaf=True)
-    a = HipCircuit(plan, tensors, inlaunch_params=False, params_at_end=False, **kw)
-    b = HipCircuit(plan, tensors, inlaunch_params=True, **kw)
-    assert b._bind(B).params_in_leaf and not a._bind(B).params_in_leaf
-    assert b.num_launches_ll(B) == a.num_launches_ll(B) - 1 and b._inlaunch["rest"] is None
-    assert b.kernel_label(b._groups[0].root, B).endswith("true, false>")  # (.., PARAMS, XP)
-    rng = np.random.default_rng(B)
-    for step in range(4):
-        x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(11 * B + step))
-        x[::5, ::7] = -1
-        x = x.to(hip_device)
-        ya, yb = a(x).clone(), b(x).clone()
-        ra, rb = a._groups[0].root, b._groups[0].root
-        assert torch.equal(a._group_dev[ra][1], b._group_dev[rb][1])  # the (F, C + 1, 32) linear tables
-        assert torch.equal(a._group_dev[ra][3], b._group_dev[rb][3])  # their log scales
-        for j in b._tail:
-            assert torch.equal(a.layers[j]._w, b.layers[j]._w), j
-        assert torch.equal(ya, yb)
-        assert torch.equal(a.log_likelihood_sum(x), b.log_likelihood_sum(x))
-        for name in list(tensors)[:4]:  # new parameter values for the next step (the same for both circuits)
-            new = a.store[name].cpu().numpy() + 0.1 * rng.standard_normal(tuple(a.store[name].shape)).astype(np.float32)
-            a.store.set(name, new)
-            b.store.set(name, new)
-
-
 def test_forward_only_mode_keeps_results(hip_device):
     """`keep_layer_outputs=False` / `log_likelihood_sum`: the 32-unit folds of the tail that nobody outside it reads are
     not stored (ck_tail16_fold.skip_store: 24.7 MB per 4096-row batch at the north-star configuration) -- circuit outputs
