@@ -93,6 +93,7 @@ class LeafBwdLaunch(C.Structure):
         ("unit_tab", C.c_void_p),
         ("work", C.c_void_p),
         ("n_seg", C.c_int32), ("n_wg", C.c_int32), ("B", C.c_int32), ("C", C.c_int32), ("D", C.c_int32), ("leaf", C.c_int32),
+        ("waves", C.c_int32), ("gin_rowmajor", C.c_int32),
         ("gin", C.c_void_p),
         ("y_p", C.c_void_p),
         ("y_q", C.c_void_p),
@@ -192,8 +193,12 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_gaussian_product_logz": [_p, _p, _p, _p, _p, _l, _i, _i, _p],
     "ck_segment_add_rows": [_p, _p, _p, _p, _p, _i, _l, _p],
     "ck_param_scatter_add_folds": [_p, _p, _p, _l, _l, _p],
-    "ck_categorical_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_categorical_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "ck_param_softmax_bwd_batch": [_p, _i, _i, _p],
+    "ck_fill_latch": [_p, _l, _f, _p, _p, _p, _p],
     "ck_leaf_walk_bwd": [C.POINTER(LeafBwdLaunch), _p],
+    "ck_table_dense_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "ck_leaf_walk_bwd_redo": [_p, _p, _p, _i, _i, _i, _p, C.POINTER(C.c_int32), _i, _p, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _p, _p, _p, _i, _p],
     "ck_param_softmax_bwd": [_p, _p, _p, _l, _i, _i, _p],
     "ck_param_log_table_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],
     "ck_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p, _p],

@@ -492,8 +492,9 @@ class HipCircuit:
         bd.direct = self._direct_input(B)
         bd.params_at_end = self._params_at_end(B)
         bd.program = self._record(bd, with_ll=False)  # the launch list, recorded once
-        if bd.direct and self.use_graph and capi.load().ck_program_num_ops(bd.program) > self.graph_min_launches:
-            # a hipGraph keeps the pointers of its capture: long launch lists read the staged copy of the batch
+        # a hipGraph keeps the pointers of its capture: long launch lists read the staged copy of the batch.  The list of
+        # `log_likelihood_sum` (recorded on first use, with this binding's `direct`) can be one launch longer: decide on that
+        if bd.direct and self.use_graph and capi.load().ck_program_num_ops(bd.program) + 1 > self.graph_min_launches:
             capi.load().ck_program_destroy(bd.program)
             bd.direct = False
             bd.program = self._record(bd, with_ll=False)
@@ -1180,14 +1181,15 @@ class HipCircuit:
         )
 
     def _keep_buffers(self, g: SubtreeGroup, bd: _Binding):
-        """`keep_levels`: ([(F_l, B, 32) per fused level], (F_root, tiles) int32 flags) of group g in this binding, else None."""
+        """`keep_levels`: ([(F_l, tiles, 1024) tile-native per fused level], (F_root, tiles) int32 flags) of group g in this
+        binding, else None."""
         if not self.keep_levels:
             return None
         hit = bd.keep.get(g.root)
         if hit is None:
             tiles = (bd.B + 31) // 32
             hit = bd.keep[g.root] = (
-                [torch.empty((self.layers[j].num_folds, bd.B, 32), dtype=torch.float32, device=self.device) for j in g.levels],
+                [torch.empty((self.layers[j].num_folds, tiles, 1024), dtype=torch.float32, device=self.device) for j in g.levels],
                 torch.zeros(self.layers[g.root].num_folds * tiles, dtype=torch.int32, device=self.device))
         return hit
 

@@ -209,6 +209,38 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// One output unit over 32 inputs (the scalar root of a circuit, CK_SUM_PROD / H = 1): a half-wave per batch row, lane = input
+// unit; dW accumulates in the lane's register over the rows of the block and leaves with one atomic per lane and half-wave.
+__global__ void __launch_bounds__(256)
+    sum_lse_bwd_scalar32(const float* __restrict__ arena, float* __restrict__ garena, const int64_t* __restrict__ row_off,
+                         const int64_t* __restrict__ grow_off, const float* __restrict__ w, const float* __restrict__ gout,
+                         float* __restrict__ dw, int H, int B, int rows_per_block, int accumulate) {
+  const int f = blockIdx.y, i = threadIdx.x & 31, hw = threadIdx.x >> 5;  // 8 half-waves per block
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t* gro = grow_off + static_cast<int64_t>(f) * H;
+  const float wi = w[static_cast<int64_t>(f) * kK + i];
+  float dwi = 0.f;
+  const int b0 = blockIdx.x * rows_per_block;
+  for (int b = b0 + hw; b < min(b0 + rows_per_block, B); b += 8) {
+    float v = 0.f;
+    for (int h = 0; h < H; ++h) v += arena[ro[h] + static_cast<int64_t>(b) * kK + i];
+    float m = v;
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 32));
+    m = ck::clamp_finite(m);
+    const float e = expf(v - m);
+    float y = wi * e;
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) y += __shfl_xor(y, s, 32);
+    const float go = gout[static_cast<int64_t>(f) * B + b];
+    const float gy = (y > 0.f && go != 0.f) ? go / y : 0.f;
+    dwi = fmaf(gy, e, dwi);
+    const float gv = wi * e * gy;
+    for (int h = 0; h < H; ++h) grad_store(garena + gro[h] + static_cast<int64_t>(b) * kK + i, gv, accumulate);
+  }
+  if (dwi != 0.f) atomicAdd(dw + static_cast<int64_t>(f) * kK + i, dwi);
+}
+
 // K = 32 product-type sum layers (dense / CP-T) on the register tile of ck_tile.h: three exact fp32
 // MFMA contractions per 32-row tile --  y = W e,  gv = e * (W^T gy),  dW += gy^T e.  The last one
 // contracts over the batch rows, so gy and e are transposed through LDS (8 KB per wave) into the
@@ -582,7 +614,7 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     categorical_bwd_kernel(const float* __restrict__ gout, const int32_t* __restrict__ gfold, const int32_t* __restrict__ xt,
                            const int64_t* __restrict__ scope, float* __restrict__ dtable, int B, int K,
-                           int C) {
+                           int C, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float hist[];  // [C+1][K] (row C: marginalised rows)
   const int f = blockIdx.x;
   for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) hist[i] = 0.f;
@@ -630,7 +662,7 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   float* dst = dtable + static_cast<int64_t>(f) * (C + 1) * K;
-  for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) dst[i] += hist[i];
+  for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) dst[i] = accumulate ? dst[i] + hist[i] : hist[i];
 }
 
 // The same reduction without floating-point atomics in the inner loop (LDS float atomics retire ~4 cycles per lane on
@@ -642,12 +674,13 @@ __global__ void __launch_bounds__(256)
 constexpr int kCatChunk = 4096;  // rows sorted at a time
 __global__ void __launch_bounds__(1024)
     categorical_bwd_sorted_kernel(const float* __restrict__ gout, const int32_t* __restrict__ gfold, const int32_t* __restrict__ xt,
-                                  const int64_t* __restrict__ scope, float* __restrict__ dtable, int B, int K, int C) {
+                                  const int64_t* __restrict__ scope, float* __restrict__ dtable, int B, int K, int C, int accumulate,
+                                  const int32_t* __restrict__ fold_order) {
   extern __shared__ __attribute__((aligned(16))) float hist[];  // [C+1][K], then the int arrays below
   int* start = reinterpret_cast<int*>(hist + (C + 1) * K);      // [C+2] exclusive prefix of the counts
   int* cur = start + (C + 2);                                   // [C+1] scatter cursors
   int* order = cur + (C + 1);                                   // [kCatChunk] row numbers grouped by category
-  const int f = blockIdx.x;
+  const int f = fold_order != nullptr ? fold_order[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int k_in = lane & 31, slot = lane >> 5;
   for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) hist[i] = 0.f;
@@ -717,7 +750,7 @@ __global__ void __launch_bounds__(1024)
     __syncthreads();
   }
   float* dst = dtable + static_cast<int64_t>(f) * (C + 1) * K;
-  for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) dst[i] += hist[i];
+  for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) dst[i] = accumulate ? dst[i] + hist[i] : hist[i];
 }
 
 // softmax backward over rows: dtheta = W * (dW - sum(W * dW));  W given row-major (rows, len).
@@ -739,6 +772,35 @@ __global__ void __launch_bounds__(256)
     else
       dtheta[row * len + i] = g;
   }
+}
+
+// The same for a list of parameter tensors in ONE launch (a training step has one per sum layer): block b belongs to the job
+// with first_block <= b < first_block of the next one, 4 rows per block.
+struct SoftmaxBwdJob {
+  const float* w;
+  const float* dw;
+  float* dtheta;
+  int64_t rows;
+  int32_t len;
+  int32_t first_block;
+};
+__global__ void __launch_bounds__(256) softmax_bwd_batch_kernel(const SoftmaxBwdJob* __restrict__ jobs, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {  // last job whose first block is <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= static_cast<int>(blockIdx.x)) lo = mid;
+    else hi = mid - 1;
+  }
+  const SoftmaxBwdJob j = jobs[lo];
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x - j.first_block) * 4 + (threadIdx.x >> 6);
+  if (row >= j.rows) return;
+  const float* wr = j.w + row * j.len;
+  const float* dr = j.dw + row * j.len;
+  float dot = 0.f;
+  for (int i = lane; i < j.len; i += 64) dot = fmaf(wr[i], dr[i], dot);
+  dot = ck::wave_sum(dot);
+  for (int i = lane; i < j.len; i += 64) j.dtheta[row * j.len + i] = wr[i] * (dr[i] - dot);
 }
 
 // Categorical parameter backward: table (F, C+1, K) = log softmax_C(theta (F, K, C)) transposed.
@@ -999,7 +1061,19 @@ __global__ void __launch_bounds__(256)
     y[i] = fmaf(a, x[i], y[i]);
 }
 
-__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, int64_t n, float v) {
+// latch (nullable triple): *step = *src, *sticky |= *src, *src = 0 -- the validation flag a forward raised becomes this
+// step's flag (what the optimizer launch reads) and the sticky one (what check_inputs() reports) in the launch that zeroes
+// the gradient buffers anyway
+__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, int64_t n, float v, int32_t* __restrict__ src,
+                                                    int32_t* __restrict__ step, int32_t* __restrict__ sticky) {
+  if (src != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int32_t f = *src;
+    *step = f;
+    if (f != 0) {
+      *sticky |= f;
+      *src = 0;
+    }
+  }
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x)
     p[i] = v;
@@ -1064,7 +1138,19 @@ int ck_fill_f32(float* p, int64_t n, float value, void* stream) {
   dim3 grid(grid1(n)), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(fill_kernel, grid, block, 0, s, p, n, value);
+        hipLaunchKernelGGL(fill_kernel, grid, block, 0, s, p, n, value, static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                           static_cast<int32_t*>(nullptr));
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_fill_latch(float* p, int64_t n, float value, int32_t* src, int32_t* step_flag, int32_t* sticky, void* stream) {
+  CK_REQUIRE(p != nullptr && n > 0 && src && step_flag && sticky, "ck_fill_latch: bad arguments");
+  dim3 grid(grid1(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(fill_kernel, grid, block, 0, s, p, n, value, src, step_flag, sticky);
         return hipGetLastError();
       },
       stream);
@@ -1196,6 +1282,17 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
   CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD || mode == CK_SUM_KRON, "ck_sum_lse_bwd: unsupported mode %d", mode);
   CK_REQUIRE(accumulate >= 0 && accumulate <= 2, "ck_sum_lse_bwd: accumulate must be 0, 1 or 2");
   CK_REQUIRE(F <= 65535, "ck_sum_lse_bwd: F=%d exceeds grid.y", F);
+  if ((mode == CK_SUM_PROD || H == 1) && Ki == kK && Ko == 1 && !g_bwd_force_generic) {
+    const int rpb = B >= 8 * 2048 ? 64 : 8;  // rows per block (8 half-waves): one row each unless the batch is huge -- the launch is a chain of
+                                              // dependent loads and shuffles per row, so rows in flight are what matters
+    dim3 grid((B + rpb - 1) / rpb, F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          hipLaunchKernelGGL(sum_lse_bwd_scalar32, grid, block, 0, s, arena, garena, row_off, grow, w, gout, dw, H, B, rpb, accumulate);
+          return hipGetLastError();
+        },
+        stream);
+  }
   if ((mode == CK_SUM_PROD || H == 1) && Ki == kK && Ko == kK && !g_bwd_force_generic && ck::aligned16(arena) &&
       ck::aligned16(garena) && ck::aligned16(w) && ck::aligned16(gout)) {
     const int tiles = (B + 31) / 32;
@@ -1306,7 +1403,7 @@ int ck_hadamard_bwd(float* garena, const int64_t* row_off, const float* gout, in
 }
 
 int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* xt, const int64_t* scope, float* dtable, int F,
-                       int B, int K, int C, void* stream) {
+                       int B, int K, int C, int accumulate, const int32_t* fold_order, void* stream) {
   CK_REQUIRE(gout && xt && scope && dtable, "ck_categorical_bwd: null pointer");
   CK_REQUIRE(F > 0 && B > 0 && K > 0 && C > 0, "ck_categorical_bwd: non-positive size");
   const size_t lds = static_cast<size_t>(C + 1) * K * sizeof(float);
@@ -1321,11 +1418,12 @@ int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* x
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_sorted));
             if (e != hipSuccess) return e;
           }
-          hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds_sorted, s, gout, gfold, xt, scope, dtable, B, K, C);
+          hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds_sorted, s, gout, gfold, xt, scope, dtable, B, K, C, accumulate, fold_order);
           return hipGetLastError();
         },
         stream);
   }
+  CK_REQUIRE(fold_order == nullptr, "ck_categorical_bwd: fold_order is only read by the sorted launch (K %% 32 == 0, B >= 256)");
   dim3 grid(F), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
@@ -1334,7 +1432,7 @@ int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* x
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
           if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(categorical_bwd_kernel, grid, block, lds, s, gout, gfold, xt, scope, dtable, B, K, C);
+        hipLaunchKernelGGL(categorical_bwd_kernel, grid, block, lds, s, gout, gfold, xt, scope, dtable, B, K, C, accumulate);
         return hipGetLastError();
       },
       stream);
@@ -1348,6 +1446,18 @@ int ck_param_softmax_bwd(const float* w, const float* dw, float* dtheta, int64_t
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(softmax_bwd_rows_kernel, grid, block, 0, s, w, dw, dtheta, rows, len, accumulate);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_softmax_bwd_batch(const ck_softmax_bwd_job* jobs, int n_jobs, int n_blocks, void* stream) {
+  CK_REQUIRE(jobs != nullptr && n_jobs > 0 && n_blocks > 0, "ck_param_softmax_bwd_batch: bad arguments");
+  static_assert(sizeof(SoftmaxBwdJob) == sizeof(ck_softmax_bwd_job), "job layout");
+  dim3 grid(static_cast<unsigned>(n_blocks)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(softmax_bwd_batch_kernel, grid, block, 0, s, reinterpret_cast<const SoftmaxBwdJob*>(jobs), n_jobs);
         return hipGetLastError();
       },
       stream);

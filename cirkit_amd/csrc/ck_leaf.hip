@@ -50,7 +50,8 @@ struct LeafArgs {
   int D;
   int32_t* bad_flag;  // XRAW: raised (atomicOr 1) when a row holds an illegal value; nullptr = rows are not checked
   int x_pairs;        // XRAW: leaves 2j, 2j + 1 of every root read adjacent, 16-byte aligned variables (one load per pair)
-  // KEEP (training forward): the linear tile of every node is stored as well -- keep[l - 1]: (F_l, B, 32), the value the NEXT
+  // KEEP (training forward): the linear tile of every node is stored as well -- keep[l - 1]: (F_l, tiles, 1024) in tile-native
+  // order (ck_tile.h tile_store_native; rows beyond B of the last tile hold whatever their lanes computed), the value the NEXT
   // level multiplies (the backward, ck_leaf_bwd.hip, needs a level's tiles to be consistent with each other, not their log
   // scales); tiles whose walk left the linear range are marked in `redo` (their kept tiles mean nothing)
   float* keep[kMaxDepthP];
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       static_for<0, steps_after(i)>([&](auto lc) {
         constexpr int l = decltype(lc)::value, k = steps_before(i) + l;
         const int fold = __builtin_amdgcn_readfirstlane(node_fold[k]);
-        if constexpr (KEEP) keep_base[k] = a.keep[l] + static_cast<int64_t>(fold) * a.B * kK;
+        if constexpr (KEEP) keep_base[k] = a.keep[l] + static_cast<int64_t>(fold) * ((a.B + 31) >> 5) * 1024;  // (F_l, tiles, 1024)
         // lane's 16 bytes of chunk q: tiled, dword 256 q + 4 lane; row-major, W[lane & 31][8 q + 4 (lane >> 5) ..] (ck_tile.h)
         const float* src = a.w[l] + static_cast<int64_t>(fold) * 1024 + (a.w_rowmajor ? (lane & 31) * 32 + 4 * (lane >> 5) : lane * 4);
         const int qstride = a.w_rowmajor ? 8 : 256;
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
     for (; tile < chunk_end; tile += WAVES, ++nth, bad_cur = bad_next) {
       const int b = tile * 32 + b_in;
       const bool live = b < a.B;
-      const int koff = b * kK + 4 * kh;  // (KEEP) this lane's part of a node's (B, 32) block
+      const int koff = tile * 1024;  // (KEEP) this tile's block in a node's (tiles, 1024) array
       float stack[D][16], sstack[D];
       float cur[16], cs = 0.f, sprev = 0.f;
       bool bad = false;
@@ -483,9 +484,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             }
             __builtin_amdgcn_sched_barrier(0);
             contract_linear<CK_W_TILED_F32>(wcur, cur);
-            if constexpr (KEEP) {
-              if (live) tile_store(keep_base[step] + koff, cur);
-            }
+            if constexpr (KEEP) tile_store_native(keep_base[step] + koff, lane, cur);
           });
           if constexpr (steps_after(o) < D) {  // left sibling at this level: wait for the right one
             constexpr int l = steps_after(o);
@@ -564,9 +563,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           // v_pk_mul_f32 that follows an MFMA back into two multiplies)
           __builtin_amdgcn_sched_barrier(0);
           contract_linear<CK_W_TILED_F32>(wcur, cur);
-          if constexpr (KEEP) {
-            if (live) tile_store(keep_base[step] + koff, cur);
-          }
+          if constexpr (KEEP) tile_store_native(keep_base[step] + koff, lane, cur);
         });
         if constexpr (steps_after(i) < D) {  // left sibling at this level: wait for the right one
           constexpr int l = steps_after(i);
@@ -823,6 +820,9 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
         LeafArgs b = a;
         if (slot != nullptr) b.x64 = static_cast<const int64_t*>(*slot);  // the batch of THIS replay (ck_program_set_input)
         if (b.x64 == nullptr) return hipErrorInvalidValue;
+        // (the 16-byte loads of the pair form need the batch of THIS replay 16-byte aligned: a view with an odd storage
+        // offset takes the 8-byte loads)
+        if ((reinterpret_cast<uintptr_t>(b.x64) & 15u) != 0) b.x_pairs = 0;
         return launch_depth<true>(b, depth, waves, is_signed, n_roots, grid, s);
       },
       stream);

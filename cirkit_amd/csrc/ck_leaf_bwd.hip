@@ -24,6 +24,7 @@
 // Tiles whose forward walk left the linear range (LeafArgs::redo) are skipped here and taken by leaf_bwd_redo_kernel:
 // the whole subtree of that (root, tile) again in log space -- the reference's arithmetic -- forward and backward.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ck_internal.h"
 #include "ck_tile.h"
@@ -34,18 +35,25 @@ struct BwdArgs {
   const int32_t* unit_tab;  // (n_p, 16): gin fold, P fold, Q0 fold, Q1 fold, c0..c3 (fold of the child level / table fold), v0..v3 (variables), root
   const int32_t* work;      // (n_seg, 4): row of unit_tab, first tile, end tile, 0
   int n_seg, B, C, D;
-  const float* gin;  // (F, B, 32) log-space gradient tiles, indexed by unit_tab[.., 0]
-  const float* y_p;  // kept linear tiles of P's level
+  const float* gin;  // log-space gradient tiles, indexed by unit_tab[.., 0]: (F, tiles, 1024) tile-native, or (gin_rowmajor) (F, B, 32)
+  const float* y_p;  // kept linear tiles of P's level, (F_l, tiles, 1024) tile-native (ck_tile.h)
   const float* y_q;  // ... of the level below
   const float* y_c;  // !LEAF: ... of the level below that
+  int gin_rowmajor;
   const float* table;    // LEAF: (F0, C + 1, 32) linear table rows
   const int64_t* x64;    // LEAF: raw (B, D) batch
   const float* w_p;      // (F_p, 32, 32) row-major linear weights of P's level
   const float* w_q;
   float* dw_p;           // += gy^T e
   float* dw_q;
-  float* gout;           // (F_q, B, 32): the gradient tile node Q leaves for its two children
+  float* gout;           // the gradient tile node Q leaves for its two children: (F_q, tiles, 1024) tile-native; LEAF: (F_q, B, 32) row-major
+                         // (what the Categorical scatter reads row by row)
   const int32_t* redo;   // (n_roots, tiles) flags of the forward, or nullptr
+#ifdef CK_BWD_STAMPS
+  long long* stamps;     // (scripts/bwd_stamps.py) shader-clock stamps: [wave][unit < 16][8] of workgroup stamp_wg
+  int stamp_wg;
+#endif
+  int exp;               // timing experiments (CK_BWD_EXP, wrong results): 1 no dW contraction, 2 no W^T contraction, 4 every tile reads rows 0..31, 8 no stores
 };
 
 constexpr int kUnitTab = 16;
@@ -114,16 +122,37 @@ __device__ __forceinline__ void forward_product(float (&cur)[16], const float (&
   linear_product<RESCALE>(cur, sib, s, 0.f, bad);
 }
 
-template <bool LEAF>
-__global__ void __launch_bounds__(512) leaf_bwd_kernel(const BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float wt_lds[3 * 1024];      // W^T of P, Q0, Q1 ("transposed tiled")
-  __shared__ __attribute__((aligned(16))) float scratch[8 * 2 * 1024];  // per wave: the gy and e tiles of a dW contraction
+// WAVES = 8: two waves per SIMD, a unit's loads issued at its start (the other wave computes meanwhile).  Measured at the
+// north-star configuration the launches are LATENCY-bound in that form (scripts/exp_leaf_bwd.sh: without any MFMA 224 of 245 us;
+// loads, stores and the rest add up): a unit is ~15 us of dependent memory round trips against 3.4 us of instructions, and
+// two units in flight per SIMD do not cover that.
+// WAVES = 4 (one wave per SIMD, up to 512 registers): software-pipelined -- the raw tiles of unit k + 1 travel while unit k
+// computes.  An iteration first CONSUMES the raw registers of its unit (gy = g / y, the three products: 96 registers), then
+// refills the same raw registers with the loads of the next unit, stores the previous unit's results (carried in registers, so
+// that no store is younger than the loads the next iteration waits for first: the compiler's wait there is vmcnt(0)), and
+// computes.  Marked units are computed with every row dead (no contribution, nothing stored).
+template <bool LEAF, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float wt_lds[3 * 1024];          // W^T of P, Q0, Q1 ("transposed tiled")
+  __shared__ __attribute__((aligned(16))) float scratch[WAVES * 2 * 1024];  // per wave: the gy and e tiles of a dW contraction
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b_in = lane & 31, kh = lane >> 5;
   float* const s_gy = scratch + wave * 2048;
   float* const s_e = s_gy + 1024;
   const int n_tiles = (a.B + 31) >> 5;
+#ifdef CK_BWD_STAMPS
+  int stamp_unit = 0;
+#define CK_BSTAMP(id)                                                                                              \
+  do {                                                                                                             \
+    if (a.stamps != nullptr && static_cast<int>(blockIdx.x) == a.stamp_wg && stamp_unit < 16) {                    \
+      const long long c_ = clock64();                                                                              \
+      if (lane == 0) a.stamps[(wave * 16 + stamp_unit) * 8 + (id)] = c_;                                           \
+    }                                                                                                              \
+  } while (0)
+#else
+#define CK_BSTAMP(id)
+#endif
   for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
     const int p = a.work[4 * seg], tile_begin = a.work[4 * seg + 1], tile_end = a.work[4 * seg + 2];
     const int32_t* ut = a.unit_tab + static_cast<int64_t>(p) * kUnitTab;
@@ -135,7 +164,7 @@ __global__ void __launch_bounds__(512) leaf_bwd_kernel(const BwdArgs a) {
     // W^T of the three nodes: row-major W[o][i] -> dword (o >> 3) * 256 + (i + 32 ((o >> 2) & 1)) * 4 + (o & 3)
     for (int n = 0; n < 3; ++n) {
       const float* w = n == 0 ? a.w_p + static_cast<int64_t>(p_fold) * 1024 : a.w_q + static_cast<int64_t>(q_fold[n - 1]) * 1024;
-      for (int idx = threadIdx.x; idx < 1024; idx += 512) {
+      for (int idx = threadIdx.x; idx < 1024; idx += WAVES * 64) {
         const int o = idx >> 5, i = idx & 31;
         wt_lds[n * 1024 + (o >> 3) * 256 + (i + 32 * ((o >> 2) & 1)) * 4 + (o & 3)] = w[idx];
       }
@@ -146,52 +175,154 @@ __global__ void __launch_bounds__(512) leaf_bwd_kernel(const BwdArgs a) {
     for (int n = 0; n < 3; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dw[n][r] = 0.f;
-    const float* gin = a.gin + static_cast<int64_t>(gin_fold) * a.B * kK;
-    const float* yp = a.y_p + static_cast<int64_t>(p_fold) * a.B * kK;
-    for (int tile = tile_begin + wave; tile < tile_end; tile += 8) {
-      if (a.redo != nullptr && a.redo[static_cast<int64_t>(root) * n_tiles + tile] != 0) continue;  // (leaf_bwd_redo_kernel's)
-      const int b = tile * 32 + b_in;
-      const bool live = b < a.B;
-      const int bl = live ? b : a.B - 1;
-      const int64_t off = static_cast<int64_t>(bl) * kK + 4 * kh;
-      float g[16], y[16], yq0[16], yq1[16];
-      tile_load(gin + off, g);
-      tile_load(yp + off, y);
-      tile_load(a.y_q + static_cast<int64_t>(q_fold[0]) * a.B * kK + off, yq0);
-      tile_load(a.y_q + static_cast<int64_t>(q_fold[1]) * a.B * kK + off, yq1);
-      // the four bottom tiles: table rows of the four leaves (LEAF), kept tiles of the level below otherwise
-      const float* cptr[4];
+    const int64_t fold_stride = static_cast<int64_t>(n_tiles) * 1024;  // floats per fold of a tile-native array
+    const float* gin = a.gin + (a.gin_rowmajor ? static_cast<int64_t>(gin_fold) * a.B * kK : gin_fold * fold_stride);
+    const float* yp = a.y_p + p_fold * fold_stride;
+    const float* yq0p = a.y_q + q_fold[0] * fold_stride;
+    const float* yq1p = a.y_q + q_fold[1] * fold_stride;
+    // marks of the segment's tiles (the units leaf_bwd_redo_kernel takes): one load per lane, then a bit per tile of this wave
+    uint64_t marked = 0;  // bit k: tile tile_begin + wave + WAVES k
+    if (a.redo != nullptr) {
+      const int tl = tile_begin + wave + WAVES * lane;
+      marked = __ballot(tl < tile_end && a.redo[static_cast<int64_t>(root) * n_tiles + tl] != 0);
+    }
+    auto is_marked = [&](int nth, int tile) {
+      return nth < 64 ? ((marked >> nth) & 1) != 0 : (a.redo != nullptr && a.redo[static_cast<int64_t>(root) * n_tiles + tile] != 0);
+    };
+    // the raw tiles of a unit: batch values (LEAF), gradient tile, kept tiles of P and Q0 / Q1, the four bottom tiles
+    uint32_t xlo[4];
+    float g[16], y[16], yq0[16], yq1[16], c[4][16];
+    auto issue_a = [&](int tile) mutable {  // everything whose address is known: the batch values first (they return first)
+      if (a.exp & 4) tile = 0;
+      const int bl = min(tile * 32 + b_in, a.B - 1);
+      const int64_t blk = static_cast<int64_t>(tile) * 1024;
+      if constexpr (LEAF) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (LEAF) {
-          const uint32_t lo = static_cast<uint32_t>(a.x64[static_cast<int64_t>(bl) * a.D + var[i]]);
-          const uint32_t row = min(lo, static_cast<uint32_t>(a.C));  // negative: the integral row (as the forward)
-          cptr[i] = a.table + (static_cast<int64_t>(c_fold[i]) * (a.C + 1) + row) * kK + 4 * kh;
-        } else {
-          cptr[i] = a.y_c + static_cast<int64_t>(c_fold[i]) * a.B * kK + off;
+        for (int i = 0; i < 4; ++i) xlo[i] = static_cast<uint32_t>(a.x64[static_cast<int64_t>(bl) * a.D + var[i]]);
+      }
+      if (a.gin_rowmajor) tile_load(gin + static_cast<int64_t>(bl) * kK + 4 * kh, g);
+      else tile_load_native(gin + blk, lane, g);
+      tile_load_native(yp + blk, lane, y);
+      tile_load_native(yq0p + blk, lane, yq0);
+      tile_load_native(yq1p + blk, lane, yq1);
+      if constexpr (!LEAF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile_load_native(a.y_c + c_fold[i] * fold_stride + blk, lane, c[i]);
+      }
+    };
+    auto issue_b = [&]() {  // LEAF: the gathered table rows, once the batch values are here
+      if constexpr (LEAF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t row = min(xlo[i], static_cast<uint32_t>(a.C));  // negative: the integral row (as the forward)
+          tile_load(a.table + (static_cast<int64_t>(c_fold[i]) * (a.C + 1) + row) * kK + 4 * kh, c[i]);
         }
       }
-      float gy[16], e[16], gq[16];
-      // ---- node P
+    };
+    auto node = [&](int n, const float (&gy)[16], const float (&e)[16], float (&out)[16]) {
+      if (!(a.exp & 1)) dw_accumulate(dw[n], s_gy, s_e, b_in, kh, gy, e);
+      if (!(a.exp & 2)) child_gradient(wt_lds + n * 1024, lane, gy, e, out);
+      else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) e[r] = yq1[r];
-      forward_product<true>(e, yq0);
-      grad_over_y(g, y, live, gy);
-      dw_accumulate(dw[0], s_gy, s_e, b_in, kh, gy, e);
-      child_gradient(wt_lds, lane, gy, e, gq);
-      // ---- nodes Q0, Q1
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        float c0[16];
-        tile_load(cptr[2 * n], c0);
-        tile_load(cptr[2 * n + 1], e);
-        forward_product<!LEAF>(e, c0);
-        grad_over_y(gq, n == 0 ? yq0 : yq1, live, gy);
-        dw_accumulate(dw[1 + n], s_gy, s_e, b_in, kh, gy, e);
-        float gc[16];
-        child_gradient(wt_lds + (1 + n) * 1024, lane, gy, e, gc);
-        if (live) tile_store(a.gout + static_cast<int64_t>(q_fold[n]) * a.B * kK + static_cast<int64_t>(b) * kK + 4 * kh, gc);
+        for (int r = 0; r < 16; ++r) out[r] = e[r] * gy[r];
       }
+    };
+    auto store = [&](int tile, const float (&r0)[16], const float (&r1)[16]) {
+      if (a.exp & 8) return;
+      if constexpr (LEAF) {
+        const int b = tile * 32 + b_in;
+        if (b < a.B) {
+          tile_store(a.gout + static_cast<int64_t>(q_fold[0]) * a.B * kK + static_cast<int64_t>(b) * kK + 4 * kh, r0);
+          tile_store(a.gout + static_cast<int64_t>(q_fold[1]) * a.B * kK + static_cast<int64_t>(b) * kK + 4 * kh, r1);
+        }
+      } else {
+        tile_store_native(a.gout + q_fold[0] * fold_stride + static_cast<int64_t>(tile) * 1024, lane, r0);
+        tile_store_native(a.gout + q_fold[1] * fold_stride + static_cast<int64_t>(tile) * 1024, lane, r1);
+      }
+    };
+    if constexpr (WAVES == 8) {
+      int nth = 0;
+      for (int tile = tile_begin + wave; tile < tile_end; tile += WAVES, ++nth) {
+        if (is_marked(nth, tile)) continue;
+        const bool live = tile * 32 + b_in < a.B;
+        CK_BSTAMP(0);
+        issue_a(tile);
+        issue_b();
+        __builtin_amdgcn_sched_barrier(0);
+        CK_BSTAMP(1);
+        float gy[16], e[16], gq[16], r0[16], r1[16];
+        grad_over_y(g, y, live, gy);
+        CK_BSTAMP(2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e[r] = yq1[r];
+        forward_product<true>(e, yq0);
+        node(0, gy, e, gq);
+        CK_BSTAMP(3);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) e[r] = c[2 * n + 1][r];
+          forward_product<!LEAF>(e, c[2 * n]);
+          grad_over_y(gq, n == 0 ? yq0 : yq1, live, gy);
+          node(1 + n, gy, e, n == 0 ? r0 : r1);
+          CK_BSTAMP(4 + n);
+        }
+        store(tile, r0, r1);
+        CK_BSTAMP(6);
+#ifdef CK_BWD_STAMPS
+        ++stamp_unit;
+#endif
+      }
+    } else {
+      const int first = tile_begin + wave;
+      const int n_mine = first < tile_end ? (tile_end - first + WAVES - 1) / WAVES : 0;
+      float r0[16], r1[16];
+      int rtile = -1;  // the unit whose results r0 / r1 hold (-1: none to store)
+      if (n_mine > 0) {
+        issue_a(first);
+        issue_b();
+      }
+      for (int k = 0; k < n_mine; ++k) {
+        const int tile = first + k * WAVES;
+        const bool live = tile * 32 + b_in < a.B && !is_marked(k, tile);
+        CK_BSTAMP(0);
+        // consume the raw tiles of this unit (the first touch waits for all of them; nothing younger is in flight)
+        float gyp[16], ep[16], eq0[16], eq1[16], dq0[16], dq1[16];
+        grad_over_y(g, y, live, gyp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ep[r] = yq1[r];
+          dq0[r] = yq0[r];
+          dq1[r] = yq1[r];
+          eq0[r] = c[1][r];
+          eq1[r] = c[3][r];
+        }
+        forward_product<true>(ep, yq0);
+        forward_product<!LEAF>(eq0, c[0]);
+        forward_product<!LEAF>(eq1, c[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        CK_BSTAMP(1);
+        // refill them with the next unit's (the last unit fetches itself again: nobody reads that)
+        issue_a(first + min(k + 1, n_mine - 1) * WAVES);
+        if (rtile >= 0) store(rtile, r0, r1);
+        __builtin_amdgcn_sched_barrier(0);
+        CK_BSTAMP(2);
+        float gq[16], gy[16];
+        node(0, gyp, ep, gq);
+        CK_BSTAMP(3);
+        issue_b();
+        grad_over_y(gq, dq0, live, gy);
+        node(1, gy, eq0, r0);
+        CK_BSTAMP(4);
+        grad_over_y(gq, dq1, live, gy);
+        node(2, gy, eq1, r1);
+        CK_BSTAMP(5);
+#ifdef CK_BWD_STAMPS
+        ++stamp_unit;
+#endif
+        rtile = live ? tile : (__any(live) ? tile : -1);
+      }
+      if (rtile >= 0) store(rtile, r0, r1);
     }
     // the segment's weight gradients: summed over the waves in LDS, one atomic per element
     __syncthreads();
@@ -201,14 +332,276 @@ __global__ void __launch_bounds__(512) leaf_bwd_kernel(const BwdArgs a) {
       for (int r = 0; r < 16; ++r) s_gy[(8 * (r >> 2) + 4 * kh + (r & 3)) * 32 + b_in] = dw[n][r];
       __syncthreads();
       float* dst = n == 0 ? a.dw_p + static_cast<int64_t>(p_fold) * 1024 : a.dw_q + static_cast<int64_t>(q_fold[n - 1]) * 1024;
-      for (int idx = threadIdx.x; idx < 1024; idx += 512) {
+      for (int idx = threadIdx.x; idx < 1024; idx += WAVES * 64) {
         float sacc = 0.f;
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) sacc += scratch[w8 * 2048 + idx];
+        for (int w8 = 0; w8 < WAVES; ++w8) sacc += scratch[w8 * 2048 + idx];
         if (sacc != 0.f) atomicAdd(dst + idx, sacc);
       }
       __syncthreads();
     }
+  }
+}
+
+}  // namespace
+
+namespace {
+
+// ---- tiles whose forward walk left the linear range ---------------------------------------------------------------------
+// One wave per marked (root, tile) -- one workgroup of four waves per root looks for marks --: the whole subtree again in LOG space, the reference's arithmetic (semiring.py:383-408),
+// forward values recomputed on the way down (a node's children are walked again for its own backward: rare tiles, simple
+// code).  Writes the gradient tiles of the level-1 nodes where leaf_bwd_kernel<true> would have left them and adds the
+// weight gradients of every level with float atomics.
+struct RedoArgs {
+  const float* table;    // (F0, C + 1, 32) linear rows
+  const float* scale;    // (F0, C + 1) their log scales
+  const int64_t* x64;
+  int B, C, D;
+  const int32_t* nodes;  // packed node tables of the region (as ck_leaf_walk_fwd)
+  int node_off[5];
+  int leaf_off;
+  const int64_t* scope;  // variable of each input-layer fold
+  const float* w[4];     // row-major (F_l, 32, 32) weights of level l + 1
+  float* dw[4];
+  const float* gin;      // (F_root, B, 32)
+  float* gout1;          // (F_1, B, 32)
+  int32_t* redo;         // (n_roots, tiles): cleared here
+};
+
+template <int D>
+struct RedoWalk {
+  const RedoArgs& a;
+  int t, lane, b_in, kh, bl;
+  bool live;
+  float* lds;  // 2 x 4 KB
+
+  __device__ __forceinline__ int fold(int level, int j) const { return a.nodes[a.node_off[level] + t * ((1 << D) >> level) + j]; }
+
+  // log-space output of node j of `level` (level 0: the leaf's table row)
+  template <int L>
+  __device__ __noinline__ void value(int j, float (&v)[16]) const {
+    if constexpr (L == 0) {
+      const int64_t var = a.scope[a.nodes[a.leaf_off + t * (1 << D) + j]];
+      const uint32_t row = min(static_cast<uint32_t>(a.x64[static_cast<int64_t>(bl) * a.D + var]), static_cast<uint32_t>(a.C));
+      const int64_t r = static_cast<int64_t>(fold(0, j)) * (a.C + 1) + row;
+      tile_load(a.table + r * kK + 4 * kh, v);
+      const float sc = a.scale[r];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = logf(v[q]) + sc;
+    } else {
+      float u[16];
+      value<L - 1>(2 * j, v);
+      value<L - 1>(2 * j + 1, u);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] += u[q];
+      WRegs w;
+      load_w<CK_W_ROWMAJOR>(a.w[L - 1] + static_cast<int64_t>(fold(L, j)) * 1024, lane, w);
+      sum_step<CK_W_ROWMAJOR>(w, v);
+    }
+  }
+
+  template <int L>
+  __device__ __noinline__ void backward(int j, const float (&g)[16]) const {
+    float e[16], u[16];
+    value<L - 1>(2 * j, e);
+    value<L - 1>(2 * j + 1, u);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) e[q] += u[q];
+    const float m = row_max16(e);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) e[q] = live ? expf(e[q] - m) : 0.f;
+    const float* wf = a.w[L - 1] + static_cast<int64_t>(fold(L, j)) * 1024;
+    WRegs w;
+    load_w<CK_W_ROWMAJOR>(wf, lane, w);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) u[q] = e[q];
+    contract_linear<CK_W_ROWMAJOR>(w, u);  // y = W e
+    float gy[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gy[q] = (live && u[q] > 0.f && g[q] != 0.f) ? g[q] / u[q] : 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    dw_accumulate(acc, lds, lds + 1024, b_in, kh, gy, e);
+    float* dwf = a.dw[L - 1] + static_cast<int64_t>(fold(L, j)) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (acc[r] != 0.f) atomicAdd(dwf + (8 * (r >> 2) + 4 * kh + (r & 3)) * 32 + b_in, acc[r]);
+    // gc = e * (W^T gy)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(8 * (q >> 2) + 4 * kh + (q & 3)) * kK + b_in], gy[q], acc, 0, 0, 0);
+    float gc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gc[r] = acc[r] * e[r];
+    if constexpr (L == 1) {
+      if (live) tile_store(a.gout1 + (static_cast<int64_t>(fold(1, j)) * a.B + bl) * kK + 4 * kh, gc);
+    } else {
+      backward<L - 1>(2 * j, gc);
+      backward<L - 1>(2 * j + 1, gc);
+    }
+  }
+};
+
+template <int D>
+__global__ void __launch_bounds__(256) leaf_bwd_redo_kernel(const RedoArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[4][2048];
+  const int t = blockIdx.x, n_tiles = (a.B + 31) >> 5;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int32_t* flags = a.redo + static_cast<int64_t>(t) * n_tiles;
+  // one workgroup per root: a wave looks at 64 marks at a time (almost always: none set) and walks the marked tiles
+  for (int base = wave * 64; base < n_tiles; base += 256) {
+    const int tl = base + lane;
+    uint64_t marked = __ballot(tl < n_tiles && flags[tl] != 0);
+    while (marked != 0) {
+      const int tile = base + __builtin_ctzll(marked);
+      marked &= marked - 1;
+      const int b = tile * 32 + (lane & 31);
+      const RedoWalk<D> walk{a, t, lane, lane & 31, lane >> 5, min(b, a.B - 1), b < a.B, lds[wave]};
+      float g[16];
+      tile_load(a.gin + (static_cast<int64_t>(walk.fold(D, 0)) * a.B + walk.bl) * kK + 4 * walk.kh, g);
+      walk.template backward<D>(0, g);
+      if (lane == 0) flags[tile] = 0;
+    }
+  }
+}
+
+
+// ---- the dense layer and the Categorical log-softmax, backward, ON THE TABLE ----------------------------------------------
+// The forward pushes the dense layer through the (C + 1)-row log-table of its Categorical fold (ck_softmax.h kind 5:
+// T'[c] = dense(T[c]), T = log softmax_C(theta), layers/input.py:399-412 + layers/inner.py:266-273), so the gradient the
+// scatter leaves is w.r.t. T' (F, C + 1, 32) and both layers' backward is a (C + 1)-row problem per fold -- B / C times
+// less than per batch row.  One workgroup per dense fold: T and W = softmax(theta_d) are rebuilt in LDS from the raw
+// parameters, the C + 1 rows go through the three contractions of a sum layer's backward on 32-row tiles
+// (y = W e, dW += gy^T e, gT = e * (W^T gy)), then
+//     dtheta_d[o, i] = W[o, i] (dW[o, i] - <W[o, :], dW[o, :]>)                   (TorchSoftmaxParameter, nodes.py:764-772)
+//     dtheta_c[i, c] = gT[c, i] - exp(T[c, i]) sum_c' gT[c', i]      (c < C)       (log-softmax over the categories)
+// are written straight into the parameter gradients: nothing table-sized but the scatter's output is read, nothing but the
+// two gradients written.  Row C (the integral row, T = 0) contributes to dW only.
+struct TableBwdArgs {
+  const float* cat_logits;    // (F_cat, 32, C)
+  const int64_t* cat_idx;     // (F) Categorical fold of each dense fold, or nullptr: the identity
+  const float* dense_logits;  // (F, 32, 32)
+  const float* dtp;           // (F, C + 1, 32) gradient w.r.t. the log-space table T'
+  float* g_cat;               // (F_cat, 32, C)
+  float* g_dense;             // (F, 32, 32)
+  int C;
+};
+
+__global__ void __launch_bounds__(512) table_dense_bwd_kernel(const TableBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tb_lds[];
+  const int C = a.C, rows = C + 1, n_t = (rows + 31) >> 5;
+  float* t_s = tb_lds;               // [n_t * 32][32] T, swizzled (tsw)
+  float* g_s = t_s + n_t * 1024;      // [n_t * 32][32] gT, swizzled
+  float* w_t = g_s + n_t * 1024;      // W, CK_W_TILED_F32 (A operand of y = W e)
+  float* wt_t = w_t + 1024;           // W^T, "transposed tiled" (A operand of W^T gy)
+  float* w_rm = wt_t + 1024;          // W row-major
+  float* scratch = w_rm + 1024;       // 8 x 2048: per wave gy / e tiles of the dW contraction
+  const int d = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int64_t f = a.cat_idx != nullptr ? a.cat_idx[d] : d;
+  const float* theta = a.cat_logits + f * 32 * C;
+  // W = softmax over the last axis of the fold's (32, 32) logits: 16 lanes per row, two entries each
+  {
+    const int o = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const float2 v = *reinterpret_cast<const float2*>(a.dense_logits + static_cast<int64_t>(d) * 1024 + o * 32 + 2 * j);
+    float m = fmaxf(v.x, v.y);
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 16));
+    const float e0 = expf(v.x - m), e1 = expf(v.y - m);
+    float sum = e0 + e1;
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) sum += __shfl_xor(sum, s, 16);
+    const float p[2] = {e0 / sum, e1 / sum};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = 2 * j + k;
+      w_rm[o * 32 + i] = p[k];
+      w_t[(i >> 3) * 256 + (o + 32 * ((i >> 2) & 1)) * 4 + (i & 3)] = p[k];
+      wt_t[(o >> 3) * 256 + (i + 32 * ((o >> 2) & 1)) * 4 + (o & 3)] = p[k];
+    }
+  }
+  // T[c][i] = theta[i][c] - logsumexp_c theta[i][:]: four units per wave, lanes over the categories
+  for (int i = wave * 4; i < wave * 4 + 4; ++i) {
+    const float* row = theta + i * C;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+    m = ck::wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += expf(row[c] - m);
+    sum = ck::wave_sum(sum);
+    const float lse = m + logf(sum);
+    for (int c = lane; c < n_t * 32; c += 64) t_s[tsw(c, i)] = c < C ? row[c] - lse : 0.f;  // (row C: the integral row; beyond: padding)
+  }
+  __syncthreads();
+  f32x16 dw;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dw[r] = 0.f;
+  float* s_gy = scratch + wave * 2048;
+  float* s_e = s_gy + 1024;
+  const float* dtp = a.dtp + static_cast<int64_t>(d) * rows * kK;
+  for (int tile = wave; tile < n_t; tile += 8) {
+    const int c = tile * 32 + b_in;
+    const bool live = c < rows;
+    float v[16], e[16], gy[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // register layout out of the swizzled tile
+      const float4 t4 = *reinterpret_cast<const float4*>(t_s + c * 32 + 4 * ((2 * g + kh) ^ (c & 7)));
+      v[4 * g + 0] = t4.x;
+      v[4 * g + 1] = t4.y;
+      v[4 * g + 2] = t4.z;
+      v[4 * g + 3] = t4.w;
+    }
+    const float m = row_max16(v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = live ? expf(v[r] - m) : 0.f;
+    WRegs w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w.q[q] = *reinterpret_cast<const float4*>(w_t + q * 256 + lane * 4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = e[r];
+    contract_linear<CK_W_TILED_F32>(w, v);  // y = W e
+    float go[16];
+    tile_load(dtp + static_cast<int64_t>(live ? c : rows - 1) * kK + 4 * kh, go);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gy[r] = (live && v[r] > 0.f && go[r] != 0.f) ? go[r] / v[r] : 0.f;
+    dw_accumulate(dw, s_gy, s_e, b_in, kh, gy, e);
+    float gt[16];
+    child_gradient(wt_t, lane, gy, e, gt);
+    tile_to_lds(g_s + tile * 1024, b_in, kh, gt);
+  }
+  __syncthreads();
+  // dW over the waves -> row-major in scratch[0 .. 1024), then the softmax backward of the dense weights
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_gy[(8 * (r >> 2) + 4 * kh + (r & 3)) * 32 + b_in] = dw[r];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 1024; idx += 512) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) sacc += scratch[w8 * 2048 + idx];
+    scratch[8 * 2048 - 1024 + idx] = sacc;  // (the last wave's e tile: free by now)
+  }
+  __syncthreads();
+  {
+    const float* dwr = scratch + 8 * 2048 - 1024;
+    const int o = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const float w0 = w_rm[o * 32 + 2 * j], w1 = w_rm[o * 32 + 2 * j + 1];
+    const float d0 = dwr[o * 32 + 2 * j], d1 = dwr[o * 32 + 2 * j + 1];
+    float dot = w0 * d0 + w1 * d1;
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) dot += __shfl_xor(dot, s, 16);
+    *reinterpret_cast<float2*>(a.g_dense + static_cast<int64_t>(d) * 1024 + o * 32 + 2 * j) = make_float2(w0 * (d0 - dot), w1 * (d1 - dot));
+  }
+  // column sums of gT over the categories (row C has no gradient), then dtheta_c, coalesced along the categories
+  for (int i = wave * 4; i < wave * 4 + 4; ++i) {
+    float sacc = 0.f;
+    for (int c = lane; c < C; c += 64) sacc += g_s[tsw(c, i)];
+    sacc = ck::wave_sum(sacc);
+    float* out = a.g_cat + f * 32 * C + i * C;
+    for (int c = lane; c < C; c += 64) out[c] = g_s[tsw(c, i)] - expf(t_s[tsw(c, i)]) * sacc;
   }
 }
 
@@ -243,12 +636,83 @@ int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* d, void* stream) {
   a.dw_q = d->dw_q;
   a.gout = d->gout;
   a.redo = d->redo;
+  a.gin_rowmajor = d->gin_rowmajor;
+  a.exp = getenv("CK_BWD_EXP") != nullptr ? atoi(getenv("CK_BWD_EXP")) : 0;
+#ifdef CK_BWD_STAMPS
+  a.stamps = getenv("CK_BWD_STAMP_PTR") != nullptr && (d->leaf != 0) == (getenv("CK_BWD_STAMP_TOP") == nullptr)
+                 ? reinterpret_cast<long long*>(strtoull(getenv("CK_BWD_STAMP_PTR"), nullptr, 0)) : nullptr;
+  a.stamp_wg = getenv("CK_BWD_STAMP_WG") != nullptr ? atoi(getenv("CK_BWD_STAMP_WG")) : 8;
+#endif
   const bool leaf = d->leaf != 0;
+  CK_REQUIRE(d->waves == 4 || d->waves == 8, "ck_leaf_walk_bwd: waves must be 4 or 8 (got %d)", d->waves);
+  const int waves = d->waves;
   dim3 grid(static_cast<unsigned>(std::min(d->n_wg, d->n_seg)));
   return ck::dispatch(
       [=](hipStream_t s) {
-        if (leaf) hipLaunchKernelGGL((leaf_bwd_kernel<true>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((leaf_bwd_kernel<false>), grid, dim3(512), 0, s, a);
+        if (waves == 4) {
+          if (leaf) hipLaunchKernelGGL((leaf_bwd_kernel<true, 4>), grid, dim3(256), 0, s, a);
+          else hipLaunchKernelGGL((leaf_bwd_kernel<false, 4>), grid, dim3(256), 0, s, a);
+        } else {
+          if (leaf) hipLaunchKernelGGL((leaf_bwd_kernel<true, 8>), grid, dim3(512), 0, s, a);
+          else hipLaunchKernelGGL((leaf_bwd_kernel<false, 8>), grid, dim3(512), 0, s, a);
+        }
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_table_dense_bwd(const float* cat_logits, const int64_t* cat_idx, const float* dense_logits, const float* dtable, float* g_cat,
+                       float* g_dense, int F, int C, void* stream) {
+  CK_REQUIRE(cat_logits && dense_logits && dtable && g_cat && g_dense, "ck_table_dense_bwd: null pointer");
+  CK_REQUIRE(F > 0 && C > 0, "ck_table_dense_bwd: non-positive size");
+  const int n_t = (C + 1 + 31) / 32;
+  const size_t lds = (static_cast<size_t>(2 * n_t + 3) * 1024 + 8 * 2048) * sizeof(float);
+  if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_table_dense_bwd: C=%d does not fit in LDS", C);
+  TableBwdArgs a{cat_logits, cat_idx, dense_logits, dtable, g_cat, g_dense, C};
+  dim3 grid(static_cast<unsigned>(F));
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(table_dense_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(table_dense_bwd_kernel, grid, dim3(512), lds, s, a);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_leaf_walk_bwd_redo(const float* table, const float* table_scale, const int64_t* x_rows, int B, int C, int D,
+                          const int32_t* nodes, const int32_t* node_off, int leaf_off, const int64_t* scope, int depth,
+                          const float* const* w_levels, float* const* dw_levels, const float* gin, float* gout1, int32_t* redo,
+                          int n_roots, void* stream) {
+  CK_REQUIRE(table && table_scale && x_rows && nodes && node_off && scope && w_levels && dw_levels && gin && gout1 && redo,
+             "ck_leaf_walk_bwd_redo: null pointer");
+  CK_REQUIRE(B > 0 && C > 0 && D > 0 && n_roots > 0 && n_roots <= 65535, "ck_leaf_walk_bwd_redo: bad sizes");
+  CK_REQUIRE(depth == 2 || depth == 4, "ck_leaf_walk_bwd_redo: depth %d (2 or 4)", depth);
+  RedoArgs a{};
+  a.table = table;
+  a.scale = table_scale;
+  a.x64 = x_rows;
+  a.B = B;
+  a.C = C;
+  a.D = D;
+  a.nodes = nodes;
+  for (int l = 0; l <= depth; ++l) a.node_off[l] = node_off[l];
+  a.leaf_off = leaf_off;
+  a.scope = scope;
+  for (int l = 0; l < depth; ++l) {
+    CK_REQUIRE(w_levels[l] && dw_levels[l], "ck_leaf_walk_bwd_redo: null level %d", l + 1);
+    a.w[l] = w_levels[l];
+    a.dw[l] = dw_levels[l];
+  }
+  a.gin = gin;
+  a.gout1 = gout1;
+  a.redo = redo;
+  dim3 grid(static_cast<unsigned>(n_roots));
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (depth == 2) hipLaunchKernelGGL((leaf_bwd_redo_kernel<2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((leaf_bwd_redo_kernel<4>), grid, dim3(256), 0, s, a);
         return hipGetLastError();
       },
       stream);

@@ -397,6 +397,27 @@ __device__ __forceinline__ void tile_store_clog(float* __restrict__ dst_row, con
   }
 }
 
+// The same tile in TILE-NATIVE order: a 4 KB block per (fold, 32-row tile) whose dword (g, lane, t) is unit 8g + 4 (lane >> 5) + t
+// of row lane & 31 -- the register layout itself, so that a wave instruction moves one contiguous KiB (8 cache lines) where the
+// row-major forms above touch 32 lines, 32 bytes of each.  Used for tiles that only tile kernels read (the training forward's
+// kept tiles, gradient tiles between the backward launches): the texture addresser's time per line is what bounds those
+// launches (scripts/exp_leaf_bwd.sh).  `block`: the tile's 1024 floats.
+__device__ __forceinline__ void tile_load_native(const float* __restrict__ block, int lane, float (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 t4 = *reinterpret_cast<const float4*>(block + g * 256 + lane * 4);
+    v[4 * g + 0] = t4.x;
+    v[4 * g + 1] = t4.y;
+    v[4 * g + 2] = t4.z;
+    v[4 * g + 3] = t4.w;
+  }
+}
+__device__ __forceinline__ void tile_store_native(float* __restrict__ block, int lane, const float (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(block + g * 256 + lane * 4) = make_float4(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+
 __device__ __forceinline__ void tile_store(float* __restrict__ dst_row, const float (&v)[16]) {
 #pragma unroll
   for (int g = 0; g < 4; ++g)

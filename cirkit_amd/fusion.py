@@ -384,3 +384,35 @@ def leaf_segments(num_roots: int, num_tiles: int, num_wg: int) -> np.ndarray:
         b = np.arange(num_wg)
         return np.ascontiguousarray(by_slot[(b % 8) * (num_wg // 8) + b // 8])
     return by_slot
+
+
+def balanced_segments(num_roots: int, num_tiles: int, num_wg: int, waves: int = 8, max_pieces: int = 16,
+                      overhead: float = 0.5) -> np.ndarray:
+    """Segment list ``(n_seg, 4)`` for a persistent launch whose workgroups take SEVERAL segments (`ck_leaf_walk_bwd`:
+    workgroup g takes segments g, g + num_wg, ...).  A segment's tiles are dealt round-robin to the `waves` waves of its
+    workgroup, so it costs ceil(tiles / waves) unit times plus `overhead` (weights staged, weight gradients flushed), and
+    the launch takes as long as its busiest workgroup.  Every root is therefore cut into k ranges of WHOLE wave rounds
+    (multiples of `waves` tiles, the remainder in the last one), k chosen to minimise that critical path, and the segments are
+    dealt longest first.  196 roots x 128 tiles on 256 workgroups of 8 waves: one segment per root leaves 60 workgroups
+    idle and 16 units per wave on the others (ideal: 12.25); k = 5 (3, 3, 3, 3, 4 rounds) gets 14."""
+    rounds = -(-num_tiles // waves)  # wave rounds per root
+
+    def pieces(k: int) -> list[tuple[int, int]]:
+        out, r0 = [], 0
+        for j in range(k):
+            r1 = (j + 1) * rounds // k
+            if r1 > r0:
+                out.append((r0 * waves, min(r1 * waves, num_tiles)))
+            r0 = r1
+        return out
+
+    def schedule(k: int):
+        segs = [(b - a, r, a, b) for r in range(num_roots) for a, b in pieces(k)]
+        segs.sort(key=lambda t: (-t[0], t[1], t[2]))  # longest first; a root's equal pieces stay adjacent
+        cost = np.zeros(num_wg)
+        for i, (n, _, _, _) in enumerate(segs):
+            cost[i % num_wg] += -(-n // waves) + overhead
+        return float(cost.max()), segs
+
+    best = min((schedule(k) for k in range(1, max(1, min(max_pieces, rounds)) + 1)), key=lambda t: t[0])
+    return np.asarray([[r, a, b, 0] for _, r, a, b in best[1]], dtype=np.int32).reshape(-1, 4)

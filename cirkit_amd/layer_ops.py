@@ -188,9 +188,12 @@ class _Embedding(torch.autograd.Function):
         g = (gout.real if gout.is_complex() else gout).to(torch.float32).contiguous()
         dtable = torch.zeros((F, C + 1, K), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            capi.call("ck_categorical_bwd", g.data_ptr(), None, xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C,
+            capi.call("ck_categorical_bwd", g.data_ptr(), None, xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C, 1, None,
                       _stream(g.device))
-        dw = dtable[:, :C] / table[:, :C]  # (entries no batch row selected: 0 / w = 0)
+        # d log w / d w = 1 / w at the entries some batch row selected; the others have no gradient (also where w == 0:
+        # 0 / 0 would be NaN there and poison the optimizer's moments -- the reference's indexing backward leaves 0)
+        num = dtable[:, :C]
+        dw = torch.where(num != 0, num / table[:, :C], torch.zeros_like(num))
         return dw.transpose(1, 2).contiguous().to(ctx.dtype), None, None
 
 
@@ -223,7 +226,7 @@ class _Categorical(torch.autograd.Function):
         g = gout.to(torch.float32).contiguous()
         dtable = torch.zeros((F, C + 1, K), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            capi.call("ck_categorical_bwd", g.data_ptr(), None, xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C,
+            capi.call("ck_categorical_bwd", g.data_ptr(), None, xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, K, C, 1, None,
                       _stream(g.device))
         return dtable[:, :C].transpose(1, 2).contiguous().to(ctx.dtype), None
 

@@ -34,6 +34,7 @@ class TensorStore:
         self._t: dict[str, torch.Tensor] = {}
         self.version = 0  # bumps when a tensor OBJECT is replaced (recorded pointers go stale)
         self.data_version = 0  # bumps on every value change (derived-parameter caches go stale)
+        self._volatile = 0  # `state()` calls that could not read a version counter (inference tensors)
         # set by a HipCircuit that padded its unit counts (cirkit_amd/padding.py): values arrive and leave in
         # the shapes of the user's plan
         self._pad = None
@@ -43,7 +44,17 @@ class TensorStore:
         """What a cache of derived parameters compares: `data_version` (set / touch) and the sum of the tensors' torch
         version counters -- any in-place torch operation on a stored tensor (an optimizer step, `store[name].mul_(..)`)
         bumps one.  Writes through raw pointers by foreign kernels are invisible to both: call `touch()` after them."""
-        return (self.data_version, sum(t._version for t in self._t.values()))
+        total = 0
+        for t in self._t.values():
+            try:
+                total += t._version
+            except RuntimeError:
+                # a tensor created under torch.inference_mode() has no version counter: its in-place updates cannot be
+                # seen, so no state of this store ever equals an earlier one (derived parameters are re-evaluated at the
+                # start of every forward, as the reference does)
+                self._volatile += 1
+                return (self.data_version, -self._volatile)
+        return (self.data_version, total)
 
     def touch(self) -> None:
         """Record that tensor values were modified in place outside `set`."""

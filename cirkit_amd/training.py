@@ -26,6 +26,7 @@ templates build with 'cp', 'cp-t' and 'tucker' (BASELINE configs 1-4, the refere
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Mapping
 
 import numpy as np
@@ -131,6 +132,7 @@ class HipTrainer:
         # input validation: the circuit's flag is raised by a batch with an out-of-range category; a step on such a batch
         # changes nothing (`step`), the flag is latched into `_bad_seen` -- what `check_inputs()` reports -- and cleared
         self._bad_seen = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._step_flag = torch.zeros(1, dtype=torch.int32, device=self.device)  # fused: the flag of the step being taken
         self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)  # Adam steps that did not count
 
     # ------------------------------------------------------------------------------------------
@@ -192,16 +194,13 @@ class HipTrainer:
         if not np.array_equal(leaf_of_dense, np.arange(cat.num_folds)):
             return "the dense layer must read the Categorical folds in order"
         self.circuit, self.fused = c, True
+        # wavefronts per workgroup of the backward walk: 4 = one per SIMD with the next unit's tiles in flight (ck_leaf_bwd.hip)
+        self._bwd_waves = int(os.environ.get("CK_BWD_WAVES", "4"))
         dev = c.device
         dl = c.layers[g.dense_layer]
         Cn = cat.num_categories
-        from .parameters import ParamBatch
-
-        extra = ParamBatch()  # what only the backward reads: the log-table itself and the dense layer's linear weights
-        T = torch.empty((cat.num_folds, Cn + 1, 32), dtype=torch.float32, device=dev)
-        Wd = torch.empty((dl.num_folds, 32, 32), dtype=torch.float32, device=dev)
-        extra.add_log_table(cat.probs.softmax_source(), T)
-        extra.add_softmax(dl.weight.softmax_source(), Wd)
+        if (2 * ((Cn + 1 + 31) // 32) + 3) * 4096 + 8 * 8192 > 160 * 1024:
+            return "too many categories for the table backward's LDS"
         kl = 1 << g.depth
         nodes = np.asarray(g.nodes).astype(np.int64)
         n_roots = c.layers[g.root].num_folds
@@ -235,11 +234,21 @@ class HipTrainer:
                 d = lvl(0, t, i)
                 gfold[d] = lvl(1, t, i >> 1)
                 var_of_table[d] = var_of_leaf[int(nodes[g.leaf_off + t * kl + i])]
+        # the two leaves under a level-1 node read the same gradient tile: their workgroups are placed 8 apart (same XCD, same time)
+        by_tile: dict[int, list[int]] = {}
+        for d in range(dl.num_folds):
+            by_tile.setdefault(int(gfold[d]), []).append(d)
+        groups = list(by_tile.values())
+        fold_order = []
+        for i0 in range(0, len(groups), 8):  # 8 groups at a time: member m of group j -> block 8 m + j of this stretch
+            chunk = groups[i0:i0 + 8]
+            for m in range(max(len(gr) for gr in chunk)):
+                fold_order += [gr[m] for gr in chunk if m < len(gr)]
+        assert sorted(fold_order) == list(range(dl.num_folds))
         self._fz = {
-            "group": g, "extra": extra, "T": T, "Wd": Wd, "launches": launches,
+            "group": g, "launches": launches, "fold_order": torch.from_numpy(np.asarray(fold_order, dtype=np.int32)).to(dev),
             "gfold": torch.from_numpy(gfold).to(dev), "var": torch.from_numpy(var_of_table).to(dev),
-            "trow": (torch.arange(dl.num_folds, dtype=torch.int64) * ((Cn + 1) * 32)).to(dev),
-            "gT": torch.empty_like(T), "dTp": None, "per_B": {},
+            "per_B": {},
         }
         return None
 
@@ -248,41 +257,80 @@ class HipTrainer:
         hit = fz["per_B"].get(B)
         if hit is not None and hit["arena_ptr"] == bd.arena.data_ptr():
             return hit
-        from .fusion import leaf_segments
+        from .fusion import balanced_segments
 
         c, g = self.circuit, fz["group"]
         dev = self.device
         n_tiles = (B + 31) // 32
         hit = {"arena_ptr": bd.arena.data_ptr(), "work": [], "G": []}
         for tab, top in fz["launches"]:
-            hit["work"].append(torch.from_numpy(leaf_segments(int(tab.shape[0]), n_tiles, c._n_cu)).to(dev))
+            hit["work"].append(torch.from_numpy(balanced_segments(int(tab.shape[0]), n_tiles, c._n_cu, waves=self._bwd_waves)).to(dev))
             # the tiles this launch leaves for the level below its Q nodes (one per Q node)
-            hit["G"].append(torch.empty((c.layers[g.levels[top - 2]].num_folds, B, 32), dtype=torch.float32, device=dev))
+            # (tile-native between two of these launches, row-major where the Categorical scatter reads them)
+            nq = c.layers[g.levels[top - 2]].num_folds
+            hit["G"].append(torch.empty((nq, B, 32) if top == 2 else (nq, n_tiles, 1024), dtype=torch.float32, device=dev))
         while len(fz["per_B"]) >= 4:
             fz["per_B"].pop(next(iter(fz["per_B"])))
         fz["per_B"][B] = hit
         return hit
 
+    def _softmax_bwd_jobs(self, st: dict) -> tuple[torch.Tensor, int]:
+        """(device job table, blocks) of `ck_param_softmax_bwd_batch` over every sum layer of the fused trainer."""
+        fz = self._fz
+        if fz.get("sm_jobs") is None or fz["sm_jobs_key"] != st["dw_flat"].data_ptr():
+            c, g = self.circuit, fz["group"]
+            rows = []
+            for j in list(c._tail) + list(g.levels):  # (the dense layer's is part of ck_table_dense_bwd)
+                l = c.layers[j]
+                w = l._w
+                rows.append((w.data_ptr(), st["dws"][j].data_ptr(), self.grads[l.weight.graph.nodes[0].config["tensor"]].data_ptr(),
+                             l.num_folds * l.num_output_units, l.num_input_units))
+            jt = np.zeros(len(rows), dtype=np.dtype([("w", "<u8"), ("dw", "<u8"), ("dtheta", "<u8"), ("rows", "<i8"), ("len", "<i4"), ("first", "<i4")]))
+            first = 0
+            for r, (w, dw, dt, n, ln) in zip(jt, rows):
+                r["w"], r["dw"], r["dtheta"], r["rows"], r["len"], r["first"] = w, dw, dt, n, ln, first
+                first += (n + 3) // 4
+            fz["sm_jobs"] = (torch.from_numpy(jt.view(np.uint8).reshape(len(rows), -1)).to(self.device), first)
+            fz["sm_jobs_key"] = st["dw_flat"].data_ptr()
+        return fz["sm_jobs"]
+
     def _backward_fused(self, B: int, gB: float, seed, bd, st: dict, stream: int) -> None:
         c, fz = self.circuit, self._fz
         g = fz["group"]
         fb = self._fused_binding(B, bd)
+        if fz.get("dw_sum_key") != st["dw_flat"].data_ptr():
+            # the part of the flat linear-gradient buffer that float atomics add to: everything but the table gradient,
+            # which the scatter overwrites (it is the last block: the Categorical layer comes first in the plan ... or not)
+            dT = st["dws"][g.input_layer]
+            flat = st["dw_flat"]
+            lo = (dT.data_ptr() - flat.data_ptr()) // 4
+            hi = lo + dT.numel()
+            if lo == 0:
+                fz["dw_sum"] = flat[hi:]
+            elif hi == flat.numel():
+                fz["dw_sum"] = flat[:lo]
+            else:
+                fz["dw_sum"] = flat
+            fz["dw_sum_key"] = flat.data_ptr()
         keep, redo = bd.keep[g.root]
         gviews = st["gviews"]
-        capi.call("ck_fill_f32", st["dw_flat"].data_ptr(), st["dw_flat"].numel(), 0.0, stream)
-        capi.call("ck_fill_f32", self._flat_grad.data_ptr(), self._flat_grad.numel(), 0.0, stream)
+        # ONE fill: the linear-space weight gradients (float atomics add to them).  The parameter gradients themselves are
+        # written, each exactly once, by the parameter backward launches; the table gradient by the scatter.  The launch also
+        # turns the validation flag of the forward into this step's flag (`step`: what the optimizer launch skips on)
+        capi.call("ck_fill_latch", fz["dw_sum"].data_ptr(), fz["dw_sum"].numel(), 0.0, c._bad_input.data_ptr(),
+                  self._step_flag.data_ptr(), self._bad_seen.data_ptr(), stream)
         for p in st["need_zero"]:
             if gviews[p] is not None:
                 capi.call("ck_fill_f32", gviews[p].data_ptr(), gviews[p].numel(), 0.0, stream)
         po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
         if c.layers[po].num_output_units != 1:
             raise NotImplementedError("training needs a scalar output unit")
-        capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel(), 0.0, stream)
+        if gviews[po].numel() != B:
+            capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel(), 0.0, stream)
         if seed is None:
             capi.call("ck_fill_f32", gviews[po][fo].data_ptr(), B, -1.0 / gB, stream)
         else:
             gviews[po][fo].reshape(-1)[:B].copy_(seed.reshape(-1))
-        fz["extra"].launch(stream)  # (the log-table and the dense weights the table backward reads)
         for i in reversed(c._tail):  # the few-fold layers above the leaf region, layer by layer
             self._bwd_sum_layer(i, bd, st, B, stream)
         # the leaf region, two levels per launch, top first
@@ -292,9 +340,9 @@ class HipTrainer:
             lp, lq = g.levels[top - 1], g.levels[top - 2]
             d = capi.LeafBwdLaunch()
             d.unit_tab, d.work = tab.data_ptr(), fb["work"][k].data_ptr()
-            d.n_seg, d.n_wg, d.B = int(fb["work"][k].shape[0]), c._n_cu, B
+            d.n_seg, d.n_wg, d.B, d.waves = int(fb["work"][k].shape[0]), c._n_cu, B, self._bwd_waves
             d.C, d.D, d.leaf = cat.num_categories, self.plan.num_variables, 1 if top == 2 else 0
-            d.gin = gin.data_ptr()
+            d.gin, d.gin_rowmajor = gin.data_ptr(), 1 if k == 0 else 0
             d.y_p, d.y_q = keep[top - 1].data_ptr(), keep[top - 2].data_ptr()
             if top == 2:
                 d.table, d.x_rows = c._group_dev[g.root][1].data_ptr(), bd.x_last.data_ptr()
@@ -306,56 +354,63 @@ class HipTrainer:
             d.redo = redo.data_ptr()
             capi.call("ck_leaf_walk_bwd", C.byref(d), stream)
             gin = fb["G"][k]
-        for j in g.levels:  # softmax parameterisation of the level weights
-            l = c.layers[j]
-            name = l.weight.graph.nodes[0].config["tensor"]
-            capi.call("ck_param_softmax_bwd", l._w.data_ptr(), st["dws"][j].data_ptr(), self.grads[name].data_ptr(),
-                      l.num_folds * 32, 32, 0, stream)
+        # (root, tile) units whose forward walk left the linear range: in log space, by a launch in which every other wave exits
+        depth = g.depth
+        capi.call("ck_leaf_walk_bwd_redo", c._group_dev[g.root][1].data_ptr(), c._group_dev[g.root][3].data_ptr(), bd.x_last.data_ptr(),
+                  B, cat.num_categories, self.plan.num_variables, c._group_dev[g.root][0].data_ptr(),
+                  (C.c_int32 * (depth + 1))(*g.node_off), g.leaf_off, cat._scope(self.device).data_ptr(), depth,
+                  (C.c_void_p * depth)(*[c.layers[j]._w.data_ptr() for j in g.levels]),
+                  (C.c_void_p * depth)(*[st["dws"][j].data_ptr() for j in g.levels]),
+                  gviews[g.root].data_ptr(), gin.data_ptr(), redo.data_ptr(), c.layers[g.root].num_folds, stream)
         # leaves: scatter by category into the gradient of the (F0, C + 1, 32) table T' = dense(log-table) ...
         Cn = cat.num_categories
         dTp = st["dws"][g.input_layer]
         capi.call("ck_transpose_i64_to_i32", bd.x_last.data_ptr(), bd.xt_i.data_ptr(), B, self.plan.num_variables, stream)
         capi.call("ck_categorical_bwd", gin.data_ptr(), fz["gfold"].data_ptr(), bd.xt_i.data_ptr(), fz["var"].data_ptr(),
-                  dTp.data_ptr(), dl.num_folds, B, 32, Cn, stream)
+                  dTp.data_ptr(), dl.num_folds, B, 32, Cn, 0, (fz["fold_order"].data_ptr() if B >= 256 else None), stream)
         # ... then the dense layer and the log-softmax of the Categorical layer backward ON THE TABLE (C + 1 rows per fold)
-        dWd = st["dws"][g.dense_layer]
-        capi.call("ck_sum_lse_bwd", fz["T"].data_ptr(), fz["gT"].data_ptr(), fz["trow"].data_ptr(), fz["trow"].data_ptr(),
-                  fz["Wd"].data_ptr(), fz["T"].data_ptr(), dTp.data_ptr(), dWd.data_ptr(), dl.num_folds, 1, Cn + 1, 32, 32,
-                  dl._mode, 0, stream)
-        capi.call("ck_param_softmax_bwd", fz["Wd"].data_ptr(), dWd.data_ptr(),
-                  self.grads[dl.weight.graph.nodes[0].config["tensor"]].data_ptr(), dl.num_folds * 32, 32, 0, stream)
-        capi.call("ck_param_log_table_bwd", fz["T"].data_ptr(), fz["gT"].data_ptr(),
-                  self.grads[cat.probs.graph.nodes[0].config["tensor"]].data_ptr(), cat.num_folds, 32, Cn, 0, stream)
+        capi.call("ck_table_dense_bwd", cat.probs.softmax_source().data_ptr(), None, dl.weight.softmax_source().data_ptr(),
+                  dTp.data_ptr(), self.grads[cat.probs.graph.nodes[0].config["tensor"]].data_ptr(),
+                  self.grads[dl.weight.graph.nodes[0].config["tensor"]].data_ptr(), dl.num_folds, Cn, stream)
+        # softmax parameterisation of every sum layer's weights (tail, fused levels, dense layer): one launch
+        jobs, n_blocks = self._softmax_bwd_jobs(st)
+        capi.call("ck_param_softmax_bwd_batch", jobs.data_ptr(), jobs.shape[0], n_blocks, stream)
 
     def _accumulate_flags(self) -> tuple[dict[int, int], set[int]]:
         """Per consumer layer: 0 store / 1 add / 2 atomic; and the producer layers whose gradient
-        block must be zeroed first."""
+        block must be zeroed first.  A layer whose children -- (producer, fold) pairs -- are read by nobody else (any
+        tree-structured region graph) STORES their gradients: nothing to zero, nothing to add."""
         c = self.circuit
-        consumers: dict[int, list[int]] = {}
+        count: dict[tuple[int, int], int] = {}
         dup_in_layer: dict[int, bool] = {}
         for j, ch in enumerate(c._children):
             if ch is None:
                 continue
             pairs = ch.reshape(-1, 2)
-            dup_in_layer[j] = len(np.unique(pairs, axis=0)) != len(pairs)
-            for p in np.unique(pairs[:, 0]):
-                consumers.setdefault(int(p), []).append(j)
-        need_zero = {p for p, js in consumers.items() if len(js) > 1 or any(dup_in_layer[j] for j in js)}
+            uniq = np.unique(pairs, axis=0)
+            dup_in_layer[j] = len(uniq) != len(pairs)
+            for p, f in uniq:
+                count[(int(p), int(f))] = count.get((int(p), int(f)), 0) + 1
         flags: dict[int, int] = {}
         for j, ch in enumerate(c._children):
             if ch is None:
                 continue
-            prods = {int(p) for p in np.unique(ch[..., 0])}
             if dup_in_layer[j]:
                 flags[j] = 2
-            elif prods & need_zero:
+            elif any(count[(int(p), int(f))] > 1 for p, f in ch.reshape(-1, 2)):
                 flags[j] = 1
             else:
                 flags[j] = 0
         # a launch with flag 1/2 adds into ALL its producers: they all must start from zero
+        need_zero: set[int] = set()
         for j, fl in flags.items():
             if fl:
                 need_zero |= {int(p) for p in np.unique(c._children[j][..., 0])}
+        # ... and a store into a block that another launch adds to must come first: the launches run from the last layer to
+        # the first, so a storing layer k and an adding layer j > k on the same producer would lose j's contribution
+        for k, fl in list(flags.items()):
+            if fl == 0 and {int(p) for p in np.unique(c._children[k][..., 0])} & need_zero:
+                flags[k] = 1
         return flags, need_zero
 
     def _bind_backward(self, B: int) -> dict:
@@ -444,12 +499,7 @@ class HipTrainer:
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
         """The training forward: [sum log p, count] of the batch; fused: kept tiles of the leaf region + tail outputs,
         layer-wise: every activation stays in the arena."""
-        c = self.circuit
-        if self.fused:  # the tiles a previous forward marked as evaluated in log space
-            kept = c._bind(int(x.shape[0])).keep.get(self._fz["group"].root)
-            if kept is not None:
-                capi.call("ck_fill_f32", kept[1].data_ptr(), kept[1].numel(), 0.0, torch.cuda.current_stream(self.device).cuda_stream)
-        return c.log_likelihood_sum(x)
+        return self.circuit.log_likelihood_sum(x)
 
     def _backward(self, B: int, gB: float, seed: torch.Tensor | None) -> None:
         """The backward launch list over the activations of the LAST forward at batch size B: gradients of
@@ -493,7 +543,7 @@ class HipTrainer:
             if isinstance(l, HipCategoricalLayer):
                 dT = st["dws"][i]
                 capi.call("ck_categorical_bwd", gviews[i].data_ptr(), None, bd.xt_i.data_ptr(), l._scope(self.device).data_ptr(),
-                          dT.data_ptr(), l.num_folds, B, l.num_output_units, l.num_categories, stream)
+                          dT.data_ptr(), l.num_folds, B, l.num_output_units, l.num_categories, 1, None, stream)
                 name = l.probs.graph.nodes[0].config["tensor"]
                 capi.call("ck_param_log_table_bwd", l._table.data_ptr(), dT.data_ptr(), self.grads[name].data_ptr(),
                           l.num_folds, l.num_output_units, l.num_categories, 0, stream)
@@ -547,6 +597,8 @@ class HipTrainer:
         if sh is not None:
             capi.call("ck_segment_add_rows", st["tmp"].data_ptr(), sh["cptr"].data_ptr(), sh["clist"].data_ptr(),
                       sh["coff"].data_ptr(), st["garena"].data_ptr(), sh["n_child"], sh["block"], stream)
+        if self.fused:
+            return  # (one batched softmax backward for all layers at the end of `_backward_fused`)
         if self._fast_softmax(l):
             name = l.weight.graph.nodes[0].config["tensor"]
             rows = l.num_folds * l.num_output_units
@@ -609,17 +661,18 @@ class HipTrainer:
         c = self.circuit
         validate = c.validate_inputs and c._int_input
         alone = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        if validate:
-            # a batch with an out-of-range category (NaN log-likelihood) must not reach the parameters.  The flag it raised is
-            # THIS step's (it is latched and cleared below), everything stays on the device -- no host synchronisation:
-            # its gradients are dropped before the exchange, and on a single rank the optimizer launch changes nothing at all
-            # (with several ranks the other ranks' gradients are valid and every rank must take the same step)
+        # a batch with an out-of-range category (NaN log-likelihood) must not reach the parameters.  The flag it raised is THIS
+        # step's (fused: handed on by the backward's first launch; layer-wise: latched and cleared below), everything stays on
+        # the device -- no host synchronisation: on a single rank the optimizer launch changes nothing at all; with several
+        # ranks the other ranks' gradients are valid and every rank must take the same step, so this rank's are dropped
+        flag = self._step_flag if self.fused else c._bad_input
+        if validate and not alone:
             with torch.cuda.device(self.device):
-                capi.call("ck_zero_if_flag", self._flat_grad.data_ptr(), self._flat_grad.numel(), c._bad_input.data_ptr(),
+                capi.call("ck_zero_if_flag", self._flat_grad.data_ptr(), self._flat_grad.numel(), flag.data_ptr(),
                           torch.cuda.current_stream(self.device).cuda_stream)
         self.all_reduce_grads()
-        self.apply_gradients(c._bad_input if (validate and alone) else None)
-        if validate:
+        self.apply_gradients(flag if (validate and alone) else None)
+        if validate and not self.fused:
             with torch.cuda.device(self.device):
                 capi.call("ck_latch_flag", c._bad_input.data_ptr(), self._bad_seen.data_ptr(),
                           torch.cuda.current_stream(self.device).cuda_stream)

@@ -296,8 +296,8 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
  *  *bad_input (a DEVICE int32 owned by the caller, as ck_stage_categories' flag) is raised; with bad_input == NULL such a
  *  value is evaluated as the integral row (memory-safe, not meaningful).  B * D * 8 must be below 2^32.
  *  Training forward (keep_levels != NULL; raw input, unsigned values, 8 waves): beside the root outputs the launch stores the
- *  LINEAR tile of every node it evaluates -- keep_levels[l - 1] is (F_l, B, 32) for CP-T level l = 1 .. depth, the value the
- *  next level multiplies (per row it differs from exp(layer output) by the power-of-two scale the walk carries; the backward,
+ *  LINEAR tile of every node it evaluates -- keep_levels[l - 1] is (F_l, ceil(B / 32), 1024) for CP-T level l = 1 .. depth in
+ *  tile-native order (see ck_leaf_walk_bwd), the value the next level multiplies (per row it differs from exp(layer output) by the power-of-two scale the walk carries; the backward,
  *  ck_leaf_walk_bwd, only needs a level's tiles to be consistent with each other) -- i.e. what the reference's autograd keeps
  *  alive as the outputs of those layers (graph/modules.py:303-335).  keep_redo: (n_roots, ceil(B / 32)) int32, zero on
  *  entry: tiles whose products left the linear range (evaluated again in log space for `out`) are marked 1 there; their
@@ -555,11 +555,13 @@ int ck_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
 int ck_param_scatter_add_folds(const float* dsrc, const int64_t* idx, float* ddst, int64_t n, int64_t per_fold,
                                void* stream);
 /* TorchCategoricalLayer backward (the scatter-add that autograd performs for the advanced indexing of
- * layers/input.py:399-412): dtable[f,c,:] += sum_{b: x[b,scope f]=c} gout[g(f),b,:]  (dtable (F,C+1,K), same transposed
- * layout as the forward table).  gfold: NULL (g(f) = f), or DEVICE (F) int32: the (B, K) block of `gout` that holds fold f's
- * gradient -- in a fused backward the two leaves of a product share ONE gradient tile (ck_leaf_walk_bwd). */
+ * layers/input.py:399-412): dtable[f,c,:] (+)= sum_{b: x[b,scope f]=c} gout[g(f),b,:]  (dtable (F,C+1,K), same transposed
+ * layout as the forward table; accumulate 0 overwrites it -- every row of it -- 1 adds).  gfold: NULL (g(f) = f), or DEVICE (F) int32: the (B, K) block of `gout` that holds fold f's
+ * gradient -- in a fused backward the two leaves of a product share ONE gradient tile (ck_leaf_walk_bwd).  fold_order: NULL,
+ * or DEVICE (F) int32 permutation: workgroup b evaluates fold fold_order[b] (workgroups b and b + 8 run on the same XCD at about
+ * the same time: folds that read the same gout block placed 8 apart fetch it from memory once); needs K % 32 == 0, B >= 256. */
 int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* xt, const int64_t* scope, float* dtable, int F,
-                       int B, int K, int C, void* stream);
+                       int B, int K, int C, int accumulate, const int32_t* fold_order, void* stream);
 
 /* Backward of the fused leaf region, two CP-T levels per launch (cirkit_amd/csrc/ck_leaf_bwd.hip) -- what autograd does for
  * TorchCPTLayer.forward (layers/optimized.py:171-178) under LSESumSemiring.apply_reduce (semiring.py:383-408), on the tiles
@@ -568,17 +570,23 @@ int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* x
  * != 0, L = 2 -- the Categorical table rows of four leaves), for one 32-row batch tile.  unit_tab: DEVICE (n_units, 16)
  * int32 rows [fold of P's gradient tile in `gin`, fold of P, of Q0, of Q1, of c0..c3 (leaf: table folds), variables of the four
  * leaves (leaf only), root fold of the region (for `redo`), 0, 0, 0]; work: DEVICE (n_seg, 4) [row of unit_tab, first tile,
- * end tile, 0] dealt to n_wg resident workgroups.  gin: (F, B, 32) gradient w.r.t. the LOG-space output of P (for the top
- * launch the gradient of the root layer's output; below, the tile the previous launch left in ITS `gout` for P's parent).
- * y_p / y_q / y_c: the kept linear tiles of the three levels ((F_l, B, 32)); w_p / w_q: (F_l, 32, 32) row-major linear
- * weights; dw_p / dw_q: their gradients, accumulated (+=, atomically per segment); gout: (F_q, B, 32), written: the
- * log-space gradient node Q leaves for BOTH its children (the two children of a product receive the same one).
+ * end tile, 0] dealt to n_wg resident workgroups.  gin: gradient w.r.t. the LOG-space output of P (for the top launch the
+ * gradient of the root layer's output, (F, B, 32) row-major: gin_rowmajor; below, the tile the previous launch left in ITS
+ * `gout` for P's parent).  Tiles that only these launches exchange are TILE-NATIVE: a (F_l, ceil(B / 32), 1024) array whose
+ * 4 KB block (fold, tile) holds, at dword (g, lane, t), unit 8g + 4 (lane >> 5) + t of row 32 tile + (lane & 31) -- the MFMA
+ * register layout, one contiguous KiB per wave instruction.  y_p / y_q / y_c: the kept linear tiles of the three levels
+ * (tile-native, ck_leaf_walk_fwd keep_levels); w_p / w_q: (F_l, 32, 32) row-major linear weights; dw_p / dw_q: their
+ * gradients, accumulated (+=, atomically per segment); gout, written: the log-space gradient node Q leaves for BOTH its
+ * children (the two children of a product receive the same one) -- tile-native (F_q, tiles, 1024), or, leaf != 0,
+ * (F_q, B, 32) row-major (ck_categorical_bwd reads it row by row).
  * redo: NULL or ck_leaf_walk_fwd's keep_redo flags: flagged (root, tile) units are skipped (their kept tiles are not
  * meaningful; the caller evaluates them with the layer-wise kernels). */
 typedef struct ck_leaf_bwd_launch {
   const int32_t* unit_tab;
   const int32_t* work;
   int32_t n_seg, n_wg, B, C, D, leaf;
+  int32_t waves, gin_rowmajor;  /* gin_rowmajor != 0: gin is (F, B, 32) row-major (a layer-wise launch wrote it); wavefronts per workgroup: 8 (two per SIMD, a unit's loads issued at its start) or 4 (one per SIMD, up to 512
+                               registers each: the next unit's tiles travel while the current one computes) */
   const float* gin;
   const float* y_p;
   const float* y_q;
@@ -593,11 +601,39 @@ typedef struct ck_leaf_bwd_launch {
   const int32_t* redo;
 } ck_leaf_bwd_launch;
 int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* desc, void* stream);
+/* Backward of `dense_on_table` (ck_param_softmax_batch's kind-5 job: T' = dense(log-table), layers/input.py:399-412 +
+ * layers/inner.py:266-273 with both parameters softmaxes, nodes.py:764-772): dtable (F, C + 1, 32) is the gradient w.r.t. the
+ * LOG-space table T' (ck_categorical_bwd's output); g_cat (F_cat, 32, C) and g_dense (F, 32, 32) receive (=) the gradients of
+ * the raw parameters cat_logits / dense_logits (cat_idx: NULL or the Categorical fold of each dense fold; folds must not
+ * repeat).  One workgroup per fold rebuilds T and W from the raw parameters and runs the (C + 1)-row backward in LDS. */
+int ck_table_dense_bwd(const float* cat_logits, const int64_t* cat_idx, const float* dense_logits, const float* dtable, float* g_cat,
+                       float* g_dense, int F, int C, void* stream);
+/* The (root, tile) units ck_leaf_walk_fwd marked in keep_redo (products that left the linear range), for the whole region of
+ * `depth` (2 or 4) levels at once: one wave per marked unit walks the subtree in LOG space -- the reference's arithmetic,
+ * semiring.py:383-408, forward values recomputed -- adds the weight gradients of every level (dw_levels[l - 1], row-major,
+ * float atomics), writes the gradient tiles of the level-1 nodes into gout1 (where the leaf launch of ck_leaf_walk_bwd
+ * leaves them) and clears the mark.  Unmarked units exit at once.  table / table_scale / nodes / node_off / leaf_off /
+ * scope as ck_leaf_walk_fwd; w_levels, dw_levels: HOST arrays of `depth` DEVICE pointers; gin: (F_root, B, 32). */
+int ck_leaf_walk_bwd_redo(const float* table, const float* table_scale, const int64_t* x_rows, int B, int C, int D,
+                          const int32_t* nodes, const int32_t* node_off, int leaf_off, const int64_t* scope, int depth,
+                          const float* const* w_levels, float* const* dw_levels, const float* gin, float* gout1, int32_t* redo,
+                          int n_roots, void* stream);
 /* softmax parameter backward over the last axis: dtheta = W * (dW - sum(W*dW)). */
 int ck_param_softmax_bwd(const float* w, const float* dw, float* dtheta, int64_t rows, int len,
                          int accumulate, void* stream);
 /* Categorical probs backward: table (F,C+1,K) = transposed log softmax_C(theta (F,K,C));
  * dtheta[f,k,c] = dT[f,c,k] - exp(T[f,c,k]) sum_c' dT[f,c',k]. */
+/* ck_param_softmax_bwd (accumulate 0) for a list of tensors in ONE launch.  jobs: DEVICE array, first_block ascending
+ * from 0 with job k owning ceil(rows_k / 4) blocks; n_blocks = their total. */
+typedef struct ck_softmax_bwd_job {
+  const float* w;
+  const float* dw;
+  float* dtheta;
+  int64_t rows;
+  int32_t len;
+  int32_t first_block;
+} ck_softmax_bwd_job;
+int ck_param_softmax_bwd_batch(const ck_softmax_bwd_job* jobs, int n_jobs, int n_blocks, void* stream);
 int ck_param_log_table_bwd(const float* table, const float* dtable, float* dtheta, int F, int K, int C,
                            int accumulate, void* stream);
 /* Optimiser steps on one flat tensor; grad_scale multiplies the gradient first (e.g. 1/world). Adam
@@ -612,6 +648,10 @@ int ck_adam_step(float* p, const float* g, float* m1, float* m2, int64_t n, floa
 int ck_sgd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, const int32_t* skip_flag, void* stream);
 /* *dst |= *src; *src = 0 (DEVICE int32 flags): turns a per-step validation flag into a sticky one. */
 int ck_latch_flag(int32_t* src, int32_t* dst, void* stream);
+/* ck_fill_f32 that also hands a validation flag on: *step_flag = *src; if it is nonzero, *sticky |= *src and *src = 0
+ * (DEVICE int32 words): the flag a forward raised (ck_leaf_walk_fwd's bad_input) becomes this step's flag -- what the
+ * optimizer launch skips on -- and the sticky one in the launch that zeroes the gradient buffers anyway. */
+int ck_fill_latch(float* p, int64_t n, float value, int32_t* src, int32_t* step_flag, int32_t* sticky, void* stream);
 
 /* ---------------------------------------------------------------- reductions --------------- */
 /* Sum of B log-likelihoods (stride in floats between consecutive rows) into out_dev[0] (fp64) and
