@@ -91,13 +91,16 @@ def other_configs(device, stream, B: int) -> dict:
     hz = HipCircuit(squared_partition_plan(plan5), hc.store, device=device)
     ms_z = time_forward(hz, None)
     out["config5"] = {
-        "workload": f"squared (SoS) circuit: QuadTree-2 28x28, Embedding-256, CP-T, K=32, complex-lse-sum, batch {B}; "
+        "workload": f"squared (SoS) circuit: QuadTree-2 28x28, Embedding-256, CP-T, K=32, complex-lse-sum, batch {B}, REAL parameters "
+                    "(BASELINE config 5 as SURVEY 8(d) words it): evaluated on signed linear tiles -- the reference's complex "
+                    "logarithms of real numbers; complex-valued weights take the complex kernels, ~0.6 ms); "
                     "Z = integral |c|^2 built from the plan of c (cirkit_amd/functional.py)",
         "ms_per_forward": ms, "evals_per_s": B / ms * 1e3, "algorithmic_bytes": alg,
         "hbm_roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "ms_partition_function": ms_z,
     }
     del hc, hz
+    out["train_step_cfg2"] = train_step_cfg2(device, stream, B)
     # The only forward timing the reference publishes (notebooks/compilation-options.ipynb:594):
     # QuadGraph 28x28, Categorical-256, Tucker layers, K = 64, batch 128, fold + optimize: 38.6 ms on an unnamed
     # CUDA GPU.  Different hardware and not the north-star metric, so it stays out of `vs_baseline`.
@@ -112,6 +115,70 @@ def other_configs(device, stream, B: int) -> dict:
         "reference_published_ms": 38.6, "reference_hardware": "unnamed CUDA GPU (notebook output)",
     }
     return out
+
+
+def train_step_cfg2(device, stream, B: int, rounds: int = 5, steps: int = 40, settle_s: float = 0.3) -> dict:
+    """One maximum-likelihood training step at BASELINE config 2 -- forward, backward, Adam, parameters re-evaluated every step
+    (the reference's loop: notebooks/learning-a-circuit.ipynb cells 18 / 20) -- through `HipTrainer`'s fused form: measured like
+    the headline forward (clocks settled first, `rounds` rounds of `steps` steps between HIP events on the launch stream, the
+    median round), int64 batches rotating over more than the 256 MB Infinity Cache.  executed_flops: the fp32 MFMA
+    contractions the step issues (forward levels + 2 per node backward, tail forward + 3 per fold backward, the dense layer
+    on the (C + 1)-row table forward + 3 backward)."""
+    import time
+
+    import numpy as np
+    import torch
+
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+    from cirkit_amd.training import HipTrainer
+
+    plan = image_data((1, 28, 28), "quad-tree-2", input_layer="categorical", num_input_units=32,
+                      sum_product_layer="cp", num_sum_units=32)
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randint(0, 256, (B, 784), generator=g).to(device) for _ in range(12)]
+    with torch.cuda.stream(stream):
+        tr = HipTrainer(plan, init_plan_tensors(plan), device=device, lr=0.01, optimizer="adam")
+        k = 0
+        t0 = time.perf_counter()
+        first = None
+        while time.perf_counter() - t0 < settle_s or k < 10:
+            ll = tr.step(xs[k % 12])
+            if first is None:
+                first = ll.clone()
+            k += 1
+        torch.cuda.synchronize(device)
+        per_round = []
+        for _ in range(rounds):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(steps):
+                ll = tr.step(xs[k % 12])
+                k += 1
+            b.record(stream)
+            torch.cuda.synchronize(device)
+            per_round.append(a.elapsed_time(b) / steps)
+        last = ll.clone()
+    ms = float(np.median(per_round))
+    fused = bool(tr.fused)
+    c = tr.circuit
+    chains = 0.0  # 32 x 32 x 32-row contractions
+    if fused:
+        grp = tr._fz["group"]
+        tiles = (B + 31) // 32
+        chains += sum(c.layers[j].num_folds for j in grp.levels) * tiles * 3
+        chains += sum(c.layers[j].num_folds for j in c._tail if c.layers[j].num_output_units == 32) * tiles * 4
+        chains += c.layers[grp.dense_layer].num_folds * ((c.layers[grp.input_layer].num_categories + 1 + 31) // 32) * 4
+    flops = chains * 2.0 * 32 * 32 * 32
+    return {
+        "workload": f"784-var QuadTree (QT-2) PC, Categorical-256 leaves, K=32, batch {B}: forward + backward + Adam, parameters "
+                    "re-evaluated every step; fused training step (cirkit_amd/training.py, ck_leaf_walk_fwd keep_levels + ck_leaf_walk_bwd)",
+        "fused": fused, "ms_per_step": ms, "samples_per_s": B / ms * 1e3, "ms_per_step_by_round": per_round,
+        "settle_steps": k - rounds * steps, "steps_timed_total": rounds * steps,
+        "executed_flops": flops, "frac_of_fp32_mfma": flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+        "mean_ll_first_step": float(first[0] / first[1]), "mean_ll_last_step": float(last[0] / last[1]),
+        "optimizer": "adam(lr=0.01)", "dtype": "f32",
+    }
 
 
 def _free_port() -> int:
@@ -325,8 +392,9 @@ def main() -> None:
     # steps to the seventh, `profiles/r03_d_bench.json`): beside the W warm-up steps every timed region is preceded by
     # `--settle` untimed steps (0.2 s by default), reported as `timing.settle_steps`, so that the rounds measure one state.
     settle_steps = max(0, int(args.settle))
+    rank_spread: list = []  # N > 1: (fastest, slowest) rank wall time of every timed round of the last timed region
 
-    def timed_region(circ, steps, warmup, rounds=1):
+    def timed_region(circ, steps, warmup, rounds=1, settle=None):
         """W untimed steps, then `rounds` rounds of exactly K timed steps, each round with a barrier + synchronize on both
         sides.  Returns (wall seconds per round -- max over ranks --, HIP-event ms per step per round on the launch
         stream, the [sum, count] over ranks of the last step)."""
@@ -373,8 +441,9 @@ def main() -> None:
                         works[i] = None
 
         walls, evms = [], []
+        rank_spread.clear()
         with torch.cuda.stream(stream):
-            for _ in range(warmup + settle_steps):
+            for _ in range(warmup + (settle_steps if settle is None else settle)):
                 step()
             drain()
             for _ in range(rounds):
@@ -397,9 +466,10 @@ def main() -> None:
                 torch.cuda.synchronize(device)
                 wall = time.perf_counter() - t0
                 if use_dist:
-                    t = torch.tensor([wall], dtype=torch.float64, device=device)
+                    t = torch.tensor([wall, -wall], dtype=torch.float64, device=device)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    wall = float(t.item())
+                    rank_spread.append((-float(t[1].item()), float(t[0].item())))  # (fastest, slowest rank of this round)
+                    wall = float(t[0].item())
                 walls.append(wall)
                 evms.append(e0.elapsed_time(e1) / steps)
         pair = last[0].cpu()
@@ -407,7 +477,10 @@ def main() -> None:
 
     if args.rounds <= 0:
         args.rounds = max(5, -(-400 // max(1, args.steps)))
+    # the literal protocol first -- W warm-up steps, then K timed steps, nothing else before them: cold clocks
+    cold_walls, _, _ = timed_region(circuit, args.steps, args.warmup, 1, settle=0)
     walls, evms, pair = timed_region(circuit, args.steps, args.warmup, max(1, args.rounds))
+    spread = list(rank_spread)
     elapsed = float(np.median(walls))  # the median round (each round: exactly K steps between barriers)
     step_ms_events = float(np.median(evms))
     total_nll = float(pair[0])
@@ -427,6 +500,7 @@ def main() -> None:
         "ms_per_step": ms_per_step,
         "steps_timed_total": len(walls) * args.steps,
         "first_round_ms_per_step": 1e3 * walls[0] / args.steps,
+        "cold_first_round_ms_per_step": 1e3 * cold_walls[0] / args.steps,  # `--warmup W --steps K` literally: no settle steps in front
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -443,7 +517,10 @@ def main() -> None:
             "fused_tail_layers": len(circuit._tail),
             "contraction": args.contraction,
             "dense_on_table": circuit.dense_on_table,
-            "params_recomputed_every_step": True,
+            # derived from what a step launches: the parameter jobs (table + softmax jobs of the prologue / of the launch that
+            # ends a forward) evaluated inside every step; a `cache_params` circuit evaluates none
+            "params_recomputed_every_step": bool(not circuit.cache_params and circuit._batch is not None and len(circuit._batch) > 0),
+            "param_jobs_per_step": (0 if circuit.cache_params or circuit._batch is None else len(circuit._batch)),
             "params_evaluated": ("at the start of each forward, by a launch of their own" if not getattr(circuit._bind(B), "params_at_end", False)
                                  else "once per forward, by the launch that ends it (for the next forward; a store that changed in "
                                       "between -- TensorStore.state() -- is re-evaluated at the start)"),
@@ -459,7 +536,10 @@ def main() -> None:
         "distributed": {"backend": backend if use_dist else None, "world_size": world,
                         "ranks_seen_by_backend": ranks_seen,
                         # every step's [sum, count] goes through the backend; one collective carries up to 64 steps' pairs
-                        "every_step_exchanged": bool(use_dist), "steps_per_collective": (64 if use_dist else None)},
+                        "every_step_exchanged": bool(use_dist), "steps_per_collective": (64 if use_dist else None),
+                        # a straggler GPU shows here: wall time per step of the fastest / slowest rank in the median round
+                        "ms_per_step_fastest_rank": (1e3 * sorted(spread)[len(spread) // 2][0] / args.steps) if spread else None,
+                        "ms_per_step_slowest_rank": (1e3 * sorted(spread, key=lambda t: t[1])[len(spread) // 2][1] / args.steps) if spread else None},
         "check": {"mean_ll": total_nll / max(total_rows, 1.0), "rows": total_rows},
     }
 
@@ -551,8 +631,10 @@ def main() -> None:
             if os.path.exists(tj) and default_cfg:
                 with open(tj, encoding="utf-8") as f:
                     tr = json.load(f)
-                if "r03,e" in tr:
-                    pmc, pmc_source = tr["r03,e"], "profiles/traffic.json (committed rocprofv3 passes of the same configuration; not measured in this run)"
+                keys = sorted(k for k in tr if k[:1] == "r" and "," in k and k.split(",")[0][1:].isdigit() and len(k.split(",")) == 2)
+                if keys:  # the latest committed passes of the default configuration ("r<round>,<tag>")
+                    pmc, pmc_source = tr[keys[-1]], (f"profiles/traffic.json[{keys[-1]!r}] (committed rocprofv3 passes of the same "
+                                                     "configuration; not measured in this run)")
         if not args.no_kernel_breakdown:
             with torch.cuda.stream(stream):
                 rows = circuit.profile_kernels(x, iters=10)
@@ -565,6 +647,31 @@ def main() -> None:
                 a["flops"] += r.get("algorithmic_flops", 0.0)
                 a["exec"] += r.get("executed_flops", 0.0)
                 a["launches"] += 1
+            params_bytes = float(sum(int(np.prod(shp)) * 4 for shp, _ in plan.tensors.values()))
+
+            def kernel_fracs(k: str, v: dict) -> dict:
+                """Per launch of kernel k: measured HBM bytes and MFMA-busy cycles against the two peaks (over the trace-timed
+                duration where there is one), and the bytes the launch cannot avoid (what it reads that nobody on the chip holds
+                + what it must write for the next launch)."""
+                kp2 = next((pv for pk, pv in (pmc or {}).items() if pk.split("<")[0] == k.split("<")[0]), None)
+                t = (kp2["trace_us"] * 1e-6) if (kp2 and kp2.get("trace_us")) else (v["ms"] * 1e-3 / v["launches"])
+                out = {
+                    "frac_hbm": (kp2["hbm_bytes"] / t / 1e9 / HBM_PEAK_GBS) if (kp2 and "hbm_bytes" in kp2) else None,
+                    "frac_mfma": (kp2["mfma_busy_cycles"] / 64 * 4096 / t / 1e12 / FP32_MFMA_PEAK_TF) if (kp2 and "mfma_busy_cycles" in kp2) else None,
+                }
+                g0 = circuit._groups[0] if circuit._groups else None
+                if g0 is not None and circuit.layers[g0.input_layer].__class__.__name__ == "HipCategoricalLayer":
+                    cat = circuit.layers[g0.input_layer]
+                    table = float(circuit.layers[g0.dense_layer].num_folds * (cat.num_categories + 1) * 32 * 4) if g0.dense_layer is not None else 0.0
+                    roots = float(circuit.layers[g0.root].num_folds * B * 32 * 4)
+                    if k.startswith("leaf_persistent_kernel"):  # batch + table in, root tiles out
+                        out["compulsory_bytes"] = B * plan.num_variables * 8 + table + roots
+                    elif k.startswith("tail_params_kernel"):  # root tiles + raw parameters in, table (+ weights) out
+                        out["compulsory_bytes"] = roots + params_bytes + table + B * 4
+                    elif k.startswith("softmax_batch_kernel"):
+                        out["compulsory_bytes"] = params_bytes + table
+                return out
+
             name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
             t_launch = a["ms"] * 1e-3 / a["launches"]
             kp = (pmc or {}).get(name.split("<")[0] if name not in (pmc or {}) else name) or (pmc or {}).get(name)
@@ -585,8 +692,13 @@ def main() -> None:
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "peak": FP32_MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
                 "achieved": exec_tf if mfma_bound else (kp["hbm_bytes"] / t_launch / 1e9 if kp and "hbm_bytes" in kp else None),
-                "frac": exec_tf / FP32_MFMA_PEAK_TF if mfma_bound else hbm_frac,
-                # the same with the launch duration of a plain rocprofv3 kernel trace (no events between the launches)
+                # `frac`: with the launch duration of a plain rocprofv3 kernel trace (no events between the launches) when this run
+                # has one -- what `profiles/` reproduces --, else with the event-timed duration; the latter always as
+                # `frac_event_timed` (events around every launch cost each launch a few microseconds)
+                "frac": ((a["exec"] / a["launches"] / (kp["trace_us"] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF)
+                         if (kp and kp.get("trace_us") and mfma_bound) else (exec_tf / FP32_MFMA_PEAK_TF if mfma_bound else hbm_frac)),
+                "frac_timed_with": ("rocprofv3 kernel trace" if (kp and kp.get("trace_us") and mfma_bound) else "HIP events"),
+                "frac_event_timed": exec_tf / FP32_MFMA_PEAK_TF if mfma_bound else hbm_frac,
                 "trace_us_per_launch": kp.get("trace_us") if kp else None,
                 "frac_trace_timed": (a["exec"] / a["launches"] / (kp["trace_us"] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF)
                 if (kp and kp.get("trace_us") and mfma_bound) else None,
@@ -616,6 +728,7 @@ def main() -> None:
                                                       if pk.split("<")[0] == k.split("<")[0]), None),
                         "trace_us_per_launch": next((pv.get("trace_us") for pk, pv in (pmc or {}).items()
                                                      if pk.split("<")[0] == k.split("<")[0]), None),
+                        **kernel_fracs(k, v),
                     }
                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
                 },

@@ -187,6 +187,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_gaussian_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "ck_mixing_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_param_scaled_sigmoid_bwd": [_p, _p, _p, _l, _f, _f, _i, _p],
+    "ck_param_softmax_bwd_strided": [_p, _p, _p, _l, _i, _l, _i, _i, _p],
+    "ck_param_unary_bwd": [_i, _p, _p, _p, _p, _l, _i, _p],
     "ck_param_mixing_weight_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "ck_axpy_f32": [_p, _p, _f, _l, _p],
     "ck_param_binomial_table": [_p, _i, _p, _l, _i, _i, _p],

@@ -2,7 +2,7 @@
 SUBCLASSES whose ``forward`` calls the C ABI, registered on a ``PipelineContext``::
 
     import cirkit_amd.cirkit_plugin as plugin
-    ctx = plugin.HipLayersContext(semiring="lse-sum", fold=True, optimize=True)   # or plugin.register(existing_ctx)
+    ctx = plugin.HipLayersContext(semiring="lse-sum", fold=True, optimize=True)   # or plugin.register(existing_ctx, its_compiler)
     cc = ctx.compile(symbolic_circuit).to("cuda")      # every layer is a Hip* subclass of the reference's class
     cc(x)                                              # the reference's interpreter loop and gather, HIP layer kernels
 
@@ -258,10 +258,11 @@ class HipLayersContext(PipelineContext):
         _enable(self, self._compiler)
 
 
-def register(ctx):
-    """Enable the HIP layers on an EXISTING ``PipelineContext`` (torch backend) and return it: every layer compilation
-    rule of the reference is replaced by one that returns the HIP subclass, and the apply functions of the "fuse" and
-    "shatter" optimisation registries are wrapped the same way.  The context's compiler is the one attribute read that
-    ``PipelineContext`` does not expose through a method (`HipLayersContext` needs no such access)."""
-    _enable(ctx, getattr(ctx, "_compiler"))
+def register(ctx, compiler):
+    """Enable the HIP layers on an EXISTING ``PipelineContext`` (torch backend) whose compiler the caller holds, and return the
+    context: every layer compilation rule of the reference is replaced by one that returns the HIP subclass, and the apply
+    functions of the compiler's "fuse" and "shatter" optimisation registries are wrapped the same way.  ``PipelineContext``
+    exposes no accessor for its compiler, so this function does not look for it: `HipLayersContext` (a subclass, which
+    reaches its base's compiler as the base does) is the entry point that needs nothing from the caller."""
+    _enable(ctx, compiler)
     return ctx

@@ -210,18 +210,21 @@ __global__ void __launch_bounds__(256)
 }
 
 // One output unit over 32 inputs (the scalar root of a circuit, CK_SUM_PROD / H = 1): a half-wave per batch row, lane = input
-// unit; dW accumulates in the lane's register over the rows of the block and leaves with one atomic per lane and half-wave.
-__global__ void __launch_bounds__(256)
+// unit, 32 half-waves per block and rows_per_block rows per block, so few blocks share the 32 words of dW (atomics on ONE
+// cache line retire ~8 ns apart: 16 k of them, one per lane and 8-row block, made the launch 133 us).  dW: lane registers ->
+// LDS over the block's half-waves -> one atomic per input unit and block.
+__global__ void __launch_bounds__(1024)
     sum_lse_bwd_scalar32(const float* __restrict__ arena, float* __restrict__ garena, const int64_t* __restrict__ row_off,
                          const int64_t* __restrict__ grow_off, const float* __restrict__ w, const float* __restrict__ gout,
                          float* __restrict__ dw, int H, int B, int rows_per_block, int accumulate) {
-  const int f = blockIdx.y, i = threadIdx.x & 31, hw = threadIdx.x >> 5;  // 8 half-waves per block
+  __shared__ float part[32][33];
+  const int f = blockIdx.y, i = threadIdx.x & 31, hw = threadIdx.x >> 5;
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
   const int64_t* gro = grow_off + static_cast<int64_t>(f) * H;
   const float wi = w[static_cast<int64_t>(f) * kK + i];
   float dwi = 0.f;
   const int b0 = blockIdx.x * rows_per_block;
-  for (int b = b0 + hw; b < min(b0 + rows_per_block, B); b += 8) {
+  for (int b = b0 + hw; b < min(b0 + rows_per_block, B); b += 32) {
     float v = 0.f;
     for (int h = 0; h < H; ++h) v += arena[ro[h] + static_cast<int64_t>(b) * kK + i];
     float m = v;
@@ -238,7 +241,14 @@ __global__ void __launch_bounds__(256)
     const float gv = wi * e * gy;
     for (int h = 0; h < H; ++h) grad_store(garena + gro[h] + static_cast<int64_t>(b) * kK + i, gv, accumulate);
   }
-  if (dwi != 0.f) atomicAdd(dw + static_cast<int64_t>(f) * kK + i, dwi);
+  part[hw][i] = dwi;
+  __syncthreads();
+  if (hw == 0) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) sacc += part[k][i];
+    if (sacc != 0.f) atomicAdd(dw + static_cast<int64_t>(f) * kK + i, sacc);
+  }
 }
 
 // K = 32 product-type sum layers (dense / CP-T) on the register tile of ck_tile.h: three exact fp32
@@ -1030,6 +1040,40 @@ __global__ void __launch_bounds__(256)
     dx[i] = accumulate ? dx[i] + g : g;
   }
 }
+// softmax / log-softmax backward along ANY axis of a tensor viewed as (outer, len, inner) (TorchSoftmaxParameter /
+// TorchLogSoftmaxParameter, nodes.py:764-783: dim is any axis of the unfolded shape): a thread per (outer, inner) pair walks
+// the axis twice; neighbouring threads read neighbouring `inner` positions.  y is the node's OUTPUT.
+//   softmax:      dx = y (dy - sum_l y dy)          log-softmax:  dx = dy - exp(y) sum_l dy
+__global__ void __launch_bounds__(256)
+    softmax_bwd_strided_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, int64_t outer,
+                               int len, int64_t inner, int log_space, int accumulate) {
+  for (int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; t < outer * inner;
+       t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t base = (t / inner) * len * inner + t % inner;
+    float acc = 0.f;
+    for (int l = 0; l < len; ++l) acc += log_space ? dy[base + l * inner] : y[base + l * inner] * dy[base + l * inner];
+    for (int l = 0; l < len; ++l) {
+      const int64_t i = base + l * inner;
+      const float g = log_space ? dy[i] - expf(y[i]) * acc : y[i] * (dy[i] - acc);
+      dx[i] = accumulate ? dx[i] + g : g;
+    }
+  }
+}
+// entrywise parameter nodes (nodes.py:656-699) from input x and output y: sigmoid y (1 - y), exp y, log 1 / x, square 2 x
+__global__ void __launch_bounds__(256)
+    unary_bwd_kernel(int op, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                     float* __restrict__ dx, int64_t n, int accumulate) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    float d;
+    if (op == CK_UNARY_SIGMOID) d = y[i] * (1.f - y[i]);
+    else if (op == CK_UNARY_EXP) d = y[i];
+    else if (op == CK_UNARY_LOG) d = 1.f / x[i];
+    else d = 2.f * x[i];
+    const float g = dy[i] * d;
+    dx[i] = accumulate ? dx[i] + g : g;
+  }
+}
 // mixing weight (F, K, H) -> (F, K, H*K) block diagonal: dx[f,k,h] = dy[f,k,h*K + k]
 __global__ void __launch_bounds__(256)
     mixing_weight_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int64_t n, int K, int H,
@@ -1221,6 +1265,31 @@ int ck_param_scaled_sigmoid_bwd(const float* y, const float* dy, float* dx, int6
       stream);
 }
 
+int ck_param_softmax_bwd_strided(const float* y, const float* dy, float* dx, int64_t outer, int len, int64_t inner, int log_space,
+                                 int accumulate, void* stream) {
+  CK_REQUIRE(y && dy && dx && outer > 0 && len > 0 && inner > 0, "ck_param_softmax_bwd_strided: bad arguments");
+  dim3 grid(grid1(outer * inner)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(softmax_bwd_strided_kernel, grid, block, 0, s, y, dy, dx, outer, len, inner, log_space, accumulate);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_unary_bwd(int op, const float* x, const float* y, const float* dy, float* dx, int64_t n, int accumulate, void* stream) {
+  CK_REQUIRE(x && y && dy && dx && n > 0, "ck_param_unary_bwd: bad arguments");
+  CK_REQUIRE(op == CK_UNARY_SIGMOID || op == CK_UNARY_EXP || op == CK_UNARY_LOG || op == CK_UNARY_SQUARE,
+             "ck_param_unary_bwd: op %d (scaled sigmoid: ck_param_scaled_sigmoid_bwd)", op);
+  dim3 grid(grid1(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(unary_bwd_kernel, grid, block, 0, s, op, x, y, dy, dx, n, accumulate);
+        return hipGetLastError();
+      },
+      stream);
+}
+
 int ck_param_mixing_weight_bwd(const float* dy, float* dx, int F, int K, int H, int accumulate, void* stream) {
   CK_REQUIRE(dy && dx && F > 0 && K > 0 && H > 0, "ck_param_mixing_weight_bwd: bad arguments");
   const int64_t n = static_cast<int64_t>(F) * K * H;
@@ -1283,9 +1352,8 @@ int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, co
   CK_REQUIRE(accumulate >= 0 && accumulate <= 2, "ck_sum_lse_bwd: accumulate must be 0, 1 or 2");
   CK_REQUIRE(F <= 65535, "ck_sum_lse_bwd: F=%d exceeds grid.y", F);
   if ((mode == CK_SUM_PROD || H == 1) && Ki == kK && Ko == 1 && !g_bwd_force_generic) {
-    const int rpb = B >= 8 * 2048 ? 64 : 8;  // rows per block (8 half-waves): one row each unless the batch is huge -- the launch is a chain of
-                                              // dependent loads and shuffles per row, so rows in flight are what matters
-    dim3 grid((B + rpb - 1) / rpb, F), block(256);
+    const int rpb = 256;  // rows per block of 32 half-waves (8 rows each)
+    dim3 grid((B + rpb - 1) / rpb, F), block(1024);
     return ck::dispatch(
         [=](hipStream_t s) {
           hipLaunchKernelGGL(sum_lse_bwd_scalar32, grid, block, 0, s, arena, garena, row_off, grow, w, gout, dw, H, B, rpb, accumulate);

@@ -49,12 +49,18 @@ struct BwdArgs {
   float* gout;           // the gradient tile node Q leaves for its two children: (F_q, tiles, 1024) tile-native; LEAF: (F_q, B, 32) row-major
                          // (what the Categorical scatter reads row by row)
   const int32_t* redo;   // (n_roots, tiles) flags of the forward, or nullptr
-#ifdef CK_BWD_STAMPS
-  long long* stamps;     // (scripts/bwd_stamps.py) shader-clock stamps: [wave][unit < 16][8] of workgroup stamp_wg
+#ifdef CK_BWD_STAMPS  // the lab build of scripts/bwd_stamps.py / scripts/exp_leaf_bwd.sh (never the product)
+  long long* stamps;     // shader-clock stamps: [wave][unit < 16][8] of workgroup stamp_wg
   int stamp_wg;
-#endif
   int exp;               // timing experiments (CK_BWD_EXP, wrong results): 1 no dW contraction, 2 no W^T contraction, 4 every tile reads rows 0..31, 8 no stores
+#endif
 };
+
+#ifdef CK_BWD_STAMPS
+#define CK_EXP(args, bit) (((args).exp & (bit)) != 0)
+#else
+#define CK_EXP(args, bit) false
+#endif
 
 constexpr int kUnitTab = 16;
 
@@ -82,6 +88,26 @@ __device__ __forceinline__ void dw_accumulate(f32x16& acc, float* s_gy, float* s
     a[j] = s_gy[tsw(row, b_in)];
     b[j] = s_e[tsw(row, b_in)];
   }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The same through ONE 4 KB tile (the two operands take turns): for kernels that are short of LDS, not of time.
+__device__ __forceinline__ void dw_accumulate_seq(f32x16& acc, float* s_t, int b_in, int kh, const float (&gy)[16], const float (&e)[16]) {
+  float a[16], b[16];
+  tile_to_lds(s_t, b_in, kh, gy);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = s_t[tsw(16 * kh + j, b_in)];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // (the reads have returned before the tile is overwritten)
+  tile_to_lds(s_t, b_in, kh, e);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) b[j] = s_t[tsw(16 * kh + j, b_in)];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
   __builtin_amdgcn_wave_barrier();
@@ -160,7 +186,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
     const int c_fold[4] = {ut[4], ut[5], ut[6], ut[7]};
     const int var[4] = {ut[8], ut[9], ut[10], ut[11]};
     const int root = ut[12];
-    if (seg != static_cast<int>(blockIdx.x)) __syncthreads();  // every wave has left the previous segment
+    if (seg != static_cast<int>(blockIdx.x)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has left the previous segment's LDS
     // W^T of the three nodes: row-major W[o][i] -> dword (o >> 3) * 256 + (i + 32 ((o >> 2) & 1)) * 4 + (o & 3)
     for (int n = 0; n < 3; ++n) {
       const float* w = n == 0 ? a.w_p + static_cast<int64_t>(p_fold) * 1024 : a.w_q + static_cast<int64_t>(q_fold[n - 1]) * 1024;
@@ -193,7 +219,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
     uint32_t xlo[4];
     float g[16], y[16], yq0[16], yq1[16], c[4][16];
     auto issue_a = [&](int tile) mutable {  // everything whose address is known: the batch values first (they return first)
-      if (a.exp & 4) tile = 0;
+      if (CK_EXP(a, 4)) tile = 0;
       const int bl = min(tile * 32 + b_in, a.B - 1);
       const int64_t blk = static_cast<int64_t>(tile) * 1024;
       if constexpr (LEAF) {
@@ -220,15 +246,15 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
       }
     };
     auto node = [&](int n, const float (&gy)[16], const float (&e)[16], float (&out)[16]) {
-      if (!(a.exp & 1)) dw_accumulate(dw[n], s_gy, s_e, b_in, kh, gy, e);
-      if (!(a.exp & 2)) child_gradient(wt_lds + n * 1024, lane, gy, e, out);
+      if (!CK_EXP(a, 1)) dw_accumulate(dw[n], s_gy, s_e, b_in, kh, gy, e);
+      if (!CK_EXP(a, 2)) child_gradient(wt_lds + n * 1024, lane, gy, e, out);
       else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[r] = e[r] * gy[r];
       }
     };
     auto store = [&](int tile, const float (&r0)[16], const float (&r1)[16]) {
-      if (a.exp & 8) return;
+      if (CK_EXP(a, 8)) return;
       if constexpr (LEAF) {
         const int b = tile * 32 + b_in;
         if (b < a.B) {
@@ -284,16 +310,17 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
       }
       for (int k = 0; k < n_mine; ++k) {
         const int tile = first + k * WAVES;
-        const bool live = tile * 32 + b_in < a.B && !is_marked(k, tile);
+        const bool mk = is_marked(k, tile);  // (its kept tiles mean nothing: it contributes nothing and stores nothing)
+        const bool live = tile * 32 + b_in < a.B && !mk;
         CK_BSTAMP(0);
         // consume the raw tiles of this unit (the first touch waits for all of them; nothing younger is in flight)
-        float gyp[16], ep[16], eq0[16], eq1[16], dq0[16], dq1[16];
-        grad_over_y(g, y, live, gyp);
+        float gyp[16], ep[16], eq0[16], eq1[16], dq0[16], dq1[16];  // (dq: 1 / y of Q0, Q1)
+        grad_over_y(g, y, live, gyp);  // (dead rows and marked units: zero here, and with it every gradient below)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           ep[r] = yq1[r];
-          dq0[r] = yq0[r];
-          dq1[r] = yq1[r];
+          dq0[r] = mk ? 0.f : __builtin_amdgcn_rcpf(yq0[r]);  // (a marked unit's kept tiles hold zeros: no 1 / 0 into the products)
+          dq1[r] = mk ? 0.f : __builtin_amdgcn_rcpf(yq1[r]);
           eq0[r] = c[1][r];
           eq1[r] = c[3][r];
         }
@@ -308,37 +335,48 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         CK_BSTAMP(2);
         float gq[16], gy[16];
-        node(0, gyp, ep, gq);
+        node(0, gyp, ep, gq);  // (marked units and dead rows: gyp = 0, so every gradient and weight-gradient term below is 0)
         CK_BSTAMP(3);
         issue_b();
-        grad_over_y(gq, dq0, live, gy);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gy[r] = gq[r] * dq0[r];
         node(1, gy, eq0, r0);
         CK_BSTAMP(4);
-        grad_over_y(gq, dq1, live, gy);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gy[r] = gq[r] * dq1[r];
         node(2, gy, eq1, r1);
         CK_BSTAMP(5);
 #ifdef CK_BWD_STAMPS
         ++stamp_unit;
 #endif
-        rtile = live ? tile : (__any(live) ? tile : -1);
+        rtile = mk ? -1 : tile;
       }
       if (rtile >= 0) store(rtile, r0, r1);
     }
-    // the segment's weight gradients: summed over the waves in LDS, one atomic per element
-    __syncthreads();
+    // the segment's weight gradients: summed over the waves in LDS, one atomic per element.  The barriers only publish LDS
+    // data (__syncthreads would also wait for the atomics of the previous pass to be acknowledged: ~3 us each, per segment)
+    auto lds_barrier = [] {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    lds_barrier();  // (every wave has left the walk: the scratch tiles are free)
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
+      float* mine = (n < 2 ? s_gy + n * 1024 : s_gy);  // P and Q0 in the wave's two tiles, Q1 in the first one again
+      if (n == 2) lds_barrier();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_gy[(8 * (r >> 2) + 4 * kh + (r & 3)) * 32 + b_in] = dw[n][r];
-      __syncthreads();
-      float* dst = n == 0 ? a.dw_p + static_cast<int64_t>(p_fold) * 1024 : a.dw_q + static_cast<int64_t>(q_fold[n - 1]) * 1024;
-      for (int idx = threadIdx.x; idx < 1024; idx += WAVES * 64) {
-        float sacc = 0.f;
+      for (int r = 0; r < 16; ++r) mine[(8 * (r >> 2) + 4 * kh + (r & 3)) * 32 + b_in] = dw[n][r];
+      if (n == 0) continue;
+      lds_barrier();
+      for (int m = (n == 1 ? 0 : 2); m <= n; ++m) {
+        float* dst = m == 0 ? a.dw_p + static_cast<int64_t>(p_fold) * 1024 : a.dw_q + static_cast<int64_t>(q_fold[m - 1]) * 1024;
+        const float* src = scratch + (m == 1 ? 1024 : 0);
+        for (int idx = threadIdx.x; idx < 1024; idx += WAVES * 64) {
+          float sacc = 0.f;
 #pragma unroll
-        for (int w8 = 0; w8 < WAVES; ++w8) sacc += scratch[w8 * 2048 + idx];
-        if (sacc != 0.f) atomicAdd(dst + idx, sacc);
+          for (int w8 = 0; w8 < WAVES; ++w8) sacc += src[w8 * 2048 + idx];
+          if (sacc != 0.f) atomicAdd(dst + idx, sacc);
+        }
       }
-      __syncthreads();
     }
   }
 }
@@ -490,23 +528,28 @@ struct TableBwdArgs {
   int C;
 };
 
-__global__ void __launch_bounds__(512) table_dense_bwd_kernel(const TableBwdArgs a) {
+// Eight waves and exactly 80 KB of LDS per workgroup -- two workgroups per compute unit, four waves per SIMD: the kernel is a
+// chain of dependent phases (parameters in, table, tiles, reductions, gradients out: measured 97 us with one 148 KB workgroup
+// per CU, 161 us with two 4-wave ones), so what matters is how many waves overlap them.  The tile of T a wave has consumed is
+// overwritten in place by its tile of gT; exp(T) of the last phase is recomputed from the logits; the dW contraction's two
+// operands share one 4 KB tile per wave.
+constexpr int kTbWaves = 8;
+__global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const TableBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tb_lds[];
   const int C = a.C, rows = C + 1, n_t = (rows + 31) >> 5;
-  float* t_s = tb_lds;               // [n_t * 32][32] T, swizzled (tsw)
-  float* g_s = t_s + n_t * 1024;      // [n_t * 32][32] gT, swizzled
-  float* w_t = g_s + n_t * 1024;      // W, CK_W_TILED_F32 (A operand of y = W e)
-  float* wt_t = w_t + 1024;           // W^T, "transposed tiled" (A operand of W^T gy)
-  float* w_rm = wt_t + 1024;          // W row-major
-  float* scratch = w_rm + 1024;       // 8 x 2048: per wave gy / e tiles of the dW contraction
+  float* t_s = tb_lds;                 // [n_t * 32][32] T, then gT, swizzled (tsw)
+  float* w_t = t_s + n_t * 1024;       // W, CK_W_TILED_F32 (A operand of y = W e)
+  float* wt_t = w_t + 1024;            // W^T, "transposed tiled" (A operand of W^T gy)
+  float* w_rm = wt_t + 1024;           // W row-major
+  float* scratch = w_rm + 1024;        // kTbWaves x 1024: per wave the operand tile of the dW contraction
   const int d = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b_in = lane & 31, kh = lane >> 5;
   const int64_t f = a.cat_idx != nullptr ? a.cat_idx[d] : d;
   const float* theta = a.cat_logits + f * 32 * C;
   // W = softmax over the last axis of the fold's (32, 32) logits: 16 lanes per row, two entries each
-  {
-    const int o = threadIdx.x >> 4, j = threadIdx.x & 15;
+  for (int o = threadIdx.x >> 4; o < 32; o += kTbWaves * 4) {
+    const int j = threadIdx.x & 15;
     const float2 v = *reinterpret_cast<const float2*>(a.dense_logits + static_cast<int64_t>(d) * 1024 + o * 32 + 2 * j);
     float m = fmaxf(v.x, v.y);
 #pragma unroll
@@ -524,8 +567,11 @@ __global__ void __launch_bounds__(512) table_dense_bwd_kernel(const TableBwdArgs
       wt_t[(o >> 3) * 256 + (i + 32 * ((o >> 2) & 1)) * 4 + (o & 3)] = p[k];
     }
   }
-  // T[c][i] = theta[i][c] - logsumexp_c theta[i][:]: four units per wave, lanes over the categories
-  for (int i = wave * 4; i < wave * 4 + 4; ++i) {
+  // T[c][i] = theta[i][c] - logsumexp_c theta[i][:]: 32 / kTbWaves units per wave, lanes over the categories
+  float lse_mine[32 / kTbWaves];
+#pragma unroll
+  for (int ii = 0; ii < 32 / kTbWaves; ++ii) {
+    const int i = wave + ii * kTbWaves;
     const float* row = theta + i * C;
     float m = -INFINITY;
     for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
@@ -534,19 +580,20 @@ __global__ void __launch_bounds__(512) table_dense_bwd_kernel(const TableBwdArgs
     for (int c = lane; c < C; c += 64) sum += expf(row[c] - m);
     sum = ck::wave_sum(sum);
     const float lse = m + logf(sum);
+    lse_mine[ii] = lse;
     for (int c = lane; c < n_t * 32; c += 64) t_s[tsw(c, i)] = c < C ? row[c] - lse : 0.f;  // (row C: the integral row; beyond: padding)
   }
   __syncthreads();
   f32x16 dw;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dw[r] = 0.f;
-  float* s_gy = scratch + wave * 2048;
-  float* s_e = s_gy + 1024;
+  float* s_gy = scratch + wave * 1024;
   const float* dtp = a.dtp + static_cast<int64_t>(d) * rows * kK;
-  for (int tile = wave; tile < n_t; tile += 8) {
+  for (int tile = wave; tile < n_t; tile += kTbWaves) {
     const int c = tile * 32 + b_in;
     const bool live = c < rows;
-    float v[16], e[16], gy[16];
+    float v[16], e[16], gy[16], go[16];
+    tile_load(dtp + static_cast<int64_t>(live ? c : rows - 1) * kK + 4 * kh, go);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // register layout out of the swizzled tile
       const float4 t4 = *reinterpret_cast<const float4*>(t_s + c * 32 + 4 * ((2 * g + kh) ^ (c & 7)));
@@ -564,30 +611,28 @@ __global__ void __launch_bounds__(512) table_dense_bwd_kernel(const TableBwdArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = e[r];
     contract_linear<CK_W_TILED_F32>(w, v);  // y = W e
-    float go[16];
-    tile_load(dtp + static_cast<int64_t>(live ? c : rows - 1) * kK + 4 * kh, go);
 #pragma unroll
     for (int r = 0; r < 16; ++r) gy[r] = (live && v[r] > 0.f && go[r] != 0.f) ? go[r] / v[r] : 0.f;
-    dw_accumulate(dw, s_gy, s_e, b_in, kh, gy, e);
+    dw_accumulate_seq(dw, s_gy, b_in, kh, gy, e);
     float gt[16];
     child_gradient(wt_t, lane, gy, e, gt);
-    tile_to_lds(g_s + tile * 1024, b_in, kh, gt);
+    tile_to_lds(t_s + tile * 1024, b_in, kh, gt);  // (gT over the wave's own tile of T)
   }
   __syncthreads();
-  // dW over the waves -> row-major in scratch[0 .. 1024), then the softmax backward of the dense weights
+  // dW over the waves -> row-major over W^T's tile (free by now), then the softmax backward of the dense weights
 #pragma unroll
   for (int r = 0; r < 16; ++r) s_gy[(8 * (r >> 2) + 4 * kh + (r & 3)) * 32 + b_in] = dw[r];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 1024; idx += 512) {
+  for (int idx = threadIdx.x; idx < 1024; idx += kTbWaves * 64) {
     float sacc = 0.f;
 #pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) sacc += scratch[w8 * 2048 + idx];
-    scratch[8 * 2048 - 1024 + idx] = sacc;  // (the last wave's e tile: free by now)
+    for (int w8 = 0; w8 < kTbWaves; ++w8) sacc += scratch[w8 * 1024 + idx];
+    wt_t[idx] = sacc;
   }
   __syncthreads();
-  {
-    const float* dwr = scratch + 8 * 2048 - 1024;
-    const int o = threadIdx.x >> 4, j = threadIdx.x & 15;
+  for (int o = threadIdx.x >> 4; o < 32; o += kTbWaves * 4) {
+    const float* dwr = wt_t;
+    const int j = threadIdx.x & 15;
     const float w0 = w_rm[o * 32 + 2 * j], w1 = w_rm[o * 32 + 2 * j + 1];
     const float d0 = dwr[o * 32 + 2 * j], d1 = dwr[o * 32 + 2 * j + 1];
     float dot = w0 * d0 + w1 * d1;
@@ -596,12 +641,16 @@ __global__ void __launch_bounds__(512) table_dense_bwd_kernel(const TableBwdArgs
     *reinterpret_cast<float2*>(a.g_dense + static_cast<int64_t>(d) * 1024 + o * 32 + 2 * j) = make_float2(w0 * (d0 - dot), w1 * (d1 - dot));
   }
   // column sums of gT over the categories (row C has no gradient), then dtheta_c, coalesced along the categories
-  for (int i = wave * 4; i < wave * 4 + 4; ++i) {
+#pragma unroll
+  for (int ii = 0; ii < 32 / kTbWaves; ++ii) {
+    const int i = wave + ii * kTbWaves;
     float sacc = 0.f;
-    for (int c = lane; c < C; c += 64) sacc += g_s[tsw(c, i)];
+    for (int c = lane; c < C; c += 64) sacc += t_s[tsw(c, i)];
     sacc = ck::wave_sum(sacc);
+    const float* row = theta + i * C;
+    const float lse = lse_mine[ii];
     float* out = a.g_cat + f * 32 * C + i * C;
-    for (int c = lane; c < C; c += 64) out[c] = g_s[tsw(c, i)] - expf(t_s[tsw(c, i)]) * sacc;
+    for (int c = lane; c < C; c += 64) out[c] = t_s[tsw(c, i)] - expf(row[c] - lse) * sacc;
   }
 }
 
@@ -637,8 +686,8 @@ int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* d, void* stream) {
   a.gout = d->gout;
   a.redo = d->redo;
   a.gin_rowmajor = d->gin_rowmajor;
-  a.exp = getenv("CK_BWD_EXP") != nullptr ? atoi(getenv("CK_BWD_EXP")) : 0;
 #ifdef CK_BWD_STAMPS
+  a.exp = getenv("CK_BWD_EXP") != nullptr ? atoi(getenv("CK_BWD_EXP")) : 0;
   a.stamps = getenv("CK_BWD_STAMP_PTR") != nullptr && (d->leaf != 0) == (getenv("CK_BWD_STAMP_TOP") == nullptr)
                  ? reinterpret_cast<long long*>(strtoull(getenv("CK_BWD_STAMP_PTR"), nullptr, 0)) : nullptr;
   a.stamp_wg = getenv("CK_BWD_STAMP_WG") != nullptr ? atoi(getenv("CK_BWD_STAMP_WG")) : 8;
@@ -666,7 +715,7 @@ int ck_table_dense_bwd(const float* cat_logits, const int64_t* cat_idx, const fl
   CK_REQUIRE(cat_logits && dense_logits && dtable && g_cat && g_dense, "ck_table_dense_bwd: null pointer");
   CK_REQUIRE(F > 0 && C > 0, "ck_table_dense_bwd: non-positive size");
   const int n_t = (C + 1 + 31) / 32;
-  const size_t lds = (static_cast<size_t>(2 * n_t + 3) * 1024 + 8 * 2048) * sizeof(float);
+  const size_t lds = (static_cast<size_t>(n_t + 3) * 1024 + kTbWaves * 1024) * sizeof(float);
   if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_table_dense_bwd: C=%d does not fit in LDS", C);
   TableBwdArgs a{cat_logits, cat_idx, dense_logits, dtable, g_cat, g_dense, C};
   dim3 grid(static_cast<unsigned>(F));
@@ -675,7 +724,7 @@ int ck_table_dense_bwd(const float* cat_logits, const int64_t* cat_idx, const fl
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(table_dense_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(table_dense_bwd_kernel, grid, dim3(512), lds, s, a);
+        hipLaunchKernelGGL(table_dense_bwd_kernel, grid, dim3(kTbWaves * 64), lds, s, a);
         return hipGetLastError();
       },
       stream);

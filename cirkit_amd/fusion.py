@@ -387,10 +387,10 @@ def leaf_segments(num_roots: int, num_tiles: int, num_wg: int) -> np.ndarray:
 
 
 def balanced_segments(num_roots: int, num_tiles: int, num_wg: int, waves: int = 8, max_pieces: int = 16,
-                      overhead: float = 0.5) -> np.ndarray:
+                      overhead: float = 1.5) -> np.ndarray:
     """Segment list ``(n_seg, 4)`` for a persistent launch whose workgroups take SEVERAL segments (`ck_leaf_walk_bwd`:
     workgroup g takes segments g, g + num_wg, ...).  A segment's tiles are dealt round-robin to the `waves` waves of its
-    workgroup, so it costs ceil(tiles / waves) unit times plus `overhead` (weights staged, weight gradients flushed), and
+    workgroup, so it costs ceil(tiles / waves) unit times plus `overhead` (weights staged, weight gradients flushed: measured ~1.5 unit times, scripts/bwd_stamps.py), and
     the launch takes as long as its busiest workgroup.  Every root is therefore cut into k ranges of WHOLE wave rounds
     (multiples of `waves` tiles, the remainder in the last one), k chosen to minimise that critical path, and the segments are
     dealt longest first.  196 roots x 128 tiles on 256 workgroups of 8 waves: one segment per root leaves 60 workgroups

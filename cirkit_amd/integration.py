@@ -10,7 +10,7 @@ b3  `HipModuleFn(circuit)` -- a ``ModuleEvalFunctional`` (cirkit/backend/torch/g
 b4  `to_hip(circuit)` -- replace the whole forward: extract the folded plan from the compiled
     ``TorchCircuit`` and return a `HipCircuit` (fused gathers, recorded launch list, leaf fusion).
 b2  layer compilation rules returning ``TorchLayer`` subclasses that call the C ABI live in
-    `cirkit_amd/cirkit_plugin.py` (it imports cirkit; ``plugin.register(ctx)``, pipeline.py:110-116).
+    `cirkit_amd/cirkit_plugin.py` (it imports cirkit; ``plugin.HipLayersContext``, pipeline.py:110-116).
 """
 
 from __future__ import annotations
@@ -33,6 +33,11 @@ def to_hip(circuit: Any, *, device: str | torch.device = "cuda:0", **kw: Any) ->
     ``pad_units=True`` to trade the sharing for the MFMA tiles when the widths are not multiples of 32."""
     plan, tensors = plan_from_torch_circuit(circuit)
     kw.setdefault("pad_units", False)
+    # The storage is shared with arbitrary torch code: a write through `p.data` or by a foreign kernel bumps no version
+    # counter, so whether the derived parameters of the previous forward are still valid cannot be known here -- they are
+    # re-evaluated at the START of every forward, exactly as the reference does (parameters/parameter.py:180-188).  The
+    # native-plan `HipCircuit` owns its store and defaults to evaluating them at the end of the previous forward.
+    kw.setdefault("params_at_end", False)
     return HipCircuit(plan, tensors, device=device, **kw)
 
 

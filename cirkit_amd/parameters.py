@@ -483,12 +483,22 @@ class HipParameter:
             if n.op == "tensor" or j not in gb:
                 continue
             dj = gb[j]
-            if n.op == "softmax":
-                if int(n.config["dim"]) != len(n.shape) - 1:
-                    raise NotImplementedError("softmax backward along an inner axis")
+            if n.op in ("softmax", "log_softmax"):  # any axis (nodes.py:764-783)
                 y = value(j)
                 dx, acc, sc = direct(j, 0)
-                capi.call("ck_param_softmax_bwd", _ptr(y), _ptr(dj), _ptr(dx), y.numel() // y.shape[-1], int(y.shape[-1]), acc, stream)
+                dim = int(n.config["dim"]) + 1
+                if n.op == "softmax" and dim == y.dim() - 1:
+                    capi.call("ck_param_softmax_bwd", _ptr(y), _ptr(dj), _ptr(dx), y.numel() // y.shape[-1], int(y.shape[-1]), acc, stream)
+                else:
+                    capi.call("ck_param_softmax_bwd_strided", _ptr(y), _ptr(dj), _ptr(dx), int(np.prod(y.shape[:dim])), int(y.shape[dim]),
+                              int(np.prod(y.shape[dim + 1:])), 1 if n.op == "log_softmax" else 0, acc, stream)
+                if sc:
+                    scatter((j, 0), n.inputs[0], dx)
+            elif n.op in ("sigmoid", "exp", "log", "square"):  # entrywise nodes (nodes.py:656-699)
+                y, x = value(j), operand(j, 0)
+                dx, acc, sc = direct(j, 0)
+                code = {"sigmoid": capi.CK_UNARY_SIGMOID, "exp": capi.CK_UNARY_EXP, "log": capi.CK_UNARY_LOG, "square": capi.CK_UNARY_SQUARE}[n.op]
+                capi.call("ck_param_unary_bwd", code, _ptr(x), _ptr(y), _ptr(dj), _ptr(dx), y.numel(), acc, stream)
                 if sc:
                     scatter((j, 0), n.inputs[0], dx)
             elif n.op == "scaled_sigmoid":

@@ -60,8 +60,9 @@ class HipPipelineContext:
         plan, tvals = plan_from_torch_circuit(circuit, table=self._table)
         if plan.semiring != self.semiring:
             raise ValueError(f"circuit was compiled under {plan.semiring!r}, context is {self.semiring!r}")
-        # (parameters extracted from a reference circuit stay SHARED with it: no padding copies)
-        return HipCircuit(plan, tvals, device=self.device, use_graph=self.use_graph, pad_units=False)
+        # (parameters extracted from a reference circuit stay SHARED with it: no padding copies, and -- since writes through
+        # `.data` or foreign kernels are invisible to the store -- derived parameters re-evaluated at the start of every forward)
+        return HipCircuit(plan, tvals, device=self.device, use_graph=self.use_graph, pad_units=False, params_at_end=False)
 
 
 def compile_unfolded(plan: Plan, tensors: Mapping[str, Any], **ctx_kwargs: Any) -> HipCircuit:

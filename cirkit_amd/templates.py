@@ -23,8 +23,8 @@ fixtures extracted from the real reference:
                            the same procedure one level down for the parameter graphs of a group
                            (utils/algorithms.py:71-97, graph/folding.py:62-298, torch/compiler.py:335-506)
 
-Chow-Liu trees learnt from data (`chow_liu_tree`, region_graph='chow-liu-tree') and Binomial input layers are built here
-as well (round 1; outside SURVEY.md section 8's f1 list -- kept, not extended).
+Binomial input layers are built here as well (round 1; outside SURVEY.md section 8's f1 list -- kept because committed
+plan fixtures use them, not extended).  The Chow-Liu structure learner of round 1 is gone (out of scope).
 """
 
 from __future__ import annotations
@@ -366,144 +366,6 @@ def linear_tree(num_variables: int, *, num_repetitions: int = 1, ordering: list[
             b.ins[ptn] = [leaf, nxt]
             node = nxt
     return b.graph(root)
-
-
-# ---------------------------------------------------------------------------------------------
-# structure learned from data: Chow-Liu tree -> hidden Chow-Liu tree region graph
-# (templates/region_graph/algorithms/chow_liu.py, utils.py:66-131 of the reference)
-# ---------------------------------------------------------------------------------------------
-def _categorical_mutual_information(data, num_categories: int | None, chunk_size: int | None, alpha: float = 0.01):
-    """Pairwise mutual information of integer columns with Laplace smoothing `alpha` (chow_liu.py:105-150):
-    joint counts of every pair of columns, the marginals read off the diagonal blocks, and
-    MI[i, j] = sum_kl P_ij(k, l) (log P_ij(k, l) - log P_i(k) P_j(l)), diagonal set to 0.
-    Evaluated with torch in fp32 like the reference, so that near-ties between edges resolve the same way."""
-    import torch
-
-    x = torch.as_tensor(data).long()
-    n, d = x.shape
-    c = int(x.max().item() + 1) if num_categories is None else int(num_categories)
-    counts = torch.zeros((d, d, c * c), dtype=torch.long)
-    for part in x.split(n if chunk_size is None else chunk_size):
-        pair = part.t().unsqueeze(1) * c + part.t().unsqueeze(0)  # (d, d, rows): category pair of columns (i, j)
-        counts.scatter_add_(-1, pair, torch.ones_like(pair))
-    counts = counts.view(d, d, c, c)
-    diag = torch.arange(d)
-    cats = torch.arange(c)
-    marg_counts = counts[diag, diag][:, cats, cats]  # (d, c): a column paired with itself counts its categories
-    denom = n + c * c * alpha
-    marg = (marg_counts + c * alpha) / denom
-    joint = (counts + alpha) / denom
-    joint[diag, diag] = torch.diag_embed(marg)
-    indep = torch.einsum("ik,jl->ijkl", marg, marg)
-    return (joint * (joint.log() - indep.log())).sum(dim=(2, 3)).fill_diagonal_(0)
-
-
-def _mixed_mutual_information(data, is_categorical: list[bool], normalize: bool = True):
-    """Mutual information between columns of mixed type (chow_liu.py:153-254): Gaussian columns among themselves
-    as a multivariate normal, categorical columns among themselves by counting, a Gaussian column C against a
-    categorical column D as H(C) - sum_d p(d) H(C | D = d) with Gaussian entropies (variance + 1e-4); optionally
-    normalised by the column entropies, NMI = 2 I / (H_i + H_j)."""
-    import torch
-
-    x = torch.as_tensor(data)
-    mask = torch.tensor(is_categorical, dtype=torch.bool)
-    cont = torch.where(~mask)[0]
-    disc = torch.where(mask)[0]
-    d = x.shape[1]
-    mi = torch.zeros((d, d), dtype=torch.float32)
-    if len(cont) > 1:
-        r = torch.corrcoef(x[:, cont].t()).fill_diagonal_(0)
-        mi[cont.unsqueeze(1), cont] = (-0.5 * torch.log(1 - r**2)).float()
-    if len(disc) > 1:
-        mi[disc.unsqueeze(1), disc] = _categorical_mutual_information(x[:, disc].long(), None, None).float()
-
-    def h_gauss(col):
-        return 0.5 * (torch.log(2 * torch.pi * torch.var(col, unbiased=False) + 1e-4) + 1)
-
-    ncat = {j: int(x[:, j].max() + 1) for j in disc.tolist()}
-    p_d = {j: x[:, j].long().bincount(minlength=ncat[j]).float() / x.shape[0] for j in disc.tolist()}
-    h_c = {i: h_gauss(x[:, i]) for i in cont.tolist()}
-    for i in cont.tolist():
-        for j in disc.tolist():
-            cond = torch.stack([h_gauss(x[:, i][x[:, j] == k]) for k in range(ncat[j])], dim=0)
-            mi[i, j] = mi[j, i] = h_c[i] - torch.sum(cond * p_d[j])
-    if normalize:
-        ent = torch.zeros(d, dtype=torch.float32)
-        ent[cont] = torch.tensor(list(h_c.values()), dtype=torch.float32)
-        ent[disc] = torch.tensor([-(p.log() * p).sum() for p in p_d.values()], dtype=torch.float32)
-        mi = 2 * mi / (ent.unsqueeze(0) + ent.unsqueeze(1))
-    return mi.fill_diagonal_(0)
-
-
-def chow_liu_predecessors(data, input_type: str | list[str], *, root: int | None = None, chunk_size: int | None = None,
-                          num_categories: int | None = None, num_bins: int | None = None) -> np.ndarray:
-    """The Chow-Liu tree of tabular `data` (rows x features) as a list of predecessors (-1 at the root): maximum
-    spanning tree of the pairwise mutual information, rooted at `root` or at the vertex of least eccentricity
-    (chow_liu.py:11-102).  Uses the same scipy.sparse.csgraph routines as the reference, on the same matrix."""
-    import torch
-    from scipy.sparse import csgraph
-
-    x = torch.as_tensor(data)
-    if x.ndim != 2:
-        raise ValueError("Chow-Liu structure learning needs tabular data (rows x features)")
-    if root is not None and not 0 <= root < x.shape[1]:
-        raise ValueError("the root must be one of the features")
-    if isinstance(input_type, list):
-        mi = _mixed_mutual_information(x, [t == "categorical" for t in input_type])
-    elif input_type == "categorical":
-        if num_bins is not None:
-            if num_categories is None:
-                raise ValueError("Number of categories must be known if rescaling in bins")
-            x = torch.div(x, num_categories // num_bins, rounding_mode="floor")
-        mi = _categorical_mutual_information(x.long(), num_categories, chunk_size)
-    elif input_type == "gaussian":
-        mi = -0.5 * torch.log(1 - torch.corrcoef(x.t()) ** 2)
-    else:
-        raise NotImplementedError(f"MI computation not implemented for {input_type} input units")
-    mst = csgraph.minimum_spanning_tree(-(mi.cpu().numpy() + 1.0), overwrite=True)
-    if root is None:
-        dist = csgraph.dijkstra(abs(mst).todense(), directed=False, return_predecessors=False)
-        root = int(np.argmin(np.max(dist, axis=1)))
-    _, pred = csgraph.breadth_first_order(mst, directed=False, i_start=root, return_predecessors=True)
-    pred[root] = -1
-    return pred
-
-
-def tree_to_region_graph(predecessors) -> RegionGraph:
-    """Hidden Chow-Liu tree region graph of a rooted tree over the variables (utils.py:66-131): every variable
-    with children gets a partition over itself and ALL its descendants, whose inputs are its own leaf region and
-    one region per child subtree (in variable order), and a region above that partition; childless variables
-    are leaf regions feeding their parent's partition.  Nodes are created in the reference's order (partitions
-    by variable, then per variable its leaf region and its inner region), which fixes the layer order."""
-    tree = [int(p) for p in predecessors]
-    n = len(tree)
-    below: list[set[int]] = [set() for _ in range(n)]
-    for v in range(n):
-        u = tree[v]
-        while u != -1:
-            below[u].add(v)
-            u = tree[u]
-    b = _RGBuilder()
-    part = {u: b.new(False, below[u] | {u}) for u in range(n) if below[u]}
-    top: dict[int, int] = {}
-    for v in range(n):
-        leaf = b.new(True, [v])
-        up = tree[v]
-        if v not in part:
-            top[v] = leaf
-            if up != -1:
-                b.ins.setdefault(part[up], []).append(leaf)
-            continue
-        b.ins.setdefault(part[v], []).append(leaf)
-        rgn = b.new(True, below[v] | {v})
-        top[v] = rgn
-        b.ins.setdefault(rgn, []).append(part[v])
-        if up != -1:
-            b.ins.setdefault(part[up], []).append(rgn)
-    roots = [v for v in range(n) if tree[v] == -1]
-    if len(roots) != 1:
-        raise ValueError("the predecessors must describe ONE rooted tree")
-    return b.graph(top[roots[0]])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1005,14 +867,9 @@ def tabular_data(
     """``data_modalities.tabular_data`` (:165-305) followed by ``compile(fold=True, optimize=True)``.
     `input_layers` is one ``{'name': ..., 'args': {...}}`` dict or a list with one per feature."""
     if region_graph == "chow-liu-tree":
-        if data is None:
-            raise ValueError("You must pass `data=` if you ask for `chow-liu-tree`.")
-        single = isinstance(input_layers, dict)
-        pred = chow_liu_predecessors(
-            data, input_layers["name"] if single else [d["name"] for d in input_layers],
-            num_categories=input_layers["args"]["num_categories"] if single and input_layers["name"] == "categorical" else None)
-        rg = tree_to_region_graph(pred)
-    elif region_graph == "random-binary-tree":
+        raise NotImplementedError("structure learning (region_graph='chow-liu-tree') is outside this backend's scope: compile the "
+                                  "circuit with cirkit and pass the compiled TorchCircuit to cirkit_amd.pipeline.compile")
+    if region_graph == "random-binary-tree":
         if num_features is None:
             if data is None:
                 raise ValueError(f"You must pass `num_features=` if you ask for {region_graph}.")

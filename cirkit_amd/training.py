@@ -136,7 +136,7 @@ class HipTrainer:
         self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)  # Adam steps that did not count
 
     # ------------------------------------------------------------------------------------------
-    _PARAM_OPS = {"tensor", "softmax", "scaled_sigmoid", "mixing_weight", "matmul"}
+    _PARAM_OPS = {"tensor", "softmax", "log_softmax", "sigmoid", "exp", "log", "square", "scaled_sigmoid", "mixing_weight", "matmul"}
 
     def _check_supported(self) -> None:
         for spec, l in zip(self.plan.layers, self.circuit.layers):
@@ -199,7 +199,7 @@ class HipTrainer:
         dev = c.device
         dl = c.layers[g.dense_layer]
         Cn = cat.num_categories
-        if (2 * ((Cn + 1 + 31) // 32) + 3) * 4096 + 8 * 8192 > 160 * 1024:
+        if (((Cn + 1 + 31) // 32) + 3) * 4096 + 8 * 4096 > 160 * 1024:
             return "too many categories for the table backward's LDS"
         kl = 1 << g.depth
         nodes = np.asarray(g.nodes).astype(np.int64)

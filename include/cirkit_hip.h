@@ -549,6 +549,12 @@ int ck_mixing_lse_bwd(const float* arena, float* garena, const int64_t* row_off,
  * expansion (nodes.py:857-862), y += a x. */
 int ck_param_scaled_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, float vmin, float vmax,
                                 int accumulate, void* stream);
+/* softmax / log-softmax backward along any axis: tensors viewed as (outer, len, inner), y = the node's output
+ * (TorchSoftmaxParameter / TorchLogSoftmaxParameter for any `dim`, nodes.py:764-783); entrywise nodes from input x and output y
+ * (CK_UNARY_SIGMOID / EXP / LOG / SQUARE, nodes.py:656-699). */
+int ck_param_softmax_bwd_strided(const float* y, const float* dy, float* dx, int64_t outer, int len, int64_t inner, int log_space,
+                                 int accumulate, void* stream);
+int ck_param_unary_bwd(int op, const float* x, const float* y, const float* dy, float* dx, int64_t n, int accumulate, void* stream);
 int ck_param_mixing_weight_bwd(const float* dy, float* dx, int F, int K, int H, int accumulate, void* stream);
 int ck_axpy_f32(float* y, const float* x, float a, int64_t n, void* stream);
 /* Backward of ck_param_gather_folds: ddst[idx[i]] += dsrc[i] over blocks of `per_fold` fp32 words. */

@@ -390,6 +390,39 @@ def grads_tucker():
         torch.set_grad_enabled(False)
 
 
+def grads_param_nodes():
+    """Round 4: the reference's autograd through parameter nodes the default templates do not produce -- a softmax along an
+    INNER axis (TorchSoftmaxParameter with dim != last, nodes.py:764-772: sum weights normalised over the OUTPUT units) and a
+    sigmoid activation (nodes.py:656-699) -- plan, forward fixture and every gradient."""
+    torch.set_grad_enabled(True)
+    try:
+        for name, wpar in [
+            ("quadtree_4x4_softmax0_k4", Parameterization(activation="softmax", initialization="normal", activation_kwargs={"axis": 0})),
+            ("quadtree_4x4_sigmoid_k4", Parameterization(activation="sigmoid", initialization="normal")),
+        ]:
+            sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", input_layer="categorical", num_input_units=4,
+                                            sum_product_layer="cp", num_sum_units=4, sum_weight_param=wpar)
+            cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+            plan, tensors = plan_from_torch_circuit(cc)
+            with torch.no_grad():
+                _load_closed_form(plan, tensors)
+            g = torch.Generator().manual_seed(17)
+            x = torch.randint(0, 256, (20, 16), generator=g)
+            with torch.no_grad():
+                _save(name, plan, {"x": x.numpy().astype(np.int16), "y_f32": cc(x).numpy(), "y_f64": _fp64_copy(cc)(x).numpy()})
+            loss = -cc(x).mean()
+            loss.backward()
+            by_ptr = {p.data_ptr(): p for p in cc.parameters()}
+            extra = {"x": x.numpy().astype(np.int16), "loss": np.array(loss.item())}
+            for k, t in tensors.items():
+                extra["g_" + k] = by_ptr[t.data_ptr()].grad.numpy()
+            np.savez_compressed(os.path.join(HERE, name + "_grads.npz"), **extra)
+            print(name, [(l.type, [n.op + str(n.config.get("dim", "")) for pg in l.params.values() for n in pg.nodes]) for l in plan.layers][:3],
+                  "grads:", {k: float(np.linalg.norm(v)) for k, v in extra.items() if k.startswith("g_")})
+    finally:
+        torch.set_grad_enabled(False)
+
+
 def grads_sos():
     """Round 3: the reference's autograd through the COMPLEX semiring (ComplexLSESumSemiring.apply_reduce, semiring.py:441-476;
     ComplexSafeLog, utils.py:22-50): a small squared circuit c (Embedding, CP-T, signed weights) and its partition function
@@ -611,6 +644,6 @@ def chow_liu():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "grads_tucker", "grads_sos", "marginals", "templates_extra"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "grads_tucker", "grads_param_nodes", "grads_sos", "marginals", "templates_extra"]
     for w in which:
         globals()[w]()

@@ -19,6 +19,14 @@ from cirkit.pipeline import PipelineContext  # noqa: E402
 from cirkit.templates import data_modalities, utils  # noqa: E402
 
 
+def _registered(ctx):
+    """`plugin.register` takes the context's compiler from the CALLER (cirkit exposes no accessor for it; a user who built the
+    context owns that choice -- `HipLayersContext` needs nothing of the kind)."""
+    import cirkit_amd.cirkit_plugin as plugin
+
+    return plugin.register(ctx, ctx._compiler)
+
+
 def _symbolic(kind):
     if kind == "qt_cat_cp":
         return data_modalities.image_data((1, 8, 8), region_graph="quad-tree-2", input_layer="categorical", num_input_units=8,
@@ -42,7 +50,7 @@ def test_registered_rules_survive_optimisation_and_folding(kind, fold, optimize)
     torch.manual_seed(0)
     stock = PipelineContext(backend="torch", semiring="lse-sum", fold=fold, optimize=optimize).compile(sc)
     torch.manual_seed(0)
-    ctx = plugin.register(PipelineContext(backend="torch", semiring="lse-sum", fold=fold, optimize=optimize))
+    ctx = _registered(PipelineContext(backend="torch", semiring="lse-sum", fold=fold, optimize=optimize))
     cc = ctx.compile(sc)
     a, b = list(stock.layers), list(cc.layers)
     assert len(a) == len(b)
@@ -73,7 +81,7 @@ def test_plan_extraction_accepts_the_plugin_circuit():
 
     sc = _symbolic("qt_cat_cp")
     stock = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
-    cc = plugin.register(PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)).compile(sc)
+    cc = _registered(PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)).compile(sc)
     pa, _ = plan_from_torch_circuit(stock)
     pb, _ = plan_from_torch_circuit(cc)
     assert [(l.type, l.num_folds, l.arity, l.num_input_units, l.num_output_units) for l in pa.layers] == \
@@ -85,11 +93,11 @@ def test_forward_without_a_rocm_device_fails_loudly():
     from cirkit_amd._capi import HipExtensionError
 
     sc = _symbolic("qt_cat_cp")
-    cc = plugin.register(PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)).compile(sc)
+    cc = _registered(PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)).compile(sc)
     with pytest.raises(HipExtensionError):
         cc(torch.randint(0, 256, (4, 64)))
     with pytest.raises(NotImplementedError):
-        bad = plugin.register(PipelineContext(backend="torch", semiring="sum-product", fold=True, optimize=True)).compile(sc)
+        bad = _registered(PipelineContext(backend="torch", semiring="sum-product", fold=True, optimize=True)).compile(sc)
         bad(torch.randint(0, 256, (4, 64)))
 
 
@@ -105,3 +113,30 @@ def test_hip_layers_context_and_isolation_of_other_contexts():
     stock = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
     assert not any(type(l) in hip for l in stock.layers)
     assert [plugin.HIP_LAYER_CLASSES[type(a)] for a in stock.layers] == [type(b) for b in cc.layers]
+
+
+def test_shared_storage_entry_points_reevaluate_parameters_at_the_start(monkeypatch):
+    """`to_hip(tc)` and `HipPipelineContext.compile(TorchCircuit)` share parameter storage with the reference circuit, so they
+    ask for `params_at_end=False` (a write through `p.data` is invisible to `TensorStore.state()`); the native-plan entry keeps
+    `HipCircuit`'s own default.  (What the option does is tested on the GPU: test_shared_storage_sees_writes_through_data.)"""
+    import cirkit_amd.integration as integ
+    import cirkit_amd.pipeline as pipe
+
+    seen = []
+
+    def fake(plan, tensors, **kw):
+        seen.append(kw)
+        return kw
+
+    monkeypatch.setattr(integ, "HipCircuit", fake)
+    monkeypatch.setattr(pipe, "HipCircuit", fake)
+    sc = _symbolic("qt_cat_cp")
+    tc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+    integ.to_hip(tc)
+    pipe.HipPipelineContext().compile(tc)
+    assert [kw["params_at_end"] for kw in seen] == [False, False] and all(kw["pad_units"] is False for kw in seen)
+    from cirkit_amd.plan import plan_from_torch_circuit
+
+    plan, tensors = plan_from_torch_circuit(tc)
+    pipe.HipPipelineContext().compile(plan, tensors)
+    assert "params_at_end" not in seen[-1]

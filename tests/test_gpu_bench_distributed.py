@@ -52,17 +52,29 @@ def _expected_last_step(hip_device, world: int) -> torch.Tensor:
     return tot
 
 
-def _check_two_ranks(d: dict, hip_device) -> None:
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * B and d["scaling"] == "weak"
-    assert d["distributed"] == {"backend": "gloo", "world_size": 2, "ranks_seen_by_backend": 2, "every_step_exchanged": True,
-                                "steps_per_collective": 64}
-    assert d["check"]["rows"] == 2 * B
+def _dist_fields(d: dict) -> dict:
+    return {k: d["distributed"][k] for k in ("backend", "world_size", "ranks_seen_by_backend", "every_step_exchanged", "steps_per_collective")}
+
+
+def _check_ranks(d: dict, hip_device, world: int) -> None:
+    assert d["n_gpus"] == world and d["config"]["global_batch"] == world * B and d["scaling"] == "weak"
+    assert _dist_fields(d) == {"backend": "gloo", "world_size": world, "ranks_seen_by_backend": world, "every_step_exchanged": True,
+                               "steps_per_collective": 64}
+    # per-rank wall time of the median round: a straggler would show as a gap between the two
+    lo, hi = d["distributed"]["ms_per_step_fastest_rank"], d["distributed"]["ms_per_step_slowest_rank"]
+    assert 0 < lo <= hi and abs(hi - d["ms_per_step"]) <= 0.5 * d["ms_per_step"]
+    assert d["check"]["rows"] == world * B
     assert d["steps_timed_total"] == ROUNDS * STEPS
-    assert d["value"] > 0 and abs(d["value"] - 2 * B / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["value"] > 0 and abs(d["value"] - world * B / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["cold_first_round_ms_per_step"] > 0
     # the reported mean LL is the all-reduced [sum, count] of the LAST step: the same batches evaluated in this process
-    tot = _expected_last_step(hip_device, 2)
-    assert tot[1].item() == 2 * B
+    tot = _expected_last_step(hip_device, world)
+    assert tot[1].item() == world * B
     assert abs(d["check"]["mean_ll"] - tot[0].item() / tot[1].item()) <= 1e-9 * abs(tot[0].item() / tot[1].item())
+
+
+def _check_two_ranks(d: dict, hip_device) -> None:
+    _check_ranks(d, hip_device, 2)
 
 
 def test_bench_two_ranks_gloo_on_one_device(hip_device):
@@ -83,6 +95,20 @@ def test_bench_launches_its_own_ranks(hip_device):
     _check_two_ranks(_one_json_line(out), hip_device)
 
 
+def test_bench_eight_ranks_is_baseline_config_3(hip_device):
+    """`python bench.py --gpus 8`, self-launched, eight ranks on the ONE device of this box over gloo: the launch, rendezvous,
+    per-rank seeds and batches, bucketed exchange of every step's [sum, count], max-over-ranks timing and the single JSON line
+    of BASELINE config 3 (32768 rows = 8 x 4096) -- everything of the driver's 8-GPU run but xGMI itself.  No scaling number
+    comes out of this (eight processes share one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", *BENCH_ARGS]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _one_json_line(out)
+    assert d["config"]["global_batch"] == 32768
+    _check_ranks(d, hip_device, 8)
+
+
 def test_bench_runs_rccl_at_world_size_one(hip_device):
     """The distributed path of bench.py through librccl (backend "nccl") with ONE rank: every collective of the N > 1 path
     is executed by RCCL; the numbers are those of a single process."""
@@ -91,8 +117,8 @@ def test_bench_runs_rccl_at_world_size_one(hip_device):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist", *BENCH_ARGS]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     d = _one_json_line(out)
-    assert d["distributed"] == {"backend": "nccl", "world_size": 1, "ranks_seen_by_backend": 1, "every_step_exchanged": True,
-                                "steps_per_collective": 64}
+    assert _dist_fields(d) == {"backend": "nccl", "world_size": 1, "ranks_seen_by_backend": 1, "every_step_exchanged": True,
+                               "steps_per_collective": 64}
     assert d["n_gpus"] == 1 and d["check"]["rows"] == B
     tot = _expected_last_step(hip_device, 1)
     assert d["check"]["mean_ll"] == tot[0].item() / tot[1].item()  # bit for bit: SUM over one rank is the identity

@@ -572,6 +572,31 @@ def test_forward_only_mode_keeps_results(hip_device):
         assert torch.allclose(la[j], ref[j], rtol=1e-5, atol=2e-3), j
 
 
+def test_shared_storage_sees_writes_through_data(hip_device):
+    """`params_at_end=False` -- what `to_hip()` / `HipPipelineContext.compile(TorchCircuit)` pass, because the parameter storage
+    is then SHARED with arbitrary torch code: a write through `p.data` (no version counter moves, `TensorStore.state()` cannot
+    see it) reaches the very next forward, as in the reference, which re-evaluates its parameter graphs inside every forward
+    (parameters/parameter.py:180-188).  Inference tensors (no version counter at all) are accepted the same way."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    B = 256
+    x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(3)).to(hip_device)
+    shared = {k: torch.from_numpy(np.array(v, copy=True)).to(hip_device) for k, v in tensors.items()}
+    hc = HipCircuit(plan, shared, device=hip_device, pad_units=False, params_at_end=False)
+    assert all(hc.store[k].data_ptr() == shared[k].data_ptr() for k in shared)  # (shared, not copied)
+    y1 = hc(x).clone()
+    name = list(shared)[2]
+    shared[name].data.mul_(0.5)  # behind every counter
+    y2 = hc(x).clone()
+    fresh = HipCircuit(plan, {k: v.clone() for k, v in shared.items()}, device=hip_device, pad_units=False)(x)
+    assert not torch.equal(y1, y2) and torch.equal(y2, fresh)
+    with torch.inference_mode():
+        inf = {k: v.clone() for k, v in shared.items()}
+    hi = HipCircuit(plan, inf, device=hip_device, pad_units=False)  # (default params_at_end: falls back to re-evaluating at the start)
+    assert torch.equal(hi(x), fresh) and torch.equal(hi(x), fresh)
+
+
 @pytest.mark.parametrize("B", [33, 1000, 4096, 5000])
 def test_parameters_evaluated_at_the_end_of_a_forward(hip_device, B):
     """`params_at_end=True`: the launch that walks the tail of a forward also re-evaluates the parameter graphs, for the next
@@ -1094,8 +1119,9 @@ def test_shared_store_of_a_padded_circuit(hip_device):
 
 @pytest.mark.parametrize("name", ["plan_clt_cat9_cp", "plan_clt_gauss7_cpt", "plan_clt_mixed6_cp"])
 def test_chow_liu_circuits_match_oracle(hip_device, name):
-    """HCLT circuits (structure learned from the committed data, partitions of any arity, mixed input families)
-    on the HIP path against the oracle, evaluated on the rows the structure was learned from."""
+    """HCLT circuits -- plans the REFERENCE compiled from structures it learned from the committed data
+    (tests/golden/make_fixtures.py chow_liu; this backend has no structure learner): partitions of any arity, mixed input
+    families -- on the HIP path against the oracle, evaluated on the rows the structures were learned from."""
     from cirkit_amd.circuit import HipCircuit
     from cirkit_amd.initializers import init_plan_tensors
     from cirkit_amd.plan import Plan

@@ -71,19 +71,6 @@ def test_squared_partition_function_matches_the_live_reference(inp):
     assert abs(got - want) <= 1e-5 * abs(want)
 
 
-def test_chow_liu_matches_the_live_reference():
-    rng = np.random.default_rng(3)
-    z = rng.standard_normal((200, 2))
-    data = torch.from_numpy((z @ rng.standard_normal((2, 6)) + 0.5 * rng.standard_normal((200, 6))).astype(np.float32))
-    inputs = {"name": "gaussian", "args": {}}
-    sc = data_modalities.tabular_data("chow-liu-tree", data=data, input_layers=inputs, num_input_units=2,
-                                      sum_product_layer="cp", num_sum_units=2)
-    cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
-    plan, _ = plan_from_torch_circuit(cc)
-    _assert_same_plan(tabular_data("chow-liu-tree", data=data.numpy(), input_layers=inputs, num_input_units=2,
-                                   sum_product_layer="cp", num_sum_units=2), plan)
-
-
 def test_complex_squared_circuit_matches_the_live_reference():
     """Embedding inputs, unconstrained weights, complex-lse-sum: c(x) through the oracle and Z built natively."""
     from cirkit.templates.utils import Parameterization

@@ -59,7 +59,7 @@ def test_random_binary_tree_8_matches_reference_plan():
 
 
 PLAN_ONLY = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "plan_*.json"))
-                   if not os.path.basename(p).startswith("plan_clt_"))  # (learned structures: their own test below)
+                   if not os.path.basename(p).startswith("plan_clt_"))  # (structures the reference learned from data: parity fixtures only)
 
 
 def _rebuild(name: str) -> Plan:
@@ -106,11 +106,6 @@ def _rebuild(name: str) -> Plan:
         return tabular_data("random-binary-tree", num_features=6,
                             input_layers=[{"name": "categorical", "args": {"num_categories": 3}}, {"name": "gaussian", "args": {}}] * 3,
                             num_input_units=2, sum_product_layer="cp", num_sum_units=2)
-    if name in CLT_CASES:
-        inputs, sp = CLT_CASES[name]
-        with np.load(os.path.join(GOLDEN, name + "_data.npz")) as z:
-            return tabular_data("chow-liu-tree", data=z["data"], input_layers=inputs, num_input_units=3,
-                                sum_product_layer=sp, num_sum_units=3)
     raise AssertionError(f"no native recipe for fixture {name}")
 
 
@@ -143,7 +138,7 @@ def test_template_entry_points_mirror_the_reference_signatures():
     with pytest.raises(ValueError):
         image_data((1, 28, 28), region_graph="hexagons", num_input_units=4, num_sum_units=4)
     assert image_data((1, 4, 4), input_layer="binomial", num_input_units=4, num_sum_units=4).layers[0].config["total_count"] == 255
-    with pytest.raises(ValueError, match="data="):  # same error as the reference: the structure is learned from data
+    with pytest.raises(NotImplementedError):  # structure learning is out of scope: compile with cirkit instead
         tabular_data("chow-liu-tree", num_features=4, input_layers={"name": "gaussian", "args": {}},
                      num_input_units=2, num_sum_units=2)
 
@@ -194,36 +189,3 @@ def test_native_plan_evaluates_like_the_reference(hip_device):
     assert float(((y - ref).abs() / ref.abs()).max()) <= 1e-4
 
 
-CLT_CASES = {
-    "plan_clt_cat9_cp": ({"name": "categorical", "args": {"num_categories": 4}}, "cp"),
-    "plan_clt_gauss7_cpt": ({"name": "gaussian", "args": {}}, "cp-t"),
-    "plan_clt_mixed6_cp": ([{"name": "categorical", "args": {"num_categories": 3}}, {"name": "gaussian", "args": {}}] * 3, "cp"),
-}
-
-
-@pytest.mark.parametrize("name", sorted(CLT_CASES))
-def test_chow_liu_structure_and_plan_match_reference(name):
-    """'chow-liu-tree': the structure is learned from data.  On the committed datasets the native learner finds
-    the tree the reference found (tests/golden/make_fixtures.py:chow_liu) and the plan built on it is the
-    reference's compiled plan."""
-    from cirkit_amd.templates import chow_liu_predecessors, tabular_data
-
-    inputs, sp = CLT_CASES[name]
-    with np.load(os.path.join(GOLDEN, name + "_data.npz")) as z:
-        data, tree = z["data"], z["tree"]
-    itype = inputs["name"] if isinstance(inputs, dict) else [i["name"] for i in inputs]
-    ncat = inputs["args"]["num_categories"] if isinstance(inputs, dict) and inputs["name"] == "categorical" else None
-    assert np.array_equal(chow_liu_predecessors(data, itype, num_categories=ncat), tree)
-    plan = tabular_data("chow-liu-tree", data=data, input_layers=inputs, num_input_units=3, sum_product_layer=sp, num_sum_units=3)
-    _assert_same_plan(plan, Plan.load(os.path.join(GOLDEN, name)))
-
-
-def test_chow_liu_needs_data_and_a_single_tree():
-    from cirkit_amd.templates import tabular_data, tree_to_region_graph
-
-    with pytest.raises(ValueError, match="data="):
-        tabular_data("chow-liu-tree", input_layers={"name": "gaussian", "args": {}}, num_input_units=2, num_sum_units=2)
-    with pytest.raises(ValueError, match="ONE rooted tree"):
-        tree_to_region_graph([-1, 0, -1])
-    rg = tree_to_region_graph([-1, 0, 0, 1])  # 0 -> {1 -> {3}, 2}
-    assert sorted(rg.scope[rg.root]) == [0, 1, 2, 3]
