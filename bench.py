@@ -573,6 +573,41 @@ def main() -> None:
                 "launches_per_step": alt.num_launches_ll(B) if hasattr(alt, "num_launches_ll") else None,
             }
             del alt
+        # The contraction off the fp32 lanes: every fp32 operand cut into bf16 pieces, products on the bf16
+        # matrix pipe with fp32 accumulation.  Labelled variants: `value`, `dtype` and `roofline` stay exact fp32.
+        gold = os.path.join(ROOT, "tests", "golden", "cfg2_qt784_golden.npz")
+        for cname in ("bf16x3", "bf16x6"):
+            alt = HipCircuit(plan, tensors, device=device, use_graph=not args.no_graph, fuse=fuse, contraction=cname)
+            try:
+                wbs, _, pairb = timed_region(alt, args.steps, args.warmup, 3)
+            except ValueError as e:  # (not the depth-4 launch over the raw batch at this batch size)
+                variants[f"contraction={cname}"] = {"skipped": str(e)}
+                del alt
+                continue
+            wb = float(np.median(wbs))
+            entry = {
+                "what": ("the leaf launch's contractions on v_mfma_f32_32x32x16_bf16: operands split by truncation into "
+                         + ("2 bf16 pieces, 3 products (~2^-15 per product)" if cname == "bf16x3" else "3 bf16 pieces, 6 products (fp32-like)")
+                         + ", fp32 accumulation; every other launch exact fp32.  Not the reference's arithmetic: never `value`"),
+                "value": world * B * args.steps / wb,
+                "ms_per_step": 1e3 * wb / args.steps,
+                "mean_ll": float(pairb[0]) / max(float(pairb[1]), 1.0),
+            }
+            if os.path.exists(gold):
+                with np.load(gold) as z:
+                    xg = torch.from_numpy(z["x"].astype(np.int64))
+                    y64 = torch.from_numpy(z["y_f64"]).reshape(-1).double()
+                    y32 = torch.from_numpy(z["y_f32"]).reshape(-1).double()
+                xq = x.clone()
+                xq[: xg.shape[0]] = xg.to(device)
+                with torch.cuda.stream(stream):
+                    ya = alt(xq).reshape(-1).double().cpu()[: xg.shape[0]]
+                    yf = circuit(xq).reshape(-1).double().cpu()[: xg.shape[0]]
+                entry["max_rel_err_vs_reference_fp64"] = float(((ya - y64).abs() / y64.abs()).max())
+                entry["exact_f32_path_same_rows"] = float(((yf - y64).abs() / y64.abs()).max())
+                entry["reference_fp32_same_rows"] = float(((y32 - y64).abs() / y64.abs()).max())
+            variants[f"contraction={cname}"] = entry
+            del alt
         # Two forwards in flight (cirkit_amd.circuit.HipCircuitStreams): the small latency-bound kernels of
         # one step (parameter prologue, fused tail) fill the bubbles of the other step's leaf kernel.
         from cirkit_amd.circuit import HipCircuitStreams

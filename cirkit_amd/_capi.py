@@ -79,6 +79,7 @@ class LeafLaunch(C.Structure):
         ("x_rows", C.c_void_p),
         ("bad_input", C.c_void_p),
         ("D", C.c_int32),
+        ("contraction", C.c_int32), ("reserved2", C.c_int32),
         ("keep_levels", C.POINTER(C.c_void_p)),
         ("keep_redo", C.c_void_p),
         ("x_pairs", C.c_int32),

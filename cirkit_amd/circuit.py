@@ -84,8 +84,12 @@ class HipCircuit:
             of fused CP-T levels, False evaluates layer by layer (every layer output materialised).
         batch_params: recompute all softmax parameters with one launch per forward
             (`ck_param_softmax_batch`) instead of one launch per parameter node.
-        contraction: how the K = 32 sum layers contract in linear space: ``"f32"``, exact fp32
-            (v_mfma_f32_32x32x2_f32), is the only value (a split-fp16 variant, "f16x3", was slower and is gone).
+        contraction: how the K = 32 sum layers contract in linear space.  ``"f32"``: exact fp32 (v_mfma_f32_32x32x2_f32) -- the
+            product, what every reported number uses.  ``"bf16x3"`` / ``"bf16x6"``: labelled VARIANTS of the depth-4 persistent
+            leaf launch: every fp32 operand cut into two / three bf16 pieces (truncation, exact residuals; bf16 keeps fp32's
+            exponent range), 3 / 6 products per contraction on the bf16 matrix pipe with fp32 accumulation -- ~2^-15 per
+            product, resp. fp32-like (tests/test_gpu_parity.py measures both against the fp64 goldens).  The tail, the
+            parameter jobs and every other launch stay exact fp32.
         dense_on_table: a Categorical input layer followed fold-by-fold by a dense sum layer only
             takes C distinct values per fold, so the dense layer is applied once per forward to the
             (F, C, K) log-probability table (same kernel, batch = C) instead of to every batch row;
@@ -350,8 +354,8 @@ class HipCircuit:
         self.batch_params = batch_params
         self._batch: ParamBatch | None = None
         self._batch_version = -1
-        if contraction != "f32":
-            raise ValueError(f"unknown contraction {contraction!r} (only 'f32', exact fp32, exists)")
+        if contraction not in ("f32", "bf16x3", "bf16x6"):
+            raise ValueError(f"unknown contraction {contraction!r} ('f32' = exact fp32, the product; 'bf16x3' / 'bf16x6' = labelled variants)")
         self.contraction = contraction
         self.dense_on_table = bool(dense_on_table)
         self.tiled_weights = bool(tiled_weights)
@@ -849,7 +853,7 @@ class HipCircuit:
         """Which jobs of the prologue the launch that walks the tail takes over (`params_at_end`): the table job of the
         (single) leaf group, the softmaxes of its level weights, and every other 32-wide softmax; what is left stays a
         (smaller, often empty) prologue launch.  None: nothing is taken over."""
-        if not (self.params_at_end and self.batch_params and not self.cache_params and self.contraction == "f32"
+        if not (self.params_at_end and self.batch_params and not self.cache_params
                 and len(self._groups) == 1 and not self._signed):
             return None
         g = self._groups[0]
@@ -1263,6 +1267,10 @@ class HipCircuit:
         d.w_levels, d.nodes, d.node_off, d.leaf_off = levels, nodes.data_ptr(), node_off, leaf_off
         d.out, d.work, d.n_seg, d.n_wg, d.waves, d.depth = out.data_ptr(), work.data_ptr(), int(work.shape[0]), self._n_cu, waves, depth
         d.B, d.K, d.C, d.w_layout = bd.B, K, Cn, w_layout
+        d.contraction = {"f32": 0, "bf16x3": 3, "bf16x6": 6}[self.contraction]
+        if d.contraction and not (bd.direct and depth == 4 and redo is None and keep is None):
+            raise ValueError(f"contraction={self.contraction!r} is a variant of the depth-4 persistent leaf launch over the caller's batch "
+                             "(unsigned values, inference forward); this circuit / batch does not take that launch")
         d.signed_redo, d.n_roots = (None if redo is None else redo.data_ptr()), n_roots
         d.root_tab = self._leaf_root_table(nodes, node_off, leaf_off, scope, depth, n_roots).data_ptr()
         if bd.direct:
@@ -1532,7 +1540,7 @@ class HipCircuit:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root and self._signed:
             raw = "true" if self._direct_input(B) else "false"
-            return f"leaf_persistent_kernel<{self._group_of_root[i].depth}, 8, true, {raw}, false, false> (signed: real-valued complex circuit)"
+            return f"leaf_persistent_kernel<{self._group_of_root[i].depth}, 8, true, {raw}, false, false, 0> (signed: real-valued complex circuit)"
         if i in self._group_of_root:
             g = self._group_of_root[i]
             in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)
@@ -1540,7 +1548,8 @@ class HipCircuit:
                 if self._leaf_is_persistent(g, B):
                     raw = "true" if self._direct_input(B) else "false"
                     xp = "true" if (raw == "true" and g.depth >= 2 and self._leaves_in_adjacent_pairs(g)) else "false"
-                    return f"leaf_persistent_kernel<{g.depth}, 8, false, {raw}, {xp}, false>"
+                    ct = {"f32": 0, "bf16x3": 3, "bf16x6": 6}[self.contraction]
+                    return f"leaf_persistent_kernel<{g.depth}, 8, false, {raw}, {xp}, {'true' if self.keep_levels else 'false'}, {ct}>"
                 return f"subtree_linear_kernel<{g.depth}, {self._group_layout(g)}>"
             return (f"subtree_cat_cpt_kernel<{g.depth}, {'true' if in_kernel_dense else 'false'}, "
                     f"{self._group_layout(g)}>")

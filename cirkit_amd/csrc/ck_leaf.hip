@@ -44,6 +44,7 @@ struct LeafArgs {
   int n_seg, B, C;
   int preclamped;  // xt holds -1 .. C - 1 only
   int32_t* redo;   // SIGNED: (F_root, tiles) flags of the tiles to evaluate again in log space (leaf_signed_redo_kernel); KEEP: see below
+  int contraction;  // 0 exact fp32; 3 / 6: the bf16x3 / bf16x6 variants (depth 4, raw batch)
   int w_rowmajor;  // the level weights are row-major (F_l, 32, 32) matrices instead of CK_W_TILED_F32
   // XRAW: the batch as the caller holds it, (B, D) int64 row-major -- no staging launch in front of this one
   const int64_t* x64;
@@ -82,13 +83,19 @@ __host__ __device__ constexpr int keep_stores_plain(int i, int slots) {  // leaf
   for (int m = i - slots; m < i; ++m) n += steps_after(m);
   return 4 * n;
 }
-template <int D, int WAVES, bool SIGNED, bool XRAW, bool XP = false, bool KEEP = false>
+// CT: 0 = the contraction in exact fp32 (the product); 3 / 6 = the labelled bf16-split VARIANTS (ck_tile.h contract_bf16:
+// "bf16x3" with two pieces per operand, "bf16x6" with three): the subtree weights are cut into pieces while they are staged
+// (registers, not DMA), a node takes 4 / 6 KB of LDS -- with three pieces the gather ring has two slots per wave (the walk goes
+// leaf by leaf) so that everything still fits 160 KB.
+template <int D, int WAVES, bool SIGNED, bool XRAW, bool XP = false, bool KEEP = false, int CT = 0>
 __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafArgs a) {
   static_assert(!KEEP || (!SIGNED && WAVES == 8), "the training forward walks unsigned values with 8 waves");
-  constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2) ? 3 : 2;
+  static_assert(CT == 0 || (CT == 3 && !SIGNED && !KEEP) || (CT == 6 && !SIGNED && !KEEP), "bf16 variants: unsigned inference forward");
+  constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2 && CT != 6) ? 3 : 2;
+  constexpr int kWNode = CT == 6 ? 1536 : 1024;  // dwords of LDS per node
   // (two arrays, not one: with the gather slots at a constant offset inside a single array their addresses became
   // values in scalar registers -- 110 spilled instead of 36)
-  __shared__ __attribute__((aligned(16))) float w_lds[kNodes * 1024];  // subtree weights, in step order
+  __shared__ __attribute__((aligned(16))) float w_lds[kNodes * kWNode];  // subtree weights, in step order
   // gathered leaf tiles, a ring of kSlots 4 KB slots per wave (a gather that misses the XCD's L2 -- six roots' tables,
   // 3.6 MB, are live per XCD -- takes ~1 us: with three slots a leaf is requested three leaves, ~1.5 contractions,
   // before it is read).  The slots are READ with inline-asm ds_read_b128: the compiler's
@@ -185,6 +192,29 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         constexpr int l = decltype(lc)::value, k = steps_before(i) + l;
         const int fold = __builtin_amdgcn_readfirstlane(node_fold[k]);
         if constexpr (KEEP) keep_base[k] = a.keep[l] + static_cast<int64_t>(fold) * ((a.B + 31) >> 5) * 1024;  // (F_l, tiles, 1024)
+        if constexpr (CT != 0) {  // cut into bf16 pieces on the way (ck_tile.h bf16_piece_index)
+          const float* wsrc = a.w[l] + static_cast<int64_t>(fold) * 1024;
+          uint16_t* dst = reinterpret_cast<uint16_t*>(w_lds + k * kWNode);
+          for (int idx = threadIdx.x; idx < 1024; idx += WAVES * 64) {
+            int o, i;
+            if (a.w_rowmajor) {
+              o = idx >> 5;
+              i = idx & 31;
+            } else {  // CK_W_TILED_F32: dword (q, lane, t) = W[lane & 31][8q + 4 (lane >> 5) + t]
+              const int ln = (idx >> 2) & 63;
+              o = ln & 31;
+              i = 8 * (idx >> 8) + 4 * (ln >> 5) + (idx & 3);
+            }
+            float rw = wsrc[idx];
+#pragma unroll
+            for (int p = 0; p < CT / 3 + 1; ++p) {
+              const uint32_t bits = __float_as_uint(rw);
+              dst[bf16_piece_index(p, o, i)] = static_cast<uint16_t>(bits >> 16);
+              rw -= __uint_as_float(bits & 0xffff0000u);
+            }
+          }
+          return;
+        }
         // lane's 16 bytes of chunk q: tiled, dword 256 q + 4 lane; row-major, W[lane & 31][8 q + 4 (lane >> 5) ..] (ck_tile.h)
         const float* src = a.w[l] + static_cast<int64_t>(fold) * 1024 + (a.w_rowmajor ? (lane & 31) * 32 + 4 * (lane >> 5) : lane * 4);
         const int qstride = a.w_rowmajor ? 8 : 256;
@@ -429,7 +459,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             constexpr int kYounger = 5 * (kLeaves - 1 - i < 2 ? kLeaves - 1 - i : 2) + (i >= 2 && i <= 4 ? kXLoads : 0) +
                                      (KEEP && i >= 3 ? keep_stores_pipe(i) : 0);
             f32x4 r0, r1, r2, r3;
-            if constexpr (h == 1) {  // (the weights of the pair's first contraction with the slot reads: one LDS round trip)
+            if constexpr (h == 1 && CT == 0) {  // (the weights of the pair's first contraction with the slot reads: one LDS round trip)
 #pragma unroll
               for (int q = 0; q < 4; ++q) wfirst.q[q] = *reinterpret_cast<const float4*>(w_lds + steps_before(o) * 1024 + q * 256 + lane * 4);
             }
@@ -476,14 +506,17 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             constexpr int l = decltype(lc)::value, step = steps_before(o) + l;
             WRegs wcur;
             if constexpr (l == 0) {
-              wcur = wfirst;
+              if constexpr (CT == 0) wcur = wfirst;
             } else {
+              if constexpr (CT == 0) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
+                for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
+              }
               linear_product<true, SIGNED>(cur, stack[l], cs, sstack[l], bad);
             }
             __builtin_amdgcn_sched_barrier(0);
-            contract_linear<CK_W_TILED_F32>(wcur, cur);
+            if constexpr (CT == 0) contract_linear<CK_W_TILED_F32>(wcur, cur);
+            else contract_bf16<CT / 3 + 1>(w_lds + step * kWNode, lane, cur);
             if constexpr (KEEP) tile_store_native(keep_base[step] + koff, lane, cur);
           });
           if constexpr (steps_after(o) < D) {  // left sibling at this level: wait for the right one
@@ -507,7 +540,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
                                  (KEEP && i >= kSlots ? keep_stores_plain(i, kSlots) : 0);
         // (the weights of the leaf's first contraction are requested in front of the slot reads: one LDS round trip for both)
         WRegs wfirst;
-        if constexpr (steps_after(i) > 0) {
+        if constexpr (steps_after(i) > 0 && CT == 0) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) wfirst.q[q] = *reinterpret_cast<const float4*>(w_lds + steps_before(i) * 1024 + q * 256 + lane * 4);
         }
@@ -548,11 +581,13 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
         static_for<0, steps_after(i)>([&](auto lc) {
           constexpr int l = decltype(lc)::value, step = steps_before(i) + l;
           WRegs wcur;
-          if constexpr (l == 0) {
-            wcur = wfirst;
-          } else {
+          if constexpr (CT == 0) {
+            if constexpr (l == 0) {
+              wcur = wfirst;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
+              for (int q = 0; q < 4; ++q) wcur.q[q] = *reinterpret_cast<const float4*>(w_lds + step * 1024 + q * 256 + lane * 4);
+            }
           }
           if constexpr (l == 0) {
             tile_mul(cur, stack[0]);  // first level: the bare product (ck_tile.h)
@@ -562,7 +597,8 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           // (the products stay in front of the MFMA chain: interleaved into it, the compiler's pre-emit pass splits every
           // v_pk_mul_f32 that follows an MFMA back into two multiplies)
           __builtin_amdgcn_sched_barrier(0);
-          contract_linear<CK_W_TILED_F32>(wcur, cur);
+          if constexpr (CT == 0) contract_linear<CK_W_TILED_F32>(wcur, cur);
+          else contract_bf16<CT / 3 + 1>(w_lds + step * kWNode, lane, cur);
           if constexpr (KEEP) tile_store_native(keep_base[step] + koff, lane, cur);
         });
         if constexpr (steps_after(i) < D) {  // left sibling at this level: wait for the right one
@@ -624,14 +660,20 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       src.scope = a.scope;
       src.leaf_ids = leaf_ids;
       src.fold0 = fold0;
-      src.w_steps = w_lds;
+      src.w_steps = CT == 0 ? w_lds : nullptr;  // (the variants hold bf16 pieces in LDS: the log-space walk reads the fp32 weights)
+      if constexpr (CT != 0) {
+        for (int l = 0; l < D; ++l) src.w[l] = a.w[l];
+        src.nodes = a.nodes;
+        for (int l = 0; l <= D; ++l) src.node_off[l] = a.node_off[l];
+      }
       src.t = t;
       src.B = a.B;
       src.C = a.C;
       src.bl = min(b, a.B - 1);
       float fb[16];
       if constexpr (!SIGNED) {
-        subtree_tile_logspace<D, CK_W_TILED_F32>(src, lane, fb);
+        if (CT != 0 && a.w_rowmajor) subtree_tile_logspace<D, CK_W_ROWMAJOR>(src, lane, fb);
+        else subtree_tile_logspace<D, CK_W_TILED_F32>(src, lane, fb);
         if constexpr (XRAW) {  // (rows with an illegal value are NaN here too)
           RawT xb[kLeaves];
           uint32_t cb[kLeaves / 2];
@@ -704,6 +746,20 @@ hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_root
         }
       }
       hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, false, true>), grid, dim3(512), 0, s, a);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  if (a.contraction != 0) {  // (checked by the caller: depth 4, raw input, unsigned, no kept tiles)
+    if constexpr (XRAW && D == 4) {
+      if (a.contraction == 3) {
+        if (a.x_pairs) hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, true, false, 3>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, false, false, 3>), grid, dim3(512), 0, s, a);
+      } else {
+        if (a.x_pairs) hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, true, false, 6>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, false, false, 6>), grid, dim3(512), 0, s, a);
+      }
       return hipGetLastError();
     } else {
       return hipErrorInvalidValue;
@@ -792,6 +848,12 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
       CK_REQUIRE(slot != nullptr, "ck_leaf_walk_fwd: x_input=%d names a program input, but no program is being recorded on this "
                                   "thread (or the index is out of range)", d->x_input);
     }
+  }
+  CK_REQUIRE(d->contraction == 0 || d->contraction == 3 || d->contraction == 6, "ck_leaf_walk_fwd: contraction %d (0, 3 or 6)", d->contraction);
+  if (d->contraction != 0) {
+    if (!(raw && d->depth == 4 && d->signed_redo == nullptr && d->keep_levels == nullptr))
+      return ck::fail(CK_ERR_UNSUPPORTED, "ck_leaf_walk_fwd: the bf16-split contraction variants exist for depth-4 unsigned launches over the raw batch");
+    a.contraction = d->contraction;
   }
   if (d->keep_levels != nullptr) {
     CK_REQUIRE(raw && d->waves == 8 && d->signed_redo == nullptr, "ck_leaf_walk_fwd: the training forward (keep_levels) reads the raw batch "

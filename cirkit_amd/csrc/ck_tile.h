@@ -108,6 +108,66 @@ __device__ __forceinline__ void contract_linear(const WRegs& w, float (&e)[16]) 
   }
 }
 
+// e <- W . e with the fp32 operands SPLIT into bf16 pieces and contracted on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16,
+// fp32 accumulation) -- a labelled VARIANT of contract_linear, never the default: the exact path is an fp32 fmaf chain on the
+// fp32 lanes (16 x 64 cycles, shared with every other vector instruction), the bf16 pipe is separate hardware at 16x the rate.
+// bf16 keeps fp32's exponent, so the pieces of a small weight do not underflow (what killed the split-fp16 variant of
+// rounds 1-2).  A value is cut by TRUNCATION into h + m (+ l): 8 significant bits each, residuals exact.
+//   PIECES 2 ("bf16x3"): W_h e_h + W_h e_m + W_m e_h          dropped terms <= 2^-15 of a product
+//   PIECES 3 ("bf16x6"): + W_h e_l + W_m e_m + W_l e_h         dropped terms <= 2^-23: fp32-like
+// wnode: the node's weight pieces in LDS -- dword ((p * 2 + m) * 64 + lane) * 4 + d holds, as two bf16, piece p of
+// W[lane & 31][u(8m + 2d, lane >> 5)] and of W[lane & 31][u(8m + 2d + 1, lane >> 5)], u(j, kh) = 8 (j >> 2) + 4 kh + (j & 3): the A
+// operand of half m (units of registers 8m .. 8m + 7), laid out so that one ds_read_b128 per (piece, half) fetches it.
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+template <int PIECES>
+__device__ __forceinline__ void contract_bf16(const float* wnode, int lane, float (&e)[16]) {
+  u32x4v ep[PIECES][2];
+  float r[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) r[j] = e[j];
+#pragma unroll
+  for (int p = 0; p < PIECES; ++p) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)  // the high halves of two residuals, the first in the low 16 bits
+        ep[p][m][d] = __builtin_amdgcn_perm(__float_as_uint(r[8 * m + 2 * d + 1]), __float_as_uint(r[8 * m + 2 * d]), 0x07060302u);
+    if (p + 1 < PIECES) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) r[j] -= __uint_as_float(__float_as_uint(r[j]) & 0xffff0000u);  // exact
+    }
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const u32x4v* wp = reinterpret_cast<const u32x4v*>(wnode);
+  auto mm = [&](u32x4v a, u32x4v b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, a), __builtin_bit_cast(bf16x8v, b), acc, 0, 0, 0);
+  };
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    u32x4v w[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) w[p] = wp[(p * 2 + m) * 64 + lane];
+    if constexpr (PIECES == 3) {  // (smallest terms first)
+      mm(w[2], ep[0][m]);
+      mm(w[1], ep[1][m]);
+      mm(w[0], ep[2][m]);
+    }
+    mm(w[1], ep[0][m]);
+    mm(w[0], ep[1][m]);
+    mm(w[0], ep[0][m]);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) e[k] = acc[k];
+}
+// Where piece p of W[o][i] goes in that layout (halfword index inside the node's block).
+__device__ __forceinline__ int bf16_piece_index(int p, int o, int i) {
+  const int g = i >> 3, kh = (i >> 2) & 1, t = i & 3;
+  return (((p * 2 + (g >> 1)) * 64 + o + 32 * kh) * 4 + (2 * (g & 1) + (t >> 1))) * 2 + (t & 1);
+}
+
 // ---- linear-domain chaining of fused CP-T levels (ck_fused.hip, ck_leaf.hip) -------------------------------------
 // A node is carried as (y: linear tile, s: per-row log scale), value = log y + s.  A level forms e = y_l * y_r
 // (linear_product) and contracts y = W e (contract_linear).  What this costs matters: fp32-input MFMA and the VALU

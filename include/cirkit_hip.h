@@ -333,6 +333,10 @@ typedef struct ck_leaf_launch {
   const int64_t* x_rows;         /* raw (B, D) int64 batch, or NULL */
   int32_t* bad_input;            /* raw input: validation flag (rows with illegal values become NaN), or NULL */
   int32_t D;                     /* variables per row of the raw batch */
+  int32_t contraction;           /* 0: exact fp32 (v_mfma_f32_32x32x2_f32).  3 / 6: labelled VARIANTS -- every fp32 operand of a contraction cut
+                                    into 2 / 3 bf16 pieces, 3 / 6 products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation ("bf16x3": ~2^-15 per
+                                    product; "bf16x6": fp32-like); depth 4, raw input, unsigned, no keep_levels */
+  int32_t reserved2;
   float* const* keep_levels;     /* NULL, or HOST array of `depth` DEVICE pointers: (F_l, B, 32) linear tiles of level l's nodes */
   int32_t* keep_redo;            /* with keep_levels: DEVICE (n_roots, ceil(B / 32)) flags of the tiles evaluated in log space */
   int32_t x_pairs;                          /* raw input: for every root, leaves 2j and 2j + 1 read variables v and v + 1 with v even

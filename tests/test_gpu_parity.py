@@ -572,6 +572,39 @@ def test_forward_only_mode_keeps_results(hip_device):
         assert torch.allclose(la[j], ref[j], rtol=1e-5, atol=2e-3), j
 
 
+def test_bf16_split_contraction_variants_against_the_fp64_golden(hip_device, capsys):
+    """`contraction="bf16x3"` / `"bf16x6"`: the depth-4 leaf launch with every fp32 operand of a contraction cut into two / three
+    bf16 pieces and contracted on the bf16 matrix pipe (fp32 accumulation) -- labelled variants, never `value`.  Measured against
+    the reference's float64 outputs at BASELINE config 2 (tests/golden/cfg2_qt784_golden.npz, y_f64), next to the exact-fp32
+    path and to the reference's own fp32 run: bf16x6 must be fp32-like, bf16x3 within the 1e-4 bar; tiles that leave the linear
+    range (read by the log-space walk from the fp32 weights) must still agree."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    x = torch.from_numpy(g["x"].astype(np.int64))
+    y64 = torch.from_numpy(g["y_f64"]).reshape(-1).double()
+    ref32 = float(((torch.from_numpy(g["y_f32"]).reshape(-1).double() - y64).abs() / y64.abs()).max())
+    B = 4096  # (the persistent launch; the golden rows first)
+    xb = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(5))
+    xb[: x.shape[0]] = x
+    xb = xb.to(hip_device)
+    err, outs = {}, {}
+    for c in ("f32", "bf16x3", "bf16x6"):
+        hc = HipCircuit(plan, tensors, device=hip_device, contraction=c, persistent_leaf=True)
+        y = hc(xb).reshape(-1).double().cpu()
+        assert hc.kernel_label(hc._groups[0].root, B).startswith("leaf_persistent_kernel")
+        outs[c] = y
+        err[c] = float(((y[: x.shape[0]] - y64).abs() / y64.abs()).max())
+    with capsys.disabled():
+        print(f"\n[bf16 variants] max rel err vs the reference's fp64 output, config 2: reference fp32 {ref32:.2e}, "
+              f"HIP f32 {err['f32']:.2e}, bf16x3 {err['bf16x3']:.2e}, bf16x6 {err['bf16x6']:.2e}")
+    assert err["f32"] <= 1e-6 and err["bf16x6"] <= max(4.0 * err["f32"], 1e-6) and err["bf16x3"] <= 1e-4
+    rel_all = float(((outs["bf16x6"] - outs["f32"]).abs() / outs["f32"].abs()).max())
+    assert rel_all <= 2e-6  # (all 4096 rows against the exact path)
+    with pytest.raises(ValueError):  # a variant of THAT launch only
+        HipCircuit(plan, tensors, device=hip_device, contraction="bf16x3", persistent_leaf=True, direct_input=False)(xb)
+
+
 def test_shared_storage_sees_writes_through_data(hip_device):
     """`params_at_end=False` -- what `to_hip()` / `HipPipelineContext.compile(TorchCircuit)` pass, because the parameter storage
     is then SHARED with arbitrary torch code: a write through `p.data` (no version counter moves, `TensorStore.state()` cannot
@@ -727,7 +760,9 @@ def test_ll_sum(hip_device):
 # multi-channel inputs, per-feature input families)
 # ---------------------------------------------------------------------------------------------
 def _native_plan_names():
-    return sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLDEN, "plan_*.json")))
+    from test_templates import PLAN_ONLY  # (the HCLT plans have no native recipe: test_chow_liu_circuits_match_oracle)
+
+    return PLAN_ONLY
 
 
 def _random_batch(plan, B, seed):
