@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -97,7 +97,6 @@ class LeafBwdLaunch(C.Structure):
         ("waves", C.c_int32), ("gin_rowmajor", C.c_int32),
         ("gin", C.c_void_p),
         ("y_p", C.c_void_p),
-        ("y_q", C.c_void_p),
         ("y_c", C.c_void_p),
         ("table", C.c_void_p),
         ("x_rows", C.c_void_p),

@@ -1185,15 +1185,16 @@ class HipCircuit:
         )
 
     def _keep_buffers(self, g: SubtreeGroup, bd: _Binding):
-        """`keep_levels`: ([(F_l, tiles, 1024) tile-native per fused level], (F_root, tiles) int32 flags) of group g in this
-        binding, else None."""
+        """`keep_levels`: ([(F_l, tiles, 1024) tile-native per fused level l = 2, 4 -- None for the levels in between, which the
+        backward recomputes], (F_root, tiles) int32 flags) of group g in this binding, else None."""
         if not self.keep_levels:
             return None
         hit = bd.keep.get(g.root)
         if hit is None:
             tiles = (bd.B + 31) // 32
             hit = bd.keep[g.root] = (
-                [torch.empty((self.layers[j].num_folds, tiles, 1024), dtype=torch.float32, device=self.device) for j in g.levels],
+                [torch.empty((self.layers[j].num_folds, tiles, 1024), dtype=torch.float32, device=self.device) if l % 2 == 1 else None
+                 for l, j in enumerate(g.levels)],
                 torch.zeros(self.layers[g.root].num_folds * tiles, dtype=torch.int32, device=self.device))
         return hit
 
@@ -1283,7 +1284,7 @@ class HipCircuit:
         if keep is not None:
             if not bd.direct:
                 raise ValueError("keep_levels needs the leaf launch to read the caller's batch (direct_input)")
-            d.keep_levels = (C.c_void_p * depth)(*[t.data_ptr() for t in keep[0]])
+            d.keep_levels = (C.c_void_p * depth)(*[None if t is None else t.data_ptr() for t in keep[0]])
             d.keep_redo = keep[1].data_ptr()
         capi.call("ck_leaf_walk_fwd", C.byref(d), stream)
 

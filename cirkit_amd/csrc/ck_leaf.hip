@@ -51,7 +51,8 @@ struct LeafArgs {
   int D;
   int32_t* bad_flag;  // XRAW: raised (atomicOr 1) when a row holds an illegal value; nullptr = rows are not checked
   int x_pairs;        // XRAW: leaves 2j, 2j + 1 of every root read adjacent, 16-byte aligned variables (one load per pair)
-  // KEEP (training forward): the linear tile of every node is stored as well -- keep[l - 1]: (F_l, tiles, 1024) in tile-native
+  // KEEP (training forward): the linear tile of the nodes of every SECOND level (l = 2, 4: kept_level) is stored as well -- what
+  // the backward walk reads as the P of its two-level units; the levels in between it recomputes -- keep[l - 1]: (F_l, tiles, 1024) in tile-native
   // order (ck_tile.h tile_store_native; rows beyond B of the last tile hold whatever their lanes computed), the value the NEXT
   // level multiplies (the backward, ck_leaf_bwd.hip, needs a level's tiles to be consistent with each other, not their log
   // scales); tiles whose walk left the linear range are marked in `redo` (their kept tiles mean nothing)
@@ -73,14 +74,16 @@ struct LeafArgs {
 // KEEP: the training forward (LeafArgs::keep).  Its stores sit between the gathers of the walk: vector-memory operations of
 // a wave complete in the order they were issued (loads and stores share vmcnt on gfx9: the compiler's own wait counts rely
 // on it), so the explicit vmcnt(N) in front of a slot read counts the stores issued since that slot's request as well.
+__host__ __device__ constexpr bool kept_level(int l) { return (l & 1) == 1; }  // step l = CP-T level l + 1: levels 2 and 4 are kept
+__host__ __device__ constexpr int kept_steps(int n_steps) { return n_steps >> 1; }  // of the steps 0 .. n_steps - 1
 __host__ __device__ constexpr int keep_stores_pipe(int i) {  // pair walk: between the request of leaf i >= 3 and its slot read
   int n = 0;
-  for (int q = (i - 3) >> 1; q < (i >> 1); ++q) n += steps_after(2 * q + 1);
+  for (int q = (i - 3) >> 1; q < (i >> 1); ++q) n += kept_steps(steps_after(2 * q + 1));
   return 4 * n;
 }
 __host__ __device__ constexpr int keep_stores_plain(int i, int slots) {  // leaf-by-leaf walk: leaf i >= slots
   int n = 0;
-  for (int m = i - slots; m < i; ++m) n += steps_after(m);
+  for (int m = i - slots; m < i; ++m) n += kept_steps(steps_after(m));
   return 4 * n;
 }
 // CT: 0 = the contraction in exact fp32 (the product); 3 / 6 = the labelled bf16-split VARIANTS (ck_tile.h contract_bf16:
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
       static_for<0, steps_after(i)>([&](auto lc) {
         constexpr int l = decltype(lc)::value, k = steps_before(i) + l;
         const int fold = __builtin_amdgcn_readfirstlane(node_fold[k]);
-        if constexpr (KEEP) keep_base[k] = a.keep[l] + static_cast<int64_t>(fold) * ((a.B + 31) >> 5) * 1024;  // (F_l, tiles, 1024)
+        if constexpr (KEEP && kept_level(l)) keep_base[k] = a.keep[l] + static_cast<int64_t>(fold) * ((a.B + 31) >> 5) * 1024;  // (F_l, tiles, 1024)
         if constexpr (CT != 0) {  // cut into bf16 pieces on the way (ck_tile.h bf16_piece_index)
           const float* wsrc = a.w[l] + static_cast<int64_t>(fold) * 1024;
           uint16_t* dst = reinterpret_cast<uint16_t*>(w_lds + k * kWNode);
@@ -517,7 +520,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (CT == 0) contract_linear<CK_W_TILED_F32>(wcur, cur);
             else contract_bf16<CT / 3 + 1>(w_lds + step * kWNode, lane, cur);
-            if constexpr (KEEP) tile_store_native(keep_base[step] + koff, lane, cur);
+            if constexpr (KEEP && kept_level(l)) tile_store_native(keep_base[step] + koff, lane, cur);
           });
           if constexpr (steps_after(o) < D) {  // left sibling at this level: wait for the right one
             constexpr int l = steps_after(o);
@@ -599,7 +602,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (CT == 0) contract_linear<CK_W_TILED_F32>(wcur, cur);
           else contract_bf16<CT / 3 + 1>(w_lds + step * kWNode, lane, cur);
-          if constexpr (KEEP) tile_store_native(keep_base[step] + koff, lane, cur);
+          if constexpr (KEEP && kept_level(l)) tile_store_native(keep_base[step] + koff, lane, cur);
         });
         if constexpr (steps_after(i) < D) {  // left sibling at this level: wait for the right one
           constexpr int l = steps_after(i);
@@ -737,7 +740,7 @@ __global__ void __launch_bounds__(64) leaf_signed_redo_kernel(const LeafArgs a) 
 
 template <int D, bool XRAW>
 hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_roots, dim3 grid, hipStream_t s) {
-  if (a.keep[0] != nullptr) {  // (checked by the caller: raw input, unsigned, 8 waves)
+  if (D >= 2 && a.keep[1] != nullptr) {  // the training forward (checked by the caller: raw input, unsigned, 8 waves, depth 2 | 4)
     if constexpr (XRAW) {
       if constexpr (D >= 2) {
         if (a.x_pairs) {
@@ -860,7 +863,8 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
                "with 8-wave workgroups and walks unsigned values");
     CK_REQUIRE(d->keep_redo != nullptr, "ck_leaf_walk_fwd: keep_levels needs keep_redo");
     CK_REQUIRE(static_cast<int64_t>(d->B) * kK < (int64_t{1} << 31), "ck_leaf_walk_fwd: B=%d rows exceed the 32-bit offsets of the kept tiles", d->B);
-    for (int l = 0; l < d->depth; ++l) {
+    CK_REQUIRE(d->depth == 2 || d->depth == 4, "ck_leaf_walk_fwd: keep_levels needs a region of 2 or 4 levels (got %d)", d->depth);
+    for (int l = 1; l < d->depth; l += 2) {  // (levels 2 and 4; the entries of levels 1 and 3 are not read)
       CK_REQUIRE(d->keep_levels[l] != nullptr && ck::aligned16(d->keep_levels[l]), "ck_leaf_walk_fwd: bad keep_levels[%d]", l);
       a.keep[l] = d->keep_levels[l];
     }

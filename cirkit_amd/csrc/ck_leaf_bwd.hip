@@ -6,10 +6,13 @@
 // (log-space values v), e = exp(v_a + v_b - m), y = W e, out = log y + m:
 //     gy = g_out / y          dW += gy^T e          g_a = g_b = e * (W^T gy)
 // -- the SAME log-space gradient tile goes to both children of a product, so one tile per node walks down the tree.  Nothing
-// depends on the row scale m as long as e and y carry the same one: the training forward keeps the LINEAR tile y of every
-// node (LeafArgs::keep), this walk forms e from the kept children with the forward's own instructions (bare product at the
-// first level, exact power-of-two renormalisation above: ck_tile.h linear_product), so the kept y of the node IS W e bit for
-// bit and is not recomputed.
+// depends on the row scale m as long as e and y carry the same one: the training forward keeps the LINEAR tile y of the
+// nodes of every SECOND level (LeafArgs::keep: the P's of the units below), this walk forms e from the kept (or gathered)
+// children with the forward's own instructions (bare product at the first level, exact power-of-two renormalisation above:
+// ck_tile.h linear_product), so the kept y of P IS W e bit for bit; the y of Q0 / Q1 -- the level in between -- is the
+// forward's contraction again (W_Q e_Q, same operands, same instruction: the same bits).  The launches move bytes, not flops
+// (scripts/exp_leaf_bwd.sh: all contractions removed -8 %; 44 KB per unit through L2 at ~5 TB/s IS the launch time), so 2 more
+// contractions per unit are cheaper than 8 KB of kept tiles written by the forward and read here.
 //
 // One launch covers TWO levels: a unit is (node P, its children Q0, Q1, their four children c0..c3) for one 32-row batch
 // tile; P's gradient tile is read (written by the launch above: the tile its parent left for its two children; at the top,
@@ -37,8 +40,7 @@ struct BwdArgs {
   int n_seg, B, C, D;
   const float* gin;  // log-space gradient tiles, indexed by unit_tab[.., 0]: (F, tiles, 1024) tile-native, or (gin_rowmajor) (F, B, 32)
   const float* y_p;  // kept linear tiles of P's level, (F_l, tiles, 1024) tile-native (ck_tile.h)
-  const float* y_q;  // ... of the level below
-  const float* y_c;  // !LEAF: ... of the level below that
+  const float* y_c;  // !LEAF: ... of the level two below (the level in between is recomputed)
   int gin_rowmajor;
   const float* table;    // LEAF: (F0, C + 1, 32) linear table rows
   const int64_t* x64;    // LEAF: raw (B, D) batch
@@ -160,6 +162,7 @@ __device__ __forceinline__ void forward_product(float (&cur)[16], const float (&
 template <bool LEAF, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float wt_lds[3 * 1024];          // W^T of P, Q0, Q1 ("transposed tiled")
+  __shared__ __attribute__((aligned(16))) float wq_lds[2 * 1024];          // W of Q0, Q1 (CK_W_TILED_F32: the forward's operand)
   __shared__ __attribute__((aligned(16))) float scratch[WAVES * 2 * 1024];  // per wave: the gy and e tiles of a dW contraction
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -193,6 +196,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
       for (int idx = threadIdx.x; idx < 1024; idx += WAVES * 64) {
         const int o = idx >> 5, i = idx & 31;
         wt_lds[n * 1024 + (o >> 3) * 256 + (i + 32 * ((o >> 2) & 1)) * 4 + (o & 3)] = w[idx];
+        if (n > 0) wq_lds[(n - 1) * 1024 + (i >> 3) * 256 + (o + 32 * ((i >> 2) & 1)) * 4 + (i & 3)] = w[idx];
       }
     }
     __syncthreads();
@@ -204,8 +208,6 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
     const int64_t fold_stride = static_cast<int64_t>(n_tiles) * 1024;  // floats per fold of a tile-native array
     const float* gin = a.gin + (a.gin_rowmajor ? static_cast<int64_t>(gin_fold) * a.B * kK : gin_fold * fold_stride);
     const float* yp = a.y_p + p_fold * fold_stride;
-    const float* yq0p = a.y_q + q_fold[0] * fold_stride;
-    const float* yq1p = a.y_q + q_fold[1] * fold_stride;
     // marks of the segment's tiles (the units leaf_bwd_redo_kernel takes): one load per lane, then a bit per tile of this wave
     uint64_t marked = 0;  // bit k: tile tile_begin + wave + WAVES k
     if (a.redo != nullptr) {
@@ -217,30 +219,32 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
     };
     // the raw tiles of a unit: batch values (LEAF), gradient tile, kept tiles of P and Q0 / Q1, the four bottom tiles
     uint32_t xlo[4];
-    float g[16], y[16], yq0[16], yq1[16], c[4][16];
-    auto issue_a = [&](int tile) mutable {  // everything whose address is known: the batch values first (they return first)
+    float g[16], y[16], c[4][16];
+    auto issue_x = [&](int tile, uint32_t (&x)[4]) {  // LEAF: the batch values of the unit's four leaves
+      if constexpr (LEAF) {
+        if (CK_EXP(a, 4)) tile = 0;
+        const int bl = min(tile * 32 + b_in, a.B - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = static_cast<uint32_t>(a.x64[static_cast<int64_t>(bl) * a.D + var[i]]);
+      }
+    };
+    auto issue_a = [&](int tile) mutable {  // every tile whose address is known
       if (CK_EXP(a, 4)) tile = 0;
       const int bl = min(tile * 32 + b_in, a.B - 1);
       const int64_t blk = static_cast<int64_t>(tile) * 1024;
-      if constexpr (LEAF) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xlo[i] = static_cast<uint32_t>(a.x64[static_cast<int64_t>(bl) * a.D + var[i]]);
-      }
       if (a.gin_rowmajor) tile_load(gin + static_cast<int64_t>(bl) * kK + 4 * kh, g);
       else tile_load_native(gin + blk, lane, g);
       tile_load_native(yp + blk, lane, y);
-      tile_load_native(yq0p + blk, lane, yq0);
-      tile_load_native(yq1p + blk, lane, yq1);
       if constexpr (!LEAF) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) tile_load_native(a.y_c + c_fold[i] * fold_stride + blk, lane, c[i]);
       }
     };
-    auto issue_b = [&]() {  // LEAF: the gathered table rows, once the batch values are here
+    auto issue_b = [&](const uint32_t (&x)[4]) {  // LEAF: the gathered table rows, once the batch values are here
       if constexpr (LEAF) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const uint32_t row = min(xlo[i], static_cast<uint32_t>(a.C));  // negative: the integral row (as the forward)
+          const uint32_t row = min(x[i], static_cast<uint32_t>(a.C));  // negative: the integral row (as the forward)
           tile_load(a.table + (static_cast<int64_t>(c_fold[i]) * (a.C + 1) + row) * kK + 4 * kh, c[i]);
         }
       }
@@ -252,6 +256,13 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[r] = e[r] * gy[r];
       }
+    };
+    auto recompute = [&](int n, const float (&e)[16], float (&yq)[16]) {  // y of Q_n = W e, as the forward computed it
+      WRegs w;
+      load_w<CK_W_TILED_F32>(wq_lds + n * 1024, lane, w);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yq[r] = e[r];
+      contract_linear<CK_W_TILED_F32>(w, yq);
     };
     auto store = [&](int tile, const float (&r0)[16], const float (&r1)[16]) {
       if (CK_EXP(a, 8)) return;
@@ -272,25 +283,30 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
         if (is_marked(nth, tile)) continue;
         const bool live = tile * 32 + b_in < a.B;
         CK_BSTAMP(0);
+        issue_x(tile, xlo);
         issue_a(tile);
-        issue_b();
+        issue_b(xlo);
         __builtin_amdgcn_sched_barrier(0);
         CK_BSTAMP(1);
-        float gy[16], e[16], gq[16], r0[16], r1[16];
+        float gy[16], e[16], gq[16], r0[16], r1[16], eq[2][16], yq[2][16];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) eq[n][r] = c[2 * n + 1][r];
+          forward_product<!LEAF>(eq[n], c[2 * n]);
+          recompute(n, eq[n], yq[n]);
+        }
         grad_over_y(g, y, live, gy);
         CK_BSTAMP(2);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) e[r] = yq1[r];
-        forward_product<true>(e, yq0);
+        for (int r = 0; r < 16; ++r) e[r] = yq[1][r];
+        forward_product<true>(e, yq[0]);
         node(0, gy, e, gq);
         CK_BSTAMP(3);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) e[r] = c[2 * n + 1][r];
-          forward_product<!LEAF>(e, c[2 * n]);
-          grad_over_y(gq, n == 0 ? yq0 : yq1, live, gy);
-          node(1 + n, gy, e, n == 0 ? r0 : r1);
+          grad_over_y(gq, yq[n], live, gy);
+          node(1 + n, gy, eq[n], n == 0 ? r0 : r1);
           CK_BSTAMP(4 + n);
         }
         store(tile, r0, r1);
@@ -304,9 +320,14 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
       const int n_mine = first < tile_end ? (tile_end - first + WAVES - 1) / WAVES : 0;
       float r0[16], r1[16];
       int rtile = -1;  // the unit whose results r0 / r1 hold (-1: none to store)
+      // batch values travel TWO units ahead, so that a unit's table rows are requested together with its tiles (a whole
+      // unit's compute before they are needed) instead of behind a wait in the middle of the previous unit
+      uint32_t xnext[4] = {0, 0, 0, 0};
       if (n_mine > 0) {
+        issue_x(first, xlo);
         issue_a(first);
-        issue_b();
+        issue_b(xlo);
+        issue_x(first + min(1, n_mine - 1) * WAVES, xnext);
       }
       for (int k = 0; k < n_mine; ++k) {
         const int tile = first + k * WAVES;
@@ -318,26 +339,37 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
         grad_over_y(g, y, live, gyp);  // (dead rows and marked units: zero here, and with it every gradient below)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          ep[r] = yq1[r];
-          dq0[r] = mk ? 0.f : __builtin_amdgcn_rcpf(yq0[r]);  // (a marked unit's kept tiles hold zeros: no 1 / 0 into the products)
-          dq1[r] = mk ? 0.f : __builtin_amdgcn_rcpf(yq1[r]);
           eq0[r] = c[1][r];
           eq1[r] = c[3][r];
         }
-        forward_product<true>(ep, yq0);
         forward_product<!LEAF>(eq0, c[0]);
         forward_product<!LEAF>(eq1, c[2]);
+        {
+          float yq0[16], yq1[16];
+          recompute(0, eq0, yq0);
+          recompute(1, eq1, yq1);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            ep[r] = yq1[r];
+            dq0[r] = mk ? 0.f : __builtin_amdgcn_rcpf(yq0[r]);  // (a marked unit's tiles mean nothing: no 1 / 0 into the products)
+            dq1[r] = mk ? 0.f : __builtin_amdgcn_rcpf(yq1[r]);
+          }
+          forward_product<true>(ep, yq0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         CK_BSTAMP(1);
         // refill them with the next unit's (the last unit fetches itself again: nobody reads that)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xlo[i] = xnext[i];  // (requested an iteration ago; the wait above covered it)
         issue_a(first + min(k + 1, n_mine - 1) * WAVES);
+        issue_b(xlo);
+        issue_x(first + min(k + 2, n_mine - 1) * WAVES, xnext);
         if (rtile >= 0) store(rtile, r0, r1);
         __builtin_amdgcn_sched_barrier(0);
         CK_BSTAMP(2);
         float gq[16], gy[16];
         node(0, gyp, ep, gq);  // (marked units and dead rows: gyp = 0, so every gradient and weight-gradient term below is 0)
         CK_BSTAMP(3);
-        issue_b();
 #pragma unroll
         for (int r = 0; r < 16; ++r) gy[r] = gq[r] * dq0[r];
         node(1, gy, eq0, r0);
@@ -660,7 +692,7 @@ extern "C" {
 
 int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* d, void* stream) {
   CK_REQUIRE(d != nullptr, "ck_leaf_walk_bwd: null descriptor");
-  CK_REQUIRE(d->unit_tab && d->work && d->gin && d->y_p && d->y_q && d->w_p && d->w_q && d->dw_p && d->dw_q && d->gout,
+  CK_REQUIRE(d->unit_tab && d->work && d->gin && d->y_p && d->w_p && d->w_q && d->dw_p && d->dw_q && d->gout,
              "ck_leaf_walk_bwd: null pointer");
   CK_REQUIRE(d->n_seg > 0 && d->n_wg > 0 && d->B > 0, "ck_leaf_walk_bwd: non-positive size");
   CK_REQUIRE(static_cast<int64_t>(d->B) * kK < (int64_t{1} << 31), "ck_leaf_walk_bwd: B=%d too large", d->B);
@@ -675,7 +707,6 @@ int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* d, void* stream) {
   a.D = d->D;
   a.gin = d->gin;
   a.y_p = d->y_p;
-  a.y_q = d->y_q;
   a.y_c = d->y_c;
   a.table = d->table;
   a.x64 = d->x_rows;

@@ -387,7 +387,7 @@ def leaf_segments(num_roots: int, num_tiles: int, num_wg: int) -> np.ndarray:
 
 
 def balanced_segments(num_roots: int, num_tiles: int, num_wg: int, waves: int = 8, max_pieces: int = 16,
-                      overhead: float = 1.5) -> np.ndarray:
+                      overhead: float = 1.5, xcd_aware: bool = True) -> np.ndarray:
     """Segment list ``(n_seg, 4)`` for a persistent launch whose workgroups take SEVERAL segments (`ck_leaf_walk_bwd`:
     workgroup g takes segments g, g + num_wg, ...).  A segment's tiles are dealt round-robin to the `waves` waves of its
     workgroup, so it costs ceil(tiles / waves) unit times plus `overhead` (weights staged, weight gradients flushed: measured ~1.5 unit times, scripts/bwd_stamps.py), and
@@ -415,4 +415,17 @@ def balanced_segments(num_roots: int, num_tiles: int, num_wg: int, waves: int = 
         return float(cost.max()), segs
 
     best = min((schedule(k) for k in range(1, max(1, min(max_pieces, rounds)) + 1)), key=lambda t: t[0])
-    return np.asarray([[r, a, b, 0] for _, r, a, b in best[1]], dtype=np.int32).reshape(-1, 4)
+    segs = np.asarray([[r, a, b, 0] for _, r, a, b in best[1]], dtype=np.int32).reshape(-1, 4)
+    if xcd_aware and num_wg % 8 == 0 and len(segs) >= num_wg:
+        # workgroup g runs on XCD g % 8: within every dealing round hand position s to workgroup 8 (s % (num_wg / 8)) +
+        # s // (num_wg / 8), so that neighbouring positions -- the pieces of ONE root, which gather from the same tables and
+        # stage the same weights -- run side by side on one XCD (one L2) instead of on eight
+        per = num_wg // 8
+        g = np.arange(num_wg)
+        perm = (g % 8) * per + g // 8  # position whose segment workgroup g takes
+        out = segs.copy()
+        full = len(segs) // num_wg * num_wg
+        for r0 in range(0, full, num_wg):  # (a last partial round stays as dealt)
+            out[r0:r0 + num_wg] = segs[r0 + perm]
+        return out
+    return segs

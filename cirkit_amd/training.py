@@ -195,7 +195,7 @@ class HipTrainer:
             return "the dense layer must read the Categorical folds in order"
         self.circuit, self.fused = c, True
         # wavefronts per workgroup of the backward walk: 4 = one per SIMD with the next unit's tiles in flight (ck_leaf_bwd.hip)
-        self._bwd_waves = int(os.environ.get("CK_BWD_WAVES", "4"))
+        self._bwd_waves = int(os.environ.get("CK_BWD_WAVES", "8"))
         dev = c.device
         dl = c.layers[g.dense_layer]
         Cn = cat.num_categories
@@ -343,7 +343,7 @@ class HipTrainer:
             d.n_seg, d.n_wg, d.B, d.waves = int(fb["work"][k].shape[0]), c._n_cu, B, self._bwd_waves
             d.C, d.D, d.leaf = cat.num_categories, self.plan.num_variables, 1 if top == 2 else 0
             d.gin, d.gin_rowmajor = gin.data_ptr(), 1 if k == 0 else 0
-            d.y_p, d.y_q = keep[top - 1].data_ptr(), keep[top - 2].data_ptr()
+            d.y_p = keep[top - 1].data_ptr()  # (the level in between, top - 1, is recomputed by the launch)
             if top == 2:
                 d.table, d.x_rows = c._group_dev[g.root][1].data_ptr(), bd.x_last.data_ptr()
             else:

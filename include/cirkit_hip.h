@@ -296,7 +296,8 @@ int ck_leaf_persistent_fwd(const float* table, const float* table_scale, const i
  *  *bad_input (a DEVICE int32 owned by the caller, as ck_stage_categories' flag) is raised; with bad_input == NULL such a
  *  value is evaluated as the integral row (memory-safe, not meaningful).  B * D * 8 must be below 2^32.
  *  Training forward (keep_levels != NULL; raw input, unsigned values, 8 waves): beside the root outputs the launch stores the
- *  LINEAR tile of every node it evaluates -- keep_levels[l - 1] is (F_l, ceil(B / 32), 1024) for CP-T level l = 1 .. depth in
+ *  LINEAR tile of the nodes of every SECOND level -- keep_levels[l - 1] is (F_l, ceil(B / 32), 1024) for the CP-T levels l = 2, 4
+ *  (the entries of levels 1 and 3 are not read and may be NULL: ck_leaf_walk_bwd recomputes those tiles from their children) in
  *  tile-native order (see ck_leaf_walk_bwd), the value the next level multiplies (per row it differs from exp(layer output) by the power-of-two scale the walk carries; the backward,
  *  ck_leaf_walk_bwd, only needs a level's tiles to be consistent with each other) -- i.e. what the reference's autograd keeps
  *  alive as the outputs of those layers (graph/modules.py:303-335).  keep_redo: (n_roots, ceil(B / 32)) int32, zero on
@@ -584,7 +585,7 @@ int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* x
  * gradient of the root layer's output, (F, B, 32) row-major: gin_rowmajor; below, the tile the previous launch left in ITS
  * `gout` for P's parent).  Tiles that only these launches exchange are TILE-NATIVE: a (F_l, ceil(B / 32), 1024) array whose
  * 4 KB block (fold, tile) holds, at dword (g, lane, t), unit 8g + 4 (lane >> 5) + t of row 32 tile + (lane & 31) -- the MFMA
- * register layout, one contiguous KiB per wave instruction.  y_p / y_q / y_c: the kept linear tiles of the three levels
+ * register layout, one contiguous KiB per wave instruction.  y_p / y_c: the kept linear tiles of P's level and of the level two below (Q's tiles are recomputed)
  * (tile-native, ck_leaf_walk_fwd keep_levels); w_p / w_q: (F_l, 32, 32) row-major linear weights; dw_p / dw_q: their
  * gradients, accumulated (+=, atomically per segment); gout, written: the log-space gradient node Q leaves for BOTH its
  * children (the two children of a product receive the same one) -- tile-native (F_q, tiles, 1024), or, leaf != 0,
@@ -599,7 +600,6 @@ typedef struct ck_leaf_bwd_launch {
                                registers each: the next unit's tiles travel while the current one computes) */
   const float* gin;
   const float* y_p;
-  const float* y_q;
   const float* y_c;
   const float* table;
   const int64_t* x_rows;

@@ -37,9 +37,10 @@ for _ in range(3):
     ll = tr.step(x)
 torch.cuda.synchronize()
 t = time.perf_counter()
-for _ in range(steps):
+for k in range(steps):
     ll = tr.step(x)
-    lls.append(ll.clone())
+    if k in (0, steps - 1):
+        lls.append(ll.clone())
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / steps
 print(f"train step {dt * 1e3:.3f} ms  {B / dt:.3e} samples/s  mean LL first {float(lls[0][0] / lls[0][1]):.3f} last {float(lls[-1][0] / lls[-1][1]):.3f}")
