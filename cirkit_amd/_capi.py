@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 34
+ABI_VERSION = 36
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -196,6 +196,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_segment_add_rows": [_p, _p, _p, _p, _p, _i, _l, _p],
     "ck_param_scatter_add_folds": [_p, _p, _p, _l, _l, _p],
     "ck_categorical_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "ck_tail_bwd": [_p, _i, _p, _i, _i, C.c_int64, _p],
     "ck_param_softmax_bwd_batch": [_p, _i, _i, _p],
     "ck_fill_latch": [_p, _l, _f, _p, _p, _p, _p],
     "ck_leaf_walk_bwd": [C.POINTER(LeafBwdLaunch), _p],

@@ -793,6 +793,9 @@ struct SoftmaxBwdJob {
   int64_t rows;
   int32_t len;
   int32_t first_block;
+  int64_t part_stride;  // n_part > 1: dW = the sum of n_part slots, part_stride floats apart (ck_tail_bwd.hip)
+  int32_t n_part;
+  int32_t reserved;
 };
 __global__ void __launch_bounds__(256) softmax_bwd_batch_kernel(const SoftmaxBwdJob* __restrict__ jobs, int n_jobs) {
   int lo = 0, hi = n_jobs - 1;
@@ -805,12 +808,34 @@ __global__ void __launch_bounds__(256) softmax_bwd_batch_kernel(const SoftmaxBwd
   const int lane = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x - j.first_block) * 4 + (threadIdx.x >> 6);
   if (row >= j.rows) return;
-  const float* wr = j.w + row * j.len;
-  const float* dr = j.dw + row * j.len;
+  const auto* wr = ck::as_global(j.w + row * j.len);  // (pointers out of the job table: device memory, not FLAT)
+  const auto* dr = ck::as_global(j.dw + row * j.len);
+  auto* dth = ck::as_global(j.dtheta);
+  if (j.n_part > 1 && j.len == 32) {
+    // the row's gradient is spread over n_part slots: the two half-waves take every other slot, eight loads in flight each
+    const int i = lane & 31;
+    float acc = 0.f;
+    int p = lane >> 5;
+    for (; p + 14 < j.n_part; p += 16) {
+      float t8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t8[q] = dr[(p + 2 * q) * j.part_stride + i];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += t8[q];
+    }
+    for (; p < j.n_part; p += 2) acc += dr[p * j.part_stride + i];
+    acc += __shfl_xor(acc, 32, 64);
+    const float w = wr[i];
+    float dot = w * acc;
+#pragma unroll
+    for (int s = 1; s < 32; s <<= 1) dot += __shfl_xor(dot, s, 64);
+    if (lane < 32) dth[row * j.len + i] = w * (acc - dot);
+    return;
+  }
   float dot = 0.f;
   for (int i = lane; i < j.len; i += 64) dot = fmaf(wr[i], dr[i], dot);
   dot = ck::wave_sum(dot);
-  for (int i = lane; i < j.len; i += 64) j.dtheta[row * j.len + i] = wr[i] * (dr[i] - dot);
+  for (int i = lane; i < j.len; i += 64) dth[row * j.len + i] = wr[i] * (dr[i] - dot);
 }
 
 // Categorical parameter backward: table (F, C+1, K) = log softmax_C(theta (F, K, C)) transposed.

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "ck_bwd_tile.h"
 #include "ck_internal.h"
 #include "ck_tile.h"
 
@@ -65,81 +66,6 @@ struct BwdArgs {
 #endif
 
 constexpr int kUnitTab = 16;
-
-// Row r, unit u of a 32 x 32 tile in a wave's LDS scratch: 16-byte chunks XOR-swizzled by the row so that the b128 writes of
-// the register layout (lane = row) and the b32 reads of the transposed layout (lane = unit) are both conflict-free.
-__device__ __forceinline__ int tsw(int r, int u) { return r * 32 + 4 * ((u >> 2) ^ (r & 7)) + (u & 3); }
-
-__device__ __forceinline__ void tile_to_lds(float* s, int b_in, int kh, const float (&v)[16]) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-    *reinterpret_cast<float4*>(s + b_in * 32 + 4 * ((2 * g + kh) ^ (b_in & 7))) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-}
-
-// acc += gy^T e over the 32 rows of the tile: A[m = o][k = row] = gy[row][o], B[k = row][n = i] = e[row][i]; lanes (., kb)
-// contract rows 16 kb + j at step j.  Result D[o][i] in lane (i, hi) register r, o = 8 (r >> 2) + 4 hi + (r & 3).
-__device__ __forceinline__ void dw_accumulate(f32x16& acc, float* s_gy, float* s_e, int b_in, int kh, const float (&gy)[16], const float (&e)[16]) {
-  tile_to_lds(s_gy, b_in, kh, gy);
-  tile_to_lds(s_e, b_in, kh, e);
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
-  float a[16], b[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int row = 16 * kh + j;
-    a[j] = s_gy[tsw(row, b_in)];
-    b[j] = s_e[tsw(row, b_in)];
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
-  __builtin_amdgcn_wave_barrier();
-}
-
-// The same through ONE 4 KB tile (the two operands take turns): for kernels that are short of LDS, not of time.
-__device__ __forceinline__ void dw_accumulate_seq(f32x16& acc, float* s_t, int b_in, int kh, const float (&gy)[16], const float (&e)[16]) {
-  float a[16], b[16];
-  tile_to_lds(s_t, b_in, kh, gy);
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) a[j] = s_t[tsw(16 * kh + j, b_in)];
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // (the reads have returned before the tile is overwritten)
-  tile_to_lds(s_t, b_in, kh, e);
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) b[j] = s_t[tsw(16 * kh + j, b_in)];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
-  __builtin_amdgcn_wave_barrier();
-}
-
-// v <- e * (W^T gy): wt = the node's weights in "transposed tiled" order (dword (q, lane, t) = W[8q + 4 (lane >> 5) + t][lane & 31])
-__device__ __forceinline__ void child_gradient(const float* wt_lds, int lane, const float (&gy)[16], const float (&e)[16], float (&out)[16]) {
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 w = *reinterpret_cast<const float4*>(wt_lds + q * 256 + lane * 4);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, gy[4 * q + 0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, gy[4 * q + 1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, gy[4 * q + 2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, gy[4 * q + 3], acc, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) out[r] = acc[r] * e[r];
-}
-
-// gy = g / y (0 where the row is padding, the gradient is 0 or y is 0)
-__device__ __forceinline__ void grad_over_y(const float (&g)[16], const float (&y)[16], bool live, float (&gy)[16]) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float q = g[r] * __builtin_amdgcn_rcpf(y[r]);
-    gy[r] = (live && y[r] > 0.f && g[r] != 0.f) ? q : 0.f;
-  }
-}
 
 // e <- a * b as the forward forms it (ck_tile.h): the bare product at the first fused level, renormalised by the power of two
 // of the row maximum above it -- the kept y of the node is W e for exactly this e.
@@ -626,6 +552,20 @@ __global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const Ta
     const bool live = c < rows;
     float v[16], e[16], gy[16], go[16];
     tile_load(dtp + static_cast<int64_t>(live ? c : rows - 1) * kK + 4 * kh, go);
+    if (tile == n_t - 1 && (rows & 31) != 0 && (rows & 31) <= 4) {
+      // a tile without any gradient contributes nothing and leaves gT = 0: with C = 256 the ninth tile holds the integral
+      // row alone, whose gradient is zero unless the batch had marginalised variables -- and it would be a second round of
+      // the whole chain for one of the eight waves.  (Only asked of such a tile: the test waits for the gradient rows,
+      // which every other tile needs three contractions later.)
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) any = any || (live && go[r] != 0.f);
+      if (__ballot(any) == 0) {
+        const float zero[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        tile_to_lds(t_s + tile * 1024, b_in, kh, zero);
+        continue;
+      }
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // register layout out of the swizzled tile
       const float4 t4 = *reinterpret_cast<const float4*>(t_s + c * 32 + 4 * ((2 * g + kh) ^ (c & 7)));

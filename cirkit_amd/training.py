@@ -274,25 +274,80 @@ class HipTrainer:
         fz["per_B"][B] = hit
         return hit
 
-    def _softmax_bwd_jobs(self, st: dict) -> tuple[torch.Tensor, int]:
-        """(device job table, blocks) of `ck_param_softmax_bwd_batch` over every sum layer of the fused trainer."""
-        fz = self._fz
-        if fz.get("sm_jobs") is None or fz["sm_jobs_key"] != st["dw_flat"].data_ptr():
-            c, g = self.circuit, fz["group"]
+    def _tail_bwd_tables(self, B: int, bd, st: dict, fb: dict) -> dict | None:
+        """Descriptors of `ck_tail_bwd` -- the few-fold layers above the leaf region in ONE backward launch -- for this
+        binding, or None when a layer does not qualify (then they run layer by layer, `_bwd_sum_layer`): CP-T / arity-1
+        layers of 32 input units and 32 outputs (1 for a scalar root), every child read by exactly one fold."""
+        key = (bd.arena.data_ptr(), st["garena"].data_ptr())
+        hit = fb.get("tail_bwd")
+        if hit is not None and hit["key"] == key:
+            return hit["tabs"]
+        c = self.circuit
+        tabs = None
+        layers = list(reversed(c._tail))
+        ok = bool(layers) and os.environ.get("CK_TAIL_BWD", "1") != "0"
+        for i in layers:
+            l = c.layers[i]
+            ok = ok and (st["flags"][i] == 0 and st["shared"].get(i) is None and l.num_input_units == 32 and l.arity <= 2
+                         and (l.num_output_units == 32 or (l.num_output_units == 1 and l.num_folds == 1 and i == layers[0]))
+                         and (l._mode == capi.CK_SUM_PROD or l.arity == 1) and not l.is_complex and l._w_layout == capi.CK_W_ROWMAJOR)
+        if ok:
+            n_tiles = (B + 31) // 32
+            dt = np.dtype([("w", "<u8"), ("gout", "<u8"), ("dw_part", "<u8"), ("child", "<u8", 4), ("gchild", "<u8", 4), ("H", "<i4"), ("Ko", "<i4")])
+            assert dt.itemsize == 96
+            n_folds = sum(c.layers[i].num_folds for i in layers)
+            stride = sum(c.layers[i].num_folds * c.layers[i].num_output_units * 32 for i in layers)
+            part = torch.empty(n_tiles * stride, dtype=torch.float32, device=self.device)
+            tab = np.zeros(n_folds, dtype=dt)
+            level_begin, k, off, part_of = [0], 0, 0, {}
+            arena, garena = bd.arena.data_ptr(), st["garena"].data_ptr()
+            for i in layers:
+                l = c.layers[i]
+                ro = bd.row_off[i].cpu().numpy().reshape(l.num_folds, l.arity)
+                part_of[i] = part.data_ptr() + 4 * off
+                wbytes = l.num_output_units * 32 * 4
+                for f in range(l.num_folds):
+                    r = tab[k]
+                    r["w"] = l._w.data_ptr() + f * wbytes
+                    r["gout"] = st["gviews"][i].data_ptr() + f * B * l.num_output_units * 4
+                    r["dw_part"] = part_of[i] + f * wbytes
+                    for h in range(2):  # (a single child is named twice: the launch issues a fixed number of loads and stores)
+                        r["child"][h] = arena + 4 * int(ro[f, min(h, l.arity - 1)])
+                        r["gchild"][h] = garena + 4 * int(ro[f, min(h, l.arity - 1)])
+                    r["H"], r["Ko"] = l.arity, l.num_output_units
+                    k += 1
+                off += l.num_folds * l.num_output_units * 32
+                level_begin.append(k)
+            tabs = {"folds": torch.from_numpy(tab.view(np.uint8).reshape(n_folds, -1)).to(self.device), "n_folds": n_folds,
+                    "levels": torch.from_numpy(np.asarray(level_begin, dtype=np.int32)).to(self.device), "n_levels": len(layers),
+                    "part": part, "part_of": part_of, "stride": stride, "n_tiles": n_tiles}
+        fb["tail_bwd"] = {"key": key, "tabs": tabs}
+        fb.pop("sm_jobs", None)
+        return tabs
+
+    def _softmax_bwd_jobs(self, st: dict, fb: dict, tail: dict | None) -> tuple[torch.Tensor, int]:
+        """(device job table, blocks) of `ck_param_softmax_bwd_batch` over every sum layer of the fused trainer; the tail
+        layers' weight gradients are the per-tile slots `ck_tail_bwd` left (summed by that launch) when `tail` is given."""
+        hit = fb.get("sm_jobs")
+        key = (st["dw_flat"].data_ptr(), None if tail is None else tail["part"].data_ptr())
+        if hit is None or hit[0] != key:
+            c, g = self.circuit, self._fz["group"]
             rows = []
             for j in list(c._tail) + list(g.levels):  # (the dense layer's is part of ck_table_dense_bwd)
                 l = c.layers[j]
                 w = l._w
-                rows.append((w.data_ptr(), st["dws"][j].data_ptr(), self.grads[l.weight.graph.nodes[0].config["tensor"]].data_ptr(),
-                             l.num_folds * l.num_output_units, l.num_input_units))
-            jt = np.zeros(len(rows), dtype=np.dtype([("w", "<u8"), ("dw", "<u8"), ("dtheta", "<u8"), ("rows", "<i8"), ("len", "<i4"), ("first", "<i4")]))
+                parted = tail is not None and j in tail["part_of"]
+                rows.append((w.data_ptr(), tail["part_of"][j] if parted else st["dws"][j].data_ptr(),
+                             self.grads[l.weight.graph.nodes[0].config["tensor"]].data_ptr(), l.num_folds * l.num_output_units,
+                             l.num_input_units, tail["stride"] if parted else 0, tail["n_tiles"] if parted else 0))
+            jt = np.zeros(len(rows), dtype=np.dtype([("w", "<u8"), ("dw", "<u8"), ("dtheta", "<u8"), ("rows", "<i8"), ("len", "<i4"), ("first", "<i4"),
+                                                     ("part_stride", "<i8"), ("n_part", "<i4"), ("reserved", "<i4")]))
             first = 0
-            for r, (w, dw, dt, n, ln) in zip(jt, rows):
-                r["w"], r["dw"], r["dtheta"], r["rows"], r["len"], r["first"] = w, dw, dt, n, ln, first
+            for r, (w, dw, dt, n, ln, ps, npart) in zip(jt, rows):
+                r["w"], r["dw"], r["dtheta"], r["rows"], r["len"], r["first"], r["part_stride"], r["n_part"] = w, dw, dt, n, ln, first, ps, npart
                 first += (n + 3) // 4
-            fz["sm_jobs"] = (torch.from_numpy(jt.view(np.uint8).reshape(len(rows), -1)).to(self.device), first)
-            fz["sm_jobs_key"] = st["dw_flat"].data_ptr()
-        return fz["sm_jobs"]
+            hit = fb["sm_jobs"] = (key, (torch.from_numpy(jt.view(np.uint8).reshape(len(rows), -1)).to(self.device), first))
+        return hit[1]
 
     def _backward_fused(self, B: int, gB: float, seed, bd, st: dict, stream: int) -> None:
         c, fz = self.circuit, self._fz
@@ -327,12 +382,21 @@ class HipTrainer:
             raise NotImplementedError("training needs a scalar output unit")
         if gviews[po].numel() != B:
             capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel(), 0.0, stream)
-        if seed is None:
-            capi.call("ck_fill_f32", gviews[po][fo].data_ptr(), B, -1.0 / gB, stream)
+        if seed is None:  # (nobody writes this block: the constant seed of the mean log-likelihood is filled once per binding)
+            key = (gviews[po].data_ptr(), B, float(gB))
+            if fb.get("seed_key") != key:
+                capi.call("ck_fill_f32", gviews[po][fo].data_ptr(), B, -1.0 / gB, stream)
+                fb["seed_key"] = key
         else:
             gviews[po][fo].reshape(-1)[:B].copy_(seed.reshape(-1))
-        for i in reversed(c._tail):  # the few-fold layers above the leaf region, layer by layer
-            self._bwd_sum_layer(i, bd, st, B, stream)
+            fb["seed_key"] = None
+        tail = self._tail_bwd_tables(B, bd, st, fb)
+        if tail is not None:  # the few-fold layers above the leaf region: one launch, a workgroup per 32-row tile
+            capi.call("ck_tail_bwd", tail["folds"].data_ptr(), tail["n_folds"], tail["levels"].data_ptr(), tail["n_levels"], B,
+                      tail["stride"], stream)
+        else:
+            for i in reversed(c._tail):  # ... or layer by layer
+                self._bwd_sum_layer(i, bd, st, B, stream)
         # the leaf region, two levels per launch, top first
         cat, dl = c.layers[g.input_layer], c.layers[g.dense_layer]
         gin = gviews[g.root]
@@ -373,7 +437,7 @@ class HipTrainer:
                   dTp.data_ptr(), self.grads[cat.probs.graph.nodes[0].config["tensor"]].data_ptr(),
                   self.grads[dl.weight.graph.nodes[0].config["tensor"]].data_ptr(), dl.num_folds, Cn, stream)
         # softmax parameterisation of every sum layer's weights (tail, fused levels, dense layer): one launch
-        jobs, n_blocks = self._softmax_bwd_jobs(st)
+        jobs, n_blocks = self._softmax_bwd_jobs(st, fb, tail)
         capi.call("ck_param_softmax_bwd_batch", jobs.data_ptr(), jobs.shape[0], n_blocks, stream)
 
     def _accumulate_flags(self) -> tuple[dict[int, int], set[int]]:

@@ -611,6 +611,26 @@ typedef struct ck_leaf_bwd_launch {
   const int32_t* redo;
 } ck_leaf_bwd_launch;
 int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* desc, void* stream);
+/* Backward of a circuit's trailing few-fold sum layers in ONE launch (cirkit_amd/csrc/ck_tail_bwd.hip): what autograd does
+ * for TorchCPTLayer.forward (optimized.py:171-178) / dense TorchSumLayer.forward (inner.py:266-273) under
+ * LSESumSemiring.apply_reduce (semiring.py:383-408), for all of these layers, one workgroup per 32-row batch tile walking them
+ * top down.  folds: DEVICE array, the folds of the top layer first; level_begin: DEVICE (n_levels + 1) first fold of each
+ * layer.  Per fold: w (Ko, 32) row-major LINEAR weights (Ko = 32, or 1 for a scalar root); gout (B, Ko) the gradient w.r.t.
+ * its log-space output (a Ko = 1 fold must be the only fold of the first level); child[h] / gchild[h], h < H <= 2: the (B, 32)
+ * log-space outputs of its children (multiplied: CP-T, or H = 1 -- then child[1] / gchild[1] must name the first child again)
+ * and the blocks their gradient is WRITTEN to (each child must have one consumer); dw_part: the fold's (Ko, 32) slot
+ * of tile 0 in a buffer of per-tile weight-gradient contributions, slots of consecutive tiles part_stride floats apart --
+ * written, not added: ck_param_softmax_bwd_batch sums the ceil(B / 32) slots (n_part / part_stride of its jobs). */
+typedef struct ck_tail_bwd_fold {
+  const float* w;
+  const float* gout;
+  float* dw_part;
+  const float* child[4];
+  float* gchild[4];
+  int32_t H, Ko;
+} ck_tail_bwd_fold;
+int ck_tail_bwd(const ck_tail_bwd_fold* folds, int n_folds, const int32_t* level_begin, int n_levels, int B, int64_t part_stride,
+                void* stream);
 /* Backward of `dense_on_table` (ck_param_softmax_batch's kind-5 job: T' = dense(log-table), layers/input.py:399-412 +
  * layers/inner.py:266-273 with both parameters softmaxes, nodes.py:764-772): dtable (F, C + 1, 32) is the gradient w.r.t. the
  * LOG-space table T' (ck_categorical_bwd's output); g_cat (F_cat, 32, C) and g_dense (F, 32, 32) receive (=) the gradients of
@@ -642,6 +662,9 @@ typedef struct ck_softmax_bwd_job {
   int64_t rows;
   int32_t len;
   int32_t first_block;
+  int64_t part_stride;  /* n_part > 1: dW is the sum of n_part slots, part_stride floats apart (ck_tail_bwd's dw_part) */
+  int32_t n_part;       /* 0 or 1: dw is the gradient itself */
+  int32_t reserved;
 } ck_softmax_bwd_job;
 int ck_param_softmax_bwd_batch(const ck_softmax_bwd_job* jobs, int n_jobs, int n_blocks, void* stream);
 int ck_param_log_table_bwd(const float* table, const float* dtable, float* dtheta, int F, int K, int C,
