@@ -367,6 +367,7 @@ class HipParameter:
             else:
                 raise NotImplementedError(f"parameter op {n.op}")
             outs.append(y)
+        self._last_outs = outs  # (what `backward` differentiates: nodes that alias their input own no buffer of their own)
         if upto is not None:
             return outs[upto]
         return self._select("out", outs, g.output, stream)
@@ -425,7 +426,10 @@ class HipParameter:
 
         def value(j: int) -> torch.Tensor:
             n = g.nodes[j]
-            return self.store[n.config["tensor"]] if n.op == "tensor" else self._bufs[j]
+            if n.op == "tensor":
+                return self.store[n.config["tensor"]]
+            outs = getattr(self, "_last_outs", None)
+            return outs[j] if outs is not None and j < len(outs) else self._bufs[j]
 
         gb: dict[int, torch.Tensor] = {}
 
@@ -524,6 +528,36 @@ class HipParameter:
                 capi.call("ck_param_bmm", _ptr(a), _ptr(dj), _ptr(db), F, Kd, N, M, 1, 0, stream)
                 scatter((j, 0), n.inputs[0], da)
                 scatter((j, 1), n.inputs[1], db)
+            elif n.op == "pointer":  # a gather of folds of a stored tensor (nodes.py:277-279): scatter-add back
+                t = grads[n.config["tensor"]]
+                if dj.is_complex() or t.is_complex():
+                    raise NotImplementedError("parameter backward through a complex pointer")
+                idx = n.config.get("fold_idx")
+                if idx is None:
+                    capi.call("ck_axpy_f32", _ptr(t), _ptr(dj), 1.0, dj.numel(), stream)
+                else:
+                    capi.call("ck_param_scatter_add_folds", _ptr(dj), _ptr(self._index_tensor(("pi", j), np.asarray(idx, dtype=np.int64))),
+                              _ptr(t), len(idx), dj.numel() // dj.shape[0], stream)
+            elif n.op == "conj":  # (of a real value: the identity, nodes.py:745-746)
+                if dj.is_complex() or operand(j, 0).is_complex():
+                    raise NotImplementedError("parameter backward through the conjugate of a complex value")
+                scatter((j, 0), n.inputs[0], dj)
+            elif n.op == "flatten":  # nodes.py:843-844
+                scatter((j, 0), n.inputs[0], dj.reshape(operand(j, 0).shape))
+            elif n.op == "einsum":  # y = sum over the contracted indices of prod_k x_k: d x_k = the same sum with y's gradient in x_k's place
+                xs = [operand(j, k) for k in range(len(n.inputs))]
+                if dj.is_complex() or any(x.is_complex() for x in xs):
+                    raise NotImplementedError("parameter backward through an einsum over complex operands")
+                *ins, out_idx = [tuple(int(i) for i in e) for e in n.config["einsum"]]
+                for k in range(len(xs)):
+                    others = [m for m in range(len(xs)) if m != k]
+                    have = set(out_idx) | {i for m in others for i in ins[m]}
+                    if not set(ins[k]) <= have or len(set(ins[k])) != len(ins[k]):
+                        raise NotImplementedError(f"parameter backward through einsum {n.config['einsum']}: operand {k} carries an index "
+                                                  "that is summed out on its own or repeated")
+                    spec = [out_idx, *[ins[m] for m in others], ins[k]]
+                    dk = self._einsum(("ge", j, k), spec, [dj.contiguous(), *[xs[m] for m in others]], stream)
+                    scatter((j, k), n.inputs[k], dk)
             else:
                 raise NotImplementedError(f"parameter backward through {n.op!r}")
 

@@ -63,7 +63,9 @@ class HipTrainer:
         `fused`: None takes the fused forward / backward when the plan qualifies (module docstring), True insists
         (NotImplementedError says why not), False forces the layer-wise form."""
         if plan.semiring != "lse-sum":
-            raise NotImplementedError("training is implemented for the real lse-sum semiring")
+            raise NotImplementedError("HipTrainer trains circuits under the real lse-sum semiring; squared circuits compiled under "
+                                      "complex-lse-sum (Embedding / CP-T for c, ConstantValue / Hadamard / TensorDot for Z) train with "
+                                      "cirkit_amd.training_complex.HipSquaredTrainer")
         if optimizer not in ("adam", "sgd"):
             raise ValueError(f"unknown optimizer {optimizer!r}")
         self.user_plan, self._pad_info = plan, None

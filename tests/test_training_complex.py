@@ -1,0 +1,66 @@
+"""Plan-level training of a squared circuit (complex-lse-sum for c, Z from ConstantValue / Hadamard / TensorDot layers with
+pointer / conj / einsum / flatten parameter graphs): `cirkit_amd.training_complex.HipSquaredTrainer` against the gradients of
+the reference's own ``loss.backward()`` for ``loss = -mean(2 Re c(x) - Re Z)`` (tests/golden/sos_4x4_k4_grads.npz,
+make_fixtures.py `grads_sos`)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+from cirkit_amd.initializers import init_plan_tensors  # noqa: E402
+from cirkit_amd.plan import Plan  # noqa: E402
+
+
+def _case():
+    plan_c, plan_z = Plan.load(os.path.join(GOLDEN, "sos_4x4_c_k4")), Plan.load(os.path.join(GOLDEN, "sos_4x4_z_k4"))
+    with np.load(os.path.join(GOLDEN, "sos_4x4_k4_grads.npz")) as z:
+        ref = {k: z[k] for k in z.files}
+    return plan_c, plan_z, init_plan_tensors(plan_c), ref
+
+
+def test_squared_trainer_refuses_real_plans():
+    from cirkit_amd.training_complex import HipSquaredTrainer
+
+    plan = Plan.load(os.path.join(GOLDEN, "cfg1_rbt8"))
+    with pytest.raises(NotImplementedError, match="complex-lse-sum"):
+        HipSquaredTrainer(plan, init_plan_tensors(plan), device="cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("native_z", [False, True])
+def test_squared_circuit_gradients_match_the_reference(hip_device, native_z):
+    """Both circuits through the HIP forward, both reverse launch lists, the parameter graphs of Z in reverse mode: the
+    loss and every parameter gradient of the reference's autograd.  native_z: Z built from the plan of c
+    (cirkit_amd/functional.py) instead of the plan the reference compiled."""
+    from cirkit_amd.training_complex import HipSquaredTrainer
+
+    plan_c, plan_z, tensors, ref = _case()
+    tr = HipSquaredTrainer(plan_c, tensors, plan_z=None if native_z else plan_z, device=hip_device)
+    x = torch.from_numpy(ref["x"].astype(np.int64)).to(hip_device)
+    ll = tr.loss_and_grads(x).cpu().numpy()
+    loss = -ll[0] / ll[1]
+    assert abs(loss - float(ref["loss"])) <= 2e-5 * abs(float(ref["loss"])), (loss, float(ref["loss"]))
+    got = tr.gradients()
+    for k in tensors:
+        want = ref["g_" + k]
+        err = float(np.abs(got[k] - want).max())
+        assert err <= 1e-3 * max(1e-3, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+def test_squared_circuit_training_steps_increase_the_likelihood(hip_device):
+    from cirkit_amd.training_complex import HipSquaredTrainer
+
+    plan_c, _, tensors, ref = _case()
+    tr = HipSquaredTrainer(plan_c, tensors, device=hip_device, lr=0.01)
+    x = torch.from_numpy(ref["x"].astype(np.int64)).to(hip_device)
+    lls = [float(tr.step(x)[0]) for _ in range(8)]
+    assert all(np.isfinite(lls)) and lls[-1] > lls[0], lls
+    # the parameters the two circuits share moved, and the normaliser follows them: sum_x |c(x)|^2 / Z stays a density
+    assert any(np.abs(tr.parameters()[k] - tensors[k]).max() > 1e-4 for k in tensors)
