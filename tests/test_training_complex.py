@@ -64,3 +64,30 @@ def test_squared_circuit_training_steps_increase_the_likelihood(hip_device):
     assert all(np.isfinite(lls)) and lls[-1] > lls[0], lls
     # the parameters the two circuits share moved, and the normaliser follows them: sum_x |c(x)|^2 / Z stays a density
     assert any(np.abs(tr.parameters()[k] - tensors[k]).max() > 1e-4 for k in tensors)
+
+
+@pytest.mark.gpu
+def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_device):
+    """BASELINE config 5 (QuadTree 28x28, Embedding-256, CP-T, K = 32; Z from its own plan): the gradients of 32 rows against
+    torch autograd through the oracle's restatement of the reference forward (bit-identical to the reference on CPU)."""
+    from cirkit_amd.training_complex import HipSquaredTrainer
+    from oracle import torch_oracle as oracle  # (tests may: the oracle is the checker)
+
+    plan_c, plan_z = Plan.load(os.path.join(GOLDEN, "cfg5_sos_c_k32")), Plan.load(os.path.join(GOLDEN, "cfg5_sos_z_k32"))
+    tensors = init_plan_tensors(plan_c)
+    # (the counter-based generator emits a few exact zeros: log 0 under autograd is NaN in the reference as well)
+    tensors = {k: np.where(v == 0, np.float32(1e-2), v).astype(np.float32) for k, v in tensors.items()}
+    x = torch.randint(0, 256, (32, 784), generator=torch.Generator().manual_seed(5))
+    leaves = {k: torch.from_numpy(np.ascontiguousarray(v)).to(torch.float64).requires_grad_(True) for k, v in tensors.items()}
+    c = oracle.evaluate_plan(plan_c, leaves, x, grad=True)
+    z = oracle.evaluate_plan(plan_z, leaves, None, grad=True)
+    loss = -(2.0 * c.real - z.real).mean()
+    loss.backward()
+    tr = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)
+    ll = tr.loss_and_grads(x.to(hip_device)).cpu().numpy()
+    assert abs(-ll[0] / ll[1] - loss.item()) <= 1e-4 * abs(loss.item()), (-ll[0] / ll[1], loss.item())
+    got = tr.gradients()
+    for k in tensors:
+        want = leaves[k].grad.numpy()
+        err = float(np.abs(got[k] - want).max())
+        assert err <= 2e-3 * max(1e-6, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
