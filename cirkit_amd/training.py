@@ -65,7 +65,7 @@ class HipTrainer:
         if plan.semiring != "lse-sum":
             raise NotImplementedError("HipTrainer trains circuits under the real lse-sum semiring; squared circuits compiled under "
                                       "complex-lse-sum (Embedding / CP-T for c, ConstantValue / Hadamard / TensorDot for Z) train with "
-                                      "cirkit_amd.training_complex.HipSquaredTrainer")
+                                      "cirkit_amd.training_squared.HipSquaredTrainer")
         if optimizer not in ("adam", "sgd"):
             raise ValueError(f"unknown optimizer {optimizer!r}")
         self.user_plan, self._pad_info = plan, None

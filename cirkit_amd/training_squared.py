@@ -1,16 +1,19 @@
-"""Plan-level training under the complex semiring: squared circuits p(x) = |c(x)|^2 / Z with real parameters.
+"""Plan-level training of squared circuits p(x) = |c(x)|^2 / Z with real parameters, under complex-lse-sum or lse-sum.
 
 The reference trains such a model with autograd through its torch layers (``loss = -mean(2 Re c(x) - Re Z)``: c compiled under
 complex-lse-sum -- Embedding + CP-T / sum layers, layers/input.py:258-266, optimized.py:171-178, semiring.py:441-476 -- and
 Z = integrate(multiply(c, conj(c))) made of ConstantValue, Hadamard and TensorDot layers whose parameters are pointer / conj /
-einsum / flatten graphs over the tensors of c, symbolic/operators.py:39-322).  `cirkit_amd.training.HipTrainer` covers the real
-lse-sum semiring; this module is its counterpart for that model class:
+einsum / flatten graphs over the tensors of c, symbolic/operators.py:39-322; a REAL circuit squares the same way under lse-sum,
+``loss = -mean(2 c(x) - Z)``, Categorical inputs whose products integrate to logs of Gram matrices, operators.py:51-63,
+106-139).  `cirkit_amd.training.HipTrainer` covers single real circuits; this module is its counterpart for that model class:
 
 * forward: two layer-wise `HipCircuit`s (c on the batch, Z on no input) sharing ONE parameter store;
-* backward: a reverse launch list per circuit over the complex gradient arena -- `ck_sum_lse_bwd_c` for sum / CP-T / Tucker
-  layers and, on a permuted copy of their input, TensorDot layers; `ck_hadamard_bwd` on (re, im) pairs; `ck_categorical_bwd`
-  + d log w / dw for Embedding layers; the batch sum + d log v / dv for ConstantValue layers -- and `HipParameter.backward`
-  through the parameter graphs (pointer gathers, conj of real values, einsum, flatten: cirkit_amd/parameters.py);
+* backward: a reverse launch list per circuit over the gradient arena (complex64 or fp32) -- `ck_sum_lse_bwd_c` /
+  `ck_sum_lse_bwd` for sum / CP-T / Tucker layers and, on a permuted copy of their input, TensorDot layers; `ck_hadamard_bwd`
+  (on (re, im) pairs under the complex semiring); `ck_categorical_bwd` + d log w / dw for Embedding layers, +
+  `ck_param_log_table_bwd` for Categorical layers; the batch sum (+ d log v / dv) for ConstantValue layers -- and
+  `HipParameter.backward` through the parameter graphs (pointer gathers, conj of real values, softmax, einsum, log, flatten:
+  cirkit_amd/parameters.py);
 * one flat parameter / gradient / moment buffer: one optimizer launch, one all-reduce.
 
 torch appears as storage and for data movement only (real parts, permutations of a handful of small tensors); every arithmetic
@@ -26,17 +29,18 @@ import torch
 
 from . import _capi as capi
 from .circuit import HipCircuit
-from .layers import (HipConstantValueLayer, HipCPTLayer, HipEmbeddingLayer, HipHadamardLayer, HipSumLayer, HipTensorDotLayer,
-                     HipTuckerLayer)
+from .layers import (HipCategoricalLayer, HipConstantValueLayer, HipCPTLayer, HipEmbeddingLayer, HipHadamardLayer, HipSumLayer,
+                     HipTensorDotLayer, HipTuckerLayer)
 from .parameters import TensorStore
 from .plan import Plan
 
 
-class _ComplexBackward:
-    """The reverse launch list of ONE complex-lse-sum circuit over the activations of its last forward."""
+class _PlanBackward:
+    """The reverse launch list of ONE layer-wise circuit (complex-lse-sum or lse-sum) over the activations of its last forward."""
 
     def __init__(self, circuit: HipCircuit, grads: Mapping[str, torch.Tensor]) -> None:
         self.c, self.grads = circuit, grads
+        self.cplx = circuit.plan.semiring == "complex-lse-sum"
         self._bound: dict[int, dict] = {}
         c = circuit
         if len(c._out_pairs) != 1:
@@ -50,24 +54,27 @@ class _ComplexBackward:
                 continue
             for p, f in ch.reshape(-1, 2):
                 if (int(p), int(f)) in seen:
-                    raise NotImplementedError("complex training: a fold read by several consumers (gradients are stored, not added)")
+                    raise NotImplementedError("squared-circuit training: a fold read by several consumers (gradients are stored, not added)")
                 seen.add((int(p), int(f)))
         for spec, l in zip(c.plan.layers, c.layers):
             if isinstance(l, (HipSumLayer, HipCPTLayer, HipTuckerLayer)):
                 if getattr(l, "_mixing", False):
-                    raise NotImplementedError("complex training: mixing layers")
+                    raise NotImplementedError("squared-circuit training: mixing layers")
+            elif isinstance(l, HipCategoricalLayer):
+                if self.cplx or l.probs is None or l.probs.softmax_source() is None:
+                    raise NotImplementedError("squared-circuit training: Categorical layers need lse-sum and probs = softmax(tensor)")
             elif not isinstance(l, (HipEmbeddingLayer, HipConstantValueLayer, HipHadamardLayer, HipTensorDotLayer)):
-                raise NotImplementedError(f"complex training: layer type {spec.type!r}")
+                raise NotImplementedError(f"squared-circuit training: layer type {spec.type!r}")
 
     def _bind(self, B: int) -> dict:
         bd = self.c._bind(B)
         st = self._bound.get(B)
         if st is not None and st["arena_ptr"] == bd.arena.data_ptr():
             return st
-        garena = torch.zeros_like(bd.arena)  # complex64, the mirror of the activation arena
+        garena = torch.zeros_like(bd.arena)  # complex64 / fp32, the mirror of the activation arena
         gviews = []
         for i, l in enumerate(self.c.layers):
-            off = (bd.views[i].data_ptr() - bd.arena.data_ptr()) // 8
+            off = (bd.views[i].data_ptr() - bd.arena.data_ptr()) // bd.arena.element_size()
             gviews.append(garena[off : off + l.num_folds * B * l.num_output_units].view(l.num_folds, B, l.num_output_units))
         st = {"arena_ptr": bd.arena.data_ptr(), "garena": garena, "gviews": gviews}
         while len(self._bound) >= 4:
@@ -83,8 +90,21 @@ class _ComplexBackward:
         garena, gviews = st["garena"], st["gviews"]
         po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
         gviews[po].zero_()
-        gviews[po][fo] = complex(seed_real, 0.0)
+        gviews[po][fo] = complex(seed_real, 0.0) if self.cplx else seed_real
         ga = garena.data_ptr()
+        cplx = self.cplx
+
+        def sum_bwd(arena_ptr, garena_ptr, row_off, w, out_ptr, g_ptr, dw, F, H, rows, Ki, Ko, mode):
+            if cplx:
+                capi.call("ck_sum_lse_bwd_c", arena_ptr, garena_ptr, row_off.data_ptr(), w.data_ptr(), out_ptr, g_ptr, dw.data_ptr(),
+                          F, H, rows, Ki, Ko, mode, 1 if w.is_complex() else 0, stream)
+            else:
+                capi.call("ck_sum_lse_bwd", arena_ptr, garena_ptr, row_off.data_ptr(), None, w.data_ptr(), out_ptr, g_ptr, dw.data_ptr(),
+                          F, H, rows, Ki, Ko, mode, 0, stream)
+
+        def real_part(g):
+            return torch.view_as_real(g)[..., 0] if cplx else g
+
         for i in range(len(c.layers) - 1, -1, -1):
             l = c.layers[i]
             F, K = l.num_folds, l.num_output_units
@@ -98,10 +118,11 @@ class _ComplexBackward:
                 xp = x.permute(0, 1, 3, 2).contiguous().view(F, B * Kq, Kj)
                 gx = torch.empty_like(xp)
                 w = l._w
+                if w.is_complex():
+                    raise NotImplementedError("squared-circuit training: complex-valued weights")
                 dw = torch.zeros((F, Kk, Kj), dtype=torch.float32, device=w.device)
                 rows = (torch.arange(F, dtype=torch.int64, device=w.device) * (B * Kq * Kj)).reshape(F, 1)
-                capi.call("ck_sum_lse_bwd_c", xp.data_ptr(), gx.data_ptr(), rows.data_ptr(), w.data_ptr(), bd.views[i].data_ptr(),
-                          g.data_ptr(), dw.data_ptr(), F, 1, B * Kq, Kj, Kk, capi.CK_SUM_PROD, 1 if w.is_complex() else 0, stream)
+                sum_bwd(xp.data_ptr(), gx.data_ptr(), rows, w, bd.views[i].data_ptr(), g.data_ptr(), dw, F, 1, B * Kq, Kj, Kk, capi.CK_SUM_PROD)
                 gxp = gx.view(F, B, Kq, Kj).permute(0, 1, 3, 2).contiguous().view(F, B * Kj * Kq)
                 for f, o in enumerate(ro.tolist()):
                     garena[int(o) : int(o) + B * Kj * Kq] = gxp[f]
@@ -109,18 +130,26 @@ class _ComplexBackward:
             elif isinstance(l, (HipSumLayer, HipCPTLayer, HipTuckerLayer)):
                 w = l._w
                 if w.is_complex():
-                    raise NotImplementedError("complex training: complex-valued weights")
+                    raise NotImplementedError("squared-circuit training: complex-valued weights")
                 dw = torch.zeros_like(w)
-                capi.call("ck_sum_lse_bwd_c", bd.arena.data_ptr(), ga, bd.row_off[i].data_ptr(), w.data_ptr(), bd.views[i].data_ptr(),
-                          g.data_ptr(), dw.data_ptr(), F, l.arity, B, l.num_input_units, K, l._mode, 0, stream)
+                sum_bwd(bd.arena.data_ptr(), ga, bd.row_off[i], w, bd.views[i].data_ptr(), g.data_ptr(), dw, F, l.arity, B, l.num_input_units, K,
+                        l._mode)
                 l.weight.backward(dw, self.grads, stream)
             elif isinstance(l, HipHadamardLayer):  # log space: the sum of the children -- (re, im) pairs as 2 K floats
-                ro2 = (bd.row_off[i] * 2).contiguous()
-                capi.call("ck_hadamard_bwd", ga, ro2.data_ptr(), g.data_ptr(), F, l.arity, B, 2 * K, 0, stream)
+                e = 2 if cplx else 1
+                ro2 = (bd.row_off[i] * e).contiguous()
+                capi.call("ck_hadamard_bwd", ga, ro2.data_ptr(), g.data_ptr(), F, l.arity, B, e * K, 0, stream)
+            elif isinstance(l, HipCategoricalLayer):  # (lse-sum) the scatter-add into the log-table, then log softmax backward
+                Cn = l.num_categories
+                dtable = torch.zeros((F, Cn + 1, K), dtype=torch.float32, device=g.device)
+                capi.call("ck_categorical_bwd", g.data_ptr(), None, bd.xt_i.data_ptr(), l._scope(g.device).data_ptr(), dtable.data_ptr(),
+                          F, B, K, Cn, 1, None, stream)
+                name = l.probs.graph.nodes[0].config["tensor"]
+                capi.call("ck_param_log_table_bwd", l._table.data_ptr(), dtable.data_ptr(), self.grads[name].data_ptr(), F, K, Cn, 1, stream)
             elif isinstance(l, HipEmbeddingLayer):
                 # out = log(w[f, :, x]): the scatter-add of Re(gout) over the batch, divided by w
                 Cn = l.num_states
-                gr = torch.view_as_real(g)[..., 0].contiguous()
+                gr = real_part(g).contiguous()
                 dtable = torch.zeros((F, Cn + 1, K), dtype=torch.float32, device=gr.device)
                 capi.call("ck_categorical_bwd", gr.data_ptr(), None, bd.xt_i.data_ptr(), l._scope(gr.device).data_ptr(), dtable.data_ptr(),
                           F, B, K, Cn, 1, None, stream)
@@ -132,8 +161,8 @@ class _ComplexBackward:
             elif isinstance(l, HipConstantValueLayer):
                 v = l._val
                 if v.is_complex():
-                    raise NotImplementedError("complex training: complex constant values")
-                gr = torch.view_as_real(g)[..., 0]
+                    raise NotImplementedError("squared-circuit training: complex constant values")
+                gr = real_part(g)
                 gsum = (gr[:, 0] if B == 1 else gr.sum(dim=1)).contiguous()  # (F, K)
                 if l.log_space:
                     dv = gsum
@@ -147,12 +176,13 @@ class _ComplexBackward:
 
 class HipSquaredTrainer:
     """Maximum-likelihood training of a squared circuit with real parameters: ``loss = -mean_b (2 Re c(x_b) - Re Z)``
-    (the reference's loop for sum-of-squares circuits; c under complex-lse-sum, Z built from the plan of c)."""
+    (the reference's loop for sum-of-squares circuits; c under complex-lse-sum -- or a real circuit under lse-sum --, Z built
+    from the plan of c)."""
 
     def __init__(self, plan_c: Plan, tensors: Mapping[str, object], *, plan_z: Plan | None = None, device: str | torch.device = "cuda:0",
                  lr: float = 0.01, optimizer: str = "adam", betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8) -> None:
-        if plan_c.semiring != "complex-lse-sum":
-            raise NotImplementedError("HipSquaredTrainer trains circuits compiled under complex-lse-sum (HipTrainer: lse-sum)")
+        if plan_c.semiring not in ("complex-lse-sum", "lse-sum"):
+            raise NotImplementedError(f"HipSquaredTrainer: semiring {plan_c.semiring!r}")
         if optimizer not in ("adam", "sgd"):
             raise ValueError(f"unknown optimizer {optimizer!r}")
         if plan_z is None:
@@ -175,7 +205,10 @@ class HipSquaredTrainer:
             off += sz
         store.version += 1
         self.plan_c, self.plan_z, self.store = plan_c, plan_z, store
-        kw = dict(device=dev, use_graph=False, fuse=False, pad_units=False, signed_real=False)
+        # (every layer evaluates its own parameter graph -- no batched prologue --: `HipParameter.backward` differentiates what
+        #  `HipParameter.evaluate` left behind)
+        kw = dict(device=dev, use_graph=False, fuse=False, pad_units=False, signed_real=False, tiled_weights=False, dense_on_table=False,
+                  fused_weight_softmax=False, batch_params=False)
         self.c = HipCircuit(plan_c, store, **kw)
         self.z = HipCircuit(plan_z, store, **kw)
         self.device = self.c.device
@@ -185,7 +218,7 @@ class HipSquaredTrainer:
         for n, sz in zip(names, sizes):
             self.grads[n] = self._flat_grad[off : off + sz].view(plan_c.tensors[n][0])
             off += sz
-        self._bwd_c, self._bwd_z = _ComplexBackward(self.c, self.grads), _ComplexBackward(self.z, self.grads)
+        self._bwd_c, self._bwd_z = _PlanBackward(self.c, self.grads), _PlanBackward(self.z, self.grads)
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self._m1 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
         self._m2 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
@@ -204,8 +237,10 @@ class HipSquaredTrainer:
                 global_batch = B * dist.get_world_size()
             gB = float(global_batch or B)
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            yc = self.c(x)          # (B, 1, 1) complex64
+            yc = self.c(x)          # (B, 1, 1) complex64 / fp32
             yz = self.z()           # (1, 1, 1)
+            if not yc.is_complex():
+                yc, yz = torch.complex(yc, torch.zeros_like(yc)), torch.complex(yz, torch.zeros_like(yz))
             capi.call("ck_fill_f32", self._flat_grad.data_ptr(), self._flat_grad.numel(), 0.0, stream)
             self._bwd_c.run(B, -2.0 / gB, stream)
             self._bwd_z.run(1, B / gB, stream)

@@ -1,5 +1,5 @@
 """Plan-level training of a squared circuit (complex-lse-sum for c, Z from ConstantValue / Hadamard / TensorDot layers with
-pointer / conj / einsum / flatten parameter graphs): `cirkit_amd.training_complex.HipSquaredTrainer` against the gradients of
+pointer / conj / einsum / flatten parameter graphs): `cirkit_amd.training_squared.HipSquaredTrainer` against the gradients of
 the reference's own ``loss.backward()`` for ``loss = -mean(2 Re c(x) - Re Z)`` (tests/golden/sos_4x4_k4_grads.npz,
 make_fixtures.py `grads_sos`)."""
 import os
@@ -24,12 +24,12 @@ def _case():
     return plan_c, plan_z, init_plan_tensors(plan_c), ref
 
 
-def test_squared_trainer_refuses_real_plans():
-    from cirkit_amd.training_complex import HipSquaredTrainer
+def test_trainer_points_at_the_squared_trainer_for_complex_plans():
+    from cirkit_amd.training import HipTrainer
 
-    plan = Plan.load(os.path.join(GOLDEN, "cfg1_rbt8"))
-    with pytest.raises(NotImplementedError, match="complex-lse-sum"):
-        HipSquaredTrainer(plan, init_plan_tensors(plan), device="cpu")
+    plan_c, _, tensors, _ = _case()
+    with pytest.raises(NotImplementedError, match="HipSquaredTrainer"):
+        HipTrainer(plan_c, tensors, device="cpu")
 
 
 @pytest.mark.gpu
@@ -38,7 +38,7 @@ def test_squared_circuit_gradients_match_the_reference(hip_device, native_z):
     """Both circuits through the HIP forward, both reverse launch lists, the parameter graphs of Z in reverse mode: the
     loss and every parameter gradient of the reference's autograd.  native_z: Z built from the plan of c
     (cirkit_amd/functional.py) instead of the plan the reference compiled."""
-    from cirkit_amd.training_complex import HipSquaredTrainer
+    from cirkit_amd.training_squared import HipSquaredTrainer
 
     plan_c, plan_z, tensors, ref = _case()
     tr = HipSquaredTrainer(plan_c, tensors, plan_z=None if native_z else plan_z, device=hip_device)
@@ -55,7 +55,7 @@ def test_squared_circuit_gradients_match_the_reference(hip_device, native_z):
 
 @pytest.mark.gpu
 def test_squared_circuit_training_steps_increase_the_likelihood(hip_device):
-    from cirkit_amd.training_complex import HipSquaredTrainer
+    from cirkit_amd.training_squared import HipSquaredTrainer
 
     plan_c, _, tensors, ref = _case()
     tr = HipSquaredTrainer(plan_c, tensors, device=hip_device, lr=0.01)
@@ -70,7 +70,7 @@ def test_squared_circuit_training_steps_increase_the_likelihood(hip_device):
 def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_device):
     """BASELINE config 5 (QuadTree 28x28, Embedding-256, CP-T, K = 32; Z from its own plan): the gradients of 32 rows against
     torch autograd through the oracle's restatement of the reference forward (bit-identical to the reference on CPU)."""
-    from cirkit_amd.training_complex import HipSquaredTrainer
+    from cirkit_amd.training_squared import HipSquaredTrainer
     from oracle import torch_oracle as oracle  # (tests may: the oracle is the checker)
 
     plan_c, plan_z = Plan.load(os.path.join(GOLDEN, "cfg5_sos_c_k32")), Plan.load(os.path.join(GOLDEN, "cfg5_sos_z_k32"))
@@ -91,3 +91,26 @@ def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_d
         want = leaves[k].grad.numpy()
         err = float(np.abs(got[k] - want).max())
         assert err <= 2e-3 * max(1e-6, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+def test_real_squared_circuit_gradients_match_the_reference(hip_device):
+    """A REAL circuit squared (Categorical inputs, CP-T, lse-sum): loss = -mean(2 c(x) - Z), Z built natively from the plan of c
+    (ConstantValue layers over logs of Gram matrices of softmaxed rows, Hadamard, TensorDot) -- against the gradients of the
+    reference's own `loss.backward()` (make_fixtures.py grads_sq_categorical)."""
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    plan_c = Plan.load(os.path.join(GOLDEN, "sq_cat_qt4x4_k5"))
+    with np.load(os.path.join(GOLDEN, "sq_cat_qt4x4_k5_grads.npz")) as z:
+        ref = {k: z[k] for k in z.files}
+    tensors = init_plan_tensors(plan_c, seed=6)
+    tr = HipSquaredTrainer(plan_c, tensors, device=hip_device)
+    x = torch.from_numpy(ref["x"].astype(np.int64)).to(hip_device)
+    ll = tr.loss_and_grads(x).cpu().numpy()
+    loss = -ll[0] / ll[1]
+    assert abs(loss - float(ref["loss"])) <= 2e-5 * abs(float(ref["loss"])), (loss, float(ref["loss"]))
+    got = tr.gradients()
+    for k in tensors:
+        want = ref["g_" + k]
+        err = float(np.abs(got[k] - want).max())
+        assert err <= 1e-3 * max(1e-3, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
