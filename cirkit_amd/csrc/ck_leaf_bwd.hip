@@ -492,6 +492,9 @@ struct TableBwdArgs {
 // overwritten in place by its tile of gT; exp(T) of the last phase is recomputed from the logits; the dW contraction's two
 // operands share one 4 KB tile per wave.
 constexpr int kTbWaves = 8;
+// exp on v_exp_f32 (one multiply + the native exp2, as every forward kernel: ~5e-7 relative at |x| <= 10): the library expf is
+// ~25 instructions, and a lane evaluates 48 of them per fold here
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * kL2E); }
 __global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const TableBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tb_lds[];
   const int C = a.C, rows = C + 1, n_t = (rows + 31) >> 5;
@@ -526,20 +529,34 @@ __global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const Ta
     }
   }
   // T[c][i] = theta[i][c] - logsumexp_c theta[i][:]: 32 / kTbWaves units per wave, lanes over the categories
-  float lse_mine[32 / kTbWaves];
+  // (the logits of the wave's units are read ONCE, all loads in flight together, and stay in registers for the last phase:
+  //  three passes over a row and a fourth at the end were sixteen dependent trips to L2 per wave; C <= 256: four per lane and unit)
+  constexpr int kUnits = 32 / kTbWaves;
+  float lse_mine[kUnits];
+  float th[kUnits][4];
 #pragma unroll
-  for (int ii = 0; ii < 32 / kTbWaves; ++ii) {
+  for (int ii = 0; ii < kUnits; ++ii)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = lane + 64 * q;
+      th[ii][q] = c < C ? theta[(wave + ii * kTbWaves) * C + c] : -INFINITY;
+    }
+#pragma unroll
+  for (int ii = 0; ii < kUnits; ++ii) {
     const int i = wave + ii * kTbWaves;
-    const float* row = theta + i * C;
-    float m = -INFINITY;
-    for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+    float m = fmaxf(fmaxf(th[ii][0], th[ii][1]), fmaxf(th[ii][2], th[ii][3]));
     m = ck::wave_max(m);
     float sum = 0.f;
-    for (int c = lane; c < C; c += 64) sum += expf(row[c] - m);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum += fexp(th[ii][q] - m);  // (lanes beyond C: exp(-inf) = 0)
     sum = ck::wave_sum(sum);
     const float lse = m + logf(sum);
     lse_mine[ii] = lse;
-    for (int c = lane; c < n_t * 32; c += 64) t_s[tsw(c, i)] = c < C ? row[c] - lse : 0.f;  // (row C: the integral row; beyond: padding)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {  // (row C: the integral row; beyond: padding)
+      const int c = lane + 64 * q;
+      if (c < n_t * 32) t_s[tsw(c, i)] = (q < 4 && c < C) ? th[ii][q < 4 ? q : 0] - lse : 0.f;
+    }
   }
   __syncthreads();
   f32x16 dw;
@@ -576,7 +593,7 @@ __global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const Ta
     }
     const float m = row_max16(v);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) e[r] = live ? expf(v[r] - m) : 0.f;
+    for (int r = 0; r < 16; ++r) e[r] = live ? fexp(v[r] - m) : 0.f;
     WRegs w;
 #pragma unroll
     for (int q = 0; q < 4; ++q) w.q[q] = *reinterpret_cast<const float4*>(w_t + q * 256 + lane * 4);
@@ -614,15 +631,24 @@ __global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const Ta
   }
   // column sums of gT over the categories (row C has no gradient), then dtheta_c, coalesced along the categories
 #pragma unroll
-  for (int ii = 0; ii < 32 / kTbWaves; ++ii) {
+  for (int ii = 0; ii < kUnits; ++ii) {
     const int i = wave + ii * kTbWaves;
+    float gt[4];
     float sacc = 0.f;
-    for (int c = lane; c < C; c += 64) sacc += t_s[tsw(c, i)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = lane + 64 * q;
+      gt[q] = c < C ? t_s[tsw(c, i)] : 0.f;
+      sacc += gt[q];
+    }
     sacc = ck::wave_sum(sacc);
-    const float* row = theta + i * C;
     const float lse = lse_mine[ii];
     float* out = a.g_cat + f * 32 * C + i * C;
-    for (int c = lane; c < C; c += 64) out[c] = t_s[tsw(c, i)] - expf(row[c] - lse) * sacc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = lane + 64 * q;
+      if (c < C) out[c] = gt[q] - fexp(th[ii][q] - lse) * sacc;
+    }
   }
 }
 
@@ -685,6 +711,7 @@ int ck_table_dense_bwd(const float* cat_logits, const int64_t* cat_idx, const fl
                        float* g_dense, int F, int C, void* stream) {
   CK_REQUIRE(cat_logits && dense_logits && dtable && g_cat && g_dense, "ck_table_dense_bwd: null pointer");
   CK_REQUIRE(F > 0 && C > 0, "ck_table_dense_bwd: non-positive size");
+  if (C > 256) return ck::fail(CK_ERR_UNSUPPORTED, "ck_table_dense_bwd: C=%d (at most 256 categories: a lane keeps four logits per unit)", C);
   const int n_t = (C + 1 + 31) / 32;
   const size_t lds = (static_cast<size_t>(n_t + 3) * 1024 + kTbWaves * 1024) * sizeof(float);
   if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_table_dense_bwd: C=%d does not fit in LDS", C);

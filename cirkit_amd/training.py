@@ -175,8 +175,8 @@ class HipTrainer:
         cat = c.layers[g.input_layer]
         if g.depth not in (2, 4) or g.dense_layer is None or g.root not in c._table_fused or not c.linear_levels:
             return "the leaf region must be Categorical -> dense -> 2 or 4 CP-T levels with the table built by one prologue job"
-        if not isinstance(cat, HipCategoricalLayer) or cat.num_output_units != 32:
-            return "the leaf region needs a 32-unit Categorical input layer"
+        if not isinstance(cat, HipCategoricalLayer) or cat.num_output_units != 32 or cat.num_categories > 256:
+            return "the leaf region needs a 32-unit Categorical input layer of at most 256 categories"
         covered = set(g.virtual) | {g.root} | set(c._tail)
         if covered != set(range(len(c.layers))) or c._tdense or c._cp_blocks or c._regions or c._input_prod:
             return "layers outside the leaf region and the tail"
