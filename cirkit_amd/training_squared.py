@@ -76,7 +76,19 @@ class _PlanBackward:
         for i, l in enumerate(self.c.layers):
             off = (bd.views[i].data_ptr() - bd.arena.data_ptr()) // bd.arena.element_size()
             gviews.append(garena[off : off + l.num_folds * B * l.num_output_units].view(l.num_folds, B, l.num_output_units))
-        st = {"arena_ptr": bd.arena.data_ptr(), "garena": garena, "gviews": gviews}
+        # host copies of the child offsets (read once: a `.tolist()` per step would be a device synchronisation per layer), the
+        # offset tables in float units for the Hadamard launches, and the row tables of the TensorDot layers' permuted inputs
+        host_ro, ro2, td_rows = {}, {}, {}
+        for i, l in enumerate(self.c.layers):
+            if bd.row_off[i] is None:
+                continue
+            if isinstance(l, HipTensorDotLayer):
+                host_ro[i] = bd.row_off[i].reshape(-1).cpu().numpy()
+                n = B * l.num_input_units
+                td_rows[i] = (torch.arange(l.num_folds, dtype=torch.int64, device=garena.device) * n).reshape(l.num_folds, 1)
+            elif isinstance(l, HipHadamardLayer):
+                ro2[i] = (bd.row_off[i] * (2 if self.cplx else 1)).contiguous()
+        st = {"arena_ptr": bd.arena.data_ptr(), "garena": garena, "gviews": gviews, "host_ro": host_ro, "ro2": ro2, "td_rows": td_rows}
         while len(self._bound) >= 4:
             self._bound.pop(next(iter(self._bound)))
         self._bound[B] = st
@@ -112,8 +124,11 @@ class _PlanBackward:
             if isinstance(l, HipTensorDotLayer):
                 Kj, Kq = l._num_contract_units, l._num_batch_units
                 Kk = K // Kq
-                ro = bd.row_off[i].reshape(-1)  # (arity 1: one (B, Kj * Kq) block per fold)
-                x = torch.stack([bd.arena[int(o) : int(o) + B * Kj * Kq] for o in ro.tolist()]).view(F, B, Kj, Kq)
+                ro = st["host_ro"][i]  # (arity 1: one (B, Kj * Kq) block per fold)
+                n = B * Kj * Kq
+                packed = bool(np.array_equal(ro, ro[0] + n * np.arange(F)))  # the producer's folds in order: one slice of the arena
+                x = (bd.arena[int(ro[0]) : int(ro[0]) + F * n] if packed else
+                     torch.stack([bd.arena[int(o) : int(o) + n] for o in ro])).view(F, B, Kj, Kq)
                 # the layer IS a dense sum over the rows (b, q) of the permuted input (optimized.py:289-296)
                 xp = x.permute(0, 1, 3, 2).contiguous().view(F, B * Kq, Kj)
                 gx = torch.empty_like(xp)
@@ -121,11 +136,14 @@ class _PlanBackward:
                 if w.is_complex():
                     raise NotImplementedError("squared-circuit training: complex-valued weights")
                 dw = torch.zeros((F, Kk, Kj), dtype=torch.float32, device=w.device)
-                rows = (torch.arange(F, dtype=torch.int64, device=w.device) * (B * Kq * Kj)).reshape(F, 1)
+                rows = st["td_rows"][i]
                 sum_bwd(xp.data_ptr(), gx.data_ptr(), rows, w, bd.views[i].data_ptr(), g.data_ptr(), dw, F, 1, B * Kq, Kj, Kk, capi.CK_SUM_PROD)
-                gxp = gx.view(F, B, Kq, Kj).permute(0, 1, 3, 2).contiguous().view(F, B * Kj * Kq)
-                for f, o in enumerate(ro.tolist()):
-                    garena[int(o) : int(o) + B * Kj * Kq] = gxp[f]
+                gxp = gx.view(F, B, Kq, Kj).permute(0, 1, 3, 2).contiguous().view(F, n)
+                if packed:
+                    garena[int(ro[0]) : int(ro[0]) + F * n] = gxp.reshape(-1)
+                else:
+                    for f, o in enumerate(ro):
+                        garena[int(o) : int(o) + n] = gxp[f]
                 l.weight.backward(dw, self.grads, stream)
             elif isinstance(l, (HipSumLayer, HipCPTLayer, HipTuckerLayer)):
                 w = l._w
@@ -137,8 +155,7 @@ class _PlanBackward:
                 l.weight.backward(dw, self.grads, stream)
             elif isinstance(l, HipHadamardLayer):  # log space: the sum of the children -- (re, im) pairs as 2 K floats
                 e = 2 if cplx else 1
-                ro2 = (bd.row_off[i] * e).contiguous()
-                capi.call("ck_hadamard_bwd", ga, ro2.data_ptr(), g.data_ptr(), F, l.arity, B, e * K, 0, stream)
+                capi.call("ck_hadamard_bwd", ga, st["ro2"][i].data_ptr(), g.data_ptr(), F, l.arity, B, e * K, 0, stream)
             elif isinstance(l, HipCategoricalLayer):  # (lse-sum) the scatter-add into the log-table, then log softmax backward
                 Cn = l.num_categories
                 dtable = torch.zeros((F, Cn + 1, K), dtype=torch.float32, device=g.device)

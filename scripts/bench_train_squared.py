@@ -1,0 +1,18 @@
+import os,sys,time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from cirkit_amd.plan import Plan
+from cirkit_amd.initializers import init_plan_tensors
+from cirkit_amd.training_squared import HipSquaredTrainer
+G=os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"),"tests","golden")
+plan_c=Plan.load(os.path.join(G,"cfg5_sos_c_k32"))
+t=init_plan_tensors(plan_c); t={k:np.where(v==0,np.float32(1e-2),v).astype(np.float32) for k,v in t.items()}
+tr=HipSquaredTrainer(plan_c,t,device="cuda:0",lr=1e-3)
+for B in (256,4096):
+    x=torch.randint(0,256,(B,784)).cuda()
+    for _ in range(3): ll=tr.step(x)
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    n=10
+    for _ in range(n): ll=tr.step(x)
+    torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/n
+    print(f"squared-circuit training step (config 5 plans, B={B}): {dt*1e3:.2f} ms, mean LL {float(ll[0]/ll[1]):.3f}")
