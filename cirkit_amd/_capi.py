@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -193,6 +193,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_axpy_f32": [_p, _p, _f, _l, _p],
     "ck_param_binomial_table": [_p, _i, _p, _l, _i, _i, _p],
     "ck_param_gaussian_product_logz": [_p, _p, _p, _p, _p, _l, _i, _i, _p],
+    "ck_param_gaussian_product_logz_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p],
     "ck_segment_add_rows": [_p, _p, _p, _p, _p, _i, _l, _p],
     "ck_param_scatter_add_folds": [_p, _p, _p, _l, _l, _p],
     "ck_categorical_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],

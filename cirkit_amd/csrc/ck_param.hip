@@ -836,6 +836,44 @@ __global__ void __launch_bounds__(256) gaussian_product_logz_kernel(const float*
   }
 }
 
+// Backward of gaussian_product_logz_kernel: with v = s1_i^2 + s2_j^2, d = m1_i - m2_j and g = dout[f, i K2 + j],
+//   dm1_i = sum_j -g d / v      ds1_i = sum_j g s1_i (d^2 / v - 1) / v      (and the mirror image for operand 2; four distinct buffers).
+// One thread per (fold, unit) of either operand walks the other operand's units: no atomics, deterministic.
+__global__ void __launch_bounds__(256) gaussian_product_logz_bwd_kernel(const float* __restrict__ m1, const float* __restrict__ s1,
+                                                                        const float* __restrict__ m2, const float* __restrict__ s2,
+                                                                        const float* __restrict__ dout, float* __restrict__ dm1,
+                                                                        float* __restrict__ ds1, float* __restrict__ dm2,
+                                                                        float* __restrict__ ds2, int64_t F, int K1, int K2) {
+  const int64_t n = F * (K1 + K2);
+  for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < n;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t f = e / (K1 + K2);
+    const int u = static_cast<int>(e - f * (K1 + K2));
+    const bool first = u < K1;
+    const int i = first ? u : u - K1;
+    const float mu = first ? m1[f * K1 + i] : m2[f * K2 + i];
+    const float sd = first ? s1[f * K1 + i] : s2[f * K2 + i];
+    const int Ko = first ? K2 : K1;
+    float gm = 0.f, gs = 0.f;
+    for (int j = 0; j < Ko; ++j) {
+      const float om = first ? m2[f * K2 + j] : m1[f * K1 + j];
+      const float os = first ? s2[f * K2 + j] : s1[f * K1 + j];
+      const float g = first ? dout[(f * K1 + i) * K2 + j] : dout[(f * K1 + j) * K2 + i];
+      const float v = sd * sd + os * os, d = mu - om;  // (d: this unit minus the other -- the sign of dm flips with the operand, d^2 does not)
+      const float rv = 1.f / v;
+      gm -= g * d * rv;
+      gs += g * sd * (d * d * rv - 1.f) * rv;
+    }
+    if (first) {
+      dm1[f * K1 + i] = gm;
+      ds1[f * K1 + i] = gs;
+    } else {
+      dm2[f * K2 + i] = gm;
+      ds2[f * K2 + i] = gs;
+    }
+  }
+}
+
 // ---- log-likelihood sum ------------------------------------------------------------------------
 // Single workgroup: B is a batch (<= a few 10^5 rows), and a one-block tree gives a
 // run-to-run deterministic fp64 sum (no atomics).
@@ -1126,6 +1164,22 @@ int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, con
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(gaussian_product_logz_kernel, grid, block, 0, s, mean1, stddev1, mean2, stddev2, out, F, K1, K2);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_gaussian_product_logz_bwd(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
+                                       const float* dout, float* dmean1, float* dstddev1, float* dmean2, float* dstddev2, int64_t F,
+                                       int K1, int K2, void* stream) {
+  CK_REQUIRE(mean1 && stddev1 && mean2 && stddev2 && dout && dmean1 && dstddev1 && dmean2 && dstddev2,
+             "ck_param_gaussian_product_logz_bwd: null pointer");
+  CK_REQUIRE(F > 0 && K1 > 0 && K2 > 0, "ck_param_gaussian_product_logz_bwd: non-positive size");
+  dim3 grid(grid1d(F * (K1 + K2))), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(gaussian_product_logz_bwd_kernel, grid, block, 0, s, mean1, stddev1, mean2, stddev2, dout, dmean1, dstddev1,
+                           dmean2, dstddev2, F, K1, K2);
         return hipGetLastError();
       },
       stream);

@@ -558,6 +558,14 @@ class HipParameter:
                     spec = [out_idx, *[ins[m] for m in others], ins[k]]
                     dk = self._einsum(("ge", j, k), spec, [dj.contiguous(), *[xs[m] for m in others]], stream)
                     scatter((j, k), n.inputs[k], dk)
+            elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
+                m1, s1, m2, s2 = (operand(j, k).contiguous() for k in range(4))
+                F, K1, K2 = int(m1.shape[0]), int(m1.shape[1]), int(m2.shape[1])
+                ds = [self._buf(("gop", j, k), operand(j, k).shape) for k in range(4)]
+                capi.call("ck_param_gaussian_product_logz_bwd", _ptr(m1), _ptr(s1), _ptr(m2), _ptr(s2), _ptr(dj.contiguous()),
+                          _ptr(ds[0]), _ptr(ds[1]), _ptr(ds[2]), _ptr(ds[3]), F, K1, K2, stream)
+                for k in range(4):
+                    scatter((j, k), n.inputs[k], ds[k])
             else:
                 raise NotImplementedError(f"parameter backward through {n.op!r}")
 

@@ -29,8 +29,8 @@ import torch
 
 from . import _capi as capi
 from .circuit import HipCircuit
-from .layers import (HipCategoricalLayer, HipConstantValueLayer, HipCPTLayer, HipEmbeddingLayer, HipHadamardLayer, HipSumLayer,
-                     HipTensorDotLayer, HipTuckerLayer)
+from .layers import (HipCategoricalLayer, HipConstantValueLayer, HipCPTLayer, HipEmbeddingLayer, HipGaussianLayer, HipHadamardLayer,
+                     HipSumLayer, HipTensorDotLayer, HipTuckerLayer)
 from .parameters import TensorStore
 from .plan import Plan
 
@@ -63,6 +63,9 @@ class _PlanBackward:
             elif isinstance(l, HipCategoricalLayer):
                 if self.cplx or l.probs is None or l.probs.softmax_source() is None:
                     raise NotImplementedError("squared-circuit training: Categorical layers need lse-sum and probs = softmax(tensor)")
+            elif isinstance(l, HipGaussianLayer):
+                if self.cplx or l.log_partition is not None:
+                    raise NotImplementedError("squared-circuit training: Gaussian layers need lse-sum and no log-partition parameter")
             elif not isinstance(l, (HipEmbeddingLayer, HipConstantValueLayer, HipHadamardLayer, HipTensorDotLayer)):
                 raise NotImplementedError(f"squared-circuit training: layer type {spec.type!r}")
 
@@ -163,6 +166,13 @@ class _PlanBackward:
                           F, B, K, Cn, 1, None, stream)
                 name = l.probs.graph.nodes[0].config["tensor"]
                 capi.call("ck_param_log_table_bwd", l._table.data_ptr(), dtable.data_ptr(), self.grads[name].data_ptr(), F, K, Cn, 1, stream)
+            elif isinstance(l, HipGaussianLayer):  # (lse-sum) batch sums of d log N / d mean, d log N / d stddev
+                mean, stddev, _ = l._vals
+                dm, dsd = torch.empty_like(mean), torch.empty_like(stddev)
+                capi.call("ck_gaussian_bwd", g.data_ptr(), bd.xt.data_ptr(), l._scope(g.device).data_ptr(), mean.data_ptr(), stddev.data_ptr(),
+                          dm.data_ptr(), dsd.data_ptr(), F, B, K, stream)
+                l.mean.backward(dm, self.grads, stream)
+                l.stddev.backward(dsd, self.grads, stream)
             elif isinstance(l, HipEmbeddingLayer):
                 # out = log(w[f, :, x]): the scatter-add of Re(gout) over the batch, divided by w
                 Cn = l.num_states

@@ -466,6 +466,10 @@ int ck_param_binomial_table(const float* p, int is_logits, float* table, int64_t
  * of Gaussian unit i of (mean1, stddev1) and unit j of (mean2, stddev2); all inputs (F, K). */
 int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
                                    float* out, int64_t F, int K1, int K2, void* stream);
+/* Its backward: dout (F, K1 K2) -> the gradients of the four operands, WRITTEN (four distinct buffers, (F, K1) / (F, K2)). */
+int ck_param_gaussian_product_logz_bwd(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
+                                       const float* dout, float* dmean1, float* dstddev1, float* dmean2, float* dstddev2, int64_t F,
+                                       int K1, int K2, void* stream);
 /* entrywise ops (nodes.py:656-699); a, b only used by CK_UNARY_SCALED_SIGMOID (vmin, vmax). */
 int ck_param_unary(int op, const float* in, float* out, int64_t n, float a, float b, void* stream);
 /* out[f] = in[idx[f]] over blocks of `per_fold` 4-byte words (pointer fold_idx nodes.py:277-279,

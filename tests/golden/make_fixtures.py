@@ -492,6 +492,34 @@ def grads_sq_categorical():
         torch.set_grad_enabled(False)
 
 
+def grads_sq_gaussian():
+    """Round 4: the same for Gaussian inputs (the circuit of `sq_gaussian`): the constant layers of Z hold the closed-form log
+    integrals of products of two Gaussian units (nodes.py:975-988) over pointer / scaled-sigmoid graphs."""
+    torch.set_grad_enabled(True)
+    try:
+        sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", input_layer="gaussian", num_input_units=4,
+                                        sum_product_layer="cp", num_sum_units=4)
+        ctx = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True)
+        cc = ctx.compile(sc)
+        zc = ctx.compile(SF.integrate(SF.multiply(sc, sc)))
+        table = tensor_table()
+        plan_c, tensors = plan_from_torch_circuit(cc, table=table)
+        with torch.no_grad():
+            _load_closed_form(plan_c, tensors, seed=8)
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn((8, 16), generator=g)
+        loss = -(2.0 * cc(x) - zc()).mean()
+        loss.backward()
+        by_ptr = {p.data_ptr(): p for p in cc.parameters()}
+        extra = {"x": x.numpy(), "loss": np.array(loss.item())}
+        for k, t in tensors.items():
+            extra["g_" + k] = by_ptr[t.data_ptr()].grad.numpy()
+        np.savez_compressed(os.path.join(HERE, "sq_gauss_qt4x4_k4_grads.npz"), **extra)
+        print("sq_gauss grads: loss", loss.item(), {k: float(np.linalg.norm(v)) for k, v in extra.items() if k.startswith("g_")})
+    finally:
+        torch.set_grad_enabled(False)
+
+
 def marginals():
     """Marginal queries through the reference's IntegrateQuery (cirkit/backend/torch/queries.py):
     the KAT circuits (reference ground truth: mar (1,0,1,1,.) = 16.845, Z = 318; mar (0.3,.) =
@@ -673,6 +701,6 @@ def chow_liu():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "grads_tucker", "grads_param_nodes", "grads_sos", "grads_sq_categorical", "marginals", "templates_extra"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "grads_tucker", "grads_param_nodes", "grads_sos", "grads_sq_categorical", "grads_sq_gaussian", "marginals", "templates_extra"]
     for w in which:
         globals()[w]()

@@ -114,3 +114,26 @@ def test_real_squared_circuit_gradients_match_the_reference(hip_device):
         want = ref["g_" + k]
         err = float(np.abs(got[k] - want).max())
         assert err <= 1e-3 * max(1e-3, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+def test_real_squared_gaussian_circuit_gradients_match_the_reference(hip_device):
+    """Gaussian inputs, dense + CP-T layers under lse-sum, squared: the constant layers of the natively built Z hold closed-form
+    log integrals of products of Gaussian units (`ck_param_gaussian_product_logz` and its backward) over pointer /
+    scaled-sigmoid graphs -- against the reference's `loss.backward()` (make_fixtures.py grads_sq_gaussian)."""
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    plan_c = Plan.load(os.path.join(GOLDEN, "sq_gauss_qt4x4_k4"))
+    with np.load(os.path.join(GOLDEN, "sq_gauss_qt4x4_k4_grads.npz")) as z:
+        ref = {k: z[k] for k in z.files}
+    tensors = init_plan_tensors(plan_c, seed=8)
+    tr = HipSquaredTrainer(plan_c, tensors, device=hip_device)
+    x = torch.from_numpy(ref["x"].astype(np.float32)).to(hip_device)
+    ll = tr.loss_and_grads(x).cpu().numpy()
+    loss = -ll[0] / ll[1]
+    assert abs(loss - float(ref["loss"])) <= 2e-5 * max(1.0, abs(float(ref["loss"]))), (loss, float(ref["loss"]))
+    got = tr.gradients()
+    for k in tensors:
+        want = ref["g_" + k]
+        err = float(np.abs(got[k] - want).max())
+        assert err <= 1e-3 * max(1e-3, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
