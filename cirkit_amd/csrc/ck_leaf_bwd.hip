@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
 #endif
   for (int seg = blockIdx.x; seg < a.n_seg; seg += gridDim.x) {
     const int p = a.work[4 * seg], tile_begin = a.work[4 * seg + 1], tile_end = a.work[4 * seg + 2];
+    if (tile_begin >= tile_end) continue;  // (an empty second segment of fusion.balanced_segments' flat schedule; uniform)
     const int32_t* ut = a.unit_tab + static_cast<int64_t>(p) * kUnitTab;
     const int gin_fold = ut[0], p_fold = ut[1], q_fold[2] = {ut[2], ut[3]};
     const int c_fold[4] = {ut[4], ut[5], ut[6], ut[7]};

@@ -415,6 +415,30 @@ def balanced_segments(num_roots: int, num_tiles: int, num_wg: int, waves: int = 
         return float(cost.max()), segs
 
     best = min((schedule(k) for k in range(1, max(1, min(max_pieces, rounds)) + 1)), key=lambda t: t[0])
+    # ... or the flat list of (root, wave round) units cut into num_wg contiguous, equally long stretches: a stretch crosses at
+    # most one root boundary when a root has at least as many rounds as a stretch, i.e. a workgroup takes at most two segments
+    # (its second one may be empty: first tile = end tile).  196 roots x 16 rounds on 256 workgroups of 8 waves: 13 rounds + two
+    # overheads = 16 against 17.5 for whole roots on 196 of the 256 workgroups.
+    total = num_roots * rounds
+    if total >= num_wg and rounds * num_wg >= total:
+        first = np.zeros((num_wg, 4), dtype=np.int32)
+        second = np.zeros((num_wg, 4), dtype=np.int32)
+        worst = 0.0
+        for g in range(num_wg):
+            u0, u1 = g * total // num_wg, (g + 1) * total // num_wg
+            r0, r1 = u0 // rounds, (u1 - 1) // rounds
+            a0 = (u0 - r0 * rounds) * waves
+            if r0 == r1:
+                first[g] = (r0, a0, min((u1 - r0 * rounds) * waves, num_tiles), 0)
+                second[g] = (r0, 0, 0, 0)
+                cost = (u1 - u0) + overhead
+            else:  # (r1 == r0 + 1: a stretch is no longer than a root)
+                first[g] = (r0, a0, num_tiles, 0)
+                second[g] = (r1, 0, min((u1 - r1 * rounds) * waves, num_tiles), 0)
+                cost = (u1 - u0) + 2 * overhead
+            worst = max(worst, cost)
+        if worst < best[0]:
+            return np.ascontiguousarray(np.concatenate([first, second]))  # (neighbouring workgroups share roots: dealt as they are)
     segs = np.asarray([[r, a, b, 0] for _, r, a, b in best[1]], dtype=np.int32).reshape(-1, 4)
     if xcd_aware and num_wg % 8 == 0 and len(segs) >= num_wg:
         # workgroup g runs on XCD g % 8: within every dealing round hand position s to workgroup 8 (s % (num_wg / 8)) +
