@@ -11,6 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
+from cirkit_amd import _capi  # noqa: E402
+
+if os.environ.get("CK_LIB"):  # a lab build of the library (scripts/bwd_stamps.py leaves one and prints its path)
+    _capi._LIB_PATH = os.environ["CK_LIB"]
 from cirkit_amd.initializers import init_plan_tensors  # noqa: E402
 from cirkit_amd.templates import image_data  # noqa: E402
 from cirkit_amd.training import HipTrainer  # noqa: E402

@@ -30,6 +30,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from cirkit_amd import _capi  # noqa: E402
 
+print("lab library:", lib)  # (CK_LIB=<this> python scripts/bench_train.py ... runs the timing experiments of scripts/exp_leaf_bwd.sh)
+
 _capi._LIB_PATH = lib
 from cirkit_amd.initializers import init_plan_tensors  # noqa: E402
 from cirkit_amd.templates import image_data  # noqa: E402

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing experiments on the fused backward launches (wrong results on purpose): CK_BWD_EXP bits -- 1 no dW contraction,
 # 2 no W^T contraction, 4 every tile reads rows 0..31 (cache hits), 8 no gradient-tile stores; CK_BWD_WAVES 4 / 8.
-# Needs the lab build (python scripts/bwd_stamps.py builds it; CK_LIB points bench_train at it).
+# Needs the lab build: python scripts/bwd_stamps.py builds it and prints its path; export CK_LIB=<that path> first.
 # Prints the two launch times (bottom = leaf_bwd_kernel<true, .>, top = <false, .>).
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for w in 4 8; do for e in ${EXPS:-0 3 4 8 15}; do
