@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256)
     const float m = row_max16(v);
     float e[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) e[j] = live ? expf(v[j] - m) : 0.f;  // accurate exp: softmax gradients cancel
+    for (int j = 0; j < 16; ++j) e[j] = live ? __builtin_amdgcn_exp2f((v[j] - m) * kL2E) : 0.f;  // (v_exp_f32, as the forward: ~5e-7 relative)
     // y = W e
     f32x16 acc;
 #pragma unroll
@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256)
       float go[16];
       tile_load(gout + (static_cast<int64_t>(f) * B + bl) * kK + 4 * kh, go);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gy[r] = (live && acc[r] > 0.f && go[r] != 0.f) ? go[r] / acc[r] : 0.f;
+      for (int r = 0; r < 16; ++r) gy[r] = (live && acc[r] > 0.f && go[r] != 0.f) ? go[r] * __builtin_amdgcn_rcpf(acc[r]) : 0.f;
     }
     // gv = e * (W^T gy)
 #pragma unroll
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) e[q][j] = live ? expf(e[q][j] - m) : 0.f;  // accurate exp: softmax gradients cancel
+      for (int j = 0; j < 16; ++j) e[q][j] = live ? __builtin_amdgcn_exp2f((e[q][j] - m) * kL2E) : 0.f;  // (v_exp_f32, as the forward)
     // y = W e, gy = gout / y
     float gy[2][16];
 #pragma unroll
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256)
       float go[16];
       tile_load(gout + (static_cast<int64_t>(f) * B + bl) * K + 32 * p + 4 * kh, go);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gy[p][r] = (live && acc[r] > 0.f && go[r] != 0.f) ? go[r] / acc[r] : 0.f;
+      for (int r = 0; r < 16; ++r) gy[p][r] = (live && acc[r] > 0.f && go[r] != 0.f) ? go[r] * __builtin_amdgcn_rcpf(acc[r]) : 0.f;
     }
     // gv = e * (W^T gy)
 #pragma unroll
