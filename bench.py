@@ -106,14 +106,33 @@ def other_configs(device, stream, B: int) -> dict:
     # CUDA GPU.  Different hardware and not the north-star metric, so it stays out of `vs_baseline`.
     plan_nb = image_data((1, 28, 28), "quad-graph", input_layer="categorical", num_input_units=64,
                          sum_product_layer="tucker", num_sum_units=64)
-    hc = HipCircuit(plan_nb, init_plan_tensors(plan_nb), device=device)
-    ms = time_forward(hc, torch.randint(0, 256, (128, 784), generator=g).to(device))
+    t_nb = init_plan_tensors(plan_nb)
+    x_nb = torch.randint(0, 256, (128, 784), generator=g).to(device)
+    hc = HipCircuit(plan_nb, t_nb, device=device)
+    ms = time_forward(hc, x_nb)
+    y_exact = hc(x_nb).double().cpu()
     out["notebook_quadgraph_tucker_k64_b128"] = {
         "workload": "QuadGraph 28x28, Categorical-256, Tucker, K=64, batch 128 (the reference's compilation-options "
                     "notebook); Tucker layers on MFMA (cirkit_amd/csrc/ck_gemm.hip)",
         "ms_per_forward": ms, "evals_per_s": 128 / ms * 1e3,
         "reference_published_ms": 38.6, "reference_hardware": "unnamed CUDA GPU (notebook output)",
+        "variants": {},
     }
+    del hc
+    # Labelled variants, never `ms_per_forward`: the stream-K Tucker launch on the bf16 matrix instructions (the staged weights
+    # and e_r cut into 2 / 3 bf16 pieces, 3 / 6 products per 16 right indices, fp32 accumulation: ck_tucker_fwd).
+    for cname in ("bf16x3", "bf16x6"):
+        hv = HipCircuit(plan_nb, t_nb, device=device, contraction=cname)
+        ms_v = time_forward(hv, x_nb)
+        y_v = hv(x_nb).double().cpu()
+        out["notebook_quadgraph_tucker_k64_b128"]["variants"][f"contraction={cname}"] = {
+            "ms_per_forward": ms_v, "evals_per_s": 128 / ms_v * 1e3,
+            "max_rel_diff_to_exact_fp32": float(((y_v - y_exact).abs() / y_exact.abs()).max()),
+            "what": ("Tucker contractions on v_mfma_f32_32x32x16_bf16: operands split by truncation into "
+                     + ("2 bf16 pieces, 3 products (~2^-15 per product)" if cname == "bf16x3" else "3 bf16 pieces, 6 products (fp32-like)")
+                     + "; everything else exact fp32"),
+        }
+        del hv
     return out
 
 

@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -151,6 +151,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_constant_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_sum_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_tucker_logits_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_tucker_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_debug_force_generic": [_i],
     "ck_sum_lse_fwd_c": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_sum_clse_gather_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -88,8 +88,10 @@ class HipCircuit:
             product, what every reported number uses.  ``"bf16x3"`` / ``"bf16x6"``: labelled VARIANTS of the depth-4 persistent
             leaf launch: every fp32 operand cut into two / three bf16 pieces (truncation, exact residuals; bf16 keeps fp32's
             exponent range), 3 / 6 products per contraction on the bf16 matrix pipe with fp32 accumulation -- ~2^-15 per
-            product, resp. fp32-like (tests/test_gpu_parity.py measures both against the fp64 goldens).  The tail, the
-            parameter jobs and every other launch stay exact fp32.
+            product, resp. fp32-like (tests/test_gpu_parity.py measures both against the fp64 goldens) -- and of the stream-K
+            launch of Tucker layers with 32 / 64 units (`ck_tucker_fwd`: the weights are cut into pieces while they are
+            staged, behind the online softmax's exponential).  The tail, the parameter jobs and every other launch stay
+            exact fp32.
         dense_on_table: a Categorical input layer followed fold-by-fold by a dense sum layer only
             takes C distinct values per fold, so the dense layer is applied once per forward to the
             (F, C, K) log-probability table (same kernel, batch = C) instead of to every batch row;
@@ -230,6 +232,7 @@ class HipCircuit:
         for l in self.layers:  # Tucker weights softmax(theta): the launch reads the logits (ck_tucker_logits_fwd)
             if hasattr(l, "_logits_ok"):
                 l._logits_ok = bool(fused_weight_softmax)
+                l._contraction = {"f32": 0, "bf16x3": 3, "bf16x6": 6}[contraction]
         self._folds = [l.num_folds for l in self.layers]
         self._complex = plan.semiring == "complex-lse-sum"
         self._act_dtype = torch.complex64 if self._complex else torch.float32

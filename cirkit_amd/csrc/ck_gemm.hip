@@ -504,6 +504,12 @@ __device__ __forceinline__ float oct_sum(float v) {
   return v + __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true));
 }
 
+#ifndef CK_TUCKER_LABBITS
+#define CK_TUCKER_LABBITS 0
+#endif
+// lab builds (scripts/exp_tucker_bf16.sh; wrong results on purpose): 1 = every chunk read from the same 32 KiB, 2 = no LDS stores
+// of the staged chunk, 4 = no LDS reads of the A operand, 8 = no MFMAs, 16 = no exponentials, 32 = no cut into pieces, 64 = no barrier
+constexpr int kLab = CK_TUCKER_LABBITS;
 struct StreamKArgs {
   const float* arena;
   const int64_t* row_off;
@@ -522,15 +528,26 @@ struct StreamKArgs {
 // first), keeps sum exp(theta - m) beside the accumulators and subtracts log(sum) once per output; partial tiles carry
 // (m, sum) per weight row into the combine.  The logits are read ONCE per forward and no normalised copy or normaliser
 // ever exists in memory.
-template <int NK, bool LOGITS>
-__global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArgs a) {  // three workgroups per CU
+//
+// CT: 0 = the contraction in exact fp32 (the product); 3 / 6 = the labelled bf16-split VARIANTS ("bf16x3" / "bf16x6", ck_tile.h
+// contract_bf16): a chunk's weights are cut by truncation into P = 2 / 3 bf16 pieces while they are staged (after the online
+// softmax's exponential), e_r once per tile, and the chain over j runs as 3 / 6 products per 16 right indices on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  A chunk in LDS is [piece][block of 16 right indices][slot] x 8 bf16: what
+// lane o + 32 kh of the A operand reads with one ds_read_b128, slot = lane ^ 8 kh so that the 8-byte stores of a staging wave
+// (8 rows x 8 float4 columns) fall on every bank twice, the minimum.
+// DEPTH: weight chunks a thread has requested ahead of the one being staged (registers; the exact launch is bound by its
+// instruction stream and keeps one, the variants are bound by the memory's latency: with D chunks of 8 KiB in flight per
+// workgroup the launch moves (workgroups x D x 8 KiB) / latency).  OCC: workgroups per CU the registers are budgeted for.
+template <int NK, bool LOGITS, int CT = 0, int DEPTH = 1, int OCC = 3>
+__global__ void __launch_bounds__(256, OCC) tucker_streamk_kernel(const StreamKArgs a) {
   constexpr int Ki = 32 * NK;
   constexpr int N = Ki * Ki;
+  constexpr int P = CT == 0 ? 1 : CT / 3 + 1;
   // floats of one chunk: 32 outputs x Ki right indices as [c4][o_local ^ 8 (c4 & 1)] float4s -- the operand layout with
   // the rows of odd float4 columns swizzled, so that the 64 float4s a wave stages per instruction (8 rows x 8 columns)
   // fall on 16 bank groups x 4, the minimum
-  constexpr int CHUNK = NK * 1024;
-  constexpr int PF = CHUNK / 4 / 256;
+  constexpr int CHUNK = CT == 0 ? NK * 1024 : P * NK * 512;
+  constexpr int PF = NK;  // float4s of a chunk per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* w_s = smem;               // [2][CHUNK]
   float* el_s = smem + 2 * CHUNK;  // [4 waves][Ki][32]
@@ -550,7 +567,7 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
   };
   const int64_t c0 = start_of(g), c1 = start_of(g + 1);
   const int64_t first_tile = c0 / Ki;
-  float4 pre[PF];
+  float4 pre[DEPTH][PF];
 
   for (int64_t c = c0; c < c1;) {
     const int64_t tile = c / Ki;
@@ -569,19 +586,24 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
     // c4 = lane % 8 + 8 k: 8 lanes read 128 contiguous bytes; the operand layout in LDS is [c4][o_local] float4s
     const int o_local = wave * 8 + (lane >> 3);
     const bool o_live = o_base + o_local < a.Ko;
-    auto fetch = [&](int i) {
+    auto fetch = [&](int i, auto slot) {
+      constexpr int sl = decltype(slot)::value;
       const float fill = LOGITS ? -INFINITY : 0.f;  // (an absent row: weight 0 whatever the running maximum is)
 #pragma unroll
       for (int k = 0; k < PF; ++k)
-        pre[k] = o_live ? *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o_base + o_local) * N + i * Ki + 4 * ((lane & 7) + 8 * k))
+        if constexpr (DEPTH > 1)  // (never around a branch: a row past Ko reads the last row -- its outputs are not stored)
+          pre[sl][k] = *reinterpret_cast<const float4*>(((kLab & 1) ? a.w : wf) + static_cast<int64_t>((kLab & 1) ? o_local % a.Ko : min(o_base + o_local, a.Ko - 1)) * N + ((kLab & 1) ? (i & 3) : i) * Ki + 4 * ((lane & 7) + 8 * k));
+        else
+        pre[sl][k] = o_live ? *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(o_base + o_local) * N + i * Ki + 4 * ((lane & 7) + 8 * k))
                         : make_float4(fill, fill, fill, fill);
     };
     float mrun = 0.f, srun = 0.f;  // LOGITS: running maximum (log2 units) of the row, this lane's share of sum exp2(t - mrun)
-    auto commit = [&](int i, int buf) {
+    auto commit = [&](int i, int buf, auto slot) {
+      constexpr int sl = decltype(slot)::value;
       float* dst = w_s + buf * CHUNK;
       float4 v[PF];
 #pragma unroll
-      for (int k = 0; k < PF; ++k) v[k] = pre[k];
+      for (int k = 0; k < PF; ++k) v[k] = pre[sl][k];
       if constexpr (LOGITS) {
         // The row maximum of a chunk is only computed when it is needed: on the first chunk of a tile part, and when the
         // exponentials against the running maximum come out larger than 2^24 for some lane (then the maximum is raised and
@@ -611,7 +633,11 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
             part += (e[k].x + e[k].y) + (e[k].z + e[k].w);
           }
         };
-        exps();
+        if (!(kLab & 16)) exps(); else {
+#pragma unroll
+          for (int k = 0; k < PF; ++k) e[k] = v[k];
+          part = 1.f;
+        }
         if (__any(!(part <= 134217728.f))) {  // 2^27 = 8 values of 2^24 (or a NaN): rare, uniform over the wave
           const float cm = row_max();
           if (cm > mrun) {
@@ -629,11 +655,46 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
         const bool any_raised = __any(raised);
         if (lane == 0) flag_s[buf * 4 + wave] = any_raised ? 1u : 0u;
       }
+      if constexpr (CT == 0) {
 #pragma unroll
-      for (int k = 0; k < PF; ++k)
-        *reinterpret_cast<float4*>(dst + (((lane & 7) + 8 * k) * 32 + (o_local ^ ((lane & 1) * 8))) * 4) = v[k];
+        for (int k = 0; k < PF; ++k)
+          *reinterpret_cast<float4*>(dst + (((lane & 7) + 8 * k) * 32 + (o_local ^ ((lane & 1) * 8))) * 4) = v[k];
+      } else {
+        // float4 column c4 = lane % 8 + 8 k holds right indices 32 q + 16 m + 8 s + 4 kh + t, t = 0..3 (q = k, m, s, kh = bits 2, 1, 0
+        // of lane % 8): dwords 2 s, 2 s + 1 of slot (o_local + 32 kh) ^ 8 kh of block 2 q + m, once per piece
+        const int kh_w = lane & 1, s_w = (lane >> 1) & 1, m_w = (lane >> 2) & 1;
+        const int slot = (o_local ^ (8 * kh_w)) + 32 * kh_w;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+          float r[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            uint2 d;
+            if (kLab & 32) { d.x = __float_as_uint(r[0]); d.y = __float_as_uint(r[2]); } else {
+            d.x = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
+            d.y = __builtin_amdgcn_perm(__float_as_uint(r[3]), __float_as_uint(r[2]), 0x07060302u);
+            }
+            if (!(kLab & 2)) *reinterpret_cast<uint2*>(dst + ((p * 2 * NK + 2 * k + m_w) * 64 + slot) * 4 + 2 * s_w) = d;
+            if (p + 1 < P && !(kLab & 32)) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) r[t] -= __uint_as_float(__float_as_uint(r[t]) & 0xffff0000u);  // exact
+            }
+          }
+        }
+      }
     };
-    fetch(i_begin);
+    // chunk c of this tile part travels in ring slot (c - i_begin) % DEPTH.  With DEPTH > 1 every step requests exactly one chunk
+    // (past the end: the last one again) -- a number of requests in flight that depends on the path makes the compiler wait for
+    // all of them (vmcnt(0)) where it only needs the oldest
+    auto request = [&](int c, auto slot) {
+      if constexpr (DEPTH == 1) {
+        if (c < i_end) fetch(c, slot);
+      } else {
+        fetch(min(c, i_end - 1), slot);
+      }
+    };
+    fetch(i_begin, std::integral_constant<int, 0>{});
+    static_for<1, DEPTH>([&](auto d) { request(i_begin + decltype(d)::value, d); });
     // exponentiated children of (fold f, this wave's 32 rows): e_r as a register tile, e_l through LDS
     float er[NK][16];
     float m = 0.f;
@@ -666,13 +727,31 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
         }
       m = ml + mr;
     }
+    u32x4v erp[P][2 * NK];  // CT != 0: the B operands, piece p of e_r's registers 8 m .. 8 m + 7 of quarter q at [p][2 q + m]
+    if constexpr (CT != 0) {
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+              erp[p][2 * q + mh][d] = __builtin_amdgcn_perm(__float_as_uint(er[q][8 * mh + 2 * d + 1]), __float_as_uint(er[q][8 * mh + 2 * d]), 0x07060302u);
+          if (p + 1 < P) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) er[q][j] -= __uint_as_float(__float_as_uint(er[q][j]) & 0xffff0000u);  // exact
+          }
+        }
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* el_w = el_s + wave * (Ki * 32) + b_in;
-    auto stage_ahead = [&](int i) {  // after the barrier of chunk i: chunk i + 1 into the other buffer, chunk i + 2 requested
-      if (i + 1 < i_end) commit(i + 1, (i + 1 - i_begin) & 1);
-      if (i + 2 < i_end) fetch(i + 2);
+    // after the barrier of chunk i: chunk i + 1 (ring slot `slot`) into the other buffer, chunk i + 1 + DEPTH requested
+    auto stage_ahead = [&](int i, auto slot) {
+      if (i + 1 < i_end) commit(i + 1, (i + 1 - i_begin) & 1, slot);
+      request(i + 1 + DEPTH, slot);
     };
     auto contract = [&](int i) {  // chunk i against the outer-product row e_l[i] * e_r[.]
       const float* wb = w_s + ((i - i_begin) & 1) * CHUNK;
@@ -694,6 +773,36 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
       // accumulators with ONE multiply-add per output (16 per chunk instead of the 32 products e_l[i] * e_r[j])
       const float eli = el_w[i * 32];
       f32x16 part;
+      if constexpr (CT != 0) {
+        const u32x4v* wp = reinterpret_cast<const u32x4v*>(wb) + (lane ^ (8 * kh));
+        bool first = true;
+        auto mm = [&](u32x4v x, u32x4v y) {
+          if (first) {
+            f32x16 zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, x), __builtin_bit_cast(bf16x8v, y), zero, 0, 0, 0);
+            first = false;
+          } else {
+            part = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, x), __builtin_bit_cast(bf16x8v, y), part, 0, 0, 0);
+          }
+        };
+#pragma unroll
+        for (int blk = 0; blk < 2 * NK; ++blk) {
+          u32x4v w[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) w[p] = (kLab & 4) ? erp[p][blk] : wp[(p * 2 * NK + blk) * 64];
+          if (kLab & 8) { part[blk] = __uint_as_float(w[0][0] ^ w[P - 1][1]); continue; }
+          if constexpr (P == 3) {  // (smallest terms first)
+            mm(w[2], erp[0][blk]);
+            mm(w[1], erp[1][blk]);
+            mm(w[0], erp[2][blk]);
+          }
+          mm(w[1], erp[0][blk]);
+          mm(w[0], erp[1][blk]);
+          mm(w[0], erp[0][blk]);
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < NK; ++q)
 #pragma unroll
@@ -711,15 +820,37 @@ __global__ void __launch_bounds__(256, 3) tucker_streamk_kernel(const StreamKArg
           part = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, er[q][4 * gq + 2], part, 0, 0, 0);
           part = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, er[q][4 * gq + 3], part, 0, 0, 0);
         }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = fmaf(part[r], eli, acc[r]);
     };
-    commit(i_begin, 0);
-    if (i_begin + 1 < i_end) fetch(i_begin + 1);
-    for (int i = i_begin; i < i_end; ++i) {
-      __syncthreads();  // chunk i (and, the first time, e_l) is in LDS; every wave has left chunk i - 1
-      stage_ahead(i);
-      contract(i);
+    commit(i_begin, 0, std::integral_constant<int, 0>{});
+    request(i_begin + DEPTH, std::integral_constant<int, 0>{});
+    if constexpr (DEPTH == 1) {
+      for (int i = i_begin; i < i_end; ++i) {
+        __syncthreads();  // chunk i (and, the first time, e_l) is in LDS; every wave has left chunk i - 1
+        stage_ahead(i, std::integral_constant<int, 0>{});
+        contract(i);
+      }
+    } else {
+      // whole turns of the ring without a branch around a request, then the rest of the part (nothing left to request)
+      int i = i_begin;
+      for (; i + DEPTH <= i_end; i += DEPTH) {
+        static_for<0, DEPTH>([&](auto d) {
+          const int ii = i + decltype(d)::value;
+          if (!(kLab & 64)) __syncthreads();
+          stage_ahead(ii, std::integral_constant<int, (decltype(d)::value + 1) % DEPTH>{});
+          contract(ii);
+        });
+      }
+      static_for<0, DEPTH - 1>([&](auto d) {
+        const int ii = i + decltype(d)::value;
+        if (ii < i_end) {
+          __syncthreads();
+          if (ii + 1 < i_end) commit(ii + 1, (ii + 1 - i_begin) & 1, std::integral_constant<int, decltype(d)::value + 1>{});
+          contract(ii);
+        }
+      });
     }
     float* dst = a.out + (static_cast<int64_t>(f) * a.B + bl) * a.Ko;
     const int o0 = o_base + 4 * kh;
@@ -869,7 +1000,7 @@ bool tucker_applies(int H, int Ki, int Ko, int mode) { return mode == CK_SUM_KRO
 
 // Tucker layer of arity 2 with 32 or 64 units per child.
 int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int B, int Ki, int Ko,
-               void* stream, bool logits) {
+               void* stream, bool logits, int contraction) {
   const int tiles = (B + 31) / 32, nblocks = (Ko + 31) / 32;
   // Many workgroups: two blocks of outputs share every e_l * e_r product.  Fewer: one block per workgroup, so that a
   // fold's work is spread over Ko / 32 workgroups.  Fewer than the chip has CUs: the waves of a workgroup split the
@@ -879,12 +1010,14 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
   // if the caller lent a workspace for the partial tiles
   {
     const int slots = ck::num_cus() * 3;  // 48 KiB of LDS per workgroup
+    // (the bf16 variants: two workgroups per CU with four chunks each in flight)
+    const int resident = ck::num_cus() * (contraction != 0 ? 2 : 3);
     const ck::Workspace ws = ck::workspace();
     const int rgroups = (tiles + 3) / 4;
     const int64_t total = wg1 * Ki;
     // (at least 8 chunks per workgroup: each pays the exponentials of its tile's children once; measured 4 / 8 / 16 / 32:
     // 22 / 22 / 30 / 48 us for the layers of 2..12 folds, no difference for the large ones)
-    const int64_t G = std::max<int64_t>(1, std::min<int64_t>(total / 8, slots));
+    const int64_t G = std::max<int64_t>(1, std::min<int64_t>(total / 8, resident));
     // workspace layout (the same for every launch that shares it):
     // [slots x 2 partial tiles of 16 KiB][slots x 2 x (32 maxima, 32 sums)][ticket per tile]
     const int64_t slot_bytes = static_cast<int64_t>(slots) * 2 * 4 * 1024 * static_cast<int64_t>(sizeof(float));
@@ -915,13 +1048,25 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
               return hipGetLastError();
             };
             constexpr size_t extra = 2 * 32 + 2 * 4 + 2 * 32;  // (alpha_s, flag_s, stat_s)
-            const size_t lds = ((Ki == 32 ? 2 * 1024 + 4 * 32 * 32 : 2 * 2048 + 4 * 64 * 32) + extra) * sizeof(float);
+            const int nk = Ki / 32, chunk = contraction == 0 ? nk * 1024 : (contraction / 3 + 1) * nk * 512;
+            const size_t lds = (2 * chunk + 4 * Ki * 32 + extra) * sizeof(float);
+            if (contraction == 3) {
+              if (logits) return Ki == 32 ? go(tucker_streamk_kernel<1, true, 3, 4, 2>, lds) : go(tucker_streamk_kernel<2, true, 3, 4, 2>, lds);
+              return Ki == 32 ? go(tucker_streamk_kernel<1, false, 3, 4, 2>, lds) : go(tucker_streamk_kernel<2, false, 3, 4, 2>, lds);
+            }
+            if (contraction == 6) {
+              if (logits) return Ki == 32 ? go(tucker_streamk_kernel<1, true, 6, 4, 2>, lds) : go(tucker_streamk_kernel<2, true, 6, 4, 2>, lds);
+              return Ki == 32 ? go(tucker_streamk_kernel<1, false, 6, 4, 2>, lds) : go(tucker_streamk_kernel<2, false, 6, 4, 2>, lds);
+            }
             if (logits) return Ki == 32 ? go(tucker_streamk_kernel<1, true>, lds) : go(tucker_streamk_kernel<2, true>, lds);
             return Ki == 32 ? go(tucker_streamk_kernel<1, false>, lds) : go(tucker_streamk_kernel<2, false>, lds);
           },
           stream);
     }
   }
+  if (contraction != 0)
+    return ck::fail(CK_ERR_UNSUPPORTED, "Tucker launch, contraction variant %d: %lld tiles need the stream-K launch (a workspace and at most %d tiles)",
+                    contraction, static_cast<long long>(wg1), 8 * ck::num_cus() * 3);
   if (logits)  // (one workgroup per tile would apply the exponential once per 128 rows: the caller normalises first)
     return ck::fail(CK_ERR_UNSUPPORTED, "Tucker launch on logits: %lld tiles need the stream-K launch (a workspace and at most %d tiles)",
                     static_cast<long long>(wg1), 8 * ck::num_cus() * 3);

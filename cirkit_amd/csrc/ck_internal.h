@@ -53,8 +53,9 @@ bool debug_force_generic();
 bool gemm_applies(int H, int Ki, int Ko, int mode);
 bool tucker_applies(int H, int Ki, int Ko, int mode);
 int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int B, int Ki, int Ko,
-               void* stream, bool logits = false);
-// logits: w holds logits theta and the weights are softmax(theta) over the last axis, normalised online by the launch
+               void* stream, bool logits = false, int contraction = 0);
+// logits: w holds logits theta and the weights are softmax(theta) over the last axis, normalised online by the launch;
+// contraction: 0 exact fp32, 3 / 6 the bf16-split variants (stream-K launch only)
 int sum_lse_gemm(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int Ki,
                  int Ko, int mode, void* stream);
 int cat_dense(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,

@@ -628,18 +628,24 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
   return launch_generic<float, float>(arena, row_off, w, out, F, H, B, Ki, Ko, mode, stream);
 }
 
-int ck_tucker_logits_fwd(const float* arena, const int64_t* row_off, const float* theta, float* out, int F, int B, int Ki,
-                         int Ko, void* stream) {
-  CK_REQUIRE(arena && row_off && theta && out, "ck_tucker_logits_fwd: null pointer");
-  CK_REQUIRE(F > 0 && B > 0 && Ko > 0, "ck_tucker_logits_fwd: non-positive size F=%d B=%d Ko=%d", F, B, Ko);
-  CK_REQUIRE(Ki == 32 || Ki == 64, "ck_tucker_logits_fwd: Ki must be 32 or 64, found %d", Ki);
-  CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(theta) && ck::aligned16(out), "ck_tucker_logits_fwd: buffers must be 16-byte aligned");
+int ck_tucker_fwd(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int B, int Ki, int Ko,
+                  int w_is_logits, int contraction, void* stream) {
+  CK_REQUIRE(arena && row_off && w && out, "ck_tucker_fwd: null pointer");
+  CK_REQUIRE(F > 0 && B > 0 && Ko > 0, "ck_tucker_fwd: non-positive size F=%d B=%d Ko=%d", F, B, Ko);
+  CK_REQUIRE(Ki == 32 || Ki == 64, "ck_tucker_fwd: Ki must be 32 or 64, found %d", Ki);
+  CK_REQUIRE(contraction == 0 || contraction == 3 || contraction == 6, "ck_tucker_fwd: contraction %d (0, 3 or 6)", contraction);
+  CK_REQUIRE(ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out), "ck_tucker_fwd: buffers must be 16-byte aligned");
   if (F > ck::kMaxFoldsPerLaunch)
     return ck::chunk_folds(F, [&](int f0, int n) {
-      return ck_tucker_logits_fwd(arena, row_off + static_cast<int64_t>(f0) * 2, theta + static_cast<int64_t>(f0) * Ko * Ki * Ki,
-                                  out + static_cast<int64_t>(f0) * B * Ko, n, B, Ki, Ko, stream);
+      return ck_tucker_fwd(arena, row_off + static_cast<int64_t>(f0) * 2, w + static_cast<int64_t>(f0) * Ko * Ki * Ki,
+                           out + static_cast<int64_t>(f0) * B * Ko, n, B, Ki, Ko, w_is_logits, contraction, stream);
     });
-  return ck::tucker_lse(arena, row_off, theta, out, F, B, Ki, Ko, stream, true);
+  return ck::tucker_lse(arena, row_off, w, out, F, B, Ki, Ko, stream, w_is_logits != 0, contraction);
+}
+
+int ck_tucker_logits_fwd(const float* arena, const int64_t* row_off, const float* theta, float* out, int F, int B, int Ki,
+                         int Ko, void* stream) {
+  return ck_tucker_fwd(arena, row_off, theta, out, F, B, Ki, Ko, 1, 0, stream);
 }
 
 int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w, float* out_c,

@@ -677,6 +677,9 @@ class HipTuckerLayer(HipSumLayer):
     _logits_ok = False
     _theta: torch.Tensor | None = None
     _use_logits = False
+    # set by HipCircuit(contraction="bf16x3" / "bf16x6"): the stream-K launch contracts on the bf16 matrix pipe (a labelled
+    # variant, `ck_tucker_fwd`); where that launch does not apply (a large batch) the layer runs in exact fp32
+    _contraction = 0
 
     def register_batched(self, batch) -> bool:
         self._theta = None
@@ -699,10 +702,18 @@ class HipTuckerLayer(HipSumLayer):
 
     def launch(self, arena, row_off, out, B, stream) -> None:
         if not self._use_logits:
+            if (self._contraction and not self.is_complex and self.arity == 2 and self.num_input_units in (32, 64)
+                    and self._w_layout == capi.CK_W_ROWMAJOR):
+                try:
+                    capi.call("ck_tucker_fwd", _ptr(arena), _ptr(row_off), _ptr(self._w), _ptr(out), self.num_folds, B,
+                              self.num_input_units, self.num_output_units, 0, self._contraction, stream)
+                    return
+                except NotImplementedError:
+                    pass
             return super().launch(arena, row_off, out, B, stream)
         try:
-            capi.call("ck_tucker_logits_fwd", _ptr(arena), _ptr(row_off), _ptr(self._theta), _ptr(out),
-                      self.num_folds, B, self.num_input_units, self.num_output_units, stream)
+            capi.call("ck_tucker_fwd", _ptr(arena), _ptr(row_off), _ptr(self._theta), _ptr(out),
+                      self.num_folds, B, self.num_input_units, self.num_output_units, 1, self._contraction, stream)
         except NotImplementedError:
             # many tiles per resident workgroup (a large batch): one workgroup per tile would exponentiate the weights once
             # per 128 rows, so the normalised weights are written after all and the ordinary launch reads them

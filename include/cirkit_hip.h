@@ -157,6 +157,14 @@ int ck_debug_force_generic(int on);
  * rows: evaluate softmax(theta) with ck_param_softmax and call ck_sum_lse_fwd instead). */
 int ck_tucker_logits_fwd(const float* arena, const int64_t* row_off, const float* theta, float* out, int F, int B, int Ki,
                          int Ko, void* stream);
+/* The stream-K Tucker launch in full: w (F, Ko, Ki^2) holds logits (w_is_logits = 1, as ck_tucker_logits_fwd) or the weights
+ * themselves (0, as ck_sum_lse_fwd in CK_SUM_KRON mode).  contraction: 0 = exact fp32 (v_mfma_f32_32x32x2_f32), the product;
+ * 3 / 6 = the labelled "bf16x3" / "bf16x6" VARIANTS: the (exponentiated) weights and e_r cut by truncation into 2 / 3 bf16
+ * pieces with exact residuals, 3 / 6 products per 16 right indices on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * (dropped terms <= 2^-15 / <= 2^-23 of a product).  CK_ERR_UNSUPPORTED where the stream-K launch does not apply (no
+ * workspace, or more than 8 tiles per resident workgroup). */
+int ck_tucker_fwd(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int B, int Ki, int Ko,
+                  int w_is_logits, int contraction, void* stream);
 /* complex-lse-sum variant (semiring.py:441-476); w real (w_is_complex=0) or complex64. */
 int ck_sum_lse_fwd_c(const float* arena_c, const int64_t* row_off, const float* w, float* out_c,
                      int F, int H, int B, int Ki, int Ko, int mode, int w_is_complex, void* stream);

@@ -9,6 +9,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from cirkit_amd import _capi  # noqa: E402
+
+if os.environ.get("CK_LIB"):  # a lab build of the library (scripts/exp_tucker_bf16.py)
+    _capi._LIB_PATH = os.environ["CK_LIB"]
 from cirkit_amd.circuit import HipCircuit  # noqa: E402
 from cirkit_amd.initializers import init_plan_tensors  # noqa: E402
 from cirkit_amd.templates import image_data  # noqa: E402
@@ -21,8 +25,10 @@ plan = image_data((1, 28, 28), "quad-graph", input_layer="categorical", num_inpu
 tensors = init_plan_tensors(plan)
 x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(0)).to(dev)
 outs = {}
-for fused in (True, False):
-    hc = HipCircuit(plan, tensors, device=dev, fused_weight_softmax=fused)
+# (fused, contraction): the product, the prologue-normalised form, and the labelled bf16-split variants of the stream-K launch
+for fused in ((True, False, "bf16x3", "bf16x6") if not os.environ.get("ONLY") else os.environ["ONLY"].split(",")):
+    hc = (HipCircuit(plan, tensors, device=dev, fused_weight_softmax=True, contraction=fused) if isinstance(fused, str)
+          else HipCircuit(plan, tensors, device=dev, fused_weight_softmax=fused))
     for _ in range(5):
         y = hc(x)
     times = []
@@ -36,10 +42,14 @@ for fused in (True, False):
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1) / steps)
     outs[fused] = y.double().cpu()
-    print(f"fused_weight_softmax={fused}: {sorted(times)[2]:.3f} ms / forward (median of 5 x {steps}), mean LL {float(y.mean()):.4f}", flush=True)
+    print(f"{'contraction' if isinstance(fused, str) else 'fused_weight_softmax'}={fused}: {sorted(times)[2]:.3f} ms / forward (median of 5 x {steps}), mean LL {float(y.mean()):.4f}", flush=True)
     if os.environ.get("KERNELS"):
         for r in sorted(hc.profile_kernels(x, 10), key=lambda r: -r["ms"])[:10]:
             print(f"    layer {r['layer']:3d} {r['kernel'][:70]:70s} {r['ms']:.4f} ms")
     del hc
+if os.environ.get("ONLY"):
+    sys.exit(0)
 d = (outs[True] - outs[False]).abs().max() / outs[False].abs().max()
 print(f"max relative difference between the two: {float(d):.2e}")
+for c in ("bf16x3", "bf16x6"):
+    print(f"max relative difference of contraction={c} to the exact launch: {float(((outs[c] - outs[True]).abs() / outs[True].abs()).max()):.2e}")

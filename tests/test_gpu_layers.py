@@ -254,6 +254,60 @@ def test_tucker_logits_launch(hip_device, F, B, Ki, Ko, streamk):
     _close(out.cpu(), want)
 
 
+@pytest.mark.parametrize("F,B,Ki,Ko", [(3, 128, 64, 64), (7, 37, 32, 64), (1, 128, 64, 1), (2, 100, 64, 40), (5, 300, 32, 32),
+                                       (20, 128, 64, 64), (9, 128, 64, 128)])
+@pytest.mark.parametrize("logits", [False, True])
+def test_tucker_bf16_split_variants(hip_device, F, B, Ki, Ko, logits, capsys):
+    """`ck_tucker_fwd(contraction = 3 / 6)`: the stream-K Tucker launch with the staged weights and e_r cut into 2 / 3 bf16 pieces
+    and contracted on `v_mfma_f32_32x32x16_bf16` (fp32 accumulation) -- labelled variants of the exact launch (contraction 0).
+    Against the fp64 evaluation of the same layer: bf16x6 must be as close as the exact fp32 launch is (fp32-like), bf16x3
+    within the 1e-4 bar; -inf rows and weights that underflow to 0 behave as in the exact launch."""
+    from cirkit_amd import _capi as capi
+
+    g = torch.Generator().manual_seed(F + B + Ki + Ko + 17)
+    theta = torch.randn(F, Ko, Ki * Ki, generator=g) * 2
+    theta[0, 0, 5] = -200.0
+    theta[0, Ko - 1, Ki * Ki - 3] = 60.0  # (the running maximum of the online softmax rises in the last chunk)
+    w = torch.softmax(theta, dim=-1)
+    x = torch.randn(F, 2, B, Ki, generator=g) * 3 - 4
+    x[0, 0, 1] = float("-inf")  # an impossible row
+    xl, xr = x[:, 0].double(), x[:, 1].double()
+    prod = (xl[:, :, :, None] + xr[:, :, None, :]).reshape(F, B, Ki * Ki)  # (F, B, Ki^2)
+    want = torch.logsumexp(prod[:, :, None, :] + torch.log_softmax(theta.double(), dim=-1)[:, None, :, :], dim=-1) if F * B * Ko * Ki * Ki < 3e7 else None
+    if want is None:  # (chunked over the outputs: the broadcast above would not fit)
+        lw = torch.log_softmax(theta.double(), dim=-1)
+        want = torch.stack([torch.logsumexp(prod + lw[:, None, o, :], dim=-1) for o in range(Ko)], dim=-1)
+    xd = x.to(hip_device).contiguous()
+    wd = (theta if logits else w).to(hip_device).contiguous()
+    row_off = (torch.arange(F * 2, dtype=torch.int64) * (B * Ki)).reshape(F, 2).to(hip_device)
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    n_cu = torch.cuda.get_device_properties(hip_device).multi_processor_count
+    tiles = F * ((Ko + 31) // 32) * ((B + 127) // 128)
+    slot_words = n_cu * 3 * 2 * (4 * 1024 + 64)
+    ws = torch.zeros(slot_words + tiles, dtype=torch.int32, device=hip_device)
+    err = {}
+    capi.call("ck_set_workspace", ws.data_ptr(), ws.numel() * 4)
+    try:
+        for ct in (0, 3, 6):
+            for _ in range(2):
+                out = torch.full((F, B, Ko), float("nan"), device=hip_device)
+                capi.call("ck_tucker_fwd", xd.data_ptr(), row_off.data_ptr(), wd.data_ptr(), out.data_ptr(), F, B, Ki, Ko,
+                          1 if logits else 0, ct, stream)
+                torch.cuda.synchronize()
+                assert int(ws[slot_words:].abs().max()) == 0  # tickets back at zero
+            got = out.cpu().double()
+            fin = torch.isfinite(want)
+            assert torch.equal(torch.isfinite(got), fin)
+            assert torch.equal(got[~fin], want[~fin])
+            err[ct] = float(((got[fin] - want[fin]).abs() / want[fin].abs().clamp_min(1.0)).max())
+    finally:
+        capi.call("ck_set_workspace", None, 0)
+    with capsys.disabled():
+        print(f"\n[tucker bf16 variants F={F} B={B} Ki={Ki} Ko={Ko} logits={logits}] max rel err vs fp64: f32 {err[0]:.2e}, "
+              f"bf16x3 {err[3]:.2e}, bf16x6 {err[6]:.2e}")
+    assert err[0] <= 2e-6 and err[6] <= max(4.0 * err[0], 1e-6) and err[3] <= 1e-4
+
+
 def test_lse_edge_values(hip_device):
     """Rows that are entirely -inf give -inf (amax clamped to finfo.min, semiring.py:392-399), single
     finite entries survive, and a 200-nat spread does not underflow the result."""

@@ -605,6 +605,35 @@ def test_bf16_split_contraction_variants_against_the_fp64_golden(hip_device, cap
         HipCircuit(plan, tensors, device=hip_device, contraction="bf16x3", persistent_leaf=True, direct_input=False)(xb)
 
 
+@pytest.mark.parametrize("K", [32, 64])
+def test_bf16_split_variants_of_a_tucker_circuit_against_fp64(hip_device, K, capsys):
+    """`contraction="bf16x3"` / `"bf16x6"` on a circuit of Tucker layers (QuadGraph 8x8, Categorical-256, K units, batch 128: the
+    notebook configuration in small): the stream-K Tucker launch contracts on the bf16 matrix instructions (`ck_tucker_fwd`),
+    with the weights normalised online or by the prologue.  Against the oracle's fp64 evaluation of the whole circuit."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+
+    plan = image_data((1, 8, 8), "quad-graph", input_layer="categorical", num_input_units=K, sum_product_layer="tucker",
+                      num_sum_units=K)
+    tensors = init_plan_tensors(plan, seed=3)
+    x = torch.randint(0, 256, (128, 64), generator=torch.Generator().manual_seed(2))
+    y64 = _fp64_outputs(plan, tensors, x)[0].reshape(-1).double()
+    err = {}
+    for fused in (True, False):
+        for c in ("f32", "bf16x3", "bf16x6"):
+            hc = HipCircuit(plan, tensors, device=hip_device, contraction=c, fused_weight_softmax=fused)
+            y = hc(x.to(hip_device)).reshape(-1).double().cpu()
+            if c != "f32":  # the variant did run: the results differ from the exact launch's in the last bits
+                assert any("tucker" in hc.kernel_label(j, 128) for j in range(len(hc.layers)))
+            err[fused, c] = float(((y - y64).abs() / y64.abs()).max())
+    with capsys.disabled():
+        print(f"\n[bf16 variants, Tucker circuit K={K}] max rel err vs fp64: " + ", ".join(f"{'logits' if f else 'weights'} {c} {e:.2e}" for (f, c), e in err.items()))
+    for fused in (True, False):
+        assert err[fused, "f32"] <= 1e-6 and err[fused, "bf16x6"] <= max(4.0 * err[fused, "f32"], 1e-6) and err[fused, "bf16x3"] <= 1e-4
+        assert err[fused, "bf16x3"] > err[fused, "bf16x6"]  # (the three-product form is measurably coarser: it is what ran)
+
+
 def test_shared_storage_sees_writes_through_data(hip_device):
     """`params_at_end=False` -- what `to_hip()` / `HipPipelineContext.compile(TorchCircuit)` pass, because the parameter storage
     is then SHARED with arbitrary torch code: a write through `p.data` (no version counter moves, `TensorStore.state()` cannot
