@@ -72,16 +72,34 @@ def other_configs(device, stream, B: int) -> dict:
     g = torch.Generator().manual_seed(4)
     plan4 = image_data((1, 28, 28), "poon-domingos", input_layer="gaussian", num_input_units=64,
                        sum_product_layer="cp", num_sum_units=64)
-    hc = HipCircuit(plan4, init_plan_tensors(plan4), device=device)
-    ms = time_forward(hc, torch.randn((B, 784), generator=g).to(device))
+    t4 = init_plan_tensors(plan4)
+    x4 = torch.randn((B, 784), generator=g).to(device)
+    hc = HipCircuit(plan4, t4, device=device)
+    ms = time_forward(hc, x4)
+    y4 = hc(x4).double().cpu()
     alg = plan4.algorithmic_bytes(B)["total"]
     out["config4"] = {
         "workload": f"Poon-Domingos 28x28 (delta 4), Gaussian leaves, CP sum layers, mixing layers, K=64, batch {B}, "
                     "38 folded layers; CP blocks + mixing layers fused per region (cirkit_amd/csrc/ck_cp.hip)",
         "ms_per_forward": ms, "evals_per_s": B / ms * 1e3, "algorithmic_bytes": alg,
         "hbm_roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "variants": {},
     }
     del hc
+    # Labelled variants, never `ms_per_forward`: the region / CP-block launches on the bf16 matrix instructions (a weight unit cut
+    # into 2 / 3 bf16 pieces in LDS, the exponentiated tile in registers; fp32 accumulation: ck_region_lse_fwd_v, ck_cp_lse_fwd_v).
+    for cname in ("bf16x3", "bf16x6"):
+        hv = HipCircuit(plan4, t4, device=device, contraction=cname)
+        ms_v = time_forward(hv, x4)
+        y_v = hv(x4).double().cpu()
+        out["config4"]["variants"][f"contraction={cname}"] = {
+            "ms_per_forward": ms_v, "evals_per_s": B / ms_v * 1e3,
+            "max_rel_diff_to_exact_fp32": float(((y_v - y4).abs() / y4.abs()).max()),
+            "what": ("K = 64 contractions of the region / CP-block launches on v_mfma_f32_32x32x16_bf16: operands split by truncation into "
+                     + ("2 bf16 pieces, 3 products (~2^-15 per product)" if cname == "bf16x3" else "3 bf16 pieces, 6 products (fp32-like)")
+                     + "; everything else exact fp32"),
+        }
+        del hv
     plan5 = image_data((1, 28, 28), "quad-tree-2", input_layer="embedding", num_input_units=32, sum_product_layer="cp-t",
                        num_sum_units=32, sum_weight_activation="none", semiring="complex-lse-sum")
     t5 = init_plan_tensors(plan5)

@@ -158,6 +158,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_mixing_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_cp_lse_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_region_lse_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "ck_cp_lse_fwd_v": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_region_lse_fwd_v": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_hadamard_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_kronecker_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_tensordot_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -90,8 +90,9 @@ class HipCircuit:
             exponent range), 3 / 6 products per contraction on the bf16 matrix pipe with fp32 accumulation -- ~2^-15 per
             product, resp. fp32-like (tests/test_gpu_parity.py measures both against the fp64 goldens) -- and of the stream-K
             launch of Tucker layers with 32 / 64 units (`ck_tucker_fwd`: the weights are cut into pieces while they are
-            staged, behind the online softmax's exponential).  The tail, the parameter jobs and every other launch stay
-            exact fp32.
+            staged, behind the online softmax's exponential), and of the DMA-staged region / CP-block launches
+            (`ck_region_lse_fwd_v`, `ck_cp_lse_fwd_v`: a weight unit is cut in LDS by the workgroup).  The tail, the
+            parameter jobs and every other launch stay exact fp32.
         dense_on_table: a Categorical input layer followed fold-by-fold by a dense sum layer only
             takes C distinct values per fold, so the dense layer is applied once per forward to the
             (F, C, K) log-probability table (same kernel, batch = C) instead of to every batch row;
@@ -360,6 +361,7 @@ class HipCircuit:
         if contraction not in ("f32", "bf16x3", "bf16x6"):
             raise ValueError(f"unknown contraction {contraction!r} ('f32' = exact fp32, the product; 'bf16x3' / 'bf16x6' = labelled variants)")
         self.contraction = contraction
+        self._ct = {"f32": 0, "bf16x3": 3, "bf16x6": 6}[contraction]
         self.dense_on_table = bool(dense_on_table)
         self.tiled_weights = bool(tiled_weights)
         self._assign_weight_layouts()
@@ -760,10 +762,10 @@ class HipCircuit:
             redo = bd.cp_tabs.get((i, "redo"))
             if redo is None:
                 redo = bd.cp_tabs[(i, "redo")] = torch.zeros(F * ((bd.B + 127) // 128), dtype=torch.int32, device=self.device)
-        capi.call("ck_region_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), l._w.data_ptr(),
+        capi.call("ck_region_lse_fwd_v", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), l._w.data_ptr(),
                   bd.views[i].data_ptr(), None if ga is None else ga.data_ptr(), None if gv is None else gv.data_ptr(),
                   None if ga is None else bd.xt_i.data_ptr(), Cn, None if redo is None else redo.data_ptr(),
-                  F, H, S, bd.B, K, stream)
+                  F, H, S, bd.B, K, self._ct, stream)
 
     def _launch_input_prod(self, i: int, bd: _Binding, stream: int) -> None:
         """`ck_gaussian_prod_fwd`: a Hadamard layer over Gaussian folds, straight from the batch."""
@@ -804,12 +806,12 @@ class HipCircuit:
             gargs = (None if ga is None else ga.data_ptr(), None if gv is None else gv.data_ptr(),
                      None if ga is None else bd.xt_i.data_ptr(), Cn)
             if sub is None:
-                capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), pp, None,
-                          bd.views[i].data_ptr(), *gargs, F, S, 1, bd.B, K, stream)
+                capi.call("ck_cp_lse_fwd_v", bd.arena.data_ptr(), bd.row_off[i].data_ptr(), tab.data_ptr(), pp, None,
+                          bd.views[i].data_ptr(), *gargs, F, S, 1, bd.B, K, self._ct, stream)
             else:
                 ro, oo = bd.leftover[i]
-                capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), pp, oo.data_ptr(),
-                          bd.arena.data_ptr(), *gargs, len(sub), S, 1, bd.B, K, stream)
+                capi.call("ck_cp_lse_fwd_v", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), pp, oo.data_ptr(),
+                          bd.arena.data_ptr(), *gargs, len(sub), S, 1, bd.B, K, self._ct, stream)
             return
         folds = self._cp_leftover[i]
         ro, oo = bd.leftover[i]

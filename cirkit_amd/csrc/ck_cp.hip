@@ -398,7 +398,12 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
 // Same arithmetic, in the same order, as region_lse_kernel: the two agree bit for bit.
 // BLOCK: the launch is a CP block on its own (H = 1, LINEAR = false; see below) -- the variants without it carry neither
 // the CP-T step nor the table gathers, the variant with it no mixing sum.
-template <int NK, int WAVES, int MINW, bool LINEAR, bool BLOCK = false>
+// CT: 0 = the contractions in exact fp32 (the product); 3 / 6 = the labelled bf16-split VARIANTS ("bf16x3" / "bf16x6", ck_tile.h
+// contract_bf16): a weight unit arrives by DMA as it always does and is cut IN PLACE into P = 2 / 3 bf16 pieces by the workgroup
+// (thread (block of 16 inputs, lane) reads the two float4s of its lane that hold inputs 16 m .. 16 m + 15 and writes their pieces
+// over them -- and, P = 3, into a third of a buffer behind the unit; one more barrier per unit), the exponentiated tile in
+// registers, and the chain runs as 3 / 6 products per 16 inputs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+template <int NK, int WAVES, int MINW, bool LINEAR, bool BLOCK = false, int CT = 0>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
     region_dma_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                       const int64_t* __restrict__ w_addr, const float* __restrict__ mw, float* __restrict__ out,
@@ -419,9 +424,12 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   constexpr int UF4 = 32 * K / 4;    // float4 elements of one weight UNIT: the 32 output rows 32 p .. 32 p + 31 of a matrix
   constexpr int CH = K / 4;          // 16-byte chunks per row
   constexpr int TD = 32 * CH / 64;   // wave DMAs per tile
+  constexpr int NP = CT == 0 ? 1 : CT / 3 + 1;
+  constexpr int UB = CT == 6 ? 48 * K : 32 * K;  // floats of a ring buffer (bf16x6: the third pieces behind the unit)
+  static_assert(CT == 0 || 2 * NK * 64 <= WAVES * 64, "one (block, lane) item per thread cuts a unit into pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* w_s = smem;                           // [2][32*K]: ring of two weight units
-  float* tile_s = smem + 2 * 32 * K;           // [WAVES][32*K]
+  float* w_s = smem;                           // [2][UB]: ring of two weight units
+  float* tile_s = smem + 2 * UB;               // [WAVES][32*K]
   float* mw_s = tile_s + WAVES * 32 * K;       // [H][K]
   int32_t* xg_s = reinterpret_cast<int32_t*>(mw_s + H * K);  // gather slots: [WAVES][T][32] batch values, DMA order
   // BLOCK: a one-dimensional grid, XCD-aware (consecutive workgroup ids go to consecutive XCDs): every workgroup of a
@@ -446,14 +454,16 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   const int64_t* wa = w_addr + static_cast<int64_t>(f) * T;
   const int TU = (T + (BLOCK && w_post != nullptr ? 1 : 0)) * NK;  // weight units of the launch
   // weight unit u = t * NK + p goes to ring buffer u & 1, in the operand layout [(q * 4 + g) * 64 + lane] float4
-  constexpr int PF = (UF4 + WAVES * 64 - 1) / (WAVES * 64);
+  // CT != 0: thread (wave, lane) of the first 2 NK waves stages float4s 2 wave and 2 wave + 1 of its lane -- the two its own
+  // item of the cut reads (see cut_unit: nobody waits for anybody else's requests before cutting)
+  constexpr int PF = CT != 0 ? 2 : (UF4 + WAVES * 64 - 1) / (WAVES * 64);
   static_assert(NK == 1 || UF4 % (WAVES * 64) == 0, "the vmcnt bookkeeping of later units assumes every wave stages a share");
   // (addresses = a uniform base + a 32-bit lane offset: global_load_lds with an SGPR base, no 64-bit lane arithmetic)
   const int w_ld = w_cat != nullptr ? K * T : K;  // row stride of a weight matrix
   uint32_t w_off[PF];  // byte offset of this lane's 16 bytes inside a unit's 32 rows
 #pragma unroll
   for (int k = 0; k < PF; ++k) {
-    const int i = threadIdx.x + k * (WAVES * 64);
+    const int i = CT != 0 ? (2 * wave + k) * 64 + lane : static_cast<int>(threadIdx.x) + k * (WAVES * 64);
     const int ln = i & 63, g = (i >> 6) & 3, q = i >> 8;
     w_off[k] = static_cast<uint32_t>(((ln & 31) * w_ld + 32 * q + 8 * g + 4 * (ln >> 5)) * 4);
   }
@@ -467,9 +477,16 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
     const uint64_t wu = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv >> 32)))) << 32) |
                         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv)));
     const char* wf = reinterpret_cast<const char*>(static_cast<uintptr_t>(wu)) + static_cast<int64_t>(p) * (32 * 4) * w_ld;
-    float* dstb = w_s + (u & 1) * (32 * K);
+    float* dstb = w_s + (u & 1) * UB;
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
+      if constexpr (CT != 0) {
+        if (wave_u >= 2 * NK) continue;  // (whole waves)
+        uint32_t o = w_off[k];
+        asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds((ck::gptr_t)(wf + o), (ck::lptr_t)(dstb + 4 * ((2 * wave_u + k) * 64)), 16, 0, 0);
+        continue;
+      }
       if (UF4 % (WAVES * 64) != 0 && static_cast<int>(threadIdx.x) + k * (WAVES * 64) >= UF4) continue;  // (whole waves)
       uint32_t o = w_off[k];
       asm volatile("" : "+v"(o));
@@ -522,6 +539,102 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   const uint32_t rd_row = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(my_tile)) + (b_in * CH + swz_b) * 16;
   const uint32_t w_rd = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + lane * 16;
 
+  // CT != 0: unit u (fp32, operand layout [(4 q + g) * 64 + lane] float4) cut into pieces in place: item (blk = 2 q + m, lane) =
+  // thread blk * 64 + lane owns float4s 2 blk and 2 blk + 1 of its lane -- inputs 32 q + 16 m + 8 s + 4 kh + t of row lane % 32,
+  // s = 0 / 1, which this very thread requested (stage_w) -- and leaves piece 0 in the first, piece 1 in the second, piece 2 at
+  // float4 (4 NK + blk) * 64 + lane.  Called BEFORE the barrier of the unit, behind the wait for the wave's own requests.
+  auto cut_unit = [&](int u) {
+    if (static_cast<int>(threadIdx.x) < 2 * NK * 64) {
+      const uint32_t a0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + (u & 1) * (UB * 4) + (2 * wave_u * 64 + lane) * 16;
+      f32x4v x0, x1;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(a0) : "memory");
+      float r[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc) {
+        u32x4v d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = __builtin_amdgcn_perm(__float_as_uint(r[2 * j + 1]), __float_as_uint(r[2 * j]), 0x07060302u);
+        const uint32_t ad = pc < 2 ? a0 + 1024 * pc : static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + (u & 1) * (UB * 4) + ((4 * NK + wave_u) * 64 + lane) * 16;
+        asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(d) : "memory");
+        if (pc + 1 < NP) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) r[j] -= __uint_as_float(__float_as_uint(r[j]) & 0xffff0000u);  // exact
+        }
+      }
+    }
+  };
+  // acc = W_u . x for the 32 outputs of unit u (in LDS; CT != 0: cut into pieces), x the exponentiated tile of this wave
+  auto unit_product = [&](int u, const float (&x)[NK][16], const u32x4v (&xp)[NP][2 * NK], f32x16& acc) {
+    const uint32_t wb = w_rd + (u & 1) * (UB * 4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (CT == 0) {
+      static_for<0, NK>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int o = q * 4096;
+        f32x4v w0, w1, w2, w3;
+        lds_read4_off<o, o + 1024, o + 2048, o + 3072>(w0, w1, w2, w3, wb);
+        const f32x4v* wg[4] = {&w0, &w1, &w2, &w3};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[0], x[q][4 * g + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[1], x[q][4 * g + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[2], x[q][4 * g + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[3], x[q][4 * g + 3], acc, 0, 0, 0);
+        }
+      });
+    } else {
+      auto mm = [&](const f32x4v& w, const u32x4v& y) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, w), __builtin_bit_cast(bf16x8v, y), acc, 0, 0, 0);
+      };
+      static_for<0, NK>([&](auto qc) {  // blocks 2 q, 2 q + 1: pieces 0, 1 at float4s 4 q .. 4 q + 3, piece 2 behind the unit
+        constexpr int q = decltype(qc)::value;
+        constexpr int o = q * 4096;
+        f32x4v w00, w01, w10, w11, w20, w21;
+        lds_read4_off<o, o + 1024, o + 2048, o + 3072>(w00, w01, w10, w11, wb);  // (block 2 q: pieces 0, 1; block 2 q + 1: pieces 0, 1)
+        if constexpr (NP == 3) {
+          asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(w20), "=&v"(w21)
+                       : "v"(wb), "n"((4 * NK + 2 * q) * 1024), "n"((4 * NK + 2 * q + 1) * 1024)
+                       : "memory");
+          mm(w20, xp[0][2 * q]);  // (smallest terms first)
+          mm(w01, xp[1][2 * q]);
+          mm(w00, xp[2][2 * q]);
+        }
+        mm(w01, xp[0][2 * q]);
+        mm(w00, xp[1][2 * q]);
+        mm(w00, xp[0][2 * q]);
+        if constexpr (NP == 3) {
+          mm(w21, xp[0][2 * q + 1]);
+          mm(w11, xp[1][2 * q + 1]);
+          mm(w10, xp[2][2 * q + 1]);
+        }
+        mm(w11, xp[0][2 * q + 1]);
+        mm(w10, xp[1][2 * q + 1]);
+        mm(w10, xp[0][2 * q + 1]);
+      });
+    }
+  };
+  // the exponentiated tile cut into the B operands: piece p of registers 8 m .. 8 m + 7 of quarter q at [p][2 q + m]
+  auto cut_tile = [&](float (&x)[NK][16], u32x4v (&xp)[NP][2 * NK]) {
+    if constexpr (CT != 0) {
+#pragma unroll
+      for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+              xp[pc][2 * q + mh][d] = __builtin_amdgcn_perm(__float_as_uint(x[q][8 * mh + 2 * d + 1]), __float_as_uint(x[q][8 * mh + 2 * d]), 0x07060302u);
+          if (pc + 1 < NP) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[q][j] -= __uint_as_float(__float_as_uint(x[q][j]) & 0xffff0000u);  // exact
+          }
+        }
+    }
+  };
+
   for (int i = threadIdx.x; i < K * H; i += WAVES * 64) {
     const int k = i / H, h = i - k * H;
     mw_s[h * K + k] = mw != nullptr ? mw[static_cast<int64_t>(f) * K * H + i] : 1.f;
@@ -545,7 +658,13 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   int t = 0;
   bool bad = false;
   for (int h = 0; h < H; ++h) {
+    // the product of the slots starts at the neutral element and every slot multiplies (adds) into it IN PLACE: with
+    // `s == 0 ? x : P * x` the compiler keeps the result in fresh registers and copies all 32 back at the end of every slot
     float P[NK][16];
+#pragma unroll
+    for (int p = 0; p < NK; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P[p][r] = LINEAR ? 1.f : 0.f;
     float sc = 0.f;  // LINEAR: log scale of the rows of P
     for (int s = 0; s < S; ++s, ++t) {
       float v[NK][16];
@@ -580,6 +699,8 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[q][j] = __builtin_amdgcn_exp2f(fmaf(v[q][j], kL2E, nml));
       }
+      u32x4v vp[NP][2 * NK];
+      if (dense) cut_tile(v, vp);
       static_for<0, NK>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         const int u = t * NK + p;
@@ -589,49 +710,36 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
           if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TD) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if constexpr (CT != 0) {
+          if (dense) cut_unit(u);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... and every wave has left unit u - 1
         if (u + 1 < TU) stage_w(u + 1);
         if constexpr (p == 0) {
           if (t + 1 < T) stage_tile(t + 1);  // (the slot is free since its reads returned)
         }
         if (dense) {
-          const uint32_t wb = w_rd + (u & 1) * (32 * K * 4);
           f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          static_for<0, NK>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            constexpr int o = q * 4096;
-            f32x4v w0, w1, w2, w3;
-            lds_read4_off<o, o + 1024, o + 2048, o + 3072>(w0, w1, w2, w3, wb);
-            const f32x4v* wg[4] = {&w0, &w1, &w2, &w3};
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[0], v[q][4 * g + 0], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[1], v[q][4 * g + 1], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[2], v[q][4 * g + 2], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[3], v[q][4 * g + 3], acc, 0, 0, 0);
-            }
-          });
+          unit_product(u, v, vp, acc);
           if constexpr (LINEAR) {  // P = prod_s G_s stays in linear space; the row's log scale is the sum of the m_s
 #pragma unroll
-            for (int r = 0; r < 16; ++r) P[p][r] = s == 0 ? acc[r] : P[p][r] * acc[r];
+            for (int r = 0; r < 16; ++r) P[p][r] *= acc[r];
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float gs = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m);
-              P[p][r] = s == 0 ? gs : P[p][r] + gs;
+              P[p][r] += gs;
             }
           }
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            if constexpr (LINEAR) P[p][j] = s == 0 ? v[p][j] : P[p][j] * v[p][j];  // (exp(v - m): see below)
-            else P[p][j] = s == 0 ? v[p][j] : P[p][j] + v[p][j];
+            if constexpr (LINEAR) P[p][j] *= v[p][j];  // (exp(v - m): see below)
+            else P[p][j] += v[p][j];
           }
         }
       });
-      if constexpr (LINEAR) sc = s == 0 ? m : sc + m;
+      if constexpr (LINEAR) sc += m;
     }
     if constexpr (BLOCK) {
       {  // (H = 1, no mixing layer behind the product)
@@ -648,30 +756,17 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
           for (int q = 0; q < NK; ++q)
 #pragma unroll
             for (int j = 0; j < 16; ++j) e[q][j] = __builtin_amdgcn_exp2f(fmaf(P[q][j], kL2E, nml));
+          u32x4v ep[NP][2 * NK];
+          cut_tile(e, ep);
           static_for<0, NK>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
             const int u = T * NK + p;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's share of unit u has landed
+            if constexpr (CT != 0) cut_unit(u);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everybody's; every wave has left unit u - 1
             if (u + 1 < TU) stage_w(u + 1);
-            const uint32_t wb = w_rd + (u & 1) * (32 * K * 4);
             f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            static_for<0, NK>([&](auto qc) {
-              constexpr int q = decltype(qc)::value;
-              constexpr int o = q * 4096;
-              f32x4v w0, w1, w2, w3;
-              lds_read4_off<o, o + 1024, o + 2048, o + 3072>(w0, w1, w2, w3, wb);
-              const f32x4v* wg[4] = {&w0, &w1, &w2, &w3};
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[0], e[q][4 * g + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[1], e[q][4 * g + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[2], e[q][4 * g + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[3], e[q][4 * g + 3], acc, 0, 0, 0);
-              }
-            });
+            unit_product(u, e, ep, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) P[p][r] = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m);
           });
@@ -921,9 +1016,10 @@ int cp_single_slot(const float* arena, const int64_t* row_off, const float* w, f
 }
 }  // namespace ck
 
-extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* w_post,
-                             const int64_t* out_off, float* out, const int64_t* g_addr, const int32_t* g_var,
-                             const int32_t* xt, int C, int F, int S, int H, int B, int K, void* stream) {
+extern "C" int ck_cp_lse_fwd_v(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* w_post,
+                               const int64_t* out_off, float* out, const int64_t* g_addr, const int32_t* g_var,
+                               const int32_t* xt, int C, int F, int S, int H, int B, int K, int contraction, void* stream) {
+  CK_REQUIRE(contraction == 0 || contraction == 3 || contraction == 6, "ck_cp_lse_fwd_v: contraction %d (0, 3 or 6)", contraction);
   CK_REQUIRE(g_var == nullptr || (g_addr && xt && C > 0), "ck_cp_lse_fwd: gather slots need g_addr, xt and C");
   const GatherSlots gs{g_addr, g_var, xt, C, F};
   CK_REQUIRE(arena && row_off && w_addr && out, "ck_cp_lse_fwd: null pointer");
@@ -935,7 +1031,7 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
   // matrix included) prefetched a step ahead through LDS
   {
     const int waves = K == 64 ? 4 : 8;
-    const size_t lds_dma = (static_cast<size_t>(2) * 32 * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(K) +
+    const size_t lds_dma = (static_cast<size_t>(2) * (contraction == 6 ? 48 : 32) * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(K) +
                             (g_var != nullptr ? static_cast<size_t>(waves) * S * 32 : 0)) * sizeof(float);
     if (H == 1 && (g_var == nullptr || S <= 8) && out_off == nullptr && !ck::debug_force_generic() &&
         static_cast<int64_t>(B) * K < (int64_t{1} << 30)) {
@@ -951,19 +1047,29 @@ extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const i
                                  static_cast<int32_t*>(nullptr), 1, S, B, static_cast<const float*>(nullptr), w_post, gs);
               return hipGetLastError();
             };
+            if (contraction == 3) return K == 64 ? go(region_dma_kernel<2, 4, 3, false, true, 3>) : go(region_dma_kernel<1, 8, 2, false, true, 3>);
+            if (contraction == 6) return K == 64 ? go(region_dma_kernel<2, 4, 2, false, true, 6>) : go(region_dma_kernel<1, 8, 2, false, true, 6>);
             return K == 64 ? go(region_dma_kernel<2, 4, 3, false, true>) : go(region_dma_kernel<1, 8, 2, false, true>);
           },
           stream);
     }
   }
+  // (blocks the DMA-staged launch does not take are evaluated in exact fp32 whatever `contraction` says)
   if (K == 64) return launch_cp<2>(arena, row_off, w_addr, nullptr, w_post, out_off, out, gs, F, S, H, B, stream);
   return launch_cp<1>(arena, row_off, w_addr, nullptr, w_post, out_off, out, gs, F, S, H, B, stream);
 }
 
-extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
-                                 float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
-                                 int32_t* redo, int F, int H, int S, int B, int K, void* stream) {
+extern "C" int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* w_post,
+                             const int64_t* out_off, float* out, const int64_t* g_addr, const int32_t* g_var,
+                             const int32_t* xt, int C, int F, int S, int H, int B, int K, void* stream) {
+  return ck_cp_lse_fwd_v(arena, row_off, w_addr, w_post, out_off, out, g_addr, g_var, xt, C, F, S, H, B, K, 0, stream);
+}
+
+extern "C" int ck_region_lse_fwd_v(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
+                                   float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
+                                   int32_t* redo, int F, int H, int S, int B, int K, int contraction, void* stream) {
   CK_REQUIRE(g_var == nullptr || (g_addr && xt && C > 0), "ck_region_lse_fwd: gather slots need g_addr, xt and C");
+  CK_REQUIRE(contraction == 0 || contraction == 3 || contraction == 6, "ck_region_lse_fwd_v: contraction %d (0, 3 or 6)", contraction);
   const GatherSlots gs{g_addr, g_var, xt, C, F};
   CK_REQUIRE(arena && row_off && w_addr && mw && out, "ck_region_lse_fwd: null pointer");
   CK_REQUIRE(F > 0 && S > 0 && H > 0 && B > 0, "ck_region_lse_fwd: non-positive size F=%d H=%d S=%d B=%d", F, H, S, B);
@@ -976,7 +1082,7 @@ extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, con
   const int waves = K == 64 ? 4 : 8;  // (both kernels: one 32-row tile per wave, the same workgroup <-> tiles mapping)
   const dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
   // every operand through the LDS DMA path (region_dma_kernel) unless a slot gathers table rows
-  const size_t lds_dma = (static_cast<size_t>(2) * 32 * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(H) * K) * sizeof(float);
+  const size_t lds_dma = (static_cast<size_t>(2) * (contraction == 6 ? 48 : 32) * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(H) * K) * sizeof(float);
   const bool dma = g_var == nullptr && !ck::debug_force_generic() && lds_dma <= 80 * 1024 &&
                    static_cast<int64_t>(B) * K < (int64_t{1} << 30);
   auto exact = [=](hipStream_t s, int32_t* redo_ws) {  // region_lse_kernel: everything, or (redo_ws) the marked workgroups
@@ -1000,10 +1106,27 @@ extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, con
           return hipGetLastError();
         };
         // K = 64: 48 KiB + H x 256 B of LDS and <= 168 VGPRs: three workgroups (12 waves) per CU while H <= 20
+        // (the variants: launches that gather table rows, and the tiles the linear-space launch marks, stay exact fp32)
+        if (contraction == 3) {
+          if (redo == nullptr) return K == 64 ? go(region_dma_kernel<2, 4, 3, false, false, 3>) : go(region_dma_kernel<1, 8, 2, false, false, 3>);
+          const hipError_t e = K == 64 ? go(region_dma_kernel<2, 4, 3, true, false, 3>) : go(region_dma_kernel<1, 8, 2, true, false, 3>);
+          return e != hipSuccess ? e : exact(s, redo);
+        }
+        if (contraction == 6) {  // (K = 64: 56 KiB + H x 256 B of LDS: two workgroups per CU)
+          if (redo == nullptr) return K == 64 ? go(region_dma_kernel<2, 4, 2, false, false, 6>) : go(region_dma_kernel<1, 8, 2, false, false, 6>);
+          const hipError_t e = K == 64 ? go(region_dma_kernel<2, 4, 2, true, false, 6>) : go(region_dma_kernel<1, 8, 2, true, false, 6>);
+          return e != hipSuccess ? e : exact(s, redo);
+        }
         if (redo == nullptr) return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
         const hipError_t e = K == 64 ? go(region_dma_kernel<2, 4, 3, true>) : go(region_dma_kernel<1, 8, 2, true>);
         if (e != hipSuccess) return e;
         return exact(s, redo);  // the workgroups the linear-space launch marked, in log space (none, normally: they exit at once)
       },
       stream);
+}
+
+extern "C" int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
+                                 float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
+                                 int32_t* redo, int F, int H, int S, int B, int K, void* stream) {
+  return ck_region_lse_fwd_v(arena, row_off, w_addr, mw, out, g_addr, g_var, xt, C, redo, F, H, S, B, K, 0, stream);
 }

@@ -202,6 +202,13 @@ int ck_mixing_lse_fwd(const float* arena, const int64_t* row_off, const float* m
 int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* w_post,
                   const int64_t* out_off, float* out, const int64_t* g_addr, const int32_t* g_var,
                   const int32_t* xt, int C, int F, int S, int H, int B, int K, void* stream);
+/* ck_cp_lse_fwd with the contraction named: 0 = exact fp32 (what ck_cp_lse_fwd does); 3 / 6 = the labelled "bf16x3" / "bf16x6"
+ * VARIANTS of the DMA-staged launch (blocks of one child per slot with contiguous output): a weight unit is cut in LDS, the
+ * exponentiated tile in registers, into 2 / 3 bf16 pieces (truncation, exact residuals) and contracted with 3 / 6 products per
+ * 16 inputs on v_mfma_f32_32x32x16_bf16, fp32 accumulation.  Blocks that launch does not take run in exact fp32. */
+int ck_cp_lse_fwd_v(const float* arena, const int64_t* row_off, const int64_t* w_addr, const int64_t* w_post,
+                    const int64_t* out_off, float* out, const int64_t* g_addr, const int32_t* g_var,
+                    const int32_t* xt, int C, int F, int S, int H, int B, int K, int contraction, void* stream);
 
 /* A region with H partitionings in one launch: the H CP blocks (as in ck_cp_lse_fwd, S slots each)
  * and the mixing layer that combines them (templates/region_graph/graph.py:556-583: `mix_ins` and the
@@ -219,6 +226,11 @@ int ck_cp_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_a
 int ck_region_lse_fwd(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
                       float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
                       int32_t* redo, int F, int H, int S, int B, int K, void* stream);
+/* ck_region_lse_fwd with the contraction named (0 exact fp32; 3 / 6 the bf16-split variants, as ck_cp_lse_fwd_v): regions
+ * without table slots.  The tiles a linear-space launch marks in `redo` are evaluated again in exact fp32 log space. */
+int ck_region_lse_fwd_v(const float* arena, const int64_t* row_off, const int64_t* w_addr, const float* mw,
+                        float* out, const int64_t* g_addr, const int32_t* g_var, const int32_t* xt, int C,
+                        int32_t* redo, int F, int H, int S, int B, int K, int contraction, void* stream);
 
 /* TorchHadamardLayer.forward, inner.py:126-127 (lse: sum over the arity axis). esize = 1 (fp32)
  * or 2 (complex64: K counts complex elements). */

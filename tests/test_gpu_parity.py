@@ -963,6 +963,23 @@ def test_region_kernels_agree_bit_for_bit(hip_device, K, F, H, S, B):
     torch.cuda.synchronize()
     assert int(redo.abs().sum()) == 0
     assert float(((out.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-5
+    # the labelled bf16-split variants of the DMA-staged launch (ck_region_lse_fwd_v), log-space and linear-space form: bf16x6 as
+    # close to the fp64 value as the exact launch; bf16x3 drops terms <= 2^-15 of a product, S + 1 contractions deep: 5e-4 of a
+    # layer output of size ~3 (the 1e-4 bar is that of a circuit's output, |log-likelihood| ~ 1e3: test_bf16_split_*)
+    def rel(o):
+        return float(((o.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max())
+
+    e0 = rel(outs[0])
+    for ct, bar in ((3, 5e-4), (6, max(4.0 * e0, 1e-6))):
+        for ws in (None, redo):
+            out = torch.full((F, B, K), float("nan"), device=hip_device)
+            capi.call("ck_region_lse_fwd_v", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), mw.data_ptr(), out.data_ptr(),
+                      None, None, None, 0, None if ws is None else ws.data_ptr(), F, H, S, B, K, ct, stream)
+            torch.cuda.synchronize()
+            assert int(redo.abs().sum()) == 0
+            assert rel(out) <= bar, (ct, ws is None, rel(out), e0)
+            if ct == 3:
+                assert rel(out) > e0  # (the three-product form is measurably coarser: it is what ran)
 
 
 @pytest.mark.parametrize("post,gather", [(False, False), (True, False), (True, True), (False, True)])
@@ -1028,6 +1045,15 @@ def test_cp_block_launches_agree_bit_for_bit(hip_device, K, F, S, B, post, gathe
             mx = ref[f].amax(dim=-1, keepdim=True)
             ref[f] = torch.log(torch.exp(ref[f] - mx) @ wp[f].cpu().double().T) + mx
     assert float(((outs[0].double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-5
+    # the labelled bf16-split variants (ck_cp_lse_fwd_v; blocks of at most 8 slots, or without gathers, take the DMA-staged launch)
+    e0 = float(((outs[0].double() - ref).abs() / ref.abs().clamp_min(1.0)).max())
+    for ct, bar in ((3, 5e-4), (6, max(4.0 * e0, 1e-6))):
+        out = torch.full((F, B, K), float("nan"), device=hip_device)
+        capi.call("ck_cp_lse_fwd_v", arena.data_ptr(), row_off.data_ptr(), addr.data_ptr(), paddr.data_ptr() if post else None, None,
+                  out.data_ptr(), *gargs, F, S, 1, B, K, ct, stream)
+        torch.cuda.synchronize()
+        err = float(((out.cpu().double() - ref).abs() / ref.abs().clamp_min(1.0)).max())
+        assert err <= bar, (ct, err, e0)
 
 
 @pytest.mark.parametrize("K", [64, 32])
