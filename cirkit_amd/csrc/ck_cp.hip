@@ -403,6 +403,10 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)  // MINW waves per SIMD: cap
 // (thread (block of 16 inputs, lane) reads the two float4s of its lane that hold inputs 16 m .. 16 m + 15 and writes their pieces
 // over them -- and, P = 3, into a third of a buffer behind the unit; one more barrier per unit), the exponentiated tile in
 // registers, and the chain runs as 3 / 6 products per 16 inputs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+#ifndef CK_REGION_LABBITS
+#define CK_REGION_LABBITS 0  // lab builds (scripts/exp_region.py, LAB_NOTES R4.5): 1 = two 16-deep MFMA chains per unit, 2 = two workgroups
+                             // per CU, 4 = one barrier per slot (needs 2), 8 = operand reads of unit (t, 1) under the chain of (t, 0) (needs 4)
+#endif
 template <int NK, int WAVES, int MINW, bool LINEAR, bool BLOCK = false, int CT = 0>
 __global__ void __launch_bounds__(WAVES * 64, MINW)
     region_dma_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
@@ -428,8 +432,11 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   constexpr int UB = CT == 6 ? 48 * K : 32 * K;  // floats of a ring buffer (bf16x6: the third pieces behind the unit)
   static_assert(CT == 0 || 2 * NK * 64 <= WAVES * 64, "one (block, lane) item per thread cuts a unit into pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // LAB bit 4: a ring of two whole matrices (four units) and ONE barrier per slot
+  constexpr bool ONEB = (CK_REGION_LABBITS & 4) != 0 && NK == 2 && CT == 0 && !BLOCK && LINEAR;
+  constexpr int RS = ONEB ? 3 : 1;
   float* w_s = smem;                           // [2][UB]: ring of two weight units
-  float* tile_s = smem + 2 * UB;               // [WAVES][32*K]
+  float* tile_s = smem + (RS + 1) * UB;        // [WAVES][32*K]
   float* mw_s = tile_s + WAVES * 32 * K;       // [H][K]
   int32_t* xg_s = reinterpret_cast<int32_t*>(mw_s + H * K);  // gather slots: [WAVES][T][32] batch values, DMA order
   // BLOCK: a one-dimensional grid, XCD-aware (consecutive workgroup ids go to consecutive XCDs): every workgroup of a
@@ -477,7 +484,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
     const uint64_t wu = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv >> 32)))) << 32) |
                         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(wv)));
     const char* wf = reinterpret_cast<const char*>(static_cast<uintptr_t>(wu)) + static_cast<int64_t>(p) * (32 * 4) * w_ld;
-    float* dstb = w_s + (u & 1) * UB;
+    float* dstb = w_s + (u & RS) * UB;
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
       if constexpr (CT != 0) {
@@ -545,7 +552,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   // float4 (4 NK + blk) * 64 + lane.  Called BEFORE the barrier of the unit, behind the wait for the wave's own requests.
   auto cut_unit = [&](int u) {
     if (static_cast<int>(threadIdx.x) < 2 * NK * 64) {
-      const uint32_t a0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + (u & 1) * (UB * 4) + (2 * wave_u * 64 + lane) * 16;
+      const uint32_t a0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + (u & RS) * (UB * 4) + (2 * wave_u * 64 + lane) * 16;
       f32x4v x0, x1;
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(a0) : "memory");
       float r[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
@@ -554,7 +561,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
         u32x4v d;
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = __builtin_amdgcn_perm(__float_as_uint(r[2 * j + 1]), __float_as_uint(r[2 * j]), 0x07060302u);
-        const uint32_t ad = pc < 2 ? a0 + 1024 * pc : static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + (u & 1) * (UB * 4) + ((4 * NK + wave_u) * 64 + lane) * 16;
+        const uint32_t ad = pc < 2 ? a0 + 1024 * pc : static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + (u & RS) * (UB * 4) + ((4 * NK + wave_u) * 64 + lane) * 16;
         asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(d) : "memory");
         if (pc + 1 < NP) {
 #pragma unroll
@@ -565,10 +572,28 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
   };
   // acc = W_u . x for the 32 outputs of unit u (in LDS; CT != 0: cut into pieces), x the exponentiated tile of this wave
   auto unit_product = [&](int u, const float (&x)[NK][16], const u32x4v (&xp)[NP][2 * NK], f32x16& acc) {
-    const uint32_t wb = w_rd + (u & 1) * (UB * 4);
+    const uint32_t wb = w_rd + (u & RS) * (UB * 4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if constexpr (CT == 0) {
+    if constexpr (CT == 0 && NK == 2 && (CK_REGION_LABBITS & 1)) {  // LAB: two independent 16-deep chains, interleaved
+      f32x4v w0, w1, w2, w3, u0, u1, u2, u3;
+      lds_read4_off<0, 1024, 2048, 3072>(w0, w1, w2, w3, wb);
+      lds_read4_off<4096, 4096 + 1024, 4096 + 2048, 4096 + 3072>(u0, u1, u2, u3, wb);
+      const f32x4v* wg[4] = {&w0, &w1, &w2, &w3};
+      const f32x4v* ug[4] = {&u0, &u1, &u2, &u3};
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32((*wg[g])[e], x[0][4 * g + e], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32((*ug[g])[e], x[1][4 * g + e], acc2, 0, 0, 0);
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    } else if constexpr (CT == 0) {
       static_for<0, NK>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int o = q * 4096;
@@ -647,6 +672,7 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
     }
   }
   stage_w(0);
+  if constexpr (ONEB) stage_w(1);
   stage_tile(0);
 
   float A[NK][16];
@@ -700,26 +726,60 @@ __global__ void __launch_bounds__(WAVES * 64, MINW)
           for (int j = 0; j < 16; ++j) v[q][j] = __builtin_amdgcn_exp2f(fmaf(v[q][j], kL2E, nml));
       }
       u32x4v vp[NP][2 * NK];
+      f32x4v wn[8];  // (LAB bit 8)
       if (dense) cut_tile(v, vp);
       static_for<0, NK>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         const int u = t * NK + p;
         // unit u is in LDS: this wave's share has landed (at p = 0 by the wait at the top of the step; later units were
         // requested BEFORE the next tile, whose TD requests may still be in flight) -- and so have the other waves'
-        if constexpr (p > 0) {
+        if constexpr (p > 0 && !ONEB) {
           if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TD) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if constexpr (CT != 0) {
           if (dense) cut_unit(u);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... and every wave has left unit u - 1
-        if (u + 1 < TU) stage_w(u + 1);
+        if constexpr (!ONEB || p == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... and every wave has left unit u - 1
+        if constexpr (ONEB) {
+          if constexpr (p == 0) {
+            if (u + 2 < TU) stage_w(u + 2);
+            if (u + 3 < TU) stage_w(u + 3);
+          }
+        } else if (u + 1 < TU) stage_w(u + 1);
         if constexpr (p == 0) {
           if (t + 1 < T) stage_tile(t + 1);  // (the slot is free since its reads returned)
         }
         if (dense) {
           f32x16 acc;
+          if constexpr (ONEB && (CK_REGION_LABBITS & 8) != 0) {  // LAB: the operands of unit (t, 1) requested under the chain of (t, 0)
+            auto chain = [&](const f32x4v (&a)[8]) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + g][e], v[q][4 * g + e], acc, 0, 0, 0);
+            };
+            if constexpr (p == 0) {
+              f32x4v a[8];
+              const uint32_t wb0 = w_rd + (u & RS) * (UB * 4), wb1 = w_rd + ((u + 1) & RS) * (UB * 4);
+              lds_read4_off<0, 1024, 2048, 3072>(a[0], a[1], a[2], a[3], wb0);
+              lds_read4_off<4096, 4096 + 1024, 4096 + 2048, 4096 + 3072>(a[4], a[5], a[6], a[7], wb0);
+              asm volatile(
+                  "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+                  "ds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\tds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168"
+                  : "=&v"(wn[0]), "=&v"(wn[1]), "=&v"(wn[2]), "=&v"(wn[3]), "=&v"(wn[4]), "=&v"(wn[5]), "=&v"(wn[6]), "=&v"(wn[7])
+                  : "v"(wb1)
+                  : "memory");
+              chain(a);
+            } else {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              chain(wn);
+            }
+          } else
           unit_product(u, v, vp, acc);
           if constexpr (LINEAR) {  // P = prod_s G_s stays in linear space; the row's log scale is the sum of the m_s
 #pragma unroll
@@ -1082,7 +1142,8 @@ extern "C" int ck_region_lse_fwd_v(const float* arena, const int64_t* row_off, c
   const int waves = K == 64 ? 4 : 8;  // (both kernels: one 32-row tile per wave, the same workgroup <-> tiles mapping)
   const dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
   // every operand through the LDS DMA path (region_dma_kernel) unless a slot gathers table rows
-  const size_t lds_dma = (static_cast<size_t>(2) * (contraction == 6 ? 48 : 32) * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(H) * K) * sizeof(float);
+  size_t lds_dma = (static_cast<size_t>(2) * (contraction == 6 ? 48 : 32) * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(H) * K) * sizeof(float);
+  if ((CK_REGION_LABBITS & 4) != 0 && K == 64 && contraction == 0) lds_dma += 2 * 32 * K * sizeof(float);  // LAB
   const bool dma = g_var == nullptr && !ck::debug_force_generic() && lds_dma <= 80 * 1024 &&
                    static_cast<int64_t>(B) * K < (int64_t{1} << 30);
   auto exact = [=](hipStream_t s, int32_t* redo_ws) {  // region_lse_kernel: everything, or (redo_ws) the marked workgroups
@@ -1116,6 +1177,12 @@ extern "C" int ck_region_lse_fwd_v(const float* arena, const int64_t* row_off, c
           if (redo == nullptr) return K == 64 ? go(region_dma_kernel<2, 4, 2, false, false, 6>) : go(region_dma_kernel<1, 8, 2, false, false, 6>);
           const hipError_t e = K == 64 ? go(region_dma_kernel<2, 4, 2, true, false, 6>) : go(region_dma_kernel<1, 8, 2, true, false, 6>);
           return e != hipSuccess ? e : exact(s, redo);
+        }
+        if constexpr ((CK_REGION_LABBITS & 2) != 0) {  // LAB: two workgroups per CU (256 registers)
+          if (K == 64 && redo != nullptr) {
+            const hipError_t e2 = go(region_dma_kernel<2, 4, 2, true>);
+            return e2 != hipSuccess ? e2 : exact(s, redo);
+          }
         }
         if (redo == nullptr) return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
         const hipError_t e = K == 64 ? go(region_dma_kernel<2, 4, 3, true>) : go(region_dma_kernel<1, 8, 2, true>);
