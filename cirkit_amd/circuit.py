@@ -1534,14 +1534,15 @@ class HipCircuit:
         def gathers(slot_dense) -> bool:  # some slot reads a tabulated dense layer
             return any(int(d) in self._tdense for d in np.unique(slot_dense[..., 0]) if d >= 0)
 
-        dma = "2, 4, 3" if l.num_output_units == 64 else "1, 8, 2"  # (ck_cp.hip: region_dma_kernel<NK, WAVES, MINW, ..>)
+        # (ck_cp.hip: region_dma_kernel<NK, WAVES, MINW, LINEAR, BLOCK, CT>; bf16x6 at K = 64: two workgroups per CU)
+        dma = ("2, 4, 2" if self._ct == 6 else "2, 4, 3") if l.num_output_units == 64 else "1, 8, 2"
         if i in self._regions:
             if gathers(self._regions[i].slot_dense):
                 return "region_lse_kernel<2, 4, 3>" if l.num_output_units == 64 else "region_lse_kernel<1, 8, 4>"
-            return f"region_dma_kernel<{dma}, {'true' if self.linear_levels else 'false'}, false>"
+            return f"region_dma_kernel<{dma}, {'true' if self.linear_levels else 'false'}, false, {self._ct}>"
         if i in self._cp_blocks and self._cp_subset.get(i) is None and (
                 self._cp_blocks[i].slot_dense.shape[1] <= 8 or not gathers(self._cp_blocks[i].slot_dense)):
-            return f"region_dma_kernel<{dma}, false, true>"
+            return f"region_dma_kernel<{dma}, false, true, {self._ct}>"
         if i in self._cp_blocks or i in self._cp_leftover:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root and self._signed:
@@ -1600,8 +1601,10 @@ class HipCircuit:
                 return f"sum_lse_gemm_split_kernel<{n // 32 // sp}, {sp}, {'true' if cat else 'false'}>"
         if not self._complex and s.type == "tucker" and l.arity == 2 and l.num_input_units in (32, 64):
             wg1 = l.num_folds * ((l.num_output_units + 31) // 32) * ((B + 127) // 128)
-            if wg1 <= 8 * 3 * self._n_cu and self._scratch() is not None:  # (ck_gemm.hip tucker_lse: few tiles per slot)
-                return f"tucker_streamk_kernel<{l.num_input_units // 32}>"
+            # (ck_gemm.hip tucker_lse: few tiles per resident slot; the bf16 variants take the stream-K launch at any size)
+            if (wg1 <= 8 * 3 * self._n_cu or self._ct) and self._scratch() is not None:
+                logits = "true" if getattr(l, "_use_logits", False) or (l._logits_ok and l._theta is not None) else "false"
+                return f"tucker_streamk_kernel<{l.num_input_units // 32}, {logits}, {self._ct}, {4 if self._ct else 1}, {2 if self._ct else 3}>"
             return f"tucker_lse_kernel<{l.num_input_units // 32}>"
         return "sum_lse_generic"
 

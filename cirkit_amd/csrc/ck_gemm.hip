@@ -1023,7 +1023,9 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
     const int64_t slot_bytes = static_cast<int64_t>(slots) * 2 * 4 * 1024 * static_cast<int64_t>(sizeof(float));
     const int64_t stat_bytes = static_cast<int64_t>(slots) * 2 * 64 * static_cast<int64_t>(sizeof(float));
     const int64_t need = slot_bytes + stat_bytes + wg1 * 4;
-    if (wg1 <= 8 * static_cast<int64_t>(slots) && ws.ptr != nullptr && ws.bytes >= need && !ck::debug_force_generic()) {
+    // (the bf16 variants exist in this launch only and take it at any size: a chunk costs them a third to a half of the exact
+    // chain, the exponentials of a logits launch repeated per 128 rows included)
+    if ((wg1 <= 8 * static_cast<int64_t>(slots) || contraction != 0) && ws.ptr != nullptr && ws.bytes >= need && !ck::debug_force_generic()) {
       StreamKArgs a{};
       a.arena = arena;
       a.row_off = row_off;

@@ -701,24 +701,26 @@ class HipTuckerLayer(HipSumLayer):
             self._w = self.weight.evaluate(stream)  # (the per-node path evaluates the normalised weights)
 
     def launch(self, arena, row_off, out, B, stream) -> None:
-        if not self._use_logits:
-            if (self._contraction and not self.is_complex and self.arity == 2 and self.num_input_units in (32, 64)
-                    and self._w_layout == capi.CK_W_ROWMAJOR):
-                try:
-                    capi.call("ck_tucker_fwd", _ptr(arena), _ptr(row_off), _ptr(self._w), _ptr(out), self.num_folds, B,
-                              self.num_input_units, self.num_output_units, 0, self._contraction, stream)
-                    return
-                except NotImplementedError:
-                    pass
-            return super().launch(arena, row_off, out, B, stream)
-        try:
-            capi.call("ck_tucker_fwd", _ptr(arena), _ptr(row_off), _ptr(self._theta), _ptr(out),
-                      self.num_folds, B, self.num_input_units, self.num_output_units, 1, self._contraction, stream)
-        except NotImplementedError:
-            # many tiles per resident workgroup (a large batch): one workgroup per tile would exponentiate the weights once
-            # per 128 rows, so the normalised weights are written after all and the ordinary launch reads them
+        ct = self._contraction if (not self.is_complex and self.arity == 2 and self.num_input_units in (32, 64)) else 0
+        args = (self.num_folds, B, self.num_input_units, self.num_output_units)
+        if self._use_logits:
+            # the stream-K launch reads the logits and normalises them online.  With many tiles per resident workgroup (a large
+            # batch) the exact launch refuses them (NotImplementedError: one workgroup per tile would exponentiate the weights
+            # once per 128 rows) and the normalised weights are written after all; the bf16 variants take the logits at any
+            # size (measured: as fast as on written weights, and the prologue's pass over them is saved)
+            try:
+                capi.call("ck_tucker_fwd", _ptr(arena), _ptr(row_off), _ptr(self._theta), _ptr(out), *args, 1, ct, stream)
+                return
+            except NotImplementedError:
+                pass
             self._w = self.weight.evaluate(stream)
-            super().launch(arena, row_off, out, B, stream)
+        if ct and self._w_layout == capi.CK_W_ROWMAJOR:  # the labelled variants of the stream-K launch (any batch size)
+            try:
+                capi.call("ck_tucker_fwd", _ptr(arena), _ptr(row_off), _ptr(self._w), _ptr(out), *args, 0, ct, stream)
+                return
+            except NotImplementedError:
+                pass
+        super().launch(arena, row_off, out, B, stream)
 
 
 class HipTensorDotLayer(HipInnerLayer):

@@ -26,7 +26,7 @@ tensors = init_plan_tensors(plan)
 x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(0)).to(dev)
 outs = {}
 # (fused, contraction): the product, the prologue-normalised form, and the labelled bf16-split variants of the stream-K launch
-for fused in ((True, False, "bf16x3", "bf16x6") if not os.environ.get("ONLY") else os.environ["ONLY"].split(",")):
+for fused in ((True, False, "bf16x3", "bf16x6") if not os.environ.get("ONLY") else [{"True": True, "False": False}.get(v, v) for v in os.environ["ONLY"].split(",")]):
     hc = (HipCircuit(plan, tensors, device=dev, fused_weight_softmax=True, contraction=fused) if isinstance(fused, str)
           else HipCircuit(plan, tensors, device=dev, fused_weight_softmax=fused))
     for _ in range(5):
