@@ -3,7 +3,7 @@
 (-DCK_TUCKER_LABBITS=<bits>, wrong results on purpose; the bits are listed beside `kLab` in ck_gemm.hip) and the time of the
 largest layer of the notebook configuration (784 folds, K = 64, batch 128) under each.  The product library is not touched.
 
-    python scripts/exp_tucker_bf16.py [bits ...]"""
+    [BATCH=128] python scripts/exp_tucker_bf16.py [bits ...]      (BATCH=1024: every weight an L2 hit, HBM out of the picture)"""
 import os
 import subprocess
 import sys
@@ -31,7 +31,7 @@ with ThreadPoolExecutor(max_workers=8) as ex:
     libs = list(ex.map(make, bits))
 for b, lib in zip(bits, libs):
     env = dict(os.environ, CK_LIB=lib, ONLY="bf16x3,bf16x6", KERNELS="1")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_notebook.py"), "128", "10"], env=env, capture_output=True, text=True).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_notebook.py"), os.environ.get("BATCH", "128"), "10"], env=env, capture_output=True, text=True).stdout
     t = [l.split()[-2] for l in out.splitlines() if l.strip().startswith("layer   1 ")]
     tot = [l.split()[1] for l in out.splitlines() if l.startswith("contraction=")]
     print(f"bits {b:3d}: largest layer bf16x3 / bf16x6 = {' / '.join(t)} ms, forward {' / '.join(tot)} ms", flush=True)
