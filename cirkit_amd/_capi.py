@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -150,6 +150,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_lse_to_clse": [_p, _p, _l, _p],
     "ck_constant_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_sum_lse_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_sum_lse_fwd_v": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_tucker_logits_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_tucker_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_debug_force_generic": [_i],

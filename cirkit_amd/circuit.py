@@ -91,8 +91,9 @@ class HipCircuit:
             product, resp. fp32-like (tests/test_gpu_parity.py measures both against the fp64 goldens) -- and of the stream-K
             launch of Tucker layers with 32 / 64 units (`ck_tucker_fwd`: the weights are cut into pieces while they are
             staged, behind the online softmax's exponential), and of the DMA-staged region / CP-block launches
-            (`ck_region_lse_fwd_v`, `ck_cp_lse_fwd_v`: a weight unit is cut in LDS by the workgroup).  The tail, the
-            parameter jobs and every other launch stay exact fp32.
+            (`ck_region_lse_fwd_v`, `ck_cp_lse_fwd_v`: a weight unit is cut in LDS by the workgroup), and of the layer-wise
+            dense / CP-T launches with 64..256 contracted inputs (`ck_sum_lse_fwd_v`).  The tail, the parameter jobs and
+            every other launch stay exact fp32.
         dense_on_table: a Categorical input layer followed fold-by-fold by a dense sum layer only
             takes C distinct values per fold, so the dense layer is applied once per forward to the
             (F, C, K) log-probability table (same kernel, batch = C) instead of to every batch row;
@@ -233,6 +234,7 @@ class HipCircuit:
         for l in self.layers:  # Tucker weights softmax(theta): the launch reads the logits (ck_tucker_logits_fwd)
             if hasattr(l, "_logits_ok"):
                 l._logits_ok = bool(fused_weight_softmax)
+            if hasattr(l, "_contraction"):  # (sum layers: the launches that have a bf16-piece variant)
                 l._contraction = {"f32": 0, "bf16x3": 3, "bf16x6": 6}[contraction]
         self._folds = [l.num_folds for l in self.layers]
         self._complex = plan.semiring == "complex-lse-sum"

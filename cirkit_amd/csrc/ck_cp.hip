@@ -1031,12 +1031,12 @@ int launch_cp(const float* arena, const int64_t* row_off, const int64_t* w_addr,
 namespace ck {
 // Dense layer over the concatenation of H children, contiguous (F, K, H*K) weights, K in {32, 64}.
 int cat_dense(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,
-              void* stream) {
+              void* stream, int contraction) {
   constexpr int WAVES = 8;
   const int tiles = (B + 31) / 32;
   {  // as a region of H one-slot "partitionings" on the DMA-staged kernel (inputs and weights prefetched a step ahead)
     const int waves = K == 64 ? 4 : 8;
-    const size_t lds_dma = (static_cast<size_t>(2) * 32 * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(H) * K) * sizeof(float);
+    const size_t lds_dma = (static_cast<size_t>(2) * (contraction == 6 ? 48 : 32) * K + static_cast<size_t>(waves) * 32 * K + static_cast<size_t>(H) * K) * sizeof(float);
     if (lds_dma <= 80 * 1024 && static_cast<int64_t>(B) * K < (int64_t{1} << 30) && static_cast<int64_t>(H) * K * 32 * 4 < (int64_t{1} << 31) &&
         !ck::debug_force_generic()) {
       const dim3 grid((tiles + waves - 1) / waves, F), block(waves * 64);
@@ -1051,12 +1051,14 @@ int cat_dense(const float* arena, const int64_t* row_off, const float* w, float*
                                  static_cast<const int64_t*>(nullptr), GatherSlots{});
               return hipGetLastError();
             };
+            if (contraction == 3) return K == 64 ? go(region_dma_kernel<2, 4, 3, false, false, 3>) : go(region_dma_kernel<1, 8, 2, false, false, 3>);
+            if (contraction == 6) return K == 64 ? go(region_dma_kernel<2, 4, 2, false, false, 6>) : go(region_dma_kernel<1, 8, 2, false, false, 6>);
             return K == 64 ? go(region_dma_kernel<2, 4, 3, false>) : go(region_dma_kernel<1, 8, 2, false>);
           },
           stream);
     }
   }
-  dim3 grid((tiles + WAVES - 1) / WAVES, F), block(WAVES * 64);
+  dim3 grid((tiles + WAVES - 1) / WAVES, F), block(WAVES * 64);  // (exact fp32 whatever `contraction` says)
   return ck::dispatch(
       [=](hipStream_t s) {
         if (K == 64)

@@ -18,12 +18,20 @@
 namespace {
 
 // NQ: N / 32 (1..8).  CAT: the N inputs are the concatenation of H children of Ki units (else their product).
-template <int NQ, bool CAT>
+// CT: 0 = exact fp32 (the product); 3 / 6 = the labelled bf16-split VARIANTS (ck_tile.h contract_bf16; ck_cp.hip region_dma_kernel
+// has the same scheme): a staged block of weights is cut in LDS, in place, into P = 2 / 3 bf16 pieces by the threads that requested
+// it (thread (block of 16 inputs, lane) requests the two float4s of its lane it cuts; the third pieces go behind the block) while
+// the previous block is being contracted by nobody else's leave -- i.e. behind the wave's own chain; the exponentiated row block is
+// cut ONCE per row tile, and every 16 inputs cost 3 / 6 v_mfma_f32_32x32x16_bf16 instead of 8 v_mfma_f32_32x32x2_f32.
+template <int NQ, bool CAT, int CT = 0>
 __global__ void __launch_bounds__(256)
     sum_lse_gemm_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                         const float* __restrict__ w, float* __restrict__ out, int H, int B, int Ki, int Ko) {
   constexpr int N = 32 * NQ;
-  extern __shared__ __attribute__((aligned(16))) float w_s[];  // [2][NQ][4][64] float4
+  constexpr int P = CT == 0 ? 1 : CT / 3 + 1;
+  constexpr int BUF = CT == 6 ? NQ * 1536 : NQ * 1024;  // floats of one block buffer
+  constexpr int ITEMS = (NQ + 1) / 2;                   // CT != 0: (block of 16 inputs, lane) items per thread
+  extern __shared__ __attribute__((aligned(16))) float w_s[];  // [2][NQ][4][64] float4 (CT = 6: + [2 NQ][64] third pieces)
   const int f = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 31, kh = lane >> 5;
@@ -39,13 +47,52 @@ __global__ void __launch_bounds__(256)
   // during a whole block of MFMAs and a wave waits for its own share (vmcnt) before the barrier that publishes it
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto stage_async = [&](int p, int buf) {
-    float* dst = w_s + buf * (NQ * 1024);
+    float* dst = w_s + buf * BUF;
+    if constexpr (CT != 0) {
+#pragma unroll
+      for (int r = 0; r < ITEMS; ++r) {
+        const int blk = wave_u + 4 * r;  // (whole waves)
+        if (blk >= 2 * NQ) continue;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int q = blk >> 1, g = 2 * (blk & 1) + k;
+          const float* src = wf + static_cast<int64_t>(32 * p + (lane & 31)) * N + 32 * q + 8 * g + 4 * (lane >> 5);
+          __builtin_amdgcn_global_load_lds((ck::gptr_t)src, (ck::lptr_t)(dst + 4 * ((2 * blk + k) * 64)), 16, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
       const int i = threadIdx.x + 256 * k;
       const int ln = i & 63, g = (i >> 6) & 3, q = i >> 8;
       const float* src = wf + static_cast<int64_t>(32 * p + (ln & 31)) * N + 32 * q + 8 * g + 4 * (ln >> 5);
       __builtin_amdgcn_global_load_lds((ck::gptr_t)src, (ck::lptr_t)(dst + 4 * (256 * k + 64 * wave_u)), 16, 0, 0);
+    }
+  };
+  // CT != 0: this thread's items of the block in buffer `buf` (landed: behind the wave's own vmcnt wait), cut in place
+  auto cut_block = [&](int buf) {
+    const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + buf * (BUF * 4) + lane * 16;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      const int blk = wave_u + 4 * r;
+      if (blk >= 2 * NQ) continue;
+      const uint32_t a0 = base + 2 * blk * 1024;
+      f32x4v x0, x1;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x0), "=&v"(x1) : "v"(a0) : "memory");
+      float rr[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+      for (int pc = 0; pc < P; ++pc) {
+        u32x4v d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = __builtin_amdgcn_perm(__float_as_uint(rr[2 * j + 1]), __float_as_uint(rr[2 * j]), 0x07060302u);
+        const uint32_t ad = pc < 2 ? a0 + 1024 * pc : base + (4 * NQ + blk) * 1024;
+        asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(d) : "memory");
+        if (pc + 1 < P) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rr[j] -= __uint_as_float(__float_as_uint(rr[j]) & 0xffff0000u);  // exact
+        }
+      }
     }
   };
   stage_async(0, 0);
@@ -75,16 +122,71 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < 16; ++j) e[q][j] = __builtin_amdgcn_exp2f(fmaf(e[q][j], kL2E, nml));
 
+  // CT != 0: the B operands, piece pc of registers 8 m .. 8 m + 7 of input block q at [pc][2 q + m] (cut once per row tile)
+  u32x4v ep[P][2 * NQ];
+  if constexpr (CT != 0) {
+#pragma unroll
+    for (int pc = 0; pc < P; ++pc)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            ep[pc][2 * q + mh][d] = __builtin_amdgcn_perm(__float_as_uint(e[q][8 * mh + 2 * d + 1]), __float_as_uint(e[q][8 * mh + 2 * d]), 0x07060302u);
+        if (pc + 1 < P) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) e[q][j] -= __uint_as_float(__float_as_uint(e[q][j]) & 0xffff0000u);  // exact
+        }
+      }
+  }
+
+  if constexpr (CT != 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    cut_block(0);
+  }
   float* dst = out + (static_cast<int64_t>(f) * B + bl) * Ko + 4 * kh;
   for (int p = 0; p < npb; ++p) {
-    // this wave's share of block p has landed in LDS; block p is staged when every wave has; every wave has left block p - 1
+    // this wave's share of block p has landed in LDS (CT != 0: and is cut); block p is staged when every wave has; every wave has
+    // left block p - 1
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (p + 1 < npb) stage_async(p + 1, (p + 1) & 1);
     // (inline LDS reads: with plain loads the compiler waits for the block requested two lines above, ck_tile.h)
-    const uint32_t wb = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + (p & 1) * (NQ * 4096) + lane * 16;
+    const uint32_t wb = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(w_s)) + (p & 1) * (BUF * 4) + lane * 16;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (CT != 0) {
+      auto mm = [&](const f32x4v& ww, const u32x4v& y) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, ww), __builtin_bit_cast(bf16x8v, y), acc, 0, 0, 0);
+      };
+      static_for<0, NQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int o = q * 4096;
+        f32x4v w00, w01, w10, w11, w20, w21;
+        lds_read4_off<o, o + 1024, o + 2048, o + 3072>(w00, w01, w10, w11, wb);
+        if constexpr (P == 3) {
+          asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(w20), "=&v"(w21)
+                       : "v"(wb), "n"((4 * NQ + 2 * q) * 1024), "n"((4 * NQ + 2 * q + 1) * 1024)
+                       : "memory");
+          mm(w20, ep[0][2 * q]);  // (smallest terms first)
+          mm(w01, ep[1][2 * q]);
+          mm(w00, ep[2][2 * q]);
+        }
+        mm(w01, ep[0][2 * q]);
+        mm(w00, ep[1][2 * q]);
+        mm(w00, ep[0][2 * q]);
+        if constexpr (P == 3) {
+          mm(w21, ep[0][2 * q + 1]);
+          mm(w11, ep[1][2 * q + 1]);
+          mm(w10, ep[2][2 * q + 1]);
+        }
+        mm(w11, ep[0][2 * q + 1]);
+        mm(w10, ep[1][2 * q + 1]);
+        mm(w10, ep[0][2 * q + 1]);
+      });
+    } else
     static_for<0, NQ>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       constexpr int o = q * 4096;
@@ -108,6 +210,12 @@ __global__ void __launch_bounds__(256)
         o4.z = fmaf(__builtin_amdgcn_logf(acc[4 * g + 2]), kLN2, m);
         o4.w = fmaf(__builtin_amdgcn_logf(acc[4 * g + 3]), kLN2, m);
         *reinterpret_cast<float4*>(dst + 32 * p + 8 * g) = o4;
+      }
+    }
+    if constexpr (CT != 0) {  // block p + 1 (requested at the top of this step: in flight during the chain above) cut behind the chain
+      if (p + 1 < npb) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cut_block((p + 1) & 1);
       }
     }
   }
@@ -971,7 +1079,7 @@ __global__ void __launch_bounds__(256, OCC) tucker_streamk_kernel(const StreamKA
 }
 
 template <int NQ>
-hipError_t launch_nq(bool cat, dim3 grid, size_t lds, hipStream_t s, const float* arena, const int64_t* row_off,
+hipError_t launch_nq(bool cat, int ct, dim3 grid, size_t lds, hipStream_t s, const float* arena, const int64_t* row_off,
                      const float* w, float* out, int H, int B, int Ki, int Ko) {
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) {
@@ -982,6 +1090,8 @@ hipError_t launch_nq(bool cat, dim3 grid, size_t lds, hipStream_t s, const float
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, arena, row_off, w, out, H, B, Ki, Ko);
     return hipGetLastError();
   };
+  if (ct == 3) return cat ? go(sum_lse_gemm_kernel<NQ, true, 3>) : go(sum_lse_gemm_kernel<NQ, false, 3>);
+  if (ct == 6) return cat ? go(sum_lse_gemm_kernel<NQ, true, 6>) : go(sum_lse_gemm_kernel<NQ, false, 6>);
   return cat ? go(sum_lse_gemm_kernel<NQ, true>) : go(sum_lse_gemm_kernel<NQ, false>);
 }
 
@@ -1089,7 +1199,8 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
 
 // Real dense / CP-T layer with Ki, Ko multiples of 32 and at most 1024 contracted inputs.
 int sum_lse_gemm(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int Ki,
-                 int Ko, int mode, void* stream) {
+                 int Ko, int mode, void* stream, int contraction) {
+  const int ct = contraction;  // (up to 256 contracted inputs; the split launches beyond stay exact fp32)
   const bool cat = mode == CK_SUM_CAT && H > 1;
   const int nq = (cat ? H * Ki : Ki) / 32;
   if (nq > 8) {  // the inputs of a row tile are split over 2 or 4 waves
@@ -1106,20 +1217,20 @@ int sum_lse_gemm(const float* arena, const int64_t* row_off, const float* w, flo
         },
         stream);
   }
-  const size_t lds = static_cast<size_t>(2) * nq * 1024 * sizeof(float);
+  const size_t lds = static_cast<size_t>(2) * nq * (ct == 6 ? 1536 : 1024) * sizeof(float);
   const int tiles = (B + 31) / 32;
   dim3 grid((tiles + 3) / 4, F);
   return ck::dispatch(
       [=](hipStream_t s) {
         switch (nq) {
-          case 1: return launch_nq<1>(cat, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
-          case 2: return launch_nq<2>(cat, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
-          case 3: return launch_nq<3>(cat, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
-          case 4: return launch_nq<4>(cat, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
-          case 5: return launch_nq<5>(cat, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
-          case 6: return launch_nq<6>(cat, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
-          case 7: return launch_nq<7>(cat, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
-          default: return launch_nq<8>(cat, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
+          case 1: return launch_nq<1>(cat, ct, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
+          case 2: return launch_nq<2>(cat, ct, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
+          case 3: return launch_nq<3>(cat, ct, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
+          case 4: return launch_nq<4>(cat, ct, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
+          case 5: return launch_nq<5>(cat, ct, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
+          case 6: return launch_nq<6>(cat, ct, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
+          case 7: return launch_nq<7>(cat, ct, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
+          default: return launch_nq<8>(cat, ct, grid, lds, s, arena, row_off, w, out, H, B, Ki, Ko);
         }
       },
       stream);

@@ -57,9 +57,9 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
 // logits: w holds logits theta and the weights are softmax(theta) over the last axis, normalised online by the launch;
 // contraction: 0 exact fp32, 3 / 6 the bf16-split variants (stream-K launch only)
 int sum_lse_gemm(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int Ki,
-                 int Ko, int mode, void* stream);
+                 int Ko, int mode, void* stream, int contraction = 0);
 int cat_dense(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,
-              void* stream);
+              void* stream, int contraction = 0);
 int cp_single_slot(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int K,
                    void* stream);
 

@@ -581,15 +581,21 @@ int ck_debug_force_generic(int on) {
 
 int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
                    int H, int B, int Ki, int Ko, int mode, int w_layout, void* stream) {
+  return ck_sum_lse_fwd_v(arena, row_off, w, out, F, H, B, Ki, Ko, mode, w_layout, 0, stream);
+}
+
+int ck_sum_lse_fwd_v(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
+                     int H, int B, int Ki, int Ko, int mode, int w_layout, int contraction, void* stream) {
   if (int st = check_sum_args(arena, row_off, w, out, F, H, B, Ki, Ko, mode, "ck_sum_lse_fwd")) return st;
   CK_REQUIRE(w_layout == CK_W_ROWMAJOR || w_layout == CK_W_TILED_F32, "ck_sum_lse_fwd: unknown w_layout %d", w_layout);
+  CK_REQUIRE(contraction == 0 || contraction == 3 || contraction == 6, "ck_sum_lse_fwd_v: contraction %d (0, 3 or 6)", contraction);
   if (F > ck::kMaxFoldsPerLaunch) {  // (words of weights per fold: Ko x the contracted inputs, whatever the layout)
     int64_t nin = Ki;
     if (mode == CK_SUM_CAT) nin = static_cast<int64_t>(H) * Ki;
     if (mode == CK_SUM_KRON) for (int h = 1; h < H; ++h) nin *= Ki;
     return ck::chunk_folds(F, [&](int f0, int n) {
-      return ck_sum_lse_fwd(arena, row_off + static_cast<int64_t>(f0) * H, w + static_cast<int64_t>(f0) * Ko * nin, out + static_cast<int64_t>(f0) * B * Ko, n,
-                            H, B, Ki, Ko, mode, w_layout, stream);
+      return ck_sum_lse_fwd_v(arena, row_off + static_cast<int64_t>(f0) * H, w + static_cast<int64_t>(f0) * Ko * nin, out + static_cast<int64_t>(f0) * B * Ko, n,
+                              H, B, Ki, Ko, mode, w_layout, contraction, stream);
     });
   }
   const bool prod_like = mode == CK_SUM_PROD || H == 1;
@@ -620,11 +626,16 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
   }
   if (!g_force_generic && mode == CK_SUM_CAT && H > 1 && Ki == Ko && (Ki == 32 || Ki == 64) && ck::aligned16(arena) &&
       ck::aligned16(w) && ck::aligned16(out))
-    return ck::cat_dense(arena, row_off, w, out, F, H, B, Ki, stream);  // ck_cp.hip
+    return ck::cat_dense(arena, row_off, w, out, F, H, B, Ki, stream, contraction);  // ck_cp.hip
   if (!g_force_generic && ck::gemm_applies(H, Ki, Ko, mode) && ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out))
-    return ck::sum_lse_gemm(arena, row_off, w, out, F, H, B, Ki, Ko, mode, stream);  // ck_gemm.hip
-  if (!g_force_generic && ck::tucker_applies(H, Ki, Ko, mode) && ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out))
+    return ck::sum_lse_gemm(arena, row_off, w, out, F, H, B, Ki, Ko, mode, stream, contraction);  // ck_gemm.hip
+  if (!g_force_generic && ck::tucker_applies(H, Ki, Ko, mode) && ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out)) {
+    if (contraction != 0) {  // (the variants exist in the stream-K launch: where it does not apply, exact fp32)
+      const int st = ck::tucker_lse(arena, row_off, w, out, F, B, Ki, Ko, stream, false, contraction);
+      if (st != CK_ERR_UNSUPPORTED) return st;
+    }
     return ck::tucker_lse(arena, row_off, w, out, F, B, Ki, Ko, stream);  // ck_gemm.hip
+  }
   return launch_generic<float, float>(arena, row_off, w, out, F, H, B, Ki, Ko, mode, stream);
 }
 

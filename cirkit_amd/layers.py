@@ -530,6 +530,9 @@ class HipSumLayer(HipInnerLayer):
 
     _mode = capi.CK_SUM_CAT
 
+    # set by HipCircuit(contraction="bf16x3" / "bf16x6"): the launches that have a bf16-piece variant use it (`ck_sum_lse_fwd_v`)
+    _contraction = 0
+
     def __init__(
         self,
         num_input_units: int,
@@ -632,8 +635,8 @@ class HipSumLayer(HipInnerLayer):
             if w.is_complex():
                 raise ValueError("complex weights under the real lse-sum semiring")
             capi.call(
-                "ck_sum_lse_fwd", _ptr(arena), _ptr(row_off), _ptr(w), _ptr(out), self.num_folds, self.arity,
-                B, self.num_input_units, self.num_output_units, self._mode, self._w_layout, stream,
+                "ck_sum_lse_fwd_v", _ptr(arena), _ptr(row_off), _ptr(w), _ptr(out), self.num_folds, self.arity,
+                B, self.num_input_units, self.num_output_units, self._mode, self._w_layout, self._contraction, stream,
             )
 
 

@@ -146,6 +146,12 @@ int ck_constant_fwd(const float* value, float* out, int F, int B, int K, int log
  * out: (F, B, Ko). */
 int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
                    int H, int B, int Ki, int Ko, int mode, int w_layout, void* stream);
+/* ck_sum_lse_fwd with the contraction named: 0 = exact fp32 (what ck_sum_lse_fwd does); 3 / 6 = the labelled "bf16x3" / "bf16x6"
+ * VARIANTS (operands cut into 2 / 3 bf16 pieces with exact residuals, 3 / 6 products per 16 inputs on v_mfma_f32_32x32x16_bf16,
+ * fp32 accumulation) of the launches that have one: dense layers over concatenated children with 32 / 64 units, dense / CP-T
+ * layers with 96..256 contracted inputs, Tucker layers (stream-K launch).  Every other shape runs in exact fp32. */
+int ck_sum_lse_fwd_v(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
+                     int H, int B, int Ki, int Ko, int mode, int w_layout, int contraction, void* stream);
 /* Test hook: route ck_sum_lse_fwd through the shape-generic kernel even where the MFMA kernel
  * applies (A/B parity of the two implementations). */
 int ck_debug_force_generic(int on);

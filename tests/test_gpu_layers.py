@@ -315,6 +315,41 @@ def test_tucker_bf16_split_variants(hip_device, F, B, Ki, Ko, logits, capsys):
     assert err[0] <= 2e-6 and err[6] <= max(4.0 * err[0], 1e-6) and err[3] <= 1e-4
 
 
+@pytest.mark.parametrize("mode,F,H,B,Ki,Ko", [("cat", 3, 2, 300, 64, 64), ("cat", 2, 3, 130, 32, 32), ("cat", 2, 3, 77, 32, 96),
+                                              ("prod", 2, 2, 260, 128, 128), ("prod", 1, 1, 100, 256, 64), ("cat", 1, 7, 64, 32, 160),
+                                              ("prod", 2, 1, 40, 160, 32)])
+def test_dense_bf16_split_variants(hip_device, mode, F, H, B, Ki, Ko, capsys):
+    """`ck_sum_lse_fwd_v(contraction = 3 / 6)`: dense layers over concatenated children with 32 / 64 units (the DMA-staged region
+    launch) and dense / CP-T layers with 96..256 contracted inputs (`sum_lse_gemm_kernel<NQ, CAT, CT>`) on bf16 pieces -- against
+    the fp64 value of the layer: bf16x6 as close as the exact launch, bf16x3 within 5e-4 of a layer output of size ~5."""
+    from cirkit_amd import _capi as capi
+
+    g = torch.Generator().manual_seed(F + H + B + Ki + Ko)
+    N = H * Ki if mode == "cat" else Ki
+    w = torch.softmax(torch.randn(F, Ko, N, generator=g) * 1.5, dim=-1)
+    x = torch.randn(F, H, B, Ki, generator=g) * 3 - 4
+    x[0, 0, 1] = float("-inf")  # (prod: an impossible row; cat: a child without mass)
+    xin = (torch.cat([x[:, h] for h in range(H)], dim=-1) if mode == "cat" else x.sum(dim=1)).double()  # (F, B, N)
+    want = torch.logsumexp(xin[:, :, None, :] + torch.log(w.double())[:, None, :, :], dim=-1)
+    xd, wd = x.to(hip_device).contiguous(), w.to(hip_device).contiguous()
+    row_off = (torch.arange(F * H, dtype=torch.int64) * (B * Ki)).reshape(F, H).to(hip_device)
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    err = {}
+    for ct in (0, 3, 6):
+        out = torch.full((F, B, Ko), float("nan"), device=hip_device)
+        capi.call("ck_sum_lse_fwd_v", xd.data_ptr(), row_off.data_ptr(), wd.data_ptr(), out.data_ptr(), F, H, B, Ki, Ko,
+                  capi.CK_SUM_CAT if mode == "cat" else capi.CK_SUM_PROD, capi.CK_W_ROWMAJOR, ct, stream)
+        torch.cuda.synchronize()
+        got = out.cpu().double()
+        fin = torch.isfinite(want)
+        assert torch.equal(torch.isfinite(got), fin) and torch.equal(got[~fin], want[~fin])
+        err[ct] = float(((got[fin] - want[fin]).abs() / want[fin].abs().clamp_min(1.0)).max())
+    with capsys.disabled():
+        print(f"\n[dense bf16 variants {mode} F={F} H={H} B={B} Ki={Ki} Ko={Ko}] max rel err vs fp64: f32 {err[0]:.2e}, bf16x3 {err[3]:.2e}, bf16x6 {err[6]:.2e}")
+    assert err[0] <= 2e-6 and err[6] <= max(4.0 * err[0], 1e-6) and err[3] <= 5e-4
+    assert err[3] > err[6]  # (the three-product form is measurably coarser: the variant launch is what ran)
+
+
 def test_lse_edge_values(hip_device):
     """Rows that are entirely -inf give -inf (amax clamped to finfo.min, semiring.py:392-399), single
     finite entries survive, and a 200-nat spread does not underflow the result."""
