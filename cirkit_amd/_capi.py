@@ -145,6 +145,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_gaussian_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_gaussian_prod_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_embedding_clog_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ck_embedding_clog_c_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_embedding_log_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_categorical_clog_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ck_lse_to_clse": [_p, _p, _l, _p],
@@ -181,6 +182,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_bmm": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_param_einsum": [_p, _p],
     "ck_param_transpose_last2": [_p, _p, _l, _i, _i, _i, _i, _p],
+    "ck_param_transpose_last2_c": [_p, _p, _l, _i, _i, _i, _p],
     "ck_param_table_integral_row": [_p, _i, _i, _i, _i, _p],
     "ck_fill_f32": [_p, _l, _f, _p],
     "ck_sum_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -286,7 +286,8 @@ class HipCircuit:
         # that nobody else reads: they gather from its weight table, the Embedding output is never written
         self._emb_gather: dict[int, int] = {}
         self._emb_gather_dev: dict[int, tuple] = {}
-        if fuse is not False and self._complex:
+        # (the gather launch reads a REAL weight table: circuits with a complex parameter anywhere evaluate the Embedding layer)
+        if fuse is not False and self._complex and not any(self.store[n].is_complex() for n in self.store.names()):
             readers: dict[int, set[int]] = {}
             for j, ch in enumerate(self._children):
                 if ch is not None:

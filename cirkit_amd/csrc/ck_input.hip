@@ -92,6 +92,9 @@ int transpose_impl(const TI* x, TO* xt, int B, int D, void* stream, const char* 
 // MODE 2: complex log of the real table row (embedding, complex-lse-sum): (log|w|, w<0 ? pi : 0)
 // MODE 3: table row as a complex number with phase 0 (categorical, complex-lse-sum: the real log-likelihood mapped into
 //         the complex semiring, layers/input.py:276-278 + semiring.py:512-514)
+// MODE 4: complex log of a COMPLEX table row (embedding with complex weights under complex-lse-sum, input.py:258-266 +
+//         utils.py:32-35: torch.log of a complex number = (log|w|, arg w)); the row is K = 2 x units floats (re, im) and so
+//         is the output
 __device__ __forceinline__ float4 log4(float4 v) {
   return make_float4(__logf(v.x), __logf(v.y), __logf(v.z), __logf(v.w));
 }
@@ -127,6 +130,8 @@ __global__ void __launch_bounds__(256)
       float4* oc = reinterpret_cast<float4*>(out + 2 * o);
       oc[0] = make_float4(v.x, 0.f, v.y, 0.f);
       oc[1] = make_float4(v.z, 0.f, v.w, 0.f);
+    } else if (MODE == 4) {
+      *reinterpret_cast<float4*>(out + o) = make_float4(logf(hypotf(v.x, v.y)), atan2f(v.y, v.x), logf(hypotf(v.z, v.w)), atan2f(v.w, v.z));
     } else {
       const float pi = 3.14159265358979323846f;
       float4 l = make_float4(logf(fabsf(v.x)), logf(fabsf(v.y)), logf(fabsf(v.z)), logf(fabsf(v.w)));
@@ -160,6 +165,12 @@ __global__ void __launch_bounds__(256)
     } else if (MODE == 3) {
       out[2 * o] = v;
       out[2 * o + 1] = 0.f;
+    } else if (MODE == 4) {  // (k even: the real part of a unit; its imaginary part is the next float)
+      if ((k & 1) == 0) {
+        const float im = table[(static_cast<int64_t>(f) * (C + 1) + c) * K + k + 1];
+        out[o] = logf(hypotf(v, im));
+        out[o + 1] = atan2f(im, v);
+      }
     } else {
       out[2 * o] = logf(fabsf(v));
       out[2 * o + 1] = v < 0.f ? 3.14159265358979323846f : 0.f;
@@ -176,7 +187,7 @@ int gather_impl(const float* table, const int32_t* xt, const int64_t* scope, flo
   if (F > ck::kMaxFoldsPerLaunch)
     return ck::chunk_folds(F, [&](int f0, int n) {
       return gather_impl<MODE>(table + static_cast<int64_t>(f0) * (C + 1) * K, xt, scope + f0,
-                               out + static_cast<int64_t>(f0) * B * K * (MODE >= 2 ? 2 : 1), n, B, K, C, D, stream, who);
+                               out + static_cast<int64_t>(f0) * B * K * (MODE == 2 || MODE == 3 ? 2 : 1), n, B, K, C, D, stream, who);
     });
   const bool vec = (K % 4 == 0) && (K / 4 <= 256) && ck::aligned16(table) && ck::aligned16(out);
   if (vec) {
@@ -398,6 +409,12 @@ int ck_embedding_log_fwd(const float* table, const int32_t* xt, const int64_t* s
 int ck_embedding_clog_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out_c,
                           int F, int B, int K, int C, int D, void* stream) {
   return gather_impl<2>(table, xt, scope, out_c, F, B, K, C, D, stream, "ck_embedding_clog_fwd");
+}
+
+int ck_embedding_clog_c_fwd(const float* table_c, const int32_t* xt, const int64_t* scope, float* out_c,
+                            int F, int B, int K, int C, int D, void* stream) {
+  CK_REQUIRE(K > 0 && K <= (1 << 29), "ck_embedding_clog_c_fwd: K=%d", K);
+  return gather_impl<4>(table_c, xt, scope, out_c, F, B, 2 * K, C, D, stream, "ck_embedding_clog_c_fwd");
 }
 
 int ck_gaussian_fwd(const float* mean, const float* stddev, const float* log_partition,

@@ -140,21 +140,23 @@ __global__ void __launch_bounds__(256)
 }
 
 // (R, A, Bd) -> (R, Bd, A) through a 32x32 LDS tile, optional log.
+template <class T>
 __global__ void __launch_bounds__(256)
-    transpose_last2_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int Bd,
+    transpose_last2_kernel(const T* __restrict__ in, T* __restrict__ out, int A, int Bd,
                            int take_log, int out_rows) {
-  __shared__ float tile[32][33];
+  __shared__ T tile[32][33];
   const int64_t r = blockIdx.z;
-  const float* src = in + r * static_cast<int64_t>(A) * Bd;
-  float* dst = out + r * static_cast<int64_t>(A) * out_rows;
+  const T* src = in + r * static_cast<int64_t>(A) * Bd;
+  T* dst = out + r * static_cast<int64_t>(A) * out_rows;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // (32, 8)
   const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
 #pragma unroll
   for (int j = 0; j < 32; j += 8) {
     const int ai = a0 + ty + j, bi = b0 + tx;
     if (ai < A && bi < Bd) {
-      const float v = src[static_cast<int64_t>(ai) * Bd + bi];
-      tile[ty + j][tx] = take_log ? logf(v) : v;
+      const T v = src[static_cast<int64_t>(ai) * Bd + bi];
+      if constexpr (sizeof(T) == sizeof(float)) tile[ty + j][tx] = take_log ? logf(v) : v;
+      else tile[ty + j][tx] = v;
     }
   }
   __syncthreads();
@@ -167,12 +169,12 @@ __global__ void __launch_bounds__(256)
 
 // integral row of a gather table (F, C+1, K): mode 0 zeros (normalised probs), 1 logsumexp over the
 // C rows (unnormalised logits, TorchCategoricalLayer.log_partition_function input.py:414-421),
-// 2 ones (embedding tables: never selected, kept finite)
+// 2 ones (embedding tables: never selected, kept finite), 3 complex ones (K floats = K / 2 pairs (1, 0))
 __global__ void __launch_bounds__(256)
     table_integral_row_kernel(float* __restrict__ table, int C, int K, int mode) {
   float* t = table + static_cast<int64_t>(blockIdx.x) * (C + 1) * K;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float v = mode == 2 ? 1.f : 0.f;
+    float v = (mode == 2 || (mode == 3 && (k & 1) == 0)) ? 1.f : 0.f;
     if (mode == 1) {
       float mx = -INFINITY;
       for (int c = 0; c < C; ++c) mx = fmaxf(mx, t[c * K + k]);
@@ -1067,7 +1069,22 @@ int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int 
   dim3 grid((Bd + 31) / 32, (A + 31) / 32, static_cast<unsigned>(R)), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(transpose_last2_kernel, grid, block, 0, s, in, out, A, Bd, take_log, out_rows);
+        hipLaunchKernelGGL(transpose_last2_kernel<float>, grid, block, 0, s, in, out, A, Bd, take_log, out_rows);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_transpose_last2_c(const float* in_c, float* out_c, int64_t R, int A, int Bd, int out_rows, void* stream) {
+  CK_REQUIRE(in_c && out_c, "ck_param_transpose_last2_c: null pointer");
+  CK_REQUIRE(R > 0 && A > 0 && Bd > 0, "ck_param_transpose_last2_c: non-positive size");
+  CK_REQUIRE(out_rows >= Bd, "ck_param_transpose_last2_c: out_rows=%d < Bd=%d", out_rows, Bd);
+  CK_REQUIRE(R <= 65535, "ck_param_transpose_last2_c: R exceeds grid.z");
+  dim3 grid((Bd + 31) / 32, (A + 31) / 32, static_cast<unsigned>(R)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(transpose_last2_kernel<float2>, grid, block, 0, s, reinterpret_cast<const float2*>(in_c),
+                           reinterpret_cast<float2*>(out_c), A, Bd, 0, out_rows);
         return hipGetLastError();
       },
       stream);
@@ -1075,7 +1092,7 @@ int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int 
 
 int ck_param_table_integral_row(float* table, int F, int C, int K, int mode, void* stream) {
   CK_REQUIRE(table != nullptr, "ck_param_table_integral_row: null pointer");
-  CK_REQUIRE(F > 0 && C > 0 && K > 0 && mode >= 0 && mode <= 2, "ck_param_table_integral_row: bad arguments");
+  CK_REQUIRE(F > 0 && C > 0 && K > 0 && mode >= 0 && mode <= 3, "ck_param_table_integral_row: bad arguments");
   dim3 grid(F), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {

@@ -169,6 +169,18 @@ class _Embedding(torch.autograd.Function):
         F, K, C = weight.shape
         B = xi.shape[1]
         dev = xi.device
+        ctx.cplx_w = bool(weight.is_complex())
+        if ctx.cplx_w:  # complex weights: torch.log of a complex number, (log|w|, arg w) (utils.py:32-35)
+            table = torch.zeros((F, C + 1, K), dtype=torch.complex64, device=dev)
+            table[:, :C] = weight.detach().to(torch.complex64).transpose(1, 2)
+            scope = torch.arange(F, dtype=torch.int64, device=dev)
+            out = torch.empty((F, B, K), dtype=torch.complex64, device=dev)
+            with torch.cuda.device(dev):
+                capi.call("ck_embedding_clog_c_fwd", table.data_ptr(), xi.data_ptr(), scope.data_ptr(), out.data_ptr(), F, B, K, C, F,
+                          _stream(dev))
+            ctx.save_for_backward(xi, scope, table)
+            ctx.dims, ctx.dtype = (F, K, C, B), weight.dtype
+            return out
         # (F, C + 1, K) like every gather table (row C: the integral row of the marginal queries, not reachable from here)
         table = torch.zeros((F, C + 1, K), dtype=torch.float32, device=dev)
         table[:, :C] = weight.detach().to(torch.float32).transpose(1, 2)
@@ -185,6 +197,15 @@ class _Embedding(torch.autograd.Function):
     def backward(ctx, gout):
         xi, scope, table = ctx.saved_tensors
         F, K, C, B = ctx.dims
+        if ctx.cplx_w:  # ComplexSafeLog.backward (utils.py:44-47): gout / conj(w), scatter-added over the batch as float pairs
+            g = torch.view_as_real(gout.to(torch.complex64).contiguous()).reshape(F, B, 2 * K)
+            dtable = torch.zeros((F, C + 1, 2 * K), dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device):
+                capi.call("ck_categorical_bwd", g.data_ptr(), None, xi.data_ptr(), scope.data_ptr(), dtable.data_ptr(), F, B, 2 * K, C, 1,
+                          None, _stream(g.device))
+            num = torch.view_as_complex(dtable[:, :C].reshape(F, C, K, 2).contiguous())
+            dw = torch.where(num != 0, num / table[:, :C].conj(), torch.zeros_like(num))
+            return dw.transpose(1, 2).contiguous().to(ctx.dtype), None, None
         g = (gout.real if gout.is_complex() else gout).to(torch.float32).contiguous()
         dtable = torch.zeros((F, C + 1, K), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
@@ -379,9 +400,9 @@ def gaussian_log_likelihood(x: torch.Tensor, mean: torch.Tensor, stddev: torch.T
 
 def embedding(x: torch.Tensor, weight: torch.Tensor, *, complex_out: bool) -> torch.Tensor:
     """``TorchEmbeddingLayer.forward`` (input.py:258-266) mapped into lse-sum (log) / complex-lse-sum (complex log):
-    x (F, B, 1) states, weight (F, K, C) real -> (F, B, K)."""
-    if weight.is_complex():
-        raise ValueError("embedding: a real weight is expected")
+    x (F, B, 1) states, weight (F, K, C) real -- or complex under complex-lse-sum (rules/parameters.py:75-86) -> (F, B, K)."""
+    if weight.is_complex() and not complex_out:
+        raise ValueError("embedding: complex weights under the real lse-sum semiring")
     F, K, C = weight.shape
     xi = _discrete_input(x, C)
     return _Embedding.apply(weight, xi, bool(complex_out))

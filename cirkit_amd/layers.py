@@ -325,20 +325,29 @@ class HipEmbeddingLayer(HipInputLayer):
 
     def prepare(self, stream: int, batched: bool = False) -> None:
         v = self.weight.evaluate(stream)
-        if v.is_complex():
-            raise NotImplementedError("complex embedding weights")
         F, K, C = v.shape
-        if self._table is None or self._table.device != v.device:
+        if v.is_complex():
+            # complex weights (rules/parameters.py:75-86 compiles DataType.COMPLEX tensors): a complex table, the complex
+            # logarithm of its rows (`ck_embedding_clog_c_fwd`) -- under complex-lse-sum only, as in the reference, where the
+            # real lse-sum semiring cannot hold a complex value (semiring.py:383-408 works on real tensors)
+            if not self.is_complex:
+                raise ValueError("complex embedding weights under the real lse-sum semiring")
+            if self._table is None or self._table.device != v.device or self._table.dtype != torch.complex64:
+                self._table = torch.empty((F, C + 1, K), dtype=torch.complex64, device=v.device)
+            capi.call("ck_param_transpose_last2_c", _ptr(v), _ptr(self._table), F, K, C, C + 1, stream)
+            capi.call("ck_param_table_integral_row", _ptr(self._table), F, C, 2 * K, 3, stream)
+            return
+        if self._table is None or self._table.device != v.device or self._table.dtype != torch.float32:
             self._table = torch.empty((F, C + 1, K), dtype=torch.float32, device=v.device)
         capi.call("ck_param_transpose_last2", _ptr(v), _ptr(self._table), F, K, C, 0, C + 1, stream)
         capi.call("ck_param_table_integral_row", _ptr(self._table), F, C, K, 2, stream)
 
     def launch_input(self, xt, D, out, B, stream) -> None:
-        capi.call(
-            "ck_embedding_clog_fwd" if self.is_complex else "ck_embedding_log_fwd",
-            _ptr(self._table), _ptr(xt), _ptr(self._scope(xt.device)), _ptr(out),
-            self.num_folds, B, self.num_output_units, self.num_states, D, stream,
-        )
+        name = "ck_embedding_log_fwd"
+        if self.is_complex:
+            name = "ck_embedding_clog_c_fwd" if self._table.is_complex() else "ck_embedding_clog_fwd"
+        capi.call(name, _ptr(self._table), _ptr(xt), _ptr(self._scope(xt.device)), _ptr(out),
+                  self.num_folds, B, self.num_output_units, self.num_states, D, stream)
 
 
 class HipGaussianLayer(HipInputLayer):

@@ -118,6 +118,12 @@ int ck_gaussian_prod_fwd(const float* mean, const float* stddev, const float* lo
  * integral row sum_c weight[f,k,c], selected by a negative state as in ck_categorical_fwd). */
 int ck_embedding_clog_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out_c,
                           int F, int B, int K, int C, int D, void* stream);
+/* The same with COMPLEX weights (the reference compiles DataType.COMPLEX tensors, rules/parameters.py:75-86, and
+ * TorchEmbeddingLayer.forward maps them with torch.log of a complex number, input.py:258-266, utils.py:32-35): table_c
+ * (F, C+1, K) complex64 as float pairs (ck_param_transpose_last2_c + ck_param_table_integral_row mode 3 on 2 K floats);
+ * out_c[f, b, k] = (log|w|, arg w) of w = table_c[f, x[b, scope[f]], k]. */
+int ck_embedding_clog_c_fwd(const float* table_c, const int32_t* xt, const int64_t* scope, float* out_c,
+                            int F, int B, int K, int C, int D, void* stream);
 /* same under lse-sum (semiring.py:495-497): out = log(weight[...]) */
 int ck_embedding_log_fwd(const float* table, const int32_t* xt, const int64_t* scope, float* out,
                          int F, int B, int K, int C, int D, void* stream);
@@ -533,8 +539,11 @@ typedef struct ck_einsum_desc {
 int ck_param_einsum(const ck_einsum_desc* d, void* stream);
 int ck_param_transpose_last2(const float* in, float* out, int64_t R, int A, int Bd, int take_log,
                              int out_rows, void* stream);
+/* The same transposition of COMPLEX elements (float pairs), no logarithm. */
+int ck_param_transpose_last2_c(const float* in_c, float* out_c, int64_t R, int A, int Bd, int out_rows, void* stream);
 /* Integral row (row C) of a gather table (F, C+1, K): mode 0 zeros (normalised probabilities),
- * 1 logsumexp over the C category rows (unnormalised logits, input.py:414-421), 2 ones (embedding). */
+ * 1 logsumexp over the C category rows (unnormalised logits, input.py:414-421), 2 ones (embedding),
+ * 3 complex ones: K counts floats, the row becomes K / 2 pairs (1, 0) (embedding with complex weights). */
 int ck_param_table_integral_row(float* table, int F, int C, int K, int mode, void* stream);
 
 /* ---------------------------------------------------------------- backward (training) ------ */

@@ -340,3 +340,13 @@ def test_complex_semiring_backward(hip_device, F, H, B, Ki, Ko, wc):
     wd = w0.to(hip_device).requires_grad_(True)
     (ops.embedding(xc.to(hip_device), wd, complex_out=True) * c.to(hip_device)).real.sum().backward()
     _grads_close(wd.grad, wr.grad)
+    # Embedding with COMPLEX weights: torch.log of a complex number, gradient gout / conj(w) (utils.py:32-47)
+    wc0 = torch.complex(torch.randn(F, Ki, C, generator=g), torch.randn(F, Ki, C, generator=g))
+    wcr = wc0.to(torch.complex128).requires_grad_(True)
+    ref = torch.log(wcr)[idx[:, None], :, xc.squeeze(2)]
+    (ref * c.to(torch.complex128)).real.sum().backward()
+    wcd = wc0.to(hip_device).requires_grad_(True)
+    got = ops.embedding(xc.to(hip_device), wcd, complex_out=True)
+    assert float((got.detach().cpu().to(torch.complex128) - ref.detach()).abs().max()) <= 1e-5
+    (got * c.to(hip_device)).real.sum().backward()
+    assert float((wcd.grad.cpu().to(torch.complex128) - wcr.grad).abs().max()) <= 1e-4 * float(wcr.grad.abs().max())

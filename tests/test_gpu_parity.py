@@ -173,6 +173,37 @@ def test_sos_complex_circuit_and_partition(hip_device):
     _check_layers(plan_z, tensors, None, hz)
 
 
+@pytest.mark.parametrize("complex_sums", [False, True])
+def test_complex_embedding_weights(hip_device, complex_sums):
+    """Config 5's circuit c(x) with COMPLEX Embedding weights (the reference compiles DataType.COMPLEX tensors,
+    rules/parameters.py:75-86; TorchEmbeddingLayer.forward maps them with torch.log of a complex number, input.py:258-266):
+    the input layers gather a complex table and write (log|w|, arg w) (`ck_embedding_clog_c_fwd`), everything behind them
+    runs on the complex kernels.  Against the oracle in complex128 with the oracle's own complex64 error as yardstick."""
+    from cirkit_amd.circuit import HipCircuit
+    from oracle.torch_oracle import as_torch, evaluate_plan
+
+    plan, tensors, g = load_case("cfg5_sos_c_k32")
+    rng = np.random.default_rng(5)
+    emb = {n.config["tensor"] for sp in plan.layers if sp.type == "embedding" for n in sp.params["weight"].nodes if n.op == "tensor"}
+    t2 = {}
+    for k, v in tensors.items():
+        v = np.asarray(v)
+        if k in emb or (complex_sums and v.dtype.kind == "f"):
+            v = (v * np.exp(1j * rng.uniform(-np.pi, np.pi, v.shape))).astype(np.complex64)  # (same moduli, random phases)
+        t2[k] = v
+    x = _x_of(plan, g)
+    hc = HipCircuit(plan, t2, device=hip_device, use_graph=False)
+    assert not hc._signed and not hc._emb_gather
+    y = hc(x.to(hip_device)).cpu()
+    y64 = _fp64_outputs(plan, t2, x)[0]
+    y32 = evaluate_plan(plan, as_torch(t2), x)
+    d_ref = float((y32.real.double() - y64.real).abs().max())
+    assert torch.isfinite(y.real).all()
+    assert float((y.real.double() - y64.real).abs().max()) <= 4.0 * d_ref + 1e-4 * float(y64.real.abs().max())
+    assert float((torch.exp(1j * y.imag.double()) - torch.exp(1j * y64.imag)).abs().max()) <= 2e-2
+    _check_layers(plan, t2, x, hc)
+
+
 @pytest.mark.parametrize("name", ["sos_cat_c_qt4x4_k6", "sos_gauss_c_qt4x4_k4"])
 def test_real_input_layers_in_a_complex_circuit(hip_device, name):
     """SURVEY.md 8d config 5 in its other form: Categorical (logits) -- and Gaussian -- input layers under
