@@ -176,6 +176,9 @@ class _PlanBackward:
             elif isinstance(l, HipEmbeddingLayer):
                 # out = log(w[f, :, x]): the scatter-add of Re(gout) over the batch, divided by w
                 Cn = l.num_states
+                if l._table.is_complex():
+                    raise NotImplementedError("squared-circuit training: complex Embedding weights (the layer-level autograd of "
+                                              "cirkit_amd.layer_ops.embedding differentiates them)")
                 gr = real_part(g).contiguous()
                 dtable = torch.zeros((F, Cn + 1, K), dtype=torch.float32, device=gr.device)
                 capi.call("ck_categorical_bwd", gr.data_ptr(), None, bd.xt_i.data_ptr(), l._scope(gr.device).data_ptr(), dtable.data_ptr(),
