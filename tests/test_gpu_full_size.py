@@ -56,7 +56,9 @@ def test_full_batch_is_consistent_deterministic_and_matches_the_oracle(hip_devic
     want = evaluate_plan(plan, as_torch(tensors), x[rows])
     got = y[rows].cpu()
     if cfg == 5:
-        assert float((got.real - want.real).abs().max()) <= 2e-4 * float(want.real.abs().max())
+        e5 = float((got.real - want.real).abs().max()) / float(want.real.abs().max())
+        print(f"\n[config 5, full size] max rel err of Re c(x) against the oracle slice: {e5:.2e}")
+        assert e5 <= 1e-4  # (north_star's bar, as for the real configurations)
     else:
         assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
 
