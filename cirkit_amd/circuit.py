@@ -92,7 +92,7 @@ class HipCircuit:
             launch of Tucker layers with 32 / 64 units (`ck_tucker_fwd`: the weights are cut into pieces while they are
             staged, behind the online softmax's exponential), and of the DMA-staged region / CP-block launches
             (`ck_region_lse_fwd_v`, `ck_cp_lse_fwd_v`: a weight unit is cut in LDS by the workgroup), and of the layer-wise
-            dense / CP-T launches with 64..256 contracted inputs (`ck_sum_lse_fwd_v`).  The tail, the parameter jobs and
+            dense / CP-T launches with 64..512 contracted inputs (`ck_sum_lse_fwd_v`).  The tail, the parameter jobs and
             every other launch stay exact fp32.
         dense_on_table: a Categorical input layer followed fold-by-fold by a dense sum layer only
             takes C distinct values per fold, so the dense layer is applied once per forward to the

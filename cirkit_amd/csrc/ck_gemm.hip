@@ -226,7 +226,10 @@ __global__ void __launch_bounds__(256)
 // outputs every wave contracts its inputs against its slice of the weight rows and the S partial sums are added
 // through LDS in a fixed order.  Weights travel global -> registers -> LDS one step ahead of their use (steps of
 // QS input blocks per wave, two LDS buffers), as in the Tucker kernel below.
-template <int NQ, int S, bool CAT>
+// CT: 0 = exact fp32; 3 / 6 = the labelled bf16-split variants: a thread requests the two float4s of one lane that hold 16 inputs
+// (an item = (slice, input block, half, lane)), cuts their 8 weights into P = 2 / 3 bf16 pieces on the way to LDS (layout
+// [(slice, block, half)][piece][lane] x 8 bf16: one ds_read_b128 per operand), the exponentiated row block once per row tile.
+template <int NQ, int S, bool CAT, int CT = 0>
 __global__ void __launch_bounds__(256)
     sum_lse_gemm_split_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off,
                               const float* __restrict__ w, float* __restrict__ out, int H, int B, int Ki, int Ko) {
@@ -234,8 +237,10 @@ __global__ void __launch_bounds__(256)
   constexpr int R = 4 / S;                                    // row tiles per workgroup
   constexpr int QS = S == 4 ? 2 : (NQ % 2 == 0 ? NQ / 2 : NQ);  // input blocks per wave and step
   constexpr int STEPS = NQ / QS;
-  constexpr int CHUNK = S * QS * 1024;                        // floats per buffer
-  constexpr int PF = CHUNK / 4 / 256;
+  constexpr int P = CT == 0 ? 1 : CT / 3 + 1;
+  constexpr int CHUNK = CT == 6 ? S * QS * 1536 : S * QS * 1024;  // floats per buffer
+  constexpr int PF = S * QS * 1024 / 4 / 256;                 // float4s of a step per thread
+  static_assert(CT == 0 || PF % 2 == 0, "items of two float4s");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* w_s = smem;                    // [2][S][QS][4][64] float4
   float* red_s = smem + 2 * CHUNK;      // [4 waves][16][64] partial sums; first used for the row maxima
@@ -255,7 +260,9 @@ __global__ void __launch_bounds__(256)
     const int p = c / STEPS, h = c % STEPS;
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
-      const int i = threadIdx.x + 256 * k;
+      // CT != 0: float4s 2 r and 2 r + 1 of a thread are the two halves (g = 2 m, 2 m + 1) of item j = thread + 256 r
+      const int i = CT == 0 ? static_cast<int>(threadIdx.x) + 256 * k
+                            : ((((static_cast<int>(threadIdx.x) + 256 * (k >> 1)) >> 6) * 2 + (k & 1)) << 6) + lane;
       const int ln = i & 63, g = (i >> 6) & 3, qq = (i >> 8) % QS, s2 = (i >> 8) / QS;
       const float4 v = *reinterpret_cast<const float4*>(wf + static_cast<int64_t>(32 * p + (ln & 31)) * N +
                                                         32 * (s2 * NQ + h * QS + qq) + 8 * g + 4 * (ln >> 5));
@@ -267,6 +274,25 @@ __global__ void __launch_bounds__(256)
   };
   auto commit = [&](int buf) {
     float* dst = w_s + buf * CHUNK;
+    if constexpr (CT != 0) {
+#pragma unroll
+      for (int r = 0; r < PF / 2; ++r) {
+        const int j = static_cast<int>(threadIdx.x) + 256 * r;  // item: (slice, block, half) = j >> 6, lane = j & 63
+        float rr[8] = {pre[2 * r][0], pre[2 * r][1], pre[2 * r][2], pre[2 * r][3], pre[2 * r + 1][0], pre[2 * r + 1][1], pre[2 * r + 1][2], pre[2 * r + 1][3]};
+#pragma unroll
+        for (int pc = 0; pc < P; ++pc) {
+          u32x4v d;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) d[t] = __builtin_amdgcn_perm(__float_as_uint(rr[2 * t + 1]), __float_as_uint(rr[2 * t]), 0x07060302u);
+          *reinterpret_cast<u32x4v*>(dst + 4 * (((j >> 6) * P + pc) * 64 + lane)) = d;
+          if (pc + 1 < P) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) rr[t] -= __uint_as_float(__float_as_uint(rr[t]) & 0xffff0000u);  // exact
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < PF; ++k) *reinterpret_cast<float4*>(dst + 4 * (threadIdx.x + 256 * k)) = make_float4(pre[k][0], pre[k][1], pre[k][2], pre[k][3]);
   };
@@ -305,6 +331,23 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < 16; ++j) e[q][j] = __builtin_amdgcn_exp2f(fmaf(e[q][j], kL2E, nml));
   __syncthreads();  // the maxima have been read: red_s is free for the partial sums
+  u32x4v ep[P][2 * NQ];  // CT != 0: the B operands, piece pc of registers 8 m .. 8 m + 7 of input block q at [pc][2 q + m]
+  if constexpr (CT != 0) {
+#pragma unroll
+    for (int pc = 0; pc < P; ++pc)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            ep[pc][2 * q + mh][d] = __builtin_amdgcn_perm(__float_as_uint(e[q][8 * mh + 2 * d + 1]), __float_as_uint(e[q][8 * mh + 2 * d]), 0x07060302u);
+        if (pc + 1 < P) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) e[q][j] -= __uint_as_float(__float_as_uint(e[q][j]) & 0xffff0000u);  // exact
+        }
+      }
+  }
 
   float* dst = out + (static_cast<int64_t>(f) * B + bl) * Ko + 4 * kh;
   f32x16 acc;
@@ -316,11 +359,32 @@ __global__ void __launch_bounds__(256)
     __syncthreads();  // step c is in LDS; every wave has left step c - 1
     if (c + 1 < nsteps) commit((c + 1) & 1);
     fetch(c + 2 < nsteps ? c + 2 : nsteps - 1);  // (the last two fetches are redundant re-reads, never committed)
-    const float* wb = w_s + (c & 1) * CHUNK + sp * (QS * 1024);
+    const float* wb = w_s + (c & 1) * CHUNK + sp * (CT == 0 ? QS * 1024 : QS * 512 * P);
     const int h = c % STEPS;
 #pragma unroll
     for (int hh = 0; hh < STEPS; ++hh)  // static register indices: the body of the taken h only
       if (hh == h) {
+        if constexpr (CT != 0) {
+          const u32x4v* wp = reinterpret_cast<const u32x4v*>(wb) + lane;
+          auto mm = [&](const u32x4v& x, const u32x4v& y) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, x), __builtin_bit_cast(bf16x8v, y), acc, 0, 0, 0);
+          };
+#pragma unroll
+          for (int bq = 0; bq < 2 * QS; ++bq) {  // block bq = 2 qq + m of this slice
+            u32x4v wq[P];
+#pragma unroll
+            for (int pc = 0; pc < P; ++pc) wq[pc] = wp[(bq * P + pc) * 64];
+            const int eb = 2 * (hh * QS) + bq;
+            if constexpr (P == 3) {  // (smallest terms first)
+              mm(wq[2], ep[0][eb]);
+              mm(wq[1], ep[1][eb]);
+              mm(wq[0], ep[2][eb]);
+            }
+            mm(wq[1], ep[0][eb]);
+            mm(wq[0], ep[1][eb]);
+            mm(wq[0], ep[0][eb]);
+          }
+        } else
 #pragma unroll
         for (int qq = 0; qq < QS; ++qq)
 #pragma unroll
@@ -364,10 +428,10 @@ __global__ void __launch_bounds__(256)
 }
 
 template <int NQ, int S>
-hipError_t launch_split(bool cat, hipStream_t s, const float* arena, const int64_t* row_off, const float* w, float* out,
+hipError_t launch_split(bool cat, int ct, hipStream_t s, const float* arena, const int64_t* row_off, const float* w, float* out,
                         int F, int H, int B, int Ki, int Ko) {
   constexpr int QS = S == 4 ? 2 : (NQ % 2 == 0 ? NQ / 2 : NQ);
-  const size_t lds = (2 * S * QS * 1024 + 4 * 16 * 64) * sizeof(float);
+  const size_t lds = (2 * S * QS * (ct == 6 ? 1536 : 1024) + 4 * 16 * 64) * sizeof(float);
   const int tiles = (B + 31) / 32, R = 4 / S;
   const dim3 grid((tiles + R - 1) / R, F);
   auto go = [&](auto kern) {
@@ -379,6 +443,8 @@ hipError_t launch_split(bool cat, hipStream_t s, const float* arena, const int64
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, arena, row_off, w, out, H, B, Ki, Ko);
     return hipGetLastError();
   };
+  if (ct == 3) return cat ? go(sum_lse_gemm_split_kernel<NQ, S, true, 3>) : go(sum_lse_gemm_split_kernel<NQ, S, false, 3>);
+  if (ct == 6) return cat ? go(sum_lse_gemm_split_kernel<NQ, S, true, 6>) : go(sum_lse_gemm_split_kernel<NQ, S, false, 6>);
   return cat ? go(sum_lse_gemm_split_kernel<NQ, S, true>) : go(sum_lse_gemm_split_kernel<NQ, S, false>);
 }
 
@@ -1200,19 +1266,26 @@ int tucker_lse(const float* arena, const int64_t* row_off, const float* w, float
 // Real dense / CP-T layer with Ki, Ko multiples of 32 and at most 1024 contracted inputs.
 int sum_lse_gemm(const float* arena, const int64_t* row_off, const float* w, float* out, int F, int H, int B, int Ki,
                  int Ko, int mode, void* stream, int contraction) {
-  const int ct = contraction;  // (up to 256 contracted inputs; the split launches beyond stay exact fp32)
+  int ct = contraction;
   const bool cat = mode == CK_SUM_CAT && H > 1;
   const int nq = (cat ? H * Ki : Ki) / 32;
   if (nq > 8) {  // the inputs of a row tile are split over 2 or 4 waves
+    // (the variants: two-wave splits whose pieces fit in LDS; the four-wave splits -- 768, 1024 inputs, one wave per SIMD at 256
+    // registers -- measured slower on pieces than in exact fp32 and stay exact)
+    if (ct != 0) {
+      const int nqw = nq / 2, qs = nqw % 2 == 0 ? nqw / 2 : nqw;
+      const size_t need = (static_cast<size_t>(2) * 2 * qs * (ct == 6 ? 1536 : 1024) + 4 * 16 * 64) * sizeof(float);
+      if (nq > 16 || need > 160 * 1024) ct = 0;
+    }
     return ck::dispatch(
         [=](hipStream_t s) {
           switch (nq) {
-            case 10: return launch_split<5, 2>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
-            case 12: return launch_split<6, 2>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
-            case 14: return launch_split<7, 2>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
-            case 16: return launch_split<8, 2>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
-            case 24: return launch_split<6, 4>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
-            default: return launch_split<8, 4>(cat, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            case 10: return launch_split<5, 2>(cat, ct, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            case 12: return launch_split<6, 2>(cat, ct, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            case 14: return launch_split<7, 2>(cat, ct, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            case 16: return launch_split<8, 2>(cat, ct, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            case 24: return launch_split<6, 4>(cat, ct, s, arena, row_off, w, out, F, H, B, Ki, Ko);
+            default: return launch_split<8, 4>(cat, ct, s, arena, row_off, w, out, F, H, B, Ki, Ko);
           }
         },
         stream);

@@ -155,7 +155,7 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
 /* ck_sum_lse_fwd with the contraction named: 0 = exact fp32 (what ck_sum_lse_fwd does); 3 / 6 = the labelled "bf16x3" / "bf16x6"
  * VARIANTS (operands cut into 2 / 3 bf16 pieces with exact residuals, 3 / 6 products per 16 inputs on v_mfma_f32_32x32x16_bf16,
  * fp32 accumulation) of the launches that have one: dense layers over concatenated children with 32 / 64 units, dense / CP-T
- * layers with 96..256 contracted inputs, Tucker layers (stream-K launch).  Every other shape runs in exact fp32. */
+ * layers with 96..512 contracted inputs, Tucker layers (stream-K launch).  Every other shape runs in exact fp32. */
 int ck_sum_lse_fwd_v(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
                      int H, int B, int Ki, int Ko, int mode, int w_layout, int contraction, void* stream);
 /* Test hook: route ck_sum_lse_fwd through the shape-generic kernel even where the MFMA kernel

@@ -317,10 +317,12 @@ def test_tucker_bf16_split_variants(hip_device, F, B, Ki, Ko, logits, capsys):
 
 @pytest.mark.parametrize("mode,F,H,B,Ki,Ko", [("cat", 3, 2, 300, 64, 64), ("cat", 2, 3, 130, 32, 32), ("cat", 2, 3, 77, 32, 96),
                                               ("prod", 2, 2, 260, 128, 128), ("prod", 1, 1, 100, 256, 64), ("cat", 1, 7, 64, 32, 160),
-                                              ("prod", 2, 1, 40, 160, 32)])
+                                              ("prod", 2, 1, 40, 160, 32), ("prod", 1, 1, 70, 512, 64), ("cat", 1, 3, 40, 256, 32),
+                                              ("prod", 1, 1, 33, 1024, 32), ("prod", 2, 2, 50, 320, 64), ("cat", 1, 7, 20, 64, 32)])
 def test_dense_bf16_split_variants(hip_device, mode, F, H, B, Ki, Ko, capsys):
     """`ck_sum_lse_fwd_v(contraction = 3 / 6)`: dense layers over concatenated children with 32 / 64 units (the DMA-staged region
-    launch) and dense / CP-T layers with 96..256 contracted inputs (`sum_lse_gemm_kernel<NQ, CAT, CT>`) on bf16 pieces -- against
+    launch) and dense / CP-T layers with 96..1024 contracted inputs (`sum_lse_gemm_kernel<NQ, CAT, CT>`, beyond 256 inputs
+    `sum_lse_gemm_split_kernel<NQ, S, CAT, CT>`) on bf16 pieces -- against
     the fp64 value of the layer: bf16x6 as close as the exact launch, bf16x3 within 5e-4 of a layer output of size ~5."""
     from cirkit_amd import _capi as capi
 
@@ -347,7 +349,10 @@ def test_dense_bf16_split_variants(hip_device, mode, F, H, B, Ki, Ko, capsys):
     with capsys.disabled():
         print(f"\n[dense bf16 variants {mode} F={F} H={H} B={B} Ki={Ki} Ko={Ko}] max rel err vs fp64: f32 {err[0]:.2e}, bf16x3 {err[3]:.2e}, bf16x6 {err[6]:.2e}")
     assert err[0] <= 2e-6 and err[6] <= max(4.0 * err[0], 1e-6) and err[3] <= 5e-4
-    assert err[3] > err[6]  # (the three-product form is measurably coarser: the variant launch is what ran)
+    if N <= 512:
+        assert err[3] > err[6]  # (the three-product form is measurably coarser: the variant launch is what ran)
+    else:  # four-wave splits (768, 1024 inputs) have no variant: measured slower on pieces, they run in exact fp32
+        assert err[3] == err[0] and err[6] == err[0]
 
 
 def test_lse_edge_values(hip_device):
