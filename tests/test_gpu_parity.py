@@ -173,6 +173,30 @@ def test_sos_complex_circuit_and_partition(hip_device):
     _check_layers(plan_z, tensors, None, hz)
 
 
+def test_bf16_split_variants_of_a_wide_circuit_against_fp64(hip_device, capsys):
+    """`contraction="bf16x3"` / `"bf16x6"` on a circuit whose sum layers have 128 units (QuadTree 8x8, Categorical-256, CP-T):
+    the layer-wise dense / CP-T launches on bf16 pieces (`ck_sum_lse_fwd_v`), everything else exact.  Against the oracle's
+    fp64 evaluation of the whole circuit."""
+    from cirkit_amd.circuit import HipCircuit
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+
+    plan = image_data((1, 8, 8), "quad-tree-2", input_layer="categorical", num_input_units=128, sum_product_layer="cp-t",
+                      num_sum_units=128)
+    tensors = init_plan_tensors(plan, seed=4)
+    x = torch.randint(0, 256, (200, 64), generator=torch.Generator().manual_seed(3))
+    y64 = _fp64_outputs(plan, tensors, x)[0].reshape(-1).double()
+    err = {}
+    for c in ("f32", "bf16x3", "bf16x6"):
+        hc = HipCircuit(plan, tensors, device=hip_device, contraction=c)
+        y = hc(x.to(hip_device)).reshape(-1).double().cpu()
+        err[c] = float(((y - y64).abs() / y64.abs()).max())
+    with capsys.disabled():
+        print(f"\n[bf16 variants, K = 128 circuit] max rel err vs fp64: " + ", ".join(f"{c} {e:.2e}" for c, e in err.items()))
+    assert err["f32"] <= 1e-6 and err["bf16x6"] <= max(4.0 * err["f32"], 1e-6) and err["bf16x3"] <= 1e-4
+    assert err["bf16x3"] > err["bf16x6"]  # (the variant launches are what ran)
+
+
 @pytest.mark.parametrize("complex_sums", [False, True])
 def test_complex_embedding_weights(hip_device, complex_sums):
     """Config 5's circuit c(x) with COMPLEX Embedding weights (the reference compiles DataType.COMPLEX tensors,
