@@ -7,7 +7,7 @@
 //     gw_on = sum_b conj(exp(v_n - y_o)) gy_o            (real weights: the real part)
 // v is what the layer contracts: the concatenation of the children (CK_SUM_CAT), their sum (CK_SUM_PROD: a product in
 // log space) or, for Tucker layers (CK_SUM_KRON, optimized.py:89-103), v_(i0..iH-1) = sum_h x_h[i_h]; gv goes back to the
-// children accordingly.  A shape-generic kernel (correct, not fast): one workgroup per (fold, TB batch rows); the TB rows'
+// children accordingly.  A shape-generic kernel on the vector lanes: one workgroup per (fold, TB batch rows); the TB rows'
 // contributions to dW are added up in the workgroup before ONE atomic per weight entry.
 #include "ck_internal.h"
 
@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(256)
   c32* y_s = v_s + static_cast<size_t>(TB) * N;  // [TB][Ko]
   c32* g_s = y_s + static_cast<size_t>(TB) * Ko;  // [TB][Ko]
   c32* gv_s = g_s + static_cast<size_t>(TB) * Ko;  // [TB][N]
+  float* m_s = reinterpret_cast<float*>(gv_s + static_cast<size_t>(TB) * N);  // [TB] the rows' shifts
   const int f = blockIdx.y, b0 = blockIdx.x * TB;
   const int rows = min(TB, B - b0);
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
@@ -68,30 +69,36 @@ __global__ void __launch_bounds__(256)
     if constexpr (WC) return {wf[2 * (static_cast<int64_t>(o) * N + n)], wf[2 * (static_cast<int64_t>(o) * N + n) + 1]};
     else return {wf[static_cast<int64_t>(o) * N + n], 0.f};
   };
-  // gv[r][n] = sum_o conj(w_on exp(v_n - y_o)) gy_o
+  // exp(v_n - y_o) = a_n b_o with a_n = exp(v_n - m), b_o = exp(m - y_o) and m the row's largest real part (the shift of the
+  // forward, semiring.py:441-476): N + Ko complex exponentials per row instead of two per (n, o) pair.  With
+  // t_o = conj(b_o) gy_o:   gv_n = conj(a_n) sum_o conj(w_on) t_o,   dW_on = sum_r conj(a_n) t_o.
+  for (int r = tid; r < rows; r += 256) {
+    float m = -INFINITY;
+    for (int n = 0; n < N; ++n) m = fmaxf(m, v_s[r * N + n].re);
+    m_s[r] = ck::clamp_finite(m);
+  }
+  __syncthreads();
+  for (int i = tid; i < rows * N; i += 256) {
+    const c32 v = v_s[i];
+    v_s[i] = cexp({v.re - m_s[i / N], v.im});  // a
+  }
+  for (int i = tid; i < rows * Ko; i += 256) {
+    const c32 g = g_s[i], y = y_s[i];
+    // (an output that receives no gradient contributes nothing -- also where y = -inf and b would be infinite)
+    g_s[i] = (g.re == 0.f && g.im == 0.f) ? c32{0.f, 0.f} : cmul(cconj(cexp({m_s[i / Ko] - y.re, -y.im})), g);  // t
+  }
+  __syncthreads();
   for (int i = tid; i < rows * N; i += 256) {
     const int r = i / N, n = i - r * N;
-    const c32 v = v_s[i];
     c32 acc{0.f, 0.f};
-    for (int o = 0; o < Ko; ++o) {
-      const c32 y = y_s[r * Ko + o];
-      const c32 g = g_s[r * Ko + o];
-      if (g.re == 0.f && g.im == 0.f) continue;  // (also skips exp(v - y) of a y = -inf that receives no gradient)
-      const c32 e = cexp({v.re - y.re, v.im - y.im});
-      acc = ck::c_add(acc, cmul(cconj(cmul(weight(o, n), e)), g));
-    }
-    gv_s[i] = acc;
+    for (int o = 0; o < Ko; ++o) acc = ck::c_add(acc, cmul(cconj(weight(o, n)), g_s[r * Ko + o]));
+    gv_s[i] = cmul(cconj(v_s[i]), acc);
   }
-  // dW[o][n] += sum_r conj(exp(v_n - y_o)) gy_o
+  // dW[o][n] += sum_r conj(a_n) t_o
   for (int i = tid; i < Ko * N; i += 256) {
     const int o = i / N, n = i - o * N;
     c32 acc{0.f, 0.f};
-    for (int r = 0; r < rows; ++r) {
-      const c32 g = g_s[r * Ko + o];
-      if (g.re == 0.f && g.im == 0.f) continue;
-      const c32 v = v_s[r * N + n], y = y_s[r * Ko + o];
-      acc = ck::c_add(acc, cmul(cconj(cexp({v.re - y.re, v.im - y.im})), g));
-    }
+    for (int r = 0; r < rows; ++r) acc = ck::c_add(acc, cmul(cconj(v_s[r * N + n]), g_s[r * Ko + o]));
     float* d = dw + (static_cast<int64_t>(f) * Ko * N + i) * (WC ? 2 : 1);
     atomicAdd(d, acc.re);
     if constexpr (WC) atomicAdd(d + 1, acc.im);
@@ -133,9 +140,11 @@ extern "C" int ck_sum_lse_bwd_c(const float* arena_c, float* garena_c, const int
   int64_t N = Ki;
   if (mode == CK_SUM_CAT) N = static_cast<int64_t>(H) * Ki;
   if (mode == CK_SUM_KRON) for (int h = 1; h < H; ++h) N *= Ki;
-  int TB = 8;
-  while (TB > 1 && static_cast<int64_t>(TB) * (2 * N + 2 * Ko) * 8 > 96 * 1024) TB /= 2;
-  const size_t lds = static_cast<size_t>(TB) * (2 * N + 2 * Ko) * 8;
+  // rows per workgroup: as many as 64 KiB of LDS hold (two workgroups per CU) -- every workgroup ends with one float atomic per
+  // weight entry, 64 rows instead of 8 are an eighth of them
+  int TB = 64;
+  while (TB > 1 && static_cast<int64_t>(TB) * ((2 * N + 2 * Ko) * 8 + 4) > 64 * 1024) TB /= 2;
+  const size_t lds = static_cast<size_t>(TB) * ((2 * N + 2 * Ko) * 8 + 4);
   if (lds > 128 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_sum_lse_bwd_c: %lld contracted inputs do not fit the LDS", static_cast<long long>(N));
   const dim3 grid((B + TB - 1) / TB, F), block(256);
   const int Ni = static_cast<int>(N);
