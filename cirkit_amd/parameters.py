@@ -556,7 +556,17 @@ class HipParameter:
                         raise NotImplementedError(f"parameter backward through einsum {n.config['einsum']}: operand {k} carries an index "
                                                   "that is summed out on its own or repeated")
                     spec = [out_idx, *[ins[m] for m in others], ins[k]]
-                    dk = self._einsum(("ge", j, k), spec, [dj.contiguous(), *[xs[m] for m in others]], stream)
+                    ops_k = [dj.contiguous(), *[xs[m] for m in others]]
+                    mb = _einsum_as_bmm(spec, [tuple(x.shape[1:]) for x in ops_k]) if len(ops_k) == 2 else None
+                    if mb is None:
+                        dk = self._einsum(("ge", j, k), spec, ops_k, stream)
+                    else:  # a product of per-fold matrices (the Gram / Kronecker parameters of a squared circuit): the MFMA-free
+                        # batched matmul instead of the index-generic kernel (0.85 ms -> tens of us per node at config 5)
+                        swap, M, N, Kd, ta, tb = mb
+                        a, b = (ops_k[1], ops_k[0]) if swap else (ops_k[0], ops_k[1])
+                        a, b = a.contiguous(), b.contiguous()
+                        dk = self._buf(("ge", j, k), (a.shape[0], M, N))
+                        capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(dk), a.shape[0], M, N, Kd, ta, tb, stream)
                     scatter((j, k), n.inputs[k], dk)
             elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
                 m1, s1, m2, s2 = (operand(j, k).contiguous() for k in range(4))
