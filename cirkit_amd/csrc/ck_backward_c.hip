@@ -10,6 +10,7 @@
 // children accordingly.  A shape-generic kernel on the vector lanes: one workgroup per (fold, TB batch rows); the TB rows'
 // contributions to dW are added up in the workgroup before ONE atomic per weight entry.
 #include "ck_internal.h"
+#include "ck_bwd_tile.h"
 
 namespace {
 
@@ -128,6 +129,123 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same for the shape the squared circuits are made of -- REAL weights, 32 -> 32 units, a product of H children or one child --
+// on the matrix instructions.  With a = exp(v - m) and t = conj(exp(m - y)) gy (both complex, m the row's shift):
+//     gv = conj(a) (W^T t_re + i W^T t_im)          dW = t_re^T a_re + t_im^T a_im
+// i.e. four real 32 x 32 contractions per 32-row tile, the ones of the real backward (ck_bwd_tile.h: child_gradient,
+// dw_accumulate).  A workgroup = four waves walking the row tiles of one fold with dW in registers; one float atomic per weight
+// entry and workgroup at the end.
+__global__ void __launch_bounds__(256)
+    sum_clse_bwd_tile32(const c32* __restrict__ arena, c32* __restrict__ garena, const int64_t* __restrict__ row_off,
+                        const float* __restrict__ w, const c32* __restrict__ out, const c32* __restrict__ gout,
+                        float* __restrict__ dw, int H, int B) {
+  __shared__ __attribute__((aligned(16))) float wt_s[1024];        // W^T, "transposed tiled" (child_gradient)
+  __shared__ __attribute__((aligned(16))) float scr_s[4][2][1024];  // per wave: the two operands of dw_accumulate
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const float* wf = w + static_cast<int64_t>(f) * 1024;
+  for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    const int q = idx >> 8, ln = (idx >> 2) & 63, t = idx & 3;
+    wt_s[idx] = wf[(8 * q + 4 * (ln >> 5) + t) * 32 + (ln & 31)];
+  }
+  __syncthreads();
+  // 4 complex units = 8 floats: units 8 g + 4 kh + t of a row of 32 complex numbers
+  auto load_c = [&](const c32* row, float (&re)[16], float (&im)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4* p = reinterpret_cast<const float4*>(row + 8 * g + 4 * kh);
+      const float4 x = p[0], y = p[1];
+      re[4 * g + 0] = x.x; im[4 * g + 0] = x.y; re[4 * g + 1] = x.z; im[4 * g + 1] = x.w;
+      re[4 * g + 2] = y.x; im[4 * g + 2] = y.y; re[4 * g + 3] = y.z; im[4 * g + 3] = y.w;
+    }
+  };
+  f32x16 dacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+  float ones[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ones[r] = 1.f;
+  const int tiles = (B + 31) / 32;
+  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    const int b = tile * 32 + b_in;
+    const bool live = b < B;
+    const int64_t bl = live ? b : B - 1;
+    float vre[16], vim[16];
+    load_c(arena + ro[0] + bl * 32, vre, vim);
+    for (int h = 1; h < H; ++h) {
+      float xr[16], xi[16];
+      load_c(arena + ro[h] + bl * 32, xr, xi);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        vre[j] += xr[j];
+        vim[j] += xi[j];
+      }
+    }
+    float m = vre[0];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) m = fmaxf(m, vre[j]);
+    m = ck::clamp_finite(ck::xhalf_max(m));
+    float are[16], aim[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const c32 a = ck::c_exp_shift_tile({vre[j], vim[j]}, m);
+      are[j] = a.re;
+      aim[j] = a.im;
+    }
+    float tre[16], tim[16];
+    {
+      float yre[16], yim[16], gre[16], gim[16];
+      load_c(out + (static_cast<int64_t>(f) * B + bl) * 32, yre, yim);
+      load_c(gout + (static_cast<int64_t>(f) * B + bl) * 32, gre, gim);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        // conj(exp(m - y)) = exp(m - y_re) (cos y_im + i sin y_im); an output without gradient contributes nothing (also
+        // where y = -inf and the factor would be infinite)
+        const bool on = live && !(gre[j] == 0.f && gim[j] == 0.f);
+        const c32 cb = ck::c_exp_shift_tile({-yre[j], yim[j]}, -m);
+        tre[j] = on ? cb.re * gre[j] - cb.im * gim[j] : 0.f;
+        tim[j] = on ? cb.re * gim[j] + cb.im * gre[j] : 0.f;
+      }
+    }
+    float Gre[16], Gim[16];
+    child_gradient(wt_s, lane, tre, ones, Gre);
+    child_gradient(wt_s, lane, tim, ones, Gim);
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 x, y;  // conj(a) G
+        x.x = are[4 * g + 0] * Gre[4 * g + 0] + aim[4 * g + 0] * Gim[4 * g + 0];
+        x.y = are[4 * g + 0] * Gim[4 * g + 0] - aim[4 * g + 0] * Gre[4 * g + 0];
+        x.z = are[4 * g + 1] * Gre[4 * g + 1] + aim[4 * g + 1] * Gim[4 * g + 1];
+        x.w = are[4 * g + 1] * Gim[4 * g + 1] - aim[4 * g + 1] * Gre[4 * g + 1];
+        y.x = are[4 * g + 2] * Gre[4 * g + 2] + aim[4 * g + 2] * Gim[4 * g + 2];
+        y.y = are[4 * g + 2] * Gim[4 * g + 2] - aim[4 * g + 2] * Gre[4 * g + 2];
+        y.z = are[4 * g + 3] * Gre[4 * g + 3] + aim[4 * g + 3] * Gim[4 * g + 3];
+        y.w = are[4 * g + 3] * Gim[4 * g + 3] - aim[4 * g + 3] * Gre[4 * g + 3];
+        for (int h = 0; h < H; ++h) {
+          float4* p = reinterpret_cast<float4*>(garena + ro[h] + bl * 32 + 8 * g + 4 * kh);
+          p[0] = x;
+          p[1] = y;
+        }
+      }
+    }
+    dw_accumulate(dacc, scr_s[wave][0], scr_s[wave][1], b_in, kh, tre, are);
+    dw_accumulate(dacc, scr_s[wave][0], scr_s[wave][1], b_in, kh, tim, aim);
+  }
+  // D[o][i] sits in lane (i, hi) register r with o = 8 (r >> 2) + 4 hi + (r & 3): the four waves' sums through LDS
+  __syncthreads();
+  float* red = &scr_s[0][0][0];  // [4][1024]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + (8 * (r >> 2) + 4 * kh + (r & 3)) * 32 + b_in] = dacc[r];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    const float v = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+    if (v != 0.f) atomicAdd(dw + static_cast<int64_t>(f) * 1024 + idx, v);
+  }
+}
+
 }  // namespace
 
 extern "C" int ck_sum_lse_bwd_c(const float* arena_c, float* garena_c, const int64_t* row_off, const float* w, const float* out_c,
@@ -137,6 +255,18 @@ extern "C" int ck_sum_lse_bwd_c(const float* arena_c, float* garena_c, const int
   CK_REQUIRE(F > 0 && H > 0 && B > 0 && Ki > 0 && Ko > 0, "ck_sum_lse_bwd_c: non-positive size");
   CK_REQUIRE(mode == CK_SUM_CAT || mode == CK_SUM_PROD || mode == CK_SUM_KRON, "ck_sum_lse_bwd_c: unknown mode %d", mode);
   CK_REQUIRE(F <= 65535, "ck_sum_lse_bwd_c: F=%d exceeds grid.y", F);
+  if (!w_is_complex && Ki == 32 && Ko == 32 && (mode == CK_SUM_PROD || H == 1) && ck::aligned16(arena_c) && ck::aligned16(garena_c) &&
+      ck::aligned16(out_c) && ck::aligned16(gout_c)) {  // (offsets in row_off are multiples of 32 complex numbers per row)
+    const int tiles = (B + 31) / 32;
+    const dim3 grid(static_cast<unsigned>(std::max(1, std::min((tiles + 3) / 4, 16))), F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          hipLaunchKernelGGL(sum_clse_bwd_tile32, grid, block, 0, s, reinterpret_cast<const ck::c32*>(arena_c), reinterpret_cast<ck::c32*>(garena_c),
+                             row_off, w, reinterpret_cast<const ck::c32*>(out_c), reinterpret_cast<const ck::c32*>(gout_c), dw, H, B);
+          return hipGetLastError();
+        },
+        stream);
+  }
   int64_t N = Ki;
   if (mode == CK_SUM_CAT) N = static_cast<int64_t>(H) * Ki;
   if (mode == CK_SUM_KRON) for (int h = 1; h < H; ++h) N *= Ki;

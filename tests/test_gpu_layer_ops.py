@@ -289,7 +289,8 @@ def test_products_and_inputs_backward(hip_device):
     assert float((vd.grad.cpu().to(torch.complex128) - vr.grad).abs().max()) <= 1e-4 * float(vr.grad.abs().max())
 
 
-@pytest.mark.parametrize("F,H,B,Ki,Ko,wc", [(2, 2, 7, 16, 4, False), (3, 1, 33, 32, 32, False), (2, 2, 9, 8, 6, True), (2, 3, 5, 4, 3, True)])
+@pytest.mark.parametrize("F,H,B,Ki,Ko,wc", [(2, 2, 7, 16, 4, False), (3, 1, 33, 32, 32, False), (2, 2, 9, 8, 6, True), (2, 3, 5, 4, 3, True),
+                                           (2, 2, 1000, 32, 32, False)])
 def test_complex_semiring_backward(hip_device, F, H, B, Ki, Ko, wc):
     """Backward through complex-lse-sum (ComplexLSESumSemiring.apply_reduce, semiring.py:441-476; ComplexSafeLog,
     utils.py:22-50): `sum_lse` (three modes, real or complex weights), `hadamard` and `embedding` under autograd against
