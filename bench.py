@@ -260,6 +260,12 @@ def live_pmc(argv_child: list[str], timeout_s: float = 200.0) -> dict | None:
 
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         env = dict(os.environ, TMPDIR="/tmp", CIRKIT_BENCH_NO_PMC="1")
+        # rank 0 of an N > 1 run profiles a plain single-process child on its own device (the other ranks wait at the
+        # closing barrier): nothing of the launcher's rendezvous may reach it
+        for k in list(env):
+            if k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "MASTER_ADDR",
+                     "MASTER_PORT", "BENCH_FORCE_DIST") or k.startswith(("TORCHELASTIC_", "GROUP_WORLD_", "ROLE_WORLD_")):
+                env.pop(k)
         # pass 0: kernel trace alone (no counters): the launch durations the profiler sees, warm -- 1500 steps, the last
         # 50 dispatches of every kernel averaged.  HIP events around every launch (the instrumented pass of
         # profile_kernels) stretch a launch by a few microseconds; this is the figure a rocprofv3 --stats summary gives.
@@ -685,7 +691,9 @@ def main() -> None:
             },
         }
         pmc, pmc_source = None, None
-        if world == 1 and not args.no_live_pmc:
+        # (at N > 1 too: rank 0 measures its own device after the timed region while the other ranks wait at the closing
+        #  barrier -- the N > 1 line carries the same `roofline` and `cpu_baseline` as the N = 1 line)
+        if not args.no_live_pmc and local_rank == 0:
             child = ["--batch", str(B), "--fuse", str(args.fuse), "--contraction", args.contraction, "--batches", str(nb)]
             if args.no_graph:
                 child.append("--no-graph")
@@ -810,7 +818,7 @@ def main() -> None:
                          "achieved": roof["forward"]["achieved_GBps"], "frac": roof["forward"]["frac_of_8TBps"], "traffic": None})
         result["roofline"] = roof
 
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:  # (rank 0, any N: timed on the host cores while the other ranks wait at the closing barrier)
             from oracle.torch_oracle import as_torch, evaluate_plan
 
             tt = as_torch(tensors)

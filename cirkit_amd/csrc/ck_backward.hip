@@ -1095,7 +1095,8 @@ __global__ void __launch_bounds__(256)
     else if (op == CK_UNARY_EXP) d = y[i];
     else if (op == CK_UNARY_LOG) d = 1.f / x[i];
     else d = 2.f * x[i];
-    const float g = dy[i] * d;
+    // (an entry nobody selected has dy == 0: its gradient is 0 whatever the derivative -- 0 * inf at log(0) would be NaN)
+    const float g = dy[i] == 0.f ? 0.f : dy[i] * d;
     dx[i] = accumulate ? dx[i] + g : g;
   }
 }

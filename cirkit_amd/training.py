@@ -195,14 +195,22 @@ class HipTrainer:
         leaf_of_dense = c._children[g.dense_layer][:, 0, 1].astype(np.int64)
         if not np.array_equal(leaf_of_dense, np.arange(cat.num_folds)):
             return "the dense layer must read the Categorical folds in order"
-        self.circuit, self.fused = c, True
-        # wavefronts per workgroup of the backward walk: 4 = one per SIMD with the next unit's tiles in flight (ck_leaf_bwd.hip)
-        self._bwd_waves = int(os.environ.get("CK_BWD_WAVES", "8"))
-        dev = c.device
-        dl = c.layers[g.dense_layer]
         Cn = cat.num_categories
         if (((Cn + 1 + 31) // 32) + 3) * 4096 + 8 * 4096 > 160 * 1024:
             return "too many categories for the table backward's LDS"
+        # every parameter gradient of the fused backward is WRITTEN, exactly once, by the launch that owns its tensor (nothing
+        # zeroes the flat gradient): the tensors behind the Categorical table, the dense layer, the levels and the tail must be
+        # pairwise distinct and cover the plan's tensors
+        owned = [cat.probs.graph.nodes[0].config["tensor"]] + [
+            c.layers[j].weight.graph.nodes[0].config["tensor"] for j in [g.dense_layer] + list(g.levels) + list(c._tail)]
+        if len(set(owned)) != len(owned) or set(owned) != set(plan.tensors):
+            return "parameter tensors shared between layers (or not reached by any layer)"
+        self.circuit, self.fused = c, True
+        # wavefronts per workgroup of the backward walk: 8 = two per SIMD; 4 = one per SIMD with the next unit's tiles in
+        # flight (ck_leaf_bwd.hip), within 3 %
+        self._bwd_waves = int(os.environ.get("CK_BWD_WAVES", "8"))
+        dev = c.device
+        dl = c.layers[g.dense_layer]
         kl = 1 << g.depth
         nodes = np.asarray(g.nodes).astype(np.int64)
         n_roots = c.layers[g.root].num_folds
@@ -472,11 +480,8 @@ class HipTrainer:
         for j, fl in flags.items():
             if fl:
                 need_zero |= {int(p) for p in np.unique(c._children[j][..., 0])}
-        # ... and a store into a block that another launch adds to must come first: the launches run from the last layer to
-        # the first, so a storing layer k and an adding layer j > k on the same producer would lose j's contribution
-        for k, fl in list(flags.items()):
-            if fl == 0 and {int(p) for p in np.unique(c._children[k][..., 0])} & need_zero:
-                flags[k] = 1
+        # (a storing layer may share a producer LAYER with an adding one: its own (producer, fold) blocks have no other writer
+        #  -- that is what flag 0 means -- and the zero fills run before every backward launch, so the store loses nothing)
         return flags, need_zero
 
     def _bind_backward(self, B: int) -> dict:

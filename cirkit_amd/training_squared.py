@@ -253,6 +253,7 @@ class HipSquaredTrainer:
         self._m1 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
         self._m2 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
         self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._bad_seen = torch.zeros(1, dtype=torch.int32, device=self.device)  # latched by `step`, reported by `check_inputs`
         self.step_count = 0
 
     def loss_and_grads(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
@@ -283,23 +284,56 @@ class HipSquaredTrainer:
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
 
-    def apply_gradients(self) -> None:
+    def apply_gradients(self, skip_flag: torch.Tensor | None = None) -> None:
+        """The optimizer step on `self.grads`.  `skip_flag`: a device int32; nonzero at launch time = the step changes nothing
+        (parameters, moments, Adam's step count)."""
         with torch.cuda.device(self.device):
             self.step_count += 1
             stream = torch.cuda.current_stream(self.device).cuda_stream
             p, g = self._flat_param, self._flat_grad
+            skip = None if skip_flag is None else skip_flag.data_ptr()
             if self.optimizer == "adam":
                 capi.call("ck_adam_step", p.data_ptr(), g.data_ptr(), self._m1.data_ptr(), self._m2.data_ptr(), p.numel(), self.lr,
-                          self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, None, self._skipped.data_ptr(), stream)
+                          self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, skip, self._skipped.data_ptr(), stream)
             else:
-                capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, None, stream)
+                capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, skip, stream)
             self.store.touch()
 
     def step(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
+        """One optimisation step.  A batch with an out-of-range category (an ``IndexError`` in the reference, NaN outputs here)
+        must not reach the parameters, exactly as in `HipTrainer.step`: alone, the optimizer launch changes nothing while the
+        circuit's flag is up; with several ranks this rank's gradients are zeroed before the all-reduce (every rank takes the
+        same step).  The flag is then latched into what `check_inputs()` reports and cleared -- no host synchronisation."""
+        import torch.distributed as dist
+
         ll = self.loss_and_grads(x, global_batch=global_batch)
+        c = self.c
+        validate = c.validate_inputs and c._int_input
+        alone = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if validate and not alone:
+            with torch.cuda.device(self.device):
+                capi.call("ck_zero_if_flag", self._flat_grad.data_ptr(), self._flat_grad.numel(), c._bad_input.data_ptr(),
+                          torch.cuda.current_stream(self.device).cuda_stream)
         self.all_reduce_grads()
-        self.apply_gradients()
+        self.apply_gradients(c._bad_input if (validate and alone) else None)
+        if validate:
+            with torch.cuda.device(self.device):
+                capi.call("ck_latch_flag", c._bad_input.data_ptr(), self._bad_seen.data_ptr(),
+                          torch.cuda.current_stream(self.device).cuda_stream)
         return ll
+
+    @property
+    def skipped_steps(self) -> int:
+        return int(self._skipped.item())
+
+    def check_inputs(self) -> None:
+        """Raise ``IndexError`` if a batch since the last check held a category out of range (layers/input.py:258-266,
+        399-412 index with it); on a single rank the steps on such batches changed nothing."""
+        if int(self._bad_seen.item()) != 0:
+            self._bad_seen.zero_()
+            self.c._bad_input.zero_()
+            raise IndexError("a batch held a category outside [0, num_categories) of its variable")
+        self.c.check_inputs()
 
     def gradients(self) -> dict[str, np.ndarray]:
         return {n: g.detach().cpu().numpy() for n, g in self.grads.items()}

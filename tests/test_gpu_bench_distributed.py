@@ -102,11 +102,35 @@ def test_bench_eight_ranks_is_baseline_config_3(hip_device):
     comes out of this (eight processes share one GPU)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", *BENCH_ARGS]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    # (VERDICT r4 #8: the N > 1 line is as complete as the N = 1 line -- rank 0 times the CPU oracle, checks 64 rows against it
+    #  and fills `roofline` from its own instrumented pass while the other ranks wait at the closing barrier)
+    args = [a for a in BENCH_ARGS if a not in ("--no-cpu-baseline", "--no-kernel-breakdown")]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", *args]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     d = _one_json_line(out)
     assert d["config"]["global_batch"] == 32768
     _check_ranks(d, hip_device, 8)
+    c, r = d["cpu_baseline"], d["roofline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert d["check"]["max_rel_err_vs_oracle"] <= 1e-5 and d["check"]["rows_checked_against_oracle"] == 64
+    assert r["kernel"].startswith("leaf_persistent_kernel") and r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= 1.0
+    assert any(k.startswith("tail_params_kernel") for k in r["kernels"])
+
+
+def test_bench_two_ranks_with_live_counter_passes(hip_device):
+    """Rank 0 of an N = 2 run (launched as the driver launches it) runs the rocprofv3 counter passes on a plain single-process
+    child -- none of the launcher's rendezvous variables may reach it -- so `roofline.traffic` is measured at N > 1 too (or,
+    where rocprofv3 is not usable, taken from the committed profiles/traffic.json; never missing)."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = [a for a in BENCH_ARGS if a not in ("--no-kernel-breakdown", "--no-live-pmc")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29619", os.path.join(ROOT, "bench.py"), "--gpus", "2", *args]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    d = _one_json_line(out)
+    _check_two_ranks(d, hip_device)
+    r = d["roofline"]
+    assert r["traffic"] is not None and r["traffic"] > 0 and r["traffic_source"]
+    assert r["kernel"].startswith("leaf_persistent_kernel") and 0 < r["frac"] <= 1.0
 
 
 def test_bench_runs_rccl_at_world_size_one(hip_device):

@@ -137,3 +137,53 @@ def test_real_squared_gaussian_circuit_gradients_match_the_reference(hip_device)
         want = ref["g_" + k]
         err = float(np.abs(got[k] - want).max())
         assert err <= 1e-3 * max(1e-3, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+def test_squared_trainer_drops_a_batch_with_an_illegal_category(hip_device):
+    """an out-of-range category (an IndexError in the reference) makes c(x) NaN; the step on that batch must
+    change nothing (parameters, moments), `check_inputs()` reports it, and later batches train normally."""
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    plan_c, _, tensors, ref = _case()
+    tr = HipSquaredTrainer(plan_c, tensors, device=hip_device, lr=0.01)
+    x = torch.from_numpy(ref["x"].astype(np.int64)).to(hip_device)
+    tr.step(x)
+    before = {k: v.copy() for k, v in tr.parameters().items()}
+    bad = x.clone()
+    bad[1, 2] = 10 ** 6
+    tr.step(bad)
+    after = tr.parameters()
+    assert all(np.array_equal(before[k], after[k]) for k in before)
+    assert tr.skipped_steps == 1
+    with pytest.raises(IndexError):
+        tr.check_inputs()
+    tr.step(x)
+    now = tr.parameters()
+    assert all(np.isfinite(v).all() for v in now.values()) and any(not np.array_equal(before[k], now[k]) for k in before)
+    tr.check_inputs()
+
+
+@pytest.mark.gpu
+def test_squared_trainer_zero_embedding_weight_nobody_selects(hip_device):
+    """an Embedding weight that is exactly 0 and that no batch row selects has gradient 0 through c(x) (0 * d log w
+    would be NaN); the flat gradient stays finite."""
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    plan_c, _, tensors, ref = _case()
+    x = torch.from_numpy(ref["x"].astype(np.int64))
+    emb = next(l for l in plan_c.layers if l.type == "embedding")
+    name = emb.params["weight"].nodes[0].config["tensor"]
+    w = np.array(tensors[name], copy=True)  # (F, K, C)
+    var0 = int(emb.scope_idx[0, 0])
+    unused = next(c for c in range(w.shape[-1]) if c not in set(x[:, var0].tolist()))
+    w[0, 0, unused] = 0.0
+    tensors = dict(tensors)
+    tensors[name] = w
+    tr = HipSquaredTrainer(plan_c, tensors, device=hip_device)
+    tr.c(x.to(hip_device))  # (the backward of c is what divides by w; Z's Gram matrices see the zero as a plain factor)
+    tr._flat_grad.zero_()
+    with torch.cuda.device(tr.device):
+        tr._bwd_c.run(int(x.shape[0]), -2.0 / int(x.shape[0]), torch.cuda.current_stream(tr.device).cuda_stream)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(tr._flat_grad).all())
