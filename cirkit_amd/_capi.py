@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -132,6 +132,38 @@ class TailParamsLaunch(C.Structure):
     ]
 
 
+class OptState(C.Structure):
+    """ck_opt_state of include/cirkit_hip.h (a DEVICE struct: this mirror is for building its initial bytes)."""
+
+    _fields_ = [("lr", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float), ("bc1", C.c_float), ("bc2", C.c_float),
+                ("step", C.c_int32), ("skipped", C.c_int32), ("skip_now", C.c_int32), ("kind", C.c_int32)]
+
+
+class RootLaunch(C.Structure):
+    """ck_root_launch of include/cirkit_hip.h."""
+
+    _fields_ = [
+        ("pool", C.c_void_p), ("in_off", C.c_void_p), ("n_in", C.c_void_p), ("w", C.c_void_p), ("c", C.c_void_p), ("out", C.c_void_p),
+        ("gx", C.c_void_p), ("seed", C.c_void_p), ("ll", C.c_void_p), ("part", C.c_void_p), ("ticket", C.c_void_p),
+        ("dtheta_w", C.c_void_p), ("dtheta_c", C.c_void_p), ("theta_w", C.c_void_p), ("m1_w", C.c_void_p), ("m2_w", C.c_void_p),
+        ("w_out", C.c_void_p), ("theta_c", C.c_void_p), ("m1_c", C.c_void_p), ("m2_c", C.c_void_p), ("c_out", C.c_void_p),
+        ("opt", C.c_void_p), ("bad_flag", C.c_void_p),
+        ("seed_const", C.c_float), ("R", C.c_int32), ("B", C.c_int32), ("mode", C.c_int32), ("n_wg", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+# numpy mirrors of the DEVICE job tables (ck_sum_job / ck_mix_job: 128 bytes; ck_nsum_job: 16 bytes)
+SUM_JOB_DTYPE = [("w", "<u8"), ("out", "<u8"), ("gx", "<u8"), ("dtheta", "<u8"), ("theta", "<u8"), ("m1", "<u8"), ("m2", "<u8"),
+                 ("w_out", "<u8"), ("part", "<u8"), ("ticket", "<u8"), ("in_off", "<i4"), ("n_in", "<i4"), ("g_off", "<i4"),
+                 ("n_g", "<i4"), ("row0", "<i4"), ("row1", "<i4"), ("split", "<i4"), ("n_split", "<i4"), ("mode", "<i4"),
+                 ("reserved0", "<i4"), ("reserved1", "<i8")]
+MIX_JOB_DTYPE = [("w", "<u8"), ("out", "<u8"), ("gx", "<u8"), ("dtheta", "<u8"), ("theta", "<u8"), ("m1", "<u8"), ("m2", "<u8"),
+                 ("w_out", "<u8"), ("part", "<u8"), ("ticket", "<u8"), ("in_off", "<i4"), ("H", "<i4"), ("g_off", "<i4"),
+                 ("n_g", "<i4"), ("row0", "<i4"), ("row1", "<i4"), ("split", "<i4"), ("n_split", "<i4"), ("mode", "<i4"),
+                 ("S", "<i4"), ("reserved1", "<i8")]
+NSUM_JOB_DTYPE = [("out", "<u8"), ("in_off", "<i4"), ("n_in", "<i4")]
+
+
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
 SIGNATURES: dict[str, list[Any]] = {
     "ck_abi_version": [],
@@ -214,6 +246,13 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p, _p],
     "ck_sgd_step": [_p, _p, _l, _f, _f, _p, _p],
     "ck_latch_flag": [_p, _p, _p],
+    "ck_jobs_sum64_fwd": [_p, _i, _p, _p],
+    "ck_jobs_sum64_bwd": [_p, _i, _p, _p, _p],
+    "ck_jobs_mix_fwd": [_p, _i, _p, _i, _p],
+    "ck_jobs_mix_bwd": [_p, _i, _p, _i, _l, _p, _p],
+    "ck_jobs_nsum": [_p, _i, _p, _l, _p],
+    "ck_jobs_root": [C.POINTER(RootLaunch), _p],
+    "ck_opt_tick": [_p, _p, _p, _p],
     "ck_ll_sum": [_p, _l, _l, _p, _p],
     "ck_program_begin": [C.POINTER(_p)],
     "ck_program_end": [_p],

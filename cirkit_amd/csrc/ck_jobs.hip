@@ -1,0 +1,843 @@
+// Job-list launches of the training step for circuits of 64-unit CP layers (the circuit of the
+// reference's learning notebook -- QuadGraph, CP, K = 64, notebooks/learning-a-circuit.ipynb cells 4 / 16 / 18 -- and BASELINE
+// config 4, Poon-Domingos with Gaussian leaves).
+//
+// The reference differentiates its layer-by-layer forward with autograd (layers/inner.py:126-127, 266-273 through
+// semiring.py:383-408 and utils.py:10-30).  Here a training step is a short list of LEVEL launches over JOBS:
+//
+// * a SUM job is one fold of a dense / CP-T layer with 64 inputs and 64 outputs: v = the sum of its input blocks (a Hadamard
+//   product in log space: the product layer itself is never evaluated), e = exp(v - max v), y = W e, out = log y + max v.
+//   Backward (ck_backward.hip, head comment): gy = G / y with G the SUM of the job's gradient blocks, gx = e * (W^T gy) --
+//   ONE block, the gradient of every input of the product --, dW = gy^T e accumulated over the job's rows in registers,
+//   reduced in LDS and pushed through the softmax parameterisation W = softmax(theta) by the same workgroup
+//   (nodes.py:764-772): d theta = W (dW - <W, dW>) is written once, no atomics, no zero fill, no dW in memory -- and, with the
+//   fused optimizer, Adam's update of theta and the softmax of the NEXT step's weights follow in the same epilogue;
+// * a MIX job is one fold of a mixing layer (nodes.py:847-862): elementwise over units, H slots that are sums of blocks;
+// * an NSUM job adds blocks (a product layer that is kept, or a gradient with many readers);
+// * the ROOT launch evaluates the scalar sum folds and the final mixing layer at the top of the circuit, sums the
+//   log-likelihood, and runs their backward in the same launch (the seed of the mean log-likelihood is a constant).
+//
+// Every gradient block has ONE writer (plain stores); a reader adds the blocks of its list.  Blocks are (rows, 64) fp32,
+// row-major -- the reference's layout.  All tables (jobs, pointer pool) live in device memory and are built once per batch
+// size by cirkit_amd/train_jobs.py.
+#include "ck_internal.h"
+#include "ck_tile.h"
+
+namespace {
+
+constexpr int kU = 64;    // units per block row
+constexpr int kWS = 65;   // row stride of a weight matrix in LDS (odd: column AND row walks are conflict-free)
+constexpr int kTS = 68;   // row stride of the transpose tiles (16-byte aligned rows)
+
+typedef ck_sum_job SumJob;
+typedef ck_mix_job MixJob;
+
+__device__ __forceinline__ float row16_reduce_max(float v) {
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x140, 0xF, 0xF, true)));
+  return v;
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true));
+  v += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));
+  return v;
+}
+
+// The (64, 64) row-major weights of a job into LDS, row stride kWS: all loads first, then the stores.
+template <int THREADS>
+__device__ __forceinline__ void stage_weights(const float* __restrict__ w, float* __restrict__ w_s, int tid) {
+  constexpr int N = 1024 / THREADS;
+  float4 v[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] = ck::gload4(w + 4 * (tid + THREADS * u));
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int i = tid + THREADS * u;
+    float* d = w_s + (i >> 4) * kWS + (i & 15) * 4;
+    d[0] = v[u].x;
+    d[1] = v[u].y;
+    d[2] = v[u].z;
+    d[3] = v[u].w;
+  }
+}
+
+// v[q][.] = sum over the job's input blocks of row bl, units 32 q + 8 g + 4 kh + t (register 4 g + t)
+__device__ __forceinline__ void load_inputs(const float* const* __restrict__ pool, int off, int n, int64_t bl, int kh,
+                                            float (&e)[2][16]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[q][j] = 0.f;
+  for (int s = 0; s < n; ++s) {
+    const float* src = pool[off + s] + bl * kU + 4 * kh;
+    tile_load_add(src, e[0]);
+    tile_load_add(src + 32, e[1]);
+  }
+}
+
+__device__ __forceinline__ float exp_tile(float (&e)[2][16], bool live) {
+  float m = e[0][0];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, e[q][j]);
+  m = ck::clamp_finite(ck::xhalf_max(m));
+  const float nml = exp_offset(m, 0.f);
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) e[q][j] = live ? __builtin_amdgcn_exp2f(fmaf(e[q][j], kL2E, nml)) : 0.f;
+  return m;
+}
+
+// y[p] = W e for the 32 outputs 32 p + ...: A operand lane (o, kh) = W[32 p + o][32 q + 8 g + 4 kh + t]
+__device__ __forceinline__ f32x16 contract_rows(const float* __restrict__ w_s, int p, int b_in, int kh, const float (&e)[2][16]) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* wr = w_s + (32 * p + b_in) * kWS + 4 * kh;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * q + 8 * g + t], e[q][4 * g + t], acc, 0, 0, 0);
+  return acc;
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+    jobs_sum64_fwd_kernel(const SumJob* __restrict__ jobs, const float* const* __restrict__ pool) {
+  __shared__ float w_s[kU * kWS];
+  const SumJob& J = jobs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  stage_weights<WAVES * 64>(J.w, w_s, threadIdx.x);
+  __syncthreads();
+  const int in_off = J.in_off, n_in = J.n_in, row1 = J.row1;
+  float* __restrict__ out = J.out;
+  for (int b0 = J.row0 + 32 * wave; b0 < row1; b0 += 32 * WAVES) {
+    const int b = b0 + b_in;
+    const bool live = b < row1;
+    const int64_t bl = live ? b : row1 - 1;
+    float e[2][16];
+    load_inputs(pool, in_off, n_in, bl, kh, e);
+    const float m = exp_tile(e, true);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f32x16 acc = contract_rows(w_s, p, b_in, kh, e);
+      if (live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          ck::gstore4(out + bl * kU + 32 * p + 8 * g + 4 * kh,
+                      make_float4(fmaf(__builtin_amdgcn_logf(acc[4 * g]), kLN2, m), fmaf(__builtin_amdgcn_logf(acc[4 * g + 1]), kLN2, m),
+                                  fmaf(__builtin_amdgcn_logf(acc[4 * g + 2]), kLN2, m), fmaf(__builtin_amdgcn_logf(acc[4 * g + 3]), kLN2, m)));
+      }
+    }
+  }
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------------------
+// Adam's update of one entry (torch.optim.Adam without weight decay / amsgrad; the bias corrections come from `ck_opt_tick`)
+__device__ __forceinline__ float opt_update(const ck_opt_state& o, float p, float g, float& m1, float& m2) {
+  if (o.kind == 0) return p - o.lr * g;
+  m1 = o.b1 * m1 + (1.f - o.b1) * g;
+  m2 = o.b2 * m2 + (1.f - o.b2) * g * g;
+  return p - o.lr * (m1 / o.bc1) / (sqrtf(m2 / o.bc2) + o.eps);
+}
+
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+    jobs_sum64_bwd_kernel(const SumJob* __restrict__ jobs, const float* const* __restrict__ pool,
+                          const ck_opt_state* __restrict__ opt) {
+  static_assert(WAVES == 4, "the epilogue assigns 4 threads to a weight row");
+  // [weights 64 x 65][per wave: gy 16 x 68, e 16 x 68 -- later two 64 x 64 sum buffers]
+  constexpr int kArea = WAVES * 2 * 16 * kTS > 8192 ? WAVES * 2 * 16 * kTS : 8192;
+  __shared__ __attribute__((aligned(16))) float lds[kU * kWS + kArea];
+  __shared__ unsigned int s_ticket;
+  float* w_s = lds;
+  float* area = lds + kU * kWS;  // (64 x 65 floats: a multiple of 16 bytes)
+  const SumJob& J = jobs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  stage_weights<WAVES * 64>(J.w, w_s, threadIdx.x);
+  __syncthreads();
+  float* gy_s = area + wave * (2 * 16 * kTS);
+  float* e_s = gy_s + 16 * kTS;
+  f32x16 dwacc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dwacc[p][q][r] = 0.f;
+  const int in_off = J.in_off, n_in = J.n_in, g_off = J.g_off, n_g = J.n_g, row1 = J.row1;
+  float* __restrict__ gx = J.gx;
+  for (int b0 = J.row0 + 32 * wave; b0 < row1; b0 += 32 * WAVES) {
+    const int b = b0 + b_in;
+    const bool live = b < row1;
+    const int64_t bl = live ? b : row1 - 1;
+    float e[2][16];
+    load_inputs(pool, in_off, n_in, bl, kh, e);
+    float gy[2][16];
+    {  // G = the sum of the job's gradient blocks (same register layout as the outputs)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gy[p][j] = 0.f;
+      for (int s = 0; s < n_g; ++s) {
+        const float* src = pool[g_off + s] + bl * kU + 4 * kh;
+        tile_load_add(src, gy[0]);
+        tile_load_add(src + 32, gy[1]);
+      }
+    }
+    exp_tile(e, live);
+    // y = W e, gy = G / y
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f32x16 acc = contract_rows(w_s, p, b_in, kh, e);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gy[p][r] = (live && acc[r] > 0.f && gy[p][r] != 0.f) ? gy[p][r] * __builtin_amdgcn_rcpf(acc[r]) : 0.f;
+    }
+    // gx = e * (W^T gy): A operand lane (n, kh) = W[32 p + 8 g + 4 kh + t][32 q + n]
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w_s[(32 * p + 8 * g + 4 * kh + t) * kWS + 32 * q + b_in], gy[p][4 * g + t], acc, 0, 0, 0);
+      if (live) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          ck::gstore4(gx + bl * kU + 32 * q + 8 * g + 4 * kh,
+                      make_float4(acc[4 * g] * e[q][4 * g], acc[4 * g + 1] * e[q][4 * g + 1], acc[4 * g + 2] * e[q][4 * g + 2],
+                                  acc[4 * g + 3] * e[q][4 * g + 3]));
+      }
+    }
+    // dW += gy^T e: contracts over the rows, so both tiles go through LDS, 16 rows at a time (row r, unit u at [r * kTS + u])
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((b_in >> 4) == half) {
+        const int r = b_in & 15;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<float4*>(gy_s + r * kTS + 32 * q + 8 * g + 4 * kh) =
+                make_float4(gy[q][4 * g], gy[q][4 * g + 1], gy[q][4 * g + 2], gy[q][4 * g + 3]);
+            *reinterpret_cast<float4*>(e_s + r * kTS + 32 * q + 8 * g + 4 * kh) =
+                make_float4(e[q][4 * g], e[q][4 * g + 1], e[q][4 * g + 2], e[q][4 * g + 3]);
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        const int bb = 8 * kh + s2;  // row (of this half) contracted by lanes (., kh) at step s2
+        const float a0 = gy_s[bb * kTS + b_in], a1 = gy_s[bb * kTS + 32 + b_in];
+        const float c0 = e_s[bb * kTS + b_in], c1 = e_s[bb * kTS + 32 + b_in];
+        dwacc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c0, dwacc[0][0], 0, 0, 0);
+        dwacc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c1, dwacc[0][1], 0, 0, 0);
+        dwacc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c0, dwacc[1][0], 0, 0, 0);
+        dwacc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c1, dwacc[1][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // (the reads are done before the next half overwrites the tiles)
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // dW of the job's rows: the four waves' accumulators added in LDS (two (64, 64) buffers, two rounds)
+  __syncthreads();
+  float* buf = area + (wave & 1) * 4096;
+  if (wave < 2) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[(32 * p + 8 * (r >> 2) + 4 * kh + (r & 3)) * kU + 32 * q + b_in] = dwacc[p][q][r];
+  }
+  __syncthreads();
+  if (wave >= 2) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[(32 * p + 8 * (r >> 2) + 4 * kh + (r & 3)) * kU + 32 * q + b_in] += dwacc[p][q][r];
+  }
+  __syncthreads();
+  float* dw_s = area;  // (64, 64) after the sum below
+  if (J.n_split > 1) {
+    // the job's rows are cut over several workgroups: partial sums go to slots (write-through), the last arrival adds them
+    float* slot = J.part + static_cast<int64_t>(J.split) * 4096;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      __hip_atomic_store(slot + i, area[i] + area[4096 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(J.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != static_cast<unsigned int>(J.n_split - 1)) return;
+    if (threadIdx.x == 0) __hip_atomic_store(J.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next step
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      float t = 0.f;
+      for (int sp = 0; sp < J.n_split; ++sp)
+        t += __hip_atomic_load(J.part + static_cast<int64_t>(sp) * 4096 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dw_s[i] = t;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      dw_s[i] = area[i] + area[4096 + i];
+    }
+  }
+  __syncthreads();
+  // epilogue: thread (o = tid >> 2, quarter = tid & 3) owns 16 entries of weight row o
+  const int o = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
+  float wv[16], dv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    wv[k] = w_s[o * kWS + c0 + k];
+    dv[k] = dw_s[o * kU + c0 + k];
+  }
+  if (J.mode == 0) {  // the gradient of the linear weights, for a parameter graph this epilogue does not know
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) ck::gstore4(J.dtheta + o * kU + c0 + k, make_float4(dv[k], dv[k + 1], dv[k + 2], dv[k + 3]));
+    return;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s = fmaf(wv[k], dv[k], s);
+  s = quad_sum(s);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dv[k] = wv[k] * (dv[k] - s);  // d theta (nodes.py:764-772 under autograd)
+  if (J.mode == 1) {
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) ck::gstore4(J.dtheta + o * kU + c0 + k, make_float4(dv[k], dv[k + 1], dv[k + 2], dv[k + 3]));
+    return;
+  }
+  // mode 2: the optimizer's update of theta and the softmax of the next step's weights, here
+  const ck_opt_state os = *opt;
+  if (os.skip_now) return;
+  float th[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 16; k += 4) {
+    const float4 t4 = ck::gload4(J.theta + o * kU + c0 + k);
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+    if (os.kind != 0) {
+      a4 = ck::gload4(J.m1 + o * kU + c0 + k);
+      b4 = ck::gload4(J.m2 + o * kU + c0 + k);
+    }
+    th[k] = opt_update(os, t4.x, dv[k], a4.x, b4.x);
+    th[k + 1] = opt_update(os, t4.y, dv[k + 1], a4.y, b4.y);
+    th[k + 2] = opt_update(os, t4.z, dv[k + 2], a4.z, b4.z);
+    th[k + 3] = opt_update(os, t4.w, dv[k + 3], a4.w, b4.w);
+    ck::gstore4(J.theta + o * kU + c0 + k, make_float4(th[k], th[k + 1], th[k + 2], th[k + 3]));
+    if (os.kind != 0) {
+      ck::gstore4(J.m1 + o * kU + c0 + k, a4);
+      ck::gstore4(J.m2 + o * kU + c0 + k, b4);
+    }
+    mx = fmaxf(fmaxf(mx, fmaxf(th[k], th[k + 1])), fmaxf(th[k + 2], th[k + 3]));
+  }
+  mx = quad_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    th[k] = expf(th[k] - mx);
+    sum += th[k];
+  }
+  sum = quad_sum(sum);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int k = 0; k < 16; k += 4)
+    ck::gstore4(J.w_out + o * kU + c0 + k, make_float4(th[k] * inv, th[k + 1] * inv, th[k + 2] * inv, th[k + 3] * inv));
+}
+
+// ---- mixing jobs ----------------------------------------------------------------------------------------------------------
+// out[k] = log(sum_h w[k, h] e_h[k]) + m,  e_h[k] = exp(x_h[k] - m),  m = the maximum of the row over (h, k)  (a TorchSumLayer
+// whose weight is a TorchMixingWeightParameter, nodes.py:847-862, under semiring.py:383-408);  x_h = the sum of slot h's blocks.
+// 256 threads: 16 rows per pass, thread (r, c) owns units 4 c .. 4 c + 3 of its row.
+__global__ void __launch_bounds__(256)
+    jobs_mix_fwd_kernel(const MixJob* __restrict__ jobs, const float* const* __restrict__ pool) {
+  __shared__ float w_s[kU * 17];
+  const MixJob& J = jobs[blockIdx.x];
+  const int H = J.H, S = J.S, in_off = J.in_off, row1 = J.row1;
+  for (int i = threadIdx.x; i < kU * H; i += 256) w_s[(i / H) * 17 + (i % H)] = J.w[i];
+  __syncthreads();
+  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  for (int b0 = J.row0; b0 < row1; b0 += 16) {
+    const int b = b0 + r;
+    const bool live = b < row1;
+    const int64_t bl = live ? b : row1 - 1;
+    float m = -INFINITY;
+    for (int hs = 0; hs < H * S; hs += S) {
+      float4 x = ck::gload4(pool[in_off + hs] + bl * kU + 4 * c);
+      for (int s = 1; s < S; ++s) {
+        const float4 t = ck::gload4(pool[in_off + hs + s] + bl * kU + 4 * c);
+        x.x += t.x, x.y += t.y, x.z += t.z, x.w += t.w;
+      }
+      m = fmaxf(fmaxf(m, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+    }
+    m = ck::clamp_finite(row16_reduce_max(m));
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = 0; h < H; ++h) {
+      float4 x = ck::gload4(pool[in_off + h * S] + bl * kU + 4 * c);
+      for (int s = 1; s < S; ++s) {
+        const float4 t = ck::gload4(pool[in_off + h * S + s] + bl * kU + 4 * c);
+        x.x += t.x, x.y += t.y, x.z += t.z, x.w += t.w;
+      }
+      y.x = fmaf(w_s[(4 * c + 0) * 17 + h], expf(x.x - m), y.x);
+      y.y = fmaf(w_s[(4 * c + 1) * 17 + h], expf(x.y - m), y.y);
+      y.z = fmaf(w_s[(4 * c + 2) * 17 + h], expf(x.z - m), y.z);
+      y.w = fmaf(w_s[(4 * c + 3) * 17 + h], expf(x.w - m), y.w);
+    }
+    if (live) ck::gstore4(J.out + bl * kU + 4 * c, make_float4(logf(y.x) + m, logf(y.y) + m, logf(y.z) + m, logf(y.w) + m));
+  }
+}
+
+// Backward: gx_h[k] = G[k] w[k, h] e_h[k] / y[k] (one block per slot), d w[k, h] = sum_b G[k] e_h[k] / y[k] in registers over the
+// job's rows, reduced over the workgroup, then the softmax over h behind the mixing coefficients (nodes.py:764-772, 847-862).
+template <int HMAX>
+__global__ void __launch_bounds__(256)
+    jobs_mix_bwd_kernel(const MixJob* __restrict__ jobs, const float* const* __restrict__ pool, const ck_opt_state* __restrict__ opt,
+                        int64_t gx_stride) {
+  __shared__ float w_s[kU * 17];
+  __shared__ float red[4][kU * HMAX];
+  __shared__ unsigned int s_ticket;
+  const MixJob& J = jobs[blockIdx.x];
+  const int H = J.H, S = J.S, in_off = J.in_off, g_off = J.g_off, n_g = J.n_g, row1 = J.row1;
+  for (int i = threadIdx.x; i < kU * H; i += 256) w_s[(i / H) * 17 + (i % H)] = J.w[i];
+  __syncthreads();
+  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  float4 dacc[HMAX];
+#pragma unroll
+  for (int h = 0; h < HMAX; ++h) dacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b0 = J.row0; b0 < row1; b0 += 16) {
+    const int b = b0 + r;
+    const bool live = b < row1;
+    const int64_t bl = live ? b : row1 - 1;
+    float4 x[HMAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (h < H) {
+        x[h] = ck::gload4(pool[in_off + h * S] + bl * kU + 4 * c);
+        for (int s = 1; s < S; ++s) {
+          const float4 t = ck::gload4(pool[in_off + h * S + s] + bl * kU + 4 * c);
+          x[h].x += t.x, x[h].y += t.y, x[h].z += t.z, x[h].w += t.w;
+        }
+        m = fmaxf(fmaxf(m, fmaxf(x[h].x, x[h].y)), fmaxf(x[h].z, x[h].w));
+      }
+    m = ck::clamp_finite(row16_reduce_max(m));
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (h < H) {
+        x[h] = make_float4(expf(x[h].x - m), expf(x[h].y - m), expf(x[h].z - m), expf(x[h].w - m));
+        y.x = fmaf(w_s[(4 * c + 0) * 17 + h], x[h].x, y.x);
+        y.y = fmaf(w_s[(4 * c + 1) * 17 + h], x[h].y, y.y);
+        y.z = fmaf(w_s[(4 * c + 2) * 17 + h], x[h].z, y.z);
+        y.w = fmaf(w_s[(4 * c + 3) * 17 + h], x[h].w, y.w);
+      }
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < n_g; ++s) {
+      const float4 t = ck::gload4(pool[g_off + s] + bl * kU + 4 * c);
+      g.x += t.x, g.y += t.y, g.z += t.z, g.w += t.w;
+    }
+    g.x = (live && y.x > 0.f && g.x != 0.f) ? g.x / y.x : 0.f;
+    g.y = (live && y.y > 0.f && g.y != 0.f) ? g.y / y.y : 0.f;
+    g.z = (live && y.z > 0.f && g.z != 0.f) ? g.z / y.z : 0.f;
+    g.w = (live && y.w > 0.f && g.w != 0.f) ? g.w / y.w : 0.f;
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h)
+      if (h < H) {
+        const float4 ge = make_float4(g.x * x[h].x, g.y * x[h].y, g.z * x[h].z, g.w * x[h].w);
+        dacc[h].x += ge.x, dacc[h].y += ge.y, dacc[h].z += ge.z, dacc[h].w += ge.w;
+        if (live)
+          ck::gstore4(J.gx + h * gx_stride + bl * kU + 4 * c,
+                      make_float4(ge.x * w_s[(4 * c + 0) * 17 + h], ge.y * w_s[(4 * c + 1) * 17 + h], ge.z * w_s[(4 * c + 2) * 17 + h],
+                                  ge.w * w_s[(4 * c + 3) * 17 + h]));
+      }
+  }
+  // the four row groups of a wave (lanes 16 apart), then the four waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int h = 0; h < HMAX; ++h) {
+    float4 v = dacc[h];
+    v.x += __shfl_xor(v.x, 16, 64), v.y += __shfl_xor(v.y, 16, 64), v.z += __shfl_xor(v.z, 16, 64), v.w += __shfl_xor(v.w, 16, 64);
+    v.x += __shfl_xor(v.x, 32, 64), v.y += __shfl_xor(v.y, 32, 64), v.z += __shfl_xor(v.z, 32, 64), v.w += __shfl_xor(v.w, 32, 64);
+    if (lane < 16) {
+      red[wave][(4 * c + 0) * HMAX + h] = v.x;
+      red[wave][(4 * c + 1) * HMAX + h] = v.y;
+      red[wave][(4 * c + 2) * HMAX + h] = v.z;
+      red[wave][(4 * c + 3) * HMAX + h] = v.w;
+    }
+  }
+  __syncthreads();
+  float* dw_s = red[0];
+  for (int i = threadIdx.x; i < kU * HMAX; i += 256) dw_s[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  __syncthreads();
+  if (J.n_split > 1) {
+    float* slot = J.part + static_cast<int64_t>(J.split) * (kU * HMAX);
+    for (int i = threadIdx.x; i < kU * HMAX; i += 256) __hip_atomic_store(slot + i, dw_s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(J.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != static_cast<unsigned int>(J.n_split - 1)) return;
+    if (threadIdx.x == 0) __hip_atomic_store(J.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < kU * HMAX; i += 256) {
+      float t = 0.f;
+      for (int sp = 0; sp < J.n_split; ++sp)
+        t += __hip_atomic_load(J.part + static_cast<int64_t>(sp) * (kU * HMAX) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dw_s[i] = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x >= kU) return;
+  const int k = threadIdx.x;
+  if (J.mode == 0) {
+    for (int h = 0; h < H; ++h) J.dtheta[k * H + h] = dw_s[k * HMAX + h];
+    return;
+  }
+  float s = 0.f;
+  for (int h = 0; h < H; ++h) s = fmaf(w_s[k * 17 + h], dw_s[k * HMAX + h], s);
+  if (J.mode == 1) {
+    for (int h = 0; h < H; ++h) J.dtheta[k * H + h] = w_s[k * 17 + h] * (dw_s[k * HMAX + h] - s);
+    return;
+  }
+  const ck_opt_state os = *opt;
+  if (os.skip_now) return;
+  float mx = -INFINITY;
+  for (int h = 0; h < H; ++h) {
+    const float g = w_s[k * 17 + h] * (dw_s[k * HMAX + h] - s);
+    float a = os.kind ? J.m1[k * H + h] : 0.f, v = os.kind ? J.m2[k * H + h] : 0.f;
+    const float th = opt_update(os, J.theta[k * H + h], g, a, v);
+    J.theta[k * H + h] = th;
+    if (os.kind) {
+      J.m1[k * H + h] = a;
+      J.m2[k * H + h] = v;
+    }
+    dw_s[k * HMAX + h] = th;
+    mx = fmaxf(mx, th);
+  }
+  float sum = 0.f;
+  for (int h = 0; h < H; ++h) {
+    const float ex = expf(dw_s[k * HMAX + h] - mx);
+    dw_s[k * HMAX + h] = ex;
+    sum += ex;
+  }
+  for (int h = 0; h < H; ++h) J.w_out[k * H + h] = dw_s[k * HMAX + h] / sum;
+}
+
+// ---- block sums ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    jobs_nsum_kernel(const ck_nsum_job* __restrict__ jobs, const float* const* __restrict__ pool, int64_t elems) {
+  const ck_nsum_job& J = jobs[blockIdx.y];
+  for (int64_t i = (blockIdx.x * 256ll + threadIdx.x) * 4; i < elems; i += gridDim.x * 1024ll) {
+    float4 a = ck::gload4(pool[J.in_off] + i);
+    for (int s = 1; s < J.n_in; ++s) {
+      const float4 t = ck::gload4(pool[J.in_off + s] + i);
+      a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+    }
+    ck::gstore4(J.out + i, a);
+  }
+}
+
+// ---- the top of the circuit -----------------------------------------------------------------------------------------------------
+// R scalar sum folds (64 inputs each: o_r = log(sum_n w_r[n] exp(v_r[n] - m_r)) + m_r, v_r the sum of the fold's blocks) under a
+// final mixing layer out = log(sum_r c_r exp(o_r - M)) + M (or out = o_0 when there is none); the log-likelihood sum; and, with
+// `gx`, their backward for the loss  sum_b seed_b out_b:  gx_r[n] = seed p_r w_r[n] e_r[n] / y_r  with  p_r = c_r exp(o_r - M) / Y,
+// d w_r[n] = sum_b seed p_r e_r[n] / y_r,  d c_r = sum_b seed exp(o_r - M) / Y -- per-workgroup partial sums, the last arrival adds
+// them in workgroup order and applies the softmax parameterisations.  One wave per row, lane = input unit.
+constexpr int kRootMax = 16;
+__global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) {
+  __shared__ float red[4][kRootMax * kU + kRootMax];
+  __shared__ double red_ll[4];
+  __shared__ unsigned int s_ticket;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int R = a.R, B = a.B;
+  const bool bad = a.bad_flag != nullptr && *a.bad_flag != 0;
+  float wr[kRootMax], dw[kRootMax], dc[kRootMax], cr[kRootMax];
+#pragma unroll
+  for (int r = 0; r < kRootMax; ++r) {
+    wr[r] = r < R ? a.w[r][lane] : 0.f;
+    cr[r] = (r < R && a.c != nullptr) ? a.c[r] : 1.f;
+    dw[r] = 0.f;
+    dc[r] = 0.f;
+  }
+  double ll = 0.0;
+  for (int b = blockIdx.x * 4 + wave; b < B; b += gridDim.x * 4) {
+    float e[kRootMax], o[kRootMax], yr[kRootMax];
+    float M = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < kRootMax; ++r)
+      if (r < R) {
+        float v = 0.f;
+        for (int s = 0; s < a.n_in[r]; ++s) v += a.pool[a.in_off[r] + s][static_cast<int64_t>(b) * kU + lane];
+        const float m = ck::clamp_finite(ck::wave_max(v));
+        e[r] = expf(v - m);
+        yr[r] = ck::wave_sum(wr[r] * e[r]);
+        o[r] = logf(yr[r]) + m;
+        M = fmaxf(M, o[r]);
+      }
+    float out;
+    float Y = 0.f;
+    if (a.c != nullptr) {
+      M = ck::clamp_finite(M);
+#pragma unroll
+      for (int r = 0; r < kRootMax; ++r)
+        if (r < R) {
+          o[r] = expf(o[r] - M);  // from here on: exp(o_r - M)
+          Y = fmaf(cr[r], o[r], Y);
+        }
+      out = logf(Y) + M;
+    } else {
+      out = o[0];
+      o[0] = 1.f;
+      Y = 1.f;
+    }
+    if (bad) out = __builtin_nanf("");
+    if (lane == 0) a.out[b] = out;
+    ll += static_cast<double>(out);
+    if (a.gx != nullptr) {
+      const float seed = a.seed != nullptr ? a.seed[b] : a.seed_const;
+#pragma unroll
+      for (int r = 0; r < kRootMax; ++r)
+        if (r < R) {
+          const float q = (Y > 0.f) ? seed * o[r] / Y : 0.f;  // seed * exp(o_r - M) / Y
+          const float t = (yr[r] > 0.f) ? q * cr[r] * e[r] / yr[r] : 0.f;
+          dc[r] += q;
+          dw[r] += t;
+          a.gx[(static_cast<int64_t>(r) * B + b) * kU + lane] = t * wr[r];
+        }
+    }
+  }
+  // partial sums of this workgroup
+#pragma unroll
+  for (int r = 0; r < kRootMax; ++r)
+    if (r < R) {
+      red[wave][r * kU + lane] = dw[r];
+      if (lane == 0) red[wave][kRootMax * kU + r] = dc[r];
+    }
+  if (lane == 0) red_ll[wave] = ll;
+  __syncthreads();
+  const int n_part = R * kU + R;
+  float* slot = a.part + static_cast<int64_t>(blockIdx.x) * (kRootMax * kU + kRootMax + 2);
+  for (int i = threadIdx.x; i < n_part; i += 256) {
+    const int j = i < R * kU ? i : kRootMax * kU + (i - R * kU);
+    __hip_atomic_store(slot + i, (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) {
+    const double t = (red_ll[0] + red_ll[1]) + (red_ll[2] + red_ll[3]);
+    __hip_atomic_store(reinterpret_cast<double*>(slot + kRootMax * kU + kRootMax), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;
+  if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* tot = &red[0][0];
+  for (int i = threadIdx.x; i < n_part; i += 256) {
+    float t = 0.f;
+    for (unsigned int g = 0; g < gridDim.x; ++g)
+      t += __hip_atomic_load(a.part + static_cast<int64_t>(g) * (kRootMax * kU + kRootMax + 2) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot[i] = t;
+  }
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (unsigned int g = 0; g < gridDim.x; ++g)
+      t += __hip_atomic_load(reinterpret_cast<const double*>(a.part + static_cast<int64_t>(g) * (kRootMax * kU + kRootMax + 2) + kRootMax * kU + kRootMax),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.ll[0] = t;
+    a.ll[1] = static_cast<double>(B);
+  }
+  __syncthreads();
+  if (a.gx == nullptr || a.mode == 0) {
+    if (a.gx != nullptr) {  // raw gradients of the linear weights
+      for (int i = threadIdx.x; i < R * kU; i += 256) a.dtheta_w[i / kU][i % kU] = tot[i];
+      if (a.c != nullptr && threadIdx.x < R) a.dtheta_c[threadIdx.x] = tot[R * kU + threadIdx.x];
+    }
+    return;
+  }
+  const ck_opt_state os = a.mode == 2 ? *a.opt : ck_opt_state{};
+  if (a.mode == 2 && os.skip_now) return;
+  // softmax behind every weight row (wave w takes folds w, w + 4, ...) ...
+  for (int r = wave; r < R; r += 4) {
+    const float w = a.w[r][lane], d = tot[r * kU + lane];
+    const float s = ck::wave_sum(w * d);
+    const float g = w * (d - s);
+    if (a.mode == 1) {
+      a.dtheta_w[r][lane] = g;
+    } else {
+      float m1 = os.kind ? a.m1_w[r][lane] : 0.f, m2 = os.kind ? a.m2_w[r][lane] : 0.f;
+      const float th = opt_update(os, a.theta_w[r][lane], g, m1, m2);
+      a.theta_w[r][lane] = th;
+      if (os.kind) {
+        a.m1_w[r][lane] = m1;
+        a.m2_w[r][lane] = m2;
+      }
+      const float mx = ck::wave_max(th);
+      const float ex = expf(th - mx);
+      const float sum = ck::wave_sum(ex);
+      a.w_out[r][lane] = ex / sum;
+    }
+  }
+  // ... and behind the mixing coefficients (wave 0 after its folds: lanes r < R)
+  if (a.c != nullptr && wave == 0) {
+    const bool on = lane < R;
+    const float c = on ? a.c[lane] : 0.f, d = on ? tot[R * kU + lane] : 0.f;
+    const float s = ck::wave_sum(c * d);
+    const float g = c * (d - s);
+    if (a.mode == 1) {
+      if (on) a.dtheta_c[lane] = g;
+    } else {
+      float m1 = (on && os.kind) ? a.m1_c[lane] : 0.f, m2 = (on && os.kind) ? a.m2_c[lane] : 0.f;
+      const float th = on ? opt_update(os, a.theta_c[lane], g, m1, m2) : -INFINITY;
+      const float mx = ck::wave_max(th);
+      const float ex = on ? expf(th - mx) : 0.f;
+      const float sum = ck::wave_sum(ex);
+      if (on) {
+        a.theta_c[lane] = th;
+        if (os.kind) {
+          a.m1_c[lane] = m1;
+          a.m2_c[lane] = m2;
+        }
+        a.c_out[lane] = ex / sum;
+      }
+    }
+  }
+}
+
+// The optimizer's clock, once per step on the device: a batch with an illegal category (the circuit's flag) makes this step's
+// updates no-ops -- parameters, moments and the bias corrections' step count stay -- and the flag is latched for `check_inputs`.
+__global__ void opt_tick_kernel(ck_opt_state* __restrict__ o, int32_t* __restrict__ flag, int32_t* __restrict__ sticky) {
+  const bool bad = flag != nullptr && *flag != 0;
+  if (bad) {
+    if (sticky != nullptr) *sticky |= *flag;
+    *flag = 0;
+    o->skip_now = 1;
+    o->skipped += 1;
+    return;
+  }
+  o->skip_now = 0;
+  o->step += 1;
+  const float t = static_cast<float>(o->step);
+  o->bc1 = 1.f - powf(o->b1, t);
+  o->bc2 = 1.f - powf(o->b2, t);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ck_jobs_sum64_fwd(const ck_sum_job* jobs, int n_units, const float* const* pool, void* stream) {
+  CK_REQUIRE(jobs && pool && n_units > 0, "ck_jobs_sum64_fwd: bad arguments");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(jobs_sum64_fwd_kernel<4>, dim3(n_units), dim3(256), 0, s, jobs, pool);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_jobs_sum64_bwd(const ck_sum_job* jobs, int n_units, const float* const* pool, const ck_opt_state* opt, void* stream) {
+  CK_REQUIRE(jobs && pool && n_units > 0, "ck_jobs_sum64_bwd: bad arguments");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(jobs_sum64_bwd_kernel<4>, dim3(n_units), dim3(256), 0, s, jobs, pool, opt);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_jobs_mix_fwd(const ck_mix_job* jobs, int n_units, const float* const* pool, int h_max, void* stream) {
+  CK_REQUIRE(jobs && pool && n_units > 0, "ck_jobs_mix_fwd: bad arguments");
+  CK_REQUIRE(h_max >= 1 && h_max <= 16, "ck_jobs_mix_fwd: at most 16 slots per mixing job");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(jobs_mix_fwd_kernel, dim3(n_units), dim3(256), 0, s, jobs, pool);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_jobs_mix_bwd(const ck_mix_job* jobs, int n_units, const float* const* pool, int h_max, int64_t gx_stride,
+                    const ck_opt_state* opt, void* stream) {
+  CK_REQUIRE(jobs && pool && n_units > 0 && gx_stride > 0, "ck_jobs_mix_bwd: bad arguments");
+  CK_REQUIRE(h_max >= 1 && h_max <= 16, "ck_jobs_mix_bwd: at most 16 slots per mixing job");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (h_max <= 2)
+          hipLaunchKernelGGL(jobs_mix_bwd_kernel<2>, dim3(n_units), dim3(256), 0, s, jobs, pool, opt, gx_stride);
+        else if (h_max <= 4)
+          hipLaunchKernelGGL(jobs_mix_bwd_kernel<4>, dim3(n_units), dim3(256), 0, s, jobs, pool, opt, gx_stride);
+        else if (h_max <= 8)
+          hipLaunchKernelGGL(jobs_mix_bwd_kernel<8>, dim3(n_units), dim3(256), 0, s, jobs, pool, opt, gx_stride);
+        else
+          hipLaunchKernelGGL(jobs_mix_bwd_kernel<16>, dim3(n_units), dim3(256), 0, s, jobs, pool, opt, gx_stride);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_jobs_nsum(const ck_nsum_job* jobs, int n_jobs, const float* const* pool, int64_t elems, void* stream) {
+  CK_REQUIRE(jobs && pool && n_jobs > 0 && n_jobs <= 65535 && elems > 0 && elems % 4 == 0, "ck_jobs_nsum: bad arguments");
+  const unsigned gx = static_cast<unsigned>(std::min<int64_t>((elems / 4 + 255) / 256, 64));
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(jobs_nsum_kernel, dim3(gx, n_jobs), dim3(256), 0, s, jobs, pool, elems);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_jobs_root(const ck_root_launch* a, void* stream) {
+  CK_REQUIRE(a && a->pool && a->in_off && a->n_in && a->w && a->out && a->ll && a->part && a->ticket, "ck_jobs_root: null pointer");
+  CK_REQUIRE(a->R >= 1 && a->R <= kRootMax && a->B > 0, "ck_jobs_root: 1..16 scalar folds");
+  CK_REQUIRE(a->c != nullptr || a->R == 1, "ck_jobs_root: several scalar folds need the final mixing coefficients");
+  CK_REQUIRE(a->n_wg >= 1 && a->n_wg <= 64, "ck_jobs_root: 1..64 workgroups");
+  CK_REQUIRE(a->gx == nullptr || a->mode == 0 || a->mode == 1 || (a->mode == 2 && a->opt), "ck_jobs_root: bad mode");
+  const ck_root_launch v = *a;
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(jobs_root_kernel, dim3(v.n_wg), dim3(256), 0, s, v);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_opt_tick(ck_opt_state* state, int32_t* flag, int32_t* sticky, void* stream) {
+  CK_REQUIRE(state, "ck_opt_tick: null state");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(opt_tick_kernel, dim3(1), dim3(1), 0, s, state, flag, sticky);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+}  // extern "C"

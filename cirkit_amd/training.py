@@ -55,13 +55,17 @@ class HipTrainer:
         eps: float = 1e-8,
         pad_units: bool = False,
         fused: bool | None = None,
+        jobs: bool | None = None,
     ) -> None:
         """`pad_units`: train the plan with its unit counts padded to multiples of 32 (cirkit_amd/padding.py), so that
         the MFMA forward / backward tiles apply to any width.  The padded entries never receive a gradient (softmax
         at a -inf logit, zero weight on every padded unit), so the padded circuit stays the same function; `self.grads`
         and the parameter store then hold the PADDED tensors -- `gradients()` / `parameters()` return user shapes.
         `fused`: None takes the fused forward / backward when the plan qualifies (module docstring), True insists
-        (NotImplementedError says why not), False forces the layer-wise form."""
+        (NotImplementedError says why not), False forces the layer-wise form.
+        `jobs`: circuits of 64-unit dense / CP-T / mixing / Hadamard layers (the reference's learning notebook, BASELINE config 4)
+        step as level launches over jobs (cirkit_amd/train_jobs.py) when the fused form does not apply: None where the plan
+        qualifies, True insists, False never."""
         if plan.semiring != "lse-sum":
             raise NotImplementedError("HipTrainer trains circuits under the real lse-sum semiring; squared circuits compiled under "
                                       "complex-lse-sum (Embedding / CP-T for c, ConstantValue / Hadamard / TensorDot for Z) train with "
@@ -108,6 +112,7 @@ class HipTrainer:
                                       batch_params=True, tiled_weights=False, dense_on_table=False, pad_units=False,
                                       fused_weight_softmax=False)
         self.device = self.circuit.device
+        self._jobs = None
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self.step_count = 0
         c = self.circuit
@@ -136,6 +141,16 @@ class HipTrainer:
         self._bad_seen = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._step_flag = torch.zeros(1, dtype=torch.int32, device=self.device)  # fused: the flag of the step being taken
         self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)  # Adam steps that did not count
+        if not self.fused and jobs is not False and self._pad_info is None:
+            from .train_jobs import JobStep
+
+            js = JobStep(self)
+            if js.why is None:
+                self._jobs = js
+            elif jobs is True:
+                raise NotImplementedError(f"the job form of the training step does not apply to this plan: {js.why}")
+        elif jobs is True:
+            raise NotImplementedError("the job form of the training step needs an unpadded plan outside the fused form")
 
     # ------------------------------------------------------------------------------------------
     _PARAM_OPS = {"tensor", "softmax", "log_softmax", "sigmoid", "exp", "log", "square", "scaled_sigmoid", "mixing_weight", "matmul"}
@@ -563,6 +578,8 @@ class HipTrainer:
         if global_batch is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             global_batch = int(x.shape[0]) * dist.get_world_size()
         B = int(x.shape[0])
+        if self._jobs is not None:  # one recorded launch list: parameters, forward levels, root, backward levels
+            return self._jobs.loss_and_grads(x, float(global_batch or B))
         ll = self._forward(x)
         self._backward(B, float(global_batch or B), None)
         return ll
@@ -802,7 +819,7 @@ class HipCircuitModule(torch.nn.Module):
 
     def __init__(self, plan: Plan, tensors: Mapping[str, object], *, device: str | torch.device = "cuda:0") -> None:
         super().__init__()
-        self._trainer = HipTrainer(plan, tensors, device=device, optimizer="sgd", lr=0.0)
+        self._trainer = HipTrainer(plan, tensors, device=device, optimizer="sgd", lr=0.0, jobs=False)  # (any output gradient)
         self._names = list(self._trainer.plan.tensors)
         self._generation = 0
         self.params = torch.nn.ParameterList([torch.nn.Parameter(self._trainer.circuit.store[n]) for n in self._names])

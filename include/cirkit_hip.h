@@ -725,6 +725,116 @@ int ck_latch_flag(int32_t* src, int32_t* dst, void* stream);
  * optimizer launch skips on -- and the sticky one in the launch that zeroes the gradient buffers anyway. */
 int ck_fill_latch(float* p, int64_t n, float value, int32_t* src, int32_t* step_flag, int32_t* sticky, void* stream);
 
+/* ---------------------------------------------------------------- training step as job lists (64-unit CP circuits) ---- */
+/* The reference trains with autograd through its layer-by-layer forward (notebooks/learning-a-circuit.ipynb cell 18:
+ * `loss = -torch.mean(circuit(batch)); loss.backward(); optimizer.step()` over layers/inner.py:126-127, 266-273,
+ * semiring.py:383-408, utils.py:10-30, parameters/nodes.py:764-772, 847-862).  For circuits made of 64-unit dense / CP-T /
+ * mixing / Hadamard layers (the notebook's QuadGraph CP circuit, BASELINE config 4) a step is a short list of LEVEL launches
+ * over JOBS (cirkit_amd/csrc/ck_jobs.hip, built by cirkit_amd/train_jobs.py).  All tables are DEVICE arrays; `pool` is a
+ * DEVICE array of block pointers, blocks are (rows, 64) fp32 row-major.  A job's rows may be cut over n_split workgroups
+ * (units of the launch); the units of one job share `part` (n_split slots) and `ticket` (zero, zero again afterwards). */
+typedef struct ck_opt_state {  /* DEVICE: the optimizer's constants and clock, advanced by ck_opt_tick once per step */
+  float lr, b1, b2, eps;
+  float bc1, bc2;      /* Adam's bias corrections of THIS step */
+  int32_t step;        /* steps taken (skipped ones do not count) */
+  int32_t skipped;     /* steps dropped because their batch held an illegal category */
+  int32_t skip_now;    /* this step is dropped: the epilogues change nothing */
+  int32_t kind;        /* 0 SGD, 1 Adam */
+} ck_opt_state;
+/* One fold of a TorchSumLayer (arity 1) / TorchCPTLayer with 64 inputs and 64 outputs (layers/inner.py:266-273,
+ * optimized.py:171-178):  v = sum of the n_in blocks pool[in_off ..] (the Hadamard product of the children in log space),
+ * out = log(W exp(v - max v)) + max v.  Backward: G = sum of the n_g blocks pool[g_off ..]; gx = the gradient w.r.t. v;
+ * mode 0: dtheta <- dW (64, 64);  mode 1: dtheta <- W (dW - <W, dW>), the gradient of the logits of W = softmax(theta)
+ * (nodes.py:764-772);  mode 2: the optimizer's update of theta / m1 / m2 in place and w_out <- softmax(theta'). */
+typedef struct ck_sum_job {
+  const float* w;
+  float* out;
+  float* gx;
+  float* dtheta;
+  float* theta;
+  float* m1;
+  float* m2;
+  float* w_out;
+  float* part;
+  uint32_t* ticket;
+  int32_t in_off, n_in;
+  int32_t g_off, n_g;
+  int32_t row0, row1;
+  int32_t split, n_split;
+  int32_t mode, reserved0;
+  int64_t reserved1;
+} ck_sum_job;
+int ck_jobs_sum64_fwd(const ck_sum_job* jobs, int n_units, const float* const* pool, void* stream);
+int ck_jobs_sum64_bwd(const ck_sum_job* jobs, int n_units, const float* const* pool, const ck_opt_state* opt, void* stream);
+/* One fold of a mixing layer (a TorchSumLayer whose weight ends in TorchMixingWeightParameter, nodes.py:847-862): H slots,
+ * slot h = the sum of the S blocks pool[in_off + h S ..]; w (64, H) coefficients.  Backward: gx + h gx_stride <- the gradient
+ * of slot h; dtheta (64, H) as for ck_sum_job (the softmax runs over h); part slots are 64 x (2 | 4 | 8 | 16) floats (the
+ * smallest that holds h_max). */
+typedef struct ck_mix_job {
+  const float* w;
+  float* out;
+  float* gx;
+  float* dtheta;
+  float* theta;
+  float* m1;
+  float* m2;
+  float* w_out;
+  float* part;
+  uint32_t* ticket;
+  int32_t in_off, H;
+  int32_t g_off, n_g;
+  int32_t row0, row1;
+  int32_t split, n_split;
+  int32_t mode, S;
+  int64_t reserved1;
+} ck_mix_job;
+int ck_jobs_mix_fwd(const ck_mix_job* jobs, int n_units, const float* const* pool, int h_max, void* stream);
+int ck_jobs_mix_bwd(const ck_mix_job* jobs, int n_units, const float* const* pool, int h_max, int64_t gx_stride,
+                    const ck_opt_state* opt, void* stream);
+/* out <- the sum of n_in blocks of `elems` floats (a Hadamard layer that is kept: layers/inner.py:126-127 in log space; or a
+ * gradient that several jobs read). */
+typedef struct ck_nsum_job {
+  float* out;
+  int32_t in_off, n_in;
+} ck_nsum_job;
+int ck_jobs_nsum(const ck_nsum_job* jobs, int n_jobs, const float* const* pool, int64_t elems, void* stream);
+/* The top of the circuit in one launch: R <= 16 scalar sum folds (64 inputs, weight rows w[r]) under the final mixing layer
+ * (coefficients c (R), or NULL with R = 1), `out` (B) log-likelihoods, ll <- [sum, B] (fp64; what ck_ll_sum gives), and with
+ * gx (R, B, 64) their backward for loss = sum_b seed_b out_b (seed NULL: seed_const, the -1 / batch of the mean NLL).  mode as
+ * for ck_sum_job, per weight row (dtheta_w[r] (64)) and for the coefficients (dtheta_c (R)); *bad_flag != 0 -> NaN outputs
+ * (ck_poison_outputs).  part: n_wg x 1042 floats, ticket zero. */
+typedef struct ck_root_launch {
+  const float* const* pool;
+  const int32_t* in_off;
+  const int32_t* n_in;
+  const float* const* w;
+  const float* c;
+  float* out;
+  float* gx;
+  const float* seed;
+  double* ll;
+  float* part;
+  uint32_t* ticket;
+  float* const* dtheta_w;
+  float* dtheta_c;
+  float* const* theta_w;
+  float* const* m1_w;
+  float* const* m2_w;
+  float* const* w_out;
+  float* theta_c;
+  float* m1_c;
+  float* m2_c;
+  float* c_out;
+  const ck_opt_state* opt;
+  const int32_t* bad_flag;
+  float seed_const;
+  int32_t R, B, mode, n_wg, reserved;
+} ck_root_launch;
+int ck_jobs_root(const ck_root_launch* a, void* stream);
+/* Once per step, before the backward launches: *flag != 0 (the forward's validation flag) -> this step is dropped (skip_now = 1,
+ * skipped += 1, *sticky |= *flag, *flag = 0); else step += 1 and the bias corrections of this step.  flag / sticky may be NULL. */
+int ck_opt_tick(ck_opt_state* state, int32_t* flag, int32_t* sticky, void* stream);
+
 /* ---------------------------------------------------------------- reductions --------------- */
 /* Sum of B log-likelihoods (stride in floats between consecutive rows) into out_dev[0] (fp64) and
  * the row count into out_dev[1]; the pair feeds the one RCCL all-reduce of the data-parallel NLL

@@ -34,8 +34,10 @@ else:
     plan = image_data((1, 28, 28), "quad-tree-2", num_input_units=32, num_sum_units=32)
     x = torch.randint(0, 256, (B, 784)).cuda()
 mode = sys.argv[4] if len(sys.argv) > 4 else "auto"
-tr = HipTrainer(plan, init_plan_tensors(plan), device="cuda:0", lr=0.01, fused={"auto": None, "fused": True, "layerwise": False}[mode])
-print("fused" if tr.fused else "layer-wise", "training step")
+tr = HipTrainer(plan, init_plan_tensors(plan), device="cuda:0", lr=0.01, fused={"auto": None, "fused": True, "layerwise": False, "jobs": None}[mode],
+                jobs={"auto": None, "jobs": True}.get(mode, False))
+print("fused" if tr.fused else ("job-list" if tr._jobs is not None else "layer-wise"), "training step",
+      f"({tr._jobs.num_launches(B)} launches per step)" if tr._jobs is not None else "")
 lls = []
 for _ in range(3):
     ll = tr.step(x)

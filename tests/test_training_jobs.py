@@ -1,0 +1,104 @@
+"""The job form of the training step (cirkit_amd/train_jobs.py, csrc/ck_jobs.hip): circuits of 64-unit dense / CP-T / mixing /
+Hadamard layers -- the circuit of the reference's learning notebook (QuadGraph, CP, K = 64; notebooks/learning-a-circuit.ipynb
+cells 4 / 16 / 18) and BASELINE config 4 (Poon-Domingos, Gaussian leaves) -- step as level launches over jobs.  Checked against
+the layer-wise launch list (its checker) and against fp64 autograd through the oracle (the reference's arithmetic)."""
+import numpy as np
+import pytest
+import torch
+
+from test_training import _oracle_grads
+
+CASES = {
+    "quadgraph_cat": dict(region_graph="quad-graph", input_layer="categorical"),
+    "pd_gauss": dict(region_graph="poon-domingos", input_layer="gaussian"),
+    "quadtree_cat": dict(region_graph="quad-tree-2", input_layer="categorical"),
+}
+
+
+def _case(name, B, seed=4):
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+
+    kw = CASES[name]
+    plan = image_data((1, 8, 8), num_input_units=64, num_sum_units=64, sum_product_layer="cp", **kw)
+    tensors = init_plan_tensors(plan, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, 64), generator=g) if kw["input_layer"] == "gaussian" else torch.randint(0, 256, (B, 64), generator=g)
+    return plan, tensors, x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,B", [("quadgraph_cat", 150), ("quadgraph_cat", 32), ("quadtree_cat", 600), ("pd_gauss", 150),
+                                    ("pd_gauss", 1000)])
+def test_job_step_gradients_match_the_layerwise_trainer_and_autograd(hip_device, name, B):
+    from cirkit_amd.training import HipTrainer
+
+    plan, tensors, x = _case(name, B)
+    a = HipTrainer(plan, tensors, device=hip_device, optimizer="sgd", jobs=False)
+    b = HipTrainer(plan, tensors, device=hip_device, optimizer="sgd", jobs=True)
+    assert a._jobs is None and b._jobs is not None
+    xd = x.to(hip_device)
+    la = a.loss_and_grads(xd).clone()
+    b.loss_and_grads(xd)
+    lb = b.loss_and_grads(xd).clone()  # (the second pass: nothing may depend on buffers that only start as zeros)
+    torch.cuda.synchronize()
+    assert float(la[1]) == float(lb[1]) == B and abs(float(la[0] - lb[0])) <= 2e-6 * abs(float(la[0]))
+    loss64, ref = _oracle_grads(plan, tensors, x, torch.float64)
+    _, ref32 = _oracle_grads(plan, tensors, x, torch.float32)  # the reference's own fp32 autograd: the yardstick for noise
+    assert abs(-float(lb[0]) / B - loss64) <= 1e-5 * abs(loss64)
+    for k in plan.tensors:
+        ga, gb, want = a.grads[k].cpu().double(), b.grads[k].cpu().double(), ref[k]
+        scale = float(want.abs().max()) + 1e-12
+        err_a, err_b = float((ga - want).abs().max()), float((gb - want).abs().max())
+        err32 = float((ref32[k].double() - want).abs().max())
+        if max(err32, err_a) > 0.05 * scale:
+            # softmax gradients W (dW - <W, dW>) that cancel to rounding noise -- for the reference's fp32 autograd and for the
+            # layer-wise launch list as well: only sanity-bound
+            assert err_b <= 50.0 * max(err32, err_a), (k, err_b, err_a, err32, scale)
+            continue
+        assert err_b <= 2.0 * err_a + 6.0 * err32 + 5e-4 * scale, (k, err_b, err_a, err32, scale)
+        # (deep softmax gradients are cancellation noise in fp32 for every implementation, the reference's included: the
+        #  layer-wise launch list's own deviation is the yardstick)
+        na = abs(float(ga.norm()) - float(want.norm()))
+        assert abs(float(gb.norm()) - float(want.norm())) <= 2e-3 * float(want.norm()) + 2.0 * na + 1e-9, k
+
+
+@pytest.mark.gpu
+def test_job_step_trains_like_the_layerwise_trainer(hip_device):
+    """Five Adam steps of both forms from the same parameters: the log-likelihood they reach (Adam normalises every entry's step,
+    so entries whose gradient is rounding noise differ entry by entry)."""
+    from cirkit_amd.training import HipTrainer
+
+    plan, tensors, x = _case("quadgraph_cat", 256)
+    a = HipTrainer(plan, tensors, device=hip_device, lr=0.01, jobs=False)
+    b = HipTrainer(plan, tensors, device=hip_device, lr=0.01, jobs=True)
+    xd = x.to(hip_device)
+    first = None
+    for _ in range(5):
+        la, lb = a.step(xd).clone(), b.step(xd).clone()
+        first = float(lb[0]) if first is None else first
+    la, lb = a.loss_and_grads(xd).clone(), b.loss_and_grads(xd).clone()
+    torch.cuda.synchronize()
+    assert abs(float(la[0] - lb[0])) <= 2e-4 * abs(float(la[0])) and float(lb[0]) > first
+    assert all(np.isfinite(v).all() for v in b.parameters().values())
+
+
+@pytest.mark.gpu
+def test_job_step_drops_a_batch_with_an_illegal_category(hip_device):
+    from cirkit_amd.training import HipTrainer
+
+    plan, tensors, x = _case("quadgraph_cat", 64)
+    tr = HipTrainer(plan, tensors, device=hip_device, lr=0.01, jobs=True)
+    xd = x.to(hip_device)
+    tr.step(xd)
+    before = {k: v.copy() for k, v in tr.parameters().items()}
+    bad = xd.clone()
+    bad[3, 2] = 999
+    ll = tr.step(bad).cpu()
+    assert bool(torch.isnan(ll[0]))
+    after = tr.parameters()
+    assert all(np.array_equal(before[k], after[k]) for k in before)
+    with pytest.raises(IndexError):
+        tr.check_inputs()
+    tr.step(xd)
+    assert all(np.isfinite(v).all() for v in tr.parameters().values())
