@@ -148,7 +148,7 @@ class RootLaunch(C.Structure):
         ("dtheta_w", C.c_void_p), ("dtheta_c", C.c_void_p), ("theta_w", C.c_void_p), ("m1_w", C.c_void_p), ("m2_w", C.c_void_p),
         ("w_out", C.c_void_p), ("theta_c", C.c_void_p), ("m1_c", C.c_void_p), ("m2_c", C.c_void_p), ("c_out", C.c_void_p),
         ("opt", C.c_void_p), ("bad_flag", C.c_void_p),
-        ("seed_const", C.c_float), ("R", C.c_int32), ("B", C.c_int32), ("mode", C.c_int32), ("n_wg", C.c_int32), ("reserved", C.c_int32),
+        ("seed_const", C.c_float), ("R", C.c_int32), ("B", C.c_int32), ("mode", C.c_int32), ("n_wg", C.c_int32), ("S", C.c_int32),
     ]
 
 
@@ -162,6 +162,9 @@ MIX_JOB_DTYPE = [("w", "<u8"), ("out", "<u8"), ("gx", "<u8"), ("dtheta", "<u8"),
                  ("n_g", "<i4"), ("row0", "<i4"), ("row1", "<i4"), ("split", "<i4"), ("n_split", "<i4"), ("mode", "<i4"),
                  ("S", "<i4"), ("reserved1", "<i8")]
 NSUM_JOB_DTYPE = [("out", "<u8"), ("in_off", "<i4"), ("n_in", "<i4")]
+GAUSS_JOB_DTYPE = [("mean", "<u8"), ("stddev", "<u8"), ("x", "<u8"), ("dmean", "<u8"), ("dsd", "<u8"), ("th_mean", "<u8"), ("m1_mean", "<u8"),
+                   ("m2_mean", "<u8"), ("th_sd", "<u8"), ("m1_sd", "<u8"), ("m2_sd", "<u8"), ("mean_out", "<u8"), ("sd_out", "<u8"),
+                   ("g_off", "<i4"), ("n_g", "<i4"), ("vmin", "<f4"), ("vmax", "<f4"), ("has_ss", "<i4"), ("mode", "<i4")]
 
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
@@ -252,6 +255,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_jobs_mix_bwd": [_p, _i, _p, _i, _l, _p, _p],
     "ck_jobs_nsum": [_p, _i, _p, _l, _p],
     "ck_jobs_root": [C.POINTER(RootLaunch), _p],
+    "ck_jobs_gauss_bwd": [_p, _i, _p, _i, _p, _p],
+    "ck_opt_step_range": [_p, _p, _p, _p, _l, _p, _p],
     "ck_opt_tick": [_p, _p, _p, _p],
     "ck_ll_sum": [_p, _l, _l, _p, _p],
     "ck_program_begin": [C.POINTER(_p)],

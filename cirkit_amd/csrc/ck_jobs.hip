@@ -376,8 +376,9 @@ __global__ void __launch_bounds__(WAVES * 64)
 }
 
 // ---- mixing jobs ----------------------------------------------------------------------------------------------------------
-// out[k] = log(sum_h w[k, h] e_h[k]) + m,  e_h[k] = exp(x_h[k] - m),  m = the maximum of the row over (h, k)  (a TorchSumLayer
-// whose weight is a TorchMixingWeightParameter, nodes.py:847-862, under semiring.py:383-408);  x_h = the sum of slot h's blocks.
+// out[k] = log(sum_h w[k, h] e_h[k]) + m[k],  e_h[k] = exp(x_h[k] - m[k]),  m[k] = max_h x_h[k]  (a TorchSumLayer whose weight is a
+// TorchMixingWeightParameter, nodes.py:847-862, under semiring.py:383-408: the reference shifts by the maximum of the whole row,
+// the value is the same for any shift that bounds the unit's own inputs);  x_h = the sum of slot h's blocks.
 // 256 threads: 16 rows per pass, thread (r, c) owns units 4 c .. 4 c + 3 of its row.
 __global__ void __launch_bounds__(256)
     jobs_mix_fwd_kernel(const MixJob* __restrict__ jobs, const float* const* __restrict__ pool) {
@@ -391,29 +392,24 @@ __global__ void __launch_bounds__(256)
     const int b = b0 + r;
     const bool live = b < row1;
     const int64_t bl = live ? b : row1 - 1;
-    float m = -INFINITY;
-    for (int hs = 0; hs < H * S; hs += S) {
-      float4 x = ck::gload4(pool[in_off + hs] + bl * kU + 4 * c);
-      for (int s = 1; s < S; ++s) {
-        const float4 t = ck::gload4(pool[in_off + hs + s] + bl * kU + 4 * c);
-        x.x += t.x, x.y += t.y, x.z += t.z, x.w += t.w;
-      }
-      m = fmaxf(fmaxf(m, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
-    }
-    m = ck::clamp_finite(row16_reduce_max(m));
-    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ONE pass over the slots: a running maximum PER UNIT (the sum of a unit only involves that unit's inputs, so any
+    // shift that bounds them gives the reference's value; the reference shifts by the maximum of the whole row)
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), y = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int h = 0; h < H; ++h) {
       float4 x = ck::gload4(pool[in_off + h * S] + bl * kU + 4 * c);
       for (int s = 1; s < S; ++s) {
         const float4 t = ck::gload4(pool[in_off + h * S + s] + bl * kU + 4 * c);
         x.x += t.x, x.y += t.y, x.z += t.z, x.w += t.w;
       }
-      y.x = fmaf(w_s[(4 * c + 0) * 17 + h], expf(x.x - m), y.x);
-      y.y = fmaf(w_s[(4 * c + 1) * 17 + h], expf(x.y - m), y.y);
-      y.z = fmaf(w_s[(4 * c + 2) * 17 + h], expf(x.z - m), y.z);
-      y.w = fmaf(w_s[(4 * c + 3) * 17 + h], expf(x.w - m), y.w);
+      const float4 mn = make_float4(ck::clamp_finite(fmaxf(m.x, x.x)), ck::clamp_finite(fmaxf(m.y, x.y)), ck::clamp_finite(fmaxf(m.z, x.z)),
+                                    ck::clamp_finite(fmaxf(m.w, x.w)));
+      y.x = fmaf(w_s[(4 * c + 0) * 17 + h], expf(x.x - mn.x), y.x * expf(m.x - mn.x));
+      y.y = fmaf(w_s[(4 * c + 1) * 17 + h], expf(x.y - mn.y), y.y * expf(m.y - mn.y));
+      y.z = fmaf(w_s[(4 * c + 2) * 17 + h], expf(x.z - mn.z), y.z * expf(m.z - mn.z));
+      y.w = fmaf(w_s[(4 * c + 3) * 17 + h], expf(x.w - mn.w), y.w * expf(m.w - mn.w));
+      m = mn;
     }
-    if (live) ck::gstore4(J.out + bl * kU + 4 * c, make_float4(logf(y.x) + m, logf(y.y) + m, logf(y.z) + m, logf(y.w) + m));
+    if (live) ck::gstore4(J.out + bl * kU + 4 * c, make_float4(logf(y.x) + m.x, logf(y.y) + m.y, logf(y.z) + m.z, logf(y.w) + m.w));
   }
 }
 
@@ -439,7 +435,7 @@ __global__ void __launch_bounds__(256)
     const bool live = b < row1;
     const int64_t bl = live ? b : row1 - 1;
     float4 x[HMAX];
-    float m = -INFINITY;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
     for (int h = 0; h < HMAX; ++h)
       if (h < H) {
@@ -448,14 +444,14 @@ __global__ void __launch_bounds__(256)
           const float4 t = ck::gload4(pool[in_off + h * S + s] + bl * kU + 4 * c);
           x[h].x += t.x, x[h].y += t.y, x[h].z += t.z, x[h].w += t.w;
         }
-        m = fmaxf(fmaxf(m, fmaxf(x[h].x, x[h].y)), fmaxf(x[h].z, x[h].w));
+        m = make_float4(fmaxf(m.x, x[h].x), fmaxf(m.y, x[h].y), fmaxf(m.z, x[h].z), fmaxf(m.w, x[h].w));  // (per unit, as the forward)
       }
-    m = ck::clamp_finite(row16_reduce_max(m));
+    m = make_float4(ck::clamp_finite(m.x), ck::clamp_finite(m.y), ck::clamp_finite(m.z), ck::clamp_finite(m.w));
     float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int h = 0; h < HMAX; ++h)
       if (h < H) {
-        x[h] = make_float4(expf(x[h].x - m), expf(x[h].y - m), expf(x[h].z - m), expf(x[h].w - m));
+        x[h] = make_float4(expf(x[h].x - m.x), expf(x[h].y - m.y), expf(x[h].z - m.z), expf(x[h].w - m.w));
         y.x = fmaf(w_s[(4 * c + 0) * 17 + h], x[h].x, y.x);
         y.y = fmaf(w_s[(4 * c + 1) * 17 + h], x[h].y, y.y);
         y.z = fmaf(w_s[(4 * c + 2) * 17 + h], x[h].z, y.z);
@@ -580,6 +576,11 @@ __global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int R = a.R, B = a.B;
   const bool bad = a.bad_flag != nullptr && *a.bad_flag != 0;
+  // the block pointers of every (fold, list position) once, in LDS: a row's loads are then issued together (one round trip)
+  __shared__ const float* ptr_s[kRootMax * 4];
+  const int S = a.S;
+  for (int i = threadIdx.x; i < R * S; i += 256) ptr_s[(i / S) * 4 + (i % S)] = a.pool[a.in_off[i / S] + (i % S)];
+  __syncthreads();
   float wr[kRootMax], dw[kRootMax], dc[kRootMax], cr[kRootMax];
 #pragma unroll
   for (int r = 0; r < kRootMax; ++r) {
@@ -593,10 +594,18 @@ __global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) 
     float e[kRootMax], o[kRootMax], yr[kRootMax];
     float M = -INFINITY;
 #pragma unroll
+    for (int r = 0; r < kRootMax; ++r) {
+      e[r] = 0.f;
+      if (r < R) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+          if (s2 < S) e[r] += *ck::as_global(ptr_s[r * 4 + s2] + static_cast<int64_t>(b) * kU + lane);
+      }
+    }
+#pragma unroll
     for (int r = 0; r < kRootMax; ++r)
       if (r < R) {
-        float v = 0.f;
-        for (int s = 0; s < a.n_in[r]; ++s) v += a.pool[a.in_off[r] + s][static_cast<int64_t>(b) * kU + lane];
+        const float v = e[r];
         const float m = ck::clamp_finite(ck::wave_max(v));
         e[r] = expf(v - m);
         yr[r] = ck::wave_sum(wr[r] * e[r]);
@@ -663,8 +672,16 @@ __global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) 
   float* tot = &red[0][0];
   for (int i = threadIdx.x; i < n_part; i += 256) {
     float t = 0.f;
-    for (unsigned int g = 0; g < gridDim.x; ++g)
-      t += __hip_atomic_load(a.part + static_cast<int64_t>(g) * (kRootMax * kU + kRootMax + 2) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned int g0 = 0; g0 < gridDim.x; g0 += 8) {  // eight slots' loads in flight, added in workgroup order
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        v[k] = g0 + k < gridDim.x ? __hip_atomic_load(a.part + static_cast<int64_t>(g0 + k) * (kRootMax * kU + kRootMax + 2) + i, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT)
+                                  : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += v[k];
+    }
     tot[i] = t;
   }
   if (threadIdx.x == 0) {
@@ -728,6 +745,96 @@ __global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) 
         }
         a.c_out[lane] = ex / sum;
       }
+    }
+  }
+}
+
+// ---- Gaussian input layers -------------------------------------------------------------------------------------------------------
+// One fold of a TorchGaussianLayer (layers/input.py:661-670): log N(x; mu_k, sigma_k) per unit k.  With G the sum of the fold's
+// gradient blocks:  d mu_k = sum_b G[b, k] (x_b - mu_k) / sigma_k^2,   d sigma_k = sum_b G[b, k] ((x_b - mu_k)^2 / sigma_k^2 - 1) / sigma_k
+// (a NaN x_b -- a marginalised variable -- contributes nothing), then through the scaled sigmoid behind sigma
+// (nodes.py:698-699: sigma = vmin + (vmax - vmin) sigmoid(theta), d theta = d sigma (sigma - vmin)(vmax - sigma) / (vmax - vmin)).
+__global__ void __launch_bounds__(256)
+    jobs_gauss_bwd_kernel(const ck_gauss_job* __restrict__ jobs, const float* const* __restrict__ pool, const ck_opt_state* __restrict__ opt,
+                          int B) {
+  __shared__ float red[4][2][kU];
+  const ck_gauss_job& J = jobs[blockIdx.x];
+  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+  const float4 mu = ck::gload4(J.mean + 4 * c), sd = ck::gload4(J.stddev + 4 * c);
+  const float4 is = make_float4(1.f / sd.x, 1.f / sd.y, 1.f / sd.z, 1.f / sd.w);
+  float4 dm = make_float4(0.f, 0.f, 0.f, 0.f), ds = dm;
+  const int g_off = J.g_off, n_g = J.n_g;
+  for (int b = r; b < B; b += 16) {
+    const float x = J.x[b];
+    float4 g = ck::gload4(pool[g_off] + static_cast<int64_t>(b) * kU + 4 * c);
+    for (int s2 = 1; s2 < n_g; ++s2) {
+      const float4 t = ck::gload4(pool[g_off + s2] + static_cast<int64_t>(b) * kU + 4 * c);
+      g.x += t.x, g.y += t.y, g.z += t.z, g.w += t.w;
+    }
+    if (x == x) {
+      const float4 z = make_float4((x - mu.x) * is.x, (x - mu.y) * is.y, (x - mu.z) * is.z, (x - mu.w) * is.w);
+      dm.x = fmaf(g.x, z.x * is.x, dm.x), dm.y = fmaf(g.y, z.y * is.y, dm.y), dm.z = fmaf(g.z, z.z * is.z, dm.z), dm.w = fmaf(g.w, z.w * is.w, dm.w);
+      ds.x = fmaf(g.x, (z.x * z.x - 1.f) * is.x, ds.x), ds.y = fmaf(g.y, (z.y * z.y - 1.f) * is.y, ds.y);
+      ds.z = fmaf(g.z, (z.z * z.z - 1.f) * is.z, ds.z), ds.w = fmaf(g.w, (z.w * z.w - 1.f) * is.w, ds.w);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float v[8] = {dm.x, dm.y, dm.z, dm.w, ds.x, ds.y, ds.z, ds.w};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] += __shfl_xor(v[k], 16, 64);
+    v[k] += __shfl_xor(v[k], 32, 64);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      red[wave][0][4 * c + k] = v[k];
+      red[wave][1][4 * c + k] = v[4 + k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= 2 * kU) return;
+  const int which = threadIdx.x >> 6, k = threadIdx.x & 63;  // wave 0: the means, wave 1: the standard deviations
+  float g = (red[0][which][k] + red[1][which][k]) + (red[2][which][k] + red[3][which][k]);
+  const float sdk = J.stddev[k];
+  if (which == 1 && J.has_ss) g *= (sdk - J.vmin) * (J.vmax - sdk) / (J.vmax - J.vmin);
+  float* dst = which == 0 ? J.dmean : J.dsd;
+  if (J.mode != 2) {
+    dst[k] = g;
+    return;
+  }
+  const ck_opt_state os = *opt;
+  if (os.skip_now) return;
+  float* th = which == 0 ? J.th_mean : J.th_sd;
+  float* m1 = which == 0 ? J.m1_mean : J.m1_sd;
+  float* m2 = which == 0 ? J.m2_mean : J.m2_sd;
+  float a = os.kind ? m1[k] : 0.f, b2 = os.kind ? m2[k] : 0.f;
+  const float t = opt_update(os, th[k], g, a, b2);
+  th[k] = t;
+  if (os.kind) {
+    m1[k] = a;
+    m2[k] = b2;
+  }
+  if (which == 0) {
+    if (J.mean_out != nullptr) J.mean_out[k] = t;
+  } else {
+    J.sd_out[k] = J.has_ss ? J.vmin + (J.vmax - J.vmin) / (1.f + expf(-t)) : t;
+  }
+}
+
+// The optimizer step on one flat range with the constants and clock of a DEVICE ck_opt_state (recordable: nothing of the step
+// count is baked into the launch) -- the tensors no job epilogue updates.
+__global__ void __launch_bounds__(256)
+    opt_range_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, int64_t n,
+                     const ck_opt_state* __restrict__ opt) {
+  const ck_opt_state os = *opt;
+  if (os.skip_now) return;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
+    float a = os.kind ? m1[i] : 0.f, b = os.kind ? m2[i] : 0.f;
+    p[i] = opt_update(os, p[i], g[i], a, b);
+    if (os.kind) {
+      m1[i] = a;
+      m2[i] = b;
     }
   }
 }
@@ -820,11 +927,33 @@ int ck_jobs_root(const ck_root_launch* a, void* stream) {
   CK_REQUIRE(a->R >= 1 && a->R <= kRootMax && a->B > 0, "ck_jobs_root: 1..16 scalar folds");
   CK_REQUIRE(a->c != nullptr || a->R == 1, "ck_jobs_root: several scalar folds need the final mixing coefficients");
   CK_REQUIRE(a->n_wg >= 1 && a->n_wg <= 64, "ck_jobs_root: 1..64 workgroups");
+  CK_REQUIRE(a->S >= 1 && a->S <= 4, "ck_jobs_root: 1..4 blocks per scalar fold");
   CK_REQUIRE(a->gx == nullptr || a->mode == 0 || a->mode == 1 || (a->mode == 2 && a->opt), "ck_jobs_root: bad mode");
   const ck_root_launch v = *a;
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(jobs_root_kernel, dim3(v.n_wg), dim3(256), 0, s, v);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_jobs_gauss_bwd(const ck_gauss_job* jobs, int n_jobs, const float* const* pool, int B, const ck_opt_state* opt, void* stream) {
+  CK_REQUIRE(jobs && pool && n_jobs > 0 && B > 0, "ck_jobs_gauss_bwd: bad arguments");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(jobs_gauss_bwd_kernel, dim3(n_jobs), dim3(256), 0, s, jobs, pool, opt, B);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_opt_step_range(float* p, const float* g, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream) {
+  CK_REQUIRE(p && g && opt && n > 0, "ck_opt_step_range: bad arguments");
+  const unsigned grid = static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 2048));
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(opt_range_kernel, dim3(grid), dim3(256), 0, s, p, g, m1, m2, n, opt);
         return hipGetLastError();
       },
       stream);

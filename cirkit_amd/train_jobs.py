@@ -61,6 +61,9 @@ class JobStep:
         self.tr = trainer
         self.c = trainer.circuit
         self._bound: dict[int, dict] = {}
+        self._opt: torch.Tensor | None = None
+        self._opt_key = None
+        self._own_state = None  # the store's state after this object's last in-place update (fused optimizer)
         self.why = self._analyse()
 
     # ---- analysis -------------------------------------------------------------------------------------------------------
@@ -76,6 +79,7 @@ class JobStep:
         self.mix_jobs: list[dict] = []
         self.nsum_jobs: list[dict] = []
         self.inputs: list[int] = []
+        self.gauss: dict[int, list[dict]] = {}  # Gaussian layers whose folds are backward jobs
         self.n_extra = 0
         gsrc: dict[tuple, list] = {}
         producer: dict[tuple, dict] = {}  # block -> the job that writes it (forward)
@@ -137,6 +141,22 @@ class JobStep:
                 for f in range(F):
                     vals[(i, f)] = [("a", i, f)]
                 self.inputs.append(i)
+                # mean = a tensor, stddev = a tensor or its scaled sigmoid (what the templates build): the fold's backward is a
+                # job of its own (`ck_jobs_gauss_bwd`) reading its gradient list; anything else takes the layer-wise launches
+                recs = []
+                for f in range(F):
+                    em, es = _out_expr(l.mean.graph, f), _out_expr(l.stddev.graph, f)
+                    ss = es[0] == "scaled_sigmoid"
+                    et = es[3] if ss else es
+                    if em[0] != "tensor" or et[0] != "tensor" or l.scope_idx.shape[1] != 1:
+                        recs = None
+                        break
+                    cfg = l.stddev.graph.nodes[es[1]].config if ss else {}
+                    recs.append({"mean": (em[3], em[2]), "sd": (et[3], et[2]), "ss": ss, "vmin": float(cfg.get("vmin", 0.0)),
+                                 "vmax": float(cfg.get("vmax", 1.0))})
+                if recs is not None and all(claim(r["mean"][0], r["mean"][1], f"layer {i}") and claim(r["sd"][0], r["sd"][1], f"layer {i}")
+                                            for r in recs):
+                    self.gauss[i] = recs
             elif isinstance(l, HipHadamardLayer):
                 for f in range(F):
                     lst = gather(ch[f])
@@ -157,7 +177,7 @@ class JobStep:
                     for f in range(F):
                         if not claim(name, f, f"layer {i}"):
                             return f"tensor {name} is shared"
-                        scalars[(i, f)] = {"layer": i, "fold": f, "ins": gather(ch[f]), "theta": (name, f)}
+                        scalars[(i, f)] = {"layer": i, "fold": f, "ins": shorten(gather(ch[f])), "theta": (name, f)}
                 elif Ko == 1 and Ki == 1 and l._mixing and l.weight.mixing_softmax_source() is not None and F == 1 and i == po:
                     name = l.weight.graph.nodes[0].config["tensor"]
                     if not claim(name, 0, f"layer {i}"):
@@ -235,7 +255,7 @@ class JobStep:
         if len(order) > 16:
             return "more than 16 scalar folds under the final mixing layer"
         g0 = extra(len(order))
-        self.root = {"folds": [scalars[k] for k in order], "mix": final_mix, "gx0": g0}
+        self.root = {"folds": [scalars[k] for k in order], "mix": final_mix, "gx0": g0, "zero": extra()}  # (a block nobody writes)
         for r, k in enumerate(order):
             feed(scalars[k]["ins"], ("x", g0 + r))
         if not self.sum_jobs:
@@ -295,7 +315,7 @@ class JobStep:
         self.input_g: dict[int, dict] = {}
         for i in self.inputs:
             Fi = c.layers[i].num_folds
-            first = extra(Fi)
+            first = -1 if i in self.gauss else extra(Fi)
             lists = [list(self._sources(("a", i, f))) for f in range(Fi)]
             if any(not lst for lst in lists):
                 return f"input layer {i} has a fold nobody reads"
@@ -329,6 +349,34 @@ class JobStep:
         t = c.layers[i].weight._last_outs[node]
         return t.data_ptr() + fold * (t.numel() // t.shape[0]) * 4
 
+    def _uncovered(self) -> list[int]:
+        """Input layers whose parameters no job epilogue updates (their gradients go to the flat buffer; the fused step runs
+        the optimizer on their tensors' ranges and re-evaluates their parameter graphs at its start)."""
+        return [i for i in self.inputs if i not in self.gauss]
+
+    def _opt_state(self) -> torch.Tensor:
+        """The DEVICE ck_opt_state of the fused optimizer (created on first use; its constants follow the trainer's)."""
+        tr = self.tr
+        key = (float(tr.lr), tuple(float(b) for b in tr.betas), float(tr.eps), tr.optimizer)
+        if self._opt is None:
+            o = capi.OptState()
+            o.lr, o.b1, o.b2, o.eps, o.bc1, o.bc2 = tr.lr, tr.betas[0], tr.betas[1], tr.eps, 1.0, 1.0
+            o.step, o.skipped, o.skip_now, o.kind = 0, 0, 0, 1 if tr.optimizer == "adam" else 0
+            self._opt = torch.frombuffer(bytearray(bytes(o)), dtype=torch.uint8).to(self.c.device)
+            self._opt_key = key
+        elif key != self._opt_key:  # (the learning rate was changed between steps: the first 16 bytes)
+            head = torch.tensor([tr.lr, tr.betas[0], tr.betas[1], tr.eps], dtype=torch.float32).view(torch.uint8)
+            self._opt[:16].copy_(head.to(self.c.device))
+            self._opt_key = key
+        return self._opt
+
+    def opt_counters(self) -> tuple[int, int]:
+        """(steps taken, steps dropped) of the fused optimizer (a device read)."""
+        if self._opt is None:
+            return 0, 0
+        v = self._opt[24:32].cpu().view(torch.int32)
+        return int(v[0]), int(v[1])
+
     def bind(self, B: int) -> dict:
         tr, c = self.tr, self.c
         bd = c._bind(B)
@@ -336,7 +384,8 @@ class JobStep:
         if st is not None and st["arena_ptr"] == bd.arena.data_ptr() and st["store_version"] == c.store.version:
             return st
         if st is not None:
-            capi.load().ck_program_destroy(st["prog"])
+            for pr in st["prog"].values():
+                capi.load().ck_program_destroy(pr)
         dev = c.device
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -360,7 +409,7 @@ class JobStep:
             pool.extend(addr(x) for x in blocks)
             return off, len(blocks)
 
-        grads, flat_g, flat_p = tr.grads, tr._flat_grad, tr._flat_param
+        grads, flat_p = tr.grads, tr._flat_param
 
         def grad_ptr(theta) -> int:
             t = grads[theta[0]]
@@ -375,14 +424,43 @@ class JobStep:
             return p, m1, m2
 
         tiles = (B + 31) // 32
-        parts: list[torch.Tensor] = []
         keep: list[torch.Tensor] = [extra]
+
+        def upload(tab: np.ndarray, both_modes: bool) -> dict:
+            """The DEVICE copy of a job table -- for the backward launches one per mode (1: d theta to the flat gradient,
+            2: the optimizer's update in the epilogue)."""
+            out = {}
+            for mode in ((1, 2) if both_modes else (1,)):
+                if both_modes:
+                    tab["mode"] = mode
+                t = torch.from_numpy(tab.view(np.uint8).reshape(len(tab), -1).copy()).to(dev)
+                keep.append(t)
+                out[mode] = t
+            return out
 
         def splits_for(n_jobs: int, max_split: int) -> int:
             return int(max(1, min(max_split, -(-2 * n_cu // max(1, n_jobs)))))
 
-        def sum_table(jobs: list[dict], backward: bool) -> tuple[torch.Tensor, int]:
-            ns = splits_for(len(jobs), max(1, tiles // 4))
+        def sum_splits(n_jobs: int, backward: bool) -> int:
+            """Row splits per job of a sum launch: the launch runs in ROUNDS of as many workgroups as the chip holds (2 per CU
+            for the backward kernel, 4 for the forward one) and a round lasts as long as one unit, so 1040 jobs on 512 slots
+            take three rounds where 2.03 would do -- finer units waste less of the last round, at a fixed cost per unit
+            (weights staged again; backward: the partial sums of dW through memory).  Measured unit times [MI355X]: backward
+            ~8 us + 12 us per tile and wave (+5 us with partial sums), forward ~3 us + 6 us."""
+            slots = n_cu * (2 if backward else 4)
+            t_fix, t_tile = (8.0, 12.0) if backward else (3.0, 6.0)
+            best, best_t = 1, None
+            for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+                if sp > 1 and -(-tiles // sp) < 4:  # (at least a tile per wave)
+                    break
+                per_wave = -(-(-(-tiles // sp)) // 4)
+                t = -(-n_jobs * sp // slots) * (t_fix + (5.0 if (backward and sp > 1) else 0.0) + t_tile * per_wave)
+                if best_t is None or t < best_t - 1e-9:
+                    best, best_t = sp, t
+            return best
+
+        def sum_table(jobs: list[dict], backward: bool) -> tuple[dict, int]:
+            ns = sum_splits(len(jobs), backward)
             rows_per = -(-tiles // ns) * 32
             ns = -(-B // rows_per)
             tab = np.zeros(len(jobs) * ns, dtype=np.dtype(capi.SUM_JOB_DTYPE))
@@ -405,11 +483,9 @@ class JobStep:
                     r["split"], r["n_split"], r["mode"] = sp, ns, 1
                     if part is not None:
                         r["part"], r["ticket"] = part.data_ptr() + n * ns * 4096 * 4, tick.data_ptr() + n * 4
-            t = torch.from_numpy(tab.view(np.uint8).reshape(len(tab), -1)).to(dev)
-            keep.append(t)
-            return t, len(tab)
+            return upload(tab, backward), len(tab)
 
-        def mix_table(jobs: list[dict], backward: bool) -> tuple[torch.Tensor, int, int]:
+        def mix_table(jobs: list[dict], backward: bool) -> tuple[dict, int, int]:
             hmax = max(j["H"] for j in jobs)
             hpad = 2 if hmax <= 2 else 4 if hmax <= 4 else 8 if hmax <= 8 else 16
             ns = splits_for(len(jobs), max(1, B // 64))
@@ -435,18 +511,34 @@ class JobStep:
                     r["split"], r["n_split"], r["mode"] = sp, ns, 1
                     if part is not None:
                         r["part"], r["ticket"] = part.data_ptr() + n * ns * K * hpad * 4, tick.data_ptr() + n * 4
-            t = torch.from_numpy(tab.view(np.uint8).reshape(len(tab), -1)).to(dev)
-            keep.append(t)
-            return t, len(tab), hmax
+            return upload(tab, backward), len(tab), hmax
 
-        def nsum_table(items: list[tuple[list, int]]) -> tuple[torch.Tensor, int]:
+        def nsum_table(items: list[tuple[list, int]]) -> tuple[dict, int]:
             tab = np.zeros(len(items), dtype=np.dtype(capi.NSUM_JOB_DTYPE))
             for r, (ins, out) in zip(tab, items):
                 r["in_off"], r["n_in"] = put(ins)
                 r["out"] = out
-            t = torch.from_numpy(tab.view(np.uint8).reshape(len(tab), -1)).to(dev)
-            keep.append(t)
-            return t, len(tab)
+            return upload(tab, False), len(tab)
+
+        def gauss_table(i: int) -> tuple[dict, int]:
+            l = c.layers[i]
+            mean, stddev, _ = l._vals
+            recs = self.gauss[i]
+            tab = np.zeros(len(recs), dtype=np.dtype(capi.GAUSS_JOB_DTYPE))
+            for f, (r, rec, lst) in enumerate(zip(tab, recs, self.input_g[i]["lists"])):
+                thm, m1m, m2m = theta_ptrs(rec["mean"])
+                ths, m1s, m2s = theta_ptrs(rec["sd"])
+                mp, sp_ = mean.data_ptr() + f * K * 4, stddev.data_ptr() + f * K * 4
+                r["mean"], r["stddev"] = mp, sp_
+                r["x"] = bd.xt.data_ptr() + int(l.scope_idx[f, 0]) * B * 4
+                r["dmean"], r["dsd"] = grad_ptr(rec["mean"]), grad_ptr(rec["sd"])
+                r["th_mean"], r["m1_mean"], r["m2_mean"] = thm, m1m, m2m
+                r["th_sd"], r["m1_sd"], r["m2_sd"] = ths, m1s, m2s
+                r["mean_out"] = 0 if mp == thm else mp
+                r["sd_out"] = sp_
+                r["g_off"], r["n_g"] = put(lst)
+                r["vmin"], r["vmax"], r["has_ss"], r["mode"] = rec["vmin"], rec["vmax"], 1 if rec["ss"] else 0, 1
+            return upload(tab, True), len(tab)
 
         def by_level(jobs: list[dict], key: str) -> dict[int, list[dict]]:
             out: dict[int, list[dict]] = {}
@@ -454,7 +546,7 @@ class JobStep:
                 out.setdefault(j[key], []).append(j)
             return out
 
-        launches: list[tuple] = []  # (what, table, n, ...), in issue order
+        launches: list[tuple] = []  # (what, table(s), n, ...), in issue order
         fs, fm, fn = by_level(self.sum_jobs, "lf"), by_level(self.mix_jobs, "lf"), by_level(self.nsum_jobs, "lf")
         for lv in sorted(set(fs) | set(fm) | set(fn)):
             if lv in fn:
@@ -465,7 +557,7 @@ class JobStep:
                 launches.append(("mix_fwd",) + mix_table(fm[lv], False))
         launches.append(("root",))
         bs, bm, bg = by_level(self.sum_jobs, "lb"), by_level(self.mix_jobs, "lb"), by_level(self.gsum_jobs, "lb")
-        bi = {}
+        bi: dict[int, list[int]] = {}
         for i, ig in self.input_g.items():
             bi.setdefault(ig["lb"], []).append(i)
         for lv in sorted(set(bs) | set(bm) | set(bg) | set(bi)):
@@ -477,66 +569,97 @@ class JobStep:
                 launches.append(("mix_bwd",) + mix_table(bm[lv], True))
             for i in bi.get(lv, []):
                 ig = self.input_g[i]
-                launches.append(("input_bwd", i) + nsum_table([(lst, x0 + (ig["first"] + f) * blk * 4) for f, lst in enumerate(ig["lists"])]))
+                if i in self.gauss:
+                    launches.append(("gauss_bwd", i) + gauss_table(i))
+                else:
+                    launches.append(("input_bwd", i) + nsum_table([(lst, x0 + (ig["first"] + f) * blk * 4) for f, lst in enumerate(ig["lists"])]))
         # the root launch
         root = self.root
         R = len(root["folds"])
         rin = np.zeros((2, R), dtype=np.int32)
         ptrs = np.zeros((6, R), dtype=np.uint64)  # w, dtheta, theta, m1, m2, w_out
-        for r, sc in enumerate(root["folds"]):
-            rin[0, r], rin[1, r] = put(sc["ins"])
+        S_root = max(len(sc["ins"]) for sc in root["folds"])
+        for r, sc in enumerate(root["folds"]):  # (lists of one length: shorter ones are padded with the block of zeros)
+            rin[0, r], rin[1, r] = put(list(sc["ins"]) + [("x", root["zero"])] * (S_root - len(sc["ins"])))
             l = c.layers[sc["layer"]]
             w = l._w.data_ptr() + sc["fold"] * K * 4
             th, m1, m2 = theta_ptrs(sc["theta"])
             ptrs[:, r] = (w, grad_ptr(sc["theta"]), th, m1, m2, w)
         rin_d = torch.from_numpy(rin).to(dev)
         ptrs_d = torch.from_numpy(ptrs.view(np.int64)).to(dev)
-        n_wg = int(max(1, min(64, (B + 3) // 4)))
+        n_wg = int(max(1, min(64, B // 16)))
         rpart = torch.zeros(n_wg * 1042, dtype=torch.float32, device=dev)
         rtick = torch.zeros(1, dtype=torch.int32, device=dev)
         seed = torch.zeros(B, dtype=torch.float32, device=dev)
         pool_d = torch.from_numpy(np.asarray(pool, dtype=np.uint64).view(np.int64)).to(dev)
         keep.extend([rin_d, ptrs_d, rpart, rtick, seed, pool_d])
-        ra = capi.RootLaunch()
-        ra.pool, ra.in_off, ra.n_in = pool_d.data_ptr(), rin_d[0].data_ptr(), rin_d[1].data_ptr()
-        ra.w, ra.dtheta_w, ra.theta_w = ptrs_d[0].data_ptr(), ptrs_d[1].data_ptr(), ptrs_d[2].data_ptr()
-        ra.m1_w, ra.m2_w, ra.w_out = ptrs_d[3].data_ptr(), ptrs_d[4].data_ptr(), ptrs_d[5].data_ptr()
-        po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
-        ra.out = bd.views[po][fo].data_ptr()
-        ra.gx, ra.seed, ra.ll = x0 + root["gx0"] * blk * 4, seed.data_ptr(), bd.ll.data_ptr()
-        ra.part, ra.ticket = rpart.data_ptr(), rtick.data_ptr()
-        if root["mix"] is not None:
-            lm = c.layers[root["mix"]["layer"]]
-            th, m1, m2 = theta_ptrs(root["mix"]["theta"])
-            ra.c, ra.dtheta_c = lm._w.data_ptr(), grad_ptr(root["mix"]["theta"])
-            ra.theta_c, ra.m1_c, ra.m2_c, ra.c_out = th, m1, m2, lm._w.data_ptr()
-        ra.opt, ra.bad_flag = None, (c._bad_input.data_ptr() if (c.validate_inputs and c._int_input) else None)
-        ra.seed_const, ra.R, ra.B, ra.mode, ra.n_wg = 0.0, R, B, 1, n_wg
-        st = {"arena_ptr": bd.arena.data_ptr(), "store_version": c.store.version, "keep": keep, "launches": launches, "root": ra,
-              "pool": pool_d, "seed": seed, "seed_value": None, "extra": extra, "x0": x0, "prog": None, "dT": {}}
-        st["prog"] = self._record(bd, st, B)
+        opt = self._opt_state()
+
+        def root_args(mode: int):
+            ra = capi.RootLaunch()
+            ra.pool, ra.in_off, ra.n_in = pool_d.data_ptr(), rin_d[0].data_ptr(), rin_d[1].data_ptr()
+            ra.w, ra.dtheta_w, ra.theta_w = ptrs_d[0].data_ptr(), ptrs_d[1].data_ptr(), ptrs_d[2].data_ptr()
+            ra.m1_w, ra.m2_w, ra.w_out = ptrs_d[3].data_ptr(), ptrs_d[4].data_ptr(), ptrs_d[5].data_ptr()
+            po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
+            ra.out = bd.views[po][fo].data_ptr()
+            ra.gx, ra.seed, ra.ll = x0 + root["gx0"] * blk * 4, seed.data_ptr(), bd.ll.data_ptr()
+            ra.part, ra.ticket = rpart.data_ptr(), rtick.data_ptr()
+            if root["mix"] is not None:
+                lm = c.layers[root["mix"]["layer"]]
+                th, m1, m2 = theta_ptrs(root["mix"]["theta"])
+                ra.c, ra.dtheta_c = lm._w.data_ptr(), grad_ptr(root["mix"]["theta"])
+                ra.theta_c, ra.m1_c, ra.m2_c, ra.c_out = th, m1, m2, lm._w.data_ptr()
+            validate = c.validate_inputs and c._int_input
+            # mode 1: the circuit's own flag (latched after the step by the trainer); mode 2: `ck_opt_tick` has moved it into
+            # the optimizer state's skip_now (byte 32) by the time the root launch runs
+            ra.opt = opt.data_ptr() if mode == 2 else None
+            ra.bad_flag = (opt.data_ptr() + 32) if mode == 2 else (c._bad_input.data_ptr() if validate else None)
+            ra.seed_const, ra.R, ra.B, ra.mode, ra.n_wg, ra.S = 0.0, R, B, mode, n_wg, S_root
+            return ra
+
+        st = {"arena_ptr": bd.arena.data_ptr(), "store_version": c.store.version, "keep": keep, "launches": launches,
+              "root": {1: root_args(1), 2: root_args(2)}, "pool": pool_d, "seed": seed, "seed_value": None, "extra": extra, "x0": x0,
+              "prog": {}, "dT": {}}
         while len(self._bound) >= 4:
             old = self._bound.pop(next(iter(self._bound)))
-            capi.load().ck_program_destroy(old["prog"])
+            for pr in old["prog"].values():
+                capi.load().ck_program_destroy(pr)
         self._bound[B] = st
         return st
 
     # ---- the launch list ----------------------------------------------------------------------------------------------------
-    def _record(self, bd, st: dict, B: int):
-        tr, c = self.tr, self.c
-        prog = C.c_void_p()
-        capi.call("ck_program_begin", C.byref(prog))
-        try:
-            self._enqueue(bd, st, B, 0)
-        finally:
-            capi.call("ck_program_end", prog)
+    def _program(self, st: dict, B: int, mode: int):
+        prog = st["prog"].get(mode)
+        if prog is None:
+            bd = self.c._bind(B)
+            prog = C.c_void_p()
+            capi.call("ck_program_begin", C.byref(prog))
+            try:
+                self._enqueue(bd, st, B, mode, 0)
+            finally:
+                capi.call("ck_program_end", prog)
+            st["prog"][mode] = prog
         return prog
 
-    def _enqueue(self, bd, st: dict, B: int, stream: int) -> None:
+    def _enqueue(self, bd, st: dict, B: int, mode: int, stream: int) -> None:
+        """mode 1: parameters, forward, backward with d theta into the trainer's flat gradient (the optimizer launch and the
+        collective follow outside).  mode 2 (one rank): the optimizer runs in the job epilogues -- `ck_opt_tick` first, the
+        parameter graphs of the layers no epilogue covers re-evaluated, and the optimizer on their tensors at the end."""
         tr, c = self.tr, self.c
         pool = st["pool"].data_ptr()
         blk = B * K
-        c._enqueue_params(stream)  # every parameter graph, once per step (parameters/parameter.py:180-188)
+        opt = self._opt_state().data_ptr() if mode == 2 else None
+        validate = c.validate_inputs and c._int_input
+        if mode == 2:
+            capi.call("ck_opt_tick", opt, c._bad_input.data_ptr() if validate else None, tr._bad_seen.data_ptr() if validate else None, stream)
+            for i in self._uncovered():  # their parameter graphs, as every forward of the reference evaluates them
+                idx = c._jobs_of_layer.get(i)
+                if idx:
+                    c._batch.subset(idx).launch(stream)
+                else:
+                    c.layers[i].prepare(stream, batched=False)
+        else:
+            c._enqueue_params(stream)  # every parameter graph, once per step (parameters/parameter.py:180-188)
         D = c.plan.num_variables
         for i in self.inputs:
             l = c.layers[i]
@@ -544,21 +667,39 @@ class JobStep:
         for la in st["launches"]:
             what = la[0]
             if what == "nsum":
-                capi.call("ck_jobs_nsum", la[1].data_ptr(), la[2], pool, blk, stream)
+                capi.call("ck_jobs_nsum", la[1][1].data_ptr(), la[2], pool, blk, stream)
             elif what == "sum_fwd":
-                capi.call("ck_jobs_sum64_fwd", la[1].data_ptr(), la[2], pool, stream)
+                capi.call("ck_jobs_sum64_fwd", la[1][1].data_ptr(), la[2], pool, stream)
             elif what == "mix_fwd":
-                capi.call("ck_jobs_mix_fwd", la[1].data_ptr(), la[2], pool, la[3], stream)
+                capi.call("ck_jobs_mix_fwd", la[1][1].data_ptr(), la[2], pool, la[3], stream)
             elif what == "root":
-                capi.call("ck_jobs_root", C.byref(st["root"]), stream)
+                capi.call("ck_jobs_root", C.byref(st["root"][mode]), stream)
             elif what == "sum_bwd":
-                capi.call("ck_jobs_sum64_bwd", la[1].data_ptr(), la[2], pool, None, stream)
+                capi.call("ck_jobs_sum64_bwd", la[1][mode].data_ptr(), la[2], pool, opt, stream)
             elif what == "mix_bwd":
-                capi.call("ck_jobs_mix_bwd", la[1].data_ptr(), la[2], pool, la[3], blk, None, stream)
+                capi.call("ck_jobs_mix_bwd", la[1][mode].data_ptr(), la[2], pool, la[3], blk, opt, stream)
+            elif what == "gauss_bwd":
+                capi.call("ck_jobs_gauss_bwd", la[2][mode].data_ptr(), la[3], pool, B, opt, stream)
             elif what == "input_bwd":
                 i = la[1]
-                capi.call("ck_jobs_nsum", la[2].data_ptr(), la[3], pool, blk, stream)
+                capi.call("ck_jobs_nsum", la[2][1].data_ptr(), la[3], pool, blk, stream)
                 self._input_backward(i, bd, st, B, stream)
+        if mode == 2:  # the tensors of the layers no epilogue covers: the optimizer on their ranges of the flat buffers
+            for i in self._uncovered():
+                for name in self._tensors_of(i):
+                    t, g = c.store[name], tr.grads[name]
+                    off = t.data_ptr() - tr._flat_param.data_ptr()
+                    capi.call("ck_opt_step_range", t.data_ptr(), g.data_ptr(), (tr._m1.data_ptr() + off) if tr._m1 is not None else None,
+                              (tr._m2.data_ptr() + off) if tr._m2 is not None else None, t.numel(), opt, stream)
+
+    def _tensors_of(self, i: int) -> list[str]:
+        l = self.c.layers[i]
+        names: list[str] = []
+        for p in l.params.values():
+            for n in p.graph.nodes:
+                if n.op == "tensor" and n.config["tensor"] not in names:
+                    names.append(n.config["tensor"])
+        return names
 
     def _input_backward(self, i: int, bd, st: dict, B: int, stream: int) -> None:
         """The backward of input layer i over its gathered (F, B, 64) gradient -- the launches of the layer-wise trainer."""
@@ -575,7 +716,7 @@ class JobStep:
             name = l.probs.graph.nodes[0].config["tensor"]
             capi.call("ck_param_log_table_bwd", l._table.data_ptr(), dT.data_ptr(), tr.grads[name].data_ptr(), l.num_folds, K,
                       l.num_categories, 0, stream)
-        else:  # Gaussian
+        else:  # a Gaussian layer with parameter graphs the job epilogue does not know
             mean, stddev, _ = l._vals
             dm = st["dT"].get((i, "m"))
             if dm is None:
@@ -584,31 +725,48 @@ class JobStep:
             ds = st["dT"][(i, "s")]
             capi.call("ck_gaussian_bwd", g, bd.xt.data_ptr(), l._scope(dev).data_ptr(), mean.data_ptr(), stddev.data_ptr(), dm.data_ptr(),
                       ds.data_ptr(), l.num_folds, B, K, stream)
-            for p in (l.mean, l.stddev):  # (the parameter backward ADDS into the tensors' gradients)
-                for n in p.graph.nodes:
-                    if n.op == "tensor":
-                        t = tr.grads[n.config["tensor"]]
-                        capi.call("ck_fill_f32", t.data_ptr(), t.numel(), 0.0, stream)
+            for name in self._tensors_of(i):  # (the parameter backward ADDS into the tensors' gradients)
+                t = tr.grads[name]
+                capi.call("ck_fill_f32", t.data_ptr(), t.numel(), 0.0, stream)
             l.mean.backward(dm, tr.grads, stream)
             l.stddev.backward(ds, tr.grads, stream)
 
     # ---- one step -------------------------------------------------------------------------------------------------------------
-    def loss_and_grads(self, x: torch.Tensor, gB: float) -> torch.Tensor:
-        """Forward + backward of ``-(1 / gB) sum_b log p(x_b)`` over the recorded launch list; returns the circuit's
-        [sum log p, rows] pair (device, overwritten by the next call at this batch size)."""
+    def _launch(self, x: torch.Tensor, gB: float, mode: int) -> torch.Tensor:
         c = self.c
         B = int(x.shape[0])
         st = self.bind(B)
         bd = c._bind(B)
         with torch.cuda.device(c.device):
             stream = torch.cuda.current_stream(c.device).cuda_stream
+            if mode == 2:
+                self._opt_state()
+                if self._own_state != c.store.state():
+                    # somebody else changed a parameter since this object last derived them: all graphs, once
+                    c._enqueue_params(stream)
+            prog = self._program(st, B, mode)
             if st["seed_value"] != -1.0 / gB:
                 capi.call("ck_fill_f32", st["seed"].data_ptr(), B, -1.0 / gB, stream)
                 st["seed_value"] = -1.0 / gB
             xf, xi = c._prepare_input(x)
             c._stage_input(bd, xf, xi, stream)
-            capi.call("ck_program_launch", st["prog"], 0, stream)
+            capi.call("ck_program_launch", prog, 0, stream)
+            if mode == 2:
+                c.store.touch()
+                self._own_state = c.store.state()
         return bd.ll
 
-    def num_launches(self, B: int) -> int:
-        return int(capi.load().ck_program_num_ops(self.bind(B)["prog"]))
+    def loss_and_grads(self, x: torch.Tensor, gB: float) -> torch.Tensor:
+        """Forward + backward of ``-(1 / gB) sum_b log p(x_b)`` over the recorded launch list; the parameter gradients land in
+        the trainer's flat buffer; returns the circuit's [sum log p, rows] pair (device, overwritten by the next call at this
+        batch size)."""
+        return self._launch(x, gB, 1)
+
+    def step(self, x: torch.Tensor, gB: float) -> torch.Tensor:
+        """One optimisation step with the optimizer inside the job epilogues (a single rank: no gradient leaves the launch
+        that computed it, so there is nothing a collective could reduce)."""
+        return self._launch(x, gB, 2)
+
+    def num_launches(self, B: int, mode: int = 2) -> int:
+        st = self.bind(B)
+        return int(capi.load().ck_program_num_ops(self._program(st, B, mode)))

@@ -56,6 +56,7 @@ class HipTrainer:
         pad_units: bool = False,
         fused: bool | None = None,
         jobs: bool | None = None,
+        fuse_optimizer: bool = True,
     ) -> None:
         """`pad_units`: train the plan with its unit counts padded to multiples of 32 (cirkit_amd/padding.py), so that
         the MFMA forward / backward tiles apply to any width.  The padded entries never receive a gradient (softmax
@@ -65,7 +66,10 @@ class HipTrainer:
         (NotImplementedError says why not), False forces the layer-wise form.
         `jobs`: circuits of 64-unit dense / CP-T / mixing / Hadamard layers (the reference's learning notebook, BASELINE config 4)
         step as level launches over jobs (cirkit_amd/train_jobs.py) when the fused form does not apply: None where the plan
-        qualifies, True insists, False never."""
+        qualifies, True insists, False never.  `fuse_optimizer` (job form, one rank): `step` runs the optimizer inside the job
+        epilogues -- the workgroup that holds a weight's gradient updates its logits and moments and writes the next step's
+        softmax; no gradient, no normalised weight and no optimizer launch for those tensors (`loss_and_grads` still leaves
+        every gradient in `grads`)."""
         if plan.semiring != "lse-sum":
             raise NotImplementedError("HipTrainer trains circuits under the real lse-sum semiring; squared circuits compiled under "
                                       "complex-lse-sum (Embedding / CP-T for c, ConstantValue / Hadamard / TensorDot for Z) train with "
@@ -113,6 +117,7 @@ class HipTrainer:
                                       fused_weight_softmax=False)
         self.device = self.circuit.device
         self._jobs = None
+        self._fuse_optimizer = bool(fuse_optimizer)
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self.step_count = 0
         c = self.circuit
@@ -745,10 +750,14 @@ class HipTrainer:
         of the shard (before the update)."""
         import torch.distributed as dist
 
-        ll = self.loss_and_grads(x, global_batch=global_batch)
         c = self.circuit
-        validate = c.validate_inputs and c._int_input
         alone = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if self._jobs is not None and self._fuse_optimizer and alone:
+            # the whole step is one recorded launch list; the optimizer runs where the gradients are (cirkit_amd/train_jobs.py)
+            self.step_count += 1
+            return self._jobs.step(x, float(global_batch or int(x.shape[0])))
+        ll = self.loss_and_grads(x, global_batch=global_batch)
+        validate = c.validate_inputs and c._int_input
         # a batch with an out-of-range category (NaN log-likelihood) must not reach the parameters.  The flag it raised is THIS
         # step's (fused: handed on by the backward's first launch; layer-wise: latched and cleared below), everything stays on
         # the device -- no host synchronisation: on a single rank the optimizer launch changes nothing at all; with several
@@ -765,6 +774,14 @@ class HipTrainer:
                 capi.call("ck_latch_flag", c._bad_input.data_ptr(), self._bad_seen.data_ptr(),
                           torch.cuda.current_stream(self.device).cuda_stream)
         return ll
+
+    @property
+    def skipped_steps(self) -> int:
+        """Steps that changed nothing because their batch held an illegal category (a device read)."""
+        n = int(self._skipped.item())
+        if self._jobs is not None:
+            n += self._jobs.opt_counters()[1]
+        return n
 
     def check_inputs(self) -> None:
         """Raise ``IndexError`` if a batch since the last check held a category out of range (as

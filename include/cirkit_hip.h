@@ -828,9 +828,36 @@ typedef struct ck_root_launch {
   const ck_opt_state* opt;
   const int32_t* bad_flag;
   float seed_const;
-  int32_t R, B, mode, n_wg, reserved;
+  int32_t R, B, mode, n_wg;
+  int32_t S; /* blocks per scalar fold: every fold's list pool[in_off[r] .. + S) has this length (pad with a block of zeros) */
 } ck_root_launch;
 int ck_jobs_root(const ck_root_launch* a, void* stream);
+/* One fold of a TorchGaussianLayer with 64 units (layers/input.py:661-670), backward: G = the sum of the n_g blocks pool[g_off ..],
+ * x the (B) column of the staged batch (NaN = marginalised); mode 1: dmean / dsd <- the gradients of the tensors behind mean and
+ * stddev (has_ss: stddev = vmin + (vmax - vmin) sigmoid(theta), nodes.py:698-699); mode 2: the optimizer's update in place,
+ * mean_out (or NULL: mean IS its tensor) / sd_out <- the values of the next step. */
+typedef struct ck_gauss_job {
+  const float* mean;
+  const float* stddev;
+  const float* x;
+  float* dmean;
+  float* dsd;
+  float* th_mean;
+  float* m1_mean;
+  float* m2_mean;
+  float* th_sd;
+  float* m1_sd;
+  float* m2_sd;
+  float* mean_out;
+  float* sd_out;
+  int32_t g_off, n_g;
+  float vmin, vmax;
+  int32_t has_ss, mode;
+} ck_gauss_job;
+int ck_jobs_gauss_bwd(const ck_gauss_job* jobs, int n_jobs, const float* const* pool, int B, const ck_opt_state* opt, void* stream);
+/* The optimizer step p <- p - ... on one flat range with the constants and the clock of a DEVICE ck_opt_state (m1 / m2 may be
+ * NULL for SGD): what ck_adam_step / ck_sgd_step do, recordable (no step count in the launch) and skipped with the state. */
+int ck_opt_step_range(float* p, const float* g, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream);
 /* Once per step, before the backward launches: *flag != 0 (the forward's validation flag) -> this step is dropped (skip_now = 1,
  * skipped += 1, *sticky |= *flag, *flag = 0); else step += 1 and the bias corrections of this step.  flag / sticky may be NULL. */
 int ck_opt_tick(ck_opt_state* state, int32_t* flag, int32_t* sticky, void* stream);

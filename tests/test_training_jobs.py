@@ -64,31 +64,44 @@ def test_job_step_gradients_match_the_layerwise_trainer_and_autograd(hip_device,
 
 
 @pytest.mark.gpu
-def test_job_step_trains_like_the_layerwise_trainer(hip_device):
-    """Five Adam steps of both forms from the same parameters: the log-likelihood they reach (Adam normalises every entry's step,
-    so entries whose gradient is rounding noise differ entry by entry)."""
+@pytest.mark.parametrize("name,opt,fuse", [("quadgraph_cat", "adam", True), ("quadgraph_cat", "adam", False), ("pd_gauss", "adam", True),
+                                           ("quadgraph_cat", "sgd", True)])
+def test_job_step_trains_like_the_layerwise_trainer(hip_device, name, opt, fuse):
+    """Five optimizer steps of both forms from the same parameters: the log-likelihood they reach (Adam normalises every entry's
+    step, so entries whose gradient is rounding noise differ entry by entry) -- with the optimizer inside the job epilogues
+    (`fuse_optimizer`, the default on one rank) and with the trainer's own optimizer launch; after SGD steps also the
+    parameters themselves."""
     from cirkit_amd.training import HipTrainer
 
-    plan, tensors, x = _case("quadgraph_cat", 256)
-    a = HipTrainer(plan, tensors, device=hip_device, lr=0.01, jobs=False)
-    b = HipTrainer(plan, tensors, device=hip_device, lr=0.01, jobs=True)
+    plan, tensors, x = _case(name, 256)
+    lr = 0.01 if opt == "adam" else 0.05
+    a = HipTrainer(plan, tensors, device=hip_device, lr=lr, optimizer=opt, jobs=False)
+    b = HipTrainer(plan, tensors, device=hip_device, lr=lr, optimizer=opt, jobs=True, fuse_optimizer=fuse)
     xd = x.to(hip_device)
     first = None
     for _ in range(5):
         la, lb = a.step(xd).clone(), b.step(xd).clone()
         first = float(lb[0]) if first is None else first
+        assert abs(float(la[0] - lb[0])) <= 2e-4 * abs(float(la[0]))  # (step by step: the same trajectory)
     la, lb = a.loss_and_grads(xd).clone(), b.loss_and_grads(xd).clone()
     torch.cuda.synchronize()
     assert abs(float(la[0] - lb[0])) <= 2e-4 * abs(float(la[0])) and float(lb[0]) > first
-    assert all(np.isfinite(v).all() for v in b.parameters().values())
+    pa, pb = a.parameters(), b.parameters()
+    assert all(np.isfinite(v).all() for v in pb.values())
+    if opt == "sgd":
+        for k in pa:
+            assert float(np.abs(pa[k] - pb[k]).max()) <= 1e-4 * max(1.0, float(np.abs(pa[k]).max())), k
+    if fuse:
+        assert b._jobs.opt_counters() == (5, 0) and b.skipped_steps == 0
 
 
 @pytest.mark.gpu
-def test_job_step_drops_a_batch_with_an_illegal_category(hip_device):
+@pytest.mark.parametrize("fuse", [True, False])
+def test_job_step_drops_a_batch_with_an_illegal_category(hip_device, fuse):
     from cirkit_amd.training import HipTrainer
 
     plan, tensors, x = _case("quadgraph_cat", 64)
-    tr = HipTrainer(plan, tensors, device=hip_device, lr=0.01, jobs=True)
+    tr = HipTrainer(plan, tensors, device=hip_device, lr=0.01, jobs=True, fuse_optimizer=fuse)
     xd = x.to(hip_device)
     tr.step(xd)
     before = {k: v.copy() for k, v in tr.parameters().items()}
@@ -100,5 +113,7 @@ def test_job_step_drops_a_batch_with_an_illegal_category(hip_device):
     assert all(np.array_equal(before[k], after[k]) for k in before)
     with pytest.raises(IndexError):
         tr.check_inputs()
+    assert tr.skipped_steps == 1
     tr.step(xd)
     assert all(np.isfinite(v).all() for v in tr.parameters().values())
+    assert any(not np.array_equal(before[k], tr.parameters()[k]) for k in before)  # (training goes on)
