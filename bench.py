@@ -119,6 +119,10 @@ def other_configs(device, stream, B: int) -> dict:
     }
     del hc, hz
     out["train_step_cfg2"] = train_step_cfg2(device, stream, B)
+    # the reference's own training loop (notebooks/learning-a-circuit.ipynb cells 4 / 16 / 18: QuadGraph, CP, K = 64, batch 256,
+    # Adam) and BASELINE config 4 at 1024 rows: the job form of the training step (cirkit_amd/train_jobs.py)
+    out["train_step_notebook_quadgraph_cp_k64_b256"] = train_step_k64(device, stream, "notebook", 256)
+    out["train_step_cfg4_b1024"] = train_step_k64(device, stream, "cfg4", 1024)
     # The only forward timing the reference publishes (notebooks/compilation-options.ipynb:594):
     # QuadGraph 28x28, Categorical-256, Tucker layers, K = 64, batch 128, fold + optimize: 38.6 ms on an unnamed
     # CUDA GPU.  Different hardware and not the north-star metric, so it stays out of `vs_baseline`.
@@ -215,6 +219,68 @@ def train_step_cfg2(device, stream, B: int, rounds: int = 5, steps: int = 40, se
         "executed_flops": flops, "frac_of_fp32_mfma": flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
         "mean_ll_first_step": float(first[0] / first[1]), "mean_ll_last_step": float(last[0] / last[1]),
         "optimizer": "adam(lr=0.01)", "dtype": "f32",
+    }
+
+
+def train_step_k64(device, stream, which: str, B: int, rounds: int = 5, steps: int = 30, settle_s: float = 0.3) -> dict:
+    """One maximum-likelihood training step of a 64-unit CP circuit -- forward, backward, Adam, every parameter graph evaluated
+    every step -- through `HipTrainer`'s job form (level launches over jobs, the optimizer in the job epilogues): `which` =
+    "notebook": the circuit the reference trains in notebooks/learning-a-circuit.ipynb (QuadGraph 28x28, Categorical-256, CP,
+    K = 64; cell 16: batch 256, cell 18: Adam(lr=0.01)); "cfg4": BASELINE config 4 (Poon-Domingos 28x28, Gaussian leaves, CP,
+    K = 64).  Measured like `train_step_cfg2`.  executed_flops: the fp32 MFMA contractions of the sum jobs (1 per 64 x 64 x 32-row
+    tile forward, 3 backward)."""
+    import time
+
+    import numpy as np
+    import torch
+
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+    from cirkit_amd.training import HipTrainer
+
+    g = torch.Generator().manual_seed(13)
+    if which == "cfg4":
+        plan = image_data((1, 28, 28), "poon-domingos", input_layer="gaussian", num_input_units=64, sum_product_layer="cp", num_sum_units=64)
+        xs = [torch.randn((B, 784), generator=g).to(device) for _ in range(12)]
+        workload = f"Poon-Domingos 28x28, Gaussian leaves, CP sum layers, K=64 (BASELINE config 4), batch {B}"
+    else:
+        plan = image_data((1, 28, 28), "quad-graph", input_layer="categorical", num_input_units=64, sum_product_layer="cp", num_sum_units=64)
+        xs = [torch.randint(0, 256, (B, 784), generator=g).to(device) for _ in range(12)]
+        workload = f"QuadGraph 28x28, Categorical-256, CP, K=64, batch {B} (the reference's learning-a-circuit notebook)"
+    with torch.cuda.stream(stream):
+        tr = HipTrainer(plan, init_plan_tensors(plan), device=device, lr=0.01, optimizer="adam")
+        k, t0, first = 0, time.perf_counter(), None
+        while time.perf_counter() - t0 < settle_s or k < 10:
+            ll = tr.step(xs[k % 12])
+            if first is None:
+                first = ll.clone()
+            k += 1
+        torch.cuda.synchronize(device)
+        per_round = []
+        for _ in range(rounds):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(steps):
+                ll = tr.step(xs[k % 12])
+                k += 1
+            b.record(stream)
+            torch.cuda.synchronize(device)
+            per_round.append(a.elapsed_time(b) / steps)
+        last = ll.clone()
+    ms = float(np.median(per_round))
+    js = tr._jobs
+    tiles = (B + 31) // 32
+    flops = (len(js.sum_jobs) * tiles * 4 * 2.0 * 64 * 64 * 32) if js is not None else 0.0
+    return {
+        "workload": workload + ": forward + backward + Adam, parameters re-evaluated every step",
+        "form": "job list (cirkit_amd/train_jobs.py, csrc/ck_jobs.hip)" if js is not None else "layer-wise launch list",
+        "launches_per_step": js.num_launches(B) if js is not None else None,
+        "sum_jobs": len(js.sum_jobs) if js is not None else None, "mix_jobs": len(js.mix_jobs) if js is not None else None,
+        "ms_per_step": ms, "samples_per_s": B / ms * 1e3, "ms_per_step_by_round": per_round,
+        "settle_steps": k - rounds * steps, "steps_timed_total": rounds * steps,
+        "executed_flops": flops, "frac_of_fp32_mfma": flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+        "mean_ll_first_step": float(first[0] / first[1]), "mean_ll_last_step": float(last[0] / last[1]),
+        "optimizer": "adam(lr=0.01), in the job epilogues", "dtype": "f32",
     }
 
 

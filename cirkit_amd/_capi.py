@@ -250,7 +250,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_sgd_step": [_p, _p, _l, _f, _f, _p, _p],
     "ck_latch_flag": [_p, _p, _p],
     "ck_jobs_sum64_fwd": [_p, _i, _p, _p],
-    "ck_jobs_sum64_bwd": [_p, _i, _p, _p, _p],
+    "ck_jobs_sum64_bwd": [_p, _i, _p, _p, _i, _p],
     "ck_jobs_mix_fwd": [_p, _i, _p, _i, _p],
     "ck_jobs_mix_bwd": [_p, _i, _p, _i, _l, _p, _p],
     "ck_jobs_nsum": [_p, _i, _p, _l, _p],

@@ -120,16 +120,18 @@ __global__ void __launch_bounds__(WAVES * 64)
   const SumJob& J = jobs[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 31, kh = lane >> 5;
+  const int in_off = J.in_off, n_in = J.n_in, row1 = J.row1;
+  float e[2][16];
+  int b0 = J.row0 + 32 * wave;
+  if (b0 < row1) load_inputs(pool, in_off, n_in, b0 + b_in < row1 ? b0 + b_in : row1 - 1, kh, e);  // (in flight while the weights are staged)
   stage_weights<WAVES * 64>(J.w, w_s, threadIdx.x);
   __syncthreads();
-  const int in_off = J.in_off, n_in = J.n_in, row1 = J.row1;
   float* __restrict__ out = J.out;
-  for (int b0 = J.row0 + 32 * wave; b0 < row1; b0 += 32 * WAVES) {
+  for (bool first = true; b0 < row1; b0 += 32 * WAVES, first = false) {
     const int b = b0 + b_in;
     const bool live = b < row1;
     const int64_t bl = live ? b : row1 - 1;
-    float e[2][16];
-    load_inputs(pool, in_off, n_in, bl, kh, e);
+    if (!first) load_inputs(pool, in_off, n_in, bl, kh, e);
     const float m = exp_tile(e, true);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -154,13 +156,17 @@ __device__ __forceinline__ float opt_update(const ck_opt_state& o, float p, floa
   return p - o.lr * (m1 / o.bc1) / (sqrtf(m2 / o.bc2) + o.eps);
 }
 
+#ifndef CK_JOBS_BWD_OCC
+#define CK_JOBS_BWD_OCC 2  // waves per SIMD the backward kernel is compiled for (lab builds: 3 spills 34 registers)
+#endif
 template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(CK_JOBS_BWD_OCC, CK_JOBS_BWD_OCC)))
     jobs_sum64_bwd_kernel(const SumJob* __restrict__ jobs, const float* const* __restrict__ pool,
                           const ck_opt_state* __restrict__ opt) {
-  static_assert(WAVES == 4, "the epilogue assigns 4 threads to a weight row");
-  // [weights 64 x 65][per wave: gy 16 x 68, e 16 x 68 -- later two 64 x 64 sum buffers]
-  constexpr int kArea = WAVES * 2 * 16 * kTS > 8192 ? WAVES * 2 * 16 * kTS : 8192;
+  static_assert(WAVES == 4 || WAVES == 8, "the epilogue assigns WAVES threads to a weight row");
+  // [weights 64 x 65][per wave: gy 16 x 68, e 16 x 68 -- later WAVES / 2 sum buffers of 64 x 64]
+  constexpr int kBufs = WAVES / 2;
+  constexpr int kArea = WAVES * 2 * 16 * kTS > kBufs * 4096 ? WAVES * 2 * 16 * kTS : kBufs * 4096;
   __shared__ __attribute__((aligned(16))) float lds[kU * kWS + kArea];
   __shared__ unsigned int s_ticket;
   float* w_s = lds;
@@ -168,6 +174,15 @@ __global__ void __launch_bounds__(WAVES * 64)
   const SumJob& J = jobs[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 31, kh = lane >> 5;
+  const int in_off = J.in_off, n_in = J.n_in, g_off = J.g_off, n_g = J.n_g, row1 = J.row1;
+  float e[2][16], gy[2][16];
+  // the operands of a tile: v (into e) and G = the sum of the job's gradient blocks (into gy: the layout of the outputs)
+  auto load_tile = [&](int64_t bl) {
+    load_inputs(pool, in_off, n_in, bl, kh, e);
+    load_inputs(pool, g_off, n_g, bl, kh, gy);
+  };
+  int b0 = J.row0 + 32 * wave;
+  if (b0 < row1) load_tile(b0 + b_in < row1 ? b0 + b_in : row1 - 1);  // (the first tile's loads fly while the weights are staged)
   stage_weights<WAVES * 64>(J.w, w_s, threadIdx.x);
   __syncthreads();
   float* gy_s = area + wave * (2 * 16 * kTS);
@@ -179,26 +194,12 @@ __global__ void __launch_bounds__(WAVES * 64)
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dwacc[p][q][r] = 0.f;
-  const int in_off = J.in_off, n_in = J.n_in, g_off = J.g_off, n_g = J.n_g, row1 = J.row1;
   float* __restrict__ gx = J.gx;
-  for (int b0 = J.row0 + 32 * wave; b0 < row1; b0 += 32 * WAVES) {
+  for (bool first = true; b0 < row1; b0 += 32 * WAVES, first = false) {
     const int b = b0 + b_in;
     const bool live = b < row1;
     const int64_t bl = live ? b : row1 - 1;
-    float e[2][16];
-    load_inputs(pool, in_off, n_in, bl, kh, e);
-    float gy[2][16];
-    {  // G = the sum of the job's gradient blocks (same register layout as the outputs)
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) gy[p][j] = 0.f;
-      for (int s = 0; s < n_g; ++s) {
-        const float* src = pool[g_off + s] + bl * kU + 4 * kh;
-        tile_load_add(src, gy[0]);
-        tile_load_add(src + 32, gy[1]);
-      }
-    }
+    if (!first) load_tile(bl);
     exp_tile(e, live);
     // y = W e, gy = G / y
 #pragma unroll
@@ -261,10 +262,29 @@ __global__ void __launch_bounds__(WAVES * 64)
       __builtin_amdgcn_wave_barrier();
     }
   }
-  // dW of the job's rows: the four waves' accumulators added in LDS (two (64, 64) buffers, two rounds)
+  // mode 2: the optimizer's operands of this thread's 16 entries (row o, quarter c0), requested now -- they arrive while the
+  // accumulators are reduced below
+  constexpr int kTPR = WAVES;       // threads per weight row
+  constexpr int kEPT = kU / kTPR;   // entries per thread: 16 | 8
+  const int o = threadIdx.x / kTPR, c0 = (threadIdx.x % kTPR) * kEPT;
+  float4 pth[kEPT / 4], pm1[kEPT / 4], pm2[kEPT / 4];
+  const bool fused_opt = J.mode == 2;
+  const bool adam = fused_opt && opt->kind != 0;
+  if (fused_opt) {
+#pragma unroll
+    for (int k = 0; k < kEPT / 4; ++k) {
+      pth[k] = ck::gload4(J.theta + o * kU + c0 + 4 * k);
+      if (adam) {
+        pm1[k] = ck::gload4(J.m1 + o * kU + c0 + 4 * k);
+        pm2[k] = ck::gload4(J.m2 + o * kU + c0 + 4 * k);
+      }
+    }
+  }
+  // dW of the job's rows: the waves' accumulators added in LDS (WAVES / 2 buffers of (64, 64): the first half of the waves
+  // stores, the second half adds)
   __syncthreads();
-  float* buf = area + (wave & 1) * 4096;
-  if (wave < 2) {
+  float* buf = area + (wave % kBufs) * 4096;
+  if (wave < kBufs) {
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -273,7 +293,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         for (int r = 0; r < 16; ++r) buf[(32 * p + 8 * (r >> 2) + 4 * kh + (r & 3)) * kU + 32 * q + b_in] = dwacc[p][q][r];
   }
   __syncthreads();
-  if (wave >= 2) {
+  if (wave >= kBufs) {
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -283,13 +303,20 @@ __global__ void __launch_bounds__(WAVES * 64)
   }
   __syncthreads();
   float* dw_s = area;  // (64, 64) after the sum below
+  constexpr int kPer = 4096 / (WAVES * 64);  // entries of the sum per thread
+  auto sum_bufs = [&](int i) {
+    float t = area[i];
+#pragma unroll
+    for (int k = 1; k < kBufs; ++k) t += area[k * 4096 + i];
+    return t;
+  };
   if (J.n_split > 1) {
     // the job's rows are cut over several workgroups: partial sums go to slots (write-through), the last arrival adds them
     float* slot = J.part + static_cast<int64_t>(J.split) * 4096;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = threadIdx.x + 256 * u;
-      __hip_atomic_store(slot + i, area[i] + area[4096 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int u = 0; u < kPer; ++u) {
+      const int i = threadIdx.x + WAVES * 64 * u;
+      __hip_atomic_store(slot + i, sum_bufs(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -298,57 +325,67 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (s_ticket != static_cast<unsigned int>(J.n_split - 1)) return;
     if (threadIdx.x == 0) __hip_atomic_store(J.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next step
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = threadIdx.x + 256 * u;
+    for (int u = 0; u < kPer; ++u) {
+      const int i = threadIdx.x + WAVES * 64 * u;
       float t = 0.f;
       for (int sp = 0; sp < J.n_split; ++sp)
         t += __hip_atomic_load(J.part + static_cast<int64_t>(sp) * 4096 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       dw_s[i] = t;
     }
   } else {
+    float t[kPer];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = threadIdx.x + 256 * u;
-      dw_s[i] = area[i] + area[4096 + i];
-    }
+    for (int u = 0; u < kPer; ++u) t[u] = sum_bufs(threadIdx.x + WAVES * 64 * u);
+    if (kBufs > 1) __syncthreads();  // (every thread has read its entries of all buffers before buffer 0 is overwritten)
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) dw_s[threadIdx.x + WAVES * 64 * u] = t[u];
   }
   __syncthreads();
-  // epilogue: thread (o = tid >> 2, quarter = tid & 3) owns 16 entries of weight row o
-  const int o = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
-  float wv[16], dv[16];
+  // epilogue: thread (o, part) owns kEPT consecutive entries of weight row o
+  auto row_sum = [&](float v) {
+    v = quad_sum(v);
+    if (kTPR == 8) v += __shfl_xor(v, 4, 64);
+    return v;
+  };
+  auto row_max = [&](float v) {
+    v = quad_max(v);
+    if (kTPR == 8) v = fmaxf(v, __shfl_xor(v, 4, 64));
+    return v;
+  };
+  float wv[kEPT], dv[kEPT];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < kEPT; ++k) {
     wv[k] = w_s[o * kWS + c0 + k];
     dv[k] = dw_s[o * kU + c0 + k];
   }
   if (J.mode == 0) {  // the gradient of the linear weights, for a parameter graph this epilogue does not know
 #pragma unroll
-    for (int k = 0; k < 16; k += 4) ck::gstore4(J.dtheta + o * kU + c0 + k, make_float4(dv[k], dv[k + 1], dv[k + 2], dv[k + 3]));
+    for (int k = 0; k < kEPT; k += 4) ck::gstore4(J.dtheta + o * kU + c0 + k, make_float4(dv[k], dv[k + 1], dv[k + 2], dv[k + 3]));
     return;
   }
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) s = fmaf(wv[k], dv[k], s);
-  s = quad_sum(s);
+  for (int k = 0; k < kEPT; ++k) s = fmaf(wv[k], dv[k], s);
+  s = row_sum(s);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) dv[k] = wv[k] * (dv[k] - s);  // d theta (nodes.py:764-772 under autograd)
+  for (int k = 0; k < kEPT; ++k) dv[k] = wv[k] * (dv[k] - s);  // d theta (nodes.py:764-772 under autograd)
   if (J.mode == 1) {
 #pragma unroll
-    for (int k = 0; k < 16; k += 4) ck::gstore4(J.dtheta + o * kU + c0 + k, make_float4(dv[k], dv[k + 1], dv[k + 2], dv[k + 3]));
+    for (int k = 0; k < kEPT; k += 4) ck::gstore4(J.dtheta + o * kU + c0 + k, make_float4(dv[k], dv[k + 1], dv[k + 2], dv[k + 3]));
     return;
   }
   // mode 2: the optimizer's update of theta and the softmax of the next step's weights, here
   const ck_opt_state os = *opt;
   if (os.skip_now) return;
-  float th[16];
+  float th[kEPT];
   float mx = -INFINITY;
 #pragma unroll
-  for (int k = 0; k < 16; k += 4) {
-    const float4 t4 = ck::gload4(J.theta + o * kU + c0 + k);
+  for (int k = 0; k < kEPT; k += 4) {
+    const float4 t4 = pth[k >> 2];
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
     if (os.kind != 0) {
-      a4 = ck::gload4(J.m1 + o * kU + c0 + k);
-      b4 = ck::gload4(J.m2 + o * kU + c0 + k);
+      a4 = pm1[k >> 2];
+      b4 = pm2[k >> 2];
     }
     th[k] = opt_update(os, t4.x, dv[k], a4.x, b4.x);
     th[k + 1] = opt_update(os, t4.y, dv[k + 1], a4.y, b4.y);
@@ -361,17 +398,17 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
     mx = fmaxf(fmaxf(mx, fmaxf(th[k], th[k + 1])), fmaxf(th[k + 2], th[k + 3]));
   }
-  mx = quad_max(mx);
+  mx = row_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < kEPT; ++k) {
     th[k] = expf(th[k] - mx);
     sum += th[k];
   }
-  sum = quad_sum(sum);
+  sum = row_sum(sum);
   const float inv = 1.f / sum;
 #pragma unroll
-  for (int k = 0; k < 16; k += 4)
+  for (int k = 0; k < kEPT; k += 4)
     ck::gstore4(J.w_out + o * kU + c0 + k, make_float4(th[k] * inv, th[k + 1] * inv, th[k + 2] * inv, th[k + 3] * inv));
 }
 
@@ -871,11 +908,16 @@ int ck_jobs_sum64_fwd(const ck_sum_job* jobs, int n_units, const float* const* p
       stream);
 }
 
-int ck_jobs_sum64_bwd(const ck_sum_job* jobs, int n_units, const float* const* pool, const ck_opt_state* opt, void* stream) {
+int ck_jobs_sum64_bwd(const ck_sum_job* jobs, int n_units, const float* const* pool, const ck_opt_state* opt, int waves, void* stream) {
   CK_REQUIRE(jobs && pool && n_units > 0, "ck_jobs_sum64_bwd: bad arguments");
+  CK_REQUIRE(waves == 4 || waves == 8, "ck_jobs_sum64_bwd: 4 or 8 waves per workgroup");
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(jobs_sum64_bwd_kernel<4>, dim3(n_units), dim3(256), 0, s, jobs, pool, opt);
+        if (waves == 8) {
+          hipLaunchKernelGGL(jobs_sum64_bwd_kernel<8>, dim3(n_units), dim3(512), 0, s, jobs, pool, opt);
+        } else {
+          hipLaunchKernelGGL(jobs_sum64_bwd_kernel<4>, dim3(n_units), dim3(256), 0, s, jobs, pool, opt);
+        }
         return hipGetLastError();
       },
       stream);

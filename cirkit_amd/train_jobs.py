@@ -441,26 +441,33 @@ class JobStep:
         def splits_for(n_jobs: int, max_split: int) -> int:
             return int(max(1, min(max_split, -(-2 * n_cu // max(1, n_jobs)))))
 
-        def sum_splits(n_jobs: int, backward: bool) -> int:
-            """Row splits per job of a sum launch: the launch runs in ROUNDS of as many workgroups as the chip holds (2 per CU
-            for the backward kernel, 4 for the forward one) and a round lasts as long as one unit, so 1040 jobs on 512 slots
-            take three rounds where 2.03 would do -- finer units waste less of the last round, at a fixed cost per unit
-            (weights staged again; backward: the partial sums of dW through memory).  Measured unit times [MI355X]: backward
-            ~8 us + 12 us per tile and wave (+5 us with partial sums), forward ~3 us + 6 us."""
-            slots = n_cu * (2 if backward else 4)
-            t_fix, t_tile = (8.0, 12.0) if backward else (3.0, 6.0)
-            best, best_t = 1, None
-            for sp in (1, 2, 3, 4, 6, 8, 12, 16):
-                if sp > 1 and -(-tiles // sp) < 4:  # (at least a tile per wave)
-                    break
-                per_wave = -(-(-(-tiles // sp)) // 4)
-                t = -(-n_jobs * sp // slots) * (t_fix + (5.0 if (backward and sp > 1) else 0.0) + t_tile * per_wave)
-                if best_t is None or t < best_t - 1e-9:
-                    best, best_t = sp, t
+        def sum_config(n_jobs: int, backward: bool) -> tuple[int, int]:
+            """(row splits per job, waves per workgroup) of a sum launch.  The launch runs in ROUNDS of as many workgroups as the
+            chip holds (backward: 2 per CU with 4 waves, 1 with 8; forward: 4 per CU) and a round lasts as long as one unit, so
+            1040 jobs on 512 slots take three rounds where 2.03 would do -- finer units waste less of the last round, at a fixed
+            cost per unit.  Measured [MI355X, scripts/exp_jobs_fixed.py]: a backward unit costs ~10 us beside its tiles (launch,
+            weights staged, accumulators reduced, optimizer epilogue), ~10 us more when its partial sums of dW go through memory,
+            and a tile ~10 us of a wave that has its SIMD to itself, ~14 us when two waves share it; forward ~3 us + 6 us per
+            tile.  Eight waves halve a unit's chain of tiles (what the few-fold levels at the top of a circuit consist of)."""
+            best, best_t = (1, 4), None
+            for waves in ((4, 8) if backward else (4,)):
+                slots = n_cu * ((2 if waves == 4 else 1) if backward else 4)
+                for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+                    if sp > 1 and -(-tiles // sp) < waves:  # (at least a tile per wave)
+                        break
+                    per_wave = -(-(-(-tiles // sp)) // waves)
+                    if backward:
+                        shared = waves == 8 or n_jobs * sp > n_cu
+                        unit = 10.0 + (10.0 if sp > 1 else 0.0) + (14.0 if shared else 10.0) * per_wave
+                    else:
+                        unit = 3.0 + 6.0 * per_wave
+                    t = -(-n_jobs * sp // slots) * unit
+                    if best_t is None or t < best_t - 1e-9:
+                        best, best_t = (sp, waves), t
             return best
 
-        def sum_table(jobs: list[dict], backward: bool) -> tuple[dict, int]:
-            ns = sum_splits(len(jobs), backward)
+        def sum_table(jobs: list[dict], backward: bool) -> tuple[dict, int, int]:
+            ns, waves = sum_config(len(jobs), backward)
             rows_per = -(-tiles // ns) * 32
             ns = -(-B // rows_per)
             tab = np.zeros(len(jobs) * ns, dtype=np.dtype(capi.SUM_JOB_DTYPE))
@@ -483,7 +490,7 @@ class JobStep:
                     r["split"], r["n_split"], r["mode"] = sp, ns, 1
                     if part is not None:
                         r["part"], r["ticket"] = part.data_ptr() + n * ns * 4096 * 4, tick.data_ptr() + n * 4
-            return upload(tab, backward), len(tab)
+            return upload(tab, backward), len(tab), waves
 
         def mix_table(jobs: list[dict], backward: bool) -> tuple[dict, int, int]:
             hmax = max(j["H"] for j in jobs)
@@ -675,7 +682,7 @@ class JobStep:
             elif what == "root":
                 capi.call("ck_jobs_root", C.byref(st["root"][mode]), stream)
             elif what == "sum_bwd":
-                capi.call("ck_jobs_sum64_bwd", la[1][mode].data_ptr(), la[2], pool, opt, stream)
+                capi.call("ck_jobs_sum64_bwd", la[1][mode].data_ptr(), la[2], pool, opt, la[3], stream)
             elif what == "mix_bwd":
                 capi.call("ck_jobs_mix_bwd", la[1][mode].data_ptr(), la[2], pool, la[3], blk, opt, stream)
             elif what == "gauss_bwd":

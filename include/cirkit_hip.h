@@ -765,7 +765,8 @@ typedef struct ck_sum_job {
   int64_t reserved1;
 } ck_sum_job;
 int ck_jobs_sum64_fwd(const ck_sum_job* jobs, int n_units, const float* const* pool, void* stream);
-int ck_jobs_sum64_bwd(const ck_sum_job* jobs, int n_units, const float* const* pool, const ck_opt_state* opt, void* stream);
+/* waves: 4 or 8 wavefronts per workgroup (a wave takes every waves-th 32-row tile of the unit's rows; 8: one workgroup per CU) */
+int ck_jobs_sum64_bwd(const ck_sum_job* jobs, int n_units, const float* const* pool, const ck_opt_state* opt, int waves, void* stream);
 /* One fold of a mixing layer (a TorchSumLayer whose weight ends in TorchMixingWeightParameter, nodes.py:847-862): H slots,
  * slot h = the sum of the S blocks pool[in_off + h S ..]; w (64, H) coefficients.  Backward: gx + h gx_stride <- the gradient
  * of slot h; dtheta (64, H) as for ck_sum_job (the softmax runs over h); part slots are 64 x (2 | 4 | 8 | 16) floats (the

@@ -13,6 +13,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from cirkit_amd import _capi as capi  # noqa: E402
+
+if os.environ.get("CK_LIB"):  # a lab build of the library
+    capi._LIB_PATH = os.environ["CK_LIB"]
 from cirkit_amd.initializers import init_plan_tensors  # noqa: E402
 from cirkit_amd.templates import image_data  # noqa: E402
 from cirkit_amd.training import HipTrainer  # noqa: E402
@@ -31,6 +34,8 @@ for _ in range(3):
     tr.step(x)
 torch.cuda.synchronize()
 st = js.bind(B)
+MODE = int(os.environ.get("MODE", "2"))  # 2: the optimizer inside the epilogues (what `step` runs on one rank); 1: d theta only
+OPT = js._opt_state().data_ptr() if MODE == 2 else None
 pool = st["pool"].data_ptr()
 blk = B * 64
 stream = torch.cuda.current_stream().cuda_stream
@@ -39,13 +44,18 @@ print(f"{'launch':10s} {'units':>6s} {'jobs':>6s} {'split':>5s} {'n_in':>9s} {'n
 for la in st["launches"]:
     what = la[0]
     if what == "root":
-        fn = lambda: capi.call("ck_jobs_root", C.byref(st["root"]), stream)
+        fn = lambda: capi.call("ck_jobs_root", C.byref(st["root"][MODE]), stream)
         desc = (1, 1, 1, "", "")
     else:
-        tab = la[2] if what == "input_bwd" else la[1]
-        n = la[3] if what == "input_bwd" else la[2]
+        tabs = la[2] if what in ("input_bwd", "gauss_bwd") else la[1]
+        n = la[3] if what in ("input_bwd", "gauss_bwd") else la[2]
+        tab = tabs.get(MODE, tabs[1])
         raw = tab.cpu().numpy()
-        if what in ("nsum", "input_bwd"):
+        if what == "gauss_bwd":
+            t = raw.view(np.dtype(capi.GAUSS_JOB_DTYPE)).reshape(-1)
+            desc = (n, n, 1, "", f"{t['n_g'].mean():.1f}/{t['n_g'].max()}")
+            fn = (lambda tab=tab, n=n: capi.call("ck_jobs_gauss_bwd", tab.data_ptr(), n, pool, B, OPT, stream))
+        elif what in ("nsum", "input_bwd"):
             t = raw.view(np.dtype(capi.NSUM_JOB_DTYPE)).reshape(-1)
             desc = (n, n, 1, f"{t['n_in'].mean():.1f}/{t['n_in'].max()}", "")
             fn = (lambda tab=tab, n=n: capi.call("ck_jobs_nsum", tab.data_ptr(), n, pool, blk, stream))
@@ -55,14 +65,15 @@ for la in st["launches"]:
             desc = (n, n // ns, ns, f"{t['n_in'].mean():.1f}/{t['n_in'].max()}", f"{t['n_g'].mean():.1f}/{t['n_g'].max()}")
             name = "ck_jobs_sum64_fwd" if what == "sum_fwd" else "ck_jobs_sum64_bwd"
             fn = ((lambda tab=tab, n=n: capi.call("ck_jobs_sum64_fwd", tab.data_ptr(), n, pool, stream)) if what == "sum_fwd" else
-                  (lambda tab=tab, n=n: capi.call("ck_jobs_sum64_bwd", tab.data_ptr(), n, pool, None, stream)))
+                  (lambda tab=tab, n=n, wv=la[3]: capi.call("ck_jobs_sum64_bwd", tab.data_ptr(), n, pool, OPT, wv, stream)))
+            what = what + (f"/{la[3]}w" if what == "sum_bwd" else "")
         else:
             t = raw.view(np.dtype(capi.MIX_JOB_DTYPE)).reshape(-1)
             ns = int(t["n_split"][0])
             desc = (n, n // ns, ns, f"H{t['H'].mean():.1f}/{t['H'].max()} S{t['S'].max()}", f"{t['n_g'].mean():.1f}/{t['n_g'].max()}")
             hm = la[3]
             fn = ((lambda tab=tab, n=n, hm=hm: capi.call("ck_jobs_mix_fwd", tab.data_ptr(), n, pool, hm, stream)) if what == "mix_fwd" else
-                  (lambda tab=tab, n=n, hm=hm: capi.call("ck_jobs_mix_bwd", tab.data_ptr(), n, pool, hm, blk, None, stream)))
+                  (lambda tab=tab, n=n, hm=hm: capi.call("ck_jobs_mix_bwd", tab.data_ptr(), n, pool, hm, blk, OPT, stream)))
     for _ in range(3):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -75,4 +86,4 @@ for la in st["launches"]:
     us = e0.elapsed_time(e1) * 1e3 / 20
     total += us
     print(f"{what:10s} {desc[0]:6d} {desc[1]:6d} {desc[2]:5d} {desc[3]:>9s} {desc[4]:>9s} {us:8.1f}")
-print(f"sum of the job launches {total:.0f} us  ({len(st['launches'])} launches; the recorded step has {js.num_launches(B)})")
+print(f"sum of the job launches {total:.0f} us  ({len(st['launches'])} launches; the recorded step has {js.num_launches(B, MODE)})")

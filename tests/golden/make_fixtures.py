@@ -354,6 +354,47 @@ def grads():
         torch.set_grad_enabled(False)
 
 
+def grads_k64():
+    """Round 5: the reference's own `loss.backward()` on 64-unit CP circuits of the two kinds the job form of the training step
+    (cirkit_amd/train_jobs.py) covers -- a QuadGraph circuit with Categorical leaves (the model of notebooks/learning-a-circuit.ipynb
+    cells 4 / 16 / 18, at 6x6 pixels) and a Poon-Domingos circuit with Gaussian leaves (BASELINE config 4 at 6x6): the plans, the
+    loss, and per parameter tensor its gradient's norm, sum and first 32 entries (the tensors themselves come from
+    cirkit_amd.initializers, closed form)."""
+    torch.set_grad_enabled(True)
+    try:
+        for name, build, xgen in [
+            ("quadgraph_6x6_k64", lambda: data_modalities.image_data(
+                (1, 6, 6), "quad-graph", input_layer="categorical", num_input_units=64, sum_product_layer="cp", num_sum_units=64),
+             lambda g: torch.randint(0, 256, (48, 36), generator=g)),
+            ("pd_gauss_6x6_k64", lambda: data_modalities.image_data(
+                (1, 6, 6), "poon-domingos", input_layer="gaussian", num_input_units=64, sum_product_layer="cp", num_sum_units=64),
+             lambda g: torch.randn(48, 36, generator=g)),
+        ]:
+            cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(build())
+            plan, tensors = plan_from_torch_circuit(cc)
+            with torch.no_grad():
+                _load_closed_form(plan, tensors)
+            g = torch.Generator().manual_seed(17)
+            x = xgen(g)
+            y = cc(x)
+            loss = -y.mean()
+            loss.backward()
+            by_ptr = {p.data_ptr(): p for p in cc.parameters()}
+            extra = {"x": x.numpy().astype(np.float32 if x.is_floating_point() else np.int16), "loss": np.array(loss.item()),
+                     "y_f32": y.detach().numpy()}
+            for k, t in tensors.items():
+                gr = by_ptr[t.data_ptr()].grad
+                extra["gnorm_" + k] = np.array(gr.norm().item())
+                extra["gsum_" + k] = np.array(gr.double().sum().item())
+                extra["ghead_" + k] = gr.reshape(-1)[:32].numpy()
+            plan.name = name
+            plan.save(os.path.join(HERE, name))
+            np.savez_compressed(os.path.join(HERE, name + "_grads.npz"), **extra)
+            print(name, "loss", float(loss), "tensors", len(tensors), "layers", len(plan.layers))
+    finally:
+        torch.set_grad_enabled(False)
+
+
 def grads_tucker():
     """Round 3: parameter gradients of the reference's autograd through Tucker layers (optimized.py:89-103) and through
     stand-alone Kronecker + dense sum layers (inner.py:178-187; `optimize=False` keeps them unfused) -- the plans, a forward
@@ -701,6 +742,6 @@ def chow_liu():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "grads_tucker", "grads_param_nodes", "grads_sos", "grads_sq_categorical", "grads_sq_gaussian", "marginals", "templates_extra"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg2_cpt", "cfg4", "cfg5", "kats", "tucker", "plans_only", "grads", "grads_k64", "grads_tucker", "grads_param_nodes", "grads_sos", "grads_sq_categorical", "grads_sq_gaussian", "marginals", "templates_extra"]
     for w in which:
         globals()[w]()

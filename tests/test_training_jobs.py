@@ -117,3 +117,65 @@ def test_job_step_drops_a_batch_with_an_illegal_category(hip_device, fuse):
     tr.step(xd)
     assert all(np.isfinite(v).all() for v in tr.parameters().values())
     assert any(not np.array_equal(before[k], tr.parameters()[k]) for k in before)  # (training goes on)
+
+
+def _fixture(name):
+    import os
+
+    from conftest import GOLDEN
+
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.plan import Plan
+
+    plan = Plan.load(os.path.join(GOLDEN, name))
+    with np.load(os.path.join(GOLDEN, name + "_grads.npz")) as z:
+        ref = {k: z[k] for k in z.files}
+    x = torch.from_numpy(ref["x"].astype(np.float32 if ref["x"].dtype.kind == "f" else np.int64))
+    return plan, init_plan_tensors(plan), x, ref
+
+
+@pytest.mark.parametrize("name", ["quadgraph_6x6_k64", "pd_gauss_6x6_k64"])
+def test_oracle_autograd_reproduces_the_reference_gradients_of_the_k64_fixtures(name):
+    """tests/golden/make_fixtures.py grads_k64: the loss and every parameter gradient (norm, sum, first 32 entries) of the
+    reference's own `loss.backward()` on 64-unit CP circuits -- reproduced by autograd through the oracle (CPU)."""
+    plan, tensors, x, ref = _fixture(name)
+    loss, grads = _oracle_grads(plan, tensors, x)
+    assert abs(loss - float(ref["loss"])) <= 1e-6 * abs(float(ref["loss"]))
+    for k in plan.tensors:
+        gr = grads[k]
+        assert abs(float(gr.norm()) - float(ref["gnorm_" + k])) <= 1e-4 * float(ref["gnorm_" + k]) + 1e-12, k
+        head = ref["ghead_" + k]
+        assert np.abs(gr.reshape(-1)[:32].numpy() - head).max() <= 1e-5 * max(1e-6, np.abs(head).max()) + 1e-9, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["quadgraph_6x6_k64", "pd_gauss_6x6_k64"])
+@pytest.mark.parametrize("jobs", [True, False])
+def test_hip_gradients_match_the_reference_gradient_fixture_k64(hip_device, name, jobs):
+    """The gradients of the reference's own `loss.backward()`: through the job form of the training step and
+    through the layer-wise launch list.  Tensors whose gradient is cancellation noise in fp32 -- the reference's norm of them
+    differs from the fp64 oracle's by more than 1 % -- are only sanity-bounded."""
+    from cirkit_amd.training import HipTrainer
+
+    plan, tensors, x, ref = _fixture(name)
+    tr = HipTrainer(plan, tensors, device=hip_device, optimizer="sgd", jobs=jobs)
+    assert (tr._jobs is not None) == jobs
+    tr.loss_and_grads(x.to(hip_device))
+    ll = tr.loss_and_grads(x.to(hip_device)).cpu()
+    torch.cuda.synchronize()
+    assert abs(-float(ll[0]) / float(ll[1]) - float(ref["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+    _, g64 = _oracle_grads(plan, tensors, x, torch.float64)
+    checked = 0
+    for k in plan.tensors:
+        got = tr.grads[k].cpu()
+        n_ref, n64 = float(ref["gnorm_" + k]), float(g64[k].norm())
+        noise = abs(n_ref - n64) > 1e-2 * n64
+        if noise:
+            assert float(got.norm()) <= 10.0 * max(n_ref, n64) + 1e-12, k
+            continue
+        checked += 1
+        assert abs(float(got.norm()) - n_ref) <= 3e-3 * n_ref + 1e-12, (k, float(got.norm()), n_ref)
+        head = ref["ghead_" + k]
+        # (entry by entry at 2 %: the deeper tensors' gradients are ~1e-7 and carry the fp32 rounding of every layer below them)
+        assert np.abs(got.reshape(-1)[:32].numpy() - head).max() <= 2e-2 * max(np.abs(head).max(), float(got.abs().max()) * 1e-2) + 1e-12, k
+    assert checked >= len(plan.tensors) // 2
