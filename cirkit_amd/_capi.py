@@ -162,6 +162,8 @@ MIX_JOB_DTYPE = [("w", "<u8"), ("out", "<u8"), ("gx", "<u8"), ("dtheta", "<u8"),
                  ("n_g", "<i4"), ("row0", "<i4"), ("row1", "<i4"), ("split", "<i4"), ("n_split", "<i4"), ("mode", "<i4"),
                  ("S", "<i4"), ("reserved1", "<i8")]
 NSUM_JOB_DTYPE = [("out", "<u8"), ("in_off", "<i4"), ("n_in", "<i4")]
+CAT_JOB_DTYPE = [("x", "<u8"), ("theta", "<u8"), ("table", "<u8"), ("dtheta", "<u8"), ("theta_out", "<u8"), ("m1", "<u8"), ("m2", "<u8"),
+                 ("table_out", "<u8"), ("g_off", "<i4"), ("n_g", "<i4"), ("mode", "<i4"), ("reserved", "<i4")]
 GAUSS_JOB_DTYPE = [("mean", "<u8"), ("stddev", "<u8"), ("x", "<u8"), ("dmean", "<u8"), ("dsd", "<u8"), ("th_mean", "<u8"), ("m1_mean", "<u8"),
                    ("m2_mean", "<u8"), ("th_sd", "<u8"), ("m1_sd", "<u8"), ("m2_sd", "<u8"), ("mean_out", "<u8"), ("sd_out", "<u8"),
                    ("g_off", "<i4"), ("n_g", "<i4"), ("vmin", "<f4"), ("vmax", "<f4"), ("has_ss", "<i4"), ("mode", "<i4")]
@@ -255,6 +257,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_jobs_mix_bwd": [_p, _i, _p, _i, _l, _p, _p],
     "ck_jobs_nsum": [_p, _i, _p, _l, _p],
     "ck_jobs_root": [C.POINTER(RootLaunch), _p],
+    "ck_jobs_cat_bwd": [_p, _i, _p, _i, _i, _p, _p],
     "ck_jobs_gauss_bwd": [_p, _i, _p, _i, _p, _p],
     "ck_opt_step_range": [_p, _p, _p, _p, _l, _p, _p],
     "ck_opt_tick": [_p, _p, _p, _p],

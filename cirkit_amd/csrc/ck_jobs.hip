@@ -786,6 +786,200 @@ __global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) 
   }
 }
 
+// ---- Categorical input layers ---------------------------------------------------------------------------------------------------
+// One fold of a TorchCategoricalLayer with 64 units (layers/input.py:399-412: out[b, :] = log softmax(theta)[:, x_b]), backward in
+// ONE workgroup: G = the sum of the fold's gradient blocks; dT[c, :] = sum over the rows with x_b = c of G[b, :] (the scatter-add
+// autograd performs for the advanced indexing) -- rows counting-sorted by category in LDS (integer atomics), every category
+// owned by one wave, plain row loads eight at a time, no float atomics --; then through the log-softmax:
+// d theta[k, c] = dT[c, k] - p[k, c] sum_c' dT[c', k]  (nodes.py:764-783), with p = exp(theta - lse) and lse read off the forward's
+// table.  mode 2: the optimizer's update of theta and the next step's (C + 1, 64) table, transposed through LDS.
+constexpr int kCatRows = 512;   // rows sorted at a time (LDS: two workgroups per CU at 256 categories)
+constexpr int kHS = 65;         // row stride of the (C + 1, 64) histogram in LDS
+__global__ void __launch_bounds__(1024)
+    jobs_cat_bwd_kernel(const ck_cat_job* __restrict__ jobs, const float* const* __restrict__ pool, const ck_opt_state* __restrict__ opt,
+                        int B, int C) {
+  extern __shared__ __attribute__((aligned(16))) float cat_smem[];
+  const int per = (C + 1 + 15) / 16;  // categories per wave; key(c) = (c % 16) * per + c / 16: a wave's categories are contiguous keys
+  const int nkeys = 16 * per;
+  float* hist = cat_smem;                                   // [C + 1][kHS]
+  float* red = hist + (C + 1) * kHS;                        // [16][64]
+  float* tk = red + 16 * kU;                                // [64] column sums, then the new log-normalisers
+  float* lse = tk + kU;                                     // [64]
+  int* start = reinterpret_cast<int*>(lse + kU);            // [nkeys + 1]
+  int* cur = start + nkeys + 1;                             // [nkeys]
+  int* order = cur + nkeys;                                 // [kCatRows]
+  int* keys = order + kCatRows;                             // [kCatRows]
+  const ck_cat_job& J = jobs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < (C + 1) * kHS; i += 1024) hist[i] = 0.f;
+  const int g_off = J.g_off, n_g = J.n_g;
+  for (int b0 = 0; b0 < B; b0 += kCatRows) {
+    const int nb = min(kCatRows, B - b0);
+    for (int i = threadIdx.x; i <= nkeys; i += 1024) start[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += 1024) {
+      const int cc = J.x[b0 + i];
+      const int c = cc < 0 ? C : min(cc, C - 1);
+      atomicAdd(&start[(c & 15) * per + (c >> 4) + 1], 1);
+    }
+    __syncthreads();
+    if (wave == 0) {  // inclusive scan of start[1 .. nkeys]: a run of bins per lane, then a wave scan of the run totals
+      const int run_len = (nkeys + 63) / 64;
+      int tot = 0;
+      for (int j = 0; j < run_len; ++j) {
+        const int idx = 1 + lane * run_len + j;
+        if (idx <= nkeys) tot += start[idx];
+      }
+      int incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      int run = incl - tot;
+      for (int j = 0; j < run_len; ++j) {
+        const int idx = 1 + lane * run_len + j;
+        if (idx <= nkeys) {
+          run += start[idx];
+          start[idx] = run;
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nkeys; i += 1024) cur[i] = start[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += 1024) {
+      const int cc = J.x[b0 + i];
+      const int c = cc < 0 ? C : min(cc, C - 1);
+      const int key = (c & 15) * per + (c >> 4);
+      const int pos = atomicAdd(&cur[key], 1);
+      order[pos] = b0 + i;
+      keys[pos] = key;
+    }
+    __syncthreads();
+    {  // this wave's rows: positions [start[wave per], start[(wave + 1) per]), lane = unit
+      const int s0 = start[wave * per], s1 = start[(wave + 1) * per];
+      int cur_key = -1;
+      float acc = 0.f;
+      for (int i = s0; i < s1; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = 0.f;
+          if (i + u < s1) {
+            const int64_t row = order[i + u];
+            for (int s2 = 0; s2 < n_g; ++s2) v[u] += *ck::as_global(pool[g_off + s2] + row * kU + lane);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (i + u < s1) {
+            const int key = keys[i + u];
+            if (key != cur_key) {
+              if (cur_key >= 0) hist[((cur_key % per) * 16 + cur_key / per) * kHS + lane] += acc;
+              acc = 0.f;
+              cur_key = key;
+            }
+            acc += v[u];
+          }
+        }
+      }
+      if (cur_key >= 0) hist[((cur_key % per) * 16 + cur_key / per) * kHS + lane] += acc;
+    }
+    __syncthreads();
+  }
+  // column sums over the C categories (the integral row C carries no parameter) and the forward's log-normalisers
+  {
+    float t = 0.f;
+    for (int c = wave; c < C; c += 16) t += hist[c * kHS + lane];
+    red[wave * kU + lane] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kU) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w * kU + threadIdx.x];
+    tk[threadIdx.x] = t;
+    lse[threadIdx.x] = J.theta[static_cast<int64_t>(threadIdx.x) * C] - J.table[threadIdx.x];  // theta[k, 0] - log p[k, 0]
+  }
+  __syncthreads();
+  const int n = kU * C;
+  // (four entries per thread and pass, every load of a pass issued before its arithmetic: a pass is one memory round trip)
+  if (J.mode != 2) {
+    for (int e0 = threadIdx.x; e0 < n; e0 += 4096) {
+      float th[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) th[u] = e0 + 1024 * u < n ? *ck::as_global(J.theta + e0 + 1024 * u) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 1024 * u;
+        if (e < n) {
+          const int k = e / C, c = e - k * C;
+          *ck::as_global(J.dtheta + e) = hist[c * kHS + k] - expf(th[u] - lse[k]) * tk[k];
+        }
+      }
+    }
+    return;
+  }
+  const ck_opt_state os = *opt;
+  if (os.skip_now) return;
+  for (int e0 = threadIdx.x; e0 < n; e0 += 4096) {
+    float th[4], a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool on = e0 + 1024 * u < n;
+      th[u] = on ? *ck::as_global(J.theta_out + e0 + 1024 * u) : 0.f;
+      a[u] = (on && os.kind) ? *ck::as_global(J.m1 + e0 + 1024 * u) : 0.f;
+      b[u] = (on && os.kind) ? *ck::as_global(J.m2 + e0 + 1024 * u) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + 1024 * u;
+      if (e < n) {
+        const int k = e / C, c = e - k * C;
+        const float g = hist[c * kHS + k] - expf(th[u] - lse[k]) * tk[k];
+        const float t = opt_update(os, th[u], g, a[u], b[u]);
+        *ck::as_global(J.theta_out + e) = t;
+        if (os.kind) {
+          *ck::as_global(J.m1 + e) = a[u];
+          *ck::as_global(J.m2 + e) = b[u];
+        }
+        hist[c * kHS + k] = t;  // (this thread's own slot: the updated logits, transposed, for the next table)
+      }
+    }
+  }
+  __syncthreads();
+  {  // log-sum-exp over the categories of every unit: wave w takes c = w, w + 16, ...
+    float mx = -INFINITY;
+    for (int c = wave; c < C; c += 16) mx = fmaxf(mx, hist[c * kHS + lane]);
+    red[wave * kU + lane] = mx;
+    __syncthreads();
+    if (threadIdx.x < kU) {
+      float m2 = red[threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) m2 = fmaxf(m2, red[w * kU + threadIdx.x]);
+      tk[threadIdx.x] = m2;
+    }
+    __syncthreads();
+    float sm = 0.f;
+    for (int c = wave; c < C; c += 16) sm += expf(hist[c * kHS + lane] - tk[lane]);
+    __syncthreads();
+    red[wave * kU + lane] = sm;
+    __syncthreads();
+    if (threadIdx.x < kU) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) t += red[w * kU + threadIdx.x];
+      lse[threadIdx.x] = tk[threadIdx.x] + logf(t);
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < n; e += 1024) {  // table[c, k] = log softmax(theta')[k, c]
+    const int c = e >> 6, k = e & 63;
+    J.table_out[e] = hist[c * kHS + k] - lse[k];
+  }
+}
+
 // ---- Gaussian input layers -------------------------------------------------------------------------------------------------------
 // One fold of a TorchGaussianLayer (layers/input.py:661-670): log N(x; mu_k, sigma_k) per unit k.  With G the sum of the fold's
 // gradient blocks:  d mu_k = sum_b G[b, k] (x_b - mu_k) / sigma_k^2,   d sigma_k = sum_b G[b, k] ((x_b - mu_k)^2 / sigma_k^2 - 1) / sigma_k
@@ -975,6 +1169,22 @@ int ck_jobs_root(const ck_root_launch* a, void* stream) {
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(jobs_root_kernel, dim3(v.n_wg), dim3(256), 0, s, v);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_jobs_cat_bwd(const ck_cat_job* jobs, int n_jobs, const float* const* pool, int B, int C, const ck_opt_state* opt, void* stream) {
+  CK_REQUIRE(jobs && pool && n_jobs > 0 && B > 0 && C > 0, "ck_jobs_cat_bwd: bad arguments");
+  const int per = (C + 1 + 15) / 16, nkeys = 16 * per;
+  const size_t lds = (static_cast<size_t>(C + 1) * kHS + 16 * kU + 2 * kU) * sizeof(float) + (2 * nkeys + 1 + 2 * kCatRows) * sizeof(int);
+  if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_jobs_cat_bwd: %d categories do not fit one workgroup's LDS", C);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jobs_cat_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(jobs_cat_bwd_kernel, dim3(n_jobs), dim3(1024), lds, s, jobs, pool, opt, B, C);
         return hipGetLastError();
       },
       stream);

@@ -80,6 +80,7 @@ class JobStep:
         self.nsum_jobs: list[dict] = []
         self.inputs: list[int] = []
         self.gauss: dict[int, list[dict]] = {}  # Gaussian layers whose folds are backward jobs
+        self.cat: set[int] = set()  # Categorical layers whose folds are backward jobs
         self.n_extra = 0
         gsrc: dict[tuple, list] = {}
         producer: dict[tuple, dict] = {}  # block -> the job that writes it (forward)
@@ -135,6 +136,8 @@ class JobStep:
                     if not claim(name, f, f"layer {i}"):
                         return f"tensor {name} is shared"
                 self.inputs.append(i)
+                if l.scope_idx.shape[1] == 1 and ((l.num_categories + 1) * 65 + 1280) * 4 + (2 * 16 * ((l.num_categories + 16) // 16) + 4100) * 4 <= 160 * 1024:
+                    self.cat.add(i)  # its folds' backward (+ optimizer + next table) is one launch of jobs (`ck_jobs_cat_bwd`)
             elif isinstance(l, HipGaussianLayer):
                 if l.num_output_units != K or l.log_partition is not None or (set(l.mean.ops) | set(l.stddev.ops)) - tr._PARAM_OPS:
                     return f"layer {i}: Gaussian layers need 64 units, no log-partition and plain parameters"
@@ -315,7 +318,7 @@ class JobStep:
         self.input_g: dict[int, dict] = {}
         for i in self.inputs:
             Fi = c.layers[i].num_folds
-            first = -1 if i in self.gauss else extra(Fi)
+            first = -1 if (i in self.gauss or i in self.cat) else extra(Fi)
             lists = [list(self._sources(("a", i, f))) for f in range(Fi)]
             if any(not lst for lst in lists):
                 return f"input layer {i} has a fold nobody reads"
@@ -352,7 +355,7 @@ class JobStep:
     def _uncovered(self) -> list[int]:
         """Input layers whose parameters no job epilogue updates (their gradients go to the flat buffer; the fused step runs
         the optimizer on their tensors' ranges and re-evaluates their parameter graphs at its start)."""
-        return [i for i in self.inputs if i not in self.gauss]
+        return [i for i in self.inputs if i not in self.gauss and i not in self.cat]
 
     def _opt_state(self) -> torch.Tensor:
         """The DEVICE ck_opt_state of the fused optimizer (created on first use; its constants follow the trainer's)."""
@@ -547,6 +550,21 @@ class JobStep:
                 r["vmin"], r["vmax"], r["has_ss"], r["mode"] = rec["vmin"], rec["vmax"], 1 if rec["ss"] else 0, 1
             return upload(tab, True), len(tab)
 
+        def cat_table(i: int) -> tuple[dict, int]:
+            l = c.layers[i]
+            name = l.probs.graph.nodes[0].config["tensor"]
+            Cn = l.num_categories
+            tab = np.zeros(l.num_folds, dtype=np.dtype(capi.CAT_JOB_DTYPE))
+            for f, (r, lst) in enumerate(zip(tab, self.input_g[i]["lists"])):
+                th, m1, m2 = theta_ptrs((name, f))
+                tb = l._table.data_ptr() + f * (Cn + 1) * K * 4
+                r["x"] = bd.xt_i.data_ptr() + int(l.scope_idx[f, 0]) * B * 4
+                r["theta"], r["table"], r["dtheta"] = th, tb, grad_ptr((name, f))
+                r["theta_out"], r["m1"], r["m2"], r["table_out"] = th, m1, m2, tb
+                r["g_off"], r["n_g"] = put(lst)
+                r["mode"] = 1
+            return upload(tab, True), len(tab)
+
         def by_level(jobs: list[dict], key: str) -> dict[int, list[dict]]:
             out: dict[int, list[dict]] = {}
             for j in jobs:
@@ -578,6 +596,8 @@ class JobStep:
                 ig = self.input_g[i]
                 if i in self.gauss:
                     launches.append(("gauss_bwd", i) + gauss_table(i))
+                elif i in self.cat:
+                    launches.append(("cat_bwd", i) + cat_table(i))
                 else:
                     launches.append(("input_bwd", i) + nsum_table([(lst, x0 + (ig["first"] + f) * blk * 4) for f, lst in enumerate(ig["lists"])]))
         # the root launch
@@ -687,6 +707,8 @@ class JobStep:
                 capi.call("ck_jobs_mix_bwd", la[1][mode].data_ptr(), la[2], pool, la[3], blk, opt, stream)
             elif what == "gauss_bwd":
                 capi.call("ck_jobs_gauss_bwd", la[2][mode].data_ptr(), la[3], pool, B, opt, stream)
+            elif what == "cat_bwd":
+                capi.call("ck_jobs_cat_bwd", la[2][mode].data_ptr(), la[3], pool, B, c.layers[la[1]].num_categories, opt, stream)
             elif what == "input_bwd":
                 i = la[1]
                 capi.call("ck_jobs_nsum", la[2][1].data_ptr(), la[3], pool, blk, stream)

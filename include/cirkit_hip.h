@@ -833,6 +833,23 @@ typedef struct ck_root_launch {
   int32_t S; /* blocks per scalar fold: every fold's list pool[in_off[r] .. + S) has this length (pad with a block of zeros) */
 } ck_root_launch;
 int ck_jobs_root(const ck_root_launch* a, void* stream);
+/* One fold of a TorchCategoricalLayer with 64 units and probs = softmax(theta) (layers/input.py:399-412, nodes.py:764-783), backward:
+ * G = the sum of the n_g blocks pool[g_off ..], x the (B) int32 column of the staged batch (-1 = marginalised), theta (64, C) the
+ * logits, table (C + 1, 64) the log-probabilities the forward gathered from.  mode 1: dtheta (64, C) <- the gradient of the
+ * logits; mode 2: the optimizer's update of theta_out / m1 / m2 in place and table_out <- the next step's table (rows < C). */
+typedef struct ck_cat_job {
+  const int32_t* x;
+  const float* theta;
+  const float* table;
+  float* dtheta;
+  float* theta_out;
+  float* m1;
+  float* m2;
+  float* table_out;
+  int32_t g_off, n_g;
+  int32_t mode, reserved;
+} ck_cat_job;
+int ck_jobs_cat_bwd(const ck_cat_job* jobs, int n_jobs, const float* const* pool, int B, int C, const ck_opt_state* opt, void* stream);
 /* One fold of a TorchGaussianLayer with 64 units (layers/input.py:661-670), backward: G = the sum of the n_g blocks pool[g_off ..],
  * x the (B) column of the staged batch (NaN = marginalised); mode 1: dmean / dsd <- the gradients of the tensors behind mean and
  * stddev (has_ss: stddev = vmin + (vmax - vmin) sigmoid(theta), nodes.py:698-699); mode 2: the optimizer's update in place,

@@ -47,11 +47,15 @@ for la in st["launches"]:
         fn = lambda: capi.call("ck_jobs_root", C.byref(st["root"][MODE]), stream)
         desc = (1, 1, 1, "", "")
     else:
-        tabs = la[2] if what in ("input_bwd", "gauss_bwd") else la[1]
-        n = la[3] if what in ("input_bwd", "gauss_bwd") else la[2]
+        tabs = la[2] if what in ("input_bwd", "gauss_bwd", "cat_bwd") else la[1]
+        n = la[3] if what in ("input_bwd", "gauss_bwd", "cat_bwd") else la[2]
         tab = tabs.get(MODE, tabs[1])
         raw = tab.cpu().numpy()
-        if what == "gauss_bwd":
+        if what == "cat_bwd":
+            t = raw.view(np.dtype(capi.CAT_JOB_DTYPE)).reshape(-1)
+            desc = (n, n, 1, "", f"{t['n_g'].mean():.1f}/{t['n_g'].max()}")
+            fn = (lambda tab=tab, n=n, Cn=tr.circuit.layers[la[1]].num_categories: capi.call("ck_jobs_cat_bwd", tab.data_ptr(), n, pool, B, Cn, OPT, stream))
+        elif what == "gauss_bwd":
             t = raw.view(np.dtype(capi.GAUSS_JOB_DTYPE)).reshape(-1)
             desc = (n, n, 1, "", f"{t['n_g'].mean():.1f}/{t['n_g'].max()}")
             fn = (lambda tab=tab, n=n: capi.call("ck_jobs_gauss_bwd", tab.data_ptr(), n, pool, B, OPT, stream))

@@ -174,8 +174,11 @@ def test_hip_gradients_match_the_reference_gradient_fixture_k64(hip_device, name
             assert float(got.norm()) <= 10.0 * max(n_ref, n64) + 1e-12, k
             continue
         checked += 1
-        assert abs(float(got.norm()) - n_ref) <= 3e-3 * n_ref + 1e-12, (k, float(got.norm()), n_ref)
-        head = ref["ghead_" + k]
-        # (entry by entry at 2 %: the deeper tensors' gradients are ~1e-7 and carry the fp32 rounding of every layer below them)
-        assert np.abs(got.reshape(-1)[:32].numpy() - head).max() <= 2e-2 * max(np.abs(head).max(), float(got.abs().max()) * 1e-2) + 1e-12, k
+        assert abs(float(got.norm()) - n_ref) <= 1e-2 * n_ref + 1e-12, (k, float(got.norm()), n_ref)
+        # entry by entry against the fp64 oracle, with the error of the reference's own fp32 `loss.backward()` as the yardstick
+        # (the deeper tensors' gradients are ~1e-6 and carry the fp32 rounding of every layer below them -- in the reference too)
+        head, head64 = ref["ghead_" + k].astype(np.float64), g64[k].reshape(-1)[:32].numpy()
+        e_ref = np.abs(head - head64).max()
+        e_got = np.abs(got.reshape(-1)[:32].double().numpy() - head64).max()
+        assert e_got <= 4.0 * e_ref + 5e-3 * np.abs(head64).max() + 1e-12, (k, e_got, e_ref, np.abs(head64).max())
     assert checked >= len(plan.tensors) // 2
