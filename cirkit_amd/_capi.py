@@ -156,7 +156,7 @@ class RootLaunch(C.Structure):
 SUM_JOB_DTYPE = [("w", "<u8"), ("out", "<u8"), ("gx", "<u8"), ("dtheta", "<u8"), ("theta", "<u8"), ("m1", "<u8"), ("m2", "<u8"),
                  ("w_out", "<u8"), ("part", "<u8"), ("ticket", "<u8"), ("in_off", "<i4"), ("n_in", "<i4"), ("g_off", "<i4"),
                  ("n_g", "<i4"), ("row0", "<i4"), ("row1", "<i4"), ("split", "<i4"), ("n_split", "<i4"), ("mode", "<i4"),
-                 ("reserved0", "<i4"), ("reserved1", "<i8")]
+                 ("C", "<i4"), ("xrow", "<u8")]
 MIX_JOB_DTYPE = [("w", "<u8"), ("out", "<u8"), ("gx", "<u8"), ("dtheta", "<u8"), ("theta", "<u8"), ("m1", "<u8"), ("m2", "<u8"),
                  ("w_out", "<u8"), ("part", "<u8"), ("ticket", "<u8"), ("in_off", "<i4"), ("H", "<i4"), ("g_off", "<i4"),
                  ("n_g", "<i4"), ("row0", "<i4"), ("row1", "<i4"), ("split", "<i4"), ("n_split", "<i4"), ("mode", "<i4"),

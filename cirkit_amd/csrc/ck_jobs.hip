@@ -68,6 +68,14 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ w, float
   }
 }
 
+// The row of the input blocks a batch row reads: itself, or -- a job whose input is a Categorical fold (`xrow`) -- the row of the
+// fold's (C + 1, 64) log-probability table its category selects (layers/input.py:399-412; negative = marginalised = row C).
+__device__ __forceinline__ int64_t input_row(const int32_t* __restrict__ xrow, int C, int64_t bl) {
+  if (xrow == nullptr) return bl;
+  const int cc = xrow[bl];
+  return cc < 0 ? C : min(cc, C - 1);
+}
+
 // v[q][.] = sum over the job's input blocks of row bl, units 32 q + 8 g + 4 kh + t (register 4 g + t)
 __device__ __forceinline__ void load_inputs(const float* const* __restrict__ pool, int off, int n, int64_t bl, int kh,
                                             float (&e)[2][16]) {
@@ -123,7 +131,9 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int in_off = J.in_off, n_in = J.n_in, row1 = J.row1;
   float e[2][16];
   int b0 = J.row0 + 32 * wave;
-  if (b0 < row1) load_inputs(pool, in_off, n_in, b0 + b_in < row1 ? b0 + b_in : row1 - 1, kh, e);  // (in flight while the weights are staged)
+  const int32_t* xrow = reinterpret_cast<const int32_t*>(J.xrow);
+  const int Cn = J.C;
+  if (b0 < row1) load_inputs(pool, in_off, n_in, input_row(xrow, Cn, b0 + b_in < row1 ? b0 + b_in : row1 - 1), kh, e);  // (in flight while the weights are staged)
   stage_weights<WAVES * 64>(J.w, w_s, threadIdx.x);
   __syncthreads();
   float* __restrict__ out = J.out;
@@ -131,7 +141,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     const int b = b0 + b_in;
     const bool live = b < row1;
     const int64_t bl = live ? b : row1 - 1;
-    if (!first) load_inputs(pool, in_off, n_in, bl, kh, e);
+    if (!first) load_inputs(pool, in_off, n_in, input_row(xrow, Cn, bl), kh, e);
     const float m = exp_tile(e, true);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -177,8 +187,10 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   const int in_off = J.in_off, n_in = J.n_in, g_off = J.g_off, n_g = J.n_g, row1 = J.row1;
   float e[2][16], gy[2][16];
   // the operands of a tile: v (into e) and G = the sum of the job's gradient blocks (into gy: the layout of the outputs)
+  const int32_t* xrow = reinterpret_cast<const int32_t*>(J.xrow);
+  const int Cn = J.C;
   auto load_tile = [&](int64_t bl) {
-    load_inputs(pool, in_off, n_in, bl, kh, e);
+    load_inputs(pool, in_off, n_in, input_row(xrow, Cn, bl), kh, e);
     load_inputs(pool, g_off, n_g, bl, kh, gy);
   };
   int b0 = J.row0 + 32 * wave;

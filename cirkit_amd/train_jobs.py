@@ -264,6 +264,28 @@ class JobStep:
         if not self.sum_jobs:
             return "no 64-unit sum layer"
 
+        # a Categorical layer whose folds are only read by sum jobs, each as the job's single input, is never evaluated: those jobs
+        # gather the rows of its log-probability table themselves
+        self.gathered: set[int] = set()
+        if self.cat:
+            seen: dict[int, bool] = {i: True for i in self.cat}
+            def note(blocks, ok: bool) -> None:
+                for x in blocks:
+                    if x[0] == "a" and x[1] in seen and not ok:
+                        seen[x[1]] = False
+            for j in self.sum_jobs:
+                note(j["ins"], len(j["ins"]) == 1)
+            for j in self.mix_jobs:
+                note([x for sl in j["slots"] for x in sl], False)
+            for j in self.nsum_jobs:
+                note(j["ins"], False)
+            for k in order:
+                note(scalars[k]["ins"], False)
+            self.gathered = {i for i, ok in seen.items() if ok and (po != i)}
+            for j in self.sum_jobs:
+                x = j["ins"][0]
+                if len(j["ins"]) == 1 and x[0] == "a" and x[1] in self.gathered:
+                    j["gather"] = (x[1], x[2])
         # gradient lists: expand references to kept products, then materialise lists that several readers share
         memo: dict[tuple, tuple] = {}
 
@@ -480,12 +502,22 @@ class JobStep:
                 tick = torch.zeros(len(jobs), dtype=torch.int32, device=dev)
                 keep.extend([part, tick])
             for n, j in enumerate(jobs):
-                ioff, inum = put(j["ins"])
+                xrow = Cg = 0
+                if "gather" in j:  # the input is a Categorical fold: the pool entry is its table, rows picked by the batch column
+                    gi, gf = j["gather"]
+                    gl = c.layers[gi]
+                    Cg = gl.num_categories
+                    xrow = bd.xt_i.data_ptr() + int(gl.scope_idx[gf, 0]) * B * 4
+                    ioff, inum = len(pool), 1
+                    pool.append(gl._table.data_ptr() + gf * (Cg + 1) * K * 4)
+                else:
+                    ioff, inum = put(j["ins"])
                 goff, gnum = put(j["g"]) if backward else (0, 0)
                 th, m1, m2 = theta_ptrs(j["theta"])
                 w = self._weight_ptr(j["w"])
                 for sp in range(ns):
                     r = tab[n * ns + sp]
+                    r["xrow"], r["C"] = xrow, Cg
                     r["w"], r["out"], r["gx"], r["dtheta"] = w, addr(j["out"]), addr(j["gx"]), grad_ptr(j["theta"])
                     r["theta"], r["m1"], r["m2"], r["w_out"] = th, m1, m2, w
                     r["in_off"], r["n_in"], r["g_off"], r["n_g"] = ioff, inum, goff, gnum
@@ -614,7 +646,7 @@ class JobStep:
             ptrs[:, r] = (w, grad_ptr(sc["theta"]), th, m1, m2, w)
         rin_d = torch.from_numpy(rin).to(dev)
         ptrs_d = torch.from_numpy(ptrs.view(np.int64)).to(dev)
-        n_wg = int(max(1, min(64, B // 16)))
+        n_wg = int(max(1, min(64, B // 4)))  # (a row per wave up to 256 rows: the launch is a chain of row-long round trips)
         rpart = torch.zeros(n_wg * 1042, dtype=torch.float32, device=dev)
         rtick = torch.zeros(1, dtype=torch.int32, device=dev)
         seed = torch.zeros(B, dtype=torch.float32, device=dev)
@@ -689,6 +721,8 @@ class JobStep:
             c._enqueue_params(stream)  # every parameter graph, once per step (parameters/parameter.py:180-188)
         D = c.plan.num_variables
         for i in self.inputs:
+            if i in self.gathered:
+                continue  # (its consumers read the table)
             l = c.layers[i]
             l.launch_input(bd.xt if l.wants_float_input else bd.xt_i, D, bd.views[i], B, stream)
         for la in st["launches"]:

@@ -761,8 +761,10 @@ typedef struct ck_sum_job {
   int32_t g_off, n_g;
   int32_t row0, row1;
   int32_t split, n_split;
-  int32_t mode, reserved0;
-  int64_t reserved1;
+  int32_t mode;
+  int32_t C;           /* with xrow: the number of categories */
+  const int32_t* xrow; /* NULL, or the (B) int32 column of the staged batch: the job's ONE input block is a Categorical fold's (C + 1, 64)
+                          table and batch row b reads the table row of its category (the input layer's output is never written) */
 } ck_sum_job;
 int ck_jobs_sum64_fwd(const ck_sum_job* jobs, int n_units, const float* const* pool, void* stream);
 /* waves: 4 or 8 wavefronts per workgroup (a wave takes every waves-th 32-row tile of the unit's rows; 8: one workgroup per CU) */

@@ -18,3 +18,15 @@ for spec in "256 40 6" "1024 20 4"; do
   find "$OUT" -name '*.db' -delete
   head -45 "$OUT/${ROUND}_${TAG}_train_$name.txt"
 done
+# counter passes (one counter per pass, kernel trace only) of the notebook configuration: HBM bytes and MFMA-busy cycles per launch
+if [ "${PMC:-0}" = "1" ]; then
+  CMD="python scripts/bench_train.py 256 40 6 $MODE"
+  dbs=()
+  for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
+    rocprofv3 --kernel-trace --pmc $c -d "$OUT/tpmc_${TAG}_$c" -o pmc -- $CMD > "$OUT/tpmc_${TAG}_$c.log" 2>&1
+    db=$(find "$OUT/tpmc_${TAG}_$c" -name '*.db' | head -1)
+    [ -n "$db" ] && dbs+=("$db")
+  done
+  python scripts/rocprof_summary.py "${dbs[0]}" --pmc "${dbs[@]}" | sed -n '/# PMC/,$p' >> "$OUT/${ROUND}_${TAG}_train_cfg6_b256.txt"
+  find "$OUT" -name '*.db' -delete
+fi
