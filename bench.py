@@ -376,7 +376,10 @@ def live_pmc(argv_child: list[str], timeout_s: float = 200.0) -> dict | None:
                 e = out.setdefault(short, {})
                 e["launches_sampled"] = int(n)
                 if ctr == "FETCH_SIZE":
+                    # x 2: measured for every access kind of these kernels -- coalesced streams, 128- and 256-byte row gathers, through
+                    # registers and through LDS DMA alike (scripts/ubench/fetch_calib.hip, profiles/r05_fetch_calib.txt: 2.000 each)
                     e["read_bytes"] = 2.0 * avg * 1024.0
+                    e["read_bytes_raw"] = avg * 1024.0
                 elif ctr == "WRITE_SIZE":
                     e["write_bytes"] = avg * 1024.0
                 else:
@@ -384,6 +387,7 @@ def live_pmc(argv_child: list[str], timeout_s: float = 200.0) -> dict | None:
     for e in out.values():
         if "read_bytes" in e and "write_bytes" in e:
             e["hbm_bytes"] = e["read_bytes"] + e["write_bytes"]
+            e["hbm_bytes_raw"] = e["read_bytes_raw"] + e["write_bytes"]
     return out
 
 
@@ -850,6 +854,11 @@ def main() -> None:
                 if (kp and kp.get("trace_us") and mfma_bound) else None,
                 "executed_flops_per_launch": a["exec"] / a["launches"],
                 "traffic": kp.get("hbm_bytes") if kp else None,
+                # the counters as rocprofv3 reports them (FETCH_SIZE + WRITE_SIZE, KiB -> bytes) and the correction applied above
+                "traffic_raw": kp.get("hbm_bytes_raw") if kp else None,
+                "traffic_correction": "2 x FETCH_SIZE + WRITE_SIZE: gfx950 tallies a 128-byte read request at 64 bytes; the factor was "
+                                      "measured as 2.000 for coalesced 16- and 4-byte-per-lane streams and for random 128- / 256-byte row "
+                                      "gathers through registers and through LDS DMA (scripts/ubench/fetch_calib.hip, profiles/r05_fetch_calib.txt)",
                 "traffic_source": pmc_source,
                 "hbm_measured_frac": hbm_frac,
                 "mfma_busy_frac": (kp["mfma_busy_cycles"] / (4 * n_cu * t_launch * 2.4e9)) if kp and "mfma_busy_cycles" in kp else None,
