@@ -207,8 +207,6 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_leaf_persistent_fwd": [_p, _p, _p, _p, C.POINTER(_p), _p, C.POINTER(C.c_int32), _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "ck_leaf_walk_fwd": [C.POINTER(LeafLaunch), _p],
     "ck_tail_params_fwd": [C.POINTER(TailParamsLaunch), _p],
-    "ck_tail_lse_fwd": [_p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(C.c_int32),
-                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i, _i, _i, _p],
     "ck_tail16_lse_fwd": [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p],
     "ck_param_softmax": [_p, _p, _l, _i, _l, _i, _p],
     "ck_param_softmax_batch": [C.POINTER(SoftmaxJob), _i, _p],

@@ -116,8 +116,6 @@ class HipCircuit:
         validate_inputs: discrete inputs are range-checked on the device while they are staged (no extra launch, no host
             synchronisation): a category >= the layer's number of categories -- an ``IndexError`` in the reference -- makes
             the outputs NaN and `check_inputs()` raise.  Negative values are this library's "marginalised" sentinel.
-        tail16: the fused tail on 16-row tiles with its fold outputs kept in LDS and `log_likelihood_sum`'s reduction
-            folded in (cirkit_amd/csrc/ck_tail16.hip); False keeps the 32-row walk of ck_tail.hip.
         direct_input: when the persistent leaf launches are the only readers of a discrete batch, they read -- and validate --
             the caller's ``(B, D)`` int64 tensor themselves (`ck_leaf_walk_fwd` with a program input): no staging launch,
             no staged copy.  An out-of-range category then makes the outputs of ITS ROW NaN (and `check_inputs()` raise)
@@ -159,7 +157,6 @@ class HipCircuit:
         linear_levels: bool = True,
         pad_units: bool = True,
         persistent_leaf: bool | None = None,
-        tail16: bool = True,
         validate_inputs: bool = True,
         direct_input: bool = True,
         keep_layer_outputs: bool = True,
@@ -204,7 +201,6 @@ class HipCircuit:
         self.cache_params = bool(cache_params)
         self.linear_levels = bool(linear_levels)
         self.persistent_leaf = persistent_leaf
-        self.tail16 = bool(tail16)
         self.validate_inputs = bool(validate_inputs)
         self.direct_input = bool(direct_input)
         self.keep_layer_outputs = bool(keep_layer_outputs)
@@ -260,7 +256,7 @@ class HipCircuit:
         # squared circuits of BASELINE config 5 -- is REAL-valued: the reference carries (log|v|, 0 or pi).  Its fused
         # launches then work on signed linear tiles (ck_leaf.hip, ck_tail16.hip with signed_values) instead of pairs of
         # complex exponentials; memory blocks stay complex64 as the reference's layer outputs are.
-        self._signed = bool(signed_real) and self._complex and fuse is not False and persistent_leaf is not False and tail16 \
+        self._signed = bool(signed_real) and self._complex and fuse is not False and persistent_leaf is not False \
             and linear_levels and self._is_real_valued()
         self._groups: list[SubtreeGroup] = (
             find_subtree_groups(plan, self.layers, self._children, self._out_pairs, depth, signed=self._signed)
@@ -1002,7 +998,7 @@ class HipCircuit:
         row-major or tiled fp32 layout, at most 64 folds (kTail16MaxFolds) of 32 units."""
         ls = [self.layers[j] for j in self._tail]
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
-        return (self.tail16 and lay in (capi.CK_W_ROWMAJOR, capi.CK_W_TILED_F32) and len(ls) <= 15
+        return (lay in (capi.CK_W_ROWMAJOR, capi.CK_W_TILED_F32) and len(ls) <= 15
                 and sum(l.num_folds for l in ls) <= 64 and all(l.arity <= 4 and l.num_input_units == 32 for l in ls))
 
     def _poison_in_tail(self) -> bool:
@@ -1021,14 +1017,12 @@ class HipCircuit:
                 and self.layers[last].num_output_units == 1)
 
     def _launch_tail(self, bd: _Binding, stream: int, *, with_ll: bool = False) -> None:
-        """One launch for the trailing few-fold layers (cirkit_amd/csrc/ck_tail16.hip; ck_tail.hip otherwise)."""
+        """One launch for the trailing few-fold layers (cirkit_amd/csrc/ck_tail16.hip, ck_tailp.hip)."""
         n = len(self._tail)
         ls = [self.layers[j] for j in self._tail]
         for l in ls:
             if l._w.is_complex():
                 raise ValueError("complex weights in the fused tail")
-        vp = C.c_void_p * n
-        ip = C.c_int32 * n
         lay = next((l._w_layout for l in ls if l.num_output_units == 32), capi.CK_W_ROWMAJOR)
         if self._tail16_ok() and bd.params_at_end:
             keep = self.keep_layer_outputs and (not with_ll or self.keep_levels)  # (a training forward keeps them for the backward)
@@ -1067,12 +1061,7 @@ class HipCircuit:
                 1 if self._signed else 0, stream,
             )
             return
-        capi.call(
-            "ck_tail_lse_fwd", bd.arena.data_ptr(), n,
-            vp(*[bd.row_off[j].data_ptr() for j in self._tail]), vp(*[l._w.data_ptr() for l in ls]),
-            vp(*[bd.views[j].data_ptr() for j in self._tail]), ip(*[l.num_folds for l in ls]),
-            ip(*[l.arity for l in ls]), ip(*[l.num_output_units for l in ls]), bd.B, ls[0].num_input_units, lay, stream,
-        )
+        raise capi.HipExtensionError("a fused tail that does not fit the 16-row walk (cirkit_amd/fusion.py find_tail only proposes tails that do)")
 
     def _tail16_tables(self, bd: _Binding, *, keep: bool = True, slots: bool = False) -> tuple:
         """(fold descriptors, level table, number of folds, per-tile LL sums, LL ticket, weight layout) of the 16-row tail
@@ -1759,7 +1748,7 @@ class HipCircuit:
                 if i == self._tail[-1]:
                     tl = next((self.layers[j]._w_layout for j in self._tail
                                if self.layers[j].num_output_units == 32), 0)
-                    rows.append({"layer": self._tail[0], "kernel": ("tail_params_kernel" if bd.params_at_end else f"tail16_kernel<{tl}, {'true' if self._signed else 'false'}>" if self._tail16_ok() else f"tail_kernel<{tl}>"),
+                    rows.append({"layer": self._tail[0], "kernel": ("tail_params_kernel" if bd.params_at_end else f"tail16_kernel<{tl}, {'true' if self._signed else 'false'}>"),
                                  "ms": float(mean[2 * self._tail[0] + 1]),
                                  "algorithmic_bytes": sum(layer_bytes[j] for j in self._tail),
                                  "algorithmic_flops": sum(layer_flops[j] for j in self._tail)})

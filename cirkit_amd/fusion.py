@@ -126,7 +126,7 @@ MAX_TAIL_LAYERS = 12
 
 
 def find_tail(plan, layers, skip: set[int], max_folds: int = 64, *, signed: bool = False) -> list[int]:
-    """Trailing layers with few folds that `ck_tail_lse_fwd` evaluates in one launch: real CP-T /
+    """Trailing layers with few folds that `ck_tail16_lse_fwd` / `ck_tail_params_fwd` evaluate in one launch: real CP-T /
     dense sum steps with 32 input units, 32 output units (fewer only for terminal layers, e.g. the
     scalar root), at most `max_folds` folds each."""
     if plan.semiring != ("complex-lse-sum" if signed else "lse-sum"):
@@ -148,6 +148,12 @@ def find_tail(plan, layers, skip: set[int], max_folds: int = 64, *, signed: bool
             break
         tail.append(i)
     tail.reverse()
+    # the walk keeps every fold output of the tail in LDS (ck_tail16.hip: at most 64 folds, children of arity <= 4): a longer
+    # candidate loses its first layers, which then run as ordinary layer launches
+    while tail and (sum(layers[i].num_folds for i in tail) > 64 or layers[tail[0]].arity > 4):
+        tail.pop(0)
+    if any(layers[i].arity > 4 for i in tail):
+        return []
     # a terminal layer with Ko < 32 may only be consumed by the circuit output
     return tail if len(tail) >= 2 else []
 

@@ -414,18 +414,10 @@ typedef struct ck_tail_params_launch {
 } ck_tail_params_launch;
 int ck_tail_params_fwd(const ck_tail_params_launch* desc, void* stream);
 
-/* The last `n_layers` levels of a circuit (few folds each) in one launch: one workgroup per 32-row
- * batch tile walks the layers in order, a workgroup barrier between levels.  Layer i is a
- * TorchCPTLayer / dense TorchSumLayer step over the product of its H[i] children (CK_SUM_PROD
- * semantics), Ki = 32, Ko[i] = 32 or < 32 (e.g. the scalar root).  All arrays are HOST arrays of
- * length n_layers; row_off[i] (F[i], H[i]) device offset tables, w[i] (F[i], Ko[i], 32), out[i]
- * (F[i], B, Ko[i]) inside or outside the arena.  w_layout applies to the Ko = 32 layers; layers
- * with Ko < 32 always take row-major fp32 weights. */
-int ck_tail_lse_fwd(const float* arena, int n_layers, const int64_t* const* row_off,
-                    const float* const* w, float* const* out, const int32_t* F, const int32_t* H,
-                    const int32_t* Ko, int B, int K, int w_layout, void* stream);
-
-/* The same walk on 16-row tiles (v_mfma_f32_16x16x4_f32): one workgroup of 16 wavefronts per 16 batch rows; the fold
+/* The last levels of a circuit (few folds each) in one launch, on 16-row tiles: layer i is a TorchCPTLayer / dense TorchSumLayer
+ * step over the product of its children (CK_SUM_PROD semantics), Ki = 32, Ko = 32 or < 32 for the terminal layer (e.g. the
+ * scalar root).  (A 32-row form of this walk, ck_tail_lse_fwd, existed until round 5: nothing reached it any more.) */
+/* The walk on 16-row tiles (v_mfma_f32_16x16x4_f32): one workgroup of 16 wavefronts per 16 batch rows; the fold
  * descriptors are staged in LDS once, every fold output is kept in LDS for the levels above it (and written to its
  * `out` block as before), the weights of a wave's next fold are requested before the level barrier.
  * folds: DEVICE array of n_folds descriptors in level order (16-byte aligned); level_begin: DEVICE (n_levels + 1)

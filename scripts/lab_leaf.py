@@ -25,8 +25,7 @@ from cirkit_amd.initializers import init_plan_tensors
 from cirkit_amd.templates import image_data
 
 CONFIGS = {
-    "classic": dict(persistent_leaf=False, tail16=False),
-    "tail32": dict(tail16=False),
+    "classic": dict(persistent_leaf=False),
     "default": dict(),
     "persistent": dict(persistent_leaf=True),
 }

@@ -102,7 +102,7 @@ def _check_complex_layers_locally(plan, tensors, x, hc, outs_ref, atol_scale):
 @pytest.mark.parametrize("name", ["cfg1_rbt8", "cfg2_qt784", "cfg2t_qt784_cpt16", "cfg4_pd784", "tucker_qt16_k6",
                                   "tucker4_qt16_k3", "quadgraph_6x6_k4", "rbt6_perfeature_k2", "pd_gauss_6x6_k4"])
 @pytest.mark.parametrize("use_graph", [False, True])
-@pytest.mark.parametrize("fuse", [False, 1, 2, 3, True])
+@pytest.mark.parametrize("fuse", [False, True])
 def test_real_configs_match_reference(hip_device, name, use_graph, fuse):
     from cirkit_amd.circuit import HipCircuit
 
@@ -122,6 +122,22 @@ def test_real_configs_match_reference(hip_device, name, use_graph, fuse):
     # a second call replays the recorded program / graph
     y2 = hc(x.to(hip_device)).cpu()
     assert torch.equal(y, y2)
+    _check_layers(plan, tensors, x, hc)
+
+
+@pytest.mark.parametrize("fuse", [1, 2, 3])
+def test_leaf_fusion_capped_at_fewer_levels(hip_device, fuse):
+    """`HipCircuit(fuse=n)`: the leaf region fused over n CP-T levels only (the levels above run layer by layer) -- BASELINE
+    config 2 against the reference's outputs, every materialised layer against the oracle."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg2_qt784")
+    x = _x_of(plan, g)
+    hc = HipCircuit(plan, tensors, device=hip_device, fuse=fuse)
+    assert hc._groups and hc._groups[0].depth == fuse
+    y = hc(x.to(hip_device)).cpu()
+    ref = torch.from_numpy(g["y_f32"])
+    assert float(((y - ref).abs() / ref.abs().clamp_min(1e-30)).max()) <= REL
     _check_layers(plan, tensors, x, hc)
 
 
@@ -556,19 +572,20 @@ def test_persistent_leaf_falls_back_to_log_space(hip_device):
 @pytest.mark.parametrize("B", [1, 17, 300, 4096])
 def test_tail_on_16_row_tiles(hip_device, B):
     """The fused tail on 16-row tiles (ck_tail16.hip: descriptors and fold outputs in LDS, v_mfma_f32_16x16x4_f32)
-    against the 32-row walk of ck_tail.hip and the layer-wise evaluation: every tail layer's output agrees to fp32
-    rounding (the two MFMA shapes add the 32 products in different orders), and the log-likelihood sum folded into the
-    launch equals the sum of its own outputs (fp64, deterministic)."""
+    against the layer-wise evaluation (32-row tiles, one launch per layer): every tail layer's output agrees to fp32
+    rounding (the two MFMA shapes add the 32 products in different orders; the leaf region below is evaluated in linear
+    space by the fused circuit), and the log-likelihood sum folded into the launch equals the sum of its own outputs (fp64,
+    deterministic)."""
     from cirkit_amd.circuit import HipCircuit
 
     plan, tensors, g = load_case("cfg2_qt784")
     x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(B)).to(hip_device)
-    a = HipCircuit(plan, tensors, device=hip_device, tail16=False)
-    b = HipCircuit(plan, tensors, device=hip_device, tail16=True)
-    assert b._tail16_ok() and b._tail_fuses_ll() and not a._tail16_ok()
+    a = HipCircuit(plan, tensors, device=hip_device, fuse=False)
+    b = HipCircuit(plan, tensors, device=hip_device)
+    assert b._tail16_ok() and b._tail_fuses_ll() and not a._tail
     la, lb = a.layer_outputs(x), b.layer_outputs(x)
     for j in b._tail:
-        assert torch.allclose(la[j], lb[j], rtol=1e-6, atol=1e-6 * float(la[j].abs().max())), j
+        assert torch.allclose(la[j], lb[j], rtol=2e-6, atol=2e-6 * float(la[j].abs().max())), j
     y = b(x).clone()
     s1 = b.log_likelihood_sum(x).clone().cpu()
     s2 = b.log_likelihood_sum(x).clone().cpu()
