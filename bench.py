@@ -118,6 +118,16 @@ def other_configs(device, stream, B: int) -> dict:
         "ms_partition_function": ms_z,
     }
     del hc, hz
+    # ... and on the complex kernels (what a circuit with complex-valued parameters takes; `signed_real=False` forces them for
+    # these real parameters): layer-wise (log|v|, phase) pairs, two fp32 MFMA tiles per step, polynomial sin / cos / atan
+    hq = HipCircuit(plan5, t5, device=device, signed_real=False)
+    ms_q = time_forward(hq, torch.randint(0, 256, (B, 784), generator=g).to(device))
+    out["config5_complex_weights"] = {
+        "workload": "the same circuit evaluated as complex-valued parameters require: every layer on (log|v|, arg v) pairs "
+                    "(sum_clse_tile32: VALU-issue and HBM bound, profiles/r05_c_cfg5_complex.txt)",
+        "ms_per_forward": ms_q, "evals_per_s": B / ms_q * 1e3, "launches": hq.num_launches(B),
+    }
+    del hq
     out["train_step_cfg2"] = train_step_cfg2(device, stream, B)
     # the reference's own training loop (notebooks/learning-a-circuit.ipynb cells 4 / 16 / 18: QuadGraph, CP, K = 64, batch 256,
     # Adam) and BASELINE config 4 at 1024 rows: the job form of the training step (cirkit_amd/train_jobs.py)

@@ -1518,7 +1518,7 @@ class HipCircuit:
         """Name of the HIP kernel that evaluates layer i (as it appears in a rocprofv3 trace)."""
         l, s = self.layers[i], self.plan.layers[i]
         if i in self._input_prod:
-            return "gaussian_prod_kernel<8>"
+            return "gaussian_prod_rows16_kernel" if (B % 4 == 0 and l.num_output_units in (32, 64, 128, 256)) else "gaussian_prod_kernel<8>"
         if i in self._tdense:
             return "gather_rows_vec (dense layer tabulated over its categories)"
         if i in self._emb_gather:
