@@ -491,17 +491,53 @@ class JobStep:
                         best, best_t = (sp, waves), t
             return best
 
+        def sum_layout(n_jobs: int, backward: bool) -> tuple[list[int], int]:
+            """(row splits of every job, waves per workgroup): `sum_config`'s uniform answer, or -- a backward launch of more
+            jobs than the chip holds -- whole jobs for the full rounds and only the REMAINDER cut fine, issued last: 1060 jobs
+            on 512 slots are two rounds of whole jobs + 36 jobs in 8 pieces each instead of three rounds."""
+            sp, waves = sum_config(n_jobs, backward)
+            if not backward:
+                return [sp] * n_jobs, waves
+
+            def unit(s_: int, w_: int, shared: bool) -> float:
+                per_wave = -(-(-(-tiles // s_)) // w_)
+                return 10.0 + (10.0 if s_ > 1 else 0.0) + (14.0 if shared else 10.0) * per_wave
+
+            slots_u = n_cu * (2 if waves == 4 else 1)
+            t_uniform = -(-n_jobs * sp // slots_u) * unit(sp, waves, waves == 8 or n_jobs * sp > n_cu)
+            best = ([sp] * n_jobs, waves, t_uniform)
+            for w_ in (4, 8):
+                slots = n_cu * (2 if w_ == 4 else 1)
+                full = (n_jobs // slots) * slots
+                rem = n_jobs - full
+                if full == 0 or rem == 0:
+                    continue
+                for sr in (2, 3, 4, 6, 8, 12, 16):
+                    if -(-tiles // sr) < w_:
+                        break
+                    t = (full // slots) * unit(1, w_, True) + -(-rem * sr // slots) * unit(sr, w_, True)
+                    if t < best[2] - 1e-9:
+                        best = ([1] * full + [sr] * rem, w_, t)
+            return best[0], best[1]
+
         def sum_table(jobs: list[dict], backward: bool) -> tuple[dict, int, int]:
-            ns, waves = sum_config(len(jobs), backward)
-            rows_per = -(-tiles // ns) * 32
-            ns = -(-B // rows_per)
-            tab = np.zeros(len(jobs) * ns, dtype=np.dtype(capi.SUM_JOB_DTYPE))
+            splits, waves = sum_layout(len(jobs), backward)
+            rows_of, first_unit, n_units = [], [], 0
+            for ns_j in splits:  # (a job's pieces: whole 32-row tiles, as equal as they come)
+                rp = -(-tiles // ns_j) * 32
+                rows_of.append(rp)
+                first_unit.append(n_units)
+                n_units += -(-B // rp)
+            tab = np.zeros(n_units, dtype=np.dtype(capi.SUM_JOB_DTYPE))
             part = tick = None
-            if backward and ns > 1:
-                part = torch.zeros(len(jobs) * ns * 4096, dtype=torch.float32, device=dev)
+            if backward and n_units > len(jobs):
+                part = torch.zeros(n_units * 4096, dtype=torch.float32, device=dev)
                 tick = torch.zeros(len(jobs), dtype=torch.int32, device=dev)
                 keep.extend([part, tick])
             for n, j in enumerate(jobs):
+                rows_per = rows_of[n]
+                ns = -(-B // rows_per)
+                u0 = first_unit[n]
                 xrow = Cg = 0
                 if "gather" in j:  # the input is a Categorical fold: the pool entry is its table, rows picked by the batch column
                     gi, gf = j["gather"]
@@ -516,15 +552,15 @@ class JobStep:
                 th, m1, m2 = theta_ptrs(j["theta"])
                 w = self._weight_ptr(j["w"])
                 for sp in range(ns):
-                    r = tab[n * ns + sp]
+                    r = tab[u0 + sp]
                     r["xrow"], r["C"] = xrow, Cg
                     r["w"], r["out"], r["gx"], r["dtheta"] = w, addr(j["out"]), addr(j["gx"]), grad_ptr(j["theta"])
                     r["theta"], r["m1"], r["m2"], r["w_out"] = th, m1, m2, w
                     r["in_off"], r["n_in"], r["g_off"], r["n_g"] = ioff, inum, goff, gnum
                     r["row0"], r["row1"] = sp * rows_per, min(B, (sp + 1) * rows_per)
                     r["split"], r["n_split"], r["mode"] = sp, ns, 1
-                    if part is not None:
-                        r["part"], r["ticket"] = part.data_ptr() + n * ns * 4096 * 4, tick.data_ptr() + n * 4
+                    if part is not None and ns > 1:
+                        r["part"], r["ticket"] = part.data_ptr() + u0 * 4096 * 4, tick.data_ptr() + n * 4
             return upload(tab, backward), len(tab), waves
 
         def mix_table(jobs: list[dict], backward: bool) -> tuple[dict, int, int]:

@@ -65,8 +65,8 @@ for la in st["launches"]:
             fn = (lambda tab=tab, n=n: capi.call("ck_jobs_nsum", tab.data_ptr(), n, pool, blk, stream))
         elif what.startswith("sum"):
             t = raw.view(np.dtype(capi.SUM_JOB_DTYPE)).reshape(-1)
-            ns = int(t["n_split"][0])
-            desc = (n, n // ns, ns, f"{t['n_in'].mean():.1f}/{t['n_in'].max()}", f"{t['n_g'].mean():.1f}/{t['n_g'].max()}")
+            ns = int(t["n_split"].max())
+            desc = (n, int((t["split"] == 0).sum()), ns, f"{t['n_in'].mean():.1f}/{t['n_in'].max()}", f"{t['n_g'].mean():.1f}/{t['n_g'].max()}")
             name = "ck_jobs_sum64_fwd" if what == "sum_fwd" else "ck_jobs_sum64_bwd"
             fn = ((lambda tab=tab, n=n: capi.call("ck_jobs_sum64_fwd", tab.data_ptr(), n, pool, stream)) if what == "sum_fwd" else
                   (lambda tab=tab, n=n, wv=la[3]: capi.call("ck_jobs_sum64_bwd", tab.data_ptr(), n, pool, OPT, wv, stream)))
