@@ -156,7 +156,8 @@ class RootLaunch(C.Structure):
 SUM_JOB_DTYPE = [("w", "<u8"), ("out", "<u8"), ("gx", "<u8"), ("dtheta", "<u8"), ("theta", "<u8"), ("m1", "<u8"), ("m2", "<u8"),
                  ("w_out", "<u8"), ("part", "<u8"), ("ticket", "<u8"), ("in_off", "<i4"), ("n_in", "<i4"), ("g_off", "<i4"),
                  ("n_g", "<i4"), ("row0", "<i4"), ("row1", "<i4"), ("split", "<i4"), ("n_split", "<i4"), ("mode", "<i4"),
-                 ("C", "<i4"), ("xrow", "<u8")]
+                 ("C", "<i4"), ("xrow", "<u8"), ("mix_out", "<u8"), ("mix_w", "<u8"), ("mix_dw", "<u8"), ("partner_off", "<i4"),
+                 ("n_partner", "<i4"), ("mix_h", "<i4"), ("mix_H", "<i4"), ("reserved_a", "<i8"), ("reserved_b", "<i8"), ("reserved_c", "<i8")]
 MIX_JOB_DTYPE = [("w", "<u8"), ("out", "<u8"), ("gx", "<u8"), ("dtheta", "<u8"), ("theta", "<u8"), ("m1", "<u8"), ("m2", "<u8"),
                  ("w_out", "<u8"), ("part", "<u8"), ("ticket", "<u8"), ("in_off", "<i4"), ("H", "<i4"), ("g_off", "<i4"),
                  ("n_g", "<i4"), ("row0", "<i4"), ("row1", "<i4"), ("split", "<i4"), ("n_split", "<i4"), ("mode", "<i4"),
@@ -251,6 +252,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_latch_flag": [_p, _p, _p],
     "ck_jobs_sum64_fwd": [_p, _i, _p, _p],
     "ck_jobs_sum64_bwd": [_p, _i, _p, _p, _i, _p],
+    "ck_jobs_mix_params": [_p, _i, _p, _p],
     "ck_jobs_mix_fwd": [_p, _i, _p, _i, _p],
     "ck_jobs_mix_bwd": [_p, _i, _p, _i, _l, _p, _p],
     "ck_jobs_nsum": [_p, _i, _p, _l, _p],

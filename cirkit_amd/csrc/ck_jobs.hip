@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   constexpr int kArea = WAVES * 2 * 16 * kTS > kBufs * 4096 ? WAVES * 2 * 16 * kTS : kBufs * 4096;
   __shared__ __attribute__((aligned(16))) float lds[kU * kWS + kArea];
   __shared__ unsigned int s_ticket;
+  __shared__ float lw_s[kU];  // a job under a mixing fold: log of its slot's coefficient per unit
   float* w_s = lds;
   float* area = lds + kU * kWS;  // (64 x 65 floats: a multiple of 16 bytes)
   const SumJob& J = jobs[blockIdx.x];
@@ -195,6 +196,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   };
   int b0 = J.row0 + 32 * wave;
   if (b0 < row1) load_tile(b0 + b_in < row1 ? b0 + b_in : row1 - 1);  // (the first tile's loads fly while the weights are staged)
+  const float* __restrict__ mix_out = J.mix_out;
+  const int partner_off = J.partner_off, n_partner = J.n_partner;
+  if (mix_out != nullptr && threadIdx.x < kU) lw_s[threadIdx.x] = logf(J.mix_w[threadIdx.x * J.mix_H + J.mix_h]);
   stage_weights<WAVES * 64>(J.w, w_s, threadIdx.x);
   __syncthreads();
   float* gy_s = area + wave * (2 * 16 * kTS);
@@ -212,11 +216,25 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     const bool live = b < row1;
     const int64_t bl = live ? b : row1 - 1;
     if (!first) load_tile(bl);
-    exp_tile(e, live);
+    const float m_in = exp_tile(e, live);
     // y = W e, gy = G / y
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const f32x16 acc = contract_rows(w_s, p, b_in, kh, e);
+      if (mix_out != nullptr) {
+        // the gradient of this job's output through the mixing fold above it: (the fold's G) * w_h * exp(x_h - out_mix), x_h = the
+        // job's own output -- recomputed exactly as the forward stored it -- plus the other factors of its slot
+        float xh[16], om[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xh[r] = fmaf(__builtin_amdgcn_logf(acc[r]), kLN2, m_in);
+        for (int s2 = 0; s2 < n_partner; ++s2) tile_load_add(pool[partner_off + s2] + bl * kU + 32 * p + 4 * kh, xh);
+        tile_load(mix_out + bl * kU + 32 * p + 4 * kh, om);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float t = xh[r] + lw_s[32 * p + 8 * (r >> 2) + 4 * kh + (r & 3)] - om[r];
+          gy[p][r] = (acc[r] > 0.f && gy[p][r] != 0.f) ? gy[p][r] * __builtin_amdgcn_exp2f(t * kL2E) : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) gy[p][r] = (live && acc[r] > 0.f && gy[p][r] != 0.f) ? gy[p][r] * __builtin_amdgcn_rcpf(acc[r]) : 0.f;
     }
@@ -370,15 +388,16 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     wv[k] = w_s[o * kWS + c0 + k];
     dv[k] = dw_s[o * kU + c0 + k];
   }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kEPT; ++k) s = fmaf(wv[k], dv[k], s);
+  s = row_sum(s);  // = sum_b G[b, o]: sum_n W[o, n] dW[o, n] = sum_b gy[b, o] y[b, o]
+  if (J.mix_dw != nullptr && threadIdx.x % kTPR == 0) J.mix_dw[o * J.mix_H + J.mix_h] = s / J.mix_w[o * J.mix_H + J.mix_h];
   if (J.mode == 0) {  // the gradient of the linear weights, for a parameter graph this epilogue does not know
 #pragma unroll
     for (int k = 0; k < kEPT; k += 4) ck::gstore4(J.dtheta + o * kU + c0 + k, make_float4(dv[k], dv[k + 1], dv[k + 2], dv[k + 3]));
     return;
   }
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < kEPT; ++k) s = fmaf(wv[k], dv[k], s);
-  s = row_sum(s);
 #pragma unroll
   for (int k = 0; k < kEPT; ++k) dv[k] = wv[k] * (dv[k] - s);  // d theta (nodes.py:764-772 under autograd)
   if (J.mode == 1) {
@@ -595,6 +614,45 @@ __global__ void __launch_bounds__(256)
     sum += ex;
   }
   for (int h = 0; h < H; ++h) J.w_out[k * H + h] = dw_s[k * HMAX + h] / sum;
+}
+
+// The parameter step of mixing folds whose backward ran inside their factors' sum jobs: d w (64, H) is in `part`.
+__global__ void __launch_bounds__(64) jobs_mix_params_kernel(const MixJob* __restrict__ jobs, const ck_opt_state* __restrict__ opt) {
+  const MixJob& J = jobs[blockIdx.x];
+  const int H = J.H, k = threadIdx.x;
+  const float* dw = J.part + k * H;
+  const float* w = J.w + k * H;
+  if (J.mode == 0) {
+    for (int h = 0; h < H; ++h) J.dtheta[k * H + h] = dw[h];
+    return;
+  }
+  float s = 0.f;
+  for (int h = 0; h < H; ++h) s = fmaf(w[h], dw[h], s);
+  if (J.mode == 1) {
+    for (int h = 0; h < H; ++h) J.dtheta[k * H + h] = w[h] * (dw[h] - s);
+    return;
+  }
+  const ck_opt_state os = *opt;
+  if (os.skip_now) return;
+  float th[16];
+  float mx = -INFINITY;
+  for (int h = 0; h < H; ++h) {
+    const float g = w[h] * (dw[h] - s);
+    float a = os.kind ? J.m1[k * H + h] : 0.f, v = os.kind ? J.m2[k * H + h] : 0.f;
+    th[h] = opt_update(os, J.theta[k * H + h], g, a, v);
+    J.theta[k * H + h] = th[h];
+    if (os.kind) {
+      J.m1[k * H + h] = a;
+      J.m2[k * H + h] = v;
+    }
+    mx = fmaxf(mx, th[h]);
+  }
+  float sum = 0.f;
+  for (int h = 0; h < H; ++h) {
+    th[h] = expf(th[h] - mx);
+    sum += th[h];
+  }
+  for (int h = 0; h < H; ++h) J.w_out[k * H + h] = th[h] / sum;
 }
 
 // ---- block sums ---------------------------------------------------------------------------------------------------------------
@@ -1135,6 +1193,16 @@ int ck_jobs_mix_fwd(const ck_mix_job* jobs, int n_units, const float* const* poo
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(jobs_mix_fwd_kernel, dim3(n_units), dim3(256), 0, s, jobs, pool);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_jobs_mix_params(const ck_mix_job* jobs, int n_jobs, const ck_opt_state* opt, void* stream) {
+  CK_REQUIRE(jobs && n_jobs > 0, "ck_jobs_mix_params: bad arguments");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(jobs_mix_params_kernel, dim3(n_jobs), dim3(64), 0, s, jobs, opt);
         return hipGetLastError();
       },
       stream);

@@ -19,6 +19,7 @@ collective; `JobStep.applies(trainer)` says why a plan does not take this form (
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -29,6 +30,7 @@ from .plan import resolve_fold_index
 
 MAX_LIST = 4  # a product of more blocks than this is materialised by an NSUM job
 K = 64
+FOLD_MIX_BWD = os.environ.get("CK_JOBS_FOLD_MIX", "1") != "0"  # (lab switch: 0 keeps a backward launch per mixing level)
 
 
 def _expr(g, j: int, f: int):
@@ -301,8 +303,30 @@ class JobStep:
             memo[x] = tuple(out)
             return memo[x]
 
+        # a mixing fold whose every factor is the output of a sum job that nobody else reads has no backward launch: each of
+        # those sum jobs forms its own gradient from the MIXING fold's gradient list (ck_sum_job.mix_out), and one job per slot
+        # leaves d w[:, h]; the softmax behind the coefficients is differentiated by one launch for all such folds at the end
+        sum_of = {j["out"]: j for j in self.sum_jobs}
+        self.mix_fold_bwd = FOLD_MIX_BWD
+        for r in (self.mix_jobs if FOLD_MIX_BWD else []):
+            ok = True
+            for h, sl in enumerate(r["slots"]):
+                for x in sl:
+                    if x not in sum_of or gsrc.get(x) != [("x", r["gx0"] + h)] or "mix" in sum_of[x]:
+                        ok = False
+            if not ok or r["S"] > 4:
+                continue
+            r["folded"] = True
+            for h, sl in enumerate(r["slots"]):
+                for k, x in enumerate(sl):
+                    sum_of[x]["mix"] = {"job": r, "h": h, "partners": [y for y in sl if y is not x], "writer": k == 0}
+        for j in self.sum_jobs:
+            j["gof"] = j["mix"]["job"]["out"] if "mix" in j else j["out"]  # the block whose gradient list the job reads
+        live_mix = [r for r in self.mix_jobs if not r.get("folded")]
+        for r in live_mix:
+            r["gof"] = r["out"]
         readers: dict[tuple, int] = {}
-        wanted = [j["out"] for j in self.sum_jobs + self.mix_jobs] + [("a", i, f) for i in self.inputs for f in range(c.layers[i].num_folds)]
+        wanted = [j["gof"] for j in self.sum_jobs + live_mix] + [("a", i, f) for i in self.inputs for f in range(c.layers[i].num_folds)]
         for x in wanted:
             readers[sources(x)] = readers.get(sources(x), 0) + 1
         self.gsum_jobs: list[dict] = []
@@ -313,8 +337,8 @@ class JobStep:
                 shared[lst] = out
                 self.gsum_jobs.append({"ins": list(lst), "out": out})
         self._sources = lambda x: ((shared[sources(x)],) if sources(x) in shared else sources(x))
-        for j in self.sum_jobs + self.mix_jobs:
-            j["g"] = list(self._sources(j["out"]))
+        for j in self.sum_jobs + live_mix:
+            j["g"] = list(self._sources(j["gof"]))
             if not j["g"]:
                 return f"layer {j['layer']} fold {j['fold']} feeds nothing"
         # backward levels: the root is level 0; a job follows the writers of its gradient list
@@ -323,7 +347,7 @@ class JobStep:
             writer[("x", g0 + r)] = {"lb": 0}
         for j in self.sum_jobs:
             writer[j["gx"]] = j
-        for j in self.mix_jobs:
+        for j in live_mix:
             for h in range(j["H"]):
                 writer[("x", j["gx0"] + h)] = j
         for j in self.gsum_jobs:
@@ -334,7 +358,7 @@ class JobStep:
                 j["lb"] = 1 + max(lb(writer[gsid]) for gsid in (j["g"] if "g" in j else j["ins"]))
             return j["lb"]
 
-        for j in self.sum_jobs + self.mix_jobs + self.gsum_jobs:
+        for j in self.sum_jobs + live_mix + self.gsum_jobs:
             lb(j)
         # the gradient of every input-layer fold, gathered into a contiguous (F, B, 64) block per layer for its backward
         self.input_g: dict[int, dict] = {}
@@ -491,6 +515,18 @@ class JobStep:
                         best, best_t = (sp, waves), t
             return best
 
+        folded = [r for r in self.mix_jobs if r.get("folded")]
+        mix_dw = torch.zeros(max(1, sum(K * r["H"] for r in folded)), dtype=torch.float32, device=dev)
+        keep.append(mix_dw)
+        mix_dw_off: dict[int, int] = {}
+        off_f = 0
+        for r in folded:
+            mix_dw_off[id(r)] = off_f
+            off_f += K * r["H"]
+
+        def mix_dw_ptr(r: dict) -> int:
+            return mix_dw.data_ptr() + 4 * mix_dw_off[id(r)]
+
         def sum_layout(n_jobs: int, backward: bool) -> tuple[list[int], int]:
             """(row splits of every job, waves per workgroup): `sum_config`'s uniform answer, or -- a backward launch of more
             jobs than the chip holds -- whole jobs for the full rounds and only the REMAINDER cut fine, issued last: 1060 jobs
@@ -551,9 +587,18 @@ class JobStep:
                 goff, gnum = put(j["g"]) if backward else (0, 0)
                 th, m1, m2 = theta_ptrs(j["theta"])
                 w = self._weight_ptr(j["w"])
+                mx = j.get("mix") if backward else None
+                if mx is not None:
+                    mj = mx["job"]
+                    poff, pnum = put(mx["partners"])
+                    m_out, m_w = addr(mj["out"]), self._weight_ptr(mj["w"])
+                    m_dw = mix_dw_ptr(mj) if mx["writer"] else 0
                 for sp in range(ns):
                     r = tab[u0 + sp]
                     r["xrow"], r["C"] = xrow, Cg
+                    if mx is not None:
+                        r["mix_out"], r["mix_w"], r["mix_dw"] = m_out, m_w, m_dw
+                        r["partner_off"], r["n_partner"], r["mix_h"], r["mix_H"] = poff, pnum, mx["h"], mj["H"]
                     r["w"], r["out"], r["gx"], r["dtheta"] = w, addr(j["out"]), addr(j["gx"]), grad_ptr(j["theta"])
                     r["theta"], r["m1"], r["m2"], r["w_out"] = th, m1, m2, w
                     r["in_off"], r["n_in"], r["g_off"], r["n_g"] = ioff, inum, goff, gnum
@@ -649,7 +694,8 @@ class JobStep:
             if lv in fm:
                 launches.append(("mix_fwd",) + mix_table(fm[lv], False))
         launches.append(("root",))
-        bs, bm, bg = by_level(self.sum_jobs, "lb"), by_level(self.mix_jobs, "lb"), by_level(self.gsum_jobs, "lb")
+        bs, bm, bg = (by_level(self.sum_jobs, "lb"), by_level([r for r in self.mix_jobs if not r.get("folded")], "lb"),
+                      by_level(self.gsum_jobs, "lb"))
         bi: dict[int, list[int]] = {}
         for i, ig in self.input_g.items():
             bi.setdefault(ig["lb"], []).append(i)
@@ -668,6 +714,14 @@ class JobStep:
                     launches.append(("cat_bwd", i) + cat_table(i))
                 else:
                     launches.append(("input_bwd", i) + nsum_table([(lst, x0 + (ig["first"] + f) * blk * 4) for f, lst in enumerate(ig["lists"])]))
+        if folded:  # the coefficients of the mixing folds without a backward launch: one launch for all of them
+            tab = np.zeros(len(folded), dtype=np.dtype(capi.MIX_JOB_DTYPE))
+            for r, j in zip(tab, folded):
+                th, m1, m2 = theta_ptrs(j["theta"])
+                w = self._weight_ptr(j["w"])
+                r["w"], r["dtheta"], r["theta"], r["m1"], r["m2"], r["w_out"] = w, grad_ptr(j["theta"]), th, m1, m2, w
+                r["part"], r["H"], r["mode"] = mix_dw_ptr(j), j["H"], 1
+            launches.append(("mix_params",) + (upload(tab, True), len(tab)))
         # the root launch
         root = self.root
         R = len(root["folds"])
@@ -775,6 +829,8 @@ class JobStep:
                 capi.call("ck_jobs_sum64_bwd", la[1][mode].data_ptr(), la[2], pool, opt, la[3], stream)
             elif what == "mix_bwd":
                 capi.call("ck_jobs_mix_bwd", la[1][mode].data_ptr(), la[2], pool, la[3], blk, opt, stream)
+            elif what == "mix_params":
+                capi.call("ck_jobs_mix_params", la[1][mode].data_ptr(), la[2], opt, stream)
             elif what == "gauss_bwd":
                 capi.call("ck_jobs_gauss_bwd", la[2][mode].data_ptr(), la[3], pool, B, opt, stream)
             elif what == "cat_bwd":

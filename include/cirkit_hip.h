@@ -757,6 +757,17 @@ typedef struct ck_sum_job {
   int32_t C;           /* with xrow: the number of categories */
   const int32_t* xrow; /* NULL, or the (B) int32 column of the staged batch: the job's ONE input block is a Categorical fold's (C + 1, 64)
                           table and batch row b reads the table row of its category (the input layer's output is never written) */
+  /* backward through a MIXING fold without a launch of its own (mix_out != NULL): this job's output is one factor of slot
+   * mix_h of a mixing fold with output block mix_out (B, 64) and coefficients mix_w (64, mix_H); the job's gradient list is the
+   * MIXING fold's, and G = (sum of the list) * w[:, h] * exp(x_h - mix_out) with x_h = this job's output (recomputed) + the
+   * n_partner other factors pool[partner_off ..] of the slot.  mix_dw: NULL, or (64, mix_H) floats whose column mix_h receives
+   * d w[:, h] = sum_b G / w[:, h] (one job per slot writes it; ck_jobs_mix_params differentiates the softmax behind w). */
+  const float* mix_out;
+  const float* mix_w;
+  float* mix_dw;
+  int32_t partner_off, n_partner;
+  int32_t mix_h, mix_H;
+  int64_t reserved[3];
 } ck_sum_job;
 int ck_jobs_sum64_fwd(const ck_sum_job* jobs, int n_units, const float* const* pool, void* stream);
 /* waves: 4 or 8 wavefronts per workgroup (a wave takes every waves-th 32-row tile of the unit's rows; 8: one workgroup per CU) */
@@ -783,6 +794,9 @@ typedef struct ck_mix_job {
   int32_t mode, S;
   int64_t reserved1;
 } ck_mix_job;
+/* The parameter step of mixing folds whose backward ran inside their factors' sum jobs (ck_sum_job.mix_out): one workgroup of 64
+ * threads per job; `part` (64, H) holds d w (written by those sum jobs), mode as for ck_sum_job. */
+int ck_jobs_mix_params(const ck_mix_job* jobs, int n_jobs, const ck_opt_state* opt, void* stream);
 int ck_jobs_mix_fwd(const ck_mix_job* jobs, int n_units, const float* const* pool, int h_max, void* stream);
 int ck_jobs_mix_bwd(const ck_mix_job* jobs, int n_units, const float* const* pool, int h_max, int64_t gx_stride,
                     const ck_opt_state* opt, void* stream);

@@ -43,6 +43,8 @@ total = 0.0
 print(f"{'launch':10s} {'units':>6s} {'jobs':>6s} {'split':>5s} {'n_in':>9s} {'n_g':>9s} {'us':>8s}")
 for la in st["launches"]:
     what = la[0]
+    if what == "mix_params":
+        continue
     if what == "root":
         fn = lambda: capi.call("ck_jobs_root", C.byref(st["root"][MODE]), stream)
         desc = (1, 1, 1, "", "")
