@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 40
+ABI_VERSION = 41
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
