@@ -182,3 +182,86 @@ def test_hip_gradients_match_the_reference_gradient_fixture_k64(hip_device, name
         e_got = np.abs(got.reshape(-1)[:32].double().numpy() - head64).max()
         assert e_got <= 4.0 * e_ref + 5e-3 * np.abs(head64).max() + 1e-12, (k, e_got, e_ref, np.abs(head64).max())
     assert checked >= len(plan.tensors) // 2
+
+
+def _dp_jobs_worker(rank, world, port, out_path):
+    import os
+    import sys
+
+    from conftest import ROOT
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from cirkit_amd.distributed import init_from_env, shard_bounds
+    from cirkit_amd.training import HipTrainer
+
+    init_from_env("gloo")  # both ranks share the one GPU of the test box; the exchange goes through gloo
+    plan, tensors, x = _case("quadgraph_cat", 96)
+    lo, hi = shard_bounds(len(x), rank, world)
+    tr = HipTrainer(plan, tensors, device="cuda:0", optimizer="adam", lr=0.01, jobs=True)
+    for _ in range(3):
+        tr.step(x[lo:hi].to("cuda:0"), global_batch=len(x))
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(out_path, **{k: tr.circuit.store[k].cpu().numpy() for k in plan.tensors})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_job_step_data_parallel_equals_single_process(hip_device, tmp_path):
+    """Two ranks, the batch sharded 48 + 48: the job form writes d theta into the flat gradient buffer, ONE all-reduce per step,
+    the trainer's optimizer launch -- after three Adam steps the parameters are those of one process on the whole batch (which
+    runs the optimizer inside the job epilogues)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from cirkit_amd.training import HipTrainer
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp_jobs.npz")
+    mp.spawn(_dp_jobs_worker, args=(2, port, out), nprocs=2, join=True)
+    plan, tensors, x = _case("quadgraph_cat", 96)
+    tr = HipTrainer(plan, tensors, device=hip_device, optimizer="adam", lr=0.01, jobs=True)
+    for _ in range(3):
+        tr.step(x.to(hip_device))
+    torch.cuda.synchronize()
+    ll_one = tr.loss_and_grads(x.to(hip_device)).cpu()
+    with np.load(out) as z:
+        two = {k: z[k] for k in plan.tensors}
+    # Adam normalises every entry's step: entries whose gradient is rounding noise move by +-lr in either run, so the runs are
+    # compared through the likelihood their parameters give, and entry by entry on the tensors that carry the gradient mass
+    tr2 = HipTrainer(plan, two, device=hip_device, optimizer="adam", lr=0.01, jobs=True)
+    ll_two = tr2.loss_and_grads(x.to(hip_device)).cpu()
+    assert abs(float(ll_one[0] - ll_two[0])) <= 2e-5 * abs(float(ll_one[0]))
+    for k in list(plan.tensors)[:3]:
+        a, b = two[k], tr.circuit.store[k].cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-3 * max(1.0, np.abs(b).max()), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["quadgraph_cat", "pd_gauss"])
+def test_job_step_with_marginalised_variables(hip_device, name):
+    """Negative categories / NaN values marginalise a variable (the table's integral row; log 1 for a Gaussian): the job form --
+    sum jobs gathering table rows themselves, Categorical and Gaussian folds as backward jobs -- against the layer-wise trainer."""
+    from cirkit_amd.training import HipTrainer
+
+    plan, tensors, x = _case(name, 100)
+    x = x.clone()
+    if x.is_floating_point():
+        x[::3, ::5] = float("nan")
+    else:
+        x[::3, ::5] = -1
+    a = HipTrainer(plan, tensors, device=hip_device, optimizer="sgd", jobs=False)
+    b = HipTrainer(plan, tensors, device=hip_device, optimizer="sgd", jobs=True)
+    la, lb = a.loss_and_grads(x.to(hip_device)).clone(), b.loss_and_grads(x.to(hip_device)).clone()
+    torch.cuda.synchronize()
+    assert abs(float(la[0] - lb[0])) <= 2e-6 * abs(float(la[0]))
+    for k in list(plan.tensors)[:4]:  # the input layers' parameters and the first sum layers: where the marginalisation acts
+        ga, gb = a.grads[k].double(), b.grads[k].double()
+        assert float((ga - gb).abs().max()) <= 2e-3 * float(ga.abs().max()) + 1e-12, k
