@@ -653,10 +653,41 @@ class HipCircuit:
         finally:
             capi.call("ck_set_workspace", None, 0)
 
+    def _flush_leftover(self, pending: list[int], bd: _Binding, stream: int) -> None:
+        """The dense folds that consumers outside CP blocks still read, of SEVERAL layers, in one `ck_cp_lse_fwd` launch (a
+        launch per layer of one or two folds each was five 10 us launches on BASELINE config 4's critical path): every
+        fold has its own child offset, weight address and output offset, so the launch does not care which layer owns it."""
+        if len(pending) == 1:
+            return self._launch_cp(pending[0], bd, stream)
+        key = ("leftover", tuple(pending))
+        tabs = bd.cp_tabs.get(key)
+        K = self.layers[pending[0]].num_output_units
+        if tabs is None:
+            ros, oos, ws = [], [], []
+            for i in pending:
+                ro, oo = bd.leftover[i]
+                ros.append(ro.reshape(-1))
+                oos.append(oo.reshape(-1))
+                ws.append(torch.from_numpy(self.layers[i]._w.data_ptr() + self._cp_leftover[i].astype(np.int64) * (K * K * 4)).to(self.device))
+            tabs = bd.cp_tabs[key] = (torch.cat(ros).contiguous(), torch.cat(ws).contiguous(), torch.cat(oos).contiguous())
+        ro, tab, oo = tabs
+        capi.call("ck_cp_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), tab.data_ptr(), None, oo.data_ptr(),
+                  bd.arena.data_ptr(), None, None, None, 0, int(ro.numel()), 1, 1, bd.B, K, stream)
+
     def _enqueue_layers_(self, bd: _Binding, stream: int, *, with_ll: bool = False) -> None:
         B = bd.B
+        pending: list[int] = []  # leftover dense folds (`_cp_leftover`) not launched yet: they wait for their first reader
         for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
+            if pending and self._children[i] is not None and set(int(p) for p in np.unique(self._children[i][..., 0])) & set(pending):
+                self._flush_leftover(pending, bd, stream)
+                pending = []
             if self._tail and i in self._tail:
+                if i == self._tail[0]:
+                    if pending:
+                        self._flush_leftover(pending, bd, stream)
+                        pending = []
+                    self._launch_tail(bd, stream, with_ll=with_ll)
+                continue
                 if i == self._tail[0]:
                     self._launch_tail(bd, stream, with_ll=with_ll)
                 continue
@@ -668,6 +699,9 @@ class HipCircuit:
                 self._launch_table_dense(i, bd, stream)
             elif i in self._emb_gather:
                 self._launch_emb_gather(i, bd, stream)
+            elif i in self._cp_leftover and i not in self._cp_blocks and not self._complex and (
+                    not pending or self.layers[pending[0]].num_output_units == l.num_output_units):
+                pending.append(i)  # (launched together with the other leftovers, before the first layer that reads one)
             elif i in self._cp_blocks or i in self._cp_leftover:
                 self._launch_cp(i, bd, stream)
             elif i in self._regions:
@@ -680,6 +714,8 @@ class HipCircuit:
                 l.launch_input(bd.xt if l.wants_float_input else bd.xt_i, self.plan.num_variables, view, B, stream)
             else:
                 l.launch(bd.arena, ro, view, B, stream)
+        if pending:
+            self._flush_leftover(pending, bd, stream)
 
     def _launch_emb_gather(self, i: int, bd: _Binding, stream: int) -> None:
         """`ck_sum_clse_gather_fwd`: a complex CP-T / dense layer reading its Embedding children from the table."""
@@ -1598,6 +1634,9 @@ class HipCircuit:
                 logits = "true" if getattr(l, "_use_logits", False) or (l._logits_ok and l._theta is not None) else "false"
                 return f"tucker_streamk_kernel<{l.num_input_units // 32}, {logits}, {self._ct}, {4 if self._ct else 1}, {2 if self._ct else 3}>"
             return f"tucker_lse_kernel<{l.num_input_units // 32}>"
+        if (not self._complex and s.type in ("sum", "cpt") and not getattr(l, "_mixing", False) and (s.type == "cpt" or l.arity == 1)
+                and l.num_output_units <= 4 and l.num_input_units in (32, 64)):
+            return f"sum_lse_few_outputs_kernel<{l.num_input_units}>"  # (the scalar folds at the top of a circuit)
         return "sum_lse_generic"
 
     def profile_kernels(self, x: torch.Tensor | None, iters: int = 10) -> list[dict]:

@@ -67,6 +67,39 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Few outputs over 32 or 64 product-type inputs (the scalar sum folds at the top of a circuit: TorchCPTLayer with one output
+// unit, optimized.py:171-178): a HALF-wave per batch row when Ki = 32, a wave when Ki = 64, lane = input unit; the row's maximum
+// and every output's dot product are lane reductions, no LDS, no staging.  (These folds used to take the shape-generic kernel:
+// 12 us per launch at BASELINE config 4 for 4 folds x 4096 rows.)
+template <int KI>
+__global__ void __launch_bounds__(256)
+    sum_lse_few_outputs_kernel(const float* __restrict__ arena, const int64_t* __restrict__ row_off, const float* __restrict__ w,
+                               float* __restrict__ out, int H, int B, int Ko) {
+  constexpr int kRowsPerWave = 64 / KI;
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane % KI, sub = lane / KI;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  for (int b0 = (blockIdx.x * 4 + wave) * kRowsPerWave; b0 < B; b0 += gridDim.x * 4 * kRowsPerWave) {
+    const int b = b0 + sub;
+    const bool live = b < B;
+    const int64_t bl = live ? b : B - 1;
+    float v = 0.f;
+    for (int h = 0; h < H; ++h) v += arena[ro[h] + bl * KI + n];
+    float m = v;
+#pragma unroll
+    for (int s2 = 1; s2 < KI; s2 <<= 1) m = fmaxf(m, __shfl_xor(m, s2, 64));
+    m = ck::clamp_finite(m);
+    const float e = __expf(v - m);
+    for (int o = 0; o < Ko; ++o) {
+      float y = w[(static_cast<int64_t>(f) * Ko + o) * KI + n] * e;
+#pragma unroll
+      for (int s2 = 1; s2 < KI; s2 <<= 1) y += __shfl_xor(y, s2, 64);
+      if (live && n == 0) out[(static_cast<int64_t>(f) * B + b) * Ko + o] = __logf(y) + m;
+    }
+  }
+}
+
 // complex-lse-sum, K = 32, real weights (ComplexLSESumSemiring.apply_reduce, semiring.py:441-476, with
 // `cast(weight)` real -> complex, :416-422): exp(z - m) = E_re + i E_im is split into two real 32 x 32
 // register tiles, each goes through the SAME fp32 MFMA chain as the real layer (W . E_re, W . E_im),
@@ -623,6 +656,17 @@ int ck_sum_lse_fwd_v(const float* arena, const int64_t* row_off, const float* w,
                        ck::aligned16(arena) && ck::aligned16(w) && ck::aligned16(out);
   if (mfma_ok) {
     return ck::cp_single_slot(arena, row_off, w, out, F, H, B, Ki, stream);  // ck_cp.hip
+  }
+  if (!g_force_generic && prod_like && Ko <= 4 && (Ki == 32 || Ki == 64)) {
+    const int rows_per_block = 4 * (64 / Ki);
+    dim3 grid(static_cast<unsigned>(std::min((B + rows_per_block - 1) / rows_per_block, 1024)), F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          if (Ki == 32) hipLaunchKernelGGL(sum_lse_few_outputs_kernel<32>, grid, block, 0, s, arena, row_off, w, out, H, B, Ko);
+          else hipLaunchKernelGGL(sum_lse_few_outputs_kernel<64>, grid, block, 0, s, arena, row_off, w, out, H, B, Ko);
+          return hipGetLastError();
+        },
+        stream);
   }
   if (!g_force_generic && mode == CK_SUM_CAT && H > 1 && Ki == Ko && (Ki == 32 || Ki == 64) && ck::aligned16(arena) &&
       ck::aligned16(w) && ck::aligned16(out))
