@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 41
+ABI_VERSION = 42
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -249,6 +249,11 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_log_table_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],
     "ck_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p, _p],
     "ck_sgd_step": [_p, _p, _l, _f, _f, _p, _p],
+    "ck_copy_strided_f32": [_p, _p, _l, _l, _l, _p],
+    "ck_fill_strided_f32": [_p, _l, _l, _f, _p],
+    "ck_embedding_weight_bwd": [_p, _p, _p, _i, _i, _i, _p],
+    "ck_squared_ll": [_p, _l, _l, _p, _p, _p],
+    "ck_embedding_bwd": [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_latch_flag": [_p, _p, _p],
     "ck_jobs_sum64_fwd": [_p, _i, _p, _p],
     "ck_jobs_sum64_bwd": [_p, _i, _p, _p, _i, _p],

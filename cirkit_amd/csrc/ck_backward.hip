@@ -685,17 +685,22 @@ constexpr int kCatChunk = 4096;  // rows sorted at a time
 __global__ void __launch_bounds__(1024)
     categorical_bwd_sorted_kernel(const float* __restrict__ gout, const int32_t* __restrict__ gfold, const int32_t* __restrict__ xt,
                                   const int64_t* __restrict__ scope, float* __restrict__ dtable, int B, int K, int C, int accumulate,
-                                  const int32_t* __restrict__ fold_order) {
-  extern __shared__ __attribute__((aligned(16))) float hist[];  // [C+1][K], then the int arrays below
-  int* start = reinterpret_cast<int*>(hist + (C + 1) * K);      // [C+2] exclusive prefix of the counts
+                                  const int32_t* __restrict__ fold_order, int gs, const float* __restrict__ wtable) {
+  // gs: floats between consecutive gout entries (2: the real parts of complex gradients).  wtable != nullptr (the Embedding
+  // layer under a log, ck_embedding_bwd): the result is d w (F, K, C) = hist / wtable (an entry nobody selected: 0), transposed
+  // through LDS rows of K + 1 floats.
+  const int KS = wtable != nullptr ? K + 1 : K;
+  extern __shared__ __attribute__((aligned(16))) float hist[];  // [C+1][KS], then the int arrays below
+  int* start = reinterpret_cast<int*>(hist + (C + 1) * KS);     // [C+2] exclusive prefix of the counts
   int* cur = start + (C + 2);                                   // [C+1] scatter cursors
   int* order = cur + (C + 1);                                   // [kCatChunk] row numbers grouped by category
   const int f = fold_order != nullptr ? fold_order[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int k_in = lane & 31, slot = lane >> 5;
-  for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) hist[i] = 0.f;
+  for (int i = threadIdx.x; i < (C + 1) * KS; i += blockDim.x) hist[i] = 0.f;
   const int32_t* xrow = xt + scope[f] * static_cast<int64_t>(B);
-  const float* g = gout + static_cast<int64_t>(gfold != nullptr ? gfold[f] : f) * B * K;
+  const float* g = gout + static_cast<int64_t>(gfold != nullptr ? gfold[f] : f) * B * K * gs;
+  const int64_t rs = static_cast<int64_t>(K) * gs;  // floats between rows
   for (int b0 = 0; b0 < B; b0 += kCatChunk) {
     const int nb = min(kCatChunk, B - b0);
     for (int i = threadIdx.x; i < C + 2; i += blockDim.x) start[i] = 0;
@@ -742,22 +747,37 @@ __global__ void __launch_bounds__(1024)
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int i = s0 + slot;
         for (; i + 6 < s1; i += 8) {
-          const float v0 = g[static_cast<int64_t>(order[i]) * K + k];
-          const float v1 = g[static_cast<int64_t>(order[i + 2]) * K + k];
-          const float v2 = g[static_cast<int64_t>(order[i + 4]) * K + k];
-          const float v3 = g[static_cast<int64_t>(order[i + 6]) * K + k];
+          const float v0 = g[order[i] * rs + k * gs];
+          const float v1 = g[order[i + 2] * rs + k * gs];
+          const float v2 = g[order[i + 4] * rs + k * gs];
+          const float v3 = g[order[i + 6] * rs + k * gs];
           a0 += v0;
           a1 += v1;
           a2 += v2;
           a3 += v3;
         }
-        for (; i < s1; i += 2) a0 += g[static_cast<int64_t>(order[i]) * K + k];
+        for (; i < s1; i += 2) a0 += g[order[i] * rs + k * gs];
         float acc = (a0 + a1) + (a2 + a3);
         acc += __shfl_xor(acc, 32, 64);
-        if (slot == 0) hist[c * K + k] += acc;
+        if (slot == 0) hist[c * KS + k] += acc;
       }
     }
     __syncthreads();
+  }
+  if (wtable != nullptr) {
+    const float* t = wtable + static_cast<int64_t>(f) * (C + 1) * K;
+    for (int i = threadIdx.x; i < C * K; i += blockDim.x) {
+      const int c = i / K, k = i - c * K;
+      const float h = hist[c * KS + k];
+      hist[c * KS + k] = h == 0.f ? 0.f : h / t[i];
+    }
+    __syncthreads();
+    float* dst = dtable + static_cast<int64_t>(f) * K * C;
+    for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+      const int k = i / C, c = i - k * C;
+      dst[i] = accumulate ? dst[i] + hist[c * KS + k] : hist[c * KS + k];
+    }
+    return;
   }
   float* dst = dtable + static_cast<int64_t>(f) * (C + 1) * K;
   for (int i = threadIdx.x; i < (C + 1) * K; i += blockDim.x) dst[i] = accumulate ? dst[i] + hist[i] : hist[i];
@@ -1189,6 +1209,47 @@ __global__ void latch_flag_kernel(int32_t* __restrict__ src, int32_t* __restrict
   }
 }
 
+// ---- squared circuits: the pieces of `loss = -mean(2 Re c(x) - Re Z)` that are neither a layer nor a parameter node -------
+// dst[i * dst_stride] = src[i * src_stride] (the real parts of complex values; one column of a table)
+__global__ void __launch_bounds__(256)
+    copy_strided_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int64_t src_stride, int64_t dst_stride) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) dst[i * dst_stride] = src[i * src_stride];
+}
+__global__ void __launch_bounds__(256) fill_strided_kernel(float* __restrict__ p, int64_t n, int64_t stride, float v) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) p[i * stride] = v;
+}
+// d w[f, k, c] = d log|w| / w from the gather table (F, C + 1, K) and the scattered gradient in the same layout (an entry nobody
+// selected has gradient 0 whatever w is): TorchEmbeddingLayer under the log of csafelog (input.py:258-266, utils.py:32-50)
+__global__ void __launch_bounds__(256)
+    embedding_weight_bwd_kernel(const float* __restrict__ table, const float* __restrict__ dtable, float* __restrict__ dw, int C, int K) {
+  const int f = blockIdx.y;
+  const float* t = table + static_cast<int64_t>(f) * (C + 1) * K;
+  const float* d = dtable + static_cast<int64_t>(f) * (C + 1) * K;
+  float* o = dw + static_cast<int64_t>(f) * K * C;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < K * C; i += gridDim.x * 256) {
+    const int k = i / C, c = i - k * C;
+    const float g = d[c * K + k];
+    o[i] = g == 0.f ? 0.f : g / t[c * K + k];
+  }
+}
+// out = [2 sum_b yc[b * stride] - B z[0], B] in fp64 (one workgroup: a deterministic tree, as ck_ll_sum)
+__global__ void __launch_bounds__(1024)
+    squared_ll_kernel(const float* __restrict__ yc, int64_t B, int64_t stride, const float* __restrict__ z, double* __restrict__ out) {
+  __shared__ double part[16];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) acc += static_cast<double>(yc[i * stride]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < static_cast<int>(blockDim.x >> 6); ++i) t += part[i];
+    out[0] = 2.0 * t - static_cast<double>(B) * static_cast<double>(z[0]);
+    out[1] = static_cast<double>(B);
+  }
+}
+
 bool g_bwd_force_generic = false;
 
 unsigned grid1(int64_t n, int cap = 2048) { return static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, cap)); }
@@ -1512,7 +1573,8 @@ int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* x
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_sorted));
             if (e != hipSuccess) return e;
           }
-          hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds_sorted, s, gout, gfold, xt, scope, dtable, B, K, C, accumulate, fold_order);
+          hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds_sorted, s, gout, gfold, xt, scope, dtable, B, K, C, accumulate, fold_order,
+                             1, static_cast<const float*>(nullptr));
           return hipGetLastError();
         },
         stream);
@@ -1527,6 +1589,29 @@ int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* x
           if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(categorical_bwd_kernel, grid, block, lds, s, gout, gfold, xt, scope, dtable, B, K, C, accumulate);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* xt, const int64_t* scope, const float* table, float* dw, int F,
+                     int B, int K, int C, void* stream) {
+  CK_REQUIRE(gout && xt && scope && table && dw, "ck_embedding_bwd: null pointer");
+  CK_REQUIRE(F > 0 && B > 0 && K > 0 && C > 0 && (gout_stride == 1 || gout_stride == 2), "ck_embedding_bwd: bad arguments");
+  const size_t lds = (static_cast<size_t>(C + 1) * (K + 1) + static_cast<size_t>(2) * C + 3 + kCatChunk) * sizeof(float);
+  if (K % 32 != 0 || lds > 160 * 1024)
+    return ck::fail(CK_ERR_UNSUPPORTED, "ck_embedding_bwd: needs K %% 32 == 0 and (C + 1) (K + 1) + 2 C + %d words of LDS (K=%d, C=%d)",
+                    kCatChunk + 3, K, C);
+  dim3 grid(F), block(1024);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (lds > 48 * 1024) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(categorical_bwd_sorted_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(160 * 1024));
+          if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds, s, gout, static_cast<const int32_t*>(nullptr), xt, scope, dw, B, K, C,
+                           0, static_cast<const int32_t*>(nullptr), gout_stride, table);
         return hipGetLastError();
       },
       stream);
@@ -1598,6 +1683,49 @@ int ck_sgd_step(float* p, const float* g, int64_t n, float lr, float grad_scale,
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(sgd_kernel, grid, block, 0, s, p, g, n, lr, grad_scale, skip_flag);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_copy_strided_f32(const float* src, float* dst, int64_t n, int64_t src_stride, int64_t dst_stride, void* stream) {
+  CK_REQUIRE(src && dst && n > 0 && src_stride > 0 && dst_stride > 0, "ck_copy_strided_f32: bad arguments");
+  dim3 grid(grid1(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(copy_strided_kernel, grid, block, 0, s, src, dst, n, src_stride, dst_stride);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_fill_strided_f32(float* p, int64_t n, int64_t stride, float value, void* stream) {
+  CK_REQUIRE(p && n > 0 && stride > 0, "ck_fill_strided_f32: bad arguments");
+  dim3 grid(grid1(n)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(fill_strided_kernel, grid, block, 0, s, p, n, stride, value);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_embedding_weight_bwd(const float* table, const float* dtable, float* dw, int F, int C, int K, void* stream) {
+  CK_REQUIRE(table && dtable && dw && F > 0 && F <= 65535 && C > 0 && K > 0, "ck_embedding_weight_bwd: bad arguments");
+  dim3 grid(static_cast<unsigned>(std::min((K * C + 255) / 256, 64)), F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(embedding_weight_bwd_kernel, grid, block, 0, s, table, dtable, dw, C, K);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_squared_ll(const float* yc, int64_t B, int64_t stride, const float* z, double* out, void* stream) {
+  CK_REQUIRE(yc && z && out && B > 0 && stride > 0, "ck_squared_ll: bad arguments");
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(squared_ll_kernel, dim3(1), dim3(1024), 0, s, yc, B, stride, z, out);
         return hipGetLastError();
       },
       stream);

@@ -447,9 +447,25 @@ class HipParameter:
             return len(fi.ids) == 1 and (fi.kind == IDX_NONE or (
                 fi.kind == IDX_ARRAY and np.array_equal(np.asarray(fi.array).reshape(-1), np.arange(folds[fi.ids[0]]))))
 
+        # how many places read node i (operands of later nodes, the output): a node read ONCE, through an identity index, takes
+        # its reader's gradient buffer as its own -- no zeroed scratch, no add (conj of a real value, flatten, the pointer chains
+        # of a squared circuit's partition function: one launch instead of five per parameter)
+        readers = [0] * len(g.nodes)
+        for j, n in enumerate(g.nodes[: last + 1]):
+            for fi in n.inputs:
+                for i in fi.ids:
+                    readers[i] += 1
+        if upto is None:
+            for i in g.output.ids:
+                readers[i] += 1
+
         def scatter(key, fi: FoldIndex, dgathered: torch.Tensor) -> None:
             """Backward of `_select`: add the rows of `dgathered` into the producers they were gathered from."""
             if is_identity(fi):
+                i = fi.ids[0]
+                if g.nodes[i].op != "tensor" and readers[i] == 1 and i not in gb and dgathered.is_contiguous():
+                    gb[i] = dgathered.view(value(i).shape) if dgathered.numel() == value(i).numel() else dgathered
+                    return
                 t = target(fi.ids[0])
                 if t.data_ptr() != dgathered.data_ptr():
                     capi.call("ck_axpy_f32", _ptr(t), _ptr(dgathered), 1.0, dgathered.numel(), stream)
@@ -475,7 +491,11 @@ class HipParameter:
             """(buffer, accumulate flag, needs scatter) for the gradient of operand k of node j."""
             fi = g.nodes[j].inputs[k]
             if is_identity(fi):
-                return target(fi.ids[0]), 1, False
+                i = fi.ids[0]
+                if g.nodes[i].op != "tensor" and readers[i] == 1 and i not in gb:  # its only gradient: written, not added
+                    gb[i] = self._buf(("grad", i), value(i).shape)
+                    return gb[i], 0, False
+                return target(i), 1, False
             return self._buf(("gop", j, k), operand(j, k).shape), 0, True
 
         if upto is None:

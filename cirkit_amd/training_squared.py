@@ -16,8 +16,9 @@ einsum / flatten graphs over the tensors of c, symbolic/operators.py:39-322; a R
   cirkit_amd/parameters.py);
 * one flat parameter / gradient / moment buffer: one optimizer launch, one all-reduce.
 
-torch appears as storage and for data movement only (real parts, permutations of a handful of small tensors); every arithmetic
-step is a kernel of the C ABI.  Restrictions (checked, `NotImplementedError`): real parameter tensors, every (layer, fold)
+torch appears as storage only: after the forwards of c and Z (two recorded programs each) the backward lists, the
+log-likelihood pair and -- on one rank -- the optimizer with its device clock (`ck_opt_state`) are ONE recorded `ck_program` per
+batch size, replayed as a hipGraph; no tensor-library kernel and no allocation in a step.  Restrictions (checked, `NotImplementedError`): real parameter tensors, every (layer, fold)
 read by exactly one consumer (trees: what `squared_partition_plan` and the region-graph templates give), a scalar output."""
 from __future__ import annotations
 
@@ -36,7 +37,9 @@ from .plan import Plan
 
 
 class _PlanBackward:
-    """The reverse launch list of ONE layer-wise circuit (complex-lse-sum or lse-sum) over the activations of its last forward."""
+    """The reverse launch list of ONE layer-wise circuit (complex-lse-sum or lse-sum) over the activations of its last forward.
+    Every buffer a launch touches is allocated when a batch size is bound, `run` issues calls of the C ABI only: the list can be
+    recorded into a `ck_program` (HipSquaredTrainer does) and holds no tensor-library kernel."""
 
     def __init__(self, circuit: HipCircuit, grads: Mapping[str, torch.Tensor]) -> None:
         self.c, self.grads = circuit, grads
@@ -74,28 +77,85 @@ class _PlanBackward:
         st = self._bound.get(B)
         if st is not None and st["arena_ptr"] == bd.arena.data_ptr():
             return st
+        dev = bd.arena.device
+        cplx = self.cplx
+        e = 2 if cplx else 1  # floats per value
         garena = torch.zeros_like(bd.arena)  # complex64 / fp32, the mirror of the activation arena
         gviews = []
         for i, l in enumerate(self.c.layers):
             off = (bd.views[i].data_ptr() - bd.arena.data_ptr()) // bd.arena.element_size()
             gviews.append(garena[off : off + l.num_folds * B * l.num_output_units].view(l.num_folds, B, l.num_output_units))
-        # host copies of the child offsets (read once: a `.tolist()` per step would be a device synchronisation per layer), the
-        # offset tables in float units for the Hadamard launches, and the row tables of the TensorDot layers' permuted inputs
-        host_ro, ro2, td_rows = {}, {}, {}
+
+        def f32(*shape):
+            return torch.zeros(shape, dtype=torch.float32, device=dev)
+
+        # per layer: the scratch of its backward (gradients of its evaluated parameters, permuted copies, gather tables), the
+        # child offsets on the host (read once: a `.tolist()` per step would be a device synchronisation per layer) and in float units
+        scratch: dict[int, dict] = {}
         for i, l in enumerate(self.c.layers):
-            if bd.row_off[i] is None:
-                continue
+            F, K = l.num_folds, l.num_output_units
+            sc: dict = {}
             if isinstance(l, HipTensorDotLayer):
-                host_ro[i] = bd.row_off[i].reshape(-1).cpu().numpy()
-                n = B * l.num_input_units
-                td_rows[i] = (torch.arange(l.num_folds, dtype=torch.int64, device=garena.device) * n).reshape(l.num_folds, 1)
+                Kj, Kq = l._num_contract_units, l._num_batch_units
+                n = B * Kj * Kq  # (arity 1: one (B, Kj * Kq) block per fold)
+                ro = bd.row_off[i].reshape(-1).cpu().numpy()
+                sc["ro"] = [int(o) for o in ro]
+                sc["packed"] = bool(np.array_equal(ro, ro[0] + n * np.arange(F)))  # the producer's folds in order: one slice
+                sc["rows"] = (torch.arange(F, dtype=torch.int64, device=dev) * n).reshape(F, 1)
+                sc["xp"], sc["gx"] = f32(F * n * e), f32(F * n * e)
+                if not sc["packed"]:
+                    sc["xs"], sc["gxp"] = f32(F * n * e), f32(F * n * e)
+            elif isinstance(l, (HipSumLayer, HipCPTLayer, HipTuckerLayer)):
+                pass  # (d w: a slice of the pool, `_weight_pool`)
             elif isinstance(l, HipHadamardLayer):
-                ro2[i] = (bd.row_off[i] * (2 if self.cplx else 1)).contiguous()
-        st = {"arena_ptr": bd.arena.data_ptr(), "garena": garena, "gviews": gviews, "host_ro": host_ro, "ro2": ro2, "td_rows": td_rows}
+                sc["ro"] = (bd.row_off[i] * e).contiguous()
+            elif isinstance(l, HipCategoricalLayer):
+                sc["dtable"] = f32(F, l.num_categories + 1, K)
+            elif isinstance(l, HipGaussianLayer):
+                sc["dm"], sc["dsd"] = f32(F, K), f32(F, K)
+            elif isinstance(l, HipEmbeddingLayer):
+                sc["dw"] = f32(F, K, l.num_states)
+                words = (l.num_states + 1) * (K + 1) + 2 * l.num_states + 3 + 4096
+                sc["one_launch"] = K % 32 == 0 and words * 4 <= 160 * 1024  # (ck_embedding_bwd's conditions)
+                if not sc["one_launch"]:
+                    sc["dtable"] = f32(F, l.num_states + 1, K)
+                    if cplx:
+                        sc["gr"] = f32(F, B, K)
+            elif isinstance(l, HipConstantValueLayer):
+                if cplx or B > 1:
+                    sc["gsum"] = f32(F, K)
+                if B > 1:
+                    sc["ones"] = torch.ones((F, 1, B), dtype=torch.float32, device=dev)
+                    if cplx:
+                        sc["gr"] = f32(F, B, K)
+                if not l.log_space:
+                    sc["dv"] = f32(F, K)
+            scratch[i] = sc
+        st = {"arena_ptr": bd.arena.data_ptr(), "garena": garena, "gviews": gviews, "scratch": scratch, "pool": None}
         while len(self._bound) >= 4:
             self._bound.pop(next(iter(self._bound)))
         self._bound[B] = st
         return st
+
+    def _weight_pool(self, st: dict) -> torch.Tensor:
+        """The gradients of the evaluated weights of every sum / TensorDot layer as slices of ONE buffer (the kernels add into
+        them with atomics: one fill per step zeroes them all); sized at the first run, when the forward has evaluated the weights."""
+        if st["pool"] is None:
+            shapes, off = {}, 0
+            for i, l in enumerate(self.c.layers):
+                if isinstance(l, HipTensorDotLayer):
+                    shape = (l.num_folds, l.num_output_units // l._num_batch_units, l._num_contract_units)
+                elif isinstance(l, (HipSumLayer, HipCPTLayer, HipTuckerLayer)):
+                    shape = tuple(l._w.shape)
+                else:
+                    continue
+                shapes[i] = (off, shape)
+                off += (int(np.prod(shape)) + 3) // 4 * 4
+            pool = torch.zeros(max(off, 4), dtype=torch.float32, device=st["garena"].device)
+            for i, (o, shape) in shapes.items():
+                st["scratch"][i]["dw"] = pool[o : o + int(np.prod(shape))].view(shape)
+            st["pool"] = pool
+        return st["pool"]
 
     def run(self, B: int, seed_real: float, stream: int) -> None:
         """Gradients of ``seed_real * sum_b Re out_b`` w.r.t. the parameter tensors, ADDED into `grads`."""
@@ -103,102 +163,116 @@ class _PlanBackward:
         bd = c._bind(B)
         st = self._bind(B)
         garena, gviews = st["garena"], st["gviews"]
-        po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
-        gviews[po].zero_()
-        gviews[po][fo] = complex(seed_real, 0.0) if self.cplx else seed_real
-        ga = garena.data_ptr()
         cplx = self.cplx
+        e = 2 if cplx else 1
+        esz = 4 * e
+        po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
+        capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel() * e, 0.0, stream)
+        capi.call("ck_fill_strided_f32", gviews[po][fo].data_ptr(), B, e, float(seed_real), stream)  # (Re = seed, Im = 0)
+        ga, aa = garena.data_ptr(), bd.arena.data_ptr()
+        pool = self._weight_pool(st)
+        capi.call("ck_fill_f32", pool.data_ptr(), pool.numel(), 0.0, stream)
 
         def sum_bwd(arena_ptr, garena_ptr, row_off, w, out_ptr, g_ptr, dw, F, H, rows, Ki, Ko, mode):
+            if w.is_complex():
+                raise NotImplementedError("squared-circuit training: complex-valued weights")
             if cplx:
                 capi.call("ck_sum_lse_bwd_c", arena_ptr, garena_ptr, row_off.data_ptr(), w.data_ptr(), out_ptr, g_ptr, dw.data_ptr(),
-                          F, H, rows, Ki, Ko, mode, 1 if w.is_complex() else 0, stream)
+                          F, H, rows, Ki, Ko, mode, 0, stream)
             else:
                 capi.call("ck_sum_lse_bwd", arena_ptr, garena_ptr, row_off.data_ptr(), None, w.data_ptr(), out_ptr, g_ptr, dw.data_ptr(),
                           F, H, rows, Ki, Ko, mode, 0, stream)
 
-        def real_part(g):
-            return torch.view_as_real(g)[..., 0] if cplx else g
+        def transpose(src_ptr, dst_ptr, R, A, Bd):  # (R, A, Bd) -> (R, Bd, A) values
+            if cplx:
+                capi.call("ck_param_transpose_last2_c", src_ptr, dst_ptr, R, A, Bd, Bd, stream)
+            else:
+                capi.call("ck_param_transpose_last2", src_ptr, dst_ptr, R, A, Bd, 0, Bd, stream)
+
+        def real_part(g, sc):  # (F, B, K) fp32: the real parts of a gradient block
+            if not cplx:
+                return g
+            capi.call("ck_copy_strided_f32", g.data_ptr(), sc["gr"].data_ptr(), g.numel(), 2, 1, stream)
+            return sc["gr"]
 
         for i in range(len(c.layers) - 1, -1, -1):
             l = c.layers[i]
             F, K = l.num_folds, l.num_output_units
             g = gviews[i]
+            sc = st["scratch"][i]
             if isinstance(l, HipTensorDotLayer):
                 Kj, Kq = l._num_contract_units, l._num_batch_units
                 Kk = K // Kq
-                ro = st["host_ro"][i]  # (arity 1: one (B, Kj * Kq) block per fold)
+                ro = sc["ro"]
                 n = B * Kj * Kq
-                packed = bool(np.array_equal(ro, ro[0] + n * np.arange(F)))  # the producer's folds in order: one slice of the arena
-                x = (bd.arena[int(ro[0]) : int(ro[0]) + F * n] if packed else
-                     torch.stack([bd.arena[int(o) : int(o) + n] for o in ro])).view(F, B, Kj, Kq)
-                # the layer IS a dense sum over the rows (b, q) of the permuted input (optimized.py:289-296)
-                xp = x.permute(0, 1, 3, 2).contiguous().view(F, B * Kq, Kj)
-                gx = torch.empty_like(xp)
-                w = l._w
-                if w.is_complex():
-                    raise NotImplementedError("squared-circuit training: complex-valued weights")
-                dw = torch.zeros((F, Kk, Kj), dtype=torch.float32, device=w.device)
-                rows = st["td_rows"][i]
-                sum_bwd(xp.data_ptr(), gx.data_ptr(), rows, w, bd.views[i].data_ptr(), g.data_ptr(), dw, F, 1, B * Kq, Kj, Kk, capi.CK_SUM_PROD)
-                gxp = gx.view(F, B, Kq, Kj).permute(0, 1, 3, 2).contiguous().view(F, n)
-                if packed:
-                    garena[int(ro[0]) : int(ro[0]) + F * n] = gxp.reshape(-1)
+                if sc["packed"]:
+                    x_ptr, gdst = aa + ro[0] * esz, ga + ro[0] * esz
                 else:
                     for f, o in enumerate(ro):
-                        garena[int(o) : int(o) + n] = gxp[f]
-                l.weight.backward(dw, self.grads, stream)
+                        capi.call("ck_copy_strided_f32", aa + o * esz, sc["xs"].data_ptr() + f * n * esz, n * e, 1, 1, stream)
+                    x_ptr, gdst = sc["xs"].data_ptr(), sc["gxp"].data_ptr()
+                # the layer IS a dense sum over the rows (b, q) of the permuted input (optimized.py:289-296)
+                transpose(x_ptr, sc["xp"].data_ptr(), F * B, Kj, Kq)
+                sum_bwd(sc["xp"].data_ptr(), sc["gx"].data_ptr(), sc["rows"], l._w, bd.views[i].data_ptr(), g.data_ptr(), sc["dw"],
+                        F, 1, B * Kq, Kj, Kk, capi.CK_SUM_PROD)
+                transpose(sc["gx"].data_ptr(), gdst, F * B, Kq, Kj)
+                if not sc["packed"]:
+                    for f, o in enumerate(ro):
+                        capi.call("ck_copy_strided_f32", gdst + f * n * esz, ga + o * esz, n * e, 1, 1, stream)
+                l.weight.backward(sc["dw"], self.grads, stream)
             elif isinstance(l, (HipSumLayer, HipCPTLayer, HipTuckerLayer)):
                 w = l._w
-                if w.is_complex():
-                    raise NotImplementedError("squared-circuit training: complex-valued weights")
-                dw = torch.zeros_like(w)
-                sum_bwd(bd.arena.data_ptr(), ga, bd.row_off[i], w, bd.views[i].data_ptr(), g.data_ptr(), dw, F, l.arity, B, l.num_input_units, K,
-                        l._mode)
-                l.weight.backward(dw, self.grads, stream)
+                sum_bwd(aa, ga, bd.row_off[i], w, bd.views[i].data_ptr(), g.data_ptr(), sc["dw"], F, l.arity, B, l.num_input_units, K, l._mode)
+                l.weight.backward(sc["dw"], self.grads, stream)
             elif isinstance(l, HipHadamardLayer):  # log space: the sum of the children -- (re, im) pairs as 2 K floats
-                e = 2 if cplx else 1
-                capi.call("ck_hadamard_bwd", ga, st["ro2"][i].data_ptr(), g.data_ptr(), F, l.arity, B, e * K, 0, stream)
+                capi.call("ck_hadamard_bwd", ga, sc["ro"].data_ptr(), g.data_ptr(), F, l.arity, B, e * K, 0, stream)
             elif isinstance(l, HipCategoricalLayer):  # (lse-sum) the scatter-add into the log-table, then log softmax backward
                 Cn = l.num_categories
-                dtable = torch.zeros((F, Cn + 1, K), dtype=torch.float32, device=g.device)
+                dtable = sc["dtable"]
                 capi.call("ck_categorical_bwd", g.data_ptr(), None, bd.xt_i.data_ptr(), l._scope(g.device).data_ptr(), dtable.data_ptr(),
-                          F, B, K, Cn, 1, None, stream)
+                          F, B, K, Cn, 0, None, stream)
                 name = l.probs.graph.nodes[0].config["tensor"]
                 capi.call("ck_param_log_table_bwd", l._table.data_ptr(), dtable.data_ptr(), self.grads[name].data_ptr(), F, K, Cn, 1, stream)
             elif isinstance(l, HipGaussianLayer):  # (lse-sum) batch sums of d log N / d mean, d log N / d stddev
                 mean, stddev, _ = l._vals
-                dm, dsd = torch.empty_like(mean), torch.empty_like(stddev)
                 capi.call("ck_gaussian_bwd", g.data_ptr(), bd.xt.data_ptr(), l._scope(g.device).data_ptr(), mean.data_ptr(), stddev.data_ptr(),
-                          dm.data_ptr(), dsd.data_ptr(), F, B, K, stream)
-                l.mean.backward(dm, self.grads, stream)
-                l.stddev.backward(dsd, self.grads, stream)
+                          sc["dm"].data_ptr(), sc["dsd"].data_ptr(), F, B, K, stream)
+                l.mean.backward(sc["dm"].view(mean.shape), self.grads, stream)
+                l.stddev.backward(sc["dsd"].view(stddev.shape), self.grads, stream)
             elif isinstance(l, HipEmbeddingLayer):
                 # out = log(w[f, :, x]): the scatter-add of Re(gout) over the batch, divided by w
                 Cn = l.num_states
                 if l._table.is_complex():
                     raise NotImplementedError("squared-circuit training: complex Embedding weights (the layer-level autograd of "
                                               "cirkit_amd.layer_ops.embedding differentiates them)")
-                gr = real_part(g).contiguous()
-                dtable = torch.zeros((F, Cn + 1, K), dtype=torch.float32, device=gr.device)
-                capi.call("ck_categorical_bwd", gr.data_ptr(), None, bd.xt_i.data_ptr(), l._scope(gr.device).data_ptr(), dtable.data_ptr(),
-                          F, B, K, Cn, 1, None, stream)
-                wt = l._table[:, :Cn].contiguous()  # (F, C, K): the weight, transposed like every gather table
-                num = dtable[:, :Cn].contiguous()
-                dwt = torch.empty_like(num)
-                capi.call("ck_param_unary_bwd", capi.CK_UNARY_LOG, wt.data_ptr(), wt.data_ptr(), num.data_ptr(), dwt.data_ptr(), num.numel(), 0, stream)
-                l.weight.backward(dwt.transpose(1, 2).contiguous(), self.grads, stream)
+                if sc["one_launch"]:
+                    capi.call("ck_embedding_bwd", g.data_ptr(), e, bd.xt_i.data_ptr(), l._scope(g.device).data_ptr(), l._table.data_ptr(),
+                              sc["dw"].data_ptr(), F, B, K, Cn, stream)
+                else:
+                    gr = real_part(g, sc)
+                    capi.call("ck_categorical_bwd", gr.data_ptr(), None, bd.xt_i.data_ptr(), l._scope(gr.device).data_ptr(),
+                              sc["dtable"].data_ptr(), F, B, K, Cn, 0, None, stream)
+                    capi.call("ck_embedding_weight_bwd", l._table.data_ptr(), sc["dtable"].data_ptr(), sc["dw"].data_ptr(), F, Cn, K, stream)
+                l.weight.backward(sc["dw"], self.grads, stream)
             elif isinstance(l, HipConstantValueLayer):
                 v = l._val
                 if v.is_complex():
                     raise NotImplementedError("squared-circuit training: complex constant values")
-                gr = real_part(g)
-                gsum = (gr[:, 0] if B == 1 else gr.sum(dim=1)).contiguous()  # (F, K)
+                if B == 1:
+                    if cplx:
+                        capi.call("ck_copy_strided_f32", g.data_ptr(), sc["gsum"].data_ptr(), F * K, 2, 1, stream)
+                        gsum = sc["gsum"]
+                    else:
+                        gsum = g.view(F, K)
+                else:  # the batch sum as a product with a row of ones
+                    gr = real_part(g, sc)
+                    gsum = sc["gsum"]
+                    capi.call("ck_param_bmm", sc["ones"].data_ptr(), gr.data_ptr(), gsum.data_ptr(), F, 1, K, B, 0, 0, stream)
                 if l.log_space:
                     dv = gsum
                 else:
-                    dv = torch.empty_like(gsum)
-                    capi.call("ck_param_unary_bwd", capi.CK_UNARY_LOG, v.data_ptr(), v.data_ptr(), gsum.data_ptr(), dv.data_ptr(), gsum.numel(), 0, stream)
+                    dv = sc["dv"]
+                    capi.call("ck_param_unary_bwd", capi.CK_UNARY_LOG, v.data_ptr(), v.data_ptr(), gsum.data_ptr(), dv.data_ptr(), F * K, 0, stream)
                 l.value.backward(dv.view(v.shape), self.grads, stream)
             else:  # (checked in __init__)
                 raise NotImplementedError(type(l).__name__)
@@ -210,7 +284,8 @@ class HipSquaredTrainer:
     from the plan of c)."""
 
     def __init__(self, plan_c: Plan, tensors: Mapping[str, object], *, plan_z: Plan | None = None, device: str | torch.device = "cuda:0",
-                 lr: float = 0.01, optimizer: str = "adam", betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8) -> None:
+                 lr: float = 0.01, optimizer: str = "adam", betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 use_graph: bool = True) -> None:
         if plan_c.semiring not in ("complex-lse-sum", "lse-sum"):
             raise NotImplementedError(f"HipSquaredTrainer: semiring {plan_c.semiring!r}")
         if optimizer not in ("adam", "sgd"):
@@ -248,35 +323,133 @@ class HipSquaredTrainer:
         for n, sz in zip(names, sizes):
             self.grads[n] = self._flat_grad[off : off + sz].view(plan_c.tensors[n][0])
             off += sz
-        self._bwd_c, self._bwd_z = _PlanBackward(self.c, self.grads), _PlanBackward(self.z, self.grads)
+        # Z's launches run beside c's on a second stream: their gradients go to a buffer of their own, added before the optimizer
+        self._flat_grad_z = torch.zeros_like(self._flat_grad)
+        grads_z, off = {}, 0
+        for n, sz in zip(names, sizes):
+            grads_z[n] = self._flat_grad_z[off : off + sz].view(plan_c.tensors[n][0])
+            off += sz
+        self._bwd_c, self._bwd_z = _PlanBackward(self.c, self.grads), _PlanBackward(self.z, grads_z)
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self._m1 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
         self._m2 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
-        self._skipped = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._bad_seen = torch.zeros(1, dtype=torch.int32, device=self.device)  # latched by `step`, reported by `check_inputs`
-        self.step_count = 0
+        self._ll = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self._opt: torch.Tensor | None = None  # the DEVICE ck_opt_state: constants, clock, dropped steps
+        self._opt_key = None
+        self.use_graph = bool(use_graph)
+        self._programs: dict[tuple, tuple] = {}
+        self._side: tuple[torch.cuda.Stream, torch.cuda.Stream] | None = None
+
+    def __del__(self):
+        try:
+            for pr, _ in self._programs.values():
+                capi.load().ck_program_destroy(pr)
+        except Exception:
+            pass
+
+    # -- the recorded step ----------------------------------------------------------------------------------------------
+    def _opt_state(self) -> torch.Tensor:
+        key = (float(self.lr), tuple(float(b) for b in self.betas), float(self.eps))
+        if self._opt is None:
+            o = capi.OptState()
+            o.lr, o.b1, o.b2, o.eps, o.bc1, o.bc2 = self.lr, self.betas[0], self.betas[1], self.eps, 1.0, 1.0
+            o.step, o.skipped, o.skip_now, o.kind = 0, 0, 0, 1 if self.optimizer == "adam" else 0
+            self._opt = torch.frombuffer(bytearray(bytes(o)), dtype=torch.uint8).to(self.device)
+        elif key != self._opt_key:  # (the learning rate was changed between steps: the first 16 bytes)
+            head = torch.tensor([self.lr, self.betas[0], self.betas[1], self.eps], dtype=torch.float32).view(torch.uint8)
+            self._opt[:16].copy_(head.to(self.device))
+        self._opt_key = key
+        return self._opt
+
+    def _enqueue_optimizer(self, stream: int) -> None:
+        p = self._flat_param
+        capi.call("ck_opt_step_range", p.data_ptr(), self._flat_grad.data_ptr(), None if self._m1 is None else self._m1.data_ptr(),
+                  None if self._m2 is None else self._m2.data_ptr(), p.numel(), self._opt_state().data_ptr(), stream)
+
+    def _enqueue(self, part: str, B: int, gB: float, with_optimizer: bool, stream: int) -> None:
+        n = self._flat_grad.numel()
+        if part == "c":
+            capi.call("ck_fill_f32", self._flat_grad.data_ptr(), n, 0.0, stream)
+            self._bwd_c.run(B, -2.0 / gB, stream)
+        elif part == "z":
+            capi.call("ck_fill_f32", self._flat_grad_z.data_ptr(), n, 0.0, stream)
+            self._bwd_z.run(1, B / gB, stream)
+        else:  # both gradients are there: the sum, the log-likelihood pair, the optimizer
+            c, z = self.c, self.z
+            validate = c.validate_inputs and c._int_input
+            if with_optimizer:  # the clock first: a batch with an illegal category drops the step (skip_now)
+                capi.call("ck_opt_tick", self._opt_state().data_ptr(), c._bad_input.data_ptr() if validate else None,
+                          self._bad_seen.data_ptr() if validate else None, stream)
+            capi.call("ck_axpy_f32", self._flat_grad.data_ptr(), self._flat_grad_z.data_ptr(), 1.0, n, stream)
+            yc = c._bind(B).views[int(c._out_pairs[0, 0])][int(c._out_pairs[0, 1])]
+            yz = z._bind(1).views[int(z._out_pairs[0, 0])][int(z._out_pairs[0, 1])]
+            capi.call("ck_squared_ll", yc.data_ptr(), B, 2 if yc.is_complex() else 1, yz.data_ptr(), self._ll.data_ptr(), stream)
+            if with_optimizer:
+                self._enqueue_optimizer(stream)
+
+    def _part(self, part: str, B: int, gB: float, with_optimizer: bool, run: torch.cuda.Stream) -> None:
+        """One of the three recorded launch lists of a step -- "c": the backward of c; "z": the backward of Z; "end": the sum of
+        the two gradients, the log-likelihood pair and (alone) the optimizer -- per (batch size, global batch): the first two
+        calls run eagerly (they size the scratch of the parameter graphs), the third records, later ones replay (as a hipGraph
+        when `use_graph`)."""
+        key = (part, B, float(gB), bool(with_optimizer), self.c._bind(B).arena.data_ptr(), self.z._bind(1).arena.data_ptr())
+        prog, seen = self._programs.get(key, (None, 0))
+        if prog is None:
+            if seen < 2:
+                self._enqueue(part, B, gB, with_optimizer, run.cuda_stream)
+                self._programs[key] = (None, seen + 1)
+                return
+            for k in [k for k in self._programs if k[:4] == key[:4] and k != key]:  # (rebound arenas: their lists are stale)
+                if self._programs[k][0] is not None:
+                    capi.load().ck_program_destroy(self._programs[k][0])
+                del self._programs[k]
+            prog = C.c_void_p()
+            capi.call("ck_program_begin", C.byref(prog))
+            try:
+                self._enqueue(part, B, gB, with_optimizer, run.cuda_stream)
+            finally:
+                capi.call("ck_program_end", prog)
+            self._programs[key] = (prog, seen)
+        capi.call("ck_program_launch", prog, 1 if self.use_graph else 0, run.cuda_stream)
+
+    def _launch(self, x: torch.Tensor, B: int, gB: float, with_optimizer: bool) -> None:
+        """Forward and backward of c on the caller's stream, forward and backward of Z (a few hundred launches on one row: they
+        fill a fraction of the chip) on a second stream beside it, then the end of the step."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+        main = self._side[0] if (self.use_graph and cur.cuda_stream == 0) else cur  # (a capture cannot run on the legacy stream)
+        side = self._side[1]
+        if main is not cur:
+            main.wait_stream(cur)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self.z._run(None)  # (1, 1, 1)
+            self._part("z", B, gB, with_optimizer, side)
+        with torch.cuda.stream(main):
+            self.c._run(x)     # (B, 1, 1) complex64 / fp32 in c's arena
+            self._part("c", B, gB, with_optimizer, main)
+            main.wait_stream(side)
+            self._part("end", B, gB, with_optimizer, main)
+        if main is not cur:
+            cur.wait_stream(main)
+
+    def _global_batch(self, B: int, global_batch: int | None) -> float:
+        import torch.distributed as dist
+
+        if global_batch is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            global_batch = B * dist.get_world_size()
+        return float(global_batch or B)
 
     def loss_and_grads(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
         """Forward of c on the batch and of Z, then both backward launch lists: the gradients of
         ``-(1 / global_batch) sum_b (2 Re c(x_b)) + (B / global_batch) Re Z`` land in `self.grads`; returns the device tensor
-        ``[sum_b 2 Re c(x_b) - B Re Z, B]`` (the shard's summed log-likelihood and its rows)."""
-        import torch.distributed as dist
-
+        ``[sum_b 2 Re c(x_b) - B Re Z, B]`` (the shard's summed log-likelihood and its rows; fp64, rewritten by the next call)."""
         with torch.cuda.device(self.device):
             B = int(x.shape[0])
-            if global_batch is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                global_batch = B * dist.get_world_size()
-            gB = float(global_batch or B)
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            yc = self.c(x)          # (B, 1, 1) complex64 / fp32
-            yz = self.z()           # (1, 1, 1)
-            if not yc.is_complex():
-                yc, yz = torch.complex(yc, torch.zeros_like(yc)), torch.complex(yz, torch.zeros_like(yz))
-            capi.call("ck_fill_f32", self._flat_grad.data_ptr(), self._flat_grad.numel(), 0.0, stream)
-            self._bwd_c.run(B, -2.0 / gB, stream)
-            self._bwd_z.run(1, B / gB, stream)
-            ll = 2.0 * yc.real.sum(dtype=torch.float64) - B * yz.real.reshape(()).to(torch.float64)
-            return torch.stack([ll, torch.tensor(float(B), dtype=torch.float64, device=self.device)])
+            self._launch(x, B, self._global_batch(B, global_batch), False)
+            return self._ll
 
     def all_reduce_grads(self) -> None:
         import torch.distributed as dist
@@ -286,45 +459,56 @@ class HipSquaredTrainer:
 
     def apply_gradients(self, skip_flag: torch.Tensor | None = None) -> None:
         """The optimizer step on `self.grads`.  `skip_flag`: a device int32; nonzero at launch time = the step changes nothing
-        (parameters, moments, Adam's step count)."""
+        (parameters, moments, Adam's step count), the flag is latched into what `check_inputs()` reports and cleared."""
         with torch.cuda.device(self.device):
-            self.step_count += 1
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            p, g = self._flat_param, self._flat_grad
-            skip = None if skip_flag is None else skip_flag.data_ptr()
-            if self.optimizer == "adam":
-                capi.call("ck_adam_step", p.data_ptr(), g.data_ptr(), self._m1.data_ptr(), self._m2.data_ptr(), p.numel(), self.lr,
-                          self.betas[0], self.betas[1], self.eps, self.step_count, 1.0, skip, self._skipped.data_ptr(), stream)
-            else:
-                capi.call("ck_sgd_step", p.data_ptr(), g.data_ptr(), p.numel(), self.lr, 1.0, skip, stream)
+            capi.call("ck_opt_tick", self._opt_state().data_ptr(), None if skip_flag is None else skip_flag.data_ptr(),
+                      None if skip_flag is None else self._bad_seen.data_ptr(), stream)
+            self._enqueue_optimizer(stream)
             self.store.touch()
 
     def step(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
         """One optimisation step.  A batch with an out-of-range category (an ``IndexError`` in the reference, NaN outputs here)
-        must not reach the parameters, exactly as in `HipTrainer.step`: alone, the optimizer launch changes nothing while the
-        circuit's flag is up; with several ranks this rank's gradients are zeroed before the all-reduce (every rank takes the
-        same step).  The flag is then latched into what `check_inputs()` reports and cleared -- no host synchronisation."""
+        must not reach the parameters, exactly as in `HipTrainer.step`: alone, the optimizer's clock (`ck_opt_tick`) moves the
+        circuit's flag into the step's skip state and the update changes nothing; with several ranks this rank's gradients are
+        zeroed before the all-reduce (every rank takes the same step).  The flag is latched into what `check_inputs()` reports
+        and cleared -- no host synchronisation, and alone everything after the two forwards is one replayed launch list."""
         import torch.distributed as dist
 
-        ll = self.loss_and_grads(x, global_batch=global_batch)
         c = self.c
         validate = c.validate_inputs and c._int_input
         alone = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        if validate and not alone:
-            with torch.cuda.device(self.device):
-                capi.call("ck_zero_if_flag", self._flat_grad.data_ptr(), self._flat_grad.numel(), c._bad_input.data_ptr(),
-                          torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            B = int(x.shape[0])
+            self._launch(x, B, self._global_batch(B, global_batch), alone)
+            if alone:
+                self.store.touch()
+                return self._ll
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            if validate:
+                capi.call("ck_zero_if_flag", self._flat_grad.data_ptr(), self._flat_grad.numel(), c._bad_input.data_ptr(), stream)
         self.all_reduce_grads()
-        self.apply_gradients(c._bad_input if (validate and alone) else None)
+        self.apply_gradients(None)
         if validate:
             with torch.cuda.device(self.device):
                 capi.call("ck_latch_flag", c._bad_input.data_ptr(), self._bad_seen.data_ptr(),
                           torch.cuda.current_stream(self.device).cuda_stream)
-        return ll
+        return self._ll
+
+    def opt_counters(self) -> tuple[int, int]:
+        """(steps taken, steps dropped) of the optimizer's device clock (a device read)."""
+        if self._opt is None:
+            return 0, 0
+        v = self._opt[24:32].cpu().view(torch.int32)
+        return int(v[0]), int(v[1])
+
+    @property
+    def step_count(self) -> int:
+        return self.opt_counters()[0]
 
     @property
     def skipped_steps(self) -> int:
-        return int(self._skipped.item())
+        return self.opt_counters()[1]
 
     def check_inputs(self) -> None:
         """Raise ``IndexError`` if a batch since the last check held a category out of range (layers/input.py:258-266,

@@ -710,6 +710,20 @@ int ck_adam_step(float* p, const float* g, float* m1, float* m2, int64_t n, floa
                  float beta2, float eps, int step, float grad_scale, const int32_t* skip_flag, int32_t* skipped,
                  void* stream);
 int ck_sgd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, const int32_t* skip_flag, void* stream);
+/* Pieces of the squared-circuit loss -mean(2 Re c(x) - Re Z) (symbolic/functional.py:161,259,594 + the reference's training
+ * loop) that are neither a layer nor a parameter node, so that a step needs no tensor-library arithmetic:
+ * dst[i dst_stride] = src[i src_stride] (real parts of complex values); p[i stride] = value (the seed Re = v, Im = 0);
+ * d w (F, K, C) = dtable / table on the gather-table layout (F, C + 1, K) (TorchEmbeddingLayer under the complex log,
+ * input.py:258-266, utils.py:32-50; an entry nobody selected gets 0); out = [2 sum_b yc[b stride] - B z[0], B] in fp64. */
+int ck_copy_strided_f32(const float* src, float* dst, int64_t n, int64_t src_stride, int64_t dst_stride, void* stream);
+int ck_fill_strided_f32(float* p, int64_t n, int64_t stride, float value, void* stream);
+int ck_embedding_weight_bwd(const float* table, const float* dtable, float* dw, int F, int C, int K, void* stream);
+int ck_squared_ll(const float* yc, int64_t B, int64_t stride, const float* z, double* out, void* stream);
+/* The whole backward of an Embedding layer under a logarithm in one launch (K % 32 == 0, (C + 1)(K + 1) + 2 C + 4099 words of
+ * LDS; CK_ERR_UNSUPPORTED otherwise): d w[f, k, c] = (sum over the rows b with x[b, scope[f]] = c of gout[f, b, k]) / table[f, c, k],
+ * 0 where nobody selected c.  gout_stride: floats between consecutive entries of gout (2: the real parts of a complex64 block). */
+int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* xt, const int64_t* scope, const float* table, float* dw, int F,
+                     int B, int K, int C, void* stream);
 /* *dst |= *src; *src = 0 (DEVICE int32 flags): turns a per-step validation flag into a sticky one. */
 int ck_latch_flag(int32_t* src, int32_t* dst, void* stream);
 /* ck_fill_f32 that also hands a validation flag on: *step_flag = *src; if it is nonzero, *sticky |= *src and *src = 0
