@@ -1,0 +1,323 @@
+// Signed-log sum layers (K = 32): the training path of squared circuits with REAL parameters.
+//
+// A circuit compiled under complex-lse-sum whose parameters are all real -- Embedding inputs, CP-T / sum layers with real
+// weights: the c(x) of a squared circuit, BASELINE config 5 -- is real-valued: the reference carries every value as
+// (log|v|, 0 or pi) (ComplexLSESumSemiring, semiring.py:441-476; csafelog, utils.py:32-50; TorchEmbeddingLayer.forward,
+// layers/input.py:258-266; TorchCPTLayer.forward, optimized.py:171-178).  Here a value is an fp32 log|v| plus ONE BIT: blocks
+// are (rows, 32) fp32 with one sign word per row (bit k set: unit k is negative) -- 4.1 bytes per value instead of 8, one MFMA
+// contraction per step instead of two, and the gradient of a loss that reads log|c(x)| (the squared circuit's
+// 2 Re c(x) - Re Z) is real.  With x_j = s_j exp(v_j) the product of the children, a_j = x_j exp(-m), y = W a:
+//     out_o = log|y_o| + m, sign y_o        t_o = G_o exp(m) / y_o        g v_j = a_j (W^T t)_j        dW = t^T a
+// -- the three contractions of the real backward (ck_bwd_tile.h) on signed operands.  Children that are folds of an
+// Embedding layer are read from its weight table (F0, C + 1, 32) by the batch values (the layer's output is never stored);
+// their gradient blocks are (B, 32) fp32, what ck_embedding_bwd scatters.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "ck_bwd_tile.h"
+#include "ck_internal.h"
+#include "ck_tile.h"
+
+namespace {
+
+// the 16 values lane (b, kh) holds of a row: units 8 g + 4 kh + t in register 4 g + t
+__device__ __forceinline__ void load16(const float* __restrict__ row, int kh, float (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 x = *reinterpret_cast<const float4*>(row + 8 * g + 4 * kh);
+    v[4 * g + 0] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
+  }
+}
+__device__ __forceinline__ bool bit_of(uint32_t word, int j, int kh) { return (word >> (8 * (j >> 2) + 4 * kh + (j & 3))) & 1u; }
+
+struct Gather {
+  const float* table;         // (F0, C + 1, 32) REAL Embedding weights, row C the integral row; nullptr: children in the arena
+  const int32_t* child_fold;  // (F, H) Embedding fold of each child
+  const int32_t* child_var;   // (F, H) its variable
+  const int32_t* xt;          // (D, B) staged batch
+  int C;
+};
+
+// v <- sum over the children of log|x_h|, sign <- the product of their signs (a word; bits of all 32 units)
+__device__ __forceinline__ uint32_t load_children(const float* __restrict__ arena, const uint32_t* __restrict__ signs,
+                                                  const int64_t* __restrict__ ro, const Gather& ga, int f, int H, int B, int64_t bl, int kh,
+                                                  float (&v)[16]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = 0.f;
+  uint32_t sw = 0;
+  for (int h = 0; h < H; ++h) {
+    float x[16];
+    if (ga.table != nullptr) {
+      const int64_t e = static_cast<int64_t>(f) * H + h;
+      const int xv = ga.xt[static_cast<int64_t>(ga.child_var[e]) * B + bl];
+      const int c = xv < 0 ? ga.C : min(xv, ga.C - 1);
+      load16(ga.table + (static_cast<int64_t>(ga.child_fold[e]) * (ga.C + 1) + c) * 32, kh, x);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        sw ^= (x[j] < 0.f ? 1u : 0u) << (8 * (j >> 2) + 4 * kh + (j & 3));
+        v[j] += logf(fabsf(x[j]));
+      }
+    } else {
+      load16(arena + ro[h] + bl * 32, kh, x);
+      sw ^= signs[(ro[h] >> 5) + bl];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] += x[j];
+    }
+  }
+  if (ga.table != nullptr) sw |= __shfl_xor(sw, 32, 64);  // (each half built the bits of its own units)
+  return sw;
+}
+
+__global__ void __launch_bounds__(256)
+    slse_tile32_fwd(const float* __restrict__ arena, const uint32_t* __restrict__ signs, const int64_t* __restrict__ row_off,
+                    const float* __restrict__ w, float* __restrict__ out, uint32_t* __restrict__ sout, int H, int B, int tiles_per_wave,
+                    Gather ga) {
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  WRegs wr;
+  load_w<CK_W_ROWMAJOR>(w + static_cast<int64_t>(f) * kK * kK, lane, wr);
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+  for (int tt = 0; tt < tiles_per_wave; ++tt) {
+    const int b0 = (tile0 + tt) * 32;
+    if (b0 >= B) break;
+    const int b = b0 + b_in;
+    const bool live = b < B;
+    const int64_t bl = live ? b : B - 1;
+    float v[16];
+    const uint32_t sw = load_children(arena, signs, ro, ga, f, H, B, bl, kh, v);
+    const float m = row_max16(v);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float e = expf(v[j] - m);
+      v[j] = bit_of(sw, j, kh) ? -e : e;
+    }
+    contract_linear<CK_W_ROWMAJOR>(wr, v);
+    uint32_t so = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      so |= (v[j] < 0.f ? 1u : 0u) << (8 * (j >> 2) + 4 * kh + (j & 3));
+      v[j] = logf(fabsf(v[j])) + m;
+    }
+    so |= __shfl_xor(so, 32, 64);
+    if (live) {
+      float* dst = out + (static_cast<int64_t>(f) * B + b) * kK + 4 * kh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+      if (kh == 0) sout[static_cast<int64_t>(f) * B + b] = so;
+    }
+  }
+}
+
+// Four waves walk the row tiles of one fold with dW in registers; one float atomic per weight entry and workgroup at the end
+// (the skeleton of sum_clse_bwd_tile32, ck_backward_c.hip, with half its contractions).
+__global__ void __launch_bounds__(256)
+    slse_tile32_bwd(const float* __restrict__ arena, const uint32_t* __restrict__ signs, float* __restrict__ garena,
+                    const int64_t* __restrict__ row_off, const float* __restrict__ w, const float* __restrict__ out,
+                    const uint32_t* __restrict__ sout, const float* __restrict__ gout, float* __restrict__ dw, int H, int B, Gather ga) {
+  __shared__ __attribute__((aligned(16))) float wt_s[1024];        // W^T, "transposed tiled" (child_gradient)
+  __shared__ __attribute__((aligned(16))) float scr_s[4][2][1024];  // per wave: the two operands of dw_accumulate
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b_in = lane & 31, kh = lane >> 5;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const float* wf = w + static_cast<int64_t>(f) * 1024;
+  for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    const int q = idx >> 8, ln = (idx >> 2) & 63, t = idx & 3;
+    wt_s[idx] = wf[(8 * q + 4 * (ln >> 5) + t) * 32 + (ln & 31)];
+  }
+  __syncthreads();
+  f32x16 dacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+  const int tiles = (B + 31) / 32;
+  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    const int b = tile * 32 + b_in;
+    const bool live = b < B;
+    const int64_t bl = live ? b : B - 1;
+    float a[16];
+    const uint32_t sw = load_children(arena, signs, ro, ga, f, H, B, bl, kh, a);
+    const float m = row_max16(a);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float e = expf(a[j] - m);
+      a[j] = bit_of(sw, j, kh) ? -e : e;
+    }
+    float t[16];
+    {
+      float y[16], g[16];
+      load16(out + (static_cast<int64_t>(f) * B + bl) * 32, kh, y);
+      load16(gout + (static_cast<int64_t>(f) * B + bl) * 32, kh, g);
+      const uint32_t so = sout[static_cast<int64_t>(f) * B + bl];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        // exp(m) / y_o = sign exp(m - out_o); an output without gradient contributes nothing (also where out = -inf)
+        const float r = expf(m - y[j]) * g[j];
+        t[j] = (live && g[j] != 0.f) ? (bit_of(so, j, kh) ? -r : r) : 0.f;
+      }
+    }
+    float gv[16];
+    child_gradient(wt_s, lane, t, a, gv);
+    if (live) {
+      for (int h = 0; h < H; ++h) {
+        float* dst = garena + ro[h] + bl * 32 + 4 * kh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]);
+      }
+    }
+    dw_accumulate(dacc, scr_s[wave][0], scr_s[wave][1], b_in, kh, t, a);
+  }
+  // D[o][i] sits in lane (i, hi) register r with o = 8 (r >> 2) + 4 hi + (r & 3): the four waves' sums through LDS
+  __syncthreads();
+  float* red = &scr_s[0][0][0];  // [4][1024]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + (8 * (r >> 2) + 4 * kh + (r & 3)) * 32 + b_in] = dacc[r];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    const float v = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+    if (v != 0.f) atomicAdd(dw + static_cast<int64_t>(f) * 1024 + idx, v);
+  }
+}
+
+// Few outputs (Ko <= 4: the scalar sum fold at the top of the circuit) over 32 product-type inputs: a half-wave per batch row,
+// lane = input unit, the dot products are lane reductions.  BWD: also the children's gradient and dW (registers over the rows
+// a half-wave walks, float atomics at the end).
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+    slse_few_kernel(const float* __restrict__ arena, const uint32_t* __restrict__ signs, float* __restrict__ garena,
+                    const int64_t* __restrict__ row_off, const float* __restrict__ w, float* __restrict__ out, uint32_t* __restrict__ sout,
+                    const float* __restrict__ gout, float* __restrict__ dw, int H, int B, int Ko) {
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, sub = lane >> 5;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  float wv[4], dacc[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    wv[o] = o < Ko ? w[(static_cast<int64_t>(f) * Ko + o) * 32 + n] : 0.f;
+    dacc[o] = 0.f;
+  }
+  for (int b0 = (blockIdx.x * 4 + wave) * 2; b0 < B; b0 += gridDim.x * 8) {
+    const int b = b0 + sub;
+    const bool live = b < B;
+    const int64_t bl = live ? b : B - 1;
+    float v = 0.f;
+    uint32_t sw = 0;
+    for (int h = 0; h < H; ++h) {
+      v += arena[ro[h] + bl * 32 + n];
+      sw ^= signs[(ro[h] >> 5) + bl];
+    }
+    float m = v;
+#pragma unroll
+    for (int s2 = 1; s2 < 32; s2 <<= 1) m = fmaxf(m, __shfl_xor(m, s2, 64));
+    m = ck::clamp_finite(m);
+    float e = expf(v - m);
+    if ((sw >> n) & 1u) e = -e;
+    float gsum = 0.f;
+    uint32_t so = 0;
+    if constexpr (BWD) so = sout[static_cast<int64_t>(f) * B + bl];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o >= Ko) break;
+      if constexpr (!BWD) {
+        float y = wv[o] * e;
+#pragma unroll
+        for (int s2 = 1; s2 < 32; s2 <<= 1) y += __shfl_xor(y, s2, 64);
+        if (y < 0.f) so |= 1u << o;
+        if (live && n == 0) out[(static_cast<int64_t>(f) * B + b) * Ko + o] = logf(fabsf(y)) + m;
+      } else {
+        const float g = gout[(static_cast<int64_t>(f) * B + bl) * Ko + o];
+        const float r = expf(m - out[(static_cast<int64_t>(f) * B + bl) * Ko + o]) * g;
+        const float t = (live && g != 0.f) ? (((so >> o) & 1u) ? -r : r) : 0.f;
+        gsum = fmaf(wv[o], t, gsum);
+        dacc[o] = fmaf(t, e, dacc[o]);
+      }
+    }
+    if constexpr (!BWD) {
+      if (live && n == 0) sout[static_cast<int64_t>(f) * B + b] = so;
+    } else if (live) {
+      const float gx = e * gsum;
+      for (int h = 0; h < H; ++h) garena[ro[h] + bl * 32 + n] = gx;
+    }
+  }
+  if constexpr (BWD) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o >= Ko) break;
+      const float d = dacc[o] + __shfl_xor(dacc[o], 32, 64);
+      if (sub == 0 && d != 0.f) atomicAdd(dw + (static_cast<int64_t>(f) * Ko + o) * 32 + n, d);
+    }
+  }
+}
+
+int check(const void* arena, const void* signs, const int64_t* row_off, const float* w, const void* out, const void* sout, int F, int H, int B,
+          int Ko, const float* table, const int32_t* child_fold, const int32_t* child_var, const int32_t* xt, int C, const char* who) {
+  CK_REQUIRE(w && out && sout, "%s: null pointer", who);
+  CK_REQUIRE(F > 0 && F <= 65535 && H > 0 && B > 0, "%s: bad sizes (F=%d, H=%d, B=%d)", who, F, H, B);
+  CK_REQUIRE(Ko == 32 || (Ko >= 1 && Ko <= 4), "%s: 32 output units, or 1 .. 4 (Ko=%d)", who, Ko);
+  if (table != nullptr) {
+    CK_REQUIRE(child_fold && child_var && xt && C > 0 && Ko == 32, "%s: a gathering layer needs child_fold, child_var, xt, C and 32 outputs", who);
+  } else {
+    CK_REQUIRE(arena && signs && row_off, "%s: null pointer", who);
+    CK_REQUIRE(ck::aligned16(arena), "%s: the arena must be 16-byte aligned", who);
+  }
+  CK_REQUIRE(ck::aligned16(w) && ck::aligned16(out), "%s: buffers must be 16-byte aligned", who);
+  return CK_OK;
+}
+
+}  // namespace
+
+extern "C" int ck_slse_fwd(const float* arena, const uint32_t* signs, const int64_t* row_off, const float* w, float* out, uint32_t* sout,
+                           int F, int H, int B, int Ko, const float* table, const int32_t* child_fold, const int32_t* child_var,
+                           const int32_t* xt, int C, void* stream) {
+  if (int st = check(arena, signs, row_off, w, out, sout, F, H, B, Ko, table, child_fold, child_var, xt, C, "ck_slse_fwd")) return st;
+  const Gather ga{table, child_fold, child_var, xt, C};
+  if (Ko == 32) {
+    const int tiles = (B + 31) / 32;
+    int tpw = 1;
+    while (tpw < 4 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
+    const dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          hipLaunchKernelGGL(slse_tile32_fwd, grid, block, 0, s, arena, signs, row_off, w, out, sout, H, B, tpw, ga);
+          return hipGetLastError();
+        },
+        stream);
+  }
+  const dim3 grid(static_cast<unsigned>(std::max(1, std::min((B + 7) / 8, 1024))), F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(slse_few_kernel<false>, grid, block, 0, s, arena, signs, static_cast<float*>(nullptr), row_off, w, out, sout,
+                           static_cast<const float*>(nullptr), static_cast<float*>(nullptr), H, B, Ko);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+extern "C" int ck_slse_bwd(const float* arena, const uint32_t* signs, float* garena, const int64_t* row_off, const float* w, const float* out,
+                           const uint32_t* sout, const float* gout, float* dw, int F, int H, int B, int Ko, const float* table,
+                           const int32_t* child_fold, const int32_t* child_var, const int32_t* xt, int C, void* stream) {
+  if (int st = check(arena, signs, row_off, w, out, sout, F, H, B, Ko, table, child_fold, child_var, xt, C, "ck_slse_bwd")) return st;
+  CK_REQUIRE(garena && row_off && gout && dw, "ck_slse_bwd: null pointer");
+  const Gather ga{table, child_fold, child_var, xt, C};
+  if (Ko == 32) {
+    const int tiles = (B + 31) / 32;
+    const dim3 grid(static_cast<unsigned>(std::max(1, std::min((tiles + 3) / 4, 16))), F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          hipLaunchKernelGGL(slse_tile32_bwd, grid, block, 0, s, arena, signs, garena, row_off, w, out, sout, gout, dw, H, B, ga);
+          return hipGetLastError();
+        },
+        stream);
+  }
+  const dim3 grid(static_cast<unsigned>(std::max(1, std::min((B + 7) / 8, 256))), F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(slse_few_kernel<true>, grid, block, 0, s, arena, signs, garena, row_off, w, const_cast<float*>(out),
+                           const_cast<uint32_t*>(sout), gout, dw, H, B, Ko);
+        return hipGetLastError();
+      },
+      stream);
+}

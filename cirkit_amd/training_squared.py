@@ -278,6 +278,180 @@ class _PlanBackward:
                 raise NotImplementedError(type(l).__name__)
 
 
+class _SignedCircuit:
+    """c(x) of a squared circuit with real parameters on SIGNED-LOG blocks (cirkit_amd/csrc/ck_signed.hip): fp32 log|v| plus one
+    sign word per row instead of the reference's (log|v|, 0 or pi) pairs -- half the bytes and half the contractions of the
+    complex layers, Embedding outputs never stored (the first sum layer reads the weight table), weight gradients added
+    straight into the flat gradient.  Qualifies: Embedding layers (weight = a tensor, 32 units) under CP-T / arity-1 sum
+    layers of 32 inputs and 32 (or, not directly over an Embedding layer, 1 .. 4) outputs whose weights are tensors; every
+    fold read once; one scalar output.  `why` says what does not fit (the trainer then keeps the complex launch lists)."""
+
+    def __init__(self, circuit: HipCircuit, grads: Mapping[str, torch.Tensor]) -> None:
+        self.c, self.grads = circuit, grads
+        self.why = self._analyse()
+        self._bound: dict[int, dict] = {}
+
+    def _analyse(self) -> str | None:
+        c = self.c
+        if c.plan.semiring != "complex-lse-sum":
+            return "not a complex-lse-sum circuit"
+        if len(c._out_pairs) != 1:
+            return "several outputs"
+        self.kind: dict[int, str] = {}
+        self.wname: dict[int, str] = {}
+        for i, (spec, l) in enumerate(zip(c.plan.layers, c.layers)):
+            ch = c._children[i]
+            if isinstance(l, HipEmbeddingLayer):
+                words = (l.num_states + 1) * 33 + 2 * l.num_states + 3 + 4096
+                if l.num_output_units != 32 or l.weight.ops != ["tensor"] or words * 4 > 160 * 1024 or l.scope_idx.shape[1] != 1:
+                    return f"layer {i}: Embedding layers need 32 units, a plain weight tensor and a table that fits the LDS"
+                self.kind[i] = "emb"
+                self.wname[i] = l.weight.graph.nodes[0].config["tensor"]
+            elif type(l) in (HipSumLayer, HipCPTLayer) and not getattr(l, "_mixing", False):
+                if type(l) is HipSumLayer and l.arity != 1:
+                    return f"layer {i}: a sum layer over several concatenated children"
+                Ko = l.num_output_units
+                if l.num_input_units != 32 or not (Ko == 32 or 1 <= Ko <= 4) or l.weight.ops != ["tensor"]:
+                    return f"layer {i}: needs 32 input units, 32 or 1 .. 4 output units and a plain weight tensor"
+                kinds = {self.kind.get(int(p)) for p in np.unique(ch[..., 0])}
+                if kinds == {"emb"}:
+                    if Ko != 32 or len(np.unique(ch[..., 0])) != 1:
+                        return f"layer {i}: a layer over Embedding folds needs 32 outputs and ONE Embedding layer beneath it"
+                    self.kind[i] = "gather"
+                elif kinds == {"sum"} or kinds == {"sum", "gather"} or kinds == {"gather"}:
+                    self.kind[i] = "sum"
+                else:
+                    return f"layer {i}: children of mixed kinds"
+                self.wname[i] = l.weight.graph.nodes[0].config["tensor"]
+            else:
+                return f"layer {i}: {spec.type!r} has no signed-log form"
+        names = list(self.wname.values())
+        if len(set(names)) != len(names):
+            return "a parameter tensor shared between layers"
+        for n in names:
+            if self.c.store[n].is_complex():
+                return "complex parameter tensors"
+        po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
+        if self.kind.get(po) not in ("sum", "gather") or c.layers[po].num_output_units != 1:
+            return "the output is not a scalar sum unit"
+        for i, k in self.kind.items():  # an Embedding fold read by nobody would keep an unwritten gradient block
+            if k == "emb":
+                read = np.zeros(c.layers[i].num_folds, dtype=bool)
+                for j, ch in enumerate(c._children):
+                    if ch is not None:
+                        read[ch[..., 1][ch[..., 0] == i]] = True
+                if not read.all():
+                    return f"layer {i}: Embedding folds that nothing reads"
+        return None
+
+    def bind(self, B: int) -> dict:
+        st = self._bound.get(B)
+        if st is not None:
+            return st
+        c = self.c
+        dev = c.device
+        off, n = {}, 0
+        for i, k in self.kind.items():  # values and gradients share offsets; the Embedding blocks (gradients only) come last
+            if k != "emb":
+                off[i] = n
+                n += c.layers[i].num_folds * B * 32  # (a 1 .. 4 unit layer: rows of Ko floats in a 32-float stride block)
+        n_val = n
+        for i, k in self.kind.items():
+            if k == "emb":
+                off[i] = n
+                n += c.layers[i].num_folds * B * 32
+        st = {
+            "arena": torch.zeros(max(n_val, 32), dtype=torch.float32, device=dev),
+            "signs": torch.zeros(max(n_val // 32, 1), dtype=torch.int32, device=dev),
+            "garena": torch.zeros(n, dtype=torch.float32, device=dev),
+            "xt": torch.zeros((max(1, c.plan.num_variables), B), dtype=torch.int32, device=dev),
+            "off": off, "ro": {}, "tabs": {},
+        }
+        for i, k in self.kind.items():
+            if k == "emb":
+                continue
+            ch = c._children[i]  # (F, H, 2)
+            ro = np.zeros(ch.shape[:2], dtype=np.int64)
+            for p in np.unique(ch[..., 0]):
+                sel = ch[..., 0] == p
+                ro[sel] = off[int(p)] + ch[..., 1][sel].astype(np.int64) * B * 32
+            st["ro"][i] = torch.from_numpy(ro).to(dev)
+            if k == "gather":
+                emb = c.layers[int(ch[0, 0, 0])]
+                folds = ch[..., 1].astype(np.int32)
+                st["tabs"][i] = (torch.from_numpy(np.ascontiguousarray(folds)).to(dev),
+                                 torch.from_numpy(np.ascontiguousarray(emb.scope_idx[folds, 0].astype(np.int32))).to(dev), int(ch[0, 0, 0]))
+        while len(self._bound) >= 4:
+            self._bound.pop(next(iter(self._bound)))
+        self._bound[B] = st
+        return st
+
+    def _views(self, st: dict, i: int, B: int):
+        l = self.c.layers[i]
+        o = st["off"][i]
+        return o, l.num_folds, l.num_output_units
+
+    def output(self, B: int) -> torch.Tensor:
+        """(B,) fp32: log|c(x_b)|."""
+        c, st = self.c, self.bind(B)
+        po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
+        o = st["off"][po] + fo * B
+        return st["arena"][o : o + B]
+
+    def stage(self, x: torch.Tensor, stream: int) -> None:
+        """The (B, D) batch -> (D, B) int32, checked against the number of states (`HipCircuit._stage_input`)."""
+        c = self.c
+        B = int(x.shape[0])
+        st = self.bind(B)
+        _, xi = c._prepare_input(x)
+        D = c.plan.num_variables
+        if c.validate_inputs:
+            capi.call("ck_stage_categories", xi.data_ptr(), st["xt"].data_ptr(), B, D, c._num_states_dev().data_ptr(),
+                      c._bad_input.data_ptr(), 1 if c._preclamp() else 0, stream)
+        else:
+            capi.call("ck_transpose_i64_to_i32", xi.data_ptr(), st["xt"].data_ptr(), B, D, stream)
+
+    def _args(self, st: dict, i: int):
+        c = self.c
+        if self.kind[i] == "gather":
+            folds, variables, e = st["tabs"][i]
+            emb = c.layers[e]
+            return emb._table.data_ptr(), folds.data_ptr(), variables.data_ptr(), st["xt"].data_ptr(), emb.num_states
+        return None, None, None, None, 0
+
+    def forward(self, B: int, stream: int) -> None:
+        c, st = self.c, self.bind(B)
+        a, sg = st["arena"].data_ptr(), st["signs"].data_ptr()
+        for i, k in self.kind.items():
+            l = c.layers[i]
+            if k == "emb":
+                l.prepare(stream, batched=False)  # the weight table (F, C + 1, 32) of this step's parameters
+                continue
+            o = st["off"][i]
+            capi.call("ck_slse_fwd", a, sg, st["ro"][i].data_ptr(), c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32),
+                      l.num_folds, l.arity, B, l.num_output_units, *self._args(st, i), stream)
+        if c.validate_inputs and c._int_input:
+            y = self.output(B)
+            capi.call("ck_poison_outputs", y.data_ptr(), B, c._bad_input.data_ptr(), stream)
+
+    def backward(self, B: int, seed: float, stream: int) -> None:
+        """Gradients of ``seed * sum_b log|c(x_b)|`` ADDED into `grads` (the Embedding weights': written)."""
+        c, st = self.c, self.bind(B)
+        a, sg, ga = st["arena"].data_ptr(), st["signs"].data_ptr(), st["garena"].data_ptr()
+        po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
+        capi.call("ck_fill_f32", ga + 4 * st["off"][po], c.layers[po].num_folds * B, 0.0, stream)
+        capi.call("ck_fill_f32", ga + 4 * (st["off"][po] + fo * B), B, float(seed), stream)
+        for i in reversed(list(self.kind)):
+            l, k = c.layers[i], self.kind[i]
+            o = st["off"][i]
+            if k == "emb":
+                capi.call("ck_embedding_bwd", ga + 4 * o, 1, st["xt"].data_ptr(), l._scope(c.device).data_ptr(), l._table.data_ptr(),
+                          self.grads[self.wname[i]].data_ptr(), l.num_folds, B, 32, l.num_states, stream)
+                continue
+            capi.call("ck_slse_bwd", a, sg, ga, st["ro"][i].data_ptr(), c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32),
+                      ga + 4 * o, self.grads[self.wname[i]].data_ptr(), l.num_folds, l.arity, B, l.num_output_units, *self._args(st, i), stream)
+
+
 class HipSquaredTrainer:
     """Maximum-likelihood training of a squared circuit with real parameters: ``loss = -mean_b (2 Re c(x_b) - Re Z)``
     (the reference's loop for sum-of-squares circuits; c under complex-lse-sum -- or a real circuit under lse-sum --, Z built
@@ -285,7 +459,7 @@ class HipSquaredTrainer:
 
     def __init__(self, plan_c: Plan, tensors: Mapping[str, object], *, plan_z: Plan | None = None, device: str | torch.device = "cuda:0",
                  lr: float = 0.01, optimizer: str = "adam", betas: tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
-                 use_graph: bool = True) -> None:
+                 use_graph: bool = True, signed: bool | None = None) -> None:
         if plan_c.semiring not in ("complex-lse-sum", "lse-sum"):
             raise NotImplementedError(f"HipSquaredTrainer: semiring {plan_c.semiring!r}")
         if optimizer not in ("adam", "sgd"):
@@ -330,6 +504,11 @@ class HipSquaredTrainer:
             grads_z[n] = self._flat_grad_z[off : off + sz].view(plan_c.tensors[n][0])
             off += sz
         self._bwd_c, self._bwd_z = _PlanBackward(self.c, self.grads), _PlanBackward(self.z, grads_z)
+        # c on signed-log blocks where its layers allow it (`signed`: None = where they do, True = required, False = never)
+        sc = _SignedCircuit(self.c, self.grads) if signed is not False else None
+        if signed is True and sc.why is not None:
+            raise NotImplementedError(f"HipSquaredTrainer(signed=True): {sc.why}")
+        self._signed = sc if (sc is not None and sc.why is None) else None
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self._m1 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
         self._m2 = torch.zeros_like(self._flat_grad) if optimizer == "adam" else None
@@ -371,7 +550,11 @@ class HipSquaredTrainer:
         n = self._flat_grad.numel()
         if part == "c":
             capi.call("ck_fill_f32", self._flat_grad.data_ptr(), n, 0.0, stream)
-            self._bwd_c.run(B, -2.0 / gB, stream)
+            if self._signed is not None:  # (its forward is part of the list: only the staging of the batch is not)
+                self._signed.forward(B, stream)
+                self._signed.backward(B, -2.0 / gB, stream)
+            else:
+                self._bwd_c.run(B, -2.0 / gB, stream)
         elif part == "z":
             capi.call("ck_fill_f32", self._flat_grad_z.data_ptr(), n, 0.0, stream)
             self._bwd_z.run(1, B / gB, stream)
@@ -382,7 +565,7 @@ class HipSquaredTrainer:
                 capi.call("ck_opt_tick", self._opt_state().data_ptr(), c._bad_input.data_ptr() if validate else None,
                           self._bad_seen.data_ptr() if validate else None, stream)
             capi.call("ck_axpy_f32", self._flat_grad.data_ptr(), self._flat_grad_z.data_ptr(), 1.0, n, stream)
-            yc = c._bind(B).views[int(c._out_pairs[0, 0])][int(c._out_pairs[0, 1])]
+            yc = self._signed.output(B) if self._signed is not None else c._bind(B).views[int(c._out_pairs[0, 0])][int(c._out_pairs[0, 1])]
             yz = z._bind(1).views[int(z._out_pairs[0, 0])][int(z._out_pairs[0, 1])]
             capi.call("ck_squared_ll", yc.data_ptr(), B, 2 if yc.is_complex() else 1, yz.data_ptr(), self._ll.data_ptr(), stream)
             if with_optimizer:
@@ -393,7 +576,8 @@ class HipSquaredTrainer:
         the two gradients, the log-likelihood pair and (alone) the optimizer -- per (batch size, global batch): the first two
         calls run eagerly (they size the scratch of the parameter graphs), the third records, later ones replay (as a hipGraph
         when `use_graph`)."""
-        key = (part, B, float(gB), bool(with_optimizer), self.c._bind(B).arena.data_ptr(), self.z._bind(1).arena.data_ptr())
+        c_arena = self._signed.bind(B)["arena"] if self._signed is not None else self.c._bind(B).arena
+        key = (part, B, float(gB), bool(with_optimizer), c_arena.data_ptr(), self.z._bind(1).arena.data_ptr())
         prog, seen = self._programs.get(key, (None, 0))
         if prog is None:
             if seen < 2:
@@ -428,7 +612,10 @@ class HipSquaredTrainer:
             self.z._run(None)  # (1, 1, 1)
             self._part("z", B, gB, with_optimizer, side)
         with torch.cuda.stream(main):
-            self.c._run(x)     # (B, 1, 1) complex64 / fp32 in c's arena
+            if self._signed is not None:
+                self._signed.stage(x, main.cuda_stream)
+            else:
+                self.c._run(x)  # (B, 1, 1) complex64 / fp32 in c's arena
             self._part("c", B, gB, with_optimizer, main)
             main.wait_stream(side)
             self._part("end", B, gB, with_optimizer, main)

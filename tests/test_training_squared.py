@@ -67,9 +67,12 @@ def test_squared_circuit_training_steps_increase_the_likelihood(hip_device):
 
 
 @pytest.mark.gpu
-def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_device):
+@pytest.mark.parametrize("signed", [False, True])
+def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_device, signed):
     """BASELINE config 5 (QuadTree 28x28, Embedding-256, CP-T, K = 32; Z from its own plan): the gradients of 32 rows against
-    torch autograd through the oracle's restatement of the reference forward (bit-identical to the reference on CPU)."""
+    torch autograd through the oracle's restatement of the reference forward (bit-identical to the reference on CPU).
+    signed: c(x) on signed-log blocks (ck_signed.hip: fp32 log|v| + a sign bit, Embedding rows gathered by the first sum
+    layer) instead of the complex layer-wise launch list -- what the trainer picks by itself for this circuit."""
     from cirkit_amd.training_squared import HipSquaredTrainer
     from oracle import torch_oracle as oracle  # (tests may: the oracle is the checker)
 
@@ -83,14 +86,86 @@ def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_d
     z = oracle.evaluate_plan(plan_z, leaves, None, grad=True)
     loss = -(2.0 * c.real - z.real).mean()
     loss.backward()
-    tr = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)
-    ll = tr.loss_and_grads(x.to(hip_device)).cpu().numpy()
-    assert abs(-ll[0] / ll[1] - loss.item()) <= 1e-4 * abs(loss.item()), (-ll[0] / ll[1], loss.item())
-    got = tr.gradients()
-    for k in tensors:
-        want = leaves[k].grad.numpy()
-        err = float(np.abs(got[k] - want).max())
-        assert err <= 2e-3 * max(1e-6, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
+    tr = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device, signed=signed)
+    assert (tr._signed is not None) == signed
+    assert HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)._signed is not None  # (the default for this circuit)
+    for _ in range(4):  # (eager, eager, recorded, replayed: the same numbers every time)
+        ll = tr.loss_and_grads(x.to(hip_device)).cpu().numpy()
+        assert abs(-ll[0] / ll[1] - loss.item()) <= 1e-4 * abs(loss.item()), (-ll[0] / ll[1], loss.item())
+        got = tr.gradients()
+        for k in tensors:
+            want = leaves[k].grad.numpy()
+            err = float(np.abs(got[k] - want).max())
+            assert err <= 2e-3 * max(1e-6, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+def test_signed_log_layers_match_the_complex_layers(hip_device):
+    """ck_slse_fwd / ck_slse_bwd against ck_sum_lse_fwd_c / ck_sum_lse_bwd_c on the same values (32 -> 32 and 32 -> 1 CP-T folds,
+    ragged batch of 77 rows, negative weights and inputs): log|out| and sign = (re, im / pi) of the complex output, the children's
+    gradient = the real part of the complex one, the same dW."""
+    from cirkit_amd import _capi as capi
+
+    g = torch.Generator().manual_seed(11)
+    B, H = 77, 2
+    for F, Ko in ((3, 32), (2, 1)):
+        w = (torch.randn(F, Ko, 32, generator=g) * 0.3).to(hip_device)
+        mag = torch.randn(F * H, B, 32, generator=g).to(hip_device)
+        neg = (torch.rand(F * H, B, 32, generator=g) < 0.4).to(hip_device)
+        signs = (neg.to(torch.int64) * weights).sum(-1).to(torch.int32) if False else \
+            torch.from_numpy(((neg.cpu().numpy().astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)).to(hip_device)
+        xc = torch.complex(mag, torch.pi * neg.to(torch.float32)).contiguous()
+        ro = (torch.arange(F * H, dtype=torch.int64) * B * 32).reshape(F, H).to(hip_device)
+        stream = torch.cuda.current_stream().cuda_stream
+        out, sout = torch.zeros(F, B, Ko, device=hip_device), torch.zeros(F, B, dtype=torch.int32, device=hip_device)
+        capi.call("ck_slse_fwd", mag.data_ptr(), signs.data_ptr(), ro.data_ptr(), w.data_ptr(), out.data_ptr(), sout.data_ptr(), F, H, B, Ko,
+                  None, None, None, None, 0, stream)
+        outc = torch.zeros(F, B, Ko, dtype=torch.complex64, device=hip_device)
+        capi.call("ck_sum_lse_fwd_c", xc.data_ptr(), ro.data_ptr(), w.data_ptr(), outc.data_ptr(), F, H, B, 32, Ko, capi.CK_SUM_PROD, 0, stream)
+        torch.cuda.synchronize()
+        assert torch.allclose(out, outc.real, rtol=1e-5, atol=2e-5)
+        bits = ((sout.cpu().numpy().view(np.uint32)[..., None] >> np.arange(Ko, dtype=np.uint32)) & 1).astype(bool)
+        assert np.array_equal(bits, np.abs(outc.imag.cpu().numpy()) > 1.5)
+        gout = torch.randn(F, B, Ko, generator=g).to(hip_device)
+        gx, dw = torch.zeros_like(mag), torch.zeros_like(w)
+        capi.call("ck_slse_bwd", mag.data_ptr(), signs.data_ptr(), gx.data_ptr(), ro.data_ptr(), w.data_ptr(), out.data_ptr(), sout.data_ptr(),
+                  gout.data_ptr(), dw.data_ptr(), F, H, B, Ko, None, None, None, None, 0, stream)
+        gxc, dwc = torch.zeros_like(xc), torch.zeros_like(w)
+        goutc = torch.complex(gout, torch.zeros_like(gout)).contiguous()
+        capi.call("ck_sum_lse_bwd_c", xc.data_ptr(), gxc.data_ptr(), ro.data_ptr(), w.data_ptr(), outc.data_ptr(), goutc.data_ptr(), dwc.data_ptr(),
+                  F, H, B, 32, Ko, capi.CK_SUM_PROD, 0, stream)
+        torch.cuda.synchronize()
+        scale = float(gxc.real.abs().max())
+        assert float((gx - gxc.real).abs().max()) <= 1e-4 * scale
+        assert float((dw - dwc).abs().max()) <= 1e-4 * float(dwc.abs().max())
+
+
+@pytest.mark.gpu
+def test_signed_squared_trainer_drops_a_batch_with_an_illegal_category(hip_device):
+    """The signed-log path stages and checks the batch itself: an out-of-range category leaves parameters and moments alone."""
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    plan_c = Plan.load(os.path.join(GOLDEN, "cfg5_sos_c_k32"))
+    tensors = {k: np.where(v == 0, np.float32(1e-2), v).astype(np.float32) for k, v in init_plan_tensors(plan_c).items()}
+    tr = HipSquaredTrainer(plan_c, tensors, device=hip_device, lr=1e-3)
+    assert tr._signed is not None
+    x = torch.randint(0, 256, (64, 784), generator=torch.Generator().manual_seed(3)).to(hip_device)
+    for _ in range(4):
+        tr.step(x)
+    before = {k: v.copy() for k, v in tr.parameters().items()}
+    bad = x.clone()
+    bad[5, 100] = 256
+    ll = tr.step(bad)
+    assert not np.isfinite(float(ll[0]))
+    after = tr.parameters()
+    assert all(np.array_equal(before[k], after[k]) for k in before)
+    assert tr.skipped_steps == 1 and tr.step_count == 4
+    with pytest.raises(IndexError):
+        tr.check_inputs()
+    tr.step(x)
+    now = tr.parameters()
+    assert all(np.isfinite(v).all() for v in now.values()) and any(not np.array_equal(before[k], now[k]) for k in before)
+    tr.check_inputs()
 
 
 @pytest.mark.gpu
