@@ -9,8 +9,10 @@
 // 2 Re c(x) - Re Z) is real.  With x_j = s_j exp(v_j) the product of the children, a_j = x_j exp(-m), y = W a:
 //     out_o = log|y_o| + m, sign y_o        t_o = G_o exp(m) / y_o        g v_j = a_j (W^T t)_j        dW = t^T a
 // -- the three contractions of the real backward (ck_bwd_tile.h) on signed operands.  Children that are folds of an
-// Embedding layer are read from its weight table (F0, C + 1, 32) by the batch values (the layer's output is never stored);
-// their gradient blocks are (B, 32) fp32, what ck_embedding_bwd scatters.
+// Embedding layer are read from the signed-log form of its weight table (ck_slse_table: (F0, C + 1, 32) log|w| and a sign
+// word per row) by the batch values: the layer's output is never stored.  The H children of a product receive the SAME
+// gradient: a fold writes it once, into its own (B, 32) block, and its children (ck_slse_bwd's gout_off, ck_embedding_bwd's
+// gfold) read it there.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -31,8 +33,29 @@ __device__ __forceinline__ void load16(const float* __restrict__ row, int kh, fl
 }
 __device__ __forceinline__ bool bit_of(uint32_t word, int j, int kh) { return (word >> (8 * (j >> 2) + 4 * kh + (j & 3))) & 1u; }
 
+// exp(d), d <= 0: v_exp_f32 on d log2(e) with the rounding error of that product put back (1 + lo ln 2): ~1e-7 relative, as expf,
+// at a quarter of its instructions (the layers are otherwise bound by these: 48 transcendentals per lane and tile)
+__device__ __forceinline__ float exp_fast(float d) {
+#ifdef CK_SLSE_LIBM
+  return expf(d);
+#else
+  const float t = d * kL2E;
+  const float lo = fmaf(d, kL2E, -t);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fabsf(t) < 1e30f ? fmaf(e, lo * kLN2, e) : e;  // (d = -inf: 0, not the NaN of inf - inf)
+#endif
+}
+__device__ __forceinline__ float log_abs(float y) {
+#ifdef CK_SLSE_LIBM
+  return logf(fabsf(y));
+#else
+  return __builtin_amdgcn_logf(fabsf(y)) * kLN2;
+#endif
+}
+
 struct Gather {
-  const float* table;         // (F0, C + 1, 32) REAL Embedding weights, row C the integral row; nullptr: children in the arena
+  const float* table;         // (F0, C + 1, 32) log|w| of the Embedding weights, row C the integral row; nullptr: children in the arena
+  const uint32_t* tsigns;     // (F0, C + 1) their sign words
   const int32_t* child_fold;  // (F, H) Embedding fold of each child
   const int32_t* child_var;   // (F, H) its variable
   const int32_t* xt;          // (D, B) staged batch
@@ -52,20 +75,16 @@ __device__ __forceinline__ uint32_t load_children(const float* __restrict__ aren
       const int64_t e = static_cast<int64_t>(f) * H + h;
       const int xv = ga.xt[static_cast<int64_t>(ga.child_var[e]) * B + bl];
       const int c = xv < 0 ? ga.C : min(xv, ga.C - 1);
-      load16(ga.table + (static_cast<int64_t>(ga.child_fold[e]) * (ga.C + 1) + c) * 32, kh, x);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        sw ^= (x[j] < 0.f ? 1u : 0u) << (8 * (j >> 2) + 4 * kh + (j & 3));
-        v[j] += logf(fabsf(x[j]));
-      }
+      const int64_t row = static_cast<int64_t>(ga.child_fold[e]) * (ga.C + 1) + c;
+      load16(ga.table + row * 32, kh, x);
+      sw ^= ga.tsigns[row];
     } else {
       load16(arena + ro[h] + bl * 32, kh, x);
       sw ^= signs[(ro[h] >> 5) + bl];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] += x[j];
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] += x[j];
   }
-  if (ga.table != nullptr) sw |= __shfl_xor(sw, 32, 64);  // (each half built the bits of its own units)
   return sw;
 }
 
@@ -91,7 +110,7 @@ __global__ void __launch_bounds__(256)
     const float m = row_max16(v);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float e = expf(v[j] - m);
+      const float e = exp_fast(v[j] - m);
       v[j] = bit_of(sw, j, kh) ? -e : e;
     }
     contract_linear<CK_W_ROWMAJOR>(wr, v);
@@ -99,7 +118,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       so |= (v[j] < 0.f ? 1u : 0u) << (8 * (j >> 2) + 4 * kh + (j & 3));
-      v[j] = logf(fabsf(v[j])) + m;
+      v[j] = log_abs(v[j]) + m;
     }
     so |= __shfl_xor(so, 32, 64);
     if (live) {
@@ -114,9 +133,10 @@ __global__ void __launch_bounds__(256)
 // Four waves walk the row tiles of one fold with dW in registers; one float atomic per weight entry and workgroup at the end
 // (the skeleton of sum_clse_bwd_tile32, ck_backward_c.hip, with half its contractions).
 __global__ void __launch_bounds__(256)
-    slse_tile32_bwd(const float* __restrict__ arena, const uint32_t* __restrict__ signs, float* __restrict__ garena,
+    slse_tile32_bwd(const float* __restrict__ arena, const uint32_t* __restrict__ signs, float* __restrict__ gx,
                     const int64_t* __restrict__ row_off, const float* __restrict__ w, const float* __restrict__ out,
-                    const uint32_t* __restrict__ sout, const float* __restrict__ gout, float* __restrict__ dw, int H, int B, Gather ga) {
+                    const uint32_t* __restrict__ sout, const float* __restrict__ gout, const int64_t* __restrict__ gout_off,
+                    float* __restrict__ dw, int H, int B, Gather ga) {
   __shared__ __attribute__((aligned(16))) float wt_s[1024];        // W^T, "transposed tiled" (child_gradient)
   __shared__ __attribute__((aligned(16))) float scr_s[4][2][1024];  // per wave: the two operands of dw_accumulate
   const int f = blockIdx.y;
@@ -133,6 +153,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
   for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
   const int tiles = (B + 31) / 32;
+  const float* gf = gout + (gout_off != nullptr ? gout_off[f] : static_cast<int64_t>(f) * B * 32);
   for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
     const int b = tile * 32 + b_in;
     const bool live = b < B;
@@ -142,30 +163,28 @@ __global__ void __launch_bounds__(256)
     const float m = row_max16(a);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float e = expf(a[j] - m);
+      const float e = exp_fast(a[j] - m);
       a[j] = bit_of(sw, j, kh) ? -e : e;
     }
     float t[16];
     {
       float y[16], g[16];
       load16(out + (static_cast<int64_t>(f) * B + bl) * 32, kh, y);
-      load16(gout + (static_cast<int64_t>(f) * B + bl) * 32, kh, g);
+      load16(gf + bl * 32, kh, g);
       const uint32_t so = sout[static_cast<int64_t>(f) * B + bl];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         // exp(m) / y_o = sign exp(m - out_o); an output without gradient contributes nothing (also where out = -inf)
-        const float r = expf(m - y[j]) * g[j];
+        const float r = exp_fast(m - y[j]) * g[j];
         t[j] = (live && g[j] != 0.f) ? (bit_of(so, j, kh) ? -r : r) : 0.f;
       }
     }
     float gv[16];
     child_gradient(wt_s, lane, t, a, gv);
     if (live) {
-      for (int h = 0; h < H; ++h) {
-        float* dst = garena + ro[h] + bl * 32 + 4 * kh;
+      float* dst = gx + (static_cast<int64_t>(f) * B + b) * 32 + 4 * kh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]);
-      }
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]);
     }
     dw_accumulate(dacc, scr_s[wave][0], scr_s[wave][1], b_in, kh, t, a);
   }
@@ -186,7 +205,7 @@ __global__ void __launch_bounds__(256)
 // a half-wave walks, float atomics at the end).
 template <bool BWD>
 __global__ void __launch_bounds__(256)
-    slse_few_kernel(const float* __restrict__ arena, const uint32_t* __restrict__ signs, float* __restrict__ garena,
+    slse_few_kernel(const float* __restrict__ arena, const uint32_t* __restrict__ signs, float* __restrict__ gxo,
                     const int64_t* __restrict__ row_off, const float* __restrict__ w, float* __restrict__ out, uint32_t* __restrict__ sout,
                     const float* __restrict__ gout, float* __restrict__ dw, int H, int B, int Ko) {
   const int f = blockIdx.y;
@@ -213,7 +232,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int s2 = 1; s2 < 32; s2 <<= 1) m = fmaxf(m, __shfl_xor(m, s2, 64));
     m = ck::clamp_finite(m);
-    float e = expf(v - m);
+    float e = exp_fast(v - m);
     if ((sw >> n) & 1u) e = -e;
     float gsum = 0.f;
     uint32_t so = 0;
@@ -226,10 +245,10 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int s2 = 1; s2 < 32; s2 <<= 1) y += __shfl_xor(y, s2, 64);
         if (y < 0.f) so |= 1u << o;
-        if (live && n == 0) out[(static_cast<int64_t>(f) * B + b) * Ko + o] = logf(fabsf(y)) + m;
+        if (live && n == 0) out[(static_cast<int64_t>(f) * B + b) * Ko + o] = log_abs(y) + m;
       } else {
         const float g = gout[(static_cast<int64_t>(f) * B + bl) * Ko + o];
-        const float r = expf(m - out[(static_cast<int64_t>(f) * B + bl) * Ko + o]) * g;
+        const float r = exp_fast(m - out[(static_cast<int64_t>(f) * B + bl) * Ko + o]) * g;
         const float t = (live && g != 0.f) ? (((so >> o) & 1u) ? -r : r) : 0.f;
         gsum = fmaf(wv[o], t, gsum);
         dacc[o] = fmaf(t, e, dacc[o]);
@@ -238,8 +257,7 @@ __global__ void __launch_bounds__(256)
     if constexpr (!BWD) {
       if (live && n == 0) sout[static_cast<int64_t>(f) * B + b] = so;
     } else if (live) {
-      const float gx = e * gsum;
-      for (int h = 0; h < H; ++h) garena[ro[h] + bl * 32 + n] = gx;
+      gxo[(static_cast<int64_t>(f) * B + b) * 32 + n] = e * gsum;
     }
   }
   if constexpr (BWD) {
@@ -252,13 +270,29 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// rows of 32 weights -> log|w| and one sign word per row (a half-wave per row)
+__global__ void __launch_bounds__(256)
+    slse_table_kernel(const float* __restrict__ table, float* __restrict__ ltab, uint32_t* __restrict__ tsigns, int64_t rows) {
+  const int64_t row = (blockIdx.x * 256ll + threadIdx.x) >> 5;
+  const int k = threadIdx.x & 31;
+  if (row >= rows) return;
+  const float w = table[row * 32 + k];
+  ltab[row * 32 + k] = logf(fabsf(w));
+  uint32_t bit = w < 0.f ? (1u << k) : 0u;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) bit |= __shfl_xor(bit, o, 64);
+  if (k == 0) tsigns[row] = bit;
+}
+
 int check(const void* arena, const void* signs, const int64_t* row_off, const float* w, const void* out, const void* sout, int F, int H, int B,
-          int Ko, const float* table, const int32_t* child_fold, const int32_t* child_var, const int32_t* xt, int C, const char* who) {
+          int Ko, const Gather& ga, const char* who) {
   CK_REQUIRE(w && out && sout, "%s: null pointer", who);
   CK_REQUIRE(F > 0 && F <= 65535 && H > 0 && B > 0, "%s: bad sizes (F=%d, H=%d, B=%d)", who, F, H, B);
   CK_REQUIRE(Ko == 32 || (Ko >= 1 && Ko <= 4), "%s: 32 output units, or 1 .. 4 (Ko=%d)", who, Ko);
-  if (table != nullptr) {
-    CK_REQUIRE(child_fold && child_var && xt && C > 0 && Ko == 32, "%s: a gathering layer needs child_fold, child_var, xt, C and 32 outputs", who);
+  if (ga.table != nullptr) {
+    CK_REQUIRE(ga.tsigns && ga.child_fold && ga.child_var && ga.xt && ga.C > 0 && Ko == 32,
+               "%s: a gathering layer needs table_signs, child_fold, child_var, xt, C and 32 outputs", who);
+    CK_REQUIRE(ck::aligned16(ga.table), "%s: the table must be 16-byte aligned", who);
   } else {
     CK_REQUIRE(arena && signs && row_off, "%s: null pointer", who);
     CK_REQUIRE(ck::aligned16(arena), "%s: the arena must be 16-byte aligned", who);
@@ -269,11 +303,22 @@ int check(const void* arena, const void* signs, const int64_t* row_off, const fl
 
 }  // namespace
 
+extern "C" int ck_slse_table(const float* table, float* log_table, uint32_t* table_signs, int64_t rows, void* stream) {
+  CK_REQUIRE(table && log_table && table_signs && rows > 0, "ck_slse_table: bad arguments");
+  const dim3 grid(static_cast<unsigned>((rows * 32 + 255) / 256)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(slse_table_kernel, grid, block, 0, s, table, log_table, table_signs, rows);
+        return hipGetLastError();
+      },
+      stream);
+}
+
 extern "C" int ck_slse_fwd(const float* arena, const uint32_t* signs, const int64_t* row_off, const float* w, float* out, uint32_t* sout,
-                           int F, int H, int B, int Ko, const float* table, const int32_t* child_fold, const int32_t* child_var,
-                           const int32_t* xt, int C, void* stream) {
-  if (int st = check(arena, signs, row_off, w, out, sout, F, H, B, Ko, table, child_fold, child_var, xt, C, "ck_slse_fwd")) return st;
-  const Gather ga{table, child_fold, child_var, xt, C};
+                           int F, int H, int B, int Ko, const float* log_table, const uint32_t* table_signs, const int32_t* child_fold,
+                           const int32_t* child_var, const int32_t* xt, int C, void* stream) {
+  const Gather ga{log_table, table_signs, child_fold, child_var, xt, C};
+  if (int st = check(arena, signs, row_off, w, out, sout, F, H, B, Ko, ga, "ck_slse_fwd")) return st;
   if (Ko == 32) {
     const int tiles = (B + 31) / 32;
     int tpw = 1;
@@ -296,26 +341,28 @@ extern "C" int ck_slse_fwd(const float* arena, const uint32_t* signs, const int6
       stream);
 }
 
-extern "C" int ck_slse_bwd(const float* arena, const uint32_t* signs, float* garena, const int64_t* row_off, const float* w, const float* out,
-                           const uint32_t* sout, const float* gout, float* dw, int F, int H, int B, int Ko, const float* table,
-                           const int32_t* child_fold, const int32_t* child_var, const int32_t* xt, int C, void* stream) {
-  if (int st = check(arena, signs, row_off, w, out, sout, F, H, B, Ko, table, child_fold, child_var, xt, C, "ck_slse_bwd")) return st;
-  CK_REQUIRE(garena && row_off && gout && dw, "ck_slse_bwd: null pointer");
-  const Gather ga{table, child_fold, child_var, xt, C};
+extern "C" int ck_slse_bwd(const float* arena, const uint32_t* signs, const int64_t* row_off, const float* w, const float* out,
+                           const uint32_t* sout, const float* gout, const int64_t* gout_off, float* gx, float* dw, int F, int H, int B, int Ko,
+                           const float* log_table, const uint32_t* table_signs, const int32_t* child_fold, const int32_t* child_var,
+                           const int32_t* xt, int C, void* stream) {
+  const Gather ga{log_table, table_signs, child_fold, child_var, xt, C};
+  if (int st = check(arena, signs, row_off, w, out, sout, F, H, B, Ko, ga, "ck_slse_bwd")) return st;
+  CK_REQUIRE(gx && gout && dw && ck::aligned16(gx) && ck::aligned16(gout), "ck_slse_bwd: null or misaligned pointer");
   if (Ko == 32) {
     const int tiles = (B + 31) / 32;
     const dim3 grid(static_cast<unsigned>(std::max(1, std::min((tiles + 3) / 4, 16))), F), block(256);
     return ck::dispatch(
         [=](hipStream_t s) {
-          hipLaunchKernelGGL(slse_tile32_bwd, grid, block, 0, s, arena, signs, garena, row_off, w, out, sout, gout, dw, H, B, ga);
+          hipLaunchKernelGGL(slse_tile32_bwd, grid, block, 0, s, arena, signs, gx, row_off, w, out, sout, gout, gout_off, dw, H, B, ga);
           return hipGetLastError();
         },
         stream);
   }
+  CK_REQUIRE(gout_off == nullptr, "ck_slse_bwd: gout_off is read by 32-output layers only");
   const dim3 grid(static_cast<unsigned>(std::max(1, std::min((B + 7) / 8, 256))), F), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(slse_few_kernel<true>, grid, block, 0, s, arena, signs, garena, row_off, w, const_cast<float*>(out),
+        hipLaunchKernelGGL(slse_few_kernel<true>, grid, block, 0, s, arena, signs, gx, row_off, w, const_cast<float*>(out),
                            const_cast<uint32_t*>(sout), gout, dw, H, B, Ko);
         return hipGetLastError();
       },

@@ -246,7 +246,7 @@ class _PlanBackward:
                     raise NotImplementedError("squared-circuit training: complex Embedding weights (the layer-level autograd of "
                                               "cirkit_amd.layer_ops.embedding differentiates them)")
                 if sc["one_launch"]:
-                    capi.call("ck_embedding_bwd", g.data_ptr(), e, bd.xt_i.data_ptr(), l._scope(g.device).data_ptr(), l._table.data_ptr(),
+                    capi.call("ck_embedding_bwd", g.data_ptr(), e, None, bd.xt_i.data_ptr(), l._scope(g.device).data_ptr(), l._table.data_ptr(),
                               sc["dw"].data_ptr(), F, B, K, Cn, stream)
                 else:
                     gr = real_part(g, sc)
@@ -351,45 +351,58 @@ class _SignedCircuit:
         c = self.c
         dev = c.device
         off, n = {}, 0
-        for i, k in self.kind.items():  # values and gradients share offsets; the Embedding blocks (gradients only) come last
-            if k != "emb":
+        for i, k in self.kind.items():  # a block of (F, B, 32) floats per sum layer -- values, and at the same offset in the
+            if k != "emb":              # gradient arena the gradient w.r.t. the product of its children
                 off[i] = n
-                n += c.layers[i].num_folds * B * 32  # (a 1 .. 4 unit layer: rows of Ko floats in a 32-float stride block)
-        n_val = n
-        for i, k in self.kind.items():
-            if k == "emb":
-                off[i] = n
-                n += c.layers[i].num_folds * B * 32
+                n += c.layers[i].num_folds * B * 32  # (a 1 .. 4 unit layer: rows of Ko floats at the start of its block)
+        po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
         st = {
-            "arena": torch.zeros(max(n_val, 32), dtype=torch.float32, device=dev),
-            "signs": torch.zeros(max(n_val // 32, 1), dtype=torch.int32, device=dev),
-            "garena": torch.zeros(n, dtype=torch.float32, device=dev),
+            "arena": torch.zeros(max(n, 32), dtype=torch.float32, device=dev),
+            "signs": torch.zeros(max(n // 32, 1), dtype=torch.int32, device=dev),
+            "garena": torch.zeros(max(n, 32), dtype=torch.float32, device=dev),
+            "seed": torch.zeros(c.layers[po].num_folds * B, dtype=torch.float32, device=dev),  # the output layer's gradient
             "xt": torch.zeros((max(1, c.plan.num_variables), B), dtype=torch.int32, device=dev),
-            "off": off, "ro": {}, "tabs": {},
+            "off": off, "ro": {}, "tabs": {}, "gout_off": {}, "gfold": {}, "ltab": {},
         }
+        parent: dict[tuple[int, int], tuple[int, int]] = {}  # (layer, fold) -> the (layer, fold) that reads it
         for i, k in self.kind.items():
             if k == "emb":
+                l = c.layers[i]
+                rows = l.num_folds * (l.num_states + 1)
+                st["ltab"][i] = (torch.zeros(rows * 32, dtype=torch.float32, device=dev), torch.zeros(rows, dtype=torch.int32, device=dev))
                 continue
             ch = c._children[i]  # (F, H, 2)
-            ro = np.zeros(ch.shape[:2], dtype=np.int64)
-            for p in np.unique(ch[..., 0]):
-                sel = ch[..., 0] == p
-                ro[sel] = off[int(p)] + ch[..., 1][sel].astype(np.int64) * B * 32
-            st["ro"][i] = torch.from_numpy(ro).to(dev)
+            for f in range(ch.shape[0]):
+                for h in range(ch.shape[1]):
+                    parent[(int(ch[f, h, 0]), int(ch[f, h, 1]))] = (i, f)
             if k == "gather":
                 emb = c.layers[int(ch[0, 0, 0])]
                 folds = ch[..., 1].astype(np.int32)
                 st["tabs"][i] = (torch.from_numpy(np.ascontiguousarray(folds)).to(dev),
                                  torch.from_numpy(np.ascontiguousarray(emb.scope_idx[folds, 0].astype(np.int32))).to(dev), int(ch[0, 0, 0]))
+            else:
+                ro = np.zeros(ch.shape[:2], dtype=np.int64)
+                for p in np.unique(ch[..., 0]):
+                    sel = ch[..., 0] == p
+                    ro[sel] = off[int(p)] + ch[..., 1][sel].astype(np.int64) * B * 32
+                st["ro"][i] = torch.from_numpy(ro).to(dev)
+        for i, k in self.kind.items():  # where each fold finds the gradient of its output: its reader's block
+            F = c.layers[i].num_folds
+            if i == po:
+                continue
+            if k == "emb":
+                gather = {parent[(i, f)][0] for f in range(F)}
+                assert len(gather) == 1
+                st["gfold"][i] = (torch.from_numpy(np.asarray([parent[(i, f)][1] for f in range(F)], dtype=np.int32)).to(dev), gather.pop())
+            else:
+                if any((i, f) not in parent for f in range(F)):
+                    raise NotImplementedError(f"layer {i}: folds that nothing reads")
+                st["gout_off"][i] = torch.from_numpy(np.asarray(
+                    [off[parent[(i, f)][0]] + parent[(i, f)][1] * B * 32 for f in range(F)], dtype=np.int64)).to(dev)
         while len(self._bound) >= 4:
             self._bound.pop(next(iter(self._bound)))
         self._bound[B] = st
         return st
-
-    def _views(self, st: dict, i: int, B: int):
-        l = self.c.layers[i]
-        o = st["off"][i]
-        return o, l.num_folds, l.num_output_units
 
     def output(self, B: int) -> torch.Tensor:
         """(B,) fp32: log|c(x_b)|."""
@@ -415,21 +428,24 @@ class _SignedCircuit:
         c = self.c
         if self.kind[i] == "gather":
             folds, variables, e = st["tabs"][i]
-            emb = c.layers[e]
-            return emb._table.data_ptr(), folds.data_ptr(), variables.data_ptr(), st["xt"].data_ptr(), emb.num_states
-        return None, None, None, None, 0
+            ltab, tsg = st["ltab"][e]
+            return None, ltab.data_ptr(), tsg.data_ptr(), folds.data_ptr(), variables.data_ptr(), st["xt"].data_ptr(), c.layers[e].num_states
+        return st["ro"][i].data_ptr(), None, None, None, None, None, 0
 
     def forward(self, B: int, stream: int) -> None:
         c, st = self.c, self.bind(B)
         a, sg = st["arena"].data_ptr(), st["signs"].data_ptr()
         for i, k in self.kind.items():
             l = c.layers[i]
-            if k == "emb":
-                l.prepare(stream, batched=False)  # the weight table (F, C + 1, 32) of this step's parameters
+            if k == "emb":  # the weight table (F, C + 1, 32) of this step's parameters, and its signed-log form
+                l.prepare(stream, batched=False)
+                ltab, tsg = st["ltab"][i]
+                capi.call("ck_slse_table", l._table.data_ptr(), ltab.data_ptr(), tsg.data_ptr(), l.num_folds * (l.num_states + 1), stream)
                 continue
             o = st["off"][i]
-            capi.call("ck_slse_fwd", a, sg, st["ro"][i].data_ptr(), c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32),
-                      l.num_folds, l.arity, B, l.num_output_units, *self._args(st, i), stream)
+            ro, *gather = self._args(st, i)
+            capi.call("ck_slse_fwd", a, sg, ro, c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32),
+                      l.num_folds, l.arity, B, l.num_output_units, *gather, stream)
         if c.validate_inputs and c._int_input:
             y = self.output(B)
             capi.call("ck_poison_outputs", y.data_ptr(), B, c._bad_input.data_ptr(), stream)
@@ -439,17 +455,21 @@ class _SignedCircuit:
         c, st = self.c, self.bind(B)
         a, sg, ga = st["arena"].data_ptr(), st["signs"].data_ptr(), st["garena"].data_ptr()
         po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
-        capi.call("ck_fill_f32", ga + 4 * st["off"][po], c.layers[po].num_folds * B, 0.0, stream)
-        capi.call("ck_fill_f32", ga + 4 * (st["off"][po] + fo * B), B, float(seed), stream)
+        if c.layers[po].num_folds > 1:
+            capi.call("ck_fill_f32", st["seed"].data_ptr(), st["seed"].numel(), 0.0, stream)
+        capi.call("ck_fill_f32", st["seed"].data_ptr() + 4 * fo * B, B, float(seed), stream)
         for i in reversed(list(self.kind)):
             l, k = c.layers[i], self.kind[i]
-            o = st["off"][i]
             if k == "emb":
-                capi.call("ck_embedding_bwd", ga + 4 * o, 1, st["xt"].data_ptr(), l._scope(c.device).data_ptr(), l._table.data_ptr(),
-                          self.grads[self.wname[i]].data_ptr(), l.num_folds, B, 32, l.num_states, stream)
+                gfold, g = st["gfold"][i]
+                capi.call("ck_embedding_bwd", ga + 4 * st["off"][g], 1, gfold.data_ptr(), st["xt"].data_ptr(), l._scope(c.device).data_ptr(),
+                          l._table.data_ptr(), self.grads[self.wname[i]].data_ptr(), l.num_folds, B, 32, l.num_states, stream)
                 continue
-            capi.call("ck_slse_bwd", a, sg, ga, st["ro"][i].data_ptr(), c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32),
-                      ga + 4 * o, self.grads[self.wname[i]].data_ptr(), l.num_folds, l.arity, B, l.num_output_units, *self._args(st, i), stream)
+            o = st["off"][i]
+            ro, *gather = self._args(st, i)
+            gout, gout_off = (st["seed"].data_ptr(), None) if i == po else (ga, st["gout_off"][i].data_ptr())
+            capi.call("ck_slse_bwd", a, sg, ro, c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32), gout, gout_off,
+                      ga + 4 * o, self.grads[self.wname[i]].data_ptr(), l.num_folds, l.arity, B, l.num_output_units, *gather, stream)
 
 
 class HipSquaredTrainer:

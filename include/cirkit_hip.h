@@ -721,25 +721,30 @@ int ck_embedding_weight_bwd(const float* table, const float* dtable, float* dw, 
 int ck_squared_ll(const float* yc, int64_t B, int64_t stride, const float* z, double* out, void* stream);
 /* The whole backward of an Embedding layer under a logarithm in one launch (K % 32 == 0, (C + 1)(K + 1) + 2 C + 4099 words of
  * LDS; CK_ERR_UNSUPPORTED otherwise): d w[f, k, c] = (sum over the rows b with x[b, scope[f]] = c of gout[f, b, k]) / table[f, c, k],
- * 0 where nobody selected c.  gout_stride: floats between consecutive entries of gout (2: the real parts of a complex64 block). */
-int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* xt, const int64_t* scope, const float* table, float* dw, int F,
-                     int B, int K, int C, void* stream);
+ * 0 where nobody selected c.  gout_stride: floats between consecutive entries of gout (2: the real parts of a complex64 block);
+ * gfold: NULL, or the (B, K) block of gout each fold reads (folds that were multiplied share their gradient: ck_slse_bwd). */
+int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, const int32_t* xt, const int64_t* scope, const float* table,
+                     float* dw, int F, int B, int K, int C, void* stream);
 /* Signed-log sum layers (cirkit_amd/csrc/ck_signed.hip): TorchCPTLayer / TorchSumLayer (arity 1) under complex-lse-sum
  * (optimized.py:171-178, inner.py:266-273, semiring.py:441-476) for circuits whose parameters are all REAL -- every value is
  * real, the reference's (log|v|, 0 or pi) is stored as fp32 log|v| in (rows, 32) blocks plus ONE sign word per row (bit k:
  * unit k negative).  arena / signs: the blocks and their sign words; row_off (F, H): float offsets of the children's blocks
  * (multiples of 32; the sign words of a block start at offset / 32); 32 input units; w (F, Ko, 32) real, Ko = 32 or 1 .. 4;
- * out (F, B, Ko), sout (F, B) (bit o: output o negative).  table != NULL (Ko = 32): the children are folds of an Embedding
- * layer, read as rows of its weight table (F0, C + 1, 32) (layers/input.py:258-266; child_fold / child_var (F, H): fold and
- * variable of each child, xt (D, B) the staged batch) -- arena / signs / row_off are not read by the forward.
- * Backward, for a loss that reads log|out|: gout (F, B, Ko) real; garena + row_off[f, h] <- the gradient w.r.t. log|child h|
- * ((B, 32) fp32, written; with table: what ck_embedding_bwd scatters); dw (F, Ko, 32) += (float atomics: zero it first). */
+ * out (F, B, Ko), sout (F, B) (bit o: output o negative).  log_table != NULL (Ko = 32): the children are folds of an Embedding
+ * layer (layers/input.py:258-266), read as rows of the signed-log form of its weight table -- ck_slse_table: (rows, 32) real
+ * weights -> log|w| and a sign word per row, rows = F0 (C + 1) of the gather table -- by the batch values (child_fold /
+ * child_var (F, H): fold and variable of each child, xt (D, B) the staged batch); arena / signs / row_off are not read then.
+ * Backward, for a loss that reads log|out|: gout + gout_off[f] (gout_off NULL: + f B Ko) the (B, Ko) real gradient of fold
+ * f's output; gx (F, B, 32) <- the gradient w.r.t. log|product of the children| -- the SAME for each of the H children, who
+ * read it there (their gout_off; ck_embedding_bwd's gfold); dw (F, Ko, 32) += (float atomics: zero it first). */
+int ck_slse_table(const float* table, float* log_table, uint32_t* table_signs, int64_t rows, void* stream);
 int ck_slse_fwd(const float* arena, const uint32_t* signs, const int64_t* row_off, const float* w, float* out, uint32_t* sout,
-                int F, int H, int B, int Ko, const float* table, const int32_t* child_fold, const int32_t* child_var,
+                int F, int H, int B, int Ko, const float* log_table, const uint32_t* table_signs, const int32_t* child_fold,
+                const int32_t* child_var, const int32_t* xt, int C, void* stream);
+int ck_slse_bwd(const float* arena, const uint32_t* signs, const int64_t* row_off, const float* w, const float* out,
+                const uint32_t* sout, const float* gout, const int64_t* gout_off, float* gx, float* dw, int F, int H, int B, int Ko,
+                const float* log_table, const uint32_t* table_signs, const int32_t* child_fold, const int32_t* child_var,
                 const int32_t* xt, int C, void* stream);
-int ck_slse_bwd(const float* arena, const uint32_t* signs, float* garena, const int64_t* row_off, const float* w, const float* out,
-                const uint32_t* sout, const float* gout, float* dw, int F, int H, int B, int Ko, const float* table,
-                const int32_t* child_fold, const int32_t* child_var, const int32_t* xt, int C, void* stream);
 /* *dst |= *src; *src = 0 (DEVICE int32 flags): turns a per-step validation flag into a sticky one. */
 int ck_latch_flag(int32_t* src, int32_t* dst, void* stream);
 /* ck_fill_f32 that also hands a validation flag on: *step_flag = *src; if it is nonzero, *sticky |= *src and *src = 0

@@ -112,31 +112,39 @@ def test_signed_log_layers_match_the_complex_layers(hip_device):
         w = (torch.randn(F, Ko, 32, generator=g) * 0.3).to(hip_device)
         mag = torch.randn(F * H, B, 32, generator=g).to(hip_device)
         neg = (torch.rand(F * H, B, 32, generator=g) < 0.4).to(hip_device)
-        signs = (neg.to(torch.int64) * weights).sum(-1).to(torch.int32) if False else \
-            torch.from_numpy(((neg.cpu().numpy().astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)).to(hip_device)
+        signs = torch.from_numpy(((neg.cpu().numpy().astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1) & 0xFFFFFFFF)
+                                 .astype(np.uint32).view(np.int32)).to(hip_device)
         xc = torch.complex(mag, torch.pi * neg.to(torch.float32)).contiguous()
         ro = (torch.arange(F * H, dtype=torch.int64) * B * 32).reshape(F, H).to(hip_device)
         stream = torch.cuda.current_stream().cuda_stream
         out, sout = torch.zeros(F, B, Ko, device=hip_device), torch.zeros(F, B, dtype=torch.int32, device=hip_device)
         capi.call("ck_slse_fwd", mag.data_ptr(), signs.data_ptr(), ro.data_ptr(), w.data_ptr(), out.data_ptr(), sout.data_ptr(), F, H, B, Ko,
-                  None, None, None, None, 0, stream)
+                  None, None, None, None, None, 0, stream)
         outc = torch.zeros(F, B, Ko, dtype=torch.complex64, device=hip_device)
         capi.call("ck_sum_lse_fwd_c", xc.data_ptr(), ro.data_ptr(), w.data_ptr(), outc.data_ptr(), F, H, B, 32, Ko, capi.CK_SUM_PROD, 0, stream)
         torch.cuda.synchronize()
-        assert torch.allclose(out, outc.real, rtol=1e-5, atol=2e-5)
+        # random signs cancel: the yardstick is the sum of the magnitudes, sum_j |W_oj| |x_j|, in the linear domain
         bits = ((sout.cpu().numpy().view(np.uint32)[..., None] >> np.arange(Ko, dtype=np.uint32)) & 1).astype(bool)
-        assert np.array_equal(bits, np.abs(outc.imag.cpu().numpy()) > 1.5)
+        v = mag.view(F, H, B, 32).sum(1).double()
+        m = v.amax(-1, keepdim=True)
+        yard = torch.einsum("foi,fbi->fbo", w.abs().double(), (v - m).exp())
+        y_signed = torch.where(torch.from_numpy(bits).to(hip_device), -1.0, 1.0) * (out.double() - m).exp()
+        y_complex = ((outc.to(torch.complex128) - m).exp()).real
+        assert float(((y_signed - y_complex).abs() / yard).max()) <= 2e-6
+        sure = ((y_complex.abs() / yard) > 1e-5).cpu().numpy()  # (the sign of a sum that cancelled to rounding noise is anybody's)
+        assert np.array_equal(bits[sure], (np.abs(outc.imag.cpu().numpy()) > 1.5)[sure])
         gout = torch.randn(F, B, Ko, generator=g).to(hip_device)
-        gx, dw = torch.zeros_like(mag), torch.zeros_like(w)
-        capi.call("ck_slse_bwd", mag.data_ptr(), signs.data_ptr(), gx.data_ptr(), ro.data_ptr(), w.data_ptr(), out.data_ptr(), sout.data_ptr(),
-                  gout.data_ptr(), dw.data_ptr(), F, H, B, Ko, None, None, None, None, 0, stream)
+        gx, dw = torch.zeros(F, B, 32, device=hip_device), torch.zeros_like(w)  # (one gradient block per fold: its children share it)
+        capi.call("ck_slse_bwd", mag.data_ptr(), signs.data_ptr(), ro.data_ptr(), w.data_ptr(), out.data_ptr(), sout.data_ptr(),
+                  gout.data_ptr(), None, gx.data_ptr(), dw.data_ptr(), F, H, B, Ko, None, None, None, None, None, 0, stream)
         gxc, dwc = torch.zeros_like(xc), torch.zeros_like(w)
         goutc = torch.complex(gout, torch.zeros_like(gout)).contiguous()
         capi.call("ck_sum_lse_bwd_c", xc.data_ptr(), gxc.data_ptr(), ro.data_ptr(), w.data_ptr(), outc.data_ptr(), goutc.data_ptr(), dwc.data_ptr(),
                   F, H, B, 32, Ko, capi.CK_SUM_PROD, 0, stream)
         torch.cuda.synchronize()
         scale = float(gxc.real.abs().max())
-        assert float((gx - gxc.real).abs().max()) <= 1e-4 * scale
+        for h in range(H):
+            assert float((gx - gxc.real.view(F, H, B, 32)[:, h]).abs().max()) <= 1e-4 * scale
         assert float((dw - dwc).abs().max()) <= 1e-4 * float(dwc.abs().max())
 
 
