@@ -246,7 +246,114 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// TensorDot backward on the layer's own layout (TorchTensorDotLayer, optimized.py:289-296: x (B, Kj, Kq), per (b, q) a dense sum
+// over j with weights W (Kk, Kj), out (B, Kq, Kk)): one workgroup per (fold, batch row), everything in LDS -- instead of a
+// transposed copy of x, the dense kernel on its rows (b, q) and a transposed copy of the gradient back.  T: c32 (complex-lse-sum:
+// the conventions of sum_clse_bwd_kernel above, REAL weights) or float (lse-sum).
+struct TdC {
+  using T = c32;
+  static __device__ __forceinline__ float re(c32 a) { return a.re; }
+  static __device__ __forceinline__ c32 exp_shift(c32 v, float m) { return cexp({v.re - m, v.im}); }                 // a
+  static __device__ __forceinline__ c32 tee(c32 y, c32 g, float m) {                                                 // t
+    return (g.re == 0.f && g.im == 0.f) ? c32{0.f, 0.f} : cmul(cconj(cexp({m - y.re, -y.im})), g);
+  }
+  static __device__ __forceinline__ c32 zero() { return {0.f, 0.f}; }
+  static __device__ __forceinline__ c32 fma_w(float w, c32 t, c32 acc) { return {fmaf(w, t.re, acc.re), fmaf(w, t.im, acc.im)}; }
+  static __device__ __forceinline__ c32 child(c32 a, c32 acc) { return cmul(cconj(a), acc); }
+  static __device__ __forceinline__ float dw(c32 a, c32 t) { return a.re * t.re + a.im * t.im; }  // Re(conj(a) t)
+};
+struct TdR {
+  using T = float;
+  static __device__ __forceinline__ float re(float a) { return a; }
+  static __device__ __forceinline__ float exp_shift(float v, float m) { return expf(v - m); }
+  static __device__ __forceinline__ float tee(float y, float g, float m) { return g == 0.f ? 0.f : expf(m - y) * g; }
+  static __device__ __forceinline__ float zero() { return 0.f; }
+  static __device__ __forceinline__ float fma_w(float w, float t, float acc) { return fmaf(w, t, acc); }
+  static __device__ __forceinline__ float child(float a, float acc) { return a * acc; }
+  static __device__ __forceinline__ float dw(float a, float t) { return a * t; }
+};
+
+template <class S>
+__global__ void __launch_bounds__(256)
+    tensordot_lse_bwd_kernel(const typename S::T* __restrict__ arena, typename S::T* __restrict__ garena, const int64_t* __restrict__ row_off,
+                             const float* __restrict__ w, const typename S::T* __restrict__ out, const typename S::T* __restrict__ gout,
+                             float* __restrict__ dw, int B, int Kj, int Kq, int Kk) {
+  using T = typename S::T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* a_s = reinterpret_cast<T*>(smem);                               // [Kq][Kj + 1]: x, then a = exp(x - m_q)
+  T* t_s = a_s + static_cast<size_t>(Kq) * (Kj + 1);                 // [Kq][Kk + 1]
+  float* w_s = reinterpret_cast<float*>(t_s + static_cast<size_t>(Kq) * (Kk + 1));  // [Kk][Kj + 1]
+  float* m_s = w_s + static_cast<size_t>(Kk) * (Kj + 1);             // [Kq]
+  const int f = blockIdx.y, b = blockIdx.x;
+  const int64_t xoff = row_off[f] + static_cast<int64_t>(b) * Kj * Kq;
+  const float* wf = w + static_cast<int64_t>(f) * Kk * Kj;
+  for (int i = threadIdx.x; i < Kk * Kj; i += 256) w_s[(i / Kj) * (Kj + 1) + i % Kj] = wf[i];
+  for (int i = threadIdx.x; i < Kj * Kq; i += 256) {  // coalesced read of x[j][q]
+    const int j = i / Kq, q = i - j * Kq;
+    a_s[q * (Kj + 1) + j] = arena[xoff + i];
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < Kq; q += 256) {
+    float mx = -INFINITY;
+    for (int j = 0; j < Kj; ++j) mx = fmaxf(mx, S::re(a_s[q * (Kj + 1) + j]));
+    m_s[q] = ck::clamp_finite(mx);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Kq * Kj; i += 256) {
+    const int q = i / Kj, j = i - q * Kj;
+    a_s[q * (Kj + 1) + j] = S::exp_shift(a_s[q * (Kj + 1) + j], m_s[q]);
+  }
+  const int64_t ooff = (static_cast<int64_t>(f) * B + b) * Kq * Kk;
+  for (int i = threadIdx.x; i < Kq * Kk; i += 256) {
+    const int q = i / Kk, k = i - q * Kk;
+    t_s[q * (Kk + 1) + k] = S::tee(out[ooff + i], gout[ooff + i], m_s[q]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Kj * Kq; i += 256) {  // the gradient of x[j][q], written in x's layout
+    const int j = i / Kq, q = i - j * Kq;
+    T acc = S::zero();
+    for (int k = 0; k < Kk; ++k) acc = S::fma_w(w_s[k * (Kj + 1) + j], t_s[q * (Kk + 1) + k], acc);
+    garena[xoff + i] = S::child(a_s[q * (Kj + 1) + j], acc);
+  }
+  for (int i = threadIdx.x; i < Kk * Kj; i += 256) {
+    const int k = i / Kj, j = i - k * Kj;
+    float acc = 0.f;
+    for (int q = 0; q < Kq; ++q) acc += S::dw(a_s[q * (Kj + 1) + j], t_s[q * (Kk + 1) + k]);
+    if (acc != 0.f) atomicAdd(dw + static_cast<int64_t>(f) * Kk * Kj + i, acc);
+  }
+}
+
+template <class S>
+int launch_tensordot_bwd(const typename S::T* arena, typename S::T* garena, const int64_t* row_off, const float* w, const typename S::T* out,
+                         const typename S::T* gout, float* dw, int F, int B, int Kj, int Kq, int Kk, void* stream) {
+  CK_REQUIRE(arena && garena && row_off && w && out && gout && dw, "ck_tensordot_lse_bwd: null pointer");
+  CK_REQUIRE(F > 0 && F <= 65535 && B > 0 && Kj > 0 && Kq > 0 && Kk > 0, "ck_tensordot_lse_bwd: bad sizes");
+  const size_t lds = (static_cast<size_t>(Kq) * (Kj + 1) + static_cast<size_t>(Kq) * (Kk + 1)) * sizeof(typename S::T) +
+                     (static_cast<size_t>(Kk) * (Kj + 1) + Kq) * sizeof(float);
+  if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_tensordot_lse_bwd: Kj=%d, Kq=%d, Kk=%d do not fit in LDS", Kj, Kq, Kk);
+  const dim3 grid(B, F), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        auto kern = tensordot_lse_bwd_kernel<S>;
+        if (lds > 48 * 1024) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+          if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, block, lds, s, arena, garena, row_off, w, out, gout, dw, B, Kj, Kq, Kk);
+        return hipGetLastError();
+      },
+      stream);
+}
+
 }  // namespace
+
+extern "C" int ck_tensordot_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* w, const float* out,
+                                    const float* gout, float* dw, int F, int B, int Kj, int Kq, int Kk, int complex_values, void* stream) {
+  if (complex_values)
+    return launch_tensordot_bwd<TdC>(reinterpret_cast<const ck::c32*>(arena), reinterpret_cast<ck::c32*>(garena), row_off, w,
+                                     reinterpret_cast<const ck::c32*>(out), reinterpret_cast<const ck::c32*>(gout), dw, F, B, Kj, Kq, Kk, stream);
+  return launch_tensordot_bwd<TdR>(arena, garena, row_off, w, out, gout, dw, F, B, Kj, Kq, Kk, stream);
+}
 
 extern "C" int ck_sum_lse_bwd_c(const float* arena_c, float* garena_c, const int64_t* row_off, const float* w, const float* out_c,
                                 const float* gout_c, float* dw, int F, int H, int B, int Ki, int Ko, int mode, int w_is_complex,

@@ -599,6 +599,26 @@ class HipParameter:
             else:
                 raise NotImplementedError(f"parameter backward through {n.op!r}")
 
+    def passthrough_tensor(self) -> str | None:
+        """The name of the stored REAL tensor that `evaluate` returns as it is -- a tensor or a pointer to all its folds, seen
+        through conjugates and identity fold indices (the weights of a squared circuit's partition function) -- else None.
+        A layer whose weight passes through may add its weight gradient straight into that tensor's gradient."""
+        g = self.graph
+        if not g.nodes or g.nodes[0].op not in ("tensor", "pointer") or g.nodes[0].config.get("fold_idx") is not None:
+            return None
+        for j, n in enumerate(g.nodes[1:], start=1):
+            if n.op != "conj" or len(n.inputs) != 1:
+                return None
+            fi = n.inputs[0]
+            if fi.ids != [j - 1] or not (fi.kind == IDX_NONE or (
+                    fi.kind == IDX_ARRAY and np.array_equal(np.asarray(fi.array).reshape(-1), np.arange(g.nodes[j - 1].num_folds)))):
+                return None
+        if g.output.ids != [len(g.nodes) - 1] or not (g.output.kind == IDX_NONE or np.array_equal(
+                np.asarray(g.output.array).reshape(-1), np.arange(g.nodes[-1].num_folds))):
+            return None
+        name = g.nodes[0].config["tensor"]
+        return None if self.store[name].is_complex() else name
+
     def softmax_source(self) -> torch.Tensor | None:
         """The raw tensor when the graph is exactly ``tensor -> softmax(last axis)`` with identity
         fold indices (the default parameterisation of sum weights and Categorical probs), else None."""

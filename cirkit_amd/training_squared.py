@@ -96,15 +96,7 @@ class _PlanBackward:
             F, K = l.num_folds, l.num_output_units
             sc: dict = {}
             if isinstance(l, HipTensorDotLayer):
-                Kj, Kq = l._num_contract_units, l._num_batch_units
-                n = B * Kj * Kq  # (arity 1: one (B, Kj * Kq) block per fold)
-                ro = bd.row_off[i].reshape(-1).cpu().numpy()
-                sc["ro"] = [int(o) for o in ro]
-                sc["packed"] = bool(np.array_equal(ro, ro[0] + n * np.arange(F)))  # the producer's folds in order: one slice
-                sc["rows"] = (torch.arange(F, dtype=torch.int64, device=dev) * n).reshape(F, 1)
-                sc["xp"], sc["gx"] = f32(F * n * e), f32(F * n * e)
-                if not sc["packed"]:
-                    sc["xs"], sc["gxp"] = f32(F * n * e), f32(F * n * e)
+                pass  # (d w: a slice of the pool, or the tensor's gradient itself, `_weight_pool`)
             elif isinstance(l, (HipSumLayer, HipCPTLayer, HipTuckerLayer)):
                 pass  # (d w: a slice of the pool, `_weight_pool`)
             elif isinstance(l, HipHadamardLayer):
@@ -149,11 +141,18 @@ class _PlanBackward:
                     shape = tuple(l._w.shape)
                 else:
                     continue
+                # a weight that IS a stored tensor (a pointer, through conjugates): the kernel adds into that tensor's gradient
+                name = l.weight.passthrough_tensor()
+                if name is not None and self.grads[name].numel() == int(np.prod(shape)) and self.grads[name].is_contiguous():
+                    st["scratch"][i]["dw"] = self.grads[name].view(shape)
+                    st["scratch"][i]["direct"] = True
+                    continue
                 shapes[i] = (off, shape)
                 off += (int(np.prod(shape)) + 3) // 4 * 4
             pool = torch.zeros(max(off, 4), dtype=torch.float32, device=st["garena"].device)
             for i, (o, shape) in shapes.items():
                 st["scratch"][i]["dw"] = pool[o : o + int(np.prod(shape))].view(shape)
+                st["scratch"][i]["direct"] = False
             st["pool"] = pool
         return st["pool"]
 
@@ -183,12 +182,6 @@ class _PlanBackward:
                 capi.call("ck_sum_lse_bwd", arena_ptr, garena_ptr, row_off.data_ptr(), None, w.data_ptr(), out_ptr, g_ptr, dw.data_ptr(),
                           F, H, rows, Ki, Ko, mode, 0, stream)
 
-        def transpose(src_ptr, dst_ptr, R, A, Bd):  # (R, A, Bd) -> (R, Bd, A) values
-            if cplx:
-                capi.call("ck_param_transpose_last2_c", src_ptr, dst_ptr, R, A, Bd, Bd, stream)
-            else:
-                capi.call("ck_param_transpose_last2", src_ptr, dst_ptr, R, A, Bd, 0, Bd, stream)
-
         def real_part(g, sc):  # (F, B, K) fp32: the real parts of a gradient block
             if not cplx:
                 return g
@@ -200,30 +193,19 @@ class _PlanBackward:
             F, K = l.num_folds, l.num_output_units
             g = gviews[i]
             sc = st["scratch"][i]
-            if isinstance(l, HipTensorDotLayer):
+            if isinstance(l, HipTensorDotLayer):  # (optimized.py:289-296) on its own layout: x (B, Kj, Kq) -> out (B, Kq, Kk)
                 Kj, Kq = l._num_contract_units, l._num_batch_units
-                Kk = K // Kq
-                ro = sc["ro"]
-                n = B * Kj * Kq
-                if sc["packed"]:
-                    x_ptr, gdst = aa + ro[0] * esz, ga + ro[0] * esz
-                else:
-                    for f, o in enumerate(ro):
-                        capi.call("ck_copy_strided_f32", aa + o * esz, sc["xs"].data_ptr() + f * n * esz, n * e, 1, 1, stream)
-                    x_ptr, gdst = sc["xs"].data_ptr(), sc["gxp"].data_ptr()
-                # the layer IS a dense sum over the rows (b, q) of the permuted input (optimized.py:289-296)
-                transpose(x_ptr, sc["xp"].data_ptr(), F * B, Kj, Kq)
-                sum_bwd(sc["xp"].data_ptr(), sc["gx"].data_ptr(), sc["rows"], l._w, bd.views[i].data_ptr(), g.data_ptr(), sc["dw"],
-                        F, 1, B * Kq, Kj, Kk, capi.CK_SUM_PROD)
-                transpose(sc["gx"].data_ptr(), gdst, F * B, Kq, Kj)
-                if not sc["packed"]:
-                    for f, o in enumerate(ro):
-                        capi.call("ck_copy_strided_f32", gdst + f * n * esz, ga + o * esz, n * e, 1, 1, stream)
-                l.weight.backward(sc["dw"], self.grads, stream)
+                if l._w.is_complex():
+                    raise NotImplementedError("squared-circuit training: complex-valued weights")
+                capi.call("ck_tensordot_lse_bwd", aa, ga, bd.row_off[i].data_ptr(), l._w.data_ptr(), bd.views[i].data_ptr(), g.data_ptr(),
+                          sc["dw"].data_ptr(), F, B, Kj, Kq, K // Kq, 1 if cplx else 0, stream)
+                if not sc["direct"]:
+                    l.weight.backward(sc["dw"], self.grads, stream)
             elif isinstance(l, (HipSumLayer, HipCPTLayer, HipTuckerLayer)):
                 w = l._w
                 sum_bwd(aa, ga, bd.row_off[i], w, bd.views[i].data_ptr(), g.data_ptr(), sc["dw"], F, l.arity, B, l.num_input_units, K, l._mode)
-                l.weight.backward(sc["dw"], self.grads, stream)
+                if not sc["direct"]:
+                    l.weight.backward(sc["dw"], self.grads, stream)
             elif isinstance(l, HipHadamardLayer):  # log space: the sum of the children -- (re, im) pairs as 2 K floats
                 capi.call("ck_hadamard_bwd", ga, sc["ro"].data_ptr(), g.data_ptr(), F, l.arity, B, e * K, 0, stream)
             elif isinstance(l, HipCategoricalLayer):  # (lse-sum) the scatter-add into the log-table, then log softmax backward
