@@ -253,7 +253,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_fill_strided_f32": [_p, _l, _l, _f, _p],
     "ck_embedding_weight_bwd": [_p, _p, _p, _i, _i, _i, _p],
     "ck_squared_ll": [_p, _l, _l, _p, _p, _p],
-    "ck_embedding_bwd": [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ck_embedding_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_tensordot_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ck_slse_table": [_p, _p, _p, _l, _p],
     "ck_slse_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],

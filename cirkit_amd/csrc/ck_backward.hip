@@ -1594,8 +1594,8 @@ int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* x
       stream);
 }
 
-int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, const int32_t* xt, const int64_t* scope, const float* table,
-                     float* dw, int F, int B, int K, int C, void* stream) {
+int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, const int32_t* fold_order, const int32_t* xt,
+                     const int64_t* scope, const float* table, float* dw, int F, int B, int K, int C, void* stream) {
   CK_REQUIRE(gout && xt && scope && table && dw, "ck_embedding_bwd: null pointer");
   CK_REQUIRE(F > 0 && B > 0 && K > 0 && C > 0 && (gout_stride == 1 || gout_stride == 2), "ck_embedding_bwd: bad arguments");
   const size_t lds = (static_cast<size_t>(C + 1) * (K + 1) + static_cast<size_t>(2) * C + 3 + kCatChunk) * sizeof(float);
@@ -1610,8 +1610,7 @@ int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, c
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(160 * 1024));
           if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds, s, gout, gfold, xt, scope, dw, B, K, C,
-                           0, static_cast<const int32_t*>(nullptr), gout_stride, table);
+        hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds, s, gout, gfold, xt, scope, dw, B, K, C, 0, fold_order, gout_stride, table);
         return hipGetLastError();
       },
       stream);

@@ -91,14 +91,18 @@ __device__ __forceinline__ uint32_t load_children(const float* __restrict__ aren
 __global__ void __launch_bounds__(256)
     slse_tile32_fwd(const float* __restrict__ arena, const uint32_t* __restrict__ signs, const int64_t* __restrict__ row_off,
                     const float* __restrict__ w, float* __restrict__ out, uint32_t* __restrict__ sout, int H, int B, int tiles_per_wave,
-                    Gather ga) {
-  const int f = blockIdx.y;
+                    Gather ga, int F, int nx) {
+  // consecutive workgroups go to consecutive XCDs: the nx workgroups of a fold are spaced 8 apart so that they share one L2
+  // (a gathering fold re-reads its children's 2 x 33 KB table rows there instead of in the MALL)
+  const int seq = blockIdx.x >> 3;
+  const int f = (seq / nx) * 8 + (blockIdx.x & 7), bx = seq % nx;
+  if (f >= F) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 31, kh = lane >> 5;
   WRegs wr;
   load_w<CK_W_ROWMAJOR>(w + static_cast<int64_t>(f) * kK * kK, lane, wr);
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
-  const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+  const int tile0 = (bx * 4 + wave) * tiles_per_wave;
   for (int tt = 0; tt < tiles_per_wave; ++tt) {
     const int b0 = (tile0 + tt) * 32;
     if (b0 >= B) break;
@@ -136,10 +140,12 @@ __global__ void __launch_bounds__(256)
     slse_tile32_bwd(const float* __restrict__ arena, const uint32_t* __restrict__ signs, float* __restrict__ gx,
                     const int64_t* __restrict__ row_off, const float* __restrict__ w, const float* __restrict__ out,
                     const uint32_t* __restrict__ sout, const float* __restrict__ gout, const int64_t* __restrict__ gout_off,
-                    float* __restrict__ dw, int H, int B, Gather ga) {
+                    float* __restrict__ dw, int H, int B, Gather ga, int F, int nx) {
   __shared__ __attribute__((aligned(16))) float wt_s[1024];        // W^T, "transposed tiled" (child_gradient)
   __shared__ __attribute__((aligned(16))) float scr_s[4][2][1024];  // per wave: the two operands of dw_accumulate
-  const int f = blockIdx.y;
+  const int seq = blockIdx.x >> 3;  // (the workgroups of a fold on one XCD, as in the forward)
+  const int f = (seq / nx) * 8 + (blockIdx.x & 7), bx = seq % nx;
+  if (f >= F) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b_in = lane & 31, kh = lane >> 5;
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
@@ -154,7 +160,7 @@ __global__ void __launch_bounds__(256)
   for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
   const int tiles = (B + 31) / 32;
   const float* gf = gout + (gout_off != nullptr ? gout_off[f] : static_cast<int64_t>(f) * B * 32);
-  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+  for (int tile = bx * 4 + wave; tile < tiles; tile += nx * 4) {
     const int b = tile * 32 + b_in;
     const bool live = b < B;
     const int64_t bl = live ? b : B - 1;
@@ -323,10 +329,11 @@ extern "C" int ck_slse_fwd(const float* arena, const uint32_t* signs, const int6
     const int tiles = (B + 31) / 32;
     int tpw = 1;
     while (tpw < 4 && static_cast<int64_t>(F) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
-    const dim3 grid((tiles + 4 * tpw - 1) / (4 * tpw), F), block(256);
+    const int nx = (tiles + 4 * tpw - 1) / (4 * tpw);
+    const dim3 grid(static_cast<unsigned>((F + 7) / 8 * 8 * nx)), block(256);
     return ck::dispatch(
         [=](hipStream_t s) {
-          hipLaunchKernelGGL(slse_tile32_fwd, grid, block, 0, s, arena, signs, row_off, w, out, sout, H, B, tpw, ga);
+          hipLaunchKernelGGL(slse_tile32_fwd, grid, block, 0, s, arena, signs, row_off, w, out, sout, H, B, tpw, ga, F, nx);
           return hipGetLastError();
         },
         stream);
@@ -350,10 +357,11 @@ extern "C" int ck_slse_bwd(const float* arena, const uint32_t* signs, const int6
   CK_REQUIRE(gx && gout && dw && ck::aligned16(gx) && ck::aligned16(gout), "ck_slse_bwd: null or misaligned pointer");
   if (Ko == 32) {
     const int tiles = (B + 31) / 32;
-    const dim3 grid(static_cast<unsigned>(std::max(1, std::min((tiles + 3) / 4, 16))), F), block(256);
+    const int nx = std::max(1, std::min((tiles + 3) / 4, 16));
+    const dim3 grid(static_cast<unsigned>((F + 7) / 8 * 8 * nx)), block(256);
     return ck::dispatch(
         [=](hipStream_t s) {
-          hipLaunchKernelGGL(slse_tile32_bwd, grid, block, 0, s, arena, signs, gx, row_off, w, out, sout, gout, gout_off, dw, H, B, ga);
+          hipLaunchKernelGGL(slse_tile32_bwd, grid, block, 0, s, arena, signs, gx, row_off, w, out, sout, gout, gout_off, dw, H, B, ga, F, nx);
           return hipGetLastError();
         },
         stream);

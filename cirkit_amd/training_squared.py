@@ -228,7 +228,7 @@ class _PlanBackward:
                     raise NotImplementedError("squared-circuit training: complex Embedding weights (the layer-level autograd of "
                                               "cirkit_amd.layer_ops.embedding differentiates them)")
                 if sc["one_launch"]:
-                    capi.call("ck_embedding_bwd", g.data_ptr(), e, None, bd.xt_i.data_ptr(), l._scope(g.device).data_ptr(), l._table.data_ptr(),
+                    capi.call("ck_embedding_bwd", g.data_ptr(), e, None, None, bd.xt_i.data_ptr(), l._scope(g.device).data_ptr(), l._table.data_ptr(),
                               sc["dw"].data_ptr(), F, B, K, Cn, stream)
                 else:
                     gr = real_part(g, sc)
@@ -375,7 +375,20 @@ class _SignedCircuit:
             if k == "emb":
                 gather = {parent[(i, f)][0] for f in range(F)}
                 assert len(gather) == 1
-                st["gfold"][i] = (torch.from_numpy(np.asarray([parent[(i, f)][1] for f in range(F)], dtype=np.int32)).to(dev), gather.pop())
+                gfold = np.asarray([parent[(i, f)][1] for f in range(F)], dtype=np.int32)
+                # folds that share a gradient block: 8 workgroups apart (one XCD, the same time: the block is read from HBM once)
+                by_block: dict[int, list[int]] = {}
+                for f in range(F):
+                    by_block.setdefault(int(gfold[f]), []).append(f)
+                groups, order = list(by_block.values()), []
+                for i0 in range(0, len(groups), 8):
+                    chunk = groups[i0 : i0 + 8]
+                    for m in range(max(len(gr) for gr in chunk)):
+                        order += [gr[m] if m < len(gr) else -1 for gr in chunk]
+                if -1 in order or len(chunk) != 8:  # (ragged groups: the plain order)
+                    order = list(range(F))
+                assert sorted(order) == list(range(F))
+                st["gfold"][i] = (torch.from_numpy(gfold).to(dev), gather.pop(), torch.from_numpy(np.asarray(order, dtype=np.int32)).to(dev))
             else:
                 if any((i, f) not in parent for f in range(F)):
                     raise NotImplementedError(f"layer {i}: folds that nothing reads")
@@ -443,8 +456,8 @@ class _SignedCircuit:
         for i in reversed(list(self.kind)):
             l, k = c.layers[i], self.kind[i]
             if k == "emb":
-                gfold, g = st["gfold"][i]
-                capi.call("ck_embedding_bwd", ga + 4 * st["off"][g], 1, gfold.data_ptr(), st["xt"].data_ptr(), l._scope(c.device).data_ptr(),
+                gfold, g, order = st["gfold"][i]
+                capi.call("ck_embedding_bwd", ga + 4 * st["off"][g], 1, gfold.data_ptr(), order.data_ptr(), st["xt"].data_ptr(), l._scope(c.device).data_ptr(),
                           l._table.data_ptr(), self.grads[self.wname[i]].data_ptr(), l.num_folds, B, 32, l.num_states, stream)
                 continue
             o = st["off"][i]
@@ -557,7 +570,10 @@ class HipSquaredTrainer:
                 self._signed.backward(B, -2.0 / gB, stream)
             else:
                 self._bwd_c.run(B, -2.0 / gB, stream)
-        elif part == "z":
+        elif part == "z":  # parameters of Z, its forward (no input: everything is part of the list), its backward
+            z = self.z
+            z._enqueue_params(stream)
+            z._enqueue_layers(z._bind(1), stream)
             capi.call("ck_fill_f32", self._flat_grad_z.data_ptr(), n, 0.0, stream)
             self._bwd_z.run(1, B / gB, stream)
         else:  # both gradients are there: the sum, the log-likelihood pair, the optimizer
@@ -610,15 +626,15 @@ class HipSquaredTrainer:
         if main is not cur:
             main.wait_stream(cur)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            self.z._run(None)  # (1, 1, 1)
-            self._part("z", B, gB, with_optimizer, side)
-        with torch.cuda.stream(main):
+        with torch.cuda.stream(main):  # (the long list first)
             if self._signed is not None:
                 self._signed.stage(x, main.cuda_stream)
             else:
                 self.c._run(x)  # (B, 1, 1) complex64 / fp32 in c's arena
             self._part("c", B, gB, with_optimizer, main)
+        with torch.cuda.stream(side):
+            self._part("z", B, gB, with_optimizer, side)
+        with torch.cuda.stream(main):
             main.wait_stream(side)
             self._part("end", B, gB, with_optimizer, main)
         if main is not cur:

@@ -728,9 +728,11 @@ int ck_squared_ll(const float* yc, int64_t B, int64_t stride, const float* z, do
 /* The whole backward of an Embedding layer under a logarithm in one launch (K % 32 == 0, (C + 1)(K + 1) + 2 C + 4099 words of
  * LDS; CK_ERR_UNSUPPORTED otherwise): d w[f, k, c] = (sum over the rows b with x[b, scope[f]] = c of gout[f, b, k]) / table[f, c, k],
  * 0 where nobody selected c.  gout_stride: floats between consecutive entries of gout (2: the real parts of a complex64 block);
- * gfold: NULL, or the (B, K) block of gout each fold reads (folds that were multiplied share their gradient: ck_slse_bwd). */
-int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, const int32_t* xt, const int64_t* scope, const float* table,
-                     float* dw, int F, int B, int K, int C, void* stream);
+ * gfold: NULL, or the (B, K) block of gout each fold reads (folds that were multiplied share their gradient: ck_slse_bwd);
+ * fold_order: NULL, or the fold each workgroup takes (a permutation: folds that share a block placed 8 workgroups apart run
+ * on one XCD at the same time and the second read of the block comes from its L2). */
+int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, const int32_t* fold_order, const int32_t* xt,
+                     const int64_t* scope, const float* table, float* dw, int F, int B, int K, int C, void* stream);
 /* Signed-log sum layers (cirkit_amd/csrc/ck_signed.hip): TorchCPTLayer / TorchSumLayer (arity 1) under complex-lse-sum
  * (optimized.py:171-178, inner.py:266-273, semiring.py:441-476) for circuits whose parameters are all REAL -- every value is
  * real, the reference's (log|v|, 0 or pi) is stored as fp32 log|v| in (rows, 32) blocks plus ONE sign word per row (bit k:

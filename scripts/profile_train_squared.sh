@@ -10,6 +10,7 @@ for B in ${BATCHES:-256 4096}; do
   db=$(find $OUT/prof_$B -name '*.db' | head -1)
   { echo "# python scripts/bench_train_squared.py $B   (3 + 10 steps; the first two run eagerly and size the scratch)"; grep "training step" $OUT/plain_$B.log; echo;
     python $ROOT/scripts/rocprof_summary.py "$db"; } > $OUT/stats_$B.txt
+  python $ROOT/scripts/rocprof_timeline.py "$db" opt_range_kernel > $OUT/timeline_$B.txt 2>&1
   find $OUT -name '*.db' -delete
   head -50 $OUT/stats_$B.txt
 done
