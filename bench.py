@@ -133,6 +133,8 @@ def other_configs(device, stream, B: int) -> dict:
     # Adam) and BASELINE config 4 at 1024 rows: the job form of the training step (cirkit_amd/train_jobs.py)
     out["train_step_notebook_quadgraph_cp_k64_b256"] = train_step_k64(device, stream, "notebook", 256)
     out["train_step_cfg4_b1024"] = train_step_k64(device, stream, "cfg4", 1024)
+    # BASELINE config 5 trained: loss = -mean(2 Re c(x) - Re Z), Adam, every parameter graph of c and of Z evaluated every step
+    out["train_step_cfg5_squared"] = train_step_squared(device, stream, plan5, t5, B)
     # The only forward timing the reference publishes (notebooks/compilation-options.ipynb:594):
     # QuadGraph 28x28, Categorical-256, Tucker layers, K = 64, batch 128, fold + optimize: 38.6 ms on an unnamed
     # CUDA GPU.  Different hardware and not the north-star metric, so it stays out of `vs_baseline`.
@@ -291,6 +293,56 @@ def train_step_k64(device, stream, which: str, B: int, rounds: int = 5, steps: i
         "executed_flops": flops, "frac_of_fp32_mfma": flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
         "mean_ll_first_step": float(first[0] / first[1]), "mean_ll_last_step": float(last[0] / last[1]),
         "optimizer": "adam(lr=0.01), in the job epilogues", "dtype": "f32",
+    }
+
+
+def train_step_squared(device, stream, plan_c, tensors, B: int, rounds: int = 5, steps: int = 20, settle_s: float = 0.3) -> dict:
+    """One maximum-likelihood step of the squared circuit of BASELINE config 5 through `HipSquaredTrainer`: c(x) on signed-log
+    blocks (csrc/ck_signed.hip), Z = integral |c|^2 (ConstantValue / Hadamard / TensorDot layers over Gram matrices of the
+    Embedding weights) forward and backward beside it on a second stream, one optimizer launch with a device clock; three
+    recorded launch lists replayed as hipGraphs.  Measured like `train_step_cfg2`."""
+    import time
+
+    import numpy as np
+    import torch
+
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    g = torch.Generator().manual_seed(17)
+    # (the counter-based initializer emits a few exact zeros: log 0 under autograd is NaN in the reference as well)
+    tensors = {k: np.where(np.asarray(v) == 0, np.float32(1e-2), np.asarray(v)).astype(np.float32) for k, v in tensors.items()}
+    xs = [torch.randint(0, 256, (B, 784), generator=g).to(device) for _ in range(12)]
+    with torch.cuda.stream(stream):
+        tr = HipSquaredTrainer(plan_c, tensors, device=device, lr=1e-3, optimizer="adam")
+        k, t0, first = 0, time.perf_counter(), None
+        while time.perf_counter() - t0 < settle_s or k < 10:
+            ll = tr.step(xs[k % 12])
+            if first is None:
+                first = ll.clone()
+            k += 1
+        torch.cuda.synchronize(device)
+        per_round = []
+        for _ in range(rounds):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(steps):
+                ll = tr.step(xs[k % 12])
+                k += 1
+            b.record(stream)
+            torch.cuda.synchronize(device)
+            per_round.append(a.elapsed_time(b) / steps)
+        last = ll.clone()
+        taken, dropped = tr.opt_counters()
+    ms = float(np.median(per_round))
+    return {
+        "workload": f"BASELINE config 5 (squared QuadTree-2 28x28, Embedding-256, CP-T, K=32, real parameters), batch {B}: forward + backward "
+                    "of c and of Z + Adam, parameters re-evaluated every step",
+        "form": ("c on signed-log blocks (fp32 log|v| + a sign bit, ck_signed.hip)" if tr._signed is not None else "c on complex layer-wise kernels")
+                + "; Z layer-wise on a second stream; three recorded launch lists (hipGraphs)",
+        "ms_per_step": ms, "samples_per_s": B / ms * 1e3, "ms_per_step_by_round": per_round,
+        "settle_steps": k - rounds * steps, "steps_timed_total": rounds * steps, "optimizer_steps_taken": taken, "steps_dropped": dropped,
+        "mean_ll_first_step": float(first[0] / first[1]), "mean_ll_last_step": float(last[0] / last[1]),
+        "optimizer": "adam(lr=0.001), one launch on the flat parameter buffer, device-side clock", "dtype": "f32",
     }
 
 

@@ -682,14 +682,16 @@ __global__ void __launch_bounds__(256)
 // only ever touched by the wave that owns it, so no atomics and no races; 16 waves per workgroup keep enough rows in
 // flight to stream gout at HBM rate.  K must be a multiple of 32.
 constexpr int kCatChunk = 4096;  // rows sorted at a time
+template <int GS, bool EMB>
 __global__ void __launch_bounds__(1024)
     categorical_bwd_sorted_kernel(const float* __restrict__ gout, const int32_t* __restrict__ gfold, const int32_t* __restrict__ xt,
                                   const int64_t* __restrict__ scope, float* __restrict__ dtable, int B, int K, int C, int accumulate,
-                                  const int32_t* __restrict__ fold_order, int gs, const float* __restrict__ wtable) {
-  // gs: floats between consecutive gout entries (2: the real parts of complex gradients).  wtable != nullptr (the Embedding
-  // layer under a log, ck_embedding_bwd): the result is d w (F, K, C) = hist / wtable (an entry nobody selected: 0), transposed
-  // through LDS rows of K + 1 floats.
-  const int KS = wtable != nullptr ? K + 1 : K;
+                                  const int32_t* __restrict__ fold_order, const float* __restrict__ wtable) {
+  // GS: floats between consecutive gout entries (2: the real parts of complex gradients).  EMB (the Embedding layer under a
+  // log, ck_embedding_bwd): the result is d w (F, K, C) = hist / wtable (an entry nobody selected: 0), transposed through LDS
+  // rows of K + 1 floats.  (Template parameters: the Categorical instantiation <1, false> is the kernel it was.)
+  constexpr int gs = GS;
+  const int KS = EMB ? K + 1 : K;
   extern __shared__ __attribute__((aligned(16))) float hist[];  // [C+1][KS], then the int arrays below
   int* start = reinterpret_cast<int*>(hist + (C + 1) * KS);     // [C+2] exclusive prefix of the counts
   int* cur = start + (C + 2);                                   // [C+1] scatter cursors
@@ -700,7 +702,7 @@ __global__ void __launch_bounds__(1024)
   for (int i = threadIdx.x; i < (C + 1) * KS; i += blockDim.x) hist[i] = 0.f;
   const int32_t* xrow = xt + scope[f] * static_cast<int64_t>(B);
   const float* g = gout + static_cast<int64_t>(gfold != nullptr ? gfold[f] : f) * B * K * gs;
-  const int64_t rs = static_cast<int64_t>(K) * gs;  // floats between rows
+  const int rs = K * gs;  // floats between rows
   for (int b0 = 0; b0 < B; b0 += kCatChunk) {
     const int nb = min(kCatChunk, B - b0);
     for (int i = threadIdx.x; i < C + 2; i += blockDim.x) start[i] = 0;
@@ -747,16 +749,16 @@ __global__ void __launch_bounds__(1024)
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int i = s0 + slot;
         for (; i + 6 < s1; i += 8) {
-          const float v0 = g[order[i] * rs + k * gs];
-          const float v1 = g[order[i + 2] * rs + k * gs];
-          const float v2 = g[order[i + 4] * rs + k * gs];
-          const float v3 = g[order[i + 6] * rs + k * gs];
+          const float v0 = g[static_cast<int64_t>(order[i]) * rs + k * gs];
+          const float v1 = g[static_cast<int64_t>(order[i + 2]) * rs + k * gs];
+          const float v2 = g[static_cast<int64_t>(order[i + 4]) * rs + k * gs];
+          const float v3 = g[static_cast<int64_t>(order[i + 6]) * rs + k * gs];
           a0 += v0;
           a1 += v1;
           a2 += v2;
           a3 += v3;
         }
-        for (; i < s1; i += 2) a0 += g[order[i] * rs + k * gs];
+        for (; i < s1; i += 2) a0 += g[static_cast<int64_t>(order[i]) * rs + k * gs];
         float acc = (a0 + a1) + (a2 + a3);
         acc += __shfl_xor(acc, 32, 64);
         if (slot == 0) hist[c * KS + k] += acc;
@@ -764,7 +766,7 @@ __global__ void __launch_bounds__(1024)
     }
     __syncthreads();
   }
-  if (wtable != nullptr) {
+  if constexpr (EMB) {
     const float* t = wtable + static_cast<int64_t>(f) * (C + 1) * K;
     for (int i = threadIdx.x; i < C * K; i += blockDim.x) {
       const int c = i / K, k = i - c * K;
@@ -1569,12 +1571,12 @@ int ck_categorical_bwd(const float* gout, const int32_t* gfold, const int32_t* x
     return ck::dispatch(
         [=](hipStream_t s) {
           if (lds_sorted > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(categorical_bwd_sorted_kernel),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(categorical_bwd_sorted_kernel<1, false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_sorted));
             if (e != hipSuccess) return e;
           }
-          hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds_sorted, s, gout, gfold, xt, scope, dtable, B, K, C, accumulate, fold_order,
-                             1, static_cast<const float*>(nullptr));
+          hipLaunchKernelGGL((categorical_bwd_sorted_kernel<1, false>), grid, block, lds_sorted, s, gout, gfold, xt, scope, dtable, B, K, C, accumulate,
+                             fold_order, static_cast<const float*>(nullptr));
           return hipGetLastError();
         },
         stream);
@@ -1605,13 +1607,16 @@ int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, c
   dim3 grid(F), block(1024);
   return ck::dispatch(
       [=](hipStream_t s) {
-        if (lds > 48 * 1024) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(categorical_bwd_sorted_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(160 * 1024));
-          if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(categorical_bwd_sorted_kernel, grid, block, lds, s, gout, gfold, xt, scope, dw, B, K, C, 0, fold_order, gout_stride, table);
-        return hipGetLastError();
+        auto go = [&](auto kern) {
+          if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(160 * 1024));
+            if (e != hipSuccess) return e;
+          }
+          hipLaunchKernelGGL(kern, grid, block, lds, s, gout, gfold, xt, scope, dw, B, K, C, 0, fold_order, table);
+          return hipGetLastError();
+        };
+        return gout_stride == 2 ? go(categorical_bwd_sorted_kernel<2, true>) : go(categorical_bwd_sorted_kernel<1, true>);
       },
       stream);
 }
