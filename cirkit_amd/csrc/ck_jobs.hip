@@ -159,11 +159,20 @@ __global__ void __launch_bounds__(WAVES * 64)
 
 // ---- backward -----------------------------------------------------------------------------------------------------------
 // Adam's update of one entry (torch.optim.Adam without weight decay / amsgrad; the bias corrections come from `ck_opt_tick`)
-__device__ __forceinline__ float opt_update(const ck_opt_state& o, float p, float g, float& m1, float& m2) {
+// (the step's constants once per thread: lr / bc1 and 1 / bc2, so that an entry costs v_sqrt_f32 + v_rcp_f32 -- 1 ulp each --
+//  instead of three IEEE divisions and a library square root: the Categorical epilogue updates 16 K entries per workgroup)
+struct OptK {
+  float b1, c1, b2, c2, step, rbc2, eps, lr;
+  int kind;
+};
+__device__ __forceinline__ OptK opt_k(const ck_opt_state& o) {
+  return {o.b1, 1.f - o.b1, o.b2, 1.f - o.b2, o.lr / o.bc1, 1.f / o.bc2, o.eps, o.lr, o.kind};
+}
+__device__ __forceinline__ float opt_update(const OptK& o, float p, float g, float& m1, float& m2) {
   if (o.kind == 0) return p - o.lr * g;
-  m1 = o.b1 * m1 + (1.f - o.b1) * g;
-  m2 = o.b2 * m2 + (1.f - o.b2) * g * g;
-  return p - o.lr * (m1 / o.bc1) / (sqrtf(m2 / o.bc2) + o.eps);
+  m1 = fmaf(o.b1, m1, o.c1 * g);
+  m2 = fmaf(o.b2, m2, o.c2 * g * g);
+  return fmaf(-o.step * m1, __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(m2 * o.rbc2) + o.eps), p);
 }
 
 #ifndef CK_JOBS_BWD_OCC
@@ -407,6 +416,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
   }
   // mode 2: the optimizer's update of theta and the softmax of the next step's weights, here
   const ck_opt_state os = *opt;
+  const OptK ok = opt_k(os);
   if (os.skip_now) return;
   float th[kEPT];
   float mx = -INFINITY;
@@ -418,10 +428,10 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
       a4 = pm1[k >> 2];
       b4 = pm2[k >> 2];
     }
-    th[k] = opt_update(os, t4.x, dv[k], a4.x, b4.x);
-    th[k + 1] = opt_update(os, t4.y, dv[k + 1], a4.y, b4.y);
-    th[k + 2] = opt_update(os, t4.z, dv[k + 2], a4.z, b4.z);
-    th[k + 3] = opt_update(os, t4.w, dv[k + 3], a4.w, b4.w);
+    th[k] = opt_update(ok, t4.x, dv[k], a4.x, b4.x);
+    th[k + 1] = opt_update(ok, t4.y, dv[k + 1], a4.y, b4.y);
+    th[k + 2] = opt_update(ok, t4.z, dv[k + 2], a4.z, b4.z);
+    th[k + 3] = opt_update(ok, t4.w, dv[k + 3], a4.w, b4.w);
     ck::gstore4(J.theta + o * kU + c0 + k, make_float4(th[k], th[k + 1], th[k + 2], th[k + 3]));
     if (os.kind != 0) {
       ck::gstore4(J.m1 + o * kU + c0 + k, a4);
@@ -593,12 +603,13 @@ __global__ void __launch_bounds__(256)
     return;
   }
   const ck_opt_state os = *opt;
+  const OptK ok = opt_k(os);
   if (os.skip_now) return;
   float mx = -INFINITY;
   for (int h = 0; h < H; ++h) {
     const float g = w_s[k * 17 + h] * (dw_s[k * HMAX + h] - s);
     float a = os.kind ? J.m1[k * H + h] : 0.f, v = os.kind ? J.m2[k * H + h] : 0.f;
-    const float th = opt_update(os, J.theta[k * H + h], g, a, v);
+    const float th = opt_update(ok, J.theta[k * H + h], g, a, v);
     J.theta[k * H + h] = th;
     if (os.kind) {
       J.m1[k * H + h] = a;
@@ -633,13 +644,14 @@ __global__ void __launch_bounds__(64) jobs_mix_params_kernel(const MixJob* __res
     return;
   }
   const ck_opt_state os = *opt;
+  const OptK ok = opt_k(os);
   if (os.skip_now) return;
   float th[16];
   float mx = -INFINITY;
   for (int h = 0; h < H; ++h) {
     const float g = w[h] * (dw[h] - s);
     float a = os.kind ? J.m1[k * H + h] : 0.f, v = os.kind ? J.m2[k * H + h] : 0.f;
-    th[h] = opt_update(os, J.theta[k * H + h], g, a, v);
+    th[h] = opt_update(ok, J.theta[k * H + h], g, a, v);
     J.theta[k * H + h] = th[h];
     if (os.kind) {
       J.m1[k * H + h] = a;
@@ -808,6 +820,7 @@ __global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) 
     return;
   }
   const ck_opt_state os = a.mode == 2 ? *a.opt : ck_opt_state{};
+  const OptK ok = opt_k(os);
   if (a.mode == 2 && os.skip_now) return;
   // softmax behind every weight row (wave w takes folds w, w + 4, ...) ...
   for (int r = wave; r < R; r += 4) {
@@ -818,7 +831,7 @@ __global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) 
       a.dtheta_w[r][lane] = g;
     } else {
       float m1 = os.kind ? a.m1_w[r][lane] : 0.f, m2 = os.kind ? a.m2_w[r][lane] : 0.f;
-      const float th = opt_update(os, a.theta_w[r][lane], g, m1, m2);
+      const float th = opt_update(ok, a.theta_w[r][lane], g, m1, m2);
       a.theta_w[r][lane] = th;
       if (os.kind) {
         a.m1_w[r][lane] = m1;
@@ -840,7 +853,7 @@ __global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) 
       if (on) a.dtheta_c[lane] = g;
     } else {
       float m1 = (on && os.kind) ? a.m1_c[lane] : 0.f, m2 = (on && os.kind) ? a.m2_c[lane] : 0.f;
-      const float th = on ? opt_update(os, a.theta_c[lane], g, m1, m2) : -INFINITY;
+      const float th = on ? opt_update(ok, a.theta_c[lane], g, m1, m2) : -INFINITY;
       const float mx = ck::wave_max(th);
       const float ex = on ? expf(th - mx) : 0.f;
       const float sum = ck::wave_sum(ex);
@@ -880,6 +893,8 @@ __global__ void __launch_bounds__(1024)
   int* order = cur + nkeys;                                 // [kCatRows]
   int* keys = order + kCatRows;                             // [kCatRows]
   const ck_cat_job& J = jobs[blockIdx.x];
+  const int cshift = (C & (C - 1)) == 0 ? 31 - __clz(C) : -1;  // entry e = k C + c of theta (64, C): shifts where C is a power of two
+  auto unit_of = [&](int e) { return cshift >= 0 ? e >> cshift : e / C; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < (C + 1) * kHS; i += 1024) hist[i] = 0.f;
   const int g_off = J.g_off, n_g = J.n_g;
@@ -927,19 +942,35 @@ __global__ void __launch_bounds__(1024)
       keys[pos] = key;
     }
     __syncthreads();
-    {  // this wave's rows: positions [start[wave per], start[(wave + 1) per]), lane = unit
+#ifndef CK_CAT_LAB
+#define CK_CAT_LAB 0
+#endif
+    if (!(CK_CAT_LAB & 1)) {  // this wave's rows: positions [start[wave per], start[(wave + 1) per]), lane = unit
       const int s0 = start[wave * per], s1 = start[(wave + 1) * per];
       int cur_key = -1;
       float acc = 0.f;
       for (int i = s0; i < s1; i += 8) {
         float v[8];
+        int64_t row[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           v[u] = 0.f;
-          if (i + u < s1) {
-            const int64_t row = order[i + u];
-            for (int s2 = 0; s2 < n_g; ++s2) v[u] += *ck::as_global(pool[g_off + s2] + row * kU + lane);
-          }
+          row[u] = i + u < s1 ? order[i + u] : -1;
+        }
+        // (four blocks of the list at a time: 32 independent loads in flight -- a loop over the list inside the loop over the rows
+        //  is a load, a wait and an add per (row, block): 75 us of this launch at 256 rows and lists of 2 .. 4)
+        for (int s2 = 0; s2 < n_g; s2 += 4) {
+          const float* gp[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gp[q] = pool[g_off + min(s2 + q, n_g - 1)];
+          float x[8][4];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              x[u][q] = (row[u] >= 0 && s2 + q < n_g) ? *ck::as_global(gp[q] + row[u] * kU + lane) : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = (((v[u] + x[u][0]) + x[u][1]) + x[u][2]) + x[u][3];  // (list order, as before)
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -958,6 +989,7 @@ __global__ void __launch_bounds__(1024)
     }
     __syncthreads();
   }
+  if (CK_CAT_LAB & 2) return;
   // column sums over the C categories (the integral row C carries no parameter) and the forward's log-normalisers
   {
     float t = 0.f;
@@ -984,14 +1016,15 @@ __global__ void __launch_bounds__(1024)
       for (int u = 0; u < 4; ++u) {
         const int e = e0 + 1024 * u;
         if (e < n) {
-          const int k = e / C, c = e - k * C;
-          *ck::as_global(J.dtheta + e) = hist[c * kHS + k] - expf(th[u] - lse[k]) * tk[k];
+          const int k = unit_of(e), c = e - k * C;
+          *ck::as_global(J.dtheta + e) = hist[c * kHS + k] - __expf(th[u] - lse[k]) * tk[k];
         }
       }
     }
     return;
   }
   const ck_opt_state os = *opt;
+  const OptK ok = opt_k(os);
   if (os.skip_now) return;
   for (int e0 = threadIdx.x; e0 < n; e0 += 4096) {
     float th[4], a[4], b[4];
@@ -1006,9 +1039,9 @@ __global__ void __launch_bounds__(1024)
     for (int u = 0; u < 4; ++u) {
       const int e = e0 + 1024 * u;
       if (e < n) {
-        const int k = e / C, c = e - k * C;
-        const float g = hist[c * kHS + k] - expf(th[u] - lse[k]) * tk[k];
-        const float t = opt_update(os, th[u], g, a[u], b[u]);
+        const int k = unit_of(e), c = e - k * C;
+        const float g = hist[c * kHS + k] - __expf(th[u] - lse[k]) * tk[k];
+        const float t = opt_update(ok, th[u], g, a[u], b[u]);
         *ck::as_global(J.theta_out + e) = t;
         if (os.kind) {
           *ck::as_global(J.m1 + e) = a[u];
@@ -1019,6 +1052,7 @@ __global__ void __launch_bounds__(1024)
     }
   }
   __syncthreads();
+  if (CK_CAT_LAB & 4) return;
   {  // log-sum-exp over the categories of every unit: wave w takes c = w, w + 16, ...
     float mx = -INFINITY;
     for (int c = wave; c < C; c += 16) mx = fmaxf(mx, hist[c * kHS + lane]);
@@ -1032,7 +1066,7 @@ __global__ void __launch_bounds__(1024)
     }
     __syncthreads();
     float sm = 0.f;
-    for (int c = wave; c < C; c += 16) sm += expf(hist[c * kHS + lane] - tk[lane]);
+    for (int c = wave; c < C; c += 16) sm += __expf(hist[c * kHS + lane] - tk[lane]);
     __syncthreads();
     red[wave * kU + lane] = sm;
     __syncthreads();
@@ -1105,12 +1139,13 @@ __global__ void __launch_bounds__(256)
     return;
   }
   const ck_opt_state os = *opt;
+  const OptK ok = opt_k(os);
   if (os.skip_now) return;
   float* th = which == 0 ? J.th_mean : J.th_sd;
   float* m1 = which == 0 ? J.m1_mean : J.m1_sd;
   float* m2 = which == 0 ? J.m2_mean : J.m2_sd;
   float a = os.kind ? m1[k] : 0.f, b2 = os.kind ? m2[k] : 0.f;
-  const float t = opt_update(os, th[k], g, a, b2);
+  const float t = opt_update(ok, th[k], g, a, b2);
   th[k] = t;
   if (os.kind) {
     m1[k] = a;
@@ -1129,10 +1164,11 @@ __global__ void __launch_bounds__(256)
     opt_range_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, int64_t n,
                      const ck_opt_state* __restrict__ opt) {
   const ck_opt_state os = *opt;
+  const OptK ok = opt_k(os);
   if (os.skip_now) return;
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
     float a = os.kind ? m1[i] : 0.f, b = os.kind ? m2[i] : 0.f;
-    p[i] = opt_update(os, p[i], g[i], a, b);
+    p[i] = opt_update(ok, p[i], g[i], a, b);
     if (os.kind) {
       m1[i] = a;
       m2[i] = b;
