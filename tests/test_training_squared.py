@@ -270,3 +270,61 @@ def test_squared_trainer_zero_embedding_weight_nobody_selects(hip_device):
         tr._bwd_c.run(int(x.shape[0]), -2.0 / int(x.shape[0]), torch.cuda.current_stream(tr.device).cuda_stream)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(tr._flat_grad).all())
+
+
+def _dp_squared_worker(rank, world, port, out_path, signed):
+    import torch.distributed as dist
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cirkit_amd.distributed import init_from_env, shard_bounds
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    init_from_env("gloo")  # both ranks share the one GPU of the test box; the exchange goes through gloo
+    plan_c, tensors, x = _cfg5_case(64)
+    lo, hi = shard_bounds(len(x), rank, world)
+    tr = HipSquaredTrainer(plan_c, tensors, device="cuda:0", optimizer="sgd", lr=1e-4, signed=signed)
+    for _ in range(3):
+        tr.step(x[lo:hi].to("cuda:0"), global_batch=len(x))
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(out_path, **tr.parameters())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _cfg5_case(B):
+    plan_c = Plan.load(os.path.join(GOLDEN, "cfg5_sos_c_k32"))
+    tensors = {k: np.where(v == 0, np.float32(1e-2), v).astype(np.float32) for k, v in init_plan_tensors(plan_c).items()}
+    return plan_c, tensors, torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(9))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("signed", [False, True])
+def test_squared_trainer_data_parallel_equals_single_process(hip_device, tmp_path, signed):
+    """Two ranks, the batch sharded 32 + 32 (`global_batch`): each adds its rows' gradients of c and its share of Z's, ONE
+    all-reduce of the flat gradient, the optimizer launch on every rank -- after three SGD steps the parameters are those of one
+    process on the whole batch (which runs the optimizer inside its recorded list)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp_sq.npz")
+    mp.spawn(_dp_squared_worker, args=(2, port, out, signed), nprocs=2, join=True)
+    plan_c, tensors, x = _cfg5_case(64)
+    tr = HipSquaredTrainer(plan_c, tensors, device=hip_device, optimizer="sgd", lr=1e-4, signed=signed)
+    for _ in range(3):
+        tr.step(x.to(hip_device))
+    torch.cuda.synchronize()
+    one = tr.parameters()
+    with np.load(out) as z:
+        two = {k: z[k] for k in one}
+    for k in one:
+        moved = float(np.abs(one[k] - tensors[k]).max())
+        assert moved > 0.0, k
+        # (the two runs add the rows' gradients in different orders: fp32 rounding of the sums, a fraction of the step)
+        assert float(np.abs(one[k] - two[k]).max()) <= 2e-3 * moved + 1e-7, (k, float(np.abs(one[k] - two[k]).max()), moved)
