@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -254,7 +254,10 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_embedding_weight_bwd": [_p, _p, _p, _i, _i, _i, _p],
     "ck_squared_ll": [_p, _l, _l, _p, _p, _p],
     "ck_embedding_bwd": [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "ck_tensordot_lse_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_tensordot_lse_fwd_h": [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_tensordot2_lse_fwd": [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_tensordot_lse_bwd": [_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_tensordot2_lse_bwd": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_slse_table": [_p, _p, _p, _l, _p],
     "ck_slse_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "ck_slse_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],

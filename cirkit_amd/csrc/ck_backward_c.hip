@@ -246,14 +246,21 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// TensorDot backward on the layer's own layout (TorchTensorDotLayer, optimized.py:289-296: x (B, Kj, Kq), per (b, q) a dense sum
-// over j with weights W (Kk, Kj), out (B, Kq, Kk)): one workgroup per (fold, batch row), everything in LDS -- instead of a
-// transposed copy of x, the dense kernel on its rows (b, q) and a transposed copy of the gradient back.  T: c32 (complex-lse-sum:
-// the conventions of sum_clse_bwd_kernel above, REAL weights) or float (lse-sum).
+// TensorDot layers on their own layout (TorchTensorDotLayer, optimized.py:289-296: x (B, Kj, Kq), per (b, q) a dense sum over j
+// with weights W (Kk, Kj), out (B, Kq, Kk)) for the partition function of a squared circuit -- one row, a chain of ~30 such
+// layers, every launch a fixed cost: one workgroup per (fold, batch row), everything in LDS, and
+//   * the Hadamard layer beneath (inner.py:126-127: a sum of H children in log space) read as a list of H blocks, its gradient
+//     written to all of them (the layer itself is never launched);
+//   * the PAIR of TensorDot layers a squared sum layer becomes (one over W, one over conj W: M' = W M W^T) in ONE launch, the
+//     block between them handed over through memory inside the workgroup;
+//   * the backward without transposed copies (the dense backward on rows (b, q) needs x permuted and permutes the gradient back).
+// S: the arithmetic -- TdC: complex-lse-sum (the conventions of sum_clse_bwd_kernel above, REAL weights), TdR: lse-sum.
 struct TdC {
   using T = c32;
   static __device__ __forceinline__ float re(c32 a) { return a.re; }
+  static __device__ __forceinline__ c32 add(c32 a, c32 b) { return ck::c_add(a, b); }
   static __device__ __forceinline__ c32 exp_shift(c32 v, float m) { return cexp({v.re - m, v.im}); }                 // a
+  static __device__ __forceinline__ c32 log_shift(c32 y, float m) { return ck::c_log_shift(y, m); }
   static __device__ __forceinline__ c32 tee(c32 y, c32 g, float m) {                                                 // t
     return (g.re == 0.f && g.im == 0.f) ? c32{0.f, 0.f} : cmul(cconj(cexp({m - y.re, -y.im})), g);
   }
@@ -265,7 +272,9 @@ struct TdC {
 struct TdR {
   using T = float;
   static __device__ __forceinline__ float re(float a) { return a; }
+  static __device__ __forceinline__ float add(float a, float b) { return a + b; }
   static __device__ __forceinline__ float exp_shift(float v, float m) { return expf(v - m); }
+  static __device__ __forceinline__ float log_shift(float y, float m) { return logf(y) + m; }
   static __device__ __forceinline__ float tee(float y, float g, float m) { return g == 0.f ? 0.f : expf(m - y) * g; }
   static __device__ __forceinline__ float zero() { return 0.f; }
   static __device__ __forceinline__ float fma_w(float w, float t, float acc) { return fmaf(w, t, acc); }
@@ -273,24 +282,21 @@ struct TdR {
   static __device__ __forceinline__ float dw(float a, float t) { return a * t; }
 };
 
+// LDS of a stage: a [Kq][Kj + 1] values, (backward) t [Kq][Kk + 1] values, W [Kk][Kj + 1] floats, m [Kq] floats
 template <class S>
-__global__ void __launch_bounds__(256)
-    tensordot_lse_bwd_kernel(const typename S::T* __restrict__ arena, typename S::T* __restrict__ garena, const int64_t* __restrict__ row_off,
-                             const float* __restrict__ w, const typename S::T* __restrict__ out, const typename S::T* __restrict__ gout,
-                             float* __restrict__ dw, int B, int Kj, int Kq, int Kk) {
-  using T = typename S::T;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* a_s = reinterpret_cast<T*>(smem);                               // [Kq][Kj + 1]: x, then a = exp(x - m_q)
-  T* t_s = a_s + static_cast<size_t>(Kq) * (Kj + 1);                 // [Kq][Kk + 1]
-  float* w_s = reinterpret_cast<float*>(t_s + static_cast<size_t>(Kq) * (Kk + 1));  // [Kk][Kj + 1]
-  float* m_s = w_s + static_cast<size_t>(Kk) * (Kj + 1);             // [Kq]
-  const int f = blockIdx.y, b = blockIdx.x;
-  const int64_t xoff = row_off[f] + static_cast<int64_t>(b) * Kj * Kq;
-  const float* wf = w + static_cast<int64_t>(f) * Kk * Kj;
+__host__ __device__ constexpr size_t td_lds(int Kj, int Kq, int Kk, bool bwd) {
+  return (static_cast<size_t>(Kq) * (Kj + 1) + (bwd ? static_cast<size_t>(Kq) * (Kk + 1) : 0)) * sizeof(typename S::T) +
+         (static_cast<size_t>(Kk) * (Kj + 1) + Kq) * sizeof(float);
+}
+
+// a <- exp(x - m_q) with x[j][q] = load(j Kq + q), W staged: the common first half of both directions
+template <class S, class Load>
+__device__ __forceinline__ void td_stage(typename S::T* a_s, float* w_s, float* m_s, Load&& load, const float* __restrict__ wf, int Kj, int Kq,
+                                         int Kk) {
   for (int i = threadIdx.x; i < Kk * Kj; i += 256) w_s[(i / Kj) * (Kj + 1) + i % Kj] = wf[i];
   for (int i = threadIdx.x; i < Kj * Kq; i += 256) {  // coalesced read of x[j][q]
     const int j = i / Kq, q = i - j * Kq;
-    a_s[q * (Kj + 1) + j] = arena[xoff + i];
+    a_s[q * (Kj + 1) + j] = load(i);
   }
   __syncthreads();
   for (int q = threadIdx.x; q < Kq; q += 256) {
@@ -303,56 +309,189 @@ __global__ void __launch_bounds__(256)
     const int q = i / Kj, j = i - q * Kj;
     a_s[q * (Kj + 1) + j] = S::exp_shift(a_s[q * (Kj + 1) + j], m_s[q]);
   }
-  const int64_t ooff = (static_cast<int64_t>(f) * B + b) * Kq * Kk;
+}
+
+template <class S, class Load>
+__device__ __forceinline__ void td_fwd_body(char* smem, Load&& load, const float* __restrict__ wf, typename S::T* __restrict__ dst, int Kj, int Kq,
+                                            int Kk) {
+  using T = typename S::T;
+  T* a_s = reinterpret_cast<T*>(smem);
+  float* w_s = reinterpret_cast<float*>(a_s + static_cast<size_t>(Kq) * (Kj + 1));
+  float* m_s = w_s + static_cast<size_t>(Kk) * (Kj + 1);
+  td_stage<S>(a_s, w_s, m_s, load, wf, Kj, Kq, Kk);
+  __syncthreads();
   for (int i = threadIdx.x; i < Kq * Kk; i += 256) {
     const int q = i / Kk, k = i - q * Kk;
-    t_s[q * (Kk + 1) + k] = S::tee(out[ooff + i], gout[ooff + i], m_s[q]);
+    T acc = S::zero();
+    for (int j = 0; j < Kj; ++j) acc = S::fma_w(w_s[k * (Kj + 1) + j], a_s[q * (Kj + 1) + j], acc);
+    dst[i] = S::log_shift(acc, m_s[q]);
+  }
+}
+
+// store(i, g): the gradient of x[i]; dwf: the fold's (Kk, Kj) weight gradient, added with float atomics
+template <class S, class Load, class Store>
+__device__ __forceinline__ void td_bwd_body(char* smem, Load&& load, Store&& store, const float* __restrict__ wf,
+                                            const typename S::T* __restrict__ out, const typename S::T* __restrict__ gout, float* __restrict__ dwf,
+                                            int Kj, int Kq, int Kk) {
+  using T = typename S::T;
+  T* a_s = reinterpret_cast<T*>(smem);
+  T* t_s = a_s + static_cast<size_t>(Kq) * (Kj + 1);
+  float* w_s = reinterpret_cast<float*>(t_s + static_cast<size_t>(Kq) * (Kk + 1));
+  float* m_s = w_s + static_cast<size_t>(Kk) * (Kj + 1);
+  td_stage<S>(a_s, w_s, m_s, load, wf, Kj, Kq, Kk);
+  for (int i = threadIdx.x; i < Kq * Kk; i += 256) {
+    const int q = i / Kk, k = i - q * Kk;
+    t_s[q * (Kk + 1) + k] = S::tee(out[i], gout[i], m_s[q]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < Kj * Kq; i += 256) {  // the gradient of x[j][q], written in x's layout
+  for (int i = threadIdx.x; i < Kj * Kq; i += 256) {  // the gradient of x[j][q], in x's layout
     const int j = i / Kq, q = i - j * Kq;
     T acc = S::zero();
     for (int k = 0; k < Kk; ++k) acc = S::fma_w(w_s[k * (Kj + 1) + j], t_s[q * (Kk + 1) + k], acc);
-    garena[xoff + i] = S::child(a_s[q * (Kj + 1) + j], acc);
+    store(i, S::child(a_s[q * (Kj + 1) + j], acc));
   }
   for (int i = threadIdx.x; i < Kk * Kj; i += 256) {
     const int k = i / Kj, j = i - k * Kj;
     float acc = 0.f;
     for (int q = 0; q < Kq; ++q) acc += S::dw(a_s[q * (Kj + 1) + j], t_s[q * (Kk + 1) + k]);
-    if (acc != 0.f) atomicAdd(dw + static_cast<int64_t>(f) * Kk * Kj + i, acc);
+    if (acc != 0.f) atomicAdd(dwf + i, acc);
   }
 }
 
-template <class S>
-int launch_tensordot_bwd(const typename S::T* arena, typename S::T* garena, const int64_t* row_off, const float* w, const typename S::T* out,
-                         const typename S::T* gout, float* dw, int F, int B, int Kj, int Kq, int Kk, void* stream) {
-  CK_REQUIRE(arena && garena && row_off && w && out && gout && dw, "ck_tensordot_lse_bwd: null pointer");
-  CK_REQUIRE(F > 0 && F <= 65535 && B > 0 && Kj > 0 && Kq > 0 && Kk > 0, "ck_tensordot_lse_bwd: bad sizes");
-  const size_t lds = (static_cast<size_t>(Kq) * (Kj + 1) + static_cast<size_t>(Kq) * (Kk + 1)) * sizeof(typename S::T) +
-                     (static_cast<size_t>(Kk) * (Kj + 1) + Kq) * sizeof(float);
-  if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_tensordot_lse_bwd: Kj=%d, Kq=%d, Kk=%d do not fit in LDS", Kj, Kq, Kk);
+// One or two stages.  Stage 1: x = the sum of the H blocks arena + row_off[f, h] (+ b Kj Kq), weights w1 (F, Kk1, Kj), output
+// (Kq, Kk1) -- to `out`, or with TWO to `mid`; stage 2 reads it as (Kj2 = Kq, Kq2 = Kk1), weights w2 (F, Kk2, Kq), output (Kk1, Kk2).
+template <class S, bool TWO>
+__global__ void __launch_bounds__(256)
+    td_fwd_kernel(const typename S::T* __restrict__ arena, const int64_t* __restrict__ row_off, int H, const float* __restrict__ w1,
+                  typename S::T* __restrict__ mid, const float* __restrict__ w2, typename S::T* __restrict__ out, int B, int Kj, int Kq, int Kk1,
+                  int Kk2) {
+  using T = typename S::T;
+  extern __shared__ __attribute__((aligned(16))) char td_smem[];
+  const int f = blockIdx.y, b = blockIdx.x;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t boff = static_cast<int64_t>(b) * Kj * Kq;
+  auto load1 = [&](int i) {
+    T v = arena[ro[0] + boff + i];
+    for (int h = 1; h < H; ++h) v = S::add(v, arena[ro[h] + boff + i]);
+    return v;
+  };
+  T* o1 = (TWO ? mid : out) + (static_cast<int64_t>(f) * B + b) * Kq * Kk1;
+  td_fwd_body<S>(td_smem, load1, w1 + static_cast<int64_t>(f) * Kk1 * Kj, o1, Kj, Kq, Kk1);
+  if constexpr (TWO) {
+    __syncthreads();  // (the block between the stages: written and read by this workgroup only)
+    const T* m1 = o1;
+    td_fwd_body<S>(td_smem, [&](int i) { return m1[i]; }, w2 + static_cast<int64_t>(f) * Kk2 * Kq,
+                   out + (static_cast<int64_t>(f) * B + b) * Kk1 * Kk2, Kq, Kk1, Kk2);
+  }
+}
+
+template <class S, bool TWO>
+__global__ void __launch_bounds__(256)
+    td_bwd_kernel(const typename S::T* __restrict__ arena, typename S::T* __restrict__ garena, const int64_t* __restrict__ row_off, int H,
+                  const float* __restrict__ w1, const typename S::T* __restrict__ mid, typename S::T* __restrict__ gmid, const float* __restrict__ w2,
+                  const typename S::T* __restrict__ out, const typename S::T* __restrict__ gout, float* __restrict__ dw1, float* __restrict__ dw2,
+                  int B, int Kj, int Kq, int Kk1, int Kk2) {
+  using T = typename S::T;
+  extern __shared__ __attribute__((aligned(16))) char td_smem[];
+  const int f = blockIdx.y, b = blockIdx.x;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t boff = static_cast<int64_t>(b) * Kj * Kq;
+  const int64_t o1 = (static_cast<int64_t>(f) * B + b) * Kq * Kk1;
+  const T* y1 = (TWO ? mid : out) + o1;   // stage 1's output and its gradient
+  const T* g1 = (TWO ? gmid : gout) + o1;
+  if constexpr (TWO) {
+    const int64_t o2 = (static_cast<int64_t>(f) * B + b) * Kk1 * Kk2;
+    T* gm = gmid + o1;
+    td_bwd_body<S>(td_smem, [&](int i) { return y1[i]; }, [&](int i, T g) { gm[i] = g; }, w2 + static_cast<int64_t>(f) * Kk2 * Kq,
+                   out + o2, gout + o2, dw2 + static_cast<int64_t>(f) * Kk2 * Kq, Kq, Kk1, Kk2);
+    __syncthreads();
+  }
+  auto load1 = [&](int i) {
+    T v = arena[ro[0] + boff + i];
+    for (int h = 1; h < H; ++h) v = S::add(v, arena[ro[h] + boff + i]);
+    return v;
+  };
+  auto store1 = [&](int i, T g) {
+    for (int h = 0; h < H; ++h) garena[ro[h] + boff + i] = g;  // (every factor of the product receives the same gradient)
+  };
+  td_bwd_body<S>(td_smem, load1, store1, w1 + static_cast<int64_t>(f) * Kk1 * Kj, y1, g1, dw1 + static_cast<int64_t>(f) * Kk1 * Kj, Kj, Kq, Kk1);
+}
+
+template <class S, bool TWO, bool BWD>
+int td_launch(const typename S::T* arena, typename S::T* garena, const int64_t* row_off, int H, const float* w1, typename S::T* mid,
+              typename S::T* gmid, const float* w2, typename S::T* out, const typename S::T* gout, float* dw1, float* dw2, int F, int B, int Kj,
+              int Kq, int Kk1, int Kk2, void* stream, const char* who) {
+  CK_REQUIRE(arena && row_off && w1 && out, "%s: null pointer", who);
+  CK_REQUIRE(!TWO || (mid && w2), "%s: null pointer", who);
+  CK_REQUIRE(!BWD || (garena && gout && dw1 && (!TWO || (gmid && dw2))), "%s: null pointer", who);
+  CK_REQUIRE(F > 0 && F <= 65535 && H > 0 && B > 0 && Kj > 0 && Kq > 0 && Kk1 > 0 && (!TWO || Kk2 > 0), "%s: bad sizes", who);
+  size_t lds = td_lds<S>(Kj, Kq, Kk1, BWD);
+  if (TWO) lds = std::max(lds, td_lds<S>(Kq, Kk1, Kk2, BWD));
+  if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "%s: Kj=%d, Kq=%d, Kk=%d, %d do not fit in LDS", who, Kj, Kq, Kk1, Kk2);
   const dim3 grid(B, F), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        auto kern = tensordot_lse_bwd_kernel<S>;
-        if (lds > 48 * 1024) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-          if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, grid, block, lds, s, arena, garena, row_off, w, out, gout, dw, B, Kj, Kq, Kk);
-        return hipGetLastError();
+        auto go = [&](auto kern, auto&&... args) {
+          if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+          }
+          hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
+          return hipGetLastError();
+        };
+        if constexpr (BWD)
+          return go(td_bwd_kernel<S, TWO>, arena, garena, row_off, H, w1, static_cast<const typename S::T*>(mid), gmid, w2,
+                    static_cast<const typename S::T*>(out), gout, dw1, dw2, B, Kj, Kq, Kk1, Kk2);
+        else
+          return go(td_fwd_kernel<S, TWO>, arena, row_off, H, w1, mid, w2, out, B, Kj, Kq, Kk1, Kk2);
       },
       stream);
 }
 
 }  // namespace
 
-extern "C" int ck_tensordot_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* w, const float* out,
-                                    const float* gout, float* dw, int F, int B, int Kj, int Kq, int Kk, int complex_values, void* stream) {
+extern "C" int ck_tensordot_lse_fwd_h(const float* arena, const int64_t* row_off, int H, const float* w, float* out, int F, int B, int Kj,
+                                      int Kq, int Kk, int complex_values, void* stream) {
+  const char* who = "ck_tensordot_lse_fwd_h";
   if (complex_values)
-    return launch_tensordot_bwd<TdC>(reinterpret_cast<const ck::c32*>(arena), reinterpret_cast<ck::c32*>(garena), row_off, w,
-                                     reinterpret_cast<const ck::c32*>(out), reinterpret_cast<const ck::c32*>(gout), dw, F, B, Kj, Kq, Kk, stream);
-  return launch_tensordot_bwd<TdR>(arena, garena, row_off, w, out, gout, dw, F, B, Kj, Kq, Kk, stream);
+    return td_launch<TdC, false, false>(reinterpret_cast<const ck::c32*>(arena), nullptr, row_off, H, w, nullptr, nullptr, nullptr,
+                                        reinterpret_cast<ck::c32*>(out), nullptr, nullptr, nullptr, F, B, Kj, Kq, Kk, 0, stream, who);
+  return td_launch<TdR, false, false>(arena, nullptr, row_off, H, w, nullptr, nullptr, nullptr, out, nullptr, nullptr, nullptr, F, B, Kj, Kq, Kk, 0,
+                                      stream, who);
+}
+
+extern "C" int ck_tensordot2_lse_fwd(const float* arena, const int64_t* row_off, int H, const float* w1, float* mid, const float* w2, float* out,
+                                     int F, int B, int Kj, int Kq, int Kk1, int Kk2, int complex_values, void* stream) {
+  const char* who = "ck_tensordot2_lse_fwd";
+  if (complex_values)
+    return td_launch<TdC, true, false>(reinterpret_cast<const ck::c32*>(arena), nullptr, row_off, H, w1, reinterpret_cast<ck::c32*>(mid), nullptr,
+                                       w2, reinterpret_cast<ck::c32*>(out), nullptr, nullptr, nullptr, F, B, Kj, Kq, Kk1, Kk2, stream, who);
+  return td_launch<TdR, true, false>(arena, nullptr, row_off, H, w1, mid, nullptr, w2, out, nullptr, nullptr, nullptr, F, B, Kj, Kq, Kk1, Kk2, stream,
+                                     who);
+}
+
+extern "C" int ck_tensordot_lse_bwd(const float* arena, float* garena, const int64_t* row_off, int H, const float* w, const float* out,
+                                    const float* gout, float* dw, int F, int B, int Kj, int Kq, int Kk, int complex_values, void* stream) {
+  const char* who = "ck_tensordot_lse_bwd";
+  if (complex_values)
+    return td_launch<TdC, false, true>(reinterpret_cast<const ck::c32*>(arena), reinterpret_cast<ck::c32*>(garena), row_off, H, w, nullptr, nullptr,
+                                       nullptr, reinterpret_cast<ck::c32*>(const_cast<float*>(out)), reinterpret_cast<const ck::c32*>(gout), dw,
+                                       nullptr, F, B, Kj, Kq, Kk, 0, stream, who);
+  return td_launch<TdR, false, true>(arena, garena, row_off, H, w, nullptr, nullptr, nullptr, const_cast<float*>(out), gout, dw, nullptr, F, B, Kj, Kq,
+                                     Kk, 0, stream, who);
+}
+
+extern "C" int ck_tensordot2_lse_bwd(const float* arena, float* garena, const int64_t* row_off, int H, const float* w1, const float* mid,
+                                     float* gmid, const float* w2, const float* out, const float* gout, float* dw1, float* dw2, int F, int B,
+                                     int Kj, int Kq, int Kk1, int Kk2, int complex_values, void* stream) {
+  const char* who = "ck_tensordot2_lse_bwd";
+  if (complex_values)
+    return td_launch<TdC, true, true>(reinterpret_cast<const ck::c32*>(arena), reinterpret_cast<ck::c32*>(garena), row_off, H, w1,
+                                      reinterpret_cast<ck::c32*>(const_cast<float*>(mid)), reinterpret_cast<ck::c32*>(gmid), w2,
+                                      reinterpret_cast<ck::c32*>(const_cast<float*>(out)), reinterpret_cast<const ck::c32*>(gout), dw1, dw2, F, B,
+                                      Kj, Kq, Kk1, Kk2, stream, who);
+  return td_launch<TdR, true, true>(arena, garena, row_off, H, w1, const_cast<float*>(mid), gmid, w2, const_cast<float*>(out), gout, dw1, dw2, F, B, Kj,
+                                    Kq, Kk1, Kk2, stream, who);
 }
 
 extern "C" int ck_sum_lse_bwd_c(const float* arena_c, float* garena_c, const int64_t* row_off, const float* w, const float* out_c,

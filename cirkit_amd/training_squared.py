@@ -71,6 +71,40 @@ class _PlanBackward:
                     raise NotImplementedError("squared-circuit training: Gaussian layers need lse-sum and no log-partition parameter")
             elif not isinstance(l, (HipEmbeddingLayer, HipConstantValueLayer, HipHadamardLayer, HipTensorDotLayer)):
                 raise NotImplementedError(f"squared-circuit training: layer type {spec.type!r}")
+        # What the TensorDot launches take over (ck_tensordot_lse_fwd_h / ck_tensordot2_*): `had_of[a] = h`: the Hadamard layer h
+        # whose folds TensorDot layer a reads one to one and nobody else reads -- a reads h's children as a list, h is never
+        # launched; `pair_of[b] = a`: TensorDot layer b over TensorDot layer a, fold by fold, a read by nobody else (the W and
+        # conj W halves of a squared sum layer): one launch for both.
+        readers: dict[int, set[int]] = {}
+        for j, ch in enumerate(c._children):
+            if ch is not None:
+                for p in np.unique(ch[..., 0]):
+                    readers.setdefault(int(p), set()).add(j)
+
+        def one_to_one(j: int):
+            ch = c._children[j]
+            if ch is None or ch.shape[1] != 1 or len(np.unique(ch[..., 0])) != 1:
+                return None
+            p = int(ch[0, 0, 0])
+            if c.layers[p].num_folds != c.layers[j].num_folds or not np.array_equal(ch[:, 0, 1], np.arange(c.layers[j].num_folds)):
+                return None
+            return p if readers.get(p) == {j} and p != po else None
+
+        self.had_of: dict[int, int] = {}
+        self.pair_of: dict[int, int] = {}
+        for j, l in enumerate(c.layers):
+            if not isinstance(l, HipTensorDotLayer):
+                continue
+            p = one_to_one(j)
+            if p is None:
+                continue
+            lp = c.layers[p]
+            if isinstance(lp, HipHadamardLayer):
+                self.had_of[j] = p
+            elif (isinstance(lp, HipTensorDotLayer) and p not in self.pair_of and l._num_contract_units == lp._num_batch_units
+                  and l._num_batch_units == lp.num_output_units // lp._num_batch_units):
+                self.pair_of[j] = p
+        self._skip = set(self.had_of.values()) | set(self.pair_of.values())
 
     def _bind(self, B: int) -> dict:
         bd = self.c._bind(B)
@@ -128,6 +162,41 @@ class _PlanBackward:
             self._bound.pop(next(iter(self._bound)))
         self._bound[B] = st
         return st
+
+    def _td_args(self, i: int, bd):
+        """(row offsets, list length) of TensorDot layer i's input: its own block, or the children of the Hadamard layer it absorbs."""
+        h = self.had_of.get(i)
+        return (bd.row_off[i].data_ptr(), 1) if h is None else (bd.row_off[h].data_ptr(), self.c.layers[h].arity)
+
+    def forward(self, B: int, stream: int) -> None:
+        """The layer launches of a circuit WITHOUT input variables (the partition function: `HipCircuit._enqueue_layers` with the
+        Hadamard layers read as lists and the TensorDot pairs in one launch each); the parameters must have been evaluated."""
+        c = self.c
+        if c.plan.num_variables:
+            raise NotImplementedError("_PlanBackward.forward: circuits with input variables go through HipCircuit")
+        bd = c._bind(B)
+        aa, cv = bd.arena.data_ptr(), 1 if self.cplx else 0
+        for i, l in enumerate(c.layers):
+            if i in self._skip:
+                continue
+            if isinstance(l, HipTensorDotLayer):
+                if l._w.is_complex():
+                    raise NotImplementedError("squared-circuit training: complex-valued weights")
+                a = self.pair_of.get(i)
+                if a is None:
+                    ro, H = self._td_args(i, bd)
+                    capi.call("ck_tensordot_lse_fwd_h", aa, ro, H, l._w.data_ptr(), bd.views[i].data_ptr(), l.num_folds, B,
+                              l._num_contract_units, l._num_batch_units, l.num_output_units // l._num_batch_units, cv, stream)
+                else:
+                    la = c.layers[a]
+                    ro, H = self._td_args(a, bd)
+                    capi.call("ck_tensordot2_lse_fwd", aa, ro, H, la._w.data_ptr(), bd.views[a].data_ptr(), l._w.data_ptr(), bd.views[i].data_ptr(),
+                              l.num_folds, B, la._num_contract_units, la._num_batch_units, la.num_output_units // la._num_batch_units,
+                              l.num_output_units // l._num_batch_units, cv, stream)
+            elif isinstance(l, HipConstantValueLayer):
+                l.launch_const(bd.views[i], B, stream)
+            else:
+                l.launch(bd.arena, bd.row_off[i], bd.views[i], B, stream)
 
     def _weight_pool(self, st: dict) -> torch.Tensor:
         """The gradients of the evaluated weights of every sum / TensorDot layer as slices of ONE buffer (the kernels add into
@@ -193,12 +262,28 @@ class _PlanBackward:
             F, K = l.num_folds, l.num_output_units
             g = gviews[i]
             sc = st["scratch"][i]
+            if i in self._skip:  # (its reader's launch did its part: an absorbed Hadamard layer, the first half of a pair)
+                continue
             if isinstance(l, HipTensorDotLayer):  # (optimized.py:289-296) on its own layout: x (B, Kj, Kq) -> out (B, Kq, Kk)
-                Kj, Kq = l._num_contract_units, l._num_batch_units
                 if l._w.is_complex():
                     raise NotImplementedError("squared-circuit training: complex-valued weights")
-                capi.call("ck_tensordot_lse_bwd", aa, ga, bd.row_off[i].data_ptr(), l._w.data_ptr(), bd.views[i].data_ptr(), g.data_ptr(),
-                          sc["dw"].data_ptr(), F, B, Kj, Kq, K // Kq, 1 if cplx else 0, stream)
+                cv = 1 if cplx else 0
+                a = self.pair_of.get(i)
+                if a is None:
+                    ro, H = self._td_args(i, bd)
+                    capi.call("ck_tensordot_lse_bwd", aa, ga, ro, H, l._w.data_ptr(), bd.views[i].data_ptr(), g.data_ptr(), sc["dw"].data_ptr(),
+                              F, B, l._num_contract_units, l._num_batch_units, K // l._num_batch_units, cv, stream)
+                else:
+                    la, sa = c.layers[a], st["scratch"][a]
+                    if la._w.is_complex():
+                        raise NotImplementedError("squared-circuit training: complex-valued weights")
+                    ro, H = self._td_args(a, bd)
+                    capi.call("ck_tensordot2_lse_bwd", aa, ga, ro, H, la._w.data_ptr(), bd.views[a].data_ptr(), gviews[a].data_ptr(),
+                              l._w.data_ptr(), bd.views[i].data_ptr(), g.data_ptr(), sa["dw"].data_ptr(), sc["dw"].data_ptr(), F, B,
+                              la._num_contract_units, la._num_batch_units, la.num_output_units // la._num_batch_units, K // l._num_batch_units,
+                              cv, stream)
+                    if not sa["direct"]:
+                        la.weight.backward(sa["dw"], self.grads, stream)
                 if not sc["direct"]:
                     l.weight.backward(sc["dw"], self.grads, stream)
             elif isinstance(l, (HipSumLayer, HipCPTLayer, HipTuckerLayer)):
@@ -573,7 +658,7 @@ class HipSquaredTrainer:
         elif part == "z":  # parameters of Z, its forward (no input: everything is part of the list), its backward
             z = self.z
             z._enqueue_params(stream)
-            z._enqueue_layers(z._bind(1), stream)
+            self._bwd_z.forward(1, stream)
             capi.call("ck_fill_f32", self._flat_grad_z.data_ptr(), n, 0.0, stream)
             self._bwd_z.run(1, B / gB, stream)
         else:  # both gradients are there: the sum, the log-likelihood pair, the optimizer

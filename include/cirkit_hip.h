@@ -710,12 +710,24 @@ int ck_adam_step(float* p, const float* g, float* m1, float* m2, int64_t n, floa
                  float beta2, float eps, int step, float grad_scale, const int32_t* skip_flag, int32_t* skipped,
                  void* stream);
 int ck_sgd_step(float* p, const float* g, int64_t n, float lr, float grad_scale, const int32_t* skip_flag, void* stream);
-/* TorchTensorDotLayer backward (optimized.py:289-296; forward: ck_tensordot_lse_fwd / _fwd_c) on the layer's own layout: x at
- * arena + row_off[f] is (B, Kj, Kq), out / gout (F, B, Kq Kk), REAL weights w (F, Kk, Kj); the gradient of x is WRITTEN to
- * garena + row_off[f] in x's layout, dw (F, Kk, Kj) += (float atomics).  complex_values != 0: complex64 values (offsets in
- * complex numbers, the conventions of ck_sum_lse_bwd_c); 0: fp32 (lse-sum). */
-int ck_tensordot_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const float* w, const float* out,
+/* TorchTensorDotLayer (optimized.py:289-296) for the partition function of a squared circuit -- a chain of such layers on ONE
+ * row, every launch a fixed cost (cirkit_amd/csrc/ck_backward_c.hip): REAL weights; complex_values != 0: complex64 values (offsets
+ * in complex numbers, the conventions of ck_sum_lse_bwd_c), 0: fp32 (lse-sum).
+ * x = the SUM of the H blocks arena + row_off[f, h] -- the TorchHadamardLayer beneath (inner.py:126-127 in log space) read as a
+ * list, never launched -- viewed (B, Kj, Kq); w (F, Kk, Kj); out (F, B, Kq Kk).
+ * ck_tensordot2_*: the PAIR of layers a squared sum layer becomes (M' = W M W^T: one over W, one over conj W) in one launch:
+ * stage 1 writes mid (F, B, Kq Kk1), stage 2 reads it as (Kq, Kk1) -> out (F, B, Kk1 Kk2) with w2 (F, Kk2, Kq).
+ * Backward: the gradient of x is WRITTEN to garena + row_off[f, h] for every h (each factor of the product receives it), in x's
+ * layout; gmid <- the gradient of mid; dw (F, Kk, Kj) += (float atomics). */
+int ck_tensordot_lse_fwd_h(const float* arena, const int64_t* row_off, int H, const float* w, float* out, int F, int B, int Kj,
+                           int Kq, int Kk, int complex_values, void* stream);
+int ck_tensordot2_lse_fwd(const float* arena, const int64_t* row_off, int H, const float* w1, float* mid, const float* w2, float* out,
+                          int F, int B, int Kj, int Kq, int Kk1, int Kk2, int complex_values, void* stream);
+int ck_tensordot_lse_bwd(const float* arena, float* garena, const int64_t* row_off, int H, const float* w, const float* out,
                          const float* gout, float* dw, int F, int B, int Kj, int Kq, int Kk, int complex_values, void* stream);
+int ck_tensordot2_lse_bwd(const float* arena, float* garena, const int64_t* row_off, int H, const float* w1, const float* mid,
+                          float* gmid, const float* w2, const float* out, const float* gout, float* dw1, float* dw2, int F, int B,
+                          int Kj, int Kq, int Kk1, int Kk2, int complex_values, void* stream);
 /* Pieces of the squared-circuit loss -mean(2 Re c(x) - Re Z) (symbolic/functional.py:161,259,594 + the reference's training
  * loop) that are neither a layer nor a parameter node, so that a step needs no tensor-library arithmetic:
  * dst[i dst_stride] = src[i src_stride] (real parts of complex values); p[i stride] = value (the seed Re = v, Im = 0);

@@ -3,6 +3,7 @@ ROOT=os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from cirkit_amd import _capi as capi
+if os.environ.get('CK_LIB'): capi._LIB_PATH=os.path.join(ROOT,os.environ['CK_LIB'])
 from cirkit_amd.plan import Plan
 from cirkit_amd.initializers import init_plan_tensors
 from cirkit_amd.training_squared import HipSquaredTrainer
