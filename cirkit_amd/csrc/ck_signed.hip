@@ -290,6 +290,29 @@ __global__ void __launch_bounds__(256)
   if (k == 0) tsigns[row] = bit;
 }
 
+// The three tables of an Embedding fold from its weight (32, C) in one pass through LDS: the gather table (C + 1, 32) the
+// backward divides by (row C: the integral row of ones, input.py:280-282), its signed-log form and the sign words.
+__global__ void __launch_bounds__(256)
+    slse_tables_kernel(const float* __restrict__ weight, float* __restrict__ table, float* __restrict__ ltab, uint32_t* __restrict__ tsigns,
+                       int C) {
+  extern __shared__ float tw_s[];  // [32][C + 1]
+  const int f = blockIdx.x, ld = C + 1;
+  const float* wf = weight + static_cast<int64_t>(f) * 32 * C;
+  for (int i = threadIdx.x; i < 32 * C; i += 256) tw_s[(i / C) * ld + i % C] = wf[i];
+  __syncthreads();
+  const int64_t row0 = static_cast<int64_t>(f) * (C + 1);
+  for (int i = threadIdx.x; i < (C + 1) * 32; i += 256) {  // (a half-wave per row of 32 units)
+    const int c = i >> 5, k = i & 31;
+    const float w = c < C ? tw_s[k * ld + c] : 1.f;
+    table[row0 * 32 + i] = w;
+    ltab[row0 * 32 + i] = logf(fabsf(w));
+    uint32_t bit = w < 0.f ? (1u << k) : 0u;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) bit |= __shfl_xor(bit, o, 64);
+    if (k == 0) tsigns[row0 + c] = bit;
+  }
+}
+
 int check(const void* arena, const void* signs, const int64_t* row_off, const float* w, const void* out, const void* sout, int F, int H, int B,
           int Ko, const Gather& ga, const char* who) {
   CK_REQUIRE(w && out && sout, "%s: null pointer", who);
@@ -315,6 +338,23 @@ extern "C" int ck_slse_table(const float* table, float* log_table, uint32_t* tab
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(slse_table_kernel, grid, block, 0, s, table, log_table, table_signs, rows);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+extern "C" int ck_slse_tables(const float* weight, float* table, float* log_table, uint32_t* table_signs, int F, int C, void* stream) {
+  CK_REQUIRE(weight && table && log_table && table_signs && F > 0 && C > 0, "ck_slse_tables: bad arguments");
+  const size_t lds = static_cast<size_t>(32) * (C + 1) * sizeof(float);
+  if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_slse_tables: %d states do not fit in LDS", C);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (lds > 48 * 1024) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(slse_tables_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds));
+          if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(slse_tables_kernel, dim3(F), dim3(256), lds, s, weight, table, log_table, table_signs, C);
         return hipGetLastError();
       },
       stream);

@@ -518,9 +518,11 @@ class _SignedCircuit:
         for i, k in self.kind.items():
             l = c.layers[i]
             if k == "emb":  # the weight table (F, C + 1, 32) of this step's parameters, and its signed-log form
-                l.prepare(stream, batched=False)
+                if l._table is None or l._table.dtype != torch.float32:
+                    l.prepare(stream, batched=False)  # (allocates the table; first call only)
                 ltab, tsg = st["ltab"][i]
-                capi.call("ck_slse_table", l._table.data_ptr(), ltab.data_ptr(), tsg.data_ptr(), l.num_folds * (l.num_states + 1), stream)
+                capi.call("ck_slse_tables", c.store[self.wname[i]].data_ptr(), l._table.data_ptr(), ltab.data_ptr(), tsg.data_ptr(),
+                          l.num_folds, l.num_states, stream)
                 continue
             o = st["off"][i]
             ro, *gather = self._args(st, i)
@@ -717,11 +719,9 @@ class HipSquaredTrainer:
             else:
                 self.c._run(x)  # (B, 1, 1) complex64 / fp32 in c's arena
             self._part("c", B, gB, with_optimizer, main)
-        with torch.cuda.stream(side):
-            self._part("z", B, gB, with_optimizer, side)
-        with torch.cuda.stream(main):
-            main.wait_stream(side)
-            self._part("end", B, gB, with_optimizer, main)
+        self._part("z", B, gB, with_optimizer, side)
+        main.wait_stream(side)
+        self._part("end", B, gB, with_optimizer, main)
         if main is not cur:
             cur.wait_stream(main)
 

@@ -758,6 +758,9 @@ int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, c
  * f's output; gx (F, B, 32) <- the gradient w.r.t. log|product of the children| -- the SAME for each of the H children, who
  * read it there (their gout_off; ck_embedding_bwd's gfold); dw (F, Ko, 32) += (float atomics: zero it first). */
 int ck_slse_table(const float* table, float* log_table, uint32_t* table_signs, int64_t rows, void* stream);
+/* ... or all three tables of an Embedding layer of 32 units from its weight (F, 32, C) (layers/input.py:258-266) in one launch:
+ * table (F, C + 1, 32) (the transposed weight, row C the integral row of ones), its signed-log form and sign words. */
+int ck_slse_tables(const float* weight, float* table, float* log_table, uint32_t* table_signs, int F, int C, void* stream);
 int ck_slse_fwd(const float* arena, const uint32_t* signs, const int64_t* row_off, const float* w, float* out, uint32_t* sout,
                 int F, int H, int B, int Ko, const float* log_table, const uint32_t* table_signs, const int32_t* child_fold,
                 const int32_t* child_var, const int32_t* xt, int C, void* stream);
