@@ -300,7 +300,7 @@ def train_step_squared(device, stream, plan_c, tensors, B: int, rounds: int = 5,
     """One maximum-likelihood step of the squared circuit of BASELINE config 5 through `HipSquaredTrainer`: c(x) on signed-log
     blocks (csrc/ck_signed.hip), Z = integral |c|^2 (ConstantValue / Hadamard / TensorDot layers over Gram matrices of the
     Embedding weights) forward and backward beside it on a second stream, one optimizer launch with a device clock; three
-    recorded launch lists replayed as hipGraphs.  Measured like `train_step_cfg2`."""
+    recorded launch lists replayed by the native executor.  Measured like `train_step_cfg2`."""
     import time
 
     import numpy as np
@@ -338,7 +338,7 @@ def train_step_squared(device, stream, plan_c, tensors, B: int, rounds: int = 5,
         "workload": f"BASELINE config 5 (squared QuadTree-2 28x28, Embedding-256, CP-T, K=32, real parameters), batch {B}: forward + backward "
                     "of c and of Z + Adam, parameters re-evaluated every step",
         "form": ("c on signed-log blocks (fp32 log|v| + a sign bit, ck_signed.hip)" if tr._signed is not None else "c on complex layer-wise kernels")
-                + "; Z layer-wise on a second stream; three recorded launch lists (hipGraphs)",
+                + "; Z (Hadamard layers as lists, TensorDot pairs in one launch) on a second stream; three recorded launch lists",
         "ms_per_step": ms, "samples_per_s": B / ms * 1e3, "ms_per_step_by_round": per_round,
         "settle_steps": k - rounds * steps, "steps_timed_total": rounds * steps, "optimizer_steps_taken": taken, "steps_dropped": dropped,
         "mean_ll_first_step": float(first[0] / first[1]), "mean_ll_last_step": float(last[0] / last[1]),
