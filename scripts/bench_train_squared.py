@@ -7,7 +7,7 @@ from cirkit_amd.training_squared import HipSquaredTrainer
 G=os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"),"tests","golden")
 plan_c=Plan.load(os.path.join(G,"cfg5_sos_c_k32"))
 t=init_plan_tensors(plan_c); t={k:np.where(v==0,np.float32(1e-2),v).astype(np.float32) for k,v in t.items()}
-tr=HipSquaredTrainer(plan_c,t,device="cuda:0",lr=1e-3,signed={"0":False,"1":True}.get(os.environ.get("CK_SIGNED"),None),use_graph=os.environ.get("CK_SQ_GRAPH","1")=="1")
+tr=HipSquaredTrainer(plan_c,t,device="cuda:0",lr=1e-3,signed={"0":False,"1":True}.get(os.environ.get("CK_SIGNED"),None),use_graph=os.environ.get("CK_SQ_GRAPH","0")=="1")
 for B in ([int(a) for a in sys.argv[1:]] or [256,4096]):
     x=torch.randint(0,256,(B,784),generator=torch.Generator().manual_seed(B)).cuda()
     for _ in range(3): ll=tr.step(x)
