@@ -13,6 +13,11 @@
 // word per row) by the batch values: the layer's output is never stored.  The H children of a product receive the SAME
 // gradient: a fold writes it once, into its own (B, 32) block, and its children (ck_slse_bwd's gout_off, ck_embedding_bwd's
 // gfold) read it there.
+// Layout: a fold's block is TILE-NATIVE -- ceil(B / 32) tiles of 1024 floats, dword (g, lane, t) of a tile = unit 8 g + 4 (lane >> 5) + t
+// of row 32 tile + (lane & 31): the MFMA register order, so that a wave instruction loads or stores ONE contiguous KiB (a row-major
+// block is 32 lines of 32 bytes per instruction: 3.3 TB/s where these layers stream).  Blocks are Bp = 32 ceil(B / 32) rows long
+// (the padding rows hold anything); sign words stay one per row.  Row-major are only what other kernels read: the top layer's
+// (B, Ko <= 4) outputs and a gathering layer's gradient block (ck_embedding_bwd scatters rows).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -31,6 +36,25 @@ __device__ __forceinline__ void load16(const float* __restrict__ row, int kh, fl
     v[4 * g + 0] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
   }
 }
+// tile `tile` of a tile-native block: register 4 g + t of lane l <-> dword 1024 tile + 256 g + 4 l + t
+__device__ __forceinline__ void load_tile_native(const float* __restrict__ blk, int tile, int lane, float (&v)[16]) {
+  const float* p = blk + static_cast<int64_t>(tile) * 1024 + 4 * lane;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 x = *reinterpret_cast<const float4*>(p + 256 * g);
+    v[4 * g + 0] = x.x; v[4 * g + 1] = x.y; v[4 * g + 2] = x.z; v[4 * g + 3] = x.w;
+  }
+}
+__device__ __forceinline__ void store_tile_native(float* __restrict__ blk, int tile, int lane, const float (&v)[16]) {
+  float* p = blk + static_cast<int64_t>(tile) * 1024 + 4 * lane;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(p + 256 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+// dword of (row, unit) inside a tile-native block
+__device__ __forceinline__ int64_t native_index(int64_t row, int unit) {
+  return (row >> 5) * 1024 + (unit >> 3) * 256 + ((row & 31) + 32 * ((unit >> 2) & 1)) * 4 + (unit & 3);
+}
+__device__ __forceinline__ int padded_rows(int B) { return ((B + 31) >> 5) << 5; }
 __device__ __forceinline__ bool bit_of(uint32_t word, int j, int kh) { return (word >> (8 * (j >> 2) + 4 * kh + (j & 3))) & 1u; }
 
 // exp(d), d <= 0: v_exp_f32 on d log2(e) with the rounding error of that product put back (1 + lo ln 2): ~1e-7 relative, as expf,
@@ -65,7 +89,7 @@ struct Gather {
 // v <- sum over the children of log|x_h|, sign <- the product of their signs (a word; bits of all 32 units)
 __device__ __forceinline__ uint32_t load_children(const float* __restrict__ arena, const uint32_t* __restrict__ signs,
                                                   const int64_t* __restrict__ ro, const Gather& ga, int f, int H, int B, int64_t bl, int kh,
-                                                  float (&v)[16]) {
+                                                  int tile, int lane, float (&v)[16]) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = 0.f;
   uint32_t sw = 0;
@@ -79,7 +103,7 @@ __device__ __forceinline__ uint32_t load_children(const float* __restrict__ aren
       load16(ga.table + row * 32, kh, x);
       sw ^= ga.tsigns[row];
     } else {
-      load16(arena + ro[h] + bl * 32, kh, x);
+      load_tile_native(arena + ro[h], tile, lane, x);
       sw ^= signs[(ro[h] >> 5) + bl];
     }
 #pragma unroll
@@ -103,6 +127,7 @@ __global__ void __launch_bounds__(256)
   load_w<CK_W_ROWMAJOR>(w + static_cast<int64_t>(f) * kK * kK, lane, wr);
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
   const int tile0 = (bx * 4 + wave) * tiles_per_wave;
+  const int Bp = padded_rows(B);
   for (int tt = 0; tt < tiles_per_wave; ++tt) {
     const int b0 = (tile0 + tt) * 32;
     if (b0 >= B) break;
@@ -110,7 +135,7 @@ __global__ void __launch_bounds__(256)
     const bool live = b < B;
     const int64_t bl = live ? b : B - 1;
     float v[16];
-    const uint32_t sw = load_children(arena, signs, ro, ga, f, H, B, bl, kh, v);
+    const uint32_t sw = load_children(arena, signs, ro, ga, f, H, B, bl, kh, tile0 + tt, lane, v);
     const float m = row_max16(v);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -125,12 +150,8 @@ __global__ void __launch_bounds__(256)
       v[j] = log_abs(v[j]) + m;
     }
     so |= __shfl_xor(so, 32, 64);
-    if (live) {
-      float* dst = out + (static_cast<int64_t>(f) * B + b) * kK + 4 * kh;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
-      if (kh == 0) sout[static_cast<int64_t>(f) * B + b] = so;
-    }
+    store_tile_native(out + static_cast<int64_t>(f) * Bp * kK, tile0 + tt, lane, v);  // (rows past B: padding)
+    if (live && kh == 0) sout[static_cast<int64_t>(f) * Bp + b] = so;
   }
 }
 
@@ -140,7 +161,7 @@ __global__ void __launch_bounds__(256)
     slse_tile32_bwd(const float* __restrict__ arena, const uint32_t* __restrict__ signs, float* __restrict__ gx,
                     const int64_t* __restrict__ row_off, const float* __restrict__ w, const float* __restrict__ out,
                     const uint32_t* __restrict__ sout, const float* __restrict__ gout, const int64_t* __restrict__ gout_off,
-                    float* __restrict__ dw, int H, int B, Gather ga, int F, int nx) {
+                    float* __restrict__ dw, int H, int B, Gather ga, int F, int nx, int gx_rowmajor) {
   __shared__ __attribute__((aligned(16))) float wt_s[1024];        // W^T, "transposed tiled" (child_gradient)
   __shared__ __attribute__((aligned(16))) float scr_s[4][2][1024];  // per wave: the two operands of dw_accumulate
   const int seq = blockIdx.x >> 3;  // (the workgroups of a fold on one XCD, as in the forward)
@@ -159,13 +180,14 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
   for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
   const int tiles = (B + 31) / 32;
-  const float* gf = gout + (gout_off != nullptr ? gout_off[f] : static_cast<int64_t>(f) * B * 32);
+  const int Bp = padded_rows(B);
+  const float* gf = gout + (gout_off != nullptr ? gout_off[f] : static_cast<int64_t>(f) * Bp * 32);
   for (int tile = bx * 4 + wave; tile < tiles; tile += nx * 4) {
     const int b = tile * 32 + b_in;
     const bool live = b < B;
     const int64_t bl = live ? b : B - 1;
     float a[16];
-    const uint32_t sw = load_children(arena, signs, ro, ga, f, H, B, bl, kh, a);
+    const uint32_t sw = load_children(arena, signs, ro, ga, f, H, B, bl, kh, tile, lane, a);
     const float m = row_max16(a);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -175,9 +197,9 @@ __global__ void __launch_bounds__(256)
     float t[16];
     {
       float y[16], g[16];
-      load16(out + (static_cast<int64_t>(f) * B + bl) * 32, kh, y);
-      load16(gf + bl * 32, kh, g);
-      const uint32_t so = sout[static_cast<int64_t>(f) * B + bl];
+      load_tile_native(out + static_cast<int64_t>(f) * Bp * 32, tile, lane, y);
+      load_tile_native(gf, tile, lane, g);
+      const uint32_t so = sout[static_cast<int64_t>(f) * Bp + bl];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         // exp(m) / y_o = sign exp(m - out_o); an output without gradient contributes nothing (also where out = -inf)
@@ -187,7 +209,9 @@ __global__ void __launch_bounds__(256)
     }
     float gv[16];
     child_gradient(wt_s, lane, t, a, gv);
-    if (live) {
+    if (!gx_rowmajor) {
+      store_tile_native(gx + static_cast<int64_t>(f) * Bp * 32, tile, lane, gv);
+    } else if (live) {  // (a gathering layer: rows of (B, 32), what ck_embedding_bwd scatters)
       float* dst = gx + (static_cast<int64_t>(f) * B + b) * 32 + 4 * kh;
 #pragma unroll
       for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]);
@@ -231,7 +255,7 @@ __global__ void __launch_bounds__(256)
     float v = 0.f;
     uint32_t sw = 0;
     for (int h = 0; h < H; ++h) {
-      v += arena[ro[h] + bl * 32 + n];
+      v += arena[ro[h] + native_index(bl, n)];
       sw ^= signs[(ro[h] >> 5) + bl];
     }
     float m = v;
@@ -263,7 +287,7 @@ __global__ void __launch_bounds__(256)
     if constexpr (!BWD) {
       if (live && n == 0) sout[static_cast<int64_t>(f) * B + b] = so;
     } else if (live) {
-      gxo[(static_cast<int64_t>(f) * B + b) * 32 + n] = e * gsum;
+      gxo[static_cast<int64_t>(f) * padded_rows(B) * 32 + native_index(b, n)] = e * gsum;
     }
   }
   if constexpr (BWD) {
@@ -401,7 +425,8 @@ extern "C" int ck_slse_bwd(const float* arena, const uint32_t* signs, const int6
     const dim3 grid(static_cast<unsigned>((F + 7) / 8 * 8 * nx)), block(256);
     return ck::dispatch(
         [=](hipStream_t s) {
-          hipLaunchKernelGGL(slse_tile32_bwd, grid, block, 0, s, arena, signs, gx, row_off, w, out, sout, gout, gout_off, dw, H, B, ga, F, nx);
+          hipLaunchKernelGGL(slse_tile32_bwd, grid, block, 0, s, arena, signs, gx, row_off, w, out, sout, gout, gout_off, dw, H, B, ga, F, nx,
+                             ga.table != nullptr ? 1 : 0);
           return hipGetLastError();
         },
         stream);

@@ -419,10 +419,11 @@ class _SignedCircuit:
         c = self.c
         dev = c.device
         off, n = {}, 0
-        for i, k in self.kind.items():  # a block of (F, B, 32) floats per sum layer -- values, and at the same offset in the
+        Bp = (B + 31) // 32 * 32  # rows of a fold's block: whole 32-row tiles (TILE-NATIVE blocks, ck_signed.hip)
+        for i, k in self.kind.items():  # a block of (F, Bp, 32) floats per sum layer -- values, and at the same offset in the
             if k != "emb":              # gradient arena the gradient w.r.t. the product of its children
                 off[i] = n
-                n += c.layers[i].num_folds * B * 32  # (a 1 .. 4 unit layer: rows of Ko floats at the start of its block)
+                n += c.layers[i].num_folds * Bp * 32  # (a 1 .. 4 unit layer: rows of Ko floats at the start of its block)
         po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
         st = {
             "arena": torch.zeros(max(n, 32), dtype=torch.float32, device=dev),
@@ -452,7 +453,7 @@ class _SignedCircuit:
                 ro = np.zeros(ch.shape[:2], dtype=np.int64)
                 for p in np.unique(ch[..., 0]):
                     sel = ch[..., 0] == p
-                    ro[sel] = off[int(p)] + ch[..., 1][sel].astype(np.int64) * B * 32
+                    ro[sel] = off[int(p)] + ch[..., 1][sel].astype(np.int64) * Bp * 32
                 st["ro"][i] = torch.from_numpy(ro).to(dev)
         for i, k in self.kind.items():  # where each fold finds the gradient of its output: its reader's block
             F = c.layers[i].num_folds
@@ -479,7 +480,7 @@ class _SignedCircuit:
                 if any((i, f) not in parent for f in range(F)):
                     raise NotImplementedError(f"layer {i}: folds that nothing reads")
                 st["gout_off"][i] = torch.from_numpy(np.asarray(
-                    [off[parent[(i, f)][0]] + parent[(i, f)][1] * B * 32 for f in range(F)], dtype=np.int64)).to(dev)
+                    [off[parent[(i, f)][0]] + parent[(i, f)][1] * Bp * 32 for f in range(F)], dtype=np.int64)).to(dev)
         while len(self._bound) >= 4:
             self._bound.pop(next(iter(self._bound)))
         self._bound[B] = st

@@ -747,16 +747,20 @@ int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, c
                      const int64_t* scope, const float* table, float* dw, int F, int B, int K, int C, void* stream);
 /* Signed-log sum layers (cirkit_amd/csrc/ck_signed.hip): TorchCPTLayer / TorchSumLayer (arity 1) under complex-lse-sum
  * (optimized.py:171-178, inner.py:266-273, semiring.py:441-476) for circuits whose parameters are all REAL -- every value is
- * real, the reference's (log|v|, 0 or pi) is stored as fp32 log|v| in (rows, 32) blocks plus ONE sign word per row (bit k:
- * unit k negative).  arena / signs: the blocks and their sign words; row_off (F, H): float offsets of the children's blocks
- * (multiples of 32; the sign words of a block start at offset / 32); 32 input units; w (F, Ko, 32) real, Ko = 32 or 1 .. 4;
- * out (F, B, Ko), sout (F, B) (bit o: output o negative).  log_table != NULL (Ko = 32): the children are folds of an Embedding
+ * real, the reference's (log|v|, 0 or pi) is stored as fp32 log|v| plus ONE sign word per row (bit k: unit k negative).
+ * A fold's block of 32-unit rows is TILE-NATIVE: Bp = 32 ceil(B / 32) rows, tile t = rows 32 t .. 32 t + 31 in 1024 floats,
+ * (row r, unit u) at dword 1024 (r / 32) + 256 (u / 8) + 4 ((r % 32) + 32 ((u / 4) % 2)) + u % 4 -- the MFMA register order,
+ * one contiguous KiB per wave instruction; rows past B are padding (written, never meaningful).  arena / signs: the blocks and
+ * their sign words; row_off (F, H): float offsets of the children's blocks (multiples of 32; the sign words of a block start
+ * at offset / 32, one per row); 32 input units; w (F, Ko, 32) real, Ko = 32 or 1 .. 4; out: (F, Bp, 32) tile-native with
+ * sout (F, Bp) (bit o: output o negative), or Ko <= 4: (F, B, Ko) row-major with sout (F, B).  log_table != NULL (Ko = 32): the children are folds of an Embedding
  * layer (layers/input.py:258-266), read as rows of the signed-log form of its weight table -- ck_slse_table: (rows, 32) real
  * weights -> log|w| and a sign word per row, rows = F0 (C + 1) of the gather table -- by the batch values (child_fold /
  * child_var (F, H): fold and variable of each child, xt (D, B) the staged batch); arena / signs / row_off are not read then.
- * Backward, for a loss that reads log|out|: gout + gout_off[f] (gout_off NULL: + f B Ko) the (B, Ko) real gradient of fold
- * f's output; gx (F, B, 32) <- the gradient w.r.t. log|product of the children| -- the SAME for each of the H children, who
- * read it there (their gout_off; ck_embedding_bwd's gfold); dw (F, Ko, 32) += (float atomics: zero it first). */
+ * Backward, for a loss that reads log|out|: gout + gout_off[f] (gout_off NULL: + f Bp 32, or + f B Ko for Ko <= 4) the real
+ * gradient of fold f's output, in the layout of out; gx (F, Bp, 32) tile-native <- the gradient w.r.t. log|product of the
+ * children| -- the SAME for each of the H children, who read it there (their gout_off) --, or, for a gathering layer,
+ * (F, B, 32) ROW-MAJOR (ck_embedding_bwd's gfold scatters rows); dw (F, Ko, 32) += (float atomics: zero it first). */
 int ck_slse_table(const float* table, float* log_table, uint32_t* table_signs, int64_t rows, void* stream);
 /* ... or all three tables of an Embedding layer of 32 units from its weight (F, 32, C) (layers/input.py:258-266) in one launch:
  * table (F, C + 1, 32) (the transposed weight, row C the integral row of ones), its signed-log form and sign words. */

@@ -99,6 +99,25 @@ def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_d
             assert err <= 2e-3 * max(1e-6, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
 
 
+def _to_tile_native(x):
+    """(..., B, 32) row-major -> (..., Bp * 32) in the tile-native order of ck_signed.hip (rows padded to whole 32-row tiles)."""
+    *lead, B, K = x.shape
+    Bp = (B + 31) // 32 * 32
+    xp = torch.zeros(*lead, Bp, K, dtype=x.dtype, device=x.device)
+    xp[..., :B, :] = x
+    # dword (tile, g, kh, b, t) <- row 32 tile + b, unit 8 g + 4 kh + t
+    return xp.reshape(*lead, Bp // 32, 32, 4, 2, 4).permute(*range(len(lead)), len(lead), len(lead) + 2, len(lead) + 3, len(lead) + 1,
+                                                             len(lead) + 4).reshape(*lead, Bp * K).contiguous()
+
+
+def _from_tile_native(y, B):
+    *lead, n = y.shape
+    Bp = n // 32
+    x = y.reshape(*lead, Bp // 32, 4, 2, 32, 4).permute(*range(len(lead)), len(lead), len(lead) + 3, len(lead) + 1, len(lead) + 2,
+                                                        len(lead) + 4).reshape(*lead, Bp, 32)
+    return x[..., :B, :].contiguous()
+
+
 @pytest.mark.gpu
 def test_signed_log_layers_match_the_complex_layers(hip_device):
     """ck_slse_fwd / ck_slse_bwd against ck_sum_lse_fwd_c / ck_sum_lse_bwd_c on the same values (32 -> 32 and 32 -> 1 CP-T folds,
@@ -108,23 +127,31 @@ def test_signed_log_layers_match_the_complex_layers(hip_device):
 
     g = torch.Generator().manual_seed(11)
     B, H = 77, 2
+    Bp = (B + 31) // 32 * 32
     for F, Ko in ((3, 32), (2, 1)):
         w = (torch.randn(F, Ko, 32, generator=g) * 0.3).to(hip_device)
         mag = torch.randn(F * H, B, 32, generator=g).to(hip_device)
         neg = (torch.rand(F * H, B, 32, generator=g) < 0.4).to(hip_device)
-        signs = torch.from_numpy(((neg.cpu().numpy().astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1) & 0xFFFFFFFF)
-                                 .astype(np.uint32).view(np.int32)).to(hip_device)
+        sw = ((neg.cpu().numpy().astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        signs_np = np.zeros((F * H, Bp), dtype=np.int32)  # (one word per row, blocks of Bp rows)
+        signs_np[:, :B] = sw
+        signs = torch.from_numpy(signs_np).to(hip_device)
+        mag_n = _to_tile_native(mag)  # (F H, Bp 32): the layout the signed-log kernels read and write
         xc = torch.complex(mag, torch.pi * neg.to(torch.float32)).contiguous()
-        ro = (torch.arange(F * H, dtype=torch.int64) * B * 32).reshape(F, H).to(hip_device)
+        ro_c = (torch.arange(F * H, dtype=torch.int64) * B * 32).reshape(F, H).to(hip_device)
+        ro_n = (torch.arange(F * H, dtype=torch.int64) * Bp * 32).reshape(F, H).to(hip_device)
         stream = torch.cuda.current_stream().cuda_stream
-        out, sout = torch.zeros(F, B, Ko, device=hip_device), torch.zeros(F, B, dtype=torch.int32, device=hip_device)
-        capi.call("ck_slse_fwd", mag.data_ptr(), signs.data_ptr(), ro.data_ptr(), w.data_ptr(), out.data_ptr(), sout.data_ptr(), F, H, B, Ko,
+        native_out = Ko == 32
+        out_n = torch.zeros(F, Bp * 32 if native_out else B * Ko, device=hip_device)
+        sout = torch.zeros(F, Bp if native_out else B, dtype=torch.int32, device=hip_device)
+        capi.call("ck_slse_fwd", mag_n.data_ptr(), signs.data_ptr(), ro_n.data_ptr(), w.data_ptr(), out_n.data_ptr(), sout.data_ptr(), F, H, B, Ko,
                   None, None, None, None, None, 0, stream)
         outc = torch.zeros(F, B, Ko, dtype=torch.complex64, device=hip_device)
-        capi.call("ck_sum_lse_fwd_c", xc.data_ptr(), ro.data_ptr(), w.data_ptr(), outc.data_ptr(), F, H, B, 32, Ko, capi.CK_SUM_PROD, 0, stream)
+        capi.call("ck_sum_lse_fwd_c", xc.data_ptr(), ro_c.data_ptr(), w.data_ptr(), outc.data_ptr(), F, H, B, 32, Ko, capi.CK_SUM_PROD, 0, stream)
         torch.cuda.synchronize()
+        out = _from_tile_native(out_n, B) if native_out else out_n.view(F, B, Ko)
         # random signs cancel: the yardstick is the sum of the magnitudes, sum_j |W_oj| |x_j|, in the linear domain
-        bits = ((sout.cpu().numpy().view(np.uint32)[..., None] >> np.arange(Ko, dtype=np.uint32)) & 1).astype(bool)
+        bits = ((sout[:, :B].cpu().numpy().view(np.uint32)[..., None] >> np.arange(Ko, dtype=np.uint32)) & 1).astype(bool)
         v = mag.view(F, H, B, 32).sum(1).double()
         m = v.amax(-1, keepdim=True)
         yard = torch.einsum("foi,fbi->fbo", w.abs().double(), (v - m).exp())
@@ -134,18 +161,30 @@ def test_signed_log_layers_match_the_complex_layers(hip_device):
         sure = ((y_complex.abs() / yard) > 1e-5).cpu().numpy()  # (the sign of a sum that cancelled to rounding noise is anybody's)
         assert np.array_equal(bits[sure], (np.abs(outc.imag.cpu().numpy()) > 1.5)[sure])
         gout = torch.randn(F, B, Ko, generator=g).to(hip_device)
-        gx, dw = torch.zeros(F, B, 32, device=hip_device), torch.zeros_like(w)  # (one gradient block per fold: its children share it)
-        capi.call("ck_slse_bwd", mag.data_ptr(), signs.data_ptr(), ro.data_ptr(), w.data_ptr(), out.data_ptr(), sout.data_ptr(),
-                  gout.data_ptr(), None, gx.data_ptr(), dw.data_ptr(), F, H, B, Ko, None, None, None, None, None, 0, stream)
+        gout_n = _to_tile_native(gout) if native_out else gout.reshape(F, B * Ko).contiguous()
+        gx_n, dw = torch.zeros(F, Bp * 32, device=hip_device), torch.zeros_like(w)  # (one gradient block per fold: its children share it)
+        capi.call("ck_slse_bwd", mag_n.data_ptr(), signs.data_ptr(), ro_n.data_ptr(), w.data_ptr(), out_n.data_ptr(), sout.data_ptr(),
+                  gout_n.data_ptr(), None, gx_n.data_ptr(), dw.data_ptr(), F, H, B, Ko, None, None, None, None, None, 0, stream)
         gxc, dwc = torch.zeros_like(xc), torch.zeros_like(w)
         goutc = torch.complex(gout, torch.zeros_like(gout)).contiguous()
-        capi.call("ck_sum_lse_bwd_c", xc.data_ptr(), gxc.data_ptr(), ro.data_ptr(), w.data_ptr(), outc.data_ptr(), goutc.data_ptr(), dwc.data_ptr(),
+        capi.call("ck_sum_lse_bwd_c", xc.data_ptr(), gxc.data_ptr(), ro_c.data_ptr(), w.data_ptr(), outc.data_ptr(), goutc.data_ptr(), dwc.data_ptr(),
                   F, H, B, 32, Ko, capi.CK_SUM_PROD, 0, stream)
         torch.cuda.synchronize()
+        gx = _from_tile_native(gx_n, B)
         scale = float(gxc.real.abs().max())
         for h in range(H):
             assert float((gx - gxc.real.view(F, H, B, 32)[:, h]).abs().max()) <= 1e-4 * scale
         assert float((dw - dwc).abs().max()) <= 1e-4 * float(dwc.abs().max())
+
+
+def test_tile_native_layout_helpers_round_trip():
+    """(row r, unit u) sits at dword 1024 (r / 32) + 256 (u / 8) + 4 ((r % 32) + 32 ((u / 4) % 2)) + u % 4 (include/cirkit_hip.h)."""
+    x = torch.arange(2 * 45 * 32, dtype=torch.float32).reshape(2, 45, 32)
+    y = _to_tile_native(x)
+    assert y.shape == (2, 64 * 32) and torch.equal(_from_tile_native(y, 45), x)
+    for r, u in ((0, 0), (1, 0), (0, 5), (33, 12), (44, 31)):
+        d = 1024 * (r // 32) + 256 * (u // 8) + 4 * ((r % 32) + 32 * ((u // 4) % 2)) + u % 4
+        assert float(y[1, d]) == float(x[1, r, u]), (r, u)
 
 
 @pytest.mark.gpu
