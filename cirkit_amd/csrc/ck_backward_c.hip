@@ -9,6 +9,9 @@
 // log space) or, for Tucker layers (CK_SUM_KRON, optimized.py:89-103), v_(i0..iH-1) = sum_h x_h[i_h]; gv goes back to the
 // children accordingly.  A shape-generic kernel on the vector lanes: one workgroup per (fold, TB batch rows); the TB rows'
 // contributions to dW are added up in the workgroup before ONE atomic per weight entry.
+#include <cstdlib>
+#include <type_traits>
+
 #include "ck_internal.h"
 #include "ck_bwd_tile.h"
 
@@ -255,6 +258,18 @@ __global__ void __launch_bounds__(256)
 //     block between them handed over through memory inside the workgroup;
 //   * the backward without transposed copies (the dense backward on rows (b, q) needs x permuted and permutes the gradient back).
 // S: the arithmetic -- TdC: complex-lse-sum (the conventions of sum_clse_bwd_kernel above, REAL weights), TdR: lse-sum.
+#ifdef CK_TD_STAMPS  // lab build (scripts/ubench/td_stamps.hip): wall-clock stamps of workgroup (0, 0)
+__device__ long long* g_td_stamps = nullptr;
+__device__ int g_td_n = 0;
+#define TD_STAMP()                                                                                             \
+  do {                                                                                                         \
+    if (g_td_stamps != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && g_td_n < 32)        \
+      g_td_stamps[g_td_n++] = static_cast<long long>(wall_clock64());                                          \
+  } while (0)
+#else
+#define TD_STAMP() do {} while (0)
+#endif
+
 struct TdC {
   using T = c32;
   static __device__ __forceinline__ float re(c32 a) { return a.re; }
@@ -299,16 +314,19 @@ __device__ __forceinline__ void td_stage(typename S::T* a_s, float* w_s, float* 
     a_s[q * (Kj + 1) + j] = load(i);
   }
   __syncthreads();
+  TD_STAMP();
   for (int q = threadIdx.x; q < Kq; q += 256) {
     float mx = -INFINITY;
     for (int j = 0; j < Kj; ++j) mx = fmaxf(mx, S::re(a_s[q * (Kj + 1) + j]));
     m_s[q] = ck::clamp_finite(mx);
   }
   __syncthreads();
+  TD_STAMP();
   for (int i = threadIdx.x; i < Kq * Kj; i += 256) {
     const int q = i / Kj, j = i - q * Kj;
     a_s[q * (Kj + 1) + j] = S::exp_shift(a_s[q * (Kj + 1) + j], m_s[q]);
   }
+  TD_STAMP();
 }
 
 template <class S, class Load>
@@ -320,12 +338,14 @@ __device__ __forceinline__ void td_fwd_body(char* smem, Load&& load, const float
   float* m_s = w_s + static_cast<size_t>(Kk) * (Kj + 1);
   td_stage<S>(a_s, w_s, m_s, load, wf, Kj, Kq, Kk);
   __syncthreads();
+  TD_STAMP();
   for (int i = threadIdx.x; i < Kq * Kk; i += 256) {
     const int q = i / Kk, k = i - q * Kk;
     T acc = S::zero();
     for (int j = 0; j < Kj; ++j) acc = S::fma_w(w_s[k * (Kj + 1) + j], a_s[q * (Kj + 1) + j], acc);
     dst[i] = S::log_shift(acc, m_s[q]);
   }
+  TD_STAMP();
 }
 
 // store(i, g): the gradient of x[i]; dwf: the fold's (Kk, Kj) weight gradient, added with float atomics
@@ -344,18 +364,21 @@ __device__ __forceinline__ void td_bwd_body(char* smem, Load&& load, Store&& sto
     t_s[q * (Kk + 1) + k] = S::tee(out[i], gout[i], m_s[q]);
   }
   __syncthreads();
+  TD_STAMP();
   for (int i = threadIdx.x; i < Kj * Kq; i += 256) {  // the gradient of x[j][q], in x's layout
     const int j = i / Kq, q = i - j * Kq;
     T acc = S::zero();
     for (int k = 0; k < Kk; ++k) acc = S::fma_w(w_s[k * (Kj + 1) + j], t_s[q * (Kk + 1) + k], acc);
     store(i, S::child(a_s[q * (Kj + 1) + j], acc));
   }
+  TD_STAMP();
   for (int i = threadIdx.x; i < Kk * Kj; i += 256) {
     const int k = i / Kj, j = i - k * Kj;
     float acc = 0.f;
     for (int q = 0; q < Kq; ++q) acc += S::dw(a_s[q * (Kj + 1) + j], t_s[q * (Kk + 1) + k]);
     if (acc != 0.f) atomicAdd(dwf + i, acc);
   }
+  TD_STAMP();
 }
 
 // One or two stages.  Stage 1: x = the sum of the H blocks arena + row_off[f, h] (+ b Kj Kq), weights w1 (F, Kk1, Kj), output
@@ -368,6 +391,7 @@ __global__ void __launch_bounds__(256)
   using T = typename S::T;
   extern __shared__ __attribute__((aligned(16))) char td_smem[];
   const int f = blockIdx.y, b = blockIdx.x;
+  TD_STAMP();
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
   const int64_t boff = static_cast<int64_t>(b) * Kj * Kq;
   auto load1 = [&](int i) {
@@ -394,6 +418,7 @@ __global__ void __launch_bounds__(256)
   using T = typename S::T;
   extern __shared__ __attribute__((aligned(16))) char td_smem[];
   const int f = blockIdx.y, b = blockIdx.x;
+  TD_STAMP();
   const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
   const int64_t boff = static_cast<int64_t>(b) * Kj * Kq;
   const int64_t o1 = (static_cast<int64_t>(f) * B + b) * Kq * Kk1;
@@ -417,6 +442,235 @@ __global__ void __launch_bounds__(256)
   td_bwd_body<S>(td_smem, load1, store1, w1 + static_cast<int64_t>(f) * Kk1 * Kj, y1, g1, dw1 + static_cast<int64_t>(f) * Kk1 * Kj, Kj, Kq, Kk1);
 }
 
+// ---- 32 units everywhere (the partition function of BASELINE config 5: M' = W M W^T per fold, (32, 32) blocks) ---------------------
+// The shape-generic bodies above are chains of phases of 1 - 4 us each on ONE row (scripts/ubench/td_stamps.hip: per stage 1.7 us of
+// loads, 1.8 a serial maximum per column, 1.2 library exponentials, 3.9 a contraction whose 4 x 32 dependent LDS reads the
+// compiler cannot unroll for run-time sizes + library logarithms; the second stage reloads from memory what the workgroup has
+// just stored: 17 us forward, 28 us backward for ONE fold).  With the sizes fixed thread t owns the elements i = t + 256 r of every
+// (32, 32) block in play -- the same four for the stage's input x[j][q] (i = 32 j + q), its output / the tee (i = 32 q + k), the
+// child gradient (i = 32 j + q) and the weight gradient (i = 32 k + j) -- so the column maxima are four registers + one shuffle +
+// four LDS words, the second stage's input and the gradient between the stages never leave the registers, and every LDS loop is
+// unrolled over 16-byte reads.  The order of every sum is the generic kernels' (bit-identical contractions); exp / log / sincos /
+// atan are the polynomial forms of the complex tile kernels (ck_internal.h, <= 2 ulp).
+struct TdC32 : TdC {
+  static constexpr int kA = 34;  // values per LDS row of a (32, 32) block: rows start on 16 bytes
+  static __device__ __forceinline__ c32 exp_shift(c32 v, float m) { return ck::c_exp_shift_tile(v, m); }
+  static __device__ __forceinline__ c32 log_shift(c32 y, float m) { return ck::c_log_shift_tile(y, m); }
+  static __device__ __forceinline__ c32 tee(c32 y, c32 g, float m) {
+    return (g.re == 0.f && g.im == 0.f) ? c32{0.f, 0.f} : cmul(cconj(ck::c_exp_shift_tile({-y.re, -y.im}, -m)), g);
+  }
+  static __device__ __forceinline__ void read4(const c32* p, c32 (&v)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 2);
+    v[0] = {a.x, a.y};
+    v[1] = {a.z, a.w};
+    v[2] = {b.x, b.y};
+    v[3] = {b.z, b.w};
+  }
+};
+struct TdR32 : TdR {
+  static constexpr int kA = 36;
+  static __device__ __forceinline__ void read4(const float* p, float (&v)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x;
+    v[1] = a.y;
+    v[2] = a.z;
+    v[3] = a.w;
+  }
+};
+constexpr int kTdW = 36;  // floats per LDS row of a (32, 32) weight matrix
+
+template <class S>
+struct Td32Lds {
+  typename S::T a[32 * S::kA];   // a[q][j] = exp(x[j][q] - m_q)
+  typename S::T t[32 * S::kA];   // (backward) t[q][k]
+  typename S::T tt[32 * S::kA];  // (backward) t[q][k] at [k][q]
+  float w[2][32 * kTdW];         // W[k][j] of the two stages
+  float wt[2][32 * kTdW];        // (backward) W[k][j] at [j][k]
+  float m[32];
+  float red[4][32];
+};
+
+// the weights of a stage into LDS (visible after the stage's first barrier)
+template <bool BWD>
+__device__ __forceinline__ void td32_stage_w(const float* __restrict__ wf, float* w_s, float* wt_s, int t) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = t + 256 * r;
+    const float v = wf[i];
+    w_s[(i >> 5) * kTdW + (i & 31)] = v;
+    if (BWD) wt_s[(i & 31) * kTdW + (i >> 5)] = v;
+  }
+}
+
+// m_q = the clamped maximum of column q = t & 31 (this thread's four values are rows j = (t >> 5) + 8 r of it), a = exp(x - m_q):
+// into `a` and, transposed, into LDS; m into LDS.  Ends with a barrier.
+template <class S, class L>
+__device__ __forceinline__ void td32_exp(L& l, const typename S::T (&x)[4], typename S::T (&a)[4], int t) {
+  float pm = fmaxf(fmaxf(S::re(x[0]), S::re(x[1])), fmaxf(S::re(x[2]), S::re(x[3])));
+  pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+  if ((t & 63) < 32) l.red[t >> 6][t & 31] = pm;
+  __syncthreads();
+  const int q = t & 31;
+  const float m = ck::clamp_finite(fmaxf(fmaxf(l.red[0][q], l.red[1][q]), fmaxf(l.red[2][q], l.red[3][q])));
+  if (t < 32) l.m[t] = m;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    a[r] = S::exp_shift(x[r], m);
+    l.a[q * S::kA + (t >> 5) + 8 * r] = a[r];
+  }
+  __syncthreads();
+}
+
+// y[q'][k] = log(sum_j W[k][j] a[q'][j]) + m_q' for this thread's elements i = 32 q' + k
+template <class S, class L>
+__device__ __forceinline__ void td32_fwd_stage(L& l, const float* w_s, const typename S::T (&x)[4], typename S::T (&y)[4], int t) {
+  using T = typename S::T;
+  T a[4];
+  td32_exp<S>(l, x, a, t);
+  const int k = t & 31, q0 = t >> 5;
+  T acc[4] = {S::zero(), S::zero(), S::zero(), S::zero()};
+#pragma unroll 2
+  for (int j = 0; j < 32; j += 4) {
+    const float4 w4 = *reinterpret_cast<const float4*>(w_s + k * kTdW + j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T av[4];
+      S::read4(l.a + (q0 + 8 * r) * S::kA + j, av);
+      acc[r] = S::fma_w(w4.x, av[0], acc[r]);
+      acc[r] = S::fma_w(w4.y, av[1], acc[r]);
+      acc[r] = S::fma_w(w4.z, av[2], acc[r]);
+      acc[r] = S::fma_w(w4.w, av[3], acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) y[r] = S::log_shift(acc[r], l.m[q0 + 8 * r]);
+}
+
+// x, y, g: the stage's input, output and output gradient at this thread's elements; gx: the gradient of x; dwf += the fold's dW
+template <class S, class L>
+__device__ __forceinline__ void td32_bwd_stage(L& l, const float* wt_s, const typename S::T (&x)[4], const typename S::T (&y)[4],
+                                               const typename S::T (&g)[4], typename S::T (&gx)[4], float* __restrict__ dwf, int t) {
+  using T = typename S::T;
+  T a[4];
+  td32_exp<S>(l, x, a, t);
+  const int c = t & 31, r0 = t >> 5;  // element i = 32 (r0 + 8 r) + c
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // i = 32 q' + k
+    const int qp = r0 + 8 * r;
+    const T tv = S::tee(y[r], g[r], l.m[qp]);
+    l.t[qp * S::kA + c] = tv;
+    l.tt[c * S::kA + qp] = tv;
+  }
+  __syncthreads();
+  {  // i = 32 j + q: gx[j][q] = child(a[q][j], sum_k W[k][j] t[q][k])
+    T acc[4] = {S::zero(), S::zero(), S::zero(), S::zero()};
+#pragma unroll 2
+    for (int k = 0; k < 32; k += 4) {
+      T tv[4];
+      S::read4(l.t + c * S::kA + k, tv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wt_s + (r0 + 8 * r) * kTdW + k);
+        acc[r] = S::fma_w(w4.x, tv[0], acc[r]);
+        acc[r] = S::fma_w(w4.y, tv[1], acc[r]);
+        acc[r] = S::fma_w(w4.z, tv[2], acc[r]);
+        acc[r] = S::fma_w(w4.w, tv[3], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gx[r] = S::child(a[r], acc[r]);
+  }
+  {  // i = 32 k + j: dW[k][j] = sum_q dw(a[q][j], t[q][k])
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int q = 0; q < 32; q += 4) {
+      T av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) av[u] = l.a[(q + u) * S::kA + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T tv[4];
+        S::read4(l.tt + (r0 + 8 * r) * S::kA + q, tv);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[r] += S::dw(av[u], tv[u]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (acc[r] != 0.f) atomicAdd(dwf + t + 256 * r, acc[r]);
+  }
+}
+
+template <class S, bool TWO>
+__global__ void __launch_bounds__(256, 2)
+    td32_fwd_kernel(const typename S::T* __restrict__ arena, const int64_t* __restrict__ row_off, int H, const float* __restrict__ w1,
+                    typename S::T* __restrict__ mid, const float* __restrict__ w2, typename S::T* __restrict__ out, int B) {
+  using T = typename S::T;
+  __shared__ __attribute__((aligned(16))) Td32Lds<S> l;
+  const int t = threadIdx.x, f = blockIdx.y, b = blockIdx.x;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t boff = static_cast<int64_t>(b) * 1024, fb = (static_cast<int64_t>(f) * B + b) * 1024;
+  T x[4], y[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) x[r] = arena[ro[0] + boff + t + 256 * r];
+  for (int h = 1; h < H; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = S::add(x[r], arena[ro[h] + boff + t + 256 * r]);
+  td32_stage_w<false>(w1 + static_cast<int64_t>(f) * 1024, l.w[0], nullptr, t);
+  if (TWO) td32_stage_w<false>(w2 + static_cast<int64_t>(f) * 1024, l.w[1], nullptr, t);
+  td32_fwd_stage<S>(l, l.w[0], x, y, t);
+  T* o1 = (TWO ? mid : out) + fb;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o1[t + 256 * r] = y[r];
+  if constexpr (TWO) {  // (stage 2 reads stage 1's (Kq, Kk1) block as its (Kj, Kq): element i of the one is element i of the other)
+    td32_fwd_stage<S>(l, l.w[1], y, x, t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[fb + t + 256 * r] = x[r];
+  }
+}
+
+template <class S, bool TWO>
+__global__ void __launch_bounds__(256, 2)
+    td32_bwd_kernel(const typename S::T* __restrict__ arena, typename S::T* __restrict__ garena, const int64_t* __restrict__ row_off, int H,
+                    const float* __restrict__ w1, const typename S::T* __restrict__ mid, typename S::T* __restrict__ gmid,
+                    const float* __restrict__ w2, const typename S::T* __restrict__ out, const typename S::T* __restrict__ gout,
+                    float* __restrict__ dw1, float* __restrict__ dw2, int B) {
+  using T = typename S::T;
+  __shared__ __attribute__((aligned(16))) Td32Lds<S> l;
+  const int t = threadIdx.x, f = blockIdx.y, b = blockIdx.x;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t boff = static_cast<int64_t>(b) * 1024, fb = (static_cast<int64_t>(f) * B + b) * 1024;
+  // everything the launch reads from memory is requested before the first barrier
+  T x1[4], y1[4], g1[4], y2[4], g2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = t + 256 * r;
+    x1[r] = arena[ro[0] + boff + i];
+    y1[r] = (TWO ? mid : out)[fb + i];
+    if (TWO) {
+      y2[r] = out[fb + i];
+      g2[r] = gout[fb + i];
+    } else {
+      g1[r] = gout[fb + i];
+    }
+  }
+  for (int h = 1; h < H; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x1[r] = S::add(x1[r], arena[ro[h] + boff + t + 256 * r]);
+  td32_stage_w<true>(w1 + static_cast<int64_t>(f) * 1024, l.w[0], l.wt[0], t);
+  if constexpr (TWO) {
+    td32_stage_w<true>(w2 + static_cast<int64_t>(f) * 1024, l.w[1], l.wt[1], t);
+    td32_bwd_stage<S>(l, l.wt[1], y1, y2, g2, g1, dw2 + static_cast<int64_t>(f) * 1024, t);  // (stage 2's input is stage 1's output)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gmid[fb + t + 256 * r] = g1[r];
+  }
+  T gx[4];
+  td32_bwd_stage<S>(l, l.wt[0], x1, y1, g1, gx, dw1 + static_cast<int64_t>(f) * 1024, t);
+  for (int h = 0; h < H; ++h)  // (every factor of the product receives the same gradient)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) garena[ro[h] + boff + t + 256 * r] = gx[r];
+}
+
 template <class S, bool TWO, bool BWD>
 int td_launch(const typename S::T* arena, typename S::T* garena, const int64_t* row_off, int H, const float* w1, typename S::T* mid,
               typename S::T* gmid, const float* w2, typename S::T* out, const typename S::T* gout, float* dw1, float* dw2, int F, int B, int Kj,
@@ -429,6 +683,10 @@ int td_launch(const typename S::T* arena, typename S::T* garena, const int64_t* 
   if (TWO) lds = std::max(lds, td_lds<S>(Kq, Kk1, Kk2, BWD));
   if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "%s: Kj=%d, Kq=%d, Kk=%d, %d do not fit in LDS", who, Kj, Kq, Kk1, Kk2);
   const dim3 grid(B, F), block(256);
+  // (CK_TD_GENERIC=1: the shape-generic kernels also for 32 units -- tests compare the two)
+  const char* env = getenv("CK_TD_GENERIC");
+  const bool generic_only = env != nullptr && atoi(env) != 0;
+  const bool all32 = !generic_only && Kj == 32 && Kq == 32 && Kk1 == 32 && (!TWO || Kk2 == 32);
   return ck::dispatch(
       [=](hipStream_t s) {
         auto go = [&](auto kern, auto&&... args) {
@@ -439,6 +697,15 @@ int td_launch(const typename S::T* arena, typename S::T* garena, const int64_t* 
           hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
           return hipGetLastError();
         };
+        if (all32) {  // (static LDS: 30 - 46 KB)
+          using S32 = std::conditional_t<std::is_same_v<S, TdC>, TdC32, TdR32>;
+          if constexpr (BWD)
+            hipLaunchKernelGGL((td32_bwd_kernel<S32, TWO>), grid, block, 0, s, arena, garena, row_off, H, w1, static_cast<const typename S::T*>(mid),
+                               gmid, w2, static_cast<const typename S::T*>(out), gout, dw1, dw2, B);
+          else
+            hipLaunchKernelGGL((td32_fwd_kernel<S32, TWO>), grid, block, 0, s, arena, row_off, H, w1, mid, w2, out, B);
+          return hipGetLastError();
+        }
         if constexpr (BWD)
           return go(td_bwd_kernel<S, TWO>, arena, garena, row_off, H, w1, static_cast<const typename S::T*>(mid), gmid, w2,
                     static_cast<const typename S::T*>(out), gout, dw1, dw2, B, Kj, Kq, Kk1, Kk2);

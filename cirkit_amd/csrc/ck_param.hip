@@ -139,6 +139,68 @@ __global__ void __launch_bounds__(256)
   if (m < M && n < N) out[f * static_cast<int64_t>(M) * N + static_cast<int64_t>(m) * N + n] = acc;
 }
 
+// The same product on (32, 64) output tiles, 2 x 4 outputs per thread, 32 contracted entries per barrier pair, every access to
+// memory a coalesced run along the operand's fastest axis (the 16 x 16 form above reads and writes a line per 16 threads and
+// spends two barriers per 16 multiply-adds: 40 - 48 us for the 784 Gram matrices W W^T / their backward (G + G^T) W of a squared
+// circuit -- 25.7 MB operands, i.e. ~5 us of traffic).  The sum over k runs in the same order: bit-identical.
+constexpr int kBT_M = 32, kBT_N = 64, kBT_K = 32;
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256)
+    bmm_tile_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int M, int N, int Kd) {
+  __shared__ __attribute__((aligned(16))) float as[kBT_K][kBT_M + 2];   // [k][m]
+  __shared__ __attribute__((aligned(16))) float bs[kBT_K][kBT_N + 4];   // [k][n]
+  const int64_t f = blockIdx.z;
+  const float* af = a + f * static_cast<int64_t>(M) * Kd;
+  const float* bf = b + f * static_cast<int64_t>(Kd) * N;
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const int m0 = blockIdx.y * kBT_M, n0 = blockIdx.x * kBT_N;
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int k0 = 0; k0 < Kd; k0 += kBT_K) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // A: 32 x 32
+      const int i = t + 256 * r;
+      const int mm = TA ? (i & 31) : (i >> 5), kk = TA ? (i >> 5) : (i & 31);
+      const int m = m0 + mm, k = k0 + kk;
+      as[kk][mm] = (m < M && k < Kd) ? (TA ? af[static_cast<int64_t>(k) * M + m] : af[static_cast<int64_t>(m) * Kd + k]) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {  // B: 32 x 64
+      const int i = t + 256 * r;
+      const int nn = TB ? (i >> 5) : (i & 63), kk = TB ? (i & 31) : (i >> 6);
+      const int n = n0 + nn, k = k0 + kk;
+      bs[kk][nn] = (n < N && k < Kd) ? (TB ? bf[static_cast<int64_t>(n) * Kd + k] : bf[static_cast<int64_t>(k) * N + n]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < kBT_K; ++k) {
+      const float2 av = *reinterpret_cast<const float2*>(&as[k][2 * ty]);
+      const float4 bv = *reinterpret_cast<const float4*>(&bs[k][4 * tx]);
+      acc[0][0] = fmaf(av.x, bv.x, acc[0][0]);
+      acc[0][1] = fmaf(av.x, bv.y, acc[0][1]);
+      acc[0][2] = fmaf(av.x, bv.z, acc[0][2]);
+      acc[0][3] = fmaf(av.x, bv.w, acc[0][3]);
+      acc[1][0] = fmaf(av.y, bv.x, acc[1][0]);
+      acc[1][1] = fmaf(av.y, bv.y, acc[1][1]);
+      acc[1][2] = fmaf(av.y, bv.z, acc[1][2]);
+      acc[1][3] = fmaf(av.y, bv.w, acc[1][3]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int m = m0 + 2 * ty + u;
+    if (m >= M) continue;
+    float* o = out + f * static_cast<int64_t>(M) * N + static_cast<int64_t>(m) * N + n0 + 4 * tx;
+    if (n0 + 4 * tx + 3 < N && (N & 3) == 0) {
+      *reinterpret_cast<float4*>(o) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (n0 + 4 * tx + v < N) o[v] = acc[u][v];
+    }
+  }
+}
+
 // (R, A, Bd) -> (R, Bd, A) through a 32x32 LDS tile, optional log.
 template <class T>
 __global__ void __launch_bounds__(256)
@@ -1051,6 +1113,18 @@ int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N
   CK_REQUIRE(a && b && out, "ck_param_bmm: null pointer");
   CK_REQUIRE(F > 0 && M > 0 && N > 0 && Kd > 0, "ck_param_bmm: non-positive size");
   CK_REQUIRE(F <= 65535, "ck_param_bmm: F exceeds grid.z");
+  if (M * static_cast<int64_t>(N) >= 512 && ck::aligned16(out)) {  // (small products, e.g. a row of ones times a block: the 16 x 16 form)
+    dim3 grid((N + kBT_N - 1) / kBT_N, (M + kBT_M - 1) / kBT_M, F), block(256);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          if (trans_a && trans_b) hipLaunchKernelGGL((bmm_tile_kernel<true, true>), grid, block, 0, s, a, b, out, M, N, Kd);
+          else if (trans_a) hipLaunchKernelGGL((bmm_tile_kernel<true, false>), grid, block, 0, s, a, b, out, M, N, Kd);
+          else if (trans_b) hipLaunchKernelGGL((bmm_tile_kernel<false, true>), grid, block, 0, s, a, b, out, M, N, Kd);
+          else hipLaunchKernelGGL((bmm_tile_kernel<false, false>), grid, block, 0, s, a, b, out, M, N, Kd);
+          return hipGetLastError();
+        },
+        stream);
+  }
   dim3 grid((N + kMM - 1) / kMM, (M + kMM - 1) / kMM, F), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {

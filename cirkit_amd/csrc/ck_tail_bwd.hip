@@ -11,6 +11,7 @@
 // slots -- 128 workgroups adding into the few folds of a level at the same moment is exactly the pattern float atomics are
 // slowest at (~8 ns per atomic on one line: scripts/ubench/atomic_scatter.hip).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ck_bwd_tile.h"
 #include "ck_internal.h"
@@ -35,7 +36,6 @@ struct TailBwdArgs {
   int64_t part_stride;         // floats between the slots of consecutive tiles
 };
 
-constexpr int kTbwWaves = 8;
 
 // Pointers out of the descriptor table are generic: say "device memory" on every access (FLAT instructions count on vmcnt AND
 // lgkmcnt -- every LDS wait behind one would also wait for the prefetched tiles; ck_internal.h gload4 / gstore4).
@@ -54,6 +54,8 @@ __device__ __forceinline__ void gtile_store(float* row, const float (&v)[16]) {
   for (int g = 0; g < 4; ++g) ck::gstore4(row + 8 * g, make_float4(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]));
 }
 
+// kTbwWaves wavefronts per workgroup: a level of n folds takes ceil(n / kTbwWaves) rounds of one ~6 us unit chain each
+template <int kTbwWaves>
 __global__ void __launch_bounds__(kTbwWaves * 64) tail_bwd_kernel(const TailBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tbw_lds[];
   float* scratch = tbw_lds;                                                    // kTbwWaves x 2 x 1024: the operands of a wave's dW contraction
@@ -220,7 +222,15 @@ extern "C" int ck_tail_bwd(const ck_tail_bwd_fold* folds, int n_folds, const int
   CK_REQUIRE(ck::aligned16(folds), "ck_tail_bwd: folds not 16-byte aligned");
   // (per fold -- DEVICE data, not checked here: H in {1, 2} with child[1] / gchild[1] naming the first child again when H = 1;
   //  Ko = 32 everywhere but, possibly, in a single first fold that is a level of its own)
-  const size_t lds = static_cast<size_t>(kTbwWaves) * 2048 * sizeof(float) + static_cast<size_t>(n_folds) * sizeof(TailBwdFold) +
+  // (lab switch.  12 waves -- three per SIMD, 160 registers -- walk config 2's tail (1, 2, 4, 6, 11, 24 folds) in 7 rounds instead of
+  //  9 and take the same 59 us: the launch is the levels' dependent round trips + the MFMA chains of one CU, not rounds;
+  //  16 waves spill 38 registers: step 0.683 against 0.641 ms.  LAB_NOTES R5.4)
+  static const int waves = [] {
+    const char* e = getenv("CK_TAIL_BWD_WAVES");
+    const int w = e ? atoi(e) : 8;
+    return (w == 12 || w == 16) ? w : 8;
+  }();
+  const size_t lds = static_cast<size_t>(waves) * 2048 * sizeof(float) + static_cast<size_t>(n_folds) * sizeof(TailBwdFold) +
                      static_cast<size_t>(n_levels + 1) * sizeof(int32_t);
   if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_tail_bwd: %d folds do not fit in LDS", n_folds);
   TailBwdArgs a{};
@@ -231,14 +241,15 @@ extern "C" int ck_tail_bwd(const ck_tail_bwd_fold* folds, int n_folds, const int
   a.B = B;
   a.part_stride = part_stride;
   const dim3 grid(static_cast<unsigned>((B + 31) / 32));
+  auto kern = waves == 8 ? tail_bwd_kernel<8> : (waves == 16 ? tail_bwd_kernel<16> : tail_bwd_kernel<12>);
   return ck::dispatch(
       [=](hipStream_t s) {
         if (lds > 48 * 1024) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tail_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));
           if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(tail_bwd_kernel, grid, dim3(kTbwWaves * 64), lds, s, a);
+        hipLaunchKernelGGL(kern, grid, dim3(waves * 64), lds, s, a);
         return hipGetLastError();
       },
       stream);

@@ -12,7 +12,10 @@ for B in ([int(a) for a in sys.argv[1:]] or [256,4096]):
     x=torch.randint(0,256,(B,784),generator=torch.Generator().manual_seed(B)).cuda()
     for _ in range(3): ll=tr.step(x)
     torch.cuda.synchronize(); t0=time.perf_counter()
-    n=10
-    for _ in range(n): ll=tr.step(x)
+    n=int(os.environ.get("CK_SQ_STEPS","10"))
+    host=[]
+    for _ in range(n):
+        h0=time.perf_counter(); ll=tr.step(x); host.append(time.perf_counter()-h0)
     torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/n
+    print("host time per step() call, us:", " ".join(f"{1e6*h:.0f}" for h in host[:12]))
     print(f"squared-circuit training step (config 5 plans, B={B}): {dt*1e3:.2f} ms, mean LL {float(ll[0]/ll[1]):.3f}")
