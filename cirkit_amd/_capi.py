@@ -9,7 +9,7 @@ from typing import Any
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -216,6 +216,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_conj": [_p, _p, _l, _p],
     "ck_param_mixing_weight": [_p, _p, _i, _i, _i, _p],
     "ck_param_bmm": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ck_param_bmm_acc": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_param_einsum": [_p, _p],
     "ck_param_transpose_last2": [_p, _p, _l, _i, _i, _i, _i, _p],
     "ck_param_transpose_last2_c": [_p, _p, _l, _i, _i, _i, _p],
@@ -273,6 +274,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_jobs_cat_bwd": [_p, _i, _p, _i, _i, _p, _p],
     "ck_jobs_gauss_bwd": [_p, _i, _p, _i, _p, _p],
     "ck_opt_step_range": [_p, _p, _p, _p, _l, _p, _p],
+    "ck_opt_step_range2": [_p, _p, _p, _p, _p, _l, _p, _p],
     "ck_opt_tick": [_p, _p, _p, _p],
     "ck_ll_sum": [_p, _l, _l, _p, _p],
     "ck_program_begin": [C.POINTER(_p)],

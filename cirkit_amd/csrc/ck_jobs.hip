@@ -1161,14 +1161,14 @@ __global__ void __launch_bounds__(256)
 // The optimizer step on one flat range with the constants and clock of a DEVICE ck_opt_state (recordable: nothing of the step
 // count is baked into the launch) -- the tensors no job epilogue updates.
 __global__ void __launch_bounds__(256)
-    opt_range_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, int64_t n,
-                     const ck_opt_state* __restrict__ opt) {
+    opt_range_kernel(float* __restrict__ p, const float* __restrict__ g, const float* __restrict__ g2, float* __restrict__ m1,
+                     float* __restrict__ m2, int64_t n, const ck_opt_state* __restrict__ opt) {
   const ck_opt_state os = *opt;
   const OptK ok = opt_k(os);
   if (os.skip_now) return;
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) {
     float a = os.kind ? m1[i] : 0.f, b = os.kind ? m2[i] : 0.f;
-    p[i] = opt_update(ok, p[i], g[i], a, b);
+    p[i] = opt_update(ok, p[i], g2 != nullptr ? g[i] + g2[i] : g[i], a, b);
     if (os.kind) {
       m1[i] = a;
       m2[i] = b;
@@ -1317,11 +1317,15 @@ int ck_jobs_gauss_bwd(const ck_gauss_job* jobs, int n_jobs, const float* const* 
 }
 
 int ck_opt_step_range(float* p, const float* g, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream) {
+  return ck_opt_step_range2(p, g, nullptr, m1, m2, n, opt, stream);
+}
+
+int ck_opt_step_range2(float* p, const float* g, const float* g2, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream) {
   CK_REQUIRE(p && g && opt && n > 0, "ck_opt_step_range: bad arguments");
   const unsigned grid = static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 2048));
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(opt_range_kernel, dim3(grid), dim3(256), 0, s, p, g, m1, m2, n, opt);
+        hipLaunchKernelGGL(opt_range_kernel, dim3(grid), dim3(256), 0, s, p, g, g2, m1, m2, n, opt);
         return hipGetLastError();
       },
       stream);

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256)
 constexpr int kMM = 16;
 __global__ void __launch_bounds__(256)
     bmm_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-               int M, int N, int Kd, int trans_a, int trans_b) {
+               int M, int N, int Kd, int trans_a, int trans_b, int accumulate) {
   __shared__ float as[kMM][kMM + 1], bs[kMM][kMM + 1];
   const int64_t f = blockIdx.z;
   const float* af = a + f * static_cast<int64_t>(M) * Kd;
@@ -136,7 +136,10 @@ __global__ void __launch_bounds__(256)
     for (int k = 0; k < kMM; ++k) acc = fmaf(as[ty][k], bs[k][tx], acc);
     __syncthreads();
   }
-  if (m < M && n < N) out[f * static_cast<int64_t>(M) * N + static_cast<int64_t>(m) * N + n] = acc;
+  if (m < M && n < N) {
+    float* o = out + f * static_cast<int64_t>(M) * N + static_cast<int64_t>(m) * N + n;
+    *o = accumulate ? *o + acc : acc;
+  }
 }
 
 // The same product on (32, 64) output tiles, 2 x 4 outputs per thread, 32 contracted entries per barrier pair, every access to
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(256)
 constexpr int kBT_M = 32, kBT_N = 64, kBT_K = 32;
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256)
-    bmm_tile_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int M, int N, int Kd) {
+    bmm_tile_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int M, int N, int Kd, int accumulate) {
   __shared__ __attribute__((aligned(16))) float as[kBT_K][kBT_M + 2];   // [k][m]
   __shared__ __attribute__((aligned(16))) float bs[kBT_K][kBT_N + 4];   // [k][n]
   const int64_t f = blockIdx.z;
@@ -192,11 +195,16 @@ __global__ void __launch_bounds__(256)
     if (m >= M) continue;
     float* o = out + f * static_cast<int64_t>(M) * N + static_cast<int64_t>(m) * N + n0 + 4 * tx;
     if (n0 + 4 * tx + 3 < N && (N & 3) == 0) {
-      *reinterpret_cast<float4*>(o) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+      float4 r = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+      if (accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(o);
+        r = make_float4(old.x + r.x, old.y + r.y, old.z + r.z, old.w + r.w);
+      }
+      *reinterpret_cast<float4*>(o) = r;
     } else {
 #pragma unroll
       for (int v = 0; v < 4; ++v)
-        if (n0 + 4 * tx + v < N) o[v] = acc[u][v];
+        if (n0 + 4 * tx + v < N) o[v] = accumulate ? o[v] + acc[u][v] : acc[u][v];
     }
   }
 }
@@ -1110,6 +1118,11 @@ int ck_param_mixing_weight(const float* in, float* out, int F, int K, int H, voi
 
 int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd,
                  int trans_a, int trans_b, void* stream) {
+  return ck_param_bmm_acc(a, b, out, F, M, N, Kd, trans_a, trans_b, 0, stream);
+}
+
+int ck_param_bmm_acc(const float* a, const float* b, float* out, int F, int M, int N, int Kd, int trans_a, int trans_b, int accumulate,
+                     void* stream) {
   CK_REQUIRE(a && b && out, "ck_param_bmm: null pointer");
   CK_REQUIRE(F > 0 && M > 0 && N > 0 && Kd > 0, "ck_param_bmm: non-positive size");
   CK_REQUIRE(F <= 65535, "ck_param_bmm: F exceeds grid.z");
@@ -1117,10 +1130,10 @@ int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N
     dim3 grid((N + kBT_N - 1) / kBT_N, (M + kBT_M - 1) / kBT_M, F), block(256);
     return ck::dispatch(
         [=](hipStream_t s) {
-          if (trans_a && trans_b) hipLaunchKernelGGL((bmm_tile_kernel<true, true>), grid, block, 0, s, a, b, out, M, N, Kd);
-          else if (trans_a) hipLaunchKernelGGL((bmm_tile_kernel<true, false>), grid, block, 0, s, a, b, out, M, N, Kd);
-          else if (trans_b) hipLaunchKernelGGL((bmm_tile_kernel<false, true>), grid, block, 0, s, a, b, out, M, N, Kd);
-          else hipLaunchKernelGGL((bmm_tile_kernel<false, false>), grid, block, 0, s, a, b, out, M, N, Kd);
+          if (trans_a && trans_b) hipLaunchKernelGGL((bmm_tile_kernel<true, true>), grid, block, 0, s, a, b, out, M, N, Kd, accumulate);
+          else if (trans_a) hipLaunchKernelGGL((bmm_tile_kernel<true, false>), grid, block, 0, s, a, b, out, M, N, Kd, accumulate);
+          else if (trans_b) hipLaunchKernelGGL((bmm_tile_kernel<false, true>), grid, block, 0, s, a, b, out, M, N, Kd, accumulate);
+          else hipLaunchKernelGGL((bmm_tile_kernel<false, false>), grid, block, 0, s, a, b, out, M, N, Kd, accumulate);
           return hipGetLastError();
         },
         stream);
@@ -1128,7 +1141,7 @@ int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N
   dim3 grid((N + kMM - 1) / kMM, (M + kMM - 1) / kMM, F), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(bmm_kernel, grid, block, 0, s, a, b, out, M, N, Kd, trans_a, trans_b);
+        hipLaunchKernelGGL(bmm_kernel, grid, block, 0, s, a, b, out, M, N, Kd, trans_a, trans_b, accumulate);
         return hipGetLastError();
       },
       stream);

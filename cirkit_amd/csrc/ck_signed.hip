@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "ck_bwd_tile.h"
 #include "ck_internal.h"
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(256)
 
 // Four waves walk the row tiles of one fold with dW in registers; one float atomic per weight entry and workgroup at the end
 // (the skeleton of sum_clse_bwd_tile32, ck_backward_c.hip, with half its contractions).
+template <bool READ_Y>  // (lab, CK_SLSE_READ_Y=1: the stored outputs instead of y = W a again)
 __global__ void __launch_bounds__(256)
     slse_tile32_bwd(const float* __restrict__ arena, const uint32_t* __restrict__ signs, float* __restrict__ gx,
                     const int64_t* __restrict__ row_off, const float* __restrict__ w, const float* __restrict__ out,
@@ -175,6 +177,8 @@ __global__ void __launch_bounds__(256)
     const int q = idx >> 8, ln = (idx >> 2) & 63, t = idx & 3;
     wt_s[idx] = wf[(8 * q + 4 * (ln >> 5) + t) * 32 + (ln & 31)];
   }
+  WRegs wr;  // (A operand of y = W a)
+  load_w<CK_W_ROWMAJOR>(wf, lane, wr);
   __syncthreads();
   f32x16 dacc;
 #pragma unroll
@@ -196,15 +200,25 @@ __global__ void __launch_bounds__(256)
     }
     float t[16];
     {
+      // y = W a again instead of the stored output (16 MFMAs against 4 KB per tile of a launch that waits for memory: the
+      // first layer of config 5 reads 205 MB less): t_o = G_o exp(m) / (y_o exp(m)) = G_o / (W a)_o, signed as it comes; an
+      // output without gradient contributes nothing (also where y = 0: out = -inf)
       float y[16], g[16];
-      load_tile_native(out + static_cast<int64_t>(f) * Bp * 32, tile, lane, y);
       load_tile_native(gf, tile, lane, g);
-      const uint32_t so = sout[static_cast<int64_t>(f) * Bp + bl];
+      if constexpr (READ_Y) {
+        load_tile_native(out + static_cast<int64_t>(f) * Bp * 32, tile, lane, y);
+        const uint32_t so = sout[static_cast<int64_t>(f) * Bp + bl];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        // exp(m) / y_o = sign exp(m - out_o); an output without gradient contributes nothing (also where out = -inf)
-        const float r = exp_fast(m - y[j]) * g[j];
-        t[j] = (live && g[j] != 0.f) ? (bit_of(so, j, kh) ? -r : r) : 0.f;
+        for (int j = 0; j < 16; ++j) {
+          const float r = exp_fast(m - y[j]) * g[j];  // exp(m) / y_o = sign exp(m - out_o)
+          t[j] = (live && g[j] != 0.f) ? (bit_of(so, j, kh) ? -r : r) : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) y[j] = a[j];
+        contract_linear<CK_W_ROWMAJOR>(wr, y);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = (live && g[j] != 0.f && y[j] != 0.f) ? g[j] * __builtin_amdgcn_rcpf(y[j]) : 0.f;
       }
     }
     float gv[16];
@@ -423,10 +437,16 @@ extern "C" int ck_slse_bwd(const float* arena, const uint32_t* signs, const int6
     const int tiles = (B + 31) / 32;
     const int nx = std::max(1, std::min((tiles + 3) / 4, 16));
     const dim3 grid(static_cast<unsigned>((F + 7) / 8 * 8 * nx)), block(256);
+    const char* env = getenv("CK_SLSE_READ_Y");
+    const bool read_y = env != nullptr && atoi(env) != 0;
     return ck::dispatch(
         [=](hipStream_t s) {
-          hipLaunchKernelGGL(slse_tile32_bwd, grid, block, 0, s, arena, signs, gx, row_off, w, out, sout, gout, gout_off, dw, H, B, ga, F, nx,
-                             ga.table != nullptr ? 1 : 0);
+          if (read_y)
+            hipLaunchKernelGGL(slse_tile32_bwd<true>, grid, block, 0, s, arena, signs, gx, row_off, w, out, sout, gout, gout_off, dw, H, B, ga, F,
+                               nx, ga.table != nullptr ? 1 : 0);
+          else
+            hipLaunchKernelGGL(slse_tile32_bwd<false>, grid, block, 0, s, arena, signs, gx, row_off, w, out, sout, gout, gout_off, dw, H, B, ga, F,
+                               nx, ga.table != nullptr ? 1 : 0);
           return hipGetLastError();
         },
         stream);

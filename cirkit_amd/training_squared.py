@@ -646,10 +646,13 @@ class HipSquaredTrainer:
         self._opt_key = key
         return self._opt
 
-    def _enqueue_optimizer(self, stream: int) -> None:
+    def _enqueue_optimizer(self, stream: int, with_z: bool = False) -> None:
+        """`with_z`: the optimizer reads c's and Z's gradient buffers and adds them itself (no axpy launch before it; `grads`
+        then holds c's part only -- `loss_and_grads` leaves the sum)."""
         p = self._flat_param
-        capi.call("ck_opt_step_range", p.data_ptr(), self._flat_grad.data_ptr(), None if self._m1 is None else self._m1.data_ptr(),
-                  None if self._m2 is None else self._m2.data_ptr(), p.numel(), self._opt_state().data_ptr(), stream)
+        capi.call("ck_opt_step_range2", p.data_ptr(), self._flat_grad.data_ptr(), self._flat_grad_z.data_ptr() if with_z else None,
+                  None if self._m1 is None else self._m1.data_ptr(), None if self._m2 is None else self._m2.data_ptr(), p.numel(),
+                  self._opt_state().data_ptr(), stream)
 
     def _enqueue(self, part: str, B: int, gB: float, with_optimizer: bool, stream: int) -> None:
         n = self._flat_grad.numel()
@@ -672,12 +675,13 @@ class HipSquaredTrainer:
             if with_optimizer:  # the clock first: a batch with an illegal category drops the step (skip_now)
                 capi.call("ck_opt_tick", self._opt_state().data_ptr(), c._bad_input.data_ptr() if validate else None,
                           self._bad_seen.data_ptr() if validate else None, stream)
-            capi.call("ck_axpy_f32", self._flat_grad.data_ptr(), self._flat_grad_z.data_ptr(), 1.0, n, stream)
+            if not with_optimizer:
+                capi.call("ck_axpy_f32", self._flat_grad.data_ptr(), self._flat_grad_z.data_ptr(), 1.0, n, stream)
             yc = self._signed.output(B) if self._signed is not None else c._bind(B).views[int(c._out_pairs[0, 0])][int(c._out_pairs[0, 1])]
             yz = z._bind(1).views[int(z._out_pairs[0, 0])][int(z._out_pairs[0, 1])]
             capi.call("ck_squared_ll", yc.data_ptr(), B, 2 if yc.is_complex() else 1, yz.data_ptr(), self._ll.data_ptr(), stream)
             if with_optimizer:
-                self._enqueue_optimizer(stream)
+                self._enqueue_optimizer(stream, with_z=True)
 
     def _part(self, part: str, B: int, gB: float, with_optimizer: bool, run: torch.cuda.Stream) -> None:
         """One of the three recorded launch lists of a step -- "c": the backward of c; "z": the backward of Z; "end": the sum of

@@ -510,6 +510,11 @@ int ck_param_mixing_weight(const float* in, float* out, int F, int K, int H, voi
  * trans_a; b: (F,Kd,N) or (F,N,Kd) if trans_b; out: (F,M,N). */
 int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd,
                  int trans_a, int trans_b, void* stream);
+/* The same with `accumulate` != 0: out[f] += op(a[f]) . op(b[f]) -- the gradient of an einsum operand added straight into the
+ * gradient of the stored tensor behind it (autograd's accumulation through TorchPointerParameter / TorchConjugateParameter /
+ * TorchFlattenParameter, nodes.py:277-279, 745-746, 843-844) instead of a product buffer and an axpy. */
+int ck_param_bmm_acc(const float* a, const float* b, float* out, int F, int M, int N, int Kd, int trans_a, int trans_b, int accumulate,
+                     void* stream);
 /* (R, A, Bd) -> (R, out_rows >= Bd, A) transpose of the last two axes (rows beyond Bd untouched),
  * optionally taking log first (categorical: log(probs) -> table (F, C+1, K), input.py:405-408). */
 /* TorchEinsumParameter (parameters/optimized.py:282-284) for any pattern: out[f, o...] = sum over the contracted indices of
@@ -946,6 +951,9 @@ int ck_jobs_gauss_bwd(const ck_gauss_job* jobs, int n_jobs, const float* const* 
 /* The optimizer step p <- p - ... on one flat range with the constants and the clock of a DEVICE ck_opt_state (m1 / m2 may be
  * NULL for SGD): what ck_adam_step / ck_sgd_step do, recordable (no step count in the launch) and skipped with the state. */
 int ck_opt_step_range(float* p, const float* g, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream);
+/* The same on the SUM of two gradient buffers (g2 may be null): a squared circuit's step adds the gradient of Z -- accumulated
+ * in a buffer of its own beside c's launches -- where the optimizer reads it instead of in an axpy launch before. */
+int ck_opt_step_range2(float* p, const float* g, const float* g2, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream);
 /* Once per step, before the backward launches: *flag != 0 (the forward's validation flag) -> this step is dropped (skip_now = 1,
  * skipped += 1, *sticky |= *flag, *flag = 0); else step += 1 and the bias corrections of this step.  flag / sticky may be NULL. */
 int ck_opt_tick(ck_opt_state* state, int32_t* flag, int32_t* sticky, void* stream);
