@@ -458,6 +458,40 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 // TorchMixingWeightParameter, nodes.py:847-862, under semiring.py:383-408: the reference shifts by the maximum of the whole row,
 // the value is the same for any shift that bounds the unit's own inputs);  x_h = the sum of slot h's blocks.
 // 256 threads: 16 rows per pass, thread (r, c) owns units 4 c .. 4 c + 3 of its row.
+//
+// One slot into a unit's running sum: y <- w exp(x - m') + y exp(m - m'), m' = clamp(max(m, x)), m <- m'.  The larger of (m, x)
+// IS m' unless it is infinite, so its exponential is 1 (inf / 0 at +-inf): ONE exponential per slot and unit, of the smaller
+// one -- the launch was bound by issuing two library exponentials per slot and unit (config 4: 0.56 ms of a 4.6 ms step).
+#ifndef CK_MIX_LIBM
+#define CK_MIX_LIBM 0  // 1: expf / logf of the library instead of v_exp_f32 / v_log_f32 (as the sum jobs: ~1e-7 relative)
+#endif
+__device__ __forceinline__ float mix_exp(float d) {  // d <= 0 (or NaN)
+#if CK_MIX_LIBM
+  return expf(d);
+#else
+  const float t = d * kL2E;
+  const float lo = fmaf(d, kL2E, -t);  // the rounding error of the product, put back: exp2(t + lo) = exp2(t) (1 + lo ln 2)
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fabsf(t) < 1e30f ? fmaf(e, lo * kLN2, e) : e;
+#endif
+}
+__device__ __forceinline__ float mix_log(float y) {
+#if CK_MIX_LIBM
+  return logf(y);
+#else
+  return __builtin_amdgcn_logf(y) * kLN2;
+#endif
+}
+__device__ __forceinline__ void mix_step(float w, float x, float& m, float& y) {
+  const bool x_big = x >= m;
+  const float big = fmaxf(m, x);  // (a NaN x is the "smaller" one: its exponential is NaN, as before)
+  const float mn = ck::clamp_finite(big);
+  const float t = mix_exp((x_big ? m : x) - mn);
+  const float db = big - mn;
+  const float eb = db == 0.f ? 1.f : (db > 0.f ? INFINITY : (db < 0.f ? 0.f : db));
+  y = fmaf(w, x_big ? eb : t, y * (x_big ? t : eb));
+  m = mn;
+}
 __global__ void __launch_bounds__(256)
     jobs_mix_fwd_kernel(const MixJob* __restrict__ jobs, const float* const* __restrict__ pool) {
   __shared__ float w_s[kU * 17];
@@ -473,21 +507,31 @@ __global__ void __launch_bounds__(256)
     // ONE pass over the slots: a running maximum PER UNIT (the sum of a unit only involves that unit's inputs, so any
     // shift that bounds them gives the reference's value; the reference shifts by the maximum of the whole row)
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), y = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int h = 0; h < H; ++h) {
-      float4 x = ck::gload4(pool[in_off + h * S] + bl * kU + 4 * c);
+    for (int h0 = 0; h0 < H; h0 += 4) {
+      // four slots' blocks in flight (slot after slot, block after block was a chain of H S round trips per 16 rows); a slot's
+      // blocks are added in list order, the slots enter the running sum in order
+      float4 xs[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xs[k] = ck::gload4(pool[in_off + min(h0 + k, H - 1) * S] + bl * kU + 4 * c);
       for (int s = 1; s < S; ++s) {
-        const float4 t = ck::gload4(pool[in_off + h * S + s] + bl * kU + 4 * c);
-        x.x += t.x, x.y += t.y, x.z += t.z, x.w += t.w;
+        float4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = ck::gload4(pool[in_off + min(h0 + k, H - 1) * S + s] + bl * kU + 4 * c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[k].x += t[k].x, xs[k].y += t[k].y, xs[k].z += t[k].z, xs[k].w += t[k].w;
       }
-      const float4 mn = make_float4(ck::clamp_finite(fmaxf(m.x, x.x)), ck::clamp_finite(fmaxf(m.y, x.y)), ck::clamp_finite(fmaxf(m.z, x.z)),
-                                    ck::clamp_finite(fmaxf(m.w, x.w)));
-      y.x = fmaf(w_s[(4 * c + 0) * 17 + h], expf(x.x - mn.x), y.x * expf(m.x - mn.x));
-      y.y = fmaf(w_s[(4 * c + 1) * 17 + h], expf(x.y - mn.y), y.y * expf(m.y - mn.y));
-      y.z = fmaf(w_s[(4 * c + 2) * 17 + h], expf(x.z - mn.z), y.z * expf(m.z - mn.z));
-      y.w = fmaf(w_s[(4 * c + 3) * 17 + h], expf(x.w - mn.w), y.w * expf(m.w - mn.w));
-      m = mn;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int h = h0 + k;
+        if (h >= H) break;
+        const float4 x = xs[k];
+        mix_step(w_s[(4 * c + 0) * 17 + h], x.x, m.x, y.x);
+        mix_step(w_s[(4 * c + 1) * 17 + h], x.y, m.y, y.y);
+        mix_step(w_s[(4 * c + 2) * 17 + h], x.z, m.z, y.z);
+        mix_step(w_s[(4 * c + 3) * 17 + h], x.w, m.w, y.w);
+      }
     }
-    if (live) ck::gstore4(J.out + bl * kU + 4 * c, make_float4(logf(y.x) + m.x, logf(y.y) + m.y, logf(y.z) + m.z, logf(y.w) + m.w));
+    if (live) ck::gstore4(J.out + bl * kU + 4 * c, make_float4(mix_log(y.x) + m.x, mix_log(y.y) + m.y, mix_log(y.z) + m.z, mix_log(y.w) + m.w));
   }
 }
 
@@ -671,11 +715,22 @@ __global__ void __launch_bounds__(64) jobs_mix_params_kernel(const MixJob* __res
 __global__ void __launch_bounds__(256)
     jobs_nsum_kernel(const ck_nsum_job* __restrict__ jobs, const float* const* __restrict__ pool, int64_t elems) {
   const ck_nsum_job& J = jobs[blockIdx.y];
+  const int n_in = J.n_in;
+  const float* const* __restrict__ src = pool + J.in_off;
   for (int64_t i = (blockIdx.x * 256ll + threadIdx.x) * 4; i < elems; i += gridDim.x * 1024ll) {
-    float4 a = ck::gload4(pool[J.in_off] + i);
-    for (int s = 1; s < J.n_in; ++s) {
-      const float4 t = ck::gload4(pool[J.in_off + s] + i);
-      a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+    // four blocks' loads in flight (a thread has ONE iteration at 1024 rows: block after block is a chain of round trips),
+    // added in list order
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < n_in; s0 += 4) {
+      float4 t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = ck::gload4(src[min(s0 + k, n_in - 1)] + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (s0 + k < n_in) {
+          if (s0 + k == 0) a = t[k];
+          else a.x += t[k].x, a.y += t[k].y, a.z += t[k].z, a.w += t[k].w;
+        }
     }
     ck::gstore4(J.out + i, a);
   }

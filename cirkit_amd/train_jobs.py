@@ -612,6 +612,10 @@ class JobStep:
             hmax = max(j["H"] for j in jobs)
             hpad = 2 if hmax <= 2 else 4 if hmax <= 4 else 8 if hmax <= 8 else 16
             ns = splits_for(len(jobs), max(1, B // 64))
+            if not backward:
+                # the forward has no sums over the rows: eight workgroups per CU instead of two (a workgroup is a chain of one
+                # round trip per 16 rows, and 256 threads with 4 KB of LDS leave room for eight of them)
+                ns = int(max(1, min(max(1, B // 64), -(-int(os.environ.get("CK_MIX_FWD_WG", "8")) * n_cu // max(1, len(jobs))))))
             rows_per = -(-(-(-B // ns)) // 16) * 16
             ns = -(-B // rows_per)
             tab = np.zeros(len(jobs) * ns, dtype=np.dtype(capi.MIX_JOB_DTYPE))
