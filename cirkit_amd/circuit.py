@@ -26,7 +26,7 @@ from . import _capi as capi
 from . import padding
 from .fusion import (CPBlock, RegionBlock, SubtreeGroup, find_cp_blocks, find_input_products, find_region_blocks,
                      find_subtree_groups, find_table_dense, find_tail, leaf_segments)
-from .layers import HipConstantValueLayer, HipEmbeddingLayer, HipInputLayer, HipLayer, layer_from_spec
+from .layers import HipConstantValueLayer, HipEmbeddingLayer, HipInputLayer, HipLayer, HipTensorDotLayer, layer_from_spec
 from .parameters import ParamBatch, TensorStore
 from .plan import Plan, resolve_fold_index
 
@@ -304,6 +304,19 @@ class HipCircuit:
                         and e not in outs and self.layers[e].scope_idx.shape[1] == 1):
                     self._emb_gather[j] = e
                     self._virtual.add(e)
+        # TensorDot layers of a product circuit with real parameters (the partition function of a squared circuit, BASELINE
+        # config 5): the Hadamard layer beneath one is read as a list (never materialised), the W / conj W pair of a squared sum
+        # layer is one launch (cirkit_amd/fusion.py tensordot_lists; 32 units everywhere: td32_fwd_kernel)
+        self._td_had: dict[int, int] = {}
+        self._td_pair: dict[int, int] = {}
+        if fuse is not False and any(isinstance(l, HipTensorDotLayer) for l in self.layers) \
+                and not any(self.store[n].is_complex() for n in self.store.names()):
+            from .fusion import tensordot_lists
+
+            busy = self._virtual | set(self._group_of_root) | set(self._tail) | set(self._emb_gather)
+            self._td_had, self._td_pair = tensordot_lists(self.layers, self._children, {int(p) for p in self._out_pairs[:, 0]}, busy)
+            self._virtual |= set(self._td_had.values())
+        self._td_first = set(self._td_pair.values())  # (launched together with the layer above them)
         self._tdense: dict[int, int] = {}  # dense layer -> the Categorical layer it is tabulated over
         self._tdense_dev: dict[int, tuple] = {}  # dense layer -> (T' (F, C+1, 32), scope (F) int64, variables (F) numpy)
         if fuse is not False and dense_on_table and batch_params:
@@ -470,8 +483,8 @@ class HipCircuit:
         # children offset tables: element offsets into the arena (replaces circuits.py:42-47)
         bd.row_off = []
         for i, (ch, l) in enumerate(zip(self._children, self.layers)):
-            if ch is None or i in self._virtual or i in self._group_of_root:
-                bd.row_off.append(None)
+            if ch is None or (i in self._virtual and i not in self._td_had.values()) or i in self._group_of_root:
+                bd.row_off.append(None)  # (a Hadamard layer read as a list by its TensorDot layer keeps its children's offsets)
                 continue
             if i in self._cp_blocks:  # slots read the dense folds' own inputs
                 ch = self._cp_blocks[i].slot_child
@@ -691,9 +704,11 @@ class HipCircuit:
                 if i == self._tail[0]:
                     self._launch_tail(bd, stream, with_ll=with_ll)
                 continue
-            if i in self._virtual:
+            if i in self._virtual or i in self._td_first:
                 continue
-            if i in self._group_of_root:
+            if i in self._td_had or i in self._td_pair:
+                self._launch_tensordot(i, bd, stream)
+            elif i in self._group_of_root:
                 self._launch_group(self._group_of_root[i], bd, view, stream)
             elif i in self._tdense:
                 self._launch_table_dense(i, bd, stream)
@@ -716,6 +731,23 @@ class HipCircuit:
                 l.launch(bd.arena, ro, view, B, stream)
         if pending:
             self._flush_leftover(pending, bd, stream)
+
+    def _launch_tensordot(self, i: int, bd: _Binding, stream: int) -> None:
+        """TensorDot layer i with what it absorbed (`_td_had`, `_td_pair`): `ck_tensordot_lse_fwd_h` / `ck_tensordot2_lse_fwd`."""
+        l = self.layers[i]
+        a = self._td_pair.get(i)
+        first = i if a is None else a
+        h = self._td_had.get(first)
+        ro, H = (bd.row_off[first], 1) if h is None else (bd.row_off[h], self.layers[h].arity)
+        cv = 1 if self._complex else 0
+        if a is None:
+            capi.call("ck_tensordot_lse_fwd_h", bd.arena.data_ptr(), ro.data_ptr(), H, l._w.data_ptr(), bd.views[i].data_ptr(), l.num_folds,
+                      bd.B, l._num_contract_units, l._num_batch_units, l.num_output_units // l._num_batch_units, cv, stream)
+        else:
+            la = self.layers[a]
+            capi.call("ck_tensordot2_lse_fwd", bd.arena.data_ptr(), ro.data_ptr(), H, la._w.data_ptr(), bd.views[a].data_ptr(),
+                      l._w.data_ptr(), bd.views[i].data_ptr(), l.num_folds, bd.B, la._num_contract_units, la._num_batch_units,
+                      la.num_output_units // la._num_batch_units, l.num_output_units // l._num_batch_units, cv, stream)
 
     def _launch_emb_gather(self, i: int, bd: _Binding, stream: int) -> None:
         """`ck_sum_clse_gather_fwd`: a complex CP-T / dense layer reading its Embedding children from the table."""
@@ -1693,8 +1725,10 @@ class HipCircuit:
                 if in_tail:
                     if i == self._tail[0]:
                         self._launch_tail(bd, stream)
-                elif i in self._virtual:
+                elif i in self._virtual or i in self._td_first:
                     pass
+                elif i in self._td_had or i in self._td_pair:
+                    self._launch_tensordot(i, bd, stream)
                 elif i in self._group_of_root:
                     self._launch_group(self._group_of_root[i], bd, view, stream)
                 elif i in self._tdense:

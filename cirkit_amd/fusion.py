@@ -459,3 +459,48 @@ def balanced_segments(num_roots: int, num_tiles: int, num_wg: int, waves: int = 
             out[r0:r0 + num_wg] = segs[r0 + perm]
         return out
     return segs
+
+
+def tensordot_lists(layers, children, out_layers: set[int], busy: set[int] = frozenset()) -> tuple[dict[int, int], dict[int, int]]:
+    """What the TensorDot launches of a squared circuit's partition function take over (`ck_tensordot_lse_fwd_h`,
+    `ck_tensordot2_lse_fwd / _bwd`, cirkit_amd/csrc/ck_backward_c.hip; TorchTensorDotLayer, optimized.py:287-300, over
+    TorchHadamardLayer, inner.py:126-127):
+
+    * ``had_of[a] = h``: the Hadamard layer h whose folds TensorDot layer a reads one to one and nobody else reads -- a reads h's
+      children as a list, h is never launched;
+    * ``pair_of[b] = a``: TensorDot layer b over TensorDot layer a, fold by fold, a read by nobody else (the W and conj W halves
+      of a squared sum layer, M' = W M W^T): one launch for both.
+
+    `out_layers`: layers that hold a circuit output (never absorbed); `busy`: layers another fusion already owns."""
+    from .layers import HipHadamardLayer, HipTensorDotLayer
+
+    readers: dict[int, set[int]] = {}
+    for j, ch in enumerate(children):
+        if ch is not None:
+            for p in np.unique(ch[..., 0]):
+                readers.setdefault(int(p), set()).add(j)
+
+    def one_to_one(j: int):
+        ch = children[j]
+        if ch is None or ch.shape[1] != 1 or len(np.unique(ch[..., 0])) != 1:
+            return None
+        p = int(ch[0, 0, 0])
+        if layers[p].num_folds != layers[j].num_folds or not np.array_equal(ch[:, 0, 1], np.arange(layers[j].num_folds)):
+            return None
+        return p if readers.get(p) == {j} and p not in out_layers and p not in busy else None
+
+    had_of: dict[int, int] = {}
+    pair_of: dict[int, int] = {}
+    for j, l in enumerate(layers):
+        if not isinstance(l, HipTensorDotLayer) or j in busy:
+            continue
+        p = one_to_one(j)
+        if p is None:
+            continue
+        lp = layers[p]
+        if isinstance(lp, HipHadamardLayer):
+            had_of[j] = p
+        elif (isinstance(lp, HipTensorDotLayer) and p not in pair_of and l._num_contract_units == lp._num_batch_units
+              and l._num_batch_units == lp.num_output_units // lp._num_batch_units):
+            pair_of[j] = p
+    return had_of, pair_of

@@ -73,39 +73,11 @@ class _PlanBackward:
                     raise NotImplementedError("squared-circuit training: Gaussian layers need lse-sum and no log-partition parameter")
             elif not isinstance(l, (HipEmbeddingLayer, HipConstantValueLayer, HipHadamardLayer, HipTensorDotLayer)):
                 raise NotImplementedError(f"squared-circuit training: layer type {spec.type!r}")
-        # What the TensorDot launches take over (ck_tensordot_lse_fwd_h / ck_tensordot2_*): `had_of[a] = h`: the Hadamard layer h
-        # whose folds TensorDot layer a reads one to one and nobody else reads -- a reads h's children as a list, h is never
-        # launched; `pair_of[b] = a`: TensorDot layer b over TensorDot layer a, fold by fold, a read by nobody else (the W and
-        # conj W halves of a squared sum layer): one launch for both.
-        readers: dict[int, set[int]] = {}
-        for j, ch in enumerate(c._children):
-            if ch is not None:
-                for p in np.unique(ch[..., 0]):
-                    readers.setdefault(int(p), set()).add(j)
+        # What the TensorDot launches take over (cirkit_amd/fusion.py: Hadamard layers read as lists, the W / conj W pair of
+        # TensorDot layers in one launch)
+        from .fusion import tensordot_lists
 
-        def one_to_one(j: int):
-            ch = c._children[j]
-            if ch is None or ch.shape[1] != 1 or len(np.unique(ch[..., 0])) != 1:
-                return None
-            p = int(ch[0, 0, 0])
-            if c.layers[p].num_folds != c.layers[j].num_folds or not np.array_equal(ch[:, 0, 1], np.arange(c.layers[j].num_folds)):
-                return None
-            return p if readers.get(p) == {j} and p != po else None
-
-        self.had_of: dict[int, int] = {}
-        self.pair_of: dict[int, int] = {}
-        for j, l in enumerate(c.layers):
-            if not isinstance(l, HipTensorDotLayer):
-                continue
-            p = one_to_one(j)
-            if p is None:
-                continue
-            lp = c.layers[p]
-            if isinstance(lp, HipHadamardLayer):
-                self.had_of[j] = p
-            elif (isinstance(lp, HipTensorDotLayer) and p not in self.pair_of and l._num_contract_units == lp._num_batch_units
-                  and l._num_batch_units == lp.num_output_units // lp._num_batch_units):
-                self.pair_of[j] = p
+        self.had_of, self.pair_of = tensordot_lists(c.layers, c._children, {po})
         self._skip = set(self.had_of.values()) | set(self.pair_of.values())
 
     def _bind(self, B: int) -> dict:
