@@ -158,22 +158,39 @@ __global__ void __launch_bounds__(256)
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const int m0 = blockIdx.y * kBT_M, n0 = blockIdx.x * kBT_N;
   float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  for (int k0 = 0; k0 < Kd; k0 += kBT_K) {
+  // the operands of chunk k0 + 32 travel while chunk k0 is multiplied (the Gram matrices contract 256 entries: eight chunks of a
+  // load -> LDS -> barrier chain were 32 us for 784 resident workgroups)
+  float ar[4], br[8];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // A: 32 x 32
       const int i = t + 256 * r;
       const int mm = TA ? (i & 31) : (i >> 5), kk = TA ? (i >> 5) : (i & 31);
       const int m = m0 + mm, k = k0 + kk;
-      as[kk][mm] = (m < M && k < Kd) ? (TA ? af[static_cast<int64_t>(k) * M + m] : af[static_cast<int64_t>(m) * Kd + k]) : 0.f;
+      ar[r] = (m < M && k < Kd) ? (TA ? af[static_cast<int64_t>(k) * M + m] : af[static_cast<int64_t>(m) * Kd + k]) : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {  // B: 32 x 64
       const int i = t + 256 * r;
       const int nn = TB ? (i >> 5) : (i & 63), kk = TB ? (i & 31) : (i >> 6);
       const int n = n0 + nn, k = k0 + kk;
-      bs[kk][nn] = (n < N && k < Kd) ? (TB ? bf[static_cast<int64_t>(n) * Kd + k] : bf[static_cast<int64_t>(k) * N + n]) : 0.f;
+      br[r] = (n < N && k < Kd) ? (TB ? bf[static_cast<int64_t>(n) * Kd + k] : bf[static_cast<int64_t>(k) * N + n]) : 0.f;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < Kd; k0 += kBT_K) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = t + 256 * r;
+      as[TA ? (i >> 5) : (i & 31)][TA ? (i & 31) : (i >> 5)] = ar[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int i = t + 256 * r;
+      bs[TB ? (i & 31) : (i >> 6)][TB ? (i >> 5) : (i & 63)] = br[r];
     }
     __syncthreads();
+    if (k0 + kBT_K < Kd) fetch(k0 + kBT_K);
 #pragma unroll 8
     for (int k = 0; k < kBT_K; ++k) {
       const float2 av = *reinterpret_cast<const float2*>(&as[k][2 * ty]);
