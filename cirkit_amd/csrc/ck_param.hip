@@ -147,10 +147,10 @@ __global__ void __launch_bounds__(256)
 // spends two barriers per 16 multiply-adds: 40 - 48 us for the 784 Gram matrices W W^T / their backward (G + G^T) W of a squared
 // circuit -- 25.7 MB operands, i.e. ~5 us of traffic).  The sum over k runs in the same order: bit-identical.
 constexpr int kBT_M = 32, kBT_N = 64, kBT_K = 32;
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool VEC>
 __global__ void __launch_bounds__(256)
     bmm_tile_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int M, int N, int Kd, int accumulate) {
-  __shared__ __attribute__((aligned(16))) float as[kBT_K][kBT_M + 2];   // [k][m]
+  __shared__ __attribute__((aligned(16))) float as[kBT_K][kBT_M + 4];   // [k][m]
   __shared__ __attribute__((aligned(16))) float bs[kBT_K][kBT_N + 4];   // [k][n]
   const int64_t f = blockIdx.z;
   const float* af = a + f * static_cast<int64_t>(M) * Kd;
@@ -159,36 +159,83 @@ __global__ void __launch_bounds__(256)
   const int m0 = blockIdx.y * kBT_M, n0 = blockIdx.x * kBT_N;
   float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   // the operands of chunk k0 + 32 travel while chunk k0 is multiplied (the Gram matrices contract 256 entries: eight chunks of a
-  // load -> LDS -> barrier chain were 32 us for 784 resident workgroups)
-  float ar[4], br[8];
+  // load -> LDS -> barrier chain were 32 us for 784 resident workgroups).  VEC (every extent a multiple of 4, 16-byte aligned
+  // operands): 16-byte loads along each operand's fastest axis -- 3 load instructions per thread and chunk instead of 12.
+  constexpr int NA = VEC ? 1 : 4, NB = VEC ? 2 : 8;
+  float4 ar[NA], br[NB];  // (scalar form: .x only)
   auto fetch = [&](int k0) {
+    if constexpr (VEC) {
+      {  // A: 32 x 32 = 256 float4
+        const int row = t >> 3, c4 = (t & 7) * 4;
+        const int m = m0 + (TA ? c4 : row), k = k0 + (TA ? row : c4);
+        ar[0] = (m < M && k < Kd) ? *reinterpret_cast<const float4*>(TA ? af + static_cast<int64_t>(k) * M + m : af + static_cast<int64_t>(m) * Kd + k)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {  // A: 32 x 32
-      const int i = t + 256 * r;
-      const int mm = TA ? (i & 31) : (i >> 5), kk = TA ? (i >> 5) : (i & 31);
-      const int m = m0 + mm, k = k0 + kk;
-      ar[r] = (m < M && k < Kd) ? (TA ? af[static_cast<int64_t>(k) * M + m] : af[static_cast<int64_t>(m) * Kd + k]) : 0.f;
+      for (int r = 0; r < 2; ++r) {  // B: 32 x 64 = 512 float4
+        const int i = t + 256 * r;
+        const int nn = TB ? (i >> 3) : (i & 15) * 4, kk = TB ? (i & 7) * 4 : (i >> 4);
+        const int n = n0 + nn, k = k0 + kk;
+        br[r] = (n < N && k < Kd) ? *reinterpret_cast<const float4*>(TB ? bf + static_cast<int64_t>(n) * Kd + k : bf + static_cast<int64_t>(k) * N + n)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // A: 32 x 32
+        const int i = t + 256 * r;
+        const int mm = TA ? (i & 31) : (i >> 5), kk = TA ? (i >> 5) : (i & 31);
+        const int m = m0 + mm, k = k0 + kk;
+        ar[r].x = (m < M && k < Kd) ? (TA ? af[static_cast<int64_t>(k) * M + m] : af[static_cast<int64_t>(m) * Kd + k]) : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {  // B: 32 x 64
+        const int i = t + 256 * r;
+        const int nn = TB ? (i >> 5) : (i & 63), kk = TB ? (i & 31) : (i >> 6);
+        const int n = n0 + nn, k = k0 + kk;
+        br[r].x = (n < N && k < Kd) ? (TB ? bf[static_cast<int64_t>(n) * Kd + k] : bf[static_cast<int64_t>(k) * N + n]) : 0.f;
+      }
     }
+  };
+  auto stage = [&]() {
+    if constexpr (VEC) {
+      const int row = t >> 3, c4 = (t & 7) * 4;
+      if (TA) {
+        *reinterpret_cast<float4*>(&as[row][c4]) = ar[0];
+      } else {
+        as[c4 + 0][row] = ar[0].x;
+        as[c4 + 1][row] = ar[0].y;
+        as[c4 + 2][row] = ar[0].z;
+        as[c4 + 3][row] = ar[0].w;
+      }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {  // B: 32 x 64
-      const int i = t + 256 * r;
-      const int nn = TB ? (i >> 5) : (i & 63), kk = TB ? (i & 31) : (i >> 6);
-      const int n = n0 + nn, k = k0 + kk;
-      br[r] = (n < N && k < Kd) ? (TB ? bf[static_cast<int64_t>(n) * Kd + k] : bf[static_cast<int64_t>(k) * N + n]) : 0.f;
+      for (int r = 0; r < 2; ++r) {
+        const int i = t + 256 * r;
+        if (TB) {
+          const int nn = i >> 3, k4 = (i & 7) * 4;
+          bs[k4 + 0][nn] = br[r].x;
+          bs[k4 + 1][nn] = br[r].y;
+          bs[k4 + 2][nn] = br[r].z;
+          bs[k4 + 3][nn] = br[r].w;
+        } else {
+          *reinterpret_cast<float4*>(&bs[i >> 4][(i & 15) * 4]) = br[r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = t + 256 * r;
+        as[TA ? (i >> 5) : (i & 31)][TA ? (i & 31) : (i >> 5)] = ar[r].x;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int i = t + 256 * r;
+        bs[TB ? (i & 31) : (i >> 6)][TB ? (i >> 5) : (i & 63)] = br[r].x;
+      }
     }
   };
   fetch(0);
   for (int k0 = 0; k0 < Kd; k0 += kBT_K) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = t + 256 * r;
-      as[TA ? (i >> 5) : (i & 31)][TA ? (i & 31) : (i >> 5)] = ar[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int i = t + 256 * r;
-      bs[TB ? (i & 31) : (i >> 6)][TB ? (i >> 5) : (i & 63)] = br[r];
-    }
+    stage();
     __syncthreads();
     if (k0 + kBT_K < Kd) fetch(k0 + kBT_K);
 #pragma unroll 8
@@ -1147,10 +1194,19 @@ int ck_param_bmm_acc(const float* a, const float* b, float* out, int F, int M, i
     dim3 grid((N + kBT_N - 1) / kBT_N, (M + kBT_M - 1) / kBT_M, F), block(256);
     return ck::dispatch(
         [=](hipStream_t s) {
-          if (trans_a && trans_b) hipLaunchKernelGGL((bmm_tile_kernel<true, true>), grid, block, 0, s, a, b, out, M, N, Kd, accumulate);
-          else if (trans_a) hipLaunchKernelGGL((bmm_tile_kernel<true, false>), grid, block, 0, s, a, b, out, M, N, Kd, accumulate);
-          else if (trans_b) hipLaunchKernelGGL((bmm_tile_kernel<false, true>), grid, block, 0, s, a, b, out, M, N, Kd, accumulate);
-          else hipLaunchKernelGGL((bmm_tile_kernel<false, false>), grid, block, 0, s, a, b, out, M, N, Kd, accumulate);
+          const bool vec = (M & 3) == 0 && (N & 3) == 0 && (Kd & 3) == 0 && ck::aligned16(a) && ck::aligned16(b);
+          auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, a, b, out, M, N, Kd, accumulate); };
+          if (vec) {
+            if (trans_a && trans_b) go(bmm_tile_kernel<true, true, true>);
+            else if (trans_a) go(bmm_tile_kernel<true, false, true>);
+            else if (trans_b) go(bmm_tile_kernel<false, true, true>);
+            else go(bmm_tile_kernel<false, false, true>);
+          } else {
+            if (trans_a && trans_b) go(bmm_tile_kernel<true, true, false>);
+            else if (trans_a) go(bmm_tile_kernel<true, false, false>);
+            else if (trans_b) go(bmm_tile_kernel<false, true, false>);
+            else go(bmm_tile_kernel<false, false, false>);
+          }
           return hipGetLastError();
         },
         stream);

@@ -112,7 +112,7 @@ def test_tensordot_32_units_matches_the_generic_kernels(hip_device, cplx, two, F
 
 @pytest.mark.parametrize("ta", [0, 1])
 @pytest.mark.parametrize("tb", [0, 1])
-@pytest.mark.parametrize("F,M,N,Kd", [(5, 32, 256, 32), (3, 32, 32, 256), (2, 33, 70, 45), (2, 64, 24, 7), (1, 1, 512, 3)])
+@pytest.mark.parametrize("F,M,N,Kd", [(5, 32, 256, 32), (3, 32, 32, 256), (2, 36, 72, 40), (2, 33, 70, 45), (2, 64, 24, 7), (1, 1, 512, 3)])
 def test_bmm_tiles(hip_device, ta, tb, F, M, N, Kd):
     g = torch.Generator().manual_seed(M * 131 + N * 7 + Kd + 2 * ta + tb)
     a = torch.randn((F, Kd, M) if ta else (F, M, Kd), generator=g)
