@@ -24,7 +24,6 @@ read by exactly one consumer (trees: what `squared_partition_plan` and the regio
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Mapping
 
 import numpy as np
@@ -692,16 +691,13 @@ class HipSquaredTrainer:
         if main is not cur:
             main.wait_stream(cur)
         side.wait_stream(cur)
-        only = os.environ.get("CK_SQ_ONLY", "")  # (lab: time one list alone -- wrong results)
         with torch.cuda.stream(main):  # (the long list first)
             if self._signed is not None:
                 self._signed.stage(x, main.cuda_stream)
             else:
                 self.c._run(x)  # (B, 1, 1) complex64 / fp32 in c's arena
-            if only != "z":
-                self._part("c", B, gB, with_optimizer, main)
-        if only != "c":
-            self._part("z", B, gB, with_optimizer, side)
+            self._part("c", B, gB, with_optimizer, main)
+        self._part("z", B, gB, with_optimizer, side)
         main.wait_stream(side)
         self._part("end", B, gB, with_optimizer, main)
         if main is not cur:
