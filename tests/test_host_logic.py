@@ -156,3 +156,40 @@ def test_no_fusion_where_the_pattern_does_not_hold():
     for name in ("cfg1_rbt8", "cfg4_pd784", "cfg5_sos_c_k32"):
         plan, tensors, g, layers, children, out_pairs = _setup(name)
         assert find_subtree_groups(plan, layers, children, out_pairs, 4) == []
+
+
+def test_tensordot_lists_of_a_squared_circuits_partition_function():
+    """`fusion.tensordot_lists` on Z = integral |c|^2 of a squared QuadTree circuit (symbolic/operators.py:39-322 applied to the
+    plan of c, cirkit_amd/functional.py): every sum layer of c became a PAIR of TensorDot layers (W, conj W) over one Hadamard
+    layer -- the second reads the first fold by fold, the first reads the Hadamard layer fold by fold, nobody else reads either:
+    one launch per sum layer, the Hadamard layers read as lists; the output layer is never absorbed."""
+    from cirkit_amd.functional import squared_partition_plan
+    from cirkit_amd.fusion import tensordot_lists
+    from cirkit_amd.initializers import init_plan_tensors
+    from cirkit_amd.templates import image_data
+
+    plan_c = image_data((1, 8, 8), "quad-tree-2", input_layer="embedding", num_input_units=4, sum_product_layer="cp-t", num_sum_units=4,
+                        sum_weight_activation="none", semiring="complex-lse-sum")
+    z = squared_partition_plan(plan_c)
+    store = TensorStore("cpu")
+    store.update(init_plan_tensors(plan_c))
+    layers = [layer_from_spec(s, store, z.semiring) for s in z.layers]
+    folds = [l.num_folds for l in layers]
+    children = [None if s.inputs is None else resolve_fold_index(s.inputs, folds) for s in z.layers]
+    out = {int(p) for p in resolve_fold_index(z.output, folds).reshape(-1, 2)[:, 0]}
+    had_of, pair_of = tensordot_lists(layers, children, out)
+    td = [i for i, l in enumerate(layers) if isinstance(l, HipTensorDotLayer)]
+    had = [i for i, l in enumerate(layers) if isinstance(l, HipHadamardLayer)]
+    n_sum = sum(1 for s in plan_c.layers if s.type in ("cpt", "sum"))
+    assert len(td) == 2 * n_sum and len(pair_of) == n_sum and len(had_of) == len(had) == n_sum
+    for b, a in pair_of.items():  # second over first, first over its Hadamard layer
+        assert a in had_of and b not in had_of and a not in out and b > a > had_of[a]
+        assert layers[a].num_folds == layers[b].num_folds == layers[had_of[a]].num_folds
+    assert set(pair_of) | set(pair_of.values()) == set(td)
+    # a layer some other fusion owns, or that holds the output, is left alone
+    first = min(pair_of.values())
+    h2, p2 = tensordot_lists(layers, children, out, busy={had_of[first]})
+    assert first not in h2 and len(h2) == n_sum - 1 and p2 == pair_of
+    top = max(pair_of)
+    h3, p3 = tensordot_lists(layers, children, out | {pair_of[top]})
+    assert top not in p3 and len(p3) == n_sum - 1
