@@ -671,6 +671,105 @@ __global__ void __launch_bounds__(256, 2)
     for (int r = 0; r < 4; ++r) garena[ro[h] + boff + t + 256 * r] = gx[r];
 }
 
+// The ROOT of a squared circuit's partition function: the pair over a scalar sum layer (Kj = Kq = 32, ONE output unit in both
+// stages: Z = w^T M w in log space).  Stage 1 is a (32, 32) block against one weight row, stage 2 thirty-two values against one:
+// `td32_exp` + a row sum per lane, the sums in the shape-generic kernels' order (which spend 10 us on this fold alone, 30 beside
+// other launches: phases sized for 1024 outputs).
+template <class S>
+__global__ void __launch_bounds__(256)
+    td32_root_fwd_kernel(const typename S::T* __restrict__ arena, const int64_t* __restrict__ row_off, int H, const float* __restrict__ w1,
+                         typename S::T* __restrict__ mid, const float* __restrict__ w2, typename S::T* __restrict__ out, int B) {
+  using T = typename S::T;
+  __shared__ __attribute__((aligned(16))) Td32Lds<S> l;
+  const int t = threadIdx.x, f = blockIdx.y, b = blockIdx.x;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t boff = static_cast<int64_t>(b) * 1024, fb = static_cast<int64_t>(f) * B + b;
+  T x[4], a[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) x[r] = arena[ro[0] + boff + t + 256 * r];
+  for (int h = 1; h < H; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = S::add(x[r], arena[ro[h] + boff + t + 256 * r]);
+  if (t < 32) {
+    l.w[0][t] = w1[static_cast<int64_t>(f) * 32 + t];
+    l.w[1][t] = w2[static_cast<int64_t>(f) * 32 + t];
+  }
+  td32_exp<S>(l, x, a, t);
+  if (t >= 32) return;  // (no barrier below: wave 0 alone)
+  T acc = S::zero();
+#pragma unroll 8
+  for (int j = 0; j < 32; ++j) acc = S::fma_w(l.w[0][j], l.a[t * S::kA + j], acc);
+  const T o1 = S::log_shift(acc, l.m[t]);
+  mid[fb * 32 + t] = o1;
+  float m2 = S::re(o1);
+#pragma unroll
+  for (int s2 = 1; s2 < 32; s2 <<= 1) m2 = fmaxf(m2, __shfl_xor(m2, s2, 64));
+  m2 = ck::clamp_finite(m2);
+  l.t[t] = S::exp_shift(o1, m2);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+  if (t == 0) {
+    T y2 = S::zero();
+    for (int q = 0; q < 32; ++q) y2 = S::fma_w(l.w[1][q], l.t[q], y2);
+    out[fb] = S::log_shift(y2, m2);
+  }
+}
+
+template <class S>
+__global__ void __launch_bounds__(256)
+    td32_root_bwd_kernel(const typename S::T* __restrict__ arena, typename S::T* __restrict__ garena, const int64_t* __restrict__ row_off, int H,
+                         const float* __restrict__ w1, const typename S::T* __restrict__ mid, typename S::T* __restrict__ gmid,
+                         const float* __restrict__ w2, const typename S::T* __restrict__ out, const typename S::T* __restrict__ gout,
+                         float* __restrict__ dw1, float* __restrict__ dw2, int B) {
+  using T = typename S::T;
+  __shared__ __attribute__((aligned(16))) Td32Lds<S> l;
+  const int t = threadIdx.x, f = blockIdx.y, b = blockIdx.x;
+  const int64_t* ro = row_off + static_cast<int64_t>(f) * H;
+  const int64_t boff = static_cast<int64_t>(b) * 1024, fb = static_cast<int64_t>(f) * B + b;
+  T x[4], a[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) x[r] = arena[ro[0] + boff + t + 256 * r];
+  for (int h = 1; h < H; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = S::add(x[r], arena[ro[h] + boff + t + 256 * r]);
+  if (t < 32) {
+    l.w[0][t] = w1[static_cast<int64_t>(f) * 32 + t];
+    // stage 2 backward, lane j: a2 = exp(y1[j] - m2), t2 = tee(out, gout, m2), g y1[j] = child(a2, W2[j] t2), dW2[j] = dw(a2, t2)
+    const T y1 = mid[fb * 32 + t];
+    float m2 = S::re(y1);
+#pragma unroll
+    for (int s2 = 1; s2 < 32; s2 <<= 1) m2 = fmaxf(m2, __shfl_xor(m2, s2, 64));
+    m2 = ck::clamp_finite(m2);
+    const T a2 = S::exp_shift(y1, m2);
+    const T t2 = S::tee(out[fb], gout[fb], m2);
+    const T g1 = S::child(a2, S::fma_w(w2[static_cast<int64_t>(f) * 32 + t], t2, S::zero()));
+    gmid[fb * 32 + t] = g1;
+    const float d2 = 0.f + S::dw(a2, t2);
+    if (d2 != 0.f) atomicAdd(dw2 + static_cast<int64_t>(f) * 32 + t, d2);
+    l.tt[t] = y1;  // (kept for the tee of stage 1 below, which needs m_q)
+    l.tt[32 + t] = g1;
+  }
+  td32_exp<S>(l, x, a, t);  // (two barriers: the rows above are visible after them)
+  if (t < 32) l.t[t] = S::tee(l.tt[t], l.tt[32 + t], l.m[t]);  // t1[q]
+  __syncthreads();
+  {  // the gradient of x[j][q] at this thread's elements i = 32 j + q
+    const int q = t & 31, j0 = t >> 5;
+    T gx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gx[r] = S::child(a[r], S::fma_w(l.w[0][j0 + 8 * r], l.t[q], S::zero()));
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) garena[ro[h] + boff + t + 256 * r] = gx[r];
+  }
+  if (t < 32) {  // dW1[j] = sum_q dw(a[q][j], t1[q])
+    float acc = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) acc += S::dw(l.a[q * S::kA + t], l.t[q]);
+    if (acc != 0.f) atomicAdd(dw1 + static_cast<int64_t>(f) * 32 + t, acc);
+  }
+}
+
 template <class S, bool TWO, bool BWD>
 int td_launch(const typename S::T* arena, typename S::T* garena, const int64_t* row_off, int H, const float* w1, typename S::T* mid,
               typename S::T* gmid, const float* w2, typename S::T* out, const typename S::T* gout, float* dw1, float* dw2, int F, int B, int Kj,
@@ -687,6 +786,7 @@ int td_launch(const typename S::T* arena, typename S::T* garena, const int64_t* 
   const char* env = getenv("CK_TD_GENERIC");
   const bool generic_only = env != nullptr && atoi(env) != 0;
   const bool all32 = !generic_only && Kj == 32 && Kq == 32 && Kk1 == 32 && (!TWO || Kk2 == 32);
+  const bool root32 = !generic_only && TWO && Kj == 32 && Kq == 32 && Kk1 == 1 && Kk2 == 1;
   return ck::dispatch(
       [=](hipStream_t s) {
         auto go = [&](auto kern, auto&&... args) {
@@ -697,6 +797,17 @@ int td_launch(const typename S::T* arena, typename S::T* garena, const int64_t* 
           hipLaunchKernelGGL(kern, grid, block, lds, s, args...);
           return hipGetLastError();
         };
+        if constexpr (TWO) {
+          if (root32) {
+            using S32 = std::conditional_t<std::is_same_v<S, TdC>, TdC32, TdR32>;
+            if constexpr (BWD)
+              hipLaunchKernelGGL((td32_root_bwd_kernel<S32>), grid, block, 0, s, arena, garena, row_off, H, w1, static_cast<const typename S::T*>(mid),
+                                 gmid, w2, static_cast<const typename S::T*>(out), gout, dw1, dw2, B);
+            else
+              hipLaunchKernelGGL((td32_root_fwd_kernel<S32>), grid, block, 0, s, arena, row_off, H, w1, mid, w2, out, B);
+            return hipGetLastError();
+          }
+        }
         if (all32) {  // (static LDS: 30 - 46 KB)
           using S32 = std::conditional_t<std::is_same_v<S, TdC>, TdC32, TdR32>;
           if constexpr (BWD)

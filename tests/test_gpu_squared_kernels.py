@@ -127,3 +127,58 @@ def test_bmm_tiles(hip_device, ta, tb, F, M, N, Kd):
     want = a64 @ b64
     err = float((out.cpu().to(torch.float64) - want).abs().max())
     assert err <= 1e-5 * (float(want.abs().max()) + 1.0) * max(1.0, Kd / 32), err
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("F,B,H", [(1, 1, 2), (3, 2, 1)])
+def test_tensordot_root_pair_matches_the_generic_kernels(hip_device, cplx, F, B, H):
+    """The pair over a SCALAR sum layer (the root of a squared circuit's partition function: 32 x 32 block, one output unit in both
+    stages) on `td32_root_*` against the shape-generic kernels and float64."""
+    K = 32
+    g = torch.Generator().manual_seed(5 * F + B + (11 if cplx else 0))
+    e = 2 if cplx else 1
+    dev = hip_device
+    blocks = torch.randn(F * H, B, K * K, e, generator=g)
+    w1, w2 = torch.randn(F, 1, K, generator=g), torch.randn(F, 1, K, generator=g)
+    if not cplx:
+        w1, w2 = w1.abs() + 0.05, w2.abs() + 0.05
+    gout = torch.randn(F, B, 1, e, generator=g)
+    ro = (torch.arange(F * H, dtype=torch.int64).reshape(F, H) * (B * K * K)).contiguous()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def run(generic):
+        if generic:
+            os.environ["CK_TD_GENERIC"] = "1"
+        try:
+            arena, garena = blocks.to(dev).contiguous(), torch.zeros_like(blocks, device=dev)
+            mid, gmid = torch.zeros(F, B, K, e, device=dev), torch.zeros(F, B, K, e, device=dev)
+            out = torch.zeros(F, B, 1, e, device=dev)
+            dw1, dw2 = torch.zeros(F, 1, K, device=dev), torch.zeros(F, 1, K, device=dev)
+            a, b, go, rod = w1.to(dev), w2.to(dev), gout.to(dev), ro.to(dev)
+            capi.call("ck_tensordot2_lse_fwd", arena.data_ptr(), rod.data_ptr(), H, a.data_ptr(), mid.data_ptr(), b.data_ptr(), out.data_ptr(),
+                      F, B, K, K, 1, 1, int(cplx), stream)
+            capi.call("ck_tensordot2_lse_bwd", arena.data_ptr(), garena.data_ptr(), rod.data_ptr(), H, a.data_ptr(), mid.data_ptr(),
+                      gmid.data_ptr(), b.data_ptr(), out.data_ptr(), go.data_ptr(), dw1.data_ptr(), dw2.data_ptr(), F, B, K, K, 1, 1, int(cplx),
+                      stream)
+            torch.cuda.synchronize()
+            return [t.cpu() for t in (out, mid, garena, gmid, dw1, dw2)]
+        finally:
+            os.environ.pop("CK_TD_GENERIC", None)
+
+    fast, slow = run(False), run(True)
+    x64 = blocks.to(torch.float64)
+    x64 = (torch.view_as_complex(x64.contiguous()) if cplx else x64[..., 0]).reshape(F, H, B, K, K).sum(dim=1)
+    y1 = _stage_ref(x64, w1.to(torch.float64))            # (F, B, 32, 1)
+    want = _stage_ref(y1, w2.to(torch.float64)).reshape(F, B)
+    got = fast[0].to(torch.float64)
+    got = (torch.view_as_complex(got.contiguous()) if cplx else got[..., 0]).reshape(F, B)
+    d = (torch.exp(got - want) - 1).abs() if cplx else (got - want).abs() / (1 + want.abs())
+    assert float(d.max()) <= 2e-4, float(d.max())
+    for n, a, b in zip(("out", "mid", "gx", "gmid", "dw1", "dw2"), fast, slow):
+        a, b = a.to(torch.float64), b.to(torch.float64)
+        if cplx and n in ("out", "mid"):
+            err = float((torch.exp(torch.view_as_complex(a.contiguous()) - torch.view_as_complex(b.contiguous())) - 1).abs().max())
+            assert err <= 1e-4, (n, err)
+        else:
+            err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+            assert err <= (2e-4 if cplx else 2e-5), (n, err)
