@@ -273,6 +273,68 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same product on the matrix cores, one wavefront per (32, 32) output tile: `v_mfma_f32_32x32x2_f32` with A = op(a) rows
+// and B = op(b) columns as operands, 16 steps per 32 contracted entries.  Lane (i, kh) of a step's operand holds entry
+// k = 16 kh + s of its row / column (ANY pairing of the 32 entries into 16 steps is the same sum as long as both operands use
+// it): an operand whose fastest axis is k is four 16-byte loads per lane and chunk, the other form sixteen 4-byte loads that
+// coalesce across the lanes.  The multiply-add tiles above are bound by issue where the output is small (the Gram matrices
+// W W^T of a squared circuit: (32, 32) outputs over 256 entries, 27 us for 784 folds -- 128 MFMAs per fold here).
+// Extents: multiples of 32 (the launcher falls back otherwise).  Order of the sum: chunks of 32 in order, inside a chunk the
+// pairs (s, 16 + s) -- not the tile kernels' order (fp32 rounding differs in the last bits).
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(64)
+    bmm_mfma_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int M, int N, int Kd, int accumulate) {
+  const int64_t f = blockIdx.z;
+  const float* af = a + f * static_cast<int64_t>(M) * Kd;
+  const float* bf = b + f * static_cast<int64_t>(Kd) * N;
+  const int lane = threadIdx.x, i32 = lane & 31, kh = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  float av[16], bv[16], an[16], bn[16];
+  auto fetch = [&](int k0, float (&x)[16], float (&y)[16]) {
+    const int kb = k0 + 16 * kh;
+    if (TA) {  // a[k][m]
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) x[s2] = af[static_cast<int64_t>(kb + s2) * M + m0 + i32];
+    } else {   // a[m][k]
+      const float4* p = reinterpret_cast<const float4*>(af + static_cast<int64_t>(m0 + i32) * Kd + kb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = p[q];
+        x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+      }
+    }
+    if (TB) {  // b[n][k]
+      const float4* p = reinterpret_cast<const float4*>(bf + static_cast<int64_t>(n0 + i32) * Kd + kb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = p[q];
+        y[4 * q] = v.x, y[4 * q + 1] = v.y, y[4 * q + 2] = v.z, y[4 * q + 3] = v.w;
+      }
+    } else {   // b[k][n]
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) y[s2] = bf[static_cast<int64_t>(kb + s2) * N + n0 + i32];
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  fetch(0, av, bv);
+  for (int k0 = 0; k0 < Kd; k0 += 32) {
+    if (k0 + 32 < Kd) fetch(k0 + 32, an, bn);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) av[s2] = an[s2], bv[s2] = bn[s2];
+  }
+  // D[m][n] sits in lane (n, hi) register r with m = 8 (r >> 2) + 4 hi + (r & 3)
+  float* o = out + f * static_cast<int64_t>(M) * N + n0 + i32;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float* dst = o + static_cast<int64_t>(m0 + 8 * (r >> 2) + 4 * kh + (r & 3)) * N;
+    *dst = accumulate ? *dst + acc[r] : acc[r];
+  }
+}
+
 // (R, A, Bd) -> (R, Bd, A) through a 32x32 LDS tile, optional log.
 template <class T>
 __global__ void __launch_bounds__(256)
@@ -1190,6 +1252,19 @@ int ck_param_bmm_acc(const float* a, const float* b, float* out, int F, int M, i
   CK_REQUIRE(a && b && out, "ck_param_bmm: null pointer");
   CK_REQUIRE(F > 0 && M > 0 && N > 0 && Kd > 0, "ck_param_bmm: non-positive size");
   CK_REQUIRE(F <= 65535, "ck_param_bmm: F exceeds grid.z");
+  if ((M & 31) == 0 && (N & 31) == 0 && (Kd & 31) == 0 && ck::aligned16(a) && ck::aligned16(b) && N <= 65535 * 32 && M <= 65535 * 32) {
+    dim3 grid(N / 32, M / 32, F), block(64);
+    return ck::dispatch(
+        [=](hipStream_t s) {
+          auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, a, b, out, M, N, Kd, accumulate); };
+          if (trans_a && trans_b) go(bmm_mfma_kernel<true, true>);
+          else if (trans_a) go(bmm_mfma_kernel<true, false>);
+          else if (trans_b) go(bmm_mfma_kernel<false, true>);
+          else go(bmm_mfma_kernel<false, false>);
+          return hipGetLastError();
+        },
+        stream);
+  }
   if (M * static_cast<int64_t>(N) >= 512 && ck::aligned16(out)) {  // (small products, e.g. a row of ones times a block: the 16 x 16 form)
     dim3 grid((N + kBT_N - 1) / kBT_N, (M + kBT_M - 1) / kBT_M, F), block(256);
     return ck::dispatch(
