@@ -507,7 +507,8 @@ int ck_param_conj(const float* in_c, float* out_c, int64_t n, void* stream);
 int ck_param_mixing_weight(const float* in, float* out, int F, int K, int H, void* stream);
 /* Batched matmul out[f] = op(a[f]) . op(b[f]): TorchMatMulParameter (nodes.py:802-805) and the
  * two-operand TorchEinsumParameter patterns (optimized.py:282-284).  a: (F,M,Kd) or (F,Kd,M) if
- * trans_a; b: (F,Kd,N) or (F,N,Kd) if trans_b; out: (F,M,N). */
+ * trans_a; b: (F,Kd,N) or (F,N,Kd) if trans_b; out: (F,M,N).  Extents that are multiples of 32: one wavefront per (32, 32)
+ * output tile on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate); otherwise (32, 64) multiply-add tiles. */
 int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd,
                  int trans_a, int trans_b, void* stream);
 /* The same with `accumulate` != 0: out[f] += op(a[f]) . op(b[f]) -- the gradient of an einsum operand added straight into the
