@@ -182,3 +182,20 @@ def test_tensordot_root_pair_matches_the_generic_kernels(hip_device, cplx, F, B,
         else:
             err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
             assert err <= (2e-4 if cplx else 2e-5), (n, err)
+
+
+@pytest.mark.parametrize("F,M,Kd", [(4, 32, 256), (2, 64, 128)])
+def test_bmm_gram_matrices(hip_device, F, M, Kd):
+    """out = a a^T (TorchEinsumParameter of a squared circuit's partition function: W and conj W contracted over the states): both
+    operands the SAME tensor -- diagonal tiles read their chunk once -- against float64."""
+    g = torch.Generator().manual_seed(F * 7 + M + Kd)
+    a = torch.randn(F, M, Kd, generator=g)
+    ad = a.to(hip_device)
+    out = torch.full((F, M, M), float("nan"), device=hip_device)
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    capi.call("ck_param_bmm", ad.data_ptr(), ad.data_ptr(), out.data_ptr(), F, M, M, Kd, 0, 1, stream)
+    capi.call("ck_param_bmm_acc", ad.data_ptr(), ad.data_ptr(), out.data_ptr(), F, M, M, Kd, 0, 1, 1, stream)  # (out += the same)
+    torch.cuda.synchronize()
+    want = 2 * (a.to(torch.float64) @ a.to(torch.float64).transpose(1, 2))
+    err = float((out.cpu().to(torch.float64) - want).abs().max())
+    assert err <= 1e-5 * (float(want.abs().max()) + 1.0) * (Kd / 32), err
