@@ -43,6 +43,59 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s mea
 FP32_MFMA_PEAK_TF = 157.3  # dense fp32-input MFMA peak (= fp32 vector peak), same guide
 
 
+def contraction_flops(plan, B: int, real_products: int = 1) -> float:
+    """The fp32 contraction flops one forward of `plan` executes on B rows: 2 Ko Ki per row and fold of every dense / CP-T fold
+    (x H for a dense layer over concatenated children); a mixing layer is an element-wise weighted sum (no contraction), a
+    collapsed Sum -> Sum pair (MatMul weight) is evaluated as the mixing + dense pair it was.  `real_products`: real contractions
+    per complex one (1 for real circuits and for real-parameter circuits on signed tiles, 4 on the complex kernels)."""
+    total = 0.0
+    for l in plan.layers:
+        if l.type not in ("sum", "cpt", "tucker", "tensordot"):
+            continue
+        ops = [op for pg in l.params.values() for op in pg.ops]
+        per_fold = 2.0 * l.num_output_units * l.num_input_units
+        if l.type == "tucker":
+            per_fold *= l.num_input_units ** (l.arity - 1)
+        elif l.type == "sum" and l.arity > 1:
+            if "mixing_weight" in ops and "matmul" not in ops:
+                continue
+            if "mixing_weight" not in ops:
+                per_fold *= l.arity
+        total += per_fold * l.num_folds * B
+    return total * real_products
+
+
+def bench_summary(result: dict) -> dict:
+    """The numbers DESIGN.md section 8 quotes, compact, as the LAST key of the line (the driver's record keeps the line's tail)."""
+    oc = result.get("other_configs") or {}
+
+    def pick(d, ms_key):
+        if not d or ms_key not in d:
+            return None
+        o = {"ms": round(float(d[ms_key]), 4)}
+        if d.get("frac_of_fp32_mfma") is not None:
+            o["mfma"] = round(float(d["frac_of_fp32_mfma"]), 3)
+        return o
+
+    roof = result.get("roofline") or {}
+    s = {
+        "cfg2_fwd": {"ms": round(float(result["ms_per_step"]), 4), "mfma": (round(float(roof["frac"]), 3) if roof.get("frac") is not None else None)},
+        "cfg4_fwd": pick(oc.get("config4"), "ms_per_forward"),
+        "cfg5_fwd": pick(oc.get("config5"), "ms_per_forward"),
+        "cfg5_Z": ({"ms": round(float(oc["config5"]["ms_partition_function"]), 4)} if "config5" in oc else None),
+        "cfg5_complex_fwd": pick(oc.get("config5_complex_weights"), "ms_per_forward"),
+        "tucker_nb_fwd": pick(oc.get("notebook_quadgraph_tucker_k64_b128"), "ms_per_forward"),
+        "train_cfg2": pick(oc.get("train_step_cfg2"), "ms_per_step"),
+        "train_nb_k64_b256": pick(oc.get("train_step_notebook_quadgraph_cp_k64_b256"), "ms_per_step"),
+        "train_cfg4_b1024": pick(oc.get("train_step_cfg4_b1024"), "ms_per_step"),
+        "train_cfg5_sq": pick(oc.get("train_step_cfg5_squared"), "ms_per_step"),
+        "cpu_evals_s": (round(float(result["cpu_baseline"]["value"]), 1) if "cpu_baseline" in result else None),
+        "dist": (result.get("distributed") or {}).get("backend"),
+        "note": "ms per forward / per training step; mfma = executed contraction flops / time / 157.3 TFLOP/s (fp32-input MFMA peak)",
+    }
+    return {k: v for k, v in s.items() if v is not None}
+
+
 def other_configs(device, stream, B: int) -> dict:
     """BASELINE configs 4 and 5 (parity-test cases, tests/test_gpu_parity.py) timed for reference:
     plans built natively, closed-form parameters, synthetic batch, recorded launch list replayed per call, HIP events on
@@ -83,6 +136,8 @@ def other_configs(device, stream, B: int) -> dict:
                     "38 folded layers; CP blocks + mixing layers fused per region (cirkit_amd/csrc/ck_cp.hip)",
         "ms_per_forward": ms, "evals_per_s": B / ms * 1e3, "algorithmic_bytes": alg,
         "hbm_roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "executed_flops": contraction_flops(plan4, B),
+        "frac_of_fp32_mfma": contraction_flops(plan4, B) / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
         "variants": {},
     }
     del hc
@@ -115,6 +170,8 @@ def other_configs(device, stream, B: int) -> dict:
                     "Z = integral |c|^2 built from the plan of c (cirkit_amd/functional.py)",
         "ms_per_forward": ms, "evals_per_s": B / ms * 1e3, "algorithmic_bytes": alg,
         "hbm_roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "executed_flops": contraction_flops(plan5, B),  # signed tiles: one real contraction per complex one
+        "frac_of_fp32_mfma": contraction_flops(plan5, B) / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
         "ms_partition_function": ms_z,
     }
     del hc, hz
@@ -126,6 +183,8 @@ def other_configs(device, stream, B: int) -> dict:
         "workload": "the same circuit evaluated as complex-valued parameters require: every layer on (log|v|, arg v) pairs "
                     "(sum_clse_tile32: VALU-issue and HBM bound, profiles/r05_c_cfg5_complex.txt)",
         "ms_per_forward": ms_q, "evals_per_s": B / ms_q * 1e3, "launches": hq.num_launches(B),
+        "executed_flops": contraction_flops(plan5, B, 4),  # four real (32, 32) contractions per complex one
+        "frac_of_fp32_mfma": contraction_flops(plan5, B, 4) / (ms_q * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
     }
     del hq
     out["train_step_cfg2"] = train_step_cfg2(device, stream, B)
@@ -150,6 +209,8 @@ def other_configs(device, stream, B: int) -> dict:
                     "notebook); Tucker layers on MFMA (cirkit_amd/csrc/ck_gemm.hip)",
         "ms_per_forward": ms, "evals_per_s": 128 / ms * 1e3,
         "reference_published_ms": 38.6, "reference_hardware": "unnamed CUDA GPU (notebook output)",
+        "executed_flops": contraction_flops(plan_nb, 128),
+        "frac_of_fp32_mfma": contraction_flops(plan_nb, 128) / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
         "variants": {},
     }
     del hc
@@ -342,6 +403,9 @@ def train_step_squared(device, stream, plan_c, tensors, B: int, rounds: int = 5,
         "ms_per_step": ms, "samples_per_s": B / ms * 1e3, "ms_per_step_by_round": per_round,
         "settle_steps": k - rounds * steps, "steps_timed_total": rounds * steps, "optimizer_steps_taken": taken, "steps_dropped": dropped,
         "mean_ll_first_step": float(first[0] / first[1]), "mean_ll_last_step": float(last[0] / last[1]),
+        # c's contractions: 1 forward + 3 backward (y again, W^T t, dW) per fold and tile; Z's one-row layers are not counted
+        "executed_flops": 4.0 * contraction_flops(plan_c, B),
+        "frac_of_fp32_mfma": 4.0 * contraction_flops(plan_c, B) / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
         "optimizer": "adam(lr=0.001), one launch on the flat parameter buffer, device-side clock", "dtype": "f32",
     }
 
@@ -489,6 +553,9 @@ def main() -> None:
     ap.add_argument("--staged-input", action="store_true",
                     help="stage the batch (int64 (B, D) -> int32 (D, B)) with a launch of its own, as in round 2, instead of "
                          "letting the leaf launch read the caller's tensor")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="exchange the [sum, count] pairs through torch.distributed (bucketed, 64 steps per collective) instead of "
+                         "the library's own RCCL communicator (ck_comm_*, one collective per step on the launch stream)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-steps", type=int, default=12, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -538,6 +605,20 @@ def main() -> None:
         one = torch.ones(1, dtype=torch.float64, device=device)
         dist.all_reduce(one, op=dist.ReduceOp.SUM)
         ranks_seen = int(one.item())
+    # The exchange of the data path goes through the C ABI: an RCCL communicator owned by libcirkit_hip (ck_comm_*), its
+    # all-reduce enqueued on the launch stream right behind the launch that writes the pair -- one collective per step, no
+    # host work in between.  torch.distributed only carried the 128-byte ncclUniqueId (and keeps the barriers / the MAX of
+    # the wall clocks, which are not on the data path).  BENCH_DIST_BACKEND=gloo (several ranks on ONE device, which RCCL
+    # refuses) keeps torch.distributed for the exchange, bucketed as before.
+    comm = None
+    if use_dist and backend == "nccl" and not args.torch_collectives:
+        from cirkit_amd.distributed import HipComm, set_default_comm
+
+        comm = HipComm.from_process_group(device)
+        set_default_comm(comm)
+        probe = torch.ones(1, dtype=torch.float64, device=device)
+        comm.all_reduce(probe)
+        ranks_seen = int(probe.item())
 
     # BASELINE configs[1], built natively (cirkit_amd/templates.py; identical to the plan the reference
     # compiles -- tests/test_templates.py pins it against the committed reference fixture)
@@ -594,10 +675,15 @@ def main() -> None:
                     works[1 - i].wait()  # (stream-level: the buffer about to be refilled has been reduced)
                     works[1 - i] = None
 
+        ring = torch.zeros((8, 2), dtype=torch.float64, device=device) if comm is not None else None
+
         def step() -> None:
             x = xs[fed[0] % nb]
             fed[0] += 1
-            if use_dist:
+            if comm is not None:
+                # forward + device-side sum + the all-reduce of the pair, all enqueued on `stream` by the library
+                last[0] = circ.log_likelihood_sum(x, out=ring[fed[0] % 8], reduce=True)
+            elif use_dist:
                 i, n = cur
                 # forward + device-side sum, enqueued on `stream`; the launch that ends the forward writes the pair into its row
                 last[0] = circ.log_likelihood_sum(x, out=bufs[i][n])
@@ -608,7 +694,7 @@ def main() -> None:
                 last[0] = circ.log_likelihood_sum(x)
 
         def drain() -> None:
-            if use_dist:
+            if use_dist and comm is None:
                 flush()
                 for i in range(2):
                     if works[i] is not None:
@@ -708,10 +794,13 @@ def main() -> None:
             "hip_event_ms_per_step_by_round": evms,
             "input_batches_rotated": nb, "input_bytes_resident": nb * B * plan.num_variables * 8,
         },
-        "distributed": {"backend": backend if use_dist else None, "world_size": world,
+        "distributed": {"backend": ("rccl-capi" if comm is not None else backend) if use_dist else None, "world_size": world,
                         "ranks_seen_by_backend": ranks_seen,
-                        # every step's [sum, count] goes through the backend; one collective carries up to 64 steps' pairs
-                        "every_step_exchanged": bool(use_dist), "steps_per_collective": (64 if use_dist else None),
+                        # rccl-capi: ck_comm_all_reduce_f64 on the launch stream behind every step (the library's own RCCL
+                        # communicator); torch backends: one collective carries up to 64 steps' pairs
+                        "every_step_exchanged": bool(use_dist),
+                        "steps_per_collective": ((1 if comm is not None else 64) if use_dist else None),
+                        "librccl": (comm.info()["librccl"] if comm is not None else None),
                         # a straggler GPU shows here: wall time per step of the fastest / slowest rank in the median round
                         "ms_per_step_fastest_rank": (1e3 * sorted(spread)[len(spread) // 2][0] / args.steps) if spread else None,
                         "ms_per_step_slowest_rank": (1e3 * sorted(spread, key=lambda t: t[1])[len(spread) // 2][1] / args.steps) if spread else None},
@@ -999,10 +1088,14 @@ def main() -> None:
         result["variants"] = variants
         if world == 1 and not args.no_other_configs:
             result["other_configs"] = other_configs(device, stream, B)
+        result["summary"] = bench_summary(result)  # LAST key: every figure DESIGN.md section 8 quotes, within the line's last 1500 characters
         print(json.dumps(result), flush=True)
 
     if use_dist:
         dist.barrier()
+        if comm is not None:
+            torch.cuda.synchronize(device)
+            comm.destroy()
         dist.destroy_process_group()
 
 

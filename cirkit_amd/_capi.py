@@ -7,9 +7,10 @@ import ctypes as C
 import os
 from typing import Any
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
+# CIRKIT_HIP_LIB: a lab build of the same library (scripts/lab_build.sh, scripts/defect_injection.sh); never a different backend
+_LIB_PATH = os.environ.get("CIRKIT_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 44
+ABI_VERSION = 45
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -136,7 +137,8 @@ class OptState(C.Structure):
     """ck_opt_state of include/cirkit_hip.h (a DEVICE struct: this mirror is for building its initial bytes)."""
 
     _fields_ = [("lr", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float), ("bc1", C.c_float), ("bc2", C.c_float),
-                ("step", C.c_int32), ("skipped", C.c_int32), ("skip_now", C.c_int32), ("kind", C.c_int32)]
+                ("step", C.c_int32), ("skipped", C.c_int32), ("skip_now", C.c_int32), ("kind", C.c_int32),
+                ("b1d", C.c_double), ("b2d", C.c_double)]
 
 
 class RootLaunch(C.Structure):
@@ -173,6 +175,13 @@ GAUSS_JOB_DTYPE = [("mean", "<u8"), ("stddev", "<u8"), ("x", "<u8"), ("dmean", "
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
 SIGNATURES: dict[str, list[Any]] = {
     "ck_abi_version": [],
+    "ck_comm_load": [C.c_char_p],
+    "ck_comm_unique_id": [_p],
+    "ck_comm_init": [_p, _i, _i, _i, C.POINTER(C.c_void_p)],
+    "ck_comm_all_reduce_f64": [_p, _p, _l, _p],
+    "ck_comm_all_reduce_f32": [_p, _p, _l, _p],
+    "ck_comm_info": [_p, C.POINTER(C.c_int32), C.c_char_p, _i],
+    "ck_comm_destroy": [_p],
     "ck_device_info": [_i, C.POINTER(_l)],
     "ck_transpose_i64_to_i32": [_p, _p, _i, _i, _p],
     "ck_transpose_f32": [_p, _p, _i, _i, _p],

@@ -701,9 +701,6 @@ class HipCircuit:
                         pending = []
                     self._launch_tail(bd, stream, with_ll=with_ll)
                 continue
-                if i == self._tail[0]:
-                    self._launch_tail(bd, stream, with_ll=with_ll)
-                continue
             if i in self._virtual or i in self._td_first:
                 continue
             if i in self._td_had or i in self._td_pair:
@@ -1560,9 +1557,12 @@ class HipCircuit:
             views = [v if v is None else v[..., : s.num_output_units] for v, s in zip(views, self.user_plan.layers)]
         return views
 
-    def log_likelihood_sum(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    def log_likelihood_sum(self, x: torch.Tensor, out: torch.Tensor | None = None, *, reduce: bool = False) -> torch.Tensor:
         """Device tensor ``[sum_b log p(x_b), B]`` in fp64 -- the two numbers the data-parallel
         all-reduce exchanges (SURVEY.md section 8 e).  Requires a single scalar output.
+
+        `reduce`: SUM the pair over the data-parallel ranks, in place, right behind the forward on the same stream
+        (`cirkit_amd.distributed.all_reduce_sum`: RCCL through the C ABI when a `HipComm` is set, torch.distributed otherwise).
 
         `out`: a contiguous fp64 tensor of two elements on this device (e.g. one row of a (steps, 2) buffer that a single
         collective will carry) that receives the pair and is returned; the launch that ends the forward writes it there
@@ -1578,8 +1578,17 @@ class HipCircuit:
             if out.dtype != torch.float64 or out.numel() != 2 or not out.is_contiguous() or not out.is_cuda or out.device.index != index:
                 raise ValueError(f"out must be a contiguous float64 tensor of 2 elements on {self.device}")
             self._run(x, with_ll=True, ll_out=out)
+            if reduce:
+                from .distributed import all_reduce_sum
+
+                all_reduce_sum(out)
             return out
-        return self._run(x, with_ll=True).ll
+        ll = self._run(x, with_ll=True).ll
+        if reduce:
+            from .distributed import all_reduce_sum
+
+            all_reduce_sum(ll)
+        return ll
 
     # -- instrumentation -------------------------------------------------------------------------
     def kernel_label(self, i: int, B: int = 4096) -> str:

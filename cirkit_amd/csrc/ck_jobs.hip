@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(J.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(J.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != static_cast<unsigned int>(J.n_split - 1)) return;
     if (threadIdx.x == 0) __hip_atomic_store(J.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next step
@@ -401,7 +401,15 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
   for (int k = 0; k < kEPT; ++k) s = fmaf(wv[k], dv[k], s);
   s = row_sum(s);  // = sum_b G[b, o]: sum_n W[o, n] dW[o, n] = sum_b gy[b, o] y[b, o]
-  if (J.mix_dw != nullptr && threadIdx.x % kTPR == 0) J.mix_dw[o * J.mix_H + J.mix_h] = s / J.mix_w[o * J.mix_H + J.mix_h];
+#ifdef CK_JOBS_LAB_DEFECT  // lab build only (scripts/defect_injection.sh): a wrong <W, dW> that the gradient tests must see
+  s *= 1.f + CK_JOBS_LAB_DEFECT;
+#endif
+  if (J.mix_dw != nullptr && threadIdx.x % kTPR == 0) {
+    // d w[o, h] = s / w.  A coefficient that underflowed to 0 (a logit gap beyond ~87) made every G of this slot 0, so s = 0
+    // and the quotient would be 0 / 0: its logit's gradient w (dw - s') is 0 whatever dw is, as in the reference's autograd
+    const float wmix = J.mix_w[o * J.mix_H + J.mix_h];
+    J.mix_dw[o * J.mix_H + J.mix_h] = wmix > 0.f ? s / wmix : 0.f;
+  }
   if (J.mode == 0) {  // the gradient of the linear weights, for a parameter graph this epilogue does not know
 #pragma unroll
     for (int k = 0; k < kEPT; k += 4) ck::gstore4(J.dtheta + o * kU + c0 + k, make_float4(dv[k], dv[k + 1], dv[k + 2], dv[k + 3]));
@@ -622,7 +630,7 @@ __global__ void __launch_bounds__(256)
     for (int i = threadIdx.x; i < kU * HMAX; i += 256) __hip_atomic_store(slot + i, dw_s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(J.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(J.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != static_cast<unsigned int>(J.n_split - 1)) return;
     if (threadIdx.x == 0) __hip_atomic_store(J.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -839,7 +847,7 @@ __global__ void __launch_bounds__(256) jobs_root_kernel(const ck_root_launch a) 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (s_ticket != gridDim.x - 1) return;
   if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1244,9 +1252,11 @@ __global__ void opt_tick_kernel(ck_opt_state* __restrict__ o, int32_t* __restric
   }
   o->skip_now = 0;
   o->step += 1;
-  const float t = static_cast<float>(o->step);
-  o->bc1 = 1.f - powf(o->b1, t);
-  o->bc2 = 1.f - powf(o->b2, t);
+  // in double from the caller's double betas, as torch.optim.Adam and ck_adam_step's host side do (1 - 0.999f^1 in fp32 is
+  // off by 1.3e-5 relative: the fused and the separate optimizer would disagree in the first steps)
+  const double t = static_cast<double>(o->step);
+  o->bc1 = static_cast<float>(-expm1(t * log(o->b1d)));
+  o->bc2 = static_cast<float>(-expm1(t * log(o->b2d)));
 }
 
 }  // namespace

@@ -7,11 +7,16 @@ are independent across the batch axis, so the multi-GPU path is: rank r of R eva
 RCCL/xGMI gives the global summed log-likelihood (SURVEY.md section 8 e).  No activation ever
 crosses a GPU boundary; the collective is latency-bound, so bucket size / ring order are moot.
 
-The helpers are backend-agnostic (`nccl` = RCCL on ROCm, `gloo` for the CPU tests).
+The exchange itself goes through the C ABI when the tensors live on a GPU: `HipComm` (`ck_comm_*`, include/cirkit_hip.h) is
+an RCCL communicator owned by the library; the collective is enqueued on the launch stream by the library itself.
+torch.distributed is used for ONE thing in that case -- handing rank 0's `ncclUniqueId` to the other ranks
+(`HipComm.from_process_group`; `HipComm.from_file` needs no process group at all) -- and remains the fallback of the HOST logic
+where there is no GPU (the `gloo` tests on CPU).
 """
 
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Callable
 
@@ -43,10 +48,140 @@ def init_from_env(backend: str | None = None, device: torch.device | None = None
     return rank, world, local_rank
 
 
+class HipComm:
+    """An RCCL communicator behind the C ABI (`ck_comm_init` / `ck_comm_all_reduce_f64|f32` / `ck_comm_destroy`): in-place SUM
+    all-reduces of fp32 / fp64 device tensors, enqueued on the CURRENT stream of the communicator's device (or recorded into a
+    `ck_program`).  One per process and device."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: torch.device | str | int):
+        from . import _capi as capi
+
+        self.device = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        if self.device.type != "cuda":
+            raise capi.HipExtensionError("HipComm needs a ROCm device (the CPU tests of the host logic use torch.distributed / gloo)")
+        if len(unique_id) != 128:
+            raise ValueError("an ncclUniqueId is 128 bytes")
+        self.rank, self.world = int(rank), int(world)
+        self._capi = capi
+        self._h = ctypes.c_void_p()
+        _bind_rccl(capi)
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        with torch.cuda.device(self.device):
+            capi.call("ck_comm_init", ctypes.cast(buf, ctypes.c_void_p), self.rank, self.world,
+                      self.device.index if self.device.index is not None else torch.cuda.current_device(), ctypes.byref(self._h))
+
+    # ---------------------------------------------------------------- bootstrap: only the 128-byte id travels outside RCCL
+    @staticmethod
+    def new_unique_id() -> bytes:
+        from . import _capi as capi
+
+        _bind_rccl(capi)
+        buf = ctypes.create_string_buffer(128)
+        capi.call("ck_comm_unique_id", ctypes.cast(buf, ctypes.c_void_p))
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, device: torch.device | str | int, group=None) -> "HipComm":
+        """Rank 0 draws the id, torch.distributed (any backend, gloo included) broadcasts those 128 bytes, every rank joins."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], rank, world, device)
+
+    @classmethod
+    def from_file(cls, path: str, rank: int, world: int, device: torch.device | str | int, timeout_s: float = 120.0) -> "HipComm":
+        """Without any process group: rank 0 writes the id to `path` (atomically), the others wait for the file."""
+        import time
+
+        if rank == 0:
+            uid = cls.new_unique_id()
+            with open(path + ".tmp", "wb") as f:
+                f.write(uid)
+            os.replace(path + ".tmp", path)
+        else:
+            t0 = time.time()
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError(f"no ncclUniqueId at {path} after {timeout_s} s")
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                uid = f.read()
+        return cls(uid, rank, world, device)
+
+    # ---------------------------------------------------------------- the exchange
+    def all_reduce(self, t: torch.Tensor, stream: int | None = None) -> torch.Tensor:
+        """In-place SUM over the ranks; ordered on `stream` (default: the current stream of the tensor's device)."""
+        if self._h.value is None:
+            raise self._capi.HipExtensionError("HipComm: communicator destroyed")
+        if t.device != self.device and not (t.device.type == "cuda" and t.device.index == self.device.index):
+            raise ValueError(f"HipComm on {self.device}: tensor on {t.device}")
+        if not t.is_contiguous() or t.dtype not in (torch.float32, torch.float64):
+            raise ValueError("HipComm.all_reduce: a contiguous float32 / float64 tensor")
+        if t.numel() == 0:
+            return t
+        with torch.cuda.device(self.device):
+            s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+            self._capi.call("ck_comm_all_reduce_f64" if t.dtype == torch.float64 else "ck_comm_all_reduce_f32",
+                            self._h, t.data_ptr(), t.numel(), s)
+        return t
+
+    def info(self) -> dict:
+        out = (ctypes.c_int32 * 3)()
+        origin = ctypes.create_string_buffer(256)
+        self._capi.call("ck_comm_info", self._h, out, origin, 256)
+        return {"rank": int(out[0]), "world": int(out[1]), "device": int(out[2]), "librccl": origin.value.decode()}
+
+    def destroy(self) -> None:
+        global _default_comm
+        if self._h.value is not None:
+            h, self._h = self._h, ctypes.c_void_p()
+            if _default_comm is self:
+                _default_comm = None
+            self._capi.call("ck_comm_destroy", h)
+
+
+def _bind_rccl(capi) -> None:
+    """RCCL is bound at run time: PyTorch-ROCm's own copy (built against the HIP runtime this process already holds) first."""
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    capi.call("ck_comm_load", cand.encode() if os.path.exists(cand) else None)
+
+
+_default_comm: HipComm | None = None
+
+
+def set_default_comm(comm: HipComm | None) -> None:
+    """The communicator `all_reduce_ll`, `HipCircuit.log_likelihood_sum(reduce=True)` and the trainers' `all_reduce_grads` use."""
+    global _default_comm
+    _default_comm = comm
+
+
+def default_comm() -> HipComm | None:
+    return _default_comm
+
+
+def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
+    """In-place SUM all-reduce over the data-parallel ranks: through the C ABI (RCCL, on the current stream) when a `HipComm`
+    is set and `t` lives on its device; through torch.distributed otherwise (the CPU / gloo tests of the host logic; RCCL via
+    torch when no communicator was created); the identity for a single process."""
+    c = _default_comm
+    if c is not None and t.device.type == "cuda" and t.dtype in (torch.float32, torch.float64) and t.is_contiguous():
+        return c.all_reduce(t)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def world_size() -> int:
+    c = _default_comm
+    if c is not None:
+        return c.world
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def all_reduce_ll(pair: torch.Tensor) -> torch.Tensor:
     """In-place SUM all-reduce of the ``[sum, count]`` pair (no-op for a single process)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(pair, op=dist.ReduceOp.SUM)
+    if world_size() > 1 or _default_comm is not None:
+        all_reduce_sum(pair)
     return pair
 
 
@@ -56,8 +191,9 @@ class DataParallelEvaluator:
 
     def __init__(self, ll_sum_fn: Callable[[torch.Tensor], torch.Tensor]):
         self.ll_sum_fn = ll_sum_fn
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        c = default_comm()
+        self.rank = c.rank if c is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        self.world = c.world if c is not None else (dist.get_world_size() if dist.is_initialized() else 1)
 
     def local_rows(self, x_global: torch.Tensor) -> torch.Tensor:
         a, b = shard_bounds(x_global.shape[0], self.rank, self.world)

@@ -411,11 +411,13 @@ class JobStep:
             o = capi.OptState()
             o.lr, o.b1, o.b2, o.eps, o.bc1, o.bc2 = tr.lr, tr.betas[0], tr.betas[1], tr.eps, 1.0, 1.0
             o.step, o.skipped, o.skip_now, o.kind = 0, 0, 0, 1 if tr.optimizer == "adam" else 0
+            o.b1d, o.b2d = float(tr.betas[0]), float(tr.betas[1])  # the bias corrections are formed in double (torch.optim.Adam does)
             self._opt = torch.frombuffer(bytearray(bytes(o)), dtype=torch.uint8).to(self.c.device)
             self._opt_key = key
         elif key != self._opt_key:  # (the learning rate was changed between steps: the first 16 bytes)
             head = torch.tensor([tr.lr, tr.betas[0], tr.betas[1], tr.eps], dtype=torch.float32).view(torch.uint8)
             self._opt[:16].copy_(head.to(self.c.device))
+            self._opt[40:56].copy_(torch.tensor([tr.betas[0], tr.betas[1]], dtype=torch.float64).view(torch.uint8).to(self.c.device))
             self._opt_key = key
         return self._opt
 

@@ -32,6 +32,7 @@ from typing import Mapping
 import numpy as np
 import torch
 
+from .distributed import all_reduce_sum as _all_reduce_sum, default_comm as _default_comm, world_size as _world_size
 from . import _capi as capi
 from .circuit import HipCircuit
 from .layers import (HipCategoricalLayer, HipCPTLayer, HipGaussianLayer, HipHadamardLayer, HipKroneckerLayer, HipSumLayer,
@@ -120,6 +121,8 @@ class HipTrainer:
         self._fuse_optimizer = bool(fuse_optimizer)
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self.step_count = 0
+        self._clock: str | None = None  # which optimizer clock has advanced: "device" (fused job step) | "host" (apply_gradients)
+        self._grads_current = False  # `grads` holds the gradients of the last step (false after a fused job step)
         c = self.circuit
         if len(c._out_pairs) != 1:
             raise NotImplementedError("training needs a single circuit output")
@@ -578,10 +581,11 @@ class HipTrainer:
             return self._loss_and_grads(x, global_batch)
 
     def _loss_and_grads(self, x: torch.Tensor, global_batch: int | None) -> torch.Tensor:
+        self._grads_current = True
         import torch.distributed as dist
 
-        if global_batch is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            global_batch = int(x.shape[0]) * dist.get_world_size()
+        if global_batch is None and _world_size() > 1:
+            global_batch = int(x.shape[0]) * _world_size()
         B = int(x.shape[0])
         if self._jobs is not None:  # one recorded launch list: parameters, forward levels, root, backward levels
             return self._jobs.loss_and_grads(x, float(global_batch or B))
@@ -702,6 +706,9 @@ class HipTrainer:
 
     def gradients(self) -> dict[str, np.ndarray]:
         """The gradients of the last `loss_and_grads`, host copies in the shapes of the user's plan."""
+        if not self._grads_current:
+            raise RuntimeError("gradients(): the last step was a fused job step, whose gradients never reach `grads` (the optimizer runs "
+                               "in the job epilogues); call loss_and_grads() to obtain them")
         out = {}
         for n in self.user_plan.tensors:
             g = self.grads[n].detach().cpu().numpy()
@@ -718,8 +725,9 @@ class HipTrainer:
         import torch.distributed as dist
 
         # (also at world size 1: the collective is then RCCL's identity, and the same call path is what a 1-GPU box can test)
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+        # RCCL through the C ABI (ck_comm_all_reduce_f32, on the launch stream) when a HipComm is set; torch.distributed otherwise
+        if _default_comm() is not None or (dist.is_available() and dist.is_initialized()):
+            _all_reduce_sum(self._flat_grad)
 
     def apply_gradients(self, skip_flag: torch.Tensor | None = None) -> None:
         """The optimizer step on `self.grads`.  `skip_flag`: a device int32; when it is nonzero at launch time the step
@@ -727,7 +735,18 @@ class HipTrainer:
         with torch.cuda.device(self.device):
             self._apply_gradients(skip_flag)
 
+    def _use_clock(self, which: str) -> None:
+        """ONE optimizer clock per trainer: the fused job step counts Adam's steps on the device (`ck_opt_state.step`, not advanced
+        by dropped batches), `apply_gradients` on the host (`step_count`).  Both update the same moments, so a trainer that has
+        stepped with one refuses the other rather than applying inconsistent bias corrections."""
+        if self._clock is not None and self._clock != which:
+            raise RuntimeError(f"this trainer's optimizer clock is on the {self._clock}: step() (fused job form, one rank) and "
+                               "loss_and_grads() + apply_gradients() (or a process group initialised mid-run) cannot be mixed on "
+                               "one HipTrainer; construct it with fuse_optimizer=False to use the host clock throughout")
+        self._clock = which
+
     def _apply_gradients(self, skip_flag: torch.Tensor | None = None) -> None:
+        self._use_clock("host")
         self.step_count += 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         p, g = self._flat_param, self._flat_grad
@@ -751,10 +770,12 @@ class HipTrainer:
         import torch.distributed as dist
 
         c = self.circuit
-        alone = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        alone = _world_size() <= 1
         if self._jobs is not None and self._fuse_optimizer and alone:
             # the whole step is one recorded launch list; the optimizer runs where the gradients are (cirkit_amd/train_jobs.py)
+            self._use_clock("device")
             self.step_count += 1
+            self._grads_current = False
             return self._jobs.step(x, float(global_batch or int(x.shape[0])))
         ll = self.loss_and_grads(x, global_batch=global_batch)
         validate = c.validate_inputs and c._int_input

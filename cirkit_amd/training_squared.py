@@ -29,6 +29,7 @@ from typing import Mapping
 import numpy as np
 import torch
 
+from .distributed import all_reduce_sum as _all_reduce_sum, default_comm as _default_comm, world_size as _world_size
 from . import _capi as capi
 from .circuit import HipCircuit
 from .layers import (HipCategoricalLayer, HipConstantValueLayer, HipCPTLayer, HipEmbeddingLayer, HipGaussianLayer, HipHadamardLayer,
@@ -610,10 +611,12 @@ class HipSquaredTrainer:
             o = capi.OptState()
             o.lr, o.b1, o.b2, o.eps, o.bc1, o.bc2 = self.lr, self.betas[0], self.betas[1], self.eps, 1.0, 1.0
             o.step, o.skipped, o.skip_now, o.kind = 0, 0, 0, 1 if self.optimizer == "adam" else 0
+            o.b1d, o.b2d = float(self.betas[0]), float(self.betas[1])  # the bias corrections are formed in double (torch.optim.Adam does)
             self._opt = torch.frombuffer(bytearray(bytes(o)), dtype=torch.uint8).to(self.device)
         elif key != self._opt_key:  # (the learning rate was changed between steps: the first 16 bytes)
             head = torch.tensor([self.lr, self.betas[0], self.betas[1], self.eps], dtype=torch.float32).view(torch.uint8)
             self._opt[:16].copy_(head.to(self.device))
+            self._opt[40:56].copy_(torch.tensor([self.betas[0], self.betas[1]], dtype=torch.float64).view(torch.uint8).to(self.device))
         self._opt_key = key
         return self._opt
 
@@ -706,8 +709,8 @@ class HipSquaredTrainer:
     def _global_batch(self, B: int, global_batch: int | None) -> float:
         import torch.distributed as dist
 
-        if global_batch is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            global_batch = B * dist.get_world_size()
+        if global_batch is None and _world_size() > 1:
+            global_batch = B * _world_size()
         return float(global_batch or B)
 
     def loss_and_grads(self, x: torch.Tensor, *, global_batch: int | None = None) -> torch.Tensor:
@@ -722,8 +725,9 @@ class HipSquaredTrainer:
     def all_reduce_grads(self) -> None:
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+        # RCCL through the C ABI (ck_comm_all_reduce_f32, on the launch stream) when a HipComm is set; torch.distributed otherwise
+        if _default_comm() is not None or (dist.is_available() and dist.is_initialized()):
+            _all_reduce_sum(self._flat_grad)
 
     def apply_gradients(self, skip_flag: torch.Tensor | None = None) -> None:
         """The optimizer step on `self.grads`.  `skip_flag`: a device int32; nonzero at launch time = the step changes nothing
@@ -745,7 +749,7 @@ class HipSquaredTrainer:
 
         c = self.c
         validate = c.validate_inputs and c._int_input
-        alone = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        alone = _world_size() <= 1
         with torch.cuda.device(self.device):
             B = int(x.shape[0])
             self._launch(x, B, self._global_batch(B, global_batch), alone)

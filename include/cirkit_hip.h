@@ -800,6 +800,7 @@ typedef struct ck_opt_state {  /* DEVICE: the optimizer's constants and clock, a
   int32_t skipped;     /* steps dropped because their batch held an illegal category */
   int32_t skip_now;    /* this step is dropped: the epilogues change nothing */
   int32_t kind;        /* 0 SGD, 1 Adam */
+  double b1d, b2d;     /* the betas in double: ck_opt_tick forms bc1 / bc2 = 1 - b^step in double, as torch.optim.Adam does */
 } ck_opt_state;
 /* One fold of a TorchSumLayer (arity 1) / TorchCPTLayer with 64 inputs and 64 outputs (layers/inner.py:266-273,
  * optimized.py:171-178):  v = sum of the n_in blocks pool[in_off ..] (the Hadamard product of the children in log space),
@@ -981,6 +982,27 @@ int ck_program_launch(ck_program* prog, int use_graph, void* stream);
  * valid until the replayed launches have run (stream order).  This is what lets the recorded forward -- the replacement
  * of TorchCircuit.forward(x), circuits.py:242-278 -- take a different batch per call without staging it. */
 int ck_program_set_input(ck_program* prog, int index, const void* ptr);
+
+/* ---- the exchange step -------------------------------------------------------------------------
+ * The path shards on the batch axis: a rank evaluates its rows and ONE SUM all-reduce carries the [sum log p, count] pair
+ * of a forward (or the flat gradient buffer of a training step) over RCCL / xGMI.  The reference has no distributed code
+ * (SURVEY.md section 5): these replace the torch.distributed.all_reduce a user would write around TorchCircuit.forward
+ * (circuits.py:242-278).  The collective is enqueued on the caller's stream by the library -- no host work between the
+ * launch that writes the pair and the exchange -- and, inside ck_program_begin / _end, becomes a step of the recorded list.
+ * RCCL is bound at run time (the copy already mapped into the process, else `librccl_path`, else the system's); without it
+ * every ck_comm_* call returns CK_ERR_UNSUPPORTED.  Bootstrap: rank 0 calls ck_comm_unique_id, hands the 128 bytes to the
+ * other ranks by any means (torch.distributed's store, a file, MPI), every rank calls ck_comm_init (collective: returns
+ * when all `world` ranks have called it).  One communicator per process and device. */
+typedef struct ck_comm ck_comm;
+int ck_comm_load(const char* librccl_path);
+int ck_comm_unique_id(void* id128);
+int ck_comm_init(const void* id128, int rank, int world, int device, ck_comm** out);
+/* in place, SUM over the ranks, ordered on `stream` like any launch of this library */
+int ck_comm_all_reduce_f64(ck_comm* comm, double* buf, int64_t n, void* stream);
+int ck_comm_all_reduce_f32(ck_comm* comm, float* buf, int64_t n, void* stream);
+/* out = [rank, world, device]; origin: which librccl was bound */
+int ck_comm_info(const ck_comm* comm, int32_t out[3], char* origin, int origin_len);
+int ck_comm_destroy(ck_comm* comm);
 
 /* Lend a device scratch buffer to the launches this THREAD issues or records from now on (NULL, 0: take it back).  It
  * must be ZERO when lent; the part that has to stay zero (ticket counters behind the first CUs x 3 x (32 KiB + 512 B)) is zero

@@ -51,6 +51,12 @@ def _worker(rank, world, port, n_rows, out_path):
         y = evaluate_plan(plan, tt, xl).double()
         return torch.stack([y.sum(), torch.tensor(float(xl.shape[0]), dtype=torch.float64)])
 
+    from cirkit_amd.distributed import all_reduce_sum, default_comm, world_size
+
+    # no GPU here, hence no HipComm: the host logic falls back to torch.distributed (gloo) for the same calls
+    assert default_comm() is None and world_size() == world
+    probe = all_reduce_sum(torch.tensor([1.0, float(rank)], dtype=torch.float32))
+    assert probe.tolist() == [float(world), float(sum(range(world)))]
     ev = DataParallelEvaluator(ll_sum)
     s = ev.summed_ll(ev.local_rows(x))
     if rank == 0:
@@ -75,3 +81,15 @@ def test_two_process_gloo_all_reduce_matches_single_process(tmp_path, n_rows):
     y = evaluate_plan(plan, as_torch(tensors), x).double()
     assert pair[1] == n_rows
     assert abs(pair[0] - float(y.sum())) <= 1e-6 * abs(float(y.sum()))  # fp32 evals, different GEMM blocking per shard
+
+
+def test_hip_comm_needs_a_device_and_never_falls_back_silently():
+    """`HipComm` is the GPU exchange (RCCL through the C ABI); on a CPU device it refuses instead of standing in gloo."""
+    from cirkit_amd import _capi as capi
+    from cirkit_amd.distributed import HipComm, all_reduce_sum, default_comm, world_size
+
+    with pytest.raises(capi.HipExtensionError):
+        HipComm(bytes(128), 0, 1, "cpu")
+    assert default_comm() is None and world_size() == 1
+    t = torch.arange(4, dtype=torch.float64)
+    assert torch.equal(all_reduce_sum(t.clone()), t)  # a single process without a group: the identity

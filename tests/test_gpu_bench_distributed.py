@@ -141,8 +141,10 @@ def test_bench_runs_rccl_at_world_size_one(hip_device):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist", *BENCH_ARGS]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     d = _one_json_line(out)
-    assert _dist_fields(d) == {"backend": "nccl", "world_size": 1, "ranks_seen_by_backend": 1, "every_step_exchanged": True,
-                               "steps_per_collective": 64}
+    # the exchange is the library's own RCCL communicator (ck_comm_*): one all-reduce per step on the launch stream
+    assert _dist_fields(d) == {"backend": "rccl-capi", "world_size": 1, "ranks_seen_by_backend": 1, "every_step_exchanged": True,
+                               "steps_per_collective": 1}
+    assert "rccl" in d["distributed"]["librccl"]
     assert d["n_gpus"] == 1 and d["check"]["rows"] == B
     tot = _expected_last_step(hip_device, 1)
     assert d["check"]["mean_ll"] == tot[0].item() / tot[1].item()  # bit for bit: SUM over one rank is the identity
@@ -159,6 +161,13 @@ from cirkit_amd.training import HipTrainer
 use_dist = sys.argv[2] == "1"
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
+if sys.argv[2] == "2":  # the library's own communicator, no process group at all: the id never leaves this process
+    from cirkit_amd.distributed import HipComm, set_default_comm
+    comm = HipComm(HipComm.new_unique_id(), 0, 1, dev)
+    set_default_comm(comm)
+    probe = torch.ones(3, dtype=torch.float32, device=dev)
+    comm.all_reduce(probe)
+    assert probe.tolist() == [1.0, 1.0, 1.0] and "rccl" in comm.info()["librccl"]
 if use_dist:
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     probe = torch.ones(1, dtype=torch.float64, device=dev)
@@ -175,6 +184,9 @@ for _ in range(3):
 torch.cuda.synchronize()
 h = float(sum(float(np.abs(v).sum()) for v in tr.parameters().values()))
 print("RESULT " + json.dumps({"lls": lls, "param_abs_sum": h, "dist": use_dist}))
+if sys.argv[2] == "2":
+    assert tr.circuit is not None
+    comm.destroy()
 if use_dist:
     dist.destroy_process_group()
 """
@@ -186,7 +198,7 @@ def test_trainer_gradient_all_reduce_through_rccl(hip_device, tmp_path):
     script = tmp_path / "rccl_trainer.py"
     script.write_text(_TRAINER_SCRIPT)
     res = []
-    for flag in ("1", "0"):
+    for flag in ("1", "0", "2"):
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
         out = subprocess.run([sys.executable, str(script), ROOT, flag], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -199,6 +211,11 @@ def test_trainer_gradient_all_reduce_through_rccl(hip_device, tmp_path):
     for a, b in zip(res[0]["lls"], res[1]["lls"]):
         assert a[1] == b[1] and abs(a[0] - b[0]) <= 1e-6 * abs(b[0])
     assert abs(res[0]["param_abs_sum"] - res[1]["param_abs_sum"]) <= 1e-6 * res[1]["param_abs_sum"]
+    # ... and through ck_comm_all_reduce_f32 (HipComm as the default communicator, no torch.distributed)
+    assert res[2]["lls"][0] == res[1]["lls"][0]
+    for a, b in zip(res[2]["lls"], res[1]["lls"]):
+        assert a[1] == b[1] and abs(a[0] - b[0]) <= 1e-6 * abs(b[0])
+    assert abs(res[2]["param_abs_sum"] - res[1]["param_abs_sum"]) <= 1e-6 * res[1]["param_abs_sum"]
 
 
 def test_bench_line_carries_the_contract(hip_device):
