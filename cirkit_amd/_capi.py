@@ -224,8 +224,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_gather_folds": [_p, _p, _p, _l, _l, _p],
     "ck_param_conj": [_p, _p, _l, _p],
     "ck_param_mixing_weight": [_p, _p, _i, _i, _i, _p],
-    "ck_param_bmm": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "ck_param_bmm_acc": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ck_param_bmm": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_param_einsum": [_p, _p],
     "ck_param_transpose_last2": [_p, _p, _l, _i, _i, _i, _i, _p],
     "ck_param_transpose_last2_c": [_p, _p, _l, _i, _i, _i, _p],
@@ -282,8 +281,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_jobs_root": [C.POINTER(RootLaunch), _p],
     "ck_jobs_cat_bwd": [_p, _i, _p, _i, _i, _p, _p],
     "ck_jobs_gauss_bwd": [_p, _i, _p, _i, _p, _p],
-    "ck_opt_step_range": [_p, _p, _p, _p, _l, _p, _p],
-    "ck_opt_step_range2": [_p, _p, _p, _p, _p, _l, _p, _p],
+    "ck_opt_step_range": [_p, _p, _p, _p, _p, _l, _p, _p],
     "ck_opt_tick": [_p, _p, _p, _p],
     "ck_ll_sum": [_p, _l, _l, _p, _p],
     "ck_program_begin": [C.POINTER(_p)],

@@ -35,7 +35,8 @@ def _newer(target: str, deps: list[str]) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(SRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(SRC, "*.h"))) + [
-        os.path.join(os.path.dirname(HERE), "include", "cirkit_hip.h")
+        os.path.join(os.path.dirname(HERE), "include", "cirkit_hip.h"),
+        os.path.join(os.path.dirname(HERE), "include", "cirkit_hip_internal.h"),
     ]
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []

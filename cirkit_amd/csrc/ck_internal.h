@@ -7,6 +7,7 @@
 #include <functional>
 
 #include "../../include/cirkit_hip.h"
+#include "../../include/cirkit_hip_internal.h"
 
 namespace ck {
 

@@ -1381,11 +1381,7 @@ int ck_jobs_gauss_bwd(const ck_gauss_job* jobs, int n_jobs, const float* const* 
       stream);
 }
 
-int ck_opt_step_range(float* p, const float* g, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream) {
-  return ck_opt_step_range2(p, g, nullptr, m1, m2, n, opt, stream);
-}
-
-int ck_opt_step_range2(float* p, const float* g, const float* g2, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream) {
+int ck_opt_step_range(float* p, const float* g, const float* g2, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream) {
   CK_REQUIRE(p && g && opt && n > 0, "ck_opt_step_range: bad arguments");
   const unsigned grid = static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 2048));
   return ck::dispatch(

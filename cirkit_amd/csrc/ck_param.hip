@@ -1242,12 +1242,7 @@ int ck_param_mixing_weight(const float* in, float* out, int F, int K, int H, voi
       stream);
 }
 
-int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd,
-                 int trans_a, int trans_b, void* stream) {
-  return ck_param_bmm_acc(a, b, out, F, M, N, Kd, trans_a, trans_b, 0, stream);
-}
-
-int ck_param_bmm_acc(const float* a, const float* b, float* out, int F, int M, int N, int Kd, int trans_a, int trans_b, int accumulate,
+int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd, int trans_a, int trans_b, int accumulate,
                      void* stream) {
   CK_REQUIRE(a && b && out, "ck_param_bmm: null pointer");
   CK_REQUIRE(F > 0 && M > 0 && N > 0 && Kd > 0, "ck_param_bmm: non-positive size");

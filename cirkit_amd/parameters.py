@@ -345,7 +345,7 @@ class HipParameter:
                     F, M, Kd = a.shape
                     N = b.shape[2]
                     y = self._buf(j, (F, M, N))
-                    capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), F, M, N, Kd, 0, 0, stream)
+                    capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), F, M, N, Kd, 0, 0, 0, stream)
             elif n.op == "einsum":  # optimized.py:282-284
                 m = None
                 if len(xs) == 2 and not any(x.is_complex() for x in xs):
@@ -356,7 +356,7 @@ class HipParameter:
                     swap, M, N, Kd, ta, tb = m
                     a, b = (xs[1], xs[0]) if swap else (xs[0], xs[1])
                     y = self._buf(j, (a.shape[0], M, N))
-                    capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), a.shape[0], M, N, Kd, ta, tb, stream)
+                    capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), a.shape[0], M, N, Kd, ta, tb, 0, stream)
             elif n.op == "flatten":  # nodes.py:843-844
                 y = xs[0].reshape(shape)
             elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
@@ -491,7 +491,7 @@ class HipParameter:
             """The stored tensor's gradient that a REAL gradient handed to `fi` ends up added to, element for element -- through
             identity indices and conj (of real values) / flatten nodes down to a tensor node or a whole-tensor pointer (every
             one of them the identity map on the entries, so whatever else those nodes collect travels separately) -- or None:
-            the producer then adds into it directly (`ck_param_bmm_acc`) instead of leaving a buffer that travels down the
+            the producer then adds into it directly (`ck_param_bmm` with `accumulate`) instead of leaving a buffer that travels down the
             chain through zero-filled node gradients and axpys."""
             while is_identity(fi):
                 i = fi.ids[0]
@@ -563,8 +563,8 @@ class HipParameter:
                 N = b.shape[2]
                 da = self._buf(("gtmp", j, 0), (F, M, Kd))
                 db = self._buf(("gtmp", j, 1), (F, Kd, N))
-                capi.call("ck_param_bmm", _ptr(dj), _ptr(b), _ptr(da), F, M, Kd, N, 0, 1, stream)
-                capi.call("ck_param_bmm", _ptr(a), _ptr(dj), _ptr(db), F, Kd, N, M, 1, 0, stream)
+                capi.call("ck_param_bmm", _ptr(dj), _ptr(b), _ptr(da), F, M, Kd, N, 0, 1, 0, stream)
+                capi.call("ck_param_bmm", _ptr(a), _ptr(dj), _ptr(db), F, Kd, N, M, 1, 0, 0, stream)
                 scatter((j, 0), n.inputs[0], da)
                 scatter((j, 1), n.inputs[1], db)
             elif n.op == "pointer":  # a gather of folds of a stored tensor (nodes.py:277-279): scatter-add back
@@ -606,10 +606,10 @@ class HipParameter:
                         a, b = a.contiguous(), b.contiguous()
                         dst = sink(n.inputs[k], a.shape[0] * M * N)
                         if dst is not None:  # (the Gram parameters of a squared circuit: 2 x (25 MB written + an axpy over 75 MB) less per step)
-                            capi.call("ck_param_bmm_acc", _ptr(a), _ptr(b), _ptr(dst), a.shape[0], M, N, Kd, ta, tb, 1, stream)
+                            capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(dst), a.shape[0], M, N, Kd, ta, tb, 1, stream)
                             continue
                         dk = self._buf(("ge", j, k), (a.shape[0], M, N))
-                        capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(dk), a.shape[0], M, N, Kd, ta, tb, stream)
+                        capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(dk), a.shape[0], M, N, Kd, ta, tb, 0, stream)
                     scatter((j, k), n.inputs[k], dk)
             elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
                 m1, s1, m2, s2 = (operand(j, k).contiguous() for k in range(4))

@@ -850,7 +850,7 @@ class JobStep:
                 for name in self._tensors_of(i):
                     t, g = c.store[name], tr.grads[name]
                     off = t.data_ptr() - tr._flat_param.data_ptr()
-                    capi.call("ck_opt_step_range", t.data_ptr(), g.data_ptr(), (tr._m1.data_ptr() + off) if tr._m1 is not None else None,
+                    capi.call("ck_opt_step_range", t.data_ptr(), g.data_ptr(), None, (tr._m1.data_ptr() + off) if tr._m1 is not None else None,
                               (tr._m2.data_ptr() + off) if tr._m2 is not None else None, t.numel(), opt, stream)
 
     def _tensors_of(self, i: int) -> list[str]:

@@ -308,7 +308,7 @@ class _PlanBackward:
                 else:  # the batch sum as a product with a row of ones
                     gr = real_part(g, sc)
                     gsum = sc["gsum"]
-                    capi.call("ck_param_bmm", sc["ones"].data_ptr(), gr.data_ptr(), gsum.data_ptr(), F, 1, K, B, 0, 0, stream)
+                    capi.call("ck_param_bmm", sc["ones"].data_ptr(), gr.data_ptr(), gsum.data_ptr(), F, 1, K, B, 0, 0, 0, stream)
                 if l.log_space:
                     dv = gsum
                 else:
@@ -624,7 +624,7 @@ class HipSquaredTrainer:
         """`with_z`: the optimizer reads c's and Z's gradient buffers and adds them itself (no axpy launch before it; `grads`
         then holds c's part only -- `loss_and_grads` leaves the sum)."""
         p = self._flat_param
-        capi.call("ck_opt_step_range2", p.data_ptr(), self._flat_grad.data_ptr(), self._flat_grad_z.data_ptr() if with_z else None,
+        capi.call("ck_opt_step_range", p.data_ptr(), self._flat_grad.data_ptr(), self._flat_grad_z.data_ptr() if with_z else None,
                   None if self._m1 is None else self._m1.data_ptr(), None if self._m2 is None else self._m2.data_ptr(), p.numel(),
                   self._opt_state().data_ptr(), stream)
 

@@ -158,9 +158,6 @@ int ck_sum_lse_fwd(const float* arena, const int64_t* row_off, const float* w, f
  * layers with 96..512 contracted inputs, Tucker layers (stream-K launch).  Every other shape runs in exact fp32. */
 int ck_sum_lse_fwd_v(const float* arena, const int64_t* row_off, const float* w, float* out, int F,
                      int H, int B, int Ki, int Ko, int mode, int w_layout, int contraction, void* stream);
-/* Test hook: route ck_sum_lse_fwd through the shape-generic kernel even where the MFMA kernel
- * applies (A/B parity of the two implementations). */
-int ck_debug_force_generic(int on);
 /* TorchTuckerLayer.forward (optimized.py:89-103) of arity 2 with 32 / 64 input units whose weight is softmax(theta) over its
  * last axis (parameters/nodes.py:764-772), WITHOUT the normalised weights in memory: theta (F, Ko, Ki^2) raw logits, which
  * the launch reads once and normalises online (running row maximum and sum beside the accumulators).  This is the stream-K
@@ -509,12 +506,10 @@ int ck_param_mixing_weight(const float* in, float* out, int F, int K, int H, voi
  * two-operand TorchEinsumParameter patterns (optimized.py:282-284).  a: (F,M,Kd) or (F,Kd,M) if
  * trans_a; b: (F,Kd,N) or (F,N,Kd) if trans_b; out: (F,M,N).  Extents that are multiples of 32: one wavefront per (32, 32)
  * output tile on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate); otherwise (32, 64) multiply-add tiles. */
-int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd,
-                 int trans_a, int trans_b, void* stream);
-/* The same with `accumulate` != 0: out[f] += op(a[f]) . op(b[f]) -- the gradient of an einsum operand added straight into the
+/* `accumulate` != 0: out[f] += op(a[f]) . op(b[f]) -- the gradient of an einsum operand added straight into the
  * gradient of the stored tensor behind it (autograd's accumulation through TorchPointerParameter / TorchConjugateParameter /
  * TorchFlattenParameter, nodes.py:277-279, 745-746, 843-844) instead of a product buffer and an axpy. */
-int ck_param_bmm_acc(const float* a, const float* b, float* out, int F, int M, int N, int Kd, int trans_a, int trans_b, int accumulate,
+int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd, int trans_a, int trans_b, int accumulate,
                      void* stream);
 /* (R, A, Bd) -> (R, out_rows >= Bd, A) transpose of the last two axes (rows beyond Bd untouched),
  * optionally taking log first (categorical: log(probs) -> table (F, C+1, K), input.py:405-408). */
@@ -563,7 +558,6 @@ int ck_segment_add_rows(const float* tmp, const int32_t* cptr, const int32_t* cl
 int ck_sum_lse_bwd(const float* arena, float* garena, const int64_t* row_off, const int64_t* grad_row_off,
                    const float* w, const float* out, const float* gout, float* dw, int F, int H, int B, int Ki, int Ko,
                    int mode, int accumulate, void* stream);
-int ck_debug_force_generic_bwd(int on); /* test hook, like ck_debug_force_generic */
 /* The same layers under complex-lse-sum (ComplexLSESumSemiring.apply_reduce, semiring.py:441-476; ComplexSafeLog,
  * utils.py:22-50): arena / garena / out / gout hold complex64 (re, im) pairs, row_off counts complex elements, the
  * children's gradients are STORED at row_off of garena (torch's convention: conj(dy/dx) * gout), dw -- (F, Ko, N) floats, or
@@ -952,10 +946,9 @@ typedef struct ck_gauss_job {
 int ck_jobs_gauss_bwd(const ck_gauss_job* jobs, int n_jobs, const float* const* pool, int B, const ck_opt_state* opt, void* stream);
 /* The optimizer step p <- p - ... on one flat range with the constants and the clock of a DEVICE ck_opt_state (m1 / m2 may be
  * NULL for SGD): what ck_adam_step / ck_sgd_step do, recordable (no step count in the launch) and skipped with the state. */
-int ck_opt_step_range(float* p, const float* g, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream);
-/* The same on the SUM of two gradient buffers (g2 may be null): a squared circuit's step adds the gradient of Z -- accumulated
- * in a buffer of its own beside c's launches -- where the optimizer reads it instead of in an axpy launch before. */
-int ck_opt_step_range2(float* p, const float* g, const float* g2, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream);
+/* g2 (may be NULL): a second gradient buffer, the step runs on g + g2 -- a squared circuit's step adds the gradient of Z,
+ * accumulated in a buffer of its own beside c's launches, where the optimizer reads it instead of in an axpy launch before. */
+int ck_opt_step_range(float* p, const float* g, const float* g2, float* m1, float* m2, int64_t n, const ck_opt_state* opt, void* stream);
 /* Once per step, before the backward launches: *flag != 0 (the forward's validation flag) -> this step is dropped (skip_now = 1,
  * skipped += 1, *sticky |= *flag, *flag = 0); else step += 1 and the bias corrections of this step.  flag / sticky may be NULL. */
 int ck_opt_tick(ck_opt_state* state, int32_t* flag, int32_t* sticky, void* stream);

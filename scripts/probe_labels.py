@@ -1,5 +1,6 @@
+"""Which launch (kernel label) every layer of the committed fixtures / BASELINE shapes takes on the GPU box: python scripts/probe_labels.py"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from cirkit_amd.circuit import HipCircuit

@@ -13,10 +13,16 @@ from cirkit_amd import _capi as capi
 HEADER = os.path.join(ROOT, "include", "cirkit_hip.h")
 
 
-def _declared_symbols():
-    text = open(HEADER, encoding="utf-8").read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ck_[a-z0-9_]+)\s*\(", text)))
+INTERNAL = os.path.join(ROOT, "include", "cirkit_hip_internal.h")  # test hooks: exported, not part of the boundary
+
+
+def _declared_symbols(headers=(HEADER, INTERNAL)):
+    names = set()
+    for h in headers:
+        text = open(h, encoding="utf-8").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(ck_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -28,6 +34,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     # and the ctypes table binds exactly the declared entry points
     assert set(capi.SIGNATURES) | {"ck_last_error"} == set(names)
     assert lib.ck_abi_version() == capi.ABI_VERSION
+    # the boundary header holds no test hooks, the internal one nothing else
+    assert not [n for n in _declared_symbols((HEADER,)) if n.startswith("ck_debug_")]
+    assert all(n.startswith("ck_debug_") for n in _declared_symbols((INTERNAL,)))
 
 
 def test_invalid_arguments_return_status_and_message():

@@ -119,7 +119,7 @@ def test_bmm_tiles(hip_device, ta, tb, F, M, N, Kd):
     b = torch.randn((F, N, Kd) if tb else (F, Kd, N), generator=g)
     out = torch.full((F, M, N), float("nan"), device=hip_device)
     ad, bd = a.to(hip_device), b.to(hip_device)
-    capi.call("ck_param_bmm", ad.data_ptr(), bd.data_ptr(), out.data_ptr(), F, M, N, Kd, ta, tb,
+    capi.call("ck_param_bmm", ad.data_ptr(), bd.data_ptr(), out.data_ptr(), F, M, N, Kd, ta, tb, 0,
               torch.cuda.current_stream(hip_device).cuda_stream)
     torch.cuda.synchronize()
     a64 = (a.transpose(1, 2) if ta else a).to(torch.float64)
@@ -193,8 +193,8 @@ def test_bmm_gram_matrices(hip_device, F, M, Kd):
     ad = a.to(hip_device)
     out = torch.full((F, M, M), float("nan"), device=hip_device)
     stream = torch.cuda.current_stream(hip_device).cuda_stream
-    capi.call("ck_param_bmm", ad.data_ptr(), ad.data_ptr(), out.data_ptr(), F, M, M, Kd, 0, 1, stream)
-    capi.call("ck_param_bmm_acc", ad.data_ptr(), ad.data_ptr(), out.data_ptr(), F, M, M, Kd, 0, 1, 1, stream)  # (out += the same)
+    capi.call("ck_param_bmm", ad.data_ptr(), ad.data_ptr(), out.data_ptr(), F, M, M, Kd, 0, 1, 0, stream)
+    capi.call("ck_param_bmm", ad.data_ptr(), ad.data_ptr(), out.data_ptr(), F, M, M, Kd, 0, 1, 1, stream)  # (out += the same)
     torch.cuda.synchronize()
     want = 2 * (a.to(torch.float64) @ a.to(torch.float64).transpose(1, 2))
     err = float((out.cpu().to(torch.float64) - want).abs().max())
