@@ -175,6 +175,9 @@ GAUSS_JOB_DTYPE = [("mean", "<u8"), ("stddev", "<u8"), ("x", "<u8"), ("dmean", "
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
 SIGNATURES: dict[str, list[Any]] = {
     "ck_abi_version": [],
+    "ck_clin_table": [_p, _i, _p, _p, _i, _i, _p],
+    "ck_clin_leaf_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
+    "ck_clin_layer_fwd": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_comm_load": [C.c_char_p],
     "ck_comm_unique_id": [_p],
     "ck_comm_init": [_p, _i, _i, _i, C.POINTER(C.c_void_p)],

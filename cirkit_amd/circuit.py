@@ -159,6 +159,7 @@ class HipCircuit(_LaunchMixin, _ProfilingMixin):
         keep_layer_outputs: bool = True,
         params_at_end: bool = True,
         keep_levels: bool = False,
+        complex_linear: bool = True,
     ) -> None:
         if plan.semiring not in ("lse-sum", "complex-lse-sum"):
             raise ValueError(f"semiring {plan.semiring!r} is not evaluated by the HIP backend")
@@ -255,6 +256,16 @@ class HipCircuit(_LaunchMixin, _ProfilingMixin):
         # complex exponentials; memory blocks stay complex64 as the reference's layer outputs are.
         self._signed = bool(signed_real) and self._complex and fuse is not False and persistent_leaf is not False \
             and linear_levels and self._is_real_valued()
+        # A complex-lse-sum circuit with COMPLEX values (complex parameters, or `signed_real=False`) over one Embedding layer:
+        # 32-unit CP-T / dense layers chained on linear (re, im) tiles, the complex logarithm taken once (circuit_clin.py,
+        # csrc/ck_clin.hip).  It owns the whole launch list: none of the fusions below applies beside it.
+        self._clin = None
+        if self._complex and not self._signed and fuse is not False and complex_linear and linear_levels:
+            from .circuit_clin import ClinPath
+
+            self._clin = ClinPath.build(self, depth)
+        if self._clin is not None:
+            fuse = False
         self._groups: list[SubtreeGroup] = (
             find_subtree_groups(plan, self.layers, self._children, self._out_pairs, depth, signed=self._signed)
             if fuse is not False else []
@@ -263,6 +274,8 @@ class HipCircuit(_LaunchMixin, _ProfilingMixin):
             self._signed, self._groups = False, []
         self._group_of_root = {g.root: g for g in self._groups}
         self._virtual = {i for g in self._groups for i in g.virtual}
+        if self._clin is not None:
+            self._virtual = self._clin.virtual_layers()
         self._group_dev: dict[int, tuple] = {}
         self._tail: list[int] = (
             find_tail(plan, self.layers, self._virtual | set(self._group_of_root), signed=self._signed) if fuse is not False else []
@@ -506,6 +519,8 @@ class HipCircuit(_LaunchMixin, _ProfilingMixin):
             bd.leftover[d] = (bd.row_off[d][torch.from_numpy(folds).to(self.device)].contiguous(),
                               torch.from_numpy(bases[d] + folds * (B * K)).to(self.device))
         bd.ll = torch.empty(2, dtype=torch.float64, device=self.device)
+        if self._clin is not None:
+            self._clin.bind(bd)
         self._ensure_param_batch()  # (which leaf launches are persistent depends on the prologue's table jobs)
         bd.direct = self._direct_input(B)
         bd.params_at_end = self._params_at_end(B)
@@ -686,6 +701,9 @@ class HipCircuit(_LaunchMixin, _ProfilingMixin):
 
     def _enqueue_layers_(self, bd: _Binding, stream: int, *, with_ll: bool = False) -> None:
         B = bd.B
+        if self._clin is not None:
+            self._clin.enqueue(bd, stream)
+            return
         pending: list[int] = []  # leftover dense folds (`_cp_leftover`) not launched yet: they wait for their first reader
         for i, (l, view, ro) in enumerate(zip(self.layers, bd.views, bd.row_off)):
             if pending and self._children[i] is not None and set(int(p) for p in np.unique(self._children[i][..., 0])) & set(pending):

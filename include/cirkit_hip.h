@@ -976,6 +976,30 @@ int ck_program_launch(ck_program* prog, int use_graph, void* stream);
  * of TorchCircuit.forward(x), circuits.py:242-278 -- take a different batch per call without staging it. */
 int ck_program_set_input(ck_program* prog, int index, const void* ptr);
 
+/* ---- complex-lse-sum on linear (re, im) tiles (cirkit_amd/csrc/ck_clin.hip) --------------------------------------------
+ * TorchEmbeddingLayer.forward (layers/input.py:258-266) -> TorchCPTLayer / TorchSumLayer (arity 1) of 32 units
+ * (layers/optimized.py:171-178, inner.py:266-273) under ComplexLSESumSemiring.apply_reduce (semiring.py:441-476) for circuits
+ * whose VALUES are complex (complex Embedding weights and / or complex sum weights): between launches a value is
+ * (re + i im) 2^e -- tile-native blocks (fold, tile) -> 1024 dwords re + 1024 dwords im in the MFMA register order, one int32
+ * exponent per (fold, row) -- a product of children is a complex multiply + a power-of-two renormalisation, a sum two (real
+ * weights) or four (complex weights) fp32 MFMA chains; the reference's (log|v|, arg v) pairs are written only by the layer a
+ * circuit outputs (`out_log`).  Results equal the reference's to fp32 rounding; phases modulo 2 pi.
+ * ck_clin_table: w (F, 32, C) fp32 or complex64 -> table (F, C + 1, 32 | 64) = [re 32 | im 32 if complex], each row divided
+ *   by 2^table_e[f, c] (largest |re|, |im| in [0.5, 1)); row C = the sum over the categories (TorchEmbeddingLayer.integrate).
+ * ck_clin_leaf_fwd: `depth` (1..4) CP-T levels over the table in one launch.  xt (D, B) int32 staged categories (negative:
+ *   row C), leaf_fold / leaf_var (R, 2^depth) the Embedding fold and variable of every leaf in walk order, wnode
+ *   (R, 2^depth - 1) DEVICE array of weight-matrix addresses (32, 32) fp32 or complex64 row-major in the order the depth-first
+ *   walk contracts them (after leaf i: levels 1 .. number of trailing one bits of i); out (R, tiles, 2048), out_e (R, tiles 32).
+ * ck_clin_layer_fwd: one layer of F folds, H children each at float offset child_off[f, h] (tile 0 of the child fold's
+ *   block) in `lin` and child_eoff[f, h] in `lin_e`; w (F) DEVICE array of weight-matrix addresses (Ko, 32), Ko <= 32;
+ *   out / out_e (tile blocks, may be NULL) and / or out_log (F, B, Ko) complex64. */
+int ck_clin_table(const float* w, int w_is_complex, float* table, int32_t* table_e, int F, int C, void* stream);
+int ck_clin_leaf_fwd(const float* table, const int32_t* table_e, const int32_t* xt, const int32_t* leaf_fold, const int32_t* leaf_var,
+                     const float* const* wnode, int w_is_complex, int table_is_complex, float* out, int32_t* out_e, int R, int depth,
+                     int B, int C, void* stream);
+int ck_clin_layer_fwd(const float* lin, const int32_t* lin_e, const int64_t* child_off, const int64_t* child_eoff, const float* const* w,
+                      int w_is_complex, float* out, int32_t* out_e, float* out_log, int F, int H, int Ko, int B, void* stream);
+
 /* ---- the exchange step -------------------------------------------------------------------------
  * The path shards on the batch axis: a rank evaluates its rows and ONE SUM all-reduce carries the [sum log p, count] pair
  * of a forward (or the flat gradient buffer of a training step) over RCCL / xGMI.  The reference has no distributed code

@@ -19,10 +19,24 @@ plan = image_data((1, 28, 28), "quad-tree-2", input_layer="embedding", num_input
                   sum_weight_activation="none", semiring="complex-lse-sum")
 t = init_plan_tensors(plan)
 x = torch.randint(0, 256, (B, 784), generator=torch.Generator().manual_seed(0)).cuda()
-for label, kw in (("complex kernels", dict(signed_real=False)), ("signed tiles", {})):
+cases = [("linear (re, im) tiles depth %d" % d, dict(signed_real=False), d) for d in (2, 3, 4)]
+cases += [("layer-wise complex kernels", dict(signed_real=False, complex_linear=False), None), ("signed tiles (real parameters)", {}, None)]
+if os.environ.get("COMPLEX_W"):  # complex-valued sum weights and Embedding weights (random phases): four chains per contraction
+    import numpy as np
+
+    rng = np.random.default_rng(5)
+    tc = {k: (np.asarray(v) * np.exp(1j * rng.uniform(-np.pi, np.pi, np.asarray(v).shape))).astype(np.complex64) for k, v in t.items()}
+    cases = [("complex parameters, linear tiles depth %d" % d, dict(), d) for d in (2, 3)] + [("complex parameters, layer-wise kernels", dict(complex_linear=False), None)]
+for label, kw, depth in cases:
     if os.environ.get("ONLY") and os.environ["ONLY"] not in label:
         continue
-    hc = HipCircuit(plan, t, device="cuda:0", **kw)
+    if depth is not None:
+        os.environ["CK_CLIN_DEPTH"] = str(depth)
+    if os.environ.get("COMPLEX_W"):
+        t_use = tc
+    else:
+        t_use = t
+    hc = HipCircuit(plan, t_use, device="cuda:0", **kw)
     for _ in range(5):
         y = hc(x)
     times = []

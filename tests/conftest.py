@@ -12,6 +12,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle is ATen on the host.  A GPU box has 256 cores: at ATen's default (one thread per core) the small ops of a
+    # folded circuit spend their time in thread hand-overs (the K = 64 gradient checks took 100 s of mostly system time there;
+    # bench.py's cpu_baseline probes 8 .. 64 threads for the same reason).  16 threads serve every oracle call of the suite.
+    try:
+        import torch
+
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except ImportError:  # pragma: no cover
+        pass
 
 
 def load_case(name):
