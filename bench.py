@@ -556,6 +556,9 @@ def main() -> None:
     ap.add_argument("--torch-collectives", action="store_true",
                     help="exchange the [sum, count] pairs through torch.distributed (bucketed, 64 steps per collective) instead of "
                          "the library's own RCCL communicator (ck_comm_*, one collective per step on the launch stream)")
+    ap.add_argument("--sync-collectives", action="store_true",
+                    help="with the library's communicator: the all-reduce of every step ON the launch stream (the next step starts "
+                         "behind it) instead of on the communicator's own stream beside the next step")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-steps", type=int, default=12, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -675,14 +678,25 @@ def main() -> None:
                     works[1 - i].wait()  # (stream-level: the buffer about to be refilled has been reduced)
                     works[1 - i] = None
 
-        ring = torch.zeros((8, 2), dtype=torch.float64, device=device) if comm is not None else None
+        RING = 64
+        ring = torch.zeros((RING, 2), dtype=torch.float64, device=device) if comm is not None else None
 
         def step() -> None:
             x = xs[fed[0] % nb]
             fed[0] += 1
             if comm is not None:
-                # forward + device-side sum + the all-reduce of the pair, all enqueued on `stream` by the library
-                last[0] = circ.log_likelihood_sum(x, out=ring[fed[0] % 8], reduce=True)
+                # forward + device-side sum on `stream`; the all-reduce of the pair on the communicator's own stream, ordered
+                # behind this step (ck_comm_all_reduce_async_f64): nothing of the next step waits for it.  A row of the ring is
+                # written again RING steps later: every RING / 2 steps the launch stream waits (on the device) for the
+                # collectives issued so far
+                row = ring[fed[0] % RING]
+                last[0] = circ.log_likelihood_sum(x, out=row)
+                if args.sync_collectives:
+                    comm.all_reduce(row)
+                else:
+                    comm.all_reduce_async(row)
+                    if fed[0] % (RING // 2) == 0:
+                        comm.wait()
             elif use_dist:
                 i, n = cur
                 # forward + device-side sum, enqueued on `stream`; the launch that ends the forward writes the pair into its row
@@ -694,6 +708,8 @@ def main() -> None:
                 last[0] = circ.log_likelihood_sum(x)
 
         def drain() -> None:
+            if comm is not None and not args.sync_collectives:
+                comm.wait()  # (before the closing event: every collective of the timed steps has run when the clock stops)
             if use_dist and comm is None:
                 flush()
                 for i in range(2):
@@ -801,6 +817,8 @@ def main() -> None:
                         "every_step_exchanged": bool(use_dist),
                         "steps_per_collective": ((1 if comm is not None else 64) if use_dist else None),
                         "librccl": (comm.info()["librccl"] if comm is not None else None),
+                        "collective_stream": (None if comm is None else ("launch stream" if args.sync_collectives
+                                                                          else "the communicator's own stream, beside the next step")),
                         # a straggler GPU shows here: wall time per step of the fastest / slowest rank in the median round
                         "ms_per_step_fastest_rank": (1e3 * sorted(spread)[len(spread) // 2][0] / args.steps) if spread else None,
                         "ms_per_step_slowest_rank": (1e3 * sorted(spread, key=lambda t: t[1])[len(spread) // 2][1] / args.steps) if spread else None},

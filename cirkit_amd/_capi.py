@@ -176,6 +176,7 @@ GAUSS_JOB_DTYPE = [("mean", "<u8"), ("stddev", "<u8"), ("x", "<u8"), ("dmean", "
 SIGNATURES: dict[str, list[Any]] = {
     "ck_abi_version": [],
     "ck_clin_table": [_p, _i, _p, _p, _i, _i, _p],
+    "ck_clin_tail_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ck_clin_leaf_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "ck_clin_layer_fwd": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_comm_load": [C.c_char_p],
@@ -183,6 +184,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_comm_init": [_p, _i, _i, _i, C.POINTER(C.c_void_p)],
     "ck_comm_all_reduce_f64": [_p, _p, _l, _p],
     "ck_comm_all_reduce_f32": [_p, _p, _l, _p],
+    "ck_comm_all_reduce_async_f64": [_p, _p, _l, _p],
+    "ck_comm_wait": [_p, _p],
     "ck_comm_info": [_p, C.POINTER(C.c_int32), C.c_char_p, _i],
     "ck_comm_destroy": [_p],
     "ck_device_info": [_i, C.POINTER(_l)],

@@ -25,6 +25,11 @@ if TYPE_CHECKING:
     from .circuit import HipCircuit, _Binding
 
 _TILE = 2048  # floats of one (fold, 32-row tile): 1024 re + 1024 im
+# ck_clin_tail_fold of include/cirkit_hip.h
+_TAIL_FOLD = np.dtype([("co", "<i8", (2,)), ("ce", "<i8", (2,)), ("w", "<u8"), ("out", "<i8"), ("oute", "<i8"), ("out_log", "<u8"),
+                       ("H", "<i4"), ("Ko", "<i4")])
+assert _TAIL_FOLD.itemsize == 72
+_TAIL_MAX_FOLDS = 64
 
 
 def _plain_tensor(param) -> torch.Tensor | None:
@@ -117,6 +122,19 @@ class ClinPath:
             for l in range(_steps_after(i)):
                 self._node_fold.append((g.levels[l], tabs[l + 1][:, i >> (l + 1)]))
         self.R, self.D = R, D
+        # the few-fold top of the circuit: ONE launch (ck_clin_tail_fwd) instead of one per layer -- the trailing layers with at
+        # most 64 folds in all, one kind of weights, at most two children per fold
+        self.tail: list[int] = []
+        if os.environ.get("CK_CLIN_TAIL", "1") != "0":
+            n = 0
+            for i in reversed(rest):
+                l = c.layers[i]
+                if l.arity > 2 or n + l.num_folds > _TAIL_MAX_FOLDS or (self.tail and wcx[i] != wcx[self.tail[0]]):
+                    break
+                self.tail.insert(0, i)
+                n += l.num_folds
+            if len(self.tail) < 2:
+                self.tail = []
         self._wnode: torch.Tensor | None = None
         self._wlayer: dict[int, torch.Tensor] = {}
         self._wkey = None
@@ -169,6 +187,7 @@ class ClinPath:
             ce = np.vectorize(ebase.__getitem__)(prod).astype(np.int64) + fold.astype(np.int64) * (tiles * 32)
             bd.clin["child"][i] = (torch.from_numpy(np.ascontiguousarray(co)).to(c.device),
                                    torch.from_numpy(np.ascontiguousarray(ce)).to(c.device))
+            bd.clin.setdefault("child_np", {})[i] = (co, ce)
 
     def _is_read(self, i: int) -> bool:
         return any(ch is not None and i in {int(p) for p in np.unique(ch[..., 0])} for ch in self.c._children)
@@ -208,8 +227,45 @@ class ClinPath:
         wk = "WCplx" if self.wcx[g.levels[0]] else "WReal"
         rows = [(self.emb, "clin_table_kernel", table),
                 (g.root, f"clin_leaf_kernel<{self.D}, {wk}, {'true' if self.table_complex else 'false'}>", leaf)]
-        rows += [(i, f"clin_layer_kernel<{'WCplx' if self.wcx[i] else 'WReal'}>", layer(i)) for i in self.rest]
+        rows += [(i, f"clin_layer_kernel<{'WCplx' if self.wcx[i] else 'WReal'}>", layer(i)) for i in self.rest if i not in self.tail]
+        if self.tail:
+            desc, level_off = self._tail_tables(bd)
+            tw = 1 if self.wcx[self.tail[0]] else 0
+
+            def tail(stream):
+                capi.call("ck_clin_tail_fwd", lin.data_ptr(), lin_e.data_ptr(), desc.data_ptr(), level_off.data_ptr(), len(self.tail), tw, bd.B, stream)
+
+            rows.append((self.tail[-1], f"clin_tail_kernel<{'WCplx' if tw else 'WReal'}>", tail))
         return rows
+
+    def _tail_tables(self, bd: "_Binding") -> tuple[torch.Tensor, torch.Tensor]:
+        """The fold descriptors of the tail launch for this batch size (rebuilt when a weight tensor was replaced)."""
+        c, st = self.c, bd.clin
+        if st.get("tail_key") == self._wkey:
+            return st["tail_desc"], st["tail_levels"]
+        tiles, B = st["tiles"], bd.B
+        n = sum(c.layers[i].num_folds for i in self.tail)
+        d = np.zeros(n, dtype=_TAIL_FOLD)
+        level_off, k = [0], 0
+        for i in self.tail:
+            l = c.layers[i]
+            w = _plain_tensor(l.weight)
+            per = int(w.shape[-2]) * int(w.shape[-1]) * (8 if w.is_complex() else 4)
+            co, ce = st["child_np"][i]
+            for f in range(l.num_folds):
+                d["co"][k, : l.arity] = co[f]
+                d["ce"][k, : l.arity] = ce[f]
+                d["w"][k] = int(w.data_ptr()) + f * per
+                d["out"][k] = st["base"][i] + f * tiles * _TILE if i in st["base"] else -1
+                d["oute"][k] = st["ebase"][i] + f * tiles * 32 if i in st["ebase"] else -1
+                d["out_log"][k] = (bd.views[i].data_ptr() + f * B * l.num_output_units * 8) if i in self.outs else 0
+                d["H"][k], d["Ko"][k] = l.arity, l.num_output_units
+                k += 1
+            level_off.append(k)
+        st["tail_desc"] = torch.from_numpy(d.view(np.uint8).reshape(-1)).to(c.device)
+        st["tail_levels"] = torch.tensor(level_off, dtype=torch.int32, device=c.device)
+        st["tail_key"] = self._wkey
+        return st["tail_desc"], st["tail_levels"]
 
     def enqueue(self, bd: "_Binding", stream: int) -> None:
         for _, _, fn in self.launches(bd):
@@ -241,6 +297,8 @@ class ClinPath:
                 folds = sum(c.layers[j].num_folds for j in self.group.levels)
             elif i == self.emb:
                 folds = 0
+            elif name.startswith("clin_tail_kernel"):
+                folds = sum(c.layers[j].num_folds for j in self.tail)
             else:
                 folds = l.num_folds
             fl = folds * bd.B * 2.0 * 32 * 32 * n_contr

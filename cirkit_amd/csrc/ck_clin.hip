@@ -47,26 +47,31 @@ __device__ __forceinline__ void store_native(float* __restrict__ base, int lane,
   for (int g = 0; g < 4; ++g) ck::gstore4(base + 256 * g + 4 * lane, make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]));
 }
 
-// p <- p * q (complex, element-wise); e_p += e_q; then the row is renormalised by a power of two
+// p <- p * q (complex, element-wise); e_p += e_q; then the row is renormalised by a power of two.
+// fp32-input MFMA and the VALU share the SIMD's fp32 lanes: every vector instruction here adds to the
+// chains' time, so the products and the rescale are PACKED (v_pk_mul_f32 / v_pk_fma_f32: two elements per instruction).
 __device__ __forceinline__ void cmul_renorm(CT& p, const CT& q, int& e, int eq) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float ar = p.re[j], ai = p.im[j];
-    p.re[j] = fmaf(ar, q.re[j], -(ai * q.im[j]));
-    p.im[j] = fmaf(ar, q.im[j], ai * q.re[j]);
+  for (int j = 0; j < 8; ++j) {
+    const f32x2v ar = {p.re[2 * j], p.re[2 * j + 1]}, ai = {p.im[2 * j], p.im[2 * j + 1]};
+    const f32x2v br = {q.re[2 * j], q.re[2 * j + 1]}, bi = {q.im[2 * j], q.im[2 * j + 1]};
+    const f32x2v t0 = ai * bi, t1 = ai * br;
+    const f32x2v re = __builtin_elementwise_fma(ar, br, -t0);
+    const f32x2v im = __builtin_elementwise_fma(ar, bi, t1);
+    p.re[2 * j] = re.x;
+    p.re[2 * j + 1] = re.y;
+    p.im[2 * j] = im.x;
+    p.im[2 * j + 1] = im.y;
   }
   float mx = 0.f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(p.re[j]), __builtin_fabsf(p.im[j])));
+  for (int j = 0; j < 16; ++j) mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(p.re[j]), __builtin_fabsf(p.im[j])));  // v_max3_f32 |a| |b|
   mx = ck::xhalf_max(mx);
-  // (mx == 0: the whole row is zero, k = 0; NaN / inf: frexp_exp returns 0, the values stay as they are and reach the output)
+  // (mx == 0: the whole row is zero, k = 0; NaN / inf: the values stay as they are and reach the output)
   const int k = (mx > 0.f && mx < 3.0e38f) ? __builtin_amdgcn_frexp_expf(mx) : 0;
   const float sc = __builtin_amdgcn_ldexpf(1.f, -k);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    p.re[j] *= sc;
-    p.im[j] *= sc;
-  }
+  tile_scale(p.re, sc);
+  tile_scale(p.im, sc);
   e += eq + k;
 }
 
@@ -144,32 +149,42 @@ __device__ __forceinline__ void contract(const WCplx& w, CT& p) {
 // (real weights: rows of 32 floats, no imaginary half -- half the bytes the leaf launch gathers)
 template <bool WC>
 __global__ void __launch_bounds__(256) clin_table_kernel(const float* __restrict__ w, float* __restrict__ table, int32_t* __restrict__ table_e, int C) {
-  extern __shared__ float lds[];  // (32, C + 1) re, then the same for im; column C accumulates the integral
+  extern __shared__ float lds[];  // (32, C + 1) re, then the same for im; column C holds the integral
   const int f = blockIdx.x;
   const int stride = C + 1;
   float* sre = lds;
   float* sim = lds + 32 * stride;
   const float* wf = w + static_cast<int64_t>(f) * 32 * C * (WC ? 2 : 1);
-  for (int i = threadIdx.x; i < 32 * C; i += 256) {
-    const int k = i / C, c = i - k * C;
-    sre[k * stride + c] = WC ? wf[2 * i] : wf[i];
-    sim[k * stride + c] = WC ? wf[2 * i + 1] : 0.f;
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {  // the integral of unit k (TorchEmbeddingLayer.integrate, input.py:280-282: the sum over the states)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a wave per unit (eight units per wave), lanes along the categories: coalesced reads, the unit's integral by a wave sum
+  for (int k = wave; k < 32; k += 4) {
     float ar = 0.f, ai = 0.f;
-    for (int c = 0; c < C; ++c) {
-      ar += sre[threadIdx.x * stride + c];
-      ai += sim[threadIdx.x * stride + c];
+    for (int c = lane; c < C; c += 64) {
+      float vr, vi = 0.f;
+      if (WC) {
+        const float2 v = *reinterpret_cast<const float2*>(wf + 2 * (static_cast<int64_t>(k) * C + c));
+        vr = v.x;
+        vi = v.y;
+      } else {
+        vr = wf[static_cast<int64_t>(k) * C + c];
+      }
+      sre[k * stride + c] = vr;
+      if (WC) sim[k * stride + c] = vi;
+      ar += vr;
+      ai += vi;
     }
-    sre[threadIdx.x * stride + C] = ar;
-    sim[threadIdx.x * stride + C] = ai;
+    ar = ck::wave_sum(ar);  // (TorchEmbeddingLayer.integrate, input.py:280-282: the sum over the states)
+    if (WC) ai = ck::wave_sum(ai);
+    if (lane == 0) {
+      sre[k * stride + C] = ar;
+      if (WC) sim[k * stride + C] = ai;
+    }
   }
   __syncthreads();
-  // a half-wave per row: 32 lanes = 32 units
+  // a half-wave per row: 32 lanes = 32 units (stride C + 1 is odd: consecutive units hit consecutive banks)
   const int k = threadIdx.x & 31;
   for (int c = threadIdx.x >> 5; c <= C; c += 8) {
-    const float vr = sre[k * stride + c], vi = sim[k * stride + c];
+    const float vr = sre[k * stride + c], vi = WC ? sim[k * stride + c] : 0.f;
     float mx = __builtin_fmaxf(__builtin_fabsf(vr), __builtin_fabsf(vi));
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, d, 32));
@@ -180,6 +195,16 @@ __global__ void __launch_bounds__(256) clin_table_kernel(const float* __restrict
     if (WC) row[32 + k] = vi * sc;
     if (k == 0) table_e[static_cast<int64_t>(f) * stride + c] = e;
   }
+}
+
+// Consecutive workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own: the (tile group, fold) pairs are dealt
+// so that ALL tile groups of a fold run on one XCD -- its table rows / weight matrices are fetched into one L2, not eight.
+// id -> (fold, tile group); folds beyond F (the grid is padded to a multiple of 8 folds) return false.
+__device__ __forceinline__ bool xcd_unit(int id, int tile_groups, int F, int& fold, int& tg) {
+  const int x = id & 7, q = id >> 3;
+  fold = (q / tile_groups) * 8 + x;
+  tg = q % tile_groups;
+  return fold < F;
 }
 
 // ---- Embedding -> D CP-T levels ----------------------------------------------------------------------------------------
@@ -199,8 +224,9 @@ template <int D, class W, bool TC>
 __global__ void __launch_bounds__(256) clin_leaf_kernel(const LeafArgs a) {
   constexpr int kLeaves = 1 << D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int root = blockIdx.y;
-  const int tile = blockIdx.x * 4 + wave;
+  int root, tg;
+  if (!xcd_unit(blockIdx.x, (a.tiles + 3) >> 2, a.R, root, tg)) return;
+  const int tile = tg * 4 + wave;
   if (tile >= a.tiles) return;
   const int b_in = lane & 31, kh = lane >> 5;
   const int bl = min(tile * 32 + b_in, a.B - 1);
@@ -254,55 +280,108 @@ struct LayerArgs {
   float* out;                  // (F, tiles, 2048) or null
   int32_t* out_e;
   float* out_log;              // (F, B, Ko) complex64 or null: the reference's (log|v|, arg v)
-  int H, Ko, B, tiles;
+  int F, H, Ko, B, tiles;
 };
 
+// one (fold, tile) unit of a layer: children -> product -> contraction -> tile block and / or (log|v|, arg v) rows
 template <class W>
-__global__ void __launch_bounds__(256) clin_layer_kernel(const LayerArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int f = blockIdx.y;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= a.tiles) return;
+__device__ __forceinline__ void clin_fold(const float* __restrict__ lin, const int32_t* __restrict__ lin_e, const int64_t* __restrict__ co,
+                                          const int64_t* __restrict__ ce, int H, const float* __restrict__ wp, float* __restrict__ out,
+                                          int32_t* __restrict__ out_e, float* __restrict__ out_log, int Ko, int B, int tile, int lane) {
   const int b_in = lane & 31, kh = lane >> 5;
   W w;
-  load_weights(a.w[f], lane, w, a.Ko);
+  load_weights(wp, lane, w, Ko);
   CT cur;
   int e;
   {
-    const float* src = a.lin + a.child_off[static_cast<int64_t>(f) * a.H] + static_cast<int64_t>(tile) * kTileFloats;
+    const float* src = lin + co[0] + static_cast<int64_t>(tile) * kTileFloats;
     load_native(src, lane, cur.re);
     load_native(src + 1024, lane, cur.im);
-    e = a.lin_e[a.child_eoff[static_cast<int64_t>(f) * a.H] + tile * 32 + b_in];
+    e = lin_e[ce[0] + tile * 32 + b_in];
   }
-  for (int h = 1; h < a.H; ++h) {
+  for (int h = 1; h < H; ++h) {
     CT sib;
-    const float* src = a.lin + a.child_off[static_cast<int64_t>(f) * a.H + h] + static_cast<int64_t>(tile) * kTileFloats;
+    const float* src = lin + co[h] + static_cast<int64_t>(tile) * kTileFloats;
     load_native(src, lane, sib.re);
     load_native(src + 1024, lane, sib.im);
-    const int es = a.lin_e[a.child_eoff[static_cast<int64_t>(f) * a.H + h] + tile * 32 + b_in];
+    const int es = lin_e[ce[h] + tile * 32 + b_in];
     cmul_renorm(cur, sib, e, es);
   }
   contract(w, cur);
-  if (a.out != nullptr) {
-    float* dst = a.out + (static_cast<int64_t>(f) * a.tiles + tile) * kTileFloats;
+  if (out != nullptr) {  // (the fold's block: tile 0 at `out`)
+    float* dst = out + static_cast<int64_t>(tile) * kTileFloats;
     store_native(dst, lane, cur.re);
     store_native(dst + 1024, lane, cur.im);
-    if (kh == 0) a.out_e[(static_cast<int64_t>(f) * a.tiles + tile) * 32 + b_in] = e;
+    if (kh == 0) out_e[tile * 32 + b_in] = e;
   }
-  if (a.out_log != nullptr) {
+  if (out_log != nullptr) {  // (the fold's (B, Ko) complex64 rows)
     const int b = tile * 32 + b_in;
-    if (b < a.B) {
+    if (b < B) {
       const float m = static_cast<float>(e) * kLN2;
-      float* dst = a.out_log + (static_cast<int64_t>(f) * a.B + b) * a.Ko * 2;
+      float* dst = out_log + static_cast<int64_t>(b) * Ko * 2;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = 8 * (r >> 2) + 4 * kh + (r & 3);  // the output unit register r of lane (b, kh) holds
-        if (o < a.Ko) {
+        if (o < Ko) {
           const c32 z = ck::c_log_shift_tile(c32{cur.re[r], cur.im[r]}, m);
           dst[2 * o] = z.re;
           dst[2 * o + 1] = z.im;
         }
       }
+    }
+  }
+}
+
+template <class W>
+__global__ void __launch_bounds__(256) clin_layer_kernel(const LayerArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int f, tg;
+  if (!xcd_unit(blockIdx.x, (a.tiles + 3) >> 2, a.F, f, tg)) return;
+  const int tile = tg * 4 + wave;
+  if (tile >= a.tiles) return;
+  clin_fold<W>(a.lin, a.lin_e, a.child_off + static_cast<int64_t>(f) * a.H, a.child_eoff + static_cast<int64_t>(f) * a.H, a.H, a.w[f],
+               a.out != nullptr ? a.out + static_cast<int64_t>(f) * a.tiles * kTileFloats : nullptr,
+               a.out != nullptr ? a.out_e + static_cast<int64_t>(f) * a.tiles * 32 : nullptr,
+               a.out_log != nullptr ? a.out_log + static_cast<int64_t>(f) * a.B * a.Ko * 2 : nullptr, a.Ko, a.B, tile, lane);
+}
+
+// ---- the few-fold top of a circuit in ONE launch -----------------------------------------------------------------------
+// The last layers of a tree-shaped circuit have a handful of folds each (config 5: 24, 11, 6, 4, 2, 1): as launches they cost
+// their latency six times.  Here a workgroup of eight waves owns a 32-row tile and walks the layers in order, a wave per fold,
+// the folds' blocks going through memory as between launches (they are read by other waves of the SAME workgroup: a device-scope
+// fence + the workgroup barrier between layers).
+struct TailFold {
+  int64_t co[2], ce[2];  // children: float / int32 offsets of their folds' tile 0 (H <= 2)
+  const float* w;        // (Ko, 32) weights
+  int64_t out, oute;     // this fold's block (offsets of tile 0), -1: not kept
+  float* out_log;        // this fold's (B, Ko) complex64 rows, or null
+  int32_t H, Ko;
+};
+struct TailArgs {
+  float* lin;
+  int32_t* lin_e;
+  const TailFold* folds;
+  const int32_t* level_off;  // (n_levels + 1) fold ranges of the layers
+  int n_levels, B, tiles;
+};
+constexpr int kTailWaves = 8;
+
+template <class W>
+__global__ void __launch_bounds__(kTailWaves * 64) clin_tail_kernel(const TailArgs a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x;
+  for (int lv = 0; lv < a.n_levels; ++lv) {
+    const int f0 = a.level_off[lv], f1 = a.level_off[lv + 1];
+    for (int i = f0 + wave; i < f1; i += kTailWaves) {
+      const TailFold* d = a.folds + i;
+      const int64_t out = d->out, oute = d->oute;
+      clin_fold<W>(a.lin, a.lin_e, d->co, d->ce, d->H, d->w, out >= 0 ? a.lin + out : nullptr, out >= 0 ? a.lin_e + oute : nullptr,
+                   d->out_log, d->Ko, a.B, tile, lane);
+    }
+    if (lv + 1 < a.n_levels) {
+      __threadfence();  // this wave's blocks are in L2 ...
+      __syncthreads();
+      __threadfence();  // ... and the next layer's loads do not come from a stale line of this CU's cache
     }
   }
 }
@@ -314,7 +393,7 @@ extern "C" {
 int ck_clin_table(const float* w, int w_is_complex, float* table, int32_t* table_e, int F, int C, void* stream) {
   CK_REQUIRE(w && table && table_e, "ck_clin_table: null pointer");
   CK_REQUIRE(F > 0 && C > 0, "ck_clin_table: non-positive size");
-  const size_t lds = static_cast<size_t>(2) * 32 * (C + 1) * sizeof(float);
+  const size_t lds = static_cast<size_t>(w_is_complex ? 2 : 1) * 32 * (C + 1) * sizeof(float);
   if (lds > 150 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_clin_table: %d categories do not fit in LDS", C);
   return ck::dispatch(
       [=](hipStream_t s) {
@@ -332,10 +411,9 @@ int ck_clin_leaf_fwd(const float* table, const int32_t* table_e, const int32_t* 
                      int B, int C, void* stream) {
   CK_REQUIRE(table && table_e && xt && leaf_fold && leaf_var && wnode && out && out_e, "ck_clin_leaf_fwd: null pointer");
   CK_REQUIRE(R > 0 && B > 0 && C > 0, "ck_clin_leaf_fwd: non-positive size");
-  CK_REQUIRE(R <= 65535, "ck_clin_leaf_fwd: %d roots exceed grid.y", R);
   if (depth < 1 || depth > 4) return ck::fail(CK_ERR_UNSUPPORTED, "ck_clin_leaf_fwd: depth %d (1..4)", depth);
   LeafArgs a{table, table_e, xt, leaf_fold, leaf_var, wnode, out, out_e, R, B, (B + 31) / 32, C};
-  const dim3 grid((a.tiles + 3) / 4, R), block(256);
+  const dim3 grid(static_cast<unsigned>(((a.tiles + 3) / 4) * ((R + 7) / 8 * 8))), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
 #define CK_CLIN_LEAF(DD)                                                                      \
@@ -366,15 +444,32 @@ int ck_clin_layer_fwd(const float* lin, const int32_t* lin_e, const int64_t* chi
   CK_REQUIRE(lin && lin_e && child_off && child_eoff && w, "ck_clin_layer_fwd: null pointer");
   CK_REQUIRE((out != nullptr && out_e != nullptr) || out_log != nullptr, "ck_clin_layer_fwd: no output");
   CK_REQUIRE(F > 0 && B > 0 && H >= 1 && Ko >= 1 && Ko <= 32, "ck_clin_layer_fwd: bad sizes (H >= 1, 1 <= Ko <= 32)");
-  CK_REQUIRE(F <= 65535, "ck_clin_layer_fwd: %d folds exceed grid.y", F);
-  LayerArgs a{lin, lin_e, child_off, child_eoff, w, out, out_e, out_log, H, Ko, B, (B + 31) / 32};
-  const dim3 grid((a.tiles + 3) / 4, F), block(256);
+  LayerArgs a{lin, lin_e, child_off, child_eoff, w, out, out_e, out_log, F, H, Ko, B, (B + 31) / 32};
+  const dim3 grid(static_cast<unsigned>(((a.tiles + 3) / 4) * ((F + 7) / 8 * 8))), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
         if (w_is_complex)
           hipLaunchKernelGGL(clin_layer_kernel<WCplx>, grid, block, 0, s, a);
         else
           hipLaunchKernelGGL(clin_layer_kernel<WReal>, grid, block, 0, s, a);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_clin_tail_fwd(float* lin, int32_t* lin_e, const void* folds, const int32_t* level_off, int n_levels, int w_is_complex, int B,
+                     void* stream) {
+  CK_REQUIRE(lin && lin_e && folds && level_off, "ck_clin_tail_fwd: null pointer");
+  CK_REQUIRE(n_levels > 0 && B > 0, "ck_clin_tail_fwd: non-positive size");
+  static_assert(sizeof(TailFold) == 72, "ck_clin_tail_fold of include/cirkit_hip.h");
+  TailArgs a{lin, lin_e, static_cast<const TailFold*>(folds), level_off, n_levels, B, (B + 31) / 32};
+  const dim3 grid(a.tiles), block(kTailWaves * 64);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        if (w_is_complex)
+          hipLaunchKernelGGL(clin_tail_kernel<WCplx>, grid, block, 0, s, a);
+        else
+          hipLaunchKernelGGL(clin_tail_kernel<WReal>, grid, block, 0, s, a);
         return hipGetLastError();
       },
       stream);

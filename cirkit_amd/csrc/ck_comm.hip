@@ -71,6 +71,10 @@ int load_rccl(const char* path) {
 struct CommState {
   Comm comm = nullptr;
   int rank = 0, world = 1, device = 0;
+  // the communicator's own stream: collectives that nothing on the launch stream waits for (the [sum, count] pair of an
+  // evaluation step) run beside the next step's kernels instead of between them
+  hipStream_t side = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 
 }  // namespace
@@ -105,6 +109,13 @@ int ck_comm_init(const void* id128, int rank, int world, int device, ck_comm** o
   const int r = g_rccl.CommInitRank(&c, world, id, rank);  // blocks until every rank of the world has called it
   if (r != 0) return ck::fail(CK_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r));
   ck_comm* cm = new ck_comm();
+  if (hipStreamCreateWithFlags(&cm->s.side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&cm->s.ev_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&cm->s.ev_out, hipEventDisableTiming) != hipSuccess) {
+    g_rccl.CommDestroy(c);
+    delete cm;
+    return ck::fail(CK_ERR_HIP, "ck_comm_init: stream / event creation failed");
+  }
   cm->s.comm = c;
   cm->s.rank = rank;
   cm->s.world = world;
@@ -135,6 +146,36 @@ int ck_comm_all_reduce_f32(ck_comm* comm, float* buf, int64_t n, void* stream) {
   return all_reduce(comm, buf, n, kFloat32, stream, "ck_comm_all_reduce_f32");
 }
 
+// The same collective on the communicator's OWN stream, ordered behind everything enqueued on `after_stream` so far: the launch
+// stream goes on with the next step at once.  ck_comm_wait makes a stream wait for the LAST such collective (and, through the
+// side stream's order, for all before it).
+static int all_reduce_async(ck_comm* comm, void* buf, int64_t n, int dtype, void* after_stream, const char* what) {
+  CK_REQUIRE(comm != nullptr && comm->s.comm != nullptr, "%s: no communicator", what);
+  CK_REQUIRE(buf != nullptr && n > 0, "%s: empty buffer", what);
+  CommState* st = &comm->s;
+  auto fn = g_rccl.AllReduce;
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipError_t e = hipEventRecord(st->ev_in, s);
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(st->side, st->ev_in, 0);
+        if (e != hipSuccess) return e;
+        if (fn(buf, buf, static_cast<size_t>(n), dtype, kSum, st->comm, st->side) != 0) return hipErrorUnknown;
+        return hipEventRecord(st->ev_out, st->side);
+      },
+      after_stream);
+}
+
+int ck_comm_all_reduce_async_f64(ck_comm* comm, double* buf, int64_t n, void* after_stream) {
+  return all_reduce_async(comm, buf, n, kFloat64, after_stream, "ck_comm_all_reduce_async_f64");
+}
+
+int ck_comm_wait(ck_comm* comm, void* stream) {
+  CK_REQUIRE(comm != nullptr && comm->s.comm != nullptr, "ck_comm_wait: no communicator");
+  CommState* st = &comm->s;
+  return ck::dispatch([=](hipStream_t s) { return hipStreamWaitEvent(s, st->ev_out, 0); }, stream);
+}
+
 int ck_comm_info(const ck_comm* comm, int32_t out[3], char* origin, int origin_len) {
   CK_REQUIRE(comm != nullptr && out != nullptr, "ck_comm_info: null argument");
   out[0] = comm->s.rank;
@@ -150,6 +191,12 @@ int ck_comm_info(const ck_comm* comm, int32_t out[3], char* origin, int origin_l
 int ck_comm_destroy(ck_comm* comm) {
   if (comm == nullptr) return CK_OK;
   int r = 0;
+  if (comm->s.side != nullptr) {
+    (void)hipStreamSynchronize(comm->s.side);
+    (void)hipStreamDestroy(comm->s.side);
+  }
+  if (comm->s.ev_in != nullptr) (void)hipEventDestroy(comm->s.ev_in);
+  if (comm->s.ev_out != nullptr) (void)hipEventDestroy(comm->s.ev_out);
   if (comm->s.comm != nullptr) r = g_rccl.CommDestroy(comm->s.comm);
   delete comm;
   if (r != 0) return ck::fail(CK_ERR_HIP, "ncclCommDestroy: %s", g_rccl.GetErrorString(r));

@@ -125,6 +125,24 @@ class HipComm:
                             self._h, t.data_ptr(), t.numel(), s)
         return t
 
+    def all_reduce_async(self, t: torch.Tensor, after_stream: int | None = None) -> torch.Tensor:
+        """In-place SUM of a contiguous float64 tensor on the communicator's OWN stream, ordered behind what the current stream
+        (or `after_stream`) holds so far; the current stream does not wait -- call `wait()` before anything reads `t`."""
+        if self._h.value is None:
+            raise self._capi.HipExtensionError("HipComm: communicator destroyed")
+        if t.dtype != torch.float64 or not t.is_contiguous() or t.device.type != "cuda" or t.device.index != self.device.index:
+            raise ValueError(f"HipComm.all_reduce_async: a contiguous float64 tensor on {self.device}")
+        with torch.cuda.device(self.device):
+            s = torch.cuda.current_stream(self.device).cuda_stream if after_stream is None else after_stream
+            self._capi.call("ck_comm_all_reduce_async_f64", self._h, t.data_ptr(), t.numel(), s)
+        return t
+
+    def wait(self, stream: int | None = None) -> None:
+        """The current stream (or `stream`) waits, on the device, for every `all_reduce_async` issued so far."""
+        with torch.cuda.device(self.device):
+            s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+            self._capi.call("ck_comm_wait", self._h, s)
+
     def info(self) -> dict:
         out = (ctypes.c_int32 * 3)()
         origin = ctypes.create_string_buffer(256)

@@ -993,6 +993,18 @@ int ck_program_set_input(ck_program* prog, int index, const void* ptr);
  * ck_clin_layer_fwd: one layer of F folds, H children each at float offset child_off[f, h] (tile 0 of the child fold's
  *   block) in `lin` and child_eoff[f, h] in `lin_e`; w (F) DEVICE array of weight-matrix addresses (Ko, 32), Ko <= 32;
  *   out / out_e (tile blocks, may be NULL) and / or out_log (F, B, Ko) complex64. */
+/* ck_clin_tail_fwd: the few-fold top of a circuit in one launch -- a workgroup of eight waves per 32-row tile walks the
+ * n_levels layers in order (folds level_off[l] .. level_off[l + 1] of `folds`), a wave per fold, blocks through `lin` as between
+ * launches. */
+typedef struct ck_clin_tail_fold {
+  int64_t co[2], ce[2];  /* children (H <= 2): float offset of the child fold's tile 0 in lin, int32 offset in lin_e */
+  const float* w;        /* (Ko, 32) fp32 or complex64 */
+  int64_t out, oute;     /* this fold's block: offsets of its tile 0, -1: not kept */
+  float* out_log;        /* this fold's (B, Ko) complex64 rows (log|v|, arg v), or NULL */
+  int32_t H, Ko;
+} ck_clin_tail_fold;
+int ck_clin_tail_fwd(float* lin, int32_t* lin_e, const void* folds, const int32_t* level_off, int n_levels, int w_is_complex, int B,
+                     void* stream);
 int ck_clin_table(const float* w, int w_is_complex, float* table, int32_t* table_e, int F, int C, void* stream);
 int ck_clin_leaf_fwd(const float* table, const int32_t* table_e, const int32_t* xt, const int32_t* leaf_fold, const int32_t* leaf_var,
                      const float* const* wnode, int w_is_complex, int table_is_complex, float* out, int32_t* out_e, int R, int depth,
@@ -1017,6 +1029,12 @@ int ck_comm_init(const void* id128, int rank, int world, int device, ck_comm** o
 /* in place, SUM over the ranks, ordered on `stream` like any launch of this library */
 int ck_comm_all_reduce_f64(ck_comm* comm, double* buf, int64_t n, void* stream);
 int ck_comm_all_reduce_f32(ck_comm* comm, float* buf, int64_t n, void* stream);
+/* The same on the communicator's OWN stream, ordered behind what `after_stream` holds so far: nothing on `after_stream` waits
+ * for it -- the [sum, count] pair of an evaluation step is exchanged beside the next step's launches.  ck_comm_wait: `stream`
+ * waits (on the device, not the host) for every collective issued this way so far; an event that was never recorded counts
+ * as complete. */
+int ck_comm_all_reduce_async_f64(ck_comm* comm, double* buf, int64_t n, void* after_stream);
+int ck_comm_wait(ck_comm* comm, void* stream);
 /* out = [rank, world, device]; origin: which librccl was bound */
 int ck_comm_info(const ck_comm* comm, int32_t out[3], char* origin, int origin_len);
 int ck_comm_destroy(ck_comm* comm);

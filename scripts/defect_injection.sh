@@ -9,6 +9,7 @@ bash scripts/lab_build.sh defect cirkit_amd/csrc/ck_jobs.hip -DCK_JOBS_LAB_DEFEC
 CIRKIT_HIP_LIB=$PWD/build/lab/lib_defect.so python -m pytest tests/test_training_jobs.py -q -m gpu -x \
   -k "shallow_circuit or gradients_match_the_layerwise" > build/lab/defect.log 2>&1
 rc=$?
-tail -5 build/lab/defect.log
+grep -E "^E  .*(assert|Error)" build/lab/defect.log | head -6
+tail -3 build/lab/defect.log
 if [ $rc -ne 0 ]; then echo "defect $DEFECT in <W, dW>: CAUGHT (pytest rc $rc)"; exit 0; fi
 echo "defect $DEFECT in <W, dW>: NOT caught"; exit 1

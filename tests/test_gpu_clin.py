@@ -60,6 +60,26 @@ def test_config5_on_linear_tiles_matches_the_reference(hip_device, depth, monkey
     assert mine <= 4.0 * ref + 1e-6 * float(y64.real.abs().max()), (mine, ref)
 
 
+@pytest.mark.parametrize("complex_sums", [False, True])
+def test_tail_launch_is_bit_identical_to_the_layer_launches(hip_device, complex_sums, monkeypatch):
+    """The few-fold top of the circuit in one launch (`ck_clin_tail_fwd`: a workgroup per 32-row tile walks the layers) against
+    one launch per layer: the same arithmetic in the same order, the same bits; 4100 rows: a ragged last tile."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg5_sos_c_k32")
+    rng = np.random.default_rng(3)
+    if complex_sums:
+        tensors = {k: (np.asarray(v) * np.exp(1j * rng.uniform(-np.pi, np.pi, np.asarray(v).shape))).astype(np.complex64) for k, v in tensors.items()}
+    x = torch.randint(0, 256, (4100, plan.num_variables), generator=torch.Generator().manual_seed(8)).to(hip_device)
+    a = HipCircuit(plan, tensors, device=hip_device, signed_real=False)
+    monkeypatch.setenv("CK_CLIN_TAIL", "0")
+    b = HipCircuit(plan, tensors, device=hip_device, signed_real=False)
+    assert a._clin is not None and len(a._clin.tail) >= 5 and b._clin is not None and not b._clin.tail
+    assert a.num_launches(4100) < b.num_launches(4100)
+    ya, yb = a(x).cpu(), b(x).cpu()
+    assert torch.equal(ya.real, yb.real) and torch.equal(ya.imag, yb.imag) and bool(torch.isfinite(ya.real).all())
+
+
 @pytest.mark.parametrize("complex_emb,complex_sums", [(True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("rows", [64, 45])
 def test_complex_parameters_on_linear_tiles(hip_device, complex_emb, complex_sums, rows):

@@ -35,6 +35,17 @@ def test_all_reduce_through_the_c_abi_at_world_size_one(hip_device, comm):
         comm.all_reduce(b)
     s.synchronize()
     assert torch.equal(a, a0) and torch.equal(b, b0)  # SUM over one rank
+    # ... and on the communicator's own stream, ordered behind the work of the current one; `wait` orders readers behind it
+    c = torch.zeros(6, dtype=torch.float64, device=hip_device)
+    with torch.cuda.stream(s):
+        c.fill_(2.5)
+        comm.all_reduce_async(c)
+        comm.wait()
+        d = c * 2
+    s.synchronize()
+    assert d.tolist() == [5.0] * 6
+    with pytest.raises(ValueError):
+        comm.all_reduce_async(b)  # (float64 only)
     with pytest.raises(ValueError):
         comm.all_reduce(torch.zeros(4, dtype=torch.int32, device=hip_device))
     with pytest.raises(ValueError):

@@ -254,9 +254,10 @@ def test_tucker_logits_launch(hip_device, F, B, Ki, Ko, streamk):
     _close(out.cpu(), want)
 
 
-@pytest.mark.parametrize("F,B,Ki,Ko", [(3, 128, 64, 64), (7, 37, 32, 64), (1, 128, 64, 1), (2, 100, 64, 40), (5, 300, 32, 32),
-                                       (20, 128, 64, 64), (9, 128, 64, 128), (12, 4000, 32, 64)])
-@pytest.mark.parametrize("logits", [False, True])
+# (one representative per pipeline: the notebook configuration's shape on weights and on logits, 32 inputs, a scalar top, a
+#  ragged output count -- VERDICT r5 #7; the 4000-row case and the duplicates of these shapes went, 16 -> 6 cases)
+@pytest.mark.parametrize("F,B,Ki,Ko,logits", [(20, 128, 64, 64, True), (20, 128, 64, 64, False), (7, 37, 32, 64, True), (1, 128, 64, 1, False),
+                                              (2, 100, 64, 40, True), (9, 128, 64, 128, False)])
 def test_tucker_bf16_split_variants(hip_device, F, B, Ki, Ko, logits, capsys):
     """`ck_tucker_fwd(contraction = 3 / 6)`: the stream-K Tucker launch with the staged weights and e_r cut into 2 / 3 bf16 pieces
     and contracted on `v_mfma_f32_32x32x16_bf16` (fp32 accumulation) -- labelled variants of the exact launch (contraction 0).
@@ -315,10 +316,10 @@ def test_tucker_bf16_split_variants(hip_device, F, B, Ki, Ko, logits, capsys):
     assert err[0] <= 2e-6 and err[6] <= max(4.0 * err[0], 1e-6) and err[3] <= 1e-4
 
 
-@pytest.mark.parametrize("mode,F,H,B,Ki,Ko", [("cat", 3, 2, 300, 64, 64), ("cat", 2, 3, 130, 32, 32), ("cat", 2, 3, 77, 32, 96),
-                                              ("prod", 2, 2, 260, 128, 128), ("prod", 1, 1, 100, 256, 64), ("cat", 1, 7, 64, 32, 160),
-                                              ("prod", 2, 1, 40, 160, 32), ("prod", 1, 1, 70, 512, 64), ("cat", 1, 3, 40, 256, 32),
-                                              ("prod", 1, 1, 33, 1024, 32), ("prod", 2, 2, 50, 320, 64), ("cat", 1, 7, 20, 64, 32)])
+# (one representative per launch: cat_dense at 64 and at 32 units, the GEMM launch, the split GEMM launch (512 inputs), a
+#  shape beyond the variants (1024 inputs: stays exact) -- VERDICT r5 #7: 12 -> 6 cases)
+@pytest.mark.parametrize("mode,F,H,B,Ki,Ko", [("cat", 3, 2, 300, 64, 64), ("cat", 2, 3, 130, 32, 32), ("prod", 2, 2, 260, 128, 128),
+                                              ("prod", 1, 1, 70, 512, 64), ("prod", 1, 1, 33, 1024, 32), ("cat", 1, 7, 64, 32, 160)])
 def test_dense_bf16_split_variants(hip_device, mode, F, H, B, Ki, Ko, capsys):
     """`ck_sum_lse_fwd_v(contraction = 3 / 6)`: dense layers over concatenated children with 32 / 64 units (the DMA-staged region
     launch) and dense / CP-T layers with 96..1024 contracted inputs (`sum_lse_gemm_kernel<NQ, CAT, CT>`, beyond 256 inputs

@@ -524,7 +524,7 @@ def test_persistent_leaf_segments_longer_than_a_chunk(hip_device, monkeypatch):
     """A segment of more than 64 x 8 tiles is walked in chunks (the 64-bit mask of tiles to redo covers one chunk): with
     whole roots as segments and 17 000 rows (532 tiles per segment) the launch is still bit-identical to the
     workgroup-per-128-rows launch."""
-    import cirkit_amd.circuit as circuit_mod
+    import cirkit_amd.circuit_launch as circuit_mod  # (where `leaf_segments` is looked up by the leaf launches)
     from cirkit_amd.circuit import HipCircuit
 
     plan, tensors, g = load_case("cfg2_qt784")
@@ -885,8 +885,15 @@ def _random_batch(plan, B, seed):
     return x if "gaussian" in kinds else x.long()
 
 
-@pytest.mark.parametrize("name", _native_plan_names())
-@pytest.mark.parametrize("fuse", [True, False])
+# Every fixture with the default launches; layer by layer (`fuse=False`) only the fixtures that differ in WHICH layer kernels
+# they reach (one per region graph / sum-product layer / input arrangement) -- VERDICT r5 #7: 62 -> 45 cases
+_LAYERWISE_TOO = {"plan_ff4_r3_cp", "plan_lt5_r2_rand3_cpt", "plan_pd_1x12x12_delta6-3_cp", "plan_poondomingos_1x20x20_tucker",
+                  "plan_poondomingos_2x17x9_cp", "plan_quadgraph_1x4x4_cp_nc3", "plan_quadgraph_1x5x7_cpt", "plan_quadgraph_1x6x6_tucker",
+                  "plan_quadgraph_1x8x8_cp_mixFalse", "plan_quadtree2_2x3x5_cpt", "plan_quadtree4_1x4x4_tucker", "plan_quadtree4_7x7_cpt",
+                  "plan_randombinarytree_1x12x13_cp", "plan_rbt6_perfeature_cp"}
+
+
+@pytest.mark.parametrize("name,fuse", [(n, True) for n in _native_plan_names()] + [(n, False) for n in _native_plan_names() if n in _LAYERWISE_TOO])
 def test_native_template_plans_match_oracle(name, fuse, hip_device):
     from cirkit_amd import HipCircuit
     from cirkit_amd.initializers import init_plan_tensors
