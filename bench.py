@@ -613,15 +613,26 @@ def main() -> None:
     # host work in between.  torch.distributed only carried the 128-byte ncclUniqueId (and keeps the barriers / the MAX of
     # the wall clocks, which are not on the data path).  BENCH_DIST_BACKEND=gloo (several ranks on ONE device, which RCCL
     # refuses) keeps torch.distributed for the exchange, bucketed as before.
-    comm = None
+    comm, comm_error = None, None
     if use_dist and backend == "nccl" and not args.torch_collectives:
         from cirkit_amd.distributed import HipComm, set_default_comm
 
-        comm = HipComm.from_process_group(device)
-        set_default_comm(comm)
-        probe = torch.ones(1, dtype=torch.float64, device=device)
-        comm.all_reduce(probe)
-        ranks_seen = int(probe.item())
+        try:
+            comm = HipComm.from_process_group(device)
+            set_default_comm(comm)
+            probe = torch.ones(1, dtype=torch.float64, device=device)
+            comm.all_reduce(probe)
+            ranks_seen = int(probe.item())
+        except Exception as e:  # noqa: BLE001 -- e.g. no librccl to bind: the exchange stays on torch.distributed (reported)
+            comm, comm_error = None, f"{type(e).__name__}: {e}"
+            set_default_comm(None)
+        # (every rank must take the same path: a rank whose communicator failed makes all of them fall back)
+        ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if comm is not None and float(ok.item()) == 0.0:
+            comm.destroy()
+            comm, comm_error = None, "another rank could not create its communicator"
+            set_default_comm(None)
 
     # BASELINE configs[1], built natively (cirkit_amd/templates.py; identical to the plan the reference
     # compiles -- tests/test_templates.py pins it against the committed reference fixture)
@@ -817,6 +828,7 @@ def main() -> None:
                         "every_step_exchanged": bool(use_dist),
                         "steps_per_collective": ((1 if comm is not None else 64) if use_dist else None),
                         "librccl": (comm.info()["librccl"] if comm is not None else None),
+                        "rccl_capi_error": comm_error,
                         "collective_stream": (None if comm is None else ("launch stream" if args.sync_collectives
                                                                           else "the communicator's own stream, beside the next step")),
                         # a straggler GPU shows here: wall time per step of the fastest / slowest rank in the median round

@@ -621,6 +621,8 @@ class HipCircuit(_LaunchMixin, _ProfilingMixin):
         remaining parameter graphs, table re-layouts, and the dense layer pushed through the table.
         `at_end`: the tail launch of the PREVIOUS forward evaluated what `_plan_tail_params` assigned to it; only the rest is
         launched here."""
+        if self._clin is not None:
+            return  # (plain tensors everywhere; the one derived parameter, the linear table, is the path's own first launch)
         if at_end:
             self._ensure_param_batch()
             if self._tailp["rest"] is not None:

@@ -13,7 +13,8 @@
 // argument of the final complex number: equal modulo 2 pi.
 //
 //   clin_table_kernel   Embedding weights (F, 32, C) real or complex -> table rows (F, C + 1, 64) = [re 32 | im 32] normalised
-//                       to max(|re|, |im|) in [0.5, 1) + an exponent per row; row C is the layer's integral (sum over c)
+//                       to max(|re|, |im|) in [0.5, 1) + an exponent per row; row C is the sum over c (a negative category;
+//                       the reference's Embedding layer has no integral, HipEmbeddingLayer refuses `integrate_vars`)
 //   clin_leaf_kernel<D> Embedding -> D CP-T levels in one launch: a wave walks a (root, 32-row tile) unit depth-first, sibling
 //                       tiles in registers, leaves gathered from the table; writes the root's tile + exponents
 //   clin_layer_kernel   one CP-T / dense layer on tile blocks (children from any earlier block), optionally writing the
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) clin_table_kernel(const float* __restrict
       ar += vr;
       ai += vi;
     }
-    ar = ck::wave_sum(ar);  // (TorchEmbeddingLayer.integrate, input.py:280-282: the sum over the states)
+    ar = ck::wave_sum(ar);  // (row C: the sum over the states -- what a negative category selects, as in the other gather tables)
     if (WC) ai = ck::wave_sum(ai);
     if (lane == 0) {
       sre[k * stride + C] = ar;
@@ -348,8 +349,8 @@ __global__ void __launch_bounds__(256) clin_layer_kernel(const LayerArgs a) {
 // ---- the few-fold top of a circuit in ONE launch -----------------------------------------------------------------------
 // The last layers of a tree-shaped circuit have a handful of folds each (config 5: 24, 11, 6, 4, 2, 1): as launches they cost
 // their latency six times.  Here a workgroup of eight waves owns a 32-row tile and walks the layers in order, a wave per fold,
-// the folds' blocks going through memory as between launches (they are read by other waves of the SAME workgroup: a device-scope
-// fence + the workgroup barrier between layers).
+// the folds' blocks going through memory as between launches (they are read by other waves of the SAME workgroup: a
+// workgroup-scope fence + the workgroup barrier between layers).
 struct TailFold {
   int64_t co[2], ce[2];  // children: float / int32 offsets of their folds' tile 0 (H <= 2)
   const float* w;        // (Ko, 32) weights
@@ -379,9 +380,13 @@ __global__ void __launch_bounds__(kTailWaves * 64) clin_tail_kernel(const TailAr
                    d->out_log, d->Ko, a.B, tile, lane);
     }
     if (lv + 1 < a.n_levels) {
-      __threadfence();  // this wave's blocks are in L2 ...
+      // The next layer's readers are waves of THIS workgroup, i.e. of this compute unit: workgroup scope.  (A device-scope fence
+      // writes back and invalidates the whole L2 of the XCD on gfx950 -- measured: 255 us for this launch instead of ~20.)  The
+      // stores have left the CU when vmcnt reaches 0 (the vector cache is write-through); the blocks a layer reads were never
+      // read before in this launch, so no stale line of them can sit in the CU's cache.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
-      __threadfence();  // ... and the next layer's loads do not come from a stale line of this CU's cache
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   }
 }

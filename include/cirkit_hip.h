@@ -985,7 +985,8 @@ int ck_program_set_input(ck_program* prog, int index, const void* ptr);
  * weights) or four (complex weights) fp32 MFMA chains; the reference's (log|v|, arg v) pairs are written only by the layer a
  * circuit outputs (`out_log`).  Results equal the reference's to fp32 rounding; phases modulo 2 pi.
  * ck_clin_table: w (F, 32, C) fp32 or complex64 -> table (F, C + 1, 32 | 64) = [re 32 | im 32 if complex], each row divided
- *   by 2^table_e[f, c] (largest |re|, |im| in [0.5, 1)); row C = the sum over the categories (TorchEmbeddingLayer.integrate).
+ *   by 2^table_e[f, c] (largest |re|, |im| in [0.5, 1)); row C = the sum over the categories (what a negative
+ *   category selects; the reference's Embedding layer has no integral and the host API refuses marginalisation through it).
  * ck_clin_leaf_fwd: `depth` (1..4) CP-T levels over the table in one launch.  xt (D, B) int32 staged categories (negative:
  *   row C), leaf_fold / leaf_var (R, 2^depth) the Embedding fold and variable of every leaf in walk order, wnode
  *   (R, 2^depth - 1) DEVICE array of weight-matrix addresses (32, 32) fp32 or complex64 row-major in the order the depth-first
