@@ -175,16 +175,20 @@ def other_configs(device, stream, B: int) -> dict:
         "ms_partition_function": ms_z,
     }
     del hc, hz
-    # ... and on the complex kernels (what a circuit with complex-valued parameters takes; `signed_real=False` forces them for
-    # these real parameters): layer-wise (log|v|, phase) pairs, two fp32 MFMA tiles per step, polynomial sin / cos / atan
+    # ... and on the complex path (what a circuit with complex-valued parameters takes; `signed_real=False` forces it for
+    # these real parameters): linear (re, im) tiles, two fp32 MFMA chains per contraction
     hq = HipCircuit(plan5, t5, device=device, signed_real=False)
     ms_q = time_forward(hq, torch.randint(0, 256, (B, 784), generator=g).to(device))
     out["config5_complex_weights"] = {
-        "workload": "the same circuit evaluated as complex-valued parameters require: every layer on (log|v|, arg v) pairs "
-                    "(sum_clse_tile32: VALU-issue and HBM bound, profiles/r05_c_cfg5_complex.txt)",
+        "workload": "the same circuit evaluated as complex-valued parameters require (signed_real=False): values as (re + i im) 2^e tiles, "
+                    "Embedding -> 3 CP-T levels in one launch, the complex logarithm once at the output (profiles/r06_b_cfg5_complex.txt; "
+                    "0.575 ms on the layer-wise (log|v|, arg v) kernels of round 5)",
         "ms_per_forward": ms_q, "evals_per_s": B / ms_q * 1e3, "launches": hq.num_launches(B),
-        "executed_flops": contraction_flops(plan5, B, 4),  # four real (32, 32) contractions per complex one
-        "frac_of_fp32_mfma": contraction_flops(plan5, B, 4) / (ms_q * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+        # real weights on complex values: two real (32, 32) contractions per layer and tile (W re, W im); four with complex weights
+        "executed_flops": contraction_flops(plan5, B, 2),
+        "frac_of_fp32_mfma": contraction_flops(plan5, B, 2) / (ms_q * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+        "path": ("linear (re, im) tiles (cirkit_amd/circuit_clin.py, csrc/ck_clin.hip)" if getattr(hq, "_clin", None) is not None
+                 else "layer-wise (log|v|, arg v) kernels"),
     }
     del hq
     out["train_step_cfg2"] = train_step_cfg2(device, stream, B)
