@@ -22,6 +22,8 @@ CK_UNARY_SCALED_SIGMOID = 1
 CK_UNARY_EXP = 2
 CK_UNARY_LOG = 3
 CK_UNARY_SQUARE = 4
+CK_UNARY_CLAMP = 5
+CK_UNARY_SOFTPLUS = 6
 
 _p = C.c_void_p
 _i = C.c_int
@@ -177,7 +179,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_abi_version": [],
     "ck_clin_table": [_p, _i, _p, _p, _i, _i, _p],
     "ck_clin_tail_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
-    "ck_clin_leaf_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
+    "ck_clin_leaf_fwd": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p],
     "ck_clin_layer_fwd": [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "ck_comm_load": [C.c_char_p],
     "ck_comm_unique_id": [_p],

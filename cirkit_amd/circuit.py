@@ -17,6 +17,7 @@ with ~10 ATen launches per layer.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Mapping
 
 import numpy as np
@@ -542,6 +543,8 @@ class HipCircuit(_LaunchMixin, _ProfilingMixin):
         """Whether a forward at batch size B needs no staged copy of the discrete batch: its only readers are persistent
         leaf launches, which then read -- and validate -- the caller's int64 tensor (`ck_leaf_walk_fwd` with x_input).
         Byte offsets into the batch are 32-bit."""
+        if self._clin is not None:  # (the leaf launch of the linear-tile path reads and validates the int64 batch itself)
+            return bool(self.direct_input and self._int_input and os.environ.get("CK_CLIN_STAGED", "0") != "1")
         if not (self.direct_input and self._int_input and self._groups):
             return False
         if self.plan.num_variables * B * 8 >= 2**32:

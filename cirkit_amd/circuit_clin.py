@@ -206,9 +206,17 @@ class ClinPath:
         def table(stream):
             capi.call("ck_clin_table", _plain_tensor(le.weight).data_ptr(), tc, self.table.data_ptr(), self.table_e.data_ptr(), le.num_folds, self.C, stream)
 
+        # the batch: the caller's int64 tensor itself (program input cell 0 while recording; validated by the launch: a bad row
+        # becomes NaN and raises the circuit's flag), or the staged (D, B) int32 copy
+        if bd.direct:
+            x_rows, x_input = c._raw_batch_args(bd)
+            xt, flag = None, (c._bad_input.data_ptr() if c.validate_inputs else None)
+        else:
+            xt, x_rows, x_input, flag = bd.xt_i.data_ptr(), None, -1, None
+
         def leaf(stream):
-            capi.call("ck_clin_leaf_fwd", self.table.data_ptr(), self.table_e.data_ptr(), bd.xt_i.data_ptr(), self.leaf_fold.data_ptr(),
-                      self.leaf_var.data_ptr(), self._wnode.data_ptr(), 1 if self.wcx[g.levels[0]] else 0, tc,
+            capi.call("ck_clin_leaf_fwd", self.table.data_ptr(), self.table_e.data_ptr(), xt, x_rows, x_input, c.plan.num_variables, flag,
+                      self.leaf_fold.data_ptr(), self.leaf_var.data_ptr(), self._wnode.data_ptr(), 1 if self.wcx[g.levels[0]] else 0, tc,
                       lin.data_ptr() + 4 * st["base"][g.root], lin_e.data_ptr() + 4 * st["ebase"][g.root], self.R, self.D, bd.B, self.C,
                       stream)
 

@@ -26,7 +26,7 @@ import numpy as np
 from .plan import IDX_ARRAY, IDX_NONE, FoldIndex, LayerSpec, ParamGraph, ParamNode, Plan, resolve_fold_index
 from .templates import _fold_index, _kahn_frontiers, _outgoings
 
-_UNARY_PARAM_OPS = ("softmax", "log_softmax", "sigmoid", "scaled_sigmoid", "exp", "log", "square", "conj")
+_UNARY_PARAM_OPS = ("softmax", "log_softmax", "sigmoid", "scaled_sigmoid", "exp", "log", "square", "clamp", "softplus", "conj")
 
 
 def _children(plan: Plan) -> list[list[tuple[int, int]] | None]:

@@ -1116,6 +1116,8 @@ __global__ void __launch_bounds__(256)
     if (op == CK_UNARY_SIGMOID) d = y[i] * (1.f - y[i]);
     else if (op == CK_UNARY_EXP) d = y[i];
     else if (op == CK_UNARY_LOG) d = 1.f / x[i];
+    else if (op == CK_UNARY_CLAMP) d = y[i] == x[i] ? 1.f : 0.f;  // (inside [vmin, vmax], bounds included: torch.clamp's backward)
+    else if (op == CK_UNARY_SOFTPLUS) d = x[i] > 20.f ? 1.f : 1.f / (1.f + expf(-x[i]));
     else d = 2.f * x[i];
     // (an entry nobody selected has dy == 0: its gradient is 0 whatever the derivative -- 0 * inf at log(0) would be NaN)
     const float g = dy[i] == 0.f ? 0.f : dy[i] * d;
@@ -1368,7 +1370,8 @@ int ck_param_softmax_bwd_strided(const float* y, const float* dy, float* dx, int
 
 int ck_param_unary_bwd(int op, const float* x, const float* y, const float* dy, float* dx, int64_t n, int accumulate, void* stream) {
   CK_REQUIRE(x && y && dy && dx && n > 0, "ck_param_unary_bwd: bad arguments");
-  CK_REQUIRE(op == CK_UNARY_SIGMOID || op == CK_UNARY_EXP || op == CK_UNARY_LOG || op == CK_UNARY_SQUARE,
+  CK_REQUIRE(op == CK_UNARY_SIGMOID || op == CK_UNARY_EXP || op == CK_UNARY_LOG || op == CK_UNARY_SQUARE || op == CK_UNARY_CLAMP ||
+                 op == CK_UNARY_SOFTPLUS,
              "ck_param_unary_bwd: op %d (scaled sigmoid: ck_param_scaled_sigmoid_bwd)", op);
   dim3 grid(grid1(n)), block(256);
   return ck::dispatch(

@@ -212,7 +212,10 @@ __device__ __forceinline__ bool xcd_unit(int id, int tile_groups, int F, int& fo
 struct LeafArgs {
   const float* table;
   const int32_t* table_e;
-  const int32_t* xt;         // (D_vars, B) staged categories (negative: integrate the variable)
+  const int32_t* xt;         // (D_vars, B) staged categories (negative: row C), or null: the raw batch below
+  const int64_t* x64;        // (B, D_vars) the caller's int64 batch, read -- and validated -- by the launch itself
+  int32_t* bad_flag;         // raw batch: raised when a category is >= C (the row's values become NaN); null: no validation
+  int n_vars;
   const int32_t* leaf_fold;  // (R, 2^D) Embedding fold of every leaf, walk order
   const int32_t* leaf_var;   // (R, 2^D) its variable
   const float* const* wnode; // (R, 2^D - 1) weight matrices in the order the walk contracts them
@@ -221,7 +224,7 @@ struct LeafArgs {
   int R, B, tiles, C;
 };
 
-template <int D, class W, bool TC>
+template <int D, class W, bool TC, bool XRAW>
 __global__ void __launch_bounds__(256) clin_leaf_kernel(const LeafArgs a) {
   constexpr int kLeaves = 1 << D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -238,11 +241,19 @@ __global__ void __launch_bounds__(256) clin_leaf_kernel(const LeafArgs a) {
   int estack[D];
   CT cur;
   int e = 0;
+  bool row_bad = false;  // (raw batch: a category outside the layer's range -- TorchEmbeddingLayer's indexing raises there)
   static_for<0, kLeaves>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     {  // leaf i: a table row
-      const int xv = a.xt[static_cast<int64_t>(lv[i]) * a.B + bl];
-      const int c = xv < 0 ? a.C : min(xv, a.C - 1);
+      int c;
+      if constexpr (XRAW) {
+        const int64_t xv = a.x64[static_cast<int64_t>(bl) * a.n_vars + lv[i]];
+        row_bad |= xv >= a.C;
+        c = xv < 0 ? a.C : (xv >= a.C ? a.C - 1 : static_cast<int>(xv));
+      } else {
+        const int xv = a.xt[static_cast<int64_t>(lv[i]) * a.B + bl];
+        c = xv < 0 ? a.C : min(xv, a.C - 1);
+      }
       const int64_t r = static_cast<int64_t>(lf[i]) * (a.C + 1) + c;
       const float* row = a.table + r * (TC ? 64 : 32) + 4 * kh;
 #pragma unroll
@@ -265,6 +276,15 @@ __global__ void __launch_bounds__(256) clin_leaf_kernel(const LeafArgs a) {
       estack[steps_after(i)] = e;
     }
   });
+  if constexpr (XRAW) {
+    if (a.bad_flag != nullptr) {  // a bad ROW becomes NaN (it travels through every product and contraction above) and raises the flag
+      if (row_bad) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cur.re[j] = __builtin_nanf("");
+      }
+      if (__ballot(row_bad) != 0 && lane == 0) atomicOr(a.bad_flag, 1);
+    }
+  }
   float* dst = a.out + (static_cast<int64_t>(root) * a.tiles + tile) * kTileFloats;
   store_native(dst, lane, cur.re);
   store_native(dst + 1024, lane, cur.im);
@@ -411,26 +431,46 @@ int ck_clin_table(const float* w, int w_is_complex, float* table, int32_t* table
       stream);
 }
 
-int ck_clin_leaf_fwd(const float* table, const int32_t* table_e, const int32_t* xt, const int32_t* leaf_fold, const int32_t* leaf_var,
-                     const float* const* wnode, int w_is_complex, int table_is_complex, float* out, int32_t* out_e, int R, int depth,
-                     int B, int C, void* stream) {
-  CK_REQUIRE(table && table_e && xt && leaf_fold && leaf_var && wnode && out && out_e, "ck_clin_leaf_fwd: null pointer");
+int ck_clin_leaf_fwd(const float* table, const int32_t* table_e, const int32_t* xt, const int64_t* x_rows, int x_input, int n_vars,
+                     int32_t* bad_flag, const int32_t* leaf_fold, const int32_t* leaf_var, const float* const* wnode, int w_is_complex,
+                     int table_is_complex, float* out, int32_t* out_e, int R, int depth, int B, int C, void* stream) {
+  CK_REQUIRE(table && table_e && leaf_fold && leaf_var && wnode && out && out_e, "ck_clin_leaf_fwd: null pointer");
   CK_REQUIRE(R > 0 && B > 0 && C > 0, "ck_clin_leaf_fwd: non-positive size");
   if (depth < 1 || depth > 4) return ck::fail(CK_ERR_UNSUPPORTED, "ck_clin_leaf_fwd: depth %d (1..4)", depth);
-  LeafArgs a{table, table_e, xt, leaf_fold, leaf_var, wnode, out, out_e, R, B, (B + 31) / 32, C};
+  const bool raw = xt == nullptr;
+  const void* const* slot = nullptr;
+  if (raw) {
+    CK_REQUIRE(x_rows != nullptr || x_input >= 0, "ck_clin_leaf_fwd: neither a staged batch (xt) nor the raw batch (x_rows / x_input)");
+    CK_REQUIRE(n_vars > 0, "ck_clin_leaf_fwd: the raw batch needs its row length (n_vars)");
+    if (x_input >= 0) {
+      slot = ck::program_input_slot(x_input);
+      CK_REQUIRE(slot != nullptr, "ck_clin_leaf_fwd: x_input=%d names a program input, but no program is being recorded on this thread "
+                                  "(or the index is out of range)", x_input);
+    }
+  }
+  LeafArgs a{table, table_e, xt, x_rows, raw ? bad_flag : nullptr, n_vars, leaf_fold, leaf_var, wnode, out, out_e, R, B, (B + 31) / 32, C};
   const dim3 grid(static_cast<unsigned>(((a.tiles + 3) / 4) * ((R + 7) / 8 * 8))), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-#define CK_CLIN_LEAF(DD)                                                                      \
-  case DD:                                                                                    \
-    if (w_is_complex && table_is_complex)                                                     \
-      hipLaunchKernelGGL((clin_leaf_kernel<DD, WCplx, true>), grid, block, 0, s, a);          \
-    else if (w_is_complex)                                                                    \
-      hipLaunchKernelGGL((clin_leaf_kernel<DD, WCplx, false>), grid, block, 0, s, a);         \
-    else if (table_is_complex)                                                                \
-      hipLaunchKernelGGL((clin_leaf_kernel<DD, WReal, true>), grid, block, 0, s, a);          \
-    else                                                                                      \
-      hipLaunchKernelGGL((clin_leaf_kernel<DD, WReal, false>), grid, block, 0, s, a);         \
+        LeafArgs b = a;
+        if (slot != nullptr) b.x64 = static_cast<const int64_t*>(*slot);  // the batch of THIS replay (ck_program_set_input)
+        if (raw && b.x64 == nullptr) return hipErrorInvalidValue;
+#define CK_CLIN_LEAF_X(DD, WW, TT)                                                       \
+  if (raw)                                                                              \
+    hipLaunchKernelGGL((clin_leaf_kernel<DD, WW, TT, true>), grid, block, 0, s, b);     \
+  else                                                                                  \
+    hipLaunchKernelGGL((clin_leaf_kernel<DD, WW, TT, false>), grid, block, 0, s, b);
+#define CK_CLIN_LEAF(DD)                                            \
+  case DD:                                                          \
+    if (w_is_complex && table_is_complex) {                         \
+      CK_CLIN_LEAF_X(DD, WCplx, true)                               \
+    } else if (w_is_complex) {                                      \
+      CK_CLIN_LEAF_X(DD, WCplx, false)                              \
+    } else if (table_is_complex) {                                  \
+      CK_CLIN_LEAF_X(DD, WReal, true)                               \
+    } else {                                                        \
+      CK_CLIN_LEAF_X(DD, WReal, false)                              \
+    }                                                               \
     break;
         switch (depth) {
           CK_CLIN_LEAF(1)
@@ -439,6 +479,7 @@ int ck_clin_leaf_fwd(const float* table, const int32_t* table_e, const int32_t* 
           CK_CLIN_LEAF(4)
         }
 #undef CK_CLIN_LEAF
+#undef CK_CLIN_LEAF_X
         return hipGetLastError();
       },
       stream);

@@ -73,6 +73,12 @@ __global__ void __launch_bounds__(256)
       case CK_UNARY_LOG:
         y = logf(x);
         break;
+      case CK_UNARY_CLAMP:  // torch.clamp(x, min=a, max=b): NaN stays NaN
+        y = x < a ? a : (x > b ? b : x);
+        break;
+      case CK_UNARY_SOFTPLUS:  // torch.nn.functional.softplus (beta 1, threshold 20)
+        y = x > 20.f ? x : log1pf(expf(x));
+        break;
       default:
         y = x * x;
         break;
@@ -1193,7 +1199,7 @@ int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_
 int ck_param_unary(int op, const float* in, float* out, int64_t n, float a, float b, void* stream) {
   CK_REQUIRE(in && out, "ck_param_unary: null pointer");
   CK_REQUIRE(n > 0, "ck_param_unary: n must be positive");
-  CK_REQUIRE(op >= CK_UNARY_SIGMOID && op <= CK_UNARY_SQUARE, "ck_param_unary: unknown op %d", op);
+  CK_REQUIRE(op >= CK_UNARY_SIGMOID && op <= CK_UNARY_SOFTPLUS, "ck_param_unary: unknown op %d", op);
   dim3 grid(grid1d(n)), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {

@@ -34,8 +34,8 @@ import numpy as np
 
 from .plan import LayerSpec, ParamGraph, ParamNode, Plan
 
-_UNARY = {"softmax", "sigmoid", "scaled_sigmoid", "exp", "square"}
-_ZERO_AT_NEG_INF = {"softmax", "sigmoid", "exp"}  # ops that map -inf to exactly 0
+_UNARY = {"softmax", "sigmoid", "scaled_sigmoid", "exp", "square", "softplus"}
+_ZERO_AT_NEG_INF = {"softmax", "sigmoid", "exp", "softplus"}  # ops that map -inf to exactly 0 (a positive clamp has no zero: not padded)
 _LAYERS = {"categorical", "binomial", "gaussian", "sum", "cpt", "tucker", "hadamard"}
 
 

@@ -309,7 +309,7 @@ class HipParameter:
                     "ck_param_softmax", _ptr(x), _ptr(y), outer, int(x.shape[dim]), inner,
                     1 if n.op == "log_softmax" else 0, stream,
                 )
-            elif n.op in ("sigmoid", "scaled_sigmoid", "exp", "log", "square"):  # nodes.py:656-699
+            elif n.op in ("sigmoid", "scaled_sigmoid", "exp", "log", "square", "clamp", "softplus"):  # nodes.py:656-739
                 x = xs[0]
                 if x.is_complex():
                     raise NotImplementedError(f"{n.op} of a complex parameter")
@@ -319,12 +319,16 @@ class HipParameter:
                     "exp": capi.CK_UNARY_EXP,
                     "log": capi.CK_UNARY_LOG,
                     "square": capi.CK_UNARY_SQUARE,
+                    "clamp": capi.CK_UNARY_CLAMP,
+                    "softplus": capi.CK_UNARY_SOFTPLUS,
                 }[n.op]
                 y = self._buf(j, shape)
-                capi.call(
-                    "ck_param_unary", code, _ptr(x), _ptr(y), x.numel(),
-                    float(c.get("vmin", 0.0)), float(c.get("vmax", 1.0)), stream,
-                )
+                if n.op == "clamp":  # (an absent bound: no clamping on that side, nodes.py:727-728)
+                    lo = float("-inf") if c.get("vmin") is None else float(c["vmin"])
+                    hi = float("inf") if c.get("vmax") is None else float(c["vmax"])
+                else:
+                    lo, hi = float(c.get("vmin", 0.0)), float(c.get("vmax", 1.0))
+                capi.call("ck_param_unary", code, _ptr(x), _ptr(y), x.numel(), lo, hi, stream)
             elif n.op == "conj":  # nodes.py:745-746
                 x = xs[0]
                 if x.is_complex():
@@ -537,10 +541,11 @@ class HipParameter:
                               int(np.prod(y.shape[dim + 1:])), 1 if n.op == "log_softmax" else 0, acc, stream)
                 if sc:
                     scatter((j, 0), n.inputs[0], dx)
-            elif n.op in ("sigmoid", "exp", "log", "square"):  # entrywise nodes (nodes.py:656-699)
+            elif n.op in ("sigmoid", "exp", "log", "square", "clamp", "softplus"):  # entrywise nodes (nodes.py:656-739)
                 y, x = value(j), operand(j, 0)
                 dx, acc, sc = direct(j, 0)
-                code = {"sigmoid": capi.CK_UNARY_SIGMOID, "exp": capi.CK_UNARY_EXP, "log": capi.CK_UNARY_LOG, "square": capi.CK_UNARY_SQUARE}[n.op]
+                code = {"sigmoid": capi.CK_UNARY_SIGMOID, "exp": capi.CK_UNARY_EXP, "log": capi.CK_UNARY_LOG, "square": capi.CK_UNARY_SQUARE,
+                        "clamp": capi.CK_UNARY_CLAMP, "softplus": capi.CK_UNARY_SOFTPLUS}[n.op]
                 capi.call("ck_param_unary_bwd", code, _ptr(x), _ptr(y), _ptr(dj), _ptr(dx), y.numel(), acc, stream)
                 if sc:
                     scatter((j, 0), n.inputs[0], dx)

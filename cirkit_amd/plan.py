@@ -57,6 +57,8 @@ PARAM_OPS = {
     "TorchExpParameter": "exp",
     "TorchLogParameter": "log",
     "TorchSquareParameter": "square",
+    "TorchClampParameter": "clamp",
+    "TorchSoftplusParameter": "softplus",
     "TorchConjugateParameter": "conj",
     "TorchMixingWeightParameter": "mixing_weight",
     "TorchMatMulParameter": "matmul",

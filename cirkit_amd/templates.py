@@ -398,6 +398,10 @@ def _activation_node(shape: tuple[int, ...], activation: str) -> _PN | None:
         return _PN("scaled_sigmoid", shape, {"vmin": 1e-05, "vmax": 1.0})
     if activation == "sigmoid":
         return _PN("sigmoid", shape, {})
+    if activation == "positive-clamp":  # (templates/utils.py:189-192: ClampParameter with vmin = 1e-18)
+        return _PN("clamp", shape, {"vmin": 1e-18})
+    if activation == "softplus":  # (templates/utils.py:193-194)
+        return _PN("softplus", shape, {})
     if activation == "none":
         return None
     raise NotImplementedError(f"activation {activation!r}")

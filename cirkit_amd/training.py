@@ -161,7 +161,7 @@ class HipTrainer:
             raise NotImplementedError("the job form of the training step needs an unpadded plan outside the fused form")
 
     # ------------------------------------------------------------------------------------------
-    _PARAM_OPS = {"tensor", "softmax", "log_softmax", "sigmoid", "exp", "log", "square", "scaled_sigmoid", "mixing_weight", "matmul"}
+    _PARAM_OPS = {"tensor", "softmax", "log_softmax", "sigmoid", "exp", "log", "square", "clamp", "softplus", "scaled_sigmoid", "mixing_weight", "matmul"}
 
     def _check_supported(self) -> None:
         for spec, l in zip(self.plan.layers, self.circuit.layers):

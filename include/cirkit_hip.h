@@ -54,6 +54,8 @@ typedef enum ck_status {
 #define CK_UNARY_EXP 2
 #define CK_UNARY_LOG 3
 #define CK_UNARY_SQUARE 4
+#define CK_UNARY_CLAMP 5    /* min(max(x, a), b), a / b = -inf / +inf when absent ; TorchClampParameter nodes.py:702-728 */
+#define CK_UNARY_SOFTPLUS 6 /* log(1 + exp(x)), x above 20 as it is ; TorchSoftplusParameter nodes.py:731-739 */
 
 const char* ck_last_error(void);
 /* ABI version; bumped on any signature change. */
@@ -491,7 +493,7 @@ int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, con
 int ck_param_gaussian_product_logz_bwd(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
                                        const float* dout, float* dmean1, float* dstddev1, float* dmean2, float* dstddev2, int64_t F,
                                        int K1, int K2, void* stream);
-/* entrywise ops (nodes.py:656-699); a, b only used by CK_UNARY_SCALED_SIGMOID (vmin, vmax). */
+/* entrywise ops (nodes.py:656-739); a, b only used by CK_UNARY_SCALED_SIGMOID and CK_UNARY_CLAMP (vmin, vmax). */
 int ck_param_unary(int op, const float* in, float* out, int64_t n, float a, float b, void* stream);
 /* out[f] = in[idx[f]] over blocks of `per_fold` 4-byte words (pointer fold_idx nodes.py:277-279,
  * parameter address-book gathers parameter.py:41-47). */
@@ -587,7 +589,8 @@ int ck_param_scaled_sigmoid_bwd(const float* y, const float* dy, float* dx, int6
                                 int accumulate, void* stream);
 /* softmax / log-softmax backward along any axis: tensors viewed as (outer, len, inner), y = the node's output
  * (TorchSoftmaxParameter / TorchLogSoftmaxParameter for any `dim`, nodes.py:764-783); entrywise nodes from input x and output y
- * (CK_UNARY_SIGMOID / EXP / LOG / SQUARE, nodes.py:656-699). */
+ * (CK_UNARY_SIGMOID / EXP / LOG / SQUARE / CLAMP / SOFTPLUS, nodes.py:656-739; clamp: the gradient passes where y == x, as
+ * torch.clamp's backward does inside [vmin, vmax]; softplus: sigmoid(x)). */
 int ck_param_softmax_bwd_strided(const float* y, const float* dy, float* dx, int64_t outer, int len, int64_t inner, int log_space,
                                  int accumulate, void* stream);
 int ck_param_unary_bwd(int op, const float* x, const float* y, const float* dy, float* dx, int64_t n, int accumulate, void* stream);
@@ -988,7 +991,10 @@ int ck_program_set_input(ck_program* prog, int index, const void* ptr);
  *   by 2^table_e[f, c] (largest |re|, |im| in [0.5, 1)); row C = the sum over the categories (what a negative
  *   category selects; the reference's Embedding layer has no integral and the host API refuses marginalisation through it).
  * ck_clin_leaf_fwd: `depth` (1..4) CP-T levels over the table in one launch.  xt (D, B) int32 staged categories (negative:
- *   row C), leaf_fold / leaf_var (R, 2^depth) the Embedding fold and variable of every leaf in walk order, wnode
+ *   row C) -- or xt NULL and the caller's (B, n_vars) int64 batch itself, as ck_leaf_walk_fwd takes it: x_rows, or x_input >= 0
+ *   = the program input cell that holds its pointer at replay (ck_program_set_input); the launch then validates it: a category
+ *   >= C makes its ROW NaN and raises *bad_flag (bad_flag NULL: clamped silently), i.e. x.long() + the index check of
+ *   layers/input.py:258-266 without a staged copy.  leaf_fold / leaf_var (R, 2^depth) the Embedding fold and variable of every leaf in walk order, wnode
  *   (R, 2^depth - 1) DEVICE array of weight-matrix addresses (32, 32) fp32 or complex64 row-major in the order the depth-first
  *   walk contracts them (after leaf i: levels 1 .. number of trailing one bits of i); out (R, tiles, 2048), out_e (R, tiles 32).
  * ck_clin_layer_fwd: one layer of F folds, H children each at float offset child_off[f, h] (tile 0 of the child fold's
@@ -1007,9 +1013,9 @@ typedef struct ck_clin_tail_fold {
 int ck_clin_tail_fwd(float* lin, int32_t* lin_e, const void* folds, const int32_t* level_off, int n_levels, int w_is_complex, int B,
                      void* stream);
 int ck_clin_table(const float* w, int w_is_complex, float* table, int32_t* table_e, int F, int C, void* stream);
-int ck_clin_leaf_fwd(const float* table, const int32_t* table_e, const int32_t* xt, const int32_t* leaf_fold, const int32_t* leaf_var,
-                     const float* const* wnode, int w_is_complex, int table_is_complex, float* out, int32_t* out_e, int R, int depth,
-                     int B, int C, void* stream);
+int ck_clin_leaf_fwd(const float* table, const int32_t* table_e, const int32_t* xt, const int64_t* x_rows, int x_input, int n_vars,
+                     int32_t* bad_flag, const int32_t* leaf_fold, const int32_t* leaf_var, const float* const* wnode, int w_is_complex,
+                     int table_is_complex, float* out, int32_t* out_e, int R, int depth, int B, int C, void* stream);
 int ck_clin_layer_fwd(const float* lin, const int32_t* lin_e, const int64_t* child_off, const int64_t* child_eoff, const float* const* w,
                       int w_is_complex, float* out, int32_t* out_e, float* out_log, int F, int H, int Ko, int B, void* stream);
 

@@ -181,6 +181,10 @@ def eval_param(pg: ParamGraph, tensors: Mapping[str, Tensor]) -> Tensor:
             y = torch.log(xs[0])
         elif n.op == "square":
             y = torch.square(xs[0])
+        elif n.op == "clamp":  # nodes.py:727-728
+            y = torch.clamp(xs[0], min=c.get("vmin"), max=c.get("vmax"))
+        elif n.op == "softplus":  # nodes.py:738-739
+            y = torch.nn.functional.softplus(xs[0])
         elif n.op == "conj":  # nodes.py:745-746
             y = torch.conj(xs[0])
         elif n.op == "mixing_weight":  # nodes.py:857-862

@@ -440,7 +440,14 @@ def grads_param_nodes():
         for name, wpar in [
             ("quadtree_4x4_softmax0_k4", Parameterization(activation="softmax", initialization="normal", activation_kwargs={"axis": 0})),
             ("quadtree_4x4_sigmoid_k4", Parameterization(activation="sigmoid", initialization="normal")),
+            # round 6: the two remaining activations of templates/utils.py name_to_parameter_activation (:189-194):
+            # TorchSoftplusParameter (nodes.py:731-739) and TorchClampParameter with vmin = 1e-18 (nodes.py:702-728) -- with the
+            # closed-form pseudo-normal parameters about half the entries sit ON the clamp, where the gradient is zero
+            ("quadtree_4x4_softplus_k4", Parameterization(activation="softplus", initialization="normal")),
+            ("quadtree_4x4_posclamp_k4", Parameterization(activation="positive-clamp", initialization="normal")),
         ]:
+            if os.environ.get("ONLY_NEW") and os.path.exists(os.path.join(HERE, name + "_grads.npz")):
+                continue
             sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", input_layer="categorical", num_input_units=4,
                                             sum_product_layer="cp", num_sum_units=4, sum_weight_param=wpar)
             cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)

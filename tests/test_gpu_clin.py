@@ -60,6 +60,41 @@ def test_config5_on_linear_tiles_matches_the_reference(hip_device, depth, monkey
     assert mine <= 4.0 * ref + 1e-6 * float(y64.real.abs().max()), (mine, ref)
 
 
+def test_leaf_launch_reads_and_validates_the_raw_batch(hip_device, monkeypatch):
+    """The leaf launch takes the caller's (B, D) int64 tensor itself (`ck_clin_leaf_fwd` with x_input): no staged copy, no
+    poison launch -- the same bits as over the staged batch; a category outside the Embedding layer's range (what
+    TorchEmbeddingLayer's indexing raises for, layers/input.py:258-266) makes ITS row NaN, leaves the others alone and raises the
+    flag `check_inputs()` turns into IndexError; batches rotate without re-recording."""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case("cfg5_sos_c_k32")
+    gen = torch.Generator().manual_seed(12)
+    xa = torch.randint(0, 256, (200, plan.num_variables), generator=gen).to(hip_device)
+    xb = torch.randint(0, 256, (200, plan.num_variables), generator=gen).to(hip_device)
+    a = HipCircuit(plan, tensors, device=hip_device, signed_real=False)
+    monkeypatch.setenv("CK_CLIN_STAGED", "1")
+    b = HipCircuit(plan, tensors, device=hip_device, signed_real=False)
+    assert a._bind(200).direct and not b._bind(200).direct
+    assert a.num_launches(200) == b.num_launches(200) - 2  # (no staging launch, no poison launch)
+    for x in (xa, xb, xa):
+        ya, yb = a(x).cpu(), b(x).cpu()
+        assert torch.equal(ya.real, yb.real) and torch.equal(ya.imag, yb.imag)
+    a.check_inputs()
+    bad = xa.clone()
+    bad[7, 300] = 256
+    bad[150, 2] = 1 << 40
+    y = a(bad).cpu()
+    nan_rows = torch.isnan(y.real.reshape(200, -1)).any(dim=1)
+    assert nan_rows.nonzero().reshape(-1).tolist() == [7, 150]
+    ok = ~nan_rows
+    assert torch.equal(y.real.reshape(200, -1)[ok], a(xa).cpu().real.reshape(200, -1)[ok])
+    with pytest.raises(IndexError):
+        a.check_inputs()
+    a.check_inputs()  # (the flag was consumed)
+    quiet = HipCircuit(plan, tensors, device=hip_device, signed_real=False, validate_inputs=False)
+    assert bool(torch.isfinite(quiet(bad).real).all())  # (clamped to the last category, silently)
+
+
 @pytest.mark.parametrize("complex_sums", [False, True])
 def test_tail_launch_is_bit_identical_to_the_layer_launches(hip_device, complex_sums, monkeypatch):
     """The few-fold top of the circuit in one launch (`ck_clin_tail_fwd`: a workgroup per 32-row tile walks the layers) against

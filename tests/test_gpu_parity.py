@@ -125,6 +125,24 @@ def test_real_configs_match_reference(hip_device, name, use_graph, fuse):
     _check_layers(plan, tensors, x, hc)
 
 
+@pytest.mark.parametrize("name", ["quadtree_4x4_softmax0_k4", "quadtree_4x4_sigmoid_k4", "quadtree_4x4_softplus_k4", "quadtree_4x4_posclamp_k4"])
+def test_sum_weight_activations_match_reference(hip_device, name):
+    """Sum weights behind the other activations templates/utils.py:185-194 names -- softmax along the output units, sigmoid, softplus,
+    positive-clamp (TorchSoftmaxParameter / TorchSigmoidParameter / TorchSoftplusParameter / TorchClampParameter, nodes.py:656-772):
+    the reference's committed outputs and every layer against the oracle.  (Four units: padded to 32 where the activation has a
+    zero pre-image -- not under the positive clamp, whose circuit runs on the shape-generic kernels.)"""
+    from cirkit_amd.circuit import HipCircuit
+
+    plan, tensors, g = load_case(name)
+    x = _x_of(plan, g)
+    hc = HipCircuit(plan, tensors, device=hip_device)
+    y = hc(x.to(hip_device)).cpu()
+    for key in ("y_f32", "y_f64"):
+        ref = torch.from_numpy(g[key]).double()
+        assert float(((y.double() - ref).abs() / ref.abs().clamp_min(1e-30)).max()) <= REL, key
+    _check_layers(plan, tensors, x, hc)
+
+
 @pytest.mark.parametrize("fuse", [1, 2, 3])
 def test_leaf_fusion_capped_at_fewer_levels(hip_device, fuse):
     """`HipCircuit(fuse=n)`: the leaf region fused over n CP-T levels only (the levels above run layer by layer) -- BASELINE

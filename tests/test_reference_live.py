@@ -56,6 +56,27 @@ def test_plan_and_forward_match_the_live_reference(shape, rg, inp, sp, k, ncls, 
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("activation,native", [("softplus", "softplus"), ("positive-clamp", "positive-clamp"), ("sigmoid", "sigmoid")])
+def test_sum_weight_activations_match_the_live_reference(activation, native):
+    """The sum-weight activations templates/utils.py name_to_parameter_activation names beside softmax (:185-194): the natively
+    built plan is the reference's (TorchSoftplusParameter / TorchClampParameter with vmin = 1e-18 / TorchSigmoidParameter nodes)
+    and the oracle reproduces the reference's forward bit for bit."""
+    from cirkit.templates.utils import Parameterization
+
+    torch.manual_seed(0)
+    sc = data_modalities.image_data((1, 4, 4), "quad-tree-2", input_layer="categorical", num_input_units=3, sum_product_layer="cp",
+                                    num_sum_units=3, sum_weight_param=Parameterization(activation=activation, initialization="normal"))
+    cc = PipelineContext(backend="torch", semiring="lse-sum", fold=True, optimize=True).compile(sc)
+    plan, tensors = plan_from_torch_circuit(cc)
+    _assert_same_plan(image_data((1, 4, 4), "quad-tree-2", input_layer="categorical", num_input_units=3, sum_product_layer="cp",
+                                 num_sum_units=3, sum_weight_activation=native), plan)
+    x = torch.randint(0, 256, (6, 16), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want = cc(x)
+        got = evaluate_plan(plan, {n: t.detach() for n, t in tensors.items()}, x)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("inp", ["categorical", "gaussian"])
 def test_squared_partition_function_matches_the_live_reference(inp):
     torch.manual_seed(0)
