@@ -543,8 +543,11 @@ class HipCircuit(_LaunchMixin, _ProfilingMixin):
         """Whether a forward at batch size B needs no staged copy of the discrete batch: its only readers are persistent
         leaf launches, which then read -- and validate -- the caller's int64 tensor (`ck_leaf_walk_fwd` with x_input).
         Byte offsets into the batch are 32-bit."""
-        if self._clin is not None:  # (the leaf launch of the linear-tile path reads and validates the int64 batch itself)
-            return bool(self.direct_input and self._int_input and os.environ.get("CK_CLIN_STAGED", "0") != "1")
+        if self._clin is not None:
+            # (the leaf launch of the linear-tile path CAN read and validate the int64 batch itself -- `CK_CLIN_RAW=1` when the
+            #  circuit is built -- but its 8-byte row gathers cost the launch more than the staging + poison launches they save:
+            #  0.248 against 0.240 ms at config 5, LAB_NOTES R6.1; the staged (D, B) copy is the default)
+            return bool(self.direct_input and self._int_input and self._clin.raw_batch)
         if not (self.direct_input and self._int_input and self._groups):
             return False
         if self.plan.num_variables * B * 8 >= 2**32:

@@ -122,6 +122,7 @@ class ClinPath:
             for l in range(_steps_after(i)):
                 self._node_fold.append((g.levels[l], tabs[l + 1][:, i >> (l + 1)]))
         self.R, self.D = R, D
+        self.raw_batch = os.environ.get("CK_CLIN_RAW", "0") == "1"  # (lab switch: the leaf launch reads the caller's int64 batch)
         # the few-fold top of the circuit: ONE launch (ck_clin_tail_fwd) instead of one per layer -- the trailing layers with at
         # most 64 folds in all, one kind of weights, at most two children per fold
         self.tail: list[int] = []

@@ -61,8 +61,8 @@ def test_config5_on_linear_tiles_matches_the_reference(hip_device, depth, monkey
 
 
 def test_leaf_launch_reads_and_validates_the_raw_batch(hip_device, monkeypatch):
-    """The leaf launch takes the caller's (B, D) int64 tensor itself (`ck_clin_leaf_fwd` with x_input): no staged copy, no
-    poison launch -- the same bits as over the staged batch; a category outside the Embedding layer's range (what
+    """The leaf launch can take the caller's (B, D) int64 tensor itself (`ck_clin_leaf_fwd` with x_input; `CK_CLIN_RAW=1`: measured
+    slower than the staged copy, which stays the default): no staged copy, no poison launch -- the same bits as over the staged batch; a category outside the Embedding layer's range (what
     TorchEmbeddingLayer's indexing raises for, layers/input.py:258-266) makes ITS row NaN, leaves the others alone and raises the
     flag `check_inputs()` turns into IndexError; batches rotate without re-recording."""
     from cirkit_amd.circuit import HipCircuit
@@ -71,9 +71,9 @@ def test_leaf_launch_reads_and_validates_the_raw_batch(hip_device, monkeypatch):
     gen = torch.Generator().manual_seed(12)
     xa = torch.randint(0, 256, (200, plan.num_variables), generator=gen).to(hip_device)
     xb = torch.randint(0, 256, (200, plan.num_variables), generator=gen).to(hip_device)
+    b = HipCircuit(plan, tensors, device=hip_device, signed_real=False)  # (the default: a staged (D, B) int32 copy)
+    monkeypatch.setenv("CK_CLIN_RAW", "1")
     a = HipCircuit(plan, tensors, device=hip_device, signed_real=False)
-    monkeypatch.setenv("CK_CLIN_STAGED", "1")
-    b = HipCircuit(plan, tensors, device=hip_device, signed_real=False)
     assert a._bind(200).direct and not b._bind(200).direct
     assert a.num_launches(200) == b.num_launches(200) - 2  # (no staging launch, no poison launch)
     for x in (xa, xb, xa):
@@ -91,7 +91,7 @@ def test_leaf_launch_reads_and_validates_the_raw_batch(hip_device, monkeypatch):
     with pytest.raises(IndexError):
         a.check_inputs()
     a.check_inputs()  # (the flag was consumed)
-    quiet = HipCircuit(plan, tensors, device=hip_device, signed_real=False, validate_inputs=False)
+    quiet = HipCircuit(plan, tensors, device=hip_device, signed_real=False, validate_inputs=False)  # (built under CK_CLIN_RAW=1)
     assert bool(torch.isfinite(quiet(bad).real).all())  # (clamped to the last category, silently)
 
 
