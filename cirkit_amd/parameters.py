@@ -166,6 +166,35 @@ class ParamBatch:
         capi.call("ck_param_softmax_batch", self._arr, len(self._jobs), stream)
 
 
+def _node_as_einsum(op: str, config: Mapping[str, Any], shapes: list[tuple[int, ...]]) -> tuple[tuple, tuple[int, ...]]:
+    """Product-type parameter nodes as the einsum they are: (index tuples of the operands then of the output, the output's shape
+    BEFORE the node's reshape).  hadamard (nodes.py:510-528): the same indices everywhere; kronecker (nodes.py:531-550, torch.kron
+    per fold): out[(a_0, b_0), (a_1, b_1), ...] = x1[a...] x2[b...]; outer_product along `dim` (nodes.py:553-612):
+    out[..., (i1, i2), ...] = x1[..., i1, ...] x2[..., i2, ...]; reduce_sum along `dim` (nodes.py:749-751)."""
+    n = len(shapes[0])
+    if op == "hadamard":
+        idx = tuple(range(n))
+        return (idx, idx, idx), tuple(shapes[0])
+    if op == "kronecker":
+        a, b = tuple(range(0, 2 * n, 2)), tuple(range(1, 2 * n, 2))
+        out = tuple(range(2 * n))
+        return (a, b, out), tuple(d for pair in zip(shapes[0], shapes[1]) for d in pair)
+    d = int(config.get("dim", -1))
+    d = d if d >= 0 else d + n
+    if op == "outer_product":
+        a = tuple(range(n))
+        b = tuple(n if i == d else i for i in range(n))
+        out = tuple(a[:d]) + (d, n) + tuple(a[d + 1:])
+        return (a, b, out), tuple(shapes[0][:d]) + (shapes[0][d], shapes[1][d]) + tuple(shapes[0][d + 1:])
+    if op == "reduce_sum":
+        a = tuple(range(n))
+        return (a, tuple(i for i in a if i != d)), tuple(s for i, s in enumerate(shapes[0]) if i != d)
+    raise NotImplementedError(op)
+
+
+_EINSUM_NODES = ("hadamard", "kronecker", "outer_product", "reduce_sum")
+
+
 def _einsum_as_bmm(einsum, shapes):
     """Map a two-operand einsum over per-fold matrices onto ck_param_bmm; returns
     (swap, M, N, Kd, trans_a, trans_b) or None."""
@@ -363,6 +392,16 @@ class HipParameter:
                     capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(y), a.shape[0], M, N, Kd, ta, tb, 0, stream)
             elif n.op == "flatten":  # nodes.py:843-844
                 y = xs[0].reshape(shape)
+            elif n.op in _EINSUM_NODES:  # nodes.py:510-612, 749-751: products and sums over indices -- the generic einsum launch
+                spec, _ = _node_as_einsum(n.op, c, [tuple(x.shape[1:]) for x in xs])
+                y = self._einsum(j, spec, [x.contiguous() for x in xs], stream).reshape(shape)
+            elif n.op == "sum":  # nodes.py:491-507: x1 + x2
+                a, b = xs
+                if a.is_complex() or b.is_complex():
+                    raise NotImplementedError("sum of complex parameters")
+                y = self._buf(j, shape)
+                capi.call("ck_copy_strided_f32", _ptr(a.contiguous()), _ptr(y), y.numel(), 1, 1, stream)
+                capi.call("ck_axpy_f32", _ptr(y), _ptr(b.contiguous()), 1.0, y.numel(), stream)
             elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
                 m1, s1, m2, s2 = (x.contiguous() for x in xs)
                 F, K1, K2 = m1.shape[0], m1.shape[1], m2.shape[1]
@@ -588,16 +627,34 @@ class HipParameter:
                 scatter((j, 0), n.inputs[0], dj)
             elif n.op == "flatten":  # nodes.py:843-844
                 scatter((j, 0), n.inputs[0], dj.reshape(operand(j, 0).shape))
-            elif n.op == "einsum":  # y = sum over the contracted indices of prod_k x_k: d x_k = the same sum with y's gradient in x_k's place
+            elif n.op == "sum":  # nodes.py:491-507
+                scatter((j, 0), n.inputs[0], dj)
+                scatter((j, 1), n.inputs[1], dj)
+            elif n.op == "reduce_sum":  # nodes.py:749-751: the gradient is the output's, repeated along the summed axis
+                x = operand(j, 0)
+                if dj.is_complex() or x.is_complex():
+                    raise NotImplementedError("parameter backward through a sum over complex entries")
+                (a_idx, o_idx), _ = _node_as_einsum("reduce_sum", n.config, [tuple(x.shape[1:])])
+                d = next(i for i in a_idx if i not in o_idx)
+                ones = self._buf(("ones", j), (x.shape[0], x.shape[1 + d]))
+                capi.call("ck_fill_f32", _ptr(ones), ones.numel(), 1.0, stream)
+                dx = self._einsum(("ge", j, 0), (o_idx, (d,), a_idx), [dj.contiguous(), ones], stream)
+                scatter((j, 0), n.inputs[0], dx)
+            elif n.op == "einsum" or n.op in _EINSUM_NODES:  # y = sum over the contracted indices of prod_k x_k: d x_k = the same sum with y's gradient in x_k's place
                 xs = [operand(j, k) for k in range(len(n.inputs))]
                 if dj.is_complex() or any(x.is_complex() for x in xs):
                     raise NotImplementedError("parameter backward through an einsum over complex operands")
-                *ins, out_idx = [tuple(int(i) for i in e) for e in n.config["einsum"]]
+                if n.op == "einsum":
+                    spec_all = n.config["einsum"]
+                else:  # (the node's output is a reshape of the einsum's: its gradient back in the einsum's shape)
+                    spec_all, eshape = _node_as_einsum(n.op, n.config, [tuple(x.shape[1:]) for x in xs])
+                    dj = dj.contiguous().reshape(dj.shape[0], *eshape)
+                *ins, out_idx = [tuple(int(i) for i in e) for e in spec_all]
                 for k in range(len(xs)):
                     others = [m for m in range(len(xs)) if m != k]
                     have = set(out_idx) | {i for m in others for i in ins[m]}
                     if not set(ins[k]) <= have or len(set(ins[k])) != len(ins[k]):
-                        raise NotImplementedError(f"parameter backward through einsum {n.config['einsum']}: operand {k} carries an index "
+                        raise NotImplementedError(f"parameter backward through einsum {spec_all}: operand {k} carries an index "
                                                   "that is summed out on its own or repeated")
                     spec = [out_idx, *[ins[m] for m in others], ins[k]]
                     ops_k = [dj.contiguous(), *[xs[m] for m in others]]

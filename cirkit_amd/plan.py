@@ -58,6 +58,11 @@ PARAM_OPS = {
     "TorchLogParameter": "log",
     "TorchSquareParameter": "square",
     "TorchClampParameter": "clamp",
+    "TorchSumParameter": "sum",
+    "TorchHadamardParameter": "hadamard",
+    "TorchKroneckerParameter": "kronecker",
+    "TorchOuterProductParameter": "outer_product",
+    "TorchReduceSumParameter": "reduce_sum",
     "TorchSoftplusParameter": "softplus",
     "TorchConjugateParameter": "conj",
     "TorchMixingWeightParameter": "mixing_weight",

@@ -181,6 +181,17 @@ def eval_param(pg: ParamGraph, tensors: Mapping[str, Tensor]) -> Tensor:
             y = torch.log(xs[0])
         elif n.op == "square":
             y = torch.square(xs[0])
+        elif n.op == "sum":  # nodes.py:506-507
+            y = xs[0] + xs[1]
+        elif n.op == "hadamard":  # nodes.py:527-528
+            y = xs[0] * xs[1]
+        elif n.op == "kronecker":  # nodes.py:549-550
+            y = torch.vmap(torch.kron)(xs[0], xs[1])
+        elif n.op == "outer_product":  # nodes.py:604-612
+            d = c["dim"]
+            y = (xs[0].unsqueeze(d + 2) * xs[1].unsqueeze(d + 1)).reshape(n.num_folds, *n.shape)
+        elif n.op == "reduce_sum":  # nodes.py:750-751
+            y = torch.sum(xs[0], dim=c["dim"] + 1)
         elif n.op == "clamp":  # nodes.py:727-728
             y = torch.clamp(xs[0], min=c.get("vmin"), max=c.get("vmax"))
         elif n.op == "softplus":  # nodes.py:738-739

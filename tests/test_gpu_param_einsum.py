@@ -68,3 +68,50 @@ def test_complex_matmul_parameter(hip_device):
     torch.cuda.synchronize()
     want = torch.matmul(a.to(torch.complex128), b.to(torch.complex128))
     assert float((y.cpu().to(torch.complex128) - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("op,config,shapes,out_shape", [
+    ("hadamard", {}, [(3, 5), (3, 5)], (3, 5)),                                  # nodes.py:510-528
+    ("kronecker", {}, [(2, 3), (4, 5)], (8, 15)),                                # nodes.py:531-550 (torch.kron per fold)
+    ("kronecker", {}, [(3,), (4,)], (12,)),
+    ("outer_product", {"dim": 1}, [(3, 2), (3, 4)], (3, 8)),                     # nodes.py:553-612
+    ("outer_product", {"dim": 0}, [(2, 5), (3, 5)], (6, 5)),
+    ("reduce_sum", {"dim": 1}, [(3, 6)], (3,)),                                  # nodes.py:749-751
+    ("reduce_sum", {"dim": 0}, [(4, 2, 3)], (2, 3)),
+    ("sum", {}, [(4, 3), (4, 3)], (4, 3)),                                       # nodes.py:491-507
+    ("clamp", {"vmin": -0.3, "vmax": 0.4}, [(5, 7)], (5, 7)),                    # nodes.py:702-728
+    ("clamp", {"vmin": 1e-18}, [(5, 7)], (5, 7)),
+    ("softplus", {}, [(5, 7)], (5, 7)),                                          # nodes.py:731-739
+])
+def test_product_sum_and_entrywise_parameter_nodes(hip_device, op, config, shapes, out_shape):
+    """The parameter nodes of nodes.py:491-612, 702-751 beside einsum / matmul -- what products of circuits and the clamp / softplus
+    activations compile to -- forward against the reference's own formula (the oracle's `eval_param`, fp64) and reverse mode
+    (`HipParameter.backward`) against torch autograd through it."""
+    from cirkit_amd.plan import ParamGraph as PG
+    from oracle.torch_oracle import eval_param
+
+    g = torch.Generator().manual_seed(len(op) * 5 + len(shapes))
+    F = 3
+    store = TensorStore(hip_device)
+    p, vals = _graph(store, shapes, "r" * len(shapes), op, config, out_shape, F, g)
+    if op == "softplus":  # (both sides of the threshold of 20)
+        vals[0][0, 0, :3] = torch.tensor([25.0, -30.0, 19.5])
+        store.set("t0", vals[0])
+    stream = torch.cuda.current_stream(hip_device).cuda_stream
+    y = p.evaluate(stream)
+    leaves = {f"t{i}": v.double().requires_grad_(True) for i, v in enumerate(vals)}
+    torch.set_default_dtype(torch.float64)
+    try:
+        want = eval_param(p.graph, leaves)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(want.shape) == (F, *out_shape)
+    assert float((y.cpu().double() - want.detach()).abs().max()) <= 2e-6 * (float(want.abs().max()) + 1.0)
+    dout = torch.randn(want.shape, generator=g)
+    want.backward(dout.double())
+    grads = {k: torch.zeros_like(store[k]) for k in leaves}
+    p.backward(dout.to(hip_device), grads, stream)
+    torch.cuda.synchronize()
+    for k, v in leaves.items():
+        assert float((grads[k].cpu().double() - v.grad).abs().max()) <= 2e-6 * (float(v.grad.abs().max()) + 1.0), (op, k)

@@ -113,3 +113,35 @@ def test_complex_squared_circuit_matches_the_live_reference():
         want = zc().reshape(-1)[0]
         got = evaluate_plan(squared_partition_plan(plan), tens, None).reshape(-1)[0]
     assert abs(float(got.real) - float(want.real)) <= 1e-5 * abs(float(want.real))
+
+
+@pytest.mark.parametrize("cls,kwargs,shapes,op,config", [
+    ("TorchHadamardParameter", {}, [(3, 5), (3, 5)], "hadamard", {}),
+    ("TorchKroneckerParameter", {}, [(2, 3), (4, 5)], "kronecker", {}),
+    ("TorchOuterProductParameter", {"dim": 1}, [(3, 2), (3, 4)], "outer_product", {"dim": 1}),
+    ("TorchReduceSumParameter", {"dim": 0}, [(4, 2, 3)], "reduce_sum", {"dim": 0}),
+    ("TorchSumParameter", {}, [(4, 3), (4, 3)], "sum", {}),
+    ("TorchClampParameter", {"vmin": 1e-18}, [(5, 7)], "clamp", {"vmin": 1e-18}),
+    ("TorchClampParameter", {"vmin": -0.3, "vmax": 0.4}, [(5, 7)], "clamp", {"vmin": -0.3, "vmax": 0.4}),
+    ("TorchSoftplusParameter", {}, [(5, 7)], "softplus", {}),
+])
+def test_oracle_parameter_nodes_equal_the_reference_modules(cls, kwargs, shapes, op, config):
+    """The oracle's restatement of the parameter nodes added in round 6 (nodes.py:491-612, 702-751) against the reference's own
+    modules on the same operands: bit for bit, and the plan extraction maps each class to its op."""
+    from cirkit.backend.torch.parameters import nodes as ref_nodes
+
+    from cirkit_amd.plan import IDX_NONE, PARAM_OPS, FoldIndex, ParamGraph, ParamNode
+    from oracle.torch_oracle import eval_param
+
+    assert PARAM_OPS[cls] == op
+    F = 3
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn((F, *s), generator=g) for s in shapes]
+    mod = getattr(ref_nodes, cls)(*shapes, num_folds=F, **kwargs)
+    with torch.no_grad():
+        want = mod(*xs)
+    nodes = [ParamNode("tensor", F, tuple(s), {"tensor": f"t{i}"}, []) for i, s in enumerate(shapes)]
+    nodes.append(ParamNode(op, F, tuple(mod.shape), dict(config), [FoldIndex([i], IDX_NONE) for i in range(len(shapes))]))
+    pg = ParamGraph(nodes, FoldIndex([len(nodes) - 1], IDX_NONE), F, tuple(mod.shape))
+    got = eval_param(pg, {f"t{i}": x for i, x in enumerate(xs)})
+    assert got.shape == want.shape and torch.equal(got, want)
