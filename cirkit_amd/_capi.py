@@ -177,6 +177,10 @@ GAUSS_JOB_DTYPE = [("mean", "<u8"), ("stddev", "<u8"), ("x", "<u8"), ("dmean", "
 # name -> argtypes (restype is always int unless listed in _RESTYPES)
 SIGNATURES: dict[str, list[Any]] = {
     "ck_abi_version": [],
+    "ck_param_reduce": [_i, _p, _p, _l, _i, _l, _p],
+    "ck_param_reduce_bwd": [_i, _p, _p, _p, _p, _l, _i, _l, _p],
+    "ck_param_outer_sum": [_p, _p, _p, _l, _i, _i, _l, _p],
+    "ck_param_outer_sum_bwd": [_p, _p, _l, _i, _i, _l, _i, _p],
     "ck_clin_table": [_p, _i, _p, _p, _i, _i, _p],
     "ck_clin_tail_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "ck_clin_leaf_fwd": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p],

@@ -36,6 +36,82 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// TorchReduceProductParameter / TorchReduceLSEParameter (nodes.py:754-761) along one axis of a tensor viewed (outer, len, inner):
+// a thread per (outer, inner) pair.  BWD: dx = dy y / x (product; an entry that is 0 takes the product of the others) and
+// dx = dy exp(x - y) (log-sum-exp).  TorchOuterSumParameter (nodes.py:615-653): out[o, i1 * n2 + i2, r] = a[o, i1, r] + b[o, i2, r].
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+    reduce_axis_kernel(int op, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ out,
+                       int64_t outer, int len, int64_t inner) {
+  const int64_t t = blockIdx.x * static_cast<int64_t>(256) + threadIdx.x;
+  if (t >= outer * inner) return;
+  const int64_t o = t / inner, r = t - o * inner;
+  const float* src = x + o * len * inner + r;
+  if constexpr (!BWD) {
+    if (op == 0) {
+      float p = 1.f;
+      for (int j = 0; j < len; ++j) p *= src[j * inner];
+      out[t] = p;
+    } else {
+      float m = -INFINITY;
+      for (int j = 0; j < len; ++j) m = fmaxf(m, src[j * inner]);
+      if (!(fabsf(m) < INFINITY)) {  // (all -inf: -inf; an +inf entry: +inf -- torch.logsumexp)
+        out[t] = m;
+        return;
+      }
+      float sum = 0.f;
+      for (int j = 0; j < len; ++j) sum += expf(src[j * inner] - m);
+      out[t] = m + logf(sum);
+    }
+  } else {
+    float* dst = out + o * len * inner + r;
+    const float g = dy[t], yy = y[t];
+    for (int j = 0; j < len; ++j) {
+      float d;
+      if (op == 0) {
+        const float xv = src[j * inner];
+        if (xv != 0.f) {
+          d = yy / xv;
+        } else {  // (the product of the other entries)
+          d = 1.f;
+          for (int k = 0; k < len; ++k)
+            if (k != j) d *= src[k * inner];
+        }
+      } else {
+        d = fabsf(yy) < INFINITY ? expf(src[j * inner] - yy) : 0.f;
+      }
+      dst[j * inner] = g == 0.f ? 0.f : g * d;
+    }
+  }
+}
+__global__ void __launch_bounds__(256)
+    outer_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t outer, int n1, int n2, int64_t inner) {
+  const int64_t t = blockIdx.x * static_cast<int64_t>(256) + threadIdx.x;
+  if (t >= outer * n1 * n2 * inner) return;
+  const int64_t r = t % inner, q = t / inner;
+  const int i2 = static_cast<int>(q % n2);
+  const int64_t q2 = q / n2;
+  const int i1 = static_cast<int>(q2 % n1);
+  const int64_t o = q2 / n1;
+  out[t] = a[(o * n1 + i1) * inner + r] + b[(o * n2 + i2) * inner + r];
+}
+// its backward: da[o, i1, r] = sum over i2 of dout[o, i1, i2, r] (which = 0) / db[o, i2, r] = sum over i1 (which = 1)
+__global__ void __launch_bounds__(256)
+    outer_sum_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int64_t outer, int n1, int n2, int64_t inner, int which) {
+  const int n_keep = which == 0 ? n1 : n2, n_red = which == 0 ? n2 : n1;
+  const int64_t t = blockIdx.x * static_cast<int64_t>(256) + threadIdx.x;
+  if (t >= outer * n_keep * inner) return;
+  const int64_t r = t % inner, q = t / inner;
+  const int ik = static_cast<int>(q % n_keep);
+  const int64_t o = q / n_keep;
+  float acc = 0.f;
+  for (int j = 0; j < n_red; ++j) {
+    const int i1 = which == 0 ? ik : j, i2 = which == 0 ? j : ik;
+    acc += dout[((o * n1 + i1) * n2 + i2) * inner + r];
+  }
+  dx[t] = acc;
+}
+
 __global__ void __launch_bounds__(256)
     softmax_strided_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t outer,
                            int len, int64_t inner, int log_space) {
@@ -1172,6 +1248,55 @@ int launch_long_rows(const ck_softmax_job& j, void* stream) {
 }  // namespace
 
 extern "C" {
+
+int ck_param_reduce(int op, const float* x, float* y, int64_t outer, int len, int64_t inner, void* stream) {
+  CK_REQUIRE(x && y && outer > 0 && len > 0 && inner > 0, "ck_param_reduce: bad arguments");
+  CK_REQUIRE(op == 0 || op == 1, "ck_param_reduce: op %d (0 product, 1 log-sum-exp)", op);
+  dim3 grid(static_cast<unsigned>((outer * inner + 255) / 256)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(reduce_axis_kernel<false>, grid, block, 0, s, op, x, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), y,
+                           outer, len, inner);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_reduce_bwd(int op, const float* x, const float* y, const float* dy, float* dx, int64_t outer, int len, int64_t inner, void* stream) {
+  CK_REQUIRE(x && y && dy && dx && outer > 0 && len > 0 && inner > 0, "ck_param_reduce_bwd: bad arguments");
+  CK_REQUIRE(op == 0 || op == 1, "ck_param_reduce_bwd: op %d (0 product, 1 log-sum-exp)", op);
+  dim3 grid(static_cast<unsigned>((outer * inner + 255) / 256)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(reduce_axis_kernel<true>, grid, block, 0, s, op, x, y, dy, dx, outer, len, inner);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_outer_sum(const float* a, const float* b, float* out, int64_t outer, int n1, int n2, int64_t inner, void* stream) {
+  CK_REQUIRE(a && b && out && outer > 0 && n1 > 0 && n2 > 0 && inner > 0, "ck_param_outer_sum: bad arguments");
+  const int64_t n = outer * n1 * n2 * inner;
+  dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(outer_sum_kernel, grid, block, 0, s, a, b, out, outer, n1, n2, inner);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_outer_sum_bwd(const float* dout, float* dx, int64_t outer, int n1, int n2, int64_t inner, int which, void* stream) {
+  CK_REQUIRE(dout && dx && outer > 0 && n1 > 0 && n2 > 0 && inner > 0 && (which == 0 || which == 1), "ck_param_outer_sum_bwd: bad arguments");
+  const int64_t n = outer * (which == 0 ? n1 : n2) * inner;
+  dim3 grid(static_cast<unsigned>((n + 255) / 256)), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(outer_sum_bwd_kernel, grid, block, 0, s, dout, dx, outer, n1, n2, inner, which);
+        return hipGetLastError();
+      },
+      stream);
+}
 
 int ck_param_softmax(const float* in, float* out, int64_t outer, int len, int64_t inner,
                      int log_space, void* stream) {

@@ -253,6 +253,17 @@ class HipParameter:
             self._bufs[key] = t
         return t
 
+    def _onehot(self, j: int, indices, n_in: int, F: int) -> torch.Tensor:
+        """(F, len(indices), n_in) one-hot rows: TorchIndexParameter as a product the einsum launch (and its backward) takes."""
+        key = ("onehot", j)
+        t = self._idx.get(key)
+        if t is None:
+            m = np.zeros((F, len(indices), n_in), dtype=np.float32)
+            m[:, np.arange(len(indices)), np.asarray(indices, dtype=np.int64)] = 1.0
+            t = torch.from_numpy(m).to(self.store.device)
+            self._idx[key] = t
+        return t
+
     def _index_tensor(self, key, arr: np.ndarray) -> torch.Tensor:
         t = self._idx.get(key)
         if t is None:
@@ -395,6 +406,32 @@ class HipParameter:
             elif n.op in _EINSUM_NODES:  # nodes.py:510-612, 749-751: products and sums over indices -- the generic einsum launch
                 spec, _ = _node_as_einsum(n.op, c, [tuple(x.shape[1:]) for x in xs])
                 y = self._einsum(j, spec, [x.contiguous() for x in xs], stream).reshape(shape)
+            elif n.op in ("reduce_prod", "reduce_lse"):  # nodes.py:754-761
+                x = xs[0].contiguous()
+                if x.is_complex():
+                    raise NotImplementedError(f"{n.op} of a complex parameter")
+                d = int(c.get("dim", -1))
+                d = (d if d >= 0 else d + x.dim() - 1) + 1
+                y = self._buf(j, shape)
+                capi.call("ck_param_reduce", 0 if n.op == "reduce_prod" else 1, _ptr(x), _ptr(y), int(np.prod(x.shape[:d])), int(x.shape[d]),
+                          int(np.prod(x.shape[d + 1:])), stream)
+            elif n.op == "outer_sum":  # nodes.py:615-653
+                a, b = (x.contiguous() for x in xs)
+                if a.is_complex() or b.is_complex():
+                    raise NotImplementedError("outer sum of complex parameters")
+                d = int(c.get("dim", -1))
+                d = (d if d >= 0 else d + a.dim() - 1) + 1
+                y = self._buf(j, shape)
+                capi.call("ck_param_outer_sum", _ptr(a), _ptr(b), _ptr(y), int(np.prod(a.shape[:d])), int(a.shape[d]), int(b.shape[d]),
+                          int(np.prod(a.shape[d + 1:])), stream)
+            elif n.op == "index":  # nodes.py:450-488: x[:, indices] -- the first axis of the per-fold value, as the reference's forward does
+                x = xs[0].contiguous()
+                if x.is_complex():
+                    raise NotImplementedError("index of a complex parameter")
+                sel = self._onehot(j, c["indices"], int(x.shape[1]), int(x.shape[0]))
+                rest = tuple(range(2, x.dim()))
+                spec = ((0, 1), (1, *rest), (0, *rest))
+                y = self._einsum(j, spec, [sel, x], stream)
             elif n.op == "sum":  # nodes.py:491-507: x1 + x2
                 a, b = xs
                 if a.is_complex() or b.is_complex():
@@ -630,6 +667,29 @@ class HipParameter:
             elif n.op == "sum":  # nodes.py:491-507
                 scatter((j, 0), n.inputs[0], dj)
                 scatter((j, 1), n.inputs[1], dj)
+            elif n.op in ("reduce_prod", "reduce_lse"):
+                x, y = operand(j, 0).contiguous(), value(j)
+                d = int(n.config.get("dim", -1))
+                d = (d if d >= 0 else d + x.dim() - 1) + 1
+                dx = self._buf(("gtmp", j, 0), x.shape)
+                capi.call("ck_param_reduce_bwd", 0 if n.op == "reduce_prod" else 1, _ptr(x), _ptr(y), _ptr(dj.contiguous()), _ptr(dx),
+                          int(np.prod(x.shape[:d])), int(x.shape[d]), int(np.prod(x.shape[d + 1:])), stream)
+                scatter((j, 0), n.inputs[0], dx)
+            elif n.op == "outer_sum":
+                a, b = operand(j, 0), operand(j, 1)
+                d = int(n.config.get("dim", -1))
+                d = (d if d >= 0 else d + a.dim() - 1) + 1
+                outer, inner = int(np.prod(a.shape[:d])), int(np.prod(a.shape[d + 1:]))
+                for k, x in enumerate((a, b)):
+                    dx = self._buf(("gtmp", j, k), x.shape)
+                    capi.call("ck_param_outer_sum_bwd", _ptr(dj.contiguous()), _ptr(dx), outer, int(a.shape[d]), int(b.shape[d]), inner, k, stream)
+                    scatter((j, k), n.inputs[k], dx)
+            elif n.op == "index":  # y = S x with S the one-hot selection: dx = S^T dy
+                x = operand(j, 0)
+                sel = self._onehot(j, n.config["indices"], int(x.shape[1]), int(x.shape[0]))
+                rest = tuple(range(2, x.dim()))
+                dx = self._einsum(("ge", j, 0), ((0, 1), (0, *rest), (1, *rest)), [sel, dj.contiguous()], stream)
+                scatter((j, 0), n.inputs[0], dx)
             elif n.op == "reduce_sum":  # nodes.py:749-751: the gradient is the output's, repeated along the summed axis
                 x = operand(j, 0)
                 if dj.is_complex() or x.is_complex():

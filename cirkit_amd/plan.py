@@ -63,6 +63,10 @@ PARAM_OPS = {
     "TorchKroneckerParameter": "kronecker",
     "TorchOuterProductParameter": "outer_product",
     "TorchReduceSumParameter": "reduce_sum",
+    "TorchReduceProductParameter": "reduce_prod",
+    "TorchReduceLSEParameter": "reduce_lse",
+    "TorchOuterSumParameter": "outer_sum",
+    "TorchIndexParameter": "index",
     "TorchSoftplusParameter": "softplus",
     "TorchConjugateParameter": "conj",
     "TorchMixingWeightParameter": "mixing_weight",

@@ -493,6 +493,13 @@ int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, con
 int ck_param_gaussian_product_logz_bwd(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
                                        const float* dout, float* dmean1, float* dstddev1, float* dmean2, float* dstddev2, int64_t F,
                                        int K1, int K2, void* stream);
+/* TorchReduceProductParameter / TorchReduceLSEParameter (nodes.py:754-761): op 0 = product, 1 = log-sum-exp along the middle axis
+ * of x viewed (outer, len, inner) -> y (outer, inner); _bwd: dx from x, y and dy.  TorchOuterSumParameter (nodes.py:615-653):
+ * out[o, i1 n2 + i2, r] = a[o, i1, r] + b[o, i2, r]; _bwd: the gradient of operand `which` (0: a, 1: b) from dout. */
+int ck_param_reduce(int op, const float* x, float* y, int64_t outer, int len, int64_t inner, void* stream);
+int ck_param_reduce_bwd(int op, const float* x, const float* y, const float* dy, float* dx, int64_t outer, int len, int64_t inner, void* stream);
+int ck_param_outer_sum(const float* a, const float* b, float* out, int64_t outer, int n1, int n2, int64_t inner, void* stream);
+int ck_param_outer_sum_bwd(const float* dout, float* dx, int64_t outer, int n1, int n2, int64_t inner, int which, void* stream);
 /* entrywise ops (nodes.py:656-739); a, b only used by CK_UNARY_SCALED_SIGMOID and CK_UNARY_CLAMP (vmin, vmax). */
 int ck_param_unary(int op, const float* in, float* out, int64_t n, float a, float b, void* stream);
 /* out[f] = in[idx[f]] over blocks of `per_fold` 4-byte words (pointer fold_idx nodes.py:277-279,

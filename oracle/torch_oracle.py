@@ -192,6 +192,15 @@ def eval_param(pg: ParamGraph, tensors: Mapping[str, Tensor]) -> Tensor:
             y = (xs[0].unsqueeze(d + 2) * xs[1].unsqueeze(d + 1)).reshape(n.num_folds, *n.shape)
         elif n.op == "reduce_sum":  # nodes.py:750-751
             y = torch.sum(xs[0], dim=c["dim"] + 1)
+        elif n.op == "reduce_prod":  # nodes.py:755-756
+            y = torch.prod(xs[0], dim=c["dim"] + 1)
+        elif n.op == "reduce_lse":  # nodes.py:760-761
+            y = torch.logsumexp(xs[0], dim=c["dim"] + 1)
+        elif n.op == "outer_sum":  # nodes.py:646-653
+            d = c["dim"]
+            y = (xs[0].unsqueeze(d + 2) + xs[1].unsqueeze(d + 1)).reshape(n.num_folds, *n.shape)
+        elif n.op == "index":  # nodes.py:487-488 (the FIRST axis of the per-fold value, whatever `dim` says: as the reference does)
+            y = xs[0][:, torch.tensor(c["indices"])]
         elif n.op == "clamp":  # nodes.py:727-728
             y = torch.clamp(xs[0], min=c.get("vmin"), max=c.get("vmax"))
         elif n.op == "softplus":  # nodes.py:738-739

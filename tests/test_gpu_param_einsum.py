@@ -79,6 +79,12 @@ def test_complex_matmul_parameter(hip_device):
     ("reduce_sum", {"dim": 1}, [(3, 6)], (3,)),                                  # nodes.py:749-751
     ("reduce_sum", {"dim": 0}, [(4, 2, 3)], (2, 3)),
     ("sum", {}, [(4, 3), (4, 3)], (4, 3)),                                       # nodes.py:491-507
+    ("reduce_prod", {"dim": 1}, [(3, 6)], (3,)),                                 # nodes.py:754-756
+    ("reduce_lse", {"dim": 0}, [(4, 2, 3)], (2, 3)),                             # nodes.py:759-761
+    ("reduce_lse", {"dim": 1}, [(5, 33)], (5,)),
+    ("outer_sum", {"dim": 1}, [(3, 2), (3, 4)], (3, 8)),                         # nodes.py:615-653
+    ("outer_sum", {"dim": 0}, [(2, 5), (3, 5)], (6, 5)),
+    ("index", {"indices": [2, 0, 2, 4], "dim": 0}, [(5, 3)], (4, 3)),            # nodes.py:450-488
     ("clamp", {"vmin": -0.3, "vmax": 0.4}, [(5, 7)], (5, 7)),                    # nodes.py:702-728
     ("clamp", {"vmin": 1e-18}, [(5, 7)], (5, 7)),
     ("softplus", {}, [(5, 7)], (5, 7)),                                          # nodes.py:731-739

@@ -121,6 +121,10 @@ def test_complex_squared_circuit_matches_the_live_reference():
     ("TorchOuterProductParameter", {"dim": 1}, [(3, 2), (3, 4)], "outer_product", {"dim": 1}),
     ("TorchReduceSumParameter", {"dim": 0}, [(4, 2, 3)], "reduce_sum", {"dim": 0}),
     ("TorchSumParameter", {}, [(4, 3), (4, 3)], "sum", {}),
+    ("TorchReduceProductParameter", {"dim": 1}, [(3, 6)], "reduce_prod", {"dim": 1}),
+    ("TorchReduceLSEParameter", {"dim": 0}, [(4, 2, 3)], "reduce_lse", {"dim": 0}),
+    ("TorchOuterSumParameter", {"dim": 1}, [(3, 2), (3, 4)], "outer_sum", {"dim": 1}),
+    ("TorchIndexParameter", {"indices": [2, 0, 2, 4], "dim": 0}, [(5, 3)], "index", {"indices": [2, 0, 2, 4], "dim": 0}),
     ("TorchClampParameter", {"vmin": 1e-18}, [(5, 7)], "clamp", {"vmin": 1e-18}),
     ("TorchClampParameter", {"vmin": -0.3, "vmax": 0.4}, [(5, 7)], "clamp", {"vmin": -0.3, "vmax": 0.4}),
     ("TorchSoftplusParameter", {}, [(5, 7)], "softplus", {}),
