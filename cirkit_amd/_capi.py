@@ -255,6 +255,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_mixing_weight_bwd": [_p, _p, _i, _i, _i, _i, _p],
     "ck_axpy_f32": [_p, _p, _f, _l, _p],
     "ck_param_binomial_table": [_p, _i, _p, _l, _i, _i, _p],
+    "ck_param_gaussian_product_ms": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "ck_param_gaussian_product_ms_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "ck_param_gaussian_product_logz": [_p, _p, _p, _p, _p, _l, _i, _i, _p],
     "ck_param_gaussian_product_logz_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p],
     "ck_segment_add_rows": [_p, _p, _p, _p, _p, _i, _l, _p],

@@ -1116,6 +1116,69 @@ __global__ void __launch_bounds__(256) gaussian_product_logz_kernel(const float*
   }
 }
 
+// TorchGaussianProductMean / TorchGaussianProductStddev (nodes.py:865-938): the mean and the standard deviation of the product of
+// two Gaussian densities for every unit pair (i, j): with v1 = s1_i^2, v2 = s2_j^2,
+//   mean = (m1_i v2 + m2_j v1) / (v1 + v2)          stddev = sqrt(v1 v2 / (v1 + v2))
+// op 0: mean (m1, m2 read), op 1: stddev.
+__global__ void __launch_bounds__(256) gaussian_product_ms_kernel(int op, const float* __restrict__ m1, const float* __restrict__ s1,
+                                                                  const float* __restrict__ m2, const float* __restrict__ s2,
+                                                                  float* __restrict__ out, int64_t F, int K1, int K2) {
+  const int64_t n = F * K1 * K2;
+  for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < n;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t f = e / (static_cast<int64_t>(K1) * K2);
+    const int r = static_cast<int>(e - f * K1 * K2), i = r / K2, j = r - i * K2;
+    const float a = s1[f * K1 + i], b = s2[f * K2 + j];
+    const float v1 = a * a, v2 = b * b;
+    if (op == 0)
+      out[e] = (m1[f * K1 + i] * v2 + m2[f * K2 + j] * v1) * (1.f / (v1 + v2));
+    else
+      out[e] = sqrtf(1.f / (1.f / v1 + 1.f / v2));
+  }
+}
+// Their backward, one thread per (fold, unit) of either operand walking the other operand's units (no atomics).  With D = v1 + v2:
+//   mean:    d/dm1 = v2 / D,  d/dm2 = v1 / D,  d/ds1 = 2 s1 (m2 - mean) / D,  d/ds2 = 2 s2 (m1 - mean) / D
+//   stddev:  d/ds1 = (s1 / out) v2^2 / D^2,  d/ds2 = (s2 / out) v1^2 / D^2
+__global__ void __launch_bounds__(256) gaussian_product_ms_bwd_kernel(int op, const float* __restrict__ m1, const float* __restrict__ s1,
+                                                                      const float* __restrict__ m2, const float* __restrict__ s2,
+                                                                      const float* __restrict__ dout, float* __restrict__ dm1,
+                                                                      float* __restrict__ ds1, float* __restrict__ dm2,
+                                                                      float* __restrict__ ds2, int64_t F, int K1, int K2) {
+  const int64_t n = F * (K1 + K2);
+  for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < n;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t f = e / (K1 + K2);
+    const int u = static_cast<int>(e - f * (K1 + K2));
+    const bool first = u < K1;
+    const int i = first ? u : u - K1;
+    const float sd = first ? s1[f * K1 + i] : s2[f * K2 + i];
+    const float mu = op == 0 ? (first ? m1[f * K1 + i] : m2[f * K2 + i]) : 0.f;
+    const int Ko = first ? K2 : K1;
+    const float vt = sd * sd;
+    float gm = 0.f, gs = 0.f;
+    for (int j = 0; j < Ko; ++j) {
+      const float os = first ? s2[f * K2 + j] : s1[f * K1 + j];
+      const float g = first ? dout[(f * K1 + i) * K2 + j] : dout[(f * K1 + j) * K2 + i];
+      const float vo = os * os, rd = 1.f / (vt + vo);
+      if (op == 0) {
+        const float om = first ? m2[f * K2 + j] : m1[f * K1 + j];
+        const float mean = (mu * vo + om * vt) * rd;
+        gm += g * vo * rd;
+        gs += g * 2.f * sd * (om - mean) * rd;
+      } else {
+        const float out = sqrtf(vt * vo * rd);
+        gs += g * (sd / out) * vo * vo * rd * rd;
+      }
+    }
+    if (first) {
+      if (op == 0) dm1[f * K1 + i] = gm;
+      ds1[f * K1 + i] = gs;
+    } else {
+      if (op == 0) dm2[f * K2 + i] = gm;
+      ds2[f * K2 + i] = gs;
+    }
+  }
+}
 // Backward of gaussian_product_logz_kernel: with v = s1_i^2 + s2_j^2, d = m1_i - m2_j and g = dout[f, i K2 + j],
 //   dm1_i = sum_j -g d / v      ds1_i = sum_j g s1_i (d^2 / v - 1) / v      (and the mirror image for operand 2; four distinct buffers).
 // One thread per (fold, unit) of either operand walks the other operand's units: no atomics, deterministic.
@@ -1542,6 +1605,39 @@ int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, con
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(gaussian_product_logz_kernel, grid, block, 0, s, mean1, stddev1, mean2, stddev2, out, F, K1, K2);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_gaussian_product_ms(int op, const float* mean1, const float* stddev1, const float* mean2, const float* stddev2, float* out,
+                                 int F, int K1, int K2, void* stream) {
+  CK_REQUIRE(op == 0 || op == 1, "ck_param_gaussian_product_ms: op %d (0 mean, 1 stddev)", op);
+  CK_REQUIRE(stddev1 && stddev2 && out && (op == 1 || (mean1 && mean2)), "ck_param_gaussian_product_ms: null pointer");
+  CK_REQUIRE(F > 0 && K1 > 0 && K2 > 0, "ck_param_gaussian_product_ms: non-positive size");
+  const int64_t n = static_cast<int64_t>(F) * K1 * K2;
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 4096))), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(gaussian_product_ms_kernel, grid, block, 0, s, op, mean1, stddev1, mean2, stddev2, out, static_cast<int64_t>(F), K1, K2);
+        return hipGetLastError();
+      },
+      stream);
+}
+
+int ck_param_gaussian_product_ms_bwd(int op, const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
+                                     const float* dout, float* dmean1, float* dstddev1, float* dmean2, float* dstddev2, int F, int K1, int K2,
+                                     void* stream) {
+  CK_REQUIRE(op == 0 || op == 1, "ck_param_gaussian_product_ms_bwd: op %d (0 mean, 1 stddev)", op);
+  CK_REQUIRE(stddev1 && stddev2 && dout && dstddev1 && dstddev2 && (op == 1 || (mean1 && mean2 && dmean1 && dmean2)),
+             "ck_param_gaussian_product_ms_bwd: null pointer");
+  CK_REQUIRE(F > 0 && K1 > 0 && K2 > 0, "ck_param_gaussian_product_ms_bwd: non-positive size");
+  const int64_t n = static_cast<int64_t>(F) * (K1 + K2);
+  dim3 grid(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 4096))), block(256);
+  return ck::dispatch(
+      [=](hipStream_t s) {
+        hipLaunchKernelGGL(gaussian_product_ms_bwd_kernel, grid, block, 0, s, op, mean1, stddev1, mean2, stddev2, dout, dmean1, dstddev1, dmean2,
+                           dstddev2, static_cast<int64_t>(F), K1, K2);
         return hipGetLastError();
       },
       stream);

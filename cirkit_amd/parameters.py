@@ -439,6 +439,16 @@ class HipParameter:
                 y = self._buf(j, shape)
                 capi.call("ck_copy_strided_f32", _ptr(a.contiguous()), _ptr(y), y.numel(), 1, 1, stream)
                 capi.call("ck_axpy_f32", _ptr(y), _ptr(b.contiguous()), 1.0, y.numel(), stream)
+            elif n.op in ("gaussian_product_mean", "gaussian_product_stddev"):  # nodes.py:865-938
+                ops = [x.contiguous() for x in xs]
+                if any(x.dim() > 2 and int(np.prod(x.shape[2:])) != 1 for x in ops):
+                    raise NotImplementedError(f"{n.op} over several channels")
+                mean = n.op == "gaussian_product_mean"
+                m1, s1, m2, s2 = ops if mean else (None, ops[0], None, ops[1])
+                F, K1, K2 = int(s1.shape[0]), int(s1.shape[1]), int(s2.shape[1])
+                y = self._buf(j, (F, *shape))
+                capi.call("ck_param_gaussian_product_ms", 0 if mean else 1, None if m1 is None else _ptr(m1), _ptr(s1),
+                          None if m2 is None else _ptr(m2), _ptr(s2), _ptr(y), F, K1, K2, stream)
             elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
                 m1, s1, m2, s2 = (x.contiguous() for x in xs)
                 F, K1, K2 = m1.shape[0], m1.shape[1], m2.shape[1]
@@ -733,6 +743,18 @@ class HipParameter:
                         dk = self._buf(("ge", j, k), (a.shape[0], M, N))
                         capi.call("ck_param_bmm", _ptr(a), _ptr(b), _ptr(dk), a.shape[0], M, N, Kd, ta, tb, 0, stream)
                     scatter((j, k), n.inputs[k], dk)
+            elif n.op in ("gaussian_product_mean", "gaussian_product_stddev"):  # nodes.py:865-938
+                mean = n.op == "gaussian_product_mean"
+                ops = [operand(j, k).contiguous() for k in range(len(n.inputs))]
+                m1, s1, m2, s2 = ops if mean else (None, ops[0], None, ops[1])
+                F, K1, K2 = int(s1.shape[0]), int(s1.shape[1]), int(s2.shape[1])
+                ds = [self._buf(("gop", j, k), ops[k].shape) for k in range(len(ops))]
+                dm1, ds1, dm2, ds2 = ds if mean else (None, ds[0], None, ds[1])
+                capi.call("ck_param_gaussian_product_ms_bwd", 0 if mean else 1, None if m1 is None else _ptr(m1), _ptr(s1),
+                          None if m2 is None else _ptr(m2), _ptr(s2), _ptr(dj.contiguous()), None if dm1 is None else _ptr(dm1), _ptr(ds1),
+                          None if dm2 is None else _ptr(dm2), _ptr(ds2), F, K1, K2, stream)
+                for k in range(len(ops)):
+                    scatter((j, k), n.inputs[k], ds[k])
             elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988
                 m1, s1, m2, s2 = (operand(j, k).contiguous() for k in range(4))
                 F, K1, K2 = int(m1.shape[0]), int(m1.shape[1]), int(m2.shape[1])

@@ -74,6 +74,8 @@ PARAM_OPS = {
     "TorchEinsumParameter": "einsum",
     "TorchFlattenParameter": "flatten",
     "TorchGaussianProductLogPartition": "gaussian_product_log_partition",
+    "TorchGaussianProductMean": "gaussian_product_mean",
+    "TorchGaussianProductStddev": "gaussian_product_stddev",
 }
 
 

@@ -489,6 +489,14 @@ int ck_param_binomial_table(const float* p, int is_logits, float* table, int64_t
  * of Gaussian unit i of (mean1, stddev1) and unit j of (mean2, stddev2); all inputs (F, K). */
 int ck_param_gaussian_product_logz(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
                                    float* out, int64_t F, int K1, int K2, void* stream);
+/* TorchGaussianProductMean / TorchGaussianProductStddev.forward (nodes.py:865-938) for every unit pair, out (F, K1 K2):
+ * op 0 the mean (m1 s2^2 + m2 s1^2) / (s1^2 + s2^2), op 1 the standard deviation sqrt(s1^2 s2^2 / (s1^2 + s2^2)) (the means are
+ * not read and may be NULL); _bwd: dout -> the operands' gradients, WRITTEN (op 1: dmean1 / dmean2 untouched, may be NULL). */
+int ck_param_gaussian_product_ms(int op, const float* mean1, const float* stddev1, const float* mean2, const float* stddev2, float* out,
+                                 int F, int K1, int K2, void* stream);
+int ck_param_gaussian_product_ms_bwd(int op, const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
+                                     const float* dout, float* dmean1, float* dstddev1, float* dmean2, float* dstddev2, int F, int K1, int K2,
+                                     void* stream);
 /* Its backward: dout (F, K1 K2) -> the gradients of the four operands, WRITTEN (four distinct buffers, (F, K1) / (F, K2)). */
 int ck_param_gaussian_product_logz_bwd(const float* mean1, const float* stddev1, const float* mean2, const float* stddev2,
                                        const float* dout, float* dmean1, float* dstddev1, float* dmean2, float* dstddev2, int64_t F,

@@ -201,6 +201,17 @@ def eval_param(pg: ParamGraph, tensors: Mapping[str, Tensor]) -> Tensor:
             y = (xs[0].unsqueeze(d + 2) + xs[1].unsqueeze(d + 1)).reshape(n.num_folds, *n.shape)
         elif n.op == "index":  # nodes.py:487-488 (the FIRST axis of the per-fold value, whatever `dim` says: as the reference does)
             y = xs[0][:, torch.tensor(c["indices"])]
+        elif n.op == "gaussian_product_mean":  # nodes.py:899-908
+            mean1, stddev1, mean2, stddev2 = xs
+            var1, var2 = torch.square(stddev1), torch.square(stddev2)
+            inv_var12 = torch.reciprocal(var1.unsqueeze(dim=2) + var2.unsqueeze(dim=1))
+            wm1 = mean1.unsqueeze(dim=2) * var2.unsqueeze(dim=1)
+            wm2 = mean2.unsqueeze(dim=1) * var1.unsqueeze(dim=2)
+            y = ((wm1 + wm2) * inv_var12).view(-1, *n.shape)
+        elif n.op == "gaussian_product_stddev":  # nodes.py:931-938
+            var1, var2 = torch.square(xs[0]), torch.square(xs[1])
+            inv_var1, inv_var2 = torch.reciprocal(var1).unsqueeze(dim=2), torch.reciprocal(var2).unsqueeze(dim=1)
+            y = torch.sqrt(torch.reciprocal(inv_var1 + inv_var2)).view(-1, *n.shape)
         elif n.op == "clamp":  # nodes.py:727-728
             y = torch.clamp(xs[0], min=c.get("vmin"), max=c.get("vmax"))
         elif n.op == "softplus":  # nodes.py:738-739

@@ -85,6 +85,8 @@ def test_complex_matmul_parameter(hip_device):
     ("outer_sum", {"dim": 1}, [(3, 2), (3, 4)], (3, 8)),                         # nodes.py:615-653
     ("outer_sum", {"dim": 0}, [(2, 5), (3, 5)], (6, 5)),
     ("index", {"indices": [2, 0, 2, 4], "dim": 0}, [(5, 3)], (4, 3)),            # nodes.py:450-488
+    ("gaussian_product_mean", {}, [(4, 1), (4, 1), (3, 1), (3, 1)], (12,)),      # nodes.py:865-908 (mean1, stddev1, mean2, stddev2)
+    ("gaussian_product_stddev", {}, [(4, 1), (3, 1)], (12,)),                  # nodes.py:910-938
     ("clamp", {"vmin": -0.3, "vmax": 0.4}, [(5, 7)], (5, 7)),                    # nodes.py:702-728
     ("clamp", {"vmin": 1e-18}, [(5, 7)], (5, 7)),
     ("softplus", {}, [(5, 7)], (5, 7)),                                          # nodes.py:731-739
@@ -100,6 +102,11 @@ def test_product_sum_and_entrywise_parameter_nodes(hip_device, op, config, shape
     F = 3
     store = TensorStore(hip_device)
     p, vals = _graph(store, shapes, "r" * len(shapes), op, config, out_shape, F, g)
+    if op.startswith("gaussian_product"):  # (standard deviations are positive)
+        for i, v in enumerate(vals):
+            if op.endswith("stddev") or i % 2 == 1:
+                vals[i] = v.abs() + 0.3
+                store.set(f"t{i}", vals[i])
     if op == "softplus":  # (both sides of the threshold of 20)
         vals[0][0, 0, :3] = torch.tensor([25.0, -30.0, 19.5])
         store.set("t0", vals[0])

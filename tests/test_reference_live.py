@@ -125,6 +125,8 @@ def test_complex_squared_circuit_matches_the_live_reference():
     ("TorchReduceLSEParameter", {"dim": 0}, [(4, 2, 3)], "reduce_lse", {"dim": 0}),
     ("TorchOuterSumParameter", {"dim": 1}, [(3, 2), (3, 4)], "outer_sum", {"dim": 1}),
     ("TorchIndexParameter", {"indices": [2, 0, 2, 4], "dim": 0}, [(5, 3)], "index", {"indices": [2, 0, 2, 4], "dim": 0}),
+    ("TorchGaussianProductMean", {}, [(4, 1), (4, 1), (3, 1), (3, 1)], "gaussian_product_mean", {}),
+    ("TorchGaussianProductStddev", {}, [(4, 1), (3, 1)], "gaussian_product_stddev", {}),
     ("TorchClampParameter", {"vmin": 1e-18}, [(5, 7)], "clamp", {"vmin": 1e-18}),
     ("TorchClampParameter", {"vmin": -0.3, "vmax": 0.4}, [(5, 7)], "clamp", {"vmin": -0.3, "vmax": 0.4}),
     ("TorchSoftplusParameter", {}, [(5, 7)], "softplus", {}),
@@ -141,6 +143,8 @@ def test_oracle_parameter_nodes_equal_the_reference_modules(cls, kwargs, shapes,
     F = 3
     g = torch.Generator().manual_seed(5)
     xs = [torch.randn((F, *s), generator=g) for s in shapes]
+    if "Gaussian" in cls:
+        xs = [x.abs() + 0.3 for x in xs]
     mod = getattr(ref_nodes, cls)(*shapes, num_folds=F, **kwargs)
     with torch.no_grad():
         want = mod(*xs)
