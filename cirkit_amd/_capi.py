@@ -283,6 +283,8 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_tensordot2_lse_bwd": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_slse_table": [_p, _p, _p, _l, _p],
     "ck_slse_tables": [_p, _p, _p, _p, _i, _i, _p],
+    "ck_slse_pair_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
+    "ck_slse_pair_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "ck_slse_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "ck_slse_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "ck_latch_flag": [_p, _p, _p],
