@@ -10,7 +10,7 @@ from typing import Any
 # CIRKIT_HIP_LIB: a lab build of the same library (scripts/lab_build.sh, scripts/defect_injection.sh); never a different backend
 _LIB_PATH = os.environ.get("CIRKIT_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 45
+ABI_VERSION = 46
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -87,6 +87,7 @@ class LeafLaunch(C.Structure):
         ("keep_redo", C.c_void_p),
         ("x_pairs", C.c_int32),
         ("root_tab", C.c_void_p),
+        ("signs_out", C.c_void_p),
     ]
 
 
@@ -109,6 +110,7 @@ class LeafBwdLaunch(C.Structure):
         ("dw_q", C.c_void_p),
         ("gout", C.c_void_p),
         ("redo", C.c_void_p),
+        ("is_signed", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -197,7 +199,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_device_info": [_i, C.POINTER(_l)],
     "ck_transpose_i64_to_i32": [_p, _p, _i, _i, _p],
     "ck_transpose_f32": [_p, _p, _i, _i, _p],
-    "ck_stage_categories": [_p, _p, _i, _i, _p, _p, _i, _p],
+    "ck_stage_categories": [_p, _p, _i, _i, _p, _p, _i, _p, _p],
     "ck_poison_outputs": [_p, _l, _p, _p],
     "ck_zero_if_flag": [_p, _l, _p, _p],
     "ck_categorical_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -267,7 +269,7 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_fill_latch": [_p, _l, _f, _p, _p, _p, _p],
     "ck_leaf_walk_bwd": [C.POINTER(LeafBwdLaunch), _p],
     "ck_table_dense_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
-    "ck_leaf_walk_bwd_redo": [_p, _p, _p, _i, _i, _i, _p, C.POINTER(C.c_int32), _i, _p, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _p, _p, _p, _i, _p],
+    "ck_leaf_walk_bwd_redo": [_p, _p, _p, _i, _i, _i, _p, C.POINTER(C.c_int32), _i, _p, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _p, _p, _p, _i, _p, _i, _p],
     "ck_param_softmax_bwd": [_p, _p, _p, _l, _i, _i, _p],
     "ck_param_log_table_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],
     "ck_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _i, _f, _p, _p, _p],

@@ -779,7 +779,7 @@ class HipCircuit(_LaunchMixin, _ProfilingMixin):
         if xi is not None:
             if self.validate_inputs:
                 capi.call("ck_stage_categories", xi.data_ptr(), bd.xt_i.data_ptr(), bd.B, self.plan.num_variables,
-                          self._num_states_dev().data_ptr(), self._bad_input.data_ptr(), 1 if self._preclamp() else 0, stream)
+                          self._num_states_dev().data_ptr(), self._bad_input.data_ptr(), 1 if self._preclamp() else 0, None, stream)
             else:
                 capi.call("ck_transpose_i64_to_i32", xi.data_ptr(), bd.xt_i.data_ptr(), bd.B, self.plan.num_variables, stream)
 

@@ -35,7 +35,8 @@ __global__ void transpose_kernel(const TI* __restrict__ x, TO* __restrict__ xt, 
 // (num_states[d] > 0) raises the sticky flag -- the reference's advanced indexing raises IndexError there
 // (layers/input.py:399-412); the consumers clamp for memory safety, the circuit's last launch turns the flag into NaN outputs.
 __global__ void stage_categories_kernel(const int64_t* __restrict__ x, int32_t* __restrict__ xt, int B, int D,
-                                        const int32_t* __restrict__ num_states, int32_t* __restrict__ flag, int clamp) {
+                                        const int32_t* __restrict__ num_states, int32_t* __restrict__ flag, int clamp,
+                                        int64_t* __restrict__ x_copy) {
   __shared__ int32_t tile[kTile][kTile + 1];
   const int d0 = blockIdx.x * kTile, b0 = blockIdx.y * kTile;
   const int tx = threadIdx.x, ty = threadIdx.y;  // (32, 8)
@@ -45,6 +46,7 @@ __global__ void stage_categories_kernel(const int64_t* __restrict__ x, int32_t* 
     const int b = b0 + ty + j, d = d0 + tx;
     if (b < B && d < D) {
       const int64_t v = x[static_cast<int64_t>(b) * D + d];
+      if (x_copy != nullptr) x_copy[static_cast<int64_t>(b) * D + d] = v;  // (the batch at an address of the caller's: recorded launches read it)
       const int ns = num_states[d];
       bad |= ns > 0 && v >= ns;
       // clamp: an out-of-range category is stored as the last one (what every consumer would make of it), a negative
@@ -387,13 +389,13 @@ int ck_transpose_i64_to_i32(const int64_t* x, int32_t* xt, int B, int D, void* s
 }
 
 int ck_stage_categories(const int64_t* x, int32_t* xt, int B, int D, const int32_t* num_states, int32_t* flag, int clamp,
-                        void* stream) {
+                        int64_t* x_copy, void* stream) {
   CK_REQUIRE(x && xt && num_states && flag, "ck_stage_categories: null pointer");
   CK_REQUIRE(B > 0 && D > 0, "ck_stage_categories: B=%d D=%d must be positive", B, D);
   dim3 grid((D + kTile - 1) / kTile, (B + kTile - 1) / kTile), block(kTile, 8);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(stage_categories_kernel, grid, block, 0, s, x, xt, B, D, num_states, flag, clamp);
+        hipLaunchKernelGGL(stage_categories_kernel, grid, block, 0, s, x, xt, B, D, num_states, flag, clamp, x_copy);
         return hipGetLastError();
       },
       stream);

@@ -60,6 +60,8 @@ struct LeafArgs {
 #ifdef CK_LEAF_STAMPS
   int stamp_wg, stamp_tile;
 #endif
+  uint32_t* sout;  // SIGNED: nullptr (out is the (F_root, B, 32) complex64 block of (log|v|, 0 or pi)), or the sign words (F_root, Bp) of
+                   // SIGNED-LOG blocks (ck_signed.hip): out is then (F_root, Bp, 32) fp32 log|v| in tile-native order, Bp = 32 ceil(B / 32)
   const int32_t* root_tab;  // nullptr, or (F_root, 3 * 2^D): per root the variable and the table fold of every leaf and the folds
                             // of its 2^D - 1 nodes in step order -- what the start of a segment otherwise collects from `nodes`,
                             // `scope` and the level tables in three dependent rounds of loads
@@ -86,13 +88,26 @@ __host__ __device__ constexpr int keep_stores_plain(int i, int slots) {  // leaf
   for (int m = i - slots; m < i; ++m) n += kept_steps(steps_after(m));
   return 4 * n;
 }
+// A SIGNED tile as a signed-log block of ck_signed.hip: log|v| in tile-native order and ONE sign word per row (bit k: unit k is
+// negative; a lane holds the bits of units 8 (j >> 2) + 4 kh + (j & 3), the two halves of a row are or-ed)
+__device__ __forceinline__ void store_signed_log(const LeafArgs& a, int t, int tile, int b, int lane, const float (&v)[16], uint32_t sg) {
+  const int kh = lane >> 5;
+  const int64_t Bp = static_cast<int64_t>((a.B + 31) >> 5) * 32;
+  tile_store_native(a.out + (static_cast<int64_t>(t) * Bp + static_cast<int64_t>(tile) * 32) * kK, lane, v);
+  uint32_t so = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) so |= ((sg >> j) & 1u) << (8 * (j >> 2) + 4 * kh + (j & 3));
+  so |= __shfl_xor(so, 32, 64);
+  if (kh == 0 && b < a.B) a.sout[static_cast<int64_t>(t) * Bp + b] = so;
+}
+
 // CT: 0 = the contraction in exact fp32 (the product); 3 / 6 = the labelled bf16-split VARIANTS (ck_tile.h contract_bf16:
 // "bf16x3" with two pieces per operand, "bf16x6" with three): the subtree weights are cut into pieces while they are staged
 // (registers, not DMA), a node takes 4 / 6 KB of LDS -- with three pieces the gather ring has two slots per wave (the walk goes
 // leaf by leaf) so that everything still fits 160 KB.
 template <int D, int WAVES, bool SIGNED, bool XRAW, bool XP = false, bool KEEP = false, int CT = 0>
 __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafArgs a) {
-  static_assert(!KEEP || (!SIGNED && WAVES == 8), "the training forward walks unsigned values with 8 waves");
+  static_assert(!KEEP || WAVES == 8, "the training forward walks with 8 waves");
   static_assert(CT == 0 || (CT == 3 && !SIGNED && !KEEP) || (CT == 6 && !SIGNED && !KEEP), "bf16 variants: unsigned inference forward");
   constexpr int kLeaves = 1 << D, kNodes = kLeaves - 1, kSlots = (WAVES == 8 && D >= 2 && CT != 6) ? 3 : 2;
   constexpr int kWNode = CT == 6 ? 1536 : 1024;  // dwords of LDS per node
@@ -639,7 +654,8 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_persistent_kernel(const LeafA
             sg |= (cur[j] < 0.f ? 1u : 0u) << j;
             cur[j] = fmaf(__builtin_amdgcn_logf(__builtin_fabsf(cur[j])), kLN2, cs);
           }
-          tile_store_clog(a.out + ((static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh) * 2, cur, sg);
+          if (a.sout != nullptr) store_signed_log(a, t, tile, b, lane, cur, sg);
+          else tile_store_clog(a.out + ((static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh) * 2, cur, sg);
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j) cur[j] = fmaf(__builtin_amdgcn_logf(cur[j]), kLN2, cs);
@@ -734,14 +750,25 @@ __global__ void __launch_bounds__(64) leaf_signed_redo_kernel(const LeafArgs a) 
   uint32_t sg = 0;
   if (a.w_rowmajor) subtree_tile_logspace<D, CK_W_ROWMAJOR, true>(src, lane, v, &sg);
   else subtree_tile_logspace<D, CK_W_TILED_F32, true>(src, lane, v, &sg);
-  if (b < a.B) tile_store_clog(a.out + ((static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh) * 2, v, sg);
-  if (lane == 0) *flag = 0;  // ready for the next replay
+  if (a.sout != nullptr) store_signed_log(a, t, tile, b, lane, v, sg);  // (all 32 rows of the block; sign words of the live ones)
+  else if (b < a.B) tile_store_clog(a.out + ((static_cast<int64_t>(t) * a.B + b) * kK + 4 * kh) * 2, v, sg);
+  if (lane == 0 && a.keep[1] == nullptr) *flag = 0;  // ready for the next replay (a training forward: the backward clears it)
 }
 
 template <int D, bool XRAW>
 hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_roots, dim3 grid, hipStream_t s) {
-  if (D >= 2 && a.keep[1] != nullptr) {  // the training forward (checked by the caller: raw input, unsigned, 8 waves, depth 2 | 4)
+  if (D >= 2 && a.keep[1] != nullptr) {  // the training forward (checked by the caller: raw input, 8 waves, depth 2 | 4)
     if constexpr (XRAW) {
+      if constexpr (D == 2 || D == 4) {
+        if (is_signed) {  // signed values (a squared circuit's c(x) with real parameters): marked tiles by the signed log-space walk
+          if (a.x_pairs) hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true, true, true, true>), grid, dim3(512), 0, s, a);
+          else hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true, true, false, true>), grid, dim3(512), 0, s, a);
+          if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+          hipLaunchKernelGGL((leaf_signed_redo_kernel<D>), dim3((a.B + 31) / 32, n_roots), dim3(64), 0, s, a);
+          return hipGetLastError();
+        }
+      }
+      if (is_signed) return hipErrorInvalidValue;
       if constexpr (D >= 2) {
         if (a.x_pairs) {
           hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, false, true, true, true>), grid, dim3(512), 0, s, a);
@@ -835,6 +862,8 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
   CK_REQUIRE(d->w_layout == CK_W_TILED_F32 || d->w_layout == CK_W_ROWMAJOR, "ck_leaf_walk_fwd: weights must be CK_W_TILED_F32 or row-major");
   CK_REQUIRE(d->signed_redo == nullptr || (d->n_roots > 0 && d->n_roots <= 65535), "ck_leaf_walk_fwd: signed launch needs 0 < n_roots <= 65535");
   a.redo = d->signed_redo;
+  CK_REQUIRE(d->signs_out == nullptr || d->signed_redo != nullptr, "ck_leaf_walk_fwd: signs_out belongs to a signed launch");
+  a.sout = d->signs_out;
   a.w_rowmajor = d->w_layout == CK_W_ROWMAJOR ? 1 : 0;
   const void* const* slot = nullptr;
   if (raw) {
@@ -859,8 +888,9 @@ int ck_leaf_walk_fwd(const ck_leaf_launch* d, void* stream) {
     a.contraction = d->contraction;
   }
   if (d->keep_levels != nullptr) {
-    CK_REQUIRE(raw && d->waves == 8 && d->signed_redo == nullptr, "ck_leaf_walk_fwd: the training forward (keep_levels) reads the raw batch "
-               "with 8-wave workgroups and walks unsigned values");
+    CK_REQUIRE(raw && d->waves == 8, "ck_leaf_walk_fwd: the training forward (keep_levels) reads the raw batch with 8-wave workgroups");
+    CK_REQUIRE(d->signed_redo == nullptr || d->signed_redo == d->keep_redo, "ck_leaf_walk_fwd: a signed training forward marks its tiles in ONE "
+               "flag array (signed_redo == keep_redo)");
     CK_REQUIRE(d->keep_redo != nullptr, "ck_leaf_walk_fwd: keep_levels needs keep_redo");
     CK_REQUIRE(static_cast<int64_t>(d->B) * kK < (int64_t{1} << 31), "ck_leaf_walk_fwd: B=%d rows exceed the 32-bit offsets of the kept tiles", d->B);
     CK_REQUIRE(d->depth == 2 || d->depth == 4, "ck_leaf_walk_fwd: keep_levels needs a region of 2 or 4 levels (got %d)", d->depth);

@@ -69,11 +69,24 @@ constexpr int kUnitTab = 16;
 
 // e <- a * b as the forward forms it (ck_tile.h): the bare product at the first fused level, renormalised by the power of two
 // of the row maximum above it -- the kept y of the node is W e for exactly this e.
-template <bool RESCALE>
+template <bool RESCALE, bool SIGNED>
 __device__ __forceinline__ void forward_product(float (&cur)[16], const float (&sib)[16]) {
   float s = 0.f;
   bool bad = false;
-  linear_product<RESCALE>(cur, sib, s, 0.f, bad);
+  linear_product<RESCALE, SIGNED>(cur, sib, s, 0.f, bad);
+}
+// gy = g / y for SIGNED tiles (y of either sign; ck_bwd_tile.h grad_over_y tests y > 0)
+template <bool SIGNED>
+__device__ __forceinline__ void grad_over(const float (&g)[16], const float (&y)[16], bool live, float (&gy)[16]) {
+  if constexpr (SIGNED) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float q = g[r] * __builtin_amdgcn_rcpf(y[r]);
+      gy[r] = (live && y[r] != 0.f && g[r] != 0.f) ? q : 0.f;
+    }
+  } else {
+    grad_over_y(g, y, live, gy);
+  }
 }
 
 // WAVES = 8: two waves per SIMD, a unit's loads issued at its start (the other wave computes meanwhile).  Measured at the
@@ -85,7 +98,10 @@ __device__ __forceinline__ void forward_product(float (&cur)[16], const float (&
 // refills the same raw registers with the loads of the next unit, stores the previous unit's results (carried in registers, so
 // that no store is younger than the loads the next iteration waits for first: the compiler's wait there is vmcnt(0)), and
 // computes.  Marked units are computed with every row dead (no contribution, nothing stored).
-template <bool LEAF, int WAVES>
+// SIGNED: the tiles of a real-valued circuit under complex-lse-sum (ck_leaf.hip SIGNED + KEEP: a squared circuit's c(x)): linear
+// values of either sign, renormalised by the row maximum of |.|; the gradients are those w.r.t. log|.| -- the same three
+// contractions (ck_signed.hip).
+template <bool LEAF, int WAVES, bool SIGNED = false>
 __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float wt_lds[3 * 1024];          // W^T of P, Q0, Q1 ("transposed tiled")
   __shared__ __attribute__((aligned(16))) float wq_lds[2 * 1024];          // W of Q0, Q1 (CK_W_TILED_F32: the forward's operand)
@@ -220,19 +236,19 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
         for (int n = 0; n < 2; ++n) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) eq[n][r] = c[2 * n + 1][r];
-          forward_product<!LEAF>(eq[n], c[2 * n]);
+          forward_product<!LEAF, SIGNED>(eq[n], c[2 * n]);
           recompute(n, eq[n], yq[n]);
         }
-        grad_over_y(g, y, live, gy);
+        grad_over<SIGNED>(g, y, live, gy);
         CK_BSTAMP(2);
 #pragma unroll
         for (int r = 0; r < 16; ++r) e[r] = yq[1][r];
-        forward_product<true>(e, yq[0]);
+        forward_product<true, SIGNED>(e, yq[0]);
         node(0, gy, e, gq);
         CK_BSTAMP(3);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          grad_over_y(gq, yq[n], live, gy);
+          grad_over<SIGNED>(gq, yq[n], live, gy);
           node(1 + n, gy, eq[n], n == 0 ? r0 : r1);
           CK_BSTAMP(4 + n);
         }
@@ -263,14 +279,14 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
         CK_BSTAMP(0);
         // consume the raw tiles of this unit (the first touch waits for all of them; nothing younger is in flight)
         float gyp[16], ep[16], eq0[16], eq1[16], dq0[16], dq1[16];  // (dq: 1 / y of Q0, Q1)
-        grad_over_y(g, y, live, gyp);  // (dead rows and marked units: zero here, and with it every gradient below)
+        grad_over<SIGNED>(g, y, live, gyp);  // (dead rows and marked units: zero here, and with it every gradient below)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           eq0[r] = c[1][r];
           eq1[r] = c[3][r];
         }
-        forward_product<!LEAF>(eq0, c[0]);
-        forward_product<!LEAF>(eq1, c[2]);
+        forward_product<!LEAF, SIGNED>(eq0, c[0]);
+        forward_product<!LEAF, SIGNED>(eq1, c[2]);
         {
           float yq0[16], yq1[16];
           recompute(0, eq0, yq0);
@@ -278,10 +294,10 @@ __global__ void __launch_bounds__(WAVES * 64) leaf_bwd_kernel(const BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             ep[r] = yq1[r];
-            dq0[r] = mk ? 0.f : __builtin_amdgcn_rcpf(yq0[r]);  // (a marked unit's tiles mean nothing: no 1 / 0 into the products)
-            dq1[r] = mk ? 0.f : __builtin_amdgcn_rcpf(yq1[r]);
+            dq0[r] = (mk || (SIGNED && yq0[r] == 0.f)) ? 0.f : __builtin_amdgcn_rcpf(yq0[r]);  // (a marked unit's tiles mean nothing: no 1 / 0 into the products)
+            dq1[r] = (mk || (SIGNED && yq1[r] == 0.f)) ? 0.f : __builtin_amdgcn_rcpf(yq1[r]);
           }
-          forward_product<true>(ep, yq0);
+          forward_product<true, SIGNED>(ep, yq0);
         }
         __builtin_amdgcn_sched_barrier(0);
         CK_BSTAMP(1);
@@ -361,11 +377,12 @@ struct RedoArgs {
   const float* w[4];     // row-major (F_l, 32, 32) weights of level l + 1
   float* dw[4];
   const float* gin;      // (F_root, B, 32)
+  const int32_t* gin_fold;  // nullptr, or (n_roots): gin is tile-native, (., tiles, 1024), and root t's tiles are block gin_fold[t] of it
   float* gout1;          // (F_1, B, 32)
   int32_t* redo;         // (n_roots, tiles): cleared here
 };
 
-template <int D>
+template <int D, bool SIGNED>
 struct RedoWalk {
   const RedoArgs& a;
   int t, lane, b_in, kh, bl;
@@ -374,9 +391,10 @@ struct RedoWalk {
 
   __device__ __forceinline__ int fold(int level, int j) const { return a.nodes[a.node_off[level] + t * ((1 << D) >> level) + j]; }
 
-  // log-space output of node j of `level` (level 0: the leaf's table row)
+  // log-space output of node j of `level` (level 0: the leaf's table row); SIGNED: log|v| and the lane's 16 sign bits in sg
   template <int L>
-  __device__ __noinline__ void value(int j, float (&v)[16]) const {
+  __device__ __noinline__ void value(int j, float (&v)[16], uint32_t& sg) const {
+    sg = 0;
     if constexpr (L == 0) {
       const int64_t var = a.scope[a.nodes[a.leaf_off + t * (1 << D) + j]];
       const uint32_t row = min(static_cast<uint32_t>(a.x64[static_cast<int64_t>(bl) * a.D + var]), static_cast<uint32_t>(a.C));
@@ -384,29 +402,40 @@ struct RedoWalk {
       tile_load(a.table + r * kK + 4 * kh, v);
       const float sc = a.scale[r];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = logf(v[q]) + sc;
+      for (int q = 0; q < 16; ++q) {
+        if constexpr (SIGNED) sg |= (v[q] < 0.f ? 1u : 0u) << q;
+        v[q] = logf(SIGNED ? __builtin_fabsf(v[q]) : v[q]) + sc;
+      }
     } else {
       float u[16];
-      value<L - 1>(2 * j, v);
-      value<L - 1>(2 * j + 1, u);
+      uint32_t su = 0;
+      value<L - 1>(2 * j, v, sg);
+      value<L - 1>(2 * j + 1, u, su);
 #pragma unroll
       for (int q = 0; q < 16; ++q) v[q] += u[q];
+      sg ^= su;
       WRegs w;
       load_w<CK_W_ROWMAJOR>(a.w[L - 1] + static_cast<int64_t>(fold(L, j)) * 1024, lane, w);
-      sum_step<CK_W_ROWMAJOR>(w, v);
+      if constexpr (SIGNED) sum_step_signed<CK_W_ROWMAJOR>(w, v, sg);
+      else sum_step<CK_W_ROWMAJOR>(w, v);
     }
   }
 
   template <int L>
   __device__ __noinline__ void backward(int j, const float (&g)[16]) const {
     float e[16], u[16];
-    value<L - 1>(2 * j, e);
-    value<L - 1>(2 * j + 1, u);
+    uint32_t se = 0, su = 0;
+    value<L - 1>(2 * j, e, se);
+    value<L - 1>(2 * j + 1, u, su);
 #pragma unroll
     for (int q = 0; q < 16; ++q) e[q] += u[q];
+    se ^= su;
     const float m = row_max16(e);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) e[q] = live ? expf(e[q] - m) : 0.f;
+    for (int q = 0; q < 16; ++q) {
+      const float x = live ? expf(e[q] - m) : 0.f;
+      e[q] = (SIGNED && ((se >> q) & 1u)) ? -x : x;
+    }
     const float* wf = a.w[L - 1] + static_cast<int64_t>(fold(L, j)) * 1024;
     WRegs w;
     load_w<CK_W_ROWMAJOR>(wf, lane, w);
@@ -415,7 +444,7 @@ struct RedoWalk {
     contract_linear<CK_W_ROWMAJOR>(w, u);  // y = W e
     float gy[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) gy[q] = (live && u[q] > 0.f && g[q] != 0.f) ? g[q] / u[q] : 0.f;
+    for (int q = 0; q < 16; ++q) gy[q] = (live && (SIGNED ? u[q] != 0.f : u[q] > 0.f) && g[q] != 0.f) ? g[q] / u[q] : 0.f;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -442,7 +471,7 @@ struct RedoWalk {
   }
 };
 
-template <int D>
+template <int D, bool SIGNED>
 __global__ void __launch_bounds__(256) leaf_bwd_redo_kernel(const RedoArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[4][2048];
   const int t = blockIdx.x, n_tiles = (a.B + 31) >> 5;
@@ -456,9 +485,12 @@ __global__ void __launch_bounds__(256) leaf_bwd_redo_kernel(const RedoArgs a) {
       const int tile = base + __builtin_ctzll(marked);
       marked &= marked - 1;
       const int b = tile * 32 + (lane & 31);
-      const RedoWalk<D> walk{a, t, lane, lane & 31, lane >> 5, min(b, a.B - 1), b < a.B, lds[wave]};
+      const RedoWalk<D, SIGNED> walk{a, t, lane, lane & 31, lane >> 5, min(b, a.B - 1), b < a.B, lds[wave]};
       float g[16];
-      tile_load(a.gin + (static_cast<int64_t>(walk.fold(D, 0)) * a.B + walk.bl) * kK + 4 * walk.kh, g);
+      if (a.gin_fold != nullptr)  // (tile-native blocks of n_tiles tiles: the gradient arena of ck_signed.hip's layers)
+        tile_load_native(a.gin + (static_cast<int64_t>(a.gin_fold[t]) * n_tiles + tile) * 1024, lane, g);
+      else
+        tile_load(a.gin + (static_cast<int64_t>(walk.fold(D, 0)) * a.B + walk.bl) * kK + 4 * walk.kh, g);
       walk.template backward<D>(0, g);
       if (lane == 0) flags[tile] = 0;
     }
@@ -693,10 +725,15 @@ int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* d, void* stream) {
   const bool leaf = d->leaf != 0;
   CK_REQUIRE(d->waves == 4 || d->waves == 8, "ck_leaf_walk_bwd: waves must be 4 or 8 (got %d)", d->waves);
   const int waves = d->waves;
+  const bool is_signed = d->is_signed != 0;
   dim3 grid(static_cast<unsigned>(std::min(d->n_wg, d->n_seg)));
   return ck::dispatch(
       [=](hipStream_t s) {
-        if (waves == 4) {
+        if (is_signed) {
+          if (waves != 8) return hipErrorInvalidValue;
+          if (leaf) hipLaunchKernelGGL((leaf_bwd_kernel<true, 8, true>), grid, dim3(512), 0, s, a);
+          else hipLaunchKernelGGL((leaf_bwd_kernel<false, 8, true>), grid, dim3(512), 0, s, a);
+        } else if (waves == 4) {
           if (leaf) hipLaunchKernelGGL((leaf_bwd_kernel<true, 4>), grid, dim3(256), 0, s, a);
           else hipLaunchKernelGGL((leaf_bwd_kernel<false, 4>), grid, dim3(256), 0, s, a);
         } else {
@@ -732,7 +769,7 @@ int ck_table_dense_bwd(const float* cat_logits, const int64_t* cat_idx, const fl
 int ck_leaf_walk_bwd_redo(const float* table, const float* table_scale, const int64_t* x_rows, int B, int C, int D,
                           const int32_t* nodes, const int32_t* node_off, int leaf_off, const int64_t* scope, int depth,
                           const float* const* w_levels, float* const* dw_levels, const float* gin, float* gout1, int32_t* redo,
-                          int n_roots, void* stream) {
+                          int n_roots, const int32_t* gin_fold, int is_signed, void* stream) {
   CK_REQUIRE(table && table_scale && x_rows && nodes && node_off && scope && w_levels && dw_levels && gin && gout1 && redo,
              "ck_leaf_walk_bwd_redo: null pointer");
   CK_REQUIRE(B > 0 && C > 0 && D > 0 && n_roots > 0 && n_roots <= 65535, "ck_leaf_walk_bwd_redo: bad sizes");
@@ -754,13 +791,17 @@ int ck_leaf_walk_bwd_redo(const float* table, const float* table_scale, const in
     a.dw[l] = dw_levels[l];
   }
   a.gin = gin;
+  a.gin_fold = gin_fold;
   a.gout1 = gout1;
   a.redo = redo;
   dim3 grid(static_cast<unsigned>(n_roots));
   return ck::dispatch(
       [=](hipStream_t s) {
-        if (depth == 2) hipLaunchKernelGGL((leaf_bwd_redo_kernel<2>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((leaf_bwd_redo_kernel<4>), grid, dim3(256), 0, s, a);
+        if (is_signed) {
+          if (depth == 2) hipLaunchKernelGGL((leaf_bwd_redo_kernel<2, true>), grid, dim3(256), 0, s, a);
+          else hipLaunchKernelGGL((leaf_bwd_redo_kernel<4, true>), grid, dim3(256), 0, s, a);
+        } else if (depth == 2) hipLaunchKernelGGL((leaf_bwd_redo_kernel<2, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((leaf_bwd_redo_kernel<4, false>), grid, dim3(256), 0, s, a);
         return hipGetLastError();
       },
       stream);

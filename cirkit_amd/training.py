@@ -458,7 +458,7 @@ class HipTrainer:
                   (C.c_int32 * (depth + 1))(*g.node_off), g.leaf_off, cat._scope(self.device).data_ptr(), depth,
                   (C.c_void_p * depth)(*[c.layers[j]._w.data_ptr() for j in g.levels]),
                   (C.c_void_p * depth)(*[st["dws"][j].data_ptr() for j in g.levels]),
-                  gviews[g.root].data_ptr(), gin.data_ptr(), redo.data_ptr(), c.layers[g.root].num_folds, stream)
+                  gviews[g.root].data_ptr(), gin.data_ptr(), redo.data_ptr(), c.layers[g.root].num_folds, None, 0, stream)
         # leaves: scatter by category into the gradient of the (F0, C + 1, 32) table T' = dense(log-table) ...
         Cn = cat.num_categories
         dTp = st["dws"][g.input_layer]

@@ -375,17 +375,25 @@ class _SignedCircuit:
         po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
         if self.kind.get(po) not in ("sum", "gather") or c.layers[po].num_output_units != 1:
             return "the output is not a scalar sum unit"
-        # PAIRS of layers evaluated by one launch forward and one backward (ck_slse_pair_fwd / _bwd): a CP-T layer P (32 -> 32) whose
-        # children are ALL the folds of one 32 -> 32 layer Q, each read once -- Q's outputs never reach memory.  Bottom up:
-        # config 5 pairs its first two and its next two layers (94 % of its fold tiles).
-        self.pair_of: dict[int, int] = {}  # P -> Q
-        self.paired_q: set[int] = set()
         import os
 
-        if os.environ.get("CK_SLSE_PAIR", "1") != "0":
+        # The LEAF REGION -- Embedding -> 2 or 4 levels of binary CP-T layers, every fold read once (fusion.find_subtree_groups) -- as
+        # ONE forward launch on signed LINEAR tiles (ck_leaf_walk_fwd, signed + keep_levels: no exponential or logarithm below the
+        # region's roots, the tiles of every second level kept) and one backward launch per two levels (ck_leaf_walk_bwd, is_signed):
+        # what the trainer of real circuits does for Categorical -> CP-T regions (training.py), on values of either sign.
+        self.leaf = self._leaf_region() if os.environ.get("CK_SLSE_LEAF", "1") != "0" else None
+        in_leaf = set(self.leaf.levels) if self.leaf is not None else set()
+        # PAIRS of layers evaluated by one launch forward and one backward (ck_slse_pair_fwd / _bwd): a CP-T layer P (32 -> 32) whose
+        # children are ALL the folds of one 32 -> 32 layer Q, each read once -- Q's outputs never reach memory.  A lab switch
+        # (CK_SLSE_PAIR=1): the backward launch needs 292 registers -- one wave per SIMD -- and loses what the forward gains
+        # (LAB_NOTES R6.4).
+        self.pair_of: dict[int, int] = {}  # P -> Q
+        self.paired_q: set[int] = set()
+
+        if os.environ.get("CK_SLSE_PAIR", "0") == "1":
             outs = {int(p) for p in c._out_pairs[:, 0]}
             for i, l in enumerate(c.layers):
-                if self.kind.get(i) != "sum" or type(l) is not HipCPTLayer or l.arity != 2 or l.num_output_units != 32:
+                if self.kind.get(i) != "sum" or type(l) is not HipCPTLayer or l.arity != 2 or l.num_output_units != 32 or i in in_leaf:
                     continue
                 ch = c._children[i]
                 prods = np.unique(ch[..., 0])
@@ -410,6 +418,81 @@ class _SignedCircuit:
                 if not read.all():
                     return f"layer {i}: Embedding folds that nothing reads"
         return None
+
+    def _leaf_region(self):
+        """The fused leaf region of c (a `fusion.SubtreeGroup` of depth 2 or 4), or None."""
+        from .fusion import find_subtree_groups
+
+        c = self.c
+        for depth in (4, 2):
+            groups = [g for g in find_subtree_groups(c.plan, c.layers, c._children, c._out_pairs, max_depth=depth, signed=True)
+                      if g.depth == depth]
+            if groups:
+                break
+        else:
+            return None
+        if len(groups) != 1:  # (several Embedding layers with a region each: layer by layer)
+            return None
+        g = groups[0]
+        if (self.kind.get(g.input_layer) != "emb" or self.kind.get(g.levels[0]) != "gather"
+                or any(self.kind.get(j) != "sum" for j in g.levels[1:]) or c.layers[g.input_layer].num_states >= 65535):
+            return None
+        return g
+
+    def _bind_leaf(self, st: dict, B: int, Bp: int, parent: dict) -> dict:
+        """Descriptors and buffers of the leaf region's launches at batch size B."""
+        from .fusion import balanced_segments, leaf_segments
+
+        c, g = self.c, self.leaf
+        dev = c.device
+        emb = c.layers[g.input_layer]
+        D, kl, tiles = g.depth, 1 << g.depth, Bp // 32
+        n_roots = c.layers[g.root].num_folds
+        nodes = np.asarray(g.nodes).astype(np.int64)
+        noff = [int(v) for v in g.node_off]
+        var_of_leaf = emb.scope_idx[:, 0].astype(np.int64)
+
+        def lvl(l: int, t: int, j: int) -> int:  # fold of the j-th node of level l under root t (level 0: Embedding folds)
+            return int(nodes[noff[l] + t * (kl >> l) + j])
+
+        # where a root finds the gradient of its output: the block of the fold that reads it, as a block index of the gradient arena
+        gin_block = np.asarray([(st["off"][parent[(g.root, f)][0]] + parent[(g.root, f)][1] * Bp * 32) // (Bp * 32) for f in range(n_roots)],
+                               dtype=np.int32)
+        launches = []  # top first: (unit table, level of P, work segments)
+        for top in range(D, 0, -2):
+            per_root = kl >> top
+            tab = np.zeros((n_roots * per_root, 16), dtype=np.int32)
+            for t in range(n_roots):
+                for j in range(per_root):
+                    r = tab[t * per_root + j]
+                    r[0] = gin_block[lvl(D, t, 0)] if top == D else lvl(top + 1, t, j >> 1)
+                    r[1] = lvl(top, t, j)
+                    r[2], r[3] = lvl(top - 1, t, 2 * j), lvl(top - 1, t, 2 * j + 1)
+                    for i in range(4):
+                        r[4 + i] = lvl(top - 2, t, 4 * j + i)
+                        if top == 2:
+                            r[8 + i] = var_of_leaf[r[4 + i]]
+                    r[12] = t
+            work = balanced_segments(int(tab.shape[0]), tiles, c._n_cu, waves=8)
+            launches.append((torch.from_numpy(tab).to(dev), top, torch.from_numpy(work).to(dev)))
+        nodes_dev = torch.from_numpy(np.ascontiguousarray(g.nodes)).to(dev)
+        scope = emb._scope(dev)
+        node_off_c = (C.c_int32 * (D + 1))(*noff)
+        keep = [torch.empty((c.layers[j].num_folds, tiles, 1024), dtype=torch.float32, device=dev) if l % 2 == 1 else None
+                for l, j in enumerate(g.levels)]
+        return {
+            "launches": launches, "keep": keep,
+            "redo": torch.zeros(n_roots * tiles, dtype=torch.int32, device=dev),
+            "G": [torch.empty((c.layers[g.levels[top - 2]].num_folds, tiles, 1024), dtype=torch.float32, device=dev) if top > 2 else None
+                  for _, top, _ in launches],
+            "nodes": nodes_dev, "node_off": node_off_c, "scope": scope,
+            "scale": torch.zeros((emb.num_folds, emb.num_states + 1), dtype=torch.float32, device=dev),
+            "work": torch.from_numpy(leaf_segments(n_roots, tiles, c._n_cu)).to(dev),
+            "root_tab": c._leaf_root_table(nodes_dev, node_off_c, g.leaf_off, scope, D, n_roots),
+            "x64": torch.zeros((B, max(1, c.plan.num_variables)), dtype=torch.int64, device=dev),
+            "gin_fold": torch.from_numpy(gin_block[[lvl(D, t, 0) for t in range(n_roots)]].copy()).to(dev),
+            "pairs": 1 if c._leaves_in_adjacent_pairs(g) else 0,
+        }
 
     def bind(self, B: int) -> dict:
         st = self._bound.get(B)
@@ -481,6 +564,10 @@ class _SignedCircuit:
                     raise NotImplementedError(f"layer {i}: folds that nothing reads")
                 st["gout_off"][i] = torch.from_numpy(np.asarray(
                     [off[parent[(i, f)][0]] + parent[(i, f)][1] * Bp * 32 for f in range(F)], dtype=np.int64)).to(dev)
+        if self.leaf is not None:
+            if B * max(1, c.plan.num_variables) * 8 >= 2**32 or B * 32 >= 2**31:
+                raise NotImplementedError(f"squared-circuit training: a batch of {B} rows exceeds the 32-bit offsets of the leaf launches")
+            st["leaf"] = self._bind_leaf(st, B, Bp, parent)
         while len(self._bound) >= 4:
             self._bound.pop(next(iter(self._bound)))
         self._bound[B] = st
@@ -500,11 +587,14 @@ class _SignedCircuit:
         st = self.bind(B)
         _, xi = c._prepare_input(x)
         D = c.plan.num_variables
+        x64 = st["leaf"]["x64"] if "leaf" in st else None  # (the leaf launches read the batch as it is: a copy at a recorded address)
         if c.validate_inputs:
             capi.call("ck_stage_categories", xi.data_ptr(), st["xt"].data_ptr(), B, D, c._num_states_dev().data_ptr(),
-                      c._bad_input.data_ptr(), 1 if c._preclamp() else 0, stream)
+                      c._bad_input.data_ptr(), 1 if c._preclamp() else 0, None if x64 is None else x64.data_ptr(), stream)
         else:
             capi.call("ck_transpose_i64_to_i32", xi.data_ptr(), st["xt"].data_ptr(), B, D, stream)
+            if x64 is not None:
+                x64.copy_(xi)
 
     def _args(self, st: dict, i: int):
         c = self.c
@@ -528,6 +618,10 @@ class _SignedCircuit:
                 continue
             if i in self.paired_q:  # (evaluated inside the launch of the layer above it)
                 continue
+            if self.leaf is not None and i in self.leaf.levels:  # (the whole region with the launch of its first level)
+                if i == self.leaf.levels[0]:
+                    self._leaf_forward(st, B, stream)
+                continue
             o = st["off"][i]
             if i in self.pair_of:
                 qi = self.pair_of[i]
@@ -541,6 +635,55 @@ class _SignedCircuit:
         if c.validate_inputs and c._int_input:
             y = self.output(B)
             capi.call("ck_poison_outputs", y.data_ptr(), B, c._bad_input.data_ptr(), stream)
+
+    def _leaf_forward(self, st: dict, B: int, stream: int) -> None:
+        c, g, L = self.c, self.leaf, st["leaf"]
+        emb = c.layers[g.input_layer]
+        o = st["off"][g.root]
+        d = capi.LeafLaunch()
+        d.table, d.table_scale, d.scope = emb._table.data_ptr(), L["scale"].data_ptr(), L["scope"].data_ptr()
+        d.w_levels = (C.c_void_p * g.depth)(*[c.store[self.wname[j]].data_ptr() for j in g.levels])
+        d.nodes, d.node_off, d.leaf_off = L["nodes"].data_ptr(), L["node_off"], g.leaf_off
+        d.out, d.signs_out = st["arena"].data_ptr() + 4 * o, st["signs"].data_ptr() + 4 * (o // 32)
+        d.work, d.n_seg, d.n_wg, d.waves, d.depth = L["work"].data_ptr(), int(L["work"].shape[0]), c._n_cu, 8, g.depth
+        d.B, d.K, d.C, d.w_layout = B, 32, emb.num_states, capi.CK_W_ROWMAJOR
+        d.signed_redo = d.keep_redo = L["redo"].data_ptr()
+        d.n_roots, d.root_tab = c.layers[g.root].num_folds, L["root_tab"].data_ptr()
+        d.xt, d.preclamped, d.D, d.x_rows, d.x_input = None, 0, c.plan.num_variables, L["x64"].data_ptr(), -1
+        d.bad_input = c._bad_input.data_ptr() if c.validate_inputs else None
+        d.x_pairs = L["pairs"]
+        d.keep_levels = (C.c_void_p * g.depth)(*[None if t is None else t.data_ptr() for t in L["keep"]])
+        capi.call("ck_leaf_walk_fwd", C.byref(d), stream)
+
+    def _leaf_backward(self, st: dict, B: int, stream: int) -> None:
+        c, g, L = self.c, self.leaf, st["leaf"]
+        emb = c.layers[g.input_layer]
+        ga = st["garena"].data_ptr()
+        gout1 = ga + 4 * st["off"][g.levels[0]]  # (F_1, B, 32) row-major: what ck_embedding_bwd scatters
+        gin = ga
+        for k, (tab, top, work) in enumerate(L["launches"]):
+            lp, lq = g.levels[top - 1], g.levels[top - 2]
+            d = capi.LeafBwdLaunch()
+            d.unit_tab, d.work, d.n_seg, d.n_wg, d.B, d.waves = tab.data_ptr(), work.data_ptr(), int(work.shape[0]), c._n_cu, B, 8
+            d.C, d.D, d.leaf, d.is_signed = emb.num_states, c.plan.num_variables, 1 if top == 2 else 0, 1
+            d.gin, d.gin_rowmajor = gin, 0
+            d.y_p = L["keep"][top - 1].data_ptr()
+            if top == 2:
+                d.table, d.x_rows = emb._table.data_ptr(), L["x64"].data_ptr()
+            else:
+                d.y_c = L["keep"][top - 3].data_ptr()
+            d.w_p, d.w_q = c.store[self.wname[lp]].data_ptr(), c.store[self.wname[lq]].data_ptr()
+            d.dw_p, d.dw_q = self.grads[self.wname[lp]].data_ptr(), self.grads[self.wname[lq]].data_ptr()
+            d.gout = gout1 if top == 2 else L["G"][k].data_ptr()
+            d.redo = L["redo"].data_ptr()
+            capi.call("ck_leaf_walk_bwd", C.byref(d), stream)
+            gin = d.gout
+        # (root, tile) units whose forward walk left the linear range: in signed log space, by a launch in which every other wave exits
+        capi.call("ck_leaf_walk_bwd_redo", emb._table.data_ptr(), L["scale"].data_ptr(), L["x64"].data_ptr(), B, emb.num_states,
+                  c.plan.num_variables, L["nodes"].data_ptr(), L["node_off"], g.leaf_off, L["scope"].data_ptr(), g.depth,
+                  (C.c_void_p * g.depth)(*[c.store[self.wname[j]].data_ptr() for j in g.levels]),
+                  (C.c_void_p * g.depth)(*[self.grads[self.wname[j]].data_ptr() for j in g.levels]),
+                  ga, gout1, L["redo"].data_ptr(), c.layers[g.root].num_folds, L["gin_fold"].data_ptr(), 1, stream)
 
     def backward(self, B: int, seed: float, stream: int) -> None:
         """Gradients of ``seed * sum_b log|c(x_b)|`` ADDED into `grads` (the Embedding weights': written)."""
@@ -558,6 +701,10 @@ class _SignedCircuit:
                           l._table.data_ptr(), self.grads[self.wname[i]].data_ptr(), l.num_folds, B, 32, l.num_states, stream)
                 continue
             if i in self.paired_q:  # (its gradient block and weight gradient were left by the launch of the layer above it)
+                continue
+            if self.leaf is not None and i in self.leaf.levels:  # (the whole region when its root layer is reached)
+                if i == self.leaf.root:
+                    self._leaf_backward(st, B, stream)
                 continue
             o = st["off"][i]
             if i in self.pair_of:

@@ -77,9 +77,10 @@ int ck_transpose_i64_to_i32(const int64_t* x, int32_t* xt, int B, int D, void* s
  * the host when it next looks (HipCircuit.check_inputs).  Negative values stay what they are for this library: the
  * "marginalised variable" sentinel of the integral row.  clamp != 0: checked variables are stored range-mapped --
  * min(x, n - 1), or -1 for any negative x, n = num_states[d] -- which every consumer's own mapping leaves unchanged and
- * lets the persistent leaf launch (preclamped) turn a value into its table row with one unsigned minimum. */
+ * lets the persistent leaf launch (preclamped) turn a value into its table row with one unsigned minimum.  x_copy: NULL, or
+ * (B, D) int64: the batch as it is, at an address recorded launches keep reading (ck_leaf_walk_fwd / _bwd x_rows). */
 int ck_stage_categories(const int64_t* x, int32_t* xt, int B, int D, const int32_t* num_states, int32_t* flag, int clamp,
-                        void* stream);
+                        int64_t* x_copy, void* stream);
 /* out[0..n) = NaN if *flag != 0 (one small launch; circuits whose last launch is ck_tail16_lse_fwd do not need it). */
 int ck_poison_outputs(float* out, int64_t n, const int32_t* flag, void* stream);
 /* p[0..n) = 0 if *flag != 0: the gradients of a batch that held an illegal category are dropped before the optimizer
@@ -378,6 +379,10 @@ typedef struct ck_leaf_launch {
                                                nodes[node_off[0] + t 2^depth + i], then the folds of the root's 2^depth - 1 nodes in the
                                                order of the walk's steps (rest of the row unused): one load round at the start of a
                                                segment instead of three dependent ones */
+  uint32_t* signs_out;                      /* signed launches: NULL, or DEVICE (n_roots, Bp) sign words, Bp = 32 ceil(B / 32): `out` is
+                                               then a SIGNED-LOG block (ck_slse_fwd: (n_roots, Bp, 32) fp32 log|v| in tile-native order,
+                                               bit k of a row's word = unit k is negative) instead of (n_roots, B, 32) complex64.  With
+                                               keep_levels (signed_redo == keep_redo): the forward of a squared circuit's training step */
 } ck_leaf_launch;
 int ck_leaf_walk_fwd(const ck_leaf_launch* desc, void* stream);
 
@@ -658,6 +663,9 @@ typedef struct ck_leaf_bwd_launch {
   float* dw_q;
   float* gout;
   const int32_t* redo;
+  int32_t is_signed;  /* != 0: the tiles of ck_leaf_walk_fwd's SIGNED training forward (signs_out + keep_levels): linear values of either
+                         sign, gradients w.r.t. log|.|; waves must be 8 */
+  int32_t reserved;
 } ck_leaf_bwd_launch;
 int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* desc, void* stream);
 /* Backward of a circuit's trailing few-fold sum layers in ONE launch (cirkit_amd/csrc/ck_tail_bwd.hip): what autograd does
@@ -692,11 +700,13 @@ int ck_table_dense_bwd(const float* cat_logits, const int64_t* cat_idx, const fl
  * semiring.py:383-408, forward values recomputed -- adds the weight gradients of every level (dw_levels[l - 1], row-major,
  * float atomics), writes the gradient tiles of the level-1 nodes into gout1 (where the leaf launch of ck_leaf_walk_bwd
  * leaves them) and clears the mark.  Unmarked units exit at once.  table / table_scale / nodes / node_off / leaf_off /
- * scope as ck_leaf_walk_fwd; w_levels, dw_levels: HOST arrays of `depth` DEVICE pointers; gin: (F_root, B, 32). */
+ * scope as ck_leaf_walk_fwd; w_levels, dw_levels: HOST arrays of `depth` DEVICE pointers; gin: (F_root, B, 32) -- or,
+ * gin_fold != NULL, a tile-native array of (ceil(B / 32), 1024) blocks of which block gin_fold[t] (DEVICE, n_roots) is root t's.
+ * is_signed != 0: the tiles of a SIGNED training forward (values (log|v|, sign) as semiring.py:441-476 carries a real number). */
 int ck_leaf_walk_bwd_redo(const float* table, const float* table_scale, const int64_t* x_rows, int B, int C, int D,
                           const int32_t* nodes, const int32_t* node_off, int leaf_off, const int64_t* scope, int depth,
                           const float* const* w_levels, float* const* dw_levels, const float* gin, float* gout1, int32_t* redo,
-                          int n_roots, void* stream);
+                          int n_roots, const int32_t* gin_fold, int is_signed, void* stream);
 /* softmax parameter backward over the last axis: dtheta = W * (dW - sum(W*dW)). */
 int ck_param_softmax_bwd(const float* w, const float* dw, float* dtheta, int64_t rows, int len,
                          int accumulate, void* stream);

@@ -192,7 +192,7 @@ def test_stage_categories(hip_device, B, D, clamp):
         xt = torch.full((D, B), -7, dtype=torch.int32, device=hip_device)
         flag = torch.zeros(1, dtype=torch.int32, device=hip_device)
         xd, nsd = xx.to(hip_device), ns.to(hip_device)
-        capi.call("ck_stage_categories", xd.data_ptr(), xt.data_ptr(), B, D, nsd.data_ptr(), flag.data_ptr(), clamp, stream)
+        capi.call("ck_stage_categories", xd.data_ptr(), xt.data_ptr(), B, D, nsd.data_ptr(), flag.data_ptr(), clamp, None, stream)
         torch.cuda.synchronize()
         want = xx.t().clone()
         if clamp:

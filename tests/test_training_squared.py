@@ -67,14 +67,20 @@ def test_squared_circuit_training_steps_increase_the_likelihood(hip_device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("signed", [False, True])
-def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_device, signed):
+@pytest.mark.parametrize("signed", [False, True, "layers"])
+def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_device, signed, monkeypatch):
     """BASELINE config 5 (QuadTree 28x28, Embedding-256, CP-T, K = 32; Z from its own plan): the gradients of 32 rows against
     torch autograd through the oracle's restatement of the reference forward (bit-identical to the reference on CPU).
     signed: c(x) on signed-log blocks (ck_signed.hip: fp32 log|v| + a sign bit, Embedding rows gathered by the first sum
-    layer) instead of the complex layer-wise launch list -- what the trainer picks by itself for this circuit."""
+    layer) instead of the complex layer-wise launch list -- what the trainer picks by itself for this circuit, with the
+    Embedding -> four CP-T levels region on signed LINEAR tiles (one forward launch with kept tiles, two backward launches:
+    `ck_leaf_walk_fwd / _bwd` signed); "layers": every signed-log layer a launch of its own (`CK_SLSE_LEAF=0`)."""
     from cirkit_amd.training_squared import HipSquaredTrainer
     from oracle import torch_oracle as oracle  # (tests may: the oracle is the checker)
+
+    if signed == "layers":
+        monkeypatch.setenv("CK_SLSE_LEAF", "0")
+        signed = True
 
     plan_c, plan_z = Plan.load(os.path.join(GOLDEN, "cfg5_sos_c_k32")), Plan.load(os.path.join(GOLDEN, "cfg5_sos_z_k32"))
     tensors = init_plan_tensors(plan_c)
@@ -88,6 +94,9 @@ def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_d
     loss.backward()
     tr = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device, signed=signed)
     assert (tr._signed is not None) == signed
+    if signed:
+        leaf = tr._signed.leaf
+        assert (leaf is None) == (os.environ.get("CK_SLSE_LEAF") == "0") and (leaf is None or leaf.depth == 4)
     assert HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)._signed is not None  # (the default for this circuit)
     for _ in range(4):  # (eager, eager, recorded, replayed: the same numbers every time)
         ll = tr.loss_and_grads(x.to(hip_device)).cpu().numpy()
@@ -97,6 +106,89 @@ def test_squared_trainer_on_baseline_config_5_against_the_oracles_autograd(hip_d
             want = leaves[k].grad.numpy()
             err = float(np.abs(got[k] - want).max())
             assert err <= 2e-3 * max(1e-6, float(np.abs(want).max())), (k, err, float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [300, 4096])
+def test_leaf_region_on_linear_tiles_agrees_with_the_layer_launches(hip_device, rows, monkeypatch):
+    """Config 5's c(x): Embedding -> four CP-T levels in ONE forward launch on signed linear tiles (kept tiles of levels 2 and
+    4) and two backward launches, against one signed-log launch per layer (`CK_SLSE_LEAF=0`) -- other arithmetic (products
+    renormalised by powers of two instead of exp / log per layer), so values agree to rounding: log|c(x)| per row, the
+    log-likelihood, every gradient (against the layer-wise one, in the norm: a batch holds rows whose c(x) nearly cancels and
+    amplifies rounding, LAB_NOTES R5.3); 300 rows: a ragged last tile; eager and recorded launches give the same numbers."""
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    plan_c, plan_z = Plan.load(os.path.join(GOLDEN, "cfg5_sos_c_k32")), Plan.load(os.path.join(GOLDEN, "cfg5_sos_z_k32"))
+    tensors = init_plan_tensors(plan_c)
+    tensors = {k: np.where(v == 0, np.float32(1e-2), v).astype(np.float32) for k, v in tensors.items()}
+    x = torch.randint(0, 256, (rows, 784), generator=torch.Generator().manual_seed(6)).to(hip_device)
+    a = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)
+    monkeypatch.setenv("CK_SLSE_LEAF", "0")
+    b = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)
+    assert a._signed.leaf is not None and a._signed.leaf.depth == 4 and b._signed.leaf is None
+    lb = b.loss_and_grads(x).cpu().numpy()
+    yb, gb = b._signed.output(rows).cpu().double(), b.gradients()
+    for it in range(4):  # (eager, eager, recorded, replayed)
+        la = a.loss_and_grads(x).cpu().numpy()
+        ya = a._signed.output(rows).cpu().double()
+        assert bool(torch.isfinite(ya).all())
+        dy = (ya - yb).abs()  # (log|c| ~ 1300: 1e-7 relative is 1e-4; a row whose c(x) nearly cancels shows the amplified rounding)
+        assert float(dy.median()) <= 5e-4 and float((dy > 1e-2).double().mean()) <= 0.01, (it, float(dy.median()), float(dy.max()))
+        assert la[1] == lb[1] == rows and abs(la[0] - lb[0]) <= 1e-5 * abs(lb[0]), (la, lb)
+        ga = a.gradients()
+        for k in tensors:
+            d, n = float(np.linalg.norm((ga[k] - gb[k]).astype(np.float64))), float(np.linalg.norm(gb[k].astype(np.float64)))
+            assert d <= 2e-2 * n + 1e-12, (it, k, d, n)
+    assert int(a._signed.bind(rows)["leaf"]["redo"].sum()) == 0  # (no tile left the linear range)
+
+
+@pytest.mark.gpu
+def test_leaf_region_tiles_that_leave_the_linear_range(hip_device, monkeypatch):
+    """Embedding rows whose large units do not overlap: the products of the first levels fall below the linear floor, the
+    forward marks such (root, tile) units and evaluates them in signed log space (`leaf_signed_redo_kernel`), the backward
+    launches skip their kept tiles and `ck_leaf_walk_bwd_redo` (is_signed) walks them -- same values and gradients as the
+    layer-wise launch list, marks cleared."""
+    from cirkit_amd.templates import image_data
+    from cirkit_amd.training_squared import HipSquaredTrainer
+
+    plan_c = image_data((1, 8, 8), "quad-tree-2", input_layer="embedding", num_input_units=32, sum_product_layer="cp-t", num_sum_units=32,
+                        sum_weight_activation="none", semiring="complex-lse-sum")
+    tensors = init_plan_tensors(plan_c, seed=3)
+    emb = next(n.config["tensor"] for sp in plan_c.layers if sp.type == "embedding" for n in sp.params["weight"].nodes if n.op == "tensor")
+    w = tensors[emb].copy()  # (F, 32, C)
+    half = np.arange(32) < 16
+    var = np.arange(w.shape[0]) % 2 == 0
+    w[np.ix_(var, half, [0, 1])] *= 1e-20   # states 0 / 1 of even variables live on the upper units, of odd ones on the lower
+    w[np.ix_(~var, ~half, [0, 1])] *= 1e-20
+    tensors = {k: np.where(v == 0, np.float32(1e-2), v).astype(np.float32) for k, v in {**tensors, emb: w}.items()}
+    B = 200
+    x = torch.randint(0, 4, (B, 64), generator=torch.Generator().manual_seed(2)).to(hip_device)
+    a = HipSquaredTrainer(plan_c, tensors, device=hip_device)
+    monkeypatch.setenv("CK_SLSE_LEAF", "0")
+    b = HipSquaredTrainer(plan_c, tensors, device=hip_device)
+    assert a._signed is not None and a._signed.leaf is not None and b._signed.leaf is None
+    stream = torch.cuda.current_stream().cuda_stream
+    a._signed.stage(x, stream)
+    a._signed.forward(B, stream)
+    marks = a._signed.bind(B)["leaf"]["redo"]
+    assert int(marks.sum()) > 0  # (the case this test is about)
+    a._flat_grad.zero_()
+    a._signed.backward(B, -2.0 / B, stream)
+    torch.cuda.synchronize()
+    assert int(marks.sum()) == 0
+    lb = b.loss_and_grads(x)
+    ya, yb = a._signed.output(B).cpu().double(), b._signed.output(B).cpu().double()
+    assert bool(torch.isfinite(ya).all()) and float((ya - yb).abs().max()) <= 1e-3
+    b2 = HipSquaredTrainer(plan_c, tensors, device=hip_device)  # (c's gradient alone, layer by layer)
+    b2._signed.stage(x, stream)
+    b2._signed.forward(B, stream)
+    b2._flat_grad.zero_()
+    b2._signed.backward(B, -2.0 / B, stream)
+    torch.cuda.synchronize()
+    for k in tensors:
+        ga, gb = a.grads[k].double().cpu(), b2.grads[k].double().cpu()
+        assert bool(torch.isfinite(ga).all()), k
+        assert float((ga - gb).norm()) <= 2e-2 * float(gb.norm()) + 1e-12, (k, float((ga - gb).norm()), float(gb.norm()))
 
 
 @pytest.mark.gpu
@@ -112,10 +204,12 @@ def test_layer_pairs_in_one_launch_equal_the_layer_launches(hip_device, rows, mo
     tensors = init_plan_tensors(plan_c)
     tensors = {k: np.where(v == 0, np.float32(1e-2), v).astype(np.float32) for k, v in tensors.items()}
     x = torch.randint(0, 256, (rows, 784), generator=torch.Generator().manual_seed(6)).to(hip_device)
+    monkeypatch.setenv("CK_SLSE_LEAF", "0")  # (the launches this test is about are a lab switch: the leaf region takes these layers)
+    monkeypatch.setenv("CK_SLSE_PAIR", "1")
     a = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)
     monkeypatch.setenv("CK_SLSE_PAIR", "0")
     b = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)
-    assert a._signed is not None and len(a._signed.pair_of) == 2 and not b._signed.pair_of
+    assert a._signed is not None and len(a._signed.pair_of) >= 2 and not b._signed.pair_of
     for _ in range(2):  # (eager, then recorded)
         la, lb = a.loss_and_grads(x).cpu().numpy(), b.loss_and_grads(x).cpu().numpy()
     torch.cuda.synchronize()
