@@ -509,13 +509,15 @@ __global__ void __launch_bounds__(256)
   extern __shared__ float tw_s[];  // [32][C + 1]
   const int f = blockIdx.x, ld = C + 1;
   const float* wf = weight + static_cast<int64_t>(f) * 32 * C;
-  for (int i = threadIdx.x; i < 32 * C; i += 256) tw_s[(i / C) * ld + i % C] = wf[i];
+  for (int k = threadIdx.x >> 6; k < 32; k += 4)  // (a wave per unit: no division by C)
+    for (int c = threadIdx.x & 63; c < C; c += 64) tw_s[k * ld + c] = wf[k * C + c];
   __syncthreads();
   const int64_t row0 = static_cast<int64_t>(f) * (C + 1);
   for (int i = threadIdx.x; i < (C + 1) * 32; i += 256) {  // (a half-wave per row of 32 units)
     const int c = i >> 5, k = i & 31;
     const float w = c < C ? tw_s[k * ld + c] : 1.f;
     table[row0 * 32 + i] = w;
+    if (ltab == nullptr) continue;  // (uniform: the linear table alone -- the leaf region reads no other)
     ltab[row0 * 32 + i] = logf(fabsf(w));
     uint32_t bit = w < 0.f ? (1u << k) : 0u;
 #pragma unroll
@@ -555,7 +557,7 @@ extern "C" int ck_slse_table(const float* table, float* log_table, uint32_t* tab
 }
 
 extern "C" int ck_slse_tables(const float* weight, float* table, float* log_table, uint32_t* table_signs, int F, int C, void* stream) {
-  CK_REQUIRE(weight && table && log_table && table_signs && F > 0 && C > 0, "ck_slse_tables: bad arguments");
+  CK_REQUIRE(weight && table && (log_table != nullptr) == (table_signs != nullptr) && F > 0 && C > 0, "ck_slse_tables: bad arguments");
   const size_t lds = static_cast<size_t>(32) * (C + 1) * sizeof(float);
   if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_slse_tables: %d states do not fit in LDS", C);
   return ck::dispatch(

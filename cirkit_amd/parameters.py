@@ -446,7 +446,7 @@ class HipParameter:
                 mean = n.op == "gaussian_product_mean"
                 m1, s1, m2, s2 = ops if mean else (None, ops[0], None, ops[1])
                 F, K1, K2 = int(s1.shape[0]), int(s1.shape[1]), int(s2.shape[1])
-                y = self._buf(j, (F, *shape))
+                y = self._buf(j, shape)  # ((F, K1 K2): `shape` holds the fold axis already)
                 capi.call("ck_param_gaussian_product_ms", 0 if mean else 1, None if m1 is None else _ptr(m1), _ptr(s1),
                           None if m2 is None else _ptr(m2), _ptr(s2), _ptr(y), F, K1, K2, stream)
             elif n.op == "gaussian_product_log_partition":  # nodes.py:975-988

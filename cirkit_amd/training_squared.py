@@ -24,6 +24,7 @@ read by exactly one consumer (trees: what `squared_partition_plan` and the regio
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Mapping
 
 import numpy as np
@@ -209,8 +210,10 @@ class _PlanBackward:
         e = 2 if cplx else 1
         esz = 4 * e
         po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
-        capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel() * e, 0.0, stream)
-        capi.call("ck_fill_strided_f32", gviews[po][fo].data_ptr(), B, e, float(seed_real), stream)  # (Re = seed, Im = 0)
+        if st.get("seed_key") != float(seed_real):  # (the output layer's gradient is read, never written: once per binding and seed)
+            capi.call("ck_fill_f32", gviews[po].data_ptr(), gviews[po].numel() * e, 0.0, stream)
+            capi.call("ck_fill_strided_f32", gviews[po][fo].data_ptr(), B, e, float(seed_real), stream)  # (Re = seed, Im = 0)
+            st["seed_key"] = float(seed_real)
         ga, aa = garena.data_ptr(), bd.arena.data_ptr()
         pool = self._weight_pool(st)
         capi.call("ck_fill_f32", pool.data_ptr(), pool.numel(), 0.0, stream)
@@ -443,10 +446,13 @@ class _SignedCircuit:
         """Descriptors and buffers of the leaf region's launches at batch size B."""
         from .fusion import balanced_segments, leaf_segments
 
+        import os
+
         c, g = self.c, self.leaf
         dev = c.device
         emb = c.layers[g.input_layer]
         D, kl, tiles = g.depth, 1 << g.depth, Bp // 32
+        n_wg = max(8, c._n_cu - int(os.environ.get("CK_SQ_RESERVE_CUS", "0")))
         n_roots = c.layers[g.root].num_folds
         nodes = np.asarray(g.nodes).astype(np.int64)
         noff = [int(v) for v in g.node_off]
@@ -473,7 +479,7 @@ class _SignedCircuit:
                         if top == 2:
                             r[8 + i] = var_of_leaf[r[4 + i]]
                     r[12] = t
-            work = balanced_segments(int(tab.shape[0]), tiles, c._n_cu, waves=8)
+            work = balanced_segments(int(tab.shape[0]), tiles, n_wg, waves=8)
             launches.append((torch.from_numpy(tab).to(dev), top, torch.from_numpy(work).to(dev)))
         nodes_dev = torch.from_numpy(np.ascontiguousarray(g.nodes)).to(dev)
         scope = emb._scope(dev)
@@ -487,7 +493,7 @@ class _SignedCircuit:
                   for _, top, _ in launches],
             "nodes": nodes_dev, "node_off": node_off_c, "scope": scope,
             "scale": torch.zeros((emb.num_folds, emb.num_states + 1), dtype=torch.float32, device=dev),
-            "work": torch.from_numpy(leaf_segments(n_roots, tiles, c._n_cu)).to(dev),
+            "work": torch.from_numpy(leaf_segments(n_roots, tiles, n_wg)).to(dev), "n_wg": n_wg,
             "root_tab": c._leaf_root_table(nodes_dev, node_off_c, g.leaf_off, scope, D, n_roots),
             "x64": torch.zeros((B, max(1, c.plan.num_variables)), dtype=torch.int64, device=dev),
             "gin_fold": torch.from_numpy(gin_block[[lvl(D, t, 0) for t in range(n_roots)]].copy()).to(dev),
@@ -613,8 +619,9 @@ class _SignedCircuit:
                 if l._table is None or l._table.dtype != torch.float32:
                     l.prepare(stream, batched=False)  # (allocates the table; first call only)
                 ltab, tsg = st["ltab"][i]
-                capi.call("ck_slse_tables", c.store[self.wname[i]].data_ptr(), l._table.data_ptr(), ltab.data_ptr(), tsg.data_ptr(),
-                          l.num_folds, l.num_states, stream)
+                in_region = self.leaf is not None and i == self.leaf.input_layer  # (the leaf launches read the linear table only)
+                capi.call("ck_slse_tables", c.store[self.wname[i]].data_ptr(), l._table.data_ptr(), None if in_region else ltab.data_ptr(),
+                          None if in_region else tsg.data_ptr(), l.num_folds, l.num_states, stream)
                 continue
             if i in self.paired_q:  # (evaluated inside the launch of the layer above it)
                 continue
@@ -632,7 +639,7 @@ class _SignedCircuit:
             ro, *gather = self._args(st, i)
             capi.call("ck_slse_fwd", a, sg, ro, c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32),
                       l.num_folds, l.arity, B, l.num_output_units, *gather, stream)
-        if c.validate_inputs and c._int_input:
+        if c.validate_inputs and c._int_input and self.leaf is None:  # (the leaf launch checks the rows it reads: theirs are NaN)
             y = self.output(B)
             capi.call("ck_poison_outputs", y.data_ptr(), B, c._bad_input.data_ptr(), stream)
 
@@ -645,7 +652,7 @@ class _SignedCircuit:
         d.w_levels = (C.c_void_p * g.depth)(*[c.store[self.wname[j]].data_ptr() for j in g.levels])
         d.nodes, d.node_off, d.leaf_off = L["nodes"].data_ptr(), L["node_off"], g.leaf_off
         d.out, d.signs_out = st["arena"].data_ptr() + 4 * o, st["signs"].data_ptr() + 4 * (o // 32)
-        d.work, d.n_seg, d.n_wg, d.waves, d.depth = L["work"].data_ptr(), int(L["work"].shape[0]), c._n_cu, 8, g.depth
+        d.work, d.n_seg, d.n_wg, d.waves, d.depth = L["work"].data_ptr(), int(L["work"].shape[0]), L["n_wg"], 8, g.depth
         d.B, d.K, d.C, d.w_layout = B, 32, emb.num_states, capi.CK_W_ROWMAJOR
         d.signed_redo = d.keep_redo = L["redo"].data_ptr()
         d.n_roots, d.root_tab = c.layers[g.root].num_folds, L["root_tab"].data_ptr()
@@ -664,7 +671,7 @@ class _SignedCircuit:
         for k, (tab, top, work) in enumerate(L["launches"]):
             lp, lq = g.levels[top - 1], g.levels[top - 2]
             d = capi.LeafBwdLaunch()
-            d.unit_tab, d.work, d.n_seg, d.n_wg, d.B, d.waves = tab.data_ptr(), work.data_ptr(), int(work.shape[0]), c._n_cu, B, 8
+            d.unit_tab, d.work, d.n_seg, d.n_wg, d.B, d.waves = tab.data_ptr(), work.data_ptr(), int(work.shape[0]), L["n_wg"], B, 8
             d.C, d.D, d.leaf, d.is_signed = emb.num_states, c.plan.num_variables, 1 if top == 2 else 0, 1
             d.gin, d.gin_rowmajor = gin, 0
             d.y_p = L["keep"][top - 1].data_ptr()
@@ -690,9 +697,11 @@ class _SignedCircuit:
         c, st = self.c, self.bind(B)
         a, sg, ga = st["arena"].data_ptr(), st["signs"].data_ptr(), st["garena"].data_ptr()
         po, fo = int(c._out_pairs[0, 0]), int(c._out_pairs[0, 1])
-        if c.layers[po].num_folds > 1:
-            capi.call("ck_fill_f32", st["seed"].data_ptr(), st["seed"].numel(), 0.0, stream)
-        capi.call("ck_fill_f32", st["seed"].data_ptr() + 4 * fo * B, B, float(seed), stream)
+        if st.get("seed_key") != float(seed):  # (nobody writes this block: filled once per binding and seed, outside the recorded lists)
+            if c.layers[po].num_folds > 1:
+                capi.call("ck_fill_f32", st["seed"].data_ptr(), st["seed"].numel(), 0.0, stream)
+            capi.call("ck_fill_f32", st["seed"].data_ptr() + 4 * fo * B, B, float(seed), stream)
+            st["seed_key"] = float(seed)
         for i in reversed(list(self.kind)):
             l, k = c.layers[i], self.kind[i]
             if k == "emb":

@@ -791,7 +791,8 @@ int ck_embedding_bwd(const float* gout, int gout_stride, const int32_t* gfold, c
  * (F, B, 32) ROW-MAJOR (ck_embedding_bwd's gfold scatters rows); dw (F, Ko, 32) += (float atomics: zero it first). */
 int ck_slse_table(const float* table, float* log_table, uint32_t* table_signs, int64_t rows, void* stream);
 /* ... or all three tables of an Embedding layer of 32 units from its weight (F, 32, C) (layers/input.py:258-266) in one launch:
- * table (F, C + 1, 32) (the transposed weight, row C the integral row of ones), its signed-log form and sign words. */
+ * table (F, C + 1, 32) (the transposed weight, row C the integral row of ones), its signed-log form and sign words (both NULL:
+ * the linear table alone -- what ck_leaf_walk_fwd's signed launch reads). */
 int ck_slse_tables(const float* weight, float* table, float* log_table, uint32_t* table_signs, int F, int C, void* stream);
 /* TWO such layers in one launch: a CP-T layer P (F_P folds, 32 -> 32, two children each) over the folds q_fold[f, 0 / 1] of ONE
  * layer Q (32 -> 32, H_Q children per fold: arena blocks at ro_q (F_Q, H_Q), or -- log_table != NULL -- Embedding table rows,
