@@ -363,7 +363,9 @@ __global__ void __launch_bounds__(256)
 // W W^T of a squared circuit: (32, 32) outputs over 256 entries, 27 us for 784 folds -- 128 MFMAs per fold here).
 // Extents: multiples of 32 (the launcher falls back otherwise).  Order of the sum: chunks of 32 in order, inside a chunk the
 // pairs (s, 16 + s) -- not the tile kernels' order (fp32 rounding differs in the last bits).
-template <bool TA, bool TB>
+// TA = 2: the A operand SYMMETRISED, A[m][k] = a[m][k] + a[k][m] (M = Kd): both operand gradients of a Gram product y = x x^T
+// in one launch, d x = (d y + d y^T) x.
+template <int TA, bool TB>
 __global__ void __launch_bounds__(64)
     bmm_mfma_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int M, int N, int Kd, int accumulate) {
   const int64_t f = blockIdx.z;
@@ -374,7 +376,16 @@ __global__ void __launch_bounds__(64)
   float av[16], bv[16], an[16], bn[16];
   auto fetch = [&](int k0, float (&x)[16], float (&y)[16]) {
     const int kb = k0 + 16 * kh;
-    if (TA) {  // a[k][m]
+    if (TA == 2) {  // a[m][k] + a[k][m]
+      const float4* p = reinterpret_cast<const float4*>(af + static_cast<int64_t>(m0 + i32) * Kd + kb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = p[q];
+        x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) x[s2] += af[static_cast<int64_t>(kb + s2) * M + m0 + i32];
+    } else if (TA == 1) {  // a[k][m]
 #pragma unroll
       for (int s2 = 0; s2 < 16; ++s2) x[s2] = af[static_cast<int64_t>(kb + s2) * M + m0 + i32];
     } else {   // a[m][k]
@@ -1441,15 +1452,18 @@ int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N
   CK_REQUIRE(a && b && out, "ck_param_bmm: null pointer");
   CK_REQUIRE(F > 0 && M > 0 && N > 0 && Kd > 0, "ck_param_bmm: non-positive size");
   CK_REQUIRE(F <= 65535, "ck_param_bmm: F exceeds grid.z");
+  if (trans_a == 2 && !(M == Kd && (M & 31) == 0 && (N & 31) == 0 && ck::aligned16(a) && ck::aligned16(b)))
+    return ck::fail(CK_ERR_UNSUPPORTED, "ck_param_bmm: the symmetrised form (trans_a = 2) needs M = Kd and extents that are multiples of 32");
   if ((M & 31) == 0 && (N & 31) == 0 && (Kd & 31) == 0 && ck::aligned16(a) && ck::aligned16(b) && N <= 65535 * 32 && M <= 65535 * 32) {
     dim3 grid(N / 32, M / 32, F), block(64);
     return ck::dispatch(
         [=](hipStream_t s) {
           auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, a, b, out, M, N, Kd, accumulate); };
-          if (trans_a && trans_b) go(bmm_mfma_kernel<true, true>);
-          else if (trans_a) go(bmm_mfma_kernel<true, false>);
-          else if (trans_b) go(bmm_mfma_kernel<false, true>);
-          else go(bmm_mfma_kernel<false, false>);
+          if (trans_a == 2) trans_b ? go(bmm_mfma_kernel<2, true>) : go(bmm_mfma_kernel<2, false>);
+          else if (trans_a && trans_b) go(bmm_mfma_kernel<1, true>);
+          else if (trans_a) go(bmm_mfma_kernel<1, false>);
+          else if (trans_b) go(bmm_mfma_kernel<0, true>);
+          else go(bmm_mfma_kernel<0, false>);
           return hipGetLastError();
         },
         stream);

@@ -229,6 +229,27 @@ class HipParameter:
         self._bufs: dict[object, torch.Tensor] = {}
         self._idx: dict[object, torch.Tensor] = {}
 
+    def _gram_backward(self, n, xs, ins, out_idx, dj, sink, stream) -> bool:
+        """The operand gradients of a Gram product ``y[f] = x[f] x[f]^T`` (both operands the SAME stored tensor: the Gram matrices
+        of a squared circuit's input layers) as one accumulating launch, ``d x += (d y + d y^T) x`` -- autograd's two products
+        ``d y x`` and ``d y^T x`` summed before the multiplication.  False: not that pattern (the caller takes the general path)."""
+        if len(xs) != 2 or xs[0].data_ptr() != xs[1].data_ptr() or xs[0].shape != xs[1].shape:
+            return False
+        shapes = [tuple(dj.shape[1:]), tuple(xs[1].shape[1:])]
+        m0 = _einsum_as_bmm([out_idx, ins[1], ins[0]], shapes)
+        m1 = _einsum_as_bmm([out_idx, ins[0], ins[1]], shapes)
+        if m0 is None or m1 is None or m0[0] or m1[0] or m0[1:4] != m1[1:4] or m0[5] != m1[5] or {m0[4], m1[4]} != {0, 1}:
+            return False
+        _, M, N, Kd, _, tb = m0
+        if M != Kd or M % 32 or N % 32:
+            return False
+        F = int(xs[0].shape[0])
+        d0, d1 = sink(n.inputs[0], F * M * N), sink(n.inputs[1], F * M * N)
+        if d0 is None or d1 is None or d0.data_ptr() != d1.data_ptr():
+            return False
+        capi.call("ck_param_bmm", _ptr(dj.contiguous()), _ptr(xs[1].contiguous()), _ptr(d0), F, M, N, Kd, 2, tb, 1, stream)
+        return True
+
     # -- surface mirrored from TorchParameter -------------------------------------------------
     @property
     def num_folds(self) -> int:
@@ -720,6 +741,8 @@ class HipParameter:
                     spec_all, eshape = _node_as_einsum(n.op, n.config, [tuple(x.shape[1:]) for x in xs])
                     dj = dj.contiguous().reshape(dj.shape[0], *eshape)
                 *ins, out_idx = [tuple(int(i) for i in e) for e in spec_all]
+                if self._gram_backward(n, xs, ins, out_idx, dj, sink, stream):  # (y = x x^T: d x = (d y + d y^T) x, one launch)
+                    continue
                 for k in range(len(xs)):
                     others = [m for m in range(len(xs)) if m != k]
                     have = set(out_idx) | {i for m in others for i in ins[m]}

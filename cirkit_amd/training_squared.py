@@ -200,7 +200,12 @@ class _PlanBackward:
             st["pool"] = pool
         return st["pool"]
 
-    def run(self, B: int, seed_real: float, stream: int) -> None:
+    def zero_pool(self, B: int, stream: int) -> None:
+        """Zero the weight-gradient pool of this binding (what `run(..., pool_zeroed=True)` then adds into)."""
+        pool = self._weight_pool(self._bind(B))
+        capi.call("ck_fill_f32", pool.data_ptr(), pool.numel(), 0.0, stream)
+
+    def run(self, B: int, seed_real: float, stream: int, pool_zeroed: bool = False) -> None:
         """Gradients of ``seed_real * sum_b Re out_b`` w.r.t. the parameter tensors, ADDED into `grads`."""
         c = self.c
         bd = c._bind(B)
@@ -216,7 +221,8 @@ class _PlanBackward:
             st["seed_key"] = float(seed_real)
         ga, aa = garena.data_ptr(), bd.arena.data_ptr()
         pool = self._weight_pool(st)
-        capi.call("ck_fill_f32", pool.data_ptr(), pool.numel(), 0.0, stream)
+        if not pool_zeroed:
+            capi.call("ck_fill_f32", pool.data_ptr(), pool.numel(), 0.0, stream)
 
         def sum_bwd(arena_ptr, garena_ptr, row_off, w, out_ptr, g_ptr, dw, F, H, rows, Ki, Ko, mode):
             if w.is_complex():
@@ -831,36 +837,41 @@ class HipSquaredTrainer:
 
     def _enqueue(self, part: str, B: int, gB: float, with_optimizer: bool, stream: int) -> None:
         n = self._flat_grad.numel()
-        if part == "c":
+        if part == "pre":  # every buffer the two backward lists ADD into, zeroed on c's stream: Z's list is the longer chain beside
+            # c's whole-chip launches (LAB_NOTES R6.4), its backward waits for this list behind its forward
             capi.call("ck_fill_f32", self._flat_grad.data_ptr(), n, 0.0, stream)
+            capi.call("ck_fill_f32", self._flat_grad_z.data_ptr(), n, 0.0, stream)
+            self._bwd_z.zero_pool(1, stream)
+        elif part == "c":
             if self._signed is not None:  # (its forward is part of the list: only the staging of the batch is not)
                 self._signed.forward(B, stream)
                 self._signed.backward(B, -2.0 / gB, stream)
             else:
                 self._bwd_c.run(B, -2.0 / gB, stream)
-        elif part == "z":  # parameters of Z, its forward (no input: everything is part of the list), its backward
-            z = self.z
-            z._enqueue_params(stream)
+        elif part == "zf":  # parameters of Z and its forward (no input: everything is part of the list) ...
+            self.z._enqueue_params(stream)
             self._bwd_z.forward(1, stream)
-            capi.call("ck_fill_f32", self._flat_grad_z.data_ptr(), n, 0.0, stream)
-            self._bwd_z.run(1, B / gB, stream)
-        else:  # both gradients are there: the sum, the log-likelihood pair, the optimizer
+        elif part == "zb":  # ... its backward
+            self._bwd_z.run(1, B / gB, stream, pool_zeroed=True)
+        elif part == "mid":  # both forwards are there: the optimizer's clock and the log-likelihood pair (beside Z's backward)
             c, z = self.c, self.z
             validate = c.validate_inputs and c._int_input
-            if with_optimizer:  # the clock first: a batch with an illegal category drops the step (skip_now)
+            if with_optimizer:  # a batch with an illegal category drops the step (skip_now)
                 capi.call("ck_opt_tick", self._opt_state().data_ptr(), c._bad_input.data_ptr() if validate else None,
                           self._bad_seen.data_ptr() if validate else None, stream)
-            if not with_optimizer:
-                capi.call("ck_axpy_f32", self._flat_grad.data_ptr(), self._flat_grad_z.data_ptr(), 1.0, n, stream)
             yc = self._signed.output(B) if self._signed is not None else c._bind(B).views[int(c._out_pairs[0, 0])][int(c._out_pairs[0, 1])]
             yz = z._bind(1).views[int(z._out_pairs[0, 0])][int(z._out_pairs[0, 1])]
             capi.call("ck_squared_ll", yc.data_ptr(), B, 2 if yc.is_complex() else 1, yz.data_ptr(), self._ll.data_ptr(), stream)
+        else:  # both gradients are there: their sum, or the optimizer reading both
             if with_optimizer:
                 self._enqueue_optimizer(stream, with_z=True)
+            else:
+                capi.call("ck_axpy_f32", self._flat_grad.data_ptr(), self._flat_grad_z.data_ptr(), 1.0, n, stream)
 
     def _part(self, part: str, B: int, gB: float, with_optimizer: bool, run: torch.cuda.Stream) -> None:
-        """One of the three recorded launch lists of a step -- "c": the backward of c; "z": the backward of Z; "end": the sum of
-        the two gradients, the log-likelihood pair and (alone) the optimizer -- per (batch size, global batch): the first two
+        """One of the recorded launch lists of a step -- "pre": the zero fills of both gradient buffers; "c": forward and backward of
+        c; "zf" / "zb": parameters + forward and the backward of Z; "end": the sum of the two gradients, the log-likelihood pair and
+        (alone) the optimizer ("mid": the clock and the pair, as soon as both forwards are there) -- per (batch size, global batch): the first two
         calls run eagerly (they size the scratch of the parameter graphs), the third records, later ones replay (as a hipGraph
         when `use_graph`)."""
         c_arena = self._signed.bind(B)["arena"] if self._signed is not None else self.c._bind(B).arena
@@ -896,12 +907,21 @@ class HipSquaredTrainer:
             main.wait_stream(cur)
         side.wait_stream(cur)
         with torch.cuda.stream(main):  # (the long list first)
+            self._part("pre", B, gB, with_optimizer, main)
+            zeroed = torch.cuda.Event()
+            zeroed.record(main)
             if self._signed is not None:
                 self._signed.stage(x, main.cuda_stream)
             else:
                 self.c._run(x)  # (B, 1, 1) complex64 / fp32 in c's arena
             self._part("c", B, gB, with_optimizer, main)
-        self._part("z", B, gB, with_optimizer, side)
+        self._part("zf", B, gB, with_optimizer, side)
+        z_forward = torch.cuda.Event()
+        z_forward.record(side)
+        side.wait_event(zeroed)
+        self._part("zb", B, gB, with_optimizer, side)
+        main.wait_event(z_forward)
+        self._part("mid", B, gB, with_optimizer, main)
         main.wait_stream(side)
         self._part("end", B, gB, with_optimizer, main)
         if main is not cur:

@@ -530,7 +530,9 @@ int ck_param_mixing_weight(const float* in, float* out, int F, int K, int H, voi
  * output tile on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate); otherwise (32, 64) multiply-add tiles. */
 /* `accumulate` != 0: out[f] += op(a[f]) . op(b[f]) -- the gradient of an einsum operand added straight into the
  * gradient of the stored tensor behind it (autograd's accumulation through TorchPointerParameter / TorchConjugateParameter /
- * TorchFlattenParameter, nodes.py:277-279, 745-746, 843-844) instead of a product buffer and an axpy. */
+ * TorchFlattenParameter, nodes.py:277-279, 745-746, 843-844) instead of a product buffer and an axpy.
+ * trans_a == 2 (M == Kd, extents multiples of 32): op(a) = a + a^T -- both operand gradients of a Gram product y = x x^T
+ * (autograd sends d y x and d y^T x to the same tensor) as ONE product. */
 int ck_param_bmm(const float* a, const float* b, float* out, int F, int M, int N, int Kd, int trans_a, int trans_b, int accumulate,
                      void* stream);
 /* (R, A, Bd) -> (R, out_rows >= Bd, A) transpose of the last two axes (rows beyond Bd untouched),
