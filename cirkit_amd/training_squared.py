@@ -452,13 +452,11 @@ class _SignedCircuit:
         """Descriptors and buffers of the leaf region's launches at batch size B."""
         from .fusion import balanced_segments, leaf_segments
 
-        import os
-
         c, g = self.c, self.leaf
         dev = c.device
         emb = c.layers[g.input_layer]
         D, kl, tiles = g.depth, 1 << g.depth, Bp // 32
-        n_wg = max(8, c._n_cu - int(os.environ.get("CK_SQ_RESERVE_CUS", "0")))
+        n_wg = c._n_cu
         n_roots = c.layers[g.root].num_folds
         nodes = np.asarray(g.nodes).astype(np.int64)
         noff = [int(v) for v in g.node_off]
