@@ -1,4 +1,4 @@
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_training.py -x -q -m gpu > gpurun_out/pt_tr.log 2>&1; echo "pytest rc=$?"; grep -v "^  File\|^Extension" gpurun_out/pt_tr.log | tail -5
-python scripts/bench_train.py 4096 100 2 fused | tail -1
-python scripts/bench_train.py 4096 100 2 fused | tail -1
+bash scripts/profile_round.sh r06 c > gpurun_out/profile_round.log 2>&1
+BATCHES="256 4096" bash scripts/profile_train_squared.sh > gpurun_out/prof_sq.log 2>&1
+bash scripts/profile_train.sh r06 c fused > gpurun_out/prof_train.log 2>&1
+ls gpurun_out/r06 gpurun_out/train_sq
