@@ -41,7 +41,9 @@ class _ProfilingMixin:
             return f"cp_lse_kernel<{l.num_output_units // 32}, 8, {'true' if i in self._cp_blocks else 'false'}>"
         if i in self._group_of_root and self._signed:
             raw = "true" if self._direct_input(B) else "false"
-            return f"leaf_persistent_kernel<{self._group_of_root[i].depth}, 8, true, {raw}, false, false, 0> (signed: real-valued complex circuit)"
+            g = self._group_of_root[i]
+            xp = "true" if (raw == "true" and g.depth >= 2 and self._leaves_in_adjacent_pairs(g)) else "false"
+            return f"leaf_persistent_kernel<{g.depth}, 8, true, {raw}, {xp}, false, 0> (signed: real-valued complex circuit)"
         if i in self._group_of_root:
             g = self._group_of_root[i]
             in_kernel_dense = g.dense_layer is not None and not (self.dense_on_table and g.depth > 0)

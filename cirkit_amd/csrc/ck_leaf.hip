@@ -796,7 +796,14 @@ hipError_t launch_waves(const LeafArgs& a, int waves, bool is_signed, int n_root
     }
   }
   if (is_signed) {
-    hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true, XRAW>), grid, dim3(512), 0, s, a);
+    bool pairs = false;
+    if constexpr (XRAW && D >= 2) {  // (adjacent variables under the leaves 2j, 2j + 1: one 16-byte load per pair, as the unsigned launch)
+      if (a.x_pairs) {
+        pairs = true;
+        hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true, true, true>), grid, dim3(512), 0, s, a);
+      }
+    }
+    if (!pairs) hipLaunchKernelGGL((leaf_persistent_kernel<D, 8, true, XRAW>), grid, dim3(512), 0, s, a);
     if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     hipLaunchKernelGGL((leaf_signed_redo_kernel<D>), dim3((a.B + 31) / 32, n_roots), dim3(64), 0, s, a);
   } else {

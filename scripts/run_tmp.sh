@@ -1,4 +1,2 @@
-bash scripts/profile_round.sh r06 c > gpurun_out/profile_round.log 2>&1
-BATCHES="256 4096" bash scripts/profile_train_squared.sh > gpurun_out/prof_sq.log 2>&1
-bash scripts/profile_train.sh r06 c fused > gpurun_out/prof_train.log 2>&1
-ls gpurun_out/r06 gpurun_out/train_sq
+python scripts/bench_plan.py cfg5_sos_c_k32 4096 30 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_size.py -x -q -m gpu -k "5 or sos or signed or complex" 2>&1 | tail -3
