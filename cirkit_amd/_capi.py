@@ -10,7 +10,7 @@ from typing import Any
 # CIRKIT_HIP_LIB: a lab build of the same library (scripts/lab_build.sh, scripts/defect_injection.sh); never a different backend
 _LIB_PATH = os.environ.get("CIRKIT_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 46
+ABI_VERSION = 47
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -285,8 +285,6 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_tensordot2_lse_bwd": [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ck_slse_table": [_p, _p, _p, _l, _p],
     "ck_slse_tables": [_p, _p, _p, _p, _i, _i, _p],
-    "ck_slse_pair_fwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
-    "ck_slse_pair_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "ck_slse_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "ck_slse_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p],
     "ck_latch_flag": [_p, _p, _p],

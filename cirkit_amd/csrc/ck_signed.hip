@@ -244,179 +244,6 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// ---- TWO layers in one launch --------------------------------------------------------------------------------------------
-// A CP-T layer P whose two children are folds of ONE layer Q that nobody else reads (config 5: the first CP-T layer over the
-// Embedding folds and the layer above it -- 75 % of the circuit's fold tiles).  Layer by layer Q's outputs are written, read back by
-// P, and in the backward P's input gradient is written and read twice by Q's folds: 0.9 GB of the step's traffic.  Here a wave takes
-// a (P fold, 32-row tile) unit through Q0, Q1 and P with the SAME device code as slse_tile32_fwd / _bwd in the same order -- the
-// same bits --, Q's values never leave the registers; the backward evaluates Q0, Q1 and P again from Q's children (2 contractions
-// more per unit than the three launches it replaces spent on recomputing y) and leaves what Q's children read: the gradient
-// block of each Q fold.
-struct PairArgs {
-  const float* arena;
-  const uint32_t* signs;
-  const int32_t* q_fold;  // (F_P, 2): the folds of Q under each fold of P
-  const int64_t* ro_q;    // (F_Q, H_Q) float offsets of Q's children in the arena, or null: gathered (ga)
-  Gather ga;              // child_fold / child_var are (F_Q, H_Q)
-  const float* w_q;       // (F_Q, 32, 32)
-  const float* w_p;       // (F_P, 32, 32)
-  float* out;             // P's block (F_P, Bp, 32) tile-native        [forward]
-  uint32_t* sout;         // (F_P, Bp)                                   [forward]
-  const float* gout;      // gradient of P's outputs: + gout_off[f]      [backward]
-  const int64_t* gout_off;
-  float* gx_q;            // Q's gradient blocks: (F_Q, B, 32) row-major when gathered, else (F_Q, Bp, 32) tile-native   [backward]
-  float* dw_q;            // (F_Q, 32, 32) +=                            [backward]
-  float* dw_p;            // (F_P, 32, 32) +=
-  int H_Q, B, F_P, nx;
-};
-
-// one sum step on signed-log inputs: v (sum of the children's log|x|) and sw (their sign word) -> a = +-exp(v - m) (kept in `a`),
-// y = W a (kept in `y`), out = log|y| + m in v, the sign word of y returned
-__device__ __forceinline__ uint32_t slse_step(const WRegs& wr, float (&v)[16], uint32_t sw, int kh, float (&a)[16], float (&y)[16]) {
-  const float m = row_max16(v);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float e = exp_fast(v[j] - m);
-    a[j] = bit_of(sw, j, kh) ? -e : e;
-    y[j] = a[j];
-  }
-  contract_linear<CK_W_ROWMAJOR>(wr, y);
-  uint32_t so = 0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    so |= (y[j] < 0.f ? 1u : 0u) << (8 * (j >> 2) + 4 * kh + (j & 3));
-    v[j] = log_abs(y[j]) + m;
-  }
-  so |= __shfl_xor(so, 32, 64);
-  return so;
-}
-
-__global__ void __launch_bounds__(256) slse_pair_fwd(const PairArgs p, int tiles_per_wave) {
-  const int seq = blockIdx.x >> 3;  // (the workgroups of a fold on one XCD, as slse_tile32_fwd)
-  const int f = (seq / p.nx) * 8 + (blockIdx.x & 7), bx = seq % p.nx;
-  if (f >= p.F_P) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b_in = lane & 31, kh = lane >> 5;
-  const int q[2] = {p.q_fold[2 * f], p.q_fold[2 * f + 1]};
-  WRegs wq[2], wp;
-  load_w<CK_W_ROWMAJOR>(p.w_q + static_cast<int64_t>(q[0]) * kK * kK, lane, wq[0]);
-  load_w<CK_W_ROWMAJOR>(p.w_q + static_cast<int64_t>(q[1]) * kK * kK, lane, wq[1]);
-  load_w<CK_W_ROWMAJOR>(p.w_p + static_cast<int64_t>(f) * kK * kK, lane, wp);
-  const int tile0 = (bx * 4 + wave) * tiles_per_wave;
-  const int Bp = padded_rows(p.B);
-  for (int tt = 0; tt < tiles_per_wave; ++tt) {
-    const int b0 = (tile0 + tt) * 32;
-    if (b0 >= p.B) break;
-    const int b = b0 + b_in;
-    const bool live = b < p.B;
-    const int64_t bl = live ? b : p.B - 1;
-    float v[16], a[16], y[16];
-    uint32_t sw = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float vq[16];
-      const int64_t* ro = p.ro_q != nullptr ? p.ro_q + static_cast<int64_t>(q[s]) * p.H_Q : nullptr;
-      const uint32_t swq = load_children(p.arena, p.signs, ro, p.ga, q[s], p.H_Q, p.B, bl, kh, tile0 + tt, lane, vq);
-      sw ^= slse_step(wq[s], vq, swq, kh, a, y);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] += vq[j];
-    }
-    const uint32_t so = slse_step(wp, v, sw, kh, a, y);
-    store_tile_native(p.out + static_cast<int64_t>(f) * Bp * kK, tile0 + tt, lane, v);
-    if (live && kh == 0) p.sout[static_cast<int64_t>(f) * Bp + b] = so;
-  }
-}
-
-__global__ void __launch_bounds__(256) slse_pair_bwd(const PairArgs p) {
-  __shared__ __attribute__((aligned(16))) float wt_s[3][1024];      // W^T of Q0, Q1, P ("transposed tiled": child_gradient)
-  __shared__ __attribute__((aligned(16))) float scr_s[4][2][1024];  // per wave: the two operands of dw_accumulate
-  const int seq = blockIdx.x >> 3;
-  const int f = (seq / p.nx) * 8 + (blockIdx.x & 7), bx = seq % p.nx;
-  if (f >= p.F_P) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b_in = lane & 31, kh = lane >> 5;
-  const int q[2] = {p.q_fold[2 * f], p.q_fold[2 * f + 1]};
-  const float* wf[3] = {p.w_q + static_cast<int64_t>(q[0]) * 1024, p.w_q + static_cast<int64_t>(q[1]) * 1024, p.w_p + static_cast<int64_t>(f) * 1024};
-#pragma unroll
-  for (int n = 0; n < 3; ++n)
-    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
-      const int qq = idx >> 8, ln = (idx >> 2) & 63, t = idx & 3;
-      wt_s[n][idx] = wf[n][(8 * qq + 4 * (ln >> 5) + t) * 32 + (ln & 31)];
-    }
-  WRegs wr[3];  // (A operands of y = W a)
-#pragma unroll
-  for (int n = 0; n < 3; ++n) load_w<CK_W_ROWMAJOR>(wf[n], lane, wr[n]);
-  __syncthreads();
-  f32x16 dacc[3];
-#pragma unroll
-  for (int n = 0; n < 3; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dacc[n][r] = 0.f;
-  const int tiles = (p.B + 31) / 32;
-  const int Bp = padded_rows(p.B);
-  const bool gathered = p.ga.table != nullptr;
-  const float* gf = p.gout + (p.gout_off != nullptr ? p.gout_off[f] : static_cast<int64_t>(f) * Bp * 32);
-  for (int tile = bx * 4 + wave; tile < tiles; tile += p.nx * 4) {
-    const int b = tile * 32 + b_in;
-    const bool live = b < p.B;
-    const int64_t bl = live ? b : p.B - 1;
-    float aq[2][16], yq[2][16], v[16];
-    uint32_t sw = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {  // Q0, Q1 again, as the forward evaluated them
-      float vq[16];
-      const int64_t* ro = p.ro_q != nullptr ? p.ro_q + static_cast<int64_t>(q[s]) * p.H_Q : nullptr;
-      const uint32_t swq = load_children(p.arena, p.signs, ro, p.ga, q[s], p.H_Q, p.B, bl, kh, tile, lane, vq);
-      sw ^= slse_step(wr[s], vq, swq, kh, aq[s], yq[s]);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] += vq[j];
-    }
-    float ap[16], t[16], gq[16];
-    {  // P: t = G / y, the gradient its two children share, dW_P
-      float yp[16], g[16];
-      load_tile_native(gf, tile, lane, g);
-      (void)slse_step(wr[2], v, sw, kh, ap, yp);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) t[j] = (live && g[j] != 0.f && yp[j] != 0.f) ? g[j] * __builtin_amdgcn_rcpf(yp[j]) : 0.f;
-    }
-    child_gradient(wt_s[2], lane, t, ap, gq);
-    dw_accumulate(dacc[2], scr_s[wave][0], scr_s[wave][1], b_in, kh, t, ap);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {  // Q_s: its output's gradient is gq (what slse_tile32_bwd of P would have written for it to read)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) t[j] = (live && gq[j] != 0.f && yq[s][j] != 0.f) ? gq[j] * __builtin_amdgcn_rcpf(yq[s][j]) : 0.f;
-      float gv[16];
-      child_gradient(wt_s[s], lane, t, aq[s], gv);
-      if (!gathered) {
-        store_tile_native(p.gx_q + static_cast<int64_t>(q[s]) * Bp * 32, tile, lane, gv);
-      } else if (live) {  // (rows of (B, 32): what ck_embedding_bwd scatters)
-        float* dst = p.gx_q + (static_cast<int64_t>(q[s]) * p.B + b) * 32 + 4 * kh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(gv[4 * g], gv[4 * g + 1], gv[4 * g + 2], gv[4 * g + 3]);
-      }
-      dw_accumulate(dacc[s], scr_s[wave][0], scr_s[wave][1], b_in, kh, t, aq[s]);
-    }
-  }
-  // the four waves' sums through LDS, one float atomic per weight entry and workgroup (as slse_tile32_bwd), node after node
-  float* red = &scr_s[0][0][0];  // [4][1024] of the 8 x 1024
-#pragma unroll
-  for (int n = 0; n < 3; ++n) {
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave * 1024 + (8 * (r >> 2) + 4 * kh + (r & 3)) * 32 + b_in] = dacc[n][r];
-    __syncthreads();
-    float* dw = n == 2 ? p.dw_p + static_cast<int64_t>(f) * 1024 : p.dw_q + static_cast<int64_t>(q[n]) * 1024;
-    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
-      const float vsum = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
-      if (vsum != 0.f) atomicAdd(dw + idx, vsum);
-    }
-  }
-}
-
 // Few outputs (Ko <= 4: the scalar sum fold at the top of the circuit) over 32 product-type inputs: a half-wave per batch row,
 // lane = input unit, the dot products are lane reductions.  BWD: also the children's gradient and dW (registers over the rows
 // a half-wave walks, float atomics at the end).
@@ -632,55 +459,6 @@ extern "C" int ck_slse_bwd(const float* arena, const uint32_t* signs, const int6
       [=](hipStream_t s) {
         hipLaunchKernelGGL(slse_few_kernel<true>, grid, block, 0, s, arena, signs, gx, row_off, w, const_cast<float*>(out),
                            const_cast<uint32_t*>(sout), gout, dw, H, B, Ko);
-        return hipGetLastError();
-      },
-      stream);
-}
-
-// The pair launches: P (F_P folds, two children each: folds q_fold[f, 0 / 1] of Q) over Q (H_Q children per fold: arena blocks at
-// ro_q (F_Q, H_Q), or -- log_table != NULL -- rows of an Embedding table as in ck_slse_fwd, child_fold / child_var (F_Q, H_Q)).
-extern "C" int ck_slse_pair_fwd(const float* arena, const uint32_t* signs, const int32_t* q_fold, const int64_t* ro_q, const float* w_q,
-                                const float* w_p, float* out, uint32_t* sout, int F_P, int H_Q, int B, const float* log_table,
-                                const uint32_t* table_signs, const int32_t* child_fold, const int32_t* child_var, const int32_t* xt, int C,
-                                void* stream) {
-  const Gather ga{log_table, table_signs, child_fold, child_var, xt, C};
-  CK_REQUIRE(q_fold && w_q && w_p && out && sout, "ck_slse_pair_fwd: null pointer");
-  CK_REQUIRE(F_P > 0 && H_Q > 0 && B > 0, "ck_slse_pair_fwd: non-positive size");
-  CK_REQUIRE((log_table != nullptr) != (ro_q != nullptr), "ck_slse_pair_fwd: Q's children are EITHER arena blocks (ro_q) OR table rows (log_table)");
-  if (log_table != nullptr) CK_REQUIRE(table_signs && child_fold && child_var && xt && C > 0, "ck_slse_pair_fwd: incomplete gather arguments");
-  else CK_REQUIRE(arena && signs, "ck_slse_pair_fwd: null arena");
-  const int tiles = (B + 31) / 32;
-  int tpw = 1;
-  while (tpw < 4 && static_cast<int64_t>(F_P) * ((tiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) >= 2048) tpw *= 2;
-  const int nx = (tiles + 4 * tpw - 1) / (4 * tpw);
-  PairArgs p{arena, signs, q_fold, ro_q, ga, w_q, w_p, out, sout, nullptr, nullptr, nullptr, nullptr, nullptr, H_Q, B, F_P, nx};
-  const dim3 grid(static_cast<unsigned>((F_P + 7) / 8 * 8 * nx)), block(256);
-  return ck::dispatch(
-      [=](hipStream_t s) {
-        hipLaunchKernelGGL(slse_pair_fwd, grid, block, 0, s, p, tpw);
-        return hipGetLastError();
-      },
-      stream);
-}
-
-extern "C" int ck_slse_pair_bwd(const float* arena, const uint32_t* signs, const int32_t* q_fold, const int64_t* ro_q, const float* w_q,
-                                const float* w_p, const float* gout, const int64_t* gout_off, float* gx_q, float* dw_q, float* dw_p, int F_P,
-                                int H_Q, int B, const float* log_table, const uint32_t* table_signs, const int32_t* child_fold,
-                                const int32_t* child_var, const int32_t* xt, int C, void* stream) {
-  const Gather ga{log_table, table_signs, child_fold, child_var, xt, C};
-  CK_REQUIRE(q_fold && w_q && w_p && gout && gx_q && dw_q && dw_p, "ck_slse_pair_bwd: null pointer");
-  CK_REQUIRE(F_P > 0 && H_Q > 0 && B > 0, "ck_slse_pair_bwd: non-positive size");
-  CK_REQUIRE((log_table != nullptr) != (ro_q != nullptr), "ck_slse_pair_bwd: Q's children are EITHER arena blocks (ro_q) OR table rows (log_table)");
-  if (log_table != nullptr) CK_REQUIRE(table_signs && child_fold && child_var && xt && C > 0, "ck_slse_pair_bwd: incomplete gather arguments");
-  else CK_REQUIRE(arena && signs, "ck_slse_pair_bwd: null arena");
-  CK_REQUIRE(ck::aligned16(gx_q) && ck::aligned16(gout), "ck_slse_pair_bwd: misaligned pointer");
-  const int tiles = (B + 31) / 32;
-  const int nx = std::max(1, std::min((tiles + 3) / 4, 16));
-  PairArgs p{arena, signs, q_fold, ro_q, ga, w_q, w_p, nullptr, nullptr, gout, gout_off, gx_q, dw_q, dw_p, H_Q, B, F_P, nx};
-  const dim3 grid(static_cast<unsigned>((F_P + 7) / 8 * 8 * nx)), block(256);
-  return ck::dispatch(
-      [=](hipStream_t s) {
-        hipLaunchKernelGGL(slse_pair_bwd, grid, block, 0, s, p);
         return hipGetLastError();
       },
       stream);

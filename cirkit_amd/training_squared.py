@@ -391,33 +391,6 @@ class _SignedCircuit:
         # region's roots, the tiles of every second level kept) and one backward launch per two levels (ck_leaf_walk_bwd, is_signed):
         # what the trainer of real circuits does for Categorical -> CP-T regions (training.py), on values of either sign.
         self.leaf = self._leaf_region() if os.environ.get("CK_SLSE_LEAF", "1") != "0" else None
-        in_leaf = set(self.leaf.levels) if self.leaf is not None else set()
-        # PAIRS of layers evaluated by one launch forward and one backward (ck_slse_pair_fwd / _bwd): a CP-T layer P (32 -> 32) whose
-        # children are ALL the folds of one 32 -> 32 layer Q, each read once -- Q's outputs never reach memory.  A lab switch
-        # (CK_SLSE_PAIR=1): the backward launch needs 292 registers -- one wave per SIMD -- and loses what the forward gains
-        # (LAB_NOTES R6.4).
-        self.pair_of: dict[int, int] = {}  # P -> Q
-        self.paired_q: set[int] = set()
-
-        if os.environ.get("CK_SLSE_PAIR", "0") == "1":
-            outs = {int(p) for p in c._out_pairs[:, 0]}
-            for i, l in enumerate(c.layers):
-                if self.kind.get(i) != "sum" or type(l) is not HipCPTLayer or l.arity != 2 or l.num_output_units != 32 or i in in_leaf:
-                    continue
-                ch = c._children[i]
-                prods = np.unique(ch[..., 0])
-                if len(prods) != 1:
-                    continue
-                qi = int(prods[0])
-                lq = c.layers[qi]
-                if self.kind.get(qi) not in ("gather", "sum") or lq.num_output_units != 32 or qi in outs or qi in self.pair_of or qi in self.paired_q:
-                    continue
-                if sorted(int(f) for f in ch[..., 1].reshape(-1)) != list(range(lq.num_folds)):
-                    continue  # (every fold of Q exactly once under P)
-                if any(cj is not None and j != i and qi in {int(p) for p in np.unique(cj[..., 0])} for j, cj in enumerate(c._children)):
-                    continue  # (another reader of Q)
-                self.pair_of[i] = qi
-                self.paired_q.add(qi)
         for i, k in self.kind.items():  # an Embedding fold read by nobody would keep an unwritten gradient block
             if k == "emb":
                 read = np.zeros(c.layers[i].num_folds, dtype=bool)
@@ -524,7 +497,6 @@ class _SignedCircuit:
             "seed": torch.zeros(c.layers[po].num_folds * B, dtype=torch.float32, device=dev),  # the output layer's gradient
             "xt": torch.zeros((max(1, c.plan.num_variables), B), dtype=torch.int32, device=dev),
             "off": off, "ro": {}, "tabs": {}, "gout_off": {}, "gfold": {}, "ltab": {},
-            "qfold": {pi: torch.from_numpy(np.ascontiguousarray(c._children[pi][..., 1].astype(np.int32))).to(dev) for pi in self.pair_of},
         }
         parent: dict[tuple[int, int], tuple[int, int]] = {}  # (layer, fold) -> the (layer, fold) that reads it
         for i, k in self.kind.items():
@@ -627,19 +599,11 @@ class _SignedCircuit:
                 capi.call("ck_slse_tables", c.store[self.wname[i]].data_ptr(), l._table.data_ptr(), None if in_region else ltab.data_ptr(),
                           None if in_region else tsg.data_ptr(), l.num_folds, l.num_states, stream)
                 continue
-            if i in self.paired_q:  # (evaluated inside the launch of the layer above it)
-                continue
             if self.leaf is not None and i in self.leaf.levels:  # (the whole region with the launch of its first level)
                 if i == self.leaf.levels[0]:
                     self._leaf_forward(st, B, stream)
                 continue
             o = st["off"][i]
-            if i in self.pair_of:
-                qi = self.pair_of[i]
-                ro_q, *gather = self._args(st, qi)
-                capi.call("ck_slse_pair_fwd", a, sg, st["qfold"][i].data_ptr(), ro_q, c.store[self.wname[qi]].data_ptr(),
-                          c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32), l.num_folds, c.layers[qi].arity, B, *gather, stream)
-                continue
             ro, *gather = self._args(st, i)
             capi.call("ck_slse_fwd", a, sg, ro, c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32),
                       l.num_folds, l.arity, B, l.num_output_units, *gather, stream)
@@ -713,21 +677,11 @@ class _SignedCircuit:
                 capi.call("ck_embedding_bwd", ga + 4 * st["off"][g], 1, gfold.data_ptr(), order.data_ptr(), st["xt"].data_ptr(), l._scope(c.device).data_ptr(),
                           l._table.data_ptr(), self.grads[self.wname[i]].data_ptr(), l.num_folds, B, 32, l.num_states, stream)
                 continue
-            if i in self.paired_q:  # (its gradient block and weight gradient were left by the launch of the layer above it)
-                continue
             if self.leaf is not None and i in self.leaf.levels:  # (the whole region when its root layer is reached)
                 if i == self.leaf.root:
                     self._leaf_backward(st, B, stream)
                 continue
             o = st["off"][i]
-            if i in self.pair_of:
-                qi = self.pair_of[i]
-                ro_q, *gather = self._args(st, qi)
-                capi.call("ck_slse_pair_bwd", a, sg, st["qfold"][i].data_ptr(), ro_q, c.store[self.wname[qi]].data_ptr(),
-                          c.store[self.wname[i]].data_ptr(), ga, st["gout_off"][i].data_ptr(), ga + 4 * st["off"][qi],
-                          self.grads[self.wname[qi]].data_ptr(), self.grads[self.wname[i]].data_ptr(), l.num_folds, c.layers[qi].arity, B,
-                          *gather, stream)
-                continue
             ro, *gather = self._args(st, i)
             gout, gout_off = (st["seed"].data_ptr(), None) if i == po else (ga, st["gout_off"][i].data_ptr())
             capi.call("ck_slse_bwd", a, sg, ro, c.store[self.wname[i]].data_ptr(), a + 4 * o, sg + 4 * (o // 32), gout, gout_off,

@@ -796,19 +796,6 @@ int ck_slse_table(const float* table, float* log_table, uint32_t* table_signs, i
  * table (F, C + 1, 32) (the transposed weight, row C the integral row of ones), its signed-log form and sign words (both NULL:
  * the linear table alone -- what ck_leaf_walk_fwd's signed launch reads). */
 int ck_slse_tables(const float* weight, float* table, float* log_table, uint32_t* table_signs, int F, int C, void* stream);
-/* TWO such layers in one launch: a CP-T layer P (F_P folds, 32 -> 32, two children each) over the folds q_fold[f, 0 / 1] of ONE
- * layer Q (32 -> 32, H_Q children per fold: arena blocks at ro_q (F_Q, H_Q), or -- log_table != NULL -- Embedding table rows,
- * child_fold / child_var (F_Q, H_Q)) that nothing else reads: Q's outputs are never written.  The same arithmetic in the same
- * order as ck_slse_fwd / ck_slse_bwd on Q then P (bit-identical outputs and input gradients).  _bwd: gout / gout_off as
- * ck_slse_bwd for P; gx_q <- the gradient block of every Q fold ((F_Q, B, 32) row-major when gathered, else (F_Q, Bp, 32)
- * tile-native), dw_q (F_Q, 32, 32) and dw_p (F_P, 32, 32) += (float atomics). */
-int ck_slse_pair_fwd(const float* arena, const uint32_t* signs, const int32_t* q_fold, const int64_t* ro_q, const float* w_q,
-                     const float* w_p, float* out, uint32_t* sout, int F_P, int H_Q, int B, const float* log_table,
-                     const uint32_t* table_signs, const int32_t* child_fold, const int32_t* child_var, const int32_t* xt, int C, void* stream);
-int ck_slse_pair_bwd(const float* arena, const uint32_t* signs, const int32_t* q_fold, const int64_t* ro_q, const float* w_q,
-                     const float* w_p, const float* gout, const int64_t* gout_off, float* gx_q, float* dw_q, float* dw_p, int F_P, int H_Q,
-                     int B, const float* log_table, const uint32_t* table_signs, const int32_t* child_fold, const int32_t* child_var,
-                     const int32_t* xt, int C, void* stream);
 int ck_slse_fwd(const float* arena, const uint32_t* signs, const int64_t* row_off, const float* w, float* out, uint32_t* sout,
                 int F, int H, int B, int Ko, const float* log_table, const uint32_t* table_signs, const int32_t* child_fold,
                 const int32_t* child_var, const int32_t* xt, int C, void* stream);

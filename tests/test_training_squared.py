@@ -201,37 +201,6 @@ def test_leaf_region_tiles_that_leave_the_linear_range(hip_device, monkeypatch):
         assert float((ga - gb).norm()) <= 2e-2 * float(gb.norm()) + 1e-12, (k, float((ga - gb).norm()), float(gb.norm()))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("rows", [300, 4096])
-def test_layer_pairs_in_one_launch_equal_the_layer_launches(hip_device, rows, monkeypatch):
-    """`ck_slse_pair_fwd / _bwd`: the first two and the next two CP-T layers of config 5's c(x) as ONE launch each forward and
-    backward (the lower layer's outputs never written) against one launch per layer (`CK_SLSE_PAIR=0`): the same device code in
-    the same order -- log|c(x)| bit for bit; gradients to the rounding of their float atomics (the partial sums of a weight
-    gradient are cut over the batch differently)."""
-    from cirkit_amd.training_squared import HipSquaredTrainer
-
-    plan_c, plan_z = Plan.load(os.path.join(GOLDEN, "cfg5_sos_c_k32")), Plan.load(os.path.join(GOLDEN, "cfg5_sos_z_k32"))
-    tensors = init_plan_tensors(plan_c)
-    tensors = {k: np.where(v == 0, np.float32(1e-2), v).astype(np.float32) for k, v in tensors.items()}
-    x = torch.randint(0, 256, (rows, 784), generator=torch.Generator().manual_seed(6)).to(hip_device)
-    monkeypatch.setenv("CK_SLSE_LEAF", "0")  # (the launches this test is about are a lab switch: the leaf region takes these layers)
-    monkeypatch.setenv("CK_SLSE_PAIR", "1")
-    a = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)
-    monkeypatch.setenv("CK_SLSE_PAIR", "0")
-    b = HipSquaredTrainer(plan_c, tensors, plan_z=plan_z, device=hip_device)
-    assert a._signed is not None and len(a._signed.pair_of) >= 2 and not b._signed.pair_of
-    for _ in range(2):  # (eager, then recorded)
-        la, lb = a.loss_and_grads(x).cpu().numpy(), b.loss_and_grads(x).cpu().numpy()
-    torch.cuda.synchronize()
-    ya, yb = a._signed.output(rows).cpu(), b._signed.output(rows).cpu()
-    assert torch.equal(ya, yb) and bool(torch.isfinite(ya).all())
-    assert la[1] == lb[1] == rows and abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0])
-    ga, gb = a.gradients(), b.gradients()
-    for k in tensors:
-        scale = float(np.abs(gb[k]).max())
-        assert float(np.abs(ga[k] - gb[k]).max()) <= 2e-5 * scale + 1e-12, (k, float(np.abs(ga[k] - gb[k]).max()), scale)
-
-
 def _to_tile_native(x):
     """(..., B, 32) row-major -> (..., Bp * 32) in the tile-native order of ck_signed.hip (rows padded to whole 32-row tiles)."""
     *lead, B, K = x.shape
