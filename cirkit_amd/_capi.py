@@ -10,7 +10,7 @@ from typing import Any
 # CIRKIT_HIP_LIB: a lab build of the same library (scripts/lab_build.sh, scripts/defect_injection.sh); never a different backend
 _LIB_PATH = os.environ.get("CIRKIT_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcirkit_hip.so")
 
-ABI_VERSION = 47
+ABI_VERSION = 48
 
 CK_SUM_CAT = 0
 CK_SUM_PROD = 1
@@ -135,6 +135,13 @@ class TailParamsLaunch(C.Structure):
         ("n_tables", C.c_int32), ("n_rows", C.c_int32),
         ("ll_cell", C.c_int32),
     ]
+
+
+class TableOpt(C.Structure):
+    """ck_table_opt of include/cirkit_hip.h."""
+
+    _fields_ = [("state", C.c_void_p), ("m1_cat", C.c_void_p), ("m2_cat", C.c_void_p), ("m1_dense", C.c_void_p), ("m2_dense", C.c_void_p),
+                ("table", C.c_void_p), ("table_scale", C.c_void_p)]
 
 
 class OptState(C.Structure):
@@ -265,10 +272,10 @@ SIGNATURES: dict[str, list[Any]] = {
     "ck_param_scatter_add_folds": [_p, _p, _p, _l, _l, _p],
     "ck_categorical_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p],
     "ck_tail_bwd": [_p, _i, _p, _i, _i, C.c_int64, _p],
-    "ck_param_softmax_bwd_batch": [_p, _i, _i, _p],
-    "ck_fill_latch": [_p, _l, _f, _p, _p, _p, _p],
+    "ck_param_softmax_bwd_batch": [_p, _i, _i, _p, _p],
+    "ck_fill_latch": [_p, _l, _f, _p, _p, _p, _p, _p],
     "ck_leaf_walk_bwd": [C.POINTER(LeafBwdLaunch), _p],
-    "ck_table_dense_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "ck_table_dense_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, C.POINTER(TableOpt), _p],
     "ck_leaf_walk_bwd_redo": [_p, _p, _p, _i, _i, _i, _p, C.POINTER(C.c_int32), _i, _p, _i, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _p, _p, _p, _i, _p, _i, _p],
     "ck_param_softmax_bwd": [_p, _p, _p, _l, _i, _i, _p],
     "ck_param_log_table_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],

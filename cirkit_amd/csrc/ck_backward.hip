@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "ck_internal.h"
+#include "ck_opt.h"
 #include "ck_tile.h"
 
 namespace {
@@ -818,8 +819,52 @@ struct SoftmaxBwdJob {
   int64_t part_stride;  // n_part > 1: dW = the sum of n_part slots, part_stride floats apart (ck_tail_bwd.hip)
   int32_t n_part;
   int32_t reserved;
+  float* theta;  // the optimizer in the epilogue (len == 32): logits, moments, next step's softmax
+  float* m1;
+  float* m2;
+  float* w_out;
 };
-__global__ void __launch_bounds__(256) softmax_bwd_batch_kernel(const SoftmaxBwdJob* __restrict__ jobs, int n_jobs) {
+// the optimizer's step on one entry of a 32-wide row held by the lanes 0 .. 31 (i = lane) and the row's next softmax
+// (the entry's logit and moments are requested by `softmax_row_fetch` before the row's gradient is formed: one round trip, not two)
+struct RowOpt {
+  float th, m1, m2;
+  bool on;
+};
+__device__ __forceinline__ RowOpt softmax_row_fetch(const SoftmaxBwdJob& j, const ck_opt_state* opt, int64_t at, int lane) {
+  RowOpt r{0.f, 0.f, 0.f, opt != nullptr && j.theta != nullptr && opt->skip_now == 0};
+  if (r.on && lane < 32) {
+    r.th = ck::as_global(j.theta)[at];
+    if (opt->kind != 0) {
+      r.m1 = ck::as_global(j.m1)[at];
+      r.m2 = ck::as_global(j.m2)[at];
+    }
+  }
+  return r;
+}
+__device__ __forceinline__ void softmax_row_step(const SoftmaxBwdJob& j, const ck_opt_state* opt, const RowOpt& r, int64_t at, float g, int lane) {
+  if (!r.on) return;
+  const OptK ok = opt_k(*opt);
+  float th = 0.f;
+  if (lane < 32) {
+    float m1 = r.m1, m2 = r.m2;
+    th = opt_update(ok, r.th, g, m1, m2);
+    ck::as_global(j.theta)[at] = th;
+    if (ok.kind != 0) {
+      ck::as_global(j.m1)[at] = m1;
+      ck::as_global(j.m2)[at] = m2;
+    }
+  }
+  float mx = th;
+#pragma unroll
+  for (int s = 1; s < 32; s <<= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
+  const float e = expf(th - mx);
+  float sum = e;
+#pragma unroll
+  for (int s = 1; s < 32; s <<= 1) sum += __shfl_xor(sum, s, 64);
+  if (lane < 32) ck::as_global(j.w_out)[at] = e / sum;
+}
+__global__ void __launch_bounds__(256) softmax_bwd_batch_kernel(const SoftmaxBwdJob* __restrict__ jobs, int n_jobs,
+                                                                const ck_opt_state* __restrict__ opt) {
   int lo = 0, hi = n_jobs - 1;
   while (lo < hi) {  // last job whose first block is <= blockIdx.x
     const int mid = (lo + hi + 1) >> 1;
@@ -836,6 +881,7 @@ __global__ void __launch_bounds__(256) softmax_bwd_batch_kernel(const SoftmaxBwd
   if (j.n_part > 1 && j.len == 32) {
     // the row's gradient is spread over n_part slots: the two half-waves take every other slot, eight loads in flight each
     const int i = lane & 31;
+    const RowOpt ro = softmax_row_fetch(j, opt, row * 32 + i, lane);
     float acc = 0.f;
     int p = lane >> 5;
     for (; p + 14 < j.n_part; p += 16) {
@@ -851,7 +897,20 @@ __global__ void __launch_bounds__(256) softmax_bwd_batch_kernel(const SoftmaxBwd
     float dot = w * acc;
 #pragma unroll
     for (int s = 1; s < 32; s <<= 1) dot += __shfl_xor(dot, s, 64);
-    if (lane < 32) dth[row * j.len + i] = w * (acc - dot);
+    const float g = w * (acc - dot);
+    if (lane < 32) dth[row * j.len + i] = g;
+    softmax_row_step(j, opt, ro, row * 32 + i, g, lane);
+    return;
+  }
+  if (j.len == 32) {  // (one entry per lane of the lower half: the form the optimizer epilogue takes)
+    const int i = lane & 31;
+    const RowOpt ro = softmax_row_fetch(j, opt, row * 32 + i, lane);
+    const float w = wr[i], dv = dr[i];
+    float dot = lane < 32 ? w * dv : 0.f;
+    dot = ck::wave_sum(dot);
+    const float g = w * (dv - dot);
+    if (lane < 32) dth[row * 32 + i] = g;
+    softmax_row_step(j, opt, ro, row * 32 + i, g, lane);
     return;
   }
   float dot = 0.f;
@@ -1158,14 +1217,29 @@ __global__ void __launch_bounds__(256)
 // latch (nullable triple): *step = *src, *sticky |= *src, *src = 0 -- the validation flag a forward raised becomes this
 // step's flag (what the optimizer launch reads) and the sticky one (what check_inputs() reports) in the launch that zeroes
 // the gradient buffers anyway
+// opt (nullable, with the latch): the optimizer's clock of this step as well (ck_opt_tick: a flagged step is dropped -- skip_now,
+// counted in `skipped` --, otherwise the step count and Adam's bias corrections advance), for the launches of the step whose
+// epilogues update parameters
 __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, int64_t n, float v, int32_t* __restrict__ src,
-                                                    int32_t* __restrict__ step, int32_t* __restrict__ sticky) {
+                                                    int32_t* __restrict__ step, int32_t* __restrict__ sticky, ck_opt_state* __restrict__ opt) {
   if (src != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
     const int32_t f = *src;
     *step = f;
     if (f != 0) {
       *sticky |= f;
       *src = 0;
+    }
+    if (opt != nullptr) {
+      if (f != 0) {
+        opt->skip_now = 1;
+        opt->skipped += 1;
+      } else {
+        opt->skip_now = 0;
+        opt->step += 1;
+        const double t = static_cast<double>(opt->step);  // (in double from the double betas, as ck_opt_tick)
+        opt->bc1 = static_cast<float>(-expm1(t * log(opt->b1d)));
+        opt->bc2 = static_cast<float>(-expm1(t * log(opt->b2d)));
+      }
     }
   }
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
@@ -1274,18 +1348,18 @@ int ck_fill_f32(float* p, int64_t n, float value, void* stream) {
   return ck::dispatch(
       [=](hipStream_t s) {
         hipLaunchKernelGGL(fill_kernel, grid, block, 0, s, p, n, value, static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
-                           static_cast<int32_t*>(nullptr));
+                           static_cast<int32_t*>(nullptr), static_cast<ck_opt_state*>(nullptr));
         return hipGetLastError();
       },
       stream);
 }
 
-int ck_fill_latch(float* p, int64_t n, float value, int32_t* src, int32_t* step_flag, int32_t* sticky, void* stream) {
+int ck_fill_latch(float* p, int64_t n, float value, int32_t* src, int32_t* step_flag, int32_t* sticky, ck_opt_state* opt, void* stream) {
   CK_REQUIRE(p != nullptr && n > 0 && src && step_flag && sticky, "ck_fill_latch: bad arguments");
   dim3 grid(grid1(n)), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(fill_kernel, grid, block, 0, s, p, n, value, src, step_flag, sticky);
+        hipLaunchKernelGGL(fill_kernel, grid, block, 0, s, p, n, value, src, step_flag, sticky, opt);
         return hipGetLastError();
       },
       stream);
@@ -1637,13 +1711,13 @@ int ck_param_softmax_bwd(const float* w, const float* dw, float* dtheta, int64_t
       stream);
 }
 
-int ck_param_softmax_bwd_batch(const ck_softmax_bwd_job* jobs, int n_jobs, int n_blocks, void* stream) {
+int ck_param_softmax_bwd_batch(const ck_softmax_bwd_job* jobs, int n_jobs, int n_blocks, const ck_opt_state* opt, void* stream) {
   CK_REQUIRE(jobs != nullptr && n_jobs > 0 && n_blocks > 0, "ck_param_softmax_bwd_batch: bad arguments");
   static_assert(sizeof(SoftmaxBwdJob) == sizeof(ck_softmax_bwd_job), "job layout");
   dim3 grid(static_cast<unsigned>(n_blocks)), block(256);
   return ck::dispatch(
       [=](hipStream_t s) {
-        hipLaunchKernelGGL(softmax_bwd_batch_kernel, grid, block, 0, s, reinterpret_cast<const SoftmaxBwdJob*>(jobs), n_jobs);
+        hipLaunchKernelGGL(softmax_bwd_batch_kernel, grid, block, 0, s, reinterpret_cast<const SoftmaxBwdJob*>(jobs), n_jobs, opt);
         return hipGetLastError();
       },
       stream);

@@ -31,6 +31,8 @@
 
 #include "ck_bwd_tile.h"
 #include "ck_internal.h"
+#include "ck_opt.h"
+#include "ck_softmax.h"
 #include "ck_tile.h"
 
 namespace {
@@ -517,6 +519,17 @@ struct TableBwdArgs {
   float* g_cat;               // (F_cat, 32, C)
   float* g_dense;             // (F, 32, 32)
   int C;
+  // the optimizer in the epilogue (ck_table_opt; all NULL: gradients only): the workgroup that holds d theta of a fold updates its
+  // logits and moments in place and builds the fold's table of the NEXT forward from them
+  const ck_opt_state* opt;
+  float* th_cat;              // = cat_logits, written
+  float* th_dense;            // = dense_logits, written
+  float* m1_cat;
+  float* m2_cat;
+  float* m1_dense;
+  float* m2_dense;
+  float* table;               // (F, C + 1, 32) linear rows of T' = dense(log-table) (ck_softmax.h table_dense_rows, KIND5)
+  float* table_scale;         // (F, C + 1) their log scales
 };
 
 // Eight waves and exactly 80 KB of LDS per workgroup -- two workgroups per compute unit, four waves per SIMD: the kernel is a
@@ -528,7 +541,7 @@ constexpr int kTbWaves = 8;
 // exp on v_exp_f32 (one multiply + the native exp2, as every forward kernel: ~5e-7 relative at |x| <= 10): the library expf is
 // ~25 instructions, and a lane evaluates 48 of them per fold here
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * kL2E); }
-__global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const TableBwdArgs a) {
+__global__ void __launch_bounds__(kTbWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) table_dense_bwd_kernel(const TableBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tb_lds[];
   const int C = a.C, rows = C + 1, n_t = (rows + 31) >> 5;
   float* t_s = tb_lds;                 // [n_t * 32][32] T, then gT, swizzled (tsw)
@@ -567,13 +580,21 @@ __global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const Ta
   constexpr int kUnits = 32 / kTbWaves;
   float lse_mine[kUnits];
   float th[kUnits][4];
+  // (lane l holds categories 4 l .. 4 l + 3 of its units: the layout table_dense_rows_x takes for the next table)
 #pragma unroll
-  for (int ii = 0; ii < kUnits; ++ii)
+  for (int ii = 0; ii < kUnits; ++ii) {
+    if ((C & 3) == 0) {
+      float4 t4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (4 * lane < C) t4 = *reinterpret_cast<const float4*>(theta + (wave + ii * kTbWaves) * C + 4 * lane);
+      th[ii][0] = t4.x, th[ii][1] = t4.y, th[ii][2] = t4.z, th[ii][3] = t4.w;
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = lane + 64 * q;
-      th[ii][q] = c < C ? theta[(wave + ii * kTbWaves) * C + c] : -INFINITY;
+      for (int q = 0; q < 4; ++q) {
+        const int c = 4 * lane + q;
+        th[ii][q] = c < C ? theta[(wave + ii * kTbWaves) * C + c] : -INFINITY;
+      }
     }
+  }
 #pragma unroll
   for (int ii = 0; ii < kUnits; ++ii) {
     const int i = wave + ii * kTbWaves;
@@ -586,10 +607,11 @@ __global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const Ta
     const float lse = m + logf(sum);
     lse_mine[ii] = lse;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {  // (row C: the integral row; beyond: padding)
-      const int c = lane + 64 * q;
-      if (c < n_t * 32) t_s[tsw(c, i)] = (q < 4 && c < C) ? th[ii][q < 4 ? q : 0] - lse : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * lane + q;
+      if (c < n_t * 32) t_s[tsw(c, i)] = c < C ? th[ii][q] - lse : 0.f;  // (row C: the integral row; beyond: padding)
     }
+    for (int c = 256 + lane; c < n_t * 32; c += 64) t_s[tsw(c, i)] = 0.f;  // (C <= 256: rows the four per lane do not reach)
   }
   __syncthreads();
   f32x16 dw;
@@ -652,6 +674,11 @@ __global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const Ta
     wt_t[idx] = sacc;
   }
   __syncthreads();
+  const bool step_on = a.opt != nullptr && a.opt->skip_now == 0;  // (uniform; a dropped step changes nothing: the table stays)
+  OptK ok{};
+  if (a.opt != nullptr) ok = opt_k(*a.opt);
+  float nd[2] = {0.f, 0.f};  // the thread's two new dense logits (row o = tid >> 4 of the first pass; kTbWaves * 4 = 32 rows: ONE pass)
+  static_assert(kTbWaves * 4 == 32, "one pass over the dense rows");
   for (int o = threadIdx.x >> 4; o < 32; o += kTbWaves * 4) {
     const float* dwr = wt_t;
     const int j = threadIdx.x & 15;
@@ -660,29 +687,104 @@ __global__ void __launch_bounds__(kTbWaves * 64) table_dense_bwd_kernel(const Ta
     float dot = w0 * d0 + w1 * d1;
 #pragma unroll
     for (int s = 1; s < 16; s <<= 1) dot += __shfl_xor(dot, s, 16);
-    *reinterpret_cast<float2*>(a.g_dense + static_cast<int64_t>(d) * 1024 + o * 32 + 2 * j) = make_float2(w0 * (d0 - dot), w1 * (d1 - dot));
+    const float g0 = w0 * (d0 - dot), g1 = w1 * (d1 - dot);
+    const int64_t at = static_cast<int64_t>(d) * 1024 + o * 32 + 2 * j;
+    *reinterpret_cast<float2*>(a.g_dense + at) = make_float2(g0, g1);
+    if (step_on) {
+      const float2 t2 = *reinterpret_cast<const float2*>(a.dense_logits + at);
+      float2 m1 = make_float2(0.f, 0.f), m2 = make_float2(0.f, 0.f);
+      if (ok.kind != 0) {
+        m1 = *reinterpret_cast<const float2*>(a.m1_dense + at);
+        m2 = *reinterpret_cast<const float2*>(a.m2_dense + at);
+      }
+      nd[0] = opt_update(ok, t2.x, g0, m1.x, m2.x);
+      nd[1] = opt_update(ok, t2.y, g1, m1.y, m2.y);
+      *reinterpret_cast<float2*>(a.th_dense + at) = make_float2(nd[0], nd[1]);
+      if (ok.kind != 0) {
+        *reinterpret_cast<float2*>(a.m1_dense + at) = m1;
+        *reinterpret_cast<float2*>(a.m2_dense + at) = m2;
+      }
+    }
   }
   // column sums of gT over the categories (row C has no gradient), then dtheta_c, coalesced along the categories
+  // (the moments of unit ii + 1 travel while unit ii is reduced and updated: a unit is otherwise two dependent round trips)
+  const bool vec = (C & 3) == 0 && 4 * lane < C;
+  float4 pm1 = make_float4(0.f, 0.f, 0.f, 0.f), pm2 = pm1;
+  auto fetch_moments = [&](int ii, float4& m1, float4& m2) {
+    if (step_on && ok.kind != 0 && vec) {
+      const int64_t at = f * 32 * C + static_cast<int64_t>(wave + ii * kTbWaves) * C + 4 * lane;
+      m1 = *reinterpret_cast<const float4*>(a.m1_cat + at);
+      m2 = *reinterpret_cast<const float4*>(a.m2_cat + at);
+    }
+  };
+  fetch_moments(0, pm1, pm2);
 #pragma unroll
   for (int ii = 0; ii < kUnits; ++ii) {
     const int i = wave + ii * kTbWaves;
+    float4 m1 = pm1, m2 = pm2;
+    if (ii + 1 < kUnits) fetch_moments(ii + 1, pm1, pm2);
     float gt[4];
     float sacc = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int c = lane + 64 * q;
+      const int c = 4 * lane + q;
       gt[q] = c < C ? t_s[tsw(c, i)] : 0.f;
       sacc += gt[q];
     }
     sacc = ck::wave_sum(sacc);
     const float lse = lse_mine[ii];
-    float* out = a.g_cat + f * 32 * C + i * C;
+    const int64_t row = f * 32 * C + static_cast<int64_t>(i) * C;
+    if ((C & 3) == 0) {  // (uniform; the lane's four categories as one 16-byte access per array)
+      if (4 * lane < C) {
+        const int64_t at = row + 4 * lane;
+        float g[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = lane + 64 * q;
-      if (c < C) out[c] = gt[q] - fexp(th[ii][q] - lse) * sacc;
+        for (int q = 0; q < 4; ++q) g[q] = gt[q] - fexp(th[ii][q] - lse) * sacc;
+        *reinterpret_cast<float4*>(a.g_cat + at) = make_float4(g[0], g[1], g[2], g[3]);
+        if (step_on) {
+          th[ii][0] = opt_update(ok, th[ii][0], g[0], m1.x, m2.x);
+          th[ii][1] = opt_update(ok, th[ii][1], g[1], m1.y, m2.y);
+          th[ii][2] = opt_update(ok, th[ii][2], g[2], m1.z, m2.z);
+          th[ii][3] = opt_update(ok, th[ii][3], g[3], m1.w, m2.w);
+          *reinterpret_cast<float4*>(a.th_cat + at) = make_float4(th[ii][0], th[ii][1], th[ii][2], th[ii][3]);
+          if (ok.kind != 0) {
+            *reinterpret_cast<float4*>(a.m1_cat + at) = m1;
+            *reinterpret_cast<float4*>(a.m2_cat + at) = m2;
+          }
+        }
+      }
+    } else {  // (gradients only: the launcher refuses the optimizer for such a C)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 4 * lane + q;
+        if (c < C) a.g_cat[row + c] = gt[q] - fexp(th[ii][q] - lse) * sacc;
+      }
     }
   }
+  if (!step_on) return;
+  // the fold's table of the next forward from the logits this workgroup has just updated (the kind-5 job of the prologue,
+  // ck_softmax.h: the same function on the same layout of the logits, so the table is the prologue's bit for bit)
+  __syncthreads();  // (gT and the dense layer's tiles have been read: the LDS is free)
+  float* tile = tb_lds;                       // 32 x (C + 4) log-probabilities + 1024 linear weights (table_dense_rows_x)
+  float* nd_s = tb_lds + 32 * (C + 4) + 1024;  // the new dense logits, row-major
+  {
+    const int o = threadIdx.x >> 4, j = threadIdx.x & 15;
+    nd_s[o * 32 + 2 * j] = nd[0];
+    nd_s[o * 32 + 2 * j + 1] = nd[1];
+  }
+  __syncthreads();
+  float4 x[kUnits];
+#pragma unroll
+  for (int ii = 0; ii < kUnits; ++ii) x[ii] = make_float4(th[ii][0], th[ii][1], th[ii][2], th[ii][3]);
+  float* dst = a.table + static_cast<int64_t>(d) * rows * kK;
+  float* dsc = a.table_scale + static_cast<int64_t>(d) * rows;
+  table_dense_rows_x<kTbWaves, true, true>(x, true, nd_s, C, tile, wave, lane, [] { __syncthreads(); },
+                                           [&](int c, const float (&v)[16], float m) {
+                                             if (c <= C) {
+                                               tile_store(dst + static_cast<int64_t>(c) * kK + 4 * kh, v);
+                                               if (kh == 0) dsc[c] = m;
+                                             }
+                                           });
 }
 
 }  // namespace
@@ -746,14 +848,31 @@ int ck_leaf_walk_bwd(const ck_leaf_bwd_launch* d, void* stream) {
 }
 
 int ck_table_dense_bwd(const float* cat_logits, const int64_t* cat_idx, const float* dense_logits, const float* dtable, float* g_cat,
-                       float* g_dense, int F, int C, void* stream) {
+                       float* g_dense, int F, int C, const ck_table_opt* opt, void* stream) {
   CK_REQUIRE(cat_logits && dense_logits && dtable && g_cat && g_dense, "ck_table_dense_bwd: null pointer");
+  if (opt != nullptr) {
+    CK_REQUIRE(opt->state && opt->table && opt->table_scale && opt->m1_cat && opt->m2_cat && opt->m1_dense && opt->m2_dense,
+               "ck_table_dense_bwd: null pointer in the optimizer descriptor");
+    CK_REQUIRE(cat_idx == nullptr, "ck_table_dense_bwd: the optimizer epilogue needs one Categorical fold per dense fold (cat_idx NULL)");
+    if ((C & 3) != 0) return ck::fail(CK_ERR_UNSUPPORTED, "ck_table_dense_bwd: the optimizer epilogue needs C %% 4 == 0 (C=%d)", C);
+  }
   CK_REQUIRE(F > 0 && C > 0, "ck_table_dense_bwd: non-positive size");
   if (C > 256) return ck::fail(CK_ERR_UNSUPPORTED, "ck_table_dense_bwd: C=%d (at most 256 categories: a lane keeps four logits per unit)", C);
   const int n_t = (C + 1 + 31) / 32;
   const size_t lds = (static_cast<size_t>(n_t + 3) * 1024 + kTbWaves * 1024) * sizeof(float);
   if (lds > 160 * 1024) return ck::fail(CK_ERR_UNSUPPORTED, "ck_table_dense_bwd: C=%d does not fit in LDS", C);
   TableBwdArgs a{cat_logits, cat_idx, dense_logits, dtable, g_cat, g_dense, C};
+  if (opt != nullptr) {
+    a.opt = opt->state;
+    a.th_cat = const_cast<float*>(cat_logits);
+    a.th_dense = const_cast<float*>(dense_logits);
+    a.m1_cat = opt->m1_cat;
+    a.m2_cat = opt->m2_cat;
+    a.m1_dense = opt->m1_dense;
+    a.m2_dense = opt->m2_dense;
+    a.table = opt->table;
+    a.table_scale = opt->table_scale;
+  }
   dim3 grid(static_cast<unsigned>(F));
   return ck::dispatch(
       [=](hipStream_t s) {

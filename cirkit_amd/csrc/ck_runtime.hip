@@ -70,7 +70,7 @@ extern "C" {
 
 const char* ck_last_error(void) { return g_err; }
 
-int ck_abi_version(void) { return 47; }
+int ck_abi_version(void) { return 48; }
 
 int ck_device_info(int device, int64_t out[4]) {
   if (out == nullptr) return ck::fail(CK_ERR_INVALID, "ck_device_info: out is null");

@@ -197,32 +197,56 @@ __device__ __forceinline__ void log_softmax_rows(float4 (&x)[R]) {
 // `store(c, v, m)` receives the finished row tile: category c = tile * 32 + (lane & 31) of this lane, its 16 values, and m.
 // theta: the fold's (32, C) logits; theta_w: the dense fold's (32, 32) logits (both may be nullptr: the wave then only
 // takes part in the barriers -- a group with nothing to do in this round).
+// (table_dense_rows_x: the same with the wave's logits already in registers -- x[r] = categories 4 lane .. 4 lane + 3 of unit
+//  w + NW r, -inf in the lanes past C / 4 -- and theta_w anywhere (an LDS copy): the epilogue of ck_table_dense_bwd, which has just
+//  updated both, builds the next step's table from them)
+template <int NW, bool KIND5, bool WLDS = false, class Sync, class Store>
+__device__ __forceinline__ void table_dense_rows_x(float4 (&x)[32 / NW], bool have, const float* theta_w, int C, float* tile, int w, int lane,
+                                                   Sync&& sync, Store&& store);
+
 template <int NW, bool KIND5, class Sync, class Store>
 __device__ __forceinline__ void table_dense_rows(const float* __restrict__ theta, const float* __restrict__ theta_w, int C,
                                                  float* tile, int w, int lane, Sync&& sync, Store&& store) {
+  constexpr int RPW = 32 / NW;  // units (rows of logits) per wave
+  const int n4 = C >> 2;
+  float4 x[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) x[r] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  if (lane < n4 && theta != nullptr) {  // unit k = w + NW r: one row of C logits per wave and r, all loads in flight
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) x[r] = reinterpret_cast<const float4*>(theta)[(w + NW * r) * n4 + lane];
+  }
+  table_dense_rows_x<NW, KIND5, false>(x, theta != nullptr, theta_w, C, tile, w, lane, sync, store);
+}
+
+template <int NW, bool KIND5, bool WLDS, class Sync, class Store>
+__device__ __forceinline__ void table_dense_rows_x(float4 (&x)[32 / NW], bool have, const float* theta_w, int C, float* tile, int w, int lane,
+                                                   Sync&& sync, Store&& store) {
   constexpr int K = 32;
   static_assert(K % NW == 0 && 16 % NW == 0, "waves per job");
   constexpr int RPW = K / NW;  // units (rows of logits) per wave
   __builtin_assume(w >= 0 && w < NW);  // (every row of W this wave takes exists: no bounds branch per pass)
   const int n4 = C >> 2, ld = C + 4;  // row stride of tile[k][c]: 16-byte aligned rows, conflict-free both ways
   float* w_s = tile + K * ld;          // [32][32] row-major linear weights of the dense fold
-  const bool on = lane < n4 && theta != nullptr;
-  float4 x[RPW];
+  const bool on = lane < n4 && have;
+  if (theta_w != nullptr) {  // W: 32 rows of 32, two rows per wave pass
+    auto put = [&](int row, int l, float p) { w_s[row * 32 + l] = p; };
+    if constexpr (WLDS) {  // (the logits sit in LDS: plain reads, the same reductions)
+      float xw[16 / NW];
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) x[r] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-  if (on) {  // unit k = w + NW r: one row of C logits per wave and r, all loads in flight
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) x[r] = reinterpret_cast<const float4*>(theta)[(w + NW * r) * n4 + lane];
+      for (int p = 0; p < 16 / NW; ++p) xw[p] = theta_w[(2 * (w + p * NW) + (lane >> 5)) * 32 + (lane & 31)];
+      softmax_rows32_apply<16 / NW>(xw, 32, w, NW, lane, put);
+    } else {
+      softmax_rows32<16 / NW>(theta_w, 32, w, NW, lane, put);
+    }
   }
-  if (theta_w != nullptr)  // W: 32 rows of 32, two rows per wave pass
-    softmax_rows32<16 / NW>(theta_w, 32, w, NW, lane, [&](int row, int l, float p) { w_s[row * 32 + l] = p; });
   log_softmax_rows<RPW>(x);
   if (on) {
 #pragma unroll
     for (int r = 0; r < RPW; ++r) *reinterpret_cast<float4*>(tile + (w + NW * r) * ld + 4 * lane) = x[r];
   }
   sync();
-  if (theta == nullptr) return;
+  if (!have) return;
   WRegs wr;
   load_w<CK_W_ROWMAJOR>(w_s, lane, wr);
   const int b_in = lane & 31, kh = lane >> 5;

@@ -67,7 +67,7 @@ class HipTrainer:
         (NotImplementedError says why not), False forces the layer-wise form.
         `jobs`: circuits of 64-unit dense / CP-T / mixing / Hadamard layers (the reference's learning notebook, BASELINE config 4)
         step as level launches over jobs (cirkit_amd/train_jobs.py) when the fused form does not apply: None where the plan
-        qualifies, True insists, False never.  `fuse_optimizer` (job form, one rank): `step` runs the optimizer inside the job
+        qualifies, True insists, False never.  `fuse_optimizer` (fused and job forms, one rank): `step` runs the optimizer inside the backward
         epilogues -- the workgroup that holds a weight's gradient updates its logits and moments and writes the next step's
         softmax; no gradient, no normalised weight and no optimizer launch for those tensors (`loss_and_grads` still leaves
         every gradient in `grads`)."""
@@ -108,6 +108,9 @@ class HipTrainer:
         store.version += 1
         self.plan = plan
         self.fused, self._fz = False, None
+        self._fuse_optimizer = bool(fuse_optimizer)
+        self._opt: torch.Tensor | None = None  # the DEVICE ck_opt_state of the fused form's optimizer epilogues
+        self._opt_key = None
         why = "fused=False" if fused is False else self._setup_fused(plan, store, device)
         if why is not None:
             if fused is True:
@@ -118,7 +121,6 @@ class HipTrainer:
                                       fused_weight_softmax=False)
         self.device = self.circuit.device
         self._jobs = None
-        self._fuse_optimizer = bool(fuse_optimizer)
         self.lr, self.optimizer, self.betas, self.eps = lr, optimizer, betas, eps
         self.step_count = 0
         self._clock: str | None = None  # which optimizer clock has advanced: "device" (fused job step) | "host" (apply_gradients)
@@ -188,9 +190,12 @@ class HipTrainer:
         """Build the fused training circuit; returns None on success, else why the plan does not qualify."""
         if self._pad_info is not None:
             return "padded unit counts"
+        # (`cache_params`: with the optimizer in the backward epilogues -- `step`, one rank -- the launches that update the logits
+        #  write the derived parameters of the next forward themselves; the prologue runs only after the store was changed
+        #  from outside)
         c = HipCircuit(plan, store, device=device, use_graph=False, fuse=True, batch_params=True, tiled_weights=False,
                        dense_on_table=True, pad_units=False, fused_weight_softmax=False, persistent_leaf=True,
-                       params_at_end=False, keep_levels=True, direct_input=True)
+                       params_at_end=False, keep_levels=True, direct_input=True, cache_params=self._fuse_optimizer)
         if len(c._out_pairs) != 1 or c._signed or len(c._groups) != 1:
             return "needs one output and exactly one fused leaf region"
         g = c._groups[0]
@@ -356,12 +361,15 @@ class HipTrainer:
                     "part": part, "part_of": part_of, "stride": stride, "n_tiles": n_tiles}
         fb["tail_bwd"] = {"key": key, "tabs": tabs}
         fb.pop("sm_jobs", None)
+        fb.pop("sm_jobs_opt", None)
         return tabs
 
-    def _softmax_bwd_jobs(self, st: dict, fb: dict, tail: dict | None) -> tuple[torch.Tensor, int]:
+    def _softmax_bwd_jobs(self, st: dict, fb: dict, tail: dict | None, with_opt: bool = False) -> tuple[torch.Tensor, int]:
         """(device job table, blocks) of `ck_param_softmax_bwd_batch` over every sum layer of the fused trainer; the tail
-        layers' weight gradients are the per-tile slots `ck_tail_bwd` left (summed by that launch) when `tail` is given."""
-        hit = fb.get("sm_jobs")
+        layers' weight gradients are the per-tile slots `ck_tail_bwd` left (summed by that launch) when `tail` is given.
+        `with_opt`: the jobs also name the logits, their moments and the evaluated weights (the optimizer epilogue)."""
+        name_ = "sm_jobs_opt" if with_opt else "sm_jobs"
+        hit = fb.get(name_)
         key = (st["dw_flat"].data_ptr(), None if tail is None else tail["part"].data_ptr())
         if hit is None or hit[0] != key:
             c, g = self.circuit, self._fz["group"]
@@ -370,19 +378,27 @@ class HipTrainer:
                 l = c.layers[j]
                 w = l._w
                 parted = tail is not None and j in tail["part_of"]
+                name = l.weight.graph.nodes[0].config["tensor"]
+                opt = (0, 0, 0, 0)
+                if with_opt:
+                    m1, m2 = self._moments.get(name, (None, None))
+                    opt = (self.circuit.store[name].data_ptr(), 0 if m1 is None else m1.data_ptr(), 0 if m2 is None else m2.data_ptr(), w.data_ptr())
                 rows.append((w.data_ptr(), tail["part_of"][j] if parted else st["dws"][j].data_ptr(),
-                             self.grads[l.weight.graph.nodes[0].config["tensor"]].data_ptr(), l.num_folds * l.num_output_units,
-                             l.num_input_units, tail["stride"] if parted else 0, tail["n_tiles"] if parted else 0))
+                             self.grads[name].data_ptr(), l.num_folds * l.num_output_units,
+                             l.num_input_units, tail["stride"] if parted else 0, tail["n_tiles"] if parted else 0, *opt))
             jt = np.zeros(len(rows), dtype=np.dtype([("w", "<u8"), ("dw", "<u8"), ("dtheta", "<u8"), ("rows", "<i8"), ("len", "<i4"), ("first", "<i4"),
-                                                     ("part_stride", "<i8"), ("n_part", "<i4"), ("reserved", "<i4")]))
+                                                     ("part_stride", "<i8"), ("n_part", "<i4"), ("reserved", "<i4"),
+                                                     ("theta", "<u8"), ("m1", "<u8"), ("m2", "<u8"), ("w_out", "<u8")]))
+            assert jt.dtype.itemsize == 88
             first = 0
-            for r, (w, dw, dt, n, ln, ps, npart) in zip(jt, rows):
+            for r, (w, dw, dt, n, ln, ps, npart, th, m1, m2, wo) in zip(jt, rows):
                 r["w"], r["dw"], r["dtheta"], r["rows"], r["len"], r["first"], r["part_stride"], r["n_part"] = w, dw, dt, n, ln, first, ps, npart
+                r["theta"], r["m1"], r["m2"], r["w_out"] = th, m1, m2, wo
                 first += (n + 3) // 4
-            hit = fb["sm_jobs"] = (key, (torch.from_numpy(jt.view(np.uint8).reshape(len(rows), -1)).to(self.device), first))
+            hit = fb[name_] = (key, (torch.from_numpy(jt.view(np.uint8).reshape(len(rows), -1)).to(self.device), first))
         return hit[1]
 
-    def _backward_fused(self, B: int, gB: float, seed, bd, st: dict, stream: int) -> None:
+    def _backward_fused(self, B: int, gB: float, seed, bd, st: dict, stream: int, with_opt: bool = False) -> None:
         c, fz = self.circuit, self._fz
         g = fz["group"]
         fb = self._fused_binding(B, bd)
@@ -405,8 +421,9 @@ class HipTrainer:
         # ONE fill: the linear-space weight gradients (float atomics add to them).  The parameter gradients themselves are
         # written, each exactly once, by the parameter backward launches; the table gradient by the scatter.  The launch also
         # turns the validation flag of the forward into this step's flag (`step`: what the optimizer launch skips on)
+        # (with the optimizer in the epilogues -- `with_opt`, one rank -- it is the optimizer's clock as well: a flagged step is dropped)
         capi.call("ck_fill_latch", fz["dw_sum"].data_ptr(), fz["dw_sum"].numel(), 0.0, c._bad_input.data_ptr(),
-                  self._step_flag.data_ptr(), self._bad_seen.data_ptr(), stream)
+                  self._step_flag.data_ptr(), self._bad_seen.data_ptr(), self._opt_state().data_ptr() if with_opt else None, stream)
         for p in st["need_zero"]:
             if gviews[p] is not None:
                 capi.call("ck_fill_f32", gviews[p].data_ptr(), gviews[p].numel(), 0.0, stream)
@@ -466,12 +483,26 @@ class HipTrainer:
         capi.call("ck_categorical_bwd", gin.data_ptr(), fz["gfold"].data_ptr(), bd.xt_i.data_ptr(), fz["var"].data_ptr(),
                   dTp.data_ptr(), dl.num_folds, B, 32, Cn, 0, (fz["fold_order"].data_ptr() if B >= 256 else None), stream)
         # ... then the dense layer and the log-softmax of the Categorical layer backward ON THE TABLE (C + 1 rows per fold)
+        n_cat, n_dense = cat.probs.graph.nodes[0].config["tensor"], dl.weight.graph.nodes[0].config["tensor"]
+        topt, state = None, None
+        if with_opt:
+            # the optimizer in the epilogues (one rank): the launch that
+            # holds the gradients of the Categorical and dense logits updates them and writes the next forward's table, the
+            # launch that differentiates the weight softmaxes updates those logits and writes the next forward's weights
+            state = self._opt_state().data_ptr()  # (its clock of this step: the fill launch at the start of the list)
+            topt = capi.TableOpt()
+            topt.state = state
+            (m1c, m2c), (m1d, m2d) = self._moments.get(n_cat, (None, None)), self._moments.get(n_dense, (None, None))
+            ph = self._flat_grad  # (SGD: the moment pointers are never read)
+            topt.m1_cat, topt.m2_cat = (ph if m1c is None else m1c).data_ptr(), (ph if m2c is None else m2c).data_ptr()
+            topt.m1_dense, topt.m2_dense = (ph if m1d is None else m1d).data_ptr(), (ph if m2d is None else m2d).data_ptr()
+            topt.table, topt.table_scale = c._group_dev[g.root][1].data_ptr(), c._group_dev[g.root][3].data_ptr()
         capi.call("ck_table_dense_bwd", cat.probs.softmax_source().data_ptr(), None, dl.weight.softmax_source().data_ptr(),
-                  dTp.data_ptr(), self.grads[cat.probs.graph.nodes[0].config["tensor"]].data_ptr(),
-                  self.grads[dl.weight.graph.nodes[0].config["tensor"]].data_ptr(), dl.num_folds, Cn, stream)
+                  dTp.data_ptr(), self.grads[n_cat].data_ptr(), self.grads[n_dense].data_ptr(), dl.num_folds, Cn,
+                  None if topt is None else C.byref(topt), stream)
         # softmax parameterisation of every sum layer's weights (tail, fused levels, dense layer): one launch
-        jobs, n_blocks = self._softmax_bwd_jobs(st, fb, tail)
-        capi.call("ck_param_softmax_bwd_batch", jobs.data_ptr(), jobs.shape[0], n_blocks, stream)
+        jobs, n_blocks = self._softmax_bwd_jobs(st, fb, tail, with_opt)
+        capi.call("ck_param_softmax_bwd_batch", jobs.data_ptr(), jobs.shape[0], n_blocks, state, stream)
 
     def _accumulate_flags(self) -> tuple[dict[int, int], set[int]]:
         """Per consumer layer: 0 store / 1 add / 2 atomic; and the producer layers whose gradient
@@ -598,7 +629,7 @@ class HipTrainer:
         layer-wise: every activation stays in the arena."""
         return self.circuit.log_likelihood_sum(x)
 
-    def _backward(self, B: int, gB: float, seed: torch.Tensor | None) -> None:
+    def _backward(self, B: int, gB: float, seed: torch.Tensor | None, with_opt: bool = False) -> None:
         """The backward launch list over the activations of the LAST forward at batch size B: gradients of
         ``sum_b seed[b] * log p(x_b)`` (seed None: of ``-(1 / gB) sum_b log p(x_b)``) into `self.grads`."""
         c = self.circuit
@@ -606,7 +637,7 @@ class HipTrainer:
         st = self._bind_backward(B)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.fused:
-            return self._backward_fused(B, gB, seed, bd, st, stream)
+            return self._backward_fused(B, gB, seed, bd, st, stream, with_opt)
         capi.call("ck_fill_f32", st["dw_flat"].data_ptr(), st["dw_flat"].numel(), 0.0, stream)
         capi.call("ck_fill_f32", self._flat_grad.data_ptr(), self._flat_grad.numel(), 0.0, stream)
         gviews, flags = st["gviews"], st["flags"]
@@ -735,6 +766,28 @@ class HipTrainer:
         with torch.cuda.device(self.device):
             self._apply_gradients(skip_flag)
 
+    def _fused_opt_ok(self) -> bool:
+        """The fused form takes the optimizer into its backward epilogues: `fuse_optimizer`, no padded duplicates to follow,
+        a Categorical table the epilogue's table job applies to (C % 4 == 0; `_setup_fused` checked C <= 256)."""
+        return (self.fused and self._fuse_optimizer and self._pad_info is None and self._jobs is None
+                and self.circuit.layers[self._fz["group"].input_layer].num_categories % 4 == 0)
+
+    def _opt_state(self) -> torch.Tensor:
+        """The DEVICE `ck_opt_state` (constants, clock, dropped steps) of the optimizer epilogues."""
+        key = (float(self.lr), tuple(float(b) for b in self.betas), float(self.eps))
+        if self._opt is None:
+            o = capi.OptState()
+            o.lr, o.b1, o.b2, o.eps, o.bc1, o.bc2 = self.lr, self.betas[0], self.betas[1], self.eps, 1.0, 1.0
+            o.step, o.skipped, o.skip_now, o.kind = 0, 0, 0, 1 if self.optimizer == "adam" else 0
+            o.b1d, o.b2d = float(self.betas[0]), float(self.betas[1])
+            self._opt = torch.frombuffer(bytearray(bytes(o)), dtype=torch.uint8).to(self.device)
+        elif key != self._opt_key:  # (the learning rate was changed between steps: the first 16 bytes)
+            head = torch.tensor([self.lr, self.betas[0], self.betas[1], self.eps], dtype=torch.float32).view(torch.uint8)
+            self._opt[:16].copy_(head.to(self.device))
+            self._opt[40:56].copy_(torch.tensor([self.betas[0], self.betas[1]], dtype=torch.float64).view(torch.uint8).to(self.device))
+        self._opt_key = key
+        return self._opt
+
     def _use_clock(self, which: str) -> None:
         """ONE optimizer clock per trainer: the fused job step counts Adam's steps on the device (`ck_opt_state.step`, not advanced
         by dropped batches), `apply_gradients` on the host (`step_count`).  Both update the same moments, so a trainer that has
@@ -777,6 +830,17 @@ class HipTrainer:
             self.step_count += 1
             self._grads_current = False
             return self._jobs.step(x, float(global_batch or int(x.shape[0])))
+        if self._fused_opt_ok() and alone:
+            # the fused form with the optimizer in its backward epilogues: no optimizer launch, no parameter prologue before
+            # the next forward (`grads` still receives every gradient)
+            self._use_clock("device")
+            self.step_count += 1
+            with torch.cuda.device(self.device):
+                self._grads_current = True
+                B = int(x.shape[0])
+                ll = self._forward(x)
+                self._backward(B, float(global_batch or B), None, with_opt=True)
+            return ll
         ll = self.loss_and_grads(x, global_batch=global_batch)
         validate = c.validate_inputs and c._int_input
         # a batch with an out-of-range category (NaN log-likelihood) must not reach the parameters.  The flag it raised is THIS
@@ -802,6 +866,8 @@ class HipTrainer:
         n = int(self._skipped.item())
         if self._jobs is not None:
             n += self._jobs.opt_counters()[1]
+        if self._opt is not None:
+            n += int(self._opt[28:32].cpu().view(torch.int32)[0])
         return n
 
     def check_inputs(self) -> None:

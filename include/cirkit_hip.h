@@ -695,8 +695,23 @@ int ck_tail_bwd(const ck_tail_bwd_fold* folds, int n_folds, const int32_t* level
  * LOG-space table T' (ck_categorical_bwd's output); g_cat (F_cat, 32, C) and g_dense (F, 32, 32) receive (=) the gradients of
  * the raw parameters cat_logits / dense_logits (cat_idx: NULL or the Categorical fold of each dense fold; folds must not
  * repeat).  One workgroup per fold rebuilds T and W from the raw parameters and runs the (C + 1)-row backward in LDS. */
+struct ck_opt_state; /* (defined with the job form of the training step below) */
+/* opt != NULL (one rank, C % 4 == 0, cat_idx NULL): the optimizer in the launch's epilogue -- the workgroup that holds the
+ * gradients of a fold's Categorical and dense logits updates both tensors and their moments in place (`optimizer.step()` of
+ * the reference's loop for these two tensors: torch.optim.Adam / SGD, constants and clock in the DEVICE ck_opt_state that
+ * ck_opt_tick advances; a dropped step changes nothing) and writes the fold's table of the NEXT forward, table (F, C + 1, 32)
+ * linear rows and table_scale (F, C + 1) (what ck_param_softmax_batch's table job would make of the new logits, bit for bit). */
+typedef struct ck_table_opt {
+  const struct ck_opt_state* state;
+  float* m1_cat;
+  float* m2_cat;
+  float* m1_dense;
+  float* m2_dense;
+  float* table;
+  float* table_scale;
+} ck_table_opt;
 int ck_table_dense_bwd(const float* cat_logits, const int64_t* cat_idx, const float* dense_logits, const float* dtable, float* g_cat,
-                       float* g_dense, int F, int C, void* stream);
+                       float* g_dense, int F, int C, const ck_table_opt* opt, void* stream);
 /* The (root, tile) units ck_leaf_walk_fwd marked in keep_redo (products that left the linear range), for the whole region of
  * `depth` (2 or 4) levels at once: one wave per marked unit walks the subtree in LOG space -- the reference's arithmetic,
  * semiring.py:383-408, forward values recomputed -- adds the weight gradients of every level (dw_levels[l - 1], row-major,
@@ -726,8 +741,14 @@ typedef struct ck_softmax_bwd_job {
   int64_t part_stride;  /* n_part > 1: dW is the sum of n_part slots, part_stride floats apart (ck_tail_bwd's dw_part) */
   int32_t n_part;       /* 0 or 1: dw is the gradient itself */
   int32_t reserved;
+  float* theta;         /* with `opt` (len == 32 only): the logits, their moments and the (rows, 32) row-major buffer the NEXT forward */
+  float* m1;            /* reads softmax(theta') from -- the row's wave updates them in place (all four NULL: gradients only) */
+  float* m2;
+  float* w_out;
 } ck_softmax_bwd_job;
-int ck_param_softmax_bwd_batch(const ck_softmax_bwd_job* jobs, int n_jobs, int n_blocks, void* stream);
+/* opt: NULL, or the DEVICE optimizer state (ck_opt_tick): jobs with `theta` take the optimizer's step on their rows in the launch's
+ * epilogue (`optimizer.step()` for these tensors + TorchSoftmaxParameter.forward of the next step, nodes.py:764-772). */
+int ck_param_softmax_bwd_batch(const ck_softmax_bwd_job* jobs, int n_jobs, int n_blocks, const struct ck_opt_state* opt, void* stream);
 int ck_param_log_table_bwd(const float* table, const float* dtable, float* dtheta, int F, int K, int C,
                            int accumulate, void* stream);
 /* Optimiser steps on one flat tensor; grad_scale multiplies the gradient first (e.g. 1/world). Adam
@@ -807,8 +828,9 @@ int ck_slse_bwd(const float* arena, const uint32_t* signs, const int64_t* row_of
 int ck_latch_flag(int32_t* src, int32_t* dst, void* stream);
 /* ck_fill_f32 that also hands a validation flag on: *step_flag = *src; if it is nonzero, *sticky |= *src and *src = 0
  * (DEVICE int32 words): the flag a forward raised (ck_leaf_walk_fwd's bad_input) becomes this step's flag -- what the
- * optimizer launch skips on -- and the sticky one in the launch that zeroes the gradient buffers anyway. */
-int ck_fill_latch(float* p, int64_t n, float value, int32_t* src, int32_t* step_flag, int32_t* sticky, void* stream);
+ * optimizer launch skips on -- and the sticky one in the launch that zeroes the gradient buffers anyway.  opt: NULL, or the
+ * DEVICE optimizer state: the launch is this step's ck_opt_tick as well (the flag decides whether the step counts). */
+int ck_fill_latch(float* p, int64_t n, float value, int32_t* src, int32_t* step_flag, int32_t* sticky, struct ck_opt_state* opt, void* stream);
 
 /* ---------------------------------------------------------------- training step as job lists (64-unit CP circuits) ---- */
 /* The reference trains with autograd through its layer-by-layer forward (notebooks/learning-a-circuit.ipynb cell 18:
