@@ -290,12 +290,13 @@ def train_step_cfg2(device, stream, B: int, rounds: int = 5, steps: int = 40, se
     flops = chains * 2.0 * 32 * 32 * 32
     return {
         "workload": f"784-var QuadTree (QT-2) PC, Categorical-256 leaves, K=32, batch {B}: forward + backward + Adam, parameters "
-                    "re-evaluated every step; fused training step (cirkit_amd/training.py, ck_leaf_walk_fwd keep_levels + ck_leaf_walk_bwd)",
+                    "re-evaluated every step; fused training step (cirkit_amd/training.py, ck_leaf_walk_fwd keep_levels + ck_leaf_walk_bwd), the optimizer "
+                    "and the next step's parameters in the backward epilogues (ck_table_dense_bwd / ck_param_softmax_bwd_batch with opt)",
         "fused": fused, "ms_per_step": ms, "samples_per_s": B / ms * 1e3, "ms_per_step_by_round": per_round,
         "settle_steps": k - rounds * steps, "steps_timed_total": rounds * steps,
         "executed_flops": flops, "frac_of_fp32_mfma": flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
         "mean_ll_first_step": float(first[0] / first[1]), "mean_ll_last_step": float(last[0] / last[1]),
-        "optimizer": "adam(lr=0.01)", "dtype": "f32",
+        "optimizer": "adam(lr=0.01), in the backward epilogues, device-side clock" if tr._fused_opt_ok() else "adam(lr=0.01)", "dtype": "f32",
     }
 
 
